@@ -1,0 +1,20 @@
+"""CPU oracle: a float64 NumPy restatement of the QuantumLiquids/PEPS boundary-MPS hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``peps_amd/`` may import this package; only
+``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` do,
+and there only as the checker.
+
+Every function cites the reference file:line it restates (paths relative to
+``/root/reference``).  The arithmetic of the reference lives in the un-vendored
+TensorToolkit (``qlten``) dependency; its semantics (``Contract``, ``QR``, truncating
+``SVD``) are restated in ``oracle/tensor.py`` from the call sites.
+
+Parity pinning (see tests/test_oracle_*.py, tests/golden/):
+  K1  12x12 critical Ising partition function vs exact transfer matrix
+      (tests/test_2d_tn/test_bmps_contractor.cpp:27-126,128-271,472-493)
+  K3  PunchHole . site == Trace, EraseEnvsAfterUpdate + regrow (…:407-470)
+  K4  2x2 fixtures, exact-summation energies (tests/test_algorithm/test_exact_summation_evaluator.cpp)
+  K5  4x4 D=8 Heisenberg fixture, exact-sum energy / checkerboard amplitude
+The SVD truncation rule for trunc_err > 0 and every Z2-graded (fermion) semantic are
+"parity unpinned" (no reference binary can be produced here).
+"""

@@ -1,0 +1,354 @@
+"""Wave-function component, MC sweep updaters, model energy solvers, exact-summation evaluator.
+
+Restates (bosonic paths):
+  include/qlpeps/vmc_basic/wave_function_component.h:136-379
+  include/qlpeps/vmc_basic/configuration_update_strategies/square_nn_updater.h:25-189,253-293
+  include/qlpeps/vmc_basic/monte_carlo_tools/suwa_todo_update.h:53-112
+  include/qlpeps/algorithm/vmc_update/model_solvers/base/square_nnn_energy_solver.h:79-316
+  include/qlpeps/algorithm/vmc_update/model_solvers/base/bond_traversal_mixin.h:113-144
+  include/qlpeps/algorithm/vmc_update/model_solvers/square_spin_onehalf_xxz_obc.h:72-104
+  include/qlpeps/algorithm/vmc_update/model_solvers/transverse_field_ising_square_obc.h:160-247
+  include/qlpeps/algorithm/vmc_update/exact_summation_energy_evaluator.h:74-95,173-302
+Oracle = test infrastructure only.
+"""
+import itertools
+import numpy as np
+
+from .bmps import LEFT, DOWN, RIGHT, UP, HORIZONTAL, VERTICAL
+from .contractor import TensorNetwork2D, BMPSContractor
+
+
+class TPSWaveFunctionComponent:
+    """wave_function_component.h:136-379.  `sitps[r][c]` = list (physical index) of rank-4 arrays."""
+
+    def __init__(self, sitps, config, trun_para):
+        self.config = np.array(config, dtype=np.int64)
+        self.trun_para = trun_para
+        rows, cols = self.config.shape
+        self.tn = TensorNetwork2D.from_sitps(sitps, self.config)          # :159
+        self.contractor = BMPSContractor(rows, cols)
+        self.contractor.Init(self.tn)                                     # :160
+        self.amplitude = None
+        self.EvaluateAmplitude()                                          # :161
+
+    def EvaluateAmplitude(self):
+        """wave_function_component.h:187-212"""
+        c, tn = self.contractor, self.tn
+        c.SetTruncateParams(self.trun_para)
+        c.GrowBMPSForRow(tn, 0)
+        c.GrowFullBTen(tn, RIGHT, 0, 2, True)
+        c.InitBTen(tn, LEFT, 0)
+        self.amplitude = c.Trace(tn, (0, 0), HORIZONTAL)
+        return self.amplitude
+
+    def UpdateLocal(self, sitps, new_amplitude, *site_configs):
+        """wave_function_component.h:345-378"""
+        for site, cfg in site_configs:
+            self.config[site[0], site[1]] = cfg
+            self.tn.update_site_tensor(site, cfg, sitps)
+            self.contractor.EraseEnvsAfterUpdate(site)
+        self.amplitude = new_amplitude
+
+
+# ---------------------------------------------------------------------------------------------
+def suwa_todo_state_update(init_state, weights, uniform01):
+    """suwa_todo_update.h:53-112.  `uniform01()` returns a deviate in [0,1); the reference draws
+    uniform_real_distribution<long double>(start, start+w_i) from the engine."""
+    w = [float(x) for x in weights]
+    n = len(w)
+    max_id = int(np.argmax(w))
+    if max_id != 0:
+        w[0], w[max_id] = w[max_id], w[0]
+    if init_state == max_id:
+        init_state = 0
+    elif init_state == 0:
+        init_state = max_id
+    s = np.cumsum(np.array(w, dtype=np.longdouble))
+    S = s[-1]
+    s_im1 = np.longdouble(0) if init_state == 0 else s[init_state - 1]
+    start = s_im1 + np.longdouble(w[0])
+    if start >= S:
+        start -= S
+    x = start + np.longdouble(uniform01()) * np.longdouble(w[init_state])
+    if x >= S:
+        x -= S
+    final = int(np.searchsorted(s, x, side="right"))
+    final = min(final, n - 1)
+    if max_id != 0:
+        if final == 0:
+            final = max_id
+        elif final == max_id:
+            final = 0
+    return final
+
+
+class MCUpdateSquareNNUpdateBaseOBC:
+    """square_nn_updater.h:25-83: sweep schedule."""
+
+    def __init__(self, seed=0):
+        self.rng = np.random.RandomState(seed)   # the reference uses std::mt19937 (same generator
+        # family; the variate transformation differs, so chains are compared on statistics only)
+
+    def u_double(self):
+        return self.rng.random_sample()
+
+    def __call__(self, sitps, comp):
+        tn, c = comp.tn, comp.contractor
+        accept = 0
+        c.SetTruncateParams(comp.trun_para)
+        c.GenerateBMPSApproach(tn, UP)
+        for row in range(tn.rows):
+            c.InitBTen(tn, LEFT, row)
+            c.GrowFullBTen(tn, RIGHT, row, 2, True)
+            for col in range(tn.cols - 1):
+                accept += self.two_site_update((row, col), (row, col + 1), HORIZONTAL, sitps, comp)
+                if col < tn.cols - 2:
+                    c.ShiftBTenWindow(tn, RIGHT)
+            if row < tn.rows - 1:
+                c.ShiftBMPSWindow(tn, DOWN)
+        c.DeleteInnerBMPS(LEFT)
+        c.DeleteInnerBMPS(RIGHT)
+        c.GenerateBMPSApproach(tn, LEFT)
+        for col in range(tn.cols):
+            c.InitBTen(tn, UP, col)
+            c.GrowFullBTen(tn, DOWN, col, 2, True)
+            for row in range(tn.rows - 1):
+                accept += self.two_site_update((row, col), (row + 1, col), VERTICAL, sitps, comp)
+                if row < tn.rows - 2:
+                    c.ShiftBTenWindow(tn, DOWN)
+            if col < tn.cols - 1:
+                c.ShiftBMPSWindow(tn, RIGHT)
+        c.DeleteInnerBMPS(UP)
+        bond_num = tn.cols * (tn.rows - 1) + tn.rows * (tn.cols - 1)
+        return [accept / bond_num]
+
+
+class MCUpdateSquareNNExchangeOBC(MCUpdateSquareNNUpdateBaseOBC):
+    """square_nn_updater.h:142-189"""
+
+    def two_site_update(self, s1, s2, bond_dir, sitps, comp):
+        c1, c2 = int(comp.config[s1]), int(comp.config[s2])
+        if c1 == c2:
+            return False
+        psi_b = comp.contractor.ReplaceNNSiteTrace(comp.tn, s1, s2, bond_dir,
+                                                   sitps[s1[0]][s1[1]][c2], sitps[s2[0]][s2[1]][c1])
+        psi_a = comp.amplitude
+        if abs(psi_b) < abs(psi_a):
+            div = abs(psi_b) / abs(psi_a)
+            if not (self.u_double() < div * div):
+                return False
+        comp.UpdateLocal(sitps, psi_b, (s1, c2), (s2, c1))
+        return True
+
+
+class MCUpdateSquareNNFullSpaceUpdateOBC(MCUpdateSquareNNUpdateBaseOBC):
+    """square_nn_updater.h:253-293"""
+
+    def two_site_update(self, s1, s2, bond_dir, sitps, comp):
+        dim = len(sitps[0][0])
+        init = int(comp.config[s1]) * dim + int(comp.config[s2])
+        alt = [None] * (dim * dim)
+        alt[init] = comp.amplitude
+        for k1 in range(dim):
+            for k2 in range(dim):
+                k = k1 * dim + k2
+                if k != init:
+                    alt[k] = comp.contractor.ReplaceNNSiteTrace(comp.tn, s1, s2, bond_dir,
+                                                                sitps[s1[0]][s1[1]][k1], sitps[s2[0]][s2[1]][k2])
+        weights = [abs(a / comp.amplitude) ** 2 for a in alt]
+        final = suwa_todo_state_update(init, weights, self.u_double)
+        if final == init:
+            return False
+        comp.UpdateLocal(sitps, alt[final], (s1, final // dim), (s2, final % dim))
+        return True
+
+
+# ---------------------------------------------------------------------------------------------
+class SquareNNModelEnergySolver:
+    """square_nnn_energy_solver.h:37-316 with has_nnn_interaction = false
+    (+ bond_traversal_mixin.h:113-144 for the vertical pass)."""
+
+    def CalEnergyAndHoles(self, sitps, comp, calchols=True):
+        tn, c = comp.tn, comp.contractor
+        rows, cols = tn.rows, tn.cols
+        holes = [[None] * cols for _ in range(rows)]
+        bond_e, psi_list = [], []
+        c.SetTruncateParams(comp.trun_para)
+        c.GenerateBMPSApproach(tn, UP)                                    # :116
+        for row in range(rows):
+            c.InitBTen(tn, LEFT, row)                                     # :142
+            c.GrowFullBTen(tn, RIGHT, row, 1, True)                       # :143
+            psi = c.Trace(tn, (row, 0), HORIZONTAL)                       # :147
+            if psi == 0:
+                raise RuntimeError("Wavefunction amplitude is near zero, causing division by zero.")
+            inv_psi = 1.0 / psi
+            psi_list.append(psi)
+            for col in range(cols):
+                s1 = (row, col)
+                if calchols:
+                    holes[row][col] = np.conj(c.PunchHole(tn, s1, HORIZONTAL))   # :163 Dag(env)
+                if col < cols - 1:
+                    s2 = (row, col + 1)
+                    bond_e.append(self.EvaluateBondEnergy(s1, s2, int(comp.config[s1]), int(comp.config[s2]),
+                                                          HORIZONTAL, tn, c, sitps[row][col], sitps[row][col + 1],
+                                                          inv_psi))
+                    c.ShiftBTenWindow(tn, RIGHT)                          # :200
+            if row < rows - 1:
+                c.ShiftBMPSWindow(tn, DOWN)                               # :126
+        # vertical pass: bond_traversal_mixin.h:113-144
+        c.GenerateBMPSApproach(tn, LEFT)
+        for col in range(cols):
+            c.InitBTen(tn, UP, col)
+            c.GrowFullBTen(tn, DOWN, col, 2, True)
+            psi = c.Trace(tn, (0, col), VERTICAL)
+            if psi == 0:
+                raise RuntimeError("Wavefunction amplitude is near zero, causing division by zero.")
+            inv_psi = 1.0 / psi
+            psi_list.append(psi)
+            for row in range(rows - 1):
+                s1, s2 = (row, col), (row + 1, col)
+                bond_e.append(self.EvaluateBondEnergy(s1, s2, int(comp.config[s1]), int(comp.config[s2]),
+                                                      VERTICAL, tn, c, sitps[row][col], sitps[row + 1][col],
+                                                      inv_psi))
+                if row < rows - 2:
+                    c.ShiftBTenWindow(tn, DOWN)
+            if col < cols - 1:
+                c.ShiftBMPSWindow(tn, RIGHT)
+        energy = sum(bond_e) + self.EvaluateTotalOnsiteEnergy(comp.config)   # :97-101
+        return energy, holes, psi_list
+
+
+class SquareSpinOneHalfXXZModelOBC(SquareNNModelEnergySolver):
+    """square_spin_onehalf_xxz_obc.h:64-190"""
+
+    def __init__(self, jz=1.0, jxy=1.0, pinning00=0.0):
+        self.jz, self.jxy, self.pin = jz, jxy, pinning00
+
+    def EvaluateBondEnergy(self, s1, s2, c1, c2, orient, tn, contractor, t1, t2, inv_psi):
+        """:72-104"""
+        if c1 == c2:
+            return 0.25 * self.jz
+        psi_ex = contractor.ReplaceNNSiteTrace(tn, s1, s2, orient, t1[c2], t2[c1])
+        ratio = np.conj(psi_ex * inv_psi)
+        return -0.25 * self.jz + ratio * 0.5 * self.jxy
+
+    def EvaluateTotalOnsiteEnergy(self, config):
+        """:139-141"""
+        return -self.pin * (float(config[0, 0]) - 0.5)
+
+
+class TransverseFieldIsingSquareOBC:
+    """transverse_field_ising_square_obc.h:28-247: H = -sum_<ij> sz sz - h sum_i sx"""
+
+    def __init__(self, h):
+        self.h = h
+
+    def CalDiagTermEnergy(self, config):
+        """:160-182"""
+        cfg = np.asarray(config)
+        e = 0.0
+        e += np.sum(np.where(cfg[:, :-1] == cfg[:, 1:], -1.0, 1.0))
+        e += np.sum(np.where(cfg[:-1, :] == cfg[1:, :], -1.0, 1.0))
+        return float(e)
+
+    def CalEnergyAndHoles(self, sitps, comp, calchols=True):
+        """:211-247"""
+        tn, c = comp.tn, comp.contractor
+        rows, cols = tn.rows, tn.cols
+        holes = [[None] * cols for _ in range(rows)]
+        psi_list = []
+        energy = 0.0
+        c.SetTruncateParams(comp.trun_para)
+        c.GenerateBMPSApproach(tn, UP)
+        for row in range(rows):
+            c.InitBTen(tn, LEFT, row)
+            c.GrowFullBTen(tn, RIGHT, row, 1, True)
+            psi = c.Trace(tn, (row, 0), HORIZONTAL)
+            inv_psi = 1.0 / psi
+            psi_list.append(psi)
+            for col in range(cols):
+                site = (row, col)
+                if calchols:
+                    holes[row][col] = np.conj(c.PunchHole(tn, site, HORIZONTAL))
+                cfg = int(comp.config[site])
+                psi_ex = c.ReplaceOneSiteTrace(tn, site, sitps[row][col][1 - cfg], HORIZONTAL)   # :195-203
+                energy = energy + (-self.h) * np.conj(psi_ex * inv_psi)
+                if col < cols - 1:
+                    c.ShiftBTenWindow(tn, RIGHT)
+            if row < rows - 1:
+                c.ShiftBMPSWindow(tn, DOWN)
+        energy = energy + self.CalDiagTermEnergy(comp.config)
+        return energy, holes, psi_list
+
+
+# ---------------------------------------------------------------------------------------------
+def generate_all_permutation_configs(particle_counts, lx, ly):
+    """exact_summation_energy_evaluator.h:74-95 (std::next_permutation order)."""
+    base = []
+    for i, n in enumerate(particle_counts):
+        base += [i] * n
+    seen = []
+    # lexicographic distinct permutations == std::next_permutation sequence from sorted input
+    for p in _distinct_perms(base):
+        seen.append(np.array(p, dtype=np.int64).reshape(ly, lx))
+    return seen
+
+
+def _distinct_perms(seq):
+    seq = sorted(seq)
+    n = len(seq)
+    while True:
+        yield tuple(seq)
+        i = n - 2
+        while i >= 0 and seq[i] >= seq[i + 1]:
+            i -= 1
+        if i < 0:
+            return
+        j = n - 1
+        while seq[j] <= seq[i]:
+            j -= 1
+        seq[i], seq[j] = seq[j], seq[i]
+        seq[i + 1:] = reversed(seq[i + 1:])
+
+
+def all_product_configs(d, lx, ly):
+    """All d^(lx*ly) configurations (TFIM has no conserved quantum number)."""
+    return [np.array(p, dtype=np.int64).reshape(ly, lx) for p in itertools.product(range(d), repeat=lx * ly)]
+
+
+def exact_sum_energy_evaluator(sitps, all_configs, trun_para, model, rank=0, size=1):
+    """exact_summation_energy_evaluator.h:173-302 (bosonic branch).  Returns
+    (energy, gradient[r][c][s], weight_sum) for the configurations i = rank, rank+size, ...
+    (the partial sums S_O, S_EO, sum w, sum wE of one rank are returned when size > 1 via
+    `partials=True` semantics of exact_sum_partials)."""
+    so, seo, wsum, wesum = exact_sum_partials(sitps, all_configs, trun_para, model, rank, size)
+    return finish_exact_sum(so, seo, wsum, wesum)
+
+
+def exact_sum_partials(sitps, all_configs, trun_para, model, rank=0, size=1):
+    rows, cols = len(sitps), len(sitps[0])
+    d = len(sitps[0][0])
+    so = [[[np.zeros_like(sitps[r][c][s]) for s in range(d)] for c in range(cols)] for r in range(rows)]
+    seo = [[[np.zeros_like(sitps[r][c][s]) for s in range(d)] for c in range(cols)] for r in range(rows)]
+    wsum, wesum = 0.0, 0.0
+    for i in range(rank, len(all_configs), size):                           # :201
+        comp = TPSWaveFunctionComponent(sitps, all_configs[i], trun_para)
+        w = abs(comp.amplitude) ** 2
+        e_loc, holes, _ = model.CalEnergyAndHoles(sitps, comp, True)
+        for r in range(rows):
+            for c in range(cols):
+                b = int(comp.config[r, c])
+                inc = comp.amplitude * holes[r][c]                          # :231
+                so[r][c][b] = so[r][c][b] + inc
+                seo[r][c][b] = seo[r][c][b] + np.conj(e_loc) * inc
+        wsum += w
+        wesum = wesum + e_loc * w
+    return so, seo, wsum, wesum
+
+
+def finish_exact_sum(so, seo, wsum, wesum):
+    """exact_summation_energy_evaluator.h:286-295"""
+    energy = wesum / wsum
+    grad = [[[(seo[r][c][s] - np.conj(energy) * so[r][c][s]) / wsum for s in range(len(so[r][c]))]
+             for c in range(len(so[0]))] for r in range(len(so))]
+    return energy, grad, wsum

@@ -1,0 +1,154 @@
+"""CPU suite: the oracle against the reference's own known answers (SURVEY.md section 8c K1,K3,K4,K5)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ising, qlten_io
+from oracle.bmps import BMPSTruncateParams, LEFT, DOWN, RIGHT, UP, HORIZONTAL, VERTICAL
+from oracle.contractor import BMPSContractor, TensorNetwork2D
+from oracle import vmc
+
+
+def test_k1_ising_free_energy_all_routes():
+    """tests/test_2d_tn/test_bmps_contractor.cpp:273-405,472-493 (NN routes, SVD(10,30,1e-15)), tol 1e-8."""
+    tn, lognorm, beta = ising.build_ising_tn(12, 12)
+    f_ex = ising.exact_free_energy(12, 12, 1.0 / beta)
+    c = BMPSContractor(12, 12)
+    c.Init(tn)
+    c.SetTruncateParams(BMPSTruncateParams.SVD(10, 30, 1e-15))
+    amps = []
+    c.GrowBMPSForRow(tn, 2)
+    c.InitBTen(tn, LEFT, 2)
+    c.GrowFullBTen(tn, RIGHT, 2, 2, True)
+    amps.append(c.Trace(tn, (2, 0), HORIZONTAL))
+    c.ShiftBTenWindow(tn, RIGHT)
+    amps.append(c.Trace(tn, (2, 1), HORIZONTAL))
+    c.GrowBMPSForCol(tn, 1)
+    c.InitBTen(tn, DOWN, 1)
+    c.GrowFullBTen(tn, UP, 1, 2, True)
+    amps.append(c.Trace(tn, (10, 1), VERTICAL))
+    c.ShiftBTenWindow(tn, UP)
+    amps.append(c.Trace(tn, (9, 1), VERTICAL))
+    # one-site trace route (trace.h:30-88) on row 2
+    c.GrowBMPSForRow(tn, 2)
+    c.GrowFullBTen(tn, LEFT, 2, 1, True)
+    c.GrowFullBTen(tn, RIGHT, 2, 1, True)
+    c.TruncateBTen(LEFT, 4)
+    c.TruncateBTen(RIGHT, 12 - 3)
+    amps.append(c.ReplaceOneSiteTrace(tn, (2, 3), tn((2, 3)), HORIZONTAL))
+    for a in amps:
+        assert abs(-(np.log(a) + lognorm) / 144 / beta - f_ex) < 1e-8
+
+
+def test_k3_punch_hole_and_invalidate():
+    """tests/test_2d_tn/test_bmps_contractor.cpp:407-470"""
+    tn, _, _ = ising.build_ising_tn(12, 12)
+    c = BMPSContractor(12, 12)
+    c.Init(tn)
+    c.SetTruncateParams(BMPSTruncateParams.SVD(4, 10, 1e-10))
+    c.GrowBMPSForRow(tn, 2)
+    c.GrowFullBTen(tn, LEFT, 2, 2, True)
+    c.GrowFullBTen(tn, RIGHT, 2, 2, True)
+    val1 = c.Trace(tn, (2, 0), HORIZONTAL)
+    hole = c.PunchHole(tn, (2, 1), HORIZONTAL)
+    tr = c.Trace(tn, (2, 1), HORIZONTAL)
+    assert abs(np.tensordot(hole, tn((2, 1)), axes=4) - tr) < 1e-10
+    tn.set((2, 1), tn((2, 1)) * 0.5)
+    c.EraseEnvsAfterUpdate((2, 1))
+    c.GrowBMPSForRow(tn, 2)
+    c.GrowFullBTen(tn, LEFT, 2, 2, True)
+    c.GrowFullBTen(tn, RIGHT, 2, 2, True)
+    val2 = c.Trace(tn, (2, 0), HORIZONTAL)
+    assert abs(val2 - 0.5 * val1) < 1e-10
+
+
+K4 = [
+    # directory, model, configs, reference energy, tolerance, reference citation
+    ("heisenberg_tps_double_from_simple_update", "xxz", "perm22", -1.99521278793, 1e-10,
+     "test_exact_summation_evaluator.cpp:606"),
+    ("heisenberg_tps_doublelowest", "xxz", "perm22", -2.0, 6e-8, "test_exact_summation_evaluator.cpp:139-174"),
+    ("transverse_ising_tps_double_from_simple_update", "tfim", "all", -5.19991995228, 1e-10,
+     "test_exact_summation_evaluator.cpp:775"),
+    ("transverse_ising_tps_doublelowest", "tfim", "all",
+     -2.0 * (np.sqrt(2 - 2 * np.cos(np.pi / 4)) + np.sqrt(2 - 2 * np.cos(3 * np.pi / 4))), 6e-8,
+     "test_exact_summation_evaluator.cpp:250-259"),
+]
+
+
+@pytest.mark.parametrize("name,model,cfgs,e_ref,tol,cite", K4)
+def test_k4_2x2_exact_sum_energy(fixtures_dir, name, model, cfgs, e_ref, tol, cite):
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, name))
+    tp = BMPSTruncateParams.SVD(1, 8, 1e-16)   # truncation used by the reference test (:355,:870)
+    if model == "xxz":
+        m = vmc.SquareSpinOneHalfXXZModelOBC()
+        configs = vmc.generate_all_permutation_configs([2, 2], 2, 2)
+    else:
+        m = vmc.TransverseFieldIsingSquareOBC(1.0)
+        configs = vmc.all_product_configs(2, 2, 2)
+    e, grad, w = vmc.exact_sum_energy_evaluator(s, configs, tp, m)
+    assert abs(e - e_ref) < tol, cite
+
+
+def test_k4_complex_matches_real(fixtures_dir):
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, "heisenberg_tps_complex_from_simple_update"),
+                            complex_data=True)
+    tp = BMPSTruncateParams.SVD(1, 8, 1e-16)
+    e, _, _ = vmc.exact_sum_energy_evaluator(s, vmc.generate_all_permutation_configs([2, 2], 2, 2), tp,
+                                             vmc.SquareSpinOneHalfXXZModelOBC())
+    assert abs(e - (-1.99521278793)) < 1e-10 and abs(e.imag) < 1e-12
+
+
+def test_exact_sum_rank_partition(fixtures_dir):
+    """exact_summation_energy_evaluator.h:201: round-robin partition over ranks sums to the same result
+    (the reference runs this test under mpirun -n 4)."""
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, "heisenberg_tps_double_from_simple_update"))
+    tp = BMPSTruncateParams.SVD(1, 8, 1e-16)
+    cfgs = vmc.generate_all_permutation_configs([2, 2], 2, 2)
+    m = vmc.SquareSpinOneHalfXXZModelOBC()
+    e1, g1, _ = vmc.exact_sum_energy_evaluator(s, cfgs, tp, m)
+    parts = [vmc.exact_sum_partials(s, cfgs, tp, m, r, 4) for r in range(4)]
+    so, seo, w, we = parts[0]
+    for p in parts[1:]:
+        for r in range(2):
+            for c in range(2):
+                for k in range(2):
+                    so[r][c][k] = so[r][c][k] + p[0][r][c][k]
+                    seo[r][c][k] = seo[r][c][k] + p[1][r][c][k]
+        w += p[2]
+        we += p[3]
+    e4, g4, _ = vmc.finish_exact_sum(so, seo, w, we)
+    assert abs(e1 - e4) < 1e-13
+    assert np.allclose(g1[1][0][1], g4[1][0][1], atol=1e-13)
+
+
+def test_k5_4x4_d8_amplitude(fixtures_dir):
+    """tests/slow_tests/test_data/tps_square_heisenberg4x4D8Double: BMPS amplitude of the checkerboard
+    configuration converges to the brute-force contraction (1.441641034201432e+02)."""
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, "tps_square_heisenberg4x4D8Double"))
+    cb = np.array([[(r + c) % 2 for c in range(4)] for r in range(4)])
+    exact = ising.exact_contract(TensorNetwork2D.from_sitps(s, cb))
+    assert abs(exact - 1.441641034201432e+02) < 1e-9
+    comp = vmc.TPSWaveFunctionComponent(s, cb, BMPSTruncateParams.SVD(64, 64, 0.0))
+    assert abs(comp.amplitude - exact) < 1e-9 * abs(exact)
+    comp16 = vmc.TPSWaveFunctionComponent(s, cb, BMPSTruncateParams.SVD(16, 16, 0.0))
+    assert abs(comp16.amplitude - exact) < 1e-5 * abs(exact)
+
+
+def test_sweep_keeps_amplitude_consistent(fixtures_dir):
+    """After a full MC sweep (square_nn_updater.h:30-81) the carried amplitude equals a fresh
+    EvaluateAmplitude of the final configuration; Sz is conserved by the exchange updater."""
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, "tps_square_heisenberg4x4D8Double"))
+    cb = np.array([[(r + c) % 2 for c in range(4)] for r in range(4)])
+    tp = BMPSTruncateParams.SVD(64, 64, 0.0)
+    comp = vmc.TPSWaveFunctionComponent(s, cb, tp)
+    upd = vmc.MCUpdateSquareNNExchangeOBC(seed=3)
+    rates = upd(s, comp)
+    assert 0.0 <= rates[0] <= 1.0
+    assert comp.config.sum() == 8
+    fresh = vmc.TPSWaveFunctionComponent(s, comp.config, tp)
+    assert abs(fresh.amplitude - comp.amplitude) < 1e-9 * abs(fresh.amplitude)
+    upd2 = vmc.MCUpdateSquareNNFullSpaceUpdateOBC(seed=5)
+    upd2(s, comp)
+    fresh = vmc.TPSWaveFunctionComponent(s, comp.config, tp)
+    assert abs(fresh.amplitude - comp.amplitude) < 1e-9 * abs(fresh.amplitude)
