@@ -1,0 +1,132 @@
+/* pepsgpu.h -- C ABI of the MI355X boundary-MPS contraction library (libpepsgpu.so).
+ *
+ * The reference (QuantumLiquids/PEPS v0.1.0) has NO FFI: its seam is the compile-time
+ * `ContractorT` template parameter (include/qlpeps/vmc_basic/wave_function_component.h:136-140,
+ * concepts :24-87) filled by `BMPSContractor<TenElemT,QNT>`
+ * (include/qlpeps/two_dim_tn/tensor_network_2d/bmps/bmps_contractor.h:187-1027).
+ * Each entry point below replaces one method of that class (cited per function), batched over
+ * the Monte-Carlo walkers of one GPU: where the reference holds one TensorNetwork2D + one
+ * BMPSContractor per MPI rank, a context holds `n` walkers that advance in lockstep.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; host buffers are caller-owned; no exceptions cross the ABI.
+ *   - every call returns 0 on success or a PEPSGPU_E* code; pepsgpu_last_error(ctx) gives the text.
+ *     The host wrappers re-raise them as the reference's C++ exceptions (bmps_impl.h:839-843,
+ *     bmps_contractor.h:221-226, tensor_network_2d_basic_impl.h:37-66).
+ *   - positions: LEFT=0, DOWN=1, RIGHT=2, UP=3 (include/qlpeps/basic.h:58-63);
+ *     bond orientation: HORIZONTAL=0, VERTICAL=1 (basic.h:19-22).
+ *   - site tensors have leg order (L, D, R, U) (tensor_network_2d.h:39-45).
+ *   - amplitudes are returned as float64 (the device keeps per-environment log-scales).
+ */
+#ifndef PEPSGPU_H
+#define PEPSGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pepsgpu_ctx pepsgpu_ctx;
+
+enum {
+  PEPSGPU_OK = 0,
+  PEPSGPU_EINVAL = 1,     /* std::invalid_argument */
+  PEPSGPU_EHIP = 2,       /* device/runtime failure */
+  PEPSGPU_ESTATE = 3,     /* std::logic_error: environment / parameters not ready */
+  PEPSGPU_ERANGE = 4,     /* std::out_of_range: configuration value >= physical dim */
+  PEPSGPU_EEMPTY = 5      /* std::runtime_error: empty (zero) tensor, bmps_impl.h:839-843 */
+};
+enum { PEPSGPU_F32 = 0, PEPSGPU_F64 = 1 };
+enum { PEPSGPU_LEFT = 0, PEPSGPU_DOWN = 1, PEPSGPU_RIGHT = 2, PEPSGPU_UP = 3 };
+enum { PEPSGPU_HORIZONTAL = 0, PEPSGPU_VERTICAL = 1 };
+enum { PEPSGPU_SVD_COMPRESS = 0 };   /* bmps.h:31-35; variational schemes: not implemented */
+
+/* BMPSContractor(rows, cols) + SetTruncateParams(BMPSTruncateParams{D_min, D_max, trunc_err, scheme})
+ * (bmps_contractor.h:187-226, bmps.h:47-98).  dtype = element type of the device tensors. */
+int pepsgpu_ctx_create(pepsgpu_ctx **out, int device, int dtype, int rows, int cols, int D, int phys_dim,
+                       int chi_min, int chi_max, double trunc_err, int scheme, int max_walkers);
+void pepsgpu_ctx_destroy(pepsgpu_ctx *ctx);
+const char *pepsgpu_last_error(pepsgpu_ctx *ctx);
+
+/* SplitIndexTPS (two_dim_tn/tps/split_index_tps.h:80-606) as one flat host buffer
+ * [row][col][s][L][D][R][U], every leg zero-padded to D; host_dtype = PEPSGPU_F32 / PEPSGPU_F64.
+ * Replaces the MPI_Bcast of the state (mc_energy_grad_evaluator.h:161). */
+int pepsgpu_state_upload(pepsgpu_ctx *ctx, const void *sitps_flat, int host_dtype);
+
+/* TensorNetwork2D(sitps, config) + BMPSContractor::Init(tn) for n walkers
+ * (tensor_network_2d_basic_impl.h:24-74, bmps_contractor_init.h:25-70).  configs = [n][rows][cols]. */
+int pepsgpu_walkers_set_configs(pepsgpu_ctx *ctx, int n, const int32_t *configs);
+int pepsgpu_walkers_get_configs(pepsgpu_ctx *ctx, int32_t *configs_out);
+int pepsgpu_n_walkers(pepsgpu_ctx *ctx);
+
+/* BMPS stacks -- bmps_contractor_grow.h */
+int pepsgpu_grow_bmps_step(pepsgpu_ctx *ctx, int pos);          /* GrowBMPSStep(tn,pos)      :32-47   */
+int pepsgpu_grow_full_bmps(pepsgpu_ctx *ctx, int pos);          /* GrowFullBMPS              :49-86   */
+int pepsgpu_grow_bmps_for_row(pepsgpu_ctx *ctx, int row);       /* GrowBMPSForRow            :88-104  */
+int pepsgpu_grow_bmps_for_col(pepsgpu_ctx *ctx, int col);       /* GrowBMPSForCol            :106-122 */
+int pepsgpu_shift_bmps_window(pepsgpu_ctx *ctx, int pos);       /* ShiftBMPSWindow           :143-148 */
+int pepsgpu_delete_inner_bmps(pepsgpu_ctx *ctx, int pos);       /* DeleteInnerBMPS  bmps_contractor.h:320-324 */
+int pepsgpu_generate_bmps_approach(pepsgpu_ctx *ctx, int pos);  /* GenerateBMPSApproach      :11-17   */
+int pepsgpu_bmps_stack_size(pepsgpu_ctx *ctx, int pos);         /* GetBMPS(pos).size(); <0 on error */
+/* GetBMPS(pos)[level][idx]: dims_out[3]; data_out [n][d0*d1*d2] float64 (may be NULL);
+ * logscale_out [n] (may be NULL): the BMPS represents tensors * exp(logscale). Gauge differs
+ * from the reference (only gauge-invariant contractions are comparable). */
+int pepsgpu_get_bmps_tensor(pepsgpu_ctx *ctx, int pos, int level, int idx, int *dims_out, double *data_out,
+                            double *logscale_out);
+
+/* BTen (rank-3 environments of one row/column) -- bmps_contractor_init.h:72-128, grow.h:243-373,:517-582 */
+int pepsgpu_init_bten(pepsgpu_ctx *ctx, int pos, int slice);                               /* InitBTen      */
+int pepsgpu_grow_full_bten(pepsgpu_ctx *ctx, int pos, int slice, int remain_sites, int init); /* GrowFullBTen */
+int pepsgpu_grow_bten_step(pepsgpu_ctx *ctx, int pos);                                     /* GrowBTenStep  */
+int pepsgpu_shift_bten_window(pepsgpu_ctx *ctx, int pos);                                  /* ShiftBTenWindow */
+int pepsgpu_truncate_bten(pepsgpu_ctx *ctx, int pos, int length);                          /* TruncateBTen  */
+int pepsgpu_bten_stack_size(pepsgpu_ctx *ctx, int pos);
+
+/* Scalar contractions -- bmps_contractor_trace.h.  out_amp = [n] (or [n][n_cand]) float64. */
+int pepsgpu_trace(pepsgpu_ctx *ctx, int row, int col, int bond_dir, double *out_amp);       /* Trace :11-28 */
+/* ReplaceNNSiteTrace(tn, site_a, site_b, dir, T_a[cand[..][0]], T_b[cand[..][1]])  :90-205.
+ * cand_states = [n][n_cand][2] physical states put on (site_a, site_b). */
+int pepsgpu_replace_nn_trace(pepsgpu_ctx *ctx, int row, int col, int bond_dir, int n_cand,
+                             const int32_t *cand_states, double *out_amp);
+/* ReplaceOneSiteTrace(tn, site, T[cand], mps_orient)  :30-88.  cand_states = [n][n_cand]. */
+int pepsgpu_replace_one_trace(pepsgpu_ctx *ctx, int row, int col, int mps_orient, int n_cand,
+                              const int32_t *cand_states, double *out_amp);
+/* PunchHole(tn, site, mps_orient)  grow.h:150-183.  out = [n][D][D][D][D] float64 (legs L,D,R,U, zero padded). */
+int pepsgpu_punch_hole(pepsgpu_ctx *ctx, int row, int col, int mps_orient, double *out);
+
+/* TPSWaveFunctionComponent::UpdateLocal (wave_function_component.h:345-378) for the walkers with
+ * accept_mask[w] != 0 (NULL = all): config(site_k) = new_states[w][k], tn.UpdateSiteTensor,
+ * contractor.EraseEnvsAfterUpdate(site_k) (trace.h:538-589).  sites = [n_sites][2] (row, col). */
+int pepsgpu_update_local(pepsgpu_ctx *ctx, int n_sites, const int32_t *sites, const int32_t *new_states,
+                         const uint8_t *accept_mask);
+int pepsgpu_erase_envs_after_update(pepsgpu_ctx *ctx, int row, int col);                   /* trace.h:538-589 */
+
+/* TPSWaveFunctionComponent::EvaluateAmplitude (wave_function_component.h:187-212):
+ * GrowBMPSForRow(0); GrowFullBTen(RIGHT,0,2,true); InitBTen(LEFT,0); Trace({0,0},HORIZONTAL). */
+int pepsgpu_evaluate_amplitude(pepsgpu_ctx *ctx, double *out_amp);
+
+/* walker_flags[w] != 0: a boundary tensor of walker w vanished (reference throws, bmps_impl.h:839-843). */
+int pepsgpu_walker_flags(pepsgpu_ctx *ctx, int32_t *flags_out);
+int pepsgpu_sync(pepsgpu_ctx *ctx);
+/* stats_out: [0] row absorptions, [1] Jacobi launches, [2] reserved, [3] device bytes held */
+int pepsgpu_stats(pepsgpu_ctx *ctx, double *stats_out, int n);
+
+/* Energy/gradient accumulation that replaces MPIMeanTensor / MPI_Reduce
+ * (monte_carlo_tools/statistics_tensor.h:37-79, mc_energy_grad_evaluator.h:292-310): in-place
+ * sum over ranks of a DEVICE buffer is done by the host layer with RCCL (torch.distributed
+ * backend "nccl"); the library only exposes the device pointer arithmetic it needs. */
+
+/* ---- diagnostics (unit tests of the kernels; not part of the reference surface) ---- */
+int pepsgpu_diag_tgemm(int dtype_in, int dtype_out, const int *desc_ints, int n_ints, const void *A, size_t a_elems,
+                       const void *B, size_t b_elems, void *C, size_t c_elems, int nbatch, long wA, long wB, long wC);
+int pepsgpu_diag_chol(int dtype_out, const double *G, int n, int nbatch, void *R_out);
+int pepsgpu_diag_jacobi(int dtype, void *M, int m, int len, int nbatch, int k, void *Vt_out, void *S_out,
+                        int force_global, int *sweeps_out);
+const char *pepsgpu_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEPSGPU_H */

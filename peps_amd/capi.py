@@ -1,0 +1,264 @@
+"""ctypes binding of the C ABI declared in include/pepsgpu.h (libpepsgpu.so, HIP/gfx950).
+
+This is the Python-side stub a maintainer would write to bind the library; it contains no
+arithmetic and no CPU fallback: if the shared library is missing, import fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpepsgpu.so")
+
+F32, F64 = 0, 1
+LEFT, DOWN, RIGHT, UP = 0, 1, 2, 3
+HORIZONTAL, VERTICAL = 0, 1
+SVD_COMPRESS = 0
+
+_ERR = {1: ValueError, 2: RuntimeError, 3: RuntimeError, 4: IndexError, 5: RuntimeError}
+
+SYMBOLS = [
+    "pepsgpu_ctx_create", "pepsgpu_ctx_destroy", "pepsgpu_last_error", "pepsgpu_state_upload",
+    "pepsgpu_walkers_set_configs", "pepsgpu_walkers_get_configs", "pepsgpu_n_walkers",
+    "pepsgpu_grow_bmps_step", "pepsgpu_grow_full_bmps", "pepsgpu_grow_bmps_for_row", "pepsgpu_grow_bmps_for_col",
+    "pepsgpu_shift_bmps_window", "pepsgpu_delete_inner_bmps", "pepsgpu_generate_bmps_approach",
+    "pepsgpu_bmps_stack_size", "pepsgpu_get_bmps_tensor", "pepsgpu_init_bten", "pepsgpu_grow_full_bten",
+    "pepsgpu_grow_bten_step", "pepsgpu_shift_bten_window", "pepsgpu_truncate_bten", "pepsgpu_bten_stack_size",
+    "pepsgpu_trace", "pepsgpu_replace_nn_trace", "pepsgpu_replace_one_trace", "pepsgpu_punch_hole",
+    "pepsgpu_update_local", "pepsgpu_erase_envs_after_update", "pepsgpu_evaluate_amplitude",
+    "pepsgpu_walker_flags", "pepsgpu_sync", "pepsgpu_stats",
+    "pepsgpu_diag_tgemm", "pepsgpu_diag_chol", "pepsgpu_diag_jacobi", "pepsgpu_version",
+]
+
+
+def load_library(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise ImportError("libpepsgpu.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+    lib = C.CDLL(path)
+    vp, ip, dp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    lib.pepsgpu_ctx_create.argtypes = [C.POINTER(vp)] + [C.c_int] * 8 + [C.c_double, C.c_int, C.c_int]
+    lib.pepsgpu_ctx_destroy.argtypes = [vp]
+    lib.pepsgpu_ctx_destroy.restype = None
+    lib.pepsgpu_last_error.argtypes = [vp]
+    lib.pepsgpu_last_error.restype = C.c_char_p
+    lib.pepsgpu_version.restype = C.c_char_p
+    lib.pepsgpu_state_upload.argtypes = [vp, vp, C.c_int]
+    lib.pepsgpu_walkers_set_configs.argtypes = [vp, C.c_int, ip]
+    lib.pepsgpu_walkers_get_configs.argtypes = [vp, ip]
+    lib.pepsgpu_n_walkers.argtypes = [vp]
+    for name in ("grow_bmps_step", "grow_full_bmps", "grow_bmps_for_row", "grow_bmps_for_col", "shift_bmps_window",
+                 "delete_inner_bmps", "generate_bmps_approach", "bmps_stack_size", "bten_stack_size",
+                 "grow_bten_step", "shift_bten_window"):
+        getattr(lib, "pepsgpu_" + name).argtypes = [vp, C.c_int]
+    lib.pepsgpu_get_bmps_tensor.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip, dp, dp]
+    lib.pepsgpu_init_bten.argtypes = [vp, C.c_int, C.c_int]
+    lib.pepsgpu_truncate_bten.argtypes = [vp, C.c_int, C.c_int]
+    lib.pepsgpu_grow_full_bten.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.pepsgpu_trace.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
+    lib.pepsgpu_replace_nn_trace.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp]
+    lib.pepsgpu_replace_one_trace.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp]
+    lib.pepsgpu_punch_hole.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
+    lib.pepsgpu_update_local.argtypes = [vp, C.c_int, ip, ip, C.POINTER(C.c_uint8)]
+    lib.pepsgpu_erase_envs_after_update.argtypes = [vp, C.c_int, C.c_int]
+    lib.pepsgpu_evaluate_amplitude.argtypes = [vp, dp]
+    lib.pepsgpu_walker_flags.argtypes = [vp, ip]
+    lib.pepsgpu_sync.argtypes = [vp]
+    lib.pepsgpu_stats.argtypes = [vp, dp, C.c_int]
+    lib.pepsgpu_diag_tgemm.argtypes = [C.c_int, C.c_int, ip, C.c_int, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t,
+                                       C.c_int, C.c_long, C.c_long, C.c_long]
+    lib.pepsgpu_diag_chol.argtypes = [C.c_int, dp, C.c_int, C.c_int, vp]
+    lib.pepsgpu_diag_jacobi.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, ip]
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load_library()
+    return _lib
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Context:
+    """Thin RAII wrapper of a pepsgpu_ctx: one walker batch on one GPU."""
+
+    def __init__(self, rows, cols, D, phys_dim, chi, dtype=F32, device=0, max_walkers=256, chi_min=None,
+                 trunc_err=0.0):
+        self._l = lib()
+        self.rows, self.cols, self.D, self.d = rows, cols, D, phys_dim
+        self.dtype = dtype
+        h = C.c_void_p()
+        rc = self._l.pepsgpu_ctx_create(C.byref(h), device, dtype, rows, cols, D, phys_dim,
+                                        chi if chi_min is None else chi_min, chi, trunc_err, SVD_COMPRESS, max_walkers)
+        if rc != 0:
+            raise _ERR.get(rc, RuntimeError)("pepsgpu_ctx_create failed (%d): %s"
+                                             % (rc, self._l.pepsgpu_last_error(None).decode()))
+        self._h = h
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.pepsgpu_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise _ERR.get(rc, RuntimeError)("pepsgpu error %d: %s" % (rc, self._l.pepsgpu_last_error(self._h).decode()))
+
+    # -- state / walkers --
+    def state_upload(self, flat):
+        flat = np.ascontiguousarray(flat)
+        assert flat.shape == (self.rows, self.cols, self.d, self.D, self.D, self.D, self.D), flat.shape
+        hd = F32 if flat.dtype == np.float32 else F64
+        if hd == F64:
+            flat = flat.astype(np.float64, copy=False)
+        self._ck(self._l.pepsgpu_state_upload(self._h, flat.ctypes.data_as(C.c_void_p), hd))
+
+    def set_configs(self, configs):
+        cfg = np.ascontiguousarray(configs, dtype=np.int32)
+        assert cfg.ndim == 3 and cfg.shape[1:] == (self.rows, self.cols)
+        self._ck(self._l.pepsgpu_walkers_set_configs(self._h, cfg.shape[0], _ip(cfg)))
+        self.n = cfg.shape[0]
+
+    def get_configs(self):
+        out = np.zeros((self.n, self.rows, self.cols), dtype=np.int32)
+        self._ck(self._l.pepsgpu_walkers_get_configs(self._h, _ip(out)))
+        return out
+
+    # -- contractor mirror --
+    def grow_bmps_step(self, pos): self._ck(self._l.pepsgpu_grow_bmps_step(self._h, pos))
+    def grow_full_bmps(self, pos): self._ck(self._l.pepsgpu_grow_full_bmps(self._h, pos))
+    def grow_bmps_for_row(self, row): self._ck(self._l.pepsgpu_grow_bmps_for_row(self._h, row))
+    def grow_bmps_for_col(self, col): self._ck(self._l.pepsgpu_grow_bmps_for_col(self._h, col))
+    def shift_bmps_window(self, pos): self._ck(self._l.pepsgpu_shift_bmps_window(self._h, pos))
+    def delete_inner_bmps(self, pos): self._ck(self._l.pepsgpu_delete_inner_bmps(self._h, pos))
+    def generate_bmps_approach(self, pos): self._ck(self._l.pepsgpu_generate_bmps_approach(self._h, pos))
+    def bmps_stack_size(self, pos): return self._l.pepsgpu_bmps_stack_size(self._h, pos)
+    def bten_stack_size(self, pos): return self._l.pepsgpu_bten_stack_size(self._h, pos)
+    def init_bten(self, pos, slice_num): self._ck(self._l.pepsgpu_init_bten(self._h, pos, slice_num))
+    def grow_full_bten(self, pos, slice_num, remain_sites=2, init=True):
+        self._ck(self._l.pepsgpu_grow_full_bten(self._h, pos, slice_num, remain_sites, int(init)))
+    def grow_bten_step(self, pos): self._ck(self._l.pepsgpu_grow_bten_step(self._h, pos))
+    def shift_bten_window(self, pos): self._ck(self._l.pepsgpu_shift_bten_window(self._h, pos))
+    def truncate_bten(self, pos, length): self._ck(self._l.pepsgpu_truncate_bten(self._h, pos, length))
+
+    def get_bmps_tensor(self, pos, level, idx):
+        dims = np.zeros(3, dtype=np.int32)
+        self._ck(self._l.pepsgpu_get_bmps_tensor(self._h, pos, level, idx, _ip(dims), None, None))
+        data = np.zeros((self.n,) + tuple(int(x) for x in dims), dtype=np.float64)
+        ls = np.zeros(self.n, dtype=np.float64)
+        self._ck(self._l.pepsgpu_get_bmps_tensor(self._h, pos, level, idx, _ip(dims), _dp(data), _dp(ls)))
+        return data, ls
+
+    def trace(self, row, col, bond_dir):
+        out = np.zeros(self.n, dtype=np.float64)
+        self._ck(self._l.pepsgpu_trace(self._h, row, col, bond_dir, _dp(out)))
+        return out
+
+    def replace_nn_trace(self, row, col, bond_dir, cand_states):
+        cand = np.ascontiguousarray(cand_states, dtype=np.int32)
+        assert cand.ndim == 3 and cand.shape[0] == self.n and cand.shape[2] == 2
+        out = np.zeros((self.n, cand.shape[1]), dtype=np.float64)
+        self._ck(self._l.pepsgpu_replace_nn_trace(self._h, row, col, bond_dir, cand.shape[1], _ip(cand), _dp(out)))
+        return out
+
+    def replace_one_trace(self, row, col, orient, cand_states):
+        cand = np.ascontiguousarray(cand_states, dtype=np.int32)
+        assert cand.ndim == 2 and cand.shape[0] == self.n
+        out = np.zeros((self.n, cand.shape[1]), dtype=np.float64)
+        self._ck(self._l.pepsgpu_replace_one_trace(self._h, row, col, orient, cand.shape[1], _ip(cand), _dp(out)))
+        return out
+
+    def punch_hole(self, row, col, orient):
+        out = np.zeros((self.n, self.D, self.D, self.D, self.D), dtype=np.float64)
+        self._ck(self._l.pepsgpu_punch_hole(self._h, row, col, orient, _dp(out)))
+        return out
+
+    def update_local(self, sites, new_states, accept_mask=None):
+        sites = np.ascontiguousarray(sites, dtype=np.int32).reshape(-1, 2)
+        ns = np.ascontiguousarray(new_states, dtype=np.int32).reshape(self.n, sites.shape[0])
+        m = None
+        if accept_mask is not None:
+            m = np.ascontiguousarray(accept_mask, dtype=np.uint8)
+        self._ck(self._l.pepsgpu_update_local(self._h, sites.shape[0], _ip(sites), _ip(ns),
+                                              m.ctypes.data_as(C.POINTER(C.c_uint8)) if m is not None else None))
+
+    def erase_envs_after_update(self, row, col):
+        self._ck(self._l.pepsgpu_erase_envs_after_update(self._h, row, col))
+
+    def evaluate_amplitude(self):
+        out = np.zeros(self.n, dtype=np.float64)
+        self._ck(self._l.pepsgpu_evaluate_amplitude(self._h, _dp(out)))
+        return out
+
+    def walker_flags(self):
+        out = np.zeros(self.n, dtype=np.int32)
+        self._ck(self._l.pepsgpu_walker_flags(self._h, _ip(out)))
+        return out
+
+    def sync(self):
+        self._ck(self._l.pepsgpu_sync(self._h))
+
+    def stats(self):
+        out = np.zeros(5, dtype=np.float64)
+        self._ck(self._l.pepsgpu_stats(self._h, _dp(out), 5))
+        return {"absorptions": int(out[0]), "jacobi_launches": int(out[1]), "jacobi_sweeps_sum": int(out[2]),
+                "device_bytes": int(out[3]), "jacobi_sweeps_max": int(out[4])}
+
+
+# -- diagnostics (kernel unit tests) --
+def diag_tgemm(dtype_in, dtype_out, I, J, K, sAi, sAk, sBk, sBj, sCi, sCj, A, B, C_init, nbatch, wA, wB, wC):
+    ints = np.array(list(I) + list(J) + list(K) + list(sAi) + list(sAk) + list(sBk) + list(sBj) + list(sCi) + list(sCj),
+                    dtype=np.int32)
+    tin = np.float32 if dtype_in == F32 else np.float64
+    tout = np.float32 if dtype_out == F32 else np.float64
+    A = np.ascontiguousarray(A, dtype=tin)
+    B = np.ascontiguousarray(B, dtype=tin)
+    Cc = np.ascontiguousarray(C_init, dtype=tout).copy()
+    rc = lib().pepsgpu_diag_tgemm(dtype_in, dtype_out, _ip(ints), 27, A.ctypes.data_as(C.c_void_p), A.size,
+                                  B.ctypes.data_as(C.c_void_p), B.size, Cc.ctypes.data_as(C.c_void_p), Cc.size,
+                                  nbatch, wA, wB, wC)
+    if rc != 0:
+        raise RuntimeError("diag_tgemm failed: %s" % lib().pepsgpu_last_error(None).decode())
+    return Cc
+
+
+def diag_chol(dtype_out, G):
+    G = np.ascontiguousarray(G, dtype=np.float64)
+    nb, n, _ = G.shape
+    R = np.zeros((nb, n, n), dtype=np.float32 if dtype_out == F32 else np.float64)
+    rc = lib().pepsgpu_diag_chol(dtype_out, _dp(G), n, nb, R.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise RuntimeError("diag_chol failed: %s" % lib().pepsgpu_last_error(None).decode())
+    return R
+
+
+def diag_jacobi(dtype, M, k, force_global=False):
+    t = np.float32 if dtype == F32 else np.float64
+    M = np.ascontiguousarray(M, dtype=t).copy()
+    nb, m, ln = M.shape
+    Vt = np.zeros((nb, k, ln), dtype=t)
+    S = np.zeros((nb, k), dtype=t)
+    sw = np.zeros(nb, dtype=np.int32)
+    rc = lib().pepsgpu_diag_jacobi(dtype, M.ctypes.data_as(C.c_void_p), m, ln, nb, k, Vt.ctypes.data_as(C.c_void_p),
+                                   S.ctypes.data_as(C.c_void_p), int(force_global), _ip(sw))
+    if rc != 0:
+        raise RuntimeError("diag_jacobi failed: %s" % lib().pepsgpu_last_error(None).decode())
+    return M, Vt, S, sw

@@ -1,0 +1,238 @@
+// extern "C" boundary of libpepsgpu.so (declared in include/pepsgpu.h).
+#include <cstring>
+#include "../../include/pepsgpu.h"
+#include "engine_impl.h"
+
+using namespace pepsgpu;
+
+namespace pepsgpu {
+bool tgemm_use_mfma() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("PEPSGPU_NO_MFMA");
+    v = (e && e[0] == '1') ? 0 : 1;
+  }
+  return v == 1;
+}
+}  // namespace pepsgpu
+
+struct pepsgpu_ctx {
+  EngineBase *eng = nullptr;
+  std::string err;
+};
+
+static thread_local std::string g_err;
+
+template <typename F>
+static int guarded(pepsgpu_ctx *ctx, F &&f) {
+  try {
+    f();
+    return PEPSGPU_OK;
+  } catch (const Error &e) {
+    if (ctx) ctx->err = e.what(); else g_err = e.what();
+    return e.code;
+  } catch (const std::exception &e) {
+    if (ctx) ctx->err = e.what(); else g_err = e.what();
+    return PEPSGPU_EHIP;
+  }
+}
+
+#define CTX_CALL(body)                                     \
+  if (!ctx || !ctx->eng) return PEPSGPU_EINVAL;            \
+  return guarded(ctx, [&]() { body; })
+
+extern "C" {
+
+const char *pepsgpu_version(void) { return "pepsgpu 0.1 (gfx950)"; }
+
+int pepsgpu_ctx_create(pepsgpu_ctx **out, int device, int dtype, int rows, int cols, int D, int phys_dim,
+                       int chi_min, int chi_max, double trunc_err, int scheme, int max_walkers) {
+  if (!out) return PEPSGPU_EINVAL;
+  *out = nullptr;
+  pepsgpu_ctx *ctx = new pepsgpu_ctx;
+  int rc = guarded(nullptr, [&]() {
+    PG_REQUIRE(scheme == PEPSGPU_SVD_COMPRESS, 1, "only CompressMPSScheme::SVD_COMPRESS is implemented");
+    PG_REQUIRE(chi_min <= chi_max, 1, "D_min > D_max");
+    int ndev = 0;
+    PG_CHECK_HIP(hipGetDeviceCount(&ndev));
+    PG_REQUIRE(ndev > 0 && device >= 0 && device < ndev, 2, "no such HIP device");
+    if (dtype == PEPSGPU_F32)
+      ctx->eng = new Engine<float>(device, rows, cols, D, phys_dim, chi_min, chi_max, trunc_err, max_walkers);
+    else if (dtype == PEPSGPU_F64)
+      ctx->eng = new Engine<double>(device, rows, cols, D, phys_dim, chi_min, chi_max, trunc_err, max_walkers);
+    else
+      throw Error(1, "unknown dtype");
+  });
+  if (rc != PEPSGPU_OK) {
+    delete ctx;
+    return rc;
+  }
+  *out = ctx;
+  return PEPSGPU_OK;
+}
+
+void pepsgpu_ctx_destroy(pepsgpu_ctx *ctx) {
+  if (!ctx) return;
+  delete ctx->eng;
+  delete ctx;
+}
+
+const char *pepsgpu_last_error(pepsgpu_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int pepsgpu_state_upload(pepsgpu_ctx *ctx, const void *p, int host_dtype) {
+  CTX_CALL(PG_REQUIRE(p != nullptr, 1, "null state buffer"); ctx->eng->state_upload(p, host_dtype));
+}
+int pepsgpu_walkers_set_configs(pepsgpu_ctx *ctx, int n, const int32_t *cfg) {
+  CTX_CALL(PG_REQUIRE(cfg != nullptr, 1, "null configuration buffer"); ctx->eng->set_configs(n, cfg));
+}
+int pepsgpu_walkers_get_configs(pepsgpu_ctx *ctx, int32_t *out) { CTX_CALL(ctx->eng->get_configs(out)); }
+int pepsgpu_n_walkers(pepsgpu_ctx *ctx) { return (ctx && ctx->eng) ? ctx->eng->n_walkers() : -1; }
+
+static void check_pos(int pos) { PG_REQUIRE(pos >= 0 && pos < 4, 1, "bad BMPSPOSITION"); }
+
+int pepsgpu_grow_bmps_step(pepsgpu_ctx *ctx, int pos) { CTX_CALL(check_pos(pos); ctx->eng->grow_bmps_step(pos)); }
+int pepsgpu_grow_full_bmps(pepsgpu_ctx *ctx, int pos) { CTX_CALL(check_pos(pos); ctx->eng->grow_full_bmps(pos)); }
+int pepsgpu_grow_bmps_for_row(pepsgpu_ctx *ctx, int row) { CTX_CALL(ctx->eng->grow_bmps_for_row(row)); }
+int pepsgpu_grow_bmps_for_col(pepsgpu_ctx *ctx, int col) { CTX_CALL(ctx->eng->grow_bmps_for_col(col)); }
+int pepsgpu_shift_bmps_window(pepsgpu_ctx *ctx, int pos) { CTX_CALL(check_pos(pos); ctx->eng->shift_bmps_window(pos)); }
+int pepsgpu_delete_inner_bmps(pepsgpu_ctx *ctx, int pos) { CTX_CALL(check_pos(pos); ctx->eng->delete_inner_bmps(pos)); }
+int pepsgpu_generate_bmps_approach(pepsgpu_ctx *ctx, int pos) {
+  CTX_CALL(check_pos(pos); ctx->eng->generate_bmps_approach(pos));
+}
+int pepsgpu_bmps_stack_size(pepsgpu_ctx *ctx, int pos) {
+  if (!ctx || !ctx->eng || pos < 0 || pos > 3) return -1;
+  return ctx->eng->bmps_size(pos);
+}
+int pepsgpu_bten_stack_size(pepsgpu_ctx *ctx, int pos) {
+  if (!ctx || !ctx->eng || pos < 0 || pos > 3) return -1;
+  return ctx->eng->bten_size(pos);
+}
+int pepsgpu_get_bmps_tensor(pepsgpu_ctx *ctx, int pos, int level, int idx, int *dims, double *data, double *ls) {
+  CTX_CALL(check_pos(pos); ctx->eng->get_bmps_tensor(pos, level, idx, dims, data, ls));
+}
+
+int pepsgpu_init_bten(pepsgpu_ctx *ctx, int pos, int slice) { CTX_CALL(check_pos(pos); ctx->eng->init_bten(pos, slice)); }
+int pepsgpu_grow_full_bten(pepsgpu_ctx *ctx, int pos, int slice, int remain, int init) {
+  CTX_CALL(check_pos(pos); ctx->eng->grow_full_bten(pos, slice, remain, init));
+}
+int pepsgpu_grow_bten_step(pepsgpu_ctx *ctx, int pos) { CTX_CALL(check_pos(pos); ctx->eng->grow_bten_step(pos)); }
+int pepsgpu_shift_bten_window(pepsgpu_ctx *ctx, int pos) { CTX_CALL(check_pos(pos); ctx->eng->shift_bten_window(pos)); }
+int pepsgpu_truncate_bten(pepsgpu_ctx *ctx, int pos, int len) { CTX_CALL(check_pos(pos); ctx->eng->truncate_bten(pos, len)); }
+
+int pepsgpu_trace(pepsgpu_ctx *ctx, int row, int col, int dir, double *out) {
+  CTX_CALL(ctx->eng->trace(row, col, dir, out));
+}
+int pepsgpu_replace_nn_trace(pepsgpu_ctx *ctx, int row, int col, int dir, int ncand, const int32_t *cand, double *out) {
+  CTX_CALL(PG_REQUIRE(ncand >= 1 && cand, 1, "need >= 1 candidate"); ctx->eng->replace_nn_trace(row, col, dir, ncand, cand, out));
+}
+int pepsgpu_replace_one_trace(pepsgpu_ctx *ctx, int row, int col, int orient, int ncand, const int32_t *cand, double *out) {
+  CTX_CALL(PG_REQUIRE(ncand >= 1 && cand, 1, "need >= 1 candidate"); ctx->eng->replace_one_trace(row, col, orient, ncand, cand, out));
+}
+int pepsgpu_punch_hole(pepsgpu_ctx *ctx, int row, int col, int orient, double *out) {
+  CTX_CALL(ctx->eng->punch_hole(row, col, orient, out));
+}
+int pepsgpu_update_local(pepsgpu_ctx *ctx, int nsites, const int32_t *sites, const int32_t *ns, const uint8_t *mask) {
+  CTX_CALL(ctx->eng->update_local(nsites, sites, ns, mask));
+}
+int pepsgpu_erase_envs_after_update(pepsgpu_ctx *ctx, int row, int col) {
+  CTX_CALL(ctx->eng->erase_envs_after_update(row, col));
+}
+int pepsgpu_evaluate_amplitude(pepsgpu_ctx *ctx, double *out) { CTX_CALL(ctx->eng->evaluate_amplitude(out)); }
+int pepsgpu_walker_flags(pepsgpu_ctx *ctx, int32_t *out) { CTX_CALL(ctx->eng->read_flags(out)); }
+int pepsgpu_sync(pepsgpu_ctx *ctx) { CTX_CALL(ctx->eng->sync()); }
+int pepsgpu_stats(pepsgpu_ctx *ctx, double *out, int n) { CTX_CALL(ctx->eng->stats(out, n)); }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// diagnostics
+template <typename TI, typename TO, typename TAcc>
+static void diag_tgemm_t(const TGemmDesc &d, const void *A, size_t na, const void *B, size_t nb, void *C, size_t nc) {
+  TI *dA, *dB;
+  TO *dC;
+  PG_CHECK_HIP(hipMalloc(&dA, na * sizeof(TI)));
+  PG_CHECK_HIP(hipMalloc(&dB, nb * sizeof(TI)));
+  PG_CHECK_HIP(hipMalloc(&dC, nc * sizeof(TO)));
+  PG_CHECK_HIP(hipMemcpy(dA, A, na * sizeof(TI), hipMemcpyHostToDevice));
+  PG_CHECK_HIP(hipMemcpy(dB, B, nb * sizeof(TI), hipMemcpyHostToDevice));
+  PG_CHECK_HIP(hipMemcpy(dC, C, nc * sizeof(TO), hipMemcpyHostToDevice));
+  tgemm_launch<TI, TI, TO, TAcc>(0, d, dA, dB, dC);
+  PG_CHECK_HIP(hipDeviceSynchronize());
+  PG_CHECK_HIP(hipMemcpy(C, dC, nc * sizeof(TO), hipMemcpyDeviceToHost));
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
+}
+
+extern "C" int pepsgpu_diag_tgemm(int dtype_in, int dtype_out, const int *di, int n_ints, const void *A, size_t na, const void *B,
+                       size_t nb, void *C, size_t nc, int nbatch, long wA, long wB, long wC) {
+  return guarded(nullptr, [&]() {
+    PG_REQUIRE(n_ints == 27, 1, "descriptor needs 27 ints");
+    TGemmDesc d;
+    for (int k = 0; k < 3; ++k) {
+      d.I[k] = di[k]; d.J[k] = di[3 + k]; d.K[k] = di[6 + k];
+      d.sAi[k] = di[9 + k]; d.sAk[k] = di[12 + k]; d.sBk[k] = di[15 + k];
+      d.sBj[k] = di[18 + k]; d.sCi[k] = di[21 + k]; d.sCj[k] = di[24 + k];
+    }
+    d.wA = wA; d.wB = wB; d.wC = wC; d.nbatch = nbatch;
+    if (dtype_in == 0 && dtype_out == 0) diag_tgemm_t<float, float, float>(d, A, na, B, nb, C, nc);
+    else if (dtype_in == 1 && dtype_out == 1) diag_tgemm_t<double, double, double>(d, A, na, B, nb, C, nc);
+    else if (dtype_in == 0 && dtype_out == 1) diag_tgemm_t<float, double, double>(d, A, na, B, nb, C, nc);
+    else throw Error(1, "unsupported dtype combination");
+  });
+}
+
+template <typename T>
+static void diag_chol_t(const double *G, int n, int nbatch, void *Rout) {
+  double *dG;
+  T *dR;
+  size_t ne = (size_t)n * n * nbatch;
+  PG_CHECK_HIP(hipMalloc(&dG, ne * sizeof(double)));
+  PG_CHECK_HIP(hipMalloc(&dR, ne * sizeof(T)));
+  PG_CHECK_HIP(hipMemcpy(dG, G, ne * sizeof(double), hipMemcpyHostToDevice));
+  size_t smem = sizeof(double) * ((size_t)CH_NB * n + 64 * CH_NB);
+  allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
+  hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nbatch), dim3(256), smem, 0, dG, (long)n * n, n, dR, (long)n * n);
+  PG_CHECK_HIP(hipGetLastError());
+  PG_CHECK_HIP(hipDeviceSynchronize());
+  PG_CHECK_HIP(hipMemcpy(Rout, dR, ne * sizeof(T), hipMemcpyDeviceToHost));
+  (void)hipFree(dG); (void)hipFree(dR);
+}
+extern "C" int pepsgpu_diag_chol(int dtype_out, const double *G, int n, int nbatch, void *R_out) {
+  return guarded(nullptr, [&]() {
+    if (dtype_out == 0) diag_chol_t<float>(G, n, nbatch, R_out); else diag_chol_t<double>(G, n, nbatch, R_out);
+  });
+}
+
+template <typename T>
+static void diag_jacobi_t(void *M, int m, int len, int nbatch, int k, void *Vt, void *S, int force_global, int *sweeps) {
+  T *dM, *dV, *dS;
+  int *dsw;
+  size_t ne = (size_t)m * len * nbatch;
+  PG_CHECK_HIP(hipMalloc(&dM, ne * sizeof(T)));
+  PG_CHECK_HIP(hipMalloc(&dV, (size_t)k * len * nbatch * sizeof(T)));
+  PG_CHECK_HIP(hipMalloc(&dS, (size_t)k * nbatch * sizeof(T)));
+  PG_CHECK_HIP(hipMalloc(&dsw, nbatch * sizeof(int)));
+  PG_CHECK_HIP(hipMemcpy(dM, M, ne * sizeof(T), hipMemcpyHostToDevice));
+  const size_t need = sizeof(T) * (size_t)m * (len | 1);
+  const int use_lds = !force_global && need <= JACOBI_LDS_MAX;
+  if (use_lds) allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), need);
+  hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nbatch), dim3(1024), use_lds ? need : 0, 0, dM, (long)m * len, m, len,
+                     len, 40, use_lds, dsw);
+  PG_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nbatch), dim3(256), 0, 0, (const T *)dM, (long)m * len, m, len, len, k,
+                     dV, (long)k * len, dS, (long)k);
+  PG_CHECK_HIP(hipGetLastError());
+  PG_CHECK_HIP(hipDeviceSynchronize());
+  PG_CHECK_HIP(hipMemcpy(M, dM, ne * sizeof(T), hipMemcpyDeviceToHost));
+  PG_CHECK_HIP(hipMemcpy(Vt, dV, (size_t)k * len * nbatch * sizeof(T), hipMemcpyDeviceToHost));
+  PG_CHECK_HIP(hipMemcpy(S, dS, (size_t)k * nbatch * sizeof(T), hipMemcpyDeviceToHost));
+  if (sweeps) PG_CHECK_HIP(hipMemcpy(sweeps, dsw, nbatch * sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(dM); (void)hipFree(dV); (void)hipFree(dS); (void)hipFree(dsw);
+}
+extern "C" int pepsgpu_diag_jacobi(int dtype, void *M, int m, int len, int nbatch, int k, void *Vt, void *S, int force_global,
+                        int *sweeps) {
+  return guarded(nullptr, [&]() {
+    PG_REQUIRE(m <= 1024 && k <= m, 1, "bad sizes");
+    if (dtype == 0) diag_jacobi_t<float>(M, m, len, nbatch, k, Vt, S, force_global, sweeps);
+    else diag_jacobi_t<double>(M, m, len, nbatch, k, Vt, S, force_global, sweeps);
+  });
+}

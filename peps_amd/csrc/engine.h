@@ -1,0 +1,689 @@
+// Walker-batched boundary-MPS engine (device side of the C ABI in include/pepsgpu.h).
+//
+// All walkers of a context advance in lockstep through the same contractor calls; every tensor
+// of the reference's per-walker BMPSContractor (bmps_contractor.h:187-232) becomes one device
+// buffer [walker][elements].  The projected TensorNetwork2D (tensor_network_2d_basic_impl.h:24-74)
+// is never materialised: kernels pick T[r][c][config[w][r][c]] out of the shared SITPS buffer.
+//
+// Row absorption (BMPS::MultiplyMPO, bmps_impl.h:756-862 + :225-263) is restated "Q-less":
+//   forward   P_i = R_i (A_i x W_i)            (same two contractions as :806-807)
+//             R_{i+1}: R^T R = P_i^T P_i       (f64 Gram + Cholesky; equals the R of QR :821)
+//   backward  T_i = (A_i x W_i) Y_{i+1},  M_i = R_i T_i  (= Q_i . (u s)_{i+1} of :254)
+//             rows of M_i -> Jacobi -> Vt_i (chi largest),  Y_i = T_i Vt_i^T
+//   res[i] = Vt_i, res[0] = T_0.  The result equals the reference's up to the bond gauge
+//   (validated against the op-for-op oracle); see DESIGN.md.
+#pragma once
+#include <cmath>
+#include <memory>
+#include "common.h"
+#include "linalg.h"
+#include "tgemm.h"
+
+namespace pepsgpu {
+
+enum { LEFT = 0, DOWN = 1, RIGHT = 2, UP = 3 };      // include/qlpeps/basic.h:58-63
+enum { HORIZONTAL = 0, VERTICAL = 1 };               // include/qlpeps/basic.h:19-22
+
+struct EngineBase {
+  virtual ~EngineBase() {}
+  std::string last_error;
+  int dtype = 0;
+  // --- contractor surface (all walkers in lockstep) ---
+  virtual void state_upload(const void *host, int host_dtype) = 0;
+  virtual void set_configs(int n, const int32_t *cfg) = 0;
+  virtual void get_configs(int32_t *out) = 0;
+  virtual int n_walkers() const = 0;
+  virtual void init_bmps(int pos) = 0;
+  virtual int bmps_size(int pos) const = 0;
+  virtual int bten_size(int pos) const = 0;
+  virtual void grow_bmps_step(int pos) = 0;
+  virtual void grow_full_bmps(int pos) = 0;
+  virtual void grow_bmps_for_row(int row) = 0;
+  virtual void grow_bmps_for_col(int col) = 0;
+  virtual void shift_bmps_window(int pos) = 0;
+  virtual void delete_inner_bmps(int pos) = 0;
+  virtual void generate_bmps_approach(int pos) = 0;
+  virtual void init_bten(int pos, int slice) = 0;
+  virtual void grow_full_bten(int pos, int slice, int remain, int init) = 0;
+  virtual void grow_bten_step(int pos) = 0;
+  virtual void shift_bten_window(int pos) = 0;
+  virtual void truncate_bten(int pos, int len) = 0;
+  virtual void trace(int row, int col, int dir, double *out) = 0;
+  virtual void replace_nn_trace(int row, int col, int dir, int ncand, const int32_t *cand, double *out) = 0;
+  virtual void replace_one_trace(int row, int col, int orient, int ncand, const int32_t *cand, double *out) = 0;
+  virtual void punch_hole(int row, int col, int orient, double *out) = 0;
+  virtual void update_local(int nsites, const int32_t *sites, const int32_t *new_states, const uint8_t *mask) = 0;
+  virtual void erase_envs_after_update(int row, int col) = 0;
+  virtual void evaluate_amplitude(double *out) = 0;
+  virtual void get_bmps_tensor(int pos, int level, int idx, int *dims, double *out, double *logscale) = 0;
+  virtual void sync() = 0;
+  virtual void read_flags(int32_t *out) = 0;
+  virtual size_t device_bytes() const = 0;
+  virtual void stats(double *out, int n) = 0;
+};
+
+template <typename T>
+struct DTen {
+  T *p = nullptr;
+  int d[4] = {1, 1, 1, 1};
+  long n = 0;   // elements per walker (= batch stride)
+  int rank = 3;
+};
+
+template <typename T>
+class Engine : public EngineBase {
+ public:
+  Engine(int device, int Ly, int Lx, int D, int dphys, int chi_min, int chi_max, double trunc_err, int max_walkers)
+      : Ly_(Ly), Lx_(Lx), D_(D), dp_(dphys), chi_min_(chi_min), chi_(chi_max), trunc_err_(trunc_err),
+        maxw_(max_walkers) {
+    PG_REQUIRE(Ly >= 2 && Lx >= 2, 1, "lattice must be at least 2x2");
+    PG_REQUIRE(D >= 1 && dphys >= 1 && chi_max >= 1 && max_walkers >= 1, 1, "bad dimensions");
+    PG_REQUIRE(trunc_err == 0.0, 1,
+               "only trunc_err == 0 (fixed bond dimension D_max) is implemented on the device");
+    PG_CHECK_HIP(hipSetDevice(device));
+    device_ = device;
+    PG_CHECK_HIP(hipStreamCreate(&stream_));
+    slot_ = (long)D * D * D * D;
+    sitps_ = (T *)arena_.alloc(sizeof(T) * slot_ * dp_ * Ly * Lx);
+    cfg_ = (int *)arena_.alloc(sizeof(int) * (size_t)maxw_ * Ly * Lx);
+    flag_ = (int *)arena_.alloc(sizeof(int) * (size_t)maxw_);
+    sweeps_ = (int *)arena_.alloc(sizeof(int) * (size_t)maxw_);
+    { const char *e = getenv("PEPSGPU_DEBUG_SWEEPS"); dbg_sweeps_ = e && e[0] == '1'; }
+    PG_CHECK_HIP(hipMemsetAsync(flag_, 0, sizeof(int) * (size_t)maxw_, stream_));
+    dtype = sizeof(T) == 4 ? 0 : 1;
+  }
+  ~Engine() override {
+    (void)hipStreamSynchronize(stream_);
+    arena_.release();
+    (void)hipStreamDestroy(stream_);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  void site_dims(int r, int c, int *dd) const {
+    dd[0] = c == 0 ? 1 : D_;
+    dd[1] = r == Ly_ - 1 ? 1 : D_;
+    dd[2] = c == Lx_ - 1 ? 1 : D_;
+    dd[3] = r == 0 ? 1 : D_;
+  }
+  void site_strides(int r, int c, int *ss) const {
+    int dd[4];
+    site_dims(r, c, dd);
+    ss[3] = 1; ss[2] = dd[3]; ss[1] = dd[2] * dd[3]; ss[0] = dd[1] * dd[2] * dd[3];
+  }
+
+  void state_upload(const void *host, int host_dtype) override {
+    // host layout [row][col][s][L][D][R][U] zero padded to D^4; stored compact in each slot
+    std::vector<T> buf((size_t)slot_ * dp_ * Ly_ * Lx_, T(0));
+    for (int r = 0; r < Ly_; ++r)
+      for (int c = 0; c < Lx_; ++c) {
+        int dd[4];
+        site_dims(r, c, dd);
+        for (int s = 0; s < dp_; ++s) {
+          size_t base = ((size_t)(r * Lx_ + c) * dp_ + s) * slot_;
+          size_t o = 0;
+          for (int a = 0; a < dd[0]; ++a)
+            for (int b = 0; b < dd[1]; ++b)
+              for (int cc = 0; cc < dd[2]; ++cc)
+                for (int e = 0; e < dd[3]; ++e) {
+                  size_t src = base + (((size_t)a * D_ + b) * D_ + cc) * D_ + e;
+                  double v = host_dtype == 0 ? (double)((const float *)host)[src] : ((const double *)host)[src];
+                  buf[base + o++] = T(v);
+                }
+        }
+      }
+    PG_CHECK_HIP(hipMemcpyAsync(sitps_, buf.data(), buf.size() * sizeof(T), hipMemcpyHostToDevice, stream_));
+    PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    have_state_ = true;
+  }
+
+  void set_configs(int n, const int32_t *cfg) override {
+    PG_REQUIRE(n >= 1 && n <= maxw_, 1, "walker count out of range");
+    for (long i = 0; i < (long)n * Ly_ * Lx_; ++i)
+      PG_REQUIRE(cfg[i] >= 0 && cfg[i] < dp_, 4, "configuration value exceeds physical dimension");
+    nw_ = n;
+    hcfg_.assign(cfg, cfg + (size_t)n * Ly_ * Lx_);
+    PG_CHECK_HIP(hipMemcpyAsync(cfg_, hcfg_.data(), hcfg_.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+    PG_CHECK_HIP(hipMemsetAsync(flag_, 0, sizeof(int) * (size_t)maxw_, stream_));
+    PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    // Init(tn): bmps_contractor_init.h:25-32
+    for (int p = 0; p < 4; ++p) {
+      clear_bmps(p, 0);
+      clear_bten(p, 0);
+      init_bmps(p);
+    }
+  }
+  void get_configs(int32_t *out) override { std::copy(hcfg_.begin(), hcfg_.end(), out); }
+  int n_walkers() const override { return nw_; }
+
+  // ------------------------------------------------------------------------------------------
+  struct BMPSDev {
+    std::vector<DTen<T>> t;
+    double *logscale = nullptr;
+  };
+  struct BTenDev {
+    DTen<T> t;
+    double *logscale = nullptr;
+  };
+
+  int mps_len(int pos) const { return (pos == DOWN || pos == UP) ? Lx_ : Ly_; }
+  int bmps_size(int pos) const override { return (int)bmps_[pos].size(); }
+  int bten_size(int pos) const override { return (int)bten_[pos].size(); }
+
+  void init_bmps(int pos) override {   // bmps_contractor_init.h:34-70, bmps_impl.h:60-96
+    PG_REQUIRE(nw_ > 0, 3, "set walker configurations first");
+    PG_REQUIRE(bmps_[pos].empty(), 3, "InitBMPS: stack not empty");
+    BMPSDev b;
+    int n = mps_len(pos);
+    for (int i = 0; i < n; ++i) b.t.push_back(ones3());
+    b.logscale = zeros_f64();
+    bmps_[pos].push_back(std::move(b));
+  }
+
+  void grow_bmps_step(int pos) override {   // bmps_contractor_grow.h:32-47
+    require_ready();
+    int existed = bmps_size(pos);
+    PG_REQUIRE(existed > 0, 3, "GrowBMPSStep: stack empty");
+    int num;
+    if (pos == UP || pos == LEFT) num = existed - 1;
+    else if (pos == DOWN) num = Ly_ - existed;
+    else num = Lx_ - existed;
+    int lim = (pos == UP || pos == DOWN) ? Ly_ : Lx_;
+    PG_REQUIRE(num >= 0 && num < lim, 3, "GrowBMPSStep: no slice left to absorb");
+    absorb(pos, num);
+  }
+  void grow_full_bmps(int pos) override {   // grow.h:49-86
+    int existed = bmps_size(pos);
+    PG_REQUIRE(existed > 0, 3, "GrowFullBMPS: stack empty");
+    int lim = (pos == UP || pos == DOWN) ? Ly_ : Lx_;
+    for (int k = existed; k < lim; ++k) grow_bmps_step(pos);
+  }
+  void grow_bmps_for_row(int row) override {   // grow.h:88-104
+    while (Ly_ - bmps_size(DOWN) > row) grow_bmps_step(DOWN);
+    while (bmps_size(UP) - 1 < row) grow_bmps_step(UP);
+  }
+  void grow_bmps_for_col(int col) override {   // grow.h:106-122
+    while (Lx_ - bmps_size(RIGHT) > col) grow_bmps_step(RIGHT);
+    while (bmps_size(LEFT) - 1 < col) grow_bmps_step(LEFT);
+  }
+  void shift_bmps_window(int pos) override {   // grow.h:143-148
+    PG_REQUIRE(bmps_size(pos) > 0, 3, "ShiftBMPSWindow: stack empty");
+    clear_bmps(pos, bmps_size(pos) - 1);
+    grow_bmps_step((pos + 2) % 4);
+  }
+  void delete_inner_bmps(int pos) override {   // bmps_contractor.h:320-324
+    if (bmps_size(pos) > 1) clear_bmps(pos, 1);
+  }
+  void generate_bmps_approach(int pos) override {   // grow.h:11-17
+    delete_inner_bmps(pos);
+    grow_full_bmps((pos + 2) % 4);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  void init_bten(int pos, int slice) override {   // init.h:72-120
+    require_ready();
+    (void)slice;
+    clear_bten(pos, 0);
+    BTenDev b;
+    b.t = ones3();
+    b.logscale = zeros_f64();
+    bten_[pos].push_back(b);
+  }
+  void truncate_bten(int pos, int len) override {   // init.h:122-128
+    if (bten_size(pos) > len) clear_bten(pos, len);
+  }
+
+  const BMPSDev &bmps_at_slice(int pos, int idx) const {   // bmps_contractor.h:985-999
+    int k = idx;
+    if (pos == DOWN) k = Ly_ - 1 - idx;
+    if (pos == RIGHT) k = Lx_ - 1 - idx;
+    PG_REQUIRE(k >= 0 && k < (int)bmps_[pos].size(), 3, "BMPS environment not available for this slice");
+    return bmps_[pos][k];
+  }
+  const BTenDev &bten_at_slice(int pos, int idx) const {   // bmps_contractor.h:1003-1009
+    int k = idx;
+    if (pos == DOWN) k = Ly_ - 1 - idx;
+    if (pos == RIGHT) k = Lx_ - 1 - idx;
+    PG_REQUIRE(k >= 0 && k < (int)bten_[pos].size(), 3, "BTen environment not available for this slice");
+    return bten_[pos][k];
+  }
+  static const DTen<T> &at_logical(const BMPSDev &b, int pos, int col) {   // bmps.h:214-227
+    int n = (int)b.t.size();
+    return (pos == UP || pos == RIGHT) ? b.t[n - 1 - col] : b.t[col];
+  }
+
+  void grow_full_bten(int pos, int slice, int remain, int init) override {   // grow.h:243-373
+    require_ready();
+    if (init) init_bten(pos, slice);
+    PG_REQUIRE(bten_size(pos) > 0, 3, "GrowFullBTen: BTen not initialised");
+    int n = (pos == DOWN || pos == UP) ? Ly_ : Lx_;
+    int pre = (pos + 3) % 4, nxt = (pos + 1) % 4;
+    const BMPSDev &b1 = bmps_at_slice(pre, slice);
+    const BMPSDev &b2 = bmps_at_slice(nxt, slice);
+    for (int i = bten_size(pos) - 1; i < n - remain; ++i) {
+      int r, c;
+      switch (pos) {
+        case DOWN: r = n - i - 1; c = slice; break;
+        case UP: r = i; c = slice; break;
+        case LEFT: r = slice; c = i; break;
+        default: r = slice; c = n - i - 1; break;
+      }
+      SiteSel sel = cfg_site(r, c);
+      BTenDev nb = bten_step(pos, bten_[pos].back(), b1.t[n - i - 1], sel, b2.t[i], 1, true);
+      bten_[pos].push_back(nb);
+    }
+  }
+
+  void grow_bten_step(int pos) override {   // grow.h:529-582
+    require_ready();
+    int pre = (pos + 3) % 4, nxt = (pos + 1) % 4;
+    int bs = bten_size(pos);
+    PG_REQUIRE(bs > 0, 3, "GrowBTenStep: BTen not initialised");
+    int n, r, c;
+    switch (pos) {
+      case DOWN: c = bmps_size(LEFT) - 1; n = Ly_; r = n - bs; break;
+      case UP: c = bmps_size(LEFT) - 1; n = Ly_; r = bs - 1; break;
+      case LEFT: r = bmps_size(UP) - 1; n = Lx_; c = bs - 1; break;
+      default: r = bmps_size(UP) - 1; n = Lx_; c = n - bs; break;
+    }
+    PG_REQUIRE(bs <= n && !bmps_[pre].empty() && !bmps_[nxt].empty(), 3, "GrowBTenStep: environment missing");
+    SiteSel sel = cfg_site(r, c);
+    BTenDev nb = bten_step(pos, bten_[pos].back(), bmps_[pre].back().t[n - bs], sel, bmps_[nxt].back().t[bs - 1], 1, true);
+    bten_[pos].push_back(nb);
+  }
+  void shift_bten_window(int pos) override {   // grow.h:517-521
+    PG_REQUIRE(bten_size(pos) > 0, 3, "ShiftBTenWindow: BTen empty");
+    clear_bten(pos, bten_size(pos) - 1);
+    grow_bten_step((pos + 2) % 4);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // amplitudes: trace.h:11-28, :90-205, :30-88
+  void trace(int row, int col, int dir, double *out) override {
+    replace_nn_trace(row, col, dir, 0, nullptr, out);
+  }
+
+  void replace_nn_trace(int row, int col, int dir, int ncand, const int32_t *cand, double *out) override {
+    require_ready();
+    int rb = row + (dir == VERTICAL), cb = col + (dir == HORIZONTAL);
+    PG_REQUIRE(row >= 0 && col >= 0 && rb < Ly_ && cb < Lx_, 1, "ReplaceNNSiteTrace: bond outside the lattice");
+    const int nc = ncand > 0 ? ncand : 1;
+    SiteSel sa = cfg_site(row, col), sb = cfg_site(rb, cb);
+    int *dcand = nullptr;
+    if (ncand > 0) {
+      size_t cnt = (size_t)nw_ * ncand * 2;
+      for (size_t i = 0; i < cnt; ++i) PG_REQUIRE(cand[i] >= 0 && cand[i] < dp_, 4, "candidate state out of range");
+      dcand = (int *)arena_.alloc(cnt * sizeof(int));
+      PG_CHECK_HIP(hipMemcpyAsync(dcand, cand, cnt * sizeof(int), hipMemcpyHostToDevice, stream_));
+      sa.sel = dcand; sa.inc = 2;
+      sb.sel = dcand + 1; sb.inc = 2;
+    }
+    BTenDev t2, t5;
+    double *lsum = zeros_f64();
+    if (dir == HORIZONTAL) {
+      const BMPSDev &up = bmps_at_slice(UP, row), &dn = bmps_at_slice(DOWN, row);
+      PG_REQUIRE(bten_size(LEFT) > col, 3, "ReplaceNNSiteTrace: LEFT BTen missing");
+      t2 = bten_step(LEFT, bten_[LEFT][col], at_logical(up, UP, col), sa, at_logical(dn, DOWN, col), nc, false);
+      t5 = bten_step(RIGHT, bten_at_slice(RIGHT, cb), at_logical(dn, DOWN, cb), sb, at_logical(up, UP, cb), nc, false);
+      add_logs(lsum, up.logscale, dn.logscale, bten_[LEFT][col].logscale, bten_at_slice(RIGHT, cb).logscale);
+    } else {
+      const BMPSDev &lf = bmps_at_slice(LEFT, col), &rt = bmps_at_slice(RIGHT, col);
+      PG_REQUIRE(bten_size(UP) > row, 3, "ReplaceNNSiteTrace: UP BTen missing");
+      t2 = bten_step(UP, bten_[UP][row], at_logical(rt, RIGHT, row), sa, at_logical(lf, LEFT, row), nc, false);
+      t5 = bten_step(DOWN, bten_at_slice(DOWN, rb), at_logical(lf, LEFT, rb), sb, at_logical(rt, RIGHT, rb), nc, false);
+      add_logs(lsum, lf.logscale, rt.logscale, bten_[UP][row].logscale, bten_at_slice(DOWN, rb).logscale);
+    }
+    finish_dot(t2.t, nc, t5.t, nc, nc, lsum, out);
+    free_ten(t2.t); free_ten(t5.t);
+    arena_.free(lsum);
+    if (dcand) arena_.free(dcand);
+  }
+
+  void replace_one_trace(int row, int col, int orient, int ncand, const int32_t *cand, double *out) override {
+    require_ready();
+    PG_REQUIRE(row >= 0 && col >= 0 && row < Ly_ && col < Lx_, 1, "ReplaceOneSiteTrace: site outside the lattice");
+    const int nc = ncand > 0 ? ncand : 1;
+    SiteSel sa = cfg_site(row, col);
+    int *dcand = nullptr;
+    if (ncand > 0) {
+      size_t cnt = (size_t)nw_ * ncand;
+      for (size_t i = 0; i < cnt; ++i) PG_REQUIRE(cand[i] >= 0 && cand[i] < dp_, 4, "candidate state out of range");
+      dcand = (int *)arena_.alloc(cnt * sizeof(int));
+      PG_CHECK_HIP(hipMemcpyAsync(dcand, cand, cnt * sizeof(int), hipMemcpyHostToDevice, stream_));
+      sa.sel = dcand; sa.inc = 1;
+    }
+    BTenDev t2;
+    double *lsum = zeros_f64();
+    const DTen<T> *other;
+    if (orient == HORIZONTAL) {
+      const BMPSDev &up = bmps_at_slice(UP, row), &dn = bmps_at_slice(DOWN, row);
+      PG_REQUIRE(bten_size(LEFT) > col, 3, "ReplaceOneSiteTrace: LEFT BTen missing");
+      const BTenDev &rb = bten_at_slice(RIGHT, col);
+      t2 = bten_step(LEFT, bten_[LEFT][col], at_logical(up, UP, col), sa, at_logical(dn, DOWN, col), nc, false);
+      add_logs(lsum, up.logscale, dn.logscale, bten_[LEFT][col].logscale, rb.logscale);
+      other = &rb.t;
+    } else {
+      const BMPSDev &lf = bmps_at_slice(LEFT, col), &rt = bmps_at_slice(RIGHT, col);
+      PG_REQUIRE(bten_size(UP) > row, 3, "ReplaceOneSiteTrace: UP BTen missing");
+      const BTenDev &db = bten_at_slice(DOWN, row);
+      t2 = bten_step(UP, bten_[UP][row], at_logical(rt, RIGHT, row), sa, at_logical(lf, LEFT, row), nc, false);
+      add_logs(lsum, lf.logscale, rt.logscale, bten_[UP][row].logscale, db.logscale);
+      other = &db.t;
+    }
+    finish_dot(t2.t, nc, *other, 1, nc, lsum, out);
+    free_ten(t2.t);
+    arena_.free(lsum);
+    if (dcand) arena_.free(dcand);
+  }
+
+  void punch_hole(int row, int col, int orient, double *out) override {   // grow.h:150-183
+    require_ready();
+    const DTen<T> *left, *down, *right, *up;
+    double *lsum = zeros_f64();
+    if (orient == HORIZONTAL) {
+      const BMPSDev &ub = bmps_at_slice(UP, row), &db = bmps_at_slice(DOWN, row);
+      PG_REQUIRE(bten_size(LEFT) > col, 3, "PunchHole: LEFT BTen missing");
+      up = &at_logical(ub, UP, col); down = &at_logical(db, DOWN, col);
+      left = &bten_[LEFT][col].t; right = &bten_at_slice(RIGHT, col).t;
+      add_logs(lsum, ub.logscale, db.logscale, bten_[LEFT][col].logscale, bten_at_slice(RIGHT, col).logscale);
+    } else {
+      const BMPSDev &lb = bmps_at_slice(LEFT, col), &rb = bmps_at_slice(RIGHT, col);
+      PG_REQUIRE(bten_size(UP) > row, 3, "PunchHole: UP BTen missing");
+      left = &at_logical(lb, LEFT, row); right = &at_logical(rb, RIGHT, row);
+      up = &bten_[UP][row].t; down = &bten_at_slice(DOWN, row).t;
+      add_logs(lsum, lb.logscale, rb.logscale, bten_[UP][row].logscale, bten_at_slice(DOWN, row).logscale);
+    }
+    // tmp1[l0,l1,d1,d2] = sum_c left[l0,l1,c] down[c,d1,d2]
+    DTen<T> tmp1 = alloc_ten(left->d[0], left->d[1], down->d[1], down->d[2]);
+    {
+      TGemmDesc g;
+      g.I[2] = left->d[0] * left->d[1]; g.sAi[2] = left->d[2]; g.sCi[2] = down->d[1] * down->d[2];
+      g.K[2] = left->d[2]; g.sAk[2] = 1; g.sBk[2] = down->d[1] * down->d[2];
+      g.J[2] = down->d[1] * down->d[2]; g.sBj[2] = 1; g.sCj[2] = 1;
+      g.wA = left->n; g.wB = down->n; g.wC = tmp1.n; g.nbatch = nw_;
+      tgemm_launch<T, T, T, T>(stream_, g, left->p, down->p, tmp1.p);
+    }
+    DTen<T> tmp2 = alloc_ten(right->d[0], right->d[1], up->d[1], up->d[2]);
+    {
+      TGemmDesc g;
+      g.I[2] = right->d[0] * right->d[1]; g.sAi[2] = right->d[2]; g.sCi[2] = up->d[1] * up->d[2];
+      g.K[2] = right->d[2]; g.sAk[2] = 1; g.sBk[2] = up->d[1] * up->d[2];
+      g.J[2] = up->d[1] * up->d[2]; g.sBj[2] = 1; g.sCj[2] = 1;
+      g.wA = right->n; g.wB = up->n; g.wC = tmp2.n; g.nbatch = nw_;
+      tgemm_launch<T, T, T, T>(stream_, g, right->p, up->p, tmp2.p);
+    }
+    // res[l1,d1,r1,u1] = sum_{l0,d2} tmp1[l0,l1,d1,d2] tmp2[r0=d2, r1, u1, u2=l0]
+    int l0 = tmp1.d[0], l1 = tmp1.d[1], d1 = tmp1.d[2], d2 = tmp1.d[3];
+    int r0 = tmp2.d[0], r1 = tmp2.d[1], u1 = tmp2.d[2], u2 = tmp2.d[3];
+    PG_REQUIRE(l0 == u2 && d2 == r0, 3, "PunchHole: environment bond mismatch");
+    DTen<T> res = alloc_ten(l1, d1, r1, u1);
+    {
+      TGemmDesc g;
+      g.I[1] = l1; g.I[2] = d1; g.sAi[1] = d1 * d2; g.sAi[2] = d2; g.sCi[1] = d1 * r1 * u1; g.sCi[2] = r1 * u1;
+      g.K[1] = l0; g.K[2] = d2; g.sAk[1] = l1 * d1 * d2; g.sAk[2] = 1; g.sBk[1] = 1; g.sBk[2] = r1 * u1 * u2;
+      g.J[1] = r1; g.J[2] = u1; g.sBj[1] = u1 * u2; g.sBj[2] = u2; g.sCj[1] = u1; g.sCj[2] = 1;
+      g.wA = tmp1.n; g.wB = tmp2.n; g.wC = res.n; g.nbatch = nw_;
+      tgemm_launch<T, T, T, T>(stream_, g, tmp1.p, tmp2.p, res.p);
+    }
+    std::vector<T> h((size_t)res.n * nw_);
+    std::vector<double> hl(nw_);
+    PG_CHECK_HIP(hipMemcpyAsync(h.data(), res.p, h.size() * sizeof(T), hipMemcpyDeviceToHost, stream_));
+    PG_CHECK_HIP(hipMemcpyAsync(hl.data(), lsum, nw_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    // output padded to D^4 per walker, leg order (L,D,R,U)
+    const long slot = slot_;
+    std::fill(out, out + (size_t)slot * nw_, 0.0);
+    for (int w = 0; w < nw_; ++w) {
+      double sc = std::exp(hl[w]);
+      size_t o = 0;
+      for (int a = 0; a < l1; ++a)
+        for (int b = 0; b < d1; ++b)
+          for (int c = 0; c < r1; ++c)
+            for (int e = 0; e < u1; ++e)
+              out[(size_t)w * slot + (((size_t)a * D_ + b) * D_ + c) * D_ + e] = (double)h[(size_t)w * res.n + o++] * sc;
+    }
+    free_ten(tmp1); free_ten(tmp2); free_ten(res);
+    arena_.free(lsum);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  void erase_envs_after_update(int row, int col) override {   // trace.h:538-589
+    if (bmps_size(LEFT) > col + 1) clear_bmps(LEFT, col + 1);
+    if (bmps_size(UP) > row + 1) clear_bmps(UP, row + 1);
+    if (bmps_size(DOWN) > Ly_ - row) clear_bmps(DOWN, Ly_ - row);
+    if (bmps_size(RIGHT) > Lx_ - col) clear_bmps(RIGHT, Lx_ - col);
+    if (bten_size(LEFT) > col + 1) clear_bten(LEFT, col + 1);
+    if (bten_size(UP) > row + 1) clear_bten(UP, row + 1);
+    if (bten_size(RIGHT) > Lx_ - col) clear_bten(RIGHT, Lx_ - col);
+    if (bten_size(DOWN) > Ly_ - row) clear_bten(DOWN, Ly_ - row);
+  }
+
+  // wave_function_component.h:345-378 for the walkers with mask[w] != 0 (all walkers share the
+  // cache bookkeeping: an environment is dropped if ANY walker changed the site it crosses).
+  void update_local(int nsites, const int32_t *sites, const int32_t *new_states, const uint8_t *mask) override {
+    require_ready();
+    bool any = false;
+    for (int w = 0; w < nw_; ++w) {
+      if (mask && !mask[w]) continue;
+      for (int k = 0; k < nsites; ++k) {
+        int r = sites[2 * k], c = sites[2 * k + 1];
+        PG_REQUIRE(r >= 0 && r < Ly_ && c >= 0 && c < Lx_, 1, "UpdateLocal: site outside the lattice");
+        int s = new_states[(size_t)w * nsites + k];
+        PG_REQUIRE(s >= 0 && s < dp_, 4, "UpdateLocal: configuration value exceeds physical dimension");
+        hcfg_[(size_t)w * Ly_ * Lx_ + r * Lx_ + c] = s;
+        any = true;
+      }
+    }
+    if (!any) return;
+    PG_CHECK_HIP(hipMemcpyAsync(cfg_, hcfg_.data(), hcfg_.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+    PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    for (int k = 0; k < nsites; ++k) erase_envs_after_update(sites[2 * k], sites[2 * k + 1]);
+  }
+
+  void evaluate_amplitude(double *out) override {   // wave_function_component.h:187-212
+    grow_bmps_for_row(0);
+    grow_full_bten(RIGHT, 0, 2, 1);
+    init_bten(LEFT, 0);
+    trace(0, 0, HORIZONTAL, out);
+  }
+
+  void get_bmps_tensor(int pos, int level, int idx, int *dims, double *out, double *logscale) override {
+    PG_REQUIRE(level >= 0 && level < bmps_size(pos), 1, "BMPS level out of range");
+    const BMPSDev &b = bmps_[pos][level];
+    PG_REQUIRE(idx >= 0 && idx < (int)b.t.size(), 1, "BMPS tensor index out of range");
+    const DTen<T> &t = b.t[idx];
+    dims[0] = t.d[0]; dims[1] = t.d[1]; dims[2] = t.d[2];
+    if (out) {
+      std::vector<T> h((size_t)t.n * nw_);
+      PG_CHECK_HIP(hipMemcpyAsync(h.data(), t.p, h.size() * sizeof(T), hipMemcpyDeviceToHost, stream_));
+      PG_CHECK_HIP(hipStreamSynchronize(stream_));
+      for (size_t i = 0; i < h.size(); ++i) out[i] = (double)h[i];
+    }
+    if (logscale) {
+      PG_CHECK_HIP(hipMemcpyAsync(logscale, b.logscale, nw_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+      PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    }
+  }
+
+  void sync() override { PG_CHECK_HIP(hipStreamSynchronize(stream_)); }
+  void read_flags(int32_t *out) override {
+    PG_CHECK_HIP(hipMemcpyAsync(out, flag_, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    PG_CHECK_HIP(hipStreamSynchronize(stream_));
+  }
+  size_t device_bytes() const override { return arena_.total_bytes(); }
+  void stats(double *out, int n) override {
+    double v[5] = {(double)n_absorb_, (double)n_jacobi_, (double)jacobi_sweeps_sum_, (double)arena_.total_bytes(), (double)jacobi_sweeps_max_};
+    for (int i = 0; i < n && i < 5; ++i) out[i] = v[i];
+  }
+  hipStream_t stream() const { return stream_; }
+
+ private:
+  struct SiteSel {
+    int r, c;
+    const int *sel;   // device selector (configuration or candidate table)
+    int inc;          // selector stride per batch entry
+  };
+  SiteSel cfg_site(int r, int c) const { return SiteSel{r, c, cfg_ + r * Lx_ + c, Ly_ * Lx_}; }
+  const T *site_base(int r, int c) const { return sitps_ + (long)(r * Lx_ + c) * dp_ * slot_; }
+
+  void require_ready() const {
+    PG_REQUIRE(have_state_, 3, "no state uploaded (pepsgpu_state_upload)");
+    PG_REQUIRE(nw_ > 0, 3, "no walker configurations set (pepsgpu_walkers_set_configs)");
+  }
+
+  DTen<T> alloc_ten(int d0, int d1, int d2, int d3 = 1, int nb = -1) {
+    DTen<T> t;
+    t.d[0] = d0; t.d[1] = d1; t.d[2] = d2; t.d[3] = d3;
+    t.n = (long)d0 * d1 * d2 * d3;
+    t.p = (T *)arena_.alloc(sizeof(T) * (size_t)t.n * (nb < 0 ? nw_ : nb));
+    return t;
+  }
+  void free_ten(DTen<T> &t) { arena_.free(t.p); t.p = nullptr; }
+  DTen<T> ones3() {
+    DTen<T> t = alloc_ten(1, 1, 1);
+    hipLaunchKernelGGL(fill_kernel<T>, dim3((nw_ + 255) / 256), dim3(256), 0, stream_, t.p, (long)nw_, T(1));
+    return t;
+  }
+  double *zeros_f64() {
+    double *p = (double *)arena_.alloc(sizeof(double) * nw_);
+    PG_CHECK_HIP(hipMemsetAsync(p, 0, sizeof(double) * nw_, stream_));
+    return p;
+  }
+  void clear_bmps(int pos, int keep) {
+    auto &v = bmps_[pos];
+    while ((int)v.size() > keep) {
+      for (auto &t : v.back().t) arena_.free(t.p);
+      arena_.free(v.back().logscale);
+      v.pop_back();
+    }
+  }
+  void clear_bten(int pos, int keep) {
+    auto &v = bten_[pos];
+    while ((int)v.size() > keep) {
+      arena_.free(v.back().t.p);
+      arena_.free(v.back().logscale);
+      v.pop_back();
+    }
+  }
+
+  void normalize(T *x, long n, long stride, int nb, double *logscale) {
+    hipLaunchKernelGGL(normalize_kernel<T>, dim3(nb), dim3(256), 0, stream_, x, stride, (int)n, logscale, flag_);
+  }
+
+  // acc[w] += a[w] + b[w] + c[w] + d[w]
+  void add_logs(double *acc, const double *a, const double *b, const double *c, const double *d);
+  void add_log(double *acc, const double *a);
+
+  // out[(w,cand)] = sum t2[a,b,c] t5[c,b,a] * exp(lsum[w])
+  void finish_dot(const DTen<T> &t2, int nc2, const DTen<T> &t5, int nc5, int nc, double *lsum, double *out) {
+    PG_REQUIRE(t2.d[0] == t5.d[2] && t2.d[1] == t5.d[1] && t2.d[2] == t5.d[0], 3, "trace: environment bond mismatch");
+    const int nb = nw_ * nc;
+    double *res = (double *)arena_.alloc(sizeof(double) * nb);
+    TGemmDesc g;
+    g.K[0] = t2.d[0]; g.K[1] = t2.d[1]; g.K[2] = t2.d[2];
+    g.sAk[0] = t2.d[1] * t2.d[2]; g.sAk[1] = t2.d[2]; g.sAk[2] = 1;
+    g.sBk[0] = 1; g.sBk[1] = t5.d[2]; g.sBk[2] = t5.d[1] * t5.d[2];
+    g.wA = t2.n; g.wB = t5.n; g.wC = 1; g.nbatch = nb;
+    g.bdivA = nc / nc2; g.bdivB = nc / nc5;
+    tgemm_launch<T, T, double, double>(stream_, g, t2.p, t5.p, res);
+    std::vector<double> h(nb), hl(nw_);
+    PG_CHECK_HIP(hipMemcpyAsync(h.data(), res, nb * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    PG_CHECK_HIP(hipMemcpyAsync(hl.data(), lsum, nw_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    for (int i = 0; i < nb; ++i) out[i] = h[i] * std::exp(hl[i / nc]);
+    arena_.free(res);
+  }
+
+  // One BTen growth step with an explicit site selector (grow.h:577-579 and the half-steps of
+  // trace.h:129-131 / :149-156): out[x, s_opp, y] from bten[c,b1,b2], mps1[x,p1,c], site, mps2[b2,s1,y].
+  // Batch = walker x ncand (environment tensors shared by the candidates of one walker).
+  BTenDev bten_step(int post, const BTenDev &bt, const DTen<T> &mps1, const SiteSel &ss, const DTen<T> &mps2,
+                    int ncand, bool normalise) {
+    const int nb = nw_ * ncand;
+    int dd[4], st[4];
+    site_dims(ss.r, ss.c, dd);
+    site_strides(ss.r, ss.c, st);
+    const int lc = (post + 3) % 4, lb = post, l1 = (post + 1) % 4, l2 = (post + 2) % 4;
+    const int x = mps1.d[0], p1 = mps1.d[1], cdim = mps1.d[2];
+    const int b1 = bt.t.d[1], b2 = bt.t.d[2];
+    const int s1 = dd[l1], s2 = dd[l2], y = mps2.d[2];
+    PG_REQUIRE(cdim == bt.t.d[0] && p1 == dd[lc] && b1 == dd[lb] && mps2.d[0] == b2 && mps2.d[1] == s1, 3,
+               "BTen step: bond dimension mismatch between environment tensors");
+    // tmp1[x,p1,b1,b2] = sum_c mps1[x,p1,c] bten[c,b1,b2]     (per walker)
+    DTen<T> tmp1 = alloc_ten(x, p1, b1, b2);
+    {
+      TGemmDesc g;
+      g.I[2] = x * p1; g.sAi[2] = cdim; g.sCi[2] = b1 * b2;
+      g.K[2] = cdim; g.sAk[2] = 1; g.sBk[2] = b1 * b2;
+      g.J[2] = b1 * b2; g.sBj[2] = 1; g.sCj[2] = 1;
+      g.wA = mps1.n; g.wB = bt.t.n; g.wC = tmp1.n; g.nbatch = nw_;
+      tgemm_launch<T, T, T, T>(stream_, g, mps1.p, bt.t.p, tmp1.p);
+    }
+    // tmp2[b2,x,s1,s2] = sum_{p1,b1} tmp1[x,p1,b1,b2] site[lc<-p1, lb<-b1, l1->s1, l2->s2]
+    DTen<T> tmp2 = alloc_ten(b2, x, s1, s2, nb);
+    {
+      TGemmDesc g;
+      g.I[1] = b2; g.I[2] = x; g.sAi[1] = 1; g.sAi[2] = p1 * b1 * b2; g.sCi[1] = x * s1 * s2; g.sCi[2] = s1 * s2;
+      g.K[1] = p1; g.K[2] = b1; g.sAk[1] = b1 * b2; g.sAk[2] = b2; g.sBk[1] = st[lc]; g.sBk[2] = st[lb];
+      g.J[1] = s1; g.J[2] = s2; g.sBj[1] = st[l1]; g.sBj[2] = st[l2]; g.sCj[1] = s2; g.sCj[2] = 1;
+      g.wA = tmp1.n; g.bdivA = ncand; g.wC = tmp2.n; g.nbatch = nb;
+      launch_site_gemm(g, ss, ncand, tmp1.p, tmp2.p);
+    }
+    // out[x,s2,y] = sum_{b2,s1} tmp2[b2,x,s1,s2] mps2[b2,s1,y]
+    BTenDev o;
+    o.t = alloc_ten(x, s2, y, 1, nb);
+    {
+      TGemmDesc g;
+      g.I[1] = x; g.I[2] = s2; g.sAi[1] = s1 * s2; g.sAi[2] = 1; g.sCi[1] = s2 * y; g.sCi[2] = y;
+      g.K[1] = b2; g.K[2] = s1; g.sAk[1] = x * s1 * s2; g.sAk[2] = s2; g.sBk[1] = s1 * y; g.sBk[2] = y;
+      g.J[2] = y; g.sBj[2] = 1; g.sCj[2] = 1;
+      g.wA = tmp2.n; g.wB = mps2.n; g.bdivB = ncand; g.wC = o.t.n; g.nbatch = nb;
+      tgemm_launch<T, T, T, T>(stream_, g, tmp2.p, mps2.p, o.t.p);
+    }
+    free_ten(tmp1); free_ten(tmp2);
+    o.logscale = nullptr;
+    if (normalise) {
+      o.logscale = (double *)arena_.alloc(sizeof(double) * nw_);
+      PG_CHECK_HIP(hipMemcpyAsync(o.logscale, bt.logscale, sizeof(double) * nw_, hipMemcpyDeviceToDevice, stream_));
+      normalize(o.t.p, o.t.n, o.t.n, nw_, o.logscale);
+    }
+    return o;
+  }
+
+  // site-tensor GEMM: B operand = sitps slot chosen by a selector.  Configuration selectors are
+  // indexed by walker (b / ncand), candidate tables by batch entry.
+  void launch_site_gemm(TGemmDesc &g, const SiteSel &ss, int ncand, const T *A, T *C) {
+    g.selB = ss.sel;
+    g.selB_mul = slot_;
+    const bool per_walker = (ss.inc == Ly_ * Lx_);
+    if (per_walker) {
+      // emulate sel[(b / ncand) * inc] with inc applied to the walker index
+      g.selB_inc = ss.inc;
+      g.seldivB = ncand;
+    } else {
+      g.selB_inc = ss.inc;
+      g.seldivB = 1;
+    }
+    g.wB = 0;
+    tgemm_launch<T, T, T, T>(stream_, g, A, site_base(ss.r, ss.c), C);
+  }
+
+  void absorb(int pos, int num);
+
+  int Ly_, Lx_, D_, dp_, chi_min_, chi_;
+  double trunc_err_;
+  int maxw_, nw_ = 0, device_ = 0;
+  long slot_;
+  bool have_state_ = false;
+  hipStream_t stream_;
+  Arena arena_;
+  T *sitps_ = nullptr;
+  int *cfg_ = nullptr, *flag_ = nullptr;
+  std::vector<int> hcfg_;
+  std::vector<BMPSDev> bmps_[4];
+  std::vector<BTenDev> bten_[4];
+  long n_absorb_ = 0, n_jacobi_ = 0, jacobi_sweeps_sum_ = 0, jacobi_sweeps_max_ = 0;
+  int *sweeps_ = nullptr;
+  bool dbg_sweeps_ = false;
+};
+
+}  // namespace pepsgpu

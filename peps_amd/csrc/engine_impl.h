@@ -1,0 +1,208 @@
+// Row absorption and small helpers of Engine<T> (see engine.h for the algorithm statement).
+#pragma once
+#include "engine.h"
+
+namespace pepsgpu {
+
+__global__ void add_logs_kernel(double *acc, const double *a, const double *b, const double *c, const double *d, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) acc[i] += (a ? a[i] : 0.0) + (b ? b[i] : 0.0) + (c ? c[i] : 0.0) + (d ? d[i] : 0.0);
+}
+
+template <typename T>
+void Engine<T>::add_logs(double *acc, const double *a, const double *b, const double *c, const double *d) {
+  hipLaunchKernelGGL(add_logs_kernel, dim3((nw_ + 255) / 256), dim3(256), 0, stream_, acc, a, b, c, d, nw_);
+}
+template <typename T>
+void Engine<T>::add_log(double *acc, const double *a) {
+  add_logs(acc, a, nullptr, nullptr, nullptr);
+}
+
+// BMPS::MultiplyMPO with SVD compression (bmps_impl.h:404-437, :756-862, :225-263), Q-less form.
+// `num` = index of the absorbed row (UP/DOWN) or column (LEFT/RIGHT); sites are visited in the
+// storage order of the BMPS (reversed for UP/RIGHT, bmps_impl.h:694-699).
+template <typename T>
+void Engine<T>::absorb(int pos, int num) {
+  const int N = mps_len(pos);
+  // copy of the tensor descriptors: push_back below may reallocate bmps_[pos]
+  const std::vector<DTen<T>> cur = bmps_[pos].back().t;
+  const double *cur_log = bmps_[pos].back().logscale;
+  PG_REQUIRE((int)cur.size() == N, 3, "MultiplyMPO: MPS/MPO length mismatch");
+  auto site_rc = [&](int i, int &r, int &c) {
+    switch (pos) {
+      case DOWN: r = num; c = i; break;
+      case UP: r = num; c = N - 1 - i; break;
+      case LEFT: r = i; c = num; break;
+      default: r = N - 1 - i; c = num; break;
+    }
+  };
+  const int ll = (pos + 3) % 4, lp = pos, lr = (pos + 1) % 4, lu = (pos + 2) % 4;
+
+  // ---------------- forward: R_{i+1} from P_i = R_i (A_i x W_i) ----------------
+  std::vector<DTen<T>> R(N);
+  R[0] = ones3();
+  for (int i = 0; i + 1 < N; ++i) {
+    int r, c, dd[4], st[4];
+    site_rc(i, r, c);
+    site_dims(r, c, dd);
+    site_strides(r, c, st);
+    const DTen<T> &A = cur[i];
+    const int m = R[i].d[0], l = R[i].d[1], a = R[i].d[2];
+    const int p = A.d[1], a2 = A.d[2];
+    const int l2 = dd[lr], u = dd[lu];
+    PG_REQUIRE(l == dd[ll] && a == A.d[0] && p == dd[lp], 3, "MultiplyMPO: bond dimension mismatch");
+    // X[m,l,p,a2] = sum_a R[m,l,a] A[a,p,a2]                      (bmps_impl.h:806)
+    DTen<T> X = alloc_ten(m * l, p, a2);
+    {
+      TGemmDesc g;
+      g.I[2] = m * l; g.sAi[2] = a; g.sCi[2] = p * a2;
+      g.K[2] = a; g.sAk[2] = 1; g.sBk[2] = p * a2;
+      g.J[2] = p * a2; g.sBj[2] = 1; g.sCj[2] = 1;
+      g.wA = R[i].n; g.wB = A.n; g.wC = X.n; g.nbatch = nw_;
+      tgemm_launch<T, T, T, T>(stream_, g, R[i].p, A.p, X.p);
+    }
+    // P[m,u,l2,a2] = sum_{l,p} X[m,l,p,a2] W[l,p,l2,u]           (bmps_impl.h:807 + :815-817)
+    DTen<T> P = alloc_ten(m, u, l2, a2);
+    {
+      TGemmDesc g;
+      g.I[1] = m; g.I[2] = a2; g.sAi[1] = l * p * a2; g.sAi[2] = 1; g.sCi[1] = u * l2 * a2; g.sCi[2] = 1;
+      g.K[1] = l; g.K[2] = p; g.sAk[1] = p * a2; g.sAk[2] = a2; g.sBk[1] = st[ll]; g.sBk[2] = st[lp];
+      g.J[1] = l2; g.J[2] = u; g.sBj[1] = st[lr]; g.sBj[2] = st[lu]; g.sCj[1] = a2; g.sCj[2] = l2 * a2;
+      g.wA = X.n; g.wC = P.n; g.nbatch = nw_;
+      launch_site_gemm(g, cfg_site(r, c), 1, X.p, P.p);
+    }
+    free_ten(X);
+    const int rows = m * u, cols = l2 * a2;
+    if (rows < cols) {
+      // economy QR would return R = Q^T P with rows x cols; any R with R^T R = P^T P serves
+      // (rows == cols goes through the Cholesky: a triangular carry makes the Jacobi converge 3x faster)
+      P.d[0] = rows; P.d[1] = l2; P.d[2] = a2; P.d[3] = 1;
+      normalize(P.p, P.n, P.n, nw_, nullptr);
+      R[i + 1] = P;
+    } else {
+      double *G = (double *)arena_.alloc(sizeof(double) * (size_t)cols * cols * nw_);
+      {
+        TGemmDesc g;
+        g.I[2] = cols; g.sAi[2] = 1; g.sCi[2] = cols;
+        g.K[2] = rows; g.sAk[2] = cols; g.sBk[2] = cols;
+        g.J[2] = cols; g.sBj[2] = 1; g.sCj[2] = 1;
+        g.wA = P.n; g.wB = P.n; g.wC = (long)cols * cols; g.nbatch = nw_;
+        tgemm_launch<T, T, double, double>(stream_, g, P.p, P.p, G);
+      }
+      R[i + 1] = alloc_ten(cols, l2, a2);
+      size_t smem = sizeof(double) * ((size_t)CH_NB * cols + 64 * CH_NB);
+      PG_REQUIRE(smem <= 150 * 1024, 1, "Cholesky panel does not fit LDS (D*chi too large)");
+      allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
+      hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nw_), dim3(256), smem, stream_, G, (long)cols * cols, cols,
+                         R[i + 1].p, R[i + 1].n);
+      PG_CHECK_HIP(hipGetLastError());
+      arena_.free(G);
+      free_ten(P);
+    }
+  }
+
+  // ---------------- backward: truncate right to left ----------------
+  BMPSDev out;
+  out.t.resize(N);
+  out.logscale = (double *)arena_.alloc(sizeof(double) * nw_);
+  PG_CHECK_HIP(hipMemcpyAsync(out.logscale, cur_log, sizeof(double) * nw_, hipMemcpyDeviceToDevice, stream_));
+  DTen<T> Y = ones3();   // [l2, a2, k2]
+  for (int i = N - 1; i >= 0; --i) {
+    int r, c, dd[4], st[4];
+    site_rc(i, r, c);
+    site_dims(r, c, dd);
+    site_strides(r, c, st);
+    const DTen<T> &A = cur[i];
+    const int a = A.d[0], p = A.d[1], a2 = A.d[2];
+    const int l = dd[ll], l2 = dd[lr], u = dd[lu];
+    const int k2 = Y.d[2];
+    PG_REQUIRE(Y.d[0] == l2 && Y.d[1] == a2 && p == dd[lp], 3, "MultiplyMPO: bond dimension mismatch (backward)");
+    // Z1[a,p,l2,k2] = sum_{a2} A[a,p,a2] Y[l2,a2,k2]
+    DTen<T> Z1 = alloc_ten(a, p, l2, k2);
+    {
+      TGemmDesc g;
+      g.I[2] = a * p; g.sAi[2] = a2; g.sCi[2] = l2 * k2;
+      g.K[2] = a2; g.sAk[2] = 1; g.sBk[2] = k2;
+      g.J[1] = l2; g.J[2] = k2; g.sBj[1] = a2 * k2; g.sBj[2] = 1; g.sCj[1] = k2; g.sCj[2] = 1;
+      g.wA = A.n; g.wB = Y.n; g.wC = Z1.n; g.nbatch = nw_;
+      tgemm_launch<T, T, T, T>(stream_, g, A.p, Y.p, Z1.p);
+    }
+    // Tt[l,a,u,k2] = sum_{p,l2} Z1[a,p,l2,k2] W[l,p,l2,u]
+    DTen<T> Tt = alloc_ten(l, a, u, k2);
+    {
+      TGemmDesc g;
+      g.I[1] = a; g.I[2] = k2; g.sAi[1] = p * l2 * k2; g.sAi[2] = 1; g.sCi[1] = u * k2; g.sCi[2] = 1;
+      g.K[1] = p; g.K[2] = l2; g.sAk[1] = l2 * k2; g.sAk[2] = k2; g.sBk[1] = st[lp]; g.sBk[2] = st[lr];
+      g.J[1] = l; g.J[2] = u; g.sBj[1] = st[ll]; g.sBj[2] = st[lu]; g.sCj[1] = a * u * k2; g.sCj[2] = k2;
+      g.wA = Z1.n; g.wC = Tt.n; g.nbatch = nw_;
+      launch_site_gemm(g, cfg_site(r, c), 1, Z1.p, Tt.p);
+    }
+    free_ten(Z1);
+    free_ten(Y);
+    if (i == 0) {
+      PG_REQUIRE(l == 1 && a == 1, 3, "MultiplyMPO: left boundary bond is not trivial");
+      Tt.d[0] = 1; Tt.d[1] = u; Tt.d[2] = k2; Tt.d[3] = 1;
+      normalize(Tt.p, Tt.n, Tt.n, nw_, out.logscale);
+      out.t[0] = Tt;
+      break;
+    }
+    // M[m,(u,k2)] = sum_{(l,a)} R_i[m,(l,a)] Tt[(l,a),(u,k2)]
+    const int m = R[i].d[0], la = l * a, uk = u * k2;
+    PG_REQUIRE(R[i].d[1] == l && R[i].d[2] == a, 3, "MultiplyMPO: carry dimension mismatch");
+    DTen<T> M = alloc_ten(m, uk, 1);
+    {
+      TGemmDesc g;
+      g.I[2] = m; g.sAi[2] = la; g.sCi[2] = uk;
+      g.K[2] = la; g.sAk[2] = 1; g.sBk[2] = uk;
+      g.J[2] = uk; g.sBj[2] = 1; g.sCj[2] = 1;
+      g.wA = R[i].n; g.wB = Tt.n; g.wC = M.n; g.nbatch = nw_;
+      tgemm_launch<T, T, T, T>(stream_, g, R[i].p, Tt.p, M.p);
+    }
+    // rows of M -> mutually orthogonal (sigma_k v_k^T)
+    {
+      const size_t need = sizeof(T) * (size_t)m * (uk | 1);
+      const int use_lds = need <= JACOBI_LDS_MAX;
+      if (use_lds) allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), need);
+      hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), use_lds ? need : 0, stream_, M.p, M.n, m, uk,
+                         uk, 40, use_lds, sweeps_);
+      PG_CHECK_HIP(hipGetLastError());
+      ++n_jacobi_;
+      if (dbg_sweeps_) {   // diagnostics only: per-launch sweep counts (forces a sync)
+        std::vector<int> hs(nw_);
+        PG_CHECK_HIP(hipMemcpyAsync(hs.data(), sweeps_, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        PG_CHECK_HIP(hipStreamSynchronize(stream_));
+        long mx = 0;
+        for (int v : hs) mx = std::max<long>(mx, v);
+        jacobi_sweeps_sum_ += mx;
+        jacobi_sweeps_max_ = std::max(jacobi_sweeps_max_, mx);
+        if (getenv("PEPSGPU_DEBUG_VERBOSE")) fprintf(stderr, "[pepsgpu] jacobi m=%d len=%d sweeps(max)=%ld\n", m, uk, mx);
+      }
+    }
+    const int k = std::min(chi_, std::min(m, uk));
+    PG_REQUIRE(m <= 1024, 1, "bond dimension too large for select_rows_kernel");
+    DTen<T> V = alloc_ten(k, u, k2);
+    hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)M.p, M.n, m, uk, uk, k, V.p,
+                       V.n, (T *)nullptr, 0L);
+    PG_CHECK_HIP(hipGetLastError());
+    free_ten(M);
+    out.t[i] = V;
+    // Ynew[(l,a),q] = sum_{(u,k2)} Tt[(l,a),(u,k2)] V[q,(u,k2)]
+    DTen<T> Yn = alloc_ten(l, a, k);
+    {
+      TGemmDesc g;
+      g.I[2] = la; g.sAi[2] = uk; g.sCi[2] = k;
+      g.K[2] = uk; g.sAk[2] = 1; g.sBk[2] = 1;
+      g.J[2] = k; g.sBj[2] = uk; g.sCj[2] = 1;
+      g.wA = Tt.n; g.wB = V.n; g.wC = Yn.n; g.nbatch = nw_;
+      tgemm_launch<T, T, T, T>(stream_, g, Tt.p, V.p, Yn.p);
+    }
+    normalize(Yn.p, Yn.n, Yn.n, nw_, out.logscale);
+    free_ten(Tt);
+    Y = Yn;
+  }
+  for (auto &t : R) arena_.free(t.p);
+  bmps_[pos].push_back(std::move(out));
+  ++n_absorb_;
+}
+
+}  // namespace pepsgpu

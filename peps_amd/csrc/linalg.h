@@ -1,0 +1,279 @@
+// Batched small dense factorizations for the chi-truncation step (gfx950).
+//
+//  * chol_upper_kernel : R^T R = G (f64 Gram of the carried block, cols x cols), semi-definite
+//    safe; replaces the R factor of qlten::QR at bmps_impl.h:821 (only R is ever needed, see
+//    DESIGN.md "Q-less absorption").
+//  * jacobi_rows_kernel: one-sided (Hestenes) Jacobi that orthogonalises the ROWS of
+//    M = R_i T_i in place; the rotated rows are sigma_k v_k^T, so the right singular vectors the
+//    reference takes from qlten::SVD (bmps_impl.h:235-238) come out without accumulating any
+//    rotation matrix.
+//  * select_rows_kernel: norms, rank by counting, keep the chi largest, normalise -> Vt, S.
+//  * normalize_kernel  : x /= |x|, logscale += log|x| (the reference never normalises and
+//    relies on fp64 range, monte_carlo_engine.h:206-240; fp32 needs the log-scale).
+#pragma once
+#include "common.h"
+
+namespace pepsgpu {
+
+template <typename T> struct Eps;
+template <> struct Eps<float> { static constexpr float v = 5.9604645e-8f; };
+template <> struct Eps<double> { static constexpr double v = 1.1102230246251565e-16; };
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// In-place upper Cholesky of the symmetric PSD matrix G (n x n, row-major, f64): on exit the
+// upper triangle holds R with R^T R = G.  A pivot below n*eps*max(diag) zeroes its row (the
+// direction carries no weight).  Then R * out_scale is written as type T (zeros below the
+// diagonal) to Rout (n x n row-major).  One 256-thread block per batch entry.
+constexpr int CH_NB = 16;
+
+template <typename T>
+__global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg, long wG, int n,
+                                                         T *__restrict__ Rg, long wR) {
+  extern __shared__ double ch_smem[];
+  double *sP = ch_smem;                 // [CH_NB][n]   current block row of R
+  double *sK = ch_smem + CH_NB * n;     // [64][CH_NB]  staged R[k][jb..jb+nb)
+  __shared__ double s_piv, s_maxd;
+  const int tid = threadIdx.x;
+  double *G = Gg + (long)blockIdx.x * wG;
+  T *Rout = Rg + (long)blockIdx.x * wR;
+
+  double md = 0.0;
+  for (int i = tid; i < n; i += 256) md = fmax(md, G[(long)i * n + i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
+  __shared__ double s_red[4];
+  if ((tid & 63) == 0) s_red[tid >> 6] = md;
+  __syncthreads();
+  if (tid == 0) s_maxd = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+  __syncthreads();
+  const double maxd = s_maxd;
+  const double thresh = (double)n * 2.220446049250313e-16 * maxd;
+
+  for (int jb = 0; jb < n; jb += CH_NB) {
+    const int nb = min(CH_NB, n - jb);
+    // panel init from G
+    for (int e = tid; e < nb * n; e += 256) {
+      int c = e / n, r = e % n;
+      sP[c * n + r] = (r >= jb) ? G[(long)(jb + c) * n + r] : 0.0;
+    }
+    __syncthreads();
+    // left-looking update with the finished rows k < jb (held in G's upper triangle)
+    for (int k0 = 0; k0 < jb; k0 += 64) {
+      const int kc = min(64, jb - k0);
+      for (int e = tid; e < kc * nb; e += 256) {
+        int k = e / nb, c = e % nb;
+        sK[k * CH_NB + c] = G[(long)(k0 + k) * n + jb + c];
+      }
+      __syncthreads();
+      for (int r = jb + tid; r < n; r += 256) {
+        double acc[CH_NB];
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c) acc[c] = 0.0;
+        for (int k = 0; k < kc; ++k) {
+          double rv = G[(long)(k0 + k) * n + r];
+#pragma unroll
+          for (int c = 0; c < CH_NB; ++c) acc[c] += sK[k * CH_NB + c] * rv;
+        }
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c)
+          if (c < nb) sP[c * n + r] -= acc[c];
+      }
+      __syncthreads();
+    }
+    // factor the panel row by row
+    for (int c = 0; c < nb; ++c) {
+      if (tid == 0) s_piv = sP[c * n + jb + c];
+      __syncthreads();
+      const double piv = s_piv;
+      const bool ok = piv > thresh;
+      const double inv = ok ? 1.0 / sqrt(piv) : 0.0;
+      for (int r = jb + c + tid; r < n; r += 256) sP[c * n + r] *= inv;
+      __syncthreads();
+      for (int e = tid; e < (nb - c - 1) * (n - jb); e += 256) {
+        int c2 = c + 1 + e / (n - jb), r = jb + e % (n - jb);
+        if (r >= jb + c2) sP[c2 * n + r] -= sP[c * n + jb + c2] * sP[c * n + r];
+      }
+      __syncthreads();
+    }
+    // publish the finished rows (needed by later panels) -- upper part only
+    for (int e = tid; e < nb * n; e += 256) {
+      int c = e / n, r = e % n;
+      if (r >= jb + c) G[(long)(jb + c) * n + r] = sP[c * n + r];
+    }
+    __syncthreads();
+  }
+  const double sc = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
+  for (int e = tid; e < n * n; e += 256) {
+    int k = e / n, r = e % n;
+    Rout[e] = (r >= k) ? T(G[e] * sc) : T(0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One-sided Jacobi on the rows of M (m x len, row stride ld), in place.  Round-robin tournament
+// ordering, one wave per row pair.  Rows whose norm is below NOISE_C*eps*|M|_F (an invariant of
+// the rotations) are numerically zero and take no part: with more rows than the rank (m > len,
+// or a rank-deficient carry) the surplus rows can never become "relatively" orthogonal.  The
+// working copy lives in LDS when it fits (use_lds), else in global memory (L2-resident).
+constexpr double NOISE_C = 8.0;
+template <typename T>
+__global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, long wM, int m, int len,
+                                                           int ld, int max_sweeps, int use_lds,
+                                                           int *__restrict__ sweeps_out) {
+  extern __shared__ unsigned char jc_smem_raw[];
+  T *sM = reinterpret_cast<T *>(jc_smem_raw);
+  __shared__ int s_rot;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  T *Mglob = Mg + (long)blockIdx.x * wM;
+  T *M = Mglob;
+  int lds_ld = ld;
+  if (use_lds) {
+    lds_ld = len | 1;  // odd pitch: rows of a pair start on different banks
+    for (int e = tid; e < m * len; e += blockDim.x) sM[(e / len) * lds_ld + (e % len)] = Mglob[(long)(e / len) * ld + (e % len)];
+    M = sM;
+    __syncthreads();
+  }
+  const int mp = m + (m & 1);
+  const T tol = T(2) * sqrt(T(len)) * Eps<T>::v;
+  __shared__ double s_fro[16];
+  {
+    double f = 0.0;
+    for (int e = tid; e < m * len; e += blockDim.x) { double x = (double)M[(long)(e / len) * lds_ld + (e % len)]; f += x * x; }
+    f = wave_sum(f);
+    if (lane == 0) s_fro[wave] = f;
+    __syncthreads();
+    if (tid == 0) { double t = 0.0; for (int w = 0; w < nw; ++w) t += s_fro[w]; s_fro[0] = t; }
+    __syncthreads();
+  }
+  const T floor2 = T(NOISE_C * NOISE_C * (double)Eps<T>::v * (double)Eps<T>::v * s_fro[0]);
+  int sweep = 0;
+  for (; sweep < max_sweeps; ++sweep) {
+    if (tid == 0) s_rot = 0;
+    __syncthreads();
+    for (int r = 0; r < mp - 1; ++r) {
+      for (int p = wave; p < mp / 2; p += nw) {
+        int a, b;
+        if (p == 0) { a = mp - 1; b = r; }
+        else { a = (r + p) % (mp - 1); b = (r - p + (mp - 1)) % (mp - 1); }
+        if (a > b) { int t = a; a = b; b = t; }
+        if (b >= m) continue;
+        T *pa = M + (long)a * lds_ld, *pb = M + (long)b * lds_ld;
+        T alpha = 0, beta = 0, gamma = 0;
+        for (int c = lane; c < len; c += 64) {
+          T x = pa[c], y = pb[c];
+          alpha += x * x; beta += y * y; gamma += x * y;
+        }
+        alpha = wave_sum(alpha); beta = wave_sum(beta); gamma = wave_sum(gamma);
+        const T ab = sqrt(alpha) * sqrt(beta);
+        // no de Rijk row swapping: exchanging rows inside a round-robin tournament breaks the
+        // pair coverage of the sweep (measured: 2x the sweeps); select_rows_kernel sorts afterwards
+        if (fabs(gamma) > tol * ab && alpha > floor2 && beta > floor2) {
+          // rotation parameters in f64 (one scalar per pair): keeps c^2 + s^2 = 1 to f32 rounding
+          const double zeta = ((double)beta - (double)alpha) / (2.0 * (double)gamma);
+          const double td = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          const double cd = 1.0 / sqrt(1.0 + td * td);
+          const T cs = T(cd), sn = T(cd * td);
+          for (int c = lane; c < len; c += 64) {
+            T x = pa[c], y = pb[c];
+            T xn = cs * x - sn * y, yn = sn * x + cs * y;
+            pa[c] = xn;
+            pb[c] = yn;
+          }
+          if (lane == 0) atomicAdd(&s_rot, 1);
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    const int rot = s_rot;
+    __syncthreads();
+    if (rot == 0) { ++sweep; break; }
+  }
+  if (use_lds) {
+    for (int e = tid; e < m * len; e += blockDim.x) Mglob[(long)(e / len) * ld + (e % len)] = sM[(e / len) * lds_ld + (e % len)];
+  }
+  if (tid == 0 && sweeps_out) sweeps_out[blockIdx.x] = sweep;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rows of M are mutually orthogonal: sigma_i = |row_i|.  Keep the k largest (ties by index),
+// write Vt[rank][:] = row/sigma (zero row if sigma == 0) and S[rank] = sigma.
+// Block = 256 threads, one batch entry per block; m <= 1024.
+template <typename T>
+__global__ __launch_bounds__(256) void select_rows_kernel(const T *__restrict__ Mg, long wM, int m, int len,
+                                                          int ld, int k, T *__restrict__ Vg, long wV,
+                                                          T *__restrict__ Sg, long wS) {
+  __shared__ double s_norm[1024];
+  __shared__ int s_rank[1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const T *M = Mg + (long)blockIdx.x * wM;
+  T *V = Vg + (long)blockIdx.x * wV;
+  for (int r = wave; r < m; r += 4) {
+    double a = 0.0;
+    for (int c = lane; c < len; c += 64) { double x = (double)M[(long)r * ld + c]; a += x * x; }
+    a = wave_sum(a);
+    if (lane == 0) s_norm[r] = sqrt(a);
+  }
+  __syncthreads();
+  for (int r = tid; r < m; r += 256) {
+    double v = s_norm[r];
+    int rk = 0;
+    for (int q = 0; q < m; ++q) {
+      double u = s_norm[q];
+      rk += (u > v) || (u == v && q < r);
+    }
+    s_rank[r] = rk;
+    if (rk < k && Sg) Sg[(long)blockIdx.x * wS + rk] = T(v);
+  }
+  __syncthreads();
+  double fro2 = 0.0;
+  for (int q = 0; q < m; ++q) fro2 += s_norm[q] * s_norm[q];
+  const double nfloor = NOISE_C * (double)Eps<T>::v * sqrt(fro2);
+  for (int r = wave; r < m; r += 4) {
+    int rk = s_rank[r];
+    if (rk >= k) continue;
+    double nv = s_norm[r];
+    T inv = nv > nfloor ? T(1.0 / nv) : T(0);   // numerically zero direction -> zero row of Vt
+    for (int c = lane; c < len; c += 64) V[(long)rk * len + c] = M[(long)r * ld + c] * inv;
+  }
+}
+
+// x[b][0..n) /= |x|;  logscale[b] += log|x|;  zero / non-finite norm sets flag[b] = 1.
+template <typename T>
+__global__ __launch_bounds__(256) void normalize_kernel(T *__restrict__ Xg, long wX, int n,
+                                                        double *__restrict__ logscale, int *__restrict__ flag) {
+  __shared__ double s_red[4];
+  __shared__ double s_nrm;
+  const int tid = threadIdx.x;
+  T *X = Xg + (long)blockIdx.x * wX;
+  double a = 0.0;
+  for (int i = tid; i < n; i += 256) { double x = (double)X[i]; a += x * x; }
+  a = wave_sum(a);
+  if ((tid & 63) == 0) s_red[tid >> 6] = a;
+  __syncthreads();
+  if (tid == 0) s_nrm = sqrt(s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+  __syncthreads();
+  const double nrm = s_nrm;
+  if (!(nrm > 0.0) || !isfinite(nrm)) {
+    if (tid == 0 && flag) flag[blockIdx.x] = 1;
+    return;
+  }
+  const T inv = T(1.0 / nrm);
+  for (int i = tid; i < n; i += 256) X[i] *= inv;
+  if (tid == 0 && logscale) logscale[blockIdx.x] += log(nrm);
+}
+
+template <typename T>
+__global__ void fill_kernel(T *p, long n, T v) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+}  // namespace pepsgpu

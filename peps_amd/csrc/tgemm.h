@@ -1,0 +1,240 @@
+// Batched strided tensor-contraction GEMM for gfx950 (MI355X).
+//
+//   C[b][(i0,i1,i2),(j0,j1,j2)] (+)= sum_{(k0,k1,k2)} A[b][(i..),(k..)] * B[b][(k..),(j..)]
+//
+// Every index group (I, J, K) is a product of up to three sub-indices with arbitrary element
+// strides, so the leg permutations the reference performs with qlten::Transpose before each
+// qlten::Contract (e.g. include/qlpeps/one_dim_tn/boundary_mps/bmps_impl.h:806-817) are folded
+// into the address computation of the global->LDS staging; operands are never permuted in HBM.
+// `b` runs over (walker x candidate); an optional per-batch selector adds sel[b]*mul to an
+// operand base, which is how a walker's configuration picks its projected site tensor out of
+// the shared SITPS buffer (reference: tensor_network_2d_basic_impl.h:24-74 copies it instead).
+//
+// Math: f32 -> v_mfma_f32_32x32x2_f32, f64 (and f32 inputs accumulated in f64 for the Gram
+// matrices) -> v_mfma_f64_16x16x4_f64; 64x64x16 LDS tiles, 4 waves, register-prefetched
+// global loads.  A VALU path (PEPSGPU_NO_MFMA=1) exists only to cross-check the MFMA lane maps.
+#pragma once
+#include "common.h"
+
+namespace pepsgpu {
+
+struct TGemmDesc {
+  int I[3] = {1, 1, 1}, J[3] = {1, 1, 1}, K[3] = {1, 1, 1};  // sub-dims, innermost last
+  int sAi[3] = {0, 0, 0}, sAk[3] = {0, 0, 0};
+  int sBk[3] = {0, 0, 0}, sBj[3] = {0, 0, 0};
+  int sCi[3] = {0, 0, 0}, sCj[3] = {0, 0, 0};
+  long wA = 0, wB = 0, wC = 0;   // batch strides (elements)
+  const int *selA = nullptr, *selB = nullptr;
+  int selA_inc = 0, selB_inc = 0;    // selector read at sel[b * inc]
+  long selA_mul = 0, selB_mul = 0;   // base += sel * mul
+  int bdivA = 1, bdivB = 1, bdivC = 1;  // operand batch index = b / bdiv (candidates share env.)
+  int seldivA = 1, seldivB = 1;         // selector index = (b / seldiv) * inc
+  int nbatch = 1;
+  int accumulate = 0;
+  double alpha = 1.0;
+
+  __host__ __device__ int Itot() const { return I[0] * I[1] * I[2]; }
+  __host__ __device__ int Jtot() const { return J[0] * J[1] * J[2]; }
+  __host__ __device__ int Ktot() const { return K[0] * K[1] * K[2]; }
+};
+
+constexpr int TG_BM = 64, TG_BN = 64, TG_BK = 16, TG_KTAB = 2048;
+
+template <typename T> struct TgPitch { static constexpr int v = 64; };
+template <> struct TgPitch<double> { static constexpr int v = 80; };  // 640 B: halves land 128 B apart
+
+__device__ __forceinline__ int tg_off3(int idx, const int *dims, const int *strides) {
+  int i2 = idx % dims[2];
+  int r = idx / dims[2];
+  int i1 = r % dims[1];
+  int i0 = r / dims[1];
+  return i0 * strides[0] + i1 * strides[1] + i2 * strides[2];
+}
+
+typedef float tg_f32x16 __attribute__((ext_vector_type(16)));
+typedef double tg_f64x4 __attribute__((ext_vector_type(4)));
+
+template <typename TA, typename TB, typename TC, typename TAcc, bool USE_MFMA>
+__global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__restrict__ Ag,
+                                                    const TB *__restrict__ Bg, TC *__restrict__ Cg) {
+  constexpr int PITCH = TgPitch<TAcc>::v;
+  __shared__ TAcc As[TG_BK][PITCH];
+  __shared__ TAcc Bs[TG_BK][PITCH];
+  __shared__ int offAi[TG_BM], offBj[TG_BN], offCi[TG_BM], offCj[TG_BN];
+  __shared__ int offAk[TG_KTAB], offBk[TG_KTAB];
+
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z;
+  const int i0 = blockIdx.x * TG_BM, j0 = blockIdx.y * TG_BN;
+  const int Itot = d.Itot(), Jtot = d.Jtot(), Ktot = d.Ktot();
+
+  long baseA = (long)(b / d.bdivA) * d.wA, baseB = (long)(b / d.bdivB) * d.wB;
+  if (d.selA) baseA += (long)d.selA[(long)(b / d.seldivA) * d.selA_inc] * d.selA_mul;
+  if (d.selB) baseB += (long)d.selB[(long)(b / d.seldivB) * d.selB_inc] * d.selB_mul;
+  const TA *A = Ag + baseA;
+  const TB *B = Bg + baseB;
+  TC *C = Cg + (long)(b / d.bdivC) * d.wC;
+
+  if (tid < TG_BM) {
+    int i = i0 + tid;
+    offAi[tid] = (i < Itot) ? tg_off3(i, d.I, d.sAi) : -1;
+    offCi[tid] = (i < Itot) ? tg_off3(i, d.I, d.sCi) : -1;
+  } else if (tid < TG_BM + TG_BN) {
+    int j = j0 + tid - TG_BM;
+    offBj[tid - TG_BM] = (j < Jtot) ? tg_off3(j, d.J, d.sBj) : -1;
+    offCj[tid - TG_BM] = (j < Jtot) ? tg_off3(j, d.J, d.sCj) : -1;
+  }
+
+  // staging order: run consecutive threads along whichever index is closer to unit stride
+  const bool a_ifast = d.sAi[2] <= d.sAk[2];
+  const bool b_jfast = d.sBj[2] <= d.sBk[2];
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  tg_f32x16 acc32;
+  tg_f64x4 acc64[2][2];
+  TAcc accv[4][4];
+  if constexpr (USE_MFMA) {
+    if constexpr (sizeof(TAcc) == 4) {
+      for (int r = 0; r < 16; ++r) acc32[r] = 0.f;
+    } else {
+      for (int a = 0; a < 2; ++a)
+        for (int c = 0; c < 2; ++c)
+          for (int r = 0; r < 4; ++r) acc64[a][c][r] = 0.0;
+    }
+  } else {
+    for (int a = 0; a < 4; ++a)
+      for (int c = 0; c < 4; ++c) accv[a][c] = TAcc(0);
+  }
+
+  TAcc ra[4], rb[4];
+  for (int kc = 0; kc < Ktot; kc += TG_KTAB) {
+    const int kchunk = min(TG_KTAB, Ktot - kc);
+    __syncthreads();
+    for (int k = tid; k < kchunk; k += 256) {
+      offAk[k] = tg_off3(kc + k, d.K, d.sAk);
+      offBk[k] = tg_off3(kc + k, d.K, d.sBk);
+    }
+    __syncthreads();
+    const int nkt = (kchunk + TG_BK - 1) / TG_BK;
+
+    auto load_regs = [&](int kt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int e = tid + 256 * r;
+        int ia, ka, jb, kb;
+        if (a_ifast) { ia = e & 63; ka = e >> 6; } else { ka = e & 15; ia = e >> 4; }
+        if (b_jfast) { jb = e & 63; kb = e >> 6; } else { kb = e & 15; jb = e >> 4; }
+        int kka = kt * TG_BK + ka, kkb = kt * TG_BK + kb;
+        int oa = offAi[ia], ob = offBj[jb];
+        ra[r] = (oa >= 0 && kka < kchunk) ? TAcc(A[oa + offAk[kka]]) : TAcc(0);
+        rb[r] = (ob >= 0 && kkb < kchunk) ? TAcc(B[ob + offBk[kkb]]) : TAcc(0);
+      }
+    };
+    auto store_regs = [&]() {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int e = tid + 256 * r;
+        int ia, ka, jb, kb;
+        if (a_ifast) { ia = e & 63; ka = e >> 6; } else { ka = e & 15; ia = e >> 4; }
+        if (b_jfast) { jb = e & 63; kb = e >> 6; } else { kb = e & 15; jb = e >> 4; }
+        As[ka][ia] = ra[r];
+        Bs[kb][jb] = rb[r];
+      }
+    };
+
+    load_regs(0);
+    store_regs();
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      if (kt + 1 < nkt) load_regs(kt + 1);
+      if constexpr (USE_MFMA) {
+        if constexpr (sizeof(TAcc) == 4) {
+#pragma unroll
+          for (int kk = 0; kk < TG_BK; kk += 2) {
+            float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
+            float bb = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
+            acc32 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc32, 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < TG_BK; kk += 4) {
+            double a0 = As[kk + (lane >> 4)][wm * 32 + (lane & 15)];
+            double a1 = As[kk + (lane >> 4)][wm * 32 + 16 + (lane & 15)];
+            double b0 = Bs[kk + (lane >> 4)][wn * 32 + (lane & 15)];
+            double b1 = Bs[kk + (lane >> 4)][wn * 32 + 16 + (lane & 15)];
+            acc64[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc64[0][0], 0, 0, 0);
+            acc64[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc64[0][1], 0, 0, 0);
+            acc64[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc64[1][0], 0, 0, 0);
+            acc64[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc64[1][1], 0, 0, 0);
+          }
+        }
+      } else {
+        const int ti = (tid >> 4) * 4, tj = (tid & 15) * 4;
+#pragma unroll
+        for (int kk = 0; kk < TG_BK; ++kk) {
+          TAcc av[4], bv[4];
+          for (int a = 0; a < 4; ++a) av[a] = As[kk][ti + a];
+          for (int c = 0; c < 4; ++c) bv[c] = Bs[kk][tj + c];
+          for (int a = 0; a < 4; ++a)
+            for (int c = 0; c < 4; ++c) accv[a][c] += av[a] * bv[c];
+        }
+      }
+      __syncthreads();
+      if (kt + 1 < nkt) {
+        store_regs();
+        __syncthreads();
+      }
+    }
+  }
+
+  const TAcc alpha = TAcc(d.alpha);
+  auto put = [&](int li, int lj, TAcc v) {
+    int oi = offCi[li], oj = offCj[lj];
+    if (oi >= 0 && oj >= 0) {
+      TC *p = C + oi + oj;
+      v *= alpha;
+      if (d.accumulate) v += TAcc(*p);
+      *p = TC(v);
+    }
+  };
+  if constexpr (USE_MFMA) {
+    if constexpr (sizeof(TAcc) == 4) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        put(wm * 32 + row, wn * 32 + (lane & 31), acc32[r]);
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int row = (lane >> 4) + 4 * r;
+            put(wm * 32 + a * 16 + row, wn * 32 + c * 16 + (lane & 15), acc64[a][c][r]);
+          }
+    }
+  } else {
+    const int ti = (tid >> 4) * 4, tj = (tid & 15) * 4;
+    for (int a = 0; a < 4; ++a)
+      for (int c = 0; c < 4; ++c) put(ti + a, tj + c, accv[a][c]);
+  }
+}
+
+bool tgemm_use_mfma();
+
+template <typename TA, typename TB, typename TC, typename TAcc>
+void tgemm_launch(hipStream_t s, const TGemmDesc &d, const TA *A, const TB *B, TC *C) {
+  if (d.nbatch <= 0 || d.Itot() <= 0 || d.Jtot() <= 0) return;
+  dim3 grid((d.Itot() + TG_BM - 1) / TG_BM, (d.Jtot() + TG_BN - 1) / TG_BN, d.nbatch);
+  if (tgemm_use_mfma())
+    hipLaunchKernelGGL((tgemm_kernel<TA, TB, TC, TAcc, true>), grid, dim3(256), 0, s, d, A, B, C);
+  else
+    hipLaunchKernelGGL((tgemm_kernel<TA, TB, TC, TAcc, false>), grid, dim3(256), 0, s, d, A, B, C);
+  PG_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace pepsgpu

@@ -1,0 +1,146 @@
+"""GPU unit tests of the HIP kernels through the C ABI diagnostics (tgemm / Cholesky / Jacobi)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _capi():
+    from peps_amd import capi
+    return capi
+
+
+def _ref_tgemm(I, J, K, sAi, sAk, sBk, sBj, sCi, sCj, A, B, C, nb, wA, wB, wC):
+    C = C.astype(np.float64).copy()
+    A = A.astype(np.float64)
+    B = B.astype(np.float64)
+    ii = np.indices(I).reshape(3, -1)
+    jj = np.indices(J).reshape(3, -1)
+    kk = np.indices(K).reshape(3, -1)
+    oAi = (np.array(sAi)[:, None] * ii).sum(0)
+    oCi = (np.array(sCi)[:, None] * ii).sum(0)
+    oAk = (np.array(sAk)[:, None] * kk).sum(0)
+    oBk = (np.array(sBk)[:, None] * kk).sum(0)
+    oBj = (np.array(sBj)[:, None] * jj).sum(0)
+    oCj = (np.array(sCj)[:, None] * jj).sum(0)
+    for b in range(nb):
+        Am = A[b * wA + oAi[:, None] + oAk[None, :]]
+        Bm = B[b * wB + oBk[:, None] + oBj[None, :]]
+        C[b * wC + oCi[:, None] + oCj[None, :]] = Am @ Bm
+    return C
+
+
+CASES = [
+    # I, J, K sub-dims (outer..inner) -- plain, odd sizes, multi-index, K > table chunk
+    ((1, 1, 64), (1, 1, 64), (1, 1, 32)),
+    ((1, 1, 70), (1, 1, 33), (1, 1, 19)),
+    ((1, 5, 7), (1, 3, 11), (1, 4, 9)),
+    ((2, 3, 5), (3, 2, 4), (2, 5, 3)),
+    ((1, 1, 130), (1, 1, 129), (1, 1, 2100)),
+    ((1, 1, 1), (1, 1, 1), (3, 4, 5)),
+    ((1, 1, 256), (1, 1, 8), (1, 1, 8)),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+@pytest.mark.parametrize("dt", ["f32", "f64", "f32f64"])
+def test_tgemm_matches_numpy(case, dt):
+    capi = _capi()
+    I, J, K = CASES[case]
+    rng = np.random.default_rng(100 + case)
+    ni, nj, nk = int(np.prod(I)), int(np.prod(J)), int(np.prod(K))
+    # A stored with a random permutation of the 6 (i,k) sub-indices, likewise B, C
+    def strides(dims, perm):
+        st = [0] * len(dims)
+        acc = 1
+        for ax in reversed(perm):
+            st[ax] = acc
+            acc *= dims[ax]
+        return st
+    pa = rng.permutation(6)
+    stA = strides(list(I) + list(K), list(pa))
+    pb = rng.permutation(6)
+    stB = strides(list(K) + list(J), list(pb))
+    pc = rng.permutation(6)
+    stC = strides(list(I) + list(J), list(pc))
+    nb = 3
+    wA, wB, wC = ni * nk + 5, nk * nj + 3, ni * nj + 7
+    A = rng.standard_normal(nb * wA)
+    B = rng.standard_normal(nb * wB)
+    C0 = np.full(nb * wC, 7.0)
+    din = capi.F64 if dt == "f64" else capi.F32
+    dout = capi.F32 if dt == "f32" else capi.F64
+    if din == capi.F32:
+        A = A.astype(np.float32)
+        B = B.astype(np.float32)
+    got = capi.diag_tgemm(din, dout, I, J, K, stA[:3], stA[3:], stB[:3], stB[3:], stC[:3], stC[3:], A, B, C0, nb, wA, wB, wC)
+    ref = _ref_tgemm(I, J, K, stA[:3], stA[3:], stB[:3], stB[3:], stC[:3], stC[3:], A, B, C0, nb, wA, wB, wC)
+    tol = 2e-5 * np.sqrt(nk) if dt == "f32" else 1e-12 * np.sqrt(nk)
+    assert np.max(np.abs(got - ref)) < tol * max(1.0, np.max(np.abs(ref)))
+    # untouched padding between batches keeps the initial value
+    mask = np.ones(nb * wC, bool)
+    for b in range(nb):
+        mask[b * wC:b * wC + ni * nj] = False
+    assert np.all(got[mask] == 7.0)
+
+
+@pytest.mark.parametrize("n", [1, 7, 16, 40, 129, 256])
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_cholesky(n, dt):
+    capi = _capi()
+    rng = np.random.default_rng(n)
+    nb = 3
+    X = rng.standard_normal((nb, 2 * n + 3, n)) * np.logspace(0, -3, n)[None, None, :]
+    G = np.einsum("bri,brj->bij", X, X)
+    R = capi.diag_chol(capi.F32 if dt == "f32" else capi.F64, G).astype(np.float64)
+    for b in range(nb):
+        sc = np.max(np.diag(G[b]))
+        assert np.allclose(np.tril(R[b], -1), 0)
+        err = np.max(np.abs(R[b].T @ R[b] * sc - G[b])) / sc
+        assert err < (3e-6 if dt == "f32" else 1e-12)
+
+
+def test_cholesky_rank_deficient():
+    capi = _capi()
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((2, 10, 32))        # rank 10 < 32
+    G = np.einsum("bri,brj->bij", X, X)
+    R = capi.diag_chol(capi.F64, G)
+    for b in range(2):
+        sc = np.max(np.diag(G[b]))
+        assert np.all(np.isfinite(R[b]))
+        assert np.max(np.abs(R[b].T @ R[b] * sc - G[b])) / sc < 1e-10
+
+
+@pytest.mark.parametrize("shape", [(1, 5), (2, 2), (9, 33), (64, 64), (144, 144), (256, 256), (37, 200)])
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("force_global", [False, True])
+def test_jacobi_rows(shape, dt, force_global):
+    capi = _capi()
+    m, ln = shape
+    if force_global and m * ln > 64 * 64 and (m, ln) != (256, 256):
+        pytest.skip("global-memory path covered by the small and the 256x256 cases")
+    rng = np.random.default_rng(m * 1000 + ln)
+    nb = 2
+    r = min(m, ln)
+    # graded spectrum like a boundary-MPS bond
+    U, _ = np.linalg.qr(rng.standard_normal((m, r)))
+    V, _ = np.linalg.qr(rng.standard_normal((ln, r)))
+    s = np.logspace(0, -5, r)
+    M = np.stack([(U * s) @ V.T, (U * s[::-1]) @ V.T])
+    k = max(1, r // 2)
+    dtc = capi.F32 if dt == "f32" else capi.F64
+    Mo, Vt, S, sw = capi.diag_jacobi(dtc, M, k, force_global)
+    eps = 3e-5 if dt == "f32" else 1e-12
+    for b in range(nb):
+        sref = np.linalg.svd(M[b], compute_uv=False)
+        assert np.max(np.abs(S[b].astype(np.float64) - sref[:k])) < eps * sref[0]
+        # rows of Vt orthonormal and spanning the dominant right singular subspace
+        Vb = Vt[b].astype(np.float64)
+        assert np.max(np.abs(Vb @ Vb.T - np.eye(k))) < 20 * eps
+        Pref = np.linalg.svd(M[b])[2][:k]
+        # projector difference only checked where the spectrum has a gap at k
+        if k < r and sref[k] < 0.5 * sref[k - 1]:
+            gap_tol = 50 * eps * sref[0] / (sref[k - 1] - sref[k])
+            assert np.max(np.abs(Vb.T @ Vb - Pref.T @ Pref)) < max(gap_tol, 50 * eps)
+        assert sw[b] < 40

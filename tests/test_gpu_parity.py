@@ -1,0 +1,195 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the float64 oracle on the
+same seeded inputs, against the reference's fixtures, and through size-independent properties."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ising, qlten_io, vmc
+from oracle.bmps import BMPSTruncateParams, LEFT, DOWN, RIGHT, UP, HORIZONTAL, VERTICAL
+from oracle.contractor import BMPSContractor, TensorNetwork2D
+from peps_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f32": 1e-5, "f64": 1e-9}     # relative amplitude tolerance device vs float64 oracle (1e-5)
+
+
+def _ctx(L, D, d, chi, dt, n):
+    from peps_amd import capi
+    return capi.Context(L, L, D, d, chi, dtype=capi.F32 if dt == "f32" else capi.F64, max_walkers=max(n, 1))
+
+
+def _upload(ctx, sitps, D):
+    ctx.state_upload(synthetic.sitps_to_flat(sitps, D, np.float64))
+
+
+def _oracle_amps(sitps, configs, chi):
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    return np.array([vmc.TPSWaveFunctionComponent(sitps, c, tp).amplitude for c in configs])
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("L,D,chi", [(4, 2, 4), (5, 3, 6), (6, 4, 8), (8, 4, 16)])
+def test_evaluate_amplitude_synthetic(L, D, chi, dt):
+    sitps = synthetic.make_sitps(L, D)
+    cfgs = synthetic.make_configs(L, 6, "heisenberg")
+    ref = _oracle_amps(sitps, cfgs, chi)
+    ctx = _ctx(L, D, 2, chi, dt, len(cfgs))
+    _upload(ctx, sitps, D)
+    ctx.set_configs(cfgs)
+    got = ctx.evaluate_amplitude()
+    assert np.all(ctx.walker_flags() == 0)
+    assert np.max(np.abs(got / ref - 1)) < TOL[dt], (got, ref)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_k5_fixture_4x4_d8(fixtures_dir, dt):
+    """Reference fixture tests/slow_tests/test_data/tps_square_heisenberg4x4D8Double."""
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, "tps_square_heisenberg4x4D8Double"))
+    cfgs = np.stack([synthetic.checkerboard(4)] + list(synthetic.make_configs(4, 5, "heisenberg")))
+    for chi in (16, 64):
+        ref = _oracle_amps(s, cfgs, chi)
+        ctx = _ctx(4, 8, 2, chi, dt, len(cfgs))
+        _upload(ctx, s, 8)
+        ctx.set_configs(cfgs)
+        got = ctx.evaluate_amplitude()
+        assert np.max(np.abs(got / ref - 1)) < TOL[dt]
+    # chi = 64 is exact: brute-force value of SURVEY 8c
+    assert abs(got[0] / 1.441641034201432e+02 - 1) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_all_trace_routes_and_positions(dt):
+    """Every stack direction (UP/DOWN/LEFT/RIGHT), BTen direction and trace route gives the same
+    amplitude (tests/test_2d_tn/test_bmps_contractor.cpp:273-405 does this for the reference)."""
+    L, D, chi = 6, 3, 9
+    sitps = synthetic.make_sitps(L, D)
+    cfgs = synthetic.make_configs(L, 4, "heisenberg")
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    ctx = _ctx(L, D, 2, chi, dt, len(cfgs))
+    _upload(ctx, sitps, D)
+    ctx.set_configs(cfgs)
+    dev = []
+    ctx.grow_bmps_for_row(2)
+    ctx.init_bten(LEFT, 2)
+    ctx.grow_full_bten(RIGHT, 2, 2, True)
+    dev.append(ctx.trace(2, 0, HORIZONTAL))
+    ctx.shift_bten_window(RIGHT)
+    dev.append(ctx.trace(2, 1, HORIZONTAL))
+    ctx.grow_bmps_for_col(1)
+    ctx.init_bten(DOWN, 1)
+    ctx.grow_full_bten(UP, 1, 2, True)
+    dev.append(ctx.trace(L - 2, 1, VERTICAL))
+    ctx.shift_bten_window(UP)
+    dev.append(ctx.trace(L - 3, 1, VERTICAL))
+    ref = []
+    for w, cfg in enumerate(cfgs):
+        tn = TensorNetwork2D.from_sitps(sitps, cfg)
+        c = BMPSContractor(L, L)
+        c.Init(tn)
+        c.SetTruncateParams(tp)
+        r = []
+        c.GrowBMPSForRow(tn, 2)
+        c.InitBTen(tn, LEFT, 2)
+        c.GrowFullBTen(tn, RIGHT, 2, 2, True)
+        r.append(c.Trace(tn, (2, 0), HORIZONTAL))
+        c.ShiftBTenWindow(tn, RIGHT)
+        r.append(c.Trace(tn, (2, 1), HORIZONTAL))
+        c.GrowBMPSForCol(tn, 1)
+        c.InitBTen(tn, DOWN, 1)
+        c.GrowFullBTen(tn, UP, 1, 2, True)
+        r.append(c.Trace(tn, (L - 2, 1), VERTICAL))
+        c.ShiftBTenWindow(tn, UP)
+        r.append(c.Trace(tn, (L - 3, 1), VERTICAL))
+        ref.append(r)
+    ref = np.array(ref).T
+    dev = np.array(dev)
+    assert np.max(np.abs(dev / ref - 1)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_replace_traces_and_punch_hole(dt):
+    """ReplaceNNSiteTrace / ReplaceOneSiteTrace ratios and PunchHole . site == Trace (K3,
+    test_bmps_contractor.cpp:407-470), both orientations."""
+    L, D, chi = 5, 3, 9
+    sitps = synthetic.make_sitps(L, D)
+    cfgs = synthetic.make_configs(L, 3, "heisenberg")
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    ctx = _ctx(L, D, 2, chi, dt, len(cfgs))
+    _upload(ctx, sitps, D)
+    ctx.set_configs(cfgs)
+    row, col = 2, 1
+    ctx.grow_bmps_for_row(row)
+    ctx.grow_full_bten(LEFT, row, L - col, True)        # LEFT btens 0..col
+    ctx.grow_full_bten(RIGHT, row, col + 2, True)       # RIGHT btens up to slice col+1
+    cand = np.array([[[0, 0], [0, 1], [1, 0], [1, 1]]] * len(cfgs), dtype=np.int32)
+    nn = ctx.replace_nn_trace(row, col, HORIZONTAL, cand)
+    psi = ctx.trace(row, col, HORIZONTAL)
+    # one more RIGHT step so that the one-site environment of (row, col) is available
+    ctx.grow_bten_step(RIGHT)
+    one = ctx.replace_one_trace(row, col, HORIZONTAL, np.array([[0, 1]] * len(cfgs), dtype=np.int32))
+    hole = ctx.punch_hole(row, col, HORIZONTAL)
+    for w, cfg in enumerate(cfgs):
+        tn = TensorNetwork2D.from_sitps(sitps, cfg)
+        c = BMPSContractor(L, L)
+        c.Init(tn)
+        c.SetTruncateParams(tp)
+        c.GrowBMPSForRow(tn, row)
+        c.GrowFullBTen(tn, LEFT, row, L - col, True)
+        c.GrowFullBTen(tn, RIGHT, row, col + 2, True)
+        for k, (s1, s2) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+            ref = c.ReplaceNNSiteTrace(tn, (row, col), (row, col + 1), HORIZONTAL, sitps[row][col][s1], sitps[row][col + 1][s2])
+            assert abs(nn[w, k] - ref) < TOL[dt] * abs(c.Trace(tn, (row, col), HORIZONTAL)) * 10
+        ref_psi = c.Trace(tn, (row, col), HORIZONTAL)
+        assert abs(psi[w] / ref_psi - 1) < TOL[dt]
+        c.GrowBTenStep(tn, RIGHT)
+        for k in range(2):
+            ref = c.ReplaceOneSiteTrace(tn, (row, col), sitps[row][col][k], HORIZONTAL)
+            assert abs(one[w, k] - ref) < TOL[dt] * abs(ref_psi) * 10
+        h_ref = c.PunchHole(tn, (row, col), HORIZONTAL)
+        dd = h_ref.shape
+        h_dev = hole[w][:dd[0], :dd[1], :dd[2], :dd[3]]
+        assert np.max(np.abs(h_dev - h_ref)) < TOL[dt] * 10 * np.max(np.abs(h_ref))
+        assert abs(np.sum(h_dev * tn((row, col))) / ref_psi - 1) < TOL[dt] * 10
+
+
+def test_k1_ising_device_f64():
+    """K1 on the device: the 12x12 critical Ising network (uniform 'configuration') with fixed
+    chi = 30 reproduces the exact free energy to 1e-8 (reference tolerance)."""
+    tn, lognorm, beta = ising.build_ising_tn(12, 12)
+    f_ex = ising.exact_free_energy(12, 12, 1.0 / beta)
+    sitps = [[[tn((r, c))] for c in range(12)] for r in range(12)]
+    ctx = _ctx(12, 2, 1, 30, "f64", 1)
+    _upload(ctx, sitps, 2)
+    ctx.set_configs(np.zeros((1, 12, 12), dtype=np.int32))
+    amps = []
+    ctx.grow_bmps_for_row(2)
+    ctx.init_bten(LEFT, 2)
+    ctx.grow_full_bten(RIGHT, 2, 2, True)
+    amps.append(ctx.trace(2, 0, HORIZONTAL)[0])
+    ctx.shift_bten_window(RIGHT)
+    amps.append(ctx.trace(2, 1, HORIZONTAL)[0])
+    ctx.grow_bmps_for_col(1)
+    ctx.init_bten(DOWN, 1)
+    ctx.grow_full_bten(UP, 1, 2, True)
+    amps.append(ctx.trace(10, 1, VERTICAL)[0])
+    for a in amps:
+        assert abs(-(np.log(a) + lognorm) / 144 / beta - f_ex) < 1e-8
+
+
+def test_error_codes():
+    from peps_amd import capi
+    ctx = capi.Context(4, 4, 2, 2, 4, dtype=capi.F32, max_walkers=2)
+    with pytest.raises(RuntimeError):          # std::logic_error analogue: nothing uploaded
+        ctx.n = 1
+        ctx.evaluate_amplitude()
+    sitps = synthetic.make_sitps(4, 2)
+    _upload(ctx, sitps, 2)
+    with pytest.raises(IndexError):            # std::out_of_range: config value >= physical dim
+        ctx.set_configs(np.full((1, 4, 4), 2, dtype=np.int32))
+    with pytest.raises(ValueError):            # too many walkers
+        ctx.set_configs(np.zeros((3, 4, 4), dtype=np.int32))
+    ctx.set_configs(np.zeros((2, 4, 4), dtype=np.int32))
+    with pytest.raises(RuntimeError):          # trace without environments
+        ctx.trace(1, 1, HORIZONTAL)
