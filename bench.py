@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: configuration-amplitudes/sec of the boundary-MPS hot path on MI355X.
+
+A "step" = one pass of the hot path over one batch of synthetic input: `walkers` FRESH
+configurations per GPU, each through TPSWaveFunctionComponent::EvaluateAmplitude
+(wave_function_component.h:187-212: L-1 row absorptions with SVD(chi,chi,0), L-2 BTen steps, one
+trace).  Workload at N=1 = BASELINE.json's metric configuration: 12x12 spin-1/2 Heisenberg PEPS,
+D=8, chi=32, synthetic state of SURVEY 8(d).  N>1: one rank per GPU, walkers
+sharded, no data-path collective (weak scaling).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}     # /opt/skills/guides/MI355X_MICROARCH.md, dense MFMA peaks
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--walkers", type=int, default=512, help="walkers (fresh configurations) per GPU per step")
+    ap.add_argument("--workload", default="C4", choices=["C2", "C3", "C4"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time budget of the CPU (oracle) baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(sitps, cfgs, chi, budget_s):
+    """Oracle ("port" of the reference algorithm, float64 NumPy/LAPACK) timed on the host cores on a
+    bounded sample of the same workload; returns (amplitudes/s, n, amplitudes, threads)."""
+    from oracle import vmc
+    from oracle.bmps import BMPSTruncateParams
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    amps = []
+    t0 = time.perf_counter()
+    for c in cfgs:
+        amps.append(vmc.TPSWaveFunctionComponent(sitps, c, tp).amplitude)
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return len(amps) / dt, len(amps), np.array(amps), threads
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from peps_amd import capi, synthetic
+    from peps_amd.flops import reference_flops
+
+    L, D, chi, model = synthetic.CONFIGS[args.workload]
+    nw = args.walkers
+    dt = capi.F32 if args.dtype == "f32" else capi.F64
+    ctx = capi.Context(L, L, D, 2, chi, dtype=dt, device=local_rank, max_walkers=nw)
+
+    # synthetic state of SURVEY 8(d); psi(S_ref) normalisation evaluated with the device path itself
+    sitps = synthetic.make_sitps(L, D)
+    ctx.state_upload(synthetic.sitps_to_flat(sitps, D, np.float64))
+    ctx.set_configs(synthetic.checkerboard(L)[None])
+    psi_ref = float(ctx.evaluate_amplitude()[0])
+    sitps = synthetic.rescale_sitps(sitps, psi_ref)
+    ctx.state_upload(synthetic.sitps_to_flat(sitps, D, np.float64))
+
+    total_steps = args.warmup + args.steps
+    batches = [synthetic.make_configs(L, nw, "heisenberg", seed0=7 + (s * world + rank) * nw) for s in range(total_steps)]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.sync()
+
+    amps_first = None
+    for s in range(args.warmup):
+        ctx.set_configs(batches[s])
+        a = ctx.evaluate_amplitude()
+        if amps_first is None:
+            amps_first = a
+    ctx.profile_enable(True)
+    ctx.profile_read()
+    barrier()
+    t0 = time.perf_counter()
+    nz = 0
+    for s in range(args.warmup, total_steps):
+        ctx.set_configs(batches[s])
+        a = ctx.evaluate_amplitude()
+        nz += int(np.count_nonzero(ctx.walker_flags()))
+        if amps_first is None:
+            amps_first = a
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        n_amp = nw * args.steps * world
+        value = n_amp / elapsed
+        fl = reference_flops(L, D, chi)
+        dom = max(prof, key=lambda k: prof[k]["ms"])
+        dsec = prof[dom]["ms"] * 1e-3
+        achieved = prof[dom]["alg_flops"] / dsec / 1e12 if dsec > 0 else 0.0
+        peak = PEAK_TFLOPS[args.dtype]
+        out = {
+            "metric": "configuration-amplitudes/sec",
+            "value": value,
+            "unit": "amplitudes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: %dx%d spin-1/2 Heisenberg PEPS, D=%d, chi=%d, fresh EvaluateAmplitude per configuration "
+                            "(SVD(chi,chi,0) truncation)" % (args.workload, L, L, D, chi),
+                "walkers_per_gpu": nw,
+                "parallelism": "walkers sharded over %d GPU(s), no data-path collective" % world,
+                "flops_per_amplitude_reference_algorithm": fl["total"],
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": dom,
+                "achieved": achieved,
+                "peak": peak,
+                "unit": "TFLOP/s",
+                "frac": achieved / peak,
+                "traffic": None,
+                "avg_launch_ms": prof[dom]["ms"] / max(prof[dom]["launches"], 1),
+                "launches": prof[dom]["launches"],
+                "note": "achieved = reference-algorithm flops of the op this kernel replaces (SURVEY 8d) / "
+                        "HIP-event time on the launch stream",
+            },
+            "job_tflops_reference_count": value * fl["total"] / 1e12 / world,
+            "job_frac_of_peak": value * fl["total"] / 1e12 / world / peak,
+            "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]},
+            "walkers_with_vanishing_amplitude": nz,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            ncheck = 8
+            rate, n, amps, threads = cpu_baseline(sitps, batches[0][:ncheck], chi, args.cpu_seconds)
+            out["cpu_baseline"] = {
+                "value": rate, "unit": "amplitudes/s", "cores": threads, "kind": "port",
+                "sample": "%d configuration(s) of the same %s workload through the float64 NumPy/LAPACK oracle "
+                          "(op-for-op restatement of bmps_impl.h:756-862); upstream binary cannot be built here" % (n, args.workload),
+            }
+            out["parity_on_sample"] = {
+                "max_rel_err_amplitude": float(np.max(np.abs(amps_first[:n] / amps - 1))), "n": n,
+                "tolerance": 1e-5,
+            }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

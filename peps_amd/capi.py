@@ -27,7 +27,7 @@ SYMBOLS = [
     "pepsgpu_grow_bten_step", "pepsgpu_shift_bten_window", "pepsgpu_truncate_bten", "pepsgpu_bten_stack_size",
     "pepsgpu_trace", "pepsgpu_replace_nn_trace", "pepsgpu_replace_one_trace", "pepsgpu_punch_hole",
     "pepsgpu_update_local", "pepsgpu_erase_envs_after_update", "pepsgpu_evaluate_amplitude",
-    "pepsgpu_walker_flags", "pepsgpu_sync", "pepsgpu_stats",
+    "pepsgpu_walker_flags", "pepsgpu_sync", "pepsgpu_stats", "pepsgpu_profile_enable", "pepsgpu_profile_read",
     "pepsgpu_diag_tgemm", "pepsgpu_diag_chol", "pepsgpu_diag_jacobi", "pepsgpu_version",
 ]
 
@@ -65,6 +65,8 @@ def load_library(path=LIB_PATH):
     lib.pepsgpu_walker_flags.argtypes = [vp, ip]
     lib.pepsgpu_sync.argtypes = [vp]
     lib.pepsgpu_stats.argtypes = [vp, dp, C.c_int]
+    lib.pepsgpu_profile_enable.argtypes = [vp, C.c_int]
+    lib.pepsgpu_profile_read.argtypes = [vp, dp]
     lib.pepsgpu_diag_tgemm.argtypes = [C.c_int, C.c_int, ip, C.c_int, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t,
                                        C.c_int, C.c_long, C.c_long, C.c_long]
     lib.pepsgpu_diag_chol.argtypes = [C.c_int, dp, C.c_int, C.c_int, vp]
@@ -215,6 +217,17 @@ class Context:
 
     def sync(self):
         self._ck(self._l.pepsgpu_sync(self._h))
+
+    PROF_CATS = ("contract", "gram_f64", "cholesky", "jacobi", "select", "normalize", "env", "other")
+
+    def profile_enable(self, on=True):
+        self._ck(self._l.pepsgpu_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        out = np.zeros((8, 4), dtype=np.float64)
+        self._ck(self._l.pepsgpu_profile_read(self._h, _dp(out)))
+        return {name: {"ms": out[i, 0], "launches": int(out[i, 1]), "alg_flops": out[i, 2], "exec_flops": out[i, 3]}
+                for i, name in enumerate(self.PROF_CATS)}
 
     def stats(self):
         out = np.zeros(5, dtype=np.float64)

@@ -141,6 +141,8 @@ int pepsgpu_evaluate_amplitude(pepsgpu_ctx *ctx, double *out) { CTX_CALL(ctx->en
 int pepsgpu_walker_flags(pepsgpu_ctx *ctx, int32_t *out) { CTX_CALL(ctx->eng->read_flags(out)); }
 int pepsgpu_sync(pepsgpu_ctx *ctx) { CTX_CALL(ctx->eng->sync()); }
 int pepsgpu_stats(pepsgpu_ctx *ctx, double *out, int n) { CTX_CALL(ctx->eng->stats(out, n)); }
+int pepsgpu_profile_enable(pepsgpu_ctx *ctx, int on) { CTX_CALL(ctx->eng->profile_enable(on)); }
+int pepsgpu_profile_read(pepsgpu_ctx *ctx, double *out) { CTX_CALL(ctx->eng->profile_read(out)); }
 
 }  // extern "C"
 

@@ -24,6 +24,10 @@ namespace pepsgpu {
 enum { LEFT = 0, DOWN = 1, RIGHT = 2, UP = 3 };      // include/qlpeps/basic.h:58-63
 enum { HORIZONTAL = 0, VERTICAL = 1 };               // include/qlpeps/basic.h:19-22
 
+// kernel categories of the event profile (pepsgpu_profile_read)
+enum { PROF_CONTRACT = 0, PROF_GRAM = 1, PROF_CHOL = 2, PROF_JACOBI = 3, PROF_SELECT = 4, PROF_NORM = 5,
+       PROF_ENV = 6, PROF_NCAT = 8 };
+
 struct EngineBase {
   virtual ~EngineBase() {}
   std::string last_error;
@@ -60,6 +64,8 @@ struct EngineBase {
   virtual void read_flags(int32_t *out) = 0;
   virtual size_t device_bytes() const = 0;
   virtual void stats(double *out, int n) = 0;
+  virtual void profile_enable(int on) = 0;
+  virtual void profile_read(double *out) = 0;   // [PROF_NCAT][4]: ms, launches, algorithmic flops, executed flops
 };
 
 template <typename T>
@@ -516,6 +522,44 @@ class Engine : public EngineBase {
   }
   hipStream_t stream() const { return stream_; }
 
+  // ---- per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----
+  void profile_enable(int on) override {
+    prof_resolve();
+    prof_on_ = on != 0;
+  }
+  void profile_read(double *out) override {
+    prof_resolve();
+    for (int c = 0; c < PROF_NCAT; ++c) {
+      out[4 * c + 0] = prof_ms_[c]; out[4 * c + 1] = (double)prof_n_[c];
+      out[4 * c + 2] = prof_alg_[c]; out[4 * c + 3] = prof_exec_[c];
+      prof_ms_[c] = 0; prof_n_[c] = 0; prof_alg_[c] = 0; prof_exec_[c] = 0;
+    }
+  }
+  void prof_begin(int cat, double alg_flops, double exec_flops) {
+    if (!prof_on_) return;
+    ProfRec r;
+    if (!ev_pool_.empty()) { r.a = ev_pool_.back(); ev_pool_.pop_back(); } else PG_CHECK_HIP(hipEventCreate(&r.a));
+    if (!ev_pool_.empty()) { r.b = ev_pool_.back(); ev_pool_.pop_back(); } else PG_CHECK_HIP(hipEventCreate(&r.b));
+    r.cat = cat; r.alg = alg_flops; r.exec = exec_flops;
+    PG_CHECK_HIP(hipEventRecord(r.a, stream_));
+    prof_.push_back(r);
+  }
+  void prof_end() {
+    if (!prof_on_) return;
+    PG_CHECK_HIP(hipEventRecord(prof_.back().b, stream_));
+  }
+  void prof_resolve() {
+    if (prof_.empty()) return;
+    PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    for (auto &r : prof_) {
+      float ms = 0.f;
+      PG_CHECK_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+      prof_ms_[r.cat] += ms; prof_n_[r.cat] += 1; prof_alg_[r.cat] += r.alg; prof_exec_[r.cat] += r.exec;
+      ev_pool_.push_back(r.a); ev_pool_.push_back(r.b);
+    }
+    prof_.clear();
+  }
+
  private:
   struct SiteSel {
     int r, c;
@@ -616,7 +660,10 @@ class Engine : public EngineBase {
       g.K[2] = cdim; g.sAk[2] = 1; g.sBk[2] = b1 * b2;
       g.J[2] = b1 * b2; g.sBj[2] = 1; g.sCj[2] = 1;
       g.wA = mps1.n; g.wB = bt.t.n; g.wC = tmp1.n; g.nbatch = nw_;
+      const double fl = 2.0 * nw_ * (double)(x * p1) * cdim * (double)(b1 * b2);
+      prof_begin(PROF_ENV, fl, fl);
       tgemm_launch<T, T, T, T>(stream_, g, mps1.p, bt.t.p, tmp1.p);
+      prof_end();
     }
     // tmp2[b2,x,s1,s2] = sum_{p1,b1} tmp1[x,p1,b1,b2] site[lc<-p1, lb<-b1, l1->s1, l2->s2]
     DTen<T> tmp2 = alloc_ten(b2, x, s1, s2, nb);
@@ -626,7 +673,10 @@ class Engine : public EngineBase {
       g.K[1] = p1; g.K[2] = b1; g.sAk[1] = b1 * b2; g.sAk[2] = b2; g.sBk[1] = st[lc]; g.sBk[2] = st[lb];
       g.J[1] = s1; g.J[2] = s2; g.sBj[1] = st[l1]; g.sBj[2] = st[l2]; g.sCj[1] = s2; g.sCj[2] = 1;
       g.wA = tmp1.n; g.bdivA = ncand; g.wC = tmp2.n; g.nbatch = nb;
+      const double fl = 2.0 * nb * (double)(b2 * x) * (double)(p1 * b1) * (double)(s1 * s2);
+      prof_begin(PROF_ENV, fl, fl);
       launch_site_gemm(g, ss, ncand, tmp1.p, tmp2.p);
+      prof_end();
     }
     // out[x,s2,y] = sum_{b2,s1} tmp2[b2,x,s1,s2] mps2[b2,s1,y]
     BTenDev o;
@@ -637,7 +687,10 @@ class Engine : public EngineBase {
       g.K[1] = b2; g.K[2] = s1; g.sAk[1] = x * s1 * s2; g.sAk[2] = s2; g.sBk[1] = s1 * y; g.sBk[2] = y;
       g.J[2] = y; g.sBj[2] = 1; g.sCj[2] = 1;
       g.wA = tmp2.n; g.wB = mps2.n; g.bdivB = ncand; g.wC = o.t.n; g.nbatch = nb;
+      const double fl = 2.0 * nb * (double)(x * s2) * (double)(b2 * s1) * (double)y;
+      prof_begin(PROF_ENV, fl, fl);
       tgemm_launch<T, T, T, T>(stream_, g, tmp2.p, mps2.p, o.t.p);
+      prof_end();
     }
     free_ten(tmp1); free_ten(tmp2);
     o.logscale = nullptr;
@@ -681,6 +734,12 @@ class Engine : public EngineBase {
   std::vector<int> hcfg_;
   std::vector<BMPSDev> bmps_[4];
   std::vector<BTenDev> bten_[4];
+  struct ProfRec { hipEvent_t a, b; int cat; double alg, exec; };
+  std::vector<ProfRec> prof_;
+  std::vector<hipEvent_t> ev_pool_;
+  bool prof_on_ = false;
+  double prof_ms_[PROF_NCAT] = {0}, prof_alg_[PROF_NCAT] = {0}, prof_exec_[PROF_NCAT] = {0};
+  long prof_n_[PROF_NCAT] = {0};
   long n_absorb_ = 0, n_jacobi_ = 0, jacobi_sweeps_sum_ = 0, jacobi_sweeps_max_ = 0;
   int *sweeps_ = nullptr;
   bool dbg_sweeps_ = false;

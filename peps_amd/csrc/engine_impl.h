@@ -59,7 +59,10 @@ void Engine<T>::absorb(int pos, int num) {
       g.K[2] = a; g.sAk[2] = 1; g.sBk[2] = p * a2;
       g.J[2] = p * a2; g.sBj[2] = 1; g.sCj[2] = 1;
       g.wA = R[i].n; g.wB = A.n; g.wC = X.n; g.nbatch = nw_;
+      const double fl = 2.0 * nw_ * (double)(m * l) * a * (double)(p * a2);
+      prof_begin(PROF_CONTRACT, fl, fl);
       tgemm_launch<T, T, T, T>(stream_, g, R[i].p, A.p, X.p);
+      prof_end();
     }
     // P[m,u,l2,a2] = sum_{l,p} X[m,l,p,a2] W[l,p,l2,u]           (bmps_impl.h:807 + :815-817)
     DTen<T> P = alloc_ten(m, u, l2, a2);
@@ -69,7 +72,10 @@ void Engine<T>::absorb(int pos, int num) {
       g.K[1] = l; g.K[2] = p; g.sAk[1] = p * a2; g.sAk[2] = a2; g.sBk[1] = st[ll]; g.sBk[2] = st[lp];
       g.J[1] = l2; g.J[2] = u; g.sBj[1] = st[lr]; g.sBj[2] = st[lu]; g.sCj[1] = a2; g.sCj[2] = l2 * a2;
       g.wA = X.n; g.wC = P.n; g.nbatch = nw_;
+      const double fl = 2.0 * nw_ * (double)(m * a2) * (double)(l * p) * (double)(l2 * u);
+      prof_begin(PROF_CONTRACT, fl, fl);
       launch_site_gemm(g, cfg_site(r, c), 1, X.p, P.p);
+      prof_end();
     }
     free_ten(X);
     const int rows = m * u, cols = l2 * a2;
@@ -77,7 +83,10 @@ void Engine<T>::absorb(int pos, int num) {
       // economy QR would return R = Q^T P with rows x cols; any R with R^T R = P^T P serves
       // (rows == cols goes through the Cholesky: a triangular carry makes the Jacobi converge 3x faster)
       P.d[0] = rows; P.d[1] = l2; P.d[2] = a2; P.d[3] = 1;
+      // reference op here: QR of the (rows x cols) block, rows < cols (swap R,C)
+      prof_begin(PROF_NORM, nw_ * 2.0 * (2.0 * cols * (double)rows * rows - 2.0 / 3.0 * (double)rows * rows * rows), 0.0);
       normalize(P.p, P.n, P.n, nw_, nullptr);
+      prof_end();
       R[i + 1] = P;
     } else {
       double *G = (double *)arena_.alloc(sizeof(double) * (size_t)cols * cols * nw_);
@@ -87,15 +96,21 @@ void Engine<T>::absorb(int pos, int num) {
         g.K[2] = rows; g.sAk[2] = cols; g.sBk[2] = cols;
         g.J[2] = cols; g.sBj[2] = 1; g.sCj[2] = 1;
         g.wA = P.n; g.wB = P.n; g.wC = (long)cols * cols; g.nbatch = nw_;
+        // algorithmic flops of the op this replaces: geqrf + orgqr of (rows x cols)
+        prof_begin(PROF_GRAM, nw_ * 2.0 * (2.0 * rows * (double)cols * cols - 2.0 / 3.0 * (double)cols * cols * cols),
+                   2.0 * nw_ * (double)cols * cols * rows);
         tgemm_launch<T, T, double, double>(stream_, g, P.p, P.p, G);
+        prof_end();
       }
       R[i + 1] = alloc_ten(cols, l2, a2);
       size_t smem = sizeof(double) * ((size_t)CH_NB * cols + 64 * CH_NB);
       PG_REQUIRE(smem <= 150 * 1024, 1, "Cholesky panel does not fit LDS (D*chi too large)");
       allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
+      prof_begin(PROF_CHOL, 0.0, nw_ * (double)cols * cols * cols / 3.0);
       hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nw_), dim3(256), smem, stream_, G, (long)cols * cols, cols,
                          R[i + 1].p, R[i + 1].n);
       PG_CHECK_HIP(hipGetLastError());
+      prof_end();
       arena_.free(G);
       free_ten(P);
     }
@@ -125,7 +140,9 @@ void Engine<T>::absorb(int pos, int num) {
       g.K[2] = a2; g.sAk[2] = 1; g.sBk[2] = k2;
       g.J[1] = l2; g.J[2] = k2; g.sBj[1] = a2 * k2; g.sBj[2] = 1; g.sCj[1] = k2; g.sCj[2] = 1;
       g.wA = A.n; g.wB = Y.n; g.wC = Z1.n; g.nbatch = nw_;
+      prof_begin(PROF_CONTRACT, 0.0, 2.0 * nw_ * (double)(a * p) * a2 * (double)(l2 * k2));
       tgemm_launch<T, T, T, T>(stream_, g, A.p, Y.p, Z1.p);
+      prof_end();
     }
     // Tt[l,a,u,k2] = sum_{p,l2} Z1[a,p,l2,k2] W[l,p,l2,u]
     DTen<T> Tt = alloc_ten(l, a, u, k2);
@@ -135,14 +152,18 @@ void Engine<T>::absorb(int pos, int num) {
       g.K[1] = p; g.K[2] = l2; g.sAk[1] = l2 * k2; g.sAk[2] = k2; g.sBk[1] = st[lp]; g.sBk[2] = st[lr];
       g.J[1] = l; g.J[2] = u; g.sBj[1] = st[ll]; g.sBj[2] = st[lu]; g.sCj[1] = a * u * k2; g.sCj[2] = k2;
       g.wA = Z1.n; g.wC = Tt.n; g.nbatch = nw_;
+      prof_begin(PROF_CONTRACT, 0.0, 2.0 * nw_ * (double)(a * k2) * (double)(p * l2) * (double)(l * u));
       launch_site_gemm(g, cfg_site(r, c), 1, Z1.p, Tt.p);
+      prof_end();
     }
     free_ten(Z1);
     free_ten(Y);
     if (i == 0) {
       PG_REQUIRE(l == 1 && a == 1, 3, "MultiplyMPO: left boundary bond is not trivial");
       Tt.d[0] = 1; Tt.d[1] = u; Tt.d[2] = k2; Tt.d[3] = 1;
+      prof_begin(PROF_NORM, 0.0, 0.0);
       normalize(Tt.p, Tt.n, Tt.n, nw_, out.logscale);
+      prof_end();
       out.t[0] = Tt;
       break;
     }
@@ -156,16 +177,23 @@ void Engine<T>::absorb(int pos, int num) {
       g.K[2] = la; g.sAk[2] = 1; g.sBk[2] = uk;
       g.J[2] = uk; g.sBj[2] = 1; g.sCj[2] = 1;
       g.wA = R[i].n; g.wB = Tt.n; g.wC = M.n; g.nbatch = nw_;
+      prof_begin(PROF_CONTRACT, 0.0, 2.0 * nw_ * (double)m * la * (double)uk);
       tgemm_launch<T, T, T, T>(stream_, g, R[i].p, Tt.p, M.p);
+      prof_end();
     }
     // rows of M -> mutually orthogonal (sigma_k v_k^T)
     {
       const size_t need = sizeof(T) * (size_t)m * (uk | 1);
       const int use_lds = need <= JACOBI_LDS_MAX;
       if (use_lds) allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), need);
+      {   // reference op: gesdd of the (m x uk) block: 4 r c^2 + 22 c^3, r >= c
+        const double rr = std::max(m, uk), cc = std::min(m, uk);
+        prof_begin(PROF_JACOBI, nw_ * (4.0 * rr * cc * cc + 22.0 * cc * cc * cc), 0.0);
+      }
       hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), use_lds ? need : 0, stream_, M.p, M.n, m, uk,
                          uk, 40, use_lds, sweeps_);
       PG_CHECK_HIP(hipGetLastError());
+      prof_end();
       ++n_jacobi_;
       if (dbg_sweeps_) {   // diagnostics only: per-launch sweep counts (forces a sync)
         std::vector<int> hs(nw_);
@@ -181,9 +209,11 @@ void Engine<T>::absorb(int pos, int num) {
     const int k = std::min(chi_, std::min(m, uk));
     PG_REQUIRE(m <= 1024, 1, "bond dimension too large for select_rows_kernel");
     DTen<T> V = alloc_ten(k, u, k2);
+    prof_begin(PROF_SELECT, 0.0, 0.0);
     hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)M.p, M.n, m, uk, uk, k, V.p,
                        V.n, (T *)nullptr, 0L);
     PG_CHECK_HIP(hipGetLastError());
+    prof_end();
     free_ten(M);
     out.t[i] = V;
     // Ynew[(l,a),q] = sum_{(u,k2)} Tt[(l,a),(u,k2)] V[q,(u,k2)]
@@ -194,9 +224,17 @@ void Engine<T>::absorb(int pos, int num) {
       g.K[2] = uk; g.sAk[2] = 1; g.sBk[2] = 1;
       g.J[2] = k; g.sBj[2] = uk; g.sCj[2] = 1;
       g.wA = Tt.n; g.wB = V.n; g.wC = Yn.n; g.nbatch = nw_;
+      // reference op: res[i-1] . (u s)  (bmps_impl.h:254): 2 (m_{i-1} D_u) m_i k_i
+      int rp, cp, ddp[4];
+      site_rc(i - 1, rp, cp);
+      site_dims(rp, cp, ddp);
+      prof_begin(PROF_CONTRACT, 2.0 * nw_ * (double)R[i - 1].d[0] * ddp[lu] * (double)m * k, 2.0 * nw_ * (double)la * uk * (double)k);
       tgemm_launch<T, T, T, T>(stream_, g, Tt.p, V.p, Yn.p);
+      prof_end();
     }
+    prof_begin(PROF_NORM, 0.0, 0.0);
     normalize(Yn.p, Yn.n, Yn.n, nw_, out.logscale);
+    prof_end();
     free_ten(Tt);
     Y = Yn;
   }
