@@ -218,7 +218,7 @@ class Context:
     def sync(self):
         self._ck(self._l.pepsgpu_sync(self._h))
 
-    PROF_CATS = ("contract", "gram_f64", "cholesky", "jacobi", "select", "normalize", "env", "other")
+    PROF_CATS = ("contract", "gram_f64", "cholesky", "jacobi", "select", "normalize", "env", "jacobi_edge")
 
     def profile_enable(self, on=True):
         self._ck(self._l.pepsgpu_profile_enable(self._h, int(on)))
@@ -274,4 +274,4 @@ def diag_jacobi(dtype, M, k, force_global=False):
                                    S.ctypes.data_as(C.c_void_p), int(force_global), _ip(sw))
     if rc != 0:
         raise RuntimeError("diag_jacobi failed: %s" % lib().pepsgpu_last_error(None).decode())
-    return M, Vt, S, sw
+    return M, Vt, S, sw & 0xFF      # high bits: diagnostics (rows above the noise floor at entry)

@@ -217,8 +217,14 @@ static void diag_jacobi_t(void *M, int m, int len, int nbatch, int k, void *Vt, 
   const size_t need = sizeof(T) * (size_t)m * (len | 1);
   const int use_lds = !force_global && need <= JACOBI_LDS_MAX;
   if (use_lds) allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), need);
-  hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nbatch), dim3(1024), use_lds ? need : 0, 0, dM, (long)m * len, m, len,
-                     len, 40, use_lds, dsw);
+  if (sizeof(T) == 4 && force_global == 2) {
+    PG_REQUIRE(m <= 256 && len <= 256, 1, "register Jacobi handles up to 256 x 256");
+    hipLaunchKernelGGL(jacobi_rows_reg256_kernel, dim3(nbatch), dim3(512), 0, 0, (float *)dM, (long)m * len, m, len, len,
+                       40, dsw);
+  } else {
+    hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nbatch), dim3(1024), use_lds ? need : 0, 0, dM, (long)m * len, m, len,
+                       len, 40, use_lds, dsw);
+  }
   PG_CHECK_HIP(hipGetLastError());
   hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nbatch), dim3(256), 0, 0, (const T *)dM, (long)m * len, m, len, len, k,
                      dV, (long)k * len, dS, (long)k);

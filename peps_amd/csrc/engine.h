@@ -721,6 +721,7 @@ class Engine : public EngineBase {
   }
 
   void absorb(int pos, int num);
+  void launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t need);
 
   int Ly_, Lx_, D_, dp_, chi_min_, chi_;
   double trunc_err_;

@@ -1,6 +1,7 @@
 // Row absorption and small helpers of Engine<T> (see engine.h for the algorithm statement).
 #pragma once
 #include "engine.h"
+#include "jacobi_reg.h"
 
 namespace pepsgpu {
 
@@ -16,6 +17,24 @@ void Engine<T>::add_logs(double *acc, const double *a, const double *b, const do
 template <typename T>
 void Engine<T>::add_log(double *acc, const double *a) {
   add_logs(acc, a, nullptr, nullptr, nullptr);
+}
+
+// Jacobi dispatch: LDS-resident generic kernel when the block fits, register-resident kernel for
+// the f32 bulk blocks (<= 256 x 256), global-memory generic kernel otherwise (f64 bulk blocks).
+template <typename T>
+void Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t need) {
+  if constexpr (sizeof(T) == 4) {
+    static const bool no_reg = getenv("PEPSGPU_NO_REGJACOBI") != nullptr;
+    if (!use_lds && m <= 256 && len <= 256 && !no_reg) {
+      hipLaunchKernelGGL(jacobi_rows_reg256_kernel, dim3(nw_), dim3(512), 0, stream_, (float *)M, wM, m, len, len, 40,
+                         sweeps_);
+      PG_CHECK_HIP(hipGetLastError());
+      return;
+    }
+  }
+  hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), use_lds ? need : 0, stream_, M, wM, m, len, len, 40,
+                     use_lds, sweeps_);
+  PG_CHECK_HIP(hipGetLastError());
 }
 
 // BMPS::MultiplyMPO with SVD compression (bmps_impl.h:404-437, :756-862, :225-263), Q-less form.
@@ -188,22 +207,24 @@ void Engine<T>::absorb(int pos, int num) {
       if (use_lds) allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), need);
       {   // reference op: gesdd of the (m x uk) block: 4 r c^2 + 22 c^3, r >= c
         const double rr = std::max(m, uk), cc = std::min(m, uk);
-        prof_begin(PROF_JACOBI, nw_ * (4.0 * rr * cc * cc + 22.0 * cc * cc * cc), 0.0);
+        // category 3 = register kernel (bulk blocks), 7 = generic LDS/global kernel (edge blocks)
+        const bool bulk = sizeof(T) == 4 && !use_lds && m <= 256 && uk <= 256;
+        prof_begin(bulk ? PROF_JACOBI : 7, nw_ * (4.0 * rr * cc * cc + 22.0 * cc * cc * cc), 0.0);
       }
-      hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), use_lds ? need : 0, stream_, M.p, M.n, m, uk,
-                         uk, 40, use_lds, sweeps_);
-      PG_CHECK_HIP(hipGetLastError());
+      launch_jacobi(M.p, M.n, m, uk, use_lds, need);
       prof_end();
       ++n_jacobi_;
       if (dbg_sweeps_) {   // diagnostics only: per-launch sweep counts (forces a sync)
         std::vector<int> hs(nw_);
         PG_CHECK_HIP(hipMemcpyAsync(hs.data(), sweeps_, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
         PG_CHECK_HIP(hipStreamSynchronize(stream_));
-        long mx = 0;
-        for (int v : hs) mx = std::max<long>(mx, v);
+        long mx = 0, live = 0, sw_sum = 0;
+        for (int v : hs) { mx = std::max<long>(mx, v & 0xFF); sw_sum += v & 0xFF; live += v >> 8; }
         jacobi_sweeps_sum_ += mx;
         jacobi_sweeps_max_ = std::max(jacobi_sweeps_max_, mx);
-        if (getenv("PEPSGPU_DEBUG_VERBOSE")) fprintf(stderr, "[pepsgpu] jacobi m=%d len=%d sweeps(max)=%ld\n", m, uk, mx);
+        if (getenv("PEPSGPU_DEBUG_VERBOSE"))
+          fprintf(stderr, "[pepsgpu] jacobi m=%d len=%d sweeps max=%ld mean=%.2f live_rows_mean=%.1f\n", m, uk, mx,
+                  (double)sw_sum / nw_, (double)live / nw_);
       }
     }
     const int k = std::min(chi_, std::min(m, uk));

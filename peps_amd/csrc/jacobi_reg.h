@@ -1,0 +1,300 @@
+// Register-resident one-sided Jacobi for the bulk chi-truncation blocks (up to 256 x 256, f32).
+//
+// The 256 KiB working matrix of the C4 workload (12x12, D=8, chi=32: M_i = R_i T_i is 256 x 256)
+// fits neither the 160 KiB LDS nor one wave, but it fits the register file of one CU: 8 waves x
+// 32 rows x 256 columns = 128 VGPRs per lane (2 waves per SIMD, 256-VGPR budget, no spills).
+// Rows are grouped in 16 blocks of 16; wave j holds the pair (top[j], bottom[j]) of a round-robin
+// tournament over blocks.  One "super-round" = every wave orthogonalises the 256 row pairs
+// between its two blocks entirely in registers (dot products by DPP / permlane-swap all-reduce),
+// then the blocks move one step round the circle through LDS (9 x 16 KiB slots).  15 super-rounds
+// = one sweep over all row pairs (and one full turn of the circle, so every block is back in its
+// own place); the pairs inside a block are done once per sweep.  Each row crosses LDS once per 16
+// rotations, so the LDS write bandwidth -- the limit of an LDS-resident Jacobi, which rewrites
+// 2 KiB per rotation -- is off the critical path.
+//
+// Same mathematics as jacobi_rows_kernel (linalg.h): threshold 2*sqrt(len)*eps, noise floor
+// NOISE_C*eps*|M|_F, no row swapping (select_rows_kernel sorts by norm afterwards).
+#pragma once
+#include "linalg.h"
+
+namespace pepsgpu {
+
+typedef float jr_f2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ float jr_dpp_add(float v) {
+  const int iv = __builtin_bit_cast(int, v);
+  const int r = __builtin_amdgcn_update_dpp(iv, iv, CTRL, 0xF, 0xF, false);
+  return v + __builtin_bit_cast(float, r);
+}
+
+// sum over the 64 lanes, result in every lane: 4 DPP adds inside a row of 16, then the two
+// gfx950 half-swaps across rows
+__device__ __forceinline__ float jr_allsum(float v) {
+  v = jr_dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = jr_dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = jr_dpp_add<0x141>(v);   // row_half_mirror
+  v = jr_dpp_add<0x140>(v);   // row_mirror
+  {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto p = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (unsigned)p[0]) + __builtin_bit_cast(float, (unsigned)p[1]);
+  }
+  {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto p = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (unsigned)p[0]) + __builtin_bit_cast(float, (unsigned)p[1]);
+  }
+  return v;
+}
+
+struct JrRow { jr_f2 lo, hi; };   // columns 4*lane .. 4*lane+3
+
+__device__ __forceinline__ float jr_dot(const JrRow &x, const JrRow &y) {
+  const jr_f2 p = x.lo * y.lo + x.hi * y.hi;
+  return p.x + p.y;
+}
+
+// Branch-free Hestenes rotation.  Parameters in f32 with hardware rcp/sqrt/rsq: an error in
+// (c, s) only scales BOTH rows by sqrt(c^2+s^2) (they stay orthogonal) and rows are normalised at
+// the end.  A pair below threshold gets t = 0, i.e. the identity.
+__device__ __forceinline__ int jr_apply(JrRow &x, JrRow &y, float &nx, float &ny, const float g, const float tol2,
+                                        const float floor2) {
+  const bool go = g * g > tol2 * nx * ny && nx > floor2 && ny > floor2;
+  const float zeta = (ny - nx) * __builtin_amdgcn_rcpf(2.f * g);
+  const float az = fabsf(zeta);
+  float t = copysignf(__builtin_amdgcn_rcpf(az + __builtin_amdgcn_sqrtf(fmaf(az, az, 1.f))), zeta);
+  t = go ? t : 0.f;
+  const float cs = __builtin_amdgcn_rsqf(fmaf(t, t, 1.f)), sn = cs * t;
+  const jr_f2 c2 = {cs, cs}, s2 = {sn, sn};
+  const jr_f2 xl = x.lo, xh = x.hi, yl = y.lo, yh = y.hi;
+  x.lo = c2 * xl - s2 * yl;
+  x.hi = c2 * xh - s2 * yh;
+  y.lo = s2 * xl + c2 * yl;
+  y.hi = s2 * xh + c2 * yh;
+  const float tg = t * g;
+  nx = fmaxf(nx - tg, 0.f);
+  ny = ny + tg;
+  return go ? 1 : 0;
+}
+
+constexpr int JR_BR = 16;        // rows per block
+constexpr int JR_NW = 8;         // waves
+constexpr int JR_SLOTS = JR_NW + 1;
+
+__global__ __launch_bounds__(512) void jacobi_rows_reg256_kernel(float *__restrict__ Mg, long wM, int m, int len, int ld,
+                                                                 int max_sweeps, int *__restrict__ sweeps_out) {
+  __shared__ float4 xch[JR_SLOTS][JR_BR][64];   // 9 x 16 KiB
+  __shared__ float xnorm[JR_SLOTS][JR_BR];
+  __shared__ float s_n2[256];
+  __shared__ short s_perm[256];
+  __shared__ double s_fro[JR_NW];
+  __shared__ int s_rot, s_live0;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  float *M = Mg + (long)blockIdx.x * wM;
+
+  // ---- prepass: row norms, noise floor, rows ranked by decreasing norm ----
+  // Row order is free (select_rows_kernel sorts afterwards), so the rows are taken in rank
+  // order: the live rows (norm above the floor) fill the first blocks and the tournament runs
+  // over those blocks only -- cost ~ (numerical rank)^2 instead of m^2.
+  if (tid == 0) s_live0 = 0;
+  for (int r = w; r < 256; r += JR_NW) {
+    float n2 = 0.f;
+    if (r < m) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 4 * lane + q;
+        const float v = c < len ? M[(long)r * ld + c] : 0.f;
+        n2 = fmaf(v, v, n2);
+      }
+    }
+    n2 = jr_allsum(n2);
+    if (lane == 0) s_n2[r] = n2;
+  }
+  __syncthreads();
+  {
+    double f = 0.0;
+    for (int r = tid; r < 256; r += 512) f += (double)s_n2[r];
+    f = wave_sum(f);
+    if (lane == 0) s_fro[w] = f;
+    __syncthreads();
+    if (tid == 0) { double t = 0.0; for (int k = 0; k < JR_NW; ++k) t += s_fro[k]; s_fro[0] = t; }
+    __syncthreads();
+  }
+  const float floor2 = (float)(NOISE_C * NOISE_C * (double)Eps<float>::v * (double)Eps<float>::v * s_fro[0]);
+  const float tol2 = 4.f * (float)len * Eps<float>::v * Eps<float>::v;   // (2 sqrt(len) eps)^2
+  if (tid < 256) {
+    const float v = s_n2[tid];
+    int rk = 0;
+    for (int q = 0; q < 256; ++q) {
+      const float u = s_n2[q];
+      rk += (u > v) || (u == v && q < tid);
+    }
+    s_perm[rk] = (short)tid;
+    if (v > floor2) atomicAdd(&s_live0, 1);
+  }
+  __syncthreads();
+  const int live0 = s_live0;
+  const int nbl = (live0 + JR_BR - 1) / JR_BR;            // live blocks
+  const int nwv = nbl <= 2 ? 1 : (nbl + 1) / 2;           // waves taking part in the tournament
+  const bool active = w < nwv;
+
+  JrRow a[JR_BR], b[JR_BR];
+  float na[JR_BR], nb[JR_BR];
+  auto load_block = [&](JrRow(&blk)[JR_BR], int bid) {
+#pragma unroll
+    for (int i = 0; i < JR_BR; ++i) {
+      const int pos = bid * JR_BR + i;
+      const int r = (active && pos < nbl * JR_BR) ? (int)s_perm[pos] : m;
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 4 * lane + q;
+        v[q] = (r < m && c < len) ? M[(long)r * ld + c] : 0.f;
+      }
+      blk[i].lo = jr_f2{v[0], v[1]};
+      blk[i].hi = jr_f2{v[2], v[3]};
+    }
+  };
+  load_block(a, w);
+  load_block(b, nwv + w);
+
+  int sweep = 0;
+  for (; sweep < max_sweeps; ++sweep) {
+    if (tid == 0) s_rot = 0;
+    // exact norms at sweep start
+#pragma unroll
+    for (int i = 0; i < JR_BR; ++i) {
+      na[i] = jr_allsum(jr_dot(a[i], a[i]));
+      nb[i] = jr_allsum(jr_dot(b[i], b[i]));
+    }
+    int rot = 0;
+    // pairs inside each block, once per sweep: circle method on the 16 rows of a block.  The
+    // rows are physically rotated in registers so that the pairing is always (i, 15-i) with
+    // static indices inside a ROLLED loop (a fully unrolled tournament makes the scheduler
+    // hoist across rounds and spill).
+#pragma unroll 1
+    for (int r = 0; r < (active ? JR_BR - 1 : 0); ++r) {
+      float ga[JR_BR / 2], gb[JR_BR / 2];
+#pragma unroll
+      for (int p = 0; p < JR_BR / 2; ++p) {
+        ga[p] = jr_allsum(jr_dot(a[p], a[JR_BR - 1 - p]));
+        gb[p] = jr_allsum(jr_dot(b[p], b[JR_BR - 1 - p]));
+      }
+#pragma unroll
+      for (int p = 0; p < JR_BR / 2; ++p) {
+        rot += jr_apply(a[p], a[JR_BR - 1 - p], na[p], na[JR_BR - 1 - p], ga[p], tol2, floor2);
+        rot += jr_apply(b[p], b[JR_BR - 1 - p], nb[p], nb[JR_BR - 1 - p], gb[p], tol2, floor2);
+      }
+      {   // rows 1..15 move one place round the circle (row 0 fixed); 15 rounds = identity
+        const JrRow ta = a[JR_BR - 1], tb = b[JR_BR - 1];
+        const float fa = na[JR_BR - 1], fb = nb[JR_BR - 1];
+#pragma unroll
+        for (int i = JR_BR - 1; i >= 2; --i) { a[i] = a[i - 1]; b[i] = b[i - 1]; na[i] = na[i - 1]; nb[i] = nb[i - 1]; }
+        a[1] = ta; b[1] = tb; na[1] = fa; nb[1] = fb;
+      }
+    }
+    __syncthreads();   // s_rot reset visible; LDS slots free
+    for (int sr = 0; sr < 2 * nwv - 1; ++sr) {
+      // A block whose rows are all below the noise floor takes part in no rotation (jr_apply
+      // would return the identity for every one of its pairs): skip its 256 pairs outright.
+      float mxa = na[0], mxb = nb[0];
+#pragma unroll
+      for (int i = 1; i < JR_BR; ++i) { mxa = fmaxf(mxa, na[i]); mxb = fmaxf(mxb, nb[i]); }
+      const bool live = active && mxa > floor2 && mxb > floor2;
+#pragma unroll 1
+      for (int t = 0; t < (live ? JR_BR : 0); ++t) {
+        // the 16 pairs (a[i], b[i]) of a round are disjoint: dots + reductions first, then rotations
+        float g[JR_BR];
+#pragma unroll
+        for (int i = 0; i < JR_BR; ++i) g[i] = jr_allsum(jr_dot(a[i], b[i]));
+#pragma unroll
+        for (int i = 0; i < JR_BR; ++i) rot += jr_apply(a[i], b[i], na[i], nb[i], g[i], tol2, floor2);
+        {   // b rows shift by one place (cyclic); 16 rounds = identity
+          const JrRow tb = b[0];
+          const float fb = nb[0];
+#pragma unroll
+          for (int i = 0; i < JR_BR - 1; ++i) { b[i] = b[i + 1]; nb[i] = nb[i + 1]; }
+          b[JR_BR - 1] = tb; nb[JR_BR - 1] = fb;
+        }
+      }
+      if (nwv == 1) continue;   // two blocks only: nothing moves
+      // ---- move the blocks one step round the circle (top[0] fixed) ----
+      // phase 1: bottom[j] <- bottom[j+1], bottom[last] <- top[last]; old bottom[0] stays in slot 0
+      if (active) {
+#pragma unroll
+        for (int i = 0; i < JR_BR; ++i) xch[w][i][lane] = make_float4(b[i].lo.x, b[i].lo.y, b[i].hi.x, b[i].hi.y);
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < JR_BR; ++i) xnorm[w][i] = nb[i];
+        }
+        if (w == nwv - 1) {
+#pragma unroll
+          for (int i = 0; i < JR_BR; ++i) xch[nwv][i][lane] = make_float4(a[i].lo.x, a[i].lo.y, a[i].hi.x, a[i].hi.y);
+          if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < JR_BR; ++i) xnorm[nwv][i] = na[i];
+          }
+        }
+      }
+      __syncthreads();
+      if (active) {
+        const int src = (w == nwv - 1) ? nwv : w + 1;
+#pragma unroll
+        for (int i = 0; i < JR_BR; ++i) {
+          const float4 t4 = xch[src][i][lane];
+          b[i].lo = jr_f2{t4.x, t4.y};
+          b[i].hi = jr_f2{t4.z, t4.w};
+          nb[i] = xnorm[src][i];
+        }
+      }
+      __syncthreads();
+      // phase 2: top[j] <- top[j-1] (j >= 2), top[1] <- old bottom[0] (still in slot 0)
+      if (active && w >= 1 && w <= nwv - 2) {
+#pragma unroll
+        for (int i = 0; i < JR_BR; ++i) xch[w][i][lane] = make_float4(a[i].lo.x, a[i].lo.y, a[i].hi.x, a[i].hi.y);
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < JR_BR; ++i) xnorm[w][i] = na[i];
+        }
+      }
+      __syncthreads();
+      if (active && w >= 1) {
+        const int src = w - 1;   // w == 1 reads slot 0 = old bottom[0]
+#pragma unroll
+        for (int i = 0; i < JR_BR; ++i) {
+          const float4 t4 = xch[src][i][lane];
+          a[i].lo = jr_f2{t4.x, t4.y};
+          a[i].hi = jr_f2{t4.z, t4.w};
+          na[i] = xnorm[src][i];
+        }
+      }
+      __syncthreads();
+    }
+    if (lane == 0 && rot) atomicAdd(&s_rot, rot);
+    __syncthreads();
+    const int total = s_rot;
+    __syncthreads();
+    if (total == 0) { ++sweep; break; }
+  }
+  // 2*nwv-1 exchanges = one full turn of the circle: at the end of every sweep each block is back
+  // in its initial (wave, slot), so every row returns to the address it was loaded from
+  auto store_block = [&](JrRow(&blk)[JR_BR], int bid) {
+#pragma unroll
+    for (int i = 0; i < JR_BR; ++i) {
+      const int pos = bid * JR_BR + i;
+      const int r = (active && pos < nbl * JR_BR) ? (int)s_perm[pos] : m;
+      const float v[4] = {blk[i].lo.x, blk[i].lo.y, blk[i].hi.x, blk[i].hi.y};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 4 * lane + q;
+        if (r < m && c < len) M[(long)r * ld + c] = v[q];
+      }
+    }
+  };
+  store_block(a, w);
+  store_block(b, nwv + w);
+  if (tid == 0 && sweeps_out) sweeps_out[blockIdx.x] = sweep | (live0 << 8);
+}
+
+}  // namespace pepsgpu

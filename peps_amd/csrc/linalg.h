@@ -153,17 +153,46 @@ __global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, l
     __syncthreads();
   }
   const T floor2 = T(NOISE_C * NOISE_C * (double)Eps<T>::v * (double)Eps<T>::v * s_fro[0]);
+  // The tournament runs over the LIVE rows only (norm above the noise floor), re-listed at the
+  // start of every sweep: a row below the floor takes part in no rotation anyway, and with a
+  // fast-decaying boundary spectrum most rows of M are dead (cost ~ rank^2, not m^2).
+  __shared__ short s_idx[1024];
+  __shared__ unsigned char s_flag[1024];
+  __shared__ int s_nl;
+  (void)mp;
   int sweep = 0;
   for (; sweep < max_sweeps; ++sweep) {
     if (tid == 0) s_rot = 0;
+    for (int r = wave; r < m; r += nw) {
+      const T *pr = M + (long)r * lds_ld;
+      T n2 = 0;
+      for (int c = lane; c < len; c += 64) { T x = pr[c]; n2 += x * x; }
+      n2 = wave_sum(n2);
+      if (lane == 0) s_flag[r] = n2 > floor2;
+    }
     __syncthreads();
-    for (int r = 0; r < mp - 1; ++r) {
-      for (int p = wave; p < mp / 2; p += nw) {
+    if (wave == 0) {   // deterministic compaction of the live row list
+      int cnt = 0;
+      for (int base = 0; base < m; base += 64) {
+        const int r = base + lane;
+        const bool f = r < m && s_flag[r];
+        const unsigned long long mask = __ballot(f);
+        if (f) s_idx[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (short)r;
+        cnt += __popcll(mask);
+      }
+      if (lane == 0) s_nl = cnt;
+    }
+    __syncthreads();
+    const int nl = s_nl;
+    const int lp = nl + (nl & 1);
+    for (int r = 0; r < lp - 1; ++r) {
+      for (int p = wave; p < lp / 2; p += nw) {
         int a, b;
-        if (p == 0) { a = mp - 1; b = r; }
-        else { a = (r + p) % (mp - 1); b = (r - p + (mp - 1)) % (mp - 1); }
+        if (p == 0) { a = lp - 1; b = r; }
+        else { a = (r + p) % (lp - 1); b = (r - p + (lp - 1)) % (lp - 1); }
         if (a > b) { int t = a; a = b; b = t; }
-        if (b >= m) continue;
+        if (b >= nl) continue;
+        a = s_idx[a]; b = s_idx[b];
         T *pa = M + (long)a * lds_ld, *pb = M + (long)b * lds_ld;
         T alpha = 0, beta = 0, gamma = 0;
         for (int c = lane; c < len; c += 64) {

@@ -144,3 +144,35 @@ def test_jacobi_rows(shape, dt, force_global):
             gap_tol = 50 * eps * sref[0] / (sref[k - 1] - sref[k])
             assert np.max(np.abs(Vb.T @ Vb - Pref.T @ Pref)) < max(gap_tol, 50 * eps)
         assert sw[b] < 40
+
+
+@pytest.mark.parametrize("shape", [(256, 256), (200, 256), (256, 130), (129, 255), (17, 40)])
+def test_jacobi_register_kernel_matches_generic(shape):
+    """Register-resident 256x256 f32 Jacobi (jacobi_reg.h) == generic kernel: same singular values,
+    orthonormal Vt, same dominant subspace; application-like input M = R T with R upper triangular."""
+    capi = _capi()
+    m, ln = shape
+    rng = np.random.default_rng(m + 7 * ln)
+    nb = 3
+    Ms = []
+    for b in range(nb):
+        R = np.triu(rng.standard_normal((m, m))) * np.logspace(0, -6, m)[:, None]
+        T = rng.standard_normal((m, ln))
+        Ms.append(R @ T)
+    M = np.stack(Ms)
+    k = min(32, m, ln)
+    Mo, Vt, S, sw = capi.diag_jacobi(capi.F32, M, k, 2)
+    Mg, Vtg, Sg, swg = capi.diag_jacobi(capi.F32, M, k, 1)
+    for b in range(nb):
+        sref = np.linalg.svd(M[b], compute_uv=False)
+        assert np.max(np.abs(S[b].astype(np.float64) - sref[:k])) < 3e-5 * sref[0]
+        Vb = Vt[b].astype(np.float64)
+        live = sref[:k] > 1e-5 * sref[0]          # rows under the noise floor come back as zero rows
+        G = Vb @ Vb.T
+        assert np.max(np.abs(G[np.ix_(live, live)] - np.eye(int(live.sum())))) < 1e-4
+        # rotated rows stay a rotation of the input: Gram of the rows' span is preserved
+        assert abs(np.linalg.norm(Mo[b]) / np.linalg.norm(M[b]) - 1) < 1e-5
+        assert sw[b] < 40 and swg[b] < 40
+        Pref = np.linalg.svd(M[b])[2][:k]
+        if live.all() and (sref[k] < 0.5 * sref[k - 1] if k < len(sref) else True):
+            assert np.max(np.abs(Vb.T @ Vb - Pref.T @ Pref)) < 2e-3
