@@ -69,7 +69,8 @@ def suwa_todo_state_update(init_state, weights, uniform01):
     start = s_im1 + np.longdouble(w[0])
     if start >= S:
         start -= S
-    x = start + np.longdouble(uniform01()) * np.longdouble(w[init_state])
+    hi = np.nextafter(start + np.longdouble(w[init_state]), start)
+    x = np.longdouble(uniform01()) * (hi - start) + start
     if x >= S:
         x -= S
     final = int(np.searchsorted(s, x, side="right"))
@@ -82,15 +83,42 @@ def suwa_todo_state_update(init_state, weights, uniform01):
     return final
 
 
+class StdMT19937:
+    """std::mt19937 + libstdc++ std::generate_canonical, restated so that the oracle draws the SAME
+    deviates as the C++ updaters (monte_carlo_sweep_updater_base.h:18-47 uses std::mt19937 and
+    std::uniform_real_distribution<double>(0,1); suwa_todo_update.h:96-101 draws a long double)."""
+
+    def __init__(self, seed):
+        self.bg = np.random.MT19937()
+        self.bg._legacy_seeding(int(seed))        # init_genrand(seed) == std::mt19937(seed)
+
+    def raw(self):
+        return int(self.bg.random_raw())
+
+    def u_double(self):
+        s = float(self.raw()) * 1.0
+        s = s + float(self.raw()) * 4294967296.0
+        r = s / 18446744073709551616.0
+        return r if r < 1.0 else float(np.nextafter(1.0, 0.0))
+
+    def u_longdouble(self):
+        s = np.longdouble(self.raw())
+        s = s + np.longdouble(self.raw()) * np.longdouble(4294967296.0)
+        r = s / (np.longdouble(4294967296.0) * np.longdouble(4294967296.0))
+        return r if r < 1 else np.nextafter(np.longdouble(1), np.longdouble(0))
+
+
 class MCUpdateSquareNNUpdateBaseOBC:
     """square_nn_updater.h:25-83: sweep schedule."""
 
     def __init__(self, seed=0):
-        self.rng = np.random.RandomState(seed)   # the reference uses std::mt19937 (same generator
-        # family; the variate transformation differs, so chains are compared on statistics only)
+        self.rng = StdMT19937(seed)
 
     def u_double(self):
-        return self.rng.random_sample()
+        return self.rng.u_double()
+
+    def u_longdouble(self):
+        return self.rng.u_longdouble()
 
     def __call__(self, sitps, comp):
         tn, c = comp.tn, comp.contractor
@@ -156,7 +184,7 @@ class MCUpdateSquareNNFullSpaceUpdateOBC(MCUpdateSquareNNUpdateBaseOBC):
                     alt[k] = comp.contractor.ReplaceNNSiteTrace(comp.tn, s1, s2, bond_dir,
                                                                 sitps[s1[0]][s1[1]][k1], sitps[s2[0]][s2[1]][k2])
         weights = [abs(a / comp.amplitude) ** 2 for a in alt]
-        final = suwa_todo_state_update(init, weights, self.u_double)
+        final = suwa_todo_state_update(init, weights, self.u_longdouble)
         if final == init:
             return False
         comp.UpdateLocal(sitps, alt[final], (s1, final // dim), (s2, final % dim))

@@ -1,0 +1,60 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on
+ROCm, "gloo" in CPU tests).  The hot path shards walkers / configurations with NO data-path
+collective; the only exchange is one all-reduce(sum) of the packed energy / gradient accumulators
+per evaluation, which replaces the reference's MPI calls:
+  MPIMeanTensor per (site, component)       monte_carlo_tools/statistics_tensor.h:37-79
+  MPI_Gather/Gatherv of energy bins         monte_carlo_tools/statistics.h:185-207
+  MPI_Send/Recv of S_O, S_EO + MPI_Reduce   exact_summation_energy_evaluator.h:252-280
+  MPI_Allreduce(MAX) of acceptance rates    mc_energy_grad_evaluator.h:405-410
+"""
+import os
+
+import numpy as np
+
+
+def init(backend=None):
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend, rank=int(os.environ.get("RANK", "0")), world_size=int(os.environ.get("WORLD_SIZE", "1")))
+    return dist
+
+
+def shard_indices(n, rank, size):
+    """Round-robin partition i = rank, rank + size, ... (exact_summation_energy_evaluator.h:201;
+    walkers: monte_carlo_engine.h:97-98)."""
+    return range(rank, n, size)
+
+
+def walker_seed(base, rank, walker, walkers_per_rank):
+    """Per-walker stream, distinct across ranks (pattern of tests/test_algorithm/test_boson_mc_sr_golden.cpp:85-87)."""
+    return (int(base) ^ (0x9E3779B97F4A7C15 * (rank * walkers_per_rank + walker + 1))) & 0xFFFFFFFF
+
+
+def _reduce(vec, op):
+    import torch
+    import torch.distributed as dist
+    v = np.ascontiguousarray(vec, dtype=np.float64)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return v.copy()
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.from_numpy(v.copy()).to(dev)
+    dist.all_reduce(t, op=op)
+    return t.cpu().numpy()
+
+
+def allreduce_sum(vec):
+    import torch.distributed as dist
+    return _reduce(vec, dist.ReduceOp.SUM)
+
+
+def allreduce_max(vec):
+    import torch.distributed as dist
+    return _reduce(vec, dist.ReduceOp.MAX)

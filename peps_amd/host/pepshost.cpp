@@ -1,0 +1,138 @@
+// C shim over the C++ host layer (qlpeps_gpu.h) so that the Python tests / bench drive exactly the
+// host code a reference user would compile (updaters, solvers, evaluators), not a re-implementation.
+#include <cstring>
+#include <memory>
+
+#include "qlpeps_gpu.h"
+
+using namespace qlpeps_gpu;
+
+namespace {
+thread_local std::string g_err;
+
+template <typename F>
+int guarded(F &&f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::invalid_argument &e) { g_err = e.what(); return PEPSGPU_EINVAL;
+  } catch (const std::out_of_range &e) { g_err = e.what(); return PEPSGPU_ERANGE;
+  } catch (const std::logic_error &e) { g_err = e.what(); return PEPSGPU_ESTATE;
+  } catch (const std::exception &e) { g_err = e.what(); return PEPSGPU_EEMPTY; }
+}
+
+SplitIndexTPS make_state(int rows, int cols, int D, int d, const double *flat) {
+  SplitIndexTPS s(rows, cols, d, D);
+  std::copy(flat, flat + s.flat().size(), s.flat().begin());
+  return s;
+}
+Configuration make_cfg(int n, int rows, int cols, const int32_t *cfg) {
+  Configuration c(n, rows, cols);
+  std::copy(cfg, cfg + (size_t)n * rows * cols, c.data());
+  return c;
+}
+}  // namespace
+
+extern "C" {
+
+const char *pepshost_last_error(void) { return g_err.c_str(); }
+
+// n_sweeps Monte-Carlo sweeps (square_nn_updater.h:30-81) of n walkers; updater 0 = NN exchange,
+// 1 = NN full-space (Suwa-Todo).  configs are updated in place; one std::mt19937(seed[w]) per walker.
+int pepshost_mc_sweeps(int rows, int cols, int D, int d, int chi, int dtype, const double *sitps_flat, int n,
+                       int32_t *configs, const uint64_t *seeds, int updater, int n_sweeps, double *amplitudes_out,
+                       double *accept_rates_out) {
+  return guarded([&]() {
+    SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
+    BMPSContractor contractor(rows, cols, D, d, BMPSTruncateParams::SVD(chi, chi, 0.0), n, dtype);
+    TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor);
+    std::vector<uint64_t> sd(seeds, seeds + n);
+    std::vector<double> rates, acc(n, 0.0);
+    if (updater == 0) {
+      MCUpdateSquareNNExchangeOBC upd(sd);
+      for (int s = 0; s < n_sweeps; ++s) { upd(sitps, comp, rates); for (int w = 0; w < n; ++w) acc[w] += rates[w]; }
+    } else {
+      MCUpdateSquareNNFullSpaceUpdateOBC upd(sd);
+      for (int s = 0; s < n_sweeps; ++s) { upd(sitps, comp, rates); for (int w = 0; w < n; ++w) acc[w] += rates[w]; }
+    }
+    std::copy(comp.config.data(), comp.config.data() + (size_t)n * rows * cols, configs);
+    std::copy(comp.amplitude.begin(), comp.amplitude.end(), amplitudes_out);
+    for (int w = 0; w < n; ++w) accept_rates_out[w] = n_sweeps ? acc[w] / n_sweeps : 0.0;
+  });
+}
+
+// CalEnergyAndHoles (model_energy_solver.h:32-126) for n configurations; model 0 = XXZ (p = jz, jxy,
+// pinning00), 1 = TFIM (p[0] = h).  holes_out (nullable) = [n][rows][cols][D^4]; psi_out = [n_psi][n].
+int pepshost_energy_and_holes(int rows, int cols, int D, int d, int chi, int dtype, const double *sitps_flat, int n,
+                              const int32_t *configs, int model, const double *p, double *amplitudes_out,
+                              double *energies_out, double *holes_out, double *psi_out, int *n_psi_out) {
+  return guarded([&]() {
+    SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
+    BMPSContractor contractor(rows, cols, D, d, BMPSTruncateParams::SVD(chi, chi, 0.0), n, dtype);
+    TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor);
+    EnergyAndHoles eh;
+    if (model == 0) {
+      SquareSpinOneHalfXXZModelOBC m(p[0], p[1], p[2]);
+      eh = holes_out ? m.CalEnergyAndHoles<true>(sitps, comp) : m.CalEnergyAndHoles<false>(sitps, comp);
+    } else {
+      TransverseFieldIsingSquareOBC m(p[0]);
+      eh = holes_out ? m.CalEnergyAndHoles<true>(sitps, comp) : m.CalEnergyAndHoles<false>(sitps, comp);
+    }
+    std::copy(comp.amplitude.begin(), comp.amplitude.end(), amplitudes_out);
+    std::copy(eh.energy.begin(), eh.energy.end(), energies_out);
+    if (holes_out) std::copy(eh.holes.begin(), eh.holes.end(), holes_out);
+    if (n_psi_out) *n_psi_out = (int)eh.psi_list.size();
+    if (psi_out)
+      for (size_t k = 0; k < eh.psi_list.size(); ++k) std::copy(eh.psi_list[k].begin(), eh.psi_list[k].end(), psi_out + k * n);
+  });
+}
+
+// Rank-local part of ExactSumEnergyEvaluatorMPI (exact_summation_energy_evaluator.h:173-245):
+// packed_out = [S_O | S_EO | sum w | sum wE | sum wE^2 | samples], length 2*rows*cols*d*D^4 + 4.
+int pepshost_exact_sum_partial(int rows, int cols, int D, int d, int chi, int dtype, const double *sitps_flat,
+                               const int32_t *all_configs, int n_configs, int model, const double *p, int rank, int size,
+                               int batch, double *packed_out) {
+  return guarded([&]() {
+    SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
+    BMPSContractor contractor(rows, cols, D, d, BMPSTruncateParams::SVD(chi, chi, 0.0), batch, dtype);
+    std::vector<std::vector<int32_t>> all(n_configs);
+    for (int i = 0; i < n_configs; ++i) all[i].assign(all_configs + (size_t)i * rows * cols, all_configs + (size_t)(i + 1) * rows * cols);
+    std::vector<double> packed;
+    auto capture = [&](std::vector<double> &v) { packed = v; };
+    if (model == 0) {
+      SquareSpinOneHalfXXZModelOBC m(p[0], p[1], p[2]);
+      ExactSumEnergyEvaluator(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
+    } else {
+      TransverseFieldIsingSquareOBC m(p[0]);
+      ExactSumEnergyEvaluator(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
+    }
+    std::copy(packed.begin(), packed.end(), packed_out);
+  });
+}
+
+// energy = sum wE / sum w, gradient = (S_EO - E S_O)/sum w   (:286-295) from the rank-summed accumulators
+int pepshost_exact_sum_finish(int rows, int cols, int D, int d, const double *packed, double *energy_out, double *grad_out) {
+  return guarded([&]() {
+    SplitIndexTPS like(rows, cols, d, D);
+    GradAccumulator acc(like);
+    std::vector<double> v(packed, packed + 2 * like.flat().size() + 4);
+    acc.Unpack(v);
+    auto res = acc.Finish();
+    *energy_out = res.first;
+    std::copy(res.second.flat().begin(), res.second.flat().end(), grad_out);
+  });
+}
+
+// SplitIndexTPS::Load round trip for the reference's dump format (dense fixtures)
+int pepshost_load_sitps(const char *dir, int D, int *rows, int *cols, int *d, double *flat_out, size_t flat_cap) {
+  return guarded([&]() {
+    SplitIndexTPS s = SplitIndexTPS::Load(dir, D);
+    *rows = (int)s.rows(); *cols = (int)s.cols(); *d = (int)s.PhysicalDim();
+    if (flat_out) {
+      if (flat_cap < s.flat().size()) throw std::invalid_argument("output buffer too small");
+      std::copy(s.flat().begin(), s.flat().end(), flat_out);
+    }
+  });
+}
+
+}  // extern "C"

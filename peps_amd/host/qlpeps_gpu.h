@@ -1,0 +1,658 @@
+// qlpeps_gpu.h -- C++ host layer above the pepsgpu C ABI, mirroring the reference's operator /
+// plugin surface for the boundary-MPS hot path (same names, argument meaning, error behaviour),
+// batched over the walkers of one GPU.  Header-only, like the reference.
+//
+//   reference (one walker per MPI rank)                       here (n walkers per context)
+//   BMPSTruncateParams           bmps.h:47-98                 qlpeps_gpu::BMPSTruncateParams
+//   Configuration                configuration.h:57           qlpeps_gpu::Configuration
+//   SplitIndexTPS                split_index_tps.h:80-606     qlpeps_gpu::SplitIndexTPS (dense, real)
+//   BMPSContractor               bmps_contractor.h:187-1027   qlpeps_gpu::BMPSContractor
+//   TPSWaveFunctionComponent     wave_function_component.h:136-379   qlpeps_gpu::TPSWaveFunctionComponent
+//   MCUpdateSquareNN*OBC         square_nn_updater.h:25-293   qlpeps_gpu::MCUpdateSquareNN*OBC (CRTP)
+//   SuwaTodoStateUpdate          suwa_todo_update.h:53-112    qlpeps_gpu::SuwaTodoStateUpdate
+//   SquareNNModelEnergySolver    square_nnn_energy_solver.h   qlpeps_gpu::SquareNNModelEnergySolver (CRTP)
+//   SquareSpinOneHalfXXZModelOBC square_spin_onehalf_xxz_obc.h:64-190
+//   TransverseFieldIsingSquareOBC transverse_field_ising_square_obc.h:28-247
+//   ExactSumEnergyEvaluatorMPI   exact_summation_energy_evaluator.h:173-302
+//   MCEnergyGradEvaluator accumulation  mc_energy_grad_evaluator.h:245-310
+//
+// Error codes of the ABI are re-raised as the reference's exception types.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <fstream>
+#include <functional>
+#include <numeric>
+#include <random>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/pepsgpu.h"
+
+namespace qlpeps_gpu {
+
+enum BondOrientation { HORIZONTAL = 0, VERTICAL = 1 };      // basic.h:19-22
+enum BMPSPOSITION { LEFT = 0, DOWN = 1, RIGHT = 2, UP = 3 };  // basic.h:58-63
+using BTenPOSITION = BMPSPOSITION;
+enum class CompressMPSScheme { SVD_COMPRESS = 0 };           // bmps.h:31-35 (variational: not implemented)
+
+struct SiteIdx {                                             // framework/site_idx.h:20-26
+  size_t r = 0, c = 0;
+  size_t row() const { return r; }
+  size_t col() const { return c; }
+};
+
+struct BMPSTruncateParams {                                  // bmps.h:47-98
+  size_t D_min = 1, D_max = 1;
+  double trunc_err = 0.0;
+  CompressMPSScheme compress_scheme = CompressMPSScheme::SVD_COMPRESS;
+  static BMPSTruncateParams SVD(size_t d_min, size_t d_max, double trunc_error) {
+    BMPSTruncateParams p;
+    p.D_min = d_min; p.D_max = d_max; p.trunc_err = trunc_error;
+    return p;
+  }
+};
+
+inline void check_rc(int rc, pepsgpu_ctx *ctx) {
+  if (rc == PEPSGPU_OK) return;
+  std::string msg = pepsgpu_last_error(ctx);
+  switch (rc) {
+    case PEPSGPU_EINVAL: throw std::invalid_argument(msg);
+    case PEPSGPU_ESTATE: throw std::logic_error(msg);
+    case PEPSGPU_ERANGE: throw std::out_of_range(msg);
+    default: throw std::runtime_error(msg);
+  }
+}
+
+// Walker batch of configurations (configuration.h:57): config(w, site)
+class Configuration {
+ public:
+  Configuration() = default;
+  Configuration(size_t n, size_t rows, size_t cols) : n_(n), rows_(rows), cols_(cols), v_(n * rows * cols, 0) {}
+  size_t walkers() const { return n_; }
+  size_t rows() const { return rows_; }
+  size_t cols() const { return cols_; }
+  int32_t &operator()(size_t w, const SiteIdx &s) { return v_[(w * rows_ + s.r) * cols_ + s.c]; }
+  int32_t operator()(size_t w, const SiteIdx &s) const { return v_[(w * rows_ + s.r) * cols_ + s.c]; }
+  const int32_t *data() const { return v_.data(); }
+  int32_t *data() { return v_.data(); }
+
+ private:
+  size_t n_ = 0, rows_ = 0, cols_ = 0;
+  std::vector<int32_t> v_;
+};
+
+// Dense real SplitIndexTPS in the ABI upload layout [row][col][s][L][D][R][U], legs zero padded to D.
+class SplitIndexTPS {
+ public:
+  SplitIndexTPS() = default;
+  SplitIndexTPS(size_t rows, size_t cols, size_t phys_dim, size_t D)
+      : rows_(rows), cols_(cols), d_(phys_dim), D_(D), v_(rows * cols * phys_dim * D * D * D * D, 0.0) {}
+  size_t rows() const { return rows_; }
+  size_t cols() const { return cols_; }
+  size_t PhysicalDim() const { return d_; }
+  size_t D() const { return D_; }
+  size_t slot() const { return D_ * D_ * D_ * D_; }
+  size_t size() const { return rows_ * cols_; }
+  double *component(size_t r, size_t c, size_t s) { return v_.data() + ((r * cols_ + c) * d_ + s) * slot(); }
+  const double *component(size_t r, size_t c, size_t s) const { return v_.data() + ((r * cols_ + c) * d_ + s) * slot(); }
+  std::vector<double> &flat() { return v_; }
+  const std::vector<double> &flat() const { return v_; }
+  double NormSquare() const { return std::inner_product(v_.begin(), v_.end(), v_.begin(), 0.0); }
+
+  // SplitIndexTPS::Load (split_index_tps_impl.h:340-437): tps_meta.txt + tps_ten{r}_{c}_{s}.qlten,
+  // dense TrivialRepQN float64 payloads only (format: SURVEY.md section 8c).
+  static SplitIndexTPS Load(const std::string &dir, size_t D) {
+    std::ifstream meta(dir + "/tps_meta.txt");
+    if (!meta) throw std::runtime_error("SplitIndexTPS::Load: cannot open " + dir + "/tps_meta.txt");
+    size_t rows, cols, d;
+    meta >> rows >> cols >> d;
+    SplitIndexTPS t(rows, cols, d, D);
+    for (size_t r = 0; r < rows; ++r)
+      for (size_t c = 0; c < cols; ++c)
+        for (size_t s = 0; s < d; ++s) {
+          std::string path = dir + "/tps_ten" + std::to_string(r) + "_" + std::to_string(c) + "_" + std::to_string(s) + ".qlten";
+          std::ifstream f(path, std::ios::binary);
+          if (!f) throw std::runtime_error("SplitIndexTPS::Load: cannot open " + path);
+          std::string line;
+          auto next = [&]() { std::getline(f, line); return std::stoll(line); };
+          long rank = next();
+          if (rank != 4) throw std::runtime_error("SplitIndexTPS::Load: rank-4 dense tensors only");
+          size_t dims[4];
+          for (int k = 0; k < 4; ++k) {
+            long nsec = next();
+            if (nsec != 1) throw std::runtime_error("SplitIndexTPS::Load: block-sparse tensors are not supported");
+            next(); next();          // degeneracy, sector hash
+            next();                  // direction
+            dims[k] = (size_t)next();
+            std::getline(f, line);   // index hash (u64, may exceed long)
+          }
+          long nblocks = next();
+          if (nblocks != 1) throw std::runtime_error("SplitIndexTPS::Load: expected one dense block");
+          for (int k = 0; k < 4; ++k) next();
+          std::vector<double> buf(dims[0] * dims[1] * dims[2] * dims[3]);
+          f.read(reinterpret_cast<char *>(buf.data()), buf.size() * sizeof(double));
+          if (!f) throw std::runtime_error("SplitIndexTPS::Load: truncated payload in " + path);
+          double *dst = t.component(r, c, s);
+          size_t o = 0;
+          for (size_t a = 0; a < dims[0]; ++a)
+            for (size_t b = 0; b < dims[1]; ++b)
+              for (size_t cc = 0; cc < dims[2]; ++cc)
+                for (size_t e = 0; e < dims[3]; ++e) dst[((a * D + b) * D + cc) * D + e] = buf[o++];
+        }
+    return t;
+  }
+
+ private:
+  size_t rows_ = 0, cols_ = 0, d_ = 0, D_ = 0;
+  std::vector<double> v_;
+};
+
+// BMPSContractor (bmps_contractor.h:187-1027): same method names; `tn` arguments disappear because
+// the projected network is (sitps, configs) held by the context.  Scalars come back per walker.
+class BMPSContractor {
+ public:
+  BMPSContractor(size_t rows, size_t cols, size_t D, size_t phys_dim, const BMPSTruncateParams &p, size_t max_walkers,
+                 int dtype = PEPSGPU_F64, int device = 0)
+      : rows_(rows), cols_(cols), D_(D), d_(phys_dim), trunc_(p) {
+    int rc = pepsgpu_ctx_create(&ctx_, device, dtype, (int)rows, (int)cols, (int)D, (int)phys_dim, (int)p.D_min,
+                                (int)p.D_max, p.trunc_err, (int)p.compress_scheme, (int)max_walkers);
+    if (rc != PEPSGPU_OK) { ctx_ = nullptr; check_rc(rc, nullptr); }
+  }
+  ~BMPSContractor() { if (ctx_) pepsgpu_ctx_destroy(ctx_); }
+  BMPSContractor(const BMPSContractor &) = delete;
+  BMPSContractor &operator=(const BMPSContractor &) = delete;
+
+  pepsgpu_ctx *ctx() const { return ctx_; }
+  size_t rows() const { return rows_; }
+  size_t cols() const { return cols_; }
+  size_t walkers() const { return (size_t)pepsgpu_n_walkers(ctx_); }
+  const BMPSTruncateParams &GetTruncateParams() const { return trunc_; }
+
+  void UploadState(const SplitIndexTPS &s) { check_rc(pepsgpu_state_upload(ctx_, s.flat().data(), PEPSGPU_F64), ctx_); }
+  void Init(const Configuration &cfg) { check_rc(pepsgpu_walkers_set_configs(ctx_, (int)cfg.walkers(), cfg.data()), ctx_); }
+
+  void GrowBMPSStep(BMPSPOSITION p) { check_rc(pepsgpu_grow_bmps_step(ctx_, p), ctx_); }
+  void GrowFullBMPS(BMPSPOSITION p) { check_rc(pepsgpu_grow_full_bmps(ctx_, p), ctx_); }
+  void GrowBMPSForRow(size_t row) { check_rc(pepsgpu_grow_bmps_for_row(ctx_, (int)row), ctx_); }
+  void GrowBMPSForCol(size_t col) { check_rc(pepsgpu_grow_bmps_for_col(ctx_, (int)col), ctx_); }
+  void ShiftBMPSWindow(BMPSPOSITION p) { check_rc(pepsgpu_shift_bmps_window(ctx_, p), ctx_); }
+  void DeleteInnerBMPS(BMPSPOSITION p) { check_rc(pepsgpu_delete_inner_bmps(ctx_, p), ctx_); }
+  void GenerateBMPSApproach(BMPSPOSITION p) { check_rc(pepsgpu_generate_bmps_approach(ctx_, p), ctx_); }
+  void InitBTen(BTenPOSITION p, size_t slice) { check_rc(pepsgpu_init_bten(ctx_, p, (int)slice), ctx_); }
+  void GrowFullBTen(BTenPOSITION p, size_t slice, size_t remain_sites = 2, bool init = true) {
+    check_rc(pepsgpu_grow_full_bten(ctx_, p, (int)slice, (int)remain_sites, init), ctx_);
+  }
+  void GrowBTenStep(BTenPOSITION p) { check_rc(pepsgpu_grow_bten_step(ctx_, p), ctx_); }
+  void ShiftBTenWindow(BTenPOSITION p) { check_rc(pepsgpu_shift_bten_window(ctx_, p), ctx_); }
+  void TruncateBTen(BTenPOSITION p, size_t len) { check_rc(pepsgpu_truncate_bten(ctx_, p, (int)len), ctx_); }
+  void EraseEnvsAfterUpdate(const SiteIdx &s) { check_rc(pepsgpu_erase_envs_after_update(ctx_, (int)s.r, (int)s.c), ctx_); }
+
+  std::vector<double> Trace(const SiteIdx &a, BondOrientation dir) const {
+    std::vector<double> out(walkers());
+    check_rc(pepsgpu_trace(ctx_, (int)a.r, (int)a.c, dir, out.data()), ctx_);
+    return out;
+  }
+  // ReplaceNNSiteTrace for n_cand candidate (state_a, state_b) pairs per walker: cand[w][k][2]
+  std::vector<double> ReplaceNNSiteTrace(const SiteIdx &a, BondOrientation dir, int n_cand, const std::vector<int32_t> &cand) const {
+    std::vector<double> out(walkers() * n_cand);
+    check_rc(pepsgpu_replace_nn_trace(ctx_, (int)a.r, (int)a.c, dir, n_cand, cand.data(), out.data()), ctx_);
+    return out;
+  }
+  std::vector<double> ReplaceOneSiteTrace(const SiteIdx &s, BondOrientation orient, int n_cand, const std::vector<int32_t> &cand) const {
+    std::vector<double> out(walkers() * n_cand);
+    check_rc(pepsgpu_replace_one_trace(ctx_, (int)s.r, (int)s.c, orient, n_cand, cand.data(), out.data()), ctx_);
+    return out;
+  }
+  // PunchHole: [walker][D^4] (legs L,D,R,U zero padded)
+  std::vector<double> PunchHole(const SiteIdx &s, BondOrientation orient) const {
+    std::vector<double> out(walkers() * D_ * D_ * D_ * D_);
+    check_rc(pepsgpu_punch_hole(ctx_, (int)s.r, (int)s.c, orient, out.data()), ctx_);
+    return out;
+  }
+  void UpdateLocal(const std::vector<int32_t> &sites, const std::vector<int32_t> &new_states, const std::vector<uint8_t> &mask) {
+    check_rc(pepsgpu_update_local(ctx_, (int)(sites.size() / 2), sites.data(), new_states.data(), mask.data()), ctx_);
+  }
+  std::vector<double> EvaluateAmplitude() {
+    std::vector<double> out(walkers());
+    check_rc(pepsgpu_evaluate_amplitude(ctx_, out.data()), ctx_);
+    return out;
+  }
+  std::vector<int32_t> WalkerFlags() const {
+    std::vector<int32_t> f(walkers());
+    check_rc(pepsgpu_walker_flags(ctx_, f.data()), ctx_);
+    return f;
+  }
+
+ private:
+  size_t rows_, cols_, D_, d_;
+  BMPSTruncateParams trunc_;
+  pepsgpu_ctx *ctx_ = nullptr;
+};
+
+// TPSWaveFunctionComponent (wave_function_component.h:136-379), one entry per walker.
+struct TPSWaveFunctionComponent {
+  Configuration config;
+  std::vector<double> amplitude;
+  BMPSContractor &contractor;
+  BMPSTruncateParams trun_para;
+
+  TPSWaveFunctionComponent(const SplitIndexTPS &sitps, const Configuration &cfg, BMPSContractor &c)
+      : config(cfg), contractor(c), trun_para(c.GetTruncateParams()) {
+    contractor.UploadState(sitps);
+    contractor.Init(config);                 // tn = TensorNetwork2D(sitps, config); contractor.Init(tn)  (:159-160)
+    EvaluateAmplitude();                     // :161
+  }
+  const std::vector<double> &EvaluateAmplitude() {      // :187-212
+    amplitude = contractor.EvaluateAmplitude();
+    auto flags = contractor.WalkerFlags();
+    for (size_t w = 0; w < flags.size(); ++w)
+      if (flags[w])
+        throw std::runtime_error("BMPS::MultiplyMPOSVDCompress_: Empty tensor (walker " + std::to_string(w) +
+                                 "). Configuration may have near-zero amplitude due to numerical degeneracy.");
+    return amplitude;
+  }
+  void ReplaceGlobalConfig(const Configuration &cfg) {   // :180-185
+    config = cfg;
+    contractor.Init(config);
+    EvaluateAmplitude();
+  }
+  // UpdateLocal (:345-378) for the walkers with mask != 0
+  void UpdateLocal(const std::vector<double> &new_amplitude, const std::vector<SiteIdx> &sites,
+                   const std::vector<int32_t> &new_states /* [walker][site] */, const std::vector<uint8_t> &mask) {
+    std::vector<int32_t> flat_sites;
+    for (auto &s : sites) { flat_sites.push_back((int32_t)s.r); flat_sites.push_back((int32_t)s.c); }
+    contractor.UpdateLocal(flat_sites, new_states, mask);
+    for (size_t w = 0; w < mask.size(); ++w) {
+      if (!mask[w]) continue;
+      for (size_t k = 0; k < sites.size(); ++k) config(w, sites[k]) = new_states[w * sites.size() + k];
+      amplitude[w] = new_amplitude[w];
+    }
+  }
+  bool IsAmplitudeSquareLegal(size_t w) const {          // :309-315
+    double a = std::fabs(amplitude[w]);
+    return !std::isnan(a) && a > std::sqrt(std::numeric_limits<double>::min()) && a < std::sqrt(std::numeric_limits<double>::max());
+  }
+};
+
+// suwa_todo_update.h:53-112
+template <class RandGenerator>
+size_t SuwaTodoStateUpdate(size_t init_state, std::vector<double> weights, RandGenerator &generator) {
+  const size_t n = weights.size();
+  auto max_it = std::max_element(weights.cbegin(), weights.cend());
+  const size_t max_id = max_it - weights.cbegin();
+  if (max_id != 0) std::swap(weights[0], weights[max_id]);
+  if (init_state == max_id) init_state = 0;
+  else if (init_state == 0) init_state = max_id;
+  std::vector<long double> s(n);
+  s[0] = weights[0];
+  for (size_t i = 1; i < n; i++) s[i] = s[i - 1] + (long double)weights[i];
+  const long double S = s.back();
+  const long double s_im1 = (init_state == 0) ? 0.0L : s[init_state - 1];
+  long double start = s_im1 + (long double)weights[0];
+  if (start >= S) start -= S;
+  std::uniform_real_distribution<long double> dist(start, std::nextafter(start + (long double)weights[init_state], start));
+  long double x = dist(generator);
+  if (x >= S) x -= S;
+  size_t final_state = std::upper_bound(s.begin(), s.end(), x) - s.begin();
+  if (final_state >= n) final_state = n - 1;
+  if (max_id != 0) {
+    if (final_state == 0) final_state = max_id;
+    else if (final_state == max_id) final_state = 0;
+  }
+  return final_state;
+}
+
+// MonteCarloSweepUpdaterBase (monte_carlo_sweep_updater_base.h:18-47): one std::mt19937 per walker
+class MonteCarloSweepUpdaterBase {
+ public:
+  explicit MonteCarloSweepUpdaterBase(const std::vector<uint64_t> &seeds) : u_double_(0.0, 1.0) {
+    for (auto s : seeds) engines_.emplace_back((std::mt19937::result_type)s);
+  }
+ protected:
+  std::vector<std::mt19937> engines_;
+  std::uniform_real_distribution<double> u_double_;
+};
+
+// square_nn_updater.h:25-83: sweep schedule, CRTP hook TwoSiteNNUpdateLocalImpl(site1, site2, dir, sitps, comp) -> accepted[w]
+template <typename MCUpdater>
+class MCUpdateSquareNNUpdateBaseOBC : public MonteCarloSweepUpdaterBase {
+ public:
+  using MonteCarloSweepUpdaterBase::MonteCarloSweepUpdaterBase;
+  void operator()(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp, std::vector<double> &accept_rates) {
+    auto &c = comp.contractor;
+    const size_t rows = c.rows(), cols = c.cols(), n = comp.config.walkers();
+    std::vector<size_t> acc(n, 0);
+    auto add = [&](const std::vector<uint8_t> &a) { for (size_t w = 0; w < n; ++w) acc[w] += a[w]; };
+    c.GenerateBMPSApproach(UP);
+    for (size_t row = 0; row < rows; row++) {
+      c.InitBTen(LEFT, row);
+      c.GrowFullBTen(RIGHT, row, 2, true);
+      for (size_t col = 0; col + 1 < cols; col++) {
+        add(static_cast<MCUpdater *>(this)->TwoSiteNNUpdateLocalImpl({row, col}, {row, col + 1}, HORIZONTAL, sitps, comp));
+        if (col + 2 < cols) c.ShiftBTenWindow(RIGHT);
+      }
+      if (row + 1 < rows) c.ShiftBMPSWindow(DOWN);
+    }
+    c.DeleteInnerBMPS(LEFT);
+    c.DeleteInnerBMPS(RIGHT);
+    c.GenerateBMPSApproach(LEFT);
+    for (size_t col = 0; col < cols; col++) {
+      c.InitBTen(UP, col);
+      c.GrowFullBTen(DOWN, col, 2, true);
+      for (size_t row = 0; row + 1 < rows; row++) {
+        add(static_cast<MCUpdater *>(this)->TwoSiteNNUpdateLocalImpl({row, col}, {row + 1, col}, VERTICAL, sitps, comp));
+        if (row + 2 < rows) c.ShiftBTenWindow(DOWN);
+      }
+      if (col + 1 < cols) c.ShiftBMPSWindow(RIGHT);
+    }
+    c.DeleteInnerBMPS(UP);
+    const double bond_num = double(cols * (rows - 1) + rows * (cols - 1));
+    accept_rates.assign(n, 0.0);
+    for (size_t w = 0; w < n; ++w) accept_rates[w] = double(acc[w]) / bond_num;
+  }
+};
+
+// square_nn_updater.h:142-189
+class MCUpdateSquareNNExchangeOBC : public MCUpdateSquareNNUpdateBaseOBC<MCUpdateSquareNNExchangeOBC> {
+ public:
+  using MCUpdateSquareNNUpdateBaseOBC<MCUpdateSquareNNExchangeOBC>::MCUpdateSquareNNUpdateBaseOBC;
+  std::vector<uint8_t> TwoSiteNNUpdateLocalImpl(const SiteIdx &s1, const SiteIdx &s2, BondOrientation dir,
+                                                const SplitIndexTPS &, TPSWaveFunctionComponent &comp) {
+    const size_t n = comp.config.walkers();
+    std::vector<int32_t> cand(n * 2);
+    bool any = false;
+    for (size_t w = 0; w < n; ++w) {
+      cand[2 * w] = comp.config(w, s2);
+      cand[2 * w + 1] = comp.config(w, s1);
+      any |= cand[2 * w] != cand[2 * w + 1];
+    }
+    std::vector<uint8_t> exchange(n, 0);
+    if (!any) return exchange;            // every walker has equal spins on the bond (:149-151)
+    std::vector<double> psi_b = comp.contractor.ReplaceNNSiteTrace(s1, dir, 1, cand);
+    for (size_t w = 0; w < n; ++w) {
+      if (comp.config(w, s1) == comp.config(w, s2)) continue;
+      const double pa = std::fabs(comp.amplitude[w]), pb = std::fabs(psi_b[w]);
+      if (pb >= pa) exchange[w] = 1;
+      else {
+        const double div = pb / pa;
+        exchange[w] = u_double_(engines_[w]) < div * div;
+      }
+    }
+    comp.UpdateLocal(psi_b, {s1, s2}, cand, exchange);
+    return exchange;
+  }
+};
+
+// square_nn_updater.h:253-293
+class MCUpdateSquareNNFullSpaceUpdateOBC : public MCUpdateSquareNNUpdateBaseOBC<MCUpdateSquareNNFullSpaceUpdateOBC> {
+ public:
+  using MCUpdateSquareNNUpdateBaseOBC<MCUpdateSquareNNFullSpaceUpdateOBC>::MCUpdateSquareNNUpdateBaseOBC;
+  std::vector<uint8_t> TwoSiteNNUpdateLocalImpl(const SiteIdx &s1, const SiteIdx &s2, BondOrientation dir,
+                                                const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp) {
+    const size_t n = comp.config.walkers(), dim = sitps.PhysicalDim(), nc = dim * dim;
+    std::vector<int32_t> cand(n * nc * 2);
+    for (size_t w = 0; w < n; ++w)
+      for (size_t k = 0; k < nc; ++k) { cand[(w * nc + k) * 2] = (int32_t)(k / dim); cand[(w * nc + k) * 2 + 1] = (int32_t)(k % dim); }
+    std::vector<double> alt = comp.contractor.ReplaceNNSiteTrace(s1, dir, (int)nc, cand);
+    std::vector<uint8_t> changed(n, 0);
+    std::vector<int32_t> ns(n * 2);
+    std::vector<double> new_amp(n);
+    for (size_t w = 0; w < n; ++w) {
+      const size_t init = comp.config(w, s1) * dim + comp.config(w, s2);
+      alt[w * nc + init] = comp.amplitude[w];
+      std::vector<double> weights(nc);
+      for (size_t k = 0; k < nc; ++k) { const double r = alt[w * nc + k] / comp.amplitude[w]; weights[k] = r * r; }
+      const size_t fin = SuwaTodoStateUpdate(init, weights, engines_[w]);
+      changed[w] = fin != init;
+      ns[2 * w] = (int32_t)(fin / dim); ns[2 * w + 1] = (int32_t)(fin % dim);
+      new_amp[w] = alt[w * nc + fin];
+    }
+    comp.UpdateLocal(new_amp, {s1, s2}, ns, changed);
+    return changed;
+  }
+};
+
+// Result of CalEnergyAndHoles for a walker batch
+struct EnergyAndHoles {
+  std::vector<double> energy;                 // [walker]
+  std::vector<double> holes;                  // [walker][row][col][D^4]  (Dag(PunchHole); real: identity)
+  std::vector<std::vector<double>> psi_list;  // [row/col pass][walker]
+};
+
+// SquareNNNModelEnergySolver with has_nnn_interaction = false (square_nnn_energy_solver.h:37-316)
+// + BondTraversalMixin::TraverseVerticalBonds (bond_traversal_mixin.h:113-144).  CRTP hooks:
+//   EvaluateBondEnergy(site1, site2, orient, comp, inv_psi) -> [walker]   and   EvaluateTotalOnsiteEnergy(config, w)
+template <class ExplicitlyModel>
+class SquareNNModelEnergySolver {
+ public:
+  template <bool calchols = true>
+  EnergyAndHoles CalEnergyAndHoles(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp) {
+    auto &c = comp.contractor;
+    const size_t rows = c.rows(), cols = c.cols(), n = comp.config.walkers(), slot = sitps.slot();
+    EnergyAndHoles out;
+    out.energy.assign(n, 0.0);
+    if (calchols) out.holes.assign(n * rows * cols * slot, 0.0);
+    auto *self = static_cast<ExplicitlyModel *>(this);
+    c.GenerateBMPSApproach(UP);                                              // :116
+    for (size_t row = 0; row < rows; row++) {
+      c.InitBTen(LEFT, row);                                                 // :142
+      c.GrowFullBTen(RIGHT, row, 1, true);                                   // :143
+      std::vector<double> psi = c.Trace({row, 0}, HORIZONTAL);               // :147
+      std::vector<double> inv_psi(n);
+      for (size_t w = 0; w < n; ++w) {
+        if (psi[w] == 0.0) throw std::runtime_error("Wavefunction amplitude is near zero, causing division by zero.");
+        inv_psi[w] = 1.0 / psi[w];
+      }
+      out.psi_list.push_back(psi);
+      for (size_t col = 0; col < cols; col++) {
+        if (calchols) {
+          std::vector<double> h = c.PunchHole({row, col}, HORIZONTAL);        // :163
+          for (size_t w = 0; w < n; ++w)
+            std::copy(h.begin() + w * slot, h.begin() + (w + 1) * slot, out.holes.begin() + ((w * rows + row) * cols + col) * slot);
+        }
+        if (col + 1 < cols) {
+          std::vector<double> e = self->EvaluateBondEnergy({row, col}, {row, col + 1}, HORIZONTAL, comp, inv_psi);
+          for (size_t w = 0; w < n; ++w) out.energy[w] += e[w];
+          c.ShiftBTenWindow(RIGHT);                                           // :200
+        }
+      }
+      if (row + 1 < rows) c.ShiftBMPSWindow(DOWN);                            // :126
+    }
+    c.GenerateBMPSApproach(LEFT);                                            // bond_traversal_mixin.h:120
+    for (size_t col = 0; col < cols; col++) {
+      c.InitBTen(UP, col);
+      c.GrowFullBTen(DOWN, col, 2, true);
+      std::vector<double> psi = c.Trace({0, col}, VERTICAL);
+      std::vector<double> inv_psi(n);
+      for (size_t w = 0; w < n; ++w) {
+        if (psi[w] == 0.0) throw std::runtime_error("Wavefunction amplitude is near zero, causing division by zero.");
+        inv_psi[w] = 1.0 / psi[w];
+      }
+      out.psi_list.push_back(psi);
+      for (size_t row = 0; row + 1 < rows; row++) {
+        std::vector<double> e = self->EvaluateBondEnergy({row, col}, {row + 1, col}, VERTICAL, comp, inv_psi);
+        for (size_t w = 0; w < n; ++w) out.energy[w] += e[w];
+        if (row + 2 < rows) c.ShiftBTenWindow(DOWN);
+      }
+      if (col + 1 < cols) c.ShiftBMPSWindow(RIGHT);
+    }
+    for (size_t w = 0; w < n; ++w) out.energy[w] += self->EvaluateTotalOnsiteEnergy(comp.config, w);   // :99-101
+    return out;
+  }
+};
+
+// square_spin_onehalf_xxz_obc.h:64-190
+class SquareSpinOneHalfXXZModelOBC : public SquareNNModelEnergySolver<SquareSpinOneHalfXXZModelOBC> {
+ public:
+  SquareSpinOneHalfXXZModelOBC() : jz_(1.0), jxy_(1.0), pinning00_(0.0) {}
+  SquareSpinOneHalfXXZModelOBC(double jz, double jxy, double pinning00) : jz_(jz), jxy_(jxy), pinning00_(pinning00) {}
+  std::vector<double> EvaluateBondEnergy(const SiteIdx &s1, const SiteIdx &s2, BondOrientation orient,
+                                         TPSWaveFunctionComponent &comp, const std::vector<double> &inv_psi) {   // :72-104
+    const size_t n = comp.config.walkers();
+    std::vector<int32_t> cand(n * 2);
+    bool any = false;
+    for (size_t w = 0; w < n; ++w) {
+      cand[2 * w] = comp.config(w, s2);
+      cand[2 * w + 1] = comp.config(w, s1);
+      any |= cand[2 * w] != cand[2 * w + 1];
+    }
+    std::vector<double> e(n, 0.25 * jz_);
+    if (!any) return e;
+    std::vector<double> psi_ex = comp.contractor.ReplaceNNSiteTrace(s1, orient, 1, cand);
+    for (size_t w = 0; w < n; ++w)
+      if (comp.config(w, s1) != comp.config(w, s2)) e[w] = -0.25 * jz_ + psi_ex[w] * inv_psi[w] * 0.5 * jxy_;
+    return e;
+  }
+  double EvaluateTotalOnsiteEnergy(const Configuration &config, size_t w) const {   // :139-141
+    return -pinning00_ * (double(config(w, {0, 0})) - 0.5);
+  }
+ private:
+  double jz_, jxy_, pinning00_;
+};
+
+// transverse_field_ising_square_obc.h:28-247
+class TransverseFieldIsingSquareOBC {
+ public:
+  explicit TransverseFieldIsingSquareOBC(double h) : h_(h) {}
+  double CalDiagTermEnergy(const Configuration &config, size_t w) const {   // :160-182
+    double e = 0;
+    for (size_t r = 0; r < config.rows(); r++)
+      for (size_t c = 0; c + 1 < config.cols(); c++) e += (config(w, {r, c}) == config(w, {r, c + 1})) ? -1 : 1;
+    for (size_t c = 0; c < config.cols(); c++)
+      for (size_t r = 0; r + 1 < config.rows(); r++) e += (config(w, {r, c}) == config(w, {r + 1, c})) ? -1 : 1;
+    return e;
+  }
+  template <bool calchols = true>
+  EnergyAndHoles CalEnergyAndHoles(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp) {   // :211-247
+    auto &c = comp.contractor;
+    const size_t rows = c.rows(), cols = c.cols(), n = comp.config.walkers(), slot = sitps.slot();
+    EnergyAndHoles out;
+    out.energy.assign(n, 0.0);
+    if (calchols) out.holes.assign(n * rows * cols * slot, 0.0);
+    c.GenerateBMPSApproach(UP);
+    for (size_t row = 0; row < rows; row++) {
+      c.InitBTen(LEFT, row);
+      c.GrowFullBTen(RIGHT, row, 1, true);
+      std::vector<double> psi = c.Trace({row, 0}, HORIZONTAL);
+      out.psi_list.push_back(psi);
+      for (size_t col = 0; col < cols; col++) {
+        if (calchols) {
+          std::vector<double> h = c.PunchHole({row, col}, HORIZONTAL);
+          for (size_t w = 0; w < n; ++w)
+            std::copy(h.begin() + w * slot, h.begin() + (w + 1) * slot, out.holes.begin() + ((w * rows + row) * cols + col) * slot);
+        }
+        std::vector<int32_t> cand(n);
+        for (size_t w = 0; w < n; ++w) cand[w] = 1 - comp.config(w, {row, col});
+        std::vector<double> psi_ex = c.ReplaceOneSiteTrace({row, col}, HORIZONTAL, 1, cand);      // :195-203
+        for (size_t w = 0; w < n; ++w) out.energy[w] += (-h_) * psi_ex[w] / psi[w];
+        if (col + 1 < cols) c.ShiftBTenWindow(RIGHT);
+      }
+      if (row + 1 < rows) c.ShiftBMPSWindow(DOWN);
+    }
+    for (size_t w = 0; w < n; ++w) out.energy[w] += CalDiagTermEnergy(comp.config, w);
+    return out;
+  }
+ private:
+  double h_;
+};
+
+// Accumulators of the evaluators: S_O = sum w O*, S_EO = sum w E_loc* O*, sum w, sum w E_loc
+// (exact_summation_energy_evaluator.h:195-245; mc_energy_grad_evaluator.h:245-278 with w = 1).
+struct GradAccumulator {
+  SplitIndexTPS Ostar_sum, ELocConj_Ostar_sum;
+  double weight_sum = 0.0, e_loc_sum = 0.0, e_loc_sq_sum = 0.0;
+  size_t samples = 0;
+  GradAccumulator(const SplitIndexTPS &like)
+      : Ostar_sum(like.rows(), like.cols(), like.PhysicalDim(), like.D()),
+        ELocConj_Ostar_sum(like.rows(), like.cols(), like.PhysicalDim(), like.D()) {}
+
+  // exact summation: weight |psi|^2, O* increment = psi * hole  (:231)
+  // Monte Carlo:     weight 1,       O* = hole / psi           (mc_energy_grad_evaluator.h:266)
+  void Accumulate(const TPSWaveFunctionComponent &comp, const EnergyAndHoles &eh, bool exact_sum) {
+    const size_t n = comp.config.walkers(), rows = Ostar_sum.rows(), cols = Ostar_sum.cols(), slot = Ostar_sum.slot();
+    for (size_t w = 0; w < n; ++w) {
+      const double psi = comp.amplitude[w], e = eh.energy[w];
+      const double wt = exact_sum ? psi * psi : 1.0;
+      const double f = exact_sum ? psi : 1.0 / psi;
+      for (size_t r = 0; r < rows; ++r)
+        for (size_t c = 0; c < cols; ++c) {
+          const size_t basis = (size_t)comp.config(w, {r, c});
+          const double *h = eh.holes.data() + ((w * rows + r) * cols + c) * slot;
+          double *so = Ostar_sum.component(r, c, basis), *seo = ELocConj_Ostar_sum.component(r, c, basis);
+          for (size_t k = 0; k < slot; ++k) { so[k] += f * h[k]; seo[k] += e * f * h[k]; }
+        }
+      weight_sum += wt;
+      e_loc_sum += e * wt;
+      e_loc_sq_sum += e * e * wt;
+      ++samples;
+    }
+  }
+  // Flat view for the cross-rank sum that replaces MPIMeanTensor / MPI_Reduce
+  // (statistics_tensor.h:37-79, exact_summation_energy_evaluator.h:252-280): one all-reduce(sum).
+  std::vector<double> Pack() const {
+    std::vector<double> v;
+    v.reserve(2 * Ostar_sum.flat().size() + 4);
+    v.insert(v.end(), Ostar_sum.flat().begin(), Ostar_sum.flat().end());
+    v.insert(v.end(), ELocConj_Ostar_sum.flat().begin(), ELocConj_Ostar_sum.flat().end());
+    v.push_back(weight_sum); v.push_back(e_loc_sum); v.push_back(e_loc_sq_sum); v.push_back((double)samples);
+    return v;
+  }
+  void Unpack(const std::vector<double> &v) {
+    const size_t m = Ostar_sum.flat().size();
+    std::copy(v.begin(), v.begin() + m, Ostar_sum.flat().begin());
+    std::copy(v.begin() + m, v.begin() + 2 * m, ELocConj_Ostar_sum.flat().begin());
+    weight_sum = v[2 * m]; e_loc_sum = v[2 * m + 1]; e_loc_sq_sum = v[2 * m + 2]; samples = (size_t)v[2 * m + 3];
+  }
+  // energy = sum wE / sum w ; gradient = (S_EO - E* S_O) / sum w   (exact_summation_energy_evaluator.h:286-295)
+  std::pair<double, SplitIndexTPS> Finish() const {
+    const double energy = e_loc_sum / weight_sum;
+    SplitIndexTPS grad(Ostar_sum.rows(), Ostar_sum.cols(), Ostar_sum.PhysicalDim(), Ostar_sum.D());
+    const auto &so = Ostar_sum.flat(), &seo = ELocConj_Ostar_sum.flat();
+    auto &g = grad.flat();
+    for (size_t k = 0; k < g.size(); ++k) g[k] = (seo[k] - energy * so[k]) / weight_sum;
+    return {energy, grad};
+  }
+};
+
+// GenerateAllPermutationConfigs (exact_summation_energy_evaluator.h:74-95) for one walker batch layout
+inline std::vector<std::vector<int32_t>> GenerateAllPermutationConfigs(const std::vector<size_t> &particle_counts, size_t Lx, size_t Ly) {
+  std::vector<int32_t> base;
+  for (size_t i = 0; i < particle_counts.size(); ++i)
+    for (size_t j = 0; j < particle_counts[i]; ++j) base.push_back((int32_t)i);
+  (void)Lx; (void)Ly;
+  std::vector<std::vector<int32_t>> all;
+  do { all.push_back(base); } while (std::next_permutation(base.begin(), base.end()));
+  return all;
+}
+
+// ExactSumEnergyEvaluatorMPI (exact_summation_energy_evaluator.h:173-302): configurations
+// i = rank, rank + size, ... are evaluated in batches of `batch` walkers; `allreduce` sums the
+// packed accumulators over ranks in place (RCCL all-reduce in the host program; identity if null).
+template <typename ModelT>
+std::pair<double, SplitIndexTPS> ExactSumEnergyEvaluator(const SplitIndexTPS &sitps, const std::vector<std::vector<int32_t>> &all_configs,
+                                                          BMPSContractor &contractor, ModelT &model, int rank, int size,
+                                                          size_t batch, const std::function<void(std::vector<double> &)> &allreduce) {
+  const size_t rows = sitps.rows(), cols = sitps.cols();
+  GradAccumulator acc(sitps);
+  std::vector<size_t> mine;
+  for (size_t i = rank; i < all_configs.size(); i += size) mine.push_back(i);                 // :201
+  contractor.UploadState(sitps);
+  for (size_t b0 = 0; b0 < mine.size(); b0 += batch) {
+    const size_t nb = std::min(batch, mine.size() - b0);
+    Configuration cfg(nb, rows, cols);
+    for (size_t w = 0; w < nb; ++w) std::copy(all_configs[mine[b0 + w]].begin(), all_configs[mine[b0 + w]].end(), cfg.data() + w * rows * cols);
+    TPSWaveFunctionComponent comp(sitps, cfg, contractor);
+    EnergyAndHoles eh = model.template CalEnergyAndHoles<true>(sitps, comp);
+    acc.Accumulate(comp, eh, true);
+  }
+  std::vector<double> packed = acc.Pack();
+  if (allreduce) allreduce(packed);
+  acc.Unpack(packed);
+  return acc.Finish();
+}
+
+}  // namespace qlpeps_gpu

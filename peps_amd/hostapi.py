@@ -1,0 +1,101 @@
+"""ctypes binding of libpepshost.so: the C++ host layer (peps_amd/host/qlpeps_gpu.h) that mirrors the
+reference's updater / solver / evaluator surface on top of the pepsgpu C ABI."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpepshost.so")
+
+SYMBOLS = ["pepshost_last_error", "pepshost_mc_sweeps", "pepshost_energy_and_holes", "pepshost_exact_sum_partial",
+           "pepshost_exact_sum_finish", "pepshost_load_sitps"]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libpepshost.so not built: run __graft_entry__.build()")
+        from . import capi
+        capi.lib()                         # make sure libpepsgpu.so is resolvable first
+        _lib = C.CDLL(LIB_PATH)
+        _lib.pepshost_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def _ck(rc):
+    if rc != 0:
+        msg = lib().pepshost_last_error().decode()
+        raise {1: ValueError, 3: RuntimeError, 4: IndexError}.get(rc, RuntimeError)("pepshost error %d: %s" % (rc, msg))
+
+
+def _dims(flat):
+    rows, cols, d, D = flat.shape[0], flat.shape[1], flat.shape[2], flat.shape[3]
+    return rows, cols, d, D
+
+
+def mc_sweeps(flat, configs, seeds, chi, updater="exchange", n_sweeps=1, dtype=1):
+    flat = np.ascontiguousarray(flat, dtype=np.float64)
+    rows, cols, d, D = _dims(flat)
+    cfg = np.ascontiguousarray(configs, dtype=np.int32).copy()
+    n = cfg.shape[0]
+    sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+    amps = np.zeros(n)
+    rates = np.zeros(n)
+    _ck(lib().pepshost_mc_sweeps(rows, cols, D, d, chi, dtype, _p(flat, C.c_double), n, _p(cfg, C.c_int32),
+                                 _p(sd, C.c_uint64), 0 if updater == "exchange" else 1, n_sweeps,
+                                 _p(amps, C.c_double), _p(rates, C.c_double)))
+    return cfg, amps, rates
+
+
+def energy_and_holes(flat, configs, chi, model="xxz", params=(1.0, 1.0, 0.0), holes=True, dtype=1):
+    flat = np.ascontiguousarray(flat, dtype=np.float64)
+    rows, cols, d, D = _dims(flat)
+    cfg = np.ascontiguousarray(configs, dtype=np.int32)
+    n = cfg.shape[0]
+    p = np.array(list(params) + [0.0, 0.0, 0.0], dtype=np.float64)
+    amps, en = np.zeros(n), np.zeros(n)
+    h = np.zeros((n, rows, cols, D, D, D, D)) if holes else None
+    psi = np.zeros((rows + cols, n))
+    npsi = C.c_int(0)
+    _ck(lib().pepshost_energy_and_holes(rows, cols, D, d, chi, dtype, _p(flat, C.c_double), n, _p(cfg, C.c_int32),
+                                        0 if model == "xxz" else 1, _p(p, C.c_double), _p(amps, C.c_double),
+                                        _p(en, C.c_double), _p(h, C.c_double), _p(psi, C.c_double), C.byref(npsi)))
+    return amps, en, h, psi[:npsi.value]
+
+
+def exact_sum_partial(flat, all_configs, chi, model="xxz", params=(1.0, 1.0, 0.0), rank=0, size=1, batch=64, dtype=1):
+    flat = np.ascontiguousarray(flat, dtype=np.float64)
+    rows, cols, d, D = _dims(flat)
+    cfg = np.ascontiguousarray(all_configs, dtype=np.int32)
+    p = np.array(list(params) + [0.0, 0.0, 0.0], dtype=np.float64)
+    packed = np.zeros(2 * flat.size + 4)
+    _ck(lib().pepshost_exact_sum_partial(rows, cols, D, d, chi, dtype, _p(flat, C.c_double), _p(cfg, C.c_int32),
+                                         cfg.shape[0], 0 if model == "xxz" else 1, _p(p, C.c_double), rank, size, batch,
+                                         _p(packed, C.c_double)))
+    return packed
+
+
+def exact_sum_finish(packed, shape):
+    rows, cols, d, D = shape[:4]
+    packed = np.ascontiguousarray(packed, dtype=np.float64)
+    e = C.c_double(0)
+    grad = np.zeros((rows, cols, d, D, D, D, D))
+    _ck(lib().pepshost_exact_sum_finish(rows, cols, D, d, _p(packed, C.c_double), C.byref(e), _p(grad, C.c_double)))
+    return e.value, grad
+
+
+def load_sitps(directory, D):
+    rows, cols, d = C.c_int(0), C.c_int(0), C.c_int(0)
+    _ck(lib().pepshost_load_sitps(directory.encode(), D, C.byref(rows), C.byref(cols), C.byref(d), None, 0))
+    flat = np.zeros((rows.value, cols.value, d.value, D, D, D, D))
+    _ck(lib().pepshost_load_sitps(directory.encode(), D, C.byref(rows), C.byref(cols), C.byref(d),
+                                  _p(flat, C.c_double), flat.size))
+    return flat

@@ -67,7 +67,7 @@ def make_configs(L, n_walkers, model="heisenberg", seed0=7):
     return out
 
 
-def sitps_to_flat(sitps, D, dtype=np.float32):
+def sitps_to_flat(sitps, D, dtype=np.float64):
     """Pack into the C-ABI upload layout [row][col][s][L][D][R][U] zero-padded to D^4 per
     component (include/pepsgpu.h: pepsgpu_state_upload)."""
     L = len(sitps)

@@ -1,0 +1,145 @@
+"""GPU parity tests of the C++ host layer (peps_amd/host/qlpeps_gpu.h: updaters, solvers, evaluators)
+driven through libpepshost.so, against the oracle on identical configuration lists / seeds."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import qlten_io, vmc
+from oracle.bmps import BMPSTruncateParams
+from peps_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+F32, F64 = 0, 1
+
+
+def _host():
+    from peps_amd import hostapi
+    return hostapi
+
+
+def _oracle_energy(sitps, cfgs, chi, model):
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    out = []
+    for c in cfgs:
+        comp = vmc.TPSWaveFunctionComponent(sitps, c, tp)
+        e, holes, psis = model.CalEnergyAndHoles(sitps, comp, True)
+        out.append((comp.amplitude, e, holes, psis))
+    return out
+
+
+@pytest.mark.parametrize("dt,tol", [(F64, 1e-9), (F32, 2e-5)])
+def test_xxz_energy_and_holes_fixed_configs(fixtures_dir, dt, tol):
+    """E_loc(S) and hole tensors on identical configurations: 4x4 D=8 reference fixture (K5), chi=16."""
+    host = _host()
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, "tps_square_heisenberg4x4D8Double"))
+    cfgs = np.stack([synthetic.checkerboard(4)] + list(synthetic.make_configs(4, 5, "heisenberg")))
+    ref = _oracle_energy(s, cfgs, 16, vmc.SquareSpinOneHalfXXZModelOBC())
+    amps, en, holes, psi = host.energy_and_holes(synthetic.sitps_to_flat(s, 8), cfgs, 16, "xxz", (1.0, 1.0, 0.0), True, dt)
+    for w, (a, e, h, ps) in enumerate(ref):
+        assert abs(amps[w] / a - 1) < tol
+        assert abs(en[w] - e) < tol * max(1.0, abs(e)) * 10
+        for r in range(4):
+            for c in range(4):
+                hr = h[r][c]
+                hd = holes[w, r, c][:hr.shape[0], :hr.shape[1], :hr.shape[2], :hr.shape[3]]
+                assert np.max(np.abs(hd - hr)) < tol * 10 * np.max(np.abs(hr))
+        assert np.max(np.abs(psi[:, w] / np.array(ps) - 1)) < tol * 10      # psi along every row and column
+
+
+@pytest.mark.parametrize("dt,tol", [(F64, 1e-9), (F32, 2e-5)])
+def test_tfim_energy_fixed_configs(dt, tol):
+    host = _host()
+    L, D, chi = 5, 3, 9
+    s = synthetic.make_sitps(L, D)
+    cfgs = synthetic.make_configs(L, 6, "tfim")
+    ref = _oracle_energy(s, cfgs, chi, vmc.TransverseFieldIsingSquareOBC(0.7))
+    amps, en, holes, psi = host.energy_and_holes(synthetic.sitps_to_flat(s, D), cfgs, chi, "tfim", (0.7,), True, dt)
+    for w, (a, e, h, ps) in enumerate(ref):
+        assert abs(amps[w] / a - 1) < tol
+        assert abs(en[w] - e) < tol * max(1.0, abs(e)) * 10
+
+
+K4 = [("heisenberg_tps_double_from_simple_update", "xxz", -1.99521278793, 1e-10),
+      ("heisenberg_tps_doublelowest", "xxz", -2.0, 6e-8),
+      ("transverse_ising_tps_double_from_simple_update", "tfim", -5.19991995228, 1e-10),
+      ("transverse_ising_tps_doublelowest", "tfim",
+       -2.0 * (np.sqrt(2 - 2 * np.cos(np.pi / 4)) + np.sqrt(2 - 2 * np.cos(3 * np.pi / 4))), 6e-8)]
+
+
+@pytest.mark.parametrize("name,model,e_ref,tol", K4)
+def test_k4_exact_sum_on_device(fixtures_dir, name, model, e_ref, tol):
+    """The reference's own exact-summation known answers (test_exact_summation_evaluator.cpp:139-174,
+    :250-259, :606, :775) through the C++ ExactSumEnergyEvaluator on the device (f64), incl. the
+    4-rank round-robin partition of exact_summation_energy_evaluator.h:201; gradient vs the oracle."""
+    host = _host()
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, name))
+    flat = synthetic.sitps_to_flat(s, 4)
+    if model == "xxz":
+        cfgs = np.array(vmc.generate_all_permutation_configs([2, 2], 2, 2))
+        params, m = (1.0, 1.0, 0.0), vmc.SquareSpinOneHalfXXZModelOBC()
+    else:
+        cfgs = np.array(vmc.all_product_configs(2, 2, 2))
+        params, m = (1.0,), vmc.TransverseFieldIsingSquareOBC(1.0)
+    packed = sum(host.exact_sum_partial(flat, cfgs, 8, model, params, r, 4, 3, F64) for r in range(4))
+    e, grad = host.exact_sum_finish(packed, flat.shape)
+    assert abs(e - e_ref) < tol
+    e_o, g_o, _ = vmc.exact_sum_energy_evaluator(s, list(cfgs), BMPSTruncateParams.SVD(8, 8, 0.0), m)
+    assert abs(e - e_o) < 1e-10
+    for r in range(2):
+        for c in range(2):
+            for k in range(2):
+                go = g_o[r][c][k]
+                gd = grad[r, c, k][:go.shape[0], :go.shape[1], :go.shape[2], :go.shape[3]]
+                assert np.max(np.abs(gd - go)) < 1e-9
+
+
+def test_k5_exact_sum_4x4_d8(fixtures_dir):
+    """All 12 870 Sz=0 configurations of the 4x4 D=8 reference state on the device (f32, chi=16):
+    E = -9.1891559611 (dense contraction), north-star tolerance 1e-6 relative."""
+    host = _host()
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, "tps_square_heisenberg4x4D8Double"))
+    flat = synthetic.sitps_to_flat(s, 8)
+    cfgs = np.array(vmc.generate_all_permutation_configs([8, 8], 4, 4)).astype(np.int32)
+    assert len(cfgs) == 12870
+    packed = host.exact_sum_partial(flat, cfgs, 64, "xxz", (1.0, 1.0, 0.0), 0, 1, 1024, F32)
+    e, grad = host.exact_sum_finish(packed, flat.shape)
+    assert abs(e / -9.1891559611 - 1) < 1e-6
+
+
+def test_mc_chain_identical_to_oracle_f64():
+    """Same std::mt19937 stream, same sweep schedule, f64 device path: the Markov chain is the
+    oracle's chain -- identical configurations after 2 sweeps for both updaters."""
+    host = _host()
+    L, D, chi = 4, 3, 9
+    s = synthetic.make_sitps(L, D)
+    flat = synthetic.sitps_to_flat(s, D)
+    cfgs = synthetic.make_configs(L, 5, "heisenberg")
+    seeds = np.array([11, 12, 13, 14, 15], dtype=np.uint64)
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    for name, cls in (("exchange", vmc.MCUpdateSquareNNExchangeOBC), ("fullspace", vmc.MCUpdateSquareNNFullSpaceUpdateOBC)):
+        out_cfg, amps, rates = host.mc_sweeps(flat, cfgs, seeds, chi, name, 2, F64)
+        for w in range(len(cfgs)):
+            comp = vmc.TPSWaveFunctionComponent(s, cfgs[w], tp)
+            upd = cls(seed=int(seeds[w]))
+            r = [upd(s, comp)[0] for _ in range(2)]
+            assert np.array_equal(comp.config, out_cfg[w]), (name, w)
+            assert abs(amps[w] / comp.amplitude - 1) < 1e-8
+            assert abs(rates[w] - np.mean(r)) < 1e-12
+
+
+def test_mc_sweep_consistency_f32(fixtures_dir):
+    """f32 path: after sweeps the carried amplitude equals a fresh EvaluateAmplitude of the final
+    configuration (oracle), and the exchange updater conserves Sz."""
+    host = _host()
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, "tps_square_heisenberg4x4D8Double"))
+    flat = synthetic.sitps_to_flat(s, 8)
+    cfgs = synthetic.make_configs(4, 8, "heisenberg")
+    out_cfg, amps, rates = host.mc_sweeps(flat, cfgs, np.arange(8, dtype=np.uint64) + 3, 16, "exchange", 3, F32)
+    tp = BMPSTruncateParams.SVD(16, 16, 0.0)
+    assert np.all(out_cfg.reshape(8, -1).sum(1) == 8)
+    assert np.all((rates >= 0) & (rates <= 1)) and rates.max() > 0
+    for w in range(8):
+        fresh = vmc.TPSWaveFunctionComponent(s, out_cfg[w], tp).amplitude
+        assert abs(amps[w] / fresh - 1) < 1e-4
