@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time budget of the CPU (oracle) baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--noise", type=float, default=0.1,
+                    help="relative noise of the synthetic site tensors (SURVEY 8d: 0.1; 1.0 = full-rank stress case)")
     return ap.parse_args()
 
 
@@ -83,7 +85,7 @@ def main():
     ctx = capi.Context(L, L, D, 2, chi, dtype=dt, device=local_rank, max_walkers=nw)
 
     # synthetic state of SURVEY 8(d); psi(S_ref) normalisation evaluated with the device path itself
-    sitps = synthetic.make_sitps(L, D)
+    sitps = synthetic.make_sitps(L, D, noise=args.noise)
     ctx.state_upload(synthetic.sitps_to_flat(sitps, D, np.float64))
     ctx.set_configs(synthetic.checkerboard(L)[None])
     psi_ref = float(ctx.evaluate_amplitude()[0])
@@ -153,6 +155,7 @@ def main():
                 "walkers_per_gpu": nw,
                 "parallelism": "walkers sharded over %d GPU(s), no data-path collective" % world,
                 "flops_per_amplitude_reference_algorithm": fl["total"],
+                "synthetic_noise": args.noise,
             },
             "roofline": {
                 "bound": "mfma",
@@ -172,6 +175,18 @@ def main():
             "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]},
             "walkers_with_vanishing_amplitude": nz,
         }
+        # diagnostics outside the timed region: numerical rank of the carry on this workload (the
+        # Jacobi / Gram / Cholesky cost follows it)
+        os.environ["PEPSGPU_DEBUG_SWEEPS"] = "1"
+        dctx = capi.Context(L, L, D, 2, chi, dtype=dt, device=local_rank, max_walkers=16)
+        dctx.state_upload(synthetic.sitps_to_flat(sitps, D, np.float64))
+        dctx.set_configs(batches[0][:16])
+        dctx.evaluate_amplitude()
+        st = dctx.stats()
+        out["workload_rank"] = {"carry_live_fraction": st["carry_live_fraction"], "noise": args.noise,
+                                "jacobi_sweeps_max": st["jacobi_sweeps_max"]}
+        del dctx
+        os.environ.pop("PEPSGPU_DEBUG_SWEEPS", None)
         if world == 1 and not args.no_cpu_baseline:
             ncheck = 8
             rate, n, amps, threads = cpu_baseline(sitps, batches[0][:ncheck], chi, args.cpu_seconds)

@@ -190,9 +190,10 @@ static void diag_chol_t(const double *G, int n, int nbatch, void *Rout) {
   PG_CHECK_HIP(hipMalloc(&dG, ne * sizeof(double)));
   PG_CHECK_HIP(hipMalloc(&dR, ne * sizeof(T)));
   PG_CHECK_HIP(hipMemcpy(dG, G, ne * sizeof(double), hipMemcpyHostToDevice));
-  size_t smem = sizeof(double) * ((size_t)CH_NB * n + 64 * CH_NB);
+  size_t smem = chol_smem_bytes(n);
   allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
-  hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nbatch), dim3(256), smem, 0, dG, (long)n * n, n, dR, (long)n * n);
+  hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nbatch), dim3(256), smem, 0, dG, (long)n * n, n, dR, (long)n * n,
+                     (int *)nullptr);
   PG_CHECK_HIP(hipGetLastError());
   PG_CHECK_HIP(hipDeviceSynchronize());
   PG_CHECK_HIP(hipMemcpy(Rout, dR, ne * sizeof(T), hipMemcpyDeviceToHost));
@@ -220,14 +221,14 @@ static void diag_jacobi_t(void *M, int m, int len, int nbatch, int k, void *Vt, 
   if (sizeof(T) == 4 && force_global == 2) {
     PG_REQUIRE(m <= 256 && len <= 256, 1, "register Jacobi handles up to 256 x 256");
     hipLaunchKernelGGL(jacobi_rows_reg256_kernel, dim3(nbatch), dim3(512), 0, 0, (float *)dM, (long)m * len, m, len, len,
-                       40, dsw);
+                       40, dsw, (const int *)nullptr, 1);
   } else {
     hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nbatch), dim3(1024), use_lds ? need : 0, 0, dM, (long)m * len, m, len,
-                       len, 40, use_lds, dsw);
+                       len, 40, use_lds, dsw, (const int *)nullptr, 1);
   }
   PG_CHECK_HIP(hipGetLastError());
   hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nbatch), dim3(256), 0, 0, (const T *)dM, (long)m * len, m, len, len, k,
-                     dV, (long)k * len, dS, (long)k);
+                     dV, (long)k * len, dS, (long)k, (const int *)nullptr, 1);
   PG_CHECK_HIP(hipGetLastError());
   PG_CHECK_HIP(hipDeviceSynchronize());
   PG_CHECK_HIP(hipMemcpy(M, dM, ne * sizeof(T), hipMemcpyDeviceToHost));

@@ -517,8 +517,9 @@ class Engine : public EngineBase {
   }
   size_t device_bytes() const override { return arena_.total_bytes(); }
   void stats(double *out, int n) override {
-    double v[5] = {(double)n_absorb_, (double)n_jacobi_, (double)jacobi_sweeps_sum_, (double)arena_.total_bytes(), (double)jacobi_sweeps_max_};
-    for (int i = 0; i < n && i < 5; ++i) out[i] = v[i];
+    double v[7] = {(double)n_absorb_, (double)n_jacobi_, (double)jacobi_sweeps_sum_, (double)arena_.total_bytes(),
+                   (double)jacobi_sweeps_max_, live_sum_, live_full_};
+    for (int i = 0; i < n && i < 7; ++i) out[i] = v[i];
   }
   hipStream_t stream() const { return stream_; }
 
@@ -609,8 +610,9 @@ class Engine : public EngineBase {
     }
   }
 
-  void normalize(T *x, long n, long stride, int nb, double *logscale) {
-    hipLaunchKernelGGL(normalize_kernel<T>, dim3(nb), dim3(256), 0, stream_, x, stride, (int)n, logscale, flag_);
+  void normalize(T *x, long n, long stride, int nb, double *logscale, const int *ndyn = nullptr, int ndyn_mul = 1) {
+    hipLaunchKernelGGL(normalize_kernel<T>, dim3(nb), dim3(256), 0, stream_, x, stride, (int)n, logscale, flag_, ndyn,
+                       ndyn_mul);
   }
 
   // acc[w] += a[w] + b[w] + c[w] + d[w]
@@ -721,7 +723,7 @@ class Engine : public EngineBase {
   }
 
   void absorb(int pos, int num);
-  void launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t need);
+  void launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t need, const int *mdyn, int mdyn_mul);
 
   int Ly_, Lx_, D_, dp_, chi_min_, chi_;
   double trunc_err_;
@@ -742,6 +744,7 @@ class Engine : public EngineBase {
   double prof_ms_[PROF_NCAT] = {0}, prof_alg_[PROF_NCAT] = {0}, prof_exec_[PROF_NCAT] = {0};
   long prof_n_[PROF_NCAT] = {0};
   long n_absorb_ = 0, n_jacobi_ = 0, jacobi_sweeps_sum_ = 0, jacobi_sweeps_max_ = 0;
+  double live_sum_ = 0, live_full_ = 0;   // diagnostics: sum of live carry rows / sum of carry sizes
   int *sweeps_ = nullptr;
   bool dbg_sweeps_ = false;
 };

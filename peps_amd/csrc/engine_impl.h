@@ -22,24 +22,29 @@ void Engine<T>::add_log(double *acc, const double *a) {
 // Jacobi dispatch: LDS-resident generic kernel when the block fits, register-resident kernel for
 // the f32 bulk blocks (<= 256 x 256), global-memory generic kernel otherwise (f64 bulk blocks).
 template <typename T>
-void Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t need) {
+void Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t need, const int *mdyn, int mdyn_mul) {
   if constexpr (sizeof(T) == 4) {
     static const bool no_reg = getenv("PEPSGPU_NO_REGJACOBI") != nullptr;
     if (!use_lds && m <= 256 && len <= 256 && !no_reg) {
       hipLaunchKernelGGL(jacobi_rows_reg256_kernel, dim3(nw_), dim3(512), 0, stream_, (float *)M, wM, m, len, len, 40,
-                         sweeps_);
+                         sweeps_, mdyn, mdyn_mul);
       PG_CHECK_HIP(hipGetLastError());
       return;
     }
   }
   hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), use_lds ? need : 0, stream_, M, wM, m, len, len, 40,
-                     use_lds, sweeps_);
+                     use_lds, sweeps_, mdyn, mdyn_mul);
   PG_CHECK_HIP(hipGetLastError());
 }
 
 // BMPS::MultiplyMPO with SVD compression (bmps_impl.h:404-437, :756-862, :225-263), Q-less form.
 // `num` = index of the absorbed row (UP/DOWN) or column (LEFT/RIGHT); sites are visited in the
 // storage order of the BMPS (reversed for UP/RIGHT, bmps_impl.h:694-699).
+//
+// Rank-adaptive carry: the Cholesky kernel drops the rows of R_{i+1} that are numerically zero
+// (below the rounding of the T-typed data) and reports the live count per walker; every launch
+// that runs over the carry index m (X = R.A, P = X.W, the Gram's K index, M = R.T, the Jacobi)
+// takes that count as a per-walker dynamic extent.  Buffers keep their static (worst case) shape.
 template <typename T>
 void Engine<T>::absorb(int pos, int num) {
   const int N = mps_len(pos);
@@ -56,9 +61,12 @@ void Engine<T>::absorb(int pos, int num) {
     }
   };
   const int ll = (pos + 3) % 4, lp = pos, lr = (pos + 1) % 4, lu = (pos + 2) % 4;
+  static const bool adaptive = getenv("PEPSGPU_NO_RANK_ADAPT") == nullptr;
 
   // ---------------- forward: R_{i+1} from P_i = R_i (A_i x W_i) ----------------
   std::vector<DTen<T>> R(N);
+  std::vector<int *> mdyn(N, nullptr);     // live rows of R[i] = mdyn[i][w] * mmul[i] (nullptr: all rows)
+  std::vector<int> mmul(N, 1);
   R[0] = ones3();
   for (int i = 0; i + 1 < N; ++i) {
     int r, c, dd[4], st[4];
@@ -78,6 +86,7 @@ void Engine<T>::absorb(int pos, int num) {
       g.K[2] = a; g.sAk[2] = 1; g.sBk[2] = p * a2;
       g.J[2] = p * a2; g.sBj[2] = 1; g.sCj[2] = 1;
       g.wA = R[i].n; g.wB = A.n; g.wC = X.n; g.nbatch = nw_;
+      g.dynI = mdyn[i]; g.dynI_mul = mmul[i] * l;
       const double fl = 2.0 * nw_ * (double)(m * l) * a * (double)(p * a2);
       prof_begin(PROF_CONTRACT, fl, fl);
       tgemm_launch<T, T, T, T>(stream_, g, R[i].p, A.p, X.p);
@@ -91,6 +100,7 @@ void Engine<T>::absorb(int pos, int num) {
       g.K[1] = l; g.K[2] = p; g.sAk[1] = p * a2; g.sAk[2] = a2; g.sBk[1] = st[ll]; g.sBk[2] = st[lp];
       g.J[1] = l2; g.J[2] = u; g.sBj[1] = st[lr]; g.sBj[2] = st[lu]; g.sCj[1] = a2; g.sCj[2] = l2 * a2;
       g.wA = X.n; g.wC = P.n; g.nbatch = nw_;
+      g.dynI = mdyn[i]; g.dynI_mul = mmul[i] * a2;
       const double fl = 2.0 * nw_ * (double)(m * a2) * (double)(l * p) * (double)(l2 * u);
       prof_begin(PROF_CONTRACT, fl, fl);
       launch_site_gemm(g, cfg_site(r, c), 1, X.p, P.p);
@@ -104,9 +114,11 @@ void Engine<T>::absorb(int pos, int num) {
       P.d[0] = rows; P.d[1] = l2; P.d[2] = a2; P.d[3] = 1;
       // reference op here: QR of the (rows x cols) block, rows < cols (swap R,C)
       prof_begin(PROF_NORM, nw_ * 2.0 * (2.0 * cols * (double)rows * rows - 2.0 / 3.0 * (double)rows * rows * rows), 0.0);
-      normalize(P.p, P.n, P.n, nw_, nullptr);
+      normalize(P.p, P.n, P.n, nw_, nullptr, mdyn[i], mmul[i] * u * cols);
       prof_end();
       R[i + 1] = P;
+      mdyn[i + 1] = mdyn[i];                 // live rows of P = live rows of R_i times u (m is P's outer index)
+      mmul[i + 1] = mmul[i] * u;
     } else {
       double *G = (double *)arena_.alloc(sizeof(double) * (size_t)cols * cols * nw_);
       {
@@ -115,6 +127,7 @@ void Engine<T>::absorb(int pos, int num) {
         g.K[2] = rows; g.sAk[2] = cols; g.sBk[2] = cols;
         g.J[2] = cols; g.sBj[2] = 1; g.sCj[2] = 1;
         g.wA = P.n; g.wB = P.n; g.wC = (long)cols * cols; g.nbatch = nw_;
+        g.dynK = mdyn[i]; g.dynK_mul = mmul[i] * u;
         // algorithmic flops of the op this replaces: geqrf + orgqr of (rows x cols)
         prof_begin(PROF_GRAM, nw_ * 2.0 * (2.0 * rows * (double)cols * cols - 2.0 / 3.0 * (double)cols * cols * cols),
                    2.0 * nw_ * (double)cols * cols * rows);
@@ -122,14 +135,23 @@ void Engine<T>::absorb(int pos, int num) {
         prof_end();
       }
       R[i + 1] = alloc_ten(cols, l2, a2);
-      size_t smem = sizeof(double) * ((size_t)CH_NB * cols + 64 * CH_NB);
-      PG_REQUIRE(smem <= 150 * 1024, 1, "Cholesky panel does not fit LDS (D*chi too large)");
+      const size_t smem = chol_smem_bytes(cols);
+      PG_REQUIRE(smem <= 150 * 1024 && cols < 32768, 1, "Cholesky panel does not fit LDS (D*chi too large)");
       allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
+      int *ml = adaptive ? (int *)arena_.alloc(sizeof(int) * nw_) : nullptr;
       prof_begin(PROF_CHOL, 0.0, nw_ * (double)cols * cols * cols / 3.0);
       hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nw_), dim3(256), smem, stream_, G, (long)cols * cols, cols,
-                         R[i + 1].p, R[i + 1].n);
+                         R[i + 1].p, R[i + 1].n, ml);
       PG_CHECK_HIP(hipGetLastError());
       prof_end();
+      if (dbg_sweeps_ && ml) {   // diagnostics: numerical rank of the carry (forces a sync)
+        std::vector<int> h(nw_);
+        PG_CHECK_HIP(hipMemcpyAsync(h.data(), ml, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+        PG_CHECK_HIP(hipStreamSynchronize(stream_));
+        for (int v : h) { live_sum_ += v; live_full_ += cols; }
+      }
+      mdyn[i + 1] = ml;
+      mmul[i + 1] = 1;
       arena_.free(G);
       free_ten(P);
     }
@@ -196,6 +218,7 @@ void Engine<T>::absorb(int pos, int num) {
       g.K[2] = la; g.sAk[2] = 1; g.sBk[2] = uk;
       g.J[2] = uk; g.sBj[2] = 1; g.sCj[2] = 1;
       g.wA = R[i].n; g.wB = Tt.n; g.wC = M.n; g.nbatch = nw_;
+      g.dynI = mdyn[i]; g.dynI_mul = mmul[i];
       prof_begin(PROF_CONTRACT, 0.0, 2.0 * nw_ * (double)m * la * (double)uk);
       tgemm_launch<T, T, T, T>(stream_, g, R[i].p, Tt.p, M.p);
       prof_end();
@@ -211,7 +234,7 @@ void Engine<T>::absorb(int pos, int num) {
         const bool bulk = sizeof(T) == 4 && !use_lds && m <= 256 && uk <= 256;
         prof_begin(bulk ? PROF_JACOBI : 7, nw_ * (4.0 * rr * cc * cc + 22.0 * cc * cc * cc), 0.0);
       }
-      launch_jacobi(M.p, M.n, m, uk, use_lds, need);
+      launch_jacobi(M.p, M.n, m, uk, use_lds, need, mdyn[i], mmul[i]);
       prof_end();
       ++n_jacobi_;
       if (dbg_sweeps_) {   // diagnostics only: per-launch sweep counts (forces a sync)
@@ -232,7 +255,7 @@ void Engine<T>::absorb(int pos, int num) {
     DTen<T> V = alloc_ten(k, u, k2);
     prof_begin(PROF_SELECT, 0.0, 0.0);
     hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)M.p, M.n, m, uk, uk, k, V.p,
-                       V.n, (T *)nullptr, 0L);
+                       V.n, (T *)nullptr, 0L, (const int *)mdyn[i], mmul[i]);
     PG_CHECK_HIP(hipGetLastError());
     prof_end();
     free_ten(M);
@@ -260,6 +283,11 @@ void Engine<T>::absorb(int pos, int num) {
     Y = Yn;
   }
   for (auto &t : R) arena_.free(t.p);
+  {   // the dynamic-extent arrays (several R_i may share one)
+    int *last = nullptr;
+    for (int *p : mdyn)
+      if (p && p != last) { arena_.free(p); last = p; }
+  }
   bmps_[pos].push_back(std::move(out));
   ++n_absorb_;
 }

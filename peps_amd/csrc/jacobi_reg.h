@@ -83,8 +83,10 @@ constexpr int JR_NW = 8;         // waves
 constexpr int JR_SLOTS = JR_NW + 1;
 
 __global__ __launch_bounds__(512) void jacobi_rows_reg256_kernel(float *__restrict__ Mg, long wM, int m, int len, int ld,
-                                                                 int max_sweeps, int *__restrict__ sweeps_out) {
+                                                                 int max_sweeps, int *__restrict__ sweeps_out,
+                                                                 const int *__restrict__ mdyn, int mdyn_mul) {
   __shared__ float4 xch[JR_SLOTS][JR_BR][64];   // 9 x 16 KiB
+  if (mdyn) m = min(m, mdyn[blockIdx.x] * mdyn_mul);   // rows that exist for this walker
   __shared__ float xnorm[JR_SLOTS][JR_BR];
   __shared__ float s_n2[256];
   __shared__ short s_perm[256];

@@ -27,20 +27,34 @@ __device__ __forceinline__ T wave_sum(T v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// In-place upper Cholesky of the symmetric PSD matrix G (n x n, row-major, f64): on exit the
-// upper triangle holds R with R^T R = G.  A pivot below n*eps*max(diag) zeroes its row (the
-// direction carries no weight).  Then R * out_scale is written as type T (zeros below the
-// diagonal) to Rout (n x n row-major).  One 256-thread block per batch entry.
+// In-place upper Cholesky of the symmetric PSD Gram matrix G (n x n, row-major, f64) and rank
+// compaction of the factor.  R^T R = G; a pivot below max(n*eps64, (NOISE_C*eps_T)^2) * max(diag)
+// zeroes its row: that direction carries less weight than the rounding of the T-typed data the
+// Gram was built from.  The left-looking update only visits live rows, so the cost follows the
+// numerical rank.  On exit the live rows (norm above NOISE_C*eps_T*|R|_F), in their original
+// order, are written as type T to the first mlive rows of Rout (n x n row-major, scaled by
+// 1/sqrt(max diag)); the remaining rows are zero and mlive_out[b] = mlive.  Only R^T R matters
+// downstream, so dropping and reordering rows is free.  One 256-thread block per batch entry.
 constexpr int CH_NB = 16;
+constexpr double NOISE_C = 8.0;
+
+inline size_t chol_smem_bytes(int n) {
+  return sizeof(double) * ((size_t)CH_NB * n + 64 * CH_NB + n) + sizeof(short) * 2 * (size_t)n + 64;
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg, long wG, int n,
-                                                         T *__restrict__ Rg, long wR) {
+                                                         T *__restrict__ Rg, long wR, int *__restrict__ mlive_out) {
   extern __shared__ double ch_smem[];
-  double *sP = ch_smem;                 // [CH_NB][n]   current block row of R
-  double *sK = ch_smem + CH_NB * n;     // [64][CH_NB]  staged R[k][jb..jb+nb)
-  __shared__ double s_piv, s_maxd;
-  const int tid = threadIdx.x;
+  double *sP = ch_smem;                          // [CH_NB][n]   current block row of R
+  double *sK = sP + CH_NB * n;                   // [64][CH_NB]  staged R[list[k]][jb..jb+nb)
+  double *sN = sK + 64 * CH_NB;                  // [n]          row norms^2 of the finished factor
+  short *sList = reinterpret_cast<short *>(sN + n);   // [n] live rows so far
+  short *sPos = sList + n;                             // [n] output position of a row, -1 = dropped
+  __shared__ double s_piv, s_maxd, s_fro;
+  __shared__ double s_red[4];
+  __shared__ int s_nlive;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double *G = Gg + (long)blockIdx.x * wG;
   T *Rout = Rg + (long)blockIdx.x * wR;
 
@@ -48,28 +62,29 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
   for (int i = tid; i < n; i += 256) md = fmax(md, G[(long)i * n + i]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
-  __shared__ double s_red[4];
-  if ((tid & 63) == 0) s_red[tid >> 6] = md;
+  if (lane == 0) s_red[wave] = md;
+  if (tid == 0) s_nlive = 0;
   __syncthreads();
   if (tid == 0) s_maxd = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
   __syncthreads();
   const double maxd = s_maxd;
-  const double thresh = (double)n * 2.220446049250313e-16 * maxd;
+  const double eT = NOISE_C * (double)Eps<T>::v;
+  const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
 
   for (int jb = 0; jb < n; jb += CH_NB) {
     const int nb = min(CH_NB, n - jb);
-    // panel init from G
     for (int e = tid; e < nb * n; e += 256) {
       int c = e / n, r = e % n;
       sP[c * n + r] = (r >= jb) ? G[(long)(jb + c) * n + r] : 0.0;
     }
     __syncthreads();
-    // left-looking update with the finished rows k < jb (held in G's upper triangle)
-    for (int k0 = 0; k0 < jb; k0 += 64) {
-      const int kc = min(64, jb - k0);
+    // left-looking update with the finished LIVE rows (held in G's upper triangle)
+    const int nprev = s_nlive;
+    for (int k0 = 0; k0 < nprev; k0 += 64) {
+      const int kc = min(64, nprev - k0);
       for (int e = tid; e < kc * nb; e += 256) {
         int k = e / nb, c = e % nb;
-        sK[k * CH_NB + c] = G[(long)(k0 + k) * n + jb + c];
+        sK[k * CH_NB + c] = G[(long)sList[k0 + k] * n + jb + c];
       }
       __syncthreads();
       for (int r = jb + tid; r < n; r += 256) {
@@ -77,7 +92,7 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
 #pragma unroll
         for (int c = 0; c < CH_NB; ++c) acc[c] = 0.0;
         for (int k = 0; k < kc; ++k) {
-          double rv = G[(long)(k0 + k) * n + r];
+          double rv = G[(long)sList[k0 + k] * n + r];
 #pragma unroll
           for (int c = 0; c < CH_NB; ++c) acc[c] += sK[k * CH_NB + c] * rv;
         }
@@ -95,10 +110,13 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
       const bool ok = piv > thresh;
       const double inv = ok ? 1.0 / sqrt(piv) : 0.0;
       for (int r = jb + c + tid; r < n; r += 256) sP[c * n + r] *= inv;
+      if (tid == 0 && ok) { sList[s_nlive] = (short)(jb + c); s_nlive = s_nlive + 1; }
       __syncthreads();
-      for (int e = tid; e < (nb - c - 1) * (n - jb); e += 256) {
-        int c2 = c + 1 + e / (n - jb), r = jb + e % (n - jb);
-        if (r >= jb + c2) sP[c2 * n + r] -= sP[c * n + jb + c2] * sP[c * n + r];
+      if (ok) {
+        for (int e = tid; e < (nb - c - 1) * (n - jb); e += 256) {
+          int c2 = c + 1 + e / (n - jb), r = jb + e % (n - jb);
+          if (r >= jb + c2) sP[c2 * n + r] -= sP[c * n + jb + c2] * sP[c * n + r];
+        }
       }
       __syncthreads();
     }
@@ -109,11 +127,44 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
     }
     __syncthreads();
   }
+  // ---- rank compaction: rows with norm below NOISE_C*eps_T*|R|_F are dropped ----
+  for (int k = wave; k < n; k += 4) {
+    double a = 0.0;
+    for (int r = k + lane; r < n; r += 64) { double x = G[(long)k * n + r]; a += x * x; }
+    a = wave_sum(a);
+    if (lane == 0) sN[k] = a;
+  }
+  __syncthreads();
+  {
+    double f = 0.0;
+    for (int k = tid; k < n; k += 256) f += sN[k];
+    f = wave_sum(f);
+    if (lane == 0) s_red[wave] = f;
+    __syncthreads();
+    if (tid == 0) s_fro = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+  }
+  const double nfloor = eT * eT * s_fro;
+  if (wave == 0) {
+    int cnt = 0;
+    for (int base = 0; base < n; base += 64) {
+      const int k = base + lane;
+      const bool f = k < n && sN[k] > nfloor;
+      const unsigned long long mask = __ballot(f);
+      if (k < n) sPos[k] = f ? (short)(cnt + __popcll(mask & ((1ull << lane) - 1ull))) : (short)-1;
+      cnt += __popcll(mask);
+    }
+    if (lane == 0) { s_nlive = cnt; if (mlive_out) mlive_out[blockIdx.x] = cnt; }
+  }
+  __syncthreads();
+  const int mlive = s_nlive;
   const double sc = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
   for (int e = tid; e < n * n; e += 256) {
     int k = e / n, r = e % n;
-    Rout[e] = (r >= k) ? T(G[e] * sc) : T(0);
+    const int pos = sPos[k];
+    if (pos >= 0) Rout[(long)pos * n + r] = (r >= k) ? T(G[e] * sc) : T(0);
   }
+  for (int e = tid + mlive * n; e < n * n; e += 256) Rout[e] = T(0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -122,13 +173,15 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
 // the rotations) are numerically zero and take no part: with more rows than the rank (m > len,
 // or a rank-deficient carry) the surplus rows can never become "relatively" orthogonal.  The
 // working copy lives in LDS when it fits (use_lds), else in global memory (L2-resident).
-constexpr double NOISE_C = 8.0;
+// mdyn (optional): per-walker number of existing rows, mdyn[b]*mdyn_mul <= m (rank-adaptive carry).
 template <typename T>
 __global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, long wM, int m, int len,
                                                            int ld, int max_sweeps, int use_lds,
-                                                           int *__restrict__ sweeps_out) {
+                                                           int *__restrict__ sweeps_out,
+                                                           const int *__restrict__ mdyn, int mdyn_mul) {
   extern __shared__ unsigned char jc_smem_raw[];
   T *sM = reinterpret_cast<T *>(jc_smem_raw);
+  if (mdyn) m = min(m, mdyn[blockIdx.x] * mdyn_mul);
   __shared__ int s_rot;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   T *Mglob = Mg + (long)blockIdx.x * wM;
@@ -238,12 +291,17 @@ __global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, l
 template <typename T>
 __global__ __launch_bounds__(256) void select_rows_kernel(const T *__restrict__ Mg, long wM, int m, int len,
                                                           int ld, int k, T *__restrict__ Vg, long wV,
-                                                          T *__restrict__ Sg, long wS) {
+                                                          T *__restrict__ Sg, long wS,
+                                                          const int *__restrict__ mdyn, int mdyn_mul) {
   __shared__ double s_norm[1024];
   __shared__ int s_rank[1024];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T *M = Mg + (long)blockIdx.x * wM;
   T *V = Vg + (long)blockIdx.x * wV;
+  if (mdyn) m = min(m, mdyn[blockIdx.x] * mdyn_mul);
+  // fewer existing rows than kept bonds: the surplus rows of Vt are zero
+  for (int e = tid + min(m, k) * len; e < k * len; e += 256) V[e] = T(0);
+  if (Sg) for (int r = min(m, k) + tid; r < k; r += 256) Sg[(long)blockIdx.x * wS + r] = T(0);
   for (int r = wave; r < m; r += 4) {
     double a = 0.0;
     for (int c = lane; c < len; c += 64) { double x = (double)M[(long)r * ld + c]; a += x * x; }
@@ -277,11 +335,13 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const T *__restrict__ 
 // x[b][0..n) /= |x|;  logscale[b] += log|x|;  zero / non-finite norm sets flag[b] = 1.
 template <typename T>
 __global__ __launch_bounds__(256) void normalize_kernel(T *__restrict__ Xg, long wX, int n,
-                                                        double *__restrict__ logscale, int *__restrict__ flag) {
+                                                        double *__restrict__ logscale, int *__restrict__ flag,
+                                                        const int *__restrict__ ndyn, int ndyn_mul) {
   __shared__ double s_red[4];
   __shared__ double s_nrm;
   const int tid = threadIdx.x;
   T *X = Xg + (long)blockIdx.x * wX;
+  if (ndyn) n = min(n, ndyn[blockIdx.x] * ndyn_mul);
   double a = 0.0;
   for (int i = tid; i < n; i += 256) { double x = (double)X[i]; a += x * x; }
   a = wave_sum(a);

@@ -29,6 +29,10 @@ struct TGemmDesc {
   long selA_mul = 0, selB_mul = 0;   // base += sel * mul
   int bdivA = 1, bdivB = 1, bdivC = 1;  // operand batch index = b / bdiv (candidates share env.)
   int seldivA = 1, seldivB = 1;         // selector index = (b / seldiv) * inc
+  // Per-walker dynamic extents (rank-adaptive carry): only the first dynI[b]*dynI_mul values of the
+  // flattened I index (resp. K index) exist; tiles beyond exit at once, C rows beyond are not written.
+  const int *dynI = nullptr, *dynK = nullptr;
+  int dynI_mul = 1, dynK_mul = 1;
   int nbatch = 1;
   int accumulate = 0;
   double alpha = 1.0;
@@ -66,7 +70,11 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__res
   const int tid = threadIdx.x;
   const int b = blockIdx.z;
   const int i0 = blockIdx.x * TG_BM, j0 = blockIdx.y * TG_BN;
-  const int Itot = d.Itot(), Jtot = d.Jtot(), Ktot = d.Ktot();
+  int Itot = d.Itot(), Ktot = d.Ktot();
+  const int Jtot = d.Jtot();
+  if (d.dynI) Itot = min(Itot, d.dynI[b] * d.dynI_mul);
+  if (d.dynK) Ktot = min(Ktot, d.dynK[b] * d.dynK_mul);
+  if (i0 >= Itot) return;   // block-uniform: this tile lies beyond the walker's live extent
 
   long baseA = (long)(b / d.bdivA) * d.wA, baseB = (long)(b / d.bdivB) * d.wB;
   if (d.selA) baseA += (long)d.selA[(long)(b / d.seldivA) * d.selA_inc] * d.selA_mul;
