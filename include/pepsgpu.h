@@ -95,6 +95,18 @@ int pepsgpu_replace_one_trace(pepsgpu_ctx *ctx, int row, int col, int mps_orient
                               const int32_t *cand_states, double *out_amp);
 /* PunchHole(tn, site, mps_orient)  grow.h:150-183.  out = [n][D][D][D][D] float64 (legs L,D,R,U, zero padded). */
 int pepsgpu_punch_hole(pepsgpu_ctx *ctx, int row, int col, int mps_orient, double *out);
+/* out == NULL: the hole of every walker stays on the device (resident hole store) for
+ * pepsgpu_grad_accumulate.  The three calls below replace the per-sample accumulation loop
+ * Ostar_sum += O*, ELocConj_Ostar_sum += E_loc^* O* (mc_energy_grad_evaluator.h:257-278; exact
+ * summation: exact_summation_energy_evaluator.h:218-239) without moving the holes over PCIe:
+ *   O*(site)[config_w(site)] = hole_w(site) / psi_w            (exact_sum = 0, weight 1)
+ *   |psi|^2 O*               = psi_w * hole_w(site)            (exact_sum = 1)
+ * psi, eloc = [n] host arrays (the solver's scalars).  pepsgpu_grad_read returns S_O and S_EO in the
+ * state layout [row][col][s][L][D][R][U]; the cross-rank mean is one all-reduce of those buffers
+ * (replaces MPIMeanTensor, statistics_tensor.h:37-79). */
+int pepsgpu_grad_reset(pepsgpu_ctx *ctx);
+int pepsgpu_grad_accumulate(pepsgpu_ctx *ctx, const double *psi, const double *eloc, int exact_sum);
+int pepsgpu_grad_read(pepsgpu_ctx *ctx, double *s_o_out, double *s_eo_out);
 
 /* TPSWaveFunctionComponent::UpdateLocal (wave_function_component.h:345-378) for the walkers with
  * accept_mask[w] != 0 (NULL = all): config(site_k) = new_states[w][k], tn.UpdateSiteTensor,

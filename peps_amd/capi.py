@@ -26,6 +26,7 @@ SYMBOLS = [
     "pepsgpu_bmps_stack_size", "pepsgpu_get_bmps_tensor", "pepsgpu_init_bten", "pepsgpu_grow_full_bten",
     "pepsgpu_grow_bten_step", "pepsgpu_shift_bten_window", "pepsgpu_truncate_bten", "pepsgpu_bten_stack_size",
     "pepsgpu_trace", "pepsgpu_replace_nn_trace", "pepsgpu_replace_one_trace", "pepsgpu_punch_hole",
+    "pepsgpu_grad_reset", "pepsgpu_grad_accumulate", "pepsgpu_grad_read",
     "pepsgpu_update_local", "pepsgpu_erase_envs_after_update", "pepsgpu_evaluate_amplitude",
     "pepsgpu_walker_flags", "pepsgpu_sync", "pepsgpu_stats", "pepsgpu_profile_enable", "pepsgpu_profile_read",
     "pepsgpu_diag_tgemm", "pepsgpu_diag_chol", "pepsgpu_diag_jacobi", "pepsgpu_version",
@@ -59,6 +60,9 @@ def load_library(path=LIB_PATH):
     lib.pepsgpu_replace_nn_trace.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp]
     lib.pepsgpu_replace_one_trace.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp]
     lib.pepsgpu_punch_hole.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
+    lib.pepsgpu_grad_reset.argtypes = [vp]
+    lib.pepsgpu_grad_accumulate.argtypes = [vp, dp, dp, C.c_int]
+    lib.pepsgpu_grad_read.argtypes = [vp, dp, dp]
     lib.pepsgpu_update_local.argtypes = [vp, C.c_int, ip, ip, C.POINTER(C.c_uint8)]
     lib.pepsgpu_erase_envs_after_update.argtypes = [vp, C.c_int, C.c_int]
     lib.pepsgpu_evaluate_amplitude.argtypes = [vp, dp]
@@ -192,6 +196,23 @@ class Context:
         out = np.zeros((self.n, self.D, self.D, self.D, self.D), dtype=np.float64)
         self._ck(self._l.pepsgpu_punch_hole(self._h, row, col, orient, _dp(out)))
         return out
+
+    def punch_hole_store(self, row, col, orient):
+        self._ck(self._l.pepsgpu_punch_hole(self._h, row, col, orient, None))
+
+    def grad_reset(self):
+        self._ck(self._l.pepsgpu_grad_reset(self._h))
+
+    def grad_accumulate(self, psi, eloc, exact_sum=False):
+        psi = np.ascontiguousarray(psi, dtype=np.float64)
+        eloc = np.ascontiguousarray(eloc, dtype=np.float64)
+        self._ck(self._l.pepsgpu_grad_accumulate(self._h, _dp(psi), _dp(eloc), int(exact_sum)))
+
+    def grad_read(self):
+        shp = (self.rows, self.cols, self.d, self.D, self.D, self.D, self.D)
+        so, seo = np.zeros(shp), np.zeros(shp)
+        self._ck(self._l.pepsgpu_grad_read(self._h, _dp(so), _dp(seo)))
+        return so, seo
 
     def update_local(self, sites, new_states, accept_mask=None):
         sites = np.ascontiguousarray(sites, dtype=np.int32).reshape(-1, 2)

@@ -131,6 +131,13 @@ int pepsgpu_replace_one_trace(pepsgpu_ctx *ctx, int row, int col, int orient, in
 int pepsgpu_punch_hole(pepsgpu_ctx *ctx, int row, int col, int orient, double *out) {
   CTX_CALL(ctx->eng->punch_hole(row, col, orient, out));
 }
+int pepsgpu_grad_reset(pepsgpu_ctx *ctx) { CTX_CALL(ctx->eng->grad_reset()); }
+int pepsgpu_grad_accumulate(pepsgpu_ctx *ctx, const double *psi, const double *eloc, int exact_sum) {
+  CTX_CALL(PG_REQUIRE(psi && eloc, 1, "null psi / eloc"); ctx->eng->grad_accumulate(psi, eloc, exact_sum));
+}
+int pepsgpu_grad_read(pepsgpu_ctx *ctx, double *so, double *seo) {
+  CTX_CALL(PG_REQUIRE(so && seo, 1, "null output"); ctx->eng->grad_read(so, seo));
+}
 int pepsgpu_update_local(pepsgpu_ctx *ctx, int nsites, const int32_t *sites, const int32_t *ns, const uint8_t *mask) {
   CTX_CALL(ctx->eng->update_local(nsites, sites, ns, mask));
 }

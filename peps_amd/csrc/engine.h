@@ -64,6 +64,9 @@ struct EngineBase {
   virtual void read_flags(int32_t *out) = 0;
   virtual size_t device_bytes() const = 0;
   virtual void stats(double *out, int n) = 0;
+  virtual void grad_reset() = 0;
+  virtual void grad_accumulate(const double *psi, const double *eloc, int exact_sum) = 0;
+  virtual void grad_read(double *so, double *seo) = 0;
   virtual void profile_enable(int on) = 0;
   virtual void profile_read(double *out) = 0;   // [PROF_NCAT][4]: ms, launches, algorithmic flops, executed flops
 };
@@ -430,6 +433,22 @@ class Engine : public EngineBase {
       g.wA = tmp1.n; g.wB = tmp2.n; g.wC = res.n; g.nbatch = nw_;
       tgemm_launch<T, T, T, T>(stream_, g, tmp1.p, tmp2.p, res.p);
     }
+    if (out == nullptr) {
+      // store mode: the hole stays on the device (mantissa in its D^4 slot, compact, + log-scale)
+      // for grad_accumulate -- mc_energy_grad_evaluator.h:257-278 without the PCIe round trip
+      const int sites = Ly_ * Lx_, site = row * Lx_ + col;
+      if (!holes_) {
+        holes_ = (T *)arena_.alloc(sizeof(T) * (size_t)maxw_ * sites * slot_);
+        holes_ls_ = (double *)arena_.alloc(sizeof(double) * (size_t)maxw_ * sites);
+      }
+      hipLaunchKernelGGL(store_hole_kernel<T>, dim3((unsigned)((res.n + 255) / 256), nw_), dim3(256), 0, stream_,
+                         (const T *)res.p, res.n, holes_ + (long)site * slot_, (long)sites * slot_, (const double *)lsum,
+                         holes_ls_ + site, sites);
+      PG_CHECK_HIP(hipGetLastError());
+      free_ten(tmp1); free_ten(tmp2); free_ten(res);
+      arena_.free(lsum);
+      return;
+    }
     std::vector<T> h((size_t)res.n * nw_);
     std::vector<double> hl(nw_);
     PG_CHECK_HIP(hipMemcpyAsync(h.data(), res.p, h.size() * sizeof(T), hipMemcpyDeviceToHost, stream_));
@@ -449,6 +468,68 @@ class Engine : public EngineBase {
     }
     free_ten(tmp1); free_ten(tmp2); free_ten(res);
     arena_.free(lsum);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Device-resident gradient accumulators S_O = sum w O*, S_EO = sum w E_loc O* over everything
+  // accumulated since grad_reset(): layout [row][col][s][D^4 slot] (compact inside the slot).
+  void grad_reset() override {
+    const size_t n = (size_t)Ly_ * Lx_ * dp_ * slot_;
+    if (!so_) {
+      so_ = (double *)arena_.alloc(sizeof(double) * n);
+      seo_ = (double *)arena_.alloc(sizeof(double) * n);
+    }
+    PG_CHECK_HIP(hipMemsetAsync(so_, 0, sizeof(double) * n, stream_));
+    PG_CHECK_HIP(hipMemsetAsync(seo_, 0, sizeof(double) * n, stream_));
+  }
+  // psi[w], eloc[w] from the host (the solver's scalars).  MC: O* = hole / psi (weight 1)
+  // (mc_energy_grad_evaluator.h:266); exact summation: |psi|^2 O* = psi * hole
+  // (exact_summation_energy_evaluator.h:231).
+  void grad_accumulate(const double *psi, const double *eloc, int exact_sum) override {
+    require_ready();
+    PG_REQUIRE(holes_ != nullptr, 3, "grad_accumulate: no holes stored (pepsgpu_punch_hole with out == NULL)");
+    if (!so_) grad_reset();
+    std::vector<double> h(3 * (size_t)nw_);
+    for (int w = 0; w < nw_; ++w) {
+      PG_REQUIRE(psi[w] != 0.0, 5, "Wavefunction amplitude is near zero, causing division by zero.");
+      h[w] = (exact_sum ? 1.0 : -1.0) * std::log(std::fabs(psi[w]));
+      h[nw_ + w] = psi[w] < 0 ? -1.0 : 1.0;
+      h[2 * nw_ + w] = eloc[w];
+    }
+    double *d = (double *)arena_.alloc(sizeof(double) * h.size());
+    PG_CHECK_HIP(hipMemcpyAsync(d, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, stream_));
+    PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    const int sites = Ly_ * Lx_;
+    hipLaunchKernelGGL(grad_accumulate_kernel<T>, dim3((unsigned)((slot_ + 255) / 256), sites), dim3(256), 0, stream_,
+                       (const T *)holes_, (const double *)holes_ls_, (const int *)cfg_, (const double *)d,
+                       (const double *)(d + nw_), (const double *)(d + 2 * nw_), so_, seo_, nw_, sites, slot_, dp_);
+    PG_CHECK_HIP(hipGetLastError());
+    arena_.free(d);
+  }
+  // out layout = state upload layout [row][col][s][L][D][R][U] zero padded to D
+  void grad_read(double *so, double *seo) override {
+    PG_REQUIRE(so_ != nullptr, 3, "grad_read: nothing accumulated");
+    const size_t n = (size_t)Ly_ * Lx_ * dp_ * slot_;
+    std::vector<double> h(n);
+    for (int pass = 0; pass < 2; ++pass) {
+      double *dst = pass ? seo : so;
+      PG_CHECK_HIP(hipMemcpyAsync(h.data(), pass ? seo_ : so_, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+      PG_CHECK_HIP(hipStreamSynchronize(stream_));
+      std::fill(dst, dst + n, 0.0);
+      for (int r = 0; r < Ly_; ++r)
+        for (int c = 0; c < Lx_; ++c) {
+          int dd[4];
+          site_dims(r, c, dd);
+          for (int s = 0; s < dp_; ++s) {
+            const size_t base = ((size_t)(r * Lx_ + c) * dp_ + s) * slot_;
+            size_t o = 0;
+            for (int a = 0; a < dd[0]; ++a)
+              for (int b = 0; b < dd[1]; ++b)
+                for (int cc = 0; cc < dd[2]; ++cc)
+                  for (int e = 0; e < dd[3]; ++e) dst[base + (((size_t)a * D_ + b) * D_ + cc) * D_ + e] = h[base + o++];
+          }
+        }
+    }
   }
 
   // ------------------------------------------------------------------------------------------
@@ -745,6 +826,9 @@ class Engine : public EngineBase {
   long prof_n_[PROF_NCAT] = {0};
   long n_absorb_ = 0, n_jacobi_ = 0, jacobi_sweeps_sum_ = 0, jacobi_sweeps_max_ = 0;
   double live_sum_ = 0, live_full_ = 0;   // diagnostics: sum of live carry rows / sum of carry sizes
+  T *holes_ = nullptr;                    // resident hole store [walker][site][D^4]
+  double *holes_ls_ = nullptr;            // its log-scales [walker][site]
+  double *so_ = nullptr, *seo_ = nullptr; // gradient accumulators
   int *sweeps_ = nullptr;
   bool dbg_sweeps_ = false;
 };

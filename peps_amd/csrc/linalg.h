@@ -365,4 +365,40 @@ __global__ void fill_kernel(T *p, long n, T v) {
   if (i < n) p[i] = v;
 }
 
+// hole of one site for every walker -> the resident hole store (grid.y = walker)
+template <typename T>
+__global__ void store_hole_kernel(const T *__restrict__ src, long n, T *__restrict__ dst, long wdst,
+                                  const double *__restrict__ ls, double *__restrict__ ls_dst, int ls_stride) {
+  const int w = blockIdx.y;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[(long)w * wdst + i] = src[(long)w * n + i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) ls_dst[(long)w * ls_stride] = ls[w];
+}
+
+// S_O[site][config_w(site)] += f_w hole_w(site),  S_EO += e_w f_w hole_w(site), f_w = sgn_w exp(ls - logabs_w)
+// (mc_energy_grad_evaluator.h:257-278 / exact_summation_energy_evaluator.h:218-239, fused over walkers;
+// deterministic: one thread owns one element of one site and loops over the walkers).
+template <typename T>
+__global__ __launch_bounds__(256) void grad_accumulate_kernel(const T *__restrict__ holes, const double *__restrict__ holes_ls,
+                                                              const int *__restrict__ cfg, const double *__restrict__ logf,
+                                                              const double *__restrict__ sgn, const double *__restrict__ ew,
+                                                              double *__restrict__ so, double *__restrict__ seo, int nw,
+                                                              int sites, long slot, int dp) {
+  const int site = blockIdx.y;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= slot) return;
+  for (int s = 0; s < dp; ++s) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < nw; ++w) {
+      if (cfg[(long)w * sites + site] != s) continue;
+      const double f = sgn[w] * exp(holes_ls[(long)w * sites + site] + logf[w]);
+      const double v = f * (double)holes[((long)w * sites + site) * slot + e];
+      a += v;
+      b += ew[w] * v;
+    }
+    so[((long)site * dp + s) * slot + e] += a;
+    seo[((long)site * dp + s) * slot + e] += b;
+  }
+}
+
 }  // namespace pepsgpu

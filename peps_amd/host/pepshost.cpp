@@ -87,6 +87,41 @@ int pepshost_energy_and_holes(int rows, int cols, int D, int d, int chi, int dty
   });
 }
 
+// Rank-local part of MCEnergyGradEvaluator::Evaluate (mc_energy_grad_evaluator.h:205-310): warm-up
+// sweeps, then n_samples x {one MC sweep, CalEnergyAndHoles, O* accumulation}; the holes and the
+// tensor sums stay on the device.  packed_out as in pepshost_exact_sum_partial (weight 1 per sample);
+// the caller all-reduces it over ranks and calls pepshost_exact_sum_finish.
+int pepshost_mc_energy_grad_partial(int rows, int cols, int D, int d, int chi, int dtype, const double *sitps_flat, int n,
+                                    int32_t *configs, const uint64_t *seeds, int updater, int model, const double *p,
+                                    int warmup_sweeps, int n_samples, double *packed_out, double *accept_out) {
+  return guarded([&]() {
+    SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
+    BMPSContractor contractor(rows, cols, D, d, BMPSTruncateParams::SVD(chi, chi, 0.0), n, dtype);
+    TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor);
+    std::vector<uint64_t> sd(seeds, seeds + n);
+    MCUpdateSquareNNExchangeOBC ex(sd);
+    MCUpdateSquareNNFullSpaceUpdateOBC fs(sd);
+    std::vector<double> rates, acc_rate(n, 0.0);
+    auto sweep = [&]() { if (updater == 0) ex(sitps, comp, rates); else fs(sitps, comp, rates); };
+    for (int s = 0; s < warmup_sweeps; ++s) sweep();
+    SquareSpinOneHalfXXZModelOBC xxz(p[0], p[1], p[2]);
+    TransverseFieldIsingSquareOBC tfim(p[0]);
+    GradAccumulator acc(sitps);
+    contractor.GradReset();
+    for (int k = 0; k < n_samples; ++k) {
+      sweep();
+      for (int w = 0; w < n; ++w) acc_rate[w] += rates[w];
+      EnergyAndHoles eh = model == 0 ? xxz.CalEnergyAndHoles<true>(sitps, comp, true) : tfim.CalEnergyAndHoles<true>(sitps, comp, true);
+      acc.AccumulateDevice(comp, eh, false);
+    }
+    if (n_samples > 0) acc.FetchDevice(contractor);
+    std::vector<double> packed = acc.Pack();
+    std::copy(packed.begin(), packed.end(), packed_out);
+    std::copy(comp.config.data(), comp.config.data() + (size_t)n * rows * cols, configs);
+    if (accept_out) for (int w = 0; w < n; ++w) accept_out[w] = n_samples ? acc_rate[w] / n_samples : 0.0;
+  });
+}
+
 // Rank-local part of ExactSumEnergyEvaluatorMPI (exact_summation_energy_evaluator.h:173-245):
 // packed_out = [S_O | S_EO | sum w | sum wE | sum wE^2 | samples], length 2*rows*cols*d*D^4 + 4.
 int pepshost_exact_sum_partial(int rows, int cols, int D, int d, int chi, int dtype, const double *sitps_flat,

@@ -213,6 +213,19 @@ class BMPSContractor {
     check_rc(pepsgpu_punch_hole(ctx_, (int)s.r, (int)s.c, orient, out.data()), ctx_);
     return out;
   }
+  // Device-resident variant: the hole stays in HBM for GradAccumulate (no PCIe round trip)
+  void PunchHoleStore(const SiteIdx &s, BondOrientation orient) {
+    check_rc(pepsgpu_punch_hole(ctx_, (int)s.r, (int)s.c, orient, nullptr), ctx_);
+  }
+  void GradReset() { check_rc(pepsgpu_grad_reset(ctx_), ctx_); }
+  void GradAccumulate(const std::vector<double> &psi, const std::vector<double> &eloc, bool exact_sum) {
+    check_rc(pepsgpu_grad_accumulate(ctx_, psi.data(), eloc.data(), exact_sum), ctx_);
+  }
+  void GradRead(std::vector<double> &so, std::vector<double> &seo) const {
+    const size_t n = rows_ * cols_ * d_ * D_ * D_ * D_ * D_;
+    so.resize(n); seo.resize(n);
+    check_rc(pepsgpu_grad_read(ctx_, so.data(), seo.data()), ctx_);
+  }
   void UpdateLocal(const std::vector<int32_t> &sites, const std::vector<int32_t> &new_states, const std::vector<uint8_t> &mask) {
     check_rc(pepsgpu_update_local(ctx_, (int)(sites.size() / 2), sites.data(), new_states.data(), mask.data()), ctx_);
   }
@@ -430,12 +443,12 @@ template <class ExplicitlyModel>
 class SquareNNModelEnergySolver {
  public:
   template <bool calchols = true>
-  EnergyAndHoles CalEnergyAndHoles(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp) {
+  EnergyAndHoles CalEnergyAndHoles(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp, bool holes_on_device = false) {
     auto &c = comp.contractor;
     const size_t rows = c.rows(), cols = c.cols(), n = comp.config.walkers(), slot = sitps.slot();
     EnergyAndHoles out;
     out.energy.assign(n, 0.0);
-    if (calchols) out.holes.assign(n * rows * cols * slot, 0.0);
+    if (calchols && !holes_on_device) out.holes.assign(n * rows * cols * slot, 0.0);
     auto *self = static_cast<ExplicitlyModel *>(this);
     c.GenerateBMPSApproach(UP);                                              // :116
     for (size_t row = 0; row < rows; row++) {
@@ -449,7 +462,9 @@ class SquareNNModelEnergySolver {
       }
       out.psi_list.push_back(psi);
       for (size_t col = 0; col < cols; col++) {
-        if (calchols) {
+        if (calchols && holes_on_device) {
+          c.PunchHoleStore({row, col}, HORIZONTAL);                           // :163, hole kept in HBM
+        } else if (calchols) {
           std::vector<double> h = c.PunchHole({row, col}, HORIZONTAL);        // :163
           for (size_t w = 0; w < n; ++w)
             std::copy(h.begin() + w * slot, h.begin() + (w + 1) * slot, out.holes.begin() + ((w * rows + row) * cols + col) * slot);
@@ -527,12 +542,12 @@ class TransverseFieldIsingSquareOBC {
     return e;
   }
   template <bool calchols = true>
-  EnergyAndHoles CalEnergyAndHoles(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp) {   // :211-247
+  EnergyAndHoles CalEnergyAndHoles(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp, bool holes_on_device = false) {   // :211-247
     auto &c = comp.contractor;
     const size_t rows = c.rows(), cols = c.cols(), n = comp.config.walkers(), slot = sitps.slot();
     EnergyAndHoles out;
     out.energy.assign(n, 0.0);
-    if (calchols) out.holes.assign(n * rows * cols * slot, 0.0);
+    if (calchols && !holes_on_device) out.holes.assign(n * rows * cols * slot, 0.0);
     c.GenerateBMPSApproach(UP);
     for (size_t row = 0; row < rows; row++) {
       c.InitBTen(LEFT, row);
@@ -540,7 +555,9 @@ class TransverseFieldIsingSquareOBC {
       std::vector<double> psi = c.Trace({row, 0}, HORIZONTAL);
       out.psi_list.push_back(psi);
       for (size_t col = 0; col < cols; col++) {
-        if (calchols) {
+        if (calchols && holes_on_device) {
+          c.PunchHoleStore({row, col}, HORIZONTAL);
+        } else if (calchols) {
           std::vector<double> h = c.PunchHole({row, col}, HORIZONTAL);
           for (size_t w = 0; w < n; ++w)
             std::copy(h.begin() + w * slot, h.begin() + (w + 1) * slot, out.holes.begin() + ((w * rows + row) * cols + col) * slot);
@@ -590,6 +607,24 @@ struct GradAccumulator {
       e_loc_sq_sum += e * e * wt;
       ++samples;
     }
+  }
+  // Same accumulation with the holes resident on the device (BMPSContractor::PunchHoleStore):
+  // the tensor sums stay in HBM until FetchDevice().
+  void AccumulateDevice(TPSWaveFunctionComponent &comp, const EnergyAndHoles &eh, bool exact_sum) {
+    comp.contractor.GradAccumulate(comp.amplitude, eh.energy, exact_sum);
+    for (size_t w = 0; w < comp.config.walkers(); ++w) {
+      const double psi = comp.amplitude[w], e = eh.energy[w];
+      const double wt = exact_sum ? psi * psi : 1.0;
+      weight_sum += wt; e_loc_sum += e * wt; e_loc_sq_sum += e * e * wt;
+      ++samples;
+    }
+  }
+  void FetchDevice(const BMPSContractor &c) {
+    std::vector<double> so, seo;
+    c.GradRead(so, seo);
+    auto &a = Ostar_sum.flat();
+    auto &b = ELocConj_Ostar_sum.flat();
+    for (size_t k = 0; k < a.size(); ++k) { a[k] += so[k]; b[k] += seo[k]; }
   }
   // Flat view for the cross-rank sum that replaces MPIMeanTensor / MPI_Reduce
   // (statistics_tensor.h:37-79, exact_summation_energy_evaluator.h:252-280): one all-reduce(sum).
@@ -641,14 +676,16 @@ std::pair<double, SplitIndexTPS> ExactSumEnergyEvaluator(const SplitIndexTPS &si
   std::vector<size_t> mine;
   for (size_t i = rank; i < all_configs.size(); i += size) mine.push_back(i);                 // :201
   contractor.UploadState(sitps);
+  contractor.GradReset();
   for (size_t b0 = 0; b0 < mine.size(); b0 += batch) {
     const size_t nb = std::min(batch, mine.size() - b0);
     Configuration cfg(nb, rows, cols);
     for (size_t w = 0; w < nb; ++w) std::copy(all_configs[mine[b0 + w]].begin(), all_configs[mine[b0 + w]].end(), cfg.data() + w * rows * cols);
     TPSWaveFunctionComponent comp(sitps, cfg, contractor);
-    EnergyAndHoles eh = model.template CalEnergyAndHoles<true>(sitps, comp);
-    acc.Accumulate(comp, eh, true);
+    EnergyAndHoles eh = model.template CalEnergyAndHoles<true>(sitps, comp, /*holes_on_device=*/true);
+    acc.AccumulateDevice(comp, eh, true);
   }
+  if (!mine.empty()) acc.FetchDevice(contractor);
   std::vector<double> packed = acc.Pack();
   if (allreduce) allreduce(packed);
   acc.Unpack(packed);

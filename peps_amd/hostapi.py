@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepshost.so")
 
 SYMBOLS = ["pepshost_last_error", "pepshost_mc_sweeps", "pepshost_energy_and_holes", "pepshost_exact_sum_partial",
+           "pepshost_mc_energy_grad_partial",
            "pepshost_exact_sum_finish", "pepshost_load_sitps"]
 
 _lib = None
@@ -99,3 +100,21 @@ def load_sitps(directory, D):
     _ck(lib().pepshost_load_sitps(directory.encode(), D, C.byref(rows), C.byref(cols), C.byref(d),
                                   _p(flat, C.c_double), flat.size))
     return flat
+
+
+def mc_energy_grad_partial(flat, configs, seeds, chi, updater="exchange", model="xxz", params=(1.0, 1.0, 0.0),
+                           warmup_sweeps=1, n_samples=1, dtype=1):
+    """Rank-local MCEnergyGradEvaluator loop; returns (packed accumulators, final configs, accept rates)."""
+    flat = np.ascontiguousarray(flat, dtype=np.float64)
+    rows, cols, d, D = _dims(flat)
+    cfg = np.ascontiguousarray(configs, dtype=np.int32).copy()
+    n = cfg.shape[0]
+    sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+    p = np.array(list(params) + [0.0, 0.0, 0.0], dtype=np.float64)
+    packed = np.zeros(2 * flat.size + 4)
+    acc = np.zeros(n)
+    _ck(lib().pepshost_mc_energy_grad_partial(rows, cols, D, d, chi, dtype, _p(flat, C.c_double), n, _p(cfg, C.c_int32),
+                                              _p(sd, C.c_uint64), 0 if updater == "exchange" else 1,
+                                              0 if model == "xxz" else 1, _p(p, C.c_double), warmup_sweeps, n_samples,
+                                              _p(packed, C.c_double), _p(acc, C.c_double)))
+    return packed, cfg, acc
