@@ -73,8 +73,12 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # test hooks (one-GPU boxes): PEPS_BENCH_BACKEND=gloo PEPS_BENCH_NDEV=1 runs N ranks on one device
+        backend = os.environ.get("PEPS_BENCH_BACKEND", "nccl")
+        ndev = int(os.environ.get("PEPS_BENCH_NDEV", "0")) or torch.cuda.device_count()
+        local_rank = local_rank % max(ndev, 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     from peps_amd import capi, synthetic
     from peps_amd.flops import reference_flops
@@ -124,7 +128,7 @@ def main():
     ctx.profile_enable(False)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -59,8 +59,8 @@ typedef float tg_f32x16 __attribute__((ext_vector_type(16)));
 typedef double tg_f64x4 __attribute__((ext_vector_type(4)));
 
 template <typename TA, typename TB, typename TC, typename TAcc, bool USE_MFMA>
-__global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__restrict__ Ag,
-                                                    const TB *__restrict__ Bg, TC *__restrict__ Cg) {
+__device__ __forceinline__ void tgemm_tile(const TGemmDesc &d, const TA *__restrict__ Ag, const TB *__restrict__ Bg,
+                                           TC *__restrict__ Cg, const int i0, const int Itot, const int Ktot) {
   constexpr int PITCH = TgPitch<TAcc>::v;
   __shared__ TAcc As[TG_BK][PITCH];
   __shared__ TAcc Bs[TG_BK][PITCH];
@@ -69,12 +69,8 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__res
 
   const int tid = threadIdx.x;
   const int b = blockIdx.z;
-  const int i0 = blockIdx.x * TG_BM, j0 = blockIdx.y * TG_BN;
-  int Itot = d.Itot(), Ktot = d.Ktot();
+  const int j0 = blockIdx.y * TG_BN;
   const int Jtot = d.Jtot();
-  if (d.dynI) Itot = min(Itot, d.dynI[b] * d.dynI_mul);
-  if (d.dynK) Ktot = min(Ktot, d.dynK[b] * d.dynK_mul);
-  if (i0 >= Itot) return;   // block-uniform: this tile lies beyond the walker's live extent
 
   long baseA = (long)(b / d.bdivA) * d.wA, baseB = (long)(b / d.bdivB) * d.wB;
   if (d.selA) baseA += (long)d.selA[(long)(b / d.seldivA) * d.selA_inc] * d.selA_mul;
@@ -93,6 +89,7 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__res
     offCj[tid - TG_BM] = (j < Jtot) ? tg_off3(j, d.J, d.sCj) : -1;
   }
 
+  __syncthreads();   // offsets visible even when the K loop is empty (dynamic K extent 0)
   // staging order: run consecutive threads along whichever index is closer to unit stride
   const bool a_ifast = d.sAi[2] <= d.sAk[2];
   const bool b_jfast = d.sBj[2] <= d.sBk[2];
@@ -232,12 +229,31 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__res
   }
 }
 
+// One block walks the I tiles blockIdx.x, blockIdx.x + gridDim.x, ... of its (j tile, batch entry):
+// with a per-walker dynamic extent the grid is launched narrow (TG_DYN_GRIDX tiles) so that the
+// launch does not consist of tens of thousands of blocks that exit at once.
+constexpr int TG_DYN_GRIDX = 2;
+template <typename TA, typename TB, typename TC, typename TAcc, bool USE_MFMA>
+__global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__restrict__ Ag,
+                                                    const TB *__restrict__ Bg, TC *__restrict__ Cg) {
+  const int b = blockIdx.z;
+  int Itot = d.Itot(), Ktot = d.Ktot();
+  if (d.dynI) Itot = min(Itot, d.dynI[b] * d.dynI_mul);
+  if (d.dynK) Ktot = min(Ktot, d.dynK[b] * d.dynK_mul);
+  for (int i0 = blockIdx.x * TG_BM; i0 < Itot; i0 += gridDim.x * TG_BM) {   // block-uniform trip count
+    tgemm_tile<TA, TB, TC, TAcc, USE_MFMA>(d, Ag, Bg, Cg, i0, Itot, Ktot);
+    __syncthreads();
+  }
+}
+
 bool tgemm_use_mfma();
 
 template <typename TA, typename TB, typename TC, typename TAcc>
 void tgemm_launch(hipStream_t s, const TGemmDesc &d, const TA *A, const TB *B, TC *C) {
   if (d.nbatch <= 0 || d.Itot() <= 0 || d.Jtot() <= 0) return;
-  dim3 grid((d.Itot() + TG_BM - 1) / TG_BM, (d.Jtot() + TG_BN - 1) / TG_BN, d.nbatch);
+  int gx = (d.Itot() + TG_BM - 1) / TG_BM;
+  if (d.dynI && gx > TG_DYN_GRIDX) gx = TG_DYN_GRIDX;
+  dim3 grid(gx, (d.Jtot() + TG_BN - 1) / TG_BN, d.nbatch);
   if (tgemm_use_mfma())
     hipLaunchKernelGGL((tgemm_kernel<TA, TB, TC, TAcc, true>), grid, dim3(256), 0, s, d, A, B, C);
   else

@@ -23,5 +23,9 @@ hostapi.energy_and_holes(flat, cfgs, chi, "xxz", (1.0, 1.0, 0.0), True, 0)
 t0 = time.time(); a, e, h, psi = hostapi.energy_and_holes(flat, cfgs, chi, "xxz", (1.0, 1.0, 0.0), True, 0); dt = time.time() - t0
 res["energy_and_holes_samples_per_s"] = nw / dt
 res["psi_consistency_max_rel_spread"] = float(np.max(np.abs(psi / psi[0] - 1)))
+t0 = time.time(); packed, _, acc = hostapi.mc_energy_grad_partial(flat, cfgs, seeds, chi, "exchange", "xxz", (1.0, 1.0, 0.0), 0, 2, 0); dt = time.time() - t0
+res["vmc_samples_per_s_sweep_plus_energy_grad_device_holes"] = 2 * nw / dt
+e, g = hostapi.exact_sum_finish(packed, flat.shape)
+res["mc_energy_per_site"] = e / (L * L)
 res["workload"] = name; res["walkers"] = nw
 print(json.dumps(res))

@@ -1,0 +1,16 @@
+"""Aggregate a rocprofv3 kernel_trace.csv by (kernel, grid) to separate the GEMM shapes of one template."""
+import csv, sys, collections
+f = sys.argv[1]
+agg = collections.defaultdict(lambda: [0, 0.0])
+with open(f) as fh:
+    rd = csv.DictReader(fh)
+    for r in rd:
+        name = r["Kernel_Name"].split("(")[0][-60:]
+        key = (name, r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", ""), r.get("Workgroup_Size_X", ""))
+        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        agg[key][0] += 1
+        agg[key][1] += dur
+tot = sum(v[1] for v in agg.values())
+print("total ms", tot)
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+    print("%8.2f ms %5d calls %7.1f us/call  %s" % (v[1], v[0], 1e3 * v[1] / v[0], k))
