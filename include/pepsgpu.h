@@ -93,6 +93,30 @@ int pepsgpu_replace_nn_trace(pepsgpu_ctx *ctx, int row, int col, int bond_dir, i
 /* ReplaceOneSiteTrace(tn, site, T[cand], mps_orient)  :30-88.  cand_states = [n][n_cand]. */
 int pepsgpu_replace_one_trace(pepsgpu_ctx *ctx, int row, int col, int mps_orient, int n_cand,
                               const int32_t *cand_states, double *out_amp);
+/* BTen2 (rank-4 environments of two adjacent rows/columns, bten_set2_) -- bmps_contractor_init.h:130-186,
+ * bmps_contractor_grow.h:375-527.  slice_num1 = the first of the two rows (LEFT/RIGHT) or columns (UP/DOWN). */
+int pepsgpu_init_bten2(pepsgpu_ctx *ctx, int pos, int slice_num1);                              /* InitBTen2  init.h:130-186 */
+int pepsgpu_grow_full_bten2(pepsgpu_ctx *ctx, int pos, int slice_num1, int remain_sites, int init); /* GrowFullBTen2 grow.h:375-470 */
+int pepsgpu_grow_bten2_step(pepsgpu_ctx *ctx, int pos, int slice_num1);                         /* GrowBTen2Step grow.h:472-515 */
+int pepsgpu_shift_bten2_window(pepsgpu_ctx *ctx, int pos, int slice_num1);                      /* ShiftBTen2Window grow.h:523-527 */
+int pepsgpu_bten2_stack_size(pepsgpu_ctx *ctx, int pos);
+/* Diagonal direction of a next-nearest / sqrt(5) link (basic.h:89-92 DIAGONAL_DIR). */
+#define PEPSGPU_LEFTUP_TO_RIGHTDOWN 0
+#define PEPSGPU_LEFTDOWN_TO_RIGHTUP 1
+/* ReplaceNNNSiteTrace(tn, left_up_site, nnn_dir, mps_orient, ten_left, ten_right)  trace.h:207-324.
+ * (row, col) = upper-left corner of the plaquette; cand_states = [n][n_cand][2] states put on the
+ * (left, right) end of the diagonal.  n_cand = 0: no replacement (the plaquette trace), out = [n]. */
+int pepsgpu_replace_nnn_trace(pepsgpu_ctx *ctx, int row, int col, int nnn_dir, int mps_orient, int n_cand,
+                              const int32_t *cand_states, double *out_amp);
+/* ReplaceTNNSiteTrace(tn, site0, mps_orient, T0, T1, T2)  trace.h:326-423.  (row, col) = first of
+ * three consecutive sites along mps_orient; cand_states = [n][n_cand][3]. */
+int pepsgpu_replace_tnn_trace(pepsgpu_ctx *ctx, int row, int col, int mps_orient, int n_cand,
+                              const int32_t *cand_states, double *out_amp);
+/* ReplaceSqrt5DistTwoSiteTrace(tn, left_up_site, sqrt5link_dir, mps_orient, ten_left, ten_right)
+ * trace.h:425-536.  (row, col) = upper-left corner of the 2x3 (HORIZONTAL) or 3x2 (VERTICAL) block;
+ * cand_states = [n][n_cand][2] states on the (left, right) end of the link. */
+int pepsgpu_replace_sqrt5_trace(pepsgpu_ctx *ctx, int row, int col, int link_dir, int mps_orient, int n_cand,
+                                const int32_t *cand_states, double *out_amp);
 /* PunchHole(tn, site, mps_orient)  grow.h:150-183.  out = [n][D][D][D][D] float64 (legs L,D,R,U, zero padded). */
 int pepsgpu_punch_hole(pepsgpu_ctx *ctx, int row, int col, int mps_orient, double *out);
 /* out == NULL: the hole of every walker stays on the device (resident hole store) for

@@ -63,6 +63,7 @@ class BMPSContractor:
         self.rows_, self.cols_ = rows, cols
         self.bmps_set = {p: [] for p in range(4)}
         self.bten_set = {p: [] for p in range(4)}
+        self.bten_set2 = {p: [] for p in range(4)}
         self.trunc = None
 
     # -- params (bmps_contractor.h:216-226) -------------------------------------------------
@@ -372,3 +373,265 @@ class BMPSContractor:
         for pos, keep in ((LEFT, col + 1), (UP, row + 1), (RIGHT, self.cols_ - col), (DOWN, self.rows_ - row)):
             if len(self.bten_set[pos]) > keep:
                 del self.bten_set[pos][keep:]
+            if len(self.bten_set2[pos]) > keep:
+                del self.bten_set2[pos][keep:]
+
+
+# =================================================================================================
+# Two-row (rank-4) environments and NNN / third-neighbour / sqrt(5) replacement traces
+# (bmps_contractor_init.h:130-186, bmps_contractor_grow.h:375-527, bmps_contractor_helpers.h:12-180,
+#  bmps_contractor_trace.h:207-536; bosonic branches).  Added as methods of BMPSContractor.
+# =================================================================================================
+LEFTUP_TO_RIGHTDOWN, LEFTDOWN_TO_RIGHTUP = 0, 1        # basic.h:89-92 DIAGONAL_DIR
+
+
+def _mpo1_axes(post):
+    """GenMpoTen1TransposeAxesForBrowBTen2<false> (helpers.h:12-26)"""
+    return ((post + 3) % 4, post % 4, (post + 2) % 4, (post + 1) % 4)
+
+
+def _grow_bten2_after_transposed(bten2, mps1, mps2, mpo1_t, mpo2, ctrct):
+    """GrowBTen2StepAfterTransposedMPOTens, bosonic branch (helpers.h:174-177)"""
+    tmp1 = T.contract_cyclic(mps1, bten2, 2, 0, 1)
+    tmp2 = T.contract_cyclic(tmp1, mpo1_t, 1, 0, 2)
+    tmp3 = T.contract_cyclic(tmp2, mpo2, 4, ctrct, 2)
+    return T.contract(tmp3, [0, 3], mps2, [0, 1])
+
+
+def _init_bten2(self, tn, position, slice_num1):
+    """init.h:130-186"""
+    if position == DOWN:
+        c1, c2 = slice_num1, slice_num1 + 1
+        dims = (self._bmps_at_slice(LEFT, c1)[tn.rows - 1].shape[2], tn((tn.rows - 1, c1)).shape[position],
+                tn((tn.rows - 1, c2)).shape[position], self._bmps_at_slice(RIGHT, c2)[0].shape[0])
+    elif position == UP:
+        c1, c2 = slice_num1, slice_num1 + 1
+        dims = (self._bmps_at_slice(RIGHT, c2)[tn.rows - 1].shape[2], tn((0, c2)).shape[position],
+                tn((0, c1)).shape[position], self._bmps_at_slice(LEFT, c1)[0].shape[0])
+    elif position == LEFT:
+        r1, r2 = slice_num1, slice_num1 + 1
+        dims = (self._bmps_at_slice(UP, r1)[tn.cols - 1].shape[2], tn((r1, 0)).shape[position],
+                tn((r2, 0)).shape[position], self._bmps_at_slice(DOWN, r2)[0].shape[0])
+    else:
+        r1, r2 = slice_num1, slice_num1 + 1
+        dims = (self._bmps_at_slice(DOWN, r2)[tn.cols - 1].shape[2], tn((r2, tn.cols - 1)).shape[position],
+                tn((r1, tn.cols - 1)).shape[position], self._bmps_at_slice(UP, r1)[0].shape[0])
+    ten = np.zeros(dims, dtype=tn((0, 0)).dtype)
+    ten[0, 0, 0, 0] = 1.0
+    self.bten_set2[position] = [ten]
+
+
+def _grow_full_bten2(self, tn, post, slice_num1, remain_sites=2, init=True):
+    """grow.h:375-470 (bosonic)"""
+    if init:
+        self.InitBTen2(tn, post, slice_num1)
+    ctrct = (post + 3) % 4
+    btens = self.bten_set2[post]
+    start = len(btens) - 1
+    if post == DOWN:
+        c1, c2 = slice_num1, slice_num1 + 1
+        mpo1, mpo2 = tn.get_col(c1)[::-1], tn.get_col(c2)[::-1]
+        pre, nxt = self._bmps_at_slice(LEFT, c1), self._bmps_at_slice(RIGHT, c2)
+    elif post == RIGHT:
+        r1, r2 = slice_num1, slice_num1 + 1
+        mpo1, mpo2 = tn.get_row(r2)[::-1], tn.get_row(r1)[::-1]
+        pre, nxt = self._bmps_at_slice(DOWN, r2), self._bmps_at_slice(UP, r1)
+    elif post == UP:
+        c1, c2 = slice_num1, slice_num1 + 1
+        mpo1, mpo2 = tn.get_col(c2), tn.get_col(c1)
+        pre, nxt = self._bmps_at_slice(RIGHT, c2), self._bmps_at_slice(LEFT, c1)
+    else:
+        r1, r2 = slice_num1, slice_num1 + 1
+        mpo1, mpo2 = tn.get_row(r1), tn.get_row(r2)
+        pre, nxt = self._bmps_at_slice(UP, r1), self._bmps_at_slice(DOWN, r2)
+    n = len(mpo1)
+    axes = _mpo1_axes(post)
+    for i in range(start, n - remain_sites):
+        m1t = np.transpose(mpo1[i], axes)
+        btens.append(_grow_bten2_after_transposed(btens[-1], pre[n - i - 1], nxt[i], m1t, mpo2[i], ctrct))
+
+
+def _grow_bten2_step(self, tn, post, slice_num1):
+    """grow.h:472-515 + SetUpCoordInfoForGrowBTen2 (helpers.h:41-92)"""
+    ctrct = (post + 3) % 4
+    pre_post, next_post = ctrct, (post + 1) % 4
+    bs = len(self.bten_set2[post])
+    rows, cols = tn.rows, tn.cols
+    if post == DOWN:
+        col = slice_num1; n = rows
+        s1, s2 = (n - bs, col), (n - bs, col + 1)
+        i1, i2 = col, cols - 1 - (col + 1)
+    elif post == UP:
+        col = slice_num1; n = rows
+        s1, s2 = (bs - 1, col + 1), (bs - 1, col)
+        i1, i2 = cols - 1 - (col + 1), col
+    elif post == LEFT:
+        row = slice_num1; n = cols
+        s1, s2 = (row, bs - 1), (row + 1, bs - 1)
+        i1, i2 = row, rows - 1 - (row + 1)
+    else:
+        row = slice_num1; n = cols
+        s1, s2 = (row + 1, n - bs), (row, n - bs)
+        i1, i2 = rows - 1 - (row + 1), row
+    m1t = np.transpose(tn(s1), _mpo1_axes(post))
+    mps1 = self.bmps_set[pre_post][i1][n - bs]
+    mps2 = self.bmps_set[next_post][i2][bs - 1]
+    self.bten_set2[post].append(_grow_bten2_after_transposed(self.bten_set2[post][-1], mps1, mps2, m1t, tn(s2), ctrct))
+
+
+def _shift_bten2_window(self, tn, position, slice_num1):
+    """grow.h:523-527"""
+    self.bten_set2[position].pop()
+    self.GrowBTen2Step(tn, opposite(position), slice_num1)
+
+
+def _bten2_at_slice(self, pos, idx):
+    """bmps_contractor.h:1012-1018"""
+    if pos == DOWN:
+        return self.bten_set2[DOWN][self.rows_ - 1 - idx]
+    if pos == RIGHT:
+        return self.bten_set2[RIGHT][self.cols_ - 1 - idx]
+    return self.bten_set2[pos][idx]
+
+
+def _replace_nnn_site_trace(self, tn, left_up_site, nnn_dir, mps_orient, ten_left, ten_right):
+    """trace.h:207-324 (bosonic branches)"""
+    row1, col1 = left_up_site
+    row2, col2 = row1 + 1, col1 + 1
+    if mps_orient == HORIZONTAL:
+        m1 = self._bmps_at_slice(UP, row1).at_logical_col(col1)
+        m2 = self._bmps_at_slice(DOWN, row2).at_logical_col(col1)
+        m3 = self._bmps_at_slice(DOWN, row2).at_logical_col(col2)
+        m4 = self._bmps_at_slice(UP, row1).at_logical_col(col2)
+        lb = self.bten_set2[LEFT][col1]
+        rb = self._bten2_at_slice(RIGHT, col2)
+        if nnn_dir == LEFTUP_TO_RIGHTDOWN:
+            t0, t2, t1, t3 = ten_left, ten_right, tn((row2, col1)), tn((row1, col2))
+        else:
+            t0, t2, t1, t3 = tn((row1, col1)), tn((row2, col2)), ten_left, ten_right
+        t0 = np.transpose(t0, (3, 0, 2, 1))
+        t2 = np.transpose(t2, (1, 2, 0, 3))
+        a = T.contract_cyclic(m1, lb, 2, 0, 1)
+        a = T.contract_cyclic(a, t0, 1, 0, 2)
+        a = T.contract_cyclic(a, t1, 4, 3, 2)
+        a = T.contract(a, [0, 3], m2, [0, 1])
+        b = T.contract_cyclic(m3, rb, 2, 0, 1)
+        b = T.contract_cyclic(b, t2, 1, 0, 2)
+        b = T.contract_cyclic(b, t3, 4, 1, 2)
+        b = T.contract(b, [0, 3], m4, [0, 1])
+        return T.contract(a, [0, 1, 2, 3], b, [3, 2, 1, 0])[()]
+    m1 = self._bmps_at_slice(LEFT, col1).at_logical_col(row2)
+    m2 = self._bmps_at_slice(RIGHT, col2).at_logical_col(row2)
+    m3 = self._bmps_at_slice(LEFT, col1).at_logical_col(row1)
+    m4 = self._bmps_at_slice(RIGHT, col2).at_logical_col(row1)
+    tb = self.bten_set2[UP][row1]
+    bb = self._bten2_at_slice(DOWN, row2)
+    if nnn_dir == LEFTUP_TO_RIGHTDOWN:
+        mpo = [tn((row2, col1)), ten_right, ten_left, tn((row1, col2))]
+    else:
+        mpo = [ten_left, tn((row2, col2)), tn((row1, col1)), ten_right]
+    mpo[0] = np.transpose(mpo[0], (0, 1, 3, 2))
+    mpo[3] = np.transpose(mpo[3], (2, 3, 1, 0))
+    a = T.contract_cyclic(m1, bb, 2, 0, 1)
+    a = T.contract_cyclic(a, mpo[0], 1, 0, 2)
+    a = T.contract_cyclic(a, mpo[1], 4, 0, 2)
+    a = T.contract(a, [0, 3], m2, [0, 1])
+    b = T.contract_cyclic(m4, tb, 2, 0, 1)
+    b = T.contract_cyclic(b, mpo[3], 1, 0, 2)
+    b = T.contract_cyclic(b, mpo[2], 4, 2, 2)
+    b = T.contract(b, [0, 3], m3, [0, 1])
+    return T.contract(a, [0, 1, 2, 3], b, [3, 2, 1, 0])[()]
+
+
+def _replace_tnn_site_trace(self, tn, site0, mps_orient, t0, t1, t2):
+    """trace.h:326-423 (bosonic)"""
+    if mps_orient == HORIZONTAL:
+        row, c0 = site0
+        ups = [self._bmps_at_slice(UP, row).at_logical_col(c0 + k) for k in range(3)]
+        dns = [self._bmps_at_slice(DOWN, row).at_logical_col(c0 + k) for k in range(3)]
+        cur = self.bten_set[LEFT][c0]
+        for k, ten in enumerate((t0, t1, t2)):
+            a = T.contract_cyclic(ups[k], cur, 2, 0, 1)
+            a = T.contract_cyclic(a, ten, 1, 3, 2)
+            cur = T.contract(a, [0, 2], dns[k], [0, 1])
+        return T.contract(cur, [0, 1, 2], self._bten_at_slice(RIGHT, c0 + 2), [2, 1, 0])[()]
+    r0, col = site0
+    rts = [self._bmps_at_slice(RIGHT, col).at_logical_col(r0 + k) for k in range(3)]
+    lfs = [self._bmps_at_slice(LEFT, col).at_logical_col(r0 + k) for k in range(3)]
+    cur = self.bten_set[UP][r0]
+    for k, ten in enumerate((t0, t1, t2)):
+        a = T.contract_cyclic(rts[k], cur, 2, 0, 1)
+        a = T.contract_cyclic(a, ten, 1, 2, 2)
+        cur = T.contract(a, [0, 2], lfs[k], [0, 1])
+    return T.contract(cur, [0, 1, 2], self._bten_at_slice(DOWN, r0 + 2), [2, 1, 0])[()]
+
+
+def _replace_sqrt5_trace(self, tn, left_up_site, link_dir, mps_orient, ten_left, ten_right):
+    """trace.h:425-536"""
+    row1, col1 = left_up_site
+    mpo = [None] * 6
+    if mps_orient == HORIZONTAL:
+        row2, col2, col3 = row1 + 1, col1 + 1, col1 + 2
+        m = [None, self._bmps_at_slice(UP, row1).at_logical_col(col1), self._bmps_at_slice(DOWN, row2).at_logical_col(col1),
+             self._bmps_at_slice(UP, row1).at_logical_col(col2), self._bmps_at_slice(DOWN, row2).at_logical_col(col2),
+             self._bmps_at_slice(UP, row1).at_logical_col(col3), self._bmps_at_slice(DOWN, row2).at_logical_col(col3)]
+        lb = self.bten_set2[LEFT][col1]
+        rb = self._bten2_at_slice(RIGHT, col3)
+        if link_dir == LEFTUP_TO_RIGHTDOWN:
+            mpo[0], mpo[1], mpo[4], mpo[5] = ten_left, tn((row2, col1)), tn((row1, col3)), ten_right
+        else:
+            mpo[0], mpo[1], mpo[4], mpo[5] = tn((row1, col1)), ten_left, ten_right, tn((row2, col3))
+        mpo[2], mpo[3] = tn((row1, col2)), tn((row2, col2))
+        mpo[0] = np.transpose(mpo[0], (3, 0, 2, 1))
+        mpo[2] = np.transpose(mpo[2], (3, 0, 2, 1))
+        mpo[5] = np.transpose(mpo[5], (1, 2, 0, 3))
+        a = T.contract_cyclic(m[1], lb, 2, 0, 1)
+        a = T.contract_cyclic(a, mpo[0], 1, 0, 2)
+        a = T.contract_cyclic(a, mpo[1], 4, 3, 2)
+        a = T.contract(a, [0, 3], m[2], [0, 1])
+        b = T.contract_cyclic(m[6], rb, 2, 0, 1)
+        b = T.contract_cyclic(b, mpo[5], 1, 0, 2)
+        b = T.contract_cyclic(b, mpo[4], 4, 1, 2)
+        b = T.contract(b, [0, 3], m[5], [0, 1])
+        c = T.contract_cyclic(m[3], a, 2, 0, 1)
+        c = T.contract_cyclic(c, mpo[2], 1, 0, 2)
+        c = T.contract_cyclic(c, mpo[3], 4, 3, 2)
+        c = T.contract(c, [0, 3], m[4], [0, 1])
+    else:
+        row2, row3, col2 = row1 + 1, row1 + 2, col1 + 1
+        m = [None, self._bmps_at_slice(LEFT, col1).at_logical_col(row3), self._bmps_at_slice(RIGHT, col2).at_logical_col(row3),
+             self._bmps_at_slice(LEFT, col1).at_logical_col(row2), self._bmps_at_slice(RIGHT, col2).at_logical_col(row2),
+             self._bmps_at_slice(LEFT, col1).at_logical_col(row1), self._bmps_at_slice(RIGHT, col2).at_logical_col(row1)]
+        tb = self.bten_set2[UP][row1]
+        bb = self._bten2_at_slice(DOWN, row3)
+        mpo[2], mpo[3] = tn((row2, col1)), tn((row2, col2))
+        if link_dir == LEFTUP_TO_RIGHTDOWN:
+            mpo[0], mpo[1], mpo[4], mpo[5] = tn((row3, col1)), ten_right, ten_left, tn((row1, col2))
+        else:
+            mpo[0], mpo[1], mpo[4], mpo[5] = ten_left, tn((row3, col2)), tn((row1, col1)), ten_right
+        mpo[0] = np.transpose(mpo[0], (0, 1, 3, 2))
+        mpo[2] = np.transpose(mpo[2], (0, 1, 3, 2))
+        mpo[5] = np.transpose(mpo[5], (2, 3, 1, 0))
+        a = T.contract_cyclic(m[1], bb, 2, 0, 1)
+        a = T.contract_cyclic(a, mpo[0], 1, 0, 2)
+        a = T.contract_cyclic(a, mpo[1], 4, 0, 2)
+        a = T.contract(a, [0, 3], m[2], [0, 1])
+        b = T.contract_cyclic(m[6], tb, 2, 0, 1)
+        b = T.contract_cyclic(b, mpo[5], 1, 0, 2)
+        b = T.contract_cyclic(b, mpo[4], 4, 2, 2)
+        b = T.contract(b, [0, 3], m[5], [0, 1])
+        c = T.contract_cyclic(m[3], a, 2, 0, 1)
+        c = T.contract_cyclic(c, mpo[2], 1, 0, 2)
+        c = T.contract_cyclic(c, mpo[3], 4, 0, 2)
+        c = T.contract(c, [0, 3], m[4], [0, 1])
+    return T.contract(c, [0, 1, 2, 3], b, [3, 2, 1, 0])[()]
+
+
+BMPSContractor.InitBTen2 = _init_bten2
+BMPSContractor.GrowFullBTen2 = _grow_full_bten2
+BMPSContractor.GrowBTen2Step = _grow_bten2_step
+BMPSContractor.ShiftBTen2Window = _shift_bten2_window
+BMPSContractor._bten2_at_slice = _bten2_at_slice
+BMPSContractor.ReplaceNNNSiteTrace = _replace_nnn_site_trace
+BMPSContractor.ReplaceTNNSiteTrace = _replace_tnn_site_trace
+BMPSContractor.ReplaceSqrt5DistTwoSiteTrace = _replace_sqrt5_trace

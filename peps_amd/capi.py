@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpepsgpu.so")
 F32, F64 = 0, 1
 LEFT, DOWN, RIGHT, UP = 0, 1, 2, 3
 HORIZONTAL, VERTICAL = 0, 1
+LEFTUP_TO_RIGHTDOWN, LEFTDOWN_TO_RIGHTUP = 0, 1   # basic.h:89-92 DIAGONAL_DIR
 SVD_COMPRESS = 0
 
 _ERR = {1: ValueError, 2: RuntimeError, 3: RuntimeError, 4: IndexError, 5: RuntimeError}
@@ -26,6 +27,9 @@ SYMBOLS = [
     "pepsgpu_bmps_stack_size", "pepsgpu_get_bmps_tensor", "pepsgpu_init_bten", "pepsgpu_grow_full_bten",
     "pepsgpu_grow_bten_step", "pepsgpu_shift_bten_window", "pepsgpu_truncate_bten", "pepsgpu_bten_stack_size",
     "pepsgpu_trace", "pepsgpu_replace_nn_trace", "pepsgpu_replace_one_trace", "pepsgpu_punch_hole",
+    "pepsgpu_init_bten2", "pepsgpu_grow_full_bten2", "pepsgpu_grow_bten2_step", "pepsgpu_shift_bten2_window",
+    "pepsgpu_bten2_stack_size", "pepsgpu_replace_nnn_trace", "pepsgpu_replace_tnn_trace",
+    "pepsgpu_replace_sqrt5_trace",
     "pepsgpu_grad_reset", "pepsgpu_grad_accumulate", "pepsgpu_grad_read",
     "pepsgpu_update_local", "pepsgpu_erase_envs_after_update", "pepsgpu_evaluate_amplitude",
     "pepsgpu_walker_flags", "pepsgpu_sync", "pepsgpu_stats", "pepsgpu_profile_enable", "pepsgpu_profile_read",
@@ -60,6 +64,13 @@ def load_library(path=LIB_PATH):
     lib.pepsgpu_replace_nn_trace.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp]
     lib.pepsgpu_replace_one_trace.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp]
     lib.pepsgpu_punch_hole.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
+    for name in ("init_bten2", "grow_bten2_step", "shift_bten2_window"):
+        getattr(lib, "pepsgpu_" + name).argtypes = [vp, C.c_int, C.c_int]
+    lib.pepsgpu_grow_full_bten2.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.pepsgpu_bten2_stack_size.argtypes = [vp, C.c_int]
+    lib.pepsgpu_replace_nnn_trace.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp]
+    lib.pepsgpu_replace_tnn_trace.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp]
+    lib.pepsgpu_replace_sqrt5_trace.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp]
     lib.pepsgpu_grad_reset.argtypes = [vp]
     lib.pepsgpu_grad_accumulate.argtypes = [vp, dp, dp, C.c_int]
     lib.pepsgpu_grad_read.argtypes = [vp, dp, dp]
@@ -190,6 +201,40 @@ class Context:
         assert cand.ndim == 2 and cand.shape[0] == self.n
         out = np.zeros((self.n, cand.shape[1]), dtype=np.float64)
         self._ck(self._l.pepsgpu_replace_one_trace(self._h, row, col, orient, cand.shape[1], _ip(cand), _dp(out)))
+        return out
+
+    # -- two-row environments, NNN / third-neighbour / sqrt(5) traces --
+    def init_bten2(self, pos, slice_num1): self._ck(self._l.pepsgpu_init_bten2(self._h, pos, slice_num1))
+    def grow_full_bten2(self, pos, slice_num1, remain_sites=2, init=True):
+        self._ck(self._l.pepsgpu_grow_full_bten2(self._h, pos, slice_num1, remain_sites, int(init)))
+    def grow_bten2_step(self, pos, slice_num1): self._ck(self._l.pepsgpu_grow_bten2_step(self._h, pos, slice_num1))
+    def shift_bten2_window(self, pos, slice_num1): self._ck(self._l.pepsgpu_shift_bten2_window(self._h, pos, slice_num1))
+    def bten2_stack_size(self, pos): return self._l.pepsgpu_bten2_stack_size(self._h, pos)
+
+    def _cand(self, cand_states, ncols):
+        """cand_states None -> no replacement (out [n]); else [n][n_cand][ncols] -> out [n][n_cand]"""
+        if cand_states is None:
+            return 0, None, np.zeros(self.n, dtype=np.float64)
+        cand = np.ascontiguousarray(cand_states, dtype=np.int32)
+        assert cand.ndim == 3 and cand.shape[0] == self.n and cand.shape[2] == ncols
+        return cand.shape[1], cand, np.zeros((self.n, cand.shape[1]), dtype=np.float64)
+
+    def replace_nnn_trace(self, row, col, nnn_dir, orient, cand_states=None):
+        nc, cand, out = self._cand(cand_states, 2)
+        self._ck(self._l.pepsgpu_replace_nnn_trace(self._h, row, col, nnn_dir, orient, nc,
+                                                   None if cand is None else _ip(cand), _dp(out)))
+        return out
+
+    def replace_tnn_trace(self, row, col, orient, cand_states=None):
+        nc, cand, out = self._cand(cand_states, 3)
+        self._ck(self._l.pepsgpu_replace_tnn_trace(self._h, row, col, orient, nc,
+                                                   None if cand is None else _ip(cand), _dp(out)))
+        return out
+
+    def replace_sqrt5_trace(self, row, col, link_dir, orient, cand_states=None):
+        nc, cand, out = self._cand(cand_states, 2)
+        self._ck(self._l.pepsgpu_replace_sqrt5_trace(self._h, row, col, link_dir, orient, nc,
+                                                     None if cand is None else _ip(cand), _dp(out)))
         return out
 
     def punch_hole(self, row, col, orient):

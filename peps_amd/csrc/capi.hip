@@ -2,6 +2,7 @@
 #include <cstring>
 #include "../../include/pepsgpu.h"
 #include "engine_impl.h"
+#include "engine_nnn.h"
 
 using namespace pepsgpu;
 
@@ -127,6 +128,36 @@ int pepsgpu_replace_nn_trace(pepsgpu_ctx *ctx, int row, int col, int dir, int nc
 }
 int pepsgpu_replace_one_trace(pepsgpu_ctx *ctx, int row, int col, int orient, int ncand, const int32_t *cand, double *out) {
   CTX_CALL(PG_REQUIRE(ncand >= 1 && cand, 1, "need >= 1 candidate"); ctx->eng->replace_one_trace(row, col, orient, ncand, cand, out));
+}
+int pepsgpu_init_bten2(pepsgpu_ctx *ctx, int pos, int slice) { CTX_CALL(check_pos(pos); ctx->eng->init_bten2(pos, slice)); }
+int pepsgpu_grow_full_bten2(pepsgpu_ctx *ctx, int pos, int slice, int remain, int init) {
+  CTX_CALL(check_pos(pos); ctx->eng->grow_full_bten2(pos, slice, remain, init));
+}
+int pepsgpu_grow_bten2_step(pepsgpu_ctx *ctx, int pos, int slice) {
+  CTX_CALL(check_pos(pos); ctx->eng->grow_bten2_step(pos, slice));
+}
+int pepsgpu_shift_bten2_window(pepsgpu_ctx *ctx, int pos, int slice) {
+  CTX_CALL(check_pos(pos); ctx->eng->shift_bten2_window(pos, slice));
+}
+int pepsgpu_bten2_stack_size(pepsgpu_ctx *ctx, int pos) {
+  if (!ctx || !ctx->eng || pos < 0 || pos > 3) return -1;
+  return ctx->eng->bten2_size(pos);
+}
+int pepsgpu_replace_nnn_trace(pepsgpu_ctx *ctx, int row, int col, int nnn_dir, int orient, int ncand, const int32_t *cand,
+                              double *out) {
+  CTX_CALL(PG_REQUIRE((ncand == 0 || cand) && ncand >= 0 && out, 1, "bad candidate table");
+           PG_REQUIRE(nnn_dir == 0 || nnn_dir == 1, 1, "bad diagonal direction");
+           ctx->eng->replace_nnn_trace(row, col, nnn_dir, orient, ncand, cand, out));
+}
+int pepsgpu_replace_tnn_trace(pepsgpu_ctx *ctx, int row, int col, int orient, int ncand, const int32_t *cand, double *out) {
+  CTX_CALL(PG_REQUIRE((ncand == 0 || cand) && ncand >= 0 && out, 1, "bad candidate table");
+           ctx->eng->replace_tnn_trace(row, col, orient, ncand, cand, out));
+}
+int pepsgpu_replace_sqrt5_trace(pepsgpu_ctx *ctx, int row, int col, int link_dir, int orient, int ncand,
+                                const int32_t *cand, double *out) {
+  CTX_CALL(PG_REQUIRE((ncand == 0 || cand) && ncand >= 0 && out, 1, "bad candidate table");
+           PG_REQUIRE(link_dir == 0 || link_dir == 1, 1, "bad diagonal direction");
+           ctx->eng->replace_sqrt5_trace(row, col, link_dir, orient, ncand, cand, out));
 }
 int pepsgpu_punch_hole(pepsgpu_ctx *ctx, int row, int col, int orient, double *out) {
   CTX_CALL(ctx->eng->punch_hole(row, col, orient, out));

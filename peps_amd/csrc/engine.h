@@ -52,6 +52,14 @@ struct EngineBase {
   virtual void grow_bten_step(int pos) = 0;
   virtual void shift_bten_window(int pos) = 0;
   virtual void truncate_bten(int pos, int len) = 0;
+  virtual void init_bten2(int pos, int slice) = 0;
+  virtual void grow_full_bten2(int pos, int slice, int remain, int init) = 0;
+  virtual void grow_bten2_step(int pos, int slice) = 0;
+  virtual void shift_bten2_window(int pos, int slice) = 0;
+  virtual int bten2_size(int pos) const = 0;
+  virtual void replace_nnn_trace(int row, int col, int diag_dir, int orient, int ncand, const int32_t *cand, double *out) = 0;
+  virtual void replace_tnn_trace(int row, int col, int orient, int ncand, const int32_t *cand, double *out) = 0;
+  virtual void replace_sqrt5_trace(int row, int col, int diag_dir, int orient, int ncand, const int32_t *cand, double *out) = 0;
   virtual void trace(int row, int col, int dir, double *out) = 0;
   virtual void replace_nn_trace(int row, int col, int dir, int ncand, const int32_t *cand, double *out) = 0;
   virtual void replace_one_trace(int row, int col, int orient, int ncand, const int32_t *cand, double *out) = 0;
@@ -158,6 +166,7 @@ class Engine : public EngineBase {
     for (int p = 0; p < 4; ++p) {
       clear_bmps(p, 0);
       clear_bten(p, 0);
+      clear_bten2(p, 0);
       init_bmps(p);
     }
   }
@@ -240,6 +249,15 @@ class Engine : public EngineBase {
   void truncate_bten(int pos, int len) override {   // init.h:122-128
     if (bten_size(pos) > len) clear_bten(pos, len);
   }
+  // two-row environments and next-nearest / third-neighbour traces: engine_nnn.h
+  int bten2_size(int pos) const override { return (int)bten2_[pos].size(); }
+  void init_bten2(int pos, int slice) override;
+  void grow_full_bten2(int pos, int slice, int remain, int init) override;
+  void grow_bten2_step(int pos, int slice) override;
+  void shift_bten2_window(int pos, int slice) override;
+  void replace_nnn_trace(int row, int col, int diag_dir, int orient, int ncand, const int32_t *cand, double *out) override;
+  void replace_tnn_trace(int row, int col, int orient, int ncand, const int32_t *cand, double *out) override;
+  void replace_sqrt5_trace(int row, int col, int diag_dir, int orient, int ncand, const int32_t *cand, double *out) override;
 
   const BMPSDev &bmps_at_slice(int pos, int idx) const {   // bmps_contractor.h:985-999
     int k = idx;
@@ -542,6 +560,10 @@ class Engine : public EngineBase {
     if (bten_size(UP) > row + 1) clear_bten(UP, row + 1);
     if (bten_size(RIGHT) > Lx_ - col) clear_bten(RIGHT, Lx_ - col);
     if (bten_size(DOWN) > Ly_ - row) clear_bten(DOWN, Ly_ - row);
+    if (bten2_size(LEFT) > col + 1) clear_bten2(LEFT, col + 1);
+    if (bten2_size(UP) > row + 1) clear_bten2(UP, row + 1);
+    if (bten2_size(RIGHT) > Lx_ - col) clear_bten2(RIGHT, Lx_ - col);
+    if (bten2_size(DOWN) > Ly_ - row) clear_bten2(DOWN, Ly_ - row);
   }
 
   // wave_function_component.h:345-378 for the walkers with mask[w] != 0 (all walkers share the
@@ -723,9 +745,12 @@ class Engine : public EngineBase {
   // One BTen growth step with an explicit site selector (grow.h:577-579 and the half-steps of
   // trace.h:129-131 / :149-156): out[x, s_opp, y] from bten[c,b1,b2], mps1[x,p1,c], site, mps2[b2,s1,y].
   // Batch = walker x ncand (environment tensors shared by the candidates of one walker).
+  // bt_ncand: the input BTen is batched over walker x bt_ncand candidates (chains of steps with
+  // replaced tensors, ReplaceTNNSiteTrace); 1 = one BTen per walker.
   BTenDev bten_step(int post, const BTenDev &bt, const DTen<T> &mps1, const SiteSel &ss, const DTen<T> &mps2,
-                    int ncand, bool normalise) {
-    const int nb = nw_ * ncand;
+                    int ncand, bool normalise, int bt_ncand = 1) {
+    const int nb = nw_ * ncand, nb1 = nw_ * bt_ncand;
+    PG_REQUIRE(ncand % bt_ncand == 0 && (!normalise || ncand == 1), 1, "BTen step: bad candidate batching");
     int dd[4], st[4];
     site_dims(ss.r, ss.c, dd);
     site_strides(ss.r, ss.c, st);
@@ -736,14 +761,14 @@ class Engine : public EngineBase {
     PG_REQUIRE(cdim == bt.t.d[0] && p1 == dd[lc] && b1 == dd[lb] && mps2.d[0] == b2 && mps2.d[1] == s1, 3,
                "BTen step: bond dimension mismatch between environment tensors");
     // tmp1[x,p1,b1,b2] = sum_c mps1[x,p1,c] bten[c,b1,b2]     (per walker)
-    DTen<T> tmp1 = alloc_ten(x, p1, b1, b2);
+    DTen<T> tmp1 = alloc_ten(x, p1, b1, b2, nb1);
     {
       TGemmDesc g;
       g.I[2] = x * p1; g.sAi[2] = cdim; g.sCi[2] = b1 * b2;
       g.K[2] = cdim; g.sAk[2] = 1; g.sBk[2] = b1 * b2;
       g.J[2] = b1 * b2; g.sBj[2] = 1; g.sCj[2] = 1;
-      g.wA = mps1.n; g.wB = bt.t.n; g.wC = tmp1.n; g.nbatch = nw_;
-      const double fl = 2.0 * nw_ * (double)(x * p1) * cdim * (double)(b1 * b2);
+      g.wA = mps1.n; g.bdivA = bt_ncand; g.wB = bt.t.n; g.wC = tmp1.n; g.nbatch = nb1;
+      const double fl = 2.0 * nb1 * (double)(x * p1) * cdim * (double)(b1 * b2);
       prof_begin(PROF_ENV, fl, fl);
       tgemm_launch<T, T, T, T>(stream_, g, mps1.p, bt.t.p, tmp1.p);
       prof_end();
@@ -755,7 +780,7 @@ class Engine : public EngineBase {
       g.I[1] = b2; g.I[2] = x; g.sAi[1] = 1; g.sAi[2] = p1 * b1 * b2; g.sCi[1] = x * s1 * s2; g.sCi[2] = s1 * s2;
       g.K[1] = p1; g.K[2] = b1; g.sAk[1] = b1 * b2; g.sAk[2] = b2; g.sBk[1] = st[lc]; g.sBk[2] = st[lb];
       g.J[1] = s1; g.J[2] = s2; g.sBj[1] = st[l1]; g.sBj[2] = st[l2]; g.sCj[1] = s2; g.sCj[2] = 1;
-      g.wA = tmp1.n; g.bdivA = ncand; g.wC = tmp2.n; g.nbatch = nb;
+      g.wA = tmp1.n; g.bdivA = ncand / bt_ncand; g.wC = tmp2.n; g.nbatch = nb;
       const double fl = 2.0 * nb * (double)(b2 * x) * (double)(p1 * b1) * (double)(s1 * s2);
       prof_begin(PROF_ENV, fl, fl);
       launch_site_gemm(g, ss, ncand, tmp1.p, tmp2.p);
@@ -804,6 +829,31 @@ class Engine : public EngineBase {
   }
 
   void absorb(int pos, int num);
+  // ---- two-row environments and NNN / TNN / sqrt5 traces (engine_nnn.h) ----
+  void clear_bten2(int pos, int keep) {
+    auto &v = bten2_[pos];
+    while ((int)v.size() > keep) {
+      arena_.free(v.back().t.p);
+      arena_.free(v.back().logscale);
+      v.pop_back();
+    }
+  }
+  const BTenDev &bten2_at_slice(int pos, int idx) const {   // bmps_contractor.h:1012-1018
+    int k = idx;
+    if (pos == DOWN) k = Ly_ - 1 - idx;
+    if (pos == RIGHT) k = Lx_ - 1 - idx;
+    PG_REQUIRE(k >= 0 && k < (int)bten2_[pos].size(), 3, "BTen2 environment not available for this slice");
+    return bten2_[pos][k];
+  }
+  struct SitePick { int r, c, cand; };   // cand < 0: the walker's configuration; else column of the candidate table
+  SiteSel pick(const SitePick &s, const int *dcand, int ncols) const {
+    if (s.cand < 0) return cfg_site(s.r, s.c);
+    return SiteSel{s.r, s.c, dcand + s.cand, ncols};
+  }
+  BTenDev bten2_step(int post, const BTenDev &bt, const DTen<T> &mps1, const SiteSel &s1, const SiteSel &s2,
+                     const DTen<T> &mps2, int ncand, int bt_ncand, bool normalise);
+  void finish_dot4(const DTen<T> &a, const DTen<T> &b, int nc, double *lsum, double *out);
+  int *upload_cand(int ncand, int ncols, const int32_t *cand);
   void launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t need, const int *mdyn, int mdyn_mul);
 
   int Ly_, Lx_, D_, dp_, chi_min_, chi_;
@@ -818,6 +868,7 @@ class Engine : public EngineBase {
   std::vector<int> hcfg_;
   std::vector<BMPSDev> bmps_[4];
   std::vector<BTenDev> bten_[4];
+  std::vector<BTenDev> bten2_[4];   // two-row (rank-4) environments, bten_set2_ of the reference
   struct ProfRec { hipEvent_t a, b; int cat; double alg, exec; };
   std::vector<ProfRec> prof_;
   std::vector<hipEvent_t> ev_pool_;

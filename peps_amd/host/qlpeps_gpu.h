@@ -36,6 +36,7 @@ namespace qlpeps_gpu {
 
 enum BondOrientation { HORIZONTAL = 0, VERTICAL = 1 };      // basic.h:19-22
 enum BMPSPOSITION { LEFT = 0, DOWN = 1, RIGHT = 2, UP = 3 };  // basic.h:58-63
+enum DIAGONAL_DIR { LEFTUP_TO_RIGHTDOWN = 0, LEFTDOWN_TO_RIGHTUP = 1 };  // basic.h:89-92
 using BTenPOSITION = BMPSPOSITION;
 enum class CompressMPSScheme { SVD_COMPRESS = 0 };           // bmps.h:31-35 (variational: not implemented)
 
@@ -205,6 +206,35 @@ class BMPSContractor {
   std::vector<double> ReplaceOneSiteTrace(const SiteIdx &s, BondOrientation orient, int n_cand, const std::vector<int32_t> &cand) const {
     std::vector<double> out(walkers() * n_cand);
     check_rc(pepsgpu_replace_one_trace(ctx_, (int)s.r, (int)s.c, orient, n_cand, cand.data(), out.data()), ctx_);
+    return out;
+  }
+  // Two-row environments (bten_set2_): init.h:130-186, grow.h:375-527
+  void InitBTen2(BTenPOSITION p, size_t slice_num1) { check_rc(pepsgpu_init_bten2(ctx_, p, (int)slice_num1), ctx_); }
+  void GrowFullBTen2(BTenPOSITION p, size_t slice_num1, size_t remain_sites = 2, bool init = true) {
+    check_rc(pepsgpu_grow_full_bten2(ctx_, p, (int)slice_num1, (int)remain_sites, init), ctx_);
+  }
+  void GrowBTen2Step(BTenPOSITION p, size_t slice_num1) { check_rc(pepsgpu_grow_bten2_step(ctx_, p, (int)slice_num1), ctx_); }
+  void ShiftBTen2Window(BTenPOSITION p, size_t slice_num1) { check_rc(pepsgpu_shift_bten2_window(ctx_, p, (int)slice_num1), ctx_); }
+  // trace.h:207-324 / :326-423 / :425-536; cand[w][k][2|3|2], n_cand = 0: no replacement
+  std::vector<double> ReplaceNNNSiteTrace(const SiteIdx &left_up, DIAGONAL_DIR nnn_dir, BondOrientation orient, int n_cand,
+                                          const std::vector<int32_t> &cand) const {
+    std::vector<double> out(walkers() * (n_cand > 0 ? n_cand : 1));
+    check_rc(pepsgpu_replace_nnn_trace(ctx_, (int)left_up.r, (int)left_up.c, nnn_dir, orient, n_cand,
+                                       n_cand > 0 ? cand.data() : nullptr, out.data()), ctx_);
+    return out;
+  }
+  std::vector<double> ReplaceTNNSiteTrace(const SiteIdx &site0, BondOrientation orient, int n_cand,
+                                          const std::vector<int32_t> &cand) const {
+    std::vector<double> out(walkers() * (n_cand > 0 ? n_cand : 1));
+    check_rc(pepsgpu_replace_tnn_trace(ctx_, (int)site0.r, (int)site0.c, orient, n_cand,
+                                       n_cand > 0 ? cand.data() : nullptr, out.data()), ctx_);
+    return out;
+  }
+  std::vector<double> ReplaceSqrt5DistTwoSiteTrace(const SiteIdx &left_up, DIAGONAL_DIR link_dir, BondOrientation orient,
+                                                   int n_cand, const std::vector<int32_t> &cand) const {
+    std::vector<double> out(walkers() * (n_cand > 0 ? n_cand : 1));
+    check_rc(pepsgpu_replace_sqrt5_trace(ctx_, (int)left_up.r, (int)left_up.c, link_dir, orient, n_cand,
+                                         n_cand > 0 ? cand.data() : nullptr, out.data()), ctx_);
     return out;
   }
   // PunchHole: [walker][D^4] (legs L,D,R,U zero padded)

@@ -178,6 +178,119 @@ def test_k1_ising_device_f64():
         assert abs(-(np.log(a) + lognorm) / 144 / beta - f_ex) < 1e-8
 
 
+def test_k1_ising_device_all_21_routes_f64():
+    """All 21 routes of Contract2DTNUsingBMPSContractor (test_bmps_contractor.cpp:273-405) on the
+    device, BTen2 / NNN / TNN / sqrt(5) included, tolerance 1e-8 as the reference."""
+    import k1_routes
+    tn, lognorm, beta = ising.build_ising_tn(12, 12)
+    f_ex = ising.exact_free_energy(12, 12, 1.0 / beta)
+    sitps = [[[tn((r, c))] for c in range(12)] for r in range(12)]
+    ctx = _ctx(12, 2, 1, 30, "f64", 1)
+    _upload(ctx, sitps, 2)
+    ctx.set_configs(np.zeros((1, 12, 12), dtype=np.int32))
+    amps = k1_routes.run_device(ctx)
+    assert len(amps) == k1_routes.N_AMPS
+    for a in amps:
+        assert abs(-(np.log(a[0]) + lognorm) / 144 / beta - f_ex) < 1e-8
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("orient", [HORIZONTAL, VERTICAL])
+def test_nnn_tnn_sqrt5_replacement_traces(dt, orient):
+    """ReplaceNNNSiteTrace / ReplaceTNNSiteTrace / ReplaceSqrt5DistTwoSiteTrace with candidate
+    states (trace.h:207-536) against the oracle, several walkers, both diagonal directions."""
+    import k1_routes
+    from oracle.contractor import LEFTUP_TO_RIGHTDOWN, LEFTDOWN_TO_RIGHTUP
+    L, D, chi = 6, 3, 9
+    sitps = synthetic.make_sitps(L, D)
+    cfgs = synthetic.make_configs(L, 3, "heisenberg")
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    ctx = _ctx(L, D, 2, chi, dt, len(cfgs))
+    _upload(ctx, sitps, D)
+    ctx.set_configs(cfgs)
+    r0, c0 = (2, 1) if orient == HORIZONTAL else (1, 2)
+    pairs = [(0, 0), (0, 1), (1, 0), (1, 1)]
+    cand2 = np.array([pairs] * len(cfgs), dtype=np.int32)
+    trip = [(0, 1, 0), (1, 0, 1), (1, 1, 0), (0, 0, 1), (1, 0, 0)]
+    cand3 = np.array([trip] * len(cfgs), dtype=np.int32)
+
+    def prepare(api, dev):
+        if orient == HORIZONTAL:
+            if dev:
+                api.grow_bmps_for_row(r0); api.grow_full_bten(LEFT, r0, L - c0, True); api.grow_full_bten(RIGHT, r0, c0 + 2, True)
+            else:
+                api[0].GrowBMPSForRow(api[1], r0); api[0].GrowFullBTen(api[1], LEFT, r0, L - c0, True)
+                api[0].GrowFullBTen(api[1], RIGHT, r0, c0 + 2, True)
+        else:
+            if dev:
+                api.grow_bmps_for_col(c0); api.grow_full_bten(UP, c0, L - r0, True); api.grow_full_bten(DOWN, c0, r0 + 2, True)
+            else:
+                api[0].GrowBMPSForCol(api[1], c0); api[0].GrowFullBTen(api[1], UP, c0, L - r0, True)
+                api[0].GrowFullBTen(api[1], DOWN, c0, r0 + 2, True)
+
+    def prepare2(api, dev):
+        # two-row environments around the 2x3 / 3x2 block with upper-left corner (r0, c0)
+        if orient == HORIZONTAL:
+            if dev:
+                api.grow_bmps_for_row(r0); api.grow_full_bten2(LEFT, r0, L - c0, True); api.grow_full_bten2(RIGHT, r0, c0 + 2, True)
+            else:
+                api[0].GrowBMPSForRow(api[1], r0); api[0].GrowFullBTen2(api[1], LEFT, r0, L - c0, True)
+                api[0].GrowFullBTen2(api[1], RIGHT, r0, c0 + 2, True)
+        else:
+            if dev:
+                api.grow_bmps_for_col(c0); api.grow_full_bten2(UP, c0, L - r0, True); api.grow_full_bten2(DOWN, c0, r0 + 2, True)
+            else:
+                api[0].GrowBMPSForCol(api[1], c0); api[0].GrowFullBTen2(api[1], UP, c0, L - r0, True)
+                api[0].GrowFullBTen2(api[1], DOWN, c0, r0 + 2, True)
+
+    prepare(ctx, True)
+    psi = ctx.trace(r0, c0, orient)
+    tnn = ctx.replace_tnn_trace(r0, c0, orient, cand3)
+    tnn0 = ctx.replace_tnn_trace(r0, c0, orient)
+    prepare2(ctx, True)
+    nnn = {d: ctx.replace_nnn_trace(r0, c0, d, orient, cand2) for d in (LEFTUP_TO_RIGHTDOWN, LEFTDOWN_TO_RIGHTUP)}
+    nnn0 = ctx.replace_nnn_trace(r0, c0, LEFTUP_TO_RIGHTDOWN, orient)
+    # the sqrt5 block needs the far BTen2 one site further out
+    s5 = {}
+    if orient == HORIZONTAL:
+        ctx.grow_full_bten2(RIGHT, r0, c0 + 3, True)
+    else:
+        ctx.grow_full_bten2(DOWN, c0, r0 + 3, True)
+    for d in (LEFTUP_TO_RIGHTDOWN, LEFTDOWN_TO_RIGHTUP):
+        s5[d] = ctx.replace_sqrt5_trace(r0, c0, d, orient, cand2)
+    assert np.all(ctx.walker_flags() == 0)
+    tol = TOL[dt] * 20
+    for w, cfg in enumerate(cfgs):
+        tn = TensorNetwork2D.from_sitps(sitps, cfg)
+        c = BMPSContractor(L, L)
+        c.Init(tn)
+        c.SetTruncateParams(tp)
+        prepare((c, tn), False)
+        ref_psi = c.Trace(tn, (r0, c0), orient)
+        assert abs(psi[w] / ref_psi - 1) < TOL[dt]
+        assert abs(tnn0[w] / ref_psi - 1) < tol
+        sites = k1_routes.tnn_sites(r0, c0, orient)
+        for k, st in enumerate(trip):
+            ref = c.ReplaceTNNSiteTrace(tn, (r0, c0), orient, *[sitps[s[0]][s[1]][x] for s, x in zip(sites, st)])
+            assert abs(tnn[w, k] - ref) < tol * abs(ref_psi), (k, tnn[w, k], ref)
+        prepare2((c, tn), False)
+        assert abs(nnn0[w] / ref_psi - 1) < tol
+        for d in (LEFTUP_TO_RIGHTDOWN, LEFTDOWN_TO_RIGHTUP):
+            sl, sr = k1_routes.nnn_sites(r0, c0, d)
+            for k, (a, b) in enumerate(pairs):
+                ref = c.ReplaceNNNSiteTrace(tn, (r0, c0), d, orient, sitps[sl[0]][sl[1]][a], sitps[sr[0]][sr[1]][b])
+                assert abs(nnn[d][w, k] - ref) < tol * abs(ref_psi), (d, k, nnn[d][w, k], ref)
+        if orient == HORIZONTAL:
+            c.GrowFullBTen2(tn, RIGHT, r0, c0 + 3, True)
+        else:
+            c.GrowFullBTen2(tn, DOWN, c0, r0 + 3, True)
+        for d in (LEFTUP_TO_RIGHTDOWN, LEFTDOWN_TO_RIGHTUP):
+            sl, sr = k1_routes.sqrt5_sites(r0, c0, d, orient)
+            for k, (a, b) in enumerate(pairs):
+                ref = c.ReplaceSqrt5DistTwoSiteTrace(tn, (r0, c0), d, orient, sitps[sl[0]][sl[1]][a], sitps[sr[0]][sr[1]][b])
+                assert abs(s5[d][w, k] - ref) < tol * abs(ref_psi), (d, k, s5[d][w, k], ref)
+
+
 def test_error_codes():
     from peps_amd import capi
     ctx = capi.Context(4, 4, 2, 2, 4, dtype=capi.F32, max_walkers=2)

@@ -41,6 +41,22 @@ def test_k1_ising_free_energy_all_routes():
         assert abs(-(np.log(a) + lognorm) / 144 / beta - f_ex) < 1e-8
 
 
+def test_k1_ising_all_21_routes_incl_bten2():
+    """The complete route list of Contract2DTNUsingBMPSContractor (test_bmps_contractor.cpp:273-405):
+    NN / TNN traces, BTen2 growth and window shifts, NNN and sqrt(5) replacement traces in both
+    orientations and both diagonal directions; tolerance 1e-8 as the reference (:472-493)."""
+    import k1_routes
+    tn, lognorm, beta = ising.build_ising_tn(12, 12)
+    f_ex = ising.exact_free_energy(12, 12, 1.0 / beta)
+    c = BMPSContractor(12, 12)
+    c.Init(tn)
+    c.SetTruncateParams(BMPSTruncateParams.SVD(10, 30, 1e-15))
+    amps = k1_routes.run_oracle(c, tn)
+    assert len(amps) == k1_routes.N_AMPS
+    for a in amps:
+        assert abs(-(np.log(a) + lognorm) / 144 / beta - f_ex) < 1e-8
+
+
 def test_k3_punch_hole_and_invalidate():
     """tests/test_2d_tn/test_bmps_contractor.cpp:407-470"""
     tn, _, _ = ising.build_ising_tn(12, 12)
