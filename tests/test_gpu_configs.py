@@ -1,0 +1,106 @@
+"""Parity at the sizes BASELINE.json names (configs C1-C4; C5 = fermionic, not built -- DESIGN.md):
+the HIP path through the C ABI / C++ host layer against the float64 oracle on identical inputs,
+plus size-independent properties at the full C4 size (route consistency, PunchHole . site == Trace)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import vmc
+from oracle.bmps import BMPSTruncateParams, LEFT, DOWN, RIGHT, UP, HORIZONTAL, VERTICAL
+from peps_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+F32, F64 = 0, 1
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _host():
+    from peps_amd import hostapi
+    return hostapi
+
+
+def _all_bits(L):
+    n = L * L
+    idx = np.arange(1 << n, dtype=np.int64)
+    return ((idx[:, None] >> np.arange(n)[None, :]) & 1).astype(np.int32).reshape(-1, L, L)
+
+
+@pytest.mark.parametrize("dt,tol", [(F64, 1e-10), (F32, 1e-6)])
+def test_c1_tfim_4x4_exact_summation(dt, tol):
+    """C1: 4x4 TFIM, D=2, chi=4, exact summation over all 2^16 configurations (ExactSumEnergyEvaluator
+    on the device, 2-rank round-robin partition) against the committed oracle golden
+    (scripts/make_c1_golden.py).  north_star: energy 1e-6 relative."""
+    host = _host()
+    g = json.load(open(os.path.join(GOLD, "c1_exact_sum.json")))
+    flat = synthetic.sitps_to_flat(synthetic.make_sitps(4, 2), 2)
+    cfgs = _all_bits(4)
+    packed = sum(host.exact_sum_partial(flat, cfgs, 4, "tfim", (g["h"],), r, 2, 4096, dt) for r in range(2))
+    e, grad = host.exact_sum_finish(packed, flat.shape)
+    assert abs(e / g["energy"] - 1) < tol
+    assert abs(np.sum(grad ** 2) / g["grad_norm2"] - 1) < max(tol * 100, 1e-8)
+    g00 = grad[0, 0, 0].ravel()
+    ref = np.array(g["grad_site00_s0"])
+    nz = g00[np.abs(g00) > 0]
+    assert np.max(np.abs(nz - ref)) < max(tol * 100, 1e-8) * np.max(np.abs(ref))
+    # amplitudes of a few probe configurations
+    from peps_amd import capi
+    ctx = capi.Context(4, 4, 2, 2, 4, dtype=dt, max_walkers=8)
+    ctx.state_upload(flat)
+    ctx.set_configs(cfgs[g["probe_config_index"]])
+    amp = ctx.evaluate_amplitude()
+    assert np.max(np.abs(amp / np.array(g["probe_amplitudes"]) - 1)) < (1e-5 if dt == F32 else 1e-10)
+
+
+def test_c2_tfim_8x8_local_updater_chain_and_energy():
+    """C2: 8x8 TFIM, D=4, chi=16, local MC updater.  f64: the Markov chain is the oracle's chain
+    (same std::mt19937 stream); f32: amplitudes / local energies of fixed configurations 1e-5."""
+    host = _host()
+    L, D, chi, h = 8, 4, 16, 3.0
+    s = synthetic.make_sitps(L, D)
+    flat = synthetic.sitps_to_flat(s, D)
+    cfgs = synthetic.make_configs(L, 3, "tfim")
+    seeds = np.array([21, 22, 23], dtype=np.uint64)
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    out_cfg, amps, rates = host.mc_sweeps(flat, cfgs, seeds, chi, "fullspace", 1, F64)
+    for w in range(len(cfgs)):
+        comp = vmc.TPSWaveFunctionComponent(s, cfgs[w], tp)
+        upd = vmc.MCUpdateSquareNNFullSpaceUpdateOBC(seed=int(seeds[w]))
+        r = upd(s, comp)[0]
+        assert np.array_equal(comp.config, out_cfg[w])
+        assert abs(amps[w] / comp.amplitude - 1) < 1e-8
+        assert abs(rates[w] - r) < 1e-12
+    model = vmc.TransverseFieldIsingSquareOBC(h)
+    a32, e32, _, psi = host.energy_and_holes(flat, cfgs, chi, "tfim", (h,), False, F32)
+    for w in range(len(cfgs)):
+        comp = vmc.TPSWaveFunctionComponent(s, cfgs[w], tp)
+        e, _, _ = model.CalEnergyAndHoles(s, comp, False)
+        assert abs(a32[w] / comp.amplitude - 1) < 1e-5
+        assert abs(e32[w] / e - 1) < 1e-5
+
+
+@pytest.mark.parametrize("name,nref", [("C3", 3), ("C4", 1)])
+def test_c3_c4_heisenberg_amplitude_and_energy(name, nref):
+    """C3 (10x10 D=6 chi=24) and C4 (12x12 D=8 chi=32): f32 device amplitude and XXZ local energy
+    of fixed Sz=0 configurations against the f64 oracle (1e-5 / 1e-5), hole . site == psi."""
+    host = _host()
+    L, D, chi, _ = synthetic.CONFIGS[name]
+    s = synthetic.make_sitps(L, D)
+    flat = synthetic.sitps_to_flat(s, D)
+    cfgs = synthetic.make_configs(L, 4, "heisenberg")
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    amps, en, holes, psi = host.energy_and_holes(flat, cfgs, chi, "xxz", (1.0, 1.0, 0.0), True, F32)
+    # size-independent properties on every walker
+    assert np.max(np.abs(psi / psi[0] - 1)) < 2e-4                 # all 2L-... routes give the same psi
+    for w in range(len(cfgs)):
+        for (r, c) in [(0, 0), (L // 2, L // 2 - 1), (L - 1, L - 1), (3, L - 2)]:
+            t = flat[r, c, cfgs[w, r, c]]
+            assert abs(np.sum(holes[w, r, c] * t) / amps[w] - 1) < 2e-4
+    model = vmc.SquareSpinOneHalfXXZModelOBC()
+    for w in range(nref):
+        comp = vmc.TPSWaveFunctionComponent(s, cfgs[w], tp)
+        assert abs(amps[w] / comp.amplitude - 1) < 1e-5
+        if name == "C3" and w == 0:
+            e, _, _ = model.CalEnergyAndHoles(s, comp, False)
+            assert abs(en[w] / e - 1) < 1e-5
