@@ -62,6 +62,33 @@ def cpu_baseline(sitps, cfgs, chi, budget_s):
     return len(amps) / dt, len(amps), np.array(amps), threads
 
 
+PMC_KERNEL = {"contract": "tgemm_kernel<float, float, float, float", "gram_f64": "tgemm_kernel<float, float, double, double",
+              "cholesky": "chol_upper_kernel<float>", "jacobi": "jacobi_rows_reg256_kernel",
+              "jacobi_edge": "jacobi_rows_kernel<float>"}
+
+
+def pmc_traffic_bytes(category, args, nw):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc_{FETCH,WRITE}_SIZE_c4_f32_nw512.txt: separate passes, values in KiB, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md 'HBM' prescribes for gfx950).  PMC counters cannot be read from
+    inside this process, so the figure is only quoted when the run has the configuration the passes
+    were collected on; otherwise null."""
+    if (args.workload, args.dtype, nw, args.noise) != ("C4", "f32", 512, 0.1) or category not in PMC_KERNEL:
+        return None
+    here = os.path.dirname(os.path.abspath(__file__))
+    vals = {}
+    for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
+        path = os.path.join(here, "profiles", "r01_pmc_%s_c4_f32_nw512.txt" % cnt)
+        if not os.path.exists(path):
+            return None
+        for line in open(path):
+            if PMC_KERNEL[category] in line and cnt in line:
+                vals[cnt] = float(line.split()[-1])          # mean KiB per launch
+    if len(vals) != 2:
+        return None
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -168,7 +195,7 @@ def main():
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
-                "traffic": None,
+                "traffic": pmc_traffic_bytes(dom, args, nw),
                 "avg_launch_ms": prof[dom]["ms"] / max(prof[dom]["launches"], 1),
                 "launches": prof[dom]["launches"],
                 "note": "achieved = reference-algorithm flops of the op this kernel replaces (SURVEY 8d) / "

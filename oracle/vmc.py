@@ -15,7 +15,7 @@ import itertools
 import numpy as np
 
 from .bmps import LEFT, DOWN, RIGHT, UP, HORIZONTAL, VERTICAL
-from .contractor import TensorNetwork2D, BMPSContractor
+from .contractor import TensorNetwork2D, BMPSContractor, LEFTUP_TO_RIGHTDOWN, LEFTDOWN_TO_RIGHTUP
 
 
 class TPSWaveFunctionComponent:
@@ -193,8 +193,9 @@ class MCUpdateSquareNNFullSpaceUpdateOBC(MCUpdateSquareNNUpdateBaseOBC):
 
 # ---------------------------------------------------------------------------------------------
 class SquareNNModelEnergySolver:
-    """square_nnn_energy_solver.h:37-316 with has_nnn_interaction = false
-    (+ bond_traversal_mixin.h:113-144 for the vertical pass)."""
+    """square_nnn_energy_solver.h:37-316 (has_nnn_interaction = false unless a subclass sets it;
+    the NNN pass is :203-265) + bond_traversal_mixin.h:113-144 for the vertical pass."""
+    has_nnn_interaction = False
 
     def CalEnergyAndHoles(self, sitps, comp, calchols=True):
         tn, c = comp.tn, comp.contractor
@@ -221,6 +222,18 @@ class SquareNNModelEnergySolver:
                                                           HORIZONTAL, tn, c, sitps[row][col], sitps[row][col + 1],
                                                           inv_psi))
                     c.ShiftBTenWindow(tn, RIGHT)                          # :200
+            if self.has_nnn_interaction and row < rows - 1:               # :203-265
+                c.InitBTen2(tn, LEFT, row)
+                c.GrowFullBTen2(tn, RIGHT, row, 2, True)
+                for col in range(cols - 1):
+                    s1, s2 = (row, col), (row + 1, col + 1)
+                    e = self.EvaluateNNNEnergy(s1, s2, int(comp.config[s1]), int(comp.config[s2]), LEFTUP_TO_RIGHTDOWN,
+                                               tn, c, sitps[s1[0]][s1[1]], sitps[s2[0]][s2[1]], inv_psi)
+                    s1, s2 = (row + 1, col), (row, col + 1)
+                    e = e + self.EvaluateNNNEnergy(s1, s2, int(comp.config[s1]), int(comp.config[s2]), LEFTDOWN_TO_RIGHTUP,
+                                                   tn, c, sitps[s1[0]][s1[1]], sitps[s2[0]][s2[1]], inv_psi)
+                    bond_e.append(e)
+                    c.ShiftBTen2Window(tn, RIGHT, row)
             if row < rows - 1:
                 c.ShiftBMPSWindow(tn, DOWN)                               # :126
         # vertical pass: bond_traversal_mixin.h:113-144
@@ -263,6 +276,24 @@ class SquareSpinOneHalfXXZModelOBC(SquareNNModelEnergySolver):
     def EvaluateTotalOnsiteEnergy(self, config):
         """:139-141"""
         return -self.pin * (float(config[0, 0]) - 0.5)
+
+
+class SquareSpinOneHalfJ1J2XXZModelOBC(SquareSpinOneHalfXXZModelOBC):
+    """square_spin_onehalf_j1j2_xxz_obc.h:25-40 + SquareSpinOneHalfXXZModelMixIn::EvaluateNNNEnergy
+    (square_spin_onehalf_xxz_obc.h:107-134)"""
+    has_nnn_interaction = True
+
+    def __init__(self, jz=1.0, jxy=1.0, jz2=0.0, jxy2=0.0, pinning00=0.0):
+        super().__init__(jz, jxy, pinning00)
+        self.jz2, self.jxy2 = jz2, jxy2
+
+    def EvaluateNNNEnergy(self, s1, s2, c1, c2, diagonal_dir, tn, contractor, t1, t2, inv_psi):
+        if c1 == c2:
+            return 0.25 * self.jz2
+        left_up = s1 if diagonal_dir == LEFTUP_TO_RIGHTDOWN else (s2[0], s1[1])
+        psi_ex = contractor.ReplaceNNNSiteTrace(tn, left_up, diagonal_dir, HORIZONTAL, t1[c2], t2[c1])
+        ratio = np.conj(psi_ex * inv_psi)
+        return -0.25 * self.jz2 + ratio * 0.5 * self.jxy2
 
 
 class TransverseFieldIsingSquareOBC:

@@ -74,6 +74,9 @@ int pepshost_energy_and_holes(int rows, int cols, int D, int d, int chi, int dty
     if (model == 0) {
       SquareSpinOneHalfXXZModelOBC m(p[0], p[1], p[2]);
       eh = holes_out ? m.CalEnergyAndHoles<true>(sitps, comp) : m.CalEnergyAndHoles<false>(sitps, comp);
+    } else if (model == 2) {
+      SquareSpinOneHalfJ1J2XXZModelOBC m(p[0], p[1], p[2], p[3], p[4]);
+      eh = holes_out ? m.CalEnergyAndHoles<true>(sitps, comp) : m.CalEnergyAndHoles<false>(sitps, comp);
     } else {
       TransverseFieldIsingSquareOBC m(p[0]);
       eh = holes_out ? m.CalEnergyAndHoles<true>(sitps, comp) : m.CalEnergyAndHoles<false>(sitps, comp);
@@ -105,13 +108,16 @@ int pepshost_mc_energy_grad_partial(int rows, int cols, int D, int d, int chi, i
     auto sweep = [&]() { if (updater == 0) ex(sitps, comp, rates); else fs(sitps, comp, rates); };
     for (int s = 0; s < warmup_sweeps; ++s) sweep();
     SquareSpinOneHalfXXZModelOBC xxz(p[0], p[1], p[2]);
+    SquareSpinOneHalfJ1J2XXZModelOBC j1j2(p[0], p[1], p[2], p[3], p[4]);
     TransverseFieldIsingSquareOBC tfim(p[0]);
     GradAccumulator acc(sitps);
     contractor.GradReset();
     for (int k = 0; k < n_samples; ++k) {
       sweep();
       for (int w = 0; w < n; ++w) acc_rate[w] += rates[w];
-      EnergyAndHoles eh = model == 0 ? xxz.CalEnergyAndHoles<true>(sitps, comp, true) : tfim.CalEnergyAndHoles<true>(sitps, comp, true);
+      EnergyAndHoles eh = model == 0   ? xxz.CalEnergyAndHoles<true>(sitps, comp, true)
+                          : model == 2 ? j1j2.CalEnergyAndHoles<true>(sitps, comp, true)
+                                       : tfim.CalEnergyAndHoles<true>(sitps, comp, true);
       acc.AccumulateDevice(comp, eh, false);
     }
     if (n_samples > 0) acc.FetchDevice(contractor);
@@ -136,6 +142,9 @@ int pepshost_exact_sum_partial(int rows, int cols, int D, int d, int chi, int dt
     auto capture = [&](std::vector<double> &v) { packed = v; };
     if (model == 0) {
       SquareSpinOneHalfXXZModelOBC m(p[0], p[1], p[2]);
+      ExactSumEnergyEvaluator(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
+    } else if (model == 2) {
+      SquareSpinOneHalfJ1J2XXZModelOBC m(p[0], p[1], p[2], p[3], p[4]);
       ExactSumEnergyEvaluator(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
     } else {
       TransverseFieldIsingSquareOBC m(p[0]);

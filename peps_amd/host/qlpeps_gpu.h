@@ -466,11 +466,13 @@ struct EnergyAndHoles {
   std::vector<std::vector<double>> psi_list;  // [row/col pass][walker]
 };
 
-// SquareNNNModelEnergySolver with has_nnn_interaction = false (square_nnn_energy_solver.h:37-316)
-// + BondTraversalMixin::TraverseVerticalBonds (bond_traversal_mixin.h:113-144).  CRTP hooks:
-//   EvaluateBondEnergy(site1, site2, orient, comp, inv_psi) -> [walker]   and   EvaluateTotalOnsiteEnergy(config, w)
-template <class ExplicitlyModel>
-class SquareNNModelEnergySolver {
+// SquareNNNModelEnergySolver (square_nnn_energy_solver.h:37-316) + BondTraversalMixin::TraverseVerticalBonds
+// (bond_traversal_mixin.h:113-144).  CRTP hooks:
+//   EvaluateBondEnergy(site1, site2, orient, comp, inv_psi) -> [walker]
+//   EvaluateNNNEnergy(site1, site2, diagonal_dir, comp, inv_psi) -> [walker]     (has_nnn_interaction only)
+//   EvaluateTotalOnsiteEnergy(config, w)
+template <class ExplicitlyModel, bool has_nnn_interaction = true>
+class SquareNNNModelEnergySolver {
  public:
   template <bool calchols = true>
   EnergyAndHoles CalEnergyAndHoles(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp, bool holes_on_device = false) {
@@ -505,6 +507,18 @@ class SquareNNModelEnergySolver {
           c.ShiftBTenWindow(RIGHT);                                           // :200
         }
       }
+      if constexpr (has_nnn_interaction) {                                    // :203-265
+        if (row + 1 < rows) {
+          c.InitBTen2(LEFT, row);
+          c.GrowFullBTen2(RIGHT, row, 2, true);
+          for (size_t col = 0; col + 1 < cols; col++) {
+            std::vector<double> e1 = self->EvaluateNNNEnergy({row, col}, {row + 1, col + 1}, LEFTUP_TO_RIGHTDOWN, comp, inv_psi);
+            std::vector<double> e2 = self->EvaluateNNNEnergy({row + 1, col}, {row, col + 1}, LEFTDOWN_TO_RIGHTUP, comp, inv_psi);
+            for (size_t w = 0; w < n; ++w) out.energy[w] += e1[w] + e2[w];
+            c.ShiftBTen2Window(RIGHT, row);
+          }
+        }
+      }
       if (row + 1 < rows) c.ShiftBMPSWindow(DOWN);                            // :126
     }
     c.GenerateBMPSApproach(LEFT);                                            // bond_traversal_mixin.h:120
@@ -530,11 +544,15 @@ class SquareNNModelEnergySolver {
   }
 };
 
-// square_spin_onehalf_xxz_obc.h:64-190
-class SquareSpinOneHalfXXZModelOBC : public SquareNNModelEnergySolver<SquareSpinOneHalfXXZModelOBC> {
+// square_nn_energy_solver.h:25
+template <class ExplicitlyModel>
+using SquareNNModelEnergySolver = SquareNNNModelEnergySolver<ExplicitlyModel, false>;
+
+// SquareSpinOneHalfXXZModelMixIn (square_spin_onehalf_xxz_obc.h:64-141): the bond / NNN-link / on-site terms
+class SquareSpinOneHalfXXZModelMixIn {
  public:
-  SquareSpinOneHalfXXZModelOBC() : jz_(1.0), jxy_(1.0), pinning00_(0.0) {}
-  SquareSpinOneHalfXXZModelOBC(double jz, double jxy, double pinning00) : jz_(jz), jxy_(jxy), pinning00_(pinning00) {}
+  SquareSpinOneHalfXXZModelMixIn(double jz, double jxy, double jz2, double jxy2, double pinning00)
+      : jz_(jz), jxy_(jxy), jz2_(jz2), jxy2_(jxy2), pinning00_(pinning00) {}
   std::vector<double> EvaluateBondEnergy(const SiteIdx &s1, const SiteIdx &s2, BondOrientation orient,
                                          TPSWaveFunctionComponent &comp, const std::vector<double> &inv_psi) {   // :72-104
     const size_t n = comp.config.walkers();
@@ -552,11 +570,48 @@ class SquareSpinOneHalfXXZModelOBC : public SquareNNModelEnergySolver<SquareSpin
       if (comp.config(w, s1) != comp.config(w, s2)) e[w] = -0.25 * jz_ + psi_ex[w] * inv_psi[w] * 0.5 * jxy_;
     return e;
   }
+  // :107-134; site1 = left end of the diagonal, site2 = right end
+  std::vector<double> EvaluateNNNEnergy(const SiteIdx &s1, const SiteIdx &s2, DIAGONAL_DIR diagonal_dir,
+                                        TPSWaveFunctionComponent &comp, const std::vector<double> &inv_psi) {
+    const size_t n = comp.config.walkers();
+    std::vector<int32_t> cand(n * 2);
+    bool any = false;
+    for (size_t w = 0; w < n; ++w) {
+      cand[2 * w] = comp.config(w, s2);
+      cand[2 * w + 1] = comp.config(w, s1);
+      any |= cand[2 * w] != cand[2 * w + 1];
+    }
+    std::vector<double> e(n, 0.25 * jz2_);
+    if (!any) return e;
+    const SiteIdx left_up = diagonal_dir == LEFTUP_TO_RIGHTDOWN ? s1 : SiteIdx{s2.r, s1.c};
+    std::vector<double> psi_ex = comp.contractor.ReplaceNNNSiteTrace(left_up, diagonal_dir, HORIZONTAL, 1, cand);
+    for (size_t w = 0; w < n; ++w)
+      if (comp.config(w, s1) != comp.config(w, s2)) e[w] = -0.25 * jz2_ + psi_ex[w] * inv_psi[w] * 0.5 * jxy2_;
+    return e;
+  }
   double EvaluateTotalOnsiteEnergy(const Configuration &config, size_t w) const {   // :139-141
     return -pinning00_ * (double(config(w, {0, 0})) - 0.5);
   }
- private:
-  double jz_, jxy_, pinning00_;
+ protected:
+  double jz_, jxy_, jz2_, jxy2_, pinning00_;
+};
+
+// square_spin_onehalf_xxz_obc.h:174-190
+class SquareSpinOneHalfXXZModelOBC : public SquareNNModelEnergySolver<SquareSpinOneHalfXXZModelOBC>,
+                                     public SquareSpinOneHalfXXZModelMixIn {
+ public:
+  SquareSpinOneHalfXXZModelOBC() : SquareSpinOneHalfXXZModelMixIn(1.0, 1.0, 0.0, 0.0, 0.0) {}
+  SquareSpinOneHalfXXZModelOBC(double jz, double jxy, double pinning00)
+      : SquareSpinOneHalfXXZModelMixIn(jz, jxy, 0.0, 0.0, pinning00) {}
+};
+
+// square_spin_onehalf_j1j2_xxz_obc.h:25-40
+class SquareSpinOneHalfJ1J2XXZModelOBC : public SquareNNNModelEnergySolver<SquareSpinOneHalfJ1J2XXZModelOBC>,
+                                         public SquareSpinOneHalfXXZModelMixIn {
+ public:
+  explicit SquareSpinOneHalfJ1J2XXZModelOBC(double j2) : SquareSpinOneHalfXXZModelMixIn(1, 1, j2, j2, 0) {}
+  SquareSpinOneHalfJ1J2XXZModelOBC(double jz, double jxy, double jz2, double jxy2, double pinning_field00)
+      : SquareSpinOneHalfXXZModelMixIn(jz, jxy, jz2, jxy2, pinning_field00) {}
 };
 
 // transverse_field_ising_square_obc.h:28-247

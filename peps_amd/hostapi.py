@@ -37,6 +37,9 @@ def _ck(rc):
         raise {1: ValueError, 3: RuntimeError, 4: IndexError}.get(rc, RuntimeError)("pepshost error %d: %s" % (rc, msg))
 
 
+MODEL_ID = {"xxz": 0, "tfim": 1, "j1j2": 2}   # params: xxz (jz, jxy, pinning00); tfim (h,); j1j2 (jz, jxy, jz2, jxy2, pinning00)
+
+
 def _dims(flat):
     rows, cols, d, D = flat.shape[0], flat.shape[1], flat.shape[2], flat.shape[3]
     return rows, cols, d, D
@@ -61,13 +64,13 @@ def energy_and_holes(flat, configs, chi, model="xxz", params=(1.0, 1.0, 0.0), ho
     rows, cols, d, D = _dims(flat)
     cfg = np.ascontiguousarray(configs, dtype=np.int32)
     n = cfg.shape[0]
-    p = np.array(list(params) + [0.0, 0.0, 0.0], dtype=np.float64)
+    p = np.array(list(params) + [0.0] * 8, dtype=np.float64)
     amps, en = np.zeros(n), np.zeros(n)
     h = np.zeros((n, rows, cols, D, D, D, D)) if holes else None
     psi = np.zeros((rows + cols, n))
     npsi = C.c_int(0)
     _ck(lib().pepshost_energy_and_holes(rows, cols, D, d, chi, dtype, _p(flat, C.c_double), n, _p(cfg, C.c_int32),
-                                        0 if model == "xxz" else 1, _p(p, C.c_double), _p(amps, C.c_double),
+                                        MODEL_ID[model], _p(p, C.c_double), _p(amps, C.c_double),
                                         _p(en, C.c_double), _p(h, C.c_double), _p(psi, C.c_double), C.byref(npsi)))
     return amps, en, h, psi[:npsi.value]
 
@@ -76,10 +79,10 @@ def exact_sum_partial(flat, all_configs, chi, model="xxz", params=(1.0, 1.0, 0.0
     flat = np.ascontiguousarray(flat, dtype=np.float64)
     rows, cols, d, D = _dims(flat)
     cfg = np.ascontiguousarray(all_configs, dtype=np.int32)
-    p = np.array(list(params) + [0.0, 0.0, 0.0], dtype=np.float64)
+    p = np.array(list(params) + [0.0] * 8, dtype=np.float64)
     packed = np.zeros(2 * flat.size + 4)
     _ck(lib().pepshost_exact_sum_partial(rows, cols, D, d, chi, dtype, _p(flat, C.c_double), _p(cfg, C.c_int32),
-                                         cfg.shape[0], 0 if model == "xxz" else 1, _p(p, C.c_double), rank, size, batch,
+                                         cfg.shape[0], MODEL_ID[model], _p(p, C.c_double), rank, size, batch,
                                          _p(packed, C.c_double)))
     return packed
 
@@ -110,11 +113,11 @@ def mc_energy_grad_partial(flat, configs, seeds, chi, updater="exchange", model=
     cfg = np.ascontiguousarray(configs, dtype=np.int32).copy()
     n = cfg.shape[0]
     sd = np.ascontiguousarray(seeds, dtype=np.uint64)
-    p = np.array(list(params) + [0.0, 0.0, 0.0], dtype=np.float64)
+    p = np.array(list(params) + [0.0] * 8, dtype=np.float64)
     packed = np.zeros(2 * flat.size + 4)
     acc = np.zeros(n)
     _ck(lib().pepshost_mc_energy_grad_partial(rows, cols, D, d, chi, dtype, _p(flat, C.c_double), n, _p(cfg, C.c_int32),
                                               _p(sd, C.c_uint64), 0 if updater == "exchange" else 1,
-                                              0 if model == "xxz" else 1, _p(p, C.c_double), warmup_sweeps, n_samples,
+                                              MODEL_ID[model], _p(p, C.c_double), warmup_sweeps, n_samples,
                                               _p(packed, C.c_double), _p(acc, C.c_double)))
     return packed, cfg, acc

@@ -200,3 +200,27 @@ def test_mc_energy_and_gradient_vs_exact_sum(fixtures_dir):
     assert abs(e_mc - e_ex) < 6 * err + 1e-3
     cosang = np.sum(g_mc * g_ex) / np.linalg.norm(g_mc) / np.linalg.norm(g_ex) if np.linalg.norm(g_ex) > 1e-8 else 1.0
     assert np.linalg.norm(g_mc - g_ex) < 0.3 * max(np.linalg.norm(g_ex), 0.05) or cosang > 0.9
+
+
+@pytest.mark.parametrize("dt,tol", [(F64, 1e-9), (F32, 2e-5)])
+def test_j1j2_energy_fixed_configs_and_exact_sum(dt, tol):
+    """J1-J2 XXZ (SquareSpinOneHalfJ1J2XXZModelOBC): the NNN pass of square_nnn_energy_solver.h:203-265
+    on the device (BTen2 growth, ShiftBTen2Window, ReplaceNNNSiteTrace per diagonal) against the oracle
+    on identical configurations, and the 3x3 exact-sum energy against the oracle's."""
+    host = _host()
+    L, D, chi = 5, 3, 9
+    s = synthetic.make_sitps(L, D)
+    cfgs = synthetic.make_configs(L, 5, "heisenberg")
+    params = (1.0, 0.9, 0.4, 0.55, 0.1)
+    ref = _oracle_energy(s, cfgs, chi, vmc.SquareSpinOneHalfJ1J2XXZModelOBC(*params))
+    amps, en, holes, psi = host.energy_and_holes(synthetic.sitps_to_flat(s, D), cfgs, chi, "j1j2", params, True, dt)
+    for w, (a, e, h, ps) in enumerate(ref):
+        assert abs(amps[w] / a - 1) < tol
+        assert abs(en[w] - e) < tol * max(1.0, abs(e)) * 10
+    s3 = synthetic.make_sitps(3, 2)
+    all_cfg = np.array(vmc.all_product_configs(2, 3, 3)).astype(np.int32)
+    packed = host.exact_sum_partial(synthetic.sitps_to_flat(s3, 2), all_cfg, 16, "j1j2", params, 0, 1, 128, dt)
+    e, grad = host.exact_sum_finish(packed, (3, 3, 2, 2))
+    e_o, g_o, _ = vmc.exact_sum_energy_evaluator(s3, list(all_cfg), BMPSTruncateParams.SVD(16, 16, 0.0),
+                                                 vmc.SquareSpinOneHalfJ1J2XXZModelOBC(*params))
+    assert abs(e / e_o - 1) < tol

@@ -168,3 +168,37 @@ def test_sweep_keeps_amplitude_consistent(fixtures_dir):
     upd2(s, comp)
     fresh = vmc.TPSWaveFunctionComponent(s, comp.config, tp)
     assert abs(fresh.amplitude - comp.amplitude) < 1e-9 * abs(fresh.amplitude)
+
+
+def test_j1j2_nnn_solver_matches_dense_hamiltonian():
+    """SquareSpinOneHalfJ1J2XXZModelOBC (NNN pass of square_nnn_energy_solver.h:203-265 through
+    BTen2 / ReplaceNNNSiteTrace) against <psi|H|psi>/<psi|psi> with a dense 512x512 J1-J2 Hamiltonian
+    built independently, 3x3 OBC, exact chi."""
+    from peps_amd import synthetic
+    sitps = synthetic.make_sitps(3, 2)
+    j2 = 0.5
+    model = vmc.SquareSpinOneHalfJ1J2XXZModelOBC(1.0, 1.0, j2, j2, 0.0)
+    cfgs = vmc.all_product_configs(2, 3, 3)
+    tp = BMPSTruncateParams.SVD(16, 16, 0.0)
+    e, _, _ = vmc.exact_sum_energy_evaluator(sitps, cfgs, tp, model)
+    psi = np.array([vmc.TPSWaveFunctionComponent(sitps, c, tp).amplitude for c in cfgs])
+    idx = {tuple(c.ravel()): i for i, c in enumerate(cfgs)}
+    bonds = []
+    for r in range(3):
+        for c in range(3):
+            if c < 2: bonds.append(((r, c), (r, c + 1), 1.0))
+            if r < 2: bonds.append(((r, c), (r + 1, c), 1.0))
+            if r < 2 and c < 2:
+                bonds.append(((r, c), (r + 1, c + 1), j2))
+                bonds.append(((r + 1, c), (r, c + 1), j2))
+    H = np.zeros((len(cfgs), len(cfgs)))
+    for i, cf in enumerate(cfgs):
+        for a, b, J in bonds:
+            if cf[a] == cf[b]:
+                H[i, i] += 0.25 * J
+            else:
+                H[i, i] -= 0.25 * J
+                c2 = cf.copy()
+                c2[a], c2[b] = cf[b], cf[a]
+                H[idx[tuple(c2.ravel())], i] += 0.5 * J
+    assert abs(e - psi @ H @ psi / (psi @ psi)) < 1e-12
