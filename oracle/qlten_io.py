@@ -82,3 +82,60 @@ def load_configuration(path, rows, cols):
     with open(path) as f:
         vals = [int(x) for x in f.read().split()]
     return np.array(vals[:rows * cols], dtype=np.int64).reshape(rows, cols)
+
+
+# ---------------------------------------------------------------------------------------------
+# Writer (dense TrivialRepQN tensors): byte-identical to the files the reference writes.  The two
+# hash fields were recovered from the fixtures (8 distinct (dir, dim) pairs over 168 files, all
+# reproduced): sector_hash = qn_hash ^ degeneracy with qn_hash = 0; index_hash = VecHash(sector
+# hashes) ^ std::hash<int>(dir), VecHash = the xxHash-style tuple hash (acc = P5; per lane
+# acc += lane*P2, rotl 31, *= P1; acc += len ^ P5).
+_M64 = (1 << 64) - 1
+_P1, _P2, _P5 = 0x9E3779B185EBCA87, 0xC2B2AE3D27D4EB4F, 0x27D4EB2F165667C5
+
+
+def trivial_index_hash(direction, dim):
+    acc = (_P5 + dim * _P2) & _M64
+    acc = ((acc << 31) | (acc >> 33)) & _M64
+    acc = (acc * _P1) & _M64
+    acc = (acc + (1 ^ _P5)) & _M64
+    return acc ^ (1 if direction == 1 else _M64)
+
+
+SITE_LEG_DIRS = (-1, 1, 1, -1)     # (L, D, R, U): IN, OUT, OUT, IN as in every fixture
+
+
+def save_qlten(path, arr, dirs=SITE_LEG_DIRS):
+    arr = np.asarray(arr)
+    cplx = np.iscomplexobj(arr)
+    head = ["%d" % arr.ndim]
+    for k in range(arr.ndim):
+        dim = arr.shape[k]
+        head += ["1", "%d" % dim, "%d" % dim, "%d" % dirs[k], "%d" % dim, "%d" % trivial_index_hash(dirs[k], dim)]
+    head += ["1"] + ["0"] * arr.ndim
+    with open(path, "wb") as f:
+        f.write(("\n".join(head) + "\n").encode())
+        f.write(np.ascontiguousarray(arr, dtype="<c16" if cplx else "<f8").tobytes())
+        f.write(b"\n")
+
+
+def save_sitps(directory, sitps, with_bc=True):
+    """SplitIndexTPS::Dump (split_index_tps_impl.h:300-330); meta = 'rows cols phy_dim [bc]' (bc 0 = open)."""
+    os.makedirs(directory, exist_ok=True)
+    rows, cols, d = len(sitps), len(sitps[0]), len(sitps[0][0])
+    for r in range(rows):
+        for c in range(cols):
+            for s in range(d):
+                save_qlten(os.path.join(directory, "tps_ten%d_%d_%d.qlten" % (r, c, s)), sitps[r][c][s])
+    with open(os.path.join(directory, "tps_meta.txt"), "wb") as f:
+        f.write(("%d %d %d" % (rows, cols, d) + (" 0" if with_bc else "")).encode())
+
+
+def save_configuration(path, config):
+    """Configuration::StreamWrite (configuration.h:457-464) + the .shape sidecar (:303-309)."""
+    cfg = np.asarray(config)
+    with open(path, "w") as f:
+        for row in cfg:
+            f.write(" ".join(str(int(x)) for x in row) + "\n")
+    with open(path + ".shape", "w") as f:
+        f.write("%d %d\n" % cfg.shape)

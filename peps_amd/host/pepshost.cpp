@@ -179,4 +179,22 @@ int pepshost_load_sitps(const char *dir, int D, int *rows, int *cols, int *d, do
   });
 }
 
+// SplitIndexTPS::Dump (OBC leg dimensions) and the configuration{label} text files
+int pepshost_dump_sitps(const char *dir, int rows, int cols, int D, int d, const double *flat) {
+  return guarded([&]() {
+    SplitIndexTPS s = make_state(rows, cols, D, d, flat);
+    s.Dump(dir);
+  });
+}
+int pepshost_dump_configuration(const char *dir, int label, int rows, int cols, const int32_t *config) {
+  return guarded([&]() { DumpConfiguration(make_cfg(1, rows, cols, config), 0, dir, (size_t)label); });
+}
+int pepshost_load_configuration(const char *dir, int label, int rows, int cols, int32_t *config_out) {
+  return guarded([&]() {
+    Configuration c(1, rows, cols);
+    LoadConfiguration(c, 0, dir, (size_t)label);
+    std::copy(c.data(), c.data() + (size_t)rows * cols, config_out);
+  });
+}
+
 }  // extern "C"

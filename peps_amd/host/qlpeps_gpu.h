@@ -10,8 +10,12 @@
 //   TPSWaveFunctionComponent     wave_function_component.h:136-379   qlpeps_gpu::TPSWaveFunctionComponent
 //   MCUpdateSquareNN*OBC         square_nn_updater.h:25-293   qlpeps_gpu::MCUpdateSquareNN*OBC (CRTP)
 //   SuwaTodoStateUpdate          suwa_todo_update.h:53-112    qlpeps_gpu::SuwaTodoStateUpdate
-//   SquareNNModelEnergySolver    square_nnn_energy_solver.h   qlpeps_gpu::SquareNNModelEnergySolver (CRTP)
+//   SquareNNNModelEnergySolver   square_nnn_energy_solver.h   qlpeps_gpu::SquareNNNModelEnergySolver<Model, has_nnn> (CRTP)
+//   SquareNNModelEnergySolver    square_nn_energy_solver.h:25 alias with has_nnn_interaction = false
 //   SquareSpinOneHalfXXZModelOBC square_spin_onehalf_xxz_obc.h:64-190
+//   SquareSpinOneHalfJ1J2XXZModelOBC square_spin_onehalf_j1j2_xxz_obc.h:25-40 (NNN pass on BTen2)
+//   SplitIndexTPS::Load / Dump   split_index_tps_impl.h:300-437 (byte-identical .qlten files)
+//   Configuration Load / Dump    configuration.h:284-330, :446-464
 //   TransverseFieldIsingSquareOBC transverse_field_ising_square_obc.h:28-247
 //   ExactSumEnergyEvaluatorMPI   exact_summation_energy_evaluator.h:173-302
 //   MCEnergyGradEvaluator accumulation  mc_energy_grad_evaluator.h:245-310
@@ -19,6 +23,7 @@
 // Error codes of the ABI are re-raised as the reference's exception types.
 #pragma once
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <fstream>
@@ -147,10 +152,80 @@ class SplitIndexTPS {
     return t;
   }
 
+  // SplitIndexTPS::Dump (split_index_tps_impl.h:300-330): the same files Load reads, byte-identical
+  // to the reference's for dense TrivialRepQN tensors (round trip of the reference fixtures is the
+  // test).  dims(r, c) = the true (un-padded) leg dimensions (L, D, R, U); OBC default: boundary legs 1.
+  static uint64_t TrivialIndexHash(int dir, uint64_t dim) {
+    // index_hash = VecHash({sector_hash}) ^ std::hash<int>(dir), sector_hash = 0 ^ degeneracy; VecHash is the
+    // xxHash-style tuple hash (recovered from the 168 fixture files of the reference, 8 distinct (dir, dim) pairs)
+    const uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full, P5 = 0x27D4EB2F165667C5ull;
+    uint64_t acc = P5 + dim * P2;
+    acc = (acc << 31) | (acc >> 33);
+    acc *= P1;
+    acc += (1ull ^ P5);
+    return acc ^ (dir == 1 ? 1ull : ~0ull);
+  }
+  void Dump(const std::string &dir, const std::function<std::array<size_t, 4>(size_t, size_t)> &dims = nullptr) const {
+    auto obc = [&](size_t r, size_t c) {
+      return std::array<size_t, 4>{c == 0 ? 1 : D_, r + 1 == rows_ ? 1 : D_, c + 1 == cols_ ? 1 : D_, r == 0 ? 1 : D_};
+    };
+    const int dirs[4] = {-1, 1, 1, -1};   // (L, D, R, U) = IN, OUT, OUT, IN in every reference fixture
+    for (size_t r = 0; r < rows_; ++r)
+      for (size_t c = 0; c < cols_; ++c) {
+        const std::array<size_t, 4> dd = dims ? dims(r, c) : obc(r, c);
+        for (size_t s = 0; s < d_; ++s) {
+          std::string path = dir + "/tps_ten" + std::to_string(r) + "_" + std::to_string(c) + "_" + std::to_string(s) + ".qlten";
+          std::ofstream f(path, std::ios::binary);
+          if (!f) throw std::ios_base::failure("Failed to open file: " + path);
+          f << 4 << "\n";
+          for (int k = 0; k < 4; ++k)
+            f << 1 << "\n" << dd[k] << "\n" << dd[k] << "\n" << dirs[k] << "\n" << dd[k] << "\n" << TrivialIndexHash(dirs[k], dd[k]) << "\n";
+          f << 1 << "\n0\n0\n0\n0\n";
+          const double *src = component(r, c, s);
+          std::vector<double> buf;
+          buf.reserve(dd[0] * dd[1] * dd[2] * dd[3]);
+          for (size_t a = 0; a < dd[0]; ++a)
+            for (size_t b = 0; b < dd[1]; ++b)
+              for (size_t cc = 0; cc < dd[2]; ++cc)
+                for (size_t e = 0; e < dd[3]; ++e) buf.push_back(src[((a * D_ + b) * D_ + cc) * D_ + e]);
+          f.write(reinterpret_cast<const char *>(buf.data()), buf.size() * sizeof(double));
+          f << "\n";
+          if (!f) throw std::ios_base::failure("Failed to write: " + path);
+        }
+      }
+    std::ofstream meta(dir + "/tps_meta.txt", std::ios::binary);
+    if (!meta) throw std::ios_base::failure("Failed to open metadata file: " + dir + "/tps_meta.txt");
+    meta << rows_ << " " << cols_ << " " << d_ << " " << 0;   // BoundaryCondition::Open
+  }
+
  private:
   size_t rows_ = 0, cols_ = 0, d_ = 0, D_ = 0;
   std::vector<double> v_;
 };
+
+// Configuration::Dump / Load for one walker (configuration.h:284-330, :446-464): text matrix
+// `configuration{label}` + the `.shape` sidecar.
+inline void DumpConfiguration(const Configuration &cfg, size_t walker, const std::string &directory, size_t label) {
+  const std::string file = directory + "/configuration" + std::to_string(label);
+  std::ofstream ofs(file, std::ofstream::binary);
+  if (!ofs.is_open()) throw std::ios_base::failure("Failed to open file: " + file);
+  for (size_t r = 0; r < cfg.rows(); ++r) {
+    for (size_t c = 0; c + 1 < cfg.cols(); ++c) ofs << cfg(walker, {r, c}) << " ";
+    ofs << cfg(walker, {r, cfg.cols() - 1}) << std::endl;
+  }
+  std::ofstream sofs(file + ".shape");
+  if (sofs.is_open()) sofs << cfg.rows() << " " << cfg.cols() << "\n";
+}
+inline void LoadConfiguration(Configuration &cfg, size_t walker, const std::string &directory, size_t label) {
+  const std::string file = directory + "/configuration" + std::to_string(label);
+  std::ifstream ifs(file, std::ifstream::binary);
+  if (!ifs.is_open()) throw std::ios_base::failure("Failed to open file: " + file);
+  for (size_t r = 0; r < cfg.rows(); ++r)
+    for (size_t c = 0; c < cfg.cols(); ++c)
+      if (!(ifs >> cfg(walker, {r, c})))
+        throw std::runtime_error("Configuration::StreamRead: Failed to read data from stream (row " + std::to_string(r) +
+                                 ", col " + std::to_string(c) + ")");
+}
 
 // BMPSContractor (bmps_contractor.h:187-1027): same method names; `tn` arguments disappear because
 // the projected network is (sitps, configs) held by the context.  Scalars come back per walker.
@@ -191,6 +266,48 @@ class BMPSContractor {
   void ShiftBTenWindow(BTenPOSITION p) { check_rc(pepsgpu_shift_bten_window(ctx_, p), ctx_); }
   void TruncateBTen(BTenPOSITION p, size_t len) { check_rc(pepsgpu_truncate_bten(ctx_, p, (int)len), ctx_); }
   void EraseEnvsAfterUpdate(const SiteIdx &s) { check_rc(pepsgpu_erase_envs_after_update(ctx_, (int)s.r, (int)s.c), ctx_); }
+  // CheckInvalidateEnvs (trace.h:591-626): no cached environment may cross `site` after an accepted
+  // move.  The reference asserts in debug builds; here the check always runs and throws.
+  void CheckInvalidateEnvs(const SiteIdx &s) const {
+    const int lim[4] = {(int)s.c + 1, (int)(rows_ - s.r), (int)(cols_ - s.c), (int)s.r + 1};   // LEFT, DOWN, RIGHT, UP
+    for (int pos = 0; pos < 4; ++pos)
+      if (pepsgpu_bmps_stack_size(ctx_, pos) > lim[pos] || pepsgpu_bten_stack_size(ctx_, pos) > lim[pos] ||
+          pepsgpu_bten2_stack_size(ctx_, pos) > lim[pos])
+        throw std::logic_error("BMPSContractor::CheckInvalidateEnvs: stale environment beyond the updated site");
+  }
+  // DirectionCheck (grow.h:185-198): a stack only ever holds BMPS of its own direction here (the
+  // direction is the stack index on the device), so the invariant holds by construction.
+  bool DirectionCheck() const { return true; }
+  size_t BMPSStackSize(BMPSPOSITION p) const { return (size_t)pepsgpu_bmps_stack_size(ctx_, p); }   // GetBMPS(p).size()
+  // Host copy of one boundary MPS, GetBMPS(pos)[level] (bmps_contractor.h:236-247): tensors[i] is
+  // [walker][d0*d1*d2] with dims[i], times exp(logscale[walker]).  The gauge differs from the reference.
+  struct BMPSHost {
+    std::vector<std::array<int, 3>> dims;
+    std::vector<std::vector<double>> tensors;
+    std::vector<double> logscale;
+  };
+  BMPSHost GetBMPS(BMPSPOSITION p, size_t level) const {
+    const size_t len = (p == UP || p == DOWN) ? cols_ : rows_, n = walkers();
+    BMPSHost b;
+    b.dims.resize(len); b.tensors.resize(len); b.logscale.assign(n, 0.0);
+    for (size_t i = 0; i < len; ++i) {
+      int d[3];
+      check_rc(pepsgpu_get_bmps_tensor(ctx_, p, (int)level, (int)i, d, nullptr, nullptr), ctx_);
+      b.dims[i] = {d[0], d[1], d[2]};
+      b.tensors[i].resize(n * (size_t)d[0] * d[1] * d[2]);
+      check_rc(pepsgpu_get_bmps_tensor(ctx_, p, (int)level, (int)i, d, b.tensors[i].data(), b.logscale.data()), ctx_);
+    }
+    return b;
+  }
+  // GetBMPSForRow / GetBMPSForCol (grow.h:124-141): grow, then the (UP, DOWN) / (LEFT, RIGHT) pair of the slice
+  std::pair<BMPSHost, BMPSHost> GetBMPSForRow(size_t row) {
+    GrowBMPSForRow(row);
+    return {GetBMPS(UP, row), GetBMPS(DOWN, rows_ - 1 - row)};
+  }
+  std::pair<BMPSHost, BMPSHost> GetBMPSForCol(size_t col) {
+    GrowBMPSForCol(col);
+    return {GetBMPS(LEFT, col), GetBMPS(RIGHT, cols_ - 1 - col)};
+  }
 
   std::vector<double> Trace(const SiteIdx &a, BondOrientation dir) const {
     std::vector<double> out(walkers());

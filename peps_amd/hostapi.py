@@ -121,3 +121,22 @@ def mc_energy_grad_partial(flat, configs, seeds, chi, updater="exchange", model=
                                               MODEL_ID[model], _p(p, C.c_double), warmup_sweeps, n_samples,
                                               _p(packed, C.c_double), _p(acc, C.c_double)))
     return packed, cfg, acc
+
+
+def dump_sitps(directory, flat):
+    """SplitIndexTPS::Dump (split_index_tps_impl.h:300-330) of a padded OBC state."""
+    flat = np.ascontiguousarray(flat, dtype=np.float64)
+    rows, cols, d, D = _dims(flat)
+    os.makedirs(directory, exist_ok=True)
+    _ck(lib().pepshost_dump_sitps(directory.encode(), rows, cols, D, d, _p(flat, C.c_double)))
+
+
+def dump_configuration(directory, label, config):
+    cfg = np.ascontiguousarray(config, dtype=np.int32)
+    _ck(lib().pepshost_dump_configuration(directory.encode(), label, cfg.shape[0], cfg.shape[1], _p(cfg, C.c_int32)))
+
+
+def load_configuration(directory, label, rows, cols):
+    out = np.zeros((rows, cols), dtype=np.int32)
+    _ck(lib().pepshost_load_configuration(directory.encode(), label, rows, cols, _p(out, C.c_int32)))
+    return out

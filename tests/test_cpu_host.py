@@ -54,6 +54,34 @@ def test_cpp_qlten_loader_matches_oracle(fixtures_dir):
         hostapi.load_sitps(os.path.join(fixtures_dir, "does_not_exist"), 8)
 
 
+@pytest.mark.parametrize("name,D", [("tps_square_heisenberg4x4D8Double", 8), ("heisenberg_tps_double_from_simple_update", 4),
+                                    ("transverse_ising_tps_doublelowest", 4)])
+def test_qlten_writer_round_trip_is_byte_identical(fixtures_dir, tmp_path, name, D):
+    """SplitIndexTPS::Load -> Dump through the C++ host layer, and the oracle's reader -> writer,
+    reproduce the reference's fixture files byte for byte (header hashes included), and the
+    configuration{rank} text files round-trip (split_index_tps_impl.h:300-437, configuration.h:284-464)."""
+    import filecmp
+    from peps_amd import hostapi
+    from oracle import qlten_io
+    src = os.path.join(fixtures_dir, name)
+    files = sorted(f for f in os.listdir(src) if f.endswith(".qlten"))
+    out_cpp, out_py = str(tmp_path / "cpp"), str(tmp_path / "py")
+    hostapi.dump_sitps(out_cpp, hostapi.load_sitps(src, D))
+    qlten_io.save_sitps(out_py, qlten_io.load_sitps(src), with_bc=False)
+    for f in files:
+        assert filecmp.cmp(os.path.join(src, f), os.path.join(out_cpp, f), shallow=False), f
+        assert filecmp.cmp(os.path.join(src, f), os.path.join(out_py, f), shallow=False), f
+    assert open(os.path.join(out_cpp, "tps_meta.txt")).read().split()[:3] == open(os.path.join(src, "tps_meta.txt")).read().split()[:3]
+    cfgs = sorted(f for f in os.listdir(src) if f.startswith("configuration") and "." not in f)
+    rows, cols = [int(x) for x in open(os.path.join(src, "tps_meta.txt")).read().split()[:2]]
+    for f in cfgs[:4]:
+        label = int(f[len("configuration"):])
+        c = hostapi.load_configuration(src, label, rows, cols)
+        assert np.array_equal(c, qlten_io.load_configuration(os.path.join(src, f), rows, cols))
+        hostapi.dump_configuration(out_cpp, label, c)
+        assert filecmp.cmp(os.path.join(src, f), os.path.join(out_cpp, f), shallow=False)
+
+
 def test_flop_model_matches_survey():
     from peps_amd.flops import reference_flops
     assert abs(reference_flops(12, 8, 32)["total"] / 7.07e10 - 1) < 5e-3
