@@ -259,7 +259,17 @@ static void diag_jacobi_t(void *M, int m, int len, int nbatch, int k, void *Vt, 
   if (sizeof(T) == 4 && force_global == 2) {
     PG_REQUIRE(m <= 256 && len <= 256, 1, "register Jacobi handles up to 256 x 256");
     hipLaunchKernelGGL(jacobi_rows_reg256_kernel, dim3(nbatch), dim3(512), 0, 0, (float *)dM, (long)m * len, m, len, len,
-                       40, dsw, (const int *)nullptr, 1);
+                       40, dsw, (const int *)nullptr, 1, 0);
+  } else if (sizeof(T) == 4 && force_global == 3) {   // one-wave-per-walker kernel (up to 32 x 256)
+    PG_REQUIRE(m <= JR_SMALL_ROWS && len <= 256, 1, "small Jacobi handles up to 32 x 256");
+    std::vector<int> hm(nbatch, m);
+    int *dm;
+    PG_CHECK_HIP(hipMalloc(&dm, nbatch * sizeof(int)));
+    PG_CHECK_HIP(hipMemcpy(dm, hm.data(), nbatch * sizeof(int), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(jacobi_rows_small_kernel, dim3((nbatch + 3) / 4), dim3(256), 0, 0, (float *)dM, (long)m * len, m, len,
+                       len, 40, dsw, (const int *)dm, 1, nbatch);
+    PG_CHECK_HIP(hipDeviceSynchronize());
+    (void)hipFree(dm);
   } else {
     hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nbatch), dim3(1024), use_lds ? need : 0, 0, dM, (long)m * len, m, len,
                        len, 40, use_lds, dsw, (const int *)nullptr, 1);

@@ -26,8 +26,15 @@ void Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
   if constexpr (sizeof(T) == 4) {
     static const bool no_reg = getenv("PEPSGPU_NO_REGJACOBI") != nullptr;
     if (!use_lds && m <= 256 && len <= 256 && !no_reg) {
+      static const bool no_small = getenv("PEPSGPU_NO_SMALLJACOBI") != nullptr;
+      const int small = (mdyn && !no_small) ? 1 : 0;
+      if (small) {
+        hipLaunchKernelGGL(jacobi_rows_small_kernel, dim3((nw_ + 3) / 4), dim3(256), 0, stream_, (float *)M, wM, m, len, len,
+                           40, sweeps_, mdyn, mdyn_mul, nw_);
+        PG_CHECK_HIP(hipGetLastError());
+      }
       hipLaunchKernelGGL(jacobi_rows_reg256_kernel, dim3(nw_), dim3(512), 0, stream_, (float *)M, wM, m, len, len, 40,
-                         sweeps_, mdyn, mdyn_mul);
+                         sweeps_, mdyn, mdyn_mul, small);
       PG_CHECK_HIP(hipGetLastError());
       return;
     }
@@ -128,9 +135,10 @@ void Engine<T>::absorb(int pos, int num) {
         g.J[2] = cols; g.sBj[2] = 1; g.sCj[2] = 1;
         g.wA = P.n; g.wB = P.n; g.wC = (long)cols * cols; g.nbatch = nw_;
         g.dynK = mdyn[i]; g.dynK_mul = mmul[i] * u;
+        g.upper_only = 1;                       // the Cholesky reads the upper triangle only
         // algorithmic flops of the op this replaces: geqrf + orgqr of (rows x cols)
         prof_begin(PROF_GRAM, nw_ * 2.0 * (2.0 * rows * (double)cols * cols - 2.0 / 3.0 * (double)cols * cols * cols),
-                   2.0 * nw_ * (double)cols * cols * rows);
+                   nw_ * (double)cols * (cols + TG_BN) * rows);
         tgemm_launch<T, T, double, double>(stream_, g, P.p, P.p, G);
         prof_end();
       }

@@ -84,9 +84,11 @@ constexpr int JR_SLOTS = JR_NW + 1;
 
 __global__ __launch_bounds__(512) void jacobi_rows_reg256_kernel(float *__restrict__ Mg, long wM, int m, int len, int ld,
                                                                  int max_sweeps, int *__restrict__ sweeps_out,
-                                                                 const int *__restrict__ mdyn, int mdyn_mul) {
+                                                                 const int *__restrict__ mdyn, int mdyn_mul,
+                                                                 int skip_small) {
   __shared__ float4 xch[JR_SLOTS][JR_BR][64];   // 9 x 16 KiB
   if (mdyn) m = min(m, mdyn[blockIdx.x] * mdyn_mul);   // rows that exist for this walker
+  if (skip_small && m <= 2 * JR_BR) return;            // jacobi_rows_small_kernel took this walker
   __shared__ float xnorm[JR_SLOTS][JR_BR];
   __shared__ float s_n2[256];
   __shared__ short s_perm[256];
@@ -297,6 +299,126 @@ __global__ __launch_bounds__(512) void jacobi_rows_reg256_kernel(float *__restri
   store_block(a, w);
   store_block(b, nwv + w);
   if (tid == 0 && sweeps_out) sweeps_out[blockIdx.x] = sweep | (live0 << 8);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Small-rank variant: a walker whose carry has at most 32 existing rows (rank-adaptive absorption:
+// the usual case away from full rank) is a 32 x 256 problem that ONE wave holds in registers, so
+// four walkers share a 256-thread workgroup and nothing crosses LDS or a workgroup barrier.  The
+// launch covers every walker; a wave whose walker has more rows returns at once and the 8-wave
+// kernel above (which returns at once for the small walkers) takes it.  Same rotation, threshold
+// and noise floor as above.
+constexpr int JR_SMALL_ROWS = 2 * JR_BR;
+
+// circle-method sweep over the first NB rows of one block (NB even): NB-1 rounds of NB/2 disjoint
+// pairs (p, NB-1-p); rows 1..NB-1 rotate physically so that the indices stay static
+template <int NB>
+__device__ __forceinline__ int jr_intra(JrRow (&a)[JR_BR], float (&na)[JR_BR], const float tol2, const float floor2) {
+  int rot = 0;
+#pragma unroll 1
+  for (int r = 0; r < NB - 1; ++r) {
+    float ga[NB / 2];
+#pragma unroll
+    for (int p = 0; p < NB / 2; ++p) ga[p] = jr_allsum(jr_dot(a[p], a[NB - 1 - p]));
+#pragma unroll
+    for (int p = 0; p < NB / 2; ++p) rot += jr_apply(a[p], a[NB - 1 - p], na[p], na[NB - 1 - p], ga[p], tol2, floor2);
+    const JrRow ta = a[NB - 1];
+    const float fa = na[NB - 1];
+#pragma unroll
+    for (int i = NB - 1; i >= 2; --i) { a[i] = a[i - 1]; na[i] = na[i - 1]; }
+    a[1] = ta; na[1] = fa;
+  }
+  return rot;
+}
+
+__global__ __launch_bounds__(256) void jacobi_rows_small_kernel(float *__restrict__ Mg, long wM, int m, int len, int ld,
+                                                                int max_sweeps, int *__restrict__ sweeps_out,
+                                                                const int *__restrict__ mdyn, int mdyn_mul, int nwalkers) {
+  const int lane = threadIdx.x & 63;
+  const int walker = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (walker >= nwalkers) return;
+  const int mm = min(m, mdyn[walker] * mdyn_mul);
+  if (mm > JR_SMALL_ROWS) return;
+  float *M = Mg + (long)walker * wM;
+  JrRow a[JR_BR], b[JR_BR];
+  float na[JR_BR], nb[JR_BR];
+  auto load_row = [&](int r) {
+    JrRow x;
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 4 * lane + q;
+      v[q] = (r < mm && c < len) ? M[(long)r * ld + c] : 0.f;
+    }
+    x.lo = jr_f2{v[0], v[1]};
+    x.hi = jr_f2{v[2], v[3]};
+    return x;
+  };
+  const bool has_b = mm > JR_BR;
+#pragma unroll
+  for (int i = 0; i < JR_BR; ++i) a[i] = load_row(i);
+#pragma unroll
+  for (int i = 0; i < JR_BR; ++i) b[i] = load_row(has_b ? JR_BR + i : mm);
+  double fro = 0.0;
+#pragma unroll
+  for (int i = 0; i < JR_BR; ++i) {
+    na[i] = jr_allsum(jr_dot(a[i], a[i]));
+    nb[i] = jr_allsum(jr_dot(b[i], b[i]));
+    fro += (double)na[i] + (double)nb[i];
+  }
+  const float floor2 = (float)(NOISE_C * NOISE_C * (double)Eps<float>::v * (double)Eps<float>::v * fro);
+  const float tol2 = 4.f * (float)len * Eps<float>::v * Eps<float>::v;
+  int sweep = 0;
+  for (; sweep < max_sweeps; ++sweep) {
+    if (sweep) {   // exact norms at sweep start
+#pragma unroll
+      for (int i = 0; i < JR_BR; ++i) na[i] = jr_allsum(jr_dot(a[i], a[i]));
+      if (has_b) {
+#pragma unroll
+        for (int i = 0; i < JR_BR; ++i) nb[i] = jr_allsum(jr_dot(b[i], b[i]));
+      }
+    }
+    int rot = 0;
+    if (mm <= 8) {
+      rot += jr_intra<8>(a, na, tol2, floor2);
+    } else {
+      rot += jr_intra<JR_BR>(a, na, tol2, floor2);
+      if (has_b) {
+        rot += jr_intra<JR_BR>(b, nb, tol2, floor2);
+#pragma unroll 1
+        for (int t = 0; t < JR_BR; ++t) {
+          float g[JR_BR];
+#pragma unroll
+          for (int i = 0; i < JR_BR; ++i) g[i] = jr_allsum(jr_dot(a[i], b[i]));
+#pragma unroll
+          for (int i = 0; i < JR_BR; ++i) rot += jr_apply(a[i], b[i], na[i], nb[i], g[i], tol2, floor2);
+          const JrRow tb = b[0];
+          const float fb = nb[0];
+#pragma unroll
+          for (int i = 0; i < JR_BR - 1; ++i) { b[i] = b[i + 1]; nb[i] = nb[i + 1]; }
+          b[JR_BR - 1] = tb; nb[JR_BR - 1] = fb;
+        }
+      }
+    }
+    if (rot == 0) { ++sweep; break; }
+  }
+  // every rotation loop above is a whole number of turns: each row is back in its own register
+  auto store_row = [&](const JrRow &x, int r) {
+    const float v[4] = {x.lo.x, x.lo.y, x.hi.x, x.hi.y};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 4 * lane + q;
+      if (r < mm && c < len) M[(long)r * ld + c] = v[q];
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < JR_BR; ++i) store_row(a[i], i);
+  if (has_b) {
+#pragma unroll
+    for (int i = 0; i < JR_BR; ++i) store_row(b[i], JR_BR + i);
+  }
+  if (lane == 0 && sweeps_out) sweeps_out[walker] = sweep | (mm << 8);
 }
 
 }  // namespace pepsgpu

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
   double *sN = sK + 64 * CH_NB;                  // [n]          row norms^2 of the finished factor
   short *sList = reinterpret_cast<short *>(sN + n);   // [n] live rows so far
   short *sPos = sList + n;                             // [n] output position of a row, -1 = dropped
-  __shared__ double s_piv, s_maxd, s_fro;
+  __shared__ double s_maxd, s_fro;
   __shared__ double s_red[4];
   __shared__ int s_nlive;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,19 +82,24 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
     const int nprev = s_nlive;
     for (int k0 = 0; k0 < nprev; k0 += 64) {
       const int kc = min(64, nprev - k0);
-      for (int e = tid; e < kc * nb; e += 256) {
-        int k = e / nb, c = e % nb;
-        sK[k * CH_NB + c] = G[(long)sList[k0 + k] * n + jb + c];
+      const int kc8 = (kc + 7) & ~7;          // zero padded to the unroll width below
+      for (int e = tid; e < kc8 * CH_NB; e += 256) {
+        int k = e / CH_NB, c = e % CH_NB;
+        sK[k * CH_NB + c] = (k < kc && c < nb) ? G[(long)sList[k0 + k] * n + jb + c] : 0.0;
       }
       __syncthreads();
       for (int r = jb + tid; r < n; r += 256) {
         double acc[CH_NB];
 #pragma unroll
         for (int c = 0; c < CH_NB; ++c) acc[c] = 0.0;
-        for (int k = 0; k < kc; ++k) {
-          double rv = G[(long)sList[k0 + k] * n + r];
+        for (int k = 0; k < kc8; k += 8) {
+          double rv[8];                          // eight independent loads in flight (L2 latency)
 #pragma unroll
-          for (int c = 0; c < CH_NB; ++c) acc[c] += sK[k * CH_NB + c] * rv;
+          for (int q = 0; q < 8; ++q) rv[q] = (k + q < kc) ? G[(long)sList[k0 + k + q] * n + r] : 0.0;
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) acc[c] += sK[(k + q) * CH_NB + c] * rv[q];
         }
 #pragma unroll
         for (int c = 0; c < CH_NB; ++c)
@@ -102,24 +107,29 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
       }
       __syncthreads();
     }
-    // factor the panel row by row
-    for (int c = 0; c < nb; ++c) {
-      if (tid == 0) s_piv = sP[c * n + jb + c];
+    // factor the panel row by row.  Dead pivots (numerically zero directions; most of the panel
+    // when the carry has low rank) cost no barrier: every wave finds the next live column itself
+    // from the current diagonal and the columns in between are zeroed in one pass.
+    int c = 0;
+    while (c < nb) {
+      const bool live_l = (lane < nb - c) && sP[(c + lane) * n + jb + c + lane] > thresh;
+      const unsigned long long lm = __ballot(live_l);
+      const int f = lm ? c + __ffsll((long long)lm) - 1 : nb;     // first live column at or after c
+      for (int e = tid; e < (f - c) * (n - jb); e += 256) sP[(c + e / (n - jb)) * n + jb + e % (n - jb)] = 0.0;
+      if (f >= nb) break;
+      const double inv = 1.0 / sqrt(sP[f * n + jb + f]);
+      __syncthreads();                       // every wave has read the diagonal before row f is scaled
+      for (int r = jb + f + tid; r < n; r += 256) sP[f * n + r] *= inv;
+      if (tid == 0) { sList[s_nlive] = (short)(jb + f); s_nlive = s_nlive + 1; }
       __syncthreads();
-      const double piv = s_piv;
-      const bool ok = piv > thresh;
-      const double inv = ok ? 1.0 / sqrt(piv) : 0.0;
-      for (int r = jb + c + tid; r < n; r += 256) sP[c * n + r] *= inv;
-      if (tid == 0 && ok) { sList[s_nlive] = (short)(jb + c); s_nlive = s_nlive + 1; }
-      __syncthreads();
-      if (ok) {
-        for (int e = tid; e < (nb - c - 1) * (n - jb); e += 256) {
-          int c2 = c + 1 + e / (n - jb), r = jb + e % (n - jb);
-          if (r >= jb + c2) sP[c2 * n + r] -= sP[c * n + jb + c2] * sP[c * n + r];
-        }
+      for (int e = tid; e < (nb - f - 1) * (n - jb); e += 256) {
+        int c2 = f + 1 + e / (n - jb), r = jb + e % (n - jb);
+        if (r >= jb + c2) sP[c2 * n + r] -= sP[f * n + jb + c2] * sP[f * n + r];
       }
       __syncthreads();
+      c = f + 1;
     }
+    __syncthreads();
     // publish the finished rows (needed by later panels) -- upper part only
     for (int e = tid; e < nb * n; e += 256) {
       int c = e / n, r = e % n;
@@ -128,16 +138,19 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
     __syncthreads();
   }
   // ---- rank compaction: rows with norm below NOISE_C*eps_T*|R|_F are dropped ----
-  for (int k = wave; k < n; k += 4) {
+  // (only the rows that passed the pivot test can be non-zero: sList[0..nfac))
+  const int nfac = s_nlive;
+  for (int q = wave; q < nfac; q += 4) {
+    const int k = sList[q];
     double a = 0.0;
     for (int r = k + lane; r < n; r += 64) { double x = G[(long)k * n + r]; a += x * x; }
     a = wave_sum(a);
-    if (lane == 0) sN[k] = a;
+    if (lane == 0) sN[q] = a;
   }
   __syncthreads();
   {
     double f = 0.0;
-    for (int k = tid; k < n; k += 256) f += sN[k];
+    for (int q = tid; q < nfac; q += 256) f += sN[q];
     f = wave_sum(f);
     if (lane == 0) s_red[wave] = f;
     __syncthreads();
@@ -147,11 +160,11 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
   const double nfloor = eT * eT * s_fro;
   if (wave == 0) {
     int cnt = 0;
-    for (int base = 0; base < n; base += 64) {
-      const int k = base + lane;
-      const bool f = k < n && sN[k] > nfloor;
+    for (int base = 0; base < nfac; base += 64) {
+      const int q = base + lane;
+      const bool f = q < nfac && sN[q] > nfloor;
       const unsigned long long mask = __ballot(f);
-      if (k < n) sPos[k] = f ? (short)(cnt + __popcll(mask & ((1ull << lane) - 1ull))) : (short)-1;
+      if (q < nfac) sPos[q] = f ? (short)(cnt + __popcll(mask & ((1ull << lane) - 1ull))) : (short)-1;
       cnt += __popcll(mask);
     }
     if (lane == 0) { s_nlive = cnt; if (mlive_out) mlive_out[blockIdx.x] = cnt; }
@@ -159,11 +172,14 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
   __syncthreads();
   const int mlive = s_nlive;
   const double sc = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
-  for (int e = tid; e < n * n; e += 256) {
-    int k = e / n, r = e % n;
-    const int pos = sPos[k];
-    if (pos >= 0) Rout[(long)pos * n + r] = (r >= k) ? T(G[e] * sc) : T(0);
+  for (int q = wave; q < nfac; q += 4) {
+    const int pos = sPos[q];
+    if (pos < 0) continue;
+    const int k = sList[q];
+    for (int r = lane; r < n; r += 64) Rout[(long)pos * n + r] = (r >= k) ? T(G[(long)k * n + r] * sc) : T(0);
   }
+  // rows beyond mlive are never read when the caller takes the live count (dynamic extents)
+  if (mlive_out) return;
   for (int e = tid + mlive * n; e < n * n; e += 256) Rout[e] = T(0);
 }
 

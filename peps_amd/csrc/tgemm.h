@@ -35,6 +35,7 @@ struct TGemmDesc {
   int dynI_mul = 1, dynK_mul = 1;
   int nbatch = 1;
   int accumulate = 0;
+  int upper_only = 0;   // symmetric result (Gram): tiles strictly below the diagonal are not computed
   double alpha = 1.0;
 
   __host__ __device__ int Itot() const { return I[0] * I[1] * I[2]; }
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__res
   if (d.dynI) Itot = min(Itot, d.dynI[b] * d.dynI_mul);
   if (d.dynK) Ktot = min(Ktot, d.dynK[b] * d.dynK_mul);
   for (int i0 = blockIdx.x * TG_BM; i0 < Itot; i0 += gridDim.x * TG_BM) {   // block-uniform trip count
+    if (d.upper_only && (int)(blockIdx.y + 1) * TG_BN <= i0) continue;
     tgemm_tile<TA, TB, TC, TAcc, USE_MFMA>(d, Ag, Bg, Cg, i0, Itot, Ktot);
     __syncthreads();
   }

@@ -176,3 +176,26 @@ def test_jacobi_register_kernel_matches_generic(shape):
         Pref = np.linalg.svd(M[b])[2][:k]
         if live.all() and (sref[k] < 0.5 * sref[k - 1] if k < len(sref) else True):
             assert np.max(np.abs(Vb.T @ Vb - Pref.T @ Pref)) < 2e-3
+
+
+@pytest.mark.parametrize("shape", [(32, 256), (16, 256), (8, 256), (5, 200), (9, 256), (20, 131), (1, 64)])
+def test_jacobi_small_rank_kernel(shape):
+    """One-wave-per-walker Jacobi (jacobi_rows_small_kernel, carries with <= 32 existing rows):
+    singular values and dominant subspace against LAPACK, several walkers per workgroup."""
+    capi = _capi()
+    m, ln = shape
+    rng = np.random.default_rng(11 * m + ln)
+    nb = 7                                        # not a multiple of the 4 walkers per workgroup
+    M = np.stack([(np.triu(rng.standard_normal((m, m))) * np.logspace(0, -4, m)[:, None]) @ rng.standard_normal((m, ln))
+                  for _ in range(nb)])
+    k = min(m, ln)
+    Mo, Vt, S, sw = capi.diag_jacobi(capi.F32, M, k, 3)
+    for b in range(nb):
+        sref = np.linalg.svd(M[b], compute_uv=False)
+        assert np.max(np.abs(S[b].astype(np.float64) - sref[:k])) < 3e-5 * sref[0]
+        Vb = Vt[b].astype(np.float64)
+        live = sref[:k] > 1e-5 * sref[0]
+        G = Vb @ Vb.T
+        assert np.max(np.abs(G[np.ix_(live, live)] - np.eye(int(live.sum())))) < 1e-4
+        assert abs(np.linalg.norm(Mo[b]) / np.linalg.norm(M[b]) - 1) < 1e-5
+        assert sw[b] < 40
