@@ -164,6 +164,9 @@ int pepsgpu_profile_read(pepsgpu_ctx *ctx, double *out);
 int pepsgpu_diag_tgemm(int dtype_in, int dtype_out, const int *desc_ints, int n_ints, const void *A, size_t a_elems,
                        const void *B, size_t b_elems, void *C, size_t c_elems, int nbatch, long wA, long wB, long wC);
 int pepsgpu_diag_chol(int dtype_out, const double *G, int n, int nbatch, void *R_out);
+/* the rank-adaptive pair used by the absorption: low-rank right-looking kernel, then the blocked
+ * kernel for the walkers whose rank exceeds its cap; mlive_out[b] = rows of R_out[b] that exist */
+int pepsgpu_diag_chol_adaptive(int dtype_out, const double *G, int n, int nbatch, void *R_out, int32_t *mlive_out);
 int pepsgpu_diag_jacobi(int dtype, void *M, int m, int len, int nbatch, int k, void *Vt_out, void *S_out,
                         int force_global, int *sweeps_out);
 const char *pepsgpu_version(void);

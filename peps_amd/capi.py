@@ -33,7 +33,7 @@ SYMBOLS = [
     "pepsgpu_grad_reset", "pepsgpu_grad_accumulate", "pepsgpu_grad_read",
     "pepsgpu_update_local", "pepsgpu_erase_envs_after_update", "pepsgpu_evaluate_amplitude",
     "pepsgpu_walker_flags", "pepsgpu_sync", "pepsgpu_stats", "pepsgpu_profile_enable", "pepsgpu_profile_read",
-    "pepsgpu_diag_tgemm", "pepsgpu_diag_chol", "pepsgpu_diag_jacobi", "pepsgpu_version",
+    "pepsgpu_diag_tgemm", "pepsgpu_diag_chol", "pepsgpu_diag_chol_adaptive", "pepsgpu_diag_jacobi", "pepsgpu_version",
 ]
 
 
@@ -85,6 +85,7 @@ def load_library(path=LIB_PATH):
     lib.pepsgpu_diag_tgemm.argtypes = [C.c_int, C.c_int, ip, C.c_int, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t,
                                        C.c_int, C.c_long, C.c_long, C.c_long]
     lib.pepsgpu_diag_chol.argtypes = [C.c_int, dp, C.c_int, C.c_int, vp]
+    lib.pepsgpu_diag_chol_adaptive.argtypes = [C.c_int, dp, C.c_int, C.c_int, vp, ip]
     lib.pepsgpu_diag_jacobi.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, ip]
     return lib
 
@@ -328,6 +329,18 @@ def diag_chol(dtype_out, G):
     if rc != 0:
         raise RuntimeError("diag_chol failed: %s" % lib().pepsgpu_last_error(None).decode())
     return R
+
+
+def diag_chol_adaptive(dtype_out, G):
+    """Low-rank + blocked Cholesky pair as the absorption runs it; returns (R, mlive)."""
+    G = np.ascontiguousarray(G, dtype=np.float64)
+    nb, n, _ = G.shape
+    R = np.zeros((nb, n, n), dtype=np.float32 if dtype_out == F32 else np.float64)
+    ml = np.zeros(nb, dtype=np.int32)
+    rc = lib().pepsgpu_diag_chol_adaptive(dtype_out, _dp(G), n, nb, R.ctypes.data_as(C.c_void_p), _ip(ml))
+    if rc != 0:
+        raise RuntimeError("diag_chol_adaptive failed: %s" % lib().pepsgpu_last_error(None).decode())
+    return R, ml
 
 
 def diag_jacobi(dtype, M, k, force_global=False):

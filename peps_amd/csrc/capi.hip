@@ -237,6 +237,38 @@ static void diag_chol_t(const double *G, int n, int nbatch, void *Rout) {
   PG_CHECK_HIP(hipMemcpy(Rout, dR, ne * sizeof(T), hipMemcpyDeviceToHost));
   (void)hipFree(dG); (void)hipFree(dR);
 }
+// rank-adaptive path of the absorption: chol_lowrank_kernel, then chol_upper_kernel for the flagged walkers
+template <typename T>
+static void diag_chol_adaptive_t(const double *G, int n, int nbatch, void *Rout, int32_t *mlive) {
+  double *dG;
+  T *dR;
+  int *dml;
+  size_t ne = (size_t)n * n * nbatch;
+  PG_REQUIRE(n <= 256 * CH_LR_Q, 1, "n too large for the low-rank Cholesky");
+  PG_CHECK_HIP(hipMalloc(&dG, ne * sizeof(double)));
+  PG_CHECK_HIP(hipMalloc(&dR, ne * sizeof(T)));
+  PG_CHECK_HIP(hipMalloc(&dml, nbatch * sizeof(int)));
+  PG_CHECK_HIP(hipMemcpy(dG, G, ne * sizeof(double), hipMemcpyHostToDevice));
+  PG_CHECK_HIP(hipMemset(dR, 0, ne * sizeof(T)));
+  const size_t lsm = chol_lowrank_smem_bytes(n), smem = chol_smem_bytes(n);
+  allow_dynamic_lds(reinterpret_cast<const void *>(&chol_lowrank_kernel<T>), lsm);
+  allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
+  hipLaunchKernelGGL(chol_lowrank_kernel<T>, dim3(nbatch), dim3(256), lsm, 0, (const double *)dG, (long)n * n, n, dR,
+                     (long)n * n, dml);
+  PG_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nbatch), dim3(256), smem, 0, dG, (long)n * n, n, dR, (long)n * n, dml, 1);
+  PG_CHECK_HIP(hipGetLastError());
+  PG_CHECK_HIP(hipDeviceSynchronize());
+  PG_CHECK_HIP(hipMemcpy(Rout, dR, ne * sizeof(T), hipMemcpyDeviceToHost));
+  PG_CHECK_HIP(hipMemcpy(mlive, dml, nbatch * sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(dG); (void)hipFree(dR); (void)hipFree(dml);
+}
+extern "C" int pepsgpu_diag_chol_adaptive(int dtype_out, const double *G, int n, int nbatch, void *R_out, int32_t *mlive_out) {
+  return guarded(nullptr, [&]() {
+    if (dtype_out == 0) diag_chol_adaptive_t<float>(G, n, nbatch, R_out, mlive_out);
+    else diag_chol_adaptive_t<double>(G, n, nbatch, R_out, mlive_out);
+  });
+}
 extern "C" int pepsgpu_diag_chol(int dtype_out, const double *G, int n, int nbatch, void *R_out) {
   return guarded(nullptr, [&]() {
     if (dtype_out == 0) diag_chol_t<float>(G, n, nbatch, R_out); else diag_chol_t<double>(G, n, nbatch, R_out);

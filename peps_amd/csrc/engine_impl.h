@@ -23,16 +23,20 @@ void Engine<T>::add_log(double *acc, const double *a) {
 // the f32 bulk blocks (<= 256 x 256), global-memory generic kernel otherwise (f64 bulk blocks).
 template <typename T>
 void Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t need, const int *mdyn, int mdyn_mul) {
+  int small = 0;
   if constexpr (sizeof(T) == 4) {
     static const bool no_reg = getenv("PEPSGPU_NO_REGJACOBI") != nullptr;
+    static const bool no_small = getenv("PEPSGPU_NO_SMALLJACOBI") != nullptr;
+    // walkers whose block has at most 32 existing rows: one wave each (jacobi_rows_small_kernel);
+    // the kernels below return at once for those walkers
+    if (len <= 256 && !no_small && (mdyn || m <= JR_SMALL_ROWS)) {
+      small = 1;
+      hipLaunchKernelGGL(jacobi_rows_small_kernel, dim3((nw_ + 3) / 4), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
+                         sweeps_, mdyn, mdyn_mul, nw_);
+      PG_CHECK_HIP(hipGetLastError());
+      if (m <= JR_SMALL_ROWS) return;
+    }
     if (!use_lds && m <= 256 && len <= 256 && !no_reg) {
-      static const bool no_small = getenv("PEPSGPU_NO_SMALLJACOBI") != nullptr;
-      const int small = (mdyn && !no_small) ? 1 : 0;
-      if (small) {
-        hipLaunchKernelGGL(jacobi_rows_small_kernel, dim3((nw_ + 3) / 4), dim3(256), 0, stream_, (float *)M, wM, m, len, len,
-                           40, sweeps_, mdyn, mdyn_mul, nw_);
-        PG_CHECK_HIP(hipGetLastError());
-      }
       hipLaunchKernelGGL(jacobi_rows_reg256_kernel, dim3(nw_), dim3(512), 0, stream_, (float *)M, wM, m, len, len, 40,
                          sweeps_, mdyn, mdyn_mul, small);
       PG_CHECK_HIP(hipGetLastError());
@@ -40,7 +44,7 @@ void Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
     }
   }
   hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), use_lds ? need : 0, stream_, M, wM, m, len, len, 40,
-                     use_lds, sweeps_, mdyn, mdyn_mul);
+                     use_lds, sweeps_, mdyn, mdyn_mul, small);
   PG_CHECK_HIP(hipGetLastError());
 }
 
@@ -148,8 +152,17 @@ void Engine<T>::absorb(int pos, int num) {
       allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
       int *ml = adaptive ? (int *)arena_.alloc(sizeof(int) * nw_) : nullptr;
       prof_begin(PROF_CHOL, 0.0, nw_ * (double)cols * cols * cols / 3.0);
+      static const bool no_lowrank = getenv("PEPSGPU_NO_LOWRANK_CHOL") != nullptr;
+      const bool lowrank = ml && !no_lowrank && cols <= 256 * CH_LR_Q;
+      if (lowrank) {   // walkers of rank <= CH_LR_CAP finish here; the others are flagged for the blocked kernel
+        const size_t lsm = chol_lowrank_smem_bytes(cols);
+        allow_dynamic_lds(reinterpret_cast<const void *>(&chol_lowrank_kernel<T>), lsm);
+        hipLaunchKernelGGL(chol_lowrank_kernel<T>, dim3(nw_), dim3(256), lsm, stream_, (const double *)G, (long)cols * cols,
+                           cols, R[i + 1].p, R[i + 1].n, ml);
+        PG_CHECK_HIP(hipGetLastError());
+      }
       hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nw_), dim3(256), smem, stream_, G, (long)cols * cols, cols,
-                         R[i + 1].p, R[i + 1].n, ml);
+                         R[i + 1].p, R[i + 1].n, ml, lowrank ? 1 : 0);
       PG_CHECK_HIP(hipGetLastError());
       prof_end();
       if (dbg_sweeps_ && ml) {   // diagnostics: numerical rank of the carry (forces a sync)

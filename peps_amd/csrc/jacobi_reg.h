@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void jacobi_rows_small_kernel(float *__restric
   const int lane = threadIdx.x & 63;
   const int walker = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (walker >= nwalkers) return;
-  const int mm = min(m, mdyn[walker] * mdyn_mul);
+  const int mm = mdyn ? min(m, mdyn[walker] * mdyn_mul) : m;
   if (mm > JR_SMALL_ROWS) return;
   float *M = Mg + (long)walker * wM;
   JrRow a[JR_BR], b[JR_BR];

@@ -44,7 +44,10 @@ inline size_t chol_smem_bytes(int n) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg, long wG, int n,
-                                                         T *__restrict__ Rg, long wR, int *__restrict__ mlive_out) {
+                                                         T *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
+                                                         int only_flagged = 0) {
+  // only_flagged: chol_lowrank_kernel ran first and left mlive_out[b] = -1 where the rank exceeded its cap
+  if (only_flagged && mlive_out[blockIdx.x] >= 0) return;
   extern __shared__ double ch_smem[];
   double *sP = ch_smem;                          // [CH_NB][n]   current block row of R
   double *sK = sP + CH_NB * n;                   // [64][CH_NB]  staged R[list[k]][jb..jb+nb)
@@ -184,6 +187,104 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
 }
 
 // ---------------------------------------------------------------------------------------------
+// Low-rank variant of the same factorisation (same column order, same pivot rule, same output):
+// right-looking, one step per LIVE row instead of one pass per 16-column panel, the factor held in
+// LDS.  The cost of the blocked kernel above is ~n/16 dependent global-memory round trips whatever
+// the rank; here it is one row read per live row.  When the rank exceeds CH_LR_CAP the kernel
+// leaves mlive_out[b] = -1 (G is untouched) and chol_upper_kernel(only_flagged = 1) redoes that
+// walker.  n <= 256 * CH_LR_Q.  Reads the upper triangle of G only.
+constexpr int CH_LR_CAP = 32, CH_LR_Q = 4;
+inline size_t chol_lowrank_smem_bytes(int n) { return sizeof(double) * (size_t)CH_LR_CAP * n; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void chol_lowrank_kernel(const double *__restrict__ Gg, long wG, int n,
+                                                           T *__restrict__ Rg, long wR, int *__restrict__ mlive_out) {
+  extern __shared__ double lr_R[];                 // [CH_LR_CAP][n]
+  __shared__ double s_red[4], s_nrm[CH_LR_CAP];
+  __shared__ int s_first[2][4];
+  __shared__ short s_pos[CH_LR_CAP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double *G = Gg + (long)blockIdx.x * wG;
+  T *Rout = Rg + (long)blockIdx.x * wR;
+  double d[CH_LR_Q];
+  double md = 0.0;
+#pragma unroll
+  for (int q = 0; q < CH_LR_Q; ++q) {
+    const int r = tid + 256 * q;
+    d[q] = r < n ? G[(long)r * n + r] : 0.0;
+    md = fmax(md, d[q]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
+  if (lane == 0) s_red[wave] = md;
+  __syncthreads();
+  const double maxd = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+  const double eT = NOISE_C * (double)Eps<T>::v;
+  const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
+  int nl = 0, f = -1;
+  for (int step = 0;; ++step) {
+    int cand = 0x7fffffff;
+#pragma unroll
+    for (int q = CH_LR_Q - 1; q >= 0; --q) {
+      const int r = tid + 256 * q;
+      if (r < n && r > f && d[q] > thresh) cand = r;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+    if (lane == 0) s_first[step & 1][wave] = cand;
+    __syncthreads();
+    f = min(min(s_first[step & 1][0], s_first[step & 1][1]), min(s_first[step & 1][2], s_first[step & 1][3]));
+    if (f == 0x7fffffff) break;
+    if (nl == CH_LR_CAP) {                 // rank above the cap: hand the walker to the blocked kernel
+      if (tid == 0) mlive_out[blockIdx.x] = -1;
+      return;
+    }
+    double piv = G[(long)f * n + f];
+    for (int j = 0; j < nl; ++j) { const double x = lr_R[j * n + f]; piv -= x * x; }
+    const double inv = 1.0 / sqrt(piv);
+#pragma unroll
+    for (int q = 0; q < CH_LR_Q; ++q) {
+      const int r = tid + 256 * q;
+      if (r < n) {
+        double v = 0.0;
+        if (r >= f) {
+          v = G[(long)f * n + r];
+          for (int j = 0; j < nl; ++j) v -= lr_R[j * n + f] * lr_R[j * n + r];
+          v *= inv;
+        }
+        lr_R[nl * n + r] = v;
+        if (r > f) d[q] -= v * v;
+      }
+    }
+    ++nl;
+    __syncthreads();
+  }
+  // ---- rank compaction, as in chol_upper_kernel ----
+  for (int j = wave; j < nl; j += 4) {
+    double a = 0.0;
+    for (int r = lane; r < n; r += 64) { const double x = lr_R[j * n + r]; a += x * x; }
+    a = wave_sum(a);
+    if (lane == 0) s_nrm[j] = a;
+  }
+  __syncthreads();
+  double fro = 0.0;
+  for (int j = 0; j < nl; ++j) fro += s_nrm[j];
+  const double nfloor = eT * eT * fro;
+  if (tid == 0) {
+    int cnt = 0;
+    for (int j = 0; j < nl; ++j) s_pos[j] = s_nrm[j] > nfloor ? (short)cnt++ : (short)-1;
+    mlive_out[blockIdx.x] = cnt;
+  }
+  __syncthreads();
+  const double sc = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
+  for (int j = 0; j < nl; ++j) {
+    const int pos = s_pos[j];
+    if (pos < 0) continue;
+    for (int r = tid; r < n; r += 256) Rout[(long)pos * n + r] = T(lr_R[j * n + r] * sc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // One-sided Jacobi on the rows of M (m x len, row stride ld), in place.  Round-robin tournament
 // ordering, one wave per row pair.  Rows whose norm is below NOISE_C*eps*|M|_F (an invariant of
 // the rotations) are numerically zero and take no part: with more rows than the rank (m > len,
@@ -194,10 +295,12 @@ template <typename T>
 __global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, long wM, int m, int len,
                                                            int ld, int max_sweeps, int use_lds,
                                                            int *__restrict__ sweeps_out,
-                                                           const int *__restrict__ mdyn, int mdyn_mul) {
+                                                           const int *__restrict__ mdyn, int mdyn_mul,
+                                                           int skip_small = 0) {
   extern __shared__ unsigned char jc_smem_raw[];
   T *sM = reinterpret_cast<T *>(jc_smem_raw);
   if (mdyn) m = min(m, mdyn[blockIdx.x] * mdyn_mul);
+  if (skip_small && m <= 32) return;   // jacobi_rows_small_kernel (jacobi_reg.h) took this walker
   __shared__ int s_rot;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   T *Mglob = Mg + (long)blockIdx.x * wM;

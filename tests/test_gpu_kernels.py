@@ -199,3 +199,29 @@ def test_jacobi_small_rank_kernel(shape):
         assert np.max(np.abs(G[np.ix_(live, live)] - np.eye(int(live.sum())))) < 1e-4
         assert abs(np.linalg.norm(Mo[b]) / np.linalg.norm(M[b]) - 1) < 1e-5
         assert sw[b] < 40
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("n,ranks", [(256, (3, 12, 31, 32, 33, 60, 256)), (144, (1, 20, 144)), (40, (5, 40))])
+def test_cholesky_rank_adaptive_pair(n, ranks, dt):
+    """chol_lowrank_kernel (rank <= 32, right-looking, LDS-resident) + chol_upper_kernel for the
+    flagged walkers, as the absorption runs them: R^T R = G on the live rows, mlive = numerical rank,
+    walkers of different rank in one launch.  Only the upper triangle of G is read."""
+    capi = _capi()
+    rng = np.random.default_rng(n + len(ranks))
+    Gs = []
+    for r in ranks:
+        X = rng.standard_normal((r, n))
+        G = X.T @ X
+        G[np.tril_indices(n, -1)] = np.nan if False else 1e30     # lower triangle must never be read
+        Gs.append(G)
+    G = np.stack(Gs)
+    R, ml = capi.diag_chol_adaptive(capi.F32 if dt == "f32" else capi.F64, G)
+    tol = 3e-6 if dt == "f32" else 1e-9      # unpivoted factor of an exactly rank-deficient block
+    for b, r in enumerate(ranks):
+        Gu = np.triu(Gs[b]) + np.triu(Gs[b], 1).T
+        sc = np.max(np.diag(Gu))
+        slack = 0 if dt == "f32" else 2          # f64 threshold sits at rounding level: a rounding-noise pivot may pass
+        assert 0 < ml[b] <= min(r + slack, n) and (r >= n or ml[b] >= r - 1), (r, ml[b])   # r = n: smallest directions may fall under the floor
+        Rb = R[b, :ml[b]].astype(np.float64)
+        assert np.max(np.abs(Rb.T @ Rb * sc - Gu)) / sc < tol, (r, ml[b])
