@@ -166,6 +166,9 @@ int pepsgpu_diag_tgemm(int dtype_in, int dtype_out, const int *desc_ints, int n_
 int pepsgpu_diag_chol(int dtype_out, const double *G, int n, int nbatch, void *R_out);
 /* the rank-adaptive pair used by the absorption: low-rank right-looking kernel, then the blocked
  * kernel for the walkers whose rank exceeds its cap; mlive_out[b] = rows of R_out[b] that exist */
+/* the Gram-free low-rank kernel alone: P = [nbatch][K][n] (dtype), R^T R = P^T P; mlive_out[b] = -1 where
+ * it declines (K or the rank above its caps) and the Gram + Cholesky pair has to run */
+int pepsgpu_diag_gram_chol(int dtype, const void *P, int K, int n, int nbatch, void *R_out, int32_t *mlive_out);
 int pepsgpu_diag_chol_adaptive(int dtype_out, const double *G, int n, int nbatch, void *R_out, int32_t *mlive_out);
 int pepsgpu_diag_jacobi(int dtype, void *M, int m, int len, int nbatch, int k, void *Vt_out, void *S_out,
                         int force_global, int *sweeps_out);

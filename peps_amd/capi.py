@@ -33,7 +33,7 @@ SYMBOLS = [
     "pepsgpu_grad_reset", "pepsgpu_grad_accumulate", "pepsgpu_grad_read",
     "pepsgpu_update_local", "pepsgpu_erase_envs_after_update", "pepsgpu_evaluate_amplitude",
     "pepsgpu_walker_flags", "pepsgpu_sync", "pepsgpu_stats", "pepsgpu_profile_enable", "pepsgpu_profile_read",
-    "pepsgpu_diag_tgemm", "pepsgpu_diag_chol", "pepsgpu_diag_chol_adaptive", "pepsgpu_diag_jacobi", "pepsgpu_version",
+    "pepsgpu_diag_tgemm", "pepsgpu_diag_chol", "pepsgpu_diag_chol_adaptive", "pepsgpu_diag_gram_chol", "pepsgpu_diag_jacobi", "pepsgpu_version",
 ]
 
 
@@ -86,6 +86,7 @@ def load_library(path=LIB_PATH):
                                        C.c_int, C.c_long, C.c_long, C.c_long]
     lib.pepsgpu_diag_chol.argtypes = [C.c_int, dp, C.c_int, C.c_int, vp]
     lib.pepsgpu_diag_chol_adaptive.argtypes = [C.c_int, dp, C.c_int, C.c_int, vp, ip]
+    lib.pepsgpu_diag_gram_chol.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, ip]
     lib.pepsgpu_diag_jacobi.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, ip]
     return lib
 
@@ -340,6 +341,19 @@ def diag_chol_adaptive(dtype_out, G):
     rc = lib().pepsgpu_diag_chol_adaptive(dtype_out, _dp(G), n, nb, R.ctypes.data_as(C.c_void_p), _ip(ml))
     if rc != 0:
         raise RuntimeError("diag_chol_adaptive failed: %s" % lib().pepsgpu_last_error(None).decode())
+    return R, ml
+
+
+def diag_gram_chol(dtype, P):
+    """gram_chol_lowrank_kernel alone; P = [nb][K][n]; returns (R [nb][n][n], mlive)."""
+    t = np.float32 if dtype == F32 else np.float64
+    P = np.ascontiguousarray(P, dtype=t)
+    nb, K, n = P.shape
+    R = np.zeros((nb, n, n), dtype=t)
+    ml = np.zeros(nb, dtype=np.int32)
+    rc = lib().pepsgpu_diag_gram_chol(dtype, P.ctypes.data_as(C.c_void_p), K, n, nb, R.ctypes.data_as(C.c_void_p), _ip(ml))
+    if rc != 0:
+        raise RuntimeError("diag_gram_chol failed: %s" % lib().pepsgpu_last_error(None).decode())
     return R, ml
 
 

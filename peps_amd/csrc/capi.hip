@@ -269,6 +269,31 @@ extern "C" int pepsgpu_diag_chol_adaptive(int dtype_out, const double *G, int n,
     else diag_chol_adaptive_t<double>(G, n, nbatch, R_out, mlive_out);
   });
 }
+// gram_chol_lowrank_kernel alone: P = [nbatch][K][n] of type T; mlive_out[b] = -1 where it declines
+template <typename T, int KCAP>
+static void diag_gram_chol_t(const void *P, int K, int n, int nbatch, void *Rout, int32_t *mlive) {
+  T *dP, *dR;
+  int *dml;
+  PG_REQUIRE(n <= 256, 1, "n too large for the fused low-rank kernel");
+  PG_CHECK_HIP(hipMalloc(&dP, (size_t)K * n * nbatch * sizeof(T)));
+  PG_CHECK_HIP(hipMalloc(&dR, (size_t)n * n * nbatch * sizeof(T)));
+  PG_CHECK_HIP(hipMalloc(&dml, nbatch * sizeof(int)));
+  PG_CHECK_HIP(hipMemcpy(dP, P, (size_t)K * n * nbatch * sizeof(T), hipMemcpyHostToDevice));
+  PG_CHECK_HIP(hipMemset(dR, 0, (size_t)n * n * nbatch * sizeof(T)));
+  hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP>), dim3(nbatch), dim3(256), 0, 0, (const T *)dP, (long)K * n, n,
+                     (const int *)nullptr, 1, K, dR, (long)n * n, dml);
+  PG_CHECK_HIP(hipGetLastError());
+  PG_CHECK_HIP(hipDeviceSynchronize());
+  PG_CHECK_HIP(hipMemcpy(Rout, dR, (size_t)n * n * nbatch * sizeof(T), hipMemcpyDeviceToHost));
+  PG_CHECK_HIP(hipMemcpy(mlive, dml, nbatch * sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(dP); (void)hipFree(dR); (void)hipFree(dml);
+}
+extern "C" int pepsgpu_diag_gram_chol(int dtype, const void *P, int K, int n, int nbatch, void *R_out, int32_t *mlive_out) {
+  return guarded(nullptr, [&]() {
+    if (dtype == 0) diag_gram_chol_t<float, 96>(P, K, n, nbatch, R_out, mlive_out);
+    else diag_gram_chol_t<double, 48>(P, K, n, nbatch, R_out, mlive_out);
+  });
+}
 extern "C" int pepsgpu_diag_chol(int dtype_out, const double *G, int n, int nbatch, void *R_out) {
   return guarded(nullptr, [&]() {
     if (dtype_out == 0) diag_chol_t<float>(G, n, nbatch, R_out); else diag_chol_t<double>(G, n, nbatch, R_out);

@@ -119,7 +119,26 @@ void Engine<T>::absorb(int pos, int num) {
     }
     free_ten(X);
     const int rows = m * u, cols = l2 * a2;
-    if (rows < cols) {
+    constexpr int FUSED_KCAP = sizeof(T) == 4 ? 96 : 48;   // rows of P a thread of the fused kernel holds in registers
+    static const bool no_fused = getenv("PEPSGPU_NO_FUSED_GRAMCHOL") != nullptr;
+    if (rows < cols && adaptive && !no_fused && cols <= 256 && rows >= 16 && rows <= FUSED_KCAP) {
+      // Fewer rows than columns, but already more rows than the usual numerical rank: compress now
+      // (gram_chol_lowrank_kernel) instead of letting the carry grow by the factor u per site until it
+      // reaches the column count.  Walkers whose rank exceeds the kernel's cap keep their rows of P.
+      R[i + 1] = alloc_ten(cols, l2, a2);
+      int *ml = (int *)arena_.alloc(sizeof(int) * nw_);
+      prof_begin(PROF_CHOL, nw_ * 2.0 * (2.0 * cols * (double)rows * rows - 2.0 / 3.0 * (double)rows * rows * rows), 0.0);
+      hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, FUSED_KCAP>), dim3(nw_), dim3(256), 0, stream_, (const T *)P.p, P.n, cols,
+                         (const int *)mdyn[i], mmul[i] * u, rows, R[i + 1].p, R[i + 1].n, ml);
+      PG_CHECK_HIP(hipGetLastError());
+      hipLaunchKernelGGL(adopt_rows_flagged_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)P.p, P.n, cols,
+                         (const int *)mdyn[i], mmul[i] * u, rows, R[i + 1].p, R[i + 1].n, ml);
+      PG_CHECK_HIP(hipGetLastError());
+      prof_end();
+      mdyn[i + 1] = ml;
+      mmul[i + 1] = 1;
+      free_ten(P);
+    } else if (rows < cols) {
       // economy QR would return R = Q^T P with rows x cols; any R with R^T R = P^T P serves
       // (rows == cols goes through the Cholesky: a triangular carry makes the Jacobi converge 3x faster)
       P.d[0] = rows; P.d[1] = l2; P.d[2] = a2; P.d[3] = 1;
@@ -132,6 +151,19 @@ void Engine<T>::absorb(int pos, int num) {
       mmul[i + 1] = mmul[i] * u;
     } else {
       double *G = (double *)arena_.alloc(sizeof(double) * (size_t)cols * cols * nw_);
+      R[i + 1] = alloc_ten(cols, l2, a2);
+      int *ml = adaptive ? (int *)arena_.alloc(sizeof(int) * nw_) : nullptr;
+      // Low-rank walkers: the factor straight from the live rows of P, no Gram matrix in memory
+      // (gram_chol_lowrank_kernel); it flags the walkers it cannot take (ml = -1) and the Gram GEMM
+      // and the Cholesky kernels below then run for those only.
+      const bool fused = ml && !no_fused && cols <= 256 && (mdyn[i] || rows <= FUSED_KCAP);
+      if (fused) {
+        prof_begin(PROF_CHOL, 0.0, 0.0);
+        hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, FUSED_KCAP>), dim3(nw_), dim3(256), 0, stream_, (const T *)P.p, P.n,
+                           cols, (const int *)mdyn[i], mmul[i] * u, rows, R[i + 1].p, R[i + 1].n, ml);
+        PG_CHECK_HIP(hipGetLastError());
+        prof_end();
+      }
       {
         TGemmDesc g;
         g.I[2] = cols; g.sAi[2] = 1; g.sCi[2] = cols;
@@ -140,17 +172,16 @@ void Engine<T>::absorb(int pos, int num) {
         g.wA = P.n; g.wB = P.n; g.wC = (long)cols * cols; g.nbatch = nw_;
         g.dynK = mdyn[i]; g.dynK_mul = mmul[i] * u;
         g.upper_only = 1;                       // the Cholesky reads the upper triangle only
+        g.batch_flag = fused ? ml : nullptr;
         // algorithmic flops of the op this replaces: geqrf + orgqr of (rows x cols)
         prof_begin(PROF_GRAM, nw_ * 2.0 * (2.0 * rows * (double)cols * cols - 2.0 / 3.0 * (double)cols * cols * cols),
                    nw_ * (double)cols * (cols + TG_BN) * rows);
         tgemm_launch<T, T, double, double>(stream_, g, P.p, P.p, G);
         prof_end();
       }
-      R[i + 1] = alloc_ten(cols, l2, a2);
       const size_t smem = chol_smem_bytes(cols);
       PG_REQUIRE(smem <= 150 * 1024 && cols < 32768, 1, "Cholesky panel does not fit LDS (D*chi too large)");
       allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
-      int *ml = adaptive ? (int *)arena_.alloc(sizeof(int) * nw_) : nullptr;
       prof_begin(PROF_CHOL, 0.0, nw_ * (double)cols * cols * cols / 3.0);
       static const bool no_lowrank = getenv("PEPSGPU_NO_LOWRANK_CHOL") != nullptr;
       const bool lowrank = ml && !no_lowrank && cols <= 256 * CH_LR_Q;
@@ -158,11 +189,11 @@ void Engine<T>::absorb(int pos, int num) {
         const size_t lsm = chol_lowrank_smem_bytes(cols);
         allow_dynamic_lds(reinterpret_cast<const void *>(&chol_lowrank_kernel<T>), lsm);
         hipLaunchKernelGGL(chol_lowrank_kernel<T>, dim3(nw_), dim3(256), lsm, stream_, (const double *)G, (long)cols * cols,
-                           cols, R[i + 1].p, R[i + 1].n, ml);
+                           cols, R[i + 1].p, R[i + 1].n, ml, fused ? 1 : 0);
         PG_CHECK_HIP(hipGetLastError());
       }
       hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nw_), dim3(256), smem, stream_, G, (long)cols * cols, cols,
-                         R[i + 1].p, R[i + 1].n, ml, lowrank ? 1 : 0);
+                         R[i + 1].p, R[i + 1].n, ml, (lowrank || fused) ? 1 : 0);
       PG_CHECK_HIP(hipGetLastError());
       prof_end();
       if (dbg_sweeps_ && ml) {   // diagnostics: numerical rank of the carry (forces a sync)

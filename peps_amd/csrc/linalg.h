@@ -198,7 +198,9 @@ inline size_t chol_lowrank_smem_bytes(int n) { return sizeof(double) * (size_t)C
 
 template <typename T>
 __global__ __launch_bounds__(256) void chol_lowrank_kernel(const double *__restrict__ Gg, long wG, int n,
-                                                           T *__restrict__ Rg, long wR, int *__restrict__ mlive_out) {
+                                                           T *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
+                                                           int only_flagged = 0) {
+  if (only_flagged && mlive_out[blockIdx.x] >= 0) return;   // gram_chol_lowrank_kernel finished this walker
   extern __shared__ double lr_R[];                 // [CH_LR_CAP][n]
   __shared__ double s_red[4], s_nrm[CH_LR_CAP];
   __shared__ int s_first[2][4];
@@ -282,6 +284,156 @@ __global__ __launch_bounds__(256) void chol_lowrank_kernel(const double *__restr
     if (pos < 0) continue;
     for (int r = tid; r < n; r += 256) Rout[(long)pos * n + r] = T(lr_R[j * n + r] * sc);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gram-free variant for the low-rank case: R^T R = P^T P straight from the live rows of P (K x n,
+// K = live carry rows, n <= 256 columns) without forming the n x n Gram matrix in memory.  Thread r
+// OWNS column r: its column of P (K values) and its column of the factor (<= CH_LR_CAP values) stay
+// in registers; a step needs one row of the Gram, G[f, r] = sum_k P[k, f] P[k, r], for which thread
+// f broadcasts its two columns through LDS.  Same column order, pivot rule, compaction and output
+// as chol_upper_kernel.  mlive_out[b] = -1 (nothing written) when K > KCAP or the rank exceeds
+// CH_LR_CAP: the Gram GEMM and chol_upper_kernel then run for that walker only (batch_flag /
+// only_flagged).  One 256-thread block per walker; f64 accumulation throughout.
+template <typename T, int KCAP>
+__global__ __launch_bounds__(256, 2) void gram_chol_lowrank_kernel(const T *__restrict__ Pg, long wP, int n,
+                                                                const int *__restrict__ kdyn, int kdyn_mul, int kmax,
+                                                                T *__restrict__ Rg, long wR, int *__restrict__ mlive_out) {
+  __shared__ __attribute__((aligned(16))) T s_pf[KCAP];   // column f of P
+  __shared__ double s_rf[CH_LR_CAP];     // column f of the factor
+  __shared__ double s_red[4], s_nrm[CH_LR_CAP], s_part[64];
+  __shared__ int s_first[2][4];
+  __shared__ short s_pos[CH_LR_CAP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = kdyn ? min(kmax, kdyn[blockIdx.x] * kdyn_mul) : kmax;
+  if (K > KCAP) {
+    if (tid == 0) mlive_out[blockIdx.x] = -1;
+    return;
+  }
+  const T *P = Pg + (long)blockIdx.x * wP;
+  T *Rout = Rg + (long)blockIdx.x * wR;
+  const int r = tid;
+  T pc[KCAP];
+  double rc[CH_LR_CAP];                   // own column of the factor (f64: pivots near the threshold amplify its rounding)
+  double d = 0.0;
+#pragma unroll
+  for (int k = 0; k < KCAP; ++k) {
+    pc[k] = (k < K && r < n) ? P[(long)k * n + r] : T(0);
+    d += (double)pc[k] * (double)pc[k];
+  }
+#pragma unroll
+  for (int j = 0; j < CH_LR_CAP; ++j) rc[j] = 0.0;
+  double md = d;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
+  if (lane == 0) s_red[wave] = md;
+  __syncthreads();
+  const double maxd = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+  const double eT = NOISE_C * (double)Eps<T>::v;
+  const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
+  int nl = 0, f = -1;
+#pragma unroll 1
+  for (int step = 0;; ++step) {
+    int cand = (r < n && r > f && d > thresh) ? r : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+    if (lane == 0) s_first[step & 1][wave] = cand;
+    __syncthreads();
+    // squared norm of the row finished in the previous step (partials written before the barrier)
+    if (tid == 0 && nl > 0)
+      s_nrm[nl - 1] = s_part[4 * ((step + 1) & 1)] + s_part[4 * ((step + 1) & 1) + 1] + s_part[4 * ((step + 1) & 1) + 2] +
+                      s_part[4 * ((step + 1) & 1) + 3];
+    f = min(min(s_first[step & 1][0], s_first[step & 1][1]), min(s_first[step & 1][2], s_first[step & 1][3]));
+    if (f == 0x7fffffff || nl >= K) break;   // the rank cannot exceed the K rows of P: later pivots are rounding noise
+    if (nl == CH_LR_CAP) {                 // rank above the cap: the blocked path redoes this walker
+      if (tid == 0) mlive_out[blockIdx.x] = -1;
+      return;
+    }
+    if (r == f) {                          // the owner of the pivot column publishes it
+#pragma unroll
+      for (int k = 0; k < KCAP; ++k) s_pf[k] = pc[k];
+#pragma unroll
+      for (int j = 0; j < CH_LR_CAP; ++j) s_rf[j] = rc[j];
+    }
+    __syncthreads();
+    double g = 0.0, piv = 0.0;             // g = G[f, r] - sum_j R[j,f] R[j,r];  piv likewise for r = f
+#pragma unroll
+    for (int kb = 0; kb < KCAP; kb += 16) {
+      if (kb >= K) break;
+      asm volatile("" ::: "memory");         // keep the LDS reads of later chunks from being hoisted (register pressure)
+      T pfv[16];                             // one batch of LDS reads, then the arithmetic
+#pragma unroll
+      for (int k = 0; k < 16; ++k) pfv[k] = s_pf[kb + k];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const double pf = (double)pfv[k];
+        T pk = pc[kb + k];
+        asm volatile("" : "+v"(pk));         // opaque copy: keeps the T -> f64 conversion of the (loop-invariant)
+                                             // column inside the step loop instead of 2*KCAP live registers
+        g = fma(pf, (double)pk, g);
+        piv = fma(pf, pf, piv);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < CH_LR_CAP; ++j) {
+      if (j < nl) {
+        const double rf = s_rf[j];
+        g = fma(-rf, rc[j], g);
+        piv = fma(-rf, rf, piv);
+      }
+    }
+    const double v = (r >= f && r < n) ? g / sqrt(piv) : 0.0;
+#pragma unroll
+    for (int j = 0; j < CH_LR_CAP; ++j) rc[j] = (j == nl) ? v : rc[j];
+    const double v2 = v * v;
+    if (r > f) d -= v2;
+    const double a = wave_sum(v2);
+    if (lane == 0) s_part[4 * (step & 1) + wave] = a;
+    ++nl;
+  }
+  __syncthreads();
+  double fro = 0.0;
+  for (int j = 0; j < nl; ++j) fro += s_nrm[j];
+  const double nfloor = eT * eT * fro;
+  if (tid == 0) {
+    int cnt = 0;
+    for (int j = 0; j < nl; ++j) s_pos[j] = s_nrm[j] > nfloor ? (short)cnt++ : (short)-1;
+    mlive_out[blockIdx.x] = cnt;
+  }
+  __syncthreads();
+  const double sc = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
+#pragma unroll
+  for (int j = 0; j < CH_LR_CAP; ++j) {
+    if (j < nl) {
+      const int pos = s_pos[j];
+      if (pos >= 0 && r < n) Rout[(long)pos * n + r] = T(rc[j] * sc);
+    }
+  }
+}
+
+// Walkers that gram_chol_lowrank_kernel declined while the block still has fewer rows than columns
+// (any R with R^T R = P^T P serves, P itself included): adopt the K live rows of P, normalised, as
+// the carry and report K.  One block per walker; walkers with mlive >= 0 are left alone.
+template <typename T>
+__global__ __launch_bounds__(256) void adopt_rows_flagged_kernel(const T *__restrict__ Pg, long wP, int cols,
+                                                                 const int *__restrict__ kdyn, int kdyn_mul, int kmax,
+                                                                 T *__restrict__ Rg, long wR, int *__restrict__ mlive) {
+  if (mlive[blockIdx.x] >= 0) return;
+  __shared__ double s_red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = kdyn ? min(kmax, kdyn[blockIdx.x] * kdyn_mul) : kmax;
+  const T *P = Pg + (long)blockIdx.x * wP;
+  T *R = Rg + (long)blockIdx.x * wR;
+  const long cnt = (long)K * cols;
+  double a = 0.0;
+  for (long e = tid; e < cnt; e += 256) { const double x = (double)P[e]; a += x * x; }
+  a = wave_sum(a);
+  if (lane == 0) s_red[wave] = a;
+  __syncthreads();
+  const double nrm2 = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  const double sc = nrm2 > 0.0 ? 1.0 / sqrt(nrm2) : 1.0;
+  for (long e = tid; e < cnt; e += 256) R[e] = T((double)P[e] * sc);
+  if (tid == 0) mlive[blockIdx.x] = K;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -36,6 +36,7 @@ struct TGemmDesc {
   int nbatch = 1;
   int accumulate = 0;
   int upper_only = 0;   // symmetric result (Gram): tiles strictly below the diagonal are not computed
+  const int *batch_flag = nullptr;   // when set, batch entry b runs only if batch_flag[b] < 0
   double alpha = 1.0;
 
   __host__ __device__ int Itot() const { return I[0] * I[1] * I[2]; }
@@ -238,6 +239,7 @@ template <typename TA, typename TB, typename TC, typename TAcc, bool USE_MFMA>
 __global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__restrict__ Ag,
                                                     const TB *__restrict__ Bg, TC *__restrict__ Cg) {
   const int b = blockIdx.z;
+  if (d.batch_flag && d.batch_flag[b] >= 0) return;
   int Itot = d.Itot(), Ktot = d.Ktot();
   if (d.dynI) Itot = min(Itot, d.dynI[b] * d.dynI_mul);
   if (d.dynK) Ktot = min(Ktot, d.dynK[b] * d.dynK_mul);

@@ -225,3 +225,28 @@ def test_cholesky_rank_adaptive_pair(n, ranks, dt):
         assert 0 < ml[b] <= min(r + slack, n) and (r >= n or ml[b] >= r - 1), (r, ml[b])   # r = n: smallest directions may fall under the floor
         Rb = R[b, :ml[b]].astype(np.float64)
         assert np.max(np.abs(Rb.T @ Rb * sc - Gu)) / sc < tol, (r, ml[b])
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("K,n,rank", [(80, 256, 10), (96, 256, 32), (64, 256, 33), (16, 144, 16), (7, 40, 3), (64, 256, 1)])
+def test_gram_free_lowrank_factor(K, n, rank, dt):
+    """gram_chol_lowrank_kernel: R^T R = P^T P straight from the K live rows of P (no Gram matrix in
+    memory); declines (mlive = -1) when the rank exceeds its cap of 32."""
+    capi = _capi()
+    if dt == "f64" and K > 48:
+        pytest.skip("f64 variant holds 48 rows of P per thread")
+    rng = np.random.default_rng(K + n + rank)
+    nb = 5
+    P = np.stack([rng.standard_normal((K, rank)) @ rng.standard_normal((rank, n)) for _ in range(nb)])
+    R, ml = capi.diag_gram_chol(capi.F32 if dt == "f32" else capi.F64, P)
+    tol = 2e-5 if dt == "f32" else 1e-9
+    for b in range(nb):
+        if rank > 32 or (rank >= 31 and ml[b] == -1):     # at the cap the rounding noise of the input may tip it over
+            assert ml[b] == -1
+            continue
+        Pb = P[b].astype(np.float32).astype(np.float64) if dt == "f32" else P[b]
+        G = Pb.T @ Pb
+        sc = np.max(np.diag(G))
+        assert rank - 1 <= ml[b] <= min(rank + 2, K, n), (rank, ml[b])     # rounding noise of the input may pass as a pivot
+        Rb = R[b, :ml[b]].astype(np.float64)
+        assert np.max(np.abs(Rb.T @ Rb * sc - G)) / sc < tol
