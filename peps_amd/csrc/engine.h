@@ -177,6 +177,9 @@ class Engine : public EngineBase {
   struct BMPSDev {
     std::vector<DTen<T>> t;
     double *logscale = nullptr;
+    // live[b][w] (b = 0..N): number of non-zero states of bond b (between tensors b-1 and b) for
+    // walker w; the tensors stay zero padded to their static shape.  nullptr = the static dimension.
+    std::vector<int *> live;
   };
   struct BTenDev {
     DTen<T> t;
@@ -193,6 +196,7 @@ class Engine : public EngineBase {
     BMPSDev b;
     int n = mps_len(pos);
     for (int i = 0; i < n; ++i) b.t.push_back(ones3());
+    b.live.assign(n + 1, nullptr);
     b.logscale = zeros_f64();
     bmps_[pos].push_back(std::move(b));
   }
@@ -700,6 +704,7 @@ class Engine : public EngineBase {
     auto &v = bmps_[pos];
     while ((int)v.size() > keep) {
       for (auto &t : v.back().t) arena_.free(t.p);
+      for (int *l : v.back().live) if (l) arena_.free(l);
       arena_.free(v.back().logscale);
       v.pop_back();
     }

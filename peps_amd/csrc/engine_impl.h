@@ -62,6 +62,13 @@ void Engine<T>::absorb(int pos, int num) {
   // copy of the tensor descriptors: push_back below may reallocate bmps_[pos]
   const std::vector<DTen<T>> cur = bmps_[pos].back().t;
   const double *cur_log = bmps_[pos].back().logscale;
+  // live bond dimensions of the absorbing BMPS (per walker, device) and of the one being built:
+  // every contraction below runs over the live part of a bond only; persistent tensors stay zero padded
+  static const bool bond_adapt = getenv("PEPSGPU_NO_BOND_ADAPT") == nullptr && getenv("PEPSGPU_NO_RANK_ADAPT") == nullptr;
+  std::vector<int *> clive = bmps_[pos].back().live;
+  clive.resize(N + 1, nullptr);
+  if (!bond_adapt) std::fill(clive.begin(), clive.end(), nullptr);
+  std::vector<int *> kn(N + 1, nullptr);
   PG_REQUIRE((int)cur.size() == N, 3, "MultiplyMPO: MPS/MPO length mismatch");
   auto site_rc = [&](int i, int &r, int &c) {
     switch (pos) {
@@ -95,9 +102,11 @@ void Engine<T>::absorb(int pos, int num) {
       TGemmDesc g;
       g.I[2] = m * l; g.sAi[2] = a; g.sCi[2] = p * a2;
       g.K[2] = a; g.sAk[2] = 1; g.sBk[2] = p * a2;
-      g.J[2] = p * a2; g.sBj[2] = 1; g.sCj[2] = 1;
+      g.J[1] = p; g.J[2] = a2; g.sBj[1] = a2; g.sBj[2] = 1; g.sCj[1] = a2; g.sCj[2] = 1;
       g.wA = R[i].n; g.wB = A.n; g.wC = X.n; g.nbatch = nw_;
       g.dynI = mdyn[i]; g.dynI_mul = mmul[i] * l;
+      g.dK[2].p = clive[i];            // live part of the bond to the left of A
+      g.dJ[2].p = clive[i + 1];        // ... and to its right
       const double fl = 2.0 * nw_ * (double)(m * l) * a * (double)(p * a2);
       prof_begin(PROF_CONTRACT, fl, fl);
       tgemm_launch<T, T, T, T>(stream_, g, R[i].p, A.p, X.p);
@@ -111,7 +120,8 @@ void Engine<T>::absorb(int pos, int num) {
       g.K[1] = l; g.K[2] = p; g.sAk[1] = p * a2; g.sAk[2] = a2; g.sBk[1] = st[ll]; g.sBk[2] = st[lp];
       g.J[1] = l2; g.J[2] = u; g.sBj[1] = st[lr]; g.sBj[2] = st[lu]; g.sCj[1] = a2; g.sCj[2] = l2 * a2;
       g.wA = X.n; g.wC = P.n; g.nbatch = nw_;
-      g.dynI = mdyn[i]; g.dynI_mul = mmul[i] * a2;
+      g.dI[1].p = mdyn[i]; g.dI[1].mul = mmul[i];
+      g.dI[2].p = clive[i + 1];
       const double fl = 2.0 * nw_ * (double)(m * a2) * (double)(l * p) * (double)(l2 * u);
       prof_begin(PROF_CONTRACT, fl, fl);
       launch_site_gemm(g, cfg_site(r, c), 1, X.p, P.p);
@@ -129,10 +139,10 @@ void Engine<T>::absorb(int pos, int num) {
       int *ml = (int *)arena_.alloc(sizeof(int) * nw_);
       prof_begin(PROF_CHOL, nw_ * 2.0 * (2.0 * cols * (double)rows * rows - 2.0 / 3.0 * (double)rows * rows * rows), 0.0);
       hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, FUSED_KCAP>), dim3(nw_), dim3(256), 0, stream_, (const T *)P.p, P.n, cols,
-                         (const int *)mdyn[i], mmul[i] * u, rows, R[i + 1].p, R[i + 1].n, ml);
+                         (const int *)mdyn[i], mmul[i] * u, rows, R[i + 1].p, R[i + 1].n, ml, a2, (const int *)clive[i + 1]);
       PG_CHECK_HIP(hipGetLastError());
       hipLaunchKernelGGL(adopt_rows_flagged_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)P.p, P.n, cols,
-                         (const int *)mdyn[i], mmul[i] * u, rows, R[i + 1].p, R[i + 1].n, ml);
+                         (const int *)mdyn[i], mmul[i] * u, rows, R[i + 1].p, R[i + 1].n, ml, a2, (const int *)clive[i + 1]);
       PG_CHECK_HIP(hipGetLastError());
       prof_end();
       mdyn[i + 1] = ml;
@@ -144,6 +154,11 @@ void Engine<T>::absorb(int pos, int num) {
       P.d[0] = rows; P.d[1] = l2; P.d[2] = a2; P.d[3] = 1;
       // reference op here: QR of the (rows x cols) block, rows < cols (swap R,C)
       prof_begin(PROF_NORM, nw_ * 2.0 * (2.0 * cols * (double)rows * rows - 2.0 / 3.0 * (double)rows * rows * rows), 0.0);
+      if (clive[i + 1]) {
+        hipLaunchKernelGGL(zero_dead_cols_kernel<T>, dim3(nw_), dim3(256), 0, stream_, P.p, P.n, cols, (const int *)mdyn[i],
+                           mmul[i] * u, rows, a2, (const int *)clive[i + 1], (const int *)nullptr);
+        PG_CHECK_HIP(hipGetLastError());
+      }
       normalize(P.p, P.n, P.n, nw_, nullptr, mdyn[i], mmul[i] * u * cols);
       prof_end();
       R[i + 1] = P;
@@ -160,9 +175,15 @@ void Engine<T>::absorb(int pos, int num) {
       if (fused) {
         prof_begin(PROF_CHOL, 0.0, 0.0);
         hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, FUSED_KCAP>), dim3(nw_), dim3(256), 0, stream_, (const T *)P.p, P.n,
-                           cols, (const int *)mdyn[i], mmul[i] * u, rows, R[i + 1].p, R[i + 1].n, ml);
+                           cols, (const int *)mdyn[i], mmul[i] * u, rows, R[i + 1].p, R[i + 1].n, ml, a2,
+                           (const int *)clive[i + 1]);
         PG_CHECK_HIP(hipGetLastError());
         prof_end();
+      }
+      if (clive[i + 1]) {   // the Gram GEMM reads whole rows: define the never-written columns (flagged walkers only)
+        hipLaunchKernelGGL(zero_dead_cols_kernel<T>, dim3(nw_), dim3(256), 0, stream_, P.p, P.n, cols, (const int *)mdyn[i],
+                           mmul[i] * u, rows, a2, (const int *)clive[i + 1], (const int *)(fused ? ml : nullptr));
+        PG_CHECK_HIP(hipGetLastError());
       }
       {
         TGemmDesc g;
@@ -233,6 +254,9 @@ void Engine<T>::absorb(int pos, int num) {
       g.K[2] = a2; g.sAk[2] = 1; g.sBk[2] = k2;
       g.J[1] = l2; g.J[2] = k2; g.sBj[1] = a2 * k2; g.sBj[2] = 1; g.sCj[1] = k2; g.sCj[2] = 1;
       g.wA = A.n; g.wB = Y.n; g.wC = Z1.n; g.nbatch = nw_;
+      g.dynI = clive[i]; g.dynI_mul = p;      // live bonds: a (rows of A), a2 (contracted), k2 (new bond to the right)
+      g.dK[2].p = clive[i + 1];
+      g.dJ[2].p = kn[i + 1];
       prof_begin(PROF_CONTRACT, 0.0, 2.0 * nw_ * (double)(a * p) * a2 * (double)(l2 * k2));
       tgemm_launch<T, T, T, T>(stream_, g, A.p, Y.p, Z1.p);
       prof_end();
@@ -245,6 +269,8 @@ void Engine<T>::absorb(int pos, int num) {
       g.K[1] = p; g.K[2] = l2; g.sAk[1] = l2 * k2; g.sAk[2] = k2; g.sBk[1] = st[lp]; g.sBk[2] = st[lr];
       g.J[1] = l; g.J[2] = u; g.sBj[1] = st[ll]; g.sBj[2] = st[lu]; g.sCj[1] = a * u * k2; g.sCj[2] = k2;
       g.wA = Z1.n; g.wC = Tt.n; g.nbatch = nw_;
+      g.dI[1].p = clive[i];
+      g.dI[2].p = kn[i + 1]; g.dI[2].mask = (i == 0);   // i == 0: Tt becomes the (persistent, zero padded) first tensor
       prof_begin(PROF_CONTRACT, 0.0, 2.0 * nw_ * (double)(a * k2) * (double)(p * l2) * (double)(l * u));
       launch_site_gemm(g, cfg_site(r, c), 1, Z1.p, Tt.p);
       prof_end();
@@ -267,10 +293,12 @@ void Engine<T>::absorb(int pos, int num) {
     {
       TGemmDesc g;
       g.I[2] = m; g.sAi[2] = la; g.sCi[2] = uk;
-      g.K[2] = la; g.sAk[2] = 1; g.sBk[2] = uk;
-      g.J[2] = uk; g.sBj[2] = 1; g.sCj[2] = 1;
+      g.K[1] = l; g.K[2] = a; g.sAk[1] = a; g.sAk[2] = 1; g.sBk[1] = a * uk; g.sBk[2] = uk;
+      g.J[1] = u; g.J[2] = k2; g.sBj[1] = k2; g.sBj[2] = 1; g.sCj[1] = k2; g.sCj[2] = 1;
       g.wA = R[i].n; g.wB = Tt.n; g.wC = M.n; g.nbatch = nw_;
       g.dynI = mdyn[i]; g.dynI_mul = mmul[i];
+      g.dK[2].p = clive[i];
+      g.dJ[2].p = kn[i + 1]; g.dJ[2].mask = 1;   // the Jacobi reads whole rows of M: dead columns are written as zeros
       prof_begin(PROF_CONTRACT, 0.0, 2.0 * nw_ * (double)m * la * (double)uk);
       tgemm_launch<T, T, T, T>(stream_, g, R[i].p, Tt.p, M.p);
       prof_end();
@@ -306,8 +334,9 @@ void Engine<T>::absorb(int pos, int num) {
     PG_REQUIRE(m <= 1024, 1, "bond dimension too large for select_rows_kernel");
     DTen<T> V = alloc_ten(k, u, k2);
     prof_begin(PROF_SELECT, 0.0, 0.0);
+    if (bond_adapt) kn[i] = (int *)arena_.alloc(sizeof(int) * nw_);
     hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)M.p, M.n, m, uk, uk, k, V.p,
-                       V.n, (T *)nullptr, 0L, (const int *)mdyn[i], mmul[i]);
+                       V.n, (T *)nullptr, 0L, (const int *)mdyn[i], mmul[i], kn[i]);
     PG_CHECK_HIP(hipGetLastError());
     prof_end();
     free_ten(M);
@@ -316,10 +345,13 @@ void Engine<T>::absorb(int pos, int num) {
     DTen<T> Yn = alloc_ten(l, a, k);
     {
       TGemmDesc g;
-      g.I[2] = la; g.sAi[2] = uk; g.sCi[2] = k;
-      g.K[2] = uk; g.sAk[2] = 1; g.sBk[2] = 1;
+      g.I[1] = l; g.I[2] = a; g.sAi[1] = a * uk; g.sAi[2] = uk; g.sCi[1] = a * k; g.sCi[2] = k;
+      g.K[1] = u; g.K[2] = k2; g.sAk[1] = k2; g.sAk[2] = 1; g.sBk[1] = k2; g.sBk[2] = 1;
       g.J[2] = k; g.sBj[2] = uk; g.sCj[2] = 1;
       g.wA = Tt.n; g.wB = V.n; g.wC = Yn.n; g.nbatch = nw_;
+      g.dI[2].p = clive[i]; g.dI[2].mask = 1;    // Yn is normalised as a whole: written in full, zeros beyond the live bonds
+      g.dK[2].p = kn[i + 1];
+      g.dJ[2].p = kn[i]; g.dJ[2].mask = 1;
       // reference op: res[i-1] . (u s)  (bmps_impl.h:254): 2 (m_{i-1} D_u) m_i k_i
       int rp, cp, ddp[4];
       site_rc(i - 1, rp, cp);
@@ -340,6 +372,7 @@ void Engine<T>::absorb(int pos, int num) {
     for (int *p : mdyn)
       if (p && p != last) { arena_.free(p); last = p; }
   }
+  out.live = kn;
   bmps_[pos].push_back(std::move(out));
   ++n_absorb_;
 }

@@ -298,7 +298,10 @@ __global__ __launch_bounds__(256) void chol_lowrank_kernel(const double *__restr
 template <typename T, int KCAP>
 __global__ __launch_bounds__(256, 2) void gram_chol_lowrank_kernel(const T *__restrict__ Pg, long wP, int n,
                                                                 const int *__restrict__ kdyn, int kdyn_mul, int kmax,
-                                                                T *__restrict__ Rg, long wR, int *__restrict__ mlive_out) {
+                                                                T *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
+                                                                int inner = 1, const int *__restrict__ inner_live = nullptr) {
+  // columns are (outer, inner) with `inner` fastest; inner_live[b] (optional) = live extent of the
+  // inner index (live bond of the boundary MPS): columns beyond hold no data and are never read
   __shared__ __attribute__((aligned(16))) T s_pf[KCAP];   // column f of P
   __shared__ double s_rf[CH_LR_CAP];     // column f of the factor
   __shared__ double s_red[4], s_nrm[CH_LR_CAP], s_part[64];
@@ -313,12 +316,13 @@ __global__ __launch_bounds__(256, 2) void gram_chol_lowrank_kernel(const T *__re
   const T *P = Pg + (long)blockIdx.x * wP;
   T *Rout = Rg + (long)blockIdx.x * wR;
   const int r = tid;
+  const bool col_ok = r < n && (!inner_live || (r % inner) < inner_live[blockIdx.x]);
   T pc[KCAP];
   double rc[CH_LR_CAP];                   // own column of the factor (f64: pivots near the threshold amplify its rounding)
   double d = 0.0;
 #pragma unroll
   for (int k = 0; k < KCAP; ++k) {
-    pc[k] = (k < K && r < n) ? P[(long)k * n + r] : T(0);
+    pc[k] = (k < K && col_ok) ? P[(long)k * n + r] : T(0);
     d += (double)pc[k] * (double)pc[k];
   }
 #pragma unroll
@@ -417,8 +421,10 @@ __global__ __launch_bounds__(256, 2) void gram_chol_lowrank_kernel(const T *__re
 template <typename T>
 __global__ __launch_bounds__(256) void adopt_rows_flagged_kernel(const T *__restrict__ Pg, long wP, int cols,
                                                                  const int *__restrict__ kdyn, int kdyn_mul, int kmax,
-                                                                 T *__restrict__ Rg, long wR, int *__restrict__ mlive) {
+                                                                 T *__restrict__ Rg, long wR, int *__restrict__ mlive,
+                                                                 int inner = 1, const int *__restrict__ inner_live = nullptr) {
   if (mlive[blockIdx.x] >= 0) return;
+  const int ilive = inner_live ? inner_live[blockIdx.x] : inner;
   __shared__ double s_red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = kdyn ? min(kmax, kdyn[blockIdx.x] * kdyn_mul) : kmax;
@@ -426,14 +432,32 @@ __global__ __launch_bounds__(256) void adopt_rows_flagged_kernel(const T *__rest
   T *R = Rg + (long)blockIdx.x * wR;
   const long cnt = (long)K * cols;
   double a = 0.0;
-  for (long e = tid; e < cnt; e += 256) { const double x = (double)P[e]; a += x * x; }
+  for (long e = tid; e < cnt; e += 256) { const double x = (e % inner) < ilive ? (double)P[e] : 0.0; a += x * x; }
   a = wave_sum(a);
   if (lane == 0) s_red[wave] = a;
   __syncthreads();
   const double nrm2 = s_red[0] + s_red[1] + s_red[2] + s_red[3];
   const double sc = nrm2 > 0.0 ? 1.0 / sqrt(nrm2) : 1.0;
-  for (long e = tid; e < cnt; e += 256) R[e] = T((double)P[e] * sc);
+  for (long e = tid; e < cnt; e += 256) R[e] = (e % inner) < ilive ? T((double)P[e] * sc) : T(0);
   if (tid == 0) mlive[blockIdx.x] = K;
+}
+
+// Columns (outer, inner) of the K live rows of P whose inner index is beyond the walker's live
+// extent were never written: zero them before a kernel that reads whole rows (Gram GEMM, normalise).
+// flag (optional): only walkers with flag[b] < 0.
+template <typename T>
+__global__ __launch_bounds__(256) void zero_dead_cols_kernel(T *__restrict__ Pg, long wP, int cols,
+                                                             const int *__restrict__ kdyn, int kdyn_mul, int kmax,
+                                                             int inner, const int *__restrict__ inner_live,
+                                                             const int *__restrict__ flag) {
+  if (flag && flag[blockIdx.x] >= 0) return;
+  const int ilive = inner_live[blockIdx.x];
+  if (ilive >= inner) return;
+  const int K = kdyn ? min(kmax, kdyn[blockIdx.x] * kdyn_mul) : kmax;
+  T *P = Pg + (long)blockIdx.x * wP;
+  const long cnt = (long)K * cols;
+  for (long e = threadIdx.x; e < cnt; e += 256)
+    if ((e % inner) >= ilive) P[e] = T(0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -563,9 +587,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void select_rows_kernel(const T *__restrict__ Mg, long wM, int m, int len,
                                                           int ld, int k, T *__restrict__ Vg, long wV,
                                                           T *__restrict__ Sg, long wS,
-                                                          const int *__restrict__ mdyn, int mdyn_mul) {
+                                                          const int *__restrict__ mdyn, int mdyn_mul,
+                                                          int *__restrict__ klive_out = nullptr) {
   __shared__ double s_norm[1024];
   __shared__ int s_rank[1024];
+  __shared__ int s_klive;
+  if (threadIdx.x == 0) s_klive = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T *M = Mg + (long)blockIdx.x * wM;
   T *V = Vg + (long)blockIdx.x * wV;
@@ -600,6 +627,12 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const T *__restrict__ 
     double nv = s_norm[r];
     T inv = nv > nfloor ? T(1.0 / nv) : T(0);   // numerically zero direction -> zero row of Vt
     for (int c = lane; c < len; c += 64) V[(long)rk * len + c] = M[(long)r * ld + c] * inv;
+    if (lane == 0 && nv > nfloor) atomicAdd(&s_klive, 1);
+  }
+  // rows are ranked by norm, so the non-zero rows of Vt are its first klive rows
+  if (klive_out) {
+    __syncthreads();
+    if (tid == 0) klive_out[blockIdx.x] = s_klive;
   }
 }
 

@@ -18,6 +18,16 @@
 
 namespace pepsgpu {
 
+// Per-walker dynamic extent of ONE sub-index: min(static dim, p[b] * mul).  Default (mask = 0):
+// the index space is compacted -- the flattened index runs over the reduced dims with the static
+// strides, elements beyond are neither read nor written.  mask = 1 (I and J only): the static
+// tiling is kept, the operand is read as zero beyond the extent and C is written (zeros) there.
+struct TgDyn {
+  const int *p = nullptr;
+  int mul = 1;
+  int mask = 0;
+};
+
 struct TGemmDesc {
   int I[3] = {1, 1, 1}, J[3] = {1, 1, 1}, K[3] = {1, 1, 1};  // sub-dims, innermost last
   int sAi[3] = {0, 0, 0}, sAk[3] = {0, 0, 0};
@@ -33,6 +43,9 @@ struct TGemmDesc {
   // flattened I index (resp. K index) exist; tiles beyond exit at once, C rows beyond are not written.
   const int *dynI = nullptr, *dynK = nullptr;
   int dynI_mul = 1, dynK_mul = 1;
+  // Per-walker dynamic extents of single sub-indices (live bond dimensions of the boundary MPS)
+  TgDyn dI[3], dJ[3], dK[3];
+  int Imask[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, Jmask[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};  // set by the kernel
   int nbatch = 1;
   int accumulate = 0;
   int upper_only = 0;   // symmetric result (Gram): tiles strictly below the diagonal are not computed
@@ -48,6 +61,16 @@ constexpr int TG_BM = 64, TG_BN = 64, TG_BK = 16, TG_KTAB = 2048;
 
 template <typename T> struct TgPitch { static constexpr int v = 64; };
 template <> struct TgPitch<double> { static constexpr int v = 80; };  // 640 B: halves land 128 B apart
+
+// offset of flattened index idx; -1 when a sub-index is at or beyond its mask limit
+__device__ __forceinline__ int tg_off3m(int idx, const int *dims, const int *strides, const int *lim) {
+  int i2 = idx % dims[2];
+  int r = idx / dims[2];
+  int i1 = r % dims[1];
+  int i0 = r / dims[1];
+  if (i2 >= lim[2] || i1 >= lim[1] || i0 >= lim[0]) return -1;
+  return i0 * strides[0] + i1 * strides[1] + i2 * strides[2];
+}
 
 __device__ __forceinline__ int tg_off3(int idx, const int *dims, const int *strides) {
   int i2 = idx % dims[2];
@@ -83,11 +106,11 @@ __device__ __forceinline__ void tgemm_tile(const TGemmDesc &d, const TA *__restr
 
   if (tid < TG_BM) {
     int i = i0 + tid;
-    offAi[tid] = (i < Itot) ? tg_off3(i, d.I, d.sAi) : -1;
+    offAi[tid] = (i < Itot) ? tg_off3m(i, d.I, d.sAi, d.Imask) : -1;
     offCi[tid] = (i < Itot) ? tg_off3(i, d.I, d.sCi) : -1;
   } else if (tid < TG_BM + TG_BN) {
     int j = j0 + tid - TG_BM;
-    offBj[tid - TG_BM] = (j < Jtot) ? tg_off3(j, d.J, d.sBj) : -1;
+    offBj[tid - TG_BM] = (j < Jtot) ? tg_off3m(j, d.J, d.sBj, d.Jmask) : -1;
     offCj[tid - TG_BM] = (j < Jtot) ? tg_off3(j, d.J, d.sCj) : -1;
   }
 
@@ -240,6 +263,13 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__res
                                                     const TB *__restrict__ Bg, TC *__restrict__ Cg) {
   const int b = blockIdx.z;
   if (d.batch_flag && d.batch_flag[b] >= 0) return;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {   // block-uniform: the walker's live extents replace / mask the static dims
+    if (d.dI[s].p) { const int e = min(d.I[s], d.dI[s].p[b] * d.dI[s].mul); if (d.dI[s].mask) d.Imask[s] = e; else d.I[s] = e; }
+    if (d.dJ[s].p) { const int e = min(d.J[s], d.dJ[s].p[b] * d.dJ[s].mul); if (d.dJ[s].mask) d.Jmask[s] = e; else d.J[s] = e; }
+    if (d.dK[s].p) d.K[s] = min(d.K[s], d.dK[s].p[b] * d.dK[s].mul);
+  }
+  if ((int)blockIdx.y * TG_BN >= d.Jtot()) return;
   int Itot = d.Itot(), Ktot = d.Ktot();
   if (d.dynI) Itot = min(Itot, d.dynI[b] * d.dynI_mul);
   if (d.dynK) Ktot = min(Ktot, d.dynK[b] * d.dynK_mul);
@@ -256,7 +286,8 @@ template <typename TA, typename TB, typename TC, typename TAcc>
 void tgemm_launch(hipStream_t s, const TGemmDesc &d, const TA *A, const TB *B, TC *C) {
   if (d.nbatch <= 0 || d.Itot() <= 0 || d.Jtot() <= 0) return;
   int gx = (d.Itot() + TG_BM - 1) / TG_BM;
-  if (d.dynI && gx > TG_DYN_GRIDX) gx = TG_DYN_GRIDX;
+  const bool dyn_i = d.dynI || (d.dI[0].p && !d.dI[0].mask) || (d.dI[1].p && !d.dI[1].mask) || (d.dI[2].p && !d.dI[2].mask);
+  if (dyn_i && gx > TG_DYN_GRIDX) gx = TG_DYN_GRIDX;
   dim3 grid(gx, (d.Jtot() + TG_BN - 1) / TG_BN, d.nbatch);
   if (tgemm_use_mfma())
     hipLaunchKernelGGL((tgemm_kernel<TA, TB, TC, TAcc, true>), grid, dim3(256), 0, s, d, A, B, C);
