@@ -833,6 +833,17 @@ class Engine : public EngineBase {
     tgemm_launch<T, T, T, T>(stream_, g, A, site_base(ss.r, ss.c), C);
   }
 
+  // same with the site tensor as the A operand (C[(site legs), (...)]: lanes of the MFMA tile then run
+  // along the other operand's contiguous index, which keeps the stores of C coalesced)
+  void launch_site_gemm_a(TGemmDesc &g, const SiteSel &ss, int ncand, const T *B, T *C) {
+    g.selA = ss.sel;
+    g.selA_mul = slot_;
+    g.selA_inc = ss.inc;
+    g.seldivA = (ss.inc == Ly_ * Lx_) ? ncand : 1;
+    g.wA = 0;
+    tgemm_launch<T, T, T, T>(stream_, g, site_base(ss.r, ss.c), B, C);
+  }
+
   void absorb(int pos, int num);
   // ---- two-row environments and NNN / TNN / sqrt5 traces (engine_nnn.h) ----
   void clear_bten2(int pos, int keep) {

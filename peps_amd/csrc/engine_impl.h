@@ -116,15 +116,16 @@ void Engine<T>::absorb(int pos, int num) {
     DTen<T> P = alloc_ten(m, u, l2, a2);
     {
       TGemmDesc g;
-      g.I[1] = m; g.I[2] = a2; g.sAi[1] = l * p * a2; g.sAi[2] = 1; g.sCi[1] = u * l2 * a2; g.sCi[2] = 1;
-      g.K[1] = l; g.K[2] = p; g.sAk[1] = p * a2; g.sAk[2] = a2; g.sBk[1] = st[ll]; g.sBk[2] = st[lp];
-      g.J[1] = l2; g.J[2] = u; g.sBj[1] = st[lr]; g.sBj[2] = st[lu]; g.sCj[1] = a2; g.sCj[2] = l2 * a2;
-      g.wA = X.n; g.wC = P.n; g.nbatch = nw_;
-      g.dI[1].p = mdyn[i]; g.dI[1].mul = mmul[i];
-      g.dI[2].p = clive[i + 1];
+      // site tensor as the A operand: the lanes of a tile run along (m, a2), contiguous in X and in P
+      g.I[1] = l2; g.I[2] = u; g.sAi[1] = st[lr]; g.sAi[2] = st[lu]; g.sCi[1] = a2; g.sCi[2] = l2 * a2;
+      g.K[1] = l; g.K[2] = p; g.sAk[1] = st[ll]; g.sAk[2] = st[lp]; g.sBk[1] = p * a2; g.sBk[2] = a2;
+      g.J[1] = m; g.J[2] = a2; g.sBj[1] = l * p * a2; g.sBj[2] = 1; g.sCj[1] = u * l2 * a2; g.sCj[2] = 1;
+      g.wB = X.n; g.wC = P.n; g.nbatch = nw_;
+      g.dJ[1].p = mdyn[i]; g.dJ[1].mul = mmul[i];
+      g.dJ[2].p = clive[i + 1];
       const double fl = 2.0 * nw_ * (double)(m * a2) * (double)(l * p) * (double)(l2 * u);
       prof_begin(PROF_CONTRACT, fl, fl);
-      launch_site_gemm(g, cfg_site(r, c), 1, X.p, P.p);
+      launch_site_gemm_a(g, cfg_site(r, c), 1, X.p, P.p);
       prof_end();
     }
     free_ten(X);
@@ -265,14 +266,15 @@ void Engine<T>::absorb(int pos, int num) {
     DTen<T> Tt = alloc_ten(l, a, u, k2);
     {
       TGemmDesc g;
-      g.I[1] = a; g.I[2] = k2; g.sAi[1] = p * l2 * k2; g.sAi[2] = 1; g.sCi[1] = u * k2; g.sCi[2] = 1;
-      g.K[1] = p; g.K[2] = l2; g.sAk[1] = l2 * k2; g.sAk[2] = k2; g.sBk[1] = st[lp]; g.sBk[2] = st[lr];
-      g.J[1] = l; g.J[2] = u; g.sBj[1] = st[ll]; g.sBj[2] = st[lu]; g.sCj[1] = a * u * k2; g.sCj[2] = k2;
-      g.wA = Z1.n; g.wC = Tt.n; g.nbatch = nw_;
-      g.dI[1].p = clive[i];
-      g.dI[2].p = kn[i + 1]; g.dI[2].mask = (i == 0);   // i == 0: Tt becomes the (persistent, zero padded) first tensor
+      // site tensor as the A operand: the lanes of a tile run along (a, k2), contiguous in Z1 and in Tt
+      g.I[1] = l; g.I[2] = u; g.sAi[1] = st[ll]; g.sAi[2] = st[lu]; g.sCi[1] = a * u * k2; g.sCi[2] = k2;
+      g.K[1] = p; g.K[2] = l2; g.sAk[1] = st[lp]; g.sAk[2] = st[lr]; g.sBk[1] = l2 * k2; g.sBk[2] = k2;
+      g.J[1] = a; g.J[2] = k2; g.sBj[1] = p * l2 * k2; g.sBj[2] = 1; g.sCj[1] = u * k2; g.sCj[2] = 1;
+      g.wB = Z1.n; g.wC = Tt.n; g.nbatch = nw_;
+      g.dJ[1].p = clive[i];
+      g.dJ[2].p = kn[i + 1]; g.dJ[2].mask = (i == 0);   // i == 0: Tt becomes the (persistent, zero padded) first tensor
       prof_begin(PROF_CONTRACT, 0.0, 2.0 * nw_ * (double)(a * k2) * (double)(p * l2) * (double)(l * u));
-      launch_site_gemm(g, cfg_site(r, c), 1, Z1.p, Tt.p);
+      launch_site_gemm_a(g, cfg_site(r, c), 1, Z1.p, Tt.p);
       prof_end();
     }
     free_ten(Z1);

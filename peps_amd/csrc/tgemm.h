@@ -50,6 +50,7 @@ struct TGemmDesc {
   int accumulate = 0;
   int upper_only = 0;   // symmetric result (Gram): tiles strictly below the diagonal are not computed
   const int *batch_flag = nullptr;   // when set, batch entry b runs only if batch_flag[b] < 0
+  int dbg_skip = 0;   // timing experiments only (PEPSGPU_TGD_SKIP): 1 no C stores, 2 no A loads, 4 no B loads
   double alpha = 1.0;
 
   __host__ __device__ int Itot() const { return I[0] * I[1] * I[2]; }
@@ -280,6 +281,96 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__res
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Direct variant for the small contractions of the rank-adaptive absorption (live extents of a few
+// tens): one WAVE per 32x32 tile of C, operands loaded from global memory straight into the MFMA
+// operand registers (lane l holds A[i0 + l%32][k + l/32] -- exactly the 32x32x2 operand layout), no
+// LDS staging and no workgroup barrier in the K loop.  A block is four independent waves that walk
+// the tiles of the walker's (dynamic) extent; the only shared state is the K offset table.
+// f32 in / f32 out.  Same descriptor semantics as tgemm_kernel.
+constexpr int TGD_KC = 32;   // K depth per round of loads (16 MFMA steps)
+__global__ __launch_bounds__(256) void tgemm_direct_kernel(TGemmDesc d, const float *__restrict__ Ag,
+                                                           const float *__restrict__ Bg, float *__restrict__ Cg) {
+  __shared__ int offAk[TG_KTAB], offBk[TG_KTAB];
+  __shared__ int offCi_s[4][32];
+  const int b = blockIdx.z;
+  if (d.batch_flag && d.batch_flag[b] >= 0) return;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    if (d.dI[s].p) { const int e = min(d.I[s], d.dI[s].p[b] * d.dI[s].mul); if (d.dI[s].mask) d.Imask[s] = e; else d.I[s] = e; }
+    if (d.dJ[s].p) { const int e = min(d.J[s], d.dJ[s].p[b] * d.dJ[s].mul); if (d.dJ[s].mask) d.Jmask[s] = e; else d.J[s] = e; }
+    if (d.dK[s].p) d.K[s] = min(d.K[s], d.dK[s].p[b] * d.dK[s].mul);
+  }
+  int Itot = d.Itot(), Ktot = d.Ktot();
+  const int Jtot = d.Jtot();
+  if (d.dynI) Itot = min(Itot, d.dynI[b] * d.dynI_mul);
+  if (d.dynK) Ktot = min(Ktot, d.dynK[b] * d.dynK_mul);
+  const int nti = (Itot + 31) >> 5, ntj = (Jtot + 31) >> 5, ntiles = nti * ntj;
+  if (ntiles == 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  long baseA = (long)(b / d.bdivA) * d.wA, baseB = (long)(b / d.bdivB) * d.wB;
+  if (d.selA) baseA += (long)d.selA[(long)(b / d.seldivA) * d.selA_inc] * d.selA_mul;
+  if (d.selB) baseB += (long)d.selB[(long)(b / d.seldivB) * d.selB_inc] * d.selB_mul;
+  const float *A = Ag + baseA;
+  const float *B = Bg + baseB;
+  float *C = Cg + (long)(b / d.bdivC) * d.wC;
+  const float alpha = (float)d.alpha;
+  const int half = lane >> 5, l31 = lane & 31;
+  for (int kc = 0; kc < Ktot || kc == 0; kc += TG_KTAB) {
+    const int kchunk = min(TG_KTAB, Ktot - kc);
+    __syncthreads();
+    for (int k = tid; k < kchunk; k += 256) {
+      offAk[k] = tg_off3(kc + k, d.K, d.sAk);
+      offBk[k] = tg_off3(kc + k, d.K, d.sBk);
+    }
+    __syncthreads();
+    const bool first = kc == 0, last = kc + TG_KTAB >= Ktot;
+    for (int t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
+      const int ti = t / ntj, tj = t - ti * ntj;
+      const int i = ti * 32 + l31, j = tj * 32 + l31;
+      const int oa = (i < Itot) ? tg_off3m(i, d.I, d.sAi, d.Imask) : -1;
+      const int ob = (j < Jtot) ? tg_off3m(j, d.J, d.sBj, d.Jmask) : -1;
+      const int ocj = (j < Jtot) ? tg_off3(j, d.J, d.sCj) : -1;
+      if (half == 0) offCi_s[wave][l31] = (i < Itot) ? tg_off3(i, d.I, d.sCi) : -1;
+      tg_f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      if (!first || d.accumulate) {   // continue a K chunk / accumulate into C: start from the stored values
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int oi = offCi_s[wave][row];
+          if (oi >= 0 && ocj >= 0) acc[r] = C[oi + ocj] / ((first) ? alpha : 1.f);
+        }
+      }
+      for (int rep = 0; rep < ((d.dbg_skip & 8) ? 2 : 1); ++rep)
+      for (int k0 = 0; k0 < kchunk; k0 += TGD_KC) {
+        float av[TGD_KC / 2], bv[TGD_KC / 2];
+#pragma unroll
+        for (int q = 0; q < TGD_KC / 2; ++q) {
+          const int k = k0 + 2 * q + half;
+          const bool kin = k < kchunk;
+          av[q] = (kin && oa >= 0 && !(d.dbg_skip & 2)) ? A[oa + offAk[k]] : 0.f;
+          bv[q] = (kin && ob >= 0 && !(d.dbg_skip & 4)) ? B[ob + offBk[k]] : 0.f;
+        }
+        const int nq = min(TGD_KC / 2, (kchunk - k0 + 1) >> 1);
+#pragma unroll
+        for (int q = 0; q < TGD_KC / 2; ++q)
+          if (q < nq) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rep ? 0.f * av[q] : av[q], bv[q], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int oi = offCi_s[wave][row];
+        if (oi >= 0 && ocj >= 0 && !(d.dbg_skip & 1)) {
+          C[oi + ocj] = last ? acc[r] * alpha : acc[r];
+          if (d.dbg_skip & 16) { __builtin_amdgcn_s_waitcnt(0); asm volatile("" ::: "memory"); C[oi + ocj] = last ? acc[r] * alpha : acc[r]; }
+        }
+      }
+    }
+  }
+}
+
 bool tgemm_use_mfma();
 
 template <typename TA, typename TB, typename TC, typename TAcc>
@@ -289,6 +380,22 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d, const TA *A, const TB *B, T
   const bool dyn_i = d.dynI || (d.dI[0].p && !d.dI[0].mask) || (d.dI[1].p && !d.dI[1].mask) || (d.dI[2].p && !d.dI[2].mask);
   if (dyn_i && gx > TG_DYN_GRIDX) gx = TG_DYN_GRIDX;
   dim3 grid(gx, (d.Jtot() + TG_BN - 1) / TG_BN, d.nbatch);
+  if constexpr (sizeof(TA) == 4 && sizeof(TB) == 4 && sizeof(TC) == 4 && sizeof(TAcc) == 4) {
+    // small per-walker extents (rank-adaptive absorption): wave-per-tile kernel without LDS staging
+    static const int direct_mode = getenv("PEPSGPU_TGEMM_DIRECT") ? atoi(getenv("PEPSGPU_TGEMM_DIRECT")) : 1;
+    const bool any_dyn = dyn_i || d.dynK || d.dK[0].p || d.dK[1].p || d.dK[2].p || d.dJ[0].p || d.dJ[1].p || d.dJ[2].p;
+    if (tgemm_use_mfma() && (direct_mode == 2 || (direct_mode == 1 && any_dyn)) && d.alpha != 0.0) {
+      static const int dbg_skip = getenv("PEPSGPU_TGD_SKIP") ? atoi(getenv("PEPSGPU_TGD_SKIP")) : 0;
+      TGemmDesc dd = d;
+      dd.dbg_skip = dbg_skip;
+      const int tiles = ((d.Itot() + 31) / 32) * ((d.Jtot() + 31) / 32);
+      const int gxd = tiles >= 64 ? 4 : tiles >= 16 ? 2 : 1;
+      hipLaunchKernelGGL(tgemm_direct_kernel, dim3(gxd, 1, d.nbatch), dim3(256), 0, s, dd, (const float *)A, (const float *)B,
+                         (float *)C);
+      PG_CHECK_HIP(hipGetLastError());
+      return;
+    }
+  }
   if (tgemm_use_mfma())
     hipLaunchKernelGGL((tgemm_kernel<TA, TB, TC, TAcc, true>), grid, dim3(256), 0, s, d, A, B, C);
   else
