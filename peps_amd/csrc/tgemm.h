@@ -50,7 +50,6 @@ struct TGemmDesc {
   int accumulate = 0;
   int upper_only = 0;   // symmetric result (Gram): tiles strictly below the diagonal are not computed
   const int *batch_flag = nullptr;   // when set, batch entry b runs only if batch_flag[b] < 0
-  int dbg_skip = 0;   // timing experiments only (PEPSGPU_TGD_SKIP): 1 no C stores, 2 no A loads, 4 no B loads
   double alpha = 1.0;
 
   __host__ __device__ int Itot() const { return I[0] * I[1] * I[2]; }
@@ -284,30 +283,35 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__res
 // ---------------------------------------------------------------------------------------------
 // Direct variant for the small contractions of the rank-adaptive absorption (live extents of a few
 // tens): one WAVE per 32x32 tile of C, operands loaded from global memory straight into the MFMA
-// operand registers (lane l holds A[i0 + l%32][k + l/32] -- exactly the 32x32x2 operand layout), no
-// LDS staging and no workgroup barrier in the K loop.  A block is four independent waves that walk
-// the tiles of the walker's (dynamic) extent; the only shared state is the K offset table.
-// f32 in / f32 out.  Same descriptor semantics as tgemm_kernel.
-constexpr int TGD_KC = 32;   // K depth per round of loads (16 MFMA steps)
+// operand registers (lane l holds A[i0 + l%32][k], B[k][j0 + l%32] -- the 32x32x2 operand layout),
+// no LDS staging, no workgroup barrier.  A block is four independent waves that walk the tiles of
+// the walker's (dynamic) extent.
+//
+// K is walked as (k0, k1) x rounds of 8 values of the innermost sub-index k2: in a round the lower
+// half-wave takes k2 = 8r..8r+3 and the upper half 8r+4..8r+7, four MFMA steps (any pairing of k
+// values with MFMA steps is valid as long as A and B agree).  An operand whose k2 is contiguous in
+// memory (AVEC / BVEC) fetches its four values as one 16-byte load: the cost of these kernels is
+// the number of memory requests, not bytes (each lane addresses its own row).
+// f32 in / f32 out.  Same descriptor semantics as tgemm_kernel (dynK is not supported here).
+template <bool AVEC, bool BVEC>
 __global__ __launch_bounds__(256) void tgemm_direct_kernel(TGemmDesc d, const float *__restrict__ Ag,
                                                            const float *__restrict__ Bg, float *__restrict__ Cg) {
-  __shared__ int offAk[TG_KTAB], offBk[TG_KTAB];
   __shared__ int offCi_s[4][32];
   const int b = blockIdx.z;
   if (d.batch_flag && d.batch_flag[b] >= 0) return;
+  const int K2s = d.K[2];                     // static extent of k2 (vector loads stay inside it)
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     if (d.dI[s].p) { const int e = min(d.I[s], d.dI[s].p[b] * d.dI[s].mul); if (d.dI[s].mask) d.Imask[s] = e; else d.I[s] = e; }
     if (d.dJ[s].p) { const int e = min(d.J[s], d.dJ[s].p[b] * d.dJ[s].mul); if (d.dJ[s].mask) d.Jmask[s] = e; else d.J[s] = e; }
     if (d.dK[s].p) d.K[s] = min(d.K[s], d.dK[s].p[b] * d.dK[s].mul);
   }
-  int Itot = d.Itot(), Ktot = d.Ktot();
+  int Itot = d.Itot();
   const int Jtot = d.Jtot();
   if (d.dynI) Itot = min(Itot, d.dynI[b] * d.dynI_mul);
-  if (d.dynK) Ktot = min(Ktot, d.dynK[b] * d.dynK_mul);
   const int nti = (Itot + 31) >> 5, ntj = (Jtot + 31) >> 5, ntiles = nti * ntj;
   if (ntiles == 0) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   long baseA = (long)(b / d.bdivA) * d.wA, baseB = (long)(b / d.bdivB) * d.wB;
   if (d.selA) baseA += (long)d.selA[(long)(b / d.seldivA) * d.selA_inc] * d.selA_mul;
   if (d.selB) baseB += (long)d.selB[(long)(b / d.seldivB) * d.selB_inc] * d.selB_mul;
@@ -316,56 +320,66 @@ __global__ __launch_bounds__(256) void tgemm_direct_kernel(TGemmDesc d, const fl
   float *C = Cg + (long)(b / d.bdivC) * d.wC;
   const float alpha = (float)d.alpha;
   const int half = lane >> 5, l31 = lane & 31;
-  for (int kc = 0; kc < Ktot || kc == 0; kc += TG_KTAB) {
-    const int kchunk = min(TG_KTAB, Ktot - kc);
-    __syncthreads();
-    for (int k = tid; k < kchunk; k += 256) {
-      offAk[k] = tg_off3(kc + k, d.K, d.sAk);
-      offBk[k] = tg_off3(kc + k, d.K, d.sBk);
+  const int K2 = d.K[2], K01 = d.K[0] * d.K[1];
+  const int nr8 = (K2 + 7) >> 3, nrounds = K01 * nr8;
+  const int sA2 = d.sAk[2], sB2 = d.sBk[2];
+
+  for (int t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
+    const int ti = t / ntj, tj = t - ti * ntj;
+    const int i = ti * 32 + l31, j = tj * 32 + l31;
+    const int oa = (i < Itot) ? tg_off3m(i, d.I, d.sAi, d.Imask) : -1;
+    const int ob = (j < Jtot) ? tg_off3m(j, d.J, d.sBj, d.Jmask) : -1;
+    const int ocj = (j < Jtot) ? tg_off3(j, d.J, d.sCj) : -1;
+    if (half == 0) offCi_s[wave][l31] = (i < Itot) ? tg_off3(i, d.I, d.sCi) : -1;
+    tg_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    // one round of operand values for this lane: k2 = 8*r8 + 4*half + (0..3) at (k0, k1) = k01
+    auto load_round = [&](int rd, float (&av)[4], float (&bv)[4]) {
+      const int k01 = rd / nr8, r8 = rd - k01 * nr8;
+      const int k0 = k01 / d.K[1], k1 = k01 - k0 * d.K[1];
+      const int kq = 8 * r8 + 4 * half;
+      const int offa = oa + k0 * d.sAk[0] + k1 * d.sAk[1], offb = ob + k0 * d.sBk[0] + k1 * d.sBk[1];
+      if constexpr (AVEC) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (oa >= 0 && kq < K2s) v = *reinterpret_cast<const float4 *>(A + offa + kq);
+        av[0] = kq + 0 < K2 ? v.x : 0.f; av[1] = kq + 1 < K2 ? v.y : 0.f;
+        av[2] = kq + 2 < K2 ? v.z : 0.f; av[3] = kq + 3 < K2 ? v.w : 0.f;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) av[q] = (oa >= 0 && kq + q < K2) ? A[offa + (kq + q) * sA2] : 0.f;
+      }
+      if constexpr (BVEC) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ob >= 0 && kq < K2s) v = *reinterpret_cast<const float4 *>(B + offb + kq);
+        bv[0] = kq + 0 < K2 ? v.x : 0.f; bv[1] = kq + 1 < K2 ? v.y : 0.f;
+        bv[2] = kq + 2 < K2 ? v.z : 0.f; bv[3] = kq + 3 < K2 ? v.w : 0.f;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[q] = (ob >= 0 && kq + q < K2) ? B[offb + (kq + q) * sB2] : 0.f;
+      }
+    };
+    float a0[4], b0[4], a1[4], b1[4];
+    if (nrounds > 0) load_round(0, a0, b0);
+    for (int rd = 0; rd < nrounds; rd += 2) {       // two rounds per trip: the next loads are in flight during the MFMAs
+      if (rd + 1 < nrounds) load_round(rd + 1, a1, b1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b0[q], acc, 0, 0, 0);
+      if (rd + 2 < nrounds) load_round(rd + 2, a0, b0);
+      if (rd + 1 < nrounds) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], b1[q], acc, 0, 0, 0);
+      }
     }
-    __syncthreads();
-    const bool first = kc == 0, last = kc + TG_KTAB >= Ktot;
-    for (int t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
-      const int ti = t / ntj, tj = t - ti * ntj;
-      const int i = ti * 32 + l31, j = tj * 32 + l31;
-      const int oa = (i < Itot) ? tg_off3m(i, d.I, d.sAi, d.Imask) : -1;
-      const int ob = (j < Jtot) ? tg_off3m(j, d.J, d.sBj, d.Jmask) : -1;
-      const int ocj = (j < Jtot) ? tg_off3(j, d.J, d.sCj) : -1;
-      if (half == 0) offCi_s[wave][l31] = (i < Itot) ? tg_off3(i, d.I, d.sCi) : -1;
-      tg_f32x16 acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      if (!first || d.accumulate) {   // continue a K chunk / accumulate into C: start from the stored values
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-          const int oi = offCi_s[wave][row];
-          if (oi >= 0 && ocj >= 0) acc[r] = C[oi + ocj] / ((first) ? alpha : 1.f);
-        }
-      }
-      for (int rep = 0; rep < ((d.dbg_skip & 8) ? 2 : 1); ++rep)
-      for (int k0 = 0; k0 < kchunk; k0 += TGD_KC) {
-        float av[TGD_KC / 2], bv[TGD_KC / 2];
-#pragma unroll
-        for (int q = 0; q < TGD_KC / 2; ++q) {
-          const int k = k0 + 2 * q + half;
-          const bool kin = k < kchunk;
-          av[q] = (kin && oa >= 0 && !(d.dbg_skip & 2)) ? A[oa + offAk[k]] : 0.f;
-          bv[q] = (kin && ob >= 0 && !(d.dbg_skip & 4)) ? B[ob + offBk[k]] : 0.f;
-        }
-        const int nq = min(TGD_KC / 2, (kchunk - k0 + 1) >> 1);
-#pragma unroll
-        for (int q = 0; q < TGD_KC / 2; ++q)
-          if (q < nq) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rep ? 0.f * av[q] : av[q], bv[q], acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int oi = offCi_s[wave][row];
-        if (oi >= 0 && ocj >= 0 && !(d.dbg_skip & 1)) {
-          C[oi + ocj] = last ? acc[r] * alpha : acc[r];
-          if (d.dbg_skip & 16) { __builtin_amdgcn_s_waitcnt(0); asm volatile("" ::: "memory"); C[oi + ocj] = last ? acc[r] * alpha : acc[r]; }
-        }
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int oi = offCi_s[wave][row];
+      if (oi >= 0 && ocj >= 0) {
+        float v = acc[r] * alpha;
+        if (d.accumulate) v += C[oi + ocj];
+        C[oi + ocj] = v;
       }
     }
   }
@@ -383,15 +397,26 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d, const TA *A, const TB *B, T
   if constexpr (sizeof(TA) == 4 && sizeof(TB) == 4 && sizeof(TC) == 4 && sizeof(TAcc) == 4) {
     // small per-walker extents (rank-adaptive absorption): wave-per-tile kernel without LDS staging
     static const int direct_mode = getenv("PEPSGPU_TGEMM_DIRECT") ? atoi(getenv("PEPSGPU_TGEMM_DIRECT")) : 1;
-    const bool any_dyn = dyn_i || d.dynK || d.dK[0].p || d.dK[1].p || d.dK[2].p || d.dJ[0].p || d.dJ[1].p || d.dJ[2].p;
-    if (tgemm_use_mfma() && (direct_mode == 2 || (direct_mode == 1 && any_dyn)) && d.alpha != 0.0) {
-      static const int dbg_skip = getenv("PEPSGPU_TGD_SKIP") ? atoi(getenv("PEPSGPU_TGD_SKIP")) : 0;
-      TGemmDesc dd = d;
-      dd.dbg_skip = dbg_skip;
+    static const bool no_vec = getenv("PEPSGPU_TGEMM_NOVEC") != nullptr;
+    const bool any_dyn = dyn_i || d.dK[0].p || d.dK[1].p || d.dK[2].p || d.dJ[0].p || d.dJ[1].p || d.dJ[2].p;
+    if (tgemm_use_mfma() && !d.dynK && (direct_mode == 2 || (direct_mode == 1 && any_dyn))) {
+      // 16-byte loads along k2 where the operand is contiguous there and every other offset keeps the alignment
+      auto al4 = [](long v) { return (v & 3) == 0; };
+      const bool avec = !no_vec && d.sAk[2] == 1 && al4(d.K[2]) && al4(d.sAi[0]) && al4(d.sAi[1]) && al4(d.sAi[2]) &&
+                        al4(d.sAk[0]) && al4(d.sAk[1]) && al4(d.wA) && al4(d.selA_mul) && (((uintptr_t)A) & 15) == 0;
+      const bool bvec = !no_vec && d.sBk[2] == 1 && al4(d.K[2]) && al4(d.sBj[0]) && al4(d.sBj[1]) && al4(d.sBj[2]) &&
+                        al4(d.sBk[0]) && al4(d.sBk[1]) && al4(d.wB) && al4(d.selB_mul) && (((uintptr_t)B) & 15) == 0;
       const int tiles = ((d.Itot() + 31) / 32) * ((d.Jtot() + 31) / 32);
-      const int gxd = tiles >= 64 ? 4 : tiles >= 16 ? 2 : 1;
-      hipLaunchKernelGGL(tgemm_direct_kernel, dim3(gxd, 1, d.nbatch), dim3(256), 0, s, dd, (const float *)A, (const float *)B,
-                         (float *)C);
+      // with per-walker live extents the tile count is a few: one block (four waves) walks them; extra blocks
+      // would only pay the chain of dependent loads (extents, selector, offsets) and exit
+      static const int gx_dyn = getenv("PEPSGPU_TGD_GX") ? atoi(getenv("PEPSGPU_TGD_GX")) : 1;
+      const dim3 gd(any_dyn ? std::min(gx_dyn, std::max(1, tiles / 4)) : (tiles >= 64 ? 4 : tiles >= 16 ? 2 : 1), 1, d.nbatch);
+      const float *Af = (const float *)A, *Bf = (const float *)B;
+      float *Cf = (float *)C;
+      if (avec && bvec) hipLaunchKernelGGL((tgemm_direct_kernel<true, true>), gd, dim3(256), 0, s, d, Af, Bf, Cf);
+      else if (avec) hipLaunchKernelGGL((tgemm_direct_kernel<true, false>), gd, dim3(256), 0, s, d, Af, Bf, Cf);
+      else if (bvec) hipLaunchKernelGGL((tgemm_direct_kernel<false, true>), gd, dim3(256), 0, s, d, Af, Bf, Cf);
+      else hipLaunchKernelGGL((tgemm_direct_kernel<false, false>), gd, dim3(256), 0, s, d, Af, Bf, Cf);
       PG_CHECK_HIP(hipGetLastError());
       return;
     }
