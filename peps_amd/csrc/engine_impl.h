@@ -31,8 +31,15 @@ void Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
     // the kernels below return at once for those walkers
     if (len <= 256 && !no_small && (mdyn || m <= JR_SMALL_ROWS)) {
       small = 1;
+      static const bool no_tiny = getenv("PEPSGPU_NO_TINYJACOBI") != nullptr;
+      if (!no_tiny) {   // walkers with <= 16 rows first (low register count: all of them resident at once)
+        hipLaunchKernelGGL(jacobi_rows_tiny_kernel, dim3((nw_ + 3) / 4), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
+                           sweeps_, mdyn, mdyn_mul, nw_);
+        PG_CHECK_HIP(hipGetLastError());
+        if (m <= JR_BR) return;
+      }
       hipLaunchKernelGGL(jacobi_rows_small_kernel, dim3((nw_ + 3) / 4), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
-                         sweeps_, mdyn, mdyn_mul, nw_);
+                         sweeps_, mdyn, mdyn_mul, nw_, no_tiny ? 0 : 1);
       PG_CHECK_HIP(hipGetLastError());
       if (m <= JR_SMALL_ROWS) return;
     }

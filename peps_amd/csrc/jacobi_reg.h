@@ -334,12 +334,13 @@ __device__ __forceinline__ int jr_intra(JrRow (&a)[JR_BR], float (&na)[JR_BR], c
 
 __global__ __launch_bounds__(256) void jacobi_rows_small_kernel(float *__restrict__ Mg, long wM, int m, int len, int ld,
                                                                 int max_sweeps, int *__restrict__ sweeps_out,
-                                                                const int *__restrict__ mdyn, int mdyn_mul, int nwalkers) {
+                                                                const int *__restrict__ mdyn, int mdyn_mul, int nwalkers,
+                                                                int skip_tiny = 0) {
   const int lane = threadIdx.x & 63;
   const int walker = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (walker >= nwalkers) return;
   const int mm = mdyn ? min(m, mdyn[walker] * mdyn_mul) : m;
-  if (mm > JR_SMALL_ROWS) return;
+  if (mm > JR_SMALL_ROWS || (skip_tiny && mm <= JR_BR)) return;   // jacobi_rows_tiny_kernel took the <= 16-row walkers
   float *M = Mg + (long)walker * wM;
   JrRow a[JR_BR], b[JR_BR];
   float na[JR_BR], nb[JR_BR];
@@ -417,6 +418,64 @@ __global__ __launch_bounds__(256) void jacobi_rows_small_kernel(float *__restric
   if (has_b) {
 #pragma unroll
     for (int i = 0; i < JR_BR; ++i) store_row(b[i], JR_BR + i);
+  }
+  if (lane == 0 && sweeps_out) sweeps_out[walker] = sweep | (mm << 8);
+}
+
+
+// At most 16 existing rows (the usual numerical rank of the carry on smooth states): one block of
+// 16 rows per wave, a third of the registers of the 32-row kernel, so that every walker of a large
+// batch is resident at once.  The tournament runs over 8, 12 or 16 rows.
+__global__ __launch_bounds__(256, 3) void jacobi_rows_tiny_kernel(float *__restrict__ Mg, long wM, int m, int len, int ld,
+                                                               int max_sweeps, int *__restrict__ sweeps_out,
+                                                               const int *__restrict__ mdyn, int mdyn_mul, int nwalkers) {
+  const int lane = threadIdx.x & 63;
+  const int walker = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (walker >= nwalkers) return;
+  const int mm = mdyn ? min(m, mdyn[walker] * mdyn_mul) : m;
+  if (mm > JR_BR) return;
+  float *M = Mg + (long)walker * wM;
+  JrRow a[JR_BR];
+  float na[JR_BR];
+  double fro = 0.0;
+#pragma unroll
+  for (int i = 0; i < JR_BR; ++i) {
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 4 * lane + q;
+      v[q] = (i < mm && c < len) ? M[(long)i * ld + c] : 0.f;
+    }
+    a[i].lo = jr_f2{v[0], v[1]};
+    a[i].hi = jr_f2{v[2], v[3]};
+  }
+#pragma unroll
+  for (int i = 0; i < JR_BR; ++i) {
+    na[i] = jr_allsum(jr_dot(a[i], a[i]));
+    fro += (double)na[i];
+  }
+  const float floor2 = (float)(NOISE_C * NOISE_C * (double)Eps<float>::v * (double)Eps<float>::v * fro);
+  const float tol2 = 4.f * (float)len * Eps<float>::v * Eps<float>::v;
+  int sweep = 0;
+  for (; sweep < max_sweeps; ++sweep) {
+    if (sweep) {
+#pragma unroll
+      for (int i = 0; i < JR_BR; ++i) na[i] = jr_allsum(jr_dot(a[i], a[i]));
+    }
+    int rot;
+    if (mm <= 8) rot = jr_intra<8>(a, na, tol2, floor2);
+    else if (mm <= 12) rot = jr_intra<12>(a, na, tol2, floor2);
+    else rot = jr_intra<JR_BR>(a, na, tol2, floor2);
+    if (rot == 0) { ++sweep; break; }
+  }
+#pragma unroll
+  for (int i = 0; i < JR_BR; ++i) {
+    const float v[4] = {a[i].lo.x, a[i].lo.y, a[i].hi.x, a[i].hi.y};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 4 * lane + q;
+      if (i < mm && c < len) M[(long)i * ld + c] = v[q];
+    }
   }
   if (lane == 0 && sweeps_out) sweeps_out[walker] = sweep | (mm << 8);
 }
