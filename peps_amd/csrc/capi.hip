@@ -280,9 +280,8 @@ static void diag_gram_chol_t(const void *P, int K, int n, int nbatch, void *Rout
   PG_CHECK_HIP(hipMalloc(&dml, nbatch * sizeof(int)));
   PG_CHECK_HIP(hipMemcpy(dP, P, (size_t)K * n * nbatch * sizeof(T), hipMemcpyHostToDevice));
   PG_CHECK_HIP(hipMemset(dR, 0, (size_t)n * n * nbatch * sizeof(T)));
-  hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP>), dim3(nbatch), dim3(256), 0, 0, (const T *)dP, (long)K * n, n,
-                     (const int *)nullptr, 1, K, dR, (long)n * n, dml);
-  PG_CHECK_HIP(hipGetLastError());
+  launch_gram_chol_lowrank<T, KCAP>(0, nbatch, (const T *)dP, (long)K * n, n, (const int *)nullptr, 1, K, dR, (long)n * n, dml, 1,
+                                    (const int *)nullptr);
   PG_CHECK_HIP(hipDeviceSynchronize());
   PG_CHECK_HIP(hipMemcpy(Rout, dR, (size_t)n * n * nbatch * sizeof(T), hipMemcpyDeviceToHost));
   PG_CHECK_HIP(hipMemcpy(mlive, dml, nbatch * sizeof(int), hipMemcpyDeviceToHost));

@@ -146,9 +146,8 @@ void Engine<T>::absorb(int pos, int num) {
       R[i + 1] = alloc_ten(cols, l2, a2);
       int *ml = (int *)arena_.alloc(sizeof(int) * nw_);
       prof_begin(PROF_CHOL, nw_ * 2.0 * (2.0 * cols * (double)rows * rows - 2.0 / 3.0 * (double)rows * rows * rows), 0.0);
-      hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, FUSED_KCAP>), dim3(nw_), dim3(256), 0, stream_, (const T *)P.p, P.n, cols,
-                         (const int *)mdyn[i], mmul[i] * u, rows, R[i + 1].p, R[i + 1].n, ml, a2, (const int *)clive[i + 1]);
-      PG_CHECK_HIP(hipGetLastError());
+      launch_gram_chol_lowrank<T, FUSED_KCAP>(stream_, nw_, (const T *)P.p, P.n, cols, (const int *)mdyn[i], mmul[i] * u, rows,
+                                              R[i + 1].p, R[i + 1].n, ml, a2, (const int *)clive[i + 1]);
       hipLaunchKernelGGL(adopt_rows_flagged_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)P.p, P.n, cols,
                          (const int *)mdyn[i], mmul[i] * u, rows, R[i + 1].p, R[i + 1].n, ml, a2, (const int *)clive[i + 1]);
       PG_CHECK_HIP(hipGetLastError());
@@ -182,10 +181,8 @@ void Engine<T>::absorb(int pos, int num) {
       const bool fused = ml && !no_fused && cols <= 256 && (mdyn[i] || rows <= FUSED_KCAP);
       if (fused) {
         prof_begin(PROF_CHOL, 0.0, 0.0);
-        hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, FUSED_KCAP>), dim3(nw_), dim3(256), 0, stream_, (const T *)P.p, P.n,
-                           cols, (const int *)mdyn[i], mmul[i] * u, rows, R[i + 1].p, R[i + 1].n, ml, a2,
-                           (const int *)clive[i + 1]);
-        PG_CHECK_HIP(hipGetLastError());
+        launch_gram_chol_lowrank<T, FUSED_KCAP>(stream_, nw_, (const T *)P.p, P.n, cols, (const int *)mdyn[i], mmul[i] * u, rows,
+                                                R[i + 1].p, R[i + 1].n, ml, a2, (const int *)clive[i + 1]);
         prof_end();
       }
       if (clive[i + 1]) {   // the Gram GEMM reads whole rows: define the never-written columns (flagged walkers only)

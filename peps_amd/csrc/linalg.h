@@ -295,17 +295,23 @@ __global__ __launch_bounds__(256) void chol_lowrank_kernel(const double *__restr
 // as chol_upper_kernel.  mlive_out[b] = -1 (nothing written) when K > KCAP or the rank exceeds
 // CH_LR_CAP: the Gram GEMM and chol_upper_kernel then run for that walker only (batch_flag /
 // only_flagged).  One 256-thread block per walker; f64 accumulation throughout.
-template <typename T, int KCAP>
-__global__ __launch_bounds__(256, 2) void gram_chol_lowrank_kernel(const T *__restrict__ Pg, long wP, int n,
+// NT threads per walker: with a live inner extent the data columns are packed onto the first threads,
+// so the 128-thread variant (twice as many walkers resident) takes every walker with <= 128 data
+// columns and leaves mlive_out[b] = -2 for the 256-thread variant (retry_only = 1) otherwise.
+template <typename T, int KCAP, int NT>
+__global__ __launch_bounds__(NT, 2) void gram_chol_lowrank_kernel(const T *__restrict__ Pg, long wP, int n,
                                                                 const int *__restrict__ kdyn, int kdyn_mul, int kmax,
                                                                 T *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
-                                                                int inner = 1, const int *__restrict__ inner_live = nullptr) {
+                                                                int inner = 1, const int *__restrict__ inner_live = nullptr,
+                                                                int retry_only = 0) {
+  constexpr int NWV = NT / 64;
+  if (retry_only && mlive_out[blockIdx.x] != -2) return;
   // columns are (outer, inner) with `inner` fastest; inner_live[b] (optional) = live extent of the
   // inner index (live bond of the boundary MPS): columns beyond hold no data and are never read
   __shared__ __attribute__((aligned(16))) T s_pf[KCAP];   // column f of P
   __shared__ double s_rf[CH_LR_CAP];     // column f of the factor
-  __shared__ double s_red[4], s_nrm[CH_LR_CAP], s_part[64];
-  __shared__ int s_first[2][4];
+  __shared__ double s_red[NWV], s_nrm[CH_LR_CAP], s_part[2 * NWV];
+  __shared__ int s_first[2][NWV];
   __shared__ short s_pos[CH_LR_CAP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = kdyn ? min(kmax, kdyn[blockIdx.x] * kdyn_mul) : kmax;
@@ -315,8 +321,15 @@ __global__ __launch_bounds__(256, 2) void gram_chol_lowrank_kernel(const T *__re
   }
   const T *P = Pg + (long)blockIdx.x * wP;
   T *Rout = Rg + (long)blockIdx.x * wR;
-  const int r = tid;
-  const bool col_ok = r < n && (!inner_live || (r % inner) < inner_live[blockIdx.x]);
+  // thread -> column: data columns (inner index below its live extent) packed in increasing order
+  const int ilive = inner_live ? min(inner, inner_live[blockIdx.x]) : inner;
+  const int ncols = (n / inner) * ilive;
+  if (ncols > NT) {
+    if (tid == 0) mlive_out[blockIdx.x] = -2;
+    return;
+  }
+  const bool col_ok = tid < ncols;
+  const int r = col_ok ? (tid / ilive) * inner + (tid % ilive) : n;
   T pc[KCAP];
   double rc[CH_LR_CAP];                   // own column of the factor (f64: pivots near the threshold amplify its rounding)
   double d = 0.0;
@@ -332,7 +345,9 @@ __global__ __launch_bounds__(256, 2) void gram_chol_lowrank_kernel(const T *__re
   for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
   if (lane == 0) s_red[wave] = md;
   __syncthreads();
-  const double maxd = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+  double maxd = s_red[0];
+#pragma unroll
+  for (int q = 1; q < NWV; ++q) maxd = fmax(maxd, s_red[q]);
   const double eT = NOISE_C * (double)Eps<T>::v;
   const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
   int nl = 0, f = -1;
@@ -344,10 +359,15 @@ __global__ __launch_bounds__(256, 2) void gram_chol_lowrank_kernel(const T *__re
     if (lane == 0) s_first[step & 1][wave] = cand;
     __syncthreads();
     // squared norm of the row finished in the previous step (partials written before the barrier)
-    if (tid == 0 && nl > 0)
-      s_nrm[nl - 1] = s_part[4 * ((step + 1) & 1)] + s_part[4 * ((step + 1) & 1) + 1] + s_part[4 * ((step + 1) & 1) + 2] +
-                      s_part[4 * ((step + 1) & 1) + 3];
-    f = min(min(s_first[step & 1][0], s_first[step & 1][1]), min(s_first[step & 1][2], s_first[step & 1][3]));
+    if (tid == 0 && nl > 0) {
+      double a = 0.0;
+#pragma unroll
+      for (int q = 0; q < NWV; ++q) a += s_part[NWV * ((step + 1) & 1) + q];
+      s_nrm[nl - 1] = a;
+    }
+    f = s_first[step & 1][0];
+#pragma unroll
+    for (int q = 1; q < NWV; ++q) f = min(f, s_first[step & 1][q]);
     if (f == 0x7fffffff || nl >= K) break;   // the rank cannot exceed the K rows of P: later pivots are rounding noise
     if (nl == CH_LR_CAP) {                 // rank above the cap: the blocked path redoes this walker
       if (tid == 0) mlive_out[blockIdx.x] = -1;
@@ -392,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void gram_chol_lowrank_kernel(const T *__re
     const double v2 = v * v;
     if (r > f) d -= v2;
     const double a = wave_sum(v2);
-    if (lane == 0) s_part[4 * (step & 1) + wave] = a;
+    if (lane == 0) s_part[NWV * (step & 1) + wave] = a;
     ++nl;
   }
   __syncthreads();
@@ -413,6 +433,21 @@ __global__ __launch_bounds__(256, 2) void gram_chol_lowrank_kernel(const T *__re
       if (pos >= 0 && r < n) Rout[(long)pos * n + r] = T(rc[j] * sc);
     }
   }
+}
+
+// Both variants in sequence: 128 threads per walker where the data columns fit, 256 otherwise.
+template <typename T, int KCAP>
+inline void launch_gram_chol_lowrank(hipStream_t s, int nbatch, const T *P, long wP, int n, const int *kdyn, int kdyn_mul,
+                                     int kmax, T *R, long wR, int *mlive, int inner, const int *inner_live) {
+  static const bool no_narrow = getenv("PEPSGPU_NO_NARROW_FUSED") != nullptr;
+  const bool narrow = !no_narrow && (inner_live != nullptr || n <= 128);
+  if (narrow)
+    hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP, 128>), dim3(nbatch), dim3(128), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
+                       R, wR, mlive, inner, inner_live, 0);
+  if (!narrow || n > 128)
+    hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP, 256>), dim3(nbatch), dim3(256), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
+                       R, wR, mlive, inner, inner_live, narrow ? 1 : 0);
+  PG_CHECK_HIP(hipGetLastError());
 }
 
 // Walkers that gram_chol_lowrank_kernel declined while the block still has fewer rows than columns
