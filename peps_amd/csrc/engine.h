@@ -637,9 +637,16 @@ class Engine : public EngineBase {
   }
   void profile_read(double *out) override {
     prof_resolve();
+    // flops the tensor GEMMs of each category actually contracted (live extents), counted on the device
+    unsigned long long hc[PROF_NCAT] = {0};
+    if (flopc_) {
+      PG_CHECK_HIP(hipMemcpyAsync(hc, flopc_, sizeof(hc), hipMemcpyDeviceToHost, stream_));
+      PG_CHECK_HIP(hipMemsetAsync(flopc_, 0, sizeof(hc), stream_));
+      PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    }
     for (int c = 0; c < PROF_NCAT; ++c) {
       out[4 * c + 0] = prof_ms_[c]; out[4 * c + 1] = (double)prof_n_[c];
-      out[4 * c + 2] = prof_alg_[c]; out[4 * c + 3] = prof_exec_[c];
+      out[4 * c + 2] = prof_alg_[c]; out[4 * c + 3] = hc[c] ? (double)hc[c] : prof_exec_[c];
       prof_ms_[c] = 0; prof_n_[c] = 0; prof_alg_[c] = 0; prof_exec_[c] = 0;
     }
   }
@@ -651,8 +658,14 @@ class Engine : public EngineBase {
     r.cat = cat; r.alg = alg_flops; r.exec = exec_flops;
     PG_CHECK_HIP(hipEventRecord(r.a, stream_));
     prof_.push_back(r);
+    if (!flopc_) {
+      flopc_ = (unsigned long long *)arena_.alloc(sizeof(unsigned long long) * PROF_NCAT);
+      PG_CHECK_HIP(hipMemsetAsync(flopc_, 0, sizeof(unsigned long long) * PROF_NCAT, stream_));
+    }
+    tg_flop_counter = flopc_ + cat;
   }
   void prof_end() {
+    tg_flop_counter = nullptr;
     if (!prof_on_) return;
     PG_CHECK_HIP(hipEventRecord(prof_.back().b, stream_));
   }
@@ -897,6 +910,7 @@ class Engine : public EngineBase {
   double *holes_ls_ = nullptr;            // its log-scales [walker][site]
   double *so_ = nullptr, *seo_ = nullptr; // gradient accumulators
   int *sweeps_ = nullptr;
+  unsigned long long *flopc_ = nullptr;   // device flop counters per profile category
   bool dbg_sweeps_ = false;
 };
 

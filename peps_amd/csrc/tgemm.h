@@ -50,6 +50,8 @@ struct TGemmDesc {
   int accumulate = 0;
   int upper_only = 0;   // symmetric result (Gram): tiles strictly below the diagonal are not computed
   const int *batch_flag = nullptr;   // when set, batch entry b runs only if batch_flag[b] < 0
+  unsigned long long *flopc = nullptr;   // profiling: += 2*I*J*K of the extents actually contracted (per batch entry)
+  int flop_stride = 1;                    // ... sampled: every flop_stride-th batch entry adds flop_stride times its count
   double alpha = 1.0;
 
   __host__ __device__ int Itot() const { return I[0] * I[1] * I[2]; }
@@ -273,6 +275,8 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__res
   int Itot = d.Itot(), Ktot = d.Ktot();
   if (d.dynI) Itot = min(Itot, d.dynI[b] * d.dynI_mul);
   if (d.dynK) Ktot = min(Ktot, d.dynK[b] * d.dynK_mul);
+  if (d.flopc && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && b % d.flop_stride == 0)
+    atomicAdd(d.flopc, (unsigned long long)(d.upper_only ? 1 : 2) * d.flop_stride * Itot * d.Jtot() * Ktot);
   for (int i0 = blockIdx.x * TG_BM; i0 < Itot; i0 += gridDim.x * TG_BM) {   // block-uniform trip count
     if (d.upper_only && (int)(blockIdx.y + 1) * TG_BN <= i0) continue;
     tgemm_tile<TA, TB, TC, TAcc, USE_MFMA>(d, Ag, Bg, Cg, i0, Itot, Ktot);
@@ -311,6 +315,8 @@ __global__ __launch_bounds__(256) void tgemm_direct_kernel(TGemmDesc d, const fl
   if (d.dynI) Itot = min(Itot, d.dynI[b] * d.dynI_mul);
   const int nti = (Itot + 31) >> 5, ntj = (Jtot + 31) >> 5, ntiles = nti * ntj;
   if (ntiles == 0) return;
+  if (d.flopc && threadIdx.x == 0 && blockIdx.x == 0 && b % d.flop_stride == 0)
+    atomicAdd(d.flopc, 2ull * d.flop_stride * Itot * Jtot * d.Ktot());
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   long baseA = (long)(b / d.bdivA) * d.wA, baseB = (long)(b / d.bdivB) * d.wB;
   if (d.selA) baseA += (long)d.selA[(long)(b / d.seldivA) * d.selA_inc] * d.selA_mul;
@@ -387,9 +393,15 @@ __global__ __launch_bounds__(256) void tgemm_direct_kernel(TGemmDesc d, const fl
 
 bool tgemm_use_mfma();
 
+// device counter the launches of the current profiling bracket add their contracted flops to (engine.h prof_begin)
+inline thread_local unsigned long long *tg_flop_counter = nullptr;
+
 template <typename TA, typename TB, typename TC, typename TAcc>
-void tgemm_launch(hipStream_t s, const TGemmDesc &d, const TA *A, const TB *B, TC *C) {
-  if (d.nbatch <= 0 || d.Itot() <= 0 || d.Jtot() <= 0) return;
+void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B, TC *C) {
+  if (d_in.nbatch <= 0 || d_in.Itot() <= 0 || d_in.Jtot() <= 0) return;
+  TGemmDesc d = d_in;
+  d.flopc = tg_flop_counter;
+  d.flop_stride = d.nbatch >= 256 ? 64 : 1;   // one atomic per 64 walkers: a same-address atomic per block costs ~10 %
   int gx = (d.Itot() + TG_BM - 1) / TG_BM;
   const bool dyn_i = d.dynI || (d.dI[0].p && !d.dI[0].mask) || (d.dI[1].p && !d.dI[1].mask) || (d.dI[2].p && !d.dI[2].mask);
   if (dyn_i && gx > TG_DYN_GRIDX) gx = TG_DYN_GRIDX;
