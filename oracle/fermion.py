@@ -1,0 +1,192 @@
+"""Fermionic (fZ2-graded) PEPS through the bosonic boundary-MPS machinery -- TEST INFRASTRUCTURE ONLY.
+
+Result used by the product (peps_amd/fermion.py, host layer) and proven here against the graded
+algebra of oracle/graded.py (tests/test_oracle_fermion.py):
+
+  With the parity legs ordered row-major, the graded contraction of the projected network equals an
+  ORDINARY contraction of sign-decorated site tensors times a sign that depends on the particle number only:
+
+      <S|Psi>_row = sigma(N_f) * Contract_dense( T_v[s_v] * (-1)^{u * (number of fermions at sites <= v, row-major)} )
+      sigma(N_f) = (-1)^{N_f + N_f (N_f - 1) / 2}
+
+  (u = parity of the U-leg index).  Derivation: move every parity leg to the front (cost: sigma), order the
+  legs of each tensor (L, U, D, R) so that horizontal bonds are adjacent [OUT][IN] pairs, contract rows
+  top-down; the evenness of every tensor turns the Koszul signs of the vertical bonds into
+  (-1)^{u (1 + l + J_v)} with J_v the Jordan-Wigner prefix parity, and the leg reordering (-1)^{u (d + r)}
+  combines with it to (-1)^{u (J_v + n_v)}.  For the parity legs in COLUMN-major order the same argument
+  (roles of rows and columns exchanged) gives the decoration
+      (-1)^{u n + u + d r + l + l u + l J_v},   J_v = number of fermions before v in column-major order.
+
+  A nearest-neighbour hop along a row (column) joins two modes that are adjacent in the row-major
+  (column-major) order, so its Jordan-Wigner sign is +1 and it changes the decoration of its two sites only:
+  every BMPS environment stays valid, and the reference's flow (horizontal bonds in the row pass, vertical
+  bonds in the column pass, psi and psi' along the same path: docs/dev/design/math/
+  fermion-sign-in-bmps-contraction.md) carries over with one ordinary (bosonic) contraction per pass.
+
+Physical states: 0 = occupied (odd), 1 = empty (even) (square_spinless_fermion.h:35-37).
+Extended state of a site = s + d * variant, variant 0/1 = row-major decoration with even/odd inclusive prefix,
+2/3 = column-major decoration with J_v = 0/1.
+"""
+import numpy as np
+
+from . import vmc
+from .graded import GT, load_qlten_z2
+
+ROW, COL = 0, 1
+NVAR = 4
+
+
+def load_fermion_sitps(directory, complex_data=False):
+    import os
+    with open(os.path.join(directory, "tps_meta.txt")) as f:
+        toks = f.read().split()
+    rows, cols, d = int(toks[0]), int(toks[1]), int(toks[2])
+    return [[[load_qlten_z2(os.path.join(directory, "tps_ten%d_%d_%d.qlten" % (r, c, s)), complex_data)
+              for s in range(d)] for c in range(cols)] for r in range(rows)]
+
+
+class FermionSITPS:
+    """dense, sign-decorated view of a graded SplitIndexTPS"""
+
+    def __init__(self, gts):
+        self.rows, self.cols, self.d = len(gts), len(gts[0]), len(gts[0][0])
+        self.gts = gts
+        self.nf = [int(gts[0][0][s].par[4][0]) for s in range(self.d)]     # fermion parity of each physical state
+        self.par = [[tuple(gts[r][c][0].par[k] for k in range(4)) for c in range(self.cols)] for r in range(self.rows)]
+        self.ext = [[self._decorate(r, c) for c in range(self.cols)] for r in range(self.rows)]
+
+    def _decorate(self, r, c):
+        pl, pd, pr, pu = self.par[r][c]
+        l = pl[:, None, None, None]; dd = pd[None, :, None, None]; rr = pr[None, None, :, None]; u = pu[None, None, None, :]
+        out = [None] * (NVAR * self.d)
+        for s in range(self.d):
+            t = self.gts[r][c][s]
+            assert t.is_even() and tuple(t.dirs) == (-1, 1, 1, -1, -1)
+            for k in range(4):
+                assert np.array_equal(t.par[k], self.par[r][c][k])
+            a = t.arr[..., 0]
+            n = self.nf[s]
+            out[s] = a
+            out[s + self.d] = a * (1 - 2 * (u % 2))
+            base = (u * n + u + dd * rr + l + l * u) % 2
+            out[s + 2 * self.d] = a * (1 - 2 * base)
+            out[s + 3 * self.d] = a * (1 - 2 * ((base + l) % 2))
+        return out
+
+    def ext_config(self, cfg, order):
+        cfg = np.asarray(cfg)
+        occ = np.array(self.nf)[cfg]                       # fermion number parity per site
+        ext = np.zeros_like(cfg)
+        if order == ROW:
+            incl = np.cumsum(occ.ravel()).reshape(cfg.shape) % 2
+            ext = cfg + self.d * incl
+        else:
+            flat = occ.T.ravel()                             # column-major
+            before = (np.cumsum(flat) - flat) % 2
+            ext = cfg + self.d * (2 + before.reshape(cfg.shape[::-1]).T)
+        return ext
+
+    def sigma(self, cfg):
+        nf = int(np.sum(np.array(self.nf)[np.asarray(cfg)]))
+        return (-1) ** (nf + nf * (nf - 1) // 2)
+
+    def kappa(self, cfg):
+        """sign of reordering the occupied modes from row-major to column-major order"""
+        occ = np.array(self.nf)[np.asarray(cfg)]
+        pos = [(c, r) for r in range(self.rows) for c in range(self.cols) if occ[r, c] % 2]   # row-major list, col-major keys
+        inv = sum(1 for i in range(len(pos)) for j in range(i + 1, len(pos)) if pos[i] > pos[j])
+        return (-1) ** inv
+
+    def component(self, cfg, order, trun_para):
+        return vmc.TPSWaveFunctionComponent(self.ext, self.ext_config(cfg, order), trun_para)
+
+    def amplitude(self, cfg, trun_para, order=ROW):
+        """<S|Psi> with the parity legs in row-major (ROW) or column-major (COL) order"""
+        return self.sigma(cfg) * self.component(cfg, order, trun_para).amplitude
+
+
+class SquareSpinlessFermionOBC:
+    """square_spinless_fermion.h:51-200: H = -t sum_<ij> (c+_i c_j + h.c.) - t2 sum_<<ij>> (...) + V sum_<ij> n_i n_j.
+    NN ratios come from ReplaceNNSiteTrace along the pass that keeps the hop local; the NNN hop is not local in
+    the decorated form and is evaluated from a fresh amplitude (only the 2x2 known answers need t2 != 0)."""
+
+    def __init__(self, t, t2=0.0, V=0.0):
+        self.t, self.t2, self.V = t, t2, V
+
+    def CalEnergy(self, fs, cfg, trun_para):
+        from .bmps import LEFT, DOWN, RIGHT, UP, HORIZONTAL, VERTICAL
+        cfg = np.asarray(cfg)
+        rows, cols, d = fs.rows, fs.cols, fs.d
+        occ = np.array(fs.nf)[cfg]
+        e = 0.0
+        psis = []
+        # ---- row pass: horizontal bonds (square_nnn_energy_solver.h:116-201)
+        comp = fs.component(cfg, ROW, trun_para)
+        tn, c = comp.tn, comp.contractor
+        ext = comp.config
+        c.GenerateBMPSApproach(tn, UP)
+        for row in range(rows):
+            c.InitBTen(tn, LEFT, row)
+            c.GrowFullBTen(tn, RIGHT, row, 1, True)
+            psis.append(c.Trace(tn, (row, 0), HORIZONTAL))
+            for col in range(cols - 1):
+                s1, s2 = (row, col), (row, col + 1)
+                e += self.V * occ[s1] * occ[s2]
+                if cfg[s1] != cfg[s2]:
+                    psi = c.Trace(tn, s1, HORIZONTAL)
+                    new = cfg.copy(); new[s1], new[s2] = cfg[s2], cfg[s1]
+                    ne = fs.ext_config(new, ROW)
+                    psi_ex = c.ReplaceNNSiteTrace(tn, s1, s2, HORIZONTAL, fs.ext[row][col][ne[s1]], fs.ext[row][col + 1][ne[s2]])
+                    e += -self.t * np.conj(psi_ex / psi)
+                c.ShiftBTenWindow(tn, RIGHT) if col < cols - 2 or True else None
+            if row < rows - 1:
+                c.ShiftBMPSWindow(tn, DOWN)
+        # ---- column pass: vertical bonds (bond_traversal_mixin.h:113-144)
+        comp = fs.component(cfg, COL, trun_para)
+        tn, c = comp.tn, comp.contractor
+        c.GenerateBMPSApproach(tn, LEFT)
+        for col in range(cols):
+            c.InitBTen(tn, UP, col)
+            c.GrowFullBTen(tn, DOWN, col, 2, True)
+            psis.append(c.Trace(tn, (0, col), VERTICAL))
+            for row in range(rows - 1):
+                s1, s2 = (row, col), (row + 1, col)
+                e += self.V * occ[s1] * occ[s2]
+                if cfg[s1] != cfg[s2]:
+                    psi = c.Trace(tn, s1, VERTICAL)
+                    new = cfg.copy(); new[s1], new[s2] = cfg[s2], cfg[s1]
+                    ne = fs.ext_config(new, COL)
+                    psi_ex = c.ReplaceNNSiteTrace(tn, s1, s2, VERTICAL, fs.ext[row][col][ne[s1]], fs.ext[row + 1][col][ne[s2]])
+                    e += -self.t * np.conj(psi_ex / psi)
+                if row < rows - 2:
+                    c.ShiftBTenWindow(tn, DOWN)
+            if col < cols - 1:
+                c.ShiftBMPSWindow(tn, RIGHT)
+        # ---- NNN hops (t2): Jordan-Wigner string in row-major order, fresh amplitudes
+        if self.t2 != 0.0:
+            psi0 = fs.amplitude(cfg, trun_para)
+            flat = occ.ravel()
+            for row in range(rows - 1):
+                for col in range(cols - 1):
+                    for (a, b) in (((row, col), (row + 1, col + 1)), ((row + 1, col), (row, col + 1))):
+                        if cfg[a] == cfg[b]:
+                            continue
+                        ia, ib = sorted((a[0] * cols + a[1], b[0] * cols + b[1]))
+                        jw = (-1) ** int(np.sum(flat[ia + 1:ib]))
+                        new = cfg.copy(); new[a], new[b] = cfg[b], cfg[a]
+                        e += -self.t2 * jw * np.conj(fs.amplitude(new, trun_para) / psi0)
+        return e, psis
+
+
+def exact_sum_energy(fs, all_configs, trun_para, model):
+    """ExactSumEnergyEvaluatorMPI (exact_summation_energy_evaluator.h:173-302), energy only"""
+    wsum = wesum = 0.0
+    for cfg in all_configs:
+        amp = fs.amplitude(cfg, trun_para)
+        if amp == 0:
+            continue
+        e, _ = model.CalEnergy(fs, cfg, trun_para)
+        w = abs(amp) ** 2
+        wsum += w
+        wesum += w * e
+    return wesum / wsum

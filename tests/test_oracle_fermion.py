@@ -1,0 +1,103 @@
+"""Fermionic (fZ2-graded) path of the oracle, pinned on the reference's own known answers
+(tests/test_algorithm/test_exact_summation_evaluator.cpp:130-150,268-470): 2x2 spinless fermions at half
+filling, t2 in {2.1, 0, -2.5}, 'lowest' states (exact free-fermion energies) and simple-update states
+(golden energies :432-436)."""
+import itertools
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fermion, graded
+from oracle.bmps import BMPSTruncateParams
+from oracle.graded import GT
+
+CASES = [(2.1, "2.100000", -4.2, -4.1879072654), (0.0, "0.000000", -2.0, -1.98218053854),
+         (-2.5, "-2.500000", -5.0, -4.98966397657)]
+
+
+def _half_filling_configs():
+    return [np.array(p).reshape(2, 2) for p in sorted(set(itertools.permutations([0, 0, 1, 1])))]
+
+
+def _dense_energy(gts, t, t2):
+    """<Psi|H|Psi>/<Psi|Psi> in the Fock basis ordered like the parity legs (row-major), amplitudes from the
+    full graded contraction -- no boundary MPS, no decoration."""
+    sites = [(0, 0), (0, 1), (1, 0), (1, 1)]
+    cfgs = []
+    for occ in itertools.combinations(range(4), 2):
+        c = np.ones((2, 2), dtype=int)
+        for o in occ:
+            c[sites[o]] = 0
+        cfgs.append((occ, c))
+    psi = np.array([graded.graded_amplitude_exact(gts, c) for _, c in cfgs])
+    idx = {occ: i for i, (occ, _) in enumerate(cfgs)}
+    H = np.zeros((6, 6))
+    for i, (occ, _) in enumerate(cfgs):
+        for a, b, amp in [(0, 1, t), (2, 3, t), (0, 2, t), (1, 3, t), (0, 3, t2), (1, 2, t2)]:
+            for src, dst in ((a, b), (b, a)):
+                if src in occ and dst not in occ:
+                    lst = list(occ)
+                    pos = lst.index(src)
+                    s = (-1) ** pos
+                    lst.pop(pos)
+                    s *= (-1) ** sum(1 for x in lst if x < dst)
+                    H[idx[tuple(sorted(lst + [dst]))], i] += -amp * s
+    return psi @ H @ psi / (psi @ psi)
+
+
+@pytest.mark.parametrize("t2,name,e_lowest,e_su", CASES)
+def test_graded_conventions_reproduce_reference_energies(fixtures_dir, t2, name, e_lowest, e_su):
+    for suffix, ref, tol in (("lowest", e_lowest, 1e-9), ("_from_simple_update", e_su, 1e-9)):
+        gts = fermion.load_fermion_sitps(os.path.join(fixtures_dir, "spinless_fermion_tps_t2_%s_double%s" % (name, suffix)))
+        assert abs(_dense_energy(gts, 1.0, t2) - ref) < tol
+
+
+@pytest.mark.parametrize("t2,name,e_lowest,e_su", CASES)
+def test_decorated_bmps_path_reproduces_reference_energies(fixtures_dir, t2, name, e_lowest, e_su):
+    """the product formulation: sign-decorated dense tensors through the bosonic BMPS contractor, NN hops from
+    ReplaceNNSiteTrace in the row / column pass, SVD(8, 8) as the reference test"""
+    tp = BMPSTruncateParams.SVD(8, 8, 0.0)
+    for suffix, ref in (("lowest", e_lowest), ("_from_simple_update", e_su)):
+        gts = fermion.load_fermion_sitps(os.path.join(fixtures_dir, "spinless_fermion_tps_t2_%s_double%s" % (name, suffix)))
+        fs = fermion.FermionSITPS(gts)
+        e = fermion.exact_sum_energy(fs, _half_filling_configs(), tp, fermion.SquareSpinlessFermionOBC(1.0, t2, 0.0))
+        assert abs(e - ref) < 1e-9
+
+
+def _random_even_network(Ly, Lx, D, rng):
+    hp = [[np.array([0]) if c in (0, Lx) else np.r_[0, rng.integers(0, 2, D - 2), 1] for c in range(Lx + 1)] for r in range(Ly)]
+    vp = [[np.array([0]) if r in (0, Ly) else np.r_[0, rng.integers(0, 2, D - 2), 1] for c in range(Lx)] for r in range(Ly + 1)]
+    sit = [[None] * Lx for _ in range(Ly)]
+    for r in range(Ly):
+        for c in range(Lx):
+            comp = []
+            for n in (1, 0):          # state 0 occupied (odd), state 1 empty (even)
+                par = [hp[r][c], vp[r + 1][c], hp[r][c + 1], vp[r][c], np.array([n])]
+                tot = (par[0][:, None, None, None, None] + par[1][None, :, None, None, None] + par[2][None, None, :, None, None]
+                       + par[3][None, None, None, :, None] + n) % 2
+                comp.append(GT(rng.standard_normal(tot.shape) * (tot == 0), par, [-1, 1, 1, -1, -1]))
+            sit[r][c] = comp
+    return sit
+
+
+@pytest.mark.parametrize("Ly,Lx,D", [(2, 3, 3), (3, 3, 3), (3, 4, 2)])
+def test_decorated_dense_contraction_equals_graded_contraction(Ly, Lx, D):
+    """<S|Psi> of the graded network (oracle/graded.py) == sigma(N_f) x ordinary contraction of the decorated
+    tensors, for EVERY configuration, parity legs in row-major and in column-major order."""
+    rng = np.random.default_rng(100 * Ly + 10 * Lx + D)
+    gts = _random_even_network(Ly, Lx, D, rng)
+    fs = fermion.FermionSITPS(gts)
+    tp = BMPSTruncateParams.SVD(64, 64, 0.0)          # exact at these sizes
+    n_nonzero = 0
+    for bits in itertools.product((0, 1), repeat=Ly * Lx):
+        cfg = np.array(bits).reshape(Ly, Lx)
+        g = graded.graded_amplitude_exact(gts, cfg)
+        if sum(1 - b for b in bits) % 2 == 1:
+            assert abs(g) < 1e-12                      # odd total parity: the network vanishes
+            continue
+        n_nonzero += 1
+        scale = max(1.0, abs(g))
+        assert abs(fs.amplitude(cfg, tp, fermion.ROW) - g) < 1e-9 * scale
+        assert abs(fs.amplitude(cfg, tp, fermion.COL) - fs.kappa(cfg) * g) < 1e-9 * scale
+    assert n_nonzero == 2 ** (Ly * Lx - 1)
