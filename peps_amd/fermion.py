@@ -1,0 +1,246 @@
+"""Fermionic (fZ2-graded) SplitIndexTPS on the bosonic device path.
+
+The graded contraction of a projected fermionic PEPS equals an ordinary contraction of sign-decorated site
+tensors times a sign that depends on the particle number only (statement and proof obligations:
+oracle/fermion.py, tests/test_oracle_fermion.py -- this module restates the construction for the product
+path and never imports the oracle):
+
+    <S|Psi>_row = sigma(N_f) * Contract( T_v[s_v] * (-1)^{u * (fermions at sites <= v, row-major)} )
+    column-major order:       decoration (-1)^{u n + u + d r + l + l u + l J_v}
+
+so a fermionic state is uploaded as a SplitIndexTPS with 4*d "extended" components per site
+(extended state = s + d * variant; variants 0/1 row-major even/odd, 2/3 column-major J = 0/1) and every
+fermionic sign becomes a choice of component, i.e. an entry of the configuration table the device already
+indexes the shared SITPS with.  Nearest-neighbour hops along a row (column) are adjacent in the row-major
+(column-major) mode order: Jordan-Wigner sign +1, only the two sites' components change, all BMPS / BTen
+environments stay valid -- the reference's flow (horizontal bonds in the row pass, vertical bonds in the
+column pass, psi and psi' along the same path; square_nnn_energy_solver.h:116-201,
+bond_traversal_mixin.h:113-144, square_spinless_fermion.h:134-159) runs unchanged.
+
+Physical states: 0 = occupied (odd), 1 = empty (even) (square_spinless_fermion.h:35-37).
+"""
+import os
+
+import numpy as np
+
+ROW, COL = 0, 1
+NVAR = 4
+
+
+def _read_qlten_z2(path):
+    """one fZ2 .qlten file -> (dense array, [parity vector per leg], [direction per leg]); format: SURVEY 8c"""
+    with open(path, "rb") as f:
+        buf = f.read()
+    pos = 0
+
+    def tok():
+        nonlocal pos
+        e = buf.index(b"\n", pos)
+        t = buf[pos:e]
+        pos = e + 1
+        return t
+
+    rank = int(tok())
+    legs = []
+    for _ in range(rank):
+        nsec = int(tok())
+        secs = []
+        for _s in range(nsec):
+            qn = int(tok()); tok(); deg = int(tok()); tok()
+            secs.append((qn, deg))
+        d = int(tok()); dim = int(tok()); tok()
+        if sum(x[1] for x in secs) != dim:
+            raise ValueError("corrupt index in %s" % path)
+        legs.append((secs, d))
+    nblocks = int(tok())
+    blocks = [[int(tok()) for _ in range(rank)] for _ in range(nblocks)]
+    shape = tuple(sum(s[1] for s in secs) for secs, _ in legs)
+    out = np.zeros(shape, dtype=np.float64)
+    offs = [np.concatenate([[0], np.cumsum([s[1] for s in secs])]) for secs, _ in legs]
+    for c in blocks:
+        bshape = tuple(legs[k][0][c[k]][1] for k in range(rank))
+        n = int(np.prod(bshape))
+        data = np.frombuffer(buf, dtype="<f8", count=n, offset=pos)
+        pos += n * 8
+        out[tuple(slice(offs[k][c[k]], offs[k][c[k] + 1]) for k in range(rank))] = data.reshape(bshape)
+    par = [np.concatenate([np.full(deg, qn % 2, dtype=np.int64) for qn, deg in secs]) for secs, _ in legs]
+    return out, par, [d for _, d in legs]
+
+
+class FermionState:
+    """tensors[r][c][s] = dense array (L, D, R, U); par[r][c] = 4 parity vectors; nf[s] = fermion parity of state s"""
+
+    def __init__(self, tensors, par, nf):
+        self.tensors, self.par, self.nf = tensors, par, np.asarray(nf, dtype=np.int64)
+        self.rows, self.cols, self.d = len(tensors), len(tensors[0]), len(tensors[0][0])
+        for r in range(self.rows):
+            for c in range(self.cols):
+                pl, pd, pr, pu = self.par[r][c]
+                tot = pl[:, None, None, None] + pd[None, :, None, None] + pr[None, None, :, None] + pu[None, None, None, :]
+                for s in range(self.d):
+                    if np.any((np.abs(self.tensors[r][c][s]) > 0) & ((tot + self.nf[s]) % 2 == 1)):
+                        raise ValueError("site tensor (%d, %d, state %d) is not parity even" % (r, c, s))
+
+    @staticmethod
+    def load(directory):
+        """SplitIndexTPS<.., fZ2QN>::Load layout: tps_meta.txt + tps_ten{r}_{c}_{s}.qlten, rank-5 tensors (L, D, R, U, parity)"""
+        with open(os.path.join(directory, "tps_meta.txt")) as f:
+            toks = f.read().split()
+        rows, cols, d = int(toks[0]), int(toks[1]), int(toks[2])
+        tensors, par, nf = [[None] * cols for _ in range(rows)], [[None] * cols for _ in range(rows)], [None] * d
+        for r in range(rows):
+            for c in range(cols):
+                comp = []
+                for s in range(d):
+                    a, p, dirs = _read_qlten_z2(os.path.join(directory, "tps_ten%d_%d_%d.qlten" % (r, c, s)))
+                    if a.ndim != 5 or tuple(dirs) != (-1, 1, 1, -1, -1) or a.shape[4] != 1:
+                        raise ValueError("expected rank-5 fermionic site tensors (L, D, R, U, parity)")
+                    if par[r][c] is None:
+                        par[r][c] = tuple(p[:4])
+                    elif any(not np.array_equal(par[r][c][k], p[k]) for k in range(4)):
+                        raise ValueError("components of one site disagree on the parity structure of a bond")
+                    if nf[s] is None:
+                        nf[s] = int(p[4][0])
+                    comp.append(a[..., 0])
+                tensors[r][c] = comp
+        return FermionState(tensors, par, nf)
+
+    @property
+    def D(self):
+        return max(max(t[0].shape) for row in self.tensors for t in row)
+
+    def extended_flat(self, D=None, dtype=np.float64):
+        """upload buffer [row][col][4 d][D][D][D][D] of the decorated components (legs zero padded to D)"""
+        D = D or self.D
+        out = np.zeros((self.rows, self.cols, NVAR * self.d, D, D, D, D), dtype=dtype)
+        for r in range(self.rows):
+            for c in range(self.cols):
+                pl, pd, pr, pu = self.par[r][c]
+                l = pl[:, None, None, None]; dd = pd[None, :, None, None]; rr = pr[None, None, :, None]; u = pu[None, None, None, :]
+                for s in range(self.d):
+                    a = self.tensors[r][c][s]
+                    n = int(self.nf[s])
+                    base = (u * n + u + dd * rr + l + l * u) % 2
+                    sl = (r, c, slice(None)) + tuple(slice(0, k) for k in a.shape)
+                    for var, sign in enumerate((np.ones_like(a), 1 - 2 * (u % 2) + 0 * a, 1 - 2 * base + 0 * a,
+                                                1 - 2 * ((base + l) % 2) + 0 * a)):
+                        out[(r, c, s + self.d * var) + tuple(slice(0, k) for k in a.shape)] = a * sign
+        return out
+
+    def ext_config(self, configs, order):
+        """configs [..., rows, cols] of physical states -> extended states for the given mode order"""
+        cfg = np.asarray(configs)
+        occ = self.nf[cfg] % 2
+        shp = cfg.shape
+        if order == ROW:
+            flat = occ.reshape(shp[:-2] + (-1,))
+            incl = np.cumsum(flat, axis=-1) % 2
+            return (cfg + self.d * incl.reshape(shp)).astype(np.int32)
+        flat = np.swapaxes(occ, -1, -2).reshape(shp[:-2] + (-1,))
+        before = (np.cumsum(flat, axis=-1) - flat) % 2
+        before = np.swapaxes(before.reshape(shp[:-2] + (shp[-1], shp[-2])), -1, -2)
+        return (cfg + self.d * (2 + before)).astype(np.int32)
+
+    def sigma(self, configs):
+        nf = np.sum(self.nf[np.asarray(configs)] % 2, axis=(-1, -2))
+        return 1 - 2 * ((nf + nf * (nf - 1) // 2) % 2)
+
+    def kappa(self, configs):
+        """sign of reordering the occupied modes from row-major to column-major order (per configuration)"""
+        cfg = np.asarray(configs)
+        occ = self.nf[cfg] % 2
+        lead = cfg.shape[:-2]
+        out = np.ones(lead, dtype=np.int64)
+        for ix in np.ndindex(*lead):
+            o = occ[ix]
+            keys = [(c, r) for r in range(self.rows) for c in range(self.cols) if o[r, c]]
+            inv = sum(1 for i in range(len(keys)) for j in range(i + 1, len(keys)) if keys[i] > keys[j])
+            out[ix] = 1 - 2 * (inv % 2)
+        return out
+
+
+def evaluate_amplitude(ctx, state, configs):
+    """<S|Psi> (parity legs in row-major order) for a batch of physical configurations; ctx must hold
+    state.extended_flat() (phys_dim = 4 d)."""
+    ctx.set_configs(state.ext_config(configs, ROW))
+    return state.sigma(configs) * ctx.evaluate_amplitude()
+
+
+def spinless_fermion_energy(ctx, state, configs, t, V=0.0):
+    """E_loc(S) of H = -t sum_<ij> (c+_i c_j + h.c.) + V sum_<ij> n_i n_j for every configuration of the batch
+    (square_spinless_fermion.h:134-159 inside the traversal of square_nnn_energy_solver.h:116-201 and
+    bond_traversal_mixin.h:113-144; the NNN pass of the reference multiplies by t2, which must be 0 here).
+    Returns (energy [n], psi_list [rows + cols][n])."""
+    from .capi import LEFT, DOWN, RIGHT, UP, HORIZONTAL, VERTICAL
+    cfg = np.asarray(configs)
+    n, rows, cols = cfg.shape
+    occ = (state.nf[cfg] % 2).astype(np.float64)
+    e = np.zeros(n)
+    psis = []
+
+    def bond(s1, s2, orient, order, ext):
+        (r1, c1), (r2, c2) = s1, s2
+        e_int = V * occ[:, r1, c1] * occ[:, r2, c2]
+        differ = cfg[:, r1, c1] != cfg[:, r2, c2]
+        if not differ.any():
+            return e_int
+        psi = ctx.trace(r1, c1, orient)                       # psi along the same path as psi' (sign consistency)
+        new = cfg.copy()
+        new[:, r1, c1], new[:, r2, c2] = cfg[:, r2, c2], cfg[:, r1, c1]
+        ne = state.ext_config(new, order)
+        cand = np.stack([ne[:, r1, c1], ne[:, r2, c2]], axis=-1)[:, None, :]
+        psi_ex = ctx.replace_nn_trace(r1, c1, orient, cand)[:, 0]
+        return e_int + np.where(differ, -t * psi_ex / np.where(psi == 0, 1.0, psi), 0.0)
+
+    ext = state.ext_config(cfg, ROW)
+    ctx.set_configs(ext)
+    ctx.generate_bmps_approach(UP)
+    for row in range(rows):
+        ctx.init_bten(LEFT, row)
+        ctx.grow_full_bten(RIGHT, row, 1, True)
+        psis.append(ctx.trace(row, 0, HORIZONTAL))
+        for col in range(cols - 1):
+            e += bond((row, col), (row, col + 1), HORIZONTAL, ROW, ext)
+            ctx.shift_bten_window(RIGHT)
+        if row < rows - 1:
+            ctx.shift_bmps_window(DOWN)
+    ext = state.ext_config(cfg, COL)
+    ctx.set_configs(ext)
+    ctx.generate_bmps_approach(LEFT)
+    for col in range(cols):
+        ctx.init_bten(UP, col)
+        ctx.grow_full_bten(DOWN, col, 2, True)
+        psis.append(ctx.trace(0, col, VERTICAL))
+        for row in range(rows - 1):
+            e += bond((row, col), (row + 1, col), VERTICAL, COL, ext)
+            if row < rows - 2:
+                ctx.shift_bten_window(DOWN)
+        if col < cols - 1:
+            ctx.shift_bmps_window(RIGHT)
+    return e, np.array(psis)
+
+
+def random_even_state(rows, cols, D, seed, n_odd=None, background=1.0, noise=0.1):
+    """synthetic fermionic state for throughput / parity runs (the reference ships no fermionic state larger
+    than 2x2): bond space = D states of which n_odd (default D // 2) are odd, site tensors N(0,1) on the
+    parity-even entries plus a positive background on the all-even entry; state 0 occupied, 1 empty."""
+    rng = np.random.default_rng(seed)
+    n_odd = D // 2 if n_odd is None else n_odd
+    bond = np.r_[np.zeros(D - n_odd, dtype=np.int64), np.ones(n_odd, dtype=np.int64)]
+    one = np.zeros(1, dtype=np.int64)
+    tensors, par = [[None] * cols for _ in range(rows)], [[None] * cols for _ in range(rows)]
+    for r in range(rows):
+        for c in range(cols):
+            p = (one if c == 0 else bond, one if r == rows - 1 else bond, one if c == cols - 1 else bond, one if r == 0 else bond)
+            par[r][c] = p
+            tot = p[0][:, None, None, None] + p[1][None, :, None, None] + p[2][None, None, :, None] + p[3][None, None, None, :]
+            comp = []
+            for s, n in enumerate((1, 0)):
+                # smooth positive background on the parity-allowed entries + noise (as the bosonic generator of
+                # SURVEY 8d): keeps the network well conditioned so that chi-truncation is meaningful
+                vec = [rng.uniform(0.5, 1.5, size=k) for k in tot.shape]
+                bg = vec[0][:, None, None, None] * vec[1][None, :, None, None] * vec[2][None, None, :, None] * vec[3][None, None, None, :]
+                a = (background * bg + noise * rng.standard_normal(tot.shape)) * ((tot + n) % 2 == 0)
+                comp.append(a / np.sqrt(max(1.0, np.sum(a * a))) * 2.0)
+            tensors[r][c] = comp
+    return FermionState(tensors, par, [1, 0])

@@ -1,0 +1,120 @@
+"""Fermionic (fZ2-graded) states on the device: sign-decorated components through the unchanged bosonic
+engine (peps_amd/fermion.py), against the graded oracle (oracle/graded.py, oracle/fermion.py) and the
+reference's 2x2 spinless-fermion known answers; BASELINE config C5 (8x8 spinless t-V, D=6, chi=24)."""
+import itertools
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fermion as ofermion, graded
+from oracle.bmps import BMPSTruncateParams
+from oracle.graded import GT
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(state, chi, dtype, n):
+    from peps_amd import capi
+    D = state.D
+    ctx = capi.Context(state.rows, state.cols, D, 4 * state.d, chi, dtype=dtype, max_walkers=n)
+    ctx.state_upload(state.extended_flat(D))
+    return ctx
+
+
+def _oracle_view(state):
+    gts = [[[GT(state.tensors[r][c][s][..., None], list(state.par[r][c]) + [np.array([int(state.nf[s])])], [-1, 1, 1, -1, -1])
+             for s in range(state.d)] for c in range(state.cols)] for r in range(state.rows)]
+    return gts, ofermion.FermionSITPS(gts)
+
+
+def _half_filling_configs():
+    return np.array([np.array(p).reshape(2, 2) for p in sorted(set(itertools.permutations([0, 0, 1, 1])))])
+
+
+@pytest.mark.parametrize("name,t2,e_ref", [("0.000000_doublelowest", 0.0, -2.0), ("0.000000_double_from_simple_update", 0.0, -1.98218053854)])
+def test_k4_spinless_fermion_exact_sum_on_device(fixtures_dir, name, t2, e_ref):
+    """reference known answers (test_exact_summation_evaluator.cpp:353-470, t2 = 0): exact summation over the six
+    half-filling configurations with amplitudes and hop ratios from the device (f64)."""
+    from peps_amd import capi, fermion
+    st = fermion.FermionState.load(os.path.join(fixtures_dir, "spinless_fermion_tps_t2_" + name))
+    cfgs = _half_filling_configs()
+    ctx = _ctx(st, 8, capi.F64, len(cfgs))
+    amp = fermion.evaluate_amplitude(ctx, st, cfgs)
+    e_loc, _ = fermion.spinless_fermion_energy(ctx, st, cfgs, 1.0, 0.0)
+    w = amp ** 2
+    assert abs(np.sum(w * e_loc) / np.sum(w) - e_ref) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["2.100000_double_from_simple_update", "-2.500000_doublelowest"])
+def test_k4_amplitudes_match_graded_contraction(fixtures_dir, name):
+    """device amplitudes (row- and column-major mode order) == full graded contraction, t2 != 0 fixtures"""
+    from peps_amd import capi, fermion
+    d = os.path.join(fixtures_dir, "spinless_fermion_tps_t2_" + name)
+    st = fermion.FermionState.load(d)
+    gts = ofermion.load_fermion_sitps(d)
+    cfgs = _half_filling_configs()
+    ctx = _ctx(st, 8, capi.F64, len(cfgs))
+    amp = fermion.evaluate_amplitude(ctx, st, cfgs)
+    ctx.set_configs(st.ext_config(cfgs, fermion.COL))
+    amp_col = st.sigma(cfgs) * ctx.evaluate_amplitude()
+    for k, cfg in enumerate(cfgs):
+        g = graded.graded_amplitude_exact(gts, cfg)
+        assert abs(amp[k] - g) < 1e-10 * max(1.0, abs(g))
+        assert abs(amp_col[k] - st.kappa(cfg) * g) < 1e-10 * max(1.0, abs(g))
+
+
+@pytest.mark.parametrize("dt,tol", [("f64", 1e-9), ("f32", 2e-5)])
+def test_random_even_state_amplitude_and_energy(dt, tol):
+    """4x4, D=4, chi=16 synthetic fermionic state: amplitudes and t-V local energies of random configurations
+    (any filling) against the oracle; psi identical along every row / column route up to the kappa sign."""
+    from peps_amd import capi, fermion
+    st = fermion.random_even_state(4, 4, 4, seed=3)
+    _, fs = _oracle_view(st)
+    rng = np.random.default_rng(5)
+    cfgs = rng.integers(0, 2, size=(6, 4, 4))
+    cfgs[(4 * 4 - cfgs.sum(axis=(1, 2))) % 2 == 1, 0, 0] ^= 1        # even particle number: non-vanishing amplitude
+    tp = BMPSTruncateParams.SVD(16, 16, 0.0)
+    ctx = _ctx(st, 16, capi.F32 if dt == "f32" else capi.F64, len(cfgs))
+    amp = fermion.evaluate_amplitude(ctx, st, cfgs)
+    e_loc, psis = fermion.spinless_fermion_energy(ctx, st, cfgs, 1.0, 0.7)
+    model = ofermion.SquareSpinlessFermionOBC(1.0, 0.0, 0.7)
+    for k, cfg in enumerate(cfgs):
+        a = fs.amplitude(cfg, tp)
+        assert abs(amp[k] / a - 1) < tol
+        e, _ = model.CalEnergy(fs, cfg, tp)
+        assert abs(e_loc[k] - e) < tol * 10 * max(1.0, abs(e))
+        sig, kap = st.sigma(cfg), st.kappa(cfg)
+        assert np.max(np.abs(sig * psis[:4, k] / a - 1)) < tol * 10          # row routes
+        assert np.max(np.abs(sig * kap * psis[4:, k] / a - 1)) < tol * 10    # column routes (column-major mode order)
+
+
+@pytest.mark.parametrize("dt,tol_amp,tol_e", [("f64", 5e-7, 2e-6), ("f32", 1e-4, 1e-3)])
+def test_c5_spinless_tV_8x8_d6_chi24(dt, tol_amp, tol_e):
+    """BASELINE config C5: 8x8 spinless-fermion t-V, Z2-graded tensors, D=6, chi=24: amplitude and local energy
+    against the f64 oracle at the full size.  Fermionic amplitudes are sums with alternating signs: single
+    configurations lose up to ~4 digits to cancellation (measured on random half-filled configurations: f32
+    3e-6 .. 4e-4, f64 5e-9 .. 9e-8 relative), hence tolerances looser than the bosonic 1e-5 and a check on the
+    configurations a Monte-Carlo run would visit; the f64 device mode is the parity-grade path for fermions."""
+    from peps_amd import capi, fermion
+    L, D, chi = 8, 6, 24
+    st = fermion.random_even_state(L, L, D, seed=11)
+    _, fs = _oracle_view(st)
+    rng = np.random.default_rng(7)
+    pool = np.stack([rng.permutation(np.r_[np.zeros(32, dtype=int), np.ones(32, dtype=int)]).reshape(L, L) for _ in range(64)])
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    ctx = _ctx(st, chi, capi.F32 if dt == "f32" else capi.F64, len(pool))
+    # Monte-Carlo sampling visits configurations by |psi|^2: take the four heaviest of 64 random ones
+    cfgs = pool[np.argsort(-np.abs(fermion.evaluate_amplitude(ctx, st, pool)))[:4]]
+    amp = fermion.evaluate_amplitude(ctx, st, cfgs)
+    e_loc, psis = fermion.spinless_fermion_energy(ctx, st, cfgs, 1.0, 1.0)
+    assert np.all(ctx.walker_flags() == 0)
+    model = ofermion.SquareSpinlessFermionOBC(1.0, 0.0, 1.0)
+    for k in range(2):
+        a = fs.amplitude(cfgs[k], tp)
+        assert abs(amp[k] / a - 1) < tol_amp
+        if k == 0:
+            e, _ = model.CalEnergy(fs, cfgs[k], tp)
+            assert abs(e_loc[k] / e - 1) < tol_e
+    # size-independent property on every walker: all 2 L routes give the same |psi| up to the chi-truncation
+    assert np.max(np.abs(np.abs(psis) / np.abs(amp)[None, :] - 1)) < (1e-3 if dt == "f32" else 1e-4)
