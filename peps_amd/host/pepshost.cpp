@@ -179,6 +179,50 @@ int pepshost_load_sitps(const char *dir, int D, int *rows, int *cols, int *d, do
   });
 }
 
+// Fermionic state (extended, sign-decorated components: peps_amd/fermion.py): E_loc of the spinless t-V model and
+// the amplitudes for a batch of physical configurations.  sitps_ext_flat has 4 * d components per site.
+int pepshost_fermion_energy(int rows, int cols, int D, int d, const int32_t *nf, int chi, int dtype,
+                            const double *sitps_ext_flat, int n, const int32_t *configs, double t, double V,
+                            double *amplitudes_out, double *energies_out, double *psi_out, int *n_psi_out) {
+  return guarded([&]() {
+    SplitIndexTPS sitps = make_state(rows, cols, D, 4 * d, sitps_ext_flat);
+    FermionDecoration dec;
+    dec.nf.assign(nf, nf + d);
+    BMPSContractor contractor(rows, cols, D, 4 * d, BMPSTruncateParams::SVD(chi, chi, 0.0), n, dtype);
+    TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor, &dec);
+    std::copy(comp.amplitude.begin(), comp.amplitude.end(), amplitudes_out);
+    SquareSpinlessFermion model(t, V);
+    EnergyAndHoles eh = model.CalEnergyAndHoles<false>(sitps, comp);
+    std::copy(eh.energy.begin(), eh.energy.end(), energies_out);
+    if (n_psi_out) *n_psi_out = (int)eh.psi_list.size();
+    if (psi_out)
+      for (size_t k = 0; k < eh.psi_list.size(); ++k) std::copy(eh.psi_list[k].begin(), eh.psi_list[k].end(), psi_out + k * n);
+  });
+}
+
+// MCUpdateSquareNNExchangeOBC on a fermionic state: n_sweeps sweeps, configurations updated in place
+int pepshost_fermion_mc_sweeps(int rows, int cols, int D, int d, const int32_t *nf, int chi, int dtype,
+                               const double *sitps_ext_flat, int n, int32_t *configs, const uint64_t *seeds, int n_sweeps,
+                               double *amplitudes_out, double *accept_out) {
+  return guarded([&]() {
+    SplitIndexTPS sitps = make_state(rows, cols, D, 4 * d, sitps_ext_flat);
+    FermionDecoration dec;
+    dec.nf.assign(nf, nf + d);
+    BMPSContractor contractor(rows, cols, D, 4 * d, BMPSTruncateParams::SVD(chi, chi, 0.0), n, dtype);
+    TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor, &dec);
+    std::vector<uint64_t> sd(seeds, seeds + n);
+    MCUpdateSquareNNExchangeOBC ex(sd);
+    std::vector<double> rates, acc(n, 0.0);
+    for (int s = 0; s < n_sweeps; ++s) {
+      ex(sitps, comp, rates);
+      for (int w = 0; w < n; ++w) acc[w] += rates[w];
+    }
+    std::copy(comp.config.data(), comp.config.data() + (size_t)n * rows * cols, configs);
+    std::copy(comp.amplitude.begin(), comp.amplitude.end(), amplitudes_out);
+    if (accept_out) for (int w = 0; w < n; ++w) accept_out[w] = n_sweeps ? acc[w] / n_sweeps : 0.0;
+  });
+}
+
 // SplitIndexTPS::Dump (OBC leg dimensions) and the configuration{label} text files
 int pepshost_dump_sitps(const char *dir, int rows, int cols, int D, int d, const double *flat) {
   return guarded([&]() {

@@ -393,39 +393,143 @@ class BMPSContractor {
   pepsgpu_ctx *ctx_ = nullptr;
 };
 
-// TPSWaveFunctionComponent (wave_function_component.h:136-379), one entry per walker.
+// ---------------------------------------------------------------------------------------------
+// Fermionic (fZ2-graded) states.  The graded contraction of the projected network equals an ordinary
+// contraction of sign-decorated site tensors (peps_amd/fermion.py; proof obligations in
+// tests/test_oracle_fermion.py), so a fermionic SplitIndexTPS is uploaded with 4 d "extended" components
+// per site and every fermionic sign becomes the choice of a component: extended state = s + d * variant,
+// variant 0/1 = row-major mode order with an even/odd number of fermions at sites <= v, variant 2/3 =
+// column-major order with an even/odd number of fermions before v.  Nearest-neighbour hops along a row
+// (column) are adjacent in the row-major (column-major) order: no Jordan-Wigner string, and only the
+// extended states of the two sites change.
+enum ModeOrder { ROW_MAJOR = 0, COL_MAJOR = 1 };
+struct FermionDecoration {
+  std::vector<int> nf;                         // fermion parity of each physical state (0 = occupied -> 1)
+  size_t d() const { return nf.size(); }
+  int n(int32_t state) const { return nf[(size_t)state] & 1; }
+  // extended state of `site` for walker w, given the physical configuration
+  int32_t Ext(const Configuration &cfg, size_t w, const SiteIdx &site, ModeOrder order) const {
+    int par = 0;
+    if (order == ROW_MAJOR) {
+      for (size_t r = 0; r <= site.r; ++r)
+        for (size_t c = 0; c < cfg.cols(); ++c) {
+          if (r == site.r && c > site.c) break;
+          par ^= n(cfg(w, {r, c}));
+        }
+      return cfg(w, site) + (int32_t)d() * par;
+    }
+    for (size_t c = 0; c <= site.c; ++c)
+      for (size_t r = 0; r < cfg.rows(); ++r) {
+        if (c == site.c && r >= site.r) break;
+        par ^= n(cfg(w, {r, c}));
+      }
+    return cfg(w, site) + (int32_t)d() * (2 + par);
+  }
+  Configuration ExtConfig(const Configuration &cfg, ModeOrder order) const {
+    Configuration e(cfg.walkers(), cfg.rows(), cfg.cols());
+    for (size_t w = 0; w < cfg.walkers(); ++w) {
+      int par = 0;
+      if (order == ROW_MAJOR) {
+        for (size_t r = 0; r < cfg.rows(); ++r)
+          for (size_t c = 0; c < cfg.cols(); ++c) { par ^= n(cfg(w, {r, c})); e(w, {r, c}) = cfg(w, {r, c}) + (int32_t)d() * par; }
+      } else {
+        for (size_t c = 0; c < cfg.cols(); ++c)
+          for (size_t r = 0; r < cfg.rows(); ++r) { e(w, {r, c}) = cfg(w, {r, c}) + (int32_t)d() * (2 + par); par ^= n(cfg(w, {r, c})); }
+      }
+    }
+    return e;
+  }
+  // <S|Psi> (parity legs in row-major order) = Sigma * ordinary contraction of the row-major decorated network
+  int Sigma(const Configuration &cfg, size_t w) const {
+    long nfm = 0;
+    for (size_t r = 0; r < cfg.rows(); ++r)
+      for (size_t c = 0; c < cfg.cols(); ++c) nfm += n(cfg(w, {r, c}));
+    return ((nfm + nfm * (nfm - 1) / 2) & 1) ? -1 : 1;
+  }
+};
+
+// TPSWaveFunctionComponent (wave_function_component.h:136-379), one entry per walker.  `config` is always the
+// PHYSICAL configuration; for a fermionic state (`fermion` set) the device is given the extended states of the
+// current mode order.
 struct TPSWaveFunctionComponent {
   Configuration config;
   std::vector<double> amplitude;
   BMPSContractor &contractor;
   BMPSTruncateParams trun_para;
+  const FermionDecoration *fermion = nullptr;
+  ModeOrder order = ROW_MAJOR;
 
-  TPSWaveFunctionComponent(const SplitIndexTPS &sitps, const Configuration &cfg, BMPSContractor &c)
-      : config(cfg), contractor(c), trun_para(c.GetTruncateParams()) {
+  TPSWaveFunctionComponent(const SplitIndexTPS &sitps, const Configuration &cfg, BMPSContractor &c,
+                           const FermionDecoration *ferm = nullptr)
+      : config(cfg), contractor(c), trun_para(c.GetTruncateParams()), fermion(ferm) {
     contractor.UploadState(sitps);
-    contractor.Init(config);                 // tn = TensorNetwork2D(sitps, config); contractor.Init(tn)  (:159-160)
+    InitDevice();                            // tn = TensorNetwork2D(sitps, config); contractor.Init(tn)  (:159-160)
     EvaluateAmplitude();                     // :161
   }
+  void InitDevice() { contractor.Init(fermion ? fermion->ExtConfig(config, order) : config); }
+  // Row pass (horizontal bonds) <-> column pass (vertical bonds) of a sweep / an energy evaluation: a fermionic
+  // network is decorated for the mode order in which the bonds of the pass are local; bosons: no-op.
+  void SetOrder(ModeOrder o) {
+    if (!fermion || o == order) return;
+    order = o;
+    InitDevice();
+  }
   const std::vector<double> &EvaluateAmplitude() {      // :187-212
+    if (fermion && order != ROW_MAJOR) SetOrder(ROW_MAJOR);
     amplitude = contractor.EvaluateAmplitude();
     auto flags = contractor.WalkerFlags();
     for (size_t w = 0; w < flags.size(); ++w)
       if (flags[w])
         throw std::runtime_error("BMPS::MultiplyMPOSVDCompress_: Empty tensor (walker " + std::to_string(w) +
                                  "). Configuration may have near-zero amplitude due to numerical degeneracy.");
+    if (fermion)
+      for (size_t w = 0; w < amplitude.size(); ++w) amplitude[w] *= fermion->Sigma(config, w);
     return amplitude;
   }
   void ReplaceGlobalConfig(const Configuration &cfg) {   // :180-185
     config = cfg;
-    contractor.Init(config);
+    InitDevice();
     EvaluateAmplitude();
   }
-  // UpdateLocal (:345-378) for the walkers with mask != 0
+  // physical candidate states of a nearest-neighbour bond (s1 before s2 in the current mode order) -> device states
+  std::vector<int32_t> DeviceStatesNN(const SiteIdx &s1, const SiteIdx &s2, int n_cand, const std::vector<int32_t> &cand) const {
+    if (!fermion) return cand;
+    const size_t nw = config.walkers(), d = fermion->d();
+    std::vector<int32_t> out(cand.size());
+    for (size_t w = 0; w < nw; ++w) {
+      // parity of the fermions before s1 in the current order (does not depend on the states of s1, s2)
+      const int32_t e1 = fermion->Ext(config, w, s1, order);
+      const int var1 = e1 / (int32_t)d;                                   // 0/1 (row: inclusive) or 2/3 (col: before)
+      const int before = order == ROW_MAJOR ? ((var1 & 1) ^ fermion->n(config(w, s1))) : (var1 & 1);
+      for (int k = 0; k < n_cand; ++k) {
+        const int32_t a = cand[(w * n_cand + k) * 2], b = cand[(w * n_cand + k) * 2 + 1];
+        const int na = fermion->n(a), nb = fermion->n(b);
+        if (order == ROW_MAJOR) {
+          out[(w * n_cand + k) * 2] = a + (int32_t)d * (before ^ na);
+          out[(w * n_cand + k) * 2 + 1] = b + (int32_t)d * (before ^ na ^ nb);
+        } else {
+          out[(w * n_cand + k) * 2] = a + (int32_t)d * (2 + before);
+          out[(w * n_cand + k) * 2 + 1] = b + (int32_t)d * (2 + (before ^ na));
+        }
+      }
+    }
+    return out;
+  }
+  std::vector<double> ReplaceNNSiteTrace(const SiteIdx &s1, const SiteIdx &s2, BondOrientation dir, int n_cand,
+                                         const std::vector<int32_t> &cand) const {
+    return contractor.ReplaceNNSiteTrace(s1, dir, n_cand, DeviceStatesNN(s1, s2, n_cand, cand));
+  }
+  // UpdateLocal (:345-378) for the walkers with mask != 0; new_states are physical, [walker][site]
   void UpdateLocal(const std::vector<double> &new_amplitude, const std::vector<SiteIdx> &sites,
-                   const std::vector<int32_t> &new_states /* [walker][site] */, const std::vector<uint8_t> &mask) {
+                   const std::vector<int32_t> &new_states, const std::vector<uint8_t> &mask) {
     std::vector<int32_t> flat_sites;
     for (auto &s : sites) { flat_sites.push_back((int32_t)s.r); flat_sites.push_back((int32_t)s.c); }
-    contractor.UpdateLocal(flat_sites, new_states, mask);
+    if (fermion) {
+      if (sites.size() != 2) throw std::invalid_argument("fermionic UpdateLocal: nearest-neighbour pairs only");
+      contractor.UpdateLocal(flat_sites, DeviceStatesNN(sites[0], sites[1], 1, new_states), mask);
+    } else {
+      contractor.UpdateLocal(flat_sites, new_states, mask);
+    }
     for (size_t w = 0; w < mask.size(); ++w) {
       if (!mask[w]) continue;
       for (size_t k = 0; k < sites.size(); ++k) config(w, sites[k]) = new_states[w * sites.size() + k];
@@ -487,6 +591,7 @@ class MCUpdateSquareNNUpdateBaseOBC : public MonteCarloSweepUpdaterBase {
     const size_t rows = c.rows(), cols = c.cols(), n = comp.config.walkers();
     std::vector<size_t> acc(n, 0);
     auto add = [&](const std::vector<uint8_t> &a) { for (size_t w = 0; w < n; ++w) acc[w] += a[w]; };
+    comp.SetOrder(ROW_MAJOR);                // fermions: horizontal bonds are local in the row-major mode order
     c.GenerateBMPSApproach(UP);
     for (size_t row = 0; row < rows; row++) {
       c.InitBTen(LEFT, row);
@@ -499,6 +604,7 @@ class MCUpdateSquareNNUpdateBaseOBC : public MonteCarloSweepUpdaterBase {
     }
     c.DeleteInnerBMPS(LEFT);
     c.DeleteInnerBMPS(RIGHT);
+    comp.SetOrder(COL_MAJOR);                // fermions: vertical bonds are local in the column-major mode order
     c.GenerateBMPSApproach(LEFT);
     for (size_t col = 0; col < cols; col++) {
       c.InitBTen(UP, col);
@@ -532,7 +638,7 @@ class MCUpdateSquareNNExchangeOBC : public MCUpdateSquareNNUpdateBaseOBC<MCUpdat
     }
     std::vector<uint8_t> exchange(n, 0);
     if (!any) return exchange;            // every walker has equal spins on the bond (:149-151)
-    std::vector<double> psi_b = comp.contractor.ReplaceNNSiteTrace(s1, dir, 1, cand);
+    std::vector<double> psi_b = comp.ReplaceNNSiteTrace(s1, s2, dir, 1, cand);
     for (size_t w = 0; w < n; ++w) {
       if (comp.config(w, s1) == comp.config(w, s2)) continue;
       const double pa = std::fabs(comp.amplitude[w]), pb = std::fabs(psi_b[w]);
@@ -557,7 +663,7 @@ class MCUpdateSquareNNFullSpaceUpdateOBC : public MCUpdateSquareNNUpdateBaseOBC<
     std::vector<int32_t> cand(n * nc * 2);
     for (size_t w = 0; w < n; ++w)
       for (size_t k = 0; k < nc; ++k) { cand[(w * nc + k) * 2] = (int32_t)(k / dim); cand[(w * nc + k) * 2 + 1] = (int32_t)(k % dim); }
-    std::vector<double> alt = comp.contractor.ReplaceNNSiteTrace(s1, dir, (int)nc, cand);
+    std::vector<double> alt = comp.ReplaceNNSiteTrace(s1, s2, dir, (int)nc, cand);
     std::vector<uint8_t> changed(n, 0);
     std::vector<int32_t> ns(n * 2);
     std::vector<double> new_amp(n);
@@ -599,6 +705,8 @@ class SquareNNNModelEnergySolver {
     out.energy.assign(n, 0.0);
     if (calchols && !holes_on_device) out.holes.assign(n * rows * cols * slot, 0.0);
     auto *self = static_cast<ExplicitlyModel *>(this);
+    if (comp.fermion && calchols) throw std::invalid_argument("hole tensors of a fermionic state are not implemented");
+    comp.SetOrder(ROW_MAJOR);
     c.GenerateBMPSApproach(UP);                                              // :116
     for (size_t row = 0; row < rows; row++) {
       c.InitBTen(LEFT, row);                                                 // :142
@@ -638,6 +746,7 @@ class SquareNNNModelEnergySolver {
       }
       if (row + 1 < rows) c.ShiftBMPSWindow(DOWN);                            // :126
     }
+    comp.SetOrder(COL_MAJOR);
     c.GenerateBMPSApproach(LEFT);                                            // bond_traversal_mixin.h:120
     for (size_t col = 0; col < cols; col++) {
       c.InitBTen(UP, col);
@@ -682,7 +791,7 @@ class SquareSpinOneHalfXXZModelMixIn {
     }
     std::vector<double> e(n, 0.25 * jz_);
     if (!any) return e;
-    std::vector<double> psi_ex = comp.contractor.ReplaceNNSiteTrace(s1, orient, 1, cand);
+    std::vector<double> psi_ex = comp.ReplaceNNSiteTrace(s1, s2, orient, 1, cand);
     for (size_t w = 0; w < n; ++w)
       if (comp.config(w, s1) != comp.config(w, s2)) e[w] = -0.25 * jz_ + psi_ex[w] * inv_psi[w] * 0.5 * jxy_;
     return e;
@@ -729,6 +838,41 @@ class SquareSpinOneHalfJ1J2XXZModelOBC : public SquareNNNModelEnergySolver<Squar
   explicit SquareSpinOneHalfJ1J2XXZModelOBC(double j2) : SquareSpinOneHalfXXZModelMixIn(1, 1, j2, j2, 0) {}
   SquareSpinOneHalfJ1J2XXZModelOBC(double jz, double jxy, double jz2, double jxy2, double pinning_field00)
       : SquareSpinOneHalfXXZModelMixIn(jz, jxy, jz2, jxy2, pinning_field00) {}
+};
+
+// square_spinless_fermion.h:51-200: H = -t sum_<ij> (c+_i c_j + h.c.) + V sum_<ij> n_i n_j (+ t2 NNN hopping, which
+// the reference routes through BTen2 / ReplaceNNNSiteTrace: not local in the decorated form, must be 0 here).
+// psi is recomputed with Trace next to psi' (same contraction path, docs/dev/design/math/
+// fermion-sign-in-bmps-contraction.md), the bosonic inv_psi argument is unused.
+class SquareSpinlessFermion : public SquareNNModelEnergySolver<SquareSpinlessFermion> {
+ public:
+  SquareSpinlessFermion(double t, double V) : t_(t), t2_(0.0), V_(V) {}
+  SquareSpinlessFermion(double t, double t2, double V) : t_(t), t2_(t2), V_(V) {
+    if (t2 != 0.0) throw std::invalid_argument("SquareSpinlessFermion: t2 != 0 (NNN hopping) is not implemented on the device");
+  }
+  double CalDensityImpl(int32_t config) const { return double(1 - config); }   // :95-97
+  std::vector<double> EvaluateBondEnergy(const SiteIdx &s1, const SiteIdx &s2, BondOrientation orient,
+                                         TPSWaveFunctionComponent &comp, const std::vector<double> &) {   // :134-159
+    const size_t n = comp.config.walkers();
+    std::vector<int32_t> cand(n * 2);
+    std::vector<double> e(n);
+    bool any = false;
+    for (size_t w = 0; w < n; ++w) {
+      cand[2 * w] = comp.config(w, s2);
+      cand[2 * w + 1] = comp.config(w, s1);
+      any |= cand[2 * w] != cand[2 * w + 1];
+      e[w] = V_ * CalDensityImpl(comp.config(w, s1)) * CalDensityImpl(comp.config(w, s2));
+    }
+    if (!any) return e;
+    std::vector<double> psi = comp.contractor.Trace(s1, orient);
+    std::vector<double> psi_ex = comp.ReplaceNNSiteTrace(s1, s2, orient, 1, cand);
+    for (size_t w = 0; w < n; ++w)
+      if (comp.config(w, s1) != comp.config(w, s2)) e[w] += -t_ * psi_ex[w] / psi[w];
+    return e;
+  }
+  double EvaluateTotalOnsiteEnergy(const Configuration &, size_t) const { return 0.0; }   // :92
+ private:
+  double t_, t2_, V_;
 };
 
 // transverse_field_ising_square_obc.h:28-247

@@ -140,3 +140,34 @@ def load_configuration(directory, label, rows, cols):
     out = np.zeros((rows, cols), dtype=np.int32)
     _ck(lib().pepshost_load_configuration(directory.encode(), label, rows, cols, _p(out, C.c_int32)))
     return out
+
+
+def fermion_energy(state, configs, chi, t, V=0.0, dtype=1):
+    """C++ host layer on a fermionic state (peps_amd.fermion.FermionState): amplitudes (row-major mode order),
+    E_loc of the spinless t-V model, psi along every row / column route."""
+    flat = np.ascontiguousarray(state.extended_flat(), dtype=np.float64)
+    rows, cols, D = flat.shape[0], flat.shape[1], flat.shape[3]
+    cfg = np.ascontiguousarray(configs, dtype=np.int32)
+    n = cfg.shape[0]
+    nf = np.ascontiguousarray(state.nf, dtype=np.int32)
+    amps, en = np.zeros(n), np.zeros(n)
+    psi = np.zeros((rows + cols, n))
+    npsi = C.c_int(0)
+    _ck(lib().pepshost_fermion_energy(rows, cols, D, state.d, _p(nf, C.c_int32), chi, dtype, _p(flat, C.c_double), n,
+                                      _p(cfg, C.c_int32), C.c_double(t), C.c_double(V), _p(amps, C.c_double),
+                                      _p(en, C.c_double), _p(psi, C.c_double), C.byref(npsi)))
+    return amps, en, psi[:npsi.value]
+
+
+def fermion_mc_sweeps(state, configs, seeds, chi, n_sweeps=1, dtype=1):
+    flat = np.ascontiguousarray(state.extended_flat(), dtype=np.float64)
+    rows, cols, D = flat.shape[0], flat.shape[1], flat.shape[3]
+    cfg = np.ascontiguousarray(configs, dtype=np.int32).copy()
+    n = cfg.shape[0]
+    nf = np.ascontiguousarray(state.nf, dtype=np.int32)
+    sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+    amps, rates = np.zeros(n), np.zeros(n)
+    _ck(lib().pepshost_fermion_mc_sweeps(rows, cols, D, state.d, _p(nf, C.c_int32), chi, dtype, _p(flat, C.c_double), n,
+                                         _p(cfg, C.c_int32), _p(sd, C.c_uint64), n_sweeps, _p(amps, C.c_double),
+                                         _p(rates, C.c_double)))
+    return cfg, amps, rates

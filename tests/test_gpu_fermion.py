@@ -118,3 +118,44 @@ def test_c5_spinless_tV_8x8_d6_chi24(dt, tol_amp, tol_e):
             assert abs(e_loc[k] / e - 1) < tol_e
     # size-independent property on every walker: all 2 L routes give the same |psi| up to the chi-truncation
     assert np.max(np.abs(np.abs(psis) / np.abs(amp)[None, :] - 1)) < (1e-3 if dt == "f32" else 1e-4)
+
+
+@pytest.mark.parametrize("dt,tol", [(1, 1e-9), (0, 5e-5)])
+def test_cpp_host_layer_fermion_energy(dt, tol):
+    """C++ host layer (FermionDecoration + TPSWaveFunctionComponent + SquareSpinlessFermion through the CRTP
+    energy solver of qlpeps_gpu.h): amplitudes and t-V local energies == Python product path == oracle."""
+    from peps_amd import capi, fermion, hostapi
+    st = fermion.random_even_state(4, 5, 4, seed=21) if False else fermion.random_even_state(4, 4, 4, seed=21)
+    _, fs = _oracle_view(st)
+    rng = np.random.default_rng(9)
+    cfgs = rng.integers(0, 2, size=(5, 4, 4))
+    cfgs[(16 - cfgs.sum(axis=(1, 2))) % 2 == 1, 0, 0] ^= 1
+    amps, en, psi = hostapi.fermion_energy(st, cfgs, 16, 1.0, 0.5, dt)
+    tp = BMPSTruncateParams.SVD(16, 16, 0.0)
+    model = ofermion.SquareSpinlessFermionOBC(1.0, 0.0, 0.5)
+    for k, cfg in enumerate(cfgs):
+        a = fs.amplitude(cfg, tp)
+        assert abs(amps[k] / a - 1) < tol
+        e, _ = model.CalEnergy(fs, cfg, tp)
+        assert abs(en[k] - e) < tol * 10 * max(1.0, abs(e))
+    assert psi.shape[0] == 8
+
+
+def test_cpp_host_layer_fermion_mc_sweep():
+    """MCUpdateSquareNNExchangeOBC on a fermionic state (f64): particle number conserved, moves accepted, and
+    the carried amplitude equals a fresh evaluation of the final configuration in magnitude."""
+    from peps_amd import capi, fermion, hostapi
+    st = fermion.random_even_state(4, 4, 4, seed=22)
+    rng = np.random.default_rng(3)
+    cfgs = np.stack([rng.permutation(np.r_[np.zeros(8, dtype=int), np.ones(8, dtype=int)]).reshape(4, 4) for _ in range(6)])
+    seeds = np.arange(6, dtype=np.uint64) + 40
+    out_cfg, amps, rates = hostapi.fermion_mc_sweeps(st, cfgs, seeds, 16, 2, 1)
+    assert np.all(out_cfg.sum(axis=(1, 2)) == 8)
+    assert np.all(rates > 0) and np.all(rates < 1)
+    assert not np.array_equal(out_cfg, cfgs)
+    ctx = _ctx(st, 16, capi.F64, len(cfgs))
+    fresh = fermion.evaluate_amplitude(ctx, st, out_cfg)
+    assert np.max(np.abs(np.abs(amps) / np.abs(fresh) - 1)) < 1e-7
+    # same seeds, same chain
+    out2, amps2, _ = hostapi.fermion_mc_sweeps(st, cfgs, seeds, 16, 2, 1)
+    assert np.array_equal(out2, out_cfg)
