@@ -159,6 +159,31 @@ class FermionState:
         return out
 
 
+def fold_gradient(state, grad_ext):
+    """gradient with respect to the extended (decorated) components [rows][cols][4 d][D^4] -> gradient with respect
+    to the stored components [rows][cols][d][D^4]: T''[s + d var] = sign_var * T[s], so dE/dT[s] = sum_var sign_var *
+    dE/dT''[s + d var]; parity-forbidden entries (not parameters of a Z2-symmetric state) are zeroed."""
+    rows, cols, d = state.rows, state.cols, state.d
+    D = grad_ext.shape[3]
+    out = np.zeros((rows, cols, d, D, D, D, D))
+    for r in range(rows):
+        for c in range(cols):
+            pl, pd, pr, pu = state.par[r][c]
+            l = pl[:, None, None, None]; dd = pd[None, :, None, None]; rr = pr[None, None, :, None]; u = pu[None, None, None, :]
+            shp = (len(pl), len(pd), len(pr), len(pu))
+            sl = tuple(slice(0, k) for k in shp)
+            for s in range(d):
+                n = int(state.nf[s])
+                base = (u * n + u + dd * rr + l + l * u) % 2
+                allowed = ((l + dd + rr + u + n) % 2 == 0)
+                signs = (np.ones(shp), 1 - 2 * (u % 2) + np.zeros(shp), 1 - 2 * base + np.zeros(shp), 1 - 2 * ((base + l) % 2) + np.zeros(shp))
+                acc = np.zeros(shp)
+                for var in range(NVAR):
+                    acc += signs[var] * grad_ext[(r, c, s + d * var) + sl]
+                out[(r, c, s) + sl] = acc * allowed
+    return out
+
+
 def evaluate_amplitude(ctx, state, configs):
     """<S|Psi> (parity legs in row-major order) for a batch of physical configurations; ctx must hold
     state.extended_flat() (phys_dim = 4 d)."""

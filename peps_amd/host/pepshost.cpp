@@ -200,6 +200,26 @@ int pepshost_fermion_energy(int rows, int cols, int D, int d, const int32_t *nf,
   });
 }
 
+// ExactSumEnergyEvaluator on a fermionic state (spinless t-V): packed accumulators over the EXTENDED components
+// (length 2 * rows*cols*4d*D^4 + 4); peps_amd.fermion.fold_gradient maps the finished gradient back
+int pepshost_fermion_exact_sum_partial(int rows, int cols, int D, int d, const int32_t *nf, int chi, int dtype,
+                                       const double *sitps_ext_flat, const int32_t *all_configs, int n_configs, double t,
+                                       double V, int rank, int size, int batch, double *packed_out) {
+  return guarded([&]() {
+    SplitIndexTPS sitps = make_state(rows, cols, D, 4 * d, sitps_ext_flat);
+    FermionDecoration dec;
+    dec.nf.assign(nf, nf + d);
+    BMPSContractor contractor(rows, cols, D, 4 * d, BMPSTruncateParams::SVD(chi, chi, 0.0), batch, dtype);
+    std::vector<std::vector<int32_t>> all(n_configs);
+    for (int i = 0; i < n_configs; ++i) all[i].assign(all_configs + (size_t)i * rows * cols, all_configs + (size_t)(i + 1) * rows * cols);
+    std::vector<double> packed;
+    auto capture = [&](std::vector<double> &v) { packed = v; };
+    SquareSpinlessFermion m(t, V);
+    ExactSumEnergyEvaluator(sitps, all, contractor, m, rank, size, (size_t)batch, capture, &dec);
+    std::copy(packed.begin(), packed.end(), packed_out);
+  });
+}
+
 // MCUpdateSquareNNExchangeOBC on a fermionic state: n_sweeps sweeps, configurations updated in place
 int pepshost_fermion_mc_sweeps(int rows, int cols, int D, int d, const int32_t *nf, int chi, int dtype,
                                const double *sitps_ext_flat, int n, int32_t *configs, const uint64_t *seeds, int n_sweeps,

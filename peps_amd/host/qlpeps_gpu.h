@@ -705,8 +705,9 @@ class SquareNNNModelEnergySolver {
     out.energy.assign(n, 0.0);
     if (calchols && !holes_on_device) out.holes.assign(n * rows * cols * slot, 0.0);
     auto *self = static_cast<ExplicitlyModel *>(this);
-    if (comp.fermion && calchols) throw std::invalid_argument("hole tensors of a fermionic state are not implemented");
-    comp.SetOrder(ROW_MAJOR);
+    if (comp.fermion && calchols && holes_on_device)
+      throw std::invalid_argument("fermionic state: the device-resident hole store is not supported (holes come back to the host)");
+    comp.SetOrder(ROW_MAJOR);                // fermions: holes are those of the row-major decorated network
     c.GenerateBMPSApproach(UP);                                              // :116
     for (size_t row = 0; row < rows; row++) {
       c.InitBTen(LEFT, row);                                                 // :142
@@ -938,12 +939,16 @@ struct GradAccumulator {
   void Accumulate(const TPSWaveFunctionComponent &comp, const EnergyAndHoles &eh, bool exact_sum) {
     const size_t n = comp.config.walkers(), rows = Ostar_sum.rows(), cols = Ostar_sum.cols(), slot = Ostar_sum.slot();
     for (size_t w = 0; w < n; ++w) {
-      const double psi = comp.amplitude[w], e = eh.energy[w];
+      // fermions: psi = sigma * Dense_row, d psi / d T''_v = sigma * hole: the derivative of ln psi with respect to the
+      // DECORATED component (extended state) uses the plain contraction value; FoldFermionGradient maps it back
+      const double psi = comp.fermion ? comp.amplitude[w] * comp.fermion->Sigma(comp.config, w) : comp.amplitude[w];
+      const double e = eh.energy[w];
       const double wt = exact_sum ? psi * psi : 1.0;
       const double f = exact_sum ? psi : 1.0 / psi;
       for (size_t r = 0; r < rows; ++r)
         for (size_t c = 0; c < cols; ++c) {
-          const size_t basis = (size_t)comp.config(w, {r, c});
+          const size_t basis = comp.fermion ? (size_t)comp.fermion->Ext(comp.config, w, {r, c}, ROW_MAJOR)
+                                            : (size_t)comp.config(w, {r, c});
           const double *h = eh.holes.data() + ((w * rows + r) * cols + c) * slot;
           double *so = Ostar_sum.component(r, c, basis), *seo = ELocConj_Ostar_sum.component(r, c, basis);
           for (size_t k = 0; k < slot; ++k) { so[k] += f * h[k]; seo[k] += e * f * h[k]; }
@@ -1016,7 +1021,8 @@ inline std::vector<std::vector<int32_t>> GenerateAllPermutationConfigs(const std
 template <typename ModelT>
 std::pair<double, SplitIndexTPS> ExactSumEnergyEvaluator(const SplitIndexTPS &sitps, const std::vector<std::vector<int32_t>> &all_configs,
                                                           BMPSContractor &contractor, ModelT &model, int rank, int size,
-                                                          size_t batch, const std::function<void(std::vector<double> &)> &allreduce) {
+                                                          size_t batch, const std::function<void(std::vector<double> &)> &allreduce,
+                                                          const FermionDecoration *fermion = nullptr) {
   const size_t rows = sitps.rows(), cols = sitps.cols();
   GradAccumulator acc(sitps);
   std::vector<size_t> mine;
@@ -1027,11 +1033,16 @@ std::pair<double, SplitIndexTPS> ExactSumEnergyEvaluator(const SplitIndexTPS &si
     const size_t nb = std::min(batch, mine.size() - b0);
     Configuration cfg(nb, rows, cols);
     for (size_t w = 0; w < nb; ++w) std::copy(all_configs[mine[b0 + w]].begin(), all_configs[mine[b0 + w]].end(), cfg.data() + w * rows * cols);
-    TPSWaveFunctionComponent comp(sitps, cfg, contractor);
-    EnergyAndHoles eh = model.template CalEnergyAndHoles<true>(sitps, comp, /*holes_on_device=*/true);
-    acc.AccumulateDevice(comp, eh, true);
+    TPSWaveFunctionComponent comp(sitps, cfg, contractor, fermion);
+    if (fermion) {   // gradient with respect to the decorated (extended) components; fold with FoldFermionGradient
+      EnergyAndHoles eh = model.template CalEnergyAndHoles<true>(sitps, comp, /*holes_on_device=*/false);
+      acc.Accumulate(comp, eh, true);
+    } else {
+      EnergyAndHoles eh = model.template CalEnergyAndHoles<true>(sitps, comp, /*holes_on_device=*/true);
+      acc.AccumulateDevice(comp, eh, true);
+    }
   }
-  if (!mine.empty()) acc.FetchDevice(contractor);
+  if (!mine.empty() && !fermion) acc.FetchDevice(contractor);
   std::vector<double> packed = acc.Pack();
   if (allreduce) allreduce(packed);
   acc.Unpack(packed);

@@ -171,3 +171,19 @@ def fermion_mc_sweeps(state, configs, seeds, chi, n_sweeps=1, dtype=1):
                                          _p(cfg, C.c_int32), _p(sd, C.c_uint64), n_sweeps, _p(amps, C.c_double),
                                          _p(rates, C.c_double)))
     return cfg, amps, rates
+
+
+def fermion_exact_sum(state, all_configs, chi, t, V=0.0, batch=64, dtype=1):
+    """ExactSumEnergyEvaluator on a fermionic state: (energy, gradient [rows][cols][d][D^4] with respect to the
+    stored site-tensor components, zero on parity-forbidden entries)."""
+    from . import fermion
+    flat = np.ascontiguousarray(state.extended_flat(), dtype=np.float64)
+    rows, cols, D = flat.shape[0], flat.shape[1], flat.shape[3]
+    cfg = np.ascontiguousarray(all_configs, dtype=np.int32)
+    nf = np.ascontiguousarray(state.nf, dtype=np.int32)
+    packed = np.zeros(2 * flat.size + 4)
+    _ck(lib().pepshost_fermion_exact_sum_partial(rows, cols, D, state.d, _p(nf, C.c_int32), chi, dtype, _p(flat, C.c_double),
+                                                 _p(cfg, C.c_int32), cfg.shape[0], C.c_double(t), C.c_double(V), 0, 1, batch,
+                                                 _p(packed, C.c_double)))
+    e, grad_ext = exact_sum_finish(packed, (rows, cols, 4 * state.d, D))
+    return e, fermion.fold_gradient(state, grad_ext)

@@ -159,3 +159,39 @@ def test_cpp_host_layer_fermion_mc_sweep():
     # same seeds, same chain
     out2, amps2, _ = hostapi.fermion_mc_sweeps(st, cfgs, seeds, 16, 2, 1)
     assert np.array_equal(out2, out_cfg)
+
+
+def test_fermion_exact_sum_gradient_vs_finite_differences(fixtures_dir):
+    """Energy gradient of a fermionic state (ExactSumEnergyEvaluator over the extended components on the device,
+    folded back to the stored components): grad = <E_loc O*> - E <O*> (exact_summation_energy_evaluator.h:286-295),
+    i.e. half the derivative of E for real parameters -- checked against central differences of the ORACLE energy."""
+    from peps_amd import fermion, hostapi
+    d = os.path.join(fixtures_dir, "spinless_fermion_tps_t2_0.000000_double_from_simple_update")
+    st = fermion.FermionState.load(d)
+    cfgs = _half_filling_configs()
+    t, V = 1.0, 0.3
+    e, grad = hostapi.fermion_exact_sum(st, cfgs, 8, t, V, batch=6, dtype=1)
+    gts = ofermion.load_fermion_sitps(d)
+    tp = BMPSTruncateParams.SVD(8, 8, 0.0)
+    model = ofermion.SquareSpinlessFermionOBC(t, 0.0, V)
+    e0 = ofermion.exact_sum_energy(ofermion.FermionSITPS(gts), list(cfgs), tp, model)
+    assert abs(e - e0) < 1e-10
+    rng = np.random.default_rng(2)
+    checked = 0
+    for r, c, s in [(0, 0, 0), (0, 1, 1), (1, 0, 0), (1, 1, 1), (0, 0, 1), (1, 1, 0)]:
+        a = gts[r][c][s].arr
+        nzs = np.argwhere(np.abs(a) > 1e-12)
+        ix = tuple(nzs[rng.integers(len(nzs))])
+        h = 1e-5
+        vals = []
+        for sgn in (+1, -1):
+            a[ix] += sgn * h
+            vals.append(ofermion.exact_sum_energy(ofermion.FermionSITPS(gts), list(cfgs), tp, model))
+            a[ix] -= sgn * h
+        fd = (vals[0] - vals[1]) / (2 * h)
+        g = grad[(r, c, s) + ix[:4]]
+        assert abs(2 * g - fd) < 1e-6 * max(1.0, abs(fd)), (r, c, s, ix, g, fd)
+        checked += 1
+    assert checked == 6
+    # parity-forbidden entries carry no gradient
+    assert np.all(grad[0, 0, 0][np.abs(st.extended_flat()[0, 0, 0]) == 0] == 0)
