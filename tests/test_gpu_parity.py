@@ -306,3 +306,49 @@ def test_error_codes():
     ctx.set_configs(np.zeros((2, 4, 4), dtype=np.int32))
     with pytest.raises(RuntimeError):          # trace without environments
         ctx.trace(1, 1, HORIZONTAL)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("Ly,Lx", [(3, 6), (6, 3), (2, 5)])
+def test_rectangular_lattices(Ly, Lx, dt):
+    """rows != cols: amplitude, horizontal / vertical trace routes and hole . site == psi against the oracle"""
+    from peps_amd import capi
+    D, chi = 3, 9
+    rng = np.random.default_rng(10 * Ly + Lx)
+    sitps = []
+    for r in range(Ly):
+        row = []
+        for c in range(Lx):
+            shp = (1 if c == 0 else D, 1 if r == Ly - 1 else D, 1 if c == Lx - 1 else D, 1 if r == 0 else D)
+            row.append([np.einsum("i,j,k,l->ijkl", *[rng.uniform(0.5, 1.5, size=n) for n in shp]) * 0.5
+                        + 0.1 * rng.standard_normal(shp) for _ in range(2)])
+        sitps.append(row)
+    flat = np.zeros((Ly, Lx, 2, D, D, D, D))
+    for r in range(Ly):
+        for c in range(Lx):
+            for s in range(2):
+                t = sitps[r][c][s]
+                flat[(r, c, s) + tuple(slice(0, k) for k in t.shape)] = t
+    cfgs = rng.integers(0, 2, size=(4, Ly, Lx))
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    ctx = capi.Context(Ly, Lx, D, 2, chi, dtype=capi.F32 if dt == "f32" else capi.F64, max_walkers=4)
+    ctx.state_upload(flat)
+    ctx.set_configs(cfgs)
+    amp = ctx.evaluate_amplitude()
+    ctx.set_configs(cfgs)      # GrowBTenStep works on the tops of the BMPS stacks (grow.h:529-582): start from empty stacks
+    r0, c0 = Ly // 2, Lx // 2 - 1
+    ctx.grow_bmps_for_row(r0); ctx.grow_full_bten(LEFT, r0, Lx - c0, True); ctx.grow_full_bten(RIGHT, r0, c0 + 2, True)
+    psi_h = ctx.trace(r0, c0, HORIZONTAL)
+    ctx.grow_bten_step(RIGHT)
+    hole = ctx.punch_hole(r0, c0, HORIZONTAL)
+    c1 = Lx // 2
+    ctx.set_configs(cfgs)
+    ctx.grow_bmps_for_col(c1); ctx.grow_full_bten(UP, c1, Ly, True); ctx.grow_full_bten(DOWN, c1, 2, True)
+    psi_v = ctx.trace(0, c1, VERTICAL)
+    for w, cfg in enumerate(cfgs):
+        ref = vmc.TPSWaveFunctionComponent(sitps, cfg, tp).amplitude
+        assert abs(amp[w] / ref - 1) < TOL[dt]
+        assert abs(psi_h[w] / ref - 1) < TOL[dt] * 10 and abs(psi_v[w] / ref - 1) < TOL[dt] * 10
+        t = sitps[r0][c0][cfg[r0, c0]]
+        h = hole[w][tuple(slice(0, k) for k in t.shape)]
+        assert abs(np.sum(h * t) / ref - 1) < TOL[dt] * 10
