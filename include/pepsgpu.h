@@ -132,6 +132,20 @@ int pepsgpu_grad_reset(pepsgpu_ctx *ctx);
 int pepsgpu_grad_accumulate(pepsgpu_ctx *ctx, const double *psi, const double *eloc, int exact_sum);
 int pepsgpu_grad_read(pepsgpu_ctx *ctx, double *s_o_out, double *s_eo_out);
 
+/* Stochastic reconfiguration: the O* samples stay in HBM and the S-matrix product of
+ * SRSMatrix::operator* (optimizer/stochastic_reconfiguration_smatrix.h:37-99) is two sweeps over them.
+ *   pepsgpu_sr_begin(max_samples)   allocate the store [sample][site][D^4]
+ *   pepsgpu_sr_append(psi)          append O*_w = hole_w / psi_w of the current walkers (resident hole store of
+ *                                   pepsgpu_punch_hole(.., NULL); replaces Ostar_samples.push_back, mc_energy_grad_evaluator.h:270)
+ *   pepsgpu_sr_sum(out)             sum_i O*_i in the state layout (the caller divides by the total sample count -> Ostar_mean)
+ *   pepsgpu_sr_matvec(v, mean_dot_v, scale, out)   out = scale * sum_i (O*_i . v - mean_dot_v) O*_i  (state layout, float64);
+ *                                   the caller all-reduces over ranks and adds diag_shift * v. */
+int pepsgpu_sr_begin(pepsgpu_ctx *ctx, int max_samples);
+int pepsgpu_sr_append(pepsgpu_ctx *ctx, const double *psi);
+int pepsgpu_sr_count(pepsgpu_ctx *ctx);
+int pepsgpu_sr_sum(pepsgpu_ctx *ctx, double *sum_out);
+int pepsgpu_sr_matvec(pepsgpu_ctx *ctx, const double *v, double mean_dot_v, double scale, double *out);
+
 /* TPSWaveFunctionComponent::UpdateLocal (wave_function_component.h:345-378) for the walkers with
  * accept_mask[w] != 0 (NULL = all): config(site_k) = new_states[w][k], tn.UpdateSiteTensor,
  * contractor.EraseEnvsAfterUpdate(site_k) (trace.h:538-589).  sites = [n_sites][2] (row, col). */

@@ -31,6 +31,7 @@ SYMBOLS = [
     "pepsgpu_bten2_stack_size", "pepsgpu_replace_nnn_trace", "pepsgpu_replace_tnn_trace",
     "pepsgpu_replace_sqrt5_trace",
     "pepsgpu_grad_reset", "pepsgpu_grad_accumulate", "pepsgpu_grad_read",
+    "pepsgpu_sr_begin", "pepsgpu_sr_append", "pepsgpu_sr_count", "pepsgpu_sr_sum", "pepsgpu_sr_matvec",
     "pepsgpu_update_local", "pepsgpu_erase_envs_after_update", "pepsgpu_evaluate_amplitude",
     "pepsgpu_walker_flags", "pepsgpu_sync", "pepsgpu_stats", "pepsgpu_profile_enable", "pepsgpu_profile_read",
     "pepsgpu_diag_tgemm", "pepsgpu_diag_chol", "pepsgpu_diag_chol_adaptive", "pepsgpu_diag_gram_chol", "pepsgpu_diag_jacobi", "pepsgpu_version",
@@ -74,6 +75,11 @@ def load_library(path=LIB_PATH):
     lib.pepsgpu_grad_reset.argtypes = [vp]
     lib.pepsgpu_grad_accumulate.argtypes = [vp, dp, dp, C.c_int]
     lib.pepsgpu_grad_read.argtypes = [vp, dp, dp]
+    lib.pepsgpu_sr_begin.argtypes = [vp, C.c_int]
+    lib.pepsgpu_sr_append.argtypes = [vp, dp]
+    lib.pepsgpu_sr_count.argtypes = [vp]
+    lib.pepsgpu_sr_sum.argtypes = [vp, dp]
+    lib.pepsgpu_sr_matvec.argtypes = [vp, dp, C.c_double, C.c_double, dp]
     lib.pepsgpu_update_local.argtypes = [vp, C.c_int, ip, ip, C.POINTER(C.c_uint8)]
     lib.pepsgpu_erase_envs_after_update.argtypes = [vp, C.c_int, C.c_int]
     lib.pepsgpu_evaluate_amplitude.argtypes = [vp, dp]
@@ -246,6 +252,28 @@ class Context:
 
     def punch_hole_store(self, row, col, orient):
         self._ck(self._l.pepsgpu_punch_hole(self._h, row, col, orient, None))
+
+    # -- stochastic reconfiguration: O* samples resident in HBM --
+    def sr_begin(self, max_samples):
+        self._ck(self._l.pepsgpu_sr_begin(self._h, max_samples))
+
+    def sr_append(self, psi):
+        psi = np.ascontiguousarray(psi, dtype=np.float64)
+        self._ck(self._l.pepsgpu_sr_append(self._h, _dp(psi)))
+
+    def sr_count(self):
+        return self._l.pepsgpu_sr_count(self._h)
+
+    def sr_sum(self):
+        out = np.zeros((self.rows, self.cols, self.d, self.D, self.D, self.D, self.D))
+        self._ck(self._l.pepsgpu_sr_sum(self._h, _dp(out)))
+        return out
+
+    def sr_matvec(self, v, mean_dot_v, scale):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        out = np.zeros_like(v)
+        self._ck(self._l.pepsgpu_sr_matvec(self._h, _dp(v), float(mean_dot_v), float(scale), _dp(out)))
+        return out
 
     def grad_reset(self):
         self._ck(self._l.pepsgpu_grad_reset(self._h))

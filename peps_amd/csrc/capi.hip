@@ -3,6 +3,7 @@
 #include "../../include/pepsgpu.h"
 #include "engine_impl.h"
 #include "engine_nnn.h"
+#include "engine_sr.h"
 
 using namespace pepsgpu;
 
@@ -168,6 +169,13 @@ int pepsgpu_grad_accumulate(pepsgpu_ctx *ctx, const double *psi, const double *e
 }
 int pepsgpu_grad_read(pepsgpu_ctx *ctx, double *so, double *seo) {
   CTX_CALL(PG_REQUIRE(so && seo, 1, "null output"); ctx->eng->grad_read(so, seo));
+}
+int pepsgpu_sr_begin(pepsgpu_ctx *ctx, int max_samples) { CTX_CALL(ctx->eng->sr_begin(max_samples)); }
+int pepsgpu_sr_append(pepsgpu_ctx *ctx, const double *psi) { CTX_CALL(PG_REQUIRE(psi, 1, "null psi"); ctx->eng->sr_append(psi)); }
+int pepsgpu_sr_count(pepsgpu_ctx *ctx) { return (ctx && ctx->eng) ? ctx->eng->sr_count() : -1; }
+int pepsgpu_sr_sum(pepsgpu_ctx *ctx, double *out) { CTX_CALL(PG_REQUIRE(out, 1, "null output"); ctx->eng->sr_sum(out)); }
+int pepsgpu_sr_matvec(pepsgpu_ctx *ctx, const double *v, double mean_dot_v, double scale, double *out) {
+  CTX_CALL(PG_REQUIRE(v && out, 1, "null vector"); ctx->eng->sr_matvec(v, mean_dot_v, scale, out));
 }
 int pepsgpu_update_local(pepsgpu_ctx *ctx, int nsites, const int32_t *sites, const int32_t *ns, const uint8_t *mask) {
   CTX_CALL(ctx->eng->update_local(nsites, sites, ns, mask));

@@ -75,6 +75,11 @@ struct EngineBase {
   virtual void grad_reset() = 0;
   virtual void grad_accumulate(const double *psi, const double *eloc, int exact_sum) = 0;
   virtual void grad_read(double *so, double *seo) = 0;
+  virtual void sr_begin(int max_samples) = 0;
+  virtual void sr_append(const double *psi) = 0;
+  virtual int sr_count() const = 0;
+  virtual void sr_sum(double *out) = 0;
+  virtual void sr_matvec(const double *v, double mean_dot_v, double scale, double *out) = 0;
   virtual void profile_enable(int on) = 0;
   virtual void profile_read(double *out) = 0;   // [PROF_NCAT][4]: ms, launches, algorithmic flops, executed flops
 };
@@ -528,6 +533,15 @@ class Engine : public EngineBase {
     PG_CHECK_HIP(hipGetLastError());
     arena_.free(d);
   }
+  // ---- stochastic-reconfiguration sample store (engine_sr.h) ----
+  void sr_begin(int max_samples) override;
+  void sr_append(const double *psi) override;
+  int sr_count() const override { return sr_n_; }
+  void sr_sum(double *out) override;
+  void sr_matvec(const double *v, double mean_dot_v, double scale, double *out) override;
+  void sr_release();
+  void sr_convert(const double *src, double *dst, bool to_compact) const;
+
   // out layout = state upload layout [row][col][s][L][D][R][U] zero padded to D
   void grad_read(double *so, double *seo) override {
     PG_REQUIRE(so_ != nullptr, 3, "grad_read: nothing accumulated");
@@ -911,6 +925,12 @@ class Engine : public EngineBase {
   double *so_ = nullptr, *seo_ = nullptr; // gradient accumulators
   int *sweeps_ = nullptr;
   unsigned long long *flopc_ = nullptr;   // device flop counters per profile category
+  T *sr_o_ = nullptr;                      // O* samples [sample][site][D^4]
+  int *sr_cfg_ = nullptr;                  // their configurations [sample][site]
+  int *sr_ne_ = nullptr;                   // elements of the (compact) site tensor per site
+  double *sr_delta_ = nullptr, *sr_v_ = nullptr, *sr_out_ = nullptr;
+  int sr_cap_ = 0, sr_n_ = 0;
+  std::vector<uint32_t> sr_map_c_, sr_map_p_;   // compact <-> padded element index of every stored tensor element
   bool dbg_sweeps_ = false;
 };
 

@@ -202,3 +202,20 @@ def test_j1j2_nnn_solver_matches_dense_hamiltonian():
                 c2[a], c2[b] = cf[b], cf[a]
                 H[idx[tuple(c2.ravel())], i] += 0.5 * J
     assert abs(e - psi @ H @ psi / (psi @ psi)) < 1e-12
+
+
+def test_sr_oracle_matches_dense_algebra():
+    """oracle/sr.py: SRSMatrix product == explicit covariance matrix, CG == dense solve (restatement of
+    stochastic_reconfiguration_smatrix.h:37-99 and conjugate_gradient_solver.h)"""
+    from oracle import sr
+    rng = np.random.default_rng(4)
+    n, m = 40, 25
+    O = rng.standard_normal((n, m))
+    mean = O.mean(axis=0)
+    S = sr.SRSMatrix(list(O), mean, 1, 0.05)
+    dense = (O - mean).T @ (O - mean) / n + 0.05 * np.eye(m)
+    v = rng.standard_normal(m)
+    assert np.max(np.abs(S * v - dense @ v)) < 1e-12
+    g = rng.standard_normal(m)
+    x, res, it = sr.conjugate_gradient(lambda y: S * y, g, np.zeros(m), 200, 1e-12)
+    assert np.max(np.abs(x - np.linalg.solve(dense, g))) < 1e-8
