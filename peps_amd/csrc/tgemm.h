@@ -400,6 +400,7 @@ template <typename TA, typename TB, typename TC, typename TAcc>
 void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B, TC *C) {
   if (d_in.nbatch <= 0 || d_in.Itot() <= 0 || d_in.Jtot() <= 0) return;
   TGemmDesc d = d_in;
+  PG_REQUIRE(d.nbatch <= 65535, 1, "walkers x candidates exceeds 65535 (grid z limit): use a smaller walker batch");
   d.flopc = tg_flop_counter;
   d.flop_stride = d.nbatch >= 256 ? 64 : 1;   // one atomic per 64 walkers: a same-address atomic per block costs ~10 %
   int gx = (d.Itot() + TG_BM - 1) / TG_BM;
