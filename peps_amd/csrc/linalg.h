@@ -303,9 +303,13 @@ __global__ __launch_bounds__(NT, 2) void gram_chol_lowrank_kernel(const T *__res
                                                                 const int *__restrict__ kdyn, int kdyn_mul, int kmax,
                                                                 T *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
                                                                 int inner = 1, const int *__restrict__ inner_live = nullptr,
-                                                                int retry_only = 0) {
+                                                                int retry_only = 0, int k0 = 0, int last_pass = 1,
+                                                                double *__restrict__ scale_io = nullptr) {
+  // Multi-pass use (more live rows than a thread can hold): pass 0 factors the first KCAP rows of P, every later
+  // pass (k0 > 0) factors [running factor (<= CH_LR_CAP rows, read back from Rg) ; next KCAP - CH_LR_CAP rows of P].
+  // scale_io[b] carries the scale of the stored factor between passes.  A walker with K <= k0 is finished.
   constexpr int NWV = NT / 64;
-  if (retry_only && mlive_out[blockIdx.x] != -2) return;
+  if (k0 == 0 && retry_only && mlive_out[blockIdx.x] != -2) return;
   // columns are (outer, inner) with `inner` fastest; inner_live[b] (optional) = live extent of the
   // inner index (live bond of the boundary MPS): columns beyond hold no data and are never read
   __shared__ __attribute__((aligned(16))) T s_pf[KCAP];   // column f of P
@@ -314,30 +318,39 @@ __global__ __launch_bounds__(NT, 2) void gram_chol_lowrank_kernel(const T *__res
   __shared__ int s_first[2][NWV];
   __shared__ short s_pos[CH_LR_CAP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int K = kdyn ? min(kmax, kdyn[blockIdx.x] * kdyn_mul) : kmax;
-  if (K > KCAP) {
+  const int Ktot = kdyn ? min(kmax, kdyn[blockIdx.x] * kdyn_mul) : kmax;
+  if (k0 == 0 && Ktot > KCAP && last_pass) {     // single-pass use: too many rows, decline
     if (tid == 0) mlive_out[blockIdx.x] = -1;
     return;
   }
+  if (k0 > 0 && (Ktot <= k0 || mlive_out[blockIdx.x] < 0)) return;   // finished in an earlier pass / already declined
+  const int nfr = k0 > 0 ? mlive_out[blockIdx.x] : 0;                 // rows of the running factor
+  const int npr = min(Ktot - k0, KCAP - (k0 > 0 ? CH_LR_CAP : 0));    // rows of P taken in this pass
+  const int K = nfr + npr;
   const T *P = Pg + (long)blockIdx.x * wP;
   T *Rout = Rg + (long)blockIdx.x * wR;
   // thread -> column: data columns (inner index below its live extent) packed in increasing order
   const int ilive = inner_live ? min(inner, inner_live[blockIdx.x]) : inner;
   const int ncols = (n / inner) * ilive;
   if (ncols > NT) {
-    if (tid == 0) mlive_out[blockIdx.x] = -2;
+    if (tid == 0 && k0 == 0) mlive_out[blockIdx.x] = -2;
     return;
   }
+  if (k0 > 0 && retry_only && ncols <= 128) return;   // the 128-thread variant took this walker in this pass
   const bool col_ok = tid < ncols;
   const int r = col_ok ? (tid / ilive) * inner + (tid % ilive) : n;
   T pc[KCAP];
   double rc[CH_LR_CAP];                   // own column of the factor (f64: pivots near the threshold amplify its rounding)
   double d = 0.0;
+  const double unscale = (k0 > 0 && scale_io) ? 1.0 / scale_io[blockIdx.x] : 1.0;
 #pragma unroll
   for (int k = 0; k < KCAP; ++k) {
-    pc[k] = (k < K && col_ok) ? P[(long)k * n + r] : T(0);
+    T x = T(0);
+    if (k < K && col_ok) x = k < nfr ? T((double)Rout[(long)k * n + r] * unscale) : P[(long)(k0 + k - nfr) * n + r];
+    pc[k] = x;
     d += (double)pc[k] * (double)pc[k];
   }
+  __syncthreads();   // the running factor has been read by every thread before any row of it is overwritten
 #pragma unroll
   for (int j = 0; j < CH_LR_CAP; ++j) rc[j] = 0.0;
   double md = d;
@@ -419,13 +432,15 @@ __global__ __launch_bounds__(NT, 2) void gram_chol_lowrank_kernel(const T *__res
   double fro = 0.0;
   for (int j = 0; j < nl; ++j) fro += s_nrm[j];
   const double nfloor = eT * eT * fro;
+  const double sc = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
   if (tid == 0) {
     int cnt = 0;
     for (int j = 0; j < nl; ++j) s_pos[j] = s_nrm[j] > nfloor ? (short)cnt++ : (short)-1;
-    mlive_out[blockIdx.x] = cnt;
+    // rows of P left after the last pass: the blocked path redoes this walker
+    mlive_out[blockIdx.x] = (last_pass && k0 + npr < Ktot) ? -1 : cnt;
+    if (scale_io) scale_io[blockIdx.x] = sc;
   }
   __syncthreads();
-  const double sc = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
 #pragma unroll
   for (int j = 0; j < CH_LR_CAP; ++j) {
     if (j < nl) {
@@ -435,18 +450,23 @@ __global__ __launch_bounds__(NT, 2) void gram_chol_lowrank_kernel(const T *__res
   }
 }
 
-// Both variants in sequence: 128 threads per walker where the data columns fit, 256 otherwise.
+// Both variants in sequence: 128 threads per walker where the data columns fit, 256 otherwise.  npass > 1
+// (kmax > KCAP with per-walker row counts): the rows of P are folded in over several passes, scale = [nbatch] doubles.
 template <typename T, int KCAP>
 inline void launch_gram_chol_lowrank(hipStream_t s, int nbatch, const T *P, long wP, int n, const int *kdyn, int kdyn_mul,
-                                     int kmax, T *R, long wR, int *mlive, int inner, const int *inner_live) {
+                                     int kmax, T *R, long wR, int *mlive, int inner, const int *inner_live,
+                                     int npass = 1, double *scale = nullptr) {
   static const bool no_narrow = getenv("PEPSGPU_NO_NARROW_FUSED") != nullptr;
   const bool narrow = !no_narrow && (inner_live != nullptr || n <= 128);
-  if (narrow)
-    hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP, 128>), dim3(nbatch), dim3(128), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
-                       R, wR, mlive, inner, inner_live, 0);
-  if (!narrow || n > 128)
-    hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP, 256>), dim3(nbatch), dim3(256), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
-                       R, wR, mlive, inner, inner_live, narrow ? 1 : 0);
+  for (int pass = 0, k0 = 0; pass < npass; ++pass, k0 += (pass == 1 ? KCAP : KCAP - CH_LR_CAP)) {
+    const int last = pass + 1 == npass;
+    if (narrow)
+      hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP, 128>), dim3(nbatch), dim3(128), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
+                         R, wR, mlive, inner, inner_live, 0, k0, last, scale);
+    if (!narrow || n > 128)
+      hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP, 256>), dim3(nbatch), dim3(256), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
+                         R, wR, mlive, inner, inner_live, narrow ? 1 : 0, k0, last, scale);
+  }
   PG_CHECK_HIP(hipGetLastError());
 }
 

@@ -228,13 +228,17 @@ def test_cholesky_rank_adaptive_pair(n, ranks, dt):
 
 
 @pytest.mark.parametrize("dt", ["f32", "f64"])
-@pytest.mark.parametrize("K,n,rank", [(80, 256, 10), (96, 256, 32), (64, 256, 33), (16, 144, 16), (7, 40, 3), (64, 256, 1)])
+@pytest.mark.parametrize("K,n,rank", [(80, 256, 10), (96, 256, 32), (64, 256, 33), (16, 144, 16), (7, 40, 3), (64, 256, 1),
+                                         (200, 256, 20), (288, 256, 28), (97, 200, 5), (300, 256, 10)])
 def test_gram_free_lowrank_factor(K, n, rank, dt):
     """gram_chol_lowrank_kernel: R^T R = P^T P straight from the K live rows of P (no Gram matrix in
     memory); declines (mlive = -1) when the rank exceeds its cap of 32."""
     capi = _capi()
-    if dt == "f64" and K > 48:
-        pytest.skip("f64 variant holds 48 rows of P per thread")
+    cap = 96 if dt == "f32" else 48
+    if K > cap + 3 * (cap - 32):                      # more rows than four passes fold in: declined
+        R, ml = capi.diag_gram_chol(capi.F32 if dt == "f32" else capi.F64, np.zeros((2, K, n)) + 1.0)
+        assert np.all(ml == -1)
+        return
     rng = np.random.default_rng(K + n + rank)
     nb = 5
     P = np.stack([rng.standard_normal((K, rank)) @ rng.standard_normal((rank, n)) for _ in range(nb)])
