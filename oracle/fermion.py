@@ -113,6 +113,13 @@ class SquareSpinlessFermionOBC:
     def __init__(self, t, t2=0.0, V=0.0):
         self.t, self.t2, self.V = t, t2, V
 
+    def bond(self, c1, c2, n1, n2):
+        """(diagonal energy, coefficient of conj(psi'/psi) for the exchanged configuration) of one NN bond"""
+        return self.V * n1 * n2, (-self.t if c1 != c2 else 0.0)
+
+    def onsite(self, cfg):
+        return 0.0
+
     def CalEnergy(self, fs, cfg, trun_para):
         from .bmps import LEFT, DOWN, RIGHT, UP, HORIZONTAL, VERTICAL
         cfg = np.asarray(cfg)
@@ -131,14 +138,15 @@ class SquareSpinlessFermionOBC:
             psis.append(c.Trace(tn, (row, 0), HORIZONTAL))
             for col in range(cols - 1):
                 s1, s2 = (row, col), (row, col + 1)
-                e += self.V * occ[s1] * occ[s2]
-                if cfg[s1] != cfg[s2]:
+                diag, off = self.bond(int(cfg[s1]), int(cfg[s2]), occ[s1], occ[s2])
+                e += diag
+                if off != 0.0:
                     psi = c.Trace(tn, s1, HORIZONTAL)
                     new = cfg.copy(); new[s1], new[s2] = cfg[s2], cfg[s1]
                     ne = fs.ext_config(new, ROW)
                     psi_ex = c.ReplaceNNSiteTrace(tn, s1, s2, HORIZONTAL, fs.ext[row][col][ne[s1]], fs.ext[row][col + 1][ne[s2]])
-                    e += -self.t * np.conj(psi_ex / psi)
-                c.ShiftBTenWindow(tn, RIGHT) if col < cols - 2 or True else None
+                    e += off * np.conj(psi_ex / psi)
+                c.ShiftBTenWindow(tn, RIGHT)
             if row < rows - 1:
                 c.ShiftBMPSWindow(tn, DOWN)
         # ---- column pass: vertical bonds (bond_traversal_mixin.h:113-144)
@@ -151,13 +159,14 @@ class SquareSpinlessFermionOBC:
             psis.append(c.Trace(tn, (0, col), VERTICAL))
             for row in range(rows - 1):
                 s1, s2 = (row, col), (row + 1, col)
-                e += self.V * occ[s1] * occ[s2]
-                if cfg[s1] != cfg[s2]:
+                diag, off = self.bond(int(cfg[s1]), int(cfg[s2]), occ[s1], occ[s2])
+                e += diag
+                if off != 0.0:
                     psi = c.Trace(tn, s1, VERTICAL)
                     new = cfg.copy(); new[s1], new[s2] = cfg[s2], cfg[s1]
                     ne = fs.ext_config(new, COL)
                     psi_ex = c.ReplaceNNSiteTrace(tn, s1, s2, VERTICAL, fs.ext[row][col][ne[s1]], fs.ext[row + 1][col][ne[s2]])
-                    e += -self.t * np.conj(psi_ex / psi)
+                    e += off * np.conj(psi_ex / psi)
                 if row < rows - 2:
                     c.ShiftBTenWindow(tn, DOWN)
             if col < cols - 1:
@@ -175,7 +184,26 @@ class SquareSpinlessFermionOBC:
                         jw = (-1) ** int(np.sum(flat[ia + 1:ib]))
                         new = cfg.copy(); new[a], new[b] = cfg[b], cfg[a]
                         e += -self.t2 * jw * np.conj(fs.amplitude(new, trun_para) / psi0)
-        return e, psis
+        return e + self.onsite(cfg), psis
+
+
+class SquaretJVModelOBC(SquareSpinlessFermionOBC):
+    """square_tJ_model.h:301-345 (SquaretJModelMixIn::EvaluateBondEnergy) + :215-228; states 0 up, 1 down, 2 empty
+    (vmc_basic/tj_single_site_state.h:19-23); H = -t sum (c+ c + h.c.) + J sum (S.S - n n / 4) + V sum n n - mu N"""
+
+    def __init__(self, t, t2, J, V, mu):
+        super().__init__(t, t2, V)
+        self.J, self.mu = J, mu
+
+    def bond(self, c1, c2, n1, n2):
+        if c1 == c2:
+            return (0.0 if c1 == 2 else self.V), 0.0
+        if c1 == 2 or c2 == 2:
+            return 0.0, -self.t
+        return -0.5 * self.J + self.V, 0.5 * self.J
+
+    def onsite(self, cfg):
+        return -self.mu * float(np.sum(np.asarray(cfg) != 2))
 
 
 def exact_sum_energy(fs, all_configs, trun_para, model):

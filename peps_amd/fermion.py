@@ -191,22 +191,45 @@ def evaluate_amplitude(ctx, state, configs):
     return state.sigma(configs) * ctx.evaluate_amplitude()
 
 
+def tj_energy(ctx, state, configs, t, J, V=0.0, mu=0.0):
+    """E_loc(S) of the t-J-V model (square_tJ_model.h:301-345 + :215-228; states 0 up, 1 down, 2 empty):
+    H = -t sum (c+ c + h.c.) + J sum (S.S - n n / 4) + V sum n n - mu N, nearest neighbours only (t2 = 0)."""
+    def bond(c1, c2):
+        same = c1 == c2
+        hole = (c1 == 2) | (c2 == 2)
+        diag = np.where(same, np.where(c1 == 2, 0.0, V), np.where(hole, 0.0, -0.5 * J + V))
+        off = np.where(same, 0.0, np.where(hole, -t, 0.5 * J))
+        return diag, off
+    e, psis = nn_energy(ctx, state, configs, bond)
+    return e - mu * np.sum(np.asarray(configs) != 2, axis=(1, 2)), psis
+
+
 def spinless_fermion_energy(ctx, state, configs, t, V=0.0):
-    """E_loc(S) of H = -t sum_<ij> (c+_i c_j + h.c.) + V sum_<ij> n_i n_j for every configuration of the batch
-    (square_spinless_fermion.h:134-159 inside the traversal of square_nnn_energy_solver.h:116-201 and
-    bond_traversal_mixin.h:113-144; the NNN pass of the reference multiplies by t2, which must be 0 here).
-    Returns (energy [n], psi_list [rows + cols][n])."""
+    """E_loc(S) of H = -t sum_<ij> (c+_i c_j + h.c.) + V sum_<ij> n_i n_j (square_spinless_fermion.h:134-159; the NNN
+    pass of the reference multiplies by t2, which must be 0 here).  Returns (energy [n], psi_list [rows + cols][n])."""
+    nf = state.nf
+    def bond(c1, c2):
+        return V * (nf[c1] % 2) * (nf[c2] % 2), np.where(c1 != c2, -t, 0.0)
+    return nn_energy(ctx, state, configs, bond)
+
+
+def nn_energy(ctx, state, configs, bond_fn):
+    """Nearest-neighbour local energy of a fermionic model for every configuration of the batch: the traversal of
+    square_nnn_energy_solver.h:116-201 / bond_traversal_mixin.h:113-144 with the fermion interface (psi recomputed
+    next to psi').  bond_fn(c1, c2) -> (diagonal energy, coefficient of psi(S with the two states exchanged)/psi(S)),
+    arrays over the batch.  Returns (energy [n], psi_list [rows + cols][n])."""
     from .capi import LEFT, DOWN, RIGHT, UP, HORIZONTAL, VERTICAL
     cfg = np.asarray(configs)
     n, rows, cols = cfg.shape
-    occ = (state.nf[cfg] % 2).astype(np.float64)
     e = np.zeros(n)
     psis = []
 
     def bond(s1, s2, orient, order, ext):
         (r1, c1), (r2, c2) = s1, s2
-        e_int = V * occ[:, r1, c1] * occ[:, r2, c2]
-        differ = cfg[:, r1, c1] != cfg[:, r2, c2]
+        e_int, off = bond_fn(cfg[:, r1, c1], cfg[:, r2, c2])
+        e_int = np.broadcast_to(np.asarray(e_int, dtype=np.float64), (n,))
+        off = np.broadcast_to(np.asarray(off, dtype=np.float64), (n,))
+        differ = off != 0.0
         if not differ.any():
             return e_int
         psi = ctx.trace(r1, c1, orient)                       # psi along the same path as psi' (sign consistency)
@@ -215,7 +238,7 @@ def spinless_fermion_energy(ctx, state, configs, t, V=0.0):
         ne = state.ext_config(new, order)
         cand = np.stack([ne[:, r1, c1], ne[:, r2, c2]], axis=-1)[:, None, :]
         psi_ex = ctx.replace_nn_trace(r1, c1, orient, cand)[:, 0]
-        return e_int + np.where(differ, -t * psi_ex / np.where(psi == 0, 1.0, psi), 0.0)
+        return e_int + np.where(differ, off * psi_ex / np.where(psi == 0, 1.0, psi), 0.0)
 
     ext = state.ext_config(cfg, ROW)
     ctx.set_configs(ext)

@@ -181,8 +181,9 @@ int pepshost_load_sitps(const char *dir, int D, int *rows, int *cols, int *d, do
 
 // Fermionic state (extended, sign-decorated components: peps_amd/fermion.py): E_loc of the spinless t-V model and
 // the amplitudes for a batch of physical configurations.  sitps_ext_flat has 4 * d components per site.
+// model 0: spinless t-V (params t, V); model 1: t-J-V (params t, J, V, mu)
 int pepshost_fermion_energy(int rows, int cols, int D, int d, const int32_t *nf, int chi, int dtype,
-                            const double *sitps_ext_flat, int n, const int32_t *configs, double t, double V,
+                            const double *sitps_ext_flat, int n, const int32_t *configs, int model, const double *prm,
                             double *amplitudes_out, double *energies_out, double *psi_out, int *n_psi_out) {
   return guarded([&]() {
     SplitIndexTPS sitps = make_state(rows, cols, D, 4 * d, sitps_ext_flat);
@@ -191,8 +192,14 @@ int pepshost_fermion_energy(int rows, int cols, int D, int d, const int32_t *nf,
     BMPSContractor contractor(rows, cols, D, 4 * d, BMPSTruncateParams::SVD(chi, chi, 0.0), n, dtype);
     TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor, &dec);
     std::copy(comp.amplitude.begin(), comp.amplitude.end(), amplitudes_out);
-    SquareSpinlessFermion model(t, V);
-    EnergyAndHoles eh = model.CalEnergyAndHoles<false>(sitps, comp);
+    EnergyAndHoles eh;
+    if (model == 0) {
+      SquareSpinlessFermion m(prm[0], prm[1]);
+      eh = m.CalEnergyAndHoles<false>(sitps, comp);
+    } else {
+      SquaretJVModel m(prm[0], 0.0, prm[1], prm[2], prm[3]);
+      eh = m.CalEnergyAndHoles<false>(sitps, comp);
+    }
     std::copy(eh.energy.begin(), eh.energy.end(), energies_out);
     if (n_psi_out) *n_psi_out = (int)eh.psi_list.size();
     if (psi_out)

@@ -876,6 +876,49 @@ class SquareSpinlessFermion : public SquareNNModelEnergySolver<SquareSpinlessFer
   double t_, t2_, V_;
 };
 
+// square_tJ_model.h:301-345 (SquaretJModelMixIn::EvaluateBondEnergy) + :215-228: states 0 up, 1 down, 2 empty
+// (vmc_basic/tj_single_site_state.h:19-23); H = -t sum (c+ c + h.c.) + J sum (S.S - n n / 4) + V sum n n - mu N.
+// NNN hopping t2 must be 0 on the device (see SquareSpinlessFermion).
+class SquaretJVModel : public SquareNNModelEnergySolver<SquaretJVModel> {
+ public:
+  SquaretJVModel(double t, double t2, double J, double V, double mu) : t_(t), J_(J), V_(V), mu_(mu) {
+    if (t2 != 0.0) throw std::invalid_argument("SquaretJVModel: t2 != 0 (NNN hopping) is not implemented on the device");
+  }
+  std::vector<double> EvaluateBondEnergy(const SiteIdx &s1, const SiteIdx &s2, BondOrientation orient,
+                                         TPSWaveFunctionComponent &comp, const std::vector<double> &) {
+    const size_t n = comp.config.walkers();
+    std::vector<int32_t> cand(n * 2);
+    std::vector<double> e(n, 0.0);
+    bool any = false;
+    for (size_t w = 0; w < n; ++w) {
+      const int32_t c1 = comp.config(w, s1), c2 = comp.config(w, s2);
+      cand[2 * w] = c2;
+      cand[2 * w + 1] = c1;
+      if (c1 == c2) e[w] = (c1 == 2) ? 0.0 : V_;            // both empty / parallel spins: sz sz - n n / 4 = 0   (:312-318)
+      else any = true;
+    }
+    if (!any) return e;
+    std::vector<double> psi = comp.contractor.Trace(s1, orient);
+    std::vector<double> psi_ex = comp.ReplaceNNSiteTrace(s1, s2, orient, 1, cand);
+    for (size_t w = 0; w < n; ++w) {
+      const int32_t c1 = comp.config(w, s1), c2 = comp.config(w, s2);
+      if (c1 == c2) continue;
+      const double ratio = psi_ex[w] / psi[w];
+      e[w] = (c1 == 2 || c2 == 2) ? -t_ * ratio : (-0.5 + 0.5 * ratio) * J_ + V_;      // :334-343
+    }
+    return e;
+  }
+  double EvaluateTotalOnsiteEnergy(const Configuration &config, size_t w) const {   // :215-228
+    if (mu_ == 0.0) return 0.0;
+    size_t ele = 0;
+    for (size_t r = 0; r < config.rows(); ++r)
+      for (size_t c = 0; c < config.cols(); ++c) ele += config(w, {r, c}) != 2;
+    return -mu_ * double(ele);
+  }
+ private:
+  double t_, J_, V_, mu_;
+};
+
 // transverse_field_ising_square_obc.h:28-247
 class TransverseFieldIsingSquareOBC {
  public:

@@ -195,3 +195,20 @@ def test_fermion_exact_sum_gradient_vs_finite_differences(fixtures_dir):
     assert checked == 6
     # parity-forbidden entries carry no gradient
     assert np.all(grad[0, 0, 0][np.abs(st.extended_flat()[0, 0, 0]) == 0] == 0)
+
+
+@pytest.mark.parametrize("name,e_ref", [("tj_model_tps_doublelowest", -2.9431635706137875),
+                                        ("tj_model_tps_double_from_simple_update", -2.78008187385)])
+def test_k4_tj_model_exact_sum_on_device(fixtures_dir, name, e_ref):
+    """2x2 t-J known answers (test_exact_summation_evaluator.cpp:795-990; three physical states per site, two odd)
+    with amplitudes and exchange / hop ratios from the device, Python path and C++ host layer."""
+    from peps_amd import capi, fermion, hostapi
+    st = fermion.FermionState.load(os.path.join(fixtures_dir, name))
+    cfgs = np.array([np.array(p).reshape(2, 2) for p in sorted(set(itertools.permutations([2, 2, 0, 1])))])
+    ctx = _ctx(st, 4, capi.F64, len(cfgs))
+    amp = fermion.evaluate_amplitude(ctx, st, cfgs)
+    e_loc, _ = fermion.tj_energy(ctx, st, cfgs, 1.0, 0.3, 0.075, 0.0)
+    w = amp ** 2
+    assert abs(np.sum(w * e_loc) / np.sum(w) - e_ref) < 1e-9
+    amps2, en2, _ = hostapi.fermion_energy(st, cfgs, 4, 1.0, 0.075, 1, "tj", 0.3, 0.0)
+    assert np.max(np.abs(amps2 - amp)) < 1e-12 * np.max(np.abs(amp)) and np.max(np.abs(en2 - e_loc)) < 1e-9

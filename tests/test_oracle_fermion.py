@@ -101,3 +101,16 @@ def test_decorated_dense_contraction_equals_graded_contraction(Ly, Lx, D):
         assert abs(fs.amplitude(cfg, tp, fermion.ROW) - g) < 1e-9 * scale
         assert abs(fs.amplitude(cfg, tp, fermion.COL) - fs.kappa(cfg) * g) < 1e-9 * scale
     assert n_nonzero == 2 ** (Ly * Lx - 1)
+
+
+@pytest.mark.parametrize("name,e_ref", [("tj_model_tps_doublelowest", -2.9431635706137875),
+                                        ("tj_model_tps_double_from_simple_update", -2.78008187385)])
+def test_tj_model_reference_energies(fixtures_dir, name, e_ref):
+    """2x2 t-J model (t = 1, J = 0.3, V = J/4, mu = 0; one up, one down, two holes): known answers of
+    test_exact_summation_evaluator.cpp:795-990 through the decorated BMPS path, SVD(4, 4)."""
+    gts = fermion.load_fermion_sitps(os.path.join(fixtures_dir, name))
+    fs = fermion.FermionSITPS(gts)
+    assert fs.d == 3 and fs.nf == [1, 1, 0]
+    cfgs = [np.array(p).reshape(2, 2) for p in sorted(set(itertools.permutations([2, 2, 0, 1])))]
+    e = fermion.exact_sum_energy(fs, cfgs, BMPSTruncateParams.SVD(4, 4, 0.0), fermion.SquaretJVModelOBC(1.0, 0.0, 0.3, 0.075, 0.0))
+    assert abs(e - e_ref) < 1e-10
