@@ -185,6 +185,9 @@ class Engine : public EngineBase {
     // live[b][w] (b = 0..N): number of non-zero states of bond b (between tensors b-1 and b) for
     // walker w; the tensors stay zero padded to their static shape.  nullptr = the static dimension.
     std::vector<int *> live;
+    // kmax[b] = max over the walkers of live[b] (host copy; -1 = unknown): the next absorption sizes the static
+    // shape of its new bond b from it instead of chi
+    std::vector<int> kmax;
   };
   struct BTenDev {
     DTen<T> t;
@@ -872,6 +875,7 @@ class Engine : public EngineBase {
   }
 
   void absorb(int pos, int num);
+  bool absorb_impl(int pos, int num, bool full_bonds);
   // ---- two-row environments and NNN / TNN / sqrt5 traces (engine_nnn.h) ----
   void clear_bten2(int pos, int keep) {
     auto &v = bten2_[pos];

@@ -63,8 +63,21 @@ void Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
 // (below the rounding of the T-typed data) and reports the live count per walker; every launch
 // that runs over the carry index m (X = R.A, P = X.W, the Gram's K index, M = R.T, the Jacobi)
 // takes that count as a per-walker dynamic extent.  Buffers keep their static (worst case) shape.
+// The new bonds get the static size chi unless the absorbed BMPS shows that far fewer states are alive
+// (bond b of the new BMPS sits above bond b of the absorbed one and grows by a few states per row): then the
+// static size is the previous row's maximum live count plus a margin.  After the absorption one small read-back
+// checks that no walker filled a shrunk bond; if one did, the absorption is repeated at full size (rare).
 template <typename T>
 void Engine<T>::absorb(int pos, int num) {
+  static const bool no_shrink = getenv("PEPSGPU_NO_BOND_SHRINK") != nullptr;
+  if (!absorb_impl(pos, num, no_shrink)) {
+    clear_bmps(pos, bmps_size(pos) - 1);
+    PG_REQUIRE(absorb_impl(pos, num, true), 5, "MultiplyMPO: internal error (full-size absorption reported clipping)");
+  }
+}
+
+template <typename T>
+bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds) {
   const int N = mps_len(pos);
   // copy of the tensor descriptors: push_back below may reallocate bmps_[pos]
   const std::vector<DTen<T>> cur = bmps_[pos].back().t;
@@ -76,6 +89,9 @@ void Engine<T>::absorb(int pos, int num) {
   clive.resize(N + 1, nullptr);
   if (!bond_adapt) std::fill(clive.begin(), clive.end(), nullptr);
   std::vector<int *> kn(N + 1, nullptr);
+  std::vector<int> cur_kmax = bmps_[pos].back().kmax;
+  cur_kmax.resize(N + 1, -1);
+  std::vector<int> kstat(N + 1, 0), kfull(N + 1, 0);   // static size chosen / full static size of each new bond
   PG_REQUIRE((int)cur.size() == N, 3, "MultiplyMPO: MPS/MPO length mismatch");
   auto site_rc = [&](int i, int &r, int &c) {
     switch (pos) {
@@ -342,7 +358,13 @@ void Engine<T>::absorb(int pos, int num) {
                   (double)sw_sum / nw_, (double)live / nw_);
       }
     }
-    const int k = std::min(chi_, std::min(m, uk));
+    const int k_full = std::min(chi_, std::min(m, uk));
+    int k = k_full;
+    if (!full_bonds && bond_adapt && cur_kmax[i] >= 0) {
+      const int want = cur_kmax[i] + std::max(2, cur_kmax[i] / 4);
+      k = std::min(k_full, (want + 3) & ~3);
+    }
+    kstat[i] = k; kfull[i] = k_full;
     PG_REQUIRE(m <= 1024, 1, "bond dimension too large for select_rows_kernel");
     DTen<T> V = alloc_ten(k, u, k2);
     prof_begin(PROF_SELECT, 0.0, 0.0);
@@ -385,8 +407,23 @@ void Engine<T>::absorb(int pos, int num) {
       if (p && p != last) { arena_.free(p); last = p; }
   }
   out.live = kn;
+  out.kmax.assign(N + 1, -1);
+  bool ok = true;
+  if (bond_adapt) {   // one small read-back per absorption: the maximum live count of every new bond
+    const int **dtab = (const int **)arena_.alloc(sizeof(int *) * (N + 1));
+    int *dmax = (int *)arena_.alloc(sizeof(int) * (N + 1));
+    PG_CHECK_HIP(hipMemcpyAsync(dtab, kn.data(), sizeof(int *) * (N + 1), hipMemcpyHostToDevice, stream_));
+    hipLaunchKernelGGL(max_over_walkers_kernel, dim3(N + 1), dim3(256), 0, stream_, (const int *const *)dtab, nw_, dmax);
+    PG_CHECK_HIP(hipGetLastError());
+    PG_CHECK_HIP(hipMemcpyAsync(out.kmax.data(), dmax, sizeof(int) * (N + 1), hipMemcpyDeviceToHost, stream_));
+    PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    arena_.free(dtab); arena_.free(dmax);
+    for (int i = 1; i < N; ++i)
+      if (kstat[i] < kfull[i] && out.kmax[i] >= kstat[i]) ok = false;   // a walker filled a shrunk bond: maybe clipped
+  }
   bmps_[pos].push_back(std::move(out));
-  ++n_absorb_;
+  if (ok) ++n_absorb_;
+  return ok;
 }
 
 }  // namespace pepsgpu

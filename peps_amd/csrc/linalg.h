@@ -718,6 +718,20 @@ __global__ __launch_bounds__(256) void normalize_kernel(T *__restrict__ Xg, long
   if (tid == 0 && logscale) logscale[blockIdx.x] += log(nrm);
 }
 
+// out[b] = max_w v[b][w]  (v[b] == nullptr: -1); one block per entry of the pointer table
+__global__ __launch_bounds__(256) void max_over_walkers_kernel(const int *const *__restrict__ tab, int nw, int *__restrict__ out) {
+  __shared__ int s_red[4];
+  const int *v = tab[blockIdx.x];
+  int m = -1;
+  if (v)
+    for (int w = threadIdx.x; w < nw; w += 256) m = max(m, v[w]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+}
+
 template <typename T>
 __global__ void fill_kernel(T *p, long n, T v) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__res
 // the number of memory requests, not bytes (each lane addresses its own row).
 // f32 in / f32 out.  Same descriptor semantics as tgemm_kernel (dynK is not supported here).
 template <bool AVEC, bool BVEC>
-__global__ __launch_bounds__(256) void tgemm_direct_kernel(TGemmDesc d, const float *__restrict__ Ag,
+__global__ __launch_bounds__(256, 6) void tgemm_direct_kernel(TGemmDesc d, const float *__restrict__ Ag,
                                                            const float *__restrict__ Bg, float *__restrict__ Cg) {
   __shared__ int offCi_s[4][32];
   const int b = blockIdx.z;
