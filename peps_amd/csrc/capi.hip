@@ -288,13 +288,10 @@ static void diag_gram_chol_t(const void *P, int K, int n, int nbatch, void *Rout
   PG_CHECK_HIP(hipMalloc(&dml, nbatch * sizeof(int)));
   PG_CHECK_HIP(hipMemcpy(dP, P, (size_t)K * n * nbatch * sizeof(T), hipMemcpyHostToDevice));
   PG_CHECK_HIP(hipMemset(dR, 0, (size_t)n * n * nbatch * sizeof(T)));
-  double *dsc = nullptr;
   const int npass = K > KCAP ? 4 : 1;          // the multi-pass use of the absorption when a pass cannot hold all rows
-  if (npass > 1) PG_CHECK_HIP(hipMalloc(&dsc, nbatch * sizeof(double)));
   launch_gram_chol_lowrank<T, KCAP>(0, nbatch, (const T *)dP, (long)K * n, n, (const int *)nullptr, 1, K, dR, (long)n * n, dml, 1,
-                                    (const int *)nullptr, npass, dsc);
+                                    (const int *)nullptr, npass);
   PG_CHECK_HIP(hipDeviceSynchronize());
-  if (dsc) (void)hipFree(dsc);
   PG_CHECK_HIP(hipDeviceSynchronize());
   PG_CHECK_HIP(hipMemcpy(Rout, dR, (size_t)n * n * nbatch * sizeof(T), hipMemcpyDeviceToHost));
   PG_CHECK_HIP(hipMemcpy(mlive, dml, nbatch * sizeof(int), hipMemcpyDeviceToHost));

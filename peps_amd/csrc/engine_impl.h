@@ -200,12 +200,10 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds) {
         // (covers K <= KCAP + 3 (KCAP - 32) rows); walkers beyond that, or of rank > 32, are flagged
         static const int max_pass = getenv("PEPSGPU_FUSED_PASSES") ? atoi(getenv("PEPSGPU_FUSED_PASSES")) : 4;
         const int npass = (mdyn[i] && rows > FUSED_KCAP) ? std::max(1, max_pass) : 1;
-        double *fscale = npass > 1 ? (double *)arena_.alloc(sizeof(double) * nw_) : nullptr;
         prof_begin(PROF_CHOL, 0.0, 0.0);
         launch_gram_chol_lowrank<T, FUSED_KCAP>(stream_, nw_, (const T *)P.p, P.n, cols, (const int *)mdyn[i], mmul[i] * u, rows,
-                                                R[i + 1].p, R[i + 1].n, ml, a2, (const int *)clive[i + 1], npass, fscale);
+                                                R[i + 1].p, R[i + 1].n, ml, a2, (const int *)clive[i + 1], npass);
         prof_end();
-        if (fscale) arena_.free(fscale);
       }
       if (clive[i + 1]) {   // the Gram GEMM reads whole rows: define the never-written columns (flagged walkers only)
         hipLaunchKernelGGL(zero_dead_cols_kernel<T>, dim3(nw_), dim3(256), 0, stream_, P.p, P.n, cols, (const int *)mdyn[i],

@@ -303,130 +303,136 @@ __global__ __launch_bounds__(NT, 2) void gram_chol_lowrank_kernel(const T *__res
                                                                 const int *__restrict__ kdyn, int kdyn_mul, int kmax,
                                                                 T *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
                                                                 int inner = 1, const int *__restrict__ inner_live = nullptr,
-                                                                int retry_only = 0, int k0 = 0, int last_pass = 1,
-                                                                double *__restrict__ scale_io = nullptr) {
-  // Multi-pass use (more live rows than a thread can hold): pass 0 factors the first KCAP rows of P, every later
-  // pass (k0 > 0) factors [running factor (<= CH_LR_CAP rows, read back from Rg) ; next KCAP - CH_LR_CAP rows of P].
-  // scale_io[b] carries the scale of the stored factor between passes.  A walker with K <= k0 is finished.
+                                                                int retry_only = 0, int max_pass = 1) {
+  // More live rows than a thread holds (moderate rank): the rows of P are folded in over several passes INSIDE the
+  // kernel -- pass 0 factors the first KCAP rows, every later pass factors [running factor (<= CH_LR_CAP rows, still
+  // in registers) ; next KCAP - CH_LR_CAP rows of P]; up to max_pass passes, beyond that the walker is declined.
   constexpr int NWV = NT / 64;
-  if (k0 == 0 && retry_only && mlive_out[blockIdx.x] != -2) return;
+  if (retry_only && mlive_out[blockIdx.x] != -2) return;
   // columns are (outer, inner) with `inner` fastest; inner_live[b] (optional) = live extent of the
   // inner index (live bond of the boundary MPS): columns beyond hold no data and are never read
   __shared__ __attribute__((aligned(16))) T s_pf[KCAP];   // column f of P
   __shared__ double s_rf[CH_LR_CAP];     // column f of the factor
-  __shared__ double s_red[NWV], s_nrm[CH_LR_CAP], s_part[2 * NWV];
+  __shared__ double s_red[2][NWV], s_nrm[CH_LR_CAP], s_part[2 * NWV];
   __shared__ int s_first[2][NWV];
   __shared__ short s_pos[CH_LR_CAP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Ktot = kdyn ? min(kmax, kdyn[blockIdx.x] * kdyn_mul) : kmax;
-  if (k0 == 0 && Ktot > KCAP && last_pass) {     // single-pass use: too many rows, decline
+  if (Ktot > KCAP + (max_pass - 1) * (KCAP - CH_LR_CAP)) {     // too many rows: decline
     if (tid == 0) mlive_out[blockIdx.x] = -1;
     return;
   }
-  if (k0 > 0 && (Ktot <= k0 || mlive_out[blockIdx.x] < 0)) return;   // finished in an earlier pass / already declined
-  const int nfr = k0 > 0 ? mlive_out[blockIdx.x] : 0;                 // rows of the running factor
-  const int npr = min(Ktot - k0, KCAP - (k0 > 0 ? CH_LR_CAP : 0));    // rows of P taken in this pass
-  const int K = nfr + npr;
   const T *P = Pg + (long)blockIdx.x * wP;
   T *Rout = Rg + (long)blockIdx.x * wR;
   // thread -> column: data columns (inner index below its live extent) packed in increasing order
   const int ilive = inner_live ? min(inner, inner_live[blockIdx.x]) : inner;
   const int ncols = (n / inner) * ilive;
   if (ncols > NT) {
-    if (tid == 0 && k0 == 0) mlive_out[blockIdx.x] = -2;
+    if (tid == 0) mlive_out[blockIdx.x] = -2;
     return;
   }
-  if (k0 > 0 && retry_only && ncols <= 128) return;   // the 128-thread variant took this walker in this pass
   const bool col_ok = tid < ncols;
   const int r = col_ok ? (tid / ilive) * inner + (tid % ilive) : n;
+  const double eT = NOISE_C * (double)Eps<T>::v;
   T pc[KCAP];
   double rc[CH_LR_CAP];                   // own column of the factor (f64: pivots near the threshold amplify its rounding)
-  double d = 0.0;
-  const double unscale = (k0 > 0 && scale_io) ? 1.0 / scale_io[blockIdx.x] : 1.0;
-#pragma unroll
-  for (int k = 0; k < KCAP; ++k) {
-    T x = T(0);
-    if (k < K && col_ok) x = k < nfr ? T((double)Rout[(long)k * n + r] * unscale) : P[(long)(k0 + k - nfr) * n + r];
-    pc[k] = x;
-    d += (double)pc[k] * (double)pc[k];
-  }
-  __syncthreads();   // the running factor has been read by every thread before any row of it is overwritten
 #pragma unroll
   for (int j = 0; j < CH_LR_CAP; ++j) rc[j] = 0.0;
-  double md = d;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
-  if (lane == 0) s_red[wave] = md;
-  __syncthreads();
-  double maxd = s_red[0];
-#pragma unroll
-  for (int q = 1; q < NWV; ++q) maxd = fmax(maxd, s_red[q]);
-  const double eT = NOISE_C * (double)Eps<T>::v;
-  const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
-  int nl = 0, f = -1;
+  int nl = 0, step = 0, k0 = 0, pass = 0;
+  double maxd = 0.0;
 #pragma unroll 1
-  for (int step = 0;; ++step) {
-    int cand = (r < n && r > f && d > thresh) ? r : 0x7fffffff;
+  for (;; ++pass) {
+    const int nfr = nl;                                                    // rows of the running factor
+    const int npr = min(Ktot - k0, KCAP - (pass > 0 ? CH_LR_CAP : 0));    // rows of P taken in this pass
+    const int K = nfr + npr;
+    double d = 0.0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
-    if (lane == 0) s_first[step & 1][wave] = cand;
+    for (int k = 0; k < KCAP; ++k) {
+      T x = T(0);
+      if (k < CH_LR_CAP && k < nfr) x = T(rc[k < CH_LR_CAP ? k : 0]);
+      else if (k < K && col_ok) x = P[(long)(k0 + k - nfr) * n + r];
+      pc[k] = x;
+      d += (double)pc[k] * (double)pc[k];
+    }
+#pragma unroll
+    for (int j = 0; j < CH_LR_CAP; ++j) rc[j] = 0.0;
+    double md = d;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
+    if (lane == 0) s_red[pass & 1][wave] = md;
     __syncthreads();
-    // squared norm of the row finished in the previous step (partials written before the barrier)
-    if (tid == 0 && nl > 0) {
-      double a = 0.0;
+    maxd = s_red[pass & 1][0];
 #pragma unroll
-      for (int q = 0; q < NWV; ++q) a += s_part[NWV * ((step + 1) & 1) + q];
-      s_nrm[nl - 1] = a;
-    }
-    f = s_first[step & 1][0];
+    for (int q = 1; q < NWV; ++q) maxd = fmax(maxd, s_red[pass & 1][q]);
+    const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
+    int f = -1;
+    nl = 0;
+#pragma unroll 1
+    for (;; ++step) {
+      int cand = (r < n && r > f && d > thresh) ? r : 0x7fffffff;
 #pragma unroll
-    for (int q = 1; q < NWV; ++q) f = min(f, s_first[step & 1][q]);
-    if (f == 0x7fffffff || nl >= K) break;   // the rank cannot exceed the K rows of P: later pivots are rounding noise
-    if (nl == CH_LR_CAP) {                 // rank above the cap: the blocked path redoes this walker
-      if (tid == 0) mlive_out[blockIdx.x] = -1;
-      return;
-    }
-    if (r == f) {                          // the owner of the pivot column publishes it
+      for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+      if (lane == 0) s_first[step & 1][wave] = cand;
+      __syncthreads();
+      // squared norm of the row finished in the previous step (partials written before the barrier)
+      if (tid == 0 && nl > 0) {
+        double a = 0.0;
 #pragma unroll
-      for (int k = 0; k < KCAP; ++k) s_pf[k] = pc[k];
-#pragma unroll
-      for (int j = 0; j < CH_LR_CAP; ++j) s_rf[j] = rc[j];
-    }
-    __syncthreads();
-    double g = 0.0, piv = 0.0;             // g = G[f, r] - sum_j R[j,f] R[j,r];  piv likewise for r = f
-#pragma unroll
-    for (int kb = 0; kb < KCAP; kb += 16) {
-      if (kb >= K) break;
-      asm volatile("" ::: "memory");         // keep the LDS reads of later chunks from being hoisted (register pressure)
-      T pfv[16];                             // one batch of LDS reads, then the arithmetic
-#pragma unroll
-      for (int k = 0; k < 16; ++k) pfv[k] = s_pf[kb + k];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const double pf = (double)pfv[k];
-        T pk = pc[kb + k];
-        asm volatile("" : "+v"(pk));         // opaque copy: keeps the T -> f64 conversion of the (loop-invariant)
-                                             // column inside the step loop instead of 2*KCAP live registers
-        g = fma(pf, (double)pk, g);
-        piv = fma(pf, pf, piv);
+        for (int q = 0; q < NWV; ++q) a += s_part[NWV * ((step + 1) & 1) + q];
+        s_nrm[nl - 1] = a;
       }
-    }
+      f = s_first[step & 1][0];
 #pragma unroll
-    for (int j = 0; j < CH_LR_CAP; ++j) {
-      if (j < nl) {
-        const double rf = s_rf[j];
-        g = fma(-rf, rc[j], g);
-        piv = fma(-rf, rf, piv);
+      for (int q = 1; q < NWV; ++q) f = min(f, s_first[step & 1][q]);
+      if (f == 0x7fffffff || nl >= K) { ++step; break; }   // the rank cannot exceed the K rows: later pivots are rounding noise
+      if (nl == CH_LR_CAP) {                 // rank above the cap: the blocked path redoes this walker
+        if (tid == 0) mlive_out[blockIdx.x] = -1;
+        return;
       }
-    }
-    const double v = (r >= f && r < n) ? g / sqrt(piv) : 0.0;
+      if (r == f) {                          // the owner of the pivot column publishes it
 #pragma unroll
-    for (int j = 0; j < CH_LR_CAP; ++j) rc[j] = (j == nl) ? v : rc[j];
-    const double v2 = v * v;
-    if (r > f) d -= v2;
-    const double a = wave_sum(v2);
-    if (lane == 0) s_part[NWV * (step & 1) + wave] = a;
-    ++nl;
+        for (int k = 0; k < KCAP; ++k) s_pf[k] = pc[k];
+#pragma unroll
+        for (int j = 0; j < CH_LR_CAP; ++j) s_rf[j] = rc[j];
+      }
+      __syncthreads();
+      double g = 0.0, piv = 0.0;             // g = G[f, r] - sum_j R[j,f] R[j,r];  piv likewise for r = f
+#pragma unroll
+      for (int kb = 0; kb < KCAP; kb += 16) {
+        if (kb >= K) break;
+        asm volatile("" ::: "memory");         // keep the LDS reads of later chunks from being hoisted (register pressure)
+        T pfv[16];                             // one batch of LDS reads, then the arithmetic
+#pragma unroll
+        for (int k = 0; k < 16; ++k) pfv[k] = s_pf[kb + k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const double pf = (double)pfv[k];
+          T pk = pc[kb + k];
+          asm volatile("" : "+v"(pk));         // opaque copy: keeps the T -> f64 conversion of the (loop-invariant)
+                                               // column inside the step loop instead of 2*KCAP live registers
+          g = fma(pf, (double)pk, g);
+          piv = fma(pf, pf, piv);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CH_LR_CAP; ++j) {
+        if (j < nl) {
+          const double rf = s_rf[j];
+          g = fma(-rf, rc[j], g);
+          piv = fma(-rf, rf, piv);
+        }
+      }
+      const double v = (r >= f && r < n) ? g / sqrt(piv) : 0.0;
+#pragma unroll
+      for (int j = 0; j < CH_LR_CAP; ++j) rc[j] = (j == nl) ? v : rc[j];
+      const double v2 = v * v;
+      if (r > f) d -= v2;
+      const double a = wave_sum(v2);
+      if (lane == 0) s_part[NWV * (step & 1) + wave] = a;
+      ++nl;
+    }
+    k0 += npr;
+    if (k0 >= Ktot) break;
   }
   __syncthreads();
   double fro = 0.0;
@@ -436,9 +442,7 @@ __global__ __launch_bounds__(NT, 2) void gram_chol_lowrank_kernel(const T *__res
   if (tid == 0) {
     int cnt = 0;
     for (int j = 0; j < nl; ++j) s_pos[j] = s_nrm[j] > nfloor ? (short)cnt++ : (short)-1;
-    // rows of P left after the last pass: the blocked path redoes this walker
-    mlive_out[blockIdx.x] = (last_pass && k0 + npr < Ktot) ? -1 : cnt;
-    if (scale_io) scale_io[blockIdx.x] = sc;
+    mlive_out[blockIdx.x] = cnt;
   }
   __syncthreads();
 #pragma unroll
@@ -450,23 +454,19 @@ __global__ __launch_bounds__(NT, 2) void gram_chol_lowrank_kernel(const T *__res
   }
 }
 
-// Both variants in sequence: 128 threads per walker where the data columns fit, 256 otherwise.  npass > 1
-// (kmax > KCAP with per-walker row counts): the rows of P are folded in over several passes, scale = [nbatch] doubles.
+// Both variants in sequence: 128 threads per walker where the data columns fit, 256 otherwise.
 template <typename T, int KCAP>
 inline void launch_gram_chol_lowrank(hipStream_t s, int nbatch, const T *P, long wP, int n, const int *kdyn, int kdyn_mul,
                                      int kmax, T *R, long wR, int *mlive, int inner, const int *inner_live,
-                                     int npass = 1, double *scale = nullptr) {
+                                     int max_pass = 1) {
   static const bool no_narrow = getenv("PEPSGPU_NO_NARROW_FUSED") != nullptr;
   const bool narrow = !no_narrow && (inner_live != nullptr || n <= 128);
-  for (int pass = 0, k0 = 0; pass < npass; ++pass, k0 += (pass == 1 ? KCAP : KCAP - CH_LR_CAP)) {
-    const int last = pass + 1 == npass;
-    if (narrow)
-      hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP, 128>), dim3(nbatch), dim3(128), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
-                         R, wR, mlive, inner, inner_live, 0, k0, last, scale);
-    if (!narrow || n > 128)
-      hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP, 256>), dim3(nbatch), dim3(256), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
-                         R, wR, mlive, inner, inner_live, narrow ? 1 : 0, k0, last, scale);
-  }
+  if (narrow)
+    hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP, 128>), dim3(nbatch), dim3(128), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
+                       R, wR, mlive, inner, inner_live, 0, max_pass);
+  if (!narrow || n > 128)
+    hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP, 256>), dim3(nbatch), dim3(256), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
+                       R, wR, mlive, inner, inner_live, narrow ? 1 : 0, max_pass);
   PG_CHECK_HIP(hipGetLastError());
 }
 
