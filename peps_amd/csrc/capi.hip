@@ -332,7 +332,10 @@ static void diag_jacobi_t(void *M, int m, int len, int nbatch, int k, void *Vt, 
     int *dm;
     PG_CHECK_HIP(hipMalloc(&dm, nbatch * sizeof(int)));
     PG_CHECK_HIP(hipMemcpy(dm, hm.data(), nbatch * sizeof(int), hipMemcpyHostToDevice));
-    if (m <= JR_BR)     // the absorption sends <= 16 rows to the tiny kernel, 17..32 to the small one
+    if (m <= JR_BR && len <= 128)     // as the absorption: short rows -> two walkers per wave
+      hipLaunchKernelGGL(jacobi_rows_tiny2_kernel, dim3((nbatch + 7) / 8), dim3(256), 0, 0, (float *)dM, (long)m * len, m, len,
+                         len, 40, dsw, (const int *)dm, 1, nbatch);
+    else if (m <= JR_BR)     // <= 16 rows -> tiny kernel, 17..32 -> small kernel
       hipLaunchKernelGGL(jacobi_rows_tiny_kernel, dim3((nbatch + 3) / 4), dim3(256), 0, 0, (float *)dM, (long)m * len, m, len,
                          len, 40, dsw, (const int *)dm, 1, nbatch);
     else

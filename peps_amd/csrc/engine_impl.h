@@ -33,8 +33,13 @@ void Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
       small = 1;
       static const bool no_tiny = getenv("PEPSGPU_NO_TINYJACOBI") != nullptr;
       if (!no_tiny) {   // walkers with <= 16 rows first (low register count: all of them resident at once)
-        hipLaunchKernelGGL(jacobi_rows_tiny_kernel, dim3((nw_ + 3) / 4), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
-                           sweeps_, mdyn, mdyn_mul, nw_);
+        static const bool no_tiny2 = getenv("PEPSGPU_NO_TINY2JACOBI") != nullptr;
+        if (len <= 128 && !no_tiny2)   // short rows (shrunk bonds): two walkers per wave
+          hipLaunchKernelGGL(jacobi_rows_tiny2_kernel, dim3((nw_ + 7) / 8), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
+                             sweeps_, mdyn, mdyn_mul, nw_);
+        else
+          hipLaunchKernelGGL(jacobi_rows_tiny_kernel, dim3((nw_ + 3) / 4), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
+                             sweeps_, mdyn, mdyn_mul, nw_);
         PG_CHECK_HIP(hipGetLastError());
         if (m <= JR_BR) return;
       }

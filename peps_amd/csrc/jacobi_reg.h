@@ -480,4 +480,94 @@ __global__ __launch_bounds__(256, 3) void jacobi_rows_tiny_kernel(float *__restr
   if (lane == 0 && sweeps_out) sweeps_out[walker] = sweep | (mm << 8);
 }
 
+
+// Two walkers per wave: with shrunk bonds the rows are short (len <= 128 = 32 lanes x 4), so each half-wave
+// holds one walker's block of 16 rows; dot products reduce over 32 lanes (no permlane32 step).  Everything per
+// row (norms, rotation parameters) is per half-wave; the loops are wave-uniform and run until both walkers
+// have converged (a converged walker only sees identity rotations).
+__device__ __forceinline__ float jr_allsum32(float v) {
+  v = jr_dpp_add<0xB1>(v);
+  v = jr_dpp_add<0x4E>(v);
+  v = jr_dpp_add<0x141>(v);
+  v = jr_dpp_add<0x140>(v);
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto p = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)p[0]) + __builtin_bit_cast(float, (unsigned)p[1]);
+}
+
+template <int NB>
+__device__ __forceinline__ int jr_intra32(JrRow (&a)[JR_BR], float (&na)[JR_BR], const float tol2, const float floor2) {
+  int rot = 0;
+#pragma unroll 1
+  for (int r = 0; r < NB - 1; ++r) {
+    float ga[NB / 2];
+#pragma unroll
+    for (int p = 0; p < NB / 2; ++p) ga[p] = jr_allsum32(jr_dot(a[p], a[NB - 1 - p]));
+#pragma unroll
+    for (int p = 0; p < NB / 2; ++p) rot += jr_apply(a[p], a[NB - 1 - p], na[p], na[NB - 1 - p], ga[p], tol2, floor2);
+    const JrRow ta = a[NB - 1];
+    const float fa = na[NB - 1];
+#pragma unroll
+    for (int i = NB - 1; i >= 2; --i) { a[i] = a[i - 1]; na[i] = na[i - 1]; }
+    a[1] = ta; na[1] = fa;
+  }
+  return rot;
+}
+
+__global__ __launch_bounds__(256, 3) void jacobi_rows_tiny2_kernel(float *__restrict__ Mg, long wM, int m, int len, int ld,
+                                                                   int max_sweeps, int *__restrict__ sweeps_out,
+                                                                   const int *__restrict__ mdyn, int mdyn_mul, int nwalkers) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+  const int walker = blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + half;
+  const bool have = walker < nwalkers;
+  int mm = have ? (mdyn ? min(m, mdyn[walker] * mdyn_mul) : m) : 0;
+  if (mm > JR_BR) mm = 0;                                     // the 32-row / 8-wave kernels take this walker
+  const int mm_max = max(mm, __shfl_xor(mm, 32, 64));         // wave-uniform
+  if (mm_max == 0) return;
+  float *M = Mg + (long)(have ? walker : 0) * wM;
+  JrRow a[JR_BR];
+  float na[JR_BR];
+  float fro = 0.f;
+#pragma unroll
+  for (int i = 0; i < JR_BR; ++i) {
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 4 * l32 + q;
+      v[q] = (i < mm && c < len) ? M[(long)i * ld + c] : 0.f;
+    }
+    a[i].lo = jr_f2{v[0], v[1]};
+    a[i].hi = jr_f2{v[2], v[3]};
+  }
+#pragma unroll
+  for (int i = 0; i < JR_BR; ++i) {
+    na[i] = jr_allsum32(jr_dot(a[i], a[i]));
+    fro += na[i];
+  }
+  const float floor2 = (float)(NOISE_C * NOISE_C * (double)Eps<float>::v * (double)Eps<float>::v) * fro;
+  const float tol2 = 4.f * (float)len * Eps<float>::v * Eps<float>::v;
+  int sweep = 0;
+  for (; sweep < max_sweeps; ++sweep) {
+    if (sweep) {
+#pragma unroll
+      for (int i = 0; i < JR_BR; ++i) na[i] = jr_allsum32(jr_dot(a[i], a[i]));
+    }
+    int rot;
+    if (mm_max <= 8) rot = jr_intra32<8>(a, na, tol2, floor2);
+    else if (mm_max <= 12) rot = jr_intra32<12>(a, na, tol2, floor2);
+    else rot = jr_intra32<JR_BR>(a, na, tol2, floor2);
+    if (!__any(rot != 0)) { ++sweep; break; }
+  }
+#pragma unroll
+  for (int i = 0; i < JR_BR; ++i) {
+    const float v[4] = {a[i].lo.x, a[i].lo.y, a[i].hi.x, a[i].hi.y};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 4 * l32 + q;
+      if (i < mm && c < len) M[(long)i * ld + c] = v[q];
+    }
+  }
+  if (l32 == 0 && mm > 0 && sweeps_out) sweeps_out[walker] = sweep | (mm << 8);
+}
+
 }  // namespace pepsgpu

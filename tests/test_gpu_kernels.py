@@ -178,7 +178,8 @@ def test_jacobi_register_kernel_matches_generic(shape):
             assert np.max(np.abs(Vb.T @ Vb - Pref.T @ Pref)) < 2e-3
 
 
-@pytest.mark.parametrize("shape", [(32, 256), (16, 256), (8, 256), (5, 200), (9, 256), (12, 256), (13, 77), (20, 131), (1, 64)])
+@pytest.mark.parametrize("shape", [(32, 256), (16, 256), (8, 256), (5, 200), (9, 256), (12, 256), (13, 77), (20, 131), (1, 64),
+                                   (10, 96), (16, 128), (7, 50), (12, 127)])
 def test_jacobi_small_rank_kernel(shape):
     """One-wave-per-walker Jacobi (jacobi_rows_small_kernel, carries with <= 32 existing rows):
     singular values and dominant subspace against LAPACK, several walkers per workgroup."""
