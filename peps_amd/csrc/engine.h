@@ -100,8 +100,7 @@ class Engine : public EngineBase {
         maxw_(max_walkers) {
     PG_REQUIRE(Ly >= 2 && Lx >= 2, 1, "lattice must be at least 2x2");
     PG_REQUIRE(D >= 1 && dphys >= 1 && chi_max >= 1 && max_walkers >= 1, 1, "bad dimensions");
-    PG_REQUIRE(trunc_err == 0.0, 1,
-               "only trunc_err == 0 (fixed bond dimension D_max) is implemented on the device");
+    PG_REQUIRE(trunc_err >= 0.0 && trunc_err < 1.0, 1, "trunc_err must be in [0, 1)");
     PG_CHECK_HIP(hipSetDevice(device));
     device_ = device;
     PG_CHECK_HIP(hipStreamCreate(&stream_));

@@ -373,7 +373,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds) {
     prof_begin(PROF_SELECT, 0.0, 0.0);
     if (bond_adapt) kn[i] = (int *)arena_.alloc(sizeof(int) * nw_);
     hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)M.p, M.n, m, uk, uk, k, V.p,
-                       V.n, (T *)nullptr, 0L, (const int *)mdyn[i], mmul[i], kn[i]);
+                       V.n, (T *)nullptr, 0L, (const int *)mdyn[i], mmul[i], kn[i], trunc_err_, chi_min_, (double *)nullptr);
     PG_CHECK_HIP(hipGetLastError());
     prof_end();
     free_ten(M);

@@ -643,11 +643,13 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const T *__restrict__ 
                                                           int ld, int k, T *__restrict__ Vg, long wV,
                                                           T *__restrict__ Sg, long wS,
                                                           const int *__restrict__ mdyn, int mdyn_mul,
-                                                          int *__restrict__ klive_out = nullptr) {
+                                                          int *__restrict__ klive_out = nullptr,
+                                                          double trunc_err = 0.0, int dmin = 0,
+                                                          double *__restrict__ err_out = nullptr) {
   __shared__ double s_norm[1024];
   __shared__ int s_rank[1024];
-  __shared__ int s_klive;
-  if (threadIdx.x == 0) s_klive = 0;
+  __shared__ int s_klive, s_kcut;
+  if (threadIdx.x == 0) { s_klive = 0; s_kcut = k; }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T *M = Mg + (long)blockIdx.x * wM;
   T *V = Vg + (long)blockIdx.x * wV;
@@ -676,9 +678,35 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const T *__restrict__ 
   double fro2 = 0.0;
   for (int q = 0; q < m; ++q) fro2 += s_norm[q] * s_norm[q];
   const double nfloor = NOISE_C * (double)Eps<T>::v * sqrt(fro2);
+  if (trunc_err > 0.0 || err_out) {
+    // qlten::SVD(trunc_err, Dmin, Dmax) as bmps_impl.h:235-238 calls it: singular values go from the
+    // smallest while more than Dmax are kept, or more than Dmin and the discarded weight / total weight
+    // stays below trunc_err (oracle/tensor.py truncation_rank; the rule itself lives in TensorToolkit).
+    __shared__ double s_sorted[1024];
+    for (int r = tid; r < m; r += 256) s_sorted[s_rank[r]] = s_norm[r];
+    __syncthreads();
+    if (tid == 0) {
+      int kept = m;
+      double err = 0.0;
+      while (kept > 0) {
+        if (kept <= dmin && kept <= k) break;
+        const double w = fro2 > 0.0 ? s_sorted[kept - 1] * s_sorted[kept - 1] / fro2 : 0.0;
+        if (kept > k || (kept > dmin && err + w < trunc_err)) { err += w; --kept; }
+        else break;
+      }
+      s_kcut = max(kept, 1);
+      if (err_out) err_out[blockIdx.x] = err;
+    }
+    __syncthreads();
+    // rows of Vt between the kept count and k are zero
+    const int kc = s_kcut;
+    for (int e = tid + kc * len; e < min(m, k) * len; e += 256) V[e] = T(0);
+    if (Sg) for (int r = kc + tid; r < min(m, k); r += 256) Sg[(long)blockIdx.x * wS + r] = T(0);
+  }
+  const int kcut = s_kcut;
   for (int r = wave; r < m; r += 4) {
     int rk = s_rank[r];
-    if (rk >= k) continue;
+    if (rk >= kcut) continue;
     double nv = s_norm[r];
     T inv = nv > nfloor ? T(1.0 / nv) : T(0);   // numerically zero direction -> zero row of Vt
     for (int c = lane; c < len; c += 64) V[(long)rk * len + c] = M[(long)r * ld + c] * inv;

@@ -352,3 +352,39 @@ def test_rectangular_lattices(Ly, Lx, dt):
         t = sitps[r0][c0][cfg[r0, c0]]
         h = hole[w][tuple(slice(0, k) for k in t.shape)]
         assert abs(np.sum(h * t) / ref - 1) < TOL[dt] * 10
+
+
+@pytest.mark.parametrize("dt,terr,tol", [("f64", 1e-6, 1e-9), ("f64", 1e-3, 1e-9), ("f32", 1e-6, 2e-3)])
+def test_truncation_by_error_dmin_dmax(dt, terr, tol):
+    """BMPSTruncateParams::SVD(D_min, D_max, trunc_err > 0) (bmps.h:47-98, qlten::SVD truncation at
+    bmps_impl.h:235-238): the kept bond dimension is chosen per walker and per bond from the discarded
+    weight; the device keeps the tensors zero padded to D_max.  Amplitudes and the kept dimensions of
+    every bond of the DOWN stack agree with the oracle run with the same parameters."""
+    from peps_amd import capi
+    L, D, dmin, dmax = 6, 4, 2, 16
+    sitps = synthetic.make_sitps(L, D, noise=0.3)
+    cfgs = synthetic.make_configs(L, 5, "heisenberg")
+    tp = BMPSTruncateParams.SVD(dmin, dmax, terr)
+    comps = [vmc.TPSWaveFunctionComponent(sitps, c, tp) for c in cfgs]
+    ref = np.array([c.amplitude for c in comps])
+    fixed = _oracle_amps(sitps, cfgs, dmax)
+    assert np.max(np.abs(ref / fixed - 1)) > 10 * tol or dt == "f32"   # the error rule does truncate more than D_max alone
+    ctx = capi.Context(L, L, D, 2, dmax, dtype=capi.F32 if dt == "f32" else capi.F64, max_walkers=len(cfgs),
+                       chi_min=dmin, trunc_err=terr)
+    _upload(ctx, sitps, D)
+    ctx.set_configs(cfgs)
+    got = ctx.evaluate_amplitude()
+    assert np.all(ctx.walker_flags() == 0)
+    assert np.max(np.abs(got / ref - 1)) < tol, (got, ref)
+    if dt == "f64":
+        n_down = ctx.bmps_stack_size(DOWN)
+        assert n_down == L
+        for level in range(1, n_down):
+            for idx in range(L):
+                data, _ = ctx.get_bmps_tensor(DOWN, level, idx)
+                for w, comp in enumerate(comps):
+                    t_ref = comp.contractor.bmps_set[DOWN][level].tensors[idx]
+                    kept_l = int(np.sum(np.any(data[w] != 0, axis=(1, 2))))
+                    kept_r = int(np.sum(np.any(data[w] != 0, axis=(0, 1))))
+                    assert (kept_l, kept_r) == (t_ref.shape[0], t_ref.shape[2]), (level, idx, w)
+        assert any(t.shape[0] < min(dmax, D ** 3) for c in comps for t in c.contractor.bmps_set[DOWN][3].tensors[1:])
