@@ -161,7 +161,8 @@ class BMPSContractor:
         """grow.h:19-30"""
         p = self.GetTruncateParams()
         s = self.bmps_set[position]
-        s.append(s[-1].multiply_mpo(mpo, p.compress_scheme, p.D_min, p.D_max, p.trunc_err))
+        s.append(s[-1].multiply_mpo(mpo, p.compress_scheme, p.D_min, p.D_max, p.trunc_err,
+                                    p.convergence_tol, p.iter_max))
         return len(s)
 
     def GrowBMPSStep(self, tn, position):

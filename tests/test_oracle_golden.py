@@ -219,3 +219,66 @@ def test_sr_oracle_matches_dense_algebra():
     g = rng.standard_normal(m)
     x, res, it = sr.conjugate_gradient(lambda y: S * y, g, np.zeros(m), 200, 1e-12)
     assert np.max(np.abs(x - np.linalg.solve(dense, g))) < 1e-8
+
+
+@pytest.mark.parametrize("scheme", ["Variational2Site", "Variational1Site"])
+def test_k1_ising_all_21_routes_variational(scheme):
+    """test_bmps_contractor.cpp:472-486: the same 21 routes with Variational2Site(10,30,1e-15,1e-14,10)
+    and Variational1Site(10,30,1e-15,1e-14,10) (bmps_impl.h:864-1172), tolerance 1e-8."""
+    import k1_routes
+    tn, lognorm, beta = ising.build_ising_tn(12, 12)
+    f_ex = ising.exact_free_energy(12, 12, 1.0 / beta)
+    c = BMPSContractor(12, 12)
+    c.Init(tn)
+    c.SetTruncateParams(getattr(BMPSTruncateParams, scheme)(10, 30, 1e-15, 1e-14, 10))
+    amps = k1_routes.run_oracle(c, tn)
+    assert len(amps) == k1_routes.N_AMPS
+    for a in amps:
+        assert abs(-(np.log(a) + lognorm) / 144 / beta - f_ex) < 1e-8
+
+
+def _mps_to_dense(tensors):
+    v = tensors[0]
+    for t in tensors[1:]:
+        v = np.tensordot(v, t, axes=([v.ndim - 1], [0]))
+    return v.reshape(-1)
+
+
+@pytest.mark.parametrize("pos", [0, 1, 2, 3])
+def test_variational_compression_is_at_least_as_close_as_its_initial_guess(pos):
+    """Property of MultiplyMPO{2,1}SiteVariationalCompress_: the alternating sweeps can only lower the distance
+    to the exact product BMPS x MPO, starting from MakeVariationalInitGuess_ (bmps_impl.h:1174-1212); at
+    D_max >= the exact bond dimension all three schemes return the exact product."""
+    from oracle import bmps as ob
+    from peps_amd import synthetic
+    L, D = 5, 3
+    sitps = synthetic.make_sitps(L, D, noise=0.5)
+    cfg = synthetic.make_configs(L, 1, "heisenberg")[0]
+    from oracle.contractor import TensorNetwork2D
+    tn = TensorNetwork2D.from_sitps(sitps, cfg)
+    c = BMPSContractor(L, L)
+    c.Init(tn)
+    c.SetTruncateParams(BMPSTruncateParams.SVD(D * D, D * D, 0.0))
+    c.GrowBMPSStep(tn, pos)                                   # exact first row: bond D
+    mps = c.bmps_set[pos][-1]
+    if pos in (1, 3):
+        num = 1 if pos == 3 else L - 2
+        mpo = [tn((num, k)) for k in range(L)]
+    else:
+        num = 1 if pos == 0 else L - 2
+        mpo = [tn((k, num)) for k in range(L)]
+    exact = mps.multiply_mpo(mpo, ob.SVD_COMPRESS, D * D, D * D, 0.0)
+    ex = _mps_to_dense(exact.tensors)
+    chi = 4
+    rev = list(reversed(mpo)) if pos > 1 else list(mpo)
+    init = mps._variational_init_guess(rev, chi, chi, 0.0)
+    d_init = np.linalg.norm(_mps_to_dense(init.tensors) - ex)
+    svd = mps.multiply_mpo(mpo, ob.SVD_COMPRESS, chi, chi, 0.0)
+    d_svd = np.linalg.norm(_mps_to_dense(svd.tensors) - ex)
+    for scheme in (ob.VARIATION2Site, ob.VARIATION1Site):
+        var = mps.multiply_mpo(mpo, scheme, chi, chi, 0.0, 1e-12, 20)
+        d_var = np.linalg.norm(_mps_to_dense(var.tensors) - ex)
+        assert d_var <= d_init * (1 + 1e-9)
+        assert d_var <= d_svd * (1 + 1e-6)                    # the variational optimum is no worse than the SVD sweep
+        full = mps.multiply_mpo(mpo, scheme, D * D, D * D, 0.0, 1e-12, 5)
+        assert np.linalg.norm(_mps_to_dense(full.tensors) - ex) < 1e-10 * np.linalg.norm(ex)
