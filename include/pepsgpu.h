@@ -41,12 +41,19 @@ enum {
 enum { PEPSGPU_F32 = 0, PEPSGPU_F64 = 1 };
 enum { PEPSGPU_LEFT = 0, PEPSGPU_DOWN = 1, PEPSGPU_RIGHT = 2, PEPSGPU_UP = 3 };
 enum { PEPSGPU_HORIZONTAL = 0, PEPSGPU_VERTICAL = 1 };
-enum { PEPSGPU_SVD_COMPRESS = 0 };   /* bmps.h:31-35; variational schemes: not implemented */
+enum { PEPSGPU_SVD_COMPRESS = 0, PEPSGPU_VARIATION2SITE = 1, PEPSGPU_VARIATION1SITE = 2 };   /* CompressMPSScheme, bmps.h:31-35 */
 
 /* BMPSContractor(rows, cols) + SetTruncateParams(BMPSTruncateParams{D_min, D_max, trunc_err, scheme})
  * (bmps_contractor.h:187-226, bmps.h:47-98).  dtype = element type of the device tensors. */
 int pepsgpu_ctx_create(pepsgpu_ctx **out, int device, int dtype, int rows, int cols, int D, int phys_dim,
                        int chi_min, int chi_max, double trunc_err, int scheme, int max_walkers);
+/* BMPSContractor::SetTruncateParams (bmps_contractor.h:216) with the full BMPSTruncateParams (bmps.h:47-98):
+ * D_min, D_max, trunc_err, scheme and, for the variational schemes, convergence_tol and iter_max
+ * (BMPS::MultiplyMPO2SiteVariationalCompress_ / 1Site, bmps_impl.h:864-1172; bosonic only as in the reference).
+ * Takes effect at the next absorption; existing BMPS stacks are kept.  A context created with a variational scheme
+ * uses convergence_tol = 1e-10, iter_max = 10 until this is called. */
+int pepsgpu_set_truncate_params(pepsgpu_ctx *ctx, int chi_min, int chi_max, double trunc_err, int scheme,
+                                double convergence_tol, int iter_max);
 void pepsgpu_ctx_destroy(pepsgpu_ctx *ctx);
 const char *pepsgpu_last_error(pepsgpu_ctx *ctx);
 

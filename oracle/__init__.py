@@ -11,7 +11,8 @@ TensorToolkit (``qlten``) dependency; its semantics (``Contract``, ``QR``, trunc
 
 Parity pinning (see tests/test_oracle_*.py, tests/golden/):
   K1  12x12 critical Ising partition function vs exact transfer matrix
-      (tests/test_2d_tn/test_bmps_contractor.cpp:27-126,128-271,472-493)
+      (tests/test_2d_tn/test_bmps_contractor.cpp:27-126,128-271,472-493), with SVD(10,30,1e-15),
+      Variational2Site(10,30,1e-15,1e-14,10) and Variational1Site(10,30,1e-15,1e-14,10) on all 21 routes
   K3  PunchHole . site == Trace, EraseEnvsAfterUpdate + regrow (…:407-470)
   K4  2x2 fixtures, exact-summation energies (tests/test_algorithm/test_exact_summation_evaluator.cpp)
   K5  4x4 D=8 Heisenberg fixture, exact-sum energy / checkerboard amplitude

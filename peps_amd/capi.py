@@ -15,12 +15,12 @@ F32, F64 = 0, 1
 LEFT, DOWN, RIGHT, UP = 0, 1, 2, 3
 HORIZONTAL, VERTICAL = 0, 1
 LEFTUP_TO_RIGHTDOWN, LEFTDOWN_TO_RIGHTUP = 0, 1   # basic.h:89-92 DIAGONAL_DIR
-SVD_COMPRESS = 0
+SVD_COMPRESS, VARIATION2SITE, VARIATION1SITE = 0, 1, 2   # CompressMPSScheme, bmps.h:31-35
 
 _ERR = {1: ValueError, 2: RuntimeError, 3: RuntimeError, 4: IndexError, 5: RuntimeError}
 
 SYMBOLS = [
-    "pepsgpu_ctx_create", "pepsgpu_ctx_destroy", "pepsgpu_last_error", "pepsgpu_state_upload",
+    "pepsgpu_ctx_create", "pepsgpu_set_truncate_params", "pepsgpu_ctx_destroy", "pepsgpu_last_error", "pepsgpu_state_upload",
     "pepsgpu_walkers_set_configs", "pepsgpu_walkers_get_configs", "pepsgpu_n_walkers",
     "pepsgpu_grow_bmps_step", "pepsgpu_grow_full_bmps", "pepsgpu_grow_bmps_for_row", "pepsgpu_grow_bmps_for_col",
     "pepsgpu_shift_bmps_window", "pepsgpu_delete_inner_bmps", "pepsgpu_generate_bmps_approach",
@@ -44,6 +44,7 @@ def load_library(path=LIB_PATH):
     lib = C.CDLL(path)
     vp, ip, dp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)
     lib.pepsgpu_ctx_create.argtypes = [C.POINTER(vp)] + [C.c_int] * 8 + [C.c_double, C.c_int, C.c_int]
+    lib.pepsgpu_set_truncate_params.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int]
     lib.pepsgpu_ctx_destroy.argtypes = [vp]
     lib.pepsgpu_ctx_destroy.restype = None
     lib.pepsgpu_last_error.argtypes = [vp]
@@ -119,18 +120,20 @@ class Context:
     """Thin RAII wrapper of a pepsgpu_ctx: one walker batch on one GPU."""
 
     def __init__(self, rows, cols, D, phys_dim, chi, dtype=F32, device=0, max_walkers=256, chi_min=None,
-                 trunc_err=0.0):
+                 trunc_err=0.0, scheme=0, convergence_tol=None, iter_max=None):
         self._l = lib()
         self.rows, self.cols, self.D, self.d = rows, cols, D, phys_dim
         self.dtype = dtype
         h = C.c_void_p()
         rc = self._l.pepsgpu_ctx_create(C.byref(h), device, dtype, rows, cols, D, phys_dim,
-                                        chi if chi_min is None else chi_min, chi, trunc_err, SVD_COMPRESS, max_walkers)
+                                        chi if chi_min is None else chi_min, chi, trunc_err, scheme, max_walkers)
         if rc != 0:
             raise _ERR.get(rc, RuntimeError)("pepsgpu_ctx_create failed (%d): %s"
                                              % (rc, self._l.pepsgpu_last_error(None).decode()))
         self._h = h
         self.n = 0
+        if scheme != SVD_COMPRESS and convergence_tol is not None:
+            self.set_truncate_params(chi if chi_min is None else chi_min, chi, trunc_err, scheme, convergence_tol, iter_max)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -148,6 +151,10 @@ class Context:
             raise _ERR.get(rc, RuntimeError)("pepsgpu error %d: %s" % (rc, self._l.pepsgpu_last_error(self._h).decode()))
 
     # -- state / walkers --
+    def set_truncate_params(self, chi_min, chi_max, trunc_err=0.0, scheme=0, convergence_tol=0.0, iter_max=0):
+        """BMPSContractor::SetTruncateParams (bmps_contractor.h:216); scheme 0 SVD, 1 Variational2Site, 2 Variational1Site."""
+        self._ck(self._l.pepsgpu_set_truncate_params(self._h, chi_min, chi_max, trunc_err, scheme, convergence_tol, iter_max))
+
     def state_upload(self, flat):
         flat = np.ascontiguousarray(flat)
         assert flat.shape == (self.rows, self.cols, self.d, self.D, self.D, self.D, self.D), flat.shape

@@ -4,6 +4,7 @@
 #include "engine_impl.h"
 #include "engine_nnn.h"
 #include "engine_sr.h"
+#include "engine_var.h"
 
 using namespace pepsgpu;
 
@@ -53,7 +54,7 @@ int pepsgpu_ctx_create(pepsgpu_ctx **out, int device, int dtype, int rows, int c
   *out = nullptr;
   pepsgpu_ctx *ctx = new pepsgpu_ctx;
   int rc = guarded(nullptr, [&]() {
-    PG_REQUIRE(scheme == PEPSGPU_SVD_COMPRESS, 1, "only CompressMPSScheme::SVD_COMPRESS is implemented");
+    PG_REQUIRE(scheme >= PEPSGPU_SVD_COMPRESS && scheme <= PEPSGPU_VARIATION1SITE, 1, "unknown CompressMPSScheme");
     PG_REQUIRE(chi_min <= chi_max, 1, "D_min > D_max");
     int ndev = 0;
     PG_CHECK_HIP(hipGetDeviceCount(&ndev));
@@ -64,6 +65,8 @@ int pepsgpu_ctx_create(pepsgpu_ctx **out, int device, int dtype, int rows, int c
       ctx->eng = new Engine<double>(device, rows, cols, D, phys_dim, chi_min, chi_max, trunc_err, max_walkers);
     else
       throw Error(1, "unknown dtype");
+    // variational schemes: convergence_tol / iter_max default to 1e-10 / 10 until pepsgpu_set_truncate_params sets them
+    if (scheme != PEPSGPU_SVD_COMPRESS) ctx->eng->set_truncate_params(chi_min, chi_max, trunc_err, scheme, 1e-10, 10);
   });
   if (rc != PEPSGPU_OK) {
     delete ctx;
@@ -71,6 +74,11 @@ int pepsgpu_ctx_create(pepsgpu_ctx **out, int device, int dtype, int rows, int c
   }
   *out = ctx;
   return PEPSGPU_OK;
+}
+
+int pepsgpu_set_truncate_params(pepsgpu_ctx *ctx, int chi_min, int chi_max, double trunc_err, int scheme,
+                                double convergence_tol, int iter_max) {
+  CTX_CALL(ctx->eng->set_truncate_params(chi_min, chi_max, trunc_err, scheme, convergence_tol, iter_max));
 }
 
 void pepsgpu_ctx_destroy(pepsgpu_ctx *ctx) {

@@ -69,6 +69,8 @@ struct EngineBase {
   virtual void evaluate_amplitude(double *out) = 0;
   virtual void get_bmps_tensor(int pos, int level, int idx, int *dims, double *out, double *logscale) = 0;
   virtual void sync() = 0;
+  // SetTruncateParams (bmps_contractor.h:216): scheme 0 SVD, 1 two-site, 2 one-site variational (bmps.h:31-35)
+  virtual void set_truncate_params(int chi_min, int chi_max, double trunc_err, int scheme, double conv_tol, int iter_max) = 0;
   virtual void read_flags(int32_t *out) = 0;
   virtual size_t device_bytes() const = 0;
   virtual void stats(double *out, int n) = 0;
@@ -83,6 +85,8 @@ struct EngineBase {
   virtual void profile_enable(int on) = 0;
   virtual void profile_read(double *out) = 0;   // [PROF_NCAT][4]: ms, launches, algorithmic flops, executed flops
 };
+
+template <typename T> struct EinView;
 
 template <typename T>
 struct DTen {
@@ -634,6 +638,15 @@ class Engine : public EngineBase {
   }
 
   void sync() override { PG_CHECK_HIP(hipStreamSynchronize(stream_)); }
+  void set_truncate_params(int chi_min, int chi_max, double trunc_err, int scheme, double conv_tol, int iter_max) override {
+    PG_REQUIRE(chi_min >= 0 && chi_max >= 1 && chi_min <= chi_max, 1, "D_min > D_max");
+    PG_REQUIRE(trunc_err >= 0.0 && trunc_err < 1.0, 1, "trunc_err must be in [0, 1)");
+    PG_REQUIRE(scheme >= 0 && scheme <= 2, 1, "unknown CompressMPSScheme");
+    PG_REQUIRE(scheme == 0 || (iter_max >= 1 && conv_tol >= 0.0), 1,
+               "variational compression needs convergence_tol and iter_max (bmps.h:81-97)");
+    chi_min_ = chi_min; chi_ = chi_max; trunc_err_ = trunc_err;
+    scheme_ = scheme; conv_tol_ = conv_tol; iter_max_ = iter_max;
+  }
   void read_flags(int32_t *out) override {
     PG_CHECK_HIP(hipMemcpyAsync(out, flag_, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
     PG_CHECK_HIP(hipStreamSynchronize(stream_));
@@ -729,12 +742,16 @@ class Engine : public EngineBase {
     PG_CHECK_HIP(hipMemsetAsync(p, 0, sizeof(double) * nw_, stream_));
     return p;
   }
+  void free_bmps(BMPSDev &b) {
+    for (auto &t : b.t) if (t.p) arena_.free(t.p);
+    for (int *l : b.live) if (l) arena_.free(l);
+    if (b.logscale) arena_.free(b.logscale);
+    b.t.clear(); b.live.clear(); b.logscale = nullptr;
+  }
   void clear_bmps(int pos, int keep) {
     auto &v = bmps_[pos];
     while ((int)v.size() > keep) {
-      for (auto &t : v.back().t) arena_.free(t.p);
-      for (int *l : v.back().live) if (l) arena_.free(l);
-      arena_.free(v.back().logscale);
+      free_bmps(v.back());
       v.pop_back();
     }
   }
@@ -874,7 +891,13 @@ class Engine : public EngineBase {
   }
 
   void absorb(int pos, int num);
-  bool absorb_impl(int pos, int num, bool full_bonds);
+  BMPSDev absorb_svd(int pos, int num, const BMPSDev &in);
+  bool absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in, BMPSDev &out);
+  // ---- variational compression schemes (engine_var.h) ----
+  BMPSDev absorb_variational(int pos, int num, const BMPSDev &in);
+  BMPSDev truncate_bmps(const BMPSDev &in, int kmax);
+  void ein(const EinView<T> &a, const EinView<T> &b, const EinView<T> &c, T *cp);
+  DTen<T> svd_rows(DTen<T> &M, int m, int len, int k, double terr, int dmin, T *S);
   // ---- two-row environments and NNN / TNN / sqrt5 traces (engine_nnn.h) ----
   void clear_bten2(int pos, int keep) {
     auto &v = bten2_[pos];
@@ -921,6 +944,9 @@ class Engine : public EngineBase {
   bool prof_on_ = false;
   double prof_ms_[PROF_NCAT] = {0}, prof_alg_[PROF_NCAT] = {0}, prof_exec_[PROF_NCAT] = {0};
   long prof_n_[PROF_NCAT] = {0};
+  int scheme_ = 0, iter_max_ = 0;
+  double conv_tol_ = 0.0;
+  long n_var_iters_ = 0;
   long n_absorb_ = 0, n_jacobi_ = 0, jacobi_sweeps_sum_ = 0, jacobi_sweeps_max_ = 0;
   double live_sum_ = 0, live_full_ = 0;   // diagnostics: sum of live carry rows / sum of carry sizes
   T *holes_ = nullptr;                    // resident hole store [walker][site][D^4]

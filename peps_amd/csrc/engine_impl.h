@@ -74,27 +74,40 @@ void Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
 // checks that no walker filled a shrunk bond; if one did, the absorption is repeated at full size (rare).
 template <typename T>
 void Engine<T>::absorb(int pos, int num) {
-  static const bool no_shrink = getenv("PEPSGPU_NO_BOND_SHRINK") != nullptr;
-  if (!absorb_impl(pos, num, no_shrink)) {
-    clear_bmps(pos, bmps_size(pos) - 1);
-    PG_REQUIRE(absorb_impl(pos, num, true), 5, "MultiplyMPO: internal error (full-size absorption reported clipping)");
+  if (scheme_ != 0 && mps_len(pos) > 2) {   // bmps_impl.h:419-430: N == 2 always takes the SVD path
+    BMPSDev out = absorb_variational(pos, num, bmps_[pos].back());
+    bmps_[pos].push_back(std::move(out));
+    return;
   }
+  BMPSDev out = absorb_svd(pos, num, bmps_[pos].back());
+  bmps_[pos].push_back(std::move(out));
 }
 
 template <typename T>
-bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds) {
+typename Engine<T>::BMPSDev Engine<T>::absorb_svd(int pos, int num, const BMPSDev &in) {
+  static const bool no_shrink = getenv("PEPSGPU_NO_BOND_SHRINK") != nullptr;
+  BMPSDev out;
+  if (!absorb_impl(pos, num, no_shrink, in, out)) {
+    free_bmps(out);
+    out = BMPSDev();
+    PG_REQUIRE(absorb_impl(pos, num, true, in, out), 5, "MultiplyMPO: internal error (full-size absorption reported clipping)");
+  }
+  return out;
+}
+
+template <typename T>
+bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in, BMPSDev &out) {
   const int N = mps_len(pos);
-  // copy of the tensor descriptors: push_back below may reallocate bmps_[pos]
-  const std::vector<DTen<T>> cur = bmps_[pos].back().t;
-  const double *cur_log = bmps_[pos].back().logscale;
+  const std::vector<DTen<T>> cur = in.t;
+  const double *cur_log = in.logscale;
   // live bond dimensions of the absorbing BMPS (per walker, device) and of the one being built:
   // every contraction below runs over the live part of a bond only; persistent tensors stay zero padded
   static const bool bond_adapt = getenv("PEPSGPU_NO_BOND_ADAPT") == nullptr && getenv("PEPSGPU_NO_RANK_ADAPT") == nullptr;
-  std::vector<int *> clive = bmps_[pos].back().live;
+  std::vector<int *> clive = in.live;
   clive.resize(N + 1, nullptr);
   if (!bond_adapt) std::fill(clive.begin(), clive.end(), nullptr);
   std::vector<int *> kn(N + 1, nullptr);
-  std::vector<int> cur_kmax = bmps_[pos].back().kmax;
+  std::vector<int> cur_kmax = in.kmax;
   cur_kmax.resize(N + 1, -1);
   std::vector<int> kstat(N + 1, 0), kfull(N + 1, 0);   // static size chosen / full static size of each new bond
   PG_REQUIRE((int)cur.size() == N, 3, "MultiplyMPO: MPS/MPO length mismatch");
@@ -261,7 +274,6 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds) {
   }
 
   // ---------------- backward: truncate right to left ----------------
-  BMPSDev out;
   out.t.resize(N);
   out.logscale = (double *)arena_.alloc(sizeof(double) * nw_);
   PG_CHECK_HIP(hipMemcpyAsync(out.logscale, cur_log, sizeof(double) * nw_, hipMemcpyDeviceToDevice, stream_));
@@ -424,7 +436,6 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds) {
     for (int i = 1; i < N; ++i)
       if (kstat[i] < kfull[i] && out.kmax[i] >= kstat[i]) ok = false;   // a walker filled a shrunk bond: maybe clipped
   }
-  bmps_[pos].push_back(std::move(out));
   if (ok) ++n_absorb_;
   return ok;
 }

@@ -1,0 +1,478 @@
+// Variational compression of BMPS x MPO on the device: CompressMPSScheme::VARIATION2Site / VARIATION1Site
+// (bmps.h:31-35; BMPS::MultiplyMPO2SiteVariationalCompress_ bmps_impl.h:864-995,
+// MultiplyMPO1SiteVariationalCompress_ :997-1172, MakeVariationalInitGuess_ :1174-1212,
+// MakeEnvironmentBoundaries_ / GrowRightEnvironments_ :701-743).  Bosonic, real element types (the
+// reference asserts !IsFermionic(); Dag() is the identity for real tensors).
+//
+// Same state as the reference up to the bond gauge:
+//  * every contraction is one strided tensor GEMM (ein() below builds the descriptor from leg names; no
+//    transposed copy is ever made);
+//  * SVD(theta) -> row Jacobi of theta (right move: the rotated rows are sigma_k v_k^T) or of theta^T
+//    (left move: sigma_k u_k^T), top rows selected and normalised by select_rows_kernel with the
+//    (trunc_err, D_min, D_max) rule; u.s of the final step = t1 . renv (theta itself is not kept);
+//  * QR(t2) of the one-site scheme -> the normalised rotated rows of t2^T: an orthonormal basis of the same
+//    column space (a rank-deficient t2 leaves zero rows where Householder QR would put arbitrary vectors;
+//    the product state has no weight there);
+//  * environments are normalised after every growth step and carry a per-walker log-scale; the convergence
+//    criteria (sum |s - s_last| / s_0, |r - r_last| / r) are evaluated on the host from the per-walker values,
+//    one small read-back per sweep pair.  Walkers move in lockstep: the sweeps stop when EVERY walker meets the
+//    criterion (a walker that converged earlier keeps being refined; the reference would stop it there).
+#pragma once
+#include "engine_impl.h"
+
+namespace pepsgpu {
+
+// a tensor operand of ein(): base pointer, batch stride and named legs (dim, stride); `site` picks the
+// projected site tensor of (r, c) by the walker's configuration instead of a per-walker buffer
+template <typename T>
+struct EinView {
+  const T *p = nullptr;
+  long w = 0;
+  int n = 0;
+  char nm[6];
+  int dim[6], st[6];
+  bool site = false;
+  int r = 0, c = 0;
+  int find(char ch) const {
+    for (int i = 0; i < n; ++i) if (nm[i] == ch) return i;
+    return -1;
+  }
+};
+
+template <typename T>
+static EinView<T> ein_view(const T *p, long w, const char *legs, std::initializer_list<int> dims) {
+  EinView<T> v;
+  v.p = p; v.w = w; v.n = (int)dims.size();
+  int i = 0;
+  for (int d : dims) { v.nm[i] = legs[i]; v.dim[i] = d; ++i; }
+  long s = 1;
+  for (int k = v.n - 1; k >= 0; --k) { v.st[k] = (int)s; s *= v.dim[k]; }
+  return v;
+}
+
+// C[legs of c] = sum over the legs shared by a and b and absent from c.  a supplies the I side, b the J side.
+template <typename T>
+void Engine<T>::ein(const EinView<T> &a, const EinView<T> &b, const EinView<T> &c, T *cp) {
+  struct Sub { int dim, s0, s1; };   // dim, stride in the first / second tensor of the group
+  std::vector<Sub> gi, gj, gk;
+  for (int x = 0; x < a.n; ++x) {
+    if (a.dim[x] == 1) continue;
+    const int ic = c.find(a.nm[x]), ib = b.find(a.nm[x]);
+    PG_REQUIRE((ic >= 0) != (ib >= 0), 5, "ein: a leg of A must be either kept or contracted");
+    if (ic >= 0) { PG_REQUIRE(c.dim[ic] == a.dim[x], 5, "ein: dim mismatch (A,C)"); gi.push_back({a.dim[x], a.st[x], c.st[ic]}); }
+    else { PG_REQUIRE(b.dim[ib] == a.dim[x], 5, "ein: dim mismatch (A,B)"); gk.push_back({a.dim[x], a.st[x], b.st[ib]}); }
+  }
+  for (int x = 0; x < b.n; ++x) {
+    if (b.dim[x] == 1 || a.find(b.nm[x]) >= 0) continue;
+    const int ic = c.find(b.nm[x]);
+    PG_REQUIRE(ic >= 0 && c.dim[ic] == b.dim[x], 5, "ein: a free leg of B is missing in C");
+    gj.push_back({b.dim[x], b.st[x], c.st[ic]});
+  }
+  auto pack = [](std::vector<Sub> &g, bool by_second) {
+    // innermost last: order by decreasing stride of the tensor that is written (C) resp. read contiguously (A for K)
+    std::sort(g.begin(), g.end(), [&](const Sub &x, const Sub &y) { return by_second ? x.s1 > y.s1 : x.s0 > y.s0; });
+    // merge neighbours that are contiguous in both tensors
+    for (size_t i = 0; i + 1 < g.size();) {
+      if (g[i].s0 == g[i + 1].s0 * g[i + 1].dim && g[i].s1 == g[i + 1].s1 * g[i + 1].dim) {
+        g[i + 1].dim *= g[i].dim;
+        g.erase(g.begin() + i);
+      } else ++i;
+    }
+    PG_REQUIRE(g.size() <= 3, 5, "ein: more than three sub-indices in one group");
+  };
+  pack(gi, true); pack(gj, true); pack(gk, false);
+  TGemmDesc g;
+  for (size_t x = 0; x < gi.size(); ++x) { const int o = 3 - (int)gi.size() + (int)x; g.I[o] = gi[x].dim; g.sAi[o] = gi[x].s0; g.sCi[o] = gi[x].s1; }
+  for (size_t x = 0; x < gj.size(); ++x) { const int o = 3 - (int)gj.size() + (int)x; g.J[o] = gj[x].dim; g.sBj[o] = gj[x].s0; g.sCj[o] = gj[x].s1; }
+  for (size_t x = 0; x < gk.size(); ++x) { const int o = 3 - (int)gk.size() + (int)x; g.K[o] = gk[x].dim; g.sAk[o] = gk[x].s0; g.sBk[o] = gk[x].s1; }
+  g.wA = a.w; g.wB = b.w; g.wC = c.w; g.nbatch = nw_;
+  const double fl = 2.0 * nw_ * (double)g.Itot() * g.Jtot() * g.Ktot();
+  prof_begin(PROF_CONTRACT, fl, fl);
+  PG_REQUIRE(!(a.site && b.site), 5, "ein: two site operands");
+  if (a.site) launch_site_gemm_a(g, cfg_site(a.r, a.c), 1, b.p, cp);
+  else if (b.site) launch_site_gemm(g, cfg_site(b.r, b.c), 1, a.p, cp);
+  else tgemm_launch<T, T, T, T>(stream_, g, a.p, b.p, cp);
+  prof_end();
+}
+
+// rows of M (m x len, contiguous) -> mutually orthogonal; the k rows of largest norm, normalised -> V (k x len);
+// optionally their norms -> S (k per walker)
+template <typename T>
+DTen<T> Engine<T>::svd_rows(DTen<T> &M, int m, int len, int k, double terr, int dmin, T *S) {
+  const size_t need = sizeof(T) * (size_t)m * (len | 1);
+  const int use_lds = need <= JACOBI_LDS_MAX;
+  if (use_lds) allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), need);
+  PG_REQUIRE(m <= 1024, 1, "bond dimension too large for select_rows_kernel");
+  prof_begin(7, 0.0, 0.0);
+  launch_jacobi(M.p, M.n, m, len, use_lds, need, nullptr, 1);
+  prof_end();
+  ++n_jacobi_;
+  DTen<T> V = alloc_ten(k, len, 1);
+  prof_begin(PROF_SELECT, 0.0, 0.0);
+  hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)M.p, M.n, m, len, len, k, V.p, V.n,
+                     S, (long)k, (const int *)nullptr, 1, (int *)nullptr, terr, dmin, (double *)nullptr);
+  PG_CHECK_HIP(hipGetLastError());
+  prof_end();
+  return V;
+}
+
+// BMPS truncated to bond dimension <= kmax: Centralize(N-1) + RightCanonicalizeTruncate(i, 1, kmax, 0)
+// (bmps_impl.h:1196-1200) in the Q-less form of the absorption: forward R_{i+1}^T R_{i+1} = (R_i A_i)^T (R_i A_i),
+// backward M_i = R_i (A_i Y_{i+1}), rows -> Vt_i, Y_i = (A_i Y_{i+1}) Vt_i^T.
+template <typename T>
+typename Engine<T>::BMPSDev Engine<T>::truncate_bmps(const BMPSDev &in, int kmax) {
+  const int N = (int)in.t.size();
+  std::vector<DTen<T>> R(N);
+  R[0] = ones3();   // (m = 1, a = 1)
+  R[0].d[1] = 1;
+  for (int i = 0; i + 1 < N; ++i) {
+    const DTen<T> &A = in.t[i];
+    const int m = R[i].d[0], a = A.d[0], p = A.d[1], b = A.d[2];
+    DTen<T> P = alloc_ten(m, p, b);
+    ein(ein_view<T>(R[i].p, R[i].n, "ma", {m, a}), ein_view<T>(A.p, A.n, "apb", {a, p, b}), ein_view<T>(P.p, P.n, "mpb", {m, p, b}), P.p);
+    const int rows = m * p, cols = b;
+    double *G = (double *)arena_.alloc(sizeof(double) * (size_t)cols * cols * nw_);
+    {
+      TGemmDesc g;
+      g.I[2] = cols; g.sAi[2] = 1; g.sCi[2] = cols;
+      g.K[2] = rows; g.sAk[2] = cols; g.sBk[2] = cols;
+      g.J[2] = cols; g.sBj[2] = 1; g.sCj[2] = 1;
+      g.wA = P.n; g.wB = P.n; g.wC = (long)cols * cols; g.nbatch = nw_;
+      prof_begin(PROF_GRAM, 0.0, 2.0 * nw_ * (double)cols * cols * rows);
+      tgemm_launch<T, T, double, double>(stream_, g, P.p, P.p, G);
+      prof_end();
+    }
+    R[i + 1] = alloc_ten(cols, cols, 1);
+    const size_t smem = chol_smem_bytes(cols);
+    allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
+    prof_begin(PROF_CHOL, 0.0, 0.0);
+    hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nw_), dim3(256), smem, stream_, G, (long)cols * cols, cols, R[i + 1].p,
+                       R[i + 1].n, (int *)nullptr, 0);
+    PG_CHECK_HIP(hipGetLastError());
+    prof_end();
+    arena_.free(G);
+    free_ten(P);
+  }
+  BMPSDev out;
+  out.t.resize(N);
+  out.logscale = (double *)arena_.alloc(sizeof(double) * nw_);
+  PG_CHECK_HIP(hipMemcpyAsync(out.logscale, in.logscale, sizeof(double) * nw_, hipMemcpyDeviceToDevice, stream_));
+  DTen<T> Y = ones3();   // (b, y)
+  int y = 1;
+  for (int i = N - 1; i >= 0; --i) {
+    const DTen<T> &A = in.t[i];
+    const int a = A.d[0], p = A.d[1], b = A.d[2];
+    DTen<T> Tt = alloc_ten(a, p, y);
+    ein(ein_view<T>(A.p, A.n, "apb", {a, p, b}), ein_view<T>(Y.p, Y.n, "by", {b, y}), ein_view<T>(Tt.p, Tt.n, "apy", {a, p, y}), Tt.p);
+    free_ten(Y);
+    if (i == 0) {
+      normalize(Tt.p, Tt.n, Tt.n, nw_, out.logscale);
+      out.t[0] = Tt;
+      break;
+    }
+    const int m = R[i].d[0];
+    DTen<T> M = alloc_ten(m, p, y);
+    ein(ein_view<T>(R[i].p, R[i].n, "ma", {m, a}), ein_view<T>(Tt.p, Tt.n, "apy", {a, p, y}), ein_view<T>(M.p, M.n, "mpy", {m, p, y}), M.p);
+    const int k = std::min(kmax, std::min(m, p * y));
+    DTen<T> V = svd_rows(M, m, p * y, k, 0.0, k, nullptr);
+    free_ten(M);
+    V.d[0] = k; V.d[1] = p; V.d[2] = y;
+    out.t[i] = V;
+    DTen<T> Yn = alloc_ten(a, k, 1);
+    ein(ein_view<T>(Tt.p, Tt.n, "apy", {a, p, y}), ein_view<T>(V.p, V.n, "npy", {k, p, y}), ein_view<T>(Yn.p, Yn.n, "an", {a, k}), Yn.p);
+    normalize(Yn.p, Yn.n, Yn.n, nw_, out.logscale);
+    free_ten(Tt);
+    Y = Yn;
+    y = k;
+  }
+  for (auto &t : R) arena_.free(t.p);
+  return out;
+}
+
+template <typename T>
+typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, const BMPSDev &in) {
+  const int N = mps_len(pos);
+  PG_REQUIRE((int)in.t.size() == N && N > 2, 3, "MultiplyMPO (variational): MPS/MPO length mismatch");
+  const int ll = (pos + 3) % 4, lp = pos, lr = (pos + 1) % 4, lu = (pos + 2) % 4;   // pre, position, next, opposite legs
+  struct Site { int r, c, e, p, f, u; char nm[5]; };
+  std::vector<Site> S(N);
+  for (int i = 0; i < N; ++i) {
+    int r, c, dd[4];
+    switch (pos) {
+      case DOWN: r = num; c = i; break;
+      case UP: r = num; c = N - 1 - i; break;
+      case LEFT: r = i; c = num; break;
+      default: r = N - 1 - i; c = num; break;
+    }
+    site_dims(r, c, dd);
+    S[i] = Site{r, c, dd[ll], dd[lp], dd[lr], dd[lu], {0, 0, 0, 0, 0}};
+  }
+  // site tensor of site i with its legs (L, D, R, U) named by role: e = pre, p = position, f = next, `un` = opposite
+  auto site_view = [&](int i, char un) {
+    EinView<T> v;
+    int dd[4], st[4];
+    site_dims(S[i].r, S[i].c, dd);
+    site_strides(S[i].r, S[i].c, st);
+    v.n = 4; v.site = true; v.r = S[i].r; v.c = S[i].c; v.p = nullptr; v.w = 0;
+    for (int l = 0; l < 4; ++l) { v.dim[l] = dd[l]; v.st[l] = st[l]; }
+    v.nm[ll] = 'e'; v.nm[lp] = 'p'; v.nm[lr] = 'f'; v.nm[lu] = un;
+    return v;
+  };
+
+  // ---- initial guess: (BMPS truncated to bond 2) x MPO, SVD-compressed (MakeVariationalInitGuess_) ----
+  BMPSDev small = truncate_bmps(in, 2);
+  const int save_min = chi_min_;
+  const double save_err = trunc_err_;
+  if (scheme_ == 2) { chi_min_ = chi_; trunc_err_ = 0.0; }   // bmps_impl.h:1012: (Dmax, Dmax, 0.0)
+  BMPSDev res;
+  try {
+    res = absorb_svd(pos, num, small);
+  } catch (...) {
+    chi_min_ = save_min; trunc_err_ = save_err;
+    throw;
+  }
+  chi_min_ = save_min; trunc_err_ = save_err;
+  free_bmps(small);
+  for (int *l : res.live) if (l) arena_.free(l);   // the sweeps below work on the zero padded static shapes
+  res.live.clear();
+  res.kmax.clear();
+  std::vector<DTen<T>> &B = res.t;   // res tensors (k, u, q)
+
+  struct Env { DTen<T> t; double *log; };
+  auto new_log = [&](const double *a) {
+    double *l = (double *)arena_.alloc(sizeof(double) * nw_);
+    if (a) PG_CHECK_HIP(hipMemcpyAsync(l, a, sizeof(double) * nw_, hipMemcpyDeviceToDevice, stream_));
+    else PG_CHECK_HIP(hipMemsetAsync(l, 0, sizeof(double) * nw_, stream_));
+    return l;
+  };
+  auto free_env = [&](Env &e) { arena_.free(e.t.p); arena_.free(e.log); };
+  std::vector<Env> lenvs, renvs;
+  lenvs.push_back(Env{ones3(), new_log(nullptr)});   // (k, e, a)
+  renvs.push_back(Env{ones3(), new_log(nullptr)});   // (b, f, q)
+
+  // t1[k,u,b,f] = sum_{a,e,p} lenv[k,e,a] A_i[a,p,b] W_i[e,p,f,u]        (bmps_impl.h:896-897)
+  auto half_left = [&](int i, const Env &le) {
+    const DTen<T> &A = in.t[i];
+    const int k = le.t.d[0], e = S[i].e, a = A.d[0], p = A.d[1], b = A.d[2], f = S[i].f, u = S[i].u;
+    PG_REQUIRE(le.t.d[1] == e && le.t.d[2] == a && p == S[i].p, 3, "variational compression: bond mismatch (left)");
+    DTen<T> t0 = alloc_ten(k * e, p, b);
+    ein(ein_view<T>(le.t.p, le.t.n, "kea", {k, e, a}), ein_view<T>(A.p, A.n, "apb", {a, p, b}), ein_view<T>(t0.p, t0.n, "kepb", {k, e, p, b}), t0.p);
+    DTen<T> t1 = alloc_ten(k, u, b, f);
+    ein(ein_view<T>(t0.p, t0.n, "kepb", {k, e, p, b}), site_view(i, 'u'), ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}), t1.p);
+    free_ten(t0);
+    return t1;
+  };
+  // t3[v,q,b,f] = sum_{c,p,g} A_j[b,p,c] renv[c,g,q] W_j[f,p,g,v]   (legs of site j: e -> 'f', next -> 'g', opposite -> 'v')
+  auto half_right = [&](int j, const Env &re) {
+    const DTen<T> &A = in.t[j];
+    const int q = re.t.d[2], g = S[j].f, a = A.d[0], p = A.d[1], c = A.d[2], e = S[j].e, v = S[j].u;
+    PG_REQUIRE(re.t.d[0] == c && re.t.d[1] == g && p == S[j].p, 3, "variational compression: bond mismatch (right)");
+    DTen<T> t2 = alloc_ten(a, p, g, q);
+    ein(ein_view<T>(A.p, A.n, "bpc", {a, p, c}), ein_view<T>(re.t.p, re.t.n, "cgq", {c, g, q}), ein_view<T>(t2.p, t2.n, "bpgq", {a, p, g, q}), t2.p);
+    EinView<T> w = site_view(j, 'v');
+    w.nm[ll] = 'f'; w.nm[lr] = 'g';
+    DTen<T> t3 = alloc_ten(v, q, a, e);
+    ein(ein_view<T>(t2.p, t2.n, "bpgq", {a, p, g, q}), w, ein_view<T>(t3.p, t3.n, "vqbf", {v, q, a, e}), t3.p);
+    free_ten(t2);
+    return t3;
+  };
+  // renv'[b,f,n] = sum_{v,q} t3[v,q,b,f] Bj[n,v,q]                  (bmps_impl.h:739, :939)
+  auto grow_right = [&](const DTen<T> &t3, const DTen<T> &Bj, const Env &re) {
+    const int v = t3.d[0], q = t3.d[1], b = t3.d[2], f = t3.d[3], n = Bj.d[0];
+    Env o{alloc_ten(b, f, n), new_log(re.log)};
+    ein(ein_view<T>(t3.p, t3.n, "vqbf", {v, q, b, f}), ein_view<T>(Bj.p, Bj.n, "nvq", {n, v, q}), ein_view<T>(o.t.p, o.t.n, "bfn", {b, f, n}), o.t.p);
+    normalize(o.t.p, o.t.n, o.t.n, nw_, o.log);
+    return o;
+  };
+  // lenv'[n,f,b] = sum_{k,u} Ut[n,k,u] t1[k,u,b,f]                  (bmps_impl.h:916-918)
+  auto grow_left = [&](const DTen<T> &t1, const DTen<T> &Ut, int n, const Env &le) {
+    const int k = t1.d[0], u = t1.d[1], b = t1.d[2], f = t1.d[3];
+    Env o{alloc_ten(n, f, b), new_log(le.log)};
+    ein(ein_view<T>(Ut.p, Ut.n, "nku", {n, k, u}), ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}), ein_view<T>(o.t.p, o.t.n, "nfb", {n, f, b}), o.t.p);
+    normalize(o.t.p, o.t.n, o.t.n, nw_, o.log);
+    return o;
+  };
+  // right environments of sites N-1 .. 2 from the initial guess (GrowRightEnvironments_)
+  for (int i = N - 1; i > 1; --i) {
+    DTen<T> t3 = half_right(i, renvs.back());
+    renvs.push_back(grow_right(t3, B[i], renvs.back()));
+    free_ten(t3);
+  }
+
+  // two-site update of bond (i, i+1); left_move: only the left environment grows (the u of the SVD), else
+  // B[i+1] = vt and the right environment grows.  Sout: singular values (padded to chi_), slog: scale of theta
+  auto two_site = [&](int i, bool left_move, double terr, int dmin, T *Sout, double *slog) {
+    DTen<T> t1 = half_left(i, lenvs.back());
+    DTen<T> t3 = half_right(i + 1, renvs.back());
+    const int k = t1.d[0], u = t1.d[1], b = t1.d[2], f = t1.d[3], v = t3.d[0], q = t3.d[1];
+    PG_REQUIRE(t3.d[2] == b && t3.d[3] == f, 3, "variational compression: bond mismatch (two-site)");
+    const int rows = left_move ? v * q : k * u, len = left_move ? k * u : v * q;
+    const int kn = std::min(chi_, std::min(rows, len));
+    DTen<T> th = alloc_ten(rows, len, 1);
+    if (left_move)
+      ein(ein_view<T>(t3.p, t3.n, "vqbf", {v, q, b, f}), ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}), ein_view<T>(th.p, th.n, "vqku", {v, q, k, u}), th.p);
+    else
+      ein(ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}), ein_view<T>(t3.p, t3.n, "vqbf", {v, q, b, f}), ein_view<T>(th.p, th.n, "kuvq", {k, u, v, q}), th.p);
+    if (Sout) PG_CHECK_HIP(hipMemsetAsync(Sout, 0, sizeof(T) * (size_t)chi_ * nw_, stream_));
+    DTen<T> V = svd_rows(th, rows, len, kn, terr, std::min(dmin, kn), Sout);
+    free_ten(th);
+    if (slog) {
+      PG_CHECK_HIP(hipMemsetAsync(slog, 0, sizeof(double) * nw_, stream_));
+      add_logs(slog, lenvs.back().log, renvs.back().log, nullptr, nullptr);
+    }
+    if (left_move) {
+      Env ne = grow_left(t1, V, kn, lenvs.back());
+      lenvs.push_back(ne);
+      free_env(renvs.back());
+      renvs.pop_back();
+      free_ten(V);
+    } else {
+      V.d[0] = kn; V.d[1] = v; V.d[2] = q;
+      arena_.free(B[i + 1].p);
+      B[i + 1] = V;
+      Env ne = grow_right(t3, V, renvs.back());
+      renvs.push_back(ne);
+      free_env(lenvs.back());
+      lenvs.pop_back();
+    }
+    free_ten(t1);
+    free_ten(t3);
+    return kn;
+  };
+  // the final two-site step at bond (0, 1): B[1] = vt, renv grows, B[0] = t1 . renv = u s   (bmps_impl.h:960-988)
+  auto close_at_zero = [&](double terr, int dmin, bool keep_env) {
+    DTen<T> t1 = half_left(0, lenvs.back());
+    DTen<T> t3 = half_right(1, renvs.back());
+    const int k = t1.d[0], u = t1.d[1], b = t1.d[2], f = t1.d[3], v = t3.d[0], q = t3.d[1];
+    const int rows = k * u, len = v * q, kn = std::min(chi_, std::min(rows, len));
+    DTen<T> th = alloc_ten(rows, len, 1);
+    ein(ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}), ein_view<T>(t3.p, t3.n, "vqbf", {v, q, b, f}), ein_view<T>(th.p, th.n, "kuvq", {k, u, v, q}), th.p);
+    DTen<T> V = svd_rows(th, rows, len, kn, terr, std::min(dmin, kn), nullptr);
+    free_ten(th);
+    V.d[0] = kn; V.d[1] = v; V.d[2] = q;
+    arena_.free(B[1].p);
+    B[1] = V;
+    Env ne = grow_right(t3, V, renvs.back());
+    free_ten(t3);
+    DTen<T> B0 = alloc_ten(k, u, kn);
+    ein(ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}), ein_view<T>(ne.t.p, ne.t.n, "bfn", {b, f, kn}), ein_view<T>(B0.p, B0.n, "kun", {k, u, kn}), B0.p);
+    free_ten(t1);
+    arena_.free(B[0].p);
+    B[0] = B0;
+    // scale of the state: |B0| exp(log renv) (the left boundary is 1)
+    PG_CHECK_HIP(hipMemcpyAsync(res.logscale, in.logscale, sizeof(double) * nw_, hipMemcpyDeviceToDevice, stream_));
+    add_log(res.logscale, ne.log);
+    if (keep_env) renvs.push_back(ne);
+    else free_env(ne);
+  };
+
+  std::vector<double> h_log(nw_), h_log_last(nw_);
+  if (scheme_ == 1) {
+    // ---------------- two-site sweeps (bmps_impl.h:888-959) ----------------
+    T *Sd = (T *)arena_.alloc(sizeof(T) * (size_t)chi_ * nw_);
+    double *slog = (double *)arena_.alloc(sizeof(double) * nw_);
+    std::vector<T> h_s((size_t)chi_ * nw_), h_last;
+    int ks_last = -1;
+    for (int it = 0; it < iter_max_; ++it) {
+      for (int i = 0; i < N - 2; ++i) two_site(i, true, trunc_err_, chi_min_, nullptr, nullptr);
+      int ks = 0;
+      for (int i = N - 2; i > 0; --i) ks = two_site(i, false, trunc_err_, chi_min_, i == 1 ? Sd : nullptr, i == 1 ? slog : nullptr);
+      ++n_var_iters_;
+      PG_CHECK_HIP(hipMemcpyAsync(h_s.data(), Sd, sizeof(T) * (size_t)ks * nw_, hipMemcpyDeviceToHost, stream_));
+      PG_CHECK_HIP(hipMemcpyAsync(h_log.data(), slog, sizeof(double) * nw_, hipMemcpyDeviceToHost, stream_));
+      PG_CHECK_HIP(hipStreamSynchronize(stream_));
+      bool all = it > 0 && ks == ks_last;
+      if (all) {
+        for (int w = 0; w < nw_ && all; ++w) {
+          const T *s = &h_s[(size_t)w * ks], *sl = &h_last[(size_t)w * ks];
+          int n = 0, nl = 0;
+          for (int x = 0; x < ks; ++x) { n += s[x] != T(0); nl += sl[x] != T(0); }
+          if (n != nl || !(s[0] > T(0))) { all = false; break; }   // bond dimension changed (bmps_impl.h:946)
+          const double rel = std::exp(h_log_last[w] - h_log[w]);
+          double diff = 0.0;
+          for (int x = 0; x < ks; ++x) diff += std::fabs((double)s[x] - (double)sl[x] * rel);
+          if (!(diff / (double)s[0] < conv_tol_)) all = false;
+        }
+      }
+      if (all) break;
+      h_last = h_s; h_log_last = h_log; ks_last = ks;
+    }
+    arena_.free(Sd);
+    arena_.free(slog);
+    close_at_zero(trunc_err_, chi_min_, false);
+  } else {
+    // ---------------- one-site scheme (bmps_impl.h:1021-1166) ----------------
+    for (int i = 0; i < N - 2; ++i) two_site(i, true, trunc_err_, chi_, nullptr, nullptr);      // SVD(.., Dmax, Dmax)
+    for (int i = N - 2; i > 0; --i) two_site(i, false, trunc_err_, chi_, nullptr, nullptr);
+    close_at_zero(trunc_err_, chi_min_, true);                                                     // renv of sites >= 1 kept
+    double *rlog = (double *)arena_.alloc(sizeof(double) * nw_);
+    for (int it = 0; it < iter_max_; ++it) {
+      for (int i = 0; i + 1 < N; ++i) {          // right-moving: Q of t2 = t1 . renv
+        DTen<T> t1 = half_left(i, lenvs.back());
+        const int k = t1.d[0], u = t1.d[1], b = t1.d[2], f = t1.d[3], q = renvs.back().t.d[2];
+        DTen<T> t2 = alloc_ten(q, k, u);
+        ein(ein_view<T>(renvs.back().t.p, renvs.back().t.n, "bfn", {b, f, q}), ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}),
+            ein_view<T>(t2.p, t2.n, "nku", {q, k, u}), t2.p);
+        const int kn = std::min(q, k * u);
+        DTen<T> Qt = svd_rows(t2, q, k * u, kn, 0.0, kn, nullptr);
+        free_ten(t2);
+        Env ne = grow_left(t1, Qt, kn, lenvs.back());
+        lenvs.push_back(ne);
+        free_env(renvs.back());
+        renvs.pop_back();
+        free_ten(Qt);
+        free_ten(t1);
+      }
+      for (int i = N - 1; i > 0; --i) {          // left-moving: Q of t2 = lenv . t3
+        DTen<T> t3 = half_right(i, renvs.back());
+        const int v = t3.d[0], q = t3.d[1], b = t3.d[2], f = t3.d[3], k = lenvs.back().t.d[0];
+        DTen<T> t2 = alloc_ten(k, v, q);
+        ein(ein_view<T>(lenvs.back().t.p, lenvs.back().t.n, "kfb", {k, f, b}), ein_view<T>(t3.p, t3.n, "vqbf", {v, q, b, f}),
+            ein_view<T>(t2.p, t2.n, "kvq", {k, v, q}), t2.p);
+        if (i == 1) {   // |r| of the last QR = |t2| exp(log lenv + log renv)   (bmps_impl.h:1149)
+          PG_CHECK_HIP(hipMemsetAsync(rlog, 0, sizeof(double) * nw_, stream_));
+          add_logs(rlog, lenvs.back().log, renvs.back().log, nullptr, nullptr);
+          normalize(t2.p, t2.n, t2.n, nw_, rlog);
+        }
+        const int kn = std::min(k, v * q);
+        DTen<T> Qt = svd_rows(t2, k, v * q, kn, 0.0, kn, nullptr);
+        free_ten(t2);
+        Qt.d[0] = kn; Qt.d[1] = v; Qt.d[2] = q;
+        arena_.free(B[i].p);
+        B[i] = Qt;
+        Env ne = grow_right(t3, Qt, renvs.back());
+        renvs.push_back(ne);
+        free_env(lenvs.back());
+        lenvs.pop_back();
+        free_ten(t3);
+      }
+      ++n_var_iters_;
+      PG_CHECK_HIP(hipMemcpyAsync(h_log.data(), rlog, sizeof(double) * nw_, hipMemcpyDeviceToHost, stream_));
+      PG_CHECK_HIP(hipStreamSynchronize(stream_));
+      bool all = it > 0;
+      for (int w = 0; w < nw_ && all; ++w)
+        if (std::fabs(1.0 - std::exp(h_log_last[w] - h_log[w])) > conv_tol_) all = false;   // |r - r_last| / |r|
+      if (all) break;
+      h_log_last = h_log;
+    }
+    arena_.free(rlog);
+    // res[0] = t1 . renv   (bmps_impl.h:1158-1164)
+    DTen<T> t1 = half_left(0, lenvs.back());
+    const int k = t1.d[0], u = t1.d[1], b = t1.d[2], f = t1.d[3], q = renvs.back().t.d[2];
+    DTen<T> B0 = alloc_ten(k, u, q);
+    ein(ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}), ein_view<T>(renvs.back().t.p, renvs.back().t.n, "bfn", {b, f, q}),
+        ein_view<T>(B0.p, B0.n, "kun", {k, u, q}), B0.p);
+    free_ten(t1);
+    arena_.free(B[0].p);
+    B[0] = B0;
+    PG_CHECK_HIP(hipMemcpyAsync(res.logscale, in.logscale, sizeof(double) * nw_, hipMemcpyDeviceToDevice, stream_));
+    add_log(res.logscale, renvs.back().log);
+  }
+  normalize(B[0].p, B[0].n, B[0].n, nw_, res.logscale);
+  for (auto &e : lenvs) free_env(e);
+  for (auto &e : renvs) free_env(e);
+  ++n_absorb_;
+  return res;
+}
+
+}  // namespace pepsgpu

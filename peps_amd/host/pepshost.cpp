@@ -26,6 +26,15 @@ SplitIndexTPS make_state(int rows, int cols, int D, int d, const double *flat) {
   std::copy(flat, flat + s.flat().size(), s.flat().begin());
   return s;
 }
+// BMPSTruncateParams of the contractors built below: SVD(chi, chi, 0) unless pepshost_set_truncate_params changed
+// D_min / trunc_err / scheme (D_max is always the call's chi)
+struct TruncOverride { int d_min = -1; double trunc_err = 0.0; int scheme = 0; double tol = 0.0; int iters = 0; } g_trunc;
+BMPSTruncateParams trunc_params(int chi) {
+  const size_t dmin = g_trunc.d_min < 0 ? (size_t)chi : (size_t)std::min(g_trunc.d_min, chi);
+  if (g_trunc.scheme == 1) return BMPSTruncateParams::Variational2Site(dmin, chi, g_trunc.trunc_err, g_trunc.tol, g_trunc.iters);
+  if (g_trunc.scheme == 2) return BMPSTruncateParams::Variational1Site(dmin, chi, g_trunc.trunc_err, g_trunc.tol, g_trunc.iters);
+  return BMPSTruncateParams::SVD(dmin, chi, g_trunc.trunc_err);
+}
 Configuration make_cfg(int n, int rows, int cols, const int32_t *cfg) {
   Configuration c(n, rows, cols);
   std::copy(cfg, cfg + (size_t)n * rows * cols, c.data());
@@ -37,6 +46,14 @@ extern "C" {
 
 const char *pepshost_last_error(void) { return g_err.c_str(); }
 
+// d_min < 0: D_min = chi.  scheme: 0 SVD_COMPRESS, 1 VARIATION2Site, 2 VARIATION1Site (bmps.h:31-35)
+int pepshost_set_truncate_params(int d_min, double trunc_err, int scheme, double convergence_tol, int iter_max) {
+  return guarded([&]() {
+    if (scheme < 0 || scheme > 2) throw std::invalid_argument("unknown CompressMPSScheme");
+    g_trunc.d_min = d_min; g_trunc.trunc_err = trunc_err; g_trunc.scheme = scheme; g_trunc.tol = convergence_tol; g_trunc.iters = iter_max;
+  });
+}
+
 // n_sweeps Monte-Carlo sweeps (square_nn_updater.h:30-81) of n walkers; updater 0 = NN exchange,
 // 1 = NN full-space (Suwa-Todo).  configs are updated in place; one std::mt19937(seed[w]) per walker.
 int pepshost_mc_sweeps(int rows, int cols, int D, int d, int chi, int dtype, const double *sitps_flat, int n,
@@ -44,7 +61,7 @@ int pepshost_mc_sweeps(int rows, int cols, int D, int d, int chi, int dtype, con
                        double *accept_rates_out) {
   return guarded([&]() {
     SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
-    BMPSContractor contractor(rows, cols, D, d, BMPSTruncateParams::SVD(chi, chi, 0.0), n, dtype);
+    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), n, dtype);
     TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor);
     std::vector<uint64_t> sd(seeds, seeds + n);
     std::vector<double> rates, acc(n, 0.0);
@@ -68,7 +85,7 @@ int pepshost_energy_and_holes(int rows, int cols, int D, int d, int chi, int dty
                               double *energies_out, double *holes_out, double *psi_out, int *n_psi_out) {
   return guarded([&]() {
     SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
-    BMPSContractor contractor(rows, cols, D, d, BMPSTruncateParams::SVD(chi, chi, 0.0), n, dtype);
+    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), n, dtype);
     TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor);
     EnergyAndHoles eh;
     if (model == 0) {
@@ -99,7 +116,7 @@ int pepshost_mc_energy_grad_partial(int rows, int cols, int D, int d, int chi, i
                                     int warmup_sweeps, int n_samples, double *packed_out, double *accept_out) {
   return guarded([&]() {
     SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
-    BMPSContractor contractor(rows, cols, D, d, BMPSTruncateParams::SVD(chi, chi, 0.0), n, dtype);
+    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), n, dtype);
     TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor);
     std::vector<uint64_t> sd(seeds, seeds + n);
     MCUpdateSquareNNExchangeOBC ex(sd);
@@ -135,7 +152,7 @@ int pepshost_exact_sum_partial(int rows, int cols, int D, int d, int chi, int dt
                                int batch, double *packed_out) {
   return guarded([&]() {
     SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
-    BMPSContractor contractor(rows, cols, D, d, BMPSTruncateParams::SVD(chi, chi, 0.0), batch, dtype);
+    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), batch, dtype);
     std::vector<std::vector<int32_t>> all(n_configs);
     for (int i = 0; i < n_configs; ++i) all[i].assign(all_configs + (size_t)i * rows * cols, all_configs + (size_t)(i + 1) * rows * cols);
     std::vector<double> packed;
@@ -189,7 +206,7 @@ int pepshost_fermion_energy(int rows, int cols, int D, int d, const int32_t *nf,
     SplitIndexTPS sitps = make_state(rows, cols, D, 4 * d, sitps_ext_flat);
     FermionDecoration dec;
     dec.nf.assign(nf, nf + d);
-    BMPSContractor contractor(rows, cols, D, 4 * d, BMPSTruncateParams::SVD(chi, chi, 0.0), n, dtype);
+    BMPSContractor contractor(rows, cols, D, 4 * d, trunc_params(chi), n, dtype);
     TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor, &dec);
     std::copy(comp.amplitude.begin(), comp.amplitude.end(), amplitudes_out);
     EnergyAndHoles eh;
@@ -216,7 +233,7 @@ int pepshost_fermion_exact_sum_partial(int rows, int cols, int D, int d, const i
     SplitIndexTPS sitps = make_state(rows, cols, D, 4 * d, sitps_ext_flat);
     FermionDecoration dec;
     dec.nf.assign(nf, nf + d);
-    BMPSContractor contractor(rows, cols, D, 4 * d, BMPSTruncateParams::SVD(chi, chi, 0.0), batch, dtype);
+    BMPSContractor contractor(rows, cols, D, 4 * d, trunc_params(chi), batch, dtype);
     std::vector<std::vector<int32_t>> all(n_configs);
     for (int i = 0; i < n_configs; ++i) all[i].assign(all_configs + (size_t)i * rows * cols, all_configs + (size_t)(i + 1) * rows * cols);
     std::vector<double> packed;
@@ -235,7 +252,7 @@ int pepshost_fermion_mc_sweeps(int rows, int cols, int D, int d, const int32_t *
     SplitIndexTPS sitps = make_state(rows, cols, D, 4 * d, sitps_ext_flat);
     FermionDecoration dec;
     dec.nf.assign(nf, nf + d);
-    BMPSContractor contractor(rows, cols, D, 4 * d, BMPSTruncateParams::SVD(chi, chi, 0.0), n, dtype);
+    BMPSContractor contractor(rows, cols, D, 4 * d, trunc_params(chi), n, dtype);
     TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor, &dec);
     std::vector<uint64_t> sd(seeds, seeds + n);
     MCUpdateSquareNNExchangeOBC ex(sd);

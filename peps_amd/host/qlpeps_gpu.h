@@ -32,6 +32,7 @@
 #include <random>
 #include <sstream>
 #include <stdexcept>
+#include <optional>
 #include <string>
 #include <vector>
 
@@ -43,7 +44,7 @@ enum BondOrientation { HORIZONTAL = 0, VERTICAL = 1 };      // basic.h:19-22
 enum BMPSPOSITION { LEFT = 0, DOWN = 1, RIGHT = 2, UP = 3 };  // basic.h:58-63
 enum DIAGONAL_DIR { LEFTUP_TO_RIGHTDOWN = 0, LEFTDOWN_TO_RIGHTUP = 1 };  // basic.h:89-92
 using BTenPOSITION = BMPSPOSITION;
-enum class CompressMPSScheme { SVD_COMPRESS = 0 };           // bmps.h:31-35 (variational: not implemented)
+enum class CompressMPSScheme { SVD_COMPRESS = 0, VARIATION2Site = 1, VARIATION1Site = 2 };   // bmps.h:31-35
 
 struct SiteIdx {                                             // framework/site_idx.h:20-26
   size_t r = 0, c = 0;
@@ -55,9 +56,21 @@ struct BMPSTruncateParams {                                  // bmps.h:47-98
   size_t D_min = 1, D_max = 1;
   double trunc_err = 0.0;
   CompressMPSScheme compress_scheme = CompressMPSScheme::SVD_COMPRESS;
+  std::optional<double> convergence_tol;                     // variational schemes only (bmps.h:55-56)
+  std::optional<size_t> iter_max;
   static BMPSTruncateParams SVD(size_t d_min, size_t d_max, double trunc_error) {
     BMPSTruncateParams p;
     p.D_min = d_min; p.D_max = d_max; p.trunc_err = trunc_error;
+    return p;
+  }
+  static BMPSTruncateParams Variational2Site(size_t d_min, size_t d_max, double trunc_error, double tol, size_t iters) {
+    BMPSTruncateParams p = SVD(d_min, d_max, trunc_error);   // bmps.h:81-88
+    p.compress_scheme = CompressMPSScheme::VARIATION2Site; p.convergence_tol = tol; p.iter_max = iters;
+    return p;
+  }
+  static BMPSTruncateParams Variational1Site(size_t d_min, size_t d_max, double trunc_error, double tol, size_t iters) {
+    BMPSTruncateParams p = SVD(d_min, d_max, trunc_error);   // bmps.h:90-97
+    p.compress_scheme = CompressMPSScheme::VARIATION1Site; p.convergence_tol = tol; p.iter_max = iters;
     return p;
   }
 };
@@ -237,8 +250,17 @@ class BMPSContractor {
     int rc = pepsgpu_ctx_create(&ctx_, device, dtype, (int)rows, (int)cols, (int)D, (int)phys_dim, (int)p.D_min,
                                 (int)p.D_max, p.trunc_err, (int)p.compress_scheme, (int)max_walkers);
     if (rc != PEPSGPU_OK) { ctx_ = nullptr; check_rc(rc, nullptr); }
+    if (p.compress_scheme != CompressMPSScheme::SVD_COMPRESS) SetTruncateParams(p);
   }
   ~BMPSContractor() { if (ctx_) pepsgpu_ctx_destroy(ctx_); }
+  // bmps_contractor.h:216; the variational schemes need convergence_tol and iter_max (bmps_impl.h:425-430 .value())
+  void SetTruncateParams(const BMPSTruncateParams &p) {
+    if (p.compress_scheme != CompressMPSScheme::SVD_COMPRESS && !(p.convergence_tol && p.iter_max))
+      throw std::invalid_argument("variational compression needs convergence_tol and iter_max");
+    check_rc(pepsgpu_set_truncate_params(ctx_, (int)p.D_min, (int)p.D_max, p.trunc_err, (int)p.compress_scheme,
+                                         p.convergence_tol.value_or(0.0), (int)p.iter_max.value_or(0)), ctx_);
+    trunc_ = p;
+  }
   BMPSContractor(const BMPSContractor &) = delete;
   BMPSContractor &operator=(const BMPSContractor &) = delete;
 

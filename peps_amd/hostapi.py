@@ -45,6 +45,14 @@ def _dims(flat):
     return rows, cols, d, D
 
 
+def set_truncate_params(d_min=-1, trunc_err=0.0, scheme=0, convergence_tol=0.0, iter_max=0):
+    """BMPSTruncateParams used by every following call (D_max = the call's chi): SVD / Variational2Site / Variational1Site
+    (bmps.h:47-98).  set_truncate_params() restores SVD(chi, chi, 0)."""
+    l = lib()
+    l.pepshost_set_truncate_params.argtypes = [C.c_int, C.c_double, C.c_int, C.c_double, C.c_int]
+    _ck(l.pepshost_set_truncate_params(d_min, trunc_err, scheme, convergence_tol, iter_max))
+
+
 def mc_sweeps(flat, configs, seeds, chi, updater="exchange", n_sweeps=1, dtype=1):
     flat = np.ascontiguousarray(flat, dtype=np.float64)
     rows, cols, d, D = _dims(flat)

@@ -224,3 +224,30 @@ def test_j1j2_energy_fixed_configs_and_exact_sum(dt, tol):
     e_o, g_o, _ = vmc.exact_sum_energy_evaluator(s3, list(all_cfg), BMPSTruncateParams.SVD(16, 16, 0.0),
                                                  vmc.SquareSpinOneHalfJ1J2XXZModelOBC(*params))
     assert abs(e / e_o - 1) < tol
+
+
+@pytest.mark.parametrize("scheme,name", [(1, "Variational2Site"), (2, "Variational1Site")])
+def test_xxz_energy_with_variational_truncate_params(scheme, name):
+    """The C++ solver with BMPSTruncateParams::Variational2Site / 1Site (bmps.h:81-97): local energies and
+    amplitudes follow the oracle run with the same parameters on a truncating contraction (5x5, D=3, chi=4)."""
+    host = _host()
+    L, D, chi = 5, 3, 4
+    s = synthetic.make_sitps(L, D, noise=1.0)
+    cfgs = synthetic.make_configs(L, 4, "heisenberg")
+    tp = getattr(BMPSTruncateParams, name)(chi, chi, 0.0, 1e-13, 30)
+    model = vmc.SquareSpinOneHalfXXZModelOBC()
+    ref = []
+    for c in cfgs:
+        comp = vmc.TPSWaveFunctionComponent(s, c, tp)
+        e, _, _ = model.CalEnergyAndHoles(s, comp, True)
+        ref.append((comp.amplitude, e))
+    svd = _oracle_energy(s, cfgs, chi, model)
+    host.set_truncate_params(chi, 0.0, scheme, 1e-13, 30)
+    try:
+        amps, en, _, _ = host.energy_and_holes(synthetic.sitps_to_flat(s, D), cfgs, chi, "xxz", (1.0, 1.0, 0.0), True, F64)
+    finally:
+        host.set_truncate_params()
+    for w, (a, e) in enumerate(ref):
+        assert abs(amps[w] / a - 1) < 1e-7
+        assert abs(en[w] - e) < 1e-6 * max(1.0, abs(e))
+    assert max(abs(svd[w][1] - ref[w][1]) for w in range(len(ref))) > 1e-5      # the scheme is in effect
