@@ -24,6 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}     # /opt/skills/guides/MI355X_MICROARCH.md, dense MFMA peaks
+PEAK_HBM_GBPS = 8000.0                        # same guide: HBM3E, ~8 TB/s
 
 
 def parse():
@@ -177,6 +178,14 @@ def main():
         achieved = counted / dsec / 1e12 if dsec > 0 else 0.0
         ref_equiv = prof[dom]["alg_flops"] / dsec / 1e12 if dsec > 0 else 0.0
         peak = PEAK_TFLOPS[args.dtype]
+        # compulsory traffic of the same launches: bytes of the live operand and result elements, counted on the
+        # device next to the flops.  Below the machine balance (peak flops / peak HBM bandwidth) the kernel is
+        # bound by HBM, not by MFMA issue, and the roofline is priced in bytes.
+        dbytes = prof[dom].get("bytes", 0.0)
+        intensity = counted / dbytes if dbytes > 0 else float("inf")
+        balance = peak * 1e12 / (PEAK_HBM_GBPS * 1e9)
+        hbm_bound = intensity < balance
+        gbps = dbytes / dsec / 1e9 if dsec > 0 else 0.0
         out = {
             "metric": "configuration-amplitudes/sec",
             "value": value,
@@ -199,18 +208,26 @@ def main():
                 "synthetic_noise": args.noise,
             },
             "roofline": {
-                "bound": "mfma",
+                "bound": "hbm" if hbm_bound else "mfma",
                 "kernel": dom,
-                "achieved": achieved,
-                "peak": peak,
-                "unit": "TFLOP/s",
-                "frac": achieved / peak,
+                "achieved": gbps if hbm_bound else achieved,
+                "peak": PEAK_HBM_GBPS if hbm_bound else peak,
+                "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": gbps / PEAK_HBM_GBPS if hbm_bound else achieved / peak,
                 "traffic": pmc_traffic_bytes(dom, args, nw),
+                "algorithmic_bytes_per_launch": dbytes / max(prof[dom]["launches"], 1),
+                "arithmetic_intensity_flop_per_byte": intensity if dbytes > 0 else None,
+                "machine_balance_flop_per_byte": balance,
+                "mfma_tflops": achieved,
+                "mfma_frac": achieved / peak,
                 "avg_launch_ms": prof[dom]["ms"] / max(prof[dom]["launches"], 1),
                 "launches": prof[dom]["launches"],
                 "reference_equivalent_tflops": ref_equiv,
-                "note": "achieved = flops this kernel category contracts (2*I*J*K over each walker's live extents, "
-                        "counted on the device) / HIP-event time on the launch stream.  reference_equivalent_tflops "
+                "note": "bound: the launches of this category contract 2*I*J*K flops over each walker's live extents and "
+                        "move (I*K + K*J + I*J) elements (both counted on the device); their ratio against the machine "
+                        "balance decides whether the roofline is priced in bytes (hbm) or flops (mfma).  achieved = that "
+                        "count / HIP-event time on the launch stream; mfma_tflops is the flop rate of the same launches.  "
+                        "traffic = measured HBM bytes per full-size launch (PMC).  reference_equivalent_tflops "
                         "prices the same launches with the flops of the reference ops they replace (SURVEY 8d): the "
                         "rank-adaptive path needs far fewer flops than the reference algorithm on this workload "
                         "(workload_rank), so that figure exceeds the machine peak.  The contractions are tiny per "

@@ -170,7 +170,7 @@ int pepsgpu_sync(pepsgpu_ctx *ctx);
 /* stats_out: [0] row absorptions, [1] Jacobi launches, [2] reserved, [3] device bytes held */
 int pepsgpu_stats(pepsgpu_ctx *ctx, double *stats_out, int n);
 /* Per-kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).
- * out = [8][4]: {ms, launches, algorithmic flops, executed flops} per category
+ * out = [8][5]: {ms, launches, algorithmic flops, executed flops, operand + result bytes of the live extents} per category
  * 0 contraction GEMMs, 1 f64 Gram, 2 Cholesky, 3 Jacobi, 4 select, 5 normalise, 6 BTen/trace GEMMs.
  * "algorithmic" = flops of the reference op the launch replaces (SURVEY.md 8d formulas). */
 int pepsgpu_profile_enable(pepsgpu_ctx *ctx, int on);

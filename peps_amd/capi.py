@@ -327,9 +327,10 @@ class Context:
         self._ck(self._l.pepsgpu_profile_enable(self._h, int(on)))
 
     def profile_read(self):
-        out = np.zeros((8, 4), dtype=np.float64)
+        out = np.zeros((8, 5), dtype=np.float64)
         self._ck(self._l.pepsgpu_profile_read(self._h, _dp(out)))
-        return {name: {"ms": out[i, 0], "launches": int(out[i, 1]), "alg_flops": out[i, 2], "exec_flops": out[i, 3]}
+        return {name: {"ms": out[i, 0], "launches": int(out[i, 1]), "alg_flops": out[i, 2], "exec_flops": out[i, 3],
+                       "bytes": out[i, 4]}
                 for i, name in enumerate(self.PROF_CATS)}
 
     def stats(self):

@@ -83,7 +83,7 @@ struct EngineBase {
   virtual void sr_sum(double *out) = 0;
   virtual void sr_matvec(const double *v, double mean_dot_v, double scale, double *out) = 0;
   virtual void profile_enable(int on) = 0;
-  virtual void profile_read(double *out) = 0;   // [PROF_NCAT][4]: ms, launches, algorithmic flops, executed flops
+  virtual void profile_read(double *out) = 0;   // [PROF_NCAT][5]: ms, launches, algorithmic flops, executed flops, operand+result bytes
 };
 
 template <typename T> struct EinView;
@@ -667,15 +667,16 @@ class Engine : public EngineBase {
   void profile_read(double *out) override {
     prof_resolve();
     // flops the tensor GEMMs of each category actually contracted (live extents), counted on the device
-    unsigned long long hc[PROF_NCAT] = {0};
+    unsigned long long hc[2 * PROF_NCAT] = {0};
     if (flopc_) {
       PG_CHECK_HIP(hipMemcpyAsync(hc, flopc_, sizeof(hc), hipMemcpyDeviceToHost, stream_));
       PG_CHECK_HIP(hipMemsetAsync(flopc_, 0, sizeof(hc), stream_));
       PG_CHECK_HIP(hipStreamSynchronize(stream_));
     }
     for (int c = 0; c < PROF_NCAT; ++c) {
-      out[4 * c + 0] = prof_ms_[c]; out[4 * c + 1] = (double)prof_n_[c];
-      out[4 * c + 2] = prof_alg_[c]; out[4 * c + 3] = hc[c] ? (double)hc[c] : prof_exec_[c];
+      out[5 * c + 0] = prof_ms_[c]; out[5 * c + 1] = (double)prof_n_[c];
+      out[5 * c + 2] = prof_alg_[c]; out[5 * c + 3] = hc[c] ? (double)hc[c] : prof_exec_[c];
+      out[5 * c + 4] = (double)hc[PROF_NCAT + c];
       prof_ms_[c] = 0; prof_n_[c] = 0; prof_alg_[c] = 0; prof_exec_[c] = 0;
     }
   }
@@ -688,13 +689,15 @@ class Engine : public EngineBase {
     PG_CHECK_HIP(hipEventRecord(r.a, stream_));
     prof_.push_back(r);
     if (!flopc_) {
-      flopc_ = (unsigned long long *)arena_.alloc(sizeof(unsigned long long) * PROF_NCAT);
-      PG_CHECK_HIP(hipMemsetAsync(flopc_, 0, sizeof(unsigned long long) * PROF_NCAT, stream_));
+      flopc_ = (unsigned long long *)arena_.alloc(sizeof(unsigned long long) * 2 * PROF_NCAT);
+      PG_CHECK_HIP(hipMemsetAsync(flopc_, 0, sizeof(unsigned long long) * 2 * PROF_NCAT, stream_));
     }
     tg_flop_counter = flopc_ + cat;
+    tg_byte_counter = flopc_ + PROF_NCAT + cat;
   }
   void prof_end() {
     tg_flop_counter = nullptr;
+    tg_byte_counter = nullptr;
     if (!prof_on_) return;
     PG_CHECK_HIP(hipEventRecord(prof_.back().b, stream_));
   }
@@ -953,7 +956,7 @@ class Engine : public EngineBase {
   double *holes_ls_ = nullptr;            // its log-scales [walker][site]
   double *so_ = nullptr, *seo_ = nullptr; // gradient accumulators
   int *sweeps_ = nullptr;
-  unsigned long long *flopc_ = nullptr;   // device flop counters per profile category
+  unsigned long long *flopc_ = nullptr;   // device flop counters [PROF_NCAT] then byte counters [PROF_NCAT]
   T *sr_o_ = nullptr;                      // O* samples [sample][site][D^4]
   int *sr_cfg_ = nullptr;                  // their configurations [sample][site]
   int *sr_ne_ = nullptr;                   // elements of the (compact) site tensor per site

@@ -51,6 +51,7 @@ struct TGemmDesc {
   int upper_only = 0;   // symmetric result (Gram): tiles strictly below the diagonal are not computed
   const int *batch_flag = nullptr;   // when set, batch entry b runs only if batch_flag[b] < 0
   unsigned long long *flopc = nullptr;   // profiling: += 2*I*J*K of the extents actually contracted (per batch entry)
+  unsigned long long *bytec = nullptr;   // profiling: += bytes of the live operand and result elements (compulsory traffic)
   int flop_stride = 1;                    // ... sampled: every flop_stride-th batch entry adds flop_stride times its count
   double alpha = 1.0;
 
@@ -276,7 +277,13 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__res
   if (d.dynI) Itot = min(Itot, d.dynI[b] * d.dynI_mul);
   if (d.dynK) Ktot = min(Ktot, d.dynK[b] * d.dynK_mul);
   if (d.flopc && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && b % d.flop_stride == 0)
+  {
     atomicAdd(d.flopc, (unsigned long long)(d.upper_only ? 1 : 2) * d.flop_stride * Itot * d.Jtot() * Ktot);
+    if (d.bytec)
+      atomicAdd(d.bytec, (unsigned long long)d.flop_stride *
+                             ((unsigned long long)Itot * Ktot * sizeof(TA) + (unsigned long long)Ktot * d.Jtot() * sizeof(TB) +
+                              (unsigned long long)Itot * d.Jtot() * sizeof(TC) / (d.upper_only ? 2 : 1)));
+  }
   for (int i0 = blockIdx.x * TG_BM; i0 < Itot; i0 += gridDim.x * TG_BM) {   // block-uniform trip count
     if (d.upper_only && (int)(blockIdx.y + 1) * TG_BN <= i0) continue;
     tgemm_tile<TA, TB, TC, TAcc, USE_MFMA>(d, Ag, Bg, Cg, i0, Itot, Ktot);
@@ -316,7 +323,10 @@ __global__ __launch_bounds__(256, 6) void tgemm_direct_kernel(TGemmDesc d, const
   const int nti = (Itot + 31) >> 5, ntj = (Jtot + 31) >> 5, ntiles = nti * ntj;
   if (ntiles == 0) return;
   if (d.flopc && threadIdx.x == 0 && blockIdx.x == 0 && b % d.flop_stride == 0)
+  {
     atomicAdd(d.flopc, 2ull * d.flop_stride * Itot * Jtot * d.Ktot());
+    if (d.bytec) atomicAdd(d.bytec, 4ull * d.flop_stride * ((unsigned long long)Itot * d.Ktot() + (unsigned long long)d.Ktot() * Jtot + (unsigned long long)Itot * Jtot));
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   long baseA = (long)(b / d.bdivA) * d.wA, baseB = (long)(b / d.bdivB) * d.wB;
   if (d.selA) baseA += (long)d.selA[(long)(b / d.seldivA) * d.selA_inc] * d.selA_mul;
@@ -395,6 +405,7 @@ bool tgemm_use_mfma();
 
 // device counter the launches of the current profiling bracket add their contracted flops to (engine.h prof_begin)
 inline thread_local unsigned long long *tg_flop_counter = nullptr;
+inline thread_local unsigned long long *tg_byte_counter = nullptr;
 
 template <typename TA, typename TB, typename TC, typename TAcc>
 void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B, TC *C) {
@@ -402,6 +413,7 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
   TGemmDesc d = d_in;
   PG_REQUIRE(d.nbatch <= 65535, 1, "walkers x candidates exceeds 65535 (grid z limit): use a smaller walker batch");
   d.flopc = tg_flop_counter;
+  d.bytec = tg_byte_counter;
   d.flop_stride = d.nbatch >= 256 ? 64 : 1;   // one atomic per 64 walkers: a same-address atomic per block costs ~10 %
   int gx = (d.Itot() + TG_BM - 1) / TG_BM;
   const bool dyn_i = d.dynI || (d.dI[0].p && !d.dI[0].mask) || (d.dI[1].p && !d.dI[1].mask) || (d.dI[2].p && !d.dI[2].mask);
