@@ -152,6 +152,24 @@ int pepsgpu_sr_append(pepsgpu_ctx *ctx, const double *psi);
 int pepsgpu_sr_count(pepsgpu_ctx *ctx);
 int pepsgpu_sr_sum(pepsgpu_ctx *ctx, double *sum_out);
 int pepsgpu_sr_matvec(pepsgpu_ctx *ctx, const double *v, double mean_dot_v, double scale, double *out);
+/* ConjugateGradientSolver (utility/conjugate_gradient_solver.h:181-276) on (S + diag_shift) x = b over the samples of THIS
+ * context, every vector resident in HBM; parameters = ConjugateGradientParams (optimizer/optimizer_params.h:50-57).
+ * b, x0 (NULL = 0) and x_out are host buffers in the state layout.  reason = CGTerminationReason:
+ * 0 converged, 1 max iterations, 2 indefinite matrix, 3 numerical breakdown, 4 stagnated; on 1..4 x_out is the best iterate.
+ * Multi-rank solves go through pepsgpu_sr_matvec + an all-reduce per product (peps_amd/sr.py). */
+int pepsgpu_sr_cg_solve(pepsgpu_ctx *ctx, const double *b, const double *x0, double diag_shift, int max_iter,
+                        double relative_tolerance, double absolute_tolerance, int residual_recompute_interval,
+                        double orthogonality_threshold, double *x_out, double *residual_norm, int *iterations, int *reason);
+/* MinSR building blocks (optimizer/minsr_tmatrix.h:53-147, optimizer_impl.h:1126-1215):
+ *   pepsgpu_sr_gram          out[i][j] = <O*_i, O*_j'>, i over the local samples, j over a batch of n_remote samples given by
+ *                            DEVICE pointers (layout of the local store: [sample][site][D^4] of the context's dtype and
+ *                            int32 [sample][site]); remote == NULL: the local batch against itself.  One MFMA GEMM, f64 sums.
+ *   pepsgpu_sr_weighted_sum  out = sum_i y[i] O*_i over the local samples (state layout) -- the back-substitution
+ *   pepsgpu_sr_copy_samples  device-to-device copy of the local store into caller-owned device buffers (what the ring
+ *                            exchange of MinSRTMatrix::Construct sends to the next rank) */
+int pepsgpu_sr_gram(pepsgpu_ctx *ctx, const void *remote_samples_dev, const int32_t *remote_configs_dev, int n_remote, double *out);
+int pepsgpu_sr_weighted_sum(pepsgpu_ctx *ctx, const double *y, double *out);
+int pepsgpu_sr_copy_samples(pepsgpu_ctx *ctx, void *dst_samples_dev, int32_t *dst_configs_dev);
 
 /* TPSWaveFunctionComponent::UpdateLocal (wave_function_component.h:345-378) for the walkers with
  * accept_mask[w] != 0 (NULL = all): config(site_k) = new_states[w][k], tn.UpdateSiteTensor,

@@ -24,6 +24,104 @@ class SRSMatrix:
         return res
 
 
+# CGTerminationReason (utility/conjugate_gradient_solver.h:74-80)
+K_CONVERGED, K_MAX_ITERATIONS, K_INDEFINITE, K_BREAKDOWN, K_STAGNATED = 0, 1, 2, 3, 4
+
+
+def conjugate_gradient_full(matvec, b, x0, max_iter=100, relative_tolerance=1e-4, absolute_tolerance=0.0,
+                            residual_recompute_interval=20, orthogonality_threshold=0.5):
+    """ConjugateGradientSolver (utility/conjugate_gradient_solver.h:181-276) with every branch of the reference:
+    indefinite-matrix exit, stagnation detection, periodic residual recomputation, NaN/Inf exits, best-iterate
+    tracking, orthogonality-based restart.  Parameter defaults = ConjugateGradientParams (optimizer_params.h:50-57).
+    Returns (x, residual_norm, iterations, reason)."""
+    b = np.asarray(b, dtype=np.float64).ravel()
+    x0 = np.asarray(x0, dtype=np.float64).ravel()
+    eps = np.finfo(np.float64).eps
+    tol_sq = max(relative_tolerance ** 2 * float(b @ b), absolute_tolerance ** 2)
+    r = b - matvec(x0)
+    rr = float(r @ r)
+    if rr <= tol_sq:
+        return x0.copy(), np.sqrt(rr), 0, K_CONVERGED
+    p, x, best_x, best_rr = r.copy(), x0.copy(), x0.copy(), rr
+    r_prev = r.copy()
+    rkp1 = rr
+    stagnation = 0
+    for k in range(max_iter):
+        rk = rkp1
+        ap = matvec(p)
+        pap = float(p @ ap)
+        if not (np.isfinite(pap) and pap > 0.0):                           # detail::pap_is_valid (:142-148)
+            return best_x, np.sqrt(best_rr), k, K_INDEFINITE
+        alpha = rk / pap
+        x = x + alpha * p
+        if alpha * alpha * float(p @ p) < eps * eps * float(x @ x):       # :227-236
+            stagnation += 1
+            if stagnation >= 3:
+                return best_x, np.sqrt(best_rr), k + 1, K_STAGNATED
+        else:
+            stagnation = 0
+        if residual_recompute_interval > 0 and (k % residual_recompute_interval) == residual_recompute_interval - 1:
+            r = b - matvec(x)                                              # :238-239
+        else:
+            r = r - alpha * ap
+        rkp1 = float(r @ r)
+        if not np.isfinite(rkp1):
+            return best_x, np.sqrt(best_rr), k + 1, K_BREAKDOWN
+        if rkp1 < best_rr:
+            best_x, best_rr = x.copy(), rkp1
+        if rkp1 <= tol_sq:
+            return x, np.sqrt(rkp1), k + 1, K_CONVERGED
+        if k > 0 and abs(float(r_prev @ r)) > orthogonality_threshold * rkp1:   # :259-266
+            p = r.copy()
+            r_prev = r.copy()
+            continue
+        r_prev = r.copy()
+        beta = rkp1 / rk
+        if not np.isfinite(beta):
+            return best_x, np.sqrt(best_rr), k + 1, K_BREAKDOWN
+        p = r + beta * p
+    return best_x, np.sqrt(best_rr), max_iter, K_MAX_ITERATIONS
+
+
+def pseudo_inverse_cutoff(eigenvalues, r_pinv, a_pinv, soft_cutoff):
+    """ApplyPseudoInverseCutoff (optimizer/minsr_eigensolve.h:44-78)."""
+    ev = np.asarray(eigenvalues, dtype=np.float64)
+    cutoff = r_pinv * (np.max(np.abs(ev)) if len(ev) else 0.0) + a_pinv
+    out = np.zeros_like(ev)
+    if soft_cutoff:
+        den = ev ** 6 + cutoff ** 6
+        nz = den != 0.0
+        out[nz] = ev[nz] ** 5 / den[nz]
+    else:
+        keep = np.abs(ev) > cutoff
+        out[keep] = 1.0 / ev[keep]
+    return out
+
+
+def minsr_tmatrix(ostar_samples):
+    """MinSRTMatrix::Construct (optimizer/minsr_tmatrix.h:53-147): raw Gram, four-term centering, 1/Ns."""
+    o = np.stack([np.asarray(x, dtype=np.float64).ravel() for x in ostar_samples])
+    ns = o.shape[0]
+    g = o @ o.T
+    m = g.sum(axis=1) / ns
+    c = m.sum() / ns
+    return (g - m[:, None] - m[None, :] + c) / ns
+
+
+def minsr_direction(ostar_samples, ostar_mean, energy_samples, energy, r_pinv=1e-12, a_pinv=0.0, soft_cutoff=True):
+    """Optimizer::CalculateMinSRDirection_ (optimizer/optimizer_impl.h:1126-1215) for one rank (or all ranks'
+    samples concatenated): epsilon_bar, T, replicated eigensolve with pseudo-inverse cutoff
+    (ReplicatedEigenSolveReal, minsr_eigensolve.h:101-155), back-substitution.  Returns (delta_theta, norm)."""
+    o = np.stack([np.asarray(x, dtype=np.float64).ravel() for x in ostar_samples])
+    ns = o.shape[0]
+    eps_bar = (np.asarray(energy_samples, dtype=np.float64) - energy) / ns
+    t = minsr_tmatrix(ostar_samples)
+    ev, z = np.linalg.eigh(t)
+    y = z @ (pseudo_inverse_cutoff(ev, r_pinv, a_pinv, soft_cutoff) * (z.T @ eps_bar))
+    delta = y @ o - y.sum() * np.asarray(ostar_mean, dtype=np.float64).ravel()
+    return delta, float(np.linalg.norm(delta))
+
+
 def conjugate_gradient(matvec, b, x0, max_iter=100, relative_tolerance=1e-10, absolute_tolerance=0.0):
     b = np.asarray(b, dtype=np.float64).ravel()
     x = np.asarray(x0, dtype=np.float64).ravel().copy()

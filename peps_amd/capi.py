@@ -32,6 +32,7 @@ SYMBOLS = [
     "pepsgpu_replace_sqrt5_trace",
     "pepsgpu_grad_reset", "pepsgpu_grad_accumulate", "pepsgpu_grad_read",
     "pepsgpu_sr_begin", "pepsgpu_sr_append", "pepsgpu_sr_count", "pepsgpu_sr_sum", "pepsgpu_sr_matvec",
+    "pepsgpu_sr_cg_solve", "pepsgpu_sr_gram", "pepsgpu_sr_weighted_sum", "pepsgpu_sr_copy_samples",
     "pepsgpu_update_local", "pepsgpu_erase_envs_after_update", "pepsgpu_evaluate_amplitude",
     "pepsgpu_walker_flags", "pepsgpu_sync", "pepsgpu_stats", "pepsgpu_profile_enable", "pepsgpu_profile_read",
     "pepsgpu_diag_tgemm", "pepsgpu_diag_chol", "pepsgpu_diag_chol_adaptive", "pepsgpu_diag_gram_chol", "pepsgpu_diag_jacobi", "pepsgpu_version",
@@ -81,6 +82,10 @@ def load_library(path=LIB_PATH):
     lib.pepsgpu_sr_count.argtypes = [vp]
     lib.pepsgpu_sr_sum.argtypes = [vp, dp]
     lib.pepsgpu_sr_matvec.argtypes = [vp, dp, C.c_double, C.c_double, dp]
+    lib.pepsgpu_sr_cg_solve.argtypes = [vp, dp, dp, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, dp, dp, ip, ip]
+    lib.pepsgpu_sr_gram.argtypes = [vp, vp, vp, C.c_int, dp]
+    lib.pepsgpu_sr_weighted_sum.argtypes = [vp, dp, dp]
+    lib.pepsgpu_sr_copy_samples.argtypes = [vp, vp, vp]
     lib.pepsgpu_update_local.argtypes = [vp, C.c_int, ip, ip, C.POINTER(C.c_uint8)]
     lib.pepsgpu_erase_envs_after_update.argtypes = [vp, C.c_int, C.c_int]
     lib.pepsgpu_evaluate_amplitude.argtypes = [vp, dp]
@@ -281,6 +286,36 @@ class Context:
         out = np.zeros_like(v)
         self._ck(self._l.pepsgpu_sr_matvec(self._h, _dp(v), float(mean_dot_v), float(scale), _dp(out)))
         return out
+
+    def sr_cg_solve(self, b, x0=None, diag_shift=0.0, max_iter=100, relative_tolerance=1e-4, absolute_tolerance=0.0,
+                    residual_recompute_interval=20, orthogonality_threshold=0.5):
+        """(S + diag_shift) x = b with every CG vector on the device; returns (x, residual_norm, iterations, reason)."""
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x0a = None if x0 is None else np.ascontiguousarray(x0, dtype=np.float64)
+        x = np.zeros_like(b)
+        res = np.zeros(1, dtype=np.float64)
+        it = np.zeros(2, dtype=np.int32)
+        self._ck(self._l.pepsgpu_sr_cg_solve(self._h, _dp(b), None if x0a is None else _dp(x0a), diag_shift, max_iter,
+                                             relative_tolerance, absolute_tolerance, residual_recompute_interval,
+                                             orthogonality_threshold, _dp(x), _dp(res), _ip(it[:1]), _ip(it[1:])))
+        return x, float(res[0]), int(it[0]), int(it[1])
+
+    def sr_gram(self, remote_samples_ptr=None, remote_configs_ptr=None, n_remote=0):
+        """raw inner products of the local O* samples with themselves (default) or with a device-resident remote batch"""
+        n = self.sr_count()
+        out = np.zeros((n, n_remote if remote_samples_ptr else n), dtype=np.float64)
+        self._ck(self._l.pepsgpu_sr_gram(self._h, remote_samples_ptr, remote_configs_ptr, n_remote, _dp(out)))
+        return out
+
+    def sr_weighted_sum(self, y):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        assert y.size == self.sr_count()
+        out = np.zeros((self.rows, self.cols, self.d, self.D, self.D, self.D, self.D), dtype=np.float64)
+        self._ck(self._l.pepsgpu_sr_weighted_sum(self._h, _dp(y), _dp(out)))
+        return out
+
+    def sr_copy_samples(self, dst_samples_ptr, dst_configs_ptr):
+        self._ck(self._l.pepsgpu_sr_copy_samples(self._h, dst_samples_ptr, dst_configs_ptr))
 
     def grad_reset(self):
         self._ck(self._l.pepsgpu_grad_reset(self._h))

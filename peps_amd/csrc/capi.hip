@@ -185,6 +185,23 @@ int pepsgpu_sr_sum(pepsgpu_ctx *ctx, double *out) { CTX_CALL(PG_REQUIRE(out, 1, 
 int pepsgpu_sr_matvec(pepsgpu_ctx *ctx, const double *v, double mean_dot_v, double scale, double *out) {
   CTX_CALL(PG_REQUIRE(v && out, 1, "null vector"); ctx->eng->sr_matvec(v, mean_dot_v, scale, out));
 }
+int pepsgpu_sr_cg_solve(pepsgpu_ctx *ctx, const double *b, const double *x0, double diag_shift, int max_iter,
+                        double relative_tolerance, double absolute_tolerance, int residual_recompute_interval,
+                        double orthogonality_threshold, double *x_out, double *residual_norm, int *iterations, int *reason) {
+  CTX_CALL(PG_REQUIRE(b && x_out && residual_norm && iterations && reason, 1, "null argument");
+           PG_REQUIRE(max_iter >= 0 && relative_tolerance >= 0.0 && absolute_tolerance >= 0.0, 1, "bad CG parameters");
+           ctx->eng->sr_cg_solve(b, x0, diag_shift, max_iter, relative_tolerance, absolute_tolerance, residual_recompute_interval,
+                                 orthogonality_threshold, x_out, residual_norm, iterations, reason));
+}
+int pepsgpu_sr_gram(pepsgpu_ctx *ctx, const void *remote_samples_dev, const int32_t *remote_configs_dev, int n_remote, double *out) {
+  CTX_CALL(PG_REQUIRE(out, 1, "null output"); ctx->eng->sr_gram(remote_samples_dev, remote_configs_dev, n_remote, out));
+}
+int pepsgpu_sr_weighted_sum(pepsgpu_ctx *ctx, const double *y, double *out) {
+  CTX_CALL(PG_REQUIRE(y && out, 1, "null argument"); ctx->eng->sr_weighted_sum(y, out));
+}
+int pepsgpu_sr_copy_samples(pepsgpu_ctx *ctx, void *dst_samples_dev, int32_t *dst_configs_dev) {
+  CTX_CALL(PG_REQUIRE(dst_samples_dev && dst_configs_dev, 1, "null destination"); ctx->eng->sr_copy_samples(dst_samples_dev, dst_configs_dev));
+}
 int pepsgpu_update_local(pepsgpu_ctx *ctx, int nsites, const int32_t *sites, const int32_t *ns, const uint8_t *mask) {
   CTX_CALL(ctx->eng->update_local(nsites, sites, ns, mask));
 }

@@ -82,6 +82,12 @@ struct EngineBase {
   virtual int sr_count() const = 0;
   virtual void sr_sum(double *out) = 0;
   virtual void sr_matvec(const double *v, double mean_dot_v, double scale, double *out) = 0;
+  virtual void sr_cg_solve(const double *b, const double *x0, double diag_shift, int max_iter, double rel_tol, double abs_tol,
+                           int recompute_interval, double ortho_threshold, double *x_out, double *residual_norm,
+                           int *iterations, int *reason) = 0;
+  virtual void sr_gram(const void *remote_o, const int32_t *remote_cfg, int n_remote, double *out) = 0;
+  virtual void sr_weighted_sum(const double *y, double *out) = 0;
+  virtual void sr_copy_samples(void *dst_o, int32_t *dst_cfg) = 0;
   virtual void profile_enable(int on) = 0;
   virtual void profile_read(double *out) = 0;   // [PROF_NCAT][5]: ms, launches, algorithmic flops, executed flops, operand+result bytes
 };
@@ -545,6 +551,12 @@ class Engine : public EngineBase {
   int sr_count() const override { return sr_n_; }
   void sr_sum(double *out) override;
   void sr_matvec(const double *v, double mean_dot_v, double scale, double *out) override;
+  void sr_cg_solve(const double *b, const double *x0, double diag_shift, int max_iter, double rel_tol, double abs_tol,
+                   int recompute_interval, double ortho_threshold, double *x_out, double *residual_norm, int *iterations,
+                   int *reason) override;
+  void sr_gram(const void *remote_o, const int32_t *remote_cfg, int n_remote, double *out) override;
+  void sr_weighted_sum(const double *y, double *out) override;
+  void sr_copy_samples(void *dst_o, int32_t *dst_cfg) override;
   void sr_release();
   void sr_convert(const double *src, double *dst, bool to_compact) const;
 

@@ -27,11 +27,11 @@ __global__ __launch_bounds__(256) void sr_append_kernel(const T *__restrict__ ho
   if (e == 0) cfg_out[(long)w * sites + site] = cfg[(long)w * sites + site];
 }
 
-// delta[i] = sum_site < O*_i(site), v(site)[cfg_i(site)] > - shift      (one block per sample)
+// delta[i] = sum_site < O*_i(site), v(site)[cfg_i(site)] > - shift - *shift_dev      (one block per sample)
 template <typename T>
 __global__ __launch_bounds__(256) void sr_delta_kernel(const T *__restrict__ o, const int *__restrict__ cfg,
                                                        const double *__restrict__ v, double shift, double *__restrict__ delta,
-                                                       int sites, long slot, int dp) {
+                                                       int sites, long slot, int dp, const double *__restrict__ shift_dev = nullptr) {
   __shared__ double s_red[4];
   const int i = blockIdx.x;
   double a = 0.0;
@@ -43,7 +43,32 @@ __global__ __launch_bounds__(256) void sr_delta_kernel(const T *__restrict__ o, 
   a = wave_sum(a);
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = a;
   __syncthreads();
-  if (threadIdx.x == 0) delta[i] = s_red[0] + s_red[1] + s_red[2] + s_red[3] - shift;
+  if (threadIdx.x == 0) delta[i] = s_red[0] + s_red[1] + s_red[2] + s_red[3] - shift - (shift_dev ? *shift_dev : 0.0);
+}
+
+// part[blockIdx.x] = sum over the block's grid-stride share of a[e] b[e]; sr_dot_final_kernel adds the partials in a
+// fixed order (no atomics: the CG scalars are reproducible run to run)
+__global__ __launch_bounds__(256) void sr_dot_kernel(const double *__restrict__ a, const double *__restrict__ b, long n,
+                                                     double *__restrict__ part) {
+  __shared__ double s_red[4];
+  double acc = 0.0;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) acc += a[e] * b[e];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+__global__ __launch_bounds__(64) void sr_dot_final_kernel(const double *__restrict__ part, int nblocks, double *__restrict__ out) {
+  double acc = 0.0;
+  for (int e = threadIdx.x; e < nblocks; e += 64) acc += part[e];
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) *out = acc;
+}
+
+// y = alpha * x + beta * y
+__global__ __launch_bounds__(256) void sr_axpby_kernel(double alpha, const double *__restrict__ x, double beta,
+                                                       double *__restrict__ y, long n) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) y[e] = alpha * x[e] + beta * y[e];
 }
 
 // out[site][s][e] = scale * sum_{i : cfg_i(site) == s} weight_i O*_i(site)[e]   (weight == nullptr: 1)
@@ -180,6 +205,225 @@ void Engine<T>::sr_matvec(const double *v, double mean_dot_v, double scale, doub
   PG_CHECK_HIP(hipMemcpyAsync(h.data(), sr_out_, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
   PG_CHECK_HIP(hipStreamSynchronize(stream_));
   sr_convert(h.data(), out, false);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-resident natural-gradient solve: ConjugateGradientSolver (utility/conjugate_gradient_solver.h:181-276)
+// on (S + diag_shift) x = b with every vector in HBM next to the samples (compact layout, f64).  One iteration =
+// two sweeps over the sample store (S p) + a few axpy / dot kernels; the host reads back the handful of scalars
+// its branches need (p.Ap, |p|^2 | |x|^2, |r|^2, r_prev.r) twice per iteration.  Every branch of the reference is
+// kept: indefinite-matrix exit, stagnation detection, periodic residual recomputation, NaN/Inf exits, best-iterate
+// tracking, orthogonality-based restart.
+template <typename T>
+void Engine<T>::sr_cg_solve(const double *b, const double *x0, double diag_shift, int max_iter, double rel_tol,
+                            double abs_tol, int recompute_interval, double ortho_threshold, double *x_out,
+                            double *residual_norm, int *iterations, int *reason) {
+  PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_cg_solve: no samples");
+  const int sites = Ly_ * Lx_;
+  const long n = (long)sites * dp_ * slot_;
+  const double scale = 1.0 / sr_n_;
+  auto dvec = [&]() { return (double *)arena_.alloc(sizeof(double) * n); };
+  double *db = dvec(), *dx = dvec(), *dr = dvec(), *dp = dvec(), *dap = dvec(), *dbest = dvec(), *dprev = dvec(), *dmean = dvec();
+  double *dsc = (double *)arena_.alloc(sizeof(double) * 8);
+  constexpr int DOT_BLOCKS = 512;
+  double *dpart = (double *)arena_.alloc(sizeof(double) * DOT_BLOCKS);
+  auto dot_into = [&](const double *a, const double *b2, double *out) {
+    hipLaunchKernelGGL(sr_dot_kernel, dim3(DOT_BLOCKS), dim3(256), 0, stream_, a, b2, n, dpart);
+    hipLaunchKernelGGL(sr_dot_final_kernel, dim3(1), dim3(64), 0, stream_, (const double *)dpart, DOT_BLOCKS, out);
+  };
+  std::vector<double> h(n);
+  auto upload = [&](const double *src, double *dst) {
+    if (src) {
+      sr_convert(src, h.data(), true);
+      PG_CHECK_HIP(hipMemcpyAsync(dst, h.data(), n * sizeof(double), hipMemcpyHostToDevice, stream_));
+      PG_CHECK_HIP(hipStreamSynchronize(stream_));   // h is reused
+    } else PG_CHECK_HIP(hipMemsetAsync(dst, 0, n * sizeof(double), stream_));
+  };
+  auto copy = [&](double *dst, const double *src) {
+    PG_CHECK_HIP(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+  };
+  const dim3 vg((unsigned)std::min<long>((n + 255) / 256, 2048));
+  auto axpby = [&](double alpha, const double *x, double beta, double *y) {
+    hipLaunchKernelGGL(sr_axpby_kernel, vg, dim3(256), 0, stream_, alpha, x, beta, y, n);
+  };
+  // dots[k] = a_k . b_k for up to four pairs, one read-back
+  auto dots = [&](std::initializer_list<std::pair<const double *, const double *>> pairs, double *out) {
+    int k = 0;
+    for (auto &pr : pairs) dot_into(pr.first, pr.second, dsc + k++);
+    PG_CHECK_HIP(hipMemcpyAsync(out, dsc, sizeof(double) * k, hipMemcpyDeviceToHost, stream_));
+    PG_CHECK_HIP(hipStreamSynchronize(stream_));
+  };
+  // out = S v + diag_shift v     (SRSMatrix::operator*, stochastic_reconfiguration_smatrix.h:37-99)
+  auto matvec = [&](const double *v, double *out) {
+    dot_into(dmean, v, dsc + 7);   // Ostar_mean . v
+    hipLaunchKernelGGL(sr_delta_kernel<T>, dim3(sr_n_), dim3(256), 0, stream_, (const T *)sr_o_, (const int *)sr_cfg_, v, 0.0,
+                       sr_delta_, sites, slot_, dp_, (const double *)(dsc + 7));
+    hipLaunchKernelGGL(sr_accum_kernel<T>, dim3((unsigned)((slot_ + 255) / 256), sites), dim3(256), 0, stream_, (const T *)sr_o_,
+                       (const int *)sr_cfg_, (const double *)sr_delta_, scale, out, sr_n_, sites, slot_, dp_);
+    PG_CHECK_HIP(hipGetLastError());
+    if (diag_shift != 0.0) axpby(diag_shift, v, 1.0, out);
+  };
+  auto finish = [&](const double *xsrc, double res_sq, int iters, int why) {
+    PG_CHECK_HIP(hipMemcpyAsync(h.data(), xsrc, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    sr_convert(h.data(), x_out, false);
+    *residual_norm = std::sqrt(res_sq); *iterations = iters; *reason = why;
+    for (double *v : {db, dx, dr, dp, dap, dbest, dprev, dmean, dsc, dpart}) arena_.free(v);
+  };
+  enum { kConverged = 0, kMaxIterations = 1, kIndefiniteMatrix = 2, kNumericalBreakdown = 3, kStagnated = 4 };
+
+  // Ostar_mean
+  hipLaunchKernelGGL(sr_accum_kernel<T>, dim3((unsigned)((slot_ + 255) / 256), sites), dim3(256), 0, stream_, (const T *)sr_o_,
+                     (const int *)sr_cfg_, (const double *)nullptr, scale, dmean, sr_n_, sites, slot_, dp_);
+  upload(b, db);
+  upload(x0, dx);
+  double s[4];
+  matvec(dx, dap);
+  copy(dr, db);
+  axpby(-1.0, dap, 1.0, dr);                      // r = b - A x0
+  dots({{db, db}, {dr, dr}}, s);
+  const double tol_sq = std::max(rel_tol * rel_tol * s[0], abs_tol * abs_tol);
+  double r_norm_sq = s[1];
+  if (r_norm_sq <= tol_sq) return finish(dx, r_norm_sq, 0, kConverged);
+  copy(dp, dr); copy(dbest, dx); copy(dprev, dr);
+  double best = r_norm_sq, rkp1 = r_norm_sq;
+  int stagnation = 0;
+  const double eps = 2.220446049250313e-16;
+  for (int k = 0; k < max_iter; ++k) {
+    const double rk = rkp1;
+    matvec(dp, dap);
+    dots({{dp, dap}, {dp, dp}}, s);
+    const double pap = s[0], pp = s[1];
+    if (!(std::isfinite(pap) && pap > 0.0)) return finish(dbest, best, k, kIndefiniteMatrix);
+    const double alpha = rk / pap;
+    axpby(alpha, dp, 1.0, dx);
+    if (recompute_interval > 0 && (k % recompute_interval) == recompute_interval - 1) {
+      matvec(dx, dr);
+      axpby(1.0, db, -1.0, dr);                   // r = b - A x
+    } else axpby(-alpha, dap, 1.0, dr);
+    dots({{dx, dx}, {dr, dr}, {dprev, dr}}, s);
+    if (alpha * alpha * pp < eps * eps * s[0]) {
+      if (++stagnation >= 3) return finish(dbest, best, k + 1, kStagnated);
+    } else stagnation = 0;
+    rkp1 = s[1];
+    if (!std::isfinite(rkp1)) return finish(dbest, best, k + 1, kNumericalBreakdown);
+    if (rkp1 < best) { copy(dbest, dx); best = rkp1; }
+    if (rkp1 <= tol_sq) return finish(dx, rkp1, k + 1, kConverged);
+    if (k > 0 && std::fabs(s[2]) > ortho_threshold * rkp1) {   // orthogonality-based restart
+      copy(dp, dr); copy(dprev, dr);
+      continue;
+    }
+    copy(dprev, dr);
+    const double beta = rkp1 / rk;
+    if (!std::isfinite(beta)) return finish(dbest, best, k + 1, kNumericalBreakdown);
+    axpby(1.0, dr, beta, dp);                      // p = r + beta p
+  }
+  finish(dbest, best, max_iter, kMaxIterations);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MinSR building blocks (optimizer/minsr_tmatrix.h, optimizer_impl.h:1126-1215): raw Gram blocks of O* samples as one
+// tensor GEMM over the compact parameter index (f64 accumulation), the weighted sum sum_i y_i O*_i, and a
+// device-to-device copy of the local samples for the ring exchange of the multi-rank T matrix.
+// A sample is expanded by its configuration into the SITPS-shaped vector the reference holds
+// (component cfg_i(site) of every site, zeros elsewhere): the Gram block is then a plain GEMM over K = sites * d * D^4.
+template <typename T>
+__global__ __launch_bounds__(256) void sr_expand_kernel(const T *__restrict__ o, const int *__restrict__ cfg, T *__restrict__ out,
+                                                        int sites, long slot, int dp, const int *__restrict__ site_ne) {
+  const int i = blockIdx.z, site = blockIdx.y;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= slot) return;
+  const int c = cfg[(long)i * sites + site];
+  const T v = e < site_ne[site] ? o[((long)i * sites + site) * slot + e] : T(0);
+  for (int s = 0; s < dp; ++s) out[(((long)i * sites + site) * dp + s) * slot + e] = s == c ? v : T(0);
+}
+
+template <typename T>
+void Engine<T>::sr_gram(const void *remote_o, const int32_t *remote_cfg, int n_remote, double *out) {
+  PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_gram: no samples");
+  PG_REQUIRE(!remote_o || (remote_cfg && n_remote > 0), 1, "sr_gram: bad remote batch");
+  const int sites = Ly_ * Lx_;
+  const long n = (long)sites * dp_ * slot_;
+  PG_REQUIRE(n < (1l << 31), 1, "sr_gram: parameter count exceeds the 32-bit strides of the tensor GEMM");
+  const int nb = remote_o ? n_remote : sr_n_;
+  auto expand = [&](const T *o, const int *cfg, int cnt) {
+    T *buf = (T *)arena_.alloc(sizeof(T) * (size_t)cnt * n);
+    hipLaunchKernelGGL(sr_expand_kernel<T>, dim3((unsigned)((slot_ + 255) / 256), sites, cnt), dim3(256), 0, stream_, o, cfg, buf,
+                       sites, slot_, dp_, (const int *)sr_ne_);
+    PG_CHECK_HIP(hipGetLastError());
+    return buf;
+  };
+  T *ea = expand((const T *)sr_o_, (const int *)sr_cfg_, sr_n_);
+  T *eb = remote_o ? expand((const T *)remote_o, (const int *)remote_cfg, nb) : ea;
+  // Row blocks keep the 32-bit element offsets of the tensor GEMM in range (a sample is n elements long); the K index is
+  // split over the batch dimension of the launch so that a few hundred samples still fill the chip (split-K, partial
+  // results summed on the host in f64).
+  const int bs = (int)std::min<long>(1024, ((1l << 31) - 1) / n) & ~63;
+  PG_REQUIRE(bs >= 64, 1, "sr_gram: parameter count too large for the blocked Gram");
+  const int groups = sites * dp_;                       // K splits must keep whole (site, state) slots together
+  std::vector<double> h((size_t)sr_n_ * nb, 0.0), part;
+  for (int ib = 0; ib < sr_n_; ib += bs) {
+    const int ni = std::min(bs, sr_n_ - ib);
+    for (int jb = remote_o ? 0 : ib; jb < nb; jb += bs) {
+      const int nj = std::min(bs, nb - jb);
+      const long tiles = (long)((ni + 63) / 64) * ((nj + 63) / 64);
+      int split = 1;
+      for (int c = 1; c <= groups; ++c)
+        if (groups % c == 0 && tiles * c <= 2048) split = c;
+      const long chunk = n / split;
+      double *d = (double *)arena_.alloc(sizeof(double) * (size_t)split * ni * nj);
+      PG_CHECK_HIP(hipMemsetAsync(d, 0, sizeof(double) * (size_t)split * ni * nj, stream_));
+      TGemmDesc g;
+      g.I[2] = ni; g.sAi[2] = (int)n; g.sCi[2] = nj;
+      g.K[2] = (int)chunk; g.sAk[2] = 1; g.sBk[2] = 1;
+      g.J[2] = nj; g.sBj[2] = (int)n; g.sCj[2] = 1;
+      g.wA = chunk; g.wB = chunk; g.wC = (long)ni * nj;
+      g.nbatch = split;
+      g.upper_only = (!remote_o && ib == jb) ? 1 : 0;
+      tgemm_launch<T, T, double, double>(stream_, g, ea + (size_t)ib * n, eb + (size_t)jb * n, d);
+      part.resize((size_t)split * ni * nj);
+      PG_CHECK_HIP(hipMemcpyAsync(part.data(), d, sizeof(double) * part.size(), hipMemcpyDeviceToHost, stream_));
+      PG_CHECK_HIP(hipStreamSynchronize(stream_));
+      arena_.free(d);
+      for (int sp = 0; sp < split; ++sp)
+        for (int i2 = 0; i2 < ni; ++i2) {
+          const double *src = &part[((size_t)sp * ni + i2) * nj];
+          double *dst = &h[(size_t)(ib + i2) * nb + jb];
+          for (int j2 = 0; j2 < nj; ++j2) dst[j2] += src[j2];
+        }
+    }
+  }
+  if (!remote_o)   // tiles on and above the diagonal were computed
+    for (int i2 = 0; i2 < sr_n_; ++i2)
+      for (int j2 = 0; j2 < i2; ++j2) h[(size_t)i2 * nb + j2] = h[(size_t)j2 * nb + i2];
+  std::copy(h.begin(), h.end(), out);
+  if (eb != ea) arena_.free(eb);
+  arena_.free(ea);
+}
+
+template <typename T>
+void Engine<T>::sr_weighted_sum(const double *y, double *out) {
+  PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_weighted_sum: no samples");
+  const int sites = Ly_ * Lx_;
+  const size_t n = (size_t)sites * dp_ * slot_;
+  PG_CHECK_HIP(hipMemcpyAsync(sr_delta_, y, sizeof(double) * sr_n_, hipMemcpyHostToDevice, stream_));
+  hipLaunchKernelGGL(sr_accum_kernel<T>, dim3((unsigned)((slot_ + 255) / 256), sites), dim3(256), 0, stream_, (const T *)sr_o_,
+                     (const int *)sr_cfg_, (const double *)sr_delta_, 1.0, sr_out_, sr_n_, sites, slot_, dp_);
+  PG_CHECK_HIP(hipGetLastError());
+  std::vector<double> h(n);
+  PG_CHECK_HIP(hipMemcpyAsync(h.data(), sr_out_, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  PG_CHECK_HIP(hipStreamSynchronize(stream_));
+  sr_convert(h.data(), out, false);
+}
+
+// device-to-device copy of the local sample store (for torch.distributed send / recv of the ring exchange)
+template <typename T>
+void Engine<T>::sr_copy_samples(void *dst_o, int32_t *dst_cfg) {
+  PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_copy_samples: no samples");
+  const size_t sites = (size_t)Ly_ * Lx_;
+  PG_CHECK_HIP(hipMemcpyAsync(dst_o, sr_o_, sizeof(T) * (size_t)sr_n_ * sites * slot_, hipMemcpyDeviceToDevice, stream_));
+  PG_CHECK_HIP(hipMemcpyAsync(dst_cfg, sr_cfg_, sizeof(int) * (size_t)sr_n_ * sites, hipMemcpyDeviceToDevice, stream_));
+  PG_CHECK_HIP(hipStreamSynchronize(stream_));
 }
 
 }  // namespace pepsgpu

@@ -28,4 +28,18 @@ t0 = time.time()
 for _ in range(5): S * v
 dt = (time.time() - t0) / 5
 bytes_ = 2.0 * nw * L * L * D ** 4 * 4
-print(json.dumps({"samples": nw, "holes_all_sites_s": t_holes, "matvec_ms": dt * 1e3, "sample_sweep_GBps": bytes_ / dt / 1e9}))
+out = {"samples": nw, "holes_all_sites_s": t_holes, "matvec_host_vectors_ms": dt * 1e3}
+# device-resident CG: fixed number of iterations (tolerance 0), time per iteration
+g = S * v
+ctx.sr_cg_solve(g, None, 1e-3, 2, 0.0, 0.0, 0, 0.5)
+t0 = time.time()
+x, res, it, why = ctx.sr_cg_solve(g, None, 1e-3, 20, 0.0, 0.0, 0, 0.5)
+dt_cg = (time.time() - t0) / max(it, 1)
+out.update({"cg_device_ms_per_iteration": dt_cg * 1e3, "cg_iterations": it, "sample_sweep_GBps_in_cg": bytes_ / dt_cg / 1e9})
+# MinSR: raw Gram of the resident samples (one GEMM, K = 2 * 144 * 4096), eigensolve on the host, back-substitution
+t0 = time.time(); gm = ctx.sr_gram(); t_gram = time.time() - t0
+flops = 2.0 * nw * nw / 2 * (L * L * 2 * D ** 4)
+e = np.random.default_rng(1).standard_normal(nw)
+t0 = time.time(); d, nrm = sr.minsr_direction(sr.DeviceSampleBatch(ctx), e, float(e.mean())); t_minsr = time.time() - t0
+out.update({"minsr_gram_s": t_gram, "minsr_gram_TFLOPs": flops / t_gram / 1e12, "minsr_direction_total_s": t_minsr})
+print(json.dumps(out))

@@ -164,3 +164,56 @@ def test_two_rank_energy_reduction_gloo():
                            capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK" in r.stdout
+
+
+MINSR_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch
+import torch.distributed as dist
+from peps_amd import dist as pdist, sr
+from oracle import sr as osr
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+pdist.init("gloo")
+
+
+class NumpyBatch:
+    """stand-in for peps_amd.sr.DeviceSampleBatch (same five methods) so that the multi-rank orchestration of
+    minsr_direction -- ring exchange order, four-term centering, all-gathers, back-substitution -- runs on CPU"""
+    def __init__(self, o): self.o, self.n = o, o.shape[0]
+    def gram_local(self): return self.o @ self.o.T
+    def export(self, device): return [torch.from_numpy(self.o.copy())]
+    def gram_with(self, batch): return self.o @ batch[0].numpy().T
+    def weighted_sum(self, y): return y @ self.o
+    def sample_sum(self): return self.o.sum(axis=0)
+
+
+rng = np.random.default_rng(5)
+ns_local, npar = 6, 40
+O = rng.standard_normal((ns_local * world, npar))
+E = rng.standard_normal(ns_local * world)
+mine = slice(rank * ns_local, (rank + 1) * ns_local)
+for kw in ({"r_pinv": 1e-12, "a_pinv": 0.0, "soft_cutoff": True}, {"r_pinv": 1e-8, "a_pinv": 1e-10, "soft_cutoff": False}):
+    d, nrm = sr.minsr_direction(NumpyBatch(O[mine]), E[mine], float(E.mean()), ring=sr.TorchRing(dist), **kw)
+    do, nrmo = osr.minsr_direction(list(O), O.mean(axis=0), E, float(E.mean()), **kw)
+    assert np.linalg.norm(d - do) < 1e-9 * nrmo, (rank, kw, np.linalg.norm(d - do), nrmo)
+if rank == 0:
+    print("OK")
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_minsr_ring_exchange_gloo():
+    """world_size-2 gloo: MinSRTMatrix::Construct's ring exchange + four-term centering and the replicated eigensolve /
+    back-substitution of CalculateMinSRDirection_ (optimizer_impl.h:1126-1215) as orchestrated by peps_amd.sr over
+    torch.distributed, against the oracle on the concatenated samples."""
+    with tempfile.TemporaryDirectory() as td:
+        wp = os.path.join(td, "worker.py")
+        open(wp, "w").write(MINSR_WORKER)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                            "--master-addr", "127.0.0.1", "--master-port", "29518", wp, ROOT],
+                           capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout

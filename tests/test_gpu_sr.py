@@ -63,3 +63,92 @@ def test_sr_matvec_and_cg(dt, tol):
     xo, reso, ito = osr.conjugate_gradient(lambda y: ref * y, g, np.zeros(g.size), 200, 1e-8)
     assert res <= 1e-8 * np.linalg.norm(g) * 1.01
     assert np.linalg.norm(x.ravel() - xo) < max(tol * 1e3, 1e-6) * np.linalg.norm(xo)
+
+
+def _store(dt, L=4, D=3, chi=9, nb=24, batches=2):
+    from peps_amd import capi
+    sitps = synthetic.make_sitps(L, D)
+    ctx = capi.Context(L, L, D, 2, chi, dtype=capi.F32 if dt == "f32" else capi.F64, max_walkers=nb)
+    ctx.state_upload(synthetic.sitps_to_flat(sitps, D))
+    ctx.sr_begin(nb * batches)
+    samples = []
+    for batch in range(batches):
+        cfgs = synthetic.make_configs(L, nb, "heisenberg", seed0=300 + 50 * batch)
+        psi, ostar = _collect(ctx, cfgs, L, D)
+        ctx.sr_append(psi)
+        samples += list(ostar)
+    return ctx, samples
+
+
+def _structural_mask(L=4, D=3):
+    """1 where the zero padded state layout holds a tensor element (boundary legs have dimension 1)"""
+    return (synthetic.sitps_to_flat(synthetic.make_sitps(L, D), D).reshape(L, L, 2, D, D, D, D) != 0).astype(np.float64)
+
+
+@pytest.mark.parametrize("dt,tol", [("f64", 1e-5), ("f32", 2e-3)])
+def test_device_resident_cg_follows_the_reference_solver(dt, tol):
+    """pepsgpu_sr_cg_solve (every vector in HBM) against the oracle restatement of ConjugateGradientSolver
+    (utility/conjugate_gradient_solver.h:181-276): same iterate, iteration count and termination reason, including the
+    periodic residual recomputation and the max-iteration / best-iterate exit."""
+    ctx, samples = _store(dt)
+    mean = np.mean(samples, axis=0)
+    shp = mean.shape
+    rng = np.random.default_rng(1)
+    mask = _structural_mask()          # the device vectors live on the tensor elements only, not on the padding
+    for shift, interval in ((1e-3, 20), (1e-2, 3)):
+        ref = osr.SRSMatrix(samples, mean, 1, shift)
+        g = (ref * (mask * rng.standard_normal(shp))).reshape(shp)
+        x, res, it, why = ctx.sr_cg_solve(g, None, shift, 200, 1e-8, 0.0, interval, 0.5)
+        xo, reso, ito, whyo = osr.conjugate_gradient_full(lambda y: ref * y, g, np.zeros(g.size), 200, 1e-8, 0.0, interval, 0.5)
+        assert why == whyo == osr.K_CONVERGED
+        # 50-100 iterations on a rank-48 system with restarts decided by thresholds: the summation order of the dots
+        # moves the exit by a few steps; the iterate itself is pinned below and, step for step, by the 3-iteration run
+        assert abs(it - ito) <= max(3, ito // 8)
+        assert np.linalg.norm(x.ravel() - xo) < tol * np.linalg.norm(xo)
+        assert res <= 1e-8 * np.linalg.norm(g) * 1.01
+        # warm start from the solution: converged at once
+        x2, res2, it2, why2 = ctx.sr_cg_solve(g, x, shift, 200, 1e-6, 0.0, interval, 0.5)
+        assert it2 == 0 and why2 == osr.K_CONVERGED
+    ref = osr.SRSMatrix(samples, mean, 1, 1e-3)
+    g = (ref * (mask * rng.standard_normal(shp))).reshape(shp)
+    x, res, it, why = ctx.sr_cg_solve(g, None, 1e-3, 3, 1e-14, 0.0, 20, 0.5)
+    xo, reso, ito, whyo = osr.conjugate_gradient_full(lambda y: ref * y, g, np.zeros(g.size), 3, 1e-14, 0.0, 20, 0.5)
+    assert (it, why) == (ito, whyo) == (3, osr.K_MAX_ITERATIONS)
+    assert abs(res / reso - 1) < max(tol, 1e-6) and np.linalg.norm(x.ravel() - xo) < tol * np.linalg.norm(xo)
+    with pytest.raises(ValueError):
+        ctx.sr_cg_solve(g, None, 0.0, -1, 1e-8)
+
+
+@pytest.mark.parametrize("dt,tol", [("f64", 1e-10), ("f32", 2e-5)])
+def test_minsr_direction_on_device(dt, tol):
+    """MinSR (optimizer/minsr_tmatrix.h, minsr_eigensolve.h, optimizer_impl.h:1126-1215): Gram of the resident samples as
+    one GEMM, T matrix, pseudo-inverse, back-substitution -- against the oracle; and the reference's own check
+    (tests/test_algorithm/test_sr_vs_minsr_equivalence.cpp): MinSR with zero cutoff == SR solved by CG without shift."""
+    from peps_amd import sr
+    ctx, samples = _store(dt)
+    n = len(samples)
+    flat = np.stack([s.ravel() for s in samples])
+    g = ctx.sr_gram()
+    want = flat @ flat.T
+    assert np.max(np.abs(g - want)) < tol * np.max(np.abs(want))
+    rng = np.random.default_rng(2)
+    y = rng.standard_normal(n)
+    ws = ctx.sr_weighted_sum(y)
+    assert np.max(np.abs(ws.ravel() - y @ flat)) < tol * 10 * np.max(np.abs(y @ flat))
+    e_loc = rng.standard_normal(n)
+    e_mean = float(e_loc.mean())
+    mean = np.mean(samples, axis=0)
+    batch = sr.DeviceSampleBatch(ctx)
+    for kw in ({"r_pinv": 1e-12, "a_pinv": 0.0, "soft_cutoff": True}, {"r_pinv": 1e-6, "a_pinv": 1e-9, "soft_cutoff": False}):
+        if dt == "f32" and kw["soft_cutoff"]:
+            kw = dict(kw, r_pinv=1e-5)          # keep the cutoff above the f32 rounding of the Gram entries
+        d, nrm = sr.minsr_direction(batch, e_loc, e_mean, **kw)
+        do, nrmo = osr.minsr_direction(samples, mean, e_loc, e_mean, **kw)
+        assert np.linalg.norm(d - do) < max(tol * 1e3, 1e-7) * nrmo, kw
+        assert abs(nrm / nrmo - 1) < max(tol * 1e3, 1e-7)
+    if dt == "f64":
+        grad = ((e_loc - e_mean)[:, None] * flat).mean(axis=0).reshape(mean.shape)
+        x, res, it, why = sr.natural_gradient(ctx, grad, 0.0, max_iter=500, relative_tolerance=1e-13)
+        d, _ = sr.minsr_direction(batch, e_loc, e_mean, r_pinv=0.0, a_pinv=1e-11, soft_cutoff=False)
+        assert why == sr.K_CONVERGED
+        assert np.linalg.norm(x.ravel() - d) < 1e-7 * np.linalg.norm(d)
