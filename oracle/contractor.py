@@ -377,6 +377,14 @@ class BMPSContractor:
             if len(self.bten_set2[pos]) > keep:
                 del self.bten_set2[pos][keep:]
 
+    def CheckInvalidateEnvs(self, site):
+        """trace.h:591-626 (debug-build assertions: no cache reaches across `site`)"""
+        row, col = site
+        assert len(self.bmps_set[LEFT]) <= col + 1 and len(self.bmps_set[UP]) <= row + 1
+        assert len(self.bmps_set[DOWN]) <= self.rows_ - row and len(self.bmps_set[RIGHT]) <= self.cols_ - col
+        for pos, keep in ((LEFT, col + 1), (UP, row + 1), (RIGHT, self.cols_ - col), (DOWN, self.rows_ - row)):
+            assert len(self.bten_set[pos]) <= keep and len(self.bten_set2[pos]) <= keep
+
 
 # =================================================================================================
 # Two-row (rank-4) environments and NNN / third-neighbour / sqrt(5) replacement traces

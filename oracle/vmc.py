@@ -296,6 +296,130 @@ class SquareSpinOneHalfJ1J2XXZModelOBC(SquareSpinOneHalfXXZModelOBC):
         return -0.25 * self.jz2 + ratio * 0.5 * self.jxy2
 
 
+def compute_psi_consistency_summary_aligned(psi_list):
+    """ComputePsiConsistencySummaryAligned (algorithm/vmc_update/psi_consistency.h:60-107): (mean, max rel. deviation)
+    after flipping the samples whose overlap with the largest-magnitude one is negative."""
+    psi = np.asarray(psi_list)
+    if psi.size == 0:
+        return 0.0, 0.0
+    ref = psi[int(np.argmax(np.abs(psi)))]
+    aligned = psi.copy()
+    if abs(ref) > 1e-14:
+        flip = np.real(psi * np.conj(ref)) < 0.0
+        aligned[flip] = -aligned[flip]
+    mean = aligned.sum() / psi.size
+    denom = max(abs(mean), np.finfo(np.float64).eps)
+    return mean, float(np.max(np.abs(aligned - mean)) / denom)
+
+
+def measure_spin_onehalf_off_diag_order_in_row(sitps, comp, inv_psi, row):
+    """MeasureSpinOneHalfOffDiagOrderInRow (model_solvers/square_spin_onehalf_xxz_obc.h:22-60): the valid channel of
+    <S+(x0) S-(x0+i)> / <S-(x0) S+(x0+i)> along `row`, x0 = lx/4, i = 1..lx/2; the BMPS of the row must exist."""
+    tn, c, config = comp.tn, comp.contractor, comp.config
+    lx = tn.cols
+    site1 = (row, lx // 4)
+    out = [0.0] * (lx // 2)
+    tn.update_site_tensor(site1, 1 - int(config[site1]), sitps)
+    c.EraseEnvsAfterUpdate(site1)
+    c.CheckInvalidateEnvs(site1)
+    c.GrowBTenStep(tn, LEFT)
+    c.GrowFullBTen(tn, RIGHT, row, lx // 4 + 2, False)
+    for i in range(1, lx // 2 + 1):
+        site2 = (row, lx // 4 + i)
+        c.CheckInvalidateEnvs(site2)
+        if config[site2] != config[site1]:
+            psi_ex = c.ReplaceOneSiteTrace(tn, site2, sitps[site2[0]][site2[1]][1 - int(config[site2])], HORIZONTAL)
+            out[i - 1] = np.conj(psi_ex * inv_psi)
+        c.CheckInvalidateEnvs(site2)
+        c.ShiftBTenWindow(tn, RIGHT)
+    tn.update_site_tensor(site1, int(config[site1]), sitps)
+    c.EraseEnvsAfterUpdate(site1)
+    return out
+
+
+class SquareNNNModelMeasurementSolver:
+    """SquareNNNModelMeasurementSolver::EvaluateObservables (model_solvers/base/square_nnn_model_measurement_solver.h:
+    30-254) over BondTraversalMixin::TraverseAllBonds (bond_traversal_mixin.h:22-145): registry keys energy, spin_z,
+    bond_energy_h/v(/dr/ur) and the psi summary of the sample.  `model` supplies the bond terms (an energy-solver
+    model of this module); XXZ adds SzSz_all2all and SmSp_row / SpSm_row (square_spin_onehalf_xxz_obc.h:215-288)."""
+
+    def __init__(self, model, spin_onehalf_xxz=True):
+        self.model, self.xxz = model, spin_onehalf_xxz
+        self.last_psi_summary = None
+
+    def EvaluateObservables(self, sitps, comp):
+        m, tn, c, config = self.model, comp.tn, comp.contractor, comp.config
+        ly, lx = tn.rows, tn.cols
+        out = {}
+        c.SetTruncateParams(comp.trun_para)
+        if self.xxz:
+            out["spin_z"] = [float(v) - 0.5 for v in config.ravel()]
+        e_h = np.zeros((ly, lx - 1)); e_v = np.zeros((ly - 1, lx))
+        e_dr = np.zeros((ly - 1, lx - 1)); e_ur = np.zeros((ly - 1, lx - 1))
+        total, psi_list = 0.0, []
+        c.GenerateBMPSApproach(tn, UP)
+        for row in range(ly):
+            c.InitBTen(tn, LEFT, row)
+            c.GrowFullBTen(tn, RIGHT, row, 1, True)
+            psi = c.Trace(tn, (row, 0), HORIZONTAL)
+            inv_psi = 1.0 / psi
+            psi_list.append(psi)
+            for col in range(lx - 1):
+                s1, s2 = (row, col), (row, col + 1)
+                e_h[row, col] = m.EvaluateBondEnergy(s1, s2, int(config[s1]), int(config[s2]), HORIZONTAL, tn, c,
+                                                     sitps[row][col], sitps[row][col + 1], inv_psi)
+                total += e_h[row, col]
+                c.ShiftBTenWindow(tn, RIGHT)
+            if m.has_nnn_interaction and row < ly - 1:
+                c.InitBTen2(tn, LEFT, row)
+                c.GrowFullBTen2(tn, RIGHT, row, 2, True)
+                for col in range(lx - 1):
+                    s1, s2 = (row, col), (row + 1, col + 1)
+                    e_dr[row, col] = m.EvaluateNNNEnergy(s1, s2, int(config[s1]), int(config[s2]), LEFTUP_TO_RIGHTDOWN, tn, c,
+                                                         sitps[s1[0]][s1[1]], sitps[s2[0]][s2[1]], inv_psi)
+                    s1, s2 = (row + 1, col), (row, col + 1)
+                    e_ur[row, col] = m.EvaluateNNNEnergy(s1, s2, int(config[s1]), int(config[s2]), LEFTDOWN_TO_RIGHTUP, tn, c,
+                                                         sitps[s1[0]][s1[1]], sitps[s2[0]][s2[1]], inv_psi)
+                    total += e_dr[row, col] + e_ur[row, col]
+                    c.ShiftBTen2Window(tn, RIGHT, row)
+            if self.xxz and row == ly // 2:                            # EvaluateOffDiagOrderInRow row hook (:256-288)
+                corr = measure_spin_onehalf_off_diag_order_in_row(sitps, comp, inv_psi, row)
+                zero = [0.0] * len(corr)
+                if int(config[row, lx // 4]) == 0:
+                    out["SmSp_row"], out["SpSm_row"] = zero, corr
+                else:
+                    out["SmSp_row"], out["SpSm_row"] = corr, zero
+            if row < ly - 1:
+                c.ShiftBMPSWindow(tn, DOWN)
+        c.GenerateBMPSApproach(tn, LEFT)
+        for col in range(lx):
+            c.InitBTen(tn, UP, col)
+            c.GrowFullBTen(tn, DOWN, col, 2, True)
+            psi = c.Trace(tn, (0, col), VERTICAL)
+            inv_psi = 1.0 / psi
+            psi_list.append(psi)
+            for row in range(ly - 1):
+                s1, s2 = (row, col), (row + 1, col)
+                e_v[row, col] = m.EvaluateBondEnergy(s1, s2, int(config[s1]), int(config[s2]), VERTICAL, tn, c,
+                                                     sitps[row][col], sitps[row + 1][col], inv_psi)
+                total += e_v[row, col]
+                if row < ly - 2:
+                    c.ShiftBTenWindow(tn, DOWN)
+            if col < lx - 1:
+                c.ShiftBMPSWindow(tn, RIGHT)
+        out["energy"] = [total + m.EvaluateTotalOnsiteEnergy(config)]
+        out["bond_energy_h"] = list(e_h.ravel())
+        out["bond_energy_v"] = list(e_v.ravel())
+        if m.has_nnn_interaction:
+            out["bond_energy_dr"] = list(e_dr.ravel())
+            out["bond_energy_ur"] = list(e_ur.ravel())
+        if self.xxz:
+            sz = np.asarray(out["spin_z"])
+            out["SzSz_all2all"] = [sz[i] * sz[j] for i in range(sz.size) for j in range(i, sz.size)]
+        self.last_psi_summary = compute_psi_consistency_summary_aligned(psi_list)
+        return out
+
+
 class TransverseFieldIsingSquareOBC:
     """transverse_field_ising_square_obc.h:28-247: H = -sum_<ij> sz sz - h sum_i sx"""
 

@@ -145,6 +145,68 @@ int pepshost_mc_energy_grad_partial(int rows, int cols, int D, int d, int chi, i
   });
 }
 
+// EvaluateObservables of the XXZ (model 0) / J1-J2 (model 2) measurement solver on fixed configurations, or -- with
+// n_samples > 0 -- a whole MCPEPSMeasurer run (warm-up, samples, statistics across the walkers, optional DumpData).
+// Results come back through a flat buffer described by `keys_out` ("key:len;key:len;..."): for n_samples == 0 the
+// per-walker values [key][walker][len], else [key][mean(len) | stderr(len)], followed by psi_mean[n], psi_rel_err[n]
+// of the last sample.
+int pepshost_measure(int rows, int cols, int D, int d, int chi, int dtype, const double *sitps_flat, int n, int32_t *configs,
+                     const uint64_t *seeds, int updater, int model, const double *p, int warmup_sweeps, int n_samples,
+                     int sweeps_between_samples, const char *dump_dir, char *keys_out, int keys_cap, double *values_out,
+                     long values_cap, long *values_len) {
+  return guarded([&]() {
+    SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
+    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), n, dtype);
+    TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor);
+    SquareSpinOneHalfXXZModelOBC xxz(p[0], p[1], p[2]);
+    SquareSpinOneHalfJ1J2XXZModelOBC j1j2(p[0], p[1], p[2], p[3], p[4]);
+    if (model != 0 && model != 2) throw std::invalid_argument("pepshost_measure: model must be xxz or j1j2");
+    std::string keys;
+    std::vector<double> vals;
+    auto emit = [&](const std::string &key, const std::vector<double> &a, const std::vector<double> *b, size_t len) {
+      keys += key + ":" + std::to_string(len) + ";";
+      vals.insert(vals.end(), a.begin(), a.end());
+      if (b) {
+        if (b->empty()) vals.insert(vals.end(), a.size(), 0.0);
+        else vals.insert(vals.end(), b->begin(), b->end());
+      }
+    };
+    PsiSummary psi;
+    if (n_samples <= 0) {
+      ObservableMap obs = model == 0 ? xxz.EvaluateObservables(sitps, comp) : j1j2.EvaluateObservables(sitps, comp);
+      for (const auto &kv : obs.values) emit(kv.first, kv.second, nullptr, obs.len(kv.first));
+      psi = model == 0 ? xxz.SquareNNModelMeasurementSolver<SquareSpinOneHalfXXZModelOBC>::EvaluatePsiSummary()
+                       : j1j2.SquareNNNModelMeasurementSolver<SquareSpinOneHalfJ1J2XXZModelOBC>::EvaluatePsiSummary();
+    } else {
+      std::vector<uint64_t> sd(seeds, seeds + n);
+      MCMeasurementParams mp;
+      mp.num_samples = n_samples; mp.num_warmup_sweeps = warmup_sweeps; mp.sweeps_between_samples = sweeps_between_samples;
+      auto run = [&](auto &upd, auto &solver) {
+        MCPEPSMeasurer<std::decay_t<decltype(upd)>, std::decay_t<decltype(solver)>> m(sitps, comp, mp, upd, solver);
+        m.Execute();
+        if (dump_dir && dump_dir[0]) m.DumpData(dump_dir);
+        for (const auto &kv : m.ObservableRegistry()) emit(kv.first, kv.second.first, &kv.second.second, kv.second.first.size());
+        psi.psi_mean.assign(n, 0.0); psi.psi_rel_err.assign(n, 0.0);
+        for (int w = 0; w < n; ++w) { psi.psi_mean[w] = m.PsiSamples().back()[w].first; psi.psi_rel_err[w] = m.PsiSamples().back()[w].second; }
+      };
+      MCUpdateSquareNNExchangeOBC ex(sd);
+      MCUpdateSquareNNFullSpaceUpdateOBC fs(sd);
+      if (updater == 0 && model == 0) run(ex, xxz);
+      else if (updater == 0) run(ex, j1j2);
+      else if (model == 0) run(fs, xxz);
+      else run(fs, j1j2);
+      std::copy(comp.config.data(), comp.config.data() + (size_t)n * rows * cols, configs);
+    }
+    vals.insert(vals.end(), psi.psi_mean.begin(), psi.psi_mean.end());
+    vals.insert(vals.end(), psi.psi_rel_err.begin(), psi.psi_rel_err.end());
+    if ((int)keys.size() + 1 > keys_cap || (long)vals.size() > values_cap) throw std::out_of_range("pepshost_measure: output buffer too small");
+    std::copy(keys.begin(), keys.end(), keys_out);
+    keys_out[keys.size()] = 0;
+    std::copy(vals.begin(), vals.end(), values_out);
+    *values_len = (long)vals.size();
+  });
+}
+
 // Rank-local part of ExactSumEnergyEvaluatorMPI (exact_summation_energy_evaluator.h:173-245):
 // packed_out = [S_O | S_EO | sum w | sum wE | sum wE^2 | samples], length 2*rows*cols*d*D^4 + 4.
 int pepshost_exact_sum_partial(int rows, int cols, int D, int d, int chi, int dtype, const double *sitps_flat,

@@ -22,12 +22,17 @@
 //
 // Error codes of the ABI are re-raised as the reference's exception types.
 #pragma once
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdint>
 #include <fstream>
 #include <functional>
+#include <iomanip>
+#include <limits>
+#include <map>
 #include <numeric>
 #include <random>
 #include <sstream>
@@ -797,6 +802,239 @@ class SquareNNNModelEnergySolver {
 template <class ExplicitlyModel>
 using SquareNNModelEnergySolver = SquareNNNModelEnergySolver<ExplicitlyModel, false>;
 
+// ---------------------------------------------------------------------------------------------
+// Measurement: registry-based observables of a walker batch.
+// ObservableMap (model_measurement_solver.h:33-34): key -> flat values; here per walker: values[key][w * len + k].
+struct ObservableMap {
+  std::map<std::string, std::vector<double>> values;
+  size_t n = 0;                                               // walkers
+  size_t len(const std::string &key) const { return values.at(key).size() / n; }
+  std::vector<double> &make(const std::string &key, size_t length) {
+    auto &v = values[key];
+    v.assign(n * length, 0.0);
+    return v;
+  }
+};
+struct ObservableMeta {                                        // model_measurement_solver.h:45-63
+  std::string key, description;
+  std::vector<size_t> shape;
+  std::vector<std::string> index_labels;
+};
+struct PsiSummary { std::vector<double> psi_mean, psi_rel_err; };   // per walker (model_measurement_solver.h:95-98)
+
+// ComputePsiConsistencySummaryAligned (psi_consistency.h:60-107), real amplitudes
+inline std::pair<double, double> ComputePsiConsistencySummaryAligned(const std::vector<double> &psi_list) {
+  if (psi_list.empty()) return {0.0, 0.0};
+  size_t ref = 0;
+  for (size_t i = 0; i < psi_list.size(); ++i)
+    if (std::fabs(psi_list[i]) > std::fabs(psi_list[ref])) ref = i;
+  const bool ref_valid = std::fabs(psi_list[ref]) > 1e-14;
+  std::vector<double> aligned(psi_list);
+  double mean = 0.0;
+  for (auto &v : aligned) {
+    if (ref_valid && v * psi_list[ref] < 0.0) v = -v;
+    mean += v;
+  }
+  mean /= (double)aligned.size();
+  const double denom = std::max(std::fabs(mean), std::numeric_limits<double>::epsilon());
+  double dev = 0.0;
+  for (double v : aligned) dev = std::max(dev, std::fabs(v - mean));
+  return {mean, dev / denom};
+}
+
+// MeasureSpinOneHalfOffDiagOrderInRow (square_spin_onehalf_xxz_obc.h:22-60) for every walker: the valid channel of
+// S+(x0) S-(x0+i) / S-(x0) S+(x0+i) along `row`, x0 = lx/4, i = 1..lx/2.  out[w * (lx/2) + i - 1].
+inline std::vector<double> MeasureSpinOneHalfOffDiagOrderInRow(TPSWaveFunctionComponent &comp, const std::vector<double> &inv_psi,
+                                                               size_t row) {
+  auto &c = comp.contractor;
+  const size_t lx = c.cols(), n = comp.config.walkers(), half = lx / 2;
+  const SiteIdx site1{row, lx / 4};
+  std::vector<double> out(n * half, 0.0);
+  const std::vector<int32_t> sites = {(int32_t)site1.r, (int32_t)site1.c};
+  const std::vector<uint8_t> all(n, 1);
+  std::vector<int32_t> flipped(n), orig(n);
+  for (size_t w = 0; w < n; ++w) { orig[w] = comp.config(w, site1); flipped[w] = 1 - orig[w]; }
+  c.UpdateLocal(sites, flipped, all);                 // tn.UpdateSiteTensor(site1, 1 - config(site1)) + EraseEnvsAfterUpdate
+  c.CheckInvalidateEnvs(site1);
+  c.GrowBTenStep(LEFT);
+  c.GrowFullBTen(RIGHT, row, lx / 4 + 2, false);
+  for (size_t i = 1; i <= half; ++i) {
+    const SiteIdx site2{row, lx / 4 + i};
+    std::vector<int32_t> cand(n);
+    bool any = false;
+    for (size_t w = 0; w < n; ++w) {
+      cand[w] = 1 - comp.config(w, site2);
+      any |= comp.config(w, site2) != comp.config(w, site1);
+    }
+    if (any) {
+      std::vector<double> psi_ex = c.ReplaceOneSiteTrace(site2, HORIZONTAL, 1, cand);
+      for (size_t w = 0; w < n; ++w)
+        if (comp.config(w, site2) != comp.config(w, site1)) out[w * half + i - 1] = psi_ex[w] * inv_psi[w];
+    }
+    c.ShiftBTenWindow(RIGHT);
+  }
+  c.UpdateLocal(sites, orig, all);                    // change back (+ EraseEnvsAfterUpdate)
+  return out;
+}
+
+// SquareNNNModelMeasurementSolver (base/square_nnn_model_measurement_solver.h:23-319) over
+// BondTraversalMixin::TraverseAllBonds (base/bond_traversal_mixin.h:22-145).  CRTP hooks of ModelType: the energy-solver
+// ones (EvaluateBondEnergy, EvaluateNNNEnergy, EvaluateTotalOnsiteEnergy) plus
+//   static constexpr bool requires_spin_sz_measurement / requires_density_measurement, CalSpinSzImpl / CalDensityImpl,
+//   EvaluateOffDiagOrderInRow(comp, row, inv_psi, out)   (row hook; may do nothing)
+template <class ModelType, bool has_nnn_interaction = true>
+class SquareNNNModelMeasurementSolver {
+ public:
+  ObservableMap EvaluateObservables(const SplitIndexTPS &, TPSWaveFunctionComponent &comp) {
+    auto &c = comp.contractor;
+    auto *derived = static_cast<ModelType *>(this);
+    const size_t ly = c.rows(), lx = c.cols(), n = comp.config.walkers();
+    ObservableMap out;
+    out.n = n;
+    if constexpr (ModelType::requires_spin_sz_measurement) {
+      auto &sz = out.make("spin_z", ly * lx);
+      for (size_t w = 0; w < n; ++w)
+        for (size_t r = 0; r < ly; ++r)
+          for (size_t cc = 0; cc < lx; ++cc) sz[w * ly * lx + r * lx + cc] = derived->CalSpinSzImpl(comp.config(w, {r, cc}));
+    }
+    if constexpr (ModelType::requires_density_measurement) {
+      auto &ch = out.make("charge", ly * lx);
+      for (size_t w = 0; w < n; ++w)
+        for (size_t r = 0; r < ly; ++r)
+          for (size_t cc = 0; cc < lx; ++cc) ch[w * ly * lx + r * lx + cc] = derived->CalDensityImpl(comp.config(w, {r, cc}));
+    }
+    auto &e_h = out.make("bond_energy_h", ly * (lx - 1));
+    auto &e_v = out.make("bond_energy_v", (ly - 1) * lx);
+    std::vector<double> *e_dr = nullptr, *e_ur = nullptr;
+    if constexpr (has_nnn_interaction) {
+      e_dr = &out.make("bond_energy_dr", (ly - 1) * (lx - 1));
+      e_ur = &out.make("bond_energy_ur", (ly - 1) * (lx - 1));
+    }
+    std::vector<double> total(n, 0.0);
+    std::vector<std::vector<double>> psi_list;
+    auto inverse = [&](const std::vector<double> &psi) {
+      std::vector<double> inv(n);
+      for (size_t w = 0; w < n; ++w) {
+        if (psi[w] == 0.0) throw std::runtime_error("Wavefunction amplitude is near zero, causing division by zero.");
+        inv[w] = 1.0 / psi[w];
+      }
+      return inv;
+    };
+    comp.SetOrder(ROW_MAJOR);
+    c.GenerateBMPSApproach(UP);
+    for (size_t row = 0; row < ly; ++row) {
+      c.InitBTen(LEFT, row);
+      c.GrowFullBTen(RIGHT, row, 1, true);
+      psi_list.push_back(c.Trace({row, 0}, HORIZONTAL));
+      const std::vector<double> inv_psi = inverse(psi_list.back());
+      for (size_t col = 0; col + 1 < lx; ++col) {
+        std::vector<double> e = derived->EvaluateBondEnergy({row, col}, {row, col + 1}, HORIZONTAL, comp, inv_psi);
+        for (size_t w = 0; w < n; ++w) { e_h[w * ly * (lx - 1) + row * (lx - 1) + col] = e[w]; total[w] += e[w]; }
+        c.ShiftBTenWindow(RIGHT);
+      }
+      if constexpr (has_nnn_interaction) {
+        if (row + 1 < ly) {
+          c.InitBTen2(LEFT, row);
+          c.GrowFullBTen2(RIGHT, row, 2, true);
+          for (size_t col = 0; col + 1 < lx; ++col) {
+            std::vector<double> e1 = derived->EvaluateNNNEnergy({row, col}, {row + 1, col + 1}, LEFTUP_TO_RIGHTDOWN, comp, inv_psi);
+            std::vector<double> e2 = derived->EvaluateNNNEnergy({row + 1, col}, {row, col + 1}, LEFTDOWN_TO_RIGHTUP, comp, inv_psi);
+            for (size_t w = 0; w < n; ++w) {
+              const size_t k = w * (ly - 1) * (lx - 1) + row * (lx - 1) + col;   // LEFTDOWN anchor mapped to the top cell (:155)
+              (*e_dr)[k] = e1[w]; (*e_ur)[k] = e2[w];
+              total[w] += e1[w] + e2[w];
+            }
+            c.ShiftBTen2Window(RIGHT, row);
+          }
+        }
+      }
+      derived->EvaluateOffDiagOrderInRow(comp, row, inv_psi, out);
+      if (row + 1 < ly) c.ShiftBMPSWindow(DOWN);
+    }
+    comp.SetOrder(COL_MAJOR);
+    c.GenerateBMPSApproach(LEFT);
+    for (size_t col = 0; col < lx; ++col) {
+      c.InitBTen(UP, col);
+      c.GrowFullBTen(DOWN, col, 2, true);
+      psi_list.push_back(c.Trace({0, col}, VERTICAL));
+      const std::vector<double> inv_psi = inverse(psi_list.back());
+      for (size_t row = 0; row + 1 < ly; ++row) {
+        std::vector<double> e = derived->EvaluateBondEnergy({row, col}, {row + 1, col}, VERTICAL, comp, inv_psi);
+        for (size_t w = 0; w < n; ++w) { e_v[w * (ly - 1) * lx + row * lx + col] = e[w]; total[w] += e[w]; }
+        if (row + 2 < ly) c.ShiftBTenWindow(DOWN);
+      }
+      if (col + 1 < lx) c.ShiftBMPSWindow(RIGHT);
+    }
+    auto &en = out.make("energy", 1);
+    last_psi_.psi_mean.assign(n, 0.0);
+    last_psi_.psi_rel_err.assign(n, 0.0);
+    std::vector<double> one(psi_list.size());
+    for (size_t w = 0; w < n; ++w) {
+      en[w] = total[w] + derived->EvaluateTotalOnsiteEnergy(comp.config, w);
+      for (size_t k = 0; k < psi_list.size(); ++k) one[k] = psi_list[k][w];
+      auto s = ComputePsiConsistencySummaryAligned(one);
+      last_psi_.psi_mean[w] = s.first;
+      last_psi_.psi_rel_err[w] = s.second;
+    }
+    return out;
+  }
+  // psi summary of the sample the last EvaluateObservables call saw (model_measurement_solver.h:101-118, cached path)
+  const PsiSummary &EvaluatePsiSummary() const { return last_psi_; }
+  std::vector<ObservableMeta> DescribeObservables(size_t ly, size_t lx) const {   // :256-291
+    std::vector<ObservableMeta> out = {{"energy", "Total energy (scalar)", {}, {}}};
+    if constexpr (ModelType::requires_spin_sz_measurement) out.push_back({"spin_z", "Local spin Sz per site", {ly, lx}, {"y", "x"}});
+    if constexpr (ModelType::requires_density_measurement) out.push_back({"charge", "Local charge per site", {ly, lx}, {"y", "x"}});
+    out.push_back({"bond_energy_h", "Bond energy on horizontal NN bonds", {ly, lx > 0 ? lx - 1 : 0}, {"bond_y", "bond_x"}});
+    out.push_back({"bond_energy_v", "Bond energy on vertical NN bonds", {ly > 0 ? ly - 1 : 0, lx}, {"bond_y", "bond_x"}});
+    if constexpr (has_nnn_interaction) {
+      out.push_back({"bond_energy_dr", "Bond energy on diagonal NNN bonds (LeftUp-RightDown)", {ly > 0 ? ly - 1 : 0, lx > 0 ? lx - 1 : 0}, {"bond_y", "bond_x"}});
+      out.push_back({"bond_energy_ur", "Bond energy on anti-diagonal NNN bonds (LeftDown-RightUp)", {ly > 0 ? ly - 1 : 0, lx > 0 ? lx - 1 : 0}, {"bond_y", "bond_x"}});
+    }
+    return out;
+  }
+ private:
+  PsiSummary last_psi_;
+};
+template <class ModelType>
+using SquareNNModelMeasurementSolver = SquareNNNModelMeasurementSolver<ModelType, false>;
+
+// The spin-1/2 part every XXZ-type model adds on top of the registry traversal (square_spin_onehalf_xxz_obc.h:205-330):
+// SzSz_all2all (packed upper triangle, i <= j) and the S+S- / S-S+ channel along the middle row.
+struct SpinOneHalfMeasurementHooks {
+  static constexpr bool requires_spin_sz_measurement = true;
+  static constexpr bool requires_density_measurement = false;
+  double CalSpinSzImpl(int32_t config) const { return double(config) - 0.5; }
+  double CalDensityImpl(int32_t) const { return 0.0; }
+  void EvaluateOffDiagOrderInRow(TPSWaveFunctionComponent &comp, size_t row, const std::vector<double> &inv_psi, ObservableMap &out) const {
+    const size_t ly = comp.contractor.rows(), lx = comp.contractor.cols(), n = comp.config.walkers(), half = lx / 2;
+    if (row != ly / 2 || half == 0) return;
+    std::vector<double> corr = MeasureSpinOneHalfOffDiagOrderInRow(comp, inv_psi, row);
+    auto &smsp = out.make("SmSp_row", half);
+    auto &spsm = out.make("SpSm_row", half);
+    for (size_t w = 0; w < n; ++w) {
+      auto &dst = comp.config(w, {row, lx / 4}) == 0 ? spsm : smsp;      // :279-284
+      std::copy(corr.begin() + w * half, corr.begin() + (w + 1) * half, dst.begin() + w * half);
+    }
+  }
+  static void AddSzSzAll2All(const TPSWaveFunctionComponent &comp, ObservableMap &out) {   // :225-236
+    const size_t ly = comp.contractor.rows(), lx = comp.contractor.cols(), n = comp.config.walkers(), N = ly * lx;
+    auto &szsz = out.make("SzSz_all2all", N * (N + 1) / 2);
+    for (size_t w = 0; w < n; ++w) {
+      size_t k = w * (N * (N + 1) / 2);
+      for (size_t i = 0; i < N; ++i) {
+        const double szi = double(comp.config(w, {i / lx, i % lx})) - 0.5;
+        for (size_t j = i; j < N; ++j) szsz[k++] = szi * (double(comp.config(w, {j / lx, j % lx})) - 0.5);
+      }
+    }
+  }
+  static void DescribeSpinOneHalf(std::vector<ObservableMeta> &base, size_t ly, size_t lx) {   // :296-330
+    const size_t N = ly * lx;
+    base.push_back({"SzSz_all2all", "Packed upper-triangular SzSz(i,j) with i<=j (flat)", {N * (N + 1) / 2}, {"pair_packed_upper_tri"}});
+    base.push_back({"SmSp_row", "Row Sm(i)Sp(j) along middle row (flat)", {lx / 2}, {"segment"}});
+    base.push_back({"SpSm_row", "Row Sp(i)Sm(j) along middle row (flat)", {lx / 2}, {"segment"}});
+  }
+};
+
 // SquareSpinOneHalfXXZModelMixIn (square_spin_onehalf_xxz_obc.h:64-141): the bond / NNN-link / on-site terms
 class SquareSpinOneHalfXXZModelMixIn {
  public:
@@ -847,17 +1085,41 @@ class SquareSpinOneHalfXXZModelMixIn {
 
 // square_spin_onehalf_xxz_obc.h:174-190
 class SquareSpinOneHalfXXZModelOBC : public SquareNNModelEnergySolver<SquareSpinOneHalfXXZModelOBC>,
+                                     public SquareNNModelMeasurementSolver<SquareSpinOneHalfXXZModelOBC>,
+                                     public SpinOneHalfMeasurementHooks,
                                      public SquareSpinOneHalfXXZModelMixIn {
  public:
   SquareSpinOneHalfXXZModelOBC() : SquareSpinOneHalfXXZModelMixIn(1.0, 1.0, 0.0, 0.0, 0.0) {}
   SquareSpinOneHalfXXZModelOBC(double jz, double jxy, double pinning00)
       : SquareSpinOneHalfXXZModelMixIn(jz, jxy, 0.0, 0.0, pinning00) {}
+  ObservableMap EvaluateObservables(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp) {   // :215-251
+    ObservableMap out = SquareNNModelMeasurementSolver<SquareSpinOneHalfXXZModelOBC>::EvaluateObservables(sitps, comp);
+    AddSzSzAll2All(comp, out);
+    return out;
+  }
+  std::vector<ObservableMeta> DescribeObservables(size_t ly, size_t lx) const {
+    auto base = SquareNNModelMeasurementSolver<SquareSpinOneHalfXXZModelOBC>::DescribeObservables(ly, lx);
+    DescribeSpinOneHalf(base, ly, lx);
+    return base;
+  }
 };
 
 // square_spin_onehalf_j1j2_xxz_obc.h:25-40
 class SquareSpinOneHalfJ1J2XXZModelOBC : public SquareNNNModelEnergySolver<SquareSpinOneHalfJ1J2XXZModelOBC>,
+                                         public SquareNNNModelMeasurementSolver<SquareSpinOneHalfJ1J2XXZModelOBC>,
+                                         public SpinOneHalfMeasurementHooks,
                                          public SquareSpinOneHalfXXZModelMixIn {
  public:
+  ObservableMap EvaluateObservables(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp) {
+    ObservableMap out = SquareNNNModelMeasurementSolver<SquareSpinOneHalfJ1J2XXZModelOBC>::EvaluateObservables(sitps, comp);
+    AddSzSzAll2All(comp, out);
+    return out;
+  }
+  std::vector<ObservableMeta> DescribeObservables(size_t ly, size_t lx) const {
+    auto base = SquareNNNModelMeasurementSolver<SquareSpinOneHalfJ1J2XXZModelOBC>::DescribeObservables(ly, lx);
+    DescribeSpinOneHalf(base, ly, lx);
+    return base;
+  }
   explicit SquareSpinOneHalfJ1J2XXZModelOBC(double j2) : SquareSpinOneHalfXXZModelMixIn(1, 1, j2, j2, 0) {}
   SquareSpinOneHalfJ1J2XXZModelOBC(double jz, double jxy, double jz2, double jxy2, double pinning_field00)
       : SquareSpinOneHalfXXZModelMixIn(jz, jxy, jz2, jxy2, pinning_field00) {}
@@ -1070,6 +1332,141 @@ struct GradAccumulator {
 };
 
 // GenerateAllPermutationConfigs (exact_summation_energy_evaluator.h:74-95) for one walker batch layout
+// MCPEPSMeasurer (algorithm/vmc_update/monte_carlo_peps_measurer{.h,_impl.h}): warm-up, then per sample
+// `sweeps_between_samples` Monte-Carlo sweeps + EvaluateObservables + psi summary.  A walker of the batch plays the role
+// of an MPI rank of the reference: per-walker sample means (SampleData::StatisticRegistry, monte_carlo_peps_measurer.h:369-396),
+// then mean and standard error across the walkers (GatherStatisticListOfData, monte_carlo_tools/statistics.h:289-340;
+// ranks of other GPUs are merged by the caller from Partial()).
+struct MCMeasurementParams {                       // MonteCarloParams (monte_carlo_peps_params.h)
+  size_t num_samples = 1, num_warmup_sweeps = 0, sweeps_between_samples = 1;
+};
+template <class MonteCarloSweepUpdater, class MeasurementSolver>
+class MCPEPSMeasurer {
+ public:
+  MCPEPSMeasurer(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp, const MCMeasurementParams &params,
+                 MonteCarloSweepUpdater &updater, MeasurementSolver &solver)
+      : sitps_(sitps), comp_(comp), params_(params), updater_(updater), solver_(solver) {
+    observables_meta_ = solver_.DescribeObservables(comp.contractor.rows(), comp.contractor.cols());
+  }
+  void Execute() {                                  // monte_carlo_peps_measurer_impl.h:172-178
+    std::vector<double> rates;
+    for (size_t s = 0; s < params_.num_warmup_sweeps; ++s) updater_(sitps_, comp_, rates);   // engine_.WarmUp()
+    Measure_();
+  }
+  // key -> (mean, stderr) over the walkers of this batch
+  const std::map<std::string, std::pair<std::vector<double>, std::vector<double>>> &ObservableRegistry() const { return registry_stats_; }
+  // per-walker sample means [key][walker][len]: what a rank contributes to GatherStatisticListOfData
+  const std::map<std::string, std::vector<double>> &WalkerMeans() const { return walker_means_; }
+  std::pair<double, double> OutputEnergy() const {  // :676-690
+    const auto &e = registry_stats_.at("energy");
+    return {e.first[0], e.second.empty() ? 0.0 : e.second[0]};
+  }
+  const std::vector<double> &AcceptRates() const { return accept_avg_; }
+  // psi_samples[sample][walker] = (psi_mean, psi_rel_err)
+  const std::vector<std::vector<std::pair<double, double>>> &PsiSamples() const { return psi_samples_; }
+  // stats/<key>_mean.csv + <key>_stderr.csv for two-dimensional observables, stats/<key>.csv ("index,mean,stderr") otherwise,
+  // samples/psi.csv (impl.h:262-345, :544-640)
+  void DumpData(const std::string &dir) const {
+    const std::string base = dir.empty() ? "./" : dir + "/";
+    auto mk = [](const std::string &d) {
+      std::string cmd;
+      for (size_t k = 1; k <= d.size(); ++k)
+        if (k == d.size() || d[k] == '/') ::mkdir(d.substr(0, k).c_str(), 0755);
+    };
+    mk(base + "stats");
+    mk(base + "samples");
+    auto csv = [](double v) {
+      std::ostringstream oss;
+      oss.setf(std::ios::scientific, std::ios::floatfield);
+      oss << std::setprecision(std::numeric_limits<double>::max_digits10) << v;
+      return oss.str();
+    };
+    for (const auto &kv : registry_stats_) {
+      const auto &vals = kv.second.first;
+      const auto &errs = kv.second.second;
+      const ObservableMeta *meta = nullptr;
+      for (const auto &m : observables_meta_) if (m.key == kv.first) meta = &m;
+      if (meta && meta->shape.size() == 2 && meta->shape[0] * meta->shape[1] == vals.size()) {
+        for (int which = 0; which < 2; ++which) {
+          std::ofstream ofs(base + "stats/" + kv.first + (which ? "_stderr.csv" : "_mean.csv"));
+          for (size_t r = 0; r < meta->shape[0]; ++r) {
+            for (size_t c = 0; c < meta->shape[1]; ++c) {
+              const size_t idx = r * meta->shape[1] + c;
+              ofs << csv(which ? (idx < errs.size() ? errs[idx] : 0.0) : vals[idx]) << (c + 1 < meta->shape[1] ? "," : "");
+            }
+            ofs << "\n";
+          }
+        }
+      } else {
+        std::ofstream ofs(base + "stats/" + kv.first + ".csv");
+        ofs << "index,mean,stderr\n";
+        for (size_t k = 0; k < vals.size(); ++k) ofs << k << "," << csv(vals[k]) << "," << csv(k < errs.size() ? errs[k] : 0.0) << "\n";
+      }
+    }
+    std::ofstream ofs(base + "samples/psi.csv");
+    ofs << "sample,walker,psi_mean,psi_rel_err\n";
+    for (size_t k = 0; k < psi_samples_.size(); ++k)
+      for (size_t w = 0; w < psi_samples_[k].size(); ++w)
+        ofs << k << "," << w << "," << csv(psi_samples_[k][w].first) << "," << csv(psi_samples_[k][w].second) << "\n";
+  }
+
+ private:
+  void Measure_() {                                 // impl.h:495-541
+    const size_t n = comp_.config.walkers();
+    std::vector<double> rates;
+    accept_avg_.assign(n, 0.0);
+    std::map<std::string, std::vector<double>> sum;
+    for (size_t sample = 0; sample < params_.num_samples; ++sample) {
+      std::vector<double> acc(n, 0.0);
+      for (size_t k = 0; k < params_.sweeps_between_samples; ++k) {    // engine_.StepSweep()
+        updater_(sitps_, comp_, rates);
+        for (size_t w = 0; w < n; ++w) acc[w] += rates[w];
+      }
+      for (size_t w = 0; w < n; ++w) accept_avg_[w] += acc[w] / double(std::max<size_t>(params_.sweeps_between_samples, 1));
+      ObservableMap obs = solver_.EvaluateObservables(sitps_, comp_);  // MeasureSample_ (:193-238)
+      for (const auto &kv : obs.values) {
+        auto &dst = sum[kv.first];
+        if (dst.empty()) dst.assign(kv.second.size(), 0.0);
+        for (size_t k = 0; k < kv.second.size(); ++k) dst[k] += kv.second[k];
+      }
+      const PsiSummary &ps = solver_.EvaluatePsiSummary();
+      std::vector<std::pair<double, double>> row(n);
+      for (size_t w = 0; w < n; ++w) row[w] = {ps.psi_mean[w], ps.psi_rel_err[w]};
+      psi_samples_.push_back(row);
+    }
+    for (auto &a : accept_avg_) a /= double(std::max<size_t>(params_.num_samples, 1));
+    // GatherStatistic_ (:242-258): local (walker) means, then mean / standard error across the walkers
+    for (auto &kv : sum) {
+      for (auto &v : kv.second) v /= double(params_.num_samples);
+      const size_t len = kv.second.size() / n;
+      std::vector<double> mean(len, 0.0), err;
+      for (size_t w = 0; w < n; ++w)
+        for (size_t k = 0; k < len; ++k) mean[k] += kv.second[w * len + k];
+      for (auto &m : mean) m /= double(n);
+      if (n > 1) {                                  // world_size == 1 leaves std_err empty (statistics.h:304-308)
+        err.assign(len, 0.0);
+        for (size_t k = 0; k < len; ++k) {
+          double var = 0.0;
+          for (size_t w = 0; w < n; ++w) var += (kv.second[w * len + k] - mean[k]) * (kv.second[w * len + k] - mean[k]);
+          err[k] = std::sqrt(var / double(n) / (double(n) - 1.0));      // StandardError (:89-96)
+        }
+      }
+      registry_stats_[kv.first] = {mean, err};
+      walker_means_[kv.first] = kv.second;
+    }
+  }
+  const SplitIndexTPS &sitps_;
+  TPSWaveFunctionComponent &comp_;
+  MCMeasurementParams params_;
+  MonteCarloSweepUpdater &updater_;
+  MeasurementSolver &solver_;
+  std::vector<ObservableMeta> observables_meta_;
+  std::map<std::string, std::pair<std::vector<double>, std::vector<double>>> registry_stats_;
+  std::map<std::string, std::vector<double>> walker_means_;
+  std::vector<std::vector<std::pair<double, double>>> psi_samples_;
+  std::vector<double> accept_avg_;
+};
+
 inline std::vector<std::vector<int32_t>> GenerateAllPermutationConfigs(const std::vector<size_t> &particle_counts, size_t Lx, size_t Ly) {
   std::vector<int32_t> base;
   for (size_t i = 0; i < particle_counts.size(); ++i)

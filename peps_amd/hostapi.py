@@ -131,6 +131,47 @@ def mc_energy_grad_partial(flat, configs, seeds, chi, updater="exchange", model=
     return packed, cfg, acc
 
 
+def measure(flat, configs, chi, model="xxz", params=(1.0, 1.0, 0.0), seeds=None, updater="exchange", warmup_sweeps=0,
+            n_samples=0, sweeps_between_samples=1, dump_dir="", dtype=1):
+    """Registry observables of the C++ measurement solver (SquareNNNModelMeasurementSolver::EvaluateObservables,
+    square_nnn_model_measurement_solver.h) on fixed configurations (n_samples = 0: dict key -> [walker][len]) or a whole
+    MCPEPSMeasurer run (n_samples > 0: dict key -> (mean[len], stderr[len]) across the walkers; configs updated in place;
+    dump_dir: stats/*.csv + samples/psi.csv as the reference writes them).  Also returns the psi summary of the last
+    sample: (psi_mean[walker], psi_rel_err[walker])."""
+    rows, cols, d, D = _dims(flat)
+    cfg = np.ascontiguousarray(configs, dtype=np.int32)
+    n = cfg.shape[0]
+    sd = np.ascontiguousarray(np.zeros(n) if seeds is None else seeds, dtype=np.uint64)
+    p = np.zeros(8, dtype=np.float64)
+    p[:len(params)] = params
+    cap = 4 * n * (rows * cols) ** 2 + 65536
+    vals = np.zeros(cap, dtype=np.float64)
+    keys = C.create_string_buffer(4096)
+    nvals = C.c_long(0)
+    l = lib()
+    l.pepshost_measure.argtypes = [C.c_int] * 6 + [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
+                                   C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p,
+                                   C.c_int, C.POINTER(C.c_double), C.c_long, C.POINTER(C.c_long)]
+    _ck(l.pepshost_measure(rows, cols, D, d, chi, dtype, _p(flat, C.c_double), n, _p(cfg, C.c_int32), _p(sd, C.c_uint64),
+                           {"exchange": 0, "fullspace": 1}[updater], MODEL_ID[model], _p(p, C.c_double), warmup_sweeps,
+                           n_samples, sweeps_between_samples, dump_dir.encode(), keys, 4096, _p(vals, C.c_double), cap,
+                           C.byref(nvals)))
+    out, off = {}, 0
+    for item in keys.value.decode().strip(";").split(";"):
+        key, ln = item.split(":")
+        ln = int(ln)
+        if n_samples > 0:
+            out[key] = (vals[off:off + ln].copy(), vals[off + ln:off + 2 * ln].copy())
+            off += 2 * ln
+        else:
+            out[key] = vals[off:off + n * ln].reshape(n, ln).copy()
+            off += n * ln
+    psi = (vals[off:off + n].copy(), vals[off + n:off + 2 * n].copy())
+    if n_samples > 0:
+        configs[...] = cfg
+    return out, psi
+
+
 def dump_sitps(directory, flat):
     """SplitIndexTPS::Dump (split_index_tps_impl.h:300-330) of a padded OBC state."""
     flat = np.ascontiguousarray(flat, dtype=np.float64)

@@ -1,0 +1,114 @@
+"""Measurement: registry observables of the C++ measurement solver and the MCPEPSMeasurer loop on the
+device against the oracle restatement (square_nnn_model_measurement_solver.h, square_spin_onehalf_xxz_obc.h:22-60,
+205-330, monte_carlo_peps_measurer_impl.h, psi_consistency.h)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import qlten_io, vmc
+from oracle.bmps import BMPSTruncateParams
+from peps_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+F32, F64 = 0, 1
+
+
+def _host():
+    from peps_amd import hostapi
+    return hostapi
+
+
+def _oracle_obs(s, cfgs, chi, model):
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    out = []
+    for c in cfgs:
+        comp = vmc.TPSWaveFunctionComponent(s, c, tp)
+        ms = vmc.SquareNNNModelMeasurementSolver(model)
+        out.append((ms.EvaluateObservables(s, comp), ms.last_psi_summary))
+    return out
+
+
+@pytest.mark.parametrize("dt,tol", [(F64, 1e-9), (F32, 5e-5)])
+@pytest.mark.parametrize("model,params", [("xxz", (1.0, 0.8, 0.3)), ("j1j2", (1.0, 1.0, 0.5, 0.4, 0.0))])
+def test_registry_observables_fixed_configs(model, params, dt, tol):
+    """every registry key of EvaluateObservables on identical configurations: energy, spin_z, bond_energy_h/v(/dr/ur),
+    SzSz_all2all, the S+S- / S-S+ channel along the middle row, and the psi summary of the sample (8x6 lattice: x0 = 1)"""
+    host = _host()
+    Ly = Lx = 6
+    D, chi = 3, 9
+    s = synthetic.make_sitps(Ly, D)
+    cfgs = synthetic.make_configs(Ly, 5, "heisenberg")
+    om = vmc.SquareSpinOneHalfXXZModelOBC(*params) if model == "xxz" else vmc.SquareSpinOneHalfJ1J2XXZModelOBC(*params)
+    ref = _oracle_obs(s, cfgs, chi, om)
+    got, psi = host.measure(synthetic.sitps_to_flat(s, D), cfgs, chi, model, params, dtype=dt)
+    assert set(got) == set(ref[0][0])
+    for w, (obs, (pm, prel)) in enumerate(ref):
+        for key, want in obs.items():
+            want = np.asarray(want, dtype=np.float64)
+            assert got[key][w].shape == want.shape, key
+            assert np.max(np.abs(got[key][w] - want)) < tol * 10 * max(1.0, np.max(np.abs(want))), (key, w)
+        assert abs(psi[0][w] / pm - 1) < tol * 10
+        assert abs(psi[1][w] - prel) < tol * 10
+    sp = np.array([np.asarray(o["SpSm_row"]) + np.asarray(o["SmSp_row"]) for o, _ in ref])
+    assert np.count_nonzero(sp) > 0                                # the off-diagonal channel is exercised
+
+
+def test_registry_observables_k5_fixture(fixtures_dir):
+    """the reference's 4x4 D=8 Heisenberg state (tests/slow_tests/test_data/tps_square_heisenberg4x4D8Double)"""
+    host = _host()
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, "tps_square_heisenberg4x4D8Double"))
+    cfgs = np.stack([synthetic.checkerboard(4)] + list(synthetic.make_configs(4, 3, "heisenberg")))
+    ref = _oracle_obs(s, cfgs, 16, vmc.SquareSpinOneHalfXXZModelOBC())
+    got, psi = host.measure(synthetic.sitps_to_flat(s, 8), cfgs, 16, "xxz", (1.0, 1.0, 0.0), dtype=F64)
+    for w, (obs, (pm, prel)) in enumerate(ref):
+        for key, want in obs.items():
+            assert np.max(np.abs(got[key][w] - np.asarray(want))) < 1e-8 * max(1.0, np.max(np.abs(want))), (key, w)
+
+
+@pytest.mark.parametrize("updater,cls", [("exchange", "MCUpdateSquareNNExchangeOBC"), ("fullspace", "MCUpdateSquareNNFullSpaceUpdateOBC")])
+def test_mc_measurer_identical_chain_statistics(updater, cls, tmp_path):
+    """MCPEPSMeasurer: warm-up + samples with the same std::mt19937 streams as the oracle chains (f64): the per-walker
+    sample means, and mean / standard error across the walkers (one walker = one MPI rank of the reference,
+    GatherStatisticListOfData), agree; DumpData writes stats/*.csv and samples/psi.csv."""
+    host = _host()
+    L, D, chi = 4, 3, 9
+    s = synthetic.make_sitps(L, D)
+    flat = synthetic.sitps_to_flat(s, D)
+    cfgs = synthetic.make_configs(L, 4, "heisenberg")
+    seeds = np.array([21, 22, 23, 24], dtype=np.uint64)
+    warm, nsamp, between = 2, 3, 2
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    model = vmc.SquareSpinOneHalfXXZModelOBC(1.0, 1.0, 0.0)
+    means = []
+    for w in range(len(cfgs)):
+        comp = vmc.TPSWaveFunctionComponent(s, cfgs[w], tp)
+        upd = getattr(vmc, cls)(seed=int(seeds[w]))
+        for _ in range(warm):
+            upd(s, comp)
+        acc = {}
+        for _ in range(nsamp):
+            for _ in range(between):
+                upd(s, comp)
+            obs = vmc.SquareNNNModelMeasurementSolver(model).EvaluateObservables(s, comp)
+            for k, v in obs.items():
+                acc[k] = acc.get(k, 0.0) + np.asarray(v, dtype=np.float64)
+        means.append({k: v / nsamp for k, v in acc.items()})
+    run_cfgs = cfgs.copy()
+    got, psi = host.measure(flat, run_cfgs, chi, "xxz", (1.0, 1.0, 0.0), seeds=seeds, updater=updater, warmup_sweeps=warm,
+                            n_samples=nsamp, sweeps_between_samples=between, dump_dir=str(tmp_path), dtype=F64)
+    n = len(cfgs)
+    for key in means[0]:
+        stack = np.stack([m[key] for m in means])
+        mean = stack.mean(axis=0)
+        err = np.sqrt(((stack - mean) ** 2).mean(axis=0) / (n - 1))          # StandardError (statistics.h:89-96)
+        assert np.max(np.abs(got[key][0] - mean)) < 1e-8 * max(1.0, np.max(np.abs(mean))), key
+        assert np.max(np.abs(got[key][1] - err)) < 1e-8 * max(1.0, np.max(np.abs(err))), key
+    assert os.path.exists(tmp_path / "stats" / "energy.csv")
+    assert os.path.exists(tmp_path / "stats" / "bond_energy_h_mean.csv") and os.path.exists(tmp_path / "stats" / "spin_z_stderr.csv")
+    rows = open(tmp_path / "stats" / "energy.csv").read().strip().split("\n")
+    assert rows[0] == "index,mean,stderr" and abs(float(rows[1].split(",")[1]) - got["energy"][0][0]) < 1e-12
+    mat = np.loadtxt(tmp_path / "stats" / "bond_energy_h_mean.csv", delimiter=",")
+    assert mat.shape == (L, L - 1) and np.max(np.abs(mat.ravel() - got["bond_energy_h"][0])) < 1e-12
+    psi_rows = open(tmp_path / "samples" / "psi.csv").read().strip().split("\n")
+    assert len(psi_rows) == 1 + nsamp * n
