@@ -454,6 +454,172 @@ __global__ __launch_bounds__(NT, 2) void gram_chol_lowrank_kernel(const T *__res
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Same interface and output contract as gram_chol_lowrank_kernel, other arithmetic: Householder QR of the live rows
+// of P in the working precision T instead of a Cholesky of the (never formed) Gram matrix in f64.  Orthogonal
+// transformations do not square the condition number, so no f64 is needed to resolve directions down to the
+// rounding of the T-typed data; a step costs 3 (K - nl) FMAs of type T per column (dot with the reflector, update,
+// remaining norm) against 2 K f64 FMAs + K conversions + the 32-term factor correction of the Gram form, the factor
+// rows live in the registers that held the finished rows of P (no second register array), and the rank is bounded
+// by the rows a thread holds (KCAP), not by CH_LR_CAP.  Thread r owns column r; the owner of the pivot column
+// publishes it through LDS, every thread builds the same reflector from it.  Columns are taken in index order,
+// skipping those whose remaining norm^2 is below the threshold (same rule as the Cholesky kernels).  More live rows
+// than KCAP: further passes re-triangularise [factor so far ; next rows of P] inside the kernel.
+template <typename T, int KCAP, int NT>
+__global__ __launch_bounds__(NT, 2) void qr_lowrank_kernel(const T *__restrict__ Pg, long wP, int n,
+                                                          const int *__restrict__ kdyn, int kdyn_mul, int kmax,
+                                                          T *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
+                                                          int inner = 1, const int *__restrict__ inner_live = nullptr,
+                                                          int retry_only = 0, int max_pass = 1, double noise_c = NOISE_C) {
+  constexpr int NWV = NT / 64;
+  constexpr int CHK = 8;                       // rows per uniform chunk of the unrolled loops
+  static_assert(KCAP % CHK == 0, "KCAP must be a multiple of the chunk");
+  if (retry_only && mlive_out[blockIdx.x] != -2) return;
+  __shared__ __attribute__((aligned(16))) T s_v[KCAP];   // pivot column
+  __shared__ T s_dn;                                     // its remaining norm^2
+  __shared__ double s_red[2][NWV], s_nrm[KCAP], s_part[2 * NWV];
+  __shared__ int s_first[2][NWV];
+  __shared__ short s_pos[KCAP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Ktot = kdyn ? min(kmax, kdyn[blockIdx.x] * kdyn_mul) : kmax;
+  const T *P = Pg + (long)blockIdx.x * wP;
+  T *Rout = Rg + (long)blockIdx.x * wR;
+  const int ilive = inner_live ? min(inner, inner_live[blockIdx.x]) : inner;
+  const int ncols = (n / inner) * ilive;
+  if (ncols > NT) {
+    if (tid == 0) mlive_out[blockIdx.x] = -2;
+    return;
+  }
+  const bool col_ok = tid < ncols;
+  const int r = col_ok ? (tid / ilive) * inner + (tid % ilive) : n;
+  const double eT = noise_c * (double)Eps<T>::v;
+  T pc[KCAP];
+#pragma unroll
+  for (int k = 0; k < KCAP; ++k) pc[k] = T(0);
+  int nl = 0, step = 0, k0 = 0;
+  double maxd = 0.0;
+#pragma unroll 1
+  for (int pass = 0;; ++pass) {
+    const int nfr = nl;                                  // factor rows carried over (rows 0..nfr of pc)
+    const int npr = min(Ktot - k0, KCAP - nfr);          // rows of P taken in this pass
+    if (pass >= max_pass || npr < min(Ktot - k0, CHK)) { // out of passes / no room left next to the factor: decline
+      if (tid == 0) mlive_out[blockIdx.x] = -1;
+      return;
+    }
+    const int K = nfr + npr;
+    T d = T(0);
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) {
+      if (k >= nfr) pc[k] = (k < K && col_ok) ? P[(long)(k0 + k - nfr) * n + r] : T(0);
+      d += pc[k] * pc[k];
+    }
+    double md = (double)d;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
+    if (lane == 0) s_red[pass & 1][wave] = md;
+    __syncthreads();
+    maxd = s_red[pass & 1][0];
+#pragma unroll
+    for (int q = 1; q < NWV; ++q) maxd = fmax(maxd, s_red[pass & 1][q]);
+    const T thresh = T(fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd);
+    int f = -1;
+    nl = 0;
+#pragma unroll 1
+    for (;; ++step) {
+      int cand = (col_ok && r > f && d > thresh) ? r : 0x7fffffff;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+      if (lane == 0) s_first[step & 1][wave] = cand;
+      __syncthreads();
+      if (tid == 0 && nl > 0) {                           // squared norm of the row finished in the previous step
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < NWV; ++q) a += s_part[NWV * ((step + 1) & 1) + q];
+        s_nrm[nl - 1] = a;
+      }
+      f = s_first[step & 1][0];
+#pragma unroll
+      for (int q = 1; q < NWV; ++q) f = min(f, s_first[step & 1][q]);
+      if (f == 0x7fffffff || nl >= K) { ++step; break; }
+      if (r == f) {                                       // the owner publishes the pivot column
+#pragma unroll
+        for (int k = 0; k < KCAP; ++k) s_v[k] = pc[k];
+        s_dn = d;
+      }
+      __syncthreads();
+      // reflector H = 1 - tau v v^T on rows nl..K-1:  v = x - alpha e_nl,  alpha = -sign(x_nl) |x|,  H x = alpha e_nl
+      const T dn = s_dn, x0 = s_v[nl];
+      const T nrmx = sqrt(dn);
+      const T alpha = x0 >= T(0) ? -nrmx : nrmx;
+      const T v0 = x0 - alpha;
+      const T tau = T(1) / (dn - x0 * alpha);             // 2 / (v^T v),  v^T v = 2 (|x|^2 - x_nl alpha)
+      T dot = T(0);
+#pragma unroll
+      for (int kb = 0; kb < KCAP; kb += CHK) {
+        if (kb + CHK > nl && kb < K) {                    // skip finished rows and rows beyond K (uniform)
+          asm volatile("" ::: "memory");                   // keep the LDS reads of later chunks from being hoisted
+#pragma unroll
+          for (int k = kb; k < kb + CHK; ++k) {
+            const T vk = k > nl ? s_v[k] : (k == nl ? v0 : T(0));
+            dot = fma(vk, pc[k], dot);
+          }
+        }
+      }
+      const T w = tau * dot;
+      T newd = T(0), rv = T(0);
+      const bool is_piv = r == f, right = col_ok && r > f;
+#pragma unroll
+      for (int kb = 0; kb < KCAP; kb += CHK) {
+        if (kb + CHK > nl && kb < K) {
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int k = kb; k < kb + CHK; ++k) {
+            const T vk = k > nl ? s_v[k] : (k == nl ? v0 : T(0));
+            T x = fma(-w, vk, pc[k]);
+            if (k == nl) {                                // the new factor row: alpha at the pivot, 0 left of it
+              x = is_piv ? alpha : (right ? x : T(0));
+              rv = x;
+            } else if (k > nl) {
+              x = right ? x : T(0);                       // the pivot column is eliminated below row nl
+              newd = fma(x, x, newd);
+            } else x = pc[k];
+            pc[k] = x;
+          }
+        }
+      }
+      d = right ? newd : T(0);
+      const double a = wave_sum((double)rv * (double)rv);
+      if (lane == 0) s_part[NWV * (step & 1) + wave] = a;
+      ++nl;
+    }
+    k0 += npr;
+    if (k0 >= Ktot) break;
+  }
+  __syncthreads();
+  double fro = 0.0;
+  for (int j = 0; j < nl; ++j) fro += s_nrm[j];
+  const double nfloor = eT * eT * fro;
+  const T sc = maxd > 0.0 ? T(1.0 / sqrt(maxd)) : T(1);
+  if (tid == 0) {
+    int cnt = 0;
+    for (int j = 0; j < nl; ++j) s_pos[j] = s_nrm[j] > nfloor ? (short)cnt++ : (short)-1;
+    mlive_out[blockIdx.x] = cnt;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int kb = 0; kb < KCAP; kb += CHK) {
+    if (kb < nl) {
+#pragma unroll
+      for (int j = kb; j < kb + CHK; ++j) {
+        if (j < nl) {
+          const int pos = s_pos[j];
+          if (pos >= 0 && r < n) Rout[(long)pos * n + r] = pc[j] * sc;
+        }
+      }
+    }
+  }
+}
+
 // Both variants in sequence: 128 threads per walker where the data columns fit, 256 otherwise.
 template <typename T, int KCAP>
 inline void launch_gram_chol_lowrank(hipStream_t s, int nbatch, const T *P, long wP, int n, const int *kdyn, int kdyn_mul,
@@ -461,6 +627,22 @@ inline void launch_gram_chol_lowrank(hipStream_t s, int nbatch, const T *P, long
                                      int max_pass = 1) {
   static const bool no_narrow = getenv("PEPSGPU_NO_NARROW_FUSED") != nullptr;
   const bool narrow = !no_narrow && (inner_live != nullptr || n <= 128);
+  // Householder form (working precision, no rank cap): measured on the headline workload it is slower than the Gram
+  // form at the same noise floor (cholesky category 226 ms vs 162 ms per two steps: f32 rounding of the reflections
+  // leaves more near-threshold columns to process) and only wins with a looser floor (PEPSGPU_QR_NOISE=128: 61.3k
+  // vs 57.4k amp/s, through fewer live carry rows in the Jacobi) -- kept for A/B runs, off by default.
+  static const bool use_qr = getenv("PEPSGPU_QR_FACTOR") != nullptr && atoi(getenv("PEPSGPU_QR_FACTOR")) != 0;
+  if (use_qr) {
+    static const double qr_noise = getenv("PEPSGPU_QR_NOISE") ? atof(getenv("PEPSGPU_QR_NOISE")) : NOISE_C;
+    if (narrow)
+      hipLaunchKernelGGL((qr_lowrank_kernel<T, KCAP, 128>), dim3(nbatch), dim3(128), 0, s, P, wP, n, kdyn, kdyn_mul, kmax, R, wR,
+                         mlive, inner, inner_live, 0, max_pass, qr_noise);
+    if (!narrow || n > 128)
+      hipLaunchKernelGGL((qr_lowrank_kernel<T, KCAP, 256>), dim3(nbatch), dim3(256), 0, s, P, wP, n, kdyn, kdyn_mul, kmax, R, wR,
+                         mlive, inner, inner_live, narrow ? 1 : 0, max_pass, qr_noise);
+    PG_CHECK_HIP(hipGetLastError());
+    return;
+  }
   if (narrow)
     hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP, 128>), dim3(nbatch), dim3(128), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
                        R, wR, mlive, inner, inner_live, 0, max_pass);

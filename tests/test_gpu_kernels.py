@@ -255,3 +255,28 @@ def test_gram_free_lowrank_factor(K, n, rank, dt):
         assert rank - 1 <= ml[b] <= min(rank + 2, K, n), (rank, ml[b])     # rounding noise of the input may pass as a pivot
         Rb = R[b, :ml[b]].astype(np.float64)
         assert np.max(np.abs(Rb.T @ Rb * sc - G)) / sc < tol
+
+
+def test_householder_factor_variant_in_subprocess():
+    """qr_lowrank_kernel (PEPSGPU_QR_FACTOR=1, an A/B variant of the Gram-free factor): R^T R = P^T P and the reported
+    rank on low-rank inputs; the switch is read once per process, hence the subprocess."""
+    import subprocess, sys, os
+    code = r'''
+import numpy as np
+from peps_amd import capi
+rng = np.random.default_rng(3)
+for dt, t, tol in ((capi.F32, np.float32, 3e-6), (capi.F64, np.float64, 1e-13)):
+    for K, n, rank in ((80, 80, 10), (40, 96, 33), (96, 128, 5)):
+        P = (rng.standard_normal((3, K, rank)) @ rng.standard_normal((3, rank, n))).astype(t)
+        R, ml = capi.diag_gram_chol(dt, P)
+        for b in range(3):
+            assert rank <= ml[b] <= rank + 2, (K, n, rank, ml)
+            G = P[b].astype(np.float64).T @ P[b].astype(np.float64)
+            Rb = R[b][:ml[b]].astype(np.float64)
+            assert np.max(np.abs(Rb.T @ Rb - G / np.max(np.diag(G)))) < tol * 10, (K, n, rank)
+print("OK")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root,
+                       env=dict(os.environ, PEPSGPU_QR_FACTOR="1", PYTHONPATH=root))
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
