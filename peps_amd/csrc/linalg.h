@@ -313,6 +313,7 @@ __global__ __launch_bounds__(NT, 2) void gram_chol_lowrank_kernel(const T *__res
   // inner index (live bond of the boundary MPS): columns beyond hold no data and are never read
   __shared__ __attribute__((aligned(16))) T s_pf[KCAP];   // column f of P
   __shared__ double s_rf[CH_LR_CAP];     // column f of the factor
+  __shared__ double s_piv;               // remaining diagonal of the pivot column = G[f,f] - sum_j R[j,f]^2
   __shared__ double s_red[2][NWV], s_nrm[CH_LR_CAP], s_part[2 * NWV];
   __shared__ int s_first[2][NWV];
   __shared__ short s_pos[CH_LR_CAP];
@@ -394,9 +395,11 @@ __global__ __launch_bounds__(NT, 2) void gram_chol_lowrank_kernel(const T *__res
         for (int k = 0; k < KCAP; ++k) s_pf[k] = pc[k];
 #pragma unroll
         for (int j = 0; j < CH_LR_CAP; ++j) s_rf[j] = rc[j];
+        s_piv = d;                           // the owner's running diagonal IS the pivot: no thread recomputes it
       }
       __syncthreads();
-      double g = 0.0, piv = 0.0;             // g = G[f, r] - sum_j R[j,f] R[j,r];  piv likewise for r = f
+      double g = 0.0;                        // g = G[f, r] - sum_j R[j,f] R[j,r]
+      const double piv = s_piv;
 #pragma unroll
       for (int kb = 0; kb < KCAP; kb += 16) {
         if (kb >= K) break;
@@ -411,20 +414,28 @@ __global__ __launch_bounds__(NT, 2) void gram_chol_lowrank_kernel(const T *__res
           asm volatile("" : "+v"(pk));         // opaque copy: keeps the T -> f64 conversion of the (loop-invariant)
                                                // column inside the step loop instead of 2*KCAP live registers
           g = fma(pf, (double)pk, g);
-          piv = fma(pf, pf, piv);
         }
       }
 #pragma unroll
-      for (int j = 0; j < CH_LR_CAP; ++j) {
-        if (j < nl) {
-          const double rf = s_rf[j];
-          g = fma(-rf, rc[j], g);
-          piv = fma(-rf, rf, piv);
+      for (int jb = 0; jb < CH_LR_CAP; jb += 8) {   // nl is block-uniform: whole chunks beyond it are skipped
+        if (jb < nl) {
+#pragma unroll
+          for (int j = jb; j < jb + 8; ++j) {
+            if (j < nl) {
+              const double rf = s_rf[j];
+              g = fma(-rf, rc[j], g);
+            }
+          }
         }
       }
       const double v = (r >= f && r < n) ? g / sqrt(piv) : 0.0;
 #pragma unroll
-      for (int j = 0; j < CH_LR_CAP; ++j) rc[j] = (j == nl) ? v : rc[j];
+      for (int jb = 0; jb < CH_LR_CAP; jb += 8) {
+        if ((nl & ~7) == jb) {
+#pragma unroll
+          for (int j = jb; j < jb + 8; ++j) rc[j] = (j == nl) ? v : rc[j];
+        }
+      }
       const double v2 = v * v;
       if (r > f) d -= v2;
       const double a = wave_sum(v2);
