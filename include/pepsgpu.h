@@ -75,6 +75,12 @@ int pepsgpu_grow_bmps_for_row(pepsgpu_ctx *ctx, int row);       /* GrowBMPSForRo
 int pepsgpu_grow_bmps_for_col(pepsgpu_ctx *ctx, int col);       /* GrowBMPSForCol            :106-122 */
 int pepsgpu_shift_bmps_window(pepsgpu_ctx *ctx, int pos);       /* ShiftBMPSWindow           :143-148 */
 int pepsgpu_delete_inner_bmps(pepsgpu_ctx *ctx, int pos);       /* DeleteInnerBMPS  bmps_contractor.h:320-324 */
+/* BMPSWalker (bmps/impl/bmps_walker.h:  a BMPS forked out of a stack, evolved row by row and contracted against an
+ * explicitly named environment of the opposite stack).  The stack itself is the walker here: park hides the levels
+ * above keep_levels (no copy) so that the BTen / trace calls see level keep_levels-1 as the top; unpark drops what was
+ * grown meanwhile and restores the hidden levels. */
+int pepsgpu_bmps_park(pepsgpu_ctx *ctx, int pos, int keep_levels);
+int pepsgpu_bmps_unpark(pepsgpu_ctx *ctx, int pos);
 int pepsgpu_generate_bmps_approach(pepsgpu_ctx *ctx, int pos);  /* GenerateBMPSApproach      :11-17   */
 int pepsgpu_bmps_stack_size(pepsgpu_ctx *ctx, int pos);         /* GetBMPS(pos).size(); <0 on error */
 /* GetBMPS(pos)[level][idx]: dims_out[3]; data_out [n][d0*d1*d2] float64 (may be NULL);

@@ -337,14 +337,59 @@ def measure_spin_onehalf_off_diag_order_in_row(sitps, comp, inv_psi, row):
     return out
 
 
+def measure_structure_factor(sitps, comp):
+    """StructureFactorMeasurementMixin::MeasureStructureFactor (model_solvers/base/structure_factor_measurement_mixin.h:
+    62-215) with BMPSWalker (two_dim_tn/tensor_network_2d/bmps/impl/bmps_walker.h): a walker forked from the UP vacuum is
+    evolved through the excited row y1 (S+ at (y1, x1), source spin down) and the standard rows below; every row y2 > y1
+    is closed against the DOWN environment of the rows below it with S- at (y2, x2) (target spin up).  Returns the flat
+    tuples [y1, x1, y2, x2, value, ...]; value = amplitude of the doubly flipped configuration, 0 for a closed channel.
+    Restated with the contractor's own primitives: the walker = an UP stack that is extended and cut back."""
+    tn, c, config = comp.tn, comp.contractor, comp.config
+    ly, lx = tn.rows, tn.cols
+    out = []
+    c.GenerateBMPSApproach(tn, UP)
+    down_full = list(c.bmps_set[DOWN])
+    for y1 in range(ly - 1):
+        main = list(c.bmps_set[UP])
+        for x1 in range(lx):
+            src_down = int(config[y1, x1]) == 0
+            if src_down:
+                tn.update_site_tensor((y1, x1), 1, sitps)
+            c.bmps_set[UP] = list(main)
+            c.GrowBMPSStep(tn, UP)
+            for y2 in range(y1 + 1, ly):
+                c.bmps_set[DOWN] = down_full[:ly - y2]                       # bottom_env = down_stack[ly-1-y2]
+                row = [0.0] * lx
+                c.InitBTen(tn, LEFT, y2)
+                c.GrowFullBTen(tn, RIGHT, y2, 1, True)
+                for x2 in range(lx):
+                    if src_down and int(config[y2, x2]) == 1:
+                        row[x2] = c.ReplaceOneSiteTrace(tn, (y2, x2), sitps[y2][x2][0], HORIZONTAL)
+                    if x2 < lx - 1:
+                        c.ShiftBTenWindow(tn, RIGHT)
+                for x2 in range(lx):
+                    out += [float(y1), float(x1), float(y2), float(x2), row[x2]]
+                if y2 < ly - 1:
+                    c.GrowBMPSStep(tn, UP)
+            if src_down:
+                tn.update_site_tensor((y1, x1), int(config[y1, x1]), sitps)
+        c.bmps_set[UP] = list(main)
+        c.bmps_set[DOWN] = list(down_full)
+        c.GrowBMPSStep(tn, UP)
+    c.bmps_set[DOWN] = list(down_full)
+    for pos in (LEFT, RIGHT, UP, DOWN):
+        c.bten_set[pos] = []
+    return out
+
+
 class SquareNNNModelMeasurementSolver:
     """SquareNNNModelMeasurementSolver::EvaluateObservables (model_solvers/base/square_nnn_model_measurement_solver.h:
     30-254) over BondTraversalMixin::TraverseAllBonds (bond_traversal_mixin.h:22-145): registry keys energy, spin_z,
     bond_energy_h/v(/dr/ur) and the psi summary of the sample.  `model` supplies the bond terms (an energy-solver
     model of this module); XXZ adds SzSz_all2all and SmSp_row / SpSm_row (square_spin_onehalf_xxz_obc.h:215-288)."""
 
-    def __init__(self, model, spin_onehalf_xxz=True):
-        self.model, self.xxz = model, spin_onehalf_xxz
+    def __init__(self, model, spin_onehalf_xxz=True, structure_factor=False):
+        self.model, self.xxz, self.structure_factor = model, spin_onehalf_xxz, structure_factor
         self.last_psi_summary = None
 
     def EvaluateObservables(self, sitps, comp):
@@ -417,6 +462,8 @@ class SquareNNNModelMeasurementSolver:
             sz = np.asarray(out["spin_z"])
             out["SzSz_all2all"] = [sz[i] * sz[j] for i in range(sz.size) for j in range(i, sz.size)]
         self.last_psi_summary = compute_psi_consistency_summary_aligned(psi_list)
+        if self.structure_factor:                                     # square_spin_onehalf_xxz_obc.h:238-248
+            out["SpSm_cross"] = measure_structure_factor(sitps, comp)
         return out
 
 

@@ -23,7 +23,7 @@ SYMBOLS = [
     "pepsgpu_ctx_create", "pepsgpu_set_truncate_params", "pepsgpu_ctx_destroy", "pepsgpu_last_error", "pepsgpu_state_upload",
     "pepsgpu_walkers_set_configs", "pepsgpu_walkers_get_configs", "pepsgpu_n_walkers",
     "pepsgpu_grow_bmps_step", "pepsgpu_grow_full_bmps", "pepsgpu_grow_bmps_for_row", "pepsgpu_grow_bmps_for_col",
-    "pepsgpu_shift_bmps_window", "pepsgpu_delete_inner_bmps", "pepsgpu_generate_bmps_approach",
+    "pepsgpu_shift_bmps_window", "pepsgpu_delete_inner_bmps", "pepsgpu_bmps_park", "pepsgpu_bmps_unpark", "pepsgpu_generate_bmps_approach",
     "pepsgpu_bmps_stack_size", "pepsgpu_get_bmps_tensor", "pepsgpu_init_bten", "pepsgpu_grow_full_bten",
     "pepsgpu_grow_bten_step", "pepsgpu_shift_bten_window", "pepsgpu_truncate_bten", "pepsgpu_bten_stack_size",
     "pepsgpu_trace", "pepsgpu_replace_nn_trace", "pepsgpu_replace_one_trace", "pepsgpu_punch_hole",
@@ -59,6 +59,8 @@ def load_library(path=LIB_PATH):
                  "delete_inner_bmps", "generate_bmps_approach", "bmps_stack_size", "bten_stack_size",
                  "grow_bten_step", "shift_bten_window"):
         getattr(lib, "pepsgpu_" + name).argtypes = [vp, C.c_int]
+    lib.pepsgpu_bmps_park.argtypes = [vp, C.c_int, C.c_int]
+    lib.pepsgpu_bmps_unpark.argtypes = [vp, C.c_int]
     lib.pepsgpu_get_bmps_tensor.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip, dp, dp]
     lib.pepsgpu_init_bten.argtypes = [vp, C.c_int, C.c_int]
     lib.pepsgpu_truncate_bten.argtypes = [vp, C.c_int, C.c_int]
@@ -186,6 +188,8 @@ class Context:
     def grow_bmps_for_col(self, col): self._ck(self._l.pepsgpu_grow_bmps_for_col(self._h, col))
     def shift_bmps_window(self, pos): self._ck(self._l.pepsgpu_shift_bmps_window(self._h, pos))
     def delete_inner_bmps(self, pos): self._ck(self._l.pepsgpu_delete_inner_bmps(self._h, pos))
+    def bmps_park(self, pos, keep): self._ck(self._l.pepsgpu_bmps_park(self._h, pos, keep))
+    def bmps_unpark(self, pos): self._ck(self._l.pepsgpu_bmps_unpark(self._h, pos))
     def generate_bmps_approach(self, pos): self._ck(self._l.pepsgpu_generate_bmps_approach(self._h, pos))
     def bmps_stack_size(self, pos): return self._l.pepsgpu_bmps_stack_size(self._h, pos)
     def bten_stack_size(self, pos): return self._l.pepsgpu_bten_stack_size(self._h, pos)

@@ -106,6 +106,8 @@ int pepsgpu_grow_bmps_for_row(pepsgpu_ctx *ctx, int row) { CTX_CALL(ctx->eng->gr
 int pepsgpu_grow_bmps_for_col(pepsgpu_ctx *ctx, int col) { CTX_CALL(ctx->eng->grow_bmps_for_col(col)); }
 int pepsgpu_shift_bmps_window(pepsgpu_ctx *ctx, int pos) { CTX_CALL(check_pos(pos); ctx->eng->shift_bmps_window(pos)); }
 int pepsgpu_delete_inner_bmps(pepsgpu_ctx *ctx, int pos) { CTX_CALL(check_pos(pos); ctx->eng->delete_inner_bmps(pos)); }
+int pepsgpu_bmps_park(pepsgpu_ctx *ctx, int pos, int keep_levels) { CTX_CALL(check_pos(pos); ctx->eng->bmps_park(pos, keep_levels)); }
+int pepsgpu_bmps_unpark(pepsgpu_ctx *ctx, int pos) { CTX_CALL(check_pos(pos); ctx->eng->bmps_unpark(pos)); }
 int pepsgpu_generate_bmps_approach(pepsgpu_ctx *ctx, int pos) {
   CTX_CALL(check_pos(pos); ctx->eng->generate_bmps_approach(pos));
 }

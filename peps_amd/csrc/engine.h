@@ -46,6 +46,8 @@ struct EngineBase {
   virtual void grow_bmps_for_col(int col) = 0;
   virtual void shift_bmps_window(int pos) = 0;
   virtual void delete_inner_bmps(int pos) = 0;
+  virtual void bmps_park(int pos, int keep) = 0;
+  virtual void bmps_unpark(int pos) = 0;
   virtual void generate_bmps_approach(int pos) = 0;
   virtual void init_bten(int pos, int slice) = 0;
   virtual void grow_full_bten(int pos, int slice, int remain, int init) = 0;
@@ -178,6 +180,8 @@ class Engine : public EngineBase {
     PG_CHECK_HIP(hipStreamSynchronize(stream_));
     // Init(tn): bmps_contractor_init.h:25-32
     for (int p = 0; p < 4; ++p) {
+      for (auto &b : parked_[p]) free_bmps(b);
+      parked_[p].clear();
       clear_bmps(p, 0);
       clear_bten(p, 0);
       clear_bten2(p, 0);
@@ -251,6 +255,25 @@ class Engine : public EngineBase {
   }
   void delete_inner_bmps(int pos) override {   // bmps_contractor.h:320-324
     if (bmps_size(pos) > 1) clear_bmps(pos, 1);
+  }
+  // BMPSWalker support (bmps/impl/bmps_walker.h): the reference forks a BMPS out of a stack and contracts rows against an
+  // explicitly named environment of the opposite stack.  Here the stack itself is the walker; parking hides the levels
+  // above `keep` (nothing is copied or freed) so that level keep-1 is the top every BTen / trace call sees, unparking
+  // drops whatever was grown meanwhile and puts the hidden levels back.
+  void bmps_park(int pos, int keep) override {
+    PG_REQUIRE(parked_[pos].empty(), 3, "bmps_park: this stack is already parked");
+    PG_REQUIRE(keep >= 1 && keep <= bmps_size(pos), 1, "bmps_park: level outside the stack");
+    parked_keep_[pos] = keep;
+    auto &v = bmps_[pos];
+    parked_[pos].assign(std::make_move_iterator(v.begin() + keep), std::make_move_iterator(v.end()));
+    v.erase(v.begin() + keep, v.end());
+  }
+  void bmps_unpark(int pos) override {
+    if (parked_[pos].empty()) return;
+    PG_REQUIRE(bmps_size(pos) >= parked_keep_[pos], 3, "bmps_unpark: the parked stack was truncated below its park level");
+    clear_bmps(pos, parked_keep_[pos]);
+    for (auto &b : parked_[pos]) bmps_[pos].push_back(std::move(b));
+    parked_[pos].clear();
   }
   void generate_bmps_approach(int pos) override {   // grow.h:11-17
     delete_inner_bmps(pos);
@@ -959,6 +982,8 @@ class Engine : public EngineBase {
   bool prof_on_ = false;
   double prof_ms_[PROF_NCAT] = {0}, prof_alg_[PROF_NCAT] = {0}, prof_exec_[PROF_NCAT] = {0};
   long prof_n_[PROF_NCAT] = {0};
+  std::vector<BMPSDev> parked_[4];
+  int parked_keep_[4] = {0, 0, 0, 0};
   int scheme_ = 0, iter_max_ = 0;
   double conv_tol_ = 0.0;
   long n_var_iters_ = 0;

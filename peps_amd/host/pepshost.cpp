@@ -161,6 +161,7 @@ int pepshost_measure(int rows, int cols, int D, int d, int chi, int dtype, const
     SquareSpinOneHalfXXZModelOBC xxz(p[0], p[1], p[2]);
     SquareSpinOneHalfJ1J2XXZModelOBC j1j2(p[0], p[1], p[2], p[3], p[4]);
     if (model != 0 && model != 2) throw std::invalid_argument("pepshost_measure: model must be xxz or j1j2");
+    xxz.SetEnableStructureFactor(p[7] != 0.0);                  // params[7]: structure factor switch (xxz only)
     std::string keys;
     std::vector<double> vals;
     auto emit = [&](const std::string &key, const std::vector<double> &a, const std::vector<double> *b, size_t len) {

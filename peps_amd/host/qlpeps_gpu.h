@@ -284,6 +284,9 @@ class BMPSContractor {
   void GrowBMPSForCol(size_t col) { check_rc(pepsgpu_grow_bmps_for_col(ctx_, (int)col), ctx_); }
   void ShiftBMPSWindow(BMPSPOSITION p) { check_rc(pepsgpu_shift_bmps_window(ctx_, p), ctx_); }
   void DeleteInnerBMPS(BMPSPOSITION p) { check_rc(pepsgpu_delete_inner_bmps(ctx_, p), ctx_); }
+  // BMPSWalker equivalents (bmps_walker.h): the stack is the walker, the opposite environment is named by parking
+  void ParkBMPS(BMPSPOSITION p, size_t keep_levels) { check_rc(pepsgpu_bmps_park(ctx_, p, (int)keep_levels), ctx_); }
+  void UnparkBMPS(BMPSPOSITION p) { check_rc(pepsgpu_bmps_unpark(ctx_, p), ctx_); }
   void GenerateBMPSApproach(BMPSPOSITION p) { check_rc(pepsgpu_generate_bmps_approach(ctx_, p), ctx_); }
   void InitBTen(BTenPOSITION p, size_t slice) { check_rc(pepsgpu_init_bten(ctx_, p, (int)slice), ctx_); }
   void GrowFullBTen(BTenPOSITION p, size_t slice, size_t remain_sites = 2, bool init = true) {
@@ -1016,6 +1019,67 @@ struct SpinOneHalfMeasurementHooks {
       std::copy(corr.begin() + w * half, corr.begin() + (w + 1) * half, dst.begin() + w * half);
     }
   }
+  // StructureFactorMeasurementMixin::MeasureStructureFactor (base/structure_factor_measurement_mixin.h:62-215):
+  // SpSm_cross = flat tuples {y1, x1, y2, x2, value} for every y1 < y2; value = amplitude of the configuration with
+  // S+ applied at (y1, x1) (source spin down) and S- at (y2, x2) (target spin up), 0 where the channel is closed.
+  // The reference forks a BMPSWalker from the UP vacuum, evolves it through the excited row y1 and the standard rows
+  // below, and contracts each row y2 against DOWN[Ly-1-y2]; here the UP stack is the walker (the excitation is a
+  // temporary UpdateLocal, undone afterwards) and the DOWN environment is named by parking the levels above it.
+  void SetEnableStructureFactor(bool enable) { enable_structure_factor_measurement_ = enable; }
+  bool IsStructureFactorEnabled() const { return enable_structure_factor_measurement_; }
+  void MeasureStructureFactor(TPSWaveFunctionComponent &comp, ObservableMap &out) const {
+    if (!enable_structure_factor_measurement_) return;
+    auto &c = comp.contractor;
+    const size_t Ly = c.rows(), Lx = c.cols(), n = comp.config.walkers();
+    const size_t per = (Ly - 1) * Lx * Ly / 2 * Lx * 5;       // sum_{y1} Lx * (Ly-1-y1) * Lx tuples of 5
+    auto &cross = out.make("SpSm_cross", per);
+    std::vector<size_t> fill(n, 0);
+    const std::vector<uint8_t> all(n, 1);
+    c.GenerateBMPSApproach(UP);                                // UP = vacuum, DOWN fully grown (traversal start state)
+    for (size_t y1 = 0; y1 + 1 < Ly; ++y1) {
+      for (size_t x1 = 0; x1 < Lx; ++x1) {
+        const std::vector<int32_t> site = {(int32_t)y1, (int32_t)x1};
+        std::vector<int32_t> orig(n), excited(n);
+        std::vector<uint8_t> src_down(n);
+        for (size_t w = 0; w < n; ++w) {
+          orig[w] = comp.config(w, {y1, x1});
+          src_down[w] = orig[w] == 0;
+          excited[w] = src_down[w] ? 1 : orig[w];
+        }
+        c.UpdateLocal(site, excited, all);                      // excited_mpo_ptrs[x1] = sitps(y1,x1)[1]
+        c.GrowBMPSStep(UP);                                     // excited_walker.Evolve(excited row y1)
+        for (size_t y2 = y1 + 1; y2 < Ly; ++y2) {
+          c.ParkBMPS(DOWN, Ly - y2);                            // bottom_env = down_stack[Ly-1-y2]
+          c.InitBTen(LEFT, y2);
+          c.GrowFullBTen(RIGHT, y2, 1, true);
+          std::vector<double> row(n * Lx, 0.0);
+          for (size_t x2 = 0; x2 < Lx; ++x2) {
+            bool any = false;
+            for (size_t w = 0; w < n; ++w) any |= src_down[w] && comp.config(w, {y2, x2}) == 1;
+            if (any) {
+              std::vector<int32_t> cand(n, 0);                  // GetSiteTensor(y2, x2, 0)
+              std::vector<double> psi_ex = c.ReplaceOneSiteTrace({y2, x2}, HORIZONTAL, 1, cand);
+              for (size_t w = 0; w < n; ++w)
+                if (src_down[w] && comp.config(w, {y2, x2}) == 1) row[w * Lx + x2] = psi_ex[w];
+            }
+            if (x2 + 1 < Lx) c.ShiftBTenWindow(RIGHT);
+          }
+          c.UnparkBMPS(DOWN);
+          for (size_t w = 0; w < n; ++w)
+            for (size_t x2 = 0; x2 < Lx; ++x2) {
+              double *t = &cross[w * per + fill[w]];
+              t[0] = (double)y1; t[1] = (double)x1; t[2] = (double)y2; t[3] = (double)x2; t[4] = row[w * Lx + x2];
+              fill[w] += 5;
+            }
+          if (y2 + 1 < Ly) c.GrowBMPSStep(UP);                  // excited_walker.Evolve(standard row y2)
+        }
+        c.UpdateLocal(site, orig, all);                         // drop the excited walker: UP back to the main walker
+      }
+      c.GrowBMPSStep(UP);                                       // main_walker.Evolve(standard row y1)
+    }
+  }
+  bool enable_structure_factor_measurement_ = false;
+
   static void AddSzSzAll2All(const TPSWaveFunctionComponent &comp, ObservableMap &out) {   // :225-236
     const size_t ly = comp.contractor.rows(), lx = comp.contractor.cols(), n = comp.config.walkers(), N = ly * lx;
     auto &szsz = out.make("SzSz_all2all", N * (N + 1) / 2);
@@ -1095,6 +1159,7 @@ class SquareSpinOneHalfXXZModelOBC : public SquareNNModelEnergySolver<SquareSpin
   ObservableMap EvaluateObservables(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp) {   // :215-251
     ObservableMap out = SquareNNModelMeasurementSolver<SquareSpinOneHalfXXZModelOBC>::EvaluateObservables(sitps, comp);
     AddSzSzAll2All(comp, out);
+    MeasureStructureFactor(comp, out);                         // :238-248 (if enabled)
     return out;
   }
   std::vector<ObservableMeta> DescribeObservables(size_t ly, size_t lx) const {

@@ -112,3 +112,29 @@ def test_mc_measurer_identical_chain_statistics(updater, cls, tmp_path):
     assert mat.shape == (L, L - 1) and np.max(np.abs(mat.ravel() - got["bond_energy_h"][0])) < 1e-12
     psi_rows = open(tmp_path / "samples" / "psi.csv").read().strip().split("\n")
     assert len(psi_rows) == 1 + nsamp * n
+
+
+@pytest.mark.parametrize("dt,tol,chi", [(F64, 1e-9, 9), (F64, 1e-9, 27), (F32, 5e-5, 9)])
+def test_structure_factor_cross_row_spsm(dt, tol, chi):
+    """StructureFactorMeasurementMixin::MeasureStructureFactor through the BMPSWalker-equivalent stack operations
+    (park / unpark of the DOWN levels, UP stack as the walker): every tuple of SpSm_cross against the oracle restatement,
+    at a truncating and at an exact chi; the registry keys measured before it are unchanged."""
+    host = _host()
+    L, D = 4, 3
+    s = synthetic.make_sitps(L, D)
+    cfgs = synthetic.make_configs(L, 4, "heisenberg")
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    params = (1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0)          # params[7] = structure factor on
+    got, _ = host.measure(synthetic.sitps_to_flat(s, D), cfgs, chi, "xxz", params, dtype=dt)
+    plain, _ = host.measure(synthetic.sitps_to_flat(s, D), cfgs, chi, "xxz", params[:3], dtype=dt)
+    assert "SpSm_cross" in got and "SpSm_cross" not in plain
+    for key in plain:
+        assert np.array_equal(plain[key], got[key]), key
+    for w, cfg in enumerate(cfgs):
+        comp = vmc.TPSWaveFunctionComponent(s, cfg, tp)
+        want = np.array(vmc.measure_structure_factor(s, comp)).reshape(-1, 5)
+        have = got["SpSm_cross"][w].reshape(-1, 5)
+        assert have.shape == want.shape
+        assert np.array_equal(have[:, :4], want[:, :4])
+        scale = np.max(np.abs(want[:, 4]))
+        assert scale > 0 and np.max(np.abs(have[:, 4] - want[:, 4])) < tol * 10 * scale

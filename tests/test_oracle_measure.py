@@ -45,3 +45,30 @@ def test_psi_consistency_summary_aligns_sign_branches():
     assert vmc.compute_psi_consistency_summary_aligned([]) == (0.0, 0.0)
     mean, rel = vmc.compute_psi_consistency_summary_aligned([2.0, 2.0])
     assert mean == 2.0 and rel == 0.0
+
+
+def test_structure_factor_equals_amplitudes_of_doubly_flipped_configurations():
+    """measure_structure_factor (BMPSWalker flow of structure_factor_measurement_mixin.h) at an exact chi: every open
+    channel equals the amplitude of the configuration with (y1,x1) raised and (y2,x2) lowered, closed channels are 0."""
+    L, D, chi = 4, 3, 27
+    s = synthetic.make_sitps(L, D)
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    cfg = synthetic.make_configs(L, 2, "heisenberg")[1]
+    comp = vmc.TPSWaveFunctionComponent(s, cfg, tp)
+    t = np.array(vmc.measure_structure_factor(s, comp)).reshape(-1, 5)
+    assert len(t) == sum(L * (L - 1 - y1) * L for y1 in range(L - 1))
+    n_open = 0
+    for y1, x1, y2, x2, val in t:
+        y1, x1, y2, x2 = int(y1), int(x1), int(y2), int(x2)
+        assert y2 > y1
+        if cfg[y1, x1] == 0 and cfg[y2, x2] == 1:
+            c2 = cfg.copy()
+            c2[y1, x1], c2[y2, x2] = 1, 0
+            ref = vmc.TPSWaveFunctionComponent(s, c2, tp).amplitude
+            assert abs(val / ref - 1) < 1e-9
+            n_open += 1
+        else:
+            assert val == 0.0
+    assert n_open > 10
+    # the measurement leaves the contractor usable: a fresh amplitude still comes out right
+    assert abs(comp.EvaluateAmplitude() / vmc.TPSWaveFunctionComponent(s, cfg, tp).amplitude - 1) < 1e-12
