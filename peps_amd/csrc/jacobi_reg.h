@@ -463,8 +463,11 @@ __global__ __launch_bounds__(256, 3) void jacobi_rows_tiny_kernel(float *__restr
       for (int i = 0; i < JR_BR; ++i) na[i] = jr_allsum(jr_dot(a[i], a[i]));
     }
     int rot;
-    if (mm <= 8) rot = jr_intra<8>(a, na, tol2, floor2);
+    if (mm <= 6) rot = jr_intra<6>(a, na, tol2, floor2);
+    else if (mm <= 8) rot = jr_intra<8>(a, na, tol2, floor2);
+    else if (mm <= 10) rot = jr_intra<10>(a, na, tol2, floor2);
     else if (mm <= 12) rot = jr_intra<12>(a, na, tol2, floor2);
+    else if (mm <= 14) rot = jr_intra<14>(a, na, tol2, floor2);
     else rot = jr_intra<JR_BR>(a, na, tol2, floor2);
     if (rot == 0) { ++sweep; break; }
   }
@@ -553,8 +556,11 @@ __global__ __launch_bounds__(256, 3) void jacobi_rows_tiny2_kernel(float *__rest
       for (int i = 0; i < JR_BR; ++i) na[i] = jr_allsum32(jr_dot(a[i], a[i]));
     }
     int rot;
-    if (mm_max <= 8) rot = jr_intra32<8>(a, na, tol2, floor2);
+    if (mm_max <= 6) rot = jr_intra32<6>(a, na, tol2, floor2);
+    else if (mm_max <= 8) rot = jr_intra32<8>(a, na, tol2, floor2);
+    else if (mm_max <= 10) rot = jr_intra32<10>(a, na, tol2, floor2);
     else if (mm_max <= 12) rot = jr_intra32<12>(a, na, tol2, floor2);
+    else if (mm_max <= 14) rot = jr_intra32<14>(a, na, tol2, floor2);
     else rot = jr_intra32<JR_BR>(a, na, tol2, floor2);
     if (!__any(rot != 0)) { ++sweep; break; }
   }
