@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--walkers", type=int, default=16384, help="walkers (fresh configurations) per GPU per step")
+    ap.add_argument("--walkers", type=int, default=32768, help="walkers (fresh configurations) per GPU per step")
     ap.add_argument("--workload", default="C4", choices=["C2", "C3", "C4"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time budget of the CPU (oracle) baseline sample")
@@ -70,16 +70,16 @@ PMC_KERNEL = {"contract": "tgemm_direct_kernel", "gram_f64": "tgemm_kernel<float
 
 def pmc_traffic_bytes(category, args, nw):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_{FETCH,WRITE}_SIZE_c4_f32_nw16384.txt: separate passes, values in KiB, FETCH_SIZE
+    (profiles/r01_pmc_{FETCH,WRITE}_SIZE_c4_f32_nw32768.txt: separate passes, values in KiB, FETCH_SIZE
     doubled as MI355X_MICROARCH.md 'HBM' prescribes for gfx950).  PMC counters cannot be read from
     inside this process, so the figure is only quoted when the run has the configuration the passes
     were collected on; otherwise null."""
-    if (args.workload, args.dtype, nw, args.noise) != ("C4", "f32", 16384, 0.1) or category not in PMC_KERNEL:
+    if (args.workload, args.dtype, nw, args.noise) != ("C4", "f32", 32768, 0.1) or category not in PMC_KERNEL:
         return None
     here = os.path.dirname(os.path.abspath(__file__))
     vals = {}
     for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
-        path = os.path.join(here, "profiles", "r01_pmc_%s_c4_f32_nw16384.txt" % cnt)
+        path = os.path.join(here, "profiles", "r01_pmc_%s_c4_f32_nw32768.txt" % cnt)
         if not os.path.exists(path):
             return None
         tot, launches = 0.0, 0
@@ -90,7 +90,7 @@ def pmc_traffic_bytes(category, args, nw):
         if launches == 0:
             return None
         # the profiled command (scripts/gpu_pmc.sh: --steps 1 --warmup 1) runs the path four times: calibration
-        # with 1 walker, warm-up and timed step with 16384, rank diagnostics with 16 -- half of the launches are
+        # with 1 walker, warm-up and timed step with 32768, rank diagnostics with 16 -- half of the launches are
         # full-size and carry all but ~0.1 % of the bytes
         vals[cnt] = tot / (launches / 2.0)                        # KiB per full-size launch
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
