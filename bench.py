@@ -32,14 +32,19 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--walkers", type=int, default=32768, help="walkers (fresh configurations) per GPU per step")
+    ap.add_argument("--walkers", type=int, default=None,
+                    help="walkers (fresh configurations) per GPU per step; default 32768 (81 GB at the low-rank "
+                         "headline workload), 4096 for f64 or for states of higher rank (--noise > 0.15: up to 11.6 MB / walker)")
     ap.add_argument("--workload", default="C4", choices=["C2", "C3", "C4"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time budget of the CPU (oracle) baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--noise", type=float, default=0.1,
                     help="relative noise of the synthetic site tensors (SURVEY 8d: 0.1; 1.0 = full-rank stress case)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.walkers is None:
+        args.walkers = 32768 if (args.dtype == "f32" and args.noise <= 0.15) else 4096
+    return args
 
 
 def cpu_baseline(sitps, cfgs, chi, budget_s):
