@@ -138,36 +138,55 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     const int l2 = dd[lr], u = dd[lu];
     PG_REQUIRE(l == dd[ll] && a == A.d[0] && p == dd[lp], 3, "MultiplyMPO: bond dimension mismatch");
     // X[m,l,p,a2] = sum_a R[m,l,a] A[a,p,a2]                      (bmps_impl.h:806)
-    DTen<T> X = alloc_ten(m * l, p, a2);
-    {
-      TGemmDesc g;
-      g.I[2] = m * l; g.sAi[2] = a; g.sCi[2] = p * a2;
-      g.K[2] = a; g.sAk[2] = 1; g.sBk[2] = p * a2;
-      g.J[1] = p; g.J[2] = a2; g.sBj[1] = a2; g.sBj[2] = 1; g.sCj[1] = a2; g.sCj[2] = 1;
-      g.wA = R[i].n; g.wB = A.n; g.wC = X.n; g.nbatch = nw_;
-      g.dynI = mdyn[i]; g.dynI_mul = mmul[i] * l;
-      g.dK[2].p = clive[i];            // live part of the bond to the left of A
-      g.dJ[2].p = clive[i + 1];        // ... and to its right
-      const double fl = 2.0 * nw_ * (double)(m * l) * a * (double)(p * a2);
-      prof_begin(PROF_CONTRACT, fl, fl);
-      tgemm_launch<T, T, T, T>(stream_, g, R[i].p, A.p, X.p);
-      prof_end();
-    }
     // P[m,u,l2,a2] = sum_{l,p} X[m,l,p,a2] W[l,p,l2,u]           (bmps_impl.h:807 + :815-817)
+    DTen<T> X = alloc_ten(m * l, p, a2);
     DTen<T> P = alloc_ten(m, u, l2, a2);
     {
-      TGemmDesc g;
+      TGemmDesc gx, gp;
+      gx.I[1] = m; gx.I[2] = l; gx.sAi[1] = l * a; gx.sAi[2] = a; gx.sCi[1] = l * p * a2; gx.sCi[2] = p * a2;
+      gx.K[2] = a; gx.sAk[2] = 1; gx.sBk[2] = p * a2;
+      gx.J[1] = p; gx.J[2] = a2; gx.sBj[1] = a2; gx.sBj[2] = 1; gx.sCj[1] = a2; gx.sCj[2] = 1;
+      gx.wA = R[i].n; gx.wB = A.n; gx.wC = X.n; gx.nbatch = nw_;
+      gx.dI[1].p = mdyn[i]; gx.dI[1].mul = mmul[i];   // live carry rows
+      gx.dK[2].p = clive[i];            // live part of the bond to the left of A
+      gx.dJ[2].p = clive[i + 1];        // ... and to its right
       // site tensor as the A operand: the lanes of a tile run along (m, a2), contiguous in X and in P
-      g.I[1] = l2; g.I[2] = u; g.sAi[1] = st[lr]; g.sAi[2] = st[lu]; g.sCi[1] = a2; g.sCi[2] = l2 * a2;
-      g.K[1] = l; g.K[2] = p; g.sAk[1] = st[ll]; g.sAk[2] = st[lp]; g.sBk[1] = p * a2; g.sBk[2] = a2;
-      g.J[1] = m; g.J[2] = a2; g.sBj[1] = l * p * a2; g.sBj[2] = 1; g.sCj[1] = u * l2 * a2; g.sCj[2] = 1;
-      g.wB = X.n; g.wC = P.n; g.nbatch = nw_;
-      g.dJ[1].p = mdyn[i]; g.dJ[1].mul = mmul[i];
-      g.dJ[2].p = clive[i + 1];
-      const double fl = 2.0 * nw_ * (double)(m * a2) * (double)(l * p) * (double)(l2 * u);
-      prof_begin(PROF_CONTRACT, fl, fl);
-      launch_site_gemm_a(g, cfg_site(r, c), 1, X.p, P.p);
+      gp.I[1] = l2; gp.I[2] = u; gp.sAi[1] = st[lr]; gp.sAi[2] = st[lu]; gp.sCi[1] = a2; gp.sCi[2] = l2 * a2;
+      gp.K[1] = l; gp.K[2] = p; gp.sAk[1] = st[ll]; gp.sAk[2] = st[lp]; gp.sBk[1] = p * a2; gp.sBk[2] = a2;
+      gp.J[1] = m; gp.J[2] = a2; gp.sBj[1] = l * p * a2; gp.sBj[2] = 1; gp.sCj[1] = u * l2 * a2; gp.sCj[2] = 1;
+      gp.wB = X.n; gp.wC = P.n; gp.nbatch = nw_;
+      gp.dJ[1].p = mdyn[i]; gp.dJ[1].mul = mmul[i];
+      gp.dJ[2].p = clive[i + 1];
+      const double flx = 2.0 * nw_ * (double)(m * l) * a * (double)(p * a2);
+      const double flp = 2.0 * nw_ * (double)(m * a2) * (double)(l * p) * (double)(l2 * u);
+      int *chain_flag = nullptr;
+      if constexpr (sizeof(T) == 4) {
+        static const bool no_chain = getenv("PEPSGPU_NO_CHAIN") != nullptr;
+        if (!no_chain) {
+          // both contractions in one launch, X stays in LDS; walkers whose live X does not fit are flagged and take the
+          // two separate launches below
+          chain_flag = (int *)arena_.alloc(sizeof(int) * nw_);
+          TGemmDesc g2 = gp;
+          const SiteSel ss = cfg_site(r, c);
+          g2.selA = ss.sel; g2.selA_mul = slot_; g2.selA_inc = ss.inc; g2.seldivA = 1; g2.wA = 0;
+          TGemmChainMap mp;
+          mp.mapK[1] = 2; mp.mapK[2] = 4;      // K2 = (l, p): l = I1[2], p = J1[1]
+          mp.mapJ[1] = 1; mp.mapJ[2] = 5;      // J2 = (m, a2): m = I1[1], a2 = J1[2]
+          prof_begin(PROF_CONTRACT, flx + flp, flx + flp);
+          const bool ok = tgemm_chain_launch(stream_, gx, g2, mp, (const float *)R[i].p, (const float *)A.p,
+                                             (const float *)site_base(r, c), (float *)P.p, chain_flag);
+          prof_end();
+          if (!ok) { arena_.free(chain_flag); chain_flag = nullptr; }
+        }
+      }
+      gx.batch_flag = chain_flag; gp.batch_flag = chain_flag;
+      prof_begin(PROF_CONTRACT, chain_flag ? 0.0 : flx, chain_flag ? 0.0 : flx);
+      tgemm_launch<T, T, T, T>(stream_, gx, R[i].p, A.p, X.p);
       prof_end();
+      prof_begin(PROF_CONTRACT, chain_flag ? 0.0 : flp, chain_flag ? 0.0 : flp);
+      launch_site_gemm_a(gp, cfg_site(r, c), 1, X.p, P.p);
+      prof_end();
+      if (chain_flag) arena_.free(chain_flag);
     }
     free_ten(X);
     const int rows = m * u, cols = l2 * a2;
@@ -289,34 +308,53 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     const int k2 = Y.d[2];
     PG_REQUIRE(Y.d[0] == l2 && Y.d[1] == a2 && p == dd[lp], 3, "MultiplyMPO: bond dimension mismatch (backward)");
     // Z1[a,p,l2,k2] = sum_{a2} A[a,p,a2] Y[l2,a2,k2]
-    DTen<T> Z1 = alloc_ten(a, p, l2, k2);
-    {
-      TGemmDesc g;
-      g.I[2] = a * p; g.sAi[2] = a2; g.sCi[2] = l2 * k2;
-      g.K[2] = a2; g.sAk[2] = 1; g.sBk[2] = k2;
-      g.J[1] = l2; g.J[2] = k2; g.sBj[1] = a2 * k2; g.sBj[2] = 1; g.sCj[1] = k2; g.sCj[2] = 1;
-      g.wA = A.n; g.wB = Y.n; g.wC = Z1.n; g.nbatch = nw_;
-      g.dynI = clive[i]; g.dynI_mul = p;      // live bonds: a (rows of A), a2 (contracted), k2 (new bond to the right)
-      g.dK[2].p = clive[i + 1];
-      g.dJ[2].p = kn[i + 1];
-      prof_begin(PROF_CONTRACT, 0.0, 2.0 * nw_ * (double)(a * p) * a2 * (double)(l2 * k2));
-      tgemm_launch<T, T, T, T>(stream_, g, A.p, Y.p, Z1.p);
-      prof_end();
-    }
     // Tt[l,a,u,k2] = sum_{p,l2} Z1[a,p,l2,k2] W[l,p,l2,u]
+    DTen<T> Z1 = alloc_ten(a, p, l2, k2);
     DTen<T> Tt = alloc_ten(l, a, u, k2);
     {
-      TGemmDesc g;
+      TGemmDesc gz, gt;
+      gz.I[1] = a; gz.I[2] = p; gz.sAi[1] = p * a2; gz.sAi[2] = a2; gz.sCi[1] = p * l2 * k2; gz.sCi[2] = l2 * k2;
+      gz.K[2] = a2; gz.sAk[2] = 1; gz.sBk[2] = k2;
+      gz.J[1] = l2; gz.J[2] = k2; gz.sBj[1] = a2 * k2; gz.sBj[2] = 1; gz.sCj[1] = k2; gz.sCj[2] = 1;
+      gz.wA = A.n; gz.wB = Y.n; gz.wC = Z1.n; gz.nbatch = nw_;
+      gz.dI[1].p = clive[i];                  // live bonds: a (rows of A), a2 (contracted), k2 (new bond to the right)
+      gz.dK[2].p = clive[i + 1];
+      gz.dJ[2].p = kn[i + 1];
       // site tensor as the A operand: the lanes of a tile run along (a, k2), contiguous in Z1 and in Tt
-      g.I[1] = l; g.I[2] = u; g.sAi[1] = st[ll]; g.sAi[2] = st[lu]; g.sCi[1] = a * u * k2; g.sCi[2] = k2;
-      g.K[1] = p; g.K[2] = l2; g.sAk[1] = st[lp]; g.sAk[2] = st[lr]; g.sBk[1] = l2 * k2; g.sBk[2] = k2;
-      g.J[1] = a; g.J[2] = k2; g.sBj[1] = p * l2 * k2; g.sBj[2] = 1; g.sCj[1] = u * k2; g.sCj[2] = 1;
-      g.wB = Z1.n; g.wC = Tt.n; g.nbatch = nw_;
-      g.dJ[1].p = clive[i];
-      g.dJ[2].p = kn[i + 1]; g.dJ[2].mask = (i == 0);   // i == 0: Tt becomes the (persistent, zero padded) first tensor
-      prof_begin(PROF_CONTRACT, 0.0, 2.0 * nw_ * (double)(a * k2) * (double)(p * l2) * (double)(l * u));
-      launch_site_gemm_a(g, cfg_site(r, c), 1, Z1.p, Tt.p);
+      gt.I[1] = l; gt.I[2] = u; gt.sAi[1] = st[ll]; gt.sAi[2] = st[lu]; gt.sCi[1] = a * u * k2; gt.sCi[2] = k2;
+      gt.K[1] = p; gt.K[2] = l2; gt.sAk[1] = st[lp]; gt.sAk[2] = st[lr]; gt.sBk[1] = l2 * k2; gt.sBk[2] = k2;
+      gt.J[1] = a; gt.J[2] = k2; gt.sBj[1] = p * l2 * k2; gt.sBj[2] = 1; gt.sCj[1] = u * k2; gt.sCj[2] = 1;
+      gt.wB = Z1.n; gt.wC = Tt.n; gt.nbatch = nw_;
+      gt.dJ[1].p = clive[i];
+      gt.dJ[2].p = kn[i + 1]; gt.dJ[2].mask = (i == 0);   // i == 0: Tt becomes the (persistent, zero padded) first tensor
+      const double flz = 2.0 * nw_ * (double)(a * p) * a2 * (double)(l2 * k2);
+      const double flt = 2.0 * nw_ * (double)(a * k2) * (double)(p * l2) * (double)(l * u);
+      int *chain_flag = nullptr;
+      if constexpr (sizeof(T) == 4) {
+        static const bool no_chain = getenv("PEPSGPU_NO_CHAIN") != nullptr;
+        if (!no_chain) {   // Z1 stays in LDS (see the forward pair)
+          chain_flag = (int *)arena_.alloc(sizeof(int) * nw_);
+          TGemmDesc g2 = gt;
+          const SiteSel ss = cfg_site(r, c);
+          g2.selA = ss.sel; g2.selA_mul = slot_; g2.selA_inc = ss.inc; g2.seldivA = 1; g2.wA = 0;
+          TGemmChainMap mp;
+          mp.mapK[1] = 2; mp.mapK[2] = 4;      // K2 = (p, l2): p = I1[2], l2 = J1[1]
+          mp.mapJ[1] = 1; mp.mapJ[2] = 5;      // J2 = (a, k2): a = I1[1], k2 = J1[2]
+          prof_begin(PROF_CONTRACT, 0.0, flz + flt);
+          const bool ok = tgemm_chain_launch(stream_, gz, g2, mp, (const float *)A.p, (const float *)Y.p,
+                                             (const float *)site_base(r, c), (float *)Tt.p, chain_flag);
+          prof_end();
+          if (!ok) { arena_.free(chain_flag); chain_flag = nullptr; }
+        }
+      }
+      gz.batch_flag = chain_flag; gt.batch_flag = chain_flag;
+      prof_begin(PROF_CONTRACT, 0.0, chain_flag ? 0.0 : flz);
+      tgemm_launch<T, T, T, T>(stream_, gz, A.p, Y.p, Z1.p);
       prof_end();
+      prof_begin(PROF_CONTRACT, 0.0, chain_flag ? 0.0 : flt);
+      launch_site_gemm_a(gt, cfg_site(r, c), 1, Z1.p, Tt.p);
+      prof_end();
+      if (chain_flag) arena_.free(chain_flag);
     }
     free_ten(Z1);
     free_ten(Y);

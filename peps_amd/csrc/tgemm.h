@@ -304,43 +304,34 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__res
 // memory (AVEC / BVEC) fetches its four values as one 16-byte load: the cost of these kernels is
 // the number of memory requests, not bytes (each lane addresses its own row).
 // f32 in / f32 out.  Same descriptor semantics as tgemm_kernel (dynK is not supported here).
-template <bool AVEC, bool BVEC>
-__global__ __launch_bounds__(256, 6) void tgemm_direct_kernel(TGemmDesc d, const float *__restrict__ Ag,
-                                                           const float *__restrict__ Bg, float *__restrict__ Cg) {
-  __shared__ int offCi_s[4][32];
-  const int b = blockIdx.z;
-  if (d.batch_flag && d.batch_flag[b] >= 0) return;
-  const int K2s = d.K[2];                     // static extent of k2 (vector loads stay inside it)
+// per-walker live extents replace / mask the static dims of a descriptor (block-uniform)
+__device__ __forceinline__ void tg_apply_extents(TGemmDesc &d, const int b) {
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     if (d.dI[s].p) { const int e = min(d.I[s], d.dI[s].p[b] * d.dI[s].mul); if (d.dI[s].mask) d.Imask[s] = e; else d.I[s] = e; }
     if (d.dJ[s].p) { const int e = min(d.J[s], d.dJ[s].p[b] * d.dJ[s].mul); if (d.dJ[s].mask) d.Jmask[s] = e; else d.J[s] = e; }
     if (d.dK[s].p) d.K[s] = min(d.K[s], d.dK[s].p[b] * d.dK[s].mul);
   }
-  int Itot = d.Itot();
-  const int Jtot = d.Jtot();
-  if (d.dynI) Itot = min(Itot, d.dynI[b] * d.dynI_mul);
-  const int nti = (Itot + 31) >> 5, ntj = (Jtot + 31) >> 5, ntiles = nti * ntj;
-  if (ntiles == 0) return;
-  if (d.flopc && threadIdx.x == 0 && blockIdx.x == 0 && b % d.flop_stride == 0)
-  {
-    atomicAdd(d.flopc, 2ull * d.flop_stride * Itot * Jtot * d.Ktot());
-    if (d.bytec) atomicAdd(d.bytec, 4ull * d.flop_stride * ((unsigned long long)Itot * d.Ktot() + (unsigned long long)d.Ktot() * Jtot + (unsigned long long)Itot * Jtot));
-  }
+}
+
+// The tile loop of the direct kernel: the block's four waves walk the 32x32 tiles of C = A B for one batch entry.
+// d has its live extents applied; A, B, C are the entry's operand bases (generic pointers: an operand may live in LDS,
+// which is how tgemm_chain_kernel keeps the intermediate of two chained contractions on chip).  K2s = static extent of
+// k2 (vector loads stay inside it).
+template <bool AVEC, bool BVEC>
+__device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *__restrict__ A, const float *__restrict__ B,
+                                               float *__restrict__ C, const int Itot, const int Jtot, const int K2s,
+                                               int (*offCi_s)[32], const int tile0, const int tile_step) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  long baseA = (long)(b / d.bdivA) * d.wA, baseB = (long)(b / d.bdivB) * d.wB;
-  if (d.selA) baseA += (long)d.selA[(long)(b / d.seldivA) * d.selA_inc] * d.selA_mul;
-  if (d.selB) baseB += (long)d.selB[(long)(b / d.seldivB) * d.selB_inc] * d.selB_mul;
-  const float *A = Ag + baseA;
-  const float *B = Bg + baseB;
-  float *C = Cg + (long)(b / d.bdivC) * d.wC;
+  const int nti = (Itot + 31) >> 5, ntj = (Jtot + 31) >> 5, ntiles = nti * ntj;
+  (void)nti;
   const float alpha = (float)d.alpha;
   const int half = lane >> 5, l31 = lane & 31;
   const int K2 = d.K[2], K01 = d.K[0] * d.K[1];
   const int nr8 = (K2 + 7) >> 3, nrounds = K01 * nr8;
   const int sA2 = d.sAk[2], sB2 = d.sBk[2];
 
-  for (int t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
+  for (int t = tile0 + wave; t < ntiles; t += tile_step) {
     const int ti = t / ntj, tj = t - ti * ntj;
     const int i = ti * 32 + l31, j = tj * 32 + l31;
     const int oa = (i < Itot) ? tg_off3m(i, d.I, d.sAi, d.Imask) : -1;
@@ -401,6 +392,99 @@ __global__ __launch_bounds__(256, 6) void tgemm_direct_kernel(TGemmDesc d, const
   }
 }
 
+template <bool AVEC, bool BVEC>
+__global__ __launch_bounds__(256, 6) void tgemm_direct_kernel(TGemmDesc d, const float *__restrict__ Ag,
+                                                           const float *__restrict__ Bg, float *__restrict__ Cg) {
+  __shared__ int offCi_s[4][32];
+  const int b = blockIdx.z;
+  if (d.batch_flag && d.batch_flag[b] >= 0) return;
+  const int K2s = d.K[2];                     // static extent of k2 (vector loads stay inside it)
+  tg_apply_extents(d, b);
+  int Itot = d.Itot();
+  const int Jtot = d.Jtot();
+  if (d.dynI) Itot = min(Itot, d.dynI[b] * d.dynI_mul);
+  if (Itot <= 0 || Jtot <= 0) return;
+  if (d.flopc && threadIdx.x == 0 && blockIdx.x == 0 && b % d.flop_stride == 0)
+  {
+    atomicAdd(d.flopc, 2ull * d.flop_stride * Itot * Jtot * d.Ktot());
+    if (d.bytec) atomicAdd(d.bytec, 4ull * d.flop_stride * ((unsigned long long)Itot * d.Ktot() + (unsigned long long)d.Ktot() * Jtot + (unsigned long long)Itot * Jtot));
+  }
+  long baseA = (long)(b / d.bdivA) * d.wA, baseB = (long)(b / d.bdivB) * d.wB;
+  if (d.selA) baseA += (long)d.selA[(long)(b / d.seldivA) * d.selA_inc] * d.selA_mul;
+  if (d.selB) baseB += (long)d.selB[(long)(b / d.seldivB) * d.selB_inc] * d.selB_mul;
+  tg_direct_body<AVEC, BVEC>(d, Ag + baseA, Bg + baseB, Cg + (long)(b / d.bdivC) * d.wC, Itot, Jtot, K2s, offCi_s,
+                             blockIdx.x * 4, gridDim.x * 4);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two chained contractions with the intermediate resident in LDS:  C1 = A1 B1,  C2 = A2 C1'
+// (C1' = C1 read with its sub-indices regrouped into the K and J of the second contraction).  One block per batch
+// entry; the live extents of both descriptors are applied first, C1 is laid out compactly (row-major over its live
+// I1 and J1 sub-indices) in the block's LDS, written by the tile loop of stage 1 and read as the B operand of stage 2.
+// mapK / mapJ name, for every K / J sub-index of the second contraction, the sub-index of C1 it runs over:
+// 0..2 = I1[s], 3..5 = J1[s], -1 = unused (extent 1).  An entry whose live C1 exceeds the LDS buffer writes
+// flag[b] = -1 and returns (the caller runs the two contractions separately for those entries), else flag[b] = 0.
+constexpr int TG_CHAIN_LDS_FLOATS = 10240;   // 40 KB: three blocks per CU
+struct TGemmChainMap { int mapK[3] = {-1, -1, -1}, mapJ[3] = {-1, -1, -1}; };
+
+template <bool AVEC1, bool BVEC1, bool AVEC2>
+__global__ __launch_bounds__(256, 3) void tgemm_chain_kernel(TGemmDesc d1, TGemmDesc d2, TGemmChainMap mp, const float *__restrict__ A1g,
+                                                            const float *__restrict__ B1g, const float *__restrict__ A2g,
+                                                            float *__restrict__ C2g, int *__restrict__ flag) {
+  __shared__ int offCi_s[4][32];
+  __shared__ float s_mid[TG_CHAIN_LDS_FLOATS];
+  const int b = blockIdx.x;
+  const int K2s1 = d1.K[2], K2s2 = d2.K[2];
+  tg_apply_extents(d1, b);
+  tg_apply_extents(d2, b);
+  int I1 = d1.Itot();
+  const int J1 = d1.Jtot();
+  if (d1.dynI) I1 = min(I1, d1.dynI[b] * d1.dynI_mul);
+  int I2 = d2.Itot();
+  const int J2 = d2.Jtot();
+  if (d2.dynI) I2 = min(I2, d2.dynI[b] * d2.dynI_mul);
+  // compact LDS layout of C1 over the live dims of (I1 sub-indices, J1 sub-indices); a flattened dynI limit of stage 1
+  // only leaves the rows beyond it unwritten (they are not read: stage 2 runs over the same live extents)
+  int lds_stride[6];
+  {
+    int st = 1;
+    for (int s = 2; s >= 0; --s) { lds_stride[3 + s] = st; st *= d1.J[s]; }
+    for (int s = 2; s >= 0; --s) { lds_stride[s] = st; st *= d1.I[s]; }
+    if (st > TG_CHAIN_LDS_FLOATS) {
+      if (threadIdx.x == 0) flag[b] = -1;
+      return;
+    }
+  }
+  if (threadIdx.x == 0) flag[b] = 0;
+  if (I1 <= 0 || J1 <= 0 || I2 <= 0 || J2 <= 0) return;
+  if (d1.flopc && threadIdx.x == 0 && b % d1.flop_stride == 0) {
+    atomicAdd(d1.flopc, 2ull * d1.flop_stride * ((unsigned long long)I1 * J1 * d1.Ktot() + (unsigned long long)I2 * J2 * d2.Ktot()));
+    if (d1.bytec)
+      atomicAdd(d1.bytec, 4ull * d1.flop_stride * ((unsigned long long)I1 * d1.Ktot() + (unsigned long long)d1.Ktot() * J1 +
+                                                    (unsigned long long)I2 * d2.Ktot() + (unsigned long long)I2 * J2));
+  }
+#pragma unroll
+  for (int s = 0; s < 3; ++s) { d1.sCi[s] = lds_stride[s]; d1.sCj[s] = lds_stride[3 + s]; }
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    d2.sBk[s] = mp.mapK[s] >= 0 ? lds_stride[mp.mapK[s]] : 0;
+    d2.sBj[s] = mp.mapJ[s] >= 0 ? lds_stride[mp.mapJ[s]] : 0;
+  }
+  long baseA1 = (long)b * d1.wA, baseB1 = (long)b * d1.wB, baseA2 = (long)b * d2.wA;
+  if (d1.selA) baseA1 += (long)d1.selA[(long)(b / d1.seldivA) * d1.selA_inc] * d1.selA_mul;
+  if (d1.selB) baseB1 += (long)d1.selB[(long)(b / d1.seldivB) * d1.selB_inc] * d1.selB_mul;
+  if (d2.selA) baseA2 += (long)d2.selA[(long)(b / d2.seldivA) * d2.selA_inc] * d2.selA_mul;
+  d1.accumulate = 0;
+  tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1, B1g + baseB1, s_mid, I1, J1, K2s1, offCi_s, 0, 4);
+  __syncthreads();
+  tg_direct_body<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC, I2, J2, K2s2, offCi_s, 0, 4);
+}
+
+// stage 2 of the chain must read exactly what stage 1 wrote: same live extents on the shared sub-indices (the caller
+// sets the same TgDyn on both), no masks on them.  Returns false when the static shapes rule the chain out.
+inline bool tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemmDesc &d2_in, const TGemmChainMap &mp,
+                               const float *A1, const float *B1, const float *A2, float *C2, int *flag);
+
 bool tgemm_use_mfma();
 
 // device counter the launches of the current profiling bracket add their contracted flops to (engine.h prof_begin)
@@ -451,6 +535,36 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
   else
     hipLaunchKernelGGL((tgemm_kernel<TA, TB, TC, TAcc, false>), grid, dim3(256), 0, s, d, A, B, C);
   PG_CHECK_HIP(hipGetLastError());
+}
+
+inline bool tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemmDesc &d2_in, const TGemmChainMap &mp,
+                               const float *A1, const float *B1, const float *A2, float *C2, int *flag) {
+  if (!tgemm_use_mfma() || d1_in.dynK || d2_in.dynK || d1_in.nbatch != d2_in.nbatch || d1_in.nbatch <= 0) return false;
+  if (d1_in.bdivA != 1 || d1_in.bdivB != 1 || d2_in.bdivA != 1 || d2_in.bdivC != 1) return false;
+  TGemmDesc d1 = d1_in, d2 = d2_in;
+  d1.flopc = tg_flop_counter; d1.bytec = tg_byte_counter;
+  d1.flop_stride = d1.nbatch >= 256 ? 64 : 1;
+  static const bool no_vec = getenv("PEPSGPU_TGEMM_NOVEC") != nullptr;
+  auto al4 = [](long v) { return (v & 3) == 0; };
+  const bool avec1 = !no_vec && d1.sAk[2] == 1 && al4(d1.K[2]) && al4(d1.sAi[0]) && al4(d1.sAi[1]) && al4(d1.sAi[2]) &&
+                     al4(d1.sAk[0]) && al4(d1.sAk[1]) && al4(d1.wA) && al4(d1.selA_mul) && (((uintptr_t)A1) & 15) == 0;
+  const bool bvec1 = !no_vec && d1.sBk[2] == 1 && al4(d1.K[2]) && al4(d1.sBj[0]) && al4(d1.sBj[1]) && al4(d1.sBj[2]) &&
+                     al4(d1.sBk[0]) && al4(d1.sBk[1]) && al4(d1.wB) && al4(d1.selB_mul) && (((uintptr_t)B1) & 15) == 0;
+  const bool avec2 = !no_vec && d2.sAk[2] == 1 && al4(d2.K[2]) && al4(d2.sAi[0]) && al4(d2.sAi[1]) && al4(d2.sAi[2]) &&
+                     al4(d2.sAk[0]) && al4(d2.sAk[1]) && al4(d2.wA) && al4(d2.selA_mul) && (((uintptr_t)A2) & 15) == 0;
+  const dim3 g(d1.nbatch), blk(256);
+#define PG_CHAIN(a1, b1, a2) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag)
+  if (avec1 && bvec1 && avec2) PG_CHAIN(true, true, true);
+  else if (avec1 && bvec1) PG_CHAIN(true, true, false);
+  else if (avec1 && avec2) PG_CHAIN(true, false, true);
+  else if (avec1) PG_CHAIN(true, false, false);
+  else if (bvec1 && avec2) PG_CHAIN(false, true, true);
+  else if (bvec1) PG_CHAIN(false, true, false);
+  else if (avec2) PG_CHAIN(false, false, true);
+  else PG_CHAIN(false, false, false);
+#undef PG_CHAIN
+  PG_CHECK_HIP(hipGetLastError());
+  return true;
 }
 
 }  // namespace pepsgpu
