@@ -424,16 +424,19 @@ __global__ __launch_bounds__(256, 6) void tgemm_direct_kernel(TGemmDesc d, const
 // mapK / mapJ name, for every K / J sub-index of the second contraction, the sub-index of C1 it runs over:
 // 0..2 = I1[s], 3..5 = J1[s], -1 = unused (extent 1).  An entry whose live C1 exceeds the LDS buffer writes
 // flag[b] = -1 and returns (the caller runs the two contractions separately for those entries), else flag[b] = 0.
-constexpr int TG_CHAIN_LDS_FLOATS = 10240;   // 40 KB: three blocks per CU
+constexpr int TG_CHAIN_LDS_FLOATS = 6144;    // 24 KB: six blocks per CU (measured: 10240 / 3 blocks 437 ms, 8192 / 4 387, 7168 / 5 363, 6144 / 6 350, 4864 / 8 352 per two steps)
+// (a second chain pass with a 48 KB buffer for the declined entries was measured slower than the two separate launches
+// they fall back to: 416 ms vs 350 ms -- three blocks per CU hide too little latency)
 struct TGemmChainMap { int mapK[3] = {-1, -1, -1}, mapJ[3] = {-1, -1, -1}; };
 
-template <bool AVEC1, bool BVEC1, bool AVEC2>
-__global__ __launch_bounds__(256, 3) void tgemm_chain_kernel(TGemmDesc d1, TGemmDesc d2, TGemmChainMap mp, const float *__restrict__ A1g,
+template <bool AVEC1, bool BVEC1, bool AVEC2, int LDSF, int MINB>
+__global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TGemmDesc d2, TGemmChainMap mp, const float *__restrict__ A1g,
                                                             const float *__restrict__ B1g, const float *__restrict__ A2g,
-                                                            float *__restrict__ C2g, int *__restrict__ flag) {
+                                                            float *__restrict__ C2g, int *__restrict__ flag, int only_flagged) {
   __shared__ int offCi_s[4][32];
-  __shared__ float s_mid[TG_CHAIN_LDS_FLOATS];
+  __shared__ float s_mid[LDSF];
   const int b = blockIdx.x;
+  if (only_flagged && flag[b] >= 0) return;     // second launch (larger buffer, fewer blocks per CU): declined entries only
   const int K2s1 = d1.K[2], K2s2 = d2.K[2];
   tg_apply_extents(d1, b);
   tg_apply_extents(d2, b);
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(256, 3) void tgemm_chain_kernel(TGemmDesc d1, TGemm
     int st = 1;
     for (int s = 2; s >= 0; --s) { lds_stride[3 + s] = st; st *= d1.J[s]; }
     for (int s = 2; s >= 0; --s) { lds_stride[s] = st; st *= d1.I[s]; }
-    if (st > TG_CHAIN_LDS_FLOATS) {
+    if (st > LDSF) {
       if (threadIdx.x == 0) flag[b] = -1;
       return;
     }
@@ -519,7 +522,8 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
       // with per-walker live extents the tile count is a few: one block (four waves) walks them; extra blocks
       // would only pay the chain of dependent loads (extents, selector, offsets) and exit
       static const int gx_dyn = getenv("PEPSGPU_TGD_GX") ? atoi(getenv("PEPSGPU_TGD_GX")) : 1;
-      const dim3 gd(any_dyn ? std::min(gx_dyn, std::max(1, tiles / 4)) : (tiles >= 64 ? 4 : tiles >= 16 ? 2 : 1), 1, d.nbatch);
+      const dim3 gd(any_dyn ? std::min(gx_dyn, std::max(1, tiles / 4)) : (tiles >= 64 ? 4 : tiles >= 16 ? 2 : 1), 1,
+                    d.nbatch);
       const float *Af = (const float *)A, *Bf = (const float *)B;
       float *Cf = (float *)C;
       if (avec && bvec) hipLaunchKernelGGL((tgemm_direct_kernel<true, true>), gd, dim3(256), 0, s, d, Af, Bf, Cf);
@@ -553,7 +557,10 @@ inline bool tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGem
   const bool avec2 = !no_vec && d2.sAk[2] == 1 && al4(d2.K[2]) && al4(d2.sAi[0]) && al4(d2.sAi[1]) && al4(d2.sAi[2]) &&
                      al4(d2.sAk[0]) && al4(d2.sAk[1]) && al4(d2.wA) && al4(d2.selA_mul) && (((uintptr_t)A2) & 15) == 0;
   const dim3 g(d1.nbatch), blk(256);
-#define PG_CHAIN(a1, b1, a2) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag)
+#define PG_CHAIN(a1, b1, a2)                                                                                                   \
+  do {                                                                                                                         \
+    hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 6>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0); \
+  } while (0)
   if (avec1 && bvec1 && avec2) PG_CHAIN(true, true, true);
   else if (avec1 && bvec1) PG_CHAIN(true, true, false);
   else if (avec1 && avec2) PG_CHAIN(true, false, true);
