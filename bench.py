@@ -68,9 +68,9 @@ def cpu_baseline(sitps, cfgs, chi, budget_s):
     return len(amps) / dt, len(amps), np.array(amps), threads
 
 
-PMC_KERNEL = {"contract": "tgemm_direct_kernel", "gram_f64": "tgemm_kernel<float, float, double, double",
-              "cholesky": "gram_chol_lowrank_kernel", "jacobi": "jacobi_rows_small_kernel",
-              "jacobi_edge": "jacobi_rows_small_kernel"}
+PMC_KERNEL = {"contract": ("tgemm_direct_kernel", "tgemm_chain_kernel"), "gram_f64": ("tgemm_kernel<float, float, double, double",),
+              "cholesky": ("gram_chol_lowrank_kernel",), "jacobi": ("jacobi_rows_small_kernel",),
+              "jacobi_edge": ("jacobi_rows_tiny2_kernel", "jacobi_rows_small_kernel")}
 
 
 def pmc_traffic_bytes(category, args, nw):
@@ -89,7 +89,7 @@ def pmc_traffic_bytes(category, args, nw):
             return None
         tot, launches = 0.0, 0
         for line in open(path):
-            if PMC_KERNEL[category] in line and cnt in line:      # every template variant of the kernel
+            if any(k in line for k in PMC_KERNEL[category]) and cnt in line:      # every kernel / template variant of the category
                 f = line.split()
                 tot += float(f[-2]); launches += int(f[-3])
         if launches == 0:
