@@ -355,7 +355,14 @@ static void diag_jacobi_t(void *M, int m, int len, int nbatch, int k, void *Vt, 
                        40, dsw, (const int *)nullptr, 1, 0);
   } else if (sizeof(T) == 4 && force_global == 3) {   // one-wave-per-walker kernel (up to 32 x 256)
     PG_REQUIRE(m <= JR_SMALL_ROWS && len <= 256, 1, "small Jacobi handles up to 32 x 256");
-    std::vector<int> hm(nbatch, m);
+    // per-walker live row count = rows up to the last non-zero one (mixed counts inside a launch, as in the absorption)
+    std::vector<int> hm(nbatch, 0);
+    for (int b = 0; b < nbatch; ++b)
+      for (int r = 0; r < m; ++r) {
+        const T *row = (const T *)M + ((size_t)b * m + r) * len;
+        for (int c = 0; c < len; ++c)
+          if (row[c] != T(0)) { hm[b] = r + 1; break; }
+      }
     int *dm;
     PG_CHECK_HIP(hipMalloc(&dm, nbatch * sizeof(int)));
     PG_CHECK_HIP(hipMemcpy(dm, hm.data(), nbatch * sizeof(int), hipMemcpyHostToDevice));

@@ -870,7 +870,12 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const T *__restrict__ 
   __syncthreads();
   double fro2 = 0.0;
   for (int q = 0; q < m; ++q) fro2 += s_norm[q] * s_norm[q];
-  const double nfloor = NOISE_C * (double)Eps<T>::v * sqrt(fro2);
+  // Liveness floor = TWICE the floor below which the Jacobi kernels freeze a row (NOISE_C eps |M|_F): a frozen row was
+  // never orthogonalised against the others, and a row whose norm sits at the common threshold could be frozen there and
+  // still counted as live here (the two kernels sum the norm differently).  Normalised, such a row -- mostly rounding
+  // residue of the dominant direction -- enters Vt with an O(1) overlap with it and corrupts the projector (measured:
+  // one walker in 8192 off by 1.4e-3 on one contraction route).  With the factor of two every live row was rotated.
+  const double nfloor = 2.0 * NOISE_C * (double)Eps<T>::v * sqrt(fro2);
   if (trunc_err > 0.0 || err_out) {
     // qlten::SVD(trunc_err, Dmin, Dmax) as bmps_impl.h:235-238 calls it: singular values go from the
     // smallest while more than Dmax are kept, or more than Dmin and the discarded weight / total weight

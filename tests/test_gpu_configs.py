@@ -104,3 +104,17 @@ def test_c3_c4_heisenberg_amplitude_and_energy(name, nref):
         if name == "C3" and w == 0:
             e, _, _ = model.CalEnergyAndHoles(s, comp, False)
             assert abs(en[w] / e - 1) < 1e-5
+
+
+def test_psi_consistency_over_all_routes_large_batch_c4():
+    """psi of the same configuration from every row and column route of CalEnergyAndHoles agrees for each of 2048
+    synthetic C4 walkers (f32; the batch size fixes the static bond sizes of the failing case): a discrete liveness decision at the noise floor once put one walker in 8192 off by
+    1.4e-3 on one route (walker 533 of this batch) while every small parity test stayed green."""
+    from peps_amd import hostapi
+    L, D, chi, model = synthetic.CONFIGS["C4"]
+    sitps = synthetic.make_sitps(L, D)
+    flat = synthetic.sitps_to_flat(sitps, D)
+    cfgs = synthetic.make_configs(L, 2048, "heisenberg")
+    a, e, h, psi = hostapi.energy_and_holes(flat, cfgs, chi, "xxz", (1.0, 1.0, 0.0), False, 0)
+    spread = np.max(np.abs(psi / np.median(psi, axis=0) - 1), axis=0)
+    assert np.max(spread) < 5e-5, (int(np.argmax(spread)), float(np.max(spread)))

@@ -280,3 +280,31 @@ print("OK")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root,
                        env=dict(os.environ, PEPSGPU_QR_FACTOR="1", PYTHONPATH=root))
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_rows_at_the_noise_floor_never_enter_vt_unorthogonalised():
+    """A row whose norm sits at the Jacobi freeze threshold (NOISE_C eps |M|_F) is not rotated; select_rows must not
+    keep it as a live direction (normalised it would overlap the dominant one).  4096 matrices with a residue-like row
+    whose norm lies within a few 1e-6 (relative) of the threshold, i.e. inside the window where the two kernels'
+    differently summed norms disagree; whatever rows come back non-zero must be orthonormal."""
+    from peps_amd import capi
+    rng = np.random.default_rng(11)
+    ln, m, nb = 96, 16, 4096
+    eps = 5.9604645e-8
+    M = np.zeros((nb, m, ln), dtype=np.float32)
+    for b in range(nb):
+        big = rng.standard_normal(ln)
+        M[b, 0] = big
+        for r in range(1, 6):
+            M[b, r] = 1e-4 * np.linalg.norm(big) * rng.standard_normal(ln) / np.sqrt(ln)
+        noise = 0.6 * big / np.linalg.norm(big) + 0.8 * rng.standard_normal(ln) / np.sqrt(ln)   # mostly along the dominant row
+        fro = np.sqrt(np.sum(M[b].astype(np.float64) ** 2))
+        M[b, 6] = (1.0 + 6e-6 * (rng.random() - 0.5)) * 8 * eps * fro * noise / np.linalg.norm(noise)
+    out, Vt, S, sw = capi.diag_jacobi(capi.F32, M, 8, force_global=3)
+    worst = 0.0
+    for b in range(nb):
+        v = Vt[b].astype(np.float64)
+        live = np.linalg.norm(v, axis=1) > 0
+        g = v[live] @ v[live].T
+        worst = max(worst, float(np.max(np.abs(g - np.eye(int(live.sum()))))))
+    assert worst < 2e-5, worst
