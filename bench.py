@@ -256,6 +256,21 @@ def main():
                                 "jacobi_sweeps_max": st["jacobi_sweeps_max"]}
         del dctx
         os.environ.pop("PEPSGPU_DEBUG_SWEEPS", None)
+        # size-independent property at the full size, outside the timed region: the amplitude of the same configuration
+        # contracted row-wise (DOWN stack, trace at row 0) and column-wise (RIGHT stack, trace at column 0) must agree
+        nrc = min(nw, 2048)
+        rctx = capi.Context(L, L, D, 2, chi, dtype=dt, device=local_rank, max_walkers=nrc)
+        rctx.state_upload(synthetic.sitps_to_flat(sitps, D, np.float64))
+        rctx.set_configs(batches[0][:nrc])
+        a_row = rctx.evaluate_amplitude()
+        rctx.set_configs(batches[0][:nrc])
+        rctx.grow_bmps_for_col(0)
+        rctx.init_bten(capi.UP, 0)
+        rctx.grow_full_bten(capi.DOWN, 0, 2, True)
+        a_col = rctx.trace(0, 0, capi.VERTICAL)
+        out["route_consistency"] = {"max_rel_spread_row_vs_column_contraction": float(np.max(np.abs(a_col / a_row - 1))),
+                                    "n": int(nrc)}
+        del rctx
         if world == 1 and not args.no_cpu_baseline:
             ncheck = 8
             rate, n, amps, threads = cpu_baseline(sitps, batches[0][:ncheck], chi, args.cpu_seconds)
