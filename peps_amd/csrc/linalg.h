@@ -298,29 +298,32 @@ __global__ __launch_bounds__(256) void chol_lowrank_kernel(const double *__restr
 // NT threads per walker: with a live inner extent the data columns are packed onto the first threads,
 // so the 128-thread variant (twice as many walkers resident) takes every walker with <= 128 data
 // columns and leaves mlive_out[b] = -2 for the 256-thread variant (retry_only = 1) otherwise.
-template <typename T, int KCAP, int NT>
-__global__ __launch_bounds__(NT, 2) void gram_chol_lowrank_kernel(const T *__restrict__ Pg, long wP, int n,
+template <typename T, int KCAP, int NT, int MINW = 2, int RCAP = CH_LR_CAP>
+__global__ __launch_bounds__(NT, MINW) void gram_chol_lowrank_kernel(const T *__restrict__ Pg, long wP, int n,
                                                                 const int *__restrict__ kdyn, int kdyn_mul, int kmax,
                                                                 T *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
                                                                 int inner = 1, const int *__restrict__ inner_live = nullptr,
-                                                                int retry_only = 0, int max_pass = 1) {
+                                                                int retry_only = 0, int max_pass = 1, int small_first = 0) {
   // More live rows than a thread holds (moderate rank): the rows of P are folded in over several passes INSIDE the
-  // kernel -- pass 0 factors the first KCAP rows, every later pass factors [running factor (<= CH_LR_CAP rows, still
-  // in registers) ; next KCAP - CH_LR_CAP rows of P]; up to max_pass passes, beyond that the walker is declined.
+  // kernel -- pass 0 factors the first KCAP rows, every later pass factors [running factor (<= RCAP rows, still
+  // in registers) ; next KCAP - RCAP rows of P]; up to max_pass passes, beyond that the walker is declined.
   constexpr int NWV = NT / 64;
-  if (retry_only && mlive_out[blockIdx.x] != -2) return;
+  // retry_only: 0 every walker; 1 those a narrower launch left at -2 (more data columns than its threads); 2 those the
+  // short launch (small_first: fewer rows and a smaller rank cap per thread, more walkers resident) handed on at -4
+  if (retry_only == 1 && mlive_out[blockIdx.x] != -2) return;
+  if (retry_only == 2 && mlive_out[blockIdx.x] != -4) return;
   // columns are (outer, inner) with `inner` fastest; inner_live[b] (optional) = live extent of the
   // inner index (live bond of the boundary MPS): columns beyond hold no data and are never read
   __shared__ __attribute__((aligned(16))) T s_pf[KCAP];   // column f of P
-  __shared__ double s_rf[CH_LR_CAP];     // column f of the factor
+  __shared__ double s_rf[RCAP];     // column f of the factor
   __shared__ double s_piv;               // remaining diagonal of the pivot column = G[f,f] - sum_j R[j,f]^2
-  __shared__ double s_red[2][NWV], s_nrm[CH_LR_CAP], s_part[2 * NWV];
+  __shared__ double s_red[2][NWV], s_nrm[RCAP], s_part[2 * NWV];
   __shared__ int s_first[2][NWV];
-  __shared__ short s_pos[CH_LR_CAP];
+  __shared__ short s_pos[RCAP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Ktot = kdyn ? min(kmax, kdyn[blockIdx.x] * kdyn_mul) : kmax;
-  if (Ktot > KCAP + (max_pass - 1) * (KCAP - CH_LR_CAP)) {     // too many rows: decline
-    if (tid == 0) mlive_out[blockIdx.x] = -1;
+  if (Ktot > KCAP + (max_pass - 1) * (KCAP - RCAP)) {     // too many rows: decline
+    if (tid == 0) mlive_out[blockIdx.x] = small_first ? -4 : -1;
     return;
   }
   const T *P = Pg + (long)blockIdx.x * wP;
@@ -336,27 +339,27 @@ __global__ __launch_bounds__(NT, 2) void gram_chol_lowrank_kernel(const T *__res
   const int r = col_ok ? (tid / ilive) * inner + (tid % ilive) : n;
   const double eT = NOISE_C * (double)Eps<T>::v;
   T pc[KCAP];
-  double rc[CH_LR_CAP];                   // own column of the factor (f64: pivots near the threshold amplify its rounding)
+  double rc[RCAP];                   // own column of the factor (f64: pivots near the threshold amplify its rounding)
 #pragma unroll
-  for (int j = 0; j < CH_LR_CAP; ++j) rc[j] = 0.0;
+  for (int j = 0; j < RCAP; ++j) rc[j] = 0.0;
   int nl = 0, step = 0, k0 = 0, pass = 0;
   double maxd = 0.0;
 #pragma unroll 1
   for (;; ++pass) {
     const int nfr = nl;                                                    // rows of the running factor
-    const int npr = min(Ktot - k0, KCAP - (pass > 0 ? CH_LR_CAP : 0));    // rows of P taken in this pass
+    const int npr = min(Ktot - k0, KCAP - (pass > 0 ? RCAP : 0));    // rows of P taken in this pass
     const int K = nfr + npr;
     double d = 0.0;
 #pragma unroll
     for (int k = 0; k < KCAP; ++k) {
       T x = T(0);
-      if (k < CH_LR_CAP && k < nfr) x = T(rc[k < CH_LR_CAP ? k : 0]);
+      if (k < RCAP && k < nfr) x = T(rc[k < RCAP ? k : 0]);
       else if (k < K && col_ok) x = P[(long)(k0 + k - nfr) * n + r];
       pc[k] = x;
       d += (double)pc[k] * (double)pc[k];
     }
 #pragma unroll
-    for (int j = 0; j < CH_LR_CAP; ++j) rc[j] = 0.0;
+    for (int j = 0; j < RCAP; ++j) rc[j] = 0.0;
     double md = d;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
@@ -386,15 +389,15 @@ __global__ __launch_bounds__(NT, 2) void gram_chol_lowrank_kernel(const T *__res
 #pragma unroll
       for (int q = 1; q < NWV; ++q) f = min(f, s_first[step & 1][q]);
       if (f == 0x7fffffff || nl >= K) { ++step; break; }   // the rank cannot exceed the K rows: later pivots are rounding noise
-      if (nl == CH_LR_CAP) {                 // rank above the cap: the blocked path redoes this walker
-        if (tid == 0) mlive_out[blockIdx.x] = -1;
+      if (nl == RCAP) {                 // rank above the cap: the blocked path (or the full-size launch) redoes this walker
+        if (tid == 0) mlive_out[blockIdx.x] = small_first ? -4 : -1;
         return;
       }
       if (r == f) {                          // the owner of the pivot column publishes it
 #pragma unroll
         for (int k = 0; k < KCAP; ++k) s_pf[k] = pc[k];
 #pragma unroll
-        for (int j = 0; j < CH_LR_CAP; ++j) s_rf[j] = rc[j];
+        for (int j = 0; j < RCAP; ++j) s_rf[j] = rc[j];
         s_piv = d;                           // the owner's running diagonal IS the pivot: no thread recomputes it
       }
       __syncthreads();
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(NT, 2) void gram_chol_lowrank_kernel(const T *__res
         }
       }
 #pragma unroll
-      for (int jb = 0; jb < CH_LR_CAP; jb += 8) {   // nl is block-uniform: whole chunks beyond it are skipped
+      for (int jb = 0; jb < RCAP; jb += 8) {   // nl is block-uniform: whole chunks beyond it are skipped
         if (jb < nl) {
 #pragma unroll
           for (int j = jb; j < jb + 8; ++j) {
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(NT, 2) void gram_chol_lowrank_kernel(const T *__res
       }
       const double v = (r >= f && r < n) ? g / sqrt(piv) : 0.0;
 #pragma unroll
-      for (int jb = 0; jb < CH_LR_CAP; jb += 8) {
+      for (int jb = 0; jb < RCAP; jb += 8) {
         if ((nl & ~7) == jb) {
 #pragma unroll
           for (int j = jb; j < jb + 8; ++j) rc[j] = (j == nl) ? v : rc[j];
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(NT, 2) void gram_chol_lowrank_kernel(const T *__res
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < CH_LR_CAP; ++j) {
+  for (int j = 0; j < RCAP; ++j) {
     if (j < nl) {
       const int pos = s_pos[j];
       if (pos >= 0 && r < n) Rout[(long)pos * n + r] = T(rc[j] * sc);
@@ -654,12 +657,20 @@ inline void launch_gram_chol_lowrank(hipStream_t s, int nbatch, const T *P, long
     PG_CHECK_HIP(hipGetLastError());
     return;
   }
+  // Short columns and a small rank cap first (fewer registers: three waves per SIMD instead of two), then the walkers
+  // it handed on (-4) with the full KCAP / CH_LR_CAP, then the ones with more data columns than 128 threads (-2).
+  constexpr int KCAP_S = sizeof(T) == 4 ? 64 : 32;
+  static const bool short_on = getenv("PEPSGPU_NO_SHORT_FUSED") == nullptr;   // measured: cholesky category 272 -> 215 ms per two steps
+  const bool short_first = narrow && short_on && kdyn != nullptr;
+  if (short_first)
+    hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP_S, 128, 3, 16>), dim3(nbatch), dim3(128), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
+                       R, wR, mlive, inner, inner_live, 0, std::max(max_pass, 2), 1);
   if (narrow)
     hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP, 128>), dim3(nbatch), dim3(128), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
-                       R, wR, mlive, inner, inner_live, 0, max_pass);
+                       R, wR, mlive, inner, inner_live, short_first ? 2 : 0, max_pass, 0);
   if (!narrow || n > 128)
     hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP, 256>), dim3(nbatch), dim3(256), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
-                       R, wR, mlive, inner, inner_live, narrow ? 1 : 0, max_pass);
+                       R, wR, mlive, inner, inner_live, narrow ? 1 : 0, max_pass, 0);
   PG_CHECK_HIP(hipGetLastError());
 }
 
