@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time budget of the CPU (oracle) baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-route-check", action="store_true", help="skip the row- vs column-contraction diagnostic (profiling runs)")
     ap.add_argument("--noise", type=float, default=0.1,
                     help="relative noise of the synthetic site tensors (SURVEY 8d: 0.1; 1.0 = full-rank stress case)")
     args = ap.parse_args()
@@ -258,19 +259,20 @@ def main():
         os.environ.pop("PEPSGPU_DEBUG_SWEEPS", None)
         # size-independent property at the full size, outside the timed region: the amplitude of the same configuration
         # contracted row-wise (DOWN stack, trace at row 0) and column-wise (RIGHT stack, trace at column 0) must agree
-        nrc = min(nw, 2048)
-        rctx = capi.Context(L, L, D, 2, chi, dtype=dt, device=local_rank, max_walkers=nrc)
-        rctx.state_upload(synthetic.sitps_to_flat(sitps, D, np.float64))
-        rctx.set_configs(batches[0][:nrc])
-        a_row = rctx.evaluate_amplitude()
-        rctx.set_configs(batches[0][:nrc])
-        rctx.grow_bmps_for_col(0)
-        rctx.init_bten(capi.UP, 0)
-        rctx.grow_full_bten(capi.DOWN, 0, 2, True)
-        a_col = rctx.trace(0, 0, capi.VERTICAL)
-        out["route_consistency"] = {"max_rel_spread_row_vs_column_contraction": float(np.max(np.abs(a_col / a_row - 1))),
-                                    "n": int(nrc)}
-        del rctx
+        nrc = 0 if args.no_route_check else min(nw, 2048)
+        rctx = None if nrc == 0 else capi.Context(L, L, D, 2, chi, dtype=dt, device=local_rank, max_walkers=nrc)
+        if rctx is not None:
+            rctx.state_upload(synthetic.sitps_to_flat(sitps, D, np.float64))
+            rctx.set_configs(batches[0][:nrc])
+            a_row = rctx.evaluate_amplitude()
+            rctx.set_configs(batches[0][:nrc])
+            rctx.grow_bmps_for_col(0)
+            rctx.init_bten(capi.UP, 0)
+            rctx.grow_full_bten(capi.DOWN, 0, 2, True)
+            a_col = rctx.trace(0, 0, capi.VERTICAL)
+            out["route_consistency"] = {"max_rel_spread_row_vs_column_contraction": float(np.max(np.abs(a_col / a_row - 1))),
+                                        "n": int(nrc)}
+            del rctx
         if world == 1 and not args.no_cpu_baseline:
             ncheck = 8
             rate, n, amps, threads = cpu_baseline(sitps, batches[0][:ncheck], chi, args.cpu_seconds)

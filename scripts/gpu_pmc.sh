@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
 run_pass() {
   tag=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc -o $tag -- python3 bench.py --walkers ${NW:-512} --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc/bench_$tag.log 2>&1
+  rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc -o $tag -- python3 bench.py --walkers ${NW:-512} --steps 1 --warmup 1 --no-cpu-baseline --no-route-check > gpurun_out/pmc/bench_$tag.log 2>&1
   echo "pass $tag rc=$?"
   f=gpurun_out/pmc/${tag}_counter_collection.csv
   if [ -f "$f" ]; then python scripts/pmc_summary.py $f > gpurun_out/pmc/${tag}_summary.txt; head -14 gpurun_out/pmc/${tag}_summary.txt; rm -f $f; fi
