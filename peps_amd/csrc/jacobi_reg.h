@@ -61,6 +61,7 @@ __device__ __forceinline__ float jr_dot(const JrRow &x, const JrRow &y) {
 __device__ __forceinline__ int jr_apply(JrRow &x, JrRow &y, float &nx, float &ny, const float g, const float tol2,
                                         const float floor2) {
   const bool go = g * g > tol2 * nx * ny && nx > floor2 && ny > floor2;
+  if (!__any(go)) return 0;     // wave-uniform: no lane rotates this pair (late sweeps: most pairs) -- the kernels are VALU bound
   const float zeta = (ny - nx) * __builtin_amdgcn_rcpf(2.f * g);
   const float az = fabsf(zeta);
   float t = copysignf(__builtin_amdgcn_rcpf(az + __builtin_amdgcn_sqrtf(fmaf(az, az, 1.f))), zeta);
@@ -553,7 +554,8 @@ __global__ __launch_bounds__(256, 3) void jacobi_rows_tiny2_kernel(float *__rest
   for (; sweep < max_sweeps; ++sweep) {
     if (sweep) {
 #pragma unroll
-      for (int i = 0; i < JR_BR; ++i) na[i] = jr_allsum32(jr_dot(a[i], a[i]));
+      for (int i = 0; i < JR_BR; ++i)
+        if (i < mm_max) na[i] = jr_allsum32(jr_dot(a[i], a[i]));     // rows beyond both walkers' counts are zero
     }
     int rot;
     if (mm_max <= 6) rot = jr_intra32<6>(a, na, tol2, floor2);
