@@ -316,9 +316,22 @@ static void diag_gram_chol_t(const void *P, int K, int n, int nbatch, void *Rout
   PG_CHECK_HIP(hipMemcpy(dP, P, (size_t)K * n * nbatch * sizeof(T), hipMemcpyHostToDevice));
   PG_CHECK_HIP(hipMemset(dR, 0, (size_t)n * n * nbatch * sizeof(T)));
   const int npass = K > KCAP ? 4 : 1;          // the multi-pass use of the absorption when a pass cannot hold all rows
-  launch_gram_chol_lowrank<T, KCAP>(0, nbatch, (const T *)dP, (long)K * n, n, (const int *)nullptr, 1, K, dR, (long)n * n, dml, 1,
+  // per-walker live row count = rows up to the last non-zero one, as the absorption passes it (mixed counts in one launch:
+  // the short first pass, the walkers it hands on and the multi-pass path all run)
+  std::vector<int> hk(nbatch, 0);
+  for (int b = 0; b < nbatch; ++b)
+    for (int r = 0; r < K; ++r) {
+      const T *row = (const T *)P + ((size_t)b * K + r) * n;
+      for (int c = 0; c < n; ++c)
+        if (row[c] != T(0)) { hk[b] = r + 1; break; }
+    }
+  int *dk;
+  PG_CHECK_HIP(hipMalloc(&dk, nbatch * sizeof(int)));
+  PG_CHECK_HIP(hipMemcpy(dk, hk.data(), nbatch * sizeof(int), hipMemcpyHostToDevice));
+  launch_gram_chol_lowrank<T, KCAP>(0, nbatch, (const T *)dP, (long)K * n, n, (const int *)dk, 1, K, dR, (long)n * n, dml, 1,
                                     (const int *)nullptr, npass);
   PG_CHECK_HIP(hipDeviceSynchronize());
+  (void)hipFree(dk);
   PG_CHECK_HIP(hipDeviceSynchronize());
   PG_CHECK_HIP(hipMemcpy(Rout, dR, (size_t)n * n * nbatch * sizeof(T), hipMemcpyDeviceToHost));
   PG_CHECK_HIP(hipMemcpy(mlive, dml, nbatch * sizeof(int), hipMemcpyDeviceToHost));

@@ -308,3 +308,32 @@ def test_rows_at_the_noise_floor_never_enter_vt_unorthogonalised():
         g = v[live] @ v[live].T
         worst = max(worst, float(np.max(np.abs(g - np.eye(int(live.sum()))))))
     assert worst < 2e-5, worst
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_gram_free_factor_mixed_rows_and_ranks_in_one_launch(dt):
+    """One launch with walkers of different live row counts and ranks: the short first pass (<= 64 rows, rank <= 16 per
+    thread), the walkers it hands on to the full kernel (more rows or rank 17..32) and the multi-pass path (more rows than
+    a pass holds) all take part; R^T R = P^T P / max diag and the rank for every walker."""
+    from peps_amd import capi
+    rng = np.random.default_rng(21)
+    t = np.float32 if dt == "f32" else np.float64
+    d = capi.F32 if dt == "f32" else capi.F64
+    K, n = 160, 96
+    cases = [(40, 6), (64, 12), (64, 20), (90, 10), (128, 14), (160, 9), (30, 30), (100, 28)] * 4
+    P = np.zeros((len(cases), K, n), dtype=t)
+    for b, (k, r) in enumerate(cases):
+        P[b, :k] = (rng.standard_normal((k, r)) @ rng.standard_normal((r, n))).astype(t)
+    R, ml = capi.diag_gram_chol(d, P)
+    tol = 5e-6 if dt == "f32" else 1e-12
+    for b, (k, r) in enumerate(cases):
+        if ml[b] < 0:                      # declined to the Gram path: only beyond the capacity of the full kernel
+            cap = 96 + 3 * 64 if dt == "f32" else 48 + 3 * 16        # KCAP + (passes - 1) (KCAP - 32)
+            assert r > 32 or k > cap, (b, k, r, ml[b])
+            continue
+        assert r <= ml[b] <= r + 2, (b, k, r, ml[b])
+        G = P[b].astype(np.float64).T @ P[b].astype(np.float64)
+        Rb = R[b][:ml[b]].astype(np.float64)
+        assert np.max(np.abs(Rb.T @ Rb - G / np.max(np.diag(G)))) < tol * 10, (b, k, r)
+    if dt == "f32":
+        assert np.all(ml >= 0)
