@@ -9,8 +9,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepshost.so")
 
 SYMBOLS = ["pepshost_last_error", "pepshost_mc_sweeps", "pepshost_energy_and_holes", "pepshost_exact_sum_partial",
-           "pepshost_mc_energy_grad_partial",
-           "pepshost_exact_sum_finish", "pepshost_load_sitps"]
+           "pepshost_mc_energy_grad_partial", "pepshost_exact_sum_finish", "pepshost_load_sitps", "pepshost_dump_sitps",
+           "pepshost_dump_configuration", "pepshost_load_configuration", "pepshost_fermion_energy",
+           "pepshost_fermion_exact_sum_partial", "pepshost_fermion_mc_sweeps", "pepshost_measure",
+           "pepshost_set_truncate_params"]
 
 _lib = None
 
