@@ -213,6 +213,9 @@ int pepsgpu_diag_chol(int dtype_out, const double *G, int n, int nbatch, void *R
  * kernel for the walkers whose rank exceeds its cap; mlive_out[b] = rows of R_out[b] that exist */
 /* the Gram-free low-rank kernel alone: P = [nbatch][K][n] (dtype), R^T R = P^T P; mlive_out[b] = -1 where
  * it declines (K or the rank above its caps) and the Gram + Cholesky pair has to run */
+/* forward contraction pair of an absorption through the LDS-chained kernel (tgemm_chain_kernel); see capi.hip */
+int pepsgpu_diag_tgemm_chain(const int *dims7, const int32_t *live3_per_entry, int nbatch, const float *R, const float *A,
+                             const float *W, float *P_out, int32_t *flags_out);
 int pepsgpu_diag_gram_chol(int dtype, const void *P, int K, int n, int nbatch, void *R_out, int32_t *mlive_out);
 int pepsgpu_diag_chol_adaptive(int dtype_out, const double *G, int n, int nbatch, void *R_out, int32_t *mlive_out);
 int pepsgpu_diag_jacobi(int dtype, void *M, int m, int len, int nbatch, int k, void *Vt_out, void *S_out,

@@ -35,7 +35,7 @@ SYMBOLS = [
     "pepsgpu_sr_cg_solve", "pepsgpu_sr_gram", "pepsgpu_sr_weighted_sum", "pepsgpu_sr_copy_samples",
     "pepsgpu_update_local", "pepsgpu_erase_envs_after_update", "pepsgpu_evaluate_amplitude",
     "pepsgpu_walker_flags", "pepsgpu_sync", "pepsgpu_stats", "pepsgpu_profile_enable", "pepsgpu_profile_read",
-    "pepsgpu_diag_tgemm", "pepsgpu_diag_chol", "pepsgpu_diag_chol_adaptive", "pepsgpu_diag_gram_chol", "pepsgpu_diag_jacobi", "pepsgpu_version",
+    "pepsgpu_diag_tgemm", "pepsgpu_diag_tgemm_chain", "pepsgpu_diag_chol", "pepsgpu_diag_chol_adaptive", "pepsgpu_diag_gram_chol", "pepsgpu_diag_jacobi", "pepsgpu_version",
 ]
 
 
@@ -395,6 +395,27 @@ def diag_tgemm(dtype_in, dtype_out, I, J, K, sAi, sAk, sBk, sBj, sCi, sCj, A, B,
     if rc != 0:
         raise RuntimeError("diag_tgemm failed: %s" % lib().pepsgpu_last_error(None).decode())
     return Cc
+
+
+def diag_tgemm_chain(R, A, W, live):
+    """P[b][m,u,l2,a2] = sum R[b][m,l,a] A[b][a,p,a2] W[b][l,p,l2,u] over the live extents live[b] = (m, a, a2), through
+    tgemm_chain_kernel with the descriptors of Engine::absorb_impl; returns (P, flags)."""
+    R = np.ascontiguousarray(R, dtype=np.float32); A = np.ascontiguousarray(A, dtype=np.float32)
+    W = np.ascontiguousarray(W, dtype=np.float32)
+    nb, m, l, a = R.shape
+    _, _, p, a2 = A.shape
+    l2, u = W.shape[3], W.shape[4]
+    dims = np.array([m, l, a, p, a2, l2, u], dtype=np.int32)
+    lv = np.ascontiguousarray(live, dtype=np.int32)
+    P = np.zeros((nb, m, u, l2, a2), dtype=np.float32)
+    fl = np.zeros(nb, dtype=np.int32)
+    f = lib().pepsgpu_diag_tgemm_chain
+    f.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    rc = f(_ip(dims), _ip(lv), nb, R.ctypes.data_as(C.c_void_p), A.ctypes.data_as(C.c_void_p), W.ctypes.data_as(C.c_void_p),
+           P.ctypes.data_as(C.c_void_p), _ip(fl))
+    if rc != 0:
+        raise RuntimeError("diag_tgemm_chain failed: %s" % lib().pepsgpu_last_error(None).decode())
+    return P, fl
 
 
 def diag_chol(dtype_out, G):

@@ -255,6 +255,54 @@ extern "C" int pepsgpu_diag_tgemm(int dtype_in, int dtype_out, const int *di, in
   });
 }
 
+// Forward pair of an absorption through tgemm_chain_kernel exactly as Engine::absorb_impl sets it up:
+//   X[m,l,p,a2] = sum_a R[m,l,a] A[a,p,a2]  (kept in LDS),   P[m,u,l2,a2] = sum_{l,p} W[l,p,l2,u] X[m,l,p,a2]
+// dims = {m, l, a, p, a2, l2, u} (static), live = per entry {m_live, a_live, a2_live}; W is one tensor per entry.
+// flags_out[b] = 0 done, -1 the live X exceeds the LDS buffer (P[b] untouched).
+extern "C" int pepsgpu_diag_tgemm_chain(const int *dims, const int32_t *live, int nbatch, const float *R, const float *A,
+                                        const float *W, float *P_out, int32_t *flags_out) {
+  return guarded(nullptr, [&]() {
+    const int m = dims[0], l = dims[1], a = dims[2], p = dims[3], a2 = dims[4], l2 = dims[5], u = dims[6];
+    const size_t nR = (size_t)m * l * a, nA = (size_t)a * p * a2, nW = (size_t)l * p * l2 * u, nP = (size_t)m * u * l2 * a2;
+    float *dR, *dA, *dW, *dP;
+    int *dl, *dflag;
+    PG_CHECK_HIP(hipMalloc(&dR, nR * nbatch * sizeof(float)));
+    PG_CHECK_HIP(hipMalloc(&dA, nA * nbatch * sizeof(float)));
+    PG_CHECK_HIP(hipMalloc(&dW, nW * nbatch * sizeof(float)));
+    PG_CHECK_HIP(hipMalloc(&dP, nP * nbatch * sizeof(float)));
+    PG_CHECK_HIP(hipMalloc(&dl, 3 * (size_t)nbatch * sizeof(int)));
+    PG_CHECK_HIP(hipMalloc(&dflag, nbatch * sizeof(int)));
+    PG_CHECK_HIP(hipMemcpy(dR, R, nR * nbatch * sizeof(float), hipMemcpyHostToDevice));
+    PG_CHECK_HIP(hipMemcpy(dA, A, nA * nbatch * sizeof(float), hipMemcpyHostToDevice));
+    PG_CHECK_HIP(hipMemcpy(dW, W, nW * nbatch * sizeof(float), hipMemcpyHostToDevice));
+    PG_CHECK_HIP(hipMemset(dP, 0, nP * nbatch * sizeof(float)));
+    std::vector<int> hl(3 * (size_t)nbatch);      // [m_live | a_live | a2_live] as three arrays
+    for (int b = 0; b < nbatch; ++b)
+      for (int q = 0; q < 3; ++q) hl[(size_t)q * nbatch + b] = live[3 * b + q];
+    PG_CHECK_HIP(hipMemcpy(dl, hl.data(), hl.size() * sizeof(int), hipMemcpyHostToDevice));
+    const int *ml = dl, *al = dl + nbatch, *a2l = dl + 2 * nbatch;
+    TGemmDesc gx, gp;
+    gx.I[1] = m; gx.I[2] = l; gx.sAi[1] = l * a; gx.sAi[2] = a; gx.sCi[1] = l * p * a2; gx.sCi[2] = p * a2;
+    gx.K[2] = a; gx.sAk[2] = 1; gx.sBk[2] = p * a2;
+    gx.J[1] = p; gx.J[2] = a2; gx.sBj[1] = a2; gx.sBj[2] = 1; gx.sCj[1] = a2; gx.sCj[2] = 1;
+    gx.wA = (long)nR; gx.wB = (long)nA; gx.wC = 0; gx.nbatch = nbatch;
+    gx.dI[1].p = ml; gx.dK[2].p = al; gx.dJ[2].p = a2l;
+    gp.I[1] = l2; gp.I[2] = u; gp.sAi[1] = u; gp.sAi[2] = 1; gp.sCi[1] = a2; gp.sCi[2] = l2 * a2;
+    gp.K[1] = l; gp.K[2] = p; gp.sAk[1] = p * l2 * u; gp.sAk[2] = l2 * u;
+    gp.J[1] = m; gp.J[2] = a2; gp.sCj[1] = u * l2 * a2; gp.sCj[2] = 1;
+    gp.wA = (long)nW; gp.wC = (long)nP; gp.nbatch = nbatch;
+    gp.dJ[1].p = ml; gp.dJ[2].p = a2l;
+    TGemmChainMap mp;
+    mp.mapK[1] = 2; mp.mapK[2] = 4;
+    mp.mapJ[1] = 1; mp.mapJ[2] = 5;
+    PG_REQUIRE(tgemm_chain_launch(0, gx, gp, mp, dR, dA, dW, dP, dflag), 1, "chain launch refused");
+    PG_CHECK_HIP(hipDeviceSynchronize());
+    PG_CHECK_HIP(hipMemcpy(P_out, dP, nP * nbatch * sizeof(float), hipMemcpyDeviceToHost));
+    PG_CHECK_HIP(hipMemcpy(flags_out, dflag, nbatch * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(dR); (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dP); (void)hipFree(dl); (void)hipFree(dflag);
+  });
+}
+
 template <typename T>
 static void diag_chol_t(const double *G, int n, int nbatch, void *Rout) {
   double *dG;
