@@ -118,3 +118,23 @@ def test_psi_consistency_over_all_routes_large_batch_c4():
     a, e, h, psi = hostapi.energy_and_holes(flat, cfgs, chi, "xxz", (1.0, 1.0, 0.0), False, 0)
     spread = np.max(np.abs(psi / np.median(psi, axis=0) - 1), axis=0)
     assert np.max(spread) < 5e-5, (int(np.argmax(spread)), float(np.max(spread)))
+
+
+def test_c4_f32_against_f64_device_mode_large_batch():
+    """Full-size check no oracle sample can afford: the f32 path against the f64 device mode (itself pinned to the oracle at
+    1e-9 on the small cases) for 2048 C4 configurations -- every walker within the 1e-5 amplitude tolerance."""
+    from peps_amd import capi
+    L, D, chi, model = synthetic.CONFIGS["C4"]
+    sitps = synthetic.make_sitps(L, D)
+    flat = synthetic.sitps_to_flat(sitps, D)
+    cfgs = synthetic.make_configs(L, 2048, "heisenberg")
+    amps = {}
+    for dt in (capi.F32, capi.F64):
+        ctx = capi.Context(L, L, D, 2, chi, dtype=dt, max_walkers=len(cfgs))
+        ctx.state_upload(flat)
+        ctx.set_configs(cfgs)
+        amps[dt] = ctx.evaluate_amplitude()
+        assert np.all(ctx.walker_flags() == 0)
+        ctx.close()
+    rel = np.abs(amps[capi.F32] / amps[capi.F64] - 1)
+    assert np.max(rel) < 1e-5, (int(np.argmax(rel)), float(np.max(rel)))
