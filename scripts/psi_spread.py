@@ -5,13 +5,16 @@ import numpy as np
 sys.path.insert(0, '.')
 from peps_amd import capi, hostapi, synthetic
 nw = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-L, D, chi, model = synthetic.CONFIGS["C4"]
-sitps = synthetic.make_sitps(L, D)
+wl = sys.argv[2] if len(sys.argv) > 2 else "C4"
+noise = float(sys.argv[3]) if len(sys.argv) > 3 else 0.1
+L, D, chi, model = synthetic.CONFIGS[wl]
+sitps = synthetic.make_sitps(L, D, noise=noise)
 ctx = capi.Context(L, L, D, 2, chi, dtype=capi.F32, max_walkers=1)
 ctx.state_upload(synthetic.sitps_to_flat(sitps, D)); ctx.set_configs(synthetic.checkerboard(L)[None])
 sitps = synthetic.rescale_sitps(sitps, float(ctx.evaluate_amplitude()[0])); del ctx
 flat = synthetic.sitps_to_flat(sitps, D)
 cfgs = synthetic.make_configs(L, nw, "heisenberg")
+print("workload", wl, "noise", noise)
 a, e, h, psi = hostapi.energy_and_holes(flat, cfgs, chi, "xxz", (1.0, 1.0, 0.0), False, 0)
 spread = np.max(np.abs(psi / psi[0] - 1), axis=0)
 w = int(np.argmax(spread))
