@@ -19,6 +19,43 @@ template <typename T> struct Eps;
 template <> struct Eps<float> { static constexpr float v = 5.9604645e-8f; };
 template <> struct Eps<double> { static constexpr double v = 1.1102230246251565e-16; };
 
+// 64-lane all-reductions on the DPP / permlane-swap path (a few cycles of latency per step, no LDS crossbar): the step
+// loops of the factor kernels are chains of dependent reductions, where the ds_bpermute behind __shfl_xor costs most
+template <int CTRL>
+__device__ __forceinline__ int lw_dpp(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ int wave_min_dpp(int v) {
+  v = min(v, lw_dpp<0xB1>(v));     // quad_perm [1,0,3,2]
+  v = min(v, lw_dpp<0x4E>(v));     // quad_perm [2,3,0,1]
+  v = min(v, lw_dpp<0x141>(v));    // row_half_mirror
+  v = min(v, lw_dpp<0x140>(v));    // row_mirror
+  {
+    const auto p = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = min((int)p[0], (int)p[1]);
+  }
+  {
+    const auto p = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    v = min((int)p[0], (int)p[1]);
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += __builtin_bit_cast(float, lw_dpp<0xB1>(__builtin_bit_cast(int, v)));
+  v += __builtin_bit_cast(float, lw_dpp<0x4E>(__builtin_bit_cast(int, v)));
+  v += __builtin_bit_cast(float, lw_dpp<0x141>(__builtin_bit_cast(int, v)));
+  v += __builtin_bit_cast(float, lw_dpp<0x140>(__builtin_bit_cast(int, v)));
+  {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto p = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (unsigned)p[0]) + __builtin_bit_cast(float, (unsigned)p[1]);
+  }
+  {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto p = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (unsigned)p[0]) + __builtin_bit_cast(float, (unsigned)p[1]);
+  }
+  return v;
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
@@ -374,8 +411,7 @@ __global__ __launch_bounds__(NT, MINW) void gram_chol_lowrank_kernel(const T *__
 #pragma unroll 1
     for (;; ++step) {
       int cand = (r < n && r > f && d > thresh) ? r : 0x7fffffff;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+      cand = wave_min_dpp(cand);
       if (lane == 0) s_first[step & 1][wave] = cand;
       __syncthreads();
       // squared norm of the row finished in the previous step (partials written before the barrier)
@@ -441,7 +477,7 @@ __global__ __launch_bounds__(NT, MINW) void gram_chol_lowrank_kernel(const T *__
       }
       const double v2 = v * v;
       if (r > f) d -= v2;
-      const double a = wave_sum(v2);
+      const double a = (double)wave_sum_dpp((float)v2);   // row norm^2 for the compaction floor: f32 is ample
       if (lane == 0) s_part[NWV * (step & 1) + wave] = a;
       ++nl;
     }
