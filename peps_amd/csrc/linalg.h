@@ -56,12 +56,35 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return v;
 }
 
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// the same for f64: both halves of the value travel through the same DPP / swap step
+template <int CTRL>
+__device__ __forceinline__ double lw_dpp_f64(double v) {
+  const int lo = lw_dpp<CTRL>(__double2loint(v)), hi = lw_dpp<CTRL>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += lw_dpp_f64<0xB1>(v);
+  v += lw_dpp_f64<0x4E>(v);
+  v += lw_dpp_f64<0x141>(v);
+  v += lw_dpp_f64<0x140>(v);
+  {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto pl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto ph = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double((int)ph[0], (int)pl[0]) + __hiloint2double((int)ph[1], (int)pl[1]);
+  }
+  {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto pl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto ph = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = __hiloint2double((int)ph[0], (int)pl[0]) + __hiloint2double((int)ph[1], (int)pl[1]);
+  }
   return v;
 }
+
+// sum over the 64 lanes of a wave, result in every lane
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) { return wave_sum_dpp(v); }
 
 // ---------------------------------------------------------------------------------------------
 // In-place upper Cholesky of the symmetric PSD Gram matrix G (n x n, row-major, f64) and rank
