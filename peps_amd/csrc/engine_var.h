@@ -99,20 +99,44 @@ void Engine<T>::ein(const EinView<T> &a, const EinView<T> &b, const EinView<T> &
 // optionally their norms -> S (k per walker)
 template <typename T>
 DTen<T> Engine<T>::svd_rows(DTen<T> &M, int m, int len, int k, double terr, int dmin, T *S) {
-  const size_t need = sizeof(T) * (size_t)m * (len | 1);
+  PG_REQUIRE(m <= 1024, 1, "bond dimension too large for select_rows_kernel");
+  // Rank compression first, as in the absorption: R with R^T R = M^T M from the Gram-free factor (the right singular
+  // vectors and the singular values of R are those of M), then the Jacobi runs on the few live rows of R instead of
+  // the m rows of M.  Walkers the factor declines (rank above its cap) keep their rows of M.
+  static const bool no_compress = getenv("PEPSGPU_NO_VAR_COMPRESS") != nullptr;
+  constexpr int KC = sizeof(T) == 4 ? 96 : 48;
+  DTen<T> Rf;
+  int *ml = nullptr;
+  T *src = M.p;
+  long wsrc = M.n;
+  int msrc = m;
+  if (!no_compress && len <= 256 && m > 16) {
+    msrc = std::max(m, len);
+    Rf = alloc_ten(msrc, len, 1);
+    ml = (int *)arena_.alloc(sizeof(int) * nw_);
+    prof_begin(PROF_CHOL, 0.0, 0.0);
+    launch_gram_chol_lowrank<T, KC>(stream_, nw_, (const T *)M.p, M.n, len, (const int *)nullptr, 1, m, Rf.p, Rf.n, ml, 1,
+                                    (const int *)nullptr, 4);
+    hipLaunchKernelGGL(adopt_rows_flagged_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)M.p, M.n, len,
+                       (const int *)nullptr, 1, m, Rf.p, Rf.n, ml, 1, (const int *)nullptr);
+    PG_CHECK_HIP(hipGetLastError());
+    prof_end();
+    src = Rf.p; wsrc = Rf.n;
+  }
+  const size_t need = sizeof(T) * (size_t)msrc * (len | 1);
   const int use_lds = need <= JACOBI_LDS_MAX;
   if (use_lds) allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), need);
-  PG_REQUIRE(m <= 1024, 1, "bond dimension too large for select_rows_kernel");
   prof_begin(7, 0.0, 0.0);
-  launch_jacobi(M.p, M.n, m, len, use_lds, need, nullptr, 1);
+  launch_jacobi(src, wsrc, msrc, len, use_lds, need, ml, 1);
   prof_end();
   ++n_jacobi_;
   DTen<T> V = alloc_ten(k, len, 1);
   prof_begin(PROF_SELECT, 0.0, 0.0);
-  hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)M.p, M.n, m, len, len, k, V.p, V.n,
-                     S, (long)k, (const int *)nullptr, 1, (int *)nullptr, terr, dmin, (double *)nullptr);
+  hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)src, wsrc, msrc, len, len, k, V.p, V.n,
+                     S, (long)k, (const int *)ml, 1, (int *)nullptr, terr, dmin, (double *)nullptr);
   PG_CHECK_HIP(hipGetLastError());
   prof_end();
+  if (ml) { arena_.free(ml); free_ten(Rf); }
   return V;
 }
 

@@ -18,12 +18,14 @@ for name, scheme in (("svd", 0), ("variational_2site", 1), ("variational_1site",
     ctx = capi.Context(L, L, D, 2, chi, dtype=capi.F32, max_walkers=nw, scheme=scheme, convergence_tol=1e-5, iter_max=iters)
     ctx.state_upload(flat)
     ctx.set_configs(cfg); a = ctx.evaluate_amplitude()
+    ctx.profile_enable(True); ctx.profile_read()
     ctx.sync(); t = time.time()
     ctx.set_configs(cfg); a = ctx.evaluate_amplitude()
     ctx.sync(); dt = time.time() - t
+    prof = ctx.profile_read(); ctx.profile_enable(False)
     if ref is None:
         ref = a
     out[name] = {"amp_per_s": round(nw / dt, 1), "max_rel_dev_from_svd": float(np.max(np.abs(a / ref - 1))),
-                 "zero_flags": int(np.sum(ctx.walker_flags() != 0)), "device_GB": round(ctx.stats().get("device_bytes", 0) / 1e9, 2)}
+                 "zero_flags": int(np.sum(ctx.walker_flags() != 0)), "kernel_ms": {k: round(v["ms"], 1) for k, v in prof.items() if v["launches"]}, "device_GB": round(ctx.stats().get("device_bytes", 0) / 1e9, 2)}
     ctx.close()
 print(json.dumps(out))
