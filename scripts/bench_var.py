@@ -26,6 +26,6 @@ for name, scheme in (("svd", 0), ("variational_2site", 1), ("variational_1site",
     if ref is None:
         ref = a
     out[name] = {"amp_per_s": round(nw / dt, 1), "max_rel_dev_from_svd": float(np.max(np.abs(a / ref - 1))),
-                 "zero_flags": int(np.sum(ctx.walker_flags() != 0)), "kernel_ms": {k: round(v["ms"], 1) for k, v in prof.items() if v["launches"]}, "device_GB": round(ctx.stats().get("device_bytes", 0) / 1e9, 2)}
+                 "zero_flags": int(np.sum(ctx.walker_flags() != 0)), "kernel_ms": {k: round(v["ms"], 1) for k, v in prof.items() if v["launches"]}, "contract_tflops": round(prof["contract"]["exec_flops"] / max(prof["contract"]["ms"], 1e-9) / 1e9, 1), "device_GB": round(ctx.stats().get("device_bytes", 0) / 1e9, 2)}
     ctx.close()
 print(json.dumps(out))
