@@ -16,6 +16,8 @@ Parity pinning (see tests/test_oracle_*.py, tests/golden/):
   K3  PunchHole . site == Trace, EraseEnvsAfterUpdate + regrow (…:407-470)
   K4  2x2 fixtures, exact-summation energies (tests/test_algorithm/test_exact_summation_evaluator.cpp)
   K5  4x4 D=8 Heisenberg fixture, exact-sum energy / checkerboard amplitude
+  K6  ExactSumMeasurerMPI registry of the 2x2 spinless-fermion simple-update state: energy, charge, per-bond
+      energies (tests/test_algorithm/test_exact_summation_measurer.cpp:205-240 -> tests/golden/k4_exact_sum_measurer.json)
 The SVD truncation rule for trunc_err > 0 is "parity unpinned" (no reference binary can be produced
 here).  Fermions: the Z2-graded algebra of oracle/graded.py is pinned on the reference's 2x2
 spinless-fermion known answers (amplitudes, ratios, energies: tests/test_oracle_fermion.py); the

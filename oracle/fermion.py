@@ -120,13 +120,18 @@ class SquareSpinlessFermionOBC:
     def onsite(self, cfg):
         return 0.0
 
-    def CalEnergy(self, fs, cfg, trun_para):
+    def CalEnergy(self, fs, cfg, trun_para, bonds=None):
+        """bonds: optional dict filled with the per-bond energies {"h": (rows, cols-1), "v": (rows-1, cols),
+        "dr"/"ur": (rows-1, cols-1)} that EvaluateObservables reports"""
         from .bmps import LEFT, DOWN, RIGHT, UP, HORIZONTAL, VERTICAL
         cfg = np.asarray(cfg)
         rows, cols, d = fs.rows, fs.cols, fs.d
         occ = np.array(fs.nf)[cfg]
         e = 0.0
         psis = []
+        if bonds is not None:
+            bonds.update(h=np.zeros((rows, cols - 1)), v=np.zeros((rows - 1, cols)), dr=np.zeros((rows - 1, cols - 1)),
+                         ur=np.zeros((rows - 1, cols - 1)))
         # ---- row pass: horizontal bonds (square_nnn_energy_solver.h:116-201)
         comp = fs.component(cfg, ROW, trun_para)
         tn, c = comp.tn, comp.contractor
@@ -139,13 +144,16 @@ class SquareSpinlessFermionOBC:
             for col in range(cols - 1):
                 s1, s2 = (row, col), (row, col + 1)
                 diag, off = self.bond(int(cfg[s1]), int(cfg[s2]), occ[s1], occ[s2])
-                e += diag
+                eb = diag
                 if off != 0.0:
                     psi = c.Trace(tn, s1, HORIZONTAL)
                     new = cfg.copy(); new[s1], new[s2] = cfg[s2], cfg[s1]
                     ne = fs.ext_config(new, ROW)
                     psi_ex = c.ReplaceNNSiteTrace(tn, s1, s2, HORIZONTAL, fs.ext[row][col][ne[s1]], fs.ext[row][col + 1][ne[s2]])
-                    e += off * np.conj(psi_ex / psi)
+                    eb = eb + off * np.conj(psi_ex / psi)
+                e += eb
+                if bonds is not None:
+                    bonds["h"][row, col] = eb
                 c.ShiftBTenWindow(tn, RIGHT)
             if row < rows - 1:
                 c.ShiftBMPSWindow(tn, DOWN)
@@ -160,13 +168,16 @@ class SquareSpinlessFermionOBC:
             for row in range(rows - 1):
                 s1, s2 = (row, col), (row + 1, col)
                 diag, off = self.bond(int(cfg[s1]), int(cfg[s2]), occ[s1], occ[s2])
-                e += diag
+                eb = diag
                 if off != 0.0:
                     psi = c.Trace(tn, s1, VERTICAL)
                     new = cfg.copy(); new[s1], new[s2] = cfg[s2], cfg[s1]
                     ne = fs.ext_config(new, COL)
                     psi_ex = c.ReplaceNNSiteTrace(tn, s1, s2, VERTICAL, fs.ext[row][col][ne[s1]], fs.ext[row + 1][col][ne[s2]])
-                    e += off * np.conj(psi_ex / psi)
+                    eb = eb + off * np.conj(psi_ex / psi)
+                e += eb
+                if bonds is not None:
+                    bonds["v"][row, col] = eb
                 if row < rows - 2:
                     c.ShiftBTenWindow(tn, DOWN)
             if col < cols - 1:
@@ -183,8 +194,19 @@ class SquareSpinlessFermionOBC:
                         ia, ib = sorted((a[0] * cols + a[1], b[0] * cols + b[1]))
                         jw = (-1) ** int(np.sum(flat[ia + 1:ib]))
                         new = cfg.copy(); new[a], new[b] = cfg[b], cfg[a]
-                        e += -self.t2 * jw * np.conj(fs.amplitude(new, trun_para) / psi0)
+                        eb = -self.t2 * jw * np.conj(fs.amplitude(new, trun_para) / psi0)
+                        e += eb
+                        if bonds is not None:
+                            bonds["dr" if a == (row, col) else "ur"][row, col] = eb
         return e + self.onsite(cfg), psis
+
+    def EvaluateObservables(self, fs, cfg, trun_para):
+        """registry of SquareNNNModelMeasurementSolver<SquareSpinlessFermion> (square_nnn_model_measurement_solver.h:33-210,
+        square_spinless_fermion.h:87-115): energy, charge (1 - config: state 0 is occupied), per-bond energies"""
+        bonds = {}
+        e, _ = self.CalEnergy(fs, cfg, trun_para, bonds)
+        return {"energy": np.array([e]), "charge": (1.0 - np.asarray(cfg)).ravel(), "bond_energy_h": bonds["h"].ravel(),
+                "bond_energy_v": bonds["v"].ravel(), "bond_energy_dr": bonds["dr"].ravel(), "bond_energy_ur": bonds["ur"].ravel()}
 
 
 class SquaretJVModelOBC(SquareSpinlessFermionOBC):
@@ -218,3 +240,21 @@ def exact_sum_energy(fs, all_configs, trun_para, model):
         wsum += w
         wesum += w * e
     return wesum / wsum
+
+
+def exact_sum_measure(fs, all_configs, trun_para, model, rank=0, size=1):
+    """ExactSumMeasurerMPI (exact_summation_measurer.h:103-257) for a fermionic state: <O> = sum_S |psi(S)|^2 O_loc(S) /
+    sum_S |psi(S)|^2 over configurations rank, rank + size, ...; returns (weighted sums by key, weight sum) for size > 1
+    and the normalised registry for size == 1."""
+    wsum, acc = 0.0, {}
+    for i in range(rank, len(all_configs), size):
+        cfg = all_configs[i]
+        w = abs(fs.amplitude(cfg, trun_para)) ** 2
+        wsum += w
+        for key, vals in model.EvaluateObservables(fs, cfg, trun_para).items():
+            acc[key] = acc.get(key, 0.0) + w * np.asarray(vals, dtype=np.float64)
+    if size > 1:
+        return acc, wsum
+    if not wsum > 0.0:
+        raise RuntimeError("ExactSumMeasurerMPI: total weight must be positive")
+    return {k: v / wsum for k, v in acc.items()}

@@ -582,3 +582,32 @@ def finish_exact_sum(so, seo, wsum, wesum):
     grad = [[[(seo[r][c][s] - np.conj(energy) * so[r][c][s]) / wsum for s in range(len(so[r][c]))]
              for c in range(len(so[0]))] for r in range(len(so))]
     return energy, grad, wsum
+
+
+def generate_all_binary_configs(lx, ly):
+    """exact_summation_measurer.h:53-72: bit b of the counter i is site (b // lx, b % lx)"""
+    n = lx * ly
+    if n >= 64:
+        raise ValueError("GenerateAllBinaryConfigs: Lx*Ly must be < size_t bit width")
+    return [np.array([(i >> b) & 1 for b in range(n)], dtype=np.int64).reshape(ly, lx) for i in range(1 << n)]
+
+
+def exact_sum_measure(sitps, all_configs, trun_para, make_solver, rank=0, size=1):
+    """ExactSumMeasurerMPI (exact_summation_measurer.h:103-257): weight |psi(S)|^2 times the registry of
+    solver.EvaluateObservables, summed over configurations rank, rank + size, ... (:130-150).  size == 1: the normalised
+    registry (:243-250); else (weighted sums by key, weight sum) of this rank (what MPI_Reduce adds up, :209-235).
+    make_solver() -> a fresh SquareNNNModelMeasurementSolver."""
+    if len(all_configs) == 0:
+        raise ValueError("ExactSumMeasurerMPI: all_configs must not be empty")                    # :113-115
+    wsum, acc = 0.0, {}
+    for i in range(rank, len(all_configs), size):
+        comp = TPSWaveFunctionComponent(sitps, all_configs[i], trun_para)
+        w = abs(comp.amplitude) ** 2
+        wsum += w
+        for key, vals in make_solver().EvaluateObservables(sitps, comp).items():
+            acc[key] = acc.get(key, 0.0) + w * np.asarray(vals, dtype=np.float64).ravel()
+    if size > 1:
+        return acc, wsum
+    if not wsum > 0.0:
+        raise RuntimeError("ExactSumMeasurerMPI: total weight must be positive")
+    return {k: v / wsum for k, v in acc.items()}

@@ -213,16 +213,54 @@ def spinless_fermion_energy(ctx, state, configs, t, V=0.0):
     return nn_energy(ctx, state, configs, bond)
 
 
-def nn_energy(ctx, state, configs, bond_fn):
+def spinless_fermion_observables(ctx, state, configs, t, V=0.0):
+    """Registry of SquareNNNModelMeasurementSolver<SquareSpinlessFermion>::EvaluateObservables
+    (square_nnn_model_measurement_solver.h:33-210, square_spinless_fermion.h:87-115) for a batch of configurations:
+    energy [n, 1], charge [n, rows*cols] (1 - config), bond_energy_h / _v and the (t2 = 0) diagonal bonds.
+    Also returns psi_list [rows + cols][n]."""
+    cfg = np.asarray(configs)
+    n, rows, cols = cfg.shape
+    nf = state.nf
+    def bond(c1, c2):
+        return V * (nf[c1] % 2) * (nf[c2] % 2), np.where(c1 != c2, -t, 0.0)
+    bonds = {}
+    e, psis = nn_energy(ctx, state, cfg, bond, bonds)
+    zero = np.zeros((n, (rows - 1) * (cols - 1)))
+    return {"energy": e[:, None], "charge": (1.0 - cfg).reshape(n, -1), "bond_energy_h": bonds["h"].reshape(n, -1),
+            "bond_energy_v": bonds["v"].reshape(n, -1), "bond_energy_dr": zero, "bond_energy_ur": zero.copy()}, psis
+
+
+def exact_sum_measure(ctx, state, all_configs, t, V=0.0, rank=0, size=1, batch=None):
+    """ExactSumMeasurerMPI (exact_summation_measurer.h:103-257) on the device: configurations rank, rank + size, ... in
+    batches of walkers; returns (weighted sums by key, weight sum) -- sum both over ranks (all-reduce) and divide."""
+    cfgs = np.asarray(all_configs)[rank::size]
+    if len(np.asarray(all_configs)) == 0:
+        raise ValueError("ExactSumMeasurerMPI: all_configs must not be empty")
+    batch = batch or max(len(cfgs), 1)
+    wsum, acc = 0.0, {}
+    for b0 in range(0, len(cfgs), batch):
+        part = cfgs[b0:b0 + batch]
+        obs, psis = spinless_fermion_observables(ctx, state, part, t, V)
+        w = psis[0] ** 2                                   # |psi(S)|^2: the sign decoration drops out
+        wsum += float(w.sum())
+        for key, vals in obs.items():
+            acc[key] = acc.get(key, 0.0) + w @ vals
+    return acc, wsum
+
+
+def nn_energy(ctx, state, configs, bond_fn, bonds=None):
     """Nearest-neighbour local energy of a fermionic model for every configuration of the batch: the traversal of
     square_nnn_energy_solver.h:116-201 / bond_traversal_mixin.h:113-144 with the fermion interface (psi recomputed
     next to psi').  bond_fn(c1, c2) -> (diagonal energy, coefficient of psi(S with the two states exchanged)/psi(S)),
-    arrays over the batch.  Returns (energy [n], psi_list [rows + cols][n])."""
+    arrays over the batch.  Returns (energy [n], psi_list [rows + cols][n]); `bonds` (a dict) receives the per-bond
+    energies "h" [n, rows, cols-1] and "v" [n, rows-1, cols] that the measurement registry reports."""
     from .capi import LEFT, DOWN, RIGHT, UP, HORIZONTAL, VERTICAL
     cfg = np.asarray(configs)
     n, rows, cols = cfg.shape
     e = np.zeros(n)
     psis = []
+    if bonds is not None:
+        bonds.update(h=np.zeros((n, rows, cols - 1)), v=np.zeros((n, rows - 1, cols)))
 
     def bond(s1, s2, orient, order, ext):
         (r1, c1), (r2, c2) = s1, s2
@@ -248,7 +286,10 @@ def nn_energy(ctx, state, configs, bond_fn):
         ctx.grow_full_bten(RIGHT, row, 1, True)
         psis.append(ctx.trace(row, 0, HORIZONTAL))
         for col in range(cols - 1):
-            e += bond((row, col), (row, col + 1), HORIZONTAL, ROW, ext)
+            eb = bond((row, col), (row, col + 1), HORIZONTAL, ROW, ext)
+            e += eb
+            if bonds is not None:
+                bonds["h"][:, row, col] = eb
             ctx.shift_bten_window(RIGHT)
         if row < rows - 1:
             ctx.shift_bmps_window(DOWN)
@@ -260,7 +301,10 @@ def nn_energy(ctx, state, configs, bond_fn):
         ctx.grow_full_bten(DOWN, col, 2, True)
         psis.append(ctx.trace(0, col, VERTICAL))
         for row in range(rows - 1):
-            e += bond((row, col), (row + 1, col), VERTICAL, COL, ext)
+            eb = bond((row, col), (row + 1, col), VERTICAL, COL, ext)
+            e += eb
+            if bonds is not None:
+                bonds["v"][:, row, col] = eb
             if row < rows - 2:
                 ctx.shift_bten_window(DOWN)
         if col < cols - 1:

@@ -234,6 +234,45 @@ int pepshost_exact_sum_partial(int rows, int cols, int D, int d, int chi, int dt
   });
 }
 
+// Rank-local part of ExactSumMeasurerMPI (exact_summation_measurer.h:103-257): un-normalised weighted sums of the
+// registry observables over configurations rank, rank + size, ...   keys_out = "key:len;...", values_out =
+// [sum w | key values in that order]; the caller sums values over ranks and divides by values[0].
+// n_configs < 0: every binary configuration (GenerateAllBinaryConfigs).
+int pepshost_exact_sum_measure_partial(int rows, int cols, int D, int d, int chi, int dtype, const double *sitps_flat,
+                                       const int32_t *all_configs, int n_configs, int model, const double *p, int rank, int size,
+                                       int batch, char *keys_out, int keys_cap, double *values_out, long values_cap, long *values_len) {
+  return guarded([&]() {
+    SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
+    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), batch, dtype);
+    std::vector<std::vector<int32_t>> all;
+    if (n_configs >= 0) {
+      all.resize(n_configs);
+      for (int i = 0; i < n_configs; ++i) all[i].assign(all_configs + (size_t)i * rows * cols, all_configs + (size_t)(i + 1) * rows * cols);
+    } else {
+      all = GenerateAllBinaryConfigs(cols, rows);
+    }
+    if (model != 0 && model != 2) throw std::invalid_argument("pepshost_exact_sum_measure_partial: model must be xxz or j1j2");
+    std::vector<double> packed;
+    auto capture = [&](std::vector<double> &v) { packed = v; v[0] = 1.0; };   // keep the raw sums; normalise in the caller
+    std::map<std::string, std::vector<double>> res;
+    if (model == 0) {
+      SquareSpinOneHalfXXZModelOBC m(p[0], p[1], p[2]);
+      m.SetEnableStructureFactor(p[7] != 0.0);
+      res = ExactSumMeasurer(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
+    } else {
+      SquareSpinOneHalfJ1J2XXZModelOBC m(p[0], p[1], p[2], p[3], p[4]);
+      res = ExactSumMeasurer(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
+    }
+    std::string keys;
+    for (const auto &kv : res) keys += kv.first + ":" + std::to_string(kv.second.size()) + ";";
+    if ((int)keys.size() + 1 > keys_cap || (long)packed.size() > values_cap) throw std::out_of_range("pepshost_exact_sum_measure_partial: output buffer too small");
+    std::copy(keys.begin(), keys.end(), keys_out);
+    keys_out[keys.size()] = 0;
+    std::copy(packed.begin(), packed.end(), values_out);
+    *values_len = (long)packed.size();
+  });
+}
+
 // energy = sum wE / sum w, gradient = (S_EO - E S_O)/sum w   (:286-295) from the rank-summed accumulators
 int pepshost_exact_sum_finish(int rows, int cols, int D, int d, const double *packed, double *energy_out, double *grad_out) {
   return guarded([&]() {

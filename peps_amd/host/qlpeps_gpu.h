@@ -1542,6 +1542,61 @@ inline std::vector<std::vector<int32_t>> GenerateAllPermutationConfigs(const std
   return all;
 }
 
+// GenerateAllBinaryConfigs (exact_summation_measurer.h:53-72): bit `b` of the counter is site (b / Lx, b % Lx)
+inline std::vector<std::vector<int32_t>> GenerateAllBinaryConfigs(size_t Lx, size_t Ly) {
+  if (Ly != 0 && Lx > std::numeric_limits<size_t>::max() / Ly) throw std::invalid_argument("GenerateAllBinaryConfigs: Lx*Ly overflows size_t");
+  const size_t N = Lx * Ly;
+  if (N >= (size_t)std::numeric_limits<size_t>::digits) throw std::invalid_argument("GenerateAllBinaryConfigs: Lx*Ly must be < size_t bit width");
+  std::vector<std::vector<int32_t>> all((size_t)1 << N, std::vector<int32_t>(N));
+  for (size_t i = 0; i < all.size(); ++i)
+    for (size_t bit = 0; bit < N; ++bit) all[i][bit] = (int32_t)((i >> bit) & 1);
+  return all;
+}
+
+// ExactSumMeasurerMPI (exact_summation_measurer.h:103-257): <O> = sum_S |psi(S)|^2 O_loc(S) / sum_S |psi(S)|^2 with
+// O_loc from the solver's registry (EvaluateObservables).  Configurations i = rank, rank + size, ... of this rank go
+// through the device `batch` walkers at a time; `allreduce` sums [weight | key values in sorted key order] over the
+// ranks in place (identity if null: the result is then this rank's share, normalised by its own weight).
+template <typename MeasurementSolverT>
+std::map<std::string, std::vector<double>> ExactSumMeasurer(const SplitIndexTPS &sitps, const std::vector<std::vector<int32_t>> &all_configs,
+                                                            BMPSContractor &contractor, MeasurementSolverT &solver, int rank, int size,
+                                                            size_t batch, const std::function<void(std::vector<double> &)> &allreduce,
+                                                            double *weight_sum_out = nullptr) {
+  if (all_configs.empty()) throw std::invalid_argument("ExactSumMeasurerMPI: all_configs must not be empty");     // :113-115
+  const size_t rows = sitps.rows(), cols = sitps.cols();
+  double weight_rank = 0.0;
+  std::map<std::string, std::vector<double>> weighted;          // std::map: keys already in the sorted order of :153-171
+  std::vector<size_t> mine;
+  for (size_t i = rank; i < all_configs.size(); i += size) mine.push_back(i);                                     // :130
+  contractor.UploadState(sitps);
+  for (size_t b0 = 0; b0 < mine.size(); b0 += batch) {
+    const size_t nb = std::min(batch, mine.size() - b0);
+    Configuration cfg(nb, rows, cols);
+    for (size_t w = 0; w < nb; ++w) std::copy(all_configs[mine[b0 + w]].begin(), all_configs[mine[b0 + w]].end(), cfg.data() + w * rows * cols);
+    TPSWaveFunctionComponent comp(sitps, cfg, contractor);
+    const std::vector<double> psi = comp.amplitude;            // the solver's passes may touch comp
+    ObservableMap obs = solver.EvaluateObservables(sitps, comp);
+    for (size_t w = 0; w < nb; ++w) weight_rank += psi[w] * psi[w];                                                // :135-136
+    for (const auto &kv : obs.values) {
+      const size_t len = kv.second.size() / nb;
+      auto &acc = weighted[kv.first];
+      if (acc.empty()) acc.assign(len, 0.0);
+      for (size_t w = 0; w < nb; ++w)
+        for (size_t j = 0; j < len; ++j) acc[j] += psi[w] * psi[w] * kv.second[w * len + j];                       // :141-149
+    }
+  }
+  std::vector<double> packed{weight_rank};
+  for (const auto &kv : weighted) packed.insert(packed.end(), kv.second.begin(), kv.second.end());
+  if (allreduce) allreduce(packed);                                                                                // :209-235
+  const double weight_sum = packed[0];
+  if (weight_sum_out) *weight_sum_out = weight_sum;
+  if (!(weight_sum > 0.0)) throw std::runtime_error("ExactSumMeasurerMPI: total weight must be positive");         // :243-245
+  size_t off = 1;
+  for (auto &kv : weighted)
+    for (auto &v : kv.second) v = packed[off++] / weight_sum;                                                      // :246-250
+  return weighted;
+}
+
 // ExactSumEnergyEvaluatorMPI (exact_summation_energy_evaluator.h:173-302): configurations
 // i = rank, rank + size, ... are evaluated in batches of `batch` walkers; `allreduce` sums the
 // packed accumulators over ranks in place (RCCL all-reduce in the host program; identity if null).

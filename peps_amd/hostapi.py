@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepshost.so")
 
-SYMBOLS = ["pepshost_last_error", "pepshost_mc_sweeps", "pepshost_energy_and_holes", "pepshost_exact_sum_partial",
+SYMBOLS = ["pepshost_last_error", "pepshost_mc_sweeps", "pepshost_energy_and_holes", "pepshost_exact_sum_partial", "pepshost_exact_sum_measure_partial",
            "pepshost_mc_energy_grad_partial", "pepshost_exact_sum_finish", "pepshost_load_sitps", "pepshost_dump_sitps",
            "pepshost_dump_configuration", "pepshost_load_configuration", "pepshost_fermion_energy",
            "pepshost_fermion_exact_sum_partial", "pepshost_fermion_mc_sweeps", "pepshost_measure",
@@ -95,6 +95,35 @@ def exact_sum_partial(flat, all_configs, chi, model="xxz", params=(1.0, 1.0, 0.0
                                          cfg.shape[0], MODEL_ID[model], _p(p, C.c_double), rank, size, batch,
                                          _p(packed, C.c_double)))
     return packed
+
+
+def exact_sum_measure_partial(flat, all_configs, chi, model="xxz", params=(1.0, 1.0, 0.0), rank=0, size=1, batch=64, dtype=1):
+    """Rank-local part of ExactSumMeasurerMPI (exact_summation_measurer.h:103-257) through the C++ measurement solver:
+    (dict key -> sum_S |psi(S)|^2 O_loc(S), sum_S |psi(S)|^2) over configurations rank, rank + size, ...  Sum both over
+    the ranks and divide.  all_configs = None: every binary configuration (GenerateAllBinaryConfigs, :53-72)."""
+    flat = np.ascontiguousarray(flat, dtype=np.float64)
+    rows, cols, d, D = _dims(flat)
+    cfg = None if all_configs is None else np.ascontiguousarray(all_configs, dtype=np.int32)
+    p = np.zeros(8, dtype=np.float64)
+    p[:len(params)] = params
+    cap = 4 * (rows * cols) ** 2 + 65536
+    vals = np.zeros(cap, dtype=np.float64)
+    keys = C.create_string_buffer(4096)
+    nvals = C.c_long(0)
+    l = lib()
+    l.pepshost_exact_sum_measure_partial.argtypes = [C.c_int] * 6 + [C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int, C.c_int,
+                                                     C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int,
+                                                     C.POINTER(C.c_double), C.c_long, C.POINTER(C.c_long)]
+    _ck(l.pepshost_exact_sum_measure_partial(rows, cols, D, d, chi, dtype, _p(flat, C.c_double),
+                                             None if cfg is None else _p(cfg, C.c_int32), -1 if cfg is None else cfg.shape[0],
+                                             MODEL_ID[model], _p(p, C.c_double), rank, size, batch, keys, 4096,
+                                             _p(vals, C.c_double), cap, C.byref(nvals)))
+    out, off = {}, 1
+    for item in filter(None, keys.value.decode().split(";")):    # a rank without configurations reports no keys
+        key, ln = item.split(":")
+        out[key] = vals[off:off + int(ln)].copy()
+        off += int(ln)
+    return out, float(vals[0])
 
 
 def exact_sum_finish(packed, shape):

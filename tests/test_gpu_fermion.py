@@ -2,6 +2,7 @@
 engine (peps_amd/fermion.py), against the graded oracle (oracle/graded.py, oracle/fermion.py) and the
 reference's 2x2 spinless-fermion known answers; BASELINE config C5 (8x8 spinless t-V, D=6, chi=24)."""
 import itertools
+import json
 import os
 
 import numpy as np
@@ -44,6 +45,29 @@ def test_k4_spinless_fermion_exact_sum_on_device(fixtures_dir, name, t2, e_ref):
     e_loc, _ = fermion.spinless_fermion_energy(ctx, st, cfgs, 1.0, 0.0)
     w = amp ** 2
     assert abs(np.sum(w * e_loc) / np.sum(w) - e_ref) < 1e-9
+
+
+@pytest.mark.parametrize("dt,tol", [("f64", 1e-10), ("f32", 2e-5)])
+def test_exact_sum_measurer_reference_registry_on_device(fixtures_dir, dt, tol):
+    """ExactSumMeasurerMPI known answers (tests/test_algorithm/test_exact_summation_measurer.cpp:205-240): energy,
+    charge and the per-bond energies of the 2x2 simple-update state, amplitudes and hop ratios from the device;
+    serial == 4-rank decomposition (:276-290)."""
+    from peps_amd import capi, fermion
+    MEASURER_GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "k4_exact_sum_measurer.json")))["observables"]
+    st = fermion.FermionState.load(os.path.join(fixtures_dir, "spinless_fermion_tps_t2_0.000000_double_from_simple_update"))
+    cfgs = _half_filling_configs()
+    ctx = _ctx(st, 8, capi.F64 if dt == "f64" else capi.F32, len(cfgs))
+    acc, w = fermion.exact_sum_measure(ctx, st, cfgs, 1.0, 0.0)
+    assert set(acc) == set(MEASURER_GOLDEN)
+    for key, want in MEASURER_GOLDEN.items():
+        assert acc[key].shape == (len(want),), key
+        assert np.max(np.abs(acc[key] / w - np.array(want))) < tol, key
+    parts = [fermion.exact_sum_measure(ctx, st, cfgs, 1.0, 0.0, r, 4, batch=1) for r in range(4)]
+    wp = sum(p[1] for p in parts)
+    for key in acc:
+        assert np.max(np.abs(sum(p[0][key] for p in parts) / wp - acc[key] / w)) < tol
+    with pytest.raises(ValueError):
+        fermion.exact_sum_measure(ctx, st, np.zeros((0, 2, 2), dtype=np.int64), 1.0)
 
 
 @pytest.mark.parametrize("name", ["2.100000_double_from_simple_update", "-2.500000_doublelowest"])

@@ -138,3 +138,38 @@ def test_structure_factor_cross_row_spsm(dt, tol, chi):
         assert np.array_equal(have[:, :4], want[:, :4])
         scale = np.max(np.abs(want[:, 4]))
         assert scale > 0 and np.max(np.abs(have[:, 4] - want[:, 4])) < tol * 10 * scale
+
+
+@pytest.mark.parametrize("dt,tol", [(F64, 1e-9), (F32, 5e-5)])
+def test_exact_sum_measurer_all_binary_configs(dt, tol):
+    """ExactSumMeasurerMPI + GenerateAllBinaryConfigs (exact_summation_measurer.h:53-72, 103-257) through the C++ solver:
+    every registry key, weighted by |psi|^2 over all 64 configurations of a 2x3 lattice, against the oracle; the rank
+    decomposition adds up to the serial result (test_exact_summation_measurer.cpp:276-290); empty list rejected."""
+    host = _host()
+    Ly, Lx, D, chi = 2, 3, 3, 9
+    rng = np.random.default_rng(5)
+    s = [[[rng.standard_normal((1 if c == 0 else D, 1 if r == Ly - 1 else D, 1 if c == Lx - 1 else D, 1 if r == 0 else D)) + 0.3
+           for _ in range(2)] for c in range(Lx)] for r in range(Ly)]
+    flat = np.zeros((Ly, Lx, 2, D, D, D, D))
+    for r in range(Ly):
+        for c in range(Lx):
+            for k in range(2):
+                t = s[r][c][k]
+                flat[r, c, k, :t.shape[0], :t.shape[1], :t.shape[2], :t.shape[3]] = t
+    params = (1.0, 0.7, 0.2)
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    all_cfgs = vmc.generate_all_binary_configs(Lx, Ly)
+    assert len(all_cfgs) == 64 and all_cfgs[5][0].tolist() == [1, 0, 1] and all_cfgs[8][1].tolist() == [1, 0, 0]
+    want = vmc.exact_sum_measure(s, all_cfgs, tp, lambda: vmc.SquareNNNModelMeasurementSolver(vmc.SquareSpinOneHalfXXZModelOBC(*params)))
+    acc, w = host.exact_sum_measure_partial(flat, None, chi, "xxz", params, 0, 1, 64, dt)
+    assert set(acc) == set(want)
+    for key, v in want.items():
+        assert acc[key].shape == v.shape, key
+        assert np.max(np.abs(acc[key] / w - v)) < tol * 10 * max(1.0, np.max(np.abs(v))), key
+    parts = [host.exact_sum_measure_partial(flat, np.array(all_cfgs), chi, "xxz", params, r, 3, 7, dt) for r in range(3)]
+    wp = sum(p[1] for p in parts)
+    assert abs(wp / w - 1) < tol
+    for key in acc:
+        assert np.max(np.abs(sum(p[0][key] for p in parts) / wp - acc[key] / w)) < tol * 10
+    with pytest.raises(Exception):
+        host.exact_sum_measure_partial(flat, np.zeros((0, Ly, Lx), dtype=np.int32), chi, "xxz", params, 0, 1, 4, dt)

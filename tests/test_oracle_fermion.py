@@ -3,6 +3,7 @@
 filling, t2 in {2.1, 0, -2.5}, 'lowest' states (exact free-fermion energies) and simple-update states
 (golden energies :432-436)."""
 import itertools
+import json
 import os
 
 import numpy as np
@@ -114,3 +115,31 @@ def test_tj_model_reference_energies(fixtures_dir, name, e_ref):
     cfgs = [np.array(p).reshape(2, 2) for p in sorted(set(itertools.permutations([2, 2, 0, 1])))]
     e = fermion.exact_sum_energy(fs, cfgs, BMPSTruncateParams.SVD(4, 4, 0.0), fermion.SquaretJVModelOBC(1.0, 0.0, 0.3, 0.075, 0.0))
     assert abs(e - e_ref) < 1e-10
+
+
+# ExactSumMeasurerMPI known answers (tests/test_algorithm/test_exact_summation_measurer.cpp:205-240, real tensors):
+# 2x2 spinless fermions, t = 1, t2 = V = 0, the simple-update state, SVD(8, 8, 1e-16), half filling
+MEASURER_GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "k4_exact_sum_measurer.json")))["observables"]
+
+
+def test_exact_sum_measurer_reproduces_reference_registry(fixtures_dir):
+    tp = BMPSTruncateParams.SVD(8, 8, 1e-16)
+    gts = fermion.load_fermion_sitps(os.path.join(fixtures_dir, "spinless_fermion_tps_t2_0.000000_double_from_simple_update"))
+    fs = fermion.FermionSITPS(gts)
+    model = fermion.SquareSpinlessFermionOBC(1.0, 0.0, 0.0)
+    cfgs = _half_filling_configs()
+    obs = fermion.exact_sum_measure(fs, cfgs, tp, model)
+    assert set(obs) == set(MEASURER_GOLDEN)
+    for key, want in MEASURER_GOLDEN.items():
+        assert obs[key].shape == (len(want),), key
+        assert np.max(np.abs(obs[key] - np.array(want))) < 1e-10, key
+    # the reference test's own structural checks (:221-229): energy = sum of bond energies, total charge = 2
+    assert abs(obs["energy"][0] - sum(obs[k].sum() for k in ("bond_energy_h", "bond_energy_v", "bond_energy_dr", "bond_energy_ur"))) < 1e-10
+    assert abs(obs["charge"].sum() - 2.0) < 1e-10
+    # rank decomposition (:276-290: serial == 4 ranks)
+    parts = [fermion.exact_sum_measure(fs, cfgs, tp, model, r, 4) for r in range(4)]
+    w = sum(p[1] for p in parts)
+    for key in obs:
+        assert np.max(np.abs(sum(p[0][key] for p in parts if key in p[0]) / w - obs[key])) < 1e-13
+    with pytest.raises(RuntimeError):
+        fermion.exact_sum_measure(fs, [], tp, model)
