@@ -204,33 +204,63 @@ def tj_energy(ctx, state, configs, t, J, V=0.0, mu=0.0):
     return e - mu * np.sum(np.asarray(configs) != 2, axis=(1, 2)), psis
 
 
-def spinless_fermion_energy(ctx, state, configs, t, V=0.0):
-    """E_loc(S) of H = -t sum_<ij> (c+_i c_j + h.c.) + V sum_<ij> n_i n_j (square_spinless_fermion.h:134-159; the NNN
-    pass of the reference multiplies by t2, which must be 0 here).  Returns (energy [n], psi_list [rows + cols][n])."""
+def spinless_fermion_energy(ctx, state, configs, t, V=0.0, t2=0.0, bonds=None):
+    """E_loc(S) of H = -t sum_<ij> (c+_i c_j + h.c.) - t2 sum_<<ij>> (c+_i c_j + h.c.) + V sum_<ij> n_i n_j
+    (square_spinless_fermion.h:134-200).  Returns (energy [n], psi_list [rows + cols][n]).  The NN hops are local
+    replacements inside the row / column pass; the diagonal hop is not local in the decorated form and is taken from a
+    fresh amplitude of the hopped configuration (nnn_hop_energy)."""
     nf = state.nf
     def bond(c1, c2):
         return V * (nf[c1] % 2) * (nf[c2] % 2), np.where(c1 != c2, -t, 0.0)
-    return nn_energy(ctx, state, configs, bond)
+    e, psis = nn_energy(ctx, state, configs, bond, bonds)
+    if t2 != 0.0:
+        e = e + nnn_hop_energy(ctx, state, configs, t2, bonds)
+    return e, psis
 
 
-def spinless_fermion_observables(ctx, state, configs, t, V=0.0):
+def nnn_hop_energy(ctx, state, configs, t2, bonds=None):
+    """sum over plaquette diagonals of -t2 * jw * psi(S with the two sites exchanged) / psi(S), jw = Jordan-Wigner string
+    of the sites strictly between the two in row-major order (square_spinless_fermion.h:161-200): one batched fresh
+    contraction per diagonal.  bonds["dr"] / ["ur"] [n, rows-1, cols-1] receive the per-bond terms."""
+    cfg = np.asarray(configs)
+    n, rows, cols = cfg.shape
+    occ = (np.asarray(state.nf)[cfg] % 2).reshape(n, -1)
+    psi0 = evaluate_amplitude(ctx, state, cfg)
+    e = np.zeros(n)
+    if bonds is not None:
+        bonds.update(dr=np.zeros((n, rows - 1, cols - 1)), ur=np.zeros((n, rows - 1, cols - 1)))
+    for row in range(rows - 1):
+        for col in range(cols - 1):
+            for key, a, b in (("dr", (row, col), (row + 1, col + 1)), ("ur", (row + 1, col), (row, col + 1))):
+                differ = cfg[:, a[0], a[1]] != cfg[:, b[0], b[1]]
+                if not differ.any():
+                    continue
+                ia, ib = sorted((a[0] * cols + a[1], b[0] * cols + b[1]))
+                jw = (-1.0) ** occ[:, ia + 1:ib].sum(axis=1)
+                new = cfg.copy()
+                new[:, a[0], a[1]], new[:, b[0], b[1]] = cfg[:, b[0], b[1]], cfg[:, a[0], a[1]]
+                eb = np.where(differ, -t2 * jw * evaluate_amplitude(ctx, state, new) / np.where(psi0 == 0, 1.0, psi0), 0.0)
+                e += eb
+                if bonds is not None:
+                    bonds[key][:, row, col] = eb
+    return e
+
+
+def spinless_fermion_observables(ctx, state, configs, t, V=0.0, t2=0.0):
     """Registry of SquareNNNModelMeasurementSolver<SquareSpinlessFermion>::EvaluateObservables
     (square_nnn_model_measurement_solver.h:33-210, square_spinless_fermion.h:87-115) for a batch of configurations:
     energy [n, 1], charge [n, rows*cols] (1 - config), bond_energy_h / _v and the (t2 = 0) diagonal bonds.
     Also returns psi_list [rows + cols][n]."""
     cfg = np.asarray(configs)
     n, rows, cols = cfg.shape
-    nf = state.nf
-    def bond(c1, c2):
-        return V * (nf[c1] % 2) * (nf[c2] % 2), np.where(c1 != c2, -t, 0.0)
-    bonds = {}
-    e, psis = nn_energy(ctx, state, cfg, bond, bonds)
-    zero = np.zeros((n, (rows - 1) * (cols - 1)))
+    bonds = {"dr": np.zeros((n, rows - 1, cols - 1)), "ur": np.zeros((n, rows - 1, cols - 1))}
+    e, psis = spinless_fermion_energy(ctx, state, cfg, t, V, t2, bonds)
     return {"energy": e[:, None], "charge": (1.0 - cfg).reshape(n, -1), "bond_energy_h": bonds["h"].reshape(n, -1),
-            "bond_energy_v": bonds["v"].reshape(n, -1), "bond_energy_dr": zero, "bond_energy_ur": zero.copy()}, psis
+            "bond_energy_v": bonds["v"].reshape(n, -1), "bond_energy_dr": bonds["dr"].reshape(n, -1),
+            "bond_energy_ur": bonds["ur"].reshape(n, -1)}, psis
 
 
-def exact_sum_measure(ctx, state, all_configs, t, V=0.0, rank=0, size=1, batch=None):
+def exact_sum_measure(ctx, state, all_configs, t, V=0.0, rank=0, size=1, batch=None, t2=0.0):
     """ExactSumMeasurerMPI (exact_summation_measurer.h:103-257) on the device: configurations rank, rank + size, ... in
     batches of walkers; returns (weighted sums by key, weight sum) -- sum both over ranks (all-reduce) and divide."""
     cfgs = np.asarray(all_configs)[rank::size]
@@ -240,7 +270,7 @@ def exact_sum_measure(ctx, state, all_configs, t, V=0.0, rank=0, size=1, batch=N
     wsum, acc = 0.0, {}
     for b0 in range(0, len(cfgs), batch):
         part = cfgs[b0:b0 + batch]
-        obs, psis = spinless_fermion_observables(ctx, state, part, t, V)
+        obs, psis = spinless_fermion_observables(ctx, state, part, t, V, t2)
         w = psis[0] ** 2                                   # |psi(S)|^2: the sign decoration drops out
         wsum += float(w.sum())
         for key, vals in obs.items():

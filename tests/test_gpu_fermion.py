@@ -33,18 +33,26 @@ def _half_filling_configs():
     return np.array([np.array(p).reshape(2, 2) for p in sorted(set(itertools.permutations([0, 0, 1, 1])))])
 
 
-@pytest.mark.parametrize("name,t2,e_ref", [("0.000000_doublelowest", 0.0, -2.0), ("0.000000_double_from_simple_update", 0.0, -1.98218053854)])
+@pytest.mark.parametrize("name,t2,e_ref", [("0.000000_doublelowest", 0.0, -2.0), ("0.000000_double_from_simple_update", 0.0, -1.98218053854),
+                                           ("2.100000_doublelowest", 2.1, -4.2), ("2.100000_double_from_simple_update", 2.1, -4.1879072654),
+                                           ("-2.500000_doublelowest", -2.5, -5.0), ("-2.500000_double_from_simple_update", -2.5, -4.98966397657)])
 def test_k4_spinless_fermion_exact_sum_on_device(fixtures_dir, name, t2, e_ref):
-    """reference known answers (test_exact_summation_evaluator.cpp:353-470, t2 = 0): exact summation over the six
-    half-filling configurations with amplitudes and hop ratios from the device (f64)."""
+    """reference known answers (test_exact_summation_evaluator.cpp:353-470, all six states): exact summation over the six
+    half-filling configurations with amplitudes and hop ratios from the device (f64); the diagonal hop (t2) through
+    fresh amplitudes with the Jordan-Wigner string of the row-major order."""
     from peps_amd import capi, fermion
     st = fermion.FermionState.load(os.path.join(fixtures_dir, "spinless_fermion_tps_t2_" + name))
     cfgs = _half_filling_configs()
     ctx = _ctx(st, 8, capi.F64, len(cfgs))
     amp = fermion.evaluate_amplitude(ctx, st, cfgs)
-    e_loc, _ = fermion.spinless_fermion_energy(ctx, st, cfgs, 1.0, 0.0)
+    e_loc, _ = fermion.spinless_fermion_energy(ctx, st, cfgs, 1.0, 0.0, t2)
     w = amp ** 2
     assert abs(np.sum(w * e_loc) / np.sum(w) - e_ref) < 1e-9
+    if t2 != 0.0:                       # registry form: the bonds add up to the energy, per configuration
+        obs, _ = fermion.spinless_fermion_observables(ctx, st, cfgs, 1.0, 0.0, t2)
+        tot = sum(obs[k].sum(axis=1) for k in ("bond_energy_h", "bond_energy_v", "bond_energy_dr", "bond_energy_ur"))
+        assert np.max(np.abs(tot - obs["energy"][:, 0])) < 1e-10 and np.max(np.abs(obs["energy"][:, 0] - e_loc)) < 1e-10
+        assert np.count_nonzero(obs["bond_energy_dr"]) + np.count_nonzero(obs["bond_energy_ur"]) > 0
 
 
 @pytest.mark.parametrize("dt,tol", [("f64", 1e-10), ("f32", 2e-5)])
