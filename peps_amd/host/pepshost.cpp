@@ -252,6 +252,11 @@ int pepshost_exact_sum_measure_partial(int rows, int cols, int D, int d, int chi
       all = GenerateAllBinaryConfigs(cols, rows);
     }
     if (model != 0 && model != 2) throw std::invalid_argument("pepshost_exact_sum_measure_partial: model must be xxz or j1j2");
+    if (!all.empty() && (size_t)rank >= all.size()) {           // a rank without configurations contributes nothing
+      if (keys_cap < 1 || values_cap < 1) throw std::out_of_range("pepshost_exact_sum_measure_partial: output buffer too small");
+      keys_out[0] = 0; values_out[0] = 0.0; *values_len = 1;
+      return;
+    }
     std::vector<double> packed;
     auto capture = [&](std::vector<double> &v) { packed = v; v[0] = 1.0; };   // keep the raw sums; normalise in the caller
     std::map<std::string, std::vector<double>> res;

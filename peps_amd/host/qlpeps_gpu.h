@@ -1568,6 +1568,8 @@ std::map<std::string, std::vector<double>> ExactSumMeasurer(const SplitIndexTPS 
   std::map<std::string, std::vector<double>> weighted;          // std::map: keys already in the sorted order of :153-171
   std::vector<size_t> mine;
   for (size_t i = rank; i < all_configs.size(); i += size) mine.push_back(i);                                     // :130
+  // the packed layout comes from the keys this rank evaluated (the reference broadcasts the master's, :173-206)
+  if (mine.empty() && allreduce) throw std::invalid_argument("ExactSumMeasurer: more ranks than configurations");
   contractor.UploadState(sitps);
   for (size_t b0 = 0; b0 < mine.size(); b0 += batch) {
     const size_t nb = std::min(batch, mine.size() - b0);

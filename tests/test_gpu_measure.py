@@ -173,3 +173,4 @@ def test_exact_sum_measurer_all_binary_configs(dt, tol):
         assert np.max(np.abs(sum(p[0][key] for p in parts) / wp - acc[key] / w)) < tol * 10
     with pytest.raises(Exception):
         host.exact_sum_measure_partial(flat, np.zeros((0, Ly, Lx), dtype=np.int32), chi, "xxz", params, 0, 1, 4, dt)
+    assert host.exact_sum_measure_partial(flat, np.array(all_cfgs[:2]), chi, "xxz", params, 3, 4, 4, dt) == ({}, 0.0)
