@@ -191,7 +191,9 @@ int pepsgpu_evaluate_amplitude(pepsgpu_ctx *ctx, double *out_amp);
 /* walker_flags[w] != 0: a boundary tensor of walker w vanished (reference throws, bmps_impl.h:839-843). */
 int pepsgpu_walker_flags(pepsgpu_ctx *ctx, int32_t *flags_out);
 int pepsgpu_sync(pepsgpu_ctx *ctx);
-/* stats_out: [0] row absorptions, [1] Jacobi launches, [2] reserved, [3] device bytes held */
+/* stats_out: [0] row absorptions, [1] Jacobi launches, [2] Jacobi sweeps (sum of per-launch maxima), [3] device bytes held,
+ * [4] largest sweep count; with PEPSGPU_DEBUG_SWEEPS=1 at context creation also [5] sum of live carry rows, [6] sum of
+ * carry sizes, [7] largest live carry of any walker (> 32: the dense Gram / Cholesky / full Jacobi route ran) */
 int pepsgpu_stats(pepsgpu_ctx *ctx, double *stats_out, int n);
 /* Per-kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).
  * out = [8][5]: {ms, launches, algorithmic flops, executed flops, operand + result bytes of the live extents} per category
@@ -200,10 +202,28 @@ int pepsgpu_stats(pepsgpu_ctx *ctx, double *stats_out, int n);
 int pepsgpu_profile_enable(pepsgpu_ctx *ctx, int on);
 int pepsgpu_profile_read(pepsgpu_ctx *ctx, double *out);
 
-/* Energy/gradient accumulation that replaces MPIMeanTensor / MPI_Reduce
- * (monte_carlo_tools/statistics_tensor.h:37-79, mc_energy_grad_evaluator.h:292-310): in-place
- * sum over ranks of a DEVICE buffer is done by the host layer with RCCL (torch.distributed
- * backend "nccl"); the library only exposes the device pointer arithmetic it needs. */
+/* ---- the one exchange step of the path: sum over ranks of the energy / gradient accumulators ----
+ * Replaces MPIMeanTensor per (site, component) (monte_carlo_tools/statistics_tensor.h:37-79), the
+ * MPI_Send/Recv + reduce of S_O, S_EO (exact_summation_energy_evaluator.h:252-280, mc_energy_grad_evaluator.h:292-310),
+ * the energy Gather (statistics.h:185-207) and the MPI_Allreduce(MAX) of acceptance rates
+ * (mc_energy_grad_evaluator.h:405-410) by RCCL all-reduces over xGMI, one rank (= one context) per GPU.
+ * The reference host owns the rendezvous (it has MPI): rank 0 calls pepsgpu_comm_unique_id and broadcasts the 128
+ * bytes (MPI_Bcast; torch.distributed.broadcast_object_list in the Python host), every rank calls pepsgpu_comm_init.
+ * A context without a communicator is a single rank: every reduction is the identity (as MPI with one rank). */
+int pepsgpu_comm_unique_id(void *id128_out);                                     /* ncclGetUniqueId: 128 bytes */
+int pepsgpu_comm_init(pepsgpu_ctx *ctx, int nranks, int rank, const void *id128); /* collective over the ranks */
+int pepsgpu_comm_size(pepsgpu_ctx *ctx);
+int pepsgpu_comm_rank(pepsgpu_ctx *ctx);
+int pepsgpu_comm_destroy(pepsgpu_ctx *ctx);
+/* in-place all-reduce of n elements on the context's stream, complete on return.  dtype: 0 f32, 1 f64, 2 int32;
+ * op: 0 sum, 1 max; on_device != 0: buf is an HBM pointer of this context's GPU (no host hop), else a host buffer
+ * staged through HBM. */
+int pepsgpu_allreduce(pepsgpu_ctx *ctx, void *buf, long n, int dtype, int op, int on_device);
+/* S_O and S_EO of pepsgpu_grad_accumulate summed over the ranks where they live (HBM), before pepsgpu_grad_read. */
+int pepsgpu_grad_allreduce(pepsgpu_ctx *ctx);
+/* device pointers of the two float64 accumulators ([row][col][s][D^4 slot], n_elems each) for hosts that run their own
+ * collective on them (torch.distributed backend "nccl" = RCCL: peps_amd/dist.py wraps them without a copy). */
+int pepsgpu_grad_device_ptr(pepsgpu_ctx *ctx, void **so_dev, void **seo_dev, long *n_elems);
 
 /* ---- diagnostics (unit tests of the kernels; not part of the reference surface) ---- */
 int pepsgpu_diag_tgemm(int dtype_in, int dtype_out, const int *desc_ints, int n_ints, const void *A, size_t a_elems,

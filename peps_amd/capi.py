@@ -30,7 +30,9 @@ SYMBOLS = [
     "pepsgpu_init_bten2", "pepsgpu_grow_full_bten2", "pepsgpu_grow_bten2_step", "pepsgpu_shift_bten2_window",
     "pepsgpu_bten2_stack_size", "pepsgpu_replace_nnn_trace", "pepsgpu_replace_tnn_trace",
     "pepsgpu_replace_sqrt5_trace",
-    "pepsgpu_grad_reset", "pepsgpu_grad_accumulate", "pepsgpu_grad_read",
+    "pepsgpu_grad_reset", "pepsgpu_grad_accumulate", "pepsgpu_grad_read", "pepsgpu_grad_device_ptr", "pepsgpu_grad_allreduce",
+    "pepsgpu_comm_unique_id", "pepsgpu_comm_init", "pepsgpu_comm_size", "pepsgpu_comm_rank", "pepsgpu_comm_destroy",
+    "pepsgpu_allreduce",
     "pepsgpu_sr_begin", "pepsgpu_sr_append", "pepsgpu_sr_count", "pepsgpu_sr_sum", "pepsgpu_sr_matvec",
     "pepsgpu_sr_cg_solve", "pepsgpu_sr_gram", "pepsgpu_sr_weighted_sum", "pepsgpu_sr_copy_samples",
     "pepsgpu_update_local", "pepsgpu_erase_envs_after_update", "pepsgpu_evaluate_amplitude",
@@ -79,6 +81,14 @@ def load_library(path=LIB_PATH):
     lib.pepsgpu_grad_reset.argtypes = [vp]
     lib.pepsgpu_grad_accumulate.argtypes = [vp, dp, dp, C.c_int]
     lib.pepsgpu_grad_read.argtypes = [vp, dp, dp]
+    lib.pepsgpu_grad_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_long)]
+    lib.pepsgpu_grad_allreduce.argtypes = [vp]
+    lib.pepsgpu_comm_unique_id.argtypes = [vp]
+    lib.pepsgpu_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.pepsgpu_comm_size.argtypes = [vp]
+    lib.pepsgpu_comm_rank.argtypes = [vp]
+    lib.pepsgpu_comm_destroy.argtypes = [vp]
+    lib.pepsgpu_allreduce.argtypes = [vp, vp, C.c_long, C.c_int, C.c_int, C.c_int]
     lib.pepsgpu_sr_begin.argtypes = [vp, C.c_int]
     lib.pepsgpu_sr_append.argtypes = [vp, dp]
     lib.pepsgpu_sr_count.argtypes = [vp]
@@ -335,6 +345,35 @@ class Context:
         self._ck(self._l.pepsgpu_grad_read(self._h, _dp(so), _dp(seo)))
         return so, seo
 
+    # -- the exchange step: RCCL all-reduce of the accumulators (one rank = one context per GPU) --
+    def grad_device_ptr(self):
+        """(S_O pointer, S_EO pointer, elements): the float64 accumulators where they live in HBM."""
+        so, seo, n = C.c_void_p(), C.c_void_p(), C.c_long()
+        self._ck(self._l.pepsgpu_grad_device_ptr(self._h, C.byref(so), C.byref(seo), C.byref(n)))
+        return so.value, seo.value, n.value
+
+    def grad_allreduce(self):
+        self._ck(self._l.pepsgpu_grad_allreduce(self._h))
+
+    def comm_init(self, nranks, rank, unique_id=None):
+        """unique_id: the 128 bytes of comm_unique_id() of rank 0 (None only for a single rank)."""
+        buf = None if unique_id is None else C.create_string_buffer(bytes(unique_id), 128)
+        self._ck(self._l.pepsgpu_comm_init(self._h, nranks, rank, buf))
+
+    def comm_size(self): return self._l.pepsgpu_comm_size(self._h)
+    def comm_rank(self): return self._l.pepsgpu_comm_rank(self._h)
+    def comm_destroy(self): self._ck(self._l.pepsgpu_comm_destroy(self._h))
+
+    def allreduce(self, arr, op="sum"):
+        """in-place all-reduce of a host NumPy array (float32 / float64 / int32) over the context's communicator"""
+        code = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.int32): 2}[arr.dtype]
+        assert arr.flags["C_CONTIGUOUS"]
+        self._ck(self._l.pepsgpu_allreduce(self._h, arr.ctypes.data_as(C.c_void_p), arr.size, code, {"sum": 0, "max": 1}[op], 0))
+        return arr
+
+    def allreduce_device(self, ptr, n, dtype=F64, op="sum"):
+        self._ck(self._l.pepsgpu_allreduce(self._h, C.c_void_p(ptr), n, {F32: 0, F64: 1}[dtype], {"sum": 0, "max": 1}[op], 1))
+
     def update_local(self, sites, new_states, accept_mask=None):
         sites = np.ascontiguousarray(sites, dtype=np.int32).reshape(-1, 2)
         ns = np.ascontiguousarray(new_states, dtype=np.int32).reshape(self.n, sites.shape[0])
@@ -373,11 +412,22 @@ class Context:
                 for i, name in enumerate(self.PROF_CATS)}
 
     def stats(self):
-        out = np.zeros(7, dtype=np.float64)
-        self._ck(self._l.pepsgpu_stats(self._h, _dp(out), 7))
+        out = np.zeros(8, dtype=np.float64)
+        self._ck(self._l.pepsgpu_stats(self._h, _dp(out), 8))
         return {"absorptions": int(out[0]), "jacobi_launches": int(out[1]), "jacobi_sweeps_sum": int(out[2]),
                 "device_bytes": int(out[3]), "jacobi_sweeps_max": int(out[4]),
-                "carry_live_fraction": float(out[5] / out[6]) if out[6] > 0 else None}
+                "carry_live_fraction": float(out[5] / out[6]) if out[6] > 0 else None,
+                "carry_live_max": int(out[7])}
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library: 128 bytes that rank 0 hands to every rank (MPI_Bcast in the reference host,
+    torch.distributed.broadcast_object_list in peps_amd/dist.py)."""
+    buf = C.create_string_buffer(128)
+    rc = lib().pepsgpu_comm_unique_id(buf)
+    if rc != 0:
+        raise RuntimeError("pepsgpu_comm_unique_id failed: %s" % lib().pepsgpu_last_error(None).decode())
+    return buf.raw
 
 
 # -- diagnostics (kernel unit tests) --

@@ -5,6 +5,7 @@
 #include "engine_nnn.h"
 #include "engine_sr.h"
 #include "engine_var.h"
+#include "comm.h"
 
 using namespace pepsgpu;
 
@@ -21,6 +22,7 @@ bool tgemm_use_mfma() {
 
 struct pepsgpu_ctx {
   EngineBase *eng = nullptr;
+  Comm comm;
   std::string err;
 };
 
@@ -40,9 +42,11 @@ static int guarded(pepsgpu_ctx *ctx, F &&f) {
   }
 }
 
+// every entry makes the context's GPU the calling thread's current device first: a context is bound to one device, the
+// caller (another context, torch, another thread) may have changed the thread's device since the last call
 #define CTX_CALL(body)                                     \
   if (!ctx || !ctx->eng) return PEPSGPU_EINVAL;            \
-  return guarded(ctx, [&]() { body; })
+  return guarded(ctx, [&]() { PG_CHECK_HIP(hipSetDevice(ctx->eng->device_id)); body; })
 
 extern "C" {
 
@@ -59,6 +63,8 @@ int pepsgpu_ctx_create(pepsgpu_ctx **out, int device, int dtype, int rows, int c
     int ndev = 0;
     PG_CHECK_HIP(hipGetDeviceCount(&ndev));
     PG_REQUIRE(ndev > 0 && device >= 0 && device < ndev, 2, "no such HIP device");
+    // walkers x candidates is the z extent of the contraction grids (65535); refuse here, not at the first launch
+    PG_REQUIRE(max_walkers >= 1 && max_walkers <= 65535, 1, "max_walkers must be in [1, 65535] (grid z limit)");
     if (dtype == PEPSGPU_F32)
       ctx->eng = new Engine<float>(device, rows, cols, D, phys_dim, chi_min, chi_max, trunc_err, max_walkers);
     else if (dtype == PEPSGPU_F64)
@@ -83,6 +89,8 @@ int pepsgpu_set_truncate_params(pepsgpu_ctx *ctx, int chi_min, int chi_max, doub
 
 void pepsgpu_ctx_destroy(pepsgpu_ctx *ctx) {
   if (!ctx) return;
+  if (ctx->eng) (void)hipSetDevice(ctx->eng->device_id);
+  ctx->comm.destroy();
   delete ctx->eng;
   delete ctx;
 }
@@ -179,6 +187,34 @@ int pepsgpu_grad_accumulate(pepsgpu_ctx *ctx, const double *psi, const double *e
 }
 int pepsgpu_grad_read(pepsgpu_ctx *ctx, double *so, double *seo) {
   CTX_CALL(PG_REQUIRE(so && seo, 1, "null output"); ctx->eng->grad_read(so, seo));
+}
+int pepsgpu_grad_device_ptr(pepsgpu_ctx *ctx, void **so, void **seo, long *n_elems) {
+  CTX_CALL(PG_REQUIRE(so && seo && n_elems, 1, "null output"); ctx->eng->grad_device_ptr(so, seo, n_elems));
+}
+int pepsgpu_comm_unique_id(void *id128_out) {
+  return guarded(nullptr, [&]() {
+    PG_REQUIRE(id128_out != nullptr, 1, "null output");
+    ncclUniqueId id;
+    PG_CHECK_RCCL(RcclApi::get().GetUniqueId(&id));
+    memcpy(id128_out, &id, sizeof(id));
+  });
+}
+int pepsgpu_comm_init(pepsgpu_ctx *ctx, int nranks, int rank, const void *id128) {
+  CTX_CALL(ctx->comm.init(nranks, rank, id128));
+}
+int pepsgpu_comm_size(pepsgpu_ctx *ctx) { return ctx ? ctx->comm.nranks : -1; }
+int pepsgpu_comm_rank(pepsgpu_ctx *ctx) { return ctx ? ctx->comm.rank : -1; }
+int pepsgpu_comm_destroy(pepsgpu_ctx *ctx) { CTX_CALL(ctx->comm.destroy()); }
+int pepsgpu_allreduce(pepsgpu_ctx *ctx, void *buf, long n, int dtype, int op, int on_device) {
+  CTX_CALL(PG_REQUIRE(buf != nullptr || n == 0, 1, "null buffer"); PG_REQUIRE(n >= 0, 1, "negative count");
+           ctx->comm.allreduce((hipStream_t)ctx->eng->stream_handle(), buf, (size_t)n, dtype, op, on_device != 0);
+           if (on_device) ctx->eng->sync());
+}
+int pepsgpu_grad_allreduce(pepsgpu_ctx *ctx) {
+  CTX_CALL(void *so = nullptr; void *seo = nullptr; long n = 0; ctx->eng->grad_device_ptr(&so, &seo, &n);
+           hipStream_t s = (hipStream_t)ctx->eng->stream_handle();
+           ctx->comm.allreduce(s, so, (size_t)n, 1, 0, true); ctx->comm.allreduce(s, seo, (size_t)n, 1, 0, true);
+           ctx->eng->sync());
 }
 int pepsgpu_sr_begin(pepsgpu_ctx *ctx, int max_samples) { CTX_CALL(ctx->eng->sr_begin(max_samples)); }
 int pepsgpu_sr_append(pepsgpu_ctx *ctx, const double *psi) { CTX_CALL(PG_REQUIRE(psi, 1, "null psi"); ctx->eng->sr_append(psi)); }

@@ -1,0 +1,111 @@
+// RCCL communicator behind pepsgpu_comm_* / pepsgpu_allreduce (include/pepsgpu.h).
+//
+// The path has ONE exchange step: the sum over ranks of the energy / gradient accumulators, which the
+// reference does with MPI on host tensors (monte_carlo_tools/statistics_tensor.h:37-79 MPIMeanTensor,
+// mc_energy_grad_evaluator.h:292-310, exact_summation_energy_evaluator.h:252-280 MPI_Send/Recv + reduce).
+// Here it is one ncclAllReduce on the HBM-resident accumulators over xGMI, on the engine's own stream
+// (ordered behind the accumulation kernels, no host hop).  librccl is opened at first use so that the
+// library loads (and its symbols can be checked) on a machine without the RCCL runtime initialised.
+#pragma once
+#include <dlfcn.h>
+#include <cstring>
+#include <rccl/rccl.h>
+#include "common.h"
+
+namespace pepsgpu {
+
+struct RcclApi {
+  void *handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+
+  static RcclApi &get() {
+    static RcclApi api;
+    if (!api.handle) {
+      const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+      for (const char *n : names) {
+        api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (api.handle) break;
+      }
+      PG_REQUIRE(api.handle != nullptr, 2, std::string("cannot open librccl: ") + (dlerror() ? dlerror() : "?"));
+      auto sym = [&](const char *s) {
+        void *p = dlsym(api.handle, s);
+        PG_REQUIRE(p != nullptr, 2, std::string("librccl lacks ") + s);
+        return p;
+      };
+      api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+      api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+      api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+      api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
+      api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+      api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    }
+    return api;
+  }
+};
+
+#define PG_CHECK_RCCL(expr)                                                                                    \
+  do {                                                                                                         \
+    ncclResult_t _r = (expr);                                                                                  \
+    if (_r != ncclSuccess)                                                                                     \
+      throw ::pepsgpu::Error(2, std::string("RCCL error ") + ::pepsgpu::RcclApi::get().GetErrorString(_r) +   \
+                                    " in " #expr);                                                             \
+  } while (0)
+
+// One communicator per context (= per GPU / rank).  A context that never called init (one rank) reduces by the identity.
+struct Comm {
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+  void *scratch = nullptr;      // device staging for host buffers
+  size_t scratch_bytes = 0;
+
+  ~Comm() { destroy(); }
+  void destroy() {
+    if (comm) { (void)RcclApi::get().CommDestroy(comm); comm = nullptr; }
+    if (scratch) { (void)hipFree(scratch); scratch = nullptr; scratch_bytes = 0; }
+    nranks = 1; rank = 0;
+  }
+  void init(int n, int r, const void *id128) {
+    PG_REQUIRE(n >= 1 && r >= 0 && r < n, 1, "pepsgpu_comm_init: bad rank / size");
+    destroy();
+    PG_REQUIRE(n == 1 || id128 != nullptr, 1, "pepsgpu_comm_init: null unique id");
+    if (id128) {   // a single rank with an id still builds a real communicator (exercises RCCL on a one-GPU box)
+      static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+      ncclUniqueId id;
+      memcpy(&id, id128, sizeof(id));
+      PG_CHECK_RCCL(RcclApi::get().CommInitRank(&comm, n, id, r));
+      int cnt = 0;
+      PG_CHECK_RCCL(RcclApi::get().CommCount(comm, &cnt));
+      PG_REQUIRE(cnt == n, 2, "pepsgpu_comm_init: communicator reports a different rank count");
+    }
+    nranks = n; rank = r;
+  }
+  // in-place all-reduce of n elements; dtype 0 f32, 1 f64, 2 i32; op 0 sum, 1 max; buf in HBM (on_device) or on the host
+  void allreduce(hipStream_t s, void *buf, size_t n, int dtype, int op, bool on_device) {
+    PG_REQUIRE(dtype >= 0 && dtype <= 2 && (op == 0 || op == 1), 1, "pepsgpu_allreduce: bad dtype / op");
+    if (!comm || n == 0) return;   // single rank without a communicator: the identity
+    const size_t esz = dtype == 1 ? 8 : 4;
+    const ncclDataType_t dt = dtype == 0 ? ncclFloat32 : dtype == 1 ? ncclFloat64 : ncclInt32;
+    const ncclRedOp_t ro = op == 0 ? ncclSum : ncclMax;
+    if (on_device) {
+      PG_CHECK_RCCL(RcclApi::get().AllReduce(buf, buf, n, dt, ro, comm, s));
+      return;
+    }
+    if (scratch_bytes < n * esz) {
+      if (scratch) (void)hipFree(scratch);
+      scratch = nullptr; scratch_bytes = 0;
+      PG_CHECK_HIP(hipMalloc(&scratch, n * esz));
+      scratch_bytes = n * esz;
+    }
+    PG_CHECK_HIP(hipMemcpyAsync(scratch, buf, n * esz, hipMemcpyHostToDevice, s));
+    PG_CHECK_RCCL(RcclApi::get().AllReduce(scratch, scratch, n, dt, ro, comm, s));
+    PG_CHECK_HIP(hipMemcpyAsync(buf, scratch, n * esz, hipMemcpyDeviceToHost, s));
+    PG_CHECK_HIP(hipStreamSynchronize(s));
+  }
+};
+
+}  // namespace pepsgpu

@@ -32,6 +32,9 @@ struct EngineBase {
   virtual ~EngineBase() {}
   std::string last_error;
   int dtype = 0;
+  int device_id = 0;   // every C-ABI call makes this the calling thread's current HIP device first (capi.hip CTX_CALL)
+  virtual void *stream_handle() = 0;                                        // hipStream_t of every launch of this context
+  virtual void grad_device_ptr(void **so, void **seo, long *n_elems) = 0;   // HBM-resident f64 accumulators (grad_reset)
   // --- contractor surface (all walkers in lockstep) ---
   virtual void state_upload(const void *host, int host_dtype) = 0;
   virtual void set_configs(int n, const int32_t *cfg) = 0;
@@ -115,6 +118,7 @@ class Engine : public EngineBase {
     PG_REQUIRE(trunc_err >= 0.0 && trunc_err < 1.0, 1, "trunc_err must be in [0, 1)");
     PG_CHECK_HIP(hipSetDevice(device));
     device_ = device;
+    device_id = device;
     PG_CHECK_HIP(hipStreamCreate(&stream_));
     slot_ = (long)D * D * D * D;
     sitps_ = (T *)arena_.alloc(sizeof(T) * slot_ * dp_ * Ly * Lx);
@@ -375,6 +379,7 @@ class Engine : public EngineBase {
 
   void replace_nn_trace(int row, int col, int dir, int ncand, const int32_t *cand, double *out) override {
     require_ready();
+    ArenaScope scope(arena_);
     int rb = row + (dir == VERTICAL), cb = col + (dir == HORIZONTAL);
     PG_REQUIRE(row >= 0 && col >= 0 && rb < Ly_ && cb < Lx_, 1, "ReplaceNNSiteTrace: bond outside the lattice");
     const int nc = ncand > 0 ? ncand : 1;
@@ -411,6 +416,7 @@ class Engine : public EngineBase {
 
   void replace_one_trace(int row, int col, int orient, int ncand, const int32_t *cand, double *out) override {
     require_ready();
+    ArenaScope scope(arena_);
     PG_REQUIRE(row >= 0 && col >= 0 && row < Ly_ && col < Lx_, 1, "ReplaceOneSiteTrace: site outside the lattice");
     const int nc = ncand > 0 ? ncand : 1;
     SiteSel sa = cfg_site(row, col);
@@ -448,6 +454,11 @@ class Engine : public EngineBase {
 
   void punch_hole(int row, int col, int orient, double *out) override {   // grow.h:150-183
     require_ready();
+    if (out == nullptr && !holes_) {   // the resident hole store is persistent: allocated outside the scope below
+      holes_ = (T *)arena_.alloc(sizeof(T) * (size_t)maxw_ * Ly_ * Lx_ * slot_);
+      holes_ls_ = (double *)arena_.alloc(sizeof(double) * (size_t)maxw_ * Ly_ * Lx_);
+    }
+    ArenaScope scope(arena_);
     const DTen<T> *left, *down, *right, *up;
     double *lsum = zeros_f64();
     if (orient == HORIZONTAL) {
@@ -499,10 +510,6 @@ class Engine : public EngineBase {
       // store mode: the hole stays on the device (mantissa in its D^4 slot, compact, + log-scale)
       // for grad_accumulate -- mc_energy_grad_evaluator.h:257-278 without the PCIe round trip
       const int sites = Ly_ * Lx_, site = row * Lx_ + col;
-      if (!holes_) {
-        holes_ = (T *)arena_.alloc(sizeof(T) * (size_t)maxw_ * sites * slot_);
-        holes_ls_ = (double *)arena_.alloc(sizeof(double) * (size_t)maxw_ * sites);
-      }
       hipLaunchKernelGGL(store_hole_kernel<T>, dim3((unsigned)((res.n + 255) / 256), nw_), dim3(256), 0, stream_,
                          (const T *)res.p, res.n, holes_ + (long)site * slot_, (long)sites * slot_, (const double *)lsum,
                          holes_ls_ + site, sites);
@@ -568,6 +575,12 @@ class Engine : public EngineBase {
     PG_CHECK_HIP(hipGetLastError());
     arena_.free(d);
   }
+  void *stream_handle() override { return (void *)stream_; }
+  void grad_device_ptr(void **so, void **seo, long *n_elems) override {
+    if (!so_) grad_reset();
+    *so = so_; *seo = seo_;
+    *n_elems = (long)Ly_ * Lx_ * dp_ * slot_;
+  }
   // ---- stochastic-reconfiguration sample store (engine_sr.h) ----
   void sr_begin(int max_samples) override;
   void sr_append(const double *psi) override;
@@ -629,15 +642,22 @@ class Engine : public EngineBase {
   // cache bookkeeping: an environment is dropped if ANY walker changed the site it crosses).
   void update_local(int nsites, const int32_t *sites, const int32_t *new_states, const uint8_t *mask) override {
     require_ready();
+    // validate everything first: a failure must leave the host and device configurations untouched and in step
+    for (int k = 0; k < nsites; ++k)
+      PG_REQUIRE(sites[2 * k] >= 0 && sites[2 * k] < Ly_ && sites[2 * k + 1] >= 0 && sites[2 * k + 1] < Lx_, 1,
+                 "UpdateLocal: site outside the lattice");
+    for (int w = 0; w < nw_; ++w) {
+      if (mask && !mask[w]) continue;
+      for (int k = 0; k < nsites; ++k) {
+        const int s = new_states[(size_t)w * nsites + k];
+        PG_REQUIRE(s >= 0 && s < dp_, 4, "UpdateLocal: configuration value exceeds physical dimension");
+      }
+    }
     bool any = false;
     for (int w = 0; w < nw_; ++w) {
       if (mask && !mask[w]) continue;
       for (int k = 0; k < nsites; ++k) {
-        int r = sites[2 * k], c = sites[2 * k + 1];
-        PG_REQUIRE(r >= 0 && r < Ly_ && c >= 0 && c < Lx_, 1, "UpdateLocal: site outside the lattice");
-        int s = new_states[(size_t)w * nsites + k];
-        PG_REQUIRE(s >= 0 && s < dp_, 4, "UpdateLocal: configuration value exceeds physical dimension");
-        hcfg_[(size_t)w * Ly_ * Lx_ + r * Lx_ + c] = s;
+        hcfg_[(size_t)w * Ly_ * Lx_ + sites[2 * k] * Lx_ + sites[2 * k + 1]] = new_states[(size_t)w * nsites + k];
         any = true;
       }
     }
@@ -688,9 +708,9 @@ class Engine : public EngineBase {
   }
   size_t device_bytes() const override { return arena_.total_bytes(); }
   void stats(double *out, int n) override {
-    double v[7] = {(double)n_absorb_, (double)n_jacobi_, (double)jacobi_sweeps_sum_, (double)arena_.total_bytes(),
-                   (double)jacobi_sweeps_max_, live_sum_, live_full_};
-    for (int i = 0; i < n && i < 7; ++i) out[i] = v[i];
+    double v[8] = {(double)n_absorb_, (double)n_jacobi_, (double)jacobi_sweeps_sum_, (double)arena_.total_bytes(),
+                   (double)jacobi_sweeps_max_, live_sum_, live_full_, (double)live_max_};
+    for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
   }
   hipStream_t stream() const { return stream_; }
 
@@ -698,6 +718,10 @@ class Engine : public EngineBase {
   void profile_enable(int on) override {
     prof_resolve();
     prof_on_ = on != 0;
+    if (prof_on_ && !flopc_) {   // persistent: allocated here, never inside an ArenaScope'd operation
+      flopc_ = (unsigned long long *)arena_.alloc(sizeof(unsigned long long) * 2 * PROF_NCAT);
+      PG_CHECK_HIP(hipMemsetAsync(flopc_, 0, sizeof(unsigned long long) * 2 * PROF_NCAT, stream_));
+    }
   }
   void profile_read(double *out) override {
     prof_resolve();
@@ -723,10 +747,6 @@ class Engine : public EngineBase {
     r.cat = cat; r.alg = alg_flops; r.exec = exec_flops;
     PG_CHECK_HIP(hipEventRecord(r.a, stream_));
     prof_.push_back(r);
-    if (!flopc_) {
-      flopc_ = (unsigned long long *)arena_.alloc(sizeof(unsigned long long) * 2 * PROF_NCAT);
-      PG_CHECK_HIP(hipMemsetAsync(flopc_, 0, sizeof(unsigned long long) * 2 * PROF_NCAT, stream_));
-    }
     tg_flop_counter = flopc_ + cat;
     tg_byte_counter = flopc_ + PROF_NCAT + cat;
   }
@@ -838,6 +858,7 @@ class Engine : public EngineBase {
   // replaced tensors, ReplaceTNNSiteTrace); 1 = one BTen per walker.
   BTenDev bten_step(int post, const BTenDev &bt, const DTen<T> &mps1, const SiteSel &ss, const DTen<T> &mps2,
                     int ncand, bool normalise, int bt_ncand = 1) {
+    ArenaScope scope(arena_);
     const int nb = nw_ * ncand, nb1 = nw_ * bt_ncand;
     PG_REQUIRE(ncand % bt_ncand == 0 && (!normalise || ncand == 1), 1, "BTen step: bad candidate batching");
     int dd[4], st[4];
@@ -989,6 +1010,7 @@ class Engine : public EngineBase {
   long n_var_iters_ = 0;
   long n_absorb_ = 0, n_jacobi_ = 0, jacobi_sweeps_sum_ = 0, jacobi_sweeps_max_ = 0;
   double live_sum_ = 0, live_full_ = 0;   // diagnostics: sum of live carry rows / sum of carry sizes
+  long live_max_ = 0;                     // ... and the largest live carry of any walker (> 32: the dense route ran)
   T *holes_ = nullptr;                    // resident hole store [walker][site][D^4]
   double *holes_ls_ = nullptr;            // its log-scales [walker][site]
   double *so_ = nullptr, *seo_ = nullptr; // gradient accumulators

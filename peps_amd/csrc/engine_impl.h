@@ -86,6 +86,7 @@ void Engine<T>::absorb(int pos, int num) {
 template <typename T>
 typename Engine<T>::BMPSDev Engine<T>::absorb_svd(int pos, int num, const BMPSDev &in) {
   static const bool no_shrink = getenv("PEPSGPU_NO_BOND_SHRINK") != nullptr;
+  ArenaScope scope(arena_);   // a throw inside returns every temporary and the half-built BMPS to the arena
   BMPSDev out;
   if (!absorb_impl(pos, num, no_shrink, in, out)) {
     free_bmps(out);
@@ -283,7 +284,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         std::vector<int> h(nw_);
         PG_CHECK_HIP(hipMemcpyAsync(h.data(), ml, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
         PG_CHECK_HIP(hipStreamSynchronize(stream_));
-        for (int v : h) { live_sum_ += v; live_full_ += cols; }
+        for (int v : h) { live_sum_ += v; live_full_ += cols; live_max_ = std::max<long>(live_max_, v); }
       }
       mdyn[i + 1] = ml;
       mmul[i + 1] = 1;

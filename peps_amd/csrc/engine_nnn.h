@@ -20,6 +20,7 @@ template <typename T>
 typename Engine<T>::BTenDev Engine<T>::bten2_step(int post, const BTenDev &bt, const DTen<T> &mps1, const SiteSel &s1,
                                                   const SiteSel &s2, const DTen<T> &mps2, int ncand, int bt_ncand,
                                                   bool normalise) {
+  ArenaScope scope(arena_);
   const int nb = nw_ * ncand, nb1 = nw_ * bt_ncand;
   PG_REQUIRE(ncand % bt_ncand == 0 && (!normalise || ncand == 1), 1, "BTen2 step: bad candidate batching");
   int d1[4], st1[4], d2[4], st2[4];
@@ -198,6 +199,7 @@ void Engine<T>::shift_bten2_window(int pos, int slice) {   // grow.h:523-527
 template <typename T>
 void Engine<T>::replace_nnn_trace(int row1, int col1, int dir, int orient, int ncand, const int32_t *cand, double *out) {
   require_ready();
+  ArenaScope scope(arena_);
   const int row2 = row1 + 1, col2 = col1 + 1;
   PG_REQUIRE(row1 >= 0 && col1 >= 0 && row2 < Ly_ && col2 < Lx_, 1, "ReplaceNNNSiteTrace: plaquette outside the lattice");
   const int nc = ncand > 0 ? ncand : 1;
@@ -236,6 +238,7 @@ void Engine<T>::replace_nnn_trace(int row1, int col1, int dir, int orient, int n
 template <typename T>
 void Engine<T>::replace_tnn_trace(int row, int col, int orient, int ncand, const int32_t *cand, double *out) {
   require_ready();
+  ArenaScope scope(arena_);
   const int nc = ncand > 0 ? ncand : 1;
   PG_REQUIRE(row >= 0 && col >= 0 && (orient == HORIZONTAL ? (col + 2 < Lx_ && row < Ly_) : (row + 2 < Ly_ && col < Lx_)), 1,
              "ReplaceTNNSiteTrace: sites outside the lattice");
@@ -282,6 +285,7 @@ void Engine<T>::replace_tnn_trace(int row, int col, int orient, int ncand, const
 template <typename T>
 void Engine<T>::replace_sqrt5_trace(int row1, int col1, int dir, int orient, int ncand, const int32_t *cand, double *out) {
   require_ready();
+  ArenaScope scope(arena_);
   const int nc = ncand > 0 ? ncand : 1;
   int *dc = upload_cand(ncand, 2, cand);
   const int cl = ncand > 0 ? 0 : -1, cr = ncand > 0 ? 1 : -1;

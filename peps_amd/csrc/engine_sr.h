@@ -219,6 +219,7 @@ void Engine<T>::sr_cg_solve(const double *b, const double *x0, double diag_shift
                             double abs_tol, int recompute_interval, double ortho_threshold, double *x_out,
                             double *residual_norm, int *iterations, int *reason) {
   PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_cg_solve: no samples");
+  ArenaScope scope(arena_);
   const int sites = Ly_ * Lx_;
   const long n = (long)sites * dp_ * slot_;
   const double scale = 1.0 / sr_n_;

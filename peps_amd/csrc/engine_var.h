@@ -217,6 +217,7 @@ template <typename T>
 typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, const BMPSDev &in) {
   const int N = mps_len(pos);
   PG_REQUIRE((int)in.t.size() == N && N > 2, 3, "MultiplyMPO (variational): MPS/MPO length mismatch");
+  ArenaScope scope(arena_);
   const int ll = (pos + 3) % 4, lp = pos, lr = (pos + 1) % 4, lu = (pos + 2) % 4;   // pre, position, next, opposite legs
   struct Site { int r, c, e, p, f, u; char nm[5]; };
   std::vector<Site> S(N);

@@ -38,6 +38,56 @@ def walker_seed(base, rank, walker, walkers_per_rank):
     return (int(base) ^ (0x9E3779B97F4A7C15 * (rank * walkers_per_rank + walker + 1))) & 0xFFFFFFFF
 
 
+class _DevicePtr:
+    """__cuda_array_interface__ view of a raw HBM pointer of the library (no copy, no ownership)."""
+
+    def __init__(self, ptr, n, typestr="<f8"):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2,
+                                         "strides": None}
+
+
+def device_tensor(ptr, n, typestr="<f8"):
+    """torch tensor aliasing n elements at device pointer ptr (the context's GPU must be torch's current device)."""
+    import torch
+    return torch.as_tensor(_DevicePtr(ptr, n, typestr), device="cuda")
+
+
+def comm_init(ctx):
+    """Give the context its own RCCL communicator (pepsgpu_comm_init) over the ranks of the initialised process group:
+    rank 0 draws the unique id, torch.distributed carries the 128 bytes (the reference host would MPI_Bcast them)."""
+    import torch.distributed as dist
+    from . import capi
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    box = [capi.comm_unique_id() if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    ctx.comm_init(dist.get_world_size(), dist.get_rank(), box[0])
+
+
+def reduced_grad(ctx, use_library_comm=False):
+    """S_O, S_EO of pepsgpu_grad_accumulate summed over the ranks (replaces MPIMeanTensor, statistics_tensor.h:37-79, and
+    the Send/Recv + reduce of exact_summation_energy_evaluator.h:252-280), returned in the state-upload layout.
+    backend "nccl": the all-reduce runs on the HBM accumulators themselves -- through torch.distributed on a zero-copy
+    alias of the device pointers, or through the library's own communicator (comm_init) -- and only the result is read
+    back.  Any other backend (gloo in the CPU / one-GPU tests): read back, reduce on the host."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return ctx.grad_read()
+    if dist.get_backend() == "nccl":
+        if use_library_comm:
+            ctx.grad_allreduce()
+        else:
+            so, seo, n = ctx.grad_device_ptr()
+            ctx.sync()                       # the accumulation kernels run on the context's stream
+            for ptr in (so, seo):
+                dist.all_reduce(device_tensor(ptr, n), op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+        return ctx.grad_read()
+    so, seo = ctx.grad_read()
+    return allreduce_sum(so.ravel()).reshape(so.shape), allreduce_sum(seo.ravel()).reshape(seo.shape)
+
+
 def _reduce(vec, op):
     import torch
     import torch.distributed as dist

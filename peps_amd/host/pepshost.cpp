@@ -9,6 +9,12 @@ using namespace qlpeps_gpu;
 
 namespace {
 thread_local std::string g_err;
+// GPU of the contractors built below: one rank per GPU -> LOCAL_RANK unless pepshost_set_device says otherwise
+int default_device() {
+  const char *e = getenv("LOCAL_RANK");
+  return e ? atoi(e) : 0;
+}
+int g_device = default_device();
 
 template <typename F>
 int guarded(F &&f) {
@@ -46,6 +52,15 @@ extern "C" {
 
 const char *pepshost_last_error(void) { return g_err.c_str(); }
 
+// HIP device of every contractor the calls below build (default: LOCAL_RANK of the launcher, else 0)
+int pepshost_set_device(int device) {
+  return guarded([&]() {
+    if (device < 0) throw std::invalid_argument("pepshost_set_device: negative device index");
+    g_device = device;
+  });
+}
+int pepshost_get_device(void) { return g_device; }
+
 // d_min < 0: D_min = chi.  scheme: 0 SVD_COMPRESS, 1 VARIATION2Site, 2 VARIATION1Site (bmps.h:31-35)
 int pepshost_set_truncate_params(int d_min, double trunc_err, int scheme, double convergence_tol, int iter_max) {
   return guarded([&]() {
@@ -61,7 +76,7 @@ int pepshost_mc_sweeps(int rows, int cols, int D, int d, int chi, int dtype, con
                        double *accept_rates_out) {
   return guarded([&]() {
     SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
-    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), n, dtype);
+    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), n, dtype, g_device);
     TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor);
     std::vector<uint64_t> sd(seeds, seeds + n);
     std::vector<double> rates, acc(n, 0.0);
@@ -85,7 +100,7 @@ int pepshost_energy_and_holes(int rows, int cols, int D, int d, int chi, int dty
                               double *energies_out, double *holes_out, double *psi_out, int *n_psi_out) {
   return guarded([&]() {
     SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
-    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), n, dtype);
+    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), n, dtype, g_device);
     TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor);
     EnergyAndHoles eh;
     if (model == 0) {
@@ -116,7 +131,7 @@ int pepshost_mc_energy_grad_partial(int rows, int cols, int D, int d, int chi, i
                                     int warmup_sweeps, int n_samples, double *packed_out, double *accept_out) {
   return guarded([&]() {
     SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
-    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), n, dtype);
+    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), n, dtype, g_device);
     TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor);
     std::vector<uint64_t> sd(seeds, seeds + n);
     MCUpdateSquareNNExchangeOBC ex(sd);
@@ -156,7 +171,7 @@ int pepshost_measure(int rows, int cols, int D, int d, int chi, int dtype, const
                      long values_cap, long *values_len) {
   return guarded([&]() {
     SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
-    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), n, dtype);
+    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), n, dtype, g_device);
     TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor);
     SquareSpinOneHalfXXZModelOBC xxz(p[0], p[1], p[2]);
     SquareSpinOneHalfJ1J2XXZModelOBC j1j2(p[0], p[1], p[2], p[3], p[4]);
@@ -215,7 +230,7 @@ int pepshost_exact_sum_partial(int rows, int cols, int D, int d, int chi, int dt
                                int batch, double *packed_out) {
   return guarded([&]() {
     SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
-    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), batch, dtype);
+    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), batch, dtype, g_device);
     std::vector<std::vector<int32_t>> all(n_configs);
     for (int i = 0; i < n_configs; ++i) all[i].assign(all_configs + (size_t)i * rows * cols, all_configs + (size_t)(i + 1) * rows * cols);
     std::vector<double> packed;
@@ -243,7 +258,7 @@ int pepshost_exact_sum_measure_partial(int rows, int cols, int D, int d, int chi
                                        int batch, char *keys_out, int keys_cap, double *values_out, long values_cap, long *values_len) {
   return guarded([&]() {
     SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
-    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), batch, dtype);
+    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), batch, dtype, g_device);
     std::vector<std::vector<int32_t>> all;
     if (n_configs >= 0) {
       all.resize(n_configs);
@@ -313,7 +328,7 @@ int pepshost_fermion_energy(int rows, int cols, int D, int d, const int32_t *nf,
     SplitIndexTPS sitps = make_state(rows, cols, D, 4 * d, sitps_ext_flat);
     FermionDecoration dec;
     dec.nf.assign(nf, nf + d);
-    BMPSContractor contractor(rows, cols, D, 4 * d, trunc_params(chi), n, dtype);
+    BMPSContractor contractor(rows, cols, D, 4 * d, trunc_params(chi), n, dtype, g_device);
     TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor, &dec);
     std::copy(comp.amplitude.begin(), comp.amplitude.end(), amplitudes_out);
     EnergyAndHoles eh;
@@ -340,7 +355,7 @@ int pepshost_fermion_exact_sum_partial(int rows, int cols, int D, int d, const i
     SplitIndexTPS sitps = make_state(rows, cols, D, 4 * d, sitps_ext_flat);
     FermionDecoration dec;
     dec.nf.assign(nf, nf + d);
-    BMPSContractor contractor(rows, cols, D, 4 * d, trunc_params(chi), batch, dtype);
+    BMPSContractor contractor(rows, cols, D, 4 * d, trunc_params(chi), batch, dtype, g_device);
     std::vector<std::vector<int32_t>> all(n_configs);
     for (int i = 0; i < n_configs; ++i) all[i].assign(all_configs + (size_t)i * rows * cols, all_configs + (size_t)(i + 1) * rows * cols);
     std::vector<double> packed;
@@ -359,7 +374,7 @@ int pepshost_fermion_mc_sweeps(int rows, int cols, int D, int d, const int32_t *
     SplitIndexTPS sitps = make_state(rows, cols, D, 4 * d, sitps_ext_flat);
     FermionDecoration dec;
     dec.nf.assign(nf, nf + d);
-    BMPSContractor contractor(rows, cols, D, 4 * d, trunc_params(chi), n, dtype);
+    BMPSContractor contractor(rows, cols, D, 4 * d, trunc_params(chi), n, dtype, g_device);
     TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor, &dec);
     std::vector<uint64_t> sd(seeds, seeds + n);
     MCUpdateSquareNNExchangeOBC ex(sd);

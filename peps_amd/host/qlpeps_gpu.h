@@ -132,8 +132,14 @@ class SplitIndexTPS {
   static SplitIndexTPS Load(const std::string &dir, size_t D) {
     std::ifstream meta(dir + "/tps_meta.txt");
     if (!meta) throw std::runtime_error("SplitIndexTPS::Load: cannot open " + dir + "/tps_meta.txt");
-    size_t rows, cols, d;
-    meta >> rows >> cols >> d;
+    long rows_l = 0, cols_l = 0, d_l = 0, bc = 0;
+    if (!(meta >> rows_l >> cols_l >> d_l) || rows_l <= 0 || cols_l <= 0 || d_l <= 0 || rows_l > 4096 || cols_l > 4096 || d_l > 4096)
+      throw std::runtime_error("SplitIndexTPS::Load: malformed tps_meta.txt (rows cols phy_dim [bc]) in " + dir);
+    // 4th field = BoundaryCondition (split_index_tps_impl.h:346-353; absent in old files = Open).  The device path is
+    // OBC only: a periodic state must not load silently as an open one.
+    if ((meta >> bc) && bc != 0)
+      throw std::runtime_error("SplitIndexTPS::Load: boundary condition " + std::to_string(bc) + " (not Open) is not supported");
+    const size_t rows = (size_t)rows_l, cols = (size_t)cols_l, d = (size_t)d_l;
     SplitIndexTPS t(rows, cols, d, D);
     for (size_t r = 0; r < rows; ++r)
       for (size_t c = 0; c < cols; ++c)
@@ -142,7 +148,12 @@ class SplitIndexTPS {
           std::ifstream f(path, std::ios::binary);
           if (!f) throw std::runtime_error("SplitIndexTPS::Load: cannot open " + path);
           std::string line;
-          auto next = [&]() { std::getline(f, line); return std::stoll(line); };
+          auto next = [&]() {
+            if (!std::getline(f, line)) throw std::runtime_error("SplitIndexTPS::Load: truncated header in " + path);
+            try { return std::stoll(line); } catch (const std::exception &) {
+              throw std::runtime_error("SplitIndexTPS::Load: malformed header in " + path);
+            }
+          };
           long rank = next();
           if (rank != 4) throw std::runtime_error("SplitIndexTPS::Load: rank-4 dense tensors only");
           size_t dims[4];
@@ -157,6 +168,10 @@ class SplitIndexTPS {
           long nblocks = next();
           if (nblocks != 1) throw std::runtime_error("SplitIndexTPS::Load: expected one dense block");
           for (int k = 0; k < 4; ++k) next();
+          for (int k = 0; k < 4; ++k)
+            if (dims[k] == 0 || dims[k] > D)
+              throw std::runtime_error("SplitIndexTPS::Load: leg " + std::to_string(k) + " of " + path + " has dimension " +
+                                       std::to_string(dims[k]) + ", the caller's bond dimension is " + std::to_string(D));
           std::vector<double> buf(dims[0] * dims[1] * dims[2] * dims[3]);
           f.read(reinterpret_cast<char *>(buf.data()), buf.size() * sizeof(double));
           if (!f) throw std::runtime_error("SplitIndexTPS::Load: truncated payload in " + path);
@@ -397,6 +412,27 @@ class BMPSContractor {
   void GradReset() { check_rc(pepsgpu_grad_reset(ctx_), ctx_); }
   void GradAccumulate(const std::vector<double> &psi, const std::vector<double> &eloc, bool exact_sum) {
     check_rc(pepsgpu_grad_accumulate(ctx_, psi.data(), eloc.data(), exact_sum), ctx_);
+  }
+  // ---- the exchange step over ranks (one contractor = one GPU = one rank): RCCL through the library ----
+  // CommInit: rank 0 draws `id` with UniqueId() and the host program broadcasts it (MPI_Bcast in the reference's MPI world).
+  static std::array<unsigned char, 128> UniqueId() {
+    std::array<unsigned char, 128> id{};
+    check_rc(pepsgpu_comm_unique_id(id.data()), nullptr);
+    return id;
+  }
+  void CommInit(int nranks, int rank, const std::array<unsigned char, 128> *id) {
+    check_rc(pepsgpu_comm_init(ctx_, nranks, rank, id ? id->data() : nullptr), ctx_);
+  }
+  int CommSize() const { return pepsgpu_comm_size(ctx_); }
+  int CommRank() const { return pepsgpu_comm_rank(ctx_); }
+  // S_O, S_EO summed over the ranks in HBM (replaces MPIMeanTensor, statistics_tensor.h:37-79)
+  void GradAllReduce() { check_rc(pepsgpu_grad_allreduce(ctx_), ctx_); }
+  // small host vectors (energies, weights, acceptance rates): staged through HBM, same communicator
+  void AllReduceSum(std::vector<double> &v) { check_rc(pepsgpu_allreduce(ctx_, v.data(), (long)v.size(), 1, 0, 0), ctx_); }
+  void AllReduceMax(std::vector<double> &v) { check_rc(pepsgpu_allreduce(ctx_, v.data(), (long)v.size(), 1, 1, 0), ctx_); }
+  // the reducer the evaluators take (std::function<void(std::vector<double>&)>), bound to this contractor's communicator
+  std::function<void(std::vector<double> &)> RcclReducer() {
+    return [this](std::vector<double> &v) { AllReduceSum(v); };
   }
   void GradRead(std::vector<double> &so, std::vector<double> &seo) const {
     const size_t n = rows_ * cols_ * d_ * D_ * D_ * D_ * D_;
@@ -1569,7 +1605,9 @@ std::map<std::string, std::vector<double>> ExactSumMeasurer(const SplitIndexTPS 
   std::vector<size_t> mine;
   for (size_t i = rank; i < all_configs.size(); i += size) mine.push_back(i);                                     // :130
   // the packed layout comes from the keys this rank evaluated (the reference broadcasts the master's, :173-206)
-  if (mine.empty() && allreduce) throw std::invalid_argument("ExactSumMeasurer: more ranks than configurations");
+  // decided from (size, count) alone, i.e. identically on every rank BEFORE any collective: a rank-divergent throw
+  // would leave the other ranks waiting in the all-reduce
+  if ((size_t)size > all_configs.size() && allreduce) throw std::invalid_argument("ExactSumMeasurer: more ranks than configurations");
   contractor.UploadState(sitps);
   for (size_t b0 = 0; b0 < mine.size(); b0 += batch) {
     const size_t nb = std::min(batch, mine.size() - b0);
@@ -1626,7 +1664,18 @@ std::pair<double, SplitIndexTPS> ExactSumEnergyEvaluator(const SplitIndexTPS &si
       acc.AccumulateDevice(comp, eh, true);
     }
   }
-  if (!mine.empty() && !fermion) acc.FetchDevice(contractor);
+  // a contractor with a communicator (CommInit) sums the tensor accumulators over the ranks where they live, in HBM
+  // (one RCCL all-reduce each, no host hop), and only the four scalars travel through the host; otherwise the packed
+  // host vector goes through the caller's `allreduce` as before
+  const bool dev_reduce = !fermion && contractor.CommSize() > 1;
+  if (dev_reduce) contractor.GradAllReduce();
+  if ((!mine.empty() || dev_reduce) && !fermion) acc.FetchDevice(contractor);
+  if (dev_reduce) {
+    std::vector<double> sc{acc.weight_sum, acc.e_loc_sum, acc.e_loc_sq_sum, (double)acc.samples};
+    contractor.AllReduceSum(sc);
+    acc.weight_sum = sc[0]; acc.e_loc_sum = sc[1]; acc.e_loc_sq_sum = sc[2]; acc.samples = (size_t)sc[3];
+    return acc.Finish();
+  }
   std::vector<double> packed = acc.Pack();
   if (allreduce) allreduce(packed);
   acc.Unpack(packed);

@@ -12,7 +12,7 @@ SYMBOLS = ["pepshost_last_error", "pepshost_mc_sweeps", "pepshost_energy_and_hol
            "pepshost_mc_energy_grad_partial", "pepshost_exact_sum_finish", "pepshost_load_sitps", "pepshost_dump_sitps",
            "pepshost_dump_configuration", "pepshost_load_configuration", "pepshost_fermion_energy",
            "pepshost_fermion_exact_sum_partial", "pepshost_fermion_mc_sweeps", "pepshost_measure",
-           "pepshost_set_truncate_params"]
+           "pepshost_set_truncate_params", "pepshost_set_device", "pepshost_get_device"]
 
 _lib = None
 
@@ -45,6 +45,19 @@ MODEL_ID = {"xxz": 0, "tfim": 1, "j1j2": 2}   # params: xxz (jz, jxy, pinning00)
 def _dims(flat):
     rows, cols, d, D = flat.shape[0], flat.shape[1], flat.shape[2], flat.shape[3]
     return rows, cols, d, D
+
+
+def set_device(device=None):
+    """GPU of every contractor the calls below build: one rank per GPU, so the default is LOCAL_RANK (else 0)."""
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    l = lib()
+    l.pepshost_set_device.argtypes = [C.c_int]
+    _ck(l.pepshost_set_device(int(device)))
+
+
+def get_device():
+    return lib().pepshost_get_device()
 
 
 def set_truncate_params(d_min=-1, trunc_err=0.0, scheme=0, convergence_tol=0.0, iter_max=0):

@@ -1,0 +1,79 @@
+"""Parity of the DENSE route of the absorption (carry rank > 32: f64 Gram GEMM, blocked Cholesky, full-size Jacobi /
+eigen truncation) at bulk shapes, end to end: device amplitude AND XXZ local energy against the float64 oracle on states of
+full rank (i.i.d. random site tensors, make_sitps(noise=1.0)), where every C3 / C4 parity test on the SURVEY 8(d) synthetic
+state only ever runs the <= 16-row kernels.  ctx.stats() proves which route ran (carry_live_max > 32)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import vmc
+from oracle.bmps import BMPSTruncateParams
+from peps_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+F32, F64 = 0, 1
+
+CASES = [("C3 10x10 D=6 chi=24", 10, 6, 24), ("6x6 D=8 chi=32", 6, 8, 32)]
+
+
+def _state(L, D):
+    from peps_amd import capi
+    sitps = synthetic.make_sitps(L, D, noise=1.0)
+    ctx = capi.Context(L, L, D, 2, 8, dtype=capi.F64, max_walkers=1)
+    ctx.state_upload(synthetic.sitps_to_flat(sitps, D))
+    ctx.set_configs(synthetic.checkerboard(L)[None])
+    psi = float(ctx.evaluate_amplitude()[0])
+    ctx.close()
+    return synthetic.rescale_sitps(sitps, psi)      # amplitudes O(1): keeps f32 ranges comfortable, nothing else
+
+
+@pytest.mark.parametrize("name,L,D,chi", CASES)
+@pytest.mark.parametrize("dt,tol_a,tol_e", [(F32, 1e-5, 1e-5), (F64, 1e-9, 1e-9)])
+def test_full_rank_amplitude_and_energy_vs_oracle(name, L, D, chi, dt, tol_a, tol_e, monkeypatch):
+    from peps_amd import capi, hostapi
+    sitps = _state(L, D)
+    flat = synthetic.sitps_to_flat(sitps, D)
+    cfgs = synthetic.make_configs(L, 4, "heisenberg", seed0=101)
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    model = vmc.SquareSpinOneHalfXXZModelOBC(1.0, 1.0, 0.0)
+    ref_a, ref_e = [], []
+    for c in cfgs:
+        comp = vmc.TPSWaveFunctionComponent(sitps, c, tp)
+        ref_a.append(comp.amplitude)
+        ref_e.append(model.CalEnergyAndHoles(sitps, comp, False)[0])
+    ref_a, ref_e = np.array(ref_a), np.array(ref_e)
+    # which route: largest live carry of any walker (diagnostics are read back only with PEPSGPU_DEBUG_SWEEPS=1)
+    monkeypatch.setenv("PEPSGPU_DEBUG_SWEEPS", "1")
+    ctx = capi.Context(L, L, D, 2, chi, dtype=dt, max_walkers=len(cfgs))
+    monkeypatch.delenv("PEPSGPU_DEBUG_SWEEPS")
+    ctx.state_upload(flat)
+    ctx.set_configs(cfgs)
+    amps = ctx.evaluate_amplitude()
+    st = ctx.stats()
+    ctx.close()
+    assert st["carry_live_max"] > 32, st            # the dense (rank > 32) route was taken
+    assert np.max(np.abs(amps / ref_a - 1)) < tol_a, (amps, ref_a)
+    a2, en, _, psi = hostapi.energy_and_holes(flat, cfgs, chi, "xxz", (1.0, 1.0, 0.0), False, dt)
+    assert np.max(np.abs(a2 / ref_a - 1)) < tol_a
+    assert np.max(np.abs(en / ref_e - 1)) < tol_e, (en, ref_e)
+
+
+def test_full_rank_route_consistency_c4_batch():
+    """full-size property no oracle sample can afford: 256 C4 walkers on the full-rank state, f32 against the f64 device mode
+    (pinned to the oracle above at 1e-9), every walker within 1e-5; and no walker flagged."""
+    from peps_amd import capi
+    L, D, chi, _ = synthetic.CONFIGS["C4"]
+    sitps = _state(L, D)
+    flat = synthetic.sitps_to_flat(sitps, D)
+    cfgs = synthetic.make_configs(L, 256, "heisenberg", seed0=303)
+    amps = {}
+    for dt in (capi.F32, capi.F64):
+        ctx = capi.Context(L, L, D, 2, chi, dtype=dt, max_walkers=len(cfgs))
+        ctx.state_upload(flat)
+        ctx.set_configs(cfgs)
+        amps[dt] = ctx.evaluate_amplitude()
+        assert np.all(ctx.walker_flags() == 0)
+        ctx.close()
+    rel = np.abs(amps[capi.F32] / amps[capi.F64] - 1)
+    assert np.max(rel) < 1e-5, (int(np.argmax(rel)), float(np.max(rel)))
