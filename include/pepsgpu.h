@@ -196,8 +196,9 @@ int pepsgpu_sync(pepsgpu_ctx *ctx);
  * carry sizes, [7] largest live carry of any walker (> 32: the dense Gram / Cholesky / full Jacobi route ran) */
 int pepsgpu_stats(pepsgpu_ctx *ctx, double *stats_out, int n);
 /* Per-kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).
- * out = [8][5]: {ms, launches, algorithmic flops, executed flops, operand + result bytes of the live extents} per category
- * 0 contraction GEMMs, 1 f64 Gram, 2 Cholesky, 3 Jacobi, 4 select, 5 normalise, 6 BTen/trace GEMMs.
+ * out = [10][5]: {ms, launches, algorithmic flops, executed flops, operand + result bytes of the live extents} per category
+ * 0 contraction GEMMs, 1 f64 Gram, 2 Cholesky, 3 Jacobi, 4 select, 5 normalise, 6 BTen/trace GEMMs, 7 Jacobi of edge blocks,
+ * 8 Gram + Cholesky of the preconditioned truncation (mid-rank route), 9 its back-multiplication.
  * "algorithmic" = flops of the reference op the launch replaces (SURVEY.md 8d formulas). */
 int pepsgpu_profile_enable(pepsgpu_ctx *ctx, int on);
 int pepsgpu_profile_read(pepsgpu_ctx *ctx, double *out);
@@ -229,6 +230,8 @@ int pepsgpu_grad_device_ptr(pepsgpu_ctx *ctx, void **so_dev, void **seo_dev, lon
 int pepsgpu_diag_tgemm(int dtype_in, int dtype_out, const int *desc_ints, int n_ints, const void *A, size_t a_elems,
                        const void *B, size_t b_elems, void *C, size_t c_elems, int nbatch, long wA, long wB, long wC);
 int pepsgpu_diag_chol(int dtype_out, const double *G, int n, int nbatch, void *R_out);
+/* the streaming f64 Gram kernel of the forward pass (gram.h): P = [nbatch][K][n], klive (nullable) = live rows per entry */
+int pepsgpu_diag_gram_cols(int dtype, const void *P, int K, int n, int nbatch, const int32_t *klive, double *G_out);
 /* the rank-adaptive pair used by the absorption: low-rank right-looking kernel, then the blocked
  * kernel for the walkers whose rank exceeds its cap; mlive_out[b] = rows of R_out[b] that exist */
 /* the Gram-free low-rank kernel alone: P = [nbatch][K][n] (dtype), R^T R = P^T P; mlive_out[b] = -1 where

@@ -65,3 +65,58 @@ def amplitudes(sitps_flat, configs, chi, nthreads=1):
     if rc != 0:
         raise RuntimeError("cbmps_amplitudes: %s" % lib().cbmps_last_error().decode())
     return out, sec.value
+
+
+# ---- one walker per PROCESS (the reference's MPI model: one rank per core) -------------------------------------------------
+# Run as a child program (`python -m oracle.cbmps job.npz`) so that the pool forks from a process that has never touched
+# the GPU; bench.py starts it with subprocess and reads the result file.
+def _chunk(args):
+    flat, cfgs, chi = args
+    if len(cfgs) == 0:
+        return np.zeros(0)
+    a, _ = amplitudes(flat, cfgs, chi, nthreads=1)
+    return a
+
+
+def amplitudes_multiprocess(sitps_flat, configs, chi, nprocs):
+    """configs sharded round-robin over `nprocs` single-threaded worker processes; returns (amplitudes, wall seconds of the
+    compute, processes used).  Starts a child interpreter (see above)."""
+    import json
+    import sys
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        job = os.path.join(td, "job.npz")
+        np.savez(job, flat=np.ascontiguousarray(sitps_flat, dtype=np.float64), cfgs=np.ascontiguousarray(configs, dtype=np.int32),
+                 chi=int(chi), nprocs=int(nprocs))
+        env = dict(os.environ, OPENBLAS_NUM_THREADS="1", OMP_NUM_THREADS="1")
+        r = subprocess.run([sys.executable, "-m", "oracle.cbmps", job], capture_output=True, text=True, env=env,
+                           cwd=os.path.dirname(_HERE))
+        if r.returncode != 0:
+            raise RuntimeError("oracle.cbmps child failed: " + r.stdout[-2000:] + r.stderr[-2000:])
+        res = np.load(os.path.join(td, "job.npz.out.npz"))
+        return res["amps"], float(res["seconds"]), int(res["nprocs"])
+
+
+def _child_main(job):
+    import multiprocessing as mp
+    import time
+    d = np.load(job)
+    flat, cfgs, chi, nprocs = d["flat"], d["cfgs"], int(d["chi"]), int(d["nprocs"])
+    nprocs = max(1, min(nprocs, len(cfgs)))
+    lib()                                          # build / load once in the parent; the forked workers inherit it
+    shards = [cfgs[i::nprocs] for i in range(nprocs)]
+    ctx = mp.get_context("fork")
+    with ctx.Pool(nprocs) as pool:
+        pool.map(_chunk, [(flat, cfgs[:0], chi)] * nprocs)      # workers up before the clock starts
+        t0 = time.perf_counter()
+        parts = pool.map(_chunk, [(flat, s, chi) for s in shards], chunksize=1)
+        sec = time.perf_counter() - t0
+    amps = np.zeros(len(cfgs))
+    for i, p in enumerate(parts):
+        amps[i::nprocs] = p
+    np.savez(job + ".out.npz", amps=amps, seconds=sec, nprocs=nprocs)
+
+
+if __name__ == "__main__":
+    import sys
+    _child_main(sys.argv[1])

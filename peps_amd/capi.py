@@ -37,7 +37,7 @@ SYMBOLS = [
     "pepsgpu_sr_cg_solve", "pepsgpu_sr_gram", "pepsgpu_sr_weighted_sum", "pepsgpu_sr_copy_samples",
     "pepsgpu_update_local", "pepsgpu_erase_envs_after_update", "pepsgpu_evaluate_amplitude",
     "pepsgpu_walker_flags", "pepsgpu_sync", "pepsgpu_stats", "pepsgpu_profile_enable", "pepsgpu_profile_read",
-    "pepsgpu_diag_tgemm", "pepsgpu_diag_tgemm_chain", "pepsgpu_diag_chol", "pepsgpu_diag_chol_adaptive", "pepsgpu_diag_gram_chol", "pepsgpu_diag_jacobi", "pepsgpu_version",
+    "pepsgpu_diag_tgemm", "pepsgpu_diag_tgemm_chain", "pepsgpu_diag_chol", "pepsgpu_diag_chol_adaptive", "pepsgpu_diag_gram_chol", "pepsgpu_diag_gram_cols", "pepsgpu_diag_jacobi", "pepsgpu_version",
 ]
 
 
@@ -399,13 +399,14 @@ class Context:
     def sync(self):
         self._ck(self._l.pepsgpu_sync(self._h))
 
-    PROF_CATS = ("contract", "gram_f64", "cholesky", "jacobi", "select", "normalize", "env", "jacobi_edge")
+    PROF_CATS = ("contract", "gram_f64", "cholesky", "jacobi", "select", "normalize", "env", "jacobi_edge", "trunc_gram",
+                 "trunc_apply")
 
     def profile_enable(self, on=True):
         self._ck(self._l.pepsgpu_profile_enable(self._h, int(on)))
 
     def profile_read(self):
-        out = np.zeros((8, 5), dtype=np.float64)
+        out = np.zeros((len(self.PROF_CATS), 5), dtype=np.float64)
         self._ck(self._l.pepsgpu_profile_read(self._h, _dp(out)))
         return {name: {"ms": out[i, 0], "launches": int(out[i, 1]), "alg_flops": out[i, 2], "exec_flops": out[i, 3],
                        "bytes": out[i, 4]}
@@ -501,6 +502,21 @@ def diag_gram_chol(dtype, P):
     if rc != 0:
         raise RuntimeError("diag_gram_chol failed: %s" % lib().pepsgpu_last_error(None).decode())
     return R, ml
+
+
+def diag_gram_cols(dtype, P, klive=None):
+    """gram_cols_f64_kernel alone; P = [nb][K][n]; returns G [nb][n][n] float64 (64 x 64 blocks on / above the diagonal)."""
+    t = np.float32 if dtype == F32 else np.float64
+    P = np.ascontiguousarray(P, dtype=t)
+    nb, K, n = P.shape
+    G = np.zeros((nb, n, n), dtype=np.float64)
+    kl = None if klive is None else np.ascontiguousarray(klive, dtype=np.int32)
+    f = lib().pepsgpu_diag_gram_cols
+    f.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    rc = f(dtype, P.ctypes.data_as(C.c_void_p), K, n, nb, None if kl is None else _ip(kl), _dp(G))
+    if rc != 0:
+        raise RuntimeError("diag_gram_cols failed: %s" % lib().pepsgpu_last_error(None).decode())
+    return G
 
 
 def diag_jacobi(dtype, M, k, force_global=False):

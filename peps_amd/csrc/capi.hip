@@ -427,6 +427,33 @@ extern "C" int pepsgpu_diag_gram_chol(int dtype, const void *P, int K, int n, in
     else diag_gram_chol_t<double, 48>(P, K, n, nbatch, R_out, mlive_out);
   });
 }
+// gram_cols_f64_kernel alone: P = [nbatch][K][n] of type T, klive[b] (optional) = live rows; G_out = [nbatch][n][n] float64,
+// blocks on or above the diagonal (64 x 64 granularity) written, the rest left at zero
+template <typename T>
+static void diag_gram_cols_t(const void *P, int K, int n, int nbatch, const int32_t *klive, double *G) {
+  T *dP;
+  double *dG;
+  int *dk = nullptr;
+  PG_CHECK_HIP(hipMalloc(&dP, (size_t)K * n * nbatch * sizeof(T)));
+  PG_CHECK_HIP(hipMalloc(&dG, (size_t)n * n * nbatch * sizeof(double)));
+  PG_CHECK_HIP(hipMemcpy(dP, P, (size_t)K * n * nbatch * sizeof(T), hipMemcpyHostToDevice));
+  PG_CHECK_HIP(hipMemset(dG, 0, (size_t)n * n * nbatch * sizeof(double)));
+  if (klive) {
+    PG_CHECK_HIP(hipMalloc(&dk, nbatch * sizeof(int)));
+    PG_CHECK_HIP(hipMemcpy(dk, klive, nbatch * sizeof(int), hipMemcpyHostToDevice));
+  }
+  launch_gram_cols_f64<T>(0, nbatch, (const T *)dP, (long)K * n, n, n, (const int *)dk, 1, K, dG, (const int *)nullptr, 1,
+                          (const int *)nullptr, (unsigned long long *)nullptr, (unsigned long long *)nullptr);
+  PG_CHECK_HIP(hipDeviceSynchronize());
+  PG_CHECK_HIP(hipMemcpy(G, dG, (size_t)n * n * nbatch * sizeof(double), hipMemcpyDeviceToHost));
+  (void)hipFree(dP); (void)hipFree(dG); if (dk) (void)hipFree(dk);
+}
+extern "C" int pepsgpu_diag_gram_cols(int dtype, const void *P, int K, int n, int nbatch, const int32_t *klive, double *G_out) {
+  return guarded(nullptr, [&]() {
+    PG_REQUIRE(K >= 1 && n >= 1 && n <= 256 && nbatch >= 1, 1, "bad sizes");
+    if (dtype == 0) diag_gram_cols_t<float>(P, K, n, nbatch, klive, G_out); else diag_gram_cols_t<double>(P, K, n, nbatch, klive, G_out);
+  });
+}
 extern "C" int pepsgpu_diag_chol(int dtype_out, const double *G, int n, int nbatch, void *R_out) {
   return guarded(nullptr, [&]() {
     if (dtype_out == 0) diag_chol_t<float>(G, n, nbatch, R_out); else diag_chol_t<double>(G, n, nbatch, R_out);
@@ -450,6 +477,10 @@ static void diag_jacobi_t(void *M, int m, int len, int nbatch, int k, void *Vt, 
     PG_REQUIRE(m <= 256 && len <= 256, 1, "register Jacobi handles up to 256 x 256");
     hipLaunchKernelGGL(jacobi_rows_reg256_kernel, dim3(nbatch), dim3(512), 0, 0, (float *)dM, (long)m * len, m, len, len,
                        40, dsw, (const int *)nullptr, 1, 0);
+  } else if (sizeof(T) == 4 && force_global == 4) {   // tournament kernel of the preconditioned mid route (up to 128 x 128)
+    PG_REQUIRE(m <= 128 && len <= 128, 1, "regx<4,2> handles up to 128 x 128");
+    hipLaunchKernelGGL((jacobi_rows_regx_kernel<4, 2>), dim3(nbatch), dim3(256), 0, 0, (float *)dM, (long)m * len, m, len, len, 40,
+                       dsw, (const int *)nullptr, 1);
   } else if (sizeof(T) == 4 && force_global == 3) {   // one-wave-per-walker kernel (up to 32 x 256)
     PG_REQUIRE(m <= JR_SMALL_ROWS && len <= 256, 1, "small Jacobi handles up to 32 x 256");
     // per-walker live row count = rows up to the last non-zero one (mixed counts inside a launch, as in the absorption)

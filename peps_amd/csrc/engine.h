@@ -18,6 +18,7 @@
 #include "common.h"
 #include "linalg.h"
 #include "tgemm.h"
+#include "gram.h"
 
 namespace pepsgpu {
 
@@ -26,7 +27,7 @@ enum { HORIZONTAL = 0, VERTICAL = 1 };               // include/qlpeps/basic.h:1
 
 // kernel categories of the event profile (pepsgpu_profile_read)
 enum { PROF_CONTRACT = 0, PROF_GRAM = 1, PROF_CHOL = 2, PROF_JACOBI = 3, PROF_SELECT = 4, PROF_NORM = 5,
-       PROF_ENV = 6, PROF_NCAT = 8 };
+       PROF_ENV = 6, PROF_JACOBI_EDGE = 7, PROF_TRUNC_GRAM = 8, PROF_TRUNC_APPLY = 9, PROF_NCAT = 10 };
 
 struct EngineBase {
   virtual ~EngineBase() {}
@@ -94,7 +95,7 @@ struct EngineBase {
   virtual void sr_weighted_sum(const double *y, double *out) = 0;
   virtual void sr_copy_samples(void *dst_o, int32_t *dst_cfg) = 0;
   virtual void profile_enable(int on) = 0;
-  virtual void profile_read(double *out) = 0;   // [PROF_NCAT][5]: ms, launches, algorithmic flops, executed flops, operand+result bytes
+  virtual void profile_read(double *out) = 0;   // [PROF_NCAT = 10][5]: ms, launches, algorithmic flops, executed flops, operand+result bytes
 };
 
 template <typename T> struct EinView;
@@ -205,6 +206,11 @@ class Engine : public EngineBase {
     // kmax[b] = max over the walkers of live[b] (host copy; -1 = unknown): the next absorption sizes the static
     // shape of its new bond b from it instead of chi
     std::vector<int> kmax;
+    // mlmax[i] = max over the walkers of the live carry rows at site i of the absorption that built this BMPS (-1 =
+    // unknown).  A performance hint only: the next absorption skips the launches of the mid-rank truncation route at
+    // the sites where no walker came near it (the general kernels take whatever was mispredicted).
+    std::vector<int> mlmax;
+    int depth = 0;   // rows absorbed so far (0 = the vacuum boundary): the carry rank can grow by the factor D per row at first
   };
   struct BTenDev {
     DTen<T> t;
@@ -982,7 +988,8 @@ class Engine : public EngineBase {
                      const DTen<T> &mps2, int ncand, int bt_ncand, bool normalise);
   void finish_dot4(const DTen<T> &a, const DTen<T> &b, int nc, double *lsum, double *out);
   int *upload_cand(int ncand, int ncols, const int32_t *cand);
-  void launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t need, const int *mdyn, int mdyn_mul);
+  void launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t need, const int *mdyn, int mdyn_mul, int mid_hi = 0);
+  static bool jacobi_small_ok(int len, int m, const int *mdyn);
 
   int Ly_, Lx_, D_, dp_, chi_min_, chi_;
   double trunc_err_;

@@ -21,15 +21,24 @@ void Engine<T>::add_log(double *acc, const double *a) {
 
 // Jacobi dispatch: LDS-resident generic kernel when the block fits, register-resident kernel for
 // the f32 bulk blocks (<= 256 x 256), global-memory generic kernel otherwise (f64 bulk blocks).
+// mid_hi > 0: walkers with 32 < rows <= mid_hi are on the preconditioned mid route (absorb_impl) and are skipped here.
 template <typename T>
-void Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t need, const int *mdyn, int mdyn_mul) {
+bool Engine<T>::jacobi_small_ok(int len, int m, const int *mdyn) {
+  if constexpr (sizeof(T) == 4) {
+    static const bool no_small = getenv("PEPSGPU_NO_SMALLJACOBI") != nullptr;
+    return len <= 256 && !no_small && (mdyn || m <= JR_SMALL_ROWS);
+  }
+  return false;
+}
+
+template <typename T>
+void Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t need, const int *mdyn, int mdyn_mul, int mid_hi) {
   int small = 0;
   if constexpr (sizeof(T) == 4) {
     static const bool no_reg = getenv("PEPSGPU_NO_REGJACOBI") != nullptr;
-    static const bool no_small = getenv("PEPSGPU_NO_SMALLJACOBI") != nullptr;
     // walkers whose block has at most 32 existing rows: one wave each (jacobi_rows_small_kernel);
     // the kernels below return at once for those walkers
-    if (len <= 256 && !no_small && (mdyn || m <= JR_SMALL_ROWS)) {
+    if (jacobi_small_ok(len, m, mdyn)) {
       small = 1;
       static const bool no_tiny = getenv("PEPSGPU_NO_TINYJACOBI") != nullptr;
       if (!no_tiny) {   // walkers with <= 16 rows first (low register count: all of them resident at once)
@@ -48,12 +57,18 @@ void Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
       PG_CHECK_HIP(hipGetLastError());
       if (m <= JR_SMALL_ROWS) return;
     }
+    if (mid_hi && m <= mid_hi) return;                 // every remaining walker is on the mid route
+    const int skip = mid_hi ? mid_hi : small;          // rows <= max(skip, 32) are taken elsewhere
     if (!use_lds && m <= 256 && len <= 256 && !no_reg) {
       hipLaunchKernelGGL(jacobi_rows_reg256_kernel, dim3(nw_), dim3(512), 0, stream_, (float *)M, wM, m, len, len, 40,
-                         sweeps_, mdyn, mdyn_mul, small);
+                         sweeps_, mdyn, mdyn_mul, skip);
       PG_CHECK_HIP(hipGetLastError());
       return;
     }
+    hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), use_lds ? need : 0, stream_, M, wM, m, len, len, 40,
+                       use_lds, sweeps_, mdyn, mdyn_mul, skip);
+    PG_CHECK_HIP(hipGetLastError());
+    return;
   }
   hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), use_lds ? need : 0, stream_, M, wM, m, len, len, 40,
                      use_lds, sweeps_, mdyn, mdyn_mul, small);
@@ -243,7 +258,9 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
                                                 R[i + 1].p, R[i + 1].n, ml, a2, (const int *)clive[i + 1], npass);
         prof_end();
       }
-      if (clive[i + 1]) {   // the Gram GEMM reads whole rows: define the never-written columns (flagged walkers only)
+      static const bool no_gd = getenv("PEPSGPU_NO_GRAMDIRECT") != nullptr;
+      const bool gram_direct = !no_gd && cols >= 32 && cols <= 256;
+      if (clive[i + 1] && !gram_direct) {   // the Gram GEMM reads whole rows: define the never-written columns (flagged walkers only)
         hipLaunchKernelGGL(zero_dead_cols_kernel<T>, dim3(nw_), dim3(256), 0, stream_, P.p, P.n, cols, (const int *)mdyn[i],
                            mmul[i] * u, rows, a2, (const int *)clive[i + 1], (const int *)(fused ? ml : nullptr));
         PG_CHECK_HIP(hipGetLastError());
@@ -260,7 +277,12 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         // algorithmic flops of the op this replaces: geqrf + orgqr of (rows x cols)
         prof_begin(PROF_GRAM, nw_ * 2.0 * (2.0 * rows * (double)cols * cols - 2.0 / 3.0 * (double)cols * cols * cols),
                    nw_ * (double)cols * (cols + TG_BN) * rows);
-        tgemm_launch<T, T, double, double>(stream_, g, P.p, P.p, G);
+        if (gram_direct)   // wave-per-block streaming kernel (gram.h): no LDS, no barrier; dead columns masked at the load
+          launch_gram_cols_f64<T>(stream_, nw_, (const T *)P.p, P.n, cols, cols, (const int *)mdyn[i], mmul[i] * u, rows, G,
+                                  (const int *)(fused ? ml : nullptr), a2, (const int *)clive[i + 1], tg_flop_counter,
+                                  tg_byte_counter);
+        else
+          tgemm_launch<T, T, double, double>(stream_, g, P.p, P.p, G);
         prof_end();
       }
       const size_t smem = chol_smem_bytes(cols);
@@ -268,7 +290,10 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
       prof_begin(PROF_CHOL, 0.0, nw_ * (double)cols * cols * cols / 3.0);
       static const bool no_lowrank = getenv("PEPSGPU_NO_LOWRANK_CHOL") != nullptr;
-      const bool lowrank = ml && !no_lowrank && cols <= 256 * CH_LR_Q;
+      // (hint from the row absorbed before: when its carry at this site ran well above the cap, every walker would spend 32
+      // steps here only to be handed on; the blocked kernel takes any rank)
+      const bool above_cap = in.depth >= 3 && (int)in.mlmax.size() > i + 1 && in.mlmax[i + 1] > CH_LR_CAP + 8;
+      const bool lowrank = ml && !no_lowrank && cols <= 256 * CH_LR_Q && !above_cap;
       if (lowrank) {   // walkers of rank <= CH_LR_CAP finish here; the others are flagged for the blocked kernel
         const size_t lsm = chol_lowrank_smem_bytes(cols);
         allow_dynamic_lds(reinterpret_cast<const void *>(&chol_lowrank_kernel<T>), lsm);
@@ -386,6 +411,57 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       prof_end();
     }
     // rows of M -> mutually orthogonal (sigma_k v_k^T)
+    //
+    // Mid route (f32, 32 < live rows <= 128: the usual size of the carry on states of higher rank): the Jacobi runs on
+    // the triangular factor B of the small Gram matrix instead of on M itself,
+    //     G = M M^T (f64 MFMA, ml x ml),  B^T B = G (Cholesky),  rows of B --Jacobi--> sigma_k u_k^T,
+    //     Vt = rows of (U^T M) normalised,
+    // the preconditioned one-sided Jacobi SVD (Drmac / Veselic): rows are ml <= 128 long instead of u * k2, the
+    // triangular factor converges in about half the sweeps, and four walkers share a CU.  sigma and Vt are those of M:
+    // select_rows_kernel sees the same singular values, the truncation rule is unchanged.
+    constexpr int MID_HI = 128;
+    bool mid = false;
+    if constexpr (sizeof(T) == 4) {
+      static const bool no_mid = getenv("PEPSGPU_NO_MIDROUTE") != nullptr;
+      // hint from the row absorbed before (the carry rank grows by a few states per row): no walker near 32 live rows
+      // at this site -> skip the route's launches; walkers that do exceed 32 rows are then taken by the general kernels
+      const bool near = in.depth < 3 || (int)in.mlmax.size() <= i || in.mlmax[i] < 0 || in.mlmax[i] > 24;
+      mid = !no_mid && adaptive && m > JR_SMALL_ROWS && uk <= 1024 && near;
+    }
+    int *midflag = nullptr, *nmid = nullptr, *mB = nullptr;
+    DTen<T> Bt, Ut;
+    const int GS = std::min(m, MID_HI);
+    if (mid) {
+      midflag = (int *)arena_.alloc(sizeof(int) * nw_);
+      nmid = (int *)arena_.alloc(sizeof(int) * nw_);
+      mB = (int *)arena_.alloc(sizeof(int) * nw_);
+      PG_CHECK_HIP(hipMemsetAsync(mB, 0, sizeof(int) * nw_, stream_));
+      const int lo = jacobi_small_ok(uk, m, mdyn[i]) ? JR_SMALL_ROWS : 0;
+      hipLaunchKernelGGL(mid_route_flag_kernel, dim3((nw_ + 255) / 256), dim3(256), 0, stream_, (const int *)mdyn[i], mmul[i], m, lo,
+                         MID_HI, nw_, midflag, nmid);
+      PG_CHECK_HIP(hipGetLastError());
+      double *Gm = (double *)arena_.alloc(sizeof(double) * (size_t)GS * GS * nw_);
+      {
+        TGemmDesc g;
+        g.I[2] = m; g.sAi[2] = uk; g.sCi[2] = GS;
+        g.K[2] = uk; g.sAk[2] = 1; g.sBk[2] = 1;
+        g.J[2] = m; g.sBj[2] = uk; g.sCj[2] = 1;
+        g.wA = M.n; g.wB = M.n; g.wC = (long)GS * GS; g.nbatch = nw_;
+        g.dI[2].p = nmid; g.dJ[2].p = nmid;
+        g.upper_only = 1;
+        g.batch_flag = midflag;
+        prof_begin(PROF_TRUNC_GRAM, 0.0, 0.0);
+        tgemm_launch<T, T, double, double>(stream_, g, M.p, M.p, Gm);
+      }
+      Bt = alloc_ten(GS, GS, 1);
+      const size_t smem = chol_smem_bytes(GS);
+      allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
+      hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nw_), dim3(256), smem, stream_, Gm, (long)GS * GS, GS, Bt.p, Bt.n, mB, 0, GS,
+                         (const int *)nmid, 1, (const int *)midflag);
+      PG_CHECK_HIP(hipGetLastError());
+      prof_end();
+      arena_.free(Gm);
+    }
     {
       const size_t need = sizeof(T) * (size_t)m * (uk | 1);
       const int use_lds = need <= JACOBI_LDS_MAX;
@@ -393,23 +469,39 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       {   // reference op: gesdd of the (m x uk) block: 4 r c^2 + 22 c^3, r >= c
         const double rr = std::max(m, uk), cc = std::min(m, uk);
         // category 3 = register kernel (bulk blocks), 7 = generic LDS/global kernel (edge blocks)
-        const bool bulk = sizeof(T) == 4 && !use_lds && m <= 256 && uk <= 256;
-        prof_begin(bulk ? PROF_JACOBI : 7, nw_ * (4.0 * rr * cc * cc + 22.0 * cc * cc * cc), 0.0);
+        const bool bulk = sizeof(T) == 4 && ((!use_lds && m <= 256 && uk <= 256) || mid);
+        prof_begin(bulk ? PROF_JACOBI : PROF_JACOBI_EDGE, nw_ * (4.0 * rr * cc * cc + 22.0 * cc * cc * cc), 0.0);
       }
-      launch_jacobi(M.p, M.n, m, uk, use_lds, need, mdyn[i], mmul[i]);
+      launch_jacobi(M.p, M.n, m, uk, use_lds, need, mdyn[i], mmul[i], mid ? MID_HI : 0);
+      if constexpr (sizeof(T) == 4) {
+        if (mid) {
+          static const bool dbg_t1 = getenv("PEPSGPU_MID_T1") != nullptr;
+          if (dbg_t1)
+            hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), 0, stream_, Bt.p, Bt.n, GS, GS, GS, 40, 0, sweeps_,
+                               (const int *)mB, 1, 0);
+          else {   // <= 64 live rows: two waves per walker (24 KB of LDS: six walkers per CU), else four
+            hipLaunchKernelGGL((jacobi_rows_regx_kernel<2, 2>), dim3(nw_), dim3(128), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS,
+                               40, sweeps_, (const int *)mB, 1, 0);
+            if (GS > 64)
+              hipLaunchKernelGGL((jacobi_rows_regx_kernel<4, 2>), dim3(nw_), dim3(256), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS,
+                                 40, sweeps_, (const int *)mB, 1, 64);
+          }
+          PG_CHECK_HIP(hipGetLastError());
+        }
+      }
       prof_end();
       ++n_jacobi_;
       if (dbg_sweeps_) {   // diagnostics only: per-launch sweep counts (forces a sync)
         std::vector<int> hs(nw_);
         PG_CHECK_HIP(hipMemcpyAsync(hs.data(), sweeps_, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
         PG_CHECK_HIP(hipStreamSynchronize(stream_));
-        long mx = 0, live = 0, sw_sum = 0;
-        for (int v : hs) { mx = std::max<long>(mx, v & 0xFF); sw_sum += v & 0xFF; live += v >> 8; }
+        long mx = 0, live = 0, sw_sum = 0, live_mx = 0;
+        for (int v : hs) { mx = std::max<long>(mx, v & 0xFF); sw_sum += v & 0xFF; live += v >> 8; live_mx = std::max<long>(live_mx, v >> 8); }
         jacobi_sweeps_sum_ += mx;
         jacobi_sweeps_max_ = std::max(jacobi_sweeps_max_, mx);
         if (getenv("PEPSGPU_DEBUG_VERBOSE"))
-          fprintf(stderr, "[pepsgpu] jacobi m=%d len=%d sweeps max=%ld mean=%.2f live_rows_mean=%.1f\n", m, uk, mx,
-                  (double)sw_sum / nw_, (double)live / nw_);
+          fprintf(stderr, "[pepsgpu] jacobi m=%d len=%d sweeps max=%ld mean=%.2f live_rows_mean=%.1f live_rows_max=%ld\n", m, uk, mx,
+                  (double)sw_sum / nw_, (double)live / nw_, live_mx);
       }
     }
     const int k_full = std::min(chi_, std::min(m, uk));
@@ -424,9 +516,55 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     prof_begin(PROF_SELECT, 0.0, 0.0);
     if (bond_adapt) kn[i] = (int *)arena_.alloc(sizeof(int) * nw_);
     hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)M.p, M.n, m, uk, uk, k, V.p,
-                       V.n, (T *)nullptr, 0L, (const int *)mdyn[i], mmul[i], kn[i], trunc_err_, chi_min_, (double *)nullptr);
+                       V.n, (T *)nullptr, 0L, (const int *)mdyn[i], mmul[i], kn[i], trunc_err_, chi_min_, (double *)nullptr,
+                       (const int *)midflag, 0);
     PG_CHECK_HIP(hipGetLastError());
-    prof_end();
+    if (mid) {
+      // sigma_k u_k^T = the rotated rows of B: the chi largest, normalised -> U^T (k x GS), kB = how many are live
+      int *kB = (int *)arena_.alloc(sizeof(int) * nw_);
+      PG_CHECK_HIP(hipMemsetAsync(kB, 0, sizeof(int) * nw_, stream_));
+      Ut = alloc_ten(k, GS, 1);
+      hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)Bt.p, Bt.n, GS, GS, GS, k, Ut.p,
+                         Ut.n, (T *)nullptr, 0L, (const int *)mB, 1, kB, trunc_err_, chi_min_, (double *)nullptr,
+                         (const int *)midflag, 1);
+      PG_CHECK_HIP(hipGetLastError());
+      prof_end();
+      // V' = U^T M (k x uk): row q is sigma_q v_q^T up to the rounding of u_q -- an error of 1e-7 in u_q brings in the
+      // dominant directions with weight 1e-7 sigma_1, which is NOT small against a row of size sigma_q << sigma_1.  So the k
+      // rows are not normalised as they come: they are handed to the one-sided Jacobi once more (a k-row problem: the
+      // one-wave kernels), which restores their mutual orthogonality relative to each row's own norm in one or two
+      // sweeps; what is left is contamination by the discarded directions only, of relative size 1e-7.
+      DTen<T> Vp = alloc_ten(k, u, k2);
+      {
+        TGemmDesc g;
+        g.I[2] = k; g.sAi[2] = GS; g.sCi[2] = uk;
+        g.K[2] = m; g.sAk[2] = 1; g.sBk[2] = uk;
+        g.J[2] = uk; g.sBj[2] = 1; g.sCj[2] = 1;
+        g.wA = Ut.n; g.wB = M.n; g.wC = Vp.n; g.nbatch = nw_;
+        g.dK[2].p = nmid;
+        g.batch_flag = midflag;
+        prof_begin(PROF_TRUNC_APPLY, 0.0, 0.0);
+        tgemm_launch<T, T, T, double>(stream_, g, Ut.p, M.p, Vp.p);   // f64 accumulation: small sigma_q are differences
+        prof_end();
+      }
+      {
+        const size_t need = sizeof(T) * (size_t)k * (uk | 1);
+        const int use_lds = need <= JACOBI_LDS_MAX;
+        if (use_lds) allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), need);
+        prof_begin(PROF_JACOBI, 0.0, 0.0);
+        launch_jacobi(Vp.p, Vp.n, k, uk, use_lds, need, kB, 1);      // walkers off the route have kB = 0 rows
+        prof_end();
+      }
+      prof_begin(PROF_SELECT, 0.0, 0.0);   // normalise, count the live rows; the truncation rule was applied on B already
+      hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)Vp.p, Vp.n, k, uk, uk, k, V.p,
+                         V.n, (T *)nullptr, 0L, (const int *)kB, 1, kn[i], 0.0, 0, (double *)nullptr, (const int *)midflag, 1);
+      PG_CHECK_HIP(hipGetLastError());
+      prof_end();
+      free_ten(Bt); free_ten(Ut); free_ten(Vp);
+      arena_.free(midflag); arena_.free(nmid); arena_.free(mB); arena_.free(kB);
+    } else {
+      prof_end();
+    }
     free_ten(M);
     out.t[i] = V;
     // Ynew[(l,a),q] = sum_{(u,k2)} Tt[(l,a),(u,k2)] V[q,(u,k2)]
@@ -454,26 +592,35 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     free_ten(Tt);
     Y = Yn;
   }
+  out.live = kn;
+  out.kmax.assign(N + 1, -1);
+  out.mlmax.assign(N, -1);
+  out.depth = in.depth + 1;
+  bool ok = true;
+  if (bond_adapt) {   // one small read-back per absorption: the maximum live count of every new bond and of every carry
+    const int ntab = 2 * N + 1;
+    std::vector<const int *> htab(ntab, nullptr);
+    for (int b = 0; b <= N; ++b) htab[b] = kn[b];
+    for (int i = 0; i < N; ++i) htab[N + 1 + i] = mdyn[i];
+    std::vector<int> hmax(ntab, -1);
+    const int **dtab = (const int **)arena_.alloc(sizeof(int *) * ntab);
+    int *dmax = (int *)arena_.alloc(sizeof(int) * ntab);
+    PG_CHECK_HIP(hipMemcpyAsync(dtab, htab.data(), sizeof(int *) * ntab, hipMemcpyHostToDevice, stream_));
+    hipLaunchKernelGGL(max_over_walkers_kernel, dim3(ntab), dim3(256), 0, stream_, (const int *const *)dtab, nw_, dmax);
+    PG_CHECK_HIP(hipGetLastError());
+    PG_CHECK_HIP(hipMemcpyAsync(hmax.data(), dmax, sizeof(int) * ntab, hipMemcpyDeviceToHost, stream_));
+    PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    arena_.free(dtab); arena_.free(dmax);
+    for (int b = 0; b <= N; ++b) out.kmax[b] = hmax[b];
+    for (int i = 0; i < N; ++i) out.mlmax[i] = mdyn[i] ? std::min(R[i].d[0], hmax[N + 1 + i] * mmul[i]) : R[i].d[0];
+    for (int i = 1; i < N; ++i)
+      if (kstat[i] < kfull[i] && out.kmax[i] >= kstat[i]) ok = false;   // a walker filled a shrunk bond: maybe clipped
+  }
   for (auto &t : R) arena_.free(t.p);
   {   // the dynamic-extent arrays (several R_i may share one)
     int *last = nullptr;
     for (int *p : mdyn)
       if (p && p != last) { arena_.free(p); last = p; }
-  }
-  out.live = kn;
-  out.kmax.assign(N + 1, -1);
-  bool ok = true;
-  if (bond_adapt) {   // one small read-back per absorption: the maximum live count of every new bond
-    const int **dtab = (const int **)arena_.alloc(sizeof(int *) * (N + 1));
-    int *dmax = (int *)arena_.alloc(sizeof(int) * (N + 1));
-    PG_CHECK_HIP(hipMemcpyAsync(dtab, kn.data(), sizeof(int *) * (N + 1), hipMemcpyHostToDevice, stream_));
-    hipLaunchKernelGGL(max_over_walkers_kernel, dim3(N + 1), dim3(256), 0, stream_, (const int *const *)dtab, nw_, dmax);
-    PG_CHECK_HIP(hipGetLastError());
-    PG_CHECK_HIP(hipMemcpyAsync(out.kmax.data(), dmax, sizeof(int) * (N + 1), hipMemcpyDeviceToHost, stream_));
-    PG_CHECK_HIP(hipStreamSynchronize(stream_));
-    arena_.free(dtab); arena_.free(dmax);
-    for (int i = 1; i < N; ++i)
-      if (kstat[i] < kfull[i] && out.kmax[i] >= kstat[i]) ok = false;   // a walker filled a shrunk bond: maybe clipped
   }
   if (ok) ++n_absorb_;
   return ok;

@@ -1,0 +1,125 @@
+// f64-accumulated Gram matrix of the columns of P for the forward pass of the absorption (gfx950):
+//
+//     G[b] = P[b]^T P[b],   P = K x n (K live rows per walker, n <= 256 columns, row stride ld), G = n x n float64
+//
+// It replaces the R factor of qlten::QR at bmps_impl.h:821 together with the Cholesky kernels of linalg.h (only
+// R^T R = P^T P is ever needed downstream).  The products of two f32 values are exact in f64, so the Gram carries the
+// f32 data without squaring their rounding; v_mfma_f64_16x16x4_f64 does the accumulation.
+//
+// Shape of the work: per walker a few hundred rows and 64..256 columns -- too small for an LDS-tiled GEMM to amortise
+// its barriers (tgemm_kernel reaches 11 TF here), so there is no LDS and no barrier at all: one WAVE owns one 64 x 64
+// block of G (16 accumulator tiles of 16 x 16 in registers) and streams the rows of P straight from global memory / L2
+// into the MFMA operand layout (lane l holds P[4 ks + l / 16][c0 + l % 16]: four 64-byte row segments per load, the A
+// and the B operand of a tile are the same kind of load).  8 loads feed 16 MFMAs per step of four rows; the next step's
+// loads are in flight during the MFMAs.  Only blocks on or above the diagonal are computed (the Cholesky reads the upper
+// triangle and the diagonal blocks); a workgroup is four independent waves = four blocks of one walker.
+#pragma once
+#include "common.h"
+
+namespace pepsgpu {
+
+typedef double gr_f64x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gram_cols_f64_kernel(const T *__restrict__ Pg, long wP, int n, int ld,
+                                                               const int *__restrict__ kdyn, int kdyn_mul, int kmax,
+                                                               double *__restrict__ Gg, long wG,
+                                                               const int *__restrict__ run_flag, int inner,
+                                                               const int *__restrict__ inner_live,
+                                                               unsigned long long *__restrict__ flopc,
+                                                               unsigned long long *__restrict__ bytec, int flop_stride) {
+  const int b = blockIdx.y;
+  if (run_flag && run_flag[b] >= 0) return;               // only the entries a cheaper kernel has declined
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nb = (n + 63) >> 6, nblk = nb * (nb + 1) / 2;
+  const int t = blockIdx.x * 4 + wave;
+  if (t >= nblk) return;
+  int bi = 0, rem = t;
+  while (rem >= nb - bi) { rem -= nb - bi; ++bi; }
+  const int bj = bi + rem;                                // bi <= bj: on or above the diagonal
+  const int K = kdyn ? min(kmax, kdyn[b] * kdyn_mul) : kmax;
+  if (flopc && t == 0 && lane == 0 && b % flop_stride == 0) {
+    atomicAdd(flopc, (unsigned long long)flop_stride * n * n * K);                 // = 2 n n K / 2 (upper triangle)
+    if (bytec) atomicAdd(bytec, (unsigned long long)flop_stride * ((unsigned long long)K * n * sizeof(T) + (unsigned long long)n * n * 4));
+  }
+  const T *P = Pg + (long)b * wP;
+  double *G = Gg + (long)b * wG;
+  const int r4 = lane >> 4, c16 = lane & 15;
+  const bool diag = bi == bj;
+  // columns are (outer, inner) with `inner` fastest; inner_live[b] (optional) = live extent of the inner index (live bond of
+  // the boundary MPS): the columns beyond it were never written and are read as zeros
+  const int ilive = inner_live ? min(inner, inner_live[b]) : inner;
+  int cola[4], colb[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    cola[c] = bi * 64 + 16 * c + c16;
+    colb[c] = bj * 64 + 16 * c + c16;
+    if (cola[c] % inner >= ilive) cola[c] = n;      // dead column: masked like a column beyond n
+    if (colb[c] % inner >= ilive) colb[c] = n;
+  }
+  gr_f64x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][c][r] = 0.0;
+
+  const int nks = (K + 3) >> 2;
+  auto load = [&](int ks, T(&av)[4], T(&bv)[4]) {
+    const int row = 4 * ks + r4;
+    const bool ok = row < K;
+    const T *pr = P + (long)row * ld;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) av[c] = (ok && cola[c] < n) ? pr[cola[c]] : T(0);
+    if (!diag) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bv[c] = (ok && colb[c] < n) ? pr[colb[c]] : T(0);
+    }
+  };
+  auto step = [&](const T(&av)[4], const T(&bv)[4]) {
+    double ad[4], bd[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ad[c] = (double)av[c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bd[c] = diag ? ad[c] : (double)bv[c];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[a], bd[c], acc[a][c], 0, 0, 0);
+  };
+  T a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { a0[c] = T(0); b0[c] = T(0); a1[c] = T(0); b1[c] = T(0); }
+  if (nks > 0) load(0, a0, b0);
+  for (int ks = 0; ks < nks; ks += 2) {
+    if (ks + 1 < nks) load(ks + 1, a1, b1);
+    step(a0, b0);
+    if (ks + 2 < nks) load(ks + 2, a0, b0);
+    if (ks + 1 < nks) step(a1, b1);
+  }
+  // accumulator layout of v_mfma_f64_16x16x4_f64: acc[r] = C[(lane >> 4) + 4 r][lane & 15]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = bi * 64 + 16 * a + r4 + 4 * r, j = bj * 64 + 16 * c + c16;
+        if (i < n && j < n) G[(long)i * n + j] = acc[a][c][r];
+      }
+}
+
+template <typename T>
+inline void launch_gram_cols_f64(hipStream_t s, int nbatch, const T *P, long wP, int n, int ld, const int *kdyn, int kdyn_mul,
+                                 int kmax, double *G, const int *run_flag, int inner, const int *inner_live,
+                                 unsigned long long *flopc, unsigned long long *bytec) {
+  if (nbatch <= 0 || n <= 0) return;
+  PG_REQUIRE(nbatch <= 65535, 1, "walker batch exceeds 65535 (grid y limit)");
+  const int nb = (n + 63) / 64, nblk = nb * (nb + 1) / 2;
+  hipLaunchKernelGGL(gram_cols_f64_kernel<T>, dim3((nblk + 3) / 4, nbatch), dim3(256), 0, s, P, wP, n, ld, kdyn, kdyn_mul, kmax, G,
+                     (long)n * n, run_flag, inner > 0 ? inner : 1, inner_live, flopc, bytec, nbatch >= 256 ? 64 : 1);
+  PG_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace pepsgpu

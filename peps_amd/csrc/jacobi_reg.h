@@ -89,7 +89,8 @@ __global__ __launch_bounds__(512) void jacobi_rows_reg256_kernel(float *__restri
                                                                  int skip_small) {
   __shared__ float4 xch[JR_SLOTS][JR_BR][64];   // 9 x 16 KiB
   if (mdyn) m = min(m, mdyn[blockIdx.x] * mdyn_mul);   // rows that exist for this walker
-  if (skip_small && m <= 2 * JR_BR) return;            // jacobi_rows_small_kernel took this walker
+  if (skip_small && m <= max(skip_small, 2 * JR_BR)) return;   // skip_small = 1: the one-wave kernels took this walker;
+                                                                // > 32: also the walkers of the preconditioned mid route
   __shared__ float xnorm[JR_SLOTS][JR_BR];
   __shared__ float s_n2[256];
   __shared__ short s_perm[256];
@@ -294,6 +295,248 @@ __global__ __launch_bounds__(512) void jacobi_rows_reg256_kernel(float *__restri
       for (int q = 0; q < 4; ++q) {
         const int c = 4 * lane + q;
         if (r < m && c < len) M[(long)r * ld + c] = v[q];
+      }
+    }
+  };
+  store_block(a, w);
+  store_block(b, nwv + w);
+  if (tid == 0 && sweeps_out) sweeps_out[blockIdx.x] = sweep | (live0 << 8);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The same tournament for the PRECONDITIONED mid-rank blocks (Engine::absorb_impl, "mid" route): the matrix is the
+// triangular factor B (B^T B = M M^T, at most 128 x 128) instead of M itself, so rows are at most 128 long (CPL = 2
+// columns per lane) and NW waves x 2 blocks x 16 rows cover it: a quarter of the registers and LDS of the 256 x 256
+// kernel, several walkers resident per CU.  Skips walkers without rows (mdyn == 0: not on this route).
+template <int CPL> struct JrRowT { float v[CPL]; };
+
+template <int CPL>
+__device__ __forceinline__ float jrx_dot(const JrRowT<CPL> &x, const JrRowT<CPL> &y) {
+  float p = x.v[0] * y.v[0];
+#pragma unroll
+  for (int q = 1; q < CPL; ++q) p = fmaf(x.v[q], y.v[q], p);
+  return p;
+}
+
+template <int CPL>
+__device__ __forceinline__ int jrx_apply(JrRowT<CPL> &x, JrRowT<CPL> &y, float &nx, float &ny, const float g, const float tol2,
+                                         const float floor2) {
+  const bool go = g * g > tol2 * nx * ny && nx > floor2 && ny > floor2;
+  if (!__any(go)) return 0;
+  const float zeta = (ny - nx) * __builtin_amdgcn_rcpf(2.f * g);
+  const float az = fabsf(zeta);
+  float t = copysignf(__builtin_amdgcn_rcpf(az + __builtin_amdgcn_sqrtf(fmaf(az, az, 1.f))), zeta);
+  t = go ? t : 0.f;
+  const float cs = __builtin_amdgcn_rsqf(fmaf(t, t, 1.f)), sn = cs * t;
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    const float xv = x.v[q], yv = y.v[q];
+    x.v[q] = cs * xv - sn * yv;
+    y.v[q] = sn * xv + cs * yv;
+  }
+  const float tg = t * g;
+  nx = fmaxf(nx - tg, 0.f);
+  ny = ny + tg;
+  return go ? 1 : 0;
+}
+
+template <int NW, int CPL>
+__global__ __launch_bounds__(NW * 64) void jacobi_rows_regx_kernel(float *__restrict__ Mg, long wM, int m, int len, int ld,
+                                                                   int max_sweeps, int *__restrict__ sweeps_out,
+                                                                   const int *__restrict__ mdyn, int mdyn_mul,
+                                                                   int lo_rows = 0) {
+  // lo_rows: walkers with at most lo_rows rows belong to a narrower instantiation launched beside this one
+  constexpr int SLOTS = NW + 1, MAXR = NW * 2 * JR_BR, NT = NW * 64;
+  __shared__ float xch[SLOTS][JR_BR][CPL][64];
+  __shared__ float xnorm[SLOTS][JR_BR];
+  __shared__ float s_n2[MAXR];
+  __shared__ short s_perm[MAXR];
+  __shared__ double s_fro[NW];
+  __shared__ int s_rot, s_live0;
+  if (mdyn) m = min(m, mdyn[blockIdx.x] * mdyn_mul);
+  if (m <= lo_rows || m > MAXR) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  float *M = Mg + (long)blockIdx.x * wM;
+  if (tid == 0) s_live0 = 0;
+  for (int r = w; r < MAXR; r += NW) {
+    float n2 = 0.f;
+    if (r < m) {
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        const int c = CPL * lane + q;
+        const float v = c < len ? M[(long)r * ld + c] : 0.f;
+        n2 = fmaf(v, v, n2);
+      }
+    }
+    n2 = jr_allsum(n2);
+    if (lane == 0) s_n2[r] = n2;
+  }
+  __syncthreads();
+  {
+    double f = 0.0;
+    for (int r = tid; r < MAXR; r += NT) f += (double)s_n2[r];
+    f = wave_sum(f);
+    if (lane == 0) s_fro[w] = f;
+    __syncthreads();
+    if (tid == 0) { double t = 0.0; for (int k = 0; k < NW; ++k) t += s_fro[k]; s_fro[0] = t; }
+    __syncthreads();
+  }
+  const float floor2 = (float)(NOISE_C * NOISE_C * (double)Eps<float>::v * (double)Eps<float>::v * s_fro[0]);
+  const float tol2 = 4.f * (float)len * Eps<float>::v * Eps<float>::v;
+  for (int r = tid; r < MAXR; r += NT) {
+    const float v = s_n2[r];
+    int rk = 0;
+    for (int q = 0; q < MAXR; ++q) {
+      const float u = s_n2[q];
+      rk += (u > v) || (u == v && q < r);
+    }
+    s_perm[rk] = (short)r;
+    if (v > floor2) atomicAdd(&s_live0, 1);
+  }
+  __syncthreads();
+  const int live0 = s_live0;
+  const int nbl = (live0 + JR_BR - 1) / JR_BR;
+  const int nwv = nbl <= 2 ? 1 : (nbl + 1) / 2;
+  const bool active = w < nwv;
+
+  JrRowT<CPL> a[JR_BR], b[JR_BR];
+  float na[JR_BR], nb[JR_BR];
+  auto load_block = [&](JrRowT<CPL>(&blk)[JR_BR], int bid) {
+#pragma unroll
+    for (int i = 0; i < JR_BR; ++i) {
+      const int pos = bid * JR_BR + i;
+      const int r = (active && pos < nbl * JR_BR) ? (int)s_perm[pos] : m;
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        const int c = CPL * lane + q;
+        blk[i].v[q] = (r < m && c < len) ? M[(long)r * ld + c] : 0.f;
+      }
+    }
+  };
+  load_block(a, w);
+  load_block(b, nwv + w);
+
+  int sweep = 0;
+  for (; sweep < max_sweeps; ++sweep) {
+    if (tid == 0) s_rot = 0;
+#pragma unroll
+    for (int i = 0; i < JR_BR; ++i) {
+      na[i] = jr_allsum(jrx_dot<CPL>(a[i], a[i]));
+      nb[i] = jr_allsum(jrx_dot<CPL>(b[i], b[i]));
+    }
+    int rot = 0;
+#pragma unroll 1
+    for (int r = 0; r < (active ? JR_BR - 1 : 0); ++r) {
+      float ga[JR_BR / 2], gb[JR_BR / 2];
+#pragma unroll
+      for (int p = 0; p < JR_BR / 2; ++p) {
+        ga[p] = jr_allsum(jrx_dot<CPL>(a[p], a[JR_BR - 1 - p]));
+        gb[p] = jr_allsum(jrx_dot<CPL>(b[p], b[JR_BR - 1 - p]));
+      }
+#pragma unroll
+      for (int p = 0; p < JR_BR / 2; ++p) {
+        rot += jrx_apply<CPL>(a[p], a[JR_BR - 1 - p], na[p], na[JR_BR - 1 - p], ga[p], tol2, floor2);
+        rot += jrx_apply<CPL>(b[p], b[JR_BR - 1 - p], nb[p], nb[JR_BR - 1 - p], gb[p], tol2, floor2);
+      }
+      {
+        const JrRowT<CPL> ta = a[JR_BR - 1], tb = b[JR_BR - 1];
+        const float fa = na[JR_BR - 1], fb = nb[JR_BR - 1];
+#pragma unroll
+        for (int i = JR_BR - 1; i >= 2; --i) { a[i] = a[i - 1]; b[i] = b[i - 1]; na[i] = na[i - 1]; nb[i] = nb[i - 1]; }
+        a[1] = ta; b[1] = tb; na[1] = fa; nb[1] = fb;
+      }
+    }
+    __syncthreads();
+    for (int sr = 0; sr < 2 * nwv - 1; ++sr) {
+      float mxa = na[0], mxb = nb[0];
+#pragma unroll
+      for (int i = 1; i < JR_BR; ++i) { mxa = fmaxf(mxa, na[i]); mxb = fmaxf(mxb, nb[i]); }
+      const bool live = active && mxa > floor2 && mxb > floor2;
+#pragma unroll 1
+      for (int t = 0; t < (live ? JR_BR : 0); ++t) {
+        float g[JR_BR];
+#pragma unroll
+        for (int i = 0; i < JR_BR; ++i) g[i] = jr_allsum(jrx_dot<CPL>(a[i], b[i]));
+#pragma unroll
+        for (int i = 0; i < JR_BR; ++i) rot += jrx_apply<CPL>(a[i], b[i], na[i], nb[i], g[i], tol2, floor2);
+        {
+          const JrRowT<CPL> tb = b[0];
+          const float fb = nb[0];
+#pragma unroll
+          for (int i = 0; i < JR_BR - 1; ++i) { b[i] = b[i + 1]; nb[i] = nb[i + 1]; }
+          b[JR_BR - 1] = tb; nb[JR_BR - 1] = fb;
+        }
+      }
+      if (nwv == 1) continue;
+      if (active) {
+#pragma unroll
+        for (int i = 0; i < JR_BR; ++i)
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) xch[w][i][q][lane] = b[i].v[q];
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < JR_BR; ++i) xnorm[w][i] = nb[i];
+        }
+        if (w == nwv - 1) {
+#pragma unroll
+          for (int i = 0; i < JR_BR; ++i)
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) xch[nwv][i][q][lane] = a[i].v[q];
+          if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < JR_BR; ++i) xnorm[nwv][i] = na[i];
+          }
+        }
+      }
+      __syncthreads();
+      if (active) {
+        const int src = (w == nwv - 1) ? nwv : w + 1;
+#pragma unroll
+        for (int i = 0; i < JR_BR; ++i) {
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) b[i].v[q] = xch[src][i][q][lane];
+          nb[i] = xnorm[src][i];
+        }
+      }
+      __syncthreads();
+      if (active && w >= 1 && w <= nwv - 2) {
+#pragma unroll
+        for (int i = 0; i < JR_BR; ++i)
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) xch[w][i][q][lane] = a[i].v[q];
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < JR_BR; ++i) xnorm[w][i] = na[i];
+        }
+      }
+      __syncthreads();
+      if (active && w >= 1) {
+        const int src = w - 1;
+#pragma unroll
+        for (int i = 0; i < JR_BR; ++i) {
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) a[i].v[q] = xch[src][i][q][lane];
+          na[i] = xnorm[src][i];
+        }
+      }
+      __syncthreads();
+    }
+    if (lane == 0 && rot) atomicAdd(&s_rot, rot);
+    __syncthreads();
+    const int total = s_rot;
+    __syncthreads();
+    if (total == 0) { ++sweep; break; }
+  }
+  auto store_block = [&](JrRowT<CPL>(&blk)[JR_BR], int bid) {
+#pragma unroll
+    for (int i = 0; i < JR_BR; ++i) {
+      const int pos = bid * JR_BR + i;
+      const int r = (active && pos < nbl * JR_BR) ? (int)s_perm[pos] : m;
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        const int c = CPL * lane + q;
+        if (r < m && c < len) M[(long)r * ld + c] = blk[i].v[q];
       }
     }
   };

@@ -105,9 +105,16 @@ inline size_t chol_smem_bytes(int n) {
 template <typename T>
 __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg, long wG, int n,
                                                          T *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
-                                                         int only_flagged = 0) {
+                                                         int only_flagged = 0, int ld = 0,
+                                                         const int *__restrict__ ndyn = nullptr, int ndyn_mul = 1,
+                                                         const int *__restrict__ run_flag = nullptr) {
   // only_flagged: chol_lowrank_kernel ran first and left mlive_out[b] = -1 where the rank exceeded its cap
   if (only_flagged && mlive_out[blockIdx.x] >= 0) return;
+  // run_flag: batch entries with run_flag[b] >= 0 are not on this route.  ld: row stride of G and of the output
+  // (default n); ndyn: per-entry order of the matrix (<= n), the rest of the ld x ld buffer is never touched.
+  if (run_flag && run_flag[blockIdx.x] >= 0) return;
+  const int ldg = ld ? ld : n;
+  if (ndyn) n = min(n, ndyn[blockIdx.x] * ndyn_mul);
   extern __shared__ double ch_smem[];
   double *sP = ch_smem;                          // [CH_NB][n]   current block row of R
   double *sK = sP + CH_NB * n;                   // [64][CH_NB]  staged R[list[k]][jb..jb+nb)
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
   T *Rout = Rg + (long)blockIdx.x * wR;
 
   double md = 0.0;
-  for (int i = tid; i < n; i += 256) md = fmax(md, G[(long)i * n + i]);
+  for (int i = tid; i < n; i += 256) md = fmax(md, G[(long)i * ldg + i]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
   if (lane == 0) s_red[wave] = md;
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
     const int nb = min(CH_NB, n - jb);
     for (int e = tid; e < nb * n; e += 256) {
       int c = e / n, r = e % n;
-      sP[c * n + r] = (r >= jb) ? G[(long)(jb + c) * n + r] : 0.0;
+      sP[c * n + r] = (r >= jb) ? G[(long)(jb + c) * ldg + r] : 0.0;
     }
     __syncthreads();
     // left-looking update with the finished LIVE rows (held in G's upper triangle)
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
       const int kc8 = (kc + 7) & ~7;          // zero padded to the unroll width below
       for (int e = tid; e < kc8 * CH_NB; e += 256) {
         int k = e / CH_NB, c = e % CH_NB;
-        sK[k * CH_NB + c] = (k < kc && c < nb) ? G[(long)sList[k0 + k] * n + jb + c] : 0.0;
+        sK[k * CH_NB + c] = (k < kc && c < nb) ? G[(long)sList[k0 + k] * ldg + jb + c] : 0.0;
       }
       __syncthreads();
       for (int r = jb + tid; r < n; r += 256) {
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
         for (int k = 0; k < kc8; k += 8) {
           double rv[8];                          // eight independent loads in flight (L2 latency)
 #pragma unroll
-          for (int q = 0; q < 8; ++q) rv[q] = (k + q < kc) ? G[(long)sList[k0 + k + q] * n + r] : 0.0;
+          for (int q = 0; q < 8; ++q) rv[q] = (k + q < kc) ? G[(long)sList[k0 + k + q] * ldg + r] : 0.0;
 #pragma unroll
           for (int q = 0; q < 8; ++q)
 #pragma unroll
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
     // publish the finished rows (needed by later panels) -- upper part only
     for (int e = tid; e < nb * n; e += 256) {
       int c = e / n, r = e % n;
-      if (r >= jb + c) G[(long)(jb + c) * n + r] = sP[c * n + r];
+      if (r >= jb + c) G[(long)(jb + c) * ldg + r] = sP[c * n + r];
     }
     __syncthreads();
   }
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
   for (int q = wave; q < nfac; q += 4) {
     const int k = sList[q];
     double a = 0.0;
-    for (int r = k + lane; r < n; r += 64) { double x = G[(long)k * n + r]; a += x * x; }
+    for (int r = k + lane; r < n; r += 64) { double x = G[(long)k * ldg + r]; a += x * x; }
     a = wave_sum(a);
     if (lane == 0) sN[q] = a;
   }
@@ -239,11 +246,12 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
     const int pos = sPos[q];
     if (pos < 0) continue;
     const int k = sList[q];
-    for (int r = lane; r < n; r += 64) Rout[(long)pos * n + r] = (r >= k) ? T(G[(long)k * n + r] * sc) : T(0);
+    // with a per-entry order (ndyn) the consumer reads whole rows of the ld-wide buffer: columns n..ld are written as zeros
+    for (int r = lane; r < (ndyn ? ldg : n); r += 64) Rout[(long)pos * ldg + r] = (r >= k && r < n) ? T(G[(long)k * ldg + r] * sc) : T(0);
   }
   // rows beyond mlive are never read when the caller takes the live count (dynamic extents)
   if (mlive_out) return;
-  for (int e = tid + mlive * n; e < n * n; e += 256) Rout[e] = T(0);
+  for (int e = tid + mlive * n; e < n * n; e += 256) Rout[(long)(e / n) * ldg + (e % n)] = T(0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -794,7 +802,7 @@ __global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, l
   extern __shared__ unsigned char jc_smem_raw[];
   T *sM = reinterpret_cast<T *>(jc_smem_raw);
   if (mdyn) m = min(m, mdyn[blockIdx.x] * mdyn_mul);
-  if (skip_small && m <= 32) return;   // jacobi_rows_small_kernel (jacobi_reg.h) took this walker
+  if (skip_small && m <= max(skip_small, 32)) return;   // the one-wave kernels (jacobi_reg.h) / the mid route took this walker
   __shared__ int s_rot;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   T *Mglob = Mg + (long)blockIdx.x * wM;
@@ -908,7 +916,10 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const T *__restrict__ 
                                                           const int *__restrict__ mdyn, int mdyn_mul,
                                                           int *__restrict__ klive_out = nullptr,
                                                           double trunc_err = 0.0, int dmin = 0,
-                                                          double *__restrict__ err_out = nullptr) {
+                                                          double *__restrict__ err_out = nullptr,
+                                                          const int *__restrict__ run_flag = nullptr, int run_if_neg = 1) {
+  // run_flag: with run_if_neg = 1 only the entries with run_flag[b] < 0 run, with 0 only those with run_flag[b] >= 0
+  if (run_flag && ((run_flag[blockIdx.x] < 0) != (run_if_neg != 0))) return;
   __shared__ double s_norm[1024];
   __shared__ int s_rank[1024];
   __shared__ int s_klive, s_kcut;
@@ -985,6 +996,18 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const T *__restrict__ 
     __syncthreads();
     if (tid == 0) klive_out[blockIdx.x] = s_klive;
   }
+}
+
+// Mid-rank route of the chi-truncation (Engine::absorb_impl): which walkers take it, and the order of their Gram matrix.
+//   ml = live rows of M (mdyn[b] * mul, or the static m);  lo < ml <= hi  ->  flag[b] = -1, nmid[b] = ml;  else 0, 0
+__global__ void mid_route_flag_kernel(const int *__restrict__ mdyn, int mdyn_mul, int m, int lo, int hi, int nbatch,
+                                      int *__restrict__ flag, int *__restrict__ nmid) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbatch) return;
+  const int ml = mdyn ? min(m, mdyn[b] * mdyn_mul) : m;
+  const bool mid = ml > lo && ml <= hi;
+  flag[b] = mid ? -1 : 0;
+  nmid[b] = mid ? ml : 0;
 }
 
 // x[b][0..n) /= |x|;  logscale[b] += log|x|;  zero / non-finite norm sets flag[b] = 1.

@@ -1,0 +1,12 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r2g
+export TMPDIR=/tmp
+run() { tag=$1; shift
+  timeout 600 python3 bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-route-check --no-full-rank > gpurun_out/r2g/bench_$tag.json 2> gpurun_out/r2g/bench_$tag.err
+  python3 -c "
+import json; d=json.load(open('gpurun_out/r2g/bench_$tag.json')); print('$tag', round(d['value'],1), round(d['ms_per_step'],1), d['kernel_ms'])"
+}
+run n1.0 --noise 1.0 --walkers 2048
+run n1.0_4096 --noise 1.0 --walkers 4096
+run n0.3 --noise 0.3 --walkers 2048
+run head
+timeout 1500 python3 -m pytest tests/test_gpu_fullrank.py tests/test_gpu_kernels.py tests/test_gpu_parity.py -x -q -m gpu > gpurun_out/r2g/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/r2g/pytest.log

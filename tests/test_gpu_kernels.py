@@ -366,3 +366,54 @@ def test_chained_contraction_pair_with_live_extents():
         got = P[b, :ml, :, :, :a2l]
         assert np.max(np.abs(got - want)) < 2e-5 * np.max(np.abs(want)), (b, live[b])
     assert n_chain > 5 and n_chain < nb
+
+
+@pytest.mark.parametrize("shape", [(128, 128), (70, 70), (96, 96), (33, 64), (100, 128), (17, 40), (64, 64)])
+def test_jacobi_mid_route_kernel(shape):
+    """jacobi_rows_regx_kernel<4,2> (tournament kernel of the preconditioned mid route, up to 128 x 128) on triangular,
+    graded input (the Cholesky factor it is given in the absorption): singular values, orthonormal Vt and dominant subspace
+    against LAPACK."""
+    capi = _capi()
+    m, ln = shape
+    rng = np.random.default_rng(5 * m + ln)
+    nb = 5
+    M = np.stack([np.triu(rng.standard_normal((m, ln))) * np.logspace(0, -5, m)[:, None] for _ in range(nb)])
+    k = min(32, m, ln)
+    Mo, Vt, S, sw = capi.diag_jacobi(capi.F32, M, k, 4)
+    for b in range(nb):
+        sref = np.linalg.svd(M[b], compute_uv=False)
+        assert np.max(np.abs(S[b].astype(np.float64) - sref[:k])) < 3e-5 * sref[0]
+        Vb = Vt[b].astype(np.float64)
+        live = sref[:k] > 1e-5 * sref[0]
+        G = Vb @ Vb.T
+        assert np.max(np.abs(G[np.ix_(live, live)] - np.eye(int(live.sum())))) < 1e-4
+        assert abs(np.linalg.norm(Mo[b]) / np.linalg.norm(M[b]) - 1) < 1e-5
+        assert sw[b] < 40
+        Pref = np.linalg.svd(M[b])[2][:k]
+        if live.all() and (sref[k] < 0.5 * sref[k - 1] if k < len(sref) else True):
+            assert np.max(np.abs(Vb.T @ Vb - Pref.T @ Pref)) < 2e-3
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("K,n", [(560, 128), (2048, 256), (37, 96), (5, 64), (301, 200), (64, 33), (1000, 72)])
+def test_streaming_gram_kernel(K, n, dt):
+    """gram_cols_f64_kernel (wave-per-block streaming Gram of the forward pass): G = P^T P with f64 accumulation of exact
+    f32 products, per-walker live row counts, every 64 x 64 block on or above the diagonal."""
+    capi = _capi()
+    rng = np.random.default_rng(K + n)
+    nb = 5
+    t = np.float32 if dt == "f32" else np.float64
+    P = rng.standard_normal((nb, K, n)).astype(t) * np.logspace(0, -6, n)[None, None, :].astype(t)
+    klive = np.array([K, max(1, K // 2), 1, max(1, K - 3), min(K, 7)], dtype=np.int32)
+    G = capi.diag_gram_cols(capi.F32 if dt == "f32" else capi.F64, P, klive)
+    for b in range(nb):
+        Pb = P[b, :klive[b]].astype(np.float64)
+        ref = Pb.T @ Pb
+        for bi in range((n + 63) // 64):
+            for bj in range(bi, (n + 63) // 64):
+                sl = (slice(64 * bi, min(n, 64 * bi + 64)), slice(64 * bj, min(n, 64 * bj + 64)))
+                scale = np.sqrt(np.outer(np.diag(ref)[sl[0]], np.diag(ref)[sl[1]])) + 1e-300
+                assert np.max(np.abs(G[b][sl] - ref[sl]) / scale) < 1e-13 * max(1, klive[b]) ** 0.5 + 1e-15
+    G0 = capi.diag_gram_cols(capi.F32 if dt == "f32" else capi.F64, P, None)
+    ref0 = P[0].astype(np.float64).T @ P[0].astype(np.float64)
+    assert np.max(np.abs(np.triu(G0[0]) - np.triu(ref0))[:64, :64]) < 1e-12 * np.max(np.abs(ref0))

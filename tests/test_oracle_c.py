@@ -33,6 +33,16 @@ def test_c_restatement_threads_are_independent_walkers():
     assert np.array_equal(a1, a4)
 
 
+def test_c_restatement_one_walker_per_process():
+    """the all-cores cpu_baseline of bench.py: configurations sharded over single-threaded worker processes of a child interpreter"""
+    L, D, chi = 5, 3, 6
+    flat = synthetic.sitps_to_flat(synthetic.make_sitps(L, D, noise=0.5), D)
+    cfgs = synthetic.make_configs(L, 7, "heisenberg")
+    a1, _ = cbmps.amplitudes(flat, cfgs, chi, nthreads=1)
+    a3, sec, nproc = cbmps.amplitudes_multiprocess(flat, cfgs, chi, 3)
+    assert np.array_equal(a1, a3) and nproc == 3 and sec > 0.0
+
+
 def test_c_restatement_on_reference_fixture_k5(fixtures_dir):
     """K5: checkerboard amplitude of the reference's 4x4 D=8 state, 1.441641034201432e+02 (brute force), BMPS chi=64 exact"""
     s = qlten_io.load_sitps(os.path.join(fixtures_dir, "tps_square_heisenberg4x4D8Double"))
