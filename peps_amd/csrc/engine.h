@@ -19,6 +19,7 @@
 #include "linalg.h"
 #include "tgemm.h"
 #include "gram.h"
+#include "trunc_mid.h"
 
 namespace pepsgpu {
 

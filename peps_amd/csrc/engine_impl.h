@@ -440,8 +440,15 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       hipLaunchKernelGGL(mid_route_flag_kernel, dim3((nw_ + 255) / 256), dim3(256), 0, stream_, (const int *)mdyn[i], mmul[i], m, lo,
                          MID_HI, nw_, midflag, nmid);
       PG_CHECK_HIP(hipGetLastError());
-      double *Gm = (double *)arena_.alloc(sizeof(double) * (size_t)GS * GS * nw_);
-      {
+      Bt = alloc_ten(GS, GS, 1);
+      prof_begin(PROF_TRUNC_GRAM, 0.0, 0.0);
+      static const bool no_fused_mid = getenv("PEPSGPU_NO_FUSED_MIDGRAM") != nullptr;
+      if constexpr (sizeof(T) == 4) {
+        if (!no_fused_mid)   // G = M M^T and its Cholesky in one kernel, G resident in LDS (trunc_mid.h)
+          launch_mid_gram_chol<T>(stream_, nw_, (const T *)M.p, M.n, uk, (const int *)nmid, (const int *)midflag, GS, Bt.p, Bt.n, mB);
+      }
+      if (sizeof(T) != 4 || no_fused_mid) {
+        double *Gm = (double *)arena_.alloc(sizeof(double) * (size_t)GS * GS * nw_);
         TGemmDesc g;
         g.I[2] = m; g.sAi[2] = uk; g.sCi[2] = GS;
         g.K[2] = uk; g.sAk[2] = 1; g.sBk[2] = 1;
@@ -450,17 +457,15 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         g.dI[2].p = nmid; g.dJ[2].p = nmid;
         g.upper_only = 1;
         g.batch_flag = midflag;
-        prof_begin(PROF_TRUNC_GRAM, 0.0, 0.0);
         tgemm_launch<T, T, double, double>(stream_, g, M.p, M.p, Gm);
+        const size_t smem = chol_smem_bytes(GS);
+        allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
+        hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nw_), dim3(256), smem, stream_, Gm, (long)GS * GS, GS, Bt.p, Bt.n, mB, 0, GS,
+                           (const int *)nmid, 1, (const int *)midflag);
+        PG_CHECK_HIP(hipGetLastError());
+        arena_.free(Gm);
       }
-      Bt = alloc_ten(GS, GS, 1);
-      const size_t smem = chol_smem_bytes(GS);
-      allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
-      hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nw_), dim3(256), smem, stream_, Gm, (long)GS * GS, GS, Bt.p, Bt.n, mB, 0, GS,
-                         (const int *)nmid, 1, (const int *)midflag);
-      PG_CHECK_HIP(hipGetLastError());
       prof_end();
-      arena_.free(Gm);
     }
     {
       const size_t need = sizeof(T) * (size_t)m * (uk | 1);

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256, 2) void gram_cols_f64_kernel(const T *__restri
   while (rem >= nb - bi) { rem -= nb - bi; ++bi; }
   const int bj = bi + rem;                                // bi <= bj: on or above the diagonal
   const int K = kdyn ? min(kmax, kdyn[b] * kdyn_mul) : kmax;
+  if (run_flag) flop_stride = 1;      // partial participation: every running entry counts itself (no sampling)
   if (flopc && t == 0 && lane == 0 && b % flop_stride == 0) {
     atomicAdd(flopc, (unsigned long long)flop_stride * n * n * K);                 // = 2 n n K / 2 (upper triangle)
     if (bytec) atomicAdd(bytec, (unsigned long long)flop_stride * ((unsigned long long)K * n * sizeof(T) + (unsigned long long)n * n * 4));
@@ -88,15 +89,24 @@ __global__ __launch_bounds__(256, 2) void gram_cols_f64_kernel(const T *__restri
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[a], bd[c], acc[a][c], 0, 0, 0);
   };
-  T a0[4], b0[4], a1[4], b1[4];
+  // software pipeline, PF steps deep: a step's operands are requested PF - 1 steps (PF - 1 x 16 MFMAs of 64 cycles) before
+  // they are consumed, which covers an L2 / Infinity-Cache round trip at two waves per SIMD
+  constexpr int PF = 4;
+  T av[PF][4], bv[PF][4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) { a0[c] = T(0); b0[c] = T(0); a1[c] = T(0); b1[c] = T(0); }
-  if (nks > 0) load(0, a0, b0);
-  for (int ks = 0; ks < nks; ks += 2) {
-    if (ks + 1 < nks) load(ks + 1, a1, b1);
-    step(a0, b0);
-    if (ks + 2 < nks) load(ks + 2, a0, b0);
-    if (ks + 1 < nks) step(a1, b1);
+  for (int p = 0; p < PF; ++p)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { av[p][c] = T(0); bv[p][c] = T(0); }
+#pragma unroll
+  for (int p = 0; p < PF - 1; ++p)
+    if (p < nks) load(p, av[p], bv[p]);
+  for (int ks = 0; ks < nks; ks += PF) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const int cur = ks + p;
+      if (cur + PF - 1 < nks) load(cur + PF - 1, av[(p + PF - 1) % PF], bv[(p + PF - 1) % PF]);
+      if (cur < nks) step(av[p], bv[p]);
+    }
   }
   // accumulator layout of v_mfma_f64_16x16x4_f64: acc[r] = C[(lane >> 4) + 4 r][lane & 15]
 #pragma unroll
