@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpepsgpu.so")
 
 F32, F64 = 0, 1
+C128 = 3          # complex float64 (TenElemT = QLTEN_Complex): every scalar / tensor output becomes complex128
 LEFT, DOWN, RIGHT, UP = 0, 1, 2, 3
 HORIZONTAL, VERTICAL = 0, 1
 LEFTUP_TO_RIGHTDOWN, LEFTDOWN_TO_RIGHTUP = 0, 1   # basic.h:89-92 DIAGONAL_DIR
@@ -141,6 +142,7 @@ class Context:
         self._l = lib()
         self.rows, self.cols, self.D, self.d = rows, cols, D, phys_dim
         self.dtype = dtype
+        self._ot = np.complex128 if dtype == C128 else np.float64      # type of every scalar / tensor the calls return
         h = C.c_void_p()
         rc = self._l.pepsgpu_ctx_create(C.byref(h), device, dtype, rows, cols, D, phys_dim,
                                         chi if chi_min is None else chi_min, chi, trunc_err, scheme, max_walkers)
@@ -175,9 +177,14 @@ class Context:
     def state_upload(self, flat):
         flat = np.ascontiguousarray(flat)
         assert flat.shape == (self.rows, self.cols, self.d, self.D, self.D, self.D, self.D), flat.shape
-        hd = F32 if flat.dtype == np.float32 else F64
-        if hd == F64:
-            flat = flat.astype(np.float64, copy=False)
+        if np.iscomplexobj(flat):
+            if self.dtype != C128:
+                raise ValueError("a complex state needs a complex context (dtype=C128)")
+            hd, flat = C128, np.ascontiguousarray(flat, dtype=np.complex128)
+        else:
+            hd = F32 if flat.dtype == np.float32 else F64
+            if hd == F64:
+                flat = flat.astype(np.float64, copy=False)
         self._ck(self._l.pepsgpu_state_upload(self._h, flat.ctypes.data_as(C.c_void_p), hd))
 
     def set_configs(self, configs):
@@ -213,27 +220,27 @@ class Context:
     def get_bmps_tensor(self, pos, level, idx):
         dims = np.zeros(3, dtype=np.int32)
         self._ck(self._l.pepsgpu_get_bmps_tensor(self._h, pos, level, idx, _ip(dims), None, None))
-        data = np.zeros((self.n,) + tuple(int(x) for x in dims), dtype=np.float64)
+        data = np.zeros((self.n,) + tuple(int(x) for x in dims), dtype=self._ot)
         ls = np.zeros(self.n, dtype=np.float64)
         self._ck(self._l.pepsgpu_get_bmps_tensor(self._h, pos, level, idx, _ip(dims), _dp(data), _dp(ls)))
         return data, ls
 
     def trace(self, row, col, bond_dir):
-        out = np.zeros(self.n, dtype=np.float64)
+        out = np.zeros(self.n, dtype=self._ot)
         self._ck(self._l.pepsgpu_trace(self._h, row, col, bond_dir, _dp(out)))
         return out
 
     def replace_nn_trace(self, row, col, bond_dir, cand_states):
         cand = np.ascontiguousarray(cand_states, dtype=np.int32)
         assert cand.ndim == 3 and cand.shape[0] == self.n and cand.shape[2] == 2
-        out = np.zeros((self.n, cand.shape[1]), dtype=np.float64)
+        out = np.zeros((self.n, cand.shape[1]), dtype=self._ot)
         self._ck(self._l.pepsgpu_replace_nn_trace(self._h, row, col, bond_dir, cand.shape[1], _ip(cand), _dp(out)))
         return out
 
     def replace_one_trace(self, row, col, orient, cand_states):
         cand = np.ascontiguousarray(cand_states, dtype=np.int32)
         assert cand.ndim == 2 and cand.shape[0] == self.n
-        out = np.zeros((self.n, cand.shape[1]), dtype=np.float64)
+        out = np.zeros((self.n, cand.shape[1]), dtype=self._ot)
         self._ck(self._l.pepsgpu_replace_one_trace(self._h, row, col, orient, cand.shape[1], _ip(cand), _dp(out)))
         return out
 
@@ -248,10 +255,10 @@ class Context:
     def _cand(self, cand_states, ncols):
         """cand_states None -> no replacement (out [n]); else [n][n_cand][ncols] -> out [n][n_cand]"""
         if cand_states is None:
-            return 0, None, np.zeros(self.n, dtype=np.float64)
+            return 0, None, np.zeros(self.n, dtype=self._ot)
         cand = np.ascontiguousarray(cand_states, dtype=np.int32)
         assert cand.ndim == 3 and cand.shape[0] == self.n and cand.shape[2] == ncols
-        return cand.shape[1], cand, np.zeros((self.n, cand.shape[1]), dtype=np.float64)
+        return cand.shape[1], cand, np.zeros((self.n, cand.shape[1]), dtype=self._ot)
 
     def replace_nnn_trace(self, row, col, nnn_dir, orient, cand_states=None):
         nc, cand, out = self._cand(cand_states, 2)
@@ -272,7 +279,7 @@ class Context:
         return out
 
     def punch_hole(self, row, col, orient):
-        out = np.zeros((self.n, self.D, self.D, self.D, self.D), dtype=np.float64)
+        out = np.zeros((self.n, self.D, self.D, self.D, self.D), dtype=self._ot)
         self._ck(self._l.pepsgpu_punch_hole(self._h, row, col, orient, _dp(out)))
         return out
 
@@ -387,7 +394,7 @@ class Context:
         self._ck(self._l.pepsgpu_erase_envs_after_update(self._h, row, col))
 
     def evaluate_amplitude(self):
-        out = np.zeros(self.n, dtype=np.float64)
+        out = np.zeros(self.n, dtype=self._ot)
         self._ck(self._l.pepsgpu_evaluate_amplitude(self._h, _dp(out)))
         return out
 

@@ -5,6 +5,7 @@
 #include "engine_nnn.h"
 #include "engine_sr.h"
 #include "engine_var.h"
+#include "engine_cplx.h"
 #include "comm.h"
 
 using namespace pepsgpu;
@@ -69,6 +70,8 @@ int pepsgpu_ctx_create(pepsgpu_ctx **out, int device, int dtype, int rows, int c
       ctx->eng = new Engine<float>(device, rows, cols, D, phys_dim, chi_min, chi_max, trunc_err, max_walkers);
     else if (dtype == PEPSGPU_F64)
       ctx->eng = new Engine<double>(device, rows, cols, D, phys_dim, chi_min, chi_max, trunc_err, max_walkers);
+    else if (dtype == PEPSGPU_C128)
+      ctx->eng = new Engine<c128>(device, rows, cols, D, phys_dim, chi_min, chi_max, trunc_err, max_walkers);
     else
       throw Error(1, "unknown dtype");
     // variational schemes: convergence_tol / iter_max default to 1e-10 / 10 until pepsgpu_set_truncate_params sets them

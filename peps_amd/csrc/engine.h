@@ -112,6 +112,9 @@ struct DTen {
 template <typename T>
 class Engine : public EngineBase {
  public:
+  typedef typename acc64_of<T>::type Acc;              // float64 accumulation type: double, or complex<double>
+  static constexpr bool kCplx = is_cplx<T>::value;     // complex element type: scalar results are (re, im) pairs
+  static constexpr int kOut = kCplx ? 2 : 1;           // doubles per scalar in every host output array
   Engine(int device, int Ly, int Lx, int D, int dphys, int chi_min, int chi_max, double trunc_err, int max_walkers)
       : Ly_(Ly), Lx_(Lx), D_(D), dp_(dphys), chi_min_(chi_min), chi_(chi_max), trunc_err_(trunc_err),
         maxw_(max_walkers) {
@@ -129,7 +132,7 @@ class Engine : public EngineBase {
     sweeps_ = (int *)arena_.alloc(sizeof(int) * (size_t)maxw_);
     { const char *e = getenv("PEPSGPU_DEBUG_SWEEPS"); dbg_sweeps_ = e && e[0] == '1'; }
     PG_CHECK_HIP(hipMemsetAsync(flag_, 0, sizeof(int) * (size_t)maxw_, stream_));
-    dtype = sizeof(T) == 4 ? 0 : 1;
+    dtype = kCplx ? 3 : (sizeof(T) == 4 ? 0 : 1);
   }
   ~Engine() override {
     (void)hipStreamSynchronize(stream_);
@@ -165,8 +168,15 @@ class Engine : public EngineBase {
               for (int cc = 0; cc < dd[2]; ++cc)
                 for (int e = 0; e < dd[3]; ++e) {
                   size_t src = base + (((size_t)a * D_ + b) * D_ + cc) * D_ + e;
-                  double v = host_dtype == 0 ? (double)((const float *)host)[src] : ((const double *)host)[src];
-                  buf[base + o++] = T(v);
+                  if constexpr (kCplx) {
+                    typedef typename real_of<T>::type R;
+                    if (host_dtype == 3) buf[base + o++] = T(R(((const double *)host)[2 * src]), R(((const double *)host)[2 * src + 1]));
+                    else buf[base + o++] = T(R(host_dtype == 0 ? (double)((const float *)host)[src] : ((const double *)host)[src]));
+                  } else {
+                    PG_REQUIRE(host_dtype == 0 || host_dtype == 1, 1, "a real context takes float32 / float64 state buffers");
+                    double v = host_dtype == 0 ? (double)((const float *)host)[src] : ((const double *)host)[src];
+                    buf[base + o++] = T(v);
+                  }
                 }
         }
       }
@@ -532,15 +542,19 @@ class Engine : public EngineBase {
     PG_CHECK_HIP(hipStreamSynchronize(stream_));
     // output padded to D^4 per walker, leg order (L,D,R,U)
     const long slot = slot_;
-    std::fill(out, out + (size_t)slot * nw_, 0.0);
+    std::fill(out, out + (size_t)slot * nw_ * kOut, 0.0);
     for (int w = 0; w < nw_; ++w) {
       double sc = std::exp(hl[w]);
       size_t o = 0;
       for (int a = 0; a < l1; ++a)
         for (int b = 0; b < d1; ++b)
           for (int c = 0; c < r1; ++c)
-            for (int e = 0; e < u1; ++e)
-              out[(size_t)w * slot + (((size_t)a * D_ + b) * D_ + c) * D_ + e] = (double)h[(size_t)w * res.n + o++] * sc;
+            for (int e = 0; e < u1; ++e) {
+              const size_t dst = (size_t)w * slot + (((size_t)a * D_ + b) * D_ + c) * D_ + e;
+              const T v = h[(size_t)w * res.n + o++];
+              if constexpr (kCplx) { out[2 * dst] = (double)v.re * sc; out[2 * dst + 1] = (double)v.im * sc; }
+              else out[dst] = (double)v * sc;
+            }
     }
     free_ten(tmp1); free_ten(tmp2); free_ten(res);
     arena_.free(lsum);
@@ -563,6 +577,13 @@ class Engine : public EngineBase {
   // (exact_summation_energy_evaluator.h:231).
   void grad_accumulate(const double *psi, const double *eloc, int exact_sum) override {
     require_ready();
+    if constexpr (kCplx) {
+      PG_REQUIRE(false, 1, "gradient accumulation is not implemented for the complex element type");
+    } else {
+    grad_accumulate_real(psi, eloc, exact_sum);
+    }
+  }
+  void grad_accumulate_real(const double *psi, const double *eloc, int exact_sum) {
     PG_REQUIRE(holes_ != nullptr, 3, "grad_accumulate: no holes stored (pepsgpu_punch_hole with out == NULL)");
     if (!so_) grad_reset();
     std::vector<double> h(3 * (size_t)nw_);
@@ -691,7 +712,10 @@ class Engine : public EngineBase {
       std::vector<T> h((size_t)t.n * nw_);
       PG_CHECK_HIP(hipMemcpyAsync(h.data(), t.p, h.size() * sizeof(T), hipMemcpyDeviceToHost, stream_));
       PG_CHECK_HIP(hipStreamSynchronize(stream_));
-      for (size_t i = 0; i < h.size(); ++i) out[i] = (double)h[i];
+      for (size_t i = 0; i < h.size(); ++i) {
+        if constexpr (kCplx) { out[2 * i] = (double)h[i].re; out[2 * i + 1] = (double)h[i].im; }
+        else out[i] = (double)h[i];
+      }
     }
     if (logscale) {
       PG_CHECK_HIP(hipMemcpyAsync(logscale, b.logscale, nw_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
@@ -842,19 +866,24 @@ class Engine : public EngineBase {
   void finish_dot(const DTen<T> &t2, int nc2, const DTen<T> &t5, int nc5, int nc, double *lsum, double *out) {
     PG_REQUIRE(t2.d[0] == t5.d[2] && t2.d[1] == t5.d[1] && t2.d[2] == t5.d[0], 3, "trace: environment bond mismatch");
     const int nb = nw_ * nc;
-    double *res = (double *)arena_.alloc(sizeof(double) * nb);
+    Acc *res = (Acc *)arena_.alloc(sizeof(Acc) * nb);
     TGemmDesc g;
     g.K[0] = t2.d[0]; g.K[1] = t2.d[1]; g.K[2] = t2.d[2];
     g.sAk[0] = t2.d[1] * t2.d[2]; g.sAk[1] = t2.d[2]; g.sAk[2] = 1;
     g.sBk[0] = 1; g.sBk[1] = t5.d[2]; g.sBk[2] = t5.d[1] * t5.d[2];
     g.wA = t2.n; g.wB = t5.n; g.wC = 1; g.nbatch = nb;
     g.bdivA = nc / nc2; g.bdivB = nc / nc5;
-    tgemm_launch<T, T, double, double>(stream_, g, t2.p, t5.p, res);
-    std::vector<double> h(nb), hl(nw_);
-    PG_CHECK_HIP(hipMemcpyAsync(h.data(), res, nb * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    tgemm_launch<T, T, Acc, Acc>(stream_, g, t2.p, t5.p, res);
+    std::vector<Acc> h(nb);
+    std::vector<double> hl(nw_);
+    PG_CHECK_HIP(hipMemcpyAsync(h.data(), res, nb * sizeof(Acc), hipMemcpyDeviceToHost, stream_));
     PG_CHECK_HIP(hipMemcpyAsync(hl.data(), lsum, nw_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
     PG_CHECK_HIP(hipStreamSynchronize(stream_));
-    for (int i = 0; i < nb; ++i) out[i] = h[i] * std::exp(hl[i / nc]);
+    for (int i = 0; i < nb; ++i) {
+      const double sc = std::exp(hl[i / nc]);
+      if constexpr (kCplx) { out[2 * i] = h[i].re * sc; out[2 * i + 1] = h[i].im * sc; }
+      else out[i] = h[i] * sc;
+    }
     arena_.free(res);
   }
 
@@ -957,6 +986,7 @@ class Engine : public EngineBase {
   }
 
   void absorb(int pos, int num);
+  BMPSDev absorb_simple(int pos, int num, const BMPSDev &in);   // engine_cplx.h
   BMPSDev absorb_svd(int pos, int num, const BMPSDev &in);
   bool absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in, BMPSDev &out);
   // ---- variational compression schemes (engine_var.h) ----

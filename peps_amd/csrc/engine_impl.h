@@ -89,13 +89,20 @@ void Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
 // checks that no walker filled a shrunk bond; if one did, the absorption is repeated at full size (rare).
 template <typename T>
 void Engine<T>::absorb(int pos, int num) {
-  if (scheme_ != 0 && mps_len(pos) > 2) {   // bmps_impl.h:419-430: N == 2 always takes the SVD path
-    BMPSDev out = absorb_variational(pos, num, bmps_[pos].back());
+  if constexpr (kCplx) {
+    // complex element type: the plain static-shape form of the same algorithm (engine_cplx.h), SVD compression only
+    PG_REQUIRE(scheme_ == 0 || mps_len(pos) <= 2, 1, "variational compression is not implemented for the complex element type");
+    BMPSDev out = absorb_simple(pos, num, bmps_[pos].back());
     bmps_[pos].push_back(std::move(out));
-    return;
+  } else {
+    if (scheme_ != 0 && mps_len(pos) > 2) {   // bmps_impl.h:419-430: N == 2 always takes the SVD path
+      BMPSDev out = absorb_variational(pos, num, bmps_[pos].back());
+      bmps_[pos].push_back(std::move(out));
+      return;
+    }
+    BMPSDev out = absorb_svd(pos, num, bmps_[pos].back());
+    bmps_[pos].push_back(std::move(out));
   }
-  BMPSDev out = absorb_svd(pos, num, bmps_[pos].back());
-  bmps_[pos].push_back(std::move(out));
 }
 
 template <typename T>

@@ -94,7 +94,7 @@ void Engine<T>::finish_dot4(const DTen<T> &a, const DTen<T> &b, int nc, double *
   PG_REQUIRE(a.d[0] == b.d[3] && a.d[1] == b.d[2] && a.d[2] == b.d[1] && a.d[3] == b.d[0], 3,
              "trace: two-row environment bond mismatch");
   const int nb = nw_ * nc;
-  double *res = (double *)arena_.alloc(sizeof(double) * nb);
+  Acc *res = (Acc *)arena_.alloc(sizeof(Acc) * nb);
   TGemmDesc g;
   // The tensor GEMM addresses three K sub-indices; the fourth (j, a site bond of size <= D) is a
   // short loop of accumulating launches.
@@ -105,13 +105,18 @@ void Engine<T>::finish_dot4(const DTen<T> &a, const DTen<T> &b, int nc, double *
   g.wA = a.n; g.wB = b.n; g.wC = 1; g.nbatch = nb;
   for (int j = 0; j < J; ++j) {
     g.accumulate = j > 0;
-    tgemm_launch<T, T, double, double>(stream_, g, a.p + (long)j * Kd * L, b.p + (long)j * I, res);
+    tgemm_launch<T, T, Acc, Acc>(stream_, g, a.p + (long)j * Kd * L, b.p + (long)j * I, res);
   }
-  std::vector<double> h(nb), hl(nw_);
-  PG_CHECK_HIP(hipMemcpyAsync(h.data(), res, nb * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  std::vector<Acc> h(nb);
+  std::vector<double> hl(nw_);
+  PG_CHECK_HIP(hipMemcpyAsync(h.data(), res, nb * sizeof(Acc), hipMemcpyDeviceToHost, stream_));
   PG_CHECK_HIP(hipMemcpyAsync(hl.data(), lsum, nw_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
   PG_CHECK_HIP(hipStreamSynchronize(stream_));
-  for (int i = 0; i < nb; ++i) out[i] = h[i] * std::exp(hl[i / nc]);
+  for (int i = 0; i < nb; ++i) {
+    const double sc = std::exp(hl[i / nc]);
+    if constexpr (kCplx) { out[2 * i] = h[i].re * sc; out[2 * i + 1] = h[i].im * sc; }
+    else out[i] = h[i] * sc;
+  }
   arena_.free(res);
 }
 

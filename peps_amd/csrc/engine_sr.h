@@ -102,6 +102,9 @@ void Engine<T>::sr_convert(const double *src, double *dst, bool to_compact) cons
 
 template <typename T>
 void Engine<T>::sr_begin(int max_samples) {
+  if constexpr (kCplx) {
+    PG_REQUIRE(false, 1, "stochastic reconfiguration is not implemented for the complex element type");
+  } else {
   PG_REQUIRE(max_samples > 0, 1, "sr_begin: need a positive sample capacity");
   sr_release();
   const size_t sites = (size_t)Ly_ * Lx_;
@@ -139,6 +142,7 @@ void Engine<T>::sr_begin(int max_samples) {
   PG_CHECK_HIP(hipStreamSynchronize(stream_));
   sr_cap_ = max_samples;
   sr_n_ = 0;
+  }
 }
 
 template <typename T>
@@ -151,6 +155,9 @@ void Engine<T>::sr_release() {
 
 template <typename T>
 void Engine<T>::sr_append(const double *psi) {
+  if constexpr (kCplx) {
+    PG_REQUIRE(false, 1, "stochastic reconfiguration is not implemented for the complex element type");
+  } else {
   require_ready();
   PG_REQUIRE(sr_o_ != nullptr, 3, "sr_append: call pepsgpu_sr_begin first");
   PG_REQUIRE(holes_ != nullptr, 3, "sr_append: no holes stored (pepsgpu_punch_hole with out == NULL)");
@@ -171,10 +178,14 @@ void Engine<T>::sr_append(const double *psi) {
   PG_CHECK_HIP(hipStreamSynchronize(stream_));
   arena_.free(d);
   sr_n_ += nw_;
+  }
 }
 
 template <typename T>
 void Engine<T>::sr_sum(double *out) {
+  if constexpr (kCplx) {
+    PG_REQUIRE(false, 1, "stochastic reconfiguration is not implemented for the complex element type");
+  } else {
   PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_sum: no samples");
   const int sites = Ly_ * Lx_;
   const size_t n = (size_t)sites * dp_ * slot_;
@@ -185,11 +196,15 @@ void Engine<T>::sr_sum(double *out) {
   PG_CHECK_HIP(hipMemcpyAsync(h.data(), sr_out_, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
   PG_CHECK_HIP(hipStreamSynchronize(stream_));
   sr_convert(h.data(), out, false);
+  }
 }
 
 // out = scale * sum_i (O*_i . v - mean_dot_v) O*_i      (caller: all-reduce over ranks, + diag_shift * v)
 template <typename T>
 void Engine<T>::sr_matvec(const double *v, double mean_dot_v, double scale, double *out) {
+  if constexpr (kCplx) {
+    PG_REQUIRE(false, 1, "stochastic reconfiguration is not implemented for the complex element type");
+  } else {
   PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_matvec: no samples");
   const int sites = Ly_ * Lx_;
   const size_t n = (size_t)sites * dp_ * slot_;
@@ -205,6 +220,7 @@ void Engine<T>::sr_matvec(const double *v, double mean_dot_v, double scale, doub
   PG_CHECK_HIP(hipMemcpyAsync(h.data(), sr_out_, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
   PG_CHECK_HIP(hipStreamSynchronize(stream_));
   sr_convert(h.data(), out, false);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -218,6 +234,9 @@ template <typename T>
 void Engine<T>::sr_cg_solve(const double *b, const double *x0, double diag_shift, int max_iter, double rel_tol,
                             double abs_tol, int recompute_interval, double ortho_threshold, double *x_out,
                             double *residual_norm, int *iterations, int *reason) {
+  if constexpr (kCplx) {
+    PG_REQUIRE(false, 1, "stochastic reconfiguration is not implemented for the complex element type");
+  } else {
   PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_cg_solve: no samples");
   ArenaScope scope(arena_);
   const int sites = Ly_ * Lx_;
@@ -320,6 +339,7 @@ void Engine<T>::sr_cg_solve(const double *b, const double *x0, double diag_shift
     axpby(1.0, dr, beta, dp);                      // p = r + beta p
   }
   finish(dbest, best, max_iter, kMaxIterations);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -341,6 +361,9 @@ __global__ __launch_bounds__(256) void sr_expand_kernel(const T *__restrict__ o,
 
 template <typename T>
 void Engine<T>::sr_gram(const void *remote_o, const int32_t *remote_cfg, int n_remote, double *out) {
+  if constexpr (kCplx) {
+    PG_REQUIRE(false, 1, "stochastic reconfiguration is not implemented for the complex element type");
+  } else {
   PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_gram: no samples");
   PG_REQUIRE(!remote_o || (remote_cfg && n_remote > 0), 1, "sr_gram: bad remote batch");
   const int sites = Ly_ * Lx_;
@@ -400,10 +423,14 @@ void Engine<T>::sr_gram(const void *remote_o, const int32_t *remote_cfg, int n_r
   std::copy(h.begin(), h.end(), out);
   if (eb != ea) arena_.free(eb);
   arena_.free(ea);
+  }
 }
 
 template <typename T>
 void Engine<T>::sr_weighted_sum(const double *y, double *out) {
+  if constexpr (kCplx) {
+    PG_REQUIRE(false, 1, "stochastic reconfiguration is not implemented for the complex element type");
+  } else {
   PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_weighted_sum: no samples");
   const int sites = Ly_ * Lx_;
   const size_t n = (size_t)sites * dp_ * slot_;
@@ -415,16 +442,21 @@ void Engine<T>::sr_weighted_sum(const double *y, double *out) {
   PG_CHECK_HIP(hipMemcpyAsync(h.data(), sr_out_, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
   PG_CHECK_HIP(hipStreamSynchronize(stream_));
   sr_convert(h.data(), out, false);
+  }
 }
 
 // device-to-device copy of the local sample store (for torch.distributed send / recv of the ring exchange)
 template <typename T>
 void Engine<T>::sr_copy_samples(void *dst_o, int32_t *dst_cfg) {
+  if constexpr (kCplx) {
+    PG_REQUIRE(false, 1, "stochastic reconfiguration is not implemented for the complex element type");
+  } else {
   PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_copy_samples: no samples");
   const size_t sites = (size_t)Ly_ * Lx_;
   PG_CHECK_HIP(hipMemcpyAsync(dst_o, sr_o_, sizeof(T) * (size_t)sr_n_ * sites * slot_, hipMemcpyDeviceToDevice, stream_));
   PG_CHECK_HIP(hipMemcpyAsync(dst_cfg, sr_cfg_, sizeof(int) * (size_t)sr_n_ * sites, hipMemcpyDeviceToDevice, stream_));
   PG_CHECK_HIP(hipStreamSynchronize(stream_));
+  }
 }
 
 }  // namespace pepsgpu

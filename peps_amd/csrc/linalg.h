@@ -12,12 +12,14 @@
 //    relies on fp64 range, monte_carlo_engine.h:206-240; fp32 needs the log-scale).
 #pragma once
 #include "common.h"
+#include "cplx.h"
 
 namespace pepsgpu {
 
 template <typename T> struct Eps;
 template <> struct Eps<float> { static constexpr float v = 5.9604645e-8f; };
 template <> struct Eps<double> { static constexpr double v = 1.1102230246251565e-16; };
+template <typename R> struct Eps<cplx<R>> { static constexpr R v = Eps<R>::v; };
 
 // 64-lane all-reductions on the DPP / permlane-swap path (a few cycles of latency per step, no LDS crossbar): the step
 // loops of the factor kernels are chains of dependent reductions, where the ds_bpermute behind __shfl_xor costs most
@@ -933,7 +935,7 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const T *__restrict__ 
   if (Sg) for (int r = min(m, k) + tid; r < k; r += 256) Sg[(long)blockIdx.x * wS + r] = T(0);
   for (int r = wave; r < m; r += 4) {
     double a = 0.0;
-    for (int c = lane; c < len; c += 64) { double x = (double)M[(long)r * ld + c]; a += x * x; }
+    for (int c = lane; c < len; c += 64) a += abs2_of(M[(long)r * ld + c]);
     a = wave_sum(a);
     if (lane == 0) s_norm[r] = sqrt(a);
   }
@@ -987,8 +989,8 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const T *__restrict__ 
     int rk = s_rank[r];
     if (rk >= kcut) continue;
     double nv = s_norm[r];
-    T inv = nv > nfloor ? T(1.0 / nv) : T(0);   // numerically zero direction -> zero row of Vt
-    for (int c = lane; c < len; c += 64) V[(long)rk * len + c] = M[(long)r * ld + c] * inv;
+    const double inv = nv > nfloor ? 1.0 / nv : 0.0;   // numerically zero direction -> zero row of Vt
+    for (int c = lane; c < len; c += 64) V[(long)rk * len + c] = scaled(M[(long)r * ld + c], inv);
     if (lane == 0 && nv > nfloor) atomicAdd(&s_klive, 1);
   }
   // rows are ranked by norm, so the non-zero rows of Vt are its first klive rows
@@ -1021,7 +1023,7 @@ __global__ __launch_bounds__(256) void normalize_kernel(T *__restrict__ Xg, long
   T *X = Xg + (long)blockIdx.x * wX;
   if (ndyn) n = min(n, ndyn[blockIdx.x] * ndyn_mul);
   double a = 0.0;
-  for (int i = tid; i < n; i += 256) { double x = (double)X[i]; a += x * x; }
+  for (int i = tid; i < n; i += 256) a += abs2_of(X[i]);
   a = wave_sum(a);
   if ((tid & 63) == 0) s_red[tid >> 6] = a;
   __syncthreads();
@@ -1032,8 +1034,8 @@ __global__ __launch_bounds__(256) void normalize_kernel(T *__restrict__ Xg, long
     if (tid == 0 && flag) flag[blockIdx.x] = 1;
     return;
   }
-  const T inv = T(1.0 / nrm);
-  for (int i = tid; i < n; i += 256) X[i] *= inv;
+  const double inv = 1.0 / nrm;
+  for (int i = tid; i < n; i += 256) X[i] = scaled(X[i], inv);
   if (tid == 0 && logscale) logscale[blockIdx.x] += log(nrm);
 }
 

@@ -1,0 +1,147 @@
+// Factorisation kernels of the chi-truncation for COMPLEX element types (TenElemT = QLTEN_Complex in the reference).
+// Parity-grade, not tuned: straightforward one-block-per-walker kernels with the same mathematics, thresholds and output
+// contract as their real counterparts in linalg.h (chol_upper_kernel, jacobi_rows_kernel); the tuned rank-adaptive
+// kernels (MFMA, register-resident Jacobi, Gram-free factor) are real-only.
+//   R^H R = G = P^H P (Hermitian, float64 complex)       replaces the R of qlten::QR, bmps_impl.h:821
+//   rows of M = R T  ->  sigma_k v_k^H by complex Hestenes rotations   replaces qlten::SVD, bmps_impl.h:235-238
+#pragma once
+#include "linalg.h"
+
+namespace pepsgpu {
+
+// In-place upper Cholesky of the Hermitian PSD matrix G (n x n, row-major, upper triangle read), right-looking in global
+// memory; a pivot below max(n eps64, (NOISE_C eps_T)^2) max(diag) drops its row.  Rout (n x n, type T): the live rows,
+// in order, scaled by 1 / sqrt(max diag), then zero rows; mlive_out[b] (optional) = live count.
+template <typename T>
+__global__ __launch_bounds__(256) void chol_upper_cplx_kernel(c128 *__restrict__ Gg, long wG, int n, T *__restrict__ Rg, long wR,
+                                                              int *__restrict__ mlive_out) {
+  __shared__ double s_red[4], s_maxd;
+  __shared__ double s_piv[1024], s_nrm[1024];
+  __shared__ short s_list[1024], s_pos[1024];
+  __shared__ int s_nl, s_cnt;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  c128 *G = Gg + (long)blockIdx.x * wG;
+  T *R = Rg + (long)blockIdx.x * wR;
+  double md = 0.0;
+  for (int i = tid; i < n; i += 256) md = fmax(md, G[(long)i * n + i].re);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
+  if (lane == 0) s_red[wave] = md;
+  if (tid == 0) s_nl = 0;
+  __syncthreads();
+  if (tid == 0) s_maxd = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+  __syncthreads();
+  const double maxd = s_maxd;
+  const double eT = NOISE_C * (double)Eps<T>::v;
+  const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
+  for (int j = 0; j < n; ++j) {
+    const double piv = G[(long)j * n + j].re;
+    if (!(piv > thresh)) continue;                      // block-uniform
+    if (tid == 0) { s_piv[s_nl] = piv; s_list[s_nl] = (short)j; s_nl = s_nl + 1; }
+    const double invp = 1.0 / piv;
+    for (int i = j + 1 + wave; i < n; i += 4) {         // G[i][r] -= conj(G[j][i]) G[j][r] / piv,  r >= i
+      const c128 f = conj_of(G[(long)j * n + i]) * invp;
+      for (int r = i + lane; r < n; r += 64) G[(long)i * n + r] -= f * G[(long)j * n + r];
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  const int nl = s_nl;
+  for (int q = wave; q < nl; q += 4) {
+    const int j = s_list[q];
+    double a = 0.0;
+    for (int r = j + lane; r < n; r += 64) a += abs2_of(G[(long)j * n + r]);
+    a = wave_sum(a);
+    if (lane == 0) s_nrm[q] = a / s_piv[q];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double f = 0.0;
+    for (int q = 0; q < nl; ++q) f += s_nrm[q];
+    const double nfloor = eT * eT * f;
+    int cnt = 0;
+    for (int q = 0; q < nl; ++q) s_pos[q] = s_nrm[q] > nfloor ? (short)cnt++ : (short)-1;
+    s_cnt = cnt;
+    if (mlive_out) mlive_out[blockIdx.x] = cnt;
+  }
+  __syncthreads();
+  const double sc = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
+  for (int q = wave; q < nl; q += 4) {
+    const int pos = s_pos[q];
+    if (pos < 0) continue;
+    const int j = s_list[q];
+    const double f = sc / sqrt(s_piv[q]);
+    for (int r = lane; r < n; r += 64) R[(long)pos * n + r] = r >= j ? T(scaled(G[(long)j * n + r], f)) : T(0);
+  }
+  for (int e = tid + s_cnt * n; e < n * n; e += 256) R[e] = T(0);
+}
+
+// One-sided Jacobi on the rows of a complex M (m x len, row stride ld) in global memory: round-robin tournament, one wave per
+// row pair.  A pair (x, y) with gamma = x^H y: y is first turned by the phase conj(gamma) / |gamma| (rows of Vt are defined up
+// to a phase), which makes the inner product real, then the real Hestenes rotation applies.  Threshold, noise floor and
+// termination as jacobi_rows_kernel.
+template <typename T>
+__global__ __launch_bounds__(1024) void jacobi_rows_cplx_kernel(T *__restrict__ Mg, long wM, int m, int len, int ld, int max_sweeps,
+                                                                int *__restrict__ sweeps_out) {
+  typedef typename real_of<T>::type R;
+  __shared__ int s_rot;
+  __shared__ double s_fro[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  T *M = Mg + (long)blockIdx.x * wM;
+  {
+    double f = 0.0;
+    for (int e = tid; e < m * len; e += blockDim.x) f += abs2_of(M[(long)(e / len) * ld + (e % len)]);
+    f = wave_sum(f);
+    if (lane == 0) s_fro[wave] = f;
+    __syncthreads();
+    if (tid == 0) { double t = 0.0; for (int w = 0; w < nw; ++w) t += s_fro[w]; s_fro[0] = t; }
+    __syncthreads();
+  }
+  const double floor2 = NOISE_C * NOISE_C * (double)Eps<T>::v * (double)Eps<T>::v * s_fro[0];
+  const double tol = 2.0 * sqrt((double)len) * (double)Eps<T>::v;
+  const int lp = m + (m & 1);
+  int sweep = 0;
+  for (; sweep < max_sweeps; ++sweep) {
+    if (tid == 0) s_rot = 0;
+    __syncthreads();
+    for (int r = 0; r < lp - 1; ++r) {
+      for (int p = wave; p < lp / 2; p += nw) {
+        int a, b;
+        if (p == 0) { a = lp - 1; b = r; }
+        else { a = (r + p) % (lp - 1); b = (r - p + (lp - 1)) % (lp - 1); }
+        if (a > b) { const int t = a; a = b; b = t; }
+        if (b >= m) continue;
+        T *pa = M + (long)a * ld, *pb = M + (long)b * ld;
+        double alpha = 0.0, beta = 0.0, gre = 0.0, gim = 0.0;
+        for (int c = lane; c < len; c += 64) {
+          const T x = pa[c], y = pb[c];
+          alpha += abs2_of(x); beta += abs2_of(y);
+          const T g = conj_of(x) * y;
+          gre += (double)g.re; gim += (double)g.im;
+        }
+        alpha = wave_sum(alpha); beta = wave_sum(beta); gre = wave_sum(gre); gim = wave_sum(gim);
+        const double absg = sqrt(gre * gre + gim * gim);
+        if (absg > tol * sqrt(alpha) * sqrt(beta) && alpha > floor2 && beta > floor2) {
+          const T ph = T(R(gre / absg), R(-gim / absg));
+          const double zeta = (beta - alpha) / (2.0 * absg);
+          const double td = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          const double cd = 1.0 / sqrt(1.0 + td * td), sd = cd * td;
+          for (int c = lane; c < len; c += 64) {
+            const T x = pa[c], y = pb[c] * ph;
+            pa[c] = scaled(x, cd) - scaled(y, sd);
+            pb[c] = scaled(x, sd) + scaled(y, cd);
+          }
+          if (lane == 0) atomicAdd(&s_rot, 1);
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    const int rot = s_rot;
+    __syncthreads();
+    if (rot == 0) { ++sweep; break; }
+  }
+  if (tid == 0 && sweeps_out) sweeps_out[blockIdx.x] = sweep;
+}
+
+}  // namespace pepsgpu

@@ -15,6 +15,7 @@
 // global loads.  A VALU path (PEPSGPU_NO_MFMA=1) exists only to cross-check the MFMA lane maps.
 #pragma once
 #include "common.h"
+#include "cplx.h"
 
 namespace pepsgpu {
 
@@ -49,6 +50,7 @@ struct TGemmDesc {
   int nbatch = 1;
   int accumulate = 0;
   int upper_only = 0;   // symmetric result (Gram): tiles strictly below the diagonal are not computed
+  int conjA = 0, conjB = 0;   // complex element types: the operand enters conjugated (P^H P, T V^H); no-op for real types
   const int *batch_flag = nullptr;   // when set, batch entry b runs only if batch_flag[b] < 0
   unsigned long long *flopc = nullptr;   // profiling: += 2*I*J*K of the extents actually contracted (per batch entry)
   unsigned long long *bytec = nullptr;   // profiling: += bytes of the live operand and result elements (compulsory traffic)
@@ -64,6 +66,7 @@ constexpr int TG_BM = 64, TG_BN = 64, TG_BK = 16, TG_KTAB = 2048;
 
 template <typename T> struct TgPitch { static constexpr int v = 64; };
 template <> struct TgPitch<double> { static constexpr int v = 80; };  // 640 B: halves land 128 B apart
+template <> struct TgPitch<c128> { static constexpr int v = 65; };
 
 // offset of flattened index idx; -1 when a sub-index is at or beyond its mask limit
 __device__ __forceinline__ int tg_off3m(int idx, const int *dims, const int *strides, const int *lim) {
@@ -163,6 +166,10 @@ __device__ __forceinline__ void tgemm_tile(const TGemmDesc &d, const TA *__restr
         int oa = offAi[ia], ob = offBj[jb];
         ra[r] = (oa >= 0 && kka < kchunk) ? TAcc(A[oa + offAk[kka]]) : TAcc(0);
         rb[r] = (ob >= 0 && kkb < kchunk) ? TAcc(B[ob + offBk[kkb]]) : TAcc(0);
+        if constexpr (is_cplx<TAcc>::value) {
+          if (d.conjA) ra[r] = conj_of(ra[r]);
+          if (d.conjB) rb[r] = conj_of(rb[r]);
+        }
       }
     };
     auto store_regs = [&]() {
@@ -534,10 +541,16 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
       return;
     }
   }
-  if (tgemm_use_mfma())
-    hipLaunchKernelGGL((tgemm_kernel<TA, TB, TC, TAcc, true>), grid, dim3(256), 0, s, d, A, B, C);
-  else
+  if constexpr (is_cplx<TAcc>::value) {
+    // complex element type (parity-grade path): the same tiling on the vector ALUs; there is no complex MFMA, and the
+    // 4-real-product form would need the operands de-interleaved
     hipLaunchKernelGGL((tgemm_kernel<TA, TB, TC, TAcc, false>), grid, dim3(256), 0, s, d, A, B, C);
+  } else {
+    if (tgemm_use_mfma())
+      hipLaunchKernelGGL((tgemm_kernel<TA, TB, TC, TAcc, true>), grid, dim3(256), 0, s, d, A, B, C);
+    else
+      hipLaunchKernelGGL((tgemm_kernel<TA, TB, TC, TAcc, false>), grid, dim3(256), 0, s, d, A, B, C);
+  }
   PG_CHECK_HIP(hipGetLastError());
 }
 

@@ -5,6 +5,12 @@ partition function; replacement traces re-insert the original tensors."""
 from oracle.bmps import LEFT, DOWN, RIGHT, UP, HORIZONTAL, VERTICAL
 from oracle.contractor import LEFTUP_TO_RIGHTDOWN as LU, LEFTDOWN_TO_RIGHTUP as LD
 
+def routes(rows=12):
+    """the walk for a lattice with `rows` rows (the vertical traces sit at rows - 2 and rows - 3, :303-311)"""
+    return [(op[0],) + tuple((rows - 12 + x) if (op[0] in ("trace", "tnn") and op[3] == VERTICAL and i == 0) else x
+                             for i, x in enumerate(op[1:])) for op in ROUTES]
+
+
 ROUTES = [
     ("grow_row", 2), ("init_bten", LEFT, 2), ("grow_full_bten", RIGHT, 2, 2),
     ("trace", 2, 0, HORIZONTAL), ("tnn", 2, 0, HORIZONTAL),
@@ -44,9 +50,9 @@ def tnn_sites(r, c, orient):
     return [(r, c + k) if orient == HORIZONTAL else (r + k, c) for k in range(3)]
 
 
-def run_oracle(c, tn):
+def run_oracle(c, tn, rows=12):
     amps = []
-    for op in ROUTES:
+    for op in routes(rows):
         k, a = op[0], op[1:]
         if k == "grow_row": c.GrowBMPSForRow(tn, a[0])
         elif k == "grow_col": c.GrowBMPSForCol(tn, a[0])
@@ -71,10 +77,10 @@ def run_oracle(c, tn):
     return amps
 
 
-def run_device(ctx):
+def run_device(ctx, rows=12):
     """same walk through the C ABI; replacement = the walker's own states (no candidate table)"""
     amps = []
-    for op in ROUTES:
+    for op in routes(rows):
         k, a = op[0], op[1:]
         if k == "grow_row": ctx.grow_bmps_for_row(a[0])
         elif k == "grow_col": ctx.grow_bmps_for_col(a[0])

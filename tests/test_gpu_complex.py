@@ -1,0 +1,187 @@
+"""Complex element type (PEPSGPU_C128 = QLTEN_Complex of the reference, whose hot-path tests are all compiled for double AND
+complex: tests/CMakeLists.txt:57-100) through the C ABI:
+  * amplitudes, replacement traces and holes of random complex states against the float64-complex oracle,
+  * K1-complex: the 12x12 critical Ising network with a random phase on every site tensor (test_bmps_contractor.cpp:244-262,
+    472-493): all 21 routes give the exact free energy to 1e-8 and a vanishing imaginary part,
+  * K2: the same physics on the 24 x 10 lattice in the Z2 (Hadamard) basis of the bonds with random phases, SVD(1, 10, 1e-15)
+    (test_bmps_contractor.cpp:499-686),
+  * K4-complex: the reference's 2x2 complex Heisenberg fixture, exact-summation energy -1.99521278793
+    (test_exact_summation_evaluator.cpp:606) from device amplitudes, with the device's complex replace-trace ratios."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ising, qlten_io, vmc
+from oracle.bmps import BMPSTruncateParams, LEFT, DOWN, RIGHT, UP, HORIZONTAL, VERTICAL
+from peps_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _complex_sitps(L, D, seed, rows=None):
+    rows = rows or L
+    rng = np.random.default_rng(seed)
+    out = []
+    for r in range(rows):
+        row = []
+        for c in range(L):
+            shp = (1 if c == 0 else D, 1 if r == rows - 1 else D, 1 if c == L - 1 else D, 1 if r == 0 else D)
+            row.append([(rng.uniform(0.2, 1.0, shp) * np.exp(2j * np.pi * rng.uniform(size=shp))
+                         + 0.5 * np.exp(2j * np.pi * rng.uniform())) / D for _ in range(2)])
+        out.append(row)
+    return out
+
+
+def _flat(sitps, D):
+    rows, cols, d = len(sitps), len(sitps[0]), len(sitps[0][0])
+    flat = np.zeros((rows, cols, d, D, D, D, D), dtype=np.complex128)
+    for r in range(rows):
+        for c in range(cols):
+            for s in range(d):
+                t = sitps[r][c][s]
+                flat[r, c, s, :t.shape[0], :t.shape[1], :t.shape[2], :t.shape[3]] = t
+    return flat
+
+
+@pytest.mark.parametrize("L,D,chi", [(4, 2, 4), (5, 3, 6), (6, 3, 9)])
+def test_complex_amplitude_traces_and_holes_vs_oracle(L, D, chi):
+    from peps_amd import capi
+    sitps = _complex_sitps(L, D, 17 * L + D)
+    cfgs = synthetic.make_configs(L, 3, "heisenberg", seed0=5)
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    ctx = capi.Context(L, L, D, 2, chi, dtype=capi.C128, max_walkers=len(cfgs))
+    ctx.state_upload(_flat(sitps, D))
+    ctx.set_configs(cfgs)
+    amps = ctx.evaluate_amplitude()
+    assert amps.dtype == np.complex128
+    comps = [vmc.TPSWaveFunctionComponent(sitps, c, tp) for c in cfgs]
+    ref = np.array([c.amplitude for c in comps])
+    assert np.max(np.abs(amps / ref - 1)) < 1e-9, (amps, ref)
+    # replacement traces along row 0 and hole . site == psi
+    cand = np.array([[(0, 1), (1, 0), (1, 1)]] * len(cfgs), dtype=np.int32)
+    rt = ctx.replace_nn_trace(0, 0, HORIZONTAL, cand)
+    for w, comp in enumerate(comps):
+        for k, (sa, sb) in enumerate(cand[w]):
+            r = comp.contractor.ReplaceNNSiteTrace(comp.tn, (0, 0), (0, 1), HORIZONTAL, sitps[0][0][sa], sitps[0][1][sb])
+            assert abs(rt[w, k] - r) < 1e-9 * abs(ref[w]), (w, k, rt[w, k], r)
+    ctx.grow_full_bten(RIGHT, 0, 1, True)            # right environment of (0, 0) = every other site of row 0
+    hole = ctx.punch_hole(0, 0, HORIZONTAL)
+    flat = _flat(sitps, D)
+    for w in range(len(cfgs)):
+        assert abs(np.sum(hole[w] * flat[0, 0, cfgs[w, 0, 0]]) / ref[w] - 1) < 1e-9
+    # the column route (LEFT / RIGHT stacks, reversed storage of RIGHT) against the oracle's column route
+    ctx.set_configs(cfgs)
+    ctx.grow_bmps_for_col(0)
+    ctx.init_bten(UP, 0)
+    ctx.grow_full_bten(DOWN, 0, 2, True)
+    col = ctx.trace(0, 0, VERTICAL)
+    for w, c in enumerate(cfgs):
+        comp = vmc.TPSWaveFunctionComponent(sitps, c, tp)
+        k, tn = comp.contractor, comp.tn
+        k.GrowBMPSForCol(tn, 0); k.InitBTen(tn, UP, 0); k.GrowFullBTen(tn, DOWN, 0, 2, True)
+        assert abs(col[w] / k.Trace(tn, (0, 0), VERTICAL) - 1) < 1e-9
+    ctx.close()
+
+
+def _phased(tn, rows, cols, seed):
+    """every site tensor times a random phase, the total phase taken off site (0, 0) (test_bmps_contractor.cpp:247-258)"""
+    rng = np.random.default_rng(seed)
+    ph = rng.uniform(size=(rows, cols))
+    out = [[[tn((r, c)).astype(np.complex128) * np.exp(2j * np.pi * ph[r, c])] for c in range(cols)] for r in range(rows)]
+    out[0][0][0] = out[0][0][0] * np.exp(-2j * np.pi * ph.sum())
+    return out
+
+
+def test_k1_complex_random_phase_network_all_21_routes():
+    import k1_routes
+    from peps_amd import capi
+    tn, lognorm, beta = ising.build_ising_tn(12, 12)
+    f_ex = ising.exact_free_energy(12, 12, 1.0 / beta)
+    sitps = _phased(tn, 12, 12, 3)
+    ctx = capi.Context(12, 12, 2, 1, 30, dtype=capi.C128, max_walkers=1, chi_min=10, trunc_err=1e-15)
+    ctx.state_upload(_flat(sitps, 2))
+    ctx.set_configs(np.zeros((1, 12, 12), dtype=np.int32))
+    amps = k1_routes.run_device(ctx)
+    assert len(amps) == k1_routes.N_AMPS
+    for a in amps:
+        z = complex(a[0])
+        assert abs(-(np.log(z.real) + lognorm) / 144 / beta - f_ex) < 1e-8
+        assert abs(z.imag) < 1e-10 * abs(z.real)
+    ctx.close()
+
+
+def test_k2_z2_basis_24x10_complex_and_real():
+    """K2: rows = 24, cols = 10, bonds in the Z2 (even / odd) basis -- the Hadamard transform of the K1 tensors, which
+    is what the reference's Z2-symmetric construction spans -- real and with random phases, SVD(1, 10, 1e-15)."""
+    import k1_routes
+    from peps_amd import capi
+    rows, cols = 24, 10
+    tn, lognorm, beta = ising.build_ising_tn(cols, rows)
+    f_ex = ising.exact_free_energy(cols, rows, 1.0 / beta)
+    H = np.array([[1.0, 1.0], [1.0, -1.0]]) / np.sqrt(2.0)
+
+    class Tn:      # every bond leg of dimension 2 rotated by H (H H = 1: the network value is unchanged)
+        def __call__(self, rc):
+            t = tn(rc)
+            for ax in range(4):
+                if t.shape[ax] == 2:
+                    t = np.moveaxis(np.tensordot(H, t, axes=([1], [ax])), 0, ax)
+            return t
+    z2 = Tn()
+    t_bulk = z2((5, 5))
+    par = np.indices(t_bulk.shape).sum(axis=0) % 2
+    assert np.max(np.abs(t_bulk[par == 1])) < 1e-14          # Z2 block structure: odd total parity vanishes
+    for cplx_mode in (False, True):
+        if cplx_mode:
+            sit = _phased(z2, rows, cols, 11)
+            flat, dt = _flat(sit, 2), capi.C128
+        else:
+            sit = [[[z2((r, c))] for c in range(cols)] for r in range(rows)]
+            flat, dt = _flat(sit, 2).real.copy(), capi.F64
+        ctx = capi.Context(rows, cols, 2, 1, 10, dtype=dt, max_walkers=1, chi_min=1, trunc_err=1e-15)
+        ctx.state_upload(flat)
+        ctx.set_configs(np.zeros((1, rows, cols), dtype=np.int32))
+        amps = k1_routes.run_device(ctx, rows)
+        for a in amps:
+            z = complex(a[0])
+            assert abs(-(np.log(z.real) + lognorm) / (rows * cols) / beta - f_ex) < 1e-8
+            assert abs(z.imag) < 1e-10 * abs(z.real)
+        ctx.close()
+
+
+def test_k4_complex_fixture_exact_sum_energy(fixtures_dir):
+    from peps_amd import capi
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, "heisenberg_tps_complex_from_simple_update"), complex_data=True)
+    D = max(max(t.shape) for row in s for comps in row for t in comps)
+    flat = _flat(s, D)
+    cfgs = np.array(vmc.generate_all_permutation_configs([2, 2], 2, 2), dtype=np.int32).reshape(-1, 2, 2)
+    ctx = capi.Context(2, 2, D, 2, 8, dtype=capi.C128, max_walkers=len(cfgs))
+    ctx.state_upload(flat)
+    ctx.set_configs(cfgs)
+    psi = ctx.evaluate_amplitude()
+    index = {tuple(c.ravel()): i for i, c in enumerate(cfgs)}
+    bonds = [((0, 0), (0, 1)), ((1, 0), (1, 1)), ((0, 0), (1, 0)), ((0, 1), (1, 1))]
+    num = 0.0
+    for i, c in enumerate(cfgs):
+        hpsi = 0.0
+        for (a, b) in bonds:
+            if c[a] == c[b]:
+                hpsi += 0.25 * psi[i]
+            else:
+                c2 = c.copy(); c2[a], c2[b] = c[b], c[a]
+                hpsi += -0.25 * psi[i] + 0.5 * psi[index[tuple(c2.ravel())]]
+        num += np.conj(psi[i]) * hpsi
+    energy = num / np.sum(np.abs(psi) ** 2)
+    assert abs(energy.real - (-1.99521278793)) < 1e-9 and abs(energy.imag) < 1e-12
+    # the ratios the reference's solver uses (ReplaceNNSiteTrace / psi, square_spin_onehalf_xxz_obc.h:72-104) in complex
+    ctx.set_configs(cfgs)
+    ctx.grow_bmps_for_row(0)
+    ctx.grow_full_bten(RIGHT, 0, 2, True)
+    ctx.init_bten(LEFT, 0)
+    cand = np.stack([np.array([[c[0, 1], c[0, 0]]], dtype=np.int32) for c in cfgs])
+    rt = ctx.replace_nn_trace(0, 0, HORIZONTAL, cand)[:, 0]
+    for i, c in enumerate(cfgs):
+        c2 = c.copy(); c2[0, 0], c2[0, 1] = c[0, 1], c[0, 0]
+        assert abs(rt[i] - psi[index[tuple(c2.ravel())]]) < 1e-10 * np.max(np.abs(psi))
+    ctx.close()
