@@ -512,6 +512,19 @@ struct FermionDecoration {
       for (size_t c = 0; c < cfg.cols(); ++c) nfm += n(cfg(w, {r, c}));
     return ((nfm + nfm * (nfm - 1) / 2) & 1) ? -1 : 1;
   }
+  // sign of reordering the occupied (odd) modes from row-major to column-major order: the decorated contraction in the
+  // column-major mode order gives the graded amplitude with the parity legs in column-major order, Kappa brings it to the
+  // row-major convention every stored amplitude uses
+  int Kappa(const Configuration &cfg, size_t w) const {
+    std::vector<std::pair<size_t, size_t>> keys;          // (col, row) of the occupied sites, listed in row-major order
+    for (size_t r = 0; r < cfg.rows(); ++r)
+      for (size_t c = 0; c < cfg.cols(); ++c)
+        if (n(cfg(w, {r, c}))) keys.emplace_back(c, r);
+    size_t inv = 0;
+    for (size_t i = 0; i < keys.size(); ++i)
+      for (size_t j = i + 1; j < keys.size(); ++j) inv += keys[i] > keys[j];
+    return (inv & 1) ? -1 : 1;
+  }
 };
 
 // TPSWaveFunctionComponent (wave_function_component.h:136-379), one entry per walker.  `config` is always the
@@ -599,7 +612,10 @@ struct TPSWaveFunctionComponent {
     for (size_t w = 0; w < mask.size(); ++w) {
       if (!mask[w]) continue;
       for (size_t k = 0; k < sites.size(); ++k) config(w, sites[k]) = new_states[w * sites.size() + k];
-      amplitude[w] = new_amplitude[w];
+      // new_amplitude is the contraction value of the replace-trace: for a fermionic state that is the DECORATED network
+      // of the current mode order; the stored amplitude is always the signed graded one (as EvaluateAmplitude stores it)
+      amplitude[w] = fermion ? new_amplitude[w] * fermion->Sigma(config, w) * (order == COL_MAJOR ? fermion->Kappa(config, w) : 1)
+                             : new_amplitude[w];
     }
   }
   bool IsAmplitudeSquareLegal(size_t w) const {          // :309-315

@@ -68,6 +68,30 @@ K4 = [("heisenberg_tps_double_from_simple_update", "xxz", -1.99521278793, 1e-10)
        -2.0 * (np.sqrt(2 - 2 * np.cos(np.pi / 4)) + np.sqrt(2 - 2 * np.cos(3 * np.pi / 4))), 6e-8)]
 
 
+@pytest.mark.parametrize("name,model,norm2,probe", [
+    ("heisenberg_tps_doublelowest", "xxz", 2.69115141087757e-08, 8.719330571244627e-09),
+    ("transverse_ising_tps_doublelowest", "tfim", 1.290630314256308e-10, 4.081475798300479e-11)])
+def test_reference_gradient_signatures_on_device(fixtures_dir, name, model, norm2, probe):
+    """The reference's golden gradient signatures (NormSquare, WeightedProbeInnerProduct: test_exact_summation_evaluator.cpp:
+    50-71, 575-576, 744-745) from the DEVICE gradient (C++ ExactSumEnergyEvaluator, holes resident in HBM, f64)."""
+    host = _host()
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, name))
+    flat = synthetic.sitps_to_flat(s, 4)
+    if model == "xxz":
+        cfgs, params = np.array(vmc.generate_all_permutation_configs([2, 2], 2, 2)), (1.0, 1.0, 0.0)
+    else:
+        cfgs, params = np.array(vmc.all_product_configs(2, 2, 2)), (1.0,)
+    e, grad = host.exact_sum_finish(host.exact_sum_partial(flat, cfgs, 8, model, params, 0, 1, 16, F64), flat.shape)
+    ns = wp = 0.0
+    for r in range(2):
+        for c in range(2):
+            for i in range(2):
+                n2 = float(np.sum(grad[r, c, i] ** 2))
+                ns += n2
+                wp += 0.012 * ((r + 1) * 11 + (c + 1) * 5 + (i + 1) * 2) * n2
+    assert abs(ns / norm2 - 1) < 1e-7 and abs(wp / probe - 1) < 1e-7
+
+
 @pytest.mark.parametrize("name,model,e_ref,tol", K4)
 def test_k4_exact_sum_on_device(fixtures_dir, name, model, e_ref, tol):
     """The reference's own exact-summation known answers (test_exact_summation_evaluator.cpp:139-174,

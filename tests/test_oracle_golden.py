@@ -282,3 +282,40 @@ def test_variational_compression_is_at_least_as_close_as_its_initial_guess(pos):
         assert d_var <= d_svd * (1 + 1e-6)                    # the variational optimum is no worse than the SVD sweep
         full = mps.multiply_mpo(mpo, scheme, D * D, D * D, 0.0, 1e-12, 5)
         assert np.linalg.norm(_mps_to_dense(full.tensors) - ex) < 1e-10 * np.linalg.norm(ex)
+
+
+# golden signatures of the exact-summation GRADIENT that the reference's tests hold (deterministic ones: NormSquare and
+# WeightedProbeInnerProduct, test_exact_summation_evaluator.cpp:50-71; the "random probe" ones need TensorToolkit's RNG)
+GRAD_SIGNATURES = [
+    ("heisenberg_tps_doublelowest", "xxz", 2.69115141087757e-08, 8.719330571244627e-09, "test_exact_summation_evaluator.cpp:575-576"),
+    ("transverse_ising_tps_doublelowest", "tfim", 1.290630314256308e-10, 4.081475798300479e-11, "test_exact_summation_evaluator.cpp:744-745"),
+]
+
+
+def gradient_signatures(grad):
+    """(NormSquare, WeightedProbeInnerProduct) of a SITPS-shaped gradient grad[r][c][i]: the probe multiplies component i of
+    site (r, c) by 0.012 ((r + 1) 11 + (c + 1) 5 + (i + 1) 2), so x * probe = sum of base times the component's norm^2."""
+    ns = wp = 0.0
+    for r, row in enumerate(grad):
+        for c, comps in enumerate(row):
+            for i, t in enumerate(comps):
+                n2 = float(np.sum(np.abs(np.asarray(t)) ** 2))
+                ns += n2
+                wp += 0.012 * ((r + 1) * 11 + (c + 1) * 5 + (i + 1) * 2) * n2
+    return ns, wp
+
+
+@pytest.mark.parametrize("name,model,norm2,probe,cite", GRAD_SIGNATURES)
+def test_reference_gradient_signatures(fixtures_dir, name, model, norm2, probe, cite):
+    """Row a17: the gradient <E* O*> - E* <O*> of the exact-sum evaluator reproduces the 16-digit golden values the
+    reference prints for its own fixtures (its assertion tolerance is an absolute 1e-8; here 1e-9 relative)."""
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, name))
+    tp = BMPSTruncateParams.SVD(1, 8, 1e-16)
+    if model == "xxz":
+        m, configs = vmc.SquareSpinOneHalfXXZModelOBC(), vmc.generate_all_permutation_configs([2, 2], 2, 2)
+    else:
+        m, configs = vmc.TransverseFieldIsingSquareOBC(1.0), vmc.all_product_configs(2, 2, 2)
+    e, grad, w = vmc.exact_sum_energy_evaluator(s, configs, tp, m)
+    ns, wp = gradient_signatures(grad)
+    assert abs(ns / norm2 - 1) < 1e-9, cite
+    assert abs(wp / probe - 1) < 1e-9, cite
