@@ -213,6 +213,8 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     }
     free_ten(X);
     const int rows = m * u, cols = l2 * a2;
+    // hint from the row absorbed before: its carry at the next site ran above the small rank cap of the factor kernels
+    const bool hint_dense = in.depth >= 3 && (int)in.mlmax.size() > i + 1 && in.mlmax[i + 1] > 14;
     constexpr int FUSED_KCAP = sizeof(T) == 4 ? 96 : 48;   // rows of P a thread of the fused kernel holds in registers
     static const bool no_fused = getenv("PEPSGPU_NO_FUSED_GRAMCHOL") != nullptr;
     if (rows < cols && adaptive && !no_fused && cols <= 256 && rows >= 16 && rows <= FUSED_KCAP) {
@@ -223,7 +225,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       int *ml = (int *)arena_.alloc(sizeof(int) * nw_);
       prof_begin(PROF_CHOL, nw_ * 2.0 * (2.0 * cols * (double)rows * rows - 2.0 / 3.0 * (double)rows * rows * rows), 0.0);
       launch_gram_chol_lowrank<T, FUSED_KCAP>(stream_, nw_, (const T *)P.p, P.n, cols, (const int *)mdyn[i], mmul[i] * u, rows,
-                                              R[i + 1].p, R[i + 1].n, ml, a2, (const int *)clive[i + 1]);
+                                              R[i + 1].p, R[i + 1].n, ml, a2, (const int *)clive[i + 1], 1, hint_dense);
       hipLaunchKernelGGL(adopt_rows_flagged_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)P.p, P.n, cols,
                          (const int *)mdyn[i], mmul[i] * u, rows, R[i + 1].p, R[i + 1].n, ml, a2, (const int *)clive[i + 1]);
       PG_CHECK_HIP(hipGetLastError());
@@ -262,7 +264,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         const int npass = (mdyn[i] && rows > FUSED_KCAP) ? std::max(1, max_pass) : 1;
         prof_begin(PROF_CHOL, 0.0, 0.0);
         launch_gram_chol_lowrank<T, FUSED_KCAP>(stream_, nw_, (const T *)P.p, P.n, cols, (const int *)mdyn[i], mmul[i] * u, rows,
-                                                R[i + 1].p, R[i + 1].n, ml, a2, (const int *)clive[i + 1], npass);
+                                                R[i + 1].p, R[i + 1].n, ml, a2, (const int *)clive[i + 1], npass, hint_dense);
         prof_end();
       }
       static const bool no_gd = getenv("PEPSGPU_NO_GRAMDIRECT") != nullptr;

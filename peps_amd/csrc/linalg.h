@@ -703,11 +703,16 @@ __global__ __launch_bounds__(NT, 2) void qr_lowrank_kernel(const T *__restrict__
   }
 }
 
+// (defined in trunc_mid.h) MFMA Gram of the live columns in registers + low-rank Cholesky, one kernel per walker
+template <typename T>
+inline void launch_colgram_chol(hipStream_t s, int nbatch, const T *P, long wP, int n, const int *kdyn, int kdyn_mul, int kmax,
+                                T *R, long wR, int *mlive, int inner, const int *inner_live, int decline_code, bool hint_dense);
+
 // Both variants in sequence: 128 threads per walker where the data columns fit, 256 otherwise.
 template <typename T, int KCAP>
 inline void launch_gram_chol_lowrank(hipStream_t s, int nbatch, const T *P, long wP, int n, const int *kdyn, int kdyn_mul,
                                      int kmax, T *R, long wR, int *mlive, int inner, const int *inner_live,
-                                     int max_pass = 1) {
+                                     int max_pass = 1, bool hint_dense = false) {
   static const bool no_narrow = getenv("PEPSGPU_NO_NARROW_FUSED") != nullptr;
   const bool narrow = !no_narrow && (inner_live != nullptr || n <= 128);
   // Householder form (working precision, no rank cap): measured on the headline workload it is slower than the Gram
@@ -731,15 +736,26 @@ inline void launch_gram_chol_lowrank(hipStream_t s, int nbatch, const T *P, long
   constexpr int KCAP_S = sizeof(T) == 4 ? 64 : 32;
   static const bool short_on = getenv("PEPSGPU_NO_SHORT_FUSED") == nullptr;   // measured: cholesky category 272 -> 215 ms per two steps
   const bool short_first = narrow && short_on && kdyn != nullptr;
-  if (short_first)
+  bool first_done = false;
+  if constexpr (sizeof(T) == 4) {
+    // dense states (hint): MFMA Gram in registers + low-rank Cholesky (trunc_mid.h) takes every walker with <= 128 live
+    // columns and rank <= 96, whatever the number of rows; what it declines (-4) goes down the kernels below
+    static const bool no_cg = getenv("PEPSGPU_NO_COLGRAM") != nullptr;
+    if (!no_cg && hint_dense && inner > 0 && n % inner == 0) {
+      launch_colgram_chol<T>(s, nbatch, P, wP, n, kdyn, kdyn_mul, kmax, R, wR, mlive, inner, inner_live, -4, hint_dense);
+      first_done = true;
+    }
+  }
+  if (short_first && !first_done)
     hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP_S, 128, 3, 16>), dim3(nbatch), dim3(128), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
                        R, wR, mlive, inner, inner_live, 0, std::max(max_pass, 2), 1);
+  const bool handed = short_first || first_done;
   if (narrow)
     hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP, 128>), dim3(nbatch), dim3(128), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
-                       R, wR, mlive, inner, inner_live, short_first ? 2 : 0, max_pass, 0);
+                       R, wR, mlive, inner, inner_live, handed ? 2 : 0, max_pass, 0);
   if (!narrow || n > 128)
     hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP, 256>), dim3(nbatch), dim3(256), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
-                       R, wR, mlive, inner, inner_live, narrow ? 1 : 0, max_pass, 0);
+                       R, wR, mlive, inner, inner_live, narrow ? 1 : (first_done ? 2 : 0), max_pass, 0);
   PG_CHECK_HIP(hipGetLastError());
 }
 

@@ -19,14 +19,50 @@ typedef double tm_f64x4 __attribute__((ext_vector_type(4)));
 constexpr int TM_KC = 32;    // columns of M staged per chunk
 constexpr int TM_LDM = TM_KC + 2;   // row pitch of the chunk: 16 rows x 2 k-lanes of an operand read hit 32 different banks
 
+// One staged chunk (TM_KC columns of the k index) of G += X X^T for the NQ tiles of this wave: per k-step of four, the 2 NQ
+// operand reads are issued together, then the NQ MFMAs -- branch free (rows of the chunk beyond the matrix are zero filled
+// once), so the LDS latency is paid once per k-step and not once per MFMA.  offa / offb = LDS offset of the tile's row.
+constexpr int TM_TPW = 9;                                // 36 tiles (order 128) / 4 waves
+template <int NQ>
+__device__ __forceinline__ void tm_gram_chunk(tm_f64x4 (&acc)[TM_TPW], const float *__restrict__ sX, const int (&offa)[TM_TPW],
+                                              const int (&offb)[TM_TPW], const int k4) {
+#pragma unroll 2
+  for (int s = 0; s < TM_KC / 4; ++s) {
+    double a[NQ], b[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      a[q] = (double)sX[offa[q] + 4 * s + k4];
+      b[q] = (double)sX[offb[q] + 4 * s + k4];
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc[q], 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void tm_gram_chunk_n(const int nq, tm_f64x4 (&acc)[TM_TPW], const float *__restrict__ sX,
+                                                const int (&offa)[TM_TPW], const int (&offb)[TM_TPW], const int k4) {
+  switch (nq) {                                          // wave-uniform
+    case 1: tm_gram_chunk<1>(acc, sX, offa, offb, k4); break;
+    case 2: tm_gram_chunk<2>(acc, sX, offa, offb, k4); break;
+    case 3: tm_gram_chunk<3>(acc, sX, offa, offb, k4); break;
+    case 4: tm_gram_chunk<4>(acc, sX, offa, offb, k4); break;
+    case 5: tm_gram_chunk<5>(acc, sX, offa, offb, k4); break;
+    case 6: tm_gram_chunk<6>(acc, sX, offa, offb, k4); break;
+    case 7: tm_gram_chunk<7>(acc, sX, offa, offb, k4); break;
+    case 8: tm_gram_chunk<8>(acc, sX, offa, offb, k4); break;
+    case 9: tm_gram_chunk<9>(acc, sX, offa, offb, k4); break;
+    default: break;
+  }
+}
+
 inline size_t mid_gram_chol_smem_bytes(int cap) {
-  return sizeof(double) * ((size_t)cap * (cap + 1) + 2 * (size_t)cap) + sizeof(float) * (size_t)cap * TM_LDM + sizeof(short) * 2 * (size_t)cap + 64;
+  const size_t capr = ((size_t)cap + 15) & ~(size_t)15;      // the staging buffer covers whole 16-row tiles
+  return sizeof(double) * ((size_t)cap * (cap + 1) + 2 * (size_t)cap) + sizeof(float) * capr * TM_LDM + sizeof(short) * 2 * (size_t)cap + 64;
 }
 
 // run_flag[b] < 0: the entry is on the route; n = nrows[b] in (lo, cap] is taken by this launch (another launch with a
 // different cap takes the rest).
 template <typename T>
-__global__ __launch_bounds__(256) void mid_gram_chol_kernel(const T *__restrict__ Mg, long wM, int uk, const int *__restrict__ nrows,
+__global__ __launch_bounds__(256, 2) void mid_gram_chol_kernel(const T *__restrict__ Mg, long wM, int uk, const int *__restrict__ nrows,
                                                             const int *__restrict__ run_flag, int lo, int cap,
                                                             T *__restrict__ Bg, long wB, int ld, int *__restrict__ mB) {
   static_assert(sizeof(T) == 4, "the mid route is f32 only (the f64 mode keeps the direct Jacobi)");
@@ -40,7 +76,7 @@ __global__ __launch_bounds__(256) void mid_gram_chol_kernel(const T *__restrict_
   double *sPiv = sG + (size_t)cap * ldG;                // [cap] pivot of a live row (0 = dropped)
   double *sNrm = sPiv + cap;                            // [cap] squared norm of a factor row
   float *sM = reinterpret_cast<float *>(sNrm + cap);    // [cap][TM_KC + 1] chunk of M
-  short *sList = reinterpret_cast<short *>(sM + (size_t)cap * TM_LDM);   // [cap] live rows in order
+  short *sList = reinterpret_cast<short *>(sM + (size_t)((cap + 15) & ~15) * TM_LDM);   // [cap] live rows in order
   short *sPos = sList + cap;                            // [cap] output position, -1 = dropped
   __shared__ double s_red[4], s_maxd, s_fro;
   __shared__ int s_nl, s_cnt;
@@ -50,44 +86,48 @@ __global__ __launch_bounds__(256) void mid_gram_chol_kernel(const T *__restrict_
 
   // ---- G = M M^T: 16 x 16 tiles on or above the diagonal, dealt round-robin to the four waves ----
   const int nt = (n + 15) >> 4, ntiles = nt * (nt + 1) / 2;
-  constexpr int TPW = 9;                                // 36 tiles (n = 128) / 4 waves
-  int ti[TPW], tj[TPW];
+  constexpr int TPW = TM_TPW;
+  const int r16 = lane & 15, k4 = lane >> 4;
+  int ti[TPW], tj[TPW], offa[TPW], offb[TPW];
+  int nq = 0;
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
     int t = wave + 4 * q, i = 0;
-    if (t < ntiles) { while (t >= nt - i) { t -= nt - i; ++i; } ti[q] = i; tj[q] = i + t; }
-    else { ti[q] = -1; tj[q] = -1; }
+    if (t < ntiles) { while (t >= nt - i) { t -= nt - i; ++i; } ti[q] = i; tj[q] = i + t; nq = q + 1; }
+    else { ti[q] = 0; tj[q] = 0; }
+    offa[q] = (16 * ti[q] + r16) * TM_LDM;
+    offb[q] = (16 * tj[q] + r16) * TM_LDM;
   }
   tm_f64x4 acc[TPW];
 #pragma unroll
   for (int q = 0; q < TPW; ++q)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[q][r] = 0.0;
-  const int r16 = lane & 15, k4 = lane >> 4;
+  // rows of the staging buffer beyond the matrix (tile padding) are read by the MFMA operands: zero, once
+  for (int e = tid + n * TM_LDM; e < 16 * nt * TM_LDM; e += 256) sM[e] = 0.f;
   for (int kc = 0; kc < uk; kc += TM_KC) {
     const int kw = min(TM_KC, uk - kc);
     __syncthreads();
-    for (int e = tid; e < n * TM_KC; e += 256) {
-      const int r = e / TM_KC, c = e % TM_KC;
-      sM[r * TM_LDM + c] = c < kw ? (float)M[(long)r * uk + kc + c] : 0.f;
-    }
-    __syncthreads();
+    {   // 32 columns x up to 128 rows = 16 elements per thread: unconditional loads (clamped address) all in flight, then the stores
+      float v[16];
 #pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-      if (ti[q] < 0) continue;                           // wave-uniform
-      const int ra = 16 * ti[q] + r16, rb = 16 * tj[q] + r16;
+      for (int i = 0; i < 16; ++i) {
+        const int e = tid + 256 * i, r = min(e >> 5, n - 1), c = min(e & 31, kw - 1);
+        v[i] = (float)M[(long)r * uk + kc + c];
+      }
 #pragma unroll
-      for (int s = 0; s < TM_KC / 4; ++s) {
-        const double a = ra < n ? (double)sM[ra * TM_LDM + 4 * s + k4] : 0.0;
-        const double bb = rb < n ? (double)sM[rb * TM_LDM + 4 * s + k4] : 0.0;
-        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[q], 0, 0, 0);
+      for (int i = 0; i < 16; ++i) {
+        const int e = tid + 256 * i, r = e >> 5, c = e & 31;
+        if (r < n) sM[r * TM_LDM + c] = c < kw ? v[i] : 0.f;
       }
     }
+    __syncthreads();
+    tm_gram_chunk_n(nq, acc, sM, offa, offb, k4);
   }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
-    if (ti[q] < 0) continue;
+    if (q >= nq) continue;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {                        // acc[r] = C[(lane >> 4) + 4 r][lane & 15]
       const int i = 16 * ti[q] + k4 + 4 * r, j = 16 * tj[q] + r16;
@@ -171,6 +211,207 @@ inline void launch_mid_gram_chol(hipStream_t s, int nbatch, const T *M, long wM,
     PG_CHECK_HIP(hipGetLastError());
     lo = cap;
   }
+}
+
+}  // namespace pepsgpu
+
+namespace pepsgpu {
+
+// ---------------------------------------------------------------------------------------------
+// Forward factor of the absorption in one kernel per walker: R^T R = P^T P for the LIVE columns of P (K live rows x n
+// columns; columns = (outer, inner), inner index live below inner_live[b]; at most 128 live columns).
+//
+//   Gram:      G = P^T P by v_mfma_f64_16x16x4_f64 from row chunks of P staged (transposed) in LDS; the 16 x 16 tiles on or
+//              above the diagonal stay in the ACCUMULATOR REGISTERS of the four waves -- G is never written anywhere.
+//   Cholesky:  right-looking, low-rank (the rule of chol_lowrank_kernel): the next pivot is the first live column whose
+//              remaining diagonal exceeds the noise of the T-typed data; row f of G is lifted out of the accumulators into
+//              an LDS row buffer, every thread (= column) subtracts the finished factor rows (kept in LDS, f64) and adds
+//              its entry of the new row.  Work and LDS follow the numerical RANK (rcap x n doubles), not n x n.
+//
+// Same output contract as gram_chol_lowrank_kernel (linalg.h): live rows compacted and scaled by 1 / sqrt(max diag),
+// written as type T at the original column positions, mlive_out[b] = live rows; an entry it cannot take (more than 128
+// live columns, rank above rcap) gets mlive_out[b] = decline_code and is left to the kernels launched after it.
+// It replaces, for the walkers it takes, the thread-per-column Gram-free kernel (f64 VALU dot products of K rows per
+// step: 26 % of the headline step) on the low-rank side and the streaming Gram + blocked Cholesky pair (global-memory
+// round trip of the 128 x 128 Gram) on the dense side.
+constexpr int CG_NC = 128;           // live columns at most
+constexpr int CG_LDR = CG_NC + 1;    // row pitch of the factor rows in LDS (doubles)
+
+inline size_t colgram_chol_smem_bytes(int rcap) {
+  return sizeof(double) * ((size_t)rcap * CG_LDR + CG_NC) + sizeof(float) * (size_t)CG_NC * TM_LDM + 64;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void colgram_chol_kernel(const T *__restrict__ Pg, long wP, int n, const int *__restrict__ kdyn,
+                                                           int kdyn_mul, int kmax, T *__restrict__ Rg, long wR,
+                                                           int *__restrict__ mlive_out, int inner,
+                                                           const int *__restrict__ inner_live, int rcap, int decline_code,
+                                                           int only_code) {
+  static_assert(sizeof(T) == 4, "f32 element type");
+  const int b = blockIdx.x;
+  if (only_code != 0 && mlive_out[b] != only_code) return;      // second launch (larger rcap): the entries the first declined
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = kdyn ? min(kmax, kdyn[b] * kdyn_mul) : kmax;
+  const int ilive = inner_live ? min(inner, inner_live[b]) : inner;
+  const int ncols = (n / inner) * ilive;
+  if (ncols > CG_NC) {
+    if (tid == 0) mlive_out[b] = decline_code;
+    return;
+  }
+  extern __shared__ double cg_smem[];
+  double *sR = cg_smem;                                   // [rcap][CG_LDR] finished factor rows (packed columns)
+  double *sRow = sR + (size_t)rcap * CG_LDR;              // [CG_NC] row f of G
+  float *sP = reinterpret_cast<float *>(sRow + CG_NC);    // [CG_NC][TM_LDM] chunk of P, transposed: [column][row]
+  __shared__ double s_red[4], s_nrm[128];
+  __shared__ int s_first[2][4];
+  __shared__ short s_pos[128];
+  const T *P = Pg + (long)b * wP;
+  T *Rout = Rg + (long)b * wR;
+  // packed column c -> column of P
+  const int my_r = tid < ncols ? (tid / ilive) * inner + (tid % ilive) : -1;
+
+  // ---- G = P^T P over the packed columns, upper tiles in registers ----
+  const int nt = (ncols + 15) >> 4, ntiles = nt * (nt + 1) / 2;
+  constexpr int TPW = TM_TPW;
+  const int r16 = lane & 15, k4 = lane >> 4;
+  int ti[TPW], tj[TPW], offa[TPW], offb[TPW];
+  int nq = 0;
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    int t = wave + 4 * q, i = 0;
+    if (t < ntiles) { while (t >= nt - i) { t -= nt - i; ++i; } ti[q] = i; tj[q] = i + t; nq = q + 1; }
+    else { ti[q] = -1; tj[q] = -1; }
+    offa[q] = (16 * max(ti[q], 0) + r16) * TM_LDM;
+    offb[q] = (16 * max(tj[q], 0) + r16) * TM_LDM;
+  }
+  tm_f64x4 acc[TPW];
+#pragma unroll
+  for (int q = 0; q < TPW; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[q][r] = 0.0;
+  const int st_c = tid & (CG_NC - 1);                                    // staging: packed column of this thread
+  const int st_r = st_c < ncols ? (st_c / ilive) * inner + (st_c % ilive) : -1;
+  // columns of the staging buffer beyond the live ones (tile padding) are read by the MFMA operands: zero, once
+  for (int e = tid + ncols * TM_LDM; e < CG_NC * TM_LDM; e += 256) sP[e] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += TM_KC) {
+    const int kw = min(TM_KC, K - k0);
+    __syncthreads();
+    if (st_r >= 0) {   // unconditional loads (clamped row), all 16 of the chunk in flight before the first store
+      float v[TM_KC / 2];
+#pragma unroll
+      for (int i = 0; i < TM_KC / 2; ++i) {
+        const int k = min((tid >> 7) + 2 * i, kw - 1);
+        v[i] = (float)P[(long)(k0 + k) * n + st_r];
+      }
+#pragma unroll
+      for (int i = 0; i < TM_KC / 2; ++i) {
+        const int k = (tid >> 7) + 2 * i;
+        sP[st_c * TM_LDM + k] = k < kw ? v[i] : 0.f;
+      }
+    }
+    __syncthreads();
+    tm_gram_chunk_n(nq, acc, sP, offa, offb, k4);
+  }
+  __syncthreads();
+  // diagonal -> sRow (used once, as the initial running diagonal)
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    if (ti[q] < 0 || ti[q] != tj[q]) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r16 == k4 + 4 * r) sRow[16 * ti[q] + r16] = acc[q][r];
+  }
+  __syncthreads();
+  double d = tid < ncols ? sRow[tid] : 0.0;             // running diagonal of the own column
+  double md = d;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
+  if (lane == 0) s_red[wave] = md;
+  __syncthreads();
+  const double maxd = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+  const double eT = NOISE_C * (double)Eps<T>::v;
+  const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
+
+  // ---- low-rank Cholesky ----
+  int nl = 0, f = -1;
+  for (int step = 0;; ++step) {
+    int cand = (tid < ncols && tid > f && d > thresh) ? tid : 0x7fffffff;
+    cand = wave_min_dpp(cand);
+    if (lane == 0) s_first[step & 1][wave] = cand;
+    __syncthreads();                                    // also: sRow / sR of the previous step are settled
+    f = min(min(s_first[step & 1][0], s_first[step & 1][1]), min(s_first[step & 1][2], s_first[step & 1][3]));
+    if (f == 0x7fffffff || nl >= K) break;              // the rank cannot exceed the K rows: later pivots are rounding noise
+    if (nl == rcap) {                                   // rank above the cap of this launch
+      if (tid == 0) mlive_out[b] = decline_code;
+      return;
+    }
+    // row f of G out of the accumulators: tiles (f / 16, tj >= f / 16), row f % 16 = lanes with k4 == (f % 16) % 4, register (f % 16) / 4
+    const int tr = f >> 4, il = f & 15, rsel = il >> 2;
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+      if (ti[q] != tr) continue;
+      const double v = rsel == 0 ? acc[q][0] : rsel == 1 ? acc[q][1] : rsel == 2 ? acc[q][2] : acc[q][3];
+      if (k4 == (il & 3)) sRow[16 * tj[q] + r16] = v;
+    }
+    __syncthreads();
+    if (tid < ncols) {
+      double g = sRow[tid], piv = sRow[f];
+      for (int j = 0; j < nl; ++j) {
+        const double rf = sR[j * CG_LDR + f];
+        g = fma(-rf, sR[j * CG_LDR + tid], g);
+        piv = fma(-rf, rf, piv);
+      }
+      const double v = tid >= f ? g / sqrt(piv) : 0.0;
+      sR[nl * CG_LDR + tid] = v;
+      if (tid > f) d -= v * v;
+    }
+    ++nl;
+  }
+  __syncthreads();
+  // ---- rank compaction (rows below NOISE_C eps_T |R|_F are dropped) and output ----
+  for (int j = wave; j < nl; j += 4) {
+    double a = 0.0;
+    for (int c = lane; c < ncols; c += 64) { const double x = sR[j * CG_LDR + c]; a += x * x; }
+    a = wave_sum(a);
+    if (lane == 0) s_nrm[j] = a;
+  }
+  __syncthreads();
+  double fro = 0.0;
+  for (int j = 0; j < nl; ++j) fro += s_nrm[j];
+  const double nfloor = eT * eT * fro;
+  if (tid == 0) {
+    int cnt = 0;
+    for (int j = 0; j < nl; ++j) s_pos[j] = s_nrm[j] > nfloor ? (short)cnt++ : (short)-1;
+    mlive_out[b] = cnt;
+  }
+  __syncthreads();
+  const double sc = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
+  if (my_r >= 0) {
+    for (int j = 0; j < nl; ++j) {
+      const int pos = s_pos[j];
+      if (pos >= 0) Rout[(long)pos * n + my_r] = T(sR[j * CG_LDR + tid] * sc);
+    }
+  }
+}
+
+// Used for DENSE states only (hint of the row absorbed before: carry rank above the caps of the thread-per-column
+// kernels), with the 96-row cap.  Measured on one MI355X, C4, two steps:
+//   dense state (noise 1.0, 4096 walkers): Gram + Cholesky 660 ms (streaming Gram + blocked Cholesky) -> 608 ms here;
+//   headline state (32768 walkers, rank ~10, cap 16): 200 ms against 194 ms of gram_chol_lowrank_kernel -- no gain: both
+//   are bound by the same chain of dependent HBM round trips (stage P, barriers), not by the arithmetic (2 us of MFMA per
+//   walker), so the headline keeps the thread-per-column kernel.  A launch whose blocks ask for the 118 KB of the 96-row cap
+//   runs one block per CU even when every block returns at once (+400 us per site on the headline batch): one launch per
+//   site, never a cascade of caps.
+template <typename T>
+inline void launch_colgram_chol(hipStream_t s, int nbatch, const T *P, long wP, int n, const int *kdyn, int kdyn_mul, int kmax,
+                                T *R, long wR, int *mlive, int inner, const int *inner_live, int decline_code, bool hint_dense) {
+  (void)hint_dense;
+  const int rcap = 96;
+  const size_t sm = colgram_chol_smem_bytes(rcap);
+  allow_dynamic_lds(reinterpret_cast<const void *>(&colgram_chol_kernel<T>), sm);
+  hipLaunchKernelGGL(colgram_chol_kernel<T>, dim3(nbatch), dim3(256), sm, s, P, wP, n, kdyn, kdyn_mul, kmax, R, wR, mlive, inner,
+                     inner_live, rcap, decline_code, 0);
+  PG_CHECK_HIP(hipGetLastError());
 }
 
 }  // namespace pepsgpu
