@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--walkers", type=int, default=None,
                     help="walkers (fresh configurations) per GPU per step; default 32768 (81 GB at the low-rank "
                          "headline workload), 4096 for f64 or for states of higher rank (--noise > 0.15: up to 11.6 MB / walker)")
-    ap.add_argument("--workload", default="C4", choices=["C2", "C3", "C4"])
+    ap.add_argument("--workload", default="C4", choices=["C2", "C3", "C4", "C5"],
+                    help="BASELINE config; C5 = 8x8 spinless-fermion t-V, fZ2-graded PEPS, D=6 chi=24 through the sign-decorated path")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -123,9 +124,24 @@ def pmc_traffic_bytes(category, args, nw, launches_per_step):
 class Leg:
     """One timed pass: `steps` batches of `nw` fresh configurations through EvaluateAmplitude on this rank's GPU."""
 
-    def __init__(self, capi, synthetic, L, D, chi, dt, device, nw, noise):
+    def __init__(self, capi, synthetic, L, D, chi, dt, device, nw, noise, fermionic=False):
         self.capi, self.synthetic = capi, synthetic
         self.L, self.D, self.chi, self.dt, self.device, self.nw, self.noise = L, D, chi, dt, device, nw, noise
+        self.fermion = None
+        if fermionic:
+            # C5: synthetic parity-even state (the reference ships no fermionic state beyond 2x2); a configuration enters the
+            # device as the row-major extended states of the decorated components (peps_amd/fermion.py), the graded amplitude
+            # is sigma(N_f) times the contraction -- the sign is applied on the host inside the timed region
+            from peps_amd import fermion
+            self.fermion = fermion
+            self.fstate = fermion.random_even_state(L, L, D, seed=11)
+            self.pdim = fermion.NVAR * self.fstate.d
+            self.ctx = capi.Context(L, L, D, self.pdim, chi, dtype=dt, device=device, max_walkers=nw)
+            self.flat = self.fstate.extended_flat(D)
+            self.ctx.state_upload(self.flat)
+            self.sitps = None
+            return
+        self.pdim = 2
         self.ctx = capi.Context(L, L, D, 2, chi, dtype=dt, device=device, max_walkers=nw)
         # synthetic state of SURVEY 8(d); psi(S_ref) normalisation evaluated with the device path itself
         sitps = synthetic.make_sitps(L, D, noise=noise)
@@ -140,10 +156,15 @@ class Leg:
         ctx, nw = self.ctx, self.nw
         total = warmup + steps
         self.batches = [self.synthetic.make_configs(self.L, nw, "heisenberg", seed0=7 + (s * world + rank) * nw) for s in range(total)]
+        sig = None
+        if self.fermion is not None:      # half filling: state 0 = occupied; device labels + graded sign per configuration
+            self.phys = self.batches
+            sig = [self.fstate.sigma(b) for b in self.phys]
+            self.batches = [self.fstate.ext_config(b, self.fermion.ROW) for b in self.phys]
         amps_first = None
         for s in range(warmup):
             ctx.set_configs(self.batches[s])
-            a = ctx.evaluate_amplitude()
+            a = ctx.evaluate_amplitude() * (sig[s] if sig else 1)
             if amps_first is None:
                 amps_first = a
         ctx.profile_enable(True)
@@ -153,7 +174,7 @@ class Leg:
         nz = 0
         for s in range(warmup, total):
             ctx.set_configs(self.batches[s])
-            a = ctx.evaluate_amplitude()
+            a = ctx.evaluate_amplitude() * (sig[s] if sig else 1)
             nz += int(np.count_nonzero(ctx.walker_flags()))
             if amps_first is None:
                 amps_first = a
@@ -168,7 +189,7 @@ class Leg:
         """numerical rank of the carry on this state (the Jacobi / Gram / Cholesky cost follows it); outside the timed region"""
         os.environ["PEPSGPU_DEBUG_SWEEPS"] = "1"
         try:
-            d = self.capi.Context(self.L, self.L, self.D, 2, self.chi, dtype=self.dt, device=self.device, max_walkers=16)
+            d = self.capi.Context(self.L, self.L, self.D, self.pdim, self.chi, dtype=self.dt, device=self.device, max_walkers=16)
             d.state_upload(self.flat)
             d.set_configs(self.batches[0][:16])
             d.evaluate_amplitude()
@@ -327,11 +348,13 @@ def main():
 
     from peps_amd import synthetic
     from peps_amd.flops import reference_flops
-    L, D, chi, model = synthetic.CONFIGS[args.workload]
+    fermionic = args.workload == "C5"
+    L, D, chi, model = (8, 6, 24, "spinless_tV") if fermionic else synthetic.CONFIGS[args.workload]
     nw = args.walkers
     fl = reference_flops(L, D, chi)
-    workload = ("%s: %dx%d spin-1/2 Heisenberg PEPS, D=%d, chi=%d, fresh EvaluateAmplitude per configuration "
-                "(SVD(chi,chi,0) truncation)" % (args.workload, L, L, D, chi))
+    workload = ("%s: %dx%d %s PEPS, D=%d, chi=%d, fresh EvaluateAmplitude per configuration (SVD(chi,chi,0) truncation)"
+                % (args.workload, L, L, "spinless-fermion t-V (fZ2-graded, sign-decorated components)" if fermionic
+                   else "spin-1/2 Heisenberg", D, chi))
 
     if args.dry_run:
         # plumbing only: rendezvous, barrier, max-over-ranks, one line from rank 0 -- no device, no measurement
@@ -353,7 +376,7 @@ def main():
 
     from peps_amd import capi
     dt = capi.F32 if args.dtype == "f32" else capi.F64
-    leg = Leg(capi, synthetic, L, D, chi, dt, local_rank, nw, args.noise)
+    leg = Leg(capi, synthetic, L, D, chi, dt, local_rank, nw, args.noise, fermionic)
     elapsed, prof, nz = leg.run(args.steps, args.warmup, rank, world, barrier)
     elapsed = max_over_ranks(elapsed)
 
@@ -405,16 +428,19 @@ def main():
         # contracted row-wise (DOWN stack, trace at row 0) and column-wise (RIGHT stack, trace at column 0) must agree
         nrc = 0 if args.no_route_check else min(nw, 2048)
         if nrc:
-            rctx = capi.Context(L, L, D, 2, chi, dtype=dt, device=local_rank, max_walkers=nrc)
+            rctx = capi.Context(L, L, D, leg.pdim, chi, dtype=dt, device=local_rank, max_walkers=nrc)
             rctx.state_upload(leg.flat)
             rctx.set_configs(leg.batches[0][:nrc])
             a_row = rctx.evaluate_amplitude()
-            rctx.set_configs(leg.batches[0][:nrc])
+            # (fermions: the column pass runs on the column-major decorated components; the two values then differ by the
+            # reordering sign of the occupied modes, so magnitudes are compared)
+            rctx.set_configs(leg.fstate.ext_config(leg.phys[0][:nrc], leg.fermion.COL) if leg.fermion else leg.batches[0][:nrc])
             rctx.grow_bmps_for_col(0)
             rctx.init_bten(capi.UP, 0)
             rctx.grow_full_bten(capi.DOWN, 0, 2, True)
             a_col = rctx.trace(0, 0, capi.VERTICAL)
-            out["route_consistency"] = {"max_rel_spread_row_vs_column_contraction": float(np.max(np.abs(a_col / a_row - 1))),
+            ratio = np.abs(a_col / a_row) if leg.fermion else a_col / a_row
+            out["route_consistency"] = {"max_rel_spread_row_vs_column_contraction": float(np.max(np.abs(ratio - 1))),
                                         "n": int(nrc)}
             rctx.close()
         if world == 1 and not args.no_cpu_baseline:
@@ -432,9 +458,19 @@ def main():
                 "host_cores": cb["cores"],
             }
             n = len(amps)
-            out["parity_on_sample"] = {"max_rel_err_amplitude": float(np.max(np.abs(leg.amps_first[:n] / amps - 1))), "n": int(n),
-                                       "tolerance": 1e-5, "checker": "oracle/cbmps.c (float64)"}
-        if world == 1 and not args.no_cpu_baseline and not args.no_energy_check:
+            if leg.fermion:
+                amps = amps * leg.fstate.sigma(leg.phys[0][:n])      # the C restatement contracts the decorated network
+            rel = np.abs(leg.amps_first[:n] / amps - 1)
+            out["parity_on_sample"] = {"max_rel_err_amplitude": float(np.max(rel)), "median_rel_err_amplitude": float(np.median(rel)),
+                                       "rms_err_over_rms_amplitude": float(np.sqrt(np.sum((leg.amps_first[:n] - amps) ** 2) / np.sum(amps ** 2))),
+                                       "n": int(n), "tolerance": 1e-5, "checker": "oracle/cbmps.c (float64)"}
+            if leg.fermion:
+                out["parity_on_sample"]["note"] = ("fermionic amplitudes are alternating sums: a configuration whose amplitude is "
+                                                   "orders of magnitude below the typical one loses that many digits in f32 (max); the "
+                                                   "tolerance 1e-4 applies to the rms error over the rms amplitude, the f64 mode is the "
+                                                   "parity-grade path (DESIGN.md 3b)")
+                out["parity_on_sample"]["tolerance"] = 1e-4
+        if world == 1 and not args.no_cpu_baseline and not args.no_energy_check and not fermionic:
             try:
                 out["energy_parity"] = energy_parity(leg, 1, 120.0)
                 out["energy_rel_err"] = out["energy_parity"]["max_rel_err_energy"]
@@ -444,7 +480,7 @@ def main():
     del leg
 
     # ---- second leg: the same shapes on a state of full rank (i.i.d. random site tensors) ----
-    if not args.no_full_rank and args.noise < 0.5:
+    if not args.no_full_rank and args.noise < 0.5 and not fermionic:
         fr = None
         try:
             fnw = min(args.full_rank_walkers, nw)
