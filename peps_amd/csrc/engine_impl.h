@@ -284,8 +284,8 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         g.upper_only = 1;                       // the Cholesky reads the upper triangle only
         g.batch_flag = fused ? ml : nullptr;
         // algorithmic flops of the op this replaces: geqrf + orgqr of (rows x cols)
-        prof_begin(PROF_GRAM, nw_ * 2.0 * (2.0 * rows * (double)cols * cols - 2.0 / 3.0 * (double)cols * cols * cols),
-                   nw_ * (double)cols * (cols + TG_BN) * rows);
+        // (executed flops of this category are counted on the device only: the launch runs for the flagged walkers)
+        prof_begin(PROF_GRAM, nw_ * 2.0 * (2.0 * rows * (double)cols * cols - 2.0 / 3.0 * (double)cols * cols * cols), 0.0);
         if (gram_direct)   // wave-per-block streaming kernel (gram.h): no LDS, no barrier; dead columns masked at the load
           launch_gram_cols_f64<T>(stream_, nw_, (const T *)P.p, P.n, cols, cols, (const int *)mdyn[i], mmul[i] * u, rows, G,
                                   (const int *)(fused ? ml : nullptr), a2, (const int *)clive[i + 1], tg_flop_counter,
@@ -489,17 +489,12 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       launch_jacobi(M.p, M.n, m, uk, use_lds, need, mdyn[i], mmul[i], mid ? MID_HI : 0);
       if constexpr (sizeof(T) == 4) {
         if (mid) {
-          static const bool dbg_t1 = getenv("PEPSGPU_MID_T1") != nullptr;
-          if (dbg_t1)
-            hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), 0, stream_, Bt.p, Bt.n, GS, GS, GS, 40, 0, sweeps_,
-                               (const int *)mB, 1, 0);
-          else {   // <= 64 live rows: two waves per walker (24 KB of LDS: six walkers per CU), else four
-            hipLaunchKernelGGL((jacobi_rows_regx_kernel<2, 2>), dim3(nw_), dim3(128), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS,
-                               40, sweeps_, (const int *)mB, 1, 0);
-            if (GS > 64)
-              hipLaunchKernelGGL((jacobi_rows_regx_kernel<4, 2>), dim3(nw_), dim3(256), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS,
-                                 40, sweeps_, (const int *)mB, 1, 64);
-          }
+          // <= 64 live rows: two waves per walker (24 KB of LDS: six walkers per CU), else four
+          hipLaunchKernelGGL((jacobi_rows_regx_kernel<2, 2>), dim3(nw_), dim3(128), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS,
+                             40, sweeps_, (const int *)mB, 1, 0);
+          if (GS > 64)
+            hipLaunchKernelGGL((jacobi_rows_regx_kernel<4, 2>), dim3(nw_), dim3(256), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS,
+                               40, sweeps_, (const int *)mB, 1, 64);
           PG_CHECK_HIP(hipGetLastError());
         }
       }
