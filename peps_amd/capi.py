@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpepsgpu.so")
+# PEPSGPU_LIB: another build of the same library (A/B measurements of kernel variants); there is no non-HIP implementation
+LIB_PATH = os.environ.get("PEPSGPU_LIB") or os.path.join(_HERE, "lib", "libpepsgpu.so")
 
 F32, F64 = 0, 1
 C128 = 3          # complex float64 (TenElemT = QLTEN_Complex): every scalar / tensor output becomes complex128

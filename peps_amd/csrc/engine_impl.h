@@ -144,6 +144,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
   };
   const int ll = (pos + 3) % 4, lp = pos, lr = (pos + 1) % 4, lu = (pos + 2) % 4;
   static const bool adaptive = getenv("PEPSGPU_NO_RANK_ADAPT") == nullptr;
+  static const int chain_chunks = getenv("PEPSGPU_CHAIN_CHUNKS") ? atoi(getenv("PEPSGPU_CHAIN_CHUNKS")) : 1;
 
   // ---------------- forward: R_{i+1} from P_i = R_i (A_i x W_i) ----------------
   std::vector<DTen<T>> R(N);
@@ -197,7 +198,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           mp.mapJ[1] = 1; mp.mapJ[2] = 5;      // J2 = (m, a2): m = I1[1], a2 = J1[2]
           prof_begin(PROF_CONTRACT, flx + flp, flx + flp);
           const bool ok = tgemm_chain_launch(stream_, gx, g2, mp, (const float *)R[i].p, (const float *)A.p,
-                                             (const float *)site_base(r, c), (float *)P.p, chain_flag);
+                                             (const float *)site_base(r, c), (float *)P.p, chain_flag, chain_chunks);
           prof_end();
           if (!ok) { arena_.free(chain_flag); chain_flag = nullptr; }
         }
@@ -377,7 +378,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           mp.mapJ[1] = 1; mp.mapJ[2] = 5;      // J2 = (a, k2): a = I1[1], k2 = J1[2]
           prof_begin(PROF_CONTRACT, 0.0, flz + flt);
           const bool ok = tgemm_chain_launch(stream_, gz, g2, mp, (const float *)A.p, (const float *)Y.p,
-                                             (const float *)site_base(r, c), (float *)Tt.p, chain_flag);
+                                             (const float *)site_base(r, c), (float *)Tt.p, chain_flag, chain_chunks);
           prof_end();
           if (!ok) { arena_.free(chain_flag); chain_flag = nullptr; }
         }

@@ -325,75 +325,160 @@ __device__ __forceinline__ void tg_apply_extents(TGemmDesc &d, const int b) {
 // d has its live extents applied; A, B, C are the entry's operand bases (generic pointers: an operand may live in LDS,
 // which is how tgemm_chain_kernel keeps the intermediate of two chained contractions on chip).  K2s = static extent of
 // k2 (vector loads stay inside it).
+// quotient and remainder of idx / dv (0 <= idx < 2^22, dv > 0) through the float reciprocal rcp ~ 1 / dv: the estimate is off by
+// at most one either way, two selects repair it -- a third of the instructions of the 32-bit integer division sequence
+__device__ __forceinline__ int tg_fdivmod(const int idx, const int dv, const float rcp, int &rem) {
+  int q = (int)((float)idx * rcp);
+  int r = idx - q * dv;
+  if (r < 0) { r += dv; --q; }
+  if (r >= dv) { r -= dv; ++q; }
+  rem = r;
+  return q;
+}
+
+// Offsets are handled in BYTES as unsigned 32-bit values (an operand of one batch entry is far below 4 GB): a load is
+// base pointer (uniform) + 32-bit lane offset, no 64-bit address arithmetic per element.
+__device__ __forceinline__ float tg_ldf(const float *__restrict__ base, const unsigned boff) {
+  return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + boff);
+}
+__device__ __forceinline__ float4 tg_ldf4(const float *__restrict__ base, const unsigned boff) {
+  return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + boff);
+}
+
+constexpr int TG_ZERO_ROW = 0x40000000;   // flag in the C-row offset table: the row exists in C but its A row reads as zero
+
 template <bool AVEC, bool BVEC>
 __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *__restrict__ A, const float *__restrict__ B,
                                                float *__restrict__ C, const int Itot, const int Jtot, const int K2s,
                                                int (*offCi_s)[32], const int tile0, const int tile_step) {
+  // Instruction budget (SQ counters, round 2: 36 VALU instructions per MFMA in the chained kernel, the launches were
+  // bound by VALU issue, not by memory): no integer division per lane (float-reciprocal split of the tile's row / column
+  // index), K walked with uniform counters, loads unconditional at clamped addresses (rows and columns that do not exist
+  // read row / column 0 and are never stored; k beyond the live extent is zeroed in the last round of a k2 run only),
+  // the loads of round r+1 issued before and consumed after the MFMAs of round r.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nti = (Itot + 31) >> 5, ntj = (Jtot + 31) >> 5, ntiles = nti * ntj;
-  (void)nti;
+  const int ntj = (Jtot + 31) >> 5, ntiles = ((Itot + 31) >> 5) * ntj;
   const float alpha = (float)d.alpha;
   const int half = lane >> 5, l31 = lane & 31;
-  const int K2 = d.K[2], K01 = d.K[0] * d.K[1];
-  const int nr8 = (K2 + 7) >> 3, nrounds = K01 * nr8;
-  const int sA2 = d.sAk[2], sB2 = d.sBk[2];
+  const int K2 = d.K[2], K1 = d.K[1];
+  const int nr8 = (K2 + 7) >> 3, nrounds = d.K[0] * K1 * nr8;
+  const unsigned sA2b = 4u * d.sAk[2], sB2b = 4u * d.sBk[2];
+  const float rI2 = __builtin_amdgcn_rcpf((float)d.I[2]), rI1 = __builtin_amdgcn_rcpf((float)d.I[1]);
+  const float rJ2 = __builtin_amdgcn_rcpf((float)d.J[2]), rJ1 = __builtin_amdgcn_rcpf((float)d.J[1]);
+  const int kh = 4 * half;
+  const bool accumulate = d.accumulate != 0;
 
   for (int t = tile0 + wave; t < ntiles; t += tile_step) {
     const int ti = t / ntj, tj = t - ti * ntj;
     const int i = ti * 32 + l31, j = tj * 32 + l31;
-    const int oa = (i < Itot) ? tg_off3m(i, d.I, d.sAi, d.Imask) : -1;
-    const int ob = (j < Jtot) ? tg_off3m(j, d.J, d.sBj, d.Jmask) : -1;
-    const int ocj = (j < Jtot) ? tg_off3(j, d.J, d.sCj) : -1;
-    if (half == 0) offCi_s[wave][l31] = (i < Itot) ? tg_off3(i, d.I, d.sCi) : -1;
+    unsigned oab, obb;    // byte offsets of this lane's A row / B column (0 when it does not exist)
+    int ocj;              // element offset of column j in C, -1: not stored; TG_ZERO_ROW set: stored as zero
+    {
+      int i2, i1, j2, j1;
+      const int qi = tg_fdivmod(i, d.I[2], rI2, i2);
+      const int i0 = tg_fdivmod(qi, d.I[1], rI1, i1);
+      const int qj = tg_fdivmod(j, d.J[2], rJ2, j2);
+      const int j0 = tg_fdivmod(qj, d.J[1], rJ1, j1);
+      const bool iv = i < Itot, jv = j < Jtot;
+      const bool iz = i2 >= d.Imask[2] || i1 >= d.Imask[1] || i0 >= d.Imask[0];
+      const bool jz = j2 >= d.Jmask[2] || j1 >= d.Jmask[1] || j0 >= d.Jmask[0];
+      oab = iv ? 4u * (unsigned)(i0 * d.sAi[0] + i1 * d.sAi[1] + i2 * d.sAi[2]) : 0u;
+      obb = jv ? 4u * (unsigned)(j0 * d.sBj[0] + j1 * d.sBj[1] + j2 * d.sBj[2]) : 0u;
+      const int oci = i0 * d.sCi[0] + i1 * d.sCi[1] + i2 * d.sCi[2];
+      if (half == 0) offCi_s[wave][l31] = iv ? (oci | (iz ? TG_ZERO_ROW : 0)) : -1;
+      ocj = jv ? ((j0 * d.sCj[0] + j1 * d.sCj[1] + j2 * d.sCj[2]) | (jz ? TG_ZERO_ROW : 0)) : -1;
+    }
     tg_f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    // one round of operand values for this lane: k2 = 8*r8 + 4*half + (0..3) at (k0, k1) = k01
-    auto load_round = [&](int rd, float (&av)[4], float (&bv)[4]) {
-      const int k01 = rd / nr8, r8 = rd - k01 * nr8;
-      const int k0 = k01 / d.K[1], k1 = k01 - k0 * d.K[1];
-      const int kq = 8 * r8 + 4 * half;
-      const int offa = oa + k0 * d.sAk[0] + k1 * d.sAk[1], offb = ob + k0 * d.sBk[0] + k1 * d.sBk[1];
+    int k0 = 0, k1 = 0, r8 = 0;          // uniform position of the round being loaded: (k0, k1), k2 = 8 r8 + 4 half + (0..3)
+    unsigned kab = 0, kbb = 0;           // byte offsets of (k0, k1) in A and B
+    auto advance = [&]() {
+      if (++r8 == nr8) {
+        r8 = 0;
+        if (++k1 == K1) { k1 = 0; ++k0; }
+        kab = 4u * (unsigned)(k0 * d.sAk[0] + k1 * d.sAk[1]);
+        kbb = 4u * (unsigned)(k0 * d.sBk[0] + k1 * d.sBk[1]);
+      }
+    };
+    auto load_raw = [&](float (&av)[4], float (&bv)[4]) {
+      const int kq = 8 * r8 + kh;
       if constexpr (AVEC) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (oa >= 0 && kq < K2s) v = *reinterpret_cast<const float4 *>(A + offa + kq);
-        av[0] = kq + 0 < K2 ? v.x : 0.f; av[1] = kq + 1 < K2 ? v.y : 0.f;
-        av[2] = kq + 2 < K2 ? v.z : 0.f; av[3] = kq + 3 < K2 ? v.w : 0.f;
+        const float4 v = tg_ldf4(A, oab + kab + 4u * (unsigned)min(kq, K2s - 4));
+        av[0] = v.x; av[1] = v.y; av[2] = v.z; av[3] = v.w;
       } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) av[q] = (oa >= 0 && kq + q < K2) ? A[offa + (kq + q) * sA2] : 0.f;
+        for (int q = 0; q < 4; ++q) av[q] = tg_ldf(A, oab + kab + (unsigned)min(kq + q, K2 - 1) * sA2b);
       }
       if constexpr (BVEC) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ob >= 0 && kq < K2s) v = *reinterpret_cast<const float4 *>(B + offb + kq);
-        bv[0] = kq + 0 < K2 ? v.x : 0.f; bv[1] = kq + 1 < K2 ? v.y : 0.f;
-        bv[2] = kq + 2 < K2 ? v.z : 0.f; bv[3] = kq + 3 < K2 ? v.w : 0.f;
+        const float4 v = tg_ldf4(B, obb + kbb + 4u * (unsigned)min(kq, K2s - 4));
+        bv[0] = v.x; bv[1] = v.y; bv[2] = v.z; bv[3] = v.w;
       } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bv[q] = (ob >= 0 && kq + q < K2) ? B[offb + (kq + q) * sB2] : 0.f;
+        for (int q = 0; q < 4; ++q) bv[q] = tg_ldf(B, obb + kbb + (unsigned)min(kq + q, K2 - 1) * sB2b);
+      }
+    };
+    auto mask_k = [&](const int r8m, float (&av)[4], float (&bv)[4]) {   // only the last round of a k2 run can be partial
+      if (8 * r8m + 8 > K2) {
+        const int kq = 8 * r8m + kh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool ok = kq + q < K2;
+          av[q] = ok ? av[q] : 0.f;
+          bv[q] = ok ? bv[q] : 0.f;
+        }
       }
     };
     float a0[4], b0[4], a1[4], b1[4];
-    if (nrounds > 0) load_round(0, a0, b0);
-    for (int rd = 0; rd < nrounds; rd += 2) {       // two rounds per trip: the next loads are in flight during the MFMAs
-      if (rd + 1 < nrounds) load_round(rd + 1, a1, b1);
+    auto mfma4 = [&](const float (&av)[4], const float (&bv)[4]) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b0[q], acc, 0, 0, 0);
-      if (rd + 2 < nrounds) load_round(rd + 2, a0, b0);
-      if (rd + 1 < nrounds) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], b1[q], acc, 0, 0, 0);
+      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+    };
+    if (nrounds > 0) {
+      load_raw(a0, b0);
+      mask_k(0, a0, b0);
+      int rd = 0;
+      // steady state without a conditional around the loads (the wait counters stay exact: the loads of the next round
+      // are in flight while the MFMAs of this one issue)
+      for (; rd + 2 < nrounds; rd += 2) {
+        advance();
+        const int r8b = r8;
+        load_raw(a1, b1);
+        mfma4(a0, b0);
+        mask_k(r8b, a1, b1);
+        advance();
+        const int r8a = r8;
+        load_raw(a0, b0);
+        mfma4(a1, b1);
+        mask_k(r8a, a0, b0);
+      }
+      if (rd + 1 < nrounds) {     // two rounds left
+        advance();
+        load_raw(a1, b1);
+        mfma4(a0, b0);
+        mask_k(r8, a1, b1);
+        mfma4(a1, b1);
+      } else {
+        mfma4(a0, b0);
       }
     }
+    // accumulator r of this lane = row 8 (r / 4) + 4 half + (r % 4), column l31 of the tile
+    const bool jzero = (ocj & TG_ZERO_ROW) != 0;
+    const int ocj_e = ocj & ~TG_ZERO_ROW;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int oi = offCi_s[wave][row];
-      if (oi >= 0 && ocj >= 0) {
-        float v = acc[r] * alpha;
-        if (d.accumulate) v += C[oi + ocj];
-        C[oi + ocj] = v;
+    for (int g = 0; g < 4; ++g) {
+      const int4 o4 = *reinterpret_cast<const int4 *>(&offCi_s[wave][8 * g + kh]);
+      const int oi4[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int oi = oi4[e];
+        if (oi >= 0 && ocj >= 0) {
+          float *p = C + ((oi & ~TG_ZERO_ROW) + ocj_e);
+          float v = ((oi & TG_ZERO_ROW) || jzero) ? 0.f : acc[4 * g + e] * alpha;
+          if (accumulate) v += *p;
+          *p = v;
+        }
       }
     }
   }
@@ -402,7 +487,7 @@ __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *
 template <bool AVEC, bool BVEC>
 __global__ __launch_bounds__(256, 6) void tgemm_direct_kernel(TGemmDesc d, const float *__restrict__ Ag,
                                                            const float *__restrict__ Bg, float *__restrict__ Cg) {
-  __shared__ int offCi_s[4][32];
+  __shared__ __attribute__((aligned(16))) int offCi_s[4][32];
   const int b = blockIdx.z;
   if (d.batch_flag && d.batch_flag[b] >= 0) return;
   const int K2s = d.K[2];                     // static extent of k2 (vector loads stay inside it)
@@ -439,8 +524,8 @@ struct TGemmChainMap { int mapK[3] = {-1, -1, -1}, mapJ[3] = {-1, -1, -1}; };
 template <bool AVEC1, bool BVEC1, bool AVEC2, int LDSF, int MINB>
 __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TGemmDesc d2, TGemmChainMap mp, const float *__restrict__ A1g,
                                                             const float *__restrict__ B1g, const float *__restrict__ A2g,
-                                                            float *__restrict__ C2g, int *__restrict__ flag, int only_flagged) {
-  __shared__ int offCi_s[4][32];
+                                                            float *__restrict__ C2g, int *__restrict__ flag, int only_flagged, int allow_chunks) {
+  __shared__ __attribute__((aligned(16))) int offCi_s[4][32];
   __shared__ float s_mid[LDSF];
   const int b = blockIdx.x;
   if (only_flagged && flag[b] >= 0) return;     // second launch (larger buffer, fewer blocks per CU): declined entries only
@@ -456,13 +541,26 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TG
   // compact LDS layout of C1 over the live dims of (I1 sub-indices, J1 sub-indices); a flattened dynI limit of stage 1
   // only leaves the rows beyond it unwritten (they are not read: stage 2 runs over the same live extents)
   int lds_stride[6];
+  int chunk = d1.I[1], jsub = -1;   // C1 is produced chunk values of I1[1] at a time (all of them when it fits the buffer)
   {
     int st = 1;
     for (int s = 2; s >= 0; --s) { lds_stride[3 + s] = st; st *= d1.J[s]; }
     for (int s = 2; s >= 0; --s) { lds_stride[s] = st; st *= d1.I[s]; }
     if (st > LDSF) {
-      if (threadIdx.x == 0) flag[b] = -1;
-      return;
+      // Larger live extents (states of higher rank): walk the middle I sub-index of stage 1 (the carry row m / the bond a)
+      // in chunks whose slice of C1 fits -- it is a J sub-index of stage 2, so every chunk is a complete pair of
+      // contractions on a slice of the result, and C1 still never leaves the chip.
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        if (mp.mapJ[s] == 1) jsub = (jsub < 0 && d2.Jmask[s] == 0x7fffffff) ? s : 3;
+        if (mp.mapK[s] == 1) jsub = 3;
+      }
+      const int per = lds_stride[1];    // floats of C1 per value of I1[1]
+      if (!allow_chunks || d1.I[0] != 1 || d1.dynI || d2.dynI || jsub < 0 || jsub > 2 || per > LDSF || d1.Imask[1] != 0x7fffffff) {
+        if (threadIdx.x == 0) flag[b] = -1;
+        return;
+      }
+      chunk = LDSF / per;
     }
   }
   if (threadIdx.x == 0) flag[b] = 0;
@@ -485,15 +583,31 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TG
   if (d1.selB) baseB1 += (long)d1.selB[(long)(b / d1.seldivB) * d1.selB_inc] * d1.selB_mul;
   if (d2.selA) baseA2 += (long)d2.selA[(long)(b / d2.seldivA) * d2.selA_inc] * d2.selA_mul;
   d1.accumulate = 0;
-  tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1, B1g + baseB1, s_mid, I1, J1, K2s1, offCi_s, 0, 4);
-  __syncthreads();
-  tg_direct_body<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC, I2, J2, K2s2, offCi_s, 0, 4);
+  if (chunk >= d1.I[1]) {
+    tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1, B1g + baseB1, s_mid, I1, J1, K2s1, offCi_s, 0, 4);
+    __syncthreads();
+    tg_direct_body<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC, I2, J2, K2s2, offCi_s, 0, 4);
+    return;
+  }
+  const int n1 = d1.I[1];
+  const int sA1 = d1.sAi[1], sC2 = jsub == 0 ? d2.sCj[0] : jsub == 1 ? d2.sCj[1] : d2.sCj[2];
+  for (int c0 = 0; c0 < n1; c0 += chunk) {
+    const int cn = min(chunk, n1 - c0);
+    d1.I[1] = cn;
+#pragma unroll
+    for (int s = 0; s < 3; ++s)      // (no dynamic indexing: the descriptors stay in registers)
+      if (s == jsub) d2.J[s] = cn;
+    if (c0) __syncthreads();     // stage 2 of the chunk before has read the buffer
+    tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1 + (long)c0 * sA1, B1g + baseB1, s_mid, d1.Itot(), J1, K2s1, offCi_s, 0, 4);
+    __syncthreads();
+    tg_direct_body<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC + (long)c0 * sC2, I2, d2.Jtot(), K2s2, offCi_s, 0, 4);
+  }
 }
 
 // stage 2 of the chain must read exactly what stage 1 wrote: same live extents on the shared sub-indices (the caller
 // sets the same TgDyn on both), no masks on them.  Returns false when the static shapes rule the chain out.
 inline bool tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemmDesc &d2_in, const TGemmChainMap &mp,
-                               const float *A1, const float *B1, const float *A2, float *C2, int *flag);
+                               const float *A1, const float *B1, const float *A2, float *C2, int *flag, int allow_chunks = 0);
 
 bool tgemm_use_mfma();
 
@@ -555,7 +669,7 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
 }
 
 inline bool tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemmDesc &d2_in, const TGemmChainMap &mp,
-                               const float *A1, const float *B1, const float *A2, float *C2, int *flag) {
+                               const float *A1, const float *B1, const float *A2, float *C2, int *flag, int allow_chunks) {
   if (!tgemm_use_mfma() || d1_in.dynK || d2_in.dynK || d1_in.nbatch != d2_in.nbatch || d1_in.nbatch <= 0) return false;
   if (d1_in.bdivA != 1 || d1_in.bdivB != 1 || d2_in.bdivA != 1 || d2_in.bdivC != 1) return false;
   TGemmDesc d1 = d1_in, d2 = d2_in;
@@ -572,7 +686,7 @@ inline bool tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGem
   const dim3 g(d1.nbatch), blk(256);
 #define PG_CHAIN(a1, b1, a2)                                                                                                   \
   do {                                                                                                                         \
-    hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 6>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0); \
+    hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 6>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
   } while (0)
   if (avec1 && bvec1 && avec2) PG_CHAIN(true, true, true);
   else if (avec1 && bvec1) PG_CHAIN(true, true, false);

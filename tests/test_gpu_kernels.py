@@ -341,31 +341,36 @@ def test_gram_free_factor_mixed_rows_and_ranks_in_one_launch(dt):
 
 def test_chained_contraction_pair_with_live_extents():
     """tgemm_chain_kernel (X = R.A kept in LDS, P = W.X) with the descriptors of the absorption: per-walker live extents of
-    the carry rows and of both bonds, entries whose live X exceeds the 24 KB LDS buffer are flagged and left untouched."""
+    the carry rows and of both bonds.  Entries whose live X exceeds the 24 KB LDS buffer are walked in chunks of carry rows
+    (X still never leaves the chip); an entry is declined (flag -1, result untouched) only when one carry row's slice of X
+    does not fit."""
     from peps_amd import capi
     rng = np.random.default_rng(5)
-    nb, m, l, a, p, a2, l2, u = 48, 24, 8, 16, 8, 16, 8, 8
-    R = rng.standard_normal((nb, m, l, a)).astype(np.float32)
-    A = rng.standard_normal((nb, a, p, a2)).astype(np.float32)
-    W = rng.standard_normal((nb, l, p, l2, u)).astype(np.float32)
-    live = np.stack([rng.integers(1, m + 1, nb), rng.integers(1, a + 1, nb), rng.integers(1, a2 + 1, nb)], axis=1)
-    live[0] = (m, a, a2)                       # static extents: 24*8*8*16 = 24576 floats > 6144 -> flagged
-    live[1] = (8, 10, 10)                      # the headline's typical live sizes: 8*8*8*10 = 5120 -> chained
-    P, fl = capi.diag_tgemm_chain(R, A, W, live)
-    n_chain = 0
-    for b in range(nb):
-        ml, al, a2l = (int(x) for x in live[b])
-        fits = ml * l * p * a2l <= 6144
-        assert fl[b] == (0 if fits else -1), (b, live[b], fl[b])
-        if not fits:
-            assert not np.any(P[b])
-            continue
-        n_chain += 1
-        X = np.einsum("mla,apc->mlpc", R[b, :ml, :, :al].astype(np.float64), A[b, :al, :, :a2l].astype(np.float64))
-        want = np.einsum("mlpc,lpqu->muqc", X, W[b].astype(np.float64))
-        got = P[b, :ml, :, :, :a2l]
-        assert np.max(np.abs(got - want)) < 2e-5 * np.max(np.abs(want)), (b, live[b])
-    assert n_chain > 5 and n_chain < nb
+    for (nb, m, l, a, p, a2, l2, u) in [(48, 24, 8, 16, 8, 16, 8, 8), (6, 40, 8, 32, 8, 32, 8, 8), (4, 5, 8, 8, 8, 128, 4, 4)]:
+        R = rng.standard_normal((nb, m, l, a)).astype(np.float32)
+        A = rng.standard_normal((nb, a, p, a2)).astype(np.float32)
+        W = rng.standard_normal((nb, l, p, l2, u)).astype(np.float32)
+        live = np.stack([rng.integers(1, m + 1, nb), rng.integers(1, a + 1, nb), rng.integers(1, a2 + 1, nb)], axis=1)
+        live[0] = (m, a, a2)                       # static extents: chunks of carry rows (or declined: third shape)
+        live[1] = (min(m, 8), min(a, 10), 10)      # the headline's typical live sizes: 8*8*8*10 = 5120 -> one chunk
+        P, fl = capi.diag_tgemm_chain(R, A, W, live)
+        n_chunked = 0
+        for b in range(nb):
+            ml, al, a2l = (int(x) for x in live[b])
+            fits_row = l * p * a2l <= 6144
+            assert fl[b] == (0 if fits_row else -1), (b, live[b], fl[b])
+            if not fits_row:
+                assert not np.any(P[b])
+                continue
+            n_chunked += ml * l * p * a2l > 6144
+            X = np.einsum("mla,apc->mlpc", R[b, :ml, :, :al].astype(np.float64), A[b, :al, :, :a2l].astype(np.float64))
+            want = np.einsum("mlpc,lpqu->muqc", X, W[b].astype(np.float64))
+            got = P[b, :ml, :, :, :a2l]
+            assert np.max(np.abs(got - want)) < 2e-5 * np.max(np.abs(want)), (b, live[b])
+        if a2 <= 32:
+            assert n_chunked >= 1
+        else:
+            assert fl[0] == -1
 
 
 @pytest.mark.parametrize("shape", [(128, 128), (70, 70), (96, 96), (33, 64), (100, 128), (17, 40), (64, 64)])
