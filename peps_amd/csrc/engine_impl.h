@@ -184,6 +184,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       const double flx = 2.0 * nw_ * (double)(m * l) * a * (double)(p * a2);
       const double flp = 2.0 * nw_ * (double)(m * a2) * (double)(l * p) * (double)(l2 * u);
       int *chain_flag = nullptr;
+      int chained = 0;
       if constexpr (sizeof(T) == 4) {
         static const bool no_chain = getenv("PEPSGPU_NO_CHAIN") != nullptr;
         if (!no_chain) {
@@ -197,19 +198,21 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           mp.mapK[1] = 2; mp.mapK[2] = 4;      // K2 = (l, p): l = I1[2], p = J1[1]
           mp.mapJ[1] = 1; mp.mapJ[2] = 5;      // J2 = (m, a2): m = I1[1], a2 = J1[2]
           prof_begin(PROF_CONTRACT, flx + flp, flx + flp);
-          const bool ok = tgemm_chain_launch(stream_, gx, g2, mp, (const float *)R[i].p, (const float *)A.p,
-                                             (const float *)site_base(r, c), (float *)P.p, chain_flag, chain_chunks);
+          chained = tgemm_chain_launch(stream_, gx, g2, mp, (const float *)R[i].p, (const float *)A.p,
+                                       (const float *)site_base(r, c), (float *)P.p, chain_flag, chain_chunks);
           prof_end();
-          if (!ok) { arena_.free(chain_flag); chain_flag = nullptr; }
+          if (!chained) { arena_.free(chain_flag); chain_flag = nullptr; }
         }
       }
-      gx.batch_flag = chain_flag; gp.batch_flag = chain_flag;
-      prof_begin(PROF_CONTRACT, chain_flag ? 0.0 : flx, chain_flag ? 0.0 : flx);
-      tgemm_launch<T, T, T, T>(stream_, gx, R[i].p, A.p, X.p);
-      prof_end();
-      prof_begin(PROF_CONTRACT, chain_flag ? 0.0 : flp, chain_flag ? 0.0 : flp);
-      launch_site_gemm_a(gp, cfg_site(r, c), 1, X.p, P.p);
-      prof_end();
+      if (chained < 2) {   // the two separate launches: for the entries the chain declined (all of them when it did not run)
+        gx.batch_flag = chain_flag; gp.batch_flag = chain_flag;
+        prof_begin(PROF_CONTRACT, chain_flag ? 0.0 : flx, chain_flag ? 0.0 : flx);
+        tgemm_launch<T, T, T, T>(stream_, gx, R[i].p, A.p, X.p);
+        prof_end();
+        prof_begin(PROF_CONTRACT, chain_flag ? 0.0 : flp, chain_flag ? 0.0 : flp);
+        launch_site_gemm_a(gp, cfg_site(r, c), 1, X.p, P.p);
+        prof_end();
+      }
       if (chain_flag) arena_.free(chain_flag);
     }
     free_ten(X);
@@ -366,6 +369,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       const double flz = 2.0 * nw_ * (double)(a * p) * a2 * (double)(l2 * k2);
       const double flt = 2.0 * nw_ * (double)(a * k2) * (double)(p * l2) * (double)(l * u);
       int *chain_flag = nullptr;
+      int chained = 0;
       if constexpr (sizeof(T) == 4) {
         static const bool no_chain = getenv("PEPSGPU_NO_CHAIN") != nullptr;
         if (!no_chain) {   // Z1 stays in LDS (see the forward pair)
@@ -377,19 +381,21 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           mp.mapK[1] = 2; mp.mapK[2] = 4;      // K2 = (p, l2): p = I1[2], l2 = J1[1]
           mp.mapJ[1] = 1; mp.mapJ[2] = 5;      // J2 = (a, k2): a = I1[1], k2 = J1[2]
           prof_begin(PROF_CONTRACT, 0.0, flz + flt);
-          const bool ok = tgemm_chain_launch(stream_, gz, g2, mp, (const float *)A.p, (const float *)Y.p,
-                                             (const float *)site_base(r, c), (float *)Tt.p, chain_flag, chain_chunks);
+          chained = tgemm_chain_launch(stream_, gz, g2, mp, (const float *)A.p, (const float *)Y.p,
+                                       (const float *)site_base(r, c), (float *)Tt.p, chain_flag, chain_chunks);
           prof_end();
-          if (!ok) { arena_.free(chain_flag); chain_flag = nullptr; }
+          if (!chained) { arena_.free(chain_flag); chain_flag = nullptr; }
         }
       }
-      gz.batch_flag = chain_flag; gt.batch_flag = chain_flag;
-      prof_begin(PROF_CONTRACT, 0.0, chain_flag ? 0.0 : flz);
-      tgemm_launch<T, T, T, T>(stream_, gz, A.p, Y.p, Z1.p);
-      prof_end();
-      prof_begin(PROF_CONTRACT, 0.0, chain_flag ? 0.0 : flt);
-      launch_site_gemm_a(gt, cfg_site(r, c), 1, Z1.p, Tt.p);
-      prof_end();
+      if (chained < 2) {
+        gz.batch_flag = chain_flag; gt.batch_flag = chain_flag;
+        prof_begin(PROF_CONTRACT, 0.0, chain_flag ? 0.0 : flz);
+        tgemm_launch<T, T, T, T>(stream_, gz, A.p, Y.p, Z1.p);
+        prof_end();
+        prof_begin(PROF_CONTRACT, 0.0, chain_flag ? 0.0 : flt);
+        launch_site_gemm_a(gt, cfg_site(r, c), 1, Z1.p, Tt.p);
+        prof_end();
+      }
       if (chain_flag) arena_.free(chain_flag);
     }
     free_ten(Z1);

@@ -606,8 +606,10 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TG
 
 // stage 2 of the chain must read exactly what stage 1 wrote: same live extents on the shared sub-indices (the caller
 // sets the same TgDyn on both), no masks on them.  Returns false when the static shapes rule the chain out.
-inline bool tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemmDesc &d2_in, const TGemmChainMap &mp,
-                               const float *A1, const float *B1, const float *A2, float *C2, int *flag, int allow_chunks = 0);
+// Returns 0 when the static shapes rule the chain out, 1 when launched (entries may be declined: flag -1), 2 when launched and
+// no entry can be declined (every slice of the intermediate fits the buffer: the caller skips the fallback launches).
+inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemmDesc &d2_in, const TGemmChainMap &mp,
+                              const float *A1, const float *B1, const float *A2, float *C2, int *flag, int allow_chunks = 0);
 
 bool tgemm_use_mfma();
 
@@ -668,10 +670,10 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
   PG_CHECK_HIP(hipGetLastError());
 }
 
-inline bool tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemmDesc &d2_in, const TGemmChainMap &mp,
-                               const float *A1, const float *B1, const float *A2, float *C2, int *flag, int allow_chunks) {
-  if (!tgemm_use_mfma() || d1_in.dynK || d2_in.dynK || d1_in.nbatch != d2_in.nbatch || d1_in.nbatch <= 0) return false;
-  if (d1_in.bdivA != 1 || d1_in.bdivB != 1 || d2_in.bdivA != 1 || d2_in.bdivC != 1) return false;
+inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemmDesc &d2_in, const TGemmChainMap &mp,
+                              const float *A1, const float *B1, const float *A2, float *C2, int *flag, int allow_chunks) {
+  if (!tgemm_use_mfma() || d1_in.dynK || d2_in.dynK || d1_in.nbatch != d2_in.nbatch || d1_in.nbatch <= 0) return 0;
+  if (d1_in.bdivA != 1 || d1_in.bdivB != 1 || d2_in.bdivA != 1 || d2_in.bdivC != 1) return 0;
   TGemmDesc d1 = d1_in, d2 = d2_in;
   d1.flopc = tg_flop_counter; d1.bytec = tg_byte_counter;
   d1.flop_stride = d1.nbatch >= 256 ? 64 : 1;
@@ -698,7 +700,16 @@ inline bool tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGem
   else PG_CHAIN(false, false, false);
 #undef PG_CHAIN
   PG_CHECK_HIP(hipGetLastError());
-  return true;
+  // the kernel's own test, on the static extents (live extents are never larger)
+  int jsub = -1;
+  for (int q = 0; q < 3; ++q) {
+    if (mp.mapJ[q] == 1) jsub = (jsub < 0 && !(d2.dJ[q].p && d2.dJ[q].mask)) ? q : 3;
+    if (mp.mapK[q] == 1) jsub = 3;
+  }
+  const long whole = (long)d1.Itot() * d1.Jtot(), per = (long)d1.I[2] * d1.Jtot();
+  const bool chunkable = allow_chunks && d1.I[0] == 1 && !d1.dynI && !d2.dynI && jsub >= 0 && jsub <= 2 &&
+                         !(d1.dI[1].p && d1.dI[1].mask) && per <= TG_CHAIN_LDS_FLOATS;
+  return (whole <= TG_CHAIN_LDS_FLOATS || chunkable) ? 2 : 1;
 }
 
 }  // namespace pepsgpu
