@@ -993,7 +993,8 @@ class Engine : public EngineBase {
   BMPSDev absorb_variational(int pos, int num, const BMPSDev &in);
   BMPSDev truncate_bmps(const BMPSDev &in, int kmax);
   void ein(const EinView<T> &a, const EinView<T> &b, const EinView<T> &c, T *cp);
-  DTen<T> svd_rows(DTen<T> &M, int m, int len, int k, double terr, int dmin, T *S);
+  DTen<T> svd_rows(DTen<T> &M, int m, int len, int k, double terr, int dmin, T *S, const int *mdyn = nullptr, int mmul = 1,
+                   int *kn_out = nullptr, int inner = 1, const int *inner_live = nullptr);
   // ---- two-row environments and NNN / TNN / sqrt5 traces (engine_nnn.h) ----
   void clear_bten2(int pos, int keep) {
     auto &v = bten2_[pos];

@@ -33,9 +33,19 @@ struct EinView {
   int dim[6], st[6];
   bool site = false;
   int r = 0, c = 0;
+  // per-walker live extent of a leg (device array, nullptr = the static dim).  On an operand: the leg is read up to the
+  // live extent only.  On the result: msk = 0 the index space is compacted (elements beyond are not written: only ein()
+  // calls given the same extent may read the tensor), msk = 1 the static tiling is kept and zeros are written beyond.
+  const int *live[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int msk[6] = {0, 0, 0, 0, 0, 0};
   int find(char ch) const {
     for (int i = 0; i < n; ++i) if (nm[i] == ch) return i;
     return -1;
+  }
+  EinView &dyn(char ch, const int *l, int mask = 0) {
+    const int i = find(ch);
+    if (i >= 0) { live[i] = l; msk[i] = mask; }
+    return *this;
   }
 };
 
@@ -53,27 +63,31 @@ static EinView<T> ein_view(const T *p, long w, const char *legs, std::initialize
 // C[legs of c] = sum over the legs shared by a and b and absent from c.  a supplies the I side, b the J side.
 template <typename T>
 void Engine<T>::ein(const EinView<T> &a, const EinView<T> &b, const EinView<T> &c, T *cp) {
-  struct Sub { int dim, s0, s1; };   // dim, stride in the first / second tensor of the group
+  struct Sub { int dim, s0, s1; const int *live; int mask; };   // dim, stride in the first / second tensor of the group
   std::vector<Sub> gi, gj, gk;
+  auto live_of = [&](char ch) -> const int * {   // the live extent of a leg may be named on any of the three views
+    for (const EinView<T> *v : {&a, &b, &c}) { const int i = v->find(ch); if (i >= 0 && v->live[i]) return v->live[i]; }
+    return nullptr;
+  };
   for (int x = 0; x < a.n; ++x) {
     if (a.dim[x] == 1) continue;
     const int ic = c.find(a.nm[x]), ib = b.find(a.nm[x]);
     PG_REQUIRE((ic >= 0) != (ib >= 0), 5, "ein: a leg of A must be either kept or contracted");
-    if (ic >= 0) { PG_REQUIRE(c.dim[ic] == a.dim[x], 5, "ein: dim mismatch (A,C)"); gi.push_back({a.dim[x], a.st[x], c.st[ic]}); }
-    else { PG_REQUIRE(b.dim[ib] == a.dim[x], 5, "ein: dim mismatch (A,B)"); gk.push_back({a.dim[x], a.st[x], b.st[ib]}); }
+    if (ic >= 0) { PG_REQUIRE(c.dim[ic] == a.dim[x], 5, "ein: dim mismatch (A,C)"); gi.push_back({a.dim[x], a.st[x], c.st[ic], live_of(a.nm[x]), c.msk[ic]}); }
+    else { PG_REQUIRE(b.dim[ib] == a.dim[x], 5, "ein: dim mismatch (A,B)"); gk.push_back({a.dim[x], a.st[x], b.st[ib], live_of(a.nm[x]), 0}); }
   }
   for (int x = 0; x < b.n; ++x) {
     if (b.dim[x] == 1 || a.find(b.nm[x]) >= 0) continue;
     const int ic = c.find(b.nm[x]);
     PG_REQUIRE(ic >= 0 && c.dim[ic] == b.dim[x], 5, "ein: a free leg of B is missing in C");
-    gj.push_back({b.dim[x], b.st[x], c.st[ic]});
+    gj.push_back({b.dim[x], b.st[x], c.st[ic], live_of(b.nm[x]), c.msk[ic]});
   }
   auto pack = [](std::vector<Sub> &g, bool by_second) {
     // innermost last: order by decreasing stride of the tensor that is written (C) resp. read contiguously (A for K)
     std::sort(g.begin(), g.end(), [&](const Sub &x, const Sub &y) { return by_second ? x.s1 > y.s1 : x.s0 > y.s0; });
     // merge neighbours that are contiguous in both tensors
     for (size_t i = 0; i + 1 < g.size();) {
-      if (g[i].s0 == g[i + 1].s0 * g[i + 1].dim && g[i].s1 == g[i + 1].s1 * g[i + 1].dim) {
+      if (!g[i].live && !g[i + 1].live && g[i].s0 == g[i + 1].s0 * g[i + 1].dim && g[i].s1 == g[i + 1].s1 * g[i + 1].dim) {
         g[i + 1].dim *= g[i].dim;
         g.erase(g.begin() + i);
       } else ++i;
@@ -82,12 +96,12 @@ void Engine<T>::ein(const EinView<T> &a, const EinView<T> &b, const EinView<T> &
   };
   pack(gi, true); pack(gj, true); pack(gk, false);
   TGemmDesc g;
-  for (size_t x = 0; x < gi.size(); ++x) { const int o = 3 - (int)gi.size() + (int)x; g.I[o] = gi[x].dim; g.sAi[o] = gi[x].s0; g.sCi[o] = gi[x].s1; }
-  for (size_t x = 0; x < gj.size(); ++x) { const int o = 3 - (int)gj.size() + (int)x; g.J[o] = gj[x].dim; g.sBj[o] = gj[x].s0; g.sCj[o] = gj[x].s1; }
-  for (size_t x = 0; x < gk.size(); ++x) { const int o = 3 - (int)gk.size() + (int)x; g.K[o] = gk[x].dim; g.sAk[o] = gk[x].s0; g.sBk[o] = gk[x].s1; }
+  for (size_t x = 0; x < gi.size(); ++x) { const int o = 3 - (int)gi.size() + (int)x; g.I[o] = gi[x].dim; g.sAi[o] = gi[x].s0; g.sCi[o] = gi[x].s1; g.dI[o].p = gi[x].live; g.dI[o].mask = gi[x].mask; }
+  for (size_t x = 0; x < gj.size(); ++x) { const int o = 3 - (int)gj.size() + (int)x; g.J[o] = gj[x].dim; g.sBj[o] = gj[x].s0; g.sCj[o] = gj[x].s1; g.dJ[o].p = gj[x].live; g.dJ[o].mask = gj[x].mask; }
+  for (size_t x = 0; x < gk.size(); ++x) { const int o = 3 - (int)gk.size() + (int)x; g.K[o] = gk[x].dim; g.sAk[o] = gk[x].s0; g.sBk[o] = gk[x].s1; g.dK[o].p = gk[x].live; }
   g.wA = a.w; g.wB = b.w; g.wC = c.w; g.nbatch = nw_;
   const double fl = 2.0 * nw_ * (double)g.Itot() * g.Jtot() * g.Ktot();
-  prof_begin(PROF_CONTRACT, fl, fl);
+  prof_begin(PROF_CONTRACT, fl, fl);   // (executed flops: counted on the device over the live extents)
   PG_REQUIRE(!(a.site && b.site), 5, "ein: two site operands");
   if (a.site) launch_site_gemm_a(g, cfg_site(a.r, a.c), 1, b.p, cp);
   else if (b.site) launch_site_gemm(g, cfg_site(b.r, b.c), 1, a.p, cp);
@@ -97,28 +111,40 @@ void Engine<T>::ein(const EinView<T> &a, const EinView<T> &b, const EinView<T> &
 
 // rows of M (m x len, contiguous) -> mutually orthogonal; the k rows of largest norm, normalised -> V (k x len);
 // optionally their norms -> S (k per walker)
+inline bool svd_rows_compresses(int m, int len) {
+  static const bool no_compress = getenv("PEPSGPU_NO_VAR_COMPRESS") != nullptr;
+  return !no_compress && len <= 256 && m > 16;
+}
+
 template <typename T>
-DTen<T> Engine<T>::svd_rows(DTen<T> &M, int m, int len, int k, double terr, int dmin, T *S) {
+DTen<T> Engine<T>::svd_rows(DTen<T> &M, int m, int len, int k, double terr, int dmin, T *S, const int *mdyn, int mmul, int *kn_out,
+                            int inner, const int *inner_live) {
+  // mdyn (optional): the first mdyn[w] * mmul rows of M exist (the rest was never written); kn_out: rows kept per walker.
+  // inner / inner_live (optional, only when svd_rows_compresses(m, len)): columns are (outer, inner) and only the first
+  // inner_live[w] values of the inner index exist -- the factor kernel reads those columns only, the others are zero in
+  // everything downstream.
   PG_REQUIRE(m <= 1024, 1, "bond dimension too large for select_rows_kernel");
   // Rank compression first, as in the absorption: R with R^T R = M^T M from the Gram-free factor (the right singular
   // vectors and the singular values of R are those of M), then the Jacobi runs on the few live rows of R instead of
   // the m rows of M.  Walkers the factor declines (rank above its cap) keep their rows of M.
-  static const bool no_compress = getenv("PEPSGPU_NO_VAR_COMPRESS") != nullptr;
   constexpr int KC = sizeof(T) == 4 ? 96 : 48;
+  PG_REQUIRE(!inner_live || svd_rows_compresses(m, len), 5, "svd_rows: live columns need the compressing path");
   DTen<T> Rf;
   int *ml = nullptr;
   T *src = M.p;
   long wsrc = M.n;
   int msrc = m;
-  if (!no_compress && len <= 256 && m > 16) {
+  if (svd_rows_compresses(m, len)) {
     msrc = std::max(m, len);
     Rf = alloc_ten(msrc, len, 1);
     ml = (int *)arena_.alloc(sizeof(int) * nw_);
     prof_begin(PROF_CHOL, 0.0, 0.0);
-    launch_gram_chol_lowrank<T, KC>(stream_, nw_, (const T *)M.p, M.n, len, (const int *)nullptr, 1, m, Rf.p, Rf.n, ml, 1,
-                                    (const int *)nullptr, 4);
+    if (inner_live)   // the factor kernel writes the data columns of its (at most CH_LR_CAP) rows only: define the others
+      PG_CHECK_HIP(hipMemset2DAsync(Rf.p, sizeof(T) * (size_t)Rf.n, 0, sizeof(T) * (size_t)std::min(msrc, CH_LR_CAP) * len, nw_, stream_));
+    launch_gram_chol_lowrank<T, KC>(stream_, nw_, (const T *)M.p, M.n, len, mdyn, mmul, m, Rf.p, Rf.n, ml, inner_live ? inner : 1,
+                                    inner_live, 4);
     hipLaunchKernelGGL(adopt_rows_flagged_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)M.p, M.n, len,
-                       (const int *)nullptr, 1, m, Rf.p, Rf.n, ml, 1, (const int *)nullptr);
+                       mdyn, mmul, m, Rf.p, Rf.n, ml, inner_live ? inner : 1, inner_live);
     PG_CHECK_HIP(hipGetLastError());
     prof_end();
     src = Rf.p; wsrc = Rf.n;
@@ -127,13 +153,15 @@ DTen<T> Engine<T>::svd_rows(DTen<T> &M, int m, int len, int k, double terr, int 
   const int use_lds = need <= JACOBI_LDS_MAX;
   if (use_lds) allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), need);
   prof_begin(7, 0.0, 0.0);
-  launch_jacobi(src, wsrc, msrc, len, use_lds, need, ml, 1);
+  const int *rdyn = ml ? ml : mdyn;       // live rows of what the Jacobi runs on: the factor, or M itself
+  const int rmul = ml ? 1 : mmul;
+  launch_jacobi(src, wsrc, msrc, len, use_lds, need, rdyn, rmul);
   prof_end();
   ++n_jacobi_;
   DTen<T> V = alloc_ten(k, len, 1);
   prof_begin(PROF_SELECT, 0.0, 0.0);
   hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)src, wsrc, msrc, len, len, k, V.p, V.n,
-                     S, (long)k, (const int *)ml, 1, (int *)nullptr, terr, dmin, (double *)nullptr);
+                     S, (long)k, rdyn, rmul, kn_out, terr, dmin, (double *)nullptr);
   PG_CHECK_HIP(hipGetLastError());
   prof_end();
   if (ml) { arena_.free(ml); free_ten(Rf); }
@@ -258,12 +286,28 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, cons
   }
   chi_min_ = save_min; trunc_err_ = save_err;
   free_bmps(small);
-  for (int *l : res.live) if (l) arena_.free(l);   // the sweeps below work on the zero padded static shapes
+  // Per-walker live extents of every bond (device arrays, nullptr = the static dim): il[i] / rl[i] = bond to the left of
+  // site i of the absorbing BMPS / of the result.  Contractions run over the live parts only (ein(): compact legs on
+  // tensors only ein() reads, masked -- zeros written -- legs where a whole-row kernel or a persistent tensor follows);
+  // every truncation returns the live count of the bond it made.  PEPSGPU_NO_VAR_ADAPT=1: static shapes throughout.
+  static const bool no_adapt = getenv("PEPSGPU_NO_VAR_ADAPT") != nullptr;
+  std::vector<int *> il(in.live.begin(), in.live.end()), rl = res.live;
+  il.resize(N + 1, nullptr);
+  rl.resize(N + 1, nullptr);
+  std::vector<int *> owned;                     // every live array made here or taken over from the initial guess
+  for (int *l : rl) if (l) owned.push_back(l);
+  if (no_adapt) { std::fill(il.begin(), il.end(), nullptr); std::fill(rl.begin(), rl.end(), nullptr); }
+  auto new_live = [&]() -> int * {
+    if (no_adapt) return nullptr;
+    int *l = (int *)arena_.alloc(sizeof(int) * nw_);
+    owned.push_back(l);
+    return l;
+  };
   res.live.clear();
   res.kmax.clear();
   std::vector<DTen<T>> &B = res.t;   // res tensors (k, u, q)
 
-  struct Env { DTen<T> t; double *log; };
+  struct Env { DTen<T> t; double *log; int *nl; };   // nl: live extent of the leg on the result's bond (k resp. q / n)
   auto new_log = [&](const double *a) {
     double *l = (double *)arena_.alloc(sizeof(double) * nw_);
     if (a) PG_CHECK_HIP(hipMemcpyAsync(l, a, sizeof(double) * nw_, hipMemcpyDeviceToDevice, stream_));
@@ -272,8 +316,8 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, cons
   };
   auto free_env = [&](Env &e) { arena_.free(e.t.p); arena_.free(e.log); };
   std::vector<Env> lenvs, renvs;
-  lenvs.push_back(Env{ones3(), new_log(nullptr)});   // (k, e, a)
-  renvs.push_back(Env{ones3(), new_log(nullptr)});   // (b, f, q)
+  lenvs.push_back(Env{ones3(), new_log(nullptr), nullptr});   // (k, e, a)
+  renvs.push_back(Env{ones3(), new_log(nullptr), nullptr});   // (b, f, q)
 
   // t1[k,u,b,f] = sum_{a,e,p} lenv[k,e,a] A_i[a,p,b] W_i[e,p,f,u]        (bmps_impl.h:896-897)
   auto half_left = [&](int i, const Env &le) {
@@ -281,9 +325,11 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, cons
     const int k = le.t.d[0], e = S[i].e, a = A.d[0], p = A.d[1], b = A.d[2], f = S[i].f, u = S[i].u;
     PG_REQUIRE(le.t.d[1] == e && le.t.d[2] == a && p == S[i].p, 3, "variational compression: bond mismatch (left)");
     DTen<T> t0 = alloc_ten(k * e, p, b);
-    ein(ein_view<T>(le.t.p, le.t.n, "kea", {k, e, a}), ein_view<T>(A.p, A.n, "apb", {a, p, b}), ein_view<T>(t0.p, t0.n, "kepb", {k, e, p, b}), t0.p);
+    ein(ein_view<T>(le.t.p, le.t.n, "kea", {k, e, a}).dyn('k', le.nl).dyn('a', il[i]), ein_view<T>(A.p, A.n, "apb", {a, p, b}).dyn('b', il[i + 1]),
+        ein_view<T>(t0.p, t0.n, "kepb", {k, e, p, b}), t0.p);
     DTen<T> t1 = alloc_ten(k, u, b, f);
-    ein(ein_view<T>(t0.p, t0.n, "kepb", {k, e, p, b}), site_view(i, 'u'), ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}), t1.p);
+    ein(ein_view<T>(t0.p, t0.n, "kepb", {k, e, p, b}).dyn('k', le.nl).dyn('b', il[i + 1]), site_view(i, 'u'),
+        ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}), t1.p);
     free_ten(t0);
     return t1;
   };
@@ -293,34 +339,41 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, cons
     const int q = re.t.d[2], g = S[j].f, a = A.d[0], p = A.d[1], c = A.d[2], e = S[j].e, v = S[j].u;
     PG_REQUIRE(re.t.d[0] == c && re.t.d[1] == g && p == S[j].p, 3, "variational compression: bond mismatch (right)");
     DTen<T> t2 = alloc_ten(a, p, g, q);
-    ein(ein_view<T>(A.p, A.n, "bpc", {a, p, c}), ein_view<T>(re.t.p, re.t.n, "cgq", {c, g, q}), ein_view<T>(t2.p, t2.n, "bpgq", {a, p, g, q}), t2.p);
+    ein(ein_view<T>(A.p, A.n, "bpc", {a, p, c}).dyn('b', il[j]).dyn('c', il[j + 1]), ein_view<T>(re.t.p, re.t.n, "cgq", {c, g, q}).dyn('q', re.nl),
+        ein_view<T>(t2.p, t2.n, "bpgq", {a, p, g, q}), t2.p);
     EinView<T> w = site_view(j, 'v');
     w.nm[ll] = 'f'; w.nm[lr] = 'g';
     DTen<T> t3 = alloc_ten(v, q, a, e);
-    ein(ein_view<T>(t2.p, t2.n, "bpgq", {a, p, g, q}), w, ein_view<T>(t3.p, t3.n, "vqbf", {v, q, a, e}), t3.p);
+    ein(ein_view<T>(t2.p, t2.n, "bpgq", {a, p, g, q}).dyn('b', il[j]).dyn('q', re.nl), w, ein_view<T>(t3.p, t3.n, "vqbf", {v, q, a, e}), t3.p);
     free_ten(t2);
     return t3;
   };
   // renv'[b,f,n] = sum_{v,q} t3[v,q,b,f] Bj[n,v,q]                  (bmps_impl.h:739, :939)
-  auto grow_right = [&](const DTen<T> &t3, const DTen<T> &Bj, const Env &re) {
+  // (j = site of t3 / Bj; nl = live extent of Bj's left bond n.  b, outermost in the result, is compacted: the live part
+  // of renv' is a prefix, n is written in full -- zeros beyond nl -- for the normalisation over that prefix)
+  auto grow_right = [&](int j, const DTen<T> &t3, const DTen<T> &Bj, const Env &re, int *nl) {
     const int v = t3.d[0], q = t3.d[1], b = t3.d[2], f = t3.d[3], n = Bj.d[0];
-    Env o{alloc_ten(b, f, n), new_log(re.log)};
-    ein(ein_view<T>(t3.p, t3.n, "vqbf", {v, q, b, f}), ein_view<T>(Bj.p, Bj.n, "nvq", {n, v, q}), ein_view<T>(o.t.p, o.t.n, "bfn", {b, f, n}), o.t.p);
-    normalize(o.t.p, o.t.n, o.t.n, nw_, o.log);
+    Env o{alloc_ten(b, f, n), new_log(re.log), nl};
+    ein(ein_view<T>(t3.p, t3.n, "vqbf", {v, q, b, f}).dyn('q', re.nl).dyn('b', il[j]), ein_view<T>(Bj.p, Bj.n, "nvq", {n, v, q}),
+        ein_view<T>(o.t.p, o.t.n, "bfn", {b, f, n}).dyn('n', nl, 1), o.t.p);
+    normalize(o.t.p, o.t.n, o.t.n, nw_, o.log, il[j], f * n);
     return o;
   };
   // lenv'[n,f,b] = sum_{k,u} Ut[n,k,u] t1[k,u,b,f]                  (bmps_impl.h:916-918)
-  auto grow_left = [&](const DTen<T> &t1, const DTen<T> &Ut, int n, const Env &le) {
+  // (i = site of t1; nl = live extent of the new bond n: compacted prefix, b masked)
+  auto grow_left = [&](int i, const DTen<T> &t1, const DTen<T> &Ut, int n, const Env &le, int *nl, bool uk_order = false) {
     const int k = t1.d[0], u = t1.d[1], b = t1.d[2], f = t1.d[3];
-    Env o{alloc_ten(n, f, b), new_log(le.log)};
-    ein(ein_view<T>(Ut.p, Ut.n, "nku", {n, k, u}), ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}), ein_view<T>(o.t.p, o.t.n, "nfb", {n, f, b}), o.t.p);
-    normalize(o.t.p, o.t.n, o.t.n, nw_, o.log);
+    Env o{alloc_ten(n, f, b), new_log(le.log), nl};
+    EinView<T> utv = uk_order ? ein_view<T>(Ut.p, Ut.n, "nuk", {n, u, k}) : ein_view<T>(Ut.p, Ut.n, "nku", {n, k, u});
+    ein(utv.dyn('n', nl).dyn('k', le.nl), ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}),
+        ein_view<T>(o.t.p, o.t.n, "nfb", {n, f, b}).dyn('b', il[i + 1], 1), o.t.p);
+    normalize(o.t.p, o.t.n, o.t.n, nw_, o.log, nl, f * b);
     return o;
   };
   // right environments of sites N-1 .. 2 from the initial guess (GrowRightEnvironments_)
   for (int i = N - 1; i > 1; --i) {
     DTen<T> t3 = half_right(i, renvs.back());
-    renvs.push_back(grow_right(t3, B[i], renvs.back()));
+    renvs.push_back(grow_right(i, t3, B[i], renvs.back(), rl[i]));
     free_ten(t3);
   }
 
@@ -334,19 +387,30 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, cons
     const int rows = left_move ? v * q : k * u, len = left_move ? k * u : v * q;
     const int kn = std::min(chi_, std::min(rows, len));
     DTen<T> th = alloc_ten(rows, len, 1);
+    const Env &le = lenvs.back(), &re = renvs.back();
+    // rows of theta: the live bond outermost (a prefix of rows exists); columns: the live bond innermost, left out when the
+    // compressing factor kernel reads theta (it takes the live columns only), else written in full (zeros)
+    // (leaving the dead columns out -- inner_live of svd_rows -- was measured: the GEMM saves what the extra zero fill of
+    // the factor costs, 3.5 k vs 3.6 k amplitudes/s at C4: the masked form is kept)
+    const int cmask = 1;
     if (left_move)
-      ein(ein_view<T>(t3.p, t3.n, "vqbf", {v, q, b, f}), ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}), ein_view<T>(th.p, th.n, "vqku", {v, q, k, u}), th.p);
+      ein(ein_view<T>(t3.p, t3.n, "vqbf", {v, q, b, f}).dyn('q', re.nl).dyn('b', il[i + 1]), ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}),
+          ein_view<T>(th.p, th.n, "qvuk", {q, v, u, k}).dyn('k', le.nl, cmask), th.p);
     else
-      ein(ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}), ein_view<T>(t3.p, t3.n, "vqbf", {v, q, b, f}), ein_view<T>(th.p, th.n, "kuvq", {k, u, v, q}), th.p);
+      ein(ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}).dyn('k', le.nl).dyn('b', il[i + 1]), ein_view<T>(t3.p, t3.n, "vqbf", {v, q, b, f}),
+          ein_view<T>(th.p, th.n, "kuvq", {k, u, v, q}).dyn('q', re.nl, cmask), th.p);
     if (Sout) PG_CHECK_HIP(hipMemsetAsync(Sout, 0, sizeof(T) * (size_t)chi_ * nw_, stream_));
-    DTen<T> V = svd_rows(th, rows, len, kn, terr, std::min(dmin, kn), Sout);
+    int *nl = new_live();
+    const int *cl = left_move ? le.nl : re.nl;     // live extent of the inner column index
+    DTen<T> V = svd_rows(th, rows, len, kn, terr, std::min(dmin, kn), Sout, left_move ? re.nl : le.nl, left_move ? v : u, nl,
+                         left_move ? k : q, cmask ? nullptr : cl);
     free_ten(th);
     if (slog) {
       PG_CHECK_HIP(hipMemsetAsync(slog, 0, sizeof(double) * nw_, stream_));
       add_logs(slog, lenvs.back().log, renvs.back().log, nullptr, nullptr);
     }
     if (left_move) {
-      Env ne = grow_left(t1, V, kn, lenvs.back());
+      Env ne = grow_left(i, t1, V, kn, lenvs.back(), nl, true);
       lenvs.push_back(ne);
       free_env(renvs.back());
       renvs.pop_back();
@@ -355,7 +419,8 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, cons
       V.d[0] = kn; V.d[1] = v; V.d[2] = q;
       arena_.free(B[i + 1].p);
       B[i + 1] = V;
-      Env ne = grow_right(t3, V, renvs.back());
+      rl[i + 1] = nl;
+      Env ne = grow_right(i + 1, t3, V, renvs.back(), nl);
       renvs.push_back(ne);
       free_env(lenvs.back());
       lenvs.pop_back();
@@ -371,16 +436,21 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, cons
     const int k = t1.d[0], u = t1.d[1], b = t1.d[2], f = t1.d[3], v = t3.d[0], q = t3.d[1];
     const int rows = k * u, len = v * q, kn = std::min(chi_, std::min(rows, len));
     DTen<T> th = alloc_ten(rows, len, 1);
-    ein(ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}), ein_view<T>(t3.p, t3.n, "vqbf", {v, q, b, f}), ein_view<T>(th.p, th.n, "kuvq", {k, u, v, q}), th.p);
-    DTen<T> V = svd_rows(th, rows, len, kn, terr, std::min(dmin, kn), nullptr);
+    const Env &le = lenvs.back(), &re = renvs.back();
+    ein(ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}).dyn('k', le.nl).dyn('b', il[1]), ein_view<T>(t3.p, t3.n, "vqbf", {v, q, b, f}),
+        ein_view<T>(th.p, th.n, "kuvq", {k, u, v, q}).dyn('q', re.nl, 1), th.p);
+    int *nl = new_live();
+    DTen<T> V = svd_rows(th, rows, len, kn, terr, std::min(dmin, kn), nullptr, le.nl, u, nl);
     free_ten(th);
     V.d[0] = kn; V.d[1] = v; V.d[2] = q;
     arena_.free(B[1].p);
     B[1] = V;
-    Env ne = grow_right(t3, V, renvs.back());
+    rl[1] = nl;
+    Env ne = grow_right(1, t3, V, renvs.back(), nl);
     free_ten(t3);
     DTen<T> B0 = alloc_ten(k, u, kn);
-    ein(ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}), ein_view<T>(ne.t.p, ne.t.n, "bfn", {b, f, kn}), ein_view<T>(B0.p, B0.n, "kun", {k, u, kn}), B0.p);
+    ein(ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}).dyn('k', le.nl).dyn('b', il[1]), ein_view<T>(ne.t.p, ne.t.n, "bfn", {b, f, kn}),
+        ein_view<T>(B0.p, B0.n, "kun", {k, u, kn}).dyn('n', nl, 1), B0.p);
     free_ten(t1);
     arena_.free(B[0].p);
     B[0] = B0;
@@ -436,12 +506,14 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, cons
         DTen<T> t1 = half_left(i, lenvs.back());
         const int k = t1.d[0], u = t1.d[1], b = t1.d[2], f = t1.d[3], q = renvs.back().t.d[2];
         DTen<T> t2 = alloc_ten(q, k, u);
-        ein(ein_view<T>(renvs.back().t.p, renvs.back().t.n, "bfn", {b, f, q}), ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}),
-            ein_view<T>(t2.p, t2.n, "nku", {q, k, u}), t2.p);
+        const Env &le = lenvs.back(), &re = renvs.back();
+        ein(ein_view<T>(re.t.p, re.t.n, "bfn", {b, f, q}).dyn('n', re.nl).dyn('b', il[i + 1]), ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}),
+            ein_view<T>(t2.p, t2.n, "nku", {q, k, u}).dyn('k', le.nl, 1), t2.p);
         const int kn = std::min(q, k * u);
-        DTen<T> Qt = svd_rows(t2, q, k * u, kn, 0.0, kn, nullptr);
+        int *nl = new_live();
+        DTen<T> Qt = svd_rows(t2, q, k * u, kn, 0.0, kn, nullptr, re.nl, 1, nl);
         free_ten(t2);
-        Env ne = grow_left(t1, Qt, kn, lenvs.back());
+        Env ne = grow_left(i, t1, Qt, kn, lenvs.back(), nl);
         lenvs.push_back(ne);
         free_env(renvs.back());
         renvs.pop_back();
@@ -452,20 +524,23 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, cons
         DTen<T> t3 = half_right(i, renvs.back());
         const int v = t3.d[0], q = t3.d[1], b = t3.d[2], f = t3.d[3], k = lenvs.back().t.d[0];
         DTen<T> t2 = alloc_ten(k, v, q);
-        ein(ein_view<T>(lenvs.back().t.p, lenvs.back().t.n, "kfb", {k, f, b}), ein_view<T>(t3.p, t3.n, "vqbf", {v, q, b, f}),
-            ein_view<T>(t2.p, t2.n, "kvq", {k, v, q}), t2.p);
+        const Env &le = lenvs.back(), &re = renvs.back();
+        ein(ein_view<T>(le.t.p, le.t.n, "kfb", {k, f, b}).dyn('k', le.nl).dyn('b', il[i]), ein_view<T>(t3.p, t3.n, "vqbf", {v, q, b, f}),
+            ein_view<T>(t2.p, t2.n, "kvq", {k, v, q}).dyn('q', re.nl, 1), t2.p);
         if (i == 1) {   // |r| of the last QR = |t2| exp(log lenv + log renv)   (bmps_impl.h:1149)
           PG_CHECK_HIP(hipMemsetAsync(rlog, 0, sizeof(double) * nw_, stream_));
           add_logs(rlog, lenvs.back().log, renvs.back().log, nullptr, nullptr);
-          normalize(t2.p, t2.n, t2.n, nw_, rlog);
+          normalize(t2.p, t2.n, t2.n, nw_, rlog, le.nl, v * q);
         }
         const int kn = std::min(k, v * q);
-        DTen<T> Qt = svd_rows(t2, k, v * q, kn, 0.0, kn, nullptr);
+        int *nl = new_live();
+        DTen<T> Qt = svd_rows(t2, k, v * q, kn, 0.0, kn, nullptr, le.nl, 1, nl);
         free_ten(t2);
         Qt.d[0] = kn; Qt.d[1] = v; Qt.d[2] = q;
         arena_.free(B[i].p);
         B[i] = Qt;
-        Env ne = grow_right(t3, Qt, renvs.back());
+        rl[i] = nl;
+        Env ne = grow_right(i, t3, Qt, renvs.back(), nl);
         renvs.push_back(ne);
         free_env(lenvs.back());
         lenvs.pop_back();
@@ -485,8 +560,8 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, cons
     DTen<T> t1 = half_left(0, lenvs.back());
     const int k = t1.d[0], u = t1.d[1], b = t1.d[2], f = t1.d[3], q = renvs.back().t.d[2];
     DTen<T> B0 = alloc_ten(k, u, q);
-    ein(ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}), ein_view<T>(renvs.back().t.p, renvs.back().t.n, "bfn", {b, f, q}),
-        ein_view<T>(B0.p, B0.n, "kun", {k, u, q}), B0.p);
+    ein(ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}).dyn('k', lenvs.back().nl).dyn('b', il[1]),
+        ein_view<T>(renvs.back().t.p, renvs.back().t.n, "bfn", {b, f, q}), ein_view<T>(B0.p, B0.n, "kun", {k, u, q}).dyn('n', renvs.back().nl, 1), B0.p);
     free_ten(t1);
     arena_.free(B[0].p);
     B[0] = B0;
@@ -496,6 +571,11 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, cons
   normalize(B[0].p, B[0].n, B[0].n, nw_, res.logscale);
   for (auto &e : lenvs) free_env(e);
   for (auto &e : renvs) free_env(e);
+  // the live extents of the result's bonds go with it (the next absorption contracts over them); the others are returned
+  res.live = rl;
+  res.live.resize(N + 1, nullptr);
+  for (int *l : owned)
+    if (std::find(res.live.begin(), res.live.end(), l) == res.live.end()) arena_.free(l);
   ++n_absorb_;
   return res;
 }

@@ -57,6 +57,25 @@ def test_variational_amplitudes_against_oracle(L, D, chi, scheme, dt, tol):
         assert np.max(np.abs(svd / ref - 1)) > 10 * err
 
 
+@pytest.mark.parametrize("dt,tol", [("f64", 1e-7), ("f32", 2e-4)])
+@pytest.mark.parametrize("scheme", list(SCHEMES))
+def test_variational_rank_adaptive_on_low_rank_state(scheme, dt, tol):
+    """A state whose boundary bonds have numerical rank well below chi (noise 0.1): the sweeps contract over per-walker live
+    extents that differ between walkers and bonds (engine_var.h: compact / masked legs of ein(), live rows of svd_rows);
+    amplitudes against the oracle run with the same scheme."""
+    L, D, chi = 6, 4, 12
+    sitps = synthetic.make_sitps(L, D, noise=0.1)
+    cfgs = synthetic.make_configs(L, 8, "heisenberg")
+    tp = getattr(BMPSTruncateParams, scheme)(chi, chi, 0.0, 1e-13, 10)
+    ref = np.array([vmc.TPSWaveFunctionComponent(sitps, c, tp).amplitude for c in cfgs])
+    ctx = _ctx(L, D, 2, chi, chi, 0.0, scheme, 1e-13, 10, dt, len(cfgs))
+    ctx.state_upload(synthetic.sitps_to_flat(sitps, D, np.float64))
+    ctx.set_configs(cfgs)
+    got = ctx.evaluate_amplitude()
+    assert np.all(ctx.walker_flags() == 0)
+    assert np.max(np.abs(got / ref - 1)) < tol, (got, ref)
+
+
 def test_set_truncate_params_switches_scheme_and_validates():
     """SetTruncateParams (bmps_contractor.h:216): switching the scheme on a live context; bad parameters are refused."""
     from peps_amd import capi
