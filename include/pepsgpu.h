@@ -149,6 +149,13 @@ int pepsgpu_punch_hole(pepsgpu_ctx *ctx, int row, int col, int mps_orient, doubl
  * (replaces MPIMeanTensor, statistics_tensor.h:37-79). */
 int pepsgpu_grad_reset(pepsgpu_ctx *ctx);
 int pepsgpu_grad_accumulate(pepsgpu_ctx *ctx, const double *psi, const double *eloc, int exact_sum);
+/* The same with the component every hole belongs to named by the caller: states = [n][rows][cols], 0 <= state < d of
+ * the context (NULL: the walkers' current configuration, as above).  Fermionic states (sign-decorated components,
+ * INTEGRATION.md): the holes are those of the row-major decoration, states = the extended states of that decoration and
+ * psi = the plain contraction value, whatever mode order the walkers have been moved to since the holes were punched
+ * (replaces the same loop, mc_energy_grad_evaluator.h:257-278, for fermionic tensors). */
+int pepsgpu_grad_accumulate_states(pepsgpu_ctx *ctx, const double *psi, const double *eloc, int exact_sum,
+                                   const int32_t *states);
 int pepsgpu_grad_read(pepsgpu_ctx *ctx, double *s_o_out, double *s_eo_out);
 
 /* Stochastic reconfiguration: the O* samples stay in HBM and the S-matrix product of

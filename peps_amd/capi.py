@@ -32,7 +32,7 @@ SYMBOLS = [
     "pepsgpu_init_bten2", "pepsgpu_grow_full_bten2", "pepsgpu_grow_bten2_step", "pepsgpu_shift_bten2_window",
     "pepsgpu_bten2_stack_size", "pepsgpu_replace_nnn_trace", "pepsgpu_replace_tnn_trace",
     "pepsgpu_replace_sqrt5_trace",
-    "pepsgpu_grad_reset", "pepsgpu_grad_accumulate", "pepsgpu_grad_read", "pepsgpu_grad_device_ptr", "pepsgpu_grad_allreduce",
+    "pepsgpu_grad_reset", "pepsgpu_grad_accumulate", "pepsgpu_grad_accumulate_states", "pepsgpu_grad_read", "pepsgpu_grad_device_ptr", "pepsgpu_grad_allreduce",
     "pepsgpu_comm_unique_id", "pepsgpu_comm_init", "pepsgpu_comm_size", "pepsgpu_comm_rank", "pepsgpu_comm_destroy",
     "pepsgpu_allreduce",
     "pepsgpu_sr_begin", "pepsgpu_sr_append", "pepsgpu_sr_count", "pepsgpu_sr_sum", "pepsgpu_sr_matvec",
@@ -82,6 +82,7 @@ def load_library(path=LIB_PATH):
     lib.pepsgpu_replace_sqrt5_trace.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp]
     lib.pepsgpu_grad_reset.argtypes = [vp]
     lib.pepsgpu_grad_accumulate.argtypes = [vp, dp, dp, C.c_int]
+    lib.pepsgpu_grad_accumulate_states.argtypes = [vp, dp, dp, C.c_int, ip]
     lib.pepsgpu_grad_read.argtypes = [vp, dp, dp]
     lib.pepsgpu_grad_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_long)]
     lib.pepsgpu_grad_allreduce.argtypes = [vp]
@@ -342,10 +343,19 @@ class Context:
     def grad_reset(self):
         self._ck(self._l.pepsgpu_grad_reset(self._h))
 
-    def grad_accumulate(self, psi, eloc, exact_sum=False):
+    def grad_accumulate(self, psi, eloc, exact_sum=False, states=None):
+        """states ([n][rows][cols], optional): the component every stored hole belongs to, when it is not the walkers'
+        current configuration (fermionic states: extended states of the row-major decoration)."""
         psi = np.ascontiguousarray(psi, dtype=np.float64)
         eloc = np.ascontiguousarray(eloc, dtype=np.float64)
-        self._ck(self._l.pepsgpu_grad_accumulate(self._h, _dp(psi), _dp(eloc), int(exact_sum)))
+        if states is None:
+            self._ck(self._l.pepsgpu_grad_accumulate(self._h, _dp(psi), _dp(eloc), int(exact_sum)))
+            return
+        states = np.ascontiguousarray(states, dtype=np.int32)
+        if states.shape != (len(psi), self.rows, self.cols):
+            raise ValueError("states must be [n][rows][cols]")
+        self._ck(self._l.pepsgpu_grad_accumulate_states(self._h, _dp(psi), _dp(eloc), int(exact_sum),
+                                                        states.ctypes.data_as(C.POINTER(C.c_int32))))
 
     def grad_read(self):
         shp = (self.rows, self.cols, self.d, self.D, self.D, self.D, self.D)

@@ -185,6 +185,9 @@ int pepsgpu_punch_hole(pepsgpu_ctx *ctx, int row, int col, int orient, double *o
   CTX_CALL(ctx->eng->punch_hole(row, col, orient, out));
 }
 int pepsgpu_grad_reset(pepsgpu_ctx *ctx) { CTX_CALL(ctx->eng->grad_reset()); }
+int pepsgpu_grad_accumulate_states(pepsgpu_ctx *ctx, const double *psi, const double *eloc, int exact_sum, const int32_t *states) {
+  CTX_CALL(PG_REQUIRE(psi && eloc, 1, "null psi / eloc"); ctx->eng->grad_accumulate(psi, eloc, exact_sum, states));
+}
 int pepsgpu_grad_accumulate(pepsgpu_ctx *ctx, const double *psi, const double *eloc, int exact_sum) {
   CTX_CALL(PG_REQUIRE(psi && eloc, 1, "null psi / eloc"); ctx->eng->grad_accumulate(psi, eloc, exact_sum));
 }

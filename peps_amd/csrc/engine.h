@@ -82,7 +82,7 @@ struct EngineBase {
   virtual size_t device_bytes() const = 0;
   virtual void stats(double *out, int n) = 0;
   virtual void grad_reset() = 0;
-  virtual void grad_accumulate(const double *psi, const double *eloc, int exact_sum) = 0;
+  virtual void grad_accumulate(const double *psi, const double *eloc, int exact_sum, const int32_t *states = nullptr) = 0;
   virtual void grad_read(double *so, double *seo) = 0;
   virtual void sr_begin(int max_samples) = 0;
   virtual void sr_append(const double *psi) = 0;
@@ -575,15 +575,18 @@ class Engine : public EngineBase {
   // psi[w], eloc[w] from the host (the solver's scalars).  MC: O* = hole / psi (weight 1)
   // (mc_energy_grad_evaluator.h:266); exact summation: |psi|^2 O* = psi * hole
   // (exact_summation_energy_evaluator.h:231).
-  void grad_accumulate(const double *psi, const double *eloc, int exact_sum) override {
+  // states (optional, [walker][row][col]): the component of each site the walker's hole belongs to, when that is not the
+  // configuration the device holds at this moment (fermionic states: the extended state of the row-major decoration the
+  // holes were punched in, while the walkers may have moved on to the column-major pass since).
+  void grad_accumulate(const double *psi, const double *eloc, int exact_sum, const int32_t *states = nullptr) override {
     require_ready();
     if constexpr (kCplx) {
       PG_REQUIRE(false, 1, "gradient accumulation is not implemented for the complex element type");
     } else {
-    grad_accumulate_real(psi, eloc, exact_sum);
+    grad_accumulate_real(psi, eloc, exact_sum, states);
     }
   }
-  void grad_accumulate_real(const double *psi, const double *eloc, int exact_sum) {
+  void grad_accumulate_real(const double *psi, const double *eloc, int exact_sum, const int32_t *states) {
     PG_REQUIRE(holes_ != nullptr, 3, "grad_accumulate: no holes stored (pepsgpu_punch_hole with out == NULL)");
     if (!so_) grad_reset();
     std::vector<double> h(3 * (size_t)nw_);
@@ -597,11 +600,20 @@ class Engine : public EngineBase {
     PG_CHECK_HIP(hipMemcpyAsync(d, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, stream_));
     PG_CHECK_HIP(hipStreamSynchronize(stream_));
     const int sites = Ly_ * Lx_;
+    int *dstates = nullptr;
+    if (states) {
+      for (size_t q = 0; q < (size_t)nw_ * sites; ++q)
+        PG_REQUIRE(states[q] >= 0 && states[q] < dp_, 1, "grad_accumulate: state index out of range");
+      dstates = (int *)arena_.alloc(sizeof(int) * (size_t)nw_ * sites);
+      PG_CHECK_HIP(hipMemcpyAsync(dstates, states, sizeof(int) * (size_t)nw_ * sites, hipMemcpyHostToDevice, stream_));
+      PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    }
     hipLaunchKernelGGL(grad_accumulate_kernel<T>, dim3((unsigned)((slot_ + 255) / 256), sites), dim3(256), 0, stream_,
-                       (const T *)holes_, (const double *)holes_ls_, (const int *)cfg_, (const double *)d,
+                       (const T *)holes_, (const double *)holes_ls_, (const int *)(dstates ? dstates : cfg_), (const double *)d,
                        (const double *)(d + nw_), (const double *)(d + 2 * nw_), so_, seo_, nw_, sites, slot_, dp_);
     PG_CHECK_HIP(hipGetLastError());
     arena_.free(d);
+    if (dstates) arena_.free(dstates);
   }
   void *stream_handle() override { return (void *)stream_; }
   void grad_device_ptr(void **so, void **seo, long *n_elems) override {

@@ -413,6 +413,12 @@ class BMPSContractor {
   void GradAccumulate(const std::vector<double> &psi, const std::vector<double> &eloc, bool exact_sum) {
     check_rc(pepsgpu_grad_accumulate(ctx_, psi.data(), eloc.data(), exact_sum), ctx_);
   }
+  // ... with the component of every site named by the caller ([walker][row][col]): fermionic states
+  void GradAccumulate(const std::vector<double> &psi, const std::vector<double> &eloc, bool exact_sum,
+                      const std::vector<int32_t> &states) {
+    if (states.size() != walkers() * rows() * cols()) throw std::invalid_argument("GradAccumulate: states must be [walker][row][col]");
+    check_rc(pepsgpu_grad_accumulate_states(ctx_, psi.data(), eloc.data(), exact_sum, states.data()), ctx_);
+  }
   // ---- the exchange step over ranks (one contractor = one GPU = one rank): RCCL through the library ----
   // CommInit: rank 0 draws `id` with UniqueId() and the host program broadcasts it (MPI_Bcast in the reference's MPI world).
   static std::array<unsigned char, 128> UniqueId() {
@@ -787,8 +793,6 @@ class SquareNNNModelEnergySolver {
     out.energy.assign(n, 0.0);
     if (calchols && !holes_on_device) out.holes.assign(n * rows * cols * slot, 0.0);
     auto *self = static_cast<ExplicitlyModel *>(this);
-    if (comp.fermion && calchols && holes_on_device)
-      throw std::invalid_argument("fermionic state: the device-resident hole store is not supported (holes come back to the host)");
     comp.SetOrder(ROW_MAJOR);                // fermions: holes are those of the row-major decorated network
     c.GenerateBMPSApproach(UP);                                              // :116
     for (size_t row = 0; row < rows; row++) {
@@ -1405,8 +1409,18 @@ struct GradAccumulator {
   }
   // Same accumulation with the holes resident on the device (BMPSContractor::PunchHoleStore):
   // the tensor sums stay in HBM until FetchDevice().
+  // Fermionic states: the stored holes are those of the row-major decorated network, d psi_dense / d T''; the device is told
+  // the extended state of every site in that decoration and the plain contraction value psi_dense = sigma * psi (the
+  // walkers themselves may be in the column-major decoration by now).
   void AccumulateDevice(TPSWaveFunctionComponent &comp, const EnergyAndHoles &eh, bool exact_sum) {
-    comp.contractor.GradAccumulate(comp.amplitude, eh.energy, exact_sum);
+    if (comp.fermion) {
+      std::vector<double> dense(comp.amplitude);
+      for (size_t w = 0; w < dense.size(); ++w) dense[w] *= comp.fermion->Sigma(comp.config, w);
+      const Configuration ext = comp.fermion->ExtConfig(comp.config, ROW_MAJOR);
+      comp.contractor.GradAccumulate(dense, eh.energy, exact_sum, std::vector<int32_t>(ext.data(), ext.data() + ext.walkers() * ext.rows() * ext.cols()));
+    } else {
+      comp.contractor.GradAccumulate(comp.amplitude, eh.energy, exact_sum);
+    }
     for (size_t w = 0; w < comp.config.walkers(); ++w) {
       const double psi = comp.amplitude[w], e = eh.energy[w];
       const double wt = exact_sum ? psi * psi : 1.0;
@@ -1672,20 +1686,16 @@ std::pair<double, SplitIndexTPS> ExactSumEnergyEvaluator(const SplitIndexTPS &si
     Configuration cfg(nb, rows, cols);
     for (size_t w = 0; w < nb; ++w) std::copy(all_configs[mine[b0 + w]].begin(), all_configs[mine[b0 + w]].end(), cfg.data() + w * rows * cols);
     TPSWaveFunctionComponent comp(sitps, cfg, contractor, fermion);
-    if (fermion) {   // gradient with respect to the decorated (extended) components; fold with FoldFermionGradient
-      EnergyAndHoles eh = model.template CalEnergyAndHoles<true>(sitps, comp, /*holes_on_device=*/false);
-      acc.Accumulate(comp, eh, true);
-    } else {
-      EnergyAndHoles eh = model.template CalEnergyAndHoles<true>(sitps, comp, /*holes_on_device=*/true);
-      acc.AccumulateDevice(comp, eh, true);
-    }
+    // (fermions: the gradient is taken with respect to the decorated -- extended -- components; FoldFermionGradient maps it back)
+    EnergyAndHoles eh = model.template CalEnergyAndHoles<true>(sitps, comp, /*holes_on_device=*/true);
+    acc.AccumulateDevice(comp, eh, true);
   }
   // a contractor with a communicator (CommInit) sums the tensor accumulators over the ranks where they live, in HBM
   // (one RCCL all-reduce each, no host hop), and only the four scalars travel through the host; otherwise the packed
   // host vector goes through the caller's `allreduce` as before
-  const bool dev_reduce = !fermion && contractor.CommSize() > 1;
+  const bool dev_reduce = contractor.CommSize() > 1;
   if (dev_reduce) contractor.GradAllReduce();
-  if ((!mine.empty() || dev_reduce) && !fermion) acc.FetchDevice(contractor);
+  if (!mine.empty() || dev_reduce) acc.FetchDevice(contractor);
   if (dev_reduce) {
     std::vector<double> sc{acc.weight_sum, acc.e_loc_sum, acc.e_loc_sq_sum, (double)acc.samples};
     contractor.AllReduceSum(sc);

@@ -201,6 +201,17 @@ def test_device_gradient_accumulation_matches_host_path(fixtures_dir):
     so, seo = ctx.grad_read()
     assert np.max(np.abs(so - ref_so)) < 1e-10 * np.max(np.abs(ref_so))
     assert np.max(np.abs(seo - ref_seo)) < 1e-10 * np.max(np.abs(ref_seo))
+    # pepsgpu_grad_accumulate_states: the component of every site named by the caller (fermionic states: the extended
+    # state of the decoration the holes were punched in) -- here the flipped configuration, after the walkers moved on
+    other = 1 - cfgs
+    ctx.set_configs(np.ascontiguousarray(cfgs[::-1]))
+    ctx.grad_reset()
+    ctx.grad_accumulate(psi, eloc, False, states=other)
+    so2, seo2 = ctx.grad_read()
+    assert np.max(np.abs(so2 - ref_so[:, :, ::-1])) < 1e-10 * np.max(np.abs(ref_so))
+    assert np.max(np.abs(seo2 - ref_seo[:, :, ::-1])) < 1e-10 * np.max(np.abs(ref_seo))
+    with pytest.raises(ValueError):
+        ctx.grad_accumulate(psi, eloc, False, states=other + 2)
 
 
 def test_mc_energy_and_gradient_vs_exact_sum(fixtures_dir):
