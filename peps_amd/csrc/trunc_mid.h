@@ -105,23 +105,28 @@ __global__ __launch_bounds__(256, 2) void mid_gram_chol_kernel(const T *__restri
     for (int r = 0; r < 4; ++r) acc[q][r] = 0.0;
   // rows of the staging buffer beyond the matrix (tile padding) are read by the MFMA operands: zero, once
   for (int e = tid + n * TM_LDM; e < 16 * nt * TM_LDM; e += 256) sM[e] = 0.f;
+  // 32 columns x up to 128 rows = 16 elements per thread: unconditional loads (clamped address); the chunk after the one being
+  // multiplied is in flight during its MFMAs (registers v), stored once the waves have left the staging buffer
+  float v[16];
+  auto issue = [&](const int kc) {
+    const int kw = min(TM_KC, uk - kc);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i, r = min(e >> 5, n - 1), c = min(e & 31, kw - 1);
+      v[i] = (float)M[(long)r * uk + kc + c];
+    }
+  };
+  if (uk > 0) issue(0);
   for (int kc = 0; kc < uk; kc += TM_KC) {
     const int kw = min(TM_KC, uk - kc);
     __syncthreads();
-    {   // 32 columns x up to 128 rows = 16 elements per thread: unconditional loads (clamped address) all in flight, then the stores
-      float v[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int e = tid + 256 * i, r = min(e >> 5, n - 1), c = min(e & 31, kw - 1);
-        v[i] = (float)M[(long)r * uk + kc + c];
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int e = tid + 256 * i, r = e >> 5, c = e & 31;
-        if (r < n) sM[r * TM_LDM + c] = c < kw ? v[i] : 0.f;
-      }
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i, r = e >> 5, c = e & 31;
+      if (r < n) sM[r * TM_LDM + c] = c < kw ? v[i] : 0.f;
     }
     __syncthreads();
+    if (kc + TM_KC < uk) issue(kc + TM_KC);
     tm_gram_chunk_n(nq, acc, sM, offa, offb, k4);
   }
   __syncthreads();
@@ -242,7 +247,7 @@ inline size_t colgram_chol_smem_bytes(int rcap) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, 3) void colgram_chol_kernel(const T *__restrict__ Pg, long wP, int n, const int *__restrict__ kdyn,
+__global__ __launch_bounds__(256, 2) void colgram_chol_kernel(const T *__restrict__ Pg, long wP, int n, const int *__restrict__ kdyn,
                                                            int kdyn_mul, int kmax, T *__restrict__ Rg, long wR,
                                                            int *__restrict__ mlive_out, int inner,
                                                            const int *__restrict__ inner_live, int rcap, int decline_code,
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(256, 3) void colgram_chol_kernel(const T *__restric
   double *sR = cg_smem;                                   // [rcap][CG_LDR] finished factor rows (packed columns)
   double *sRow = sR + (size_t)rcap * CG_LDR;              // [CG_NC] row f of G
   float *sP = reinterpret_cast<float *>(sRow + CG_NC);    // [CG_NC][TM_LDM] chunk of P, transposed: [column][row]
-  __shared__ double s_red[4], s_nrm[128];
+  __shared__ double s_red[4], s_nrm[128], s_piv;
   __shared__ int s_first[2][4];
   __shared__ short s_pos[128];
   const T *P = Pg + (long)b * wP;
@@ -293,16 +298,22 @@ __global__ __launch_bounds__(256, 3) void colgram_chol_kernel(const T *__restric
   const int st_r = st_c < ncols ? (st_c / ilive) * inner + (st_c % ilive) : -1;
   // columns of the staging buffer beyond the live ones (tile padding) are read by the MFMA operands: zero, once
   for (int e = tid + ncols * TM_LDM; e < CG_NC * TM_LDM; e += 256) sP[e] = 0.f;
+  // unconditional loads (clamped row), 16 per thread and chunk; the chunk after the one being multiplied is in flight during
+  // its MFMAs (one block per CU at the 96-row cap: nothing else would hide the latency of the loads)
+  float v[TM_KC / 2];
+  auto issue = [&](const int k0) {
+    const int kw = min(TM_KC, K - k0);
+#pragma unroll
+    for (int i = 0; i < TM_KC / 2; ++i) {
+      const int k = min((tid >> 7) + 2 * i, kw - 1);
+      v[i] = (float)P[(long)(k0 + k) * n + st_r];
+    }
+  };
+  if (K > 0 && st_r >= 0) issue(0);
   for (int k0 = 0; k0 < K; k0 += TM_KC) {
     const int kw = min(TM_KC, K - k0);
     __syncthreads();
-    if (st_r >= 0) {   // unconditional loads (clamped row), all 16 of the chunk in flight before the first store
-      float v[TM_KC / 2];
-#pragma unroll
-      for (int i = 0; i < TM_KC / 2; ++i) {
-        const int k = min((tid >> 7) + 2 * i, kw - 1);
-        v[i] = (float)P[(long)(k0 + k) * n + st_r];
-      }
+    if (st_r >= 0) {
 #pragma unroll
       for (int i = 0; i < TM_KC / 2; ++i) {
         const int k = (tid >> 7) + 2 * i;
@@ -310,6 +321,7 @@ __global__ __launch_bounds__(256, 3) void colgram_chol_kernel(const T *__restric
       }
     }
     __syncthreads();
+    if (k0 + TM_KC < K && st_r >= 0) issue(k0 + TM_KC);
     tm_gram_chunk_n(nq, acc, sP, offa, offb, k4);
   }
   __syncthreads();
@@ -353,15 +365,21 @@ __global__ __launch_bounds__(256, 3) void colgram_chol_kernel(const T *__restric
       const double v = rsel == 0 ? acc[q][0] : rsel == 1 ? acc[q][1] : rsel == 2 ? acc[q][2] : acc[q][3];
       if (k4 == (il & 3)) sRow[16 * tj[q] + r16] = v;
     }
+    if (tid == f) s_piv = d;                            // the owner's running diagonal IS the pivot: no thread recomputes it
     __syncthreads();
     if (tid < ncols) {
-      double g = sRow[tid], piv = sRow[f];
-      for (int j = 0; j < nl; ++j) {
-        const double rf = sR[j * CG_LDR + f];
-        g = fma(-rf, sR[j * CG_LDR + tid], g);
-        piv = fma(-rf, rf, piv);
+      // four independent partial sums: the step is a chain of dependent f64 FMAs otherwise (nl of them, twice)
+      double g0 = sRow[tid], g1 = 0.0, g2 = 0.0, g3 = 0.0;
+      int j = 0;
+      for (; j + 4 <= nl; j += 4) {
+        g0 = fma(-sR[(j + 0) * CG_LDR + f], sR[(j + 0) * CG_LDR + tid], g0);
+        g1 = fma(-sR[(j + 1) * CG_LDR + f], sR[(j + 1) * CG_LDR + tid], g1);
+        g2 = fma(-sR[(j + 2) * CG_LDR + f], sR[(j + 2) * CG_LDR + tid], g2);
+        g3 = fma(-sR[(j + 3) * CG_LDR + f], sR[(j + 3) * CG_LDR + tid], g3);
       }
-      const double v = tid >= f ? g / sqrt(piv) : 0.0;
+      for (; j < nl; ++j) g0 = fma(-sR[j * CG_LDR + f], sR[j * CG_LDR + tid], g0);
+      const double g = (g0 + g1) + (g2 + g3);
+      const double v = tid >= f ? g / sqrt(s_piv) : 0.0;
       sR[nl * CG_LDR + tid] = v;
       if (tid > f) d -= v * v;
     }
