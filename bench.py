@@ -217,7 +217,9 @@ def roofline_of(prof, dtype, traffic=None):
     # the flops.  Below the machine balance (peak flops / peak HBM bandwidth) the kernel is bound by HBM, not by MFMA issue.
     dbytes = prof[dom].get("bytes", 0.0)
     intensity = counted / dbytes if dbytes > 0 else float("inf")
-    kpeak = PEAK_TFLOPS["f64"] if dom == "gram_f64" else peak          # the f64 Gram runs on v_mfma_f64_16x16x4_f64
+    # the Gram kernels (streaming, and the ones fused with the Cholesky: categories cholesky / trunc_gram) run on
+    # v_mfma_f64_16x16x4_f64; a category whose launches counted no MFMA flops on the device has no MFMA roofline
+    kpeak = PEAK_TFLOPS["f64"] if dom in ("gram_f64", "cholesky", "trunc_gram", "trunc_apply") else peak
     balance = kpeak * 1e12 / (PEAK_HBM_GBPS * 1e9)
     hbm_bound = intensity < balance
     gbps = dbytes / dsec / 1e9 if dsec > 0 else 0.0
@@ -245,9 +247,9 @@ def mfma_summary(prof, dtype, step_seconds_total):
     their own time and against the whole timed region."""
     cats = {}
     tot_fl = tot_ms = 0.0
-    for k in ("contract", "gram_f64", "env", "trunc_gram", "trunc_apply"):
+    for k in ("contract", "gram_f64", "cholesky", "env", "trunc_gram", "trunc_apply"):
         if k in prof and prof[k]["launches"] and prof[k]["exec_flops"] > 0:
-            pk = PEAK_TFLOPS["f64"] if k in ("gram_f64", "trunc_gram", "trunc_apply") else PEAK_TFLOPS[dtype]
+            pk = PEAK_TFLOPS["f64"] if k in ("gram_f64", "cholesky", "trunc_gram", "trunc_apply") else PEAK_TFLOPS[dtype]
             tf = prof[k]["exec_flops"] / (prof[k]["ms"] * 1e-3) / 1e12 if prof[k]["ms"] > 0 else 0.0
             cats[k] = {"ms": round(prof[k]["ms"], 3), "tflops": tf, "peak": pk, "frac": tf / pk}
             tot_fl += prof[k]["exec_flops"]

@@ -301,7 +301,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       const size_t smem = chol_smem_bytes(cols);
       PG_REQUIRE(smem <= 150 * 1024 && cols < 32768, 1, "Cholesky panel does not fit LDS (D*chi too large)");
       allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
-      prof_begin(PROF_CHOL, 0.0, nw_ * (double)cols * cols * cols / 3.0);
+      prof_begin(PROF_CHOL, 0.0, 0.0);   // (executed flops of this category: the MFMA flops of the fused Gram kernels, counted on the device)
       static const bool no_lowrank = getenv("PEPSGPU_NO_LOWRANK_CHOL") != nullptr;
       // (hint from the row absorbed before: when its carry at this site ran well above the cap, every walker would spend 32
       // steps here only to be handed on; the blocked kernel takes any rank)

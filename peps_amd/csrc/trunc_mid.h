@@ -12,6 +12,7 @@
 #pragma once
 #include "common.h"
 #include "linalg.h"
+#include "tgemm.h"   // tg_flop_counter / tg_byte_counter of the current profiling bracket
 
 namespace pepsgpu {
 
@@ -64,12 +65,19 @@ inline size_t mid_gram_chol_smem_bytes(int cap) {
 template <typename T>
 __global__ __launch_bounds__(256, 2) void mid_gram_chol_kernel(const T *__restrict__ Mg, long wM, int uk, const int *__restrict__ nrows,
                                                             const int *__restrict__ run_flag, int lo, int cap,
-                                                            T *__restrict__ Bg, long wB, int ld, int *__restrict__ mB) {
+                                                            T *__restrict__ Bg, long wB, int ld, int *__restrict__ mB,
+                                                            unsigned long long *__restrict__ flopc, unsigned long long *__restrict__ bytec,
+                                                            int flop_stride) {
   static_assert(sizeof(T) == 4, "the mid route is f32 only (the f64 mode keeps the direct Jacobi)");
   const int b = blockIdx.x;
   if (run_flag && run_flag[b] >= 0) return;
   const int n = nrows[b];
   if (n <= lo || n > cap) return;
+  if (flopc && threadIdx.x == 0 && b % flop_stride == 0) {   // MFMA flops issued: 16 x 16 tiles on or above the diagonal
+    const unsigned long long nt_ = (unsigned long long)((n + 15) >> 4);
+    atomicAdd(flopc, (unsigned long long)flop_stride * (nt_ * (nt_ + 1) / 2) * 512ull * (unsigned long long)uk);
+    if (bytec) atomicAdd(bytec, (unsigned long long)flop_stride * 4ull * ((unsigned long long)n * uk + (unsigned long long)n * n / 2));
+  }
   extern __shared__ double tm_smem[];
   const int ldG = cap + 1;
   double *sG = tm_smem;                                 // [cap][ldG] upper triangle of G, then of the factor
@@ -212,7 +220,8 @@ inline void launch_mid_gram_chol(hipStream_t s, int nbatch, const T *M, long wM,
     if (cap <= lo) break;
     const size_t smem = mid_gram_chol_smem_bytes(cap);
     allow_dynamic_lds(reinterpret_cast<const void *>(&mid_gram_chol_kernel<T>), smem);
-    hipLaunchKernelGGL(mid_gram_chol_kernel<T>, dim3(nbatch), dim3(256), smem, s, M, wM, uk, nrows, run_flag, lo, cap, B, wB, GS, mB);
+    hipLaunchKernelGGL(mid_gram_chol_kernel<T>, dim3(nbatch), dim3(256), smem, s, M, wM, uk, nrows, run_flag, lo, cap, B, wB, GS, mB,
+                       tg_flop_counter, tg_byte_counter, nbatch >= 256 ? 64 : 1);
     PG_CHECK_HIP(hipGetLastError());
     lo = cap;
   }
@@ -240,10 +249,14 @@ namespace pepsgpu {
 // step: 26 % of the headline step) on the low-rank side and the streaming Gram + blocked Cholesky pair (global-memory
 // round trip of the 128 x 128 Gram) on the dense side.
 constexpr int CG_NC = 128;           // live columns at most
-constexpr int CG_LDR = CG_NC + 1;    // row pitch of the factor rows in LDS (doubles)
+// The finished factor rows are kept in LDS as a packed upper triangle: the pivots are taken in increasing (packed) column
+// order, so row j of the factor is zero before column f_j >= j and only its columns c >= j are stored, at cg_row(j) + c.
+// 88 rows x 128 columns: 59 KB instead of the 91 KB of the rectangle -- two blocks per CU instead of one (the kernel is
+// a chain of barriers and dependent LDS round trips per pivot: a second block is what fills the CU).
+__host__ __device__ inline int cg_row(int j) { return j * (CG_NC - 1) - (j * (j - 1)) / 2; }
 
 inline size_t colgram_chol_smem_bytes(int rcap) {
-  return sizeof(double) * ((size_t)rcap * CG_LDR + CG_NC) + sizeof(float) * (size_t)CG_NC * TM_LDM + 64;
+  return sizeof(double) * ((size_t)rcap * CG_NC - (size_t)rcap * (rcap - 1) / 2 + CG_NC) + sizeof(float) * (size_t)CG_NC * TM_LDM + 64;
 }
 
 template <typename T>
@@ -251,7 +264,8 @@ __global__ __launch_bounds__(256, 2) void colgram_chol_kernel(const T *__restric
                                                            int kdyn_mul, int kmax, T *__restrict__ Rg, long wR,
                                                            int *__restrict__ mlive_out, int inner,
                                                            const int *__restrict__ inner_live, int rcap, int decline_code,
-                                                           int only_code) {
+                                                           int only_code, unsigned long long *__restrict__ flopc,
+                                                           unsigned long long *__restrict__ bytec, int flop_stride) {
   static_assert(sizeof(T) == 4, "f32 element type");
   const int b = blockIdx.x;
   if (only_code != 0 && mlive_out[b] != only_code) return;      // second launch (larger rcap): the entries the first declined
@@ -264,8 +278,8 @@ __global__ __launch_bounds__(256, 2) void colgram_chol_kernel(const T *__restric
     return;
   }
   extern __shared__ double cg_smem[];
-  double *sR = cg_smem;                                   // [rcap][CG_LDR] finished factor rows (packed columns)
-  double *sRow = sR + (size_t)rcap * CG_LDR;              // [CG_NC] row f of G
+  double *sR = cg_smem;                                   // finished factor rows, packed triangle: (j, c >= j) at cg_row(j) + c
+  double *sRow = sR + ((size_t)rcap * CG_NC - (size_t)rcap * (rcap - 1) / 2);   // [CG_NC] row f of G
   float *sP = reinterpret_cast<float *>(sRow + CG_NC);    // [CG_NC][TM_LDM] chunk of P, transposed: [column][row]
   __shared__ double s_red[4], s_nrm[128], s_piv;
   __shared__ int s_first[2][4];
@@ -277,6 +291,10 @@ __global__ __launch_bounds__(256, 2) void colgram_chol_kernel(const T *__restric
 
   // ---- G = P^T P over the packed columns, upper tiles in registers ----
   const int nt = (ncols + 15) >> 4, ntiles = nt * (nt + 1) / 2;
+  if (flopc && tid == 0 && b % flop_stride == 0) {     // MFMA flops issued (16 x 16 x 2 per tile and row of P) and compulsory bytes
+    atomicAdd(flopc, (unsigned long long)flop_stride * (unsigned long long)ntiles * 512ull * (unsigned long long)K);
+    if (bytec) atomicAdd(bytec, (unsigned long long)flop_stride * 4ull * (unsigned long long)K * ncols);
+  }
   constexpr int TPW = TM_TPW;
   const int r16 = lane & 15, k4 = lane >> 4;
   int ti[TPW], tj[TPW], offa[TPW], offb[TPW];
@@ -299,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void colgram_chol_kernel(const T *__restric
   // columns of the staging buffer beyond the live ones (tile padding) are read by the MFMA operands: zero, once
   for (int e = tid + ncols * TM_LDM; e < CG_NC * TM_LDM; e += 256) sP[e] = 0.f;
   // unconditional loads (clamped row), 16 per thread and chunk; the chunk after the one being multiplied is in flight during
-  // its MFMAs (one block per CU at the 96-row cap: nothing else would hide the latency of the loads)
+  // its MFMAs (two blocks per CU: little else hides the latency of the loads)
   float v[TM_KC / 2];
   auto issue = [&](const int k0) {
     const int kw = min(TM_KC, K - k0);
@@ -367,21 +385,24 @@ __global__ __launch_bounds__(256, 2) void colgram_chol_kernel(const T *__restric
     }
     if (tid == f) s_piv = d;                            // the owner's running diagonal IS the pivot: no thread recomputes it
     __syncthreads();
-    if (tid < ncols) {
+    if (tid >= f && tid < ncols) {                      // (columns before the pivot: their entry of the row is zero, not stored)
       // four independent partial sums: the step is a chain of dependent f64 FMAs otherwise (nl of them, twice)
       double g0 = sRow[tid], g1 = 0.0, g2 = 0.0, g3 = 0.0;
       int j = 0;
       for (; j + 4 <= nl; j += 4) {
-        g0 = fma(-sR[(j + 0) * CG_LDR + f], sR[(j + 0) * CG_LDR + tid], g0);
-        g1 = fma(-sR[(j + 1) * CG_LDR + f], sR[(j + 1) * CG_LDR + tid], g1);
-        g2 = fma(-sR[(j + 2) * CG_LDR + f], sR[(j + 2) * CG_LDR + tid], g2);
-        g3 = fma(-sR[(j + 3) * CG_LDR + f], sR[(j + 3) * CG_LDR + tid], g3);
+        const int r0 = cg_row(j), r1 = cg_row(j + 1), r2 = cg_row(j + 2), r3 = cg_row(j + 3);
+        g0 = fma(-sR[r0 + f], sR[r0 + tid], g0);
+        g1 = fma(-sR[r1 + f], sR[r1 + tid], g1);
+        g2 = fma(-sR[r2 + f], sR[r2 + tid], g2);
+        g3 = fma(-sR[r3 + f], sR[r3 + tid], g3);
       }
-      for (; j < nl; ++j) g0 = fma(-sR[j * CG_LDR + f], sR[j * CG_LDR + tid], g0);
+      for (; j < nl; ++j) g0 = fma(-sR[cg_row(j) + f], sR[cg_row(j) + tid], g0);
       const double g = (g0 + g1) + (g2 + g3);
-      const double v = tid >= f ? g / sqrt(s_piv) : 0.0;
-      sR[nl * CG_LDR + tid] = v;
+      const double v = g / sqrt(s_piv);
+      sR[cg_row(nl) + tid] = v;
       if (tid > f) d -= v * v;
+    } else if (tid >= nl && tid < f) {
+      sR[cg_row(nl) + tid] = 0.0;                       // stored columns of the row before its pivot
     }
     ++nl;
   }
@@ -389,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void colgram_chol_kernel(const T *__restric
   // ---- rank compaction (rows below NOISE_C eps_T |R|_F are dropped) and output ----
   for (int j = wave; j < nl; j += 4) {
     double a = 0.0;
-    for (int c = lane; c < ncols; c += 64) { const double x = sR[j * CG_LDR + c]; a += x * x; }
+    for (int c = j + lane; c < ncols; c += 64) { const double x = sR[cg_row(j) + c]; a += x * x; }
     a = wave_sum(a);
     if (lane == 0) s_nrm[j] = a;
   }
@@ -407,13 +428,13 @@ __global__ __launch_bounds__(256, 2) void colgram_chol_kernel(const T *__restric
   if (my_r >= 0) {
     for (int j = 0; j < nl; ++j) {
       const int pos = s_pos[j];
-      if (pos >= 0) Rout[(long)pos * n + my_r] = T(sR[j * CG_LDR + tid] * sc);
+      if (pos >= 0) Rout[(long)pos * n + my_r] = tid >= j ? T(sR[cg_row(j) + tid] * sc) : T(0);
     }
   }
 }
 
 // Used for DENSE states only (hint of the row absorbed before: carry rank above the caps of the thread-per-column
-// kernels), with the 96-row cap.  Measured on one MI355X, C4, two steps:
+// kernels), with the 88-row cap.  Measured on one MI355X, C4, two steps:
 //   dense state (noise 1.0, 4096 walkers): Gram + Cholesky 660 ms (streaming Gram + blocked Cholesky) -> 608 ms here;
 //   headline state (32768 walkers, rank ~10, cap 16): 200 ms against 194 ms of gram_chol_lowrank_kernel -- no gain: both
 //   are bound by the same chain of dependent HBM round trips (stage P, barriers), not by the arithmetic (2 us of MFMA per
@@ -424,11 +445,11 @@ template <typename T>
 inline void launch_colgram_chol(hipStream_t s, int nbatch, const T *P, long wP, int n, const int *kdyn, int kdyn_mul, int kmax,
                                 T *R, long wR, int *mlive, int inner, const int *inner_live, int decline_code, bool hint_dense) {
   (void)hint_dense;
-  const int rcap = 96;
+  const int rcap = 88;
   const size_t sm = colgram_chol_smem_bytes(rcap);
   allow_dynamic_lds(reinterpret_cast<const void *>(&colgram_chol_kernel<T>), sm);
   hipLaunchKernelGGL(colgram_chol_kernel<T>, dim3(nbatch), dim3(256), sm, s, P, wP, n, kdyn, kdyn_mul, kmax, R, wR, mlive, inner,
-                     inner_live, rcap, decline_code, 0);
+                     inner_live, rcap, decline_code, 0, tg_flop_counter, tg_byte_counter, nbatch >= 256 ? 64 : 1);
   PG_CHECK_HIP(hipGetLastError());
 }
 
