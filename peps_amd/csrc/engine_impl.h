@@ -496,12 +496,22 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       launch_jacobi(M.p, M.n, m, uk, use_lds, need, mdyn[i], mmul[i], mid ? MID_HI : 0);
       if constexpr (sizeof(T) == 4) {
         if (mid) {
-          // <= 64 live rows: two waves per walker (24 KB of LDS: six walkers per CU), else four
-          hipLaunchKernelGGL((jacobi_rows_regx_kernel<2, 2>), dim3(nw_), dim3(128), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS,
-                             40, sweeps_, (const int *)mB, 1, 0);
-          if (GS > 64)
-            hipLaunchKernelGGL((jacobi_rows_regx_kernel<4, 2>), dim3(nw_), dim3(256), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS,
-                               40, sweeps_, (const int *)mB, 1, 64);
+          // <= 64 live rows: two waves per walker, else four; rows of 16 lanes, four pairs per wave instruction
+          // (jacobi_rows_grp_kernel; PEPSGPU_NO_GRP_JACOBI=1: the 64-lanes-per-row tournament it replaced)
+          static const bool no_grp = getenv("PEPSGPU_NO_GRP_JACOBI") != nullptr;
+          if (no_grp) {
+            hipLaunchKernelGGL((jacobi_rows_regx_kernel<2, 2>), dim3(nw_), dim3(128), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS,
+                               40, sweeps_, (const int *)mB, 1, 0);
+            if (GS > 64)
+              hipLaunchKernelGGL((jacobi_rows_regx_kernel<4, 2>), dim3(nw_), dim3(256), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS,
+                                 40, sweeps_, (const int *)mB, 1, 64);
+          } else {
+            hipLaunchKernelGGL((jacobi_rows_grp_kernel<2, 8>), dim3(nw_), dim3(128), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS,
+                               40, sweeps_, (const int *)mB, 1, 0);
+            if (GS > 64)
+              hipLaunchKernelGGL((jacobi_rows_grp_kernel<4, 8>), dim3(nw_), dim3(256), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS,
+                                 40, sweeps_, (const int *)mB, 1, 64);
+          }
           PG_CHECK_HIP(hipGetLastError());
         }
       }

@@ -547,6 +547,223 @@ __global__ __launch_bounds__(NW * 64) void jacobi_rows_regx_kernel(float *__rest
 
 
 // ---------------------------------------------------------------------------------------------
+// The mid-route tournament with SIXTEEN LANES PER ROW.  The rows of the triangular factor are at most 128 long: spread over
+// 64 lanes (the kernel above) a pair costs two FMAs per lane and a six-step 64-lane reduction -- the reduction is the
+// kernel.  Here a row lives in one DPP row of 16 lanes (CPL = 8 columns per lane), a wave instruction works on FOUR pairs
+// side by side (one per 16-lane group) and a dot product ends with four DPP steps inside the group.  The players of the
+// tournament are the 16-lane groups: 4 NW players, two blocks of JG_RB = 4 rows each (NW = 2: up to 64 rows, NW = 4: 128);
+// blocks move between players through LDS exactly as the wave-sized blocks of the kernel above do (same circle method, same
+// rotation, threshold, noise floor and sorting by norm), only the unit is a quarter of a wave.
+constexpr int JG_RB = 4;
+
+__device__ __forceinline__ float jg_sum16(float v) {
+  v = jr_dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = jr_dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = jr_dpp_add<0x141>(v);   // row_half_mirror
+  v = jr_dpp_add<0x140>(v);   // row_mirror
+  return v;
+}
+
+template <int NW, int CPL>
+__global__ __launch_bounds__(NW * 64) void jacobi_rows_grp_kernel(float *__restrict__ Mg, long wM, int m, int len, int ld,
+                                                                  int max_sweeps, int *__restrict__ sweeps_out,
+                                                                  const int *__restrict__ mdyn, int mdyn_mul,
+                                                                  int lo_rows = 0) {
+  constexpr int NP = 4 * NW, SLOTS = NP + 1, MAXR = NP * 2 * JG_RB, NT = NW * 64;
+  __shared__ float xch[SLOTS][JG_RB][CPL][16];
+  __shared__ float xnorm[SLOTS][JG_RB];
+  __shared__ float s_n2[MAXR];
+  __shared__ short s_perm[MAXR];
+  __shared__ double s_fro[NW];
+  __shared__ int s_rot, s_live0;
+  if (mdyn) m = min(m, mdyn[blockIdx.x] * mdyn_mul);
+  if (m <= lo_rows || m > MAXR) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l16 = lane & 15;
+  const int w = wv * 4 + (lane >> 4);                     // the player this lane belongs to
+  float *M = Mg + (long)blockIdx.x * wM;
+  if (tid == 0) s_live0 = 0;
+  for (int r = wv; r < MAXR; r += NW) {                   // squared row norms: one wave per row
+    float n2 = 0.f;
+    if (r < m)
+      for (int c = lane; c < len; c += 64) { const float v = M[(long)r * ld + c]; n2 = fmaf(v, v, n2); }
+    n2 = jr_allsum(n2);
+    if (lane == 0) s_n2[r] = n2;
+  }
+  __syncthreads();
+  {
+    double f = 0.0;
+    for (int r = tid; r < MAXR; r += NT) f += (double)s_n2[r];
+    f = wave_sum(f);
+    if (lane == 0) s_fro[wv] = f;
+    __syncthreads();
+    if (tid == 0) { double t = 0.0; for (int k = 0; k < NW; ++k) t += s_fro[k]; s_fro[0] = t; }
+    __syncthreads();
+  }
+  const float floor2 = (float)(NOISE_C * NOISE_C * (double)Eps<float>::v * (double)Eps<float>::v * s_fro[0]);
+  const float tol2 = 4.f * (float)len * Eps<float>::v * Eps<float>::v;
+  for (int r = tid; r < MAXR; r += NT) {                  // rows sorted by norm: the live ones come first
+    const float v = s_n2[r];
+    int rk = 0;
+    for (int q = 0; q < MAXR; ++q) {
+      const float u = s_n2[q];
+      rk += (u > v) || (u == v && q < r);
+    }
+    s_perm[rk] = (short)r;
+    if (v > floor2) atomicAdd(&s_live0, 1);
+  }
+  __syncthreads();
+  const int live0 = s_live0;
+  const int nbl = (live0 + JG_RB - 1) / JG_RB;            // blocks that hold live rows
+  const int np = nbl <= 2 ? 1 : (nbl + 1) / 2;            // players that take part
+  const bool active = w < np;
+
+  JrRowT<CPL> a[JG_RB], b[JG_RB];
+  float na[JG_RB], nb[JG_RB];
+  auto load_block = [&](JrRowT<CPL>(&blk)[JG_RB], int bid) {
+#pragma unroll
+    for (int i = 0; i < JG_RB; ++i) {
+      const int pos = bid * JG_RB + i;
+      const int r = (active && pos < nbl * JG_RB) ? (int)s_perm[pos] : m;
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        const int c = CPL * l16 + q;
+        blk[i].v[q] = (r < m && c < len) ? M[(long)r * ld + c] : 0.f;
+      }
+    }
+  };
+  load_block(a, w);
+  load_block(b, np + w);
+
+  int sweep = 0;
+  for (; sweep < max_sweeps; ++sweep) {
+    if (tid == 0) s_rot = 0;
+#pragma unroll
+    for (int i = 0; i < JG_RB; ++i) {
+      na[i] = jg_sum16(jrx_dot<CPL>(a[i], a[i]));
+      nb[i] = jg_sum16(jrx_dot<CPL>(b[i], b[i]));
+    }
+    int rot = 0;
+    // pairs inside the two blocks of a player (circle method on JG_RB rows; a player without rows holds zeros: no rotation)
+#pragma unroll 1
+    for (int r = 0; r < JG_RB - 1; ++r) {
+      float ga[JG_RB / 2], gb[JG_RB / 2];
+#pragma unroll
+      for (int p = 0; p < JG_RB / 2; ++p) {
+        ga[p] = jg_sum16(jrx_dot<CPL>(a[p], a[JG_RB - 1 - p]));
+        gb[p] = jg_sum16(jrx_dot<CPL>(b[p], b[JG_RB - 1 - p]));
+      }
+#pragma unroll
+      for (int p = 0; p < JG_RB / 2; ++p) {
+        rot += jrx_apply<CPL>(a[p], a[JG_RB - 1 - p], na[p], na[JG_RB - 1 - p], ga[p], tol2, floor2);
+        rot += jrx_apply<CPL>(b[p], b[JG_RB - 1 - p], nb[p], nb[JG_RB - 1 - p], gb[p], tol2, floor2);
+      }
+      {
+        const JrRowT<CPL> ta = a[JG_RB - 1], tb = b[JG_RB - 1];
+        const float fa = na[JG_RB - 1], fb = nb[JG_RB - 1];
+#pragma unroll
+        for (int i = JG_RB - 1; i >= 2; --i) { a[i] = a[i - 1]; b[i] = b[i - 1]; na[i] = na[i - 1]; nb[i] = nb[i - 1]; }
+        a[1] = ta; b[1] = tb; na[1] = fa; nb[1] = fb;
+      }
+    }
+    __syncthreads();
+    for (int sr = 0; sr < 2 * np - 1; ++sr) {
+      // every row of block a against every row of block b: JG_RB steps of JG_RB disjoint pairs (b turns by one row a step)
+#pragma unroll 1
+      for (int t = 0; t < JG_RB; ++t) {
+        float g[JG_RB];
+#pragma unroll
+        for (int i = 0; i < JG_RB; ++i) g[i] = jg_sum16(jrx_dot<CPL>(a[i], b[i]));
+#pragma unroll
+        for (int i = 0; i < JG_RB; ++i) rot += jrx_apply<CPL>(a[i], b[i], na[i], nb[i], g[i], tol2, floor2);
+        {
+          const JrRowT<CPL> tb = b[0];
+          const float fb = nb[0];
+#pragma unroll
+          for (int i = 0; i < JG_RB - 1; ++i) { b[i] = b[i + 1]; nb[i] = nb[i + 1]; }
+          b[JG_RB - 1] = tb; nb[JG_RB - 1] = fb;
+        }
+      }
+      if (np == 1) continue;
+      // the circle turns by one player: bottom blocks move down (w <- w + 1, the last takes the top of the last), top
+      // blocks move up (w <- w - 1, player 1 takes the old bottom of player 0); player 0 keeps its top block
+      if (active) {
+#pragma unroll
+        for (int i = 0; i < JG_RB; ++i)
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) xch[w][i][q][l16] = b[i].v[q];
+        if (l16 == 0) {
+#pragma unroll
+          for (int i = 0; i < JG_RB; ++i) xnorm[w][i] = nb[i];
+        }
+        if (w == np - 1) {
+#pragma unroll
+          for (int i = 0; i < JG_RB; ++i)
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) xch[np][i][q][l16] = a[i].v[q];
+          if (l16 == 0) {
+#pragma unroll
+            for (int i = 0; i < JG_RB; ++i) xnorm[np][i] = na[i];
+          }
+        }
+      }
+      __syncthreads();
+      if (active) {
+        const int src = (w == np - 1) ? np : w + 1;
+#pragma unroll
+        for (int i = 0; i < JG_RB; ++i) {
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) b[i].v[q] = xch[src][i][q][l16];
+          nb[i] = xnorm[src][i];
+        }
+      }
+      __syncthreads();
+      if (active && w >= 1 && w <= np - 2) {
+#pragma unroll
+        for (int i = 0; i < JG_RB; ++i)
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) xch[w][i][q][l16] = a[i].v[q];
+        if (l16 == 0) {
+#pragma unroll
+          for (int i = 0; i < JG_RB; ++i) xnorm[w][i] = na[i];
+        }
+      }
+      __syncthreads();
+      if (active && w >= 1) {
+        const int src = w - 1;   // w == 1 reads slot 0 = old bottom[0]
+#pragma unroll
+        for (int i = 0; i < JG_RB; ++i) {
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) a[i].v[q] = xch[src][i][q][l16];
+          na[i] = xnorm[src][i];
+        }
+      }
+      __syncthreads();
+    }
+    if (l16 == 0 && rot) atomicAdd(&s_rot, rot);
+    __syncthreads();
+    const int total = s_rot;
+    __syncthreads();
+    if (total == 0) { ++sweep; break; }
+  }
+  // 2 np - 1 exchanges = one full turn of the circle: every block is back with the player and slot it was loaded into
+  auto store_block = [&](JrRowT<CPL>(&blk)[JG_RB], int bid) {
+#pragma unroll
+    for (int i = 0; i < JG_RB; ++i) {
+      const int pos = bid * JG_RB + i;
+      const int r = (active && pos < nbl * JG_RB) ? (int)s_perm[pos] : m;
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        const int c = CPL * l16 + q;
+        if (r < m && c < len) M[(long)r * ld + c] = blk[i].v[q];
+      }
+    }
+  };
+  store_block(a, w);
+  store_block(b, np + w);
+  if (tid == 0 && sweeps_out) sweeps_out[blockIdx.x] = sweep | (live0 << 8);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Small-rank variant: a walker whose carry has at most 32 existing rows (rank-adaptive absorption:
 // the usual case away from full rank) is a 32 x 256 problem that ONE wave holds in registers, so
 // four walkers share a 256-thread workgroup and nothing crosses LDS or a workgroup barrier.  The

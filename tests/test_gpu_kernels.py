@@ -373,18 +373,22 @@ def test_chained_contraction_pair_with_live_extents():
             assert fl[0] == -1
 
 
-@pytest.mark.parametrize("shape", [(128, 128), (70, 70), (96, 96), (33, 64), (100, 128), (17, 40), (64, 64)])
-def test_jacobi_mid_route_kernel(shape):
-    """jacobi_rows_regx_kernel<4,2> (tournament kernel of the preconditioned mid route, up to 128 x 128) on triangular,
-    graded input (the Cholesky factor it is given in the absorption): singular values, orthonormal Vt and dominant subspace
-    against LAPACK."""
+@pytest.mark.parametrize("kernel", [4, 5, 6])
+@pytest.mark.parametrize("shape", [(128, 128), (70, 70), (96, 96), (33, 64), (100, 128), (17, 40), (64, 64), (5, 16), (61, 128)])
+def test_jacobi_mid_route_kernel(shape, kernel):
+    """Tournament kernels of the preconditioned mid route (up to 128 x 128) on triangular, graded input (the Cholesky factor
+    they are given in the absorption): singular values, orthonormal Vt and dominant subspace against LAPACK.  kernel 4:
+    jacobi_rows_regx_kernel<4,2> (a row over 64 lanes); 5 / 6: jacobi_rows_grp_kernel<4,8> / <2,8> (16 lanes per row, four
+    pairs per wave instruction; the two-wave form takes up to 64 rows)."""
     capi = _capi()
     m, ln = shape
+    if kernel == 6 and m > 64:
+        pytest.skip("two-wave tournament: up to 64 rows")
     rng = np.random.default_rng(5 * m + ln)
     nb = 5
     M = np.stack([np.triu(rng.standard_normal((m, ln))) * np.logspace(0, -5, m)[:, None] for _ in range(nb)])
     k = min(32, m, ln)
-    Mo, Vt, S, sw = capi.diag_jacobi(capi.F32, M, k, 4)
+    Mo, Vt, S, sw = capi.diag_jacobi(capi.F32, M, k, kernel)
     for b in range(nb):
         sref = np.linalg.svd(M[b], compute_uv=False)
         assert np.max(np.abs(S[b].astype(np.float64) - sref[:k])) < 3e-5 * sref[0]
