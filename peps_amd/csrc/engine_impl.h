@@ -43,7 +43,14 @@ void Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
       static const bool no_tiny = getenv("PEPSGPU_NO_TINYJACOBI") != nullptr;
       if (!no_tiny) {   // walkers with <= 16 rows first (low register count: all of them resident at once)
         static const bool no_tiny2 = getenv("PEPSGPU_NO_TINY2JACOBI") != nullptr;
-        if (len <= 128 && !no_tiny2)   // short rows (shrunk bonds): two walkers per wave
+        static const int tiny4 = getenv("PEPSGPU_TINY4") ? atoi(getenv("PEPSGPU_TINY4")) : 1;
+        if (len <= 64 && !no_tiny2 && tiny4)          // short rows (shrunk bonds): four walkers per wave, 16 lanes x 4 columns
+          hipLaunchKernelGGL((jacobi_rows_tiny4_kernel<4>), dim3((nw_ + 15) / 16), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
+                             sweeps_, mdyn, mdyn_mul, nw_);
+        else if (len <= 128 && !no_tiny2 && tiny4 == 1)   // ... 16 lanes x 8 columns
+          hipLaunchKernelGGL((jacobi_rows_tiny4_kernel<8>), dim3((nw_ + 15) / 16), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
+                             sweeps_, mdyn, mdyn_mul, nw_);
+        else if (len <= 128 && !no_tiny2)             // two walkers per wave (32 lanes x 4 columns)
           hipLaunchKernelGGL(jacobi_rows_tiny2_kernel, dim3((nw_ + 7) / 8), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
                              sweeps_, mdyn, mdyn_mul, nw_);
         else

@@ -1038,4 +1038,85 @@ __global__ __launch_bounds__(256, 3) void jacobi_rows_tiny2_kernel(float *__rest
   if (l32 == 0 && mm > 0 && sweeps_out) sweeps_out[walker] = sweep | (mm << 8);
 }
 
+
+// Four walkers per wave: a row of at most 128 elements lives in one DPP row of 16 lanes (CPL = 8 columns per lane, 4 when
+// len <= 64), a dot product ends with four DPP steps inside the lane group and every wave instruction works on four
+// walkers' pairs at once (the two-walker kernel above: five steps, two walkers).  Same rotation, threshold and noise floor.
+template <int NB, int CPL>
+__device__ __forceinline__ int jr_intra16(JrRowT<CPL> (&a)[JR_BR], float (&na)[JR_BR], const float tol2, const float floor2) {
+  int rot = 0;
+#pragma unroll 1
+  for (int r = 0; r < NB - 1; ++r) {
+    float ga[NB / 2];
+#pragma unroll
+    for (int p = 0; p < NB / 2; ++p) ga[p] = jg_sum16(jrx_dot<CPL>(a[p], a[NB - 1 - p]));
+#pragma unroll
+    for (int p = 0; p < NB / 2; ++p) rot += jrx_apply<CPL>(a[p], a[NB - 1 - p], na[p], na[NB - 1 - p], ga[p], tol2, floor2);
+    const JrRowT<CPL> ta = a[NB - 1];
+    const float fa = na[NB - 1];
+#pragma unroll
+    for (int i = NB - 1; i >= 2; --i) { a[i] = a[i - 1]; na[i] = na[i - 1]; }
+    a[1] = ta; na[1] = fa;
+  }
+  return rot;
+}
+
+template <int CPL>
+__global__ __launch_bounds__(256, CPL <= 4 ? 3 : 2) void jacobi_rows_tiny4_kernel(float *__restrict__ Mg, long wM, int m, int len, int ld,
+                                                                               int max_sweeps, int *__restrict__ sweeps_out,
+                                                                               const int *__restrict__ mdyn, int mdyn_mul, int nwalkers) {
+  const int lane = threadIdx.x & 63, l16 = lane & 15;
+  const int walker = blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + (lane >> 4);
+  const bool have = walker < nwalkers;
+  int mm = have ? (mdyn ? min(m, mdyn[walker] * mdyn_mul) : m) : 0;
+  if (mm > JR_BR) mm = 0;                                     // the 32-row / 8-wave kernels take this walker
+  int mm_max = max(mm, __shfl_xor(mm, 16, 64));               // wave-uniform: the four walkers of the wave
+  mm_max = max(mm_max, __shfl_xor(mm_max, 32, 64));
+  if (mm_max == 0) return;
+  float *M = Mg + (long)(have ? walker : 0) * wM;
+  JrRowT<CPL> a[JR_BR];
+  float na[JR_BR];
+  float fro = 0.f;
+#pragma unroll
+  for (int i = 0; i < JR_BR; ++i) {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      const int c = CPL * l16 + q;
+      a[i].v[q] = (i < mm && c < len) ? M[(long)i * ld + c] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < JR_BR; ++i) {
+    na[i] = jg_sum16(jrx_dot<CPL>(a[i], a[i]));
+    fro += na[i];
+  }
+  const float floor2 = (float)(NOISE_C * NOISE_C * (double)Eps<float>::v * (double)Eps<float>::v) * fro;
+  const float tol2 = 4.f * (float)len * Eps<float>::v * Eps<float>::v;
+  int sweep = 0;
+  for (; sweep < max_sweeps; ++sweep) {
+    if (sweep) {
+#pragma unroll
+      for (int i = 0; i < JR_BR; ++i)
+        if (i < mm_max) na[i] = jg_sum16(jrx_dot<CPL>(a[i], a[i]));   // rows beyond every walker's count are zero
+    }
+    int rot;
+    if (mm_max <= 6) rot = jr_intra16<6, CPL>(a, na, tol2, floor2);
+    else if (mm_max <= 8) rot = jr_intra16<8, CPL>(a, na, tol2, floor2);
+    else if (mm_max <= 10) rot = jr_intra16<10, CPL>(a, na, tol2, floor2);
+    else if (mm_max <= 12) rot = jr_intra16<12, CPL>(a, na, tol2, floor2);
+    else if (mm_max <= 14) rot = jr_intra16<14, CPL>(a, na, tol2, floor2);
+    else rot = jr_intra16<JR_BR, CPL>(a, na, tol2, floor2);
+    if (!__any(rot != 0)) { ++sweep; break; }
+  }
+#pragma unroll
+  for (int i = 0; i < JR_BR; ++i) {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      const int c = CPL * l16 + q;
+      if (i < mm && c < len) M[(long)i * ld + c] = a[i].v[q];
+    }
+  }
+  if (l16 == 0 && mm > 0 && sweeps_out) sweeps_out[walker] = sweep | (mm << 8);
+}
+
 }  // namespace pepsgpu
