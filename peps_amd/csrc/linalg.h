@@ -703,6 +703,159 @@ __global__ __launch_bounds__(NT, 2) void qr_lowrank_kernel(const T *__restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The Gram-free factor with ONE WAVE PER WALKER (f32 data; the first kernel every walker of the rank-adaptive absorption
+// meets).  A lane owns two packed data columns (lane, lane + 64: at most 128 columns): its rows of P (64 per pass) and its
+// entries of the factor (rank <= 16, f64) stay in registers; the pivot column is handed to the other lanes with
+// v_readlane (a scalar operand of the FMAs) instead of an LDS broadcast, and nothing in the step loop crosses a workgroup
+// barrier -- the 128-thread kernel above spends two barriers and an LDS round trip per pivot with three waves per SIMD to
+// hide them.  Same arithmetic (f64 accumulation of exact f32 products, pivot rule, multi-pass folding of more than 64 rows,
+// row compaction, scaling) and the same output contract; a walker it cannot take (more rows than the passes cover, more
+// than 128 data columns, rank above 16) gets mlive_out[b] = -4 and goes to gram_chol_lowrank_kernel.
+__device__ __forceinline__ double gw_readlane_f64(const double v, const int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(256, 2) void gram_chol_wave_kernel(const float *__restrict__ Pg, long wP, int n,
+                                                              const int *__restrict__ kdyn, int kdyn_mul, int kmax,
+                                                              float *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
+                                                              int inner, const int *__restrict__ inner_live, int max_pass,
+                                                              int nbatch) {
+  constexpr int KC = 64, RC = 16;
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= nbatch) return;
+  const int Ktot = kdyn ? min(kmax, kdyn[b] * kdyn_mul) : kmax;
+  const int ilive = inner_live ? min(inner, inner_live[b]) : inner;
+  const int ncols = (n / inner) * ilive;
+  if (Ktot > KC + (max_pass - 1) * (KC - RC) || ncols > 128) {
+    if (lane == 0) mlive_out[b] = -4;
+    return;
+  }
+  const float *P = Pg + (long)b * wP;
+  float *Rout = Rg + (long)b * wR;
+  const int c0 = lane, c1 = lane + 64;                  // packed columns of this lane
+  const bool ok0 = c0 < ncols, ok1 = c1 < ncols;
+  const int r0 = ok0 ? (c0 / ilive) * inner + (c0 % ilive) : 0, r1 = ok1 ? (c1 / ilive) * inner + (c1 % ilive) : 0;
+  const double eT = NOISE_C * (double)Eps<float>::v;
+  float p0[KC], p1[KC];
+  double q0[RC], q1[RC];                                // own entries of the factor rows
+#pragma unroll
+  for (int j = 0; j < RC; ++j) { q0[j] = 0.0; q1[j] = 0.0; }
+  int nl = 0, k0 = 0;
+  double maxd = 0.0;
+  float nrm_mine = 0.f;                                 // lane j: squared norm of factor row j
+#pragma unroll 1
+  for (int pass = 0;; ++pass) {
+    const int nfr = nl;                                 // rows of the running factor, folded in as the first rows
+    const int npr = min(Ktot - k0, KC - (pass > 0 ? RC : 0));
+    const int K = nfr + npr;
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      float x0 = 0.f, x1 = 0.f;
+      if (k < RC && k < nfr) { x0 = (float)q0[k < RC ? k : 0]; x1 = (float)q1[k < RC ? k : 0]; }
+      else if (k < K) {
+        const long ro = (long)(k0 + k - nfr) * n;
+        if (ok0) x0 = P[ro + r0];
+        if (ok1) x1 = P[ro + r1];
+      }
+      p0[k] = x0; p1[k] = x1;
+      d0 += (double)x0 * (double)x0;
+      d1 += (double)x1 * (double)x1;
+    }
+#pragma unroll
+    for (int j = 0; j < RC; ++j) { q0[j] = 0.0; q1[j] = 0.0; }
+    {
+      double md = fmax(d0, d1);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
+      maxd = md;
+    }
+    const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
+    int f = -1;
+    nl = 0;
+    nrm_mine = 0.f;
+#pragma unroll 1
+    for (;;) {
+      int cand = (ok0 && c0 > f && d0 > thresh) ? c0 : ((ok1 && c1 > f && d1 > thresh) ? c1 : 0x7fffffff);
+      cand = wave_min_dpp(cand);
+      if (cand == 0x7fffffff || nl >= K) break;         // the rank cannot exceed the K rows
+      if (nl == RC) {                                   // rank above the cap: the 128-thread kernels redo this walker
+        if (lane == 0) mlive_out[b] = -4;
+        return;
+      }
+      f = __builtin_amdgcn_readfirstlane(cand);
+      const int lf = f & 63;
+      double g0 = 0.0, g1 = 0.0, h0 = 0.0, h1 = 0.0, piv;   // (two partial sums per column: four independent FMA chains)
+      auto step = [&](const float (&pp)[KC], const double (&qq)[RC], const double dd) {
+        piv = gw_readlane_f64(dd, lf);
+#pragma unroll
+        for (int kb = 0; kb < KC; kb += 16) {
+          if (kb >= K) break;
+#pragma unroll
+          for (int k = kb; k < kb + 16; ++k) {
+            const double pf = (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pp[k]), lf));
+            float x0 = p0[k], x1 = p1[k];
+            asm volatile("" : "+v"(x0), "+v"(x1));   // opaque copies: the f32 -> f64 conversions of the (loop-invariant) columns
+                                                     // stay inside the step loop instead of 256 more live registers
+            if (k & 1) { h0 = fma(pf, (double)x0, h0); h1 = fma(pf, (double)x1, h1); }
+            else { g0 = fma(pf, (double)x0, g0); g1 = fma(pf, (double)x1, g1); }
+          }
+        }
+#pragma unroll
+        for (int jb = 0; jb < RC; jb += 8) {
+          if (jb < nl) {
+#pragma unroll
+            for (int j = jb; j < jb + 8; ++j) {
+              if (j < nl) {
+                const double rf = gw_readlane_f64(qq[j], lf);
+                g0 = fma(-rf, q0[j], g0);
+                g1 = fma(-rf, q1[j], g1);
+              }
+            }
+          }
+        }
+      };
+      if (f < 64) step(p0, q0, d0); else step(p1, q1, d1);
+      g0 += h0; g1 += h1;
+      const double inv = 1.0 / sqrt(piv);
+      const double v0 = (ok0 && c0 >= f) ? g0 * inv : 0.0, v1 = (ok1 && c1 >= f) ? g1 * inv : 0.0;
+#pragma unroll
+      for (int jb = 0; jb < RC; jb += 8) {
+        if ((nl & ~7) == jb) {
+#pragma unroll
+          for (int j = jb; j < jb + 8; ++j) { q0[j] = (j == nl) ? v0 : q0[j]; q1[j] = (j == nl) ? v1 : q1[j]; }
+        }
+      }
+      if (c0 > f) d0 -= v0 * v0;
+      if (c1 > f) d1 -= v1 * v1;
+      const float a = wave_sum_dpp((float)(v0 * v0 + v1 * v1));   // row norm^2 for the compaction floor: f32 is ample
+      if (lane == nl) nrm_mine = a;
+      ++nl;
+    }
+    k0 += npr;
+    if (k0 >= Ktot) break;
+  }
+  const float fro = wave_sum_dpp(lane < nl ? nrm_mine : 0.f);
+  const bool keep = lane < nl && (double)nrm_mine > eT * eT * (double)fro;
+  const unsigned long long km = __ballot(keep);
+  const int pos = keep ? __popcll(km & ((1ull << lane) - 1ull)) : -1;
+  if (lane == 0) mlive_out[b] = __popcll(km);
+  const double sc = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
+#pragma unroll
+  for (int j = 0; j < RC; ++j) {
+    if (j < nl) {
+      const int pj = __builtin_amdgcn_readlane(pos, j);
+      if (pj >= 0) {
+        if (ok0) Rout[(long)pj * n + r0] = (float)(q0[j] * sc);
+        if (ok1) Rout[(long)pj * n + r1] = (float)(q1[j] * sc);
+      }
+    }
+  }
+}
+
 // (defined in trunc_mid.h) MFMA Gram of the live columns in registers + low-rank Cholesky, one kernel per walker
 template <typename T>
 inline void launch_colgram_chol(hipStream_t s, int nbatch, const T *P, long wP, int n, const int *kdyn, int kdyn_mul, int kmax,
@@ -746,9 +899,20 @@ inline void launch_gram_chol_lowrank(hipStream_t s, int nbatch, const T *P, long
       first_done = true;
     }
   }
-  if (short_first && !first_done)
-    hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP_S, 128, 3, 16>), dim3(nbatch), dim3(128), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
-                       R, wR, mlive, inner, inner_live, 0, std::max(max_pass, 2), 1);
+  if (short_first && !first_done) {
+    static const bool no_wave = getenv("PEPSGPU_NO_WAVE_FACTOR") != nullptr;
+    bool done = false;
+    if constexpr (sizeof(T) == 4) {
+      if (!no_wave) {   // one wave per walker, no LDS, no barrier (gram_chol_wave_kernel)
+        hipLaunchKernelGGL(gram_chol_wave_kernel, dim3((nbatch + 3) / 4), dim3(256), 0, s, (const float *)P, wP, n, kdyn, kdyn_mul, kmax,
+                           (float *)R, wR, mlive, inner, inner_live, std::max(max_pass, 2), nbatch);
+        done = true;
+      }
+    }
+    if (!done)
+      hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP_S, 128, 3, 16>), dim3(nbatch), dim3(128), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
+                         R, wR, mlive, inner, inner_live, 0, std::max(max_pass, 2), 1);
+  }
   const bool handed = short_first || first_done;
   if (narrow)
     hipLaunchKernelGGL((gram_chol_lowrank_kernel<T, KCAP, 128>), dim3(nbatch), dim3(128), 0, s, P, wP, n, kdyn, kdyn_mul, kmax,
