@@ -866,8 +866,13 @@ class Engine : public EngineBase {
   }
 
   void normalize(T *x, long n, long stride, int nb, double *logscale, const int *ndyn = nullptr, int ndyn_mul = 1) {
-    hipLaunchKernelGGL(normalize_kernel<T>, dim3(nb), dim3(256), 0, stream_, x, stride, (int)n, logscale, flag_, ndyn,
-                       ndyn_mul);
+    static const bool no_wave = getenv("PEPSGPU_NO_WAVE_NORM") != nullptr;
+    if (n <= 4096 && nb >= 64 && !no_wave)   // short tensors, many walkers: one wave per walker
+      hipLaunchKernelGGL(normalize_wave_kernel<T>, dim3((nb + 3) / 4), dim3(256), 0, stream_, x, stride, (int)n, logscale, flag_,
+                         ndyn, ndyn_mul, nb);
+    else
+      hipLaunchKernelGGL(normalize_kernel<T>, dim3(nb), dim3(256), 0, stream_, x, stride, (int)n, logscale, flag_, ndyn,
+                         ndyn_mul);
   }
 
   // acc[w] += a[w] + b[w] + c[w] + d[w]

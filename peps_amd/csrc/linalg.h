@@ -1219,6 +1219,31 @@ __global__ __launch_bounds__(256) void normalize_kernel(T *__restrict__ Xg, long
   if (tid == 0 && logscale) logscale[blockIdx.x] += log(nrm);
 }
 
+// The same with ONE WAVE per batch entry (four entries per block) for short tensors: no barrier, four times the entries in
+// flight -- a block of 256 threads per entry spends its time in the chain load -> reduce -> barrier -> scale for a few
+// hundred elements.
+template <typename T>
+__global__ __launch_bounds__(256) void normalize_wave_kernel(T *__restrict__ Xg, long wX, int n, double *__restrict__ logscale,
+                                                             int *__restrict__ flag, const int *__restrict__ ndyn, int ndyn_mul,
+                                                             int nbatch) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= nbatch) return;
+  T *X = Xg + (long)b * wX;
+  if (ndyn) n = min(n, ndyn[b] * ndyn_mul);
+  double a = 0.0;
+  for (int i = lane; i < n; i += 64) a += abs2_of(X[i]);
+  a = wave_sum(a);
+  const double nrm = sqrt(a);
+  if (!(nrm > 0.0) || !isfinite(nrm)) {
+    if (lane == 0 && flag) flag[b] = 1;
+    return;
+  }
+  const double inv = 1.0 / nrm;
+  for (int i = lane; i < n; i += 64) X[i] = scaled(X[i], inv);
+  if (lane == 0 && logscale) logscale[b] += log(nrm);
+}
+
 // out[b] = max_w v[b][w]  (v[b] == nullptr: -1); one block per entry of the pointer table
 __global__ __launch_bounds__(256) void max_over_walkers_kernel(const int *const *__restrict__ tab, int nw, int *__restrict__ out) {
   __shared__ int s_red[4];

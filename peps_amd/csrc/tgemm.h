@@ -641,6 +641,8 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
                         al4(d.sAk[0]) && al4(d.sAk[1]) && al4(d.wA) && al4(d.selA_mul) && (((uintptr_t)A) & 15) == 0;
       const bool bvec = !no_vec && d.sBk[2] == 1 && al4(d.K[2]) && al4(d.sBj[0]) && al4(d.sBj[1]) && al4(d.sBj[2]) &&
                         al4(d.sBk[0]) && al4(d.sBk[1]) && al4(d.wB) && al4(d.selB_mul) && (((uintptr_t)B) & 15) == 0;
+      // (the wave-per-tile body splits row / column indices through a float reciprocal and addresses in 32-bit bytes)
+      PG_REQUIRE(d.Itot() < (1 << 22) && d.Jtot() < (1 << 22), 1, "tensor GEMM: more than 2^22 rows / columns in one batch entry");
       const int tiles = ((d.Itot() + 31) / 32) * ((d.Jtot() + 31) / 32);
       // with per-walker live extents the tile count is a few: one block (four waves) walks them; extra blocks
       // would only pay the chain of dependent loads (extents, selector, offsets) and exit
@@ -675,6 +677,7 @@ inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemm
   if (!tgemm_use_mfma() || d1_in.dynK || d2_in.dynK || d1_in.nbatch != d2_in.nbatch || d1_in.nbatch <= 0) return 0;
   if (d1_in.bdivA != 1 || d1_in.bdivB != 1 || d2_in.bdivA != 1 || d2_in.bdivC != 1) return 0;
   TGemmDesc d1 = d1_in, d2 = d2_in;
+  if (d1.Itot() >= (1 << 22) || d1.Jtot() >= (1 << 22) || d2.Itot() >= (1 << 22) || d2.Jtot() >= (1 << 22)) return 0;
   d1.flopc = tg_flop_counter; d1.bytec = tg_byte_counter;
   d1.flop_stride = d1.nbatch >= 256 ? 64 : 1;
   static const bool no_vec = getenv("PEPSGPU_TGEMM_NOVEC") != nullptr;
