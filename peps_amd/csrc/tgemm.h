@@ -382,8 +382,10 @@ __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *
       const bool iv = i < Itot, jv = j < Jtot;
       const bool iz = i2 >= d.Imask[2] || i1 >= d.Imask[1] || i0 >= d.Imask[0];
       const bool jz = j2 >= d.Jmask[2] || j1 >= d.Jmask[1] || j0 >= d.Jmask[0];
-      oab = iv ? 4u * (unsigned)(i0 * d.sAi[0] + i1 * d.sAi[1] + i2 * d.sAi[2]) : 0u;
-      obb = jv ? 4u * (unsigned)(j0 * d.sBj[0] + j1 * d.sBj[1] + j2 * d.sBj[2]) : 0u;
+      // (a row / column beyond a masked live extent is stored as zero whatever was multiplied: it reads row / column 0 too,
+      // instead of dragging the dead part of the operand through the memory system)
+      oab = (iv && !iz) ? 4u * (unsigned)(i0 * d.sAi[0] + i1 * d.sAi[1] + i2 * d.sAi[2]) : 0u;
+      obb = (jv && !jz) ? 4u * (unsigned)(j0 * d.sBj[0] + j1 * d.sBj[1] + j2 * d.sBj[2]) : 0u;
       const int oci = i0 * d.sCi[0] + i1 * d.sCi[1] + i2 * d.sCi[2];
       if (half == 0) offCi_s[wave][l31] = iv ? (oci | (iz ? TG_ZERO_ROW : 0)) : -1;
       ocj = jv ? ((j0 * d.sCj[0] + j1 * d.sCj[1] + j2 * d.sCj[2]) | (jz ? TG_ZERO_ROW : 0)) : -1;
