@@ -343,6 +343,8 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
   out.logscale = (double *)arena_.alloc(sizeof(double) * nw_);
   PG_CHECK_HIP(hipMemcpyAsync(out.logscale, cur_log, sizeof(double) * nw_, hipMemcpyDeviceToDevice, stream_));
   DTen<T> Y = ones3();   // [l2, a2, k2]
+  float *yscale = nullptr;   // 1 / |Y| per walker when Y was left unnormalised by the launch that wrote it (y_scaled)
+  bool y_scaled = false;
   for (int i = N - 1; i >= 0; --i) {
     int r, c, dd[4], st[4];
     site_rc(i, r, c);
@@ -363,6 +365,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       gz.K[2] = a2; gz.sAk[2] = 1; gz.sBk[2] = k2;
       gz.J[1] = l2; gz.J[2] = k2; gz.sBj[1] = a2 * k2; gz.sBj[2] = 1; gz.sCj[1] = k2; gz.sCj[2] = 1;
       gz.wA = A.n; gz.wB = Y.n; gz.wC = Z1.n; gz.nbatch = nw_;
+      if constexpr (sizeof(T) == 4) { if (y_scaled) gz.scale_in = yscale; }
       gz.dI[1].p = clive[i];                  // live bonds: a (rows of A), a2 (contracted), k2 (new bond to the right)
       gz.dK[2].p = clive[i + 1];
       gz.dJ[2].p = kn[i + 1];
@@ -615,16 +618,31 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       int rp, cp, ddp[4];
       site_rc(i - 1, rp, cp);
       site_dims(rp, cp, ddp);
+      // The norm of Yn comes out of the launch that writes it (squares of the stored values, summed in registers) as a
+      // per-walker scale that the contraction reading Yn at the next site applies to its own result: no pass over Yn.
+      bool fused_norm = false;
+      if constexpr (sizeof(T) == 4) {
+        static const bool no_fn = getenv("PEPSGPU_NO_FUSED_NORM") != nullptr;
+        if (!no_fn && bond_adapt && kn[i] && tgemm_one_block_direct(g)) {
+          if (!yscale) yscale = (float *)arena_.alloc(sizeof(float) * nw_);
+          g.scale_out = yscale; g.norm_log = out.logscale; g.norm_flag = flag_;
+          fused_norm = true;
+        }
+      }
       prof_begin(PROF_CONTRACT, 2.0 * nw_ * (double)R[i - 1].d[0] * ddp[lu] * (double)m * k, 2.0 * nw_ * (double)la * uk * (double)k);
       tgemm_launch<T, T, T, T>(stream_, g, Tt.p, V.p, Yn.p);
       prof_end();
+      y_scaled = fused_norm;
     }
-    prof_begin(PROF_NORM, 0.0, 0.0);
-    normalize(Yn.p, Yn.n, Yn.n, nw_, out.logscale);
-    prof_end();
+    if (!y_scaled) {
+      prof_begin(PROF_NORM, 0.0, 0.0);
+      normalize(Yn.p, Yn.n, Yn.n, nw_, out.logscale);
+      prof_end();
+    }
     free_ten(Tt);
     Y = Yn;
   }
+  if (yscale) arena_.free(yscale);
   out.live = kn;
   out.kmax.assign(N + 1, -1);
   out.mlmax.assign(N, -1);

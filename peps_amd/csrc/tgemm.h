@@ -56,6 +56,15 @@ struct TGemmDesc {
   unsigned long long *bytec = nullptr;   // profiling: += bytes of the live operand and result elements (compulsory traffic)
   int flop_stride = 1;                    // ... sampled: every flop_stride-th batch entry adds flop_stride times its count
   double alpha = 1.0;
+  // Normalisation of a result WITHOUT a pass over it (wave-per-tile kernels, one block per batch entry): the launch that
+  // writes C[b] sums the squares of what it stores (registers) and leaves scale_out[b] = 1 / |C[b]|, norm_log[b] += log |C[b]|
+  // (a zero / non-finite norm: scale 1, norm_flag[b] = 1); the launch that reads C[b] next multiplies its own result by
+  // scale_in[b].  Replaces normalize_kernel on the carried tensor of the truncation pass (one launch and a read + write of
+  // the tensor per site).
+  float *scale_out = nullptr;
+  double *norm_log = nullptr;
+  int *norm_flag = nullptr;
+  const float *scale_in = nullptr;
 
   __host__ __device__ int Itot() const { return I[0] * I[1] * I[2]; }
   __host__ __device__ int Jtot() const { return J[0] * J[1] * J[2]; }
@@ -350,7 +359,10 @@ constexpr int TG_ZERO_ROW = 0x40000000;   // flag in the C-row offset table: the
 template <bool AVEC, bool BVEC>
 __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *__restrict__ A, const float *__restrict__ B,
                                                float *__restrict__ C, const int Itot, const int Jtot, const int K2s,
-                                               int (*offCi_s)[32], const int tile0, const int tile_step) {
+                                               int (*offCi_s)[32], const int tile0, const int tile_step,
+                                               const float scale = 1.f, float *__restrict__ sumsq = nullptr) {
+  // scale: multiplies alpha (per-entry scale of an operand that was left unnormalised); sumsq (optional): += squares of the
+  // values this lane stores.
   // Instruction budget (SQ counters, round 2: 36 VALU instructions per MFMA in the chained kernel, the launches were
   // bound by VALU issue, not by memory): no integer division per lane (float-reciprocal split of the tile's row / column
   // index), K walked with uniform counters, loads unconditional at clamped addresses (rows and columns that do not exist
@@ -358,7 +370,8 @@ __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *
   // the loads of round r+1 issued before and consumed after the MFMAs of round r.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ntj = (Jtot + 31) >> 5, ntiles = ((Itot + 31) >> 5) * ntj;
-  const float alpha = (float)d.alpha;
+  const float alpha = (float)d.alpha * scale;
+  float ss = 0.f;
   const int half = lane >> 5, l31 = lane & 31;
   const int K2 = d.K[2], K1 = d.K[1];
   const int nr8 = (K2 + 7) >> 3, nrounds = d.K[0] * K1 * nr8;
@@ -480,10 +493,12 @@ __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *
           float v = ((oi & TG_ZERO_ROW) || jzero) ? 0.f : acc[4 * g + e] * alpha;
           if (accumulate) v += *p;
           *p = v;
+          ss = fmaf(v, v, ss);
         }
       }
     }
   }
+  if (sumsq) *sumsq += ss;
 }
 
 template <bool AVEC, bool BVEC>
@@ -497,7 +512,10 @@ __global__ __launch_bounds__(256, 6) void tgemm_direct_kernel(TGemmDesc d, const
   int Itot = d.Itot();
   const int Jtot = d.Jtot();
   if (d.dynI) Itot = min(Itot, d.dynI[b] * d.dynI_mul);
-  if (Itot <= 0 || Jtot <= 0) return;
+  if (Itot <= 0 || Jtot <= 0) {
+    if (d.scale_out && threadIdx.x == 0) { d.scale_out[b] = 1.f; if (d.norm_flag) d.norm_flag[b] = 1; }   // nothing stored: zero norm
+    return;
+  }
   if (d.flopc && threadIdx.x == 0 && blockIdx.x == 0 && b % d.flop_stride == 0)
   {
     atomicAdd(d.flopc, 2ull * d.flop_stride * Itot * Jtot * d.Ktot());
@@ -506,8 +524,27 @@ __global__ __launch_bounds__(256, 6) void tgemm_direct_kernel(TGemmDesc d, const
   long baseA = (long)(b / d.bdivA) * d.wA, baseB = (long)(b / d.bdivB) * d.wB;
   if (d.selA) baseA += (long)d.selA[(long)(b / d.seldivA) * d.selA_inc] * d.selA_mul;
   if (d.selB) baseB += (long)d.selB[(long)(b / d.seldivB) * d.selB_inc] * d.selB_mul;
+  float ss = 0.f;
   tg_direct_body<AVEC, BVEC>(d, Ag + baseA, Bg + baseB, Cg + (long)(b / d.bdivC) * d.wC, Itot, Jtot, K2s, offCi_s,
-                             blockIdx.x * 4, gridDim.x * 4);
+                             blockIdx.x * 4, gridDim.x * 4, d.scale_in ? d.scale_in[b] : 1.f, d.scale_out ? &ss : nullptr);
+  if (d.scale_out) {     // (gridDim.x == 1: this block stored all of C[b])
+    __shared__ double s_nred[4];
+    double a = (double)ss;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if ((threadIdx.x & 63) == 0) s_nred[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double nrm = sqrt(s_nred[0] + s_nred[1] + s_nred[2] + s_nred[3]);
+      if (!(nrm > 0.0) || !isfinite(nrm)) {
+        d.scale_out[b] = 1.f;
+        if (d.norm_flag) d.norm_flag[b] = 1;
+      } else {
+        d.scale_out[b] = (float)(1.0 / nrm);
+        if (d.norm_log) d.norm_log[b] += log(nrm);
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -585,8 +622,9 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TG
   if (d1.selB) baseB1 += (long)d1.selB[(long)(b / d1.seldivB) * d1.selB_inc] * d1.selB_mul;
   if (d2.selA) baseA2 += (long)d2.selA[(long)(b / d2.seldivA) * d2.selA_inc] * d2.selA_mul;
   d1.accumulate = 0;
+  const float in_scale = d1.scale_in ? d1.scale_in[b] : 1.f;   // an operand of stage 1 was left unnormalised by its producer
   if (chunk >= d1.I[1]) {
-    tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1, B1g + baseB1, s_mid, I1, J1, K2s1, offCi_s, 0, 4);
+    tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1, B1g + baseB1, s_mid, I1, J1, K2s1, offCi_s, 0, 4, in_scale);
     __syncthreads();
     tg_direct_body<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC, I2, J2, K2s2, offCi_s, 0, 4);
     return;
@@ -600,7 +638,7 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TG
     for (int s = 0; s < 3; ++s)      // (no dynamic indexing: the descriptors stay in registers)
       if (s == jsub) d2.J[s] = cn;
     if (c0) __syncthreads();     // stage 2 of the chunk before has read the buffer
-    tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1 + (long)c0 * sA1, B1g + baseB1, s_mid, d1.Itot(), J1, K2s1, offCi_s, 0, 4);
+    tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1 + (long)c0 * sA1, B1g + baseB1, s_mid, d1.Itot(), J1, K2s1, offCi_s, 0, 4, in_scale);
     __syncthreads();
     tg_direct_body<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC + (long)c0 * sC2, I2, d2.Jtot(), K2s2, offCi_s, 0, 4);
   }
@@ -619,6 +657,17 @@ bool tgemm_use_mfma();
 inline thread_local unsigned long long *tg_flop_counter = nullptr;
 inline thread_local unsigned long long *tg_byte_counter = nullptr;
 
+// whether tgemm_launch<float ...> takes the wave-per-tile kernel with ONE block per batch entry for this descriptor: the
+// condition under which scale_in / scale_out may be set
+inline bool tgemm_one_block_direct(const TGemmDesc &d) {
+  static const int direct_mode = getenv("PEPSGPU_TGEMM_DIRECT") ? atoi(getenv("PEPSGPU_TGEMM_DIRECT")) : 1;
+  static const int gx_dyn = getenv("PEPSGPU_TGD_GX") ? atoi(getenv("PEPSGPU_TGD_GX")) : 1;
+  bool any_dyn = d.dynI != nullptr;
+  for (int q = 0; q < 3; ++q) any_dyn = any_dyn || d.dI[q].p || d.dJ[q].p || d.dK[q].p;
+  return tgemm_use_mfma() && !d.dynK && direct_mode == 1 && any_dyn && gx_dyn == 1 && d.bdivC == 1 && !d.accumulate &&
+         !d.batch_flag && d.nbatch > 0 && d.Itot() > 0 && d.Jtot() > 0;
+}
+
 template <typename TA, typename TB, typename TC, typename TAcc>
 void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B, TC *C) {
   if (d_in.nbatch <= 0 || d_in.Itot() <= 0 || d_in.Jtot() <= 0) return;
@@ -627,6 +676,7 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
   d.flopc = tg_flop_counter;
   d.bytec = tg_byte_counter;
   d.flop_stride = d.nbatch >= 256 ? 64 : 1;   // one atomic per 64 walkers: a same-address atomic per block costs ~10 %
+  bool fused_norm_ok = false;
   int gx = (d.Itot() + TG_BM - 1) / TG_BM;
   const bool dyn_i = d.dynI || (d.dI[0].p && !d.dI[0].mask) || (d.dI[1].p && !d.dI[1].mask) || (d.dI[2].p && !d.dI[2].mask);
   if (dyn_i && gx > TG_DYN_GRIDX) gx = TG_DYN_GRIDX;
@@ -645,12 +695,15 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
                         al4(d.sBk[0]) && al4(d.sBk[1]) && al4(d.wB) && al4(d.selB_mul) && (((uintptr_t)B) & 15) == 0;
       // (the wave-per-tile body splits row / column indices through a float reciprocal and addresses in 32-bit bytes)
       PG_REQUIRE(d.Itot() < (1 << 22) && d.Jtot() < (1 << 22), 1, "tensor GEMM: more than 2^22 rows / columns in one batch entry");
+      fused_norm_ok = true;
       const int tiles = ((d.Itot() + 31) / 32) * ((d.Jtot() + 31) / 32);
       // with per-walker live extents the tile count is a few: one block (four waves) walks them; extra blocks
       // would only pay the chain of dependent loads (extents, selector, offsets) and exit
       static const int gx_dyn = getenv("PEPSGPU_TGD_GX") ? atoi(getenv("PEPSGPU_TGD_GX")) : 1;
       const dim3 gd(any_dyn ? std::min(gx_dyn, std::max(1, tiles / 4)) : (tiles >= 64 ? 4 : tiles >= 16 ? 2 : 1), 1,
                     d.nbatch);
+      PG_REQUIRE(!d.scale_out || (gd.x == 1 && d.bdivC == 1 && !d.accumulate && !d.batch_flag), 5,
+                 "tensor GEMM: the norm of the result needs one block per batch entry");
       const float *Af = (const float *)A, *Bf = (const float *)B;
       float *Cf = (float *)C;
       if (avec && bvec) hipLaunchKernelGGL((tgemm_direct_kernel<true, true>), gd, dim3(256), 0, s, d, Af, Bf, Cf);
@@ -661,6 +714,8 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
       return;
     }
   }
+  (void)fused_norm_ok;
+  PG_REQUIRE(!d.scale_out && !d.scale_in, 5, "tensor GEMM: scale_in / scale_out need the wave-per-tile kernel");
   if constexpr (is_cplx<TAcc>::value) {
     // complex element type (parity-grade path): the same tiling on the vector ALUs; there is no complex MFMA, and the
     // 4-real-product form would need the operands de-interleaved
