@@ -359,6 +359,11 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     // Tt[l,a,u,k2] = sum_{p,l2} Z1[a,p,l2,k2] W[l,p,l2,u]
     DTen<T> Z1 = alloc_ten(a, p, l2, k2);
     DTen<T> Tt = alloc_ten(l, a, u, k2);
+    // Layout of Tt (internal to this site step: written once, read by M = R Tt and by Y = Tt V^T): with the partially live
+    // bond k2 innermost the live part of a (l, a) slice is u runs of k2_live floats (40 bytes in 64-byte requests); with the
+    // full leg u innermost it is ONE run of k2_live * u floats.  Not at i == 0, where Tt becomes the first tensor (u, k2).
+    static const bool tt_swap = getenv("PEPSGPU_NO_TT_SWAP") == nullptr;
+    const bool tsw = tt_swap && i > 0 && sizeof(T) == 4;
     {
       TGemmDesc gz, gt;
       gz.I[1] = a; gz.I[2] = p; gz.sAi[1] = p * a2; gz.sAi[2] = a2; gz.sCi[1] = p * l2 * k2; gz.sCi[2] = l2 * k2;
@@ -373,6 +378,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       gt.I[1] = l; gt.I[2] = u; gt.sAi[1] = st[ll]; gt.sAi[2] = st[lu]; gt.sCi[1] = a * u * k2; gt.sCi[2] = k2;
       gt.K[1] = p; gt.K[2] = l2; gt.sAk[1] = st[lp]; gt.sAk[2] = st[lr]; gt.sBk[1] = l2 * k2; gt.sBk[2] = k2;
       gt.J[1] = a; gt.J[2] = k2; gt.sBj[1] = p * l2 * k2; gt.sBj[2] = 1; gt.sCj[1] = u * k2; gt.sCj[2] = 1;
+      if (tsw) { gt.sCi[2] = 1; gt.sCj[2] = u; }    // Tt[l, a, k2, u]: the fully live leg u innermost (see tsw above)
       gt.wB = Z1.n; gt.wC = Tt.n; gt.nbatch = nw_;
       gt.dJ[1].p = clive[i];
       gt.dJ[2].p = kn[i + 1]; gt.dJ[2].mask = (i == 0);   // i == 0: Tt becomes the (persistent, zero padded) first tensor
@@ -428,6 +434,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       g.I[2] = m; g.sAi[2] = la; g.sCi[2] = uk;
       g.K[1] = l; g.K[2] = a; g.sAk[1] = a; g.sAk[2] = 1; g.sBk[1] = a * uk; g.sBk[2] = uk;
       g.J[1] = u; g.J[2] = k2; g.sBj[1] = k2; g.sBj[2] = 1; g.sCj[1] = k2; g.sCj[2] = 1;
+      if (tsw) { g.sBj[1] = 1; g.sBj[2] = u; }
       g.wA = R[i].n; g.wB = Tt.n; g.wC = M.n; g.nbatch = nw_;
       g.dynI = mdyn[i]; g.dynI_mul = mmul[i];
       g.dK[2].p = clive[i];
@@ -613,6 +620,10 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       g.wA = Tt.n; g.wB = V.n; g.wC = Yn.n; g.nbatch = nw_;
       g.dI[2].p = clive[i]; g.dI[2].mask = 1;    // Yn is normalised as a whole: written in full, zeros beyond the live bonds
       g.dK[2].p = kn[i + 1];
+      if (tsw) {   // K = (k2, u): u contiguous in Tt (vector loads), k2 contiguous in V
+        g.K[1] = k2; g.K[2] = u; g.sAk[1] = u; g.sAk[2] = 1; g.sBk[1] = 1; g.sBk[2] = k2;
+        g.dK[2].p = nullptr; g.dK[1].p = kn[i + 1];
+      }
       g.dJ[2].p = kn[i]; g.dJ[2].mask = 1;
       // reference op: res[i-1] . (u s)  (bmps_impl.h:254): 2 (m_{i-1} D_u) m_i k_i
       int rp, cp, ddp[4];
