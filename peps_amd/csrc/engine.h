@@ -1037,7 +1037,10 @@ class Engine : public EngineBase {
                      const DTen<T> &mps2, int ncand, int bt_ncand, bool normalise);
   void finish_dot4(const DTen<T> &a, const DTen<T> &b, int nc, double *lsum, double *out);
   int *upload_cand(int ncand, int ncols, const int32_t *cand);
-  void launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t need, const int *mdyn, int mdyn_mul, int mid_hi = 0);
+  // sel (optional, f32): the kernel of the walkers with at most JR_BR live rows selects / normalises their rows into Vt
+  // itself; returns true when it did (select_rows_kernel then skips those walkers)
+  bool launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t need, const int *mdyn, int mdyn_mul, int mid_hi = 0,
+                     const JrSelect *sel = nullptr);
   static bool jacobi_small_ok(int len, int m, const int *mdyn);
 
   int Ly_, Lx_, D_, dp_, chi_min_, chi_;

@@ -32,8 +32,10 @@ bool Engine<T>::jacobi_small_ok(int len, int m, const int *mdyn) {
 }
 
 template <typename T>
-void Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t need, const int *mdyn, int mdyn_mul, int mid_hi) {
+bool Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t need, const int *mdyn, int mdyn_mul, int mid_hi,
+                              const JrSelect *sel) {
   int small = 0;
+  bool sel_used = false;
   if constexpr (sizeof(T) == 4) {
     static const bool no_reg = getenv("PEPSGPU_NO_REGJACOBI") != nullptr;
     // walkers whose block has at most 32 existing rows: one wave each (jacobi_rows_small_kernel);
@@ -45,11 +47,17 @@ void Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
         static const bool no_tiny2 = getenv("PEPSGPU_NO_TINY2JACOBI") != nullptr;
         static const int tiny4 = getenv("PEPSGPU_TINY4") ? atoi(getenv("PEPSGPU_TINY4")) : 1;
         if (len <= 64 && !no_tiny2 && tiny4)          // short rows (shrunk bonds): four walkers per wave, 16 lanes x 4 columns
+        {
           hipLaunchKernelGGL((jacobi_rows_tiny4_kernel<4>), dim3((nw_ + 15) / 16), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
-                             sweeps_, mdyn, mdyn_mul, nw_);
+                             sweeps_, mdyn, mdyn_mul, nw_, sel ? *sel : JrSelect());
+          sel_used = sel != nullptr;
+        }
         else if (len <= 128 && !no_tiny2 && tiny4 == 1)   // ... 16 lanes x 8 columns
+        {
           hipLaunchKernelGGL((jacobi_rows_tiny4_kernel<8>), dim3((nw_ + 15) / 16), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
-                             sweeps_, mdyn, mdyn_mul, nw_);
+                             sweeps_, mdyn, mdyn_mul, nw_, sel ? *sel : JrSelect());
+          sel_used = sel != nullptr;
+        }
         else if (len <= 128 && !no_tiny2)             // two walkers per wave (32 lanes x 4 columns)
           hipLaunchKernelGGL(jacobi_rows_tiny2_kernel, dim3((nw_ + 7) / 8), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
                              sweeps_, mdyn, mdyn_mul, nw_);
@@ -57,29 +65,30 @@ void Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
           hipLaunchKernelGGL(jacobi_rows_tiny_kernel, dim3((nw_ + 3) / 4), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
                              sweeps_, mdyn, mdyn_mul, nw_);
         PG_CHECK_HIP(hipGetLastError());
-        if (m <= JR_BR) return;
+        if (m <= JR_BR) return sel_used;
       }
       hipLaunchKernelGGL(jacobi_rows_small_kernel, dim3((nw_ + 3) / 4), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
                          sweeps_, mdyn, mdyn_mul, nw_, no_tiny ? 0 : 1);
       PG_CHECK_HIP(hipGetLastError());
-      if (m <= JR_SMALL_ROWS) return;
+      if (m <= JR_SMALL_ROWS) return sel_used;
     }
-    if (mid_hi && m <= mid_hi) return;                 // every remaining walker is on the mid route
+    if (mid_hi && m <= mid_hi) return sel_used;        // every remaining walker is on the mid route
     const int skip = mid_hi ? mid_hi : small;          // rows <= max(skip, 32) are taken elsewhere
     if (!use_lds && m <= 256 && len <= 256 && !no_reg) {
       hipLaunchKernelGGL(jacobi_rows_reg256_kernel, dim3(nw_), dim3(512), 0, stream_, (float *)M, wM, m, len, len, 40,
                          sweeps_, mdyn, mdyn_mul, skip);
       PG_CHECK_HIP(hipGetLastError());
-      return;
+      return sel_used;
     }
     hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), use_lds ? need : 0, stream_, M, wM, m, len, len, 40,
                        use_lds, sweeps_, mdyn, mdyn_mul, skip);
     PG_CHECK_HIP(hipGetLastError());
-    return;
+    return sel_used;
   }
   hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), use_lds ? need : 0, stream_, M, wM, m, len, len, 40,
                      use_lds, sweeps_, mdyn, mdyn_mul, small);
   PG_CHECK_HIP(hipGetLastError());
+  return sel_used;
 }
 
 // BMPS::MultiplyMPO with SVD compression (bmps_impl.h:404-437, :756-862, :225-263), Q-less form.
@@ -500,6 +509,19 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       }
       prof_end();
     }
+    // static size of the new bond and the tensor it leads to (before the Jacobi: the kernel of the walkers with few live rows
+    // selects and normalises their rows into V itself)
+    const int k_full = std::min(chi_, std::min(m, uk));
+    int k = k_full;
+    if (!full_bonds && bond_adapt && cur_kmax[i] >= 0) {
+      const int want = cur_kmax[i] + std::max(2, cur_kmax[i] / 4);
+      k = std::min(k_full, (want + 3) & ~3);
+    }
+    kstat[i] = k; kfull[i] = k_full;
+    PG_REQUIRE(m <= 1024, 1, "bond dimension too large for select_rows_kernel");
+    DTen<T> V = alloc_ten(k, u, k2);
+    if (bond_adapt) kn[i] = (int *)arena_.alloc(sizeof(int) * nw_);
+    bool sel_done = false;
     {
       const size_t need = sizeof(T) * (size_t)m * (uk | 1);
       const int use_lds = need <= JACOBI_LDS_MAX;
@@ -510,7 +532,12 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         const bool bulk = sizeof(T) == 4 && ((!use_lds && m <= 256 && uk <= 256) || mid);
         prof_begin(bulk ? PROF_JACOBI : PROF_JACOBI_EDGE, nw_ * (4.0 * rr * cc * cc + 22.0 * cc * cc * cc), 0.0);
       }
-      launch_jacobi(M.p, M.n, m, uk, use_lds, need, mdyn[i], mmul[i], mid ? MID_HI : 0);
+      JrSelect jsel;
+      static const bool no_jsel = getenv("PEPSGPU_NO_JACOBI_SELECT") != nullptr;
+      if constexpr (sizeof(T) == 4) {
+        if (!no_jsel && kn[i]) { jsel.V = (float *)V.p; jsel.wV = V.n; jsel.k = k; jsel.klive_out = kn[i]; jsel.trunc_err = trunc_err_; jsel.dmin = chi_min_; }
+      }
+      sel_done = launch_jacobi(M.p, M.n, m, uk, use_lds, need, mdyn[i], mmul[i], mid ? MID_HI : 0, jsel.V ? &jsel : nullptr);
       if constexpr (sizeof(T) == 4) {
         if (mid) {
           // <= 64 live rows: two waves per walker, else four; rows of 16 lanes, four pairs per wave instruction
@@ -547,20 +574,10 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
                   (double)sw_sum / nw_, (double)live / nw_, live_mx);
       }
     }
-    const int k_full = std::min(chi_, std::min(m, uk));
-    int k = k_full;
-    if (!full_bonds && bond_adapt && cur_kmax[i] >= 0) {
-      const int want = cur_kmax[i] + std::max(2, cur_kmax[i] / 4);
-      k = std::min(k_full, (want + 3) & ~3);
-    }
-    kstat[i] = k; kfull[i] = k_full;
-    PG_REQUIRE(m <= 1024, 1, "bond dimension too large for select_rows_kernel");
-    DTen<T> V = alloc_ten(k, u, k2);
     prof_begin(PROF_SELECT, 0.0, 0.0);
-    if (bond_adapt) kn[i] = (int *)arena_.alloc(sizeof(int) * nw_);
     hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)M.p, M.n, m, uk, uk, k, V.p,
                        V.n, (T *)nullptr, 0L, (const int *)mdyn[i], mmul[i], kn[i], trunc_err_, chi_min_, (double *)nullptr,
-                       (const int *)midflag, 0);
+                       (const int *)midflag, 0, sel_done ? JR_BR : 0);
     PG_CHECK_HIP(hipGetLastError());
     if (mid) {
       // sigma_k u_k^T = the rotated rows of B: the chi largest, normalised -> U^T (k x GS), kB = how many are live

@@ -1064,7 +1064,8 @@ __device__ __forceinline__ int jr_intra16(JrRowT<CPL> (&a)[JR_BR], float (&na)[J
 template <int CPL>
 __global__ __launch_bounds__(256, CPL <= 4 ? 3 : 2) void jacobi_rows_tiny4_kernel(float *__restrict__ Mg, long wM, int m, int len, int ld,
                                                                                int max_sweeps, int *__restrict__ sweeps_out,
-                                                                               const int *__restrict__ mdyn, int mdyn_mul, int nwalkers) {
+                                                                               const int *__restrict__ mdyn, int mdyn_mul, int nwalkers,
+                                                                               JrSelect sel = JrSelect()) {
   const int lane = threadIdx.x & 63, l16 = lane & 15;
   const int walker = blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + (lane >> 4);
   const bool have = walker < nwalkers;
@@ -1108,15 +1109,70 @@ __global__ __launch_bounds__(256, CPL <= 4 ? 3 : 2) void jacobi_rows_tiny4_kerne
     else rot = jr_intra16<JR_BR, CPL>(a, na, tol2, floor2);
     if (!__any(rot != 0)) { ++sweep; break; }
   }
+  if (l16 == 0 && mm > 0 && sweeps_out) sweeps_out[walker] = sweep | (mm << 8);
+  if (!sel.V) {
+#pragma unroll
+    for (int i = 0; i < JR_BR; ++i) {
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        const int c = CPL * l16 + q;
+        if (i < mm && c < len) M[(long)i * ld + c] = a[i].v[q];
+      }
+    }
+    return;
+  }
+  // ---- select: the rows are mutually orthogonal, sigma_i = |row_i| (select_rows_kernel, same rules) ----
+  if (mm == 0) return;                                     // (not this kernel's walker: select_rows_kernel takes it)
+  float *V = sel.V + (long)walker * sel.wV;
+  float n2[JR_BR];
+  float fro2 = 0.f;
 #pragma unroll
   for (int i = 0; i < JR_BR; ++i) {
+    n2[i] = i < mm ? jg_sum16(jrx_dot<CPL>(a[i], a[i])) : -1.f;   // rows that do not exist rank after every real row
+    fro2 += i < mm ? n2[i] : 0.f;
+  }
+  const float nfloor2 = (float)(4.0 * NOISE_C * NOISE_C * (double)Eps<float>::v * (double)Eps<float>::v) * fro2;   // (2 NOISE_C eps |M|_F)^2
+  int rank[JR_BR];
 #pragma unroll
-    for (int q = 0; q < CPL; ++q) {
-      const int c = CPL * l16 + q;
-      if (i < mm && c < len) M[(long)i * ld + c] = a[i].v[q];
+  for (int i = 0; i < JR_BR; ++i) {
+    int rk = 0;
+#pragma unroll
+    for (int j = 0; j < JR_BR; ++j) rk += (n2[j] > n2[i]) || (n2[j] == n2[i] && j < i);
+    rank[i] = rk;
+  }
+  int kcut = sel.k;
+  if (sel.trunc_err > 0.0) {
+    int kept = mm;
+    double err = 0.0;
+    while (kept > 0) {
+      if (kept <= sel.dmin && kept <= sel.k) break;
+      float sk2 = 0.f;                                       // squared singular value of rank kept - 1
+#pragma unroll
+      for (int i = 0; i < JR_BR; ++i) sk2 = rank[i] == kept - 1 ? n2[i] : sk2;
+      const double wgt = fro2 > 0.f ? (double)sk2 / (double)fro2 : 0.0;
+      if (kept > sel.k || (kept > sel.dmin && err + wgt < sel.trunc_err)) { err += wgt; --kept; }
+      else break;
+    }
+    kcut = max(kept, 1);
+  }
+  int klive = 0;
+#pragma unroll
+  for (int i = 0; i < JR_BR; ++i) {
+    if (i < mm && rank[i] < kcut) {
+      const bool live = n2[i] > nfloor2;
+      const float inv = live ? __builtin_amdgcn_rsqf(n2[i]) : 0.f;   // numerically zero direction -> zero row of Vt
+      klive += live ? 1 : 0;
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        const int c = CPL * l16 + q;
+        if (c < len) V[(long)rank[i] * len + c] = a[i].v[q] * inv;
+      }
     }
   }
-  if (l16 == 0 && mm > 0 && sweeps_out) sweeps_out[walker] = sweep | (mm << 8);
+  // rows of Vt from the kept count to k are zero
+  const int nkeep = min(kcut, mm);
+  for (int e = nkeep * len + l16; e < sel.k * len; e += 16) V[e] = 0.f;
+  if (l16 == 0 && sel.klive_out) sel.klive_out[walker] = klive;
 }
 
 }  // namespace pepsgpu

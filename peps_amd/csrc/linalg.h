@@ -1087,6 +1087,19 @@ __global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, l
   if (tid == 0 && sweeps_out) sweeps_out[blockIdx.x] = sweep;
 }
 
+// Optional epilogue of the four-walkers-per-wave kernel: what select_rows_kernel does with the rotated rows (rank by norm,
+// truncation rule, normalise into Vt, live count), straight from the registers -- the rows are then NOT written back to M,
+// and select_rows_kernel skips the walkers taken here (1 <= live rows <= JR_BR).
+struct JrSelect {
+  float *V = nullptr;      // [walker][k][len], nullptr: write the rows back to M as before
+  long wV = 0;
+  int k = 0;
+  int *klive_out = nullptr;
+  double trunc_err = 0.0;
+  int dmin = 0;
+};
+
+
 // ---------------------------------------------------------------------------------------------
 // Rows of M are mutually orthogonal: sigma_i = |row_i|.  Keep the k largest (ties by index),
 // write Vt[rank][:] = row/sigma (zero row if sigma == 0) and S[rank] = sigma.
@@ -1099,9 +1112,15 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const T *__restrict__ 
                                                           int *__restrict__ klive_out = nullptr,
                                                           double trunc_err = 0.0, int dmin = 0,
                                                           double *__restrict__ err_out = nullptr,
-                                                          const int *__restrict__ run_flag = nullptr, int run_if_neg = 1) {
+                                                          const int *__restrict__ run_flag = nullptr, int run_if_neg = 1,
+                                                          int skip_rows_le = 0) {
   // run_flag: with run_if_neg = 1 only the entries with run_flag[b] < 0 run, with 0 only those with run_flag[b] >= 0
   if (run_flag && ((run_flag[blockIdx.x] < 0) != (run_if_neg != 0))) return;
+  // skip_rows_le: entries with 1 .. skip_rows_le live rows were selected by the Jacobi kernel itself (JrSelect, jacobi_reg.h)
+  if (skip_rows_le > 0) {
+    const int ml = mdyn ? min(m, mdyn[blockIdx.x] * mdyn_mul) : m;
+    if (ml >= 1 && ml <= skip_rows_le) return;
+  }
   __shared__ double s_norm[1024];
   __shared__ int s_rank[1024];
   __shared__ int s_klive, s_kcut;
