@@ -343,6 +343,13 @@ class Engine : public EngineBase {
     return (pos == UP || pos == RIGHT) ? b.t[n - 1 - col] : b.t[col];
   }
 
+  // live extents (device arrays, nullptr = static) of the first and the third leg of at_logical(b, pos, col)
+  static void live_at_logical(const BMPSDev &b, int pos, int col, const int *&first, const int *&third) {
+    const int n = (int)b.t.size(), j = (pos == UP || pos == RIGHT) ? n - 1 - col : col;
+    first = (int)b.live.size() > j ? b.live[j] : nullptr;
+    third = (int)b.live.size() > j + 1 ? b.live[j + 1] : nullptr;
+  }
+
   void grow_full_bten(int pos, int slice, int remain, int init) override {   // grow.h:243-373
     require_ready();
     if (init) init_bten(pos, slice);
@@ -360,7 +367,10 @@ class Engine : public EngineBase {
         default: r = slice; c = n - i - 1; break;
       }
       SiteSel sel = cfg_site(r, c);
-      BTenDev nb = bten_step(pos, bten_[pos].back(), b1.t[n - i - 1], sel, b2.t[i], 1, true);
+      const int j1 = n - i - 1, j2 = i;
+      auto lv = [](const BMPSDev &b, int j) -> const int * { return (int)b.live.size() > j ? b.live[j] : nullptr; };
+      BTenDev nb = bten_step(pos, bten_[pos].back(), b1.t[j1], sel, b2.t[j2], 1, true, 1, lv(b1, j1), lv(b1, j1 + 1), lv(b2, j2),
+                             lv(b2, j2 + 1));
       bten_[pos].push_back(nb);
     }
   }
@@ -379,7 +389,10 @@ class Engine : public EngineBase {
     }
     PG_REQUIRE(bs <= n && !bmps_[pre].empty() && !bmps_[nxt].empty(), 3, "GrowBTenStep: environment missing");
     SiteSel sel = cfg_site(r, c);
-    BTenDev nb = bten_step(pos, bten_[pos].back(), bmps_[pre].back().t[n - bs], sel, bmps_[nxt].back().t[bs - 1], 1, true);
+    const BMPSDev &b1 = bmps_[pre].back(), &b2 = bmps_[nxt].back();
+    auto lv = [](const BMPSDev &b, int j) -> const int * { return (int)b.live.size() > j ? b.live[j] : nullptr; };
+    BTenDev nb = bten_step(pos, bten_[pos].back(), b1.t[n - bs], sel, b2.t[bs - 1], 1, true, 1, lv(b1, n - bs), lv(b1, n - bs + 1),
+                           lv(b2, bs - 1), lv(b2, bs));
     bten_[pos].push_back(nb);
   }
   void shift_bten_window(int pos) override {   // grow.h:517-521
@@ -415,14 +428,20 @@ class Engine : public EngineBase {
     if (dir == HORIZONTAL) {
       const BMPSDev &up = bmps_at_slice(UP, row), &dn = bmps_at_slice(DOWN, row);
       PG_REQUIRE(bten_size(LEFT) > col, 3, "ReplaceNNSiteTrace: LEFT BTen missing");
-      t2 = bten_step(LEFT, bten_[LEFT][col], at_logical(up, UP, col), sa, at_logical(dn, DOWN, col), nc, false);
-      t5 = bten_step(RIGHT, bten_at_slice(RIGHT, cb), at_logical(dn, DOWN, cb), sb, at_logical(up, UP, cb), nc, false);
+      const int *a1, *a3, *b1, *b3;
+      live_at_logical(up, UP, col, a1, a3); live_at_logical(dn, DOWN, col, b1, b3);
+      t2 = bten_step(LEFT, bten_[LEFT][col], at_logical(up, UP, col), sa, at_logical(dn, DOWN, col), nc, false, 1, a1, a3, b1, b3);
+      live_at_logical(dn, DOWN, cb, a1, a3); live_at_logical(up, UP, cb, b1, b3);
+      t5 = bten_step(RIGHT, bten_at_slice(RIGHT, cb), at_logical(dn, DOWN, cb), sb, at_logical(up, UP, cb), nc, false, 1, a1, a3, b1, b3);
       add_logs(lsum, up.logscale, dn.logscale, bten_[LEFT][col].logscale, bten_at_slice(RIGHT, cb).logscale);
     } else {
       const BMPSDev &lf = bmps_at_slice(LEFT, col), &rt = bmps_at_slice(RIGHT, col);
       PG_REQUIRE(bten_size(UP) > row, 3, "ReplaceNNSiteTrace: UP BTen missing");
-      t2 = bten_step(UP, bten_[UP][row], at_logical(rt, RIGHT, row), sa, at_logical(lf, LEFT, row), nc, false);
-      t5 = bten_step(DOWN, bten_at_slice(DOWN, rb), at_logical(lf, LEFT, rb), sb, at_logical(rt, RIGHT, rb), nc, false);
+      const int *a1, *a3, *b1, *b3;
+      live_at_logical(rt, RIGHT, row, a1, a3); live_at_logical(lf, LEFT, row, b1, b3);
+      t2 = bten_step(UP, bten_[UP][row], at_logical(rt, RIGHT, row), sa, at_logical(lf, LEFT, row), nc, false, 1, a1, a3, b1, b3);
+      live_at_logical(lf, LEFT, rb, a1, a3); live_at_logical(rt, RIGHT, rb, b1, b3);
+      t5 = bten_step(DOWN, bten_at_slice(DOWN, rb), at_logical(lf, LEFT, rb), sb, at_logical(rt, RIGHT, rb), nc, false, 1, a1, a3, b1, b3);
       add_logs(lsum, lf.logscale, rt.logscale, bten_[UP][row].logscale, bten_at_slice(DOWN, rb).logscale);
     }
     finish_dot(t2.t, nc, t5.t, nc, nc, lsum, out);
@@ -909,9 +928,14 @@ class Engine : public EngineBase {
   // Batch = walker x ncand (environment tensors shared by the candidates of one walker).
   // bt_ncand: the input BTen is batched over walker x bt_ncand candidates (chains of steps with
   // replaced tensors, ReplaceTNNSiteTrace); 1 = one BTen per walker.
+  // vx / vc / vb / vy (optional, per walker): live extents of mps1's bonds x, c and of mps2's bonds b2, y.  The contractions
+  // then run over the live parts only (the tensors are zero beyond them); the new BTen is written in full, zeros included.
   BTenDev bten_step(int post, const BTenDev &bt, const DTen<T> &mps1, const SiteSel &ss, const DTen<T> &mps2,
-                    int ncand, bool normalise, int bt_ncand = 1) {
+                    int ncand, bool normalise, int bt_ncand = 1, const int *vx = nullptr, const int *vc = nullptr,
+                    const int *vb = nullptr, const int *vy = nullptr) {
     ArenaScope scope(arena_);
+    static const bool no_live_env = getenv("PEPSGPU_NO_LIVE_ENV") != nullptr;
+    if (no_live_env || sizeof(T) != 4) vx = vc = vb = vy = nullptr;
     const int nb = nw_ * ncand, nb1 = nw_ * bt_ncand;
     PG_REQUIRE(ncand % bt_ncand == 0 && (!normalise || ncand == 1), 1, "BTen step: bad candidate batching");
     int dd[4], st[4];
@@ -930,6 +954,11 @@ class Engine : public EngineBase {
       g.I[2] = x * p1; g.sAi[2] = cdim; g.sCi[2] = b1 * b2;
       g.K[2] = cdim; g.sAk[2] = 1; g.sBk[2] = b1 * b2;
       g.J[2] = b1 * b2; g.sBj[2] = 1; g.sCj[2] = 1;
+      if (vx || vc || vb) {   // (x, p1) and (b1, b2) as separate sub-indices: the live bonds are x and b2
+        g.I[1] = x; g.I[2] = p1; g.sAi[1] = p1 * cdim; g.sAi[2] = cdim; g.sCi[1] = p1 * b1 * b2; g.sCi[2] = b1 * b2;
+        g.J[1] = b1; g.J[2] = b2; g.sBj[1] = b2; g.sBj[2] = 1; g.sCj[1] = b2; g.sCj[2] = 1;
+        g.dI[1].p = vx; g.dI[1].div = bt_ncand; g.dK[2].p = vc; g.dK[2].div = bt_ncand; g.dJ[2].p = vb; g.dJ[2].div = bt_ncand;
+      }
       g.wA = mps1.n; g.bdivA = bt_ncand; g.wB = bt.t.n; g.wC = tmp1.n; g.nbatch = nb1;
       const double fl = 2.0 * nb1 * (double)(x * p1) * cdim * (double)(b1 * b2);
       prof_begin(PROF_ENV, fl, fl);
@@ -944,6 +973,7 @@ class Engine : public EngineBase {
       g.K[1] = p1; g.K[2] = b1; g.sAk[1] = b1 * b2; g.sAk[2] = b2; g.sBk[1] = st[lc]; g.sBk[2] = st[lb];
       g.J[1] = s1; g.J[2] = s2; g.sBj[1] = st[l1]; g.sBj[2] = st[l2]; g.sCj[1] = s2; g.sCj[2] = 1;
       g.wA = tmp1.n; g.bdivA = ncand / bt_ncand; g.wC = tmp2.n; g.nbatch = nb;
+      g.dI[1].p = vb; g.dI[1].div = ncand; g.dI[2].p = vx; g.dI[2].div = ncand;
       const double fl = 2.0 * nb * (double)(b2 * x) * (double)(p1 * b1) * (double)(s1 * s2);
       prof_begin(PROF_ENV, fl, fl);
       launch_site_gemm(g, ss, ncand, tmp1.p, tmp2.p);
@@ -958,6 +988,9 @@ class Engine : public EngineBase {
       g.K[1] = b2; g.K[2] = s1; g.sAk[1] = x * s1 * s2; g.sAk[2] = s2; g.sBk[1] = s1 * y; g.sBk[2] = y;
       g.J[2] = y; g.sBj[2] = 1; g.sCj[2] = 1;
       g.wA = tmp2.n; g.wB = mps2.n; g.bdivB = ncand; g.wC = o.t.n; g.nbatch = nb;
+      g.dI[1].p = vx; g.dI[1].div = ncand; g.dI[1].mask = 1;     // the new BTen is written in full
+      g.dK[1].p = vb; g.dK[1].div = ncand;
+      g.dJ[2].p = vy; g.dJ[2].div = ncand; g.dJ[2].mask = 1;
       const double fl = 2.0 * nb * (double)(x * s2) * (double)(b2 * s1) * (double)y;
       prof_begin(PROF_ENV, fl, fl);
       tgemm_launch<T, T, T, T>(stream_, g, tmp2.p, mps2.p, o.t.p);

@@ -27,6 +27,7 @@ struct TgDyn {
   const int *p = nullptr;
   int mul = 1;
   int mask = 0;
+  int div = 1;      // the extent of batch entry b is p[b / div] (candidates of one walker share its live bonds)
 };
 
 struct TGemmDesc {
@@ -284,9 +285,9 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__res
   if (d.batch_flag && d.batch_flag[b] >= 0) return;
 #pragma unroll
   for (int s = 0; s < 3; ++s) {   // block-uniform: the walker's live extents replace / mask the static dims
-    if (d.dI[s].p) { const int e = min(d.I[s], d.dI[s].p[b] * d.dI[s].mul); if (d.dI[s].mask) d.Imask[s] = e; else d.I[s] = e; }
-    if (d.dJ[s].p) { const int e = min(d.J[s], d.dJ[s].p[b] * d.dJ[s].mul); if (d.dJ[s].mask) d.Jmask[s] = e; else d.J[s] = e; }
-    if (d.dK[s].p) d.K[s] = min(d.K[s], d.dK[s].p[b] * d.dK[s].mul);
+    if (d.dI[s].p) { const int e = min(d.I[s], d.dI[s].p[b / d.dI[s].div] * d.dI[s].mul); if (d.dI[s].mask) d.Imask[s] = e; else d.I[s] = e; }
+    if (d.dJ[s].p) { const int e = min(d.J[s], d.dJ[s].p[b / d.dJ[s].div] * d.dJ[s].mul); if (d.dJ[s].mask) d.Jmask[s] = e; else d.J[s] = e; }
+    if (d.dK[s].p) d.K[s] = min(d.K[s], d.dK[s].p[b / d.dK[s].div] * d.dK[s].mul);
   }
   if ((int)blockIdx.y * TG_BN >= d.Jtot()) return;
   int Itot = d.Itot(), Ktot = d.Ktot();
@@ -324,9 +325,9 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__res
 __device__ __forceinline__ void tg_apply_extents(TGemmDesc &d, const int b) {
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
-    if (d.dI[s].p) { const int e = min(d.I[s], d.dI[s].p[b] * d.dI[s].mul); if (d.dI[s].mask) d.Imask[s] = e; else d.I[s] = e; }
-    if (d.dJ[s].p) { const int e = min(d.J[s], d.dJ[s].p[b] * d.dJ[s].mul); if (d.dJ[s].mask) d.Jmask[s] = e; else d.J[s] = e; }
-    if (d.dK[s].p) d.K[s] = min(d.K[s], d.dK[s].p[b] * d.dK[s].mul);
+    if (d.dI[s].p) { const int e = min(d.I[s], d.dI[s].p[b / d.dI[s].div] * d.dI[s].mul); if (d.dI[s].mask) d.Imask[s] = e; else d.I[s] = e; }
+    if (d.dJ[s].p) { const int e = min(d.J[s], d.dJ[s].p[b / d.dJ[s].div] * d.dJ[s].mul); if (d.dJ[s].mask) d.Jmask[s] = e; else d.J[s] = e; }
+    if (d.dK[s].p) d.K[s] = min(d.K[s], d.dK[s].p[b / d.dK[s].div] * d.dK[s].mul);
   }
 }
 
