@@ -1124,14 +1124,21 @@ __global__ __launch_bounds__(256, CPL <= 4 ? 3 : 2) void jacobi_rows_tiny4_kerne
   // ---- select: the rows are mutually orthogonal, sigma_i = |row_i| (select_rows_kernel, same rules) ----
   if (mm == 0) return;                                     // (not this kernel's walker: select_rows_kernel takes it)
   float *V = sel.V + (long)walker * sel.wV;
-  float n2[JR_BR];
-  float fro2 = 0.f;
+  double n2[JR_BR];        // f64 sums of the exact f32 squares, as select_rows_kernel forms them
+  double fro2 = 0.0;
 #pragma unroll
   for (int i = 0; i < JR_BR; ++i) {
-    n2[i] = i < mm ? jg_sum16(jrx_dot<CPL>(a[i], a[i])) : -1.f;   // rows that do not exist rank after every real row
-    fro2 += i < mm ? n2[i] : 0.f;
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) t = fma((double)a[i].v[q], (double)a[i].v[q], t);
+    t += lw_dpp_f64<0xB1>(t);
+    t += lw_dpp_f64<0x4E>(t);
+    t += lw_dpp_f64<0x141>(t);
+    t += lw_dpp_f64<0x140>(t);
+    n2[i] = i < mm ? t : -1.0;                                     // rows that do not exist rank after every real row
+    fro2 += i < mm ? t : 0.0;
   }
-  const float nfloor2 = (float)(4.0 * NOISE_C * NOISE_C * (double)Eps<float>::v * (double)Eps<float>::v) * fro2;   // (2 NOISE_C eps |M|_F)^2
+  const double nfloor2 = 4.0 * NOISE_C * NOISE_C * (double)Eps<float>::v * (double)Eps<float>::v * fro2;   // (2 NOISE_C eps |M|_F)^2
   int rank[JR_BR];
 #pragma unroll
   for (int i = 0; i < JR_BR; ++i) {
@@ -1146,10 +1153,10 @@ __global__ __launch_bounds__(256, CPL <= 4 ? 3 : 2) void jacobi_rows_tiny4_kerne
     double err = 0.0;
     while (kept > 0) {
       if (kept <= sel.dmin && kept <= sel.k) break;
-      float sk2 = 0.f;                                       // squared singular value of rank kept - 1
+      double sk2 = 0.0;                                      // squared singular value of rank kept - 1
 #pragma unroll
       for (int i = 0; i < JR_BR; ++i) sk2 = rank[i] == kept - 1 ? n2[i] : sk2;
-      const double wgt = fro2 > 0.f ? (double)sk2 / (double)fro2 : 0.0;
+      const double wgt = fro2 > 0.0 ? sk2 / fro2 : 0.0;
       if (kept > sel.k || (kept > sel.dmin && err + wgt < sel.trunc_err)) { err += wgt; --kept; }
       else break;
     }
@@ -1160,7 +1167,7 @@ __global__ __launch_bounds__(256, CPL <= 4 ? 3 : 2) void jacobi_rows_tiny4_kerne
   for (int i = 0; i < JR_BR; ++i) {
     if (i < mm && rank[i] < kcut) {
       const bool live = n2[i] > nfloor2;
-      const float inv = live ? __builtin_amdgcn_rsqf(n2[i]) : 0.f;   // numerically zero direction -> zero row of Vt
+      const float inv = live ? (float)(1.0 / sqrt(n2[i])) : 0.f;     // numerically zero direction -> zero row of Vt
       klive += live ? 1 : 0;
 #pragma unroll
       for (int q = 0; q < CPL; ++q) {

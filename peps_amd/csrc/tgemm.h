@@ -361,7 +361,7 @@ template <bool AVEC, bool BVEC>
 __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *__restrict__ A, const float *__restrict__ B,
                                                float *__restrict__ C, const int Itot, const int Jtot, const int K2s,
                                                int (*offCi_s)[32], const int tile0, const int tile_step,
-                                               const float scale = 1.f, float *__restrict__ sumsq = nullptr) {
+                                               const float scale = 1.f, double *__restrict__ sumsq = nullptr) {
   // scale: multiplies alpha (per-entry scale of an operand that was left unnormalised); sumsq (optional): += squares of the
   // values this lane stores.
   // Instruction budget (SQ counters, round 2: 36 VALU instructions per MFMA in the chained kernel, the launches were
@@ -372,7 +372,7 @@ __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ntj = (Jtot + 31) >> 5, ntiles = ((Itot + 31) >> 5) * ntj;
   const float alpha = (float)d.alpha * scale;
-  float ss = 0.f;
+  double ss = 0.0;     // (f64: the norm it feeds replaces an f64 reduction over the stored tensor)
   const int half = lane >> 5, l31 = lane & 31;
   const int K2 = d.K[2], K1 = d.K[1];
   const int nr8 = (K2 + 7) >> 3, nrounds = d.K[0] * K1 * nr8;
@@ -494,7 +494,7 @@ __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *
           float v = ((oi & TG_ZERO_ROW) || jzero) ? 0.f : acc[4 * g + e] * alpha;
           if (accumulate) v += *p;
           *p = v;
-          ss = fmaf(v, v, ss);
+          if (sumsq) ss = fma((double)v, (double)v, ss);
         }
       }
     }
@@ -525,12 +525,12 @@ __global__ __launch_bounds__(256, 6) void tgemm_direct_kernel(TGemmDesc d, const
   long baseA = (long)(b / d.bdivA) * d.wA, baseB = (long)(b / d.bdivB) * d.wB;
   if (d.selA) baseA += (long)d.selA[(long)(b / d.seldivA) * d.selA_inc] * d.selA_mul;
   if (d.selB) baseB += (long)d.selB[(long)(b / d.seldivB) * d.selB_inc] * d.selB_mul;
-  float ss = 0.f;
+  double ss = 0.0;
   tg_direct_body<AVEC, BVEC>(d, Ag + baseA, Bg + baseB, Cg + (long)(b / d.bdivC) * d.wC, Itot, Jtot, K2s, offCi_s,
                              blockIdx.x * 4, gridDim.x * 4, d.scale_in ? d.scale_in[b] : 1.f, d.scale_out ? &ss : nullptr);
   if (d.scale_out) {     // (gridDim.x == 1: this block stored all of C[b])
     __shared__ double s_nred[4];
-    double a = (double)ss;
+    double a = ss;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
     if ((threadIdx.x & 63) == 0) s_nred[threadIdx.x >> 6] = a;
