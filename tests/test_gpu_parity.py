@@ -354,7 +354,7 @@ def test_rectangular_lattices(Ly, Lx, dt):
         assert abs(np.sum(h * t) / ref - 1) < TOL[dt] * 10
 
 
-@pytest.mark.parametrize("dt,terr,tol", [("f64", 1e-6, 1e-9), ("f64", 1e-3, 1e-9), ("f32", 1e-6, 2e-3)])
+@pytest.mark.parametrize("dt,terr,tol", [("f64", 1e-6, 1e-9), ("f64", 1e-3, 1e-9), ("f32", 1e-6, 2e-3), ("f32", 1e-3, 2e-3)])
 def test_truncation_by_error_dmin_dmax(dt, terr, tol):
     """BMPSTruncateParams::SVD(D_min, D_max, trunc_err > 0) (bmps.h:47-98, qlten::SVD truncation at
     bmps_impl.h:235-238): the kept bond dimension is chosen per walker and per bond from the discarded
@@ -376,7 +376,9 @@ def test_truncation_by_error_dmin_dmax(dt, terr, tol):
     got = ctx.evaluate_amplitude()
     assert np.all(ctx.walker_flags() == 0)
     assert np.max(np.abs(got / ref - 1)) < tol, (got, ref)
-    if dt == "f64":
+    # kept dimensions: f64 always; f32 (where the Jacobi kernel of the walkers with few rows applies the rule itself, from its
+    # registers) with the coarse error bound, whose cut is far from the rounding of the singular values
+    if dt == "f64" or terr >= 1e-3:
         n_down = ctx.bmps_stack_size(DOWN)
         assert n_down == L
         for level in range(1, n_down):
