@@ -85,8 +85,24 @@ bool Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
     PG_CHECK_HIP(hipGetLastError());
     return sel_used;
   }
+  int skip_le = 0;
+  if constexpr (std::is_same<T, double>::value) {
+    // f64: walkers with at most JR_BR live rows of at most 128 elements in the register kernel (16 or 32 lanes per row)
+    static const bool no_t64 = getenv("PEPSGPU_NO_TINY_F64") != nullptr;
+    if (!no_t64 && len <= 128 && (mdyn || m <= JR_BR)) {
+      if (len <= 64)
+        hipLaunchKernelGGL((jacobi_rows_tiny_f64_kernel<4, 16>), dim3((nw_ + 15) / 16), dim3(256), 0, stream_, (double *)M, wM, m, len, len,
+                           40, sweeps_, mdyn, mdyn_mul, nw_);
+      else
+        hipLaunchKernelGGL((jacobi_rows_tiny_f64_kernel<4, 32>), dim3((nw_ + 7) / 8), dim3(256), 0, stream_, (double *)M, wM, m, len, len,
+                           40, sweeps_, mdyn, mdyn_mul, nw_);
+      PG_CHECK_HIP(hipGetLastError());
+      if (m <= JR_BR) return sel_used;
+      skip_le = JR_BR;
+    }
+  }
   hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), use_lds ? need : 0, stream_, M, wM, m, len, len, 40,
-                     use_lds, sweeps_, mdyn, mdyn_mul, small);
+                     use_lds, sweeps_, mdyn, mdyn_mul, small, skip_le);
   PG_CHECK_HIP(hipGetLastError());
   return sel_used;
 }

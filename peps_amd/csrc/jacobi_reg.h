@@ -1182,4 +1182,134 @@ __global__ __launch_bounds__(256, CPL <= 4 ? 3 : 2) void jacobi_rows_tiny4_kerne
   if (l16 == 0 && sel.klive_out) sel.klive_out[walker] = klive;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The short-row kernel for the FLOAT64 element type: at most JR_BR rows of at most LPR * CPL elements, a row in LPR lanes
+// (16: four walkers per wave, rows <= 64 long; 32: two walkers, rows <= 128), rows in registers, DPP reductions inside the
+// lane group.  The f64 mode had only the general kernel (1024 threads and LDS or global memory per walker): two thirds of
+// its step.  Same Hestenes rotation, threshold (4 len eps^2) and noise floor as the f32 kernels, in f64 arithmetic.
+template <int CPL> struct JrRowD { double v[CPL]; };
+
+template <int LPR>
+__device__ __forceinline__ double jd_sum(double v) {
+  v += lw_dpp_f64<0xB1>(v);
+  v += lw_dpp_f64<0x4E>(v);
+  v += lw_dpp_f64<0x141>(v);
+  v += lw_dpp_f64<0x140>(v);
+  if constexpr (LPR == 32) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto pl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto ph = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double((int)ph[0], (int)pl[0]) + __hiloint2double((int)ph[1], (int)pl[1]);
+  }
+  return v;
+}
+
+template <int CPL>
+__device__ __forceinline__ double jd_dot(const JrRowD<CPL> &x, const JrRowD<CPL> &y) {
+  double p = x.v[0] * y.v[0];
+#pragma unroll
+  for (int q = 1; q < CPL; ++q) p = fma(x.v[q], y.v[q], p);
+  return p;
+}
+
+template <int CPL>
+__device__ __forceinline__ int jd_apply(JrRowD<CPL> &x, JrRowD<CPL> &y, double &nx, double &ny, const double g, const double tol2,
+                                        const double floor2) {
+  const bool go = g * g > tol2 * nx * ny && nx > floor2 && ny > floor2;
+  if (!__any(go)) return 0;
+  const double zeta = (ny - nx) / (2.0 * (go ? g : 1.0));
+  const double az = fabs(zeta);
+  double t = copysign(1.0 / (az + sqrt(fma(az, az, 1.0))), zeta);
+  t = go ? t : 0.0;
+  const double cs = 1.0 / sqrt(fma(t, t, 1.0)), sn = cs * t;
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    const double xv = x.v[q], yv = y.v[q];
+    x.v[q] = cs * xv - sn * yv;
+    y.v[q] = sn * xv + cs * yv;
+  }
+  const double tg = t * g;
+  nx = fmax(nx - tg, 0.0);
+  ny = ny + tg;
+  return go ? 1 : 0;
+}
+
+template <int NB, int CPL, int LPR>
+__device__ __forceinline__ int jd_intra(JrRowD<CPL> (&a)[JR_BR], double (&na)[JR_BR], const double tol2, const double floor2) {
+  int rot = 0;
+#pragma unroll 1
+  for (int r = 0; r < NB - 1; ++r) {
+    double ga[NB / 2];
+#pragma unroll
+    for (int p = 0; p < NB / 2; ++p) ga[p] = jd_sum<LPR>(jd_dot<CPL>(a[p], a[NB - 1 - p]));
+#pragma unroll
+    for (int p = 0; p < NB / 2; ++p) rot += jd_apply<CPL>(a[p], a[NB - 1 - p], na[p], na[NB - 1 - p], ga[p], tol2, floor2);
+    const JrRowD<CPL> ta = a[NB - 1];
+    const double fa = na[NB - 1];
+#pragma unroll
+    for (int i = NB - 1; i >= 2; --i) { a[i] = a[i - 1]; na[i] = na[i - 1]; }
+    a[1] = ta; na[1] = fa;
+  }
+  return rot;
+}
+
+template <int CPL, int LPR>
+__global__ __launch_bounds__(256, 2) void jacobi_rows_tiny_f64_kernel(double *__restrict__ Mg, long wM, int m, int len, int ld,
+                                                                      int max_sweeps, int *__restrict__ sweeps_out,
+                                                                      const int *__restrict__ mdyn, int mdyn_mul, int nwalkers) {
+  constexpr int WPW = 64 / LPR;                               // walkers per wave
+  const int lane = threadIdx.x & 63, ll = lane & (LPR - 1);
+  const int walker = blockIdx.x * (4 * WPW) + (threadIdx.x >> 6) * WPW + lane / LPR;
+  const bool have = walker < nwalkers;
+  int mm = have ? (mdyn ? min(m, mdyn[walker] * mdyn_mul) : m) : 0;
+  if (mm > JR_BR) mm = 0;                                     // the general kernel takes this walker
+  int mm_max = mm;
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) mm_max = max(mm_max, __shfl_xor(mm_max, o, 64));   // wave-uniform
+  if (mm_max == 0) return;
+  double *M = Mg + (long)(have ? walker : 0) * wM;
+  JrRowD<CPL> a[JR_BR];
+  double na[JR_BR];
+  double fro = 0.0;
+#pragma unroll
+  for (int i = 0; i < JR_BR; ++i) {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      const int c = CPL * ll + q;
+      a[i].v[q] = (i < mm && c < len) ? M[(long)i * ld + c] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < JR_BR; ++i) {
+    na[i] = jd_sum<LPR>(jd_dot<CPL>(a[i], a[i]));
+    fro += na[i];
+  }
+  const double floor2 = NOISE_C * NOISE_C * Eps<double>::v * Eps<double>::v * fro;
+  const double tol2 = 4.0 * (double)len * Eps<double>::v * Eps<double>::v;
+  int sweep = 0;
+  for (; sweep < max_sweeps; ++sweep) {
+    if (sweep) {
+#pragma unroll
+      for (int i = 0; i < JR_BR; ++i)
+        if (i < mm_max) na[i] = jd_sum<LPR>(jd_dot<CPL>(a[i], a[i]));
+    }
+    int rot;
+    if (mm_max <= 4) rot = jd_intra<4, CPL, LPR>(a, na, tol2, floor2);
+    else if (mm_max <= 8) rot = jd_intra<8, CPL, LPR>(a, na, tol2, floor2);
+    else if (mm_max <= 12) rot = jd_intra<12, CPL, LPR>(a, na, tol2, floor2);
+    else rot = jd_intra<JR_BR, CPL, LPR>(a, na, tol2, floor2);
+    if (!__any(rot != 0)) { ++sweep; break; }
+  }
+#pragma unroll
+  for (int i = 0; i < JR_BR; ++i) {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      const int c = CPL * ll + q;
+      if (i < mm && c < len) M[(long)i * ld + c] = a[i].v[q];
+    }
+  }
+  if (ll == 0 && mm > 0 && sweeps_out) sweeps_out[walker] = sweep | (mm << 8);
+}
+
 }  // namespace pepsgpu

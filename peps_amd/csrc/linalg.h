@@ -980,11 +980,12 @@ __global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, l
                                                            int ld, int max_sweeps, int use_lds,
                                                            int *__restrict__ sweeps_out,
                                                            const int *__restrict__ mdyn, int mdyn_mul,
-                                                           int skip_small = 0) {
+                                                           int skip_small = 0, int skip_le = 0) {
   extern __shared__ unsigned char jc_smem_raw[];
   T *sM = reinterpret_cast<T *>(jc_smem_raw);
   if (mdyn) m = min(m, mdyn[blockIdx.x] * mdyn_mul);
   if (skip_small && m <= max(skip_small, 32)) return;   // the one-wave kernels (jacobi_reg.h) / the mid route took this walker
+  if (skip_le && m <= skip_le) return;                  // (f64: the short-row kernel took it)
   __shared__ int s_rot;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   T *Mglob = Mg + (long)blockIdx.x * wM;
