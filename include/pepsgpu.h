@@ -206,7 +206,9 @@ int pepsgpu_walker_flags(pepsgpu_ctx *ctx, int32_t *flags_out);
 int pepsgpu_sync(pepsgpu_ctx *ctx);
 /* stats_out: [0] row absorptions, [1] Jacobi launches, [2] Jacobi sweeps (sum of per-launch maxima), [3] device bytes held,
  * [4] largest sweep count; with PEPSGPU_DEBUG_SWEEPS=1 at context creation also [5] sum of live carry rows, [6] sum of
- * carry sizes, [7] largest live carry of any walker (> 32: the dense Gram / Cholesky / full Jacobi route ran) */
+ * carry sizes, [7] largest live carry of any walker (> 32: the dense Gram / Cholesky / full Jacobi route ran); [8] absorptions
+ * done twice (a bond sized from the previous row's live count was filled, or a kernel size class skipped on the previous row's
+ * carry rank was needed after all: performance hints only, results never depend on them) */
 int pepsgpu_stats(pepsgpu_ctx *ctx, double *stats_out, int n);
 /* Per-kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).
  * out = [10][5]: {ms, launches, algorithmic flops, executed flops, operand + result bytes of the live extents} per category

@@ -431,12 +431,12 @@ class Context:
                 for i, name in enumerate(self.PROF_CATS)}
 
     def stats(self):
-        out = np.zeros(8, dtype=np.float64)
-        self._ck(self._l.pepsgpu_stats(self._h, _dp(out), 8))
+        out = np.zeros(9, dtype=np.float64)
+        self._ck(self._l.pepsgpu_stats(self._h, _dp(out), 9))
         return {"absorptions": int(out[0]), "jacobi_launches": int(out[1]), "jacobi_sweeps_sum": int(out[2]),
                 "device_bytes": int(out[3]), "jacobi_sweeps_max": int(out[4]),
                 "carry_live_fraction": float(out[5] / out[6]) if out[6] > 0 else None,
-                "carry_live_max": int(out[7])}
+                "carry_live_max": int(out[7]), "absorptions_redone": int(out[8])}
 
 
 def comm_unique_id():

@@ -770,9 +770,9 @@ class Engine : public EngineBase {
   }
   size_t device_bytes() const override { return arena_.total_bytes(); }
   void stats(double *out, int n) override {
-    double v[8] = {(double)n_absorb_, (double)n_jacobi_, (double)jacobi_sweeps_sum_, (double)arena_.total_bytes(),
-                   (double)jacobi_sweeps_max_, live_sum_, live_full_, (double)live_max_};
-    for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+    double v[9] = {(double)n_absorb_, (double)n_jacobi_, (double)jacobi_sweeps_sum_, (double)arena_.total_bytes(),
+                   (double)jacobi_sweeps_max_, live_sum_, live_full_, (double)live_max_, (double)n_redo_};
+    for (int i = 0; i < n && i < 9; ++i) out[i] = v[i];
   }
   hipStream_t stream() const { return stream_; }
 
@@ -1072,8 +1072,10 @@ class Engine : public EngineBase {
   int *upload_cand(int ncand, int ncols, const int32_t *cand);
   // sel (optional, f32): the kernel of the walkers with at most JR_BR live rows selects / normalises their rows into Vt
   // itself; returns true when it did (select_rows_kernel then skips those walkers)
+  // rows_cap (0 = none): the caller vouches that no walker has more live rows (hint of the row absorbed before, verified
+  // against the live counts read back at the end of the absorption): the kernels of the larger size classes are not launched
   bool launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t need, const int *mdyn, int mdyn_mul, int mid_hi = 0,
-                     const JrSelect *sel = nullptr);
+                     const JrSelect *sel = nullptr, int rows_cap = 0);
   static bool jacobi_small_ok(int len, int m, const int *mdyn);
 
   int Ly_, Lx_, D_, dp_, chi_min_, chi_;
@@ -1101,6 +1103,7 @@ class Engine : public EngineBase {
   double conv_tol_ = 0.0;
   long n_var_iters_ = 0;
   long n_absorb_ = 0, n_jacobi_ = 0, jacobi_sweeps_sum_ = 0, jacobi_sweeps_max_ = 0;
+  long n_redo_ = 0;                       // absorptions done twice: a shrunk bond was filled, or a rank hint of the row before was missed
   double live_sum_ = 0, live_full_ = 0;   // diagnostics: sum of live carry rows / sum of carry sizes
   long live_max_ = 0;                     // ... and the largest live carry of any walker (> 32: the dense route ran)
   T *holes_ = nullptr;                    // resident hole store [walker][site][D^4]

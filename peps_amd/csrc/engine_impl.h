@@ -33,7 +33,7 @@ bool Engine<T>::jacobi_small_ok(int len, int m, const int *mdyn) {
 
 template <typename T>
 bool Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t need, const int *mdyn, int mdyn_mul, int mid_hi,
-                              const JrSelect *sel) {
+                              const JrSelect *sel, int rows_cap) {
   int small = 0;
   bool sel_used = false;
   if constexpr (sizeof(T) == 4) {
@@ -65,12 +65,12 @@ bool Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
           hipLaunchKernelGGL(jacobi_rows_tiny_kernel, dim3((nw_ + 3) / 4), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
                              sweeps_, mdyn, mdyn_mul, nw_);
         PG_CHECK_HIP(hipGetLastError());
-        if (m <= JR_BR) return sel_used;
+        if (m <= JR_BR || (rows_cap > 0 && rows_cap <= JR_BR)) return sel_used;
       }
       hipLaunchKernelGGL(jacobi_rows_small_kernel, dim3((nw_ + 3) / 4), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
                          sweeps_, mdyn, mdyn_mul, nw_, no_tiny ? 0 : 1);
       PG_CHECK_HIP(hipGetLastError());
-      if (m <= JR_SMALL_ROWS) return sel_used;
+      if (m <= JR_SMALL_ROWS || (rows_cap > 0 && rows_cap <= JR_SMALL_ROWS)) return sel_used;
     }
     if (mid_hi && m <= mid_hi) return sel_used;        // every remaining walker is on the mid route
     const int skip = mid_hi ? mid_hi : small;          // rows <= max(skip, 32) are taken elsewhere
@@ -143,6 +143,7 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_svd(int pos, int num, const BMPSDe
   ArenaScope scope(arena_);   // a throw inside returns every temporary and the half-built BMPS to the arena
   BMPSDev out;
   if (!absorb_impl(pos, num, no_shrink, in, out)) {
+    ++n_redo_;
     free_bmps(out);
     out = BMPSDev();
     PG_REQUIRE(absorb_impl(pos, num, true, in, out), 5, "MultiplyMPO: internal error (full-size absorption reported clipping)");
@@ -368,6 +369,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
   out.logscale = (double *)arena_.alloc(sizeof(double) * nw_);
   PG_CHECK_HIP(hipMemcpyAsync(out.logscale, cur_log, sizeof(double) * nw_, hipMemcpyDeviceToDevice, stream_));
   DTen<T> Y = ones3();   // [l2, a2, k2]
+  std::vector<int> assume_rows(N, 0);   // per site: the live-row cap the Jacobi launches relied on (0: none)
   float *yscale = nullptr;   // 1 / |Y| per walker when Y was left unnormalised by the launch that wrote it (y_scaled)
   bool y_scaled = false;
   for (int i = N - 1; i >= 0; --i) {
@@ -553,7 +555,21 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       if constexpr (sizeof(T) == 4) {
         if (!no_jsel && kn[i]) { jsel.V = (float *)V.p; jsel.wV = V.n; jsel.k = k; jsel.klive_out = kn[i]; jsel.trunc_err = trunc_err_; jsel.dmin = chi_min_; }
       }
-      sel_done = launch_jacobi(M.p, M.n, m, uk, use_lds, need, mdyn[i], mmul[i], mid ? MID_HI : 0, jsel.V ? &jsel : nullptr);
+      // Size classes of the Jacobi kernels above the carry rank of the row absorbed before (+ margin) are not launched (each
+      // is a launch of nw blocks that return at once); the live counts read back at the end of this absorption verify it,
+      // a miss redoes the absorption without hints (absorb_svd).
+      int rows_cap = 0;
+      if constexpr (sizeof(T) == 4) {
+        static const bool no_hint_skip = getenv("PEPSGPU_NO_RANK_HINT_SKIP") != nullptr;
+        static const int force_cap = getenv("PEPSGPU_FORCE_ROWS_CAP") ? atoi(getenv("PEPSGPU_FORCE_ROWS_CAP")) : 0;   // tests: a wrong hint
+        if (!full_bonds && !no_hint_skip && adaptive && mdyn[i] && !mid) {
+          if (force_cap) rows_cap = force_cap;
+          else if (in.depth >= 3 && (int)in.mlmax.size() > i && in.mlmax[i] >= 0)
+            rows_cap = in.mlmax[i] + 3 <= JR_BR ? JR_BR : (in.mlmax[i] + 6 <= JR_SMALL_ROWS ? JR_SMALL_ROWS : 0);
+        }
+      }
+      assume_rows[i] = rows_cap;
+      sel_done = launch_jacobi(M.p, M.n, m, uk, use_lds, need, mdyn[i], mmul[i], mid ? MID_HI : 0, jsel.V ? &jsel : nullptr, rows_cap);
       if constexpr (sizeof(T) == 4) {
         if (mid) {
           // <= 64 live rows: two waves per walker, else four; rows of 16 lanes, four pairs per wave instruction
@@ -710,6 +726,8 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     for (int i = 0; i < N; ++i) out.mlmax[i] = mdyn[i] ? std::min(R[i].d[0], hmax[N + 1 + i] * mmul[i]) : R[i].d[0];
     for (int i = 1; i < N; ++i)
       if (kstat[i] < kfull[i] && out.kmax[i] >= kstat[i]) ok = false;   // a walker filled a shrunk bond: maybe clipped
+    for (int i = 0; i < N; ++i)
+      if (assume_rows[i] > 0 && out.mlmax[i] > assume_rows[i]) ok = false;   // a rank hint was missed: rows left unrotated
   }
   for (auto &t : R) arena_.free(t.p);
   {   // the dynamic-extent arrays (several R_i may share one)

@@ -77,3 +77,37 @@ def test_full_rank_route_consistency_c4_batch():
         ctx.close()
     rel = np.abs(amps[capi.F32] / amps[capi.F64] - 1)
     assert np.max(rel) < 1e-5, (int(np.argmax(rel)), float(np.max(rel)))
+
+
+def test_missed_rank_hint_redoes_the_absorption():
+    """Performance hints never decide results: with a WRONG hint forced (PEPSGPU_FORCE_ROWS_CAP=16: 'no walker has more than
+    16 live carry rows', on a state whose carry has many more) the Jacobi size classes above it are not launched, the live
+    counts read back at the end of the absorption expose the miss, and the absorption is redone without hints: amplitudes as
+    in the reference run, and the redo counter says it happened.  (The toggle is read once per process: child interpreter.)"""
+    import json
+    import subprocess
+    import sys
+    code = r'''
+import json, numpy as np
+from peps_amd import capi, synthetic
+L, D, chi = 6, 6, 24
+sitps = synthetic.make_sitps(L, D, noise=1.0)
+cfgs = synthetic.make_configs(L, 6, "heisenberg", seed0=5)
+ctx = capi.Context(L, L, D, 2, chi, dtype=capi.F32, max_walkers=len(cfgs))
+ctx.state_upload(synthetic.sitps_to_flat(sitps, D))
+ctx.set_configs(cfgs)
+a = ctx.evaluate_amplitude()
+st = ctx.stats()
+print(json.dumps({"amps": [float(x) for x in a], "redone": st["absorptions_redone"], "live_max": st["carry_live_max"]}))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, env in (("plain", {}), ("forced", {"PEPSGPU_FORCE_ROWS_CAP": "16"})):
+        e = dict(os.environ, PEPSGPU_DEBUG_SWEEPS="1", PEPSGPU_NO_MIDROUTE="1", **env)   # (the mid route has its own size classes)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert outs["forced"]["live_max"] > 16                       # the hint WAS wrong
+    assert outs["forced"]["redone"] > outs["plain"]["redone"]    # ... and the absorptions were redone
+    a, b = np.array(outs["plain"]["amps"]), np.array(outs["forced"]["amps"])
+    assert np.max(np.abs(b / a - 1)) < 2e-5
