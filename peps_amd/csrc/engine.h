@@ -133,6 +133,7 @@ class Engine : public EngineBase {
     { const char *e = getenv("PEPSGPU_DEBUG_SWEEPS"); dbg_sweeps_ = e && e[0] == '1'; }
     PG_CHECK_HIP(hipMemsetAsync(flag_, 0, sizeof(int) * (size_t)maxw_, stream_));
     dtype = kCplx ? 3 : (sizeof(T) == 4 ? 0 : 1);
+    for (int q = 0; q < 4; ++q) redo_seen_[q].assign(std::max(Ly_, Lx_) + 1, 0);
   }
   ~Engine() override {
     (void)hipStreamSynchronize(stream_);
@@ -154,6 +155,7 @@ class Engine : public EngineBase {
   }
 
   void state_upload(const void *host, int host_dtype) override {
+    for (int q = 0; q < 4; ++q) redo_seen_[q].assign(std::max(Ly_, Lx_) + 1, 0);
     // host layout [row][col][s][L][D][R][U] zero padded to D^4; stored compact in each slot
     std::vector<T> buf((size_t)slot_ * dp_ * Ly_ * Lx_, T(0));
     for (int r = 0; r < Ly_; ++r)
@@ -1103,6 +1105,7 @@ class Engine : public EngineBase {
   double conv_tol_ = 0.0;
   long n_var_iters_ = 0;
   long n_absorb_ = 0, n_jacobi_ = 0, jacobi_sweeps_sum_ = 0, jacobi_sweeps_max_ = 0;
+  std::vector<char> redo_seen_[4];        // per stack position and row / column: its hint-sized absorption was redone before
   long n_redo_ = 0;                       // absorptions done twice: a shrunk bond was filled, or a rank hint of the row before was missed
   double live_sum_ = 0, live_full_ = 0;   // diagnostics: sum of live carry rows / sum of carry sizes
   long live_max_ = 0;                     // ... and the largest live carry of any walker (> 32: the dense route ran)

@@ -142,10 +142,13 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_svd(int pos, int num, const BMPSDe
   static const bool no_shrink = getenv("PEPSGPU_NO_BOND_SHRINK") != nullptr;
   ArenaScope scope(arena_);   // a throw inside returns every temporary and the half-built BMPS to the arena
   BMPSDev out;
-  if (!absorb_impl(pos, num, no_shrink, in, out)) {
-    ++n_redo_;
-    free_bmps(out);
-    out = BMPSDev();
+  // A row whose hint-sized attempt had to be redone (its bonds grow faster than the margin: the first rows of a dense state)
+  // goes straight to the full size the next time the same row is absorbed (the walkers of the next step look like these);
+  // forgotten with the state (state_upload).
+  char &redo_seen = redo_seen_[pos][num];
+  if (redo_seen || !absorb_impl(pos, num, no_shrink, in, out)) {
+    if (!redo_seen) { ++n_redo_; free_bmps(out); out = BMPSDev(); }
+    redo_seen = 1;
     PG_REQUIRE(absorb_impl(pos, num, true, in, out), 5, "MultiplyMPO: internal error (full-size absorption reported clipping)");
   }
   return out;
