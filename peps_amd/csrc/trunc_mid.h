@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256, 2) void mid_gram_chol_kernel(const T *__restri
     if (tid == 0) { sPiv[j] = piv; sList[s_nl] = (short)j; s_nl = s_nl + 1; }
     const double invp = 1.0 / piv;
     // trailing update with the UNSCALED row j: G[i][r] -= G[j][i] G[j][r] / piv, i > j, r >= i
+    // (four rows per trip with the loads issued ahead of the stores was measured: slower -- 90 vs 82 ms per two steps)
     for (int i = j + 1 + wave; i < n; i += 4) {          // a wave per trailing row, lanes along the row
       const double f = sG[j * ldG + i] * invp;
       for (int r = i + lane; r < n; r += 64) sG[i * ldG + r] -= f * sG[j * ldG + r];
@@ -257,6 +258,166 @@ __host__ __device__ inline int cg_row(int j) { return j * (CG_NC - 1) - (j * (j 
 
 inline size_t colgram_chol_smem_bytes(int rcap) {
   return sizeof(double) * ((size_t)rcap * CG_NC - (size_t)rcap * (rcap - 1) / 2 + CG_NC) + sizeof(float) * (size_t)CG_NC * TM_LDM + 64;
+}
+
+// The same factor for DENSE walkers (rank of the order of the column count): after the Gram phase the accumulators are laid
+// down in LDS as the packed upper triangle of G (over the staging buffer, which is dead by then: 69 KB, two blocks per CU) and
+// factored right-looking -- ONE barrier per live pivot, the trailing update spread over all 256 threads -- as
+// mid_gram_chol_kernel does for M M^T.  The low-rank pivot loop of colgram_chol_kernel (row f lifted out of the accumulators,
+// a dot product over the finished rows per thread, three barriers) is the right shape for rank << columns; on the dense
+// sites of a full-rank state it was 73 % of the kernel (1.1 ms of 1.46 ms per launch of 4096 walkers).  No rank cap.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void colgram_dense_kernel(const T *__restrict__ Pg, long wP, int n, const int *__restrict__ kdyn,
+                                                            int kdyn_mul, int kmax, T *__restrict__ Rg, long wR,
+                                                            int *__restrict__ mlive_out, int inner,
+                                                            const int *__restrict__ inner_live, int decline_code,
+                                                            unsigned long long *__restrict__ flopc,
+                                                            unsigned long long *__restrict__ bytec, int flop_stride) {
+  static_assert(sizeof(T) == 4, "f32 element type");
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = kdyn ? min(kmax, kdyn[b] * kdyn_mul) : kmax;
+  const int ilive = inner_live ? min(inner, inner_live[b]) : inner;
+  const int ncols = (n / inner) * ilive;
+  if (ncols > CG_NC) {
+    if (tid == 0) mlive_out[b] = decline_code;
+    return;
+  }
+  extern __shared__ double cg_smem[];
+  float *sP = reinterpret_cast<float *>(cg_smem);          // [CG_NC][TM_LDM] chunk of P, transposed (Gram phase only)
+  double *sG = cg_smem;                                    // packed upper triangle of G / of the factor: (i, c >= i) at cg_row(i) + c
+  double *sPiv = sG + (size_t)CG_NC * (CG_NC + 1) / 2;     // [CG_NC] pivot of a live row (0 = dropped)
+  double *sNrm = sPiv + CG_NC;                             // [CG_NC] squared norm of a factor row
+  short *sList = reinterpret_cast<short *>(sNrm + CG_NC);  // [CG_NC] live rows in order
+  short *sPos = sList + CG_NC;                             // [CG_NC] output position, -1 = dropped
+  __shared__ double s_red[4], s_maxd;
+  __shared__ int s_nl;
+  const T *P = Pg + (long)b * wP;
+  T *Rout = Rg + (long)b * wR;
+
+  // ---- G = P^T P over the packed columns, upper tiles in registers ----
+  const int nt = (ncols + 15) >> 4, ntiles = nt * (nt + 1) / 2;
+  if (flopc && tid == 0 && b % flop_stride == 0) {     // MFMA flops issued (16 x 16 x 2 per tile and row of P) and compulsory bytes
+    atomicAdd(flopc, (unsigned long long)flop_stride * (unsigned long long)ntiles * 512ull * (unsigned long long)K);
+    if (bytec) atomicAdd(bytec, (unsigned long long)flop_stride * 4ull * (unsigned long long)K * ncols);
+  }
+  constexpr int TPW = TM_TPW;
+  const int r16 = lane & 15, k4 = lane >> 4;
+  int ti[TPW], tj[TPW], offa[TPW], offb[TPW];
+  int nq = 0;
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    int t = wave + 4 * q, i = 0;
+    if (t < ntiles) { while (t >= nt - i) { t -= nt - i; ++i; } ti[q] = i; tj[q] = i + t; nq = q + 1; }
+    else { ti[q] = -1; tj[q] = -1; }
+    offa[q] = (16 * max(ti[q], 0) + r16) * TM_LDM;
+    offb[q] = (16 * max(tj[q], 0) + r16) * TM_LDM;
+  }
+  tm_f64x4 acc[TPW];
+#pragma unroll
+  for (int q = 0; q < TPW; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[q][r] = 0.0;
+  const int st_c = tid & (CG_NC - 1);                                    // staging: packed column of this thread
+  const int st_r = st_c < ncols ? (st_c / ilive) * inner + (st_c % ilive) : -1;
+  // columns of the staging buffer beyond the live ones (tile padding) are read by the MFMA operands: zero, once
+  for (int e = tid + ncols * TM_LDM; e < CG_NC * TM_LDM; e += 256) sP[e] = 0.f;
+  // unconditional loads (clamped row), 16 per thread and chunk; the chunk after the one being multiplied is in flight during
+  // its MFMAs (two blocks per CU: little else hides the latency of the loads)
+  float v[TM_KC / 2];
+  auto issue = [&](const int k0) {
+    const int kw = min(TM_KC, K - k0);
+#pragma unroll
+    for (int i = 0; i < TM_KC / 2; ++i) {
+      const int k = min((tid >> 7) + 2 * i, kw - 1);
+      v[i] = (float)P[(long)(k0 + k) * n + st_r];
+    }
+  };
+  if (K > 0 && st_r >= 0) issue(0);
+  for (int k0 = 0; k0 < K; k0 += TM_KC) {
+    const int kw = min(TM_KC, K - k0);
+    __syncthreads();
+    if (st_r >= 0) {
+#pragma unroll
+      for (int i = 0; i < TM_KC / 2; ++i) {
+        const int k = (tid >> 7) + 2 * i;
+        sP[st_c * TM_LDM + k] = k < kw ? v[i] : 0.f;
+      }
+    }
+    __syncthreads();
+    if (k0 + TM_KC < K && st_r >= 0) issue(k0 + TM_KC);
+    tm_gram_chunk_n(nq, acc, sP, offa, offb, k4);
+  }
+  __syncthreads();                                         // the staging buffer is dead: G takes its place
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    if (ti[q] < 0) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                          // acc[r] = G[(lane >> 4) + 4 r][lane & 15] of the tile
+      const int i = 16 * ti[q] + k4 + 4 * r, j = 16 * tj[q] + r16;
+      if (i <= j && j < ncols) sG[cg_row(i) + j] = acc[q][r];
+    }
+  }
+  __syncthreads();
+  double md = 0.0;
+  for (int i = tid; i < ncols; i += 256) md = fmax(md, sG[cg_row(i) + i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
+  if (lane == 0) s_red[wave] = md;
+  if (tid == 0) s_nl = 0;
+  __syncthreads();
+  if (tid == 0) s_maxd = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+  __syncthreads();
+  const double maxd = s_maxd;
+  const double eT = NOISE_C * (double)Eps<T>::v;
+  const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
+  // ---- upper Cholesky, right-looking, one barrier per live pivot (unscaled rows: row j of the factor = G[j][:] / sqrt(piv)) ----
+  int nlv = 0;
+  for (int j = 0; j < ncols; ++j) {
+    const double piv = sG[cg_row(j) + j];                  // every thread reads the same, settled value
+    if (!(piv > thresh) || nlv >= K) continue;             // dead direction (or beyond the K rows: rounding noise): no part
+    if (tid == 0) { sPiv[nlv] = piv; sList[nlv] = (short)j; }
+    ++nlv;
+    const double invp = 1.0 / piv;
+    const int rj = cg_row(j);
+    for (int i = j + 1 + wave; i < ncols; i += 4) {        // a wave per trailing row, lanes along the row
+      const double f = sG[rj + i] * invp;
+      const int ri = cg_row(i);
+      for (int r = i + lane; r < ncols; r += 64) sG[ri + r] -= f * sG[rj + r];
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  const int nl = nlv;
+  // ---- rank compaction (rows with norm below NOISE_C eps_T |R|_F are dropped) and output ----
+  for (int q = wave; q < nl; q += 4) {
+    const int j = sList[q], rj = cg_row(j);
+    double a = 0.0;
+    for (int r = j + lane; r < ncols; r += 64) { const double x = sG[rj + r]; a += x * x; }
+    a = wave_sum(a);
+    if (lane == 0) sNrm[q] = a / sPiv[q];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double f = 0.0;
+    for (int q = 0; q < nl; ++q) f += sNrm[q];
+    const double nfloor = eT * eT * f;
+    int cnt = 0;
+    for (int q = 0; q < nl; ++q) sPos[q] = sNrm[q] > nfloor ? (short)cnt++ : (short)-1;
+    mlive_out[b] = cnt;
+  }
+  __syncthreads();
+  const double sc = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
+  for (int q = wave; q < nl; q += 4) {
+    const int pos = sPos[q];
+    if (pos < 0) continue;
+    const int j = sList[q], rj = cg_row(j);
+    const double f = sc / sqrt(sPiv[q]);
+    for (int c = lane; c < ncols; c += 64) {
+      const int rc = (c / ilive) * inner + (c % ilive);    // packed column -> column of P
+      Rout[(long)pos * n + rc] = c >= j ? T(sG[rj + c] * f) : T(0);
+    }
+  }
 }
 
 template <typename T>
@@ -445,7 +606,17 @@ template <typename T>
 inline void launch_colgram_chol(hipStream_t s, int nbatch, const T *P, long wP, int n, const int *kdyn, int kdyn_mul, int kmax,
                                 T *R, long wR, int *mlive, int inner, const int *inner_live, int decline_code, bool hint_dense) {
   (void)hint_dense;
-  const int rcap = 88;
+  static const bool lowrank_form = getenv("PEPSGPU_COLGRAM_LOWRANK") != nullptr;
+  if (!lowrank_form) {   // dense walkers: right-looking Cholesky of the packed triangle in LDS (colgram_dense_kernel)
+    const size_t smd = sizeof(double) * ((size_t)CG_NC * (CG_NC + 1) / 2 + 2 * CG_NC) + sizeof(short) * 2 * CG_NC + 64;
+    allow_dynamic_lds(reinterpret_cast<const void *>(&colgram_dense_kernel<T>), smd);
+    hipLaunchKernelGGL(colgram_dense_kernel<T>, dim3(nbatch), dim3(256), smd, s, P, wP, n, kdyn, kdyn_mul, kmax, R, wR, mlive, inner,
+                       inner_live, decline_code, tg_flop_counter, tg_byte_counter, nbatch >= 256 ? 64 : 1);
+    PG_CHECK_HIP(hipGetLastError());
+    return;
+  }
+  static const int rcap_env = getenv("PEPSGPU_COLGRAM_RCAP") ? atoi(getenv("PEPSGPU_COLGRAM_RCAP")) : 88;   // (diagnostics: 0 = Gram phase only)
+  const int rcap = rcap_env;
   const size_t sm = colgram_chol_smem_bytes(rcap);
   allow_dynamic_lds(reinterpret_cast<const void *>(&colgram_chol_kernel<T>), sm);
   hipLaunchKernelGGL(colgram_chol_kernel<T>, dim3(nbatch), dim3(256), sm, s, P, wP, n, kdyn, kdyn_mul, kmax, R, wR, mlive, inner,
