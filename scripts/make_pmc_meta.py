@@ -7,7 +7,7 @@ are full-size and carry all but ~0.1 % of the bytes."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CATS = {"contract": ("tgemm_direct_kernel", "tgemm_chain_kernel"), "gram_f64": ("gram_cols_f64_kernel",),
-        "cholesky": ("gram_chol_lowrank_kernel", "gram_chol_wave_kernel", "chol_upper_kernel", "chol_lowrank_kernel", "colgram_chol_kernel"),
+        "cholesky": ("gram_chol_lowrank_kernel", "gram_chol_wave_kernel", "chol_upper_kernel", "chol_lowrank_kernel", "colgram_chol_kernel", "colgram_dense_kernel"),
         "jacobi": ("jacobi_rows_regx_kernel", "jacobi_rows_grp_kernel", "jacobi_rows_reg256_kernel"),
         "jacobi_edge": ("jacobi_rows_tiny2_kernel", "jacobi_rows_tiny4_kernel", "jacobi_rows_tiny_kernel", "jacobi_rows_small_kernel")}
 
