@@ -372,6 +372,15 @@ __global__ __launch_bounds__(256, 2) void colgram_dense_kernel(const T *__restri
   const double eT = NOISE_C * (double)Eps<T>::v;
   const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
   // ---- upper Cholesky, right-looking, one barrier per live pivot (unscaled rows: row j of the factor = G[j][:] / sqrt(piv)) ----
+  // trailing update G[i][r] -= G[j][i] G[j][r] / piv (j < i <= r) on a 16 x 16 grid of threads: thread (ta, tb) owns the
+  // elements i = ta (mod 16), r = tb (mod 16) -- up to 36 of the upper triangle, independent of each other (their LDS round
+  // trips overlap; a wave per row, as mid_gram_chol_kernel does it, is a chain of dependent round trips: 4.8 k cycles per
+  // pivot); block rows that lie at or before the pivot are skipped for the whole block
+  const int ta = tid >> 4, tb = tid & 15;
+  int rowb[CG_NC / 16];
+#pragma unroll
+  for (int ii = 0; ii < CG_NC / 16; ++ii) rowb[ii] = cg_row(16 * ii + ta);
+  const int nblk = (ncols + 15) >> 4;
   int nlv = 0;
   for (int j = 0; j < ncols; ++j) {
     const double piv = sG[cg_row(j) + j];                  // every thread reads the same, settled value
@@ -380,10 +389,24 @@ __global__ __launch_bounds__(256, 2) void colgram_dense_kernel(const T *__restri
     ++nlv;
     const double invp = 1.0 / piv;
     const int rj = cg_row(j);
-    for (int i = j + 1 + wave; i < ncols; i += 4) {        // a wave per trailing row, lanes along the row
-      const double f = sG[rj + i] * invp;
-      const int ri = cg_row(i);
-      for (int r = i + lane; r < ncols; r += 64) sG[ri + r] -= f * sG[rj + r];
+    const int ii0 = (j + 1) >> 4;                          // first block row with an i > j
+    double ui[CG_NC / 16], ur[CG_NC / 16];
+#pragma unroll
+    for (int q = 0; q < CG_NC / 16; ++q) {
+      const int i = 16 * q + ta, r = 16 * q + tb;
+      ui[q] = (q >= ii0 && q < nblk && i > j && i < ncols) ? sG[rj + i] * invp : 0.0;
+      ur[q] = (q >= ii0 && q < nblk && r > j && r < ncols) ? sG[rj + r] : 0.0;
+    }
+#pragma unroll
+    for (int ii = 0; ii < CG_NC / 16; ++ii) {
+      if (ii < ii0 || ii >= nblk) continue;                // (block-uniform)
+      const int i = 16 * ii + ta;
+#pragma unroll
+      for (int rr = 0; rr < CG_NC / 16; ++rr) {
+        if (rr < ii || rr >= nblk) continue;
+        const int r = 16 * rr + tb;
+        if (i > j && r >= i && r < ncols) sG[rowb[ii] + r] -= ui[ii] * ur[rr];
+      }
     }
     __syncthreads();
   }
