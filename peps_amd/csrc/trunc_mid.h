@@ -372,40 +372,74 @@ __global__ __launch_bounds__(256, 2) void colgram_dense_kernel(const T *__restri
   const double eT = NOISE_C * (double)Eps<T>::v;
   const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
   // ---- upper Cholesky, right-looking, one barrier per live pivot (unscaled rows: row j of the factor = G[j][:] / sqrt(piv)) ----
-  // trailing update G[i][r] -= G[j][i] G[j][r] / piv (j < i <= r) on a 16 x 16 grid of threads: thread (ta, tb) owns the
-  // elements i = ta (mod 16), r = tb (mod 16) -- up to 36 of the upper triangle, independent of each other (their LDS round
-  // trips overlap; a wave per row, as mid_gram_chol_kernel does it, is a chain of dependent round trips: 4.8 k cycles per
-  // pivot); block rows that lie at or before the pivot are skipped for the whole block
+  // Blocked right-looking factorisation, panels of 16 rows.  Inside a panel the pivots are taken one by one and only the
+  // panel's own rows are updated (at most 15 rows: a short step per pivot); the rows below receive the whole panel at once,
+  // G[i][r] -= sum_p U[p][i] U[p][r] / piv_p, on a 16 x 16 grid of threads: thread (ta, tb) owns the elements
+  // i = ta (mod 16), r = tb (mod 16) of the upper triangle (up to 36 accumulators in registers), reads 16 values of U per
+  // panel row and touches each of its elements of G once per PANEL -- the unblocked form read and wrote every trailing element
+  // once per PIVOT and paid a barrier for it (2.4 k cycles per pivot on the dense sites).
+  __shared__ double s_invp[16];
   const int ta = tid >> 4, tb = tid & 15;
   int rowb[CG_NC / 16];
 #pragma unroll
   for (int ii = 0; ii < CG_NC / 16; ++ii) rowb[ii] = cg_row(16 * ii + ta);
   const int nblk = (ncols + 15) >> 4;
   int nlv = 0;
-  for (int j = 0; j < ncols; ++j) {
-    const double piv = sG[cg_row(j) + j];                  // every thread reads the same, settled value
-    if (!(piv > thresh) || nlv >= K) continue;             // dead direction (or beyond the K rows: rounding noise): no part
-    if (tid == 0) { sPiv[nlv] = piv; sList[nlv] = (short)j; }
-    ++nlv;
-    const double invp = 1.0 / piv;
-    const int rj = cg_row(j);
-    const int ii0 = (j + 1) >> 4;                          // first block row with an i > j
-    double ui[CG_NC / 16], ur[CG_NC / 16];
+  for (int kb = 0; kb < nblk; ++kb) {
+    const int j0 = 16 * kb, j1 = min(j0 + 16, ncols);
+    for (int j = j0; j < j1; ++j) {
+      const int rj = cg_row(j);
+      const double piv = sG[rj + j];                       // every thread reads the same, settled value
+      const bool live = piv > thresh && nlv < K;           // dead direction (or beyond the K rows: rounding noise): no part
+      if (tid == 0) s_invp[j - j0] = live ? 1.0 / piv : 0.0;
+      if (!live) continue;
+      if (tid == 0) { sPiv[nlv] = piv; sList[nlv] = (short)j; }
+      ++nlv;
+      const double invp = 1.0 / piv;
+      const int nrow = j1 - j - 1, W = ncols - j0;          // panel rows still to update (at most 15)
+      for (int e = tid; e < nrow * W; e += 256) {
+        const int i = j + 1 + e / W, r = j0 + e % W;
+        if (r >= i) sG[cg_row(i) + r] -= sG[rj + i] * invp * sG[rj + r];
+      }
+      __syncthreads();
+    }
+    __syncthreads();                                       // s_invp of the whole panel is settled
+    if (kb + 1 >= nblk) break;
+    double acc[CG_NC / 16][CG_NC / 16];
 #pragma unroll
-    for (int q = 0; q < CG_NC / 16; ++q) {
-      const int i = 16 * q + ta, r = 16 * q + tb;
-      ui[q] = (q >= ii0 && q < nblk && i > j && i < ncols) ? sG[rj + i] * invp : 0.0;
-      ur[q] = (q >= ii0 && q < nblk && r > j && r < ncols) ? sG[rj + r] : 0.0;
+    for (int ii = 0; ii < CG_NC / 16; ++ii)
+#pragma unroll
+      for (int rr = 0; rr < CG_NC / 16; ++rr) acc[ii][rr] = 0.0;
+    for (int p = 0; p < j1 - j0; ++p) {
+      const double ip = s_invp[p];
+      if (ip == 0.0) continue;                             // dropped row (block-uniform)
+      const int rp = cg_row(j0 + p);
+      double ua[CG_NC / 16], ub[CG_NC / 16];
+#pragma unroll
+      for (int q = 0; q < CG_NC / 16; ++q) {
+        const int i = 16 * q + ta, r = 16 * q + tb;
+        ua[q] = (q > kb && q < nblk && i < ncols) ? sG[rp + i] * ip : 0.0;
+        ub[q] = (q > kb && q < nblk && r < ncols) ? sG[rp + r] : 0.0;
+      }
+#pragma unroll
+      for (int ii = 0; ii < CG_NC / 16; ++ii) {
+        if (ii <= kb || ii >= nblk) continue;              // (block-uniform)
+#pragma unroll
+        for (int rr = 0; rr < CG_NC / 16; ++rr) {
+          if (rr < ii || rr >= nblk) continue;
+          acc[ii][rr] = fma(ua[ii], ub[rr], acc[ii][rr]);
+        }
+      }
     }
 #pragma unroll
     for (int ii = 0; ii < CG_NC / 16; ++ii) {
-      if (ii < ii0 || ii >= nblk) continue;                // (block-uniform)
+      if (ii <= kb || ii >= nblk) continue;
       const int i = 16 * ii + ta;
 #pragma unroll
       for (int rr = 0; rr < CG_NC / 16; ++rr) {
         if (rr < ii || rr >= nblk) continue;
         const int r = 16 * rr + tb;
-        if (i > j && r >= i && r < ncols) sG[rowb[ii] + r] -= ui[ii] * ur[rr];
+        if (r >= i && r < ncols) sG[rowb[ii] + r] -= acc[ii][rr];
       }
     }
     __syncthreads();
