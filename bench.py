@@ -54,14 +54,20 @@ def parse():
     ap.add_argument("--no-energy-check", action="store_true", help="skip the E_loc parity sample (device vs float64 oracle)")
     ap.add_argument("--noise", type=float, default=0.1,
                     help="relative noise of the synthetic site tensors (SURVEY 8d: 0.1; 1.0 = full-rank stress case)")
+    ap.add_argument("--state", default="synthetic", choices=["synthetic", "real"],
+                    help="state of the MAIN leg: the SURVEY 8(d) synthetic state (default) or the tiled optimised state of the "
+                         "reference (profiling runs of the real_rank leg)")
     ap.add_argument("--no-full-rank", action="store_true", help="skip the second leg on a state of full rank")
     ap.add_argument("--full-rank-walkers", type=int, default=4096)
     ap.add_argument("--full-rank-steps", type=int, default=2)
+    ap.add_argument("--no-real-rank", action="store_true", help="skip the third leg on the tiled optimised state of the reference")
+    ap.add_argument("--real-rank-walkers", type=int, default=2048)
+    ap.add_argument("--real-rank-steps", type=int, default=2)
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reduction plumbing only, NO device work: value is null (CPU tests of --gpus N)")
     args = ap.parse_args()
     if args.walkers is None:
-        args.walkers = 32768 if (args.dtype == "f32" and args.noise <= 0.15) else 4096
+        args.walkers = 32768 if (args.dtype == "f32" and args.noise <= 0.15 and args.state == "synthetic") else (2048 if args.state == "real" else 4096)
     return args
 
 
@@ -124,10 +130,11 @@ def pmc_traffic_bytes(category, args, nw, launches_per_step):
 class Leg:
     """One timed pass: `steps` batches of `nw` fresh configurations through EvaluateAmplitude on this rank's GPU."""
 
-    def __init__(self, capi, synthetic, L, D, chi, dt, device, nw, noise, fermionic=False):
+    def __init__(self, capi, synthetic, L, D, chi, dt, device, nw, noise, fermionic=False, real=False):
         self.capi, self.synthetic = capi, synthetic
         self.L, self.D, self.chi, self.dt, self.device, self.nw, self.noise = L, D, chi, dt, device, nw, noise
         self.fermion = None
+        self.real = real
         if fermionic:
             # C5: synthetic parity-even state (the reference ships no fermionic state beyond 2x2); a configuration enters the
             # device as the row-major extended states of the decorated components (peps_amd/fermion.py), the graded amplitude
@@ -143,8 +150,15 @@ class Leg:
             return
         self.pdim = 2
         self.ctx = capi.Context(L, L, D, 2, chi, dtype=dt, device=device, max_walkers=nw)
-        # synthetic state of SURVEY 8(d); psi(S_ref) normalisation evaluated with the device path itself
-        sitps = synthetic.make_sitps(L, D, noise=noise)
+        if real:
+            # the reference's own optimised D = 8 state (4x4 fixture), tiled by position class to L x L: site tensors with
+            # the singular spectra of a real PEPS (synthetic.tile_flat_state); configurations near the Neel state
+            from peps_amd import hostapi
+            assert D == 8, "the reference's optimised fixture has D = 8"
+            sitps = synthetic.flat_to_sitps(synthetic.tile_flat_state(hostapi.load_sitps(REAL_STATE, 8), L))
+        else:
+            # synthetic state of SURVEY 8(d); psi(S_ref) normalisation evaluated with the device path itself
+            sitps = synthetic.make_sitps(L, D, noise=noise)
         self.ctx.state_upload(synthetic.sitps_to_flat(sitps, D, np.float64))
         self.ctx.set_configs(synthetic.checkerboard(L)[None])
         psi_ref = float(self.ctx.evaluate_amplitude()[0])
@@ -155,7 +169,8 @@ class Leg:
     def run(self, steps, warmup, rank, world, barrier):
         ctx, nw = self.ctx, self.nw
         total = warmup + steps
-        self.batches = [self.synthetic.make_configs(self.L, nw, "heisenberg", seed0=7 + (s * world + rank) * nw) for s in range(total)]
+        gen = self.synthetic.make_configs_near_neel if self.real else (lambda L, n, seed0: self.synthetic.make_configs(L, n, "heisenberg", seed0=seed0))
+        self.batches = [gen(self.L, nw, seed0=7 + (s * world + rank) * nw) for s in range(total)]
         sig = None
         if self.fermion is not None:      # half filling: state 0 = occupied; device labels + graded sign per configuration
             self.phys = self.batches
@@ -197,7 +212,8 @@ class Leg:
             d.close()
         finally:
             os.environ.pop("PEPSGPU_DEBUG_SWEEPS", None)
-        return {"carry_live_fraction": st["carry_live_fraction"], "noise": self.noise, "jacobi_sweeps_max": st["jacobi_sweeps_max"]}
+        return {"carry_live_fraction": st["carry_live_fraction"], "carry_live_max": st["carry_live_max"], "noise": self.noise,
+                "jacobi_sweeps_max": st["jacobi_sweeps_max"]}
 
     def close(self):
         self.ctx.close()
@@ -378,7 +394,7 @@ def main():
 
     from peps_amd import capi
     dt = capi.F32 if args.dtype == "f32" else capi.F64
-    leg = Leg(capi, synthetic, L, D, chi, dt, local_rank, nw, args.noise, fermionic)
+    leg = Leg(capi, synthetic, L, D, chi, dt, local_rank, nw, args.noise, fermionic, real=args.state == "real")
     elapsed, prof, nz = leg.run(args.steps, args.warmup, rank, world, barrier)
     elapsed = max_over_ranks(elapsed)
 
@@ -417,6 +433,7 @@ def main():
                 "parallelism": "walkers sharded over %d GPU(s), no data-path collective" % world,
                 "flops_per_amplitude_reference_algorithm": fl["total"],
                 "synthetic_noise": args.noise,
+                "state": args.state,
             },
             "roofline": roof,
             "job_tflops_reference_count": value * fl["total"] / 1e12 / world,
@@ -481,34 +498,62 @@ def main():
     leg.close()
     del leg
 
-    # ---- second leg: the same shapes on a state of full rank (i.i.d. random site tensors) ----
-    if not args.no_full_rank and args.noise < 0.5 and not fermionic:
+    # ---- further legs on the same shapes: a state of full rank (i.i.d. random site tensors) and a state of the rank of a
+    #      REAL PEPS (the reference's optimised 4x4 D=8 fixture tiled to L x L, configurations near the Neel state) ----
+    def extra_leg(real, noise, walkers, steps):
         fr = None
+        fleg = None
         try:
-            fnw = min(args.full_rank_walkers, nw)
-            fleg = Leg(capi, synthetic, L, D, chi, dt, local_rank, fnw, 1.0)
-            fel, fprof, fnz = fleg.run(args.full_rank_steps, 1, rank, world, barrier)
-            fel = max_over_ranks(fel)
+            fnw = min(walkers, nw)
+            fleg = Leg(capi, synthetic, L, D, chi, dt, local_rank, fnw, noise, real=real)
+            fel, fprof, fnz = fleg.run(steps, 1, rank, world, barrier)
+        except Exception as e:
+            fr = {"error": repr(e)}
+            fel, fprof, fnz = 0.0, None, 0
+        # every rank reaches the collectives below whatever happened on it: a rank-local failure must not leave the others
+        # waiting in an all-reduce (the failure flag is reduced with MAX, then all ranks skip the leg together)
+        failed = max_over_ranks(1.0 if fr is not None else 0.0) > 0
+        fel = max_over_ranks(fel)
+        if failed:
+            if fleg is not None:
+                fleg.close()
+            return fr if fr is not None else {"error": "another rank failed on this leg"}
+        try:
             if rank == 0:
                 fdom, froof = roofline_of(fprof, args.dtype)
-                fr = {"value": fnw * args.full_rank_steps * world / fel, "unit": "amplitudes/s", "walkers_per_gpu": fnw,
-                      "steps": args.full_rank_steps, "warmup": 1, "ms_per_step": fel / args.full_rank_steps * 1e3,
-                      "synthetic_noise": 1.0, "roofline": froof,
+                fr = {"value": fnw * steps * world / fel, "unit": "amplitudes/s", "walkers_per_gpu": fnw,
+                      "steps": steps, "warmup": 1, "ms_per_step": fel / steps * 1e3,
+                      "state": ("reference fixture tps_square_heisenberg4x4D8Double tiled by position class to %dx%d, "
+                                "configurations = checkerboard + %d random NN exchanges" % (L, L, L * L // 8)) if real
+                               else "i.i.d. random site tensors (synthetic noise 1.0)",
+                      "roofline": froof,
                       "kernel_ms": {k: round(v["ms"], 3) for k, v in fprof.items() if v["launches"]},
                       "mfma": mfma_summary(fprof, args.dtype, fel),
                       "walkers_with_vanishing_amplitude": fnz, "workload_rank": fleg.rank_diagnostics()}
+                if not real:
+                    fr["synthetic_noise"] = noise
                 if world == 1 and not args.no_cpu_baseline:
                     from oracle import cbmps
                     k = min(8, os.cpu_count() or 1)
                     ra, _, _ = cbmps.amplitudes_multiprocess(fleg.flat, fleg.batches[0][:k], chi, k)
-                    fr["parity_on_sample"] = {"max_rel_err_amplitude": float(np.max(np.abs(fleg.amps_first[:k] / ra - 1))),
+                    rel = np.abs(fleg.amps_first[:k] / ra - 1)
+                    fr["parity_on_sample"] = {"max_rel_err_amplitude": float(np.max(rel)), "median_rel_err_amplitude": float(np.median(rel)),
                                               "n": int(k), "tolerance": 1e-5, "checker": "oracle/cbmps.c (float64)"}
-                fr["real_state_rank"] = real_state_rank(capi, local_rank, dt)
-            fleg.close()
         except Exception as e:
             fr = {"error": repr(e)}
+        fleg.close()
+        return fr
+
+    if not args.no_full_rank and args.noise < 0.5 and not fermionic and args.state == "synthetic":
+        fr = extra_leg(False, 1.0, args.full_rank_walkers, args.full_rank_steps)
         if rank == 0:
+            if fr is not None and "error" not in fr:
+                fr["real_state_rank"] = real_state_rank(capi, local_rank, dt)
             out["full_rank"] = fr
+    if not args.no_real_rank and args.noise < 0.5 and not fermionic and args.state == "synthetic" and D == 8 and os.path.isdir(REAL_STATE):
+        rr = extra_leg(True, 0.0, args.real_rank_walkers, args.real_rank_steps)
+        if rank == 0:
+            out["real_rank"] = rr
 
     # ---- the exchange step, outside the timed region: all-reduce of the HBM-resident accumulators over RCCL ----
     if dist is not None and backend == "nccl":

@@ -487,14 +487,14 @@ static void diag_jacobi_t(void *M, int m, int len, int nbatch, int k, void *Vt, 
     PG_REQUIRE(m <= 128 && len <= 128, 1, "regx<4,2> handles up to 128 x 128");
     hipLaunchKernelGGL((jacobi_rows_regx_kernel<4, 2>), dim3(nbatch), dim3(256), 0, 0, (float *)dM, (long)m * len, m, len, len, 40,
                        dsw, (const int *)nullptr, 1);
-  } else if (sizeof(T) == 4 && (force_global == 5 || force_global == 6)) {   // 16-lanes-per-row tournament: 5 = four waves (128 rows), 6 = two (64)
-    PG_REQUIRE(m <= (force_global == 5 ? 128 : 64) && len <= 128, 1, "grouped tournament handles up to 128 (64) x 128");
-    if (force_global == 5)
-      hipLaunchKernelGGL((jacobi_rows_grp_kernel<4, 8>), dim3(nbatch), dim3(256), 0, 0, (float *)dM, (long)m * len, m, len, len, 40,
-                         dsw, (const int *)nullptr, 1);
-    else
-      hipLaunchKernelGGL((jacobi_rows_grp_kernel<2, 8>), dim3(nbatch), dim3(128), 0, 0, (float *)dM, (long)m * len, m, len, len, 40,
-                         dsw, (const int *)nullptr, 1);
+  } else if (sizeof(T) == 4 && force_global >= 5 && force_global <= 8) {
+    // 16-lanes-per-row tournament: 5 = four waves (128 rows), 6 = two (64), rows up to 128 long; 7 / 8 = the same with rows up to 256 long
+    const int wide = force_global >= 7, four = force_global == 5 || force_global == 7;
+    PG_REQUIRE(m <= (four ? 128 : 64) && len <= (wide ? 256 : 128), 1, "grouped tournament handles up to 128 (64) x 128 (256)");
+    if (force_global == 5) launch_jacobi_grp<4, 8>(0, nbatch, (float *)dM, (long)m * len, m, len, len, 40, dsw, (const int *)nullptr, 1, 0);
+    else if (force_global == 6) launch_jacobi_grp<2, 8>(0, nbatch, (float *)dM, (long)m * len, m, len, len, 40, dsw, (const int *)nullptr, 1, 0);
+    else if (force_global == 7) launch_jacobi_grp<4, 16>(0, nbatch, (float *)dM, (long)m * len, m, len, len, 40, dsw, (const int *)nullptr, 1, 0);
+    else launch_jacobi_grp<2, 16>(0, nbatch, (float *)dM, (long)m * len, m, len, len, 40, dsw, (const int *)nullptr, 1, 0);
   } else if (sizeof(T) == 4 && force_global == 3) {   // one-wave-per-walker kernel (up to 32 x 256)
     PG_REQUIRE(m <= JR_SMALL_ROWS && len <= 256, 1, "small Jacobi handles up to 32 x 256");
     // per-walker live row count = rows up to the last non-zero one (mixed counts inside a launch, as in the absorption)

@@ -482,7 +482,12 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     // the preconditioned one-sided Jacobi SVD (Drmac / Veselic): rows are ml <= 128 long instead of u * k2, the
     // triangular factor converges in about half the sweeps, and four walkers share a CU.  sigma and Vt are those of M:
     // select_rows_kernel sees the same singular values, the truncation rule is unchanged.
-    constexpr int MID_HI = 128;
+    // Round 3: the route reaches 256 live rows.  A state of the rank of a real PEPS carries ~190-240 live rows, but M = R Tt is
+    // numerically of rank ~60-100 at the f32 floor (the singular values of the truncation input fall by five orders of magnitude
+    // over the first 32): the Cholesky of M M^T drops the dependent rows, the Jacobi runs on the <= 128 live rows of B (256 long)
+    // instead of on the 240 rows of M (19 sweeps of the 256 x 256 register kernel: 80 % of the step before).
+    static const bool no_dense_mid = getenv("PEPSGPU_NO_DENSE_MID") != nullptr;
+    const int MID_HI = (m > 128 && !no_dense_mid) ? 256 : 128;
     bool mid = false;
     if constexpr (sizeof(T) == 4) {
       static const bool no_mid = getenv("PEPSGPU_NO_MIDROUTE") != nullptr;
@@ -492,7 +497,9 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       mid = !no_mid && adaptive && m > JR_SMALL_ROWS && uk <= 1024 && near;
     }
     int *midflag = nullptr, *nmid = nullptr, *mB = nullptr;
-    DTen<T> Bt, Ut;
+    int *flagA = nullptr, *rowsA = nullptr, *flag2 = nullptr, *rows2 = nullptr, *mB2 = nullptr;   // two-level form (below)
+    bool two_level = false;
+    DTen<T> Bt, Ut, B2;
     const int GS = std::min(m, MID_HI);
     if (mid) {
       midflag = (int *)arena_.alloc(sizeof(int) * nw_);
@@ -510,23 +517,76 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         if (!no_fused_mid)   // G = M M^T and its Cholesky in one kernel, G resident in LDS (trunc_mid.h)
           launch_mid_gram_chol<T>(stream_, nw_, (const T *)M.p, M.n, uk, (const int *)nmid, (const int *)midflag, GS, Bt.p, Bt.n, mB);
       }
-      if (sizeof(T) != 4 || no_fused_mid) {
+      const bool fused_mid_ran = sizeof(T) == 4 && !no_fused_mid;
+      if (!fused_mid_ran || GS > 128) {
+        // the walkers the fused kernel does not take (more than 128 live rows; all of the route without it): Gram through HBM
+        int *hiflag = midflag, *nhi = nmid;
+        if (fused_mid_ran) {
+          hiflag = (int *)arena_.alloc(sizeof(int) * nw_);
+          nhi = (int *)arena_.alloc(sizeof(int) * nw_);
+          hipLaunchKernelGGL(mid_route_flag_kernel, dim3((nw_ + 255) / 256), dim3(256), 0, stream_, (const int *)mdyn[i], mmul[i], m, 128,
+                             MID_HI, nw_, hiflag, nhi);
+          PG_CHECK_HIP(hipGetLastError());
+        }
         double *Gm = (double *)arena_.alloc(sizeof(double) * (size_t)GS * GS * nw_);
         TGemmDesc g;
         g.I[2] = m; g.sAi[2] = uk; g.sCi[2] = GS;
         g.K[2] = uk; g.sAk[2] = 1; g.sBk[2] = 1;
         g.J[2] = m; g.sBj[2] = uk; g.sCj[2] = 1;
         g.wA = M.n; g.wB = M.n; g.wC = (long)GS * GS; g.nbatch = nw_;
-        g.dI[2].p = nmid; g.dJ[2].p = nmid;
+        g.dI[2].p = nhi; g.dJ[2].p = nhi;
         g.upper_only = 1;
-        g.batch_flag = midflag;
-        tgemm_launch<T, T, double, double>(stream_, g, M.p, M.p, Gm);
+        g.batch_flag = hiflag;
+        static const bool no_rowgram = getenv("PEPSGPU_NO_ROWGRAM") != nullptr;
+        bool rowgram = false;
+        if constexpr (sizeof(T) == 4) {
+          if (!no_rowgram && uk % 16 == 0 && M.n % 4 == 0 && m <= 256) {   // streaming wave-per-block kernel (gram.h)
+            launch_gram_rows_f64<T>(stream_, nw_, (const T *)M.p, M.n, uk, m, (const int *)nhi, Gm, (long)GS * GS, GS,
+                                    (const int *)hiflag, tg_flop_counter, tg_byte_counter);
+            rowgram = true;
+          }
+        }
+        if (!rowgram) tgemm_launch<T, T, double, double>(stream_, g, M.p, M.p, Gm);
         const size_t smem = chol_smem_bytes(GS);
         allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
         hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nw_), dim3(256), smem, stream_, Gm, (long)GS * GS, GS, Bt.p, Bt.n, mB, 0, GS,
-                           (const int *)nmid, 1, (const int *)midflag);
+                           (const int *)nhi, 1, (const int *)hiflag);
         PG_CHECK_HIP(hipGetLastError());
         arena_.free(Gm);
+        // Second level (walkers with more than 128 live rows of M whose factor B kept at most 128 rows -- the usual case: the
+        // truncation input of a real PEPS is of numerical rank 60-100): the rows of B are as long as M has live rows (up to
+        // 256), so the same compression is applied once more, B2^T B2 = B B^T (r x r, LDS resident: the fused kernel with B in
+        // the place of M), and the Jacobi runs on the r x r factor B2 (rows <= 128 long: the sixteen-lanes-per-row tournament at
+        // its fast size).  Rotated rows of B2 = sigma_k w_k^T (w: left singular vectors of B); sigma_k u_k^T = w_k^T B.
+        static const bool no_two_level = getenv("PEPSGPU_NO_TWO_LEVEL") != nullptr;
+        if constexpr (sizeof(T) == 4) {
+          if (fused_mid_ran && GS > 128 && !no_two_level) {
+            two_level = true;
+            flagA = (int *)arena_.alloc(sizeof(int) * nw_);
+            rowsA = (int *)arena_.alloc(sizeof(int) * nw_);
+            flag2 = (int *)arena_.alloc(sizeof(int) * nw_);
+            rows2 = (int *)arena_.alloc(sizeof(int) * nw_);
+            mB2 = (int *)arena_.alloc(sizeof(int) * nw_);
+            PG_CHECK_HIP(hipMemsetAsync(mB2, 0, sizeof(int) * nw_, stream_));
+            hipLaunchKernelGGL(mid_split_kernel, dim3((nw_ + 255) / 256), dim3(256), 0, stream_, (const int *)midflag, (const int *)hiflag,
+                               (const int *)mB, 128, nw_, flagA, rowsA, flag2, rows2);
+            PG_CHECK_HIP(hipGetLastError());
+            B2 = alloc_ten(128, 128, 1);
+            launch_mid_gram_chol<T>(stream_, nw_, (const T *)Bt.p, Bt.n, GS, (const int *)rows2, (const int *)flag2, 128, B2.p, B2.n, mB2);
+            if (dbg_sweeps_ && getenv("PEPSGPU_DEBUG_VERBOSE")) {   // diagnostics: rows kept by the two compressions
+              std::vector<int> h1(nw_), h2(nw_), hm(nw_);
+              PG_CHECK_HIP(hipMemcpyAsync(h1.data(), mB, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+              PG_CHECK_HIP(hipMemcpyAsync(h2.data(), mB2, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+              PG_CHECK_HIP(hipMemcpyAsync(hm.data(), nmid, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+              PG_CHECK_HIP(hipStreamSynchronize(stream_));
+              long s0 = 0, s1 = 0, s2 = 0, x0 = 0, x1 = 0, x2 = 0;
+              for (int w = 0; w < nw_; ++w) { s0 += hm[w]; s1 += h1[w]; s2 += h2[w]; x0 = std::max<long>(x0, hm[w]); x1 = std::max<long>(x1, h1[w]); x2 = std::max<long>(x2, h2[w]); }
+              fprintf(stderr, "[pepsgpu] trunc site %d: live rows of M mean %.1f max %ld -> B mean %.1f max %ld -> B2 mean %.1f max %ld\n", i,
+                      (double)s0 / nw_, x0, (double)s1 / nw_, x1, (double)s2 / nw_, x2);
+            }
+          }
+        }
+        if (fused_mid_ran) { arena_.free(hiflag); arena_.free(nhi); }
       }
       prof_end();
     }
@@ -584,12 +644,24 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
             if (GS > 64)
               hipLaunchKernelGGL((jacobi_rows_regx_kernel<4, 2>), dim3(nw_), dim3(256), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS,
                                  40, sweeps_, (const int *)mB, 1, 64);
+          } else if (GS <= 128) {
+            launch_jacobi_grp<2, 8>(stream_, nw_, (float *)Bt.p, Bt.n, GS, GS, GS, 40, sweeps_, (const int *)mB, 1, 0);
+            if (GS > 64) launch_jacobi_grp<4, 8>(stream_, nw_, (float *)Bt.p, Bt.n, GS, GS, GS, 40, sweeps_, (const int *)mB, 1, 64);
+          } else if (two_level) {
+            // on B itself: the walkers with at most 128 live rows of M (B at most 128 columns wide) and, on the 256 x 256
+            // register kernel, those whose factor kept more than 128 rows; on B2: everybody else
+            launch_jacobi_grp<2, 8>(stream_, nw_, (float *)Bt.p, Bt.n, GS, 128, GS, 40, sweeps_, (const int *)rowsA, 1, 0);
+            launch_jacobi_grp<4, 8>(stream_, nw_, (float *)Bt.p, Bt.n, GS, 128, GS, 40, sweeps_, (const int *)rowsA, 1, 64);
+            hipLaunchKernelGGL(jacobi_rows_reg256_kernel, dim3(nw_), dim3(512), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS, 40,
+                               sweeps_, (const int *)rowsA, 1, 128);
+            launch_jacobi_grp<2, 8>(stream_, nw_, (float *)B2.p, B2.n, 128, 128, 128, 40, sweeps_, (const int *)mB2, 1, 0);
+            launch_jacobi_grp<4, 8>(stream_, nw_, (float *)B2.p, B2.n, 128, 128, 128, 40, sweeps_, (const int *)mB2, 1, 64);
           } else {
-            hipLaunchKernelGGL((jacobi_rows_grp_kernel<2, 8>), dim3(nw_), dim3(128), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS,
-                               40, sweeps_, (const int *)mB, 1, 0);
-            if (GS > 64)
-              hipLaunchKernelGGL((jacobi_rows_grp_kernel<4, 8>), dim3(nw_), dim3(256), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS,
-                                 40, sweeps_, (const int *)mB, 1, 64);
+            // rows of B up to 256 long (sixteen columns per lane); more than 128 live rows of B: the 256 x 256 register kernel
+            launch_jacobi_grp<2, 16>(stream_, nw_, (float *)Bt.p, Bt.n, GS, GS, GS, 40, sweeps_, (const int *)mB, 1, 0);
+            launch_jacobi_grp<4, 16>(stream_, nw_, (float *)Bt.p, Bt.n, GS, GS, GS, 40, sweeps_, (const int *)mB, 1, 64);
+            hipLaunchKernelGGL(jacobi_rows_reg256_kernel, dim3(nw_), dim3(512), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS, 40,
+                               sweeps_, (const int *)mB, 1, 128);
           }
           PG_CHECK_HIP(hipGetLastError());
         }
@@ -620,10 +692,41 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       PG_CHECK_HIP(hipMemsetAsync(kB, 0, sizeof(int) * nw_, stream_));
       Ut = alloc_ten(k, GS, 1);
       hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)Bt.p, Bt.n, GS, GS, GS, k, Ut.p,
-                         Ut.n, (T *)nullptr, 0L, (const int *)mB, 1, kB, trunc_err_, chi_min_, (double *)nullptr,
-                         (const int *)midflag, 1);
+                         Ut.n, (T *)nullptr, 0L, (const int *)(two_level ? rowsA : mB), 1, kB, trunc_err_, chi_min_, (double *)nullptr,
+                         (const int *)(two_level ? flagA : midflag), 1);
       PG_CHECK_HIP(hipGetLastError());
       prof_end();
+      if (two_level) {
+        // W = the chi largest rotated rows of B2, normalised (truncation rule applied here); U^T = rows of W B, normalised
+        int *kB2 = (int *)arena_.alloc(sizeof(int) * nw_);
+        PG_CHECK_HIP(hipMemsetAsync(kB2, 0, sizeof(int) * nw_, stream_));
+        DTen<T> W = alloc_ten(k, 128, 1), T1 = alloc_ten(k, GS, 1);
+        prof_begin(PROF_SELECT, 0.0, 0.0);
+        hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)B2.p, B2.n, 128, 128, 128, k, W.p,
+                           W.n, (T *)nullptr, 0L, (const int *)mB2, 1, kB2, trunc_err_, chi_min_, (double *)nullptr,
+                           (const int *)flag2, 1);
+        PG_CHECK_HIP(hipGetLastError());
+        prof_end();
+        {
+          TGemmDesc g;
+          g.I[2] = k; g.sAi[2] = 128; g.sCi[2] = GS;
+          g.K[2] = 128; g.sAk[2] = 1; g.sBk[2] = GS;
+          g.J[2] = GS; g.sBj[2] = 1; g.sCj[2] = 1;
+          g.wA = W.n; g.wB = Bt.n; g.wC = T1.n; g.nbatch = nw_;
+          g.dK[2].p = rows2;
+          g.batch_flag = flag2;
+          prof_begin(PROF_TRUNC_APPLY, 0.0, 0.0);
+          tgemm_launch<T, T, T, double>(stream_, g, W.p, Bt.p, T1.p);
+          prof_end();
+        }
+        prof_begin(PROF_SELECT, 0.0, 0.0);
+        hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)T1.p, T1.n, k, GS, GS, k, Ut.p,
+                           Ut.n, (T *)nullptr, 0L, (const int *)kB2, 1, kB, 0.0, 0, (double *)nullptr, (const int *)flag2, 1);
+        PG_CHECK_HIP(hipGetLastError());
+        prof_end();
+        free_ten(W); free_ten(T1); free_ten(B2);
+        arena_.free(kB2); arena_.free(flagA); arena_.free(rowsA); arena_.free(flag2); arena_.free(rows2); arena_.free(mB2);
+      }
       // V' = U^T M (k x uk): row q is sigma_q v_q^T up to the rounding of u_q -- an error of 1e-7 in u_q brings in the
       // dominant directions with weight 1e-7 sigma_1, which is NOT small against a row of size sigma_q << sigma_1.  So the k
       // rows are not normalised as they come: they are handed to the one-sided Jacobi once more (a k-row problem: the

@@ -132,4 +132,109 @@ inline void launch_gram_cols_f64(hipStream_t s, int nbatch, const T *P, long wP,
   PG_CHECK_HIP(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row Gram of the truncation input (round 3: the route for walkers with more than 128 live carry rows):
+//
+//     G[b] = M[b] M[b]^T,   M = n x K row-major (n = nrows[b] <= 256 live rows, K = row length, multiple of 16, row stride K),
+//     G = ldg x ldg float64, upper blocks only
+//
+// Same shape of work as above (one wave = one 64 x 64 block of G in 16 accumulator tiles, no LDS, no barrier), but the
+// contracted index runs ALONG the rows of M: lane (c16, r4) loads M[i0 + c16][16 s + 4 r4 .. + 3] as one 16-byte vector and
+// feeds element t of it to MFMA t of the step -- the k index a lane supplies to an MFMA is any bijection of the 16 k of the
+// step as long as the A and the B operand use the same one.  Per 16 k: 8 vector loads per lane, 64 MFMAs.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gram_rows_f64_kernel(const T *__restrict__ Mg, long wM, int K, const int *__restrict__ nrows,
+                                                               double *__restrict__ Gg, long wG, int ldg,
+                                                               const int *__restrict__ run_flag,
+                                                               unsigned long long *__restrict__ flopc,
+                                                               unsigned long long *__restrict__ bytec) {
+  static_assert(sizeof(T) == 4, "f32 input");
+  const int b = blockIdx.y;
+  if (run_flag && run_flag[b] >= 0) return;
+  const int n = nrows[b];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nb = (n + 63) >> 6, nblk = nb * (nb + 1) / 2;
+  const int t = blockIdx.x * 4 + wave;
+  if (t >= nblk) return;
+  int bi = 0, rem = t;
+  while (rem >= nb - bi) { rem -= nb - bi; ++bi; }
+  const int bj = bi + rem;
+  if (flopc && t == 0 && lane == 0) {
+    atomicAdd(flopc, (unsigned long long)n * n * K);
+    if (bytec) atomicAdd(bytec, (unsigned long long)n * K * 4ull + (unsigned long long)n * n * 4ull);
+  }
+  const T *M = Mg + (long)b * wM;
+  double *G = Gg + (long)b * wG;
+  const int r4 = lane >> 4, c16 = lane & 15;
+  const bool diag = bi == bj;
+  typedef float gr_f32x4 __attribute__((ext_vector_type(4)));
+  const gr_f32x4 *pa[4], *pb[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {       // rows beyond n: clamped address, the products land in rows / columns that are not stored
+    pa[c] = reinterpret_cast<const gr_f32x4 *>(M + (long)min(bi * 64 + 16 * c + c16, n - 1) * K + 4 * r4);
+    pb[c] = reinterpret_cast<const gr_f32x4 *>(M + (long)min(bj * 64 + 16 * c + c16, n - 1) * K + 4 * r4);
+  }
+  gr_f64x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][c][r] = 0.0;
+  const int ns = K >> 4;
+  gr_f32x4 av[2][4], bv[2][4];
+  auto load = [&](int s, gr_f32x4(&x)[4], gr_f32x4(&y)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) x[c] = pa[c][4 * s];
+    if (!diag) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) y[c] = pb[c][4 * s];
+    }
+  };
+  auto step = [&](const gr_f32x4(&x)[4], const gr_f32x4(&y)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double ad[4], bd[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ad[c] = (double)x[c][q];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bd[c] = diag ? ad[c] : (double)y[c][q];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[a], bd[c], acc[a][c], 0, 0, 0);
+    }
+  };
+  if (ns > 0) load(0, av[0], bv[0]);
+  for (int s = 0; s < ns; s += 2) {
+    if (s + 1 < ns) load(s + 1, av[1], bv[1]);
+    step(av[0], bv[0]);
+    if (s + 1 < ns) {
+      if (s + 2 < ns) load(s + 2, av[0], bv[0]);
+      step(av[1], bv[1]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = bi * 64 + 16 * a + r4 + 4 * r, j = bj * 64 + 16 * c + c16;
+        if (i < n && j < n) G[(long)i * ldg + j] = acc[a][c][r];
+      }
+}
+
+template <typename T>
+inline void launch_gram_rows_f64(hipStream_t s, int nbatch, const T *M, long wM, int K, int nmax, const int *nrows, double *G, long wG,
+                                 int ldg, const int *run_flag, unsigned long long *flopc, unsigned long long *bytec) {
+  if (nbatch <= 0 || nmax <= 0) return;
+  PG_REQUIRE(nbatch <= 65535, 1, "walker batch exceeds 65535 (grid y limit)");
+  PG_REQUIRE(K % 16 == 0 && wM % 4 == 0, 1, "row Gram: row length must be a multiple of 16");
+  const int nb = (nmax + 63) / 64, nblk = nb * (nb + 1) / 2;
+  hipLaunchKernelGGL(gram_rows_f64_kernel<T>, dim3((nblk + 3) / 4, nbatch), dim3(256), 0, s, M, wM, K, nrows, G, wG, ldg, run_flag, flopc,
+                     bytec);
+  PG_CHECK_HIP(hipGetLastError());
+}
+
 }  // namespace pepsgpu

@@ -570,7 +570,8 @@ __global__ __launch_bounds__(NW * 64) void jacobi_rows_grp_kernel(float *__restr
                                                                   const int *__restrict__ mdyn, int mdyn_mul,
                                                                   int lo_rows = 0) {
   constexpr int NP = 4 * NW, SLOTS = NP + 1, MAXR = NP * 2 * JG_RB, NT = NW * 64;
-  __shared__ float xch[SLOTS][JG_RB][CPL][16];
+  extern __shared__ float jg_dyn[];                       // exchange slots (dynamic: 70 KB at NW = 4, CPL = 16)
+  float (*xch)[JG_RB][CPL][16] = reinterpret_cast<float (*)[JG_RB][CPL][16]>(jg_dyn);   // [SLOTS][JG_RB][CPL][16]
   __shared__ float xnorm[SLOTS][JG_RB];
   __shared__ float s_n2[MAXR];
   __shared__ short s_perm[MAXR];
@@ -761,6 +762,15 @@ __global__ __launch_bounds__(NW * 64) void jacobi_rows_grp_kernel(float *__restr
   store_block(a, w);
   store_block(b, np + w);
   if (tid == 0 && sweeps_out) sweeps_out[blockIdx.x] = sweep | (live0 << 8);
+}
+
+template <int NW, int CPL>
+inline void launch_jacobi_grp(hipStream_t s, int nbatch, float *M, long wM, int m, int len, int ld, int max_sweeps, int *sweeps_out,
+                              const int *mdyn, int mdyn_mul, int lo_rows) {
+  const size_t smem = sizeof(float) * (size_t)(4 * NW + 1) * JG_RB * CPL * 16;
+  allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_grp_kernel<NW, CPL>), smem);
+  hipLaunchKernelGGL((jacobi_rows_grp_kernel<NW, CPL>), dim3(nbatch), dim3(NW * 64), smem, s, M, wM, m, len, ld, max_sweeps, sweeps_out,
+                     mdyn, mdyn_mul, lo_rows);
 }
 
 // ---------------------------------------------------------------------------------------------

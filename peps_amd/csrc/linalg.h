@@ -1212,6 +1212,24 @@ __global__ void mid_route_flag_kernel(const int *__restrict__ mdyn, int mdyn_mul
   nmid[b] = mid ? ml : 0;
 }
 
+// Two-level form of the route: of the walkers with more than 128 live rows of M (hiflag) those whose factor B kept at most
+// `cap` rows (mB) go through a second compression (flag2 / rows2); all other walkers of the route run their Jacobi on B itself
+// (flagA / rowsA).
+__global__ void mid_split_kernel(const int *__restrict__ midflag, const int *__restrict__ hiflag, const int *__restrict__ mB, int cap,
+                                 int nbatch, int *__restrict__ flagA, int *__restrict__ rowsA, int *__restrict__ flag2,
+                                 int *__restrict__ rows2) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbatch) return;
+  const bool mid = midflag[b] < 0, hi = hiflag[b] < 0;
+  const int r = mB[b];
+  const bool two = mid && hi && r > 0 && r <= cap;
+  flag2[b] = two ? -1 : 0;
+  rows2[b] = two ? r : 0;
+  const bool a = mid && !two;
+  flagA[b] = a ? -1 : 0;
+  rowsA[b] = a ? r : 0;
+}
+
 // x[b][0..n) /= |x|;  logscale[b] += log|x|;  zero / non-finite norm sets flag[b] = 1.
 template <typename T>
 __global__ __launch_bounds__(256) void normalize_kernel(T *__restrict__ Xg, long wX, int n,

@@ -79,3 +79,62 @@ def sitps_to_flat(sitps, D, dtype=np.float64):
                 t = sitps[r][c][s]
                 flat[r, c, s, :t.shape[0], :t.shape[1], :t.shape[2], :t.shape[3]] = t
     return flat
+
+
+REAL_FIXTURE = "tps_square_heisenberg4x4D8Double"
+
+
+def tile_flat_state(flat_small, L):
+    """A L x L state of the rank of a real PEPS: the site tensors of a small optimised state (flat upload layout
+    [r][c][s][L][D][R][U] of an l x l lattice, l >= 4 even) repeated by POSITION CLASS -- the four corners, the edge
+    tensors, and the interior tensors with the period of the small lattice's interior ((l-2) x (l-2)).  Leg dimensions
+    match by construction (boundary legs 1, bulk legs D); the bond gauges of neighbouring copies do not, so this is not a
+    physical state -- it is a workload whose site tensors have the singular spectra of a VMC-optimised PEPS (the
+    reference ships no optimised state beyond 4 x 4: tests/slow_tests/test_data/tps_square_heisenberg4x4D8Double,
+    test_boson_mc_peps_measure.cpp:55-62)."""
+    l = flat_small.shape[0]
+    assert flat_small.shape[1] == l and l >= 4 and L >= l
+    per = l - 2
+
+    def cls(x):
+        return 0 if x == 0 else (l - 1 if x == L - 1 else 1 + (x - 1) % per)
+
+    idx = [cls(x) for x in range(L)]
+    return np.ascontiguousarray(flat_small[np.ix_(idx, idx)])
+
+
+def flat_to_sitps(flat, dtype=np.float64):
+    """Inverse of sitps_to_flat: per-site component arrays with their true leg dimensions (boundary legs 1)."""
+    L, D = flat.shape[0], flat.shape[3]
+    out = []
+    for r in range(L):
+        row = []
+        for c in range(L):
+            dl, dd, dr, du = bond_dims(L, D, r, c)
+            row.append([np.ascontiguousarray(flat[r, c, s, :dl, :dd, :dr, :du]).astype(dtype) for s in range(flat.shape[2])])
+        out.append(row)
+    return out
+
+
+def make_configs_near_neel(L, n_walkers, n_swaps=None, seed0=7):
+    """Configurations of the kind a Monte-Carlo run on an antiferromagnetic state visits: the checkerboard with `n_swaps`
+    random nearest-neighbour exchanges applied (default L*L/8), rng(seed0 + w).  (Uniformly random Sz = 0 shuffles have
+    amplitudes ~25 orders of magnitude below the typical one on an optimised Heisenberg state: no chain ever sits there.)"""
+    if n_swaps is None:
+        n_swaps = L * L // 8
+    out = np.empty((n_walkers, L, L), dtype=np.int32)
+    base = checkerboard(L)
+    for w in range(n_walkers):
+        rng = np.random.default_rng(seed0 + w)
+        cfg = base.copy()
+        for _ in range(n_swaps):
+            r, c = int(rng.integers(0, L)), int(rng.integers(0, L))
+            if rng.integers(0, 2):
+                r2, c2 = r, c + 1
+            else:
+                r2, c2 = r + 1, c
+            if r2 >= L or c2 >= L:
+                continue
+            cfg[r, c], cfg[r2, c2] = cfg[r2, c2], cfg[r, c]
+        out[w] = cfg
+    return out

@@ -373,17 +373,21 @@ def test_chained_contraction_pair_with_live_extents():
             assert fl[0] == -1
 
 
-@pytest.mark.parametrize("kernel", [4, 5, 6])
-@pytest.mark.parametrize("shape", [(128, 128), (70, 70), (96, 96), (33, 64), (100, 128), (17, 40), (64, 64), (5, 16), (61, 128)])
+@pytest.mark.parametrize("kernel", [4, 5, 6, 7, 8])
+@pytest.mark.parametrize("shape", [(128, 128), (70, 70), (96, 96), (33, 64), (100, 128), (17, 40), (64, 64), (5, 16), (61, 128),
+                                   (128, 256), (90, 241), (64, 256), (40, 200)])
 def test_jacobi_mid_route_kernel(shape, kernel):
     """Tournament kernels of the preconditioned mid route (up to 128 x 128) on triangular, graded input (the Cholesky factor
     they are given in the absorption): singular values, orthonormal Vt and dominant subspace against LAPACK.  kernel 4:
     jacobi_rows_regx_kernel<4,2> (a row over 64 lanes); 5 / 6: jacobi_rows_grp_kernel<4,8> / <2,8> (16 lanes per row, four
-    pairs per wave instruction; the two-wave form takes up to 64 rows)."""
+    pairs per wave instruction; the two-wave form takes up to 64 rows); 7 / 8: <4,16> / <2,16>, rows up to 256 long (round 3: the
+    route for walkers with up to 256 live carry rows, whose factor B keeps <= 128 live rows of length 256)."""
     capi = _capi()
     m, ln = shape
-    if kernel == 6 and m > 64:
+    if kernel in (6, 8) and m > 64:
         pytest.skip("two-wave tournament: up to 64 rows")
+    if kernel < 7 and ln > 128:
+        pytest.skip("rows up to 128 long")
     rng = np.random.default_rng(5 * m + ln)
     nb = 5
     M = np.stack([np.triu(rng.standard_normal((m, ln))) * np.logspace(0, -5, m)[:, None] for _ in range(nb)])

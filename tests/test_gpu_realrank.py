@@ -1,0 +1,104 @@
+"""End-to-end parity of the absorption at the numerical rank of a REAL PEPS: the reference's own optimised D = 8 Heisenberg
+state (tests/slow_tests/test_data/tps_square_heisenberg4x4D8Double, used at test_boson_mc_peps_measure.cpp:55-62) tiled by
+position class to larger lattices (peps_amd.synthetic.tile_flat_state).  Its carry is ~0.9 dense within its shapes, so at bulk
+shapes (carry D * chi = 256 rows) the f32 route above 128 live rows runs: device amplitude AND XXZ local energy against the
+float64 oracle, with ctx.stats() proving the route (carry_live_max > 128).  Configurations: checkerboard + random
+nearest-neighbour exchanges (what a Monte-Carlo chain on an antiferromagnetic state visits)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import vmc
+from oracle.bmps import BMPSTruncateParams
+from peps_amd import synthetic
+
+from conftest import FIXTURES
+
+pytestmark = pytest.mark.gpu
+F32, F64 = 0, 1
+REAL = os.path.join(FIXTURES, synthetic.REAL_FIXTURE)
+
+
+def _state(L, D=8):
+    """tiled state (flat upload layout), rescaled so that psi(checkerboard) = O(1)"""
+    from peps_amd import capi, hostapi
+    f4 = hostapi.load_sitps(REAL, 8)
+    if D < 8:        # a D < 8 variant for the C3 shapes: the leading D x D x D x D corner of every tensor
+        f4 = np.ascontiguousarray(f4[:, :, :, :D, :D, :D, :D])
+    flat = synthetic.tile_flat_state(f4, L)
+    ctx = capi.Context(L, L, D, 2, 4 * D, dtype=capi.F64, max_walkers=1)
+    ctx.state_upload(flat)
+    ctx.set_configs(synthetic.checkerboard(L)[None])
+    psi = float(ctx.evaluate_amplitude()[0])
+    ctx.close()
+    return flat * abs(psi) ** (-1.0 / (L * L))
+
+
+def _oracle(flat, cfgs, chi):
+    sitps = synthetic.flat_to_sitps(flat)
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    model = vmc.SquareSpinOneHalfXXZModelOBC(1.0, 1.0, 0.0)
+    ref_a, ref_e = [], []
+    for c in cfgs:
+        comp = vmc.TPSWaveFunctionComponent(sitps, c, tp)
+        ref_a.append(comp.amplitude)
+        ref_e.append(model.CalEnergyAndHoles(sitps, comp, False)[0])
+    return np.array(ref_a), np.array(ref_e)
+
+
+CASES = [("6x6 D=8 chi=32", 6, 8, 32, 128), ("8x8 D=8 chi=32", 8, 8, 32, 128), ("C3 shapes 10x10 D=6 chi=24", 10, 6, 24, 72)]
+
+
+@pytest.mark.parametrize("name,L,D,chi,live_min", CASES)
+@pytest.mark.parametrize("dt,tol_a,tol_e", [(F32, 1e-5, 1e-6), (F64, 1e-9, 1e-9)])
+def test_real_rank_amplitude_and_energy_vs_oracle(name, L, D, chi, live_min, dt, tol_a, tol_e, monkeypatch):
+    from peps_amd import capi, hostapi
+    flat = _state(L, D)
+    cfgs = synthetic.make_configs_near_neel(L, 3 if L >= 10 else 4, seed0=211)
+    ref_a, ref_e = _oracle(flat, cfgs, chi)
+    monkeypatch.setenv("PEPSGPU_DEBUG_SWEEPS", "1")
+    ctx = capi.Context(L, L, D, 2, chi, dtype=dt, max_walkers=len(cfgs))
+    monkeypatch.delenv("PEPSGPU_DEBUG_SWEEPS")
+    ctx.state_upload(flat)
+    ctx.set_configs(cfgs)
+    amps = ctx.evaluate_amplitude()
+    st = ctx.stats()
+    assert np.all(ctx.walker_flags() == 0)
+    ctx.close()
+    assert st["carry_live_max"] > live_min, st       # the dense route: more than 128 live carry rows (of D * chi = 256)
+    assert np.max(np.abs(amps / ref_a - 1)) < tol_a, (amps, ref_a)
+    a2, en, _, psi = hostapi.energy_and_holes(flat, cfgs, chi, "xxz", (1.0, 1.0, 0.0), False, dt)
+    assert np.max(np.abs(a2 / ref_a - 1)) < tol_a
+    assert np.max(np.abs(en / ref_e - 1)) < tol_e, (en, ref_e)
+
+
+def test_real_rank_c4_batch_f32_vs_f64_and_routes():
+    """C4 at scale on the tiled state (no oracle sample can afford it): 128 walkers, f32 against the f64 device mode (pinned to
+    the oracle above) within 1e-5, row- against column-contraction within 2e-5, live carry > 128 rows, no walker flagged."""
+    from peps_amd import capi
+    L, D, chi, _ = synthetic.CONFIGS["C4"]
+    flat = _state(L)
+    cfgs = synthetic.make_configs_near_neel(L, 128, seed0=307)
+    amps = {}
+    for dt in (capi.F32, capi.F64):
+        os.environ["PEPSGPU_DEBUG_SWEEPS"] = "1"
+        try:
+            ctx = capi.Context(L, L, D, 2, chi, dtype=dt, max_walkers=len(cfgs))
+        finally:
+            os.environ.pop("PEPSGPU_DEBUG_SWEEPS", None)
+        ctx.state_upload(flat)
+        ctx.set_configs(cfgs)
+        amps[dt] = ctx.evaluate_amplitude()
+        assert np.all(ctx.walker_flags() == 0)
+        st = ctx.stats()
+        assert st["carry_live_max"] > 128, st
+        if dt == capi.F32:
+            ctx.grow_bmps_for_col(0)
+            ctx.init_bten(capi.UP, 0)
+            ctx.grow_full_bten(capi.DOWN, 0, 2, True)
+            a_col = ctx.trace(0, 0, capi.VERTICAL)
+            assert np.max(np.abs(a_col / amps[dt] - 1)) < 2e-5
+        ctx.close()
+    rel = np.abs(amps[capi.F32] / amps[capi.F64] - 1)
+    assert np.max(rel) < 1e-5, (int(np.argmax(rel)), float(np.max(rel)))
