@@ -211,9 +211,10 @@ int pepsgpu_sync(pepsgpu_ctx *ctx);
  * carry rank was needed after all: performance hints only, results never depend on them) */
 int pepsgpu_stats(pepsgpu_ctx *ctx, double *stats_out, int n);
 /* Per-kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).
- * out = [10][5]: {ms, launches, algorithmic flops, executed flops, operand + result bytes of the live extents} per category
+ * out = [11][5]: {ms, launches, algorithmic flops, executed flops, operand + result bytes of the live extents} per category
  * 0 contraction GEMMs, 1 f64 Gram, 2 Cholesky, 3 Jacobi, 4 select, 5 normalise, 6 BTen/trace GEMMs, 7 Jacobi of edge blocks,
- * 8 Gram + Cholesky of the preconditioned truncation (mid-rank route), 9 its back-multiplication.
+ * 8 Gram + Cholesky of the preconditioned truncation (mid-rank route), 9 its back-multiplication, 10 the chained contraction
+ * kernel alone (tgemm_chain_kernel: one bracket per launch of that kernel; NOT included in category 0).
  * "algorithmic" = flops of the reference op the launch replaces (SURVEY.md 8d formulas). */
 int pepsgpu_profile_enable(pepsgpu_ctx *ctx, int on);
 int pepsgpu_profile_read(pepsgpu_ctx *ctx, double *out);
@@ -237,6 +238,11 @@ int pepsgpu_comm_destroy(pepsgpu_ctx *ctx);
 int pepsgpu_allreduce(pepsgpu_ctx *ctx, void *buf, long n, int dtype, int op, int on_device);
 /* S_O and S_EO of pepsgpu_grad_accumulate summed over the ranks where they live (HBM), before pepsgpu_grad_read. */
 int pepsgpu_grad_allreduce(pepsgpu_ctx *ctx);
+/* Broadcast of the parameter buffer after an optimizer update: the flat SITPS of rank `root` (pepsgpu_state_upload there)
+ * goes to the HBM state buffer of every rank of the context's communicator with one ncclBroadcast over xGMI -- no host upload
+ * on the other ranks.  Replaces the per-tensor MPI_Bcast of SplitIndexTPS (two_dim_tn/tps/split_index_tps_impl.h:778-880,
+ * called at algorithm/vmc_update/mc_energy_grad_evaluator.h:161).  Collective over the ranks; one rank: marks the state valid. */
+int pepsgpu_bcast_state(pepsgpu_ctx *ctx, int root);
 /* device pointers of the two float64 accumulators ([row][col][s][D^4 slot], n_elems each) for hosts that run their own
  * collective on them (torch.distributed backend "nccl" = RCCL: peps_amd/dist.py wraps them without a copy). */
 int pepsgpu_grad_device_ptr(pepsgpu_ctx *ctx, void **so_dev, void **seo_dev, long *n_elems);

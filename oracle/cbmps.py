@@ -73,15 +73,22 @@ def amplitudes(sitps_flat, configs, chi, nthreads=1):
 def _chunk(args):
     flat, cfgs, chi = args
     if len(cfgs) == 0:
-        return np.zeros(0)
+        return np.zeros(0), 0.0
+    import time
+    t0 = time.perf_counter()
     a, _ = amplitudes(flat, cfgs, chi, nthreads=1)
-    return a
+    return a, time.perf_counter() - t0
 
 
 def amplitudes_multiprocess(sitps_flat, configs, chi, nprocs):
     """configs sharded round-robin over `nprocs` single-threaded worker processes; returns (amplitudes, wall seconds of the
     compute, processes used).  Starts a child interpreter (see above)."""
-    import json
+    d = amplitudes_multiprocess_detail(sitps_flat, configs, chi, nprocs)
+    return d["amps"], d["seconds"], d["nprocs"]
+
+
+def amplitudes_multiprocess_detail(sitps_flat, configs, chi, nprocs):
+    """the same, with the busy seconds of every worker process (`proc_seconds`: how evenly the host ran them)"""
     import sys
     import tempfile
     with tempfile.TemporaryDirectory() as td:
@@ -94,7 +101,7 @@ def amplitudes_multiprocess(sitps_flat, configs, chi, nprocs):
         if r.returncode != 0:
             raise RuntimeError("oracle.cbmps child failed: " + r.stdout[-2000:] + r.stderr[-2000:])
         res = np.load(os.path.join(td, "job.npz.out.npz"))
-        return res["amps"], float(res["seconds"]), int(res["nprocs"])
+        return {"amps": res["amps"], "seconds": float(res["seconds"]), "nprocs": int(res["nprocs"]), "proc_seconds": res["proc_seconds"]}
 
 
 def _child_main(job):
@@ -112,9 +119,9 @@ def _child_main(job):
         parts = pool.map(_chunk, [(flat, s, chi) for s in shards], chunksize=1)
         sec = time.perf_counter() - t0
     amps = np.zeros(len(cfgs))
-    for i, p in enumerate(parts):
+    for i, (p, _) in enumerate(parts):
         amps[i::nprocs] = p
-    np.savez(job + ".out.npz", amps=amps, seconds=sec, nprocs=nprocs)
+    np.savez(job + ".out.npz", amps=amps, seconds=sec, nprocs=nprocs, proc_seconds=np.array([t for _, t in parts]))
 
 
 if __name__ == "__main__":

@@ -32,7 +32,7 @@ SYMBOLS = [
     "pepsgpu_init_bten2", "pepsgpu_grow_full_bten2", "pepsgpu_grow_bten2_step", "pepsgpu_shift_bten2_window",
     "pepsgpu_bten2_stack_size", "pepsgpu_replace_nnn_trace", "pepsgpu_replace_tnn_trace",
     "pepsgpu_replace_sqrt5_trace",
-    "pepsgpu_grad_reset", "pepsgpu_grad_accumulate", "pepsgpu_grad_accumulate_states", "pepsgpu_grad_read", "pepsgpu_grad_device_ptr", "pepsgpu_grad_allreduce",
+    "pepsgpu_grad_reset", "pepsgpu_grad_accumulate", "pepsgpu_grad_accumulate_states", "pepsgpu_grad_read", "pepsgpu_grad_device_ptr", "pepsgpu_grad_allreduce", "pepsgpu_bcast_state",
     "pepsgpu_comm_unique_id", "pepsgpu_comm_init", "pepsgpu_comm_size", "pepsgpu_comm_rank", "pepsgpu_comm_destroy",
     "pepsgpu_allreduce",
     "pepsgpu_sr_begin", "pepsgpu_sr_append", "pepsgpu_sr_count", "pepsgpu_sr_sum", "pepsgpu_sr_matvec",
@@ -86,6 +86,7 @@ def load_library(path=LIB_PATH):
     lib.pepsgpu_grad_read.argtypes = [vp, dp, dp]
     lib.pepsgpu_grad_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_long)]
     lib.pepsgpu_grad_allreduce.argtypes = [vp]
+    lib.pepsgpu_bcast_state.argtypes = [vp, C.c_int]
     lib.pepsgpu_comm_unique_id.argtypes = [vp]
     lib.pepsgpu_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     lib.pepsgpu_comm_size.argtypes = [vp]
@@ -370,6 +371,10 @@ class Context:
         self._ck(self._l.pepsgpu_grad_device_ptr(self._h, C.byref(so), C.byref(seo), C.byref(n)))
         return so.value, seo.value, n.value
 
+    def bcast_state(self, root=0):
+        """ncclBroadcast of the flat SITPS in HBM from rank `root` over the context's communicator (comm_init)"""
+        self._ck(self._l.pepsgpu_bcast_state(self._h, int(root)))
+
     def grad_allreduce(self):
         self._ck(self._l.pepsgpu_grad_allreduce(self._h))
 
@@ -418,7 +423,7 @@ class Context:
         self._ck(self._l.pepsgpu_sync(self._h))
 
     PROF_CATS = ("contract", "gram_f64", "cholesky", "jacobi", "select", "normalize", "env", "jacobi_edge", "trunc_gram",
-                 "trunc_apply")
+                 "trunc_apply", "contract_chain")
 
     def profile_enable(self, on=True):
         self._ck(self._l.pepsgpu_profile_enable(self._h, int(on)))

@@ -216,6 +216,12 @@ int pepsgpu_allreduce(pepsgpu_ctx *ctx, void *buf, long n, int dtype, int op, in
            ctx->comm.allreduce((hipStream_t)ctx->eng->stream_handle(), buf, (size_t)n, dtype, op, on_device != 0);
            if (on_device) ctx->eng->sync());
 }
+int pepsgpu_bcast_state(pepsgpu_ctx *ctx, int root) {
+  CTX_CALL(void *p = nullptr; size_t bytes = 0; ctx->eng->state_device_ptr(&p, &bytes);
+           PG_REQUIRE(ctx->comm.nranks == 1 || ctx->comm.comm != nullptr, 3, "pepsgpu_bcast_state: no communicator (pepsgpu_comm_init)");
+           ctx->comm.bcast((hipStream_t)ctx->eng->stream_handle(), p, bytes, root);
+           ctx->eng->state_adopted());
+}
 int pepsgpu_grad_allreduce(pepsgpu_ctx *ctx) {
   CTX_CALL(void *so = nullptr; void *seo = nullptr; long n = 0; ctx->eng->grad_device_ptr(&so, &seo, &n);
            hipStream_t s = (hipStream_t)ctx->eng->stream_handle();

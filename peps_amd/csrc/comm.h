@@ -23,26 +23,44 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
 
+  ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+
+  // Opens librccl and resolves every entry point into LOCALS first; the handle and the pointers are published together,
+  // only after every dlsym has succeeded (a partial table is never visible: a later call retries from scratch).
   static RcclApi &get() {
     static RcclApi api;
     if (!api.handle) {
       const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+      void *h = nullptr;
+      std::string why;
       for (const char *n : names) {
-        api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (api.handle) break;
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+        const char *e = dlerror();          // one call: dlerror() clears the message it returns
+        why = e ? e : "?";
       }
-      PG_REQUIRE(api.handle != nullptr, 2, std::string("cannot open librccl: ") + (dlerror() ? dlerror() : "?"));
+      PG_REQUIRE(h != nullptr, 2, std::string("cannot open librccl: ") + why);
+      RcclApi loc;
+      const char *missing = nullptr;
       auto sym = [&](const char *s) {
-        void *p = dlsym(api.handle, s);
-        PG_REQUIRE(p != nullptr, 2, std::string("librccl lacks ") + s);
+        void *p = dlsym(h, s);
+        if (!p && !missing) missing = s;
         return p;
       };
-      api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
-      api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
-      api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
-      api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
-      api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
-      api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+      loc.GetUniqueId = reinterpret_cast<decltype(loc.GetUniqueId)>(sym("ncclGetUniqueId"));
+      loc.CommInitRank = reinterpret_cast<decltype(loc.CommInitRank)>(sym("ncclCommInitRank"));
+      loc.CommDestroy = reinterpret_cast<decltype(loc.CommDestroy)>(sym("ncclCommDestroy"));
+      loc.CommCount = reinterpret_cast<decltype(loc.CommCount)>(sym("ncclCommCount"));
+      loc.AllReduce = reinterpret_cast<decltype(loc.AllReduce)>(sym("ncclAllReduce"));
+      loc.Broadcast = reinterpret_cast<decltype(loc.Broadcast)>(sym("ncclBroadcast"));
+      loc.GetErrorString = reinterpret_cast<decltype(loc.GetErrorString)>(sym("ncclGetErrorString"));
+      if (missing) {
+        const std::string m = std::string("librccl lacks ") + missing;
+        dlclose(h);
+        throw ::pepsgpu::Error(2, m);
+      }
+      loc.handle = h;
+      api = loc;
     }
     return api;
   }
@@ -51,9 +69,10 @@ struct RcclApi {
 #define PG_CHECK_RCCL(expr)                                                                                    \
   do {                                                                                                         \
     ncclResult_t _r = (expr);                                                                                  \
-    if (_r != ncclSuccess)                                                                                     \
-      throw ::pepsgpu::Error(2, std::string("RCCL error ") + ::pepsgpu::RcclApi::get().GetErrorString(_r) +   \
-                                    " in " #expr);                                                             \
+    if (_r != ncclSuccess) {                                                                                   \
+      auto _es = ::pepsgpu::RcclApi::get().GetErrorString;                                                     \
+      throw ::pepsgpu::Error(2, std::string("RCCL error ") + (_es ? _es(_r) : "?") + " in " #expr);            \
+    }                                                                                                          \
   } while (0)
 
 // One communicator per context (= per GPU / rank).  A context that never called init (one rank) reduces by the identity.
@@ -83,6 +102,13 @@ struct Comm {
       PG_REQUIRE(cnt == n, 2, "pepsgpu_comm_init: communicator reports a different rank count");
     }
     nranks = n; rank = r;
+  }
+  // state broadcast ("one broadcast of the parameter buffer after each optimizer update", replaces the MPI_Bcast
+  // of every site tensor in split_index_tps_impl.h:778-880): `bytes` of HBM at `buf` from rank `root` to all, on stream s
+  void bcast(hipStream_t s, void *buf, size_t bytes, int root) {
+    PG_REQUIRE(root >= 0 && root < nranks, 1, "pepsgpu_bcast_state: bad root");
+    if (!comm || bytes == 0) return;   // one rank: the identity
+    PG_CHECK_RCCL(RcclApi::get().Broadcast(buf, buf, bytes, ncclChar, root, comm, s));
   }
   // in-place all-reduce of n elements; dtype 0 f32, 1 f64, 2 i32; op 0 sum, 1 max; buf in HBM (on_device) or on the host
   void allreduce(hipStream_t s, void *buf, size_t n, int dtype, int op, bool on_device) {

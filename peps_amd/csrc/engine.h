@@ -28,7 +28,9 @@ enum { HORIZONTAL = 0, VERTICAL = 1 };               // include/qlpeps/basic.h:1
 
 // kernel categories of the event profile (pepsgpu_profile_read)
 enum { PROF_CONTRACT = 0, PROF_GRAM = 1, PROF_CHOL = 2, PROF_JACOBI = 3, PROF_SELECT = 4, PROF_NORM = 5,
-       PROF_ENV = 6, PROF_JACOBI_EDGE = 7, PROF_TRUNC_GRAM = 8, PROF_TRUNC_APPLY = 9, PROF_NCAT = 10 };
+       PROF_ENV = 6, PROF_JACOBI_EDGE = 7, PROF_TRUNC_GRAM = 8, PROF_TRUNC_APPLY = 9,
+       PROF_CHAIN = 10,   // tgemm_chain_kernel alone (one bracket = one launch of that kernel): the per-kernel roofline of bench.py
+       PROF_NCAT = 11 };
 
 struct EngineBase {
   virtual ~EngineBase() {}
@@ -39,6 +41,10 @@ struct EngineBase {
   virtual void grad_device_ptr(void **so, void **seo, long *n_elems) = 0;   // HBM-resident f64 accumulators (grad_reset)
   // --- contractor surface (all walkers in lockstep) ---
   virtual void state_upload(const void *host, int host_dtype) = 0;
+  // the flat SITPS buffer in HBM (pepsgpu_bcast_state: broadcast over the communicator instead of N host uploads);
+  // state_adopted(): the buffer was written from outside (broadcast): what state_upload does besides the copy
+  virtual void state_device_ptr(void **p, size_t *bytes) = 0;
+  virtual void state_adopted() = 0;
   virtual void set_configs(int n, const int32_t *cfg) = 0;
   virtual void get_configs(int32_t *out) = 0;
   virtual int n_walkers() const = 0;
@@ -96,7 +102,7 @@ struct EngineBase {
   virtual void sr_weighted_sum(const double *y, double *out) = 0;
   virtual void sr_copy_samples(void *dst_o, int32_t *dst_cfg) = 0;
   virtual void profile_enable(int on) = 0;
-  virtual void profile_read(double *out) = 0;   // [PROF_NCAT = 10][5]: ms, launches, algorithmic flops, executed flops, operand+result bytes
+  virtual void profile_read(double *out) = 0;   // [PROF_NCAT = 11][5]: ms, launches, algorithmic flops, executed flops, operand+result bytes
 };
 
 template <typename T> struct EinView;
@@ -154,6 +160,15 @@ class Engine : public EngineBase {
     ss[3] = 1; ss[2] = dd[3]; ss[1] = dd[2] * dd[3]; ss[0] = dd[1] * dd[2] * dd[3];
   }
 
+  void state_device_ptr(void **p, size_t *bytes) override {
+    *p = sitps_;
+    *bytes = sizeof(T) * (size_t)slot_ * dp_ * Ly_ * Lx_;
+  }
+  void state_adopted() override {
+    PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    for (int q = 0; q < 4; ++q) redo_seen_[q].assign(std::max(Ly_, Lx_) + 1, 0);
+    have_state_ = true;
+  }
   void state_upload(const void *host, int host_dtype) override {
     for (int q = 0; q < 4; ++q) redo_seen_[q].assign(std::max(Ly_, Lx_) + 1, 0);
     // host layout [row][col][s][L][D][R][U] zero padded to D^4; stored compact in each slot
@@ -223,6 +238,10 @@ class Engine : public EngineBase {
     // unknown).  A performance hint only: the next absorption skips the launches of the mid-rank truncation route at
     // the sites where no walker came near it (the general kernels take whatever was mispredicted).
     std::vector<int> mlmax;
+    // bmax[i] = max over the walkers of the rows the first compression of the truncation route kept at site i (-1 = unknown / not
+    // on that route): hint for the next absorption -- the 256-row Jacobi launch on the factor is skipped where no walker came
+    // near 128 rows; VERIFIED by the live counts read back at the end of the absorption (a miss redoes it without hints)
+    std::vector<int> bmax;
     int depth = 0;   // rows absorbed so far (0 = the vacuum boundary): the carry rank can grow by the factor D per row at first
   };
   struct BTenDev {
@@ -765,6 +784,7 @@ class Engine : public EngineBase {
                "variational compression needs convergence_tol and iter_max (bmps.h:81-97)");
     chi_min_ = chi_min; chi_ = chi_max; trunc_err_ = trunc_err;
     scheme_ = scheme; conv_tol_ = conv_tol; iter_max_ = iter_max;
+    for (int q = 0; q < 4; ++q) redo_seen_[q].assign(std::max(Ly_, Lx_) + 1, 0);   // the routing hints belong to the old parameters
   }
   void read_flags(int32_t *out) override {
     PG_CHECK_HIP(hipMemcpyAsync(out, flag_, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));

@@ -233,7 +233,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           TGemmChainMap mp;
           mp.mapK[1] = 2; mp.mapK[2] = 4;      // K2 = (l, p): l = I1[2], p = J1[1]
           mp.mapJ[1] = 1; mp.mapJ[2] = 5;      // J2 = (m, a2): m = I1[1], a2 = J1[2]
-          prof_begin(PROF_CONTRACT, flx + flp, flx + flp);
+          prof_begin(PROF_CHAIN, flx + flp, flx + flp);
           chained = tgemm_chain_launch(stream_, gx, g2, mp, (const float *)R[i].p, (const float *)A.p,
                                        (const float *)site_base(r, c), (float *)P.p, chain_flag, chain_chunks);
           prof_end();
@@ -373,6 +373,8 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
   PG_CHECK_HIP(hipMemcpyAsync(out.logscale, cur_log, sizeof(double) * nw_, hipMemcpyDeviceToDevice, stream_));
   DTen<T> Y = ones3();   // [l2, a2, k2]
   std::vector<int> assume_rows(N, 0);   // per site: the live-row cap the Jacobi launches relied on (0: none)
+  std::vector<int> assume_b128(N, 0);   // per site: the 256-row Jacobi on the compressed factor was not launched (hint: <= 128 rows)
+  std::vector<int *> mBkeep(N, nullptr);   // per site: rows kept by the first compression (two-level route), read back at the end
   float *yscale = nullptr;   // 1 / |Y| per walker when Y was left unnormalised by the launch that wrote it (y_scaled)
   bool y_scaled = false;
   for (int i = N - 1; i >= 0; --i) {
@@ -426,7 +428,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           TGemmChainMap mp;
           mp.mapK[1] = 2; mp.mapK[2] = 4;      // K2 = (p, l2): p = I1[2], l2 = J1[1]
           mp.mapJ[1] = 1; mp.mapJ[2] = 5;      // J2 = (a, k2): a = I1[1], k2 = J1[2]
-          prof_begin(PROF_CONTRACT, 0.0, flz + flt);
+          prof_begin(PROF_CHAIN, 0.0, flz + flt);
           chained = tgemm_chain_launch(stream_, gz, g2, mp, (const float *)A.p, (const float *)Y.p,
                                        (const float *)site_base(r, c), (float *)Tt.p, chain_flag, chain_chunks);
           prof_end();
@@ -487,7 +489,10 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     // over the first 32): the Cholesky of M M^T drops the dependent rows, the Jacobi runs on the <= 128 live rows of B (256 long)
     // instead of on the 240 rows of M (19 sweeps of the 256 x 256 register kernel: 80 % of the step before).
     static const bool no_dense_mid = getenv("PEPSGPU_NO_DENSE_MID") != nullptr;
-    const int MID_HI = (m > 128 && !no_dense_mid) ? 256 : 128;
+    // hint from the row absorbed before: no walker came near 128 live rows at this site -> the route keeps its <= 128-row form
+    // (walkers that do exceed 128 rows are then taken by the general kernels: time, never correctness)
+    const bool hint_le128 = !full_bonds && in.depth >= 3 && (int)in.mlmax.size() > i && in.mlmax[i] >= 0 && in.mlmax[i] + 12 <= 128;
+    const int MID_HI = (m > 128 && !no_dense_mid && !hint_le128) ? 256 : 128;
     bool mid = false;
     if constexpr (sizeof(T) == 4) {
       static const bool no_mid = getenv("PEPSGPU_NO_MIDROUTE") != nullptr;
@@ -652,8 +657,13 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
             // register kernel, those whose factor kept more than 128 rows; on B2: everybody else
             launch_jacobi_grp<2, 8>(stream_, nw_, (float *)Bt.p, Bt.n, GS, 128, GS, 40, sweeps_, (const int *)rowsA, 1, 0);
             launch_jacobi_grp<4, 8>(stream_, nw_, (float *)Bt.p, Bt.n, GS, 128, GS, 40, sweeps_, (const int *)rowsA, 1, 64);
-            hipLaunchKernelGGL(jacobi_rows_reg256_kernel, dim3(nw_), dim3(512), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS, 40,
-                               sweeps_, (const int *)rowsA, 1, 128);
+            // (a launch of 144 KB-LDS blocks costs ~0.8 ms even when every block returns at once: skipped where the row absorbed
+            // before kept at most ~110 rows of B at this site; verified at the end of the absorption)
+            const bool b_small = !full_bonds && in.depth >= 3 && (int)in.bmax.size() > i && in.bmax[i] >= 0 && in.bmax[i] + 16 <= 128;
+            if (b_small) assume_b128[i] = 1;
+            else
+              hipLaunchKernelGGL(jacobi_rows_reg256_kernel, dim3(nw_), dim3(512), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS, 40,
+                                 sweeps_, (const int *)rowsA, 1, 128);
             launch_jacobi_grp<2, 8>(stream_, nw_, (float *)B2.p, B2.n, 128, 128, 128, 40, sweeps_, (const int *)mB2, 1, 0);
             launch_jacobi_grp<4, 8>(stream_, nw_, (float *)B2.p, B2.n, 128, 128, 128, 40, sweeps_, (const int *)mB2, 1, 64);
           } else {
@@ -759,7 +769,8 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       PG_CHECK_HIP(hipGetLastError());
       prof_end();
       free_ten(Bt); free_ten(Ut); free_ten(Vp);
-      arena_.free(midflag); arena_.free(nmid); arena_.free(mB); arena_.free(kB);
+      arena_.free(midflag); arena_.free(nmid); arena_.free(kB);
+      if (GS > 128) mBkeep[i] = mB; else arena_.free(mB);
     } else {
       prof_end();
     }
@@ -812,13 +823,15 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
   out.live = kn;
   out.kmax.assign(N + 1, -1);
   out.mlmax.assign(N, -1);
+  out.bmax.assign(N, -1);
   out.depth = in.depth + 1;
   bool ok = true;
   if (bond_adapt) {   // one small read-back per absorption: the maximum live count of every new bond and of every carry
-    const int ntab = 2 * N + 1;
+    const int ntab = 3 * N + 1;
     std::vector<const int *> htab(ntab, nullptr);
     for (int b = 0; b <= N; ++b) htab[b] = kn[b];
     for (int i = 0; i < N; ++i) htab[N + 1 + i] = mdyn[i];
+    for (int i = 0; i < N; ++i) htab[2 * N + 1 + i] = mBkeep[i];
     std::vector<int> hmax(ntab, -1);
     const int **dtab = (const int **)arena_.alloc(sizeof(int *) * ntab);
     int *dmax = (int *)arena_.alloc(sizeof(int) * ntab);
@@ -834,7 +847,13 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       if (kstat[i] < kfull[i] && out.kmax[i] >= kstat[i]) ok = false;   // a walker filled a shrunk bond: maybe clipped
     for (int i = 0; i < N; ++i)
       if (assume_rows[i] > 0 && out.mlmax[i] > assume_rows[i]) ok = false;   // a rank hint was missed: rows left unrotated
+    for (int i = 0; i < N; ++i) {
+      out.bmax[i] = mBkeep[i] ? hmax[2 * N + 1 + i] : -1;
+      if (assume_b128[i] && out.bmax[i] > 128) ok = false;                   // the skipped 256-row launch was needed
+    }
   }
+  for (int *p : mBkeep)
+    if (p) arena_.free(p);
   for (auto &t : R) arena_.free(t.p);
   {   // the dynamic-extent arrays (several R_i may share one)
     int *last = nullptr;

@@ -108,3 +108,33 @@ def allreduce_sum(vec):
 def allreduce_max(vec):
     import torch.distributed as dist
     return _reduce(vec, dist.ReduceOp.MAX)
+
+
+def broadcast_state(ctx, flat, src=0):
+    """The parameter broadcast after an optimizer update (replaces the per-tensor MPI_Bcast of
+    split_index_tps_impl.h:778-880): rank `src` holds the new state `flat` (upload layout); every rank's context ends up with it.
+    backend "nccl" with a library communicator (comm_init): rank src uploads, ONE ncclBroadcast moves the HBM buffer to the other
+    GPUs over xGMI (pepsgpu_bcast_state) -- no host upload there.  Any other backend (gloo: CPU tests, one-GPU boxes): the host
+    array is broadcast and every rank uploads it.  `ctx` may be anything with state_upload (and bcast_state / comm_size);
+    returns the array the ranks other than src received (None on the device path)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        ctx.state_upload(flat)
+        return None
+    if dist.get_backend() == "nccl" and getattr(ctx, "comm_size", lambda: 1)() == dist.get_world_size():
+        if dist.get_rank() == src:
+            ctx.state_upload(flat)
+        ctx.bcast_state(src)
+        return None
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    shape = [None]
+    if dist.get_rank() == src:
+        flat = np.ascontiguousarray(flat, dtype=np.float64)
+        shape[0] = tuple(flat.shape)
+    dist.broadcast_object_list(shape, src=src)
+    t = torch.from_numpy(flat.copy()).to(dev) if dist.get_rank() == src else torch.empty(shape[0], dtype=torch.float64, device=dev)
+    dist.broadcast(t, src=src)
+    got = t.cpu().numpy()
+    ctx.state_upload(got)
+    return got

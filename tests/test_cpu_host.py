@@ -217,3 +217,48 @@ def test_two_rank_minsr_ring_exchange_gloo():
                            capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK" in r.stdout
+
+
+BCAST_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch.distributed as dist
+from peps_amd import dist as pdist, synthetic
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+pdist.init("gloo")
+
+
+class HostCtx:
+    """stand-in for capi.Context on a box without a GPU: records what the broadcast hands to state_upload"""
+    def __init__(self): self.state = None
+    def state_upload(self, flat): self.state = np.array(flat, dtype=np.float64)
+
+
+L, D = 4, 3
+new = synthetic.sitps_to_flat(synthetic.make_sitps(L, D, noise=0.3), D)        # what the optimizer on rank 1 produced
+ctx = HostCtx()
+got = pdist.broadcast_state(ctx, new if rank == 1 else None, src=1)
+assert ctx.state is not None and ctx.state.shape == new.shape and np.array_equal(ctx.state, new), rank
+# every rank now holds the same parameters: the all-reduced checksum is world x the local one
+chk = pdist.allreduce_sum(np.array([ctx.state.sum(), float(np.abs(ctx.state).max())]))
+assert abs(chk[0] - world * new.sum()) < 1e-9 * abs(new.sum())
+if rank == 0:
+    print("OK")
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_state_broadcast_gloo():
+    """world_size-2 gloo stand-in of the SURVEY 8(e) parameter broadcast (peps_amd.dist.broadcast_state; on GPUs with a library
+    communicator it is ONE ncclBroadcast of the HBM state buffer, pepsgpu_bcast_state): the state of rank src reaches every
+    rank's context bit for bit -- what the per-tensor MPI_Bcast of split_index_tps_impl.h:778-880 does in the reference."""
+    with tempfile.TemporaryDirectory() as td:
+        wp = os.path.join(td, "worker.py")
+        open(wp, "w").write(BCAST_WORKER)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                            "--master-addr", "127.0.0.1", "--master-port", "29519", wp, ROOT],
+                           capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout

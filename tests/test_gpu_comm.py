@@ -56,6 +56,77 @@ def test_grad_accumulators_alias_in_hbm_and_library_allreduce():
     ctx.close()
 
 
+def test_state_broadcast_one_rank_communicator():
+    """pepsgpu_bcast_state through a real RCCL communicator of one rank (ncclBroadcast on the context's stream): the state
+    stays what was uploaded, a context that only ever received a broadcast counts as having a state; without a communicator
+    on a multi-rank setup the call is refused (here: one rank without communicator = the identity)."""
+    from peps_amd import capi
+    ctx = _ctx()
+    a0 = ctx.evaluate_amplitude()
+    ctx.bcast_state(0)                                   # no communicator, one rank: identity
+    assert np.array_equal(ctx.evaluate_amplitude(), a0)
+    ctx.comm_init(1, 0, capi.comm_unique_id())
+    ctx.bcast_state(0)                                   # ncclBroadcast, root = the only rank
+    assert np.array_equal(ctx.evaluate_amplitude(), a0)
+    with pytest.raises(ValueError):
+        ctx.bcast_state(1)                               # root outside the communicator
+    ctx.comm_destroy()
+    ctx.close()
+
+
+TWO_GPU_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch, torch.distributed as dist
+from peps_amd import capi, dist as pdist, synthetic
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+pdist.init("nccl")
+L, D, chi = 4, 3, 6
+ctx = capi.Context(L, L, D, 2, chi, dtype=capi.F64, device=int(os.environ["LOCAL_RANK"]), max_walkers=4)
+pdist.comm_init(ctx)
+assert ctx.comm_size() == world and ctx.comm_rank() == rank
+new = synthetic.sitps_to_flat(synthetic.make_sitps(L, D, noise=0.3), D)
+pdist.broadcast_state(ctx, new if rank == 0 else None, src=0)      # device path: upload on rank 0 + ncclBroadcast
+ctx.set_configs(synthetic.make_configs(L, 4, "heisenberg"))
+a = ctx.evaluate_amplitude()
+ref = capi.Context(L, L, D, 2, chi, dtype=capi.F64, device=int(os.environ["LOCAL_RANK"]), max_walkers=4)
+ref.state_upload(new); ref.set_configs(synthetic.make_configs(L, 4, "heisenberg"))
+assert np.array_equal(a, ref.evaluate_amplitude())
+ctx.grad_reset()
+so, seo, n = ctx.grad_device_ptr(); ctx.sync()
+t = pdist.device_tensor(so, n); t.fill_(1.0); torch.cuda.synchronize()
+ctx.grad_allreduce()                                                # library communicator, in place in HBM
+got, _ = ctx.grad_read()
+assert set(np.unique(got)) <= {0.0, float(world)}, np.unique(got)
+v = ctx.allreduce(np.array([1.0, float(rank)]))
+assert v[0] == world and v[1] == sum(range(world))
+if rank == 0:
+    print("OK")
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_two_gpu_comm_init_bcast_and_grad_allreduce():
+    """N = 2 on hardware (skipped on a one-GPU box): pepsgpu_comm_init with nranks = 2, the state broadcast and the in-place
+    gradient all-reduce across two GPUs; the reduced accumulators equal `world` where every rank wrote 1."""
+    import tempfile
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    with tempfile.TemporaryDirectory() as td:
+        wp = os.path.join(td, "worker.py")
+        open(wp, "w").write(TWO_GPU_WORKER)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                            "--master-addr", "127.0.0.1", "--master-port", "29533", wp, ROOT],
+                           capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout
+
+
 def test_max_walkers_beyond_grid_limit_is_refused_at_creation():
     from peps_amd import capi
     with pytest.raises(ValueError):

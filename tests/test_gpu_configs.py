@@ -83,7 +83,7 @@ def test_c2_tfim_8x8_local_updater_chain_and_energy():
 @pytest.mark.parametrize("name,nref", [("C3", 4), ("C4", 3)])
 def test_c3_c4_heisenberg_amplitude_and_energy(name, nref):
     """C3 (10x10 D=6 chi=24) and C4 (12x12 D=8 chi=32): f32 device amplitude and XXZ local energy
-    of fixed Sz=0 configurations against the f64 oracle (1e-5 / 1e-5), hole . site == psi."""
+    of fixed Sz=0 configurations against the f64 oracle (amplitude 1e-5 / energy 1e-6), hole . site == psi."""
     host = _host()
     L, D, chi, _ = synthetic.CONFIGS[name]
     s = synthetic.make_sitps(L, D)
@@ -103,7 +103,7 @@ def test_c3_c4_heisenberg_amplitude_and_energy(name, nref):
         assert abs(amps[w] / comp.amplitude - 1) < 1e-5
         if w == 0:
             e, _, _ = model.CalEnergyAndHoles(s, comp, False)
-            assert abs(en[w] / e - 1) < 1e-5
+            assert abs(en[w] / e - 1) < 1e-6                        # north_star: energy to 1e-6 relative
 
 
 def test_psi_consistency_over_all_routes_large_batch_c4():

@@ -278,3 +278,27 @@ def test_k7_tj_network_route_consistency_on_device(fixtures_dir):
     c.SetTruncateParams(BMPSTruncateParams.SVD(k7_tj.DB_MIN, k7_tj.DB_MAX, 1e-15))
     ref = float(k1_routes._walk(hor[:4], c, tn, device=False)[0])
     assert abs(amps[0] / ref - 1) < 3e-7
+
+
+def test_reference_fermion_gradient_signatures_on_device(fixtures_dir):
+    """The reference's golden signatures of the exact-summation GRADIENT of a fermionic state (NormSquare and
+    WeightedProbeInnerProduct, test_exact_summation_evaluator.cpp:50-71, :379-400: spinless fermions, 'lowest' state at
+    t2 = 0, SVD(8, 8, 1e-16), six half-filling configurations): 2.184991439005157e-17 and 7.407222090395872e-18, asserted there
+    to an absolute 1e-8.  Both are sums of squares: blind to the element-wise sign convention of CalGTenForFermionicTensors
+    (which stays unpinned), but they pin the MAGNITUDE of every gradient component of the device path (holes resident in HBM,
+    pepsgpu_grad_accumulate_states, folded back to the stored components)."""
+    from peps_amd import fermion, hostapi
+    st = fermion.FermionState.load(os.path.join(fixtures_dir, "spinless_fermion_tps_t2_0.000000_doublelowest"))
+    cfgs = _half_filling_configs()
+    e, grad = hostapi.fermion_exact_sum(st, cfgs, 8, 1.0, 0.0, batch=6, dtype=1)
+    assert abs(e - (-2.0)) < 1e-7
+    ns = wp = 0.0
+    for r in range(2):
+        for c in range(2):
+            for i in range(grad.shape[2]):
+                n2 = float(np.sum(grad[r, c, i] ** 2))
+                ns += n2
+                wp += 0.012 * ((r + 1) * 11 + (c + 1) * 5 + (i + 1) * 2) * n2
+    print("fermion gradient signatures: NormSquare %.15e (ref 2.184991439005157e-17)  probe %.15e (ref 7.407222090395872e-18)" % (ns, wp))
+    assert abs(ns / 2.184991439005157e-17 - 1) < 1e-6 and abs(wp / 7.407222090395872e-18 - 1) < 1e-6    # (the reference asserts an absolute 1e-8; measured here: 1e-9 relative)
+    assert ns < 1e-12                                                                               # ... and the scale it implies

