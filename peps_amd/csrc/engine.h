@@ -604,7 +604,7 @@ class Engine : public EngineBase {
   // Device-resident gradient accumulators S_O = sum w O*, S_EO = sum w E_loc O* over everything
   // accumulated since grad_reset(): layout [row][col][s][D^4 slot] (compact inside the slot).
   void grad_reset() override {
-    const size_t n = (size_t)Ly_ * Lx_ * dp_ * slot_;
+    const size_t n = (size_t)Ly_ * Lx_ * dp_ * slot_ * kOut;   // complex: interleaved (re, im) pairs
     if (!so_) {
       so_ = (double *)arena_.alloc(sizeof(double) * n);
       seo_ = (double *)arena_.alloc(sizeof(double) * n);
@@ -620,11 +620,47 @@ class Engine : public EngineBase {
   // holes were punched in, while the walkers may have moved on to the column-major pass since).
   void grad_accumulate(const double *psi, const double *eloc, int exact_sum, const int32_t *states = nullptr) override {
     require_ready();
-    if constexpr (kCplx) {
-      PG_REQUIRE(false, 1, "gradient accumulation is not implemented for the complex element type");
-    } else {
-    grad_accumulate_real(psi, eloc, exact_sum, states);
+    if constexpr (kCplx) grad_accumulate_cplx(psi, eloc, exact_sum, states);
+    else grad_accumulate_real(psi, eloc, exact_sum, states);
+  }
+  // Complex element type (psi, eloc = interleaved (re, im) pairs).  The reference stores Dag(hole) (square_nnn_energy_solver.h:163)
+  // and accumulates O* = conj(1 / psi) Dag(hole) with weight 1 (mc_energy_grad_evaluator.h:245-278) or psi Dag(hole) under the
+  // exact-summation weight (exact_summation_energy_evaluator.h:228-240), and E_loc^* O*.  Both factors have the phase
+  // psi / |psi|: v = conj(hole) (psi / |psi|) |psi|^(-1 or +1);  S_O += v,  S_EO += conj(E_loc) v.
+  void grad_accumulate_cplx(const double *psi, const double *eloc, int exact_sum, const int32_t *states) {
+    PG_REQUIRE(holes_ != nullptr, 3, "grad_accumulate: no holes stored (pepsgpu_punch_hole with out == NULL)");
+    if (!so_) grad_reset();
+    std::vector<double> h(5 * (size_t)nw_);
+    for (int w = 0; w < nw_; ++w) {
+      const double a = std::hypot(psi[2 * w], psi[2 * w + 1]);
+      PG_REQUIRE(a != 0.0, 5, "Wavefunction amplitude is near zero, causing division by zero.");
+      h[w] = (exact_sum ? 1.0 : -1.0) * std::log(a);
+      h[nw_ + w] = psi[2 * w] / a;
+      h[2 * nw_ + w] = psi[2 * w + 1] / a;
+      h[3 * nw_ + w] = eloc[2 * w];
+      h[4 * nw_ + w] = -eloc[2 * w + 1];          // conj(E_loc)
     }
+    double *d = (double *)arena_.alloc(sizeof(double) * h.size());
+    PG_CHECK_HIP(hipMemcpyAsync(d, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, stream_));
+    PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    const int sites = Ly_ * Lx_;
+    int *dstates = nullptr;
+    if (states) {
+      for (size_t q = 0; q < (size_t)nw_ * sites; ++q)
+        PG_REQUIRE(states[q] >= 0 && states[q] < dp_, 1, "grad_accumulate: state index out of range");
+      dstates = (int *)arena_.alloc(sizeof(int) * (size_t)nw_ * sites);
+      PG_CHECK_HIP(hipMemcpyAsync(dstates, states, sizeof(int) * (size_t)nw_ * sites, hipMemcpyHostToDevice, stream_));
+      PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    }
+    if constexpr (kCplx) {
+      hipLaunchKernelGGL(grad_accumulate_cplx_kernel<T>, dim3((unsigned)((slot_ + 255) / 256), sites), dim3(256), 0, stream_,
+                         (const T *)holes_, (const double *)holes_ls_, (const int *)(dstates ? dstates : cfg_), (const double *)d,
+                         (const double *)(d + nw_), (const double *)(d + 2 * nw_), (const double *)(d + 3 * nw_),
+                         (const double *)(d + 4 * nw_), so_, seo_, nw_, sites, slot_, dp_);
+      PG_CHECK_HIP(hipGetLastError());
+    }
+    arena_.free(d);
+    if (dstates) arena_.free(dstates);
   }
   void grad_accumulate_real(const double *psi, const double *eloc, int exact_sum, const int32_t *states) {
     PG_REQUIRE(holes_ != nullptr, 3, "grad_accumulate: no holes stored (pepsgpu_punch_hole with out == NULL)");
@@ -659,7 +695,7 @@ class Engine : public EngineBase {
   void grad_device_ptr(void **so, void **seo, long *n_elems) override {
     if (!so_) grad_reset();
     *so = so_; *seo = seo_;
-    *n_elems = (long)Ly_ * Lx_ * dp_ * slot_;
+    *n_elems = (long)Ly_ * Lx_ * dp_ * slot_ * kOut;   // doubles (complex: interleaved pairs): what an all-reduce sums
   }
   // ---- stochastic-reconfiguration sample store (engine_sr.h) ----
   void sr_begin(int max_samples) override;
@@ -680,12 +716,12 @@ class Engine : public EngineBase {
   void grad_read(double *so, double *seo) override {
     PG_REQUIRE(so_ != nullptr, 3, "grad_read: nothing accumulated");
     const size_t n = (size_t)Ly_ * Lx_ * dp_ * slot_;
-    std::vector<double> h(n);
+    std::vector<double> h(n * kOut);
     for (int pass = 0; pass < 2; ++pass) {
       double *dst = pass ? seo : so;
-      PG_CHECK_HIP(hipMemcpyAsync(h.data(), pass ? seo_ : so_, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+      PG_CHECK_HIP(hipMemcpyAsync(h.data(), pass ? seo_ : so_, n * kOut * sizeof(double), hipMemcpyDeviceToHost, stream_));
       PG_CHECK_HIP(hipStreamSynchronize(stream_));
-      std::fill(dst, dst + n, 0.0);
+      std::fill(dst, dst + n * kOut, 0.0);
       for (int r = 0; r < Ly_; ++r)
         for (int c = 0; c < Lx_; ++c) {
           int dd[4];
@@ -696,7 +732,11 @@ class Engine : public EngineBase {
             for (int a = 0; a < dd[0]; ++a)
               for (int b = 0; b < dd[1]; ++b)
                 for (int cc = 0; cc < dd[2]; ++cc)
-                  for (int e = 0; e < dd[3]; ++e) dst[base + (((size_t)a * D_ + b) * D_ + cc) * D_ + e] = h[base + o++];
+                  for (int e = 0; e < dd[3]; ++e) {
+                    const size_t q = base + (((size_t)a * D_ + b) * D_ + cc) * D_ + e;
+                    for (int z = 0; z < kOut; ++z) dst[kOut * q + z] = h[kOut * (base + o) + z];
+                    ++o;
+                  }
           }
         }
     }

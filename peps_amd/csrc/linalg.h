@@ -1338,4 +1338,34 @@ __global__ __launch_bounds__(256) void grad_accumulate_kernel(const T *__restric
   }
 }
 
+// the same for the complex element type: v = conj(hole) * phase(psi) * |psi|^(+-1) (exp(logf)), S_O += v, S_EO += conj(E_loc) v;
+// accumulators = interleaved (re, im) doubles
+template <typename T>
+__global__ __launch_bounds__(256) void grad_accumulate_cplx_kernel(const T *__restrict__ holes, const double *__restrict__ holes_ls,
+                                                                   const int *__restrict__ cfg, const double *__restrict__ logf,
+                                                                   const double *__restrict__ ph_re, const double *__restrict__ ph_im,
+                                                                   const double *__restrict__ ec_re, const double *__restrict__ ec_im,
+                                                                   double *__restrict__ so, double *__restrict__ seo, int nw,
+                                                                   int sites, long slot, int dp) {
+  const int site = blockIdx.y;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= slot) return;
+  for (int s = 0; s < dp; ++s) {
+    double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
+    for (int w = 0; w < nw; ++w) {
+      if (cfg[(long)w * sites + site] != s) continue;
+      const double f = exp(holes_ls[(long)w * sites + site] + logf[w]);
+      const T hv = holes[((long)w * sites + site) * slot + e];
+      const double hr = (double)hv.re, hi = -(double)hv.im;            // Dag(hole)
+      const double vr = f * (hr * ph_re[w] - hi * ph_im[w]), vi = f * (hr * ph_im[w] + hi * ph_re[w]);
+      ar += vr; ai += vi;
+      br += ec_re[w] * vr - ec_im[w] * vi;
+      bi += ec_re[w] * vi + ec_im[w] * vr;
+    }
+    const long q = 2 * (((long)site * dp + s) * slot + e);
+    so[q] += ar; so[q + 1] += ai;
+    seo[q] += br; seo[q + 1] += bi;
+  }
+}
+
 }  // namespace pepsgpu

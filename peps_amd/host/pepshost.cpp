@@ -32,6 +32,18 @@ SplitIndexTPS make_state(int rows, int cols, int D, int d, const double *flat) {
   std::copy(flat, flat + s.flat().size(), s.flat().begin());
   return s;
 }
+// element-type generic form: `flat` = doubles, interleaved (re, im) pairs for QLTEN_Complex
+template <typename TenElemT>
+SplitIndexTPST<TenElemT> make_state_t(int rows, int cols, int D, int d, const double *flat) {
+  SplitIndexTPST<TenElemT> s(rows, cols, d, D);
+  const TenElemT *src = reinterpret_cast<const TenElemT *>(flat);
+  std::copy(src, src + s.flat().size(), s.flat().begin());
+  return s;
+}
+template <typename TenElemT>
+void copy_out(const std::vector<TenElemT> &v, double *out) {
+  if (out) std::copy(dptr(v.data()), dptr(v.data()) + v.size() * (ElemTraits<TenElemT>::is_complex ? 2 : 1), out);
+}
 // BMPSTruncateParams of the contractors built below: SVD(chi, chi, 0) unless pepshost_set_truncate_params changed
 // D_min / trunc_err / scheme (D_max is always the call's chi)
 struct TruncOverride { int d_min = -1; double trunc_err = 0.0; int scheme = 0; double tol = 0.0; int iters = 0; } g_trunc;
@@ -45,6 +57,111 @@ Configuration make_cfg(int n, int rows, int cols, const int32_t *cfg) {
   Configuration c(n, rows, cols);
   std::copy(cfg, cfg + (size_t)n * rows * cols, c.data());
   return c;
+}
+
+// ---- element-type generic bodies of the entry points below (TenElemT = QLTEN_Double / QLTEN_Complex) ----
+template <typename TenElemT>
+void energy_and_holes_impl(int rows, int cols, int D, int d, int chi, int dtype, const double *sitps_flat, int n,
+                           const int32_t *configs, int model, const double *p, double *amplitudes_out,
+                           double *energies_out, double *holes_out, double *psi_out, int *n_psi_out) {
+  SplitIndexTPST<TenElemT> sitps = make_state_t<TenElemT>(rows, cols, D, d, sitps_flat);
+  BMPSContractorT<TenElemT> contractor(rows, cols, D, d, trunc_params(chi), n, dtype, g_device);
+  TPSWaveFunctionComponentT<TenElemT> comp(sitps, make_cfg(n, rows, cols, configs), contractor);
+  EnergyAndHolesT<TenElemT> eh;
+  if (model == 0) {
+    SquareSpinOneHalfXXZModelOBC m(p[0], p[1], p[2]);
+    eh = holes_out ? m.CalEnergyAndHoles<true>(sitps, comp) : m.CalEnergyAndHoles<false>(sitps, comp);
+  } else if (model == 2) {
+    SquareSpinOneHalfJ1J2XXZModelOBC m(p[0], p[1], p[2], p[3], p[4]);
+    eh = holes_out ? m.CalEnergyAndHoles<true>(sitps, comp) : m.CalEnergyAndHoles<false>(sitps, comp);
+  } else {
+    TransverseFieldIsingSquareOBC m(p[0]);
+    eh = holes_out ? m.CalEnergyAndHoles<true>(sitps, comp) : m.CalEnergyAndHoles<false>(sitps, comp);
+  }
+  constexpr int z = ElemTraits<TenElemT>::is_complex ? 2 : 1;
+  copy_out(comp.amplitude, amplitudes_out);
+  copy_out(eh.energy, energies_out);
+  copy_out(eh.holes, holes_out);
+  if (n_psi_out) *n_psi_out = (int)eh.psi_list.size();
+  if (psi_out)
+    for (size_t k = 0; k < eh.psi_list.size(); ++k) copy_out(eh.psi_list[k], psi_out + k * n * z);
+}
+
+template <typename TenElemT>
+void exact_sum_partial_impl(int rows, int cols, int D, int d, int chi, int dtype, const double *sitps_flat,
+                            const int32_t *all_configs, int n_configs, int model, const double *p, int rank, int size,
+                            int batch, double *packed_out) {
+  SplitIndexTPST<TenElemT> sitps = make_state_t<TenElemT>(rows, cols, D, d, sitps_flat);
+  BMPSContractorT<TenElemT> contractor(rows, cols, D, d, trunc_params(chi), batch, dtype, g_device);
+  std::vector<std::vector<int32_t>> all(n_configs);
+  for (int i = 0; i < n_configs; ++i) all[i].assign(all_configs + (size_t)i * rows * cols, all_configs + (size_t)(i + 1) * rows * cols);
+  std::vector<double> packed;
+  auto capture = [&](std::vector<double> &v) { packed = v; };
+  if (model == 0) {
+    SquareSpinOneHalfXXZModelOBC m(p[0], p[1], p[2]);
+    ExactSumEnergyEvaluator(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
+  } else if (model == 2) {
+    SquareSpinOneHalfJ1J2XXZModelOBC m(p[0], p[1], p[2], p[3], p[4]);
+    ExactSumEnergyEvaluator(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
+  } else {
+    TransverseFieldIsingSquareOBC m(p[0]);
+    ExactSumEnergyEvaluator(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
+  }
+  std::copy(packed.begin(), packed.end(), packed_out);
+}
+
+template <typename TenElemT>
+void mc_energy_grad_partial_impl(int rows, int cols, int D, int d, int chi, int dtype, const double *sitps_flat, int n,
+                                 int32_t *configs, const uint64_t *seeds, int updater, int model, const double *p,
+                                 int warmup_sweeps, int n_samples, double *packed_out, double *accept_out) {
+  SplitIndexTPST<TenElemT> sitps = make_state_t<TenElemT>(rows, cols, D, d, sitps_flat);
+  BMPSContractorT<TenElemT> contractor(rows, cols, D, d, trunc_params(chi), n, dtype, g_device);
+  TPSWaveFunctionComponentT<TenElemT> comp(sitps, make_cfg(n, rows, cols, configs), contractor);
+  std::vector<uint64_t> sd(seeds, seeds + n);
+  MCUpdateSquareNNExchangeOBC ex(sd);
+  MCUpdateSquareNNFullSpaceUpdateOBC fs(sd);
+  std::vector<double> rates, acc_rate(n, 0.0);
+  auto sweep = [&]() { if (updater == 0) ex(sitps, comp, rates); else fs(sitps, comp, rates); };
+  for (int s = 0; s < warmup_sweeps; ++s) sweep();
+  SquareSpinOneHalfXXZModelOBC xxz(p[0], p[1], p[2]);
+  SquareSpinOneHalfJ1J2XXZModelOBC j1j2(p[0], p[1], p[2], p[3], p[4]);
+  TransverseFieldIsingSquareOBC tfim(p[0]);
+  GradAccumulatorT<TenElemT> acc(sitps);
+  contractor.GradReset();
+  for (int k = 0; k < n_samples; ++k) {
+    sweep();
+    for (int w = 0; w < n; ++w) acc_rate[w] += rates[w];
+    EnergyAndHolesT<TenElemT> eh = model == 0   ? xxz.CalEnergyAndHoles<true>(sitps, comp, true)
+                                   : model == 2 ? j1j2.CalEnergyAndHoles<true>(sitps, comp, true)
+                                                : tfim.CalEnergyAndHoles<true>(sitps, comp, true);
+    acc.AccumulateDevice(comp, eh, false);
+  }
+  if (n_samples > 0) acc.FetchDevice(contractor);
+  std::vector<double> packed = acc.Pack();
+  std::copy(packed.begin(), packed.end(), packed_out);
+  std::copy(comp.config.data(), comp.config.data() + (size_t)n * rows * cols, configs);
+  if (accept_out) for (int w = 0; w < n; ++w) accept_out[w] = n_samples ? acc_rate[w] / n_samples : 0.0;
+}
+
+template <typename TenElemT>
+void mc_sweeps_impl(int rows, int cols, int D, int d, int chi, int dtype, const double *sitps_flat, int n,
+                    int32_t *configs, const uint64_t *seeds, int updater, int n_sweeps, double *amplitudes_out,
+                    double *accept_rates_out) {
+  SplitIndexTPST<TenElemT> sitps = make_state_t<TenElemT>(rows, cols, D, d, sitps_flat);
+  BMPSContractorT<TenElemT> contractor(rows, cols, D, d, trunc_params(chi), n, dtype, g_device);
+  TPSWaveFunctionComponentT<TenElemT> comp(sitps, make_cfg(n, rows, cols, configs), contractor);
+  std::vector<uint64_t> sd(seeds, seeds + n);
+  std::vector<double> rates, acc(n, 0.0);
+  if (updater == 0) {
+    MCUpdateSquareNNExchangeOBC upd(sd);
+    for (int s = 0; s < n_sweeps; ++s) { upd(sitps, comp, rates); for (int w = 0; w < n; ++w) acc[w] += rates[w]; }
+  } else {
+    MCUpdateSquareNNFullSpaceUpdateOBC upd(sd);
+    for (int s = 0; s < n_sweeps; ++s) { upd(sitps, comp, rates); for (int w = 0; w < n; ++w) acc[w] += rates[w]; }
+  }
+  std::copy(comp.config.data(), comp.config.data() + (size_t)n * rows * cols, configs);
+  copy_out(comp.amplitude, amplitudes_out);
+  for (int w = 0; w < n; ++w) accept_rates_out[w] = n_sweeps ? acc[w] / n_sweeps : 0.0;
 }
 }  // namespace
 
@@ -75,21 +192,15 @@ int pepshost_mc_sweeps(int rows, int cols, int D, int d, int chi, int dtype, con
                        int32_t *configs, const uint64_t *seeds, int updater, int n_sweeps, double *amplitudes_out,
                        double *accept_rates_out) {
   return guarded([&]() {
-    SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
-    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), n, dtype, g_device);
-    TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor);
-    std::vector<uint64_t> sd(seeds, seeds + n);
-    std::vector<double> rates, acc(n, 0.0);
-    if (updater == 0) {
-      MCUpdateSquareNNExchangeOBC upd(sd);
-      for (int s = 0; s < n_sweeps; ++s) { upd(sitps, comp, rates); for (int w = 0; w < n; ++w) acc[w] += rates[w]; }
-    } else {
-      MCUpdateSquareNNFullSpaceUpdateOBC upd(sd);
-      for (int s = 0; s < n_sweeps; ++s) { upd(sitps, comp, rates); for (int w = 0; w < n; ++w) acc[w] += rates[w]; }
-    }
-    std::copy(comp.config.data(), comp.config.data() + (size_t)n * rows * cols, configs);
-    std::copy(comp.amplitude.begin(), comp.amplitude.end(), amplitudes_out);
-    for (int w = 0; w < n; ++w) accept_rates_out[w] = n_sweeps ? acc[w] / n_sweeps : 0.0;
+    mc_sweeps_impl<double>(rows, cols, D, d, chi, dtype, sitps_flat, n, configs, seeds, updater, n_sweeps, amplitudes_out, accept_rates_out);
+  });
+}
+int pepshost_mc_sweeps_c128(int rows, int cols, int D, int d, int chi, const double *sitps_flat, int n,
+                            int32_t *configs, const uint64_t *seeds, int updater, int n_sweeps, double *amplitudes_out,
+                            double *accept_rates_out) {
+  return guarded([&]() {
+    mc_sweeps_impl<QLTEN_Complex>(rows, cols, D, d, chi, PEPSGPU_C128, sitps_flat, n, configs, seeds, updater, n_sweeps, amplitudes_out,
+                                  accept_rates_out);
   });
 }
 
@@ -99,26 +210,17 @@ int pepshost_energy_and_holes(int rows, int cols, int D, int d, int chi, int dty
                               const int32_t *configs, int model, const double *p, double *amplitudes_out,
                               double *energies_out, double *holes_out, double *psi_out, int *n_psi_out) {
   return guarded([&]() {
-    SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
-    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), n, dtype, g_device);
-    TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor);
-    EnergyAndHoles eh;
-    if (model == 0) {
-      SquareSpinOneHalfXXZModelOBC m(p[0], p[1], p[2]);
-      eh = holes_out ? m.CalEnergyAndHoles<true>(sitps, comp) : m.CalEnergyAndHoles<false>(sitps, comp);
-    } else if (model == 2) {
-      SquareSpinOneHalfJ1J2XXZModelOBC m(p[0], p[1], p[2], p[3], p[4]);
-      eh = holes_out ? m.CalEnergyAndHoles<true>(sitps, comp) : m.CalEnergyAndHoles<false>(sitps, comp);
-    } else {
-      TransverseFieldIsingSquareOBC m(p[0]);
-      eh = holes_out ? m.CalEnergyAndHoles<true>(sitps, comp) : m.CalEnergyAndHoles<false>(sitps, comp);
-    }
-    std::copy(comp.amplitude.begin(), comp.amplitude.end(), amplitudes_out);
-    std::copy(eh.energy.begin(), eh.energy.end(), energies_out);
-    if (holes_out) std::copy(eh.holes.begin(), eh.holes.end(), holes_out);
-    if (n_psi_out) *n_psi_out = (int)eh.psi_list.size();
-    if (psi_out)
-      for (size_t k = 0; k < eh.psi_list.size(); ++k) std::copy(eh.psi_list[k].begin(), eh.psi_list[k].end(), psi_out + k * n);
+    energy_and_holes_impl<double>(rows, cols, D, d, chi, dtype, sitps_flat, n, configs, model, p, amplitudes_out, energies_out, holes_out,
+                                  psi_out, n_psi_out);
+  });
+}
+// the same for TenElemT = QLTEN_Complex: sitps_flat and every output scalar / tensor = interleaved (re, im) pairs
+int pepshost_energy_and_holes_c128(int rows, int cols, int D, int d, int chi, const double *sitps_flat, int n,
+                                   const int32_t *configs, int model, const double *p, double *amplitudes_out,
+                                   double *energies_out, double *holes_out, double *psi_out, int *n_psi_out) {
+  return guarded([&]() {
+    energy_and_holes_impl<QLTEN_Complex>(rows, cols, D, d, chi, PEPSGPU_C128, sitps_flat, n, configs, model, p, amplitudes_out, energies_out,
+                                         holes_out, psi_out, n_psi_out);
   });
 }
 
@@ -130,33 +232,17 @@ int pepshost_mc_energy_grad_partial(int rows, int cols, int D, int d, int chi, i
                                     int32_t *configs, const uint64_t *seeds, int updater, int model, const double *p,
                                     int warmup_sweeps, int n_samples, double *packed_out, double *accept_out) {
   return guarded([&]() {
-    SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
-    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), n, dtype, g_device);
-    TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor);
-    std::vector<uint64_t> sd(seeds, seeds + n);
-    MCUpdateSquareNNExchangeOBC ex(sd);
-    MCUpdateSquareNNFullSpaceUpdateOBC fs(sd);
-    std::vector<double> rates, acc_rate(n, 0.0);
-    auto sweep = [&]() { if (updater == 0) ex(sitps, comp, rates); else fs(sitps, comp, rates); };
-    for (int s = 0; s < warmup_sweeps; ++s) sweep();
-    SquareSpinOneHalfXXZModelOBC xxz(p[0], p[1], p[2]);
-    SquareSpinOneHalfJ1J2XXZModelOBC j1j2(p[0], p[1], p[2], p[3], p[4]);
-    TransverseFieldIsingSquareOBC tfim(p[0]);
-    GradAccumulator acc(sitps);
-    contractor.GradReset();
-    for (int k = 0; k < n_samples; ++k) {
-      sweep();
-      for (int w = 0; w < n; ++w) acc_rate[w] += rates[w];
-      EnergyAndHoles eh = model == 0   ? xxz.CalEnergyAndHoles<true>(sitps, comp, true)
-                          : model == 2 ? j1j2.CalEnergyAndHoles<true>(sitps, comp, true)
-                                       : tfim.CalEnergyAndHoles<true>(sitps, comp, true);
-      acc.AccumulateDevice(comp, eh, false);
-    }
-    if (n_samples > 0) acc.FetchDevice(contractor);
-    std::vector<double> packed = acc.Pack();
-    std::copy(packed.begin(), packed.end(), packed_out);
-    std::copy(comp.config.data(), comp.config.data() + (size_t)n * rows * cols, configs);
-    if (accept_out) for (int w = 0; w < n; ++w) accept_out[w] = n_samples ? acc_rate[w] / n_samples : 0.0;
+    mc_energy_grad_partial_impl<double>(rows, cols, D, d, chi, dtype, sitps_flat, n, configs, seeds, updater, model, p, warmup_sweeps,
+                                        n_samples, packed_out, accept_out);
+  });
+}
+// QLTEN_Complex: packed_out = [S_O | S_EO (interleaved pairs) | sum w | Re, Im sum wE | sum w|E|^2 | samples], 4 m + 5 doubles
+int pepshost_mc_energy_grad_partial_c128(int rows, int cols, int D, int d, int chi, const double *sitps_flat, int n,
+                                         int32_t *configs, const uint64_t *seeds, int updater, int model, const double *p,
+                                         int warmup_sweeps, int n_samples, double *packed_out, double *accept_out) {
+  return guarded([&]() {
+    mc_energy_grad_partial_impl<QLTEN_Complex>(rows, cols, D, d, chi, PEPSGPU_C128, sitps_flat, n, configs, seeds, updater, model, p,
+                                               warmup_sweeps, n_samples, packed_out, accept_out);
   });
 }
 
@@ -229,23 +315,16 @@ int pepshost_exact_sum_partial(int rows, int cols, int D, int d, int chi, int dt
                                const int32_t *all_configs, int n_configs, int model, const double *p, int rank, int size,
                                int batch, double *packed_out) {
   return guarded([&]() {
-    SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
-    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), batch, dtype, g_device);
-    std::vector<std::vector<int32_t>> all(n_configs);
-    for (int i = 0; i < n_configs; ++i) all[i].assign(all_configs + (size_t)i * rows * cols, all_configs + (size_t)(i + 1) * rows * cols);
-    std::vector<double> packed;
-    auto capture = [&](std::vector<double> &v) { packed = v; };
-    if (model == 0) {
-      SquareSpinOneHalfXXZModelOBC m(p[0], p[1], p[2]);
-      ExactSumEnergyEvaluator(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
-    } else if (model == 2) {
-      SquareSpinOneHalfJ1J2XXZModelOBC m(p[0], p[1], p[2], p[3], p[4]);
-      ExactSumEnergyEvaluator(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
-    } else {
-      TransverseFieldIsingSquareOBC m(p[0]);
-      ExactSumEnergyEvaluator(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
-    }
-    std::copy(packed.begin(), packed.end(), packed_out);
+    exact_sum_partial_impl<double>(rows, cols, D, d, chi, dtype, sitps_flat, all_configs, n_configs, model, p, rank, size, batch, packed_out);
+  });
+}
+// QLTEN_Complex (layout of packed_out: see pepshost_mc_energy_grad_partial_c128)
+int pepshost_exact_sum_partial_c128(int rows, int cols, int D, int d, int chi, const double *sitps_flat,
+                                    const int32_t *all_configs, int n_configs, int model, const double *p, int rank, int size,
+                                    int batch, double *packed_out) {
+  return guarded([&]() {
+    exact_sum_partial_impl<QLTEN_Complex>(rows, cols, D, d, chi, PEPSGPU_C128, sitps_flat, all_configs, n_configs, model, p, rank, size, batch,
+                                          packed_out);
   });
 }
 
@@ -304,6 +383,33 @@ int pepshost_exact_sum_finish(int rows, int cols, int D, int d, const double *pa
     *energy_out = res.first;
     std::copy(res.second.flat().begin(), res.second.flat().end(), grad_out);
   });
+}
+
+// QLTEN_Complex: packed = 4 m + 5 doubles (see pepshost_mc_energy_grad_partial_c128); energy_out = (re, im), grad_out = interleaved pairs
+int pepshost_exact_sum_finish_c128(int rows, int cols, int D, int d, const double *packed, double *energy_out, double *grad_out) {
+  return guarded([&]() {
+    SplitIndexTPST<QLTEN_Complex> like(rows, cols, d, D);
+    GradAccumulatorT<QLTEN_Complex> acc(like);
+    std::vector<double> v(packed, packed + 4 * like.flat().size() + 5);
+    acc.Unpack(v);
+    auto res = acc.Finish();
+    energy_out[0] = res.first.real(); energy_out[1] = res.first.imag();
+    copy_out(res.second.flat(), grad_out);
+  });
+}
+// SplitIndexTPS<QLTEN_Complex>::Load / Dump of the reference's complex fixtures (interleaved complex128 payloads)
+int pepshost_load_sitps_c128(const char *dir, int D, int *rows, int *cols, int *d, double *flat_out, size_t flat_cap) {
+  return guarded([&]() {
+    auto s = SplitIndexTPST<QLTEN_Complex>::Load(dir, D);
+    *rows = (int)s.rows(); *cols = (int)s.cols(); *d = (int)s.PhysicalDim();
+    if (flat_out) {
+      if (flat_cap < 2 * s.flat().size()) throw std::invalid_argument("output buffer too small");
+      copy_out(s.flat(), flat_out);
+    }
+  });
+}
+int pepshost_dump_sitps_c128(const char *dir, int rows, int cols, int D, int d, const double *flat) {
+  return guarded([&]() { make_state_t<QLTEN_Complex>(rows, cols, D, d, flat).Dump(dir); });
 }
 
 // SplitIndexTPS::Load round trip for the reference's dump format (dense fixtures)

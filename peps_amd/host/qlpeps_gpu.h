@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <complex>
 #include <cstdint>
 #include <fstream>
 #include <functional>
@@ -50,6 +51,34 @@ enum BMPSPOSITION { LEFT = 0, DOWN = 1, RIGHT = 2, UP = 3 };  // basic.h:58-63
 enum DIAGONAL_DIR { LEFTUP_TO_RIGHTDOWN = 0, LEFTDOWN_TO_RIGHTUP = 1 };  // basic.h:89-92
 using BTenPOSITION = BMPSPOSITION;
 enum class CompressMPSScheme { SVD_COMPRESS = 0, VARIATION2Site = 1, VARIATION1Site = 2 };   // bmps.h:31-35
+
+// Element type of the tensors (TenElemT of the reference: QLTEN_Double / QLTEN_Complex; every hot-path test of the reference
+// is compiled for both, tests/CMakeLists.txt:57-100).  The classes below that carry tensor elements or amplitudes are
+// templates over it (SplitIndexTPST, BMPSContractorT, TPSWaveFunctionComponentT, EnergyAndHolesT, GradAccumulatorT); the
+// un-suffixed names are the QLTEN_Double instantiations.  Updaters, solvers and evaluators deduce it from their arguments,
+// as the reference's CRTP hooks do (CalEnergyAndHolesImpl<TenElemT, QNT, calchols>, model_energy_solver.h:86-87).
+using QLTEN_Double = double;
+using QLTEN_Complex = std::complex<double>;
+template <typename TenElemT> struct ElemTraits;
+template <> struct ElemTraits<double> {
+  static constexpr bool is_complex = false;
+  static constexpr int host_dtype = PEPSGPU_F64;       // dtype code of a host buffer of this type (pepsgpu_state_upload)
+  static int ctx_dtype(int requested) { return requested; }   // PEPSGPU_F32 / PEPSGPU_F64 device tensors
+};
+template <> struct ElemTraits<std::complex<double>> {
+  static constexpr bool is_complex = true;
+  static constexpr int host_dtype = PEPSGPU_C128;
+  static int ctx_dtype(int) { return PEPSGPU_C128; }
+};
+inline double ComplexConjugate(double x) { return x; }                                   // qlten ComplexConjugate
+inline std::complex<double> ComplexConjugate(const std::complex<double> &x) { return std::conj(x); }
+inline double AbsSquare(double x) { return x * x; }
+inline double AbsSquare(const std::complex<double> &x) { return std::norm(x); }
+// every scalar / tensor the C ABI returns for a complex context is an interleaved (re, im) pair = the layout of std::complex
+inline double *dptr(double *p) { return p; }
+inline const double *dptr(const double *p) { return p; }
+inline double *dptr(std::complex<double> *p) { return reinterpret_cast<double *>(p); }
+inline const double *dptr(const std::complex<double> *p) { return reinterpret_cast<const double *>(p); }
 
 struct SiteIdx {                                             // framework/site_idx.h:20-26
   size_t r = 0, c = 0;
@@ -109,27 +138,28 @@ class Configuration {
   std::vector<int32_t> v_;
 };
 
-// Dense real SplitIndexTPS in the ABI upload layout [row][col][s][L][D][R][U], legs zero padded to D.
-class SplitIndexTPS {
+// Dense SplitIndexTPS<TenElemT, TrivialRepQN> in the ABI upload layout [row][col][s][L][D][R][U], legs zero padded to D.
+template <typename TenElemT>
+class SplitIndexTPST {
  public:
-  SplitIndexTPS() = default;
-  SplitIndexTPS(size_t rows, size_t cols, size_t phys_dim, size_t D)
-      : rows_(rows), cols_(cols), d_(phys_dim), D_(D), v_(rows * cols * phys_dim * D * D * D * D, 0.0) {}
+  SplitIndexTPST() = default;
+  SplitIndexTPST(size_t rows, size_t cols, size_t phys_dim, size_t D)
+      : rows_(rows), cols_(cols), d_(phys_dim), D_(D), v_(rows * cols * phys_dim * D * D * D * D, TenElemT(0.0)) {}
   size_t rows() const { return rows_; }
   size_t cols() const { return cols_; }
   size_t PhysicalDim() const { return d_; }
   size_t D() const { return D_; }
   size_t slot() const { return D_ * D_ * D_ * D_; }
   size_t size() const { return rows_ * cols_; }
-  double *component(size_t r, size_t c, size_t s) { return v_.data() + ((r * cols_ + c) * d_ + s) * slot(); }
-  const double *component(size_t r, size_t c, size_t s) const { return v_.data() + ((r * cols_ + c) * d_ + s) * slot(); }
-  std::vector<double> &flat() { return v_; }
-  const std::vector<double> &flat() const { return v_; }
-  double NormSquare() const { return std::inner_product(v_.begin(), v_.end(), v_.begin(), 0.0); }
+  TenElemT *component(size_t r, size_t c, size_t s) { return v_.data() + ((r * cols_ + c) * d_ + s) * slot(); }
+  const TenElemT *component(size_t r, size_t c, size_t s) const { return v_.data() + ((r * cols_ + c) * d_ + s) * slot(); }
+  std::vector<TenElemT> &flat() { return v_; }
+  const std::vector<TenElemT> &flat() const { return v_; }
+  double NormSquare() const { double a = 0.0; for (const auto &x : v_) a += AbsSquare(x); return a; }
 
   // SplitIndexTPS::Load (split_index_tps_impl.h:340-437): tps_meta.txt + tps_ten{r}_{c}_{s}.qlten,
-  // dense TrivialRepQN float64 payloads only (format: SURVEY.md section 8c).
-  static SplitIndexTPS Load(const std::string &dir, size_t D) {
+  // dense TrivialRepQN payloads only: float64, or interleaved complex128 for QLTEN_Complex (format: SURVEY.md section 8c).
+  static SplitIndexTPST Load(const std::string &dir, size_t D) {
     std::ifstream meta(dir + "/tps_meta.txt");
     if (!meta) throw std::runtime_error("SplitIndexTPS::Load: cannot open " + dir + "/tps_meta.txt");
     long rows_l = 0, cols_l = 0, d_l = 0, bc = 0;
@@ -140,7 +170,7 @@ class SplitIndexTPS {
     if ((meta >> bc) && bc != 0)
       throw std::runtime_error("SplitIndexTPS::Load: boundary condition " + std::to_string(bc) + " (not Open) is not supported");
     const size_t rows = (size_t)rows_l, cols = (size_t)cols_l, d = (size_t)d_l;
-    SplitIndexTPS t(rows, cols, d, D);
+    SplitIndexTPST t(rows, cols, d, D);
     for (size_t r = 0; r < rows; ++r)
       for (size_t c = 0; c < cols; ++c)
         for (size_t s = 0; s < d; ++s) {
@@ -172,10 +202,10 @@ class SplitIndexTPS {
             if (dims[k] == 0 || dims[k] > D)
               throw std::runtime_error("SplitIndexTPS::Load: leg " + std::to_string(k) + " of " + path + " has dimension " +
                                        std::to_string(dims[k]) + ", the caller's bond dimension is " + std::to_string(D));
-          std::vector<double> buf(dims[0] * dims[1] * dims[2] * dims[3]);
-          f.read(reinterpret_cast<char *>(buf.data()), buf.size() * sizeof(double));
+          std::vector<TenElemT> buf(dims[0] * dims[1] * dims[2] * dims[3]);
+          f.read(reinterpret_cast<char *>(buf.data()), buf.size() * sizeof(TenElemT));
           if (!f) throw std::runtime_error("SplitIndexTPS::Load: truncated payload in " + path);
-          double *dst = t.component(r, c, s);
+          TenElemT *dst = t.component(r, c, s);
           size_t o = 0;
           for (size_t a = 0; a < dims[0]; ++a)
             for (size_t b = 0; b < dims[1]; ++b)
@@ -214,14 +244,14 @@ class SplitIndexTPS {
           for (int k = 0; k < 4; ++k)
             f << 1 << "\n" << dd[k] << "\n" << dd[k] << "\n" << dirs[k] << "\n" << dd[k] << "\n" << TrivialIndexHash(dirs[k], dd[k]) << "\n";
           f << 1 << "\n0\n0\n0\n0\n";
-          const double *src = component(r, c, s);
-          std::vector<double> buf;
+          const TenElemT *src = component(r, c, s);
+          std::vector<TenElemT> buf;
           buf.reserve(dd[0] * dd[1] * dd[2] * dd[3]);
           for (size_t a = 0; a < dd[0]; ++a)
             for (size_t b = 0; b < dd[1]; ++b)
               for (size_t cc = 0; cc < dd[2]; ++cc)
                 for (size_t e = 0; e < dd[3]; ++e) buf.push_back(src[((a * D_ + b) * D_ + cc) * D_ + e]);
-          f.write(reinterpret_cast<const char *>(buf.data()), buf.size() * sizeof(double));
+          f.write(reinterpret_cast<const char *>(buf.data()), buf.size() * sizeof(TenElemT));
           f << "\n";
           if (!f) throw std::ios_base::failure("Failed to write: " + path);
         }
@@ -233,8 +263,9 @@ class SplitIndexTPS {
 
  private:
   size_t rows_ = 0, cols_ = 0, d_ = 0, D_ = 0;
-  std::vector<double> v_;
+  std::vector<TenElemT> v_;
 };
+using SplitIndexTPS = SplitIndexTPST<double>;
 
 // Configuration::Dump / Load for one walker (configuration.h:284-330, :446-464): text matrix
 // `configuration{label}` + the `.shape` sidecar.
@@ -262,17 +293,18 @@ inline void LoadConfiguration(Configuration &cfg, size_t walker, const std::stri
 
 // BMPSContractor (bmps_contractor.h:187-1027): same method names; `tn` arguments disappear because
 // the projected network is (sitps, configs) held by the context.  Scalars come back per walker.
-class BMPSContractor {
+template <typename TenElemT>
+class BMPSContractorT {
  public:
-  BMPSContractor(size_t rows, size_t cols, size_t D, size_t phys_dim, const BMPSTruncateParams &p, size_t max_walkers,
+  BMPSContractorT(size_t rows, size_t cols, size_t D, size_t phys_dim, const BMPSTruncateParams &p, size_t max_walkers,
                  int dtype = PEPSGPU_F64, int device = 0)
       : rows_(rows), cols_(cols), D_(D), d_(phys_dim), trunc_(p) {
-    int rc = pepsgpu_ctx_create(&ctx_, device, dtype, (int)rows, (int)cols, (int)D, (int)phys_dim, (int)p.D_min,
+    int rc = pepsgpu_ctx_create(&ctx_, device, ElemTraits<TenElemT>::ctx_dtype(dtype), (int)rows, (int)cols, (int)D, (int)phys_dim, (int)p.D_min,
                                 (int)p.D_max, p.trunc_err, (int)p.compress_scheme, (int)max_walkers);
     if (rc != PEPSGPU_OK) { ctx_ = nullptr; check_rc(rc, nullptr); }
     if (p.compress_scheme != CompressMPSScheme::SVD_COMPRESS) SetTruncateParams(p);
   }
-  ~BMPSContractor() { if (ctx_) pepsgpu_ctx_destroy(ctx_); }
+  ~BMPSContractorT() { if (ctx_) pepsgpu_ctx_destroy(ctx_); }
   // bmps_contractor.h:216; the variational schemes need convergence_tol and iter_max (bmps_impl.h:425-430 .value())
   void SetTruncateParams(const BMPSTruncateParams &p) {
     if (p.compress_scheme != CompressMPSScheme::SVD_COMPRESS && !(p.convergence_tol && p.iter_max))
@@ -281,8 +313,8 @@ class BMPSContractor {
                                          p.convergence_tol.value_or(0.0), (int)p.iter_max.value_or(0)), ctx_);
     trunc_ = p;
   }
-  BMPSContractor(const BMPSContractor &) = delete;
-  BMPSContractor &operator=(const BMPSContractor &) = delete;
+  BMPSContractorT(const BMPSContractorT &) = delete;
+  BMPSContractorT &operator=(const BMPSContractorT &) = delete;
 
   pepsgpu_ctx *ctx() const { return ctx_; }
   size_t rows() const { return rows_; }
@@ -290,7 +322,7 @@ class BMPSContractor {
   size_t walkers() const { return (size_t)pepsgpu_n_walkers(ctx_); }
   const BMPSTruncateParams &GetTruncateParams() const { return trunc_; }
 
-  void UploadState(const SplitIndexTPS &s) { check_rc(pepsgpu_state_upload(ctx_, s.flat().data(), PEPSGPU_F64), ctx_); }
+  void UploadState(const SplitIndexTPST<TenElemT> &s) { check_rc(pepsgpu_state_upload(ctx_, dptr(s.flat().data()), ElemTraits<TenElemT>::host_dtype), ctx_); }
   void Init(const Configuration &cfg) { check_rc(pepsgpu_walkers_set_configs(ctx_, (int)cfg.walkers(), cfg.data()), ctx_); }
 
   void GrowBMPSStep(BMPSPOSITION p) { check_rc(pepsgpu_grow_bmps_step(ctx_, p), ctx_); }
@@ -328,7 +360,7 @@ class BMPSContractor {
   // [walker][d0*d1*d2] with dims[i], times exp(logscale[walker]).  The gauge differs from the reference.
   struct BMPSHost {
     std::vector<std::array<int, 3>> dims;
-    std::vector<std::vector<double>> tensors;
+    std::vector<std::vector<TenElemT>> tensors;
     std::vector<double> logscale;
   };
   BMPSHost GetBMPS(BMPSPOSITION p, size_t level) const {
@@ -340,7 +372,7 @@ class BMPSContractor {
       check_rc(pepsgpu_get_bmps_tensor(ctx_, p, (int)level, (int)i, d, nullptr, nullptr), ctx_);
       b.dims[i] = {d[0], d[1], d[2]};
       b.tensors[i].resize(n * (size_t)d[0] * d[1] * d[2]);
-      check_rc(pepsgpu_get_bmps_tensor(ctx_, p, (int)level, (int)i, d, b.tensors[i].data(), b.logscale.data()), ctx_);
+      check_rc(pepsgpu_get_bmps_tensor(ctx_, p, (int)level, (int)i, d, dptr(b.tensors[i].data()), b.logscale.data()), ctx_);
     }
     return b;
   }
@@ -354,20 +386,20 @@ class BMPSContractor {
     return {GetBMPS(LEFT, col), GetBMPS(RIGHT, cols_ - 1 - col)};
   }
 
-  std::vector<double> Trace(const SiteIdx &a, BondOrientation dir) const {
-    std::vector<double> out(walkers());
-    check_rc(pepsgpu_trace(ctx_, (int)a.r, (int)a.c, dir, out.data()), ctx_);
+  std::vector<TenElemT> Trace(const SiteIdx &a, BondOrientation dir) const {
+    std::vector<TenElemT> out(walkers());
+    check_rc(pepsgpu_trace(ctx_, (int)a.r, (int)a.c, dir, dptr(out.data())), ctx_);
     return out;
   }
   // ReplaceNNSiteTrace for n_cand candidate (state_a, state_b) pairs per walker: cand[w][k][2]
-  std::vector<double> ReplaceNNSiteTrace(const SiteIdx &a, BondOrientation dir, int n_cand, const std::vector<int32_t> &cand) const {
-    std::vector<double> out(walkers() * n_cand);
-    check_rc(pepsgpu_replace_nn_trace(ctx_, (int)a.r, (int)a.c, dir, n_cand, cand.data(), out.data()), ctx_);
+  std::vector<TenElemT> ReplaceNNSiteTrace(const SiteIdx &a, BondOrientation dir, int n_cand, const std::vector<int32_t> &cand) const {
+    std::vector<TenElemT> out(walkers() * n_cand);
+    check_rc(pepsgpu_replace_nn_trace(ctx_, (int)a.r, (int)a.c, dir, n_cand, cand.data(), dptr(out.data())), ctx_);
     return out;
   }
-  std::vector<double> ReplaceOneSiteTrace(const SiteIdx &s, BondOrientation orient, int n_cand, const std::vector<int32_t> &cand) const {
-    std::vector<double> out(walkers() * n_cand);
-    check_rc(pepsgpu_replace_one_trace(ctx_, (int)s.r, (int)s.c, orient, n_cand, cand.data(), out.data()), ctx_);
+  std::vector<TenElemT> ReplaceOneSiteTrace(const SiteIdx &s, BondOrientation orient, int n_cand, const std::vector<int32_t> &cand) const {
+    std::vector<TenElemT> out(walkers() * n_cand);
+    check_rc(pepsgpu_replace_one_trace(ctx_, (int)s.r, (int)s.c, orient, n_cand, cand.data(), dptr(out.data())), ctx_);
     return out;
   }
   // Two-row environments (bten_set2_): init.h:130-186, grow.h:375-527
@@ -378,31 +410,31 @@ class BMPSContractor {
   void GrowBTen2Step(BTenPOSITION p, size_t slice_num1) { check_rc(pepsgpu_grow_bten2_step(ctx_, p, (int)slice_num1), ctx_); }
   void ShiftBTen2Window(BTenPOSITION p, size_t slice_num1) { check_rc(pepsgpu_shift_bten2_window(ctx_, p, (int)slice_num1), ctx_); }
   // trace.h:207-324 / :326-423 / :425-536; cand[w][k][2|3|2], n_cand = 0: no replacement
-  std::vector<double> ReplaceNNNSiteTrace(const SiteIdx &left_up, DIAGONAL_DIR nnn_dir, BondOrientation orient, int n_cand,
+  std::vector<TenElemT> ReplaceNNNSiteTrace(const SiteIdx &left_up, DIAGONAL_DIR nnn_dir, BondOrientation orient, int n_cand,
                                           const std::vector<int32_t> &cand) const {
-    std::vector<double> out(walkers() * (n_cand > 0 ? n_cand : 1));
+    std::vector<TenElemT> out(walkers() * (n_cand > 0 ? n_cand : 1));
     check_rc(pepsgpu_replace_nnn_trace(ctx_, (int)left_up.r, (int)left_up.c, nnn_dir, orient, n_cand,
-                                       n_cand > 0 ? cand.data() : nullptr, out.data()), ctx_);
+                                       n_cand > 0 ? cand.data() : nullptr, dptr(out.data())), ctx_);
     return out;
   }
-  std::vector<double> ReplaceTNNSiteTrace(const SiteIdx &site0, BondOrientation orient, int n_cand,
+  std::vector<TenElemT> ReplaceTNNSiteTrace(const SiteIdx &site0, BondOrientation orient, int n_cand,
                                           const std::vector<int32_t> &cand) const {
-    std::vector<double> out(walkers() * (n_cand > 0 ? n_cand : 1));
+    std::vector<TenElemT> out(walkers() * (n_cand > 0 ? n_cand : 1));
     check_rc(pepsgpu_replace_tnn_trace(ctx_, (int)site0.r, (int)site0.c, orient, n_cand,
-                                       n_cand > 0 ? cand.data() : nullptr, out.data()), ctx_);
+                                       n_cand > 0 ? cand.data() : nullptr, dptr(out.data())), ctx_);
     return out;
   }
-  std::vector<double> ReplaceSqrt5DistTwoSiteTrace(const SiteIdx &left_up, DIAGONAL_DIR link_dir, BondOrientation orient,
+  std::vector<TenElemT> ReplaceSqrt5DistTwoSiteTrace(const SiteIdx &left_up, DIAGONAL_DIR link_dir, BondOrientation orient,
                                                    int n_cand, const std::vector<int32_t> &cand) const {
-    std::vector<double> out(walkers() * (n_cand > 0 ? n_cand : 1));
+    std::vector<TenElemT> out(walkers() * (n_cand > 0 ? n_cand : 1));
     check_rc(pepsgpu_replace_sqrt5_trace(ctx_, (int)left_up.r, (int)left_up.c, link_dir, orient, n_cand,
-                                         n_cand > 0 ? cand.data() : nullptr, out.data()), ctx_);
+                                         n_cand > 0 ? cand.data() : nullptr, dptr(out.data())), ctx_);
     return out;
   }
   // PunchHole: [walker][D^4] (legs L,D,R,U zero padded)
-  std::vector<double> PunchHole(const SiteIdx &s, BondOrientation orient) const {
-    std::vector<double> out(walkers() * D_ * D_ * D_ * D_);
-    check_rc(pepsgpu_punch_hole(ctx_, (int)s.r, (int)s.c, orient, out.data()), ctx_);
+  std::vector<TenElemT> PunchHole(const SiteIdx &s, BondOrientation orient) const {
+    std::vector<TenElemT> out(walkers() * D_ * D_ * D_ * D_);
+    check_rc(pepsgpu_punch_hole(ctx_, (int)s.r, (int)s.c, orient, dptr(out.data())), ctx_);
     return out;
   }
   // Device-resident variant: the hole stays in HBM for GradAccumulate (no PCIe round trip)
@@ -410,14 +442,14 @@ class BMPSContractor {
     check_rc(pepsgpu_punch_hole(ctx_, (int)s.r, (int)s.c, orient, nullptr), ctx_);
   }
   void GradReset() { check_rc(pepsgpu_grad_reset(ctx_), ctx_); }
-  void GradAccumulate(const std::vector<double> &psi, const std::vector<double> &eloc, bool exact_sum) {
-    check_rc(pepsgpu_grad_accumulate(ctx_, psi.data(), eloc.data(), exact_sum), ctx_);
+  void GradAccumulate(const std::vector<TenElemT> &psi, const std::vector<TenElemT> &eloc, bool exact_sum) {
+    check_rc(pepsgpu_grad_accumulate(ctx_, dptr(psi.data()), dptr(eloc.data()), exact_sum), ctx_);
   }
   // ... with the component of every site named by the caller ([walker][row][col]): fermionic states
-  void GradAccumulate(const std::vector<double> &psi, const std::vector<double> &eloc, bool exact_sum,
+  void GradAccumulate(const std::vector<TenElemT> &psi, const std::vector<TenElemT> &eloc, bool exact_sum,
                       const std::vector<int32_t> &states) {
     if (states.size() != walkers() * rows() * cols()) throw std::invalid_argument("GradAccumulate: states must be [walker][row][col]");
-    check_rc(pepsgpu_grad_accumulate_states(ctx_, psi.data(), eloc.data(), exact_sum, states.data()), ctx_);
+    check_rc(pepsgpu_grad_accumulate_states(ctx_, dptr(psi.data()), dptr(eloc.data()), exact_sum, states.data()), ctx_);
   }
   // ---- the exchange step over ranks (one contractor = one GPU = one rank): RCCL through the library ----
   // CommInit: rank 0 draws `id` with UniqueId() and the host program broadcasts it (MPI_Bcast in the reference's MPI world).
@@ -440,17 +472,17 @@ class BMPSContractor {
   std::function<void(std::vector<double> &)> RcclReducer() {
     return [this](std::vector<double> &v) { AllReduceSum(v); };
   }
-  void GradRead(std::vector<double> &so, std::vector<double> &seo) const {
+  void GradRead(std::vector<TenElemT> &so, std::vector<TenElemT> &seo) const {
     const size_t n = rows_ * cols_ * d_ * D_ * D_ * D_ * D_;
     so.resize(n); seo.resize(n);
-    check_rc(pepsgpu_grad_read(ctx_, so.data(), seo.data()), ctx_);
+    check_rc(pepsgpu_grad_read(ctx_, dptr(so.data()), dptr(seo.data())), ctx_);
   }
   void UpdateLocal(const std::vector<int32_t> &sites, const std::vector<int32_t> &new_states, const std::vector<uint8_t> &mask) {
     check_rc(pepsgpu_update_local(ctx_, (int)(sites.size() / 2), sites.data(), new_states.data(), mask.data()), ctx_);
   }
-  std::vector<double> EvaluateAmplitude() {
-    std::vector<double> out(walkers());
-    check_rc(pepsgpu_evaluate_amplitude(ctx_, out.data()), ctx_);
+  std::vector<TenElemT> EvaluateAmplitude() {
+    std::vector<TenElemT> out(walkers());
+    check_rc(pepsgpu_evaluate_amplitude(ctx_, dptr(out.data())), ctx_);
     return out;
   }
   std::vector<int32_t> WalkerFlags() const {
@@ -464,6 +496,7 @@ class BMPSContractor {
   BMPSTruncateParams trunc_;
   pepsgpu_ctx *ctx_ = nullptr;
 };
+using BMPSContractor = BMPSContractorT<double>;
 
 // ---------------------------------------------------------------------------------------------
 // Fermionic (fZ2-graded) states.  The graded contraction of the projected network equals an ordinary
@@ -536,15 +569,16 @@ struct FermionDecoration {
 // TPSWaveFunctionComponent (wave_function_component.h:136-379), one entry per walker.  `config` is always the
 // PHYSICAL configuration; for a fermionic state (`fermion` set) the device is given the extended states of the
 // current mode order.
-struct TPSWaveFunctionComponent {
+template <typename TenElemT>
+struct TPSWaveFunctionComponentT {
   Configuration config;
-  std::vector<double> amplitude;
-  BMPSContractor &contractor;
+  std::vector<TenElemT> amplitude;
+  BMPSContractorT<TenElemT> &contractor;
   BMPSTruncateParams trun_para;
   const FermionDecoration *fermion = nullptr;
   ModeOrder order = ROW_MAJOR;
 
-  TPSWaveFunctionComponent(const SplitIndexTPS &sitps, const Configuration &cfg, BMPSContractor &c,
+  TPSWaveFunctionComponentT(const SplitIndexTPST<TenElemT> &sitps, const Configuration &cfg, BMPSContractorT<TenElemT> &c,
                            const FermionDecoration *ferm = nullptr)
       : config(cfg), contractor(c), trun_para(c.GetTruncateParams()), fermion(ferm) {
     contractor.UploadState(sitps);
@@ -559,7 +593,7 @@ struct TPSWaveFunctionComponent {
     order = o;
     InitDevice();
   }
-  const std::vector<double> &EvaluateAmplitude() {      // :187-212
+  const std::vector<TenElemT> &EvaluateAmplitude() {      // :187-212
     if (fermion && order != ROW_MAJOR) SetOrder(ROW_MAJOR);
     amplitude = contractor.EvaluateAmplitude();
     auto flags = contractor.WalkerFlags();
@@ -568,7 +602,7 @@ struct TPSWaveFunctionComponent {
         throw std::runtime_error("BMPS::MultiplyMPOSVDCompress_: Empty tensor (walker " + std::to_string(w) +
                                  "). Configuration may have near-zero amplitude due to numerical degeneracy.");
     if (fermion)
-      for (size_t w = 0; w < amplitude.size(); ++w) amplitude[w] *= fermion->Sigma(config, w);
+      for (size_t w = 0; w < amplitude.size(); ++w) amplitude[w] *= double(fermion->Sigma(config, w));
     return amplitude;
   }
   void ReplaceGlobalConfig(const Configuration &cfg) {   // :180-185
@@ -600,12 +634,12 @@ struct TPSWaveFunctionComponent {
     }
     return out;
   }
-  std::vector<double> ReplaceNNSiteTrace(const SiteIdx &s1, const SiteIdx &s2, BondOrientation dir, int n_cand,
+  std::vector<TenElemT> ReplaceNNSiteTrace(const SiteIdx &s1, const SiteIdx &s2, BondOrientation dir, int n_cand,
                                          const std::vector<int32_t> &cand) const {
     return contractor.ReplaceNNSiteTrace(s1, dir, n_cand, DeviceStatesNN(s1, s2, n_cand, cand));
   }
   // UpdateLocal (:345-378) for the walkers with mask != 0; new_states are physical, [walker][site]
-  void UpdateLocal(const std::vector<double> &new_amplitude, const std::vector<SiteIdx> &sites,
+  void UpdateLocal(const std::vector<TenElemT> &new_amplitude, const std::vector<SiteIdx> &sites,
                    const std::vector<int32_t> &new_states, const std::vector<uint8_t> &mask) {
     std::vector<int32_t> flat_sites;
     for (auto &s : sites) { flat_sites.push_back((int32_t)s.r); flat_sites.push_back((int32_t)s.c); }
@@ -620,15 +654,16 @@ struct TPSWaveFunctionComponent {
       for (size_t k = 0; k < sites.size(); ++k) config(w, sites[k]) = new_states[w * sites.size() + k];
       // new_amplitude is the contraction value of the replace-trace: for a fermionic state that is the DECORATED network
       // of the current mode order; the stored amplitude is always the signed graded one (as EvaluateAmplitude stores it)
-      amplitude[w] = fermion ? new_amplitude[w] * fermion->Sigma(config, w) * (order == COL_MAJOR ? fermion->Kappa(config, w) : 1)
+      amplitude[w] = fermion ? new_amplitude[w] * double(fermion->Sigma(config, w) * (order == COL_MAJOR ? fermion->Kappa(config, w) : 1))
                              : new_amplitude[w];
     }
   }
   bool IsAmplitudeSquareLegal(size_t w) const {          // :309-315
-    double a = std::fabs(amplitude[w]);
+    double a = std::abs(amplitude[w]);
     return !std::isnan(a) && a > std::sqrt(std::numeric_limits<double>::min()) && a < std::sqrt(std::numeric_limits<double>::max());
   }
 };
+using TPSWaveFunctionComponent = TPSWaveFunctionComponentT<double>;
 
 // suwa_todo_update.h:53-112
 template <class RandGenerator>
@@ -674,7 +709,8 @@ template <typename MCUpdater>
 class MCUpdateSquareNNUpdateBaseOBC : public MonteCarloSweepUpdaterBase {
  public:
   using MonteCarloSweepUpdaterBase::MonteCarloSweepUpdaterBase;
-  void operator()(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp, std::vector<double> &accept_rates) {
+  template <typename TenElemT>
+  void operator()(const SplitIndexTPST<TenElemT> &sitps, TPSWaveFunctionComponentT<TenElemT> &comp, std::vector<double> &accept_rates) {
     auto &c = comp.contractor;
     const size_t rows = c.rows(), cols = c.cols(), n = comp.config.walkers();
     std::vector<size_t> acc(n, 0);
@@ -714,8 +750,9 @@ class MCUpdateSquareNNUpdateBaseOBC : public MonteCarloSweepUpdaterBase {
 class MCUpdateSquareNNExchangeOBC : public MCUpdateSquareNNUpdateBaseOBC<MCUpdateSquareNNExchangeOBC> {
  public:
   using MCUpdateSquareNNUpdateBaseOBC<MCUpdateSquareNNExchangeOBC>::MCUpdateSquareNNUpdateBaseOBC;
+  template <typename TenElemT>
   std::vector<uint8_t> TwoSiteNNUpdateLocalImpl(const SiteIdx &s1, const SiteIdx &s2, BondOrientation dir,
-                                                const SplitIndexTPS &, TPSWaveFunctionComponent &comp) {
+                                                const SplitIndexTPST<TenElemT> &, TPSWaveFunctionComponentT<TenElemT> &comp) {
     const size_t n = comp.config.walkers();
     std::vector<int32_t> cand(n * 2);
     bool any = false;
@@ -726,10 +763,10 @@ class MCUpdateSquareNNExchangeOBC : public MCUpdateSquareNNUpdateBaseOBC<MCUpdat
     }
     std::vector<uint8_t> exchange(n, 0);
     if (!any) return exchange;            // every walker has equal spins on the bond (:149-151)
-    std::vector<double> psi_b = comp.ReplaceNNSiteTrace(s1, s2, dir, 1, cand);
+    std::vector<TenElemT> psi_b = comp.ReplaceNNSiteTrace(s1, s2, dir, 1, cand);
     for (size_t w = 0; w < n; ++w) {
       if (comp.config(w, s1) == comp.config(w, s2)) continue;
-      const double pa = std::fabs(comp.amplitude[w]), pb = std::fabs(psi_b[w]);
+      const double pa = std::abs(comp.amplitude[w]), pb = std::abs(psi_b[w]);
       if (pb >= pa) exchange[w] = 1;
       else {
         const double div = pb / pa;
@@ -745,21 +782,22 @@ class MCUpdateSquareNNExchangeOBC : public MCUpdateSquareNNUpdateBaseOBC<MCUpdat
 class MCUpdateSquareNNFullSpaceUpdateOBC : public MCUpdateSquareNNUpdateBaseOBC<MCUpdateSquareNNFullSpaceUpdateOBC> {
  public:
   using MCUpdateSquareNNUpdateBaseOBC<MCUpdateSquareNNFullSpaceUpdateOBC>::MCUpdateSquareNNUpdateBaseOBC;
+  template <typename TenElemT>
   std::vector<uint8_t> TwoSiteNNUpdateLocalImpl(const SiteIdx &s1, const SiteIdx &s2, BondOrientation dir,
-                                                const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp) {
+                                                const SplitIndexTPST<TenElemT> &sitps, TPSWaveFunctionComponentT<TenElemT> &comp) {
     const size_t n = comp.config.walkers(), dim = sitps.PhysicalDim(), nc = dim * dim;
     std::vector<int32_t> cand(n * nc * 2);
     for (size_t w = 0; w < n; ++w)
       for (size_t k = 0; k < nc; ++k) { cand[(w * nc + k) * 2] = (int32_t)(k / dim); cand[(w * nc + k) * 2 + 1] = (int32_t)(k % dim); }
-    std::vector<double> alt = comp.ReplaceNNSiteTrace(s1, s2, dir, (int)nc, cand);
+    std::vector<TenElemT> alt = comp.ReplaceNNSiteTrace(s1, s2, dir, (int)nc, cand);
     std::vector<uint8_t> changed(n, 0);
     std::vector<int32_t> ns(n * 2);
-    std::vector<double> new_amp(n);
+    std::vector<TenElemT> new_amp(n);
     for (size_t w = 0; w < n; ++w) {
       const size_t init = comp.config(w, s1) * dim + comp.config(w, s2);
       alt[w * nc + init] = comp.amplitude[w];
       std::vector<double> weights(nc);
-      for (size_t k = 0; k < nc; ++k) { const double r = alt[w * nc + k] / comp.amplitude[w]; weights[k] = r * r; }
+      for (size_t k = 0; k < nc; ++k) weights[k] = AbsSquare(TenElemT(alt[w * nc + k] / comp.amplitude[w]));
       const size_t fin = SuwaTodoStateUpdate(init, weights, engines_[w]);
       changed[w] = fin != init;
       ns[2 * w] = (int32_t)(fin / dim); ns[2 * w + 1] = (int32_t)(fin % dim);
@@ -771,11 +809,13 @@ class MCUpdateSquareNNFullSpaceUpdateOBC : public MCUpdateSquareNNUpdateBaseOBC<
 };
 
 // Result of CalEnergyAndHoles for a walker batch
-struct EnergyAndHoles {
-  std::vector<double> energy;                 // [walker]
-  std::vector<double> holes;                  // [walker][row][col][D^4]  (Dag(PunchHole); real: identity)
-  std::vector<std::vector<double>> psi_list;  // [row/col pass][walker]
+template <typename TenElemT>
+struct EnergyAndHolesT {
+  std::vector<TenElemT> energy;                 // [walker]
+  std::vector<TenElemT> holes;                  // [walker][row][col][D^4]  (Dag(PunchHole), square_nnn_energy_solver.h:163: the complex conjugate; real: identity)
+  std::vector<std::vector<TenElemT>> psi_list;  // [row/col pass][walker]
 };
+using EnergyAndHoles = EnergyAndHolesT<double>;
 
 // SquareNNNModelEnergySolver (square_nnn_energy_solver.h:37-316) + BondTraversalMixin::TraverseVerticalBonds
 // (bond_traversal_mixin.h:113-144).  CRTP hooks:
@@ -785,36 +825,38 @@ struct EnergyAndHoles {
 template <class ExplicitlyModel, bool has_nnn_interaction = true>
 class SquareNNNModelEnergySolver {
  public:
-  template <bool calchols = true>
-  EnergyAndHoles CalEnergyAndHoles(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp, bool holes_on_device = false) {
+  template <bool calchols = true, typename TenElemT = double>
+  EnergyAndHolesT<TenElemT> CalEnergyAndHoles(const SplitIndexTPST<TenElemT> &sitps, TPSWaveFunctionComponentT<TenElemT> &comp,
+                                              bool holes_on_device = false) {
     auto &c = comp.contractor;
     const size_t rows = c.rows(), cols = c.cols(), n = comp.config.walkers(), slot = sitps.slot();
-    EnergyAndHoles out;
-    out.energy.assign(n, 0.0);
-    if (calchols && !holes_on_device) out.holes.assign(n * rows * cols * slot, 0.0);
+    EnergyAndHolesT<TenElemT> out;
+    out.energy.assign(n, TenElemT(0.0));
+    if (calchols && !holes_on_device) out.holes.assign(n * rows * cols * slot, TenElemT(0.0));
     auto *self = static_cast<ExplicitlyModel *>(this);
     comp.SetOrder(ROW_MAJOR);                // fermions: holes are those of the row-major decorated network
     c.GenerateBMPSApproach(UP);                                              // :116
     for (size_t row = 0; row < rows; row++) {
       c.InitBTen(LEFT, row);                                                 // :142
       c.GrowFullBTen(RIGHT, row, 1, true);                                   // :143
-      std::vector<double> psi = c.Trace({row, 0}, HORIZONTAL);               // :147
-      std::vector<double> inv_psi(n);
+      std::vector<TenElemT> psi = c.Trace({row, 0}, HORIZONTAL);             // :147
+      std::vector<TenElemT> inv_psi(n);
       for (size_t w = 0; w < n; ++w) {
-        if (psi[w] == 0.0) throw std::runtime_error("Wavefunction amplitude is near zero, causing division by zero.");
-        inv_psi[w] = 1.0 / psi[w];
+        if (psi[w] == TenElemT(0.0)) throw std::runtime_error("Wavefunction amplitude is near zero, causing division by zero.");
+        inv_psi[w] = TenElemT(1.0) / psi[w];
       }
       out.psi_list.push_back(psi);
       for (size_t col = 0; col < cols; col++) {
         if (calchols && holes_on_device) {
           c.PunchHoleStore({row, col}, HORIZONTAL);                           // :163, hole kept in HBM
         } else if (calchols) {
-          std::vector<double> h = c.PunchHole({row, col}, HORIZONTAL);        // :163
+          std::vector<TenElemT> h = c.PunchHole({row, col}, HORIZONTAL);      // :163 hole_res(site) = Dag(hole)
           for (size_t w = 0; w < n; ++w)
-            std::copy(h.begin() + w * slot, h.begin() + (w + 1) * slot, out.holes.begin() + ((w * rows + row) * cols + col) * slot);
+            std::transform(h.begin() + w * slot, h.begin() + (w + 1) * slot, out.holes.begin() + ((w * rows + row) * cols + col) * slot,
+                           [](const TenElemT &x) { return ComplexConjugate(x); });
         }
         if (col + 1 < cols) {
-          std::vector<double> e = self->EvaluateBondEnergy({row, col}, {row, col + 1}, HORIZONTAL, comp, inv_psi);
+          std::vector<TenElemT> e = self->EvaluateBondEnergy({row, col}, {row, col + 1}, HORIZONTAL, comp, inv_psi);
           for (size_t w = 0; w < n; ++w) out.energy[w] += e[w];
           c.ShiftBTenWindow(RIGHT);                                           // :200
         }
@@ -824,8 +866,8 @@ class SquareNNNModelEnergySolver {
           c.InitBTen2(LEFT, row);
           c.GrowFullBTen2(RIGHT, row, 2, true);
           for (size_t col = 0; col + 1 < cols; col++) {
-            std::vector<double> e1 = self->EvaluateNNNEnergy({row, col}, {row + 1, col + 1}, LEFTUP_TO_RIGHTDOWN, comp, inv_psi);
-            std::vector<double> e2 = self->EvaluateNNNEnergy({row + 1, col}, {row, col + 1}, LEFTDOWN_TO_RIGHTUP, comp, inv_psi);
+            std::vector<TenElemT> e1 = self->EvaluateNNNEnergy({row, col}, {row + 1, col + 1}, LEFTUP_TO_RIGHTDOWN, comp, inv_psi);
+            std::vector<TenElemT> e2 = self->EvaluateNNNEnergy({row + 1, col}, {row, col + 1}, LEFTDOWN_TO_RIGHTUP, comp, inv_psi);
             for (size_t w = 0; w < n; ++w) out.energy[w] += e1[w] + e2[w];
             c.ShiftBTen2Window(RIGHT, row);
           }
@@ -838,15 +880,15 @@ class SquareNNNModelEnergySolver {
     for (size_t col = 0; col < cols; col++) {
       c.InitBTen(UP, col);
       c.GrowFullBTen(DOWN, col, 2, true);
-      std::vector<double> psi = c.Trace({0, col}, VERTICAL);
-      std::vector<double> inv_psi(n);
+      std::vector<TenElemT> psi = c.Trace({0, col}, VERTICAL);
+      std::vector<TenElemT> inv_psi(n);
       for (size_t w = 0; w < n; ++w) {
-        if (psi[w] == 0.0) throw std::runtime_error("Wavefunction amplitude is near zero, causing division by zero.");
-        inv_psi[w] = 1.0 / psi[w];
+        if (psi[w] == TenElemT(0.0)) throw std::runtime_error("Wavefunction amplitude is near zero, causing division by zero.");
+        inv_psi[w] = TenElemT(1.0) / psi[w];
       }
       out.psi_list.push_back(psi);
       for (size_t row = 0; row + 1 < rows; row++) {
-        std::vector<double> e = self->EvaluateBondEnergy({row, col}, {row + 1, col}, VERTICAL, comp, inv_psi);
+        std::vector<TenElemT> e = self->EvaluateBondEnergy({row, col}, {row + 1, col}, VERTICAL, comp, inv_psi);
         for (size_t w = 0; w < n; ++w) out.energy[w] += e[w];
         if (row + 2 < rows) c.ShiftBTenWindow(DOWN);
       }
@@ -1160,8 +1202,9 @@ class SquareSpinOneHalfXXZModelMixIn {
  public:
   SquareSpinOneHalfXXZModelMixIn(double jz, double jxy, double jz2, double jxy2, double pinning00)
       : jz_(jz), jxy_(jxy), jz2_(jz2), jxy2_(jxy2), pinning00_(pinning00) {}
-  std::vector<double> EvaluateBondEnergy(const SiteIdx &s1, const SiteIdx &s2, BondOrientation orient,
-                                         TPSWaveFunctionComponent &comp, const std::vector<double> &inv_psi) {   // :72-104
+  template <typename TenElemT>
+  std::vector<TenElemT> EvaluateBondEnergy(const SiteIdx &s1, const SiteIdx &s2, BondOrientation orient,
+                                           TPSWaveFunctionComponentT<TenElemT> &comp, const std::vector<TenElemT> &inv_psi) {   // :72-104
     const size_t n = comp.config.walkers();
     std::vector<int32_t> cand(n * 2);
     bool any = false;
@@ -1170,16 +1213,17 @@ class SquareSpinOneHalfXXZModelMixIn {
       cand[2 * w + 1] = comp.config(w, s1);
       any |= cand[2 * w] != cand[2 * w + 1];
     }
-    std::vector<double> e(n, 0.25 * jz_);
+    std::vector<TenElemT> e(n, TenElemT(0.25 * jz_));
     if (!any) return e;
-    std::vector<double> psi_ex = comp.ReplaceNNSiteTrace(s1, s2, orient, 1, cand);
+    std::vector<TenElemT> psi_ex = comp.ReplaceNNSiteTrace(s1, s2, orient, 1, cand);
     for (size_t w = 0; w < n; ++w)
-      if (comp.config(w, s1) != comp.config(w, s2)) e[w] = -0.25 * jz_ + psi_ex[w] * inv_psi[w] * 0.5 * jxy_;
+      if (comp.config(w, s1) != comp.config(w, s2)) e[w] = -0.25 * jz_ + ComplexConjugate(TenElemT(psi_ex[w] * inv_psi[w])) * (0.5 * jxy_);   // :98-100
     return e;
   }
   // :107-134; site1 = left end of the diagonal, site2 = right end
-  std::vector<double> EvaluateNNNEnergy(const SiteIdx &s1, const SiteIdx &s2, DIAGONAL_DIR diagonal_dir,
-                                        TPSWaveFunctionComponent &comp, const std::vector<double> &inv_psi) {
+  template <typename TenElemT>
+  std::vector<TenElemT> EvaluateNNNEnergy(const SiteIdx &s1, const SiteIdx &s2, DIAGONAL_DIR diagonal_dir,
+                                          TPSWaveFunctionComponentT<TenElemT> &comp, const std::vector<TenElemT> &inv_psi) {
     const size_t n = comp.config.walkers();
     std::vector<int32_t> cand(n * 2);
     bool any = false;
@@ -1188,12 +1232,12 @@ class SquareSpinOneHalfXXZModelMixIn {
       cand[2 * w + 1] = comp.config(w, s1);
       any |= cand[2 * w] != cand[2 * w + 1];
     }
-    std::vector<double> e(n, 0.25 * jz2_);
+    std::vector<TenElemT> e(n, TenElemT(0.25 * jz2_));
     if (!any) return e;
     const SiteIdx left_up = diagonal_dir == LEFTUP_TO_RIGHTDOWN ? s1 : SiteIdx{s2.r, s1.c};
-    std::vector<double> psi_ex = comp.contractor.ReplaceNNNSiteTrace(left_up, diagonal_dir, HORIZONTAL, 1, cand);
+    std::vector<TenElemT> psi_ex = comp.contractor.ReplaceNNNSiteTrace(left_up, diagonal_dir, HORIZONTAL, 1, cand);
     for (size_t w = 0; w < n; ++w)
-      if (comp.config(w, s1) != comp.config(w, s2)) e[w] = -0.25 * jz2_ + psi_ex[w] * inv_psi[w] * 0.5 * jxy2_;
+      if (comp.config(w, s1) != comp.config(w, s2)) e[w] = -0.25 * jz2_ + ComplexConjugate(TenElemT(psi_ex[w] * inv_psi[w])) * (0.5 * jxy2_);
     return e;
   }
   double EvaluateTotalOnsiteEnergy(const Configuration &config, size_t w) const {   // :139-141
@@ -1336,31 +1380,33 @@ class TransverseFieldIsingSquareOBC {
       for (size_t r = 0; r + 1 < config.rows(); r++) e += (config(w, {r, c}) == config(w, {r + 1, c})) ? -1 : 1;
     return e;
   }
-  template <bool calchols = true>
-  EnergyAndHoles CalEnergyAndHoles(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp, bool holes_on_device = false) {   // :211-247
+  template <bool calchols = true, typename TenElemT = double>
+  EnergyAndHolesT<TenElemT> CalEnergyAndHoles(const SplitIndexTPST<TenElemT> &sitps, TPSWaveFunctionComponentT<TenElemT> &comp,
+                                              bool holes_on_device = false) {   // :211-247
     auto &c = comp.contractor;
     const size_t rows = c.rows(), cols = c.cols(), n = comp.config.walkers(), slot = sitps.slot();
-    EnergyAndHoles out;
-    out.energy.assign(n, 0.0);
-    if (calchols && !holes_on_device) out.holes.assign(n * rows * cols * slot, 0.0);
+    EnergyAndHolesT<TenElemT> out;
+    out.energy.assign(n, TenElemT(0.0));
+    if (calchols && !holes_on_device) out.holes.assign(n * rows * cols * slot, TenElemT(0.0));
     c.GenerateBMPSApproach(UP);
     for (size_t row = 0; row < rows; row++) {
       c.InitBTen(LEFT, row);
       c.GrowFullBTen(RIGHT, row, 1, true);
-      std::vector<double> psi = c.Trace({row, 0}, HORIZONTAL);
+      std::vector<TenElemT> psi = c.Trace({row, 0}, HORIZONTAL);
       out.psi_list.push_back(psi);
       for (size_t col = 0; col < cols; col++) {
         if (calchols && holes_on_device) {
           c.PunchHoleStore({row, col}, HORIZONTAL);
         } else if (calchols) {
-          std::vector<double> h = c.PunchHole({row, col}, HORIZONTAL);
+          std::vector<TenElemT> h = c.PunchHole({row, col}, HORIZONTAL);
           for (size_t w = 0; w < n; ++w)
-            std::copy(h.begin() + w * slot, h.begin() + (w + 1) * slot, out.holes.begin() + ((w * rows + row) * cols + col) * slot);
+            std::transform(h.begin() + w * slot, h.begin() + (w + 1) * slot, out.holes.begin() + ((w * rows + row) * cols + col) * slot,
+                           [](const TenElemT &x) { return ComplexConjugate(x); });     // Dag(hole)
         }
         std::vector<int32_t> cand(n);
         for (size_t w = 0; w < n; ++w) cand[w] = 1 - comp.config(w, {row, col});
-        std::vector<double> psi_ex = c.ReplaceOneSiteTrace({row, col}, HORIZONTAL, 1, cand);      // :195-203
-        for (size_t w = 0; w < n; ++w) out.energy[w] += (-h_) * psi_ex[w] / psi[w];
+        std::vector<TenElemT> psi_ex = c.ReplaceOneSiteTrace({row, col}, HORIZONTAL, 1, cand);    // :195-203
+        for (size_t w = 0; w < n; ++w) out.energy[w] += (-h_) * ComplexConjugate(TenElemT(psi_ex[w] / psi[w]));
         if (col + 1 < cols) c.ShiftBTenWindow(RIGHT);
       }
       if (row + 1 < rows) c.ShiftBMPSWindow(DOWN);
@@ -1374,93 +1420,107 @@ class TransverseFieldIsingSquareOBC {
 
 // Accumulators of the evaluators: S_O = sum w O*, S_EO = sum w E_loc* O*, sum w, sum w E_loc
 // (exact_summation_energy_evaluator.h:195-245; mc_energy_grad_evaluator.h:245-278 with w = 1).
-struct GradAccumulator {
-  SplitIndexTPS Ostar_sum, ELocConj_Ostar_sum;
-  double weight_sum = 0.0, e_loc_sum = 0.0, e_loc_sq_sum = 0.0;
+template <typename TenElemT>
+struct GradAccumulatorT {
+  SplitIndexTPST<TenElemT> Ostar_sum, ELocConj_Ostar_sum;
+  double weight_sum = 0.0, e_loc_sq_sum = 0.0;
+  TenElemT e_loc_sum = TenElemT(0.0);
   size_t samples = 0;
-  GradAccumulator(const SplitIndexTPS &like)
+  static constexpr size_t kScalars = ElemTraits<TenElemT>::is_complex ? 5 : 4;   // weight, E (re [, im]), |E|^2, samples
+  GradAccumulatorT(const SplitIndexTPST<TenElemT> &like)
       : Ostar_sum(like.rows(), like.cols(), like.PhysicalDim(), like.D()),
         ELocConj_Ostar_sum(like.rows(), like.cols(), like.PhysicalDim(), like.D()) {}
 
-  // exact summation: weight |psi|^2, O* increment = psi * hole  (:231)
-  // Monte Carlo:     weight 1,       O* = hole / psi           (mc_energy_grad_evaluator.h:266)
-  void Accumulate(const TPSWaveFunctionComponent &comp, const EnergyAndHoles &eh, bool exact_sum) {
+  // exact summation: weight |psi|^2, O* increment = psi * Dag(hole)        (exact_summation_energy_evaluator.h:231)
+  // Monte Carlo:     weight 1,       O* = conj(1 / psi) * Dag(hole)          (mc_energy_grad_evaluator.h:246, :266)
+  // S_EO += conj(E_loc) * increment                                          (:239 / :272);  eh.holes already hold Dag(hole)
+  void Accumulate(const TPSWaveFunctionComponentT<TenElemT> &comp, const EnergyAndHolesT<TenElemT> &eh, bool exact_sum) {
     const size_t n = comp.config.walkers(), rows = Ostar_sum.rows(), cols = Ostar_sum.cols(), slot = Ostar_sum.slot();
     for (size_t w = 0; w < n; ++w) {
       // fermions: psi = sigma * Dense_row, d psi / d T''_v = sigma * hole: the derivative of ln psi with respect to the
       // DECORATED component (extended state) uses the plain contraction value; FoldFermionGradient maps it back
-      const double psi = comp.fermion ? comp.amplitude[w] * comp.fermion->Sigma(comp.config, w) : comp.amplitude[w];
-      const double e = eh.energy[w];
-      const double wt = exact_sum ? psi * psi : 1.0;
-      const double f = exact_sum ? psi : 1.0 / psi;
+      const TenElemT psi = comp.fermion ? comp.amplitude[w] * double(comp.fermion->Sigma(comp.config, w)) : comp.amplitude[w];
+      const TenElemT e = eh.energy[w], ec = ComplexConjugate(e);
+      const double wt = exact_sum ? AbsSquare(psi) : 1.0;
+      const TenElemT f = exact_sum ? psi : ComplexConjugate(TenElemT(TenElemT(1.0) / psi));
       for (size_t r = 0; r < rows; ++r)
         for (size_t c = 0; c < cols; ++c) {
           const size_t basis = comp.fermion ? (size_t)comp.fermion->Ext(comp.config, w, {r, c}, ROW_MAJOR)
                                             : (size_t)comp.config(w, {r, c});
-          const double *h = eh.holes.data() + ((w * rows + r) * cols + c) * slot;
-          double *so = Ostar_sum.component(r, c, basis), *seo = ELocConj_Ostar_sum.component(r, c, basis);
-          for (size_t k = 0; k < slot; ++k) { so[k] += f * h[k]; seo[k] += e * f * h[k]; }
+          const TenElemT *h = eh.holes.data() + ((w * rows + r) * cols + c) * slot;
+          TenElemT *so = Ostar_sum.component(r, c, basis), *seo = ELocConj_Ostar_sum.component(r, c, basis);
+          for (size_t k = 0; k < slot; ++k) { const TenElemT v = f * h[k]; so[k] += v; seo[k] += ec * v; }
         }
       weight_sum += wt;
       e_loc_sum += e * wt;
-      e_loc_sq_sum += e * e * wt;
+      e_loc_sq_sum += AbsSquare(e) * wt;
       ++samples;
     }
   }
   // Same accumulation with the holes resident on the device (BMPSContractor::PunchHoleStore):
-  // the tensor sums stay in HBM until FetchDevice().
+  // the tensor sums stay in HBM until FetchDevice() (the device applies Dag() and the conjugations itself).
   // Fermionic states: the stored holes are those of the row-major decorated network, d psi_dense / d T''; the device is told
   // the extended state of every site in that decoration and the plain contraction value psi_dense = sigma * psi (the
   // walkers themselves may be in the column-major decoration by now).
-  void AccumulateDevice(TPSWaveFunctionComponent &comp, const EnergyAndHoles &eh, bool exact_sum) {
+  void AccumulateDevice(TPSWaveFunctionComponentT<TenElemT> &comp, const EnergyAndHolesT<TenElemT> &eh, bool exact_sum) {
     if (comp.fermion) {
-      std::vector<double> dense(comp.amplitude);
-      for (size_t w = 0; w < dense.size(); ++w) dense[w] *= comp.fermion->Sigma(comp.config, w);
+      std::vector<TenElemT> dense(comp.amplitude);
+      for (size_t w = 0; w < dense.size(); ++w) dense[w] *= double(comp.fermion->Sigma(comp.config, w));
       const Configuration ext = comp.fermion->ExtConfig(comp.config, ROW_MAJOR);
       comp.contractor.GradAccumulate(dense, eh.energy, exact_sum, std::vector<int32_t>(ext.data(), ext.data() + ext.walkers() * ext.rows() * ext.cols()));
     } else {
       comp.contractor.GradAccumulate(comp.amplitude, eh.energy, exact_sum);
     }
     for (size_t w = 0; w < comp.config.walkers(); ++w) {
-      const double psi = comp.amplitude[w], e = eh.energy[w];
-      const double wt = exact_sum ? psi * psi : 1.0;
-      weight_sum += wt; e_loc_sum += e * wt; e_loc_sq_sum += e * e * wt;
+      const TenElemT psi = comp.amplitude[w], e = eh.energy[w];
+      const double wt = exact_sum ? AbsSquare(psi) : 1.0;
+      weight_sum += wt; e_loc_sum += e * wt; e_loc_sq_sum += AbsSquare(e) * wt;
       ++samples;
     }
   }
-  void FetchDevice(const BMPSContractor &c) {
-    std::vector<double> so, seo;
+  void FetchDevice(const BMPSContractorT<TenElemT> &c) {
+    std::vector<TenElemT> so, seo;
     c.GradRead(so, seo);
     auto &a = Ostar_sum.flat();
     auto &b = ELocConj_Ostar_sum.flat();
     for (size_t k = 0; k < a.size(); ++k) { a[k] += so[k]; b[k] += seo[k]; }
   }
-  // Flat view for the cross-rank sum that replaces MPIMeanTensor / MPI_Reduce
-  // (statistics_tensor.h:37-79, exact_summation_energy_evaluator.h:252-280): one all-reduce(sum).
+  // Flat view (doubles; a complex element = an interleaved (re, im) pair) for the cross-rank sum that replaces
+  // MPIMeanTensor / MPI_Reduce (statistics_tensor.h:37-79, exact_summation_energy_evaluator.h:252-280): one all-reduce(sum).
+  // Layout: S_O, S_EO, weight, E_loc sum (re [, im]), |E_loc|^2 sum, samples.
   std::vector<double> Pack() const {
+    const size_t m = Ostar_sum.flat().size() * (ElemTraits<TenElemT>::is_complex ? 2 : 1);
     std::vector<double> v;
-    v.reserve(2 * Ostar_sum.flat().size() + 4);
-    v.insert(v.end(), Ostar_sum.flat().begin(), Ostar_sum.flat().end());
-    v.insert(v.end(), ELocConj_Ostar_sum.flat().begin(), ELocConj_Ostar_sum.flat().end());
-    v.push_back(weight_sum); v.push_back(e_loc_sum); v.push_back(e_loc_sq_sum); v.push_back((double)samples);
+    v.reserve(2 * m + kScalars);
+    v.insert(v.end(), dptr(Ostar_sum.flat().data()), dptr(Ostar_sum.flat().data()) + m);
+    v.insert(v.end(), dptr(ELocConj_Ostar_sum.flat().data()), dptr(ELocConj_Ostar_sum.flat().data()) + m);
+    v.push_back(weight_sum);
+    v.push_back(std::real(e_loc_sum));
+    if (ElemTraits<TenElemT>::is_complex) v.push_back(std::imag(e_loc_sum));
+    v.push_back(e_loc_sq_sum); v.push_back((double)samples);
     return v;
   }
   void Unpack(const std::vector<double> &v) {
-    const size_t m = Ostar_sum.flat().size();
-    std::copy(v.begin(), v.begin() + m, Ostar_sum.flat().begin());
-    std::copy(v.begin() + m, v.begin() + 2 * m, ELocConj_Ostar_sum.flat().begin());
-    weight_sum = v[2 * m]; e_loc_sum = v[2 * m + 1]; e_loc_sq_sum = v[2 * m + 2]; samples = (size_t)v[2 * m + 3];
+    const size_t m = Ostar_sum.flat().size() * (ElemTraits<TenElemT>::is_complex ? 2 : 1);
+    std::copy(v.begin(), v.begin() + m, dptr(Ostar_sum.flat().data()));
+    std::copy(v.begin() + m, v.begin() + 2 * m, dptr(ELocConj_Ostar_sum.flat().data()));
+    size_t o = 2 * m;
+    weight_sum = v[o++];
+    if constexpr (ElemTraits<TenElemT>::is_complex) { e_loc_sum = TenElemT(v[o], v[o + 1]); o += 2; }
+    else e_loc_sum = v[o++];
+    e_loc_sq_sum = v[o++]; samples = (size_t)v[o++];
   }
   // energy = sum wE / sum w ; gradient = (S_EO - E* S_O) / sum w   (exact_summation_energy_evaluator.h:286-295)
-  std::pair<double, SplitIndexTPS> Finish() const {
-    const double energy = e_loc_sum / weight_sum;
-    SplitIndexTPS grad(Ostar_sum.rows(), Ostar_sum.cols(), Ostar_sum.PhysicalDim(), Ostar_sum.D());
+  std::pair<TenElemT, SplitIndexTPST<TenElemT>> Finish() const {
+    const TenElemT energy = e_loc_sum / weight_sum, ec = ComplexConjugate(energy);
+    SplitIndexTPST<TenElemT> grad(Ostar_sum.rows(), Ostar_sum.cols(), Ostar_sum.PhysicalDim(), Ostar_sum.D());
     const auto &so = Ostar_sum.flat(), &seo = ELocConj_Ostar_sum.flat();
     auto &g = grad.flat();
-    for (size_t k = 0; k < g.size(); ++k) g[k] = (seo[k] - energy * so[k]) / weight_sum;
+    for (size_t k = 0; k < g.size(); ++k) g[k] = (seo[k] - ec * so[k]) / weight_sum;
     return {energy, grad};
   }
 };
+using GradAccumulator = GradAccumulatorT<double>;
 
 // GenerateAllPermutationConfigs (exact_summation_energy_evaluator.h:74-95) for one walker batch layout
 // MCPEPSMeasurer (algorithm/vmc_update/monte_carlo_peps_measurer{.h,_impl.h}): warm-up, then per sample
@@ -1670,13 +1730,14 @@ std::map<std::string, std::vector<double>> ExactSumMeasurer(const SplitIndexTPS 
 // ExactSumEnergyEvaluatorMPI (exact_summation_energy_evaluator.h:173-302): configurations
 // i = rank, rank + size, ... are evaluated in batches of `batch` walkers; `allreduce` sums the
 // packed accumulators over ranks in place (RCCL all-reduce in the host program; identity if null).
-template <typename ModelT>
-std::pair<double, SplitIndexTPS> ExactSumEnergyEvaluator(const SplitIndexTPS &sitps, const std::vector<std::vector<int32_t>> &all_configs,
-                                                          BMPSContractor &contractor, ModelT &model, int rank, int size,
-                                                          size_t batch, const std::function<void(std::vector<double> &)> &allreduce,
-                                                          const FermionDecoration *fermion = nullptr) {
+template <typename ModelT, typename TenElemT>
+std::pair<TenElemT, SplitIndexTPST<TenElemT>> ExactSumEnergyEvaluator(const SplitIndexTPST<TenElemT> &sitps,
+                                                                      const std::vector<std::vector<int32_t>> &all_configs,
+                                                                      BMPSContractorT<TenElemT> &contractor, ModelT &model, int rank, int size,
+                                                                      size_t batch, const std::function<void(std::vector<double> &)> &allreduce,
+                                                                      const FermionDecoration *fermion = nullptr) {
   const size_t rows = sitps.rows(), cols = sitps.cols();
-  GradAccumulator acc(sitps);
+  GradAccumulatorT<TenElemT> acc(sitps);
   std::vector<size_t> mine;
   for (size_t i = rank; i < all_configs.size(); i += size) mine.push_back(i);                 // :201
   contractor.UploadState(sitps);
@@ -1685,9 +1746,9 @@ std::pair<double, SplitIndexTPS> ExactSumEnergyEvaluator(const SplitIndexTPS &si
     const size_t nb = std::min(batch, mine.size() - b0);
     Configuration cfg(nb, rows, cols);
     for (size_t w = 0; w < nb; ++w) std::copy(all_configs[mine[b0 + w]].begin(), all_configs[mine[b0 + w]].end(), cfg.data() + w * rows * cols);
-    TPSWaveFunctionComponent comp(sitps, cfg, contractor, fermion);
+    TPSWaveFunctionComponentT<TenElemT> comp(sitps, cfg, contractor, fermion);
     // (fermions: the gradient is taken with respect to the decorated -- extended -- components; FoldFermionGradient maps it back)
-    EnergyAndHoles eh = model.template CalEnergyAndHoles<true>(sitps, comp, /*holes_on_device=*/true);
+    EnergyAndHolesT<TenElemT> eh = model.template CalEnergyAndHoles<true>(sitps, comp, /*holes_on_device=*/true);
     acc.AccumulateDevice(comp, eh, true);
   }
   // a contractor with a communicator (CommInit) sums the tensor accumulators over the ranks where they live, in HBM
@@ -1697,9 +1758,10 @@ std::pair<double, SplitIndexTPS> ExactSumEnergyEvaluator(const SplitIndexTPS &si
   if (dev_reduce) contractor.GradAllReduce();
   if (!mine.empty() || dev_reduce) acc.FetchDevice(contractor);
   if (dev_reduce) {
-    std::vector<double> sc{acc.weight_sum, acc.e_loc_sum, acc.e_loc_sq_sum, (double)acc.samples};
+    std::vector<double> sc{acc.weight_sum, std::real(acc.e_loc_sum), std::imag(acc.e_loc_sum), acc.e_loc_sq_sum, (double)acc.samples};
     contractor.AllReduceSum(sc);
-    acc.weight_sum = sc[0]; acc.e_loc_sum = sc[1]; acc.e_loc_sq_sum = sc[2]; acc.samples = (size_t)sc[3];
+    acc.weight_sum = sc[0]; acc.e_loc_sq_sum = sc[3]; acc.samples = (size_t)sc[4];
+    if constexpr (ElemTraits<TenElemT>::is_complex) acc.e_loc_sum = TenElemT(sc[1], sc[2]); else acc.e_loc_sum = sc[1];
     return acc.Finish();
   }
   std::vector<double> packed = acc.Pack();

@@ -12,7 +12,9 @@ SYMBOLS = ["pepshost_last_error", "pepshost_mc_sweeps", "pepshost_energy_and_hol
            "pepshost_mc_energy_grad_partial", "pepshost_exact_sum_finish", "pepshost_load_sitps", "pepshost_dump_sitps",
            "pepshost_dump_configuration", "pepshost_load_configuration", "pepshost_fermion_energy",
            "pepshost_fermion_exact_sum_partial", "pepshost_fermion_mc_sweeps", "pepshost_measure",
-           "pepshost_set_truncate_params", "pepshost_set_device", "pepshost_get_device"]
+           "pepshost_set_truncate_params", "pepshost_set_device", "pepshost_get_device",
+           "pepshost_energy_and_holes_c128", "pepshost_exact_sum_partial_c128", "pepshost_exact_sum_finish_c128",
+           "pepshost_mc_energy_grad_partial_c128", "pepshost_mc_sweeps_c128", "pepshost_load_sitps_c128", "pepshost_dump_sitps_c128"]
 
 _lib = None
 
@@ -281,3 +283,98 @@ def fermion_exact_sum(state, all_configs, chi, t, V=0.0, batch=64, dtype=1):
                                                  _p(packed, C.c_double)))
     e, grad_ext = exact_sum_finish(packed, (rows, cols, 4 * state.d, D))
     return e, fermion.fold_gradient(state, grad_ext)
+
+
+# ---- TenElemT = QLTEN_Complex (std::complex<double>): the same host classes instantiated for the complex element type ----
+def _cflat(flat):
+    return np.ascontiguousarray(flat, dtype=np.complex128)
+
+
+def _cp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def load_sitps_complex(directory, D):
+    rows, cols, d = C.c_int(0), C.c_int(0), C.c_int(0)
+    _ck(lib().pepshost_load_sitps_c128(directory.encode(), D, C.byref(rows), C.byref(cols), C.byref(d), None, 0))
+    flat = np.zeros((rows.value, cols.value, d.value, D, D, D, D), dtype=np.complex128)
+    _ck(lib().pepshost_load_sitps_c128(directory.encode(), D, C.byref(rows), C.byref(cols), C.byref(d), _cp(flat), C.c_size_t(2 * flat.size)))
+    return flat
+
+
+def dump_sitps_complex(directory, flat):
+    flat = _cflat(flat)
+    rows, cols, d, D = _dims(flat)
+    os.makedirs(directory, exist_ok=True)
+    _ck(lib().pepshost_dump_sitps_c128(directory.encode(), rows, cols, D, d, _cp(flat)))
+
+
+def energy_and_holes_complex(flat, configs, chi, model="xxz", params=(1.0, 1.0, 0.0), holes=True):
+    """CalEnergyAndHoles of the C++ host layer on a COMPLEX state (BMPSContractorT<QLTEN_Complex>, PEPSGPU_C128 context):
+    (amplitudes, energies, holes = Dag(hole) [n][rows][cols][D^4] or None, psi_list [n_psi][n]), all complex128."""
+    flat = _cflat(flat)
+    rows, cols, d, D = _dims(flat)
+    cfg = np.ascontiguousarray(configs, dtype=np.int32)
+    n = cfg.shape[0]
+    p = np.array(list(params) + [0.0] * 8, dtype=np.float64)
+    amps = np.zeros(n, dtype=np.complex128)
+    en = np.zeros(n, dtype=np.complex128)
+    hl = np.zeros((n, rows, cols, D, D, D, D), dtype=np.complex128) if holes else None
+    psi = np.zeros((rows + cols, n), dtype=np.complex128)
+    npsi = C.c_int(0)
+    _ck(lib().pepshost_energy_and_holes_c128(rows, cols, D, d, chi, _cp(flat), n, _p(cfg, C.c_int32), MODEL_ID[model], _p(p, C.c_double),
+                                             _cp(amps), _cp(en), _cp(hl) if holes else None, _cp(psi), C.byref(npsi)))
+    return amps, en, hl, psi[:npsi.value]
+
+
+def exact_sum_complex(flat, all_configs, chi, model="xxz", params=(1.0, 1.0, 0.0), size=1, batch=64):
+    """ExactSumEnergyEvaluator on a complex state, the `size` rank-partials summed here: (energy complex, gradient complex128
+    in the upload layout).  Holes resident in HBM, O* accumulation with the conjugations of
+    exact_summation_energy_evaluator.h:228-240 on the device (pepsgpu_grad_accumulate for PEPSGPU_C128)."""
+    flat = _cflat(flat)
+    rows, cols, d, D = _dims(flat)
+    cfg = np.ascontiguousarray(all_configs, dtype=np.int32)
+    p = np.array(list(params) + [0.0] * 8, dtype=np.float64)
+    m = flat.size
+    tot = np.zeros(4 * m + 5)
+    for rank in range(size):
+        packed = np.zeros(4 * m + 5)
+        _ck(lib().pepshost_exact_sum_partial_c128(rows, cols, D, d, chi, _cp(flat), _p(cfg, C.c_int32), cfg.shape[0], MODEL_ID[model],
+                                                  _p(p, C.c_double), rank, size, batch, _p(packed, C.c_double)))
+        tot += packed
+    e = np.zeros(2)
+    grad = np.zeros(flat.shape, dtype=np.complex128)
+    _ck(lib().pepshost_exact_sum_finish_c128(rows, cols, D, d, _p(tot, C.c_double), _p(e, C.c_double), _cp(grad)))
+    return complex(e[0], e[1]), grad
+
+
+def mc_sweeps_complex(flat, configs, seeds, chi, updater="exchange", n_sweeps=1):
+    flat = _cflat(flat)
+    rows, cols, d, D = _dims(flat)
+    cfg = np.ascontiguousarray(configs, dtype=np.int32).copy()
+    n = cfg.shape[0]
+    sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+    amps = np.zeros(n, dtype=np.complex128)
+    rates = np.zeros(n)
+    _ck(lib().pepshost_mc_sweeps_c128(rows, cols, D, d, chi, _cp(flat), n, _p(cfg, C.c_int32), _p(sd, C.c_uint64),
+                                      0 if updater == "exchange" else 1, n_sweeps, _cp(amps), _p(rates, C.c_double)))
+    return cfg, amps, rates
+
+
+def mc_energy_grad_complex(flat, configs, seeds, chi, updater="exchange", model="xxz", params=(1.0, 1.0, 0.0), warmup_sweeps=1, n_samples=1):
+    """MCEnergyGradEvaluator loop on a complex state: (energy, gradient, final configs, accept rates)"""
+    flat = _cflat(flat)
+    rows, cols, d, D = _dims(flat)
+    cfg = np.ascontiguousarray(configs, dtype=np.int32).copy()
+    n = cfg.shape[0]
+    sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+    p = np.array(list(params) + [0.0] * 8, dtype=np.float64)
+    packed = np.zeros(4 * flat.size + 5)
+    acc = np.zeros(n)
+    _ck(lib().pepshost_mc_energy_grad_partial_c128(rows, cols, D, d, chi, _cp(flat), n, _p(cfg, C.c_int32), _p(sd, C.c_uint64),
+                                                   0 if updater == "exchange" else 1, MODEL_ID[model], _p(p, C.c_double), warmup_sweeps,
+                                                   n_samples, _p(packed, C.c_double), _p(acc, C.c_double)))
+    e = np.zeros(2)
+    grad = np.zeros(flat.shape, dtype=np.complex128)
+    _ck(lib().pepshost_exact_sum_finish_c128(rows, cols, D, d, _p(packed, C.c_double), _p(e, C.c_double), _cp(grad)))
+    return complex(e[0], e[1]), grad, cfg, acc

@@ -54,6 +54,28 @@ def test_cpp_qlten_loader_matches_oracle(fixtures_dir):
         hostapi.load_sitps(os.path.join(fixtures_dir, "does_not_exist"), 8)
 
 
+def test_complex_qlten_round_trip_is_byte_identical(fixtures_dir, tmp_path):
+    """SplitIndexTPS<QLTEN_Complex>::Load -> Dump of the host layer (qlpeps_gpu.h, TenElemT = std::complex<double>) reproduces the
+    reference's COMPLEX fixture byte for byte (interleaved complex128 payloads), and equals the oracle's reader."""
+    import filecmp
+    from peps_amd import hostapi
+    from oracle import qlten_io
+    src = os.path.join(fixtures_dir, "heisenberg_tps_complex_from_simple_update")
+    flat = hostapi.load_sitps_complex(src, 4)
+    ref = qlten_io.load_sitps(src, complex_data=True)
+    for r in range(2):
+        for c in range(2):
+            for s_ in range(2):
+                t = ref[r][c][s_]
+                assert np.array_equal(flat[r, c, s_][:t.shape[0], :t.shape[1], :t.shape[2], :t.shape[3]], t)
+    out = str(tmp_path / "cpp")
+    hostapi.dump_sitps_complex(out, flat)
+    files = sorted(f for f in os.listdir(src) if f.endswith(".qlten"))
+    assert files
+    for f in files:
+        assert filecmp.cmp(os.path.join(src, f), os.path.join(out, f), shallow=False), f
+
+
 @pytest.mark.parametrize("name,D", [("tps_square_heisenberg4x4D8Double", 8), ("heisenberg_tps_double_from_simple_update", 4),
                                     ("transverse_ising_tps_doublelowest", 4)])
 def test_qlten_writer_round_trip_is_byte_identical(fixtures_dir, tmp_path, name, D):

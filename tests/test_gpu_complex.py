@@ -185,3 +185,103 @@ def test_k4_complex_fixture_exact_sum_energy(fixtures_dir):
         c2 = c.copy(); c2[0, 0], c2[0, 1] = c[0, 1], c[0, 0]
         assert abs(rt[i] - psi[index[tuple(c2.ravel())]]) < 1e-10 * np.max(np.abs(psi))
     ctx.close()
+
+
+# ---- TenElemT = QLTEN_Complex at the C++ HOST level (qlpeps_gpu.h templates, libpepshost.so) ------------------------------
+def _oracle_exact_sum(sitps, cfgs, chi, model):
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    e, grad, w = vmc.exact_sum_energy_evaluator(sitps, [np.asarray(c) for c in cfgs], tp, model)
+    return e, grad
+
+
+def test_k4_complex_exact_sum_energy_and_gradient_through_host_layer(fixtures_dir):
+    """The reference's 2x2 complex Heisenberg fixture through ExactSumEnergyEvaluator of the C++ host layer instantiated for
+    QLTEN_Complex (SplitIndexTPST / BMPSContractorT / TPSWaveFunctionComponentT / GradAccumulatorT <std::complex<double>>,
+    holes resident in HBM, pepsgpu_grad_accumulate on a PEPSGPU_C128 context): the known energy -1.99521278793
+    (test_exact_summation_evaluator.cpp:606), and the GRADIENT (S_EO - E* S_O) / W with the conjugations of
+    exact_summation_energy_evaluator.h:228-295 element-wise against the complex oracle to 1e-9; 2-rank partition too."""
+    from peps_amd import hostapi
+    d = os.path.join(fixtures_dir, "heisenberg_tps_complex_from_simple_update")
+    s = qlten_io.load_sitps(d, complex_data=True)
+    D = max(max(t.shape) for row in s for comps in row for t in comps)
+    flat = hostapi.load_sitps_complex(d, D)
+    assert flat.dtype == np.complex128 and np.array_equal(flat, _flat(s, D))          # SplitIndexTPS<QLTEN_Complex>::Load
+    cfgs = np.array(vmc.generate_all_permutation_configs([2, 2], 2, 2), dtype=np.int32).reshape(-1, 2, 2)
+    e_ref, g_ref = _oracle_exact_sum(s, cfgs, 8, vmc.SquareSpinOneHalfXXZModelOBC())
+    for size in (1, 2):
+        e, grad = hostapi.exact_sum_complex(flat, cfgs, 8, "xxz", (1.0, 1.0, 0.0), size=size, batch=4)
+        assert abs(e.real - (-1.99521278793)) < 1e-9 and abs(e.imag) < 1e-11
+        assert abs(e - e_ref) < 1e-10
+        gmax = max(np.max(np.abs(t)) for row in g_ref for comps in row for t in comps)
+        assert gmax > 1e-6                                                                # a simple-update state: not at the minimum
+        for r in range(2):
+            for c in range(2):
+                for i in range(2):
+                    t = g_ref[r][c][i]
+                    got = grad[r, c, i][:t.shape[0], :t.shape[1], :t.shape[2], :t.shape[3]]
+                    assert np.max(np.abs(got - t)) < 1e-9 * gmax, (size, r, c, i)
+
+
+@pytest.mark.parametrize("model", ["xxz", "tfim"])
+def test_complex_cal_energy_and_holes_vs_oracle(model):
+    """CalEnergyAndHoles (XXZ: square_spin_onehalf_xxz_obc.h:72-104 with ComplexConjugate(psi_ex * inv_psi); TFIM:
+    transverse_field_ising_square_obc.h:195-203) of the host layer on a random COMPLEX 4x4 state: amplitudes, complex local
+    energies, Dag(hole) tensors and the psi list against the complex oracle (1e-9); hole . site == psi."""
+    from peps_amd import hostapi
+    L, D, chi = 4, 3, 9
+    sitps = _complex_sitps(L, D, 91)
+    flat = _flat(sitps, D)
+    cfgs = synthetic.make_configs(L, 4, "heisenberg" if model == "xxz" else "tfim", seed0=3)
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    m = vmc.SquareSpinOneHalfXXZModelOBC(0.7, 1.3, 0.0) if model == "xxz" else vmc.TransverseFieldIsingSquareOBC(0.8)
+    params = (0.7, 1.3, 0.0) if model == "xxz" else (0.8,)
+    amps, en, holes, psi = hostapi.energy_and_holes_complex(flat, cfgs, chi, model, params, True)
+    assert en.dtype == np.complex128 and np.max(np.abs(en.imag)) > 1e-6          # a complex state has complex local energies
+    for w, c in enumerate(cfgs):
+        comp = vmc.TPSWaveFunctionComponent(sitps, c, tp)
+        e, h, psi_list = m.CalEnergyAndHoles(sitps, comp, True)
+        assert abs(amps[w] / comp.amplitude - 1) < 1e-9
+        assert abs(en[w] - e) < 1e-9 * max(1.0, abs(e))
+        for r in range(L):
+            for cc in range(L):
+                t = h[r][cc]
+                got = holes[w, r, cc][:t.shape[0], :t.shape[1], :t.shape[2], :t.shape[3]]
+                assert np.max(np.abs(got - t)) < 1e-9 * max(1.0, np.max(np.abs(t)))
+        # Dag(hole) . conj(site) = conj(psi)
+        t00 = holes[w, 1, 2] * np.conj(flat[1, 2, c[1, 2]])
+        assert abs(np.sum(t00) / np.conj(amps[w]) - 1) < 1e-9
+        assert np.max(np.abs(psi[:, w] / np.array(psi_list) - 1)) < 1e-9
+
+
+def test_complex_mc_gradient_sample_vs_oracle_accumulation():
+    """MCEnergyGradEvaluator accumulation on a complex state (mc_energy_grad_evaluator.h:245-298: O* = conj(1 / psi) Dag(hole),
+    E_loc^* O*, grad = <E* O*> - E* <O*>) through the host layer with the holes resident in HBM: zero sweeps between samples
+    would repeat one configuration, so the chain is advanced on the device (exchange updater, |psi'/psi|^2 acceptance) and the
+    accumulators of the visited configurations are rebuilt with the complex oracle."""
+    from peps_amd import hostapi
+    L, D, chi = 4, 2, 4
+    sitps = _complex_sitps(L, D, 7)
+    flat = _flat(sitps, D)
+    cfgs = synthetic.make_configs(L, 6, "heisenberg", seed0=11)
+    seeds = np.arange(6, dtype=np.uint64) + 5
+    # one sample: sweep, then accumulate -- the configurations after the sweep come back
+    e, grad, out_cfg, acc = hostapi.mc_energy_grad_complex(flat, cfgs, seeds, chi, "exchange", "xxz", (1.0, 1.0, 0.0), 0, 1)
+    assert np.all(out_cfg.sum(axis=(1, 2)) == cfgs.sum(axis=(1, 2))) and 0 < acc.mean() < 1
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    m = vmc.SquareSpinOneHalfXXZModelOBC()
+    so = np.zeros(flat.shape, dtype=np.complex128); seo = np.zeros(flat.shape, dtype=np.complex128)
+    es = []
+    for c in out_cfg:
+        comp = vmc.TPSWaveFunctionComponent(sitps, c, tp)
+        el, holes, _ = m.CalEnergyAndHoles(sitps, comp, True)
+        es.append(el)
+        for r in range(L):
+            for cc in range(L):
+                t = np.conj(1.0 / comp.amplitude) * holes[r][cc]
+                sl = (r, cc, int(c[r, cc])) + tuple(slice(0, k) for k in t.shape)
+                so[sl] += t
+                seo[sl] += np.conj(el) * t
+    e_ref = np.mean(es)
+    g_ref = seo / len(out_cfg) - np.conj(e_ref) * so / len(out_cfg)
+    assert abs(e - e_ref) < 1e-9 * abs(e_ref)
+    assert np.max(np.abs(grad - g_ref)) < 1e-9 * np.max(np.abs(g_ref))
