@@ -359,11 +359,7 @@ static void diag_chol_t(const double *G, int n, int nbatch, void *Rout) {
   PG_CHECK_HIP(hipMalloc(&dG, ne * sizeof(double)));
   PG_CHECK_HIP(hipMalloc(&dR, ne * sizeof(T)));
   PG_CHECK_HIP(hipMemcpy(dG, G, ne * sizeof(double), hipMemcpyHostToDevice));
-  size_t smem = chol_smem_bytes(n);
-  allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
-  hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nbatch), dim3(256), smem, 0, dG, (long)n * n, n, dR, (long)n * n,
-                     (int *)nullptr);
-  PG_CHECK_HIP(hipGetLastError());
+  launch_chol_upper<T>(0, nbatch, dG, (long)n * n, n, dR, (long)n * n, (int *)nullptr);
   PG_CHECK_HIP(hipDeviceSynchronize());
   PG_CHECK_HIP(hipMemcpy(Rout, dR, ne * sizeof(T), hipMemcpyDeviceToHost));
   (void)hipFree(dG); (void)hipFree(dR);
@@ -387,7 +383,7 @@ static void diag_chol_adaptive_t(const double *G, int n, int nbatch, void *Rout,
   hipLaunchKernelGGL(chol_lowrank_kernel<T>, dim3(nbatch), dim3(256), lsm, 0, (const double *)dG, (long)n * n, n, dR,
                      (long)n * n, dml);
   PG_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nbatch), dim3(256), smem, 0, dG, (long)n * n, n, dR, (long)n * n, dml, 1);
+  launch_chol_upper<T>(0, nbatch, dG, (long)n * n, n, dR, (long)n * n, dml, 1);
   PG_CHECK_HIP(hipGetLastError());
   PG_CHECK_HIP(hipDeviceSynchronize());
   PG_CHECK_HIP(hipMemcpy(Rout, dR, ne * sizeof(T), hipMemcpyDeviceToHost));

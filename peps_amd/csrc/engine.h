@@ -131,6 +131,9 @@ class Engine : public EngineBase {
     device_ = device;
     device_id = device;
     PG_CHECK_HIP(hipStreamCreate(&stream_));
+    PG_CHECK_HIP(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
+    PG_CHECK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+    PG_CHECK_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     slot_ = (long)D * D * D * D;
     sitps_ = (T *)arena_.alloc(sizeof(T) * slot_ * dp_ * Ly * Lx);
     cfg_ = (int *)arena_.alloc(sizeof(int) * (size_t)maxw_ * Ly * Lx);
@@ -144,6 +147,8 @@ class Engine : public EngineBase {
   ~Engine() override {
     (void)hipStreamSynchronize(stream_);
     arena_.release();
+    (void)hipEventDestroy(ev_fork_); (void)hipEventDestroy(ev_join_);
+    (void)hipStreamDestroy(side_stream_);
     (void)hipStreamDestroy(stream_);
   }
 
@@ -1146,6 +1151,10 @@ class Engine : public EngineBase {
   long slot_;
   bool have_state_ = false;
   hipStream_t stream_;
+  // side stream for rare-walker kernels that would otherwise serialise the main stream behind a handful of long blocks
+  // (fork after ev_fork_, joined through ev_join_ before their results are read)
+  hipStream_t side_stream_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   Arena arena_;
   T *sitps_ = nullptr;
   int *cfg_ = nullptr, *flag_ = nullptr;

@@ -350,9 +350,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
                            cols, R[i + 1].p, R[i + 1].n, ml, fused ? 1 : 0);
         PG_CHECK_HIP(hipGetLastError());
       }
-      hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nw_), dim3(256), smem, stream_, G, (long)cols * cols, cols,
-                         R[i + 1].p, R[i + 1].n, ml, (lowrank || fused) ? 1 : 0);
-      PG_CHECK_HIP(hipGetLastError());
+      launch_chol_upper<T>(stream_, nw_, G, (long)cols * cols, cols, R[i + 1].p, R[i + 1].n, ml, (lowrank || fused) ? 1 : 0);
       prof_end();
       if (dbg_sweeps_ && ml) {   // diagnostics: numerical rank of the carry (forces a sync)
         std::vector<int> h(nw_);
@@ -459,6 +457,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     }
     // M[m,(u,k2)] = sum_{(l,a)} R_i[m,(l,a)] Tt[(l,a),(u,k2)]
     const int m = R[i].d[0], la = l * a, uk = u * k2;
+    bool dense_site = false;
     PG_REQUIRE(R[i].d[1] == l && R[i].d[2] == a, 3, "MultiplyMPO: carry dimension mismatch");
     DTen<T> M = alloc_ten(m, uk, 1);
     {
@@ -471,6 +470,10 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       g.dynI = mdyn[i]; g.dynI_mul = mmul[i];
       g.dK[2].p = clive[i];
       g.dJ[2].p = kn[i + 1]; g.dJ[2].mask = 1;   // the Jacobi reads whole rows of M: dead columns are written as zeros
+      // dense carry at this site (hint of the row absorbed before): the LDS-tiled kernel
+      static const bool no_tiled_hint = getenv("PEPSGPU_NO_TILED_HINT") != nullptr;
+      dense_site = !no_tiled_hint && in.depth >= 3 && (int)in.mlmax.size() > i && in.mlmax[i] > 96 && la >= 128 && uk >= 128;
+      g.prefer_tiled = dense_site;
       prof_begin(PROF_CONTRACT, 0.0, 2.0 * nw_ * (double)m * la * (double)uk);
       tgemm_launch<T, T, T, T>(stream_, g, R[i].p, Tt.p, M.p);
       prof_end();
@@ -503,6 +506,8 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     }
     int *midflag = nullptr, *nmid = nullptr, *mB = nullptr;
     int *flagA = nullptr, *rowsA = nullptr, *flag2 = nullptr, *rows2 = nullptr, *mB2 = nullptr;   // two-level form (below)
+    int *big_list = nullptr;    // walkers whose first factor kept more than 128 rows (+ their count behind the list)
+    bool side_pending = false;  // a kernel of this site runs on the side stream
     bool two_level = false;
     DTen<T> Bt, Ut, B2;
     const int GS = std::min(m, MID_HI);
@@ -554,9 +559,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         if (!rowgram) tgemm_launch<T, T, double, double>(stream_, g, M.p, M.p, Gm);
         const size_t smem = chol_smem_bytes(GS);
         allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
-        hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nw_), dim3(256), smem, stream_, Gm, (long)GS * GS, GS, Bt.p, Bt.n, mB, 0, GS,
-                           (const int *)nhi, 1, (const int *)hiflag);
-        PG_CHECK_HIP(hipGetLastError());
+        launch_chol_upper<T>(stream_, nw_, Gm, (long)GS * GS, GS, Bt.p, Bt.n, mB, 0, GS, (const int *)nhi, 1, (const int *)hiflag);
         arena_.free(Gm);
         // Second level (walkers with more than 128 live rows of M whose factor B kept at most 128 rows -- the usual case: the
         // truncation input of a real PEPS is of numerical rank 60-100): the rows of B are as long as M has live rows (up to
@@ -573,8 +576,10 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
             rows2 = (int *)arena_.alloc(sizeof(int) * nw_);
             mB2 = (int *)arena_.alloc(sizeof(int) * nw_);
             PG_CHECK_HIP(hipMemsetAsync(mB2, 0, sizeof(int) * nw_, stream_));
+            big_list = (int *)arena_.alloc(sizeof(int) * (nw_ + 1));
+            PG_CHECK_HIP(hipMemsetAsync(big_list + nw_, 0, sizeof(int), stream_));     // the count sits behind the list
             hipLaunchKernelGGL(mid_split_kernel, dim3((nw_ + 255) / 256), dim3(256), 0, stream_, (const int *)midflag, (const int *)hiflag,
-                               (const int *)mB, 128, nw_, flagA, rowsA, flag2, rows2);
+                               (const int *)mB, 128, nw_, flagA, rowsA, flag2, rows2, big_list, big_list + nw_);
             PG_CHECK_HIP(hipGetLastError());
             B2 = alloc_ten(128, 128, 1);
             launch_mid_gram_chol<T>(stream_, nw_, (const T *)Bt.p, Bt.n, GS, (const int *)rows2, (const int *)flag2, 128, B2.p, B2.n, mB2);
@@ -657,13 +662,16 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
             // register kernel, those whose factor kept more than 128 rows; on B2: everybody else
             launch_jacobi_grp<2, 8>(stream_, nw_, (float *)Bt.p, Bt.n, GS, 128, GS, 40, sweeps_, (const int *)rowsA, 1, 0);
             launch_jacobi_grp<4, 8>(stream_, nw_, (float *)Bt.p, Bt.n, GS, 128, GS, 40, sweeps_, (const int *)rowsA, 1, 64);
-            // (a launch of 144 KB-LDS blocks costs ~0.8 ms even when every block returns at once: skipped where the row absorbed
-            // before kept at most ~110 rows of B at this site; verified at the end of the absorption)
-            const bool b_small = !full_bonds && in.depth >= 3 && (int)in.bmax.size() > i && in.bmax[i] >= 0 && in.bmax[i] + 16 <= 128;
-            if (b_small) assume_b128[i] = 1;
-            else
-              hipLaunchKernelGGL(jacobi_rows_reg256_kernel, dim3(nw_), dim3(512), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS, 40,
-                                 sweeps_, (const int *)rowsA, 1, 128);
+            // (2048 blocks of 144 KB LDS cost ~0.9 ms even when every block returns at once: a small grid walks the list of the
+            // walkers that need it, usually empty)
+            // ... on the side stream: the few blocks run beside the launches below (which touch other walkers) instead of holding
+            // the whole device for ~0.8 ms; joined before the rows of B are selected
+            PG_CHECK_HIP(hipEventRecord(ev_fork_, stream_));
+            PG_CHECK_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
+            hipLaunchKernelGGL(jacobi_rows_reg256_list_kernel, dim3(std::min(nw_, 128)), dim3(512), 0, side_stream_, (float *)Bt.p, Bt.n, GS, GS,
+                               GS, 40, sweeps_, (const int *)rowsA, 1, 128, (const int *)big_list, (const int *)(big_list + nw_));
+            PG_CHECK_HIP(hipEventRecord(ev_join_, side_stream_));
+            side_pending = true;
             launch_jacobi_grp<2, 8>(stream_, nw_, (float *)B2.p, B2.n, 128, 128, 128, 40, sweeps_, (const int *)mB2, 1, 0);
             launch_jacobi_grp<4, 8>(stream_, nw_, (float *)B2.p, B2.n, 128, 128, 128, 40, sweeps_, (const int *)mB2, 1, 64);
           } else {
@@ -698,6 +706,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     PG_CHECK_HIP(hipGetLastError());
     if (mid) {
       // sigma_k u_k^T = the rotated rows of B: the chi largest, normalised -> U^T (k x GS), kB = how many are live
+      if (side_pending) { PG_CHECK_HIP(hipStreamWaitEvent(stream_, ev_join_, 0)); side_pending = false; }
       int *kB = (int *)arena_.alloc(sizeof(int) * nw_);
       PG_CHECK_HIP(hipMemsetAsync(kB, 0, sizeof(int) * nw_, stream_));
       Ut = alloc_ten(k, GS, 1);
@@ -735,7 +744,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         PG_CHECK_HIP(hipGetLastError());
         prof_end();
         free_ten(W); free_ten(T1); free_ten(B2);
-        arena_.free(kB2); arena_.free(flagA); arena_.free(rowsA); arena_.free(flag2); arena_.free(rows2); arena_.free(mB2);
+        arena_.free(kB2); arena_.free(flagA); arena_.free(rowsA); arena_.free(flag2); arena_.free(rows2); arena_.free(mB2); arena_.free(big_list);
       }
       // V' = U^T M (k x uk): row q is sigma_q v_q^T up to the rounding of u_q -- an error of 1e-7 in u_q brings in the
       // dominant directions with weight 1e-7 sigma_1, which is NOT small against a row of size sigma_q << sigma_1.  So the k
@@ -791,6 +800,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         g.dK[2].p = nullptr; g.dK[1].p = kn[i + 1];
       }
       g.dJ[2].p = kn[i]; g.dJ[2].mask = 1;
+      g.prefer_tiled = dense_site;
       // reference op: res[i-1] . (u s)  (bmps_impl.h:254): 2 (m_{i-1} D_u) m_i k_i
       int rp, cp, ddp[4];
       site_rc(i - 1, rp, cp);

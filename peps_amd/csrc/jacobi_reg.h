@@ -83,12 +83,37 @@ constexpr int JR_BR = 16;        // rows per block
 constexpr int JR_NW = 8;         // waves
 constexpr int JR_SLOTS = JR_NW + 1;
 
+__device__ __forceinline__ void jacobi_rows_reg256_body(float4 (*xch)[JR_BR][64], const int walker, float *__restrict__ Mg, long wM, int m,
+                                                        int len, int ld, int max_sweeps, int *__restrict__ sweeps_out,
+                                                        const int *__restrict__ mdyn, int mdyn_mul, int skip_small);
+
 __global__ __launch_bounds__(512) void jacobi_rows_reg256_kernel(float *__restrict__ Mg, long wM, int m, int len, int ld,
                                                                  int max_sweeps, int *__restrict__ sweeps_out,
                                                                  const int *__restrict__ mdyn, int mdyn_mul,
                                                                  int skip_small) {
   __shared__ float4 xch[JR_SLOTS][JR_BR][64];   // 9 x 16 KiB
-  if (mdyn) m = min(m, mdyn[blockIdx.x] * mdyn_mul);   // rows that exist for this walker
+  jacobi_rows_reg256_body(xch, blockIdx.x, Mg, wM, m, len, ld, max_sweeps, sweeps_out, mdyn, mdyn_mul, skip_small);
+}
+
+// The same kernel over a LIST of walkers (list[0 .. *count)), a small fixed grid whose blocks walk the list: when the list is
+// empty (the usual case where it is used: walkers whose compressed factor kept more than 128 rows) the launch costs a few
+// microseconds instead of the ~0.9 ms that 2048 blocks of 144 KB LDS cost even when every block returns at once.
+__global__ __launch_bounds__(512) void jacobi_rows_reg256_list_kernel(float *__restrict__ Mg, long wM, int m, int len, int ld,
+                                                                      int max_sweeps, int *__restrict__ sweeps_out,
+                                                                      const int *__restrict__ mdyn, int mdyn_mul, int skip_small,
+                                                                      const int *__restrict__ list, const int *__restrict__ count) {
+  __shared__ float4 xch[JR_SLOTS][JR_BR][64];
+  const int n = *count;
+  for (int q = blockIdx.x; q < n; q += gridDim.x) {
+    jacobi_rows_reg256_body(xch, list[q], Mg, wM, m, len, ld, max_sweeps, sweeps_out, mdyn, mdyn_mul, skip_small);
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void jacobi_rows_reg256_body(float4 (*xch)[JR_BR][64], const int walker, float *__restrict__ Mg, long wM, int m,
+                                                        int len, int ld, int max_sweeps, int *__restrict__ sweeps_out,
+                                                        const int *__restrict__ mdyn, int mdyn_mul, int skip_small) {
+  if (mdyn) m = min(m, mdyn[walker] * mdyn_mul);   // rows that exist for this walker
   if (skip_small && m <= max(skip_small, 2 * JR_BR)) return;   // skip_small = 1: the one-wave kernels took this walker;
                                                                 // > 32: also the walkers of the preconditioned mid route
   __shared__ float xnorm[JR_SLOTS][JR_BR];
@@ -97,7 +122,7 @@ __global__ __launch_bounds__(512) void jacobi_rows_reg256_kernel(float *__restri
   __shared__ double s_fro[JR_NW];
   __shared__ int s_rot, s_live0;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  float *M = Mg + (long)blockIdx.x * wM;
+  float *M = Mg + (long)walker * wM;
 
   // ---- prepass: row norms, noise floor, rows ranked by decreasing norm ----
   // Row order is free (select_rows_kernel sorts afterwards), so the rows are taken in rank
@@ -300,7 +325,7 @@ __global__ __launch_bounds__(512) void jacobi_rows_reg256_kernel(float *__restri
   };
   store_block(a, w);
   store_block(b, nwv + w);
-  if (tid == 0 && sweeps_out) sweeps_out[blockIdx.x] = sweep | (live0 << 8);
+  if (tid == 0 && sweeps_out) sweeps_out[walker] = sweep | (live0 << 8);
 }
 
 

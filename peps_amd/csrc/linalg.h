@@ -257,6 +257,300 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same factorisation (same pivot rule, same output contract, drop-in signature) restructured for orders of 100-256 at high
+// rank (round 3: the forward factor and the first compression of the truncation route of a dense walker batch, where the
+// kernel above spent 1.66 ms per launch of 2048 walkers on 5.6 Mflop per walker: a chain of ~50 barriers per 16-column panel):
+//   * left-looking update of a panel = a small GEMM  P[16 x (n - jb)] -= R[live, panel]^T R[live, jb..n)  on
+//     v_mfma_f64_16x16x4_f64: a wave owns up to four 16-column tiles, both operands are 128-byte segments of the finished factor
+//     rows (read from G in L2), two k-steps in flight;
+//   * the 16 x 16 diagonal block is factored by ONE wave in registers (lane c' holds column c', the pivot row travels by
+//     v_readlane: no barrier inside the block), dropping the rows whose pivot is below the noise of the T-typed data;
+//   * the rest of the panel row is a forward substitution per column, one thread per column, the factor of the block read as
+//     LDS broadcasts.
+// Three barriers per panel instead of three per column.
+typedef double chb_f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double chb_readlane(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+inline size_t chol_blocked_smem_bytes(int n) {
+  return sizeof(double) * ((size_t)CH_NB * n + n) + sizeof(short) * 2 * (size_t)n + 64;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void chol_blocked_kernel(double *__restrict__ Gg, long wG, int n,
+                                                           T *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
+                                                           int only_flagged = 0, int ld = 0,
+                                                           const int *__restrict__ ndyn = nullptr, int ndyn_mul = 1,
+                                                           const int *__restrict__ run_flag = nullptr) {
+  if (only_flagged && mlive_out[blockIdx.x] >= 0) return;
+  if (run_flag && run_flag[blockIdx.x] >= 0) return;
+  const int ldg = ld ? ld : n;
+  if (ndyn) n = min(n, ndyn[blockIdx.x] * ndyn_mul);
+  extern __shared__ double chb_smem[];
+  double *sP = chb_smem;                          // [CH_NB][n]   current block row
+  double *sN = sP + CH_NB * n;                    // [n]          row norms^2 of the finished factor
+  short *sList = reinterpret_cast<short *>(sN + n);   // [n] live rows so far
+  short *sPos = sList + n;                             // [n] output position of a row, -1 = dropped
+  __shared__ double sD[CH_NB][CH_NB + 1], sDinv[CH_NB];
+  __shared__ double s_maxd, s_fro;
+  __shared__ double s_red[4];
+  __shared__ int s_nlive;
+  __shared__ unsigned s_livemask;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double *G = Gg + (long)blockIdx.x * wG;
+  T *Rout = Rg + (long)blockIdx.x * wR;
+
+  double md = 0.0;
+  for (int i = tid; i < n; i += 256) md = fmax(md, G[(long)i * ldg + i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
+  if (lane == 0) s_red[wave] = md;
+  if (tid == 0) s_nlive = 0;
+  __syncthreads();
+  if (tid == 0) s_maxd = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+  __syncthreads();
+  const double maxd = s_maxd;
+  const double eT = NOISE_C * (double)Eps<T>::v;
+  const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
+  const double sc_out = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
+  const int i16 = lane & 15, k4 = lane >> 4;
+
+  for (int jb = 0; jb < n; jb += CH_NB) {
+    const int nb = min(CH_NB, n - jb);
+    // the panel's rows of G: requested now (registers), laid down in LDS after the update loop has issued its own loads
+    double pv[CH_NB];
+#pragma unroll
+    for (int q = 0; q < CH_NB; ++q) {
+      const int e = tid + 256 * q;
+      const int c = e / n, r = e - c * n;
+      pv[q] = (e < CH_NB * n && c < nb && r >= jb) ? G[(long)(jb + c) * ldg + r] : 0.0;
+    }
+    const int nprev = s_nlive;
+    // ---- left-looking update on the matrix cores ----
+    {
+      const int ntile = (n - jb + 15) >> 4;
+      chb_f64x4 acc[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[q][r] = 0.0;
+      int col[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = wave + 4 * q;
+        col[q] = jb + 16 * t + i16;
+        if (!(t < ntile && col[q] < n)) col[q] = jb;      // clamped address: the product lands in an entry that is not written back
+      }
+      const bool aok = jb + i16 < n;
+      const int acol = aok ? jb + i16 : jb;
+      const int nq = (ntile - wave + 3) >> 2;    // tiles of this wave (wave-uniform)
+      // unconditional loads at clamped addresses (a row beyond the live list reads the last one, its A operand is zeroed):
+      // no exec-masked load, the wait counters stay exact and PF k-steps are in flight
+      auto load = [&](int k0, double &a, double (&b)[4]) {
+        const int kk = min(k0 + k4, nprev - 1);
+        const double *row = G + (long)kk * ldg;      // finished rows sit compacted in the first rows of G (see the publish step)
+        a = row[acol];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = row[col[q]];
+      };
+      auto step = [&](int k0, const double a, const double (&b)[4]) {
+        const double am = (k0 + k4 < nprev && aok) ? a : 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q < nq) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(am, b[q], acc[q], 0, 0, 0);
+      };
+      if (nq > 0 && nprev > 0) {
+        constexpr int PF = 3;
+        double av[PF], bv[PF][4];
+        const int nks = (nprev + 3) >> 2;
+#pragma unroll
+        for (int p = 0; p < PF; ++p) { av[p] = 0.0; for (int q = 0; q < 4; ++q) bv[p][q] = 0.0; }
+#pragma unroll
+        for (int p = 0; p < PF - 1; ++p)
+          if (p < nks) load(4 * p, av[p], bv[p]);
+        for (int ks = 0; ks < nks; ks += PF) {
+#pragma unroll
+          for (int p = 0; p < PF; ++p) {
+            const int cur = ks + p;
+            if (cur + PF - 1 < nks) load(4 * (cur + PF - 1), av[(p + PF - 1) % PF], bv[(p + PF - 1) % PF]);
+            if (cur < nks) step(4 * cur, av[p], bv[p]);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < CH_NB; ++q) {
+        const int e = tid + 256 * q;
+        if (e < CH_NB * n) sP[e] = pv[q];
+      }
+      __syncthreads();                           // the panel is staged
+      if (nprev > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = wave + 4 * q;
+          const int cc = jb + 16 * t + i16;
+          if (t < ntile && cc < n) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sP[(k4 + 4 * r) * n + cc] -= acc[q][r];      // acc[r] = C[k4 + 4 r][i16]
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- the 16 x 16 diagonal block, one wave, registers ----
+    if (wave == 0) {
+      double d[CH_NB];
+#pragma unroll
+      for (int c = 0; c < CH_NB; ++c) d[c] = (lane < nb && c <= lane) ? sP[c * n + jb + lane] : 0.0;
+      unsigned livemask = 0;
+#pragma unroll
+      for (int c = 0; c < CH_NB; ++c) {
+        const double piv = chb_readlane(d[c], c);
+        const bool live = c < nb && piv > thresh;             // wave-uniform
+        if (live) {
+          double sc = __builtin_amdgcn_rsq(piv);              // ~2^-26 relative; two Newton steps -> float64
+          sc = sc * (1.5 - 0.5 * piv * sc * sc);
+          sc = sc * (1.5 - 0.5 * piv * sc * sc);
+          d[c] *= sc;
+#pragma unroll
+          for (int c2 = c + 1; c2 < CH_NB; ++c2) {
+            const double f = chb_readlane(d[c], c2);
+            d[c2] -= f * d[c];
+          }
+          livemask |= 1u << c;
+        } else {
+          d[c] = 0.0;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CH_NB; ++c)
+        if (lane < CH_NB) sD[c][lane] = lane >= c ? d[c] : 0.0;
+      if (lane < CH_NB) {
+        double dg = 0.0;
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c) dg = lane == c ? d[c] : dg;
+        double iv = __builtin_amdgcn_rcp(dg);
+        iv = iv * (2.0 - dg * iv);
+        iv = iv * (2.0 - dg * iv);
+        sDinv[lane] = ((livemask >> lane) & 1u) ? iv : 0.0;
+      }
+      if (lane == 0) s_livemask = livemask;
+    }
+    __syncthreads();
+    const unsigned livemask = s_livemask;
+    // ---- the rest of the block row: forward substitution per column; the block's own columns take the factor ----
+    {
+      const int r = jb + tid;
+      if (r < n) {
+        if (tid < CH_NB) {
+#pragma unroll
+          for (int c = 0; c < CH_NB; ++c) sP[c * n + r] = sD[c][tid];
+        } else {
+          double x[CH_NB];
+#pragma unroll
+          for (int c = 0; c < CH_NB; ++c) {
+            double v = sP[c * n + r];
+#pragma unroll
+            for (int c1 = 0; c1 < c; ++c1) v -= sD[c1][c] * x[c1];
+            x[c] = v * sDinv[c];                  // dropped row: sDinv = 0
+            sP[c * n + r] = x[c];
+            __asm__ volatile("" ::: "memory");    // keep the factor reads of the later rows from being hoisted (136 doubles)
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // publish the finished rows (upper part) for the later panels and -- scaled, as type T -- straight into the output at
+    // their provisional position (= their rank in the live list: the noise-floor compaction at the end rarely drops one);
+    // their squared norms while they are in LDS
+    // (G row `pos` <= jb + c: a row of this or an earlier panel, already consumed -- the factor rows are COMPACTED into the
+    // first rows of G, so the update loop addresses them without the live list; their columns below jb + c keep stale data
+    // that no later panel reads)
+    const int wout = ndyn ? ldg : n;
+    for (int e = tid; e < nb * n; e += 256) {
+      const int c = e / n, r = e - c * n;
+      if (r >= jb + c && ((livemask >> c) & 1u)) G[(long)(nprev + __popc(livemask & ((1u << c) - 1u))) * ldg + r] = sP[c * n + r];
+    }
+    for (int c = wave; c < nb; c += 4) {
+      if (!((livemask >> c) & 1u)) continue;
+      const int pos = nprev + __popc(livemask & ((1u << c) - 1u));
+      double a = 0.0;
+      for (int r = lane; r < wout; r += 64) {
+        const double x = (r >= jb + c && r < n) ? sP[c * n + r] : 0.0;
+        a += x * x;
+        Rout[(long)pos * ldg + r] = T(x * sc_out);
+      }
+      a = wave_sum(a);
+      if (lane == 0) sN[pos] = a;
+    }
+    if (tid == 0) {
+      int nl = s_nlive;
+      for (int c = 0; c < nb; ++c)
+        if ((livemask >> c) & 1u) sList[nl++] = (short)(jb + c);
+      s_nlive = nl;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  // ---- rank compaction: rows with norm below NOISE_C*eps_T*|R|_F are dropped (as chol_upper_kernel) ----
+  const int nfac = s_nlive;
+  {
+    double f = 0.0;
+    for (int q = tid; q < nfac; q += 256) f += sN[q];
+    f = wave_sum(f);
+    if (lane == 0) s_red[wave] = f;
+    __syncthreads();
+    if (tid == 0) s_fro = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+  }
+  const double nfloor = eT * eT * s_fro;
+  if (wave == 0) {
+    int cnt = 0;
+    for (int base = 0; base < nfac; base += 64) {
+      const int q = base + lane;
+      const bool f = q < nfac && sN[q] > nfloor;
+      const unsigned long long mask = __ballot(f);
+      if (q < nfac) sPos[q] = f ? (short)(cnt + __popcll(mask & ((1ull << lane) - 1ull))) : (short)-1;
+      cnt += __popcll(mask);
+    }
+    if (lane == 0) { s_nlive = cnt; if (mlive_out) mlive_out[blockIdx.x] = cnt; }
+  }
+  __syncthreads();
+  const int mlive = s_nlive;
+  if (mlive != nfac) {
+    // a row fell below the floor (rare): the rows after it move up, in order (the target of a row is never below it)
+    const int wrow = ndyn ? ldg : n;
+    for (int q = 0; q < nfac; ++q) {
+      const int pos = sPos[q];
+      if (pos >= 0 && pos != q)
+        for (int r = tid; r < wrow; r += 256) Rout[(long)pos * ldg + r] = Rout[(long)q * ldg + r];
+      __syncthreads();
+    }
+  }
+  if (mlive_out) return;
+  for (int e = tid + mlive * n; e < n * n; e += 256) Rout[(long)(e / n) * ldg + (e % n)] = T(0);
+}
+
+// launch of the blocked factorisation: the MFMA form above for orders >= 48 (PEPSGPU_OLD_CHOL=1: always the older kernel)
+template <typename T>
+inline void launch_chol_upper(hipStream_t s, int nbatch, double *G, long wG, int n, T *R, long wR, int *mlive_out, int only_flagged = 0,
+                              int ld = 0, const int *ndyn = nullptr, int ndyn_mul = 1, const int *run_flag = nullptr) {
+  static const bool old_chol = getenv("PEPSGPU_OLD_CHOL") != nullptr;
+  if (!old_chol && n >= 48) {
+    const size_t smem = chol_blocked_smem_bytes(n);
+    allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T>), smem);
+    hipLaunchKernelGGL(chol_blocked_kernel<T>, dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn, ndyn_mul,
+                       run_flag);
+  } else {
+    const size_t smem = chol_smem_bytes(n);
+    allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
+    hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn, ndyn_mul,
+                       run_flag);
+  }
+  PG_CHECK_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
 // Low-rank variant of the same factorisation (same column order, same pivot rule, same output):
 // right-looking, one step per LIVE row instead of one pass per 16-column panel, the factor held in
 // LDS.  The cost of the blocked kernel above is ~n/16 dependent global-memory round trips whatever
@@ -1217,7 +1511,7 @@ __global__ void mid_route_flag_kernel(const int *__restrict__ mdyn, int mdyn_mul
 // (flagA / rowsA).
 __global__ void mid_split_kernel(const int *__restrict__ midflag, const int *__restrict__ hiflag, const int *__restrict__ mB, int cap,
                                  int nbatch, int *__restrict__ flagA, int *__restrict__ rowsA, int *__restrict__ flag2,
-                                 int *__restrict__ rows2) {
+                                 int *__restrict__ rows2, int *__restrict__ big_list = nullptr, int *__restrict__ big_count = nullptr) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbatch) return;
   const bool mid = midflag[b] < 0, hi = hiflag[b] < 0;
@@ -1228,6 +1522,8 @@ __global__ void mid_split_kernel(const int *__restrict__ midflag, const int *__r
   const bool a = mid && !two;
   flagA[b] = a ? -1 : 0;
   rowsA[b] = a ? r : 0;
+  // walkers whose factor kept more than `cap` rows: the list of the 256-row Jacobi (big_count zeroed by the caller)
+  if (big_list && a && r > cap) big_list[atomicAdd(big_count, 1)] = b;
 }
 
 // x[b][0..n) /= |x|;  logscale[b] += log|x|;  zero / non-finite norm sets flag[b] = 1.

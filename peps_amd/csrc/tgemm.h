@@ -66,6 +66,10 @@ struct TGemmDesc {
   double *norm_log = nullptr;
   int *norm_flag = nullptr;
   const float *scale_in = nullptr;
+  // host-side routing hint: the live extents of this launch are large (dense carry: hundreds of rows) -> the LDS-tiled 64 x 64
+  // kernel instead of the wave-per-tile kernel that is built for extents of a few tens (M = R Tt of a dense walker batch:
+  // 233 -> 138 ms per step of 2048 walkers)
+  int prefer_tiled = 0;
 
   __host__ __device__ int Itot() const { return I[0] * I[1] * I[2]; }
   __host__ __device__ int Jtot() const { return J[0] * J[1] * J[2]; }
@@ -140,8 +144,14 @@ __device__ __forceinline__ void tgemm_tile(const TGemmDesc &d, const TA *__restr
 
   tg_f32x16 acc32;
   tg_f64x4 acc64[2][2];
+  tg_f64x4 accI[2][2];     // complex: imaginary parts (acc64 holds the real parts)
   TAcc accv[4][4];
-  if constexpr (USE_MFMA) {
+  constexpr bool CPLX = is_cplx<TAcc>::value;
+  if constexpr (USE_MFMA && CPLX) {
+    for (int a = 0; a < 2; ++a)
+      for (int c = 0; c < 2; ++c)
+        for (int r = 0; r < 4; ++r) { acc64[a][c][r] = 0.0; accI[a][c][r] = 0.0; }
+  } else if constexpr (USE_MFMA) {
     if constexpr (sizeof(TAcc) == 4) {
       for (int r = 0; r < 16; ++r) acc32[r] = 0.f;
     } else {
@@ -199,7 +209,28 @@ __device__ __forceinline__ void tgemm_tile(const TGemmDesc &d, const TA *__restr
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
       if (kt + 1 < nkt) load_regs(kt + 1);
-      if constexpr (USE_MFMA) {
+      if constexpr (USE_MFMA && CPLX) {
+        // complex128 on the f64 matrix cores: the operands sit interleaved in LDS (one 16-byte read per element), the four real
+        // products of (ar + i ai)(br + i bi) are four v_mfma_f64_16x16x4_f64 per tile: Re += ar br - ai bi, Im += ar bi + ai br
+#pragma unroll
+        for (int kk = 0; kk < TG_BK; kk += 4) {
+          const TAcc a0 = As[kk + (lane >> 4)][wm * 32 + (lane & 15)];
+          const TAcc a1 = As[kk + (lane >> 4)][wm * 32 + 16 + (lane & 15)];
+          const TAcc b0 = Bs[kk + (lane >> 4)][wn * 32 + (lane & 15)];
+          const TAcc b1 = Bs[kk + (lane >> 4)][wn * 32 + 16 + (lane & 15)];
+          const double ar[2] = {(double)a0.re, (double)a1.re}, ai[2] = {(double)a0.im, (double)a1.im};
+          const double br[2] = {(double)b0.re, (double)b1.re}, bi[2] = {(double)b0.im, (double)b1.im};
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              acc64[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], br[c], acc64[a][c], 0, 0, 0);
+              acc64[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai[a], bi[c], acc64[a][c], 0, 0, 0);
+              accI[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[a], bi[c], accI[a][c], 0, 0, 0);
+              accI[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[a], br[c], accI[a][c], 0, 0, 0);
+            }
+        }
+      } else if constexpr (USE_MFMA) {
         if constexpr (sizeof(TAcc) == 4) {
 #pragma unroll
           for (int kk = 0; kk < TG_BK; kk += 2) {
@@ -249,7 +280,17 @@ __device__ __forceinline__ void tgemm_tile(const TGemmDesc &d, const TA *__restr
       *p = TC(v);
     }
   };
-  if constexpr (USE_MFMA) {
+  if constexpr (USE_MFMA && CPLX) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int row = (lane >> 4) + 4 * r;
+          put(wm * 32 + a * 16 + row, wn * 32 + c * 16 + (lane & 15), TAcc(acc64[a][c][r], accI[a][c][r]));
+        }
+  } else if constexpr (USE_MFMA) {
     if constexpr (sizeof(TAcc) == 4) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -666,7 +707,7 @@ inline bool tgemm_one_block_direct(const TGemmDesc &d) {
   bool any_dyn = d.dynI != nullptr;
   for (int q = 0; q < 3; ++q) any_dyn = any_dyn || d.dI[q].p || d.dJ[q].p || d.dK[q].p;
   return tgemm_use_mfma() && !d.dynK && direct_mode == 1 && any_dyn && gx_dyn == 1 && d.bdivC == 1 && !d.accumulate &&
-         !d.batch_flag && d.nbatch > 0 && d.Itot() > 0 && d.Jtot() > 0;
+         !d.batch_flag && d.nbatch > 0 && d.Itot() > 0 && d.Jtot() > 0 && !d.prefer_tiled;
 }
 
 template <typename TA, typename TB, typename TC, typename TAcc>
@@ -687,7 +728,7 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
     static const int direct_mode = getenv("PEPSGPU_TGEMM_DIRECT") ? atoi(getenv("PEPSGPU_TGEMM_DIRECT")) : 1;
     static const bool no_vec = getenv("PEPSGPU_TGEMM_NOVEC") != nullptr;
     const bool any_dyn = dyn_i || d.dK[0].p || d.dK[1].p || d.dK[2].p || d.dJ[0].p || d.dJ[1].p || d.dJ[2].p;
-    if (tgemm_use_mfma() && !d.dynK && (direct_mode == 2 || (direct_mode == 1 && any_dyn))) {
+    if (tgemm_use_mfma() && !d.dynK && !d.prefer_tiled && (direct_mode == 2 || (direct_mode == 1 && any_dyn))) {
       // 16-byte loads along k2 where the operand is contiguous there and every other offset keeps the alignment
       auto al4 = [](long v) { return (v & 3) == 0; };
       const bool avec = !no_vec && d.sAk[2] == 1 && al4(d.K[2]) && al4(d.sAi[0]) && al4(d.sAi[1]) && al4(d.sAi[2]) &&
@@ -718,8 +759,16 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
   (void)fused_norm_ok;
   PG_REQUIRE(!d.scale_out && !d.scale_in, 5, "tensor GEMM: scale_in / scale_out need the wave-per-tile kernel");
   if constexpr (is_cplx<TAcc>::value) {
-    // complex element type (parity-grade path): the same tiling on the vector ALUs; there is no complex MFMA, and the
-    // 4-real-product form would need the operands de-interleaved
+    // complex element type: four real v_mfma_f64_16x16x4_f64 products per tile from the interleaved LDS operands
+    // (PEPSGPU_NO_CPLX_MFMA=1: the same tiling on the vector ALUs, round 2's path)
+    static const bool no_cmfma = getenv("PEPSGPU_NO_CPLX_MFMA") != nullptr;
+    if constexpr (std::is_same<TAcc, c128>::value) {
+      if (tgemm_use_mfma() && !no_cmfma) {
+        hipLaunchKernelGGL((tgemm_kernel<TA, TB, TC, TAcc, true>), grid, dim3(256), 0, s, d, A, B, C);
+        PG_CHECK_HIP(hipGetLastError());
+        return;
+      }
+    }
     hipLaunchKernelGGL((tgemm_kernel<TA, TB, TC, TAcc, false>), grid, dim3(256), 0, s, d, A, B, C);
   } else {
     if (tgemm_use_mfma())
