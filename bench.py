@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--full-rank-walkers", type=int, default=4096)
     ap.add_argument("--full-rank-steps", type=int, default=2)
     ap.add_argument("--no-real-rank", action="store_true", help="skip the third leg on the tiled optimised state of the reference")
-    ap.add_argument("--real-rank-walkers", type=int, default=2048)
+    ap.add_argument("--real-rank-walkers", type=int, default=4096)
     ap.add_argument("--real-rank-steps", type=int, default=2)
     ap.add_argument("--no-sweeps", action="store_true", help="skip the MC sweeps/s and VMC samples/s measurement")
     ap.add_argument("--sweep-walkers", type=int, default=2048)
@@ -299,9 +299,14 @@ ROOF_CATS = {"contract_chain": ("tgemm_chain_kernel", "f32"), "contract": ("tgem
 
 def roofline_of(prof, dtype, steps, leg_tag=None, nw=None):
     """Roofline object of the dominant kernel of a leg: the single-kernel category with the largest HIP-event time."""
-    cands = [k for k in ROOF_CATS if k in prof and prof[k]["launches"] and prof[k]["ms"] > 0]
+    cats = dict(ROOF_CATS)
+    # the factor category is one MFMA kernel family only on dense states (colgram_dense_kernel: Gram in accumulators + Cholesky in
+    # LDS, flops and bytes counted on the device); on the headline it is the VALU Gram-free factor (no counted flops): not a candidate
+    if "cholesky" in prof and prof["cholesky"]["exec_flops"] > 0 and prof["cholesky"].get("bytes", 0) > 0:
+        cats["cholesky"] = ("colgram_dense_kernel (+ chol_blocked_kernel, chol_lowrank_kernel)", "f64")
+    cands = [k for k in cats if k in prof and prof[k]["launches"] and prof[k]["ms"] > 0]
     dom = max(cands, key=lambda k: prof[k]["ms"])
-    kname, kdt = ROOF_CATS[dom]
+    kname, kdt = cats[dom]
     dsec = prof[dom]["ms"] * 1e-3
     launches = max(prof[dom]["launches"], 1)
     total_ms = sum(v["ms"] for v in prof.values())
@@ -712,6 +717,11 @@ def main():
                                                           "1e-9 (tests/test_gpu_realrank.py)")
                     if not args.no_energy_check:
                         pend_energy[name] = ((L, chi, 0 if dt == capi.F32 else 1, local_rank, fleg.flat), fleg.batches[0][:max(2, args.energy_n // 2)])
+                if real and world == 1 and not args.no_sweeps:
+                    try:       # what VMC consumes, on the state a VMC user has (fewer walkers: a sweep costs ~4 amplitudes)
+                        fr["vmc"] = vmc_rates(fleg, min(512, fnw), 1)
+                    except Exception as e:
+                        fr["vmc"] = {"error": repr(e)}
         except Exception as e:
             fr = {"error": repr(e)}
         fleg.close()

@@ -39,7 +39,7 @@ SYMBOLS = [
     "pepsgpu_sr_cg_solve", "pepsgpu_sr_gram", "pepsgpu_sr_weighted_sum", "pepsgpu_sr_copy_samples",
     "pepsgpu_update_local", "pepsgpu_erase_envs_after_update", "pepsgpu_evaluate_amplitude",
     "pepsgpu_walker_flags", "pepsgpu_sync", "pepsgpu_stats", "pepsgpu_profile_enable", "pepsgpu_profile_read",
-    "pepsgpu_diag_tgemm", "pepsgpu_diag_tgemm_chain", "pepsgpu_diag_chol", "pepsgpu_diag_chol_adaptive", "pepsgpu_diag_gram_chol", "pepsgpu_diag_gram_cols", "pepsgpu_diag_jacobi", "pepsgpu_version",
+    "pepsgpu_diag_tgemm", "pepsgpu_diag_tgemm_chain", "pepsgpu_diag_chol", "pepsgpu_diag_chol_adaptive", "pepsgpu_diag_gram_chol", "pepsgpu_diag_gram_cols", "pepsgpu_diag_gram_rows", "pepsgpu_diag_jacobi", "pepsgpu_version",
 ]
 
 
@@ -539,6 +539,21 @@ def diag_gram_cols(dtype, P, klive=None):
     rc = f(dtype, P.ctypes.data_as(C.c_void_p), K, n, nb, None if kl is None else _ip(kl), _dp(G))
     if rc != 0:
         raise RuntimeError("diag_gram_cols failed: %s" % lib().pepsgpu_last_error(None).decode())
+    return G
+
+
+def diag_gram_rows(M, nrows):
+    """gram_rows_f64_kernel alone; M = [nb][n][K] float32 (K a multiple of 16), nrows[b] live rows; returns G [nb][n][n] float64
+    (64 x 64 blocks on / above the diagonal of the live part)."""
+    M = np.ascontiguousarray(M, dtype=np.float32)
+    nb, n, K = M.shape
+    G = np.zeros((nb, n, n), dtype=np.float64)
+    nr = np.ascontiguousarray(nrows, dtype=np.int32)
+    f = lib().pepsgpu_diag_gram_rows
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    rc = f(M.ctypes.data_as(C.c_void_p), n, K, nb, _ip(nr), _dp(G))
+    if rc != 0:
+        raise RuntimeError("diag_gram_rows failed: %s" % lib().pepsgpu_last_error(None).decode())
     return G
 
 

@@ -462,6 +462,24 @@ extern "C" int pepsgpu_diag_gram_cols(int dtype, const void *P, int K, int n, in
     if (dtype == 0) diag_gram_cols_t<float>(P, K, n, nbatch, klive, G_out); else diag_gram_cols_t<double>(P, K, n, nbatch, klive, G_out);
   });
 }
+// gram_rows_f64_kernel alone: G[b] = M[b] M[b]^T for the first nrows[b] rows of M (n x K f32, K % 16 == 0), upper 64 x 64 blocks
+extern "C" int pepsgpu_diag_gram_rows(const float *M, int n, int K, int nbatch, const int32_t *nrows, double *G_out) {
+  return guarded(nullptr, [&]() {
+    PG_REQUIRE(n >= 1 && n <= 256 && K >= 16 && K % 16 == 0 && nbatch >= 1 && nrows, 1, "bad sizes");
+    float *dM; double *dG; int *dn;
+    const size_t ne = (size_t)n * K * nbatch;
+    PG_CHECK_HIP(hipMalloc(&dM, ne * sizeof(float)));
+    PG_CHECK_HIP(hipMalloc(&dG, (size_t)n * n * nbatch * sizeof(double)));
+    PG_CHECK_HIP(hipMalloc(&dn, nbatch * sizeof(int)));
+    PG_CHECK_HIP(hipMemcpy(dM, M, ne * sizeof(float), hipMemcpyHostToDevice));
+    PG_CHECK_HIP(hipMemcpy(dn, nrows, nbatch * sizeof(int), hipMemcpyHostToDevice));
+    PG_CHECK_HIP(hipMemset(dG, 0, (size_t)n * n * nbatch * sizeof(double)));
+    launch_gram_rows_f64<float>(0, nbatch, dM, (long)n * K, K, n, dn, dG, (long)n * n, n, nullptr, nullptr, nullptr);
+    PG_CHECK_HIP(hipDeviceSynchronize());
+    PG_CHECK_HIP(hipMemcpy(G_out, dG, (size_t)n * n * nbatch * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(dM); (void)hipFree(dG); (void)hipFree(dn);
+  });
+}
 extern "C" int pepsgpu_diag_chol(int dtype_out, const double *G, int n, int nbatch, void *R_out) {
   return guarded(nullptr, [&]() {
     if (dtype_out == 0) diag_chol_t<float>(G, n, nbatch, R_out); else diag_chol_t<double>(G, n, nbatch, R_out);

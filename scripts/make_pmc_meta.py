@@ -1,51 +1,72 @@
-"""profiles/r02_pmc_meta.json from the committed PMC passes (scripts/gpu_r02_profiles.sh): HBM bytes per full-size launch of
-every kernel category bench.py can report as dominant, and the launch count per step of the profiled run -- bench.py quotes
-`roofline.traffic` only for a run with the same workload AND the same launch count in that category.
-FETCH_SIZE / WRITE_SIZE are KiB; FETCH is doubled (gfx950: MI355X_MICROARCH.md, HBM).  The profiled command runs the path four
-times (calibration with 1 walker, warm-up and timed step at full size, rank diagnostics with 16 walkers): half of the launches
-are full-size and carry all but ~0.1 % of the bytes."""
-import json, os, sys
+"""profiles/r03_pmc_meta.json from the committed PMC passes (scripts/gpu_r03_profiles.sh): for every bench leg, the HBM bytes per
+full-size launch of each kernel bench.py can report as dominant, its average duration in the kernel trace of the same command, and
+its launch count per step -- bench.py quotes `roofline.traffic` (and prices `roofline.frac` with it) only for a run with the same
+walkers AND the same launch count of that kernel per step.
+FETCH_SIZE / WRITE_SIZE are KiB; FETCH is DOUBLED (gfx950: MI355X_MICROARCH.md, HBM).  The profiled command runs the path four
+times (calibration with 1 walker, warm-up and timed step at full size, rank diagnostics with 16 walkers): the full-size launches
+are identified by their grid in the kernel trace (the two largest launch groups of the kernel) and carry all but ~0.1 % of the bytes."""
+import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CATS = {"contract": ("tgemm_direct_kernel", "tgemm_chain_kernel"), "gram_f64": ("gram_cols_f64_kernel",),
-        "cholesky": ("gram_chol_lowrank_kernel", "gram_chol_wave_kernel", "chol_upper_kernel", "chol_lowrank_kernel", "colgram_chol_kernel", "colgram_dense_kernel"),
-        "jacobi": ("jacobi_rows_regx_kernel", "jacobi_rows_grp_kernel", "jacobi_rows_reg256_kernel"),
-        "jacobi_edge": ("jacobi_rows_tiny2_kernel", "jacobi_rows_tiny4_kernel", "jacobi_rows_tiny_kernel", "jacobi_rows_small_kernel")}
+KERNELS = ("tgemm_chain_kernel", "tgemm_direct_kernel", "gram_cols_f64_kernel", "gram_rows_f64_kernel", "chol_blocked_kernel",
+           "gram_chol_wave_kernel", "jacobi_rows_grp_kernel", "jacobi_rows_tiny4_kernel", "colgram_dense_kernel", "mid_gram_chol_kernel")
+LEGS = {"c4_f32_noise0.1": "c4_f32_noise0.1_nw32768", "c4_f32_noise1": "c4_f32_noise1_nw4096", "c4_f32_real": "c4_f32_real_nw2048"}
 
 
 def totals(path):
     out = {}
+    if not os.path.exists(path):
+        return out
     for line in open(path):
         f = line.split()
         if len(f) < 5 or f[-4] not in ("FETCH_SIZE", "WRITE_SIZE"):
             continue
-        name = " ".join(f[:-4])
-        out[name] = (int(f[-3]), float(f[-2]))
+        out[" ".join(f[:-4])] = (int(f[-3]), float(f[-2]))
     return out
 
 
-def main(tag, workload, dtype, walkers, noise):
-    fe = totals(os.path.join(ROOT, "profiles", "r02_pmc_FETCH_SIZE_%s.txt" % tag))
-    wr = totals(os.path.join(ROOT, "profiles", "r02_pmc_WRITE_SIZE_%s.txt" % tag))
-    bench = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_profiled_config_%s.json" % tag)))
-    meta = {"workload": workload, "dtype": dtype, "walkers": walkers, "noise": noise, "source": "profiles/r02_pmc_{FETCH,WRITE}_SIZE_%s.txt" % tag,
-            "categories": {}}
-    for cat, keys in CATS.items():
-        lf = sum(v[0] for k, v in fe.items() if any(x in k for x in keys))
-        kf = sum(v[1] for k, v in fe.items() if any(x in k for x in keys))
-        kw = sum(v[1] for k, v in wr.items() if any(x in k for x in keys))
-        if lf == 0 or cat not in bench.get("kernel_ms", {}):
+def trace(path):
+    """kernel -> list of (ms, calls, us_per_call, grid) from the by-grid summary"""
+    out = {}
+    if not os.path.exists(path):
+        return out
+    for line in open(path):
+        m = re.match(r"\s*([\d.]+) ms\s+(\d+) calls\s+([\d.]+) us/call\s+\('(.*?)', '(\d+)'", line)
+        if m:
+            out.setdefault(m.group(4), []).append((float(m.group(1)), int(m.group(2)), float(m.group(3)), int(m.group(5))))
+    return out
+
+
+def main():
+    meta = {}
+    for leg, tag in LEGS.items():
+        fe = totals(os.path.join(ROOT, "profiles", "r03_pmc_FETCH_SIZE_%s.txt" % tag))
+        wr = totals(os.path.join(ROOT, "profiles", "r03_pmc_WRITE_SIZE_%s.txt" % tag))
+        tr = trace(os.path.join(ROOT, "profiles", "r03_kernel_trace_by_grid_%s.txt" % tag))
+        cfg = os.path.join(ROOT, "profiles", "r03_bench_profiled_config_%s.json" % tag)
+        if not (fe and wr and tr and os.path.exists(cfg)):
             continue
-        full = lf / 2.0
-        meta["categories"][cat] = {"hbm_bytes_per_launch": (2.0 * kf + kw) * 1024.0 / full, "kernel_launches_full_size": full,
-                                   "fetch_KiB": kf, "write_KiB": kw}
-    # launches per step as bench.py counts them (one profiling bracket per launch site)
-    steps = bench["steps"]
-    rl = bench["roofline"]
-    meta["categories"].setdefault(rl["kernel"], {})["launches_per_step"] = rl["launches"] / steps
-    return meta
+        bench = json.load(open(cfg))
+        ent = {"walkers": bench["config"]["walkers_per_gpu"], "source": "profiles/r03_pmc_{FETCH,WRITE}_SIZE_%s.txt + r03_kernel_trace_by_grid_%s.txt" % (tag, tag),
+               "kernels": {}}
+        for k in KERNELS:
+            kf = sum(v[1] for n, v in fe.items() if k in n)
+            kw = sum(v[1] for n, v in wr.items() if k in n)
+            groups = [g for n, gs in tr.items() if k in n for g in gs]
+            if not groups:
+                continue
+            gmax = max(g[3] for g in groups)
+            full = [g for g in groups if g[3] == gmax]           # the full-size launches (largest grid)
+            calls = sum(g[1] for g in full)
+            ms = sum(g[0] for g in full)
+            if calls == 0:
+                continue
+            # profiled command = warm-up step + timed step at full size: launches per step = calls / 2
+            ent["kernels"][k] = {"hbm_bytes_per_launch": (2.0 * kf + kw) * 1024.0 / calls, "launches_per_step": calls / 2.0,
+                                 "avg_us": 1e3 * ms / calls, "fetch_KiB": kf, "write_KiB": kw}
+        meta[leg] = ent
+    json.dump(meta, open(os.path.join(ROOT, "profiles", "r03_pmc_meta.json"), "w"), indent=1)
+    print(json.dumps(meta, indent=1)[:3000])
 
 
 if __name__ == "__main__":
-    m = main("c4_f32_nw32768", "C4", "f32", 32768, 0.1)
-    json.dump(m, open(os.path.join(ROOT, "profiles", "r02_pmc_meta.json"), "w"), indent=1)
-    print(json.dumps(m, indent=1))
+    main()

@@ -430,3 +430,44 @@ def test_streaming_gram_kernel(K, n, dt):
     G0 = capi.diag_gram_cols(capi.F32 if dt == "f32" else capi.F64, P, None)
     ref0 = P[0].astype(np.float64).T @ P[0].astype(np.float64)
     assert np.max(np.abs(np.triu(G0[0]) - np.triu(ref0))[:64, :64]) < 1e-12 * np.max(np.abs(ref0))
+
+
+@pytest.mark.parametrize("n,K", [(256, 256), (241, 256), (130, 64), (64, 16), (200, 128), (17, 32)])
+def test_row_gram_kernel(n, K):
+    """gram_rows_f64_kernel (round 3: G = M M^T of the truncation input of walkers with more than 128 live carry rows): exact f32
+    products accumulated in f64 on the matrix cores, per-walker live row counts, every 64 x 64 block on or above the diagonal."""
+    capi = _capi()
+    rng = np.random.default_rng(3 * n + K)
+    nb = 4
+    M = (rng.standard_normal((nb, n, K)) * np.logspace(0, -6, n)[None, :, None]).astype(np.float32)
+    nrows = np.array([n, max(1, n // 2), 1, max(1, n - 3)], dtype=np.int32)
+    G = capi.diag_gram_rows(M, nrows)
+    for b in range(nb):
+        Mb = M[b, :nrows[b]].astype(np.float64)
+        ref = Mb @ Mb.T
+        m = nrows[b]
+        for bi in range((m + 63) // 64):
+            for bj in range(bi, (m + 63) // 64):
+                sl = (slice(64 * bi, min(m, 64 * bi + 64)), slice(64 * bj, min(m, 64 * bj + 64)))
+                scale = np.sqrt(np.outer(np.diag(ref)[sl[0]], np.diag(ref)[sl[1]])) + 1e-300
+                assert np.max(np.abs(G[b][sl] - ref[sl]) / scale) < 1e-13 * K ** 0.5 + 1e-15, (b, bi, bj)
+
+
+@pytest.mark.parametrize("n,rank", [(256, 256), (256, 97), (241, 180), (160, 33), (128, 128), (100, 7), (48, 48)])
+def test_blocked_cholesky_rank_revealing_contract(n, rank):
+    """chol_blocked_kernel (round 3, orders >= 48 through launch_chol_upper): R^T R = G on graded Gram matrices of deficient
+    rank -- the rows whose pivot falls below the noise of the f32 data are dropped, the factor comes back compacted, and what it
+    reproduces is G up to that floor."""
+    capi = _capi()
+    rng = np.random.default_rng(n + rank)
+    nb = 3
+    X = rng.standard_normal((nb, rank, n)) * np.logspace(0, -4, rank)[None, :, None]
+    G = np.einsum("bri,brj->bij", X, X)
+    R = capi.diag_chol(capi.F32, G).astype(np.float64)
+    for b in range(nb):
+        sc = np.max(np.diag(G[b]))
+        err = np.max(np.abs(R[b].T @ R[b] * sc - G[b])) / sc
+        assert err < 3e-6, (b, err)
+        live = int(np.sum(np.any(R[b] != 0, axis=1)))
+        # (a pivot at the rounding level of the Gram matrix may survive the threshold: at most a row or two of negligible norm)
+        assert live <= min(rank + 2, n) and np.all(R[b][live:] == 0)
