@@ -27,13 +27,16 @@ __global__ __launch_bounds__(256, 2) void gram_cols_f64_kernel(const T *__restri
                                                                const int *__restrict__ run_flag, int inner,
                                                                const int *__restrict__ inner_live,
                                                                unsigned long long *__restrict__ flopc,
-                                                               unsigned long long *__restrict__ bytec, int flop_stride) {
-  const int b = blockIdx.y;
-  if (run_flag && run_flag[b] >= 0) return;               // only the entries a cheaper kernel has declined
+                                                               unsigned long long *__restrict__ bytec, int flop_stride, int nbatch) {
+  // one WAVE = one 64 x 64 block of one walker; the waves of the launch are numbered across walkers (round 3: with ten blocks
+  // per walker and four waves per workgroup a per-walker grid left two of twelve wave slots idle)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nb = (n + 63) >> 6, nblk = nb * (nb + 1) / 2;
-  const int t = blockIdx.x * 4 + wave;
-  if (t >= nblk) return;
+  const long gw = (long)blockIdx.x * 4 + wave;
+  const int b = (int)(gw / nblk);
+  if (b >= nbatch) return;
+  if (run_flag && run_flag[b] >= 0) return;               // only the entries a cheaper kernel has declined
+  const int t = (int)(gw - (long)b * nblk);
   int bi = 0, rem = t;
   while (rem >= nb - bi) { rem -= nb - bi; ++bi; }
   const int bj = bi + rem;                                // bi <= bj: on or above the diagonal
@@ -67,6 +70,8 @@ __global__ __launch_bounds__(256, 2) void gram_cols_f64_kernel(const T *__restri
       for (int r = 0; r < 4; ++r) acc[a][c][r] = 0.0;
 
   const int nks = (K + 3) >> 2;
+  // (unconditional loads at clamped addresses + a select were measured here: 334 -> 553 ms per step of 2048 dense walkers -- the
+  // extra live registers cost the second wave per SIMD; the predicated loads stay)
   auto load = [&](int ks, T(&av)[4], T(&bv)[4]) {
     const int row = 4 * ks + r4;
     const bool ok = row < K;
@@ -84,10 +89,12 @@ __global__ __launch_bounds__(256, 2) void gram_cols_f64_kernel(const T *__restri
     for (int c = 0; c < 4; ++c) ad[c] = (double)av[c];
 #pragma unroll
     for (int c = 0; c < 4; ++c) bd[c] = diag ? ad[c] : (double)bv[c];
+    // a diagonal block needs its tiles on or above the diagonal only (ten of sixteen; the Cholesky reads the upper triangle)
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[a], bd[c], acc[a][c], 0, 0, 0);
+      for (int c = 0; c < 4; ++c)
+        if (!diag || c >= a) acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[a], bd[c], acc[a][c], 0, 0, 0);
   };
   // software pipeline, PF steps deep: a step's operands are requested PF - 1 steps (PF - 1 x 16 MFMAs of 64 cycles) before
   // they are consumed, which covers an L2 / Infinity-Cache round trip at two waves per SIMD
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void gram_cols_f64_kernel(const T *__restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = bi * 64 + 16 * a + r4 + 4 * r, j = bj * 64 + 16 * c + c16;
-        if (i < n && j < n) G[(long)i * n + j] = acc[a][c][r];
+        if (i < n && j < n && (!diag || c >= a)) G[(long)i * n + j] = acc[a][c][r];
       }
 }
 
@@ -127,8 +134,9 @@ inline void launch_gram_cols_f64(hipStream_t s, int nbatch, const T *P, long wP,
   if (nbatch <= 0 || n <= 0) return;
   PG_REQUIRE(nbatch <= 65535, 1, "walker batch exceeds 65535 (grid y limit)");
   const int nb = (n + 63) / 64, nblk = nb * (nb + 1) / 2;
-  hipLaunchKernelGGL(gram_cols_f64_kernel<T>, dim3((nblk + 3) / 4, nbatch), dim3(256), 0, s, P, wP, n, ld, kdyn, kdyn_mul, kmax, G,
-                     (long)n * n, run_flag, inner > 0 ? inner : 1, inner_live, flopc, bytec, nbatch >= 256 ? 64 : 1);
+  const long nwaves = (long)nblk * nbatch;
+  hipLaunchKernelGGL(gram_cols_f64_kernel<T>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, P, wP, n, ld, kdyn, kdyn_mul, kmax, G,
+                     (long)n * n, run_flag, inner > 0 ? inner : 1, inner_live, flopc, bytec, nbatch >= 256 ? 64 : 1, nbatch);
   PG_CHECK_HIP(hipGetLastError());
 }
 

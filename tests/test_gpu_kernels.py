@@ -426,7 +426,11 @@ def test_streaming_gram_kernel(K, n, dt):
             for bj in range(bi, (n + 63) // 64):
                 sl = (slice(64 * bi, min(n, 64 * bi + 64)), slice(64 * bj, min(n, 64 * bj + 64)))
                 scale = np.sqrt(np.outer(np.diag(ref)[sl[0]], np.diag(ref)[sl[1]])) + 1e-300
-                assert np.max(np.abs(G[b][sl] - ref[sl]) / scale) < 1e-13 * max(1, klive[b]) ** 0.5 + 1e-15
+                err = np.abs(G[b][sl] - ref[sl]) / scale
+                if bi == bj:      # a diagonal block holds its 16 x 16 tiles on or above the diagonal only (round 3)
+                    ii, jj = np.indices(err.shape)
+                    err = np.where(jj // 16 >= ii // 16, err, 0.0)
+                assert np.max(err) < 1e-13 * max(1, klive[b]) ** 0.5 + 1e-15
     G0 = capi.diag_gram_cols(capi.F32 if dt == "f32" else capi.F64, P, None)
     ref0 = P[0].astype(np.float64).T @ P[0].astype(np.float64)
     assert np.max(np.abs(np.triu(G0[0]) - np.triu(ref0))[:64, :64]) < 1e-12 * np.max(np.abs(ref0))
