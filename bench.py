@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--no-sweeps", action="store_true", help="skip the MC sweeps/s and VMC samples/s measurement")
     ap.add_argument("--sweep-walkers", type=int, default=2048)
     ap.add_argument("--sweep-count", type=int, default=2)
+    ap.add_argument("--no-other-modes", action="store_true", help="skip the short runs of the f64 / variational / complex / C5 modes")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-walker latency measurement (n1_ms)")
     ap.add_argument("--energy-n", type=int, default=8, help="configurations of the E_loc parity sample of the main leg (half of it on the extra legs)")
     ap.add_argument("--dry-run", action="store_true",
@@ -422,6 +423,65 @@ def vmc_rates(leg, nw, n_sweeps):
                     "accumulation (holes resident in HBM); wall time of the host-layer call incl. its context set-up"}
 
 
+def other_modes(capi, synthetic, device, L, D, chi):
+    """Driver-measured figures of the secondary modes of the path (one short run each, outside the timed region; rounds 1-2 quoted
+    them from builder scripts only): the f64 device mode, the two variational compression schemes (bmps_impl.h:864-1172), the
+    complex element type, and BASELINE config C5 (8x8 spinless fermions, fZ2-graded, D = 6, chi = 24, sign-decorated path)."""
+    out = {}
+
+    def rate(ctx, batches, post=None):
+        ctx.set_configs(batches[0]); ctx.evaluate_amplitude()
+        ctx.sync(); t0 = time.perf_counter()
+        for b in batches[1:]:
+            ctx.set_configs(b); a = ctx.evaluate_amplitude()
+        ctx.sync()
+        return sum(len(b) for b in batches[1:]) / (time.perf_counter() - t0)
+
+    sitps = synthetic.make_sitps(L, D)
+    flat = synthetic.sitps_to_flat(sitps, D, np.float64)
+    try:
+        nw = 2048
+        c = capi.Context(L, L, D, 2, chi, dtype=capi.F64, device=device, max_walkers=nw)
+        c.state_upload(flat)
+        out["f64_mode"] = {"amp_per_s": rate(c, [synthetic.make_configs(L, nw, "heisenberg", seed0=50000 + 7 * k) for k in range(2)]), "walkers": nw}
+        c.close()
+    except Exception as e:
+        out["f64_mode"] = {"error": repr(e)}
+    for name, scheme in (("variational_2site", 1), ("variational_1site", 2)):
+        try:
+            nw = 1024
+            c = capi.Context(L, L, D, 2, chi, dtype=capi.F32, device=device, max_walkers=nw, scheme=scheme, convergence_tol=1e-5, iter_max=3)
+            c.state_upload(flat)
+            out[name] = {"amp_per_s": rate(c, [synthetic.make_configs(L, nw, "heisenberg", seed0=60000 + 7 * k) for k in range(2)]), "walkers": nw,
+                         "iter_max": 3, "convergence_tol": 1e-5}
+            c.close()
+        except Exception as e:
+            out[name] = {"error": repr(e)}
+    try:
+        nw = 128
+        rng = np.random.default_rng(5)
+        cflat = flat * np.exp(2j * np.pi * rng.uniform(size=flat.shape))
+        c = capi.Context(L, L, D, 2, chi, dtype=capi.C128, device=device, max_walkers=nw)
+        c.state_upload(cflat)
+        out["complex128"] = {"amp_per_s": rate(c, [synthetic.make_configs(L, nw, "heisenberg", seed0=70000 + 7 * k) for k in range(2)]), "walkers": nw,
+                             "note": "static shapes (no rank adaptivity), GEMMs on the f64 matrix cores"}
+        c.close()
+    except Exception as e:
+        out["complex128"] = {"error": repr(e)}
+    try:
+        from peps_amd import fermion
+        l5, d5, chi5, nw = 8, 6, 24, 8192
+        st = fermion.random_even_state(l5, l5, d5, seed=11)
+        c = capi.Context(l5, l5, d5, fermion.NVAR * st.d, chi5, dtype=capi.F32, device=device, max_walkers=nw)
+        c.state_upload(st.extended_flat(d5))
+        phys = [synthetic.make_configs(l5, nw, "heisenberg", seed0=80000 + 7 * k) for k in range(3)]
+        out["C5_spinless_tV_8x8_D6_chi24"] = {"amp_per_s": rate(c, [st.ext_config(p, fermion.ROW) for p in phys]), "walkers": nw, "dtype": "f32"}
+        c.close()
+    except Exception as e:
+        out["C5_spinless_tV_8x8_D6_chi24"] = {"error": repr(e)}
+    return out
+
+
 def n1_latency(leg, reps=3):
     """latency floor: one walker, one fresh EvaluateAmplitude (what a reference-style one-walker-per-call binding pays)"""
     c = leg.capi.Context(leg.L, leg.L, leg.D, leg.pdim, leg.chi, dtype=leg.dt, device=leg.device, max_walkers=1)
@@ -666,6 +726,11 @@ def main():
                 out["vmc"] = {"error": repr(e)}
     leg.close()
     del leg
+    if rank == 0 and world == 1 and not args.no_other_modes and args.workload == "C4" and args.state == "synthetic":
+        try:
+            out["other_modes"] = other_modes(capi, synthetic, local_rank, L, D, chi)
+        except Exception as e:
+            out["other_modes"] = {"error": repr(e)}
 
     # ---- further legs on the same shapes: a state of full rank (i.i.d. random site tensors) and a state of the rank of a
     #      REAL PEPS (the reference's optimised 4x4 D=8 fixture tiled to L x L, configurations near the Neel state) ----

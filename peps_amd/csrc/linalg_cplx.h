@@ -99,9 +99,30 @@ __global__ __launch_bounds__(1024) void jacobi_rows_cplx_kernel(T *__restrict__ 
   }
   const double floor2 = NOISE_C * NOISE_C * (double)Eps<T>::v * (double)Eps<T>::v * s_fro[0];
   const double tol = 2.0 * sqrt((double)len) * (double)Eps<T>::v;
-  const int lp = m + (m & 1);
+  // Round 3: the tournament runs over the LIVE rows only (squared norm above the floor below which a row is never rotated
+  // anyway).  The complex path keeps static shapes: after the factor's rank compaction most of the m rows of M = R T are zero
+  // on a state of low numerical rank, and every pair of them still cost two row reads (C4 shapes: 12 amp/s).
+  __shared__ short s_live[1024];
+  __shared__ float s_n2[1024];
+  __shared__ int s_ml;
+  for (int r = wave; r < m; r += nw) {
+    double a = 0.0;
+    for (int c = lane; c < len; c += 64) a += abs2_of(M[(long)r * ld + c]);
+    a = wave_sum(a);
+    if (lane == 0) s_n2[r] = (float)(a > floor2 ? 1.f : 0.f);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int cnt = 0;
+    for (int r = 0; r < m; ++r)
+      if (s_n2[r] > 0.f) s_live[cnt++] = (short)r;
+    s_ml = cnt;
+  }
+  __syncthreads();
+  const int ml = s_ml;
+  const int lp = ml + (ml & 1);
   int sweep = 0;
-  for (; sweep < max_sweeps; ++sweep) {
+  for (; sweep < max_sweeps && ml > 1; ++sweep) {
     if (tid == 0) s_rot = 0;
     __syncthreads();
     for (int r = 0; r < lp - 1; ++r) {
@@ -110,8 +131,8 @@ __global__ __launch_bounds__(1024) void jacobi_rows_cplx_kernel(T *__restrict__ 
         if (p == 0) { a = lp - 1; b = r; }
         else { a = (r + p) % (lp - 1); b = (r - p + (lp - 1)) % (lp - 1); }
         if (a > b) { const int t = a; a = b; b = t; }
-        if (b >= m) continue;
-        T *pa = M + (long)a * ld, *pb = M + (long)b * ld;
+        if (b >= ml) continue;
+        T *pa = M + (long)s_live[a] * ld, *pb = M + (long)s_live[b] * ld;
         double alpha = 0.0, beta = 0.0, gre = 0.0, gim = 0.0;
         for (int c = lane; c < len; c += 64) {
           const T x = pa[c], y = pb[c];

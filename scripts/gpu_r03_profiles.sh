@@ -6,7 +6,7 @@
 # own run; no tracing domains beside --pmc.
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r03prof; mkdir -p $O
 export TMPDIR=/tmp
-COMMON="--steps 1 --warmup 1 --no-cpu-baseline --no-route-check --no-full-rank --no-real-rank --no-sweeps --no-latency --no-energy-check"
+COMMON="--steps 1 --warmup 1 --no-cpu-baseline --no-route-check --no-full-rank --no-real-rank --no-sweeps --no-latency --no-energy-check --no-other-modes"
 leg() { # tag, extra args
   tag=$1; shift
   python3 bench.py $COMMON "$@" > $O/r03_bench_profiled_config_$tag.json 2> $O/bench_$tag.err
