@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--real-rank-walkers", type=int, default=4096)
     ap.add_argument("--real-rank-steps", type=int, default=2)
     ap.add_argument("--no-sweeps", action="store_true", help="skip the MC sweeps/s and VMC samples/s measurement")
-    ap.add_argument("--sweep-walkers", type=int, default=2048)
+    ap.add_argument("--sweep-walkers", type=int, default=8192)
     ap.add_argument("--sweep-count", type=int, default=2)
     ap.add_argument("--no-other-modes", action="store_true", help="skip the short runs of the f64 / variational / complex / C5 modes")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-walker latency measurement (n1_ms)")
@@ -809,6 +809,20 @@ def main():
     if dist is not None and backend == "nccl":
         coll = {}
         st = {}
+        # Watchdog: the measured line must survive a collective that never returns (RCCL has not seen N > 1 ranks of this code
+        # on hardware before the driver's scaling run): after 240 s rank 0 prints the line with the failure noted and every
+        # rank leaves with os._exit (a blocked RCCL call cannot be interrupted from Python).
+        import threading
+        coll_done = threading.Event()
+
+        def watchdog():
+            if not coll_done.wait(timeout=240.0):
+                if rank == 0:
+                    out["collective"] = {"error": "collective section did not finish within 240 s (watchdog); the timed legs above are unaffected"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
 
         def phase(fn):
             err = None
@@ -880,6 +894,7 @@ def main():
                 st["ctx"].close()
         except Exception:
             pass
+        coll_done.set()
         if rank == 0:
             out["collective"] = coll
 
