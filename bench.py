@@ -294,7 +294,7 @@ class Leg:
 # device-counted flops and bytes: the candidates of the roofline object.  The other categories (Gram-free factor, Jacobi,
 # select ...) are VALU / latency bound and listed with their share of the step in `kernel_ms`.
 ROOF_CATS = {"contract_chain": ("tgemm_chain_kernel", "f32"), "contract": ("tgemm_direct_kernel", "f32"),
-             "gram_f64": ("gram_cols_f64_kernel", "f64"), "trunc_gram": ("gram_rows_f64_kernel + chol_upper_kernel / mid_gram_chol_kernel", "f64"),
+             "gram_f64": ("gram_cols_lds_kernel (193..256 columns) / gram_cols_f64_kernel", "f64"), "trunc_gram": ("gram_rows_f64_kernel + chol_upper_kernel / mid_gram_chol_kernel", "f64"),
              "trunc_apply": ("tgemm_kernel<f32,f32,f32,f64>", "f64"), "env": ("tgemm_kernel (BTen / trace)", "f32")}
 
 

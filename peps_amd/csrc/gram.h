@@ -127,12 +127,176 @@ __global__ __launch_bounds__(256, 2) void gram_cols_f64_kernel(const T *__restri
       }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same Gram for DENSE walkers with 129..256 columns, one WORKGROUP per walker (round 3).  The streaming kernel above gives
+// every 64 x 64 block of G its own wave, so a walker's rows of P are fetched by four different waves: 10 GB of fabric traffic per
+// launch of 2048 dense walkers against 3.1 GB of P (profiles/r03_pmc_FETCH_SIZE_c4_f32_real_nw2048.txt), 2.2 TB/s beside 50 % of
+// the f64 MFMA peak.  Here the rows of P pass through LDS once, in chunks of GL_KC rows (float4 loads, dead columns and rows
+// beyond K zeroed on the way in), and the eight waves of the workgroup hold all 136 tiles of the upper triangle in their
+// accumulators: waves 0..5 one off-diagonal 64 x 64 block each (16 tiles), waves 6 and 7 two diagonal blocks each (2 x 10
+// tiles).  Operands are read from LDS as ds_read_b32 at a row pitch of 272 floats (the four k-lanes of an operand land on
+// different banks).  Two chunk buffers: the next chunk is in flight (registers) during the MFMAs of the current one.
+constexpr int GL_KC = 32, GL_PITCH = 272;
+inline size_t gram_cols_lds_smem_bytes() { return sizeof(float) * 2 * GL_KC * GL_PITCH; }
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void gram_cols_lds_kernel(const T *__restrict__ Pg, long wP, int n, int ld,
+                                                               const int *__restrict__ kdyn, int kdyn_mul, int kmax,
+                                                               double *__restrict__ Gg, long wG,
+                                                               const int *__restrict__ run_flag, int inner,
+                                                               const int *__restrict__ inner_live,
+                                                               unsigned long long *__restrict__ flopc,
+                                                               unsigned long long *__restrict__ bytec, int flop_stride) {
+  static_assert(sizeof(T) == 4, "f32 input");
+  extern __shared__ float gl_smem[];
+  const int b = blockIdx.x;
+  if (run_flag && run_flag[b] >= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = kdyn ? min(kmax, kdyn[b] * kdyn_mul) : kmax;
+  if (run_flag) flop_stride = 1;
+  if (flopc && tid == 0 && b % flop_stride == 0) {
+    atomicAdd(flopc, (unsigned long long)flop_stride * n * n * K);
+    if (bytec) atomicAdd(bytec, (unsigned long long)flop_stride * ((unsigned long long)K * n * sizeof(T) + (unsigned long long)n * n * 4));
+  }
+  const T *P = Pg + (long)b * wP;
+  double *G = Gg + (long)b * wG;
+  const int ilive = inner_live ? min(inner, inner_live[b]) : inner;
+  const int i16 = lane & 15, k4 = lane >> 4;
+  // blocks of this wave: (bi, bj) in units of 64 columns; a diagonal block keeps its tiles with c >= a
+  int nblk_w, bi0, bj0, bi1 = 0, bj1 = 0;
+  if (wave < 6) {
+    const int pi[6] = {0, 0, 0, 1, 1, 2}, pj[6] = {1, 2, 3, 2, 3, 3};
+    nblk_w = 1; bi0 = pi[wave]; bj0 = pj[wave];
+  } else {
+    nblk_w = 2; bi0 = bj0 = 2 * (wave - 6); bi1 = bj1 = 2 * (wave - 6) + 1;
+  }
+  gr_f64x4 acc[2][10];     // waves 0..5 use acc[0][0..9] and acc[1][0..5] as their 16 tiles
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[q][t][r] = 0.0;
+
+  // ---- chunk loader: 32 rows x 256 columns = 2048 float4, four per thread ----
+  const int nch = (K + GL_KC - 1) / GL_KC;
+  float4 pv[4];
+  auto issue = [&](int ch) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 512 * q;              // float4 index: row = e / 64, column group = e % 64
+      const int r = ch * GL_KC + (e >> 6), c = 4 * (e & 63);
+      const bool ok = r < K && c < n;
+      const float4 v = ok ? *reinterpret_cast<const float4 *>(P + (long)r * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pv[q] = v;
+    }
+  };
+  auto lay = [&](int buf) {
+    float *dst = gl_smem + buf * GL_KC * GL_PITCH;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 512 * q;
+      const int rr = e >> 6, c = 4 * (e & 63);
+      float v[4] = {pv[q].x, pv[q].y, pv[q].z, pv[q].w};
+#pragma unroll
+      for (int z = 0; z < 4; ++z)
+        if ((c + z) % inner >= ilive || c + z >= n) v[z] = 0.f;      // dead / absent column: never written in P
+      *reinterpret_cast<float4 *>(dst + rr * GL_PITCH + c) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  auto mma = [&](int buf) {
+    const float *src = gl_smem + buf * GL_KC * GL_PITCH;
+#pragma unroll 2
+    for (int s = 0; s < GL_KC / 4; ++s) {
+      const float *row = src + (4 * s + k4) * GL_PITCH + i16;
+      if (nblk_w == 1) {
+        double a[4], bb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { a[c] = (double)row[bi0 * 64 + 16 * c]; bb[c] = (double)row[bj0 * 64 + 16 * c]; }
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int t = 4 * x + c;
+            if (t < 10) acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], bb[c], acc[0][t], 0, 0, 0);
+            else acc[1][t - 10] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], bb[c], acc[1][t - 10], 0, 0, 0);
+          }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int bd = q ? bi1 : bi0;
+          double a[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) a[c] = (double)row[bd * 64 + 16 * c];
+          int t = 0;
+#pragma unroll
+          for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int c = x; c < 4; ++c) { acc[q][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], a[c], acc[q][t], 0, 0, 0); ++t; }
+        }
+      }
+    }
+  };
+  if (nch > 0) { issue(0); lay(0); }
+  __syncthreads();
+  for (int ch = 0; ch < nch; ++ch) {
+    if (ch + 1 < nch) issue(ch + 1);
+    mma(ch & 1);
+    if (ch + 1 < nch) lay((ch + 1) & 1);
+    __syncthreads();
+  }
+  // ---- store: acc[r] = C[(lane >> 4) + 4 r][lane & 15] ----
+  if (nblk_w == 1) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int t = 4 * x + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = bi0 * 64 + 16 * x + k4 + 4 * r, j = bj0 * 64 + 16 * c + i16;
+          const double v = t < 10 ? acc[0][t][r] : acc[1][t - 10][r];
+          if (i < n && j < n) G[(long)i * n + j] = v;
+        }
+      }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int bd = q ? bi1 : bi0;
+      int t = 0;
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int c = x; c < 4; ++c) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = bd * 64 + 16 * x + k4 + 4 * r, j = bd * 64 + 16 * c + i16;
+            if (i < n && j < n) G[(long)i * n + j] = acc[q][t][r];
+          }
+          ++t;
+        }
+    }
+  }
+}
+
 template <typename T>
 inline void launch_gram_cols_f64(hipStream_t s, int nbatch, const T *P, long wP, int n, int ld, const int *kdyn, int kdyn_mul,
                                  int kmax, double *G, const int *run_flag, int inner, const int *inner_live,
                                  unsigned long long *flopc, unsigned long long *bytec) {
   if (nbatch <= 0 || n <= 0) return;
   PG_REQUIRE(nbatch <= 65535, 1, "walker batch exceeds 65535 (grid y limit)");
+  if constexpr (sizeof(T) == 4) {
+    static const bool no_lds_gram = getenv("PEPSGPU_NO_LDS_GRAM") != nullptr;
+    // dense walkers (hint of the caller: kmax rows, 193..256 columns = four 64-column blocks): P through LDS once per walker
+    if (!no_lds_gram && n > 192 && n <= 256 && ld % 4 == 0 && wP % 4 == 0 && (((uintptr_t)P) & 15) == 0 && kmax >= 256) {
+      const size_t smem = gram_cols_lds_smem_bytes();
+      allow_dynamic_lds(reinterpret_cast<const void *>(&gram_cols_lds_kernel<T>), smem);
+      hipLaunchKernelGGL(gram_cols_lds_kernel<T>, dim3(nbatch), dim3(512), smem, s, P, wP, n, ld, kdyn, kdyn_mul, kmax, G, (long)n * n,
+                         run_flag, inner > 0 ? inner : 1, inner_live, flopc, bytec, nbatch >= 256 ? 64 : 1);
+      PG_CHECK_HIP(hipGetLastError());
+      return;
+    }
+  }
   const int nb = (n + 63) / 64, nblk = nb * (nb + 1) / 2;
   const long nwaves = (long)nblk * nbatch;
   hipLaunchKernelGGL(gram_cols_f64_kernel<T>, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, s, P, wP, n, ld, kdyn, kdyn_mul, kmax, G,

@@ -164,7 +164,7 @@ __device__ __forceinline__ void tgemm_tile(const TGemmDesc &d, const TA *__restr
       for (int c = 0; c < 4; ++c) accv[a][c] = TAcc(0);
   }
 
-  TAcc ra2[2][4], rb2[2][4];    // two register sets: the loads of k-tile kt + 2 are issued before the MFMAs of kt (round 3)
+  TAcc ra[4], rb[4];
   for (int kc = 0; kc < Ktot; kc += TG_KTAB) {
     const int kchunk = min(TG_KTAB, Ktot - kc);
     __syncthreads();
@@ -175,7 +175,7 @@ __device__ __forceinline__ void tgemm_tile(const TGemmDesc &d, const TA *__restr
     __syncthreads();
     const int nkt = (kchunk + TG_BK - 1) / TG_BK;
 
-    auto load_regs = [&](int kt, TAcc (&ra)[4], TAcc (&rb)[4]) {
+    auto load_regs = [&](int kt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int e = tid + 256 * r;
@@ -192,7 +192,7 @@ __device__ __forceinline__ void tgemm_tile(const TGemmDesc &d, const TA *__restr
         }
       }
     };
-    auto store_regs = [&](const TAcc (&ra)[4], const TAcc (&rb)[4]) {
+    auto store_regs = [&]() {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int e = tid + 256 * r;
@@ -204,14 +204,13 @@ __device__ __forceinline__ void tgemm_tile(const TGemmDesc &d, const TA *__restr
       }
     };
 
-    load_regs(0, ra2[0], rb2[0]);
-    store_regs(ra2[0], rb2[0]);
+    // (a second register set -- the loads of k-tile kt + 2 issued before the MFMAs of kt -- was measured in round 3: the dense
+    // M = R Tt went 149 -> 171 ms per step, the f64-accumulating apply 70 -> 94: not adopted)
+    load_regs(0);
+    store_regs();
     __syncthreads();
-    if (nkt > 1) load_regs(1, ra2[1], rb2[1]);
     for (int kt = 0; kt < nkt; ++kt) {
-      if (kt + 2 < nkt) {                       // (set kt & 1 was laid down in LDS before this iteration)
-        if (kt & 1) load_regs(kt + 2, ra2[1], rb2[1]); else load_regs(kt + 2, ra2[0], rb2[0]);
-      }
+      if (kt + 1 < nkt) load_regs(kt + 1);
       if constexpr (USE_MFMA && CPLX) {
         // complex128 on the f64 matrix cores: the operands sit interleaved in LDS (one 16-byte read per element), the four real
         // products of (ar + i ai)(br + i bi) are four v_mfma_f64_16x16x4_f64 per tile: Re += ar br - ai bi, Im += ar bi + ai br
@@ -267,7 +266,7 @@ __device__ __forceinline__ void tgemm_tile(const TGemmDesc &d, const TA *__restr
       }
       __syncthreads();
       if (kt + 1 < nkt) {
-        if (kt & 1) store_regs(ra2[0], rb2[0]); else store_regs(ra2[1], rb2[1]);
+        store_regs();
         __syncthreads();
       }
     }

@@ -7,7 +7,7 @@ times (calibration with 1 walker, warm-up and timed step at full size, rank diag
 are identified by their grid in the kernel trace (the two largest launch groups of the kernel) and carry all but ~0.1 % of the bytes."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ("tgemm_chain_kernel", "tgemm_direct_kernel", "gram_cols_f64_kernel", "gram_rows_f64_kernel", "chol_blocked_kernel",
+KERNELS = ("tgemm_chain_kernel", "tgemm_direct_kernel", "gram_cols_f64_kernel", "gram_cols_lds_kernel", "gram_rows_f64_kernel", "chol_blocked_kernel",
            "gram_chol_wave_kernel", "jacobi_rows_grp_kernel", "jacobi_rows_tiny4_kernel", "colgram_dense_kernel", "mid_gram_chol_kernel")
 LEGS = {"c4_f32_noise0.1": "c4_f32_noise0.1_nw32768", "c4_f32_noise1": "c4_f32_noise1_nw4096", "c4_f32_real": "c4_f32_real_nw2048"}
 
