@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--full-rank-walkers", type=int, default=4096)
     ap.add_argument("--full-rank-steps", type=int, default=2)
     ap.add_argument("--no-real-rank", action="store_true", help="skip the third leg on the tiled optimised state of the reference")
-    ap.add_argument("--real-rank-walkers", type=int, default=4096)
+    ap.add_argument("--real-rank-walkers", type=int, default=8192)
     ap.add_argument("--real-rank-steps", type=int, default=2)
     ap.add_argument("--no-sweeps", action="store_true", help="skip the MC sweeps/s and VMC samples/s measurement")
     ap.add_argument("--sweep-walkers", type=int, default=8192)

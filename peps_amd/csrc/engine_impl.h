@@ -672,6 +672,8 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
                                GS, 40, sweeps_, (const int *)rowsA, 1, 128, (const int *)big_list, (const int *)(big_list + nw_));
             PG_CHECK_HIP(hipEventRecord(ev_join_, side_stream_));
             side_pending = true;
+            // (size classes by row length -- <2,4> for r <= 64, <3,5>, <3,6>, <4,8> -- were measured in round 3: 533 -> 576 ms per
+            // step of 4096 dense walkers; the tournament is bound by its exchange / reduction latency, not by the FMAs of a pair)
             launch_jacobi_grp<2, 8>(stream_, nw_, (float *)B2.p, B2.n, 128, 128, 128, 40, sweeps_, (const int *)mB2, 1, 0);
             launch_jacobi_grp<4, 8>(stream_, nw_, (float *)B2.p, B2.n, 128, 128, 128, 40, sweeps_, (const int *)mB2, 1, 64);
           } else {

@@ -593,7 +593,9 @@ template <int NW, int CPL>
 __global__ __launch_bounds__(NW * 64) void jacobi_rows_grp_kernel(float *__restrict__ Mg, long wM, int m, int len, int ld,
                                                                   int max_sweeps, int *__restrict__ sweeps_out,
                                                                   const int *__restrict__ mdyn, int mdyn_mul,
-                                                                  int lo_rows = 0) {
+                                                                  int lo_rows = 0, int hi_rows = 1 << 30) {
+  // lo_rows < rows <= min(hi_rows, MAXR): the size class of this instantiation (other launches take the rest); the row length
+  // covered is 16 CPL columns -- a square factor of r rows is given to the instantiation whose CPL just covers r
   constexpr int NP = 4 * NW, SLOTS = NP + 1, MAXR = NP * 2 * JG_RB, NT = NW * 64;
   extern __shared__ float jg_dyn[];                       // exchange slots (dynamic: 70 KB at NW = 4, CPL = 16)
   float (*xch)[JG_RB][CPL][16] = reinterpret_cast<float (*)[JG_RB][CPL][16]>(jg_dyn);   // [SLOTS][JG_RB][CPL][16]
@@ -603,7 +605,7 @@ __global__ __launch_bounds__(NW * 64) void jacobi_rows_grp_kernel(float *__restr
   __shared__ double s_fro[NW];
   __shared__ int s_rot, s_live0;
   if (mdyn) m = min(m, mdyn[blockIdx.x] * mdyn_mul);
-  if (m <= lo_rows || m > MAXR) return;
+  if (m <= lo_rows || m > MAXR || m > hi_rows) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l16 = lane & 15;
   const int w = wv * 4 + (lane >> 4);                     // the player this lane belongs to
   float *M = Mg + (long)blockIdx.x * wM;
@@ -791,11 +793,11 @@ __global__ __launch_bounds__(NW * 64) void jacobi_rows_grp_kernel(float *__restr
 
 template <int NW, int CPL>
 inline void launch_jacobi_grp(hipStream_t s, int nbatch, float *M, long wM, int m, int len, int ld, int max_sweeps, int *sweeps_out,
-                              const int *mdyn, int mdyn_mul, int lo_rows) {
+                              const int *mdyn, int mdyn_mul, int lo_rows, int hi_rows = 1 << 30) {
   const size_t smem = sizeof(float) * (size_t)(4 * NW + 1) * JG_RB * CPL * 16;
   allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_grp_kernel<NW, CPL>), smem);
   hipLaunchKernelGGL((jacobi_rows_grp_kernel<NW, CPL>), dim3(nbatch), dim3(NW * 64), smem, s, M, wM, m, len, ld, max_sweeps, sweeps_out,
-                     mdyn, mdyn_mul, lo_rows);
+                     mdyn, mdyn_mul, lo_rows, hi_rows);
 }
 
 // ---------------------------------------------------------------------------------------------

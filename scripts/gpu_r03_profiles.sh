@@ -1,7 +1,7 @@
 # round 3 evidence: kernel traces and PMC passes of the three bench legs
 #   headline  : SURVEY 8(d) state, C4, 32768 walkers
 #   full_rank : i.i.d. random site tensors (noise 1.0), 4096 walkers
-#   real_rank : the reference's optimised 4x4 D=8 state tiled to 12x12, 2048 walkers
+#   real_rank : the reference's optimised 4x4 D=8 state tiled to 12x12, 8192 walkers
 # One counter group per pass (FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2: MI355X_MICROARCH.md); kernel trace in its
 # own run; no tracing domains beside --pmc.
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r03prof; mkdir -p $O
@@ -26,6 +26,6 @@ leg() { # tag, extra args
 }
 leg c4_f32_noise0.1_nw32768
 leg c4_f32_noise1_nw4096 --noise 1.0 --walkers 4096
-leg c4_f32_real_nw2048 --state real --walkers 2048
+leg c4_f32_real_nw8192 --state real --walkers 8192
 find $O -name "*.csv" -size +3M -delete
 ls $O | head -60
