@@ -133,10 +133,15 @@ __global__ __launch_bounds__(256, 2) void gram_cols_f64_kernel(const T *__restri
 // launch of 2048 dense walkers against 3.1 GB of P (profiles/r03_pmc_FETCH_SIZE_c4_f32_real_nw2048.txt), 2.2 TB/s beside 50 % of
 // the f64 MFMA peak.  Here the rows of P pass through LDS once, in chunks of GL_KC rows (float4 loads, dead columns and rows
 // beyond K zeroed on the way in), and the eight waves of the workgroup hold all 136 tiles of the upper triangle in their
-// accumulators: waves 0..5 one off-diagonal 64 x 64 block each (16 tiles), waves 6 and 7 two diagonal blocks each (2 x 10
-// tiles).  Operands are read from LDS as ds_read_b32 at a row pitch of 272 floats (the four k-lanes of an operand land on
+// accumulators, seventeen tiles per wave.  Operands are read from LDS as ds_read_b32 at a row pitch of 272 floats (the four k-lanes of an operand land on
 // different banks).  Two chunk buffers: the next chunk is in flight (registers) during the MFMAs of the current one.
 constexpr int GL_KC = 32, GL_PITCH = 272;
+// tile t (0..16) of wave W: the (17 W + t)-th tile of the upper triangle of the 16 x 16 tile grid, rows first
+template <int W> struct GlTile {
+  static constexpr int start(int x) { return 16 * x - x * (x - 1) / 2; }
+  static constexpr int x(int t) { int r = 0; while (r < 15 && start(r + 1) <= 17 * W + t) ++r; return r; }
+  static constexpr int c(int t) { return x(t) + (17 * W + t - start(x(t))); }
+};
 inline size_t gram_cols_lds_smem_bytes() { return sizeof(float) * 2 * GL_KC * GL_PITCH; }
 
 template <typename T>
@@ -162,22 +167,6 @@ __global__ __launch_bounds__(512, 2) void gram_cols_lds_kernel(const T *__restri
   double *G = Gg + (long)b * wG;
   const int ilive = inner_live ? min(inner, inner_live[b]) : inner;
   const int i16 = lane & 15, k4 = lane >> 4;
-  // blocks of this wave: (bi, bj) in units of 64 columns; a diagonal block keeps its tiles with c >= a
-  int nblk_w, bi0, bj0, bi1 = 0, bj1 = 0;
-  if (wave < 6) {
-    const int pi[6] = {0, 0, 0, 1, 1, 2}, pj[6] = {1, 2, 3, 2, 3, 3};
-    nblk_w = 1; bi0 = pi[wave]; bj0 = pj[wave];
-  } else {
-    nblk_w = 2; bi0 = bj0 = 2 * (wave - 6); bi1 = bj1 = 2 * (wave - 6) + 1;
-  }
-  gr_f64x4 acc[2][10];     // waves 0..5 use acc[0][0..9] and acc[1][0..5] as their 16 tiles
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int t = 0; t < 10; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[q][t][r] = 0.0;
-
   // ---- chunk loader: 32 rows x 256 columns = 2048 float4, four per thread ----
   const int nch = (K + GL_KC - 1) / GL_KC;
   float4 pv[4];
@@ -204,78 +193,52 @@ __global__ __launch_bounds__(512, 2) void gram_cols_lds_kernel(const T *__restri
       *reinterpret_cast<float4 *>(dst + rr * GL_PITCH + c) = make_float4(v[0], v[1], v[2], v[3]);
     }
   };
-  auto mma = [&](int buf) {
-    const float *src = gl_smem + buf * GL_KC * GL_PITCH;
-#pragma unroll 2
-    for (int s = 0; s < GL_KC / 4; ++s) {
-      const float *row = src + (4 * s + k4) * GL_PITCH + i16;
-      if (nblk_w == 1) {
-        double a[4], bb[4];
+  // The 136 tiles (x, c >= x) of the 16 x 16 tile grid, row after row, dealt in runs of 17 to the eight waves: every wave
+  // issues the same number of MFMAs.  A wave's run spans two or three tile rows; per k-step it converts the <= 16 operand
+  // segments its tiles touch (the reads of the segments it does not use are dead code after unrolling) and issues 17 MFMAs.
+  auto run = [&](auto wc) {
+    constexpr int W = decltype(wc)::value;
+    gr_f64x4 acc[17];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { a[c] = (double)row[bi0 * 64 + 16 * c]; bb[c] = (double)row[bj0 * 64 + 16 * c]; }
+    for (int t = 0; t < 17; ++t)
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int t = 4 * x + c;
-            if (t < 10) acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], bb[c], acc[0][t], 0, 0, 0);
-            else acc[1][t - 10] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], bb[c], acc[1][t - 10], 0, 0, 0);
-          }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int bd = q ? bi1 : bi0;
-          double a[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) a[c] = (double)row[bd * 64 + 16 * c];
-          int t = 0;
-#pragma unroll
-          for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int c = x; c < 4; ++c) { acc[q][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], a[c], acc[q][t], 0, 0, 0); ++t; }
-        }
-      }
-    }
-  };
-  if (nch > 0) { issue(0); lay(0); }
-  __syncthreads();
-  for (int ch = 0; ch < nch; ++ch) {
-    if (ch + 1 < nch) issue(ch + 1);
-    mma(ch & 1);
-    if (ch + 1 < nch) lay((ch + 1) & 1);
+      for (int r = 0; r < 4; ++r) acc[t][r] = 0.0;
+    if (nch > 0) { issue(0); lay(0); }
     __syncthreads();
-  }
-  // ---- store: acc[r] = C[(lane >> 4) + 4 r][lane & 15] ----
-  if (nblk_w == 1) {
+    for (int ch = 0; ch < nch; ++ch) {
+      if (ch + 1 < nch) issue(ch + 1);
+      const float *src = gl_smem + (ch & 1) * GL_KC * GL_PITCH;
+#pragma unroll 2
+      for (int s2 = 0; s2 < GL_KC / 4; ++s2) {
+        const float *row = src + (4 * s2 + k4) * GL_PITCH + i16;
+        double seg[16];
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+        for (int q = 0; q < 16; ++q) seg[q] = (double)row[16 * q];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int t = 4 * x + c;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = bi0 * 64 + 16 * x + k4 + 4 * r, j = bj0 * 64 + 16 * c + i16;
-          const double v = t < 10 ? acc[0][t][r] : acc[1][t - 10][r];
-          if (i < n && j < n) G[(long)i * n + j] = v;
-        }
+        for (int t = 0; t < 17; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(seg[GlTile<W>::x(t)], seg[GlTile<W>::c(t)], acc[t], 0, 0, 0);
       }
-  } else {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int bd = q ? bi1 : bi0;
-      int t = 0;
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int c = x; c < 4; ++c) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = bd * 64 + 16 * x + k4 + 4 * r, j = bd * 64 + 16 * c + i16;
-            if (i < n && j < n) G[(long)i * n + j] = acc[q][t][r];
-          }
-          ++t;
-        }
+      if (ch + 1 < nch) lay((ch + 1) & 1);
+      __syncthreads();
     }
+    // store: acc[r] = C[(lane >> 4) + 4 r][lane & 15]
+#pragma unroll
+    for (int t = 0; t < 17; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * GlTile<W>::x(t) + k4 + 4 * r, j = 16 * GlTile<W>::c(t) + i16;
+        if (i < n && j < n) G[(long)i * n + j] = acc[t][r];
+      }
+  };
+  switch (wave) {      // (every branch executes the same number of barriers)
+    case 0: run(std::integral_constant<int, 0>{}); break;
+    case 1: run(std::integral_constant<int, 1>{}); break;
+    case 2: run(std::integral_constant<int, 2>{}); break;
+    case 3: run(std::integral_constant<int, 3>{}); break;
+    case 4: run(std::integral_constant<int, 4>{}); break;
+    case 5: run(std::integral_constant<int, 5>{}); break;
+    case 6: run(std::integral_constant<int, 6>{}); break;
+    default: run(std::integral_constant<int, 7>{}); break;
   }
 }
 
