@@ -20,6 +20,7 @@
 #include "tgemm.h"
 #include "gram.h"
 #include "trunc_mid.h"
+#include "mgemm_dense.h"
 
 namespace pepsgpu {
 

@@ -475,7 +475,18 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       dense_site = !no_tiled_hint && in.depth >= 3 && (int)in.mlmax.size() > i && in.mlmax[i] > 96 && la >= 128 && uk >= 128;
       g.prefer_tiled = dense_site;
       prof_begin(PROF_CONTRACT, 0.0, 2.0 * nw_ * (double)m * la * (double)uk);
-      tgemm_launch<T, T, T, T>(stream_, g, R[i].p, Tt.p, M.p);
+      bool mg_done = false;
+      if constexpr (sizeof(T) == 4) {
+        // dense carry: the workgroup-per-walker kernel (mgemm_dense.h): R and Tt through LDS once, eight waves x 32 columns
+        static const bool no_mgd = getenv("PEPSGPU_NO_MGEMM_DENSE") != nullptr;
+        if (dense_site && !no_mgd && m > 128 && mgemm_dense_ok(m, la, a, u, k2, R[i].n, Tt.n, R[i].p, Tt.p)) {
+          launch_mgemm_dense(stream_, nw_, (const float *)R[i].p, R[i].n, (const float *)Tt.p, Tt.n, (float *)M.p, M.n, m, la, a, u, k2,
+                             tsw ? 1 : 0, (const int *)mdyn[i], mmul[i], (const int *)clive[i], (const int *)kn[i + 1], tg_flop_counter,
+                             tg_byte_counter);
+          mg_done = true;
+        }
+      }
+      if (!mg_done) tgemm_launch<T, T, T, T>(stream_, g, R[i].p, Tt.p, M.p);
       prof_end();
     }
     // rows of M -> mutually orthogonal (sigma_k v_k^T)
