@@ -590,7 +590,7 @@ __device__ __forceinline__ float jg_sum16(float v) {
 }
 
 template <int NW, int CPL>
-__global__ __launch_bounds__(NW * 64) void jacobi_rows_grp_kernel(float *__restrict__ Mg, long wM, int m, int len, int ld,
+__global__ __launch_bounds__(NW * 64, CPL <= 8 ? 4 : 2) void jacobi_rows_grp_kernel(float *__restrict__ Mg, long wM, int m, int len, int ld,
                                                                   int max_sweeps, int *__restrict__ sweeps_out,
                                                                   const int *__restrict__ mdyn, int mdyn_mul,
                                                                   int lo_rows = 0, int hi_rows = 1 << 30) {
