@@ -343,7 +343,7 @@ extern "C" int pepsgpu_diag_tgemm_chain(const int *dims, const int32_t *live, in
     TGemmChainMap mp;
     mp.mapK[1] = 2; mp.mapK[2] = 4;
     mp.mapJ[1] = 1; mp.mapJ[2] = 5;
-    PG_REQUIRE(tgemm_chain_launch(0, gx, gp, mp, dR, dA, dW, dP, dflag, 1), 1, "chain launch refused");
+    PG_REQUIRE(tgemm_chain_launch(0, gx, gp, mp, dR, dA, dW, dP, dflag, 1, 0), 1, "chain launch refused");
     PG_CHECK_HIP(hipDeviceSynchronize());
     PG_CHECK_HIP(hipMemcpy(P_out, dP, nP * nbatch * sizeof(float), hipMemcpyDeviceToHost));
     PG_CHECK_HIP(hipMemcpy(flags_out, dflag, nbatch * sizeof(int), hipMemcpyDeviceToHost));

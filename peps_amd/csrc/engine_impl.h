@@ -154,6 +154,12 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_svd(int pos, int num, const BMPSDe
   return out;
 }
 
+// hint of the row absorbed before: the carry at site i ran at a hundred or more live rows (a dense walker batch)
+template <typename BM>
+static inline int hint_dense_carry(const BM &in, int i) {
+  return in.depth >= 3 && (int)in.mlmax.size() > i && in.mlmax[i] > 96;
+}
+
 template <typename T>
 bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in, BMPSDev &out) {
   const int N = mps_len(pos);
@@ -235,7 +241,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           mp.mapJ[1] = 1; mp.mapJ[2] = 5;      // J2 = (m, a2): m = I1[1], a2 = J1[2]
           prof_begin(PROF_CHAIN, flx + flp, flx + flp);
           chained = tgemm_chain_launch(stream_, gx, g2, mp, (const float *)R[i].p, (const float *)A.p,
-                                       (const float *)site_base(r, c), (float *)P.p, chain_flag, chain_chunks);
+                                       (const float *)site_base(r, c), (float *)P.p, chain_flag, chain_chunks, hint_dense_carry(in, i));
           prof_end();
           if (!chained) { arena_.free(chain_flag); chain_flag = nullptr; }
         }
@@ -428,7 +434,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           mp.mapJ[1] = 1; mp.mapJ[2] = 5;      // J2 = (a, k2): a = I1[1], k2 = J1[2]
           prof_begin(PROF_CHAIN, 0.0, flz + flt);
           chained = tgemm_chain_launch(stream_, gz, g2, mp, (const float *)A.p, (const float *)Y.p,
-                                       (const float *)site_base(r, c), (float *)Tt.p, chain_flag, chain_chunks);
+                                       (const float *)site_base(r, c), (float *)Tt.p, chain_flag, chain_chunks, hint_dense_carry(in, i));
           prof_end();
           if (!chained) { arena_.free(chain_flag); chain_flag = nullptr; }
         }

@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TG
 // Returns 0 when the static shapes rule the chain out, 1 when launched (entries may be declined: flag -1), 2 when launched and
 // no entry can be declined (every slice of the intermediate fits the buffer: the caller skips the fallback launches).
 inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemmDesc &d2_in, const TGemmChainMap &mp,
-                              const float *A1, const float *B1, const float *A2, float *C2, int *flag, int allow_chunks = 0);
+                              const float *A1, const float *B1, const float *A2, float *C2, int *flag, int allow_chunks = 0, int dense = 0);
 
 bool tgemm_use_mfma();
 
@@ -782,7 +782,7 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
 }
 
 inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemmDesc &d2_in, const TGemmChainMap &mp,
-                              const float *A1, const float *B1, const float *A2, float *C2, int *flag, int allow_chunks) {
+                              const float *A1, const float *B1, const float *A2, float *C2, int *flag, int allow_chunks, int dense) {
   if (!tgemm_use_mfma() || d1_in.dynK || d2_in.dynK || d1_in.nbatch != d2_in.nbatch || d1_in.nbatch <= 0) return 0;
   if (d1_in.bdivA != 1 || d1_in.bdivB != 1 || d2_in.bdivA != 1 || d2_in.bdivC != 1) return 0;
   TGemmDesc d1 = d1_in, d2 = d2_in;
@@ -798,9 +798,16 @@ inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemm
   const bool avec2 = !no_vec && d2.sAk[2] == 1 && al4(d2.K[2]) && al4(d2.sAi[0]) && al4(d2.sAi[1]) && al4(d2.sAi[2]) &&
                      al4(d2.sAk[0]) && al4(d2.sAk[1]) && al4(d2.wA) && al4(d2.selA_mul) && (((uintptr_t)A2) & 15) == 0;
   const dim3 g(d1.nbatch), blk(256);
+  // dense walker batch (hint of the caller): the intermediate is walked in chunks anyway; a 32 KB buffer holds four values of
+  // the chunked sub-index = 32 full rows per stage-1 tile and eight balanced stage-2 tiles (24 KB: 24 rows, six tiles), at four
+  // blocks per CU instead of six (PEPSGPU_CHAIN_DENSE_LDS = 0 / 8192 / 16384 floats)
+  static const int dense_lds = getenv("PEPSGPU_CHAIN_DENSE_LDS") ? atoi(getenv("PEPSGPU_CHAIN_DENSE_LDS")) : 8192;
+  const int ldsf = (dense && allow_chunks && dense_lds >= 8192) ? (dense_lds >= 16384 ? 16384 : 8192) : TG_CHAIN_LDS_FLOATS;
 #define PG_CHAIN(a1, b1, a2)                                                                                                   \
   do {                                                                                                                         \
-    hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 6>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
+    if (ldsf == 16384) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 16384, 2>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
+    else if (ldsf == 8192) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 8192, 4>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
+    else hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 6>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
   } while (0)
   if (avec1 && bvec1 && avec2) PG_CHAIN(true, true, true);
   else if (avec1 && bvec1) PG_CHAIN(true, true, false);
@@ -820,8 +827,8 @@ inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemm
   }
   const long whole = (long)d1.Itot() * d1.Jtot(), per = (long)d1.I[2] * d1.Jtot();
   const bool chunkable = allow_chunks && d1.I[0] == 1 && !d1.dynI && !d2.dynI && jsub >= 0 && jsub <= 2 &&
-                         !(d1.dI[1].p && d1.dI[1].mask) && per <= TG_CHAIN_LDS_FLOATS;
-  return (whole <= TG_CHAIN_LDS_FLOATS || chunkable) ? 2 : 1;
+                         !(d1.dI[1].p && d1.dI[1].mask) && per <= ldsf;
+  return (whole <= ldsf || chunkable) ? 2 : 1;
 }
 
 }  // namespace pepsgpu
