@@ -254,6 +254,8 @@ int pepsgpu_diag_chol(int dtype_out, const double *G, int n, int nbatch, void *R
 /* the streaming f64 Gram kernel of the forward pass (gram.h): P = [nbatch][K][n], klive (nullable) = live rows per entry */
 int pepsgpu_diag_gram_cols(int dtype, const void *P, int K, int n, int nbatch, const int32_t *klive, double *G_out);
 int pepsgpu_diag_gram_rows(const float *M, int n, int K, int nbatch, const int32_t *nrows, double *G_out);
+int pepsgpu_diag_mgemm_dense(const float *R, const float *Tt, int m, int la, int a_dim, int u_dim, int k2_dim, int tt_u_inner, int nbatch,
+                             const int32_t *m_live, const int32_t *a_live, const int32_t *k2_live, float *M_out);
 /* the rank-adaptive pair used by the absorption: low-rank right-looking kernel, then the blocked
  * kernel for the walkers whose rank exceeds its cap; mlive_out[b] = rows of R_out[b] that exist */
 /* the Gram-free low-rank kernel alone: P = [nbatch][K][n] (dtype), R^T R = P^T P; mlive_out[b] = -1 where

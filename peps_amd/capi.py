@@ -39,7 +39,7 @@ SYMBOLS = [
     "pepsgpu_sr_cg_solve", "pepsgpu_sr_gram", "pepsgpu_sr_weighted_sum", "pepsgpu_sr_copy_samples",
     "pepsgpu_update_local", "pepsgpu_erase_envs_after_update", "pepsgpu_evaluate_amplitude",
     "pepsgpu_walker_flags", "pepsgpu_sync", "pepsgpu_stats", "pepsgpu_profile_enable", "pepsgpu_profile_read",
-    "pepsgpu_diag_tgemm", "pepsgpu_diag_tgemm_chain", "pepsgpu_diag_chol", "pepsgpu_diag_chol_adaptive", "pepsgpu_diag_gram_chol", "pepsgpu_diag_gram_cols", "pepsgpu_diag_gram_rows", "pepsgpu_diag_jacobi", "pepsgpu_version",
+    "pepsgpu_diag_tgemm", "pepsgpu_diag_tgemm_chain", "pepsgpu_diag_chol", "pepsgpu_diag_chol_adaptive", "pepsgpu_diag_gram_chol", "pepsgpu_diag_gram_cols", "pepsgpu_diag_gram_rows", "pepsgpu_diag_mgemm_dense", "pepsgpu_diag_jacobi", "pepsgpu_version",
 ]
 
 
@@ -555,6 +555,26 @@ def diag_gram_rows(M, nrows):
     if rc != 0:
         raise RuntimeError("diag_gram_rows failed: %s" % lib().pepsgpu_last_error(None).decode())
     return G
+
+
+def diag_mgemm_dense(R, Tt, a_dim, u_dim, k2_dim, tt_u_inner, m_live=None, a_live=None, k2_live=None):
+    """mgemm_dense_kernel alone: R [nb][m][la], Tt [nb][la][u * k2] (inner order (u, k2), or (k2, u) with tt_u_inner) -> M [nb][m][u * k2]
+    (rows beyond m_live[b] come back as NaN: untouched)."""
+    R = np.ascontiguousarray(R, dtype=np.float32)
+    Tt = np.ascontiguousarray(Tt, dtype=np.float32)
+    nb, m, la = R.shape
+    uk = u_dim * k2_dim
+    assert Tt.shape == (nb, la, uk)
+    M = np.zeros((nb, m, uk), dtype=np.float32)
+    arrs = [None if x is None else np.ascontiguousarray(x, dtype=np.int32) for x in (m_live, a_live, k2_live)]
+    f = lib().pepsgpu_diag_mgemm_dense
+    ip = C.POINTER(C.c_int32)
+    f.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [ip, ip, ip, C.c_void_p]
+    rc = f(R.ctypes.data_as(C.c_void_p), Tt.ctypes.data_as(C.c_void_p), m, la, a_dim, u_dim, k2_dim, int(tt_u_inner), nb,
+           *[None if a is None else _ip(a) for a in arrs], M.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise RuntimeError("diag_mgemm_dense failed: %s" % lib().pepsgpu_last_error(None).decode())
+    return M
 
 
 def diag_jacobi(dtype, M, k, force_global=False):

@@ -480,6 +480,34 @@ extern "C" int pepsgpu_diag_gram_rows(const float *M, int n, int K, int nbatch, 
     (void)hipFree(dM); (void)hipFree(dG); (void)hipFree(dn);
   });
 }
+// mgemm_dense_kernel alone: M[b] = R[b] Tt[b] with per-walker live rows / a / k2 (nullable), Tt stored [la][u][k2] or [la][k2][u]
+extern "C" int pepsgpu_diag_mgemm_dense(const float *R, const float *Tt, int m, int la, int a_dim, int u_dim, int k2_dim, int tt_u_inner,
+                                        int nbatch, const int32_t *m_live, const int32_t *a_live, const int32_t *k2_live, float *M_out) {
+  return guarded(nullptr, [&]() {
+    const int uk = u_dim * k2_dim;
+    float *dR, *dT, *dM;
+    int *dl[3] = {nullptr, nullptr, nullptr};
+    const int32_t *hl[3] = {m_live, a_live, k2_live};
+    PG_CHECK_HIP(hipMalloc(&dR, (size_t)m * la * nbatch * sizeof(float)));
+    PG_CHECK_HIP(hipMalloc(&dT, (size_t)la * uk * nbatch * sizeof(float)));
+    PG_CHECK_HIP(hipMalloc(&dM, (size_t)m * uk * nbatch * sizeof(float)));
+    PG_REQUIRE(mgemm_dense_ok(m, la, a_dim, u_dim, k2_dim, (long)m * la, (long)la * uk, dR, dT), 1, "shape not supported by mgemm_dense_kernel");
+    PG_CHECK_HIP(hipMemcpy(dR, R, (size_t)m * la * nbatch * sizeof(float), hipMemcpyHostToDevice));
+    PG_CHECK_HIP(hipMemcpy(dT, Tt, (size_t)la * uk * nbatch * sizeof(float), hipMemcpyHostToDevice));
+    PG_CHECK_HIP(hipMemset(dM, 0xFF, (size_t)m * uk * nbatch * sizeof(float)));      // NaN pattern: rows beyond the live count stay untouched
+    for (int q = 0; q < 3; ++q)
+      if (hl[q]) {
+        PG_CHECK_HIP(hipMalloc(&dl[q], nbatch * sizeof(int)));
+        PG_CHECK_HIP(hipMemcpy(dl[q], hl[q], nbatch * sizeof(int), hipMemcpyHostToDevice));
+      }
+    launch_mgemm_dense(0, nbatch, dR, (long)m * la, dT, (long)la * uk, dM, (long)m * uk, m, la, a_dim, u_dim, k2_dim, tt_u_inner, dl[0], 1, dl[1],
+                       dl[2], nullptr, nullptr);
+    PG_CHECK_HIP(hipDeviceSynchronize());
+    PG_CHECK_HIP(hipMemcpy(M_out, dM, (size_t)m * uk * nbatch * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(dR); (void)hipFree(dT); (void)hipFree(dM);
+    for (int q = 0; q < 3; ++q) if (dl[q]) (void)hipFree(dl[q]);
+  });
+}
 extern "C" int pepsgpu_diag_chol(int dtype_out, const double *G, int n, int nbatch, void *R_out) {
   return guarded(nullptr, [&]() {
     if (dtype_out == 0) diag_chol_t<float>(G, n, nbatch, R_out); else diag_chol_t<double>(G, n, nbatch, R_out);

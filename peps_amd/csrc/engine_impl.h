@@ -270,8 +270,10 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       R[i + 1] = alloc_ten(cols, l2, a2);
       int *ml = (int *)arena_.alloc(sizeof(int) * nw_);
       prof_begin(PROF_CHOL, nw_ * 2.0 * (2.0 * cols * (double)rows * rows - 2.0 / 3.0 * (double)rows * rows * rows), 0.0);
+      int *flist = (int *)arena_.alloc(sizeof(int) * (nw_ + 1));
       launch_gram_chol_lowrank<T, FUSED_KCAP>(stream_, nw_, (const T *)P.p, P.n, cols, (const int *)mdyn[i], mmul[i] * u, rows,
-                                              R[i + 1].p, R[i + 1].n, ml, a2, (const int *)clive[i + 1], 1, hint_dense);
+                                              R[i + 1].p, R[i + 1].n, ml, a2, (const int *)clive[i + 1], 1, hint_dense, flist);
+      arena_.free(flist);
       hipLaunchKernelGGL(adopt_rows_flagged_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)P.p, P.n, cols,
                          (const int *)mdyn[i], mmul[i] * u, rows, R[i + 1].p, R[i + 1].n, ml, a2, (const int *)clive[i + 1]);
       PG_CHECK_HIP(hipGetLastError());
@@ -309,8 +311,10 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         static const int max_pass = getenv("PEPSGPU_FUSED_PASSES") ? atoi(getenv("PEPSGPU_FUSED_PASSES")) : 4;
         const int npass = (mdyn[i] && rows > FUSED_KCAP) ? std::max(1, max_pass) : 1;
         prof_begin(PROF_CHOL, 0.0, 0.0);
+        int *flist = (int *)arena_.alloc(sizeof(int) * (nw_ + 1));
         launch_gram_chol_lowrank<T, FUSED_KCAP>(stream_, nw_, (const T *)P.p, P.n, cols, (const int *)mdyn[i], mmul[i] * u, rows,
-                                                R[i + 1].p, R[i + 1].n, ml, a2, (const int *)clive[i + 1], npass, hint_dense);
+                                                R[i + 1].p, R[i + 1].n, ml, a2, (const int *)clive[i + 1], npass, hint_dense, flist);
+        arena_.free(flist);
         prof_end();
       }
       static const bool no_gd = getenv("PEPSGPU_NO_GRAMDIRECT") != nullptr;

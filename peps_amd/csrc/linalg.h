@@ -662,20 +662,20 @@ __global__ __launch_bounds__(256) void chol_lowrank_kernel(const double *__restr
 // NT threads per walker: with a live inner extent the data columns are packed onto the first threads,
 // so the 128-thread variant (twice as many walkers resident) takes every walker with <= 128 data
 // columns and leaves mlive_out[b] = -2 for the 256-thread variant (retry_only = 1) otherwise.
-template <typename T, int KCAP, int NT, int MINW = 2, int RCAP = CH_LR_CAP>
-__global__ __launch_bounds__(NT, MINW) void gram_chol_lowrank_kernel(const T *__restrict__ Pg, long wP, int n,
+template <typename T, int KCAP, int NT, int RCAP>
+__device__ __forceinline__ void gram_chol_lowrank_body(const int walker, const T *__restrict__ Pg, long wP, int n,
                                                                 const int *__restrict__ kdyn, int kdyn_mul, int kmax,
                                                                 T *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
-                                                                int inner = 1, const int *__restrict__ inner_live = nullptr,
-                                                                int retry_only = 0, int max_pass = 1, int small_first = 0) {
+                                                                int inner, const int *__restrict__ inner_live,
+                                                                int retry_only, int max_pass, int small_first) {
   // More live rows than a thread holds (moderate rank): the rows of P are folded in over several passes INSIDE the
   // kernel -- pass 0 factors the first KCAP rows, every later pass factors [running factor (<= RCAP rows, still
   // in registers) ; next KCAP - RCAP rows of P]; up to max_pass passes, beyond that the walker is declined.
   constexpr int NWV = NT / 64;
   // retry_only: 0 every walker; 1 those a narrower launch left at -2 (more data columns than its threads); 2 those the
   // short launch (small_first: fewer rows and a smaller rank cap per thread, more walkers resident) handed on at -4
-  if (retry_only == 1 && mlive_out[blockIdx.x] != -2) return;
-  if (retry_only == 2 && mlive_out[blockIdx.x] != -4) return;
+  if (retry_only == 1 && mlive_out[walker] != -2) return;
+  if (retry_only == 2 && mlive_out[walker] != -4) return;
   // columns are (outer, inner) with `inner` fastest; inner_live[b] (optional) = live extent of the
   // inner index (live bond of the boundary MPS): columns beyond hold no data and are never read
   __shared__ __attribute__((aligned(16))) T s_pf[KCAP];   // column f of P
@@ -685,18 +685,18 @@ __global__ __launch_bounds__(NT, MINW) void gram_chol_lowrank_kernel(const T *__
   __shared__ int s_first[2][NWV];
   __shared__ short s_pos[RCAP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Ktot = kdyn ? min(kmax, kdyn[blockIdx.x] * kdyn_mul) : kmax;
+  const int Ktot = kdyn ? min(kmax, kdyn[walker] * kdyn_mul) : kmax;
   if (Ktot > KCAP + (max_pass - 1) * (KCAP - RCAP)) {     // too many rows: decline
-    if (tid == 0) mlive_out[blockIdx.x] = small_first ? -4 : -1;
+    if (tid == 0) mlive_out[walker] = small_first ? -4 : -1;
     return;
   }
-  const T *P = Pg + (long)blockIdx.x * wP;
-  T *Rout = Rg + (long)blockIdx.x * wR;
+  const T *P = Pg + (long)walker * wP;
+  T *Rout = Rg + (long)walker * wR;
   // thread -> column: data columns (inner index below its live extent) packed in increasing order
-  const int ilive = inner_live ? min(inner, inner_live[blockIdx.x]) : inner;
+  const int ilive = inner_live ? min(inner, inner_live[walker]) : inner;
   const int ncols = (n / inner) * ilive;
   if (ncols > NT) {
-    if (tid == 0) mlive_out[blockIdx.x] = -2;
+    if (tid == 0) mlive_out[walker] = -2;
     return;
   }
   const bool col_ok = tid < ncols;
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(NT, MINW) void gram_chol_lowrank_kernel(const T *__
       for (int q = 1; q < NWV; ++q) f = min(f, s_first[step & 1][q]);
       if (f == 0x7fffffff || nl >= K) { ++step; break; }   // the rank cannot exceed the K rows: later pivots are rounding noise
       if (nl == RCAP) {                 // rank above the cap: the blocked path (or the full-size launch) redoes this walker
-        if (tid == 0) mlive_out[blockIdx.x] = small_first ? -4 : -1;
+        if (tid == 0) mlive_out[walker] = small_first ? -4 : -1;
         return;
       }
       if (r == f) {                          // the owner of the pivot column publishes it
@@ -819,7 +819,7 @@ __global__ __launch_bounds__(NT, MINW) void gram_chol_lowrank_kernel(const T *__
   if (tid == 0) {
     int cnt = 0;
     for (int j = 0; j < nl; ++j) s_pos[j] = s_nrm[j] > nfloor ? (short)cnt++ : (short)-1;
-    mlive_out[blockIdx.x] = cnt;
+    mlive_out[walker] = cnt;
   }
   __syncthreads();
 #pragma unroll
@@ -828,6 +828,32 @@ __global__ __launch_bounds__(NT, MINW) void gram_chol_lowrank_kernel(const T *__
       const int pos = s_pos[j];
       if (pos >= 0 && r < n) Rout[(long)pos * n + r] = T(rc[j] * sc);
     }
+  }
+}
+
+template <typename T, int KCAP, int NT, int MINW = 2, int RCAP = CH_LR_CAP>
+__global__ __launch_bounds__(NT, MINW) void gram_chol_lowrank_kernel(const T *__restrict__ Pg, long wP, int n,
+                                                                const int *__restrict__ kdyn, int kdyn_mul, int kmax,
+                                                                T *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
+                                                                int inner = 1, const int *__restrict__ inner_live = nullptr,
+                                                                int retry_only = 0, int max_pass = 1, int small_first = 0) {
+  gram_chol_lowrank_body<T, KCAP, NT, RCAP>(blockIdx.x, Pg, wP, n, kdyn, kdyn_mul, kmax, Rg, wR, mlive_out, inner, inner_live, retry_only,
+                                            max_pass, small_first);
+}
+
+// The same kernel over a device-built LIST of walkers (list[0 .. *count)): a small grid whose blocks walk the list.  Round 3: the
+// walkers gram_chol_wave_kernel hands on (-4) are a few per launch on the headline workload; the full-grid fallback launch cost
+// 110 us per site with every block returning at once (4 % of the step).
+template <typename T, int KCAP, int NT, int MINW = 2, int RCAP = CH_LR_CAP>
+__global__ __launch_bounds__(NT, MINW) void gram_chol_lowrank_list_kernel(const T *__restrict__ Pg, long wP, int n,
+                                                                     const int *__restrict__ kdyn, int kdyn_mul, int kmax,
+                                                                     T *__restrict__ Rg, long wR, int *__restrict__ mlive_out, int inner,
+                                                                     const int *__restrict__ inner_live, int retry_only, int max_pass,
+                                                                     const int *__restrict__ list, const int *__restrict__ count) {
+  const int nl = *count;
+  for (int q = blockIdx.x; q < nl; q += gridDim.x) {
+    gram_chol_lowrank_body<T, KCAP, NT, RCAP>(list[q], Pg, wP, n, kdyn, kdyn_mul, kmax, Rg, wR, mlive_out, inner, inner_live, retry_only, max_pass, 0);
+    __syncthreads();
   }
 }
 
@@ -1015,7 +1041,8 @@ __global__ __launch_bounds__(256, 2) void gram_chol_wave_kernel(const float *__r
                                                               const int *__restrict__ kdyn, int kdyn_mul, int kmax,
                                                               float *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
                                                               int inner, const int *__restrict__ inner_live, int max_pass,
-                                                              int nbatch) {
+                                                              int nbatch, int *__restrict__ decl_list = nullptr) {
+  // decl_list (optional, nbatch + 1 ints, the count behind the list, zeroed by the caller): the walkers handed on at -4
   constexpr int KC = 64, RC = 16;
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1024,7 +1051,7 @@ __global__ __launch_bounds__(256, 2) void gram_chol_wave_kernel(const float *__r
   const int ilive = inner_live ? min(inner, inner_live[b]) : inner;
   const int ncols = (n / inner) * ilive;
   if (Ktot > KC + (max_pass - 1) * (KC - RC) || ncols > 128) {
-    if (lane == 0) mlive_out[b] = -4;
+    if (lane == 0) { mlive_out[b] = -4; if (decl_list) decl_list[atomicAdd(decl_list + nbatch, 1)] = b; }
     return;
   }
   const float *P = Pg + (long)b * wP;
@@ -1077,7 +1104,7 @@ __global__ __launch_bounds__(256, 2) void gram_chol_wave_kernel(const float *__r
       cand = wave_min_dpp(cand);
       if (cand == 0x7fffffff || nl >= K) break;         // the rank cannot exceed the K rows
       if (nl == RC) {                                   // rank above the cap: the 128-thread kernels redo this walker
-        if (lane == 0) mlive_out[b] = -4;
+        if (lane == 0) { mlive_out[b] = -4; if (decl_list) decl_list[atomicAdd(decl_list + nbatch, 1)] = b; }
         return;
       }
       f = __builtin_amdgcn_readfirstlane(cand);
@@ -1159,7 +1186,8 @@ inline void launch_colgram_chol(hipStream_t s, int nbatch, const T *P, long wP, 
 template <typename T, int KCAP>
 inline void launch_gram_chol_lowrank(hipStream_t s, int nbatch, const T *P, long wP, int n, const int *kdyn, int kdyn_mul,
                                      int kmax, T *R, long wR, int *mlive, int inner, const int *inner_live,
-                                     int max_pass = 1, bool hint_dense = false) {
+                                     int max_pass = 1, bool hint_dense = false, int *scratch_list = nullptr) {
+  // scratch_list (optional, nbatch + 1 ints of device memory): the walkers the one-wave kernel hands on go through a list kernel
   static const bool no_narrow = getenv("PEPSGPU_NO_NARROW_FUSED") != nullptr;
   const bool narrow = !no_narrow && (inner_live != nullptr || n <= 128);
   // Householder form (working precision, no rank cap): measured on the headline workload it is slower than the Gram
@@ -1198,9 +1226,18 @@ inline void launch_gram_chol_lowrank(hipStream_t s, int nbatch, const T *P, long
     bool done = false;
     if constexpr (sizeof(T) == 4) {
       if (!no_wave) {   // one wave per walker, no LDS, no barrier (gram_chol_wave_kernel)
+        static const bool no_list = getenv("PEPSGPU_NO_FACTOR_LIST") != nullptr;
+        int *dl = no_list ? nullptr : scratch_list;
+        if (dl) PG_CHECK_HIP(hipMemsetAsync(dl + nbatch, 0, sizeof(int), s));
         hipLaunchKernelGGL(gram_chol_wave_kernel, dim3((nbatch + 3) / 4), dim3(256), 0, s, (const float *)P, wP, n, kdyn, kdyn_mul, kmax,
-                           (float *)R, wR, mlive, inner, inner_live, std::max(max_pass, 2), nbatch);
+                           (float *)R, wR, mlive, inner, inner_live, std::max(max_pass, 2), nbatch, dl);
         done = true;
+        if (dl && narrow && n <= 128) {     // the handed-on walkers: list kernel, then nothing else to launch
+          hipLaunchKernelGGL((gram_chol_lowrank_list_kernel<T, KCAP, 128>), dim3(std::min(nbatch, 512)), dim3(128), 0, s, P, wP, n, kdyn,
+                             kdyn_mul, kmax, R, wR, mlive, inner, inner_live, 2, max_pass, (const int *)dl, (const int *)(dl + nbatch));
+          PG_CHECK_HIP(hipGetLastError());
+          return;
+        }
       }
     }
     if (!done)

@@ -475,3 +475,35 @@ def test_blocked_cholesky_rank_revealing_contract(n, rank):
         live = int(np.sum(np.any(R[b] != 0, axis=1)))
         # (a pivot at the rounding level of the Gram matrix may survive the threshold: at most a row or two of negligible norm)
         assert live <= min(rank + 2, n) and np.all(R[b][live:] == 0)
+
+
+@pytest.mark.parametrize("m,l,a,u,k2,tsw", [(256, 8, 32, 8, 32, 1), (241, 8, 32, 8, 32, 0), (200, 8, 32, 8, 28, 1), (160, 8, 24, 8, 32, 1),
+                                             (256, 6, 24, 6, 32, 0)])
+def test_mgemm_dense_kernel(m, l, a, u, k2, tsw):
+    """mgemm_dense_kernel (round 3): M = R Tt of dense walkers against NumPy -- live carry rows, live a (rows of Tt beyond it are
+    garbage by contract: NaN here), live k2 (columns of M beyond it come back as zeros), both storage orders of Tt."""
+    capi = _capi()
+    la, uk = l * a, u * k2
+    if la % 16 or uk % 32:
+        pytest.skip("shape outside the kernel's contract")
+    rng = np.random.default_rng(m + la + uk + tsw)
+    nb = 4
+    R = rng.standard_normal((nb, m, l, a)).astype(np.float32)
+    T = rng.standard_normal((nb, l, a, u, k2)).astype(np.float32)
+    m_live = np.array([m, max(1, m - 17), 129, m], dtype=np.int32)
+    a_live = np.array([a, a - 3, a, max(1, a // 2)], dtype=np.int32)
+    k_live = np.array([k2, k2, max(1, k2 - 5), k2 // 2], dtype=np.int32)
+    Tdev = T.copy()
+    for b in range(nb):
+        Tdev[b, :, a_live[b]:] = np.nan                      # never written by the producer: must not be read
+    Tstore = np.transpose(Tdev, (0, 1, 2, 4, 3)) if tsw else Tdev
+    M = capi.diag_mgemm_dense(R.reshape(nb, m, la), Tstore.reshape(nb, la, uk), a, u, k2, tsw, m_live, a_live, k_live)
+    for b in range(nb):
+        ref = np.einsum("mla,lauk->muk", R[b, :, :, :a_live[b]].astype(np.float64), T[b, :, :a_live[b]].astype(np.float64))
+        ref[:, :, k_live[b]:] = 0.0
+        got = M[b].reshape(m, u, k2)
+        assert np.all(np.isfinite(got[:m_live[b]]))
+        assert np.max(np.abs(got[:m_live[b]] - ref[:m_live[b]])) < 2e-5 * np.max(np.abs(ref))
+        assert np.all(got[:m_live[b], :, k_live[b]:] == 0)
+        if m_live[b] < m:
+            assert np.all(np.isnan(got[m_live[b]:]))         # rows beyond the live count: untouched
