@@ -256,6 +256,11 @@ int pepsgpu_diag_gram_cols(int dtype, const void *P, int K, int n, int nbatch, c
 int pepsgpu_diag_gram_rows(const float *M, int n, int K, int nbatch, const int32_t *nrows, double *G_out);
 int pepsgpu_diag_mgemm_dense(const float *R, const float *Tt, int m, int la, int a_dim, int u_dim, int k2_dim, int tt_u_inner, int nbatch,
                              const int32_t *m_live, const int32_t *a_live, const int32_t *k2_live, float *M_out);
+/* diagnostics (PEPSGPU_CG_STATS=1): per-phase counters of colgram_dense_kernel, read and reset; see trunc_mid.h */
+int pepsgpu_diag_cg_stats(double *out16);
+/* the LDS-resident Gram + Cholesky kernels alone (f32): which = 0 rows form (X = [nbatch][n][K], R^T R = X X^T, nlive = live rows),
+ * which = 1 column form (X = [nbatch][K][n], R^T R = X^T X, nlive = live rows of X); R_out = [nbatch][n][n], n <= 128 */
+int pepsgpu_diag_lds_gram_chol(int which, const float *X, int n, int K, int nbatch, const int32_t *nlive, float *R_out, int32_t *mlive_out);
 /* the rank-adaptive pair used by the absorption: low-rank right-looking kernel, then the blocked
  * kernel for the walkers whose rank exceeds its cap; mlive_out[b] = rows of R_out[b] that exist */
 /* the Gram-free low-rank kernel alone: P = [nbatch][K][n] (dtype), R^T R = P^T P; mlive_out[b] = -1 where

@@ -557,6 +557,23 @@ def diag_gram_rows(M, nrows):
     return G
 
 
+def diag_lds_gram_chol(which, X, nlive):
+    """mid_gram_chol_kernel (which = 0: X [nb][n][K], R^T R = X X^T over the nlive[b] first rows) or colgram_dense_kernel (which = 1:
+    X [nb][K][n], R^T R = X^T X over the nlive[b] first rows) alone; returns (R [nb][n][n] float32 -- rows beyond mlive are NaN --, mlive)."""
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    nb = X.shape[0]
+    n, K = (X.shape[1], X.shape[2]) if which == 0 else (X.shape[2], X.shape[1])
+    R = np.zeros((nb, n, n), dtype=np.float32)
+    ml = np.zeros(nb, dtype=np.int32)
+    nl = np.ascontiguousarray(nlive, dtype=np.int32)
+    f = lib().pepsgpu_diag_lds_gram_chol
+    f.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32)]
+    rc = f(which, X.ctypes.data_as(C.c_void_p), n, K, nb, _ip(nl), R.ctypes.data_as(C.c_void_p), _ip(ml))
+    if rc != 0:
+        raise RuntimeError("diag_lds_gram_chol failed: %s" % lib().pepsgpu_last_error(None).decode())
+    return R, ml
+
+
 def diag_mgemm_dense(R, Tt, a_dim, u_dim, k2_dim, tt_u_inner, m_live=None, a_live=None, k2_live=None):
     """mgemm_dense_kernel alone: R [nb][m][la], Tt [nb][la][u * k2] (inner order (u, k2), or (k2, u) with tt_u_inner) -> M [nb][m][u * k2]
     (rows beyond m_live[b] come back as NaN: untouched)."""

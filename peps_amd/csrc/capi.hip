@@ -508,6 +508,47 @@ extern "C" int pepsgpu_diag_mgemm_dense(const float *R, const float *Tt, int m, 
     for (int q = 0; q < 3; ++q) if (dl[q]) (void)hipFree(dl[q]);
   });
 }
+// PEPSGPU_CG_STATS=1: read and reset the per-phase counters of colgram_dense_kernel (trunc_mid.h: cg_stats_dev), launches of >= 1024 walkers
+extern "C" int pepsgpu_diag_cg_stats(double *out16) {
+  return guarded(nullptr, [&]() {
+    unsigned long long h[16] = {0};
+    unsigned long long *d = cg_stats_dev();
+    if (d) {
+      PG_CHECK_HIP(hipDeviceSynchronize());
+      PG_CHECK_HIP(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+      PG_CHECK_HIP(hipMemset(d, 0, sizeof(h)));
+    }
+    for (int i = 0; i < 16; ++i) out16[i] = (double)h[i];
+  });
+}
+// The two LDS-resident Gram + Cholesky kernels alone (trunc_mid.h), f32:
+//   which = 0: mid_gram_chol_kernel    X = [nbatch][n][K]  (rows of M),   R^T R = X X^T  (n x n),  nlive[b] = live rows of X
+//   which = 1: colgram_dense_kernel    X = [nbatch][K][n]  (rows of P),   R^T R = X^T X  (n x n),  nlive[b] = live rows of X (<= K)
+// R_out = [nbatch][n][n] (rows beyond mlive_out[b] untouched = NaN pattern), mlive_out[b] = rows of the factor.
+extern "C" int pepsgpu_diag_lds_gram_chol(int which, const float *X, int n, int K, int nbatch, const int32_t *nlive, float *R_out,
+                                          int32_t *mlive_out) {
+  return guarded(nullptr, [&]() {
+    PG_REQUIRE((which == 0 || which == 1) && n >= 1 && n <= 128 && K >= 1 && nbatch >= 1 && nlive, 1, "bad sizes");
+    float *dX, *dR; int *dn, *dm;
+    const size_t ne = (size_t)n * K * nbatch, nr = (size_t)n * n * nbatch;
+    PG_CHECK_HIP(hipMalloc(&dX, ne * sizeof(float)));
+    PG_CHECK_HIP(hipMalloc(&dR, nr * sizeof(float)));
+    PG_CHECK_HIP(hipMalloc(&dn, nbatch * sizeof(int)));
+    PG_CHECK_HIP(hipMalloc(&dm, nbatch * sizeof(int)));
+    PG_CHECK_HIP(hipMemcpy(dX, X, ne * sizeof(float), hipMemcpyHostToDevice));
+    PG_CHECK_HIP(hipMemcpy(dn, nlive, nbatch * sizeof(int), hipMemcpyHostToDevice));
+    PG_CHECK_HIP(hipMemset(dR, 0xFF, nr * sizeof(float)));
+    PG_CHECK_HIP(hipMemset(dm, 0xFF, nbatch * sizeof(int)));
+    if (which == 0)
+      launch_mid_gram_chol<float>(0, nbatch, dX, (long)n * K, K, dn, nullptr, n, dR, (long)n * n, dm);
+    else
+      launch_colgram_chol<float>(0, nbatch, dX, (long)n * K, n, dn, 1, K, dR, (long)n * n, dm, 1, nullptr, -4, true);
+    PG_CHECK_HIP(hipDeviceSynchronize());
+    PG_CHECK_HIP(hipMemcpy(R_out, dR, nr * sizeof(float), hipMemcpyDeviceToHost));
+    PG_CHECK_HIP(hipMemcpy(mlive_out, dm, nbatch * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(dX); (void)hipFree(dR); (void)hipFree(dn); (void)hipFree(dm);
+  });
+}
 extern "C" int pepsgpu_diag_chol(int dtype_out, const double *G, int n, int nbatch, void *R_out) {
   return guarded(nullptr, [&]() {
     if (dtype_out == 0) diag_chol_t<float>(G, n, nbatch, R_out); else diag_chol_t<double>(G, n, nbatch, R_out);

@@ -23,6 +23,7 @@ constexpr int TM_LDM = TM_KC + 2;   // row pitch of the chunk: 16 rows x 2 k-lan
 // One staged chunk (TM_KC columns of the k index) of G += X X^T for the NQ tiles of this wave: per k-step of four, the 2 NQ
 // operand reads are issued together, then the NQ MFMAs -- branch free (rows of the chunk beyond the matrix are zero filled
 // once), so the LDS latency is paid once per k-step and not once per MFMA.  offa / offb = LDS offset of the tile's row.
+constexpr int TM_PF = 1;                                 // chunks of the Gram operand in flight (registers; 3 measured: no gain, spills in the rows form)
 constexpr int TM_TPW = 9;                                // 36 tiles (order 128) / 4 waves
 template <int NQ>
 __device__ __forceinline__ void tm_gram_chunk(tm_f64x4 (&acc)[TM_TPW], const float *__restrict__ sX, const int (&offa)[TM_TPW],
@@ -55,6 +56,192 @@ __device__ __forceinline__ void tm_gram_chunk_n(const int nq, tm_f64x4 (&acc)[TM
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Upper Cholesky of a symmetric n x n matrix whose upper triangle lives in LDS (element (i, c >= i) at sG[at(i, c)]), in place,
+// blocked in panels of 16 rows (round 3; before: one barrier, and one LDS read-modify-write round trip of the trailing rows,
+// per PIVOT -- ~1 us per pivot with two blocks on a CU, 128 us of a 128-column factor that holds 1.3 Mflop):
+//   A. the 16 x 16 diagonal block is factored by wave 0 in registers: lane c holds column c, the pivot row travels by
+//      v_readlane (no barrier inside the block); a pivot at or below `thresh`, or beyond the `kcap` live rows the data can
+//      have, drops its row (zeros);
+//   B. the rest of the block row is a forward substitution, one thread per column, the block's factor read as LDS broadcasts;
+//   C. the trailing triangle takes the whole panel at once, G[i][r] -= sum_p U[p][i] U[p][r], as 16 x 16 tiles of
+//      v_mfma_f64_16x16x4_f64 (four per tile) dealt round-robin to the four waves, operands straight from the LDS-resident rows.
+// Three barriers per panel.  Rows come out SCALED (row j of the factor itself, R^T R = G); sList[0 .. return value) = the live
+// rows in order.  Ends with a barrier.  256 threads.
+struct LdsAtPitch {
+  int ld;
+  __device__ __forceinline__ int operator()(int i, int c) const { return i * ld + c; }
+};
+template <typename At>
+__device__ __forceinline__ int lds_chol_blocked(double *__restrict__ sG, const At at, const int n, const double thresh, const int kcap,
+                                                short *__restrict__ sList, unsigned long long *__restrict__ stats = nullptr,
+                                                const int serial_wave = 0) {
+  __shared__ double sD[16][17], sDinv[16];
+  unsigned long long tA = 0, tB = 0, tC = 0, t0 = 0;
+  __shared__ unsigned s_livemask;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, k4 = lane >> 4;
+  int nl = 0;
+  // the serial part runs in ONE wave: not the same wave (= SIMD) in the blocks that share a CU
+  const int aw = serial_wave;
+  for (int jb = 0; jb < n; jb += 16) {
+    const int nb = min(16, n - jb);
+    if (stats) t0 = wall_clock64();
+    if (wave == aw) {
+      double d[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) d[c] = (lane < nb && c <= lane) ? sG[at(jb + c, jb + lane)] : 0.0;
+      unsigned livemask = 0;
+      int cnt = nl;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double piv = chb_readlane(d[c], c);
+        const bool live = c < nb && piv > thresh && cnt < kcap;   // wave-uniform
+        if (live) {
+          double sc = __builtin_amdgcn_rsq(piv);                  // ~2^-26 relative; two Newton steps -> float64
+          sc = sc * (1.5 - 0.5 * piv * sc * sc);
+          sc = sc * (1.5 - 0.5 * piv * sc * sc);
+          d[c] *= sc;
+#pragma unroll
+          for (int c2 = c + 1; c2 < 16; ++c2) {
+            const double f = chb_readlane(d[c], c2);
+            d[c2] -= f * d[c];
+          }
+          livemask |= 1u << c;
+          ++cnt;
+        } else {
+          d[c] = 0.0;
+        }
+      }
+      if (lane < 16) {
+        double dg = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          sD[c][lane] = lane >= c ? d[c] : 0.0;
+          if (lane < nb && c <= lane) sG[at(jb + c, jb + lane)] = d[c];
+          dg = lane == c ? d[c] : dg;
+        }
+        double iv = __builtin_amdgcn_rcp(dg);
+        iv = iv * (2.0 - dg * iv);
+        iv = iv * (2.0 - dg * iv);
+        const bool mine = (livemask >> lane) & 1u;
+        sDinv[lane] = mine ? iv : 0.0;
+        if (mine) sList[nl + __popc(livemask & ((1u << lane) - 1u))] = (short)(jb + lane);
+      }
+      if (lane == 0) s_livemask = livemask;
+    }
+    __syncthreads();
+    if (stats) { const unsigned long long t1 = wall_clock64(); tA += t1 - t0; t0 = t1; }
+    nl += __popc(s_livemask);
+    if (jb + 16 >= n) break;                             // (block-uniform) the last panel has no columns to its right
+    {
+      // columns to the right of the block, a quarter to each wave (a latency chain per thread: spread over the SIMDs)
+      const int Wd = n - jb - 16, chunk = (Wd + 3) >> 2;
+      const int r = jb + 16 + wave * chunk + lane;
+      if (lane < chunk && r < n) {
+        double x[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          double v = sG[at(jb + c, r)];
+#pragma unroll
+          for (int c1 = 0; c1 < c; ++c1) v -= sD[c1][c] * x[c1];
+          x[c] = v * sDinv[c];                           // dropped row: sDinv = 0
+          sG[at(jb + c, r)] = x[c];
+          __asm__ volatile("" ::: "memory");             // keep the factor reads of the later rows from being hoisted (136 doubles)
+        }
+      }
+    }
+    __syncthreads();
+    if (stats) { const unsigned long long t1 = wall_clock64(); tB += t1 - t0; t0 = t1; }
+    {
+      const int c0 = jb + 16;
+      const int nt = (n - c0 + 15) >> 4, ntl = nt * (nt + 1) / 2;
+      for (int t = wave; t < ntl; t += 4) {
+        int tt = t, ti = 0;
+        while (tt >= nt - ti) { tt -= nt - ti; ++ti; }
+        const int tj = ti + tt;
+        const int ca = min(c0 + 16 * ti + i16, n - 1), cb = min(c0 + 16 * tj + i16, n - 1);   // clamped: lands in entries not written
+        chb_f64x4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = 0.0;
+        double a[4], bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[q] = sG[at(jb + 4 * q + k4, ca)]; bq[q] = sG[at(jb + 4 * q + k4, cb)]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bq[q], acc, 0, 0, 0);
+        const int j = c0 + 16 * tj + i16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                     // acc[r] = C[k4 + 4 r][i16] of the tile
+          const int i = c0 + 16 * ti + k4 + 4 * r;
+          if (j >= i && j < n) sG[at(i, j)] -= acc[r];
+        }
+      }
+    }
+    __syncthreads();
+    if (stats) { const unsigned long long t1 = wall_clock64(); tC += t1 - t0; t0 = t1; }
+  }
+  __syncthreads();
+  if (stats && tid == 0) { atomicAdd(stats + 7, tA); atomicAdd(stats + 8, tB); atomicAdd(stats + 9, tC); }
+  return nl;
+}
+
+
+// Tail of the LDS-resident factorisations (scaled rows, lds_chol_blocked): squared norms of the nl live rows, the noise floor
+// NOISE_C eps_T |R|_F, output positions of the rows above it (sPos[q], -1 = dropped) by ballot in wave 0.  Returns the count
+// (every thread); ends with a barrier.
+template <typename At>
+__device__ __forceinline__ int lds_chol_compact(const double *__restrict__ sG, const At at, const int n, const int nl,
+                                                const short *__restrict__ sList, double *__restrict__ sNrm, short *__restrict__ sPos,
+                                                const double eT) {
+  __shared__ int s_cnt_out;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int q = wave; q < nl; q += 4) {
+    const int j = sList[q];
+    double a = 0.0;
+    for (int r = j + lane; r < n; r += 64) { const double x = sG[at(j, r)]; a += x * x; }
+    a = wave_sum(a);
+    if (lane == 0) sNrm[q] = a;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double f = 0.0;
+    for (int q = lane; q < nl; q += 64) f += sNrm[q];
+    f = wave_sum(f);
+    const double nfloor = eT * eT * f;
+    int cnt = 0;
+    for (int base = 0; base < nl; base += 64) {
+      const int q = base + lane;
+      const bool keep = q < nl && sNrm[q] > nfloor;
+      const unsigned long long mask = __ballot(keep);
+      if (q < nl) sPos[q] = keep ? (short)(cnt + __popcll(mask & ((1ull << lane) - 1ull))) : (short)-1;
+      cnt += __popcll(mask);
+    }
+    if (lane == 0) s_cnt_out = cnt;
+  }
+  __syncthreads();
+  return s_cnt_out;
+}
+
+// PEPSGPU_CG_STATS=1 (diagnostics): per-phase time of colgram_dense_kernel, summed over its blocks in a device buffer of 16 counters
+// ([0] blocks, [1] sum K, [2] sum live columns, [3..5] 10-ns ticks of the Gram / Cholesky / output phase, [6] sum live rows out)
+inline unsigned long long *cg_stats_dev() {
+  static unsigned long long *p = []() -> unsigned long long * {
+    if (!getenv("PEPSGPU_CG_STATS")) return nullptr;
+    unsigned long long *q = nullptr;
+    if (hipMalloc(&q, 16 * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+    (void)hipMemset(q, 0, 16 * sizeof(unsigned long long));
+    return q;
+  }();
+  return p;
+}
+
+// PEPSGPU_OLD_LDS_CHOL=1: the pivot-by-pivot forms of the LDS-resident factorisations (A/B runs)
+inline bool lds_chol_blocked_on() {
+  static const bool off = getenv("PEPSGPU_OLD_LDS_CHOL") != nullptr;
+  return !off;
+}
+
 inline size_t mid_gram_chol_smem_bytes(int cap) {
   const size_t capr = ((size_t)cap + 15) & ~(size_t)15;      // the staging buffer covers whole 16-row tiles
   return sizeof(double) * ((size_t)cap * (cap + 1) + 2 * (size_t)cap) + sizeof(float) * capr * TM_LDM + sizeof(short) * 2 * (size_t)cap + 64;
@@ -67,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void mid_gram_chol_kernel(const T *__restri
                                                             const int *__restrict__ run_flag, int lo, int cap,
                                                             T *__restrict__ Bg, long wB, int ld, int *__restrict__ mB,
                                                             unsigned long long *__restrict__ flopc, unsigned long long *__restrict__ bytec,
-                                                            int flop_stride) {
+                                                            int flop_stride, int blocked) {
   static_assert(sizeof(T) == 4, "the mid route is f32 only (the f64 mode keeps the direct Jacobi)");
   const int b = blockIdx.x;
   if (run_flag && run_flag[b] >= 0) return;
@@ -115,27 +302,35 @@ __global__ __launch_bounds__(256, 2) void mid_gram_chol_kernel(const T *__restri
   for (int e = tid + n * TM_LDM; e < 16 * nt * TM_LDM; e += 256) sM[e] = 0.f;
   // 32 columns x up to 128 rows = 16 elements per thread: unconditional loads (clamped address); the chunk after the one being
   // multiplied is in flight during its MFMAs (registers v), stored once the waves have left the staging buffer
-  float v[16];
-  auto issue = [&](const int kc) {
+  constexpr int PF = TM_PF;
+  float v[PF][16];
+  auto issue = [&](const int kc, float (&vv)[16]) {
     const int kw = min(TM_KC, uk - kc);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int e = tid + 256 * i, r = min(e >> 5, n - 1), c = min(e & 31, kw - 1);
-      v[i] = (float)M[(long)r * uk + kc + c];
+      vv[i] = (float)M[(long)r * uk + kc + c];
     }
   };
-  if (uk > 0) issue(0);
-  for (int kc = 0; kc < uk; kc += TM_KC) {
-    const int kw = min(TM_KC, uk - kc);
-    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int e = tid + 256 * i, r = e >> 5, c = e & 31;
-      if (r < n) sM[r * TM_LDM + c] = c < kw ? v[i] : 0.f;
+  for (int p = 0; p < PF; ++p)
+    if (p * TM_KC < uk) issue(p * TM_KC, v[p]);
+  for (int kb = 0; kb < uk; kb += PF * TM_KC) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const int kc = kb + p * TM_KC;
+      if (kc >= uk) break;                                 // (block-uniform)
+      const int kw = min(TM_KC, uk - kc);
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int e = tid + 256 * i, r = e >> 5, c = e & 31;
+        if (r < n) sM[r * TM_LDM + c] = c < kw ? v[p][i] : 0.f;
+      }
+      __syncthreads();
+      if (kc + PF * TM_KC < uk) issue(kc + PF * TM_KC, v[p]);
+      tm_gram_chunk_n(nq, acc, sM, offa, offb, k4);
     }
-    __syncthreads();
-    if (kc + TM_KC < uk) issue(kc + TM_KC);
-    tm_gram_chunk_n(nq, acc, sM, offa, offb, k4);
   }
   __syncthreads();
 #pragma unroll
@@ -162,6 +357,10 @@ __global__ __launch_bounds__(256, 2) void mid_gram_chol_kernel(const T *__restri
   const double maxd = s_maxd;
   const double eT = NOISE_C * (double)Eps<T>::v;
   const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
+  int nl;
+  if (blocked) {      // panels of 16 rows, MFMA trailing update, rows come out scaled (lds_chol_blocked)
+    nl = lds_chol_blocked(sG, LdsAtPitch{ldG}, n, thresh, n, sList, nullptr, (int)(((unsigned)b >> 3) + ((unsigned)b >> 8)) & 3);
+  } else {
   for (int j = 0; j < n; ++j) {
     const double piv = sG[j * ldG + j];                  // every thread reads the same, settled value
     if (!(piv > thresh)) {                               // dead direction: its row takes no part (block-uniform branch)
@@ -179,7 +378,21 @@ __global__ __launch_bounds__(256, 2) void mid_gram_chol_kernel(const T *__restri
     __syncthreads();
   }
   __syncthreads();
-  const int nl = s_nl;
+  nl = s_nl;
+  }
+  if (blocked) {
+    const int cnt = lds_chol_compact(sG, LdsAtPitch{ldG}, n, nl, sList, sNrm, sPos, eT);
+    if (tid == 0) mB[b] = cnt;
+    const double sc = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
+    for (int q = wave; q < nl; q += 4) {
+      const int pos = sPos[q];
+      if (pos < 0) continue;
+      const int j = sList[q];
+      // the Jacobi reads whole rows of the ld-wide buffer: columns outside [j, n) are written as zeros
+      for (int r = lane; r < ld; r += 64) B[(long)pos * ld + r] = (r >= j && r < n) ? T(sG[j * ldG + r] * sc) : T(0);
+    }
+    return;
+  }
   // ---- rank compaction (rows with norm below NOISE_C eps_T |B|_F are dropped), as chol_upper_kernel ----
   for (int q = wave; q < nl; q += 4) {
     const int j = sList[q];
@@ -222,7 +435,7 @@ inline void launch_mid_gram_chol(hipStream_t s, int nbatch, const T *M, long wM,
     const size_t smem = mid_gram_chol_smem_bytes(cap);
     allow_dynamic_lds(reinterpret_cast<const void *>(&mid_gram_chol_kernel<T>), smem);
     hipLaunchKernelGGL(mid_gram_chol_kernel<T>, dim3(nbatch), dim3(256), smem, s, M, wM, uk, nrows, run_flag, lo, cap, B, wB, GS, mB,
-                       tg_flop_counter, tg_byte_counter, nbatch >= 256 ? 64 : 1);
+                       tg_flop_counter, tg_byte_counter, nbatch >= 256 ? 64 : 1, lds_chol_blocked_on() ? 1 : 0);
     PG_CHECK_HIP(hipGetLastError());
     lo = cap;
   }
@@ -255,6 +468,9 @@ constexpr int CG_NC = 128;           // live columns at most
 // 88 rows x 128 columns: 59 KB instead of the 91 KB of the rectangle -- two blocks per CU instead of one (the kernel is
 // a chain of barriers and dependent LDS round trips per pivot: a second block is what fills the CU).
 __host__ __device__ inline int cg_row(int j) { return j * (CG_NC - 1) - (j * (j - 1)) / 2; }
+struct CgAtPacked {
+  __device__ __forceinline__ int operator()(int i, int c) const { return cg_row(i) + c; }
+};
 
 inline size_t colgram_chol_smem_bytes(int rcap) {
   return sizeof(double) * ((size_t)rcap * CG_NC - (size_t)rcap * (rcap - 1) / 2 + CG_NC) + sizeof(float) * (size_t)CG_NC * TM_LDM + 64;
@@ -272,9 +488,11 @@ __global__ __launch_bounds__(256, 2) void colgram_dense_kernel(const T *__restri
                                                             int *__restrict__ mlive_out, int inner,
                                                             const int *__restrict__ inner_live, int decline_code,
                                                             unsigned long long *__restrict__ flopc,
-                                                            unsigned long long *__restrict__ bytec, int flop_stride) {
+                                                            unsigned long long *__restrict__ bytec, int flop_stride, int blocked,
+                                                            unsigned long long *__restrict__ stats) {
   static_assert(sizeof(T) == 4, "f32 element type");
   const int b = blockIdx.x;
+  const unsigned long long t_0 = stats ? wall_clock64() : 0ull;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = kdyn ? min(kmax, kdyn[b] * kdyn_mul) : kmax;
   const int ilive = inner_live ? min(inner, inner_live[b]) : inner;
@@ -324,31 +542,46 @@ __global__ __launch_bounds__(256, 2) void colgram_dense_kernel(const T *__restri
   for (int e = tid + ncols * TM_LDM; e < CG_NC * TM_LDM; e += 256) sP[e] = 0.f;
   // unconditional loads (clamped row), 16 per thread and chunk; the chunk after the one being multiplied is in flight during
   // its MFMAs (two blocks per CU: little else hides the latency of the loads)
-  float v[TM_KC / 2];
-  auto issue = [&](const int k0) {
+  // (TM_PF chunks in flight; three measured on the full-rank state: 40.9 us against 39.1 us per block -- the loads are not what
+  // the phase waits for)
+  constexpr int PF = TM_PF;
+  unsigned long long t_stage = 0, t_mfma = 0;
+  float v[PF][TM_KC / 2];
+  auto issue = [&](const int k0, float (&vv)[TM_KC / 2]) {
     const int kw = min(TM_KC, K - k0);
 #pragma unroll
     for (int i = 0; i < TM_KC / 2; ++i) {
       const int k = min((tid >> 7) + 2 * i, kw - 1);
-      v[i] = (float)P[(long)(k0 + k) * n + st_r];
+      vv[i] = (float)P[(long)(k0 + k) * n + st_r];
     }
   };
-  if (K > 0 && st_r >= 0) issue(0);
-  for (int k0 = 0; k0 < K; k0 += TM_KC) {
-    const int kw = min(TM_KC, K - k0);
-    __syncthreads();
-    if (st_r >= 0) {
 #pragma unroll
-      for (int i = 0; i < TM_KC / 2; ++i) {
-        const int k = (tid >> 7) + 2 * i;
-        sP[st_c * TM_LDM + k] = k < kw ? v[i] : 0.f;
+  for (int p = 0; p < PF; ++p)
+    if (p * TM_KC < K && st_r >= 0) issue(p * TM_KC, v[p]);
+  for (int kb = 0; kb < K; kb += PF * TM_KC) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const int k0 = kb + p * TM_KC;
+      if (k0 >= K) break;                                  // (block-uniform)
+      const int kw = min(TM_KC, K - k0);
+      const unsigned long long tg0 = stats ? wall_clock64() : 0ull;
+      __syncthreads();
+      if (st_r >= 0) {
+#pragma unroll
+        for (int i = 0; i < TM_KC / 2; ++i) {
+          const int k = (tid >> 7) + 2 * i;
+          sP[st_c * TM_LDM + k] = k < kw ? v[p][i] : 0.f;
+        }
       }
+      __syncthreads();
+      const unsigned long long tg1 = stats ? wall_clock64() : 0ull;
+      if (k0 + PF * TM_KC < K && st_r >= 0) issue(k0 + PF * TM_KC, v[p]);
+      tm_gram_chunk_n(nq, acc, sP, offa, offb, k4);
+      if (stats) { t_stage += tg1 - tg0; t_mfma += wall_clock64() - tg1; }
     }
-    __syncthreads();
-    if (k0 + TM_KC < K && st_r >= 0) issue(k0 + TM_KC);
-    tm_gram_chunk_n(nq, acc, sP, offa, offb, k4);
   }
   __syncthreads();                                         // the staging buffer is dead: G takes its place
+  const unsigned long long t_1 = stats ? wall_clock64() : 0ull;
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
     if (ti[q] < 0) continue;
@@ -378,13 +611,16 @@ __global__ __launch_bounds__(256, 2) void colgram_dense_kernel(const T *__restri
   // i = ta (mod 16), r = tb (mod 16) of the upper triangle (up to 36 accumulators in registers), reads 16 values of U per
   // panel row and touches each of its elements of G once per PANEL -- the unblocked form read and wrote every trailing element
   // once per PIVOT and paid a barrier for it (2.4 k cycles per pivot on the dense sites).
+  int nlv = 0;
+  if (blocked) {      // panels of 16 rows, MFMA trailing update, rows come out scaled (lds_chol_blocked)
+    nlv = lds_chol_blocked(sG, CgAtPacked{}, ncols, thresh, K, sList, stats, (int)(((unsigned)b >> 3) + ((unsigned)b >> 8)) & 3);
+  } else {
   __shared__ double s_invp[16];
   const int ta = tid >> 4, tb = tid & 15;
   int rowb[CG_NC / 16];
 #pragma unroll
   for (int ii = 0; ii < CG_NC / 16; ++ii) rowb[ii] = cg_row(16 * ii + ta);
   const int nblk = (ncols + 15) >> 4;
-  int nlv = 0;
   for (int kb = 0; kb < nblk; ++kb) {
     const int j0 = 16 * kb, j1 = min(j0 + 16, ncols);
     for (int j = j0; j < j1; ++j) {
@@ -445,7 +681,32 @@ __global__ __launch_bounds__(256, 2) void colgram_dense_kernel(const T *__restri
     __syncthreads();
   }
   __syncthreads();
+  }
   const int nl = nlv;
+  const unsigned long long t_2 = stats ? wall_clock64() : 0ull;
+  if (blocked) {
+    // ---- rank compaction and output (rows are scaled already) ----
+    const int cnt = lds_chol_compact(sG, CgAtPacked{}, ncols, nl, sList, sNrm, sPos, eT);
+    if (tid == 0) mlive_out[b] = cnt;
+    const double sc = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
+    const int c0 = lane, c1 = lane + 64;                     // packed columns of this lane -> columns of P (once)
+    const int rc0 = (c0 / ilive) * inner + (c0 % ilive), rc1 = (c1 / ilive) * inner + (c1 % ilive);
+    for (int q = wave; q < nl; q += 4) {
+      const int pos = sPos[q];
+      if (pos < 0) continue;
+      const int j = sList[q], rj = cg_row(j);
+      T *row = Rout + (long)pos * n;
+      if (c0 < ncols) row[rc0] = c0 >= j ? T(sG[rj + c0] * sc) : T(0);
+      if (c1 < ncols) row[rc1] = c1 >= j ? T(sG[rj + c1] * sc) : T(0);
+    }
+    if (stats && tid == 0) {
+      const unsigned long long t_3 = wall_clock64();
+      atomicAdd(stats + 0, 1ull); atomicAdd(stats + 1, (unsigned long long)K); atomicAdd(stats + 2, (unsigned long long)ncols);
+      atomicAdd(stats + 3, t_1 - t_0); atomicAdd(stats + 4, t_2 - t_1); atomicAdd(stats + 5, t_3 - t_2);
+      atomicAdd(stats + 6, (unsigned long long)nl); atomicAdd(stats + 10, t_stage); atomicAdd(stats + 11, t_mfma);
+    }
+    return;
+  }
   // ---- rank compaction (rows with norm below NOISE_C eps_T |R|_F are dropped) and output ----
   for (int q = wave; q < nl; q += 4) {
     const int j = sList[q], rj = cg_row(j);
@@ -474,6 +735,12 @@ __global__ __launch_bounds__(256, 2) void colgram_dense_kernel(const T *__restri
       const int rc = (c / ilive) * inner + (c % ilive);    // packed column -> column of P
       Rout[(long)pos * n + rc] = c >= j ? T(sG[rj + c] * f) : T(0);
     }
+  }
+  if (stats && tid == 0) {
+    const unsigned long long t_3 = wall_clock64();
+    atomicAdd(stats + 0, 1ull); atomicAdd(stats + 1, (unsigned long long)K); atomicAdd(stats + 2, (unsigned long long)ncols);
+    atomicAdd(stats + 3, t_1 - t_0); atomicAdd(stats + 4, t_2 - t_1); atomicAdd(stats + 5, t_3 - t_2);
+    atomicAdd(stats + 6, (unsigned long long)nl);
   }
 }
 
@@ -668,7 +935,8 @@ inline void launch_colgram_chol(hipStream_t s, int nbatch, const T *P, long wP, 
     const size_t smd = sizeof(double) * ((size_t)CG_NC * (CG_NC + 1) / 2 + 2 * CG_NC) + sizeof(short) * 2 * CG_NC + 64;
     allow_dynamic_lds(reinterpret_cast<const void *>(&colgram_dense_kernel<T>), smd);
     hipLaunchKernelGGL(colgram_dense_kernel<T>, dim3(nbatch), dim3(256), smd, s, P, wP, n, kdyn, kdyn_mul, kmax, R, wR, mlive, inner,
-                       inner_live, decline_code, tg_flop_counter, tg_byte_counter, nbatch >= 256 ? 64 : 1);
+                       inner_live, decline_code, tg_flop_counter, tg_byte_counter, nbatch >= 256 ? 64 : 1, lds_chol_blocked_on() ? 1 : 0,
+                       nbatch >= 1024 ? cg_stats_dev() : nullptr);
     PG_CHECK_HIP(hipGetLastError());
     return;
   }

@@ -477,6 +477,75 @@ def test_blocked_cholesky_rank_revealing_contract(n, rank):
         assert live <= min(rank + 2, n) and np.all(R[b][live:] == 0)
 
 
+LDS_CHOL_CASES = [(128, 256, 128), (128, 200, 70), (100, 256, 100), (80, 96, 80), (72, 256, 31), (49, 64, 49), (33, 64, 12), (16, 32, 16),
+                  (9, 32, 9)]
+
+
+@pytest.mark.parametrize("which", [0, 1])
+@pytest.mark.parametrize("n,K,rank", LDS_CHOL_CASES)
+def test_lds_gram_cholesky_kernels(which, n, K, rank):
+    """mid_gram_chol_kernel (rows form, G = X X^T) and colgram_dense_kernel (column form, G = X^T X): Gram on the f64 matrix cores
+    + the LDS-resident Cholesky -- round 3: blocked in panels of 16 (diagonal block in one wave's registers, forward substitution,
+    MFMA trailing update).  Contract: R^T R = G / max diag up to the f32 floor, live rows compacted, a dependent direction
+    dropped; mixed live counts in one launch."""
+    _lds_gram_chol_case(which, n, K, rank)
+
+
+def test_lds_gram_cholesky_kernels_pivot_by_pivot_form():
+    """the same cases through the round-2 form of the two kernels (PEPSGPU_OLD_LDS_CHOL=1, read once per process: child process)"""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r); os.environ['PEPSGPU_OLD_LDS_CHOL'] = '1'\n"
+            "import test_gpu_kernels as t\n"
+            "for w in (0, 1):\n"
+            "    for c in t.LDS_CHOL_CASES: t._lds_gram_chol_case(w, *c)\n" % (os.path.dirname(here), here))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def _lds_gram_chol_case(which, n, K, rank):
+    capi = _capi()
+    rng = np.random.default_rng(1000 * which + n + rank)
+    nb = 5
+    # rows of the n x K matrix M (rows form) with `rank` independent directions, graded over two decades
+    Mx = np.zeros((nb, n, K))
+    for b in range(nb):
+        base = rng.standard_normal((rank, K)) * np.logspace(0, -2, rank)[:, None]
+        Mx[b] = base if rank == n else rng.standard_normal((n, rank)) @ base
+    nlive = np.array([n, n, max(1, n - 3), max(1, n // 2), n], dtype=np.int32)
+    if which == 0:
+        X = Mx.astype(np.float32)
+        for b in range(nb):
+            X[b, nlive[b]:] = 7.0        # rows beyond the live count must not be read into G
+        nl = nlive
+    else:
+        # column form: P = [K rows][n columns], G = P^T P; live rows of P = K (or fewer: the rank is then capped by the live rows)
+        X = np.ascontiguousarray(np.transpose(Mx, (0, 2, 1))).astype(np.float32)
+        nl = np.array([K, K, max(1, K - 5), K, max(1, K // 2)], dtype=np.int32)
+        for b in range(nb):
+            X[b, nl[b]:] = 7.0
+    R, ml = capi.diag_lds_gram_chol(which, X, nl)
+    for b in range(nb):
+        Xd = X[b].astype(np.float64)
+        if which == 0:
+            nn = int(nlive[b])
+            G = Xd[:nn] @ Xd[:nn].T
+        else:
+            nn = n
+            G = Xd[:nl[b]].T @ Xd[:nl[b]]
+        sc = np.max(np.diag(G))
+        m = int(ml[b])
+        rk = min(rank, nn if which == 0 else int(nl[b]))
+        assert 1 <= m <= min(nn, rk + 2), (b, m, nn, rk)
+        Rb = R[b, :m, :nn].astype(np.float64)
+        assert np.all(np.isfinite(Rb)), b
+        err = np.max(np.abs(Rb.T @ Rb * sc - G)) / sc
+        assert err < 5e-6, (which, b, err, m)
+        # upper "staircase": row q starts at its pivot column, pivots in increasing order
+        first = [int(np.flatnonzero(Rb[q])[0]) for q in range(m)]
+        assert all(first[q] < first[q + 1] for q in range(m - 1)), (b, first)
+
+
 @pytest.mark.parametrize("m,l,a,u,k2,tsw", [(256, 8, 32, 8, 32, 1), (241, 8, 32, 8, 32, 0), (200, 8, 32, 8, 28, 1), (160, 8, 24, 8, 32, 1),
                                              (256, 6, 24, 6, 32, 0)])
 def test_mgemm_dense_kernel(m, l, a, u, k2, tsw):
