@@ -223,6 +223,38 @@ __device__ __forceinline__ int lds_chol_compact(const double *__restrict__ sG, c
   return s_cnt_out;
 }
 
+// the same chunk step for an accumulator array of TPW tiles (the kernels below come in size classes: fewer tiles per wave,
+// fewer registers, more blocks per CU)
+template <int NQ, int TPW>
+__device__ __forceinline__ void tm_gram_chunk_t(tm_f64x4 (&acc)[TPW], const float *__restrict__ sX, const int (&offa)[TPW],
+                                                const int (&offb)[TPW], const int k4) {
+#pragma unroll 2
+  for (int s = 0; s < TM_KC / 4; ++s) {
+    double a[NQ], b[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      a[q] = (double)sX[offa[q] + 4 * s + k4];
+      b[q] = (double)sX[offb[q] + 4 * s + k4];
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc[q], 0, 0, 0);
+  }
+}
+template <int TPW>
+__device__ __forceinline__ void tm_gram_chunk_tn(const int nq, tm_f64x4 (&acc)[TPW], const float *__restrict__ sX,
+                                                 const int (&offa)[TPW], const int (&offb)[TPW], const int k4) {
+#define TM_CASE(N) if constexpr (TPW >= N) { if (nq == N) { tm_gram_chunk_t<N, TPW>(acc, sX, offa, offb, k4); return; } }
+  TM_CASE(1) TM_CASE(2) TM_CASE(3) TM_CASE(4) TM_CASE(5) TM_CASE(6) TM_CASE(7) TM_CASE(8) TM_CASE(9)
+#undef TM_CASE
+}
+
+// packed upper triangle of order nc in LDS: element (i, c >= i) at i (nc - 1) - i (i - 1) / 2 + c  (nc (nc + 1) / 2 doubles)
+struct LdsAtPacked {
+  int nc;
+  __device__ __forceinline__ int operator()(int i, int c) const { return i * (nc - 1) - ((i * (i - 1)) >> 1) + c; }
+};
+
+
 // PEPSGPU_CG_STATS=1 (diagnostics): per-phase time of colgram_dense_kernel, summed over its blocks in a device buffer of 16 counters
 // ([0] blocks, [1] sum K, [2] sum live columns, [3..5] 10-ns ticks of the Gram / Cholesky / output phase, [6] sum live rows out)
 inline unsigned long long *cg_stats_dev() {
@@ -236,25 +268,22 @@ inline unsigned long long *cg_stats_dev() {
   return p;
 }
 
-// PEPSGPU_OLD_LDS_CHOL=1: the pivot-by-pivot forms of the LDS-resident factorisations (A/B runs)
-inline bool lds_chol_blocked_on() {
-  static const bool off = getenv("PEPSGPU_OLD_LDS_CHOL") != nullptr;
-  return !off;
-}
-
 inline size_t mid_gram_chol_smem_bytes(int cap) {
   const size_t capr = ((size_t)cap + 15) & ~(size_t)15;      // the staging buffer covers whole 16-row tiles
-  return sizeof(double) * ((size_t)cap * (cap + 1) + 2 * (size_t)cap) + sizeof(float) * capr * TM_LDM + sizeof(short) * 2 * (size_t)cap + 64;
+  const size_t tri = sizeof(double) * (size_t)cap * (cap + 1) / 2, stg = (sizeof(float) * capr * TM_LDM + 7) & ~(size_t)7;
+  return std::max(tri, stg) + sizeof(double) * (size_t)cap + sizeof(short) * 2 * (size_t)cap + 64;
 }
 
 // run_flag[b] < 0: the entry is on the route; n = nrows[b] in (lo, cap] is taken by this launch (another launch with a
-// different cap takes the rest).
-template <typename T>
-__global__ __launch_bounds__(256, 2) void mid_gram_chol_kernel(const T *__restrict__ Mg, long wM, int uk, const int *__restrict__ nrows,
-                                                            const int *__restrict__ run_flag, int lo, int cap,
-                                                            T *__restrict__ Bg, long wB, int ld, int *__restrict__ mB,
-                                                            unsigned long long *__restrict__ flopc, unsigned long long *__restrict__ bytec,
-                                                            int flop_stride, int blocked) {
+// different cap takes the rest).  TPW = 16 x 16 tiles of G per wave this size class needs, MINB = blocks per CU it is built for.
+// LDS (round 3): G / the factor as a PACKED triangle laid over the dead staging buffer -- 27 KB for cap = 80 (four blocks per
+// CU; the square form took 64 KB: two), 67 KB for cap = 128 (two; was 151 KB: ONE).
+template <typename T, int TPW, int MINB>
+__global__ __launch_bounds__(256, MINB) void mid_gram_chol_kernel(const T *__restrict__ Mg, long wM, int uk, const int *__restrict__ nrows,
+                                                               const int *__restrict__ run_flag, int lo, int cap,
+                                                               T *__restrict__ Bg, long wB, int ld, int *__restrict__ mB,
+                                                               unsigned long long *__restrict__ flopc,
+                                                               unsigned long long *__restrict__ bytec, int flop_stride) {
   static_assert(sizeof(T) == 4, "the mid route is f32 only (the f64 mode keeps the direct Jacobi)");
   const int b = blockIdx.x;
   if (run_flag && run_flag[b] >= 0) return;
@@ -266,22 +295,21 @@ __global__ __launch_bounds__(256, 2) void mid_gram_chol_kernel(const T *__restri
     if (bytec) atomicAdd(bytec, (unsigned long long)flop_stride * 4ull * ((unsigned long long)n * uk + (unsigned long long)n * n / 2));
   }
   extern __shared__ double tm_smem[];
-  const int ldG = cap + 1;
-  double *sG = tm_smem;                                 // [cap][ldG] upper triangle of G, then of the factor
-  double *sPiv = sG + (size_t)cap * ldG;                // [cap] pivot of a live row (0 = dropped)
-  double *sNrm = sPiv + cap;                            // [cap] squared norm of a factor row
-  float *sM = reinterpret_cast<float *>(sNrm + cap);    // [cap][TM_KC + 1] chunk of M
-  short *sList = reinterpret_cast<short *>(sM + (size_t)((cap + 15) & ~15) * TM_LDM);   // [cap] live rows in order
+  const int capr = (cap + 15) & ~15;
+  const size_t tri = (size_t)cap * (cap + 1) / 2, stg = ((size_t)capr * TM_LDM + 1) / 2;
+  double *sG = tm_smem;                                 // packed upper triangle of G, then of the factor (after the Gram phase)
+  float *sM = reinterpret_cast<float *>(tm_smem);       // [capr][TM_LDM] chunk of M (Gram phase only)
+  double *sNrm = tm_smem + (tri > stg ? tri : stg);     // [cap] squared norm of a factor row
+  short *sList = reinterpret_cast<short *>(sNrm + cap); // [cap] live rows in order
   short *sPos = sList + cap;                            // [cap] output position, -1 = dropped
-  __shared__ double s_red[4], s_maxd, s_fro;
-  __shared__ int s_nl, s_cnt;
+  const LdsAtPacked at{cap};
+  __shared__ double s_red[4], s_maxd;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T *M = Mg + (long)b * wM;
   T *B = Bg + (long)b * wB;
 
   // ---- G = M M^T: 16 x 16 tiles on or above the diagonal, dealt round-robin to the four waves ----
   const int nt = (n + 15) >> 4, ntiles = nt * (nt + 1) / 2;
-  constexpr int TPW = TM_TPW;
   const int r16 = lane & 15, k4 = lane >> 4;
   int ti[TPW], tj[TPW], offa[TPW], offb[TPW];
   int nq = 0;
@@ -302,140 +330,90 @@ __global__ __launch_bounds__(256, 2) void mid_gram_chol_kernel(const T *__restri
   for (int e = tid + n * TM_LDM; e < 16 * nt * TM_LDM; e += 256) sM[e] = 0.f;
   // 32 columns x up to 128 rows = 16 elements per thread: unconditional loads (clamped address); the chunk after the one being
   // multiplied is in flight during its MFMAs (registers v), stored once the waves have left the staging buffer
-  constexpr int PF = TM_PF;
-  float v[PF][16];
-  auto issue = [&](const int kc, float (&vv)[16]) {
+  float v[16];
+  auto issue = [&](const int kc) {
     const int kw = min(TM_KC, uk - kc);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int e = tid + 256 * i, r = min(e >> 5, n - 1), c = min(e & 31, kw - 1);
-      vv[i] = (float)M[(long)r * uk + kc + c];
+      v[i] = (float)M[(long)r * uk + kc + c];
     }
   };
+  if (uk > 0) issue(0);
+  for (int kc = 0; kc < uk; kc += TM_KC) {
+    const int kw = min(TM_KC, uk - kc);
+    __syncthreads();
 #pragma unroll
-  for (int p = 0; p < PF; ++p)
-    if (p * TM_KC < uk) issue(p * TM_KC, v[p]);
-  for (int kb = 0; kb < uk; kb += PF * TM_KC) {
-#pragma unroll
-    for (int p = 0; p < PF; ++p) {
-      const int kc = kb + p * TM_KC;
-      if (kc >= uk) break;                                 // (block-uniform)
-      const int kw = min(TM_KC, uk - kc);
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int e = tid + 256 * i, r = e >> 5, c = e & 31;
-        if (r < n) sM[r * TM_LDM + c] = c < kw ? v[p][i] : 0.f;
-      }
-      __syncthreads();
-      if (kc + PF * TM_KC < uk) issue(kc + PF * TM_KC, v[p]);
-      tm_gram_chunk_n(nq, acc, sM, offa, offb, k4);
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i, r = e >> 5, c = e & 31;
+      if (r < n) sM[r * TM_LDM + c] = c < kw ? v[i] : 0.f;
     }
+    __syncthreads();
+    if (kc + TM_KC < uk) issue(kc + TM_KC);
+    tm_gram_chunk_tn<TPW>(nq, acc, sM, offa, offb, k4);
   }
-  __syncthreads();
+  __syncthreads();                                       // the staging buffer is dead: G takes its place
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
     if (q >= nq) continue;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {                        // acc[r] = C[(lane >> 4) + 4 r][lane & 15]
       const int i = 16 * ti[q] + k4 + 4 * r, j = 16 * tj[q] + r16;
-      if (i < n && j < n) sG[i * ldG + j] = acc[q][r];
+      if (i <= j && j < n) sG[at(i, j)] = acc[q][r];
     }
   }
   __syncthreads();
 
-  // ---- upper Cholesky, right-looking, one barrier per live pivot ----
+  // ---- upper Cholesky in LDS, panels of 16 rows (lds_chol_blocked), semi-definite safe ----
   double md = 0.0;
-  for (int i = tid; i < n; i += 256) md = fmax(md, sG[i * ldG + i]);
+  for (int i = tid; i < n; i += 256) md = fmax(md, sG[at(i, i)]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
   if (lane == 0) s_red[wave] = md;
-  if (tid == 0) s_nl = 0;
   __syncthreads();
   if (tid == 0) s_maxd = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
   __syncthreads();
   const double maxd = s_maxd;
   const double eT = NOISE_C * (double)Eps<T>::v;
   const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
-  int nl;
-  if (blocked) {      // panels of 16 rows, MFMA trailing update, rows come out scaled (lds_chol_blocked)
-    nl = lds_chol_blocked(sG, LdsAtPitch{ldG}, n, thresh, n, sList, nullptr, (int)(((unsigned)b >> 3) + ((unsigned)b >> 8)) & 3);
-  } else {
-  for (int j = 0; j < n; ++j) {
-    const double piv = sG[j * ldG + j];                  // every thread reads the same, settled value
-    if (!(piv > thresh)) {                               // dead direction: its row takes no part (block-uniform branch)
-      if (tid == 0) sPiv[j] = 0.0;
-      continue;
-    }
-    if (tid == 0) { sPiv[j] = piv; sList[s_nl] = (short)j; s_nl = s_nl + 1; }
-    const double invp = 1.0 / piv;
-    // trailing update with the UNSCALED row j: G[i][r] -= G[j][i] G[j][r] / piv, i > j, r >= i
-    // (four rows per trip with the loads issued ahead of the stores was measured: slower -- 90 vs 82 ms per two steps)
-    for (int i = j + 1 + wave; i < n; i += 4) {          // a wave per trailing row, lanes along the row
-      const double f = sG[j * ldG + i] * invp;
-      for (int r = i + lane; r < n; r += 64) sG[i * ldG + r] -= f * sG[j * ldG + r];
-    }
-    __syncthreads();
-  }
-  __syncthreads();
-  nl = s_nl;
-  }
-  if (blocked) {
-    const int cnt = lds_chol_compact(sG, LdsAtPitch{ldG}, n, nl, sList, sNrm, sPos, eT);
-    if (tid == 0) mB[b] = cnt;
-    const double sc = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
-    for (int q = wave; q < nl; q += 4) {
-      const int pos = sPos[q];
-      if (pos < 0) continue;
-      const int j = sList[q];
-      // the Jacobi reads whole rows of the ld-wide buffer: columns outside [j, n) are written as zeros
-      for (int r = lane; r < ld; r += 64) B[(long)pos * ld + r] = (r >= j && r < n) ? T(sG[j * ldG + r] * sc) : T(0);
-    }
-    return;
-  }
+  const int nl = lds_chol_blocked(sG, at, n, thresh, n, sList, nullptr, (int)(((unsigned)b >> 3) + ((unsigned)b >> 8)) & 3);
   // ---- rank compaction (rows with norm below NOISE_C eps_T |B|_F are dropped), as chol_upper_kernel ----
-  for (int q = wave; q < nl; q += 4) {
-    const int j = sList[q];
-    double a = 0.0;
-    for (int r = j + lane; r < n; r += 64) { const double x = sG[j * ldG + r]; a += x * x; }
-    a = wave_sum(a);
-    if (lane == 0) sNrm[q] = a / sPiv[j];
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double f = 0.0;
-    for (int q = 0; q < nl; ++q) f += sNrm[q];
-    const double nfloor = eT * eT * f;
-    int cnt = 0;
-    for (int q = 0; q < nl; ++q) sPos[q] = sNrm[q] > nfloor ? (short)cnt++ : (short)-1;
-    s_cnt = cnt;
-    mB[b] = cnt;
-  }
-  __syncthreads();
+  const int cnt = lds_chol_compact(sG, at, n, nl, sList, sNrm, sPos, eT);
+  if (tid == 0) mB[b] = cnt;
   const double sc = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
   for (int q = wave; q < nl; q += 4) {
     const int pos = sPos[q];
     if (pos < 0) continue;
     const int j = sList[q];
-    const double f = sc / sqrt(sPiv[j]);
     // the Jacobi reads whole rows of the ld-wide buffer: columns outside [j, n) are written as zeros
-    for (int r = lane; r < ld; r += 64) B[(long)pos * ld + r] = (r >= j && r < n) ? T(sG[j * ldG + r] * f) : T(0);
+    for (int r = lane; r < ld; r += 64) B[(long)pos * ld + r] = (r >= j && r < n) ? T(sG[at(j, min(r, n - 1))] * sc) : T(0);
   }
 }
 
 template <typename T>
 inline void launch_mid_gram_chol(hipStream_t s, int nbatch, const T *M, long wM, int uk, const int *nrows, const int *run_flag,
                                  int GS, T *B, long wB, int *mB) {
-  // two size classes: most walkers of a dense state have 50-80 live rows (52 KB of LDS: three per CU)
+  // two size classes: most walkers of a dense state have 50-80 live rows
   const int caps[2] = {80, 128};
   int lo = 0;
   for (int c = 0; c < 2; ++c) {
     const int cap = std::min(caps[c], GS);
     if (cap <= lo) break;
     const size_t smem = mid_gram_chol_smem_bytes(cap);
-    allow_dynamic_lds(reinterpret_cast<const void *>(&mid_gram_chol_kernel<T>), smem);
-    hipLaunchKernelGGL(mid_gram_chol_kernel<T>, dim3(nbatch), dim3(256), smem, s, M, wM, uk, nrows, run_flag, lo, cap, B, wB, GS, mB,
-                       tg_flop_counter, tg_byte_counter, nbatch >= 256 ? 64 : 1, lds_chol_blocked_on() ? 1 : 0);
+    static const int minb = getenv("PEPSGPU_MID_MINB") ? atoi(getenv("PEPSGPU_MID_MINB")) : 4;
+    if (cap <= 80 && minb >= 4) {      // <= 5 tile rows: 15 tiles, four per wave
+      allow_dynamic_lds(reinterpret_cast<const void *>(&mid_gram_chol_kernel<T, 4, 4>), smem);
+      hipLaunchKernelGGL((mid_gram_chol_kernel<T, 4, 4>), dim3(nbatch), dim3(256), smem, s, M, wM, uk, nrows, run_flag, lo, cap, B, wB, GS,
+                         mB, tg_flop_counter, tg_byte_counter, nbatch >= 256 ? 64 : 1);
+    } else if (cap <= 80) {
+      allow_dynamic_lds(reinterpret_cast<const void *>(&mid_gram_chol_kernel<T, 4, 3>), smem);
+      hipLaunchKernelGGL((mid_gram_chol_kernel<T, 4, 3>), dim3(nbatch), dim3(256), smem, s, M, wM, uk, nrows, run_flag, lo, cap, B, wB, GS,
+                         mB, tg_flop_counter, tg_byte_counter, nbatch >= 256 ? 64 : 1);
+    } else {
+      allow_dynamic_lds(reinterpret_cast<const void *>(&mid_gram_chol_kernel<T, 9, 2>), smem);
+      hipLaunchKernelGGL((mid_gram_chol_kernel<T, 9, 2>), dim3(nbatch), dim3(256), smem, s, M, wM, uk, nrows, run_flag, lo, cap, B, wB, GS,
+                         mB, tg_flop_counter, tg_byte_counter, nbatch >= 256 ? 64 : 1);
+    }
     PG_CHECK_HIP(hipGetLastError());
     lo = cap;
   }
@@ -477,39 +455,44 @@ inline size_t colgram_chol_smem_bytes(int rcap) {
 }
 
 // The same factor for DENSE walkers (rank of the order of the column count): after the Gram phase the accumulators are laid
-// down in LDS as the packed upper triangle of G (over the staging buffer, which is dead by then: 69 KB, two blocks per CU) and
-// factored right-looking -- ONE barrier per live pivot, the trailing update spread over all 256 threads -- as
-// mid_gram_chol_kernel does for M M^T.  The low-rank pivot loop of colgram_chol_kernel (row f lifted out of the accumulators,
-// a dot product over the finished rows per thread, three barriers) is the right shape for rank << columns; on the dense
-// sites of a full-rank state it was 73 % of the kernel (1.1 ms of 1.46 ms per launch of 4096 walkers).  No rank cap.
-template <typename T>
-__global__ __launch_bounds__(256, 2) void colgram_dense_kernel(const T *__restrict__ Pg, long wP, int n, const int *__restrict__ kdyn,
-                                                            int kdyn_mul, int kmax, T *__restrict__ Rg, long wR,
-                                                            int *__restrict__ mlive_out, int inner,
-                                                            const int *__restrict__ inner_live, int decline_code,
-                                                            unsigned long long *__restrict__ flopc,
-                                                            unsigned long long *__restrict__ bytec, int flop_stride, int blocked,
-                                                            unsigned long long *__restrict__ stats) {
+// down in LDS as the packed upper triangle of G (over the staging buffer, which is dead by then) and factored there in panels of
+// 16 rows (lds_chol_blocked: diagonal block in one wave's registers, forward substitution, MFMA trailing update).  No rank cap.
+// History: the low-rank pivot loop of colgram_chol_kernel was 73 % of the kernel on the dense sites of a full-rank state; round 2
+// factored the triangle right-looking with a barrier per pivot, then in VALU panels; round 3: lds_chol_blocked, and two SIZE
+// CLASSES -- NC = 96 live columns (21 tiles, six per wave, 38 KB of LDS: three blocks per CU) and NC = 128 (two blocks per CU):
+// measured per block on the full-rank state (445 rows x 78 columns): Gram 41 us (at the f64 MFMA rate of two resident blocks),
+// Cholesky 40 us (a latency chain in one wave), output 10 us -- the chain is what more blocks per CU overlap.
+// A launch takes the walkers with lo < live columns <= NC; the last class declines (decline_code) what is wider than NC.
+template <typename T, int NC, int TPW, int MINB>
+__global__ __launch_bounds__(256, MINB) void colgram_dense_kernel(const T *__restrict__ Pg, long wP, int n, const int *__restrict__ kdyn,
+                                                               int kdyn_mul, int kmax, T *__restrict__ Rg, long wR,
+                                                               int *__restrict__ mlive_out, int inner,
+                                                               const int *__restrict__ inner_live, int lo, int last, int decline_code,
+                                                               unsigned long long *__restrict__ flopc,
+                                                               unsigned long long *__restrict__ bytec, int flop_stride,
+                                                               unsigned long long *__restrict__ stats) {
   static_assert(sizeof(T) == 4, "f32 element type");
+  static_assert(NC % 16 == 0 && NC <= 128 && 4 * TPW >= (NC / 16) * (NC / 16 + 1) / 2, "tiles of the class over four waves");
   const int b = blockIdx.x;
   const unsigned long long t_0 = stats ? wall_clock64() : 0ull;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = kdyn ? min(kmax, kdyn[b] * kdyn_mul) : kmax;
   const int ilive = inner_live ? min(inner, inner_live[b]) : inner;
   const int ncols = (n / inner) * ilive;
-  if (ncols > CG_NC) {
-    if (tid == 0) mlive_out[b] = decline_code;
+  if (ncols <= lo) return;                                 // an earlier launch took it
+  if (ncols > NC) {
+    if (last && tid == 0) mlive_out[b] = decline_code;
     return;
   }
   extern __shared__ double cg_smem[];
-  float *sP = reinterpret_cast<float *>(cg_smem);          // [CG_NC][TM_LDM] chunk of P, transposed (Gram phase only)
-  double *sG = cg_smem;                                    // packed upper triangle of G / of the factor: (i, c >= i) at cg_row(i) + c
-  double *sPiv = sG + (size_t)CG_NC * (CG_NC + 1) / 2;     // [CG_NC] pivot of a live row (0 = dropped)
-  double *sNrm = sPiv + CG_NC;                             // [CG_NC] squared norm of a factor row
-  short *sList = reinterpret_cast<short *>(sNrm + CG_NC);  // [CG_NC] live rows in order
-  short *sPos = sList + CG_NC;                             // [CG_NC] output position, -1 = dropped
+  constexpr size_t TRI = (size_t)NC * (NC + 1) / 2, STG = ((size_t)NC * TM_LDM + 1) / 2;
+  float *sP = reinterpret_cast<float *>(cg_smem);          // [NC][TM_LDM] chunk of P, transposed (Gram phase only)
+  double *sG = cg_smem;                                    // packed upper triangle of G / of the factor
+  double *sNrm = sG + (TRI > STG ? TRI : STG);             // [NC] squared norm of a factor row
+  short *sList = reinterpret_cast<short *>(sNrm + NC);     // [NC] live rows in order
+  short *sPos = sList + NC;                                // [NC] output position, -1 = dropped
+  const LdsAtPacked at{NC};
   __shared__ double s_red[4], s_maxd;
-  __shared__ int s_nl;
   const T *P = Pg + (long)b * wP;
   T *Rout = Rg + (long)b * wR;
 
@@ -519,7 +502,6 @@ __global__ __launch_bounds__(256, 2) void colgram_dense_kernel(const T *__restri
     atomicAdd(flopc, (unsigned long long)flop_stride * (unsigned long long)ntiles * 512ull * (unsigned long long)K);
     if (bytec) atomicAdd(bytec, (unsigned long long)flop_stride * 4ull * (unsigned long long)K * ncols);
   }
-  constexpr int TPW = TM_TPW;
   const int r16 = lane & 15, k4 = lane >> 4;
   int ti[TPW], tj[TPW], offa[TPW], offb[TPW];
   int nq = 0;
@@ -536,49 +518,36 @@ __global__ __launch_bounds__(256, 2) void colgram_dense_kernel(const T *__restri
   for (int q = 0; q < TPW; ++q)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[q][r] = 0.0;
-  const int st_c = tid & (CG_NC - 1);                                    // staging: packed column of this thread
+  const int st_c = tid & 127;                                            // staging: packed column of this thread
   const int st_r = st_c < ncols ? (st_c / ilive) * inner + (st_c % ilive) : -1;
   // columns of the staging buffer beyond the live ones (tile padding) are read by the MFMA operands: zero, once
-  for (int e = tid + ncols * TM_LDM; e < CG_NC * TM_LDM; e += 256) sP[e] = 0.f;
+  for (int e = tid + ncols * TM_LDM; e < 16 * nt * TM_LDM; e += 256) sP[e] = 0.f;
   // unconditional loads (clamped row), 16 per thread and chunk; the chunk after the one being multiplied is in flight during
-  // its MFMAs (two blocks per CU: little else hides the latency of the loads)
-  // (TM_PF chunks in flight; three measured on the full-rank state: 40.9 us against 39.1 us per block -- the loads are not what
-  // the phase waits for)
-  constexpr int PF = TM_PF;
-  unsigned long long t_stage = 0, t_mfma = 0;
-  float v[PF][TM_KC / 2];
-  auto issue = [&](const int k0, float (&vv)[TM_KC / 2]) {
+  // its MFMAs (three chunks in flight measured: 40.9 us against 39.1 us -- the loads are not what the phase waits for: the MFMA
+  // loop runs at the f64 matrix rate two resident blocks share, 27 of the 41 us; staging and barriers are the rest)
+  float v[TM_KC / 2];
+  auto issue = [&](const int k0) {
     const int kw = min(TM_KC, K - k0);
 #pragma unroll
     for (int i = 0; i < TM_KC / 2; ++i) {
       const int k = min((tid >> 7) + 2 * i, kw - 1);
-      vv[i] = (float)P[(long)(k0 + k) * n + st_r];
+      v[i] = (float)P[(long)(k0 + k) * n + st_r];
     }
   };
+  if (K > 0 && st_r >= 0) issue(0);
+  for (int k0 = 0; k0 < K; k0 += TM_KC) {
+    const int kw = min(TM_KC, K - k0);
+    __syncthreads();
+    if (st_r >= 0) {
 #pragma unroll
-  for (int p = 0; p < PF; ++p)
-    if (p * TM_KC < K && st_r >= 0) issue(p * TM_KC, v[p]);
-  for (int kb = 0; kb < K; kb += PF * TM_KC) {
-#pragma unroll
-    for (int p = 0; p < PF; ++p) {
-      const int k0 = kb + p * TM_KC;
-      if (k0 >= K) break;                                  // (block-uniform)
-      const int kw = min(TM_KC, K - k0);
-      const unsigned long long tg0 = stats ? wall_clock64() : 0ull;
-      __syncthreads();
-      if (st_r >= 0) {
-#pragma unroll
-        for (int i = 0; i < TM_KC / 2; ++i) {
-          const int k = (tid >> 7) + 2 * i;
-          sP[st_c * TM_LDM + k] = k < kw ? v[p][i] : 0.f;
-        }
+      for (int i = 0; i < TM_KC / 2; ++i) {
+        const int k = (tid >> 7) + 2 * i;
+        sP[st_c * TM_LDM + k] = k < kw ? v[i] : 0.f;
       }
-      __syncthreads();
-      const unsigned long long tg1 = stats ? wall_clock64() : 0ull;
-      if (k0 + PF * TM_KC < K && st_r >= 0) issue(k0 + PF * TM_KC, v[p]);
-      tm_gram_chunk_n(nq, acc, sP, offa, offb, k4);
-      if (stats) { t_stage += tg1 - tg0; t_mfma += wall_clock64() - tg1; }
     }
+    __syncthreads();
+    if (k0 + TM_KC < K && st_r >= 0) issue(k0 + TM_KC);
+    tm_gram_chunk_tn<TPW>(nq, acc, sP, offa, offb, k4);
   }
   __syncthreads();                                         // the staging buffer is dead: G takes its place
   const unsigned long long t_1 = stats ? wall_clock64() : 0ull;
@@ -588,153 +557,37 @@ __global__ __launch_bounds__(256, 2) void colgram_dense_kernel(const T *__restri
 #pragma unroll
     for (int r = 0; r < 4; ++r) {                          // acc[r] = G[(lane >> 4) + 4 r][lane & 15] of the tile
       const int i = 16 * ti[q] + k4 + 4 * r, j = 16 * tj[q] + r16;
-      if (i <= j && j < ncols) sG[cg_row(i) + j] = acc[q][r];
+      if (i <= j && j < ncols) sG[at(i, j)] = acc[q][r];
     }
   }
   __syncthreads();
   double md = 0.0;
-  for (int i = tid; i < ncols; i += 256) md = fmax(md, sG[cg_row(i) + i]);
+  for (int i = tid; i < ncols; i += 256) md = fmax(md, sG[at(i, i)]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
   if (lane == 0) s_red[wave] = md;
-  if (tid == 0) s_nl = 0;
   __syncthreads();
   if (tid == 0) s_maxd = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
   __syncthreads();
   const double maxd = s_maxd;
   const double eT = NOISE_C * (double)Eps<T>::v;
   const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
-  // ---- upper Cholesky, right-looking, one barrier per live pivot (unscaled rows: row j of the factor = G[j][:] / sqrt(piv)) ----
-  // Blocked right-looking factorisation, panels of 16 rows.  Inside a panel the pivots are taken one by one and only the
-  // panel's own rows are updated (at most 15 rows: a short step per pivot); the rows below receive the whole panel at once,
-  // G[i][r] -= sum_p U[p][i] U[p][r] / piv_p, on a 16 x 16 grid of threads: thread (ta, tb) owns the elements
-  // i = ta (mod 16), r = tb (mod 16) of the upper triangle (up to 36 accumulators in registers), reads 16 values of U per
-  // panel row and touches each of its elements of G once per PANEL -- the unblocked form read and wrote every trailing element
-  // once per PIVOT and paid a barrier for it (2.4 k cycles per pivot on the dense sites).
-  int nlv = 0;
-  if (blocked) {      // panels of 16 rows, MFMA trailing update, rows come out scaled (lds_chol_blocked)
-    nlv = lds_chol_blocked(sG, CgAtPacked{}, ncols, thresh, K, sList, stats, (int)(((unsigned)b >> 3) + ((unsigned)b >> 8)) & 3);
-  } else {
-  __shared__ double s_invp[16];
-  const int ta = tid >> 4, tb = tid & 15;
-  int rowb[CG_NC / 16];
-#pragma unroll
-  for (int ii = 0; ii < CG_NC / 16; ++ii) rowb[ii] = cg_row(16 * ii + ta);
-  const int nblk = (ncols + 15) >> 4;
-  for (int kb = 0; kb < nblk; ++kb) {
-    const int j0 = 16 * kb, j1 = min(j0 + 16, ncols);
-    for (int j = j0; j < j1; ++j) {
-      const int rj = cg_row(j);
-      const double piv = sG[rj + j];                       // every thread reads the same, settled value
-      const bool live = piv > thresh && nlv < K;           // dead direction (or beyond the K rows: rounding noise): no part
-      if (tid == 0) s_invp[j - j0] = live ? 1.0 / piv : 0.0;
-      if (!live) continue;
-      if (tid == 0) { sPiv[nlv] = piv; sList[nlv] = (short)j; }
-      ++nlv;
-      const double invp = 1.0 / piv;
-      const int nrow = j1 - j - 1, W = ncols - j0;          // panel rows still to update (at most 15)
-      for (int e = tid; e < nrow * W; e += 256) {
-        const int i = j + 1 + e / W, r = j0 + e % W;
-        if (r >= i) sG[cg_row(i) + r] -= sG[rj + i] * invp * sG[rj + r];
-      }
-      __syncthreads();
-    }
-    __syncthreads();                                       // s_invp of the whole panel is settled
-    if (kb + 1 >= nblk) break;
-    double acc[CG_NC / 16][CG_NC / 16];
-#pragma unroll
-    for (int ii = 0; ii < CG_NC / 16; ++ii)
-#pragma unroll
-      for (int rr = 0; rr < CG_NC / 16; ++rr) acc[ii][rr] = 0.0;
-    for (int p = 0; p < j1 - j0; ++p) {
-      const double ip = s_invp[p];
-      if (ip == 0.0) continue;                             // dropped row (block-uniform)
-      const int rp = cg_row(j0 + p);
-      double ua[CG_NC / 16], ub[CG_NC / 16];
-#pragma unroll
-      for (int q = 0; q < CG_NC / 16; ++q) {
-        const int i = 16 * q + ta, r = 16 * q + tb;
-        ua[q] = (q > kb && q < nblk && i < ncols) ? sG[rp + i] * ip : 0.0;
-        ub[q] = (q > kb && q < nblk && r < ncols) ? sG[rp + r] : 0.0;
-      }
-#pragma unroll
-      for (int ii = 0; ii < CG_NC / 16; ++ii) {
-        if (ii <= kb || ii >= nblk) continue;              // (block-uniform)
-#pragma unroll
-        for (int rr = 0; rr < CG_NC / 16; ++rr) {
-          if (rr < ii || rr >= nblk) continue;
-          acc[ii][rr] = fma(ua[ii], ub[rr], acc[ii][rr]);
-        }
-      }
-    }
-#pragma unroll
-    for (int ii = 0; ii < CG_NC / 16; ++ii) {
-      if (ii <= kb || ii >= nblk) continue;
-      const int i = 16 * ii + ta;
-#pragma unroll
-      for (int rr = 0; rr < CG_NC / 16; ++rr) {
-        if (rr < ii || rr >= nblk) continue;
-        const int r = 16 * rr + tb;
-        if (r >= i && r < ncols) sG[rowb[ii] + r] -= acc[ii][rr];
-      }
-    }
-    __syncthreads();
-  }
-  __syncthreads();
-  }
-  const int nl = nlv;
+  // ---- upper Cholesky in LDS, panels of 16 rows; at most K live rows (the data has K rows: what is beyond is rounding noise) ----
+  const int nl = lds_chol_blocked(sG, at, ncols, thresh, K, sList, stats, (int)(((unsigned)b >> 3) + ((unsigned)b >> 8)) & 3);
   const unsigned long long t_2 = stats ? wall_clock64() : 0ull;
-  if (blocked) {
-    // ---- rank compaction and output (rows are scaled already) ----
-    const int cnt = lds_chol_compact(sG, CgAtPacked{}, ncols, nl, sList, sNrm, sPos, eT);
-    if (tid == 0) mlive_out[b] = cnt;
-    const double sc = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
-    const int c0 = lane, c1 = lane + 64;                     // packed columns of this lane -> columns of P (once)
-    const int rc0 = (c0 / ilive) * inner + (c0 % ilive), rc1 = (c1 / ilive) * inner + (c1 % ilive);
-    for (int q = wave; q < nl; q += 4) {
-      const int pos = sPos[q];
-      if (pos < 0) continue;
-      const int j = sList[q], rj = cg_row(j);
-      T *row = Rout + (long)pos * n;
-      if (c0 < ncols) row[rc0] = c0 >= j ? T(sG[rj + c0] * sc) : T(0);
-      if (c1 < ncols) row[rc1] = c1 >= j ? T(sG[rj + c1] * sc) : T(0);
-    }
-    if (stats && tid == 0) {
-      const unsigned long long t_3 = wall_clock64();
-      atomicAdd(stats + 0, 1ull); atomicAdd(stats + 1, (unsigned long long)K); atomicAdd(stats + 2, (unsigned long long)ncols);
-      atomicAdd(stats + 3, t_1 - t_0); atomicAdd(stats + 4, t_2 - t_1); atomicAdd(stats + 5, t_3 - t_2);
-      atomicAdd(stats + 6, (unsigned long long)nl); atomicAdd(stats + 10, t_stage); atomicAdd(stats + 11, t_mfma);
-    }
-    return;
-  }
   // ---- rank compaction (rows with norm below NOISE_C eps_T |R|_F are dropped) and output ----
-  for (int q = wave; q < nl; q += 4) {
-    const int j = sList[q], rj = cg_row(j);
-    double a = 0.0;
-    for (int r = j + lane; r < ncols; r += 64) { const double x = sG[rj + r]; a += x * x; }
-    a = wave_sum(a);
-    if (lane == 0) sNrm[q] = a / sPiv[q];
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double f = 0.0;
-    for (int q = 0; q < nl; ++q) f += sNrm[q];
-    const double nfloor = eT * eT * f;
-    int cnt = 0;
-    for (int q = 0; q < nl; ++q) sPos[q] = sNrm[q] > nfloor ? (short)cnt++ : (short)-1;
-    mlive_out[b] = cnt;
-  }
-  __syncthreads();
+  const int cnt = lds_chol_compact(sG, at, ncols, nl, sList, sNrm, sPos, eT);
+  if (tid == 0) mlive_out[b] = cnt;
   const double sc = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
+  const int c0 = lane, c1 = lane + 64;                     // packed columns of this lane -> columns of P (once)
+  const int rc0 = (c0 / ilive) * inner + (c0 % ilive), rc1 = (c1 / ilive) * inner + (c1 % ilive);
   for (int q = wave; q < nl; q += 4) {
     const int pos = sPos[q];
     if (pos < 0) continue;
-    const int j = sList[q], rj = cg_row(j);
-    const double f = sc / sqrt(sPiv[q]);
-    for (int c = lane; c < ncols; c += 64) {
-      const int rc = (c / ilive) * inner + (c % ilive);    // packed column -> column of P
-      Rout[(long)pos * n + rc] = c >= j ? T(sG[rj + c] * f) : T(0);
-    }
+    const int j = sList[q];
+    T *row = Rout + (long)pos * n;
+    if (c0 < ncols) row[rc0] = c0 >= j ? T(sG[at(j, c0)] * sc) : T(0);
+    if (c1 < ncols) row[rc1] = c1 >= j ? T(sG[at(j, c1)] * sc) : T(0);
   }
   if (stats && tid == 0) {
     const unsigned long long t_3 = wall_clock64();
@@ -931,12 +784,25 @@ inline void launch_colgram_chol(hipStream_t s, int nbatch, const T *P, long wP, 
                                 T *R, long wR, int *mlive, int inner, const int *inner_live, int decline_code, bool hint_dense) {
   (void)hint_dense;
   static const bool lowrank_form = getenv("PEPSGPU_COLGRAM_LOWRANK") != nullptr;
-  if (!lowrank_form) {   // dense walkers: right-looking Cholesky of the packed triangle in LDS (colgram_dense_kernel)
-    const size_t smd = sizeof(double) * ((size_t)CG_NC * (CG_NC + 1) / 2 + 2 * CG_NC) + sizeof(short) * 2 * CG_NC + 64;
-    allow_dynamic_lds(reinterpret_cast<const void *>(&colgram_dense_kernel<T>), smd);
-    hipLaunchKernelGGL(colgram_dense_kernel<T>, dim3(nbatch), dim3(256), smd, s, P, wP, n, kdyn, kdyn_mul, kmax, R, wR, mlive, inner,
-                       inner_live, decline_code, tg_flop_counter, tg_byte_counter, nbatch >= 256 ? 64 : 1, lds_chol_blocked_on() ? 1 : 0,
-                       nbatch >= 1024 ? cg_stats_dev() : nullptr);
+  if (!lowrank_form) {   // dense walkers: blocked Cholesky of the packed triangle in LDS (colgram_dense_kernel), two size classes
+    auto smem_of = [](int nc) {
+      const size_t tri = sizeof(double) * (size_t)nc * (nc + 1) / 2, stg = (sizeof(float) * (size_t)nc * TM_LDM + 7) & ~(size_t)7;
+      return std::max(tri, stg) + sizeof(double) * (size_t)nc + sizeof(short) * 2 * (size_t)nc + 64;
+    };
+    unsigned long long *st = nbatch >= 1024 ? cg_stats_dev() : nullptr;
+    static const bool one_class = getenv("PEPSGPU_COLGRAM_ONE_CLASS") != nullptr;
+    int lo = 0;
+    if (!one_class) {
+      const size_t sm = smem_of(96);
+      allow_dynamic_lds(reinterpret_cast<const void *>(&colgram_dense_kernel<T, 96, 6, 3>), sm);
+      hipLaunchKernelGGL((colgram_dense_kernel<T, 96, 6, 3>), dim3(nbatch), dim3(256), sm, s, P, wP, n, kdyn, kdyn_mul, kmax, R, wR, mlive,
+                         inner, inner_live, 0, 0, decline_code, tg_flop_counter, tg_byte_counter, nbatch >= 256 ? 64 : 1, st);
+      lo = 96;
+    }
+    const size_t sm = smem_of(128);
+    allow_dynamic_lds(reinterpret_cast<const void *>(&colgram_dense_kernel<T, 128, 9, 2>), sm);
+    hipLaunchKernelGGL((colgram_dense_kernel<T, 128, 9, 2>), dim3(nbatch), dim3(256), sm, s, P, wP, n, kdyn, kdyn_mul, kmax, R, wR, mlive,
+                       inner, inner_live, lo, 1, decline_code, tg_flop_counter, tg_byte_counter, nbatch >= 256 ? 64 : 1, st);
     PG_CHECK_HIP(hipGetLastError());
     return;
   }
