@@ -594,6 +594,7 @@ __global__ __launch_bounds__(256, MINB) void colgram_dense_kernel(const T *__res
     atomicAdd(stats + 0, 1ull); atomicAdd(stats + 1, (unsigned long long)K); atomicAdd(stats + 2, (unsigned long long)ncols);
     atomicAdd(stats + 3, t_1 - t_0); atomicAdd(stats + 4, t_2 - t_1); atomicAdd(stats + 5, t_3 - t_2);
     atomicAdd(stats + 6, (unsigned long long)nl);
+    atomicAdd(stats + 12 + (ncols <= 64 ? 0 : ncols <= 80 ? 1 : ncols <= 96 ? 2 : 3), 1ull);
   }
 }
 
@@ -792,11 +793,13 @@ inline void launch_colgram_chol(hipStream_t s, int nbatch, const T *P, long wP, 
     unsigned long long *st = nbatch >= 1024 ? cg_stats_dev() : nullptr;
     static const bool one_class = getenv("PEPSGPU_COLGRAM_ONE_CLASS") != nullptr;
     int lo = 0;
+    // (a third class of 80 columns at four blocks per CU -- four of five walkers of a full-rank state -- was measured: cholesky
+    // category 86 -> 91 ms per step: at 128 registers the kernel spills and four Gram phases share one MFMA pipe)
     if (!one_class) {
       const size_t sm = smem_of(96);
       allow_dynamic_lds(reinterpret_cast<const void *>(&colgram_dense_kernel<T, 96, 6, 3>), sm);
       hipLaunchKernelGGL((colgram_dense_kernel<T, 96, 6, 3>), dim3(nbatch), dim3(256), sm, s, P, wP, n, kdyn, kdyn_mul, kmax, R, wR, mlive,
-                         inner, inner_live, 0, 0, decline_code, tg_flop_counter, tg_byte_counter, nbatch >= 256 ? 64 : 1, st);
+                         inner, inner_live, lo, 0, decline_code, tg_flop_counter, tg_byte_counter, nbatch >= 256 ? 64 : 1, st);
       lo = 96;
     }
     const size_t sm = smem_of(128);

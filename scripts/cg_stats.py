@@ -21,4 +21,5 @@ for k in range(3):
     nblk = max(v[0], 1)
     print("step", k, "blocks", int(v[0]), "K %.1f ncols %.1f live_out %.1f" % (v[1] / nblk, v[2] / nblk, v[6] / nblk),
           "us per block: gram %.1f chol %.1f out %.1f" % (v[3] / nblk / 100, v[4] / nblk / 100, v[5] / nblk / 100),
-          "chol phases: diag %.1f subst %.1f update %.1f" % (v[7] / nblk / 100, v[8] / nblk / 100, v[9] / nblk / 100))
+          "chol phases: diag %.1f subst %.1f update %.1f" % (v[7] / nblk / 100, v[8] / nblk / 100, v[9] / nblk / 100),
+          "live columns <=64 / <=80 / <=96 / <=128: %s" % [round(x / nblk, 3) for x in v[12:16]])
