@@ -21,6 +21,7 @@
 #include "gram.h"
 #include "trunc_mid.h"
 #include "mgemm_dense.h"
+#include "pgram_dense.h"
 
 namespace pepsgpu {
 

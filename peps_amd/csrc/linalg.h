@@ -277,8 +277,8 @@ inline size_t chol_blocked_smem_bytes(int n) {
   return sizeof(double) * ((size_t)CH_NB * n + n) + sizeof(short) * 2 * (size_t)n + 64;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 3) void chol_blocked_kernel(double *__restrict__ Gg, long wG, int n,
+template <typename T, int MINB = 3>
+__global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restrict__ Gg, long wG, int n,
                                                            T *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
                                                            int only_flagged = 0, int ld = 0,
                                                            const int *__restrict__ ndyn = nullptr, int ndyn_mul = 1,
@@ -538,9 +538,17 @@ inline void launch_chol_upper(hipStream_t s, int nbatch, double *G, long wG, int
   static const bool old_chol = getenv("PEPSGPU_OLD_CHOL") != nullptr;
   if (!old_chol && n >= 48) {
     const size_t smem = chol_blocked_smem_bytes(n);
-    allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T>), smem);
-    hipLaunchKernelGGL(chol_blocked_kernel<T>, dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn, ndyn_mul,
-                       run_flag);
+    // (four blocks per CU -- 128 registers, 300 bytes of scratch -- measured on the real state: cholesky + trunc_gram 484 -> 531 ms)
+    static const int minb = getenv("PEPSGPU_CHB_MINB") ? atoi(getenv("PEPSGPU_CHB_MINB")) : 3;
+    if (minb >= 4) {
+      allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 4>), smem);
+      hipLaunchKernelGGL((chol_blocked_kernel<T, 4>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
+                         ndyn_mul, run_flag);
+    } else {
+      allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3>), smem);
+      hipLaunchKernelGGL((chol_blocked_kernel<T, 3>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
+                         ndyn_mul, run_flag);
+    }
   } else {
     const size_t smem = chol_smem_bytes(n);
     allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);

@@ -1,7 +1,8 @@
-# A/B helper: one short real_rank run per value of an environment switch.  usage: VAR=NAME VALS="a b c" bash scripts/ab_real.sh
+# A/B helper: one short real_rank run per value of an environment switch ("-" = unset).  usage: VAR=NAME VALS="- 1" bash scripts/ab_real.sh
 cd $GRAFT_REPO_ROOT
 for v in $VALS; do
-  env $VAR=$v python bench.py --state real --walkers ${NW:-4096} --steps 2 --warmup 1 --no-route-check --no-energy-check --no-sweeps --no-latency --no-other-modes --cpu-seconds 4 2>/dev/null > gpurun_out/ab_tmp.json
+  if [ "$v" = "-" ]; then unset $VAR; else export $VAR=$v; fi
+  python bench.py --state real --walkers ${NW:-4096} --steps 2 --warmup 1 --no-route-check --no-energy-check --no-sweeps --no-latency --no-other-modes --cpu-seconds 4 2>/dev/null > gpurun_out/ab_tmp.json
   python - <<PY
 import json
 d = json.load(open("gpurun_out/ab_tmp.json"))
