@@ -256,9 +256,6 @@ int pepsgpu_diag_gram_cols(int dtype, const void *P, int K, int n, int nbatch, c
 int pepsgpu_diag_gram_rows(const float *M, int n, int K, int nbatch, const int32_t *nrows, double *G_out);
 int pepsgpu_diag_mgemm_dense(const float *R, const float *Tt, int m, int la, int a_dim, int u_dim, int k2_dim, int tt_u_inner, int nbatch,
                              const int32_t *m_live, const int32_t *a_live, const int32_t *k2_live, float *M_out);
-/* pgram_dense_kernel alone: G[b] = P^T P, P = W (R A) at the C4 bulk shapes, P never formed in memory; see capi.hip */
-int pepsgpu_diag_pgram_dense(const float *R, const float *A, const float *W, int m, int nbatch, const int32_t *m_live,
-                             const int32_t *a_live, const int32_t *a2_live, double *G_out);
 /* diagnostics (PEPSGPU_CG_STATS=1): per-phase counters of colgram_dense_kernel, read and reset; see trunc_mid.h */
 int pepsgpu_diag_cg_stats(double *out16);
 /* the LDS-resident Gram + Cholesky kernels alone (f32): which = 0 rows form (X = [nbatch][n][K], R^T R = X X^T, nlive = live rows),

@@ -574,25 +574,6 @@ def diag_lds_gram_chol(which, X, nlive):
     return R, ml
 
 
-def diag_pgram_dense(R, A, W, m_live=None, a_live=None, a2_live=None):
-    """pgram_dense_kernel alone: R [nb][m][8][32], A [nb][32][2][32], W [nb][8][2][8][8] (l, p, l2, u) -> G [nb][256][256] float64
-    (upper 16 x 16 tiles) of P[(m,u),(l2,a2)] = sum W X, X = R A."""
-    R = np.ascontiguousarray(R, dtype=np.float32)
-    A = np.ascontiguousarray(A, dtype=np.float32)
-    W = np.ascontiguousarray(W, dtype=np.float32)
-    nb, m = R.shape[0], R.shape[1]
-    assert R.shape == (nb, m, 8, 32) and A.shape == (nb, 32, 2, 32) and W.shape == (nb, 8, 2, 8, 8)
-    G = np.zeros((nb, 256, 256), dtype=np.float64)
-    arrs = [None if x is None else np.ascontiguousarray(x, dtype=np.int32) for x in (m_live, a_live, a2_live)]
-    f = lib().pepsgpu_diag_pgram_dense
-    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
-    rc = f(R.ctypes.data_as(C.c_void_p), A.ctypes.data_as(C.c_void_p), W.ctypes.data_as(C.c_void_p), m, nb,
-           *[None if x is None else x.ctypes.data_as(C.c_void_p) for x in arrs], _dp(G))
-    if rc != 0:
-        raise RuntimeError("diag_pgram_dense failed: %s" % lib().pepsgpu_last_error(None).decode())
-    return G
-
-
 def diag_mgemm_dense(R, Tt, a_dim, u_dim, k2_dim, tt_u_inner, m_live=None, a_live=None, k2_live=None):
     """mgemm_dense_kernel alone: R [nb][m][la], Tt [nb][la][u * k2] (inner order (u, k2), or (k2, u) with tt_u_inner) -> M [nb][m][u * k2]
     (rows beyond m_live[b] come back as NaN: untouched)."""

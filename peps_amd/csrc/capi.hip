@@ -549,41 +549,6 @@ extern "C" int pepsgpu_diag_lds_gram_chol(int which, const float *X, int n, int 
     (void)hipFree(dX); (void)hipFree(dR); (void)hipFree(dn); (void)hipFree(dm);
   });
 }
-// pgram_dense_kernel alone (pgram_dense.h): G[b] = P^T P with P = W (R A) never formed in memory; C4 bulk shapes
-//   R [nbatch][m][8][32], A [nbatch][32][2][32], W [nbatch][8][2][8][8] (l, p, l2, u), live extents nullable; G_out [nbatch][256][256]
-extern "C" int pepsgpu_diag_pgram_dense(const float *R, const float *A, const float *W, int m, int nbatch, const int32_t *m_live,
-                                        const int32_t *a_live, const int32_t *a2_live, double *G_out) {
-  return guarded(nullptr, [&]() {
-    PG_REQUIRE(m >= 1 && nbatch >= 1, 1, "bad sizes");
-    float *dR, *dA, *dW; double *dG; int *dsel;
-    int *dl[3] = {nullptr, nullptr, nullptr};
-    const int32_t *hl[3] = {m_live, a_live, a2_live};
-    const size_t nR = (size_t)m * 256 * nbatch, nA = (size_t)2048 * nbatch, nW = (size_t)1024 * nbatch, nG = (size_t)65536 * nbatch;
-    PG_CHECK_HIP(hipMalloc(&dR, nR * sizeof(float)));
-    PG_CHECK_HIP(hipMalloc(&dA, nA * sizeof(float)));
-    PG_CHECK_HIP(hipMalloc(&dW, nW * sizeof(float)));
-    PG_CHECK_HIP(hipMalloc(&dG, nG * sizeof(double)));
-    PG_CHECK_HIP(hipMalloc(&dsel, nbatch * sizeof(int)));
-    PG_CHECK_HIP(hipMemcpy(dR, R, nR * sizeof(float), hipMemcpyHostToDevice));
-    PG_CHECK_HIP(hipMemcpy(dA, A, nA * sizeof(float), hipMemcpyHostToDevice));
-    PG_CHECK_HIP(hipMemcpy(dW, W, nW * sizeof(float), hipMemcpyHostToDevice));
-    PG_CHECK_HIP(hipMemset(dG, 0, nG * sizeof(double)));
-    std::vector<int> sel(nbatch);
-    for (int b = 0; b < nbatch; ++b) sel[b] = b;
-    PG_CHECK_HIP(hipMemcpy(dsel, sel.data(), nbatch * sizeof(int), hipMemcpyHostToDevice));
-    for (int q = 0; q < 3; ++q)
-      if (hl[q]) {
-        PG_CHECK_HIP(hipMalloc(&dl[q], nbatch * sizeof(int)));
-        PG_CHECK_HIP(hipMemcpy(dl[q], hl[q], nbatch * sizeof(int), hipMemcpyHostToDevice));
-      }
-    PG_REQUIRE(pgram_dense_ok(8, 2, 32, 32, 8, 8, (long)m * 256, 2048, dR, dA), 1, "shape not supported by pgram_dense_kernel");
-    launch_pgram_dense(0, nbatch, dR, (long)m * 256, m, dl[0], 1, dA, 2048, dl[1], dl[2], dW, dsel, 1, 1024, 128, 64, 8, 1, dG, nullptr, nullptr);
-    PG_CHECK_HIP(hipDeviceSynchronize());
-    PG_CHECK_HIP(hipMemcpy(G_out, dG, nG * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(dR); (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dG); (void)hipFree(dsel);
-    for (int q = 0; q < 3; ++q) if (dl[q]) (void)hipFree(dl[q]);
-  });
-}
 extern "C" int pepsgpu_diag_chol(int dtype_out, const double *G, int n, int nbatch, void *R_out) {
   return guarded(nullptr, [&]() {
     if (dtype_out == 0) diag_chol_t<float>(G, n, nbatch, R_out); else diag_chol_t<double>(G, n, nbatch, R_out);

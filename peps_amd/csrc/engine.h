@@ -21,7 +21,6 @@
 #include "gram.h"
 #include "trunc_mid.h"
 #include "mgemm_dense.h"
-#include "pgram_dense.h"
 
 namespace pepsgpu {
 

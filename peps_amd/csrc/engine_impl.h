@@ -214,41 +214,6 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     PG_REQUIRE(l == dd[ll] && a == A.d[0] && p == dd[lp], 3, "MultiplyMPO: bond dimension mismatch");
     // X[m,l,p,a2] = sum_a R[m,l,a] A[a,p,a2]                      (bmps_impl.h:806)
     // P[m,u,l2,a2] = sum_{l,p} X[m,l,p,a2] W[l,p,l2,u]           (bmps_impl.h:807 + :815-817)
-    // Dense walker batch (hint of the row absorbed before) at the bulk shapes: G = P^T P straight from R, A and W, chunk by
-    // chunk in LDS -- P (2 MB per walker) is neither written nor read (pgram_dense.h); the Cholesky below takes every walker.
-    bool pg_fused = false;
-    if constexpr (sizeof(T) == 4) {
-      static const bool no_pg = getenv("PEPSGPU_NO_PGRAM") != nullptr;
-      pg_fused = !no_pg && adaptive && hint_dense_carry(in, i) && m * u >= l2 * a2 && m >= 128 &&
-                 pgram_dense_ok(l, p, a, a2, l2, u, R[i].n, A.n, R[i].p, A.p);
-    }
-    if (pg_fused) {
-      const int cols = l2 * a2;
-      double *G = (double *)arena_.alloc(sizeof(double) * (size_t)cols * cols * nw_);
-      R[i + 1] = alloc_ten(cols, l2, a2);
-      int *ml = (int *)arena_.alloc(sizeof(int) * nw_);
-      PG_CHECK_HIP(hipMemsetAsync(ml, 0xFF, sizeof(int) * nw_, stream_));          // every walker flagged for the Cholesky
-      const SiteSel ss = cfg_site(r, c);
-      prof_begin(PROF_GRAM, nw_ * 2.0 * (2.0 * (m * u) * (double)cols * cols - 2.0 / 3.0 * (double)cols * cols * cols), 0.0);
-      if constexpr (sizeof(T) == 4)
-        launch_pgram_dense(stream_, nw_, (const float *)R[i].p, R[i].n, m, (const int *)mdyn[i], mmul[i], (const float *)A.p, A.n,
-                           (const int *)clive[i], (const int *)clive[i + 1], (const float *)site_base(r, c), ss.sel, ss.inc, (long)slot_,
-                           st[ll], st[lp], st[lr], st[lu], G, tg_flop_counter, tg_byte_counter);
-      prof_end();
-      prof_begin(PROF_CHOL, 0.0, 0.0);
-      launch_chol_upper<T>(stream_, nw_, G, (long)cols * cols, cols, R[i + 1].p, R[i + 1].n, ml, 1);
-      prof_end();
-      if (dbg_sweeps_) {   // diagnostics: numerical rank of the carry (forces a sync)
-        std::vector<int> h(nw_);
-        PG_CHECK_HIP(hipMemcpyAsync(h.data(), ml, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
-        PG_CHECK_HIP(hipStreamSynchronize(stream_));
-        for (int v : h) { live_sum_ += v; live_full_ += cols; live_max_ = std::max<long>(live_max_, v); }
-      }
-      mdyn[i + 1] = ml;
-      mmul[i + 1] = 1;
-      arena_.free(G);
-      continue;
-    }
     DTen<T> X = alloc_ten(m * l, p, a2);
     DTen<T> P = alloc_ten(m, u, l2, a2);
     {

@@ -564,39 +564,3 @@ def test_mgemm_dense_kernel(m, l, a, u, k2, tsw):
         assert np.all(got[:m_live[b], :, k_live[b]:] == 0)
         if m_live[b] < m:
             assert np.all(np.isnan(got[m_live[b]:]))         # rows beyond the live count: untouched
-
-
-@pytest.mark.parametrize("m,mixed", [(240, False), (256, True), (37, True), (4, False)])
-def test_pgram_dense_kernel(m, mixed):
-    """pgram_dense_kernel (round 3): the forward Gram G = P^T P of a dense walker batch with P = W (R A) built chunk by chunk in LDS
-    (f32 matrix cores) and consumed by the f64 Gram accumulation in the same kernel -- against float64 NumPy on the same f32 inputs;
-    live carry rows / live bonds per walker, dead parts of R filled with NaN (they were never written)."""
-    capi = _capi()
-    rng = np.random.default_rng(m)
-    nb = 4
-    R = rng.standard_normal((nb, m, 8, 32)).astype(np.float32)
-    A = rng.standard_normal((nb, 32, 2, 32)).astype(np.float32)
-    W = rng.standard_normal((nb, 8, 2, 8, 8)).astype(np.float32)
-    ml = np.array([m, max(1, m - 3), max(1, m // 2), m], dtype=np.int32) if mixed else np.full(nb, m, dtype=np.int32)
-    al = np.array([32, 29, 32, 17], dtype=np.int32) if mixed else np.full(nb, 32, dtype=np.int32)
-    a2l = np.array([32, 32, 23, 30], dtype=np.int32) if mixed else np.full(nb, 32, dtype=np.int32)
-    Rin = R.copy()
-    for b in range(nb):
-        Rin[b, ml[b]:] = np.nan
-        Rin[b, :, :, al[b]:] = np.nan
-        A[b, al[b]:] = 0.0            # persistent tensors are zero padded
-        A[b, :, :, a2l[b]:] = 0.0
-    G = capi.diag_pgram_dense(Rin, A, W, ml, al, a2l)
-    for b in range(nb):
-        X = np.einsum("mla,apc->mlpc", R[b, :ml[b], :, :al[b]].astype(np.float64), A[b, :al[b]].astype(np.float64))
-        P = np.einsum("mlpc,lpdu->mudc", X.astype(np.float32).astype(np.float64), W[b].astype(np.float64))   # X passes through f32
-        Pm = P.astype(np.float32).astype(np.float64).reshape(ml[b] * 8, 256)
-        ref = Pm.T @ Pm
-        sc = np.sqrt(np.outer(np.diag(ref), np.diag(ref))) + 1e-300
-        for ti in range(16):
-            for tj in range(ti, 16):
-                sl = (slice(16 * ti, 16 * ti + 16), slice(16 * tj, 16 * tj + 16))
-                live = np.outer(np.diag(ref)[sl[0]] > 0, np.diag(ref)[sl[1]] > 0)
-                err = np.abs(G[b][sl] - ref[sl]) / sc[sl]
-                assert np.all(np.isfinite(G[b][sl])) and np.max(err * live) < 2e-5, (b, ti, tj, float(np.max(err * live)))
-                assert np.all(G[b][sl][~live] == 0), (b, ti, tj)
