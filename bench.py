@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--walkers", type=int, default=None,
-                    help="walkers (fresh configurations) per GPU per step; default 32768 (81 GB at the low-rank "
+                    help="walkers (fresh configurations) per GPU per step; default 49152 (121 GB at the low-rank "
                          "headline workload), 4096 for f64 or for states of higher rank (--noise > 0.15: up to 11.6 MB / walker)")
     ap.add_argument("--workload", default="C4", choices=["C2", "C3", "C4", "C5"],
                     help="BASELINE config; C5 = 8x8 spinless-fermion t-V, fZ2-graded PEPS, D=6 chi=24 through the sign-decorated path")
@@ -73,7 +73,7 @@ def parse():
                     help="launcher / rendezvous / reduction plumbing only, NO device work: value is null (CPU tests of --gpus N)")
     args = ap.parse_args()
     if args.walkers is None:
-        args.walkers = 32768 if (args.dtype == "f32" and args.noise <= 0.15 and args.state == "synthetic") else (2048 if args.state == "real" else 4096)
+        args.walkers = 49152 if (args.dtype == "f32" and args.noise <= 0.15 and args.state == "synthetic") else (2048 if args.state == "real" else 4096)
     return args
 
 
