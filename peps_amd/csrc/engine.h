@@ -872,10 +872,17 @@ class Engine : public EngineBase {
   void prof_begin(int cat, double alg_flops, double exec_flops) {
     if (!prof_on_) return;
     ProfRec r;
-    if (!ev_pool_.empty()) { r.a = ev_pool_.back(); ev_pool_.pop_back(); } else PG_CHECK_HIP(hipEventCreate(&r.a));
+    // A bracket that follows another one directly starts at that one's end event (an event costs ~2.3 us on the stream: 4 000 of
+    // them were 9 ms of the 441 ms headline step): the few unbracketed operations in between (flag memsets, list kernels) are
+    // charged to the bracket that follows.  Not for the chained contraction, whose pair brackets exactly its launch (roofline).
+    static const bool share = getenv("PEPSGPU_PROF_NO_SHARE") == nullptr;
+    r.a_shared = share && prof_chain_ok_ && cat != PROF_CHAIN && !prof_.empty();
+    if (r.a_shared) r.a = prof_.back().b;
+    else if (!ev_pool_.empty()) { r.a = ev_pool_.back(); ev_pool_.pop_back(); } else PG_CHECK_HIP(hipEventCreate(&r.a));
     if (!ev_pool_.empty()) { r.b = ev_pool_.back(); ev_pool_.pop_back(); } else PG_CHECK_HIP(hipEventCreate(&r.b));
     r.cat = cat; r.alg = alg_flops; r.exec = exec_flops;
-    PG_CHECK_HIP(hipEventRecord(r.a, stream_));
+    if (!r.a_shared) PG_CHECK_HIP(hipEventRecord(r.a, stream_));
+    prof_chain_ok_ = false;
     prof_.push_back(r);
     tg_flop_counter = flopc_ + cat;
     tg_byte_counter = flopc_ + PROF_NCAT + cat;
@@ -885,6 +892,7 @@ class Engine : public EngineBase {
     tg_byte_counter = nullptr;
     if (!prof_on_) return;
     PG_CHECK_HIP(hipEventRecord(prof_.back().b, stream_));
+    prof_chain_ok_ = true;
   }
   void prof_resolve() {
     if (prof_.empty()) return;
@@ -893,9 +901,11 @@ class Engine : public EngineBase {
       float ms = 0.f;
       PG_CHECK_HIP(hipEventElapsedTime(&ms, r.a, r.b));
       prof_ms_[r.cat] += ms; prof_n_[r.cat] += 1; prof_alg_[r.cat] += r.alg; prof_exec_[r.cat] += r.exec;
-      ev_pool_.push_back(r.a); ev_pool_.push_back(r.b);
+      if (!r.a_shared) ev_pool_.push_back(r.a);
+      ev_pool_.push_back(r.b);
     }
     prof_.clear();
+    prof_chain_ok_ = false;
   }
 
  private:
@@ -908,6 +918,7 @@ class Engine : public EngineBase {
   const T *site_base(int r, int c) const { return sitps_ + (long)(r * Lx_ + c) * dp_ * slot_; }
 
   void require_ready() const {
+    prof_chain_ok_ = false;   // (entry of an API call: a bracket does not reach back into the previous call)
     PG_REQUIRE(have_state_, 3, "no state uploaded (pepsgpu_state_upload)");
     PG_REQUIRE(nw_ > 0, 3, "no walker configurations set (pepsgpu_walkers_set_configs)");
   }
@@ -1163,7 +1174,8 @@ class Engine : public EngineBase {
   std::vector<BMPSDev> bmps_[4];
   std::vector<BTenDev> bten_[4];
   std::vector<BTenDev> bten2_[4];   // two-row (rank-4) environments, bten_set2_ of the reference
-  struct ProfRec { hipEvent_t a, b; int cat; double alg, exec; };
+  struct ProfRec { hipEvent_t a, b; int cat; double alg, exec; bool a_shared; };
+  mutable bool prof_chain_ok_ = false;   // the last profiling call was a prof_end of this API call: its event can open the next bracket
   std::vector<ProfRec> prof_;
   std::vector<hipEvent_t> ev_pool_;
   bool prof_on_ = false;
