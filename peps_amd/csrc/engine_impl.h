@@ -704,9 +704,8 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
             side_pending = true;
             // (size classes by row length -- <2,4> for r <= 64, <3,5>, <3,6>, <4,8> -- were measured in round 3: 533 -> 576 ms per
             // step of 4096 dense walkers; the tournament is bound by its exchange / reduction latency, not by the FMAs of a pair)
-            static const float jtol = getenv("PEPSGPU_JTOL_SCALE") ? (float)atof(getenv("PEPSGPU_JTOL_SCALE")) : 1.f;
-            launch_jacobi_grp<2, 8>(stream_, nw_, (float *)B2.p, B2.n, 128, 128, 128, 40, sweeps_, (const int *)mB2, 1, 0, 1 << 30, jtol);
-            launch_jacobi_grp<4, 8>(stream_, nw_, (float *)B2.p, B2.n, 128, 128, 128, 40, sweeps_, (const int *)mB2, 1, 64, 1 << 30, jtol);
+            launch_jacobi_grp<2, 8>(stream_, nw_, (float *)B2.p, B2.n, 128, 128, 128, 40, sweeps_, (const int *)mB2, 1, 0);
+            launch_jacobi_grp<4, 8>(stream_, nw_, (float *)B2.p, B2.n, 128, 128, 128, 40, sweeps_, (const int *)mB2, 1, 64);
           } else {
             // rows of B up to 256 long (sixteen columns per lane); more than 128 live rows of B: the 256 x 256 register kernel
             launch_jacobi_grp<2, 16>(stream_, nw_, (float *)Bt.p, Bt.n, GS, GS, GS, 40, sweeps_, (const int *)mB, 1, 0);

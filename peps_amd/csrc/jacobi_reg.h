@@ -593,9 +593,7 @@ template <int NW, int CPL>
 __global__ __launch_bounds__(NW * 64, CPL <= 8 ? 4 : 2) void jacobi_rows_grp_kernel(float *__restrict__ Mg, long wM, int m, int len, int ld,
                                                                   int max_sweeps, int *__restrict__ sweeps_out,
                                                                   const int *__restrict__ mdyn, int mdyn_mul,
-                                                                  int lo_rows = 0, int hi_rows = 1 << 30, float tol_scale = 1.f) {
-  // tol_scale: multiplies the (squared) orthogonality threshold -- > 1 only where a polishing Jacobi follows (the rotations of the
-  // compressed factor on the two-level route)
+                                                                  int lo_rows = 0, int hi_rows = 1 << 30) {
   // lo_rows < rows <= min(hi_rows, MAXR): the size class of this instantiation (other launches take the rest); the row length
   // covered is 16 CPL columns -- a square factor of r rows is given to the instantiation whose CPL just covers r
   constexpr int NP = 4 * NW, SLOTS = NP + 1, MAXR = NP * 2 * JG_RB, NT = NW * 64;
@@ -630,7 +628,7 @@ __global__ __launch_bounds__(NW * 64, CPL <= 8 ? 4 : 2) void jacobi_rows_grp_ker
     __syncthreads();
   }
   const float floor2 = (float)(NOISE_C * NOISE_C * (double)Eps<float>::v * (double)Eps<float>::v * s_fro[0]);
-  const float tol2 = tol_scale * 4.f * (float)len * Eps<float>::v * Eps<float>::v;
+  const float tol2 = 4.f * (float)len * Eps<float>::v * Eps<float>::v;
   for (int r = tid; r < MAXR; r += NT) {                  // rows sorted by norm: the live ones come first
     const float v = s_n2[r];
     int rk = 0;
@@ -795,11 +793,11 @@ __global__ __launch_bounds__(NW * 64, CPL <= 8 ? 4 : 2) void jacobi_rows_grp_ker
 
 template <int NW, int CPL>
 inline void launch_jacobi_grp(hipStream_t s, int nbatch, float *M, long wM, int m, int len, int ld, int max_sweeps, int *sweeps_out,
-                              const int *mdyn, int mdyn_mul, int lo_rows, int hi_rows = 1 << 30, float tol_scale = 1.f) {
+                              const int *mdyn, int mdyn_mul, int lo_rows, int hi_rows = 1 << 30) {
   const size_t smem = sizeof(float) * (size_t)(4 * NW + 1) * JG_RB * CPL * 16;
   allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_grp_kernel<NW, CPL>), smem);
   hipLaunchKernelGGL((jacobi_rows_grp_kernel<NW, CPL>), dim3(nbatch), dim3(NW * 64), smem, s, M, wM, m, len, ld, max_sweeps, sweeps_out,
-                     mdyn, mdyn_mul, lo_rows, hi_rows, tol_scale);
+                     mdyn, mdyn_mul, lo_rows, hi_rows);
 }
 
 // ---------------------------------------------------------------------------------------------
