@@ -584,6 +584,12 @@ static void diag_jacobi_t(void *M, int m, int len, int nbatch, int k, void *Vt, 
     else if (force_global == 6) launch_jacobi_grp<2, 8>(0, nbatch, (float *)dM, (long)m * len, m, len, len, 40, dsw, (const int *)nullptr, 1, 0);
     else if (force_global == 7) launch_jacobi_grp<4, 16>(0, nbatch, (float *)dM, (long)m * len, m, len, len, 40, dsw, (const int *)nullptr, 1, 0);
     else launch_jacobi_grp<2, 16>(0, nbatch, (float *)dM, (long)m * len, m, len, len, 40, dsw, (const int *)nullptr, 1, 0);
+  } else if (sizeof(T) == 4 && (force_global == 9 || force_global == 10)) {
+    // the same tournament with ONE wave per walker (up to 32 rows): 9 = rows up to 128 long, 10 = up to 256 (polish of 17..32 rows,
+    // every walker of a small batch)
+    PG_REQUIRE(m <= 32 && len <= (force_global == 9 ? 128 : 256), 1, "one-wave grouped tournament handles up to 32 x 128 (256)");
+    if (force_global == 9) launch_jacobi_grp<1, 8>(0, nbatch, (float *)dM, (long)m * len, m, len, len, 40, dsw, (const int *)nullptr, 1, 0);
+    else launch_jacobi_grp<1, 16>(0, nbatch, (float *)dM, (long)m * len, m, len, len, 40, dsw, (const int *)nullptr, 1, 0);
   } else if (sizeof(T) == 4 && force_global == 3) {   // one-wave-per-walker kernel (up to 32 x 256)
     PG_REQUIRE(m <= JR_SMALL_ROWS && len <= 256, 1, "small Jacobi handles up to 32 x 256");
     // per-walker live row count = rows up to the last non-zero one (mixed counts inside a launch, as in the absorption)

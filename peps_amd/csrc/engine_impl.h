@@ -43,6 +43,10 @@ bool Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
     if (jacobi_small_ok(len, m, mdyn)) {
       small = 1;
       static const bool no_tiny = getenv("PEPSGPU_NO_TINYJACOBI") != nullptr;
+      // (small batches: giving every walker with <= 32 rows a wave of its own on the sixteen-lanes-per-row tournament -- four pairs
+      // per instruction instead of the pairs of a walker one after the other -- was measured as a latency measure: one walker
+      // 18.0 -> 19.6 ms per amplitude, 2048 walkers 34.4 -> 40.4 ms: the exchange rounds and the ranking prologue of that kernel
+      // cost more than the shorter pair chain saves)
       if (!no_tiny) {   // walkers with <= 16 rows first (low register count: all of them resident at once)
         static const bool no_tiny2 = getenv("PEPSGPU_NO_TINY2JACOBI") != nullptr;
         static const int tiny4 = getenv("PEPSGPU_TINY4") ? atoi(getenv("PEPSGPU_TINY4")) : 1;

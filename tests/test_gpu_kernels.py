@@ -564,3 +564,32 @@ def test_mgemm_dense_kernel(m, l, a, u, k2, tsw):
         assert np.all(got[:m_live[b], :, k_live[b]:] == 0)
         if m_live[b] < m:
             assert np.all(np.isnan(got[m_live[b]:]))         # rows beyond the live count: untouched
+
+
+@pytest.mark.parametrize("kernel", [9, 10])
+@pytest.mark.parametrize("shape", [(32, 128), (32, 256), (17, 80), (16, 40), (10, 80), (9, 256), (5, 16), (2, 64), (1, 32), (24, 200), (31, 97)])
+def test_jacobi_one_wave_grouped_tournament(shape, kernel):
+    """jacobi_rows_grp_kernel<1, 8> / <1, 16> (round 3): one wave per walker, four players of two blocks of four rows -- the polish
+    of 17..32 rows and every walker of a small batch (<= 2048 walkers: latency).  Dense rows of graded norm (not triangular):
+    singular values, orthonormal Vt, norm conservation against LAPACK."""
+    capi = _capi()
+    m, ln = shape
+    if kernel == 9 and ln > 128:
+        pytest.skip("rows up to 128 long")
+    rng = np.random.default_rng(7 * m + ln + kernel)
+    nb = 6
+    M = np.stack([rng.standard_normal((m, ln)) * np.logspace(0, -3, m)[:, None] for _ in range(nb)])
+    M[1] = M[1][::-1].copy()                      # rows in increasing norm
+    if m > 2:
+        M[2, m - 1] = M[2, 0]                     # a dependent row
+    k = min(32, m, ln)
+    Mo, Vt, S, sw = capi.diag_jacobi(capi.F32, M, k, kernel)
+    for b in range(nb):
+        sref = np.linalg.svd(M[b], compute_uv=False)
+        assert np.max(np.abs(S[b].astype(np.float64) - sref[:k])) < 3e-5 * sref[0], (b, S[b], sref[:k])
+        Vb = Vt[b].astype(np.float64)
+        live = sref[:k] > 1e-5 * sref[0]
+        G = Vb @ Vb.T
+        assert np.max(np.abs(G[np.ix_(live, live)] - np.eye(int(live.sum())))) < 1e-4, b
+        assert abs(np.linalg.norm(Mo[b]) / np.linalg.norm(M[b]) - 1) < 1e-5
+        assert sw[b] < 40
