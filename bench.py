@@ -58,7 +58,7 @@ def parse():
                     help="state of the MAIN leg: the SURVEY 8(d) synthetic state (default) or the tiled optimised state of the "
                          "reference (profiling runs of the real_rank leg)")
     ap.add_argument("--no-full-rank", action="store_true", help="skip the second leg on a state of full rank")
-    ap.add_argument("--full-rank-walkers", type=int, default=4096)
+    ap.add_argument("--full-rank-walkers", type=int, default=8192)
     ap.add_argument("--full-rank-steps", type=int, default=2)
     ap.add_argument("--no-real-rank", action="store_true", help="skip the third leg on the tiled optimised state of the reference")
     ap.add_argument("--real-rank-walkers", type=int, default=8192)

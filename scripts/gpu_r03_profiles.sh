@@ -1,6 +1,6 @@
 # round 3 evidence: kernel traces and PMC passes of the three bench legs
 #   headline  : SURVEY 8(d) state, C4, 49152 walkers (the default of bench.py)
-#   full_rank : i.i.d. random site tensors (noise 1.0), 4096 walkers
+#   full_rank : i.i.d. random site tensors (noise 1.0), 8192 walkers
 #   real_rank : the reference's optimised 4x4 D=8 state tiled to 12x12, 8192 walkers
 # One counter group per pass (FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2: MI355X_MICROARCH.md); kernel trace in its
 # own run; no tracing domains beside --pmc.
@@ -25,7 +25,7 @@ leg() { # tag, extra args
   head -8 $O/r03_kernel_trace_by_grid_$tag.txt
 }
 leg c4_f32_noise0.1_nw49152
-leg c4_f32_noise1_nw4096 --noise 1.0 --walkers 4096
+leg c4_f32_noise1_nw8192 --noise 1.0 --walkers 8192
 leg c4_f32_real_nw8192 --state real --walkers 8192
 find $O -name "*.csv" -size +3M -delete
 ls $O | head -60

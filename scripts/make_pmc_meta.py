@@ -9,7 +9,7 @@ import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = ("tgemm_chain_kernel", "tgemm_direct_kernel", "gram_cols_f64_kernel", "gram_cols_lds_kernel", "gram_rows_f64_kernel", "chol_blocked_kernel",
            "gram_chol_wave_kernel", "jacobi_rows_grp_kernel", "jacobi_rows_tiny4_kernel", "colgram_dense_kernel", "mid_gram_chol_kernel")
-LEGS = {"c4_f32_noise0.1": "c4_f32_noise0.1_nw49152", "c4_f32_noise1": "c4_f32_noise1_nw4096", "c4_f32_real": "c4_f32_real_nw8192"}
+LEGS = {"c4_f32_noise0.1": "c4_f32_noise0.1_nw49152", "c4_f32_noise1": "c4_f32_noise1_nw8192", "c4_f32_real": "c4_f32_real_nw8192"}
 
 
 def totals(path):
