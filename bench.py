@@ -402,28 +402,38 @@ def vmc_rates(leg, nw, n_sweeps):
     """What VMC consumes: Monte-Carlo sweeps/s of the NN-exchange updater (square_nn_updater.h:25-83: 4(L-1) row /
     column absorptions + 2L(L-1) replacement traces per sweep and walker, Metropolis on the host per bond) and complete VMC
     samples/s (one sweep + CalEnergyAndHoles + O* accumulation with the holes resident in HBM, mc_energy_grad_evaluator.h:245-278)
-    through the C++ host layer, on `nw` walkers of the leg's state; first call untimed (allocations)."""
+    through the C++ host layer, on `nw` walkers of the leg's state; marginal rates (set-up cancels)."""
     from peps_amd import hostapi
     hostapi.set_device(leg.device)
     dtc = 0 if leg.dt == leg.capi.F32 else 1
     cfgs = leg.batches[0][:nw]
     seeds = np.arange(nw, dtype=np.uint64) + 100
+    # marginal rates: wall time of a call with 1 + n sweeps minus that of a call with 1 sweep -- the context set-up, the state
+    # upload and the first-pass allocations of the host-layer call (up to a second at 8192 walkers, and moving with the state of
+    # the allocator: the figure including them varied by 20 % between otherwise identical runs) cancel
+    hostapi.mc_sweeps(leg.flat, cfgs, seeds, leg.chi, "exchange", 1, dtc)                      # untimed: kernels loaded
+    t0 = time.perf_counter()
     hostapi.mc_sweeps(leg.flat, cfgs, seeds, leg.chi, "exchange", 1, dtc)
+    t_sw1 = time.perf_counter() - t0
     t0 = time.perf_counter()
-    _, _, rates = hostapi.mc_sweeps(leg.flat, cfgs, seeds, leg.chi, "exchange", n_sweeps, dtc)
-    t_sw = time.perf_counter() - t0
-    # (first call of the gradient path untimed as well: it loads its kernels and sizes the hole / O* stores; without it the figure
-    # moved by 12 % from run to run)
+    _, _, rates = hostapi.mc_sweeps(leg.flat, cfgs, seeds, leg.chi, "exchange", 1 + n_sweeps, dtc)
+    t_swn = time.perf_counter() - t0
+    t_sw = max(t_swn - t_sw1, 1e-9)
+    hostapi.mc_energy_grad_partial(leg.flat, cfgs, seeds, leg.chi, "exchange", "xxz", (1.0, 1.0, 0.0), 0, 1, dtc)   # untimed
+    t0 = time.perf_counter()
     hostapi.mc_energy_grad_partial(leg.flat, cfgs, seeds, leg.chi, "exchange", "xxz", (1.0, 1.0, 0.0), 0, 1, dtc)
+    t_v1 = time.perf_counter() - t0
     t0 = time.perf_counter()
-    packed, _, acc = hostapi.mc_energy_grad_partial(leg.flat, cfgs, seeds, leg.chi, "exchange", "xxz", (1.0, 1.0, 0.0), 0, n_sweeps, dtc)
-    t_vmc = time.perf_counter() - t0
+    packed, _, acc = hostapi.mc_energy_grad_partial(leg.flat, cfgs, seeds, leg.chi, "exchange", "xxz", (1.0, 1.0, 0.0), 0, 1 + n_sweeps, dtc)
+    t_vn = time.perf_counter() - t0
+    t_vmc = max(t_vn - t_v1, 1e-9)
     e, _ = hostapi.exact_sum_finish(packed, leg.flat.shape)
     return {"mc_sweeps_per_s": n_sweeps * nw / t_sw, "vmc_samples_per_s": n_sweeps * nw / t_vmc, "walkers": int(nw),
             "sweeps_timed": int(n_sweeps), "updater": "MCUpdateSquareNNExchangeOBC", "accept_rate": float(np.mean(rates)),
             "mc_energy_per_site": float(e) / (leg.L * leg.L),
             "what": "sweep = 4(L-1) absorptions + 2L(L-1) replacement traces per walker; VMC sample = sweep + CalEnergyAndHoles + O* "
-                    "accumulation (holes resident in HBM); wall time of the host-layer call incl. its context set-up"}
+                    "accumulation (holes resident in HBM); marginal wall time per sweep / sample of the host-layer call (1 + n against 1)",
+            "call_seconds": {"sweeps_1": t_sw1, "sweeps_1_plus_n": t_swn, "samples_1": t_v1, "samples_1_plus_n": t_vn}}
 
 
 def other_modes(capi, synthetic, device, L, D, chi):
