@@ -1218,7 +1218,11 @@ inline void launch_gram_chol_lowrank(hipStream_t s, int nbatch, const T *P, long
   // it handed on (-4) with the full KCAP / CH_LR_CAP, then the ones with more data columns than 128 threads (-2).
   constexpr int KCAP_S = sizeof(T) == 4 ? 64 : 32;
   static const bool short_on = getenv("PEPSGPU_NO_SHORT_FUSED") == nullptr;   // measured: cholesky category 272 -> 215 ms per two steps
-  const bool short_first = narrow && short_on && kdyn != nullptr;
+  // (without per-walker row counts -- the second site of an absorption, whose 64 static rows fit one pass -- the one-wave kernel
+  // takes the launch as well: that site ran on the 128-thread kernel, 1.49 ms against ~1.0 ms per launch of 49 152 walkers)
+  static const bool no_wave_static = getenv("PEPSGPU_NO_WAVE_STATIC") != nullptr;
+  const bool wave_static = sizeof(T) == 4 && !no_wave_static && kdyn == nullptr && kmax <= 64 && getenv("PEPSGPU_NO_WAVE_FACTOR") == nullptr;
+  const bool short_first = narrow && short_on && (kdyn != nullptr || wave_static);
   bool first_done = false;
   if constexpr (sizeof(T) == 4) {
     // dense states (hint): MFMA Gram in registers + low-rank Cholesky (trunc_mid.h) takes every walker with <= 128 live
