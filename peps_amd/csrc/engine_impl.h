@@ -202,6 +202,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
   static const int chain_chunks = getenv("PEPSGPU_CHAIN_CHUNKS") ? atoi(getenv("PEPSGPU_CHAIN_CHUNKS")) : 1;
 
   // ---------------- forward: R_{i+1} from P_i = R_i (A_i x W_i) ----------------
+  std::vector<int> assume_fused(N + 1, 0);   // per carry: the Gram + Cholesky fallback of the fused factor was not launched (hint)
   std::vector<DTen<T>> R(N);
   std::vector<int *> mdyn(N, nullptr);     // live rows of R[i] = mdyn[i][w] * mmul[i] (nullptr: all rows)
   std::vector<int> mmul(N, 1);
@@ -311,13 +312,22 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       mdyn[i + 1] = mdyn[i];                 // live rows of P = live rows of R_i times u (m is P's outer index)
       mmul[i + 1] = mmul[i] * u;
     } else {
-      double *G = (double *)arena_.alloc(sizeof(double) * (size_t)cols * cols * nw_);
+      double *G = nullptr;
       R[i + 1] = alloc_ten(cols, l2, a2);
       int *ml = adaptive ? (int *)arena_.alloc(sizeof(int) * nw_) : nullptr;
       // Low-rank walkers: the factor straight from the live rows of P, no Gram matrix in memory
       // (gram_chol_lowrank_kernel); it flags the walkers it cannot take (ml = -1) and the Gram GEMM
       // and the Cholesky kernels below then run for those only.
       const bool fused = ml && !no_fused && cols <= 256 && (mdyn[i] || rows <= FUSED_KCAP);
+      // Hint of the row absorbed before: its carry stayed at <= 24 rows on both sides of this site, well inside what the fused
+      // factor covers (rank 32, 288 rows) -- the launches for the walkers it would flag (Gram, low-rank and blocked Cholesky:
+      // ~66 us per site on an empty list) are not issued.  Verified after the absorption: a walker left flagged (ml < 0) fails
+      // the attempt and the absorption is redone with every launch (absorb_svd), as for the other hints.
+      static const bool no_skip_fb = getenv("PEPSGPU_NO_SKIP_FALLBACK") != nullptr;
+      static const bool force_skip_fb = getenv("PEPSGPU_FORCE_SKIP_FALLBACK") != nullptr;     // tests: a wrong hint
+      const bool skip_fb = fused && !full_bonds && !no_skip_fb && sizeof(T) == 4 &&
+                           (force_skip_fb || (in.depth >= 3 && (int)in.mlmax.size() > i + 1 && in.mlmax[i] >= 0 && in.mlmax[i] <= 24 &&
+                                              in.mlmax[i + 1] >= 0 && in.mlmax[i + 1] <= 24));
       if (fused) {
         // more live rows than one pass holds (moderate rank): fold the rows of P in over up to four passes
         // (covers K <= KCAP + 3 (KCAP - 32) rows); walkers beyond that, or of rank > 32, are flagged
@@ -330,6 +340,9 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         arena_.free(flist);
         prof_end();
       }
+      if (skip_fb) assume_fused[i + 1] = 1;
+      else {
+      G = (double *)arena_.alloc(sizeof(double) * (size_t)cols * cols * nw_);
       static const bool no_gd = getenv("PEPSGPU_NO_GRAMDIRECT") != nullptr;
       const bool gram_direct = !no_gd && cols >= 32 && cols <= 256;
       if (clive[i + 1] && !gram_direct) {   // the Gram GEMM reads whole rows: define the never-written columns (flagged walkers only)
@@ -375,6 +388,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       }
       launch_chol_upper<T>(stream_, nw_, G, (long)cols * cols, cols, R[i + 1].p, R[i + 1].n, ml, (lowrank || fused) ? 1 : 0);
       prof_end();
+      }
       if (dbg_sweeps_ && ml) {   // diagnostics: numerical rank of the carry (forces a sync)
         std::vector<int> h(nw_);
         PG_CHECK_HIP(hipMemcpyAsync(h.data(), ml, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -873,16 +887,17 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
   out.depth = in.depth + 1;
   bool ok = true;
   if (bond_adapt) {   // one small read-back per absorption: the maximum live count of every new bond and of every carry
-    const int ntab = 3 * N + 1;
+    const int ntab = 4 * N + 1;
     std::vector<const int *> htab(ntab, nullptr);
     for (int b = 0; b <= N; ++b) htab[b] = kn[b];
     for (int i = 0; i < N; ++i) htab[N + 1 + i] = mdyn[i];
     for (int i = 0; i < N; ++i) htab[2 * N + 1 + i] = mBkeep[i];
+    for (int i = 0; i < N; ++i) htab[3 * N + 1 + i] = assume_fused[i] ? mdyn[i] : nullptr;   // (read as "any entry negative")
     std::vector<int> hmax(ntab, -1);
     const int **dtab = (const int **)arena_.alloc(sizeof(int *) * ntab);
     int *dmax = (int *)arena_.alloc(sizeof(int) * ntab);
     PG_CHECK_HIP(hipMemcpyAsync(dtab, htab.data(), sizeof(int *) * ntab, hipMemcpyHostToDevice, stream_));
-    hipLaunchKernelGGL(max_over_walkers_kernel, dim3(ntab), dim3(256), 0, stream_, (const int *const *)dtab, nw_, dmax);
+    hipLaunchKernelGGL(max_over_walkers_kernel, dim3(ntab), dim3(256), 0, stream_, (const int *const *)dtab, nw_, dmax, 3 * N + 1);
     PG_CHECK_HIP(hipGetLastError());
     PG_CHECK_HIP(hipMemcpyAsync(hmax.data(), dmax, sizeof(int) * ntab, hipMemcpyDeviceToHost, stream_));
     PG_CHECK_HIP(hipStreamSynchronize(stream_));
@@ -893,6 +908,8 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       if (kstat[i] < kfull[i] && out.kmax[i] >= kstat[i]) ok = false;   // a walker filled a shrunk bond: maybe clipped
     for (int i = 0; i < N; ++i)
       if (assume_rows[i] > 0 && out.mlmax[i] > assume_rows[i]) ok = false;   // a rank hint was missed: rows left unrotated
+    for (int i = 0; i < N; ++i)
+      if (assume_fused[i] && hmax[3 * N + 1 + i] > 0) ok = false;            // a walker the fused factor flagged had no fallback
     for (int i = 0; i < N; ++i) {
       out.bmax[i] = mBkeep[i] ? hmax[2 * N + 1 + i] : -1;
       if (assume_b128[i] && out.bmax[i] > 128) ok = false;                   // the skipped 256-row launch was needed

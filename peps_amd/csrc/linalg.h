@@ -1628,12 +1628,15 @@ __global__ __launch_bounds__(256) void normalize_wave_kernel(T *__restrict__ Xg,
 }
 
 // out[b] = max_w v[b][w]  (v[b] == nullptr: -1); one block per entry of the pointer table
-__global__ __launch_bounds__(256) void max_over_walkers_kernel(const int *const *__restrict__ tab, int nw, int *__restrict__ out) {
+// (tables from index neg_from on are read as "is any entry negative": 1 / 0 -- a flag some kernel left on a walker)
+__global__ __launch_bounds__(256) void max_over_walkers_kernel(const int *const *__restrict__ tab, int nw, int *__restrict__ out,
+                                                               int neg_from = 1 << 30) {
   __shared__ int s_red[4];
   const int *v = tab[blockIdx.x];
+  const bool neg = (int)blockIdx.x >= neg_from;
   int m = -1;
   if (v)
-    for (int w = threadIdx.x; w < nw; w += 256) m = max(m, v[w]);
+    for (int w = threadIdx.x; w < nw; w += 256) m = max(m, neg ? (v[w] < 0 ? 1 : 0) : v[w]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;

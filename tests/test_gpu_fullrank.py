@@ -111,3 +111,38 @@ print(json.dumps({"amps": [float(x) for x in a], "redone": st["absorptions_redon
     assert outs["forced"]["redone"] > outs["plain"]["redone"]    # ... and the absorptions were redone
     a, b = np.array(outs["plain"]["amps"]), np.array(outs["forced"]["amps"])
     assert np.max(np.abs(b / a - 1)) < 2e-5
+
+
+def test_missed_fallback_hint_redoes_the_absorption():
+    """The same for the hint of round 3 that skips the Gram + Cholesky launches behind the fused factor (a row whose carry stayed
+    at <= 24 rows): forced on a full-rank state (PEPSGPU_FORCE_SKIP_FALLBACK=1), the walkers the fused factor flags are left
+    without a factor, the flags read back at the end of the absorption expose it and the absorption is redone with every launch."""
+    import json
+    import subprocess
+    import sys
+    code = r'''
+import json, numpy as np
+from peps_amd import capi, synthetic
+L, D, chi = 8, 6, 24
+sitps = synthetic.make_sitps(L, D, noise=1.0)
+cfgs = synthetic.make_configs(L, 8, "heisenberg", seed0=9)
+ctx = capi.Context(L, L, D, 2, chi, dtype=capi.F32, max_walkers=len(cfgs))
+ctx.state_upload(synthetic.sitps_to_flat(sitps, D))
+ctx.set_configs(cfgs)
+a = ctx.evaluate_amplitude()
+ctx.set_configs(cfgs[::-1].copy())
+b = ctx.evaluate_amplitude()
+st = ctx.stats()
+print(json.dumps({"amps": [float(x) for x in a] + [float(x) for x in b[::-1]], "redone": st["absorptions_redone"], "live_max": st["carry_live_max"]}))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, env in (("plain", {}), ("forced", {"PEPSGPU_FORCE_SKIP_FALLBACK": "1"})):
+        e = dict(os.environ, PEPSGPU_DEBUG_SWEEPS="1", **env)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert outs["forced"]["live_max"] > 32                       # walkers beyond what the fused factor covers: the hint WAS wrong
+    assert outs["forced"]["redone"] > outs["plain"]["redone"]    # ... and the absorptions were redone
+    a, b = np.array(outs["plain"]["amps"]), np.array(outs["forced"]["amps"])
+    assert np.all(np.isfinite(b)) and np.max(np.abs(b / a - 1)) < 2e-5
