@@ -750,9 +750,14 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       }
     }
     prof_begin(PROF_SELECT, 0.0, 0.0);
-    hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)M.p, M.n, m, uk, uk, k, V.p,
-                       V.n, (T *)nullptr, 0L, (const int *)mdyn[i], mmul[i], kn[i], trunc_err_, chi_min_, (double *)nullptr,
-                       (const int *)midflag, 0, sel_done ? JR_BR : 0);
+    // (behind the rank hint "no walker above 16 rows" the short-row Jacobi has selected every walker itself: the launch would
+    // return at once for all of them -- 15 us x 160 sites per step of 49 152 walkers; a miss is caught by the same read-back)
+    static const bool no_sel_skip = getenv("PEPSGPU_NO_SELECT_SKIP") != nullptr;
+    const bool skip_select = sel_done && !mid && !no_sel_skip && assume_rows[i] > 0 && assume_rows[i] <= JR_BR;
+    if (!skip_select)
+      hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)M.p, M.n, m, uk, uk, k, V.p,
+                         V.n, (T *)nullptr, 0L, (const int *)mdyn[i], mmul[i], kn[i], trunc_err_, chi_min_, (double *)nullptr,
+                         (const int *)midflag, 0, sel_done ? JR_BR : 0);
     PG_CHECK_HIP(hipGetLastError());
     if (mid) {
       // sigma_k u_k^T = the rotated rows of B: the chi largest, normalised -> U^T (k x GS), kB = how many are live
