@@ -24,6 +24,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -531,6 +532,11 @@ def real_state_rank(capi, device, dt):
             "carry_live_fraction": st["carry_live_fraction"], "jacobi_sweeps_max": st["jacobi_sweeps_max"]}
 
 
+# exactly one JSON line per run: the main thread and the collective watchdog agree through these
+emit_lock = threading.Lock()
+emitted = [False]
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -825,15 +831,20 @@ def main():
         # Watchdog: the measured line must survive a collective that never returns (RCCL has not seen N > 1 ranks of this code
         # on hardware before the driver's scaling run): after 240 s rank 0 prints the line with the failure noted and every
         # rank leaves with os._exit (a blocked RCCL call cannot be interrupted from Python).
-        import threading
+        # The run then ends with a NON-ZERO status on every rank (a job whose collective never completed is not a success;
+        # nothing is re-executed from this GPU-initialised process), and exactly one of the watchdog and the main thread emits
+        # the JSON line (emit_lock / emitted).
         coll_done = threading.Event()
 
         def watchdog():
             if not coll_done.wait(timeout=240.0):
-                if rank == 0:
-                    out["collective"] = {"error": "collective section did not finish within 240 s (watchdog); the timed legs above are unaffected"}
-                    print(json.dumps(out), flush=True)
-                os._exit(0)
+                with emit_lock:
+                    if rank == 0 and not emitted[0]:
+                        emitted[0] = True
+                        line = dict(out)
+                        line["collective"] = {"error": "collective section did not finish within 240 s (watchdog); the timed legs above are unaffected"}
+                        print(json.dumps(line), flush=True)
+                    os._exit(3)
 
         threading.Thread(target=watchdog, daemon=True).start()
 
@@ -929,7 +940,10 @@ def main():
                 out["energy_rel_err"] = ep.get("max_rel_err_energy")
             elif isinstance(out.get(name), dict):
                 out[name]["energy_parity"] = ep
-        print(json.dumps(out))
+        with emit_lock:
+            if not emitted[0]:
+                emitted[0] = True
+                print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -141,11 +141,26 @@ class Engine : public EngineBase {
     flag_ = (int *)arena_.alloc(sizeof(int) * (size_t)maxw_);
     sweeps_ = (int *)arena_.alloc(sizeof(int) * (size_t)maxw_);
     { const char *e = getenv("PEPSGPU_DEBUG_SWEEPS"); dbg_sweeps_ = e && e[0] == '1'; }
+    if constexpr (std::is_same<T, double>::value) {
+      // error-budget experiments (scripts/error_budget.py): the float64 engine with ONE intermediate rounded to float32
+      // where the float32 engine stores it (letters of PEPSGPU_INJECT_F32: S state, P, R carry, T = Tt, M, V, Y, E environments)
+      // and / or with the noise floors of the float32 engine (PEPSGPU_F64_EPS)
+      if (const char *e = getenv("PEPSGPU_INJECT_F32"))
+        for (; *e; ++e) {
+          const char *all = "SPRTMVYE";
+          const char *q = strchr(all, *e);
+          if (q) inject_ |= 1 << (int)(q - all);
+        }
+      double eps = 1.1102230246251565e-16;
+      if (const char *e = getenv("PEPSGPU_F64_EPS")) eps = atof(e);
+      PG_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_eps64_rt), &eps, sizeof(double)));
+    }
     PG_CHECK_HIP(hipMemsetAsync(flag_, 0, sizeof(int) * (size_t)maxw_, stream_));
     dtype = kCplx ? 3 : (sizeof(T) == 4 ? 0 : 1);
     for (int q = 0; q < 4; ++q) redo_seen_[q].assign(std::max(Ly_, Lx_) + 1, 0);
   }
   ~Engine() override {
+    (void)hipStreamSynchronize(side_stream_);
     (void)hipStreamSynchronize(stream_);
     arena_.release();
     (void)hipEventDestroy(ev_fork_); (void)hipEventDestroy(ev_join_);
@@ -198,6 +213,7 @@ class Engine : public EngineBase {
                   } else {
                     PG_REQUIRE(host_dtype == 0 || host_dtype == 1, 1, "a real context takes float32 / float64 state buffers");
                     double v = host_dtype == 0 ? (double)((const float *)host)[src] : ((const double *)host)[src];
+                    if (inject_ & INJ_S) v = (double)(float)v;
                     buf[base + o++] = T(v);
                   }
                 }
@@ -244,10 +260,6 @@ class Engine : public EngineBase {
     // unknown).  A performance hint only: the next absorption skips the launches of the mid-rank truncation route at
     // the sites where no walker came near it (the general kernels take whatever was mispredicted).
     std::vector<int> mlmax;
-    // bmax[i] = max over the walkers of the rows the first compression of the truncation route kept at site i (-1 = unknown / not
-    // on that route): hint for the next absorption -- the 256-row Jacobi launch on the factor is skipped where no walker came
-    // near 128 rows; VERIFIED by the live counts read back at the end of the absorption (a miss redoes it without hints)
-    std::vector<int> bmax;
     int depth = 0;   // rows absorbed so far (0 = the vacuum boundary): the carry rank can grow by the factor D per row at first
   };
   struct BTenDev {
@@ -917,6 +929,16 @@ class Engine : public EngineBase {
   SiteSel cfg_site(int r, int c) const { return SiteSel{r, c, cfg_ + r * Lx_ + c, Ly_ * Lx_}; }
   const T *site_base(int r, int c) const { return sitps_ + (long)(r * Lx_ + c) * dp_ * slot_; }
 
+  enum { INJ_S = 1, INJ_P = 2, INJ_R = 4, INJ_T = 8, INJ_M = 16, INJ_V = 32, INJ_Y = 64, INJ_E = 128 };
+  // float64 engine only: round a stored intermediate to float32 (error budget by stage; no-op unless PEPSGPU_INJECT_F32 names it)
+  void inject(int bit, T *p, long n_per_walker, int nb = -1) {
+    if constexpr (std::is_same<T, double>::value) {
+      if (!(inject_ & bit) || !p) return;
+      const long n = n_per_walker * (nb < 0 ? nw_ : nb);
+      hipLaunchKernelGGL(round_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream_, p, n);
+    }
+  }
+
   void require_ready() const {
     prof_chain_ok_ = false;   // (entry of an API call: a bracket does not reach back into the previous call)
     PG_REQUIRE(have_state_, 3, "no state uploaded (pepsgpu_state_upload)");
@@ -1076,6 +1098,7 @@ class Engine : public EngineBase {
       prof_end();
     }
     free_ten(tmp1); free_ten(tmp2);
+    inject(INJ_E, o.t.p, o.t.n, nb);
     o.logscale = nullptr;
     if (normalise) {
       o.logscale = (double *)arena_.alloc(sizeof(double) * nw_);
@@ -1203,6 +1226,7 @@ class Engine : public EngineBase {
   int sr_cap_ = 0, sr_n_ = 0;
   std::vector<uint32_t> sr_map_c_, sr_map_p_;   // compact <-> padded element index of every stored tensor element
   bool dbg_sweeps_ = false;
+  int inject_ = 0;                         // PEPSGPU_INJECT_F32 mask (float64 engine, experiments)
 };
 
 }  // namespace pepsgpu

@@ -159,11 +159,29 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_svd(int pos, int num, const BMPSDe
   // goes straight to the full size the next time the same row is absorbed (the walkers of the next step look like these);
   // forgotten with the state (state_upload).
   char &redo_seen = redo_seen_[pos][num];
-  if (redo_seen || !absorb_impl(pos, num, no_shrink, in, out)) {
-    if (!redo_seen) { ++n_redo_; free_bmps(out); out = BMPSDev(); }
-    redo_seen = 1;
-    PG_REQUIRE(absorb_impl(pos, num, true, in, out), 5, "MultiplyMPO: internal error (full-size absorption reported clipping)");
+  // A hinted attempt that fails leaves walkers half processed (a walker the skipped fallback would have taken carries no live
+  // rows, so its Y vanishes and the norm kernels raise its sticky flag): the persistent walker flags are snapshot before such an
+  // attempt and put back when it is redone -- only the attempt that produced the result may flag a walker.
+  int *flag_keep = nullptr;
+  if (!redo_seen) {
+    flag_keep = (int *)arena_.alloc(sizeof(int) * (size_t)nw_);
+    PG_CHECK_HIP(hipMemcpyAsync(flag_keep, flag_, sizeof(int) * (size_t)nw_, hipMemcpyDeviceToDevice, stream_));
   }
+  // (a throw while a kernel of the truncation route runs on the side stream: that kernel still reads and writes buffers the
+  // ArenaScope is about to hand back -- wait for it first)
+  auto impl = [&](bool full) {
+    try { return absorb_impl(pos, num, full, in, out); }
+    catch (...) { (void)hipStreamSynchronize(side_stream_); throw; }
+  };
+  if (redo_seen || !impl(no_shrink)) {
+    if (!redo_seen) {
+      ++n_redo_; free_bmps(out); out = BMPSDev();
+      PG_CHECK_HIP(hipMemcpyAsync(flag_, flag_keep, sizeof(int) * (size_t)nw_, hipMemcpyDeviceToDevice, stream_));
+    }
+    redo_seen = 1;
+    PG_REQUIRE(impl(true), 5, "MultiplyMPO: internal error (full-size absorption reported clipping)");
+  }
+  if (flag_keep) arena_.free(flag_keep);
   return out;
 }
 
@@ -272,6 +290,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       if (chain_flag) arena_.free(chain_flag);
     }
     free_ten(X);
+    inject(INJ_P, P.p, P.n);
     const int rows = m * u, cols = l2 * a2;
     // hint from the row absorbed before: its carry at the next site ran above the small rank cap of the factor kernels
     const bool hint_dense = in.depth >= 3 && (int)in.mlmax.size() > i + 1 && in.mlmax[i + 1] > 14;
@@ -400,6 +419,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       arena_.free(G);
       free_ten(P);
     }
+    inject(INJ_R, R[i + 1].p, R[i + 1].n);
   }
 
   // ---------------- backward: truncate right to left ----------------
@@ -408,8 +428,6 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
   PG_CHECK_HIP(hipMemcpyAsync(out.logscale, cur_log, sizeof(double) * nw_, hipMemcpyDeviceToDevice, stream_));
   DTen<T> Y = ones3();   // [l2, a2, k2]
   std::vector<int> assume_rows(N, 0);   // per site: the live-row cap the Jacobi launches relied on (0: none)
-  std::vector<int> assume_b128(N, 0);   // per site: the 256-row Jacobi on the compressed factor was not launched (hint: <= 128 rows)
-  std::vector<int *> mBkeep(N, nullptr);   // per site: rows kept by the first compression (two-level route), read back at the end
   float *yscale = nullptr;   // 1 / |Y| per walker when Y was left unnormalised by the launch that wrote it (y_scaled)
   bool y_scaled = false;
   for (int i = N - 1; i >= 0; --i) {
@@ -483,12 +501,14 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     }
     free_ten(Z1);
     free_ten(Y);
+    inject(INJ_T, Tt.p, Tt.n);
     if (i == 0) {
       PG_REQUIRE(l == 1 && a == 1, 3, "MultiplyMPO: left boundary bond is not trivial");
       Tt.d[0] = 1; Tt.d[1] = u; Tt.d[2] = k2; Tt.d[3] = 1;
       prof_begin(PROF_NORM, 0.0, 0.0);
       normalize(Tt.p, Tt.n, Tt.n, nw_, out.logscale);
       prof_end();
+      inject(INJ_V, Tt.p, Tt.n);
       out.t[0] = Tt;
       break;
     }
@@ -525,6 +545,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       }
       if (!mg_done) tgemm_launch<T, T, T, T>(stream_, g, R[i].p, Tt.p, M.p);
       prof_end();
+      inject(INJ_M, M.p, M.n);
     }
     // rows of M -> mutually orthogonal (sigma_k v_k^T)
     //
@@ -834,11 +855,12 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       prof_end();
       free_ten(Bt); free_ten(Ut); free_ten(Vp);
       arena_.free(midflag); arena_.free(nmid); arena_.free(kB);
-      if (GS > 128) mBkeep[i] = mB; else arena_.free(mB);
+      arena_.free(mB);
     } else {
       prof_end();
     }
     free_ten(M);
+    inject(INJ_V, V.p, V.n);
     out.t[i] = V;
     // Ynew[(l,a),q] = sum_{(u,k2)} Tt[(l,a),(u,k2)] V[q,(u,k2)]
     DTen<T> Yn = alloc_ten(l, a, k);
@@ -881,6 +903,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       normalize(Yn.p, Yn.n, Yn.n, nw_, out.logscale);
       prof_end();
     }
+    inject(INJ_Y, Yn.p, Yn.n);
     free_ten(Tt);
     Y = Yn;
   }
@@ -888,21 +911,19 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
   out.live = kn;
   out.kmax.assign(N + 1, -1);
   out.mlmax.assign(N, -1);
-  out.bmax.assign(N, -1);
   out.depth = in.depth + 1;
   bool ok = true;
   if (bond_adapt) {   // one small read-back per absorption: the maximum live count of every new bond and of every carry
-    const int ntab = 4 * N + 1;
+    const int ntab = 3 * N + 1;
     std::vector<const int *> htab(ntab, nullptr);
     for (int b = 0; b <= N; ++b) htab[b] = kn[b];
     for (int i = 0; i < N; ++i) htab[N + 1 + i] = mdyn[i];
-    for (int i = 0; i < N; ++i) htab[2 * N + 1 + i] = mBkeep[i];
-    for (int i = 0; i < N; ++i) htab[3 * N + 1 + i] = assume_fused[i] ? mdyn[i] : nullptr;   // (read as "any entry negative")
+    for (int i = 0; i < N; ++i) htab[2 * N + 1 + i] = assume_fused[i] ? mdyn[i] : nullptr;   // (read as "any entry negative")
     std::vector<int> hmax(ntab, -1);
     const int **dtab = (const int **)arena_.alloc(sizeof(int *) * ntab);
     int *dmax = (int *)arena_.alloc(sizeof(int) * ntab);
     PG_CHECK_HIP(hipMemcpyAsync(dtab, htab.data(), sizeof(int *) * ntab, hipMemcpyHostToDevice, stream_));
-    hipLaunchKernelGGL(max_over_walkers_kernel, dim3(ntab), dim3(256), 0, stream_, (const int *const *)dtab, nw_, dmax, 3 * N + 1);
+    hipLaunchKernelGGL(max_over_walkers_kernel, dim3(ntab), dim3(256), 0, stream_, (const int *const *)dtab, nw_, dmax, 2 * N + 1);
     PG_CHECK_HIP(hipGetLastError());
     PG_CHECK_HIP(hipMemcpyAsync(hmax.data(), dmax, sizeof(int) * ntab, hipMemcpyDeviceToHost, stream_));
     PG_CHECK_HIP(hipStreamSynchronize(stream_));
@@ -914,14 +935,8 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     for (int i = 0; i < N; ++i)
       if (assume_rows[i] > 0 && out.mlmax[i] > assume_rows[i]) ok = false;   // a rank hint was missed: rows left unrotated
     for (int i = 0; i < N; ++i)
-      if (assume_fused[i] && hmax[3 * N + 1 + i] > 0) ok = false;            // a walker the fused factor flagged had no fallback
-    for (int i = 0; i < N; ++i) {
-      out.bmax[i] = mBkeep[i] ? hmax[2 * N + 1 + i] : -1;
-      if (assume_b128[i] && out.bmax[i] > 128) ok = false;                   // the skipped 256-row launch was needed
-    }
+      if (assume_fused[i] && hmax[2 * N + 1 + i] > 0) ok = false;            // a walker the fused factor flagged had no fallback
   }
-  for (int *p : mBkeep)
-    if (p) arena_.free(p);
   for (auto &t : R) arena_.free(t.p);
   {   // the dynamic-extent arrays (several R_i may share one)
     int *last = nullptr;

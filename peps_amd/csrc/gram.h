@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256, 2) void gram_cols_f64_kernel(const T *__restri
   int bi = 0, rem = t;
   while (rem >= nb - bi) { rem -= nb - bi; ++bi; }
   const int bj = bi + rem;                                // bi <= bj: on or above the diagonal
-  const int K = kdyn ? min(kmax, kdyn[b] * kdyn_mul) : kmax;
+  const int K = kdyn ? max(0, min(kmax, kdyn[b] * kdyn_mul)) : kmax;
   if (run_flag) flop_stride = 1;      // partial participation: every running entry counts itself (no sampling)
   if (flopc && t == 0 && lane == 0 && b % flop_stride == 0) {
     atomicAdd(flopc, (unsigned long long)flop_stride * n * n * K);                 // = 2 n n K / 2 (upper triangle)
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void gram_cols_lds_kernel(const T *__restri
   const int b = blockIdx.x;
   if (run_flag && run_flag[b] >= 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int K = kdyn ? min(kmax, kdyn[b] * kdyn_mul) : kmax;
+  const int K = kdyn ? max(0, min(kmax, kdyn[b] * kdyn_mul)) : kmax;
   if (run_flag) flop_stride = 1;
   if (flopc && tid == 0 && b % flop_stride == 0) {
     atomicAdd(flopc, (unsigned long long)flop_stride * n * n * K);

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(512) void jacobi_rows_reg256_list_kernel(float *__r
 __device__ __forceinline__ void jacobi_rows_reg256_body(float4 (*xch)[JR_BR][64], const int walker, float *__restrict__ Mg, long wM, int m,
                                                         int len, int ld, int max_sweeps, int *__restrict__ sweeps_out,
                                                         const int *__restrict__ mdyn, int mdyn_mul, int skip_small) {
-  if (mdyn) m = min(m, mdyn[walker] * mdyn_mul);   // rows that exist for this walker
+  if (mdyn) m = max(0, min(m, mdyn[walker] * mdyn_mul));   // rows that exist for this walker
   if (skip_small && m <= max(skip_small, 2 * JR_BR)) return;   // skip_small = 1: the one-wave kernels took this walker;
                                                                 // > 32: also the walkers of the preconditioned mid route
   __shared__ float xnorm[JR_SLOTS][JR_BR];
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(NW * 64) void jacobi_rows_regx_kernel(float *__rest
   __shared__ short s_perm[MAXR];
   __shared__ double s_fro[NW];
   __shared__ int s_rot, s_live0;
-  if (mdyn) m = min(m, mdyn[blockIdx.x] * mdyn_mul);
+  if (mdyn) m = max(0, min(m, mdyn[blockIdx.x] * mdyn_mul));
   if (m <= lo_rows || m > MAXR) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   float *M = Mg + (long)blockIdx.x * wM;
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(NW * 64, CPL <= 8 ? 4 : 2) void jacobi_rows_grp_ker
   __shared__ short s_perm[MAXR];
   __shared__ double s_fro[NW];
   __shared__ int s_rot, s_live0;
-  if (mdyn) m = min(m, mdyn[blockIdx.x] * mdyn_mul);
+  if (mdyn) m = max(0, min(m, mdyn[blockIdx.x] * mdyn_mul));
   if (m <= lo_rows || m > MAXR || m > hi_rows) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l16 = lane & 15;
   const int w = wv * 4 + (lane >> 4);                     // the player this lane belongs to
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(256) void jacobi_rows_small_kernel(float *__restric
   const int lane = threadIdx.x & 63;
   const int walker = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (walker >= nwalkers) return;
-  const int mm = mdyn ? min(m, mdyn[walker] * mdyn_mul) : m;
+  const int mm = mdyn ? max(0, min(m, mdyn[walker] * mdyn_mul)) : m;
   if (mm > JR_SMALL_ROWS || (skip_tiny && mm <= JR_BR)) return;   // jacobi_rows_tiny_kernel took the <= 16-row walkers
   float *M = Mg + (long)walker * wM;
   JrRow a[JR_BR], b[JR_BR];
@@ -930,7 +930,7 @@ __global__ __launch_bounds__(256, 3) void jacobi_rows_tiny_kernel(float *__restr
   const int lane = threadIdx.x & 63;
   const int walker = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (walker >= nwalkers) return;
-  const int mm = mdyn ? min(m, mdyn[walker] * mdyn_mul) : m;
+  const int mm = mdyn ? max(0, min(m, mdyn[walker] * mdyn_mul)) : m;
   if (mm > JR_BR) return;
   float *M = Mg + (long)walker * wM;
   JrRow a[JR_BR];
@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(256, 3) void jacobi_rows_tiny2_kernel(float *__rest
   const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
   const int walker = blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + half;
   const bool have = walker < nwalkers;
-  int mm = have ? (mdyn ? min(m, mdyn[walker] * mdyn_mul) : m) : 0;
+  int mm = have ? (mdyn ? max(0, min(m, mdyn[walker] * mdyn_mul)) : m) : 0;
   if (mm > JR_BR) mm = 0;                                     // the 32-row / 8-wave kernels take this walker
   const int mm_max = max(mm, __shfl_xor(mm, 32, 64));         // wave-uniform
   if (mm_max == 0) return;
@@ -1106,7 +1106,7 @@ __global__ __launch_bounds__(256, CPL <= 4 ? 3 : 2) void jacobi_rows_tiny4_kerne
   const int lane = threadIdx.x & 63, l16 = lane & 15;
   const int walker = blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + (lane >> 4);
   const bool have = walker < nwalkers;
-  int mm = have ? (mdyn ? min(m, mdyn[walker] * mdyn_mul) : m) : 0;
+  int mm = have ? (mdyn ? max(0, min(m, mdyn[walker] * mdyn_mul)) : m) : 0;
   if (mm > JR_BR) mm = 0;                                     // the 32-row / 8-wave kernels take this walker
   int mm_max = max(mm, __shfl_xor(mm, 16, 64));               // wave-uniform: the four walkers of the wave
   mm_max = max(mm_max, __shfl_xor(mm_max, 32, 64));
@@ -1299,7 +1299,7 @@ __global__ __launch_bounds__(256, 2) void jacobi_rows_tiny_f64_kernel(double *__
   const int lane = threadIdx.x & 63, ll = lane & (LPR - 1);
   const int walker = blockIdx.x * (4 * WPW) + (threadIdx.x >> 6) * WPW + lane / LPR;
   const bool have = walker < nwalkers;
-  int mm = have ? (mdyn ? min(m, mdyn[walker] * mdyn_mul) : m) : 0;
+  int mm = have ? (mdyn ? max(0, min(m, mdyn[walker] * mdyn_mul)) : m) : 0;
   if (mm > JR_BR) mm = 0;                                     // the general kernel takes this walker
   int mm_max = mm;
 #pragma unroll
@@ -1322,8 +1322,8 @@ __global__ __launch_bounds__(256, 2) void jacobi_rows_tiny_f64_kernel(double *__
     na[i] = jd_sum<LPR>(jd_dot<CPL>(a[i], a[i]));
     fro += na[i];
   }
-  const double floor2 = NOISE_C * NOISE_C * Eps<double>::v * Eps<double>::v * fro;
-  const double tol2 = 4.0 * (double)len * Eps<double>::v * Eps<double>::v;
+  const double floor2 = NOISE_C * NOISE_C * eps_rt<double>() * eps_rt<double>() * fro;
+  const double tol2 = 4.0 * (double)len * eps_rt<double>() * eps_rt<double>();
   int sweep = 0;
   for (; sweep < max_sweeps; ++sweep) {
     if (sweep) {

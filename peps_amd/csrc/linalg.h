@@ -20,6 +20,11 @@ template <typename T> struct Eps;
 template <> struct Eps<float> { static constexpr float v = 5.9604645e-8f; };
 template <> struct Eps<double> { static constexpr double v = 1.1102230246251565e-16; };
 template <typename R> struct Eps<cplx<R>> { static constexpr R v = Eps<R>::v; };
+// Error-budget experiments (scripts/error_budget.py): the float64 engine can run with the noise floors of the float32 one
+// (PEPSGPU_F64_EPS=<eps> at context creation sets this device global; default = the float64 epsilon, i.e. no change).
+__device__ double g_eps64_rt = 1.1102230246251565e-16;
+template <typename T> __device__ __forceinline__ double eps_rt() { return (double)Eps<T>::v; }
+template <> __device__ __forceinline__ double eps_rt<double>() { return g_eps64_rt; }
 
 // 64-lane all-reductions on the DPP / permlane-swap path (a few cycles of latency per step, no LDS crossbar): the step
 // loops of the factor kernels are chains of dependent reductions, where the ds_bpermute behind __shfl_xor costs most
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
   // (default n); ndyn: per-entry order of the matrix (<= n), the rest of the ld x ld buffer is never touched.
   if (run_flag && run_flag[blockIdx.x] >= 0) return;
   const int ldg = ld ? ld : n;
-  if (ndyn) n = min(n, ndyn[blockIdx.x] * ndyn_mul);
+  if (ndyn) n = max(0, min(n, ndyn[blockIdx.x] * ndyn_mul));
   extern __shared__ double ch_smem[];
   double *sP = ch_smem;                          // [CH_NB][n]   current block row of R
   double *sK = sP + CH_NB * n;                   // [64][CH_NB]  staged R[list[k]][jb..jb+nb)
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
   if (tid == 0) s_maxd = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
   __syncthreads();
   const double maxd = s_maxd;
-  const double eT = NOISE_C * (double)Eps<T>::v;
+  const double eT = NOISE_C * eps_rt<T>();
   const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
 
   for (int jb = 0; jb < n; jb += CH_NB) {
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
   if (only_flagged && mlive_out[blockIdx.x] >= 0) return;
   if (run_flag && run_flag[blockIdx.x] >= 0) return;
   const int ldg = ld ? ld : n;
-  if (ndyn) n = min(n, ndyn[blockIdx.x] * ndyn_mul);
+  if (ndyn) n = max(0, min(n, ndyn[blockIdx.x] * ndyn_mul));
   extern __shared__ double chb_smem[];
   double *sP = chb_smem;                          // [CH_NB][n]   current block row
   double *sN = sP + CH_NB * n;                    // [n]          row norms^2 of the finished factor
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
   if (tid == 0) s_maxd = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
   __syncthreads();
   const double maxd = s_maxd;
-  const double eT = NOISE_C * (double)Eps<T>::v;
+  const double eT = NOISE_C * eps_rt<T>();
   const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
   const double sc_out = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
   const int i16 = lane & 15, k4 = lane >> 4;
@@ -593,7 +598,7 @@ __global__ __launch_bounds__(256) void chol_lowrank_kernel(const double *__restr
   if (lane == 0) s_red[wave] = md;
   __syncthreads();
   const double maxd = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
-  const double eT = NOISE_C * (double)Eps<T>::v;
+  const double eT = NOISE_C * eps_rt<T>();
   const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
   int nl = 0, f = -1;
   for (int step = 0;; ++step) {
@@ -693,7 +698,7 @@ __device__ __forceinline__ void gram_chol_lowrank_body(const int walker, const T
   __shared__ int s_first[2][NWV];
   __shared__ short s_pos[RCAP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Ktot = kdyn ? min(kmax, kdyn[walker] * kdyn_mul) : kmax;
+  const int Ktot = kdyn ? max(0, min(kmax, kdyn[walker] * kdyn_mul)) : kmax;
   if (Ktot > KCAP + (max_pass - 1) * (KCAP - RCAP)) {     // too many rows: decline
     if (tid == 0) mlive_out[walker] = small_first ? -4 : -1;
     return;
@@ -709,7 +714,7 @@ __device__ __forceinline__ void gram_chol_lowrank_body(const int walker, const T
   }
   const bool col_ok = tid < ncols;
   const int r = col_ok ? (tid / ilive) * inner + (tid % ilive) : n;
-  const double eT = NOISE_C * (double)Eps<T>::v;
+  const double eT = NOISE_C * eps_rt<T>();
   T pc[KCAP];
   double rc[RCAP];                   // own column of the factor (f64: pivots near the threshold amplify its rounding)
 #pragma unroll
@@ -892,7 +897,7 @@ __global__ __launch_bounds__(NT, 2) void qr_lowrank_kernel(const T *__restrict__
   __shared__ int s_first[2][NWV];
   __shared__ short s_pos[KCAP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Ktot = kdyn ? min(kmax, kdyn[blockIdx.x] * kdyn_mul) : kmax;
+  const int Ktot = kdyn ? max(0, min(kmax, kdyn[blockIdx.x] * kdyn_mul)) : kmax;
   const T *P = Pg + (long)blockIdx.x * wP;
   T *Rout = Rg + (long)blockIdx.x * wR;
   const int ilive = inner_live ? min(inner, inner_live[blockIdx.x]) : inner;
@@ -903,7 +908,7 @@ __global__ __launch_bounds__(NT, 2) void qr_lowrank_kernel(const T *__restrict__
   }
   const bool col_ok = tid < ncols;
   const int r = col_ok ? (tid / ilive) * inner + (tid % ilive) : n;
-  const double eT = noise_c * (double)Eps<T>::v;
+  const double eT = noise_c * eps_rt<T>();
   T pc[KCAP];
 #pragma unroll
   for (int k = 0; k < KCAP; ++k) pc[k] = T(0);
@@ -1055,7 +1060,7 @@ __global__ __launch_bounds__(256, 2) void gram_chol_wave_kernel(const float *__r
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= nbatch) return;
-  const int Ktot = kdyn ? min(kmax, kdyn[b] * kdyn_mul) : kmax;
+  const int Ktot = kdyn ? max(0, min(kmax, kdyn[b] * kdyn_mul)) : kmax;
   const int ilive = inner_live ? min(inner, inner_live[b]) : inner;
   const int ncols = (n / inner) * ilive;
   if (Ktot > KC + (max_pass - 1) * (KC - RC) || ncols > 128) {
@@ -1278,7 +1283,7 @@ __global__ __launch_bounds__(256) void adopt_rows_flagged_kernel(const T *__rest
   const int ilive = inner_live ? inner_live[blockIdx.x] : inner;
   __shared__ double s_red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int K = kdyn ? min(kmax, kdyn[blockIdx.x] * kdyn_mul) : kmax;
+  const int K = kdyn ? max(0, min(kmax, kdyn[blockIdx.x] * kdyn_mul)) : kmax;
   const T *P = Pg + (long)blockIdx.x * wP;
   T *R = Rg + (long)blockIdx.x * wR;
   const long cnt = (long)K * cols;
@@ -1304,7 +1309,7 @@ __global__ __launch_bounds__(256) void zero_dead_cols_kernel(T *__restrict__ Pg,
   if (flag && flag[blockIdx.x] >= 0) return;
   const int ilive = inner_live[blockIdx.x];
   if (ilive >= inner) return;
-  const int K = kdyn ? min(kmax, kdyn[blockIdx.x] * kdyn_mul) : kmax;
+  const int K = kdyn ? max(0, min(kmax, kdyn[blockIdx.x] * kdyn_mul)) : kmax;
   T *P = Pg + (long)blockIdx.x * wP;
   const long cnt = (long)K * cols;
   for (long e = threadIdx.x; e < cnt; e += 256)
@@ -1326,7 +1331,7 @@ __global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, l
                                                            int skip_small = 0, int skip_le = 0) {
   extern __shared__ unsigned char jc_smem_raw[];
   T *sM = reinterpret_cast<T *>(jc_smem_raw);
-  if (mdyn) m = min(m, mdyn[blockIdx.x] * mdyn_mul);
+  if (mdyn) m = max(0, min(m, mdyn[blockIdx.x] * mdyn_mul));
   if (skip_small && m <= max(skip_small, 32)) return;   // the one-wave kernels (jacobi_reg.h) / the mid route took this walker
   if (skip_le && m <= skip_le) return;                  // (f64: the short-row kernel took it)
   __shared__ int s_rot;
@@ -1341,7 +1346,7 @@ __global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, l
     __syncthreads();
   }
   const int mp = m + (m & 1);
-  const T tol = T(2) * sqrt(T(len)) * Eps<T>::v;
+  const T tol = T(2) * sqrt(T(len)) * T(eps_rt<T>());
   __shared__ double s_fro[16];
   {
     double f = 0.0;
@@ -1352,7 +1357,7 @@ __global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, l
     if (tid == 0) { double t = 0.0; for (int w = 0; w < nw; ++w) t += s_fro[w]; s_fro[0] = t; }
     __syncthreads();
   }
-  const T floor2 = T(NOISE_C * NOISE_C * (double)Eps<T>::v * (double)Eps<T>::v * s_fro[0]);
+  const T floor2 = T(NOISE_C * NOISE_C * eps_rt<T>() * eps_rt<T>() * s_fro[0]);
   // The tournament runs over the LIVE rows only (norm above the noise floor), re-listed at the
   // start of every sweep: a row below the floor takes part in no rotation anyway, and with a
   // fast-decaying boundary spectrum most rows of M are dead (cost ~ rank^2, not m^2).
@@ -1462,7 +1467,7 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const T *__restrict__ 
   if (run_flag && ((run_flag[blockIdx.x] < 0) != (run_if_neg != 0))) return;
   // skip_rows_le: entries with 1 .. skip_rows_le live rows were selected by the Jacobi kernel itself (JrSelect, jacobi_reg.h)
   if (skip_rows_le > 0) {
-    const int ml = mdyn ? min(m, mdyn[blockIdx.x] * mdyn_mul) : m;
+    const int ml = mdyn ? max(0, min(m, mdyn[blockIdx.x] * mdyn_mul)) : m;
     if (ml >= 1 && ml <= skip_rows_le) return;
   }
   __shared__ double s_norm[1024];
@@ -1472,7 +1477,7 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const T *__restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T *M = Mg + (long)blockIdx.x * wM;
   T *V = Vg + (long)blockIdx.x * wV;
-  if (mdyn) m = min(m, mdyn[blockIdx.x] * mdyn_mul);
+  if (mdyn) m = max(0, min(m, mdyn[blockIdx.x] * mdyn_mul));
   // fewer existing rows than kept bonds: the surplus rows of Vt are zero
   for (int e = tid + min(m, k) * len; e < k * len; e += 256) V[e] = T(0);
   if (Sg) for (int r = min(m, k) + tid; r < k; r += 256) Sg[(long)blockIdx.x * wS + r] = T(0);
@@ -1501,7 +1506,7 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const T *__restrict__ 
   // still counted as live here (the two kernels sum the norm differently).  Normalised, such a row -- mostly rounding
   // residue of the dominant direction -- enters Vt with an O(1) overlap with it and corrupts the projector (measured:
   // one walker in 8192 off by 1.4e-3 on one contraction route).  With the factor of two every live row was rotated.
-  const double nfloor = 2.0 * NOISE_C * (double)Eps<T>::v * sqrt(fro2);
+  const double nfloor = 2.0 * NOISE_C * eps_rt<T>() * sqrt(fro2);
   if (trunc_err > 0.0 || err_out) {
     // qlten::SVD(trunc_err, Dmin, Dmax) as bmps_impl.h:235-238 calls it: singular values go from the
     // smallest while more than Dmax are kept, or more than Dmin and the discarded weight / total weight
@@ -1549,7 +1554,7 @@ __global__ void mid_route_flag_kernel(const int *__restrict__ mdyn, int mdyn_mul
                                       int *__restrict__ flag, int *__restrict__ nmid) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbatch) return;
-  const int ml = mdyn ? min(m, mdyn[b] * mdyn_mul) : m;
+  const int ml = mdyn ? max(0, min(m, mdyn[b] * mdyn_mul)) : m;
   const bool mid = ml > lo && ml <= hi;
   flag[b] = mid ? -1 : 0;
   nmid[b] = mid ? ml : 0;
@@ -1584,7 +1589,7 @@ __global__ __launch_bounds__(256) void normalize_kernel(T *__restrict__ Xg, long
   __shared__ double s_nrm;
   const int tid = threadIdx.x;
   T *X = Xg + (long)blockIdx.x * wX;
-  if (ndyn) n = min(n, ndyn[blockIdx.x] * ndyn_mul);
+  if (ndyn) n = max(0, min(n, ndyn[blockIdx.x] * ndyn_mul));
   double a = 0.0;
   for (int i = tid; i < n; i += 256) a += abs2_of(X[i]);
   a = wave_sum(a);
@@ -1613,7 +1618,7 @@ __global__ __launch_bounds__(256) void normalize_wave_kernel(T *__restrict__ Xg,
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= nbatch) return;
   T *X = Xg + (long)b * wX;
-  if (ndyn) n = min(n, ndyn[b] * ndyn_mul);
+  if (ndyn) n = max(0, min(n, ndyn[b] * ndyn_mul));
   double a = 0.0;
   for (int i = lane; i < n; i += 64) a += abs2_of(X[i]);
   a = wave_sum(a);
@@ -1642,6 +1647,12 @@ __global__ __launch_bounds__(256) void max_over_walkers_kernel(const int *const 
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) out[blockIdx.x] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+}
+
+// error-budget experiments: a float64 buffer rounded to float32 values in place (Engine::inject)
+__global__ void round_f32_kernel(double *p, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (double)(float)p[i];
 }
 
 template <typename T>

@@ -29,9 +29,9 @@ __global__ __launch_bounds__(512, 2) void mgemm_dense_kernel(const float *__rest
   extern __shared__ float mg_smem[];
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ml = m_live ? min(m, m_live[b] * m_mul) : m;
-  const int al = a_live ? min(a_dim, a_live[b]) : a_dim;
-  const int kl = k2_live ? min(k2_dim, k2_live[b]) : k2_dim;
+  const int ml = m_live ? max(0, min(m, m_live[b] * m_mul)) : m;
+  const int al = a_live ? max(0, min(a_dim, a_live[b])) : a_dim;
+  const int kl = k2_live ? max(0, min(k2_dim, k2_live[b])) : k2_dim;
   const int uk = u_dim * k2_dim;
   if (ml <= 0) return;
   if (flopc && tid == 0 && b % flop_stride == 0) {

@@ -328,14 +328,14 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__res
   if (d.batch_flag && d.batch_flag[b] >= 0) return;
 #pragma unroll
   for (int s = 0; s < 3; ++s) {   // block-uniform: the walker's live extents replace / mask the static dims
-    if (d.dI[s].p) { const int e = min(d.I[s], d.dI[s].p[b / d.dI[s].div] * d.dI[s].mul); if (d.dI[s].mask) d.Imask[s] = e; else d.I[s] = e; }
-    if (d.dJ[s].p) { const int e = min(d.J[s], d.dJ[s].p[b / d.dJ[s].div] * d.dJ[s].mul); if (d.dJ[s].mask) d.Jmask[s] = e; else d.J[s] = e; }
-    if (d.dK[s].p) d.K[s] = min(d.K[s], d.dK[s].p[b / d.dK[s].div] * d.dK[s].mul);
+    if (d.dI[s].p) { const int e = max(0, min(d.I[s], d.dI[s].p[b / d.dI[s].div] * d.dI[s].mul)); if (d.dI[s].mask) d.Imask[s] = e; else d.I[s] = e; }
+    if (d.dJ[s].p) { const int e = max(0, min(d.J[s], d.dJ[s].p[b / d.dJ[s].div] * d.dJ[s].mul)); if (d.dJ[s].mask) d.Jmask[s] = e; else d.J[s] = e; }
+    if (d.dK[s].p) d.K[s] = max(0, min(d.K[s], d.dK[s].p[b / d.dK[s].div] * d.dK[s].mul));
   }
   if ((int)blockIdx.y * TG_BN >= d.Jtot()) return;
   int Itot = d.Itot(), Ktot = d.Ktot();
-  if (d.dynI) Itot = min(Itot, d.dynI[b] * d.dynI_mul);
-  if (d.dynK) Ktot = min(Ktot, d.dynK[b] * d.dynK_mul);
+  if (d.dynI) Itot = max(0, min(Itot, d.dynI[b] * d.dynI_mul));
+  if (d.dynK) Ktot = max(0, min(Ktot, d.dynK[b] * d.dynK_mul));
   if (d.flopc && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && b % d.flop_stride == 0)
   {
     atomicAdd(d.flopc, (unsigned long long)(d.upper_only ? 1 : 2) * d.flop_stride * Itot * d.Jtot() * Ktot);
@@ -368,9 +368,9 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TGemmDesc d, const TA *__res
 __device__ __forceinline__ void tg_apply_extents(TGemmDesc &d, const int b) {
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
-    if (d.dI[s].p) { const int e = min(d.I[s], d.dI[s].p[b / d.dI[s].div] * d.dI[s].mul); if (d.dI[s].mask) d.Imask[s] = e; else d.I[s] = e; }
-    if (d.dJ[s].p) { const int e = min(d.J[s], d.dJ[s].p[b / d.dJ[s].div] * d.dJ[s].mul); if (d.dJ[s].mask) d.Jmask[s] = e; else d.J[s] = e; }
-    if (d.dK[s].p) d.K[s] = min(d.K[s], d.dK[s].p[b / d.dK[s].div] * d.dK[s].mul);
+    if (d.dI[s].p) { const int e = max(0, min(d.I[s], d.dI[s].p[b / d.dI[s].div] * d.dI[s].mul)); if (d.dI[s].mask) d.Imask[s] = e; else d.I[s] = e; }
+    if (d.dJ[s].p) { const int e = max(0, min(d.J[s], d.dJ[s].p[b / d.dJ[s].div] * d.dJ[s].mul)); if (d.dJ[s].mask) d.Jmask[s] = e; else d.J[s] = e; }
+    if (d.dK[s].p) d.K[s] = max(0, min(d.K[s], d.dK[s].p[b / d.dK[s].div] * d.dK[s].mul));
   }
 }
 
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256, 6) void tgemm_direct_kernel(TGemmDesc d, const
   tg_apply_extents(d, b);
   int Itot = d.Itot();
   const int Jtot = d.Jtot();
-  if (d.dynI) Itot = min(Itot, d.dynI[b] * d.dynI_mul);
+  if (d.dynI) Itot = max(0, min(Itot, d.dynI[b] * d.dynI_mul));
   if (Itot <= 0 || Jtot <= 0) {
     if (d.scale_out && threadIdx.x == 0) { d.scale_out[b] = 1.f; if (d.norm_flag) d.norm_flag[b] = 1; }   // nothing stored: zero norm
     return;
@@ -617,10 +617,10 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TG
   tg_apply_extents(d2, b);
   int I1 = d1.Itot();
   const int J1 = d1.Jtot();
-  if (d1.dynI) I1 = min(I1, d1.dynI[b] * d1.dynI_mul);
+  if (d1.dynI) I1 = max(0, min(I1, d1.dynI[b] * d1.dynI_mul));
   int I2 = d2.Itot();
   const int J2 = d2.Jtot();
-  if (d2.dynI) I2 = min(I2, d2.dynI[b] * d2.dynI_mul);
+  if (d2.dynI) I2 = max(0, min(I2, d2.dynI[b] * d2.dynI_mul));
   // compact LDS layout of C1 over the live dims of (I1 sub-indices, J1 sub-indices); a flattened dynI limit of stage 1
   // only leaves the rows beyond it unwritten (they are not read: stage 2 runs over the same live extents)
   int lds_stride[6];

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256, MINB) void colgram_dense_kernel(const T *__res
   const int b = blockIdx.x;
   const unsigned long long t_0 = stats ? wall_clock64() : 0ull;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int K = kdyn ? min(kmax, kdyn[b] * kdyn_mul) : kmax;
+  const int K = kdyn ? max(0, min(kmax, kdyn[b] * kdyn_mul)) : kmax;
   const int ilive = inner_live ? min(inner, inner_live[b]) : inner;
   const int ncols = (n / inner) * ilive;
   if (ncols <= lo) return;                                 // an earlier launch took it
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void colgram_chol_kernel(const T *__restric
   const int b = blockIdx.x;
   if (only_code != 0 && mlive_out[b] != only_code) return;      // second launch (larger rcap): the entries the first declined
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int K = kdyn ? min(kmax, kdyn[b] * kdyn_mul) : kmax;
+  const int K = kdyn ? max(0, min(kmax, kdyn[b] * kdyn_mul)) : kmax;
   const int ilive = inner_live ? min(inner, inner_live[b]) : inner;
   const int ncols = (n / inner) * ilive;
   if (ncols > CG_NC) {

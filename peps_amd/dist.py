@@ -110,6 +110,11 @@ def allreduce_max(vec):
     return _reduce(vec, dist.ReduceOp.MAX)
 
 
+def allreduce_min(vec):
+    import torch.distributed as dist
+    return _reduce(vec, dist.ReduceOp.MIN)
+
+
 def broadcast_state(ctx, flat, src=0):
     """The parameter broadcast after an optimizer update (replaces the per-tensor MPI_Bcast of
     split_index_tps_impl.h:778-880): rank `src` holds the new state `flat` (upload layout); every rank's context ends up with it.
@@ -122,19 +127,38 @@ def broadcast_state(ctx, flat, src=0):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         ctx.state_upload(flat)
         return None
-    if dist.get_backend() == "nccl" and getattr(ctx, "comm_size", lambda: 1)() == dist.get_world_size():
+    # the ranks agree on the path first (all-reduce MIN of "my context has a library communicator of the full size"): a rank whose
+    # comm_init failed must not wait in a host broadcast while the others sit in ncclBroadcast
+    have_lib = 1.0 if (dist.get_backend() == "nccl" and getattr(ctx, "comm_size", lambda: 1)() == dist.get_world_size()) else 0.0
+    if allreduce_min(np.array([have_lib]))[0] > 0.5:
         if dist.get_rank() == src:
             ctx.state_upload(flat)
         ctx.bcast_state(src)
         return None
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    shape = [None]
+    # dtype and shape travel with the object list: a complex (PEPSGPU_C128) state keeps its imaginary part
+    meta = [None]
     if dist.get_rank() == src:
-        flat = np.ascontiguousarray(flat, dtype=np.float64)
-        shape[0] = tuple(flat.shape)
-    dist.broadcast_object_list(shape, src=src)
-    t = torch.from_numpy(flat.copy()).to(dev) if dist.get_rank() == src else torch.empty(shape[0], dtype=torch.float64, device=dev)
+        flat = np.ascontiguousarray(flat)
+        if not np.iscomplexobj(flat):
+            flat = flat.astype(np.float64, copy=False)
+        else:
+            flat = flat.astype(np.complex128, copy=False)
+        meta[0] = (tuple(flat.shape), flat.dtype.str)
+    dist.broadcast_object_list(meta, src=src)
+    shape, dstr = meta[0]
+    cplx = np.dtype(dstr).kind == "c"
+    if dist.get_rank() == src:
+        host = np.ascontiguousarray(flat).view(np.float64) if cplx else flat      # interleaved (re, im) pairs
+        t = torch.from_numpy(host.copy()).to(dev)
+    else:
+        n = int(np.prod(shape)) * (2 if cplx else 1)
+        t = torch.empty(n if cplx else shape, dtype=torch.float64, device=dev)
+    if cplx:
+        t = t.reshape(-1)
     dist.broadcast(t, src=src)
     got = t.cpu().numpy()
+    if cplx:
+        got = got.view(np.complex128).reshape(shape)
     ctx.state_upload(got)
     return got

@@ -1,0 +1,122 @@
+"""f32 error budget of the amplitude by stage, on the tiled real state at C4 (or --L / --D / --chi).
+
+Two families of runs against the float64 device mode (itself pinned to the oracle at 1e-9; --oracle N also runs oracle/cbmps.c
+on the first N configurations):
+
+  * the FLOAT64 engine with exactly one stored intermediate rounded to float32 where the float32 engine stores it
+    (PEPSGPU_INJECT_F32 letters: S state, P = R (A x W), R carry, T = Tt, M = R Tt, V = Vt, Y, E environments / BTen), and / or
+    with the noise floors of the float32 engine (PEPSGPU_F64_EPS): what the float32 STORAGE of each stage costs;
+  * the FLOAT32 engine on its default route and with one route switch at a time (what the route itself costs).
+
+Prints one JSON object; per run: median / max of |psi / psi_f64 - 1|, the mean SIGNED relative difference (a common-mode bias
+shows there) and its standard error.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def run(capi, flat, cfgs, L, D, chi, dt, env):
+    keep = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        ctx = capi.Context(L, L, D, 2, chi, dtype=dt, max_walkers=len(cfgs))
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    ctx.state_upload(flat)
+    ctx.set_configs(cfgs)
+    t0 = time.perf_counter()
+    a = ctx.evaluate_amplitude()
+    sec = time.perf_counter() - t0
+    flags = int(np.sum(ctx.walker_flags() != 0))
+    ctx.close()
+    return a, sec, flags
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--L", type=int, default=12)
+    ap.add_argument("--D", type=int, default=8)
+    ap.add_argument("--chi", type=int, default=32)
+    ap.add_argument("--walkers", type=int, default=64)
+    ap.add_argument("--oracle", type=int, default=0)
+    ap.add_argument("--state", default="real", choices=["real", "synthetic", "full"])
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    from peps_amd import capi, hostapi, synthetic
+    L, D, chi = args.L, args.D, args.chi
+    if args.state == "real":
+        from conftest import FIXTURES
+        f4 = hostapi.load_sitps(os.path.join(FIXTURES, synthetic.REAL_FIXTURE), 8)
+        if D < 8:
+            f4 = np.ascontiguousarray(f4[:, :, :, :D, :D, :D, :D])
+        flat = synthetic.tile_flat_state(f4, L)
+        ctx = capi.Context(L, L, D, 2, 4 * D, dtype=capi.F64, max_walkers=1)
+        ctx.state_upload(flat)
+        ctx.set_configs(synthetic.checkerboard(L)[None])
+        psi = float(ctx.evaluate_amplitude()[0])
+        ctx.close()
+        flat = flat * abs(psi) ** (-1.0 / (L * L))
+        cfgs = synthetic.make_configs_near_neel(L, args.walkers, seed0=307)
+    else:
+        flat = synthetic.sitps_to_flat(synthetic.make_sitps(L, D, noise=1.0 if args.state == "full" else 0.1), D)
+        cfgs = synthetic.make_configs(L, args.walkers, "heisenberg")
+    EPS32 = "5.9604645e-8"
+    runs = [("f64", capi.F64, {})]
+    for c in "SPRTMVYE":
+        runs.append(("f64+round(%s)" % c, capi.F64, {"PEPSGPU_INJECT_F32": c}))
+    runs += [
+        ("f64+round(all)", capi.F64, {"PEPSGPU_INJECT_F32": "SPRTMVYE"}),
+        ("f64+floors_f32", capi.F64, {"PEPSGPU_F64_EPS": EPS32}),
+        ("f64+round(all)+floors_f32", capi.F64, {"PEPSGPU_INJECT_F32": "SPRTMVYE", "PEPSGPU_F64_EPS": EPS32}),
+        ("f32", capi.F32, {}),
+        ("f32 no hints/shrink", capi.F32, {"PEPSGPU_NO_RANK_HINT_SKIP": "1", "PEPSGPU_NO_BOND_SHRINK": "1"}),
+        ("f32 no two-level", capi.F32, {"PEPSGPU_NO_TWO_LEVEL": "1"}),
+        ("f32 no mid route (Jacobi on M)", capi.F32, {"PEPSGPU_NO_MIDROUTE": "1"}),
+        ("f32 no chain", capi.F32, {"PEPSGPU_NO_CHAIN": "1"}),
+        ("f32 no rank adapt", capi.F32, {"PEPSGPU_NO_RANK_ADAPT": "1"}),
+        ("f32 no fused factor", capi.F32, {"PEPSGPU_NO_FUSED_GRAMCHOL": "1", "PEPSGPU_NO_COLGRAM": "1"}),
+    ]
+    if args.only:
+        want = set(args.only.split(","))
+        runs = [r for r in runs if r[0] == "f64" or r[0] in want]
+    out = {"L": L, "D": D, "chi": chi, "walkers": len(cfgs), "state": args.state, "runs": {}}
+    ref = None
+    for name, dt, env in runs:
+        try:
+            a, sec, flags = run(capi, flat, cfgs, L, D, chi, dt, env)
+        except Exception as e:
+            out["runs"][name] = {"error": repr(e)}
+            continue
+        if ref is None:
+            ref = a
+            out["runs"][name] = {"seconds": sec, "flags": flags}
+            if args.oracle:
+                from oracle import cbmps
+                k = min(args.oracle, len(cfgs))
+                ra, _, _ = cbmps.amplitudes_multiprocess(flat, cfgs[:k], chi, k)
+                out["runs"][name]["vs_oracle_cbmps_max_rel"] = float(np.max(np.abs(a[:k] / ra - 1)))
+                out["oracle_n"] = k
+            continue
+        rel = a / ref - 1
+        out["runs"][name] = {"median": float(np.median(np.abs(rel))), "max": float(np.max(np.abs(rel))),
+                             "mean_signed": float(np.mean(rel)), "stderr_signed": float(np.std(rel) / np.sqrt(len(rel))),
+                             "seconds": sec, "flags": flags}
+        print(name, json.dumps(out["runs"][name]), file=sys.stderr, flush=True)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

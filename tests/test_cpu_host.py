@@ -254,7 +254,7 @@ pdist.init("gloo")
 class HostCtx:
     """stand-in for capi.Context on a box without a GPU: records what the broadcast hands to state_upload"""
     def __init__(self): self.state = None
-    def state_upload(self, flat): self.state = np.array(flat, dtype=np.float64)
+    def state_upload(self, flat): self.state = np.array(flat)
 
 
 L, D = 4, 3
@@ -265,6 +265,12 @@ assert ctx.state is not None and ctx.state.shape == new.shape and np.array_equal
 # every rank now holds the same parameters: the all-reduced checksum is world x the local one
 chk = pdist.allreduce_sum(np.array([ctx.state.sum(), float(np.abs(ctx.state).max())]))
 assert abs(chk[0] - world * new.sum()) < 1e-9 * abs(new.sum())
+# a complex (PEPSGPU_C128) state keeps its imaginary part through the host path (ADVICE r03)
+rng = np.random.default_rng(5)
+cnew = new * np.exp(2j * np.pi * rng.random(new.shape))
+cctx = HostCtx()
+pdist.broadcast_state(cctx, cnew if rank == 1 else None, src=1)
+assert cctx.state.dtype == np.complex128 and np.array_equal(cctx.state, cnew), rank
 if rank == 0:
     print("OK")
 dist.destroy_process_group()

@@ -133,7 +133,12 @@ a = ctx.evaluate_amplitude()
 ctx.set_configs(cfgs[::-1].copy())
 b = ctx.evaluate_amplitude()
 st = ctx.stats()
-print(json.dumps({"amps": [float(x) for x in a] + [float(x) for x in b[::-1]], "redone": st["absorptions_redone"], "live_max": st["carry_live_max"]}))
+flags = ctx.walker_flags()
+# the C++ host layer on the same state (TPSWaveFunctionComponent::EvaluateAmplitude throws 'Empty tensor' on a flagged walker)
+from peps_amd import hostapi
+_, e, _, _ = hostapi.energy_and_holes(synthetic.sitps_to_flat(sitps, D), cfgs[:4], chi, model="xxz", params=(1.0, 1.0, 0.0), holes=False, dtype=0)
+print(json.dumps({"amps": [float(x) for x in a] + [float(x) for x in b[::-1]], "redone": st["absorptions_redone"], "live_max": st["carry_live_max"],
+                  "flags": [int(x) for x in flags], "host_e": [float(x) for x in np.atleast_1d(e)]}))
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
@@ -146,3 +151,6 @@ print(json.dumps({"amps": [float(x) for x in a] + [float(x) for x in b[::-1]], "
     assert outs["forced"]["redone"] > outs["plain"]["redone"]    # ... and the absorptions were redone
     a, b = np.array(outs["plain"]["amps"]), np.array(outs["forced"]["amps"])
     assert np.all(np.isfinite(b)) and np.max(np.abs(b / a - 1)) < 2e-5
+    # the failed attempt must not leave its sticky walker flags behind (a valid configuration was reported as 'Empty tensor')
+    assert not any(outs["forced"]["flags"]) and not any(outs["plain"]["flags"])
+    assert np.allclose(outs["forced"]["host_e"], outs["plain"]["host_e"], rtol=1e-4)
