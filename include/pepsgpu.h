@@ -88,6 +88,42 @@ int pepsgpu_delete_inner_bmps(pepsgpu_ctx *ctx, int pos);       /* DeleteInnerBM
  * grown meanwhile and restores the hidden levels. */
 int pepsgpu_bmps_park(pepsgpu_ctx *ctx, int pos, int keep_levels);
 int pepsgpu_bmps_unpark(pepsgpu_ctx *ctx, int pos);
+/* BMPSWalker as an object -- BMPSContractor::GetWalker / class BMPSWalker, bmps_contractor.h:357-646, bmps/impl/bmps_walker.h:13-465.
+ * A walker holds the fork of the top BMPS of stack `pos` for every Monte-Carlo walker of the context (deep copy; the stacks are not
+ * touched afterwards), its stack-size counter and its own LEFT / RIGHT BTen caches.  The TransferMPO the calls below absorb / sandwich
+ * is named once with pepsgpu_walker_set_mpo: slice `num` of the network (a row for UP / DOWN walkers, a column for LEFT / RIGHT)
+ *   states == NULL && tensors == NULL : under the walkers' current configurations,
+ *   states  [n][N] (N = slice length)  : with the given SITPS component at every site of the slice, per walker (an excited row),
+ *   tensors [n_tensors][N][D^4]        : explicit site tensors, float64 (interleaved pairs for PEPSGPU_C128), leg order (L, D, R, U)
+ *                                        zero padded to D, leg dims of the slice's sites; n_tensors = 1 (shared) or n -- an MPO that is
+ *                                        NOT a row of the context's network (Evolve(const TransferMPO &), bmps_walker.h:13-21).
+ * The opposite boundary of the row operations is level `opp_level` of the DOWN stack (down_stack[opp_level] of the reference's tests:
+ * the boundary that has absorbed opp_level rows from below); only the UP walker / DOWN opposite pair is supported, as in the reference
+ * (bmps_walker.h:114-118: anything else -> PEPSGPU_EINVAL).  Errors of the reference's runtime_error checks -> PEPSGPU_ESTATE.
+ * A walker dies with pepsgpu_walkers_set_configs (it is a fork of the old configurations' stacks). */
+/* level < 0: GetWalker(tn, pos) :51-58 (fork of the top of the stack); level >= 0: BMPSWalker(tn, stack[level], pos, level + 1,
+ * trunc_params), the constructor the structure-factor mixin uses on the vacuum (structure_factor_measurement_mixin.h:121-122) */
+int pepsgpu_walker_create(pepsgpu_ctx *ctx, int pos, int level, int *walker_out);
+/* copy construction (`auto excited_walker = main_walker;`, :134); the BTen caches of the copy start empty */
+int pepsgpu_walker_clone(pepsgpu_ctx *ctx, int walker, int *walker_out);
+int pepsgpu_walker_destroy(pepsgpu_ctx *ctx, int walker);
+/* GetPosition / GetStackSize / GetBTenLeftCol / GetBTenRightCol (any pointer may be NULL) */
+int pepsgpu_walker_info(pepsgpu_ctx *ctx, int walker, int *pos_out, int *stack_size_out, int *bten_left_col_out, int *bten_right_col_out);
+int pepsgpu_walker_set_mpo(pepsgpu_ctx *ctx, int walker, int num, const int32_t *states, const double *tensors, int n_tensors);
+int pepsgpu_walker_evolve(pepsgpu_ctx *ctx, int walker);                                     /* Evolve(mpo)               :13-21  */
+int pepsgpu_walker_evolve_step(pepsgpu_ctx *ctx, int walker);                                /* EvolveStep()              :23-49  */
+int pepsgpu_walker_contract_row(pepsgpu_ctx *ctx, int walker, int opp_level, double *out);   /* ContractRow(mpo, opp)     :60-214 */
+int pepsgpu_walker_init_bten(pepsgpu_ctx *ctx, int walker, int opp_level, int position, int target_col);   /* InitBTenLeft / Right :216-272 */
+int pepsgpu_walker_grow_bten_step(pepsgpu_ctx *ctx, int walker, int opp_level, int position);   /* GrowBTenLeftStep / RightStep :274-324 */
+int pepsgpu_walker_shift_bten_window(pepsgpu_ctx *ctx, int walker, int opp_level, int position);   /* ShiftBTenWindow       :326-350 */
+/* TraceWithBTen(site, site_col, opp) :352-392 (two_site = 0) / TraceWithTwoSiteBTen(site_a, site_b, site_col, mpo, opp) :394-463
+ * (two_site = 1).  The replacement site(s): site_states [n] ([n][2]) = SITPS component per walker, or site_tensors
+ * [n_tensors] ([n_tensors][2]) [D^4] explicit (layout as above), or both NULL = the MPO's own tensors.  out [n]. */
+int pepsgpu_walker_trace_with_bten(pepsgpu_ctx *ctx, int walker, int opp_level, int site_col, int two_site, const int32_t *site_states,
+                                   const double *site_tensors, int n_tensors, double *out);
+int pepsgpu_walker_clear_bten(pepsgpu_ctx *ctx, int walker);                                  /* ClearBTen()                       */
+/* GetBMPS()[idx] of the walker (as pepsgpu_get_bmps_tensor) */
+int pepsgpu_walker_get_bmps_tensor(pepsgpu_ctx *ctx, int walker, int idx, int *dims_out, double *data_out, double *logscale_out);
 int pepsgpu_generate_bmps_approach(pepsgpu_ctx *ctx, int pos);  /* GenerateBMPSApproach      :11-17   */
 int pepsgpu_bmps_stack_size(pepsgpu_ctx *ctx, int pos);         /* GetBMPS(pos).size(); <0 on error */
 /* GetBMPS(pos)[level][idx]: dims_out[3]; data_out [n][d0*d1*d2] float64 (may be NULL);

@@ -387,6 +387,212 @@ class BMPSContractor:
 
 
 # =================================================================================================
+# BMPSWalker (bmps_contractor.h:357-646, bmps/impl/bmps_walker.h:13-465; bosonic branches of bten_operations.h:60-277)
+# =================================================================================================
+class BMPSWalker:
+    """A boundary MPS forked from a contractor stack that evolves on its own (Evolve with ANY TransferMPO, EvolveStep along the
+    lattice), is closed against a named opposite boundary (ContractRow) and keeps its own LEFT / RIGHT BTen caches for
+    multi-site traces on one row.  Only the UP walker / DOWN opposite pair is supported by the row operations, as in the
+    reference (bmps_walker.h:114-118)."""
+
+    def __init__(self, tn, bmps, pos, current_stack_size, trunc_params):
+        self.tn, self.bmps, self.pos, self.stack_size, self.trunc = tn, bmps, pos, current_stack_size, trunc_params
+        self.bten_left, self.bten_right = [], []
+        self.bten_left_col, self.bten_right_col = 0, 0
+
+    # -- evolution (bmps_walker.h:13-49) ---------------------------------------------------
+    def Evolve(self, mpo):
+        p = self.trunc
+        self.bmps = self.bmps.multiply_mpo(list(mpo), p.compress_scheme, p.D_min, p.D_max, p.trunc_err, p.convergence_tol, p.iter_max)
+
+    def EvolveStep(self):
+        assert self.stack_size > 0
+        if self.pos in (UP, LEFT):
+            mpo_num = self.stack_size - 1
+        elif self.pos == DOWN:
+            mpo_num = self.tn.rows - self.stack_size
+        else:
+            mpo_num = self.tn.cols - self.stack_size
+        if self.pos == UP and mpo_num >= self.tn.rows - 1:
+            return
+        if self.pos == LEFT and mpo_num >= self.tn.cols - 1:
+            return
+        self.Evolve(self.tn.get_slice(mpo_num, rotate(orientation(self.pos))))
+        self.stack_size += 1
+
+    def GetStackSize(self):
+        return self.stack_size
+
+    def GetPosition(self):
+        return self.pos
+
+    def GetBMPS(self):
+        return self.bmps
+
+    # -- row closure (bmps_walker.h:60-214) ---------------------------------------------------
+    def _check(self, mpo, opp, what):
+        n = len(self.bmps)
+        if n == 0 or len(mpo) != n or len(opp) != n:
+            raise RuntimeError("BMPSWalker::%s: Size mismatch." % what)
+        return n
+
+    def ContractRow(self, mpo, opposite_boundary):
+        n = self._check(mpo, opposite_boundary, "ContractRow")
+        if self.pos != UP or opposite_boundary.position != DOWN:
+            raise RuntimeError("BMPSWalker::ContractRow: Unsupported direction pair. Walker must be UP, opposite must be DOWN.")
+        acc = None
+        for i in range(n):
+            col = n - 1 - i
+            top, site, bot = self.bmps[i], mpo[col], opposite_boundary[col]
+            top_site = T.contract(top, [1], site, [3])            # (top_L, top_R, site_L, site_D, site_R)
+            column = T.contract(top_site, [3], bot, [1])          # (top_L, top_R, site_L, site_R, bot_L, bot_R)
+            if i == 0:
+                acc = column
+            elif i == 1:
+                acc = T.contract(acc, [1, 2, 4], column, [0, 3, 5])
+            else:
+                acc = T.contract(acc, [3, 4, 5], column, [0, 3, 5])
+        if acc.size != 1:
+            raise RuntimeError("BMPSWalker::ContractRow: Resulting accumulator is not a scalar.")
+        return acc.reshape(())[()]
+
+    # -- BTen caches (bmps_walker.h:216-463) ----------------------------------------------------
+    @staticmethod
+    def _vacuum(d0, d1, d2, dtype):
+        v = np.zeros((d0, d1, d2), dtype=dtype)
+        v[0, 0, 0] = 1.0
+        return v
+
+    @staticmethod
+    def _grow_left(bten, up_mps, site, down_mps):
+        """bten_ops::GrowBTenLeftStep (bten_operations.h:149-183)"""
+        tmp1 = T.contract_cyclic(up_mps, bten, 2, 0, 1)
+        tmp2 = T.contract_cyclic(tmp1, site, 1, 3, 2)
+        return T.contract(tmp2, [0, 2], down_mps, [0, 1])
+
+    @staticmethod
+    def _grow_right(bten, down_mps, site, up_mps):
+        """bten_ops::GrowBTenRightStep (:203-233)"""
+        tmp1 = T.contract_cyclic(down_mps, bten, 2, 0, 1)
+        tmp2 = T.contract_cyclic(tmp1, site, 1, 1, 2)
+        return T.contract(tmp2, [0, 2], up_mps, [0, 1])
+
+    @staticmethod
+    def _trace(up_mps, left_bten, site, down_mps, right_bten):
+        """bten_ops::TraceBTen (:251-277)"""
+        t0 = T.contract_cyclic(up_mps, left_bten, 2, 0, 1)
+        t1 = T.contract_cyclic(t0, site, 1, 3, 2)
+        t2 = T.contract(t1, [0, 2], down_mps, [0, 1])
+        return T.contract(t2, [0, 1, 2], right_bten, [2, 1, 0])[()]
+
+    def _left_vacuum(self, mpo, opp):
+        n = len(self.bmps)
+        return self._vacuum(self.bmps[n - 1].shape[2], mpo[0].shape[0], opp[0].shape[0], mpo[0].dtype)
+
+    def InitBTenLeft(self, mpo, opposite_boundary, target_col):
+        n = self._check(mpo, opposite_boundary, "InitBTenLeft")
+        self.bten_left = [self._left_vacuum(mpo, opposite_boundary)]
+        self.bten_left_col = 0
+        while self.bten_left_col < target_col and self.bten_left_col < n:
+            self.GrowBTenLeftStep(mpo, opposite_boundary)
+
+    def InitBTenRight(self, mpo, opposite_boundary, target_col):
+        n = self._check(mpo, opposite_boundary, "InitBTenRight")
+        self.bten_right = [self._vacuum(opposite_boundary[n - 1].shape[2], mpo[n - 1].shape[2], self.bmps[0].shape[0], mpo[0].dtype)]
+        self.bten_right_col = n
+        while self.bten_right_col > target_col + 1 and self.bten_right_col > 0:
+            self.GrowBTenRightStep(mpo, opposite_boundary)
+
+    def GrowBTenLeftStep(self, mpo, opposite_boundary):
+        n = self._check(mpo, opposite_boundary, "GrowBTenLeftStep")
+        if not self.bten_left:
+            if self.bten_left_col != 0:
+                raise RuntimeError("BMPSWalker::GrowBTenLeftStep: bten_left_ is empty but col != 0")
+            self.bten_left = [self._left_vacuum(mpo, opposite_boundary)]
+        if self.bten_left_col >= n:
+            raise RuntimeError("BMPSWalker::GrowBTenLeftStep: Cannot grow beyond N.")
+        col = self.bten_left_col
+        self.bten_left.append(self._grow_left(self.bten_left[-1], self.bmps[n - 1 - col], mpo[col], opposite_boundary[col]))
+        self.bten_left_col += 1
+
+    def GrowBTenRightStep(self, mpo, opposite_boundary):
+        n = len(self.bmps)
+        if not self.bten_right:
+            raise RuntimeError("BMPSWalker::GrowBTenRightStep: Right BTen cache is empty. Call InitBTenRight first.")
+        if self.bten_right_col == 0:
+            raise RuntimeError("BMPSWalker::GrowBTenRightStep: Cannot grow further left. col is already 0.")
+        col = self.bten_right_col - 1
+        self.bten_right.append(self._grow_right(self.bten_right[-1], opposite_boundary[col], mpo[col], self.bmps[n - 1 - col]))
+        self.bten_right_col -= 1
+
+    def ShiftBTenWindow(self, mpo, opposite_boundary, position):
+        if position == LEFT:
+            if not self.bten_left:
+                raise RuntimeError("BMPSWalker::ShiftBTenWindow: Left BTen cache is empty.")
+            self.bten_left.pop()
+            self.bten_left_col -= 1
+            self.GrowBTenRightStep(mpo, opposite_boundary)
+        else:
+            if not self.bten_right:
+                raise RuntimeError("BMPSWalker::ShiftBTenWindow: Right BTen cache is empty.")
+            self.bten_right.pop()
+            self.bten_right_col += 1
+            self.GrowBTenLeftStep(mpo, opposite_boundary)
+
+    def TraceWithBTen(self, site, site_col, opposite_boundary):
+        n = len(self.bmps)
+        if not self.bten_left or not self.bten_right:
+            raise RuntimeError("BMPSWalker::TraceWithBTen: BTen caches not initialized.")
+        if self.bten_left_col < site_col:
+            raise RuntimeError("BMPSWalker::TraceWithBTen: Left BTen insufficient.")
+        if self.bten_right_col > site_col + 1:
+            raise RuntimeError("BMPSWalker::TraceWithBTen: Right BTen insufficient.")
+        right_idx = n - 1 - site_col
+        if right_idx >= len(self.bten_right):
+            raise RuntimeError("BMPSWalker::TraceWithBTen: Right BTen index out of bounds.")
+        return self._trace(self.bmps[n - 1 - site_col], self.bten_left[site_col], site, opposite_boundary[site_col],
+                           self.bten_right[right_idx])
+
+    def TraceWithTwoSiteBTen(self, site_a, site_b, site_col, mpo, opposite_boundary):
+        n = len(self.bmps)
+        if site_col + 1 >= n:
+            raise RuntimeError("BMPSWalker::TraceWithTwoSiteBTen: site_col+1 out of bounds.")
+        if not self.bten_left or not self.bten_right:
+            raise RuntimeError("BMPSWalker::TraceWithTwoSiteBTen: BTen caches not initialized.")
+        if self.bten_left_col < site_col:
+            raise RuntimeError("BMPSWalker::TraceWithTwoSiteBTen: Left BTen insufficient.")
+        if self.bten_right_col > site_col + 2:
+            raise RuntimeError("BMPSWalker::TraceWithTwoSiteBTen: Right BTen insufficient.")
+        if site_col >= len(self.bten_left):
+            raise RuntimeError("BMPSWalker::TraceWithTwoSiteBTen: Left BTen index out of bounds.")
+        right_idx = n - 2 - site_col
+        if right_idx >= len(self.bten_right):
+            raise RuntimeError("BMPSWalker::TraceWithTwoSiteBTen: Right BTen index out of bounds.")
+        mid = self._grow_left(self.bten_left[site_col], self.bmps[n - 1 - site_col], site_a, opposite_boundary[site_col])
+        return self._trace(self.bmps[n - 2 - site_col], mid, site_b, opposite_boundary[site_col + 1], self.bten_right[right_idx])
+
+    def ClearBTen(self):
+        self.bten_left, self.bten_right = [], []
+        self.bten_left_col = self.bten_right_col = 0
+
+    def GetBTenLeftCol(self):
+        return self.bten_left_col
+
+    def GetBTenRightCol(self):
+        return self.bten_right_col
+
+
+def _get_walker(self, tn, position):
+    """BMPSContractor::GetWalker (bmps_walker.h:51-58): a copy of the top of the stack"""
+    stack = self.bmps_set[position]
+    assert stack, "Cannot create Walker from empty BMPS stack"
+    return BMPSWalker(tn, stack[-1].copy(), position, len(stack), self.GetTruncateParams())
+
+
+BMPSContractor.GetWalker = _get_walker
+
+
+# =================================================================================================
 # Two-row (rank-4) environments and NNN / third-neighbour / sqrt(5) replacement traces
 # (bmps_contractor_init.h:130-186, bmps_contractor_grow.h:375-527, bmps_contractor_helpers.h:12-180,
 #  bmps_contractor_trace.h:207-536; bosonic branches).  Added as methods of BMPSContractor.

@@ -26,6 +26,9 @@ SYMBOLS = [
     "pepsgpu_walkers_set_configs", "pepsgpu_walkers_get_configs", "pepsgpu_n_walkers",
     "pepsgpu_grow_bmps_step", "pepsgpu_grow_full_bmps", "pepsgpu_grow_bmps_for_row", "pepsgpu_grow_bmps_for_col",
     "pepsgpu_shift_bmps_window", "pepsgpu_delete_inner_bmps", "pepsgpu_bmps_park", "pepsgpu_bmps_unpark", "pepsgpu_generate_bmps_approach",
+    "pepsgpu_walker_create", "pepsgpu_walker_clone", "pepsgpu_walker_destroy", "pepsgpu_walker_info", "pepsgpu_walker_set_mpo", "pepsgpu_walker_evolve",
+    "pepsgpu_walker_evolve_step", "pepsgpu_walker_contract_row", "pepsgpu_walker_init_bten", "pepsgpu_walker_grow_bten_step",
+    "pepsgpu_walker_shift_bten_window", "pepsgpu_walker_trace_with_bten", "pepsgpu_walker_clear_bten", "pepsgpu_walker_get_bmps_tensor",
     "pepsgpu_bmps_stack_size", "pepsgpu_get_bmps_tensor", "pepsgpu_init_bten", "pepsgpu_grow_full_bten",
     "pepsgpu_grow_bten_step", "pepsgpu_shift_bten_window", "pepsgpu_truncate_bten", "pepsgpu_bten_stack_size",
     "pepsgpu_trace", "pepsgpu_replace_nn_trace", "pepsgpu_replace_one_trace", "pepsgpu_punch_hole",
@@ -93,6 +96,20 @@ def load_library(path=LIB_PATH):
     lib.pepsgpu_comm_rank.argtypes = [vp]
     lib.pepsgpu_comm_destroy.argtypes = [vp]
     lib.pepsgpu_allreduce.argtypes = [vp, vp, C.c_long, C.c_int, C.c_int, C.c_int]
+    lib.pepsgpu_walker_create.argtypes = [vp, C.c_int, C.c_int, ip]
+    lib.pepsgpu_walker_clone.argtypes = [vp, C.c_int, ip]
+    lib.pepsgpu_walker_destroy.argtypes = [vp, C.c_int]
+    lib.pepsgpu_walker_info.argtypes = [vp, C.c_int, ip, ip, ip, ip]
+    lib.pepsgpu_walker_set_mpo.argtypes = [vp, C.c_int, C.c_int, ip, dp, C.c_int]
+    lib.pepsgpu_walker_evolve.argtypes = [vp, C.c_int]
+    lib.pepsgpu_walker_evolve_step.argtypes = [vp, C.c_int]
+    lib.pepsgpu_walker_contract_row.argtypes = [vp, C.c_int, C.c_int, dp]
+    lib.pepsgpu_walker_init_bten.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.pepsgpu_walker_grow_bten_step.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    lib.pepsgpu_walker_shift_bten_window.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    lib.pepsgpu_walker_trace_with_bten.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp, C.c_int, dp]
+    lib.pepsgpu_walker_clear_bten.argtypes = [vp, C.c_int]
+    lib.pepsgpu_walker_get_bmps_tensor.argtypes = [vp, C.c_int, C.c_int, ip, dp, dp]
     lib.pepsgpu_sr_begin.argtypes = [vp, C.c_int]
     lib.pepsgpu_sr_append.argtypes = [vp, dp]
     lib.pepsgpu_sr_count.argtypes = [vp]
@@ -227,6 +244,13 @@ class Context:
         ls = np.zeros(self.n, dtype=np.float64)
         self._ck(self._l.pepsgpu_get_bmps_tensor(self._h, pos, level, idx, _ip(dims), _dp(data), _dp(ls)))
         return data, ls
+
+    def get_walker(self, pos, level=-1):
+        """BMPSContractor::GetWalker(tn, pos) (bmps_walker.h:51-58): a Walker object forked from the top of stack `pos`
+        (level >= 0: from that level of the stack, BMPSWalker(tn, stack[level], pos, level + 1, params))"""
+        wid = np.zeros(1, dtype=np.int32)
+        self._ck(self._l.pepsgpu_walker_create(self._h, pos, level, _ip(wid)))
+        return Walker(self, int(wid[0]))
 
     def trace(self, row, col, bond_dir):
         out = np.zeros(self.n, dtype=self._ot)
@@ -606,3 +630,97 @@ def diag_jacobi(dtype, M, k, force_global=False):
     if rc != 0:
         raise RuntimeError("diag_jacobi failed: %s" % lib().pepsgpu_last_error(None).decode())
     return M, Vt, S, sw & 0xFF      # high bits: diagnostics (rows above the noise floor at entry)
+
+
+class Walker:
+    """BMPSContractor::BMPSWalker (bmps_contractor.h:357-646) for all Monte-Carlo walkers of a context: method names follow the
+    reference.  The TransferMPO is set once (set_mpo / set_mpo_states / set_mpo_tensors); `opp_level` names the opposite
+    boundary = level of the DOWN stack (down_stack[opp_level] in the reference's tests)."""
+
+    def __init__(self, ctx, wid):
+        self.ctx, self.wid = ctx, wid
+
+    def _info(self):
+        v = np.zeros(4, dtype=np.int32)
+        c = self.ctx
+        c._ck(c._l.pepsgpu_walker_info(c._h, self.wid, _ip(v[0:1]), _ip(v[1:2]), _ip(v[2:3]), _ip(v[3:4])))
+        return v
+
+    def GetPosition(self): return int(self._info()[0])
+    def GetStackSize(self): return int(self._info()[1])
+    def GetBTenLeftCol(self): return int(self._info()[2])
+    def GetBTenRightCol(self): return int(self._info()[3])
+
+    def set_mpo(self, num):
+        c = self.ctx
+        c._ck(c._l.pepsgpu_walker_set_mpo(c._h, self.wid, num, None, None, 0))
+
+    def set_mpo_states(self, num, states):
+        c = self.ctx
+        st = np.ascontiguousarray(states, dtype=np.int32)
+        assert st.ndim == 2 and st.shape[0] == c.n
+        c._ck(c._l.pepsgpu_walker_set_mpo(c._h, self.wid, num, _ip(st), None, 0))
+
+    def set_mpo_tensors(self, num, tensors):
+        """tensors [nt][N][D][D][D][D] (leg order L, D, R, U, zero padded to D), nt = 1 or n"""
+        c = self.ctx
+        t = np.ascontiguousarray(tensors, dtype=c._ot)
+        assert t.ndim == 6 and t.shape[2:] == (c.D,) * 4
+        c._ck(c._l.pepsgpu_walker_set_mpo(c._h, self.wid, num, None, _dp(t), t.shape[0]))
+
+    def Evolve(self): self.ctx._ck(self.ctx._l.pepsgpu_walker_evolve(self.ctx._h, self.wid))
+    def EvolveStep(self): self.ctx._ck(self.ctx._l.pepsgpu_walker_evolve_step(self.ctx._h, self.wid))
+
+    def ContractRow(self, opp_level):
+        c = self.ctx
+        out = np.zeros(c.n, dtype=c._ot)
+        c._ck(c._l.pepsgpu_walker_contract_row(c._h, self.wid, opp_level, _dp(out)))
+        return out
+
+    def InitBTenLeft(self, opp_level, target_col): self.ctx._ck(self.ctx._l.pepsgpu_walker_init_bten(self.ctx._h, self.wid, opp_level, LEFT, target_col))
+    def InitBTenRight(self, opp_level, target_col): self.ctx._ck(self.ctx._l.pepsgpu_walker_init_bten(self.ctx._h, self.wid, opp_level, RIGHT, target_col))
+    def GrowBTenLeftStep(self, opp_level): self.ctx._ck(self.ctx._l.pepsgpu_walker_grow_bten_step(self.ctx._h, self.wid, opp_level, LEFT))
+    def GrowBTenRightStep(self, opp_level): self.ctx._ck(self.ctx._l.pepsgpu_walker_grow_bten_step(self.ctx._h, self.wid, opp_level, RIGHT))
+    def ShiftBTenWindow(self, opp_level, position): self.ctx._ck(self.ctx._l.pepsgpu_walker_shift_bten_window(self.ctx._h, self.wid, opp_level, position))
+    def ClearBTen(self): self.ctx._ck(self.ctx._l.pepsgpu_walker_clear_bten(self.ctx._h, self.wid))
+
+    def _trace(self, opp_level, site_col, two, states, tensors):
+        c = self.ctx
+        out = np.zeros(c.n, dtype=c._ot)
+        st = None if states is None else np.ascontiguousarray(states, dtype=np.int32)
+        tt = None if tensors is None else np.ascontiguousarray(tensors, dtype=c._ot)
+        nt = 0
+        if tt is not None:
+            tt = tt.reshape((-1,) + ((2,) if two else ()) + (c.D,) * 4)
+            nt = tt.shape[0]
+        c._ck(c._l.pepsgpu_walker_trace_with_bten(c._h, self.wid, opp_level, site_col, int(two), None if st is None else _ip(st),
+                                                  None if tt is None else _dp(tt), nt, _dp(out)))
+        return out
+
+    def TraceWithBTen(self, opp_level, site_col, states=None, tensors=None):
+        """states [n] (SITPS component per walker) or tensors [nt][D^4]; neither: the MPO's own tensor"""
+        return self._trace(opp_level, site_col, False, states, tensors)
+
+    def TraceWithTwoSiteBTen(self, opp_level, site_col, states=None, tensors=None):
+        """states [n][2] or tensors [nt][2][D^4]"""
+        return self._trace(opp_level, site_col, True, states, tensors)
+
+    def GetBMPSTensor(self, idx):
+        c = self.ctx
+        dims = np.zeros(3, dtype=np.int32)
+        c._ck(c._l.pepsgpu_walker_get_bmps_tensor(c._h, self.wid, idx, _ip(dims), None, None))
+        data = np.zeros((c.n,) + tuple(int(x) for x in dims), dtype=c._ot)
+        ls = np.zeros(c.n, dtype=np.float64)
+        c._ck(c._l.pepsgpu_walker_get_bmps_tensor(c._h, self.wid, idx, _ip(dims), _dp(data), _dp(ls)))
+        return data, ls
+
+    def clone(self):
+        """copy construction (`auto excited_walker = main_walker;`)"""
+        wid = np.zeros(1, dtype=np.int32)
+        self.ctx._ck(self.ctx._l.pepsgpu_walker_clone(self.ctx._h, self.wid, _ip(wid)))
+        return Walker(self.ctx, int(wid[0]))
+
+    def destroy(self):
+        if self.wid is not None:
+            self.ctx._ck(self.ctx._l.pepsgpu_walker_destroy(self.ctx._h, self.wid))
+            self.wid = None

@@ -6,6 +6,7 @@
 #include "engine_sr.h"
 #include "engine_var.h"
 #include "engine_cplx.h"
+#include "engine_walker.h"
 #include "comm.h"
 
 using namespace pepsgpu;
@@ -117,6 +118,43 @@ int pepsgpu_grow_bmps_for_row(pepsgpu_ctx *ctx, int row) { CTX_CALL(ctx->eng->gr
 int pepsgpu_grow_bmps_for_col(pepsgpu_ctx *ctx, int col) { CTX_CALL(ctx->eng->grow_bmps_for_col(col)); }
 int pepsgpu_shift_bmps_window(pepsgpu_ctx *ctx, int pos) { CTX_CALL(check_pos(pos); ctx->eng->shift_bmps_window(pos)); }
 int pepsgpu_delete_inner_bmps(pepsgpu_ctx *ctx, int pos) { CTX_CALL(check_pos(pos); ctx->eng->delete_inner_bmps(pos)); }
+int pepsgpu_walker_create(pepsgpu_ctx *ctx, int pos, int level, int *walker_out) {
+  CTX_CALL(check_pos(pos); PG_REQUIRE(walker_out != nullptr, 1, "null output"); *walker_out = ctx->eng->walker_create(pos, level));
+}
+int pepsgpu_walker_clone(pepsgpu_ctx *ctx, int walker, int *walker_out) {
+  CTX_CALL(PG_REQUIRE(walker_out != nullptr, 1, "null output"); *walker_out = ctx->eng->walker_clone(walker));
+}
+int pepsgpu_walker_destroy(pepsgpu_ctx *ctx, int walker) { CTX_CALL(ctx->eng->walker_destroy(walker)); }
+int pepsgpu_walker_info(pepsgpu_ctx *ctx, int walker, int *pos_out, int *stack_size_out, int *bten_left_col_out, int *bten_right_col_out) {
+  CTX_CALL(ctx->eng->walker_info(walker, pos_out, stack_size_out, bten_left_col_out, bten_right_col_out));
+}
+int pepsgpu_walker_set_mpo(pepsgpu_ctx *ctx, int walker, int num, const int32_t *states, const double *tensors, int n_tensors) {
+  CTX_CALL(ctx->eng->walker_set_mpo(walker, num, states, tensors, n_tensors));
+}
+int pepsgpu_walker_evolve(pepsgpu_ctx *ctx, int walker) { CTX_CALL(ctx->eng->walker_evolve(walker)); }
+int pepsgpu_walker_evolve_step(pepsgpu_ctx *ctx, int walker) { CTX_CALL(ctx->eng->walker_evolve_step(walker)); }
+int pepsgpu_walker_contract_row(pepsgpu_ctx *ctx, int walker, int opp_level, double *out) {
+  CTX_CALL(PG_REQUIRE(out != nullptr, 1, "null output"); ctx->eng->walker_contract_row(walker, opp_level, out));
+}
+int pepsgpu_walker_init_bten(pepsgpu_ctx *ctx, int walker, int opp_level, int position, int target_col) {
+  CTX_CALL(ctx->eng->walker_init_bten(walker, opp_level, position, target_col));
+}
+int pepsgpu_walker_grow_bten_step(pepsgpu_ctx *ctx, int walker, int opp_level, int position) {
+  CTX_CALL(ctx->eng->walker_grow_bten_step(walker, opp_level, position));
+}
+int pepsgpu_walker_shift_bten_window(pepsgpu_ctx *ctx, int walker, int opp_level, int position) {
+  CTX_CALL(ctx->eng->walker_shift_bten_window(walker, opp_level, position));
+}
+int pepsgpu_walker_trace_with_bten(pepsgpu_ctx *ctx, int walker, int opp_level, int site_col, int two_site, const int32_t *site_states,
+                                   const double *site_tensors, int n_tensors, double *out) {
+  CTX_CALL(PG_REQUIRE(out != nullptr, 1, "null output");
+           PG_REQUIRE(!(site_states && site_tensors), 1, "name the replacement by states OR by tensors");
+           ctx->eng->walker_trace(walker, opp_level, site_col, two_site, site_states, site_tensors, n_tensors, out));
+}
+int pepsgpu_walker_clear_bten(pepsgpu_ctx *ctx, int walker) { CTX_CALL(ctx->eng->walker_clear_bten(walker)); }
+int pepsgpu_walker_get_bmps_tensor(pepsgpu_ctx *ctx, int walker, int idx, int *dims_out, double *data_out, double *logscale_out) {
+  CTX_CALL(PG_REQUIRE(dims_out != nullptr, 1, "null dims"); ctx->eng->walker_get_tensor(walker, idx, dims_out, data_out, logscale_out));
+}
 int pepsgpu_bmps_park(pepsgpu_ctx *ctx, int pos, int keep_levels) { CTX_CALL(check_pos(pos); ctx->eng->bmps_park(pos, keep_levels)); }
 int pepsgpu_bmps_unpark(pepsgpu_ctx *ctx, int pos) { CTX_CALL(check_pos(pos); ctx->eng->bmps_unpark(pos)); }
 int pepsgpu_generate_bmps_approach(pepsgpu_ctx *ctx, int pos) {

@@ -102,6 +102,22 @@ struct EngineBase {
   virtual void sr_gram(const void *remote_o, const int32_t *remote_cfg, int n_remote, double *out) = 0;
   virtual void sr_weighted_sum(const double *y, double *out) = 0;
   virtual void sr_copy_samples(void *dst_o, int32_t *dst_cfg) = 0;
+  // BMPSWalker (bmps_contractor.h:357-646)
+  virtual int walker_create(int pos, int level) = 0;
+  virtual int walker_clone(int id) = 0;
+  virtual void walker_destroy(int id) = 0;
+  virtual void walker_info(int id, int *pos, int *stack, int *lcol, int *rcol) = 0;
+  virtual void walker_set_mpo(int id, int num, const int32_t *states, const double *tensors, int n_tensors) = 0;
+  virtual void walker_evolve(int id) = 0;
+  virtual void walker_evolve_step(int id) = 0;
+  virtual void walker_contract_row(int id, int opp_level, double *out) = 0;
+  virtual void walker_init_bten(int id, int opp_level, int side, int target_col) = 0;
+  virtual void walker_grow_bten_step(int id, int opp_level, int side) = 0;
+  virtual void walker_shift_bten_window(int id, int opp_level, int side) = 0;
+  virtual void walker_trace(int id, int opp_level, int site_col, int two_site, const int32_t *states, const double *tensors,
+                            int n_tensors, double *out) = 0;
+  virtual void walker_clear_bten(int id) = 0;
+  virtual void walker_get_tensor(int id, int idx, int *dims, double *out, double *logscale) = 0;
   virtual void profile_enable(int on) = 0;
   virtual void profile_read(double *out) = 0;   // [PROF_NCAT = 11][5]: ms, launches, algorithmic flops, executed flops, operand+result bytes
 };
@@ -234,6 +250,7 @@ class Engine : public EngineBase {
     PG_CHECK_HIP(hipMemsetAsync(flag_, 0, sizeof(int) * (size_t)maxw_, stream_));
     PG_CHECK_HIP(hipStreamSynchronize(stream_));
     // Init(tn): bmps_contractor_init.h:25-32
+    walkers_clear();     // a BMPSWalker is a fork of the old configurations' stacks
     for (int p = 0; p < 4; ++p) {
       for (auto &b : parked_[p]) free_bmps(b);
       parked_[p].clear();
@@ -855,6 +872,22 @@ class Engine : public EngineBase {
     for (int i = 0; i < n && i < 9; ++i) out[i] = v[i];
   }
   hipStream_t stream() const { return stream_; }
+  // ---- BMPSWalker (engine_walker.h) ----
+  int walker_create(int pos, int level) override;
+  int walker_clone(int id) override;
+  void walker_destroy(int id) override;
+  void walker_info(int id, int *pos, int *stack, int *lcol, int *rcol) override;
+  void walker_set_mpo(int id, int num, const int32_t *states, const double *tensors, int n_tensors) override;
+  void walker_evolve(int id) override;
+  void walker_evolve_step(int id) override;
+  void walker_contract_row(int id, int opp_level, double *out) override;
+  void walker_init_bten(int id, int opp_level, int side, int target_col) override;
+  void walker_grow_bten_step(int id, int opp_level, int side) override;
+  void walker_shift_bten_window(int id, int opp_level, int side) override;
+  void walker_trace(int id, int opp_level, int site_col, int two_site, const int32_t *states, const double *tensors, int n_tensors,
+                    double *out) override;
+  void walker_clear_bten(int id) override;
+  void walker_get_tensor(int id, int idx, int *dims, double *out, double *logscale) override;
 
   // ---- per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----
   void profile_enable(int on) override {
@@ -925,9 +958,23 @@ class Engine : public EngineBase {
     int r, c;
     const int *sel;   // device selector (configuration or candidate table)
     int inc;          // selector stride per batch entry
+    const T *base = nullptr;   // tensor store the selector indexes (nullptr: the SITPS slot of site (r, c))
   };
-  SiteSel cfg_site(int r, int c) const { return SiteSel{r, c, cfg_ + r * Lx_ + c, Ly_ * Lx_}; }
+  // The site tensor of (r, c) under the walkers' configurations -- or, while a BMPSWalker operation runs (MpoScope,
+  // engine_walker.h), under the walker's MPO on its slice: another configuration table, or explicit tensors.
+  SiteSel cfg_site(int r, int c) const {
+    if (ovr_on_ && (ovr_hor_ ? r : c) == ovr_num_) {
+      if (ovr_tens_) {
+        SiteSel s{r, c, ovr_nt_ == 1 ? iota_ : iota_ + 1, ovr_nt_ == 1 ? 0 : 1};
+        s.base = ovr_tens_ + (long)(ovr_hor_ ? c : r) * ovr_nt_ * slot_;
+        return s;
+      }
+      if (ovr_cfg_) return SiteSel{r, c, ovr_cfg_ + r * Lx_ + c, Ly_ * Lx_};
+    }
+    return SiteSel{r, c, cfg_ + r * Lx_ + c, Ly_ * Lx_};
+  }
   const T *site_base(int r, int c) const { return sitps_ + (long)(r * Lx_ + c) * dp_ * slot_; }
+  const T *sel_base(const SiteSel &ss) const { return ss.base ? ss.base : site_base(ss.r, ss.c); }
 
   enum { INJ_S = 1, INJ_P = 2, INJ_R = 4, INJ_T = 8, INJ_M = 16, INJ_V = 32, INJ_Y = 64, INJ_E = 128 };
   // float64 engine only: round a stored intermediate to float32 (error budget by stage; no-op unless PEPSGPU_INJECT_F32 names it)
@@ -1123,18 +1170,19 @@ class Engine : public EngineBase {
       g.seldivB = 1;
     }
     g.wB = 0;
-    tgemm_launch<T, T, T, T>(stream_, g, A, site_base(ss.r, ss.c), C);
+    tgemm_launch<T, T, T, T>(stream_, g, A, sel_base(ss), C);
   }
 
   // same with the site tensor as the A operand (C[(site legs), (...)]: lanes of the MFMA tile then run
   // along the other operand's contiguous index, which keeps the stores of C coalesced)
-  void launch_site_gemm_a(TGemmDesc &g, const SiteSel &ss, int ncand, const T *B, T *C) {
+  void launch_site_gemm_a(TGemmDesc &g, const SiteSel &ss, int ncand, const T *B, T *C, bool acc64 = false) {
     g.selA = ss.sel;
     g.selA_mul = slot_;
     g.selA_inc = ss.inc;
     g.seldivA = (ss.inc == Ly_ * Lx_) ? ncand : 1;
     g.wA = 0;
-    tgemm_launch<T, T, T, T>(stream_, g, site_base(ss.r, ss.c), B, C);
+    if (acc64) tgemm_launch<T, T, T, Acc>(stream_, g, sel_base(ss), B, C);     // (experiments: float64 accumulation)
+    else tgemm_launch<T, T, T, T>(stream_, g, sel_base(ss), B, C);
   }
 
   void absorb(int pos, int num);
@@ -1225,6 +1273,38 @@ class Engine : public EngineBase {
   double *sr_delta_ = nullptr, *sr_v_ = nullptr, *sr_out_ = nullptr;
   int sr_cap_ = 0, sr_n_ = 0;
   std::vector<uint32_t> sr_map_c_, sr_map_p_;   // compact <-> padded element index of every stored tensor element
+  // ---- BMPSWalker objects (engine_walker.h) ----
+  struct WalkerDev {
+    BMPSDev b;                       // the forked boundary MPS (all walkers of the context)
+    int pos = UP, stack = 0;         // evolution direction, layers absorbed (+1: the vacuum)
+    std::vector<BTenDev> btl, btr;   // walker-owned BTen caches; btl[k] covers columns [0, k), btr[k] columns [N - k, N)
+    int lcol = 0, rcol = 0;          // left edge (exclusive upper bound) / right edge (exclusive lower bound)
+    int mpo_num = -1;                // the current TransferMPO: slice of the network ...
+    int *mpo_cfg = nullptr;          // ... under another configuration table [walker][Ly * Lx] (nullptr: the walkers' own)
+    T *mpo_tens = nullptr;           // ... or explicit tensors [site along the slice][mpo_nt][D^4 slot]
+    int mpo_nt = 0;
+  };
+  struct MpoScope;
+  std::map<int, WalkerDev> walkers_;
+  int next_walker_id_ = 1;
+  int *iota_ = nullptr;              // [0, 0, 1, 2, ...]: selector of explicit tensor sets (iota_ : shared, iota_ + 1 : per walker)
+  bool ovr_on_ = false, ovr_hor_ = true;
+  int ovr_num_ = -1, ovr_nt_ = 0;
+  const int *ovr_cfg_ = nullptr;
+  const T *ovr_tens_ = nullptr;
+  BMPSDev copy_bmps(const BMPSDev &b);
+  BMPSDev absorb_any(int pos, int num, const BMPSDev &in);
+  WalkerDev &walker_ref(int id);
+  void walker_free_bten(WalkerDev &w);
+  void walker_free_mpo(WalkerDev &w);
+  void walkers_clear();
+  void ensure_iota();
+  const BMPSDev &walker_opposite(const WalkerDev &w, int opp_level, const char *what);
+  void walker_grow_left(WalkerDev &w, const BMPSDev &opp);
+  void walker_grow_right(WalkerDev &w, const BMPSDev &opp);
+  SiteSel walker_site(const WalkerDev &w, int col, const int32_t *states, int sstride, const double *tensor, int n_tensors, long tstride,
+                      std::vector<void *> &tmp);
+
   bool dbg_sweeps_ = false;
   int inject_ = 0;                         // PEPSGPU_INJECT_F32 mask (float64 engine, experiments)
 };

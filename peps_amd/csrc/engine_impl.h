@@ -218,6 +218,9 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
   const int ll = (pos + 3) % 4, lp = pos, lr = (pos + 1) % 4, lu = (pos + 2) % 4;
   static const bool adaptive = getenv("PEPSGPU_NO_RANK_ADAPT") == nullptr;
   static const int chain_chunks = getenv("PEPSGPU_CHAIN_CHUNKS") ? atoi(getenv("PEPSGPU_CHAIN_CHUNKS")) : 1;
+  // error-budget experiments (scripts/error_budget.py): contractions of the f32 engine with float64 accumulation, by stage
+  // (1: X / P, 2: Z1 / Tt, 4: M = R Tt, 8: Y = Tt V^T; the separate LDS-tiled launches on the f64 matrix cores)
+  static const int acc64 = (sizeof(T) == 4 && getenv("PEPSGPU_ACC64")) ? atoi(getenv("PEPSGPU_ACC64")) : 0;
 
   // ---------------- forward: R_{i+1} from P_i = R_i (A_i x W_i) ----------------
   std::vector<int> assume_fused(N + 1, 0);   // per carry: the Gram + Cholesky fallback of the fused factor was not launched (hint)
@@ -261,7 +264,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       int chained = 0;
       if constexpr (sizeof(T) == 4) {
         static const bool no_chain = getenv("PEPSGPU_NO_CHAIN") != nullptr;
-        if (!no_chain) {
+        if (!no_chain && !(acc64 & 1)) {
           // both contractions in one launch, X stays in LDS; walkers whose live X does not fit are flagged and take the
           // two separate launches below
           chain_flag = (int *)arena_.alloc(sizeof(int) * nw_);
@@ -273,7 +276,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           mp.mapJ[1] = 1; mp.mapJ[2] = 5;      // J2 = (m, a2): m = I1[1], a2 = J1[2]
           prof_begin(PROF_CHAIN, flx + flp, flx + flp);
           chained = tgemm_chain_launch(stream_, gx, g2, mp, (const float *)R[i].p, (const float *)A.p,
-                                       (const float *)site_base(r, c), (float *)P.p, chain_flag, chain_chunks, hint_dense_carry(in, i));
+                                       (const float *)sel_base(ss), (float *)P.p, chain_flag, chain_chunks, hint_dense_carry(in, i));
           prof_end();
           if (!chained) { arena_.free(chain_flag); chain_flag = nullptr; }
         }
@@ -281,10 +284,11 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       if (chained < 2) {   // the two separate launches: for the entries the chain declined (all of them when it did not run)
         gx.batch_flag = chain_flag; gp.batch_flag = chain_flag;
         prof_begin(PROF_CONTRACT, chain_flag ? 0.0 : flx, chain_flag ? 0.0 : flx);
-        tgemm_launch<T, T, T, T>(stream_, gx, R[i].p, A.p, X.p);
+        if (acc64 & 1) tgemm_launch<T, T, T, Acc>(stream_, gx, R[i].p, A.p, X.p);
+        else tgemm_launch<T, T, T, T>(stream_, gx, R[i].p, A.p, X.p);
         prof_end();
         prof_begin(PROF_CONTRACT, chain_flag ? 0.0 : flp, chain_flag ? 0.0 : flp);
-        launch_site_gemm_a(gp, cfg_site(r, c), 1, X.p, P.p);
+        launch_site_gemm_a(gp, cfg_site(r, c), 1, X.p, P.p, (acc64 & 1) != 0);
         prof_end();
       }
       if (chain_flag) arena_.free(chain_flag);
@@ -473,7 +477,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       int chained = 0;
       if constexpr (sizeof(T) == 4) {
         static const bool no_chain = getenv("PEPSGPU_NO_CHAIN") != nullptr;
-        if (!no_chain) {   // Z1 stays in LDS (see the forward pair)
+        if (!no_chain && !(acc64 & 2)) {   // Z1 stays in LDS (see the forward pair)
           chain_flag = (int *)arena_.alloc(sizeof(int) * nw_);
           TGemmDesc g2 = gt;
           const SiteSel ss = cfg_site(r, c);
@@ -483,7 +487,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           mp.mapJ[1] = 1; mp.mapJ[2] = 5;      // J2 = (a, k2): a = I1[1], k2 = J1[2]
           prof_begin(PROF_CHAIN, 0.0, flz + flt);
           chained = tgemm_chain_launch(stream_, gz, g2, mp, (const float *)A.p, (const float *)Y.p,
-                                       (const float *)site_base(r, c), (float *)Tt.p, chain_flag, chain_chunks, hint_dense_carry(in, i));
+                                       (const float *)sel_base(ss), (float *)Tt.p, chain_flag, chain_chunks, hint_dense_carry(in, i));
           prof_end();
           if (!chained) { arena_.free(chain_flag); chain_flag = nullptr; }
         }
@@ -491,10 +495,11 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       if (chained < 2) {
         gz.batch_flag = chain_flag; gt.batch_flag = chain_flag;
         prof_begin(PROF_CONTRACT, 0.0, chain_flag ? 0.0 : flz);
-        tgemm_launch<T, T, T, T>(stream_, gz, A.p, Y.p, Z1.p);
+        if (acc64 & 2) tgemm_launch<T, T, T, Acc>(stream_, gz, A.p, Y.p, Z1.p);
+        else tgemm_launch<T, T, T, T>(stream_, gz, A.p, Y.p, Z1.p);
         prof_end();
         prof_begin(PROF_CONTRACT, 0.0, chain_flag ? 0.0 : flt);
-        launch_site_gemm_a(gt, cfg_site(r, c), 1, Z1.p, Tt.p);
+        launch_site_gemm_a(gt, cfg_site(r, c), 1, Z1.p, Tt.p, (acc64 & 2) != 0);
         prof_end();
       }
       if (chain_flag) arena_.free(chain_flag);
@@ -536,14 +541,17 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       if constexpr (sizeof(T) == 4) {
         // dense carry: the workgroup-per-walker kernel (mgemm_dense.h): R and Tt through LDS once, eight waves x 32 columns
         static const bool no_mgd = getenv("PEPSGPU_NO_MGEMM_DENSE") != nullptr;
-        if (dense_site && !no_mgd && m > 128 && mgemm_dense_ok(m, la, a, u, k2, R[i].n, Tt.n, R[i].p, Tt.p)) {
+        if (dense_site && !no_mgd && !(acc64 & 4) && m > 128 && mgemm_dense_ok(m, la, a, u, k2, R[i].n, Tt.n, R[i].p, Tt.p)) {
           launch_mgemm_dense(stream_, nw_, (const float *)R[i].p, R[i].n, (const float *)Tt.p, Tt.n, (float *)M.p, M.n, m, la, a, u, k2,
                              tsw ? 1 : 0, (const int *)mdyn[i], mmul[i], (const int *)clive[i], (const int *)kn[i + 1], tg_flop_counter,
                              tg_byte_counter);
           mg_done = true;
         }
       }
-      if (!mg_done) tgemm_launch<T, T, T, T>(stream_, g, R[i].p, Tt.p, M.p);
+      if (!mg_done) {
+        if (acc64 & 4) tgemm_launch<T, T, T, Acc>(stream_, g, R[i].p, Tt.p, M.p);
+        else tgemm_launch<T, T, T, T>(stream_, g, R[i].p, Tt.p, M.p);
+      }
       prof_end();
       inject(INJ_M, M.p, M.n);
     }
@@ -860,6 +868,19 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       prof_end();
     }
     free_ten(M);
+    if constexpr (sizeof(T) == 4) {
+      // rows of Vt orthonormal to float64 accuracy (one Newton-Schulz step, ortho_rows_kernel): the projector V^T V enters the
+      // amplitude at first order at every site
+      static const int ortho = getenv("PEPSGPU_ORTHO_POLISH") ? atoi(getenv("PEPSGPU_ORTHO_POLISH")) : 1;
+      const size_t osm = ortho_rows_smem(k, uk);
+      if (ortho && k >= 2 && k <= 64 && osm <= 96 * 1024) {
+        allow_dynamic_lds(reinterpret_cast<const void *>(&ortho_rows_kernel), osm);
+        prof_begin(PROF_SELECT, 0.0, 0.0);
+        hipLaunchKernelGGL(ortho_rows_kernel, dim3(nw_), dim3(256), osm, stream_, (float *)V.p, V.n, k, uk, (const int *)kn[i], uk + 1);
+        PG_CHECK_HIP(hipGetLastError());
+        prof_end();
+      }
+    }
     inject(INJ_V, V.p, V.n);
     out.t[i] = V;
     // Ynew[(l,a),q] = sum_{(u,k2)} Tt[(l,a),(u,k2)] V[q,(u,k2)]
@@ -887,14 +908,15 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       bool fused_norm = false;
       if constexpr (sizeof(T) == 4) {
         static const bool no_fn = getenv("PEPSGPU_NO_FUSED_NORM") != nullptr;
-        if (!no_fn && bond_adapt && kn[i] && tgemm_one_block_direct(g)) {
+        if (!no_fn && !acc64 && bond_adapt && kn[i] && tgemm_one_block_direct(g)) {
           if (!yscale) yscale = (float *)arena_.alloc(sizeof(float) * nw_);
           g.scale_out = yscale; g.norm_log = out.logscale; g.norm_flag = flag_;
           fused_norm = true;
         }
       }
       prof_begin(PROF_CONTRACT, 2.0 * nw_ * (double)R[i - 1].d[0] * ddp[lu] * (double)m * k, 2.0 * nw_ * (double)la * uk * (double)k);
-      tgemm_launch<T, T, T, T>(stream_, g, Tt.p, V.p, Yn.p);
+      if (acc64 & 8) tgemm_launch<T, T, T, Acc>(stream_, g, Tt.p, V.p, Yn.p);
+      else tgemm_launch<T, T, T, T>(stream_, g, Tt.p, V.p, Yn.p);
       prof_end();
       y_scaled = fused_norm;
     }

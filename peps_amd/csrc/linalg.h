@@ -1649,6 +1649,43 @@ __global__ __launch_bounds__(256) void max_over_walkers_kernel(const int *const 
   if (threadIdx.x == 0) out[blockIdx.x] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
 }
 
+// Rows of Vt made orthonormal to float64 accuracy before they are used (round 4, f32 error budget of DESIGN 3e): one
+// Newton-Schulz step  V <- (3/2 I - 1/2 V V^T) V  with the k x k Gram matrix and the product accumulated in float64 from the
+// float32 rows (k <= 64 live rows of <= 1024 elements, staged in LDS).  The one-sided Jacobi leaves pairs of rows with
+// |cos| up to its threshold 2 sqrt(len) eps32 ~ 2e-6 and norms rounded in float32; V^T V then misses a projector by that
+// much, which enters <S|Psi> at FIRST order and -- on a state whose tensors repeat from site to site -- with the same sign
+// at every site.  After the step the deviation is its square (1e-12), what remains is the storage rounding of V itself.
+__global__ __launch_bounds__(256) void ortho_rows_kernel(float *__restrict__ Vg, long wV, int k, int len,
+                                                         const int *__restrict__ klive, int ld) {
+  extern __shared__ double or_smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int kl = klive ? max(0, min(k, klive[b])) : k;
+  if (kl <= 0) return;
+  double *sC = or_smem;                                   // [kl][kl]
+  float *sV = reinterpret_cast<float *>(sC + k * k);      // [kl][ld], ld = len + 1 (odd: conflict-free column walks)
+  float *V = Vg + (long)b * wV;
+  for (int e = tid; e < kl * len; e += 256) { const int a = e / len, j = e - a * len; sV[a * ld + j] = V[e]; }
+  __syncthreads();
+  for (int e = tid; e < kl * kl; e += 256) {
+    const int a = e / kl, c = e - a * kl;
+    const float *x = sV + a * ld, *y = sV + c * ld;
+    double s0 = 0.0, s1 = 0.0;
+    int j = 0;
+    for (; j + 1 < len; j += 2) { s0 = fma((double)x[j], (double)y[j], s0); s1 = fma((double)x[j + 1], (double)y[j + 1], s1); }
+    if (j < len) s0 = fma((double)x[j], (double)y[j], s0);
+    sC[e] = (a == c ? 1.5 : 0.0) - 0.5 * (s0 + s1);
+  }
+  __syncthreads();
+  for (int e = tid; e < kl * len; e += 256) {
+    const int a = e / len, j = e - a * len;
+    const double *cr = sC + a * kl;
+    double s = 0.0;
+    for (int c = 0; c < kl; ++c) s = fma(cr[c], (double)sV[c * ld + j], s);
+    V[e] = (float)s;
+  }
+}
+inline size_t ortho_rows_smem(int k, int len) { return sizeof(double) * (size_t)k * k + sizeof(float) * (size_t)k * (len + 1); }
+
 // error-budget experiments: a float64 buffer rounded to float32 values in place (Engine::inject)
 __global__ void round_f32_kernel(double *p, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

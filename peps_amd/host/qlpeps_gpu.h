@@ -335,6 +335,94 @@ class BMPSContractorT {
   void ParkBMPS(BMPSPOSITION p, size_t keep_levels) { check_rc(pepsgpu_bmps_park(ctx_, p, (int)keep_levels), ctx_); }
   void UnparkBMPS(BMPSPOSITION p) { check_rc(pepsgpu_bmps_unpark(ctx_, p), ctx_); }
   void GenerateBMPSApproach(BMPSPOSITION p) { check_rc(pepsgpu_generate_bmps_approach(ctx_, p), ctx_); }
+
+  // BMPSContractor::BMPSWalker (bmps_contractor.h:357-646, bmps/impl/bmps_walker.h): the object form.  One C++ walker holds the
+  // fork for every Monte-Carlo walker of the context; where the reference passes `const TransferMPO &mpo` and
+  // `const BMPS &opposite_boundary` to every call, the MPO is named once (SetMPO*: a row of the network under the walkers'
+  // configurations, under per-walker states, or explicit tensors -- an MPO that is not a row of the network) and the opposite
+  // boundary is the level of the DOWN stack (`down_stack[opp_level]` in the reference's tests).  Same method names, same
+  // std::runtime_error conditions (size / direction / cache checks of bmps_walker.h).
+  class BMPSWalker {
+   public:
+    BMPSWalker(BMPSWalker &&o) noexcept : ctx_(o.ctx_), id_(o.id_), n_(o.n_) { o.id_ = -1; }
+    BMPSWalker(const BMPSWalker &) = delete;
+    BMPSWalker &operator=(const BMPSWalker &) = delete;
+    ~BMPSWalker() { if (id_ >= 0) (void)pepsgpu_walker_destroy(ctx_, id_); }
+    void EvolveStep() { check_rc(pepsgpu_walker_evolve_step(ctx_, id_), ctx_); }
+    void SetMPO(size_t num) { check_rc(pepsgpu_walker_set_mpo(ctx_, id_, (int)num, nullptr, nullptr, 0), ctx_); }
+    // states[w][j]: component of site j of slice `num` for Monte-Carlo walker w
+    void SetMPOStates(size_t num, const std::vector<int32_t> &states) { check_rc(pepsgpu_walker_set_mpo(ctx_, id_, (int)num, states.data(), nullptr, 0), ctx_); }
+    // tensors[q][j][D^4] (leg order L, D, R, U, zero padded to D), n_tensors = 1 (shared) or the number of walkers
+    void SetMPOTensors(size_t num, const std::vector<TenElemT> &tensors, size_t n_tensors) {
+      check_rc(pepsgpu_walker_set_mpo(ctx_, id_, (int)num, nullptr, dptr(tensors.data()), (int)n_tensors), ctx_);
+    }
+    void Evolve() { check_rc(pepsgpu_walker_evolve(ctx_, id_), ctx_); }
+    std::vector<TenElemT> ContractRow(size_t opp_level) const {
+      std::vector<TenElemT> out(n_);
+      check_rc(pepsgpu_walker_contract_row(ctx_, id_, (int)opp_level, dptr(out.data())), ctx_);
+      return out;
+    }
+    void InitBTenLeft(size_t opp_level, size_t target_col) { check_rc(pepsgpu_walker_init_bten(ctx_, id_, (int)opp_level, LEFT, (int)target_col), ctx_); }
+    void InitBTenRight(size_t opp_level, size_t target_col) { check_rc(pepsgpu_walker_init_bten(ctx_, id_, (int)opp_level, RIGHT, (int)target_col), ctx_); }
+    void GrowBTenLeftStep(size_t opp_level) { check_rc(pepsgpu_walker_grow_bten_step(ctx_, id_, (int)opp_level, LEFT), ctx_); }
+    void GrowBTenRightStep(size_t opp_level) { check_rc(pepsgpu_walker_grow_bten_step(ctx_, id_, (int)opp_level, RIGHT), ctx_); }
+    void ShiftBTenWindow(size_t opp_level, BTenPOSITION position) { check_rc(pepsgpu_walker_shift_bten_window(ctx_, id_, (int)opp_level, position), ctx_); }
+    // replacement site(s): SITPS component per walker (states[w], or states[w][2] for the two-site form); empty = the MPO's own
+    std::vector<TenElemT> TraceWithBTen(size_t opp_level, size_t site_col, const std::vector<int32_t> &states = {}) const {
+      std::vector<TenElemT> out(n_);
+      check_rc(pepsgpu_walker_trace_with_bten(ctx_, id_, (int)opp_level, (int)site_col, 0, states.empty() ? nullptr : states.data(), nullptr, 0,
+                                              dptr(out.data())), ctx_);
+      return out;
+    }
+    std::vector<TenElemT> TraceWithBTenTensor(size_t opp_level, size_t site_col, const std::vector<TenElemT> &site, size_t n_tensors) const {
+      std::vector<TenElemT> out(n_);
+      check_rc(pepsgpu_walker_trace_with_bten(ctx_, id_, (int)opp_level, (int)site_col, 0, nullptr, dptr(site.data()), (int)n_tensors,
+                                              dptr(out.data())), ctx_);
+      return out;
+    }
+    std::vector<TenElemT> TraceWithTwoSiteBTen(size_t opp_level, size_t site_col, const std::vector<int32_t> &states_ab = {}) const {
+      std::vector<TenElemT> out(n_);
+      check_rc(pepsgpu_walker_trace_with_bten(ctx_, id_, (int)opp_level, (int)site_col, 1, states_ab.empty() ? nullptr : states_ab.data(), nullptr,
+                                              0, dptr(out.data())), ctx_);
+      return out;
+    }
+    void ClearBTen() { check_rc(pepsgpu_walker_clear_bten(ctx_, id_), ctx_); }
+    BMPSWalker Clone() const {                      // `auto excited_walker = main_walker;`
+      int id = -1;
+      check_rc(pepsgpu_walker_clone(ctx_, id_, &id), ctx_);
+      return BMPSWalker(ctx_, id, n_);
+    }
+    size_t GetBTenLeftCol() const { return (size_t)info(2); }
+    size_t GetBTenRightCol() const { return (size_t)info(3); }
+    size_t GetStackSize() const { return (size_t)info(1); }
+    BMPSPOSITION GetPosition() const { return (BMPSPOSITION)info(0); }
+
+   private:
+    friend class BMPSContractorT;
+    BMPSWalker(pepsgpu_ctx *ctx, int id, size_t n) : ctx_(ctx), id_(id), n_(n) {}
+    int info(int k) const {
+      int v[4];
+      check_rc(pepsgpu_walker_info(ctx_, id_, &v[0], &v[1], &v[2], &v[3]), ctx_);
+      return v[k];
+    }
+    pepsgpu_ctx *ctx_;
+    int id_;
+    size_t n_;
+  };
+  // GetWalker(tn, position) (bmps_walker.h:51-58): a detached copy of the top of the stack
+  BMPSWalker GetWalker(BMPSPOSITION position) const {
+    int id = -1;
+    check_rc(pepsgpu_walker_create(ctx_, position, -1, &id), ctx_);
+    return BMPSWalker(ctx_, id, walkers());
+  }
+  // BMPSWalker(tn, GetBMPS(position)[level], position, level + 1, trunc_params): the constructor the structure-factor mixin
+  // uses on the vacuum (structure_factor_measurement_mixin.h:121-122)
+  BMPSWalker MakeWalker(BMPSPOSITION position, size_t level) const {
+    int id = -1;
+    check_rc(pepsgpu_walker_create(ctx_, position, (int)level, &id), ctx_);
+    return BMPSWalker(ctx_, id, walkers());
+  }
+
   void InitBTen(BTenPOSITION p, size_t slice) { check_rc(pepsgpu_init_bten(ctx_, p, (int)slice), ctx_); }
   void GrowFullBTen(BTenPOSITION p, size_t slice, size_t remain_sites = 2, bool init = true) {
     check_rc(pepsgpu_grow_full_bten(ctx_, p, (int)slice, (int)remain_sites, init), ctx_);
@@ -1120,9 +1208,11 @@ struct SpinOneHalfMeasurementHooks {
   // StructureFactorMeasurementMixin::MeasureStructureFactor (base/structure_factor_measurement_mixin.h:62-215):
   // SpSm_cross = flat tuples {y1, x1, y2, x2, value} for every y1 < y2; value = amplitude of the configuration with
   // S+ applied at (y1, x1) (source spin down) and S- at (y2, x2) (target spin up), 0 where the channel is closed.
-  // The reference forks a BMPSWalker from the UP vacuum, evolves it through the excited row y1 and the standard rows
-  // below, and contracts each row y2 against DOWN[Ly-1-y2]; here the UP stack is the walker (the excitation is a
-  // temporary UpdateLocal, undone afterwards) and the DOWN environment is named by parking the levels above it.
+  // As the reference: a main BMPSWalker built on the UP vacuum (:121-122), copied per source site (:134), evolved through the
+  // excited row y1 (Evolve with an MPO that is not a row of the network: per-walker states here) and the standard rows below,
+  // closed on each row y2 against down_stack[Ly-1-y2] with the walker's own BTen caches (InitBTenLeft to Lx, InitBTenRight at the
+  // boundary, scan right to left with TraceWithBTen + GrowBTenRightStep, :160-194).  All Monte-Carlo walkers move in lockstep: a
+  // trace is computed for the batch when any walker's channel is open and masked per walker on the host.
   void SetEnableStructureFactor(bool enable) { enable_structure_factor_measurement_ = enable; }
   bool IsStructureFactorEnabled() const { return enable_structure_factor_measurement_; }
   void MeasureStructureFactor(TPSWaveFunctionComponent &comp, ObservableMap &out) const {
@@ -1132,48 +1222,50 @@ struct SpinOneHalfMeasurementHooks {
     const size_t per = (Ly - 1) * Lx * Ly / 2 * Lx * 5;       // sum_{y1} Lx * (Ly-1-y1) * Lx tuples of 5
     auto &cross = out.make("SpSm_cross", per);
     std::vector<size_t> fill(n, 0);
-    const std::vector<uint8_t> all(n, 1);
     c.GenerateBMPSApproach(UP);                                // UP = vacuum, DOWN fully grown (traversal start state)
+    auto main_walker = c.MakeWalker(UP, 0);                    // BMPSWalker(tn, up_stack[0], UP, 1, trunc_params)
+    const std::vector<int32_t> spin_down(n, 0);                // GetSiteTensor(y2, x2, 0)
     for (size_t y1 = 0; y1 + 1 < Ly; ++y1) {
       for (size_t x1 = 0; x1 < Lx; ++x1) {
-        const std::vector<int32_t> site = {(int32_t)y1, (int32_t)x1};
-        std::vector<int32_t> orig(n), excited(n);
+        std::vector<int32_t> excited(n * Lx);
         std::vector<uint8_t> src_down(n);
         for (size_t w = 0; w < n; ++w) {
-          orig[w] = comp.config(w, {y1, x1});
-          src_down[w] = orig[w] == 0;
-          excited[w] = src_down[w] ? 1 : orig[w];
+          for (size_t x = 0; x < Lx; ++x) excited[w * Lx + x] = comp.config(w, {y1, x});
+          src_down[w] = comp.config(w, {y1, x1}) == 0;
+          if (src_down[w]) excited[w * Lx + x1] = 1;            // excited_mpo_ptrs[x1] = sitps(y1, x1)[1]
         }
-        c.UpdateLocal(site, excited, all);                      // excited_mpo_ptrs[x1] = sitps(y1,x1)[1]
-        c.GrowBMPSStep(UP);                                     // excited_walker.Evolve(excited row y1)
+        auto excited_walker = main_walker.Clone();
+        excited_walker.SetMPOStates(y1, excited);
+        excited_walker.Evolve();                                // absorb the excited row y1
         for (size_t y2 = y1 + 1; y2 < Ly; ++y2) {
-          c.ParkBMPS(DOWN, Ly - y2);                            // bottom_env = down_stack[Ly-1-y2]
-          c.InitBTen(LEFT, y2);
-          c.GrowFullBTen(RIGHT, y2, 1, true);
+          const size_t bottom = Ly - 1 - y2;                    // bottom_env = down_stack[Ly-1-y2]
+          excited_walker.SetMPO(y2);                            // standard_mpo = tn.get_row(y2)
+          excited_walker.InitBTenLeft(bottom, Lx);
+          excited_walker.InitBTenRight(bottom, Lx - 1);
           std::vector<double> row(n * Lx, 0.0);
-          for (size_t x2 = 0; x2 < Lx; ++x2) {
+          for (size_t x2r = 0; x2r < Lx; ++x2r) {
+            const size_t x2 = Lx - 1 - x2r;
             bool any = false;
             for (size_t w = 0; w < n; ++w) any |= src_down[w] && comp.config(w, {y2, x2}) == 1;
             if (any) {
-              std::vector<int32_t> cand(n, 0);                  // GetSiteTensor(y2, x2, 0)
-              std::vector<double> psi_ex = c.ReplaceOneSiteTrace({y2, x2}, HORIZONTAL, 1, cand);
+              std::vector<double> psi_ex = excited_walker.TraceWithBTen(bottom, x2, spin_down);
               for (size_t w = 0; w < n; ++w)
                 if (src_down[w] && comp.config(w, {y2, x2}) == 1) row[w * Lx + x2] = psi_ex[w];
             }
-            if (x2 + 1 < Lx) c.ShiftBTenWindow(RIGHT);
+            if (x2 > 0) excited_walker.GrowBTenRightStep(bottom);
           }
-          c.UnparkBMPS(DOWN);
           for (size_t w = 0; w < n; ++w)
             for (size_t x2 = 0; x2 < Lx; ++x2) {
               double *t = &cross[w * per + fill[w]];
               t[0] = (double)y1; t[1] = (double)x1; t[2] = (double)y2; t[3] = (double)x2; t[4] = row[w * Lx + x2];
               fill[w] += 5;
             }
-          if (y2 + 1 < Ly) c.GrowBMPSStep(UP);                  // excited_walker.Evolve(standard row y2)
+          excited_walker.ClearBTen();
+          if (y2 + 1 < Ly) excited_walker.Evolve();             // absorb row y2 with the standard MPO
         }
-        c.UpdateLocal(site, orig, all);                         // drop the excited walker: UP back to the main walker
       }
-      c.GrowBMPSStep(UP);                                       // main_walker.Evolve(standard row y1)
+      main_walker.SetMPO(y1);
+      main_walker.Evolve();                                     // main_walker.Evolve(standard row y1)
     }
   }
   bool enable_structure_factor_measurement_ = false;

@@ -24,25 +24,39 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+WORKER = r"""
+import json, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from peps_amd import capi
+d = np.load(sys.argv[2])
+flat, cfgs = d["flat"], d["cfgs"]
+L, D, chi, dt = int(d["L"]), int(d["D"]), int(d["chi"]), int(d["dt"])
+ctx = capi.Context(L, L, D, 2, chi, dtype=dt, max_walkers=len(cfgs))
+ctx.state_upload(flat)
+ctx.set_configs(cfgs)
+t0 = time.perf_counter()
+a = ctx.evaluate_amplitude()
+sec = time.perf_counter() - t0
+flags = int(np.sum(ctx.walker_flags() != 0))
+ctx.close()
+np.savez(sys.argv[3], a=a, sec=sec, flags=flags)
+"""
+
+
 def run(capi, flat, cfgs, L, D, chi, dt, env):
-    keep = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        ctx = capi.Context(L, L, D, 2, chi, dtype=dt, max_walkers=len(cfgs))
-    finally:
-        for k, v in keep.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-    ctx.state_upload(flat)
-    ctx.set_configs(cfgs)
-    t0 = time.perf_counter()
-    a = ctx.evaluate_amplitude()
-    sec = time.perf_counter() - t0
-    flags = int(np.sum(ctx.walker_flags() != 0))
-    ctx.close()
-    return a, sec, flags
+    """one variant = one process: the library reads its environment switches once (static const)"""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        job, res = os.path.join(td, "job.npz"), os.path.join(td, "res.npz")
+        np.savez(job, flat=flat, cfgs=cfgs, L=L, D=D, chi=chi, dt=dt)
+        r = subprocess.run([sys.executable, "-c", WORKER, ROOT, job, res], env=dict(os.environ, **env), capture_output=True, text=True,
+                           timeout=1200)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr[-1500:])
+        d = np.load(res)
+        return d["a"], float(d["sec"]), int(d["flags"])
 
 
 def main():
@@ -82,12 +96,19 @@ def main():
         ("f64+floors_f32", capi.F64, {"PEPSGPU_F64_EPS": EPS32}),
         ("f64+round(all)+floors_f32", capi.F64, {"PEPSGPU_INJECT_F32": "SPRTMVYE", "PEPSGPU_F64_EPS": EPS32}),
         ("f32", capi.F32, {}),
+        ("f32 no ortho polish (round 3)", capi.F32, {"PEPSGPU_ORTHO_POLISH": "0"}),
+        ("f32 acc64 X,P", capi.F32, {"PEPSGPU_ACC64": "1"}),
+        ("f32 acc64 Z,Tt", capi.F32, {"PEPSGPU_ACC64": "2"}),
+        ("f32 acc64 M", capi.F32, {"PEPSGPU_ACC64": "4"}),
+        ("f32 acc64 Y", capi.F32, {"PEPSGPU_ACC64": "8"}),
+        ("f32 acc64 all contractions", capi.F32, {"PEPSGPU_ACC64": "15"}),
+        ("f32 acc64 all, no ortho polish", capi.F32, {"PEPSGPU_ACC64": "15", "PEPSGPU_ORTHO_POLISH": "0"}),
         ("f32 no hints/shrink", capi.F32, {"PEPSGPU_NO_RANK_HINT_SKIP": "1", "PEPSGPU_NO_BOND_SHRINK": "1"}),
         ("f32 no two-level", capi.F32, {"PEPSGPU_NO_TWO_LEVEL": "1"}),
         ("f32 no mid route (Jacobi on M)", capi.F32, {"PEPSGPU_NO_MIDROUTE": "1"}),
+        ("f32 no mid route, no ortho polish", capi.F32, {"PEPSGPU_NO_MIDROUTE": "1", "PEPSGPU_ORTHO_POLISH": "0"}),
         ("f32 no chain", capi.F32, {"PEPSGPU_NO_CHAIN": "1"}),
         ("f32 no rank adapt", capi.F32, {"PEPSGPU_NO_RANK_ADAPT": "1"}),
-        ("f32 no fused factor", capi.F32, {"PEPSGPU_NO_FUSED_GRAMCHOL": "1", "PEPSGPU_NO_COLGRAM": "1"}),
     ]
     if args.only:
         want = set(args.only.split(","))
