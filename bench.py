@@ -299,6 +299,28 @@ ROOF_CATS = {"contract_chain": ("tgemm_chain_kernel", "f32"), "contract": ("tgem
              "trunc_apply": ("tgemm_kernel<f32,f32,f32,f64>", "f64"), "env": ("tgemm_kernel (BTen / trace)", "f32")}
 
 
+# categories without a flop or byte roofline (VALU / exchange latency): named dominant when they are the largest (bound "valu")
+VALU_CATS = {"jacobi": "jacobi_rows_grp_kernel / jacobi_rows_tiny4_kernel (one-sided Jacobi, register tournament)",
+             "jacobi_edge": "jacobi_rows_kernel", "cholesky": "gram_chol_wave_kernel (Gram-free factor)",
+             "select": "select_rows_kernel / ortho_rows_kernel", "normalize": "normalize_kernel"}
+
+
+def pmc_sq_shares(kernel_names, leg_tag):
+    """SQ_WAIT_ANY / SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_VALU as shares of SQ_WAVE_CYCLES of the kernels of a category, from the
+    committed SQ pass of the same leg (profiles/r0N_pmc_meta.json, key "sq"); null when the pass is not there"""
+    if not os.path.exists(PMC_META):
+        return None
+    try:
+        sq = json.load(open(PMC_META)).get(leg_tag, {}).get("sq", {})
+    except Exception:
+        return None
+    out = {}
+    for k, v in sq.items():
+        if any(k in part or part.split()[0] in k for part in kernel_names.split(" / ")):
+            out[k] = v
+    return out or None
+
+
 def roofline_of(prof, dtype, steps, leg_tag=None, nw=None):
     """Roofline object of the dominant kernel of a leg: the single-kernel category with the largest HIP-event time."""
     cats = dict(ROOF_CATS)
@@ -308,6 +330,19 @@ def roofline_of(prof, dtype, steps, leg_tag=None, nw=None):
         cats["cholesky"] = ("colgram_dense_kernel (+ chol_blocked_kernel, chol_lowrank_kernel)", "f64")
     cands = [k for k in cats if k in prof and prof[k]["launches"] and prof[k]["ms"] > 0]
     dom = max(cands, key=lambda k: prof[k]["ms"])
+    # A category that runs no MFMA and streams little (one-sided Jacobi sweeps, the Gram-free factor, select / normalise) can be
+    # the largest of a leg: it is then NAMED as the dominant one (bound "valu": no flop or byte roofline applies, frac null) with
+    # its wave-cycle wait shares from the committed SQ pass, and the largest priced kernel rides along.
+    valu = {k: v for k, v in VALU_CATS.items() if k in prof and prof[k]["launches"] and prof[k]["ms"] > 0 and k not in cats}
+    vdom = max(valu, key=lambda k: prof[k]["ms"]) if valu else None
+    valu_roof = None
+    if vdom and prof[vdom]["ms"] > prof[dom]["ms"]:
+        tot = sum(v["ms"] for v in prof.values())
+        vl = max(prof[vdom]["launches"], 1)
+        valu_roof = {"bound": "valu", "kernel": VALU_CATS[vdom], "category": vdom, "achieved": None, "peak": None, "unit": None, "frac": None,
+                     "traffic": None, "avg_launch_us": prof[vdom]["ms"] / vl * 1e3, "launches_per_step": vl / max(steps, 1),
+                     "share_of_kernel_time": prof[vdom]["ms"] / tot if tot > 0 else None,
+                     "sq_wait": pmc_sq_shares(VALU_CATS[vdom], leg_tag) if leg_tag else None}
     kname, kdt = cats[dom]
     dsec = prof[dom]["ms"] * 1e-3
     launches = max(prof[dom]["launches"], 1)
@@ -352,6 +387,9 @@ def roofline_of(prof, dtype, steps, leg_tag=None, nw=None):
         "mfma_tflops": tflops,
         "mfma_frac": tflops / kpeak,
     }
+    if valu_roof is not None:
+        valu_roof["largest_priced_kernel"] = roof
+        return vdom, valu_roof
     return dom, roof
 
 

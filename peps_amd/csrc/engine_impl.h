@@ -899,6 +899,15 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       }
       g.dJ[2].p = kn[i]; g.dJ[2].mask = 1;
       g.prefer_tiled = dense_site;
+      static const bool y_tiled = getenv("PEPSGPU_Y_TILED") != nullptr;     // experiments: Y on the LDS-tiled f32 kernel
+      if (y_tiled) g.prefer_tiled = true;
+      // float64-grade accumulation of Y on the wave-per-tile kernel (f32 chains of 8 products drained into f64 registers):
+      // 0 = never, 1 = where the row absorbed before ran a carry above 32 rows at this site or gives no hint yet (default), 2 = always
+      static const int y_acc64 = getenv("PEPSGPU_Y_ACC64") ? atoi(getenv("PEPSGPU_Y_ACC64")) : 1;
+      if constexpr (sizeof(T) == 4) {
+        const bool dense_y = in.depth < 3 || (int)in.mlmax.size() <= i || in.mlmax[i] < 0 || in.mlmax[i] > 32;
+        g.acc64 = (y_acc64 == 2 || (y_acc64 == 1 && dense_y)) ? 1 : 0;
+      }
       // reference op: res[i-1] . (u s)  (bmps_impl.h:254): 2 (m_{i-1} D_u) m_i k_i
       int rp, cp, ddp[4];
       site_rc(i - 1, rp, cp);
@@ -908,7 +917,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       bool fused_norm = false;
       if constexpr (sizeof(T) == 4) {
         static const bool no_fn = getenv("PEPSGPU_NO_FUSED_NORM") != nullptr;
-        if (!no_fn && !acc64 && bond_adapt && kn[i] && tgemm_one_block_direct(g)) {
+        if (!no_fn && !acc64 && !y_tiled && bond_adapt && kn[i] && tgemm_one_block_direct(g)) {
           if (!yscale) yscale = (float *)arena_.alloc(sizeof(float) * nw_);
           g.scale_out = yscale; g.norm_log = out.logscale; g.norm_flag = flag_;
           fused_norm = true;

@@ -70,6 +70,10 @@ struct TGemmDesc {
   // kernel instead of the wave-per-tile kernel that is built for extents of a few tens (M = R Tt of a dense walker batch:
   // 233 -> 138 ms per step of 2048 walkers)
   int prefer_tiled = 0;
+  // wave-per-tile kernel: the f32 accumulator of a tile is drained into float64 registers after every round of 8 k (chains of at
+  // most 8 f32 FMAs): float64-grade sums from f32 operands at the f32 MFMA rate.  For the one contraction of the absorption whose
+  // f32 accumulation shows in the amplitude (Y = Tt V^T on dense carries).
+  int acc64 = 0;
 
   __host__ __device__ int Itot() const { return I[0] * I[1] * I[2]; }
   __host__ __device__ int Jtot() const { return J[0] * J[1] * J[2]; }
@@ -400,7 +404,7 @@ __device__ __forceinline__ float4 tg_ldf4(const float *__restrict__ base, const 
 
 constexpr int TG_ZERO_ROW = 0x40000000;   // flag in the C-row offset table: the row exists in C but its A row reads as zero
 
-template <bool AVEC, bool BVEC>
+template <bool AVEC, bool BVEC, bool ACC64 = false>
 __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *__restrict__ A, const float *__restrict__ B,
                                                float *__restrict__ C, const int Itot, const int Jtot, const int K2s,
                                                int (*offCi_s)[32], const int tile0, const int tile_step,
@@ -490,9 +494,18 @@ __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *
       }
     };
     float a0[4], b0[4], a1[4], b1[4];
+    double accd[ACC64 ? 16 : 1];
+    if constexpr (ACC64) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accd[r] = 0.0;
+    }
     auto mfma4 = [&](const float (&av)[4], const float (&bv)[4]) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+      if constexpr (ACC64) {     // drain: the f32 chain never exceeds the 8 products of one round
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accd[r] += (double)acc[r]; acc[r] = 0.f; }
+      }
     };
     if (nrounds > 0) {
       load_raw(a0, b0);
@@ -534,7 +547,9 @@ __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *
         const int oi = oi4[e];
         if (oi >= 0 && ocj >= 0) {
           float *p = C + ((oi & ~TG_ZERO_ROW) + ocj_e);
-          float v = ((oi & TG_ZERO_ROW) || jzero) ? 0.f : acc[4 * g + e] * alpha;
+          float v;
+          if constexpr (ACC64) v = ((oi & TG_ZERO_ROW) || jzero) ? 0.f : (float)(accd[4 * g + e] * (double)alpha);
+          else v = ((oi & TG_ZERO_ROW) || jzero) ? 0.f : acc[4 * g + e] * alpha;
           if (accumulate) v += *p;
           *p = v;
           if (sumsq) ss = fma((double)v, (double)v, ss);
@@ -545,8 +560,8 @@ __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *
   if (sumsq) *sumsq += ss;
 }
 
-template <bool AVEC, bool BVEC>
-__global__ __launch_bounds__(256, 6) void tgemm_direct_kernel(TGemmDesc d, const float *__restrict__ Ag,
+template <bool AVEC, bool BVEC, bool ACC64 = false>
+__global__ __launch_bounds__(256, ACC64 ? 4 : 6) void tgemm_direct_kernel(TGemmDesc d, const float *__restrict__ Ag,
                                                            const float *__restrict__ Bg, float *__restrict__ Cg) {
   __shared__ __attribute__((aligned(16))) int offCi_s[4][32];
   const int b = blockIdx.z;
@@ -569,8 +584,8 @@ __global__ __launch_bounds__(256, 6) void tgemm_direct_kernel(TGemmDesc d, const
   if (d.selA) baseA += (long)d.selA[(long)(b / d.seldivA) * d.selA_inc] * d.selA_mul;
   if (d.selB) baseB += (long)d.selB[(long)(b / d.seldivB) * d.selB_inc] * d.selB_mul;
   double ss = 0.0;
-  tg_direct_body<AVEC, BVEC>(d, Ag + baseA, Bg + baseB, Cg + (long)(b / d.bdivC) * d.wC, Itot, Jtot, K2s, offCi_s,
-                             blockIdx.x * 4, gridDim.x * 4, d.scale_in ? d.scale_in[b] : 1.f, d.scale_out ? &ss : nullptr);
+  tg_direct_body<AVEC, BVEC, ACC64>(d, Ag + baseA, Bg + baseB, Cg + (long)(b / d.bdivC) * d.wC, Itot, Jtot, K2s, offCi_s,
+                                    blockIdx.x * 4, gridDim.x * 4, d.scale_in ? d.scale_in[b] : 1.f, d.scale_out ? &ss : nullptr);
   if (d.scale_out) {     // (gridDim.x == 1: this block stored all of C[b])
     __shared__ double s_nred[4];
     double a = ss;
@@ -750,7 +765,13 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
                  "tensor GEMM: the norm of the result needs one block per batch entry");
       const float *Af = (const float *)A, *Bf = (const float *)B;
       float *Cf = (float *)C;
-      if (avec && bvec) hipLaunchKernelGGL((tgemm_direct_kernel<true, true>), gd, dim3(256), 0, s, d, Af, Bf, Cf);
+      if (d.acc64) {
+        if (avec && bvec) hipLaunchKernelGGL((tgemm_direct_kernel<true, true, true>), gd, dim3(256), 0, s, d, Af, Bf, Cf);
+        else if (avec) hipLaunchKernelGGL((tgemm_direct_kernel<true, false, true>), gd, dim3(256), 0, s, d, Af, Bf, Cf);
+        else if (bvec) hipLaunchKernelGGL((tgemm_direct_kernel<false, true, true>), gd, dim3(256), 0, s, d, Af, Bf, Cf);
+        else hipLaunchKernelGGL((tgemm_direct_kernel<false, false, true>), gd, dim3(256), 0, s, d, Af, Bf, Cf);
+      }
+      else if (avec && bvec) hipLaunchKernelGGL((tgemm_direct_kernel<true, true>), gd, dim3(256), 0, s, d, Af, Bf, Cf);
       else if (avec) hipLaunchKernelGGL((tgemm_direct_kernel<true, false>), gd, dim3(256), 0, s, d, Af, Bf, Cf);
       else if (bvec) hipLaunchKernelGGL((tgemm_direct_kernel<false, true>), gd, dim3(256), 0, s, d, Af, Bf, Cf);
       else hipLaunchKernelGGL((tgemm_direct_kernel<false, false>), gd, dim3(256), 0, s, d, Af, Bf, Cf);

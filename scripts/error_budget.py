@@ -96,13 +96,19 @@ def main():
         ("f64+floors_f32", capi.F64, {"PEPSGPU_F64_EPS": EPS32}),
         ("f64+round(all)+floors_f32", capi.F64, {"PEPSGPU_INJECT_F32": "SPRTMVYE", "PEPSGPU_F64_EPS": EPS32}),
         ("f32", capi.F32, {}),
-        ("f32 no ortho polish (round 3)", capi.F32, {"PEPSGPU_ORTHO_POLISH": "0"}),
+        ("f32 no ortho polish", capi.F32, {"PEPSGPU_ORTHO_POLISH": "0"}),
+        ("f32 Y f32 chain (round 3)", capi.F32, {"PEPSGPU_Y_ACC64": "0"}),
+        ("f32 round 3 (no ortho polish, Y f32 chain)", capi.F32, {"PEPSGPU_ORTHO_POLISH": "0", "PEPSGPU_Y_ACC64": "0"}),
         ("f32 acc64 X,P", capi.F32, {"PEPSGPU_ACC64": "1"}),
         ("f32 acc64 Z,Tt", capi.F32, {"PEPSGPU_ACC64": "2"}),
         ("f32 acc64 M", capi.F32, {"PEPSGPU_ACC64": "4"}),
         ("f32 acc64 Y", capi.F32, {"PEPSGPU_ACC64": "8"}),
         ("f32 acc64 all contractions", capi.F32, {"PEPSGPU_ACC64": "15"}),
         ("f32 acc64 all, no ortho polish", capi.F32, {"PEPSGPU_ACC64": "15", "PEPSGPU_ORTHO_POLISH": "0"}),
+        ("f32 Y on the LDS-tiled f32 kernel", capi.F32, {"PEPSGPU_Y_TILED": "1"}),
+        ("f32 no fused norm", capi.F32, {"PEPSGPU_NO_FUSED_NORM": "1"}),
+        ("f32 no tt swap", capi.F32, {"PEPSGPU_NO_TT_SWAP": "1"}),
+        ("f32 no vector loads", capi.F32, {"PEPSGPU_TGEMM_NOVEC": "1"}),
         ("f32 no hints/shrink", capi.F32, {"PEPSGPU_NO_RANK_HINT_SKIP": "1", "PEPSGPU_NO_BOND_SHRINK": "1"}),
         ("f32 no two-level", capi.F32, {"PEPSGPU_NO_TWO_LEVEL": "1"}),
         ("f32 no mid route (Jacobi on M)", capi.F32, {"PEPSGPU_NO_MIDROUTE": "1"}),
@@ -111,7 +117,7 @@ def main():
         ("f32 no rank adapt", capi.F32, {"PEPSGPU_NO_RANK_ADAPT": "1"}),
     ]
     if args.only:
-        want = set(args.only.split(","))
+        want = set(args.only.split(";"))
         runs = [r for r in runs if r[0] == "f64" or r[0] in want]
     out = {"L": L, "D": D, "chi": chi, "walkers": len(cfgs), "state": args.state, "runs": {}}
     ref = None

@@ -95,7 +95,11 @@ def test_walker_bten_cache(ising_ctx):
     t = np.zeros((1, 2, 2, 2, 2))
     t[0] = tn((2, mid))
     assert abs(w.TraceWithBTen(bot, mid, tensors=t)[0] - ref) < 1e-8 * abs(ref)
-    assert abs(ctx.get_walker(UP).ContractRow(bot)[0] - ref) < 1e-8 * abs(ref)      # a fresh fork: ContractRow as the fallback (:1276-1283)
+    fresh = ctx.get_walker(UP)                      # a fresh fork: ContractRow as the fallback (:1276-1283)
+    with pytest.raises(RuntimeError):
+        fresh.ContractRow(bot)                      # (no TransferMPO named yet)
+    fresh.set_mpo(2)
+    assert abs(fresh.ContractRow(bot)[0] - ref) < 1e-8 * abs(ref)
     with pytest.raises(RuntimeError):
         w.TraceWithBTen(bot, mid + 2)               # the left cache does not reach that far
     w.ClearBTen()
