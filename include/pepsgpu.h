@@ -88,6 +88,22 @@ int pepsgpu_delete_inner_bmps(pepsgpu_ctx *ctx, int pos);       /* DeleteInnerBM
  * grown meanwhile and restores the hidden levels. */
 int pepsgpu_bmps_park(pepsgpu_ctx *ctx, int pos, int keep_levels);
 int pepsgpu_bmps_unpark(pepsgpu_ctx *ctx, int pos);
+/* One row (orientation = PEPSGPU_HORIZONTAL, slice = row) or column (PEPSGPU_VERTICAL, slice = column) of the Monte-Carlo sweep with
+ * the nearest-neighbour EXCHANGE updater, entirely on the device: replaces, for that slice, the loop body of
+ * MCUpdateSquareNNUpdateBaseOBC::operator() (square_nn_updater.h:41-55 / :62-76: InitBTen, GrowFullBTen(.., 2, true), then per bond
+ * TwoSiteNNUpdateLocalImpl + ShiftBTenWindow) with MCUpdateSquareNNExchangeOBC::TwoSiteNNUpdateLocalImpl (:142-189: skip equal
+ * spins, ReplaceNNSiteTrace of the exchanged pair, Metropolis on |psi'/psi|^2, UpdateLocal).  The BMPS pair of the slice must be in
+ * place as for pepsgpu_init_bten (the caller keeps doing GenerateBMPSApproach / ShiftBMPSWindow between slices).
+ *   uniforms        [n][n_uniform], n_uniform >= slice length - 1: per walker the NEXT deviates of its std::mt19937 +
+ *                   uniform_real_distribution<double>(0, 1) stream, in drawing order; a walker consumes one only where the
+ *                   reference draws one (spins differ and |psi'| < |psi|), consumed_out[w] says how many -- the chain is the
+ *                   reference's chain when the caller pops exactly those from its queue;
+ *   amplitude_inout [n] psi of every walker before / after the slice;  accepted_out [n] accepted exchanges;
+ *   slice_states_out [n][slice length] (may be NULL) the configuration along the slice after the pass.
+ * Real element types only (PEPSGPU_C128 -> PEPSGPU_EINVAL: the per-bond calls remain). */
+int pepsgpu_sweep_slice_exchange(pepsgpu_ctx *ctx, int orientation, int slice, int n_uniform, const double *uniforms,
+                                 double *amplitude_inout, int32_t *consumed_out, int32_t *accepted_out, int32_t *slice_states_out);
+
 /* BMPSWalker as an object -- BMPSContractor::GetWalker / class BMPSWalker, bmps_contractor.h:357-646, bmps/impl/bmps_walker.h:13-465.
  * A walker holds the fork of the top BMPS of stack `pos` for every Monte-Carlo walker of the context (deep copy; the stacks are not
  * touched afterwards), its stack-size counter and its own LEFT / RIGHT BTen caches.  The TransferMPO the calls below absorb / sandwich

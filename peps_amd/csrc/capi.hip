@@ -7,6 +7,7 @@
 #include "engine_var.h"
 #include "engine_cplx.h"
 #include "engine_walker.h"
+#include "engine_sweep.h"
 #include "comm.h"
 
 using namespace pepsgpu;
@@ -118,6 +119,12 @@ int pepsgpu_grow_bmps_for_row(pepsgpu_ctx *ctx, int row) { CTX_CALL(ctx->eng->gr
 int pepsgpu_grow_bmps_for_col(pepsgpu_ctx *ctx, int col) { CTX_CALL(ctx->eng->grow_bmps_for_col(col)); }
 int pepsgpu_shift_bmps_window(pepsgpu_ctx *ctx, int pos) { CTX_CALL(check_pos(pos); ctx->eng->shift_bmps_window(pos)); }
 int pepsgpu_delete_inner_bmps(pepsgpu_ctx *ctx, int pos) { CTX_CALL(check_pos(pos); ctx->eng->delete_inner_bmps(pos)); }
+int pepsgpu_sweep_slice_exchange(pepsgpu_ctx *ctx, int orientation, int slice, int n_uniform, const double *uniforms,
+                                 double *amplitude_inout, int32_t *consumed_out, int32_t *accepted_out, int32_t *slice_states_out) {
+  CTX_CALL(PG_REQUIRE(uniforms && amplitude_inout && consumed_out && accepted_out, 1, "null buffer");
+           ctx->eng->sweep_slice_exchange(orientation, slice, n_uniform, uniforms, amplitude_inout, consumed_out, accepted_out,
+                                          slice_states_out));
+}
 int pepsgpu_walker_create(pepsgpu_ctx *ctx, int pos, int level, int *walker_out) {
   CTX_CALL(check_pos(pos); PG_REQUIRE(walker_out != nullptr, 1, "null output"); *walker_out = ctx->eng->walker_create(pos, level));
 }

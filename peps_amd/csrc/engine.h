@@ -102,6 +102,8 @@ struct EngineBase {
   virtual void sr_gram(const void *remote_o, const int32_t *remote_cfg, int n_remote, double *out) = 0;
   virtual void sr_weighted_sum(const double *y, double *out) = 0;
   virtual void sr_copy_samples(void *dst_o, int32_t *dst_cfg) = 0;
+  virtual void sweep_slice_exchange(int orient, int slice, int n_uniform, const double *uniforms, double *amp_inout,
+                                    int32_t *consumed_out, int32_t *accepted_out, int32_t *slice_states_out) = 0;
   // BMPSWalker (bmps_contractor.h:357-646)
   virtual int walker_create(int pos, int level) = 0;
   virtual int walker_clone(int id) = 0;
@@ -466,18 +468,31 @@ class Engine : public EngineBase {
   void replace_nn_trace(int row, int col, int dir, int ncand, const int32_t *cand, double *out) override {
     require_ready();
     ArenaScope scope(arena_);
-    int rb = row + (dir == VERTICAL), cb = col + (dir == HORIZONTAL);
-    PG_REQUIRE(row >= 0 && col >= 0 && rb < Ly_ && cb < Lx_, 1, "ReplaceNNSiteTrace: bond outside the lattice");
     const int nc = ncand > 0 ? ncand : 1;
-    SiteSel sa = cfg_site(row, col), sb = cfg_site(rb, cb);
     int *dcand = nullptr;
     if (ncand > 0) {
       size_t cnt = (size_t)nw_ * ncand * 2;
       for (size_t i = 0; i < cnt; ++i) PG_REQUIRE(cand[i] >= 0 && cand[i] < dp_, 4, "candidate state out of range");
       dcand = (int *)arena_.alloc(cnt * sizeof(int));
       PG_CHECK_HIP(hipMemcpyAsync(dcand, cand, cnt * sizeof(int), hipMemcpyHostToDevice, stream_));
-      sa.sel = dcand; sa.inc = 2;
-      sb.sel = dcand + 1; sb.inc = 2;
+    }
+    double *lsum = nullptr;
+    Acc *res = nn_trace_device(row, col, dir, nc, dcand, &lsum);
+    finish_read(res, nw_ * nc, nc, lsum, out);
+    arena_.free(res);
+    arena_.free(lsum);
+    if (dcand) arena_.free(dcand);
+  }
+
+  // ReplaceNNSiteTrace with everything left on the device: candidate table dcand [walker][nc][2] (nullptr: the configurations),
+  // result res [walker x nc] (mantissa) and lsum [walker] (log-scale): psi' = res exp(lsum).  Caller frees both.
+  Acc *nn_trace_device(int row, int col, int dir, int nc, const int *dcand, double **lsum_out) {
+    int rb = row + (dir == VERTICAL), cb = col + (dir == HORIZONTAL);
+    PG_REQUIRE(row >= 0 && col >= 0 && rb < Ly_ && cb < Lx_, 1, "ReplaceNNSiteTrace: bond outside the lattice");
+    SiteSel sa = cfg_site(row, col), sb = cfg_site(rb, cb);
+    if (dcand) {
+      sa.sel = dcand; sa.inc = 2; sa.base = nullptr;
+      sb.sel = dcand + 1; sb.inc = 2; sb.base = nullptr;
     }
     BTenDev t2, t5;
     double *lsum = zeros_f64();
@@ -500,10 +515,10 @@ class Engine : public EngineBase {
       t5 = bten_step(DOWN, bten_at_slice(DOWN, rb), at_logical(lf, LEFT, rb), sb, at_logical(rt, RIGHT, rb), nc, false, 1, a1, a3, b1, b3);
       add_logs(lsum, lf.logscale, rt.logscale, bten_[UP][row].logscale, bten_at_slice(DOWN, rb).logscale);
     }
-    finish_dot(t2.t, nc, t5.t, nc, nc, lsum, out);
+    Acc *res = finish_dot_device(t2.t, nc, t5.t, nc, nc);
     free_ten(t2.t); free_ten(t5.t);
-    arena_.free(lsum);
-    if (dcand) arena_.free(dcand);
+    *lsum_out = lsum;
+    return res;
   }
 
   void replace_one_trace(int row, int col, int orient, int ncand, const int32_t *cand, double *out) override {
@@ -872,6 +887,9 @@ class Engine : public EngineBase {
     for (int i = 0; i < n && i < 9; ++i) out[i] = v[i];
   }
   hipStream_t stream() const { return stream_; }
+  // ---- Monte-Carlo sweep of one row / column of bonds on the device (engine_sweep.h) ----
+  void sweep_slice_exchange(int orient, int slice, int n_uniform, const double *uniforms, double *amp_inout, int32_t *consumed_out,
+                            int32_t *accepted_out, int32_t *slice_states_out) override;
   // ---- BMPSWalker (engine_walker.h) ----
   int walker_create(int pos, int level) override;
   int walker_clone(int id) override;
@@ -1046,8 +1064,8 @@ class Engine : public EngineBase {
   void add_logs(double *acc, const double *a, const double *b, const double *c, const double *d);
   void add_log(double *acc, const double *a);
 
-  // out[(w,cand)] = sum t2[a,b,c] t5[c,b,a] * exp(lsum[w])
-  void finish_dot(const DTen<T> &t2, int nc2, const DTen<T> &t5, int nc5, int nc, double *lsum, double *out) {
+  // res[(w,cand)] = sum t2[a,b,c] t5[c,b,a]  (device; caller frees)
+  Acc *finish_dot_device(const DTen<T> &t2, int nc2, const DTen<T> &t5, int nc5, int nc) {
     PG_REQUIRE(t2.d[0] == t5.d[2] && t2.d[1] == t5.d[1] && t2.d[2] == t5.d[0], 3, "trace: environment bond mismatch");
     const int nb = nw_ * nc;
     Acc *res = (Acc *)arena_.alloc(sizeof(Acc) * nb);
@@ -1058,6 +1076,10 @@ class Engine : public EngineBase {
     g.wA = t2.n; g.wB = t5.n; g.wC = 1; g.nbatch = nb;
     g.bdivA = nc / nc2; g.bdivB = nc / nc5;
     tgemm_launch<T, T, Acc, Acc>(stream_, g, t2.p, t5.p, res);
+    return res;
+  }
+  // out[i] = res[i] * exp(lsum[i / nc])  (to the host)
+  void finish_read(const Acc *res, int nb, int nc, const double *lsum, double *out) {
     std::vector<Acc> h(nb);
     std::vector<double> hl(nw_);
     PG_CHECK_HIP(hipMemcpyAsync(h.data(), res, nb * sizeof(Acc), hipMemcpyDeviceToHost, stream_));
@@ -1068,6 +1090,11 @@ class Engine : public EngineBase {
       if constexpr (kCplx) { out[2 * i] = h[i].re * sc; out[2 * i + 1] = h[i].im * sc; }
       else out[i] = h[i] * sc;
     }
+  }
+  // out[(w,cand)] = sum t2[a,b,c] t5[c,b,a] * exp(lsum[w])
+  void finish_dot(const DTen<T> &t2, int nc2, const DTen<T> &t5, int nc5, int nc, double *lsum, double *out) {
+    Acc *res = finish_dot_device(t2, nc2, t5, nc5, nc);
+    finish_read(res, nw_ * nc, nc, lsum, out);
     arena_.free(res);
   }
 

@@ -868,12 +868,21 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       prof_end();
     }
     free_ten(M);
+    // "Precise" sites (f32 engine): where the carry is not of low rank -- the row absorbed before ran more than 24 live
+    // carry rows at this site, or gives no hint yet (the first three rows of a stack) -- the two places where f32 rounding showed
+    // in the amplitude get float64-grade arithmetic: the rows of Vt are made orthonormal by a Newton-Schulz step in float64
+    // (ortho_rows_kernel), and Y = Tt V^T -- whose columns of small sigma are differences of O(sigma_1) terms -- is accumulated in
+    // float64 on the f64 matrix cores (the LDS-tiled kernel; 4 Mflop of the ~190 of a site step).  The low-rank headline state
+    // keeps the one-launch f32 form with the norm fused into it.
+    bool precise_site = false;
     if constexpr (sizeof(T) == 4) {
-      // rows of Vt orthonormal to float64 accuracy (one Newton-Schulz step, ortho_rows_kernel): the projector V^T V enters the
-      // amplitude at first order at every site
+      static const int precise = getenv("PEPSGPU_PRECISE") ? atoi(getenv("PEPSGPU_PRECISE")) : 1;    // 0 never, 1 auto, 2 always
+      precise_site = precise == 2 || (precise == 1 && (in.depth < 3 || (int)in.mlmax.size() <= i || in.mlmax[i] < 0 || in.mlmax[i] > 24));
+    }
+    if constexpr (sizeof(T) == 4) {
       static const int ortho = getenv("PEPSGPU_ORTHO_POLISH") ? atoi(getenv("PEPSGPU_ORTHO_POLISH")) : 1;
       const size_t osm = ortho_rows_smem(k, uk);
-      if (ortho && k >= 2 && k <= 64 && osm <= 96 * 1024) {
+      if (ortho && precise_site && k >= 2 && k <= 64 && osm <= 96 * 1024) {
         allow_dynamic_lds(reinterpret_cast<const void *>(&ortho_rows_kernel), osm);
         prof_begin(PROF_SELECT, 0.0, 0.0);
         hipLaunchKernelGGL(ortho_rows_kernel, dim3(nw_), dim3(256), osm, stream_, (float *)V.p, V.n, k, uk, (const int *)kn[i], uk + 1);
@@ -901,12 +910,14 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       g.prefer_tiled = dense_site;
       static const bool y_tiled = getenv("PEPSGPU_Y_TILED") != nullptr;     // experiments: Y on the LDS-tiled f32 kernel
       if (y_tiled) g.prefer_tiled = true;
-      // float64-grade accumulation of Y on the wave-per-tile kernel (f32 chains of 8 products drained into f64 registers):
-      // 0 = never, 1 = where the row absorbed before ran a carry above 32 rows at this site or gives no hint yet (default), 2 = always
-      static const int y_acc64 = getenv("PEPSGPU_Y_ACC64") ? atoi(getenv("PEPSGPU_Y_ACC64")) : 1;
+      // Y on precise sites: 2 (default) = float64 accumulation on the LDS-tiled kernel (f64 matrix cores) + separate normalisation;
+      // 1 = the wave-per-tile kernel with its f32 chains of 8 products drained into float64 registers (measured: takes out a third
+      // of the error only -- the cancellation is inside the 8-term sums too); 0 = the f32 chain of round 3
+      static const int y_mode = getenv("PEPSGPU_Y_ACC64") ? atoi(getenv("PEPSGPU_Y_ACC64")) : 2;
+      bool y_f64 = false;
       if constexpr (sizeof(T) == 4) {
-        const bool dense_y = in.depth < 3 || (int)in.mlmax.size() <= i || in.mlmax[i] < 0 || in.mlmax[i] > 32;
-        g.acc64 = (y_acc64 == 2 || (y_acc64 == 1 && dense_y)) ? 1 : 0;
+        g.acc64 = (precise_site && y_mode == 1) ? 1 : 0;
+        y_f64 = precise_site && y_mode == 2;
       }
       // reference op: res[i-1] . (u s)  (bmps_impl.h:254): 2 (m_{i-1} D_u) m_i k_i
       int rp, cp, ddp[4];
@@ -917,14 +928,14 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       bool fused_norm = false;
       if constexpr (sizeof(T) == 4) {
         static const bool no_fn = getenv("PEPSGPU_NO_FUSED_NORM") != nullptr;
-        if (!no_fn && !acc64 && !y_tiled && bond_adapt && kn[i] && tgemm_one_block_direct(g)) {
+        if (!no_fn && !acc64 && !y_tiled && !y_f64 && bond_adapt && kn[i] && tgemm_one_block_direct(g)) {
           if (!yscale) yscale = (float *)arena_.alloc(sizeof(float) * nw_);
           g.scale_out = yscale; g.norm_log = out.logscale; g.norm_flag = flag_;
           fused_norm = true;
         }
       }
       prof_begin(PROF_CONTRACT, 2.0 * nw_ * (double)R[i - 1].d[0] * ddp[lu] * (double)m * k, 2.0 * nw_ * (double)la * uk * (double)k);
-      if (acc64 & 8) tgemm_launch<T, T, T, Acc>(stream_, g, Tt.p, V.p, Yn.p);
+      if ((acc64 & 8) || y_f64) tgemm_launch<T, T, T, Acc>(stream_, g, Tt.p, V.p, Yn.p);
       else tgemm_launch<T, T, T, T>(stream_, g, Tt.p, V.p, Yn.p);
       prof_end();
       y_scaled = fused_norm;

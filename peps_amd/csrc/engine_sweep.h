@@ -1,0 +1,143 @@
+// One row (or column) of nearest-neighbour exchange updates of the Monte-Carlo sweep on the device
+// (MCUpdateSquareNNUpdateBaseOBC::operator() + MCUpdateSquareNNExchangeOBC::TwoSiteNNUpdateLocalImpl, square_nn_updater.h:25-83,
+// :142-189; TPSWaveFunctionComponent::UpdateLocal, wave_function_component.h:345-378).
+//
+// The host-driven form pays, per bond, a candidate upload, the read-back of psi', the Metropolis test on the host, an upload of
+// the whole configuration table for the accepted walkers and two stream synchronisations: 264 bonds x ~3 ms per sweep of 8192
+// walkers, 3-4 x the contraction work (7.6 k sweeps/s against 29 k amplitude-equivalents).  Here ONE call runs a
+// whole slice: InitBTen + GrowFullBTen of the slice, then per bond the replacement trace of the exchanged pair (candidate table
+// built on the device), the Metropolis test, the exchange in the device's configuration table, and the BTen window shift -- no
+// host round trip inside the slice.
+//
+// Identical chains: the reference draws a uniform deviate only when the spins differ and |psi'| < |psi| (square_nn_updater.h:
+// 160-170).  The host hands over, per walker, the NEXT `n_uniform` deviates of that walker's std::mt19937 stream (drawn ahead into
+// a queue, qlpeps_gpu.h: UniformQueue); the kernel consumes them in order and reports how many it took, the host pops exactly
+// those -- the deviates a walker consumes are the ones the reference's updater would have drawn, in the same order.
+//
+// Environment bookkeeping: UpdateLocal erases the environments that cross an updated site (EraseEnvsAfterUpdate).  Inside a slice
+// pass that erase never removes anything the pass still holds (LEFT covers [0, col), RIGHT covers (col + 1, N): checked against
+// the reference's flow), so it is applied unconditionally -- the decision "did any walker accept" would cost a read-back per bond.
+#pragma once
+#include "engine.h"
+
+namespace pepsgpu {
+
+// cand[w] = (cfg[w][s2], cfg[w][s1]): the exchanged pair
+__global__ void sweep_swap_cand_kernel(const int *__restrict__ cfg, int sites, int s1, int s2, int *__restrict__ cand, int n) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n) return;
+  cand[2 * w] = cfg[(long)w * sites + s2];
+  cand[2 * w + 1] = cfg[(long)w * sites + s1];
+}
+
+// Metropolis test of the exchange (square_nn_updater.h:149-170) and the accepted exchange itself
+template <typename AccT>
+__global__ void sweep_metropolis_exchange_kernel(int *__restrict__ cfg, int sites, int s1, int s2, const AccT *__restrict__ res,
+                                                 const double *__restrict__ lsum, double *__restrict__ amp,
+                                                 const double *__restrict__ uni, int nu, int *__restrict__ uptr,
+                                                 int *__restrict__ acc, int *__restrict__ overrun, int n) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n) return;
+  const int c1 = cfg[(long)w * sites + s1], c2 = cfg[(long)w * sites + s2];
+  if (c1 == c2) return;                                   // :149-151
+  const double psi_b = (double)res[w] * exp(lsum[w]);
+  const double pa = fabs(amp[w]), pb = fabs(psi_b);
+  bool exchange;
+  if (pb >= pa) exchange = true;
+  else {
+    const double div = pb / pa;
+    const int q = uptr[w];
+    if (q >= nu) { *overrun = 1; return; }               // (cannot happen: the host hands over one deviate per bond of the slice)
+    exchange = uni[(long)w * nu + q] < div * div;
+    uptr[w] = q + 1;
+  }
+  if (exchange) {
+    cfg[(long)w * sites + s1] = c2;
+    cfg[(long)w * sites + s2] = c1;
+    amp[w] = psi_b;
+    acc[w] += 1;
+  }
+}
+
+__global__ void sweep_gather_slice_kernel(const int *__restrict__ cfg, int sites, int first, int stride, int len, int *__restrict__ out, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * len) return;
+  const int w = e / len, j = e - w * len;
+  out[e] = cfg[(long)w * sites + first + j * stride];
+}
+
+template <typename T>
+void Engine<T>::sweep_slice_exchange(int orient, int slice, int n_uniform, const double *uniforms, double *amp_inout,
+                                     int32_t *consumed_out, int32_t *accepted_out, int32_t *slice_states_out) {
+  require_ready();
+  if constexpr (kCplx) {
+    PG_REQUIRE(false, 1, "device-side slice sweep: real element types only (complex contexts use the per-bond calls)");
+  } else {
+    PG_REQUIRE(orient == HORIZONTAL || orient == VERTICAL, 1, "bad orientation");
+    const int N = orient == HORIZONTAL ? Lx_ : Ly_, lim = orient == HORIZONTAL ? Ly_ : Lx_;
+    PG_REQUIRE(slice >= 0 && slice < lim, 1, "slice outside the lattice");
+    PG_REQUIRE(n_uniform >= N - 1, 1, "one uniform deviate per bond of the slice is needed");
+    const int sites = Ly_ * Lx_;
+    // persistent-for-the-call buffers (outside the ArenaScope'd operations they bracket)
+    double *damp = (double *)arena_.alloc(sizeof(double) * nw_);
+    double *duni = (double *)arena_.alloc(sizeof(double) * (size_t)nw_ * n_uniform);
+    int *dptr = (int *)arena_.alloc(sizeof(int) * (2 * (size_t)nw_ + 1));
+    int *dacc = dptr + nw_, *dover = dptr + 2 * nw_;
+    int *dcand = (int *)arena_.alloc(sizeof(int) * 2 * (size_t)nw_);
+    int *dslice = (int *)arena_.alloc(sizeof(int) * (size_t)nw_ * N);
+    auto release = [&]() { arena_.free(damp); arena_.free(duni); arena_.free(dptr); arena_.free(dcand); arena_.free(dslice); };
+    try {
+      PG_CHECK_HIP(hipMemcpyAsync(damp, amp_inout, sizeof(double) * nw_, hipMemcpyHostToDevice, stream_));
+      PG_CHECK_HIP(hipMemcpyAsync(duni, uniforms, sizeof(double) * (size_t)nw_ * n_uniform, hipMemcpyHostToDevice, stream_));
+      PG_CHECK_HIP(hipMemsetAsync(dptr, 0, sizeof(int) * (2 * (size_t)nw_ + 1), stream_));
+      const int lo = orient == HORIZONTAL ? LEFT : UP, hi = orient == HORIZONTAL ? RIGHT : DOWN;
+      init_bten(lo, slice);
+      grow_full_bten(hi, slice, 2, 1);
+      const int gb = (nw_ + 255) / 256;
+      for (int j = 0; j + 1 < N; ++j) {
+        const int r1 = orient == HORIZONTAL ? slice : j, c1 = orient == HORIZONTAL ? j : slice;
+        const int r2 = orient == HORIZONTAL ? slice : j + 1, c2 = orient == HORIZONTAL ? j + 1 : slice;
+        const int s1 = r1 * Lx_ + c1, s2 = r2 * Lx_ + c2;
+        hipLaunchKernelGGL(sweep_swap_cand_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)cfg_, sites, s1, s2, dcand, nw_);
+        PG_CHECK_HIP(hipGetLastError());
+        double *lsum = nullptr;
+        Acc *res = nn_trace_device(r1, c1, orient, 1, dcand, &lsum);
+        hipLaunchKernelGGL(sweep_metropolis_exchange_kernel<Acc>, dim3(gb), dim3(256), 0, stream_, cfg_, sites, s1, s2, (const Acc *)res,
+                           (const double *)lsum, damp, (const double *)duni, n_uniform, dptr, dacc, dover, nw_);
+        PG_CHECK_HIP(hipGetLastError());
+        arena_.free(res);
+        arena_.free(lsum);
+        erase_envs_after_update(r1, c1);
+        erase_envs_after_update(r2, c2);
+        if (j + 2 < N) shift_bten_window(hi);
+      }
+      hipLaunchKernelGGL(sweep_gather_slice_kernel, dim3((nw_ * N + 255) / 256), dim3(256), 0, stream_, (const int *)cfg_, sites,
+                         orient == HORIZONTAL ? slice * Lx_ : slice, orient == HORIZONTAL ? 1 : Lx_, N, dslice, nw_);
+      PG_CHECK_HIP(hipGetLastError());
+      std::vector<int> hs((size_t)nw_ * N), hp(2 * (size_t)nw_ + 1);
+      PG_CHECK_HIP(hipMemcpyAsync(amp_inout, damp, sizeof(double) * nw_, hipMemcpyDeviceToHost, stream_));
+      PG_CHECK_HIP(hipMemcpyAsync(hs.data(), dslice, sizeof(int) * hs.size(), hipMemcpyDeviceToHost, stream_));
+      PG_CHECK_HIP(hipMemcpyAsync(hp.data(), dptr, sizeof(int) * hp.size(), hipMemcpyDeviceToHost, stream_));
+      PG_CHECK_HIP(hipStreamSynchronize(stream_));
+      PG_REQUIRE(hp[2 * (size_t)nw_] == 0, 5, "device-side slice sweep: uniform deviates exhausted");
+      for (int w = 0; w < nw_; ++w) {
+        consumed_out[w] = hp[w];
+        accepted_out[w] = hp[nw_ + w];
+        for (int j = 0; j < N; ++j) {
+          const int v = hs[(size_t)w * N + j];
+          const int r = orient == HORIZONTAL ? slice : j, c = orient == HORIZONTAL ? j : slice;
+          hcfg_[(size_t)w * sites + r * Lx_ + c] = v;          // host mirror of the configuration table
+          if (slice_states_out) slice_states_out[(size_t)w * N + j] = v;
+        }
+      }
+    } catch (...) {
+      // the device table may hold exchanges the host has not seen: bring the mirror back in step before reporting the failure
+      (void)hipMemcpy(hcfg_.data(), cfg_, sizeof(int) * (size_t)nw_ * sites, hipMemcpyDeviceToHost);
+      release();
+      throw;
+    }
+    release();
+  }
+}
+
+}  // namespace pepsgpu

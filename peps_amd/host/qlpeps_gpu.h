@@ -790,7 +790,30 @@ class MonteCarloSweepUpdaterBase {
  protected:
   std::vector<std::mt19937> engines_;
   std::uniform_real_distribution<double> u_double_;
+  // Deviates drawn AHEAD of their use (device-side slice sweeps hand the next few of every walker's stream to the kernel, which
+  // consumes a prefix): a walker's deviates are always taken from the front of its queue first, so the sequence it consumes is
+  // the sequence u_double_(engines_[w]) yields -- whichever path (device slice, per-bond host test) asks for the next one.
+  std::vector<std::vector<double>> ahead_;     // [walker] drawn, not yet consumed (front = ahead_head_[w])
+  std::vector<size_t> ahead_head_;
+  double NextUniform(size_t w) {
+    if (w < ahead_.size() && ahead_head_[w] < ahead_[w].size()) return ahead_[w][ahead_head_[w]++];
+    return u_double_(engines_[w]);
+  }
+  // the next `cnt` deviates of walker w without consuming them
+  const double *PeekUniforms(size_t w, size_t cnt) {
+    if (ahead_.size() < engines_.size()) { ahead_.resize(engines_.size()); ahead_head_.resize(engines_.size(), 0); }
+    auto &q = ahead_[w];
+    if (ahead_head_[w] > 0 && ahead_head_[w] == q.size()) { q.clear(); ahead_head_[w] = 0; }
+    else if (ahead_head_[w] > 64) { q.erase(q.begin(), q.begin() + (long)ahead_head_[w]); ahead_head_[w] = 0; }
+    while (q.size() - ahead_head_[w] < cnt) q.push_back(u_double_(engines_[w]));
+    return q.data() + ahead_head_[w];
+  }
+  void ConsumeUniforms(size_t w, size_t cnt) { ahead_head_[w] += cnt; }
 };
+
+// an updater opts into the device-side slice sweep with `static constexpr bool kDeviceSliceSweep = true` + SweepSliceOnDevice
+template <typename U, typename = void> struct HasDeviceSliceSweep : std::false_type {};
+template <typename U> struct HasDeviceSliceSweep<U, std::void_t<decltype(U::kDeviceSliceSweep)>> : std::bool_constant<U::kDeviceSliceSweep> {};
 
 // square_nn_updater.h:25-83: sweep schedule, CRTP hook TwoSiteNNUpdateLocalImpl(site1, site2, dir, sitps, comp) -> accepted[w]
 template <typename MCUpdater>
@@ -803,14 +826,26 @@ class MCUpdateSquareNNUpdateBaseOBC : public MonteCarloSweepUpdaterBase {
     const size_t rows = c.rows(), cols = c.cols(), n = comp.config.walkers();
     std::vector<size_t> acc(n, 0);
     auto add = [&](const std::vector<uint8_t> &a) { for (size_t w = 0; w < n; ++w) acc[w] += a[w]; };
+    // An updater whose bond move the device implements (the exchange updater, real bosonic states) runs a whole row / column of
+    // bonds in ONE call (pepsgpu_sweep_slice_exchange: traces, Metropolis tests and exchanges on the device, same deviates in the
+    // same order -> the same chain); every other updater goes through its TwoSiteNNUpdateLocalImpl hook bond by bond.
+    // PEPSHOST_NO_DEVICE_SWEEP=1 forces the hook path (A/B and the identical-chain test of the two paths).
+    static const bool no_dev = std::getenv("PEPSHOST_NO_DEVICE_SWEEP") != nullptr;
+    bool dev_slice = false;
+    if constexpr (std::is_same<TenElemT, double>::value && HasDeviceSliceSweep<MCUpdater>::value) dev_slice = !no_dev && !comp.fermion;
     comp.SetOrder(ROW_MAJOR);                // fermions: horizontal bonds are local in the row-major mode order
     c.GenerateBMPSApproach(UP);
     for (size_t row = 0; row < rows; row++) {
-      c.InitBTen(LEFT, row);
-      c.GrowFullBTen(RIGHT, row, 2, true);
-      for (size_t col = 0; col + 1 < cols; col++) {
-        add(static_cast<MCUpdater *>(this)->TwoSiteNNUpdateLocalImpl({row, col}, {row, col + 1}, HORIZONTAL, sitps, comp));
-        if (col + 2 < cols) c.ShiftBTenWindow(RIGHT);
+      if (dev_slice) {
+        if constexpr (std::is_same<TenElemT, double>::value && HasDeviceSliceSweep<MCUpdater>::value)
+          static_cast<MCUpdater *>(this)->SweepSliceOnDevice(HORIZONTAL, row, comp, acc);
+      } else {
+        c.InitBTen(LEFT, row);
+        c.GrowFullBTen(RIGHT, row, 2, true);
+        for (size_t col = 0; col + 1 < cols; col++) {
+          add(static_cast<MCUpdater *>(this)->TwoSiteNNUpdateLocalImpl({row, col}, {row, col + 1}, HORIZONTAL, sitps, comp));
+          if (col + 2 < cols) c.ShiftBTenWindow(RIGHT);
+        }
       }
       if (row + 1 < rows) c.ShiftBMPSWindow(DOWN);
     }
@@ -819,11 +854,16 @@ class MCUpdateSquareNNUpdateBaseOBC : public MonteCarloSweepUpdaterBase {
     comp.SetOrder(COL_MAJOR);                // fermions: vertical bonds are local in the column-major mode order
     c.GenerateBMPSApproach(LEFT);
     for (size_t col = 0; col < cols; col++) {
-      c.InitBTen(UP, col);
-      c.GrowFullBTen(DOWN, col, 2, true);
-      for (size_t row = 0; row + 1 < rows; row++) {
-        add(static_cast<MCUpdater *>(this)->TwoSiteNNUpdateLocalImpl({row, col}, {row + 1, col}, VERTICAL, sitps, comp));
-        if (row + 2 < rows) c.ShiftBTenWindow(DOWN);
+      if (dev_slice) {
+        if constexpr (std::is_same<TenElemT, double>::value && HasDeviceSliceSweep<MCUpdater>::value)
+          static_cast<MCUpdater *>(this)->SweepSliceOnDevice(VERTICAL, col, comp, acc);
+      } else {
+        c.InitBTen(UP, col);
+        c.GrowFullBTen(DOWN, col, 2, true);
+        for (size_t row = 0; row + 1 < rows; row++) {
+          add(static_cast<MCUpdater *>(this)->TwoSiteNNUpdateLocalImpl({row, col}, {row + 1, col}, VERTICAL, sitps, comp));
+          if (row + 2 < rows) c.ShiftBTenWindow(DOWN);
+        }
       }
       if (col + 1 < cols) c.ShiftBMPSWindow(RIGHT);
     }
@@ -838,6 +878,26 @@ class MCUpdateSquareNNUpdateBaseOBC : public MonteCarloSweepUpdaterBase {
 class MCUpdateSquareNNExchangeOBC : public MCUpdateSquareNNUpdateBaseOBC<MCUpdateSquareNNExchangeOBC> {
  public:
   using MCUpdateSquareNNUpdateBaseOBC<MCUpdateSquareNNExchangeOBC>::MCUpdateSquareNNUpdateBaseOBC;
+  static constexpr bool kDeviceSliceSweep = true;
+  // one row / column of exchange moves on the device (pepsgpu_sweep_slice_exchange); walker w consumes the next consumed[w]
+  // deviates of its stream, exactly those TwoSiteNNUpdateLocalImpl would draw
+  void SweepSliceOnDevice(BondOrientation dir, size_t slice, TPSWaveFunctionComponentT<double> &comp, std::vector<size_t> &acc) {
+    auto &c = comp.contractor;
+    const size_t n = comp.config.walkers(), N = dir == HORIZONTAL ? c.cols() : c.rows(), nu = N - 1;
+    std::vector<double> uni(n * nu);
+    for (size_t w = 0; w < n; ++w) {
+      const double *q = PeekUniforms(w, nu);
+      std::copy(q, q + nu, uni.begin() + (long)(w * nu));
+    }
+    std::vector<int32_t> consumed(n), accepted(n), states(n * N);
+    check_rc(pepsgpu_sweep_slice_exchange(c.ctx(), dir, (int)slice, (int)nu, uni.data(), comp.amplitude.data(), consumed.data(), accepted.data(),
+                                          states.data()), c.ctx());
+    for (size_t w = 0; w < n; ++w) {
+      ConsumeUniforms(w, (size_t)consumed[w]);
+      acc[w] += (size_t)accepted[w];
+      for (size_t j = 0; j < N; ++j) comp.config(w, dir == HORIZONTAL ? SiteIdx{slice, j} : SiteIdx{j, slice}) = states[w * N + j];
+    }
+  }
   template <typename TenElemT>
   std::vector<uint8_t> TwoSiteNNUpdateLocalImpl(const SiteIdx &s1, const SiteIdx &s2, BondOrientation dir,
                                                 const SplitIndexTPST<TenElemT> &, TPSWaveFunctionComponentT<TenElemT> &comp) {
@@ -858,7 +918,7 @@ class MCUpdateSquareNNExchangeOBC : public MCUpdateSquareNNUpdateBaseOBC<MCUpdat
       if (pb >= pa) exchange[w] = 1;
       else {
         const double div = pb / pa;
-        exchange[w] = u_double_(engines_[w]) < div * div;
+        exchange[w] = NextUniform(w) < div * div;
       }
     }
     comp.UpdateLocal(psi_b, {s1, s2}, cand, exchange);
@@ -870,6 +930,7 @@ class MCUpdateSquareNNExchangeOBC : public MCUpdateSquareNNUpdateBaseOBC<MCUpdat
 class MCUpdateSquareNNFullSpaceUpdateOBC : public MCUpdateSquareNNUpdateBaseOBC<MCUpdateSquareNNFullSpaceUpdateOBC> {
  public:
   using MCUpdateSquareNNUpdateBaseOBC<MCUpdateSquareNNFullSpaceUpdateOBC>::MCUpdateSquareNNUpdateBaseOBC;
+  static constexpr bool kDeviceSliceSweep = false;
   template <typename TenElemT>
   std::vector<uint8_t> TwoSiteNNUpdateLocalImpl(const SiteIdx &s1, const SiteIdx &s2, BondOrientation dir,
                                                 const SplitIndexTPST<TenElemT> &sitps, TPSWaveFunctionComponentT<TenElemT> &comp) {

@@ -30,7 +30,7 @@ constexpr int BM = 64, BN = 128, KC = 32;     // K walked in LDS chunks of 32
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int K>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float *__restrict__ Ag, const float *__restrict__ Bg, float *__restrict__ Cg,
-                                                          int M, int N) {
+                                                          int M, int N, int store, int kreps) {
   // LDS images k-major: sA[k][BM + 1], sB[k][BN + 1] (a lane reads row r of k-plane h: consecutive floats, conflict free)
   __shared__ float sA[KC][BM + 4];
   __shared__ float sB[KC][BN + 4];
@@ -40,8 +40,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float *__restric
   const float *B = Bg + (long)b * N * K + (long)n0 * K;
   const int r = lane & 31, h = lane >> 5;
   f32x16 acc0 = {0}, acc1 = {0};
+  for (int rep = 0; rep < kreps; ++rep)
   for (int kc = 0; kc < K; kc += KC) {
-    if (kc) __syncthreads();
+    if (kc || rep) __syncthreads();
     // stage: float4 along k (k-contiguous operands), transposed into the k-major images
     for (int e = tid; e < BM * KC / 4; e += 256) {
       const int rr = e / (KC / 4), k4 = (e - rr * (KC / 4)) * 4;
@@ -67,8 +68,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float *__restric
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
-    C[(long)(m0 + row) * N + n0 + 32 * wave + r] = acc0[q];
-    C[(long)(m0 + 32 + row) * N + n0 + 32 * wave + r] = acc1[q];
+    if (store || acc0[q] != acc0[q]) C[(long)(m0 + row) * N + n0 + 32 * wave + r] = acc0[q];
+    if (store || acc1[q] != acc1[q]) C[(long)(m0 + 32 + row) * N + n0 + 32 * wave + r] = acc1[q];
   }
 }
 
@@ -90,7 +91,7 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned &hi, unsigne
 
 template <int K, int NPROD>
 __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(const float *__restrict__ Ag, const float *__restrict__ Bg, float *__restrict__ Cg,
-                                                          int M, int N) {
+                                                          int M, int N, int store, int kreps) {
   constexpr int LD = KC + 8;                        // bf16 elements per LDS row (+16 bytes: conflict-free 16-byte row reads)
   __shared__ __attribute__((aligned(16))) unsigned short sA[3][BM][LD];
   __shared__ __attribute__((aligned(16))) unsigned short sB[3][BN][LD];
@@ -100,8 +101,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(const float *__restric
   const float *B = Bg + (long)b * N * K + (long)n0 * K;
   const int r = lane & 31, h = lane >> 5;
   f32x16 acc0 = {0}, acc1 = {0};
+  for (int rep = 0; rep < kreps; ++rep)
   for (int kc = 0; kc < K; kc += KC) {
-  if (kc) __syncthreads();
+  if (kc || rep) __syncthreads();
   for (int e = tid; e < BM * KC / 4; e += 256) {
     const int rr = e / (KC / 4), k4 = (e - rr * (KC / 4)) * 4;
     const float4 v = *reinterpret_cast<const float4 *>(A + (long)rr * K + kc + k4);
@@ -155,8 +157,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(const float *__restric
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
-    C[(long)(m0 + row) * N + n0 + 32 * wave + r] = acc0[q];
-    C[(long)(m0 + 32 + row) * N + n0 + 32 * wave + r] = acc1[q];
+    if (store || acc0[q] != acc0[q]) C[(long)(m0 + row) * N + n0 + 32 * wave + r] = acc0[q];
+    if (store || acc1[q] != acc1[q]) C[(long)(m0 + 32 + row) * N + n0 + 32 * wave + r] = acc1[q];
   }
 }
 
@@ -196,22 +198,31 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(dB, hB.data(), nbt * 4, hipMemcpyHostToDevice));
     const dim3 grid(s.N / BN, s.M / BM, nb);
     const double flops = 2.0 * s.M * s.N * s.K * nb;
+    for (int mode = 0; mode < 2; ++mode)      // 0: the GEMM as it is (results to HBM); 1: compute only (K loop x 16 on resident operands, no store)
     for (int variant = 0; variant < 4; ++variant) {
+      const int store = mode == 0, kreps = mode == 0 ? 1 : 16;
       auto launch = [&]() {
         if (s.K == 32) {
-          if (variant == 0) hipLaunchKernelGGL((gemm_f32_kernel<32>), grid, dim3(256), 0, 0, dA, dB, dC, s.M, s.N);
-          else if (variant == 1) hipLaunchKernelGGL((gemm_bf3_kernel<32, 6>), grid, dim3(256), 0, 0, dA, dB, dC, s.M, s.N);
-          else if (variant == 2) hipLaunchKernelGGL((gemm_bf3_kernel<32, 3>), grid, dim3(256), 0, 0, dA, dB, dC, s.M, s.N);
-          else hipLaunchKernelGGL((gemm_bf3_kernel<32, 1>), grid, dim3(256), 0, 0, dA, dB, dC, s.M, s.N);
+          if (variant == 0) hipLaunchKernelGGL((gemm_f32_kernel<32>), grid, dim3(256), 0, 0, dA, dB, dC, s.M, s.N, store, kreps);
+          else if (variant == 1) hipLaunchKernelGGL((gemm_bf3_kernel<32, 6>), grid, dim3(256), 0, 0, dA, dB, dC, s.M, s.N, store, kreps);
+          else if (variant == 2) hipLaunchKernelGGL((gemm_bf3_kernel<32, 3>), grid, dim3(256), 0, 0, dA, dB, dC, s.M, s.N, store, kreps);
+          else hipLaunchKernelGGL((gemm_bf3_kernel<32, 1>), grid, dim3(256), 0, 0, dA, dB, dC, s.M, s.N, store, kreps);
         } else {
-          if (variant == 0) hipLaunchKernelGGL((gemm_f32_kernel<64>), grid, dim3(256), 0, 0, dA, dB, dC, s.M, s.N);
-          else if (variant == 1) hipLaunchKernelGGL((gemm_bf3_kernel<64, 6>), grid, dim3(256), 0, 0, dA, dB, dC, s.M, s.N);
-          else if (variant == 2) hipLaunchKernelGGL((gemm_bf3_kernel<64, 3>), grid, dim3(256), 0, 0, dA, dB, dC, s.M, s.N);
-          else hipLaunchKernelGGL((gemm_bf3_kernel<64, 1>), grid, dim3(256), 0, 0, dA, dB, dC, s.M, s.N);
+          if (variant == 0) hipLaunchKernelGGL((gemm_f32_kernel<64>), grid, dim3(256), 0, 0, dA, dB, dC, s.M, s.N, store, kreps);
+          else if (variant == 1) hipLaunchKernelGGL((gemm_bf3_kernel<64, 6>), grid, dim3(256), 0, 0, dA, dB, dC, s.M, s.N, store, kreps);
+          else if (variant == 2) hipLaunchKernelGGL((gemm_bf3_kernel<64, 3>), grid, dim3(256), 0, 0, dA, dB, dC, s.M, s.N, store, kreps);
+          else hipLaunchKernelGGL((gemm_bf3_kernel<64, 1>), grid, dim3(256), 0, 0, dA, dB, dC, s.M, s.N, store, kreps);
         }
       };
       CK(hipMemset(dC, 0, nc * 4));
       const double ms = time_ms(launch, reps);
+      const char *vn[4] = {"f32 mfma 32x32x2", "bf16 x3, 6 products", "bf16 x3, 3 products (hi.hi, hi.mid, mid.hi)", "bf16 x1 (hi.hi only)"};
+      if (mode == 1) {
+        printf("{\"shape\": \"%s\", \"variant\": \"%s\", \"mode\": \"compute only (staging + split + MFMA x16, no store)\", \"batch\": %d, "
+               "\"ms\": %.4f, \"tflops\": %.2f}\n", s.name, vn[variant], nb, ms, flops * kreps / ms * 1e-9);
+        fflush(stdout);
+        continue;
+      }
       CK(hipMemcpy(hC.data(), dC, nc * 4, hipMemcpyDeviceToHost));
       // error against float64 on a sample of entries of batch entries 0 and nb - 1
       double emax = 0.0, erms = 0.0;
@@ -227,9 +238,9 @@ int main(int argc, char **argv) {
             const double e = fabs(hC[((size_t)bb * s.M + i) * s.N + j] - ref) / mag;
             emax = fmax(emax, e); erms += e * e; ++cnt;
           }
-      const char *vn[4] = {"f32 mfma 32x32x2", "bf16 x3, 6 products", "bf16 x3, 3 products (hi.hi, hi.mid, mid.hi)", "bf16 x1 (hi.hi only)"};
-      printf("{\"shape\": \"%s\", \"variant\": \"%s\", \"batch\": %d, \"ms\": %.4f, \"tflops\": %.2f, \"err_max_rel_to_abs_sum\": %.3e, "
-             "\"err_rms\": %.3e}\n", s.name, vn[variant], nb, ms, flops / ms * 1e-9, emax, sqrt(erms / cnt));
+      printf("{\"shape\": \"%s\", \"variant\": \"%s\", \"mode\": \"gemm (operands from HBM, result to HBM)\", \"batch\": %d, \"ms\": %.4f, "
+             "\"tflops\": %.2f, \"hbm_GBps\": %.0f, \"err_max_rel_to_abs_sum\": %.3e, \"err_rms\": %.3e}\n", s.name, vn[variant], nb, ms,
+             flops / ms * 1e-9, 4.0 * (na + nbt + nc) / ms * 1e-6, emax, sqrt(erms / cnt));
       fflush(stdout);
     }
     CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC));

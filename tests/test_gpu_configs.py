@@ -55,7 +55,8 @@ def test_c1_tfim_4x4_exact_summation(dt, tol):
 
 def test_c2_tfim_8x8_local_updater_chain_and_energy():
     """C2: 8x8 TFIM, D=4, chi=16, local MC updater.  f64: the Markov chain is the oracle's chain
-    (same std::mt19937 stream); f32: amplitudes / local energies of fixed configurations 1e-5."""
+    (same std::mt19937 stream); amplitudes / local energies of the start and the arrival configurations: f64 1e-9,
+    f32 amplitude 1e-5 / energy 1e-6."""
     host = _host()
     L, D, chi, h = 8, 4, 16, 3.0
     s = synthetic.make_sitps(L, D)
@@ -72,12 +73,19 @@ def test_c2_tfim_8x8_local_updater_chain_and_energy():
         assert abs(amps[w] / comp.amplitude - 1) < 1e-8
         assert abs(rates[w] - r) < 1e-12
     model = vmc.TransverseFieldIsingSquareOBC(h)
-    a32, e32, _, psi = host.energy_and_holes(flat, cfgs, chi, "tfim", (h,), False, F32)
-    for w in range(len(cfgs)):
-        comp = vmc.TPSWaveFunctionComponent(s, cfgs[w], tp)
-        e, _, _ = model.CalEnergyAndHoles(s, comp, False)
-        assert abs(a32[w] / comp.amplitude - 1) < 1e-5
-        assert abs(e32[w] / e - 1) < 1e-5
+    # local energy on the configurations the chains START from and on the ones they ARRIVE at (north_star: energy 1e-6 relative;
+    # f64 is the parity-grade mode, f32 the throughput mode -- both asserted at 1e-6, the amplitude at 1e-9 / 1e-5)
+    both = np.concatenate([cfgs, out_cfg])
+    ref = []
+    for c in both:
+        comp = vmc.TPSWaveFunctionComponent(s, c, tp)
+        ref.append((comp.amplitude, model.CalEnergyAndHoles(s, comp, False)[0]))
+    ref_a, ref_e = np.array([r[0] for r in ref]), np.array([r[1] for r in ref])
+    for dt, tol_a, tol_e in ((F64, 1e-9, 1e-9), (F32, 1e-5, 1e-6)):
+        a, e, _, psi = host.energy_and_holes(flat, both, chi, "tfim", (h,), False, dt)
+        ra, re = np.abs(a / ref_a - 1), np.abs(e / ref_e - 1)
+        print("C2 %s: amplitude rel err max %.2e, energy rel err max %.2e (n = %d)" % ("f64" if dt == F64 else "f32", ra.max(), re.max(), len(both)))
+        assert ra.max() < tol_a and re.max() < tol_e, (ra, re)
 
 
 @pytest.mark.parametrize("name,nref", [("C3", 4), ("C4", 3)])

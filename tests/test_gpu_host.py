@@ -169,6 +169,44 @@ def test_mc_sweep_consistency_f32(fixtures_dir):
         assert abs(amps[w] / fresh - 1) < 1e-4
 
 
+def test_device_slice_sweep_is_the_per_bond_chain():
+    """pepsgpu_sweep_slice_exchange (a whole row / column of exchange moves on the device: traces, Metropolis tests with the
+    deviates the host drew ahead, exchanges in the device's configuration table) against the per-bond hook path of the same
+    updater (PEPSHOST_NO_DEVICE_SWEEP=1): identical configurations, accept rates and amplitudes after three sweeps, f64 and f32 --
+    the device path consumes exactly the deviates the reference's TwoSiteNNUpdateLocalImpl draws, in the same order
+    (square_nn_updater.h:142-189).  (The f64 device path is also the one test_mc_chain_identical_to_oracle_f64 holds against
+    the oracle's chain.)"""
+    import json
+    import subprocess
+    import sys
+    code = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from peps_amd import hostapi, synthetic
+L, D, chi = 6, 4, 12
+flat = synthetic.sitps_to_flat(synthetic.make_sitps(L, D, noise=0.5), D)
+cfgs = synthetic.make_configs(L, 24, "heisenberg", seed0=13)
+out = {}
+for name, dt in (("f64", 1), ("f32", 0)):
+    c, a, r = hostapi.mc_sweeps(flat, cfgs, np.arange(24, dtype=np.uint64) + 90, chi, "exchange", 3, dt)
+    out[name] = {"cfg": c.tolist(), "amp": [float(x) for x in a], "rate": [float(x) for x in r]}
+print(json.dumps(out))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for name, env in (("device", {}), ("hook", {"PEPSHOST_NO_DEVICE_SWEEP": "1"})):
+        r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    for dt, tol in (("f64", 1e-12), ("f32", 1e-5)):
+        a, b = res["device"][dt], res["hook"][dt]
+        assert a["cfg"] == b["cfg"], dt                      # the same chain
+        assert a["rate"] == b["rate"] and max(a["rate"]) > 0
+        assert np.max(np.abs(np.array(a["amp"]) / np.array(b["amp"]) - 1)) < tol
+    assert res["device"]["f64"]["cfg"] != synthetic.make_configs(6, 24, "heisenberg", seed0=13).tolist()      # ... and it moved
+
+
 def test_device_gradient_accumulation_matches_host_path(fixtures_dir):
     """pepsgpu_grad_accumulate (holes resident in HBM) == host-side accumulation of PunchHole outputs."""
     from peps_amd import capi

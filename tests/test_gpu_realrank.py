@@ -109,3 +109,26 @@ def test_real_rank_c4_batch_f32_vs_f64_and_routes():
         assert np.median(rel) < 3e-5 and np.sum(rel > 1e-4) <= 2 and np.max(rel) < 3e-4, \
             (int(np.argmax(rel)), float(np.max(rel)), float(np.median(rel)), int(np.sum(rel > 1e-4)))
     assert np.max(np.abs(col[capi.F64] / row[capi.F64] - 1)) < 1e-3
+
+
+def test_real_rank_c4_amplitudes_vs_oracle():
+    """The tiled real state at C4 (12x12, D=8, chi=32) against the ORACLE itself (oracle/cbmps.c, the float64 plain-C restatement
+    of bmps_impl.h:756-862 / :225-263 on LAPACK; one configuration per process), 16 near-Neel configurations: the f64 device mode
+    to 1e-8, the f32 mode to SURVEY 8(d)'s 1e-5 on EVERY configuration (round 3 asserted a 1e-4 distribution here: the f32
+    accumulation of Y = Tt V^T carried a common-mode 1.5e-5; DESIGN 3e has the budget by stage)."""
+    from oracle import cbmps
+    from peps_amd import capi
+    L, D, chi, _ = synthetic.CONFIGS["C4"]
+    flat = _state(L)
+    cfgs = synthetic.make_configs_near_neel(L, 16, seed0=307)
+    ref, _, _ = cbmps.amplitudes_multiprocess(flat, cfgs, chi, min(16, os.cpu_count() or 1))
+    for dt, tol in ((capi.F64, 1e-8), (capi.F32, 1e-5)):
+        ctx = capi.Context(L, L, D, 2, chi, dtype=dt, max_walkers=len(cfgs))
+        ctx.state_upload(flat)
+        ctx.set_configs(cfgs)
+        a = ctx.evaluate_amplitude()
+        assert np.all(ctx.walker_flags() == 0)
+        ctx.close()
+        rel = np.abs(a / ref - 1)
+        print("C4 real state %s vs oracle/cbmps.c: max %.2e median %.2e (n = %d)" % ("f64" if dt == capi.F64 else "f32", rel.max(), np.median(rel), len(cfgs)))
+        assert rel.max() < tol, rel
