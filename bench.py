@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--real-rank-steps", type=int, default=2)
     ap.add_argument("--no-sweeps", action="store_true", help="skip the MC sweeps/s and VMC samples/s measurement")
     ap.add_argument("--sweep-walkers", type=int, default=8192)
+    ap.add_argument("--real-sweep-walkers", type=int, default=2048, help="walkers of the sweep / VMC-sample rates on the real_rank leg")
+    ap.add_argument("--real-sweep-count", type=int, default=3, help="timed sweeps / samples there")
     ap.add_argument("--sweep-count", type=int, default=2)
     ap.add_argument("--no-other-modes", action="store_true", help="skip the short runs of the f64 / variational / complex / C5 modes")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-walker latency measurement (n1_ms)")
@@ -765,7 +767,7 @@ def main():
             rel = np.abs(leg.amps_first[:n] / amps - 1)
             out["parity_on_sample"] = {"max_rel_err_amplitude": float(np.max(rel)), "median_rel_err_amplitude": float(np.median(rel)),
                                        "rms_err_over_rms_amplitude": float(np.sqrt(np.sum((leg.amps_first[:n] - amps) ** 2) / np.sum(amps ** 2))),
-                                       "n": int(n), "tolerance": 1e-5 if not leg.real else 1e-4, "checker": "oracle/cbmps.c (float64)"}
+                                       "n": int(n), "tolerance": 1e-5, "checker": "oracle/cbmps.c (float64)"}
             if leg.fermion:
                 out["parity_on_sample"]["note"] = ("fermionic amplitudes are alternating sums: a configuration whose amplitude is "
                                                    "orders of magnitude below the typical one loses that many digits in f32 (max); the "
@@ -827,21 +829,35 @@ def main():
                     fr["synthetic_noise"] = noise
                 if world == 1 and not args.no_cpu_baseline:
                     from oracle import cbmps
-                    k = min(8, os.cpu_count() or 1)
-                    ra, _, _ = cbmps.amplitudes_multiprocess(fleg.flat, fleg.batches[0][:k], chi, k)
+                    k = min(32 if real else 8, len(fleg.batches[0]))
+                    ra, _, _ = cbmps.amplitudes_multiprocess(fleg.flat, fleg.batches[0][:k], chi, min(k, 16))
                     rel = np.abs(fleg.amps_first[:k] / ra - 1)
                     fr["parity_on_sample"] = {"max_rel_err_amplitude": float(np.max(rel)), "median_rel_err_amplitude": float(np.median(rel)),
-                                              "n": int(k), "tolerance": 1e-4 if real else 1e-5, "checker": "oracle/cbmps.c (float64)"}
+                                              "n": int(k), "tolerance": 1e-5, "checker": "oracle/cbmps.c (float64)"}
                     if real:
-                        fr["parity_on_sample"]["note"] = ("f32 amplitude tolerance 1e-4 on this state: the 32 kept singular values of a bond span "
-                                                          "five decades, f32 rounding (6e-8 of the largest) is 3e-3 of the smallest kept one and "
-                                                          "accumulates over ~10^3 truncations; the local energy (ratios) holds 1e-6, the f64 mode "
-                                                          "1e-9 (tests/test_gpu_realrank.py)")
+                        fr["parity_on_sample"]["note"] = ("SURVEY 8(d) gate 1e-5 (round 3 stated 1e-4 here: the f32 accumulation of Y = Tt V^T "
+                                                          "carried a common-mode 1.5e-5 on this periodic state; DESIGN 3e has the budget by stage)")
                     if not args.no_energy_check:
                         pend_energy[name] = ((L, chi, 0 if dt == capi.F32 else 1, local_rank, fleg.flat), fleg.batches[0][:max(2, args.energy_n // 2)])
+                if real and world == 1 and not args.no_other_modes and dt == capi.F32:
+                    # the reference's own arithmetic on the realistic state (VERDICT r03 missing 6): the f64 device mode, small batch
+                    try:
+                        n64 = min(128, fnw)
+                        c64 = capi.Context(L, L, D, 2, chi, dtype=capi.F64, device=local_rank, max_walkers=n64)
+                        c64.state_upload(fleg.flat)
+                        c64.set_configs(fleg.batches[0][:8]); c64.evaluate_amplitude(); c64.sync()
+                        t0 = time.perf_counter()
+                        c64.set_configs(fleg.batches[0][:n64]); a64 = c64.evaluate_amplitude(); c64.sync()
+                        t64 = time.perf_counter() - t0
+                        c64.close()
+                        rel = np.abs(fleg.amps_first[:n64] / a64 - 1)
+                        fr["f64_mode"] = {"amp_per_s": n64 / t64, "walkers": n64,
+                                          "f32_vs_f64_amplitude": {"max_rel": float(np.max(rel)), "median_rel": float(np.median(rel)), "n": int(n64)}}
+                    except Exception as e:
+                        fr["f64_mode"] = {"error": repr(e)}
                 if real and world == 1 and not args.no_sweeps:
                     try:       # what VMC consumes, on the state a VMC user has (fewer walkers: a sweep costs ~4 amplitudes)
-                        fr["vmc"] = vmc_rates(fleg, min(512, fnw), 1)
+                        fr["vmc"] = vmc_rates(fleg, min(args.real_sweep_walkers, fnw), args.real_sweep_count)
                     except Exception as e:
                         fr["vmc"] = {"error": repr(e)}
         except Exception as e:

@@ -104,6 +104,15 @@ int pepsgpu_bmps_unpark(pepsgpu_ctx *ctx, int pos);
 int pepsgpu_sweep_slice_exchange(pepsgpu_ctx *ctx, int orientation, int slice, int n_uniform, const double *uniforms,
                                  double *amplitude_inout, int32_t *consumed_out, int32_t *accepted_out, int32_t *slice_states_out);
 
+/* One row / column of the energy evaluation for models whose nearest-neighbour off-diagonal term exchanges the two site states (XXZ,
+ * J1-J2, t-J ...): the slice part of SquareNNNModelEnergySolver::CalEnergyAndHolesImpl (square_nnn_energy_solver.h:142-200 row pass:
+ * InitBTen, GrowFullBTen(RIGHT, row, 1, true), psi = Trace, per site PunchHole, per bond the ReplaceNNSiteTrace of the exchanged pair
+ * + ShiftBTenWindow) and of the column pass (bond_traversal_mixin.h:120-144: GrowFullBTen(DOWN, col, 2, true), no holes) on the device
+ * with ONE read-back: psi_out [n], psi_exchanged_out [n][slice length - 1] (amplitude of the configuration with the two sites of bond
+ * j exchanged; for equal states it is psi).  punch_holes != 0: the holes of the slice's sites are stored in HBM as pepsgpu_punch_hole
+ * with out == NULL does.  The BMPS pair of the slice must be in place.  Real element types only. */
+int pepsgpu_nn_exchange_slice(pepsgpu_ctx *ctx, int orientation, int slice, int punch_holes, double *psi_out, double *psi_exchanged_out);
+
 /* BMPSWalker as an object -- BMPSContractor::GetWalker / class BMPSWalker, bmps_contractor.h:357-646, bmps/impl/bmps_walker.h:13-465.
  * A walker holds the fork of the top BMPS of stack `pos` for every Monte-Carlo walker of the context (deep copy; the stacks are not
  * touched afterwards), its stack-size counter and its own LEFT / RIGHT BTen caches.  The TransferMPO the calls below absorb / sandwich

@@ -26,7 +26,7 @@ SYMBOLS = [
     "pepsgpu_walkers_set_configs", "pepsgpu_walkers_get_configs", "pepsgpu_n_walkers",
     "pepsgpu_grow_bmps_step", "pepsgpu_grow_full_bmps", "pepsgpu_grow_bmps_for_row", "pepsgpu_grow_bmps_for_col",
     "pepsgpu_shift_bmps_window", "pepsgpu_delete_inner_bmps", "pepsgpu_bmps_park", "pepsgpu_bmps_unpark", "pepsgpu_generate_bmps_approach",
-    "pepsgpu_sweep_slice_exchange", "pepsgpu_walker_create", "pepsgpu_walker_clone", "pepsgpu_walker_destroy", "pepsgpu_walker_info", "pepsgpu_walker_set_mpo", "pepsgpu_walker_evolve",
+    "pepsgpu_sweep_slice_exchange", "pepsgpu_nn_exchange_slice", "pepsgpu_walker_create", "pepsgpu_walker_clone", "pepsgpu_walker_destroy", "pepsgpu_walker_info", "pepsgpu_walker_set_mpo", "pepsgpu_walker_evolve",
     "pepsgpu_walker_evolve_step", "pepsgpu_walker_contract_row", "pepsgpu_walker_init_bten", "pepsgpu_walker_grow_bten_step",
     "pepsgpu_walker_shift_bten_window", "pepsgpu_walker_trace_with_bten", "pepsgpu_walker_clear_bten", "pepsgpu_walker_get_bmps_tensor",
     "pepsgpu_bmps_stack_size", "pepsgpu_get_bmps_tensor", "pepsgpu_init_bten", "pepsgpu_grow_full_bten",
@@ -97,6 +97,7 @@ def load_library(path=LIB_PATH):
     lib.pepsgpu_comm_destroy.argtypes = [vp]
     lib.pepsgpu_allreduce.argtypes = [vp, vp, C.c_long, C.c_int, C.c_int, C.c_int]
     lib.pepsgpu_sweep_slice_exchange.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp, dp, ip, ip, ip]
+    lib.pepsgpu_nn_exchange_slice.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp, dp]
     lib.pepsgpu_walker_create.argtypes = [vp, C.c_int, C.c_int, ip]
     lib.pepsgpu_walker_clone.argtypes = [vp, C.c_int, ip]
     lib.pepsgpu_walker_destroy.argtypes = [vp, C.c_int]
@@ -257,6 +258,13 @@ class Context:
         st = np.zeros((self.n, N), dtype=np.int32)
         self._ck(self._l.pepsgpu_sweep_slice_exchange(self._h, orientation, slice_num, u.shape[1], _dp(u), _dp(amp), _ip(cons), _ip(acc), _ip(st)))
         return amp, cons, acc, st
+
+    def nn_exchange_slice(self, orientation, slice_num, punch_holes=False):
+        """psi [n] and the amplitudes with the two sites of every bond of the slice exchanged [n][N-1], one read-back"""
+        N = self.cols if orientation == HORIZONTAL else self.rows
+        psi, ex = np.zeros(self.n), np.zeros((self.n, N - 1))
+        self._ck(self._l.pepsgpu_nn_exchange_slice(self._h, orientation, slice_num, int(punch_holes), _dp(psi), _dp(ex)))
+        return psi, ex
 
     def get_walker(self, pos, level=-1):
         """BMPSContractor::GetWalker(tn, pos) (bmps_walker.h:51-58): a Walker object forked from the top of stack `pos`

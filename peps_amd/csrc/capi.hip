@@ -125,6 +125,10 @@ int pepsgpu_sweep_slice_exchange(pepsgpu_ctx *ctx, int orientation, int slice, i
            ctx->eng->sweep_slice_exchange(orientation, slice, n_uniform, uniforms, amplitude_inout, consumed_out, accepted_out,
                                           slice_states_out));
 }
+int pepsgpu_nn_exchange_slice(pepsgpu_ctx *ctx, int orientation, int slice, int punch_holes, double *psi_out, double *psi_exchanged_out) {
+  CTX_CALL(PG_REQUIRE(psi_out && psi_exchanged_out, 1, "null buffer");
+           ctx->eng->nn_exchange_slice(orientation, slice, punch_holes, psi_out, psi_exchanged_out));
+}
 int pepsgpu_walker_create(pepsgpu_ctx *ctx, int pos, int level, int *walker_out) {
   CTX_CALL(check_pos(pos); PG_REQUIRE(walker_out != nullptr, 1, "null output"); *walker_out = ctx->eng->walker_create(pos, level));
 }

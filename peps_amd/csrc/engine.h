@@ -104,6 +104,7 @@ struct EngineBase {
   virtual void sr_copy_samples(void *dst_o, int32_t *dst_cfg) = 0;
   virtual void sweep_slice_exchange(int orient, int slice, int n_uniform, const double *uniforms, double *amp_inout,
                                     int32_t *consumed_out, int32_t *accepted_out, int32_t *slice_states_out) = 0;
+  virtual void nn_exchange_slice(int orient, int slice, int punch_holes, double *psi_out, double *psi_ex_out) = 0;
   // BMPSWalker (bmps_contractor.h:357-646)
   virtual int walker_create(int pos, int level) = 0;
   virtual int walker_clone(int id) = 0;
@@ -175,7 +176,7 @@ class Engine : public EngineBase {
     }
     PG_CHECK_HIP(hipMemsetAsync(flag_, 0, sizeof(int) * (size_t)maxw_, stream_));
     dtype = kCplx ? 3 : (sizeof(T) == 4 ? 0 : 1);
-    for (int q = 0; q < 4; ++q) redo_seen_[q].assign(std::max(Ly_, Lx_) + 1, 0);
+    for (int q = 0; q < 4; ++q) { redo_seen_[q].assign(std::max(Ly_, Lx_) + 1, 0); carry_seen_[q].assign(std::max(Ly_, Lx_) + 1, -1); }
   }
   ~Engine() override {
     (void)hipStreamSynchronize(side_stream_);
@@ -205,11 +206,11 @@ class Engine : public EngineBase {
   }
   void state_adopted() override {
     PG_CHECK_HIP(hipStreamSynchronize(stream_));
-    for (int q = 0; q < 4; ++q) redo_seen_[q].assign(std::max(Ly_, Lx_) + 1, 0);
+    for (int q = 0; q < 4; ++q) { redo_seen_[q].assign(std::max(Ly_, Lx_) + 1, 0); carry_seen_[q].assign(std::max(Ly_, Lx_) + 1, -1); }
     have_state_ = true;
   }
   void state_upload(const void *host, int host_dtype) override {
-    for (int q = 0; q < 4; ++q) redo_seen_[q].assign(std::max(Ly_, Lx_) + 1, 0);
+    for (int q = 0; q < 4; ++q) { redo_seen_[q].assign(std::max(Ly_, Lx_) + 1, 0); carry_seen_[q].assign(std::max(Ly_, Lx_) + 1, -1); }
     // host layout [row][col][s][L][D][R][U] zero padded to D^4; stored compact in each slot
     std::vector<T> buf((size_t)slot_ * dp_ * Ly_ * Lx_, T(0));
     for (int r = 0; r < Ly_; ++r)
@@ -874,7 +875,7 @@ class Engine : public EngineBase {
                "variational compression needs convergence_tol and iter_max (bmps.h:81-97)");
     chi_min_ = chi_min; chi_ = chi_max; trunc_err_ = trunc_err;
     scheme_ = scheme; conv_tol_ = conv_tol; iter_max_ = iter_max;
-    for (int q = 0; q < 4; ++q) redo_seen_[q].assign(std::max(Ly_, Lx_) + 1, 0);   // the routing hints belong to the old parameters
+    for (int q = 0; q < 4; ++q) { redo_seen_[q].assign(std::max(Ly_, Lx_) + 1, 0); carry_seen_[q].assign(std::max(Ly_, Lx_) + 1, -1); }   // the routing hints belong to the old parameters
   }
   void read_flags(int32_t *out) override {
     PG_CHECK_HIP(hipMemcpyAsync(out, flag_, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -890,6 +891,7 @@ class Engine : public EngineBase {
   // ---- Monte-Carlo sweep of one row / column of bonds on the device (engine_sweep.h) ----
   void sweep_slice_exchange(int orient, int slice, int n_uniform, const double *uniforms, double *amp_inout, int32_t *consumed_out,
                             int32_t *accepted_out, int32_t *slice_states_out) override;
+  void nn_exchange_slice(int orient, int slice, int punch_holes, double *psi_out, double *psi_ex_out) override;
   // ---- BMPSWalker (engine_walker.h) ----
   int walker_create(int pos, int level) override;
   int walker_clone(int id) override;
@@ -1286,6 +1288,7 @@ class Engine : public EngineBase {
   long n_var_iters_ = 0;
   long n_absorb_ = 0, n_jacobi_ = 0, jacobi_sweeps_sum_ = 0, jacobi_sweeps_max_ = 0;
   std::vector<char> redo_seen_[4];        // per stack position and row / column: its hint-sized absorption was redone before
+  std::vector<int> carry_seen_[4];        // ... and the largest live carry of its last absorption (-1: not absorbed yet on this state)
   long n_redo_ = 0;                       // absorptions done twice: a shrunk bond was filled, or a rank hint of the row before was missed
   double live_sum_ = 0, live_full_ = 0;   // diagnostics: sum of live carry rows / sum of carry sizes
   long live_max_ = 0;                     // ... and the largest live carry of any walker (> 32: the dense route ran)

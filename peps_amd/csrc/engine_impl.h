@@ -877,7 +877,11 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     bool precise_site = false;
     if constexpr (sizeof(T) == 4) {
       static const int precise = getenv("PEPSGPU_PRECISE") ? atoi(getenv("PEPSGPU_PRECISE")) : 1;    // 0 never, 1 auto, 2 always
-      precise_site = precise == 2 || (precise == 1 && (in.depth < 3 || (int)in.mlmax.size() <= i || in.mlmax[i] < 0 || in.mlmax[i] > 24));
+      // (rows whose predecessor gives no hint yet -- the first three of a stack -- go by what the SAME row of the SAME stack showed
+      // the last time it was absorbed, carry_seen_: unknown on a fresh state -> precise)
+      const int seen = carry_seen_[pos][num];
+      const bool hinted = in.depth >= 3 && (int)in.mlmax.size() > i && in.mlmax[i] >= 0;
+      precise_site = precise == 2 || (precise == 1 && (hinted ? in.mlmax[i] > 24 : (seen < 0 || seen > 24)));
     }
     if constexpr (sizeof(T) == 4) {
       static const int ortho = getenv("PEPSGPU_ORTHO_POLISH") ? atoi(getenv("PEPSGPU_ORTHO_POLISH")) : 1;
@@ -972,6 +976,11 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     arena_.free(dtab); arena_.free(dmax);
     for (int b = 0; b <= N; ++b) out.kmax[b] = hmax[b];
     for (int i = 0; i < N; ++i) out.mlmax[i] = mdyn[i] ? std::min(R[i].d[0], hmax[N + 1 + i] * mmul[i]) : R[i].d[0];
+    if (!ovr_on_) {      // (a BMPSWalker's foreign MPO says nothing about the network's own row)
+      int mx = 0;
+      for (int i = 0; i < N; ++i) mx = std::max(mx, out.mlmax[i]);
+      carry_seen_[pos][num] = mx;
+    }
     for (int i = 1; i < N; ++i)
       if (kstat[i] < kfull[i] && out.kmax[i] >= kstat[i]) ok = false;   // a walker filled a shrunk bond: maybe clipped
     for (int i = 0; i < N; ++i)

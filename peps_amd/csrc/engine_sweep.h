@@ -66,6 +66,78 @@ __global__ void sweep_gather_slice_kernel(const int *__restrict__ cfg, int sites
   out[e] = cfg[(long)w * sites + first + j * stride];
 }
 
+// psi'[w][j] = res[w] exp(lsum[w]) into column j of a [n][stride] table
+template <typename AccT>
+__global__ void sweep_store_value_kernel(const AccT *__restrict__ res, const double *__restrict__ lsum, double *__restrict__ out,
+                                         int stride, int j, int n) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < n) out[(long)w * stride + j] = (double)res[w] * exp(lsum[w]);
+}
+
+// One row / column of the energy evaluation (SquareNNNModelEnergySolver::CalEnergyAndHolesImpl, square_nnn_energy_solver.h:
+// 116-200 row pass, bond_traversal_mixin.h:120-144 column pass) for models whose nearest-neighbour off-diagonal term is the
+// exchange of the two site states (XXZ, J1-J2, t-J ...): InitBTen + GrowFullBTen, psi of the slice, and for every bond the
+// amplitude of the configuration with the two states exchanged -- all on the device, ONE read-back per slice (psi [n] and
+// psi_ex [n][N-1]); with punch_holes the hole of every site of the slice is stored in HBM on the way (PunchHole, :163).
+template <typename T>
+void Engine<T>::nn_exchange_slice(int orient, int slice, int punch_holes, double *psi_out, double *psi_ex_out) {
+  require_ready();
+  if constexpr (kCplx) {
+    PG_REQUIRE(false, 1, "device-side energy slice: real element types only (complex contexts use the per-bond calls)");
+  } else {
+    PG_REQUIRE(orient == HORIZONTAL || orient == VERTICAL, 1, "bad orientation");
+    const int N = orient == HORIZONTAL ? Lx_ : Ly_, lim = orient == HORIZONTAL ? Ly_ : Lx_;
+    PG_REQUIRE(slice >= 0 && slice < lim, 1, "slice outside the lattice");
+    const int sites = Ly_ * Lx_;
+    if (punch_holes && !holes_) {
+      holes_ = (T *)arena_.alloc(sizeof(T) * (size_t)maxw_ * Ly_ * Lx_ * slot_);
+      holes_ls_ = (double *)arena_.alloc(sizeof(double) * (size_t)maxw_ * Ly_ * Lx_);
+    }
+    double *dval = (double *)arena_.alloc(sizeof(double) * (size_t)nw_ * N);     // column 0: psi, columns 1..N-1: psi_ex of bond j-1
+    int *dcand = (int *)arena_.alloc(sizeof(int) * 2 * (size_t)nw_);
+    auto release = [&]() { arena_.free(dval); arena_.free(dcand); };
+    try {
+      const int lo = orient == HORIZONTAL ? LEFT : UP, hi = orient == HORIZONTAL ? RIGHT : DOWN;
+      const int remain = punch_holes ? 1 : 2;         // :143 GrowFullBTen(RIGHT, row, 1, true) with holes, 2 in the column pass
+      init_bten(lo, slice);
+      grow_full_bten(hi, slice, remain, 1);
+      const int gb = (nw_ + 255) / 256;
+      {
+        double *lsum = nullptr;
+        Acc *res = nn_trace_device(orient == HORIZONTAL ? slice : 0, orient == HORIZONTAL ? 0 : slice, orient, 1, nullptr, &lsum);
+        hipLaunchKernelGGL(sweep_store_value_kernel<Acc>, dim3(gb), dim3(256), 0, stream_, (const Acc *)res, (const double *)lsum, dval, N, 0, nw_);
+        PG_CHECK_HIP(hipGetLastError());
+        arena_.free(res); arena_.free(lsum);
+      }
+      for (int j = 0; j < N; ++j) {
+        const int r1 = orient == HORIZONTAL ? slice : j, c1 = orient == HORIZONTAL ? j : slice;
+        if (punch_holes) punch_hole(r1, c1, orient, nullptr);
+        if (j + 1 < N) {
+          const int r2 = orient == HORIZONTAL ? slice : j + 1, c2 = orient == HORIZONTAL ? j + 1 : slice;
+          hipLaunchKernelGGL(sweep_swap_cand_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)cfg_, sites, r1 * Lx_ + c1, r2 * Lx_ + c2,
+                             dcand, nw_);
+          PG_CHECK_HIP(hipGetLastError());
+          double *lsum = nullptr;
+          Acc *res = nn_trace_device(r1, c1, orient, 1, dcand, &lsum);
+          hipLaunchKernelGGL(sweep_store_value_kernel<Acc>, dim3(gb), dim3(256), 0, stream_, (const Acc *)res, (const double *)lsum, dval, N,
+                             j + 1, nw_);
+          PG_CHECK_HIP(hipGetLastError());
+          arena_.free(res); arena_.free(lsum);
+          if (remain == 1 || j + 2 < N) shift_bten_window(hi);
+        }
+      }
+      std::vector<double> h((size_t)nw_ * N);
+      PG_CHECK_HIP(hipMemcpyAsync(h.data(), dval, sizeof(double) * h.size(), hipMemcpyDeviceToHost, stream_));
+      PG_CHECK_HIP(hipStreamSynchronize(stream_));
+      for (int w = 0; w < nw_; ++w) {
+        psi_out[w] = h[(size_t)w * N];
+        for (int j = 0; j + 1 < N; ++j) psi_ex_out[(size_t)w * (N - 1) + j] = h[(size_t)w * N + j + 1];
+      }
+    } catch (...) { release(); throw; }
+    release();
+  }
+}
+
 template <typename T>
 void Engine<T>::sweep_slice_exchange(int orient, int slice, int n_uniform, const double *uniforms, double *amp_inout,
                                      int32_t *consumed_out, int32_t *accepted_out, int32_t *slice_states_out) {

@@ -204,6 +204,35 @@ int pepshost_mc_sweeps_c128(int rows, int cols, int D, int d, int chi, const dou
   });
 }
 
+// MonteCarloEngine (monte_carlo_engine.h:146-240, :340-414) on a walker batch: construction (configuration validity +
+// rescue with the given amplitude window), WarmUp (warm-up sweeps with the NN exchange updater, sanity check,
+// NormalizeStateOrder1).  In place: configs, sitps_flat (the scaled state).  out[0] = overall scale factor, out[1] = walkers
+// rescued, out[2] = warmed up (0 / 1).
+int pepshost_mc_engine_warmup(int rows, int cols, int D, int d, int chi, int dtype, double *sitps_flat, int n, int32_t *configs,
+                              const uint64_t *seeds, int warmup_sweeps, int rescue_enabled, double amp_min, double amp_max,
+                              double *amplitudes_out, double *out) {
+  return guarded([&]() {
+    SplitIndexTPS sitps = make_state_t<double>(rows, cols, D, d, sitps_flat);
+    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), n, dtype, g_device);
+    TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor);
+    std::vector<uint64_t> sd(seeds, seeds + n);
+    MCUpdateSquareNNExchangeOBC upd(sd);
+    MonteCarloParams mp;
+    mp.num_warmup_sweeps = (size_t)warmup_sweeps;
+    ConfigurationRescueParams rp;
+    rp.enabled = rescue_enabled != 0;
+    if (amp_min > 0.0) rp.amplitude_min_threshold = amp_min;
+    if (amp_max > 0.0) rp.amplitude_max_threshold = amp_max;
+    MonteCarloEngine<MCUpdateSquareNNExchangeOBC> eng(sitps, comp, mp, upd, rp);
+    const size_t rescued = eng.RescuedWalkers();
+    eng.WarmUp();
+    std::copy(comp.config.data(), comp.config.data() + (size_t)n * rows * cols, configs);
+    std::copy(sitps.flat().begin(), sitps.flat().end(), sitps_flat);
+    copy_out(comp.amplitude, amplitudes_out);
+    out[0] = eng.LastScaleFactor(); out[1] = (double)rescued; out[2] = eng.IsWarmedUp() ? 1.0 : 0.0;
+  });
+}
+
 // CalEnergyAndHoles (model_energy_solver.h:32-126) for n configurations; model 0 = XXZ (p = jz, jxy,
 // pinning00), 1 = TFIM (p[0] = h).  holes_out (nullable) = [n][rows][cols][D^4]; psi_out = [n_psi][n].
 int pepshost_energy_and_holes(int rows, int cols, int D, int d, int chi, int dtype, const double *sitps_flat, int n,

@@ -693,6 +693,16 @@ struct TPSWaveFunctionComponentT {
       for (size_t w = 0; w < amplitude.size(); ++w) amplitude[w] *= double(fermion->Sigma(config, w));
     return amplitude;
   }
+  // the same without the throw: flags[w] != 0 marks a walker whose contraction ran into an empty tensor (MonteCarloEngine's
+  // TryConstructWavefunction_, monte_carlo_engine.h: a failed construction is a rescue case, not an abort)
+  std::vector<int32_t> EvaluateAmplitudeNoThrow() {
+    if (fermion && order != ROW_MAJOR) SetOrder(ROW_MAJOR);
+    amplitude = contractor.EvaluateAmplitude();
+    auto flags = contractor.WalkerFlags();
+    if (fermion)
+      for (size_t w = 0; w < amplitude.size(); ++w) amplitude[w] *= double(fermion->Sigma(config, w));
+    return flags;
+  }
   void ReplaceGlobalConfig(const Configuration &cfg) {   // :180-185
     config = cfg;
     InitDevice();
@@ -810,6 +820,11 @@ class MonteCarloSweepUpdaterBase {
   }
   void ConsumeUniforms(size_t w, size_t cnt) { ahead_head_[w] += cnt; }
 };
+
+// a model opts into the device-side energy slice with `static constexpr bool kExchangeBondEnergy = true` + the scalar hook
+// double BondEnergyFromExchange(config1, config2, psi_exchanged / psi)
+template <typename U, typename = void> struct HasExchangeBondEnergy : std::false_type {};
+template <typename U> struct HasExchangeBondEnergy<U, std::void_t<decltype(U::kExchangeBondEnergy)>> : std::bool_constant<U::kExchangeBondEnergy> {};
 
 // an updater opts into the device-side slice sweep with `static constexpr bool kDeviceSliceSweep = true` + SweepSliceOnDevice
 template <typename U, typename = void> struct HasDeviceSliceSweep : std::false_type {};
@@ -983,13 +998,43 @@ class SquareNNNModelEnergySolver {
     out.energy.assign(n, TenElemT(0.0));
     if (calchols && !holes_on_device) out.holes.assign(n * rows * cols * slot, TenElemT(0.0));
     auto *self = static_cast<ExplicitlyModel *>(this);
+    // A model whose NN off-diagonal term exchanges the two site states (it declares kExchangeBondEnergy and the scalar hook
+    // BondEnergyFromExchange) gets a whole row / column from ONE device call (pepsgpu_nn_exchange_slice: psi, the exchanged
+    // amplitudes of every bond and -- with holes resident in HBM -- the holes of the row, one read-back) instead of a
+    // ReplaceNNSiteTrace round trip per bond; same operations in the same order on the device, same numbers.
+    // PEPSHOST_NO_DEVICE_SWEEP=1 keeps the per-bond hook path.
+    static const bool no_dev = std::getenv("PEPSHOST_NO_DEVICE_SWEEP") != nullptr;
+    bool dev_slice = false;
+    if constexpr (std::is_same<TenElemT, double>::value && HasExchangeBondEnergy<ExplicitlyModel>::value)
+      dev_slice = !no_dev && !comp.fermion && (!calchols || holes_on_device);
+    auto slice_energy = [&](BondOrientation dir, size_t slice, bool holes) {
+      if constexpr (std::is_same<TenElemT, double>::value && HasExchangeBondEnergy<ExplicitlyModel>::value) {
+        const size_t N = dir == HORIZONTAL ? cols : rows;
+        std::vector<double> psi(n), ex(n * (N - 1));
+        check_rc(pepsgpu_nn_exchange_slice(c.ctx(), dir, (int)slice, holes ? 1 : 0, psi.data(), ex.data()), c.ctx());
+        for (size_t w = 0; w < n; ++w) {
+          if (psi[w] == 0.0) throw std::runtime_error("Wavefunction amplitude is near zero, causing division by zero.");
+          const double inv = 1.0 / psi[w];
+          for (size_t j = 0; j + 1 < N; ++j) {
+            const SiteIdx s1 = dir == HORIZONTAL ? SiteIdx{slice, j} : SiteIdx{j, slice};
+            const SiteIdx s2 = dir == HORIZONTAL ? SiteIdx{slice, j + 1} : SiteIdx{j + 1, slice};
+            out.energy[w] += self->BondEnergyFromExchange(comp.config(w, s1), comp.config(w, s2), ex[w * (N - 1) + j] * inv);
+          }
+        }
+        out.psi_list.push_back(psi);
+      }
+    };
     comp.SetOrder(ROW_MAJOR);                // fermions: holes are those of the row-major decorated network
     c.GenerateBMPSApproach(UP);                                              // :116
     for (size_t row = 0; row < rows; row++) {
+      std::vector<TenElemT> inv_psi(n);
+      if (dev_slice) {
+        slice_energy(HORIZONTAL, row, calchols);
+        for (size_t w = 0; w < n; ++w) inv_psi[w] = TenElemT(1.0) / out.psi_list.back()[w];     // (for the NNN pass below)
+      } else {
       c.InitBTen(LEFT, row);                                                 // :142
       c.GrowFullBTen(RIGHT, row, 1, true);                                   // :143
       std::vector<TenElemT> psi = c.Trace({row, 0}, HORIZONTAL);             // :147
-      std::vector<TenElemT> inv_psi(n);
       for (size_t w = 0; w < n; ++w) {
         if (psi[w] == TenElemT(0.0)) throw std::runtime_error("Wavefunction amplitude is near zero, causing division by zero.");
         inv_psi[w] = TenElemT(1.0) / psi[w];
@@ -1010,6 +1055,7 @@ class SquareNNNModelEnergySolver {
           c.ShiftBTenWindow(RIGHT);                                           // :200
         }
       }
+      }
       if constexpr (has_nnn_interaction) {                                    // :203-265
         if (row + 1 < rows) {
           c.InitBTen2(LEFT, row);
@@ -1027,19 +1073,23 @@ class SquareNNNModelEnergySolver {
     comp.SetOrder(COL_MAJOR);
     c.GenerateBMPSApproach(LEFT);                                            // bond_traversal_mixin.h:120
     for (size_t col = 0; col < cols; col++) {
-      c.InitBTen(UP, col);
-      c.GrowFullBTen(DOWN, col, 2, true);
-      std::vector<TenElemT> psi = c.Trace({0, col}, VERTICAL);
-      std::vector<TenElemT> inv_psi(n);
-      for (size_t w = 0; w < n; ++w) {
-        if (psi[w] == TenElemT(0.0)) throw std::runtime_error("Wavefunction amplitude is near zero, causing division by zero.");
-        inv_psi[w] = TenElemT(1.0) / psi[w];
-      }
-      out.psi_list.push_back(psi);
-      for (size_t row = 0; row + 1 < rows; row++) {
-        std::vector<TenElemT> e = self->EvaluateBondEnergy({row, col}, {row + 1, col}, VERTICAL, comp, inv_psi);
-        for (size_t w = 0; w < n; ++w) out.energy[w] += e[w];
-        if (row + 2 < rows) c.ShiftBTenWindow(DOWN);
+      if (dev_slice) {
+        slice_energy(VERTICAL, col, false);
+      } else {
+        c.InitBTen(UP, col);
+        c.GrowFullBTen(DOWN, col, 2, true);
+        std::vector<TenElemT> psi = c.Trace({0, col}, VERTICAL);
+        std::vector<TenElemT> inv_psi(n);
+        for (size_t w = 0; w < n; ++w) {
+          if (psi[w] == TenElemT(0.0)) throw std::runtime_error("Wavefunction amplitude is near zero, causing division by zero.");
+          inv_psi[w] = TenElemT(1.0) / psi[w];
+        }
+        out.psi_list.push_back(psi);
+        for (size_t row = 0; row + 1 < rows; row++) {
+          std::vector<TenElemT> e = self->EvaluateBondEnergy({row, col}, {row + 1, col}, VERTICAL, comp, inv_psi);
+          for (size_t w = 0; w < n; ++w) out.energy[w] += e[w];
+          if (row + 2 < rows) c.ShiftBTenWindow(DOWN);
+        }
       }
       if (col + 1 < cols) c.ShiftBMPSWindow(RIGHT);
     }
@@ -1396,6 +1446,11 @@ class SquareSpinOneHalfXXZModelMixIn {
   double EvaluateTotalOnsiteEnergy(const Configuration &config, size_t w) const {   // :139-141
     return -pinning00_ * (double(config(w, {0, 0})) - 0.5);
   }
+  // the bond term as a function of the two states and psi(exchanged) / psi (:98-100): what EvaluateBondEnergy computes per walker
+  static constexpr bool kExchangeBondEnergy = true;
+  double BondEnergyFromExchange(int32_t config1, int32_t config2, double ratio) const {
+    return config1 == config2 ? 0.25 * jz_ : -0.25 * jz_ + ratio * (0.5 * jxy_);
+  }
  protected:
   double jz_, jxy_, jz2_, jxy2_, pinning00_;
 };
@@ -1674,6 +1729,114 @@ struct GradAccumulatorT {
   }
 };
 using GradAccumulator = GradAccumulatorT<double>;
+
+// MonteCarloEngine (algorithm/vmc_update/monte_carlo_engine.h): warm-up, sweeps, amplitude sanity, configuration rescue and
+// the order-1 normalisation of the state, for a walker batch.  The reference holds one walker per MPI rank; here a Monte-Carlo
+// walker of the context takes the place of a rank: EnsureConfigurationValidity (:340-414) replaces the configuration of every
+// walker whose construction failed (device flag: empty tensor) or whose amplitude is outside (min, max) by the configuration of
+// the first valid walker -- the reference's "first valid rank" -- and marks the batch as not warmed up; NormalizeStateOrder1
+// (:206-240) scales every site tensor by (1 / max_w |psi_w|)^(1 / (Lx Ly)) and rebuilds the components.  More ranks: hand a
+// max-over-ranks functor (e.g. on BMPSContractor::AllReduceMax); rescue is rank-local (a rank holds thousands of walkers).
+struct ConfigurationRescueParams {                 // psi_consistency.h:59-85
+  bool enabled = true;
+  double amplitude_min_threshold = std::numeric_limits<double>::min();
+  double amplitude_max_threshold = std::numeric_limits<double>::max();
+};
+struct MonteCarloParams {                          // monte_carlo_peps_params.h
+  size_t num_warmup_sweeps = 0, sweeps_between_samples = 1;
+  bool is_warmed_up = false;
+};
+template <typename TenElemT>
+inline bool CheckWaveFunctionAmplitudeValidity(const TenElemT &amplitude, double min_threshold, double max_threshold) {   // wave_function_component.h:393-402
+  const double a = std::abs(amplitude);
+  return !std::isnan(a) && !std::isinf(a) && a > min_threshold && a < max_threshold;
+}
+template <class MonteCarloSweepUpdater, typename TenElemT = double>
+class MonteCarloEngine {
+ public:
+  MonteCarloEngine(SplitIndexTPST<TenElemT> &sitps, TPSWaveFunctionComponentT<TenElemT> &comp, const MonteCarloParams &params,
+                   MonteCarloSweepUpdater &updater, const ConfigurationRescueParams &rescue = ConfigurationRescueParams(),
+                   std::function<double(double)> max_over_ranks = nullptr)
+      : sitps_(sitps), comp_(comp), params_(params), updater_(updater), rescue_(rescue), max_over_ranks_(std::move(max_over_ranks)),
+        warm_up_(params.is_warmed_up) {
+    EnsureConfigurationValidity();                 // the constructor's last step (:112-113)
+  }
+  bool IsWarmedUp() const { return warm_up_; }
+  size_t RescuedWalkers() const { return n_rescued_; }
+  double LastScaleFactor() const { return last_scale_; }
+  std::vector<double> StepSweep(size_t sweeps) {   // :176-189
+    std::vector<double> rates;
+    for (size_t i = 0; i < sweeps; ++i) updater_(sitps_, comp_, rates);
+    return rates;
+  }
+  std::vector<double> StepSweep() { return StepSweep(params_.sweeps_between_samples); }
+  int WarmUp() {                                   // :146-173
+    if (!warm_up_) {
+      for (size_t s = 0; s < params_.num_warmup_sweeps; ++s) (void)StepSweep(1);
+      warm_up_ = true;
+    }
+    for (size_t w = 0; w < comp_.amplitude.size(); ++w)
+      if (!CheckWaveFunctionAmplitudeValidity(comp_.amplitude[w], rescue_.amplitude_min_threshold, rescue_.amplitude_max_threshold))
+        throw std::runtime_error("MonteCarloEngine::WarmUp: amplitude of walker " + std::to_string(w) + " is still not legal after warm up");
+    NormalizeStateOrder1();
+    return 0;
+  }
+  void NormalizeStateOrder1() {                    // :206-240
+    double max_abs = 0.0;
+    for (const auto &a : comp_.amplitude) max_abs = std::max(max_abs, (double)std::abs(a));
+    if (max_over_ranks_) max_abs = max_over_ranks_(max_abs);
+    if (!(max_abs > 0.0) || std::isinf(max_abs)) throw std::runtime_error("MonteCarloEngine::NormalizeStateOrder1: no finite non-zero amplitude");
+    last_scale_ = 1.0 / max_abs;
+    const double on_site = std::pow(last_scale_, 1.0 / double(comp_.contractor.rows() * comp_.contractor.cols()));
+    for (auto &x : sitps_.flat()) x *= on_site;    // split_index_tps_ *= scale_factor_on_site
+    comp_.contractor.UploadState(sitps_);          // tps_sample_ = WaveFunctionComponentT(split_index_tps_, config, trun_para)
+    comp_.InitDevice();
+    comp_.EvaluateAmplitude();
+  }
+  void EnsureConfigurationValidity() {             // :340-414
+    const size_t n = comp_.config.walkers();
+    std::vector<int32_t> flags = comp_.contractor.WalkerFlags();
+    std::vector<uint8_t> valid(n);
+    size_t num_valid = 0;
+    for (size_t w = 0; w < n; ++w) {
+      valid[w] = !flags[w] && CheckWaveFunctionAmplitudeValidity(comp_.amplitude[w], rescue_.amplitude_min_threshold, rescue_.amplitude_max_threshold);
+      num_valid += valid[w];
+    }
+    if (num_valid == n) return;
+    if (!rescue_.enabled)
+      throw std::runtime_error("MonteCarloEngine: " + std::to_string(n - num_valid) + "/" + std::to_string(n) +
+                               " walkers have invalid configurations and configuration rescue is disabled");
+    if (num_valid == 0)
+      throw std::runtime_error("MonteCarloEngine: all walkers have invalid configurations (check bond dimension, truncation cutoff, initial configuration)");
+    size_t source = 0;
+    while (!valid[source]) ++source;
+    Configuration cfg = comp_.config;
+    for (size_t w = 0; w < n; ++w)
+      if (!valid[w])
+        for (size_t r = 0; r < cfg.rows(); ++r)
+          for (size_t c = 0; c < cfg.cols(); ++c) cfg(w, {r, c}) = comp_.config(source, {r, c});
+    comp_.config = cfg;
+    comp_.InitDevice();
+    flags = comp_.EvaluateAmplitudeNoThrow();      // TryConstructWavefunction_(config_valid)
+    for (size_t w = 0; w < n; ++w)
+      if (flags[w] || !CheckWaveFunctionAmplitudeValidity(comp_.amplitude[w], rescue_.amplitude_min_threshold, rescue_.amplitude_max_threshold))
+        throw std::runtime_error("MonteCarloEngine: rescue FAILED for walker " + std::to_string(w) + " even with the valid configuration of walker " +
+                                 std::to_string(source));
+    n_rescued_ += n - num_valid;
+    warm_up_ = false;
+  }
+
+ private:
+  SplitIndexTPST<TenElemT> &sitps_;
+  TPSWaveFunctionComponentT<TenElemT> &comp_;
+  MonteCarloParams params_;
+  MonteCarloSweepUpdater &updater_;
+  ConfigurationRescueParams rescue_;
+  std::function<double(double)> max_over_ranks_;
+  bool warm_up_;
+  size_t n_rescued_ = 0;
+  double last_scale_ = 1.0;
+};
 
 // GenerateAllPermutationConfigs (exact_summation_energy_evaluator.h:74-95) for one walker batch layout
 // MCPEPSMeasurer (algorithm/vmc_update/monte_carlo_peps_measurer{.h,_impl.h}): warm-up, then per sample

@@ -84,6 +84,21 @@ def mc_sweeps(flat, configs, seeds, chi, updater="exchange", n_sweeps=1, dtype=1
     return cfg, amps, rates
 
 
+def mc_engine_warmup(flat, configs, seeds, chi, warmup_sweeps=0, rescue=True, amp_min=0.0, amp_max=0.0, dtype=1):
+    """MonteCarloEngine: configuration validity / rescue, warm-up, NormalizeStateOrder1 (monte_carlo_engine.h).
+    Returns (scaled state, configs, amplitudes, overall scale factor, walkers rescued)."""
+    st = np.array(flat, dtype=np.float64, order="C")
+    rows, cols, d, D = _dims(st)
+    cfg = np.array(configs, dtype=np.int32, order="C")
+    n = cfg.shape[0]
+    sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+    amps, out = np.zeros(n), np.zeros(3)
+    _ck(lib().pepshost_mc_engine_warmup(rows, cols, D, d, chi, dtype, _p(st, C.c_double), n, _p(cfg, C.c_int32), _p(sd, C.c_uint64),
+                                        warmup_sweeps, int(rescue), C.c_double(amp_min), C.c_double(amp_max), _p(amps, C.c_double),
+                                        _p(out, C.c_double)))
+    return st, cfg, amps, float(out[0]), int(out[1])
+
+
 def energy_and_holes(flat, configs, chi, model="xxz", params=(1.0, 1.0, 0.0), holes=True, dtype=1):
     flat = np.ascontiguousarray(flat, dtype=np.float64)
     rows, cols, d, D = _dims(flat)

@@ -191,6 +191,10 @@ out = {}
 for name, dt in (("f64", 1), ("f32", 0)):
     c, a, r = hostapi.mc_sweeps(flat, cfgs, np.arange(24, dtype=np.uint64) + 90, chi, "exchange", 3, dt)
     out[name] = {"cfg": c.tolist(), "amp": [float(x) for x in a], "rate": [float(x) for x in r]}
+    # the energy evaluation: a row / column per device call (pepsgpu_nn_exchange_slice) against the per-bond hook path
+    _, en, _, psi = hostapi.energy_and_holes(flat, cfgs, chi, "xxz", (1.0, 0.8, 0.1), False, dt)
+    packed, _, _ = hostapi.mc_energy_grad_partial(flat, cfgs, np.arange(24, dtype=np.uint64) + 90, chi, "exchange", "xxz", (1.0, 0.8, 0.1), 1, 2, dt)
+    out[name].update(energy=[float(x) for x in en], psi=np.asarray(psi).tolist(), packed_sum=float(np.sum(packed)), packed_abs=float(np.sum(np.abs(packed))))
 print(json.dumps(out))
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -204,7 +208,48 @@ print(json.dumps(out))
         assert a["cfg"] == b["cfg"], dt                      # the same chain
         assert a["rate"] == b["rate"] and max(a["rate"]) > 0
         assert np.max(np.abs(np.array(a["amp"]) / np.array(b["amp"]) - 1)) < tol
+        assert np.max(np.abs(np.array(a["energy"]) / np.array(b["energy"]) - 1)) < tol
+        assert np.max(np.abs(np.array(a["psi"]) / np.array(b["psi"]) - 1)) < tol
+        assert abs(a["packed_sum"] - b["packed_sum"]) < tol * a["packed_abs"]      # energy + gradient sums of the VMC samples
     assert res["device"]["f64"]["cfg"] != synthetic.make_configs(6, 24, "heisenberg", seed0=13).tolist()      # ... and it moved
+
+
+def test_monte_carlo_engine_rescue_and_normalize_order1(fixtures_dir):
+    """MonteCarloEngine of the host layer (monte_carlo_engine.h:146-240 WarmUp / StepSweep / NormalizeStateOrder1, :340-414
+    EnsureConfigurationValidity): walkers whose amplitude falls outside the rescue window take the configuration of the first
+    valid walker and the batch counts as not warmed up; after the warm-up sweeps every site tensor is scaled by
+    (1 / max |psi|)^(1 / (Lx Ly)), so the largest amplitude of the batch is 1 and every amplitude is the oracle's amplitude of the
+    SCALED state on the final configuration."""
+    host = _host()
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, "tps_square_heisenberg4x4D8Double"))
+    flat = synthetic.sitps_to_flat(s, 8)
+    cfgs = synthetic.make_configs(4, 12, "heisenberg", seed0=5)
+    tp = BMPSTruncateParams.SVD(16, 16, 0.0)
+    a0 = np.array([abs(vmc.TPSWaveFunctionComponent(s, c, tp).amplitude) for c in cfgs])
+    thr = float(np.sort(a0)[3] * 1.0001)             # the four smallest amplitudes are "invalid"
+    bad = a0 < thr
+    assert bad.sum() == 4 and not bad[int(np.argmax(~bad))]
+    # no sweeps: rescue + normalisation only
+    st, out_cfg, amps, scale, rescued = host.mc_engine_warmup(flat, cfgs, np.arange(12, dtype=np.uint64) + 11, 16, 0, True, thr, 0.0, F64)
+    src = int(np.argmax(~bad))
+    assert rescued == 4
+    for w in range(12):
+        assert np.array_equal(out_cfg[w], cfgs[src] if bad[w] else cfgs[w])
+    assert abs(np.max(np.abs(amps)) - 1.0) < 1e-9
+    assert abs(scale * np.max(a0[~bad]) - 1.0) < 1e-9
+    assert np.allclose(st, flat * scale ** (1.0 / 16), rtol=1e-14)
+    s2 = synthetic.flat_to_sitps(st)
+    for w in (0, src, int(np.argmax(bad))):
+        assert abs(amps[w] / vmc.TPSWaveFunctionComponent(s2, out_cfg[w], tp).amplitude - 1) < 1e-9
+    # rescue disabled: the reference aborts, the host layer throws
+    with pytest.raises(RuntimeError):
+        host.mc_engine_warmup(flat, cfgs, np.arange(12, dtype=np.uint64) + 11, 16, 0, False, thr, 0.0, F64)
+    # with warm-up sweeps (f32): amplitudes stay consistent with the scaled state, max |psi| = 1
+    st, out_cfg, amps, scale, rescued = host.mc_engine_warmup(flat, cfgs, np.arange(12, dtype=np.uint64) + 11, 16, 2, True, 0.0, 0.0, F32)
+    assert rescued == 0 and abs(np.max(np.abs(amps)) - 1.0) < 1e-5
+    s2 = synthetic.flat_to_sitps(st)
+    for w in (0, 5, 11):
+        assert abs(amps[w] / vmc.TPSWaveFunctionComponent(s2, out_cfg[w], tp).amplitude - 1) < 1e-4
 
 
 def test_device_gradient_accumulation_matches_host_path(fixtures_dir):
