@@ -1071,6 +1071,16 @@ class Engine : public EngineBase {
     PG_REQUIRE(t2.d[0] == t5.d[2] && t2.d[1] == t5.d[1] && t2.d[2] == t5.d[0], 3, "trace: environment bond mismatch");
     const int nb = nw_ * nc;
     Acc *res = (Acc *)arena_.alloc(sizeof(Acc) * nb);
+    static const bool old_dot = getenv("PEPSGPU_OLD_TRACE_DOT") != nullptr;
+    if (!old_dot) {     // dedicated dot kernel (linalg.h: trace_dot_kernel)
+      const size_t bytes = sizeof(T) * (size_t)t5.n;
+      const int use_lds = bytes <= 64 * 1024;
+      if (use_lds) allow_dynamic_lds(reinterpret_cast<const void *>(&trace_dot_kernel<T, Acc>), bytes);
+      hipLaunchKernelGGL((trace_dot_kernel<T, Acc>), dim3(nb), dim3(256), use_lds ? bytes : 0, stream_, (const T *)t2.p, t2.n, nc / nc2,
+                         (const T *)t5.p, t5.n, nc / nc5, t2.d[0], t2.d[1], t2.d[2], res, use_lds);
+      PG_CHECK_HIP(hipGetLastError());
+      return res;
+    }
     TGemmDesc g;
     g.K[0] = t2.d[0]; g.K[1] = t2.d[1]; g.K[2] = t2.d[2];
     g.sAk[0] = t2.d[1] * t2.d[2]; g.sAk[1] = t2.d[2]; g.sAk[2] = 1;
