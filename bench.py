@@ -176,7 +176,9 @@ def cpu_baseline(flat, cfgs, chi, budget_s):
     return out
 
 
-PMC_META = os.path.join(ROOT, "profiles", "r03_pmc_meta.json")
+# the newest committed PMC summary (scripts/make_pmc_meta.py N): traffic and SQ shares are quoted only for a run of the profiled shape
+PMC_META = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc_meta.json" % r) for r in (6, 5, 4, 3)) if os.path.exists(p)),
+                os.path.join(ROOT, "profiles", "r04_pmc_meta.json"))
 
 
 def pmc_traffic_bytes(kernel, leg_tag, nw, launches_per_step):
