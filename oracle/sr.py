@@ -7,17 +7,22 @@ import numpy as np
 
 
 class SRSMatrix:
+    """TenElemT = double or complex: `a * b` of two SplitIndexTPS is the positive-definite pairing sum conj(a) b
+    (split_index_tps.h:370-377, qlten::QuasiInnerProduct) = np.vdot."""
+
     def __init__(self, ostar_samples, ostar_mean=None, world_size=1, diag_shift=0.0):
-        self.samples = [np.asarray(o, dtype=np.float64).ravel() for o in ostar_samples]
-        self.mean = None if ostar_mean is None else np.asarray(ostar_mean, dtype=np.float64).ravel()
+        cplx = any(np.iscomplexobj(o) for o in ostar_samples)
+        self.dtype = np.complex128 if cplx else np.float64
+        self.samples = [np.asarray(o, dtype=self.dtype).ravel() for o in ostar_samples]
+        self.mean = None if ostar_mean is None else np.asarray(ostar_mean, dtype=self.dtype).ravel()
         self.world_size, self.diag_shift = world_size, diag_shift
 
     def __mul__(self, v0):
-        v = np.asarray(v0, dtype=np.float64).ravel()
-        mean_dot_v = 0.0 if self.mean is None else float(self.mean @ v)          # :38-42
+        v = np.asarray(v0, dtype=self.dtype).ravel()
+        mean_dot_v = 0.0 if self.mean is None else np.vdot(self.mean, v)         # :38-42
         res = np.zeros_like(v)
         for o in self.samples:                                                      # :49-54
-            res += (float(o @ v) - mean_dot_v) * o
+            res += (np.vdot(o, v) - mean_dot_v) * o
         res *= 1.0 / (len(self.samples) * self.world_size)                          # :55
         if self.mean is not None and self.diag_shift != 0.0:                        # :75-77
             res += self.diag_shift * v

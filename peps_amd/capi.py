@@ -38,7 +38,7 @@ SYMBOLS = [
     "pepsgpu_grad_reset", "pepsgpu_grad_accumulate", "pepsgpu_grad_accumulate_states", "pepsgpu_grad_read", "pepsgpu_grad_device_ptr", "pepsgpu_grad_allreduce", "pepsgpu_bcast_state",
     "pepsgpu_comm_unique_id", "pepsgpu_comm_init", "pepsgpu_comm_size", "pepsgpu_comm_rank", "pepsgpu_comm_destroy",
     "pepsgpu_allreduce",
-    "pepsgpu_sr_begin", "pepsgpu_sr_append", "pepsgpu_sr_count", "pepsgpu_sr_sum", "pepsgpu_sr_matvec",
+    "pepsgpu_sr_begin", "pepsgpu_sr_append", "pepsgpu_sr_count", "pepsgpu_sr_sum", "pepsgpu_sr_matvec", "pepsgpu_sr_matvec_c128",
     "pepsgpu_sr_cg_solve", "pepsgpu_sr_gram", "pepsgpu_sr_weighted_sum", "pepsgpu_sr_copy_samples",
     "pepsgpu_update_local", "pepsgpu_erase_envs_after_update", "pepsgpu_evaluate_amplitude",
     "pepsgpu_walker_flags", "pepsgpu_sync", "pepsgpu_stats", "pepsgpu_profile_enable", "pepsgpu_profile_read",
@@ -117,6 +117,7 @@ def load_library(path=LIB_PATH):
     lib.pepsgpu_sr_count.argtypes = [vp]
     lib.pepsgpu_sr_sum.argtypes = [vp, dp]
     lib.pepsgpu_sr_matvec.argtypes = [vp, dp, C.c_double, C.c_double, dp]
+    lib.pepsgpu_sr_matvec_c128.argtypes = [vp, dp, C.c_double, C.c_double, C.c_double, dp]
     lib.pepsgpu_sr_cg_solve.argtypes = [vp, dp, dp, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, dp, dp, ip, ip]
     lib.pepsgpu_sr_gram.argtypes = [vp, vp, vp, C.c_int, dp]
     lib.pepsgpu_sr_weighted_sum.argtypes = [vp, dp, dp]
@@ -339,21 +340,25 @@ class Context:
         self._ck(self._l.pepsgpu_sr_begin(self._h, max_samples))
 
     def sr_append(self, psi):
-        psi = np.ascontiguousarray(psi, dtype=np.float64)
+        psi = np.ascontiguousarray(psi, dtype=self._ot)
         self._ck(self._l.pepsgpu_sr_append(self._h, _dp(psi)))
 
     def sr_count(self):
         return self._l.pepsgpu_sr_count(self._h)
 
     def sr_sum(self):
-        out = np.zeros((self.rows, self.cols, self.d, self.D, self.D, self.D, self.D))
+        out = np.zeros((self.rows, self.cols, self.d, self.D, self.D, self.D, self.D), dtype=self._ot)
         self._ck(self._l.pepsgpu_sr_sum(self._h, _dp(out)))
         return out
 
     def sr_matvec(self, v, mean_dot_v, scale):
-        v = np.ascontiguousarray(v, dtype=np.float64)
+        v = np.ascontiguousarray(v, dtype=self._ot)
         out = np.zeros_like(v)
-        self._ck(self._l.pepsgpu_sr_matvec(self._h, _dp(v), float(mean_dot_v), float(scale), _dp(out)))
+        if self._ot is np.complex128:
+            m = complex(mean_dot_v)
+            self._ck(self._l.pepsgpu_sr_matvec_c128(self._h, _dp(v), m.real, m.imag, float(scale), _dp(out)))
+        else:
+            self._ck(self._l.pepsgpu_sr_matvec(self._h, _dp(v), float(mean_dot_v), float(scale), _dp(out)))
         return out
 
     def sr_cg_solve(self, b, x0=None, diag_shift=0.0, max_iter=100, relative_tolerance=1e-4, absolute_tolerance=0.0,

@@ -281,6 +281,9 @@ int pepsgpu_sr_begin(pepsgpu_ctx *ctx, int max_samples) { CTX_CALL(ctx->eng->sr_
 int pepsgpu_sr_append(pepsgpu_ctx *ctx, const double *psi) { CTX_CALL(PG_REQUIRE(psi, 1, "null psi"); ctx->eng->sr_append(psi)); }
 int pepsgpu_sr_count(pepsgpu_ctx *ctx) { return (ctx && ctx->eng) ? ctx->eng->sr_count() : -1; }
 int pepsgpu_sr_sum(pepsgpu_ctx *ctx, double *out) { CTX_CALL(PG_REQUIRE(out, 1, "null output"); ctx->eng->sr_sum(out)); }
+int pepsgpu_sr_matvec_c128(pepsgpu_ctx *ctx, const double *v, double mean_dot_v_re, double mean_dot_v_im, double scale, double *out) {
+  CTX_CALL(PG_REQUIRE(v && out, 1, "null vector"); ctx->eng->sr_matvec_cplx(v, mean_dot_v_re, mean_dot_v_im, scale, out));
+}
 int pepsgpu_sr_matvec(pepsgpu_ctx *ctx, const double *v, double mean_dot_v, double scale, double *out) {
   CTX_CALL(PG_REQUIRE(v && out, 1, "null vector"); ctx->eng->sr_matvec(v, mean_dot_v, scale, out));
 }

@@ -96,6 +96,7 @@ struct EngineBase {
   virtual int sr_count() const = 0;
   virtual void sr_sum(double *out) = 0;
   virtual void sr_matvec(const double *v, double mean_dot_v, double scale, double *out) = 0;
+  virtual void sr_matvec_cplx(const double *v, double mean_dot_v_re, double mean_dot_v_im, double scale, double *out) = 0;
   virtual void sr_cg_solve(const double *b, const double *x0, double diag_shift, int max_iter, double rel_tol, double abs_tol,
                            int recompute_interval, double ortho_threshold, double *x_out, double *residual_norm,
                            int *iterations, int *reason) = 0;
@@ -754,6 +755,7 @@ class Engine : public EngineBase {
   int sr_count() const override { return sr_n_; }
   void sr_sum(double *out) override;
   void sr_matvec(const double *v, double mean_dot_v, double scale, double *out) override;
+  void sr_matvec_cplx(const double *v, double mean_dot_v_re, double mean_dot_v_im, double scale, double *out) override;
   void sr_cg_solve(const double *b, const double *x0, double diag_shift, int max_iter, double rel_tol, double abs_tol,
                    int recompute_interval, double ortho_threshold, double *x_out, double *residual_norm, int *iterations,
                    int *reason) override;

@@ -46,6 +46,75 @@ __global__ __launch_bounds__(256) void sr_delta_kernel(const T *__restrict__ o, 
   if (threadIdx.x == 0) delta[i] = s_red[0] + s_red[1] + s_red[2] + s_red[3] - shift - (shift_dev ? *shift_dev : 0.0);
 }
 
+// ---- complex element type (TenElemT = QLTEN_Complex; SRSMatrix is templated over it, stochastic_reconfiguration_smatrix.h:36-99) ----
+// O*_i(site) = conj(1 / psi_i) Dag(hole_i)(site) = conj(hole) * (psi / |psi|) / |psi|   (mc_energy_grad_evaluator.h:245-270)
+template <typename T>
+__global__ __launch_bounds__(256) void sr_append_cplx_kernel(const T *__restrict__ holes, const double *__restrict__ holes_ls,
+                                                             const int *__restrict__ cfg, const double *__restrict__ logabs,
+                                                             const double *__restrict__ ph_re, const double *__restrict__ ph_im,
+                                                             T *__restrict__ o_out, int *__restrict__ cfg_out, int sites, long slot,
+                                                             const int *__restrict__ site_ne) {
+  const int w = blockIdx.z, site = blockIdx.y;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long base = ((long)w * sites + site) * slot;
+  if (e < slot) {
+    T v = T(0);
+    if (e < site_ne[site]) {
+      const double f = exp(holes_ls[(long)w * sites + site] - logabs[w]);
+      const double hr = (double)holes[base + e].re, hi = -(double)holes[base + e].im;            // Dag(hole)
+      v = T(f * (hr * ph_re[w] - hi * ph_im[w]), f * (hr * ph_im[w] + hi * ph_re[w]));
+    }
+    o_out[base + e] = v;
+  }
+  if (e == 0) cfg_out[(long)w * sites + site] = cfg[(long)w * sites + site];
+}
+// delta[i] = < O*_i , v > - shift,  <a, b> = sum conj(a) b  (SplitIndexTPS::operator*, split_index_tps.h:370-377); interleaved pairs
+template <typename T>
+__global__ __launch_bounds__(256) void sr_delta_cplx_kernel(const T *__restrict__ o, const int *__restrict__ cfg,
+                                                            const double *__restrict__ v, double shift_re, double shift_im,
+                                                            double *__restrict__ delta, int sites, long slot, int dp) {
+  __shared__ double s_red[8];
+  const int i = blockIdx.x;
+  double ar = 0.0, ai = 0.0;
+  for (int site = 0; site < sites; ++site) {
+    const T *oi = o + ((long)i * sites + site) * slot;
+    const double *vs = v + 2 * ((long)site * dp + cfg[(long)i * sites + site]) * slot;
+    for (long e = threadIdx.x; e < slot; e += 256) {
+      const double xr = (double)oi[e].re, xi = (double)oi[e].im, yr = vs[2 * e], yi = vs[2 * e + 1];
+      ar += xr * yr + xi * yi;
+      ai += xr * yi - xi * yr;
+    }
+  }
+  ar = wave_sum(ar); ai = wave_sum(ai);
+  if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = ar; s_red[4 + (threadIdx.x >> 6)] = ai; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    delta[2 * i] = s_red[0] + s_red[1] + s_red[2] + s_red[3] - shift_re;
+    delta[2 * i + 1] = s_red[4] + s_red[5] + s_red[6] + s_red[7] - shift_im;
+  }
+}
+// out[site][s][e] = scale * sum_{i : cfg_i(site) == s} weight_i O*_i(site)[e], complex weights (nullptr: 1); interleaved pairs
+template <typename T>
+__global__ __launch_bounds__(256) void sr_accum_cplx_kernel(const T *__restrict__ o, const int *__restrict__ cfg,
+                                                            const double *__restrict__ weight, double scale, double *__restrict__ out,
+                                                            int n, int sites, long slot, int dp) {
+  const int site = blockIdx.y;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= slot) return;
+  for (int s = 0; s < dp; ++s) {
+    double ar = 0.0, ai = 0.0;
+    for (int i = 0; i < n; ++i) {
+      if (cfg[(long)i * sites + site] != s) continue;
+      const double wr = weight ? weight[2 * i] : 1.0, wi = weight ? weight[2 * i + 1] : 0.0;
+      const T x = o[((long)i * sites + site) * slot + e];
+      ar += wr * (double)x.re - wi * (double)x.im;
+      ai += wr * (double)x.im + wi * (double)x.re;
+    }
+    const long q = 2 * (((long)site * dp + s) * slot + e);
+    out[q] = scale * ar; out[q + 1] = scale * ai;
+  }
+}
+
 // part[blockIdx.x] = sum over the block's grid-stride share of a[e] b[e]; sr_dot_final_kernel adds the partials in a
 // fixed order (no atomics: the CG scalars are reproducible run to run)
 __global__ __launch_bounds__(256) void sr_dot_kernel(const double *__restrict__ a, const double *__restrict__ b, long n,
@@ -93,26 +162,26 @@ __global__ __launch_bounds__(256) void sr_accum_kernel(const T *__restrict__ o, 
 // device keeps site tensors, holes and O* samples in (true leg dimensions, row-major inside the D^4 slot)
 template <typename T>
 void Engine<T>::sr_convert(const double *src, double *dst, bool to_compact) const {
-  const size_t n = (size_t)Ly_ * Lx_ * dp_ * slot_;
+  const size_t n = (size_t)Ly_ * Lx_ * dp_ * slot_ * kOut;      // complex: interleaved (re, im) pairs
   std::fill(dst, dst + n, 0.0);
   const size_t m = sr_map_c_.size();
-  if (to_compact) for (size_t k = 0; k < m; ++k) dst[sr_map_c_[k]] = src[sr_map_p_[k]];
-  else for (size_t k = 0; k < m; ++k) dst[sr_map_p_[k]] = src[sr_map_c_[k]];
+  for (size_t k = 0; k < m; ++k) {
+    const size_t from = kOut * (size_t)(to_compact ? sr_map_p_[k] : sr_map_c_[k]), to = kOut * (size_t)(to_compact ? sr_map_c_[k] : sr_map_p_[k]);
+    for (int z = 0; z < kOut; ++z) dst[to + z] = src[from + z];
+  }
 }
 
 template <typename T>
 void Engine<T>::sr_begin(int max_samples) {
-  if constexpr (kCplx) {
-    PG_REQUIRE(false, 1, "stochastic reconfiguration is not implemented for the complex element type");
-  } else {
+  {
   PG_REQUIRE(max_samples > 0, 1, "sr_begin: need a positive sample capacity");
   sr_release();
   const size_t sites = (size_t)Ly_ * Lx_;
   sr_o_ = (T *)arena_.alloc(sizeof(T) * (size_t)max_samples * sites * slot_);
   sr_cfg_ = (int *)arena_.alloc(sizeof(int) * (size_t)max_samples * sites);
-  sr_delta_ = (double *)arena_.alloc(sizeof(double) * (size_t)max_samples);
-  sr_v_ = (double *)arena_.alloc(sizeof(double) * sites * dp_ * slot_);
-  sr_out_ = (double *)arena_.alloc(sizeof(double) * sites * dp_ * slot_);
+  sr_delta_ = (double *)arena_.alloc(sizeof(double) * (size_t)max_samples * kOut);
+  sr_v_ = (double *)arena_.alloc(sizeof(double) * sites * dp_ * slot_ * kOut);
+  sr_out_ = (double *)arena_.alloc(sizeof(double) * sites * dp_ * slot_ * kOut);
   sr_map_c_.clear(); sr_map_p_.clear();
   for (int r = 0; r < Ly_; ++r)
     for (int c = 0; c < Lx_; ++c) {
@@ -156,7 +225,27 @@ void Engine<T>::sr_release() {
 template <typename T>
 void Engine<T>::sr_append(const double *psi) {
   if constexpr (kCplx) {
-    PG_REQUIRE(false, 1, "stochastic reconfiguration is not implemented for the complex element type");
+    require_ready();
+    PG_REQUIRE(sr_o_ != nullptr, 3, "sr_append: call pepsgpu_sr_begin first");
+    PG_REQUIRE(holes_ != nullptr, 3, "sr_append: no holes stored (pepsgpu_punch_hole with out == NULL)");
+    PG_REQUIRE(sr_n_ + nw_ <= sr_cap_, 1, "sr_append: sample store is full");
+    std::vector<double> h(3 * (size_t)nw_);
+    for (int w = 0; w < nw_; ++w) {
+      const double a = std::hypot(psi[2 * w], psi[2 * w + 1]);
+      PG_REQUIRE(a != 0.0, 5, "Wavefunction amplitude is near zero, causing division by zero.");
+      h[w] = std::log(a); h[nw_ + w] = psi[2 * w] / a; h[2 * nw_ + w] = psi[2 * w + 1] / a;
+    }
+    double *d = (double *)arena_.alloc(sizeof(double) * h.size());
+    PG_CHECK_HIP(hipMemcpyAsync(d, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, stream_));
+    const int sites = Ly_ * Lx_;
+    hipLaunchKernelGGL(sr_append_cplx_kernel<T>, dim3((unsigned)((slot_ + 255) / 256), sites, nw_), dim3(256), 0, stream_,
+                       (const T *)holes_, (const double *)holes_ls_, (const int *)cfg_, (const double *)d, (const double *)(d + nw_),
+                       (const double *)(d + 2 * nw_), sr_o_ + (size_t)sr_n_ * sites * slot_, sr_cfg_ + (size_t)sr_n_ * sites, sites, slot_,
+                       (const int *)sr_ne_);
+    PG_CHECK_HIP(hipGetLastError());
+    PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    arena_.free(d);
+    sr_n_ += nw_;
   } else {
   require_ready();
   PG_REQUIRE(sr_o_ != nullptr, 3, "sr_append: call pepsgpu_sr_begin first");
@@ -184,7 +273,16 @@ void Engine<T>::sr_append(const double *psi) {
 template <typename T>
 void Engine<T>::sr_sum(double *out) {
   if constexpr (kCplx) {
-    PG_REQUIRE(false, 1, "stochastic reconfiguration is not implemented for the complex element type");
+    PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_sum: no samples");
+    const int sites = Ly_ * Lx_;
+    const size_t n = (size_t)sites * dp_ * slot_ * 2;
+    hipLaunchKernelGGL(sr_accum_cplx_kernel<T>, dim3((unsigned)((slot_ + 255) / 256), sites), dim3(256), 0, stream_, (const T *)sr_o_,
+                       (const int *)sr_cfg_, (const double *)nullptr, 1.0, sr_out_, sr_n_, sites, slot_, dp_);
+    PG_CHECK_HIP(hipGetLastError());
+    std::vector<double> h(n);
+    PG_CHECK_HIP(hipMemcpyAsync(h.data(), sr_out_, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    sr_convert(h.data(), out, false);
   } else {
   PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_sum: no samples");
   const int sites = Ly_ * Lx_;
@@ -201,9 +299,33 @@ void Engine<T>::sr_sum(double *out) {
 
 // out = scale * sum_i (O*_i . v - mean_dot_v) O*_i      (caller: all-reduce over ranks, + diag_shift * v)
 template <typename T>
+void Engine<T>::sr_matvec_cplx(const double *v, double mean_dot_v_re, double mean_dot_v_im, double scale, double *out) {
+  if constexpr (kCplx) {
+    PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_matvec: no samples");
+    const int sites = Ly_ * Lx_;
+    const size_t n = (size_t)sites * dp_ * slot_ * 2;
+    std::vector<double> h(n);
+    sr_convert(v, h.data(), true);
+    PG_CHECK_HIP(hipMemcpyAsync(sr_v_, h.data(), n * sizeof(double), hipMemcpyHostToDevice, stream_));
+    hipLaunchKernelGGL(sr_delta_cplx_kernel<T>, dim3(sr_n_), dim3(256), 0, stream_, (const T *)sr_o_, (const int *)sr_cfg_,
+                       (const double *)sr_v_, mean_dot_v_re, mean_dot_v_im, sr_delta_, sites, slot_, dp_);
+    PG_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(sr_accum_cplx_kernel<T>, dim3((unsigned)((slot_ + 255) / 256), sites), dim3(256), 0, stream_, (const T *)sr_o_,
+                       (const int *)sr_cfg_, (const double *)sr_delta_, scale, sr_out_, sr_n_, sites, slot_, dp_);
+    PG_CHECK_HIP(hipGetLastError());
+    PG_CHECK_HIP(hipMemcpyAsync(h.data(), sr_out_, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    sr_convert(h.data(), out, false);
+  } else {
+    PG_REQUIRE(mean_dot_v_im == 0.0, 1, "sr_matvec: a real context takes a real mean_dot_v");
+    sr_matvec(v, mean_dot_v_re, scale, out);
+  }
+}
+
+template <typename T>
 void Engine<T>::sr_matvec(const double *v, double mean_dot_v, double scale, double *out) {
   if constexpr (kCplx) {
-    PG_REQUIRE(false, 1, "stochastic reconfiguration is not implemented for the complex element type");
+    sr_matvec_cplx(v, mean_dot_v, 0.0, scale, out);
   } else {
   PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_matvec: no samples");
   const int sites = Ly_ * Lx_;

@@ -152,3 +152,59 @@ def test_minsr_direction_on_device(dt, tol):
         d, _ = sr.minsr_direction(batch, e_loc, e_mean, r_pinv=0.0, a_pinv=1e-11, soft_cutoff=False)
         assert why == sr.K_CONVERGED
         assert np.linalg.norm(x.ravel() - d) < 1e-7 * np.linalg.norm(d)
+
+
+def test_sr_matvec_complex_vs_oracle():
+    """TenElemT = QLTEN_Complex (SRSMatrix is templated over it, stochastic_reconfiguration_smatrix.h:36-99): O* samples of a complex
+    state resident in HBM (O*_i = conj(1 / psi_i) Dag(hole_i), mc_energy_grad_evaluator.h:245-270), their sum and the S-matrix product
+    with the positive-definite pairing <a, b> = sum conj(a) b of SplitIndexTPS::operator* (split_index_tps.h:370-377), against the
+    oracle's SRSMatrix built from host-side holes: 1e-9."""
+    from peps_amd import capi
+    from peps_amd.capi import LEFT, RIGHT, UP, DOWN, HORIZONTAL
+    L, D, chi, n = 4, 3, 9, 16
+    rng = np.random.default_rng(12)
+    sitps = synthetic.make_sitps(L, D)
+    flat = synthetic.sitps_to_flat(sitps, D).astype(np.complex128)
+    flat = flat * np.exp(2j * np.pi * rng.random(flat.shape)) * (np.abs(flat) > 0)
+    ctx = capi.Context(L, L, D, 2, chi, dtype=capi.C128, max_walkers=n)
+    ctx.state_upload(flat)
+    ctx.sr_begin(2 * n)
+    samples = []
+    for batch in range(2):
+        cfgs = synthetic.make_configs(L, n, "heisenberg", seed0=300 + 40 * batch)
+        ctx.set_configs(cfgs)
+        psi = ctx.evaluate_amplitude()
+        ctx.set_configs(cfgs)
+        ctx.generate_bmps_approach(UP)
+        ostar = np.zeros((n, L, L, 2, D, D, D, D), dtype=np.complex128)
+        for row in range(L):
+            ctx.init_bten(LEFT, row)
+            ctx.grow_full_bten(RIGHT, row, 1, True)
+            for col in range(L):
+                h = ctx.punch_hole(row, col, HORIZONTAL)
+                ctx.punch_hole_store(row, col, HORIZONTAL)
+                for w in range(n):
+                    ostar[w, row, col, cfgs[w, row, col]] = np.conj(h[w]) / np.conj(psi[w])      # conj(1 / psi) Dag(hole)
+                if col < L - 1:
+                    ctx.shift_bten_window(RIGHT)
+            if row < L - 1:
+                ctx.shift_bmps_window(DOWN)
+        ctx.sr_append(psi)
+        samples += list(ostar)
+    assert ctx.sr_count() == 2 * n
+    total = ctx.sr_sum()
+    want_sum = np.sum(samples, axis=0)
+    assert np.max(np.abs(total - want_sum)) < 1e-9 * np.max(np.abs(want_sum))
+    mean = want_sum / (2 * n)
+    ref = osr.SRSMatrix(samples, mean, 1, 0.0)
+    for _ in range(3):
+        v = rng.standard_normal(mean.shape) + 1j * rng.standard_normal(mean.shape)
+        got = ctx.sr_matvec(v, np.vdot(mean.ravel(), v.ravel()), 1.0 / (2 * n))
+        want = (ref * v).reshape(mean.shape)
+        assert np.max(np.abs(got - want)) < 1e-9 * np.max(np.abs(want))
+    # S is Hermitian positive semi-definite under that pairing
+    v = rng.standard_normal(mean.shape) + 1j * rng.standard_normal(mean.shape)
+    sv = ctx.sr_matvec(v, np.vdot(mean.ravel(), v.ravel()), 1.0 / (2 * n))
+    q = np.vdot(v.ravel(), sv.ravel())
+    assert q.real > 0 and abs(q.imag) < 1e-9 * q.real
+    ctx.close()
