@@ -321,6 +321,159 @@ __device__ __forceinline__ void tgemm_tile(const TGemmDesc &d, const TA *__restr
   }
 }
 
+// Skinny products with float64 accumulation (round 4): C = A B where one side is at most 32 wide -- Y = Tt V^T (256 x 32),
+// V' = U^T M (32 x 256), the products of the two-level truncation route -- on the f64 matrix cores.  The 64 x 64 tile of
+// tgemm_tile gives half of its waves columns (rows) that do not exist; here the block tile is BM x BN = 128 x 32 (four waves
+// stacked along I) or 32 x 128 (along J), every wave owns a live 32 x 32 quadrant.  Same descriptor semantics (strides, masks,
+// live extents, selectors), real element types, f32 or f64 operands.
+template <typename TA, typename TB, typename TC, int BM, int BN>
+__device__ __forceinline__ void tgemm_tile_skinny(const TGemmDesc &d, const TA *__restrict__ Ag, const TB *__restrict__ Bg,
+                                                  TC *__restrict__ Cg, const int i0, const int Itot, const int Ktot) {
+  constexpr int PA = BM + 16, PB = BN + 16;
+  __shared__ double As[TG_BK][PA];
+  __shared__ double Bs[TG_BK][PB];
+  __shared__ int offAi[BM], offBj[BN], offCi[BM], offCj[BN];
+  __shared__ int offAk[TG_KTAB], offBk[TG_KTAB];
+  const int tid = threadIdx.x, b = blockIdx.z, j0 = blockIdx.y * BN, Jtot = d.Jtot();
+  long baseA = (long)(b / d.bdivA) * d.wA, baseB = (long)(b / d.bdivB) * d.wB;
+  if (d.selA) baseA += (long)d.selA[(long)(b / d.seldivA) * d.selA_inc] * d.selA_mul;
+  if (d.selB) baseB += (long)d.selB[(long)(b / d.seldivB) * d.selB_inc] * d.selB_mul;
+  const TA *A = Ag + baseA;
+  const TB *B = Bg + baseB;
+  TC *C = Cg + (long)(b / d.bdivC) * d.wC;
+  for (int t = tid; t < BM + BN; t += 256) {
+    if (t < BM) {
+      const int i = i0 + t;
+      offAi[t] = (i < Itot) ? tg_off3m(i, d.I, d.sAi, d.Imask) : -1;
+      offCi[t] = (i < Itot) ? tg_off3(i, d.I, d.sCi) : -1;
+    } else {
+      const int j = j0 + t - BM;
+      offBj[t - BM] = (j < Jtot) ? tg_off3m(j, d.J, d.sBj, d.Jmask) : -1;
+      offCj[t - BM] = (j < Jtot) ? tg_off3(j, d.J, d.sCj) : -1;
+    }
+  }
+  __syncthreads();
+  const bool a_ifast = d.sAi[2] <= d.sAk[2], b_jfast = d.sBj[2] <= d.sBk[2];
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = BM == 128 ? wave : 0, wn = BM == 128 ? 0 : wave;
+  tg_f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][c][r] = 0.0;
+  constexpr int NA = BM * TG_BK / 256, NB = BN * TG_BK / 256;
+  double ra[NA], rb[NB];
+  for (int kc = 0; kc < Ktot; kc += TG_KTAB) {
+    const int kchunk = min(TG_KTAB, Ktot - kc);
+    __syncthreads();
+    for (int k = tid; k < kchunk; k += 256) {
+      offAk[k] = tg_off3(kc + k, d.K, d.sAk);
+      offBk[k] = tg_off3(kc + k, d.K, d.sBk);
+    }
+    __syncthreads();
+    const int nkt = (kchunk + TG_BK - 1) / TG_BK;
+    auto load_regs = [&](int kt) {
+#pragma unroll
+      for (int r = 0; r < NA; ++r) {
+        const int e = tid + 256 * r;
+        int ia, ka;
+        if (a_ifast) { ia = e % BM; ka = e / BM; } else { ka = e & 15; ia = e >> 4; }
+        const int kk = kt * TG_BK + ka, oa = offAi[ia];
+        ra[r] = (oa >= 0 && kk < kchunk) ? (double)A[oa + offAk[kk]] : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+        const int e = tid + 256 * r;
+        int jb, kb;
+        if (b_jfast) { jb = e % BN; kb = e / BN; } else { kb = e & 15; jb = e >> 4; }
+        const int kk = kt * TG_BK + kb, ob = offBj[jb];
+        rb[r] = (ob >= 0 && kk < kchunk) ? (double)B[ob + offBk[kk]] : 0.0;
+      }
+    };
+    auto store_regs = [&]() {
+#pragma unroll
+      for (int r = 0; r < NA; ++r) {
+        const int e = tid + 256 * r;
+        int ia, ka;
+        if (a_ifast) { ia = e % BM; ka = e / BM; } else { ka = e & 15; ia = e >> 4; }
+        As[ka][ia] = ra[r];
+      }
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+        const int e = tid + 256 * r;
+        int jb, kb;
+        if (b_jfast) { jb = e % BN; kb = e / BN; } else { kb = e & 15; jb = e >> 4; }
+        Bs[kb][jb] = rb[r];
+      }
+    };
+    load_regs(0);
+    store_regs();
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      if (kt + 1 < nkt) load_regs(kt + 1);
+#pragma unroll
+      for (int kk = 0; kk < TG_BK; kk += 4) {
+        const double a0 = As[kk + (lane >> 4)][wm * 32 + (lane & 15)], a1 = As[kk + (lane >> 4)][wm * 32 + 16 + (lane & 15)];
+        const double b0 = Bs[kk + (lane >> 4)][wn * 32 + (lane & 15)], b1 = Bs[kk + (lane >> 4)][wn * 32 + 16 + (lane & 15)];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      }
+      __syncthreads();
+      if (kt + 1 < nkt) {
+        store_regs();
+        __syncthreads();
+      }
+    }
+  }
+  const double alpha = d.alpha;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int li = wm * 32 + a * 16 + (lane >> 4) + 4 * r, lj = wn * 32 + c * 16 + (lane & 15);
+        const int oi = offCi[li], oj = offCj[lj];
+        if (oi >= 0 && oj >= 0) {
+          TC *p = C + oi + oj;
+          double v = acc[a][c][r] * alpha;
+          if (d.accumulate) v += (double)*p;
+          *p = TC(v);
+        }
+      }
+}
+
+template <typename TA, typename TB, typename TC, int BM, int BN>
+__global__ __launch_bounds__(256) void tgemm_skinny_f64_kernel(TGemmDesc d, const TA *__restrict__ Ag, const TB *__restrict__ Bg,
+                                                               TC *__restrict__ Cg) {
+  const int b = blockIdx.z;
+  if (d.batch_flag && d.batch_flag[b] >= 0) return;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    if (d.dI[s].p) { const int e = max(0, min(d.I[s], d.dI[s].p[b / d.dI[s].div] * d.dI[s].mul)); if (d.dI[s].mask) d.Imask[s] = e; else d.I[s] = e; }
+    if (d.dJ[s].p) { const int e = max(0, min(d.J[s], d.dJ[s].p[b / d.dJ[s].div] * d.dJ[s].mul)); if (d.dJ[s].mask) d.Jmask[s] = e; else d.J[s] = e; }
+    if (d.dK[s].p) d.K[s] = max(0, min(d.K[s], d.dK[s].p[b / d.dK[s].div] * d.dK[s].mul));
+  }
+  if ((int)blockIdx.y * BN >= d.Jtot()) return;
+  int Itot = d.Itot(), Ktot = d.Ktot();
+  if (d.dynI) Itot = max(0, min(Itot, d.dynI[b] * d.dynI_mul));
+  if (d.dynK) Ktot = max(0, min(Ktot, d.dynK[b] * d.dynK_mul));
+  if (d.flopc && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && b % d.flop_stride == 0) {
+    atomicAdd(d.flopc, 2ull * d.flop_stride * Itot * d.Jtot() * Ktot);
+    if (d.bytec)
+      atomicAdd(d.bytec, (unsigned long long)d.flop_stride * ((unsigned long long)Itot * Ktot * sizeof(TA) + (unsigned long long)Ktot * d.Jtot() * sizeof(TB) +
+                                                              (unsigned long long)Itot * d.Jtot() * sizeof(TC)));
+  }
+  for (int i0 = blockIdx.x * BM; i0 < Itot; i0 += gridDim.x * BM) {
+    tgemm_tile_skinny<TA, TB, TC, BM, BN>(d, Ag, Bg, Cg, i0, Itot, Ktot);
+    __syncthreads();
+  }
+}
+
 // One block walks the I tiles blockIdx.x, blockIdx.x + gridDim.x, ... of its (j tile, batch entry):
 // with a per-walker dynamic extent the grid is launched narrow (TG_DYN_GRIDX tiles) so that the
 // launch does not consist of tens of thousands of blocks that exit at once.
@@ -781,6 +934,24 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
   }
   (void)fused_norm_ok;
   PG_REQUIRE(!d.scale_out && !d.scale_in, 5, "tensor GEMM: scale_in / scale_out need the wave-per-tile kernel");
+  if constexpr (std::is_same<TAcc, double>::value && !is_cplx<TA>::value && !is_cplx<TB>::value && !is_cplx<TC>::value) {
+    // skinny float64-accumulated products (one side <= 32): 128 x 32 / 32 x 128 block tiles, every wave on a live quadrant
+    static const bool no_skinny = getenv("PEPSGPU_NO_SKINNY") != nullptr;
+    if (tgemm_use_mfma() && !no_skinny && !d.upper_only && d.Itot() > 1 && d.Jtot() > 1) {
+      if (d.Jtot() <= 32 && d.Itot() >= 64) {
+        int gxs = (d.Itot() + 127) / 128;
+        if (dyn_i && gxs > TG_DYN_GRIDX) gxs = TG_DYN_GRIDX;
+        hipLaunchKernelGGL((tgemm_skinny_f64_kernel<TA, TB, TC, 128, 32>), dim3(gxs, 1, d.nbatch), dim3(256), 0, s, d, A, B, C);
+        PG_CHECK_HIP(hipGetLastError());
+        return;
+      }
+      if (d.Itot() <= 32 && d.Jtot() >= 64) {
+        hipLaunchKernelGGL((tgemm_skinny_f64_kernel<TA, TB, TC, 32, 128>), dim3(1, (d.Jtot() + 127) / 128, d.nbatch), dim3(256), 0, s, d, A, B, C);
+        PG_CHECK_HIP(hipGetLastError());
+        return;
+      }
+    }
+  }
   if constexpr (is_cplx<TAcc>::value) {
     // complex element type: four real v_mfma_f64_16x16x4_f64 products per tile from the interleaved LDS operands
     // (PEPSGPU_NO_CPLX_MFMA=1: the same tiling on the vector ALUs, round 2's path)

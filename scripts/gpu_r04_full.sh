@@ -5,8 +5,7 @@ python -m pytest tests -m gpu -x -q > gpurun_out/r04/full_suite.log 2>&1
 echo "pytest rc $?" >> gpurun_out/r04/full_suite.log
 tail -4 gpurun_out/r04/full_suite.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r04/smoke.log 2>&1; tail -1 gpurun_out/r04/smoke.log
-/usr/bin/time -v python bench.py --steps 20 --warmup 5 > gpurun_out/r04/bench_driver.json 2> gpurun_out/r04/bench_driver.err
-tail -c 1500 gpurun_out/r04/bench_driver.err | grep -E "Elapsed|Maximum resident" 
+python bench.py --steps 20 --warmup 5 > gpurun_out/r04/bench_driver.json 2> gpurun_out/r04/bench_driver.err
 python - <<'PY'
 import json
 d=json.loads(open('gpurun_out/r04/bench_driver.json').read().strip().splitlines()[-1])
