@@ -1136,9 +1136,45 @@ class Engine : public EngineBase {
     const int s1 = dd[l1], s2 = dd[l2], y = mps2.d[2];
     PG_REQUIRE(cdim == bt.t.d[0] && p1 == dd[lc] && b1 == dd[lb] && mps2.d[0] == b2 && mps2.d[1] == s1, 3,
                "BTen step: bond dimension mismatch between environment tensors");
+    // f32, one candidate per walker (growth steps, the half steps of the sweeps / energy slices): the first two contractions
+    // run as ONE chained launch with tmp1 resident in LDS (tgemm_chain_kernel, as the absorption's X -> P pair): one launch and
+    // the HBM round trip of tmp1 less per step; entries whose live tmp1 does not fit take the separate launches below
+    int *bt_chain_flag = nullptr;
+    int bt_chained = 0;
+    DTen<T> tmp2c;
+    if constexpr (sizeof(T) == 4) {
+      static const bool no_btc = getenv("PEPSGPU_NO_BTEN_CHAIN") != nullptr;
+      if (!no_btc && ncand == 1 && bt_ncand == 1 && x * p1 > 1 && b1 * b2 > 1) {
+        tmp2c = alloc_ten(b2, x, s1, s2, nb);
+        bt_chain_flag = (int *)arena_.alloc(sizeof(int) * nb);
+        TGemmDesc g1, g2;
+        g1.I[1] = x; g1.I[2] = p1; g1.sAi[1] = p1 * cdim; g1.sAi[2] = cdim; g1.sCi[1] = p1 * b1 * b2; g1.sCi[2] = b1 * b2;
+        g1.K[2] = cdim; g1.sAk[2] = 1; g1.sBk[2] = b1 * b2;
+        g1.J[1] = b1; g1.J[2] = b2; g1.sBj[1] = b2; g1.sBj[2] = 1; g1.sCj[1] = b2; g1.sCj[2] = 1;
+        g1.wA = mps1.n; g1.wB = bt.t.n; g1.wC = (long)x * p1 * b1 * b2; g1.nbatch = nb;
+        g1.dI[1].p = vx; g1.dK[2].p = vc; g1.dJ[2].p = vb;
+        // tmp2[b2,x,s1,s2] = sum_{p1,b1} site[p1,b1,s1,s2] tmp1[x,p1,b1,b2]:  I2 = (s1, s2), K2 = (p1, b1), J2 = (x, b2)
+        g2.I[1] = s1; g2.I[2] = s2; g2.sAi[1] = st[l1]; g2.sAi[2] = st[l2]; g2.sCi[1] = s2; g2.sCi[2] = 1;
+        g2.K[1] = p1; g2.K[2] = b1; g2.sAk[1] = st[lc]; g2.sAk[2] = st[lb]; g2.sBk[1] = b1 * b2; g2.sBk[2] = b2;
+        g2.J[1] = x; g2.J[2] = b2; g2.sBj[1] = p1 * b1 * b2; g2.sBj[2] = 1; g2.sCj[1] = s1 * s2; g2.sCj[2] = x * s1 * s2;
+        g2.wB = g1.wC; g2.wC = tmp2c.n; g2.nbatch = nb;
+        g2.dJ[1].p = vx; g2.dJ[2].p = vb;
+        g2.selA = ss.sel; g2.selA_mul = slot_; g2.selA_inc = ss.inc; g2.seldivA = 1; g2.wA = 0;
+        TGemmChainMap mp;
+        mp.mapK[1] = 2; mp.mapK[2] = 4;      // K2 = (p1, b1): p1 = I1[2], b1 = J1[1]
+        mp.mapJ[1] = 1; mp.mapJ[2] = 5;      // J2 = (x, b2):  x = I1[1],  b2 = J1[2]
+        const double fl = 2.0 * nb * ((double)(x * p1) * cdim * (double)(b1 * b2) + (double)(b2 * x) * (double)(p1 * b1) * (double)(s1 * s2));
+        prof_begin(PROF_ENV, fl, fl);
+        bt_chained = tgemm_chain_launch(stream_, g1, g2, mp, (const float *)mps1.p, (const float *)bt.t.p, (const float *)sel_base(ss),
+                                        (float *)tmp2c.p, bt_chain_flag, 1, 0);
+        prof_end();
+        if (!bt_chained) { arena_.free(bt_chain_flag); bt_chain_flag = nullptr; }
+      }
+    }
     // tmp1[x,p1,b1,b2] = sum_c mps1[x,p1,c] bten[c,b1,b2]     (per walker)
-    DTen<T> tmp1 = alloc_ten(x, p1, b1, b2, nb1);
-    {
+    DTen<T> tmp1;
+    if (bt_chained < 2) tmp1 = alloc_ten(x, p1, b1, b2, nb1);
+    if (bt_chained < 2) {
       TGemmDesc g;
       g.I[2] = x * p1; g.sAi[2] = cdim; g.sCi[2] = b1 * b2;
       g.K[2] = cdim; g.sAk[2] = 1; g.sBk[2] = b1 * b2;
@@ -1149,25 +1185,28 @@ class Engine : public EngineBase {
         g.dI[1].p = vx; g.dI[1].div = bt_ncand; g.dK[2].p = vc; g.dK[2].div = bt_ncand; g.dJ[2].p = vb; g.dJ[2].div = bt_ncand;
       }
       g.wA = mps1.n; g.bdivA = bt_ncand; g.wB = bt.t.n; g.wC = tmp1.n; g.nbatch = nb1;
+      g.batch_flag = bt_chain_flag;
       const double fl = 2.0 * nb1 * (double)(x * p1) * cdim * (double)(b1 * b2);
-      prof_begin(PROF_ENV, fl, fl);
+      prof_begin(PROF_ENV, bt_chained ? 0.0 : fl, bt_chained ? 0.0 : fl);
       tgemm_launch<T, T, T, T>(stream_, g, mps1.p, bt.t.p, tmp1.p);
       prof_end();
     }
     // tmp2[b2,x,s1,s2] = sum_{p1,b1} tmp1[x,p1,b1,b2] site[lc<-p1, lb<-b1, l1->s1, l2->s2]
-    DTen<T> tmp2 = alloc_ten(b2, x, s1, s2, nb);
-    {
+    DTen<T> tmp2 = bt_chained ? tmp2c : alloc_ten(b2, x, s1, s2, nb);
+    if (bt_chained < 2) {
       TGemmDesc g;
       g.I[1] = b2; g.I[2] = x; g.sAi[1] = 1; g.sAi[2] = p1 * b1 * b2; g.sCi[1] = x * s1 * s2; g.sCi[2] = s1 * s2;
       g.K[1] = p1; g.K[2] = b1; g.sAk[1] = b1 * b2; g.sAk[2] = b2; g.sBk[1] = st[lc]; g.sBk[2] = st[lb];
       g.J[1] = s1; g.J[2] = s2; g.sBj[1] = st[l1]; g.sBj[2] = st[l2]; g.sCj[1] = s2; g.sCj[2] = 1;
       g.wA = tmp1.n; g.bdivA = ncand / bt_ncand; g.wC = tmp2.n; g.nbatch = nb;
       g.dI[1].p = vb; g.dI[1].div = ncand; g.dI[2].p = vx; g.dI[2].div = ncand;
+      g.batch_flag = bt_chain_flag;
       const double fl = 2.0 * nb * (double)(b2 * x) * (double)(p1 * b1) * (double)(s1 * s2);
-      prof_begin(PROF_ENV, fl, fl);
+      prof_begin(PROF_ENV, bt_chained ? 0.0 : fl, bt_chained ? 0.0 : fl);
       launch_site_gemm(g, ss, ncand, tmp1.p, tmp2.p);
       prof_end();
     }
+    if (bt_chain_flag) arena_.free(bt_chain_flag);
     // out[x,s2,y] = sum_{b2,s1} tmp2[b2,x,s1,s2] mps2[b2,s1,y]
     BTenDev o;
     o.t = alloc_ten(x, s2, y, 1, nb);
@@ -1185,7 +1224,8 @@ class Engine : public EngineBase {
       tgemm_launch<T, T, T, T>(stream_, g, tmp2.p, mps2.p, o.t.p);
       prof_end();
     }
-    free_ten(tmp1); free_ten(tmp2);
+    if (tmp1.p) free_ten(tmp1);
+    free_ten(tmp2);
     inject(INJ_E, o.t.p, o.t.n, nb);
     o.logscale = nullptr;
     if (normalise) {
