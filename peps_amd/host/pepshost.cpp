@@ -468,7 +468,7 @@ int pepshost_fermion_energy(int rows, int cols, int D, int d, const int32_t *nf,
     std::copy(comp.amplitude.begin(), comp.amplitude.end(), amplitudes_out);
     EnergyAndHoles eh;
     if (model == 0) {
-      SquareSpinlessFermion m(prm[0], prm[1]);
+      SquareSpinlessFermion m(prm[0], prm[2], prm[1]);      // (t, t2, V): params = [t, V, t2, -]
       eh = m.CalEnergyAndHoles<false>(sitps, comp);
     } else {
       SquaretJVModel m(prm[0], 0.0, prm[1], prm[2], prm[3]);

@@ -1498,15 +1498,55 @@ class SquareSpinOneHalfJ1J2XXZModelOBC : public SquareNNNModelEnergySolver<Squar
       : SquareSpinOneHalfXXZModelMixIn(jz, jxy, jz2, jxy2, pinning_field00) {}
 };
 
-// square_spinless_fermion.h:51-200: H = -t sum_<ij> (c+_i c_j + h.c.) + V sum_<ij> n_i n_j (+ t2 NNN hopping, which
-// the reference routes through BTen2 / ReplaceNNNSiteTrace: not local in the decorated form, must be 0 here).
+// square_spinless_fermion.h:51-200: H = -t sum_<ij> (c+_i c_j + h.c.) - t2 sum_<<ij>> (c+_i c_j + h.c.) + V sum_<ij> n_i n_j.
 // psi is recomputed with Trace next to psi' (same contraction path, docs/dev/design/math/
 // fermion-sign-in-bmps-contraction.md), the bosonic inv_psi argument is unused.
+// NNN hopping (:161-200, routed through BTen2 / ReplaceNNNSiteTrace in the reference): a diagonal hop is not local in the
+// sign-decorated form (the Jordan-Wigner string of the sites between the two in the row-major mode order changes the components
+// of OTHER sites' decoration), so it is taken from a FRESH amplitude of the hopped configuration, batched over the walkers:
+// 2 (L - 1)^2 extra contractions per sample when t2 != 0 (round 4: the C++ model refused t2 != 0 before; peps_amd/fermion.py
+// has had the same form).  The environment-reusing form stays unbuilt.
 class SquareSpinlessFermion : public SquareNNModelEnergySolver<SquareSpinlessFermion> {
  public:
   SquareSpinlessFermion(double t, double V) : t_(t), t2_(0.0), V_(V) {}
-  SquareSpinlessFermion(double t, double t2, double V) : t_(t), t2_(t2), V_(V) {
-    if (t2 != 0.0) throw std::invalid_argument("SquareSpinlessFermion: t2 != 0 (NNN hopping) is not implemented on the device");
+  SquareSpinlessFermion(double t, double t2, double V) : t_(t), t2_(t2), V_(V) {}
+  template <bool calchols = true, typename TenElemT = double>
+  EnergyAndHolesT<TenElemT> CalEnergyAndHoles(const SplitIndexTPST<TenElemT> &sitps, TPSWaveFunctionComponentT<TenElemT> &comp,
+                                              bool holes_on_device = false) {
+    EnergyAndHolesT<TenElemT> out =
+        SquareNNModelEnergySolver<SquareSpinlessFermion>::template CalEnergyAndHoles<calchols, TenElemT>(sitps, comp, holes_on_device);
+    if (t2_ != 0.0) AddNNNHopEnergyFresh(comp, out.energy);
+    return out;
+  }
+  // sum over the plaquette diagonals of -t2 * jw * psi(S with the two sites exchanged) / psi(S); jw = (-1)^(fermions strictly
+  // between the two sites in row-major order).  Leaves comp on its original configuration.
+  template <typename TenElemT>
+  void AddNNNHopEnergyFresh(TPSWaveFunctionComponentT<TenElemT> &comp, std::vector<TenElemT> &energy) const {
+    if (!comp.fermion) throw std::logic_error("SquareSpinlessFermion: NNN hopping needs the fermionic decoration of the component");
+    const size_t n = comp.config.walkers(), rows = comp.config.rows(), cols = comp.config.cols();
+    const Configuration orig = comp.config;
+    comp.ReplaceGlobalConfig(orig);                       // psi of the original configuration, fresh (row-major order)
+    const std::vector<TenElemT> psi0 = comp.amplitude;
+    for (size_t row = 0; row + 1 < rows; ++row)
+      for (size_t col = 0; col + 1 < cols; ++col)
+        for (int diag = 0; diag < 2; ++diag) {
+          const SiteIdx a = diag == 0 ? SiteIdx{row, col} : SiteIdx{row + 1, col};
+          const SiteIdx b = diag == 0 ? SiteIdx{row + 1, col + 1} : SiteIdx{row, col + 1};
+          bool any = false;
+          for (size_t w = 0; w < n; ++w) any |= orig(w, a) != orig(w, b);
+          if (!any) continue;
+          Configuration hop = orig;
+          for (size_t w = 0; w < n; ++w) { hop(w, a) = orig(w, b); hop(w, b) = orig(w, a); }
+          comp.ReplaceGlobalConfig(hop);
+          const size_t ia = std::min(a.r * cols + a.c, b.r * cols + b.c), ib = std::max(a.r * cols + a.c, b.r * cols + b.c);
+          for (size_t w = 0; w < n; ++w) {
+            if (orig(w, a) == orig(w, b)) continue;
+            int between = 0;
+            for (size_t q = ia + 1; q < ib; ++q) between += comp.fermion->n(orig(w, {q / cols, q % cols}));
+            energy[w] += TenElemT(-t2_ * ((between & 1) ? -1.0 : 1.0)) * comp.amplitude[w] / psi0[w];
+          }
+        }
+    comp.ReplaceGlobalConfig(orig);
   }
   double CalDensityImpl(int32_t config) const { return double(1 - config); }   // :95-97
   std::vector<double> EvaluateBondEnergy(const SiteIdx &s1, const SiteIdx &s2, BondOrientation orient,

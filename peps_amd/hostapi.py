@@ -252,7 +252,7 @@ def load_configuration(directory, label, rows, cols):
     return out
 
 
-def fermion_energy(state, configs, chi, t, V=0.0, dtype=1, model="spinless", J=0.0, mu=0.0):
+def fermion_energy(state, configs, chi, t, V=0.0, dtype=1, model="spinless", J=0.0, mu=0.0, t2=0.0):
     """C++ host layer on a fermionic state (peps_amd.fermion.FermionState): amplitudes (row-major mode order),
     E_loc of the spinless t-V model (model="spinless") or of the t-J-V model (model="tj"), psi along every route."""
     flat = np.ascontiguousarray(state.extended_flat(), dtype=np.float64)
@@ -263,7 +263,7 @@ def fermion_energy(state, configs, chi, t, V=0.0, dtype=1, model="spinless", J=0
     amps, en = np.zeros(n), np.zeros(n)
     psi = np.zeros((rows + cols, n))
     npsi = C.c_int(0)
-    prm = np.array([t, V, 0.0, 0.0] if model == "spinless" else [t, J, V, mu], dtype=np.float64)
+    prm = np.array([t, V, t2, 0.0] if model == "spinless" else [t, J, V, mu], dtype=np.float64)
     _ck(lib().pepshost_fermion_energy(rows, cols, D, state.d, _p(nf, C.c_int32), chi, dtype, _p(flat, C.c_double), n,
                                       _p(cfg, C.c_int32), 0 if model == "spinless" else 1, _p(prm, C.c_double),
                                       _p(amps, C.c_double), _p(en, C.c_double), _p(psi, C.c_double), C.byref(npsi)))

@@ -53,6 +53,11 @@ def test_k4_spinless_fermion_exact_sum_on_device(fixtures_dir, name, t2, e_ref):
         tot = sum(obs[k].sum(axis=1) for k in ("bond_energy_h", "bond_energy_v", "bond_energy_dr", "bond_energy_ur"))
         assert np.max(np.abs(tot - obs["energy"][:, 0])) < 1e-10 and np.max(np.abs(obs["energy"][:, 0] - e_loc)) < 1e-10
         assert np.count_nonzero(obs["bond_energy_dr"]) + np.count_nonzero(obs["bond_energy_ur"]) > 0
+    # the C++ host layer's SquareSpinlessFermion(t, t2, V) (round 4: the diagonal hop from fresh batched amplitudes there too)
+    from peps_amd import hostapi
+    amps2, en2, _ = hostapi.fermion_energy(st, cfgs, 8, 1.0, 0.0, 1, t2=t2)
+    assert np.max(np.abs(amps2 - amp)) < 1e-12 * np.max(np.abs(amp)) and np.max(np.abs(en2 - e_loc)) < 1e-9
+    assert abs(np.sum(amps2 ** 2 * en2) / np.sum(amps2 ** 2) - e_ref) < 1e-9
 
 
 @pytest.mark.parametrize("dt,tol", [("f64", 1e-10), ("f32", 2e-5)])
@@ -178,13 +183,16 @@ def test_cpp_host_layer_fermion_energy(dt, tol):
     cfgs = rng.integers(0, 2, size=(5, 4, 4))
     cfgs[(16 - cfgs.sum(axis=(1, 2))) % 2 == 1, 0, 0] ^= 1
     amps, en, psi = hostapi.fermion_energy(st, cfgs, 16, 1.0, 0.5, dt)
+    _, en_t2, _ = hostapi.fermion_energy(st, cfgs, 16, 1.0, 0.5, dt, t2=0.7)
     tp = BMPSTruncateParams.SVD(16, 16, 0.0)
-    model = ofermion.SquareSpinlessFermionOBC(1.0, 0.0, 0.5)
+    model, model_t2 = ofermion.SquareSpinlessFermionOBC(1.0, 0.0, 0.5), ofermion.SquareSpinlessFermionOBC(1.0, 0.7, 0.5)
     for k, cfg in enumerate(cfgs):
         a = fs.amplitude(cfg, tp)
         assert abs(amps[k] / a - 1) < tol
         e, _ = model.CalEnergy(fs, cfg, tp)
         assert abs(en[k] - e) < tol * 10 * max(1.0, abs(e))
+        e2, _ = model_t2.CalEnergy(fs, cfg, tp)          # 4x4 with the diagonal hop: 18 plaquette diagonals, strings of up to 4 sites
+        assert abs(en_t2[k] - e2) < tol * 10 * max(1.0, abs(e2)) and abs(e2 - e) > 1e-3
     assert psi.shape[0] == 8
 
 
