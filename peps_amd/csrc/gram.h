@@ -242,6 +242,10 @@ __global__ __launch_bounds__(512, 2) void gram_cols_lds_kernel(const T *__restri
   }
 }
 
+}  // namespace pepsgpu
+#include "gram_i8.h"
+namespace pepsgpu {
+
 template <typename T>
 inline void launch_gram_cols_f64(hipStream_t s, int nbatch, const T *P, long wP, int n, int ld, const int *kdyn, int kdyn_mul,
                                  int kmax, double *G, const int *run_flag, int inner, const int *inner_live,
@@ -252,6 +256,16 @@ inline void launch_gram_cols_f64(hipStream_t s, int nbatch, const T *P, long wP,
     static const bool no_lds_gram = getenv("PEPSGPU_NO_LDS_GRAM") != nullptr;
     // dense walkers (hint of the caller: kmax rows, 193..256 columns = four 64-column blocks): P through LDS once per walker
     if (!no_lds_gram && n > 192 && n <= 256 && ld % 4 == 0 && wP % 4 == 0 && (((uintptr_t)P) & 15) == 0 && kmax >= 256) {
+      // round 4: the same Gram as exact integer arithmetic on the i8 matrix cores (gram_i8.h), PEPSGPU_NO_I8_GRAM=1 for the f64 form
+      static const bool no_i8_gram = getenv("PEPSGPU_NO_I8_GRAM") != nullptr;
+      if (!no_i8_gram) {
+        const size_t smem8 = gram_cols_i8_smem_bytes();
+        allow_dynamic_lds(reinterpret_cast<const void *>(&gram_cols_i8_kernel<T>), smem8);
+        hipLaunchKernelGGL(gram_cols_i8_kernel<T>, dim3(nbatch), dim3(512), smem8, s, P, wP, n, ld, kdyn, kdyn_mul, kmax, G, (long)n * n,
+                           run_flag, inner > 0 ? inner : 1, inner_live, flopc, bytec, nbatch >= 256 ? 64 : 1);
+        PG_CHECK_HIP(hipGetLastError());
+        return;
+      }
       const size_t smem = gram_cols_lds_smem_bytes();
       allow_dynamic_lds(reinterpret_cast<const void *>(&gram_cols_lds_kernel<T>), smem);
       hipLaunchKernelGGL(gram_cols_lds_kernel<T>, dim3(nbatch), dim3(512), smem, s, P, wP, n, ld, kdyn, kdyn_mul, kmax, G, (long)n * n,
