@@ -39,13 +39,17 @@ constexpr int GI_BUF = 3 * GI_PLANE;
 constexpr int GI_RAW = GI_KB * 256 * 4;       // the float32 rows of the next block (LDS-DMA image: one row = one wave-instruction)
 inline size_t gram_cols_i8_smem_bytes() { return GI_BUF + GI_RAW + 256 * sizeof(int) + 2 * 256 * sizeof(float); }
 
+// ROWS: the row Gram of the truncation input instead (gram_rows_f64_kernel of gram.h: G = M M^T, M = n x K row-major with row stride K,
+// n = nrows[b] live rows, the contracted index runs along the rows) -- the same kernel with the roles of the two indices of the
+// operand exchanged: "column" j of the text above is row j of M, a block is 64 consecutive k of every row.
 // DBG: timing-only variants of scripts/gram_i8_bench.hip (1 no drain, 2 no digit pass after block 0, 4 no MFMA).
-template <typename T, int DBG = 0>
+template <typename T, bool ROWS = false, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void gram_cols_i8_kernel(const T *__restrict__ Pg, long wP, int n, int ld,
                                                               const int *__restrict__ kdyn, int kdyn_mul, int kmax,
-                                                              double *__restrict__ Gg, long wG,
+                                                              double *__restrict__ Gg, long wG, int ldg,
                                                               const int *__restrict__ run_flag, int inner,
                                                               const int *__restrict__ inner_live,
+                                                              const int *__restrict__ nrows,
                                                               unsigned long long *__restrict__ flopc,
                                                               unsigned long long *__restrict__ bytec, int flop_stride) {
   static_assert(sizeof(T) == 4, "f32 input");
@@ -57,7 +61,11 @@ __global__ __launch_bounds__(512, 2) void gram_cols_i8_kernel(const T *__restric
   const int b = blockIdx.x;
   if (run_flag && run_flag[b] >= 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int K = kdyn ? max(0, min(kmax, kdyn[b] * kdyn_mul)) : kmax;
+  const int K = ROWS ? kmax : (kdyn ? max(0, min(kmax, kdyn[b] * kdyn_mul)) : kmax);
+  if (ROWS) {
+    n = min(n, nrows[b]);
+    if (n <= 0) return;
+  }
   if (run_flag) flop_stride = 1;
   if (flopc && tid == 0 && b % flop_stride == 0) {
     atomicAdd(flopc, (unsigned long long)flop_stride * n * n * K);
@@ -68,28 +76,44 @@ __global__ __launch_bounds__(512, 2) void gram_cols_i8_kernel(const T *__restric
   const int ilive = inner_live ? min(inner, inner_live[b]) : inner;
   const int c16 = lane & 15, g4 = lane >> 4;
   const int j = tid & 255, kh = wave >> 2;
-  const bool col_ok = j < n && (j % inner) < ilive;          // dead / absent column: never written in P
+  const bool col_ok = j < n && (ROWS || (j % inner) < ilive);          // dead / absent column: never written in P
   const int nb = (K + GI_KB - 1) / GI_KB;
-  // rows 8 wave .. 8 wave + 7 of block blk: lane l fetches floats 4 l .. 4 l + 3 of the row (rows beyond K / columns beyond n: a
-  // clamped address, masked when the image is read)
+  // cols: rows 8 wave .. 8 wave + 7 of block blk, lane l fetches floats 4 l .. 4 l + 3 of the row (rows beyond K / columns beyond n: a
+  // clamped address, masked when the image is read).  rows: the image is [row of M][64 k]; lane l of instruction q fetches for row
+  // 32 wave + 4 q + l / 16 the k-chunk (l % 16) ^ (row % 16) -- the image of a row is a permutation of its sixteen 16-byte chunks, so that
+  // the sixteen lanes of a ds_read_b128 phase (consecutive rows, same k) hit sixteen different bank groups.
   auto issue = [&](int blk) __attribute__((always_inline)) {
-    const int cs = 4 * lane < n ? 4 * lane : 0;
+    if constexpr (ROWS) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int rl = 8 * wave + q, r = min(blk * GI_KB + rl, K - 1);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(P + (long)r * ld + cs),
-                                       (__attribute__((address_space(3))) void *)(raw + rl * 256), 16, 0, 0);
+      for (int q = 0; q < 8; ++q) {
+        const int jr = 32 * wave + 4 * q + (lane >> 4);
+        const int kc = blk * GI_KB + 4 * ((lane & 15) ^ (jr & 15));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(P + (long)min(jr, n - 1) * ld + min(kc, K - 4)),
+                                         (__attribute__((address_space(3))) void *)(raw + (32 * wave + 4 * q) * 64), 16, 0, 0);
+      }
+    } else {
+      const int cs = 4 * lane < n ? 4 * lane : 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int rl = 8 * wave + q, r = min(blk * GI_KB + rl, K - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(P + (long)r * ld + cs),
+                                         (__attribute__((address_space(3))) void *)(raw + rl * 256), 16, 0, 0);
+      }
     }
   };
   // digits of block blk from the LDS image of its rows: one pass for the column maxima, a second one (sixteen rows at a time, the
   // accumulators leave few registers) for the digits
   auto lay = [&](int blk) __attribute__((always_inline)) {
     const int r0 = blk * GI_KB + 32 * kh;
-    const float *col = raw + 32 * kh * 256 + j;
+    // element q (0..31) of this thread's half column in the image
+    auto at = [&](int q) __attribute__((always_inline)) -> float {
+      if constexpr (ROWS) return raw[j * 64 + 4 * (((32 * kh + q) >> 2) ^ (j & 15)) + (q & 3)];
+      else return raw[(32 * kh + q) * 256 + j];
+    };
     const int qlive = col_ok ? min(32, K - r0) : 0;             // rows of this half that exist (the others: clamped copies, masked)
     float m = 0.f;
 #pragma unroll
-    for (int q = 0; q < 32; ++q) m = fmaxf(m, q < qlive ? fabsf(col[q * 256]) : 0.f);
+    for (int q = 0; q < 32; ++q) m = fmaxf(m, q < qlive ? fabsf(at(q)) : 0.f);
     pmax[256 * kh + j] = m;
     __syncthreads();
     m = fmaxf(pmax[j], pmax[256 + j]);
@@ -106,7 +130,7 @@ __global__ __launch_bounds__(512, 2) void gram_cols_i8_kernel(const T *__restric
 #pragma unroll
         for (int z = 0; z < 4; ++z) {
           const int q = 16 * hh + 4 * q4 + z;
-          const float x = q < qlive ? col[q * 256] : 0.f;
+          const float x = q < qlive ? at(q) : 0.f;
           // round to nearest integer by the float add: 1.5 * 2^23 + n has n (two's complement, |n| <= 2^22) in its mantissa bits
           const unsigned yb = __float_as_uint(fmaf(x, sc, 12582912.f));
           w[z] = (yb + (0x808080u - 0x4B400000u)) ^ 0x808080u;       // bytes 0, 1, 2 = the signed digits d2, d1, d0 of n
@@ -204,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void gram_cols_i8_kernel(const T *__restric
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 16 * GlTile<W>::x(t) + 4 * g4 + r, jj = 16 * GlTile<W>::c(t) + c16;
-        if (i < n && jj < n) G[(long)i * n + jj] = acc[t][r];
+        if (i < n && jj < n) G[(long)i * ldg + jj] = acc[t][r];
       }
   };
   switch (wave) {      // (every branch executes the same number of barriers)

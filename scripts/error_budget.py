@@ -115,6 +115,8 @@ def main():
         ("f32 no mid route, no ortho polish", capi.F32, {"PEPSGPU_NO_MIDROUTE": "1", "PEPSGPU_ORTHO_POLISH": "0"}),
         ("f32 no chain", capi.F32, {"PEPSGPU_NO_CHAIN": "1"}),
         ("f32 no rank adapt", capi.F32, {"PEPSGPU_NO_RANK_ADAPT": "1"}),
+        ("f32 Grams on the f64 matrix cores (no i8)", capi.F32, {"PEPSGPU_NO_I8_GRAM": "1"}),
+        ("f32 i8 column Gram only", capi.F32, {"PEPSGPU_NO_I8_ROWGRAM": "1"}),
     ]
     if args.only:
         want = set(args.only.split(";"))

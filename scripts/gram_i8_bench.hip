@@ -84,9 +84,9 @@ int main(int argc, char **argv) {
                            ildev, nullptr, nullptr, 1);
       } else {
         const size_t smem = gram_cols_i8_smem_bytes();
-#define GI_LAUNCH(D) do { allow_dynamic_lds(reinterpret_cast<const void *>(&gram_cols_i8_kernel<float, D>), smem); \
-        hipLaunchKernelGGL((gram_cols_i8_kernel<float, D>), dim3(nw), dim3(512), smem, 0, P, wP, n, ld, kdev, 1, rows, G, (long)n * n, nullptr, inner, \
-                           ildev, nullptr, nullptr, 1); } while (0)
+#define GI_LAUNCH(D) do { allow_dynamic_lds(reinterpret_cast<const void *>(&gram_cols_i8_kernel<float, false, D>), smem); \
+        hipLaunchKernelGGL((gram_cols_i8_kernel<float, false, D>), dim3(nw), dim3(512), smem, 0, P, wP, n, ld, kdev, 1, rows, G, (long)n * n, n, nullptr, inner, \
+                           ildev, nullptr, nullptr, nullptr, 1); } while (0)
         if (variant == 1) GI_LAUNCH(0); else if (variant == 2) GI_LAUNCH(1); else if (variant == 3) GI_LAUNCH(2); else if (variant == 4) GI_LAUNCH(4); else GI_LAUNCH(7);
       }
       CK(hipGetLastError());
@@ -112,6 +112,61 @@ int main(int argc, char **argv) {
     printf("{\"kernel\": \"%s\", \"walkers\": %d, \"rows\": %d, \"n\": %d, \"ms\": %.4f, \"tflops_upper_triangle\": %.2f, \"err_exact\": %.3e, \"err_image\": %.3e}\n",
            variant == 0 ? "gram_cols_lds_kernel (f64 MFMA)" : variant == 1 ? "gram_cols_i8_kernel (9 x i8 MFMA, exact)" : variant == 2 ? "timing only: no drain" : variant == 3 ? "timing only: no digit pass" : variant == 4 ? "timing only: no MFMA" : "timing only: loads + barriers", nw, rows, n, ms, flop / ms * 1e-9, eex, eim);
     fflush(stdout);
+  }
+  // ---- row Gram (the truncation input): M = nr x 256, G = M M^T, nr live rows per walker ----
+  {
+    const int Kr = 256, ldg = 256;
+    std::vector<float> Mh((size_t)2 * 256 * Kr);
+    for (int w = 0; w < 2; ++w)
+      for (int i = 0; i < 256; ++i)
+        for (int k = 0; k < Kr; ++k) Mh[((size_t)w * 256 + i) * Kr + k] = Ph[((size_t)w * rows + k) * ld + i];     // M = P^T of the first 256 rows
+    std::vector<int> nr(nw);
+    for (int b = 0; b < nw; ++b) nr[b] = 256 - (int)(rng() % 64);
+    nr[0] = 256; nr[1] = 203;
+    float *Md; int *nrd;
+    CK(hipMalloc(&Md, sizeof(float) * 256 * Kr * nw)); CK(hipMalloc(&nrd, sizeof(int) * nw));
+    for (int b = 0; b < nw; ++b) CK(hipMemcpy(Md + (size_t)256 * Kr * b, Mh.data() + (size_t)(b & 1) * 256 * Kr, sizeof(float) * 256 * Kr, hipMemcpyHostToDevice));
+    CK(hipMemcpy(nrd, nr.data(), sizeof(int) * nw, hipMemcpyHostToDevice));
+    std::vector<long double> Gx((size_t)2 * 256 * 256, 0.0L);
+    for (int w = 0; w < 2; ++w)
+      for (int i = 0; i < nr[w]; ++i)
+        for (int jx = i; jx < nr[w]; ++jx) {
+          long double sx = 0;
+          for (int k = 0; k < Kr; ++k) sx += (long double)Mh[((size_t)w * 256 + i) * Kr + k] * Mh[((size_t)w * 256 + jx) * Kr + k];
+          Gx[((size_t)w * 256 + i) * 256 + jx] = sx;
+        }
+    for (int variant = 0; variant < 2; ++variant) {
+      float ms = 0;
+      for (int rep = -1; rep < reps; ++rep) {
+        CK(hipMemset(G, 0xff, sizeof(double) * 256 * 256 * 2));
+        CK(hipEventRecord(e0));
+        if (variant == 0) {
+          hipLaunchKernelGGL(gram_rows_f64_kernel<float>, dim3((10 + 3) / 4, nw), dim3(256), 0, 0, Md, (long)256 * Kr, Kr, nrd, G, (long)256 * 256, ldg, nullptr,
+                             nullptr, nullptr);
+        } else {
+          const size_t smem = gram_cols_i8_smem_bytes();
+          allow_dynamic_lds(reinterpret_cast<const void *>(&gram_cols_i8_kernel<float, true>), smem);
+          hipLaunchKernelGGL((gram_cols_i8_kernel<float, true>), dim3(nw), dim3(512), smem, 0, Md, (long)256 * Kr, 256, Kr, nullptr, 1, Kr, G, (long)256 * 256, ldg,
+                             nullptr, 1, nullptr, nrd, nullptr, nullptr, 1);
+        }
+        CK(hipGetLastError());
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float t; CK(hipEventElapsedTime(&t, e0, e1));
+        if (rep >= 0) ms += t;
+      }
+      ms /= reps;
+      CK(hipMemcpy(Gh.data(), G, sizeof(double) * 256 * 256 * 2, hipMemcpyDeviceToHost));
+      double eex = 0;
+      for (int w = 0; w < 2; ++w)
+        for (int i = 0; i < nr[w]; ++i)
+          for (int jx = i; jx < nr[w]; ++jx) {
+            const long double sc = sqrtl(Gx[((size_t)w * 256 + i) * 256 + i] * Gx[((size_t)w * 256 + jx) * 256 + jx]);
+            eex = std::max(eex, (double)(fabsl(Gh[((size_t)w * 256 + i) * 256 + jx] - Gx[((size_t)w * 256 + i) * 256 + jx]) / sc));
+          }
+      printf("{\"kernel\": \"%s\", \"walkers\": %d, \"K\": %d, \"ms\": %.4f, \"err_exact\": %.3e}\n",
+             variant == 0 ? "gram_rows_f64_kernel (f64 MFMA)" : "gram_cols_i8_kernel<ROWS> (9 x i8 MFMA)", nw, Kr, ms, eex);
+      fflush(stdout);
+    }
   }
   return 0;
 }
