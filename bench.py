@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--real-rank-walkers", type=int, default=8192)
     ap.add_argument("--real-rank-steps", type=int, default=2)
     ap.add_argument("--no-sweeps", action="store_true", help="skip the MC sweeps/s and VMC samples/s measurement")
-    ap.add_argument("--sweep-walkers", type=int, default=8192)
+    ap.add_argument("--sweep-walkers", type=int, default=16384)
     ap.add_argument("--real-sweep-walkers", type=int, default=2048, help="walkers of the sweep / VMC-sample rates on the real_rank leg")
     ap.add_argument("--real-sweep-count", type=int, default=3, help="timed sweeps / samples there")
     ap.add_argument("--sweep-count", type=int, default=2)

@@ -488,7 +488,8 @@ class Engine : public EngineBase {
 
   // ReplaceNNSiteTrace with everything left on the device: candidate table dcand [walker][nc][2] (nullptr: the configurations),
   // result res [walker x nc] (mantissa) and lsum [walker] (log-scale): psi' = res exp(lsum).  Caller frees both.
-  Acc *nn_trace_device(int row, int col, int dir, int nc, const int *dcand, double **lsum_out) {
+  // skip (optional, per walker, nc == 1): nonzero = the result of this walker is not needed (its entry of res is undefined)
+  Acc *nn_trace_device(int row, int col, int dir, int nc, const int *dcand, double **lsum_out, const int *skip = nullptr) {
     int rb = row + (dir == VERTICAL), cb = col + (dir == HORIZONTAL);
     PG_REQUIRE(row >= 0 && col >= 0 && rb < Ly_ && cb < Lx_, 1, "ReplaceNNSiteTrace: bond outside the lattice");
     SiteSel sa = cfg_site(row, col), sb = cfg_site(rb, cb);
@@ -503,18 +504,18 @@ class Engine : public EngineBase {
       PG_REQUIRE(bten_size(LEFT) > col, 3, "ReplaceNNSiteTrace: LEFT BTen missing");
       const int *a1, *a3, *b1, *b3;
       live_at_logical(up, UP, col, a1, a3); live_at_logical(dn, DOWN, col, b1, b3);
-      t2 = bten_step(LEFT, bten_[LEFT][col], at_logical(up, UP, col), sa, at_logical(dn, DOWN, col), nc, false, 1, a1, a3, b1, b3);
+      t2 = bten_step(LEFT, bten_[LEFT][col], at_logical(up, UP, col), sa, at_logical(dn, DOWN, col), nc, false, 1, a1, a3, b1, b3, skip);
       live_at_logical(dn, DOWN, cb, a1, a3); live_at_logical(up, UP, cb, b1, b3);
-      t5 = bten_step(RIGHT, bten_at_slice(RIGHT, cb), at_logical(dn, DOWN, cb), sb, at_logical(up, UP, cb), nc, false, 1, a1, a3, b1, b3);
+      t5 = bten_step(RIGHT, bten_at_slice(RIGHT, cb), at_logical(dn, DOWN, cb), sb, at_logical(up, UP, cb), nc, false, 1, a1, a3, b1, b3, skip);
       add_logs(lsum, up.logscale, dn.logscale, bten_[LEFT][col].logscale, bten_at_slice(RIGHT, cb).logscale);
     } else {
       const BMPSDev &lf = bmps_at_slice(LEFT, col), &rt = bmps_at_slice(RIGHT, col);
       PG_REQUIRE(bten_size(UP) > row, 3, "ReplaceNNSiteTrace: UP BTen missing");
       const int *a1, *a3, *b1, *b3;
       live_at_logical(rt, RIGHT, row, a1, a3); live_at_logical(lf, LEFT, row, b1, b3);
-      t2 = bten_step(UP, bten_[UP][row], at_logical(rt, RIGHT, row), sa, at_logical(lf, LEFT, row), nc, false, 1, a1, a3, b1, b3);
+      t2 = bten_step(UP, bten_[UP][row], at_logical(rt, RIGHT, row), sa, at_logical(lf, LEFT, row), nc, false, 1, a1, a3, b1, b3, skip);
       live_at_logical(lf, LEFT, rb, a1, a3); live_at_logical(rt, RIGHT, rb, b1, b3);
-      t5 = bten_step(DOWN, bten_at_slice(DOWN, rb), at_logical(lf, LEFT, rb), sb, at_logical(rt, RIGHT, rb), nc, false, 1, a1, a3, b1, b3);
+      t5 = bten_step(DOWN, bten_at_slice(DOWN, rb), at_logical(lf, LEFT, rb), sb, at_logical(rt, RIGHT, rb), nc, false, 1, a1, a3, b1, b3, skip);
       add_logs(lsum, lf.logscale, rt.logscale, bten_[UP][row].logscale, bten_at_slice(DOWN, rb).logscale);
     }
     Acc *res = finish_dot_device(t2.t, nc, t5.t, nc, nc);
@@ -1121,7 +1122,7 @@ class Engine : public EngineBase {
   // then run over the live parts only (the tensors are zero beyond them); the new BTen is written in full, zeros included.
   BTenDev bten_step(int post, const BTenDev &bt, const DTen<T> &mps1, const SiteSel &ss, const DTen<T> &mps2,
                     int ncand, bool normalise, int bt_ncand = 1, const int *vx = nullptr, const int *vc = nullptr,
-                    const int *vb = nullptr, const int *vy = nullptr) {
+                    const int *vb = nullptr, const int *vy = nullptr, const int *skip = nullptr) {
     ArenaScope scope(arena_);
     static const bool no_live_env = getenv("PEPSGPU_NO_LIVE_ENV") != nullptr;
     if (no_live_env || sizeof(T) != 4) vx = vc = vb = vy = nullptr;
@@ -1164,6 +1165,44 @@ class Engine : public EngineBase {
         mp.mapK[1] = 2; mp.mapK[2] = 4;      // K2 = (p1, b1): p1 = I1[2], b1 = J1[1]
         mp.mapJ[1] = 1; mp.mapJ[2] = 5;      // J2 = (x, b2):  x = I1[1],  b2 = J1[2]
         const double fl = 2.0 * nb * ((double)(x * p1) * cdim * (double)(b1 * b2) + (double)(b2 * x) * (double)(p1 * b1) * (double)(s1 * s2));
+        // round 4: all three contractions in one launch (tgemm_chain3_kernel: tmp1 and tmp2 resident in LDS, the bond x walked in
+        // chunks when the live intermediates exceed the buffers); PEPSGPU_NO_BTEN_CHAIN3=1 for the two-stage chain + separate launch
+        static const bool no_bt3 = getenv("PEPSGPU_NO_BTEN_CHAIN3") != nullptr;
+        if (!no_bt3) {
+          TGemmDesc g3;
+          g3.I[1] = x; g3.I[2] = s2; g3.sCi[1] = s2 * y; g3.sCi[2] = y;
+          g3.K[1] = b2; g3.K[2] = s1; g3.sBk[1] = s1 * y; g3.sBk[2] = y;
+          g3.J[2] = y; g3.sBj[2] = 1; g3.sCj[2] = 1;
+          g3.wB = mps2.n; g3.nbatch = nb;
+          g3.dI[1].p = vx; g3.dI[1].mask = 1;     // the new BTen is written in full
+          g3.dK[1].p = vb;
+          g3.dJ[2].p = vy; g3.dJ[2].mask = 1;
+          TGemmChain3Map mp3;
+          mp3.mapI[1] = 4; mp3.mapI[2] = 2;    // I3 = (x, s2):  x = J2[1],  s2 = I2[2]
+          mp3.mapK[1] = 5; mp3.mapK[2] = 1;    // K3 = (b2, s1): b2 = J2[2], s1 = I2[1]
+          mp3.chunkI = 1;
+          BTenDev o3;
+          o3.t = alloc_ten(x, s2, y, 1, nb);
+          g3.wC = o3.t.n;
+          const double fl3 = fl + 2.0 * nb * (double)(x * s2) * (double)(b2 * s1) * (double)y;
+          prof_begin(PROF_ENV, fl3, fl3);
+          const int done = tgemm_chain3_launch(stream_, g1, g2, g3, mp, mp3, (const float *)mps1.p, (const float *)bt.t.p,
+                                               (const float *)sel_base(ss), (const float *)mps2.p, (float *)o3.t.p, bt_chain_flag, skip);
+          prof_end();
+          if (done == 2) {
+            arena_.free(bt_chain_flag);
+            free_ten(tmp2c);
+            inject(INJ_E, o3.t.p, o3.t.n, nb);
+            o3.logscale = nullptr;
+            if (normalise) {
+              o3.logscale = (double *)arena_.alloc(sizeof(double) * nw_);
+              PG_CHECK_HIP(hipMemcpyAsync(o3.logscale, bt.logscale, sizeof(double) * nw_, hipMemcpyDeviceToDevice, stream_));
+              normalize(o3.t.p, o3.t.n, o3.t.n, nw_, o3.logscale);
+            }
+            return o3;
+          }
+          free_ten(o3.t);
+        }
         prof_begin(PROF_ENV, fl, fl);
         bt_chained = tgemm_chain_launch(stream_, g1, g2, mp, (const float *)mps1.p, (const float *)bt.t.p, (const float *)sel_base(ss),
                                         (float *)tmp2c.p, bt_chain_flag, 1, 0);

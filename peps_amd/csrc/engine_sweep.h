@@ -22,12 +22,16 @@
 
 namespace pepsgpu {
 
-// cand[w] = (cfg[w][s2], cfg[w][s1]): the exchanged pair
-__global__ void sweep_swap_cand_kernel(const int *__restrict__ cfg, int sites, int s1, int s2, int *__restrict__ cand, int n) {
+// cand[w] = (cfg[w][s2], cfg[w][s1]): the exchanged pair; same[w] = 1 when the two states are equal (the exchange is the identity:
+// square_nn_updater.h:149-151 returns before any contraction, and so do the environment steps of the replacement trace here)
+__global__ void sweep_swap_cand_kernel(const int *__restrict__ cfg, int sites, int s1, int s2, int *__restrict__ cand,
+                                       int *__restrict__ same, int n) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n) return;
-  cand[2 * w] = cfg[(long)w * sites + s2];
-  cand[2 * w + 1] = cfg[(long)w * sites + s1];
+  const int a = cfg[(long)w * sites + s1], b = cfg[(long)w * sites + s2];
+  cand[2 * w] = b;
+  cand[2 * w + 1] = a;
+  same[w] = a == b;
 }
 
 // Metropolis test of the exchange (square_nn_updater.h:149-170) and the accepted exchange itself
@@ -67,11 +71,12 @@ __global__ void sweep_gather_slice_kernel(const int *__restrict__ cfg, int sites
 }
 
 // psi'[w][j] = res[w] exp(lsum[w]) into column j of a [n][stride] table
+// (same[w] != 0: the exchange was the identity and its trace was skipped -- psi' = psi, column 0 of the table)
 template <typename AccT>
 __global__ void sweep_store_value_kernel(const AccT *__restrict__ res, const double *__restrict__ lsum, double *__restrict__ out,
-                                         int stride, int j, int n) {
+                                         int stride, int j, const int *__restrict__ same, int n) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w < n) out[(long)w * stride + j] = (double)res[w] * exp(lsum[w]);
+  if (w < n) out[(long)w * stride + j] = (same && same[w]) ? out[(long)w * stride] : (double)res[w] * exp(lsum[w]);
 }
 
 // One row / column of the energy evaluation (SquareNNNModelEnergySolver::CalEnergyAndHolesImpl, square_nnn_energy_solver.h:
@@ -94,7 +99,8 @@ void Engine<T>::nn_exchange_slice(int orient, int slice, int punch_holes, double
       holes_ls_ = (double *)arena_.alloc(sizeof(double) * (size_t)maxw_ * Ly_ * Lx_);
     }
     double *dval = (double *)arena_.alloc(sizeof(double) * (size_t)nw_ * N);     // column 0: psi, columns 1..N-1: psi_ex of bond j-1
-    int *dcand = (int *)arena_.alloc(sizeof(int) * 2 * (size_t)nw_);
+    int *dcand = (int *)arena_.alloc(sizeof(int) * 3 * (size_t)nw_);
+    int *dsame = dcand + 2 * (size_t)nw_;
     auto release = [&]() { arena_.free(dval); arena_.free(dcand); };
     try {
       const int lo = orient == HORIZONTAL ? LEFT : UP, hi = orient == HORIZONTAL ? RIGHT : DOWN;
@@ -105,7 +111,7 @@ void Engine<T>::nn_exchange_slice(int orient, int slice, int punch_holes, double
       {
         double *lsum = nullptr;
         Acc *res = nn_trace_device(orient == HORIZONTAL ? slice : 0, orient == HORIZONTAL ? 0 : slice, orient, 1, nullptr, &lsum);
-        hipLaunchKernelGGL(sweep_store_value_kernel<Acc>, dim3(gb), dim3(256), 0, stream_, (const Acc *)res, (const double *)lsum, dval, N, 0, nw_);
+        hipLaunchKernelGGL(sweep_store_value_kernel<Acc>, dim3(gb), dim3(256), 0, stream_, (const Acc *)res, (const double *)lsum, dval, N, 0, (const int *)nullptr, nw_);
         PG_CHECK_HIP(hipGetLastError());
         arena_.free(res); arena_.free(lsum);
       }
@@ -115,12 +121,12 @@ void Engine<T>::nn_exchange_slice(int orient, int slice, int punch_holes, double
         if (j + 1 < N) {
           const int r2 = orient == HORIZONTAL ? slice : j + 1, c2 = orient == HORIZONTAL ? j + 1 : slice;
           hipLaunchKernelGGL(sweep_swap_cand_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)cfg_, sites, r1 * Lx_ + c1, r2 * Lx_ + c2,
-                             dcand, nw_);
+                             dcand, dsame, nw_);
           PG_CHECK_HIP(hipGetLastError());
           double *lsum = nullptr;
-          Acc *res = nn_trace_device(r1, c1, orient, 1, dcand, &lsum);
+          Acc *res = nn_trace_device(r1, c1, orient, 1, dcand, &lsum, dsame);
           hipLaunchKernelGGL(sweep_store_value_kernel<Acc>, dim3(gb), dim3(256), 0, stream_, (const Acc *)res, (const double *)lsum, dval, N,
-                             j + 1, nw_);
+                             j + 1, (const int *)dsame, nw_);
           PG_CHECK_HIP(hipGetLastError());
           arena_.free(res); arena_.free(lsum);
           if (remain == 1 || j + 2 < N) shift_bten_window(hi);
@@ -155,7 +161,8 @@ void Engine<T>::sweep_slice_exchange(int orient, int slice, int n_uniform, const
     double *duni = (double *)arena_.alloc(sizeof(double) * (size_t)nw_ * n_uniform);
     int *dptr = (int *)arena_.alloc(sizeof(int) * (2 * (size_t)nw_ + 1));
     int *dacc = dptr + nw_, *dover = dptr + 2 * nw_;
-    int *dcand = (int *)arena_.alloc(sizeof(int) * 2 * (size_t)nw_);
+    int *dcand = (int *)arena_.alloc(sizeof(int) * 3 * (size_t)nw_);
+    int *dsame = dcand + 2 * (size_t)nw_;
     int *dslice = (int *)arena_.alloc(sizeof(int) * (size_t)nw_ * N);
     auto release = [&]() { arena_.free(damp); arena_.free(duni); arena_.free(dptr); arena_.free(dcand); arena_.free(dslice); };
     try {
@@ -170,10 +177,10 @@ void Engine<T>::sweep_slice_exchange(int orient, int slice, int n_uniform, const
         const int r1 = orient == HORIZONTAL ? slice : j, c1 = orient == HORIZONTAL ? j : slice;
         const int r2 = orient == HORIZONTAL ? slice : j + 1, c2 = orient == HORIZONTAL ? j + 1 : slice;
         const int s1 = r1 * Lx_ + c1, s2 = r2 * Lx_ + c2;
-        hipLaunchKernelGGL(sweep_swap_cand_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)cfg_, sites, s1, s2, dcand, nw_);
+        hipLaunchKernelGGL(sweep_swap_cand_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)cfg_, sites, s1, s2, dcand, dsame, nw_);
         PG_CHECK_HIP(hipGetLastError());
         double *lsum = nullptr;
-        Acc *res = nn_trace_device(r1, c1, orient, 1, dcand, &lsum);
+        Acc *res = nn_trace_device(r1, c1, orient, 1, dcand, &lsum, dsame);
         hipLaunchKernelGGL(sweep_metropolis_exchange_kernel<Acc>, dim3(gb), dim3(256), 0, stream_, cfg_, sites, s1, s2, (const Acc *)res,
                            (const double *)lsum, damp, (const double *)duni, n_uniform, dptr, dacc, dover, nw_);
         PG_CHECK_HIP(hipGetLastError());

@@ -856,12 +856,120 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TG
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// THREE chained contractions, both intermediates resident in LDS (round 4: one BTen growth step = one launch):
+//     C1 = A1 B1,   C2 = A2 C1'  (C1' = C1 regrouped as the B operand of stage 2, as above),   C3 = C2' B3
+// (C2' = C2 regrouped as the A operand of stage 3: mp3.mapI / mapK name, for every I / K sub-index of stage 3, the sub-index of C2
+// it runs over, 0..2 = I2[s], 3..5 = J2[s]).  The middle I sub-index of stage 1 (I1[1]) must be a J sub-index of stage 2 AND an I
+// sub-index of stage 3 (mp3.chunkI): when the live intermediates exceed the two buffers it is walked in chunks, every chunk a
+// complete triple of contractions on a slice of the result.  Rows of C3 beyond the live extent of that sub-index are stored as
+// zeros when d3 masks it (the new environment tensor is written in full).  Entries that cannot be chunked write flag[b] = -1.
+struct TGemmChain3Map { int mapI[3] = {-1, -1, -1}, mapK[3] = {-1, -1, -1}; int chunkI = -1; };
+
+template <bool AVEC1, bool BVEC1, bool AVEC2, int LDSF, int MINB>
+__global__ __launch_bounds__(256, MINB) void tgemm_chain3_kernel(TGemmDesc d1, TGemmDesc d2, TGemmDesc d3, TGemmChainMap mp, TGemmChain3Map mp3,
+                                                             const float *__restrict__ A1g, const float *__restrict__ B1g,
+                                                             const float *__restrict__ A2g, const float *__restrict__ B3g,
+                                                             float *__restrict__ C3g, int *__restrict__ flag,
+                                                             const int *__restrict__ skip) {
+  __shared__ __attribute__((aligned(16))) int offCi_s[4][32];
+  __shared__ float s_mid1[LDSF];
+  __shared__ float s_mid2[LDSF];
+  const int b = blockIdx.x;
+  if (skip && skip[b]) return;        // the caller does not need this entry (its C3 stays undefined)
+  const int K2s1 = d1.K[2], K2s2 = d2.K[2], K2s3 = d3.K[2];
+  const int x_static = mp3.chunkI == 0 ? d3.I[0] : mp3.chunkI == 1 ? d3.I[1] : d3.I[2];
+  tg_apply_extents(d1, b);
+  tg_apply_extents(d2, b);
+  tg_apply_extents(d3, b);
+  const int I1 = d1.Itot(), J1 = d1.Jtot(), I2 = d2.Itot(), J2 = d2.Jtot(), J3 = d3.Jtot();
+  int jsub = -1;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    if (mp.mapJ[s] == 1) jsub = (jsub < 0 && d2.Jmask[s] == 0x7fffffff) ? s : 3;
+    if (mp.mapK[s] == 1) jsub = 3;
+  }
+  int lds1[6], lds2[6];
+  int st1 = 1, st2 = 1;
+  for (int s = 2; s >= 0; --s) { lds1[3 + s] = st1; st1 *= d1.J[s]; }
+  for (int s = 2; s >= 0; --s) { lds1[s] = st1; st1 *= d1.I[s]; }
+  for (int s = 2; s >= 0; --s) { lds2[3 + s] = st2; st2 *= d2.J[s]; }
+  for (int s = 2; s >= 0; --s) { lds2[s] = st2; st2 *= d2.I[s]; }
+  const int n1 = d1.I[1];                                   // live extent of the chunked sub-index
+  const int per1 = lds1[1], per2 = n1 > 0 ? st2 / n1 : 0;   // floats of C1 / C2 per value of it
+  if (jsub < 0 || jsub > 2 || mp3.chunkI < 0 || d1.I[0] != 1 || d1.dynI || d2.dynI || d3.dynI || d1.Imask[1] != 0x7fffffff ||
+      per1 > LDSF || per2 > LDSF || I1 <= 0 || J1 <= 0 || I2 <= 0 || J2 <= 0 || J3 <= 0 || d3.Ktot() <= 0) {
+    if (threadIdx.x == 0) flag[b] = -1;
+    return;
+  }
+  if (threadIdx.x == 0) flag[b] = 0;
+  const int chunk = min(n1, min(LDSF / per1, LDSF / per2));
+  const int sC3 = mp3.chunkI == 0 ? d3.sCi[0] : mp3.chunkI == 1 ? d3.sCi[1] : d3.sCi[2];
+  if (d1.flopc && threadIdx.x == 0 && b % d1.flop_stride == 0) {
+    const unsigned long long i3 = (unsigned long long)(d3.Itot() / max(1, x_static)) * n1;
+    atomicAdd(d1.flopc, 2ull * d1.flop_stride * ((unsigned long long)I1 * J1 * d1.Ktot() + (unsigned long long)I2 * J2 * d2.Ktot() + i3 * J3 * d3.Ktot()));
+    if (d1.bytec)
+      atomicAdd(d1.bytec, 4ull * d1.flop_stride * ((unsigned long long)I1 * d1.Ktot() + (unsigned long long)d1.Ktot() * J1 +
+                                                    (unsigned long long)I2 * d2.Ktot() + (unsigned long long)d3.Ktot() * J3 + i3 * J3));
+  }
+  long baseA1 = (long)b * d1.wA, baseB1 = (long)b * d1.wB, baseA2 = (long)b * d2.wA, baseB3 = (long)(b / d3.bdivB) * d3.wB;
+  if (d1.selA) baseA1 += (long)d1.selA[(long)(b / d1.seldivA) * d1.selA_inc] * d1.selA_mul;
+  if (d1.selB) baseB1 += (long)d1.selB[(long)(b / d1.seldivB) * d1.selB_inc] * d1.selB_mul;
+  if (d2.selA) baseA2 += (long)d2.selA[(long)(b / d2.seldivA) * d2.selA_inc] * d2.selA_mul;
+  d1.accumulate = 0; d2.accumulate = 0;
+  const float in_scale = d1.scale_in ? d1.scale_in[b] : 1.f;
+  float *C3 = C3g + (long)b * d3.wC;
+  const int sA1 = d1.sAi[1];
+  for (int c0 = 0; c0 < n1; c0 += chunk) {
+    const int cn = min(chunk, n1 - c0);
+    d1.I[1] = cn;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {      // (no dynamic indexing: the descriptors stay in registers)
+      if (s == jsub) d2.J[s] = cn;
+      if (s == mp3.chunkI) { d3.I[s] = cn; d3.Imask[s] = 0x7fffffff; }
+    }
+    // compact layouts of the two intermediates over the live extents of this chunk
+    {
+      int st = 1;
+      for (int s = 2; s >= 0; --s) { lds1[3 + s] = st; st *= d1.J[s]; }
+      for (int s = 2; s >= 0; --s) { lds1[s] = st; st *= d1.I[s]; }
+      st = 1;
+      for (int s = 2; s >= 0; --s) { lds2[3 + s] = st; st *= d2.J[s]; }
+      for (int s = 2; s >= 0; --s) { lds2[s] = st; st *= d2.I[s]; }
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      d1.sCi[s] = lds1[s]; d1.sCj[s] = lds1[3 + s];
+      d2.sBk[s] = mp.mapK[s] >= 0 ? lds1[mp.mapK[s]] : 0;
+      d2.sBj[s] = mp.mapJ[s] >= 0 ? lds1[mp.mapJ[s]] : 0;
+      d2.sCi[s] = lds2[s]; d2.sCj[s] = lds2[3 + s];
+      d3.sAi[s] = mp3.mapI[s] >= 0 ? lds2[mp3.mapI[s]] : 0;
+      d3.sAk[s] = mp3.mapK[s] >= 0 ? lds2[mp3.mapK[s]] : 0;
+    }
+    if (c0) __syncthreads();     // stage 3 of the chunk before has read the second buffer
+    tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1 + (long)c0 * sA1, B1g + baseB1, s_mid1, d1.Itot(), J1, K2s1, offCi_s, 0, 4, in_scale);
+    __syncthreads();
+    tg_direct_body<AVEC2, false>(d2, A2g + baseA2, s_mid1, s_mid2, I2, d2.Jtot(), K2s2, offCi_s, 0, 4);
+    __syncthreads();
+    tg_direct_body<false, false>(d3, s_mid2, B3g + baseB3, C3 + (long)c0 * sC3, d3.Itot(), J3, K2s3, offCi_s, 0, 4);
+  }
+  // rows of the result beyond the live extent of the chunked sub-index: zeros (it is the slowest sub-index of C3 in use)
+  if (n1 < x_static) {
+    const long lo = (long)n1 * sC3, hi = (long)x_static * sC3;
+    for (long e = lo + threadIdx.x; e < hi; e += 256) C3[e] = 0.f;
+  }
+}
+
 // stage 2 of the chain must read exactly what stage 1 wrote: same live extents on the shared sub-indices (the caller
 // sets the same TgDyn on both), no masks on them.  Returns false when the static shapes rule the chain out.
 // Returns 0 when the static shapes rule the chain out, 1 when launched (entries may be declined: flag -1), 2 when launched and
 // no entry can be declined (every slice of the intermediate fits the buffer: the caller skips the fallback launches).
 inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemmDesc &d2_in, const TGemmChainMap &mp,
                               const float *A1, const float *B1, const float *A2, float *C2, int *flag, int allow_chunks = 0, int dense = 0);
+
+inline int tgemm_chain3_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemmDesc &d2_in, const TGemmDesc &d3_in, const TGemmChainMap &mp,
+                               const TGemmChain3Map &mp3, const float *A1, const float *B1, const float *A2, const float *B3, float *C3, int *flag,
+                               const int *skip = nullptr);
 
 bool tgemm_use_mfma();
 
@@ -1021,6 +1129,62 @@ inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemm
   const bool chunkable = allow_chunks && d1.I[0] == 1 && !d1.dynI && !d2.dynI && jsub >= 0 && jsub <= 2 &&
                          !(d1.dI[1].p && d1.dI[1].mask) && per <= ldsf;
   return (whole <= ldsf || chunkable) ? 2 : 1;
+}
+
+// Returns 0 when the static shapes rule the three-stage chain out (nothing launched), 2 when launched and no entry can be declined
+// (the caller needs no fallback); it never launches a chain that could decline an entry.
+inline int tgemm_chain3_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemmDesc &d2_in, const TGemmDesc &d3_in, const TGemmChainMap &mp,
+                               const TGemmChain3Map &mp3, const float *A1, const float *B1, const float *A2, const float *B3, float *C3, int *flag,
+                               const int *skip) {
+  if (!tgemm_use_mfma() || d1_in.dynK || d2_in.dynK || d3_in.dynK || d1_in.nbatch != d2_in.nbatch || d1_in.nbatch != d3_in.nbatch ||
+      d1_in.nbatch <= 0)
+    return 0;
+  if (d1_in.bdivA != 1 || d1_in.bdivB != 1 || d2_in.bdivA != 1 || d2_in.bdivC != 1 || d3_in.bdivA != 1 || d3_in.bdivC != 1) return 0;
+  if (d1_in.dynI || d2_in.dynI || d3_in.dynI || d3_in.accumulate || d3_in.scale_in || d3_in.scale_out || d3_in.selA || d3_in.selB) return 0;
+  TGemmDesc d1 = d1_in, d2 = d2_in, d3 = d3_in;
+  if (d1.Itot() >= (1 << 22) || d1.Jtot() >= (1 << 22) || d2.Itot() >= (1 << 22) || d2.Jtot() >= (1 << 22) || d3.Itot() >= (1 << 22) ||
+      d3.Jtot() >= (1 << 22))
+    return 0;
+  static const int lds3 = getenv("PEPSGPU_CHAIN3_LDS") ? atoi(getenv("PEPSGPU_CHAIN3_LDS")) : 4096;     // (measured: 8192 walkers of the headline state 15.9 k sweeps/s at 4096 floats x 2 / four blocks per CU, 15.0 k at 6656 / three, 15.7 k without the third stage)
+  const int ldsf = lds3 >= 6656 ? 6656 : 4096;
+  // the kernel's own test, on the static extents (live extents are never larger)
+  int jsub = -1;
+  for (int q = 0; q < 3; ++q) {
+    if (mp.mapJ[q] == 1) jsub = (jsub < 0 && !(d2.dJ[q].p && d2.dJ[q].mask)) ? q : 3;
+    if (mp.mapK[q] == 1) jsub = 3;
+  }
+  if (jsub < 0 || jsub > 2 || mp3.chunkI < 0 || mp3.chunkI > 2 || d1.I[0] != 1 || (d1.dI[1].p && d1.dI[1].mask)) return 0;
+  if (mp3.mapI[mp3.chunkI] != 3 + jsub) return 0;                              // the chunked sub-index of stage 3 is that J of stage 2
+  for (int q = 0; q < mp3.chunkI; ++q) if (d3.I[q] != 1) return 0;               // ... and the slowest I sub-index of C3 in use
+  const long per1 = (long)d1.I[2] * d1.Jtot(), per2 = (long)d2.Itot() * d2.Jtot() / (d2.J[jsub] > 0 ? d2.J[jsub] : 1);
+  if (per1 > ldsf || per2 > ldsf) return 0;
+  d1.flopc = tg_flop_counter; d1.bytec = tg_byte_counter;
+  d1.flop_stride = d1.nbatch >= 256 ? 64 : 1;
+  static const bool no_vec = getenv("PEPSGPU_TGEMM_NOVEC") != nullptr;
+  auto al4 = [](long v) { return (v & 3) == 0; };
+  const bool avec1 = !no_vec && d1.sAk[2] == 1 && al4(d1.K[2]) && al4(d1.sAi[0]) && al4(d1.sAi[1]) && al4(d1.sAi[2]) &&
+                     al4(d1.sAk[0]) && al4(d1.sAk[1]) && al4(d1.wA) && al4(d1.selA_mul) && (((uintptr_t)A1) & 15) == 0;
+  const bool bvec1 = !no_vec && d1.sBk[2] == 1 && al4(d1.K[2]) && al4(d1.sBj[0]) && al4(d1.sBj[1]) && al4(d1.sBj[2]) &&
+                     al4(d1.sBk[0]) && al4(d1.sBk[1]) && al4(d1.wB) && al4(d1.selB_mul) && (((uintptr_t)B1) & 15) == 0;
+  const bool avec2 = !no_vec && d2.sAk[2] == 1 && al4(d2.K[2]) && al4(d2.sAi[0]) && al4(d2.sAi[1]) && al4(d2.sAi[2]) &&
+                     al4(d2.sAk[0]) && al4(d2.sAk[1]) && al4(d2.wA) && al4(d2.selA_mul) && (((uintptr_t)A2) & 15) == 0;
+  const dim3 g(d1.nbatch), blk(256);
+#define PG_CHAIN3(a1, b1, a2)                                                                                                               \
+  do {                                                                                                                                      \
+    if (ldsf == 6656) hipLaunchKernelGGL((tgemm_chain3_kernel<a1, b1, a2, 6656, 3>), g, blk, 0, s, d1, d2, d3, mp, mp3, A1, B1, A2, B3, C3, flag, skip); \
+    else hipLaunchKernelGGL((tgemm_chain3_kernel<a1, b1, a2, 4096, 4>), g, blk, 0, s, d1, d2, d3, mp, mp3, A1, B1, A2, B3, C3, flag, skip);   \
+  } while (0)
+  if (avec1 && bvec1 && avec2) PG_CHAIN3(true, true, true);
+  else if (avec1 && bvec1) PG_CHAIN3(true, true, false);
+  else if (avec1 && avec2) PG_CHAIN3(true, false, true);
+  else if (avec1) PG_CHAIN3(true, false, false);
+  else if (bvec1 && avec2) PG_CHAIN3(false, true, true);
+  else if (bvec1) PG_CHAIN3(false, true, false);
+  else if (avec2) PG_CHAIN3(false, false, true);
+  else PG_CHAIN3(false, false, false);
+#undef PG_CHAIN3
+  PG_CHECK_HIP(hipGetLastError());
+  return 2;
 }
 
 }  // namespace pepsgpu

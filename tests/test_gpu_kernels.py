@@ -1,4 +1,6 @@
 """GPU unit tests of the HIP kernels through the C ABI diagnostics (tgemm / Cholesky / Jacobi)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -407,8 +409,22 @@ def test_jacobi_mid_route_kernel(shape, kernel):
             assert np.max(np.abs(Vb.T @ Vb - Pref.T @ Pref)) < 2e-3
 
 
+def _i8_image(X, axis):
+    """float64 image of the float32 array X the exact-integer Gram kernels work on (peps_amd/csrc/gram_i8.h): per block of 64
+    entries along `axis` (the contracted index) and per line, ONE power of two from the block maximum, entries rounded to integers
+    |n| <= 2^22 (round half to even)."""
+    X = np.moveaxis(np.asarray(X, dtype=np.float32), axis, -1)
+    out = np.zeros(X.shape, dtype=np.float64)
+    for k0 in range(0, X.shape[-1], 64):
+        blk = X[..., k0:k0 + 64]
+        m = np.max(np.abs(blk), axis=-1, keepdims=True).astype(np.float32)
+        e = np.maximum(30, (m.view(np.uint32) >> 23).astype(np.int64))
+        out[..., k0:k0 + 64] = np.ldexp(np.rint(np.ldexp(blk.astype(np.float64), 148 - e)), e - 148)
+    return np.moveaxis(out, -1, axis)
+
+
 @pytest.mark.parametrize("dt", ["f32", "f64"])
-@pytest.mark.parametrize("K,n", [(560, 128), (2048, 256), (37, 96), (5, 64), (301, 200), (64, 33), (1000, 72)])
+@pytest.mark.parametrize("K,n", [(560, 128), (2048, 256), (1500, 224), (333, 256), (37, 96), (5, 64), (301, 200), (64, 33), (1000, 72)])
 def test_streaming_gram_kernel(K, n, dt):
     """gram_cols_f64_kernel (wave-per-block streaming Gram of the forward pass): G = P^T P with f64 accumulation of exact
     f32 products, per-walker live row counts, every 64 x 64 block on or above the diagonal."""
@@ -419,20 +435,30 @@ def test_streaming_gram_kernel(K, n, dt):
     P = rng.standard_normal((nb, K, n)).astype(t) * np.logspace(0, -6, n)[None, None, :].astype(t)
     klive = np.array([K, max(1, K // 2), 1, max(1, K - 3), min(K, 7)], dtype=np.int32)
     G = capi.diag_gram_cols(capi.F32 if dt == "f32" else capi.F64, P, klive)
+    # round 4: f32 launches of dense shape (193..256 columns, >= 256 rows) run as exact integer arithmetic on the i8 matrix cores
+    # (gram_i8.h): the result is the float64 Gram of the fixed-point image of P (asserted to 1e-13), which is within f32 rounding of
+    # the Gram of P itself
+    i8 = dt == "f32" and 192 < n <= 256 and K >= 256 and os.environ.get("PEPSGPU_NO_I8_GRAM") is None
     for b in range(nb):
         Pb = P[b, :klive[b]].astype(np.float64)
-        ref = Pb.T @ Pb
+        exact = Pb.T @ Pb
+        Pi = _i8_image(P[b, :klive[b]], 0) if i8 else Pb
+        ref = Pi.T @ Pi
         for bi in range((n + 63) // 64):
             for bj in range(bi, (n + 63) // 64):
                 sl = (slice(64 * bi, min(n, 64 * bi + 64)), slice(64 * bj, min(n, 64 * bj + 64)))
-                scale = np.sqrt(np.outer(np.diag(ref)[sl[0]], np.diag(ref)[sl[1]])) + 1e-300
+                scale = np.sqrt(np.outer(np.diag(exact)[sl[0]], np.diag(exact)[sl[1]])) + 1e-300
                 err = np.abs(G[b][sl] - ref[sl]) / scale
+                err_exact = np.abs(G[b][sl] - exact[sl]) / scale
                 if bi == bj:      # a diagonal block holds its 16 x 16 tiles on or above the diagonal only (round 3)
                     ii, jj = np.indices(err.shape)
                     err = np.where(jj // 16 >= ii // 16, err, 0.0)
+                    err_exact = np.where(jj // 16 >= ii // 16, err_exact, 0.0)
                 assert np.max(err) < 1e-13 * max(1, klive[b]) ** 0.5 + 1e-15
+                assert np.max(err_exact) < 1.5e-6        # (two factors, each entry within 2^-23 of its column's block maximum)
     G0 = capi.diag_gram_cols(capi.F32 if dt == "f32" else capi.F64, P, None)
-    ref0 = P[0].astype(np.float64).T @ P[0].astype(np.float64)
+    P0 = _i8_image(P[0], 0) if i8 else P[0].astype(np.float64)
+    ref0 = P0.T @ P0
     assert np.max(np.abs(np.triu(G0[0]) - np.triu(ref0))[:64, :64]) < 1e-12 * np.max(np.abs(ref0))
 
 
@@ -446,15 +472,25 @@ def test_row_gram_kernel(n, K):
     M = (rng.standard_normal((nb, n, K)) * np.logspace(0, -6, n)[None, :, None]).astype(np.float32)
     nrows = np.array([n, max(1, n // 2), 1, max(1, n - 3)], dtype=np.int32)
     G = capi.diag_gram_rows(M, nrows)
+    i8 = 128 < n <= 256 and os.environ.get("PEPSGPU_NO_I8_GRAM") is None     # round 4: exact integer arithmetic (gram_i8.h, ROWS form)
     for b in range(nb):
         Mb = M[b, :nrows[b]].astype(np.float64)
-        ref = Mb @ Mb.T
+        exact = Mb @ Mb.T
+        Mi = _i8_image(M[b, :nrows[b]], 1) if i8 else Mb
+        ref = Mi @ Mi.T
         m = nrows[b]
         for bi in range((m + 63) // 64):
             for bj in range(bi, (m + 63) // 64):
                 sl = (slice(64 * bi, min(m, 64 * bi + 64)), slice(64 * bj, min(m, 64 * bj + 64)))
-                scale = np.sqrt(np.outer(np.diag(ref)[sl[0]], np.diag(ref)[sl[1]])) + 1e-300
-                assert np.max(np.abs(G[b][sl] - ref[sl]) / scale) < 1e-13 * K ** 0.5 + 1e-15, (b, bi, bj)
+                scale = np.sqrt(np.outer(np.diag(exact)[sl[0]], np.diag(exact)[sl[1]])) + 1e-300
+                err = np.abs(G[b][sl] - ref[sl]) / scale
+                err_exact = np.abs(G[b][sl] - exact[sl]) / scale
+                if bi == bj and i8:      # (the Cholesky reads the upper triangle: the integer kernel stores the 16 x 16 tiles on or above the diagonal)
+                    ii, jj = np.indices(err.shape)
+                    err = np.where(jj // 16 >= ii // 16, err, 0.0)
+                    err_exact = np.where(jj // 16 >= ii // 16, err_exact, 0.0)
+                assert np.max(err) < 1e-13 * K ** 0.5 + 1e-15, (b, bi, bj)
+                assert np.max(err_exact) < 1.5e-6, (b, bi, bj)
 
 
 @pytest.mark.parametrize("n,rank", [(256, 256), (256, 97), (241, 180), (160, 33), (128, 128), (100, 7), (48, 48)])
