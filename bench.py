@@ -33,7 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}     # /opt/skills/guides/MI355X_MICROARCH.md, dense MFMA peaks
+PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6, "i8": 5000.0}     # /opt/skills/guides/MI355X_MICROARCH.md, dense MFMA peaks (i8: 2 x the bf16 rate)
+I8_PRODUCTS = 9      # byte products per float64-grade product of the exact-integer Gram kernels (peps_amd/csrc/gram_i8.h)
 PEAK_HBM_GBPS = 8000.0                        # same guide: HBM3E, ~8 TB/s
 REAL_STATE = os.path.join(ROOT, "tests", "golden", "ref_fixtures", "tps_square_heisenberg4x4D8Double")
 
@@ -299,7 +300,8 @@ class Leg:
 # device-counted flops and bytes: the candidates of the roofline object.  The other categories (Gram-free factor, Jacobi,
 # select ...) are VALU / latency bound and listed with their share of the step in `kernel_ms`.
 ROOF_CATS = {"contract_chain": ("tgemm_chain_kernel", "f32"), "contract": ("tgemm_direct_kernel", "f32"),
-             "gram_f64": ("gram_cols_lds_kernel (193..256 columns) / gram_cols_f64_kernel", "f64"), "trunc_gram": ("gram_rows_f64_kernel + chol_upper_kernel / mid_gram_chol_kernel", "f64"),
+             "gram_f64": ("gram_cols_i8_kernel (193..256 columns: exact integer Gram, 9 i8 products) / gram_cols_f64_kernel", "i8x9"),
+             "trunc_gram": ("gram_cols_i8_kernel<ROWS> + chol_upper_kernel / mid_gram_chol_kernel", "i8x9"),
              "trunc_apply": ("tgemm_kernel<f32,f32,f32,f64>", "f64"), "env": ("tgemm_kernel (BTen / trace)", "f32")}
 
 
@@ -352,10 +354,13 @@ def roofline_of(prof, dtype, steps, leg_tag=None, nw=None):
     launches = max(prof[dom]["launches"], 1)
     total_ms = sum(v["ms"] for v in prof.values())
     counted = prof[dom]["exec_flops"] if prof[dom]["exec_flops"] > 0 else prof[dom]["alg_flops"]
-    tflops = counted / dsec / 1e12
+    # exact-integer Gram: the device counts the float64-grade flops of the Gram; the matrix cores execute nine i8 products for each
+    i8 = kdt == "i8x9" and os.environ.get("PEPSGPU_NO_I8_GRAM") is None
+    f64_equiv = counted / dsec / 1e12
+    tflops = f64_equiv * (I8_PRODUCTS if i8 else 1)
     dbytes = prof[dom].get("bytes", 0.0)
     intensity = counted / dbytes if dbytes > 0 else float("inf")
-    kpeak = PEAK_TFLOPS["f64"] if kdt == "f64" else PEAK_TFLOPS[dtype]
+    kpeak = PEAK_TFLOPS["i8"] if i8 else PEAK_TFLOPS["f64"] if kdt in ("f64", "i8x9") else PEAK_TFLOPS[dtype]
     balance = kpeak * 1e12 / (PEAK_HBM_GBPS * 1e9)
     hbm_bound = intensity < balance
     alg_gbps = dbytes / dsec / 1e9
@@ -391,6 +396,10 @@ def roofline_of(prof, dtype, steps, leg_tag=None, nw=None):
         "mfma_tflops": tflops,
         "mfma_frac": tflops / kpeak,
     }
+    if i8:
+        roof["mfma_dtype"] = "i8 (v_mfma_i32_16x16x64_i8, %d byte products per float64-grade product)" % I8_PRODUCTS
+        roof["float64_equivalent_tflops"] = f64_equiv
+        roof["float64_mfma_peak_it_replaces"] = PEAK_TFLOPS["f64"]
     if valu_roof is not None:
         valu_roof["largest_priced_kernel"] = roof
         return vdom, valu_roof
@@ -407,6 +416,10 @@ def mfma_summary(prof, dtype, step_seconds_total):
             pk = PEAK_TFLOPS["f64"] if k in ("gram_f64", "cholesky", "trunc_gram", "trunc_apply") else PEAK_TFLOPS[dtype]
             tf = prof[k]["exec_flops"] / (prof[k]["ms"] * 1e-3) / 1e12 if prof[k]["ms"] > 0 else 0.0
             cats[k] = {"ms": round(prof[k]["ms"], 3), "tflops": tf, "peak": pk, "frac": tf / pk}
+            if k in ("gram_f64", "trunc_gram") and os.environ.get("PEPSGPU_NO_I8_GRAM") is None:
+                # (float64-grade flops counted on the device; the dense walkers run them as 9 i8 products each, gram_i8.h: the
+                # fraction is of the float64 matrix peak the integer kernel replaces and may exceed 1)
+                cats[k]["note"] = "float64-equivalent flops; dense launches execute on the i8 matrix cores"
             tot_fl += prof[k]["exec_flops"]
             tot_ms += prof[k]["ms"]
     return {"categories": cats,

@@ -455,6 +455,9 @@ class Engine : public EngineBase {
                            lv(b2, bs - 1), lv(b2, bs));
     bten_[pos].push_back(nb);
   }
+  // GrowBTenStep for the slice sweep (engine_sweep.h): walkers with take[w] != 0 adopt `half` (the un-normalised step tensor the
+  // replacement trace already computed with their NEW state of the site), the step runs for the others only; consumes `half`
+  void grow_bten_step_reuse(int pos, BTenDev &half, const int *take);
   void shift_bten_window(int pos) override {   // grow.h:517-521
     PG_REQUIRE(bten_size(pos) > 0, 3, "ShiftBTenWindow: BTen empty");
     clear_bten(pos, bten_size(pos) - 1);
@@ -489,7 +492,10 @@ class Engine : public EngineBase {
   // ReplaceNNSiteTrace with everything left on the device: candidate table dcand [walker][nc][2] (nullptr: the configurations),
   // result res [walker x nc] (mantissa) and lsum [walker] (log-scale): psi' = res exp(lsum).  Caller frees both.
   // skip (optional, per walker, nc == 1): nonzero = the result of this walker is not needed (its entry of res is undefined)
-  Acc *nn_trace_device(int row, int col, int dir, int nc, const int *dcand, double **lsum_out, const int *skip = nullptr) {
+  // keep_t2 (optional): receives the half-step tensor of the FIRST site (LEFT / UP environment grown over it with the candidate
+  // state, not normalised) instead of freeing it -- the caller frees it (free_ten) or hands it to grow_bten_step_reuse
+  Acc *nn_trace_device(int row, int col, int dir, int nc, const int *dcand, double **lsum_out, const int *skip = nullptr,
+                       BTenDev *keep_t2 = nullptr) {
     int rb = row + (dir == VERTICAL), cb = col + (dir == HORIZONTAL);
     PG_REQUIRE(row >= 0 && col >= 0 && rb < Ly_ && cb < Lx_, 1, "ReplaceNNSiteTrace: bond outside the lattice");
     SiteSel sa = cfg_site(row, col), sb = cfg_site(rb, cb);
@@ -519,7 +525,8 @@ class Engine : public EngineBase {
       add_logs(lsum, lf.logscale, rt.logscale, bten_[UP][row].logscale, bten_at_slice(DOWN, rb).logscale);
     }
     Acc *res = finish_dot_device(t2.t, nc, t5.t, nc, nc);
-    free_ten(t2.t); free_ten(t5.t);
+    if (keep_t2) *keep_t2 = t2; else free_ten(t2.t);
+    free_ten(t5.t);
     *lsum_out = lsum;
     return res;
   }

@@ -39,9 +39,10 @@ template <typename AccT>
 __global__ void sweep_metropolis_exchange_kernel(int *__restrict__ cfg, int sites, int s1, int s2, const AccT *__restrict__ res,
                                                  const double *__restrict__ lsum, double *__restrict__ amp,
                                                  const double *__restrict__ uni, int nu, int *__restrict__ uptr,
-                                                 int *__restrict__ acc, int *__restrict__ overrun, int n) {
+                                                 int *__restrict__ acc, int *__restrict__ overrun, int *__restrict__ acc_now, int n) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n) return;
+  acc_now[w] = 0;                                         // (1: this bond's exchange was accepted)
   const int c1 = cfg[(long)w * sites + s1], c2 = cfg[(long)w * sites + s2];
   if (c1 == c2) return;                                   // :149-151
   const double psi_b = (double)res[w] * exp(lsum[w]);
@@ -60,7 +61,16 @@ __global__ void sweep_metropolis_exchange_kernel(int *__restrict__ cfg, int site
     cfg[(long)w * sites + s2] = c1;
     amp[w] = psi_b;
     acc[w] += 1;
+    acc_now[w] = 1;
   }
+}
+
+// dst[w] = src[w] for the walkers with take[w] != 0 (len elements per walker)
+template <typename T>
+__global__ void sweep_take_kernel(T *__restrict__ dst, const T *__restrict__ src, long len, const int *__restrict__ take) {
+  const int w = blockIdx.y;
+  if (!take[w]) return;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += (long)gridDim.x * blockDim.x) dst[(long)w * len + e] = src[(long)w * len + e];
 }
 
 __global__ void sweep_gather_slice_kernel(const int *__restrict__ cfg, int sites, int first, int stride, int len, int *__restrict__ out, int n) {
@@ -145,6 +155,37 @@ void Engine<T>::nn_exchange_slice(int orient, int slice, int punch_holes, double
 }
 
 template <typename T>
+void Engine<T>::grow_bten_step_reuse(int pos, BTenDev &half, const int *take) {
+  require_ready();
+  int pre = (pos + 3) % 4, nxt = (pos + 1) % 4;
+  int bs = bten_size(pos);
+  PG_REQUIRE(bs > 0, 3, "GrowBTenStep: BTen not initialised");
+  int n, r, c;
+  switch (pos) {
+    case DOWN: c = bmps_size(LEFT) - 1; n = Ly_; r = n - bs; break;
+    case UP: c = bmps_size(LEFT) - 1; n = Ly_; r = bs - 1; break;
+    case LEFT: r = bmps_size(UP) - 1; n = Lx_; c = bs - 1; break;
+    default: r = bmps_size(UP) - 1; n = Lx_; c = n - bs; break;
+  }
+  PG_REQUIRE(bs <= n && !bmps_[pre].empty() && !bmps_[nxt].empty(), 3, "GrowBTenStep: environment missing");
+  SiteSel sel = cfg_site(r, c);
+  const BMPSDev &b1 = bmps_[pre].back(), &b2 = bmps_[nxt].back();
+  auto lv = [](const BMPSDev &b, int j) -> const int * { return (int)b.live.size() > j ? b.live[j] : nullptr; };
+  const BTenDev &bt = bten_[pos].back();
+  BTenDev nb = bten_step(pos, bt, b1.t[n - bs], sel, b2.t[bs - 1], 1, false, 1, lv(b1, n - bs), lv(b1, n - bs + 1), lv(b2, bs - 1),
+                         lv(b2, bs), take);
+  PG_REQUIRE(nb.t.n == half.t.n, 3, "GrowBTenStep: the kept half step has another shape");
+  hipLaunchKernelGGL(sweep_take_kernel<T>, dim3((unsigned)std::min<long>(8, (nb.t.n + 255) / 256), nw_), dim3(256), 0, stream_, nb.t.p,
+                     (const T *)half.t.p, (long)nb.t.n, take);
+  PG_CHECK_HIP(hipGetLastError());
+  free_ten(half.t);
+  nb.logscale = (double *)arena_.alloc(sizeof(double) * nw_);
+  PG_CHECK_HIP(hipMemcpyAsync(nb.logscale, bt.logscale, sizeof(double) * nw_, hipMemcpyDeviceToDevice, stream_));
+  normalize(nb.t.p, nb.t.n, nb.t.n, nw_, nb.logscale);
+  bten_[pos].push_back(nb);
+}
+
+template <typename T>
 void Engine<T>::sweep_slice_exchange(int orient, int slice, int n_uniform, const double *uniforms, double *amp_inout,
                                      int32_t *consumed_out, int32_t *accepted_out, int32_t *slice_states_out) {
   require_ready();
@@ -161,8 +202,8 @@ void Engine<T>::sweep_slice_exchange(int orient, int slice, int n_uniform, const
     double *duni = (double *)arena_.alloc(sizeof(double) * (size_t)nw_ * n_uniform);
     int *dptr = (int *)arena_.alloc(sizeof(int) * (2 * (size_t)nw_ + 1));
     int *dacc = dptr + nw_, *dover = dptr + 2 * nw_;
-    int *dcand = (int *)arena_.alloc(sizeof(int) * 3 * (size_t)nw_);
-    int *dsame = dcand + 2 * (size_t)nw_;
+    int *dcand = (int *)arena_.alloc(sizeof(int) * 4 * (size_t)nw_);
+    int *dsame = dcand + 2 * (size_t)nw_, *dnow = dcand + 3 * (size_t)nw_;
     int *dslice = (int *)arena_.alloc(sizeof(int) * (size_t)nw_ * N);
     auto release = [&]() { arena_.free(damp); arena_.free(duni); arena_.free(dptr); arena_.free(dcand); arena_.free(dslice); };
     try {
@@ -180,15 +221,25 @@ void Engine<T>::sweep_slice_exchange(int orient, int slice, int n_uniform, const
         hipLaunchKernelGGL(sweep_swap_cand_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)cfg_, sites, s1, s2, dcand, dsame, nw_);
         PG_CHECK_HIP(hipGetLastError());
         double *lsum = nullptr;
-        Acc *res = nn_trace_device(r1, c1, orient, 1, dcand, &lsum, dsame);
+        // the left half of the replacement trace IS the next environment tensor of the walkers that accept the exchange (the same
+        // kernel on the same operands): it is kept, and the growth step behind the Metropolis test runs for the others only
+        static const bool no_reuse = getenv("PEPSGPU_NO_SWEEP_REUSE") != nullptr;
+        const bool reuse = j + 2 < N && !no_reuse;
+        BTenDev half;
+        Acc *res = nn_trace_device(r1, c1, orient, 1, dcand, &lsum, dsame, reuse ? &half : nullptr);
         hipLaunchKernelGGL(sweep_metropolis_exchange_kernel<Acc>, dim3(gb), dim3(256), 0, stream_, cfg_, sites, s1, s2, (const Acc *)res,
-                           (const double *)lsum, damp, (const double *)duni, n_uniform, dptr, dacc, dover, nw_);
+                           (const double *)lsum, damp, (const double *)duni, n_uniform, dptr, dacc, dover, dnow, nw_);
         PG_CHECK_HIP(hipGetLastError());
         arena_.free(res);
         arena_.free(lsum);
         erase_envs_after_update(r1, c1);
         erase_envs_after_update(r2, c2);
-        if (j + 2 < N) shift_bten_window(hi);
+        if (reuse) {
+          clear_bten(hi, bten_size(hi) - 1);
+          grow_bten_step_reuse(lo, half, dnow);
+        } else if (j + 2 < N) {
+          shift_bten_window(hi);
+        }
       }
       hipLaunchKernelGGL(sweep_gather_slice_kernel, dim3((nw_ * N + 255) / 256), dim3(256), 0, stream_, (const int *)cfg_, sites,
                          orient == HORIZONTAL ? slice * Lx_ : slice, orient == HORIZONTAL ? 1 : Lx_, N, dslice, nw_);

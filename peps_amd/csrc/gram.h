@@ -260,8 +260,9 @@ inline void launch_gram_cols_f64(hipStream_t s, int nbatch, const T *P, long wP,
       static const bool no_i8_gram = getenv("PEPSGPU_NO_I8_GRAM") != nullptr;
       if (!no_i8_gram) {
         const size_t smem8 = gram_cols_i8_smem_bytes();
-        allow_dynamic_lds(reinterpret_cast<const void *>(&gram_cols_i8_kernel<T>), smem8);
-        hipLaunchKernelGGL(gram_cols_i8_kernel<T>, dim3(nbatch), dim3(512), smem8, s, P, wP, n, ld, kdyn, kdyn_mul, kmax, G, (long)n * n, n,
+        // twelve waves (three per SIMD, 12 / 11 tiles each): 1.61 ms against 1.85 ms with eight on 2048 walkers x 1536 rows
+        allow_dynamic_lds(reinterpret_cast<const void *>(&gram_cols_i8_kernel<T, false, 0, 12>), smem8);
+        hipLaunchKernelGGL((gram_cols_i8_kernel<T, false, 0, 12>), dim3(nbatch), dim3(768), smem8, s, P, wP, n, ld, kdyn, kdyn_mul, kmax, G, (long)n * n, n,
                            run_flag, inner > 0 ? inner : 1, inner_live, (const int *)nullptr, flopc, bytec, nbatch >= 256 ? 64 : 1);
         PG_CHECK_HIP(hipGetLastError());
         return;

@@ -18,15 +18,16 @@
 // the float64 accumulator of the tile scaled by the two column exponents of the block: the result is the float64 Gram of the
 // fixed-point image of P, every integer step exact.
 //
-// Shape of the work: one workgroup (8 waves) per walker; the 136 upper 16 x 16 tiles dealt seventeen per wave (GlTile of gram.h),
-// their float64 accumulators in registers for the whole walker (136 VGPRs; the per-tile transients of the 16 x 16 x 64 form are 44).
+// Shape of the work: one workgroup per walker (8 or 12 waves: template parameter NW); the 136 upper 16 x 16 tiles dealt in runs of
+// 17 (or 12 / 11) per wave, their float64 accumulators in registers for the whole walker (136 or 96 VGPRs; the per-tile transients
+// of the 16 x 16 x 64 form are 44).
 // Per 64-row block: the rows arrive in LDS by LDS-DMA (global_load_lds_dwordx4: one row of 256 floats per wave-instruction, no
 // staging registers, in flight during the MFMAs of the block before); thread (column j, half h) then reads rows 32 h .. 32 h + 31 of
 // its column, the column maximum goes through LDS, and the digits are laid down as three byte planes D[plane][column][k]
 // (k contiguous: a lane's MFMA operand is one ds_read_b128; any bijection of the 64 k onto (lane group, byte) serves, the A and the
 // B operand use the same one).
 #pragma once
-#include "common.h"      // (included from the middle of gram.h: GlTile above, the launcher below)
+#include "common.h"      // (included from the middle of gram.h: the launchers follow it there)
 
 namespace pepsgpu {
 
@@ -43,8 +44,20 @@ inline size_t gram_cols_i8_smem_bytes() { return GI_BUF + GI_RAW + 256 * sizeof(
 // n = nrows[b] live rows, the contracted index runs along the rows) -- the same kernel with the roles of the two indices of the
 // operand exchanged: "column" j of the text above is row j of M, a block is 64 consecutive k of every row.
 // DBG: timing-only variants of scripts/gram_i8_bench.hip (1 no drain, 2 no digit pass after block 0, 4 no MFMA).
-template <typename T, bool ROWS = false, int DBG = 0>
-__global__ __launch_bounds__(512, 2) void gram_cols_i8_kernel(const T *__restrict__ Pg, long wP, int n, int ld,
+// NW: waves of the workgroup (8: seventeen tiles per wave, two waves per SIMD; 12: twelve / eleven tiles per wave, three waves per
+// SIMD -- fewer accumulators per wave, one more wave per SIMD to fill the LDS / MFMA latencies of the tile loop; the digit pass is
+// done by the first eight waves either way).
+template <int NW, int W> struct GiTile {       // tile t of wave W: the upper triangle of the 16 x 16 tile grid, rows first, dealt in runs
+  static constexpr int per = 136 / NW, extra = 136 % NW;
+  static constexpr int count = per + (W < extra ? 1 : 0);
+  static constexpr int first = W * per + (W < extra ? W : extra);
+  static constexpr int start(int x) { return 16 * x - x * (x - 1) / 2; }
+  static constexpr int x(int t) { int r = 0; while (r < 15 && start(r + 1) <= first + t) ++r; return r; }
+  static constexpr int c(int t) { return x(t) + (first + t - start(x(t))); }
+};
+
+template <typename T, bool ROWS = false, int DBG = 0, int NW = 8>
+__global__ __launch_bounds__(64 * NW, NW == 12 ? 3 : 2) void gram_cols_i8_kernel(const T *__restrict__ Pg, long wP, int n, int ld,
                                                               const int *__restrict__ kdyn, int kdyn_mul, int kmax,
                                                               double *__restrict__ Gg, long wG, int ldg,
                                                               const int *__restrict__ run_flag, int inner,
@@ -75,14 +88,16 @@ __global__ __launch_bounds__(512, 2) void gram_cols_i8_kernel(const T *__restric
   double *G = Gg + (long)b * wG;
   const int ilive = inner_live ? min(inner, inner_live[b]) : inner;
   const int c16 = lane & 15, g4 = lane >> 4;
-  const int j = tid & 255, kh = wave >> 2;
-  const bool col_ok = j < n && (ROWS || (j % inner) < ilive);          // dead / absent column: never written in P
+  const int j = tid & 255, kh = (wave >> 2) & 1;
+  const bool layer = NW == 8 || wave < 8;          // (the digit pass: 512 threads)
+  const bool col_ok = layer && j < n && (ROWS || (j % inner) < ilive);          // dead / absent column: never written in P
   const int nb = (K + GI_KB - 1) / GI_KB;
   // cols: rows 8 wave .. 8 wave + 7 of block blk, lane l fetches floats 4 l .. 4 l + 3 of the row (rows beyond K / columns beyond n: a
   // clamped address, masked when the image is read).  rows: the image is [row of M][64 k]; lane l of instruction q fetches for row
   // 32 wave + 4 q + l / 16 the k-chunk (l % 16) ^ (row % 16) -- the image of a row is a permutation of its sixteen 16-byte chunks, so that
   // the sixteen lanes of a ds_read_b128 phase (consecutive rows, same k) hit sixteen different bank groups.
   auto issue = [&](int blk) __attribute__((always_inline)) {
+    if (NW > 8 && wave >= 8) return;
     if constexpr (ROWS) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -114,11 +129,11 @@ __global__ __launch_bounds__(512, 2) void gram_cols_i8_kernel(const T *__restric
     float m = 0.f;
 #pragma unroll
     for (int q = 0; q < 32; ++q) m = fmaxf(m, q < qlive ? fabsf(at(q)) : 0.f);
-    pmax[256 * kh + j] = m;
+    if (layer) pmax[256 * kh + j] = m;
     __syncthreads();
     m = fmaxf(pmax[j], pmax[256 + j]);
     const int e = max(30, (int)(__float_as_uint(m) >> 23));   // biased exponent of the block maximum (|x| < 2^(e - 126))
-    if (kh == 0) exps[j] = e - 148;                           // x = n 2^(e - 148), |n| <= 2^22
+    if (kh == 0 && layer) exps[j] = e - 148;                           // x = n 2^(e - 148), |n| <= 2^22
     const float sc = __uint_as_float((unsigned)(275 - e) << 23);
     unsigned char *dst = dig + j * GI_PITCH + 32 * kh;
 #pragma unroll
@@ -141,17 +156,21 @@ __global__ __launch_bounds__(512, 2) void gram_cols_i8_kernel(const T *__restric
         pl[1][q4] = __builtin_amdgcn_perm(t23l, t01l, 0x07060302u);
         pl[0][q4] = __builtin_amdgcn_perm(t23h, t01h, 0x05040100u);
       }
+      if (layer) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
-        *reinterpret_cast<uint4 *>(dst + p * GI_PLANE + 16 * hh) = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
+        for (int p = 0; p < 3; ++p)
+          *reinterpret_cast<uint4 *>(dst + p * GI_PLANE + 16 * hh) = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
+      }
     }
     __syncthreads();
   };
   auto run = [&](auto wc) __attribute__((always_inline)) {
     constexpr int W = decltype(wc)::value;
-    double acc[17][4];
+    using Tl = GiTile<NW, W>;
+    constexpr int NT = Tl::count;
+    double acc[NT][4];
 #pragma unroll
-    for (int t = 0; t < 17; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[t][r] = 0.0;
     if (nb > 0) {
@@ -163,8 +182,6 @@ __global__ __launch_bounds__(512, 2) void gram_cols_i8_kernel(const T *__restric
       if (blk + 1 < nb) issue(blk + 1);   // in flight during the MFMAs of this block
       const unsigned char *src = dig + c16 * GI_PITCH + 16 * g4;
       const int *ex = exps;
-      // operands of tile t + 1 (three byte planes of its column block, the exponent of its column) are requested before the MFMAs of tile t: their LDS latency runs behind the 9 MFMAs and the
-      // conversion of tile t instead of in front of every tile
       gi_i32x4 a[3], bq[3], ei;
       int ejb;
       auto fetch_b = [&](int c, gi_i32x4(&q)[3], int &e) __attribute__((always_inline)) {
@@ -177,12 +194,12 @@ __global__ __launch_bounds__(512, 2) void gram_cols_i8_kernel(const T *__restric
         for (int p = 0; p < 3; ++p) q[p] = *reinterpret_cast<const gi_i32x4 *>(src + p * GI_PLANE + 16 * x * GI_PITCH);
         e = *reinterpret_cast<const gi_i32x4 *>(ex + 16 * x + 4 * g4);
       };
-      fetch_a(GlTile<W>::x(0), a, ei);
-      fetch_b(GlTile<W>::c(0), bq, ejb);
+      fetch_a(Tl::x(0), a, ei);
+      fetch_b(Tl::c(0), bq, ejb);
 #pragma unroll
-      for (int t = 0; t < 17; ++t) {
-        const int c = GlTile<W>::c(t);
-        const bool new_row = t + 1 < 17 && GlTile<W>::x(t + 1 < 17 ? t + 1 : t) != GlTile<W>::x(t);
+      for (int t = 0; t < NT; ++t) {
+        const int c = Tl::c(t);
+        const bool new_row = t + 1 < NT && Tl::x(t + 1 < NT ? t + 1 : t) != Tl::x(t);
         if (t > 0) fetch_b(c, bq, ejb);
         // (wave-uniform) tile beyond the columns of this launch.  The branch also keeps the tiles apart: as one basic block (n == 256 as
         // a template parameter) the seventeen tiles are scheduled over each other and spill 1.6 KB per lane.
@@ -216,18 +233,18 @@ __global__ __launch_bounds__(512, 2) void gram_cols_i8_kernel(const T *__restric
             }
           }
         }
-        if (t + 1 < 17) {
-          if (new_row) fetch_a(GlTile<W>::x(t + 1 < 17 ? t + 1 : t), a, ei);      // (two or three times per block: not prefetched)
+        if (t + 1 < NT) {
+          if (new_row) fetch_a(Tl::x(t + 1 < NT ? t + 1 : t), a, ei);      // (two or three times per block: not prefetched)
         }
       }
       __syncthreads();                    // every wave is done with the digits of this block; the next rows have landed
       if (blk + 1 < nb && !(DBG & 2)) lay(blk + 1);
     }
 #pragma unroll
-    for (int t = 0; t < 17; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = 16 * GlTile<W>::x(t) + 4 * g4 + r, jj = 16 * GlTile<W>::c(t) + c16;
+        const int i = 16 * Tl::x(t) + 4 * g4 + r, jj = 16 * Tl::c(t) + c16;
         if (i < n && jj < n) G[(long)i * ldg + jj] = acc[t][r];
       }
   };
@@ -239,7 +256,11 @@ __global__ __launch_bounds__(512, 2) void gram_cols_i8_kernel(const T *__restric
     case 4: run(std::integral_constant<int, 4>{}); break;
     case 5: run(std::integral_constant<int, 5>{}); break;
     case 6: run(std::integral_constant<int, 6>{}); break;
-    default: run(std::integral_constant<int, 7>{}); break;
+    case 7: run(std::integral_constant<int, 7>{}); break;
+    case 8: run(std::integral_constant<int, (NW > 8 ? 8 : 0)>{}); break;
+    case 9: run(std::integral_constant<int, (NW > 8 ? 9 : 0)>{}); break;
+    case 10: run(std::integral_constant<int, (NW > 8 ? 10 : 0)>{}); break;
+    default: run(std::integral_constant<int, (NW > 8 ? 11 : 0)>{}); break;
   }
 }
 

@@ -282,7 +282,7 @@ inline size_t chol_blocked_smem_bytes(int n) {
   return sizeof(double) * ((size_t)CH_NB * n + n) + sizeof(short) * 2 * (size_t)n + 64;
 }
 
-template <typename T, int MINB = 3>
+template <typename T, int MINB = 3, int PFD = 3>      // PFD: k-steps of the update in flight (loads from L2 ahead of the MFMAs)
 __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restrict__ Gg, long wG, int n,
                                                            T *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
                                                            int only_flagged = 0, int ld = 0,
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
           if (q < nq) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(am, b[q], acc[q], 0, 0, 0);
       };
       if (nq > 0 && nprev > 0) {
-        constexpr int PF = 3;
+        constexpr int PF = PFD;
         double av[PF], bv[PF][4];
         const int nks = (nprev + 3) >> 2;
 #pragma unroll
@@ -550,9 +550,20 @@ inline void launch_chol_upper(hipStream_t s, int nbatch, double *G, long wG, int
       hipLaunchKernelGGL((chol_blocked_kernel<T, 4>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
                          ndyn_mul, run_flag);
     } else {
-      allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3>), smem);
-      hipLaunchKernelGGL((chol_blocked_kernel<T, 3>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
-                         ndyn_mul, run_flag);
+      static const int pfd = getenv("PEPSGPU_CHB_PF") ? atoi(getenv("PEPSGPU_CHB_PF")) : 3;
+      if (pfd >= 8) {
+        allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3, 8>), smem);
+        hipLaunchKernelGGL((chol_blocked_kernel<T, 3, 8>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
+                           ndyn_mul, run_flag);
+      } else if (pfd >= 5) {
+        allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3, 5>), smem);
+        hipLaunchKernelGGL((chol_blocked_kernel<T, 3, 5>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
+                           ndyn_mul, run_flag);
+      } else {
+        allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3>), smem);
+        hipLaunchKernelGGL((chol_blocked_kernel<T, 3>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
+                           ndyn_mul, run_flag);
+      }
     }
   } else {
     const size_t smem = chol_smem_bytes(n);

@@ -1,5 +1,6 @@
 #!/bin/bash
 # the driver's sequence: the whole GPU suite, smoke, the default bench line
+cd /root/repo
 mkdir -p gpurun_out/r04
 python -m pytest tests -m gpu -x -q > gpurun_out/r04/full_suite.log 2>&1
 echo "pytest rc $?" >> gpurun_out/r04/full_suite.log

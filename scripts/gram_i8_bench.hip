@@ -72,7 +72,7 @@ int main(int argc, char **argv) {
       }
   }
   std::vector<double> Gh((size_t)2 * n * n);
-  for (int variant = 0; variant < 6; ++variant) {
+  for (int variant = 0; variant < 7; ++variant) {
     float ms = 0;
     for (int rep = -1; rep < reps; ++rep) {
       CK(hipMemset(G, 0xff, sizeof(double) * n * n * 2));
@@ -87,7 +87,12 @@ int main(int argc, char **argv) {
 #define GI_LAUNCH(D) do { allow_dynamic_lds(reinterpret_cast<const void *>(&gram_cols_i8_kernel<float, false, D>), smem); \
         hipLaunchKernelGGL((gram_cols_i8_kernel<float, false, D>), dim3(nw), dim3(512), smem, 0, P, wP, n, ld, kdev, 1, rows, G, (long)n * n, n, nullptr, inner, \
                            ildev, nullptr, nullptr, nullptr, 1); } while (0)
-        if (variant == 1) GI_LAUNCH(0); else if (variant == 2) GI_LAUNCH(1); else if (variant == 3) GI_LAUNCH(2); else if (variant == 4) GI_LAUNCH(4); else GI_LAUNCH(7);
+        if (variant == 1) GI_LAUNCH(0); else if (variant == 2) GI_LAUNCH(1); else if (variant == 3) GI_LAUNCH(2); else if (variant == 4) GI_LAUNCH(4); else if (variant == 5) GI_LAUNCH(7);
+        else {
+          allow_dynamic_lds(reinterpret_cast<const void *>(&gram_cols_i8_kernel<float, false, 0, 12>), smem);
+          hipLaunchKernelGGL((gram_cols_i8_kernel<float, false, 0, 12>), dim3(nw), dim3(768), smem, 0, P, wP, n, ld, kdev, 1, rows, G, (long)n * n, n, nullptr, inner,
+                             ildev, nullptr, nullptr, nullptr, 1);
+        }
       }
       CK(hipGetLastError());
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
@@ -110,7 +115,7 @@ int main(int argc, char **argv) {
     double flop = 0;
     for (int b = 0; b < nw; ++b) flop += 2.0 * kd[b] * n * (n + 1) / 2;
     printf("{\"kernel\": \"%s\", \"walkers\": %d, \"rows\": %d, \"n\": %d, \"ms\": %.4f, \"tflops_upper_triangle\": %.2f, \"err_exact\": %.3e, \"err_image\": %.3e}\n",
-           variant == 0 ? "gram_cols_lds_kernel (f64 MFMA)" : variant == 1 ? "gram_cols_i8_kernel (9 x i8 MFMA, exact)" : variant == 2 ? "timing only: no drain" : variant == 3 ? "timing only: no digit pass" : variant == 4 ? "timing only: no MFMA" : "timing only: loads + barriers", nw, rows, n, ms, flop / ms * 1e-9, eex, eim);
+           variant == 0 ? "gram_cols_lds_kernel (f64 MFMA)" : variant == 1 ? "gram_cols_i8_kernel (9 x i8 MFMA, exact)" : variant == 2 ? "timing only: no drain" : variant == 3 ? "timing only: no digit pass" : variant == 4 ? "timing only: no MFMA" : variant == 5 ? "timing only: loads + barriers" : "gram_cols_i8_kernel, 12 waves (three per SIMD)", nw, rows, n, ms, flop / ms * 1e-9, eex, eim);
     fflush(stdout);
   }
   // ---- row Gram (the truncation input): M = nr x 256, G = M M^T, nr live rows per walker ----
@@ -135,7 +140,7 @@ int main(int argc, char **argv) {
           for (int k = 0; k < Kr; ++k) sx += (long double)Mh[((size_t)w * 256 + i) * Kr + k] * Mh[((size_t)w * 256 + jx) * Kr + k];
           Gx[((size_t)w * 256 + i) * 256 + jx] = sx;
         }
-    for (int variant = 0; variant < 2; ++variant) {
+    for (int variant = 0; variant < 3; ++variant) {
       float ms = 0;
       for (int rep = -1; rep < reps; ++rep) {
         CK(hipMemset(G, 0xff, sizeof(double) * 256 * 256 * 2));
@@ -143,10 +148,15 @@ int main(int argc, char **argv) {
         if (variant == 0) {
           hipLaunchKernelGGL(gram_rows_f64_kernel<float>, dim3((10 + 3) / 4, nw), dim3(256), 0, 0, Md, (long)256 * Kr, Kr, nrd, G, (long)256 * 256, ldg, nullptr,
                              nullptr, nullptr);
-        } else {
+        } else if (variant == 1) {
           const size_t smem = gram_cols_i8_smem_bytes();
           allow_dynamic_lds(reinterpret_cast<const void *>(&gram_cols_i8_kernel<float, true>), smem);
           hipLaunchKernelGGL((gram_cols_i8_kernel<float, true>), dim3(nw), dim3(512), smem, 0, Md, (long)256 * Kr, 256, Kr, nullptr, 1, Kr, G, (long)256 * 256, ldg,
+                             nullptr, 1, nullptr, nrd, nullptr, nullptr, 1);
+        } else {
+          const size_t smem = gram_cols_i8_smem_bytes();
+          allow_dynamic_lds(reinterpret_cast<const void *>(&gram_cols_i8_kernel<float, true, 0, 12>), smem);
+          hipLaunchKernelGGL((gram_cols_i8_kernel<float, true, 0, 12>), dim3(nw), dim3(768), smem, 0, Md, (long)256 * Kr, 256, Kr, nullptr, 1, Kr, G, (long)256 * 256, ldg,
                              nullptr, 1, nullptr, nrd, nullptr, nullptr, 1);
         }
         CK(hipGetLastError());
@@ -164,7 +174,7 @@ int main(int argc, char **argv) {
             eex = std::max(eex, (double)(fabsl(Gh[((size_t)w * 256 + i) * 256 + jx] - Gx[((size_t)w * 256 + i) * 256 + jx]) / sc));
           }
       printf("{\"kernel\": \"%s\", \"walkers\": %d, \"K\": %d, \"ms\": %.4f, \"err_exact\": %.3e}\n",
-             variant == 0 ? "gram_rows_f64_kernel (f64 MFMA)" : "gram_cols_i8_kernel<ROWS> (9 x i8 MFMA)", nw, Kr, ms, eex);
+             variant == 0 ? "gram_rows_f64_kernel (f64 MFMA)" : variant == 1 ? "gram_cols_i8_kernel<ROWS> (9 x i8 MFMA)" : "gram_cols_i8_kernel<ROWS>, 12 waves", nw, Kr, ms, eex);
       fflush(stdout);
     }
   }
