@@ -27,5 +27,11 @@ leg() { # tag, extra args
 leg c4_f32_noise0.1_nw49152
 leg c4_f32_noise1_nw8192 --noise 1.0 --walkers 8192
 leg c4_f32_real_nw8192 --state real --walkers 8192
+# kernel trace of the Monte-Carlo sweeps (1 + 2 sweeps of the exchange updater through the C++ host layer, 8192 walkers of the headline state)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt_sweep -- python3 scripts/sweep_trace.py 8192 > $O/kt_sweep.log 2>&1
+python3 scripts/trace_summary.py $O/kt_sweep_kernel_trace.csv > $O/r04_kernel_trace_by_grid_sweep_c4_f32_noise0.1_nw8192.txt
+rm -f $O/kt_sweep_kernel_trace.csv
+head -8 $O/r04_kernel_trace_by_grid_sweep_c4_f32_noise0.1_nw8192.txt
+(cd scripts && ./build/gram_i8_bench 2048 1536 5) > $O/r04_gram_i8_microbench.jsonl 2>&1
 find $O -name "*.csv" -size +3M -delete
 ls $O | head -60

@@ -7,7 +7,7 @@ times (calibration with 1 walker, warm-up and timed step at full size, rank diag
 are identified by their grid in the kernel trace (the two largest launch groups of the kernel) and carry all but ~0.1 % of the bytes."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ("tgemm_chain_kernel", "tgemm_direct_kernel", "gram_cols_f64_kernel", "gram_cols_lds_kernel", "gram_rows_f64_kernel", "chol_blocked_kernel",
+KERNELS = ("tgemm_chain_kernel", "tgemm_chain3_kernel", "tgemm_direct_kernel", "tgemm_skinny_f64_kernel", "gram_cols_i8_kernel", "gram_cols_f64_kernel", "gram_cols_lds_kernel", "gram_rows_f64_kernel", "chol_blocked_kernel",
            "gram_chol_wave_kernel", "jacobi_rows_grp_kernel", "jacobi_rows_tiny4_kernel", "colgram_dense_kernel", "mid_gram_chol_kernel",
            "ortho_rows_kernel", "mgemm_dense_kernel", "tgemm_kernel")
 RND = "r%02d" % (int(sys.argv[1]) if len(sys.argv) > 1 else 4)
