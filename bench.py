@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--sweep-walkers", type=int, default=16384)
     ap.add_argument("--real-sweep-walkers", type=int, default=2048, help="walkers of the sweep / VMC-sample rates on the real_rank leg")
     ap.add_argument("--real-sweep-count", type=int, default=3, help="timed sweeps / samples there")
-    ap.add_argument("--sweep-count", type=int, default=2)
+    ap.add_argument("--sweep-count", type=int, default=3)
     ap.add_argument("--no-other-modes", action="store_true", help="skip the short runs of the f64 / variational / complex / C5 modes")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-walker latency measurement (n1_ms)")
     ap.add_argument("--energy-n", type=int, default=8, help="configurations of the E_loc parity sample of the main leg (half of it on the extra legs)")

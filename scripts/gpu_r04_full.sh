@@ -19,3 +19,11 @@ for leg in ("full_rank","real_rank"):
 print("roofline", {k:v for k,v in d["roofline"].items() if k in ("bound","kernel","frac","achieved","traffic","avg_launch_us","frac_priced_with")})
 print("other", d.get("other_modes"))
 PY
+python bench.py > gpurun_out/r04/bench_default.json 2> gpurun_out/r04/bench_default.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r04/bench_default.json').read().strip().splitlines()[-1])
+print("default: value", d["value"], "sweeps", d.get("mc_sweeps_per_s"), "vmc", d.get("vmc_samples_per_s"), "full", d["full_rank"]["value"], "real", d["real_rank"]["value"], d["real_rank"].get("vmc", {}).get("mc_sweeps_per_s"))
+print("roofline", {k: d["roofline"].get(k) for k in ("bound", "kernel", "frac", "traffic", "frac_priced_with")})
+print("real roofline", {k: d["real_rank"]["roofline"].get(k) for k in ("bound", "kernel", "share_of_kernel_time")}, {k: d["real_rank"]["roofline"].get("largest_priced_kernel", {}).get(k) for k in ("kernel", "frac", "traffic")})
+PY
