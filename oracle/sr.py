@@ -39,12 +39,15 @@ def conjugate_gradient_full(matvec, b, x0, max_iter=100, relative_tolerance=1e-4
     indefinite-matrix exit, stagnation detection, periodic residual recomputation, NaN/Inf exits, best-iterate
     tracking, orthogonality-based restart.  Parameter defaults = ConjugateGradientParams (optimizer_params.h:50-57).
     Returns (x, residual_norm, iterations, reason)."""
-    b = np.asarray(b, dtype=np.float64).ravel()
-    x0 = np.asarray(x0, dtype=np.float64).ravel()
+    cplx = np.iscomplexobj(b) or np.iscomplexobj(x0)        # TenElemT = QLTEN_Complex: a * b = sum conj(a) b, NormSquare = sum |a|^2
+    dt = np.complex128 if cplx else np.float64
+    b = np.asarray(b, dtype=dt).ravel()
+    x0 = np.asarray(x0, dtype=dt).ravel()
     eps = np.finfo(np.float64).eps
-    tol_sq = max(relative_tolerance ** 2 * float(b @ b), absolute_tolerance ** 2)
+    nsq = lambda v: float(np.vdot(v, v).real)
+    tol_sq = max(relative_tolerance ** 2 * nsq(b), absolute_tolerance ** 2)
     r = b - matvec(x0)
-    rr = float(r @ r)
+    rr = nsq(r)
     if rr <= tol_sq:
         return x0.copy(), np.sqrt(rr), 0, K_CONVERGED
     p, x, best_x, best_rr = r.copy(), x0.copy(), x0.copy(), rr
@@ -54,12 +57,14 @@ def conjugate_gradient_full(matvec, b, x0, max_iter=100, relative_tolerance=1e-4
     for k in range(max_iter):
         rk = rkp1
         ap = matvec(p)
-        pap = float(p @ ap)
-        if not (np.isfinite(pap) and pap > 0.0):                           # detail::pap_is_valid (:142-148)
+        pap = np.vdot(p, ap) if cplx else float(p @ ap)
+        # detail::pap_is_valid (:142-148): real: pap > 0; complex: Re > 0 and |Im| < 1e-10
+        ok = (np.isfinite(pap.real) and pap.real > 0.0 and abs(pap.imag) < 1e-10) if cplx else (np.isfinite(pap) and pap > 0.0)
+        if not ok:
             return best_x, np.sqrt(best_rr), k, K_INDEFINITE
         alpha = rk / pap
         x = x + alpha * p
-        if alpha * alpha * float(p @ p) < eps * eps * float(x @ x):       # :227-236
+        if abs(alpha) ** 2 * nsq(p) < eps * eps * nsq(x):                # :227-236
             stagnation += 1
             if stagnation >= 3:
                 return best_x, np.sqrt(best_rr), k + 1, K_STAGNATED
@@ -69,14 +74,14 @@ def conjugate_gradient_full(matvec, b, x0, max_iter=100, relative_tolerance=1e-4
             r = b - matvec(x)                                              # :238-239
         else:
             r = r - alpha * ap
-        rkp1 = float(r @ r)
+        rkp1 = nsq(r)
         if not np.isfinite(rkp1):
             return best_x, np.sqrt(best_rr), k + 1, K_BREAKDOWN
         if rkp1 < best_rr:
             best_x, best_rr = x.copy(), rkp1
         if rkp1 <= tol_sq:
             return x, np.sqrt(rkp1), k + 1, K_CONVERGED
-        if k > 0 and abs(float(r_prev @ r)) > orthogonality_threshold * rkp1:   # :259-266
+        if k > 0 and abs(np.vdot(r_prev, r).real) > orthogonality_threshold * rkp1:   # :259-266 (real part)
             p = r.copy()
             r_prev = r.copy()
             continue

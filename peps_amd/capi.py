@@ -364,8 +364,9 @@ class Context:
     def sr_cg_solve(self, b, x0=None, diag_shift=0.0, max_iter=100, relative_tolerance=1e-4, absolute_tolerance=0.0,
                     residual_recompute_interval=20, orthogonality_threshold=0.5):
         """(S + diag_shift) x = b with every CG vector on the device; returns (x, residual_norm, iterations, reason)."""
-        b = np.ascontiguousarray(b, dtype=np.float64)
-        x0a = None if x0 is None else np.ascontiguousarray(x0, dtype=np.float64)
+        dt = np.complex128 if self.dtype == C128 else np.float64       # complex contexts: interleaved (re, im) pairs through the C ABI
+        b = np.ascontiguousarray(b, dtype=dt)
+        x0a = None if x0 is None else np.ascontiguousarray(x0, dtype=dt)
         x = np.zeros_like(b)
         res = np.zeros(1, dtype=np.float64)
         it = np.zeros(2, dtype=np.int32)

@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void sr_append_cplx_kernel(const T *__restrict
 template <typename T>
 __global__ __launch_bounds__(256) void sr_delta_cplx_kernel(const T *__restrict__ o, const int *__restrict__ cfg,
                                                             const double *__restrict__ v, double shift_re, double shift_im,
-                                                            double *__restrict__ delta, int sites, long slot, int dp) {
+                                                            double *__restrict__ delta, int sites, long slot, int dp,
+                                                            const double *__restrict__ shift_dev = nullptr) {
   __shared__ double s_red[8];
   const int i = blockIdx.x;
   double ar = 0.0, ai = 0.0;
@@ -89,8 +90,8 @@ __global__ __launch_bounds__(256) void sr_delta_cplx_kernel(const T *__restrict_
   if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = ar; s_red[4 + (threadIdx.x >> 6)] = ai; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    delta[2 * i] = s_red[0] + s_red[1] + s_red[2] + s_red[3] - shift_re;
-    delta[2 * i + 1] = s_red[4] + s_red[5] + s_red[6] + s_red[7] - shift_im;
+    delta[2 * i] = s_red[0] + s_red[1] + s_red[2] + s_red[3] - shift_re - (shift_dev ? shift_dev[0] : 0.0);
+    delta[2 * i + 1] = s_red[4] + s_red[5] + s_red[6] + s_red[7] - shift_im - (shift_dev ? shift_dev[1] : 0.0);
   }
 }
 // out[site][s][e] = scale * sum_{i : cfg_i(site) == s} weight_i O*_i(site)[e], complex weights (nullptr: 1); interleaved pairs
@@ -132,6 +133,40 @@ __global__ __launch_bounds__(64) void sr_dot_final_kernel(const double *__restri
   for (int e = threadIdx.x; e < nblocks; e += 64) acc += part[e];
   acc = wave_sum(acc);
   if (threadIdx.x == 0) *out = acc;
+}
+
+// complex vectors as interleaved (re, im) pairs: part[2 b], part[2 b + 1] = the block's share of sum conj(a) b  (n complex entries)
+__global__ __launch_bounds__(256) void sr_dotc_kernel(const double *__restrict__ a, const double *__restrict__ b, long n,
+                                                      double *__restrict__ part) {
+  __shared__ double s_red[8];
+  double ar = 0.0, ai = 0.0;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const double xr = a[2 * e], xi = a[2 * e + 1], yr = b[2 * e], yi = b[2 * e + 1];
+    ar += xr * yr + xi * yi;
+    ai += xr * yi - xi * yr;
+  }
+  ar = wave_sum(ar); ai = wave_sum(ai);
+  if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = ar; s_red[4 + (threadIdx.x >> 6)] = ai; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    part[2 * blockIdx.x + 1] = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+  }
+}
+__global__ __launch_bounds__(64) void sr_dotc_final_kernel(const double *__restrict__ part, int nblocks, double *__restrict__ out) {
+  double ar = 0.0, ai = 0.0;
+  for (int e = threadIdx.x; e < nblocks; e += 64) { ar += part[2 * e]; ai += part[2 * e + 1]; }
+  ar = wave_sum(ar); ai = wave_sum(ai);
+  if (threadIdx.x == 0) { out[0] = ar; out[1] = ai; }
+}
+// y = alpha * x + beta * y, alpha complex, beta real (n complex entries)
+__global__ __launch_bounds__(256) void sr_caxpby_kernel(double alpha_re, double alpha_im, const double *__restrict__ x, double beta,
+                                                        double *__restrict__ y, long n) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const double xr = x[2 * e], xi = x[2 * e + 1];
+    y[2 * e] = alpha_re * xr - alpha_im * xi + beta * y[2 * e];
+    y[2 * e + 1] = alpha_re * xi + alpha_im * xr + beta * y[2 * e + 1];
+  }
 }
 
 // y = alpha * x + beta * y
@@ -357,7 +392,113 @@ void Engine<T>::sr_cg_solve(const double *b, const double *x0, double diag_shift
                             double abs_tol, int recompute_interval, double ortho_threshold, double *x_out,
                             double *residual_norm, int *iterations, int *reason) {
   if constexpr (kCplx) {
-    PG_REQUIRE(false, 1, "stochastic reconfiguration is not implemented for the complex element type");
+    // TenElemT = QLTEN_Complex (round 4): the same solver on interleaved (re, im) vectors.  a * b = sum conj(a) b, NormSquare real,
+    // p * (A p) complex and valid when Re > 0 and |Im| < 1e-10 (detail::pap_is_valid, :142-148), alpha = rk / pap complex, beta real,
+    // the restart test takes the real part of r_prev * r (:259-266).
+    PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_cg_solve: no samples");
+    ArenaScope scope(arena_);
+    const int sites = Ly_ * Lx_;
+    const long n = (long)sites * dp_ * slot_, n2 = 2 * n;
+    const double scale = 1.0 / sr_n_;
+    auto dvec = [&]() { return (double *)arena_.alloc(sizeof(double) * n2); };
+    double *db = dvec(), *dx = dvec(), *dr = dvec(), *dp = dvec(), *dap = dvec(), *dbest = dvec(), *dprev = dvec(), *dmean = dvec();
+    double *dsc = (double *)arena_.alloc(sizeof(double) * 16);
+    constexpr int DOT_BLOCKS = 512;
+    double *dpart = (double *)arena_.alloc(sizeof(double) * 2 * DOT_BLOCKS);
+    auto nsq_into = [&](const double *a, double *out) {          // sum |a|^2: a real dot over the 2 n doubles
+      hipLaunchKernelGGL(sr_dot_kernel, dim3(DOT_BLOCKS), dim3(256), 0, stream_, a, a, n2, dpart);
+      hipLaunchKernelGGL(sr_dot_final_kernel, dim3(1), dim3(64), 0, stream_, (const double *)dpart, DOT_BLOCKS, out);
+    };
+    auto dotc_into = [&](const double *a, const double *b2, double *out) {
+      hipLaunchKernelGGL(sr_dotc_kernel, dim3(DOT_BLOCKS), dim3(256), 0, stream_, a, b2, n, dpart);
+      hipLaunchKernelGGL(sr_dotc_final_kernel, dim3(1), dim3(64), 0, stream_, (const double *)dpart, DOT_BLOCKS, out);
+    };
+    std::vector<double> h(n2);
+    auto upload = [&](const double *src, double *dst) {
+      if (src) {
+        sr_convert(src, h.data(), true);
+        PG_CHECK_HIP(hipMemcpyAsync(dst, h.data(), n2 * sizeof(double), hipMemcpyHostToDevice, stream_));
+        PG_CHECK_HIP(hipStreamSynchronize(stream_));   // h is reused
+      } else PG_CHECK_HIP(hipMemsetAsync(dst, 0, n2 * sizeof(double), stream_));
+    };
+    auto copy = [&](double *dst, const double *src) {
+      PG_CHECK_HIP(hipMemcpyAsync(dst, src, n2 * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    };
+    const dim3 vg((unsigned)std::min<long>((n + 255) / 256, 2048)), vg2((unsigned)std::min<long>((n2 + 255) / 256, 2048));
+    auto axpby = [&](double alpha, const double *x, double beta, double *y) {       // real scalars: element-wise on the doubles
+      hipLaunchKernelGGL(sr_axpby_kernel, vg2, dim3(256), 0, stream_, alpha, x, beta, y, n2);
+    };
+    auto caxpby = [&](double ar, double ai, const double *x, double beta, double *y) {
+      hipLaunchKernelGGL(sr_caxpby_kernel, vg, dim3(256), 0, stream_, ar, ai, x, beta, y, n);
+    };
+    auto read = [&](double *out, int k) {
+      PG_CHECK_HIP(hipMemcpyAsync(out, dsc, sizeof(double) * k, hipMemcpyDeviceToHost, stream_));
+      PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    };
+    auto matvec = [&](const double *v, double *out) {
+      dotc_into(dmean, v, dsc + 14);   // Ostar_mean * v = sum conj(mean) v
+      hipLaunchKernelGGL(sr_delta_cplx_kernel<T>, dim3(sr_n_), dim3(256), 0, stream_, (const T *)sr_o_, (const int *)sr_cfg_, v, 0.0, 0.0,
+                         sr_delta_, sites, slot_, dp_, (const double *)(dsc + 14));
+      hipLaunchKernelGGL(sr_accum_cplx_kernel<T>, dim3((unsigned)((slot_ + 255) / 256), sites), dim3(256), 0, stream_, (const T *)sr_o_,
+                         (const int *)sr_cfg_, (const double *)sr_delta_, scale, out, sr_n_, sites, slot_, dp_);
+      PG_CHECK_HIP(hipGetLastError());
+      if (diag_shift != 0.0) axpby(diag_shift, v, 1.0, out);
+    };
+    auto finish = [&](const double *xsrc, double res_sq, int iters, int why) {
+      PG_CHECK_HIP(hipMemcpyAsync(h.data(), xsrc, n2 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+      PG_CHECK_HIP(hipStreamSynchronize(stream_));
+      sr_convert(h.data(), x_out, false);
+      *residual_norm = std::sqrt(res_sq); *iterations = iters; *reason = why;
+      for (double *v : {db, dx, dr, dp, dap, dbest, dprev, dmean, dsc, dpart}) arena_.free(v);
+    };
+    enum { kConverged = 0, kMaxIterations = 1, kIndefiniteMatrix = 2, kNumericalBreakdown = 3, kStagnated = 4 };
+    hipLaunchKernelGGL(sr_accum_cplx_kernel<T>, dim3((unsigned)((slot_ + 255) / 256), sites), dim3(256), 0, stream_, (const T *)sr_o_,
+                       (const int *)sr_cfg_, (const double *)nullptr, scale, dmean, sr_n_, sites, slot_, dp_);
+    upload(b, db);
+    upload(x0, dx);
+    double s[8];
+    matvec(dx, dap);
+    copy(dr, db);
+    axpby(-1.0, dap, 1.0, dr);                      // r = b - A x0
+    nsq_into(db, dsc); nsq_into(dr, dsc + 1); read(s, 2);
+    const double tol_sq = std::max(rel_tol * rel_tol * s[0], abs_tol * abs_tol);
+    double r_norm_sq = s[1];
+    if (r_norm_sq <= tol_sq) return finish(dx, r_norm_sq, 0, kConverged);
+    copy(dp, dr); copy(dbest, dx); copy(dprev, dr);
+    double best = r_norm_sq, rkp1 = r_norm_sq;
+    int stagnation = 0;
+    const double eps = 2.220446049250313e-16;
+    for (int k = 0; k < max_iter; ++k) {
+      const double rk = rkp1;
+      matvec(dp, dap);
+      dotc_into(dp, dap, dsc); nsq_into(dp, dsc + 2); read(s, 3);
+      const double pap_re = s[0], pap_im = s[1], pp = s[2];
+      if (!(std::isfinite(pap_re) && pap_re > 0.0 && std::fabs(pap_im) < 1e-10)) return finish(dbest, best, k, kIndefiniteMatrix);
+      const double den = pap_re * pap_re + pap_im * pap_im;
+      const double a_re = rk * pap_re / den, a_im = -rk * pap_im / den;      // alpha = rk / pap
+      caxpby(a_re, a_im, dp, 1.0, dx);
+      if (recompute_interval > 0 && (k % recompute_interval) == recompute_interval - 1) {
+        matvec(dx, dr);
+        axpby(1.0, db, -1.0, dr);                   // r = b - A x
+      } else caxpby(-a_re, -a_im, dap, 1.0, dr);
+      nsq_into(dx, dsc); nsq_into(dr, dsc + 1); dotc_into(dprev, dr, dsc + 2); read(s, 4);
+      if ((a_re * a_re + a_im * a_im) * pp < eps * eps * s[0]) {
+        if (++stagnation >= 3) return finish(dbest, best, k + 1, kStagnated);
+      } else stagnation = 0;
+      rkp1 = s[1];
+      if (!std::isfinite(rkp1)) return finish(dbest, best, k + 1, kNumericalBreakdown);
+      if (rkp1 < best) { copy(dbest, dx); best = rkp1; }
+      if (rkp1 <= tol_sq) return finish(dx, rkp1, k + 1, kConverged);
+      if (k > 0 && std::fabs(s[2]) > ortho_threshold * rkp1) {   // orthogonality-based restart (real part of r_prev * r)
+        copy(dp, dr); copy(dprev, dr);
+        continue;
+      }
+      copy(dprev, dr);
+      const double beta = rkp1 / rk;
+      if (!std::isfinite(beta)) return finish(dbest, best, k + 1, kNumericalBreakdown);
+      axpby(1.0, dr, beta, dp);                      // p = r + beta p
+    }
+    finish(dbest, best, max_iter, kMaxIterations);
   } else {
   PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_cg_solve: no samples");
   ArenaScope scope(arena_);

@@ -207,4 +207,25 @@ def test_sr_matvec_complex_vs_oracle():
     sv = ctx.sr_matvec(v, np.vdot(mean.ravel(), v.ravel()), 1.0 / (2 * n))
     q = np.vdot(v.ravel(), sv.ravel())
     assert q.real > 0 and abs(q.imag) < 1e-9 * q.real
+    # the conjugate-gradient solve on the device (round 4: complex contexts too) against the oracle's solver on the oracle's S:
+    # same iteration count, same termination reason, same solution
+    b = (ref * (rng.standard_normal(mean.shape) + 1j * rng.standard_normal(mean.shape))).reshape(mean.shape) \
+        + 0.01 * (rng.standard_normal(mean.shape) + 1j * rng.standard_normal(mean.shape)) * (np.abs(mean) > 0)
+    # (detail::pap_is_valid asks |Im p*(A p)| < 1e-10 ABSOLUTE: with O* of this size the first product already fails it by rounding --
+    # oracle and device agree on that exit; the solves below run on a right-hand side scaled so that p*(A p) = O(1))
+    full = osr.SRSMatrix(samples, mean, 1, 1e-3)
+    _, _, ir, why_r = osr.conjugate_gradient_full(lambda x: full * x, b.ravel(), np.zeros(b.size, dtype=np.complex128), 50, 1e-8, 0.0, 20, 0.5)
+    _, _, idv, why_d = ctx.sr_cg_solve(b, None, 1e-3, 50, 1e-8, 0.0, 20, 0.5)
+    assert (idv, why_d) == (ir, why_r)
+    b = b / np.sqrt(abs(np.vdot(b.ravel(), full * b.ravel())))
+    for shift, rtol, recompute in ((1e-3, 1e-8, 20), (1e-2, 1e-5, 3)):
+        full = osr.SRSMatrix(samples, mean, 1, shift)
+        xr, rr, ir, why_r = osr.conjugate_gradient_full(lambda x: full * x, b.ravel(), np.zeros(b.size, dtype=np.complex128), 200, rtol, 0.0,
+                                                        recompute, 0.5)
+        xd, rd, idv, why_d = ctx.sr_cg_solve(b, None, shift, 200, rtol, 0.0, recompute, 0.5)
+        assert why_d == why_r == osr.K_CONVERGED and abs(idv - ir) <= 1, (idv, ir, why_d, why_r)
+        # (both iterates satisfy the termination criterion; between them stands the conditioning of S + shift times the rounding of
+        # two different summation orders)
+        assert np.max(np.abs(xd.ravel() - xr)) < 1e-4 * np.max(np.abs(xr)) and abs(rd - rr) < 1e-6 * np.linalg.norm(b.ravel()) + 0.5 * rr
+        assert np.linalg.norm((full * xd.ravel()) - b.ravel()) <= 1.5 * rtol * np.linalg.norm(b.ravel())
     ctx.close()
