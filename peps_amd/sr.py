@@ -17,7 +17,12 @@ class DeviceSRSMatrix:
         n_local = ctx.sr_count()
         tot = self._allreduce(np.array([float(n_local)]))[0]
         self.n_total = int(round(tot))
-        self.mean = self._allreduce(ctx.sr_sum()) / self.n_total          # Ostar_mean
+        tot_sum = ctx.sr_sum()
+        if np.iscomplexobj(tot_sum) and dist is not None:
+            tot_sum = self._allreduce(np.ascontiguousarray(tot_sum).view(np.float64)).view(np.complex128)
+        else:
+            tot_sum = self._allreduce(tot_sum)
+        self.mean = tot_sum / self.n_total          # Ostar_mean
 
     def _allreduce(self, arr):
         if self.dist is None:
@@ -30,9 +35,14 @@ class DeviceSRSMatrix:
         return t.cpu().numpy()
 
     def __mul__(self, v):
-        v = np.ascontiguousarray(v, dtype=np.float64)
-        mean_dot_v = float(np.vdot(self.mean, v))
-        res = self._allreduce(self.ctx.sr_matvec(v, mean_dot_v, 1.0 / self.n_total))
+        cplx = np.iscomplexobj(self.mean)               # complex contexts: a * b = sum conj(a) b (np.vdot), complex mean . v
+        v = np.ascontiguousarray(v, dtype=np.complex128 if cplx else np.float64)
+        mdv = np.vdot(self.mean, v)
+        res = self.ctx.sr_matvec(v, mdv if cplx else float(mdv), 1.0 / self.n_total)
+        if cplx and self.dist is not None:               # (torch has no complex all-reduce on every backend: as interleaved pairs)
+            res = self._allreduce(np.ascontiguousarray(res).view(np.float64)).view(np.complex128)
+        else:
+            res = self._allreduce(res)
         if self.diag_shift != 0.0:
             res = res + self.diag_shift * v
         return res
@@ -47,16 +57,19 @@ def conjugate_gradient(matrix, b, x0=None, max_iter=100, relative_tolerance=1e-4
     (`matrix` all-reduces every product).  Same branches as the reference and as the device-resident
     pepsgpu_sr_cg_solve: indefinite exit, stagnation, periodic residual recomputation, NaN/Inf exits, best iterate,
     orthogonality restart.  Returns (x, residual norm, iterations[, reason])."""
-    b = np.asarray(b, dtype=np.float64)
-    x0 = np.zeros_like(b) if x0 is None else np.array(x0, dtype=np.float64)
+    cplx = np.iscomplexobj(b) or (x0 is not None and np.iscomplexobj(x0))      # TenElemT = QLTEN_Complex
+    dt = np.complex128 if cplx else np.float64
+    b = np.asarray(b, dtype=dt)
+    x0 = np.zeros_like(b) if x0 is None else np.array(x0, dtype=dt)
     eps = np.finfo(np.float64).eps
+    nsq = lambda v: float(np.vdot(v, v).real)
 
     def ret(x, rr, it, why):
         return (x, float(np.sqrt(rr)), it, why) if full_output else (x, float(np.sqrt(rr)), it)
 
-    tol_sq = max(relative_tolerance ** 2 * float(np.vdot(b, b)), absolute_tolerance ** 2)
+    tol_sq = max(relative_tolerance ** 2 * nsq(b), absolute_tolerance ** 2)
     r = b - matrix * x0
-    rr = float(np.vdot(r, r))
+    rr = nsq(r)
     if rr <= tol_sq:
         return ret(x0, rr, 0, K_CONVERGED)
     p, x, best_x, best = r.copy(), x0.copy(), x0.copy(), rr
@@ -64,12 +77,14 @@ def conjugate_gradient(matrix, b, x0=None, max_iter=100, relative_tolerance=1e-4
     for k in range(max_iter):
         rk = rkp1
         ap = matrix * p
-        pap = float(np.vdot(p, ap))
-        if not (np.isfinite(pap) and pap > 0.0):
+        pap = np.vdot(p, ap)
+        # detail::pap_is_valid (:142-148): real pap > 0; complex Re > 0 and |Im| < 1e-10
+        ok = (np.isfinite(pap.real) and pap.real > 0.0 and abs(pap.imag) < 1e-10) if cplx else (np.isfinite(pap) and pap > 0.0)
+        if not ok:
             return ret(best_x, best, k, K_INDEFINITE)
-        alpha = rk / pap
+        alpha = rk / (pap if cplx else float(pap))
         x = x + alpha * p
-        if alpha * alpha * float(np.vdot(p, p)) < eps * eps * float(np.vdot(x, x)):
+        if abs(alpha) ** 2 * nsq(p) < eps * eps * nsq(x):
             stagnation += 1
             if stagnation >= 3:
                 return ret(best_x, best, k + 1, K_STAGNATED)
@@ -79,14 +94,14 @@ def conjugate_gradient(matrix, b, x0=None, max_iter=100, relative_tolerance=1e-4
             r = b - matrix * x
         else:
             r = r - alpha * ap
-        rkp1 = float(np.vdot(r, r))
+        rkp1 = nsq(r)
         if not np.isfinite(rkp1):
             return ret(best_x, best, k + 1, K_BREAKDOWN)
         if rkp1 < best:
             best_x, best = x.copy(), rkp1
         if rkp1 <= tol_sq:
             return ret(x, rkp1, k + 1, K_CONVERGED)
-        if k > 0 and abs(float(np.vdot(r_prev, r))) > orthogonality_threshold * rkp1:
+        if k > 0 and abs(np.vdot(r_prev, r).real) > orthogonality_threshold * rkp1:
             p, r_prev = r.copy(), r.copy()
             continue
         r_prev = r.copy()

@@ -228,4 +228,10 @@ def test_sr_matvec_complex_vs_oracle():
         # two different summation orders)
         assert np.max(np.abs(xd.ravel() - xr)) < 1e-4 * np.max(np.abs(xr)) and abs(rd - rr) < 1e-6 * np.linalg.norm(b.ravel()) + 0.5 * rr
         assert np.linalg.norm((full * xd.ravel()) - b.ravel()) <= 1.5 * rtol * np.linalg.norm(b.ravel())
+    # the host-vector solver of the multi-rank path (peps_amd/sr.py: one all-reduce per product) on the same complex store
+    from peps_amd import sr
+    S = sr.DeviceSRSMatrix(ctx, diag_shift=1e-2)
+    xh, rh, ih, why_h = sr.conjugate_gradient(S, b, max_iter=200, relative_tolerance=1e-5, residual_recompute_interval=3, full_output=True)
+    assert why_h == osr.K_CONVERGED and abs(ih - idv) <= 1 and np.max(np.abs(xh - xd)) < 1e-4 * np.max(np.abs(xd))
+    assert np.linalg.norm((osr.SRSMatrix(samples, mean, 1, 1e-2) * xh.ravel()) - b.ravel()) <= 1.5e-5 * np.linalg.norm(b.ravel())
     ctx.close()

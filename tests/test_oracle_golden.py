@@ -319,3 +319,36 @@ def test_reference_gradient_signatures(fixtures_dir, name, model, norm2, probe, 
     ns, wp = gradient_signatures(grad)
     assert abs(ns / norm2 - 1) < 1e-9, cite
     assert abs(wp / probe - 1) < 1e-9, cite
+
+
+def test_complex_conjugate_gradient_host_and_oracle_agree():
+    """ConjugateGradientSolver for TenElemT = QLTEN_Complex (utility/conjugate_gradient_solver.h:142-156, 181-276): a * b = sum conj(a) b,
+    pap valid when Re > 0 and |Im| < 1e-10, the restart test on the real part.  The host-vector solver of the multi-rank path
+    (peps_amd/sr.py) and the oracle's restatement walk the same iterates on a Hermitian positive-definite system; both solve it."""
+    from oracle import sr as osr
+    from peps_amd import sr
+    rng = np.random.default_rng(5)
+    m = 40
+    a = rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))
+    h = a.conj().T @ a / m + 0.05 * np.eye(m)
+
+    class Mat:
+        def __mul__(self, v):
+            return h @ v
+
+    b = rng.standard_normal(m) + 1j * rng.standard_normal(m)
+    xo, ro, io, wo = osr.conjugate_gradient_full(lambda v: h @ v, b, np.zeros(m, dtype=np.complex128), 300, 1e-10, 0.0, 7, 0.5)
+    xh, rh, ih, wh = sr.conjugate_gradient(Mat(), b, None, 300, 1e-10, 0.0, 7, 0.5, full_output=True)
+    assert wo == wh == osr.K_CONVERGED and io == ih and np.allclose(xo, xh, rtol=0, atol=1e-12)
+    assert np.linalg.norm(h @ xh - b) <= 1e-10 * np.linalg.norm(b) * 1.01
+    assert np.max(np.abs(xh - np.linalg.solve(h, b))) < 1e-8
+    # a matrix that is not self-adjoint: p * (A p) gets an imaginary part -> the indefinite-matrix exit, in both
+    g = h + 0.3j * np.triu(np.ones((m, m)), 1)
+    _, _, io2, wo2 = osr.conjugate_gradient_full(lambda v: g @ v, b, np.zeros(m, dtype=np.complex128), 300, 1e-10, 0.0, 7, 0.5)
+
+    class Mat2:
+        def __mul__(self, v):
+            return g @ v
+
+    _, _, ih2, wh2 = sr.conjugate_gradient(Mat2(), b, None, 300, 1e-10, 0.0, 7, 0.5, full_output=True)
+    assert wo2 == wh2 == osr.K_INDEFINITE and io2 == ih2
