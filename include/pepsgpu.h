@@ -237,8 +237,8 @@ int pepsgpu_sr_matvec(pepsgpu_ctx *ctx, const double *v, double mean_dot_v, doub
  * interleaved pairs; O*_i = conj(1 / psi_i) Dag(hole_i) (mc_energy_grad_evaluator.h:245-270); the product uses the positive-definite
  * pairing of SplitIndexTPS::operator* (split_index_tps.h:370-377):  out = scale * sum_i (<O*_i, v> - mean_dot_v) O*_i,
  * <a, b> = sum conj(a) b; v, out = state layout, interleaved pairs.  pepsgpu_sr_cg_solve works on PEPSGPU_C128 contexts too (b, x0, x_out
- * interleaved pairs; pap valid when Re > 0 and |Im| < 1e-10 as detail::pap_is_valid); the MinSR blocks (sr_gram / sr_weighted_sum) stay
- * real-only: PEPSGPU_EINVAL. */
+ * interleaved pairs; pap valid when Re > 0 and |Im| < 1e-10 as detail::pap_is_valid), and so do the MinSR blocks: pepsgpu_sr_gram returns
+ * ip_ij = O*_i * O*_j = sum conj(O*_i) O*_j as interleaved pairs, pepsgpu_sr_weighted_sum takes complex weights (interleaved). */
 int pepsgpu_sr_matvec_c128(pepsgpu_ctx *ctx, const double *v, double mean_dot_v_re, double mean_dot_v_im, double scale, double *out);
 /* ConjugateGradientSolver (utility/conjugate_gradient_solver.h:181-276) on (S + diag_shift) x = b over the samples of THIS
  * context, every vector resident in HBM; parameters = ConjugateGradientParams (optimizer/optimizer_params.h:50-57).

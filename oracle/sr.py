@@ -109,26 +109,31 @@ def pseudo_inverse_cutoff(eigenvalues, r_pinv, a_pinv, soft_cutoff):
 
 
 def minsr_tmatrix(ostar_samples):
-    """MinSRTMatrix::Construct (optimizer/minsr_tmatrix.h:53-147): raw Gram, four-term centering, 1/Ns."""
-    o = np.stack([np.asarray(x, dtype=np.float64).ravel() for x in ostar_samples])
+    """MinSRTMatrix::Construct (optimizer/minsr_tmatrix.h:53-147): raw Gram ip_ij = O*_i * O*_j = sum conj(O*_i) O*_j, four-term
+    centering (entry - m_i - conj(m_j) + c, :141-147), 1/Ns.  TenElemT = double or complex."""
+    cplx = any(np.iscomplexobj(x) for x in ostar_samples)
+    o = np.stack([np.asarray(x, dtype=np.complex128 if cplx else np.float64).ravel() for x in ostar_samples])
     ns = o.shape[0]
-    g = o @ o.T
+    g = o.conj() @ o.T
     m = g.sum(axis=1) / ns
     c = m.sum() / ns
-    return (g - m[:, None] - m[None, :] + c) / ns
+    return (g - m[:, None] - m.conj()[None, :] + c) / ns
 
 
 def minsr_direction(ostar_samples, ostar_mean, energy_samples, energy, r_pinv=1e-12, a_pinv=0.0, soft_cutoff=True):
     """Optimizer::CalculateMinSRDirection_ (optimizer/optimizer_impl.h:1126-1215) for one rank (or all ranks'
-    samples concatenated): epsilon_bar, T, replicated eigensolve with pseudo-inverse cutoff
-    (ReplicatedEigenSolveReal, minsr_eigensolve.h:101-155), back-substitution.  Returns (delta_theta, norm)."""
-    o = np.stack([np.asarray(x, dtype=np.float64).ravel() for x in ostar_samples])
+    samples concatenated): epsilon_bar = conj(E_loc - E) / Ns (:1139-1146), T, replicated eigensolve with pseudo-inverse cutoff
+    (ReplicatedEigenSolveReal / Complex, minsr_eigensolve.h:101-237: y = Z lambda+ Z^H rhs), back-substitution
+    delta = sum_i y_i O*_i - (sum_i y_i) Ostar_mean.  Returns (delta_theta, norm)."""
+    cplx = any(np.iscomplexobj(x) for x in ostar_samples) or np.iscomplexobj(energy_samples) or np.iscomplexobj(ostar_mean)
+    dt = np.complex128 if cplx else np.float64
+    o = np.stack([np.asarray(x, dtype=dt).ravel() for x in ostar_samples])
     ns = o.shape[0]
-    eps_bar = (np.asarray(energy_samples, dtype=np.float64) - energy) / ns
+    eps_bar = np.conj(np.asarray(energy_samples, dtype=dt) - energy) / ns
     t = minsr_tmatrix(ostar_samples)
     ev, z = np.linalg.eigh(t)
-    y = z @ (pseudo_inverse_cutoff(ev, r_pinv, a_pinv, soft_cutoff) * (z.T @ eps_bar))
-    delta = y @ o - y.sum() * np.asarray(ostar_mean, dtype=np.float64).ravel()
+    y = z @ (pseudo_inverse_cutoff(ev, r_pinv, a_pinv, soft_cutoff) * (z.conj().T @ eps_bar))
+    delta = y @ o - y.sum() * np.asarray(ostar_mean, dtype=dt).ravel()
     return delta, float(np.linalg.norm(delta))
 
 

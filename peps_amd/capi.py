@@ -378,14 +378,16 @@ class Context:
     def sr_gram(self, remote_samples_ptr=None, remote_configs_ptr=None, n_remote=0):
         """raw inner products of the local O* samples with themselves (default) or with a device-resident remote batch"""
         n = self.sr_count()
-        out = np.zeros((n, n_remote if remote_samples_ptr else n), dtype=np.float64)
+        dt = np.complex128 if self.dtype == C128 else np.float64       # complex contexts: ip_ij = sum conj(O*_i) O*_j, interleaved pairs
+        out = np.zeros((n, n_remote if remote_samples_ptr else n), dtype=dt)
         self._ck(self._l.pepsgpu_sr_gram(self._h, remote_samples_ptr, remote_configs_ptr, n_remote, _dp(out)))
         return out
 
     def sr_weighted_sum(self, y):
-        y = np.ascontiguousarray(y, dtype=np.float64)
+        dt = np.complex128 if self.dtype == C128 else np.float64
+        y = np.ascontiguousarray(y, dtype=dt)
         assert y.size == self.sr_count()
-        out = np.zeros((self.rows, self.cols, self.d, self.D, self.D, self.D, self.D), dtype=np.float64)
+        out = np.zeros((self.rows, self.cols, self.d, self.D, self.D, self.D, self.D), dtype=dt)
         self._ck(self._l.pepsgpu_sr_weighted_sum(self._h, _dp(y), _dp(out)))
         return out
 

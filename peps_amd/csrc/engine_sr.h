@@ -625,7 +625,69 @@ __global__ __launch_bounds__(256) void sr_expand_kernel(const T *__restrict__ o,
 template <typename T>
 void Engine<T>::sr_gram(const void *remote_o, const int32_t *remote_cfg, int n_remote, double *out) {
   if constexpr (kCplx) {
-    PG_REQUIRE(false, 1, "stochastic reconfiguration is not implemented for the complex element type");
+    // TenElemT = QLTEN_Complex (MinSRTMatrix is templated over it, minsr_tmatrix.h:38-150): ip_ij = O*_i * O*_j = sum conj(O*_i) O*_j
+    // (SplitIndexTPS::operator*), one complex tensor GEMM with the A operand conjugated; out = interleaved (re, im) pairs [n][nb][2]
+    PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_gram: no samples");
+    PG_REQUIRE(!remote_o || (remote_cfg && n_remote > 0), 1, "sr_gram: bad remote batch");
+    const int sites = Ly_ * Lx_;
+    const long n = (long)sites * dp_ * slot_;
+    PG_REQUIRE(n < (1l << 30), 1, "sr_gram: parameter count exceeds the 32-bit strides of the tensor GEMM");
+    const int nb = remote_o ? n_remote : sr_n_;
+    auto expand = [&](const T *o, const int *cfg, int cnt) {
+      T *buf = (T *)arena_.alloc(sizeof(T) * (size_t)cnt * n);
+      hipLaunchKernelGGL(sr_expand_kernel<T>, dim3((unsigned)((slot_ + 255) / 256), sites, cnt), dim3(256), 0, stream_, o, cfg, buf,
+                         sites, slot_, dp_, (const int *)sr_ne_);
+      PG_CHECK_HIP(hipGetLastError());
+      return buf;
+    };
+    T *ea = expand((const T *)sr_o_, (const int *)sr_cfg_, sr_n_);
+    T *eb = remote_o ? expand((const T *)remote_o, (const int *)remote_cfg, nb) : ea;
+    const int bs = (int)std::min<long>(1024, ((1l << 30) - 1) / n) & ~63;
+    PG_REQUIRE(bs >= 64, 1, "sr_gram: parameter count too large for the blocked Gram");
+    const int groups = sites * dp_;
+    std::vector<double> h(2 * (size_t)sr_n_ * nb, 0.0), part;
+    for (int ib = 0; ib < sr_n_; ib += bs) {
+      const int ni = std::min(bs, sr_n_ - ib);
+      for (int jb = remote_o ? 0 : ib; jb < nb; jb += bs) {
+        const int nj = std::min(bs, nb - jb);
+        const long tiles = (long)((ni + 63) / 64) * ((nj + 63) / 64);
+        int split = 1;
+        for (int c = 1; c <= groups; ++c)
+          if (groups % c == 0 && tiles * c <= 2048) split = c;
+        const long chunk = n / split;
+        T *d = (T *)arena_.alloc(sizeof(T) * (size_t)split * ni * nj);
+        PG_CHECK_HIP(hipMemsetAsync(d, 0, sizeof(T) * (size_t)split * ni * nj, stream_));
+        TGemmDesc g;
+        g.I[2] = ni; g.sAi[2] = (int)n; g.sCi[2] = nj;
+        g.K[2] = (int)chunk; g.sAk[2] = 1; g.sBk[2] = 1;
+        g.J[2] = nj; g.sBj[2] = (int)n; g.sCj[2] = 1;
+        g.wA = chunk; g.wB = chunk; g.wC = (long)ni * nj;
+        g.nbatch = split;
+        g.conjA = 1;
+        tgemm_launch<T, T, T, T>(stream_, g, ea + (size_t)ib * n, eb + (size_t)jb * n, d);
+        part.resize(2 * (size_t)split * ni * nj);
+        PG_CHECK_HIP(hipMemcpyAsync(part.data(), d, sizeof(double) * part.size(), hipMemcpyDeviceToHost, stream_));
+        PG_CHECK_HIP(hipStreamSynchronize(stream_));
+        arena_.free(d);
+        for (int sp = 0; sp < split; ++sp)
+          for (int i2 = 0; i2 < ni; ++i2) {
+            const double *src = &part[2 * (((size_t)sp * ni + i2) * nj)];
+            double *dst = &h[2 * ((size_t)(ib + i2) * nb + jb)];
+            for (int j2 = 0; j2 < 2 * nj; ++j2) dst[j2] += src[j2];
+          }
+      }
+    }
+    if (!remote_o)   // blocks below the diagonal were not computed: ip_ij = conj(ip_ji); ip_ii = sum |O*_i|^2 is real
+      for (int i2 = 0; i2 < sr_n_; ++i2) {
+        h[2 * ((size_t)i2 * nb + i2) + 1] = 0.0;
+        for (int j2 = 0; j2 < i2; ++j2) {
+          h[2 * ((size_t)i2 * nb + j2)] = h[2 * ((size_t)j2 * nb + i2)];
+          h[2 * ((size_t)i2 * nb + j2) + 1] = -h[2 * ((size_t)j2 * nb + i2) + 1];
+        }
+      }
+    std::copy(h.begin(), h.end(), out);
+    if (eb != ea) arena_.free(eb);
+    arena_.free(ea);
   } else {
   PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_gram: no samples");
   PG_REQUIRE(!remote_o || (remote_cfg && n_remote > 0), 1, "sr_gram: bad remote batch");
@@ -691,8 +753,18 @@ void Engine<T>::sr_gram(const void *remote_o, const int32_t *remote_cfg, int n_r
 
 template <typename T>
 void Engine<T>::sr_weighted_sum(const double *y, double *out) {
-  if constexpr (kCplx) {
-    PG_REQUIRE(false, 1, "stochastic reconfiguration is not implemented for the complex element type");
+  if constexpr (kCplx) {       // sum_i y_i O*_i with complex weights (interleaved pairs in, interleaved pairs out)
+    PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_weighted_sum: no samples");
+    const int sites = Ly_ * Lx_;
+    const size_t n = (size_t)sites * dp_ * slot_ * 2;
+    PG_CHECK_HIP(hipMemcpyAsync(sr_delta_, y, sizeof(double) * 2 * sr_n_, hipMemcpyHostToDevice, stream_));
+    hipLaunchKernelGGL(sr_accum_cplx_kernel<T>, dim3((unsigned)((slot_ + 255) / 256), sites), dim3(256), 0, stream_, (const T *)sr_o_,
+                       (const int *)sr_cfg_, (const double *)sr_delta_, 1.0, sr_out_, sr_n_, sites, slot_, dp_);
+    PG_CHECK_HIP(hipGetLastError());
+    std::vector<double> h(n);
+    PG_CHECK_HIP(hipMemcpyAsync(h.data(), sr_out_, n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    PG_CHECK_HIP(hipStreamSynchronize(stream_));
+    sr_convert(h.data(), out, false);
   } else {
   PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_weighted_sum: no samples");
   const int sites = Ly_ * Lx_;
@@ -711,9 +783,7 @@ void Engine<T>::sr_weighted_sum(const double *y, double *out) {
 // device-to-device copy of the local sample store (for torch.distributed send / recv of the ring exchange)
 template <typename T>
 void Engine<T>::sr_copy_samples(void *dst_o, int32_t *dst_cfg) {
-  if constexpr (kCplx) {
-    PG_REQUIRE(false, 1, "stochastic reconfiguration is not implemented for the complex element type");
-  } else {
+  {
   PG_REQUIRE(sr_o_ != nullptr && sr_n_ > 0, 3, "sr_copy_samples: no samples");
   const size_t sites = (size_t)Ly_ * Lx_;
   PG_CHECK_HIP(hipMemcpyAsync(dst_o, sr_o_, sizeof(T) * (size_t)sr_n_ * sites * slot_, hipMemcpyDeviceToDevice, stream_));

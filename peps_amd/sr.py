@@ -160,6 +160,8 @@ class TorchRing:
 
     def allgather(self, arr):
         import torch
+        if np.iscomplexobj(arr):          # complex values travel as interleaved (re, im) pairs (MPI_CXX_DOUBLE_COMPLEX in the reference)
+            return self.allgather(np.ascontiguousarray(arr, dtype=np.complex128).view(np.float64)).view(np.complex128)
         t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(self.device)
         out = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t)
@@ -167,6 +169,8 @@ class TorchRing:
 
     def allreduce(self, arr):
         import torch
+        if np.iscomplexobj(arr):
+            return self.allreduce(np.ascontiguousarray(arr, dtype=np.complex128).view(np.float64)).view(np.complex128)
         t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t.cpu().numpy()
@@ -187,7 +191,7 @@ class DeviceSampleBatch:
         import torch
         from . import capi
         sites = self.ctx.rows * self.ctx.cols
-        dt = torch.float32 if self.ctx.dtype == capi.F32 else torch.float64
+        dt = torch.float32 if self.ctx.dtype == capi.F32 else torch.complex128 if self.ctx.dtype == capi.C128 else torch.float64
         o = torch.empty((self.n, sites, self.ctx.D ** 4), dtype=dt, device=device)
         c = torch.empty((self.n, sites), dtype=torch.int32, device=device)
         self.ctx.sr_copy_samples(o.data_ptr(), c.data_ptr())
@@ -216,10 +220,13 @@ def minsr_direction(batch, energy_samples, energy, r_pinv=1e-12, a_pinv=0.0, sof
     world = 1 if ring is None else ring.world
     rank = 0 if ring is None else ring.rank
     ns = ns_local * world
-    eps_local = (np.asarray(energy_samples, dtype=np.float64) - energy) / ns
+    g0 = batch.gram_local()                                                          # round 0
+    cplx = np.iscomplexobj(g0) or np.iscomplexobj(energy_samples)                    # TenElemT = QLTEN_Complex
+    dt = np.complex128 if cplx else np.float64
+    eps_local = np.conj(np.asarray(energy_samples, dtype=dt) - energy) / ns          # conj(Delta E) / Ns (optimizer_impl.h:1139-1146)
     assert eps_local.size == ns_local
-    rows = np.zeros((ns_local, ns), dtype=np.float64)
-    rows[:, rank * ns_local:(rank + 1) * ns_local] = batch.gram_local()            # round 0
+    rows = np.zeros((ns_local, ns), dtype=dt)
+    rows[:, rank * ns_local:(rank + 1) * ns_local] = g0
     if world > 1:
         cur = batch.export(ring.device)
         for rnd in range(1, world):                                                  # rounds 1..P-1
@@ -235,12 +242,12 @@ def minsr_direction(batch, energy_samples, energy, r_pinv=1e-12, a_pinv=0.0, sof
     else:
         all_m, eps_bar = m_local, eps_local
     c = all_m.sum() / ns
-    rows = (rows - m_local[:, None] - all_m[None, :] + c) / ns
+    rows = (rows - m_local[:, None] - np.conj(all_m)[None, :] + c) / ns              # entry - m_i - conj(m_j) + c (minsr_tmatrix.h:141-147)
     t_full = rows if world == 1 else ring.allgather(rows.ravel()).reshape(ns, ns)
-    ev, z = np.linalg.eigh(t_full)                                                   # dsyev, replicated
-    y = z @ (pseudo_inverse_cutoff(ev, r_pinv, a_pinv, soft_cutoff) * (z.T @ eps_bar))
+    ev, z = np.linalg.eigh(t_full)                                                   # dsyev / zheev, replicated
+    y = z @ (pseudo_inverse_cutoff(ev, r_pinv, a_pinv, soft_cutoff) * (z.conj().T @ eps_bar))
     y_local = y[rank * ns_local:(rank + 1) * ns_local]
-    acc = np.concatenate([batch.weighted_sum(y_local).ravel(), batch.sample_sum().ravel()])
+    acc = np.concatenate([np.asarray(batch.weighted_sum(y_local)).ravel(), np.asarray(batch.sample_sum()).ravel()])
     if world > 1:
         acc = ring.allreduce(acc)
     half = acc.size // 2

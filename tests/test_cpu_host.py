@@ -220,6 +220,21 @@ for kw in ({"r_pinv": 1e-12, "a_pinv": 0.0, "soft_cutoff": True}, {"r_pinv": 1e-
     d, nrm = sr.minsr_direction(NumpyBatch(O[mine]), E[mine], float(E.mean()), ring=sr.TorchRing(dist), **kw)
     do, nrmo = osr.minsr_direction(list(O), O.mean(axis=0), E, float(E.mean()), **kw)
     assert np.linalg.norm(d - do) < 1e-9 * nrmo, (rank, kw, np.linalg.norm(d - do), nrmo)
+
+
+class NumpyBatchC(NumpyBatch):
+    """TenElemT = QLTEN_Complex: ip_ij = sum conj(O_i) O_j; batches travel as interleaved (re, im) pairs"""
+    def gram_local(self): return self.o.conj() @ self.o.T
+    def export(self, device): return [torch.from_numpy(self.o.copy().view(np.float64))]
+    def gram_with(self, batch): return self.o.conj() @ batch[0].numpy().view(np.complex128).T
+
+
+Oc = O + 1j * rng.standard_normal(O.shape)
+Ec = E + 1j * rng.standard_normal(E.shape)
+for kw in ({"r_pinv": 1e-12, "a_pinv": 0.0, "soft_cutoff": True}, {"r_pinv": 1e-8, "a_pinv": 1e-10, "soft_cutoff": False}):
+    d, nrm = sr.minsr_direction(NumpyBatchC(Oc[mine]), Ec[mine], complex(Ec.mean()), ring=sr.TorchRing(dist), **kw)
+    do, nrmo = osr.minsr_direction(list(Oc), Oc.mean(axis=0), Ec, complex(Ec.mean()), **kw)
+    assert np.iscomplexobj(d) and np.linalg.norm(d - do) < 1e-9 * nrmo, (rank, kw, np.linalg.norm(d - do), nrmo)
 if rank == 0:
     print("OK")
 dist.destroy_process_group()

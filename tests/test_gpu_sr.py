@@ -159,7 +159,7 @@ def test_sr_matvec_complex_vs_oracle():
     state resident in HBM (O*_i = conj(1 / psi_i) Dag(hole_i), mc_energy_grad_evaluator.h:245-270), their sum and the S-matrix product
     with the positive-definite pairing <a, b> = sum conj(a) b of SplitIndexTPS::operator* (split_index_tps.h:370-377), against the
     oracle's SRSMatrix built from host-side holes: 1e-9."""
-    from peps_amd import capi
+    from peps_amd import capi, sr
     from peps_amd.capi import LEFT, RIGHT, UP, DOWN, HORIZONTAL
     L, D, chi, n = 4, 3, 9, 16
     rng = np.random.default_rng(12)
@@ -228,8 +228,21 @@ def test_sr_matvec_complex_vs_oracle():
         # two different summation orders)
         assert np.max(np.abs(xd.ravel() - xr)) < 1e-4 * np.max(np.abs(xr)) and abs(rd - rr) < 1e-6 * np.linalg.norm(b.ravel()) + 0.5 * rr
         assert np.linalg.norm((full * xd.ravel()) - b.ravel()) <= 1.5 * rtol * np.linalg.norm(b.ravel())
+    # MinSR on the complex store (MinSRTMatrix / ReplicatedEigenSolveComplex are templated over TenElemT): Gram with the conjugated
+    # pairing on the device, epsilon_bar = conj(E_loc - E) / Ns, back-substitution with complex weights -- against the oracle
+    ip = ctx.sr_gram()
+    o2 = np.stack([x.ravel() for x in samples])
+    want_ip = o2.conj() @ o2.T
+    assert np.max(np.abs(ip - want_ip)) < 1e-9 * np.max(np.abs(want_ip)) and np.max(np.abs(ip - ip.conj().T)) == 0.0
+    yw = rng.standard_normal(2 * n) + 1j * rng.standard_normal(2 * n)
+    ws = ctx.sr_weighted_sum(yw)
+    assert np.max(np.abs(ws.ravel() - yw @ o2)) < 1e-9 * np.max(np.abs(yw @ o2))
+    e_loc = rng.standard_normal(2 * n) + 1j * rng.standard_normal(2 * n)
+    for kw in ({"r_pinv": 1e-12, "a_pinv": 0.0, "soft_cutoff": True}, {"r_pinv": 1e-6, "a_pinv": 0.0, "soft_cutoff": False}):
+        dm, nm = sr.minsr_direction(sr.DeviceSampleBatch(ctx), e_loc, complex(e_loc.mean()), **kw)
+        do, no = osr.minsr_direction(samples, mean, e_loc, complex(e_loc.mean()), **kw)
+        assert np.linalg.norm(dm.ravel() - do) < 1e-7 * no and abs(nm - no) < 1e-7 * no, (kw, np.linalg.norm(dm.ravel() - do), no)
     # the host-vector solver of the multi-rank path (peps_amd/sr.py: one all-reduce per product) on the same complex store
-    from peps_amd import sr
     S = sr.DeviceSRSMatrix(ctx, diag_shift=1e-2)
     xh, rh, ih, why_h = sr.conjugate_gradient(S, b, max_iter=200, relative_tolerance=1e-5, residual_recompute_interval=3, full_output=True)
     assert why_h == osr.K_CONVERGED and abs(ih - idv) <= 1 and np.max(np.abs(xh - xd)) < 1e-4 * np.max(np.abs(xd))
