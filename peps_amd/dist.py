@@ -115,6 +115,33 @@ def allreduce_min(vec):
     return _reduce(vec, dist.ReduceOp.MIN)
 
 
+def exchange_valid_configuration(n_invalid, have_valid, cfg):
+    """The collective of MonteCarloEngine::EnsureConfigurationValidity (monte_carlo_engine.h:344-387: MPI_Allgather of the validity
+    flags, MPI_BCast of the configuration of the FIRST valid rank) for ranks that hold many walkers each: every rank passes the number
+    of its invalid walkers, whether it holds a valid one, and the configuration (flat int32, one lattice) of its first valid walker.
+    Returns (total number of invalid walkers over the ranks, or -1 when no rank holds a valid one; the configuration of the lowest
+    rank that holds one).  Without an initialised process group: the local answer."""
+    cfg = np.ascontiguousarray(cfg, dtype=np.int32).ravel()
+    try:
+        import torch
+        import torch.distributed as dist
+        multi = dist.is_initialized() and dist.get_world_size() > 1
+    except ImportError:
+        multi = False
+    if not multi:
+        return (int(n_invalid) if (have_valid or n_invalid == 0) else -1), cfg
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    mine = torch.from_numpy(np.concatenate([[int(n_invalid), int(bool(have_valid))], cfg]).astype(np.int64)).to(dev)
+    allv = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(allv, mine)
+    allv = [t.cpu().numpy() for t in allv]
+    total = int(sum(int(a[0]) for a in allv))
+    src = next((r for r, a in enumerate(allv) if a[1]), None)
+    if src is None:
+        return (0 if total == 0 else -1), cfg
+    return total, allv[src][2:].astype(np.int32)
+
+
 def broadcast_state(ctx, flat, src=0):
     """The parameter broadcast after an optimizer update (replaces the per-tensor MPI_Bcast of
     split_index_tps_impl.h:778-880): rank `src` holds the new state `flat` (upload layout); every rank's context ends up with it.

@@ -208,9 +208,10 @@ int pepshost_mc_sweeps_c128(int rows, int cols, int D, int d, int chi, const dou
 // rescue with the given amplitude window), WarmUp (warm-up sweeps with the NN exchange updater, sanity check,
 // NormalizeStateOrder1).  In place: configs, sitps_flat (the scaled state).  out[0] = overall scale factor, out[1] = walkers
 // rescued, out[2] = warmed up (0 / 1).
-int pepshost_mc_engine_warmup(int rows, int cols, int D, int d, int chi, int dtype, double *sitps_flat, int n, int32_t *configs,
-                              const uint64_t *seeds, int warmup_sweeps, int rescue_enabled, double amp_min, double amp_max,
-                              double *amplitudes_out, double *out) {
+static int mc_engine_warmup_impl(int rows, int cols, int D, int d, int chi, int dtype, double *sitps_flat, int n, int32_t *configs,
+                                 const uint64_t *seeds, int warmup_sweeps, int rescue_enabled, double amp_min, double amp_max,
+                                 double *amplitudes_out, double *out, double (*max_over_ranks)(double),
+                                 int (*exchange_valid_config)(int, int, int32_t *)) {
   return guarded([&]() {
     SplitIndexTPS sitps = make_state_t<double>(rows, cols, D, d, sitps_flat);
     BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), n, dtype, g_device);
@@ -223,7 +224,11 @@ int pepshost_mc_engine_warmup(int rows, int cols, int D, int d, int chi, int dty
     rp.enabled = rescue_enabled != 0;
     if (amp_min > 0.0) rp.amplitude_min_threshold = amp_min;
     if (amp_max > 0.0) rp.amplitude_max_threshold = amp_max;
-    MonteCarloEngine<MCUpdateSquareNNExchangeOBC> eng(sitps, comp, mp, upd, rp);
+    std::function<double(double)> mx;
+    std::function<int(int, int, int32_t *)> ex;
+    if (max_over_ranks) mx = max_over_ranks;
+    if (exchange_valid_config) ex = exchange_valid_config;
+    MonteCarloEngine<MCUpdateSquareNNExchangeOBC> eng(sitps, comp, mp, upd, rp, mx, ex);
     const size_t rescued = eng.RescuedWalkers();
     eng.WarmUp();
     std::copy(comp.config.data(), comp.config.data() + (size_t)n * rows * cols, configs);
@@ -231,6 +236,22 @@ int pepshost_mc_engine_warmup(int rows, int cols, int D, int d, int chi, int dty
     copy_out(comp.amplitude, amplitudes_out);
     out[0] = eng.LastScaleFactor(); out[1] = (double)rescued; out[2] = eng.IsWarmedUp() ? 1.0 : 0.0;
   });
+}
+int pepshost_mc_engine_warmup(int rows, int cols, int D, int d, int chi, int dtype, double *sitps_flat, int n, int32_t *configs,
+                              const uint64_t *seeds, int warmup_sweeps, int rescue_enabled, double amp_min, double amp_max,
+                              double *amplitudes_out, double *out) {
+  return mc_engine_warmup_impl(rows, cols, D, d, chi, dtype, sitps_flat, n, configs, seeds, warmup_sweeps, rescue_enabled, amp_min, amp_max,
+                               amplitudes_out, out, nullptr, nullptr);
+}
+// Several ranks (one process per GPU): max_over_ranks = the MPI_Allreduce(MAX) of NormalizeStateOrder1 (monte_carlo_engine.h:214-222),
+// exchange_valid_config = the MPI_Allgather + MPI_BCast of EnsureConfigurationValidity (:344-387) -- both supplied by the caller
+// (peps_amd/dist.py over torch.distributed); either may be NULL.
+int pepshost_mc_engine_warmup_dist(int rows, int cols, int D, int d, int chi, int dtype, double *sitps_flat, int n, int32_t *configs,
+                                   const uint64_t *seeds, int warmup_sweeps, int rescue_enabled, double amp_min, double amp_max,
+                                   double *amplitudes_out, double *out, double (*max_over_ranks)(double),
+                                   int (*exchange_valid_config)(int, int, int32_t *)) {
+  return mc_engine_warmup_impl(rows, cols, D, d, chi, dtype, sitps_flat, n, configs, seeds, warmup_sweeps, rescue_enabled, amp_min, amp_max,
+                               amplitudes_out, out, max_over_ranks, exchange_valid_config);
 }
 
 // CalEnergyAndHoles (model_energy_solver.h:32-126) for n configurations; model 0 = XXZ (p = jz, jxy,

@@ -1796,9 +1796,10 @@ class MonteCarloEngine {
  public:
   MonteCarloEngine(SplitIndexTPST<TenElemT> &sitps, TPSWaveFunctionComponentT<TenElemT> &comp, const MonteCarloParams &params,
                    MonteCarloSweepUpdater &updater, const ConfigurationRescueParams &rescue = ConfigurationRescueParams(),
-                   std::function<double(double)> max_over_ranks = nullptr)
+                   std::function<double(double)> max_over_ranks = nullptr,
+                   std::function<int(int, int, int32_t *)> exchange_valid_config = nullptr)
       : sitps_(sitps), comp_(comp), params_(params), updater_(updater), rescue_(rescue), max_over_ranks_(std::move(max_over_ranks)),
-        warm_up_(params.is_warmed_up) {
+        exchange_valid_config_(std::move(exchange_valid_config)), warm_up_(params.is_warmed_up) {
     EnsureConfigurationValidity();                 // the constructor's last step (:112-113)
   }
   bool IsWarmedUp() const { return warm_up_; }
@@ -1842,26 +1843,44 @@ class MonteCarloEngine {
       valid[w] = !flags[w] && CheckWaveFunctionAmplitudeValidity(comp_.amplitude[w], rescue_.amplitude_min_threshold, rescue_.amplitude_max_threshold);
       num_valid += valid[w];
     }
-    if (num_valid == n) return;
-    if (!rescue_.enabled)
-      throw std::runtime_error("MonteCarloEngine: " + std::to_string(n - num_valid) + "/" + std::to_string(n) +
-                               " walkers have invalid configurations and configuration rescue is disabled");
-    if (num_valid == 0)
-      throw std::runtime_error("MonteCarloEngine: all walkers have invalid configurations (check bond dimension, truncation cutoff, initial configuration)");
+    // Several ranks (exchange_valid_config_ set): the reference's walkers are its MPI ranks -- MPI_Allgather of the validity flags,
+    // the FIRST valid rank broadcasts its configuration (:344-387).  Here the global order is (rank, walker): the callback is the
+    // collective (every rank calls it, valid or not): in = number of invalid local walkers, whether this rank holds a valid one and
+    // the configuration of its first valid walker; out = that configuration of the lowest rank that holds one; returns the
+    // number of invalid walkers over all ranks, -1 when no rank holds a valid one.
+    const size_t sites = comp_.config.rows() * comp_.config.cols();
+    std::vector<int32_t> donor(sites, 0);
     size_t source = 0;
-    while (!valid[source]) ++source;
+    while (source < n && !valid[source]) ++source;
+    if (source < n)
+      for (size_t r = 0; r < comp_.config.rows(); ++r)
+        for (size_t c = 0; c < comp_.config.cols(); ++c) donor[r * comp_.config.cols() + c] = (int32_t)comp_.config(source, {r, c});
+    long invalid_total = (long)(n - num_valid);
+    bool any_valid = num_valid > 0;
+    if (exchange_valid_config_) {
+      const int tot = exchange_valid_config_((int)(n - num_valid), num_valid > 0 ? 1 : 0, donor.data());
+      any_valid = tot >= 0;
+      invalid_total = tot;
+    }
+    if (invalid_total == 0) return;
+    if (!rescue_.enabled)
+      throw std::runtime_error("MonteCarloEngine: " + std::to_string(invalid_total) +
+                               " walkers have invalid configurations and configuration rescue is disabled");
+    if (!any_valid)
+      throw std::runtime_error("MonteCarloEngine: all walkers have invalid configurations (check bond dimension, truncation cutoff, initial configuration)");
+    if (num_valid == n) return;                    // (other ranks rescue theirs)
     Configuration cfg = comp_.config;
     for (size_t w = 0; w < n; ++w)
       if (!valid[w])
         for (size_t r = 0; r < cfg.rows(); ++r)
-          for (size_t c = 0; c < cfg.cols(); ++c) cfg(w, {r, c}) = comp_.config(source, {r, c});
+          for (size_t c = 0; c < cfg.cols(); ++c) cfg(w, {r, c}) = donor[r * cfg.cols() + c];
     comp_.config = cfg;
     comp_.InitDevice();
     flags = comp_.EvaluateAmplitudeNoThrow();      // TryConstructWavefunction_(config_valid)
     for (size_t w = 0; w < n; ++w)
       if (flags[w] || !CheckWaveFunctionAmplitudeValidity(comp_.amplitude[w], rescue_.amplitude_min_threshold, rescue_.amplitude_max_threshold))
-        throw std::runtime_error("MonteCarloEngine: rescue FAILED for walker " + std::to_string(w) + " even with the valid configuration of walker " +
-                                 std::to_string(source));
+        throw std::runtime_error("MonteCarloEngine: rescue FAILED for walker " + std::to_string(w) + " even with a valid configuration" +
+                                 (exchange_valid_config_ ? std::string(" of the first valid rank") : " of walker " + std::to_string(source)));
     n_rescued_ += n - num_valid;
     warm_up_ = false;
   }
@@ -1873,6 +1892,7 @@ class MonteCarloEngine {
   MonteCarloSweepUpdater &updater_;
   ConfigurationRescueParams rescue_;
   std::function<double(double)> max_over_ranks_;
+  std::function<int(int, int, int32_t *)> exchange_valid_config_;
   bool warm_up_;
   size_t n_rescued_ = 0;
   double last_scale_ = 1.0;

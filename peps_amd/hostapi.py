@@ -14,7 +14,8 @@ SYMBOLS = ["pepshost_last_error", "pepshost_mc_sweeps", "pepshost_energy_and_hol
            "pepshost_fermion_exact_sum_partial", "pepshost_fermion_mc_sweeps", "pepshost_measure",
            "pepshost_set_truncate_params", "pepshost_set_device", "pepshost_get_device",
            "pepshost_energy_and_holes_c128", "pepshost_exact_sum_partial_c128", "pepshost_exact_sum_finish_c128",
-           "pepshost_mc_energy_grad_partial_c128", "pepshost_mc_sweeps_c128", "pepshost_load_sitps_c128", "pepshost_dump_sitps_c128"]
+           "pepshost_mc_energy_grad_partial_c128", "pepshost_mc_sweeps_c128", "pepshost_load_sitps_c128", "pepshost_dump_sitps_c128",
+           "pepshost_mc_engine_warmup", "pepshost_mc_engine_warmup_dist"]
 
 _lib = None
 
@@ -84,18 +85,40 @@ def mc_sweeps(flat, configs, seeds, chi, updater="exchange", n_sweeps=1, dtype=1
     return cfg, amps, rates
 
 
-def mc_engine_warmup(flat, configs, seeds, chi, warmup_sweeps=0, rescue=True, amp_min=0.0, amp_max=0.0, dtype=1):
+def mc_engine_warmup(flat, configs, seeds, chi, warmup_sweeps=0, rescue=True, amp_min=0.0, amp_max=0.0, dtype=1, max_over_ranks=None,
+                     exchange_valid_config=None):
     """MonteCarloEngine: configuration validity / rescue, warm-up, NormalizeStateOrder1 (monte_carlo_engine.h).
-    Returns (scaled state, configs, amplitudes, overall scale factor, walkers rescued)."""
+    Returns (scaled state, configs, amplitudes, overall scale factor, walkers rescued).
+    Several ranks: max_over_ranks(x) -> max over the ranks (the MPI_Allreduce of NormalizeStateOrder1) and
+    exchange_valid_config(n_invalid, have_valid, cfg) -> (total invalid | -1, cfg of the first valid rank) (the Allgather + BCast of
+    EnsureConfigurationValidity); peps_amd.dist has both (allreduce_max, exchange_valid_configuration).  Both are collectives: every
+    rank must pass them."""
     st = np.array(flat, dtype=np.float64, order="C")
     rows, cols, d, D = _dims(st)
     cfg = np.array(configs, dtype=np.int32, order="C")
     n = cfg.shape[0]
     sd = np.ascontiguousarray(seeds, dtype=np.uint64)
     amps, out = np.zeros(n), np.zeros(3)
-    _ck(lib().pepshost_mc_engine_warmup(rows, cols, D, d, chi, dtype, _p(st, C.c_double), n, _p(cfg, C.c_int32), _p(sd, C.c_uint64),
-                                        warmup_sweeps, int(rescue), C.c_double(amp_min), C.c_double(amp_max), _p(amps, C.c_double),
-                                        _p(out, C.c_double)))
+    if max_over_ranks is None and exchange_valid_config is None:
+        _ck(lib().pepshost_mc_engine_warmup(rows, cols, D, d, chi, dtype, _p(st, C.c_double), n, _p(cfg, C.c_int32), _p(sd, C.c_uint64),
+                                            warmup_sweeps, int(rescue), C.c_double(amp_min), C.c_double(amp_max), _p(amps, C.c_double),
+                                            _p(out, C.c_double)))
+        return st, cfg, amps, float(out[0]), int(out[1])
+    MAXF = C.CFUNCTYPE(C.c_double, C.c_double)
+    EXF = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32))
+    sites = rows * cols
+
+    def _ex(n_invalid, have_valid, ptr):
+        mine = np.ctypeslib.as_array(ptr, shape=(sites,))
+        tot, got = exchange_valid_config(int(n_invalid), bool(have_valid), mine.copy())
+        mine[:] = np.asarray(got, dtype=np.int32).ravel()
+        return int(tot)
+
+    mx = MAXF(lambda x: float(max_over_ranks(float(x)))) if max_over_ranks is not None else C.cast(None, MAXF)
+    ex = EXF(_ex) if exchange_valid_config is not None else C.cast(None, EXF)
+    _ck(lib().pepshost_mc_engine_warmup_dist(rows, cols, D, d, chi, dtype, _p(st, C.c_double), n, _p(cfg, C.c_int32), _p(sd, C.c_uint64),
+                                             warmup_sweeps, int(rescue), C.c_double(amp_min), C.c_double(amp_max), _p(amps, C.c_double),
+                                             _p(out, C.c_double), mx, ex))
     return st, cfg, amps, float(out[0]), int(out[1])
 
 

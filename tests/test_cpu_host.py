@@ -305,3 +305,47 @@ def test_two_rank_state_broadcast_gloo():
                            capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK" in r.stdout
+
+
+RESCUE_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from peps_amd import dist as pdist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+pdist.init("gloo")
+L = 4
+cfg = (np.arange(L * L, dtype=np.int32) + 100 * rank) % 2
+# round 1: rank 0 holds no valid walker (3 invalid), rank 1 holds one (1 invalid): everybody gets rank 1's configuration
+tot, got = pdist.exchange_valid_configuration(3 if rank == 0 else 1, rank == 1, cfg + 7 * rank)
+assert tot == 4 and np.array_equal(got, (np.arange(L * L, dtype=np.int32) + 100) % 2 + 7), (rank, tot, got)
+# round 2: both hold valid walkers: the FIRST valid rank (0) is the donor (monte_carlo_engine.h:372-379)
+tot, got = pdist.exchange_valid_configuration(2, True, cfg + 3 * rank)
+assert tot == 4 and np.array_equal(got, np.arange(L * L, dtype=np.int32) % 2)
+# round 3: nobody holds a valid walker
+tot, got = pdist.exchange_valid_configuration(5, False, cfg)
+assert tot == -1
+# round 4: nothing to rescue
+tot, got = pdist.exchange_valid_configuration(0, True, cfg)
+assert tot == 0
+assert pdist.allreduce_max(np.array([1.0 + rank]))[0] == float(world)
+if rank == 0:
+    print("OK")
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_configuration_rescue_exchange_gloo():
+    """world_size-2 gloo: the collective of MonteCarloEngine::EnsureConfigurationValidity (monte_carlo_engine.h:344-387) as
+    peps_amd.dist.exchange_valid_configuration implements it for ranks that hold many walkers each -- validity counts gathered,
+    the configuration of the first valid rank handed to everybody."""
+    with tempfile.TemporaryDirectory() as td:
+        wp = os.path.join(td, "worker.py")
+        open(wp, "w").write(RESCUE_WORKER)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                            "--master-addr", "127.0.0.1", "--master-port", "29521", wp, ROOT],
+                           capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout

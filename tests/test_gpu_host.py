@@ -244,6 +244,33 @@ def test_monte_carlo_engine_rescue_and_normalize_order1(fixtures_dir):
     # rescue disabled: the reference aborts, the host layer throws
     with pytest.raises(RuntimeError):
         host.mc_engine_warmup(flat, cfgs, np.arange(12, dtype=np.uint64) + 11, 16, 0, False, thr, 0.0, F64)
+    # several ranks (monte_carlo_engine.h:344-387, :214-222): the two collectives are callbacks.  A stand-in for a second rank: the
+    # local batch = the eleven walkers below the largest amplitude, the window admits only that largest one -- EVERY local walker is
+    # invalid, the "other rank" holds the valid configuration and a larger maximum: all eleven take its configuration, the state is
+    # scaled by the other rank's maximum.
+    top = int(np.argmax(a0))
+    rest = np.array([w for w in range(12) if w != top])
+    thr_top = float(np.sort(a0)[-2] * 1.0001)
+    assert a0[top] > thr_top
+    calls = []
+
+    def exchange(n_invalid, have_valid, cfg):
+        calls.append((n_invalid, have_valid))
+        return n_invalid, cfgs[top].ravel().astype(np.int32)        # (the other rank: no invalid walker, it is the first valid rank)
+
+    st, out_cfg, amps, scale, rescued = host.mc_engine_warmup(flat, cfgs[rest], np.arange(11, dtype=np.uint64) + 11, 16, 0, True, thr_top, 0.0, F64,
+                                                              lambda x: max(x, 3.0 * a0[top]), exchange)
+    assert rescued == 11 and calls == [(11, False)] and all(np.array_equal(out_cfg[w], cfgs[top]) for w in range(11))
+    assert abs(scale * 3.0 * a0[top] - 1.0) < 1e-9 and np.max(np.abs(np.abs(amps) - 1.0 / 3.0)) < 1e-9
+    # a rank with valid and invalid walkers among others: the donor is what the collective returns (the first valid RANK's
+    # configuration), not the local first valid walker
+    other = int(np.argmax(~bad & (np.arange(12) != src)))
+    st, out_cfg, amps, scale, rescued = host.mc_engine_warmup(flat, cfgs, np.arange(12, dtype=np.uint64) + 11, 16, 0, True, thr, 0.0, F64, None,
+                                                              lambda ni, hv, c: (ni + 2, cfgs[other].ravel()))
+    assert rescued == 4 and all(np.array_equal(out_cfg[w], cfgs[other] if bad[w] else cfgs[w]) for w in range(12))
+    # no rank holds a valid walker: the reference aborts
+    with pytest.raises(RuntimeError):
+        host.mc_engine_warmup(flat, cfgs[rest], np.arange(11, dtype=np.uint64) + 11, 16, 0, True, thr_top, 0.0, F64, None, lambda ni, hv, c: (-1, c))
     # with warm-up sweeps (f32): amplitudes stay consistent with the scaled state, max |psi| = 1
     st, out_cfg, amps, scale, rescued = host.mc_engine_warmup(flat, cfgs, np.arange(12, dtype=np.uint64) + 11, 16, 2, True, 0.0, 0.0, F32)
     assert rescued == 0 and abs(np.max(np.abs(amps)) - 1.0) < 1e-5
