@@ -296,6 +296,19 @@ class SquareSpinOneHalfJ1J2XXZModelOBC(SquareSpinOneHalfXXZModelOBC):
         return -0.25 * self.jz2 + ratio * 0.5 * self.jxy2
 
 
+class SpinOneHalfTriHeisenbergSqrPEPS(SquareSpinOneHalfJ1J2XXZModelOBC):
+    """spin_onehalf_triangle_heisenberg_sqrpeps.h:39-112: Heisenberg model of the triangular lattice on a square PEPS -- J = 1 on the
+    nearest-neighbour bonds and on ONE diagonal of every plaquette (LEFTDOWN_TO_RIGHTUP); the other diagonal contributes 0 (:98-100)."""
+
+    def __init__(self):
+        super().__init__(1.0, 1.0, 1.0, 1.0, 0.0)
+
+    def EvaluateNNNEnergy(self, s1, s2, c1, c2, diagonal_dir, tn, contractor, t1, t2, inv_psi):
+        if diagonal_dir != LEFTDOWN_TO_RIGHTUP:
+            return 0.0
+        return super().EvaluateNNNEnergy(s1, s2, c1, c2, diagonal_dir, tn, contractor, t1, t2, inv_psi)
+
+
 def compute_psi_consistency_summary_aligned(psi_list):
     """ComputePsiConsistencySummaryAligned (algorithm/vmc_update/psi_consistency.h:60-107): (mean, max rel. deviation)
     after flipping the samples whose overlap with the largest-magnitude one is negative."""

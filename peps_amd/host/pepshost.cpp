@@ -74,6 +74,9 @@ void energy_and_holes_impl(int rows, int cols, int D, int d, int chi, int dtype,
   } else if (model == 2) {
     SquareSpinOneHalfJ1J2XXZModelOBC m(p[0], p[1], p[2], p[3], p[4]);
     eh = holes_out ? m.CalEnergyAndHoles<true>(sitps, comp) : m.CalEnergyAndHoles<false>(sitps, comp);
+  } else if (model == 3) {
+    SpinOneHalfTriHeisenbergSqrPEPS m;
+    eh = holes_out ? m.CalEnergyAndHoles<true>(sitps, comp) : m.CalEnergyAndHoles<false>(sitps, comp);
   } else {
     TransverseFieldIsingSquareOBC m(p[0]);
     eh = holes_out ? m.CalEnergyAndHoles<true>(sitps, comp) : m.CalEnergyAndHoles<false>(sitps, comp);
@@ -102,6 +105,9 @@ void exact_sum_partial_impl(int rows, int cols, int D, int d, int chi, int dtype
     ExactSumEnergyEvaluator(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
   } else if (model == 2) {
     SquareSpinOneHalfJ1J2XXZModelOBC m(p[0], p[1], p[2], p[3], p[4]);
+    ExactSumEnergyEvaluator(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
+  } else if (model == 3) {
+    SpinOneHalfTriHeisenbergSqrPEPS m;
     ExactSumEnergyEvaluator(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
   } else {
     TransverseFieldIsingSquareOBC m(p[0]);

@@ -1498,6 +1498,36 @@ class SquareSpinOneHalfJ1J2XXZModelOBC : public SquareNNNModelEnergySolver<Squar
       : SquareSpinOneHalfXXZModelMixIn(jz, jxy, jz2, jxy2, pinning_field00) {}
 };
 
+// spin_onehalf_triangle_heisenberg_sqrpeps.h:39-229: the spin-1/2 Heisenberg model of the TRIANGULAR lattice on a square PEPS -- the
+// nearest-neighbour bonds of the square lattice plus ONE diagonal of every plaquette (left-down to right-up), all with J = 1
+// (EvaluateBondEnergy :66-85, EvaluateNNNEnergy :87-112: zero for the other diagonal).  Registry: the generic NNN traversal minus
+// `bond_energy_dr` (:126-127), SzSz_all2all, the row channels (hooks of the XXZ model), the structure factor behind its switch.
+class SpinOneHalfTriHeisenbergSqrPEPS : public SquareNNNModelEnergySolver<SpinOneHalfTriHeisenbergSqrPEPS>,
+                                        public SquareNNNModelMeasurementSolver<SpinOneHalfTriHeisenbergSqrPEPS>,
+                                        public SpinOneHalfMeasurementHooks,
+                                        public SquareSpinOneHalfXXZModelMixIn {
+ public:
+  SpinOneHalfTriHeisenbergSqrPEPS() : SquareSpinOneHalfXXZModelMixIn(1, 1, 1, 1, 0) {}
+  template <typename TenElemT>
+  std::vector<TenElemT> EvaluateNNNEnergy(const SiteIdx &s1, const SiteIdx &s2, DIAGONAL_DIR diagonal_dir,
+                                          TPSWaveFunctionComponentT<TenElemT> &comp, const std::vector<TenElemT> &inv_psi) {
+    if (diagonal_dir != LEFTDOWN_TO_RIGHTUP) return std::vector<TenElemT>(comp.config.walkers(), TenElemT(0));   // :98-100
+    return SquareSpinOneHalfXXZModelMixIn::EvaluateNNNEnergy(s1, s2, diagonal_dir, comp, inv_psi);
+  }
+  ObservableMap EvaluateObservables(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp) {
+    ObservableMap out = SquareNNNModelMeasurementSolver<SpinOneHalfTriHeisenbergSqrPEPS>::EvaluateObservables(sitps, comp);
+    out.values.erase("bond_energy_dr");               // "legacy public API: only the interacting diagonal" (:126-127)
+    AddSzSzAll2All(comp, out);
+    return out;
+  }
+  std::vector<ObservableMeta> DescribeObservables(size_t ly, size_t lx) const {
+    auto base = SquareNNNModelMeasurementSolver<SpinOneHalfTriHeisenbergSqrPEPS>::DescribeObservables(ly, lx);
+    base.erase(std::remove_if(base.begin(), base.end(), [](const ObservableMeta &m) { return m.key == "bond_energy_dr"; }), base.end());
+    DescribeSpinOneHalf(base, ly, lx);
+    return base;
+  }
+};
+
 // square_spinless_fermion.h:51-200: H = -t sum_<ij> (c+_i c_j + h.c.) - t2 sum_<<ij>> (c+_i c_j + h.c.) + V sum_<ij> n_i n_j.
 // psi is recomputed with Trace next to psi' (same contraction path, docs/dev/design/math/
 // fermion-sign-in-bmps-contraction.md), the bosonic inv_psi argument is unused.

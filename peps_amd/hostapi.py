@@ -42,7 +42,8 @@ def _ck(rc):
         raise {1: ValueError, 3: RuntimeError, 4: IndexError}.get(rc, RuntimeError)("pepshost error %d: %s" % (rc, msg))
 
 
-MODEL_ID = {"xxz": 0, "tfim": 1, "j1j2": 2}   # params: xxz (jz, jxy, pinning00); tfim (h,); j1j2 (jz, jxy, jz2, jxy2, pinning00)
+MODEL_ID = {"xxz": 0, "tfim": 1, "j1j2": 2, "triangle": 3}   # params: xxz (jz, jxy, pinning00); tfim (h,); j1j2 (jz, jxy, jz2, jxy2, pinning00);
+# triangle (SpinOneHalfTriHeisenbergSqrPEPS: none; energy_and_holes / exact_sum_partial)
 
 
 def _dims(flat):

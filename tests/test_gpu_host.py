@@ -371,6 +371,31 @@ def test_j1j2_energy_fixed_configs_and_exact_sum(dt, tol):
     assert abs(e / e_o - 1) < tol
 
 
+@pytest.mark.parametrize("dt,tol", [(F64, 1e-9), (F32, 2e-5)])
+def test_triangle_heisenberg_energy_and_exact_sum(dt, tol):
+    """SpinOneHalfTriHeisenbergSqrPEPS (spin_onehalf_triangle_heisenberg_sqrpeps.h:39-112): the Heisenberg model of the triangular
+    lattice on a square PEPS -- nearest-neighbour bonds + the left-down -> right-up diagonal of every plaquette, the other diagonal
+    contributing nothing -- local energies against the oracle on identical configurations, the 3x3 exact-sum energy against the
+    oracle's, and the difference to the J1-J2 model with both diagonals (the dropped diagonal is not zero on this state)."""
+    host = _host()
+    L, D, chi = 5, 3, 9
+    s = synthetic.make_sitps(L, D)
+    cfgs = synthetic.make_configs(L, 5, "heisenberg")
+    ref = _oracle_energy(s, cfgs, chi, vmc.SpinOneHalfTriHeisenbergSqrPEPS())
+    amps, en, holes, psi = host.energy_and_holes(synthetic.sitps_to_flat(s, D), cfgs, chi, "triangle", (), True, dt)
+    _, en_j1j2, _, _ = host.energy_and_holes(synthetic.sitps_to_flat(s, D), cfgs, chi, "j1j2", (1.0, 1.0, 1.0, 1.0, 0.0), False, dt)
+    for w, (a, e, h, ps) in enumerate(ref):
+        assert abs(amps[w] / a - 1) < tol
+        assert abs(en[w] - e) < tol * max(1.0, abs(e)) * 10
+    assert np.max(np.abs(en - en_j1j2)) > 1e-2
+    s3 = synthetic.make_sitps(3, 2)
+    all_cfg = np.array(vmc.all_product_configs(2, 3, 3)).astype(np.int32)
+    packed = host.exact_sum_partial(synthetic.sitps_to_flat(s3, 2), all_cfg, 16, "triangle", (), 0, 1, 128, dt)
+    e, grad = host.exact_sum_finish(packed, (3, 3, 2, 2))
+    e_o, g_o, _ = vmc.exact_sum_energy_evaluator(s3, list(all_cfg), BMPSTruncateParams.SVD(16, 16, 0.0), vmc.SpinOneHalfTriHeisenbergSqrPEPS())
+    assert abs(e / e_o - 1) < tol
+
+
 @pytest.mark.parametrize("scheme,name", [(1, "Variational2Site"), (2, "Variational1Site")])
 def test_xxz_energy_with_variational_truncate_params(scheme, name):
     """The C++ solver with BMPSTruncateParams::Variational2Site / 1Site (bmps.h:81-97): local energies and
