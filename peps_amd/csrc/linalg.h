@@ -545,12 +545,16 @@ inline void launch_chol_upper(hipStream_t s, int nbatch, double *G, long wG, int
     const size_t smem = chol_blocked_smem_bytes(n);
     // (four blocks per CU -- 128 registers, 300 bytes of scratch -- measured on the real state: cholesky + trunc_gram 484 -> 531 ms)
     static const int minb = getenv("PEPSGPU_CHB_MINB") ? atoi(getenv("PEPSGPU_CHB_MINB")) : 3;
-    if (minb >= 4) {
+    if (minb == 2) {          // (two blocks per CU, 256 registers: no scratch)
+      allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 2>), smem);
+      hipLaunchKernelGGL((chol_blocked_kernel<T, 2>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
+                         ndyn_mul, run_flag);
+    } else if (minb >= 4) {
       allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 4>), smem);
       hipLaunchKernelGGL((chol_blocked_kernel<T, 4>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
                          ndyn_mul, run_flag);
     } else {
-      static const int pfd = getenv("PEPSGPU_CHB_PF") ? atoi(getenv("PEPSGPU_CHB_PF")) : 3;
+      static const int pfd = getenv("PEPSGPU_CHB_PF") ? atoi(getenv("PEPSGPU_CHB_PF")) : 2;     // (real leg, 8192 walkers: cholesky 925 ms per two steps with three k-steps in flight, 908 with two, 963 with five, 986 with eight; two blocks per CU: 979)
       if (pfd >= 8) {
         allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3, 8>), smem);
         hipLaunchKernelGGL((chol_blocked_kernel<T, 3, 8>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
@@ -558,6 +562,10 @@ inline void launch_chol_upper(hipStream_t s, int nbatch, double *G, long wG, int
       } else if (pfd >= 5) {
         allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3, 5>), smem);
         hipLaunchKernelGGL((chol_blocked_kernel<T, 3, 5>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
+                           ndyn_mul, run_flag);
+      } else if (pfd == 2) {
+        allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3, 2>), smem);
+        hipLaunchKernelGGL((chol_blocked_kernel<T, 3, 2>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
                            ndyn_mul, run_flag);
       } else {
         allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3>), smem);
