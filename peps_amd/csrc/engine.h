@@ -1175,7 +1175,12 @@ class Engine : public EngineBase {
         // round 4: all three contractions in one launch (tgemm_chain3_kernel: tmp1 and tmp2 resident in LDS, the bond x walked in
         // chunks when the live intermediates exceed the buffers); PEPSGPU_NO_BTEN_CHAIN3=1 for the two-stage chain + separate launch
         static const bool no_bt3 = getenv("PEPSGPU_NO_BTEN_CHAIN3") != nullptr;
-        if (!no_bt3) {
+        // ... when the bond x is walked in at most three chunks of the 4096-float buffers (static extents; they follow the live bonds
+        // through the bond shrink): with the bonds of a real state (x = b2 = 32: sixteen chunks of two) the three-stage kernel is 2 %
+        // slower than the two-stage chain + separate launch (368 against 375 sweeps/s at 2048 walkers)
+        const long per_x = (long)p1 * b1 * b2;
+        const bool few_chunks = per_x <= 4096 && (x + (4096 / per_x) - 1) / (4096 / per_x) <= 3;
+        if (!no_bt3 && few_chunks) {
           TGemmDesc g3;
           g3.I[1] = x; g3.I[2] = s2; g3.sCi[1] = s2 * y; g3.sCi[2] = y;
           g3.K[1] = b2; g3.K[2] = s1; g3.sBk[1] = s1 * y; g3.sBk[2] = y;
