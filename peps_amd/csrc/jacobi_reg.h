@@ -695,8 +695,11 @@ __global__ __launch_bounds__(NW * 64, CPL <= 8 ? 4 : 2) void jacobi_rows_grp_ker
     }
     __syncthreads();
     for (int sr = 0; sr < 2 * np - 1; ++sr) {
-      // every row of block a against every row of block b: JG_RB steps of JG_RB disjoint pairs (b turns by one row a step)
-#pragma unroll 1
+      // every row of block a against every row of block b: JG_RB steps of JG_RB disjoint pairs (b turns by one row a step).
+      // Unrolled (round 4): the turn of b is register renaming instead of 36 v_mov per step -- a fifth of the instructions of the
+      // kernel were moves; Jacobi category of the real leg 1 745 -> 1 602 ms per two steps (the three-step loop above stays rolled:
+      // unrolled too it spills 17 registers at the four blocks per CU of the 8-column form for 1 % more)
+#pragma unroll
       for (int t = 0; t < JG_RB; ++t) {
         float g[JG_RB];
 #pragma unroll
