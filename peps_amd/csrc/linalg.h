@@ -412,20 +412,20 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
       for (int c = 0; c < CH_NB; ++c) {
         const double piv = chb_readlane(d[c], c);
         const bool live = c < nb && piv > thresh;             // wave-uniform
-        if (live) {
-          double sc = __builtin_amdgcn_rsq(piv);              // ~2^-26 relative; two Newton steps -> float64
-          sc = sc * (1.5 - 0.5 * piv * sc * sc);
-          sc = sc * (1.5 - 0.5 * piv * sc * sc);
-          d[c] *= sc;
+        // branch-free (round 4): a dropped pivot zeroes its row and the updates below become no-ops -- under `if (live)` the
+        // compiler copied the whole d[] (16 v_mov_b64) at the join of every pivot step, 256 moves per panel on the one wave
+        // every other wave of the block waits for
+        const double pv = live ? piv : 1.0;
+        double sc = __builtin_amdgcn_rsq(pv);                 // ~2^-26 relative; two Newton steps -> float64
+        sc = sc * (1.5 - 0.5 * pv * sc * sc);
+        sc = sc * (1.5 - 0.5 * pv * sc * sc);
+        d[c] = live ? d[c] * sc : 0.0;
 #pragma unroll
-          for (int c2 = c + 1; c2 < CH_NB; ++c2) {
-            const double f = chb_readlane(d[c], c2);
-            d[c2] -= f * d[c];
-          }
-          livemask |= 1u << c;
-        } else {
-          d[c] = 0.0;
+        for (int c2 = c + 1; c2 < CH_NB; ++c2) {
+          const double f = chb_readlane(d[c], c2);
+          d[c2] -= f * d[c];
         }
+        livemask |= live ? 1u << c : 0u;
       }
 #pragma unroll
       for (int c = 0; c < CH_NB; ++c)

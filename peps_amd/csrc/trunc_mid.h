@@ -98,21 +98,19 @@ __device__ __forceinline__ int lds_chol_blocked(double *__restrict__ sG, const A
       for (int c = 0; c < 16; ++c) {
         const double piv = chb_readlane(d[c], c);
         const bool live = c < nb && piv > thresh && cnt < kcap;   // wave-uniform
-        if (live) {
-          double sc = __builtin_amdgcn_rsq(piv);                  // ~2^-26 relative; two Newton steps -> float64
-          sc = sc * (1.5 - 0.5 * piv * sc * sc);
-          sc = sc * (1.5 - 0.5 * piv * sc * sc);
-          d[c] *= sc;
+        // branch-free (round 4, as chol_blocked_kernel): no copy of d[] at the join of every pivot step
+        const double pv = live ? piv : 1.0;
+        double sc = __builtin_amdgcn_rsq(pv);                     // ~2^-26 relative; two Newton steps -> float64
+        sc = sc * (1.5 - 0.5 * pv * sc * sc);
+        sc = sc * (1.5 - 0.5 * pv * sc * sc);
+        d[c] = live ? d[c] * sc : 0.0;
 #pragma unroll
-          for (int c2 = c + 1; c2 < 16; ++c2) {
-            const double f = chb_readlane(d[c], c2);
-            d[c2] -= f * d[c];
-          }
-          livemask |= 1u << c;
-          ++cnt;
-        } else {
-          d[c] = 0.0;
+        for (int c2 = c + 1; c2 < 16; ++c2) {
+          const double f = chb_readlane(d[c], c2);
+          d[c2] -= f * d[c];
         }
+        livemask |= live ? 1u << c : 0u;
+        cnt += live ? 1 : 0;
       }
       if (lane < 16) {
         double dg = 0.0;
