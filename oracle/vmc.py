@@ -8,6 +8,8 @@ Restates (bosonic paths):
   include/qlpeps/algorithm/vmc_update/model_solvers/base/bond_traversal_mixin.h:113-144
   include/qlpeps/algorithm/vmc_update/model_solvers/square_spin_onehalf_xxz_obc.h:72-104
   include/qlpeps/algorithm/vmc_update/model_solvers/transverse_field_ising_square_obc.h:160-247
+  include/qlpeps/algorithm/vmc_update/model_solvers/spin_onehalf_triangle_heisenberg_sqrpeps.h:39-112
+  include/qlpeps/algorithm/vmc_update/model_solvers/spin_onehalf_triangle_heisenbergJ1J2_sqrpeps.h:48-463
   include/qlpeps/algorithm/vmc_update/exact_summation_energy_evaluator.h:74-95,173-302
 Oracle = test infrastructure only.
 """
@@ -307,6 +309,150 @@ class SpinOneHalfTriHeisenbergSqrPEPS(SquareSpinOneHalfJ1J2XXZModelOBC):
         if diagonal_dir != LEFTDOWN_TO_RIGHTUP:
             return 0.0
         return super().EvaluateNNNEnergy(s1, s2, c1, c2, diagonal_dir, tn, contractor, t1, t2, inv_psi)
+
+
+class SpinOneHalfTriJ1J2HeisenbergSqrPEPS:
+    """spin_onehalf_triangle_heisenbergJ1J2_sqrpeps.h:48-446: J1-J2 Heisenberg model of the triangular lattice on a square PEPS.
+    J1 = 1 bonds: horizontal, vertical and the left-down -> right-up diagonal of every plaquette; J2 bonds (distance sqrt 3 on the
+    triangular lattice): the other plaquette diagonal (r, c)-(r+1, c+1), the flat sqrt5 link (r+1, c)-(r, c+2) of a 2 x 3 window and
+    the steep sqrt5 link (r+2, c)-(r, c+1) of a 3 x 2 window.  Own traversal (CalEnergyAndHolesImpl :304-446): the row pass carries
+    the horizontal bonds on BTen and both diagonals + the flat link on BTen2; the column pass carries the vertical bonds on BTen and
+    the steep link on BTen2 (GrowFullBTen2(DOWN, col, 3))."""
+
+    def __init__(self, j2):
+        self.j2 = j2
+
+    @staticmethod
+    def _bond(c1, c2, psi_ex_fn, inv_psi):
+        """0.25 for equal spins, else -0.25 + 0.5 conj(psi_ex / psi)   (:338-345 and the seven other bond blocks)"""
+        if c1 == c2:
+            return 0.25
+        return -0.25 + np.conj(psi_ex_fn() * inv_psi) * 0.5
+
+    def traverse(self, sitps, comp, calchols, on_bond):
+        """The bond traversal of :317-444; on_bond(kind, s1, s2, value) for kind in h / v / ur (J1) and dr / flat / steep (J2)."""
+        tn, c, cfg = comp.tn, comp.contractor, comp.config
+        rows, cols = tn.rows, tn.cols
+        holes = [[None] * cols for _ in range(rows)]
+        psi_list = []
+        T = lambda s: sitps[s[0]][s[1]]
+        c.SetTruncateParams(comp.trun_para)
+        c.GenerateBMPSApproach(tn, UP)                                    # :317
+        for row in range(rows):
+            c.InitBTen(tn, LEFT, row)                                     # :320
+            c.GrowFullBTen(tn, RIGHT, row, 1, True)
+            psi = c.Trace(tn, (row, 0), HORIZONTAL)                       # :322
+            inv_psi = 1.0 / psi
+            psi_list.append(psi)
+            for col in range(cols):
+                s1 = (row, col)
+                if calchols:
+                    holes[row][col] = np.conj(c.PunchHole(tn, s1, HORIZONTAL))          # :329
+                if col < cols - 1:
+                    s2 = (row, col + 1)
+                    c1, c2 = int(cfg[s1]), int(cfg[s2])
+                    on_bond("h", s1, s2, self._bond(c1, c2, lambda: c.ReplaceNNSiteTrace(tn, s1, s2, HORIZONTAL, T(s1)[c2], T(s2)[c1]), inv_psi))
+                    c.ShiftBTenWindow(tn, RIGHT)                          # :346
+            if row < rows - 1:
+                c.InitBTen2(tn, LEFT, row)                                # :350
+                c.GrowFullBTen2(tn, RIGHT, row, 2, True)
+                for col in range(cols - 1):
+                    s1, s2 = (row + 1, col), (row, col + 1)               # :355-367 J1 diagonal
+                    c1, c2 = int(cfg[s1]), int(cfg[s2])
+                    on_bond("ur", s1, s2, self._bond(c1, c2, lambda: c.ReplaceNNNSiteTrace(
+                        tn, (row, col), LEFTDOWN_TO_RIGHTUP, HORIZONTAL, T(s1)[c2], T(s2)[c1]), inv_psi))
+                    s1, s2 = (row, col), (row + 1, col + 1)               # :369-381 J2 diagonal
+                    c1, c2 = int(cfg[s1]), int(cfg[s2])
+                    on_bond("dr", s1, s2, self._bond(c1, c2, lambda: c.ReplaceNNNSiteTrace(
+                        tn, (row, col), LEFTUP_TO_RIGHTDOWN, HORIZONTAL, T(s1)[c2], T(s2)[c1]), inv_psi))
+                    if col < cols - 2:                                    # :383-397 flat sqrt5 link
+                        s1, s2 = (row + 1, col), (row, col + 2)
+                        c1, c2 = int(cfg[s1]), int(cfg[s2])
+                        on_bond("flat", s1, s2, self._bond(c1, c2, lambda: c.ReplaceSqrt5DistTwoSiteTrace(
+                            tn, (row, col), LEFTDOWN_TO_RIGHTUP, HORIZONTAL, T(s1)[c2], T(s2)[c1]), inv_psi))
+                    c.ShiftBTen2Window(tn, RIGHT, row)                    # :398
+                c.ShiftBMPSWindow(tn, DOWN)                               # :400
+        c.GenerateBMPSApproach(tn, LEFT)                                  # :404
+        for col in range(cols):
+            c.InitBTen(tn, UP, col)
+            c.GrowFullBTen(tn, DOWN, col, 2, True)
+            psi = c.Trace(tn, (0, col), VERTICAL)
+            inv_psi = 1.0 / psi
+            psi_list.append(psi)
+            for row in range(rows - 1):
+                s1, s2 = (row, col), (row + 1, col)
+                c1, c2 = int(cfg[s1]), int(cfg[s2])
+                on_bond("v", s1, s2, self._bond(c1, c2, lambda: c.ReplaceNNSiteTrace(tn, s1, s2, VERTICAL, T(s1)[c2], T(s2)[c1]), inv_psi))
+                if row < rows - 2:
+                    c.ShiftBTenWindow(tn, DOWN)
+            if col < cols - 1:
+                c.InitBTen2(tn, UP, col)                                  # :425
+                c.GrowFullBTen2(tn, DOWN, col, 3, True)
+                for row in range(rows - 2):                               # :428-442 steep sqrt5 link
+                    s1, s2 = (row + 2, col), (row, col + 1)
+                    c1, c2 = int(cfg[s1]), int(cfg[s2])
+                    on_bond("steep", s1, s2, self._bond(c1, c2, lambda: c.ReplaceSqrt5DistTwoSiteTrace(
+                        tn, (row, col), LEFTDOWN_TO_RIGHTUP, VERTICAL, T(s1)[c2], T(s2)[c1]), inv_psi))
+                    if row < rows - 3:
+                        c.ShiftBTen2Window(tn, DOWN, col)
+                c.ShiftBMPSWindow(tn, RIGHT)
+        return holes, psi_list
+
+    def CalEnergyAndHoles(self, sitps, comp, calchols=True):
+        e = {"h": 0.0, "v": 0.0, "ur": 0.0, "dr": 0.0, "flat": 0.0, "steep": 0.0}
+
+        def on_bond(kind, s1, s2, val):
+            e[kind] = e[kind] + val
+        holes, psi_list = self.traverse(sitps, comp, calchols, on_bond)
+        return (e["h"] + e["v"] + e["ur"]) + self.j2 * (e["dr"] + e["flat"] + e["steep"]), holes, psi_list      # :445
+
+    def EvaluateObservables(self, sitps, comp):
+        """Registry of :65-277: energy, spin_z, bond_energy_h / v / ur (J1 bonds only; the J2 links enter the energy scalar),
+        SzSz_row / SmSp_row / SpSm_row along the middle row, SzSz_all2all (packed upper triangle).  The reference takes the
+        diagonal ratios against a second Trace of the row (`psi2`, :187) whose BTen window has been shifted away by then; the row's
+        own psi -- the same amplitude -- is used here."""
+        tn, cfg = comp.tn, comp.config
+        ly, lx = tn.rows, tn.cols
+        out = {"spin_z": [float(v) - 0.5 for v in cfg.ravel()]}
+        e_h = np.zeros((ly, max(lx - 1, 0)), dtype=complex); e_v = np.zeros((max(ly - 1, 0), lx), dtype=complex)
+        e_ur = np.zeros((max(ly - 1, 0), max(lx - 1, 0)), dtype=complex)
+        tot = {"j1": 0.0, "j2": 0.0}
+
+        def on_bond(kind, s1, s2, val):
+            if kind == "h":
+                e_h[s1] = val
+            elif kind == "v":
+                e_v[s1] = val
+            elif kind == "ur":
+                e_ur[s2[0], s1[1]] = val
+            tot["j1" if kind in ("h", "v", "ur") else "j2"] += val
+        _, psi_list = self.traverse(sitps, comp, False, on_bond)
+        real = not np.iscomplexobj(psi_list[0])
+        cast = (lambda a: [float(np.real(x)) for x in a.ravel()]) if real else (lambda a: list(a.ravel()))
+        out["energy"] = [tot["j1"] + self.j2 * tot["j2"]]
+        out["bond_energy_h"], out["bond_energy_v"], out["bond_energy_ur"] = cast(e_h), cast(e_v), cast(e_ur)
+        row = ly // 2                                                      # :131-171
+        sz1 = float(cfg[row, lx // 4]) - 0.5
+        out["SzSz_row"] = [sz1 * (float(cfg[row, lx // 4 + i]) - 0.5) for i in range(1, lx // 2 + 1)]
+        c = comp.contractor
+        c.GenerateBMPSApproach(tn, UP)
+        for _ in range(row):
+            c.ShiftBMPSWindow(tn, DOWN)
+        c.InitBTen(tn, LEFT, row)
+        c.GrowFullBTen(tn, RIGHT, row, 1, True)
+        inv_psi = 1.0 / c.Trace(tn, (row, 0), HORIZONTAL)
+        for _ in range(lx - 1):
+            c.ShiftBTenWindow(tn, RIGHT)
+        corr = measure_spin_onehalf_off_diag_order_in_row(sitps, comp, inv_psi, row)
+        zero = [0.0] * len(corr)
+        if int(cfg[row, lx // 4]) == 0:
+            out["SmSp_row"], out["SpSm_row"] = zero, corr
+        else:
+            out["SmSp_row"], out["SpSm_row"] = corr, zero
+        flat = [int(v) for v in cfg.ravel()]                               # :260-275, :449-463: +-0.25, diagonal 0.25
+        out["SzSz_all2all"] = [0.25 if flat[i] == flat[j] else -0.25 for i in range(len(flat)) for j in range(i, len(flat))]
+        self.last_psi_summary = compute_psi_consistency_summary_aligned(psi_list)
+        return out
 
 
 def compute_psi_consistency_summary_aligned(psi_list):

@@ -23,8 +23,10 @@ typedef float jr_f2 __attribute__((ext_vector_type(2)));
 
 template <int CTRL>
 __device__ __forceinline__ float jr_dpp_add(float v) {
-  const int iv = __builtin_bit_cast(int, v);
-  const int r = __builtin_amdgcn_update_dpp(iv, iv, CTRL, 0xF, 0xF, false);
+  // old = 0 with bound_ctrl: every lane of these controls (quad_perm, the mirrors) has a valid source, so `old` is never used --
+  // but passing the value itself as `old` (rounds 1-4) ties the result to a copy of it and keeps the compiler's DPP combiner from
+  // folding the move into the add: three instructions (v_mov, v_mov_dpp, v_add) instead of one v_add_f32_dpp per step
+  const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
   return v + __builtin_bit_cast(float, r);
 }
 
@@ -69,10 +71,11 @@ __device__ __forceinline__ int jr_apply(JrRow &x, JrRow &y, float &nx, float &ny
   const float cs = __builtin_amdgcn_rsqf(fmaf(t, t, 1.f)), sn = cs * t;
   const jr_f2 c2 = {cs, cs}, s2 = {sn, sn};
   const jr_f2 xl = x.lo, xh = x.hi, yl = y.lo, yh = y.hi;
-  x.lo = c2 * xl - s2 * yl;
-  x.hi = c2 * xh - s2 * yh;
-  y.lo = s2 * xl + c2 * yl;
-  y.hi = s2 * xh + c2 * yh;
+  const jr_f2 syl = s2 * yl, syh = s2 * yh, sxl = s2 * xl, sxh = s2 * xh;    // (each update may overwrite its own operand: jrx_apply)
+  x.lo = __builtin_elementwise_fma(c2, xl, -syl);
+  x.hi = __builtin_elementwise_fma(c2, xh, -syh);
+  y.lo = __builtin_elementwise_fma(c2, yl, sxl);
+  y.hi = __builtin_elementwise_fma(c2, yh, sxh);
   const float tg = t * g;
   nx = fmaxf(nx - tg, 0.f);
   ny = ny + tg;
@@ -334,14 +337,22 @@ __device__ __forceinline__ void jacobi_rows_reg256_body(float4 (*xch)[JR_BR][64]
 // triangular factor B (B^T B = M M^T, at most 128 x 128) instead of M itself, so rows are at most 128 long (CPL = 2
 // columns per lane) and NW waves x 2 blocks x 16 rows cover it: a quarter of the registers and LDS of the 256 x 256
 // kernel, several walkers resident per CU.  Skips walkers without rows (mdyn == 0: not on this route).
-template <int CPL> struct JrRowT { float v[CPL]; };
+// A row piece is stored as register PAIRS (round 4, late): the rotation runs on v_pk_mul / v_pk_fma_f32, which take 64-bit aligned
+// register pairs -- with the columns as separate floats the allocator scattered them and gathered a pair in front of every packed
+// instruction (a third of the VALU instructions of the tournament loops were v_mov).
+template <int CPL> struct JrRowT {
+  static_assert(CPL % 2 == 0, "columns per lane come in pairs");
+  jr_f2 p[CPL / 2];
+  __device__ __forceinline__ float get(int q) const { return p[q >> 1][q & 1]; }
+  __device__ __forceinline__ void set(int q, float x) { p[q >> 1][q & 1] = x; }
+};
 
 template <int CPL>
 __device__ __forceinline__ float jrx_dot(const JrRowT<CPL> &x, const JrRowT<CPL> &y) {
-  float p = x.v[0] * y.v[0];
+  jr_f2 acc = x.p[0] * y.p[0];
 #pragma unroll
-  for (int q = 1; q < CPL; ++q) p = fmaf(x.v[q], y.v[q], p);
-  return p;
+  for (int k = 1; k < CPL / 2; ++k) acc = __builtin_elementwise_fma(x.p[k], y.p[k], acc);
+  return acc[0] + acc[1];
 }
 
 template <int CPL>
@@ -354,11 +365,13 @@ __device__ __forceinline__ int jrx_apply(JrRowT<CPL> &x, JrRowT<CPL> &y, float &
   float t = copysignf(__builtin_amdgcn_rcpf(az + __builtin_amdgcn_sqrtf(fmaf(az, az, 1.f))), zeta);
   t = go ? t : 0.f;
   const float cs = __builtin_amdgcn_rsqf(fmaf(t, t, 1.f)), sn = cs * t;
+  const jr_f2 cs2 = {cs, cs}, sn2 = {sn, sn};
 #pragma unroll
-  for (int q = 0; q < CPL; ++q) {
-    const float xv = x.v[q], yv = y.v[q];
-    x.v[q] = cs * xv - sn * yv;
-    y.v[q] = sn * xv + cs * yv;
+  for (int k = 0; k < CPL / 2; ++k) {                  // both updates can overwrite their own operand: no copies at the join below
+    const jr_f2 xv = x.p[k], yv = y.p[k];
+    const jr_f2 sy = sn2 * yv, sx = sn2 * xv;
+    x.p[k] = __builtin_elementwise_fma(cs2, xv, -sy);
+    y.p[k] = __builtin_elementwise_fma(cs2, yv, sx);
   }
   const float tg = t * g;
   nx = fmaxf(nx - tg, 0.f);
@@ -435,7 +448,7 @@ __global__ __launch_bounds__(NW * 64) void jacobi_rows_regx_kernel(float *__rest
 #pragma unroll
       for (int q = 0; q < CPL; ++q) {
         const int c = CPL * lane + q;
-        blk[i].v[q] = (r < m && c < len) ? M[(long)r * ld + c] : 0.f;
+        blk[i].set(q, (r < m && c < len) ? M[(long)r * ld + c] : 0.f);
       }
     }
   };
@@ -498,7 +511,7 @@ __global__ __launch_bounds__(NW * 64) void jacobi_rows_regx_kernel(float *__rest
 #pragma unroll
         for (int i = 0; i < JR_BR; ++i)
 #pragma unroll
-          for (int q = 0; q < CPL; ++q) xch[w][i][q][lane] = b[i].v[q];
+          for (int q = 0; q < CPL; ++q) xch[w][i][q][lane] = b[i].get(q);
         if (lane == 0) {
 #pragma unroll
           for (int i = 0; i < JR_BR; ++i) xnorm[w][i] = nb[i];
@@ -507,7 +520,7 @@ __global__ __launch_bounds__(NW * 64) void jacobi_rows_regx_kernel(float *__rest
 #pragma unroll
           for (int i = 0; i < JR_BR; ++i)
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) xch[nwv][i][q][lane] = a[i].v[q];
+            for (int q = 0; q < CPL; ++q) xch[nwv][i][q][lane] = a[i].get(q);
           if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < JR_BR; ++i) xnorm[nwv][i] = na[i];
@@ -520,7 +533,7 @@ __global__ __launch_bounds__(NW * 64) void jacobi_rows_regx_kernel(float *__rest
 #pragma unroll
         for (int i = 0; i < JR_BR; ++i) {
 #pragma unroll
-          for (int q = 0; q < CPL; ++q) b[i].v[q] = xch[src][i][q][lane];
+          for (int q = 0; q < CPL; ++q) b[i].set(q, xch[src][i][q][lane]);
           nb[i] = xnorm[src][i];
         }
       }
@@ -529,7 +542,7 @@ __global__ __launch_bounds__(NW * 64) void jacobi_rows_regx_kernel(float *__rest
 #pragma unroll
         for (int i = 0; i < JR_BR; ++i)
 #pragma unroll
-          for (int q = 0; q < CPL; ++q) xch[w][i][q][lane] = a[i].v[q];
+          for (int q = 0; q < CPL; ++q) xch[w][i][q][lane] = a[i].get(q);
         if (lane == 0) {
 #pragma unroll
           for (int i = 0; i < JR_BR; ++i) xnorm[w][i] = na[i];
@@ -541,7 +554,7 @@ __global__ __launch_bounds__(NW * 64) void jacobi_rows_regx_kernel(float *__rest
 #pragma unroll
         for (int i = 0; i < JR_BR; ++i) {
 #pragma unroll
-          for (int q = 0; q < CPL; ++q) a[i].v[q] = xch[src][i][q][lane];
+          for (int q = 0; q < CPL; ++q) a[i].set(q, xch[src][i][q][lane]);
           na[i] = xnorm[src][i];
         }
       }
@@ -561,7 +574,7 @@ __global__ __launch_bounds__(NW * 64) void jacobi_rows_regx_kernel(float *__rest
 #pragma unroll
       for (int q = 0; q < CPL; ++q) {
         const int c = CPL * lane + q;
-        if (r < m && c < len) M[(long)r * ld + c] = blk[i].v[q];
+        if (r < m && c < len) M[(long)r * ld + c] = blk[i].get(q);
       }
     }
   };
@@ -655,7 +668,7 @@ __global__ __launch_bounds__(NW * 64, CPL <= 8 ? 4 : 2) void jacobi_rows_grp_ker
 #pragma unroll
       for (int q = 0; q < CPL; ++q) {
         const int c = CPL * l16 + q;
-        blk[i].v[q] = (r < m && c < len) ? M[(long)r * ld + c] : 0.f;
+        blk[i].set(q, (r < m && c < len) ? M[(long)r * ld + c] : 0.f);
       }
     }
   };
@@ -721,7 +734,7 @@ __global__ __launch_bounds__(NW * 64, CPL <= 8 ? 4 : 2) void jacobi_rows_grp_ker
 #pragma unroll
         for (int i = 0; i < JG_RB; ++i)
 #pragma unroll
-          for (int q = 0; q < CPL; ++q) xch[w][i][q][l16] = b[i].v[q];
+          for (int q = 0; q < CPL; ++q) xch[w][i][q][l16] = b[i].get(q);
         if (l16 == 0) {
 #pragma unroll
           for (int i = 0; i < JG_RB; ++i) xnorm[w][i] = nb[i];
@@ -730,7 +743,7 @@ __global__ __launch_bounds__(NW * 64, CPL <= 8 ? 4 : 2) void jacobi_rows_grp_ker
 #pragma unroll
           for (int i = 0; i < JG_RB; ++i)
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) xch[np][i][q][l16] = a[i].v[q];
+            for (int q = 0; q < CPL; ++q) xch[np][i][q][l16] = a[i].get(q);
           if (l16 == 0) {
 #pragma unroll
             for (int i = 0; i < JG_RB; ++i) xnorm[np][i] = na[i];
@@ -743,7 +756,7 @@ __global__ __launch_bounds__(NW * 64, CPL <= 8 ? 4 : 2) void jacobi_rows_grp_ker
 #pragma unroll
         for (int i = 0; i < JG_RB; ++i) {
 #pragma unroll
-          for (int q = 0; q < CPL; ++q) b[i].v[q] = xch[src][i][q][l16];
+          for (int q = 0; q < CPL; ++q) b[i].set(q, xch[src][i][q][l16]);
           nb[i] = xnorm[src][i];
         }
       }
@@ -752,7 +765,7 @@ __global__ __launch_bounds__(NW * 64, CPL <= 8 ? 4 : 2) void jacobi_rows_grp_ker
 #pragma unroll
         for (int i = 0; i < JG_RB; ++i)
 #pragma unroll
-          for (int q = 0; q < CPL; ++q) xch[w][i][q][l16] = a[i].v[q];
+          for (int q = 0; q < CPL; ++q) xch[w][i][q][l16] = a[i].get(q);
         if (l16 == 0) {
 #pragma unroll
           for (int i = 0; i < JG_RB; ++i) xnorm[w][i] = na[i];
@@ -764,7 +777,7 @@ __global__ __launch_bounds__(NW * 64, CPL <= 8 ? 4 : 2) void jacobi_rows_grp_ker
 #pragma unroll
         for (int i = 0; i < JG_RB; ++i) {
 #pragma unroll
-          for (int q = 0; q < CPL; ++q) a[i].v[q] = xch[src][i][q][l16];
+          for (int q = 0; q < CPL; ++q) a[i].set(q, xch[src][i][q][l16]);
           na[i] = xnorm[src][i];
         }
       }
@@ -785,7 +798,7 @@ __global__ __launch_bounds__(NW * 64, CPL <= 8 ? 4 : 2) void jacobi_rows_grp_ker
 #pragma unroll
       for (int q = 0; q < CPL; ++q) {
         const int c = CPL * l16 + q;
-        if (r < m && c < len) M[(long)r * ld + c] = blk[i].v[q];
+        if (r < m && c < len) M[(long)r * ld + c] = blk[i].get(q);
       }
     }
   };
@@ -1123,7 +1136,7 @@ __global__ __launch_bounds__(256, CPL <= 4 ? 3 : 2) void jacobi_rows_tiny4_kerne
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
       const int c = CPL * l16 + q;
-      a[i].v[q] = (i < mm && c < len) ? M[(long)i * ld + c] : 0.f;
+      a[i].set(q, (i < mm && c < len) ? M[(long)i * ld + c] : 0.f);
     }
   }
 #pragma unroll
@@ -1156,7 +1169,7 @@ __global__ __launch_bounds__(256, CPL <= 4 ? 3 : 2) void jacobi_rows_tiny4_kerne
 #pragma unroll
       for (int q = 0; q < CPL; ++q) {
         const int c = CPL * l16 + q;
-        if (i < mm && c < len) M[(long)i * ld + c] = a[i].v[q];
+        if (i < mm && c < len) M[(long)i * ld + c] = a[i].get(q);
       }
     }
     return;
@@ -1170,7 +1183,7 @@ __global__ __launch_bounds__(256, CPL <= 4 ? 3 : 2) void jacobi_rows_tiny4_kerne
   for (int i = 0; i < JR_BR; ++i) {
     double t = 0.0;
 #pragma unroll
-    for (int q = 0; q < CPL; ++q) t = fma((double)a[i].v[q], (double)a[i].v[q], t);
+    for (int q = 0; q < CPL; ++q) t = fma((double)a[i].get(q), (double)a[i].get(q), t);
     t += lw_dpp_f64<0xB1>(t);
     t += lw_dpp_f64<0x4E>(t);
     t += lw_dpp_f64<0x141>(t);
@@ -1212,7 +1225,7 @@ __global__ __launch_bounds__(256, CPL <= 4 ? 3 : 2) void jacobi_rows_tiny4_kerne
 #pragma unroll
       for (int q = 0; q < CPL; ++q) {
         const int c = CPL * l16 + q;
-        if (c < len) V[(long)rank[i] * len + c] = a[i].v[q] * inv;
+        if (c < len) V[(long)rank[i] * len + c] = a[i].get(q) * inv;
       }
     }
   }

@@ -29,7 +29,7 @@ template <> __device__ __forceinline__ double eps_rt<double>() { return g_eps64_
 // 64-lane all-reductions on the DPP / permlane-swap path (a few cycles of latency per step, no LDS crossbar): the step
 // loops of the factor kernels are chains of dependent reductions, where the ds_bpermute behind __shfl_xor costs most
 template <int CTRL>
-__device__ __forceinline__ int lw_dpp(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ int lw_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }   // (old unused: see jr_dpp_add)
 __device__ __forceinline__ int wave_min_dpp(int v) {
   v = min(v, lw_dpp<0xB1>(v));     // quad_perm [1,0,3,2]
   v = min(v, lw_dpp<0x4E>(v));     // quad_perm [2,3,0,1]

@@ -77,6 +77,9 @@ void energy_and_holes_impl(int rows, int cols, int D, int d, int chi, int dtype,
   } else if (model == 3) {
     SpinOneHalfTriHeisenbergSqrPEPS m;
     eh = holes_out ? m.CalEnergyAndHoles<true>(sitps, comp) : m.CalEnergyAndHoles<false>(sitps, comp);
+  } else if (model == 4) {
+    SpinOneHalfTriJ1J2HeisenbergSqrPEPS m(p[0]);
+    eh = holes_out ? m.CalEnergyAndHoles<true>(sitps, comp) : m.CalEnergyAndHoles<false>(sitps, comp);
   } else {
     TransverseFieldIsingSquareOBC m(p[0]);
     eh = holes_out ? m.CalEnergyAndHoles<true>(sitps, comp) : m.CalEnergyAndHoles<false>(sitps, comp);
@@ -108,6 +111,9 @@ void exact_sum_partial_impl(int rows, int cols, int D, int d, int chi, int dtype
     ExactSumEnergyEvaluator(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
   } else if (model == 3) {
     SpinOneHalfTriHeisenbergSqrPEPS m;
+    ExactSumEnergyEvaluator(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
+  } else if (model == 4) {
+    SpinOneHalfTriJ1J2HeisenbergSqrPEPS m(p[0]);
     ExactSumEnergyEvaluator(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
   } else {
     TransverseFieldIsingSquareOBC m(p[0]);
@@ -302,7 +308,7 @@ int pepshost_mc_energy_grad_partial_c128(int rows, int cols, int D, int d, int c
   });
 }
 
-// EvaluateObservables of the XXZ (model 0) / J1-J2 (model 2) measurement solver on fixed configurations, or -- with
+// EvaluateObservables of the XXZ (model 0) / J1-J2 (model 2) / triangular J1-J2 (model 4, p[0] = j2) measurement solver on fixed configurations, or -- with
 // n_samples > 0 -- a whole MCPEPSMeasurer run (warm-up, samples, statistics across the walkers, optional DumpData).
 // Results come back through a flat buffer described by `keys_out` ("key:len;key:len;..."): for n_samples == 0 the
 // per-walker values [key][walker][len], else [key][mean(len) | stderr(len)], followed by psi_mean[n], psi_rel_err[n]
@@ -317,7 +323,8 @@ int pepshost_measure(int rows, int cols, int D, int d, int chi, int dtype, const
     TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor);
     SquareSpinOneHalfXXZModelOBC xxz(p[0], p[1], p[2]);
     SquareSpinOneHalfJ1J2XXZModelOBC j1j2(p[0], p[1], p[2], p[3], p[4]);
-    if (model != 0 && model != 2) throw std::invalid_argument("pepshost_measure: model must be xxz or j1j2");
+    SpinOneHalfTriJ1J2HeisenbergSqrPEPS trij(p[0]);
+    if (model != 0 && model != 2 && model != 4) throw std::invalid_argument("pepshost_measure: model must be xxz, j1j2 or trij1j2");
     xxz.SetEnableStructureFactor(p[7] != 0.0);                  // params[7]: structure factor switch (xxz only)
     std::string keys;
     std::vector<double> vals;
@@ -331,10 +338,12 @@ int pepshost_measure(int rows, int cols, int D, int d, int chi, int dtype, const
     };
     PsiSummary psi;
     if (n_samples <= 0) {
-      ObservableMap obs = model == 0 ? xxz.EvaluateObservables(sitps, comp) : j1j2.EvaluateObservables(sitps, comp);
+      ObservableMap obs = model == 0 ? xxz.EvaluateObservables(sitps, comp) : model == 2 ? j1j2.EvaluateObservables(sitps, comp)
+                                                                                         : trij.EvaluateObservables(sitps, comp);
       for (const auto &kv : obs.values) emit(kv.first, kv.second, nullptr, obs.len(kv.first));
-      psi = model == 0 ? xxz.SquareNNModelMeasurementSolver<SquareSpinOneHalfXXZModelOBC>::EvaluatePsiSummary()
-                       : j1j2.SquareNNNModelMeasurementSolver<SquareSpinOneHalfJ1J2XXZModelOBC>::EvaluatePsiSummary();
+      psi = model == 0   ? xxz.SquareNNModelMeasurementSolver<SquareSpinOneHalfXXZModelOBC>::EvaluatePsiSummary()
+            : model == 2 ? j1j2.SquareNNNModelMeasurementSolver<SquareSpinOneHalfJ1J2XXZModelOBC>::EvaluatePsiSummary()
+                         : trij.EvaluatePsiSummary();
     } else {
       std::vector<uint64_t> sd(seeds, seeds + n);
       MCMeasurementParams mp;
@@ -350,9 +359,11 @@ int pepshost_measure(int rows, int cols, int D, int d, int chi, int dtype, const
       MCUpdateSquareNNExchangeOBC ex(sd);
       MCUpdateSquareNNFullSpaceUpdateOBC fs(sd);
       if (updater == 0 && model == 0) run(ex, xxz);
-      else if (updater == 0) run(ex, j1j2);
+      else if (updater == 0 && model == 2) run(ex, j1j2);
+      else if (updater == 0) run(ex, trij);
       else if (model == 0) run(fs, xxz);
-      else run(fs, j1j2);
+      else if (model == 2) run(fs, j1j2);
+      else run(fs, trij);
       std::copy(comp.config.data(), comp.config.data() + (size_t)n * rows * cols, configs);
     }
     vals.insert(vals.end(), psi.psi_mean.begin(), psi.psi_mean.end());

@@ -1528,6 +1528,223 @@ class SpinOneHalfTriHeisenbergSqrPEPS : public SquareNNNModelEnergySolver<SpinOn
   }
 };
 
+// spin_onehalf_triangle_heisenbergJ1J2_sqrpeps.h:48-463: the J1-J2 Heisenberg model of the triangular lattice on a square PEPS.
+// J1 = 1 on the horizontal and vertical bonds and on the left-down -> right-up diagonal of every plaquette; J2 on the three links of
+// distance sqrt 3: the other plaquette diagonal (r, c)-(r+1, c+1), the flat sqrt5 link (r+1, c)-(r, c+2) of a 2 x 3 window and the steep
+// sqrt5 link (r+2, c)-(r, c+1) of a 3 x 2 window.  The model has its own traversal (CalEnergyAndHolesImpl :304-446): the row pass
+// carries the horizontal bonds on BTen and both diagonals + the flat link on BTen2, the column pass the vertical bonds on BTen and the
+// steep link on BTen2 (GrowFullBTen2(DOWN, col, 3)).  Registry (:65-277): energy, spin_z, bond_energy_h / v / ur (the J2 links only
+// enter the energy scalar), SzSz_row / SmSp_row / SpSm_row of the middle row, SzSz_all2all (+-0.25, :449-463).
+class SpinOneHalfTriJ1J2HeisenbergSqrPEPS : public SpinOneHalfMeasurementHooks {
+ public:
+  explicit SpinOneHalfTriJ1J2HeisenbergSqrPEPS(double j2) : j2_(j2) {}
+  enum BondKind { BOND_H, BOND_V, BOND_UR, BOND_DR, BOND_FLAT, BOND_STEEP };
+
+  template <bool calchols = true, typename TenElemT = double>
+  EnergyAndHolesT<TenElemT> CalEnergyAndHoles(const SplitIndexTPST<TenElemT> &sitps, TPSWaveFunctionComponentT<TenElemT> &comp,
+                                              bool holes_on_device = false) {
+    const size_t n = comp.config.walkers();
+    EnergyAndHolesT<TenElemT> out;
+    std::vector<TenElemT> e1(n, TenElemT(0.0)), e2(n, TenElemT(0.0));
+    Traverse<TenElemT>(sitps, comp, calchols, holes_on_device, out, [&](BondKind kind, const SiteIdx &, const SiteIdx &, const std::vector<TenElemT> &e) {
+      auto &dst = kind <= BOND_UR ? e1 : e2;
+      for (size_t w = 0; w < n; ++w) dst[w] += e[w];
+    });
+    out.energy.resize(n);
+    for (size_t w = 0; w < n; ++w) out.energy[w] = e1[w] + j2_ * e2[w];       // :445
+    return out;
+  }
+
+  ObservableMap EvaluateObservables(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp) {
+    auto &c = comp.contractor;
+    const size_t ly = c.rows(), lx = c.cols(), n = comp.config.walkers(), half = lx / 2;
+    ObservableMap out;
+    out.n = n;
+    auto &sz = out.make("spin_z", ly * lx);
+    for (size_t w = 0; w < n; ++w)
+      for (size_t r = 0; r < ly; ++r)
+        for (size_t cc = 0; cc < lx; ++cc) sz[w * ly * lx + r * lx + cc] = double(comp.config(w, {r, cc})) - 0.5;
+    auto &e_h = out.make("bond_energy_h", ly * (lx - 1));
+    auto &e_v = out.make("bond_energy_v", (ly - 1) * lx);
+    auto &e_ur = out.make("bond_energy_ur", (ly - 1) * (lx - 1));
+    std::vector<double> e1(n, 0.0), e2(n, 0.0);
+    EnergyAndHolesT<double> scratch;
+    Traverse<double>(sitps, comp, false, false, scratch, [&](BondKind kind, const SiteIdx &s1, const SiteIdx &s2, const std::vector<double> &e) {
+      for (size_t w = 0; w < n; ++w) {
+        if (kind == BOND_H) e_h[w * ly * (lx - 1) + s1.r * (lx - 1) + s1.c] = e[w];
+        else if (kind == BOND_V) e_v[w * (ly - 1) * lx + s1.r * lx + s1.c] = e[w];
+        else if (kind == BOND_UR) e_ur[w * (ly - 1) * (lx - 1) + s2.r * (lx - 1) + s1.c] = e[w];       // e_ur(row, col): top-left cell (:201)
+        (kind <= BOND_UR ? e1 : e2)[w] += e[w];
+      }
+    });
+    auto &en = out.make("energy", 1);
+    for (size_t w = 0; w < n; ++w) en[w] = e1[w] + j2_ * e2[w];
+    // middle row (:131-171): SzSz along the row, then the S+S- / S-S+ channel.  The traversal has left the stacks in the column pass:
+    // the row window is rebuilt (the reference runs this block inside the row pass; same environments, same numbers).
+    const size_t row = ly / 2;
+    if (half > 0) {
+      auto &szsz = out.make("SzSz_row", half);
+      for (size_t w = 0; w < n; ++w) {
+        const double sz1 = double(comp.config(w, {row, lx / 4})) - 0.5;
+        for (size_t i = 1; i <= half; ++i) szsz[w * half + i - 1] = sz1 * (double(comp.config(w, {row, lx / 4 + i})) - 0.5);
+      }
+      comp.SetOrder(ROW_MAJOR);
+      c.GenerateBMPSApproach(UP);
+      for (size_t r = 0; r < row; ++r) c.ShiftBMPSWindow(DOWN);
+      c.InitBTen(LEFT, row);
+      c.GrowFullBTen(RIGHT, row, 1, true);
+      std::vector<double> inv_psi = c.Trace({row, 0}, HORIZONTAL);
+      for (auto &v : inv_psi) v = 1.0 / v;
+      for (size_t col = 0; col + 1 < lx; ++col) c.ShiftBTenWindow(RIGHT);
+      EvaluateOffDiagOrderInRow(comp, row, inv_psi, out);
+    }
+    const size_t N = ly * lx;                                                   // :260-275, :449-463
+    auto &all = out.make("SzSz_all2all", N * (N + 1) / 2);
+    for (size_t w = 0; w < n; ++w) {
+      size_t k = w * (N * (N + 1) / 2);
+      for (size_t i = 0; i < N; ++i)
+        for (size_t j = i; j < N; ++j)
+          all[k++] = comp.config(w, {i / lx, i % lx}) == comp.config(w, {j / lx, j % lx}) ? 0.25 : -0.25;
+    }
+    last_psi_.psi_mean.assign(n, 0.0);
+    last_psi_.psi_rel_err.assign(n, 0.0);
+    std::vector<double> one(scratch.psi_list.size());
+    for (size_t w = 0; w < n; ++w) {
+      for (size_t k = 0; k < one.size(); ++k) one[k] = scratch.psi_list[k][w];
+      auto s = ComputePsiConsistencySummaryAligned(one);
+      last_psi_.psi_mean[w] = s.first;
+      last_psi_.psi_rel_err[w] = s.second;
+    }
+    return out;
+  }
+  const PsiSummary &EvaluatePsiSummary() const { return last_psi_; }
+  std::vector<ObservableMeta> DescribeObservables(size_t ly, size_t lx) const {   // :279-297
+    const size_t N = ly * lx;
+    return {{"energy", "Total energy (scalar)", {}, {}},
+            {"spin_z", "Local spin Sz per site (Ly,Lx)", {ly, lx}, {"y", "x"}},
+            {"SzSz_row", "Row SzSz correlations along middle row (flat)", {lx / 2}, {"segment"}},
+            {"SmSp_row", "Row Sm(i)Sp(j) along middle row (flat)", {lx / 2}, {"segment"}},
+            {"SpSm_row", "Row Sp(i)Sm(j) along middle row (flat)", {lx / 2}, {"segment"}},
+            {"bond_energy_h", "Bond energy on horizontal NN bonds (flat)", {ly * (lx > 0 ? lx - 1 : 0)}, {"bond"}},
+            {"bond_energy_v", "Bond energy on vertical NN bonds (flat)", {(ly > 0 ? ly - 1 : 0) * lx}, {"bond"}},
+            {"bond_energy_ur", "Bond energy on diagonal (triangular, Up-Right) bonds (flat)", {(ly > 0 ? ly - 1 : 0) * (lx > 0 ? lx - 1 : 0)}, {"bond"}},
+            {"SzSz_all2all", "All-to-all SzSz correlations (upper-tri packed)", {N * (N + 1) / 2}, {"pair_packed_upper_tri"}}};
+  }
+
+ private:
+  // 0.25 for equal spins, else -0.25 + 0.5 conj(psi_ex / psi) (:338-345 and the seven other bond blocks); trace(cand) is only called
+  // when some walker's two spins differ.
+  template <typename TenElemT, class TraceFn>
+  static std::vector<TenElemT> Bond(const TPSWaveFunctionComponentT<TenElemT> &comp, const SiteIdx &s1, const SiteIdx &s2,
+                                    const std::vector<TenElemT> &inv_psi, TraceFn trace) {
+    const size_t n = comp.config.walkers();
+    std::vector<int32_t> cand(n * 2);
+    bool any = false;
+    for (size_t w = 0; w < n; ++w) {
+      cand[2 * w] = comp.config(w, s2);
+      cand[2 * w + 1] = comp.config(w, s1);
+      any |= cand[2 * w] != cand[2 * w + 1];
+    }
+    std::vector<TenElemT> e(n, TenElemT(0.25));
+    if (!any) return e;
+    std::vector<TenElemT> psi_ex = trace(cand);
+    for (size_t w = 0; w < n; ++w)
+      if (comp.config(w, s1) != comp.config(w, s2)) e[w] = -0.25 + ComplexConjugate(TenElemT(psi_ex[w] * inv_psi[w])) * 0.5;
+    return e;
+  }
+  template <typename TenElemT, class OnBond>
+  void Traverse(const SplitIndexTPST<TenElemT> &sitps, TPSWaveFunctionComponentT<TenElemT> &comp, bool calchols, bool holes_on_device,
+                EnergyAndHolesT<TenElemT> &out, OnBond on_bond) {
+    auto &c = comp.contractor;
+    const size_t rows = c.rows(), cols = c.cols(), n = comp.config.walkers(), slot = sitps.slot();
+    if (calchols && !holes_on_device) out.holes.assign(n * rows * cols * slot, TenElemT(0.0));
+    auto inverse = [&](const std::vector<TenElemT> &psi) {
+      std::vector<TenElemT> inv(n);
+      for (size_t w = 0; w < n; ++w) {
+        if (psi[w] == TenElemT(0.0)) throw std::runtime_error("Wavefunction amplitude is near zero, causing division by zero.");
+        inv[w] = TenElemT(1.0) / psi[w];
+      }
+      return inv;
+    };
+    comp.SetOrder(ROW_MAJOR);
+    c.GenerateBMPSApproach(UP);                                              // :317
+    for (size_t row = 0; row < rows; row++) {
+      c.InitBTen(LEFT, row);                                                 // :320
+      c.GrowFullBTen(RIGHT, row, 1, true);
+      out.psi_list.push_back(c.Trace({row, 0}, HORIZONTAL));                 // :322
+      const std::vector<TenElemT> inv_psi = inverse(out.psi_list.back());
+      for (size_t col = 0; col < cols; col++) {
+        const SiteIdx s1{row, col};
+        if (calchols && holes_on_device) {
+          c.PunchHoleStore(s1, HORIZONTAL);
+        } else if (calchols) {
+          std::vector<TenElemT> h = c.PunchHole(s1, HORIZONTAL);             // :329 hole_res(site) = Dag(hole)
+          for (size_t w = 0; w < n; ++w)
+            std::transform(h.begin() + w * slot, h.begin() + (w + 1) * slot, out.holes.begin() + ((w * rows + row) * cols + col) * slot,
+                           [](const TenElemT &x) { return ComplexConjugate(x); });
+        }
+        if (col + 1 < cols) {
+          const SiteIdx s2{row, col + 1};
+          on_bond(BOND_H, s1, s2, Bond<TenElemT>(comp, s1, s2, inv_psi, [&](const std::vector<int32_t> &cand) {
+                    return comp.ReplaceNNSiteTrace(s1, s2, HORIZONTAL, 1, cand); }));
+          c.ShiftBTenWindow(RIGHT);                                          // :346
+        }
+      }
+      if (row + 1 < rows) {
+        c.InitBTen2(LEFT, row);                                              // :350
+        c.GrowFullBTen2(RIGHT, row, 2, true);
+        for (size_t col = 0; col + 1 < cols; col++) {
+          const SiteIdx lu{row, col};
+          {
+            const SiteIdx s1{row + 1, col}, s2{row, col + 1};                // :355-367 J1 diagonal
+            on_bond(BOND_UR, s1, s2, Bond<TenElemT>(comp, s1, s2, inv_psi, [&](const std::vector<int32_t> &cand) {
+                      return c.ReplaceNNNSiteTrace(lu, LEFTDOWN_TO_RIGHTUP, HORIZONTAL, 1, cand); }));
+          }
+          {
+            const SiteIdx s1{row, col}, s2{row + 1, col + 1};                // :369-381 J2 diagonal
+            on_bond(BOND_DR, s1, s2, Bond<TenElemT>(comp, s1, s2, inv_psi, [&](const std::vector<int32_t> &cand) {
+                      return c.ReplaceNNNSiteTrace(lu, LEFTUP_TO_RIGHTDOWN, HORIZONTAL, 1, cand); }));
+          }
+          if (col + 2 < cols) {                                              // :383-397 flat sqrt5 link
+            const SiteIdx s1{row + 1, col}, s2{row, col + 2};
+            on_bond(BOND_FLAT, s1, s2, Bond<TenElemT>(comp, s1, s2, inv_psi, [&](const std::vector<int32_t> &cand) {
+                      return c.ReplaceSqrt5DistTwoSiteTrace(lu, LEFTDOWN_TO_RIGHTUP, HORIZONTAL, 1, cand); }));
+          }
+          c.ShiftBTen2Window(RIGHT, row);                                    // :398
+        }
+        c.ShiftBMPSWindow(DOWN);                                             // :400
+      }
+    }
+    comp.SetOrder(COL_MAJOR);
+    c.GenerateBMPSApproach(LEFT);                                            // :404
+    for (size_t col = 0; col < cols; col++) {
+      c.InitBTen(UP, col);
+      c.GrowFullBTen(DOWN, col, 2, true);
+      out.psi_list.push_back(c.Trace({0, col}, VERTICAL));
+      const std::vector<TenElemT> inv_psi = inverse(out.psi_list.back());
+      for (size_t row = 0; row + 1 < rows; row++) {
+        const SiteIdx s1{row, col}, s2{row + 1, col};
+        on_bond(BOND_V, s1, s2, Bond<TenElemT>(comp, s1, s2, inv_psi, [&](const std::vector<int32_t> &cand) {
+                  return comp.ReplaceNNSiteTrace(s1, s2, VERTICAL, 1, cand); }));
+        if (row + 2 < rows) c.ShiftBTenWindow(DOWN);
+      }
+      if (col + 1 < cols) {
+        c.InitBTen2(UP, col);                                                // :425
+        c.GrowFullBTen2(DOWN, col, 3, true);
+        for (size_t row = 0; row + 2 < rows; row++) {                        // :428-442 steep sqrt5 link
+          const SiteIdx s1{row + 2, col}, s2{row, col + 1};
+          on_bond(BOND_STEEP, s1, s2, Bond<TenElemT>(comp, s1, s2, inv_psi, [&](const std::vector<int32_t> &cand) {
+                    return c.ReplaceSqrt5DistTwoSiteTrace({row, col}, LEFTDOWN_TO_RIGHTUP, VERTICAL, 1, cand); }));
+          if (row + 3 < rows) c.ShiftBTen2Window(DOWN, col);
+        }
+        c.ShiftBMPSWindow(RIGHT);
+      }
+    }
+  }
+  double j2_;
+  PsiSummary last_psi_;
+};
+
 // square_spinless_fermion.h:51-200: H = -t sum_<ij> (c+_i c_j + h.c.) - t2 sum_<<ij>> (c+_i c_j + h.c.) + V sum_<ij> n_i n_j.
 // psi is recomputed with Trace next to psi' (same contraction path, docs/dev/design/math/
 // fermion-sign-in-bmps-contraction.md), the bosonic inv_psi argument is unused.

@@ -42,8 +42,9 @@ def _ck(rc):
         raise {1: ValueError, 3: RuntimeError, 4: IndexError}.get(rc, RuntimeError)("pepshost error %d: %s" % (rc, msg))
 
 
-MODEL_ID = {"xxz": 0, "tfim": 1, "j1j2": 2, "triangle": 3}   # params: xxz (jz, jxy, pinning00); tfim (h,); j1j2 (jz, jxy, jz2, jxy2, pinning00);
-# triangle (SpinOneHalfTriHeisenbergSqrPEPS: none; energy_and_holes / exact_sum_partial)
+MODEL_ID = {"xxz": 0, "tfim": 1, "j1j2": 2, "triangle": 3, "trij1j2": 4}   # params: xxz (jz, jxy, pinning00); tfim (h,); j1j2 (jz, jxy, jz2, jxy2, pinning00);
+# triangle (SpinOneHalfTriHeisenbergSqrPEPS: none; energy_and_holes / exact_sum_partial); trij1j2 (SpinOneHalfTriJ1J2HeisenbergSqrPEPS: (j2,);
+# energy_and_holes / exact_sum_partial / measure)
 
 
 def _dims(flat):

@@ -396,6 +396,47 @@ def test_triangle_heisenberg_energy_and_exact_sum(dt, tol):
     assert abs(e / e_o - 1) < tol
 
 
+@pytest.mark.parametrize("dt,tol", [(F64, 1e-9), (F32, 2e-5)])
+def test_triangle_j1j2_heisenberg_energy_holes_and_exact_sum(dt, tol):
+    """SpinOneHalfTriJ1J2HeisenbergSqrPEPS (spin_onehalf_triangle_heisenbergJ1J2_sqrpeps.h:304-446): the model's own traversal on the
+    device -- h / v bonds on BTen, both plaquette diagonals and the flat sqrt5 link on BTen2 in the row pass, the steep sqrt5 link on
+    BTen2(UP / DOWN, remain_sites 3) in the column pass -- local energies, holes and the psi list against the oracle on identical
+    configurations (5x5: every ShiftBTen2Window of both passes runs), j2 = 0 against j2 != 0 (the J2 links are not zero on this state)
+    and the 3x3 exact-sum energy against the oracle's."""
+    host = _host()
+    L, D, chi, j2 = 5, 3, 9, 0.35
+    s = synthetic.make_sitps(L, D)
+    cfgs = synthetic.make_configs(L, 5, "heisenberg")
+    ref = _oracle_energy(s, cfgs, chi, vmc.SpinOneHalfTriJ1J2HeisenbergSqrPEPS(j2))
+    amps, en, holes, psi = host.energy_and_holes(synthetic.sitps_to_flat(s, D), cfgs, chi, "trij1j2", (j2,), True, dt)
+    _, en_j1, _, _ = host.energy_and_holes(synthetic.sitps_to_flat(s, D), cfgs, chi, "trij1j2", (0.0,), False, dt)
+    _, en_tri, _, _ = host.energy_and_holes(synthetic.sitps_to_flat(s, D), cfgs, chi, "triangle", (), False, dt)
+    for w, (a, e, h, ps) in enumerate(ref):
+        assert abs(amps[w] / a - 1) < tol
+        assert abs(en[w] - e) < tol * max(1.0, abs(e)) * 10
+        for r in range(L):
+            for c in range(L):
+                hr = h[r][c]
+                hd = holes[w, r, c][:hr.shape[0], :hr.shape[1], :hr.shape[2], :hr.shape[3]]
+                assert np.max(np.abs(hd - hr)) < tol * 10 * np.max(np.abs(hr))
+        assert np.max(np.abs(psi[:, w] / np.array(ps) - 1)) < tol * 10
+    assert np.max(np.abs(en - en_j1)) > 1e-2
+    assert np.max(np.abs(en_j1 - en_tri)) < tol * 10 * max(1.0, np.max(np.abs(en_tri)))      # j2 = 0: the J1 model of the triangular lattice
+    s3 = synthetic.make_sitps(3, 2)
+    all_cfg = np.array(vmc.all_product_configs(2, 3, 3)).astype(np.int32)
+    packed = host.exact_sum_partial(synthetic.sitps_to_flat(s3, 2), all_cfg, 16, "trij1j2", (j2,), 0, 1, 128, dt)
+    e, grad = host.exact_sum_finish(packed, (3, 3, 2, 2))
+    e_o, g_o, _ = vmc.exact_sum_energy_evaluator(s3, list(all_cfg), BMPSTruncateParams.SVD(16, 16, 0.0), vmc.SpinOneHalfTriJ1J2HeisenbergSqrPEPS(j2))
+    assert abs(e / e_o - 1) < tol
+    gmax = max(np.max(np.abs(g_o[r][c][k])) for r in range(3) for c in range(3) for k in range(2))
+    for r in range(3):                                       # the gradient runs through this model's own hole traversal
+        for c in range(3):
+            for k in range(2):
+                go = g_o[r][c][k]
+                gd = grad[r, c, k][:go.shape[0], :go.shape[1], :go.shape[2], :go.shape[3]]
+                assert np.max(np.abs(gd - go)) < tol * 10 * max(1.0, gmax)
+
+
 @pytest.mark.parametrize("scheme,name", [(1, "Variational2Site"), (2, "Variational1Site")])
 def test_xxz_energy_with_variational_truncate_params(scheme, name):
     """The C++ solver with BMPSTruncateParams::Variational2Site / 1Site (bmps.h:81-97): local energies and

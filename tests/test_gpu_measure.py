@@ -54,6 +54,32 @@ def test_registry_observables_fixed_configs(model, params, dt, tol):
     assert np.count_nonzero(sp) > 0                                # the off-diagonal channel is exercised
 
 
+@pytest.mark.parametrize("dt,tol", [(F64, 1e-9), (F32, 5e-5)])
+def test_triangle_j1j2_registry_observables_fixed_configs(dt, tol):
+    """SpinOneHalfTriJ1J2HeisenbergSqrPEPS::EvaluateObservables (spin_onehalf_triangle_heisenbergJ1J2_sqrpeps.h:65-297): energy, spin_z,
+    the three J1 bond maps, SzSz_row / SmSp_row / SpSm_row of the middle row, SzSz_all2all and the psi summary against the oracle on
+    identical configurations (6x6)."""
+    host = _host()
+    L, D, chi, j2 = 6, 3, 9, 0.2
+    s = synthetic.make_sitps(L, D)
+    cfgs = synthetic.make_configs(L, 4, "heisenberg")
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    got, psi = host.measure(synthetic.sitps_to_flat(s, D), cfgs, chi, "trij1j2", (j2,), dtype=dt)
+    nz = 0
+    for w, c in enumerate(cfgs):
+        model = vmc.SpinOneHalfTriJ1J2HeisenbergSqrPEPS(j2)
+        obs = model.EvaluateObservables(s, vmc.TPSWaveFunctionComponent(s, c, tp))
+        assert set(got) == set(obs)
+        for key, want in obs.items():
+            want = np.asarray(want, dtype=np.float64)
+            assert got[key][w].shape == want.shape, key
+            assert np.max(np.abs(got[key][w] - want)) < tol * 10 * max(1.0, np.max(np.abs(want))), (key, w)
+        assert abs(psi[0][w] / model.last_psi_summary[0] - 1) < tol * 10
+        assert abs(psi[1][w] - model.last_psi_summary[1]) < tol * 10
+        nz += np.count_nonzero(obs["SpSm_row"]) + np.count_nonzero(obs["SmSp_row"])
+    assert nz > 0
+
+
 def test_registry_observables_k5_fixture(fixtures_dir):
     """the reference's 4x4 D=8 Heisenberg state (tests/slow_tests/test_data/tps_square_heisenberg4x4D8Double)"""
     host = _host()

@@ -72,3 +72,89 @@ def test_structure_factor_equals_amplitudes_of_doubly_flipped_configurations():
     assert n_open > 10
     # the measurement leaves the contractor usable: a fresh amplitude still comes out right
     assert abs(comp.EvaluateAmplitude() / vmc.TPSWaveFunctionComponent(s, cfg, tp).amplitude - 1) < 1e-12
+
+
+def _tri_j1j2_bonds(L, j2):
+    """bond list of the triangular J1-J2 model on a square PEPS, written from the model definition
+    (spin_onehalf_triangle_heisenbergJ1J2_sqrpeps.h:19-46), not from the traversal"""
+    bonds = []
+    for r in range(L):
+        for c in range(L):
+            if c + 1 < L: bonds.append(((r, c), (r, c + 1), 1.0))
+            if r + 1 < L: bonds.append(((r, c), (r + 1, c), 1.0))
+            if r + 1 < L and c + 1 < L:
+                bonds.append(((r + 1, c), (r, c + 1), 1.0))        # J1 diagonal of the triangular lattice
+                bonds.append(((r, c), (r + 1, c + 1), j2))         # J2: the other diagonal
+            if r + 1 < L and c + 2 < L: bonds.append(((r + 1, c), (r, c + 2), j2))   # J2: flat sqrt5 link
+            if r + 2 < L and c + 1 < L: bonds.append(((r + 2, c), (r, c + 1), j2))   # J2: steep sqrt5 link
+    return bonds
+
+
+def test_triangle_j1j2_local_energy_equals_brute_force_amplitude_ratios():
+    """SpinOneHalfTriJ1J2HeisenbergSqrPEPS (own traversal: BTen for the h / v bonds, BTen2 for both diagonals and the flat sqrt5 link
+    in the row pass, BTen2(UP / DOWN, remain 3) for the steep link in the column pass; :304-446): E_loc(S) against
+    sum_bonds J (+-1/4 + psi(S_exchanged) / (2 psi(S))) with every exchanged amplitude contracted afresh (4x4: every window shift
+    of both passes runs), and the registry (energy, J1 bond maps, row channel, SzSz_all2all, psi summary)."""
+    L, D, chi, j2 = 4, 2, 16, 0.3
+    s = synthetic.make_sitps(L, D)
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    model = vmc.SpinOneHalfTriJ1J2HeisenbergSqrPEPS(j2)
+    amp = lambda c: vmc.TPSWaveFunctionComponent(s, c, tp).amplitude
+    for cfg in synthetic.make_configs(L, 3, "heisenberg"):
+        comp = vmc.TPSWaveFunctionComponent(s, cfg, tp)
+        e, holes, psi_list = model.CalEnergyAndHoles(s, comp, True)
+        psi, ref, ref_j1 = amp(cfg), 0.0, {}
+        for a, b, J in _tri_j1j2_bonds(L, j2):
+            if cfg[a] == cfg[b]:
+                v = 0.25
+            else:
+                c2 = cfg.copy()
+                c2[a], c2[b] = cfg[b], cfg[a]
+                v = -0.25 + 0.5 * amp(c2) / psi
+            ref += J * v
+            if J == 1.0: ref_j1[(a, b)] = v
+        assert abs(e - ref) < 1e-11 * max(1.0, abs(ref))
+        assert len(psi_list) == 2 * L and np.max(np.abs(np.array(psi_list) / psi - 1)) < 1e-11
+        for r in range(L):                                   # hole . site tensor = psi  (K3's identity)
+            for c in range(L):
+                assert abs(np.sum(np.conj(holes[r][c]) * s[r][c][int(cfg[r, c])]) / psi - 1) < 1e-11
+        comp = vmc.TPSWaveFunctionComponent(s, cfg, tp)
+        obs = model.EvaluateObservables(s, comp)
+        assert abs(obs["energy"][0] - e) < 1e-12 * max(1.0, abs(e))
+        e_h = np.reshape(obs["bond_energy_h"], (L, L - 1)); e_v = np.reshape(obs["bond_energy_v"], (L - 1, L))
+        e_ur = np.reshape(obs["bond_energy_ur"], (L - 1, L - 1))
+        for (a, b), v in ref_j1.items():
+            got = e_h[a] if a[0] == b[0] else e_v[a] if a[1] == b[1] else e_ur[b[0], a[1]]
+            assert abs(got - v) < 1e-11 * max(1.0, abs(v))
+        assert set(obs) == {"energy", "spin_z", "bond_energy_h", "bond_energy_v", "bond_energy_ur", "SzSz_row", "SmSp_row", "SpSm_row", "SzSz_all2all"}
+        row, x0 = L // 2, L // 4
+        chan = "SpSm_row" if cfg[row, x0] == 0 else "SmSp_row"
+        for i in range(1, L // 2 + 1):
+            assert obs["SzSz_row"][i - 1] == (cfg[row, x0] - 0.5) * (cfg[row, x0 + i] - 0.5)
+            if cfg[row, x0] != cfg[row, x0 + i]:
+                c2 = cfg.copy()
+                c2[row, x0], c2[row, x0 + i] = c2[row, x0 + i], c2[row, x0]
+                assert abs(obs[chan][i - 1] - amp(c2) / psi) < 1e-10 * max(1.0, abs(amp(c2) / psi))
+        assert set(np.abs(obs["SzSz_all2all"])) == {0.25} and model.last_psi_summary[1] < 1e-10
+
+
+def test_triangle_j1j2_exact_sum_matches_dense_hamiltonian():
+    """3x3: sum_S |psi|^2 E_loc(S) / sum_S |psi|^2 against <psi|H|psi> / <psi|psi> with the dense 512 x 512 Hamiltonian"""
+    s = synthetic.make_sitps(3, 2)
+    j2 = 0.45
+    tp = BMPSTruncateParams.SVD(16, 16, 0.0)
+    cfgs = vmc.all_product_configs(2, 3, 3)
+    e, _, _ = vmc.exact_sum_energy_evaluator(s, cfgs, tp, vmc.SpinOneHalfTriJ1J2HeisenbergSqrPEPS(j2))
+    psi = np.array([vmc.TPSWaveFunctionComponent(s, c, tp).amplitude for c in cfgs])
+    idx = {tuple(c.ravel()): i for i, c in enumerate(cfgs)}
+    H = np.zeros((len(cfgs), len(cfgs)))
+    for i, cf in enumerate(cfgs):
+        for a, b, J in _tri_j1j2_bonds(3, j2):
+            if cf[a] == cf[b]:
+                H[i, i] += 0.25 * J
+            else:
+                H[i, i] -= 0.25 * J
+                c2 = cf.copy()
+                c2[a], c2[b] = cf[b], cf[a]
+                H[idx[tuple(c2.ravel())], i] += 0.5 * J
+    assert abs(e - psi @ H @ psi / (psi @ psi)) < 1e-12
