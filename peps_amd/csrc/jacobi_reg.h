@@ -685,7 +685,7 @@ __global__ __launch_bounds__(NW * 64, CPL <= 8 ? 4 : 2) void jacobi_rows_grp_ker
     }
     int rot = 0;
     // pairs inside the two blocks of a player (circle method on JG_RB rows; a player without rows holds zeros: no rotation)
-#pragma unroll 1
+#pragma unroll
     for (int r = 0; r < JG_RB - 1; ++r) {
       float ga[JG_RB / 2], gb[JG_RB / 2];
 #pragma unroll
