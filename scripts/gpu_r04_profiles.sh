@@ -14,6 +14,7 @@ leg() { # tag, extra args
   python3 scripts/trace_summary.py $O/kt_${tag}_kernel_trace.csv > $O/r04_kernel_trace_by_grid_$tag.txt
   cp $O/kt_${tag}_kernel_stats.csv $O/r04_kernel_stats_$tag.csv
   rm -f $O/kt_${tag}_kernel_trace.csv
+  if [ -n "$KT_ONLY" ]; then head -8 $O/r04_kernel_trace_by_grid_$tag.txt; return; fi    # (kernel traces only: the PMC passes of an earlier call stay)
   for cnt in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $cnt --output-format csv -d $O -o pmc_${cnt}_$tag -- python3 bench.py $COMMON "$@" > $O/pmc_${cnt}_$tag.log 2>&1
     python3 scripts/pmc_summary.py $O/pmc_${cnt}_${tag}_counter_collection.csv > $O/r04_pmc_${cnt}_$tag.txt
@@ -27,6 +28,7 @@ leg() { # tag, extra args
 leg c4_f32_noise0.1_nw49152
 leg c4_f32_noise1_nw8192 --noise 1.0 --walkers 8192
 leg c4_f32_real_nw8192 --state real --walkers 8192
+if [ -n "$KT_ONLY" ]; then find $O -name "*.csv" -size +3M -delete; exit 0; fi
 # kernel trace of the Monte-Carlo sweeps (1 + 2 sweeps of the exchange updater through the C++ host layer, 8192 walkers of the headline state)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kt_sweep -- python3 scripts/sweep_trace.py 8192 > $O/kt_sweep.log 2>&1
 python3 scripts/trace_summary.py $O/kt_sweep_kernel_trace.csv > $O/r04_kernel_trace_by_grid_sweep_c4_f32_noise0.1_nw8192.txt
