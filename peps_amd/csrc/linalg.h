@@ -1150,11 +1150,14 @@ __global__ __launch_bounds__(256, 2) void gram_chol_wave_kernel(const float *__r
 #pragma unroll
           for (int k = kb; k < kb + 16; ++k) {
             const double pf = (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pp[k]), lf));
-            float x0 = p0[k], x1 = p1[k];
-            asm volatile("" : "+v"(x0), "+v"(x1));   // opaque copies: the f32 -> f64 conversions of the (loop-invariant) columns
-                                                     // stay inside the step loop instead of 256 more live registers
-            if (k & 1) { h0 = fma(pf, (double)x0, h0); h1 = fma(pf, (double)x1, h1); }
-            else { g0 = fma(pf, (double)x0, g0); g1 = fma(pf, (double)x1, g1); }
+            // the f32 -> f64 conversions of the (loop-invariant) columns stay inside the step loop instead of 256 more live
+            // registers: the conversion itself is the opaque statement (rounds 2-4 converted an opaque COPY of the column: two
+            // v_mov per k, a quarter of the instructions of this loop)
+            double x0, x1;
+            asm volatile("v_cvt_f64_f32_e32 %0, %1" : "=v"(x0) : "v"(p0[k]));
+            asm volatile("v_cvt_f64_f32_e32 %0, %1" : "=v"(x1) : "v"(p1[k]));
+            if (k & 1) { h0 = fma(pf, x0, h0); h1 = fma(pf, x1, h1); }
+            else { g0 = fma(pf, x0, g0); g1 = fma(pf, x1, g1); }
           }
         }
 #pragma unroll
