@@ -1101,6 +1101,37 @@ __global__ __launch_bounds__(256, 3) void jacobi_rows_tiny2_kernel(float *__rest
 template <int NB, int CPL>
 __device__ __forceinline__ int jr_intra16(JrRowT<CPL> (&a)[JR_BR], float (&na)[JR_BR], const float tol2, const float floor2) {
   int rot = 0;
+#ifdef JR_INTRA_TWOSTEP
+  // (default off, NOT measured -- DESIGN 8, lead 2.)  Two steps per trip: the second step is written with the indices of the arrangement
+  // BEFORE the turn (a'[i] = a[T(i)], T(0) = 0, T(1) = NB - 1, T(i) = i - 1), then ONE double turn: half the register moves of the loop.
+  auto step = [&](auto turned) {
+    constexpr bool TURN = decltype(turned)::value;
+    auto T = [](int i) { return !TURN ? i : (i == 0 ? 0 : (i == 1 ? NB - 1 : i - 1)); };
+    float ga[NB / 2];
+#pragma unroll
+    for (int p = 0; p < NB / 2; ++p) ga[p] = jg_sum16(jrx_dot<CPL>(a[T(p)], a[T(NB - 1 - p)]));
+#pragma unroll
+    for (int p = 0; p < NB / 2; ++p) rot += jrx_apply<CPL>(a[T(p)], a[T(NB - 1 - p)], na[T(p)], na[T(NB - 1 - p)], ga[p], tol2, floor2);
+  };
+#pragma unroll 1
+  for (int r = 0; r + 1 < NB - 1; r += 2) {
+    step(std::false_type());
+    step(std::true_type());
+    const JrRowT<CPL> t1 = a[NB - 2], t2 = a[NB - 1];
+    const float f1 = na[NB - 2], f2 = na[NB - 1];
+#pragma unroll
+    for (int i = NB - 1; i >= 3; --i) { a[i] = a[i - 2]; na[i] = na[i - 2]; }
+    a[1] = t1; na[1] = f1; a[2] = t2; na[2] = f2;
+  }
+  {   // NB - 1 is odd: the last step and a single turn (NB - 1 turns in all: every row is back in its slot)
+    step(std::false_type());
+    const JrRowT<CPL> ta = a[NB - 1];
+    const float fa = na[NB - 1];
+#pragma unroll
+    for (int i = NB - 1; i >= 2; --i) { a[i] = a[i - 1]; na[i] = na[i - 1]; }
+    a[1] = ta; na[1] = fa;
+  }
+#else
 #pragma unroll 1
   for (int r = 0; r < NB - 1; ++r) {
     float ga[NB / 2];
@@ -1114,6 +1145,7 @@ __device__ __forceinline__ int jr_intra16(JrRowT<CPL> (&a)[JR_BR], float (&na)[J
     for (int i = NB - 1; i >= 2; --i) { a[i] = a[i - 1]; na[i] = na[i - 1]; }
     a[1] = ta; na[1] = fa;
   }
+#endif
   return rot;
 }
 
