@@ -580,4 +580,23 @@ int pepshost_load_configuration(const char *dir, int label, int rows, int cols, 
   });
 }
 
+// SuwaTodoStateUpdate (suwa_todo_update.h:53-112) alone, on the host: the chain state_{t+1} = SuwaTodoStateUpdate(state_t, weights, gen) of
+// n_steps updates with gen = std::mt19937(seed).  No device call: what the reference's test_suwa_todo_update.cpp exercises (single state,
+// zero weights, stationary distribution) and the deviate-for-deviate comparison with oracle/vmc.py run on the CPU suite.
+int pepshost_suwa_todo_chain(int init_state, const double *weights, int n, uint64_t seed, long n_steps, int32_t *states_out) {
+  return guarded([&]() {
+    if (n <= 0 || init_state < 0 || init_state >= n) throw std::invalid_argument("pepshost_suwa_todo_chain: init_state outside the weights");
+    std::vector<double> w(weights, weights + n);
+    for (double x : w)
+      if (!(x >= 0.0)) throw std::invalid_argument("pepshost_suwa_todo_chain: negative weight");
+    if (!(w[init_state] > 0.0)) throw std::invalid_argument("pepshost_suwa_todo_chain: weights[init_state] must be positive");
+    std::mt19937 gen((std::mt19937::result_type)seed);
+    size_t state = (size_t)init_state;
+    for (long t = 0; t < n_steps; ++t) {
+      state = SuwaTodoStateUpdate(state, w, gen);
+      states_out[t] = (int32_t)state;
+    }
+  });
+}
+
 }  // extern "C"

@@ -15,7 +15,7 @@ SYMBOLS = ["pepshost_last_error", "pepshost_mc_sweeps", "pepshost_energy_and_hol
            "pepshost_set_truncate_params", "pepshost_set_device", "pepshost_get_device",
            "pepshost_energy_and_holes_c128", "pepshost_exact_sum_partial_c128", "pepshost_exact_sum_finish_c128",
            "pepshost_mc_energy_grad_partial_c128", "pepshost_mc_sweeps_c128", "pepshost_load_sitps_c128", "pepshost_dump_sitps_c128",
-           "pepshost_mc_engine_warmup", "pepshost_mc_engine_warmup_dist"]
+           "pepshost_mc_engine_warmup", "pepshost_mc_engine_warmup_dist", "pepshost_suwa_todo_chain"]
 
 _lib = None
 
@@ -418,3 +418,13 @@ def mc_energy_grad_complex(flat, configs, seeds, chi, updater="exchange", model=
     grad = np.zeros(flat.shape, dtype=np.complex128)
     _ck(lib().pepshost_exact_sum_finish_c128(rows, cols, D, d, _p(packed, C.c_double), _p(e, C.c_double), _cp(grad)))
     return complex(e[0], e[1]), grad, cfg, acc
+
+
+def suwa_todo_chain(init_state, weights, seed, n_steps):
+    """The chain of n_steps SuwaTodoStateUpdate calls (suwa_todo_update.h:53-112) with std::mt19937(seed), on the host alone (no GPU):
+    states[t] for t = 1..n_steps."""
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    out = np.zeros(int(n_steps), dtype=np.int32)
+    _ck(lib().pepshost_suwa_todo_chain(int(init_state), _p(w, C.c_double), int(w.size), C.c_uint64(int(seed)), C.c_long(int(n_steps)),
+                                       _p(out, C.c_int32)))
+    return out
