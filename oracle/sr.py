@@ -59,7 +59,7 @@ def conjugate_gradient_full(matvec, b, x0, max_iter=100, relative_tolerance=1e-4
         ap = matvec(p)
         pap = np.vdot(p, ap) if cplx else float(p @ ap)
         # detail::pap_is_valid (:142-148): real: pap > 0; complex: Re > 0 and |Im| < 1e-10
-        ok = (np.isfinite(pap.real) and pap.real > 0.0 and abs(pap.imag) < 1e-10) if cplx else (np.isfinite(pap) and pap > 0.0)
+        ok = (pap.real > 0.0 and abs(pap.imag) < 1e-10) if cplx else (pap > 0.0)    # (+inf passes, NaN does not: the reference's plain comparisons)
         if not ok:
             return best_x, np.sqrt(best_rr), k, K_INDEFINITE
         alpha = rk / pap

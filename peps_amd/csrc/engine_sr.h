@@ -473,7 +473,7 @@ void Engine<T>::sr_cg_solve(const double *b, const double *x0, double diag_shift
       matvec(dp, dap);
       dotc_into(dp, dap, dsc); nsq_into(dp, dsc + 2); read(s, 3);
       const double pap_re = s[0], pap_im = s[1], pp = s[2];
-      if (!(std::isfinite(pap_re) && pap_re > 0.0 && std::fabs(pap_im) < 1e-10)) return finish(dbest, best, k, kIndefiniteMatrix);
+      if (!(pap_re > 0.0 && std::fabs(pap_im) < 1e-10)) return finish(dbest, best, k, kIndefiniteMatrix);   // (+inf passes, as in the reference: the NaN it makes of the residual is the kNumericalBreakdown exit below)
       const double den = pap_re * pap_re + pap_im * pap_im;
       const double a_re = rk * pap_re / den, a_im = -rk * pap_im / den;      // alpha = rk / pap
       caxpby(a_re, a_im, dp, 1.0, dx);
@@ -577,7 +577,7 @@ void Engine<T>::sr_cg_solve(const double *b, const double *x0, double diag_shift
     matvec(dp, dap);
     dots({{dp, dap}, {dp, dp}}, s);
     const double pap = s[0], pp = s[1];
-    if (!(std::isfinite(pap) && pap > 0.0)) return finish(dbest, best, k, kIndefiniteMatrix);
+    if (!(pap > 0.0)) return finish(dbest, best, k, kIndefiniteMatrix);   // detail::pap_is_valid (:142-144): +inf passes, NaN does not
     const double alpha = rk / pap;
     axpby(alpha, dp, 1.0, dx);
     if (recompute_interval > 0 && (k % recompute_interval) == recompute_interval - 1) {
