@@ -572,10 +572,27 @@ int pepshost_dump_sitps(const char *dir, int rows, int cols, int D, int d, const
 int pepshost_dump_configuration(const char *dir, int label, int rows, int cols, const int32_t *config) {
   return guarded([&]() { DumpConfiguration(make_cfg(1, rows, cols, config), 0, dir, (size_t)label); });
 }
-int pepshost_load_configuration(const char *dir, int label, int rows, int cols, int32_t *config_out) {
+// Configuration::Load (configuration.h:356-393): *loaded_out = 1 and the configuration in config_out, or *loaded_out = 0 (missing file, shape
+// sidecar of another size, payload that does not parse) -- never an error code for those, as the reference never throws from Load.
+// loaded_out == NULL: a configuration that cannot be loaded is an error (PEPSGPU_EEMPTY).
+int pepshost_load_configuration2(const char *dir, int label, int rows, int cols, int32_t *config_out, int *loaded_out) {
   return guarded([&]() {
     Configuration c(1, rows, cols);
-    LoadConfiguration(c, 0, dir, (size_t)label);
+    const bool ok = LoadConfiguration(c, 0, dir, (size_t)label);
+    if (loaded_out) *loaded_out = ok ? 1 : 0;
+    else if (!ok) throw std::runtime_error(std::string("Configuration::Load failed: ") + dir + "/configuration" + std::to_string(label));
+    if (ok) std::copy(c.data(), c.data() + (size_t)rows * cols, config_out);
+  });
+}
+int pepshost_load_configuration(const char *dir, int label, int rows, int cols, int32_t *config_out) {
+  return pepshost_load_configuration2(dir, label, rows, cols, config_out, nullptr);
+}
+// Configuration::StreamRead (configuration.h:446-455) of a text buffer: std::runtime_error (PEPSGPU_EEMPTY) when it holds too few numbers
+int pepshost_configuration_from_text(const char *text, int rows, int cols, int32_t *config_out) {
+  return guarded([&]() {
+    Configuration c(1, rows, cols);
+    std::istringstream iss(text);
+    StreamReadConfiguration(c, 0, iss);
     std::copy(c.data(), c.data() + (size_t)rows * cols, config_out);
   });
 }

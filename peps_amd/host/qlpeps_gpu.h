@@ -267,9 +267,23 @@ class SplitIndexTPST {
 };
 using SplitIndexTPS = SplitIndexTPST<double>;
 
-// Configuration::Dump / Load for one walker (configuration.h:284-330, :446-464): text matrix
-// `configuration{label}` + the `.shape` sidecar.
+// Configuration::Dump / Load for one walker (configuration.h:270-393): text matrix `configuration{label}` + the `.shape` sidecar.
+// Dump creates the directory (EnsureDirectoryExists) and throws std::ios_base::failure when the file cannot be written; Load never throws:
+// it returns false for a missing file, a sidecar whose (rows, cols) differ from the object's, or a payload that does not parse
+// (:356-393).  StreamReadConfiguration is Configuration::StreamRead (:420-440): throws std::runtime_error on short input.
+inline void EnsureDirectoryExists(const std::string &d) {
+  for (size_t k = 1; k <= d.size(); ++k)
+    if (k == d.size() || d[k] == '/') ::mkdir(d.substr(0, k).c_str(), 0755);
+}
+inline void StreamReadConfiguration(Configuration &cfg, size_t walker, std::istream &is) {
+  for (size_t r = 0; r < cfg.rows(); ++r)
+    for (size_t c = 0; c < cfg.cols(); ++c)
+      if (!(is >> cfg(walker, {r, c})))
+        throw std::runtime_error("Configuration::StreamRead: Failed to read data from stream (row " + std::to_string(r) +
+                                 ", col " + std::to_string(c) + ")");
+}
 inline void DumpConfiguration(const Configuration &cfg, size_t walker, const std::string &directory, size_t label) {
+  EnsureDirectoryExists(directory);
   const std::string file = directory + "/configuration" + std::to_string(label);
   std::ofstream ofs(file, std::ofstream::binary);
   if (!ofs.is_open()) throw std::ios_base::failure("Failed to open file: " + file);
@@ -277,18 +291,28 @@ inline void DumpConfiguration(const Configuration &cfg, size_t walker, const std
     for (size_t c = 0; c + 1 < cfg.cols(); ++c) ofs << cfg(walker, {r, c}) << " ";
     ofs << cfg(walker, {r, cfg.cols() - 1}) << std::endl;
   }
+  if (ofs.fail()) throw std::ios_base::failure("Failed to write configuration to file: " + file);
   std::ofstream sofs(file + ".shape");
   if (sofs.is_open()) sofs << cfg.rows() << " " << cfg.cols() << "\n";
 }
-inline void LoadConfiguration(Configuration &cfg, size_t walker, const std::string &directory, size_t label) {
+inline bool LoadConfiguration(Configuration &cfg, size_t walker, const std::string &directory, size_t label) {
   const std::string file = directory + "/configuration" + std::to_string(label);
+  {
+    std::ifstream sifs(file + ".shape");                     // (files of older versions have no sidecar)
+    if (sifs.is_open()) {
+      size_t rows = 0, cols = 0;
+      if (!(sifs >> rows >> cols)) return false;
+      if (rows != cfg.rows() || cols != cfg.cols()) return false;
+    }
+  }
   std::ifstream ifs(file, std::ifstream::binary);
-  if (!ifs.is_open()) throw std::ios_base::failure("Failed to open file: " + file);
-  for (size_t r = 0; r < cfg.rows(); ++r)
-    for (size_t c = 0; c < cfg.cols(); ++c)
-      if (!(ifs >> cfg(walker, {r, c})))
-        throw std::runtime_error("Configuration::StreamRead: Failed to read data from stream (row " + std::to_string(r) +
-                                 ", col " + std::to_string(c) + ")");
+  if (!ifs.is_open()) return false;
+  try {
+    StreamReadConfiguration(cfg, walker, ifs);
+  } catch (...) {
+    return false;
+  }
+  return !ifs.fail();
 }
 
 // BMPSContractor (bmps_contractor.h:187-1027): same method names; `tn` arguments disappear because

@@ -15,7 +15,7 @@ SYMBOLS = ["pepshost_last_error", "pepshost_mc_sweeps", "pepshost_energy_and_hol
            "pepshost_set_truncate_params", "pepshost_set_device", "pepshost_get_device",
            "pepshost_energy_and_holes_c128", "pepshost_exact_sum_partial_c128", "pepshost_exact_sum_finish_c128",
            "pepshost_mc_energy_grad_partial_c128", "pepshost_mc_sweeps_c128", "pepshost_load_sitps_c128", "pepshost_dump_sitps_c128",
-           "pepshost_mc_engine_warmup", "pepshost_mc_engine_warmup_dist", "pepshost_suwa_todo_chain"]
+           "pepshost_mc_engine_warmup", "pepshost_mc_engine_warmup_dist", "pepshost_suwa_todo_chain", "pepshost_load_configuration2", "pepshost_configuration_from_text"]
 
 _lib = None
 
@@ -274,6 +274,22 @@ def dump_configuration(directory, label, config):
 def load_configuration(directory, label, rows, cols):
     out = np.zeros((rows, cols), dtype=np.int32)
     _ck(lib().pepshost_load_configuration(directory.encode(), label, rows, cols, _p(out, C.c_int32)))
+    return out
+
+
+def try_load_configuration(directory, label, rows, cols):
+    """Configuration::Load (configuration.h:356-393): the configuration, or None where the reference returns false (missing file, `.shape`
+    sidecar of another size, payload that does not parse) -- no exception for those."""
+    out = np.zeros((rows, cols), dtype=np.int32)
+    ok = C.c_int(0)
+    _ck(lib().pepshost_load_configuration2(directory.encode(), label, rows, cols, _p(out, C.c_int32), C.byref(ok)))
+    return out if ok.value else None
+
+
+def configuration_from_text(text, rows, cols):
+    """Configuration::StreamRead (configuration.h:446-455); RuntimeError when the text holds too few numbers"""
+    out = np.zeros((rows, cols), dtype=np.int32)
+    _ck(lib().pepshost_configuration_from_text(text.encode(), rows, cols, _p(out, C.c_int32)))
     return out
 
 
