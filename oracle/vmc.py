@@ -496,45 +496,62 @@ def measure_spin_onehalf_off_diag_order_in_row(sitps, comp, inv_psi, row):
     return out
 
 
-def measure_structure_factor(sitps, comp):
+def measure_structure_factor(sitps, comp, reference_stack_state=False):
     """StructureFactorMeasurementMixin::MeasureStructureFactor (model_solvers/base/structure_factor_measurement_mixin.h:
     62-215) with BMPSWalker (two_dim_tn/tensor_network_2d/bmps/impl/bmps_walker.h): a walker forked from the UP vacuum is
     evolved through the excited row y1 (S+ at (y1, x1), source spin down) and the standard rows below; every row y2 > y1
     is closed against the DOWN environment of the rows below it with S- at (y2, x2) (target spin up).  Returns the flat
     tuples [y1, x1, y2, x2, value, ...]; value = amplitude of the doubly flipped configuration, 0 for a closed channel.
-    Restated with the contractor's own primitives: the walker = an UP stack that is extended and cut back."""
+    Restated with the contractor's own primitives: the walker = an UP stack that is extended and cut back.
+
+    reference_stack_state = False: the DOWN environments of all rows are grown first (every pair y1 < y2 is measured).
+    reference_stack_state = True: the mixin exactly as the reference runs it -- it takes `contractor.GetBMPS(DOWN)` as the
+    traversal of EvaluateObservables left it (ONE level after the row pass: the vacuum below the last row), and for a row y2
+    whose environment is not in the stack it pushes zeros and `continue`s PAST the walker's Evolve (:139-149, :205-207): the
+    values of y2 < Ly - 1 are zero, the walker of y1 < Ly - 2 reaches the last row without the rows between, only
+    y1 = Ly - 2 is the amplitude the text above describes.  This form reproduces the 96 golden values of the reference's
+    tests/test_model_solvers/test_square_xxz_measurer.cpp:246-345 (tests/test_oracle_measure.py)."""
     tn, c, config = comp.tn, comp.contractor, comp.config
     ly, lx = tn.rows, tn.cols
     out = []
-    c.GenerateBMPSApproach(tn, UP)
+    if not reference_stack_state:
+        c.GenerateBMPSApproach(tn, UP)
+    up_saved = list(c.bmps_set[UP])
     down_full = list(c.bmps_set[DOWN])
+    n_down = len(down_full)
+    main = [up_saved[0]]                                  # main_walker = BMPSWalker(tn, up_stack[0], UP, 1, trunc) (:121-122)
     for y1 in range(ly - 1):
-        main = list(c.bmps_set[UP])
         for x1 in range(lx):
             src_down = int(config[y1, x1]) == 0
             if src_down:
                 tn.update_site_tensor((y1, x1), 1, sitps)
             c.bmps_set[UP] = list(main)
-            c.GrowBMPSStep(tn, UP)
+            c.GrowBMPSStep(tn, UP)                                            # excited_walker.Evolve(excited row y1)
+            walker = c.bmps_set[UP][-1]
+            if src_down:
+                tn.update_site_tensor((y1, x1), int(config[y1, x1]), sitps)   # (the rows below are the standard ones)
             for y2 in range(y1 + 1, ly):
-                c.bmps_set[DOWN] = down_full[:ly - y2]                       # bottom_env = down_stack[ly-1-y2]
                 row = [0.0] * lx
-                c.InitBTen(tn, LEFT, y2)
-                c.GrowFullBTen(tn, RIGHT, y2, 1, True)
-                for x2 in range(lx):
-                    if src_down and int(config[y2, x2]) == 1:
-                        row[x2] = c.ReplaceOneSiteTrace(tn, (y2, x2), sitps[y2][x2][0], HORIZONTAL)
-                    if x2 < lx - 1:
-                        c.ShiftBTenWindow(tn, RIGHT)
+                if ly - 1 - y2 < n_down:
+                    c.bmps_set[UP] = [walker] * (y2 + 1)                      # the walker is the UP boundary of row y2
+                    c.bmps_set[DOWN] = down_full[:ly - y2]                    # bottom_env = down_stack[ly-1-y2]
+                    c.InitBTen(tn, LEFT, y2)
+                    c.GrowFullBTen(tn, RIGHT, y2, 1, True)
+                    for x2 in range(lx):
+                        if src_down and int(config[y2, x2]) == 1:
+                            row[x2] = c.ReplaceOneSiteTrace(tn, (y2, x2), sitps[y2][x2][0], HORIZONTAL)
+                        if x2 < lx - 1:
+                            c.ShiftBTenWindow(tn, RIGHT)
+                    if y2 < ly - 1:
+                        c.GrowBMPSStep(tn, UP)                                # excited_walker.Evolve(standard row y2)
+                        walker = c.bmps_set[UP][-1]
                 for x2 in range(lx):
                     out += [float(y1), float(x1), float(y2), float(x2), row[x2]]
-                if y2 < ly - 1:
-                    c.GrowBMPSStep(tn, UP)
-            if src_down:
-                tn.update_site_tensor((y1, x1), int(config[y1, x1]), sitps)
         c.bmps_set[UP] = list(main)
         c.bmps_set[DOWN] = list(down_full)
-        c.GrowBMPSStep(tn, UP)
+        c.GrowBMPSStep(tn, UP)                                                # main_walker.Evolve(standard row y1)
+        main = list(c.bmps_set[UP])
+    c.bmps_set[UP] = up_saved
     c.bmps_set[DOWN] = list(down_full)
     for pos in (LEFT, RIGHT, UP, DOWN):
         c.bten_set[pos] = []
@@ -547,8 +564,9 @@ class SquareNNNModelMeasurementSolver:
     bond_energy_h/v(/dr/ur) and the psi summary of the sample.  `model` supplies the bond terms (an energy-solver
     model of this module); XXZ adds SzSz_all2all and SmSp_row / SpSm_row (square_spin_onehalf_xxz_obc.h:215-288)."""
 
-    def __init__(self, model, spin_onehalf_xxz=True, structure_factor=False):
+    def __init__(self, model, spin_onehalf_xxz=True, structure_factor=False, structure_factor_reference_stack_state=False):
         self.model, self.xxz, self.structure_factor = model, spin_onehalf_xxz, structure_factor
+        self.sf_ref_state = structure_factor_reference_stack_state
         self.last_psi_summary = None
 
     def EvaluateObservables(self, sitps, comp):
@@ -622,7 +640,7 @@ class SquareNNNModelMeasurementSolver:
             out["SzSz_all2all"] = [sz[i] * sz[j] for i in range(sz.size) for j in range(i, sz.size)]
         self.last_psi_summary = compute_psi_consistency_summary_aligned(psi_list)
         if self.structure_factor:                                     # square_spin_onehalf_xxz_obc.h:238-248
-            out["SpSm_cross"] = measure_structure_factor(sitps, comp)
+            out["SpSm_cross"] = measure_structure_factor(sitps, comp, self.sf_ref_state)
         return out
 
 

@@ -158,3 +158,47 @@ def test_triangle_j1j2_exact_sum_matches_dense_hamiltonian():
                 c2[a], c2[b] = cf[b], cf[a]
                 H[idx[tuple(c2.ravel())], i] += 0.5 * J
     assert abs(e - psi @ H @ psi / (psi @ psi)) < 1e-12
+
+
+def test_reference_structure_factor_regression_golden(fixtures_dir):
+    """K8 -- the reference's own regression vector (tests/test_model_solvers/test_square_xxz_measurer.cpp:204-381): MCPEPSMeasurer on the 4x4
+    D = 8 Heisenberg fixture, checkerboard start, MCUpdateSquareNNExchange(42), 5 warm-up sweeps, NormalizeStateOrder1, 5 samples one sweep
+    apart, SVD(8, 16, 1e-15), structure factor on.  The 96 averaged SpSm_cross values (reference tolerance 1e-10) and the energy
+    (-9.22 +- 0.01) are reproduced by the oracle: the Monte-Carlo chain is the reference's deviate for deviate (std::mt19937, the
+    Metropolis rule, the sweep order), so are the order-1 rescale (monte_carlo_engine.h:206-240), the truncation with trunc_err > 0,
+    BMPSWalker Evolve / TraceWithBTen, and the state of the DOWN stack the mixin finds (`reference_stack_state`: one level -- rows
+    y2 < Ly - 1 read 0, structure_factor_measurement_mixin.h:139-149)."""
+    import json
+    import os
+    from oracle import qlten_io
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "xxz_spsm_cross_reference_golden.json")))
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, "tps_square_heisenberg4x4D8Double"))
+    L = 4
+    cfg = np.array([[(r + c) % 2 for c in range(L)] for r in range(L)])                  # CreateCheckerboardConfig (:76-84)
+    tp = BMPSTruncateParams.SVD(*gold["trunc"])
+    comp = vmc.TPSWaveFunctionComponent(s, cfg, tp)
+    upd = vmc.MCUpdateSquareNNExchangeOBC(gold["seed"])
+    for _ in range(gold["warmup_sweeps"]):                                               # MonteCarloEngine::WarmUp (:146-176)
+        upd(s, comp)
+    f = (1.0 / abs(comp.amplitude)) ** (1.0 / (L * L))                                   # NormalizeStateOrder1 (:206-240)
+    s = [[[t * f for t in s[r][c]] for c in range(L)] for r in range(L)]
+    comp = vmc.TPSWaveFunctionComponent(s, comp.config.copy(), tp)
+    model = vmc.SquareSpinOneHalfXXZModelOBC(1.0, 1.0, 0.0)
+    vals, energies = [], []
+    for _ in range(gold["samples"]):                                                     # MCPEPSMeasurer::Measure_ (impl.h:495-519)
+        upd(s, comp)
+        ms = vmc.SquareNNNModelMeasurementSolver(model, structure_factor=True, structure_factor_reference_stack_state=True)
+        obs = ms.EvaluateObservables(s, comp)
+        energies.append(obs["energy"][0])
+        t = np.array(obs["SpSm_cross"]).reshape(-1, 5)
+        assert t.shape[0] == 96
+        vals.append(t[:, 4])
+    want = np.array(gold["spsm_cross_values"])
+    got = np.mean(vals, axis=0)
+    assert np.max(np.abs(got - want)) < 1e-10                                            # the reference's own tolerance (:374-381)
+    assert np.count_nonzero(got) == np.count_nonzero(want) == 44
+    assert abs(np.mean(energies) - gold["energy"]) < gold["energy_tol"]
+    # with every DOWN environment grown (the default of this library) the pairs of the last source row are the same numbers
+    ms = vmc.SquareNNNModelMeasurementSolver(model, structure_factor=True)
+    full = np.array(ms.EvaluateObservables(s, comp)["SpSm_cross"]).reshape(-1, 5)[:, 4]
+    assert np.max(np.abs(full[80:] - vals[-1][80:])) < 1e-12 and np.count_nonzero(full[:80]) > np.count_nonzero(vals[-1][:80])
