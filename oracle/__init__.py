@@ -18,7 +18,12 @@ Parity pinning (see tests/test_oracle_*.py, tests/golden/):
   K5  4x4 D=8 Heisenberg fixture, exact-sum energy / checkerboard amplitude
   K6  ExactSumMeasurerMPI registry of the 2x2 spinless-fermion simple-update state: energy, charge, per-bond
       energies (tests/test_algorithm/test_exact_summation_measurer.cpp:205-240 -> tests/golden/k4_exact_sum_measurer.json)
-The SVD truncation rule for trunc_err > 0 is "parity unpinned" (no reference binary can be produced
+  K8  MCPEPSMeasurer regression vector of tests/test_model_solvers/test_square_xxz_measurer.cpp:204-381 (96 SpSm_cross values, seed 42,
+      SVD(8, 16, 1e-15)): the Monte-Carlo chain, the order-1 rescale, the walker traces -- reproduced to 6e-16
+      (tests/test_oracle_measure.py, tests/golden/xxz_spsm_cross_reference_golden.json)
+  and the reference's unit tests of SuwaTodoStateUpdate, ConjugateGradientSolver and Configuration I/O, case by case
+      (tests/test_cpu_suwa_todo.py, test_cpu_cg_reference_cases.py, test_cpu_configuration_reference_cases.py)
+The SVD truncation rule for trunc_err > 0 is "parity unpinned" beyond the instance K8 exercises (no reference binary can be produced
 here).  Fermions: the Z2-graded algebra of oracle/graded.py is pinned on the reference's 2x2
 spinless-fermion known answers (amplitudes, ratios, energies: tests/test_oracle_fermion.py); the
 element-wise sign convention of fermionic GRADIENT tensors (CalGTenForFermionicTensors) stays unpinned.

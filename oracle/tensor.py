@@ -64,7 +64,8 @@ def qr(a, ldims):
 def truncation_rank(s, trunc_err, dmin, dmax):
     """Kept dimension and actual truncation error of qlten::SVD(trunc_err, Dmin, Dmax).
 
-    PARITY UNPINNED for trunc_err > 0 (the rule lives in TensorToolkit): singular values are
+    PARITY UNPINNED for trunc_err > 0 beyond one instance (the rule lives in TensorToolkit; K8 -- SVD(8, 16, 1e-15) inside the
+    reference's MCPEPSMeasurer regression vector -- is reproduced to 1e-15 with it): singular values are
     discarded from the smallest while the kept count exceeds Dmax, or exceeds Dmin and the
     accumulated discarded weight / total weight stays strictly below trunc_err.  With
     trunc_err == 0 this keeps min(Dmax, len(s)) values, the only case throughput runs use
