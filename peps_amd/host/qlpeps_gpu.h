@@ -1357,7 +1357,13 @@ struct SpinOneHalfMeasurementHooks {
     const size_t per = (Ly - 1) * Lx * Ly / 2 * Lx * 5;       // sum_{y1} Lx * (Ly-1-y1) * Lx tuples of 5
     auto &cross = out.make("SpSm_cross", per);
     std::vector<size_t> fill(n, 0);
-    c.GenerateBMPSApproach(UP);                                // UP = vacuum, DOWN fully grown (traversal start state)
+    // Default: every DOWN environment is grown first, every pair y1 < y2 is measured.  SetStructureFactorReferenceStackState(true):
+    // the mixin exactly as the reference runs it -- it reads GetBMPS(DOWN) as the traversal left it (one level after the row pass),
+    // pushes zeros for a row y2 whose environment is not in the stack and `continue`s past the walker's Evolve (:139-149): this
+    // form reproduces the reference's regression vector in the oracle (K8, tests/test_oracle_measure.py); here it is NOT yet run on
+    // the GPU (round 4) and therefore off.
+    if (!structure_factor_reference_stack_state_) c.GenerateBMPSApproach(UP);   // UP = vacuum, DOWN fully grown (traversal start state)
+    const size_t n_down = c.BMPSStackSize(DOWN);
     auto main_walker = c.MakeWalker(UP, 0);                    // BMPSWalker(tn, up_stack[0], UP, 1, trunc_params)
     const std::vector<int32_t> spin_down(n, 0);                // GetSiteTensor(y2, x2, 0)
     for (size_t y1 = 0; y1 + 1 < Ly; ++y1) {
@@ -1374,6 +1380,15 @@ struct SpinOneHalfMeasurementHooks {
         excited_walker.Evolve();                                // absorb the excited row y1
         for (size_t y2 = y1 + 1; y2 < Ly; ++y2) {
           const size_t bottom = Ly - 1 - y2;                    // bottom_env = down_stack[Ly-1-y2]
+          if (bottom >= n_down) {                               // (:139-149; only in the reference stack state)
+            for (size_t w = 0; w < n; ++w)
+              for (size_t x2 = 0; x2 < Lx; ++x2) {
+                double *t = &cross[w * per + fill[w]];
+                t[0] = (double)y1; t[1] = (double)x1; t[2] = (double)y2; t[3] = (double)x2; t[4] = 0.0;
+                fill[w] += 5;
+              }
+            continue;
+          }
           excited_walker.SetMPO(y2);                            // standard_mpo = tn.get_row(y2)
           excited_walker.InitBTenLeft(bottom, Lx);
           excited_walker.InitBTenRight(bottom, Lx - 1);
@@ -1404,6 +1419,8 @@ struct SpinOneHalfMeasurementHooks {
     }
   }
   bool enable_structure_factor_measurement_ = false;
+  void SetStructureFactorReferenceStackState(bool on) { structure_factor_reference_stack_state_ = on; }
+  bool structure_factor_reference_stack_state_ = false;
 
   static void AddSzSzAll2All(const TPSWaveFunctionComponent &comp, ObservableMap &out) {   // :225-236
     const size_t ly = comp.contractor.rows(), lx = comp.contractor.cols(), n = comp.config.walkers(), N = ly * lx;
