@@ -687,6 +687,45 @@ class TransverseFieldIsingSquareOBC:
         energy = energy + self.CalDiagTermEnergy(comp.config)
         return energy, holes, psi_list
 
+    def EvaluateObservables(self, sitps, comp):
+        """Registry of the model (:60-140): energy, spin_z, sigma_x per site (= -off-diagonal term / h, 0 for h = 0), SzSz_row along the
+        middle row (x0 = lx / 4, i = 1 .. lx / 2).  Same row pass as the energy; `last_psi_summary` as the other measurement solvers."""
+        tn, c, config = comp.tn, comp.contractor, comp.config
+        ly, lx = tn.rows, tn.cols
+        out, psi_list, energy_ex = {}, [], 0.0
+        cplx = False
+        sigma_x = [[0.0] * lx for _ in range(ly)]
+        two_point = []
+        c.SetTruncateParams(comp.trun_para)
+        c.GenerateBMPSApproach(tn, UP)
+        for row in range(ly):
+            c.InitBTen(tn, LEFT, row)
+            c.GrowFullBTen(tn, RIGHT, row, 1, True)
+            psi = c.Trace(tn, (row, 0), HORIZONTAL)
+            psi_list.append(psi)
+            cplx = cplx or np.iscomplexobj(psi)
+            inv_psi = 1.0 / psi
+            for col in range(lx):
+                site = (row, col)
+                psi_ex = c.ReplaceOneSiteTrace(tn, site, sitps[row][col][1 - int(config[site])], HORIZONTAL)   # :195-203
+                ex = (-self.h) * np.conj(psi_ex * inv_psi)
+                energy_ex = energy_ex + ex
+                sigma_x[row][col] = (-ex) / self.h if self.h != 0.0 else 0.0                               # :96
+                if col < lx - 1:
+                    c.ShiftBTenWindow(tn, RIGHT)
+            if row == ly // 2:                                                                              # :101-110
+                sz1 = float(config[row, lx // 4]) - 0.5
+                two_point += [sz1 * (float(config[row, lx // 4 + i]) - 0.5) for i in range(1, lx // 2 + 1)]
+            if row < ly - 1:
+                c.ShiftBMPSWindow(tn, DOWN)
+        out["energy"] = [energy_ex + self.CalDiagTermEnergy(config)]
+        out["spin_z"] = [float(v) - 0.5 for v in np.asarray(config).ravel()]
+        out["sigma_x"] = [v for r in sigma_x for v in r]
+        if two_point:
+            out["SzSz_row"] = two_point
+        self.last_psi_summary = compute_psi_consistency_summary_aligned(psi_list)
+        return out
+
 
 # ---------------------------------------------------------------------------------------------
 def generate_all_permutation_configs(particle_counts, lx, ly):

@@ -202,3 +202,47 @@ def test_reference_structure_factor_regression_golden(fixtures_dir):
     ms = vmc.SquareNNNModelMeasurementSolver(model, structure_factor=True)
     full = np.array(ms.EvaluateObservables(s, comp)["SpSm_cross"]).reshape(-1, 5)[:, 4]
     assert np.max(np.abs(full[80:] - vals[-1][80:])) < 1e-12 and np.count_nonzero(full[:80]) > np.count_nonzero(vals[-1][:80])
+
+
+def test_reference_heisenberg_exact_sum_measurer_registry(fixtures_dir):
+    """ExactSumMeasurerMPI on the reference's 2x2 Heisenberg states (tests/test_algorithm/test_exact_summation_measurer.cpp:411-545): the
+    whole registry of the simple-update state -- energy, spin_z, bond_energy_h / v, SzSz_all2all, SmSp_row, SpSm_row -- against the
+    numbers the reference asserts at 1e-10, the key set, energy == sum of bond energies, and the closed forms of the 'lowest' state."""
+    import json
+    import os
+    from oracle import qlten_io
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "k4_heisenberg_exact_sum_measurer.json")))
+    cfgs = vmc.generate_all_permutation_configs([2, 2], 2, 2)                          # next_permutation of {0, 0, 1, 1} (:438-441)
+    tp = BMPSTruncateParams.SVD(1, 8, 1e-16)
+    make = lambda: vmc.SquareNNNModelMeasurementSolver(vmc.SquareSpinOneHalfXXZModelOBC(1.0, 1.0, 0.0))
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, "heisenberg_tps_double_from_simple_update"))
+    obs = vmc.exact_sum_measure(s, cfgs, tp, make)
+    assert set(obs) == set(gold["observables"])                                       # AssertObservableKeySet (:461-464)
+    assert abs(np.sum(obs["energy"]) - np.sum(obs["bond_energy_h"]) - np.sum(obs["bond_energy_v"])) < 1e-10
+    for key, want in gold["observables"].items():
+        assert np.max(np.abs(np.asarray(obs[key]) - np.asarray(want))) < 1e-10, key  # kTol (:458)
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, "heisenberg_tps_doublelowest"))
+    obs = vmc.exact_sum_measure(s, cfgs, tp, make)
+    tol = {"energy": 6e-8, "spin_z": 5e-4}
+    for key, want in gold["lowest"].items():
+        assert np.max(np.abs(np.asarray(obs[key]) - np.asarray(want))) < tol.get(key, 1e-5), key
+
+
+def test_reference_tfim_exact_sum_measurer_registry(fixtures_dir):
+    """TransverseFieldIsingSquareOBC::EvaluateObservables (transverse_field_ising_square_obc.h:60-140) through ExactSumMeasurerMPI on the
+    reference's 2x2 states (tests/test_algorithm/test_exact_summation_measurer.cpp:548-651): energy, spin_z, sigma_x per site and SzSz_row
+    of the simple-update state at the reference's 1e-10; the free-fermion energy and the QuSpin ED observables of the 'lowest' state."""
+    import json
+    import os
+    from oracle import qlten_io
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "k4_tfim_exact_sum_measurer.json")))
+    cfgs = vmc.generate_all_binary_configs(2, 2)                                       # GenerateAllBinaryConfigs (:575)
+    tp = BMPSTruncateParams.SVD(1, 8, 1e-16)
+    make = lambda: vmc.TransverseFieldIsingSquareOBC(1.0)
+    obs = vmc.exact_sum_measure(qlten_io.load_sitps(os.path.join(fixtures_dir, "transverse_ising_tps_double_from_simple_update")), cfgs, tp, make)
+    assert set(obs) == {"energy", "spin_z", "sigma_x", "SzSz_row"}                     # AssertObservableKeySet (:596)
+    for key, want in gold["observables"].items():
+        assert np.max(np.abs(np.asarray(obs[key]) - np.asarray(want))) < 1e-10, key
+    obs = vmc.exact_sum_measure(qlten_io.load_sitps(os.path.join(fixtures_dir, "transverse_ising_tps_doublelowest")), cfgs, tp, make)
+    for key, want in gold["lowest"].items():
+        assert np.max(np.abs(np.asarray(obs[key]) - np.asarray(want))) < (6e-8 if key == "energy" else 1e-5), key
