@@ -308,7 +308,7 @@ int pepshost_mc_energy_grad_partial_c128(int rows, int cols, int D, int d, int c
   });
 }
 
-// EvaluateObservables of the XXZ (model 0) / J1-J2 (model 2) / triangular J1-J2 (model 4, p[0] = j2) measurement solver on fixed configurations, or -- with
+// EvaluateObservables of the XXZ (model 0) / TFIM (model 1, p[0] = h) / J1-J2 (model 2) / triangular J1-J2 (model 4, p[0] = j2) measurement solver on fixed configurations, or -- with
 // n_samples > 0 -- a whole MCPEPSMeasurer run (warm-up, samples, statistics across the walkers, optional DumpData).
 // Results come back through a flat buffer described by `keys_out` ("key:len;key:len;..."): for n_samples == 0 the
 // per-walker values [key][walker][len], else [key][mean(len) | stderr(len)], followed by psi_mean[n], psi_rel_err[n]
@@ -324,8 +324,10 @@ int pepshost_measure(int rows, int cols, int D, int d, int chi, int dtype, const
     SquareSpinOneHalfXXZModelOBC xxz(p[0], p[1], p[2]);
     SquareSpinOneHalfJ1J2XXZModelOBC j1j2(p[0], p[1], p[2], p[3], p[4]);
     SpinOneHalfTriJ1J2HeisenbergSqrPEPS trij(p[0]);
-    if (model != 0 && model != 2 && model != 4) throw std::invalid_argument("pepshost_measure: model must be xxz, j1j2 or trij1j2");
+    TransverseFieldIsingSquareOBC tfim(p[0]);
+    if (model < 0 || model > 4 || model == 3) throw std::invalid_argument("pepshost_measure: model must be xxz, tfim, j1j2 or trij1j2");
     xxz.SetEnableStructureFactor(p[7] != 0.0);                  // params[7]: structure factor switch (xxz only)
+    xxz.SetStructureFactorReferenceStackState(p[6] != 0.0);     // params[6]: the DOWN stack as the reference's traversal leaves it (K8; off)
     std::string keys;
     std::vector<double> vals;
     auto emit = [&](const std::string &key, const std::vector<double> &a, const std::vector<double> *b, size_t len) {
@@ -338,10 +340,13 @@ int pepshost_measure(int rows, int cols, int D, int d, int chi, int dtype, const
     };
     PsiSummary psi;
     if (n_samples <= 0) {
-      ObservableMap obs = model == 0 ? xxz.EvaluateObservables(sitps, comp) : model == 2 ? j1j2.EvaluateObservables(sitps, comp)
-                                                                                         : trij.EvaluateObservables(sitps, comp);
+      ObservableMap obs = model == 0   ? xxz.EvaluateObservables(sitps, comp)
+                          : model == 1 ? tfim.EvaluateObservables(sitps, comp)
+                          : model == 2 ? j1j2.EvaluateObservables(sitps, comp)
+                                       : trij.EvaluateObservables(sitps, comp);
       for (const auto &kv : obs.values) emit(kv.first, kv.second, nullptr, obs.len(kv.first));
       psi = model == 0   ? xxz.SquareNNModelMeasurementSolver<SquareSpinOneHalfXXZModelOBC>::EvaluatePsiSummary()
+            : model == 1 ? tfim.EvaluatePsiSummary()
             : model == 2 ? j1j2.SquareNNNModelMeasurementSolver<SquareSpinOneHalfJ1J2XXZModelOBC>::EvaluatePsiSummary()
                          : trij.EvaluatePsiSummary();
     } else {
@@ -359,9 +364,11 @@ int pepshost_measure(int rows, int cols, int D, int d, int chi, int dtype, const
       MCUpdateSquareNNExchangeOBC ex(sd);
       MCUpdateSquareNNFullSpaceUpdateOBC fs(sd);
       if (updater == 0 && model == 0) run(ex, xxz);
+      else if (updater == 0 && model == 1) run(ex, tfim);
       else if (updater == 0 && model == 2) run(ex, j1j2);
       else if (updater == 0) run(ex, trij);
       else if (model == 0) run(fs, xxz);
+      else if (model == 1) run(fs, tfim);
       else if (model == 2) run(fs, j1j2);
       else run(fs, trij);
       std::copy(comp.config.data(), comp.config.data() + (size_t)n * rows * cols, configs);

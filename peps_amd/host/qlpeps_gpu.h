@@ -1950,8 +1950,69 @@ class TransverseFieldIsingSquareOBC {
     for (size_t w = 0; w < n; ++w) out.energy[w] += CalDiagTermEnergy(comp.config, w);
     return out;
   }
+  // Registry of the model (:60-152): energy, spin_z, sigma_x per site (= -off-diagonal term / h; 0 for h = 0), SzSz_row along the
+  // middle row (x0 = lx / 4, i = 1 .. lx / 2).  Same row pass as the energy.  (Round 4: the oracle form is pinned on the reference's
+  // exact-sum measurer numbers at 1e-10, tests/test_oracle_measure.py; this device form has not been run on the GPU yet.)
+  ObservableMap EvaluateObservables(const SplitIndexTPS &, TPSWaveFunctionComponent &comp) {
+    auto &c = comp.contractor;
+    const size_t ly = c.rows(), lx = c.cols(), n = comp.config.walkers(), half = lx / 2;
+    ObservableMap out;
+    out.n = n;
+    auto &sx = out.make("sigma_x", ly * lx);
+    auto &sz = out.make("spin_z", ly * lx);
+    auto &en = out.make("energy", 1);
+    std::vector<std::vector<double>> psi_list;
+    c.GenerateBMPSApproach(UP);
+    for (size_t row = 0; row < ly; ++row) {
+      c.InitBTen(LEFT, row);
+      c.GrowFullBTen(RIGHT, row, 1, true);
+      psi_list.push_back(c.Trace({row, 0}, HORIZONTAL));
+      const std::vector<double> &psi = psi_list.back();
+      for (size_t col = 0; col < lx; ++col) {
+        std::vector<int32_t> cand(n);
+        for (size_t w = 0; w < n; ++w) cand[w] = 1 - comp.config(w, {row, col});
+        std::vector<double> psi_ex = c.ReplaceOneSiteTrace({row, col}, HORIZONTAL, 1, cand);          // :195-203
+        for (size_t w = 0; w < n; ++w) {
+          if (psi[w] == 0.0) throw std::runtime_error("Wavefunction amplitude is near zero, causing division by zero.");
+          const double ex = (-h_) * (psi_ex[w] / psi[w]);
+          en[w] += ex;
+          sx[w * ly * lx + row * lx + col] = h_ != 0.0 ? -ex / h_ : 0.0;                              // :96
+        }
+        if (col + 1 < lx) c.ShiftBTenWindow(RIGHT);
+      }
+      if (row == ly / 2 && half > 0) {                                                                  // :101-110
+        auto &szsz = out.make("SzSz_row", half);
+        for (size_t w = 0; w < n; ++w) {
+          const double sz1 = double(comp.config(w, {row, lx / 4})) - 0.5;
+          for (size_t i = 1; i <= half; ++i) szsz[w * half + i - 1] = sz1 * (double(comp.config(w, {row, lx / 4 + i})) - 0.5);
+        }
+      }
+      if (row + 1 < ly) c.ShiftBMPSWindow(DOWN);
+    }
+    last_psi_.psi_mean.assign(n, 0.0);
+    last_psi_.psi_rel_err.assign(n, 0.0);
+    std::vector<double> one(psi_list.size());
+    for (size_t w = 0; w < n; ++w) {
+      en[w] += CalDiagTermEnergy(comp.config, w);
+      for (size_t r = 0; r < ly; ++r)
+        for (size_t cc = 0; cc < lx; ++cc) sz[w * ly * lx + r * lx + cc] = double(comp.config(w, {r, cc})) - 0.5;
+      for (size_t k = 0; k < one.size(); ++k) one[k] = psi_list[k][w];
+      auto st = ComputePsiConsistencySummaryAligned(one);
+      last_psi_.psi_mean[w] = st.first;
+      last_psi_.psi_rel_err[w] = st.second;
+    }
+    return out;
+  }
+  const PsiSummary &EvaluatePsiSummary() const { return last_psi_; }
+  std::vector<ObservableMeta> DescribeObservables(size_t ly, size_t lx) const {                        // :142-149
+    return {{"energy", "Total energy (scalar)", {}, {}},
+            {"spin_z", "Local spin Sz per site (Ly,Lx)", {ly, lx}, {"y", "x"}},
+            {"sigma_x", "Transverse magnetisation per site (Ly,Lx)", {ly, lx}, {"y", "x"}},
+            {"SzSz_row", "SzSz correlations along middle row (flat)", {lx / 2}, {"segment"}}};
+  }
  private:
   double h_;
+  PsiSummary last_psi_;
 };
 
 // Accumulators of the evaluators: S_O = sum w O*, S_EO = sum w E_loc* O*, sum w, sum w E_loc
