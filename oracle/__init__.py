@@ -21,6 +21,8 @@ Parity pinning (see tests/test_oracle_*.py, tests/golden/):
   K8  MCPEPSMeasurer regression vector of tests/test_model_solvers/test_square_xxz_measurer.cpp:204-381 (96 SpSm_cross values, seed 42,
       SVD(8, 16, 1e-15)): the Monte-Carlo chain, the order-1 rescale, the walker traces -- reproduced to 6e-16
       (tests/test_oracle_measure.py, tests/golden/xxz_spsm_cross_reference_golden.json)
+  K9  MCPEPSMeasurer regression energy of the 6x6 fU1 t-J state, tests/test_model_solvers/test_tJ_model_solver.cpp:72-75,233-275
+      (-14.74320489110316, seed 42, 20 sweeps): reproduced to 2e-15 (tests/test_oracle_fermion.py) -- the fermionic chain, truncation and signs
   and the reference's unit tests of SuwaTodoStateUpdate, ConjugateGradientSolver and Configuration I/O, case by case
       (tests/test_cpu_suwa_todo.py, test_cpu_cg_reference_cases.py, test_cpu_configuration_reference_cases.py)
 The SVD truncation rule for trunc_err > 0 is "parity unpinned" beyond the instance K8 exercises (no reference binary can be produced

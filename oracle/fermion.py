@@ -228,6 +228,72 @@ class SquaretJVModelOBC(SquareSpinlessFermionOBC):
         return -self.mu * float(np.sum(np.asarray(cfg) != 2))
 
 
+class MCUpdateSquareNNExchangeOBC:
+    """MCUpdateSquareNNExchangeOBC (vmc_basic/configuration_update_strategies/square_nn_updater.h:25-83, :142-189) on a fermionic state:
+    the row pass runs on the row-major decorated network, the column pass on the column-major one (each bond exchange is then local:
+    module docstring), both consume ONE std::mt19937 stream in the reference's order -- a deviate only when |psi_b| < |psi_a|.
+    `amplitude` is |psi_a| as the reference carries it: the value of the constructor's EvaluateAmplitude, then every accepted psi_b
+    (the sign convention of the two decorations differs, the Metropolis rule only sees magnitudes)."""
+
+    def __init__(self, seed=0):
+        self.rng = vmc.StdMT19937(seed)
+
+    def _pass(self, fs, cfg, amp_abs, order, trun_para):
+        from .bmps import LEFT, DOWN, RIGHT, UP, HORIZONTAL, VERTICAL
+        comp = fs.component(cfg, order, trun_para)
+        tn, c = comp.tn, comp.contractor
+        rows, cols = fs.rows, fs.cols
+        accepted = 0
+
+        def update(s1, s2, bond_dir):                                           # TwoSiteNNUpdateLocalImpl (:146-188)
+            nonlocal amp_abs, accepted
+            c1, c2 = int(cfg[s1]), int(cfg[s2])
+            if c1 == c2:
+                return
+            new = cfg.copy()
+            new[s1], new[s2] = c2, c1
+            ne = fs.ext_config(new, order)                                      # only the two sites of the bond change their decoration
+            psi_b = c.ReplaceNNSiteTrace(tn, s1, s2, bond_dir, fs.ext[s1[0]][s1[1]][ne[s1]], fs.ext[s2[0]][s2[1]][ne[s2]])
+            if abs(psi_b) < amp_abs:
+                div = abs(psi_b) / amp_abs
+                if not (self.rng.u_double() < div * div):
+                    return
+            cfg[s1], cfg[s2] = c2, c1
+            comp.UpdateLocal(fs.ext, psi_b, (s1, int(ne[s1])), (s2, int(ne[s2])))
+            amp_abs = abs(psi_b)
+            accepted += 1
+
+        if order == ROW:
+            c.GenerateBMPSApproach(tn, UP)
+            for row in range(rows):
+                c.InitBTen(tn, LEFT, row)
+                c.GrowFullBTen(tn, RIGHT, row, 2, True)
+                for col in range(cols - 1):
+                    update((row, col), (row, col + 1), HORIZONTAL)
+                    if col < cols - 2:
+                        c.ShiftBTenWindow(tn, RIGHT)
+                if row < rows - 1:
+                    c.ShiftBMPSWindow(tn, DOWN)
+        else:
+            c.GenerateBMPSApproach(tn, LEFT)
+            for col in range(cols):
+                c.InitBTen(tn, UP, col)
+                c.GrowFullBTen(tn, DOWN, col, 2, True)
+                for row in range(rows - 1):
+                    update((row, col), (row + 1, col), VERTICAL)
+                    if row < rows - 2:
+                        c.ShiftBTenWindow(tn, DOWN)
+                if col < cols - 1:
+                    c.ShiftBMPSWindow(tn, RIGHT)
+        return accepted, amp_abs
+
+    def __call__(self, fs, cfg, amp_abs, trun_para):
+        """one sweep; `cfg` (physical states) is updated in place.  Returns (accept rate, |psi| of the configuration reached)."""
+        a1, amp_abs = self._pass(fs, cfg, amp_abs, ROW, trun_para)
+        a2, amp_abs = self._pass(fs, cfg, amp_abs, COL, trun_para)
+        return (a1 + a2) / float(fs.cols * (fs.rows - 1) + fs.rows * (fs.cols - 1)), amp_abs
+
+
 def exact_sum_energy(fs, all_configs, trun_para, model):
     """ExactSumEnergyEvaluatorMPI (exact_summation_energy_evaluator.h:173-302), energy only"""
     wsum = wesum = 0.0

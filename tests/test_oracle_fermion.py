@@ -143,3 +143,36 @@ def test_exact_sum_measurer_reproduces_reference_registry(fixtures_dir):
         assert np.max(np.abs(sum(p[0][key] for p in parts if key in p[0]) / w - obs[key])) < 1e-13
     with pytest.raises(RuntimeError):
         fermion.exact_sum_measure(fs, [], tp, model)
+
+
+def test_k9_reference_tj_measurer_regression_energy(fixtures_dir):
+    """K9 -- the reference's deterministic regression value of MCPEPSMeasurer on a FERMIONIC state
+    (tests/test_model_solvers/test_tJ_model_solver.cpp:72-75, :233-275): 6x6 t-J state with two holes (fU1-symmetric tensors, D = 8,
+    J / t = 0.3), start configuration `configuration0`, MCUpdateSquareNNExchange(42), 10 warm-up sweeps, NormalizeStateOrder1, 10 samples one
+    sweep apart, BMPSTruncateParams::SVD(8, 16, 1e-15), SquaretJNNModel(t = 1, J = 0.3, mu = 0): energy -14.74320489110316, tolerance 1e-8.
+    The oracle reproduces it to 1e-14: the decoding of the U(1)-block-sparse fermionic tensors, the decorated-dense form of the graded
+    network at this size, the fermionic Monte-Carlo chain deviate for deviate over twenty sweeps of a three-state exchange updater, the
+    truncated boundary MPS of a fermionic network, and every sign of the t-J local energy (hole hops along rows and columns, spin exchange)."""
+    import os
+    from oracle.graded import load_qlten_z2
+    d = os.path.join(fixtures_dir, "tps_tJ_6x6Hole2_J0.3_D8_fU1")
+    L = 6
+    gts = [[[load_qlten_z2(os.path.join(d, "tps_ten%d_%d_%d.qlten" % (r, c, s))) for s in range(3)] for c in range(L)] for r in range(L)]
+    F = fermion
+    fs = F.FermionSITPS(gts)
+    assert fs.nf == [1, 1, 0]                                        # up, down: odd; empty: even (tj_single_site_state.h:19-23)
+    cfg = np.loadtxt(os.path.join(d, "configuration0"), dtype=int).reshape(L, L)
+    assert sorted(np.bincount(cfg.ravel(), minlength=3).tolist()) == [2, 17, 17]
+    tp = BMPSTruncateParams.SVD(8, 16, 1e-15)
+    amp = abs(fs.component(cfg, F.ROW, tp).amplitude)                # TPSWaveFunctionComponent constructor
+    upd = F.MCUpdateSquareNNExchangeOBC(42)
+    for _ in range(10):                                              # MonteCarloEngine::WarmUp
+        _, amp = upd(fs, cfg, amp, tp)
+    amp = abs(fs.component(cfg, F.ROW, tp).amplitude)                # NormalizeStateOrder1 rebuilds the component (the scale drops out)
+    model = F.SquaretJVModelOBC(1.0, 0.0, 0.3, 0.0, 0.0)             # SquaretJNNModel(t, J, mu) = mixin(t, 0, J, 0, mu) (square_tJ_model.h:619-623)
+    es = []
+    for _ in range(10):                                              # MCPEPSMeasurer::Measure_
+        _, amp = upd(fs, cfg, amp, tp)
+        es.append(model.CalEnergy(fs, cfg, tp)[0])
+    assert abs(np.mean(es) - (-14.74320489110316)) < 1e-8            # EXPECTED_ENERGY, ENERGY_TOLERANCE (:74-75)
+    assert abs(np.mean(es) - (-14.74320489110316)) < 1e-12
