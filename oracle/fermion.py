@@ -227,6 +227,16 @@ class SquaretJVModelOBC(SquareSpinlessFermionOBC):
     def onsite(self, cfg):
         return -self.mu * float(np.sum(np.asarray(cfg) != 2))
 
+    def EvaluateObservables(self, fs, cfg, trun_para):
+        """registry of SquareNNNModelMeasurementSolver<SquaretJVModel> (square_nnn_model_measurement_solver.h:33-210 with the t-J hooks
+        square_tJ_model.h:215-228): energy, spin_z (+1/2 up, -1/2 down, 0 empty), charge (1 on an occupied site), per-bond energies"""
+        bonds = {}
+        e, _ = self.CalEnergy(fs, cfg, trun_para, bonds)
+        c = np.asarray(cfg).ravel()
+        return {"energy": np.array([e]), "spin_z": np.where(c == 0, 0.5, np.where(c == 1, -0.5, 0.0)), "charge": (c != 2).astype(np.float64),
+                "bond_energy_h": bonds["h"].ravel(), "bond_energy_v": bonds["v"].ravel(), "bond_energy_dr": bonds["dr"].ravel(),
+                "bond_energy_ur": bonds["ur"].ravel()}
+
 
 class MCUpdateSquareNNExchangeOBC:
     """MCUpdateSquareNNExchangeOBC (vmc_basic/configuration_update_strategies/square_nn_updater.h:25-83, :142-189) on a fermionic state:

@@ -176,3 +176,25 @@ def test_k9_reference_tj_measurer_regression_energy(fixtures_dir):
         es.append(model.CalEnergy(fs, cfg, tp)[0])
     assert abs(np.mean(es) - (-14.74320489110316)) < 1e-8            # EXPECTED_ENERGY, ENERGY_TOLERANCE (:74-75)
     assert abs(np.mean(es) - (-14.74320489110316)) < 1e-12
+
+
+def test_reference_tj_exact_sum_measurer_registry(fixtures_dir):
+    """ExactSumMeasurerMPI with SquaretJVModel on the reference's 2x2 t-J states (tests/test_algorithm/test_exact_summation_measurer.cpp:
+    652-795): the whole registry of the simple-update state -- energy, spin_z, charge, the four bond-energy maps -- at the reference's
+    1e-10, total charge 2, energy == sum of the bond energies, and the 'lowest' state within the tolerances stated there."""
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "k4_tj_exact_sum_measurer.json")))
+    cfgs = [np.array(p).reshape(2, 2) for p in sorted(set(itertools.permutations([0, 1, 2, 2])))]      # :683-687
+    tp = BMPSTruncateParams.SVD(4, 4, 0.0)
+    model = fermion.SquaretJVModelOBC(1.0, 0.0, 0.3, 0.075, 0.0)
+    fs = fermion.FermionSITPS(fermion.load_fermion_sitps(os.path.join(fixtures_dir, "tj_model_tps_double_from_simple_update")))
+    obs = fermion.exact_sum_measure(fs, cfgs, tp, model)
+    assert set(obs) == set(gold["observables"])
+    assert abs(np.sum(obs["charge"]) - 2.0) < 1e-10
+    assert abs(np.sum(obs["energy"]) - sum(np.sum(obs[k]) for k in obs if k.startswith("bond_energy"))) < 1e-10
+    for key, want in gold["observables"].items():
+        assert np.max(np.abs(np.asarray(obs[key]) - np.asarray(want))) < 1e-10, key
+    fs = fermion.FermionSITPS(fermion.load_fermion_sitps(os.path.join(fixtures_dir, "tj_model_tps_doublelowest")))
+    obs = fermion.exact_sum_measure(fs, cfgs, tp, model)
+    tol = {"energy": 6e-8, "spin_z": 5e-4, "charge": 5e-4}
+    for key, want in gold["lowest"].items():
+        assert np.max(np.abs(np.asarray(obs[key]) - np.asarray(want))) < tol.get(key, 1e-5), key
