@@ -198,3 +198,26 @@ def test_reference_tj_exact_sum_measurer_registry(fixtures_dir):
     tol = {"energy": 6e-8, "spin_z": 5e-4, "charge": 5e-4}
     for key, want in gold["lowest"].items():
         assert np.max(np.abs(np.asarray(obs[key]) - np.asarray(want))) < tol.get(key, 1e-5), key
+
+
+def test_reference_spinless_fermion_measurer_t2_sweep_and_lowest_state_observables(fixtures_dir):
+    """SpinlessFermionMeasurerTest.SimpleUpdateStateT2Sweep / LowestStateT2SweepEnergy / LowestStateObservables
+    (tests/test_algorithm/test_exact_summation_measurer.cpp:292-407): for t2 in {2.1, 0, -2.5} and both states the registry has the six
+    keys, energy == sum of the four bond maps (1e-8) and total charge 2; the t2 = 2.1 'lowest' state reproduces the QuSpin ED
+    observables -- energy -4.2, uniform charge 1/2, vanishing nearest-neighbour bond energies, BOTH diagonal bond energies -2.1 (the
+    sign of every next-nearest-neighbour hop)."""
+    tp = BMPSTruncateParams.SVD(8, 8, 1e-16)
+    cfgs = _half_filling_configs()
+    keys = {"energy", "charge", "bond_energy_h", "bond_energy_v", "bond_energy_dr", "bond_energy_ur"}
+    for t2 in (2.1, 0.0, -2.5):
+        for kind in ("_double_from_simple_update", "_doublelowest"):
+            fs = fermion.FermionSITPS(fermion.load_fermion_sitps(os.path.join(fixtures_dir, "spinless_fermion_tps_t2_%.6f%s" % (t2, kind))))
+            obs = fermion.exact_sum_measure(fs, cfgs, tp, fermion.SquareSpinlessFermionOBC(1.0, t2, 0.0))
+            assert set(obs) == keys
+            assert abs(np.sum(obs["energy"]) - sum(np.sum(obs[k]) for k in keys if k.startswith("bond"))) < 1e-8
+            assert abs(np.sum(obs["charge"]) - 2.0) < 1e-8
+            if t2 == 2.1 and kind == "_doublelowest":
+                assert abs(obs["energy"][0] + 4.2) < 6e-8
+                assert np.max(np.abs(obs["charge"] - 0.5)) < 1e-5
+                assert np.max(np.abs(obs["bond_energy_h"])) < 1e-5 and np.max(np.abs(obs["bond_energy_v"])) < 1e-5
+                assert abs(obs["bond_energy_dr"][0] + 2.1) < 1e-5 and abs(obs["bond_energy_ur"][0] + 2.1) < 1e-5
