@@ -569,6 +569,43 @@ int pepshost_fermion_mc_sweeps(int rows, int cols, int D, int d, const int32_t *
   });
 }
 
+// MCPEPSMeasurer's energy on a fermionic state with ONE random stream per walker over the whole run (monte_carlo_engine.h:146-176,
+// monte_carlo_peps_measurer_impl.h:495-519): warmup_sweeps sweeps, the component rebuilt as NormalizeStateOrder1 does (the scale drops out
+// of every ratio; the amplitude is evaluated afresh), then n_samples x {sweeps_between sweeps, E_loc}.  energies_out = [sample][walker].
+// This is the call that can reproduce the reference's fermionic regression value on the device (K9 of DESIGN 2: 6x6 fU1 t-J state, seed 42,
+// -14.74320489110316) -- written at the end of round 4, NOT yet run on the GPU.
+int pepshost_fermion_measure_energy(int rows, int cols, int D, int d, const int32_t *nf, int chi, int dtype,
+                                    const double *sitps_ext_flat, int n, int32_t *configs, const uint64_t *seeds, int warmup_sweeps,
+                                    int n_samples, int sweeps_between, int model, const double *prm, double *energies_out,
+                                    double *accept_out) {
+  return guarded([&]() {
+    SplitIndexTPS sitps = make_state(rows, cols, D, 4 * d, sitps_ext_flat);
+    FermionDecoration dec;
+    dec.nf.assign(nf, nf + d);
+    BMPSContractor contractor(rows, cols, D, 4 * d, trunc_params(chi), n, dtype, g_device);
+    TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor, &dec);
+    std::vector<uint64_t> sd(seeds, seeds + n);
+    MCUpdateSquareNNExchangeOBC ex(sd);
+    std::vector<double> rates, acc(n, 0.0);
+    for (int s = 0; s < warmup_sweeps; ++s) ex(sitps, comp, rates);
+    comp.SetOrder(ROW_MAJOR);
+    comp.EvaluateAmplitude();                                  // NormalizeStateOrder1: tps_sample_ = WaveFunctionComponentT(...) (:235-236)
+    SquareSpinlessFermion spinless(prm[0], prm[2], prm[1]);     // model 0: (t, t2, V) from [t, V, t2, -]
+    SquaretJVModel tj(prm[0], 0.0, prm[1], prm[2], prm[3]);     // model 1: [t, J, V, mu]
+    for (int k = 0; k < n_samples; ++k) {
+      for (int s = 0; s < sweeps_between; ++s) {
+        ex(sitps, comp, rates);
+        for (int w = 0; w < n; ++w) acc[w] += rates[w];
+      }
+      EnergyAndHoles eh = model == 0 ? spinless.CalEnergyAndHoles<false>(sitps, comp) : tj.CalEnergyAndHoles<false>(sitps, comp);
+      std::copy(eh.energy.begin(), eh.energy.end(), energies_out + (size_t)k * n);
+    }
+    std::copy(comp.config.data(), comp.config.data() + (size_t)n * rows * cols, configs);
+    const int total = std::max(1, n_samples * sweeps_between);
+    if (accept_out) for (int w = 0; w < n; ++w) accept_out[w] = acc[w] / total;
+  });
+}
+
 // SplitIndexTPS::Dump (OBC leg dimensions) and the configuration{label} text files
 int pepshost_dump_sitps(const char *dir, int rows, int cols, int D, int d, const double *flat) {
   return guarded([&]() {

@@ -15,7 +15,8 @@ SYMBOLS = ["pepshost_last_error", "pepshost_mc_sweeps", "pepshost_energy_and_hol
            "pepshost_set_truncate_params", "pepshost_set_device", "pepshost_get_device",
            "pepshost_energy_and_holes_c128", "pepshost_exact_sum_partial_c128", "pepshost_exact_sum_finish_c128",
            "pepshost_mc_energy_grad_partial_c128", "pepshost_mc_sweeps_c128", "pepshost_load_sitps_c128", "pepshost_dump_sitps_c128",
-           "pepshost_mc_engine_warmup", "pepshost_mc_engine_warmup_dist", "pepshost_suwa_todo_chain", "pepshost_load_configuration2", "pepshost_configuration_from_text"]
+           "pepshost_mc_engine_warmup", "pepshost_mc_engine_warmup_dist", "pepshost_suwa_todo_chain", "pepshost_load_configuration2", "pepshost_configuration_from_text",
+           "pepshost_fermion_measure_energy"]
 
 _lib = None
 
@@ -323,6 +324,24 @@ def fermion_mc_sweeps(state, configs, seeds, chi, n_sweeps=1, dtype=1):
                                          _p(cfg, C.c_int32), _p(sd, C.c_uint64), n_sweeps, _p(amps, C.c_double),
                                          _p(rates, C.c_double)))
     return cfg, amps, rates
+
+
+def fermion_measure_energy(state, configs, seeds, chi, warmup_sweeps, n_samples, sweeps_between=1, model="tj", t=1.0, J=0.0, V=0.0, mu=0.0,
+                           t2=0.0, dtype=1):
+    """MCPEPSMeasurer's energy samples on a fermionic state with ONE std::mt19937 stream per walker over warm-up, rebuild and samples
+    (pepshost_fermion_measure_energy): (energies [sample][walker], final configurations, accept rates)."""
+    flat = np.ascontiguousarray(state.extended_flat(), dtype=np.float64)
+    rows, cols, D = flat.shape[0], flat.shape[1], flat.shape[3]
+    cfg = np.ascontiguousarray(configs, dtype=np.int32).copy()
+    n = cfg.shape[0]
+    nf = np.ascontiguousarray(state.nf, dtype=np.int32)
+    sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+    prm = np.array([t, J, V, mu] if model == "tj" else [t, V, t2, 0.0], dtype=np.float64)
+    en, rates = np.zeros((n_samples, n)), np.zeros(n)
+    _ck(lib().pepshost_fermion_measure_energy(rows, cols, D, state.d, _p(nf, C.c_int32), chi, dtype, _p(flat, C.c_double), n,
+                                              _p(cfg, C.c_int32), _p(sd, C.c_uint64), warmup_sweeps, n_samples, sweeps_between,
+                                              1 if model == "tj" else 0, _p(prm, C.c_double), _p(en, C.c_double), _p(rates, C.c_double)))
+    return en, cfg, rates
 
 
 def fermion_exact_sum(state, all_configs, chi, t, V=0.0, batch=64, dtype=1):
