@@ -501,6 +501,33 @@ def vmc_rates(leg, nw, n_sweeps):
             "call_seconds": {"sweeps_1": t_sw1, "sweeps_1_plus_n": t_swn, "samples_1": t_v1, "samples_1_plus_n": t_vn}}
 
 
+def c5_parity(capi, fermion, st, chi, device, cfgs):
+    """f32 and f64 device amplitude + t-V local energy of a few C5 configurations against the graded float64 oracle (checker only)."""
+    from oracle import fermion as ofermion
+    from oracle.bmps import BMPSTruncateParams
+    from oracle.graded import GT
+    gts = [[[GT(st.tensors[r][c][s][..., None], list(st.par[r][c]) + [np.array([int(st.nf[s])])], [-1, 1, 1, -1, -1])
+             for s in range(st.d)] for c in range(st.cols)] for r in range(st.rows)]
+    fs = ofermion.FermionSITPS(gts)
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    model = ofermion.SquareSpinlessFermionOBC(1.0, 0.0, 1.0)
+    # configurations as a Monte-Carlo run visits them (float64 device chains of the C++ host layer: three NN-exchange sweeps from the
+    # half-filled starts handed in) -- random occupations have amplitudes at the rounding level of the alternating sum
+    from peps_amd import hostapi
+    cfgs, _, _ = hostapi.fermion_mc_sweeps(st, cfgs, np.arange(len(cfgs), dtype=np.uint64) + 700, chi, 3, 1)
+    ref_a = np.array([fs.amplitude(c, tp) for c in cfgs])
+    ref_e = np.array([model.CalEnergy(fs, c, tp)[0] for c in cfgs])
+    res = {"n": int(len(cfgs)), "model": "t = 1, V = 1", "configurations": "end points of float64 device chains (3 sweeps, seeds 700..)"}
+    for name, dt in (("f32", capi.F32), ("f64", capi.F64)):
+        ctx = capi.Context(st.rows, st.cols, st.D, fermion.NVAR * st.d, chi, dtype=dt, device=device, max_walkers=len(cfgs))
+        ctx.state_upload(st.extended_flat(st.D))
+        amp = fermion.evaluate_amplitude(ctx, st, cfgs)
+        e_loc, _ = fermion.spinless_fermion_energy(ctx, st, cfgs, 1.0, 1.0)
+        ctx.close()
+        res[name] = {"amplitude_max_rel": float(np.max(np.abs(amp / ref_a - 1))), "energy_max_rel": float(np.max(np.abs(e_loc / ref_e - 1)))}
+    return res
+
+
 def other_modes(capi, synthetic, device, L, D, chi):
     """Driver-measured figures of the secondary modes of the path (one short run each, outside the timed region; rounds 1-2 quoted
     them from builder scripts only): the f64 device mode, the two variational compression schemes (bmps_impl.h:864-1172), the
@@ -553,8 +580,23 @@ def other_modes(capi, synthetic, device, L, D, chi):
         c = capi.Context(l5, l5, d5, fermion.NVAR * st.d, chi5, dtype=capi.F32, device=device, max_walkers=nw)
         c.state_upload(st.extended_flat(d5))
         phys = [synthetic.make_configs(l5, nw, "heisenberg", seed0=80000 + 7 * k) for k in range(3)]
-        out["C5_spinless_tV_8x8_D6_chi24"] = {"amp_per_s": rate(c, [st.ext_config(p, fermion.ROW) for p in phys]), "walkers": nw, "dtype": "f32"}
+        c5 = {"amp_per_s": rate(c, [st.ext_config(p, fermion.ROW) for p in phys]), "walkers": nw, "dtype": "f32"}
         c.close()
+        # the float64 device mode (the parity-grade path for fermions: C5's amplitudes are alternating sums) and what both modes
+        # measure against the oracle on a sample (checker only, outside every timed region): tests/test_gpu_fermion.py::C5_TOL
+        nw64 = 1024
+        c = capi.Context(l5, l5, d5, fermion.NVAR * st.d, chi5, dtype=capi.F64, device=device, max_walkers=nw64)
+        c.state_upload(st.extended_flat(d5))
+        c5["f64_mode"] = {"amp_per_s": rate(c, [st.ext_config(p[:nw64], fermion.ROW) for p in phys[:2]]), "walkers": nw64}
+        c.close()
+        c5["tolerance"] = {"f32": {"amplitude": 2e-5, "energy": 2e-5}, "f64": {"amplitude": 1e-7, "energy": 1e-7},
+                           "north_star_energy": 1e-6, "note": "relative, asserted in tests/test_gpu_fermion.py (C5_TOL) on eight chain-visited "
+                           "configurations; the f64 mode is the one that holds north_star's 1e-6 on fermionic energies"}
+        try:
+            c5["parity_on_sample"] = c5_parity(capi, fermion, st, chi5, device, phys[0][:4])
+        except Exception as e:
+            c5["parity_on_sample"] = {"error": repr(e)}
+        out["C5_spinless_tV_8x8_D6_chi24"] = c5
     except Exception as e:
         out["C5_spinless_tV_8x8_D6_chi24"] = {"error": repr(e)}
     return out

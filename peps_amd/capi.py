@@ -664,7 +664,9 @@ def diag_jacobi(dtype, M, k, force_global=False):
 class Walker:
     """BMPSContractor::BMPSWalker (bmps_contractor.h:357-646) for all Monte-Carlo walkers of a context: method names follow the
     reference.  The TransferMPO is set once (set_mpo / set_mpo_states / set_mpo_tensors); `opp_level` names the opposite
-    boundary = level of the DOWN stack (down_stack[opp_level] in the reference's tests)."""
+    boundary = level of the DOWN stack (down_stack[opp_level] in the reference's tests).
+    Lifetime: the device copy is released by destroy(), at the end of a `with ctx.get_walker(...) as w:` block, or when the object is
+    collected; Context.set_configs invalidates every walker of the context."""
 
     def __init__(self, ctx, wid):
         self.ctx, self.wid = ctx, wid
@@ -753,3 +755,28 @@ class Walker:
         if self.wid is not None:
             self.ctx._ck(self.ctx._l.pepsgpu_walker_destroy(self.ctx._h, self.wid))
             self.wid = None
+
+    # A walker is a deep copy of one boundary MPS for ALL Monte-Carlo walkers of the context: release it with the object, as the
+    # destructor of the C++ BMPSWalker does.  The error code is ignored here -- set_configs / close of the context drop every walker
+    # (a stale object then finds "no such walker"), and a context that is already closed has nothing left to free.
+    def _release_quietly(self):
+        wid, self.wid = self.wid, None
+        ctx = self.ctx
+        if wid is not None and getattr(ctx, "_h", None):
+            try:
+                ctx._l.pepsgpu_walker_destroy(ctx._h, wid)
+            except Exception:
+                pass
+
+    def __del__(self):
+        try:
+            self._release_quietly()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self._release_quietly()
+        return False

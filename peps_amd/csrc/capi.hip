@@ -348,6 +348,19 @@ extern "C" int pepsgpu_diag_tgemm(int dtype_in, int dtype_out, const int *di, in
       d.sBj[k] = di[18 + k]; d.sCi[k] = di[21 + k]; d.sCj[k] = di[24 + k];
     }
     d.wA = wA; d.wB = wB; d.wC = wC; d.nbatch = nbatch;
+    // PEPSGPU_DIAG_TGEMM_MODE (read per call; f32 only): 1 = the wave-per-tile kernel (a per-entry live extent equal to the static one
+    // routes there), 2 = the same with float64 accumulation on the f64 matrix cores (tg_direct_body_f64)
+    const char *mode_s = getenv("PEPSGPU_DIAG_TGEMM_MODE");
+    const int mode = mode_s ? atoi(mode_s) : 0;
+    int *dext = nullptr;
+    if (mode && dtype_in == 0 && dtype_out == 0) {
+      std::vector<int> h(nbatch, d.I[2]);
+      PG_CHECK_HIP(hipMalloc(&dext, sizeof(int) * nbatch));
+      PG_CHECK_HIP(hipMemcpy(dext, h.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice));
+      d.dI[2].p = dext;
+      d.acc64 = mode == 2;
+    }
+    struct Guard { int *p; ~Guard() { if (p) (void)hipFree(p); } } guard{dext};
     if (dtype_in == 0 && dtype_out == 0) diag_tgemm_t<float, float, float>(d, A, na, B, nb, C, nc);
     else if (dtype_in == 1 && dtype_out == 1) diag_tgemm_t<double, double, double>(d, A, na, B, nb, C, nc);
     else if (dtype_in == 0 && dtype_out == 1) diag_tgemm_t<float, double, double>(d, A, na, B, nb, C, nc);
@@ -395,7 +408,8 @@ extern "C" int pepsgpu_diag_tgemm_chain(const int *dims, const int32_t *live, in
     TGemmChainMap mp;
     mp.mapK[1] = 2; mp.mapK[2] = 4;
     mp.mapJ[1] = 1; mp.mapJ[2] = 5;
-    PG_REQUIRE(tgemm_chain_launch(0, gx, gp, mp, dR, dA, dW, dP, dflag, 1, 0), 1, "chain launch refused");
+    const char *f64_s = getenv("PEPSGPU_DIAG_CHAIN_F64");      // (read per call) 1: the float64-accumulating form of both stages
+    PG_REQUIRE(tgemm_chain_launch(0, gx, gp, mp, dR, dA, dW, dP, dflag, 1, 0, f64_s && atoi(f64_s) ? 1 : 0), 1, "chain launch refused");
     PG_CHECK_HIP(hipDeviceSynchronize());
     PG_CHECK_HIP(hipMemcpy(P_out, dP, nP * nbatch * sizeof(float), hipMemcpyDeviceToHost));
     PG_CHECK_HIP(hipMemcpy(flags_out, dflag, nbatch * sizeof(int), hipMemcpyDeviceToHost));

@@ -444,6 +444,23 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     const int l = dd[ll], l2 = dd[lr], u = dd[lu];
     const int k2 = Y.d[2];
     PG_REQUIRE(Y.d[0] == l2 && Y.d[1] == a2 && p == dd[lp], 3, "MultiplyMPO: bond dimension mismatch (backward)");
+    // "Precise" sites (f32 engine, DESIGN 3e): where the carry is not of low rank -- the row absorbed before ran more than 24 live
+    // carry rows at this site, or gives no hint yet (the first three rows of a stack) -- the places where f32 rounding showed in the
+    // amplitude get float64-grade arithmetic: the backward pair Z1 = A Y, Tt = W Z1 (round 5) and Y = Tt V^T accumulate in float64 on
+    // the f64 matrix cores (columns of small sigma are differences of O(sigma_1) terms), and the rows of Vt are made orthonormal by a
+    // Newton-Schulz step in float64 (ortho_rows_kernel).  The low-rank headline state keeps the f32 forms.
+    bool precise_site = false;
+    if constexpr (sizeof(T) == 4) {
+      static const int precise = getenv("PEPSGPU_PRECISE") ? atoi(getenv("PEPSGPU_PRECISE")) : 1;    // 0 never, 1 auto, 2 always
+      // (rows whose predecessor gives no hint yet -- the first three of a stack -- go by what the SAME row of the SAME stack showed
+      // the last time it was absorbed, carry_seen_: unknown on a fresh state -> precise)
+      const int seen = carry_seen_[pos][num];
+      const bool hinted = in.depth >= 3 && (int)in.mlmax.size() > i && in.mlmax[i] >= 0;
+      precise_site = precise == 2 || (precise == 1 && (hinted ? in.mlmax[i] > 24 : (seen < 0 || seen > 24)));
+    }
+    // PEPSGPU_TT_ACC64: 1 (default) = the backward pair of a precise site on the float64-accumulating chained kernel, 0 = f32 (round 4)
+    static const int tt_mode = getenv("PEPSGPU_TT_ACC64") ? atoi(getenv("PEPSGPU_TT_ACC64")) : 1;
+    const bool tt_f64 = sizeof(T) == 4 && precise_site && tt_mode != 0;
     // Z1[a,p,l2,k2] = sum_{a2} A[a,p,a2] Y[l2,a2,k2]
     // Tt[l,a,u,k2] = sum_{p,l2} Z1[a,p,l2,k2] W[l,p,l2,u]
     DTen<T> Z1 = alloc_ten(a, p, l2, k2);
@@ -487,7 +504,8 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           mp.mapJ[1] = 1; mp.mapJ[2] = 5;      // J2 = (a, k2): a = I1[1], k2 = J1[2]
           prof_begin(PROF_CHAIN, 0.0, flz + flt);
           chained = tgemm_chain_launch(stream_, gz, g2, mp, (const float *)A.p, (const float *)Y.p,
-                                       (const float *)sel_base(ss), (float *)Tt.p, chain_flag, chain_chunks, hint_dense_carry(in, i));
+                                       (const float *)sel_base(ss), (float *)Tt.p, chain_flag, chain_chunks, hint_dense_carry(in, i),
+                                       tt_f64 ? 1 : 0);
           prof_end();
           if (!chained) { arena_.free(chain_flag); chain_flag = nullptr; }
         }
@@ -495,6 +513,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       if (chained < 2) {
         gz.batch_flag = chain_flag; gt.batch_flag = chain_flag;
         prof_begin(PROF_CONTRACT, 0.0, chain_flag ? 0.0 : flz);
+        gz.acc64 = tt_f64; gt.acc64 = tt_f64;     // (entries the chain declined: the wave-per-tile kernel honours it)
         if (acc64 & 2) tgemm_launch<T, T, T, Acc>(stream_, gz, A.p, Y.p, Z1.p);
         else tgemm_launch<T, T, T, T>(stream_, gz, A.p, Y.p, Z1.p);
         prof_end();
@@ -868,21 +887,6 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       prof_end();
     }
     free_ten(M);
-    // "Precise" sites (f32 engine, DESIGN 3e): where the carry is not of low rank -- the row absorbed before ran more than 24 live
-    // carry rows at this site, or gives no hint yet (the first three rows of a stack) -- the two places where f32 rounding showed
-    // in the amplitude get float64-grade arithmetic: the rows of Vt are made orthonormal by a Newton-Schulz step in float64
-    // (ortho_rows_kernel), and Y = Tt V^T -- whose columns of small sigma are differences of O(sigma_1) terms -- is accumulated in
-    // float64 on the f64 matrix cores (the LDS-tiled kernel; 4 Mflop of the ~190 of a site step).  The low-rank headline state
-    // keeps the one-launch f32 form with the norm fused into it.
-    bool precise_site = false;
-    if constexpr (sizeof(T) == 4) {
-      static const int precise = getenv("PEPSGPU_PRECISE") ? atoi(getenv("PEPSGPU_PRECISE")) : 1;    // 0 never, 1 auto, 2 always
-      // (rows whose predecessor gives no hint yet -- the first three of a stack -- go by what the SAME row of the SAME stack showed
-      // the last time it was absorbed, carry_seen_: unknown on a fresh state -> precise)
-      const int seen = carry_seen_[pos][num];
-      const bool hinted = in.depth >= 3 && (int)in.mlmax.size() > i && in.mlmax[i] >= 0;
-      precise_site = precise == 2 || (precise == 1 && (hinted ? in.mlmax[i] > 24 : (seen < 0 || seen > 24)));
-    }
     if constexpr (sizeof(T) == 4) {
       static const int ortho = getenv("PEPSGPU_ORTHO_POLISH") ? atoi(getenv("PEPSGPU_ORTHO_POLISH")) : 1;
       const size_t osm = ortho_rows_smem(k, uk);
@@ -914,9 +918,9 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       g.prefer_tiled = dense_site;
       static const bool y_tiled = getenv("PEPSGPU_Y_TILED") != nullptr;     // experiments: Y on the LDS-tiled f32 kernel
       if (y_tiled) g.prefer_tiled = true;
-      // Y on precise sites: 2 (default) = float64 accumulation on the LDS-tiled kernel (f64 matrix cores) + separate normalisation;
-      // 1 = the wave-per-tile kernel with its f32 chains of 8 products drained into float64 registers (measured: takes out a third
-      // of the error only -- the cancellation is inside the 8-term sums too); 0 = the f32 chain of round 3
+      // Y on precise sites: 2 = float64 accumulation on the LDS-tiled kernel (f64 matrix cores) + separate normalisation (round 4);
+      // 1 = the wave-per-tile kernel with float64 accumulation (tg_direct_body_f64, round 5; the norm stays fused into the launch);
+      // 0 = the f32 chain of round 3
       static const int y_mode = getenv("PEPSGPU_Y_ACC64") ? atoi(getenv("PEPSGPU_Y_ACC64")) : 2;
       bool y_f64 = false;
       if constexpr (sizeof(T) == 4) {

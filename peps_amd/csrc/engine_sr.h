@@ -270,6 +270,7 @@ void Engine<T>::sr_append(const double *psi) {
       PG_REQUIRE(a != 0.0, 5, "Wavefunction amplitude is near zero, causing division by zero.");
       h[w] = std::log(a); h[nw_ + w] = psi[2 * w] / a; h[2 * nw_ + w] = psi[2 * w + 1] / a;
     }
+    ArenaScope scope(arena_);      // (d goes back to the arena when a HIP call below throws)
     double *d = (double *)arena_.alloc(sizeof(double) * h.size());
     PG_CHECK_HIP(hipMemcpyAsync(d, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, stream_));
     const int sites = Ly_ * Lx_;
@@ -292,6 +293,7 @@ void Engine<T>::sr_append(const double *psi) {
     h[w] = std::log(std::fabs(psi[w]));
     h[nw_ + w] = psi[w] < 0 ? -1.0 : 1.0;
   }
+  ArenaScope scope(arena_);
   double *d = (double *)arena_.alloc(sizeof(double) * h.size());
   PG_CHECK_HIP(hipMemcpyAsync(d, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, stream_));
   const int sites = Ly_ * Lx_;

@@ -174,14 +174,21 @@ void Engine<T>::grow_bten_step_reuse(int pos, BTenDev &half, const int *take) {
   const BTenDev &bt = bten_[pos].back();
   BTenDev nb = bten_step(pos, bt, b1.t[n - bs], sel, b2.t[bs - 1], 1, false, 1, lv(b1, n - bs), lv(b1, n - bs + 1), lv(b2, bs - 1),
                          lv(b2, bs), take);
-  PG_REQUIRE(nb.t.n == half.t.n, 3, "GrowBTenStep: the kept half step has another shape");
-  hipLaunchKernelGGL(sweep_take_kernel<T>, dim3((unsigned)std::min<long>(8, (nb.t.n + 255) / 256), nw_), dim3(256), 0, stream_, nb.t.p,
-                     (const T *)half.t.p, (long)nb.t.n, take);
-  PG_CHECK_HIP(hipGetLastError());
-  free_ten(half.t);
-  nb.logscale = (double *)arena_.alloc(sizeof(double) * nw_);
-  PG_CHECK_HIP(hipMemcpyAsync(nb.logscale, bt.logscale, sizeof(double) * nw_, hipMemcpyDeviceToDevice, stream_));
-  normalize(nb.t.p, nb.t.n, nb.t.n, nw_, nb.logscale);
+  try {      // (nb is not owned by anything yet: an error below must not leave it in the arena; `half` stays the caller's until consumed)
+    PG_REQUIRE(nb.t.n == half.t.n, 3, "GrowBTenStep: the kept half step has another shape");
+    hipLaunchKernelGGL(sweep_take_kernel<T>, dim3((unsigned)std::min<long>(8, (nb.t.n + 255) / 256), nw_), dim3(256), 0, stream_, nb.t.p,
+                       (const T *)half.t.p, (long)nb.t.n, take);
+    PG_CHECK_HIP(hipGetLastError());
+    free_ten(half.t);
+    half.t.p = nullptr;
+    nb.logscale = (double *)arena_.alloc(sizeof(double) * nw_);
+    PG_CHECK_HIP(hipMemcpyAsync(nb.logscale, bt.logscale, sizeof(double) * nw_, hipMemcpyDeviceToDevice, stream_));
+    normalize(nb.t.p, nb.t.n, nb.t.n, nw_, nb.logscale);
+  } catch (...) {
+    if (nb.t.p) arena_.free(nb.t.p);
+    if (nb.logscale) arena_.free(nb.logscale);
+    throw;
+  }
   bten_[pos].push_back(nb);
 }
 
@@ -205,7 +212,12 @@ void Engine<T>::sweep_slice_exchange(int orient, int slice, int n_uniform, const
     int *dcand = (int *)arena_.alloc(sizeof(int) * 4 * (size_t)nw_);
     int *dsame = dcand + 2 * (size_t)nw_, *dnow = dcand + 3 * (size_t)nw_;
     int *dslice = (int *)arena_.alloc(sizeof(int) * (size_t)nw_ * N);
-    auto release = [&]() { arena_.free(damp); arena_.free(duni); arena_.free(dptr); arena_.free(dcand); arena_.free(dslice); };
+    BTenDev half;       // the kept half step of the bond in flight (owned here until grow_bten_step_reuse consumes it)
+    half.t.p = nullptr;
+    auto release = [&]() {
+      if (half.t.p) { arena_.free(half.t.p); half.t.p = nullptr; }
+      arena_.free(damp); arena_.free(duni); arena_.free(dptr); arena_.free(dcand); arena_.free(dslice);
+    };
     try {
       PG_CHECK_HIP(hipMemcpyAsync(damp, amp_inout, sizeof(double) * nw_, hipMemcpyHostToDevice, stream_));
       PG_CHECK_HIP(hipMemcpyAsync(duni, uniforms, sizeof(double) * (size_t)nw_ * n_uniform, hipMemcpyHostToDevice, stream_));
@@ -225,7 +237,6 @@ void Engine<T>::sweep_slice_exchange(int orient, int slice, int n_uniform, const
         // kernel on the same operands): it is kept, and the growth step behind the Metropolis test runs for the others only
         static const bool no_reuse = getenv("PEPSGPU_NO_SWEEP_REUSE") != nullptr;
         const bool reuse = j + 2 < N && !no_reuse;
-        BTenDev half;
         Acc *res = nn_trace_device(r1, c1, orient, 1, dcand, &lsum, dsame, reuse ? &half : nullptr);
         hipLaunchKernelGGL(sweep_metropolis_exchange_kernel<Acc>, dim3(gb), dim3(256), 0, stream_, cfg_, sites, s1, s2, (const Acc *)res,
                            (const double *)lsum, damp, (const double *)duni, n_uniform, dptr, dacc, dover, dnow, nw_);

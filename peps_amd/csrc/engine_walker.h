@@ -87,8 +87,9 @@ int Engine<T>::walker_create(int pos, int level) {
   return id;
 }
 
-// copy construction of a walker (`auto excited_walker = main_walker;`): the BMPS, the counters and the MPO naming; the BTen caches
-// of the copy start empty
+// copy construction of a walker (`auto excited_walker = main_walker;`): the BMPS and the counters.  The MPO named by walker_set_mpo is
+// NOT copied (the reference's walker holds no MPO: Evolve takes it as an argument) -- the copy starts on the network's own slices --
+// and its BTen caches start empty
 template <typename T>
 int Engine<T>::walker_clone(int id) {
   require_ready();
@@ -129,11 +130,12 @@ void Engine<T>::walker_set_mpo(int id, int num, const int32_t *states, const dou
   const int N = mps_len(w.pos), lim = hor ? Ly_ : Lx_;
   PG_REQUIRE(num >= 0 && num < lim, 1, "BMPSWalker: MPO slice outside the lattice");
   PG_REQUIRE(!(states && tensors), 1, "BMPSWalker: name the MPO by states OR by tensors");
-  walker_free_mpo(w);
-  w.mpo_num = num;
+  PG_REQUIRE(!tensors || n_tensors == 1 || n_tensors == nw_, 1, "BMPSWalker: explicit MPO tensors come as one set or one set per walker");
+  // validate and build BEFORE the walker's current MPO is released: a bad argument leaves the walker as it was
+  std::vector<int> tab;
   if (states) {
     // a full configuration table with the slice replaced (same layout as the walkers' own table: every kernel's selector works)
-    std::vector<int> tab(hcfg_);
+    tab = hcfg_;
     for (int wk = 0; wk < nw_; ++wk)
       for (int j = 0; j < N; ++j) {
         const int s = states[(size_t)wk * N + j];
@@ -141,11 +143,14 @@ void Engine<T>::walker_set_mpo(int id, int num, const int32_t *states, const dou
         const int r = hor ? num : j, c = hor ? j : num;
         tab[(size_t)wk * Ly_ * Lx_ + r * Lx_ + c] = s;
       }
+  }
+  walker_free_mpo(w);
+  w.mpo_num = num;
+  if (states) {
     w.mpo_cfg = (int *)arena_.alloc(sizeof(int) * tab.size());
     PG_CHECK_HIP(hipMemcpyAsync(w.mpo_cfg, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, stream_));
     PG_CHECK_HIP(hipStreamSynchronize(stream_));
   } else if (tensors) {
-    PG_REQUIRE(n_tensors == 1 || n_tensors == nw_, 1, "BMPSWalker: explicit MPO tensors come as one set or one set per walker");
     // host [nt][N][L][D][R][U] zero padded to D^4 -> device [N][nt][slot], compact inside the slot (as the SITPS)
     std::vector<T> buf((size_t)N * n_tensors * slot_, T(0));
     for (int j = 0; j < N; ++j) {

@@ -38,7 +38,7 @@ constexpr int GI_PITCH = 80;                  // bytes per column and plane (64 
 constexpr int GI_PLANE = 256 * GI_PITCH;
 constexpr int GI_BUF = 3 * GI_PLANE;
 constexpr int GI_RAW = GI_KB * 256 * 4;       // the float32 rows of the next block (LDS-DMA image: one row = one wave-instruction)
-inline size_t gram_cols_i8_smem_bytes() { return GI_BUF + GI_RAW + 256 * sizeof(int) + 2 * 256 * sizeof(float); }
+inline size_t gram_cols_i8_smem_bytes() { return GI_BUF + GI_RAW + 256 * sizeof(int) + 2 * 256 * sizeof(float) + 16; }
 
 // ROWS: the row Gram of the truncation input instead (gram_rows_f64_kernel of gram.h: G = M M^T, M = n x K row-major with row stride K,
 // n = nrows[b] live rows, the contracted index runs along the rows) -- the same kernel with the roles of the two indices of the
@@ -71,8 +71,13 @@ __global__ __launch_bounds__(64 * NW, NW == 12 ? 3 : 2) void gram_cols_i8_kernel
   float *raw = reinterpret_cast<float *>(gi_smem + GI_BUF);
   int *exps = reinterpret_cast<int *>(gi_smem + GI_BUF + GI_RAW);
   float *pmax = reinterpret_cast<float *>(gi_smem + GI_BUF + GI_RAW + 256 * sizeof(int));
+  // non-finite input: the fixed-point image of a NaN / Inf is finite garbage (fmaxf drops a NaN from the column maximum, the float add
+  // of the rounding trick is reinterpreted bitwise), so the kernel looks for it itself -- x * 0 is NaN exactly for NaN and Inf -- and
+  // poisons the diagonal of G with NaN at the end: the Cholesky that follows flags the walker, as with the float64 Gram this replaces
+  int *bad_s = reinterpret_cast<int *>(gi_smem + GI_BUF + GI_RAW + 256 * sizeof(int) + 2 * 256 * sizeof(float));
   const int b = blockIdx.x;
   if (run_flag && run_flag[b] >= 0) return;
+  if (threadIdx.x == 0) *bad_s = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int K = ROWS ? kmax : (kdyn ? max(0, min(kmax, kdyn[b] * kdyn_mul)) : kmax);
   if (ROWS) {
@@ -126,9 +131,14 @@ __global__ __launch_bounds__(64 * NW, NW == 12 ? 3 : 2) void gram_cols_i8_kernel
       else return raw[(32 * kh + q) * 256 + j];
     };
     const int qlive = col_ok ? min(32, K - r0) : 0;             // rows of this half that exist (the others: clamped copies, masked)
-    float m = 0.f;
+    float m = 0.f, chk = 0.f;
 #pragma unroll
-    for (int q = 0; q < 32; ++q) m = fmaxf(m, q < qlive ? fabsf(at(q)) : 0.f);
+    for (int q = 0; q < 32; ++q) {
+      const float x = q < qlive ? at(q) : 0.f;
+      m = fmaxf(m, fabsf(x));
+      chk = fmaf(x, 0.f, chk);
+    }
+    if (chk != 0.f) *bad_s = 1;       // (NaN != 0; benign race: every writer stores 1)
     if (layer) pmax[256 * kh + j] = m;
     __syncthreads();
     m = fmaxf(pmax[j], pmax[256 + j]);
@@ -262,6 +272,8 @@ __global__ __launch_bounds__(64 * NW, NW == 12 ? 3 : 2) void gram_cols_i8_kernel
     case 10: run(std::integral_constant<int, (NW > 8 ? 10 : 0)>{}); break;
     default: run(std::integral_constant<int, (NW > 8 ? 11 : 0)>{}); break;
   }
+  __syncthreads();
+  if (*bad_s && tid < n) G[(long)tid * ldg + tid] = __longlong_as_double(0x7ff8000000000000ll);
 }
 
 }  // namespace pepsgpu

@@ -70,9 +70,9 @@ struct TGemmDesc {
   // kernel instead of the wave-per-tile kernel that is built for extents of a few tens (M = R Tt of a dense walker batch:
   // 233 -> 138 ms per step of 2048 walkers)
   int prefer_tiled = 0;
-  // wave-per-tile kernel: the f32 accumulator of a tile is drained into float64 registers after every round of 8 k (chains of at
-  // most 8 f32 FMAs): float64-grade sums from f32 operands at the f32 MFMA rate.  For the one contraction of the absorption whose
-  // f32 accumulation shows in the amplitude (Y = Tt V^T on dense carries).
+  // wave-per-tile kernel: float64 accumulation on the f64 matrix cores from the f32 operands (tg_direct_body_f64; round 4 drained
+  // f32 chains of 8 products into float64 registers instead, which removed a third of the error only).  For the contractions of the
+  // truncation pass whose f32 accumulation shows in the amplitude of a dense state.
   int acc64 = 0;
 
   __host__ __device__ int Itot() const { return I[0] * I[1] * I[2]; }
@@ -557,7 +557,7 @@ __device__ __forceinline__ float4 tg_ldf4(const float *__restrict__ base, const 
 
 constexpr int TG_ZERO_ROW = 0x40000000;   // flag in the C-row offset table: the row exists in C but its A row reads as zero
 
-template <bool AVEC, bool BVEC, bool ACC64 = false>
+template <bool AVEC, bool BVEC>
 __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *__restrict__ A, const float *__restrict__ B,
                                                float *__restrict__ C, const int Itot, const int Jtot, const int K2s,
                                                int (*offCi_s)[32], const int tile0, const int tile_step,
@@ -647,18 +647,9 @@ __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *
       }
     };
     float a0[4], b0[4], a1[4], b1[4];
-    double accd[ACC64 ? 16 : 1];
-    if constexpr (ACC64) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) accd[r] = 0.0;
-    }
     auto mfma4 = [&](const float (&av)[4], const float (&bv)[4]) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
-      if constexpr (ACC64) {     // drain: the f32 chain never exceeds the 8 products of one round
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { accd[r] += (double)acc[r]; acc[r] = 0.f; }
-      }
     };
     if (nrounds > 0) {
       load_raw(a0, b0);
@@ -700,15 +691,169 @@ __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *
         const int oi = oi4[e];
         if (oi >= 0 && ocj >= 0) {
           float *p = C + ((oi & ~TG_ZERO_ROW) + ocj_e);
-          float v;
-          if constexpr (ACC64) v = ((oi & TG_ZERO_ROW) || jzero) ? 0.f : (float)(accd[4 * g + e] * (double)alpha);
-          else v = ((oi & TG_ZERO_ROW) || jzero) ? 0.f : acc[4 * g + e] * alpha;
+          float v = ((oi & TG_ZERO_ROW) || jzero) ? 0.f : acc[4 * g + e] * alpha;
           if (accumulate) v += *p;
           *p = v;
           if (sumsq) ss = fma((double)v, (double)v, ss);
         }
       }
     }
+  }
+  if (sumsq) *sumsq += ss;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same tile loop with FLOAT64 ACCUMULATION on the f64 matrix cores (round 5): f32 operands (global memory or LDS) are
+// converted on the way into v_mfma_f64_16x16x4_f64, the f32 result is rounded once at the store.  For the contractions of the
+// truncation pass whose f32 accumulation shows in the amplitude of a dense state (Z1 = A Y, Tt = W Z1 and Y = Tt V^T --
+// columns of small sigma are differences of O(sigma_1) terms; draining f32 chains of 8 products into float64 registers removes a
+// third of it only, the cancellation sits inside the 8-term sums too).  A wave owns the same 32 x 32 tile of C as 2 x 2 quadrants
+// of 16 x 16 (lane l: rows / columns l % 16 and 16 + l % 16 of the tile, k group l / 16); a round is 8 values of k2 -- lane group
+// g takes k2 = 8 r + 2 g + (0, 1), two MFMA steps of four quadrants each -- so a k2 run of 8 (the PEPS bond) wastes nothing.
+// Half the matrix rate of the f32 body; used where the flops are few (the backward pair is an eighth of the forward pair).
+template <bool AVEC, bool BVEC>
+__device__ __forceinline__ void tg_direct_body_f64(const TGemmDesc &d, const float *__restrict__ A, const float *__restrict__ B,
+                                                   float *__restrict__ C, const int Itot, const int Jtot, const int K2s,
+                                                   int (*offCi_s)[32], const int tile0, const int tile_step,
+                                                   const float scale = 1.f, double *__restrict__ sumsq = nullptr) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntj = (Jtot + 31) >> 5, ntiles = ((Itot + 31) >> 5) * ntj;
+  const double alpha = d.alpha * (double)scale;
+  double ss = 0.0;
+  const int g4 = lane >> 4, c16 = lane & 15;
+  const int K2 = d.K[2], K1 = d.K[1];
+  const int nr8 = (K2 + 7) >> 3, nrounds = d.K[0] * K1 * nr8;
+  const unsigned sA2b = 4u * d.sAk[2], sB2b = 4u * d.sBk[2];
+  const float rI2 = __builtin_amdgcn_rcpf((float)d.I[2]), rI1 = __builtin_amdgcn_rcpf((float)d.I[1]);
+  const float rJ2 = __builtin_amdgcn_rcpf((float)d.J[2]), rJ1 = __builtin_amdgcn_rcpf((float)d.J[1]);
+  const int kh = 2 * g4;
+  const bool accumulate = d.accumulate != 0;
+
+  for (int t = tile0 + wave; t < ntiles; t += tile_step) {
+    const int ti = t / ntj, tj = t - ti * ntj;
+    unsigned oab[2], obb[2];
+    int ocj[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = ti * 32 + 16 * q + c16, j = tj * 32 + 16 * q + c16;
+      int i2, i1, j2, j1;
+      const int qi = tg_fdivmod(i, d.I[2], rI2, i2);
+      const int i0 = tg_fdivmod(qi, d.I[1], rI1, i1);
+      const int qj = tg_fdivmod(j, d.J[2], rJ2, j2);
+      const int j0 = tg_fdivmod(qj, d.J[1], rJ1, j1);
+      const bool iv = i < Itot, jv = j < Jtot;
+      const bool iz = i2 >= d.Imask[2] || i1 >= d.Imask[1] || i0 >= d.Imask[0];
+      const bool jz = j2 >= d.Jmask[2] || j1 >= d.Jmask[1] || j0 >= d.Jmask[0];
+      oab[q] = (iv && !iz) ? 4u * (unsigned)(i0 * d.sAi[0] + i1 * d.sAi[1] + i2 * d.sAi[2]) : 0u;
+      obb[q] = (jv && !jz) ? 4u * (unsigned)(j0 * d.sBj[0] + j1 * d.sBj[1] + j2 * d.sBj[2]) : 0u;
+      const int oci = i0 * d.sCi[0] + i1 * d.sCi[1] + i2 * d.sCi[2];
+      if (g4 == q) offCi_s[wave][16 * q + c16] = iv ? (oci | (iz ? TG_ZERO_ROW : 0)) : -1;
+      ocj[q] = jv ? ((j0 * d.sCj[0] + j1 * d.sCj[1] + j2 * d.sCj[2]) | (jz ? TG_ZERO_ROW : 0)) : -1;
+    }
+    tg_f64x4 acc[2][2];
+#pragma unroll
+    for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[qa][qb][r] = 0.0;
+
+    int k0 = 0, k1 = 0, r8 = 0;
+    unsigned kab = 0, kbb = 0;
+    auto advance = [&]() {
+      if (++r8 == nr8) {
+        r8 = 0;
+        if (++k1 == K1) { k1 = 0; ++k0; }
+        kab = 4u * (unsigned)(k0 * d.sAk[0] + k1 * d.sAk[1]);
+        kbb = 4u * (unsigned)(k0 * d.sBk[0] + k1 * d.sBk[1]);
+      }
+    };
+    // av[q][e]: row quadrant q, k2 = 8 r8 + kh + e
+    auto load_raw = [&](float (&av)[2][2], float (&bv)[2][2]) {
+      const int kq = 8 * r8 + kh;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if constexpr (AVEC) {
+          const float2 v = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(A) + (oab[q] + kab + 4u * (unsigned)min(kq, K2s - 2)));
+          av[q][0] = v.x; av[q][1] = v.y;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) av[q][e] = tg_ldf(A, oab[q] + kab + (unsigned)min(kq + e, K2 - 1) * sA2b);
+        }
+        if constexpr (BVEC) {
+          const float2 v = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(B) + (obb[q] + kbb + 4u * (unsigned)min(kq, K2s - 2)));
+          bv[q][0] = v.x; bv[q][1] = v.y;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) bv[q][e] = tg_ldf(B, obb[q] + kbb + (unsigned)min(kq + e, K2 - 1) * sB2b);
+        }
+      }
+    };
+    auto mask_k = [&](const int r8m, float (&av)[2][2], float (&bv)[2][2]) {   // only the last round of a k2 run can be partial
+      if (8 * r8m + 8 > K2) {
+        const int kq = 8 * r8m + kh;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const bool ok = kq + e < K2;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) { av[q][e] = ok ? av[q][e] : 0.f; bv[q][e] = ok ? bv[q][e] : 0.f; }
+        }
+      }
+    };
+    auto mfma8 = [&](const float (&av)[2][2], const float (&bv)[2][2]) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const double a0 = (double)av[0][e], a1 = (double)av[1][e], b0 = (double)bv[0][e], b1 = (double)bv[1][e];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    };
+    float a0[2][2], b0[2][2], a1[2][2], b1[2][2];
+    if (nrounds > 0) {
+      load_raw(a0, b0);
+      mask_k(0, a0, b0);
+      int rd = 0;
+      for (; rd + 2 < nrounds; rd += 2) {
+        advance();
+        const int r8b = r8;
+        load_raw(a1, b1);
+        mfma8(a0, b0);
+        mask_k(r8b, a1, b1);
+        advance();
+        const int r8a = r8;
+        load_raw(a0, b0);
+        mfma8(a1, b1);
+        mask_k(r8a, a0, b0);
+      }
+      if (rd + 1 < nrounds) {
+        advance();
+        load_raw(a1, b1);
+        mfma8(a0, b0);
+        mask_k(r8, a1, b1);
+        mfma8(a1, b1);
+      } else {
+        mfma8(a0, b0);
+      }
+    }
+    // accumulator r of quadrant (qa, qb) = row 16 qa + g4 + 4 r, column 16 qb + c16 of the tile
+#pragma unroll
+    for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int oi = offCi_s[wave][16 * qa + g4 + 4 * r];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          if (oi >= 0 && ocj[qb] >= 0) {
+            float *p = C + ((oi & ~TG_ZERO_ROW) + (ocj[qb] & ~TG_ZERO_ROW));
+            float v = ((oi & TG_ZERO_ROW) || (ocj[qb] & TG_ZERO_ROW)) ? 0.f : (float)(acc[qa][qb][r] * alpha);
+            if (accumulate) v += *p;
+            *p = v;
+            if (sumsq) ss = fma((double)v, (double)v, ss);
+          }
+        }
+      }
   }
   if (sumsq) *sumsq += ss;
 }
@@ -737,8 +882,12 @@ __global__ __launch_bounds__(256, ACC64 ? 4 : 6) void tgemm_direct_kernel(TGemmD
   if (d.selA) baseA += (long)d.selA[(long)(b / d.seldivA) * d.selA_inc] * d.selA_mul;
   if (d.selB) baseB += (long)d.selB[(long)(b / d.seldivB) * d.selB_inc] * d.selB_mul;
   double ss = 0.0;
-  tg_direct_body<AVEC, BVEC, ACC64>(d, Ag + baseA, Bg + baseB, Cg + (long)(b / d.bdivC) * d.wC, Itot, Jtot, K2s, offCi_s,
-                                    blockIdx.x * 4, gridDim.x * 4, d.scale_in ? d.scale_in[b] : 1.f, d.scale_out ? &ss : nullptr);
+  if constexpr (ACC64)
+    tg_direct_body_f64<AVEC, BVEC>(d, Ag + baseA, Bg + baseB, Cg + (long)(b / d.bdivC) * d.wC, Itot, Jtot, K2s, offCi_s,
+                                   blockIdx.x * 4, gridDim.x * 4, d.scale_in ? d.scale_in[b] : 1.f, d.scale_out ? &ss : nullptr);
+  else
+    tg_direct_body<AVEC, BVEC>(d, Ag + baseA, Bg + baseB, Cg + (long)(b / d.bdivC) * d.wC, Itot, Jtot, K2s, offCi_s,
+                               blockIdx.x * 4, gridDim.x * 4, d.scale_in ? d.scale_in[b] : 1.f, d.scale_out ? &ss : nullptr);
   if (d.scale_out) {     // (gridDim.x == 1: this block stored all of C[b])
     __shared__ double s_nred[4];
     double a = ss;
@@ -772,7 +921,8 @@ constexpr int TG_CHAIN_LDS_FLOATS = 6144;    // 24 KB: six blocks per CU (measur
 // they fall back to: 416 ms vs 350 ms -- three blocks per CU hide too little latency)
 struct TGemmChainMap { int mapK[3] = {-1, -1, -1}, mapJ[3] = {-1, -1, -1}; };
 
-template <bool AVEC1, bool BVEC1, bool AVEC2, int LDSF, int MINB>
+// F64: both stages accumulate in float64 on the f64 matrix cores (tg_direct_body_f64; the intermediate stays f32 in LDS)
+template <bool AVEC1, bool BVEC1, bool AVEC2, int LDSF, int MINB, bool F64 = false>
 __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TGemmDesc d2, TGemmChainMap mp, const float *__restrict__ A1g,
                                                             const float *__restrict__ B1g, const float *__restrict__ A2g,
                                                             float *__restrict__ C2g, int *__restrict__ flag, int only_flagged, int allow_chunks) {
@@ -836,9 +986,15 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TG
   d1.accumulate = 0;
   const float in_scale = d1.scale_in ? d1.scale_in[b] : 1.f;   // an operand of stage 1 was left unnormalised by its producer
   if (chunk >= d1.I[1]) {
-    tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1, B1g + baseB1, s_mid, I1, J1, K2s1, offCi_s, 0, 4, in_scale);
-    __syncthreads();
-    tg_direct_body<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC, I2, J2, K2s2, offCi_s, 0, 4);
+    if constexpr (F64) {
+      tg_direct_body_f64<AVEC1, BVEC1>(d1, A1g + baseA1, B1g + baseB1, s_mid, I1, J1, K2s1, offCi_s, 0, 4, in_scale);
+      __syncthreads();
+      tg_direct_body_f64<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC, I2, J2, K2s2, offCi_s, 0, 4);
+    } else {
+      tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1, B1g + baseB1, s_mid, I1, J1, K2s1, offCi_s, 0, 4, in_scale);
+      __syncthreads();
+      tg_direct_body<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC, I2, J2, K2s2, offCi_s, 0, 4);
+    }
     return;
   }
   const int n1 = d1.I[1];
@@ -850,9 +1006,15 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TG
     for (int s = 0; s < 3; ++s)      // (no dynamic indexing: the descriptors stay in registers)
       if (s == jsub) d2.J[s] = cn;
     if (c0) __syncthreads();     // stage 2 of the chunk before has read the buffer
-    tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1 + (long)c0 * sA1, B1g + baseB1, s_mid, d1.Itot(), J1, K2s1, offCi_s, 0, 4, in_scale);
-    __syncthreads();
-    tg_direct_body<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC + (long)c0 * sC2, I2, d2.Jtot(), K2s2, offCi_s, 0, 4);
+    if constexpr (F64) {
+      tg_direct_body_f64<AVEC1, BVEC1>(d1, A1g + baseA1 + (long)c0 * sA1, B1g + baseB1, s_mid, d1.Itot(), J1, K2s1, offCi_s, 0, 4, in_scale);
+      __syncthreads();
+      tg_direct_body_f64<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC + (long)c0 * sC2, I2, d2.Jtot(), K2s2, offCi_s, 0, 4);
+    } else {
+      tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1 + (long)c0 * sA1, B1g + baseB1, s_mid, d1.Itot(), J1, K2s1, offCi_s, 0, 4, in_scale);
+      __syncthreads();
+      tg_direct_body<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC + (long)c0 * sC2, I2, d2.Jtot(), K2s2, offCi_s, 0, 4);
+    }
   }
 }
 
@@ -965,7 +1127,8 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain3_kernel(TGemmDesc d1, T
 // Returns 0 when the static shapes rule the chain out, 1 when launched (entries may be declined: flag -1), 2 when launched and
 // no entry can be declined (every slice of the intermediate fits the buffer: the caller skips the fallback launches).
 inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemmDesc &d2_in, const TGemmChainMap &mp,
-                              const float *A1, const float *B1, const float *A2, float *C2, int *flag, int allow_chunks = 0, int dense = 0);
+                              const float *A1, const float *B1, const float *A2, float *C2, int *flag, int allow_chunks = 0, int dense = 0,
+                              int f64acc = 0);
 
 inline int tgemm_chain3_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemmDesc &d2_in, const TGemmDesc &d3_in, const TGemmChainMap &mp,
                                const TGemmChain3Map &mp3, const float *A1, const float *B1, const float *A2, const float *B3, float *C3, int *flag,
@@ -1082,7 +1245,7 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
 }
 
 inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemmDesc &d2_in, const TGemmChainMap &mp,
-                              const float *A1, const float *B1, const float *A2, float *C2, int *flag, int allow_chunks, int dense) {
+                              const float *A1, const float *B1, const float *A2, float *C2, int *flag, int allow_chunks, int dense, int f64acc) {
   if (!tgemm_use_mfma() || d1_in.dynK || d2_in.dynK || d1_in.nbatch != d2_in.nbatch || d1_in.nbatch <= 0) return 0;
   if (d1_in.bdivA != 1 || d1_in.bdivB != 1 || d2_in.bdivA != 1 || d2_in.bdivC != 1) return 0;
   TGemmDesc d1 = d1_in, d2 = d2_in;
@@ -1102,10 +1265,13 @@ inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemm
   // the chunked sub-index = 32 full rows per stage-1 tile and eight balanced stage-2 tiles (24 KB: 24 rows, six tiles), at four
   // blocks per CU instead of six (PEPSGPU_CHAIN_DENSE_LDS = 0 / 8192 / 16384 floats)
   static const int dense_lds = getenv("PEPSGPU_CHAIN_DENSE_LDS") ? atoi(getenv("PEPSGPU_CHAIN_DENSE_LDS")) : 8192;
-  const int ldsf = (dense && allow_chunks && dense_lds >= 8192) ? (dense_lds >= 16384 ? 16384 : 8192) : TG_CHAIN_LDS_FLOATS;
+  int ldsf = (dense && allow_chunks && dense_lds >= 8192) ? (dense_lds >= 16384 ? 16384 : 8192) : TG_CHAIN_LDS_FLOATS;
+  if (f64acc && ldsf > 8192) ldsf = 8192;       // (the float64-accumulating form is built for the two default buffer sizes)
 #define PG_CHAIN(a1, b1, a2)                                                                                                   \
   do {                                                                                                                         \
-    if (ldsf == 16384) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 16384, 2>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
+    if (f64acc && ldsf >= 8192) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 8192, 4, true>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
+    else if (f64acc) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 4, true>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
+    else if (ldsf == 16384) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 16384, 2>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
     else if (ldsf == 8192) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 8192, 4>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
     else hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 6>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
   } while (0)

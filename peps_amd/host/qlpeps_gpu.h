@@ -2265,10 +2265,19 @@ class MCPEPSMeasurer {
     observables_meta_ = solver_.DescribeObservables(comp.contractor.rows(), comp.contractor.cols());
   }
   void Execute() {                                  // monte_carlo_peps_measurer_impl.h:172-178
-    std::vector<double> rates;
-    for (size_t s = 0; s < params_.num_warmup_sweeps; ++s) updater_(sitps_, comp_, rates);   // engine_.WarmUp()
+    // engine_.WarmUp() (monte_carlo_engine.h:146-173): the warm-up sweeps, the amplitude sanity check and NormalizeStateOrder1 -- the
+    // measurer's own copy of the state is rescaled to max_w |psi_w| = 1 and the components are rebuilt.  Ratios do not see it; the
+    // structure-factor amplitudes (SpSm_cross) do, and the reference's regression vector (K8) is taken after it.
+    MonteCarloParams mc;
+    mc.num_warmup_sweeps = params_.num_warmup_sweeps;
+    mc.sweeps_between_samples = params_.sweeps_between_samples;
+    MonteCarloEngine<MonteCarloSweepUpdater> engine(sitps_, comp_, mc, updater_);
+    engine.WarmUp();
+    scale_factor_ = engine.LastScaleFactor();
     Measure_();
   }
+  double StateScaleFactor() const { return scale_factor_; }   // overall factor of NormalizeStateOrder1 (1 / max |psi| after warm-up)
+  const SplitIndexTPS &State() const { return sitps_; }       // the rescaled state the samples were taken on
   // key -> (mean, stderr) over the walkers of this batch
   const std::map<std::string, std::pair<std::vector<double>, std::vector<double>>> &ObservableRegistry() const { return registry_stats_; }
   // per-walker sample means [key][walker][len]: what a rank contributes to GatherStatisticListOfData
@@ -2371,7 +2380,8 @@ class MCPEPSMeasurer {
       walker_means_[kv.first] = kv.second;
     }
   }
-  const SplitIndexTPS &sitps_;
+  SplitIndexTPS sitps_;                             // by value, as the reference's engine holds split_index_tps_: it is rescaled
+  double scale_factor_ = 1.0;
   TPSWaveFunctionComponent &comp_;
   MCMeasurementParams params_;
   MonteCarloSweepUpdater &updater_;

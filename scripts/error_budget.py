@@ -104,6 +104,11 @@ def main():
         ("f32 acc64 M", capi.F32, {"PEPSGPU_ACC64": "4"}),
         ("f32 acc64 Y", capi.F32, {"PEPSGPU_ACC64": "8"}),
         ("f32 acc64 all contractions", capi.F32, {"PEPSGPU_ACC64": "15"}),
+        ("f32 backward pair in f32 (round 4)", capi.F32, {"PEPSGPU_TT_ACC64": "0"}),
+        ("f32 Y on the wave-per-tile f64 body", capi.F32, {"PEPSGPU_Y_ACC64": "1"}),
+        ("f32 acc64 X,P,Z,Tt", capi.F32, {"PEPSGPU_ACC64": "3"}),
+        ("f32 acc64 Z,Tt,M", capi.F32, {"PEPSGPU_ACC64": "6"}),
+        ("f32 acc64 X,P,Z,Tt,M", capi.F32, {"PEPSGPU_ACC64": "7"}),
         ("f32 acc64 all, no ortho polish", capi.F32, {"PEPSGPU_ACC64": "15", "PEPSGPU_ORTHO_POLISH": "0"}),
         ("f32 Y on the LDS-tiled f32 kernel", capi.F32, {"PEPSGPU_Y_TILED": "1"}),
         ("f32 no fused norm", capi.F32, {"PEPSGPU_NO_FUSED_NORM": "1"}),

@@ -109,9 +109,8 @@ def test_c3_c4_heisenberg_amplitude_and_energy(name, nref):
     for w in range(nref):
         comp = vmc.TPSWaveFunctionComponent(s, cfgs[w], tp)
         assert abs(amps[w] / comp.amplitude - 1) < 1e-5
-        if w == 0:
-            e, _, _ = model.CalEnergyAndHoles(s, comp, False)
-            assert abs(en[w] / e - 1) < 1e-6                        # north_star: energy to 1e-6 relative
+        e, _, _ = model.CalEnergyAndHoles(s, comp, False)           # every reference configuration, not only the first
+        assert abs(en[w] / e - 1) < 1e-6                            # north_star: energy to 1e-6 relative
 
 
 def test_psi_consistency_over_all_routes_large_batch_c4():

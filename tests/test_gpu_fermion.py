@@ -325,3 +325,23 @@ def test_reference_fermion_gradient_signatures_on_device(fixtures_dir):
     print("fermion gradient signatures: NormSquare %.15e (ref 2.184991439005157e-17)  probe %.15e (ref 7.407222090395872e-18)" % (ns, wp))
     assert abs(ns / 2.184991439005157e-17 - 1) < 1e-6 and abs(wp / 7.407222090395872e-18 - 1) < 1e-6    # (the reference asserts an absolute 1e-8; measured here: 1e-9 relative)
     assert ns < 1e-12                                                                               # ... and the scale it implies
+
+
+def test_k9_reference_tj_measurer_regression_energy_on_the_device(fixtures_dir):
+    """K9 through the HIP path (f64 mode): the REFERENCE's deterministic regression value of MCPEPSMeasurer on a fermionic state --
+    tests/test_model_solvers/test_tJ_model_solver.cpp:72-75, 233-275: -14.74320489110316 +- 1e-8 -- 6x6 t-J, two holes, fU1 tensors,
+    D = 8, configuration0, MCUpdateSquareNNExchange(42), 10 warm-up sweeps, 10 samples, SVD(8, 16, 1e-15), SquaretJNNModel(1, 0.3, 0).
+    pepshost_fermion_measure_energy: ONE std::mt19937 stream over warm-up, rebuild and samples.  (Staged at the end of round 4, first
+    run -- green -- in round 5; the oracle reproduces the value to 2e-15, tests/test_oracle_fermion.py.)"""
+    from peps_amd import fermion, hostapi
+    d = os.path.join(fixtures_dir, "tps_tJ_6x6Hole2_J0.3_D8_fU1")
+    st = fermion.FermionState.load(d)
+    cfg = np.loadtxt(os.path.join(d, "configuration0"), dtype=int).reshape(1, 6, 6)
+    hostapi.set_truncate_params(8, 1e-15, 0)                       # BMPSTruncateParams::SVD(8, 16, 1e-15)
+    try:
+        en, _, _ = hostapi.fermion_measure_energy(st, cfg, [42], 16, 10, 10, 1, "tj", t=1.0, J=0.3, V=0.0, mu=0.0, dtype=1)
+    finally:
+        hostapi.set_truncate_params()
+    e = float(np.mean(en[:, 0]))
+    print("K9 on the device: energy %.14f (reference -14.74320489110316, diff %.1e)" % (e, abs(e + 14.74320489110316)))
+    assert abs(e - (-14.74320489110316)) < 1e-8

@@ -86,6 +86,44 @@ def test_tgemm_matches_numpy(case, dt):
     assert np.all(got[mask] == 7.0)
 
 
+@pytest.mark.parametrize("case", range(len(CASES)))
+@pytest.mark.parametrize("mode", [1, 2])
+def test_tgemm_wave_per_tile_bodies(case, mode, monkeypatch):
+    """The wave-per-tile kernel on the descriptor cases of the LDS-tiled one: mode 1 = tg_direct_body (f32 MFMA 32x32x2), mode 2 =
+    tg_direct_body_f64 (round 5: f32 operands, v_mfma_f64_16x16x4_f64 accumulation -- the result is the float64 sum rounded once)."""
+    capi = _capi()
+    I, J, K = CASES[case]
+    rng = np.random.default_rng(300 + case)
+    ni, nj, nk = int(np.prod(I)), int(np.prod(J)), int(np.prod(K))
+    def strides(dims, perm):
+        st = [0] * len(dims)
+        acc = 1
+        for ax in reversed(perm):
+            st[ax] = acc
+            acc *= dims[ax]
+        return st
+    stA = strides(list(I) + list(K), list(rng.permutation(6)))
+    stB = strides(list(K) + list(J), list(rng.permutation(6)))
+    stC = strides(list(I) + list(J), list(rng.permutation(6)))
+    nb = 3
+    wA, wB, wC = ni * nk + 8, nk * nj + 4, ni * nj + 7
+    A = rng.standard_normal(nb * wA).astype(np.float32)
+    B = rng.standard_normal(nb * wB).astype(np.float32)
+    C0 = np.full(nb * wC, 7.0)
+    monkeypatch.setenv("PEPSGPU_DIAG_TGEMM_MODE", str(mode))
+    got = capi.diag_tgemm(capi.F32, capi.F32, I, J, K, stA[:3], stA[3:], stB[:3], stB[3:], stC[:3], stC[3:], A, B, C0, nb, wA, wB, wC)
+    ref = _ref_tgemm(I, J, K, stA[:3], stA[3:], stB[:3], stB[3:], stC[:3], stC[3:], A.astype(np.float64), B.astype(np.float64), C0, nb, wA, wB, wC)
+    scale = max(1.0, np.max(np.abs(ref)))
+    if mode == 2:      # one rounding to float32 of the exact float64 sum
+        assert np.max(np.abs(got - ref.astype(np.float32))) <= 1.2e-7 * scale
+    else:
+        assert np.max(np.abs(got - ref)) < 2e-5 * np.sqrt(nk) * scale
+    mask = np.ones(nb * wC, bool)
+    for b in range(nb):
+        mask[b * wC:b * wC + ni * nj] = False
+    assert np.all(got[mask] == 7.0)
+
+
 @pytest.mark.parametrize("n", [1, 7, 16, 40, 129, 256])
 @pytest.mark.parametrize("dt", ["f32", "f64"])
 def test_cholesky(n, dt):
@@ -341,12 +379,15 @@ def test_gram_free_factor_mixed_rows_and_ranks_in_one_launch(dt):
         assert np.all(ml >= 0)
 
 
-def test_chained_contraction_pair_with_live_extents():
-    """tgemm_chain_kernel (X = R.A kept in LDS, P = W.X) with the descriptors of the absorption: per-walker live extents of
+@pytest.mark.parametrize("f64acc", [0, 1])
+def test_chained_contraction_pair_with_live_extents(f64acc, monkeypatch):
+    """(f64acc = 1: the float64-accumulating form of both stages, round 5 -- the intermediate is still f32 in LDS.)
+    tgemm_chain_kernel (X = R.A kept in LDS, P = W.X) with the descriptors of the absorption: per-walker live extents of
     the carry rows and of both bonds.  Entries whose live X exceeds the 24 KB LDS buffer are walked in chunks of carry rows
     (X still never leaves the chip); an entry is declined (flag -1, result untouched) only when one carry row's slice of X
     does not fit."""
     from peps_amd import capi
+    monkeypatch.setenv("PEPSGPU_DIAG_CHAIN_F64", str(f64acc))
     rng = np.random.default_rng(5)
     for (nb, m, l, a, p, a2, l2, u) in [(48, 24, 8, 16, 8, 16, 8, 8), (6, 40, 8, 32, 8, 32, 8, 8), (4, 5, 8, 8, 8, 128, 4, 4)]:
         R = rng.standard_normal((nb, m, l, a)).astype(np.float32)
@@ -368,7 +409,7 @@ def test_chained_contraction_pair_with_live_extents():
             X = np.einsum("mla,apc->mlpc", R[b, :ml, :, :al].astype(np.float64), A[b, :al, :, :a2l].astype(np.float64))
             want = np.einsum("mlpc,lpqu->muqc", X, W[b].astype(np.float64))
             got = P[b, :ml, :, :, :a2l]
-            assert np.max(np.abs(got - want)) < 2e-5 * np.max(np.abs(want)), (b, live[b])
+            assert np.max(np.abs(got - want)) < (3e-7 if f64acc else 2e-5) * np.max(np.abs(want)), (b, live[b])
         if a2 <= 32:
             assert n_chunked >= 1
         else:
@@ -491,6 +532,24 @@ def test_row_gram_kernel(n, K):
                     err_exact = np.where(jj // 16 >= ii // 16, err_exact, 0.0)
                 assert np.max(err) < 1e-13 * K ** 0.5 + 1e-15, (b, bi, bj)
                 assert np.max(err_exact) < 1.5e-6, (b, bi, bj)
+
+
+@pytest.mark.parametrize("bad", [np.nan, np.inf])
+def test_integer_gram_kernels_propagate_non_finite_input(bad):
+    """the exact-integer Grams (gram_i8.h) turn a NaN / Inf of P into finite digits; the kernel detects non-finite input
+    itself and poisons the diagonal of G with NaN (what the float64 Gram it replaces propagated into the Cholesky pivots); a clean
+    walker of the same launch is untouched."""
+    capi = _capi()
+    rng = np.random.default_rng(11)
+    P = rng.standard_normal((2, 512, 256)).astype(np.float32)
+    P[1, 300, 77] = bad
+    G = capi.diag_gram_cols(capi.F32, P, None)
+    assert np.all(np.isfinite(np.triu(G[0])[:16, :16])) and abs(G[0][3, 3] - np.sum(P[0, :, 3].astype(np.float64) ** 2)) < 1e-4
+    assert np.all(np.isnan(np.diag(G[1])))
+    M = rng.standard_normal((2, 256, 256)).astype(np.float32)
+    M[0, 5, 200] = bad
+    Gr = capi.diag_gram_rows(M, np.array([256, 256], dtype=np.int32))
+    assert np.all(np.isnan(np.diag(Gr[0]))) and np.all(np.isfinite(np.diag(Gr[1])))
 
 
 @pytest.mark.parametrize("n,rank", [(256, 256), (256, 97), (241, 180), (160, 33), (128, 128), (100, 7), (48, 48)])

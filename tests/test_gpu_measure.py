@@ -200,3 +200,48 @@ def test_exact_sum_measurer_all_binary_configs(dt, tol):
     with pytest.raises(Exception):
         host.exact_sum_measure_partial(flat, np.zeros((0, Ly, Lx), dtype=np.int32), chi, "xxz", params, 0, 1, 4, dt)
     assert host.exact_sum_measure_partial(flat, np.array(all_cfgs[:2]), chi, "xxz", params, 3, 4, 4, dt) == ({}, 0.0)
+
+
+def _bond(sitps):
+    return max(max(t.shape) for row in sitps for site in row for t in site)
+
+
+def test_k8_reference_structure_factor_regression_on_the_device(fixtures_dir):
+    """K8 through the HIP path (f64 mode): the REFERENCE's regression vector of MCPEPSMeasurer -- tests/test_model_solvers/
+    test_square_xxz_measurer.cpp:204-381: 96 SpSm_cross values at 1e-10, energy -9.22 +- 0.01 -- 4x4 D = 8 Heisenberg fixture,
+    checkerboard start, MCUpdateSquareNNExchange(42), 5 warm-up sweeps, NormalizeStateOrder1, 5 samples, SVD(8, 16, 1e-15).
+    MCPEPSMeasurer of the host layer (its Execute runs the engine's WarmUp incl. the order-1 rescale, round 5: the first run on a GPU
+    found it missing -- every value off by the common factor 41.7); params[6] = 1: the structure factor in the stack state the
+    reference measures it in.  (Staged at the end of round 4, first run in round 5.)"""
+    import json
+    host = _host()
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "xxz_spsm_cross_reference_golden.json")))
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, "tps_square_heisenberg4x4D8Double"))
+    cfg = np.array([[[(r + c) % 2 for c in range(4)] for r in range(4)]], dtype=np.int32)
+    host.set_truncate_params(8, 1e-15, 0)
+    try:
+        out, _ = host.measure(synthetic.sitps_to_flat(s, _bond(s)), cfg, 16, "xxz", (1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 1.0), seeds=[42],
+                              updater="exchange", warmup_sweeps=5, n_samples=5, sweeps_between_samples=1, dtype=F64)
+    finally:
+        host.set_truncate_params()
+    vals = np.asarray(out["SpSm_cross"][0]).reshape(-1, 5)[:, 4]
+    want = np.array(gold["spsm_cross_values"])
+    print("K8 on the device: max |SpSm_cross - reference| = %.2e over %d values" % (np.max(np.abs(vals - want)), len(want)))
+    assert np.max(np.abs(vals - want)) < 1e-10
+    assert np.count_nonzero(vals) == np.count_nonzero(want) == 44
+    assert abs(out["energy"][0][0] - gold["energy"]) < gold["energy_tol"]
+
+
+def test_tfim_registry_on_the_device(fixtures_dir):
+    """TransverseFieldIsingSquareOBC::EvaluateObservables of the host layer on all 16 configurations of the reference's 2x2 state against
+    the oracle's registry (itself pinned on tests/test_algorithm/test_exact_summation_measurer.cpp:548-651 at 1e-10)"""
+    host = _host()
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, "transverse_ising_tps_double_from_simple_update"))
+    cfgs = np.array(vmc.generate_all_binary_configs(2, 2), dtype=np.int32)
+    got, _ = host.measure(synthetic.sitps_to_flat(s, _bond(s)), cfgs, 8, "tfim", (1.0,), dtype=F64)
+    tp = BMPSTruncateParams.SVD(8, 8, 0.0)
+    for w, c in enumerate(cfgs):
+        want = vmc.TransverseFieldIsingSquareOBC(1.0).EvaluateObservables(s, vmc.TPSWaveFunctionComponent(s, c, tp))
+        assert set(got) == set(want)
+        for key, v in want.items():
+            assert np.max(np.abs(got[key][w] - np.asarray(v, dtype=np.float64))) < 1e-9, (key, w)

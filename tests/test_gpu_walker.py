@@ -261,3 +261,37 @@ def test_walker_fermionic_bten(fixtures_dir):
     assert w.GetBTenRightCol() == mid + 1
     assert abs(abs(w.TraceWithBTen(bot, mid)[0]) / abs(ref1) - 1) < 1e-8
     ctx.close()
+
+
+def test_python_walker_releases_its_device_copy():
+    """a Python Walker is a deep copy of one BMPS for all walkers of the context; it is released by destroy(), at the end
+    of a `with` block and by the finalizer (the C++ BMPSWalker's destructor) -- a clone per source site must not pile up in the arena."""
+    import gc
+    from peps_amd import capi, synthetic
+    L, D, chi = 4, 3, 9
+    s = synthetic.make_sitps(L, D)
+    ctx = capi.Context(L, L, D, 2, chi, dtype=capi.F64, max_walkers=2)
+    ctx.state_upload(synthetic.sitps_to_flat(s, D))
+    ctx.set_configs(synthetic.make_configs(L, 2, "heisenberg"))
+    ctx.evaluate_amplitude()
+    ctx.grow_bmps_for_row(2)
+    with ctx.get_walker(capi.UP) as w:
+        wid = w.wid
+        c = w.clone()
+        cid = c.wid
+        del c
+        gc.collect()
+        with pytest.raises(RuntimeError):       # the clone is gone ...
+            capi.Walker(ctx, cid).GetStackSize()
+        assert w.GetStackSize() >= 1            # ... the walker it was copied from is not
+    with pytest.raises(RuntimeError):           # released at the end of the block
+        capi.Walker(ctx, wid).GetStackSize()
+    for _ in range(3):
+        ctx.get_walker(capi.UP).clone()
+    gc.collect()
+    base = ctx.stats()["device_bytes"]
+    for _ in range(40):                         # a clone per source site, dropped each time: the arena does not grow
+        ctx.get_walker(capi.UP).clone()
+    gc.collect()
+    assert ctx.stats()["device_bytes"] == base
+    ctx.close()
