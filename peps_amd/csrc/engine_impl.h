@@ -921,11 +921,16 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       // Y on precise sites: 2 = float64 accumulation on the LDS-tiled kernel (f64 matrix cores) + separate normalisation (round 4);
       // 1 = the wave-per-tile kernel with float64 accumulation (tg_direct_body_f64, round 5; the norm stays fused into the launch);
       // 0 = the f32 chain of round 3
-      static const int y_mode = getenv("PEPSGPU_Y_ACC64") ? atoi(getenv("PEPSGPU_Y_ACC64")) : 2;
+      // (measured, round 5, real state at C4, n = 256 vs the f64 mode: mode 1 max 6.8e-6 / median 1.67e-6 at 2 235 amp/s (4 096
+      // walkers), mode 2 8.0e-6 / 1.81e-6 at 2 200)
+      static const int y_mode = getenv("PEPSGPU_Y_ACC64") ? atoi(getenv("PEPSGPU_Y_ACC64")) : 1;
       bool y_f64 = false;
       if constexpr (sizeof(T) == 4) {
         g.acc64 = (precise_site && y_mode == 1) ? 1 : 0;
         y_f64 = precise_site && y_mode == 2;
+        // (the wave-per-tile kernel is the one that honours acc64: round 4 left prefer_tiled set on dense sites, so its "mode 1"
+        // measurement ran the LDS-tiled f32 kernel there -- the "drain removes a third only" of HISTORY 3e was that, not the drain)
+        if (g.acc64) g.prefer_tiled = false;
       }
       // reference op: res[i-1] . (u s)  (bmps_impl.h:254): 2 (m_{i-1} D_u) m_i k_i
       int rp, cp, ddp[4];

@@ -1412,7 +1412,67 @@ __global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, l
     __syncthreads();
     const int nl = s_nl;
     const int lp = nl + (nl & 1);
+    // Rows in global memory (the f64 bulk: 256 x 256 doubles do not fit LDS), at most 256 long: a wave takes FOUR pairs of the
+    // round at a time -- their eight rows are requested together (one L2 round trip instead of four, each row read once instead
+    // of twice) and rotated from registers.  Round 5: the f64 mode on a dense state spent 98 % of its time here, one dependent
+    // load -> reduce -> rotate -> store chain per pair (25 amp/s at C4 whatever the batch).
+    const bool batched = !use_lds && len <= 256;
     for (int r = 0; r < lp - 1; ++r) {
+      if (batched) {
+        constexpr int PB = 4;
+        for (int p0 = wave; p0 < lp / 2; p0 += nw * PB) {
+          T *pa[PB], *pb[PB];
+          bool ok[PB];
+          T x[PB][4], y[PB][4];
+#pragma unroll
+          for (int q = 0; q < PB; ++q) {
+            const int p = p0 + q * nw;
+            int a = 0, b = 0;
+            ok[q] = p < lp / 2;
+            if (ok[q]) {
+              if (p == 0) { a = lp - 1; b = r; }
+              else { a = (r + p) % (lp - 1); b = (r - p + (lp - 1)) % (lp - 1); }
+              if (a > b) { int t = a; a = b; b = t; }
+              ok[q] = b < nl;
+            }
+            a = ok[q] ? s_idx[a] : 0; b = ok[q] ? s_idx[b] : 0;
+            pa[q] = M + (long)a * lds_ld; pb[q] = M + (long)b * lds_ld;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int c = lane + 64 * e;
+              x[q][e] = (ok[q] && c < len) ? pa[q][c] : T(0);
+              y[q][e] = (ok[q] && c < len) ? pb[q][c] : T(0);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < PB; ++q) {
+            if (!ok[q]) continue;                       // (wave-uniform)
+            T alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { alpha += x[q][e] * x[q][e]; beta += y[q][e] * y[q][e]; gamma += x[q][e] * y[q][e]; }
+            alpha = wave_sum(alpha); beta = wave_sum(beta); gamma = wave_sum(gamma);
+            const T ab = sqrt(alpha) * sqrt(beta);
+            if (fabs(gamma) > tol * ab && alpha > floor2 && beta > floor2) {
+              const double zeta = ((double)beta - (double)alpha) / (2.0 * (double)gamma);
+              const double td = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+              const double cd = 1.0 / sqrt(1.0 + td * td);
+              const T cs = T(cd), sn = T(cd * td);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int c = lane + 64 * e;
+                if (c < len) {
+                  pa[q][c] = cs * x[q][e] - sn * y[q][e];
+                  pb[q][c] = sn * x[q][e] + cs * y[q][e];
+                }
+              }
+              if (lane == 0) atomicAdd(&s_rot, 1);
+            }
+          }
+        }
+        __threadfence_block();
+        __syncthreads();
+        continue;
+      }
       for (int p = wave; p < lp / 2; p += nw) {
         int a, b;
         if (p == 0) { a = lp - 1; b = r; }

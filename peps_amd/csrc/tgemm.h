@@ -702,6 +702,170 @@ __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *
   if (sumsq) *sumsq += ss;
 }
 
+// The same tile loop with a wave owning TWO neighbouring J tiles (a 32 x 64 block of C) at once (round 5): one A load feeds two MFMA
+// chains, so the chain of dependent operand round trips of a block -- what bounds the chained kernel on the low-rank headline state
+// (one L2 round trip per k-round, two tiles per wave one after the other) -- is half as long for stage 2 (A = the site tensor from
+// L2, B = the intermediate in LDS).  Costs 24 more registers (five blocks per CU instead of six).
+template <bool AVEC, bool BVEC>
+__device__ __forceinline__ void tg_direct_body_j2(const TGemmDesc &d, const float *__restrict__ A, const float *__restrict__ B,
+                                               float *__restrict__ C, const int Itot, const int Jtot, const int K2s,
+                                               int (*offCi_s)[32], const int tile0, const int tile_step,
+                                               const float scale = 1.f, double *__restrict__ sumsq = nullptr) {
+  // scale: multiplies alpha (per-entry scale of an operand that was left unnormalised); sumsq (optional): += squares of the
+  // values this lane stores.
+  // Instruction budget (SQ counters, round 2: 36 VALU instructions per MFMA in the chained kernel, the launches were
+  // bound by VALU issue, not by memory): no integer division per lane (float-reciprocal split of the tile's row / column
+  // index), K walked with uniform counters, loads unconditional at clamped addresses (rows and columns that do not exist
+  // read row / column 0 and are never stored; k beyond the live extent is zeroed in the last round of a k2 run only),
+  // the loads of round r+1 issued before and consumed after the MFMAs of round r.
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntj = (Jtot + 31) >> 5;
+  const float alpha = (float)d.alpha * scale;
+  double ss = 0.0;     // (f64: the norm it feeds replaces an f64 reduction over the stored tensor)
+  const int half = lane >> 5, l31 = lane & 31;
+  const int K2 = d.K[2], K1 = d.K[1];
+  const int nr8 = (K2 + 7) >> 3, nrounds = d.K[0] * K1 * nr8;
+  const unsigned sA2b = 4u * d.sAk[2], sB2b = 4u * d.sBk[2];
+  const float rI2 = __builtin_amdgcn_rcpf((float)d.I[2]), rI1 = __builtin_amdgcn_rcpf((float)d.I[1]);
+  const float rJ2 = __builtin_amdgcn_rcpf((float)d.J[2]), rJ1 = __builtin_amdgcn_rcpf((float)d.J[1]);
+  const int kh = 4 * half;
+  const bool accumulate = d.accumulate != 0;
+
+  const int ntjp = (ntj + 1) >> 1, ntp = ((Itot + 31) >> 5) * ntjp;      // pairs of neighbouring J tiles
+  for (int t = tile0 + wave; t < ntp; t += tile_step) {
+    const int ti = t / ntjp, tjp = t - ti * ntjp;
+    const int i = ti * 32 + l31;
+    unsigned oab, obb[2];    // byte offsets of this lane's A row / B columns (0 when they do not exist)
+    int ocj[2];              // element offset of column j in C, -1: not stored; TG_ZERO_ROW set: stored as zero
+    {
+      int i2, i1;
+      const int qi = tg_fdivmod(i, d.I[2], rI2, i2);
+      const int i0 = tg_fdivmod(qi, d.I[1], rI1, i1);
+      const bool iv = i < Itot;
+      const bool iz = i2 >= d.Imask[2] || i1 >= d.Imask[1] || i0 >= d.Imask[0];
+      oab = (iv && !iz) ? 4u * (unsigned)(i0 * d.sAi[0] + i1 * d.sAi[1] + i2 * d.sAi[2]) : 0u;
+      const int oci = i0 * d.sCi[0] + i1 * d.sCi[1] + i2 * d.sCi[2];
+      if (half == 0) offCi_s[wave][l31] = iv ? (oci | (iz ? TG_ZERO_ROW : 0)) : -1;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int j = (2 * tjp + q) * 32 + l31;
+        int j2, j1;
+        const int qj = tg_fdivmod(j, d.J[2], rJ2, j2);
+        const int j0 = tg_fdivmod(qj, d.J[1], rJ1, j1);
+        const bool jv = j < Jtot;
+        const bool jz = j2 >= d.Jmask[2] || j1 >= d.Jmask[1] || j0 >= d.Jmask[0];
+        obb[q] = (jv && !jz) ? 4u * (unsigned)(j0 * d.sBj[0] + j1 * d.sBj[1] + j2 * d.sBj[2]) : 0u;
+        ocj[q] = jv ? ((j0 * d.sCj[0] + j1 * d.sCj[1] + j2 * d.sCj[2]) | (jz ? TG_ZERO_ROW : 0)) : -1;
+      }
+    }
+    tg_f32x16 acc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    int k0 = 0, k1 = 0, r8 = 0;          // uniform position of the round being loaded: (k0, k1), k2 = 8 r8 + 4 half + (0..3)
+    unsigned kab = 0, kbb = 0;           // byte offsets of (k0, k1) in A and B
+    auto advance = [&]() {
+      if (++r8 == nr8) {
+        r8 = 0;
+        if (++k1 == K1) { k1 = 0; ++k0; }
+        kab = 4u * (unsigned)(k0 * d.sAk[0] + k1 * d.sAk[1]);
+        kbb = 4u * (unsigned)(k0 * d.sBk[0] + k1 * d.sBk[1]);
+      }
+    };
+    auto load_raw = [&](float (&av)[4], float (&bv)[2][4]) {
+      const int kq = 8 * r8 + kh;
+      if constexpr (AVEC) {
+        const float4 v = tg_ldf4(A, oab + kab + 4u * (unsigned)min(kq, K2s - 4));
+        av[0] = v.x; av[1] = v.y; av[2] = v.z; av[3] = v.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) av[q] = tg_ldf(A, oab + kab + (unsigned)min(kq + q, K2 - 1) * sA2b);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if constexpr (BVEC) {
+          const float4 v = tg_ldf4(B, obb[c] + kbb + 4u * (unsigned)min(kq, K2s - 4));
+          bv[c][0] = v.x; bv[c][1] = v.y; bv[c][2] = v.z; bv[c][3] = v.w;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bv[c][q] = tg_ldf(B, obb[c] + kbb + (unsigned)min(kq + q, K2 - 1) * sB2b);
+        }
+      }
+    };
+    auto mask_k = [&](const int r8m, float (&av)[4], float (&bv)[2][4]) {   // only the last round of a k2 run can be partial
+      if (8 * r8m + 8 > K2) {
+        const int kq = 8 * r8m + kh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool ok = kq + q < K2;
+          av[q] = ok ? av[q] : 0.f;       // (a zero A column kills the product whatever B holds)
+        }
+      }
+    };
+    float a0[4], b0[2][4], a1[4], b1[2][4];
+    auto mfma4 = [&](const float (&av)[4], const float (&bv)[2][4]) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[0][q], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[1][q], acc[1], 0, 0, 0);
+      }
+    };
+    if (nrounds > 0) {
+      load_raw(a0, b0);
+      mask_k(0, a0, b0);
+      int rd = 0;
+      // steady state without a conditional around the loads (the wait counters stay exact: the loads of the next round
+      // are in flight while the MFMAs of this one issue)
+      for (; rd + 2 < nrounds; rd += 2) {
+        advance();
+        const int r8b = r8;
+        load_raw(a1, b1);
+        mfma4(a0, b0);
+        mask_k(r8b, a1, b1);
+        advance();
+        const int r8a = r8;
+        load_raw(a0, b0);
+        mfma4(a1, b1);
+        mask_k(r8a, a0, b0);
+      }
+      if (rd + 1 < nrounds) {     // two rounds left
+        advance();
+        load_raw(a1, b1);
+        mfma4(a0, b0);
+        mask_k(r8, a1, b1);
+        mfma4(a1, b1);
+      } else {
+        mfma4(a0, b0);
+      }
+    }
+    // accumulator r of this lane = row 8 (r / 4) + 4 half + (r % 4), column l31 of the tile
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const bool jzero = (ocj[c] & TG_ZERO_ROW) != 0;
+      const int ocj_e = ocj[c] & ~TG_ZERO_ROW;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int4 o4 = *reinterpret_cast<const int4 *>(&offCi_s[wave][8 * g + kh]);
+        const int oi4[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int oi = oi4[e];
+          if (oi >= 0 && ocj[c] >= 0) {
+            float *p = C + ((oi & ~TG_ZERO_ROW) + ocj_e);
+            float v = ((oi & TG_ZERO_ROW) || jzero) ? 0.f : acc[c][4 * g + e] * alpha;
+            if (accumulate) v += *p;
+            *p = v;
+            if (sumsq) ss = fma((double)v, (double)v, ss);
+          }
+        }
+      }
+    }
+  }
+  if (sumsq) *sumsq += ss;
+}
+
 // ---------------------------------------------------------------------------------------------
 // The same tile loop with FLOAT64 ACCUMULATION on the f64 matrix cores (round 5): f32 operands (global memory or LDS) are
 // converted on the way into v_mfma_f64_16x16x4_f64, the f32 result is rounded once at the store.  For the contractions of the
@@ -901,8 +1065,12 @@ __global__ __launch_bounds__(256, ACC64 ? 4 : 6) void tgemm_direct_kernel(TGemmD
         d.scale_out[b] = 1.f;
         if (d.norm_flag) d.norm_flag[b] = 1;
       } else {
-        d.scale_out[b] = (float)(1.0 / nrm);
-        if (d.norm_log) d.norm_log[b] += log(nrm);
+        // the log-scale takes the scale AS APPLIED (rounded to f32), not log(nrm): the difference, up to 2^-24 per site, is the same
+        // at every repetition of a tensor and adds up coherently over the ~10^3 normalisations of one amplitude (round 5: the fused
+        // form of Y sat 8e-6 off on the tiled state with it)
+        const float sf = (float)(1.0 / nrm);
+        d.scale_out[b] = sf;
+        if (d.norm_log) d.norm_log[b] -= log((double)sf);
       }
     }
   }
@@ -922,7 +1090,8 @@ constexpr int TG_CHAIN_LDS_FLOATS = 6144;    // 24 KB: six blocks per CU (measur
 struct TGemmChainMap { int mapK[3] = {-1, -1, -1}, mapJ[3] = {-1, -1, -1}; };
 
 // F64: both stages accumulate in float64 on the f64 matrix cores (tg_direct_body_f64; the intermediate stays f32 in LDS)
-template <bool AVEC1, bool BVEC1, bool AVEC2, int LDSF, int MINB, bool F64 = false>
+// S2P: stage 2 with two J tiles per wave (tg_direct_body_j2) when it has at least two
+template <bool AVEC1, bool BVEC1, bool AVEC2, int LDSF, int MINB, bool F64 = false, bool S2P = false>
 __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TGemmDesc d2, TGemmChainMap mp, const float *__restrict__ A1g,
                                                             const float *__restrict__ B1g, const float *__restrict__ A2g,
                                                             float *__restrict__ C2g, int *__restrict__ flag, int only_flagged, int allow_chunks) {
@@ -993,7 +1162,8 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TG
     } else {
       tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1, B1g + baseB1, s_mid, I1, J1, K2s1, offCi_s, 0, 4, in_scale);
       __syncthreads();
-      tg_direct_body<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC, I2, J2, K2s2, offCi_s, 0, 4);
+      if (S2P && J2 > 32) tg_direct_body_j2<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC, I2, J2, K2s2, offCi_s, 0, 4);
+      else tg_direct_body<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC, I2, J2, K2s2, offCi_s, 0, 4);
     }
     return;
   }
@@ -1013,7 +1183,10 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TG
     } else {
       tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1 + (long)c0 * sA1, B1g + baseB1, s_mid, d1.Itot(), J1, K2s1, offCi_s, 0, 4, in_scale);
       __syncthreads();
-      tg_direct_body<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC + (long)c0 * sC2, I2, d2.Jtot(), K2s2, offCi_s, 0, 4);
+      if (S2P && d2.Jtot() > 32)
+        tg_direct_body_j2<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC + (long)c0 * sC2, I2, d2.Jtot(), K2s2, offCi_s, 0, 4);
+      else
+        tg_direct_body<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC + (long)c0 * sC2, I2, d2.Jtot(), K2s2, offCi_s, 0, 4);
     }
   }
 }
@@ -1267,10 +1440,17 @@ inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemm
   static const int dense_lds = getenv("PEPSGPU_CHAIN_DENSE_LDS") ? atoi(getenv("PEPSGPU_CHAIN_DENSE_LDS")) : 8192;
   int ldsf = (dense && allow_chunks && dense_lds >= 8192) ? (dense_lds >= 16384 ? 16384 : 8192) : TG_CHAIN_LDS_FLOATS;
   if (f64acc && ldsf > 8192) ldsf = 8192;       // (the float64-accumulating form is built for the two default buffer sizes)
+  // stage 2 with two J tiles per wave (tg_direct_body_j2; low-rank walker batches: the 24 KB / non-dense form), PEPSGPU_CHAIN_S2PAIR=1.
+  // MEASURED AND NOT ADOPTED (round 5, headline, 49 152 walkers, chained launches per three steps): 412 ms as is (six blocks per CU,
+  // 73-79 VGPRs), 497 ms with the paired form at five blocks per CU (96 VGPRs + 100-140 B of scratch), 546 ms at four blocks (no
+  // scratch): halving the chain of dependent operand round trips of a wave does not pay for the waves it costs -- the kernel lives
+  // on the number of blocks in flight, not on the length of one block's chain.  Kept behind the switch for the A/B.
+  static const int s2pair = getenv("PEPSGPU_CHAIN_S2PAIR") ? atoi(getenv("PEPSGPU_CHAIN_S2PAIR")) : 0;
 #define PG_CHAIN(a1, b1, a2)                                                                                                   \
   do {                                                                                                                         \
     if (f64acc && ldsf >= 8192) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 8192, 4, true>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
     else if (f64acc) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 4, true>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
+    else if (s2pair && ldsf == TG_CHAIN_LDS_FLOATS) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 5, false, true>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
     else if (ldsf == 16384) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 16384, 2>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
     else if (ldsf == 8192) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 8192, 4>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
     else hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 6>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \

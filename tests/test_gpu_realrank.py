@@ -75,10 +75,10 @@ def test_real_rank_amplitude_and_energy_vs_oracle(name, L, D, chi, live_min, dt,
 
 def test_real_rank_c4_batch_f32_vs_f64_and_routes():
     """C4 at scale on the tiled state (no oracle sample can afford it): 128 walkers, f32 against the f64 device mode (pinned to
-    the oracle above) on the row route AND on the column route, live carry > 128 rows, no walker flagged.  Tolerance of the f32
-    amplitude at this size: 1e-4 for all but the tail of the batch (see the assertion) -- the 32 kept singular values of a bond of this state span five decades, so f32 rounding
-    (6e-8 of the largest) is 3e-3 of the smallest kept one, and ~10^3 truncations enter one amplitude (median 1.4e-5 measured);
-    the row and the column contraction are DIFFERENT truncations of the same network: they agree to the truncation error
+    the oracle below) on the row route AND on the column route, live carry > 128 rows, no walker flagged.  Round 5: with the
+    backward pair and Y = Tt V^T of the precise sites accumulated in float64 the f32 amplitude sits at max 8e-6 / median 1.8e-6
+    (n = 256, row route); asserted here at max < 2e-5 and median < 5e-6 on both routes (round 3-4 asserted a 3e-4 distribution).
+    The row and the column contraction are DIFFERENT truncations of the same network: they agree to the truncation error
     (chi = 32 against chi = 48 changes psi by ~1e-5 on this state), asserted at 1e-3."""
     from peps_amd import capi
     L, D, chi, _ = synthetic.CONFIGS["C4"]
@@ -104,23 +104,21 @@ def test_real_rank_c4_batch_f32_vs_f64_and_routes():
         ctx.close()
     for a in (row, col):
         rel = np.abs(a[capi.F32] / a[capi.F64] - 1)
-        # distribution over the batch (measured: median 1.4e-5, 1.2e-4 on the worst walker of 128): the median, all but two walkers
-        # inside 1e-4, none beyond 3e-4
-        assert np.median(rel) < 3e-5 and np.sum(rel > 1e-4) <= 2 and np.max(rel) < 3e-4, \
-            (int(np.argmax(rel)), float(np.max(rel)), float(np.median(rel)), int(np.sum(rel > 1e-4)))
+        print("C4 real state f32 vs f64 mode, %s route: max %.2e median %.2e (n = %d)" % ("row" if a is row else "column", rel.max(), np.median(rel), len(rel)))
+        assert np.median(rel) < 5e-6 and np.max(rel) < 2e-5, (int(np.argmax(rel)), float(np.max(rel)), float(np.median(rel)))
     assert np.max(np.abs(col[capi.F64] / row[capi.F64] - 1)) < 1e-3
 
 
 def test_real_rank_c4_amplitudes_vs_oracle():
     """The tiled real state at C4 (12x12, D=8, chi=32) against the ORACLE itself (oracle/cbmps.c, the float64 plain-C restatement
-    of bmps_impl.h:756-862 / :225-263 on LAPACK; one configuration per process), 16 near-Neel configurations: the f64 device mode
+    of bmps_impl.h:756-862 / :225-263 on LAPACK; one configuration per process), 32 near-Neel configurations: the f64 device mode
     to 1e-8, the f32 mode to SURVEY 8(d)'s 1e-5 on EVERY configuration (round 3 asserted a 1e-4 distribution here: the f32
     accumulation of Y = Tt V^T carried a common-mode 1.5e-5; DESIGN 3e has the budget by stage)."""
     from oracle import cbmps
     from peps_amd import capi
     L, D, chi, _ = synthetic.CONFIGS["C4"]
     flat = _state(L)
-    cfgs = synthetic.make_configs_near_neel(L, 16, seed0=307)
+    cfgs = synthetic.make_configs_near_neel(L, 32, seed0=307)
     ref, _, _ = cbmps.amplitudes_multiprocess(flat, cfgs, chi, min(16, os.cpu_count() or 1))
     for dt, tol in ((capi.F64, 1e-8), (capi.F32, 1e-5)):
         ctx = capi.Context(L, L, D, 2, chi, dtype=dt, max_walkers=len(cfgs))

@@ -281,10 +281,10 @@ def test_python_walker_releases_its_device_copy():
         cid = c.wid
         del c
         gc.collect()
-        with pytest.raises(RuntimeError):       # the clone is gone ...
+        with pytest.raises((RuntimeError, ValueError)):       # the clone is gone ("no such walker") ...
             capi.Walker(ctx, cid).GetStackSize()
         assert w.GetStackSize() >= 1            # ... the walker it was copied from is not
-    with pytest.raises(RuntimeError):           # released at the end of the block
+    with pytest.raises((RuntimeError, ValueError)):           # released at the end of the block
         capi.Walker(ctx, wid).GetStackSize()
     for _ in range(3):
         ctx.get_walker(capi.UP).clone()
