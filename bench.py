@@ -914,12 +914,13 @@ def main():
                     if not args.no_energy_check:
                         pend_energy[name] = ((L, chi, 0 if dt == capi.F32 else 1, local_rank, fleg.flat), fleg.batches[0][:max(2, args.energy_n // 2)])
                 if real and world == 1 and not args.no_other_modes and dt == capi.F32:
-                    # the reference's own arithmetic on the realistic state (VERDICT r03 missing 6): the f64 device mode, small batch
+                    # the reference's own arithmetic on the realistic state: the f64 device mode (round 5: dense truncation route of
+                    # the f64 engine -- two-level preconditioning with oversampling, Jacobi problems in LDS), 1 024 walkers
                     try:
-                        n64 = min(128, fnw)
+                        n64 = min(1024, fnw)
                         c64 = capi.Context(L, L, D, 2, chi, dtype=capi.F64, device=local_rank, max_walkers=n64)
                         c64.state_upload(fleg.flat)
-                        c64.set_configs(fleg.batches[0][:8]); c64.evaluate_amplitude(); c64.sync()
+                        c64.set_configs(fleg.batches[0][:64]); c64.evaluate_amplitude(); c64.sync()
                         t0 = time.perf_counter()
                         c64.set_configs(fleg.batches[0][:n64]); a64 = c64.evaluate_amplitude(); c64.sync()
                         t64 = time.perf_counter() - t0

@@ -189,6 +189,23 @@ int pepsgpu_bten2_stack_size(pepsgpu_ctx *ctx, int pos);
  * (left, right) end of the diagonal.  n_cand = 0: no replacement (the plaquette trace), out = [n]. */
 int pepsgpu_replace_nnn_trace(pepsgpu_ctx *ctx, int row, int col, int nnn_dir, int mps_orient, int n_cand,
                               const int32_t *cand_states, double *out_amp);
+/* Environment-reusing diagonal (NNN) hop of a FERMIONIC state (square_spinless_fermion.h:161-213 through
+ * square_nnn_energy_solver.h:203-265).  The reference's graded ReplaceNNNSiteTrace carries the fermionic signs in the tensor
+ * algebra; in the sign-decorated form of this library a diagonal hop also changes the decoration (variant) of every site between
+ * its two ends in the row-major mode order -- row r right of the plaquette, row r + 1 left of it -- so the hopped amplitude is a
+ * local replacement against "twisted" two-row environments.  Three calls provide them:
+ *   pepsgpu_bten2_select_set(ctx, set)        set = 0 / 1: the BTen2 set init / grow / shift / replace_* work on from now on
+ *   pepsgpu_cfg_override_slice(ctx, orient, num, states)   states = [n][N] extended states the kernels read for row (HORIZONTAL) /
+ *                                              column (VERTICAL) `num` instead of the walkers' own until cleared (states = NULL)
+ *   pepsgpu_replace_plaquette_trace(ctx, row, col, n_cand, cand, left_set, right_set, out)   the plaquette with upper-left corner
+ *                                              (row, col) closed with four replaced tensors, cand = [n][n_cand][4] states of
+ *                                              (row, col), (row+1, col), (row+1, col+1), (row, col+1), between the LEFT BTen2 of
+ *                                              `left_set` and the RIGHT BTen2 of `right_set`; n_cand = 0: the walkers' own states.
+ * Any configuration update or set_configs drops the second set and the override. */
+int pepsgpu_bten2_select_set(pepsgpu_ctx *ctx, int set);
+int pepsgpu_cfg_override_slice(pepsgpu_ctx *ctx, int orient, int num, const int32_t *states);
+int pepsgpu_replace_plaquette_trace(pepsgpu_ctx *ctx, int row, int col, int n_cand, const int32_t *cand_states, int left_set,
+                                    int right_set, double *out_amp);
 /* ReplaceTNNSiteTrace(tn, site0, mps_orient, T0, T1, T2)  trace.h:326-423.  (row, col) = first of
  * three consecutive sites along mps_orient; cand_states = [n][n_cand][3]. */
 int pepsgpu_replace_tnn_trace(pepsgpu_ctx *ctx, int row, int col, int mps_orient, int n_cand,

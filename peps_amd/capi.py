@@ -34,6 +34,7 @@ SYMBOLS = [
     "pepsgpu_trace", "pepsgpu_replace_nn_trace", "pepsgpu_replace_one_trace", "pepsgpu_punch_hole",
     "pepsgpu_init_bten2", "pepsgpu_grow_full_bten2", "pepsgpu_grow_bten2_step", "pepsgpu_shift_bten2_window",
     "pepsgpu_bten2_stack_size", "pepsgpu_replace_nnn_trace", "pepsgpu_replace_tnn_trace",
+    "pepsgpu_bten2_select_set", "pepsgpu_cfg_override_slice", "pepsgpu_replace_plaquette_trace",
     "pepsgpu_replace_sqrt5_trace",
     "pepsgpu_grad_reset", "pepsgpu_grad_accumulate", "pepsgpu_grad_accumulate_states", "pepsgpu_grad_read", "pepsgpu_grad_device_ptr", "pepsgpu_grad_allreduce", "pepsgpu_bcast_state",
     "pepsgpu_comm_unique_id", "pepsgpu_comm_init", "pepsgpu_comm_size", "pepsgpu_comm_rank", "pepsgpu_comm_destroy",
@@ -81,6 +82,9 @@ def load_library(path=LIB_PATH):
     lib.pepsgpu_grow_full_bten2.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.pepsgpu_bten2_stack_size.argtypes = [vp, C.c_int]
     lib.pepsgpu_replace_nnn_trace.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp]
+    lib.pepsgpu_bten2_select_set.argtypes = [vp, C.c_int]
+    lib.pepsgpu_cfg_override_slice.argtypes = [vp, C.c_int, C.c_int, ip]
+    lib.pepsgpu_replace_plaquette_trace.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip, C.c_int, C.c_int, dp]
     lib.pepsgpu_replace_tnn_trace.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp]
     lib.pepsgpu_replace_sqrt5_trace.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp]
     lib.pepsgpu_grad_reset.argtypes = [vp]
@@ -308,6 +312,24 @@ class Context:
         cand = np.ascontiguousarray(cand_states, dtype=np.int32)
         assert cand.ndim == 3 and cand.shape[0] == self.n and cand.shape[2] == ncols
         return cand.shape[1], cand, np.zeros((self.n, cand.shape[1]), dtype=self._ot)
+
+    def bten2_select_set(self, which): self._ck(self._l.pepsgpu_bten2_select_set(self._h, int(which)))
+
+    def cfg_override_slice(self, orient, num, states=None):
+        """states [n][N] (extended states of one row / column read instead of the walkers' own), None: clear"""
+        if states is None:
+            self._ck(self._l.pepsgpu_cfg_override_slice(self._h, orient, num, None))
+        else:
+            st = np.ascontiguousarray(states, dtype=np.int32)
+            assert st.ndim == 2 and st.shape[0] == self.n
+            self._ck(self._l.pepsgpu_cfg_override_slice(self._h, orient, num, _ip(st)))
+
+    def replace_plaquette_trace(self, row, col, cand_states=None, left_set=0, right_set=0):
+        """cand_states [n][n_cand][4]: states of (row, col), (row+1, col), (row+1, col+1), (row, col+1); None: the walkers' own"""
+        nc, cand, out = self._cand(cand_states, 4)
+        self._ck(self._l.pepsgpu_replace_plaquette_trace(self._h, row, col, nc, None if cand is None else _ip(cand), left_set, right_set,
+                                                         _dp(out)))
+        return out
 
     def replace_nnn_trace(self, row, col, nnn_dir, orient, cand_states=None):
         nc, cand, out = self._cand(cand_states, 2)

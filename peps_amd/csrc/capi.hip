@@ -214,6 +214,15 @@ int pepsgpu_bten2_stack_size(pepsgpu_ctx *ctx, int pos) {
   if (!ctx || !ctx->eng || pos < 0 || pos > 3) return -1;
   return ctx->eng->bten2_size(pos);
 }
+int pepsgpu_bten2_select_set(pepsgpu_ctx *ctx, int set) { CTX_CALL(ctx->eng->bten2_select_set(set)); }
+int pepsgpu_cfg_override_slice(pepsgpu_ctx *ctx, int orient, int num, const int32_t *states) {
+  CTX_CALL(ctx->eng->cfg_override_slice(orient, num, states));
+}
+int pepsgpu_replace_plaquette_trace(pepsgpu_ctx *ctx, int row, int col, int ncand, const int32_t *cand, int left_set, int right_set,
+                                    double *out) {
+  CTX_CALL(PG_REQUIRE(out && (ncand == 0 || cand), 1, "null argument");
+           ctx->eng->replace_plaquette_trace(row, col, ncand, cand, left_set, right_set, out));
+}
 int pepsgpu_replace_nnn_trace(pepsgpu_ctx *ctx, int row, int col, int nnn_dir, int orient, int ncand, const int32_t *cand,
                               double *out) {
   CTX_CALL(PG_REQUIRE((ncand == 0 || cand) && ncand >= 0 && out, 1, "bad candidate table");

@@ -72,6 +72,9 @@ struct EngineBase {
   virtual void shift_bten2_window(int pos, int slice) = 0;
   virtual int bten2_size(int pos) const = 0;
   virtual void replace_nnn_trace(int row, int col, int diag_dir, int orient, int ncand, const int32_t *cand, double *out) = 0;
+  virtual void bten2_select_set(int set) = 0;
+  virtual void cfg_override_slice(int orient, int num, const int32_t *states) = 0;
+  virtual void replace_plaquette_trace(int row, int col, int ncand, const int32_t *cand, int left_set, int right_set, double *out) = 0;
   virtual void replace_tnn_trace(int row, int col, int orient, int ncand, const int32_t *cand, double *out) = 0;
   virtual void replace_sqrt5_trace(int row, int col, int diag_dir, int orient, int ncand, const int32_t *cand, double *out) = 0;
   virtual void trace(int row, int col, int dir, double *out) = 0;
@@ -263,6 +266,7 @@ class Engine : public EngineBase {
       clear_bten2(p, 0);
       init_bmps(p);
     }
+    clear_bten2_sets();
   }
   void get_configs(int32_t *out) override { std::copy(hcfg_.begin(), hcfg_.end(), out); }
   int n_walkers() const override { return nw_; }
@@ -381,6 +385,9 @@ class Engine : public EngineBase {
   void grow_bten2_step(int pos, int slice) override;
   void shift_bten2_window(int pos, int slice) override;
   void replace_nnn_trace(int row, int col, int diag_dir, int orient, int ncand, const int32_t *cand, double *out) override;
+  void bten2_select_set(int set) override;
+  void cfg_override_slice(int orient, int num, const int32_t *states) override;
+  void replace_plaquette_trace(int row, int col, int ncand, const int32_t *cand, int left_set, int right_set, double *out) override;
   void replace_tnn_trace(int row, int col, int orient, int ncand, const int32_t *cand, double *out) override;
   void replace_sqrt5_trace(int row, int col, int diag_dir, int orient, int ncand, const int32_t *cand, double *out) override;
 
@@ -500,8 +507,8 @@ class Engine : public EngineBase {
     PG_REQUIRE(row >= 0 && col >= 0 && rb < Ly_ && cb < Lx_, 1, "ReplaceNNSiteTrace: bond outside the lattice");
     SiteSel sa = cfg_site(row, col), sb = cfg_site(rb, cb);
     if (dcand) {
-      sa.sel = dcand; sa.inc = 2; sa.base = nullptr;
-      sb.sel = dcand + 1; sb.inc = 2; sb.base = nullptr;
+      sa.sel = dcand; sa.inc = 2; sa.base = nullptr; sa.per_walker = false;
+      sb.sel = dcand + 1; sb.inc = 2; sb.base = nullptr; sb.per_walker = false;
     }
     BTenDev t2, t5;
     double *lsum = zeros_f64();
@@ -543,7 +550,7 @@ class Engine : public EngineBase {
       for (size_t i = 0; i < cnt; ++i) PG_REQUIRE(cand[i] >= 0 && cand[i] < dp_, 4, "candidate state out of range");
       dcand = (int *)arena_.alloc(cnt * sizeof(int));
       PG_CHECK_HIP(hipMemcpyAsync(dcand, cand, cnt * sizeof(int), hipMemcpyHostToDevice, stream_));
-      sa.sel = dcand; sa.inc = 1;
+      sa.sel = dcand; sa.inc = 1; sa.per_walker = false;
     }
     BTenDev t2;
     double *lsum = zeros_f64();
@@ -817,6 +824,10 @@ class Engine : public EngineBase {
     if (bten2_size(UP) > row + 1) clear_bten2(UP, row + 1);
     if (bten2_size(RIGHT) > Lx_ - col) clear_bten2(RIGHT, Lx_ - col);
     if (bten2_size(DOWN) > Ly_ - row) clear_bten2(DOWN, Ly_ - row);
+    for (int p = 0; p < 4; ++p) {     // (the second set is scratch of one row-pair traversal: any update drops it)
+      for (auto &b : bten2_inactive_[p]) { arena_.free(b.t.p); arena_.free(b.logscale); }
+      bten2_inactive_[p].clear();
+    }
   }
 
   // wave_function_component.h:345-378 for the walkers with mask[w] != 0 (all walkers share the
@@ -989,6 +1000,9 @@ class Engine : public EngineBase {
     const int *sel;   // device selector (configuration or candidate table)
     int inc;          // selector stride per batch entry
     const T *base = nullptr;   // tensor store the selector indexes (nullptr: the SITPS slot of site (r, c))
+    // a configuration table is indexed by WALKER (batch entry / candidates), a candidate table by batch entry.  (Until round 5 this
+    // was read off inc == Ly * Lx, which a four-column candidate table on a 2 x 2 lattice also satisfies.)
+    bool per_walker = false;
   };
   // The site tensor of (r, c) under the walkers' configurations -- or, while a BMPSWalker operation runs (MpoScope,
   // engine_walker.h), under the walker's MPO on its slice: another configuration table, or explicit tensors.
@@ -999,9 +1013,11 @@ class Engine : public EngineBase {
         s.base = ovr_tens_ + (long)(ovr_hor_ ? c : r) * ovr_nt_ * slot_;
         return s;
       }
-      if (ovr_cfg_) return SiteSel{r, c, ovr_cfg_ + r * Lx_ + c, Ly_ * Lx_};
+      if (ovr_cfg_) { SiteSel s{r, c, ovr_cfg_ + r * Lx_ + c, Ly_ * Lx_}; s.per_walker = true; return s; }
     }
-    return SiteSel{r, c, cfg_ + r * Lx_ + c, Ly_ * Lx_};
+    SiteSel s{r, c, cfg_ + r * Lx_ + c, Ly_ * Lx_};
+    s.per_walker = true;
+    return s;
   }
   const T *site_base(int r, int c) const { return sitps_ + (long)(r * Lx_ + c) * dp_ * slot_; }
   const T *sel_base(const SiteSel &ss) const { return ss.base ? ss.base : site_base(ss.r, ss.c); }
@@ -1292,7 +1308,7 @@ class Engine : public EngineBase {
   void launch_site_gemm(TGemmDesc &g, const SiteSel &ss, int ncand, const T *A, T *C) {
     g.selB = ss.sel;
     g.selB_mul = slot_;
-    const bool per_walker = (ss.inc == Ly_ * Lx_);
+    const bool per_walker = ss.per_walker;
     if (per_walker) {
       // emulate sel[(b / ncand) * inc] with inc applied to the walker index
       g.selB_inc = ss.inc;
@@ -1311,7 +1327,7 @@ class Engine : public EngineBase {
     g.selA = ss.sel;
     g.selA_mul = slot_;
     g.selA_inc = ss.inc;
-    g.seldivA = (ss.inc == Ly_ * Lx_) ? ncand : 1;
+    g.seldivA = ss.per_walker ? ncand : 1;
     g.wA = 0;
     if (acc64) tgemm_launch<T, T, T, Acc>(stream_, g, sel_base(ss), B, C);     // (experiments: float64 accumulation)
     else tgemm_launch<T, T, T, T>(stream_, g, sel_base(ss), B, C);
@@ -1376,7 +1392,26 @@ class Engine : public EngineBase {
   std::vector<int> hcfg_;
   std::vector<BMPSDev> bmps_[4];
   std::vector<BTenDev> bten_[4];
-  std::vector<BTenDev> bten2_[4];   // two-row (rank-4) environments, bten_set2_ of the reference
+  std::vector<BTenDev> bten2_[4];   // two-row (rank-4) environments, bten_set2_ of the reference (the ACTIVE set)
+  // Second BTen2 set + a persistent one-slice configuration override (round 5): the environment-reusing diagonal hop of a
+  // FERMIONIC state.  In the sign-decorated form a hop across a plaquette diagonal flips the variant of every site between its
+  // two ends in the mode order, i.e. of row r right of the plaquette and of row r + 1 left of it: the hopped amplitude is a local
+  // replacement against "twisted" environments -- the LEFT BTen2 grown with row r + 1 under flipped variants, the RIGHT one with
+  // row r flipped.  bten2_select_set swaps which set the init / grow / shift calls work on; cfg_override_slice makes cfg_site
+  // read one row (column) from another table while they do; replace_plaquette_trace closes a plaquette with four replaced
+  // tensors between a LEFT environment of one set and a RIGHT environment of the other.
+  std::vector<BTenDev> bten2_inactive_[4];
+  int bten2_active_ = 0;
+  int *cfg_ovr_tab_ = nullptr;       // [walker][Ly * Lx]: the walkers' table with one slice replaced (cfg_override_slice)
+  void clear_bten2_sets() {           // every invalidation of the environments drops both sets and the override
+    for (int p = 0; p < 4; ++p) {
+      clear_bten2(p, 0);
+      for (auto &b : bten2_inactive_[p]) { arena_.free(b.t.p); arena_.free(b.logscale); }
+      bten2_inactive_[p].clear();
+    }
+    if (bten2_active_) bten2_active_ = 0;
+    if (cfg_ovr_tab_) { arena_.free(cfg_ovr_tab_); cfg_ovr_tab_ = nullptr; ovr_on_ = false; ovr_cfg_ = nullptr; }
+  }
   struct ProfRec { hipEvent_t a, b; int cat; double alg, exec; bool a_shared; };
   mutable bool prof_chain_ok_ = false;   // the last profiling call was a prof_end of this API call: its event can open the next bracket
   std::vector<ProfRec> prof_;

@@ -114,6 +114,16 @@ bool Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
       skip_le = JR_BR;
     }
   }
+  // the static block does not fit LDS: 64 KB of dynamic LDS (two blocks per CU as before) for the walkers whose live rows do
+  static const bool no_dyn_lds = getenv("PEPSGPU_NO_JACOBI_DYN_LDS") != nullptr;
+  if (!use_lds && mdyn && !no_dyn_lds) {
+    constexpr int CAP = 64 * 1024;
+    allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), (size_t)CAP);
+    hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), CAP, stream_, M, wM, m, len, len, 40, 2, sweeps_, mdyn, mdyn_mul,
+                       small, skip_le, CAP);
+    PG_CHECK_HIP(hipGetLastError());
+    return sel_used;
+  }
   hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), use_lds ? need : 0, stream_, M, wM, m, len, len, 40,
                      use_lds, sweeps_, mdyn, mdyn_mul, small, skip_le);
   PG_CHECK_HIP(hipGetLastError());
@@ -708,6 +718,154 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     PG_REQUIRE(m <= 1024, 1, "bond dimension too large for select_rows_kernel");
     DTen<T> V = alloc_ten(k, u, k2);
     if (bond_adapt) kn[i] = (int *)arena_.alloc(sizeof(int) * nw_);
+    // ---- float64 engine, dense site: two-level preconditioned truncation with oversampling (round 5) ----------------------------
+    // The f64 mode on a dense state spent 98 % of its time in the general one-sided Jacobi on the 256 x 256 block M (25 amp/s at C4:
+    // with the rows in global memory a sweep is 255 passes over the matrix).  The Gram-preconditioned route of the f32 engine cannot
+    // be taken over as it is: the Cholesky of M M^T in float64 perturbs the boundary between the kept direction chi and the discarded
+    // direction chi + 1 by ~3e-14 s_1^2 / (s_chi^2 - s_chi+1^2), i.e. ~5e-9 per truncation at s_chi / s_1 = 2e-5 -- too much for the
+    // 1e-8 parity of this mode.  With OVERSAMPLING it can: the two Gram + Cholesky compressions (B^T B = M M^T, B2^T B2 = B B^T) and
+    // the Jacobi on the small factor B2 only have to deliver a subspace U of kq = 2 chi dimensions that CONTAINS the top-chi left
+    // singular subspace -- the mixing that matters is then between direction chi and direction 2 chi + 1, smaller by
+    // s_2chi+1 / s_chi+1 and with a gap of s_chi^2 (~1e-10 per truncation on the real state) -- and the exact top-chi singular
+    // vectors inside it come from an accurate float64 Jacobi on Z = U^T M, kq x uk (Rayleigh-Ritz on M itself).  Both Jacobi problems
+    // (<= 128 x 128 and 64 x 256 doubles) live in LDS.  Walkers whose factors keep fewer than kq (or more than 128) rows take the
+    // general kernels as before (rflag = 0); trunc_err > 0 keeps the general path (the truncation rule wants every singular value).
+    int *rflag = nullptr, *fbrows = nullptr;
+    if constexpr (std::is_same<T, double>::value) {
+      static const bool no_route = getenv("PEPSGPU_NO_F64_DENSE_ROUTE") != nullptr;
+      // oversampled subspace: 2 chi directions, at most three quarters of the rank M can have (the right-edge sites are 256 x 64)
+      const int kq = std::min(2 * k_full, (3 * std::min(m, uk)) / 4);
+      if (!no_route && adaptive && trunc_err_ == 0.0 && m > 128 && m <= 256 && uk <= 256 && kq <= 64 && kq >= k_full + 8 && i > 0) {
+        const int GSd = m;
+        rflag = (int *)arena_.alloc(sizeof(int) * nw_);
+        fbrows = (int *)arena_.alloc(sizeof(int) * nw_);
+        int *rowsM = (int *)arena_.alloc(sizeof(int) * nw_), *mB1 = (int *)arena_.alloc(sizeof(int) * nw_);
+        int *mB2 = (int *)arena_.alloc(sizeof(int) * nw_), *kW = (int *)arena_.alloc(sizeof(int) * nw_);
+        PG_CHECK_HIP(hipMemsetAsync(mB1, 0, sizeof(int) * nw_, stream_));
+        PG_CHECK_HIP(hipMemsetAsync(mB2, 0, sizeof(int) * nw_, stream_));
+        PG_CHECK_HIP(hipMemsetAsync(kW, 0, sizeof(int) * nw_, stream_));
+        const int gb = (nw_ + 255) / 256;
+        hipLaunchKernelGGL(f64_route_init_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)mdyn[i], mmul[i], m, nw_, rowsM, rflag);
+        PG_CHECK_HIP(hipGetLastError());
+        prof_begin(PROF_TRUNC_GRAM, 0.0, 0.0);
+        double *Gm = (double *)arena_.alloc(sizeof(double) * (size_t)GSd * GSd * nw_);
+        DTen<T> B1 = alloc_ten(GSd, GSd, 1);
+        {   // G = M M^T over the live rows, upper triangle
+          TGemmDesc g;
+          g.I[2] = m; g.sAi[2] = uk; g.sCi[2] = GSd;
+          g.K[2] = uk; g.sAk[2] = 1; g.sBk[2] = 1;
+          g.J[2] = m; g.sBj[2] = uk; g.sCj[2] = 1;
+          g.wA = M.n; g.wB = M.n; g.wC = (long)GSd * GSd; g.nbatch = nw_;
+          g.dI[2].p = rowsM; g.dJ[2].p = rowsM;
+          g.upper_only = 1;
+          tgemm_launch<T, T, double, double>(stream_, g, M.p, M.p, Gm);
+        }
+        launch_chol_upper<T>(stream_, nw_, Gm, (long)GSd * GSd, GSd, B1.p, B1.n, mB1, 0, GSd, (const int *)rowsM, 1, (const int *)nullptr);
+        arena_.free(Gm);
+        // walkers whose first factor kept more than 128 or fewer than kq rows leave the route
+        hipLaunchKernelGGL(f64_route_check_kernel, dim3(gb), dim3(256), 0, stream_, rflag, mB1, kq, 128, nw_);
+        PG_CHECK_HIP(hipGetLastError());
+        double *G2 = (double *)arena_.alloc(sizeof(double) * (size_t)128 * 128 * nw_);
+        DTen<T> B2 = alloc_ten(128, 128, 1);
+        {   // G2 = B B^T (r x r, r = mB1 <= 128), the rows of B are GSd long (zero beyond the live rows of M)
+          TGemmDesc g;
+          g.I[2] = 128; g.sAi[2] = GSd; g.sCi[2] = 128;
+          g.K[2] = GSd; g.sAk[2] = 1; g.sBk[2] = 1;
+          g.J[2] = 128; g.sBj[2] = GSd; g.sCj[2] = 1;
+          g.wA = B1.n; g.wB = B1.n; g.wC = 128L * 128; g.nbatch = nw_;
+          g.dI[2].p = mB1; g.dJ[2].p = mB1;
+          g.dK[2].p = rowsM;
+          g.upper_only = 1;
+          g.batch_flag = rflag;
+          tgemm_launch<T, T, double, double>(stream_, g, B1.p, B1.p, G2);
+        }
+        launch_chol_upper<T>(stream_, nw_, G2, 128L * 128, 128, B2.p, B2.n, mB2, 0, 128, (const int *)mB1, 1, (const int *)rflag);
+        arena_.free(G2);
+        hipLaunchKernelGGL(f64_route_check_kernel, dim3(gb), dim3(256), 0, stream_, rflag, mB2, kq, 128, nw_);
+        PG_CHECK_HIP(hipGetLastError());
+        prof_end();
+        // rotated rows of B2 = sigma_q w_q^T (LDS-resident Jacobi: 128 x 129 doubles)
+        prof_begin(PROF_JACOBI, 0.0, 0.0);
+        {
+          const size_t need2 = sizeof(T) * (size_t)128 * 129;
+          allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), need2);
+          hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), need2, stream_, B2.p, B2.n, 128, 128, 128, 40, 1, sweeps_,
+                             (const int *)mB2, 1, 0, 0);
+          PG_CHECK_HIP(hipGetLastError());
+        }
+        prof_end();
+        DTen<T> Wt = alloc_ten(kq, 128, 1), T1 = alloc_ten(kq, GSd, 1), Uq = alloc_ten(kq, GSd, 1), Zt = alloc_ten(kq, uk, 1);
+        prof_begin(PROF_SELECT, 0.0, 0.0);
+        hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)B2.p, B2.n, 128, 128, 128, kq, Wt.p, Wt.n,
+                           (T *)nullptr, 0L, (const int *)mB2, 1, kW, 0.0, 0, (double *)nullptr, (const int *)rflag, 1);
+        PG_CHECK_HIP(hipGetLastError());
+        prof_end();
+        prof_begin(PROF_TRUNC_APPLY, 0.0, 0.0);
+        {   // sigma_q u_q^T = w_q^T B
+          TGemmDesc g;
+          g.I[2] = kq; g.sAi[2] = 128; g.sCi[2] = GSd;
+          g.K[2] = 128; g.sAk[2] = 1; g.sBk[2] = GSd;
+          g.J[2] = GSd; g.sBj[2] = 1; g.sCj[2] = 1;
+          g.wA = Wt.n; g.wB = B1.n; g.wC = T1.n; g.nbatch = nw_;
+          g.dK[2].p = mB1;
+          g.batch_flag = rflag;
+          tgemm_launch<T, T, T, double>(stream_, g, Wt.p, B1.p, T1.p);
+        }
+        prof_end();
+        prof_begin(PROF_SELECT, 0.0, 0.0);
+        hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)T1.p, T1.n, kq, GSd, GSd, kq, Uq.p, Uq.n,
+                           (T *)nullptr, 0L, (const int *)kW, 1, (int *)nullptr, 0.0, 0, (double *)nullptr, (const int *)rflag, 1);
+        PG_CHECK_HIP(hipGetLastError());
+        prof_end();
+        prof_begin(PROF_TRUNC_APPLY, 0.0, 0.0);
+        {   // Z = U^T M (kq x uk): its rows span the oversampled subspace exactly (float64 product with M itself)
+          TGemmDesc g;
+          g.I[2] = kq; g.sAi[2] = GSd; g.sCi[2] = uk;
+          g.K[2] = m; g.sAk[2] = 1; g.sBk[2] = uk;
+          g.J[2] = uk; g.sBj[2] = 1; g.sCj[2] = 1;
+          g.wA = Uq.n; g.wB = M.n; g.wC = Zt.n; g.nbatch = nw_;
+          g.dK[2].p = rowsM;
+          g.batch_flag = rflag;
+          tgemm_launch<T, T, T, double>(stream_, g, Uq.p, M.p, Zt.p);
+        }
+        prof_end();
+        prof_begin(PROF_JACOBI, 0.0, 0.0);
+        {   // the accurate SVD inside the subspace: one-sided Jacobi on the kq rows of Z, LDS resident (64 x 257 doubles)
+          const size_t needz = sizeof(T) * (size_t)kq * (uk | 1);
+          allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), needz);
+          hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), needz, stream_, Zt.p, Zt.n, kq, uk, uk, 40, 1, sweeps_,
+                             (const int *)kW, 1, 0, 0);
+          PG_CHECK_HIP(hipGetLastError());
+        }
+        prof_end();
+        prof_begin(PROF_SELECT, 0.0, 0.0);
+        hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)Zt.p, Zt.n, kq, uk, uk, k, V.p, V.n,
+                           (T *)nullptr, 0L, (const int *)kW, 1, kn[i], 0.0, chi_min_, (double *)nullptr, (const int *)rflag, 1);
+        PG_CHECK_HIP(hipGetLastError());
+        prof_end();
+        // guard (f64_route_guard_kernel): a spectrum that falls to the resolution of a Gram inside the subspace leaves the route
+        static const double guard_tol = getenv("PEPSGPU_F64_ROUTE_TOL") ? atof(getenv("PEPSGPU_F64_ROUTE_TOL")) : 1e-10;
+        hipLaunchKernelGGL(f64_route_guard_kernel, dim3(nw_), dim3(256), 0, stream_, (const double *)Zt.p, Zt.n, uk, (const int *)kW, k_full,
+                           guard_tol, rflag);
+        PG_CHECK_HIP(hipGetLastError());
+        if (dbg_sweeps_ && getenv("PEPSGPU_DEBUG_VERBOSE")) {   // diagnostics: who stays on the route, rows kept by the two compressions
+          std::vector<int> hf(nw_), h0(nw_), hk(nw_);
+          PG_CHECK_HIP(hipMemcpyAsync(hf.data(), rflag, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+          PG_CHECK_HIP(hipMemcpyAsync(h0.data(), rowsM, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+          PG_CHECK_HIP(hipMemcpyAsync(hk.data(), kW, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+          PG_CHECK_HIP(hipStreamSynchronize(stream_));
+          long on = 0, s0 = 0, sk = 0, x0 = 0;
+          for (int w = 0; w < nw_; ++w) { on += hf[w] < 0; s0 += h0[w]; sk += hk[w]; x0 = std::max<long>(x0, h0[w]); }
+          fprintf(stderr, "[pepsgpu] f64 dense route site %d (m = %d, uk = %d, kq = %d): %ld of %d walkers on the route, live rows of M mean %.1f max %ld, kept directions mean %.1f\n",
+                  i, m, uk, kq, on, nw_, (double)s0 / nw_, x0, on ? (double)sk / on : 0.0);
+        }
+        // the others: the general kernels below on their live rows (the route's walkers count zero rows there)
+        hipLaunchKernelGGL(f64_route_fallback_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)rflag, (const int *)rowsM, nw_, fbrows);
+        PG_CHECK_HIP(hipGetLastError());
+        free_ten(B1); free_ten(B2); free_ten(Wt); free_ten(T1); free_ten(Uq); free_ten(Zt);
+        arena_.free(rowsM); arena_.free(mB1); arena_.free(mB2); arena_.free(kW);
+      }
+    }
     bool sel_done = false;
     {
       const size_t need = sizeof(T) * (size_t)m * (uk | 1);
@@ -738,7 +896,8 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         }
       }
       assume_rows[i] = rows_cap;
-      sel_done = launch_jacobi(M.p, M.n, m, uk, use_lds, need, mdyn[i], mmul[i], mid ? MID_HI : 0, jsel.V ? &jsel : nullptr, rows_cap);
+      sel_done = launch_jacobi(M.p, M.n, m, uk, use_lds, need, rflag ? fbrows : mdyn[i], rflag ? 1 : mmul[i], mid ? MID_HI : 0,
+                               jsel.V ? &jsel : nullptr, rows_cap);
       if constexpr (sizeof(T) == 4) {
         if (mid) {
           // <= 64 live rows: two waves per walker, else four; rows of 16 lanes, four pairs per wave instruction
@@ -805,8 +964,9 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     if (!skip_select)
       hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)M.p, M.n, m, uk, uk, k, V.p,
                          V.n, (T *)nullptr, 0L, (const int *)mdyn[i], mmul[i], kn[i], trunc_err_, chi_min_, (double *)nullptr,
-                         (const int *)midflag, 0, sel_done ? JR_BR : 0);
+                         (const int *)(rflag ? rflag : midflag), 0, sel_done ? JR_BR : 0);
     PG_CHECK_HIP(hipGetLastError());
+    if (rflag) { arena_.free(rflag); arena_.free(fbrows); rflag = nullptr; fbrows = nullptr; }
     if (mid) {
       // sigma_k u_k^T = the rotated rows of B: the chi largest, normalised -> U^T (k x GS), kB = how many are live
       if (side_pending) { PG_CHECK_HIP(hipStreamWaitEvent(stream_, ev_join_, 0)); side_pending = false; }

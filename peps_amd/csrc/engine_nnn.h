@@ -239,6 +239,75 @@ void Engine<T>::replace_nnn_trace(int row1, int col1, int dir, int orient, int n
   if (dc) arena_.free(dc);
 }
 
+// ---- fermionic diagonal hop against twisted environments (round 5; see the declaration of bten2_inactive_ in engine.h) ----
+template <typename T>
+void Engine<T>::bten2_select_set(int set) {
+  PG_REQUIRE(set == 0 || set == 1, 1, "BTen2 set must be 0 or 1");
+  if (set == bten2_active_) return;
+  for (int p = 0; p < 4; ++p) std::swap(bten2_[p], bten2_inactive_[p]);
+  bten2_active_ = set;
+}
+
+// states = [walker][N] extended states of row (HORIZONTAL) / column (VERTICAL) `num`; nullptr clears the override.  While it is
+// set, every kernel that selects a site tensor of that slice by configuration reads this table (the walkers' own table elsewhere).
+template <typename T>
+void Engine<T>::cfg_override_slice(int orient, int num, const int32_t *states) {
+  require_ready();
+  if (!states) {
+    if (cfg_ovr_tab_) { arena_.free(cfg_ovr_tab_); cfg_ovr_tab_ = nullptr; }
+    ovr_on_ = false; ovr_cfg_ = nullptr;
+    return;
+  }
+  PG_REQUIRE(orient == HORIZONTAL || orient == VERTICAL, 1, "bad orientation");
+  const bool hor = orient == HORIZONTAL;
+  const int N = hor ? Lx_ : Ly_, lim = hor ? Ly_ : Lx_;
+  PG_REQUIRE(num >= 0 && num < lim, 1, "configuration override: slice outside the lattice");
+  PG_REQUIRE(!ovr_on_ || cfg_ovr_tab_, 3, "configuration override: a BMPSWalker operation is in progress");
+  std::vector<int> tab(hcfg_);
+  for (int w = 0; w < nw_; ++w)
+    for (int j = 0; j < N; ++j) {
+      const int st = states[(size_t)w * N + j];
+      PG_REQUIRE(st >= 0 && st < dp_, 4, "configuration override: state exceeds the physical dimension");
+      tab[(size_t)w * Ly_ * Lx_ + (hor ? num * Lx_ + j : j * Lx_ + num)] = st;
+    }
+  if (!cfg_ovr_tab_) cfg_ovr_tab_ = (int *)arena_.alloc(sizeof(int) * tab.size());
+  PG_CHECK_HIP(hipMemcpyAsync(cfg_ovr_tab_, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, stream_));
+  PG_CHECK_HIP(hipStreamSynchronize(stream_));
+  ovr_hor_ = hor; ovr_num_ = num; ovr_cfg_ = cfg_ovr_tab_; ovr_tens_ = nullptr; ovr_nt_ = 0; ovr_on_ = true;
+}
+
+// The plaquette (row1, col1) .. (row1 + 1, col1 + 1) closed with FOUR replaced tensors between the LEFT BTen2 of set `left_set` and
+// the RIGHT BTen2 of set `right_set` (row BMPS: HORIZONTAL form of ReplaceNNNSiteTrace, trace.h:207-324).
+// cand[w][k][4] = states of (row1, col1), (row2, col1), (row2, col2), (row1, col2); ncand = 0: the walkers' own states.
+template <typename T>
+void Engine<T>::replace_plaquette_trace(int row1, int col1, int ncand, const int32_t *cand, int left_set, int right_set, double *out) {
+  require_ready();
+  ArenaScope scope(arena_);
+  const int row2 = row1 + 1, col2 = col1 + 1;
+  PG_REQUIRE(row1 >= 0 && col1 >= 0 && row2 < Ly_ && col2 < Lx_, 1, "plaquette outside the lattice");
+  PG_REQUIRE((left_set == 0 || left_set == 1) && (right_set == 0 || right_set == 1), 1, "BTen2 set must be 0 or 1");
+  const int nc = ncand > 0 ? ncand : 1;
+  int *dc = upload_cand(ncand, 4, cand);
+  auto col_of = [&](int k) { return ncand > 0 ? k : -1; };
+  double *lsum = zeros_f64();
+  const std::vector<BTenDev> &ls = (left_set == bten2_active_ ? bten2_ : bten2_inactive_)[LEFT];
+  const std::vector<BTenDev> &rs = (right_set == bten2_active_ ? bten2_ : bten2_inactive_)[RIGHT];
+  const int kr = Lx_ - 1 - col2;
+  PG_REQUIRE((int)ls.size() > col1, 3, "plaquette trace: LEFT BTen2 of that set missing");
+  PG_REQUIRE(kr >= 0 && kr < (int)rs.size(), 3, "plaquette trace: RIGHT BTen2 of that set missing");
+  const BMPSDev &up = bmps_at_slice(UP, row1), &dn = bmps_at_slice(DOWN, row2);
+  const BTenDev &lb = ls[col1], &rb = rs[kr];
+  const SitePick t0{row1, col1, col_of(0)}, t1{row2, col1, col_of(1)}, t2{row2, col2, col_of(2)}, t3{row1, col2, col_of(3)};
+  // (the candidate table overrides the configuration override: a replaced site never reads either configuration table)
+  BTenDev a = bten2_step(LEFT, lb, at_logical(up, UP, col1), pick(t0, dc, 4), pick(t1, dc, 4), at_logical(dn, DOWN, col1), nc, 1, false);
+  BTenDev b = bten2_step(RIGHT, rb, at_logical(dn, DOWN, col2), pick(t2, dc, 4), pick(t3, dc, 4), at_logical(up, UP, col2), nc, 1, false);
+  add_logs(lsum, up.logscale, dn.logscale, lb.logscale, rb.logscale);
+  finish_dot4(a.t, b.t, nc, lsum, out);
+  free_ten(a.t); free_ten(b.t);
+  arena_.free(lsum);
+  if (dc) arena_.free(dc);
+}
+
 // ReplaceTNNSiteTrace (trace.h:326-423).  cand[w][k][3] = states of the three consecutive sites.
 template <typename T>
 void Engine<T>::replace_tnn_trace(int row, int col, int orient, int ncand, const int32_t *cand, double *out) {

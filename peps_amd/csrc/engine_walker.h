@@ -198,6 +198,7 @@ struct Engine<T>::MpoScope {
   Engine<T> &e;
   MpoScope(Engine<T> &eng, const WalkerDev &w) : e(eng) {
     PG_REQUIRE(w.mpo_num >= 0, 3, "BMPSWalker: no MPO set (pepsgpu_walker_set_mpo)");
+    PG_REQUIRE(!e.cfg_ovr_tab_, 3, "BMPSWalker: a configuration override is set (pepsgpu_cfg_override_slice): clear it first");
     e.ovr_hor_ = (w.pos == UP || w.pos == DOWN);
     e.ovr_num_ = w.mpo_num;
     e.ovr_cfg_ = w.mpo_cfg;

@@ -1350,12 +1350,16 @@ __global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, l
                                                            int ld, int max_sweeps, int use_lds,
                                                            int *__restrict__ sweeps_out,
                                                            const int *__restrict__ mdyn, int mdyn_mul,
-                                                           int skip_small = 0, int skip_le = 0) {
+                                                           int skip_small = 0, int skip_le = 0, int lds_cap_bytes = 0) {
   extern __shared__ unsigned char jc_smem_raw[];
   T *sM = reinterpret_cast<T *>(jc_smem_raw);
   if (mdyn) m = max(0, min(m, mdyn[blockIdx.x] * mdyn_mul));
   if (skip_small && m <= max(skip_small, 32)) return;   // the one-wave kernels (jacobi_reg.h) / the mid route took this walker
   if (skip_le && m <= skip_le) return;                  // (f64: the short-row kernel took it)
+  // use_lds == 2 (round 5): the static block does not fit LDS, but the launch carries lds_cap_bytes of dynamic LDS and a walker
+  // whose LIVE rows fit takes them -- a sweep over rows in global memory is m - 1 passes over the matrix through L2 / HBM
+  // (C5 f64: 88 % of the step on blocks of a few tens of live rows of 144 doubles)
+  if (use_lds == 2) use_lds = ((size_t)m * (size_t)(len | 1) * sizeof(T) <= (size_t)lds_cap_bytes) ? 1 : 0;
   __shared__ int s_rot;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   T *Mglob = Mg + (long)blockIdx.x * wM;
@@ -1412,67 +1416,12 @@ __global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, l
     __syncthreads();
     const int nl = s_nl;
     const int lp = nl + (nl & 1);
-    // Rows in global memory (the f64 bulk: 256 x 256 doubles do not fit LDS), at most 256 long: a wave takes FOUR pairs of the
-    // round at a time -- their eight rows are requested together (one L2 round trip instead of four, each row read once instead
-    // of twice) and rotated from registers.  Round 5: the f64 mode on a dense state spent 98 % of its time here, one dependent
-    // load -> reduce -> rotate -> store chain per pair (25 amp/s at C4 whatever the batch).
-    const bool batched = !use_lds && len <= 256;
+    // (round 5, measured and removed: a wave taking four pairs of a round at a time -- eight rows requested together, rotated from
+    // registers -- moved the f64 mode on the dense real state 25.2 -> 28.6 amp/s and C5 f64 2 268 -> 1 897: with the rows in global
+    // memory the kernel is bound by the TRAFFIC of a sweep, m - 1 passes over the whole matrix (261 MB per sweep of a 256 x 256
+    // float64 block, 512 blocks in flight = 256 MB of working set), not by the latency of a pair.  The dense f64 sites take the
+    // two-level preconditioned route of engine_impl.h instead, whose Jacobi problems fit LDS.)
     for (int r = 0; r < lp - 1; ++r) {
-      if (batched) {
-        constexpr int PB = 4;
-        for (int p0 = wave; p0 < lp / 2; p0 += nw * PB) {
-          T *pa[PB], *pb[PB];
-          bool ok[PB];
-          T x[PB][4], y[PB][4];
-#pragma unroll
-          for (int q = 0; q < PB; ++q) {
-            const int p = p0 + q * nw;
-            int a = 0, b = 0;
-            ok[q] = p < lp / 2;
-            if (ok[q]) {
-              if (p == 0) { a = lp - 1; b = r; }
-              else { a = (r + p) % (lp - 1); b = (r - p + (lp - 1)) % (lp - 1); }
-              if (a > b) { int t = a; a = b; b = t; }
-              ok[q] = b < nl;
-            }
-            a = ok[q] ? s_idx[a] : 0; b = ok[q] ? s_idx[b] : 0;
-            pa[q] = M + (long)a * lds_ld; pb[q] = M + (long)b * lds_ld;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int c = lane + 64 * e;
-              x[q][e] = (ok[q] && c < len) ? pa[q][c] : T(0);
-              y[q][e] = (ok[q] && c < len) ? pb[q][c] : T(0);
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < PB; ++q) {
-            if (!ok[q]) continue;                       // (wave-uniform)
-            T alpha = 0, beta = 0, gamma = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { alpha += x[q][e] * x[q][e]; beta += y[q][e] * y[q][e]; gamma += x[q][e] * y[q][e]; }
-            alpha = wave_sum(alpha); beta = wave_sum(beta); gamma = wave_sum(gamma);
-            const T ab = sqrt(alpha) * sqrt(beta);
-            if (fabs(gamma) > tol * ab && alpha > floor2 && beta > floor2) {
-              const double zeta = ((double)beta - (double)alpha) / (2.0 * (double)gamma);
-              const double td = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-              const double cd = 1.0 / sqrt(1.0 + td * td);
-              const T cs = T(cd), sn = T(cd * td);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int c = lane + 64 * e;
-                if (c < len) {
-                  pa[q][c] = cs * x[q][e] - sn * y[q][e];
-                  pb[q][c] = sn * x[q][e] + cs * y[q][e];
-                }
-              }
-              if (lane == 0) atomicAdd(&s_rot, 1);
-            }
-          }
-        }
-        __threadfence_block();
-        __syncthreads();
-        continue;
-      }
       for (int p = wave; p < lp / 2; p += nw) {
         int a, b;
         if (p == 0) { a = lp - 1; b = r; }
@@ -1640,6 +1589,63 @@ __global__ void mid_route_flag_kernel(const int *__restrict__ mdyn, int mdyn_mul
   const bool mid = ml > lo && ml <= hi;
   flag[b] = mid ? -1 : 0;
   nmid[b] = mid ? ml : 0;
+}
+
+// Bookkeeping of the dense float64 truncation route (Engine::absorb_impl, round 5): flag[b] = -1 on the route, 0 off it
+__global__ void f64_route_init_kernel(const int *__restrict__ mdyn, int mdyn_mul, int m, int nbatch, int *__restrict__ rows,
+                                      int *__restrict__ flag) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbatch) return;
+  rows[b] = mdyn ? max(0, min(m, mdyn[b] * mdyn_mul)) : m;
+  flag[b] = -1;
+}
+// a walker whose factor kept fewer than lo or more than hi rows leaves the route; the row count of every walker off the route reads 0
+__global__ void f64_route_check_kernel(int *__restrict__ flag, int *__restrict__ rows, int lo, int hi, int nbatch) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbatch) return;
+  if (flag[b] < 0 && (rows[b] < lo || rows[b] > hi)) flag[b] = 0;
+  if (flag[b] >= 0) rows[b] = 0;
+}
+// Guard of the route: from the norms of the rotated rows of Z (the singular values inside the oversampled subspace, kz live rows)
+// the mixing the two Gram compressions can have left between the kept direction k and what lies beyond the subspace is bounded by
+//     eps_chol (s_1 / s_k)^2 (s_last / s_1),   s_last = the weakest direction of the subspace (>= the strongest one outside),
+// eps_chol ~ 3e-15 (sqrt(n) eps of the float64 Cholesky of an order-256 Gram).  A walker whose bound exceeds `tol` -- a spectrum
+// that falls to the resolution of a Gram (2.4e-7 s_1) within the subspace -- leaves the route; the general Jacobi redoes it.
+__global__ __launch_bounds__(256) void f64_route_guard_kernel(const double *__restrict__ Zg, long wZ, int len, const int *__restrict__ kz,
+                                                              int k, double tol, int *__restrict__ flag) {
+  const int b = blockIdx.x;
+  if (flag[b] >= 0) return;
+  __shared__ double s_n[64];
+  const int rows = min(kz[b], 64), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double *Z = Zg + (long)b * wZ;
+  for (int r = wave; r < rows; r += 4) {
+    double a = 0.0;
+    for (int c = lane; c < len; c += 64) { const double x = Z[(long)r * len + c]; a += x * x; }
+    a = wave_sum(a);
+    if (lane == 0) s_n[r] = a;           // squared norms
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s1 = 0.0, slast = 1e300;
+    for (int r = 0; r < rows; ++r) { s1 = fmax(s1, s_n[r]); slast = fmin(slast, s_n[r]); }
+    // k-th largest squared norm (rows <= 64: selection by counting)
+    double sk = 0.0;
+    const int kk = min(k, rows);
+    for (int r = 0; r < rows; ++r) {
+      int larger = 0;
+      for (int q = 0; q < rows; ++q) larger += (s_n[q] > s_n[r]) || (s_n[q] == s_n[r] && q < r);
+      if (larger == kk - 1) sk = s_n[r];
+    }
+    const bool ok = rows > 0 && s1 > 0.0 && sk > 0.0 && 3e-15 * (s1 / sk) * sqrt(slast / s1) <= tol;
+    if (!ok) flag[b] = 0;
+  }
+}
+
+// live rows of M for the walkers off the route (the general kernels take them), 0 for the walkers on it
+__global__ void f64_route_fallback_kernel(const int *__restrict__ flag, const int *__restrict__ rows_m, int nbatch, int *__restrict__ fb) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbatch) return;
+  fb[b] = flag[b] < 0 ? 0 : rows_m[b];
 }
 
 // Two-level form of the route: of the walkers with more than 128 live rows of M (hiflag) those whose factor B kept at most

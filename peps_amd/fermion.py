@@ -204,18 +204,94 @@ def tj_energy(ctx, state, configs, t, J, V=0.0, mu=0.0):
     return e - mu * np.sum(np.asarray(configs) != 2, axis=(1, 2)), psis
 
 
-def spinless_fermion_energy(ctx, state, configs, t, V=0.0, t2=0.0, bonds=None):
+def spinless_fermion_energy(ctx, state, configs, t, V=0.0, t2=0.0, bonds=None, nnn="local"):
     """E_loc(S) of H = -t sum_<ij> (c+_i c_j + h.c.) - t2 sum_<<ij>> (c+_i c_j + h.c.) + V sum_<ij> n_i n_j
     (square_spinless_fermion.h:134-200).  Returns (energy [n], psi_list [rows + cols][n]).  The NN hops are local
-    replacements inside the row / column pass; the diagonal hop is not local in the decorated form and is taken from a
-    fresh amplitude of the hopped configuration (nnn_hop_energy)."""
+    replacements inside the row / column pass.  The diagonal hop (t2): nnn = "local" (round 5) reuses the environments of the
+    row pass -- a plaquette replacement against parity-twisted BTen2 environments (nnn_hop_energy_local); nnn = "fresh" takes
+    every hopped amplitude from a fresh contraction (nnn_hop_energy, rounds 2-4; kept as the independent check)."""
     nf = state.nf
     def bond(c1, c2):
         return V * (nf[c1] % 2) * (nf[c2] % 2), np.where(c1 != c2, -t, 0.0)
     e, psis = nn_energy(ctx, state, configs, bond, bonds)
     if t2 != 0.0:
-        e = e + nnn_hop_energy(ctx, state, configs, t2, bonds)
+        e = e + (nnn_hop_energy_local if nnn == "local" else nnn_hop_energy)(ctx, state, configs, t2, bonds)
     return e, psis
+
+
+def nnn_hop_energy_local(ctx, state, configs, t2, bonds=None):
+    """The diagonal hops of all plaquettes with the environments of ONE row pass (the reference's flow,
+    square_nnn_energy_solver.h:203-265: BTen2 environments of the row pair, ReplaceNNNSiteTrace per diagonal).
+
+    The reference's graded ReplaceNNNSiteTrace carries the signs in the tensor algebra.  In the sign-decorated form a hop between
+    a = (r, c) / (r+1, c) and b = (r+1, c+1) / (r, c+1) flips the variant (parity of the fermion count up to and including the
+    site, row-major) of every site between the two ends: row r right of the plaquette and row r+1 left of it.  A variant flip of
+    a whole row is a second configuration table, so the hopped amplitude is a local replacement of the four plaquette tensors
+    against TWISTED environments: the LEFT BTen2 grown with row r+1 flipped, the RIGHT BTen2 grown with row r flipped
+    (pepsgpu_cfg_override_slice + the second BTen2 set, pepsgpu_replace_plaquette_trace).  psi of the same plaquette comes from
+    the untwisted set along the same path.  Cost per row pair: two more BTen2 chains instead of 2 (cols - 1) fresh contractions."""
+    from .capi import LEFT, RIGHT, UP, DOWN, HORIZONTAL
+    cfg = np.asarray(configs)
+    n, rows, cols = cfg.shape
+    d = state.d
+    occ = (np.asarray(state.nf)[cfg] % 2).reshape(n, -1)
+    ext = state.ext_config(cfg, ROW)
+    flip = np.where(ext // d == 0, ext + d, ext - d).astype(np.int32)       # variant 0 <-> 1 (row-major variants)
+    e = np.zeros(n)
+    if bonds is not None:
+        bonds.update(dr=np.zeros((n, rows - 1, cols - 1)), ur=np.zeros((n, rows - 1, cols - 1)))
+    if cols < 2 or rows < 2:
+        return e
+    ctx.set_configs(ext)
+    ctx.generate_bmps_approach(UP)                      # DOWN stack complete, UP at the vacuum
+    try:
+        for row in range(rows - 1):
+            # untwisted set 0 and twisted set 1: the whole RIGHT stack at once (its levels are read by index), LEFT step by step
+            ctx.bten2_select_set(0)
+            ctx.grow_full_bten2(RIGHT, row, 2, True)
+            ctx.init_bten2(LEFT, row)
+            ctx.bten2_select_set(1)
+            ctx.cfg_override_slice(HORIZONTAL, row, flip[:, row, :])
+            ctx.grow_full_bten2(RIGHT, row, 2, True)
+            ctx.cfg_override_slice(HORIZONTAL, row + 1, flip[:, row + 1, :])
+            ctx.init_bten2(LEFT, row)
+            for col in range(cols - 1):
+                # (the plaquette's own states are handed over explicitly: a site that reads a configuration table would read the
+                # override that is set for the twisted chain)
+                own = np.stack([ext[:, row, col], ext[:, row + 1, col], ext[:, row + 1, col + 1], ext[:, row, col + 1]], axis=-1)
+                psi = ctx.replace_plaquette_trace(row, col, own[:, None, :], 0, 0)[:, 0]
+                cands, terms = [], []
+                for key, a, b in (("dr", (row, col), (row + 1, col + 1)), ("ur", (row + 1, col), (row, col + 1))):
+                    differ = cfg[:, a[0], a[1]] != cfg[:, b[0], b[1]]
+                    ia, ib = sorted((a[0] * cols + a[1], b[0] * cols + b[1]))
+                    jw = (-1.0) ** occ[:, ia + 1:ib].sum(axis=1)
+                    new = cfg.copy()
+                    new[:, a[0], a[1]], new[:, b[0], b[1]] = cfg[:, b[0], b[1]], cfg[:, a[0], a[1]]
+                    ne = state.ext_config(new, ROW)
+                    cands.append(np.stack([ne[:, row, col], ne[:, row + 1, col], ne[:, row + 1, col + 1], ne[:, row, col + 1]], axis=-1))
+                    terms.append((key, differ, jw))
+                if any(t[1].any() for t in terms):
+                    psi_ex = ctx.replace_plaquette_trace(row, col, np.stack(cands, axis=1), 1, 1)
+                    for k, (key, differ, jw) in enumerate(terms):
+                        eb = np.where(differ, -t2 * jw * psi_ex[:, k] / np.where(psi == 0, 1.0, psi), 0.0)
+                        e += eb
+                        if bonds is not None:
+                            bonds[key][:, row, col] = eb
+                if col < cols - 2:          # both LEFT chains advance over column col (set 1 under the row+1 override)
+                    ctx.grow_bten2_step(LEFT, row)
+                    ctx.bten2_select_set(0)
+                    ctx.cfg_override_slice(HORIZONTAL, row + 1, None)
+                    ctx.grow_bten2_step(LEFT, row)
+                    ctx.bten2_select_set(1)
+                    ctx.cfg_override_slice(HORIZONTAL, row + 1, flip[:, row + 1, :])
+            ctx.cfg_override_slice(HORIZONTAL, row + 1, None)
+            ctx.bten2_select_set(0)
+            if row < rows - 2:
+                ctx.shift_bmps_window(DOWN)
+    finally:
+        ctx.cfg_override_slice(HORIZONTAL, 0, None)
+        ctx.bten2_select_set(0)
+    return e
 
 
 def nnn_hop_energy(ctx, state, configs, t2, bonds=None):

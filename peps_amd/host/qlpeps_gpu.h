@@ -529,6 +529,19 @@ class BMPSContractorT {
                                        n_cand > 0 ? cand.data() : nullptr, dptr(out.data())), ctx_);
     return out;
   }
+  // Second BTen2 set, one-slice configuration override and the four-tensor plaquette trace: the environment-reusing diagonal hop
+  // of a fermionic state (SquareSpinlessFermion::AddNNNHopEnergyLocal below; include/pepsgpu.h has the statement)
+  void SelectBTen2Set(int set) { check_rc(pepsgpu_bten2_select_set(ctx_, set), ctx_); }
+  void OverrideSlice(BondOrientation orient, size_t num, const std::vector<int32_t> *states) {
+    check_rc(pepsgpu_cfg_override_slice(ctx_, orient, (int)num, states ? states->data() : nullptr), ctx_);
+  }
+  std::vector<TenElemT> ReplacePlaquetteTrace(const SiteIdx &left_up, int n_cand, const std::vector<int32_t> &cand, int left_set,
+                                            int right_set) const {
+    std::vector<TenElemT> out(walkers() * (n_cand > 0 ? n_cand : 1));
+    check_rc(pepsgpu_replace_plaquette_trace(ctx_, (int)left_up.r, (int)left_up.c, n_cand, n_cand > 0 ? cand.data() : nullptr, left_set,
+                                             right_set, dptr(out.data())), ctx_);
+    return out;
+  }
   std::vector<TenElemT> ReplaceTNNSiteTrace(const SiteIdx &site0, BondOrientation orient, int n_cand,
                                           const std::vector<int32_t> &cand) const {
     std::vector<TenElemT> out(walkers() * (n_cand > 0 ? n_cand : 1));
@@ -1803,8 +1816,103 @@ class SquareSpinlessFermion : public SquareNNModelEnergySolver<SquareSpinlessFer
                                               bool holes_on_device = false) {
     EnergyAndHolesT<TenElemT> out =
         SquareNNModelEnergySolver<SquareSpinlessFermion>::template CalEnergyAndHoles<calchols, TenElemT>(sitps, comp, holes_on_device);
-    if (t2_ != 0.0) AddNNNHopEnergyFresh(comp, out.energy);
+    // the diagonal hop: with the environments of a row pass (twisted BTen2 sets, round 5); PEPSHOST_NNN_FRESH=1: one fresh batched
+    // contraction per diagonal (rounds 2-4; the independent check)
+    static const bool fresh = getenv("PEPSHOST_NNN_FRESH") != nullptr;
+    if (t2_ != 0.0) { if (fresh) AddNNNHopEnergyFresh(comp, out.energy); else AddNNNHopEnergyLocal(comp, out.energy); }
     return out;
+  }
+  // The diagonal hops of every plaquette with the environments of ONE row pass -- the reference's flow (square_spinless_fermion.h:
+  // 161-213 through square_nnn_energy_solver.h:203-265: BTen2 of the row pair, ReplaceNNNSiteTrace per diagonal).  The reference's
+  // graded trace carries the signs in the tensor algebra; in the decorated form a hop between a = (r, c) / (r+1, c) and
+  // b = (r+1, c+1) / (r, c+1) flips the variant of every site between the two ends in row-major order -- row r right of the
+  // plaquette, row r+1 left of it -- so the hopped amplitude is a replacement of the four plaquette tensors against TWISTED
+  // environments: the LEFT BTen2 grown with row r+1 under flipped variants, the RIGHT BTen2 with row r flipped (second BTen2 set +
+  // slice override of the C ABI).  psi of the plaquette comes from the untwisted set along the same path.
+  template <typename TenElemT>
+  void AddNNNHopEnergyLocal(TPSWaveFunctionComponentT<TenElemT> &comp, std::vector<TenElemT> &energy) const {
+    if (!comp.fermion) throw std::logic_error("SquareSpinlessFermion: NNN hopping needs the fermionic decoration of the component");
+    const size_t n = comp.config.walkers(), rows = comp.config.rows(), cols = comp.config.cols();
+    if (rows < 2 || cols < 2) return;
+    const FermionDecoration &fd = *comp.fermion;
+    const int32_t d = (int32_t)fd.d();
+    auto &ct = comp.contractor;
+    comp.SetOrder(ROW_MAJOR);
+    comp.InitDevice();
+    const Configuration ext = fd.ExtConfig(comp.config, ROW_MAJOR);
+    auto flipped_row = [&](size_t r) {
+      std::vector<int32_t> v(n * cols);
+      for (size_t w = 0; w < n; ++w)
+        for (size_t c = 0; c < cols; ++c) { const int32_t e = ext(w, {r, c}); v[w * cols + c] = (e / d == 0) ? e + d : e - d; }
+      return v;
+    };
+    struct Restore {
+      BMPSContractorT<TenElemT> &c;
+      ~Restore() { try { c.OverrideSlice(HORIZONTAL, 0, nullptr); c.SelectBTen2Set(0); } catch (...) {} }
+    } restore{ct};
+    ct.GenerateBMPSApproach(UP);
+    for (size_t row = 0; row + 1 < rows; ++row) {
+      const std::vector<int32_t> flip0 = flipped_row(row), flip1 = flipped_row(row + 1);
+      ct.SelectBTen2Set(0);
+      ct.GrowFullBTen2(RIGHT, row, 2, true);
+      ct.InitBTen2(LEFT, row);
+      ct.SelectBTen2Set(1);
+      ct.OverrideSlice(HORIZONTAL, row, &flip0);
+      ct.GrowFullBTen2(RIGHT, row, 2, true);
+      ct.OverrideSlice(HORIZONTAL, row + 1, &flip1);
+      ct.InitBTen2(LEFT, row);
+      for (size_t col = 0; col + 1 < cols; ++col) {
+        const SiteIdx q[4] = {{row, col}, {row + 1, col}, {row + 1, col + 1}, {row, col + 1}};
+        std::vector<int32_t> own(n * 4), cand(n * 2 * 4);
+        std::vector<double> jw(n * 2, 0.0);
+        bool any = false;
+        for (size_t w = 0; w < n; ++w) {
+          for (int k = 0; k < 4; ++k) own[w * 4 + k] = ext(w, q[k]);
+          for (int diag = 0; diag < 2; ++diag) {
+            const SiteIdx a = diag == 0 ? q[0] : q[1], b = diag == 0 ? q[2] : q[3];
+            const bool differ = comp.config(w, a) != comp.config(w, b);
+            if (differ) {
+              any = true;
+              const size_t ia = std::min(a.r * cols + a.c, b.r * cols + b.c), ib = std::max(a.r * cols + a.c, b.r * cols + b.c);
+              int between = 0;
+              for (size_t x = ia + 1; x < ib; ++x) between += fd.n(comp.config(w, {x / cols, x % cols}));
+              jw[w * 2 + diag] = (between & 1) ? -1.0 : 1.0;
+            }
+            // parity of the fermion count up to and including each plaquette site under the hopped configuration
+            auto same = [](const SiteIdx &x, const SiteIdx &y) { return x.r == y.r && x.c == y.c; };
+            auto st = [&](const SiteIdx &s) { return same(s, a) ? comp.config(w, b) : (same(s, b) ? comp.config(w, a) : comp.config(w, s)); };
+            // count before (row, col): inclusive parity of ext at (row, col) minus its own occupation
+            const int p00 = (ext(w, q[0]) / d) ^ fd.n(comp.config(w, q[0]));          // fermions strictly before (row, col)
+            // row `row`: between (row, col+1) and the end, and row+1 up to col-1: unchanged occupations
+            int mid = 0;                                                               // fermions strictly between (row, col+1) and (row+1, col)
+            for (size_t c2 = col + 2; c2 < cols; ++c2) mid ^= fd.n(comp.config(w, {row, c2}));
+            for (size_t c2 = 0; c2 < col; ++c2) mid ^= fd.n(comp.config(w, {row + 1, c2}));
+            const int n0 = fd.n(st(q[0])), n3 = fd.n(st(q[3])), n1 = fd.n(st(q[1])), n2 = fd.n(st(q[2]));
+            const int i0 = p00 ^ n0, i3 = i0 ^ n3, i1 = i3 ^ mid ^ n1, i2 = i1 ^ n2;
+            int32_t *cd = &cand[(w * 2 + diag) * 4];
+            cd[0] = st(q[0]) + d * i0; cd[1] = st(q[1]) + d * i1; cd[2] = st(q[2]) + d * i2; cd[3] = st(q[3]) + d * i3;
+          }
+        }
+        if (any) {
+          const std::vector<TenElemT> psi = ct.ReplacePlaquetteTrace(q[0], 1, own, 0, 0);
+          const std::vector<TenElemT> psi_ex = ct.ReplacePlaquetteTrace(q[0], 2, cand, 1, 1);
+          for (size_t w = 0; w < n; ++w)
+            for (int diag = 0; diag < 2; ++diag)
+              if (jw[w * 2 + diag] != 0.0) energy[w] += TenElemT(-t2_ * jw[w * 2 + diag]) * psi_ex[w * 2 + diag] / psi[w];
+        }
+        if (col + 2 < cols) {      // both LEFT chains advance over column col (set 1 under the row+1 override)
+          ct.GrowBTen2Step(LEFT, row);
+          ct.SelectBTen2Set(0);
+          ct.OverrideSlice(HORIZONTAL, row + 1, nullptr);
+          ct.GrowBTen2Step(LEFT, row);
+          ct.SelectBTen2Set(1);
+          ct.OverrideSlice(HORIZONTAL, row + 1, &flip1);
+        }
+      }
+      ct.OverrideSlice(HORIZONTAL, row + 1, nullptr);
+      ct.SelectBTen2Set(0);
+      if (row + 2 < rows) ct.ShiftBMPSWindow(DOWN);
+    }
   }
   // sum over the plaquette diagonals of -t2 * jw * psi(S with the two sites exchanged) / psi(S); jw = (-1)^(fermions strictly
   // between the two sites in row-major order).  Leaves comp on its original configuration.

@@ -345,3 +345,35 @@ def test_k9_reference_tj_measurer_regression_energy_on_the_device(fixtures_dir):
     e = float(np.mean(en[:, 0]))
     print("K9 on the device: energy %.14f (reference -14.74320489110316, diff %.1e)" % (e, abs(e + 14.74320489110316)))
     assert abs(e - (-14.74320489110316)) < 1e-8
+
+
+@pytest.mark.parametrize("shape,D,chi", [((4, 4), 4, 16), ((3, 5), 3, 9)])
+def test_nnn_hop_with_twisted_environments_equals_fresh_amplitudes_and_oracle(shape, D, chi):
+    """Round 5: the diagonal (t2) hop of a fermionic state with the environments of the row pass -- the
+    reference's flow (square_spinless_fermion.h:161-213, square_nnn_energy_solver.h:203-265) -- instead of one fresh contraction
+    per hop.  In the decorated form the hop flips the variant of a whole stretch of two rows, so the hopped amplitude is a
+    plaquette replacement against parity-twisted BTen2 environments (peps_amd/fermion.py::nnn_hop_energy_local).  Checked per
+    diagonal bond against the fresh-amplitude form of rounds 2-4 and, on the total energy, against the graded oracle (f64)."""
+    from peps_amd import capi, fermion
+    rows, cols = shape
+    st = fermion.random_even_state(rows, cols, D, seed=31)
+    _, fs = _oracle_view(st)
+    rng = np.random.default_rng(17)
+    cfgs = rng.integers(0, 2, size=(6, rows, cols))
+    cfgs[(rows * cols - cfgs.sum(axis=(1, 2))) % 2 == 1, 0, 0] ^= 1
+    ctx = _ctx(st, chi, capi.F64, len(cfgs))
+    b_local, b_fresh = {}, {}
+    e_local = fermion.nnn_hop_energy_local(ctx, st, cfgs, 0.7, b_local)
+    e_fresh = fermion.nnn_hop_energy(ctx, st, cfgs, 0.7, b_fresh)
+    assert np.count_nonzero(b_fresh["dr"]) + np.count_nonzero(b_fresh["ur"]) > 10
+    for key in ("dr", "ur"):
+        assert np.max(np.abs(b_local[key] - b_fresh[key])) < 1e-9 * max(1.0, np.max(np.abs(b_fresh[key]))), key
+    assert np.max(np.abs(e_local - e_fresh)) < 1e-9 * max(1.0, np.max(np.abs(e_fresh)))
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    m0, m2 = ofermion.SquareSpinlessFermionOBC(1.0, 0.0, 0.5), ofermion.SquareSpinlessFermionOBC(1.0, 0.7, 0.5)
+    e_tot, _ = fermion.spinless_fermion_energy(ctx, st, cfgs, 1.0, 0.5, 0.7)          # nnn = "local" is the default
+    for k, cfg in enumerate(cfgs):
+        want = m2.CalEnergy(fs, cfg, tp)[0]
+        assert abs(e_tot[k] - want) < 1e-8 * max(1.0, abs(want)), (k, e_tot[k], want)
+        assert abs((want - m0.CalEnergy(fs, cfg, tp)[0]) - e_local[k]) < 1e-8 * max(1.0, abs(want))
+    assert np.all(ctx.walker_flags() == 0)
