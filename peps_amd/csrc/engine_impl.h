@@ -114,9 +114,16 @@ bool Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
       skip_le = JR_BR;
     }
   }
+  // (float64 tail of the function: a 64 x 256 block of doubles is 131.6 KB, 0.6 KB above JACOBI_LDS_MAX -- the second row of every
+  // stack at C4 ran its 18-20 sweeps from global memory; one block per CU with the block in LDS is the better trade up to 136 KB)
+  if (!use_lds && need <= 136 * 1024) {
+    use_lds = 1;
+    allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), need);
+  }
   // the static block does not fit LDS: 64 KB of dynamic LDS (two blocks per CU as before) for the walkers whose live rows do
   static const bool no_dyn_lds = getenv("PEPSGPU_NO_JACOBI_DYN_LDS") != nullptr;
   if (!use_lds && mdyn && !no_dyn_lds) {
+    // (136 KB at one block per CU for blocks like C5's 144 x 145 doubles was measured: C5 f64 2 273 -> 2 109 amp/s -- not adopted)
     constexpr int CAP = 64 * 1024;
     allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), (size_t)CAP);
     hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), CAP, stream_, M, wM, m, len, len, 40, 2, sweeps_, mdyn, mdyn_mul,
@@ -730,7 +737,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     // vectors inside it come from an accurate float64 Jacobi on Z = U^T M, kq x uk (Rayleigh-Ritz on M itself).  Both Jacobi problems
     // (<= 128 x 128 and 64 x 256 doubles) live in LDS.  Walkers whose factors keep fewer than kq (or more than 128) rows take the
     // general kernels as before (rflag = 0); trunc_err > 0 keeps the general path (the truncation rule wants every singular value).
-    int *rflag = nullptr, *fbrows = nullptr;
+    int *rflag = nullptr, *fbrows = nullptr, *early = nullptr, *fb_early = nullptr, *lateflag = nullptr;
     if constexpr (std::is_same<T, double>::value) {
       static const bool no_route = getenv("PEPSGPU_NO_F64_DENSE_ROUTE") != nullptr;
       // oversampled subspace: 2 chi directions, at most three quarters of the rank M can have (the right-edge sites are 256 x 64)
@@ -747,6 +754,17 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         const int gb = (nw_ + 255) / 256;
         hipLaunchKernelGGL(f64_route_init_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)mdyn[i], mmul[i], m, nw_, rowsM, rflag);
         PG_CHECK_HIP(hipGetLastError());
+        const bool rdbg = dbg_sweeps_ && getenv("PEPSGPU_DEBUG_VERBOSE");
+        long stage_on[3] = {0, 0, 0}, stage_hi = 0, stage_lo = 0;
+        auto count_on = [&](int st, const int *rows_after) {     // diagnostics: walkers still on the route after a stage
+          if (!rdbg) return;
+          std::vector<int> hf(nw_), hr(nw_);
+          PG_CHECK_HIP(hipMemcpyAsync(hf.data(), rflag, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+          if (rows_after) PG_CHECK_HIP(hipMemcpyAsync(hr.data(), rows_after, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+          PG_CHECK_HIP(hipStreamSynchronize(stream_));
+          for (int w = 0; w < nw_; ++w) stage_on[st] += hf[w] < 0;
+          (void)hr;
+        };
         prof_begin(PROF_TRUNC_GRAM, 0.0, 0.0);
         double *Gm = (double *)arena_.alloc(sizeof(double) * (size_t)GSd * GSd * nw_);
         DTen<T> B1 = alloc_ten(GSd, GSd, 1);
@@ -763,8 +781,37 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         launch_chol_upper<T>(stream_, nw_, Gm, (long)GSd * GSd, GSd, B1.p, B1.n, mB1, 0, GSd, (const int *)rowsM, 1, (const int *)nullptr);
         arena_.free(Gm);
         // walkers whose first factor kept more than 128 or fewer than kq rows leave the route
+        if (rdbg) {
+          std::vector<int> hr(nw_);
+          PG_CHECK_HIP(hipMemcpyAsync(hr.data(), mB1, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+          PG_CHECK_HIP(hipStreamSynchronize(stream_));
+          for (int w = 0; w < nw_; ++w) { stage_hi += hr[w] > 128; stage_lo += hr[w] < kq; }
+        }
         hipLaunchKernelGGL(f64_route_check_kernel, dim3(gb), dim3(256), 0, stream_, rflag, mB1, kq, 128, nw_);
         PG_CHECK_HIP(hipGetLastError());
+        count_on(0, nullptr);
+        // The few walkers that leave here (1-3 of 1 024 per site with more than 128 rows, some tens at the edge sites) each cost a whole
+        // general Jacobi from global memory, ~50 ms per site whatever the batch: it starts NOW on the side stream, beside the route.
+        static const bool no_side = getenv("PEPSGPU_NO_F64_ROUTE_SIDE") != nullptr;
+        if (!no_side) {
+          early = (int *)arena_.alloc(sizeof(int) * nw_);
+          fb_early = (int *)arena_.alloc(sizeof(int) * nw_);
+          PG_CHECK_HIP(hipMemcpyAsync(early, rflag, sizeof(int) * nw_, hipMemcpyDeviceToDevice, stream_));
+          hipLaunchKernelGGL(f64_route_fallback_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)rflag, (const int *)rowsM, nw_, fb_early,
+                             (const int *)nullptr, (int *)nullptr);
+          PG_CHECK_HIP(hipGetLastError());
+          PG_CHECK_HIP(hipEventRecord(ev_fork_, stream_));
+          PG_CHECK_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
+          constexpr int CAPS = 64 * 1024;
+          allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), (size_t)CAPS);
+          hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), CAPS, side_stream_, M.p, M.n, m, uk, uk, 40, 2, sweeps_,
+                             (const int *)fb_early, 1, 0, 0, CAPS);
+          hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, side_stream_, (const T *)M.p, M.n, m, uk, uk, k, V.p, V.n,
+                             (T *)nullptr, 0L, (const int *)mdyn[i], mmul[i], kn[i], trunc_err_, chi_min_, (double *)nullptr,
+                             (const int *)early, 0);
+          PG_CHECK_HIP(hipGetLastError());
+          PG_CHECK_HIP(hipEventRecord(ev_join_, side_stream_));
+        }
         double *G2 = (double *)arena_.alloc(sizeof(double) * (size_t)128 * 128 * nw_);
         DTen<T> B2 = alloc_ten(128, 128, 1);
         {   // G2 = B B^T (r x r, r = mB1 <= 128), the rows of B are GSd long (zero beyond the live rows of M)
@@ -783,6 +830,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         arena_.free(G2);
         hipLaunchKernelGGL(f64_route_check_kernel, dim3(gb), dim3(256), 0, stream_, rflag, mB2, kq, 128, nw_);
         PG_CHECK_HIP(hipGetLastError());
+        count_on(1, nullptr);
         prof_end();
         // rotated rows of B2 = sigma_q w_q^T (LDS-resident Jacobi: 128 x 129 doubles)
         prof_begin(PROF_JACOBI, 0.0, 0.0);
@@ -856,11 +904,13 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           PG_CHECK_HIP(hipStreamSynchronize(stream_));
           long on = 0, s0 = 0, sk = 0, x0 = 0;
           for (int w = 0; w < nw_; ++w) { on += hf[w] < 0; s0 += h0[w]; sk += hk[w]; x0 = std::max<long>(x0, h0[w]); }
-          fprintf(stderr, "[pepsgpu] f64 dense route site %d (m = %d, uk = %d, kq = %d): %ld of %d walkers on the route, live rows of M mean %.1f max %ld, kept directions mean %.1f\n",
-                  i, m, uk, kq, on, nw_, (double)s0 / nw_, x0, on ? (double)sk / on : 0.0);
+          fprintf(stderr, "[pepsgpu] f64 dense route site %d (m = %d, uk = %d, kq = %d): %ld of %d walkers on the route (after the first factor %ld: %ld above 128 rows, %ld below kq; after the second %ld), live rows of M mean %.1f max %ld, kept directions mean %.1f\n",
+                  i, m, uk, kq, on, nw_, stage_on[0], stage_hi, stage_lo, stage_on[1], (double)s0 / nw_, x0, on ? (double)sk / on : 0.0);
         }
         // the others: the general kernels below on their live rows (the route's walkers count zero rows there)
-        hipLaunchKernelGGL(f64_route_fallback_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)rflag, (const int *)rowsM, nw_, fbrows);
+        lateflag = (int *)arena_.alloc(sizeof(int) * nw_);
+        hipLaunchKernelGGL(f64_route_fallback_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)rflag, (const int *)rowsM, nw_, fbrows,
+                           (const int *)early, lateflag);
         PG_CHECK_HIP(hipGetLastError());
         free_ten(B1); free_ten(B2); free_ten(Wt); free_ten(T1); free_ten(Uq); free_ten(Zt);
         arena_.free(rowsM); arena_.free(mB1); arena_.free(mB2); arena_.free(kW);
@@ -964,9 +1014,18 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     if (!skip_select)
       hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)M.p, M.n, m, uk, uk, k, V.p,
                          V.n, (T *)nullptr, 0L, (const int *)mdyn[i], mmul[i], kn[i], trunc_err_, chi_min_, (double *)nullptr,
-                         (const int *)(rflag ? rflag : midflag), 0, sel_done ? JR_BR : 0);
+                         (const int *)(rflag ? lateflag : midflag), 0, sel_done ? JR_BR : 0);
     PG_CHECK_HIP(hipGetLastError());
-    if (rflag) { arena_.free(rflag); arena_.free(fbrows); rflag = nullptr; fbrows = nullptr; }
+    if (rflag) {
+      if (early) {      // the side stream's walkers: joined before anything reads V / kn of this site
+        PG_CHECK_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
+        // (their buffers go back to the arena: it hands them out to launches on stream_ only, which are ordered behind the join)
+        arena_.free(early); arena_.free(fb_early);
+        early = nullptr; fb_early = nullptr;
+      }
+      arena_.free(rflag); arena_.free(fbrows); arena_.free(lateflag);
+      rflag = nullptr; fbrows = nullptr; lateflag = nullptr;
+    }
     if (mid) {
       // sigma_k u_k^T = the rotated rows of B: the chi largest, normalised -> U^T (k x GS), kB = how many are live
       if (side_pending) { PG_CHECK_HIP(hipStreamWaitEvent(stream_, ev_join_, 0)); side_pending = false; }

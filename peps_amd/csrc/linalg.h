@@ -1641,11 +1641,16 @@ __global__ __launch_bounds__(256) void f64_route_guard_kernel(const double *__re
   }
 }
 
-// live rows of M for the walkers off the route (the general kernels take them), 0 for the walkers on it
-__global__ void f64_route_fallback_kernel(const int *__restrict__ flag, const int *__restrict__ rows_m, int nbatch, int *__restrict__ fb) {
+// live rows of M for the walkers off the route (the general kernels take them), 0 for the walkers on it.  `early` (optional): the
+// walkers that left at the first check are being handled on the side stream already (early[b] >= 0): they count 0 rows here and
+// `late_flag` (optional) marks what is left for the main stream (0: left the route later, -1: nothing to do)
+__global__ void f64_route_fallback_kernel(const int *__restrict__ flag, const int *__restrict__ rows_m, int nbatch, int *__restrict__ fb,
+                                          const int *__restrict__ early = nullptr, int *__restrict__ late_flag = nullptr) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbatch) return;
-  fb[b] = flag[b] < 0 ? 0 : rows_m[b];
+  const bool off = flag[b] >= 0 && !(early && early[b] >= 0);
+  fb[b] = off ? rows_m[b] : 0;
+  if (late_flag) late_flag[b] = off ? 0 : -1;
 }
 
 // Two-level form of the route: of the walkers with more than 128 live rows of M (hiflag) those whose factor B kept at most

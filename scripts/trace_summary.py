@@ -5,7 +5,7 @@ agg = collections.defaultdict(lambda: [0, 0.0])
 with open(f) as fh:
     rd = csv.DictReader(fh)
     for r in rd:
-        name = r["Kernel_Name"].split("(")[0][-60:]
+        name = r["Kernel_Name"].split("(")[0][-96:]      # (60 until round 5: the template lists grew)
         key = (name, r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", ""), r.get("Workgroup_Size_X", ""))
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
         agg[key][0] += 1
