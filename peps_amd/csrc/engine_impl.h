@@ -744,6 +744,9 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       const int kq = std::min(2 * k_full, (3 * std::min(m, uk)) / 4);
       if (!no_route && adaptive && trunc_err_ == 0.0 && m > 128 && m <= 256 && uk <= 256 && kq <= 64 && kq >= k_full + 8 && i > 0) {
         const int GSd = m;
+        // a walker stays on the route with as few as chi + 4 directions above the resolution of a Gram: the guard prices what its
+        // factors dropped (C5: the synthetic fermionic state keeps 30-47 of kq = 48; real state: the edge sites)
+        const int route_lo = std::min(kq, k_full + 4);
         rflag = (int *)arena_.alloc(sizeof(int) * nw_);
         fbrows = (int *)arena_.alloc(sizeof(int) * nw_);
         int *rowsM = (int *)arena_.alloc(sizeof(int) * nw_), *mB1 = (int *)arena_.alloc(sizeof(int) * nw_);
@@ -785,9 +788,9 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           std::vector<int> hr(nw_);
           PG_CHECK_HIP(hipMemcpyAsync(hr.data(), mB1, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
           PG_CHECK_HIP(hipStreamSynchronize(stream_));
-          for (int w = 0; w < nw_; ++w) { stage_hi += hr[w] > 128; stage_lo += hr[w] < kq; }
+          for (int w = 0; w < nw_; ++w) { stage_hi += hr[w] > 128; stage_lo += hr[w] < route_lo; }
         }
-        hipLaunchKernelGGL(f64_route_check_kernel, dim3(gb), dim3(256), 0, stream_, rflag, mB1, kq, 128, nw_);
+        hipLaunchKernelGGL(f64_route_check_kernel, dim3(gb), dim3(256), 0, stream_, rflag, mB1, route_lo, 128, nw_);
         PG_CHECK_HIP(hipGetLastError());
         count_on(0, nullptr);
         // The few walkers that leave here (1-3 of 1 024 per site with more than 128 rows, some tens at the edge sites) each cost a whole
@@ -828,7 +831,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         }
         launch_chol_upper<T>(stream_, nw_, G2, 128L * 128, 128, B2.p, B2.n, mB2, 0, 128, (const int *)mB1, 1, (const int *)rflag);
         arena_.free(G2);
-        hipLaunchKernelGGL(f64_route_check_kernel, dim3(gb), dim3(256), 0, stream_, rflag, mB2, kq, 128, nw_);
+        hipLaunchKernelGGL(f64_route_check_kernel, dim3(gb), dim3(256), 0, stream_, rflag, mB2, route_lo, 128, nw_);
         PG_CHECK_HIP(hipGetLastError());
         count_on(1, nullptr);
         prof_end();
@@ -894,7 +897,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         // guard (f64_route_guard_kernel): a spectrum that falls to the resolution of a Gram inside the subspace leaves the route
         static const double guard_tol = getenv("PEPSGPU_F64_ROUTE_TOL") ? atof(getenv("PEPSGPU_F64_ROUTE_TOL")) : 1e-10;
         hipLaunchKernelGGL(f64_route_guard_kernel, dim3(nw_), dim3(256), 0, stream_, (const double *)Zt.p, Zt.n, uk, (const int *)kW, k_full,
-                           guard_tol, rflag);
+                           guard_tol, rflag, kq);
         PG_CHECK_HIP(hipGetLastError());
         if (dbg_sweeps_ && getenv("PEPSGPU_DEBUG_VERBOSE")) {   // diagnostics: who stays on the route, rows kept by the two compressions
           std::vector<int> hf(nw_), h0(nw_), hk(nw_);
@@ -903,7 +906,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           PG_CHECK_HIP(hipMemcpyAsync(hk.data(), kW, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
           PG_CHECK_HIP(hipStreamSynchronize(stream_));
           long on = 0, s0 = 0, sk = 0, x0 = 0;
-          for (int w = 0; w < nw_; ++w) { on += hf[w] < 0; s0 += h0[w]; sk += hk[w]; x0 = std::max<long>(x0, h0[w]); }
+          for (int w = 0; w < nw_; ++w) { on += hf[w] < 0; s0 += h0[w]; sk += hf[w] < 0 ? hk[w] : 0; x0 = std::max<long>(x0, h0[w]); }
           fprintf(stderr, "[pepsgpu] f64 dense route site %d (m = %d, uk = %d, kq = %d): %ld of %d walkers on the route (after the first factor %ld: %ld above 128 rows, %ld below kq; after the second %ld), live rows of M mean %.1f max %ld, kept directions mean %.1f\n",
                   i, m, uk, kq, on, nw_, stage_on[0], stage_hi, stage_lo, stage_on[1], (double)s0 / nw_, x0, on ? (double)sk / on : 0.0);
         }

@@ -1611,8 +1611,10 @@ __global__ void f64_route_check_kernel(int *__restrict__ flag, int *__restrict__
 //     eps_chol (s_1 / s_k)^2 (s_last / s_1),   s_last = the weakest direction of the subspace (>= the strongest one outside),
 // eps_chol ~ 3e-15 (sqrt(n) eps of the float64 Cholesky of an order-256 Gram).  A walker whose bound exceeds `tol` -- a spectrum
 // that falls to the resolution of a Gram (2.4e-7 s_1) within the subspace -- leaves the route; the general Jacobi redoes it.
+// kq: the subspace dimension aimed at; a walker that kept fewer directions (its factors dropped the rest below the resolution of a
+// Gram, 2.4e-7 s_1) is priced with THAT as the strongest direction outside.
 __global__ __launch_bounds__(256) void f64_route_guard_kernel(const double *__restrict__ Zg, long wZ, int len, const int *__restrict__ kz,
-                                                              int k, double tol, int *__restrict__ flag) {
+                                                              int k, double tol, int *__restrict__ flag, int kq) {
   const int b = blockIdx.x;
   if (flag[b] >= 0) return;
   __shared__ double s_n[64];
@@ -1636,7 +1638,8 @@ __global__ __launch_bounds__(256) void f64_route_guard_kernel(const double *__re
       for (int q = 0; q < rows; ++q) larger += (s_n[q] > s_n[r]) || (s_n[q] == s_n[r] && q < r);
       if (larger == kk - 1) sk = s_n[r];
     }
-    const bool ok = rows > 0 && s1 > 0.0 && sk > 0.0 && 3e-15 * (s1 / sk) * sqrt(slast / s1) <= tol;
+    if (rows < kq) slast = fmax(slast, 5.7e-14 * s1);        // (squared norms: (2.4e-7)^2)
+    const bool ok = rows >= k && s1 > 0.0 && sk > 0.0 && 3e-15 * (s1 / sk) * sqrt(slast / s1) <= tol;
     if (!ok) flag[b] = 0;
   }
 }
