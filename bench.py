@@ -915,9 +915,9 @@ def main():
                         pend_energy[name] = ((L, chi, 0 if dt == capi.F32 else 1, local_rank, fleg.flat), fleg.batches[0][:max(2, args.energy_n // 2)])
                 if real and world == 1 and not args.no_other_modes and dt == capi.F32:
                     # the reference's own arithmetic on the realistic state: the f64 device mode (round 5: dense truncation route of
-                    # the f64 engine -- two-level preconditioning with oversampling, Jacobi problems in LDS), 1 024 walkers
+                    # the f64 engine -- two-level preconditioning with oversampling, Jacobi problems in LDS), 2 048 walkers
                     try:
-                        n64 = min(1024, fnw)
+                        n64 = min(2048, fnw)
                         c64 = capi.Context(L, L, D, 2, chi, dtype=capi.F64, device=local_rank, max_walkers=n64)
                         c64.state_upload(fleg.flat)
                         c64.set_configs(fleg.batches[0][:64]); c64.evaluate_amplitude(); c64.sync()

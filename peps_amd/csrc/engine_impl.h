@@ -782,6 +782,27 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           tgemm_launch<T, T, double, double>(stream_, g, M.p, M.p, Gm);
         }
         launch_chol_upper<T>(stream_, nw_, Gm, (long)GSd * GSd, GSd, B1.p, B1.n, mB1, 0, GSd, (const int *)rowsM, 1, (const int *)nullptr);
+        // Second chance for the walkers whose factor kept more than 128 rows (1-3 of 1 024 per site on the real state -- each of them
+        // would otherwise cost a whole general Jacobi, ~40 ms per site whatever the batch): the Gram again (the factorisation works in
+        // place) and the factor with the pivot threshold REDO_SCALE times higher, i.e. directions below sqrt(REDO_SCALE) 2.4e-7 s_1
+        // dropped; the guard prices exactly that for them.  Who still keeps more than 128 rows leaves the route.
+        constexpr double REDO_SCALE = 64.0;
+        int *redo = (int *)arena_.alloc(sizeof(int) * nw_), *lvl = (int *)arena_.alloc(sizeof(int) * nw_);
+        hipLaunchKernelGGL(f64_route_redo_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)mB1, 128, nw_, redo, lvl);
+        PG_CHECK_HIP(hipGetLastError());
+        {
+          TGemmDesc g;
+          g.I[2] = m; g.sAi[2] = uk; g.sCi[2] = GSd;
+          g.K[2] = uk; g.sAk[2] = 1; g.sBk[2] = 1;
+          g.J[2] = m; g.sBj[2] = uk; g.sCj[2] = 1;
+          g.wA = M.n; g.wB = M.n; g.wC = (long)GSd * GSd; g.nbatch = nw_;
+          g.dI[2].p = rowsM; g.dJ[2].p = rowsM;
+          g.upper_only = 1;
+          g.batch_flag = redo;
+          tgemm_launch<T, T, double, double>(stream_, g, M.p, M.p, Gm);
+        }
+        launch_chol_upper<T>(stream_, nw_, Gm, (long)GSd * GSd, GSd, B1.p, B1.n, mB1, 0, GSd, (const int *)rowsM, 1, (const int *)redo, REDO_SCALE);
+        arena_.free(redo);
         arena_.free(Gm);
         // walkers whose first factor kept more than 128 or fewer than kq rows leave the route
         if (rdbg) {
@@ -897,7 +918,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         // guard (f64_route_guard_kernel): a spectrum that falls to the resolution of a Gram inside the subspace leaves the route
         static const double guard_tol = getenv("PEPSGPU_F64_ROUTE_TOL") ? atof(getenv("PEPSGPU_F64_ROUTE_TOL")) : 1e-10;
         hipLaunchKernelGGL(f64_route_guard_kernel, dim3(nw_), dim3(256), 0, stream_, (const double *)Zt.p, Zt.n, uk, (const int *)kW, k_full,
-                           guard_tol, rflag, kq);
+                           guard_tol, rflag, kq, (const int *)lvl, 5.7e-14 * REDO_SCALE);
         PG_CHECK_HIP(hipGetLastError());
         if (dbg_sweeps_ && getenv("PEPSGPU_DEBUG_VERBOSE")) {   // diagnostics: who stays on the route, rows kept by the two compressions
           std::vector<int> hf(nw_), h0(nw_), hk(nw_);
@@ -916,7 +937,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
                            (const int *)early, lateflag);
         PG_CHECK_HIP(hipGetLastError());
         free_ten(B1); free_ten(B2); free_ten(Wt); free_ten(T1); free_ten(Uq); free_ten(Zt);
-        arena_.free(rowsM); arena_.free(mB1); arena_.free(mB2); arena_.free(kW);
+        arena_.free(rowsM); arena_.free(mB1); arena_.free(mB2); arena_.free(kW); arena_.free(lvl);
       }
     }
     bool sel_done = false;

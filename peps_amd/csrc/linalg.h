@@ -287,7 +287,9 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
                                                            T *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
                                                            int only_flagged = 0, int ld = 0,
                                                            const int *__restrict__ ndyn = nullptr, int ndyn_mul = 1,
-                                                           const int *__restrict__ run_flag = nullptr) {
+                                                           const int *__restrict__ run_flag = nullptr, double thresh_scale = 1.0) {
+  // thresh_scale: multiplies the pivot threshold (the dense f64 route redoes the few walkers whose factor kept more than 128 rows
+  // with a higher one)
   if (only_flagged && mlive_out[blockIdx.x] >= 0) return;
   if (run_flag && run_flag[blockIdx.x] >= 0) return;
   const int ldg = ld ? ld : n;
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
   __syncthreads();
   const double maxd = s_maxd;
   const double eT = NOISE_C * eps_rt<T>();
-  const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
+  const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd * thresh_scale;
   const double sc_out = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
   const int i16 = lane & 15, k4 = lane >> 4;
 
@@ -539,7 +541,8 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
 // launch of the blocked factorisation: the MFMA form above for orders >= 48 (PEPSGPU_OLD_CHOL=1: always the older kernel)
 template <typename T>
 inline void launch_chol_upper(hipStream_t s, int nbatch, double *G, long wG, int n, T *R, long wR, int *mlive_out, int only_flagged = 0,
-                              int ld = 0, const int *ndyn = nullptr, int ndyn_mul = 1, const int *run_flag = nullptr) {
+                              int ld = 0, const int *ndyn = nullptr, int ndyn_mul = 1, const int *run_flag = nullptr, double thresh_scale = 1.0) {
+  PG_REQUIRE(thresh_scale == 1.0 || n >= 48, 1, "pivot threshold scaling needs the blocked Cholesky (order >= 48)");
   static const bool old_chol = getenv("PEPSGPU_OLD_CHOL") != nullptr;
   if (!old_chol && n >= 48) {
     const size_t smem = chol_blocked_smem_bytes(n);
@@ -548,29 +551,29 @@ inline void launch_chol_upper(hipStream_t s, int nbatch, double *G, long wG, int
     if (minb == 2) {          // (two blocks per CU, 256 registers: no scratch)
       allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 2>), smem);
       hipLaunchKernelGGL((chol_blocked_kernel<T, 2>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
-                         ndyn_mul, run_flag);
+                         ndyn_mul, run_flag, thresh_scale);
     } else if (minb >= 4) {
       allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 4>), smem);
       hipLaunchKernelGGL((chol_blocked_kernel<T, 4>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
-                         ndyn_mul, run_flag);
+                         ndyn_mul, run_flag, thresh_scale);
     } else {
       static const int pfd = getenv("PEPSGPU_CHB_PF") ? atoi(getenv("PEPSGPU_CHB_PF")) : 2;     // (real leg, 8192 walkers: cholesky 925 ms per two steps with three k-steps in flight, 908 with two, 963 with five, 986 with eight; two blocks per CU: 979)
       if (pfd >= 8) {
         allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3, 8>), smem);
         hipLaunchKernelGGL((chol_blocked_kernel<T, 3, 8>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
-                           ndyn_mul, run_flag);
+                           ndyn_mul, run_flag, thresh_scale);
       } else if (pfd >= 5) {
         allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3, 5>), smem);
         hipLaunchKernelGGL((chol_blocked_kernel<T, 3, 5>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
-                           ndyn_mul, run_flag);
+                           ndyn_mul, run_flag, thresh_scale);
       } else if (pfd == 2) {
         allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3, 2>), smem);
         hipLaunchKernelGGL((chol_blocked_kernel<T, 3, 2>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
-                           ndyn_mul, run_flag);
+                           ndyn_mul, run_flag, thresh_scale);
       } else {
         allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3>), smem);
         hipLaunchKernelGGL((chol_blocked_kernel<T, 3>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
-                           ndyn_mul, run_flag);
+                           ndyn_mul, run_flag, thresh_scale);
       }
     }
   } else {
@@ -1599,6 +1602,14 @@ __global__ void f64_route_init_kernel(const int *__restrict__ mdyn, int mdyn_mul
   rows[b] = mdyn ? max(0, min(m, mdyn[b] * mdyn_mul)) : m;
   flag[b] = -1;
 }
+// walkers whose first factor kept more than hi rows get a second factorisation with a higher pivot threshold: redo[b] = -1 (run), lvl[b] = 1
+__global__ void f64_route_redo_kernel(const int *__restrict__ rows, int hi, int nbatch, int *__restrict__ redo, int *__restrict__ lvl) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbatch) return;
+  const bool again = rows[b] > hi;
+  redo[b] = again ? -1 : 0;
+  lvl[b] = again ? 1 : 0;
+}
 // a walker whose factor kept fewer than lo or more than hi rows leaves the route; the row count of every walker off the route reads 0
 __global__ void f64_route_check_kernel(int *__restrict__ flag, int *__restrict__ rows, int lo, int hi, int nbatch) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1614,7 +1625,9 @@ __global__ void f64_route_check_kernel(int *__restrict__ flag, int *__restrict__
 // kq: the subspace dimension aimed at; a walker that kept fewer directions (its factors dropped the rest below the resolution of a
 // Gram, 2.4e-7 s_1) is priced with THAT as the strongest direction outside.
 __global__ __launch_bounds__(256) void f64_route_guard_kernel(const double *__restrict__ Zg, long wZ, int len, const int *__restrict__ kz,
-                                                              int k, double tol, int *__restrict__ flag, int kq) {
+                                                              int k, double tol, int *__restrict__ flag, int kq,
+                                                              const int *__restrict__ lvl = nullptr, double lvl_floor2 = 0.0) {
+  // lvl[b] != 0: the walker's first factor was taken with the raised pivot threshold -- what it dropped is up to sqrt(lvl_floor2) s_1
   const int b = blockIdx.x;
   if (flag[b] >= 0) return;
   __shared__ double s_n[64];
@@ -1639,6 +1652,7 @@ __global__ __launch_bounds__(256) void f64_route_guard_kernel(const double *__re
       if (larger == kk - 1) sk = s_n[r];
     }
     if (rows < kq) slast = fmax(slast, 5.7e-14 * s1);        // (squared norms: (2.4e-7)^2)
+    if (lvl && lvl[b]) slast = fmax(slast, lvl_floor2 * s1);
     const bool ok = rows >= k && s1 > 0.0 && sk > 0.0 && 3e-15 * (s1 / sk) * sqrt(slast / s1) <= tol;
     if (!ok) flag[b] = 0;
   }
