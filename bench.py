@@ -927,7 +927,9 @@ def main():
                         c64.close()
                         rel = np.abs(fleg.amps_first[:n64] / a64 - 1)
                         fr["f64_mode"] = {"amp_per_s": n64 / t64, "walkers": n64,
-                                          "f32_vs_f64_amplitude": {"max_rel": float(np.max(rel)), "median_rel": float(np.median(rel)), "n": int(n64)}}
+                                          "f32_vs_f64_amplitude": {"max_rel": float(np.max(rel)), "median_rel": float(np.median(rel)),
+                                                                   "p99_rel": float(np.percentile(rel, 99)),
+                                                                   "share_above_1e-5": float(np.mean(rel > 1e-5)), "n": int(n64)}}
                     except Exception as e:
                         fr["f64_mode"] = {"error": repr(e)}
                 if real and world == 1 and not args.no_sweeps:
