@@ -1022,6 +1022,161 @@ __device__ __forceinline__ void tg_direct_body_f64(const TGemmDesc &d, const flo
   if (sumsq) *sumsq += ss;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The f32 tile loop on 16 x 16 x 4 MFMAs (round 5; VERDICT r02-r04: "a 16 x 16 x 4 tile body selected from the live extents"): the
+// wave's 32 x 32 tile as 2 x 2 quadrants, a quadrant without a live row / column is not multiplied.  Same operand traffic and the same
+// matrix time per FULL tile as the 32 x 32 x 2 body (8 x 32 cycles against 4 x 64 per round of 8 k); what it saves is the padding
+// of extents like 80 = 2.5 tiles.  Measured on the headline: see tgemm_chain_launch (PEPSGPU_TILE16).
+typedef float tg_f32x4 __attribute__((ext_vector_type(4)));
+template <bool AVEC, bool BVEC>
+__device__ __forceinline__ void tg_direct_body_t16(const TGemmDesc &d, const float *__restrict__ A, const float *__restrict__ B,
+                                                   float *__restrict__ C, const int Itot, const int Jtot, const int K2s,
+                                                   int (*offCi_s)[32], const int tile0, const int tile_step,
+                                                   const float scale = 1.f, double *__restrict__ sumsq = nullptr) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntj = (Jtot + 31) >> 5, ntiles = ((Itot + 31) >> 5) * ntj;
+  const float alpha = (float)d.alpha * scale;
+  double ss = 0.0;
+  const int g4 = lane >> 4, c16 = lane & 15;
+  const int K2 = d.K[2], K1 = d.K[1];
+  const int nr8 = (K2 + 7) >> 3, nrounds = d.K[0] * K1 * nr8;
+  const unsigned sA2b = 4u * d.sAk[2], sB2b = 4u * d.sBk[2];
+  const float rI2 = __builtin_amdgcn_rcpf((float)d.I[2]), rI1 = __builtin_amdgcn_rcpf((float)d.I[1]);
+  const float rJ2 = __builtin_amdgcn_rcpf((float)d.J[2]), rJ1 = __builtin_amdgcn_rcpf((float)d.J[1]);
+  const int kh = 2 * g4;
+  const bool accumulate = d.accumulate != 0;
+
+  for (int t = tile0 + wave; t < ntiles; t += tile_step) {
+    const int ti = t / ntj, tj = t - ti * ntj;
+    unsigned oab[2], obb[2];
+    int ocj[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = ti * 32 + 16 * q + c16, j = tj * 32 + 16 * q + c16;
+      int i2, i1, j2, j1;
+      const int qi = tg_fdivmod(i, d.I[2], rI2, i2);
+      const int i0 = tg_fdivmod(qi, d.I[1], rI1, i1);
+      const int qj = tg_fdivmod(j, d.J[2], rJ2, j2);
+      const int j0 = tg_fdivmod(qj, d.J[1], rJ1, j1);
+      const bool iv = i < Itot, jv = j < Jtot;
+      const bool iz = i2 >= d.Imask[2] || i1 >= d.Imask[1] || i0 >= d.Imask[0];
+      const bool jz = j2 >= d.Jmask[2] || j1 >= d.Jmask[1] || j0 >= d.Jmask[0];
+      oab[q] = (iv && !iz) ? 4u * (unsigned)(i0 * d.sAi[0] + i1 * d.sAi[1] + i2 * d.sAi[2]) : 0u;
+      obb[q] = (jv && !jz) ? 4u * (unsigned)(j0 * d.sBj[0] + j1 * d.sBj[1] + j2 * d.sBj[2]) : 0u;
+      const int oci = i0 * d.sCi[0] + i1 * d.sCi[1] + i2 * d.sCi[2];
+      if (g4 == q) offCi_s[wave][16 * q + c16] = iv ? (oci | (iz ? TG_ZERO_ROW : 0)) : -1;
+      ocj[q] = jv ? ((j0 * d.sCj[0] + j1 * d.sCj[1] + j2 * d.sCj[2]) | (jz ? TG_ZERO_ROW : 0)) : -1;
+    }
+    tg_f32x4 acc[2][2];
+#pragma unroll
+    for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[qa][qb][r] = 0.f;
+    // quadrants that hold no row / column of C at all are not multiplied (wave-uniform): the point of the 16-wide form
+    const bool liveA1 = ti * 32 + 16 < Itot, liveB1 = tj * 32 + 16 < Jtot;
+
+    int k0 = 0, k1 = 0, r8 = 0;
+    unsigned kab = 0, kbb = 0;
+    auto advance = [&]() {
+      if (++r8 == nr8) {
+        r8 = 0;
+        if (++k1 == K1) { k1 = 0; ++k0; }
+        kab = 4u * (unsigned)(k0 * d.sAk[0] + k1 * d.sAk[1]);
+        kbb = 4u * (unsigned)(k0 * d.sBk[0] + k1 * d.sBk[1]);
+      }
+    };
+    // av[q][e]: row quadrant q, k2 = 8 r8 + kh + e
+    auto load_raw = [&](float (&av)[2][2], float (&bv)[2][2]) {
+      const int kq = 8 * r8 + kh;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if constexpr (AVEC) {
+          const float2 v = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(A) + (oab[q] + kab + 4u * (unsigned)min(kq, K2s - 2)));
+          av[q][0] = v.x; av[q][1] = v.y;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) av[q][e] = tg_ldf(A, oab[q] + kab + (unsigned)min(kq + e, K2 - 1) * sA2b);
+        }
+        if constexpr (BVEC) {
+          const float2 v = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(B) + (obb[q] + kbb + 4u * (unsigned)min(kq, K2s - 2)));
+          bv[q][0] = v.x; bv[q][1] = v.y;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) bv[q][e] = tg_ldf(B, obb[q] + kbb + (unsigned)min(kq + e, K2 - 1) * sB2b);
+        }
+      }
+    };
+    auto mask_k = [&](const int r8m, float (&av)[2][2], float (&bv)[2][2]) {   // only the last round of a k2 run can be partial
+      if (8 * r8m + 8 > K2) {
+        const int kq = 8 * r8m + kh;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const bool ok = kq + e < K2;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) { av[q][e] = ok ? av[q][e] : 0.f; bv[q][e] = ok ? bv[q][e] : 0.f; }
+        }
+      }
+    };
+    auto mfma8 = [&](const float (&av)[2][2], const float (&bv)[2][2]) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][e], bv[0][e], acc[0][0], 0, 0, 0);
+        if (liveB1) acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][e], bv[1][e], acc[0][1], 0, 0, 0);
+        if (liveA1) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][e], bv[0][e], acc[1][0], 0, 0, 0);
+        if (liveA1 && liveB1) acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][e], bv[1][e], acc[1][1], 0, 0, 0);
+      }
+    };
+    float a0[2][2], b0[2][2], a1[2][2], b1[2][2];
+    if (nrounds > 0) {
+      load_raw(a0, b0);
+      mask_k(0, a0, b0);
+      int rd = 0;
+      for (; rd + 2 < nrounds; rd += 2) {
+        advance();
+        const int r8b = r8;
+        load_raw(a1, b1);
+        mfma8(a0, b0);
+        mask_k(r8b, a1, b1);
+        advance();
+        const int r8a = r8;
+        load_raw(a0, b0);
+        mfma8(a1, b1);
+        mask_k(r8a, a0, b0);
+      }
+      if (rd + 1 < nrounds) {
+        advance();
+        load_raw(a1, b1);
+        mfma8(a0, b0);
+        mask_k(r8, a1, b1);
+        mfma8(a1, b1);
+      } else {
+        mfma8(a0, b0);
+      }
+    }
+    // accumulator r of quadrant (qa, qb) = row 16 qa + 4 g4 + r, column 16 qb + c16 of the tile (f32 16x16x4: four consecutive rows
+    // per lane group; the f64 form interleaves them)
+#pragma unroll
+    for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int oi = offCi_s[wave][16 * qa + 4 * g4 + r];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          if (oi >= 0 && ocj[qb] >= 0) {
+            float *p = C + ((oi & ~TG_ZERO_ROW) + (ocj[qb] & ~TG_ZERO_ROW));
+            float v = ((oi & TG_ZERO_ROW) || (ocj[qb] & TG_ZERO_ROW)) ? 0.f : acc[qa][qb][r] * alpha;
+            if (accumulate) v += *p;
+            *p = v;
+            if (sumsq) ss = fma((double)v, (double)v, ss);
+          }
+        }
+      }
+  }
+  if (sumsq) *sumsq += ss;
+}
+
 template <bool AVEC, bool BVEC, bool ACC64 = false>
 __global__ __launch_bounds__(256, ACC64 ? 4 : 6) void tgemm_direct_kernel(TGemmDesc d, const float *__restrict__ Ag,
                                                            const float *__restrict__ Bg, float *__restrict__ Cg) {
@@ -1091,7 +1246,8 @@ struct TGemmChainMap { int mapK[3] = {-1, -1, -1}, mapJ[3] = {-1, -1, -1}; };
 
 // F64: both stages accumulate in float64 on the f64 matrix cores (tg_direct_body_f64; the intermediate stays f32 in LDS)
 // S2P: stage 2 with two J tiles per wave (tg_direct_body_j2) when it has at least two
-template <bool AVEC1, bool BVEC1, bool AVEC2, int LDSF, int MINB, bool F64 = false, bool S2P = false>
+// T16: both stages on the 16 x 16 x 4 tile body (tg_direct_body_t16)
+template <bool AVEC1, bool BVEC1, bool AVEC2, int LDSF, int MINB, bool F64 = false, bool S2P = false, bool T16 = false>
 __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TGemmDesc d2, TGemmChainMap mp, const float *__restrict__ A1g,
                                                             const float *__restrict__ B1g, const float *__restrict__ A2g,
                                                             float *__restrict__ C2g, int *__restrict__ flag, int only_flagged, int allow_chunks) {
@@ -1159,6 +1315,10 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TG
       tg_direct_body_f64<AVEC1, BVEC1>(d1, A1g + baseA1, B1g + baseB1, s_mid, I1, J1, K2s1, offCi_s, 0, 4, in_scale);
       __syncthreads();
       tg_direct_body_f64<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC, I2, J2, K2s2, offCi_s, 0, 4);
+    } else if constexpr (T16) {
+      tg_direct_body_t16<AVEC1, BVEC1>(d1, A1g + baseA1, B1g + baseB1, s_mid, I1, J1, K2s1, offCi_s, 0, 4, in_scale);
+      __syncthreads();
+      tg_direct_body_t16<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC, I2, J2, K2s2, offCi_s, 0, 4);
     } else {
       tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1, B1g + baseB1, s_mid, I1, J1, K2s1, offCi_s, 0, 4, in_scale);
       __syncthreads();
@@ -1180,6 +1340,10 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TG
       tg_direct_body_f64<AVEC1, BVEC1>(d1, A1g + baseA1 + (long)c0 * sA1, B1g + baseB1, s_mid, d1.Itot(), J1, K2s1, offCi_s, 0, 4, in_scale);
       __syncthreads();
       tg_direct_body_f64<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC + (long)c0 * sC2, I2, d2.Jtot(), K2s2, offCi_s, 0, 4);
+    } else if constexpr (T16) {
+      tg_direct_body_t16<AVEC1, BVEC1>(d1, A1g + baseA1 + (long)c0 * sA1, B1g + baseB1, s_mid, d1.Itot(), J1, K2s1, offCi_s, 0, 4, in_scale);
+      __syncthreads();
+      tg_direct_body_t16<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC + (long)c0 * sC2, I2, d2.Jtot(), K2s2, offCi_s, 0, 4);
     } else {
       tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1 + (long)c0 * sA1, B1g + baseB1, s_mid, d1.Itot(), J1, K2s1, offCi_s, 0, 4, in_scale);
       __syncthreads();
@@ -1446,10 +1610,15 @@ inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemm
   // scratch): halving the chain of dependent operand round trips of a wave does not pay for the waves it costs -- the kernel lives
   // on the number of blocks in flight, not on the length of one block's chain.  Kept behind the switch for the A/B.
   static const int s2pair = getenv("PEPSGPU_CHAIN_S2PAIR") ? atoi(getenv("PEPSGPU_CHAIN_S2PAIR")) : 0;
+  // both stages on 16 x 16 x 4 MFMAs with dead quadrants skipped (tg_direct_body_t16), PEPSGPU_TILE16=1 (read per launch: the kernel
+  // test switches it inside one process)
+  const char *t16s = getenv("PEPSGPU_TILE16");
+  const int tile16 = t16s ? atoi(t16s) : 0;
 #define PG_CHAIN(a1, b1, a2)                                                                                                   \
   do {                                                                                                                         \
     if (f64acc && ldsf >= 8192) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 8192, 4, true>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
     else if (f64acc) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 4, true>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
+    else if (tile16 && ldsf == TG_CHAIN_LDS_FLOATS) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 6, false, false, true>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
     else if (s2pair && ldsf == TG_CHAIN_LDS_FLOATS) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 5, false, true>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
     else if (ldsf == 16384) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 16384, 2>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
     else if (ldsf == 8192) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 8192, 4>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
