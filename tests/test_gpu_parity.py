@@ -390,3 +390,64 @@ def test_truncation_by_error_dmin_dmax(dt, terr, tol):
                     kept_r = int(np.sum(np.any(data[w] != 0, axis=(0, 1))))
                     assert (kept_l, kept_r) == (t_ref.shape[0], t_ref.shape[2]), (level, idx, w)
         assert any(t.shape[0] < min(dmax, D ** 3) for c in comps for t in c.contractor.bmps_set[DOWN][3].tensors[1:])
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_plaquette_trace_second_bten2_set_and_slice_override(dt):
+    """The three calls behind the environment-reusing fermionic diagonal hop (round 5: pepsgpu_bten2_select_set,
+    pepsgpu_cfg_override_slice, pepsgpu_replace_plaquette_trace), on a BOSONIC state where every piece has an independent answer:
+    (a) the plaquette trace with the walkers' own states = psi; (b) with two replaced states on a diagonal = ReplaceNNNSiteTrace;
+    (c) environments of the second set grown while rows r and r + 1 read other states, closed with four replaced tensors = the
+    amplitude of the configuration with those two rows replaced (oracle); (d) the first set is untouched by all of it."""
+    from peps_amd import capi
+    L, D, chi = 5, 3, 27          # chi large enough that the two-row environments are exact
+    sitps = synthetic.make_sitps(L, D)
+    cfgs = synthetic.make_configs(L, 4, "heisenberg")
+    rng = np.random.default_rng(3)
+    ctx = _ctx(L, D, 2, chi, dt, len(cfgs))
+    _upload(ctx, sitps, D)
+    ctx.set_configs(cfgs)
+    psi = ctx.evaluate_amplitude()
+    tol = 50 * TOL[dt]
+    row, col = 1, 2
+    ctx.generate_bmps_approach(UP)
+    ctx.shift_bmps_window(DOWN)                                   # UP has absorbed row 0, DOWN rows 3, 4: the pair (1, 2) is open
+    ctx.grow_full_bten2(RIGHT, row, 2, True)
+    ctx.init_bten2(LEFT, row)
+    for _ in range(col):
+        ctx.grow_bten2_step(LEFT, row)
+    own = np.stack([cfgs[:, row, col], cfgs[:, row + 1, col], cfgs[:, row + 1, col + 1], cfgs[:, row, col + 1]], axis=-1)
+    a = ctx.replace_plaquette_trace(row, col, None, 0, 0)
+    assert np.max(np.abs(a / psi - 1)) < tol                                                   # (a)
+    assert np.max(np.abs(ctx.replace_plaquette_trace(row, col, own[:, None, :], 0, 0)[:, 0] / psi - 1)) < tol
+    swapped = own.copy()
+    swapped[:, 0], swapped[:, 2] = own[:, 2], own[:, 0]                                        # the two ends of the dr diagonal exchanged
+    b = ctx.replace_plaquette_trace(row, col, swapped[:, None, :], 0, 0)[:, 0]
+    nnn = ctx.replace_nnn_trace(row, col, capi.LEFTUP_TO_RIGHTDOWN, HORIZONTAL, np.stack([own[:, 2], own[:, 0]], axis=-1)[:, None, :])[:, 0]
+    assert np.max(np.abs(b - nnn)) < tol * np.max(np.abs(nnn))                                 # (b)
+    # (c): rows 1 and 2 under other states
+    new = cfgs.copy()
+    new[:, row, :] = rng.integers(0, 2, size=(len(cfgs), L))
+    new[:, row + 1, :] = rng.integers(0, 2, size=(len(cfgs), L))
+    ctx.bten2_select_set(1)
+    ctx.cfg_override_slice(HORIZONTAL, row, new[:, row, :])
+    ctx.grow_full_bten2(RIGHT, row, 2, True)            # the RIGHT chain reads row 1 from the override, row 2 from the walkers' table ...
+    ctx.cfg_override_slice(HORIZONTAL, row + 1, new[:, row + 1, :])
+    ctx.init_bten2(LEFT, row)
+    for _ in range(col):
+        ctx.grow_bten2_step(LEFT, row)                  # ... and the LEFT chain row 2 from the override, row 1 from the walkers' table
+    ctx.cfg_override_slice(HORIZONTAL, 0, None)
+    # so the network that is closed is: row 1 = new right of the plaquette / old left of it, row 2 = new left / old right, plaquette = cand
+    mixed = cfgs.copy()
+    mixed[:, row, col + 2:] = new[:, row, col + 2:]
+    mixed[:, row + 1, :col] = new[:, row + 1, :col]
+    cand = np.stack([new[:, row, col], new[:, row + 1, col], new[:, row + 1, col + 1], new[:, row, col + 1]], axis=-1)
+    mixed[:, row, col], mixed[:, row + 1, col], mixed[:, row + 1, col + 1], mixed[:, row, col + 1] = cand.T
+    c = ctx.replace_plaquette_trace(row, col, cand[:, None, :], 1, 1)[:, 0]
+    want = _oracle_amps(sitps, mixed, chi)
+    assert np.max(np.abs(c / want - 1)) < tol, (c, want)                                       # (c)
+    ctx.bten2_select_set(0)
+    assert np.max(np.abs(ctx.replace_plaquette_trace(row, col, None, 0, 0) / psi - 1)) < tol   # (d)
+    with pytest.raises((RuntimeError, ValueError)):
+        ctx.bten2_select_set(2)
+    ctx.close()
