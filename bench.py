@@ -932,6 +932,22 @@ def main():
                                                                    "share_above_1e-5": float(np.mean(rel > 1e-5)), "n": int(n64)}}
                     except Exception as e:
                         fr["f64_mode"] = {"error": repr(e)}
+                if real and world == 1 and not args.no_other_modes and dt == capi.F32:
+                    # the complex element type on the same state (a random phase on every tensor element): round 5's dense route of
+                    # Engine<cplx<double>> -- 6.6 amp/s before it, whatever the batch
+                    try:
+                        nc = min(512, fnw)
+                        cflat = fleg.flat * np.exp(2j * np.pi * np.random.default_rng(5).uniform(size=fleg.flat.shape))
+                        cc = capi.Context(L, L, D, 2, chi, dtype=capi.C128, device=local_rank, max_walkers=nc)
+                        cc.state_upload(cflat)
+                        cc.set_configs(fleg.batches[0][:32]); cc.evaluate_amplitude(); cc.sync()
+                        t0 = time.perf_counter()
+                        cc.set_configs(fleg.batches[0][:nc]); cc.evaluate_amplitude(); cc.sync()
+                        fr["complex128"] = {"amp_per_s": nc / (time.perf_counter() - t0), "walkers": nc,
+                                            "flagged_walkers": int(np.sum(cc.walker_flags() != 0))}
+                        cc.close()
+                    except Exception as e:
+                        fr["complex128"] = {"error": repr(e)}
                 if real and world == 1 and not args.no_sweeps:
                     try:       # what VMC consumes, on the state a VMC user has (fewer walkers: a sweep costs ~4 amplitudes)
                         fr["vmc"] = vmc_rates(fleg, min(args.real_sweep_walkers, fnw), args.real_sweep_count)

@@ -142,21 +142,145 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_simple(int pos, int num, const BMP
       g.wA = R[i].n; g.wB = Tt.n; g.wC = M.n; g.nbatch = nw_;
       tgemm_launch<T, T, T, T>(stream_, g, R[i].p, Tt.p, M.p);
     }
+    const int k = std::min(chi_, std::min(m, uk));
+    PG_REQUIRE(m <= 1024, 1, "bond dimension too large for select_rows_kernel");
+    DTen<T> V = alloc_ten(k, u, k2);
+    // ---- dense sites, complex element type (round 5): the oversampled two-level route of the float64 engine (engine_impl.h has the
+    // statement and the error argument) with the Hermitian forms: B^H B = M M^H, B2^H B2 = B B^H, rotated rows of B2 = sigma w^H,
+    // w^H B = sigma u^H, Z = U^H M, complex Jacobi on the 2 chi rows of Z.  The complex one-sided Jacobi on the 256 x 256 block was
+    // 96 % of a dense amplitude (6.6 amp/s at C4 whatever the batch).  Static shapes (this path has no live extents); walkers whose
+    // factors keep more than 128 or fewer than chi + 4 rows, or whom the guard rejects, take the general kernel as before.
+    int *rflag = nullptr;
     if constexpr (kCplx) {
-      hipLaunchKernelGGL(jacobi_rows_cplx_kernel<T>, dim3(nw_), dim3(1024), 0, stream_, M.p, M.n, m, uk, uk, 60, sweeps_);
+      static const bool no_route = getenv("PEPSGPU_NO_C128_DENSE_ROUTE") != nullptr;
+      const int kq = std::min(2 * k, (3 * std::min(m, uk)) / 4);
+      if (!no_route && trunc_err_ == 0.0 && m > 128 && m <= 256 && uk <= 256 && kq <= 64 && kq >= k + 8) {
+        const int gb = (nw_ + 255) / 256, route_lo = std::min(kq, k + 4);
+        constexpr double REDO_SCALE = 64.0;
+        rflag = (int *)arena_.alloc(sizeof(int) * nw_);
+        int *rowsM = (int *)arena_.alloc(sizeof(int) * nw_), *mB1 = (int *)arena_.alloc(sizeof(int) * nw_);
+        int *mB2 = (int *)arena_.alloc(sizeof(int) * nw_), *kW = (int *)arena_.alloc(sizeof(int) * nw_);
+        int *redo = (int *)arena_.alloc(sizeof(int) * nw_), *lvl = (int *)arena_.alloc(sizeof(int) * nw_);
+        PG_CHECK_HIP(hipMemsetAsync(mB1, 0, sizeof(int) * nw_, stream_));
+        PG_CHECK_HIP(hipMemsetAsync(mB2, 0, sizeof(int) * nw_, stream_));
+        PG_CHECK_HIP(hipMemsetAsync(kW, 0, sizeof(int) * nw_, stream_));
+        hipLaunchKernelGGL(f64_route_init_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)nullptr, 1, m, nw_, rowsM, rflag);
+        Acc *Gm = (Acc *)arena_.alloc(sizeof(Acc) * (size_t)m * m * nw_);
+        DTen<T> B1 = alloc_ten(m, m, 1);
+        auto gram_m = [&](const int *flag) {      // G = M M^H, upper triangle
+          TGemmDesc g;
+          g.I[2] = m; g.sAi[2] = uk; g.sCi[2] = m;
+          g.K[2] = uk; g.sAk[2] = 1; g.sBk[2] = 1;
+          g.J[2] = m; g.sBj[2] = uk; g.sCj[2] = 1;
+          g.wA = M.n; g.wB = M.n; g.wC = (long)m * m; g.nbatch = nw_;
+          g.conjB = 1;
+          g.upper_only = 1;
+          g.batch_flag = flag;
+          tgemm_launch<T, T, Acc, Acc>(stream_, g, M.p, M.p, Gm);
+        };
+        gram_m(nullptr);
+        hipLaunchKernelGGL(chol_upper_cplx_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (c128 *)Gm, (long)m * m, m, B1.p, B1.n, mB1,
+                           (const int *)nullptr, 1.0);
+        // second chance for the walkers whose factor kept more than 128 rows: pivot threshold x REDO_SCALE (the guard prices it)
+        hipLaunchKernelGGL(f64_route_redo_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)mB1, 128, nw_, redo, lvl);
+        gram_m(redo);
+        hipLaunchKernelGGL(chol_upper_cplx_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (c128 *)Gm, (long)m * m, m, B1.p, B1.n, mB1,
+                           (const int *)redo, REDO_SCALE);
+        hipLaunchKernelGGL(f64_route_redo_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)mB1, 128, nw_, redo, lvl, 2);
+        gram_m(redo);
+        hipLaunchKernelGGL(chol_upper_cplx_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (c128 *)Gm, (long)m * m, m, B1.p, B1.n, mB1,
+                           (const int *)redo, REDO_SCALE * REDO_SCALE);
+        PG_CHECK_HIP(hipGetLastError());
+        arena_.free(Gm);
+        hipLaunchKernelGGL(f64_route_check_kernel, dim3(gb), dim3(256), 0, stream_, rflag, mB1, route_lo, 128, nw_);
+        Acc *G2 = (Acc *)arena_.alloc(sizeof(Acc) * (size_t)128 * 128 * nw_);
+        PG_CHECK_HIP(hipMemsetAsync(G2, 0, sizeof(Acc) * (size_t)128 * 128 * nw_, stream_));   // (the factor kernel reads the full order)
+        DTen<T> B2 = alloc_ten(128, 128, 1);
+        {   // G2 = B B^H over the kept rows of B (<= 128; rows of B are m long)
+          TGemmDesc g;
+          g.I[2] = 128; g.sAi[2] = m; g.sCi[2] = 128;
+          g.K[2] = m; g.sAk[2] = 1; g.sBk[2] = 1;
+          g.J[2] = 128; g.sBj[2] = m; g.sCj[2] = 1;
+          g.wA = B1.n; g.wB = B1.n; g.wC = 128L * 128; g.nbatch = nw_;
+          g.dI[2].p = mB1; g.dJ[2].p = mB1;
+          g.conjB = 1;
+          g.upper_only = 1;
+          g.batch_flag = rflag;
+          tgemm_launch<T, T, Acc, Acc>(stream_, g, B1.p, B1.p, G2);
+        }
+        hipLaunchKernelGGL(chol_upper_cplx_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (c128 *)G2, 128L * 128, 128, B2.p, B2.n, mB2,
+                           (const int *)rflag, 1.0);
+        PG_CHECK_HIP(hipGetLastError());
+        arena_.free(G2);
+        hipLaunchKernelGGL(f64_route_check_kernel, dim3(gb), dim3(256), 0, stream_, rflag, mB2, route_lo, 128, nw_);
+        hipLaunchKernelGGL(jacobi_rows_cplx_kernel<T>, dim3(nw_), dim3(1024), 0, stream_, B2.p, B2.n, 128, 128, 128, 60, sweeps_,
+                           (const int *)rflag, 1);
+        PG_CHECK_HIP(hipGetLastError());
+        DTen<T> Wt = alloc_ten(kq, 128, 1), T1 = alloc_ten(kq, m, 1), Uq = alloc_ten(kq, m, 1), Zt = alloc_ten(kq, uk, 1);
+        hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)B2.p, B2.n, 128, 128, 128, kq, Wt.p, Wt.n,
+                           (T *)nullptr, 0L, (const int *)mB2, 1, kW, 0.0, 0, (double *)nullptr, (const int *)rflag, 1);
+        PG_CHECK_HIP(hipGetLastError());
+        {   // sigma_q u_q^H = w_q^H B
+          TGemmDesc g;
+          g.I[2] = kq; g.sAi[2] = 128; g.sCi[2] = m;
+          g.K[2] = 128; g.sAk[2] = 1; g.sBk[2] = m;
+          g.J[2] = m; g.sBj[2] = 1; g.sCj[2] = 1;
+          g.wA = Wt.n; g.wB = B1.n; g.wC = T1.n; g.nbatch = nw_;
+          g.dK[2].p = mB1;
+          g.batch_flag = rflag;
+          tgemm_launch<T, T, T, T>(stream_, g, Wt.p, B1.p, T1.p);
+        }
+        hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)T1.p, T1.n, kq, m, m, kq, Uq.p, Uq.n,
+                           (T *)nullptr, 0L, (const int *)kW, 1, (int *)nullptr, 0.0, 0, (double *)nullptr, (const int *)rflag, 1);
+        PG_CHECK_HIP(hipGetLastError());
+        {   // Z = U^H M (kq x uk)
+          TGemmDesc g;
+          g.I[2] = kq; g.sAi[2] = m; g.sCi[2] = uk;
+          g.K[2] = m; g.sAk[2] = 1; g.sBk[2] = uk;
+          g.J[2] = uk; g.sBj[2] = 1; g.sCj[2] = 1;
+          g.wA = Uq.n; g.wB = M.n; g.wC = Zt.n; g.nbatch = nw_;
+          g.batch_flag = rflag;
+          tgemm_launch<T, T, T, T>(stream_, g, Uq.p, M.p, Zt.p);
+        }
+        hipLaunchKernelGGL(jacobi_rows_cplx_kernel<T>, dim3(nw_), dim3(1024), 0, stream_, Zt.p, Zt.n, kq, uk, uk, 60, sweeps_,
+                           (const int *)rflag, 1);
+        hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)Zt.p, Zt.n, kq, uk, uk, k, V.p, V.n,
+                           (T *)nullptr, 0L, (const int *)kW, 1, (int *)nullptr, 0.0, chi_min_, (double *)nullptr, (const int *)rflag, 1);
+        static const double guard_tol = getenv("PEPSGPU_F64_ROUTE_TOL") ? atof(getenv("PEPSGPU_F64_ROUTE_TOL")) : 1e-10;
+        hipLaunchKernelGGL(f64_route_guard_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)Zt.p, Zt.n, uk, (const int *)kW, k, guard_tol,
+                           rflag, kq, (const int *)lvl, 5.7e-14 * REDO_SCALE, 5.7e-14 * REDO_SCALE * REDO_SCALE);
+        PG_CHECK_HIP(hipGetLastError());
+        if (dbg_sweeps_ && getenv("PEPSGPU_DEBUG_VERBOSE")) {   // diagnostics: who stays on the route
+          std::vector<int> hf(nw_), h1(nw_), h2(nw_), hk(nw_);
+          PG_CHECK_HIP(hipMemcpyAsync(hf.data(), rflag, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+          PG_CHECK_HIP(hipMemcpyAsync(h1.data(), mB1, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+          PG_CHECK_HIP(hipMemcpyAsync(h2.data(), mB2, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+          PG_CHECK_HIP(hipMemcpyAsync(hk.data(), kW, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+          PG_CHECK_HIP(hipStreamSynchronize(stream_));
+          long on = 0, s1 = 0, s2 = 0, sk = 0, z1 = 0, z2 = 0;
+          for (int w = 0; w < nw_; ++w) { on += hf[w] < 0; s1 += h1[w]; s2 += h2[w]; sk += hf[w] < 0 ? hk[w] : 0; z1 += h1[w] == 0; z2 += h2[w] == 0; }
+          fprintf(stderr, "[pepsgpu] c128 dense route site %d (m = %d, uk = %d, kq = %d): %ld of %d walkers on the route; first factor rows mean %.1f (%ld off), second %.1f (%ld off), kept directions mean %.1f\n",
+                  i, m, uk, kq, on, nw_, (double)s1 / nw_, z1, (double)s2 / nw_, z2, on ? (double)sk / on : 0.0);
+        }
+        free_ten(B1); free_ten(B2); free_ten(Wt); free_ten(T1); free_ten(Uq); free_ten(Zt);
+        arena_.free(rowsM); arena_.free(mB1); arena_.free(mB2); arena_.free(kW); arena_.free(redo); arena_.free(lvl);
+      }
+    }
+    // the general kernel: every walker, or -- behind the route -- the walkers that left it (rflag >= 0)
+    if constexpr (kCplx) {
+      hipLaunchKernelGGL(jacobi_rows_cplx_kernel<T>, dim3(nw_), dim3(1024), 0, stream_, M.p, M.n, m, uk, uk, 60, sweeps_,
+                         (const int *)rflag, 0);
     } else {
       hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), 0, stream_, M.p, M.n, m, uk, uk, 60, 0, sweeps_,
                          (const int *)nullptr, 1, 0);
     }
     PG_CHECK_HIP(hipGetLastError());
     ++n_jacobi_;
-    const int k = std::min(chi_, std::min(m, uk));
-    PG_REQUIRE(m <= 1024, 1, "bond dimension too large for select_rows_kernel");
-    DTen<T> V = alloc_ten(k, u, k2);
     hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)M.p, M.n, m, uk, uk, k, V.p, V.n,
                        (T *)nullptr, 0L, (const int *)nullptr, 1, (int *)nullptr, trunc_err_, chi_min_, (double *)nullptr,
-                       (const int *)nullptr, 1);
+                       (const int *)rflag, rflag ? 0 : 1);
     PG_CHECK_HIP(hipGetLastError());
+    if (rflag) { arena_.free(rflag); rflag = nullptr; }
     free_ten(M);
     out.t[i] = V;
     DTen<T> Yn = alloc_ten(l, a, k);

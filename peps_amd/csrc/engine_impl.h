@@ -802,6 +802,22 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           tgemm_launch<T, T, double, double>(stream_, g, M.p, M.p, Gm);
         }
         launch_chol_upper<T>(stream_, nw_, Gm, (long)GSd * GSd, GSd, B1.p, B1.n, mB1, 0, GSd, (const int *)rowsM, 1, (const int *)redo, REDO_SCALE);
+        // ... and a third one at REDO_SCALE^2 for what is still above 128 rows (flat spectra: the guard decides whether that is good enough)
+        hipLaunchKernelGGL(f64_route_redo_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)mB1, 128, nw_, redo, lvl, 2);
+        PG_CHECK_HIP(hipGetLastError());
+        {
+          TGemmDesc g;
+          g.I[2] = m; g.sAi[2] = uk; g.sCi[2] = GSd;
+          g.K[2] = uk; g.sAk[2] = 1; g.sBk[2] = 1;
+          g.J[2] = m; g.sBj[2] = uk; g.sCj[2] = 1;
+          g.wA = M.n; g.wB = M.n; g.wC = (long)GSd * GSd; g.nbatch = nw_;
+          g.dI[2].p = rowsM; g.dJ[2].p = rowsM;
+          g.upper_only = 1;
+          g.batch_flag = redo;
+          tgemm_launch<T, T, double, double>(stream_, g, M.p, M.p, Gm);
+        }
+        launch_chol_upper<T>(stream_, nw_, Gm, (long)GSd * GSd, GSd, B1.p, B1.n, mB1, 0, GSd, (const int *)rowsM, 1, (const int *)redo,
+                             REDO_SCALE * REDO_SCALE);
         arena_.free(redo);
         arena_.free(Gm);
         // walkers whose first factor kept more than 128 or fewer than kq rows leave the route
@@ -917,8 +933,8 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         prof_end();
         // guard (f64_route_guard_kernel): a spectrum that falls to the resolution of a Gram inside the subspace leaves the route
         static const double guard_tol = getenv("PEPSGPU_F64_ROUTE_TOL") ? atof(getenv("PEPSGPU_F64_ROUTE_TOL")) : 1e-10;
-        hipLaunchKernelGGL(f64_route_guard_kernel, dim3(nw_), dim3(256), 0, stream_, (const double *)Zt.p, Zt.n, uk, (const int *)kW, k_full,
-                           guard_tol, rflag, kq, (const int *)lvl, 5.7e-14 * REDO_SCALE);
+        hipLaunchKernelGGL(f64_route_guard_kernel<double>, dim3(nw_), dim3(256), 0, stream_, (const double *)Zt.p, Zt.n, uk, (const int *)kW, k_full,
+                           guard_tol, rflag, kq, (const int *)lvl, 5.7e-14 * REDO_SCALE, 5.7e-14 * REDO_SCALE * REDO_SCALE);
         PG_CHECK_HIP(hipGetLastError());
         if (dbg_sweeps_ && getenv("PEPSGPU_DEBUG_VERBOSE")) {   // diagnostics: who stays on the route, rows kept by the two compressions
           std::vector<int> hf(nw_), h0(nw_), hk(nw_);

@@ -1603,12 +1603,15 @@ __global__ void f64_route_init_kernel(const int *__restrict__ mdyn, int mdyn_mul
   flag[b] = -1;
 }
 // walkers whose first factor kept more than hi rows get a second factorisation with a higher pivot threshold: redo[b] = -1 (run), lvl[b] = 1
-__global__ void f64_route_redo_kernel(const int *__restrict__ rows, int hi, int nbatch, int *__restrict__ redo, int *__restrict__ lvl) {
+// (level 1 and level 2: the second and the third factorisation; lvl[b] keeps the highest level a walker was redone at)
+__global__ void f64_route_redo_kernel(const int *__restrict__ rows, int hi, int nbatch, int *__restrict__ redo, int *__restrict__ lvl,
+                                      int level = 1) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbatch) return;
   const bool again = rows[b] > hi;
   redo[b] = again ? -1 : 0;
-  lvl[b] = again ? 1 : 0;
+  if (level == 1) lvl[b] = again ? 1 : 0;
+  else if (again) lvl[b] = level;
 }
 // a walker whose factor kept fewer than lo or more than hi rows leaves the route; the row count of every walker off the route reads 0
 __global__ void f64_route_check_kernel(int *__restrict__ flag, int *__restrict__ rows, int lo, int hi, int nbatch) {
@@ -1624,18 +1627,20 @@ __global__ void f64_route_check_kernel(int *__restrict__ flag, int *__restrict__
 // that falls to the resolution of a Gram (2.4e-7 s_1) within the subspace -- leaves the route; the general Jacobi redoes it.
 // kq: the subspace dimension aimed at; a walker that kept fewer directions (its factors dropped the rest below the resolution of a
 // Gram, 2.4e-7 s_1) is priced with THAT as the strongest direction outside.
-__global__ __launch_bounds__(256) void f64_route_guard_kernel(const double *__restrict__ Zg, long wZ, int len, const int *__restrict__ kz,
+template <typename TZ>
+__global__ __launch_bounds__(256) void f64_route_guard_kernel(const TZ *__restrict__ Zg, long wZ, int len, const int *__restrict__ kz,
                                                               int k, double tol, int *__restrict__ flag, int kq,
-                                                              const int *__restrict__ lvl = nullptr, double lvl_floor2 = 0.0) {
+                                                              const int *__restrict__ lvl = nullptr, double lvl_floor2 = 0.0,
+                                                              double lvl2_floor2 = 0.0) {
   // lvl[b] != 0: the walker's first factor was taken with the raised pivot threshold -- what it dropped is up to sqrt(lvl_floor2) s_1
   const int b = blockIdx.x;
   if (flag[b] >= 0) return;
   __shared__ double s_n[64];
   const int rows = min(kz[b], 64), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const double *Z = Zg + (long)b * wZ;
+  const TZ *Z = Zg + (long)b * wZ;
   for (int r = wave; r < rows; r += 4) {
     double a = 0.0;
-    for (int c = lane; c < len; c += 64) { const double x = Z[(long)r * len + c]; a += x * x; }
+    for (int c = lane; c < len; c += 64) a += abs2_of(Z[(long)r * len + c]);
     a = wave_sum(a);
     if (lane == 0) s_n[r] = a;           // squared norms
   }
@@ -1652,7 +1657,7 @@ __global__ __launch_bounds__(256) void f64_route_guard_kernel(const double *__re
       if (larger == kk - 1) sk = s_n[r];
     }
     if (rows < kq) slast = fmax(slast, 5.7e-14 * s1);        // (squared norms: (2.4e-7)^2)
-    if (lvl && lvl[b]) slast = fmax(slast, lvl_floor2 * s1);
+    if (lvl && lvl[b]) slast = fmax(slast, (lvl[b] >= 2 ? lvl2_floor2 : lvl_floor2) * s1);
     const bool ok = rows >= k && s1 > 0.0 && sk > 0.0 && 3e-15 * (s1 / sk) * sqrt(slast / s1) <= tol;
     if (!ok) flag[b] = 0;
   }

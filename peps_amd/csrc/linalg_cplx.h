@@ -14,7 +14,10 @@ namespace pepsgpu {
 // in order, scaled by 1 / sqrt(max diag), then zero rows; mlive_out[b] (optional) = live count.
 template <typename T>
 __global__ __launch_bounds__(256) void chol_upper_cplx_kernel(c128 *__restrict__ Gg, long wG, int n, T *__restrict__ Rg, long wR,
-                                                              int *__restrict__ mlive_out) {
+                                                              int *__restrict__ mlive_out, const int *__restrict__ run_flag = nullptr,
+                                                              double thresh_scale = 1.0) {
+  // run_flag (optional): only the entries with run_flag[b] < 0; thresh_scale: multiplies the pivot threshold (dense route, round 5)
+  if (run_flag && run_flag[blockIdx.x] >= 0) return;
   __shared__ double s_red[4], s_maxd;
   __shared__ double s_piv[1024], s_nrm[1024];
   __shared__ short s_list[1024], s_pos[1024];
@@ -33,7 +36,7 @@ __global__ __launch_bounds__(256) void chol_upper_cplx_kernel(c128 *__restrict__
   __syncthreads();
   const double maxd = s_maxd;
   const double eT = NOISE_C * (double)Eps<T>::v;
-  const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
+  const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd * thresh_scale;
   for (int j = 0; j < n; ++j) {
     const double piv = G[(long)j * n + j].re;
     if (!(piv > thresh)) continue;                      // block-uniform
@@ -82,7 +85,10 @@ __global__ __launch_bounds__(256) void chol_upper_cplx_kernel(c128 *__restrict__
 // termination as jacobi_rows_kernel.
 template <typename T>
 __global__ __launch_bounds__(1024) void jacobi_rows_cplx_kernel(T *__restrict__ Mg, long wM, int m, int len, int ld, int max_sweeps,
-                                                                int *__restrict__ sweeps_out) {
+                                                                int *__restrict__ sweeps_out, const int *__restrict__ run_flag = nullptr,
+                                                                int run_if_neg = 1) {
+  // run_flag (optional): with run_if_neg = 1 only the entries with run_flag[b] < 0 run, with 0 only those with run_flag[b] >= 0
+  if (run_flag && ((run_flag[blockIdx.x] < 0) != (run_if_neg != 0))) return;
   typedef typename real_of<T>::type R;
   __shared__ int s_rot;
   __shared__ double s_fro[16];

@@ -171,3 +171,40 @@ print("RESULT " + json.dumps({"a": a.tolist(), "trunc_gram_launches": prof["trun
     print("f64 dense route vs general kernels: max rel diff %.2e (n = %d)" % (np.max(np.abs(a / b - 1)), len(a)))
     assert res["route"]["trunc_gram_launches"] > 0 and res["general"]["trunc_gram_launches"] == 0
     assert np.max(np.abs(a / b - 1)) < 2e-9
+
+
+def test_c128_dense_truncation_route_against_the_general_kernels():
+    """The same route for the COMPLEX element type (engine_cplx.h, round 5: Hermitian Gram + Cholesky compressions, complex Jacobi on
+    the small factor and on the 2 chi rows of Z = U^H M) against the general complex Jacobi (PEPSGPU_NO_C128_DENSE_ROUTE=1, subprocess):
+    8x8 tiled real state with a random phase on every tensor element, D = 8, chi = 32 -- amplitudes (complex) agree to 2e-9."""
+    import json
+    import subprocess
+    import sys
+    code = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+from peps_amd import capi, synthetic
+import test_gpu_realrank as t
+L, D, chi = 8, 8, 32
+flat = t._state(L)
+flat = flat * np.exp(2j * np.pi * np.random.default_rng(5).uniform(size=flat.shape))
+cfgs = synthetic.make_configs_near_neel(L, 12, seed0=11)
+ctx = capi.Context(L, L, D, 2, chi, dtype=capi.C128, max_walkers=len(cfgs))
+ctx.state_upload(flat)
+ctx.set_configs(cfgs)
+a = ctx.evaluate_amplitude()
+assert np.all(ctx.walker_flags() == 0)
+print("RESULT " + json.dumps({"re": a.real.tolist(), "im": a.imag.tolist()}))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for name, env in (("route", {}), ("general", {"PEPSGPU_NO_C128_DENSE_ROUTE": "1"})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=dict(os.environ, PYTHONPATH=root, **env),
+                           timeout=1500)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        d = json.loads([l for l in r.stdout.split("\n") if l.startswith("RESULT ")][0][7:])
+        res[name] = np.array(d["re"]) + 1j * np.array(d["im"])
+    rel = np.abs(res["route"] / res["general"] - 1)
+    print("c128 dense route vs general kernels: max rel diff %.2e (n = %d)" % (rel.max(), len(rel)))
+    assert rel.max() < 2e-9
