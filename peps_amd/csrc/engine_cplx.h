@@ -77,7 +77,7 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_simple(int pos, int num, const BMP
       g.conjA = 1;
       tgemm_launch<T, T, Acc, Acc>(stream_, g, P.p, P.p, G);
       if constexpr (kCplx) {
-        hipLaunchKernelGGL(chol_upper_cplx_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (c128 *)G, (long)cols * cols, cols,
+        hipLaunchKernelGGL(chol_upper_cplx_kernel<T>, dim3(nw_), dim3(1024), 0, stream_, (c128 *)G, (long)cols * cols, cols,
                            R[i + 1].p, R[i + 1].n, (int *)nullptr);
       } else {
         const size_t smem = chol_smem_bytes(cols);
@@ -179,16 +179,16 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_simple(int pos, int num, const BMP
           tgemm_launch<T, T, Acc, Acc>(stream_, g, M.p, M.p, Gm);
         };
         gram_m(nullptr);
-        hipLaunchKernelGGL(chol_upper_cplx_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (c128 *)Gm, (long)m * m, m, B1.p, B1.n, mB1,
+        hipLaunchKernelGGL(chol_upper_cplx_kernel<T>, dim3(nw_), dim3(1024), 0, stream_, (c128 *)Gm, (long)m * m, m, B1.p, B1.n, mB1,
                            (const int *)nullptr, 1.0);
         // second chance for the walkers whose factor kept more than 128 rows: pivot threshold x REDO_SCALE (the guard prices it)
         hipLaunchKernelGGL(f64_route_redo_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)mB1, 128, nw_, redo, lvl);
         gram_m(redo);
-        hipLaunchKernelGGL(chol_upper_cplx_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (c128 *)Gm, (long)m * m, m, B1.p, B1.n, mB1,
+        hipLaunchKernelGGL(chol_upper_cplx_kernel<T>, dim3(nw_), dim3(1024), 0, stream_, (c128 *)Gm, (long)m * m, m, B1.p, B1.n, mB1,
                            (const int *)redo, REDO_SCALE);
         hipLaunchKernelGGL(f64_route_redo_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)mB1, 128, nw_, redo, lvl, 2);
         gram_m(redo);
-        hipLaunchKernelGGL(chol_upper_cplx_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (c128 *)Gm, (long)m * m, m, B1.p, B1.n, mB1,
+        hipLaunchKernelGGL(chol_upper_cplx_kernel<T>, dim3(nw_), dim3(1024), 0, stream_, (c128 *)Gm, (long)m * m, m, B1.p, B1.n, mB1,
                            (const int *)redo, REDO_SCALE * REDO_SCALE);
         PG_CHECK_HIP(hipGetLastError());
         arena_.free(Gm);
@@ -208,7 +208,7 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_simple(int pos, int num, const BMP
           g.batch_flag = rflag;
           tgemm_launch<T, T, Acc, Acc>(stream_, g, B1.p, B1.p, G2);
         }
-        hipLaunchKernelGGL(chol_upper_cplx_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (c128 *)G2, 128L * 128, 128, B2.p, B2.n, mB2,
+        hipLaunchKernelGGL(chol_upper_cplx_kernel<T>, dim3(nw_), dim3(1024), 0, stream_, (c128 *)G2, 128L * 128, 128, B2.p, B2.n, mB2,
                            (const int *)rflag, 1.0);
         PG_CHECK_HIP(hipGetLastError());
         arena_.free(G2);

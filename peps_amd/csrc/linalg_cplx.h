@@ -13,26 +13,28 @@ namespace pepsgpu {
 // memory; a pivot below max(n eps64, (NOISE_C eps_T)^2) max(diag) drops its row.  Rout (n x n, type T): the live rows,
 // in order, scaled by 1 / sqrt(max diag), then zero rows; mlive_out[b] (optional) = live count.
 template <typename T>
-__global__ __launch_bounds__(256) void chol_upper_cplx_kernel(c128 *__restrict__ Gg, long wG, int n, T *__restrict__ Rg, long wR,
+__global__ __launch_bounds__(1024) void chol_upper_cplx_kernel(c128 *__restrict__ Gg, long wG, int n, T *__restrict__ Rg, long wR,
                                                               int *__restrict__ mlive_out, const int *__restrict__ run_flag = nullptr,
                                                               double thresh_scale = 1.0) {
   // run_flag (optional): only the entries with run_flag[b] < 0; thresh_scale: multiplies the pivot threshold (dense route, round 5)
   if (run_flag && run_flag[blockIdx.x] >= 0) return;
-  __shared__ double s_red[4], s_maxd;
+  // (any block size up to 1024: round 5 launches 1024 threads -- a pivot step is one barrier whatever the width, and the trailing
+  // update of an order-256 matrix has 255 rows to hand out)
+  __shared__ double s_red[16], s_maxd;
   __shared__ double s_piv[1024], s_nrm[1024];
   __shared__ short s_list[1024], s_pos[1024];
   __shared__ int s_nl, s_cnt;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwv = blockDim.x >> 6, nth = blockDim.x;
   c128 *G = Gg + (long)blockIdx.x * wG;
   T *R = Rg + (long)blockIdx.x * wR;
   double md = 0.0;
-  for (int i = tid; i < n; i += 256) md = fmax(md, G[(long)i * n + i].re);
+  for (int i = tid; i < n; i += nth) md = fmax(md, G[(long)i * n + i].re);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
   if (lane == 0) s_red[wave] = md;
   if (tid == 0) s_nl = 0;
   __syncthreads();
-  if (tid == 0) s_maxd = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+  if (tid == 0) { double t = 0.0; for (int w = 0; w < nwv; ++w) t = fmax(t, s_red[w]); s_maxd = t; }
   __syncthreads();
   const double maxd = s_maxd;
   const double eT = NOISE_C * (double)Eps<T>::v;
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void chol_upper_cplx_kernel(c128 *__restrict__
     if (!(piv > thresh)) continue;                      // block-uniform
     if (tid == 0) { s_piv[s_nl] = piv; s_list[s_nl] = (short)j; s_nl = s_nl + 1; }
     const double invp = 1.0 / piv;
-    for (int i = j + 1 + wave; i < n; i += 4) {         // G[i][r] -= conj(G[j][i]) G[j][r] / piv,  r >= i
+    for (int i = j + 1 + wave; i < n; i += nwv) {         // G[i][r] -= conj(G[j][i]) G[j][r] / piv,  r >= i
       const c128 f = conj_of(G[(long)j * n + i]) * invp;
       for (int r = i + lane; r < n; r += 64) G[(long)i * n + r] -= f * G[(long)j * n + r];
     }
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(256) void chol_upper_cplx_kernel(c128 *__restrict__
   }
   __syncthreads();
   const int nl = s_nl;
-  for (int q = wave; q < nl; q += 4) {
+  for (int q = wave; q < nl; q += nwv) {
     const int j = s_list[q];
     double a = 0.0;
     for (int r = j + lane; r < n; r += 64) a += abs2_of(G[(long)j * n + r]);
@@ -69,14 +71,14 @@ __global__ __launch_bounds__(256) void chol_upper_cplx_kernel(c128 *__restrict__
   }
   __syncthreads();
   const double sc = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
-  for (int q = wave; q < nl; q += 4) {
+  for (int q = wave; q < nl; q += nwv) {
     const int pos = s_pos[q];
     if (pos < 0) continue;
     const int j = s_list[q];
     const double f = sc / sqrt(s_piv[q]);
     for (int r = lane; r < n; r += 64) R[(long)pos * n + r] = r >= j ? T(scaled(G[(long)j * n + r], f)) : T(0);
   }
-  for (int e = tid + s_cnt * n; e < n * n; e += 256) R[e] = T(0);
+  for (int e = tid + s_cnt * n; e < n * n; e += nth) R[e] = T(0);
 }
 
 // One-sided Jacobi on the rows of a complex M (m x len, row stride ld) in global memory: round-robin tournament, one wave per
