@@ -179,17 +179,18 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_simple(int pos, int num, const BMP
           tgemm_launch<T, T, Acc, Acc>(stream_, g, M.p, M.p, Gm);
         };
         gram_m(nullptr);
+        static const double tscale = getenv("PEPSGPU_ROUTE_THRESH_SCALE") ? atof(getenv("PEPSGPU_ROUTE_THRESH_SCALE")) : 1.0;
         hipLaunchKernelGGL(chol_upper_cplx_kernel<T>, dim3(nw_), dim3(1024), 0, stream_, (c128 *)Gm, (long)m * m, m, B1.p, B1.n, mB1,
-                           (const int *)nullptr, 1.0);
+                           (const int *)nullptr, tscale);
         // second chance for the walkers whose factor kept more than 128 rows: pivot threshold x REDO_SCALE (the guard prices it)
         hipLaunchKernelGGL(f64_route_redo_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)mB1, 128, nw_, redo, lvl);
         gram_m(redo);
         hipLaunchKernelGGL(chol_upper_cplx_kernel<T>, dim3(nw_), dim3(1024), 0, stream_, (c128 *)Gm, (long)m * m, m, B1.p, B1.n, mB1,
-                           (const int *)redo, REDO_SCALE);
+                           (const int *)redo, tscale * REDO_SCALE);
         hipLaunchKernelGGL(f64_route_redo_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)mB1, 128, nw_, redo, lvl, 2);
         gram_m(redo);
         hipLaunchKernelGGL(chol_upper_cplx_kernel<T>, dim3(nw_), dim3(1024), 0, stream_, (c128 *)Gm, (long)m * m, m, B1.p, B1.n, mB1,
-                           (const int *)redo, REDO_SCALE * REDO_SCALE);
+                           (const int *)redo, tscale * REDO_SCALE * REDO_SCALE);
         PG_CHECK_HIP(hipGetLastError());
         arena_.free(Gm);
         hipLaunchKernelGGL(f64_route_check_kernel, dim3(gb), dim3(256), 0, stream_, rflag, mB1, route_lo, 128, nw_);
@@ -248,7 +249,8 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_simple(int pos, int num, const BMP
                            (T *)nullptr, 0L, (const int *)kW, 1, (int *)nullptr, 0.0, chi_min_, (double *)nullptr, (const int *)rflag, 1);
         static const double guard_tol = getenv("PEPSGPU_F64_ROUTE_TOL") ? atof(getenv("PEPSGPU_F64_ROUTE_TOL")) : 1e-10;
         hipLaunchKernelGGL(f64_route_guard_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)Zt.p, Zt.n, uk, (const int *)kW, k, guard_tol,
-                           rflag, kq, (const int *)lvl, 5.7e-14 * REDO_SCALE, 5.7e-14 * REDO_SCALE * REDO_SCALE);
+                           rflag, kq, (const int *)lvl, 5.7e-14 * tscale * REDO_SCALE, 5.7e-14 * tscale * REDO_SCALE * REDO_SCALE, 5.7e-14 * tscale,
+                           tscale > 1.0 ? 1 : 0);
         PG_CHECK_HIP(hipGetLastError());
         if (dbg_sweeps_ && getenv("PEPSGPU_DEBUG_VERBOSE")) {   // diagnostics: who stays on the route
           std::vector<int> hf(nw_), h1(nw_), h2(nw_), hk(nw_);

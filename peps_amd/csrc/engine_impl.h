@@ -781,7 +781,10 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           g.upper_only = 1;
           tgemm_launch<T, T, double, double>(stream_, g, M.p, M.p, Gm);
         }
-        launch_chol_upper<T>(stream_, nw_, Gm, (long)GSd * GSd, GSd, B1.p, B1.n, mB1, 0, GSd, (const int *)rowsM, 1, (const int *)nullptr);
+        // (PEPSGPU_ROUTE_THRESH_SCALE: the pivot threshold of the first factorisation for EVERY walker, an experiment knob: fewer kept
+        // rows = smaller Jacobi problems, priced by the guard)
+        static const double tscale = getenv("PEPSGPU_ROUTE_THRESH_SCALE") ? atof(getenv("PEPSGPU_ROUTE_THRESH_SCALE")) : 1.0;
+        launch_chol_upper<T>(stream_, nw_, Gm, (long)GSd * GSd, GSd, B1.p, B1.n, mB1, 0, GSd, (const int *)rowsM, 1, (const int *)nullptr, tscale);
         // Second chance for the walkers whose factor kept more than 128 rows (1-3 of 1 024 per site on the real state -- each of them
         // would otherwise cost a whole general Jacobi, ~40 ms per site whatever the batch): the Gram again (the factorisation works in
         // place) and the factor with the pivot threshold REDO_SCALE times higher, i.e. directions below sqrt(REDO_SCALE) 2.4e-7 s_1
@@ -801,7 +804,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           g.batch_flag = redo;
           tgemm_launch<T, T, double, double>(stream_, g, M.p, M.p, Gm);
         }
-        launch_chol_upper<T>(stream_, nw_, Gm, (long)GSd * GSd, GSd, B1.p, B1.n, mB1, 0, GSd, (const int *)rowsM, 1, (const int *)redo, REDO_SCALE);
+        launch_chol_upper<T>(stream_, nw_, Gm, (long)GSd * GSd, GSd, B1.p, B1.n, mB1, 0, GSd, (const int *)rowsM, 1, (const int *)redo, tscale * REDO_SCALE);
         // ... and a third one at REDO_SCALE^2 for what is still above 128 rows (flat spectra: the guard decides whether that is good enough)
         hipLaunchKernelGGL(f64_route_redo_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)mB1, 128, nw_, redo, lvl, 2);
         PG_CHECK_HIP(hipGetLastError());
@@ -817,7 +820,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           tgemm_launch<T, T, double, double>(stream_, g, M.p, M.p, Gm);
         }
         launch_chol_upper<T>(stream_, nw_, Gm, (long)GSd * GSd, GSd, B1.p, B1.n, mB1, 0, GSd, (const int *)rowsM, 1, (const int *)redo,
-                             REDO_SCALE * REDO_SCALE);
+                             tscale * REDO_SCALE * REDO_SCALE);
         arena_.free(redo);
         arena_.free(Gm);
         // walkers whose first factor kept more than 128 or fewer than kq rows leave the route
@@ -934,7 +937,8 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         // guard (f64_route_guard_kernel): a spectrum that falls to the resolution of a Gram inside the subspace leaves the route
         static const double guard_tol = getenv("PEPSGPU_F64_ROUTE_TOL") ? atof(getenv("PEPSGPU_F64_ROUTE_TOL")) : 1e-10;
         hipLaunchKernelGGL(f64_route_guard_kernel<double>, dim3(nw_), dim3(256), 0, stream_, (const double *)Zt.p, Zt.n, uk, (const int *)kW, k_full,
-                           guard_tol, rflag, kq, (const int *)lvl, 5.7e-14 * REDO_SCALE, 5.7e-14 * REDO_SCALE * REDO_SCALE);
+                           guard_tol, rflag, kq, (const int *)lvl, 5.7e-14 * tscale * REDO_SCALE, 5.7e-14 * tscale * REDO_SCALE * REDO_SCALE,
+                           5.7e-14 * tscale, tscale > 1.0 ? 1 : 0);
         PG_CHECK_HIP(hipGetLastError());
         if (dbg_sweeps_ && getenv("PEPSGPU_DEBUG_VERBOSE")) {   // diagnostics: who stays on the route, rows kept by the two compressions
           std::vector<int> hf(nw_), h0(nw_), hk(nw_);

@@ -1631,7 +1631,9 @@ template <typename TZ>
 __global__ __launch_bounds__(256) void f64_route_guard_kernel(const TZ *__restrict__ Zg, long wZ, int len, const int *__restrict__ kz,
                                                               int k, double tol, int *__restrict__ flag, int kq,
                                                               const int *__restrict__ lvl = nullptr, double lvl_floor2 = 0.0,
-                                                              double lvl2_floor2 = 0.0) {
+                                                              double lvl2_floor2 = 0.0, double base_floor2 = 5.7e-14, int base_always = 0) {
+  // base_floor2: (relative, squared) what the FIRST factorisation drops -- (2.4e-7)^2 at the default pivot threshold; base_always: it
+  // was raised for every walker (PEPSGPU_ROUTE_THRESH_SCALE), so it bounds the strongest direction outside whatever was kept
   // lvl[b] != 0: the walker's first factor was taken with the raised pivot threshold -- what it dropped is up to sqrt(lvl_floor2) s_1
   const int b = blockIdx.x;
   if (flag[b] >= 0) return;
@@ -1656,7 +1658,7 @@ __global__ __launch_bounds__(256) void f64_route_guard_kernel(const TZ *__restri
       for (int q = 0; q < rows; ++q) larger += (s_n[q] > s_n[r]) || (s_n[q] == s_n[r] && q < r);
       if (larger == kk - 1) sk = s_n[r];
     }
-    if (rows < kq) slast = fmax(slast, 5.7e-14 * s1);        // (squared norms: (2.4e-7)^2)
+    if (rows < kq || base_always) slast = fmax(slast, base_floor2 * s1);        // (squared norms)
     if (lvl && lvl[b]) slast = fmax(slast, (lvl[b] >= 2 ? lvl2_floor2 : lvl_floor2) * s1);
     const bool ok = rows >= k && s1 > 0.0 && sk > 0.0 && 3e-15 * (s1 / sk) * sqrt(slast / s1) <= tol;
     if (!ok) flag[b] = 0;
