@@ -130,8 +130,9 @@ class SquareSpinlessFermionOBC:
         e = 0.0
         psis = []
         if bonds is not None:
-            bonds.update(h=np.zeros((rows, cols - 1)), v=np.zeros((rows - 1, cols)), dr=np.zeros((rows - 1, cols - 1)),
-                         ur=np.zeros((rows - 1, cols - 1)))
+            dt = np.result_type(fs.ext[0][0][0].dtype, np.float64)      # QLTEN_Complex states: complex local estimators
+            bonds.update(h=np.zeros((rows, cols - 1), dt), v=np.zeros((rows - 1, cols), dt), dr=np.zeros((rows - 1, cols - 1), dt),
+                         ur=np.zeros((rows - 1, cols - 1), dt))
         # ---- row pass: horizontal bonds (square_nnn_energy_solver.h:116-201)
         comp = fs.component(cfg, ROW, trun_para)
         tn, c = comp.tn, comp.contractor
@@ -328,7 +329,7 @@ def exact_sum_measure(fs, all_configs, trun_para, model, rank=0, size=1):
         w = abs(fs.amplitude(cfg, trun_para)) ** 2
         wsum += w
         for key, vals in model.EvaluateObservables(fs, cfg, trun_para).items():
-            acc[key] = acc.get(key, 0.0) + w * np.asarray(vals, dtype=np.float64)
+            acc[key] = acc.get(key, 0.0) + w * np.asarray(vals)
     if size > 1:
         return acc, wsum
     if not wsum > 0.0:

@@ -576,8 +576,9 @@ class SquareNNNModelMeasurementSolver:
         c.SetTruncateParams(comp.trun_para)
         if self.xxz:
             out["spin_z"] = [float(v) - 0.5 for v in config.ravel()]
-        e_h = np.zeros((ly, lx - 1)); e_v = np.zeros((ly - 1, lx))
-        e_dr = np.zeros((ly - 1, lx - 1)); e_ur = np.zeros((ly - 1, lx - 1))
+        dt = complex if np.iscomplexobj(sitps[0][0][0]) else float      # TenElemT of the registry (ObservableMap<TenElemT>)
+        e_h = np.zeros((ly, lx - 1), dt); e_v = np.zeros((ly - 1, lx), dt)
+        e_dr = np.zeros((ly - 1, lx - 1), dt); e_ur = np.zeros((ly - 1, lx - 1), dt)
         total, psi_list = 0.0, []
         c.GenerateBMPSApproach(tn, UP)
         for row in range(ly):
@@ -821,7 +822,7 @@ def exact_sum_measure(sitps, all_configs, trun_para, make_solver, rank=0, size=1
         w = abs(comp.amplitude) ** 2
         wsum += w
         for key, vals in make_solver().EvaluateObservables(sitps, comp).items():
-            acc[key] = acc.get(key, 0.0) + w * np.asarray(vals, dtype=np.float64).ravel()
+            acc[key] = acc.get(key, 0.0) + w * np.asarray(vals).ravel()
     if size > 1:
         return acc, wsum
     if not wsum > 0.0:

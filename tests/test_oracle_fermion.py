@@ -221,3 +221,29 @@ def test_reference_spinless_fermion_measurer_t2_sweep_and_lowest_state_observabl
                 assert np.max(np.abs(obs["charge"] - 0.5)) < 1e-5
                 assert np.max(np.abs(obs["bond_energy_h"])) < 1e-5 and np.max(np.abs(obs["bond_energy_v"])) < 1e-5
                 assert abs(obs["bond_energy_dr"][0] + 2.1) < 1e-5 and abs(obs["bond_energy_ur"][0] + 2.1) < 1e-5
+
+
+@pytest.mark.parametrize("t2,name,e_lowest,e_su", CASES)
+def test_complex_fixtures_reproduce_reference_energies(fixtures_dir, t2, name, e_lowest, e_su):
+    """The QLTEN_Complex build of the same reference test (tests/CMakeLists.txt:369-383 compiles test_exact_summation_evaluator.cpp for both
+    element types; `_complexlowest` / `_complex_from_simple_update` fixtures, :306-330): the same six energies from complex tensors, imaginary
+    part of the energy zero (the reference asserts |Im| < 1e-10 on the measurer side, test_exact_summation_measurer.cpp:219-257)."""
+    tp = BMPSTruncateParams.SVD(8, 8, 0.0)
+    for suffix, ref in (("lowest", e_lowest), ("_from_simple_update", e_su)):
+        gts = fermion.load_fermion_sitps(os.path.join(fixtures_dir, "spinless_fermion_tps_t2_%s_complex%s" % (name, suffix)), complex_data=True)
+        fs = fermion.FermionSITPS(gts)
+        e = fermion.exact_sum_energy(fs, _half_filling_configs(), tp, fermion.SquareSpinlessFermionOBC(1.0, t2, 0.0))
+        assert abs(e - ref) < 1e-9 and abs(np.imag(e)) < 1e-10
+    assert np.max(np.abs(gts[0][0][0].arr.imag)) > 0.1            # the simple-update fixture really is complex
+
+
+def test_exact_sum_measurer_registry_on_the_complex_fixture(fixtures_dir):
+    """test_exact_summation_measurer.cpp:243-257 (QLTEN_Complex branch): the complex simple-update state gives the real build's registry
+    (the two lists of that test agree to 1e-15) with zero imaginary parts."""
+    tp = BMPSTruncateParams.SVD(8, 8, 1e-16)
+    gts = fermion.load_fermion_sitps(os.path.join(fixtures_dir, "spinless_fermion_tps_t2_0.000000_complex_from_simple_update"), complex_data=True)
+    obs = fermion.exact_sum_measure(fermion.FermionSITPS(gts), _half_filling_configs(), tp, fermion.SquareSpinlessFermionOBC(1.0, 0.0, 0.0))
+    assert set(obs) == set(MEASURER_GOLDEN)
+    for key, want in MEASURER_GOLDEN.items():
+        assert np.max(np.abs(obs[key] - np.array(want))) < 1e-10, key                 # kTol
+        assert np.max(np.abs(np.imag(obs[key]))) < 1e-10, key                         # kImagTol

@@ -246,3 +246,28 @@ def test_reference_tfim_exact_sum_measurer_registry(fixtures_dir):
     obs = vmc.exact_sum_measure(qlten_io.load_sitps(os.path.join(fixtures_dir, "transverse_ising_tps_doublelowest")), cfgs, tp, make)
     for key, want in gold["lowest"].items():
         assert np.max(np.abs(np.asarray(obs[key]) - np.asarray(want))) < (6e-8 if key == "energy" else 1e-5), key
+
+
+def test_reference_measurer_registries_on_the_complex_fixtures(fixtures_dir):
+    """The QLTEN_Complex build of test_exact_summation_measurer.cpp (tests/CMakeLists.txt:385-398; `_complex_from_simple_update` /
+    `_complexlowest` fixtures, :419-424, :559-564): Heisenberg and TFIM registries of the complex 2x2 states equal the numbers of the real build
+    (the reference lists them separately, :486-507 and :612-623; they agree with the real lists to 1e-15) at 1e-10, imaginary parts below 1e-10."""
+    import json
+    import os
+    from oracle import qlten_io
+    tp = BMPSTruncateParams.SVD(1, 8, 1e-16)
+    cases = [("k4_heisenberg_exact_sum_measurer.json", "heisenberg_tps", vmc.generate_all_permutation_configs([2, 2], 2, 2),
+              lambda: vmc.SquareNNNModelMeasurementSolver(vmc.SquareSpinOneHalfXXZModelOBC(1.0, 1.0, 0.0)), {"energy": 6e-8, "spin_z": 5e-4}),
+             ("k4_tfim_exact_sum_measurer.json", "transverse_ising_tps", vmc.generate_all_binary_configs(2, 2),
+              lambda: vmc.TransverseFieldIsingSquareOBC(1.0), {"energy": 6e-8})]
+    for gold_file, stem, cfgs, make, lowest_tol in cases:
+        gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", gold_file)))
+        s = qlten_io.load_sitps(os.path.join(fixtures_dir, stem + "_complex_from_simple_update"), complex_data=True)
+        assert np.max(np.abs(np.imag(s[0][0][0]))) > 1e-3
+        obs = vmc.exact_sum_measure(s, cfgs, tp, make)
+        for key, want in gold["observables"].items():
+            assert np.max(np.abs(np.asarray(obs[key]) - np.asarray(want))) < 1e-10, key
+            assert np.max(np.abs(np.imag(obs[key]))) < 1e-10, key
+        obs = vmc.exact_sum_measure(qlten_io.load_sitps(os.path.join(fixtures_dir, stem + "_complexlowest"), complex_data=True), cfgs, tp, make)
+        for key, want in gold["lowest"].items():
+            assert np.max(np.abs(np.asarray(obs[key]) - np.asarray(want))) < lowest_tol.get(key, 1e-5), key
