@@ -27,8 +27,9 @@ ROW, COL = 0, 1
 NVAR = 4
 
 
-def _read_qlten_z2(path):
-    """one fZ2 .qlten file -> (dense array, [parity vector per leg], [direction per leg]); format: SURVEY 8c"""
+def _read_qlten_z2(path, complex_data=False):
+    """one fZ2 .qlten file -> (dense array, [parity vector per leg], [direction per leg]); format: SURVEY 8c.
+    complex_data: QLTEN_Complex payload (interleaved complex128)"""
     with open(path, "rb") as f:
         buf = f.read()
     pos = 0
@@ -55,13 +56,14 @@ def _read_qlten_z2(path):
     nblocks = int(tok())
     blocks = [[int(tok()) for _ in range(rank)] for _ in range(nblocks)]
     shape = tuple(sum(s[1] for s in secs) for secs, _ in legs)
-    out = np.zeros(shape, dtype=np.float64)
+    out = np.zeros(shape, dtype=np.complex128 if complex_data else np.float64)
+    item = 16 if complex_data else 8
     offs = [np.concatenate([[0], np.cumsum([s[1] for s in secs])]) for secs, _ in legs]
     for c in blocks:
         bshape = tuple(legs[k][0][c[k]][1] for k in range(rank))
         n = int(np.prod(bshape))
-        data = np.frombuffer(buf, dtype="<f8", count=n, offset=pos)
-        pos += n * 8
+        data = np.frombuffer(buf, dtype="<c16" if complex_data else "<f8", count=n, offset=pos)
+        pos += n * item
         out[tuple(slice(offs[k][c[k]], offs[k][c[k] + 1]) for k in range(rank))] = data.reshape(bshape)
     par = [np.concatenate([np.full(deg, qn % 2, dtype=np.int64) for qn, deg in secs]) for secs, _ in legs]
     return out, par, [d for _, d in legs]
@@ -82,8 +84,9 @@ class FermionState:
                         raise ValueError("site tensor (%d, %d, state %d) is not parity even" % (r, c, s))
 
     @staticmethod
-    def load(directory):
-        """SplitIndexTPS<.., fZ2QN>::Load layout: tps_meta.txt + tps_ten{r}_{c}_{s}.qlten, rank-5 tensors (L, D, R, U, parity)"""
+    def load(directory, complex_data=False):
+        """SplitIndexTPS<.., fZ2QN>::Load layout: tps_meta.txt + tps_ten{r}_{c}_{s}.qlten, rank-5 tensors (L, D, R, U, parity);
+        complex_data: a SplitIndexTPS<QLTEN_Complex, fZ2QN> dump"""
         with open(os.path.join(directory, "tps_meta.txt")) as f:
             toks = f.read().split()
         rows, cols, d = int(toks[0]), int(toks[1]), int(toks[2])
@@ -92,7 +95,7 @@ class FermionState:
             for c in range(cols):
                 comp = []
                 for s in range(d):
-                    a, p, dirs = _read_qlten_z2(os.path.join(directory, "tps_ten%d_%d_%d.qlten" % (r, c, s)))
+                    a, p, dirs = _read_qlten_z2(os.path.join(directory, "tps_ten%d_%d_%d.qlten" % (r, c, s)), complex_data)
                     if a.ndim != 5 or tuple(dirs) != (-1, 1, 1, -1, -1) or a.shape[4] != 1:
                         raise ValueError("expected rank-5 fermionic site tensors (L, D, R, U, parity)")
                     if par[r][c] is None:
@@ -109,9 +112,14 @@ class FermionState:
     def D(self):
         return max(max(t[0].shape) for row in self.tensors for t in row)
 
-    def extended_flat(self, D=None, dtype=np.float64):
-        """upload buffer [row][col][4 d][D][D][D][D] of the decorated components (legs zero padded to D)"""
+    @property
+    def is_complex(self):
+        return np.iscomplexobj(self.tensors[0][0][0])
+
+    def extended_flat(self, D=None, dtype=None):
+        """upload buffer [row][col][4 d][D][D][D][D] of the decorated components (legs zero padded to D); element type of the state"""
         D = D or self.D
+        dtype = dtype or (np.complex128 if self.is_complex else np.float64)
         out = np.zeros((self.rows, self.cols, NVAR * self.d, D, D, D, D), dtype=dtype)
         for r in range(self.rows):
             for c in range(self.cols):
@@ -165,7 +173,7 @@ def fold_gradient(state, grad_ext):
     dE/dT''[s + d var]; parity-forbidden entries (not parameters of a Z2-symmetric state) are zeroed."""
     rows, cols, d = state.rows, state.cols, state.d
     D = grad_ext.shape[3]
-    out = np.zeros((rows, cols, d, D, D, D, D))
+    out = np.zeros((rows, cols, d, D, D, D, D), dtype=grad_ext.dtype)
     for r in range(rows):
         for c in range(cols):
             pl, pd, pr, pu = state.par[r][c]
@@ -177,7 +185,7 @@ def fold_gradient(state, grad_ext):
                 base = (u * n + u + dd * rr + l + l * u) % 2
                 allowed = ((l + dd + rr + u + n) % 2 == 0)
                 signs = (np.ones(shp), 1 - 2 * (u % 2) + np.zeros(shp), 1 - 2 * base + np.zeros(shp), 1 - 2 * ((base + l) % 2) + np.zeros(shp))
-                acc = np.zeros(shp)
+                acc = np.zeros(shp, dtype=grad_ext.dtype)
                 for var in range(NVAR):
                     acc += signs[var] * grad_ext[(r, c, s + d * var) + sl]
                 out[(r, c, s) + sl] = acc * allowed
@@ -237,9 +245,10 @@ def nnn_hop_energy_local(ctx, state, configs, t2, bonds=None):
     occ = (np.asarray(state.nf)[cfg] % 2).reshape(n, -1)
     ext = state.ext_config(cfg, ROW)
     flip = np.where(ext // d == 0, ext + d, ext - d).astype(np.int32)       # variant 0 <-> 1 (row-major variants)
-    e = np.zeros(n)
+    dt = np.complex128 if state.is_complex else np.float64
+    e = np.zeros(n, dt)
     if bonds is not None:
-        bonds.update(dr=np.zeros((n, rows - 1, cols - 1)), ur=np.zeros((n, rows - 1, cols - 1)))
+        bonds.update(dr=np.zeros((n, rows - 1, cols - 1), dt), ur=np.zeros((n, rows - 1, cols - 1), dt))
     if cols < 2 or rows < 2:
         return e
     ctx.set_configs(ext)
@@ -273,7 +282,7 @@ def nnn_hop_energy_local(ctx, state, configs, t2, bonds=None):
                 if any(t[1].any() for t in terms):
                     psi_ex = ctx.replace_plaquette_trace(row, col, np.stack(cands, axis=1), 1, 1)
                     for k, (key, differ, jw) in enumerate(terms):
-                        eb = np.where(differ, -t2 * jw * psi_ex[:, k] / np.where(psi == 0, 1.0, psi), 0.0)
+                        eb = np.where(differ, -t2 * jw * np.conj(psi_ex[:, k] / np.where(psi == 0, 1.0, psi)), 0.0)
                         e += eb
                         if bonds is not None:
                             bonds[key][:, row, col] = eb
@@ -302,9 +311,10 @@ def nnn_hop_energy(ctx, state, configs, t2, bonds=None):
     n, rows, cols = cfg.shape
     occ = (np.asarray(state.nf)[cfg] % 2).reshape(n, -1)
     psi0 = evaluate_amplitude(ctx, state, cfg)
-    e = np.zeros(n)
+    dt = np.complex128 if state.is_complex else np.float64
+    e = np.zeros(n, dt)
     if bonds is not None:
-        bonds.update(dr=np.zeros((n, rows - 1, cols - 1)), ur=np.zeros((n, rows - 1, cols - 1)))
+        bonds.update(dr=np.zeros((n, rows - 1, cols - 1), dt), ur=np.zeros((n, rows - 1, cols - 1), dt))
     for row in range(rows - 1):
         for col in range(cols - 1):
             for key, a, b in (("dr", (row, col), (row + 1, col + 1)), ("ur", (row + 1, col), (row, col + 1))):
@@ -315,7 +325,7 @@ def nnn_hop_energy(ctx, state, configs, t2, bonds=None):
                 jw = (-1.0) ** occ[:, ia + 1:ib].sum(axis=1)
                 new = cfg.copy()
                 new[:, a[0], a[1]], new[:, b[0], b[1]] = cfg[:, b[0], b[1]], cfg[:, a[0], a[1]]
-                eb = np.where(differ, -t2 * jw * evaluate_amplitude(ctx, state, new) / np.where(psi0 == 0, 1.0, psi0), 0.0)
+                eb = np.where(differ, -t2 * jw * np.conj(evaluate_amplitude(ctx, state, new) / np.where(psi0 == 0, 1.0, psi0)), 0.0)
                 e += eb
                 if bonds is not None:
                     bonds[key][:, row, col] = eb
@@ -329,7 +339,8 @@ def spinless_fermion_observables(ctx, state, configs, t, V=0.0, t2=0.0):
     Also returns psi_list [rows + cols][n]."""
     cfg = np.asarray(configs)
     n, rows, cols = cfg.shape
-    bonds = {"dr": np.zeros((n, rows - 1, cols - 1)), "ur": np.zeros((n, rows - 1, cols - 1))}
+    dt = np.complex128 if state.is_complex else np.float64
+    bonds = {"dr": np.zeros((n, rows - 1, cols - 1), dt), "ur": np.zeros((n, rows - 1, cols - 1), dt)}
     e, psis = spinless_fermion_energy(ctx, state, cfg, t, V, t2, bonds)
     return {"energy": e[:, None], "charge": (1.0 - cfg).reshape(n, -1), "bond_energy_h": bonds["h"].reshape(n, -1),
             "bond_energy_v": bonds["v"].reshape(n, -1), "bond_energy_dr": bonds["dr"].reshape(n, -1),
@@ -347,7 +358,7 @@ def exact_sum_measure(ctx, state, all_configs, t, V=0.0, rank=0, size=1, batch=N
     for b0 in range(0, len(cfgs), batch):
         part = cfgs[b0:b0 + batch]
         obs, psis = spinless_fermion_observables(ctx, state, part, t, V, t2)
-        w = psis[0] ** 2                                   # |psi(S)|^2: the sign decoration drops out
+        w = np.abs(psis[0]) ** 2                           # |psi(S)|^2: the sign decoration drops out
         wsum += float(w.sum())
         for key, vals in obs.items():
             acc[key] = acc.get(key, 0.0) + w @ vals
@@ -363,10 +374,11 @@ def nn_energy(ctx, state, configs, bond_fn, bonds=None):
     from .capi import LEFT, DOWN, RIGHT, UP, HORIZONTAL, VERTICAL
     cfg = np.asarray(configs)
     n, rows, cols = cfg.shape
-    e = np.zeros(n)
+    dt = np.complex128 if state.is_complex else np.float64       # QLTEN_Complex: E_loc = sum H conj(psi' / psi) (the reference's ComplexConjugate)
+    e = np.zeros(n, dt)
     psis = []
     if bonds is not None:
-        bonds.update(h=np.zeros((n, rows, cols - 1)), v=np.zeros((n, rows - 1, cols)))
+        bonds.update(h=np.zeros((n, rows, cols - 1), dt), v=np.zeros((n, rows - 1, cols), dt))
 
     def bond(s1, s2, orient, order, ext):
         (r1, c1), (r2, c2) = s1, s2
@@ -382,7 +394,7 @@ def nn_energy(ctx, state, configs, bond_fn, bonds=None):
         ne = state.ext_config(new, order)
         cand = np.stack([ne[:, r1, c1], ne[:, r2, c2]], axis=-1)[:, None, :]
         psi_ex = ctx.replace_nn_trace(r1, c1, orient, cand)[:, 0]
-        return e_int + np.where(differ, off * psi_ex / np.where(psi == 0, 1.0, psi), 0.0)
+        return e_int + np.where(differ, off * np.conj(psi_ex / np.where(psi == 0, 1.0, psi)), 0.0)
 
     ext = state.ext_config(cfg, ROW)
     ctx.set_configs(ext)

@@ -175,6 +175,215 @@ void mc_sweeps_impl(int rows, int cols, int D, int d, int chi, int dtype, const 
   copy_out(comp.amplitude, amplitudes_out);
   for (int w = 0; w < n; ++w) accept_rates_out[w] = n_sweeps ? acc[w] / n_sweeps : 0.0;
 }
+template <typename TenElemT>
+void measure_impl(int rows, int cols, int D, int d, int chi, int dtype, const double *sitps_flat, int n, int32_t *configs,
+                  const uint64_t *seeds, int updater, int model, const double *p, int warmup_sweeps, int n_samples,
+                  int sweeps_between_samples, const char *dump_dir, char *keys_out, int keys_cap, double *values_out,
+                  long values_cap, long *values_len) {
+  SplitIndexTPST<TenElemT> sitps = make_state_t<TenElemT>(rows, cols, D, d, sitps_flat);
+  BMPSContractorT<TenElemT> contractor(rows, cols, D, d, trunc_params(chi), n, dtype, g_device);
+  TPSWaveFunctionComponentT<TenElemT> comp(sitps, make_cfg(n, rows, cols, configs), contractor);
+  SquareSpinOneHalfXXZModelOBC xxz(p[0], p[1], p[2]);
+  SquareSpinOneHalfJ1J2XXZModelOBC j1j2(p[0], p[1], p[2], p[3], p[4]);
+  SpinOneHalfTriJ1J2HeisenbergSqrPEPS trij(p[0]);
+  TransverseFieldIsingSquareOBC tfim(p[0]);
+  if (model < 0 || model > 4 || model == 3) throw std::invalid_argument("pepshost_measure: model must be xxz, tfim, j1j2 or trij1j2");
+  xxz.SetEnableStructureFactor(p[7] != 0.0);                  // params[7]: structure factor switch (xxz only)
+  xxz.SetStructureFactorReferenceStackState(p[6] != 0.0);     // params[6]: the DOWN stack as the reference's traversal leaves it (K8; off)
+  std::string keys;
+  std::vector<double> vals;                                   // QLTEN_Complex: every number as a (re, im) pair
+  auto push = [&](const auto &v) {
+    vals.push_back(std::real(v));
+    if constexpr (ElemTraits<TenElemT>::is_complex) vals.push_back(std::imag(v));
+  };
+  auto emit = [&](const std::string &key, const std::vector<TenElemT> &a, const std::vector<double> *b, size_t len) {
+    keys += key + ":" + std::to_string(len) + ";";
+    for (const auto &v : a) push(v);
+    if (b) {
+      if (b->empty()) for (size_t k = 0; k < a.size(); ++k) push(0.0);
+      else for (double v : *b) push(v);
+    }
+  };
+  PsiSummaryT<TenElemT> psi;
+  if (n_samples <= 0) {
+    ObservableMapT<TenElemT> obs = model == 0   ? xxz.EvaluateObservables(sitps, comp)
+                                   : model == 1 ? tfim.EvaluateObservables(sitps, comp)
+                                   : model == 2 ? j1j2.EvaluateObservables(sitps, comp)
+                                                : trij.EvaluateObservables(sitps, comp);
+    for (const auto &kv : obs.values) emit(kv.first, kv.second, nullptr, obs.len(kv.first));
+    psi = model == 0   ? xxz.SquareNNModelMeasurementSolver<SquareSpinOneHalfXXZModelOBC>::template EvaluatePsiSummaryT<TenElemT>()
+          : model == 1 ? tfim.template EvaluatePsiSummaryT<TenElemT>()
+          : model == 2 ? j1j2.SquareNNNModelMeasurementSolver<SquareSpinOneHalfJ1J2XXZModelOBC>::template EvaluatePsiSummaryT<TenElemT>()
+                       : trij.template EvaluatePsiSummaryT<TenElemT>();
+  } else {
+    std::vector<uint64_t> sd(seeds, seeds + n);
+    MCMeasurementParams mp;
+    mp.num_samples = n_samples; mp.num_warmup_sweeps = warmup_sweeps; mp.sweeps_between_samples = sweeps_between_samples;
+    auto run = [&](auto &upd, auto &solver) {
+      MCPEPSMeasurer<std::decay_t<decltype(upd)>, std::decay_t<decltype(solver)>, TenElemT> m(sitps, comp, mp, upd, solver);
+      m.Execute();
+      if (dump_dir && dump_dir[0]) m.DumpData(dump_dir);
+      for (const auto &kv : m.ObservableRegistry()) emit(kv.first, kv.second.first, &kv.second.second, kv.second.first.size());
+      psi.psi_mean.assign(n, TenElemT(0.0)); psi.psi_rel_err.assign(n, 0.0);
+      for (int w = 0; w < n; ++w) { psi.psi_mean[w] = m.PsiSamples().back()[w].first; psi.psi_rel_err[w] = m.PsiSamples().back()[w].second; }
+    };
+    MCUpdateSquareNNExchangeOBC ex(sd);
+    MCUpdateSquareNNFullSpaceUpdateOBC fs(sd);
+    if (updater == 0 && model == 0) run(ex, xxz);
+    else if (updater == 0 && model == 1) run(ex, tfim);
+    else if (updater == 0 && model == 2) run(ex, j1j2);
+    else if (updater == 0) run(ex, trij);
+    else if (model == 0) run(fs, xxz);
+    else if (model == 1) run(fs, tfim);
+    else if (model == 2) run(fs, j1j2);
+    else run(fs, trij);
+    std::copy(comp.config.data(), comp.config.data() + (size_t)n * rows * cols, configs);
+  }
+  for (const auto &v : psi.psi_mean) push(v);
+  for (double v : psi.psi_rel_err) push(v);
+  if ((int)keys.size() + 1 > keys_cap || (long)vals.size() > values_cap) throw std::out_of_range("pepshost_measure: output buffer too small");
+  std::copy(keys.begin(), keys.end(), keys_out);
+  keys_out[keys.size()] = 0;
+  std::copy(vals.begin(), vals.end(), values_out);
+  *values_len = (long)vals.size();
+}
+template <typename TenElemT>
+void exact_sum_measure_partial_impl(int rows, int cols, int D, int d, int chi, int dtype, const double *sitps_flat,
+                                    const int32_t *all_configs, int n_configs, int model, const double *p, int rank, int size,
+                                    int batch, char *keys_out, int keys_cap, double *values_out, long values_cap, long *values_len) {
+  SplitIndexTPST<TenElemT> sitps = make_state_t<TenElemT>(rows, cols, D, d, sitps_flat);
+  BMPSContractorT<TenElemT> contractor(rows, cols, D, d, trunc_params(chi), batch, dtype, g_device);
+  std::vector<std::vector<int32_t>> all;
+  if (n_configs >= 0) {
+    all.resize(n_configs);
+    for (int i = 0; i < n_configs; ++i) all[i].assign(all_configs + (size_t)i * rows * cols, all_configs + (size_t)(i + 1) * rows * cols);
+  } else {
+    all = GenerateAllBinaryConfigs(cols, rows);
+  }
+  if (model != 0 && model != 1 && model != 2) throw std::invalid_argument("pepshost_exact_sum_measure_partial: model must be xxz, tfim or j1j2");
+  if (!all.empty() && (size_t)rank >= all.size()) {           // a rank without configurations contributes nothing
+    if (keys_cap < 1 || values_cap < 1) throw std::out_of_range("pepshost_exact_sum_measure_partial: output buffer too small");
+    keys_out[0] = 0; values_out[0] = 0.0; *values_len = 1;
+    return;
+  }
+  std::vector<double> packed;
+  auto capture = [&](std::vector<double> &v) { packed = v; v[0] = 1.0; };   // keep the raw sums; normalise in the caller
+  std::map<std::string, std::vector<TenElemT>> res;
+  if (model == 0) {
+    SquareSpinOneHalfXXZModelOBC m(p[0], p[1], p[2]);
+    m.SetEnableStructureFactor(p[7] != 0.0);
+    res = ExactSumMeasurer(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
+  } else if (model == 1) {
+    TransverseFieldIsingSquareOBC m(p[0]);
+    res = ExactSumMeasurer(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
+  } else {
+    SquareSpinOneHalfJ1J2XXZModelOBC m(p[0], p[1], p[2], p[3], p[4]);
+    res = ExactSumMeasurer(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
+  }
+  std::string keys;
+  for (const auto &kv : res) keys += kv.first + ":" + std::to_string(kv.second.size()) + ";";
+  if ((int)keys.size() + 1 > keys_cap || (long)packed.size() > values_cap) throw std::out_of_range("pepshost_exact_sum_measure_partial: output buffer too small");
+  std::copy(keys.begin(), keys.end(), keys_out);
+  keys_out[keys.size()] = 0;
+  std::copy(packed.begin(), packed.end(), values_out);
+  *values_len = (long)packed.size();
+}
+
+// ---- fermionic entry points, element-type generic (sitps_ext_flat: 4 d sign-decorated components per site) ----
+template <typename TenElemT>
+void fermion_energy_impl(int rows, int cols, int D, int d, const int32_t *nf, int chi, int dtype,
+                         const double *sitps_ext_flat, int n, const int32_t *configs, int model, const double *prm,
+                         double *amplitudes_out, double *energies_out, double *psi_out, int *n_psi_out) {
+  SplitIndexTPST<TenElemT> sitps = make_state_t<TenElemT>(rows, cols, D, 4 * d, sitps_ext_flat);
+  FermionDecoration dec;
+  dec.nf.assign(nf, nf + d);
+  BMPSContractorT<TenElemT> contractor(rows, cols, D, 4 * d, trunc_params(chi), n, dtype, g_device);
+  TPSWaveFunctionComponentT<TenElemT> comp(sitps, make_cfg(n, rows, cols, configs), contractor, &dec);
+  copy_out(comp.amplitude, amplitudes_out);
+  EnergyAndHolesT<TenElemT> eh;
+  if (model == 0) {
+    SquareSpinlessFermion m(prm[0], prm[2], prm[1]);      // (t, t2, V): params = [t, V, t2, -]
+    eh = m.CalEnergyAndHoles<false>(sitps, comp);
+  } else {
+    SquaretJVModel m(prm[0], 0.0, prm[1], prm[2], prm[3]);
+    eh = m.CalEnergyAndHoles<false>(sitps, comp);
+  }
+  constexpr int z = ElemTraits<TenElemT>::is_complex ? 2 : 1;
+  copy_out(eh.energy, energies_out);
+  if (n_psi_out) *n_psi_out = (int)eh.psi_list.size();
+  if (psi_out)
+    for (size_t k = 0; k < eh.psi_list.size(); ++k) copy_out(eh.psi_list[k], psi_out + k * n * z);
+}
+
+template <typename TenElemT>
+void fermion_exact_sum_partial_impl(int rows, int cols, int D, int d, const int32_t *nf, int chi, int dtype,
+                                    const double *sitps_ext_flat, const int32_t *all_configs, int n_configs, double t,
+                                    double V, int rank, int size, int batch, double *packed_out) {
+  SplitIndexTPST<TenElemT> sitps = make_state_t<TenElemT>(rows, cols, D, 4 * d, sitps_ext_flat);
+  FermionDecoration dec;
+  dec.nf.assign(nf, nf + d);
+  BMPSContractorT<TenElemT> contractor(rows, cols, D, 4 * d, trunc_params(chi), batch, dtype, g_device);
+  std::vector<std::vector<int32_t>> all(n_configs);
+  for (int i = 0; i < n_configs; ++i) all[i].assign(all_configs + (size_t)i * rows * cols, all_configs + (size_t)(i + 1) * rows * cols);
+  std::vector<double> packed;
+  auto capture = [&](std::vector<double> &v) { packed = v; };
+  SquareSpinlessFermion m(t, V);
+  ExactSumEnergyEvaluator(sitps, all, contractor, m, rank, size, (size_t)batch, capture, &dec);
+  std::copy(packed.begin(), packed.end(), packed_out);
+}
+
+template <typename TenElemT>
+void fermion_mc_sweeps_impl(int rows, int cols, int D, int d, const int32_t *nf, int chi, int dtype,
+                            const double *sitps_ext_flat, int n, int32_t *configs, const uint64_t *seeds, int n_sweeps,
+                            double *amplitudes_out, double *accept_out) {
+  SplitIndexTPST<TenElemT> sitps = make_state_t<TenElemT>(rows, cols, D, 4 * d, sitps_ext_flat);
+  FermionDecoration dec;
+  dec.nf.assign(nf, nf + d);
+  BMPSContractorT<TenElemT> contractor(rows, cols, D, 4 * d, trunc_params(chi), n, dtype, g_device);
+  TPSWaveFunctionComponentT<TenElemT> comp(sitps, make_cfg(n, rows, cols, configs), contractor, &dec);
+  std::vector<uint64_t> sd(seeds, seeds + n);
+  MCUpdateSquareNNExchangeOBC ex(sd);
+  std::vector<double> rates, acc(n, 0.0);
+  for (int s = 0; s < n_sweeps; ++s) {
+    ex(sitps, comp, rates);
+    for (int w = 0; w < n; ++w) acc[w] += rates[w];
+  }
+  std::copy(comp.config.data(), comp.config.data() + (size_t)n * rows * cols, configs);
+  copy_out(comp.amplitude, amplitudes_out);
+  if (accept_out) for (int w = 0; w < n; ++w) accept_out[w] = n_sweeps ? acc[w] / n_sweeps : 0.0;
+}
+
+template <typename TenElemT>
+void fermion_measure_energy_impl(int rows, int cols, int D, int d, const int32_t *nf, int chi, int dtype,
+                                 const double *sitps_ext_flat, int n, int32_t *configs, const uint64_t *seeds, int warmup_sweeps,
+                                 int n_samples, int sweeps_between, int model, const double *prm, double *energies_out,
+                                 double *accept_out) {
+  SplitIndexTPST<TenElemT> sitps = make_state_t<TenElemT>(rows, cols, D, 4 * d, sitps_ext_flat);
+  FermionDecoration dec;
+  dec.nf.assign(nf, nf + d);
+  BMPSContractorT<TenElemT> contractor(rows, cols, D, 4 * d, trunc_params(chi), n, dtype, g_device);
+  TPSWaveFunctionComponentT<TenElemT> comp(sitps, make_cfg(n, rows, cols, configs), contractor, &dec);
+  std::vector<uint64_t> sd(seeds, seeds + n);
+  MCUpdateSquareNNExchangeOBC ex(sd);
+  std::vector<double> rates, acc(n, 0.0);
+  for (int s = 0; s < warmup_sweeps; ++s) ex(sitps, comp, rates);
+  comp.SetOrder(ROW_MAJOR);
+  comp.EvaluateAmplitude();                                  // NormalizeStateOrder1: tps_sample_ = WaveFunctionComponentT(...) (:235-236)
+  SquareSpinlessFermion spinless(prm[0], prm[2], prm[1]);     // model 0: (t, t2, V) from [t, V, t2, -]
+  SquaretJVModel tj(prm[0], 0.0, prm[1], prm[2], prm[3]);     // model 1: [t, J, V, mu]
+  constexpr int z = ElemTraits<TenElemT>::is_complex ? 2 : 1;
+  for (int k = 0; k < n_samples; ++k) {
+    for (int s = 0; s < sweeps_between; ++s) {
+      ex(sitps, comp, rates);
+      for (int w = 0; w < n; ++w) acc[w] += rates[w];
+    }
+    EnergyAndHolesT<TenElemT> eh = model == 0 ? spinless.CalEnergyAndHoles<false>(sitps, comp) : tj.CalEnergyAndHoles<false>(sitps, comp);
+    copy_out(eh.energy, energies_out + (size_t)k * n * z);
+  }
+  std::copy(comp.config.data(), comp.config.data() + (size_t)n * rows * cols, configs);
+  const int total = std::max(1, n_samples * sweeps_between);
+  if (accept_out) for (int w = 0; w < n; ++w) accept_out[w] = acc[w] / total;
+}
 }  // namespace
 
 extern "C" {
@@ -318,68 +527,19 @@ int pepshost_measure(int rows, int cols, int D, int d, int chi, int dtype, const
                      int sweeps_between_samples, const char *dump_dir, char *keys_out, int keys_cap, double *values_out,
                      long values_cap, long *values_len) {
   return guarded([&]() {
-    SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
-    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), n, dtype, g_device);
-    TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor);
-    SquareSpinOneHalfXXZModelOBC xxz(p[0], p[1], p[2]);
-    SquareSpinOneHalfJ1J2XXZModelOBC j1j2(p[0], p[1], p[2], p[3], p[4]);
-    SpinOneHalfTriJ1J2HeisenbergSqrPEPS trij(p[0]);
-    TransverseFieldIsingSquareOBC tfim(p[0]);
-    if (model < 0 || model > 4 || model == 3) throw std::invalid_argument("pepshost_measure: model must be xxz, tfim, j1j2 or trij1j2");
-    xxz.SetEnableStructureFactor(p[7] != 0.0);                  // params[7]: structure factor switch (xxz only)
-    xxz.SetStructureFactorReferenceStackState(p[6] != 0.0);     // params[6]: the DOWN stack as the reference's traversal leaves it (K8; off)
-    std::string keys;
-    std::vector<double> vals;
-    auto emit = [&](const std::string &key, const std::vector<double> &a, const std::vector<double> *b, size_t len) {
-      keys += key + ":" + std::to_string(len) + ";";
-      vals.insert(vals.end(), a.begin(), a.end());
-      if (b) {
-        if (b->empty()) vals.insert(vals.end(), a.size(), 0.0);
-        else vals.insert(vals.end(), b->begin(), b->end());
-      }
-    };
-    PsiSummary psi;
-    if (n_samples <= 0) {
-      ObservableMap obs = model == 0   ? xxz.EvaluateObservables(sitps, comp)
-                          : model == 1 ? tfim.EvaluateObservables(sitps, comp)
-                          : model == 2 ? j1j2.EvaluateObservables(sitps, comp)
-                                       : trij.EvaluateObservables(sitps, comp);
-      for (const auto &kv : obs.values) emit(kv.first, kv.second, nullptr, obs.len(kv.first));
-      psi = model == 0   ? xxz.SquareNNModelMeasurementSolver<SquareSpinOneHalfXXZModelOBC>::EvaluatePsiSummary()
-            : model == 1 ? tfim.EvaluatePsiSummary()
-            : model == 2 ? j1j2.SquareNNNModelMeasurementSolver<SquareSpinOneHalfJ1J2XXZModelOBC>::EvaluatePsiSummary()
-                         : trij.EvaluatePsiSummary();
-    } else {
-      std::vector<uint64_t> sd(seeds, seeds + n);
-      MCMeasurementParams mp;
-      mp.num_samples = n_samples; mp.num_warmup_sweeps = warmup_sweeps; mp.sweeps_between_samples = sweeps_between_samples;
-      auto run = [&](auto &upd, auto &solver) {
-        MCPEPSMeasurer<std::decay_t<decltype(upd)>, std::decay_t<decltype(solver)>> m(sitps, comp, mp, upd, solver);
-        m.Execute();
-        if (dump_dir && dump_dir[0]) m.DumpData(dump_dir);
-        for (const auto &kv : m.ObservableRegistry()) emit(kv.first, kv.second.first, &kv.second.second, kv.second.first.size());
-        psi.psi_mean.assign(n, 0.0); psi.psi_rel_err.assign(n, 0.0);
-        for (int w = 0; w < n; ++w) { psi.psi_mean[w] = m.PsiSamples().back()[w].first; psi.psi_rel_err[w] = m.PsiSamples().back()[w].second; }
-      };
-      MCUpdateSquareNNExchangeOBC ex(sd);
-      MCUpdateSquareNNFullSpaceUpdateOBC fs(sd);
-      if (updater == 0 && model == 0) run(ex, xxz);
-      else if (updater == 0 && model == 1) run(ex, tfim);
-      else if (updater == 0 && model == 2) run(ex, j1j2);
-      else if (updater == 0) run(ex, trij);
-      else if (model == 0) run(fs, xxz);
-      else if (model == 1) run(fs, tfim);
-      else if (model == 2) run(fs, j1j2);
-      else run(fs, trij);
-      std::copy(comp.config.data(), comp.config.data() + (size_t)n * rows * cols, configs);
-    }
-    vals.insert(vals.end(), psi.psi_mean.begin(), psi.psi_mean.end());
-    vals.insert(vals.end(), psi.psi_rel_err.begin(), psi.psi_rel_err.end());
-    if ((int)keys.size() + 1 > keys_cap || (long)vals.size() > values_cap) throw std::out_of_range("pepshost_measure: output buffer too small");
-    std::copy(keys.begin(), keys.end(), keys_out);
-    keys_out[keys.size()] = 0;
-    std::copy(vals.begin(), vals.end(), values_out);
-    *values_len = (long)vals.size();
+    measure_impl<double>(rows, cols, D, d, chi, dtype, sitps_flat, n, configs, seeds, updater, model, p, warmup_sweeps, n_samples,
+                         sweeps_between_samples, dump_dir, keys_out, keys_cap, values_out, values_cap, values_len);
+  });
+}
+// QLTEN_Complex (ObservableMap<TenElemT> of the reference is complex for a complex state): sitps_flat and every number of values_out --
+// observables, standard errors, psi_mean, psi_rel_err -- are interleaved (re, im) pairs; values_len counts doubles.
+int pepshost_measure_c128(int rows, int cols, int D, int d, int chi, const double *sitps_flat, int n, int32_t *configs,
+                          const uint64_t *seeds, int updater, int model, const double *p, int warmup_sweeps, int n_samples,
+                          int sweeps_between_samples, const char *dump_dir, char *keys_out, int keys_cap, double *values_out,
+                          long values_cap, long *values_len) {
+  return guarded([&]() {
+    measure_impl<QLTEN_Complex>(rows, cols, D, d, chi, PEPSGPU_C128, sitps_flat, n, configs, seeds, updater, model, p, warmup_sweeps, n_samples,
+                                sweeps_between_samples, dump_dir, keys_out, keys_cap, values_out, values_cap, values_len);
   });
 }
 
@@ -410,39 +570,17 @@ int pepshost_exact_sum_measure_partial(int rows, int cols, int D, int d, int chi
                                        const int32_t *all_configs, int n_configs, int model, const double *p, int rank, int size,
                                        int batch, char *keys_out, int keys_cap, double *values_out, long values_cap, long *values_len) {
   return guarded([&]() {
-    SplitIndexTPS sitps = make_state(rows, cols, D, d, sitps_flat);
-    BMPSContractor contractor(rows, cols, D, d, trunc_params(chi), batch, dtype, g_device);
-    std::vector<std::vector<int32_t>> all;
-    if (n_configs >= 0) {
-      all.resize(n_configs);
-      for (int i = 0; i < n_configs; ++i) all[i].assign(all_configs + (size_t)i * rows * cols, all_configs + (size_t)(i + 1) * rows * cols);
-    } else {
-      all = GenerateAllBinaryConfigs(cols, rows);
-    }
-    if (model != 0 && model != 2) throw std::invalid_argument("pepshost_exact_sum_measure_partial: model must be xxz or j1j2");
-    if (!all.empty() && (size_t)rank >= all.size()) {           // a rank without configurations contributes nothing
-      if (keys_cap < 1 || values_cap < 1) throw std::out_of_range("pepshost_exact_sum_measure_partial: output buffer too small");
-      keys_out[0] = 0; values_out[0] = 0.0; *values_len = 1;
-      return;
-    }
-    std::vector<double> packed;
-    auto capture = [&](std::vector<double> &v) { packed = v; v[0] = 1.0; };   // keep the raw sums; normalise in the caller
-    std::map<std::string, std::vector<double>> res;
-    if (model == 0) {
-      SquareSpinOneHalfXXZModelOBC m(p[0], p[1], p[2]);
-      m.SetEnableStructureFactor(p[7] != 0.0);
-      res = ExactSumMeasurer(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
-    } else {
-      SquareSpinOneHalfJ1J2XXZModelOBC m(p[0], p[1], p[2], p[3], p[4]);
-      res = ExactSumMeasurer(sitps, all, contractor, m, rank, size, (size_t)batch, capture);
-    }
-    std::string keys;
-    for (const auto &kv : res) keys += kv.first + ":" + std::to_string(kv.second.size()) + ";";
-    if ((int)keys.size() + 1 > keys_cap || (long)packed.size() > values_cap) throw std::out_of_range("pepshost_exact_sum_measure_partial: output buffer too small");
-    std::copy(keys.begin(), keys.end(), keys_out);
-    keys_out[keys.size()] = 0;
-    std::copy(packed.begin(), packed.end(), values_out);
-    *values_len = (long)packed.size();
+    exact_sum_measure_partial_impl<double>(rows, cols, D, d, chi, dtype, sitps_flat, all_configs, n_configs, model, p, rank, size, batch,
+                                           keys_out, keys_cap, values_out, values_cap, values_len);
+  });
+}
+// QLTEN_Complex: values_out = [sum w (one double) | key values as (re, im) pairs]
+int pepshost_exact_sum_measure_partial_c128(int rows, int cols, int D, int d, int chi, const double *sitps_flat,
+                                            const int32_t *all_configs, int n_configs, int model, const double *p, int rank, int size,
+                                            int batch, char *keys_out, int keys_cap, double *values_out, long values_cap, long *values_len) {
+  return guarded([&]() {
+    exact_sum_measure_partial_impl<QLTEN_Complex>(rows, cols, D, d, chi, PEPSGPU_C128, sitps_flat, all_configs, n_configs, model, p, rank, size,
+                                                  batch, keys_out, keys_cap, values_out, values_cap, values_len);
   });
 }
 
@@ -505,24 +643,17 @@ int pepshost_fermion_energy(int rows, int cols, int D, int d, const int32_t *nf,
                             const double *sitps_ext_flat, int n, const int32_t *configs, int model, const double *prm,
                             double *amplitudes_out, double *energies_out, double *psi_out, int *n_psi_out) {
   return guarded([&]() {
-    SplitIndexTPS sitps = make_state(rows, cols, D, 4 * d, sitps_ext_flat);
-    FermionDecoration dec;
-    dec.nf.assign(nf, nf + d);
-    BMPSContractor contractor(rows, cols, D, 4 * d, trunc_params(chi), n, dtype, g_device);
-    TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor, &dec);
-    std::copy(comp.amplitude.begin(), comp.amplitude.end(), amplitudes_out);
-    EnergyAndHoles eh;
-    if (model == 0) {
-      SquareSpinlessFermion m(prm[0], prm[2], prm[1]);      // (t, t2, V): params = [t, V, t2, -]
-      eh = m.CalEnergyAndHoles<false>(sitps, comp);
-    } else {
-      SquaretJVModel m(prm[0], 0.0, prm[1], prm[2], prm[3]);
-      eh = m.CalEnergyAndHoles<false>(sitps, comp);
-    }
-    std::copy(eh.energy.begin(), eh.energy.end(), energies_out);
-    if (n_psi_out) *n_psi_out = (int)eh.psi_list.size();
-    if (psi_out)
-      for (size_t k = 0; k < eh.psi_list.size(); ++k) std::copy(eh.psi_list[k].begin(), eh.psi_list[k].end(), psi_out + k * n);
+    fermion_energy_impl<double>(rows, cols, D, d, nf, chi, dtype, sitps_ext_flat, n, configs, model, prm, amplitudes_out, energies_out, psi_out,
+                                n_psi_out);
+  });
+}
+// QLTEN_Complex (SplitIndexTPS<QLTEN_Complex, fZ2QN>): the decorated components and every output as interleaved (re, im) pairs
+int pepshost_fermion_energy_c128(int rows, int cols, int D, int d, const int32_t *nf, int chi,
+                                 const double *sitps_ext_flat, int n, const int32_t *configs, int model, const double *prm,
+                                 double *amplitudes_out, double *energies_out, double *psi_out, int *n_psi_out) {
+  return guarded([&]() {
+    fermion_energy_impl<QLTEN_Complex>(rows, cols, D, d, nf, chi, PEPSGPU_C128, sitps_ext_flat, n, configs, model, prm, amplitudes_out,
+                                       energies_out, psi_out, n_psi_out);
   });
 }
 
@@ -532,17 +663,18 @@ int pepshost_fermion_exact_sum_partial(int rows, int cols, int D, int d, const i
                                        const double *sitps_ext_flat, const int32_t *all_configs, int n_configs, double t,
                                        double V, int rank, int size, int batch, double *packed_out) {
   return guarded([&]() {
-    SplitIndexTPS sitps = make_state(rows, cols, D, 4 * d, sitps_ext_flat);
-    FermionDecoration dec;
-    dec.nf.assign(nf, nf + d);
-    BMPSContractor contractor(rows, cols, D, 4 * d, trunc_params(chi), batch, dtype, g_device);
-    std::vector<std::vector<int32_t>> all(n_configs);
-    for (int i = 0; i < n_configs; ++i) all[i].assign(all_configs + (size_t)i * rows * cols, all_configs + (size_t)(i + 1) * rows * cols);
-    std::vector<double> packed;
-    auto capture = [&](std::vector<double> &v) { packed = v; };
-    SquareSpinlessFermion m(t, V);
-    ExactSumEnergyEvaluator(sitps, all, contractor, m, rank, size, (size_t)batch, capture, &dec);
-    std::copy(packed.begin(), packed.end(), packed_out);
+    fermion_exact_sum_partial_impl<double>(rows, cols, D, d, nf, chi, dtype, sitps_ext_flat, all_configs, n_configs, t, V, rank, size, batch,
+                                           packed_out);
+  });
+}
+// QLTEN_Complex: packed_out as pepshost_mc_energy_grad_partial_c128 (4 m + 5 doubles, m = rows*cols*4d*D^4); finish with
+// pepshost_exact_sum_finish_c128 on d' = 4 d
+int pepshost_fermion_exact_sum_partial_c128(int rows, int cols, int D, int d, const int32_t *nf, int chi,
+                                            const double *sitps_ext_flat, const int32_t *all_configs, int n_configs, double t,
+                                            double V, int rank, int size, int batch, double *packed_out) {
+  return guarded([&]() {
+    fermion_exact_sum_partial_impl<QLTEN_Complex>(rows, cols, D, d, nf, chi, PEPSGPU_C128, sitps_ext_flat, all_configs, n_configs, t, V, rank,
+                                                  size, batch, packed_out);
   });
 }
 
@@ -551,58 +683,39 @@ int pepshost_fermion_mc_sweeps(int rows, int cols, int D, int d, const int32_t *
                                const double *sitps_ext_flat, int n, int32_t *configs, const uint64_t *seeds, int n_sweeps,
                                double *amplitudes_out, double *accept_out) {
   return guarded([&]() {
-    SplitIndexTPS sitps = make_state(rows, cols, D, 4 * d, sitps_ext_flat);
-    FermionDecoration dec;
-    dec.nf.assign(nf, nf + d);
-    BMPSContractor contractor(rows, cols, D, 4 * d, trunc_params(chi), n, dtype, g_device);
-    TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor, &dec);
-    std::vector<uint64_t> sd(seeds, seeds + n);
-    MCUpdateSquareNNExchangeOBC ex(sd);
-    std::vector<double> rates, acc(n, 0.0);
-    for (int s = 0; s < n_sweeps; ++s) {
-      ex(sitps, comp, rates);
-      for (int w = 0; w < n; ++w) acc[w] += rates[w];
-    }
-    std::copy(comp.config.data(), comp.config.data() + (size_t)n * rows * cols, configs);
-    std::copy(comp.amplitude.begin(), comp.amplitude.end(), amplitudes_out);
-    if (accept_out) for (int w = 0; w < n; ++w) accept_out[w] = n_sweeps ? acc[w] / n_sweeps : 0.0;
+    fermion_mc_sweeps_impl<double>(rows, cols, D, d, nf, chi, dtype, sitps_ext_flat, n, configs, seeds, n_sweeps, amplitudes_out, accept_out);
+  });
+}
+int pepshost_fermion_mc_sweeps_c128(int rows, int cols, int D, int d, const int32_t *nf, int chi,
+                                    const double *sitps_ext_flat, int n, int32_t *configs, const uint64_t *seeds, int n_sweeps,
+                                    double *amplitudes_out, double *accept_out) {
+  return guarded([&]() {
+    fermion_mc_sweeps_impl<QLTEN_Complex>(rows, cols, D, d, nf, chi, PEPSGPU_C128, sitps_ext_flat, n, configs, seeds, n_sweeps, amplitudes_out,
+                                          accept_out);
   });
 }
 
 // MCPEPSMeasurer's energy on a fermionic state with ONE random stream per walker over the whole run (monte_carlo_engine.h:146-176,
 // monte_carlo_peps_measurer_impl.h:495-519): warmup_sweeps sweeps, the component rebuilt as NormalizeStateOrder1 does (the scale drops out
 // of every ratio; the amplitude is evaluated afresh), then n_samples x {sweeps_between sweeps, E_loc}.  energies_out = [sample][walker].
-// This is the call that can reproduce the reference's fermionic regression value on the device (K9 of DESIGN 2: 6x6 fU1 t-J state, seed 42,
-// -14.74320489110316) -- written at the end of round 4, NOT yet run on the GPU.
+// This is the call that reproduces the reference's fermionic regression value on the device (K9 of DESIGN 2: 6x6 fU1 t-J state, seed 42,
+// -14.74320489110316; tests/test_gpu_fermion.py).
 int pepshost_fermion_measure_energy(int rows, int cols, int D, int d, const int32_t *nf, int chi, int dtype,
                                     const double *sitps_ext_flat, int n, int32_t *configs, const uint64_t *seeds, int warmup_sweeps,
                                     int n_samples, int sweeps_between, int model, const double *prm, double *energies_out,
                                     double *accept_out) {
   return guarded([&]() {
-    SplitIndexTPS sitps = make_state(rows, cols, D, 4 * d, sitps_ext_flat);
-    FermionDecoration dec;
-    dec.nf.assign(nf, nf + d);
-    BMPSContractor contractor(rows, cols, D, 4 * d, trunc_params(chi), n, dtype, g_device);
-    TPSWaveFunctionComponent comp(sitps, make_cfg(n, rows, cols, configs), contractor, &dec);
-    std::vector<uint64_t> sd(seeds, seeds + n);
-    MCUpdateSquareNNExchangeOBC ex(sd);
-    std::vector<double> rates, acc(n, 0.0);
-    for (int s = 0; s < warmup_sweeps; ++s) ex(sitps, comp, rates);
-    comp.SetOrder(ROW_MAJOR);
-    comp.EvaluateAmplitude();                                  // NormalizeStateOrder1: tps_sample_ = WaveFunctionComponentT(...) (:235-236)
-    SquareSpinlessFermion spinless(prm[0], prm[2], prm[1]);     // model 0: (t, t2, V) from [t, V, t2, -]
-    SquaretJVModel tj(prm[0], 0.0, prm[1], prm[2], prm[3]);     // model 1: [t, J, V, mu]
-    for (int k = 0; k < n_samples; ++k) {
-      for (int s = 0; s < sweeps_between; ++s) {
-        ex(sitps, comp, rates);
-        for (int w = 0; w < n; ++w) acc[w] += rates[w];
-      }
-      EnergyAndHoles eh = model == 0 ? spinless.CalEnergyAndHoles<false>(sitps, comp) : tj.CalEnergyAndHoles<false>(sitps, comp);
-      std::copy(eh.energy.begin(), eh.energy.end(), energies_out + (size_t)k * n);
-    }
-    std::copy(comp.config.data(), comp.config.data() + (size_t)n * rows * cols, configs);
-    const int total = std::max(1, n_samples * sweeps_between);
-    if (accept_out) for (int w = 0; w < n; ++w) accept_out[w] = acc[w] / total;
+    fermion_measure_energy_impl<double>(rows, cols, D, d, nf, chi, dtype, sitps_ext_flat, n, configs, seeds, warmup_sweeps, n_samples,
+                                        sweeps_between, model, prm, energies_out, accept_out);
+  });
+}
+int pepshost_fermion_measure_energy_c128(int rows, int cols, int D, int d, const int32_t *nf, int chi,
+                                         const double *sitps_ext_flat, int n, int32_t *configs, const uint64_t *seeds, int warmup_sweeps,
+                                         int n_samples, int sweeps_between, int model, const double *prm, double *energies_out,
+                                         double *accept_out) {
+  return guarded([&]() {
+    fermion_measure_energy_impl<QLTEN_Complex>(rows, cols, D, d, nf, chi, PEPSGPU_C128, sitps_ext_flat, n, configs, seeds, warmup_sweeps,
+                                               n_samples, sweeps_between, model, prm, energies_out, accept_out);
   });
 }
 

@@ -1142,51 +1142,76 @@ using SquareNNModelEnergySolver = SquareNNNModelEnergySolver<ExplicitlyModel, fa
 // ---------------------------------------------------------------------------------------------
 // Measurement: registry-based observables of a walker batch.
 // ObservableMap (model_measurement_solver.h:33-34): key -> flat values; here per walker: values[key][w * len + k].
-struct ObservableMap {
-  std::map<std::string, std::vector<double>> values;
+// Templated over the element type as the reference's ObservableMap<TenElemT>: a complex state has complex local estimators.
+template <typename TenElemT>
+struct ObservableMapT {
+  std::map<std::string, std::vector<TenElemT>> values;
   size_t n = 0;                                               // walkers
   size_t len(const std::string &key) const { return values.at(key).size() / n; }
-  std::vector<double> &make(const std::string &key, size_t length) {
+  std::vector<TenElemT> &make(const std::string &key, size_t length) {
     auto &v = values[key];
-    v.assign(n * length, 0.0);
+    v.assign(n * length, TenElemT(0.0));
     return v;
   }
 };
+using ObservableMap = ObservableMapT<double>;
 struct ObservableMeta {                                        // model_measurement_solver.h:45-63
   std::string key, description;
   std::vector<size_t> shape;
   std::vector<std::string> index_labels;
 };
-struct PsiSummary { std::vector<double> psi_mean, psi_rel_err; };   // per walker (model_measurement_solver.h:95-98)
+// per walker (model_measurement_solver.h:95-98; PsiConsistencySummary<TenElemT>: psi_mean has the element type, psi_rel_err is real)
+template <typename TenElemT>
+struct PsiSummaryT { std::vector<TenElemT> psi_mean; std::vector<double> psi_rel_err; };
+using PsiSummary = PsiSummaryT<double>;
+// what a (non-templated) solver object keeps of its last sample; As<TenElemT>() hands it back in the caller's element type
+struct PsiSummaryStore {
+  std::vector<std::complex<double>> psi_mean;
+  std::vector<double> psi_rel_err;
+  void assign(size_t n) { psi_mean.assign(n, 0.0); psi_rel_err.assign(n, 0.0); }
+  template <typename TenElemT>
+  PsiSummaryT<TenElemT> As() const {
+    PsiSummaryT<TenElemT> out;
+    out.psi_rel_err = psi_rel_err;
+    out.psi_mean.resize(psi_mean.size());
+    for (size_t w = 0; w < psi_mean.size(); ++w) {
+      if constexpr (ElemTraits<TenElemT>::is_complex) out.psi_mean[w] = psi_mean[w]; else out.psi_mean[w] = psi_mean[w].real();
+    }
+    return out;
+  }
+};
 
-// ComputePsiConsistencySummaryAligned (psi_consistency.h:60-107), real amplitudes
-inline std::pair<double, double> ComputePsiConsistencySummaryAligned(const std::vector<double> &psi_list) {
-  if (psi_list.empty()) return {0.0, 0.0};
+// ComputePsiConsistencySummaryAligned (psi_consistency.h:119-168): the largest-magnitude sample is the reference, samples with
+// Re[psi_i conj(psi_ref)] < 0 are flipped, (mean, max_i |psi_i - mean| / |mean|)
+template <typename TenElemT>
+inline std::pair<TenElemT, double> ComputePsiConsistencySummaryAligned(const std::vector<TenElemT> &psi_list) {
+  if (psi_list.empty()) return {TenElemT(0.0), 0.0};
   size_t ref = 0;
   for (size_t i = 0; i < psi_list.size(); ++i)
-    if (std::fabs(psi_list[i]) > std::fabs(psi_list[ref])) ref = i;
-  const bool ref_valid = std::fabs(psi_list[ref]) > 1e-14;
-  std::vector<double> aligned(psi_list);
-  double mean = 0.0;
+    if (std::abs(psi_list[i]) > std::abs(psi_list[ref])) ref = i;
+  const bool ref_valid = std::abs(psi_list[ref]) > 1e-14;
+  std::vector<TenElemT> aligned(psi_list);
+  TenElemT mean(0.0);
   for (auto &v : aligned) {
-    if (ref_valid && v * psi_list[ref] < 0.0) v = -v;
+    if (ref_valid && std::real(v * ComplexConjugate(psi_list[ref])) < 0.0) v = -v;
     mean += v;
   }
   mean /= (double)aligned.size();
-  const double denom = std::max(std::fabs(mean), std::numeric_limits<double>::epsilon());
+  const double denom = std::max((double)std::abs(mean), std::numeric_limits<double>::epsilon());
   double dev = 0.0;
-  for (double v : aligned) dev = std::max(dev, std::fabs(v - mean));
+  for (const TenElemT &v : aligned) dev = std::max(dev, (double)std::abs(v - mean));
   return {mean, dev / denom};
 }
 
 // MeasureSpinOneHalfOffDiagOrderInRow (square_spin_onehalf_xxz_obc.h:22-60) for every walker: the valid channel of
 // S+(x0) S-(x0+i) / S-(x0) S+(x0+i) along `row`, x0 = lx/4, i = 1..lx/2.  out[w * (lx/2) + i - 1].
-inline std::vector<double> MeasureSpinOneHalfOffDiagOrderInRow(TPSWaveFunctionComponent &comp, const std::vector<double> &inv_psi,
-                                                               size_t row) {
+template <typename TenElemT>
+inline std::vector<TenElemT> MeasureSpinOneHalfOffDiagOrderInRow(TPSWaveFunctionComponentT<TenElemT> &comp, const std::vector<TenElemT> &inv_psi,
+                                                                 size_t row) {
   auto &c = comp.contractor;
   const size_t lx = c.cols(), n = comp.config.walkers(), half = lx / 2;
   const SiteIdx site1{row, lx / 4};
-  std::vector<double> out(n * half, 0.0);
+  std::vector<TenElemT> out(n * half, TenElemT(0.0));
   const std::vector<int32_t> sites = {(int32_t)site1.r, (int32_t)site1.c};
   const std::vector<uint8_t> all(n, 1);
   std::vector<int32_t> flipped(n), orig(n);
@@ -1204,9 +1229,9 @@ inline std::vector<double> MeasureSpinOneHalfOffDiagOrderInRow(TPSWaveFunctionCo
       any |= comp.config(w, site2) != comp.config(w, site1);
     }
     if (any) {
-      std::vector<double> psi_ex = c.ReplaceOneSiteTrace(site2, HORIZONTAL, 1, cand);
+      std::vector<TenElemT> psi_ex = c.ReplaceOneSiteTrace(site2, HORIZONTAL, 1, cand);
       for (size_t w = 0; w < n; ++w)
-        if (comp.config(w, site2) != comp.config(w, site1)) out[w * half + i - 1] = psi_ex[w] * inv_psi[w];
+        if (comp.config(w, site2) != comp.config(w, site1)) out[w * half + i - 1] = ComplexConjugate(TenElemT(psi_ex[w] * inv_psi[w]));   // :47
     }
     c.ShiftBTenWindow(RIGHT);
   }
@@ -1222,11 +1247,12 @@ inline std::vector<double> MeasureSpinOneHalfOffDiagOrderInRow(TPSWaveFunctionCo
 template <class ModelType, bool has_nnn_interaction = true>
 class SquareNNNModelMeasurementSolver {
  public:
-  ObservableMap EvaluateObservables(const SplitIndexTPS &, TPSWaveFunctionComponent &comp) {
+  template <typename TenElemT>
+  ObservableMapT<TenElemT> EvaluateObservables(const SplitIndexTPST<TenElemT> &, TPSWaveFunctionComponentT<TenElemT> &comp) {
     auto &c = comp.contractor;
     auto *derived = static_cast<ModelType *>(this);
     const size_t ly = c.rows(), lx = c.cols(), n = comp.config.walkers();
-    ObservableMap out;
+    ObservableMapT<TenElemT> out;
     out.n = n;
     if constexpr (ModelType::requires_spin_sz_measurement) {
       auto &sz = out.make("spin_z", ly * lx);
@@ -1242,18 +1268,18 @@ class SquareNNNModelMeasurementSolver {
     }
     auto &e_h = out.make("bond_energy_h", ly * (lx - 1));
     auto &e_v = out.make("bond_energy_v", (ly - 1) * lx);
-    std::vector<double> *e_dr = nullptr, *e_ur = nullptr;
+    std::vector<TenElemT> *e_dr = nullptr, *e_ur = nullptr;
     if constexpr (has_nnn_interaction) {
       e_dr = &out.make("bond_energy_dr", (ly - 1) * (lx - 1));
       e_ur = &out.make("bond_energy_ur", (ly - 1) * (lx - 1));
     }
-    std::vector<double> total(n, 0.0);
-    std::vector<std::vector<double>> psi_list;
-    auto inverse = [&](const std::vector<double> &psi) {
-      std::vector<double> inv(n);
+    std::vector<TenElemT> total(n, TenElemT(0.0));
+    std::vector<std::vector<TenElemT>> psi_list;
+    auto inverse = [&](const std::vector<TenElemT> &psi) {
+      std::vector<TenElemT> inv(n);
       for (size_t w = 0; w < n; ++w) {
-        if (psi[w] == 0.0) throw std::runtime_error("Wavefunction amplitude is near zero, causing division by zero.");
-        inv[w] = 1.0 / psi[w];
+        if (psi[w] == TenElemT(0.0)) throw std::runtime_error("Wavefunction amplitude is near zero, causing division by zero.");
+        inv[w] = TenElemT(1.0) / psi[w];
       }
       return inv;
     };
@@ -1263,9 +1289,9 @@ class SquareNNNModelMeasurementSolver {
       c.InitBTen(LEFT, row);
       c.GrowFullBTen(RIGHT, row, 1, true);
       psi_list.push_back(c.Trace({row, 0}, HORIZONTAL));
-      const std::vector<double> inv_psi = inverse(psi_list.back());
+      const std::vector<TenElemT> inv_psi = inverse(psi_list.back());
       for (size_t col = 0; col + 1 < lx; ++col) {
-        std::vector<double> e = derived->EvaluateBondEnergy({row, col}, {row, col + 1}, HORIZONTAL, comp, inv_psi);
+        std::vector<TenElemT> e = derived->EvaluateBondEnergy({row, col}, {row, col + 1}, HORIZONTAL, comp, inv_psi);
         for (size_t w = 0; w < n; ++w) { e_h[w * ly * (lx - 1) + row * (lx - 1) + col] = e[w]; total[w] += e[w]; }
         c.ShiftBTenWindow(RIGHT);
       }
@@ -1274,8 +1300,8 @@ class SquareNNNModelMeasurementSolver {
           c.InitBTen2(LEFT, row);
           c.GrowFullBTen2(RIGHT, row, 2, true);
           for (size_t col = 0; col + 1 < lx; ++col) {
-            std::vector<double> e1 = derived->EvaluateNNNEnergy({row, col}, {row + 1, col + 1}, LEFTUP_TO_RIGHTDOWN, comp, inv_psi);
-            std::vector<double> e2 = derived->EvaluateNNNEnergy({row + 1, col}, {row, col + 1}, LEFTDOWN_TO_RIGHTUP, comp, inv_psi);
+            std::vector<TenElemT> e1 = derived->EvaluateNNNEnergy({row, col}, {row + 1, col + 1}, LEFTUP_TO_RIGHTDOWN, comp, inv_psi);
+            std::vector<TenElemT> e2 = derived->EvaluateNNNEnergy({row + 1, col}, {row, col + 1}, LEFTDOWN_TO_RIGHTUP, comp, inv_psi);
             for (size_t w = 0; w < n; ++w) {
               const size_t k = w * (ly - 1) * (lx - 1) + row * (lx - 1) + col;   // LEFTDOWN anchor mapped to the top cell (:155)
               (*e_dr)[k] = e1[w]; (*e_ur)[k] = e2[w];
@@ -1294,18 +1320,17 @@ class SquareNNNModelMeasurementSolver {
       c.InitBTen(UP, col);
       c.GrowFullBTen(DOWN, col, 2, true);
       psi_list.push_back(c.Trace({0, col}, VERTICAL));
-      const std::vector<double> inv_psi = inverse(psi_list.back());
+      const std::vector<TenElemT> inv_psi = inverse(psi_list.back());
       for (size_t row = 0; row + 1 < ly; ++row) {
-        std::vector<double> e = derived->EvaluateBondEnergy({row, col}, {row + 1, col}, VERTICAL, comp, inv_psi);
+        std::vector<TenElemT> e = derived->EvaluateBondEnergy({row, col}, {row + 1, col}, VERTICAL, comp, inv_psi);
         for (size_t w = 0; w < n; ++w) { e_v[w * (ly - 1) * lx + row * lx + col] = e[w]; total[w] += e[w]; }
         if (row + 2 < ly) c.ShiftBTenWindow(DOWN);
       }
       if (col + 1 < lx) c.ShiftBMPSWindow(RIGHT);
     }
     auto &en = out.make("energy", 1);
-    last_psi_.psi_mean.assign(n, 0.0);
-    last_psi_.psi_rel_err.assign(n, 0.0);
-    std::vector<double> one(psi_list.size());
+    last_psi_.assign(n);
+    std::vector<TenElemT> one(psi_list.size());
     for (size_t w = 0; w < n; ++w) {
       en[w] = total[w] + derived->EvaluateTotalOnsiteEnergy(comp.config, w);
       for (size_t k = 0; k < psi_list.size(); ++k) one[k] = psi_list[k][w];
@@ -1316,7 +1341,8 @@ class SquareNNNModelMeasurementSolver {
     return out;
   }
   // psi summary of the sample the last EvaluateObservables call saw (model_measurement_solver.h:101-118, cached path)
-  const PsiSummary &EvaluatePsiSummary() const { return last_psi_; }
+  PsiSummary EvaluatePsiSummary() const { return last_psi_.As<double>(); }
+  template <typename TenElemT> PsiSummaryT<TenElemT> EvaluatePsiSummaryT() const { return last_psi_.As<TenElemT>(); }
   std::vector<ObservableMeta> DescribeObservables(size_t ly, size_t lx) const {   // :256-291
     std::vector<ObservableMeta> out = {{"energy", "Total energy (scalar)", {}, {}}};
     if constexpr (ModelType::requires_spin_sz_measurement) out.push_back({"spin_z", "Local spin Sz per site", {ly, lx}, {"y", "x"}});
@@ -1330,7 +1356,7 @@ class SquareNNNModelMeasurementSolver {
     return out;
   }
  private:
-  PsiSummary last_psi_;
+  PsiSummaryStore last_psi_;
 };
 template <class ModelType>
 using SquareNNModelMeasurementSolver = SquareNNNModelMeasurementSolver<ModelType, false>;
@@ -1342,10 +1368,12 @@ struct SpinOneHalfMeasurementHooks {
   static constexpr bool requires_density_measurement = false;
   double CalSpinSzImpl(int32_t config) const { return double(config) - 0.5; }
   double CalDensityImpl(int32_t) const { return 0.0; }
-  void EvaluateOffDiagOrderInRow(TPSWaveFunctionComponent &comp, size_t row, const std::vector<double> &inv_psi, ObservableMap &out) const {
+  template <typename TenElemT>
+  void EvaluateOffDiagOrderInRow(TPSWaveFunctionComponentT<TenElemT> &comp, size_t row, const std::vector<TenElemT> &inv_psi,
+                                 ObservableMapT<TenElemT> &out) const {
     const size_t ly = comp.contractor.rows(), lx = comp.contractor.cols(), n = comp.config.walkers(), half = lx / 2;
     if (row != ly / 2 || half == 0) return;
-    std::vector<double> corr = MeasureSpinOneHalfOffDiagOrderInRow(comp, inv_psi, row);
+    std::vector<TenElemT> corr = MeasureSpinOneHalfOffDiagOrderInRow(comp, inv_psi, row);
     auto &smsp = out.make("SmSp_row", half);
     auto &spsm = out.make("SpSm_row", half);
     for (size_t w = 0; w < n; ++w) {
@@ -1363,7 +1391,8 @@ struct SpinOneHalfMeasurementHooks {
   // trace is computed for the batch when any walker's channel is open and masked per walker on the host.
   void SetEnableStructureFactor(bool enable) { enable_structure_factor_measurement_ = enable; }
   bool IsStructureFactorEnabled() const { return enable_structure_factor_measurement_; }
-  void MeasureStructureFactor(TPSWaveFunctionComponent &comp, ObservableMap &out) const {
+  template <typename TenElemT>
+  void MeasureStructureFactor(TPSWaveFunctionComponentT<TenElemT> &comp, ObservableMapT<TenElemT> &out) const {
     if (!enable_structure_factor_measurement_) return;
     auto &c = comp.contractor;
     const size_t Ly = c.rows(), Lx = c.cols(), n = comp.config.walkers();
@@ -1396,7 +1425,7 @@ struct SpinOneHalfMeasurementHooks {
           if (bottom >= n_down) {                               // (:139-149; only in the reference stack state)
             for (size_t w = 0; w < n; ++w)
               for (size_t x2 = 0; x2 < Lx; ++x2) {
-                double *t = &cross[w * per + fill[w]];
+                TenElemT *t = &cross[w * per + fill[w]];
                 t[0] = (double)y1; t[1] = (double)x1; t[2] = (double)y2; t[3] = (double)x2; t[4] = 0.0;
                 fill[w] += 5;
               }
@@ -1405,13 +1434,13 @@ struct SpinOneHalfMeasurementHooks {
           excited_walker.SetMPO(y2);                            // standard_mpo = tn.get_row(y2)
           excited_walker.InitBTenLeft(bottom, Lx);
           excited_walker.InitBTenRight(bottom, Lx - 1);
-          std::vector<double> row(n * Lx, 0.0);
+          std::vector<TenElemT> row(n * Lx, TenElemT(0.0));
           for (size_t x2r = 0; x2r < Lx; ++x2r) {
             const size_t x2 = Lx - 1 - x2r;
             bool any = false;
             for (size_t w = 0; w < n; ++w) any |= src_down[w] && comp.config(w, {y2, x2}) == 1;
             if (any) {
-              std::vector<double> psi_ex = excited_walker.TraceWithBTen(bottom, x2, spin_down);
+              std::vector<TenElemT> psi_ex = excited_walker.TraceWithBTen(bottom, x2, spin_down);
               for (size_t w = 0; w < n; ++w)
                 if (src_down[w] && comp.config(w, {y2, x2}) == 1) row[w * Lx + x2] = psi_ex[w];
             }
@@ -1419,7 +1448,7 @@ struct SpinOneHalfMeasurementHooks {
           }
           for (size_t w = 0; w < n; ++w)
             for (size_t x2 = 0; x2 < Lx; ++x2) {
-              double *t = &cross[w * per + fill[w]];
+              TenElemT *t = &cross[w * per + fill[w]];
               t[0] = (double)y1; t[1] = (double)x1; t[2] = (double)y2; t[3] = (double)x2; t[4] = row[w * Lx + x2];
               fill[w] += 5;
             }
@@ -1435,7 +1464,8 @@ struct SpinOneHalfMeasurementHooks {
   void SetStructureFactorReferenceStackState(bool on) { structure_factor_reference_stack_state_ = on; }
   bool structure_factor_reference_stack_state_ = false;
 
-  static void AddSzSzAll2All(const TPSWaveFunctionComponent &comp, ObservableMap &out) {   // :225-236
+  template <typename TenElemT>
+  static void AddSzSzAll2All(const TPSWaveFunctionComponentT<TenElemT> &comp, ObservableMapT<TenElemT> &out) {   // :225-236
     const size_t ly = comp.contractor.rows(), lx = comp.contractor.cols(), n = comp.config.walkers(), N = ly * lx;
     auto &szsz = out.make("SzSz_all2all", N * (N + 1) / 2);
     for (size_t w = 0; w < n; ++w) {
@@ -1518,8 +1548,9 @@ class SquareSpinOneHalfXXZModelOBC : public SquareNNModelEnergySolver<SquareSpin
   SquareSpinOneHalfXXZModelOBC() : SquareSpinOneHalfXXZModelMixIn(1.0, 1.0, 0.0, 0.0, 0.0) {}
   SquareSpinOneHalfXXZModelOBC(double jz, double jxy, double pinning00)
       : SquareSpinOneHalfXXZModelMixIn(jz, jxy, 0.0, 0.0, pinning00) {}
-  ObservableMap EvaluateObservables(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp) {   // :215-251
-    ObservableMap out = SquareNNModelMeasurementSolver<SquareSpinOneHalfXXZModelOBC>::EvaluateObservables(sitps, comp);
+  template <typename TenElemT>
+  ObservableMapT<TenElemT> EvaluateObservables(const SplitIndexTPST<TenElemT> &sitps, TPSWaveFunctionComponentT<TenElemT> &comp) {   // :215-251
+    ObservableMapT<TenElemT> out = SquareNNModelMeasurementSolver<SquareSpinOneHalfXXZModelOBC>::EvaluateObservables(sitps, comp);
     AddSzSzAll2All(comp, out);
     MeasureStructureFactor(comp, out);                         // :238-248 (if enabled)
     return out;
@@ -1537,8 +1568,9 @@ class SquareSpinOneHalfJ1J2XXZModelOBC : public SquareNNNModelEnergySolver<Squar
                                          public SpinOneHalfMeasurementHooks,
                                          public SquareSpinOneHalfXXZModelMixIn {
  public:
-  ObservableMap EvaluateObservables(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp) {
-    ObservableMap out = SquareNNNModelMeasurementSolver<SquareSpinOneHalfJ1J2XXZModelOBC>::EvaluateObservables(sitps, comp);
+  template <typename TenElemT>
+  ObservableMapT<TenElemT> EvaluateObservables(const SplitIndexTPST<TenElemT> &sitps, TPSWaveFunctionComponentT<TenElemT> &comp) {
+    ObservableMapT<TenElemT> out = SquareNNNModelMeasurementSolver<SquareSpinOneHalfJ1J2XXZModelOBC>::EvaluateObservables(sitps, comp);
     AddSzSzAll2All(comp, out);
     return out;
   }
@@ -1568,8 +1600,9 @@ class SpinOneHalfTriHeisenbergSqrPEPS : public SquareNNNModelEnergySolver<SpinOn
     if (diagonal_dir != LEFTDOWN_TO_RIGHTUP) return std::vector<TenElemT>(comp.config.walkers(), TenElemT(0));   // :98-100
     return SquareSpinOneHalfXXZModelMixIn::EvaluateNNNEnergy(s1, s2, diagonal_dir, comp, inv_psi);
   }
-  ObservableMap EvaluateObservables(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp) {
-    ObservableMap out = SquareNNNModelMeasurementSolver<SpinOneHalfTriHeisenbergSqrPEPS>::EvaluateObservables(sitps, comp);
+  template <typename TenElemT>
+  ObservableMapT<TenElemT> EvaluateObservables(const SplitIndexTPST<TenElemT> &sitps, TPSWaveFunctionComponentT<TenElemT> &comp) {
+    ObservableMapT<TenElemT> out = SquareNNNModelMeasurementSolver<SpinOneHalfTriHeisenbergSqrPEPS>::EvaluateObservables(sitps, comp);
     out.values.erase("bond_energy_dr");               // "legacy public API: only the interacting diagonal" (:126-127)
     AddSzSzAll2All(comp, out);
     return out;
@@ -1609,10 +1642,11 @@ class SpinOneHalfTriJ1J2HeisenbergSqrPEPS : public SpinOneHalfMeasurementHooks {
     return out;
   }
 
-  ObservableMap EvaluateObservables(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp) {
+  template <typename TenElemT>
+  ObservableMapT<TenElemT> EvaluateObservables(const SplitIndexTPST<TenElemT> &sitps, TPSWaveFunctionComponentT<TenElemT> &comp) {
     auto &c = comp.contractor;
     const size_t ly = c.rows(), lx = c.cols(), n = comp.config.walkers(), half = lx / 2;
-    ObservableMap out;
+    ObservableMapT<TenElemT> out;
     out.n = n;
     auto &sz = out.make("spin_z", ly * lx);
     for (size_t w = 0; w < n; ++w)
@@ -1621,9 +1655,9 @@ class SpinOneHalfTriJ1J2HeisenbergSqrPEPS : public SpinOneHalfMeasurementHooks {
     auto &e_h = out.make("bond_energy_h", ly * (lx - 1));
     auto &e_v = out.make("bond_energy_v", (ly - 1) * lx);
     auto &e_ur = out.make("bond_energy_ur", (ly - 1) * (lx - 1));
-    std::vector<double> e1(n, 0.0), e2(n, 0.0);
-    EnergyAndHolesT<double> scratch;
-    Traverse<double>(sitps, comp, false, false, scratch, [&](BondKind kind, const SiteIdx &s1, const SiteIdx &s2, const std::vector<double> &e) {
+    std::vector<TenElemT> e1(n, TenElemT(0.0)), e2(n, TenElemT(0.0));
+    EnergyAndHolesT<TenElemT> scratch;
+    Traverse<TenElemT>(sitps, comp, false, false, scratch, [&](BondKind kind, const SiteIdx &s1, const SiteIdx &s2, const std::vector<TenElemT> &e) {
       for (size_t w = 0; w < n; ++w) {
         if (kind == BOND_H) e_h[w * ly * (lx - 1) + s1.r * (lx - 1) + s1.c] = e[w];
         else if (kind == BOND_V) e_v[w * (ly - 1) * lx + s1.r * lx + s1.c] = e[w];
@@ -1647,8 +1681,8 @@ class SpinOneHalfTriJ1J2HeisenbergSqrPEPS : public SpinOneHalfMeasurementHooks {
       for (size_t r = 0; r < row; ++r) c.ShiftBMPSWindow(DOWN);
       c.InitBTen(LEFT, row);
       c.GrowFullBTen(RIGHT, row, 1, true);
-      std::vector<double> inv_psi = c.Trace({row, 0}, HORIZONTAL);
-      for (auto &v : inv_psi) v = 1.0 / v;
+      std::vector<TenElemT> inv_psi = c.Trace({row, 0}, HORIZONTAL);
+      for (auto &v : inv_psi) v = TenElemT(1.0) / v;
       for (size_t col = 0; col + 1 < lx; ++col) c.ShiftBTenWindow(RIGHT);
       EvaluateOffDiagOrderInRow(comp, row, inv_psi, out);
     }
@@ -1660,9 +1694,8 @@ class SpinOneHalfTriJ1J2HeisenbergSqrPEPS : public SpinOneHalfMeasurementHooks {
         for (size_t j = i; j < N; ++j)
           all[k++] = comp.config(w, {i / lx, i % lx}) == comp.config(w, {j / lx, j % lx}) ? 0.25 : -0.25;
     }
-    last_psi_.psi_mean.assign(n, 0.0);
-    last_psi_.psi_rel_err.assign(n, 0.0);
-    std::vector<double> one(scratch.psi_list.size());
+    last_psi_.assign(n);
+    std::vector<TenElemT> one(scratch.psi_list.size());
     for (size_t w = 0; w < n; ++w) {
       for (size_t k = 0; k < one.size(); ++k) one[k] = scratch.psi_list[k][w];
       auto s = ComputePsiConsistencySummaryAligned(one);
@@ -1671,7 +1704,8 @@ class SpinOneHalfTriJ1J2HeisenbergSqrPEPS : public SpinOneHalfMeasurementHooks {
     }
     return out;
   }
-  const PsiSummary &EvaluatePsiSummary() const { return last_psi_; }
+  PsiSummary EvaluatePsiSummary() const { return last_psi_.As<double>(); }
+  template <typename TenElemT> PsiSummaryT<TenElemT> EvaluatePsiSummaryT() const { return last_psi_.As<TenElemT>(); }
   std::vector<ObservableMeta> DescribeObservables(size_t ly, size_t lx) const {   // :279-297
     const size_t N = ly * lx;
     return {{"energy", "Total energy (scalar)", {}, {}},
@@ -1796,7 +1830,7 @@ class SpinOneHalfTriJ1J2HeisenbergSqrPEPS : public SpinOneHalfMeasurementHooks {
     }
   }
   double j2_;
-  PsiSummary last_psi_;
+  PsiSummaryStore last_psi_;
 };
 
 // square_spinless_fermion.h:51-200: H = -t sum_<ij> (c+_i c_j + h.c.) - t2 sum_<<ij>> (c+_i c_j + h.c.) + V sum_<ij> n_i n_j.
@@ -1898,7 +1932,7 @@ class SquareSpinlessFermion : public SquareNNModelEnergySolver<SquareSpinlessFer
           const std::vector<TenElemT> psi_ex = ct.ReplacePlaquetteTrace(q[0], 2, cand, 1, 1);
           for (size_t w = 0; w < n; ++w)
             for (int diag = 0; diag < 2; ++diag)
-              if (jw[w * 2 + diag] != 0.0) energy[w] += TenElemT(-t2_ * jw[w * 2 + diag]) * psi_ex[w * 2 + diag] / psi[w];
+              if (jw[w * 2 + diag] != 0.0) energy[w] += TenElemT(-t2_ * jw[w * 2 + diag]) * ComplexConjugate(TenElemT(psi_ex[w * 2 + diag] / psi[w]));   // :210
         }
         if (col + 2 < cols) {      // both LEFT chains advance over column col (set 1 under the row+1 override)
           ct.GrowBTen2Step(LEFT, row);
@@ -1939,17 +1973,18 @@ class SquareSpinlessFermion : public SquareNNModelEnergySolver<SquareSpinlessFer
             if (orig(w, a) == orig(w, b)) continue;
             int between = 0;
             for (size_t q = ia + 1; q < ib; ++q) between += comp.fermion->n(orig(w, {q / cols, q % cols}));
-            energy[w] += TenElemT(-t2_ * ((between & 1) ? -1.0 : 1.0)) * comp.amplitude[w] / psi0[w];
+            energy[w] += TenElemT(-t2_ * ((between & 1) ? -1.0 : 1.0)) * ComplexConjugate(TenElemT(comp.amplitude[w] / psi0[w]));
           }
         }
     comp.ReplaceGlobalConfig(orig);
   }
   double CalDensityImpl(int32_t config) const { return double(1 - config); }   // :95-97
-  std::vector<double> EvaluateBondEnergy(const SiteIdx &s1, const SiteIdx &s2, BondOrientation orient,
-                                         TPSWaveFunctionComponent &comp, const std::vector<double> &) {   // :134-159
+  template <typename TenElemT>
+  std::vector<TenElemT> EvaluateBondEnergy(const SiteIdx &s1, const SiteIdx &s2, BondOrientation orient,
+                                           TPSWaveFunctionComponentT<TenElemT> &comp, const std::vector<TenElemT> &) {   // :134-159
     const size_t n = comp.config.walkers();
     std::vector<int32_t> cand(n * 2);
-    std::vector<double> e(n);
+    std::vector<TenElemT> e(n);
     bool any = false;
     for (size_t w = 0; w < n; ++w) {
       cand[2 * w] = comp.config(w, s2);
@@ -1958,10 +1993,10 @@ class SquareSpinlessFermion : public SquareNNModelEnergySolver<SquareSpinlessFer
       e[w] = V_ * CalDensityImpl(comp.config(w, s1)) * CalDensityImpl(comp.config(w, s2));
     }
     if (!any) return e;
-    std::vector<double> psi = comp.contractor.Trace(s1, orient);
-    std::vector<double> psi_ex = comp.ReplaceNNSiteTrace(s1, s2, orient, 1, cand);
+    std::vector<TenElemT> psi = comp.contractor.Trace(s1, orient);
+    std::vector<TenElemT> psi_ex = comp.ReplaceNNSiteTrace(s1, s2, orient, 1, cand);
     for (size_t w = 0; w < n; ++w)
-      if (comp.config(w, s1) != comp.config(w, s2)) e[w] += -t_ * psi_ex[w] / psi[w];
+      if (comp.config(w, s1) != comp.config(w, s2)) e[w] += -t_ * ComplexConjugate(TenElemT(psi_ex[w] / psi[w]));   // :156
     return e;
   }
   double EvaluateTotalOnsiteEnergy(const Configuration &, size_t) const { return 0.0; }   // :92
@@ -1977,11 +2012,12 @@ class SquaretJVModel : public SquareNNModelEnergySolver<SquaretJVModel> {
   SquaretJVModel(double t, double t2, double J, double V, double mu) : t_(t), J_(J), V_(V), mu_(mu) {
     if (t2 != 0.0) throw std::invalid_argument("SquaretJVModel: t2 != 0 (NNN hopping) is not implemented on the device");
   }
-  std::vector<double> EvaluateBondEnergy(const SiteIdx &s1, const SiteIdx &s2, BondOrientation orient,
-                                         TPSWaveFunctionComponent &comp, const std::vector<double> &) {
+  template <typename TenElemT>
+  std::vector<TenElemT> EvaluateBondEnergy(const SiteIdx &s1, const SiteIdx &s2, BondOrientation orient,
+                                           TPSWaveFunctionComponentT<TenElemT> &comp, const std::vector<TenElemT> &) {
     const size_t n = comp.config.walkers();
     std::vector<int32_t> cand(n * 2);
-    std::vector<double> e(n, 0.0);
+    std::vector<TenElemT> e(n, TenElemT(0.0));
     bool any = false;
     for (size_t w = 0; w < n; ++w) {
       const int32_t c1 = comp.config(w, s1), c2 = comp.config(w, s2);
@@ -1991,13 +2027,13 @@ class SquaretJVModel : public SquareNNModelEnergySolver<SquaretJVModel> {
       else any = true;
     }
     if (!any) return e;
-    std::vector<double> psi = comp.contractor.Trace(s1, orient);
-    std::vector<double> psi_ex = comp.ReplaceNNSiteTrace(s1, s2, orient, 1, cand);
+    std::vector<TenElemT> psi = comp.contractor.Trace(s1, orient);
+    std::vector<TenElemT> psi_ex = comp.ReplaceNNSiteTrace(s1, s2, orient, 1, cand);
     for (size_t w = 0; w < n; ++w) {
       const int32_t c1 = comp.config(w, s1), c2 = comp.config(w, s2);
       if (c1 == c2) continue;
-      const double ratio = psi_ex[w] / psi[w];
-      e[w] = (c1 == 2 || c2 == 2) ? -t_ * ratio : (-0.5 + 0.5 * ratio) * J_ + V_;      // :334-343
+      const TenElemT ratio = ComplexConjugate(TenElemT(psi_ex[w] / psi[w]));
+      e[w] = (c1 == 2 || c2 == 2) ? TenElemT(-t_ * ratio) : TenElemT((-0.5 + 0.5 * ratio) * J_ + V_);      // :334-343
     }
     return e;
   }
@@ -2061,30 +2097,31 @@ class TransverseFieldIsingSquareOBC {
   // Registry of the model (:60-152): energy, spin_z, sigma_x per site (= -off-diagonal term / h; 0 for h = 0), SzSz_row along the
   // middle row (x0 = lx / 4, i = 1 .. lx / 2).  Same row pass as the energy.  (Round 4: the oracle form is pinned on the reference's
   // exact-sum measurer numbers at 1e-10, tests/test_oracle_measure.py; this device form has not been run on the GPU yet.)
-  ObservableMap EvaluateObservables(const SplitIndexTPS &, TPSWaveFunctionComponent &comp) {
+  template <typename TenElemT>
+  ObservableMapT<TenElemT> EvaluateObservables(const SplitIndexTPST<TenElemT> &, TPSWaveFunctionComponentT<TenElemT> &comp) {
     auto &c = comp.contractor;
     const size_t ly = c.rows(), lx = c.cols(), n = comp.config.walkers(), half = lx / 2;
-    ObservableMap out;
+    ObservableMapT<TenElemT> out;
     out.n = n;
     auto &sx = out.make("sigma_x", ly * lx);
     auto &sz = out.make("spin_z", ly * lx);
     auto &en = out.make("energy", 1);
-    std::vector<std::vector<double>> psi_list;
+    std::vector<std::vector<TenElemT>> psi_list;
     c.GenerateBMPSApproach(UP);
     for (size_t row = 0; row < ly; ++row) {
       c.InitBTen(LEFT, row);
       c.GrowFullBTen(RIGHT, row, 1, true);
       psi_list.push_back(c.Trace({row, 0}, HORIZONTAL));
-      const std::vector<double> &psi = psi_list.back();
+      const std::vector<TenElemT> &psi = psi_list.back();
       for (size_t col = 0; col < lx; ++col) {
         std::vector<int32_t> cand(n);
         for (size_t w = 0; w < n; ++w) cand[w] = 1 - comp.config(w, {row, col});
-        std::vector<double> psi_ex = c.ReplaceOneSiteTrace({row, col}, HORIZONTAL, 1, cand);          // :195-203
+        std::vector<TenElemT> psi_ex = c.ReplaceOneSiteTrace({row, col}, HORIZONTAL, 1, cand);        // :195-203
         for (size_t w = 0; w < n; ++w) {
-          if (psi[w] == 0.0) throw std::runtime_error("Wavefunction amplitude is near zero, causing division by zero.");
-          const double ex = (-h_) * (psi_ex[w] / psi[w]);
+          if (psi[w] == TenElemT(0.0)) throw std::runtime_error("Wavefunction amplitude is near zero, causing division by zero.");
+          const TenElemT ex = (-h_) * ComplexConjugate(TenElemT(psi_ex[w] / psi[w]));                 // :202
           en[w] += ex;
-          sx[w * ly * lx + row * lx + col] = h_ != 0.0 ? -ex / h_ : 0.0;                              // :96
+          sx[w * ly * lx + row * lx + col] = h_ != 0.0 ? TenElemT(-ex / h_) : TenElemT(0.0);          // :96
         }
         if (col + 1 < lx) c.ShiftBTenWindow(RIGHT);
       }
@@ -2097,9 +2134,8 @@ class TransverseFieldIsingSquareOBC {
       }
       if (row + 1 < ly) c.ShiftBMPSWindow(DOWN);
     }
-    last_psi_.psi_mean.assign(n, 0.0);
-    last_psi_.psi_rel_err.assign(n, 0.0);
-    std::vector<double> one(psi_list.size());
+    last_psi_.assign(n);
+    std::vector<TenElemT> one(psi_list.size());
     for (size_t w = 0; w < n; ++w) {
       en[w] += CalDiagTermEnergy(comp.config, w);
       for (size_t r = 0; r < ly; ++r)
@@ -2111,7 +2147,8 @@ class TransverseFieldIsingSquareOBC {
     }
     return out;
   }
-  const PsiSummary &EvaluatePsiSummary() const { return last_psi_; }
+  PsiSummary EvaluatePsiSummary() const { return last_psi_.As<double>(); }
+  template <typename TenElemT> PsiSummaryT<TenElemT> EvaluatePsiSummaryT() const { return last_psi_.As<TenElemT>(); }
   std::vector<ObservableMeta> DescribeObservables(size_t ly, size_t lx) const {                        // :142-149
     return {{"energy", "Total energy (scalar)", {}, {}},
             {"spin_z", "Local spin Sz per site (Ly,Lx)", {ly, lx}, {"y", "x"}},
@@ -2120,7 +2157,7 @@ class TransverseFieldIsingSquareOBC {
   }
  private:
   double h_;
-  PsiSummary last_psi_;
+  PsiSummaryStore last_psi_;
 };
 
 // Accumulators of the evaluators: S_O = sum w O*, S_EO = sum w E_loc* O*, sum w, sum w E_loc
@@ -2364,10 +2401,10 @@ class MonteCarloEngine {
 struct MCMeasurementParams {                       // MonteCarloParams (monte_carlo_peps_params.h)
   size_t num_samples = 1, num_warmup_sweeps = 0, sweeps_between_samples = 1;
 };
-template <class MonteCarloSweepUpdater, class MeasurementSolver>
+template <class MonteCarloSweepUpdater, class MeasurementSolver, typename TenElemT = double>
 class MCPEPSMeasurer {
  public:
-  MCPEPSMeasurer(const SplitIndexTPS &sitps, TPSWaveFunctionComponent &comp, const MCMeasurementParams &params,
+  MCPEPSMeasurer(const SplitIndexTPST<TenElemT> &sitps, TPSWaveFunctionComponentT<TenElemT> &comp, const MCMeasurementParams &params,
                  MonteCarloSweepUpdater &updater, MeasurementSolver &solver)
       : sitps_(sitps), comp_(comp), params_(params), updater_(updater), solver_(solver) {
     observables_meta_ = solver_.DescribeObservables(comp.contractor.rows(), comp.contractor.cols());
@@ -2379,24 +2416,24 @@ class MCPEPSMeasurer {
     MonteCarloParams mc;
     mc.num_warmup_sweeps = params_.num_warmup_sweeps;
     mc.sweeps_between_samples = params_.sweeps_between_samples;
-    MonteCarloEngine<MonteCarloSweepUpdater> engine(sitps_, comp_, mc, updater_);
+    MonteCarloEngine<MonteCarloSweepUpdater, TenElemT> engine(sitps_, comp_, mc, updater_);
     engine.WarmUp();
     scale_factor_ = engine.LastScaleFactor();
     Measure_();
   }
   double StateScaleFactor() const { return scale_factor_; }   // overall factor of NormalizeStateOrder1 (1 / max |psi| after warm-up)
-  const SplitIndexTPS &State() const { return sitps_; }       // the rescaled state the samples were taken on
-  // key -> (mean, stderr) over the walkers of this batch
-  const std::map<std::string, std::pair<std::vector<double>, std::vector<double>>> &ObservableRegistry() const { return registry_stats_; }
+  const SplitIndexTPST<TenElemT> &State() const { return sitps_; }       // the rescaled state the samples were taken on
+  // key -> (mean, stderr) over the walkers of this batch; the mean has the element type, the standard error is real (statistics.h:289-340)
+  const std::map<std::string, std::pair<std::vector<TenElemT>, std::vector<double>>> &ObservableRegistry() const { return registry_stats_; }
   // per-walker sample means [key][walker][len]: what a rank contributes to GatherStatisticListOfData
-  const std::map<std::string, std::vector<double>> &WalkerMeans() const { return walker_means_; }
-  std::pair<double, double> OutputEnergy() const {  // :676-690
+  const std::map<std::string, std::vector<TenElemT>> &WalkerMeans() const { return walker_means_; }
+  std::pair<TenElemT, double> OutputEnergy() const {  // :676-690
     const auto &e = registry_stats_.at("energy");
     return {e.first[0], e.second.empty() ? 0.0 : e.second[0]};
   }
   const std::vector<double> &AcceptRates() const { return accept_avg_; }
   // psi_samples[sample][walker] = (psi_mean, psi_rel_err)
-  const std::vector<std::vector<std::pair<double, double>>> &PsiSamples() const { return psi_samples_; }
+  const std::vector<std::vector<std::pair<TenElemT, double>>> &PsiSamples() const { return psi_samples_; }
   // stats/<key>_mean.csv + <key>_stderr.csv for two-dimensional observables, stats/<key>.csv ("index,mean,stderr") otherwise,
   // samples/psi.csv (impl.h:262-345, :544-640)
   void DumpData(const std::string &dir) const {
@@ -2408,7 +2445,8 @@ class MCPEPSMeasurer {
     };
     mk(base + "stats");
     mk(base + "samples");
-    auto csv = [](double v) {
+    auto csv = [](const auto &val) {                 // (a complex mean is written by its real part, as the reference's DumpVecData)
+      const double v = std::real(val);
       std::ostringstream oss;
       oss.setf(std::ios::scientific, std::ios::floatfield);
       oss << std::setprecision(std::numeric_limits<double>::max_digits10) << v;
@@ -2448,7 +2486,7 @@ class MCPEPSMeasurer {
     const size_t n = comp_.config.walkers();
     std::vector<double> rates;
     accept_avg_.assign(n, 0.0);
-    std::map<std::string, std::vector<double>> sum;
+    std::map<std::string, std::vector<TenElemT>> sum;
     for (size_t sample = 0; sample < params_.num_samples; ++sample) {
       std::vector<double> acc(n, 0.0);
       for (size_t k = 0; k < params_.sweeps_between_samples; ++k) {    // engine_.StepSweep()
@@ -2456,14 +2494,14 @@ class MCPEPSMeasurer {
         for (size_t w = 0; w < n; ++w) acc[w] += rates[w];
       }
       for (size_t w = 0; w < n; ++w) accept_avg_[w] += acc[w] / double(std::max<size_t>(params_.sweeps_between_samples, 1));
-      ObservableMap obs = solver_.EvaluateObservables(sitps_, comp_);  // MeasureSample_ (:193-238)
+      ObservableMapT<TenElemT> obs = solver_.EvaluateObservables(sitps_, comp_);  // MeasureSample_ (:193-238)
       for (const auto &kv : obs.values) {
         auto &dst = sum[kv.first];
-        if (dst.empty()) dst.assign(kv.second.size(), 0.0);
+        if (dst.empty()) dst.assign(kv.second.size(), TenElemT(0.0));
         for (size_t k = 0; k < kv.second.size(); ++k) dst[k] += kv.second[k];
       }
-      const PsiSummary &ps = solver_.EvaluatePsiSummary();
-      std::vector<std::pair<double, double>> row(n);
+      const PsiSummaryT<TenElemT> ps = solver_.template EvaluatePsiSummaryT<TenElemT>();
+      std::vector<std::pair<TenElemT, double>> row(n);
       for (size_t w = 0; w < n; ++w) row[w] = {ps.psi_mean[w], ps.psi_rel_err[w]};
       psi_samples_.push_back(row);
     }
@@ -2472,7 +2510,8 @@ class MCPEPSMeasurer {
     for (auto &kv : sum) {
       for (auto &v : kv.second) v /= double(params_.num_samples);
       const size_t len = kv.second.size() / n;
-      std::vector<double> mean(len, 0.0), err;
+      std::vector<TenElemT> mean(len, TenElemT(0.0));
+      std::vector<double> err;
       for (size_t w = 0; w < n; ++w)
         for (size_t k = 0; k < len; ++k) mean[k] += kv.second[w * len + k];
       for (auto &m : mean) m /= double(n);
@@ -2480,7 +2519,7 @@ class MCPEPSMeasurer {
         err.assign(len, 0.0);
         for (size_t k = 0; k < len; ++k) {
           double var = 0.0;
-          for (size_t w = 0; w < n; ++w) var += (kv.second[w * len + k] - mean[k]) * (kv.second[w * len + k] - mean[k]);
+          for (size_t w = 0; w < n; ++w) var += std::norm(kv.second[w * len + k] - mean[k]);
           err[k] = std::sqrt(var / double(n) / (double(n) - 1.0));      // StandardError (:89-96)
         }
       }
@@ -2488,16 +2527,16 @@ class MCPEPSMeasurer {
       walker_means_[kv.first] = kv.second;
     }
   }
-  SplitIndexTPS sitps_;                             // by value, as the reference's engine holds split_index_tps_: it is rescaled
+  SplitIndexTPST<TenElemT> sitps_;                  // by value, as the reference's engine holds split_index_tps_: it is rescaled
   double scale_factor_ = 1.0;
-  TPSWaveFunctionComponent &comp_;
+  TPSWaveFunctionComponentT<TenElemT> &comp_;
   MCMeasurementParams params_;
   MonteCarloSweepUpdater &updater_;
   MeasurementSolver &solver_;
   std::vector<ObservableMeta> observables_meta_;
-  std::map<std::string, std::pair<std::vector<double>, std::vector<double>>> registry_stats_;
-  std::map<std::string, std::vector<double>> walker_means_;
-  std::vector<std::vector<std::pair<double, double>>> psi_samples_;
+  std::map<std::string, std::pair<std::vector<TenElemT>, std::vector<double>>> registry_stats_;
+  std::map<std::string, std::vector<TenElemT>> walker_means_;
+  std::vector<std::vector<std::pair<TenElemT, double>>> psi_samples_;
   std::vector<double> accept_avg_;
 };
 
@@ -2526,15 +2565,16 @@ inline std::vector<std::vector<int32_t>> GenerateAllBinaryConfigs(size_t Lx, siz
 // O_loc from the solver's registry (EvaluateObservables).  Configurations i = rank, rank + size, ... of this rank go
 // through the device `batch` walkers at a time; `allreduce` sums [weight | key values in sorted key order] over the
 // ranks in place (identity if null: the result is then this rank's share, normalised by its own weight).
-template <typename MeasurementSolverT>
-std::map<std::string, std::vector<double>> ExactSumMeasurer(const SplitIndexTPS &sitps, const std::vector<std::vector<int32_t>> &all_configs,
-                                                            BMPSContractor &contractor, MeasurementSolverT &solver, int rank, int size,
-                                                            size_t batch, const std::function<void(std::vector<double> &)> &allreduce,
-                                                            double *weight_sum_out = nullptr) {
+// QLTEN_Complex: the packed vector carries every value as a (re, im) pair after the (real) weight.
+template <typename MeasurementSolverT, typename TenElemT>
+std::map<std::string, std::vector<TenElemT>> ExactSumMeasurer(const SplitIndexTPST<TenElemT> &sitps, const std::vector<std::vector<int32_t>> &all_configs,
+                                                              BMPSContractorT<TenElemT> &contractor, MeasurementSolverT &solver, int rank, int size,
+                                                              size_t batch, const std::function<void(std::vector<double> &)> &allreduce,
+                                                              double *weight_sum_out = nullptr) {
   if (all_configs.empty()) throw std::invalid_argument("ExactSumMeasurerMPI: all_configs must not be empty");     // :113-115
   const size_t rows = sitps.rows(), cols = sitps.cols();
   double weight_rank = 0.0;
-  std::map<std::string, std::vector<double>> weighted;          // std::map: keys already in the sorted order of :153-171
+  std::map<std::string, std::vector<TenElemT>> weighted;        // std::map: keys already in the sorted order of :153-171
   std::vector<size_t> mine;
   for (size_t i = rank; i < all_configs.size(); i += size) mine.push_back(i);                                     // :130
   // the packed layout comes from the keys this rank evaluated (the reference broadcasts the master's, :173-206)
@@ -2546,27 +2586,31 @@ std::map<std::string, std::vector<double>> ExactSumMeasurer(const SplitIndexTPS 
     const size_t nb = std::min(batch, mine.size() - b0);
     Configuration cfg(nb, rows, cols);
     for (size_t w = 0; w < nb; ++w) std::copy(all_configs[mine[b0 + w]].begin(), all_configs[mine[b0 + w]].end(), cfg.data() + w * rows * cols);
-    TPSWaveFunctionComponent comp(sitps, cfg, contractor);
-    const std::vector<double> psi = comp.amplitude;            // the solver's passes may touch comp
-    ObservableMap obs = solver.EvaluateObservables(sitps, comp);
-    for (size_t w = 0; w < nb; ++w) weight_rank += psi[w] * psi[w];                                                // :135-136
+    TPSWaveFunctionComponentT<TenElemT> comp(sitps, cfg, contractor);
+    const std::vector<TenElemT> psi = comp.amplitude;          // the solver's passes may touch comp
+    ObservableMapT<TenElemT> obs = solver.EvaluateObservables(sitps, comp);
+    for (size_t w = 0; w < nb; ++w) weight_rank += std::norm(psi[w]);                                              // :135-136
     for (const auto &kv : obs.values) {
       const size_t len = kv.second.size() / nb;
       auto &acc = weighted[kv.first];
-      if (acc.empty()) acc.assign(len, 0.0);
+      if (acc.empty()) acc.assign(len, TenElemT(0.0));
       for (size_t w = 0; w < nb; ++w)
-        for (size_t j = 0; j < len; ++j) acc[j] += psi[w] * psi[w] * kv.second[w * len + j];                       // :141-149
+        for (size_t j = 0; j < len; ++j) acc[j] += std::norm(psi[w]) * kv.second[w * len + j];                     // :141-149
     }
   }
+  constexpr size_t z = ElemTraits<TenElemT>::is_complex ? 2 : 1;
   std::vector<double> packed{weight_rank};
-  for (const auto &kv : weighted) packed.insert(packed.end(), kv.second.begin(), kv.second.end());
+  for (const auto &kv : weighted) packed.insert(packed.end(), dptr(kv.second.data()), dptr(kv.second.data()) + z * kv.second.size());
   if (allreduce) allreduce(packed);                                                                                // :209-235
   const double weight_sum = packed[0];
   if (weight_sum_out) *weight_sum_out = weight_sum;
   if (!(weight_sum > 0.0)) throw std::runtime_error("ExactSumMeasurerMPI: total weight must be positive");         // :243-245
   size_t off = 1;
   for (auto &kv : weighted)
-    for (auto &v : kv.second) v = packed[off++] / weight_sum;                                                      // :246-250
+    for (auto &v : kv.second) {                                                                                    // :246-250
+      if constexpr (z == 2) v = TenElemT(packed[off], packed[off + 1]) / weight_sum; else v = packed[off] / weight_sum;
+      off += z;
+    }
   return weighted;
 }
 

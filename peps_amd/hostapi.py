@@ -16,7 +16,8 @@ SYMBOLS = ["pepshost_last_error", "pepshost_mc_sweeps", "pepshost_energy_and_hol
            "pepshost_energy_and_holes_c128", "pepshost_exact_sum_partial_c128", "pepshost_exact_sum_finish_c128",
            "pepshost_mc_energy_grad_partial_c128", "pepshost_mc_sweeps_c128", "pepshost_load_sitps_c128", "pepshost_dump_sitps_c128",
            "pepshost_mc_engine_warmup", "pepshost_mc_engine_warmup_dist", "pepshost_suwa_todo_chain", "pepshost_load_configuration2", "pepshost_configuration_from_text",
-           "pepshost_fermion_measure_energy"]
+           "pepshost_fermion_measure_energy", "pepshost_measure_c128", "pepshost_exact_sum_measure_partial_c128", "pepshost_fermion_energy_c128",
+           "pepshost_fermion_exact_sum_partial_c128", "pepshost_fermion_mc_sweeps_c128", "pepshost_fermion_measure_energy_c128"]
 
 _lib = None
 
@@ -156,8 +157,10 @@ def exact_sum_partial(flat, all_configs, chi, model="xxz", params=(1.0, 1.0, 0.0
 def exact_sum_measure_partial(flat, all_configs, chi, model="xxz", params=(1.0, 1.0, 0.0), rank=0, size=1, batch=64, dtype=1):
     """Rank-local part of ExactSumMeasurerMPI (exact_summation_measurer.h:103-257) through the C++ measurement solver:
     (dict key -> sum_S |psi(S)|^2 O_loc(S), sum_S |psi(S)|^2) over configurations rank, rank + size, ...  Sum both over
-    the ranks and divide.  all_configs = None: every binary configuration (GenerateAllBinaryConfigs, :53-72)."""
-    flat = np.ascontiguousarray(flat, dtype=np.float64)
+    the ranks and divide.  all_configs = None: every binary configuration (GenerateAllBinaryConfigs, :53-72).
+    A complex `flat` runs the QLTEN_Complex instantiation (float64 arithmetic; `dtype` is ignored): complex sums."""
+    cplx = np.iscomplexobj(flat)
+    flat = np.ascontiguousarray(flat, dtype=np.complex128 if cplx else np.float64)
     rows, cols, d, D = _dims(flat)
     cfg = None if all_configs is None else np.ascontiguousarray(all_configs, dtype=np.int32)
     p = np.zeros(8, dtype=np.float64)
@@ -170,15 +173,23 @@ def exact_sum_measure_partial(flat, all_configs, chi, model="xxz", params=(1.0, 
     l.pepshost_exact_sum_measure_partial.argtypes = [C.c_int] * 6 + [C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int, C.c_int,
                                                      C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int,
                                                      C.POINTER(C.c_double), C.c_long, C.POINTER(C.c_long)]
-    _ck(l.pepshost_exact_sum_measure_partial(rows, cols, D, d, chi, dtype, _p(flat, C.c_double),
-                                             None if cfg is None else _p(cfg, C.c_int32), -1 if cfg is None else cfg.shape[0],
-                                             MODEL_ID[model], _p(p, C.c_double), rank, size, batch, keys, 4096,
-                                             _p(vals, C.c_double), cap, C.byref(nvals)))
-    out, off = {}, 1
+    l.pepshost_exact_sum_measure_partial_c128.argtypes = [C.c_int] * 5 + l.pepshost_exact_sum_measure_partial.argtypes[6:]
+    if cplx:
+        _ck(l.pepshost_exact_sum_measure_partial_c128(rows, cols, D, d, chi, _cp(flat),
+                                                      None if cfg is None else _p(cfg, C.c_int32), -1 if cfg is None else cfg.shape[0],
+                                                      MODEL_ID[model], _p(p, C.c_double), rank, size, batch, keys, 4096,
+                                                      _p(vals, C.c_double), cap, C.byref(nvals)))
+    else:
+        _ck(l.pepshost_exact_sum_measure_partial(rows, cols, D, d, chi, dtype, _p(flat, C.c_double),
+                                                 None if cfg is None else _p(cfg, C.c_int32), -1 if cfg is None else cfg.shape[0],
+                                                 MODEL_ID[model], _p(p, C.c_double), rank, size, batch, keys, 4096,
+                                                 _p(vals, C.c_double), cap, C.byref(nvals)))
+    out, off, z = {}, 1, 2 if cplx else 1
     for item in filter(None, keys.value.decode().split(";")):    # a rank without configurations reports no keys
         key, ln = item.split(":")
-        out[key] = vals[off:off + int(ln)].copy()
-        off += int(ln)
+        seg = vals[off:off + z * int(ln)].copy()
+        out[key] = seg.view(np.complex128) if cplx else seg
+        off += z * int(ln)
     return out, float(vals[0])
 
 
@@ -224,14 +235,17 @@ def measure(flat, configs, chi, model="xxz", params=(1.0, 1.0, 0.0), seeds=None,
     square_nnn_model_measurement_solver.h) on fixed configurations (n_samples = 0: dict key -> [walker][len]) or a whole
     MCPEPSMeasurer run (n_samples > 0: dict key -> (mean[len], stderr[len]) across the walkers; configs updated in place;
     dump_dir: stats/*.csv + samples/psi.csv as the reference writes them).  Also returns the psi summary of the last
-    sample: (psi_mean[walker], psi_rel_err[walker])."""
+    sample: (psi_mean[walker], psi_rel_err[walker]).  A complex `flat` runs the QLTEN_Complex instantiation: complex values and means,
+    real standard errors."""
+    cplx = np.iscomplexobj(flat)
+    flat = np.ascontiguousarray(flat, dtype=np.complex128 if cplx else np.float64)
     rows, cols, d, D = _dims(flat)
     cfg = np.ascontiguousarray(configs, dtype=np.int32)
     n = cfg.shape[0]
     sd = np.ascontiguousarray(np.zeros(n) if seeds is None else seeds, dtype=np.uint64)
     p = np.zeros(8, dtype=np.float64)
     p[:len(params)] = params
-    cap = 4 * n * (rows * cols) ** 2 + 65536
+    cap = 8 * n * (rows * cols) ** 2 + 65536
     vals = np.zeros(cap, dtype=np.float64)
     keys = C.create_string_buffer(4096)
     nvals = C.c_long(0)
@@ -239,21 +253,29 @@ def measure(flat, configs, chi, model="xxz", params=(1.0, 1.0, 0.0), seeds=None,
     l.pepshost_measure.argtypes = [C.c_int] * 6 + [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
                                    C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p,
                                    C.c_int, C.POINTER(C.c_double), C.c_long, C.POINTER(C.c_long)]
-    _ck(l.pepshost_measure(rows, cols, D, d, chi, dtype, _p(flat, C.c_double), n, _p(cfg, C.c_int32), _p(sd, C.c_uint64),
-                           {"exchange": 0, "fullspace": 1}[updater], MODEL_ID[model], _p(p, C.c_double), warmup_sweeps,
-                           n_samples, sweeps_between_samples, dump_dir.encode(), keys, 4096, _p(vals, C.c_double), cap,
-                           C.byref(nvals)))
+    l.pepshost_measure_c128.argtypes = [C.c_int] * 5 + l.pepshost_measure.argtypes[6:]
+    if cplx:
+        _ck(l.pepshost_measure_c128(rows, cols, D, d, chi, _cp(flat), n, _p(cfg, C.c_int32), _p(sd, C.c_uint64),
+                                    {"exchange": 0, "fullspace": 1}[updater], MODEL_ID[model], _p(p, C.c_double), warmup_sweeps,
+                                    n_samples, sweeps_between_samples, dump_dir.encode(), keys, 4096, _p(vals, C.c_double), cap,
+                                    C.byref(nvals)))
+        vals = vals[:nvals.value].view(np.complex128)          # every number is a (re, im) pair
+    else:
+        _ck(l.pepshost_measure(rows, cols, D, d, chi, dtype, _p(flat, C.c_double), n, _p(cfg, C.c_int32), _p(sd, C.c_uint64),
+                               {"exchange": 0, "fullspace": 1}[updater], MODEL_ID[model], _p(p, C.c_double), warmup_sweeps,
+                               n_samples, sweeps_between_samples, dump_dir.encode(), keys, 4096, _p(vals, C.c_double), cap,
+                               C.byref(nvals)))
     out, off = {}, 0
     for item in keys.value.decode().strip(";").split(";"):
         key, ln = item.split(":")
         ln = int(ln)
         if n_samples > 0:
-            out[key] = (vals[off:off + ln].copy(), vals[off + ln:off + 2 * ln].copy())
+            out[key] = (vals[off:off + ln].copy(), np.real(vals[off + ln:off + 2 * ln]).copy())
             off += 2 * ln
         else:
             out[key] = vals[off:off + n * ln].reshape(n, ln).copy()
             off += n * ln
-    psi = (vals[off:off + n].copy(), vals[off + n:off + 2 * n].copy())
+    psi = (vals[off:off + n].copy(), np.real(vals[off + n:off + 2 * n]).copy())
     if n_samples > 0:
         configs[...] = cfg
     return out, psi
@@ -296,33 +318,47 @@ def configuration_from_text(text, rows, cols):
 
 def fermion_energy(state, configs, chi, t, V=0.0, dtype=1, model="spinless", J=0.0, mu=0.0, t2=0.0):
     """C++ host layer on a fermionic state (peps_amd.fermion.FermionState): amplitudes (row-major mode order),
-    E_loc of the spinless t-V model (model="spinless") or of the t-J-V model (model="tj"), psi along every route."""
-    flat = np.ascontiguousarray(state.extended_flat(), dtype=np.float64)
+    E_loc of the spinless t-V model (model="spinless") or of the t-J-V model (model="tj"), psi along every route.
+    A complex state (SplitIndexTPS<QLTEN_Complex, fZ2QN>) runs the complex instantiation in float64 (`dtype` ignored)."""
+    cplx = state.is_complex
+    et = np.complex128 if cplx else np.float64
+    flat = np.ascontiguousarray(state.extended_flat(), dtype=et)
     rows, cols, D = flat.shape[0], flat.shape[1], flat.shape[3]
     cfg = np.ascontiguousarray(configs, dtype=np.int32)
     n = cfg.shape[0]
     nf = np.ascontiguousarray(state.nf, dtype=np.int32)
-    amps, en = np.zeros(n), np.zeros(n)
-    psi = np.zeros((rows + cols, n))
+    amps, en = np.zeros(n, et), np.zeros(n, et)
+    psi = np.zeros((rows + cols, n), et)
     npsi = C.c_int(0)
     prm = np.array([t, V, t2, 0.0] if model == "spinless" else [t, J, V, mu], dtype=np.float64)
-    _ck(lib().pepshost_fermion_energy(rows, cols, D, state.d, _p(nf, C.c_int32), chi, dtype, _p(flat, C.c_double), n,
-                                      _p(cfg, C.c_int32), 0 if model == "spinless" else 1, _p(prm, C.c_double),
-                                      _p(amps, C.c_double), _p(en, C.c_double), _p(psi, C.c_double), C.byref(npsi)))
+    if cplx:
+        _ck(lib().pepshost_fermion_energy_c128(rows, cols, D, state.d, _p(nf, C.c_int32), chi, _cp(flat), n,
+                                               _p(cfg, C.c_int32), 0 if model == "spinless" else 1, _p(prm, C.c_double),
+                                               _cp(amps), _cp(en), _cp(psi), C.byref(npsi)))
+    else:
+        _ck(lib().pepshost_fermion_energy(rows, cols, D, state.d, _p(nf, C.c_int32), chi, dtype, _p(flat, C.c_double), n,
+                                          _p(cfg, C.c_int32), 0 if model == "spinless" else 1, _p(prm, C.c_double),
+                                          _p(amps, C.c_double), _p(en, C.c_double), _p(psi, C.c_double), C.byref(npsi)))
     return amps, en, psi[:npsi.value]
 
 
 def fermion_mc_sweeps(state, configs, seeds, chi, n_sweeps=1, dtype=1):
-    flat = np.ascontiguousarray(state.extended_flat(), dtype=np.float64)
+    cplx = state.is_complex
+    et = np.complex128 if cplx else np.float64
+    flat = np.ascontiguousarray(state.extended_flat(), dtype=et)
     rows, cols, D = flat.shape[0], flat.shape[1], flat.shape[3]
     cfg = np.ascontiguousarray(configs, dtype=np.int32).copy()
     n = cfg.shape[0]
     nf = np.ascontiguousarray(state.nf, dtype=np.int32)
     sd = np.ascontiguousarray(seeds, dtype=np.uint64)
-    amps, rates = np.zeros(n), np.zeros(n)
-    _ck(lib().pepshost_fermion_mc_sweeps(rows, cols, D, state.d, _p(nf, C.c_int32), chi, dtype, _p(flat, C.c_double), n,
-                                         _p(cfg, C.c_int32), _p(sd, C.c_uint64), n_sweeps, _p(amps, C.c_double),
-                                         _p(rates, C.c_double)))
+    amps, rates = np.zeros(n, et), np.zeros(n)
+    if cplx:
+        _ck(lib().pepshost_fermion_mc_sweeps_c128(rows, cols, D, state.d, _p(nf, C.c_int32), chi, _cp(flat), n,
+                                                  _p(cfg, C.c_int32), _p(sd, C.c_uint64), n_sweeps, _cp(amps), _p(rates, C.c_double)))
+    else:
+        _ck(lib().pepshost_fermion_mc_sweeps(rows, cols, D, state.d, _p(nf, C.c_int32), chi, dtype, _p(flat, C.c_double), n,
+                                             _p(cfg, C.c_int32), _p(sd, C.c_uint64), n_sweeps, _p(amps, C.c_double),
+                                             _p(rates, C.c_double)))
     return cfg, amps, rates
 
 
@@ -330,17 +366,24 @@ def fermion_measure_energy(state, configs, seeds, chi, warmup_sweeps, n_samples,
                            t2=0.0, dtype=1):
     """MCPEPSMeasurer's energy samples on a fermionic state with ONE std::mt19937 stream per walker over warm-up, rebuild and samples
     (pepshost_fermion_measure_energy): (energies [sample][walker], final configurations, accept rates)."""
-    flat = np.ascontiguousarray(state.extended_flat(), dtype=np.float64)
+    cplx = state.is_complex
+    et = np.complex128 if cplx else np.float64
+    flat = np.ascontiguousarray(state.extended_flat(), dtype=et)
     rows, cols, D = flat.shape[0], flat.shape[1], flat.shape[3]
     cfg = np.ascontiguousarray(configs, dtype=np.int32).copy()
     n = cfg.shape[0]
     nf = np.ascontiguousarray(state.nf, dtype=np.int32)
     sd = np.ascontiguousarray(seeds, dtype=np.uint64)
     prm = np.array([t, J, V, mu] if model == "tj" else [t, V, t2, 0.0], dtype=np.float64)
-    en, rates = np.zeros((n_samples, n)), np.zeros(n)
-    _ck(lib().pepshost_fermion_measure_energy(rows, cols, D, state.d, _p(nf, C.c_int32), chi, dtype, _p(flat, C.c_double), n,
-                                              _p(cfg, C.c_int32), _p(sd, C.c_uint64), warmup_sweeps, n_samples, sweeps_between,
-                                              1 if model == "tj" else 0, _p(prm, C.c_double), _p(en, C.c_double), _p(rates, C.c_double)))
+    en, rates = np.zeros((n_samples, n), et), np.zeros(n)
+    if cplx:
+        _ck(lib().pepshost_fermion_measure_energy_c128(rows, cols, D, state.d, _p(nf, C.c_int32), chi, _cp(flat), n,
+                                                       _p(cfg, C.c_int32), _p(sd, C.c_uint64), warmup_sweeps, n_samples, sweeps_between,
+                                                       1 if model == "tj" else 0, _p(prm, C.c_double), _cp(en), _p(rates, C.c_double)))
+    else:
+        _ck(lib().pepshost_fermion_measure_energy(rows, cols, D, state.d, _p(nf, C.c_int32), chi, dtype, _p(flat, C.c_double), n,
+                                                  _p(cfg, C.c_int32), _p(sd, C.c_uint64), warmup_sweeps, n_samples, sweeps_between,
+                                                  1 if model == "tj" else 0, _p(prm, C.c_double), _p(en, C.c_double), _p(rates, C.c_double)))
     return en, cfg, rates
 
 
@@ -348,6 +391,19 @@ def fermion_exact_sum(state, all_configs, chi, t, V=0.0, batch=64, dtype=1):
     """ExactSumEnergyEvaluator on a fermionic state: (energy, gradient [rows][cols][d][D^4] with respect to the
     stored site-tensor components, zero on parity-forbidden entries)."""
     from . import fermion
+    if state.is_complex:                    # QLTEN_Complex: packed = 4 m + 5 doubles, finished by pepshost_exact_sum_finish_c128 on 4 d components
+        flat = np.ascontiguousarray(state.extended_flat(), dtype=np.complex128)
+        rows, cols, D = flat.shape[0], flat.shape[1], flat.shape[3]
+        cfg = np.ascontiguousarray(all_configs, dtype=np.int32)
+        nf = np.ascontiguousarray(state.nf, dtype=np.int32)
+        packed = np.zeros(4 * flat.size + 5)
+        _ck(lib().pepshost_fermion_exact_sum_partial_c128(rows, cols, D, state.d, _p(nf, C.c_int32), chi, _cp(flat),
+                                                          _p(cfg, C.c_int32), cfg.shape[0], C.c_double(t), C.c_double(V), 0, 1, batch,
+                                                          _p(packed, C.c_double)))
+        e = np.zeros(2)
+        grad = np.zeros(flat.shape, dtype=np.complex128)
+        _ck(lib().pepshost_exact_sum_finish_c128(rows, cols, D, 4 * state.d, _p(packed, C.c_double), _p(e, C.c_double), _cp(grad)))
+        return complex(e[0], e[1]), fermion.fold_gradient(state, grad)
     flat = np.ascontiguousarray(state.extended_flat(), dtype=np.float64)
     rows, cols, D = flat.shape[0], flat.shape[1], flat.shape[3]
     cfg = np.ascontiguousarray(all_configs, dtype=np.int32)

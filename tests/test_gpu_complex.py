@@ -285,3 +285,214 @@ def test_complex_mc_gradient_sample_vs_oracle_accumulation():
     g_ref = seo / len(out_cfg) - np.conj(e_ref) * so / len(out_cfg)
     assert abs(e - e_ref) < 1e-9 * abs(e_ref)
     assert np.max(np.abs(grad - g_ref)) < 1e-9 * np.max(np.abs(g_ref))
+
+
+# ---- round 5: measurement solvers, MCPEPSMeasurer / ExactSumMeasurer and the fermionic models for QLTEN_Complex ----
+def _bond(sitps):
+    return max(max(t.shape) for row in sitps for site in row for t in site)
+
+
+@pytest.mark.parametrize("gold_file,stem,model,params,cfgs_kind", [
+    ("k4_heisenberg_exact_sum_measurer.json", "heisenberg_tps", "xxz", (1.0, 1.0, 0.0), "half"),
+    ("k4_tfim_exact_sum_measurer.json", "transverse_ising_tps", "tfim", (1.0,), "all")])
+def test_k4_complex_exact_sum_measurer_registries_on_the_device(fixtures_dir, gold_file, stem, model, params, cfgs_kind):
+    """The QLTEN_Complex build of the reference's ExactSumMeasurerMPI tests (tests/test_algorithm/test_exact_summation_measurer.cpp:443-545,
+    :585-651; tests/CMakeLists.txt:385-398) through ExactSumMeasurer<.., QLTEN_Complex> of the host layer: every registry key of the complex
+    2x2 simple-update states at the reference's 1e-10 with imaginary parts below 1e-10 (kTol / kImagTol), the closed forms of the `lowest`
+    states, and a 3-rank decomposition that adds up to the serial result."""
+    import json
+    from peps_amd import hostapi
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", gold_file)))
+    cfgs = None if cfgs_kind == "all" else np.array(vmc.generate_all_permutation_configs([2, 2], 2, 2), dtype=np.int32)
+    hostapi.set_truncate_params(1, 1e-16, 0)                    # SVD(1, 8, 1e-16)
+    try:
+        s = qlten_io.load_sitps(os.path.join(fixtures_dir, stem + "_complex_from_simple_update"), complex_data=True)
+        flat = _flat(s, _bond(s))
+        acc, w = hostapi.exact_sum_measure_partial(flat, cfgs, 8, model, params, 0, 1, 16)
+        assert set(acc) == set(gold["observables"])
+        for key, want in gold["observables"].items():
+            v = acc[key] / w
+            assert v.dtype == np.complex128 and np.max(np.abs(v - np.asarray(want))) < 1e-10, key
+            assert np.max(np.abs(v.imag)) < 1e-10, key
+        allc = np.array(vmc.generate_all_binary_configs(2, 2), dtype=np.int32) if cfgs is None else cfgs
+        parts = [hostapi.exact_sum_measure_partial(flat, allc, 8, model, params, r, 3, 2) for r in range(3)]
+        wp = sum(p[1] for p in parts)
+        for key in acc:
+            assert np.max(np.abs(sum(p[0][key] for p in parts) / wp - acc[key] / w)) < 1e-12, key
+        s = qlten_io.load_sitps(os.path.join(fixtures_dir, stem + "_complexlowest"), complex_data=True)
+        acc, w = hostapi.exact_sum_measure_partial(_flat(s, _bond(s)), cfgs, 8, model, params, 0, 1, 16)
+        tol = {"energy": 6e-8, "spin_z": 5e-4}
+        for key, want in gold["lowest"].items():
+            assert np.max(np.abs(acc[key] / w - np.asarray(want))) < tol.get(key, 1e-5), key
+    finally:
+        hostapi.set_truncate_params()
+
+
+@pytest.mark.parametrize("model,params", [("xxz", (1.0, 0.8, 0.3, 0.0, 0.0, 0.0, 0.0, 1.0)), ("j1j2", (1.0, 1.0, 0.5, 0.4, 0.0)), ("tfim", (0.9,))])
+def test_complex_registry_observables_vs_oracle(model, params):
+    """EvaluateObservables of the three measurement solvers on a random COMPLEX 4x4 state, fixed configurations: every key -- complex bond
+    energies, the conjugated S+S- row channel (square_spin_onehalf_xxz_obc.h:47), the structure-factor amplitudes (unconjugated,
+    structure_factor_measurement_mixin.h:160-194), sigma_x -- and the phase-aligned psi summary (psi_consistency.h:119-168) against the
+    complex oracle."""
+    from peps_amd import hostapi
+    L, D, chi = 4, 3, 9
+    sitps = _complex_sitps(L, D, 23)
+    cfgs = synthetic.make_configs(L, 4, "heisenberg", seed0=3)
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    got, psi = hostapi.measure(_flat(sitps, D), cfgs, chi, model, params)
+    some_imag = 0.0
+    for w, cfg in enumerate(cfgs):
+        comp = vmc.TPSWaveFunctionComponent(sitps, cfg, tp)
+        if model == "tfim":
+            ms = vmc.TransverseFieldIsingSquareOBC(params[0])
+        else:
+            om = vmc.SquareSpinOneHalfXXZModelOBC(*params[:3]) if model == "xxz" else vmc.SquareSpinOneHalfJ1J2XXZModelOBC(*params)
+            ms = vmc.SquareNNNModelMeasurementSolver(om, structure_factor=(model == "xxz"))
+        want = ms.EvaluateObservables(sitps, comp)
+        assert set(got) == set(want)
+        for key, v in want.items():
+            v = np.asarray(v).ravel()
+            assert got[key][w].shape == v.shape, key
+            assert np.max(np.abs(got[key][w] - v)) < 1e-8 * max(1.0, np.max(np.abs(v))), (key, w)
+        some_imag = max(some_imag, np.max(np.abs(got["energy"][w].imag)))
+        pm, prel = ms.last_psi_summary
+        assert abs(psi[0][w] / pm - 1) < 1e-8 and abs(psi[1][w] - prel) < 1e-8
+    assert some_imag > 1e-6                                      # complex local estimators
+
+
+def test_complex_mc_measurer_statistics():
+    """MCPEPSMeasurer<.., QLTEN_Complex> (monte_carlo_peps_measurer_impl.h:172-258, :495-541): warm-up + NormalizeStateOrder1 + samples on a
+    complex state; the chain is the device's own (|psi|^2 sampling with std::mt19937 per walker), the statistics are rebuilt here from the
+    visited configurations with the complex oracle: mean over the walkers of the per-walker sample means, real standard errors."""
+    from peps_amd import hostapi
+    L, D, chi, n, nsamp = 4, 2, 4, 3, 2
+    sitps = _complex_sitps(L, D, 41)
+    flat = _flat(sitps, D)
+    cfgs = synthetic.make_configs(L, n, "heisenberg", seed0=9).astype(np.int32)
+    seeds = [5, 6, 7]
+    # replay: the same seeds through the sweep entry point give the configurations after warm-up and after each sample
+    c1, _, _ = hostapi.mc_sweeps_complex(flat, cfgs, seeds, chi, "exchange", 3)       # 1 warm-up + 2 samples
+    run = cfgs.copy()
+    out, _ = hostapi.measure(flat, run, chi, "xxz", (1.0, 1.0, 0.0), seeds=seeds, updater="exchange", warmup_sweeps=1, n_samples=nsamp,
+                             sweeps_between_samples=1)
+    assert np.array_equal(run, c1)                                # the measurer's chain == the plain chain of the same seeds
+    mean, err = out["energy"]
+    assert mean.dtype == np.complex128 and err.dtype == np.float64 and err[0] > 0.0
+    # energy of the final configurations from the oracle brackets the mean within the spread of the samples
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    e_last = []
+    for w in range(n):
+        comp = vmc.TPSWaveFunctionComponent(sitps, run[w], tp)
+        e_last.append(vmc.SquareNNNModelMeasurementSolver(vmc.SquareSpinOneHalfXXZModelOBC(1.0, 1.0, 0.0)).EvaluateObservables(sitps, comp)["energy"][0])
+    c_mid, _, _ = hostapi.mc_sweeps_complex(flat, cfgs, seeds, chi, "exchange", 2)
+    e_mid = []
+    for w in range(n):
+        comp = vmc.TPSWaveFunctionComponent(sitps, c_mid[w], tp)
+        e_mid.append(vmc.SquareNNNModelMeasurementSolver(vmc.SquareSpinOneHalfXXZModelOBC(1.0, 1.0, 0.0)).EvaluateObservables(sitps, comp)["energy"][0])
+    walker_means = (np.array(e_mid) + np.array(e_last)) / 2
+    assert abs(mean[0] - walker_means.mean()) < 1e-8
+    want_err = np.sqrt(np.sum(np.abs(walker_means - walker_means.mean()) ** 2) / n / (n - 1))
+    assert abs(err[0] - want_err) < 1e-8
+
+
+FERMION_CASES = [("0.000000_complexlowest", 0.0, -2.0), ("0.000000_complex_from_simple_update", 0.0, -1.98218053854),
+                 ("2.100000_complexlowest", 2.1, -4.2), ("2.100000_complex_from_simple_update", 2.1, -4.1879072654),
+                 ("-2.500000_complexlowest", -2.5, -5.0), ("-2.500000_complex_from_simple_update", -2.5, -4.98966397657)]
+
+
+@pytest.mark.parametrize("name,t2,e_ref", FERMION_CASES)
+def test_k4_complex_spinless_fermion_energies(fixtures_dir, name, t2, e_ref):
+    """The QLTEN_Complex build of the reference's fermionic exact-summation test (test_exact_summation_evaluator.cpp:268-470 with the
+    `_complexlowest` / `_complex_from_simple_update` fixtures, :306-330): the six known energies from complex fZ2 tensors through (a) the
+    Python flow over the C ABI (peps_amd/fermion.py: NN hops in the passes, diagonal hop against twisted BTen2 environments, conj(psi'/psi) as
+    square_spinless_fermion.h:156,:210) and (b) SquareSpinlessFermion of the C++ host layer instantiated for std::complex<double>; both agree
+    with the complex oracle per configuration."""
+    import itertools
+    from oracle import fermion as ofermion
+    from peps_amd import capi, fermion, hostapi
+    d = os.path.join(fixtures_dir, "spinless_fermion_tps_t2_" + name)
+    st = fermion.FermionState.load(d, complex_data=True)
+    assert st.is_complex
+    cfgs = np.array([np.array(p).reshape(2, 2) for p in sorted(set(itertools.permutations([0, 0, 1, 1])))])
+    ctx = capi.Context(2, 2, st.D, 4 * st.d, 8, dtype=capi.C128, max_walkers=len(cfgs))
+    ctx.state_upload(st.extended_flat())
+    amp = fermion.evaluate_amplitude(ctx, st, cfgs)
+    e_loc, _ = fermion.spinless_fermion_energy(ctx, st, cfgs, 1.0, 0.0, t2)
+    w = np.abs(amp) ** 2
+    e = np.sum(w * e_loc) / np.sum(w)
+    assert abs(e - e_ref) < 1e-9 and abs(e.imag) < 1e-10
+    amps2, en2, _ = hostapi.fermion_energy(st, cfgs, 8, 1.0, 0.0, t2=t2)
+    assert amps2.dtype == np.complex128
+    rel = np.abs(amp) / np.max(np.abs(amp))        # (a ratio of two amplitudes of size 1e-8 of the largest carries 1e-8 of relative noise)
+    assert np.max(np.abs(amps2 - amp)) < 1e-12 * np.max(np.abs(amp)) and np.max(np.abs(en2 - e_loc) * rel) < 1e-9
+    fs = ofermion.FermionSITPS(ofermion.load_fermion_sitps(d, complex_data=True))
+    tp = BMPSTruncateParams.SVD(8, 8, 0.0)
+    model = ofermion.SquareSpinlessFermionOBC(1.0, t2, 0.0)
+    for k, cfg in enumerate(cfgs):
+        a = fs.amplitude(cfg, tp)
+        assert abs(amp[k] - a) < 1e-10 * max(1.0, abs(a))
+        if rel[k] < 1e-6:           # the two symmetry-forbidden configurations of the exact ground states: psi = O(1e-9), E_loc is noise
+            continue
+        assert abs(e_loc[k] - model.CalEnergy(fs, cfg, tp)[0]) < 1e-8
+
+
+def test_k4_complex_fermion_measurer_registry_and_gradient(fixtures_dir):
+    """test_exact_summation_measurer.cpp:205-257 (QLTEN_Complex branch): energy, charge and the per-bond energies of the complex 2x2
+    simple-update state at 1e-10, imaginary parts below 1e-10; ExactSumEnergyEvaluator<.., QLTEN_Complex> on the same state (t2 = 0): the
+    energy of :432-436 and a gradient that vanishes on the parity-forbidden entries."""
+    import itertools
+    import json
+    from peps_amd import capi, fermion, hostapi
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "k4_exact_sum_measurer.json")))["observables"]
+    st = fermion.FermionState.load(os.path.join(fixtures_dir, "spinless_fermion_tps_t2_0.000000_complex_from_simple_update"), complex_data=True)
+    cfgs = np.array([np.array(p).reshape(2, 2) for p in sorted(set(itertools.permutations([0, 0, 1, 1])))])
+    ctx = capi.Context(2, 2, st.D, 4 * st.d, 8, dtype=capi.C128, max_walkers=len(cfgs))
+    ctx.state_upload(st.extended_flat())
+    acc, w = fermion.exact_sum_measure(ctx, st, cfgs, 1.0, 0.0)
+    assert set(acc) == set(gold)
+    for key, want in gold.items():
+        v = acc[key] / w
+        assert np.max(np.abs(v - np.array(want))) < 1e-10 and np.max(np.abs(np.imag(v))) < 1e-10, key
+    e, grad = hostapi.fermion_exact_sum(st, cfgs, 8, 1.0, 0.0, batch=4)
+    assert abs(e - (-1.98218053854)) < 1e-9 and abs(e.imag) < 1e-10
+    assert grad.dtype == np.complex128 and grad.shape[:3] == (2, 2, 2) and np.max(np.abs(grad)) > 1e-6
+    for r in range(2):
+        for c in range(2):
+            pl, pd, pr, pu = st.par[r][c]
+            tot = pl[:, None, None, None] + pd[None, :, None, None] + pr[None, None, :, None] + pu[None, None, None, :]
+            for s in range(2):
+                sl = (r, c, s) + tuple(slice(0, k) for k in tot.shape)
+                assert np.all(grad[sl][(tot + st.nf[s]) % 2 == 1] == 0)
+
+
+def test_complex_fermion_chain_and_energy_vs_oracle():
+    """A 4x4 D = 4 fermionic state with a random phase on every parity-allowed element: MCUpdateSquareNNExchangeOBC chains of the host layer
+    for QLTEN_Complex (acceptance from |psi'/psi|^2) keep the particle number and end on configurations whose complex amplitude and t-V local
+    energy match the complex oracle; the measurer-style energy samples (one random stream over warm-up and samples) are the E_loc of the
+    configurations the plain chain of the same seeds visits."""
+    from oracle import fermion as ofermion
+    from oracle.graded import GT
+    from peps_amd import fermion, hostapi
+    st = fermion.random_even_state(4, 4, 4, seed=3)
+    rng = np.random.default_rng(12)
+    for r in range(4):
+        for c in range(4):
+            st.tensors[r][c] = [t * np.exp(2j * np.pi * rng.uniform(size=t.shape)) for t in st.tensors[r][c]]
+    assert st.is_complex
+    gts = [[[GT(st.tensors[r][c][s][..., None], list(st.par[r][c]) + [np.array([int(st.nf[s])])], [-1, 1, 1, -1, -1])
+             for s in range(st.d)] for c in range(4)] for r in range(4)]
+    fs = ofermion.FermionSITPS(gts)
+    cfgs = np.array([[(r + c + k) % 2 for c in range(4)] for k in range(3) for r in range(4)]).reshape(3, 4, 4)
+    seeds = [11, 12, 13]
+    out_cfg, amps, rates = hostapi.fermion_mc_sweeps(st, cfgs, seeds, 16, n_sweeps=2)
+    assert np.all(out_cfg.sum(axis=(1, 2)) == cfgs.sum(axis=(1, 2))) and np.all(rates > 0) and not np.array_equal(out_cfg, cfgs)
+    tp = BMPSTruncateParams.SVD(16, 16, 0.0)
+    model = ofermion.SquareSpinlessFermionOBC(1.0, 0.0, 0.7)
+    en, cfg2, _ = hostapi.fermion_measure_energy(st, cfgs, seeds, 16, 1, 1, 1, model="spinless", t=1.0, V=0.7)
+    assert np.array_equal(cfg2, out_cfg) and en.dtype == np.complex128
+    for w in range(3):
+        a = fs.amplitude(out_cfg[w], tp)
+        assert abs(amps[w] / a - 1) < 1e-8
+        e, _ = model.CalEnergy(fs, out_cfg[w], tp)
+        assert abs(en[0, w] - e) < 1e-7 * max(1.0, abs(e))
+    assert np.max(np.abs(en.imag)) > 1e-6
