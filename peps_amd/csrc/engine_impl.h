@@ -152,9 +152,8 @@ bool Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
 template <typename T>
 void Engine<T>::absorb(int pos, int num) {
   if constexpr (kCplx) {
-    // complex element type: the plain static-shape form of the same algorithm (engine_cplx.h), SVD compression only
-    PG_REQUIRE(scheme_ == 0 || mps_len(pos) <= 2, 1, "variational compression is not implemented for the complex element type");
-    BMPSDev out = absorb_simple(pos, num, bmps_[pos].back());
+    // complex element type: the plain static-shape form of the same algorithm (engine_cplx.h); variational schemes: engine_var.h
+    BMPSDev out = (scheme_ != 0 && mps_len(pos) > 2) ? absorb_variational(pos, num, bmps_[pos].back()) : absorb_simple(pos, num, bmps_[pos].back());
     bmps_[pos].push_back(std::move(out));
   } else {
     if (scheme_ != 0 && mps_len(pos) > 2) {   // bmps_impl.h:419-430: N == 2 always takes the SVD path

@@ -1,8 +1,11 @@
 // Variational compression of BMPS x MPO on the device: CompressMPSScheme::VARIATION2Site / VARIATION1Site
 // (bmps.h:31-35; BMPS::MultiplyMPO2SiteVariationalCompress_ bmps_impl.h:864-995,
 // MultiplyMPO1SiteVariationalCompress_ :997-1172, MakeVariationalInitGuess_ :1174-1212,
-// MakeEnvironmentBoundaries_ / GrowRightEnvironments_ :701-743).  Bosonic, real element types (the
-// reference asserts !IsFermionic(); Dag() is the identity for real tensors).
+// MakeEnvironmentBoundaries_ / GrowRightEnvironments_ :701-743).  Bosonic (the reference asserts !IsFermionic()).
+// Element types: real, and -- round 5 -- complex: the Dag() of the reference's environments is a conjugated operand of the
+// GEMM (EinView::cj), the SVD / QR are the complex row Jacobi of linalg_cplx.h on static shapes (no live extents, no
+// compressing factor: parity-grade like the complex absorption; the reference runs this combination in its Z2 Ising test,
+// test_bmps_contractor.cpp:663-673).
 //
 // Same state as the reference up to the bond gauge:
 //  * every contraction is one strided tensor GEMM (ein() below builds the descriptor from leg names; no
@@ -19,6 +22,7 @@
 //    criterion (a walker that converged earlier keeps being refined; the reference would stop it there).
 #pragma once
 #include "engine_impl.h"
+#include "linalg_cplx.h"
 
 namespace pepsgpu {
 
@@ -38,6 +42,8 @@ struct EinView {
   // calls given the same extent may read the tensor), msk = 1 the static tiling is kept and zeros are written beyond.
   const int *live[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int msk[6] = {0, 0, 0, 0, 0, 0};
+  bool conj = false;        // complex element types: the operand enters conjugated (Dag() of the reference); no-op for real types
+  EinView &cj() { conj = true; return *this; }
   int find(char ch) const {
     for (int i = 0; i < n; ++i) if (nm[i] == ch) return i;
     return -1;
@@ -100,6 +106,9 @@ void Engine<T>::ein(const EinView<T> &a, const EinView<T> &b, const EinView<T> &
   for (size_t x = 0; x < gj.size(); ++x) { const int o = 3 - (int)gj.size() + (int)x; g.J[o] = gj[x].dim; g.sBj[o] = gj[x].s0; g.sCj[o] = gj[x].s1; g.dJ[o].p = gj[x].live; g.dJ[o].mask = gj[x].mask; }
   for (size_t x = 0; x < gk.size(); ++x) { const int o = 3 - (int)gk.size() + (int)x; g.K[o] = gk[x].dim; g.sAk[o] = gk[x].s0; g.sBk[o] = gk[x].s1; g.dK[o].p = gk[x].live; }
   g.wA = a.w; g.wB = b.w; g.wC = c.w; g.nbatch = nw_;
+  PG_REQUIRE(!(a.site && a.conj) && !(b.site && b.conj), 5, "ein: a site operand cannot be conjugated");
+  g.conjA = a.conj ? 1 : 0;
+  g.conjB = b.conj ? 1 : 0;
   const double fl = 2.0 * nw_ * (double)g.Itot() * g.Jtot() * g.Ktot();
   prof_begin(PROF_CONTRACT, fl, fl);   // (executed flops: counted on the device over the live extents)
   PG_REQUIRE(!(a.site && b.site), 5, "ein: two site operands");
@@ -124,6 +133,22 @@ DTen<T> Engine<T>::svd_rows(DTen<T> &M, int m, int len, int k, double terr, int 
   // inner_live[w] values of the inner index exist -- the factor kernel reads those columns only, the others are zero in
   // everything downstream.
   PG_REQUIRE(m <= 1024, 1, "bond dimension too large for select_rows_kernel");
+  if constexpr (kCplx) {
+    // complex: rotated rows of M = sigma_k v_k^H (the rows of V^H = `vt` of qlten::SVD); static shapes, every row exists
+    PG_REQUIRE(!mdyn && !inner_live, 5, "svd_rows: the complex element type has no live extents");
+    prof_begin(7, 0.0, 0.0);
+    hipLaunchKernelGGL(jacobi_rows_cplx_kernel<T>, dim3(nw_), dim3(1024), 0, stream_, M.p, M.n, m, len, len, 60, sweeps_);
+    PG_CHECK_HIP(hipGetLastError());
+    prof_end();
+    ++n_jacobi_;
+    DTen<T> V = alloc_ten(k, len, 1);
+    prof_begin(PROF_SELECT, 0.0, 0.0);
+    hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)M.p, M.n, m, len, len, k, V.p, V.n,
+                       S, (long)k, (const int *)nullptr, 1, kn_out, terr, dmin, (double *)nullptr);
+    PG_CHECK_HIP(hipGetLastError());
+    prof_end();
+    return V;
+  } else {
   // Rank compression first, as in the absorption: R with R^T R = M^T M from the Gram-free factor (the right singular
   // vectors and the singular values of R are those of M), then the Jacobi runs on the few live rows of R instead of
   // the m rows of M.  Walkers the factor declines (rank above its cap) keep their rows of M.
@@ -166,6 +191,7 @@ DTen<T> Engine<T>::svd_rows(DTen<T> &M, int m, int len, int k, double terr, int 
   prof_end();
   if (ml) { arena_.free(ml); free_ten(Rf); }
   return V;
+  }
 }
 
 // BMPS truncated to bond dimension <= kmax: Centralize(N-1) + RightCanonicalizeTruncate(i, 1, kmax, 0)
@@ -183,23 +209,30 @@ typename Engine<T>::BMPSDev Engine<T>::truncate_bmps(const BMPSDev &in, int kmax
     DTen<T> P = alloc_ten(m, p, b);
     ein(ein_view<T>(R[i].p, R[i].n, "ma", {m, a}), ein_view<T>(A.p, A.n, "apb", {a, p, b}), ein_view<T>(P.p, P.n, "mpb", {m, p, b}), P.p);
     const int rows = m * p, cols = b;
-    double *G = (double *)arena_.alloc(sizeof(double) * (size_t)cols * cols * nw_);
+    Acc *G = (Acc *)arena_.alloc(sizeof(Acc) * (size_t)cols * cols * nw_);
     {
-      TGemmDesc g;
+      TGemmDesc g;          // G = P^H P
       g.I[2] = cols; g.sAi[2] = 1; g.sCi[2] = cols;
       g.K[2] = rows; g.sAk[2] = cols; g.sBk[2] = cols;
       g.J[2] = cols; g.sBj[2] = 1; g.sCj[2] = 1;
       g.wA = P.n; g.wB = P.n; g.wC = (long)cols * cols; g.nbatch = nw_;
+      g.conjA = 1;
       prof_begin(PROF_GRAM, 0.0, 2.0 * nw_ * (double)cols * cols * rows);
-      tgemm_launch<T, T, double, double>(stream_, g, P.p, P.p, G);
+      tgemm_launch<T, T, Acc, Acc>(stream_, g, P.p, P.p, G);
       prof_end();
     }
     R[i + 1] = alloc_ten(cols, cols, 1);
-    const size_t smem = chol_smem_bytes(cols);
-    allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
     prof_begin(PROF_CHOL, 0.0, 0.0);
-    hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nw_), dim3(256), smem, stream_, G, (long)cols * cols, cols, R[i + 1].p,
-                       R[i + 1].n, (int *)nullptr, 0);
+    if constexpr (kCplx) {
+      PG_REQUIRE(cols <= 1024, 1, "bond dimension too large for the complex Cholesky kernel");
+      hipLaunchKernelGGL(chol_upper_cplx_kernel<T>, dim3(nw_), dim3(1024), 0, stream_, (c128 *)G, (long)cols * cols, cols, R[i + 1].p,
+                         R[i + 1].n, (int *)nullptr);
+    } else {
+      const size_t smem = chol_smem_bytes(cols);
+      allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
+      hipLaunchKernelGGL(chol_upper_kernel<T>, dim3(nw_), dim3(256), smem, stream_, G, (long)cols * cols, cols, R[i + 1].p,
+                         R[i + 1].n, (int *)nullptr, 0);
+    }
     PG_CHECK_HIP(hipGetLastError());
     prof_end();
     arena_.free(G);
@@ -231,7 +264,7 @@ typename Engine<T>::BMPSDev Engine<T>::truncate_bmps(const BMPSDev &in, int kmax
     V.d[0] = k; V.d[1] = p; V.d[2] = y;
     out.t[i] = V;
     DTen<T> Yn = alloc_ten(a, k, 1);
-    ein(ein_view<T>(Tt.p, Tt.n, "apy", {a, p, y}), ein_view<T>(V.p, V.n, "npy", {k, p, y}), ein_view<T>(Yn.p, Yn.n, "an", {a, k}), Yn.p);
+    ein(ein_view<T>(Tt.p, Tt.n, "apy", {a, p, y}), ein_view<T>(V.p, V.n, "npy", {k, p, y}).cj(), ein_view<T>(Yn.p, Yn.n, "an", {a, k}), Yn.p);   // Y = T Vt^H
     normalize(Yn.p, Yn.n, Yn.n, nw_, out.logscale);
     free_ten(Tt);
     Y = Yn;
@@ -279,7 +312,8 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, cons
   if (scheme_ == 2) { chi_min_ = chi_; trunc_err_ = 0.0; }   // bmps_impl.h:1012: (Dmax, Dmax, 0.0)
   BMPSDev res;
   try {
-    res = absorb_svd(pos, num, small);
+    if constexpr (kCplx) res = absorb_simple(pos, num, small);
+    else res = absorb_svd(pos, num, small);
   } catch (...) {
     chi_min_ = save_min; trunc_err_ = save_err;
     throw;
@@ -290,7 +324,8 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, cons
   // site i of the absorbing BMPS / of the result.  Contractions run over the live parts only (ein(): compact legs on
   // tensors only ein() reads, masked -- zeros written -- legs where a whole-row kernel or a persistent tensor follows);
   // every truncation returns the live count of the bond it made.  PEPSGPU_NO_VAR_ADAPT=1: static shapes throughout.
-  static const bool no_adapt = getenv("PEPSGPU_NO_VAR_ADAPT") != nullptr;
+  static const bool no_adapt_env = getenv("PEPSGPU_NO_VAR_ADAPT") != nullptr;
+  const bool no_adapt = no_adapt_env || kCplx;      // (the complex kernels have no live extents)
   std::vector<int *> il(in.live.begin(), in.live.end()), rl = res.live;
   il.resize(N + 1, nullptr);
   rl.resize(N + 1, nullptr);
@@ -354,8 +389,8 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, cons
   auto grow_right = [&](int j, const DTen<T> &t3, const DTen<T> &Bj, const Env &re, int *nl) {
     const int v = t3.d[0], q = t3.d[1], b = t3.d[2], f = t3.d[3], n = Bj.d[0];
     Env o{alloc_ten(b, f, n), new_log(re.log), nl};
-    ein(ein_view<T>(t3.p, t3.n, "vqbf", {v, q, b, f}).dyn('q', re.nl).dyn('b', il[j]), ein_view<T>(Bj.p, Bj.n, "nvq", {n, v, q}),
-        ein_view<T>(o.t.p, o.t.n, "bfn", {b, f, n}).dyn('n', nl, 1), o.t.p);
+    ein(ein_view<T>(t3.p, t3.n, "vqbf", {v, q, b, f}).dyn('q', re.nl).dyn('b', il[j]), ein_view<T>(Bj.p, Bj.n, "nvq", {n, v, q}).cj(),
+        ein_view<T>(o.t.p, o.t.n, "bfn", {b, f, n}).dyn('n', nl, 1), o.t.p);       // Dag(res[j]) (:739)
     normalize(o.t.p, o.t.n, o.t.n, nw_, o.log, il[j], f * n);
     return o;
   };
@@ -365,7 +400,7 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, cons
     const int k = t1.d[0], u = t1.d[1], b = t1.d[2], f = t1.d[3];
     Env o{alloc_ten(n, f, b), new_log(le.log), nl};
     EinView<T> utv = uk_order ? ein_view<T>(Ut.p, Ut.n, "nuk", {n, u, k}) : ein_view<T>(Ut.p, Ut.n, "nku", {n, k, u});
-    ein(utv.dyn('n', nl).dyn('k', le.nl), ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}),
+    ein(utv.dyn('n', nl).dyn('k', le.nl).cj(), ein_view<T>(t1.p, t1.n, "kubf", {k, u, b, f}),      // Dag(u) (:916-918)
         ein_view<T>(o.t.p, o.t.n, "nfb", {n, f, b}).dyn('b', il[i + 1], 1), o.t.p);
     normalize(o.t.p, o.t.n, o.t.n, nw_, o.log, nl, f * b);
     return o;
@@ -480,13 +515,14 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, cons
       if (all) {
         for (int w = 0; w < nw_ && all; ++w) {
           const T *s = &h_s[(size_t)w * ks], *sl = &h_last[(size_t)w * ks];
+          auto sv = [](const T &x) -> double { if constexpr (kCplx) return (double)x.re; else return (double)x; };   // singular values are real
           int n = 0, nl = 0;
-          for (int x = 0; x < ks; ++x) { n += s[x] != T(0); nl += sl[x] != T(0); }
-          if (n != nl || !(s[0] > T(0))) { all = false; break; }   // bond dimension changed (bmps_impl.h:946)
+          for (int x = 0; x < ks; ++x) { n += sv(s[x]) != 0.0; nl += sv(sl[x]) != 0.0; }
+          if (n != nl || !(sv(s[0]) > 0.0)) { all = false; break; }   // bond dimension changed (bmps_impl.h:946)
           const double rel = std::exp(h_log_last[w] - h_log[w]);
           double diff = 0.0;
-          for (int x = 0; x < ks; ++x) diff += std::fabs((double)s[x] - (double)sl[x] * rel);
-          if (!(diff / (double)s[0] < conv_tol_)) all = false;
+          for (int x = 0; x < ks; ++x) diff += std::fabs(sv(s[x]) - sv(sl[x]) * rel);
+          if (!(diff / sv(s[0]) < conv_tol_)) all = false;
         }
       }
       if (all) break;

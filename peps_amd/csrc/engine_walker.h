@@ -212,7 +212,7 @@ struct Engine<T>::MpoScope {
 template <typename T>
 typename Engine<T>::BMPSDev Engine<T>::absorb_any(int pos, int num, const BMPSDev &in) {
   if constexpr (kCplx) {
-    PG_REQUIRE(scheme_ == 0 || mps_len(pos) <= 2, 1, "variational compression is not implemented for the complex element type");
+    if (scheme_ != 0 && mps_len(pos) > 2) return absorb_variational(pos, num, in);
     return absorb_simple(pos, num, in);
   } else {
     if (scheme_ != 0 && mps_len(pos) > 2) return absorb_variational(pos, num, in);

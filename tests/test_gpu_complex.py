@@ -496,3 +496,84 @@ def test_complex_fermion_chain_and_energy_vs_oracle():
         e, _ = model.CalEnergy(fs, out_cfg[w], tp)
         assert abs(en[0, w] - e) < 1e-7 * max(1.0, abs(e))
     assert np.max(np.abs(en.imag)) > 1e-6
+
+
+# ---- round 5: the variational compression schemes for QLTEN_Complex (engine_var.h: conjugated operands = Dag() of the environments) ----
+def _z2_network(rows, cols):
+    tn, lognorm, beta = ising.build_ising_tn(cols, rows)
+    H = np.array([[1.0, 1.0], [1.0, -1.0]]) / np.sqrt(2.0)
+
+    def z2(rc):
+        t = tn(rc)
+        for ax in range(4):
+            if t.shape[ax] == 2:
+                t = np.moveaxis(np.tensordot(H, t, axes=([1], [ax])), 0, ax)
+        return t
+    return z2, lognorm, beta
+
+
+def test_k2_complex_variational_one_site_reference_case():
+    """The reference's complex variational run (test_bmps_contractor.cpp:663-673): the 24 x 10 Z2-basis Ising network with a random phase
+    on every tensor, Variational1Site(1, 10, 1e-15, 1e-14, 10): every route gives the exact free energy to 1e-8, imaginary part zero."""
+    import k1_routes
+    from peps_amd import capi
+    rows, cols = 24, 10
+    z2, lognorm, beta = _z2_network(rows, cols)
+    f_ex = ising.exact_free_energy(cols, rows, 1.0 / beta)
+    sit = _phased(z2, rows, cols, 11)
+    ctx = capi.Context(rows, cols, 2, 1, 10, dtype=capi.C128, max_walkers=1, chi_min=1, trunc_err=1e-15, scheme=capi.VARIATION1SITE,
+                       convergence_tol=1e-14, iter_max=10)
+    ctx.state_upload(_flat(sit, 2))
+    ctx.set_configs(np.zeros((1, rows, cols), dtype=np.int32))
+    amps = k1_routes.run_device(ctx, rows)
+    for a in amps:
+        z = complex(a[0])
+        assert abs(-(np.log(z.real) + lognorm) / (rows * cols) / beta - f_ex) < 1e-8
+        assert abs(z.imag) < 1e-10 * abs(z.real)
+    ctx.close()
+
+
+@pytest.mark.parametrize("scheme", ["Variational2Site", "Variational1Site"])
+def test_k1_complex_variational_all_21_routes(scheme):
+    """K1-complex (12 x 12 critical Ising, random phases) under both variational schemes with the parameters of the reference's real run
+    (test_bmps_contractor.cpp:472-486: (10, 30, 1e-15, 1e-14, 10)): all 21 routes, 1e-8."""
+    import k1_routes
+    from peps_amd import capi
+    tn, lognorm, beta = ising.build_ising_tn(12, 12)
+    f_ex = ising.exact_free_energy(12, 12, 1.0 / beta)
+    sitps = _phased(tn, 12, 12, 3)
+    ctx = capi.Context(12, 12, 2, 1, 30, dtype=capi.C128, max_walkers=1, chi_min=10, trunc_err=1e-15,
+                       scheme={"Variational2Site": capi.VARIATION2SITE, "Variational1Site": capi.VARIATION1SITE}[scheme],
+                       convergence_tol=1e-14, iter_max=10)
+    ctx.state_upload(_flat(sitps, 2))
+    ctx.set_configs(np.zeros((1, 12, 12), dtype=np.int32))
+    amps = k1_routes.run_device(ctx)
+    assert len(amps) == k1_routes.N_AMPS
+    for a in amps:
+        z = complex(a[0])
+        assert abs(-(np.log(z.real) + lognorm) / 144 / beta - f_ex) < 1e-8 and abs(z.imag) < 1e-10 * abs(z.real)
+    ctx.close()
+
+
+@pytest.mark.parametrize("scheme", ["Variational2Site", "Variational1Site"])
+@pytest.mark.parametrize("L,D,chi", [(5, 3, 4), (6, 3, 5)])
+def test_complex_variational_amplitudes_against_oracle(L, D, chi, scheme):
+    """Truncating contraction of a random COMPLEX state: the device amplitudes follow the complex oracle run with the same scheme and
+    parameters (the oracle conjugates where the reference takes Dag(), oracle/bmps.py) and differ from the SVD-compressed ones."""
+    from peps_amd import capi
+    sitps = _complex_sitps(L, D, 7 * L + D)
+    cfgs = synthetic.make_configs(L, 4, "heisenberg", seed0=2)
+    tp = getattr(BMPSTruncateParams, scheme)(chi, chi, 0.0, 1e-13, 30)
+    ref = np.array([vmc.TPSWaveFunctionComponent(sitps, c, tp).amplitude for c in cfgs])
+    svd = np.array([vmc.TPSWaveFunctionComponent(sitps, c, BMPSTruncateParams.SVD(chi, chi, 0.0)).amplitude for c in cfgs])
+    ctx = capi.Context(L, L, D, 2, chi, dtype=capi.C128, max_walkers=len(cfgs), chi_min=chi, trunc_err=0.0,
+                       scheme={"Variational2Site": capi.VARIATION2SITE, "Variational1Site": capi.VARIATION1SITE}[scheme],
+                       convergence_tol=1e-13, iter_max=30)
+    ctx.state_upload(_flat(sitps, D))
+    ctx.set_configs(cfgs)
+    got = ctx.evaluate_amplitude()
+    assert np.all(ctx.walker_flags() == 0)
+    err = np.max(np.abs(got / ref - 1))
+    assert err < 1e-7, (got, ref, svd)
+    assert np.max(np.abs(svd / ref - 1)) > 10 * err
+    ctx.close()
