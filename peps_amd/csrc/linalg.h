@@ -538,13 +538,280 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
   for (int e = tid + mlive * n; e < n * n; e += 256) Rout[(long)(e / n) * ldg + (e % n)] = T(0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same factorisation once more (same pivot rule, same output contract, same signature) with the TRAILING MATRIX RESIDENT IN
+// REGISTERS (round 5).  The left-looking kernel above re-reads the finished factor rows for every panel: 1.39 MB per order-256
+// walker from L2 / MALL / HBM (10.9 GB per launch of 8192 walkers, 76 % of its wave cycles waiting), with three blocks per CU to
+// hide the pivot chain.  Here ONE 512-thread block per CU holds the upper triangle of G as 136 tiles of 16 x 16 in the accumulator
+// layout of v_mfma_f64_16x16x4_f64 (wave 0: the 16 diagonal tiles, waves 1-7: the 120 others, round robin in row order; 8 VGPRs a
+// tile), reads G ONCE (263 KB per walker) and writes only the factor.  Right-looking, per panel p of 16 rows, three barriers:
+//   A  the owners lay the block row down in LDS (16 x n doubles);
+//   C  forward substitution of the block row against the diagonal factor, one thread per column;
+//   D  every tile below the block row takes  S_IJ -= X_I^T X_J : four MFMAs, both operands read from the LDS block row (uniform
+//      if-chain over the slots: a jump table made the compiler copy the 144 accumulator registers at the joins -- 143 spills);
+//      the finished rows go out as type T with their squared norms;
+//   B  the 16 x 16 diagonal block of panel p + 1 is factored by wave 0 INSIDE D(p), right after its own update of that tile
+//      (look-ahead: the 16 dependent pivots run under the other waves' matrix work).
+// Orders 129 .. 256.  Opt-in (PEPSGPU_CHOL_RESIDENT, see launch_chol_upper): measured per block of order 256, phases switched off one at
+// a time: 181 us = G load 5 + pivot chains 34 + substitutions 33 + trailing MFMAs 21 + output rows 17 + the rest (barriers, LDS staging,
+// start-up) ~ 70; the phases add up -- nothing overlaps with one block per CU -- where the left-looking kernel hides them behind two
+// other blocks.  HISTORY (round 5, item 11) has the account.
+constexpr int CR_NS = 256 + 8;          // LDS row stride of the block row: the four rows of one k-step fall on four different bank groups
+constexpr int CR_SLOTS = 18;            // tiles per wave: 16 diagonal ones (wave 0) or ceil(120 / 7) = 18 others
+
+template <typename T>
+__global__ __launch_bounds__(512) void chol_resident_kernel(const double *__restrict__ Gg, long wG, int n,
+                                                            T *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
+                                                            int only_flagged = 0, int ld = 0,
+                                                            const int *__restrict__ ndyn = nullptr, int ndyn_mul = 1,
+                                                            const int *__restrict__ run_flag = nullptr, double thresh_scale = 1.0,
+                                                            int dbg = 0) {
+  // dbg (timing experiments only, PEPSGPU_CR_DBG; the results are wrong): 1 no pivot chain, 2 no substitution, 4 no trailing update,
+  // 8 no load of G, 16 no output rows
+  if (only_flagged && mlive_out[blockIdx.x] >= 0) return;
+  if (run_flag && run_flag[blockIdx.x] >= 0) return;
+  const int ldg = ld ? ld : n;
+  const int nfull = n;
+  if (ndyn) n = max(0, min(n, ndyn[blockIdx.x] * ndyn_mul));
+  __shared__ double sP[CH_NB][CR_NS];              // the block row
+  __shared__ double sN[256];                       // squared norms of the finished rows
+  __shared__ short sPos[256];
+  __shared__ double sD[CH_NB][CH_NB + 1], sDinv[CH_NB];
+  __shared__ double sDg[CH_NB][CH_NB + 1];         // wave 0: the diagonal tile on its way from the accumulator layout to one column per lane
+  __shared__ double s_maxd, s_fro;
+  __shared__ double s_red[8];
+  __shared__ int s_nlive;
+  __shared__ unsigned s_livemask;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, k4 = lane >> 4;
+  const double *G = Gg + (long)blockIdx.x * wG;
+  T *Rout = Rg + (long)blockIdx.x * wR;
+  const int NT = (n + 15) >> 4;
+
+  // ---- tiles of this wave: (tI[s], tJ[s]), -1 = empty slot; loaded once ----
+  int tI[CR_SLOTS], tJ[CR_SLOTS];
+  chb_f64x4 acc[CR_SLOTS];
+  double md = 0.0;
+#pragma unroll
+  for (int s = 0; s < CR_SLOTS; ++s) {
+    int I = -1, J = -1;
+    if (wave == 0) { if (s < 16) I = J = s; }
+    else {
+      int t = (wave - 1) + 7 * s;
+      if (t < 120) { I = 0; while (t >= 15 - I) { t -= 15 - I; ++I; } J = I + 1 + t; }
+    }
+    if (J >= NT) I = J = -1;
+    tI[s] = I; tJ[s] = J;
+  }
+  // (the loads in a loop of their own, unconditional at clamped addresses: next to the index loops above they were waited for slot by
+  // slot -- 33 of the 208 us of a block, measured with the load switched off)
+#pragma unroll
+  for (int s = 0; s < CR_SLOTS; ++s) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * tI[s] + k4 + 4 * r, col = 16 * tJ[s] + i16;
+      const bool ok = tI[s] >= 0 && row < n && col < n && col >= row;
+      const long off = ok ? (long)row * ldg + col : 0;
+      const double g = (dbg & 8) ? (row == col ? 2.0 : 0.0) : G[off];
+      acc[s][r] = ok ? g : 0.0;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < CH_NB; ++s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (wave == 0 && tI[s] >= 0 && k4 + 4 * r == i16) md = fmax(md, acc[s][r]);     // the diagonal lives in wave 0
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
+  if (lane == 0) s_red[wave] = md;
+  if (tid == 0) s_nlive = 0;
+  __syncthreads();
+  if (tid == 0) s_maxd = s_red[0];                 // (the diagonal lives in wave 0)
+  __syncthreads();
+  const double maxd = s_maxd;
+  const double eT = NOISE_C * eps_rt<T>();
+  const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd * thresh_scale;
+  const double sc_out = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
+  const int wout = ndyn ? ldg : n;
+
+  // wave 0: bring diagonal tile q up to date with block row q - 1 (upd), then factor it (look-ahead): 16 dependent pivots in registers,
+  // one column per lane -> sD, sDinv, s_livemask of panel q
+  auto diag_factor = [&](int q, bool upd) {
+#pragma unroll
+    for (int s = 0; s < CH_NB; ++s)
+      if (s == q) {
+        if (upd) {
+          const int ca = 16 * s + i16;
+#pragma unroll
+          for (int k0 = 0; k0 < CH_NB; k0 += 4) {
+            const double a = -sP[k0 + k4][ca], b = sP[k0 + k4][ca];
+            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[s], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sDg[k4 + 4 * r][i16] = acc[s][r];
+      }
+    const int nbq = min(CH_NB, n - 16 * q);
+
+      double d[CH_NB];
+#pragma unroll
+      for (int c = 0; c < CH_NB; ++c) d[c] = (lane < nbq && c <= lane) ? sDg[c][lane] : 0.0;
+      unsigned livemask = 0;
+      if (dbg & 1) livemask = nbq >= 16 ? 0xffffu : ((1u << nbq) - 1u);
+#pragma unroll
+      for (int c = 0; c < CH_NB; ++c) {
+        if (dbg & 1) break;
+        const double piv = chb_readlane(d[c], c);
+        const bool live = c < nbq && piv > thresh;             // wave-uniform
+        const double pv = live ? piv : 1.0;
+        double sc = __builtin_amdgcn_rsq(pv);                 // ~2^-26 relative; two Newton steps -> float64
+        sc = sc * (1.5 - 0.5 * pv * sc * sc);
+        sc = sc * (1.5 - 0.5 * pv * sc * sc);
+        d[c] = live ? d[c] * sc : 0.0;
+#pragma unroll
+        for (int c2 = c + 1; c2 < CH_NB; ++c2) {
+          const double f = chb_readlane(d[c], c2);
+          d[c2] -= f * d[c];
+        }
+        livemask |= live ? 1u << c : 0u;
+      }
+#pragma unroll
+      for (int c = 0; c < CH_NB; ++c)
+        if (lane < CH_NB) sD[c][lane] = lane >= c ? d[c] : 0.0;
+      if (lane < CH_NB) {
+        double dg = 0.0;
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c) dg = lane == c ? d[c] : dg;
+        double iv = __builtin_amdgcn_rcp(dg);
+        iv = iv * (2.0 - dg * iv);
+        iv = iv * (2.0 - dg * iv);
+        sDinv[lane] = ((livemask >> lane) & 1u) ? iv : 0.0;
+      }
+      if (lane == 0) s_livemask = livemask;
+      };
+  if (wave == 0 && NT > 0) diag_factor(0, false);
+
+  for (int p = 0; p < NT; ++p) {
+    const int jb = 16 * p, nb = min(CH_NB, n - jb);
+    // ---- A: the block row into LDS ----
+#pragma unroll
+    for (int s = 0; s < CR_SLOTS; ++s)
+      if (tI[s] == p && wave != 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sP[k4 + 4 * r][16 * tJ[s] + i16] = acc[s][r];
+      }
+    __syncthreads();
+    const unsigned livemask = s_livemask;
+    const int nprev = s_nlive;
+    // ---- C: the rest of the block row: forward substitution per column; the block's own columns take the factor ----
+    {
+      const int r = jb + tid;
+      if (r < n) {
+        if (tid < CH_NB) {
+#pragma unroll
+          for (int c = 0; c < CH_NB; ++c) sP[c][r] = sD[c][tid];
+        } else {
+          double v[CH_NB];
+#pragma unroll
+          for (int c = 0; c < CH_NB; ++c) v[c] = sP[c][r];
+#pragma unroll
+          for (int c1 = 0; c1 < CH_NB; ++c1) {
+            const double x = v[c1] * sDinv[c1];    // dropped row: sDinv = 0
+            sP[c1][r] = x;
+            if (!(dbg & 2)) {
+#pragma unroll
+              for (int c = c1 + 1; c < CH_NB; ++c) v[c] -= sD[c1][c] * x;
+            }
+            __asm__ volatile("" ::: "memory");
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- D: trailing update from the LDS block row ----
+    if (wave == 0 && p + 1 < NT) diag_factor(p + 1, true);
+    const int plim = wave == 0 ? p + 1 : p;
+#pragma unroll
+    for (int s = 0; s < CR_SLOTS; ++s)
+      if (tI[s] > plim && !(dbg & 4)) {
+        const int ca = 16 * tI[s] + i16, cb = 16 * tJ[s] + i16;
+#pragma unroll
+        for (int k0 = 0; k0 < CH_NB; k0 += 4) {
+          const double a = -sP[k0 + k4][ca], b = sP[k0 + k4][cb];
+          acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[s], 0, 0, 0);
+        }
+      }
+    // the finished rows: scaled, as type T, at their provisional position (rank in the live list); squared norms for the compaction
+    for (int c = wave; c < nb; c += 8) {
+      if (!((livemask >> c) & 1u) || (dbg & 16)) continue;
+      const int pos = nprev + __popc(livemask & ((1u << c) - 1u));
+      double a = 0.0;
+      for (int r = lane; r < wout; r += 64) {
+        const double x = (r >= jb + c && r < n) ? sP[c][r] : 0.0;
+        a += x * x;
+        Rout[(long)pos * ldg + r] = T(x * sc_out);
+      }
+      a = wave_sum(a);
+      if (lane == 0) sN[pos] = a;
+    }
+    if (tid == 0) s_nlive = nprev + __popc(livemask);
+    __syncthreads();
+  }
+  // ---- rank compaction: rows with norm below NOISE_C*eps_T*|R|_F are dropped (as the kernels above) ----
+  const int nfac = s_nlive;
+  {
+    double f = 0.0;
+    for (int q = tid; q < nfac; q += 512) f += sN[q];
+    f = wave_sum(f);
+    if (lane == 0) s_red[wave] = f;
+    __syncthreads();
+    if (tid == 0) { double t = 0.0; for (int w = 0; w < 8; ++w) t += s_red[w]; s_fro = t; }
+    __syncthreads();
+  }
+  const double nfloor = eT * eT * s_fro;
+  if (wave == 0) {
+    int cnt = 0;
+    for (int base = 0; base < nfac; base += 64) {
+      const int q = base + lane;
+      const bool f = q < nfac && sN[q] > nfloor;
+      const unsigned long long mask = __ballot(f);
+      if (q < nfac) sPos[q] = f ? (short)(cnt + __popcll(mask & ((1ull << lane) - 1ull))) : (short)-1;
+      cnt += __popcll(mask);
+    }
+    if (lane == 0) { s_nlive = cnt; if (mlive_out) mlive_out[blockIdx.x] = cnt; }
+  }
+  __syncthreads();
+  const int mlive = s_nlive;
+  if (mlive != nfac) {
+    const int wrow = ndyn ? ldg : n;
+    for (int q = 0; q < nfac; ++q) {
+      const int pos = sPos[q];
+      if (pos >= 0 && pos != q)
+        for (int r = tid; r < wrow; r += 512) Rout[(long)pos * ldg + r] = Rout[(long)q * ldg + r];
+      __syncthreads();
+    }
+  }
+  if (mlive_out) return;
+  (void)nfull;
+  for (int e = tid + mlive * n; e < n * n; e += 512) Rout[(long)(e / n) * ldg + (e % n)] = T(0);
+}
+
 // launch of the blocked factorisation: the MFMA form above for orders >= 48 (PEPSGPU_OLD_CHOL=1: always the older kernel)
 template <typename T>
 inline void launch_chol_upper(hipStream_t s, int nbatch, double *G, long wG, int n, T *R, long wR, int *mlive_out, int only_flagged = 0,
                               int ld = 0, const int *ndyn = nullptr, int ndyn_mul = 1, const int *run_flag = nullptr, double thresh_scale = 1.0) {
   PG_REQUIRE(thresh_scale == 1.0 || n >= 48, 1, "pivot threshold scaling needs the blocked Cholesky (order >= 48)");
   static const bool old_chol = getenv("PEPSGPU_OLD_CHOL") != nullptr;
-  if (!old_chol && n >= 48) {
+  // the register-resident kernel (opt-in): 181 us for a block of order 256 against 452 us of the left-looking one, but one block per CU
+  // against three -- 5.35 ms against 3.67 ms per launch of 8192 walkers.  PEPSGPU_CHOL_RESIDENT=1: every launch of order 129 .. 256;
+  // =2: only the launches that do not fill the chip once (<= 256 walkers: straggler lists, partial batches; measured +0.3 % on the real
+  // leg, within the noise, with another rounding of the affected walkers); default 0: never.
+  static const int resident = getenv("PEPSGPU_CHOL_RESIDENT") ? atoi(getenv("PEPSGPU_CHOL_RESIDENT")) : 0;
+  if (!old_chol && n > 128 && n <= 256 && (resident == 1 || (resident == 2 && nbatch <= 256))) {
+    static const int cr_dbg = getenv("PEPSGPU_CR_DBG") ? atoi(getenv("PEPSGPU_CR_DBG")) : 0;
+    hipLaunchKernelGGL((chol_resident_kernel<T>), dim3(nbatch), dim3(512), 0, s, (const double *)G, wG, n, R, wR, mlive_out, only_flagged, ld,
+                       ndyn, ndyn_mul, run_flag, thresh_scale, cr_dbg);
+  } else if (!old_chol && n >= 48) {
     const size_t smem = chol_blocked_smem_bytes(n);
     // (four blocks per CU -- 128 registers, 300 bytes of scratch -- measured on the real state: cholesky + trunc_gram 484 -> 531 ms)
     static const int minb = getenv("PEPSGPU_CHB_MINB") ? atoi(getenv("PEPSGPU_CHB_MINB")) : 3;

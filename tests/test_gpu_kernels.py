@@ -691,3 +691,46 @@ def test_jacobi_one_wave_grouped_tournament(shape, kernel):
         assert np.max(np.abs(G[np.ix_(live, live)] - np.eye(int(live.sum())))) < 1e-4, b
         assert abs(np.linalg.norm(Mo[b]) / np.linalg.norm(M[b]) - 1) < 1e-5
         assert sw[b] < 40
+
+
+def test_register_resident_cholesky_same_contract_as_the_left_looking_kernel():
+    """chol_resident_kernel (round 5, opt-in through PEPSGPU_CHOL_RESIDENT=1, read once per process: hence the subprocess): the order-129 .. 256
+    factorisation with the trailing matrix in registers gives R^T R = G at the same tolerances as the left-looking kernel -- full rank and graded
+    deficient rank, f32 and f64 output, orders that are and are not multiples of the tile size -- and the two kernels keep the same rows."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import json, numpy as np
+from peps_amd import capi
+out = {}
+for n, rank in ((256, 256), (256, 97), (241, 180), (160, 33), (129, 129)):
+    rng = np.random.default_rng(n + rank)
+    X = rng.standard_normal((3, rank, n)) * np.logspace(0, -4, rank)[None, :, None]
+    G = np.einsum("bri,brj->bij", X, X)
+    for dt, name in ((capi.F32, "f32"), (capi.F64, "f64")):
+        R = capi.diag_chol(dt, G).astype(np.float64)
+        errs, lives = [], []
+        for b in range(3):
+            sc = np.max(np.diag(G[b]))
+            errs.append(float(np.max(np.abs(R[b].T @ R[b] * sc - G[b])) / sc))
+            live = int(np.sum(np.any(R[b] != 0, axis=1)))
+            assert np.all(R[b][live:] == 0)
+            lives.append(live)
+        out["%d_%d_%s" % (n, rank, name)] = [max(errs), lives]
+print("RESULT " + json.dumps(out))
+'''
+    res = {}
+    for name, env in (("left_looking", {"PEPSGPU_CHOL_RESIDENT": "0"}), ("resident", {"PEPSGPU_CHOL_RESIDENT": "1"})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=dict(os.environ, PYTHONPATH=root, **env),
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    for key, (err, lives) in res["resident"].items():
+        n, rank, dt = key.split("_")
+        assert err < (3e-6 if dt == "f32" else 3e-6 if int(rank) < int(n) else 1e-12), (key, err)      # (deficient rank: the f32-noise pivot floor)
+        err0, lives0 = res["left_looking"][key]
+        assert all(abs(a - b) <= 1 for a, b in zip(lives, lives0)), (key, lives, lives0)
+        assert all(l <= min(int(rank) + 2, int(n)) for l in lives), (key, lives)
