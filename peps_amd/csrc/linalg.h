@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
 //   B  the 16 x 16 diagonal block of panel p + 1 is factored by wave 0 INSIDE D(p), right after its own update of that tile
 //      (look-ahead: the 16 dependent pivots run under the other waves' matrix work).
 // Orders 129 .. 256.  Opt-in (PEPSGPU_CHOL_RESIDENT, see launch_chol_upper): measured per block of order 256, phases switched off one at
-// a time: 181 us = G load 5 + pivot chains 34 + substitutions 33 + trailing MFMAs 21 + output rows 17 + the rest (barriers, LDS staging,
+// a time (instrumentation removed afterwards): 181 us = G load 5 + pivot chains 34 + substitutions 33 + trailing MFMAs 21 + output rows 17 + the rest (barriers, LDS staging,
 // start-up) ~ 70; the phases add up -- nothing overlaps with one block per CU -- where the left-looking kernel hides them behind two
 // other blocks.  HISTORY (round 5, item 11) has the account.
 constexpr int CR_NS = 256 + 8;          // LDS row stride of the block row: the four rows of one k-step fall on four different bank groups
@@ -564,10 +564,7 @@ __global__ __launch_bounds__(512) void chol_resident_kernel(const double *__rest
                                                             T *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
                                                             int only_flagged = 0, int ld = 0,
                                                             const int *__restrict__ ndyn = nullptr, int ndyn_mul = 1,
-                                                            const int *__restrict__ run_flag = nullptr, double thresh_scale = 1.0,
-                                                            int dbg = 0) {
-  // dbg (timing experiments only, PEPSGPU_CR_DBG; the results are wrong): 1 no pivot chain, 2 no substitution, 4 no trailing update,
-  // 8 no load of G, 16 no output rows
+                                                            const int *__restrict__ run_flag = nullptr, double thresh_scale = 1.0) {
   if (only_flagged && mlive_out[blockIdx.x] >= 0) return;
   if (run_flag && run_flag[blockIdx.x] >= 0) return;
   const int ldg = ld ? ld : n;
@@ -612,7 +609,7 @@ __global__ __launch_bounds__(512) void chol_resident_kernel(const double *__rest
       const int row = 16 * tI[s] + k4 + 4 * r, col = 16 * tJ[s] + i16;
       const bool ok = tI[s] >= 0 && row < n && col < n && col >= row;
       const long off = ok ? (long)row * ldg + col : 0;
-      const double g = (dbg & 8) ? (row == col ? 2.0 : 0.0) : G[off];
+      const double g = G[off];
       acc[s][r] = ok ? g : 0.0;
     }
   }
@@ -657,10 +654,8 @@ __global__ __launch_bounds__(512) void chol_resident_kernel(const double *__rest
 #pragma unroll
       for (int c = 0; c < CH_NB; ++c) d[c] = (lane < nbq && c <= lane) ? sDg[c][lane] : 0.0;
       unsigned livemask = 0;
-      if (dbg & 1) livemask = nbq >= 16 ? 0xffffu : ((1u << nbq) - 1u);
 #pragma unroll
       for (int c = 0; c < CH_NB; ++c) {
-        if (dbg & 1) break;
         const double piv = chb_readlane(d[c], c);
         const bool live = c < nbq && piv > thresh;             // wave-uniform
         const double pv = live ? piv : 1.0;
@@ -718,10 +713,8 @@ __global__ __launch_bounds__(512) void chol_resident_kernel(const double *__rest
           for (int c1 = 0; c1 < CH_NB; ++c1) {
             const double x = v[c1] * sDinv[c1];    // dropped row: sDinv = 0
             sP[c1][r] = x;
-            if (!(dbg & 2)) {
 #pragma unroll
-              for (int c = c1 + 1; c < CH_NB; ++c) v[c] -= sD[c1][c] * x;
-            }
+            for (int c = c1 + 1; c < CH_NB; ++c) v[c] -= sD[c1][c] * x;
             __asm__ volatile("" ::: "memory");
           }
         }
@@ -733,7 +726,7 @@ __global__ __launch_bounds__(512) void chol_resident_kernel(const double *__rest
     const int plim = wave == 0 ? p + 1 : p;
 #pragma unroll
     for (int s = 0; s < CR_SLOTS; ++s)
-      if (tI[s] > plim && !(dbg & 4)) {
+      if (tI[s] > plim) {
         const int ca = 16 * tI[s] + i16, cb = 16 * tJ[s] + i16;
 #pragma unroll
         for (int k0 = 0; k0 < CH_NB; k0 += 4) {
@@ -743,7 +736,7 @@ __global__ __launch_bounds__(512) void chol_resident_kernel(const double *__rest
       }
     // the finished rows: scaled, as type T, at their provisional position (rank in the live list); squared norms for the compaction
     for (int c = wave; c < nb; c += 8) {
-      if (!((livemask >> c) & 1u) || (dbg & 16)) continue;
+      if (!((livemask >> c) & 1u)) continue;
       const int pos = nprev + __popc(livemask & ((1u << c) - 1u));
       double a = 0.0;
       for (int r = lane; r < wout; r += 64) {
@@ -808,9 +801,8 @@ inline void launch_chol_upper(hipStream_t s, int nbatch, double *G, long wG, int
   // leg, within the noise, with another rounding of the affected walkers); default 0: never.
   static const int resident = getenv("PEPSGPU_CHOL_RESIDENT") ? atoi(getenv("PEPSGPU_CHOL_RESIDENT")) : 0;
   if (!old_chol && n > 128 && n <= 256 && (resident == 1 || (resident == 2 && nbatch <= 256))) {
-    static const int cr_dbg = getenv("PEPSGPU_CR_DBG") ? atoi(getenv("PEPSGPU_CR_DBG")) : 0;
     hipLaunchKernelGGL((chol_resident_kernel<T>), dim3(nbatch), dim3(512), 0, s, (const double *)G, wG, n, R, wR, mlive_out, only_flagged, ld,
-                       ndyn, ndyn_mul, run_flag, thresh_scale, cr_dbg);
+                       ndyn, ndyn_mul, run_flag, thresh_scale);
   } else if (!old_chol && n >= 48) {
     const size_t smem = chol_blocked_smem_bytes(n);
     // (four blocks per CU -- 128 registers, 300 bytes of scratch -- measured on the real state: cholesky + trunc_gram 484 -> 531 ms)

@@ -577,3 +577,24 @@ def test_complex_variational_amplitudes_against_oracle(L, D, chi, scheme):
     assert err < 1e-7, (got, ref, svd)
     assert np.max(np.abs(svd / ref - 1)) > 10 * err
     ctx.close()
+
+
+@pytest.mark.parametrize("stem,model,params,e_su,e_lowest,kind", [
+    ("transverse_ising_tps", "tfim", (1.0,), -5.19991995228, -5.226251859505506, "all"),
+    ("heisenberg_tps", "xxz", (1.0, 1.0, 0.0), -1.99521278793, -2.0, "half")])
+def test_k4_complex_exact_sum_energies_of_both_boson_models(fixtures_dir, stem, model, params, e_su, e_lowest, kind):
+    """ExactSumEnergyEvaluator<.., QLTEN_Complex> of the host layer on the reference's complex 2x2 fixtures (test_exact_summation_evaluator.cpp,
+    QLTEN_Complex build: TFIM :775 / :250-259, Heisenberg :606 / :139-174): simple-update energies to 1e-9, the closed forms of the `lowest`
+    states to the reference's 6e-8, |Im E| < 1e-10, and a gradient that is small at the optimum (NormSquare < 1e-6; the reference pins 1.29e-10 +- 1e-8 for TFIM)."""
+    from peps_amd import hostapi
+    cfgs = np.array(vmc.generate_all_binary_configs(2, 2) if kind == "all" else vmc.generate_all_permutation_configs([2, 2], 2, 2), dtype=np.int32)
+    hostapi.set_truncate_params(1, 1e-16, 0)                    # SVD(1, 8, 1e-16)
+    try:
+        for suffix, want, tol in (("_complex_from_simple_update", e_su, 1e-9), ("_complexlowest", e_lowest, 6e-8)):
+            s = qlten_io.load_sitps(os.path.join(fixtures_dir, stem + suffix), complex_data=True)
+            e, grad = hostapi.exact_sum_complex(_flat(s, _bond(s)), cfgs, 8, model, params, size=1, batch=16)
+            assert abs(e - want) < tol and abs(e.imag) < 1e-10, (suffix, e)
+            if suffix == "_complexlowest":
+                assert np.sum(np.abs(grad) ** 2) < 1e-6
+    finally:
+        hostapi.set_truncate_params()
