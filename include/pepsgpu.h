@@ -42,9 +42,9 @@ enum {
  * float64 (std::complex<double> layout, interleaved re / im).  For a complex context EVERY scalar or tensor the calls
  * below return through a `double *` is an interleaved (re, im) pair: out_amp has 2 n doubles, a hole 2 D^4 per walker, a
  * BMPS tensor 2 x elements; pepsgpu_state_upload additionally accepts host_dtype = PEPSGPU_C128.  The complex type covers
- * SVD compression, every contraction / trace / hole entry point, the walker calls, the gradient accumulation (pepsgpu_grad_* below,
- * with the reference's conjugations: psi, eloc and the accumulators are interleaved pairs) and the SR / MinSR family (pepsgpu_sr_*);
- * the variational schemes and the two device-side slice calls are real only and return PEPSGPU_EINVAL. */
+ * SVD and (since round 5) variational compression, every contraction / trace / hole entry point, the walker calls, the gradient
+ * accumulation (pepsgpu_grad_* below, with the reference's conjugations: psi, eloc and the accumulators are interleaved pairs) and
+ * the SR / MinSR family (pepsgpu_sr_*); the two device-side slice calls are real only and return PEPSGPU_EINVAL. */
 enum { PEPSGPU_F32 = 0, PEPSGPU_F64 = 1, PEPSGPU_C128 = 3 };
 enum { PEPSGPU_LEFT = 0, PEPSGPU_DOWN = 1, PEPSGPU_RIGHT = 2, PEPSGPU_UP = 3 };
 enum { PEPSGPU_HORIZONTAL = 0, PEPSGPU_VERTICAL = 1 };
