@@ -1,5 +1,6 @@
 """Kernel-time experiment for the order-256 Cholesky kernels: one diag_chol call on `nb` graded Gram matrices (run under rocprofv3
---kernel-trace --stats; the environment selects the kernel: PEPSGPU_CHOL_RESIDENT, PEPSGPU_CR_DBG)."""
+--kernel-trace --stats --output-format csv; the environment selects the kernel: PEPSGPU_CHOL_RESIDENT; the timing-only switch PEPSGPU_CR_DBG of calls 42 / 46 was removed
+from the kernel after the measurement)."""
 import sys
 import numpy as np
 sys.path.insert(0, ".")

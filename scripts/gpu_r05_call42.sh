@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 5 call 42: where the resident Cholesky spends its time (phases switched off one at a time; results of those runs are wrong by design)
+# (historical: PEPSGPU_CR_DBG was a timing-only switch of chol_resident_kernel, removed after this measurement; this call also lost 29 GPU-minutes
+# to a grep on an empty file name -- rocprofv3 needs --output-format csv for *_kernel_stats.csv)
 mkdir -p gpurun_out/r05/cr
 export TMPDIR=/tmp
 for cfg in "0 0" "1 0" "1 1" "1 2" "1 4" "1 8" "1 7" "1 15"; do

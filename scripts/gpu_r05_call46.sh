@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 5 call 46: where the resident Cholesky spends its time: 256 order-256 walkers (one block per CU, one round), phases switched off one at
 # a time (PEPSGPU_CR_DBG; the results of those runs are wrong by design).  Every step under a timeout; no grep on an empty file name.
+# (historical: the PEPSGPU_CR_DBG switch was removed from the kernel after this measurement; results in profiles/r05_chol_resident_phases.txt)
 mkdir -p gpurun_out/r05
 export TMPDIR=/tmp
 for cfg in "0 0" "1 0" "1 1" "1 2" "1 4" "1 8" "1 16" "1 31"; do
