@@ -247,3 +247,35 @@ def test_exact_sum_measurer_registry_on_the_complex_fixture(fixtures_dir):
     for key, want in MEASURER_GOLDEN.items():
         assert np.max(np.abs(obs[key] - np.array(want))) < 1e-10, key                 # kTol
         assert np.max(np.abs(np.imag(obs[key]))) < 1e-10, key                         # kImagTol
+
+
+@pytest.mark.parametrize("complex_data,name", [(False, "spinless_fermion_tps_t2_2.100000_double_from_simple_update"),
+                                               (True, "spinless_fermion_tps_t2_2.100000_complex_from_simple_update"),
+                                               (True, "spinless_fermion_tps_t2_-2.500000_complexlowest")])
+def test_product_decoration_equals_the_oracle_decoration(fixtures_dir, complex_data, name):
+    """peps_amd/fermion.py (the product's loader and sign decoration: FermionState.load / extended_flat / ext_config / sigma / kappa; NumPy
+    only, never imports the oracle) against oracle/fermion.py on the reference's fixtures, real and QLTEN_Complex: the 4 d extended
+    components the device is given are, element for element, the oracle's decorated tensors, and the extended configurations and the two
+    signs agree on all 16 configurations.  (CPU: what reaches the GPU is checked before it gets there.)"""
+    from peps_amd import fermion as pfermion
+    d = os.path.join(fixtures_dir, name)
+    st = pfermion.FermionState.load(d, complex_data=complex_data)
+    fs = fermion.FermionSITPS(fermion.load_fermion_sitps(d, complex_data=complex_data))
+    assert st.is_complex == complex_data and list(st.nf) == list(fs.nf)
+    flat = st.extended_flat()
+    assert flat.dtype == (np.complex128 if complex_data else np.float64) and flat.shape[2] == 4 * st.d
+    for r in range(st.rows):
+        for c in range(st.cols):
+            for s in range(4 * st.d):
+                want = fs.ext[r][c][s]
+                got = flat[(r, c, s) + tuple(slice(0, k) for k in want.shape)]
+                assert np.array_equal(got, want), (r, c, s)
+                pad = flat[r, c, s].copy()
+                pad[tuple(slice(0, k) for k in want.shape)] = 0
+                assert not np.any(pad)                                   # zero padding beyond the bond dimensions of the site
+    cfgs = np.array(list(itertools.product([0, 1], repeat=4))).reshape(-1, 2, 2)
+    for order in (fermion.ROW, fermion.COL):
+        ext = st.ext_config(cfgs, order)
+        for k, cfg in enumerate(cfgs):
+            assert np.array_equal(ext[k], fs.ext_config(cfg, order))
+    assert np.array_equal(st.sigma(cfgs), [fs.sigma(c) for c in cfgs]) and np.array_equal(st.kappa(cfgs), [fs.kappa(c) for c in cfgs])
