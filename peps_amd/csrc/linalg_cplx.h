@@ -134,12 +134,73 @@ __global__ __launch_bounds__(1024) void jacobi_rows_cplx_kernel(T *__restrict__ 
     if (tid == 0) s_rot = 0;
     __syncthreads();
     for (int r = 0; r < lp - 1; ++r) {
-      for (int p = wave; p < lp / 2; p += nw) {
-        int a, b;
+      auto pair_of = [&](int p, int &a, int &b) -> bool {      // pair p of tournament step r; false: a bye or a dead row
+        if (p >= lp / 2) return false;
         if (p == 0) { a = lp - 1; b = r; }
         else { a = (r + p) % (lp - 1); b = (r - p + (lp - 1)) % (lp - 1); }
         if (a > b) { const int t = a; a = b; b = t; }
-        if (b >= ml) continue;
+        return b < ml;
+      };
+      if (len <= 256) {
+        // rows of up to 256 elements (the factors and Z of the dense route, round 5): both rows of a pair stay in registers between the
+        // inner products and the rotation (one read and one write of a row instead of two reads and a write), and a wave works on TWO
+        // pairs at a time so that the loads of the second travel under the reductions of the first
+        for (int p0 = wave; p0 < lp / 2; p0 += 2 * nw) {
+          int a[2], b[2];
+          bool ok[2];
+          T xr[2][4], yr[2][4];
+          double alpha[2], beta[2], gre[2], gim[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            ok[q] = pair_of(p0 + q * nw, a[q], b[q]);
+            alpha[q] = beta[q] = gre[q] = gim[q] = 0.0;
+            if (!ok[q]) continue;
+            const T *pa = M + (long)s_live[a[q]] * ld, *pb = M + (long)s_live[b[q]] * ld;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int c = lane + 64 * j;
+              xr[q][j] = c < len ? pa[c] : T(0);
+              yr[q][j] = c < len ? pb[c] : T(0);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            if (!ok[q]) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              alpha[q] += abs2_of(xr[q][j]); beta[q] += abs2_of(yr[q][j]);
+              const T g = conj_of(xr[q][j]) * yr[q][j];
+              gre[q] += (double)g.re; gim[q] += (double)g.im;
+            }
+            alpha[q] = wave_sum(alpha[q]); beta[q] = wave_sum(beta[q]); gre[q] = wave_sum(gre[q]); gim[q] = wave_sum(gim[q]);
+          }
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            if (!ok[q]) continue;
+            const double absg = sqrt(gre[q] * gre[q] + gim[q] * gim[q]);
+            if (absg > tol * sqrt(alpha[q]) * sqrt(beta[q]) && alpha[q] > floor2 && beta[q] > floor2) {
+              const T ph = T(R(gre[q] / absg), R(-gim[q] / absg));
+              const double zeta = (beta[q] - alpha[q]) / (2.0 * absg);
+              const double td = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+              const double cd = 1.0 / sqrt(1.0 + td * td), sd = cd * td;
+              T *pa = M + (long)s_live[a[q]] * ld, *pb = M + (long)s_live[b[q]] * ld;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int c = lane + 64 * j;
+                if (c < len) {
+                  const T x = xr[q][j], y = yr[q][j] * ph;
+                  pa[c] = scaled(x, cd) - scaled(y, sd);
+                  pb[c] = scaled(x, sd) + scaled(y, cd);
+                }
+              }
+              if (lane == 0) atomicAdd(&s_rot, 1);
+            }
+          }
+        }
+      } else {
+      for (int p = wave; p < lp / 2; p += nw) {
+        int a, b;
+        if (!pair_of(p, a, b)) continue;
         T *pa = M + (long)s_live[a] * ld, *pb = M + (long)s_live[b] * ld;
         double alpha = 0.0, beta = 0.0, gre = 0.0, gim = 0.0;
         for (int c = lane; c < len; c += 64) {
@@ -162,6 +223,7 @@ __global__ __launch_bounds__(1024) void jacobi_rows_cplx_kernel(T *__restrict__ 
           }
           if (lane == 0) atomicAdd(&s_rot, 1);
         }
+      }
       }
       __threadfence_block();
       __syncthreads();
