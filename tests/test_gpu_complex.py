@@ -598,3 +598,25 @@ def test_k4_complex_exact_sum_energies_of_both_boson_models(fixtures_dir, stem, 
                 assert np.sum(np.abs(grad) ** 2) < 1e-6
     finally:
         hostapi.set_truncate_params()
+
+
+def test_k5_device_against_a_dense_contraction(fixtures_dir):
+    """The reference's 4x4 D = 8 Heisenberg fixture in both element types (tests/slow_tests/test_data/tps_square_heisenberg4x4D8{Double,Complex},
+    test_boson_mc_peps_measure.cpp:36,55-62) against an INDEPENDENT dense contraction (tests/golden/k5_complex_dense.json: 65 536 amplitudes by
+    plain tensordot, no boundary MPS): amplitude and local energy of 32 seeded Sz = 0 configurations through CalEnergyAndHoles of the host layer at
+    the exact chi = 64, float64 and complex128 device contexts, 1e-9."""
+    import json
+    from peps_amd import hostapi
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "k5_complex_dense.json")))
+    cfgs = np.array(gold["configs"], dtype=np.int32)
+    amp = np.array([complex(*z) for z in gold["amplitude"]])
+    eloc = np.array([complex(*z) for z in gold["e_loc"]])
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, "tps_square_heisenberg4x4D8Complex"), complex_data=True)
+    a, e, _, psi = hostapi.energy_and_holes_complex(_flat(s, 8), cfgs, 64, "xxz", (1.0, 1.0, 0.0), holes=False)
+    assert np.max(np.abs(a / amp - 1)) < 1e-9 and np.max(np.abs(e - eloc)) < 1e-8
+    assert np.max(np.abs(psi / a[None, :] - 1)) < 1e-9                         # every route gives the same amplitude at an exact chi
+    s = qlten_io.load_sitps(os.path.join(fixtures_dir, "tps_square_heisenberg4x4D8Double"))
+    a, e, _, _ = hostapi.energy_and_holes(synthetic.sitps_to_flat(s, 8), cfgs, 64, "xxz", (1.0, 1.0, 0.0), holes=False)
+    ratio = a / amp.real                                                       # (the double file holds the same state at another overall scale)
+    assert np.max(np.abs(ratio / ratio[0] - 1)) < 1e-9 and abs(ratio[0] - 1.77163865188) < 1e-8
+    assert np.max(np.abs(e - eloc.real)) < 1e-8

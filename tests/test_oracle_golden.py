@@ -352,3 +352,31 @@ def test_complex_conjugate_gradient_host_and_oracle_agree():
 
     _, _, ih2, wh2 = sr.conjugate_gradient(Mat2(), b, None, 300, 1e-10, 0.0, 7, 0.5, full_output=True)
     assert wo2 == wh2 == osr.K_INDEFINITE and io2 == ih2
+
+
+def test_k5_oracle_against_a_dense_contraction(fixtures_dir):
+    """The oracle's boundary-MPS path at an exact chi (64 = D^2 on the 4x4 lattice) against an INDEPENDENT dense contraction of the
+    reference's 4x4 D = 8 Heisenberg fixture (tests/golden/k5_complex_dense.json, scripts/make_k5_complex_golden.py: all 65 536 amplitudes by
+    plain tensordot, no boundary MPS): amplitude and local energy of seeded Sz = 0 configurations, for the double fixture and for its
+    QLTEN_Complex twin (the complex-typed file holds the same state: Im psi = 0 to the last bit); the exact energy of the Sz = 0 sector
+    is the number the survey quotes, -9.1891559611."""
+    import json
+    import os
+    from oracle import qlten_io, vmc
+    from oracle.bmps import BMPSTruncateParams
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "k5_complex_dense.json")))
+    assert abs(gold["energy_sz0_sector"][0] - (-9.1891559611)) < 1e-9 and gold["energy_sz0_sector"][1] == 0.0
+    tp = BMPSTruncateParams.SVD(64, 64, 0.0)
+    model = vmc.SquareSpinOneHalfXXZModelOBC(1.0, 1.0, 0.0)
+    for name, cplx in (("tps_square_heisenberg4x4D8Double", False), ("tps_square_heisenberg4x4D8Complex", True)):
+        s = qlten_io.load_sitps(os.path.join(fixtures_dir, name), complex_data=cplx)
+        ratios = []
+        for k in (0, 7, 19):
+            cfg = np.array(gold["configs"][k])
+            comp = vmc.TPSWaveFunctionComponent(s, cfg, tp)
+            ratios.append(comp.amplitude / complex(*gold["amplitude"][k]))
+            e = model.CalEnergyAndHoles(s, comp, False)[0]
+            assert abs(e - complex(*gold["e_loc"][k])) < 1e-8
+        # the golden was taken from the complex-typed file; the double file holds the same state at another overall scale (1.7716...)
+        assert np.max(np.abs(np.array(ratios) / ratios[0] - 1)) < 1e-10
+        assert abs(ratios[0] - 1) < 1e-10 if cplx else abs(ratios[0] - 1.77163865188) < 1e-9
