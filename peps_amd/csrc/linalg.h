@@ -796,7 +796,7 @@ inline void launch_chol_upper(hipStream_t s, int nbatch, double *G, long wG, int
   PG_REQUIRE(thresh_scale == 1.0 || n >= 48, 1, "pivot threshold scaling needs the blocked Cholesky (order >= 48)");
   static const bool old_chol = getenv("PEPSGPU_OLD_CHOL") != nullptr;
   // the register-resident kernel (opt-in): 181 us for a block of order 256 against 452 us of the left-looking one, but one block per CU
-  // against three -- 5.35 ms against 3.67 ms per launch of 8192 walkers.  PEPSGPU_CHOL_RESIDENT=1: every launch of order 129 .. 256;
+  // against three -- 4.57 ms against 3.67 ms per launch of 8192 walkers (5.35 before the loads left the index loops).  PEPSGPU_CHOL_RESIDENT=1: every launch of order 129 .. 256;
   // =2: only the launches that do not fill the chip once (<= 256 walkers: straggler lists, partial batches; measured +0.3 % on the real
   // leg, within the noise, with another rounding of the affected walkers); default 0: never.
   static const int resident = getenv("PEPSGPU_CHOL_RESIDENT") ? atoi(getenv("PEPSGPU_CHOL_RESIDENT")) : 0;
