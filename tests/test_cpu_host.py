@@ -54,17 +54,20 @@ def test_cpp_qlten_loader_matches_oracle(fixtures_dir):
         hostapi.load_sitps(os.path.join(fixtures_dir, "does_not_exist"), 8)
 
 
-def test_complex_qlten_round_trip_is_byte_identical(fixtures_dir, tmp_path):
+@pytest.mark.parametrize("name,D,L", [("heisenberg_tps_complex_from_simple_update", 4, 2), ("transverse_ising_tps_complexlowest", 4, 2),
+                                      ("tps_square_heisenberg4x4D8Complex", 8, 4)])
+def test_complex_qlten_round_trip_is_byte_identical(fixtures_dir, tmp_path, name, D, L):
     """SplitIndexTPS<QLTEN_Complex>::Load -> Dump of the host layer (qlpeps_gpu.h, TenElemT = std::complex<double>) reproduces the
-    reference's COMPLEX fixture byte for byte (interleaved complex128 payloads), and equals the oracle's reader."""
+    reference's COMPLEX fixtures byte for byte (interleaved complex128 payloads; 2x2 D = 4 and the 4x4 D = 8 twin of K5), and equals the
+    oracle's reader."""
     import filecmp
     from peps_amd import hostapi
     from oracle import qlten_io
-    src = os.path.join(fixtures_dir, "heisenberg_tps_complex_from_simple_update")
-    flat = hostapi.load_sitps_complex(src, 4)
+    src = os.path.join(fixtures_dir, name)
+    flat = hostapi.load_sitps_complex(src, D)
     ref = qlten_io.load_sitps(src, complex_data=True)
-    for r in range(2):
-        for c in range(2):
+    for r in range(L):
+        for c in range(L):
             for s_ in range(2):
                 t = ref[r][c][s_]
                 assert np.array_equal(flat[r, c, s_][:t.shape[0], :t.shape[1], :t.shape[2], :t.shape[3]], t)
