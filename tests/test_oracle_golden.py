@@ -380,3 +380,43 @@ def test_k5_oracle_against_a_dense_contraction(fixtures_dir):
         # the golden was taken from the complex-typed file; the double file holds the same state at another overall scale (1.7716...)
         assert np.max(np.abs(np.array(ratios) / ratios[0] - 1)) < 1e-10
         assert abs(ratios[0] - 1) < 1e-10 if cplx else abs(ratios[0] - 1.77163865188) < 1e-9
+
+
+def test_k2_complex_variational_one_site_oracle():
+    """The reference's complex variational run (test_bmps_contractor.cpp:663-673) through the ORACLE: the 24 x 10 Ising network in the Z2
+    (Hadamard) basis of the bonds with a random phase on every tensor, Variational1Site(1, 10, 1e-15, 1e-14, 10) -- every route of the
+    reference's Contract2DTNUsingBMPSContractor gives the exact free energy to 1e-8 with a vanishing imaginary part.  This pins the
+    conjugations of the oracle's variational restatement (oracle/bmps.py: Dag() of the environments) that the device test of the truncating
+    complex runs (tests/test_gpu_complex.py) leans on."""
+    import k1_routes
+    rows, cols = 24, 10
+    tn, lognorm, beta = ising.build_ising_tn(cols, rows)
+    f_ex = ising.exact_free_energy(cols, rows, 1.0 / beta)
+    H = np.array([[1.0, 1.0], [1.0, -1.0]]) / np.sqrt(2.0)
+    rng = np.random.default_rng(11)
+    ph = rng.uniform(size=(rows, cols))
+
+    def site(rc):
+        t = tn(rc)
+        for ax in range(4):
+            if t.shape[ax] == 2:
+                t = np.moveaxis(np.tensordot(H, t, axes=([1], [ax])), 0, ax)
+        t = t.astype(np.complex128) * np.exp(2j * np.pi * ph[rc])
+        return t * np.exp(-2j * np.pi * ph.sum()) if rc == (0, 0) else t
+
+    class Tn:
+        def __init__(self):
+            self.rows, self.cols = rows, cols
+
+        def __call__(self, rc):
+            return site(rc)
+    ztn = TensorNetwork2D.from_sitps([[[site((r, c))] for c in range(cols)] for r in range(rows)], np.zeros((rows, cols), dtype=int))
+    c = BMPSContractor(rows, cols)
+    c.Init(ztn)
+    c.SetTruncateParams(BMPSTruncateParams.Variational1Site(1, 10, 1e-15, 1e-14, 10))
+    amps = k1_routes.run_oracle(c, ztn, rows)
+    assert len(amps) > 10
+    for a in amps:
+        z = complex(a)
+        assert abs(-(np.log(z.real) + lognorm) / (rows * cols) / beta - f_ex) < 1e-8
+        assert abs(z.imag) < 1e-10 * abs(z.real)
