@@ -389,10 +389,13 @@ def test_complex_mc_measurer_statistics():
     for w in range(n):
         comp = vmc.TPSWaveFunctionComponent(sitps, c_mid[w], tp)
         e_mid.append(vmc.SquareNNNModelMeasurementSolver(vmc.SquareSpinOneHalfXXZModelOBC(1.0, 1.0, 0.0)).EvaluateObservables(sitps, comp)["energy"][0])
-    walker_means = (np.array(e_mid) + np.array(e_last)) / 2
-    assert abs(mean[0] - walker_means.mean()) < 1e-8
-    want_err = np.sqrt(np.sum(np.abs(walker_means - walker_means.mean()) ** 2) / n / (n - 1))
-    assert abs(err[0] - want_err) < 1e-8
+    # the reference's statistics (oracle/statistics.py, pinned on test_statistics.cpp): per-walker AveListOfData over the samples, then
+    # GatherStatisticListOfData across the walkers (a walker = an MPI rank of the reference)
+    from oracle import statistics
+    walker_means = np.array([statistics.ave_list_of_data([[e_mid[w]], [e_last[w]]]) for w in range(n)])
+    want_mean, want_err = statistics.gather_statistic_list_of_data(walker_means)
+    assert abs(mean[0] - want_mean[0]) < 1e-8
+    assert abs(err[0] - want_err[0]) < 1e-8
 
 
 FERMION_CASES = [("0.000000_complexlowest", 0.0, -2.0), ("0.000000_complex_from_simple_update", 0.0, -1.98218053854),
