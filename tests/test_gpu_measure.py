@@ -123,11 +123,11 @@ def test_mc_measurer_identical_chain_statistics(updater, cls, tmp_path):
     run_cfgs = cfgs.copy()
     got, psi = host.measure(flat, run_cfgs, chi, "xxz", (1.0, 1.0, 0.0), seeds=seeds, updater=updater, warmup_sweeps=warm,
                             n_samples=nsamp, sweeps_between_samples=between, dump_dir=str(tmp_path), dtype=F64)
+    from oracle import statistics
     n = len(cfgs)
     for key in means[0]:
         stack = np.stack([m[key] for m in means])
-        mean = stack.mean(axis=0)
-        err = np.sqrt(((stack - mean) ** 2).mean(axis=0) / (n - 1))          # StandardError (statistics.h:89-96)
+        mean, err = statistics.gather_statistic_list_of_data(stack)          # oracle/statistics.py (statistics.h:288-340, pinned on test_statistics.cpp)
         assert np.max(np.abs(got[key][0] - mean)) < 1e-8 * max(1.0, np.max(np.abs(mean))), key
         assert np.max(np.abs(got[key][1] - err)) < 1e-8 * max(1.0, np.max(np.abs(err))), key
     assert os.path.exists(tmp_path / "stats" / "energy.csv")
