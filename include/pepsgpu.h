@@ -347,6 +347,12 @@ int pepsgpu_diag_cg_stats(double *out16);
 /* the LDS-resident Gram + Cholesky kernels alone (f32): which = 0 rows form (X = [nbatch][n][K], R^T R = X X^T, nlive = live rows),
  * which = 1 column form (X = [nbatch][K][n], R^T R = X^T X, nlive = live rows of X); R_out = [nbatch][n][n], n <= 128 */
 int pepsgpu_diag_lds_gram_chol(int which, const float *X, int n, int K, int nbatch, const int32_t *nlive, float *R_out, int32_t *mlive_out);
+/* the first compression of the dense truncation route as it runs (round 6): i8 row Gram with both triangles + the diagonally pivoted
+ * factorisation stopped after kcap <= 64 rows (chol_pivot.h); X = [nbatch][n][K] f32, 128 < n <= 256; R_out = [nbatch][kcap][n], rows in pivot order */
+int pepsgpu_diag_chol_pivot(const float *X, int n, int K, int nbatch, const int32_t *nlive, int kcap, float *R_out, int32_t *mlive_out);
+/* rows_qr_kernel alone (round 6): the k <= 32 nearly orthogonal rows X = [nbatch][k][len] (len <= 256, by decreasing norm) made orthonormal in
+ * float64 (Cholesky-QR of the unit-scaled rows); V_out: live rows first, the rest zero; klive_out = their count */
+int pepsgpu_diag_rows_qr(const float *X, int k, int len, int nbatch, const int32_t *klive, float *V_out, int32_t *klive_out);
 /* the rank-adaptive pair used by the absorption: low-rank right-looking kernel, then the blocked
  * kernel for the walkers whose rank exceeds its cap; mlive_out[b] = rows of R_out[b] that exist */
 /* the Gram-free low-rank kernel alone: P = [nbatch][K][n] (dtype), R^T R = P^T P; mlive_out[b] = -1 where

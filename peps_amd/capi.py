@@ -43,7 +43,7 @@ SYMBOLS = [
     "pepsgpu_sr_cg_solve", "pepsgpu_sr_gram", "pepsgpu_sr_weighted_sum", "pepsgpu_sr_copy_samples",
     "pepsgpu_update_local", "pepsgpu_erase_envs_after_update", "pepsgpu_evaluate_amplitude",
     "pepsgpu_walker_flags", "pepsgpu_sync", "pepsgpu_stats", "pepsgpu_profile_enable", "pepsgpu_profile_read",
-    "pepsgpu_diag_tgemm", "pepsgpu_diag_tgemm_chain", "pepsgpu_diag_chol", "pepsgpu_diag_chol_adaptive", "pepsgpu_diag_gram_chol", "pepsgpu_diag_gram_cols", "pepsgpu_diag_gram_rows", "pepsgpu_diag_mgemm_dense", "pepsgpu_diag_jacobi", "pepsgpu_version",
+    "pepsgpu_diag_tgemm", "pepsgpu_diag_tgemm_chain", "pepsgpu_diag_chol", "pepsgpu_diag_chol_adaptive", "pepsgpu_diag_chol_pivot", "pepsgpu_diag_rows_qr", "pepsgpu_diag_gram_chol", "pepsgpu_diag_gram_cols", "pepsgpu_diag_gram_rows", "pepsgpu_diag_mgemm_dense", "pepsgpu_diag_jacobi", "pepsgpu_version",
 ]
 
 
@@ -647,6 +647,37 @@ def diag_lds_gram_chol(which, X, nlive):
     if rc != 0:
         raise RuntimeError("diag_lds_gram_chol failed: %s" % lib().pepsgpu_last_error(None).decode())
     return R, ml
+
+
+def diag_chol_pivot(X, nlive, kcap=64):
+    """The first compression of the dense truncation route (round 6): i8 row Gram with both triangles + chol_pivot_kernel.
+    X [nb][n][K] float32, 128 < n <= 256; returns (R [nb][kcap][n] float32 in pivot order -- rows beyond mlive are NaN --, mlive)."""
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    nb, n, K = X.shape
+    R = np.zeros((nb, kcap, n), dtype=np.float32)
+    ml = np.zeros(nb, dtype=np.int32)
+    nl = np.ascontiguousarray(nlive, dtype=np.int32)
+    f = lib().pepsgpu_diag_chol_pivot
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.POINTER(C.c_int32)]
+    rc = f(X.ctypes.data_as(C.c_void_p), n, K, nb, _ip(nl), kcap, R.ctypes.data_as(C.c_void_p), _ip(ml))
+    if rc != 0:
+        raise RuntimeError("diag_chol_pivot failed: %s" % lib().pepsgpu_last_error(None).decode())
+    return R, ml
+
+
+def diag_rows_qr(X, klive):
+    """rows_qr_kernel alone: X [nb][k][len] float32 -> (V [nb][k][len] orthonormal live rows first, klive_out)."""
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    nb, k, ln = X.shape
+    V = np.zeros_like(X)
+    ml = np.zeros(nb, dtype=np.int32)
+    kl = np.ascontiguousarray(klive, dtype=np.int32)
+    f = lib().pepsgpu_diag_rows_qr
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32)]
+    rc = f(X.ctypes.data_as(C.c_void_p), k, ln, nb, _ip(kl), V.ctypes.data_as(C.c_void_p), _ip(ml))
+    if rc != 0:
+        raise RuntimeError("diag_rows_qr failed: %s" % lib().pepsgpu_last_error(None).decode())
+    return V, ml
 
 
 def diag_mgemm_dense(R, Tt, a_dim, u_dim, k2_dim, tt_u_inner, m_live=None, a_live=None, k2_live=None):

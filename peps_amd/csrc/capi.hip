@@ -624,6 +624,60 @@ extern "C" int pepsgpu_diag_lds_gram_chol(int which, const float *X, int n, int 
     (void)hipFree(dX); (void)hipFree(dR); (void)hipFree(dn); (void)hipFree(dm);
   });
 }
+// The first compression of the dense truncation route as it runs (round 6): G = X X^T on the i8 matrix cores with both triangles written
+// (gram_i8.h, sym) + the diagonally pivoted factorisation stopped after kcap rows (chol_pivot.h).  X = [nbatch][n][K] f32 (rows of M),
+// 128 < n <= 256, K a multiple of 16; nlive[b] = live rows.  R_out = [nbatch][kcap][n] (rows in pivot order; rows beyond mlive_out[b]
+// untouched = NaN pattern).
+extern "C" int pepsgpu_diag_chol_pivot(const float *X, int n, int K, int nbatch, const int32_t *nlive, int kcap, float *R_out,
+                                       int32_t *mlive_out) {
+  return guarded(nullptr, [&]() {
+    PG_REQUIRE(n > 128 && n <= 256 && K >= 16 && K % 16 == 0 && nbatch >= 1 && nlive && kcap >= 1 && kcap <= 64, 1, "bad sizes");
+    float *dX, *dR; int *dn, *dm; double *dG;
+    const size_t ne = (size_t)n * K * nbatch, nr = (size_t)64 * n * nbatch;
+    PG_CHECK_HIP(hipMalloc(&dX, ne * sizeof(float)));
+    PG_CHECK_HIP(hipMalloc(&dR, nr * sizeof(float)));
+    PG_CHECK_HIP(hipMalloc(&dG, (size_t)n * n * nbatch * sizeof(double)));
+    PG_CHECK_HIP(hipMalloc(&dn, nbatch * sizeof(int)));
+    PG_CHECK_HIP(hipMalloc(&dm, nbatch * sizeof(int)));
+    PG_CHECK_HIP(hipMemcpy(dX, X, ne * sizeof(float), hipMemcpyHostToDevice));
+    PG_CHECK_HIP(hipMemcpy(dn, nlive, nbatch * sizeof(int), hipMemcpyHostToDevice));
+    PG_CHECK_HIP(hipMemset(dR, 0xFF, nr * sizeof(float)));
+    PG_CHECK_HIP(hipMemset(dG, 0xFF, (size_t)n * n * nbatch * sizeof(double)));
+    PG_CHECK_HIP(hipMemset(dm, 0xFF, nbatch * sizeof(int)));
+    PG_REQUIRE(gram_rows_i8_ok(dX, n), 1, "the i8 row Gram does not take this shape");
+    launch_gram_rows_f64<float>(0, nbatch, dX, (long)n * K, K, n, dn, dG, (long)n * n, n, nullptr, nullptr, nullptr, 1);
+    launch_chol_pivot<float>(0, nbatch, dG, (long)n * n, n, dR, (long)64 * n, dm, n, dn, 1, nullptr, kcap);
+    PG_CHECK_HIP(hipDeviceSynchronize());
+    std::vector<float> h(nr);
+    PG_CHECK_HIP(hipMemcpy(h.data(), dR, nr * sizeof(float), hipMemcpyDeviceToHost));
+    for (int b = 0; b < nbatch; ++b)
+      memcpy(R_out + (size_t)b * kcap * n, h.data() + (size_t)b * 64 * n, sizeof(float) * (size_t)kcap * n);
+    PG_CHECK_HIP(hipMemcpy(mlive_out, dm, nbatch * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(dX); (void)hipFree(dR); (void)hipFree(dG); (void)hipFree(dn); (void)hipFree(dm);
+  });
+}
+// rows_qr_kernel alone (round 6): X = [nbatch][k][len] f32 nearly orthogonal rows by decreasing norm, klive[b] = rows that exist;
+// V_out = [nbatch][k][len] orthonormal rows spanning the same space (live rows first, the rest zero), klive_out[b] = their count.
+extern "C" int pepsgpu_diag_rows_qr(const float *X, int k, int len, int nbatch, const int32_t *klive, float *V_out, int32_t *klive_out) {
+  return guarded(nullptr, [&]() {
+    PG_REQUIRE(rows_qr_ok(k, len) && nbatch >= 1 && klive, 1, "bad sizes");
+    float *dX, *dV; int *dn, *dm;
+    const size_t ne = (size_t)k * len * nbatch;
+    PG_CHECK_HIP(hipMalloc(&dX, ne * sizeof(float)));
+    PG_CHECK_HIP(hipMalloc(&dV, ne * sizeof(float)));
+    PG_CHECK_HIP(hipMalloc(&dn, nbatch * sizeof(int)));
+    PG_CHECK_HIP(hipMalloc(&dm, nbatch * sizeof(int)));
+    PG_CHECK_HIP(hipMemcpy(dX, X, ne * sizeof(float), hipMemcpyHostToDevice));
+    PG_CHECK_HIP(hipMemcpy(dn, klive, nbatch * sizeof(int), hipMemcpyHostToDevice));
+    PG_CHECK_HIP(hipMemset(dV, 0xFF, ne * sizeof(float)));
+    PG_CHECK_HIP(hipMemset(dm, 0xFF, nbatch * sizeof(int)));
+    launch_rows_qr(0, nbatch, dX, (long)k * len, k, len, dn, dV, (long)k * len, dm, nullptr);
+    PG_CHECK_HIP(hipDeviceSynchronize());
+    PG_CHECK_HIP(hipMemcpy(V_out, dV, ne * sizeof(float), hipMemcpyDeviceToHost));
+    PG_CHECK_HIP(hipMemcpy(klive_out, dm, nbatch * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(dX); (void)hipFree(dV); (void)hipFree(dn); (void)hipFree(dm);
+  });
+}
 extern "C" int pepsgpu_diag_chol(int dtype_out, const double *G, int n, int nbatch, void *R_out) {
   return guarded(nullptr, [&]() {
     if (dtype_out == 0) diag_chol_t<float>(G, n, nbatch, R_out); else diag_chol_t<double>(G, n, nbatch, R_out);

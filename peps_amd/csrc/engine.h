@@ -21,6 +21,8 @@
 #include "gram.h"
 #include "trunc_mid.h"
 #include "mgemm_dense.h"
+#include "chol_pivot.h"
+#include "rows_qr.h"
 
 namespace pepsgpu {
 

@@ -621,6 +621,8 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     int *big_list = nullptr;    // walkers whose first factor kept more than 128 rows (+ their count behind the list)
     bool side_pending = false;  // a kernel of this site runs on the side stream
     bool two_level = false;
+    int *ortho_skip = nullptr;  // walkers whose rows of V are orthonormal to float64 accuracy already (rows_qr.h): flag < 0
+    bool pivoted = false;       // the first factor of the two-level form came from chol_pivot_kernel: at most 64 rows per walker
     DTen<T> Bt, Ut, B2;
     const int GS = std::min(m, MID_HI);
     if (mid) {
@@ -660,25 +662,39 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         g.upper_only = 1;
         g.batch_flag = hiflag;
         static const bool no_rowgram = getenv("PEPSGPU_NO_ROWGRAM") != nullptr;
+        static const bool no_two_level = getenv("PEPSGPU_NO_TWO_LEVEL") != nullptr;
         bool rowgram = false;
         if constexpr (sizeof(T) == 4) {
           if (!no_rowgram && uk % 16 == 0 && M.n % 4 == 0 && m <= 256) {   // streaming wave-per-block kernel (gram.h)
+            // Round 6: the first compression as a diagonally PIVOTED factorisation stopped after pivot_cap rows (chol_pivot.h): the
+            // truncation keeps chi of the directions, the pivot order puts the dominant ones first -- no walker keeps more than 64 rows,
+            // so the second level below never sees the 65..128-row class nor the > 128-row stragglers.  PEPSGPU_PIVOT_CHOL=0: the full
+            // factorisation in the natural order (round 3-5); = 56 (default) / 64: the cap (measured, real leg at 8192 walkers: 2 371 amp/s
+            // without, 2 626 with 64 rows at two blocks per SIMD, 2 699 with 56 at three; graded subspace error of the prototype 3.7e-8 / 6e-8
+            // median against 2.1e-7 of the unpivoted factor).
+            static const int pivot_cap = getenv("PEPSGPU_PIVOT_CHOL") ? atoi(getenv("PEPSGPU_PIVOT_CHOL")) : 56;
+            pivoted = pivot_cap > 0 && fused_mid_ran && GS > 128 && !no_two_level && gram_rows_i8_ok(M.p, m) &&
+                      std::min(chi_, std::min(m, uk)) + 24 <= std::max(48, std::min(64, pivot_cap));
             launch_gram_rows_f64<T>(stream_, nw_, (const T *)M.p, M.n, uk, m, (const int *)nhi, Gm, (long)GS * GS, GS,
-                                    (const int *)hiflag, tg_flop_counter, tg_byte_counter);
+                                    (const int *)hiflag, tg_flop_counter, tg_byte_counter, pivoted ? 1 : 0);
             rowgram = true;
+            if (pivoted)
+              launch_chol_pivot<T>(stream_, nw_, (const double *)Gm, (long)GS * GS, GS, Bt.p, Bt.n, mB, GS, (const int *)nhi, 1, (const int *)hiflag,
+                                   pivot_cap);
           }
         }
         if (!rowgram) tgemm_launch<T, T, double, double>(stream_, g, M.p, M.p, Gm);
-        const size_t smem = chol_smem_bytes(GS);
-        allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
-        launch_chol_upper<T>(stream_, nw_, Gm, (long)GS * GS, GS, Bt.p, Bt.n, mB, 0, GS, (const int *)nhi, 1, (const int *)hiflag);
+        if (!pivoted) {
+          const size_t smem = chol_smem_bytes(GS);
+          allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
+          launch_chol_upper<T>(stream_, nw_, Gm, (long)GS * GS, GS, Bt.p, Bt.n, mB, 0, GS, (const int *)nhi, 1, (const int *)hiflag);
+        }
         arena_.free(Gm);
         // Second level (walkers with more than 128 live rows of M whose factor B kept at most 128 rows -- the usual case: the
         // truncation input of a real PEPS is of numerical rank 60-100): the rows of B are as long as M has live rows (up to
         // 256), so the same compression is applied once more, B2^T B2 = B B^T (r x r, LDS resident: the fused kernel with B in
         // the place of M), and the Jacobi runs on the r x r factor B2 (rows <= 128 long: the sixteen-lanes-per-row tournament at
         // its fast size).  Rotated rows of B2 = sigma_k w_k^T (w: left singular vectors of B); sigma_k u_k^T = w_k^T B.
-        static const bool no_two_level = getenv("PEPSGPU_NO_TWO_LEVEL") != nullptr;
         if constexpr (sizeof(T) == 4) {
           if (fused_mid_ran && GS > 128 && !no_two_level) {
             two_level = true;
@@ -1014,16 +1030,18 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
             // walkers that need it, usually empty)
             // ... on the side stream: the few blocks run beside the launches below (which touch other walkers) instead of holding
             // the whole device for ~0.8 ms; joined before the rows of B are selected
-            PG_CHECK_HIP(hipEventRecord(ev_fork_, stream_));
-            PG_CHECK_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
-            hipLaunchKernelGGL(jacobi_rows_reg256_list_kernel, dim3(std::min(nw_, 128)), dim3(512), 0, side_stream_, (float *)Bt.p, Bt.n, GS, GS,
-                               GS, 40, sweeps_, (const int *)rowsA, 1, 128, (const int *)big_list, (const int *)(big_list + nw_));
-            PG_CHECK_HIP(hipEventRecord(ev_join_, side_stream_));
-            side_pending = true;
+            if (!pivoted) {      // (a pivoted first factor keeps at most 64 rows: the list is empty by construction)
+              PG_CHECK_HIP(hipEventRecord(ev_fork_, stream_));
+              PG_CHECK_HIP(hipStreamWaitEvent(side_stream_, ev_fork_, 0));
+              hipLaunchKernelGGL(jacobi_rows_reg256_list_kernel, dim3(std::min(nw_, 128)), dim3(512), 0, side_stream_, (float *)Bt.p, Bt.n, GS, GS,
+                                 GS, 40, sweeps_, (const int *)rowsA, 1, 128, (const int *)big_list, (const int *)(big_list + nw_));
+              PG_CHECK_HIP(hipEventRecord(ev_join_, side_stream_));
+              side_pending = true;
+            }
             // (size classes by row length -- <2,4> for r <= 64, <3,5>, <3,6>, <4,8> -- were measured in round 3: 533 -> 576 ms per
             // step of 4096 dense walkers; the tournament is bound by its exchange / reduction latency, not by the FMAs of a pair)
             launch_jacobi_grp<2, 8>(stream_, nw_, (float *)B2.p, B2.n, 128, 128, 128, 40, sweeps_, (const int *)mB2, 1, 0);
-            launch_jacobi_grp<4, 8>(stream_, nw_, (float *)B2.p, B2.n, 128, 128, 128, 40, sweeps_, (const int *)mB2, 1, 64);
+            if (!pivoted) launch_jacobi_grp<4, 8>(stream_, nw_, (float *)B2.p, B2.n, 128, 128, 128, 40, sweeps_, (const int *)mB2, 1, 64);
           } else {
             // rows of B up to 256 long (sixteen columns per lane); more than 128 live rows of B: the 256 x 256 register kernel
             launch_jacobi_grp<2, 16>(stream_, nw_, (float *)Bt.p, Bt.n, GS, GS, GS, 40, sweeps_, (const int *)mB, 1, 0);
@@ -1129,21 +1147,37 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         tgemm_launch<T, T, T, double>(stream_, g, Ut.p, M.p, Vp.p);   // f64 accumulation: small sigma_q are differences
         prof_end();
       }
-      {
-        const size_t need = sizeof(T) * (size_t)k * (uk | 1);
-        const int use_lds = need <= JACOBI_LDS_MAX;
-        if (use_lds) allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), need);
-        prof_begin(PROF_JACOBI, 0.0, 0.0);
-        launch_jacobi(Vp.p, Vp.n, k, uk, use_lds, need, kB, 1);      // walkers off the route have kB = 0 rows
+      // Round 6: only the span of the k rows leaves the site, so instead of the polishing Jacobi + select_rows (+ the Newton-Schulz step of
+      // precise sites) the rows are made orthonormal in float64 in one launch (rows_qr.h: Cholesky-QR of the unit-scaled rows in their
+      // order, i.e. Gram-Schmidt from the dominant direction down; live count by the same floor).  PEPSGPU_ROWS_QR=0: rounds 3-5.
+      bool qr_done = false;
+      if constexpr (sizeof(T) == 4) {
+        static const int rows_qr = getenv("PEPSGPU_ROWS_QR") ? atoi(getenv("PEPSGPU_ROWS_QR")) : 1;
+        if (rows_qr && kn[i] && rows_qr_ok(k, uk)) {
+          prof_begin(PROF_SELECT, 0.0, 0.0);
+          launch_rows_qr(stream_, nw_, (const float *)Vp.p, Vp.n, k, uk, (const int *)kB, (float *)V.p, V.n, kn[i], (const int *)midflag);
+          prof_end();
+          qr_done = true;
+        }
+      }
+      if (!qr_done) {
+        {
+          const size_t need = sizeof(T) * (size_t)k * (uk | 1);
+          const int use_lds = need <= JACOBI_LDS_MAX;
+          if (use_lds) allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), need);
+          prof_begin(PROF_JACOBI, 0.0, 0.0);
+          launch_jacobi(Vp.p, Vp.n, k, uk, use_lds, need, kB, 1);      // walkers off the route have kB = 0 rows
+          prof_end();
+        }
+        prof_begin(PROF_SELECT, 0.0, 0.0);   // normalise, count the live rows; the truncation rule was applied on B already
+        hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)Vp.p, Vp.n, k, uk, uk, k, V.p,
+                           V.n, (T *)nullptr, 0L, (const int *)kB, 1, kn[i], 0.0, 0, (double *)nullptr, (const int *)midflag, 1);
+        PG_CHECK_HIP(hipGetLastError());
         prof_end();
       }
-      prof_begin(PROF_SELECT, 0.0, 0.0);   // normalise, count the live rows; the truncation rule was applied on B already
-      hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)Vp.p, Vp.n, k, uk, uk, k, V.p,
-                         V.n, (T *)nullptr, 0L, (const int *)kB, 1, kn[i], 0.0, 0, (double *)nullptr, (const int *)midflag, 1);
-      PG_CHECK_HIP(hipGetLastError());
-      prof_end();
       free_ten(Bt); free_ten(Ut); free_ten(Vp);
-      arena_.free(midflag); arena_.free(nmid); arena_.free(kB);
+      if (qr_done) ortho_skip = midflag; else arena_.free(midflag);     // (the walkers rows_qr took are orthonormal already)
+      arena_.free(nmid); arena_.free(kB);
       arena_.free(mB);
     } else {
       prof_end();
@@ -1155,11 +1189,13 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       if (ortho && precise_site && k >= 2 && k <= 64 && osm <= 96 * 1024) {
         allow_dynamic_lds(reinterpret_cast<const void *>(&ortho_rows_kernel), osm);
         prof_begin(PROF_SELECT, 0.0, 0.0);
-        hipLaunchKernelGGL(ortho_rows_kernel, dim3(nw_), dim3(256), osm, stream_, (float *)V.p, V.n, k, uk, (const int *)kn[i], uk + 1);
+        hipLaunchKernelGGL(ortho_rows_kernel, dim3(nw_), dim3(256), osm, stream_, (float *)V.p, V.n, k, uk, (const int *)kn[i], uk + 1,
+                           (const int *)ortho_skip);
         PG_CHECK_HIP(hipGetLastError());
         prof_end();
       }
     }
+    if (ortho_skip) { arena_.free(ortho_skip); ortho_skip = nullptr; }
     inject(INJ_V, V.p, V.n);
     out.t[i] = V;
     // Ynew[(l,a),q] = sum_{(u,k2)} Tt[(l,a),(u,k2)] V[q,(u,k2)]

@@ -375,24 +375,30 @@ __global__ __launch_bounds__(256, 2) void gram_rows_f64_kernel(const T *__restri
       }
 }
 
+inline bool gram_rows_i8_ok(const void *M, int nmax) {
+  // round 4: exact integer arithmetic on the i8 matrix cores (gram_i8.h, ROWS form), PEPSGPU_NO_I8_GRAM=1 for the f64 form
+  static const bool no_i8_gram = getenv("PEPSGPU_NO_I8_GRAM") != nullptr || getenv("PEPSGPU_NO_I8_ROWGRAM") != nullptr;
+  return !no_i8_gram && nmax > 128 && nmax <= 256 && (((uintptr_t)M) & 15) == 0;
+}
+
+// sym (i8 form only, gram_rows_i8_ok): both triangles of G are written
 template <typename T>
 inline void launch_gram_rows_f64(hipStream_t s, int nbatch, const T *M, long wM, int K, int nmax, const int *nrows, double *G, long wG,
-                                 int ldg, const int *run_flag, unsigned long long *flopc, unsigned long long *bytec) {
+                                 int ldg, const int *run_flag, unsigned long long *flopc, unsigned long long *bytec, int sym = 0) {
   if (nbatch <= 0 || nmax <= 0) return;
   PG_REQUIRE(nbatch <= 65535, 1, "walker batch exceeds 65535 (grid y limit)");
   PG_REQUIRE(K % 16 == 0 && wM % 4 == 0, 1, "row Gram: row length must be a multiple of 16");
   if constexpr (sizeof(T) == 4) {
-    // round 4: exact integer arithmetic on the i8 matrix cores (gram_i8.h, ROWS form), PEPSGPU_NO_I8_GRAM=1 for the f64 form
-    static const bool no_i8_gram = getenv("PEPSGPU_NO_I8_GRAM") != nullptr || getenv("PEPSGPU_NO_I8_ROWGRAM") != nullptr;
-    if (!no_i8_gram && nmax > 128 && nmax <= 256 && (((uintptr_t)M) & 15) == 0) {
+    if (gram_rows_i8_ok(M, nmax)) {
       const size_t smem8 = gram_cols_i8_smem_bytes();
       allow_dynamic_lds(reinterpret_cast<const void *>(&gram_cols_i8_kernel<T, true>), smem8);
       hipLaunchKernelGGL((gram_cols_i8_kernel<T, true>), dim3(nbatch), dim3(512), smem8, s, M, wM, nmax, K, (const int *)nullptr, 1, K, G, wG, ldg,
-                         run_flag, 1, (const int *)nullptr, nrows, flopc, bytec, 1);
+                         run_flag, 1, (const int *)nullptr, nrows, flopc, bytec, 1, sym);
       PG_CHECK_HIP(hipGetLastError());
       return;
     }
   }
+  PG_REQUIRE(!sym, 1, "row Gram: the symmetric form exists on the i8 kernel only");
   const int nb = (nmax + 63) / 64, nblk = nb * (nb + 1) / 2;
   hipLaunchKernelGGL(gram_rows_f64_kernel<T>, dim3((nblk + 3) / 4, nbatch), dim3(256), 0, s, M, wM, K, nrows, G, wG, ldg, run_flag, flopc,
                      bytec);

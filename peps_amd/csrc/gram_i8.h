@@ -64,7 +64,9 @@ __global__ __launch_bounds__(64 * NW, NW == 12 ? 3 : 2) void gram_cols_i8_kernel
                                                               const int *__restrict__ inner_live,
                                                               const int *__restrict__ nrows,
                                                               unsigned long long *__restrict__ flopc,
-                                                              unsigned long long *__restrict__ bytec, int flop_stride) {
+                                                              unsigned long long *__restrict__ bytec, int flop_stride, int sym = 0) {
+  // sym: the tiles above the diagonal are written to their mirror positions too (G symmetric in memory: the pivoted factorisation of
+  // chol_pivot.h reads whole rows)
   static_assert(sizeof(T) == 4, "f32 input");
   extern __shared__ __attribute__((aligned(16))) unsigned char gi_smem[];
   unsigned char *dig = gi_smem;
@@ -257,6 +259,17 @@ __global__ __launch_bounds__(64 * NW, NW == 12 ? 3 : 2) void gram_cols_i8_kernel
         const int i = 16 * Tl::x(t) + 4 * g4 + r, jj = 16 * Tl::c(t) + c16;
         if (i < n && jj < n) G[(long)i * ldg + jj] = acc[t][r];
       }
+    if (sym) {      // a lane's four values are consecutive in the mirrored row: 32-byte runs, four lanes fill a 128-byte line
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (Tl::x(t) != Tl::c(t)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * Tl::x(t) + 4 * g4 + r, jj = 16 * Tl::c(t) + c16;
+            if (i < n && jj < n) G[(long)jj * ldg + i] = acc[t][r];
+          }
+        }
+    }
   };
   switch (wave) {      // (every branch executes the same number of barriers)
     case 0: run(std::integral_constant<int, 0>{}); break;

@@ -2032,9 +2032,10 @@ __global__ __launch_bounds__(256) void max_over_walkers_kernel(const int *const 
 // much, which enters <S|Psi> at FIRST order and -- on a state whose tensors repeat from site to site -- with the same sign
 // at every site.  After the step the deviation is its square (1e-12), what remains is the storage rounding of V itself.
 __global__ __launch_bounds__(256) void ortho_rows_kernel(float *__restrict__ Vg, long wV, int k, int len,
-                                                         const int *__restrict__ klive, int ld) {
+                                                         const int *__restrict__ klive, int ld, const int *__restrict__ skip_flag = nullptr) {
   extern __shared__ double or_smem[];
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (skip_flag && skip_flag[b] < 0) return;       // made orthonormal by rows_qr_kernel already
   const int kl = klive ? max(0, min(k, klive[b])) : k;
   if (kl <= 0) return;
   double *sC = or_smem;                                   // [kl][kl]

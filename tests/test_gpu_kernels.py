@@ -734,3 +734,81 @@ print("RESULT " + json.dumps(out))
         err0, lives0 = res["left_looking"][key]
         assert all(abs(a - b) <= 1 for a, b in zip(lives, lives0)), (key, lives, lives0)
         assert all(l <= min(int(rank) + 2, int(n)) for l in lives), (key, lives)
+
+
+@pytest.mark.parametrize("n,K,rank,kcap", [(256, 256, 256, 64), (224, 256, 40, 64), (200, 128, 70, 56), (256, 256, 256, 48), (130, 64, 20, 64)])
+def test_pivoted_cholesky_first_compression(n, K, rank, kcap):
+    """chol_pivot_kernel behind the i8 row Gram with both triangles (round 6, the first compression of the dense truncation route):
+    rows in pivot order with decreasing diagonal; B^T B = X X^T exactly (f32 rounding) when the numerical rank fits the cap, and
+    otherwise the residual is a Schur complement whose diagonal sits below the last pivot; the span of the rows holds the dominant
+    left singular vectors of X in the graded sense || (I - Q Q^T) U_k s_k || <= 3e-6 s_1 for the first 32 directions (the spectrum of a
+    truncation input: five decades over the first 32, another until 64)."""
+    capi = _capi()
+    rng = np.random.default_rng(n + rank)
+    nb = 3
+    U, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    V, _ = np.linalg.qr(rng.standard_normal((K, min(K, n))))
+    r = min(rank, K, n)
+    s = np.zeros(min(K, n))
+    s[:r] = np.concatenate([np.logspace(0, -5, 32), np.logspace(-5, -6, 32)[1:], np.logspace(-6, -6.9, max(r - 63, 1))])[:r]
+    X = np.stack([((U[:, :len(s)] * s) @ V.T) * (1 + 0.1 * b) for b in range(nb)]).astype(np.float32)
+    nlive = np.array([n, n - 3, n], dtype=np.int32)
+    R, ml = capi.diag_chol_pivot(X, nlive, kcap)
+    for b in range(nb):
+        nl = int(nlive[b])
+        Xb = X[b, :nl].astype(np.float64)
+        G = Xb @ Xb.T
+        sc = np.max(np.diag(G))
+        assert 0 < ml[b] <= kcap
+        B = R[b, :ml[b]].astype(np.float64)
+        assert np.all(np.isfinite(B))
+        assert np.all(B[:, nl:] == 0)
+        piv = np.max(np.abs(B), axis=1)      # a row's largest entry is its pivot (the diagonal of the permuted factor)
+        B = B[:, :nl]
+        res = G / sc - B.T @ B
+        if r + 8 <= kcap:
+            assert np.max(np.abs(res)) < 3e-6
+            assert abs(int(ml[b]) - r) <= 4, (ml[b], r)
+        else:
+            assert ml[b] >= kcap - 4
+            assert np.max(np.diag(res)) <= np.min(piv[max(0, ml[b] - 8):ml[b]]) ** 2 * 16 + 3e-7       # what is left sits at the level of the last pivots taken
+        Us, ss, _ = np.linalg.svd(Xb, full_matrices=False)
+        k = min(32, r)
+        Q, _ = np.linalg.qr(B.T)
+        lost = Us[:, :k] * ss[:k] - Q @ (Q.T @ (Us[:, :k] * ss[:k]))
+        assert np.linalg.norm(lost, 2) / ss[0] < 3e-6, np.linalg.norm(lost, 2) / ss[0]
+
+
+@pytest.mark.parametrize("k,ln", [(32, 256), (24, 144), (32, 64), (7, 36), (1, 256)])
+def test_rows_qr_orthonormal_span(k, ln):
+    """rows_qr_kernel (round 6): rows sigma_q v_q^T (five decades) contaminated by the dominant directions at 1e-7 sigma_1 (what
+    V' = U^T M looks like) come out orthonormal to f32 storage accuracy and span the same space; a row below the liveness floor
+    (2 * 8 eps32 |X|_F) or linearly dependent on the rows before it is dropped, the live rows come first, the rest of V is zero."""
+    capi = _capi()
+    rng = np.random.default_rng(k * 1000 + ln)
+    nb = 4
+    Q, _ = np.linalg.qr(rng.standard_normal((ln, min(ln, k + 8))))
+    s = np.logspace(0, -5, k) if k > 1 else np.array([1.0])
+    X = np.zeros((nb, k, ln))
+    for b in range(nb):
+        R = Q[:, :k].T * s[:, None]
+        R = R + 1e-7 * rng.standard_normal((k, 1)) * Q[:, 0][None, :] + 1e-7 * rng.standard_normal((k, 1)) * Q[:, min(1, k - 1)][None, :]
+        X[b] = R * (1.0 + b)
+    klive = np.array([k, k, max(1, k - 2), k], dtype=np.int32)
+    if k >= 4:
+        X[1, k - 1] = X[1, 0] * 1e-3            # a dependent row: dropped
+        X[3, k - 1] *= 1e-3 / 5                 # below the floor (2e-6 |X|_F): dropped
+    V, kl = capi.diag_rows_qr(X, klive)
+    X32 = X.astype(np.float32).astype(np.float64)
+    for b in range(nb):
+        n_in = int(klive[b])
+        expect = n_in - (1 if (k >= 4 and b in (1, 3)) else 0)
+        assert kl[b] == expect, (b, kl[b], expect)
+        Vb = V[b, :kl[b]].astype(np.float64)
+        assert np.all(V[b, kl[b]:] == 0)
+        assert np.max(np.abs(Vb @ Vb.T - np.eye(kl[b]))) < 5e-7
+        # same span: every kept input row is reproduced by its projection, relative to its own norm (the dropped ones: excluded)
+        rows = [a for a in range(n_in) if not (k >= 4 and b in (1, 3) and a == k - 1)]
+        for a in rows:
+            x = X32[b, a]
+            assert np.linalg.norm(x - Vb.T @ (Vb @ x)) < 2e-6 * np.linalg.norm(x) + 2e-7 * np.linalg.norm(X32[b, 0]), (b, a)
