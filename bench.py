@@ -61,10 +61,10 @@ def parse():
                          "reference (profiling runs of the real_rank leg)")
     ap.add_argument("--no-full-rank", action="store_true", help="skip the second leg on a state of full rank")
     ap.add_argument("--full-rank-walkers", type=int, default=8192)
-    ap.add_argument("--full-rank-steps", type=int, default=2)
+    ap.add_argument("--full-rank-steps", type=int, default=5)
     ap.add_argument("--no-real-rank", action="store_true", help="skip the third leg on the tiled optimised state of the reference")
-    ap.add_argument("--real-rank-walkers", type=int, default=8192)
-    ap.add_argument("--real-rank-steps", type=int, default=2)
+    ap.add_argument("--real-rank-walkers", type=int, default=12288)
+    ap.add_argument("--real-rank-steps", type=int, default=5)
     ap.add_argument("--no-sweeps", action="store_true", help="skip the MC sweeps/s and VMC samples/s measurement")
     ap.add_argument("--sweep-walkers", type=int, default=16384)
     ap.add_argument("--real-sweep-walkers", type=int, default=2048, help="walkers of the sweep / VMC-sample rates on the real_rank leg")

@@ -418,7 +418,9 @@ extern "C" int pepsgpu_diag_tgemm_chain(const int *dims, const int32_t *live, in
     mp.mapK[1] = 2; mp.mapK[2] = 4;
     mp.mapJ[1] = 1; mp.mapJ[2] = 5;
     const char *f64_s = getenv("PEPSGPU_DIAG_CHAIN_F64");      // (read per call) 1: the float64-accumulating form of both stages
-    PG_REQUIRE(tgemm_chain_launch(0, gx, gp, mp, dR, dA, dW, dP, dflag, 1, 0, f64_s && atoi(f64_s) ? 1 : 0), 1, "chain launch refused");
+    const char *tri_s = getenv("PEPSGPU_DIAG_TRI");            // (read per call) 1: R is a row-compacted triangular factor, its zero blocks are skipped
+    PG_REQUIRE(tgemm_chain_launch(0, gx, gp, mp, dR, dA, dW, dP, dflag, 1, tri_s && atoi(tri_s) ? 1 : 0, f64_s && atoi(f64_s) ? 1 : 0,
+                                  tri_s && atoi(tri_s) ? 1 : 0), 1, "chain launch refused");
     PG_CHECK_HIP(hipDeviceSynchronize());
     PG_CHECK_HIP(hipMemcpy(P_out, dP, nP * nbatch * sizeof(float), hipMemcpyDeviceToHost));
     PG_CHECK_HIP(hipMemcpy(flags_out, dflag, nbatch * sizeof(int), hipMemcpyDeviceToHost));
@@ -576,7 +578,7 @@ extern "C" int pepsgpu_diag_mgemm_dense(const float *R, const float *Tt, int m, 
         PG_CHECK_HIP(hipMemcpy(dl[q], hl[q], nbatch * sizeof(int), hipMemcpyHostToDevice));
       }
     launch_mgemm_dense(0, nbatch, dR, (long)m * la, dT, (long)la * uk, dM, (long)m * uk, m, la, a_dim, u_dim, k2_dim, tt_u_inner, dl[0], 1, dl[1],
-                       dl[2], nullptr, nullptr);
+                       dl[2], nullptr, nullptr, getenv("PEPSGPU_DIAG_TRI") && atoi(getenv("PEPSGPU_DIAG_TRI")) ? 1 : 0);
     PG_CHECK_HIP(hipDeviceSynchronize());
     PG_CHECK_HIP(hipMemcpy(M_out, dM, (size_t)m * uk * nbatch * sizeof(float), hipMemcpyDeviceToHost));
     (void)hipFree(dR); (void)hipFree(dT); (void)hipFree(dM);

@@ -243,6 +243,11 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
   std::vector<DTen<T>> R(N);
   std::vector<int *> mdyn(N, nullptr);     // live rows of R[i] = mdyn[i][w] * mmul[i] (nullptr: all rows)
   std::vector<int> mmul(N, 1);
+  // R[i] is a Cholesky factor with compacted rows (row j zero before column j): the contractions that read it skip its zero blocks
+  // (round 6; PEPSGPU_TRI=0: off).  Set where R[i] comes out of the Gram / Cholesky branch below (every kernel of it keeps the column
+  // order), not where a walker may keep its rows of P.
+  static const bool use_tri = getenv("PEPSGPU_TRI") == nullptr || atoi(getenv("PEPSGPU_TRI")) != 0;
+  std::vector<char> R_tri(N, 0);
   R[0] = ones3();
   for (int i = 0; i + 1 < N; ++i) {
     int r, c, dd[4], st[4];
@@ -292,7 +297,8 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           mp.mapJ[1] = 1; mp.mapJ[2] = 5;      // J2 = (m, a2): m = I1[1], a2 = J1[2]
           prof_begin(PROF_CHAIN, flx + flp, flx + flp);
           chained = tgemm_chain_launch(stream_, gx, g2, mp, (const float *)R[i].p, (const float *)A.p,
-                                       (const float *)sel_base(ss), (float *)P.p, chain_flag, chain_chunks, hint_dense_carry(in, i));
+                                       (const float *)sel_base(ss), (float *)P.p, chain_flag, chain_chunks, hint_dense_carry(in, i), 0,
+                                       R_tri[i] ? 1 : 0);
           prof_end();
           if (!chained) { arena_.free(chain_flag); chain_flag = nullptr; }
         }
@@ -436,6 +442,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       }
       mdyn[i + 1] = ml;
       mmul[i + 1] = 1;
+      R_tri[i + 1] = use_tri && ml != nullptr;
       arena_.free(G);
       free_ten(P);
     }
@@ -579,7 +586,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         if (dense_site && !no_mgd && !(acc64 & 4) && m > 128 && mgemm_dense_ok(m, la, a, u, k2, R[i].n, Tt.n, R[i].p, Tt.p)) {
           launch_mgemm_dense(stream_, nw_, (const float *)R[i].p, R[i].n, (const float *)Tt.p, Tt.n, (float *)M.p, M.n, m, la, a, u, k2,
                              tsw ? 1 : 0, (const int *)mdyn[i], mmul[i], (const int *)clive[i], (const int *)kn[i + 1], tg_flop_counter,
-                             tg_byte_counter);
+                             tg_byte_counter, R_tri[i] ? 1 : 0);
           mg_done = true;
         }
       }

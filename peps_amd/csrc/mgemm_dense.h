@@ -25,7 +25,9 @@ __global__ __launch_bounds__(512, 2) void mgemm_dense_kernel(const float *__rest
                                                              int k2_dim, int tt_u_inner, const int *__restrict__ m_live, int m_mul,
                                                              const int *__restrict__ a_live, const int *__restrict__ k2_live,
                                                              unsigned long long *__restrict__ flopc, unsigned long long *__restrict__ bytec,
-                                                             int flop_stride) {
+                                                             int flop_stride, int tri) {
+  // tri (round 6): R is a row-compacted upper-triangular factor (row i is zero before column i): the 32-row blocks that start at or
+  // beyond the end of a k-chunk hold zeros there and are not multiplied -- 40 % of the MFMAs at 220 live rows
   extern __shared__ float mg_smem[];
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -35,7 +37,13 @@ __global__ __launch_bounds__(512, 2) void mgemm_dense_kernel(const float *__rest
   const int uk = u_dim * k2_dim;
   if (ml <= 0) return;
   if (flopc && tid == 0 && b % flop_stride == 0) {
-    atomicAdd(flopc, 2ull * flop_stride * ml * (unsigned long long)(la / a_dim * al) * (unsigned long long)(u_dim * kl));
+    // (executed: with the triangular form the row blocks below a k-chunk are skipped -- counted as the trapezoid they cover)
+    unsigned long long rows_k = (unsigned long long)ml * (la / a_dim * al);
+    if (tri) {
+      rows_k = 0;
+      for (int ch = 0; ch < la / MG_BK; ++ch) rows_k += (unsigned long long)min(ml, ((ch * MG_BK + MG_BK + 31) >> 5) << 5) * MG_BK * al / a_dim;
+    }
+    atomicAdd(flopc, 2ull * flop_stride * rows_k * (unsigned long long)(u_dim * kl));
     if (bytec) atomicAdd(bytec, 4ull * flop_stride * ((unsigned long long)ml * la + (unsigned long long)la * uk + (unsigned long long)ml * uk));
   }
   const float *R = Rg + (long)b * wR;
@@ -85,14 +93,14 @@ __global__ __launch_bounds__(512, 2) void mgemm_dense_kernel(const float *__rest
     }
   };
   const int half = lane >> 5, l31 = lane & 31;
-  auto mma = [&](int buf) {
+  auto mma = [&](int buf, int tmax) {
     const float *pA = sA + buf * MG_BK * MG_PITCH, *pB = sB + buf * MG_BK * MG_PITCH;
 #pragma unroll
     for (int kk = 0; kk < MG_BK; kk += 2) {
       const float bb = pB[(kk + half) * MG_PITCH + 32 * wave + l31];
 #pragma unroll
       for (int t = 0; t < 8; ++t)
-        if (t < nI) {
+        if (t < tmax) {
           const float a = pA[(kk + half) * MG_PITCH + 32 * t + l31];
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[t], 0, 0, 0);
         }
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void mgemm_dense_kernel(const float *__rest
   __syncthreads();
   for (int ch = 0; ch < nch; ++ch) {
     if (ch + 1 < nch) issue(ch + 1);
-    if (wave_on) mma(ch & 1);
+    if (wave_on) mma(ch & 1, tri ? min(nI, (ch * MG_BK + MG_BK + 31) >> 5) : nI);
     if (ch + 1 < nch) lay((ch + 1) & 1);
     __syncthreads();
   }
@@ -130,11 +138,11 @@ inline bool mgemm_dense_ok(int m, int la, int a_dim, int u_dim, int k2_dim, long
 
 inline void launch_mgemm_dense(hipStream_t s, int nbatch, const float *R, long wR, const float *Tt, long wT, float *M, long wM, int m, int la,
                                int a_dim, int u_dim, int k2_dim, int tt_u_inner, const int *m_live, int m_mul, const int *a_live,
-                               const int *k2_live, unsigned long long *flopc, unsigned long long *bytec) {
+                               const int *k2_live, unsigned long long *flopc, unsigned long long *bytec, int tri = 0) {
   const size_t smem = mgemm_dense_smem_bytes();
   allow_dynamic_lds(reinterpret_cast<const void *>(&mgemm_dense_kernel), smem);
   hipLaunchKernelGGL(mgemm_dense_kernel, dim3(nbatch), dim3(512), smem, s, R, wR, Tt, wT, M, wM, m, la, a_dim, u_dim, k2_dim, tt_u_inner, m_live,
-                     m_mul, a_live, k2_live, flopc, bytec, nbatch >= 256 ? 64 : 1);
+                     m_mul, a_live, k2_live, flopc, bytec, nbatch >= 256 ? 64 : 1, tri);
   PG_CHECK_HIP(hipGetLastError());
 }
 

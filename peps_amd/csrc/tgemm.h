@@ -702,170 +702,6 @@ __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *
   if (sumsq) *sumsq += ss;
 }
 
-// The same tile loop with a wave owning TWO neighbouring J tiles (a 32 x 64 block of C) at once (round 5): one A load feeds two MFMA
-// chains, so the chain of dependent operand round trips of a block -- what bounds the chained kernel on the low-rank headline state
-// (one L2 round trip per k-round, two tiles per wave one after the other) -- is half as long for stage 2 (A = the site tensor from
-// L2, B = the intermediate in LDS).  Costs 24 more registers (five blocks per CU instead of six).
-template <bool AVEC, bool BVEC>
-__device__ __forceinline__ void tg_direct_body_j2(const TGemmDesc &d, const float *__restrict__ A, const float *__restrict__ B,
-                                               float *__restrict__ C, const int Itot, const int Jtot, const int K2s,
-                                               int (*offCi_s)[32], const int tile0, const int tile_step,
-                                               const float scale = 1.f, double *__restrict__ sumsq = nullptr) {
-  // scale: multiplies alpha (per-entry scale of an operand that was left unnormalised); sumsq (optional): += squares of the
-  // values this lane stores.
-  // Instruction budget (SQ counters, round 2: 36 VALU instructions per MFMA in the chained kernel, the launches were
-  // bound by VALU issue, not by memory): no integer division per lane (float-reciprocal split of the tile's row / column
-  // index), K walked with uniform counters, loads unconditional at clamped addresses (rows and columns that do not exist
-  // read row / column 0 and are never stored; k beyond the live extent is zeroed in the last round of a k2 run only),
-  // the loads of round r+1 issued before and consumed after the MFMAs of round r.
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ntj = (Jtot + 31) >> 5;
-  const float alpha = (float)d.alpha * scale;
-  double ss = 0.0;     // (f64: the norm it feeds replaces an f64 reduction over the stored tensor)
-  const int half = lane >> 5, l31 = lane & 31;
-  const int K2 = d.K[2], K1 = d.K[1];
-  const int nr8 = (K2 + 7) >> 3, nrounds = d.K[0] * K1 * nr8;
-  const unsigned sA2b = 4u * d.sAk[2], sB2b = 4u * d.sBk[2];
-  const float rI2 = __builtin_amdgcn_rcpf((float)d.I[2]), rI1 = __builtin_amdgcn_rcpf((float)d.I[1]);
-  const float rJ2 = __builtin_amdgcn_rcpf((float)d.J[2]), rJ1 = __builtin_amdgcn_rcpf((float)d.J[1]);
-  const int kh = 4 * half;
-  const bool accumulate = d.accumulate != 0;
-
-  const int ntjp = (ntj + 1) >> 1, ntp = ((Itot + 31) >> 5) * ntjp;      // pairs of neighbouring J tiles
-  for (int t = tile0 + wave; t < ntp; t += tile_step) {
-    const int ti = t / ntjp, tjp = t - ti * ntjp;
-    const int i = ti * 32 + l31;
-    unsigned oab, obb[2];    // byte offsets of this lane's A row / B columns (0 when they do not exist)
-    int ocj[2];              // element offset of column j in C, -1: not stored; TG_ZERO_ROW set: stored as zero
-    {
-      int i2, i1;
-      const int qi = tg_fdivmod(i, d.I[2], rI2, i2);
-      const int i0 = tg_fdivmod(qi, d.I[1], rI1, i1);
-      const bool iv = i < Itot;
-      const bool iz = i2 >= d.Imask[2] || i1 >= d.Imask[1] || i0 >= d.Imask[0];
-      oab = (iv && !iz) ? 4u * (unsigned)(i0 * d.sAi[0] + i1 * d.sAi[1] + i2 * d.sAi[2]) : 0u;
-      const int oci = i0 * d.sCi[0] + i1 * d.sCi[1] + i2 * d.sCi[2];
-      if (half == 0) offCi_s[wave][l31] = iv ? (oci | (iz ? TG_ZERO_ROW : 0)) : -1;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int j = (2 * tjp + q) * 32 + l31;
-        int j2, j1;
-        const int qj = tg_fdivmod(j, d.J[2], rJ2, j2);
-        const int j0 = tg_fdivmod(qj, d.J[1], rJ1, j1);
-        const bool jv = j < Jtot;
-        const bool jz = j2 >= d.Jmask[2] || j1 >= d.Jmask[1] || j0 >= d.Jmask[0];
-        obb[q] = (jv && !jz) ? 4u * (unsigned)(j0 * d.sBj[0] + j1 * d.sBj[1] + j2 * d.sBj[2]) : 0u;
-        ocj[q] = jv ? ((j0 * d.sCj[0] + j1 * d.sCj[1] + j2 * d.sCj[2]) | (jz ? TG_ZERO_ROW : 0)) : -1;
-      }
-    }
-    tg_f32x16 acc[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-
-    int k0 = 0, k1 = 0, r8 = 0;          // uniform position of the round being loaded: (k0, k1), k2 = 8 r8 + 4 half + (0..3)
-    unsigned kab = 0, kbb = 0;           // byte offsets of (k0, k1) in A and B
-    auto advance = [&]() {
-      if (++r8 == nr8) {
-        r8 = 0;
-        if (++k1 == K1) { k1 = 0; ++k0; }
-        kab = 4u * (unsigned)(k0 * d.sAk[0] + k1 * d.sAk[1]);
-        kbb = 4u * (unsigned)(k0 * d.sBk[0] + k1 * d.sBk[1]);
-      }
-    };
-    auto load_raw = [&](float (&av)[4], float (&bv)[2][4]) {
-      const int kq = 8 * r8 + kh;
-      if constexpr (AVEC) {
-        const float4 v = tg_ldf4(A, oab + kab + 4u * (unsigned)min(kq, K2s - 4));
-        av[0] = v.x; av[1] = v.y; av[2] = v.z; av[3] = v.w;
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) av[q] = tg_ldf(A, oab + kab + (unsigned)min(kq + q, K2 - 1) * sA2b);
-      }
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        if constexpr (BVEC) {
-          const float4 v = tg_ldf4(B, obb[c] + kbb + 4u * (unsigned)min(kq, K2s - 4));
-          bv[c][0] = v.x; bv[c][1] = v.y; bv[c][2] = v.z; bv[c][3] = v.w;
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) bv[c][q] = tg_ldf(B, obb[c] + kbb + (unsigned)min(kq + q, K2 - 1) * sB2b);
-        }
-      }
-    };
-    auto mask_k = [&](const int r8m, float (&av)[4], float (&bv)[2][4]) {   // only the last round of a k2 run can be partial
-      if (8 * r8m + 8 > K2) {
-        const int kq = 8 * r8m + kh;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const bool ok = kq + q < K2;
-          av[q] = ok ? av[q] : 0.f;       // (a zero A column kills the product whatever B holds)
-        }
-      }
-    };
-    float a0[4], b0[2][4], a1[4], b1[2][4];
-    auto mfma4 = [&](const float (&av)[4], const float (&bv)[2][4]) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[0][q], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[1][q], acc[1], 0, 0, 0);
-      }
-    };
-    if (nrounds > 0) {
-      load_raw(a0, b0);
-      mask_k(0, a0, b0);
-      int rd = 0;
-      // steady state without a conditional around the loads (the wait counters stay exact: the loads of the next round
-      // are in flight while the MFMAs of this one issue)
-      for (; rd + 2 < nrounds; rd += 2) {
-        advance();
-        const int r8b = r8;
-        load_raw(a1, b1);
-        mfma4(a0, b0);
-        mask_k(r8b, a1, b1);
-        advance();
-        const int r8a = r8;
-        load_raw(a0, b0);
-        mfma4(a1, b1);
-        mask_k(r8a, a0, b0);
-      }
-      if (rd + 1 < nrounds) {     // two rounds left
-        advance();
-        load_raw(a1, b1);
-        mfma4(a0, b0);
-        mask_k(r8, a1, b1);
-        mfma4(a1, b1);
-      } else {
-        mfma4(a0, b0);
-      }
-    }
-    // accumulator r of this lane = row 8 (r / 4) + 4 half + (r % 4), column l31 of the tile
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const bool jzero = (ocj[c] & TG_ZERO_ROW) != 0;
-      const int ocj_e = ocj[c] & ~TG_ZERO_ROW;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int4 o4 = *reinterpret_cast<const int4 *>(&offCi_s[wave][8 * g + kh]);
-        const int oi4[4] = {o4.x, o4.y, o4.z, o4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int oi = oi4[e];
-          if (oi >= 0 && ocj[c] >= 0) {
-            float *p = C + ((oi & ~TG_ZERO_ROW) + ocj_e);
-            float v = ((oi & TG_ZERO_ROW) || jzero) ? 0.f : acc[c][4 * g + e] * alpha;
-            if (accumulate) v += *p;
-            *p = v;
-            if (sumsq) ss = fma((double)v, (double)v, ss);
-          }
-        }
-      }
-    }
-  }
-  if (sumsq) *sumsq += ss;
-}
-
 // ---------------------------------------------------------------------------------------------
 // The same tile loop with FLOAT64 ACCUMULATION on the f64 matrix cores (round 5): f32 operands (global memory or LDS) are
 // converted on the way into v_mfma_f64_16x16x4_f64, the f32 result is rounded once at the store.  For the contractions of the
@@ -1022,161 +858,6 @@ __device__ __forceinline__ void tg_direct_body_f64(const TGemmDesc &d, const flo
   if (sumsq) *sumsq += ss;
 }
 
-// ---------------------------------------------------------------------------------------------
-// The f32 tile loop on 16 x 16 x 4 MFMAs (round 5; VERDICT r02-r04: "a 16 x 16 x 4 tile body selected from the live extents"): the
-// wave's 32 x 32 tile as 2 x 2 quadrants, a quadrant without a live row / column is not multiplied.  Same operand traffic and the same
-// matrix time per FULL tile as the 32 x 32 x 2 body (8 x 32 cycles against 4 x 64 per round of 8 k); what it saves is the padding
-// of extents like 80 = 2.5 tiles.  Measured on the headline: see tgemm_chain_launch (PEPSGPU_TILE16).
-typedef float tg_f32x4 __attribute__((ext_vector_type(4)));
-template <bool AVEC, bool BVEC>
-__device__ __forceinline__ void tg_direct_body_t16(const TGemmDesc &d, const float *__restrict__ A, const float *__restrict__ B,
-                                                   float *__restrict__ C, const int Itot, const int Jtot, const int K2s,
-                                                   int (*offCi_s)[32], const int tile0, const int tile_step,
-                                                   const float scale = 1.f, double *__restrict__ sumsq = nullptr) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ntj = (Jtot + 31) >> 5, ntiles = ((Itot + 31) >> 5) * ntj;
-  const float alpha = (float)d.alpha * scale;
-  double ss = 0.0;
-  const int g4 = lane >> 4, c16 = lane & 15;
-  const int K2 = d.K[2], K1 = d.K[1];
-  const int nr8 = (K2 + 7) >> 3, nrounds = d.K[0] * K1 * nr8;
-  const unsigned sA2b = 4u * d.sAk[2], sB2b = 4u * d.sBk[2];
-  const float rI2 = __builtin_amdgcn_rcpf((float)d.I[2]), rI1 = __builtin_amdgcn_rcpf((float)d.I[1]);
-  const float rJ2 = __builtin_amdgcn_rcpf((float)d.J[2]), rJ1 = __builtin_amdgcn_rcpf((float)d.J[1]);
-  const int kh = 2 * g4;
-  const bool accumulate = d.accumulate != 0;
-
-  for (int t = tile0 + wave; t < ntiles; t += tile_step) {
-    const int ti = t / ntj, tj = t - ti * ntj;
-    unsigned oab[2], obb[2];
-    int ocj[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int i = ti * 32 + 16 * q + c16, j = tj * 32 + 16 * q + c16;
-      int i2, i1, j2, j1;
-      const int qi = tg_fdivmod(i, d.I[2], rI2, i2);
-      const int i0 = tg_fdivmod(qi, d.I[1], rI1, i1);
-      const int qj = tg_fdivmod(j, d.J[2], rJ2, j2);
-      const int j0 = tg_fdivmod(qj, d.J[1], rJ1, j1);
-      const bool iv = i < Itot, jv = j < Jtot;
-      const bool iz = i2 >= d.Imask[2] || i1 >= d.Imask[1] || i0 >= d.Imask[0];
-      const bool jz = j2 >= d.Jmask[2] || j1 >= d.Jmask[1] || j0 >= d.Jmask[0];
-      oab[q] = (iv && !iz) ? 4u * (unsigned)(i0 * d.sAi[0] + i1 * d.sAi[1] + i2 * d.sAi[2]) : 0u;
-      obb[q] = (jv && !jz) ? 4u * (unsigned)(j0 * d.sBj[0] + j1 * d.sBj[1] + j2 * d.sBj[2]) : 0u;
-      const int oci = i0 * d.sCi[0] + i1 * d.sCi[1] + i2 * d.sCi[2];
-      if (g4 == q) offCi_s[wave][16 * q + c16] = iv ? (oci | (iz ? TG_ZERO_ROW : 0)) : -1;
-      ocj[q] = jv ? ((j0 * d.sCj[0] + j1 * d.sCj[1] + j2 * d.sCj[2]) | (jz ? TG_ZERO_ROW : 0)) : -1;
-    }
-    tg_f32x4 acc[2][2];
-#pragma unroll
-    for (int qa = 0; qa < 2; ++qa)
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[qa][qb][r] = 0.f;
-    // quadrants that hold no row / column of C at all are not multiplied (wave-uniform): the point of the 16-wide form
-    const bool liveA1 = ti * 32 + 16 < Itot, liveB1 = tj * 32 + 16 < Jtot;
-
-    int k0 = 0, k1 = 0, r8 = 0;
-    unsigned kab = 0, kbb = 0;
-    auto advance = [&]() {
-      if (++r8 == nr8) {
-        r8 = 0;
-        if (++k1 == K1) { k1 = 0; ++k0; }
-        kab = 4u * (unsigned)(k0 * d.sAk[0] + k1 * d.sAk[1]);
-        kbb = 4u * (unsigned)(k0 * d.sBk[0] + k1 * d.sBk[1]);
-      }
-    };
-    // av[q][e]: row quadrant q, k2 = 8 r8 + kh + e
-    auto load_raw = [&](float (&av)[2][2], float (&bv)[2][2]) {
-      const int kq = 8 * r8 + kh;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        if constexpr (AVEC) {
-          const float2 v = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(A) + (oab[q] + kab + 4u * (unsigned)min(kq, K2s - 2)));
-          av[q][0] = v.x; av[q][1] = v.y;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 2; ++e) av[q][e] = tg_ldf(A, oab[q] + kab + (unsigned)min(kq + e, K2 - 1) * sA2b);
-        }
-        if constexpr (BVEC) {
-          const float2 v = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(B) + (obb[q] + kbb + 4u * (unsigned)min(kq, K2s - 2)));
-          bv[q][0] = v.x; bv[q][1] = v.y;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 2; ++e) bv[q][e] = tg_ldf(B, obb[q] + kbb + (unsigned)min(kq + e, K2 - 1) * sB2b);
-        }
-      }
-    };
-    auto mask_k = [&](const int r8m, float (&av)[2][2], float (&bv)[2][2]) {   // only the last round of a k2 run can be partial
-      if (8 * r8m + 8 > K2) {
-        const int kq = 8 * r8m + kh;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const bool ok = kq + e < K2;
-#pragma unroll
-          for (int q = 0; q < 2; ++q) { av[q][e] = ok ? av[q][e] : 0.f; bv[q][e] = ok ? bv[q][e] : 0.f; }
-        }
-      }
-    };
-    auto mfma8 = [&](const float (&av)[2][2], const float (&bv)[2][2]) {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][e], bv[0][e], acc[0][0], 0, 0, 0);
-        if (liveB1) acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][e], bv[1][e], acc[0][1], 0, 0, 0);
-        if (liveA1) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][e], bv[0][e], acc[1][0], 0, 0, 0);
-        if (liveA1 && liveB1) acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][e], bv[1][e], acc[1][1], 0, 0, 0);
-      }
-    };
-    float a0[2][2], b0[2][2], a1[2][2], b1[2][2];
-    if (nrounds > 0) {
-      load_raw(a0, b0);
-      mask_k(0, a0, b0);
-      int rd = 0;
-      for (; rd + 2 < nrounds; rd += 2) {
-        advance();
-        const int r8b = r8;
-        load_raw(a1, b1);
-        mfma8(a0, b0);
-        mask_k(r8b, a1, b1);
-        advance();
-        const int r8a = r8;
-        load_raw(a0, b0);
-        mfma8(a1, b1);
-        mask_k(r8a, a0, b0);
-      }
-      if (rd + 1 < nrounds) {
-        advance();
-        load_raw(a1, b1);
-        mfma8(a0, b0);
-        mask_k(r8, a1, b1);
-        mfma8(a1, b1);
-      } else {
-        mfma8(a0, b0);
-      }
-    }
-    // accumulator r of quadrant (qa, qb) = row 16 qa + 4 g4 + r, column 16 qb + c16 of the tile (f32 16x16x4: four consecutive rows
-    // per lane group; the f64 form interleaves them)
-#pragma unroll
-    for (int qa = 0; qa < 2; ++qa)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int oi = offCi_s[wave][16 * qa + 4 * g4 + r];
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-          if (oi >= 0 && ocj[qb] >= 0) {
-            float *p = C + ((oi & ~TG_ZERO_ROW) + (ocj[qb] & ~TG_ZERO_ROW));
-            float v = ((oi & TG_ZERO_ROW) || (ocj[qb] & TG_ZERO_ROW)) ? 0.f : acc[qa][qb][r] * alpha;
-            if (accumulate) v += *p;
-            *p = v;
-            if (sumsq) ss = fma((double)v, (double)v, ss);
-          }
-        }
-      }
-  }
-  if (sumsq) *sumsq += ss;
-}
-
 template <bool AVEC, bool BVEC, bool ACC64 = false>
 __global__ __launch_bounds__(256, ACC64 ? 4 : 6) void tgemm_direct_kernel(TGemmDesc d, const float *__restrict__ Ag,
                                                            const float *__restrict__ Bg, float *__restrict__ Cg) {
@@ -1245,9 +926,9 @@ constexpr int TG_CHAIN_LDS_FLOATS = 6144;    // 24 KB: six blocks per CU (measur
 struct TGemmChainMap { int mapK[3] = {-1, -1, -1}, mapJ[3] = {-1, -1, -1}; };
 
 // F64: both stages accumulate in float64 on the f64 matrix cores (tg_direct_body_f64; the intermediate stays f32 in LDS)
-// S2P: stage 2 with two J tiles per wave (tg_direct_body_j2) when it has at least two
-// T16: both stages on the 16 x 16 x 4 tile body (tg_direct_body_t16)
-template <bool AVEC1, bool BVEC1, bool AVEC2, int LDSF, int MINB, bool F64 = false, bool S2P = false, bool T16 = false>
+// (two measured-and-rejected bodies of round 5 -- 16 x 16 x 4 tiles with dead quadrants skipped, two J tiles per wave in stage 2 -- were
+// removed in round 6; HISTORY.md has their numbers)
+template <bool AVEC1, bool BVEC1, bool AVEC2, int LDSF, int MINB, bool F64 = false>
 __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TGemmDesc d2, TGemmChainMap mp, const float *__restrict__ A1g,
                                                             const float *__restrict__ B1g, const float *__restrict__ A2g,
                                                             float *__restrict__ C2g, int *__restrict__ flag, int only_flagged, int allow_chunks) {
@@ -1282,7 +963,7 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TG
         if (mp.mapK[s] == 1) jsub = 3;
       }
       const int per = lds_stride[1];    // floats of C1 per value of I1[1]
-      if (!allow_chunks || d1.I[0] != 1 || d1.dynI || d2.dynI || jsub < 0 || jsub > 2 || per > LDSF || d1.Imask[1] != 0x7fffffff) {
+      if (!(allow_chunks & 1) || d1.I[0] != 1 || d1.dynI || d2.dynI || jsub < 0 || jsub > 2 || per > LDSF || d1.Imask[1] != 0x7fffffff) {
         if (threadIdx.x == 0) flag[b] = -1;
         return;
       }
@@ -1291,8 +972,9 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TG
   }
   if (threadIdx.x == 0) flag[b] = 0;
   if (I1 <= 0 || J1 <= 0 || I2 <= 0 || J2 <= 0) return;
+  const bool tri_req = (allow_chunks & 2) && chunk < d1.I[1];     // (executed flops of the triangular form: counted chunk by chunk below)
   if (d1.flopc && threadIdx.x == 0 && b % d1.flop_stride == 0) {
-    atomicAdd(d1.flopc, 2ull * d1.flop_stride * ((unsigned long long)I1 * J1 * d1.Ktot() + (unsigned long long)I2 * J2 * d2.Ktot()));
+    if (!tri_req) atomicAdd(d1.flopc, 2ull * d1.flop_stride * ((unsigned long long)I1 * J1 * d1.Ktot() + (unsigned long long)I2 * J2 * d2.Ktot()));
     if (d1.bytec)
       atomicAdd(d1.bytec, 4ull * d1.flop_stride * ((unsigned long long)I1 * d1.Ktot() + (unsigned long long)d1.Ktot() * J1 +
                                                     (unsigned long long)I2 * d2.Ktot() + (unsigned long long)I2 * J2));
@@ -1315,44 +997,50 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TG
       tg_direct_body_f64<AVEC1, BVEC1>(d1, A1g + baseA1, B1g + baseB1, s_mid, I1, J1, K2s1, offCi_s, 0, 4, in_scale);
       __syncthreads();
       tg_direct_body_f64<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC, I2, J2, K2s2, offCi_s, 0, 4);
-    } else if constexpr (T16) {
-      tg_direct_body_t16<AVEC1, BVEC1>(d1, A1g + baseA1, B1g + baseB1, s_mid, I1, J1, K2s1, offCi_s, 0, 4, in_scale);
-      __syncthreads();
-      tg_direct_body_t16<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC, I2, J2, K2s2, offCi_s, 0, 4);
     } else {
       tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1, B1g + baseB1, s_mid, I1, J1, K2s1, offCi_s, 0, 4, in_scale);
       __syncthreads();
-      if (S2P && J2 > 32) tg_direct_body_j2<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC, I2, J2, K2s2, offCi_s, 0, 4);
-      else tg_direct_body<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC, I2, J2, K2s2, offCi_s, 0, 4);
+      tg_direct_body<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC, I2, J2, K2s2, offCi_s, 0, 4);
     }
     return;
   }
   const int n1 = d1.I[1];
   const int sA1 = d1.sAi[1], sC2 = jsub == 0 ? d2.sCj[0] : jsub == 1 ? d2.sCj[1] : d2.sCj[2];
+  // Triangular A operand of stage 1 (round 6, allow_chunks & 2): the carry R[m][l][a] of a dense walker is a Cholesky factor with its
+  // rows compacted -- row m is zero in the columns (l, a) before m.  A chunk starts at row c0, so its l-blocks before c0 / a_static hold
+  // zeros only: stage 1 skips them (the A operand starts at l0) and stage 2, whose contracted index runs over (l, p), starts there too.
+  // On 220 live rows of 256 columns that is 37 % of the MFMAs of both stages.
+  int ksub = -1;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) if (mp.mapK[s] == 2) ksub = s;
+  const int L1 = d1.I[2], sAl = d1.sAi[2];
+  const int sA2l = ksub == 0 ? d2.sAk[0] : ksub == 1 ? d2.sAk[1] : d2.sAk[2];
+  const bool tri = (allow_chunks & 2) && ksub >= 0 && sAl > 0 && d1.Imask[2] == 0x7fffffff;
+  unsigned long long fl_exec = 0;
   for (int c0 = 0; c0 < n1; c0 += chunk) {
     const int cn = min(chunk, n1 - c0);
+    const int l0 = tri ? min(c0 / sAl, L1 - 1) : 0;
     d1.I[1] = cn;
+    d1.I[2] = L1 - l0;
 #pragma unroll
-    for (int s = 0; s < 3; ++s)      // (no dynamic indexing: the descriptors stay in registers)
+    for (int s = 0; s < 3; ++s) {      // (no dynamic indexing: the descriptors stay in registers)
       if (s == jsub) d2.J[s] = cn;
+      if (tri && s == ksub) d2.K[s] = L1 - l0;
+    }
+    const long oA1 = (long)c0 * sA1 + (long)l0 * sAl, oA2 = (long)l0 * sA2l;
+    if (tri_req) fl_exec += 2ull * ((unsigned long long)d1.Itot() * J1 * d1.Ktot() + (unsigned long long)I2 * d2.Jtot() * d2.Ktot());
     if (c0) __syncthreads();     // stage 2 of the chunk before has read the buffer
     if constexpr (F64) {
-      tg_direct_body_f64<AVEC1, BVEC1>(d1, A1g + baseA1 + (long)c0 * sA1, B1g + baseB1, s_mid, d1.Itot(), J1, K2s1, offCi_s, 0, 4, in_scale);
+      tg_direct_body_f64<AVEC1, BVEC1>(d1, A1g + baseA1 + oA1, B1g + baseB1, s_mid, d1.Itot(), J1, K2s1, offCi_s, 0, 4, in_scale);
       __syncthreads();
-      tg_direct_body_f64<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC + (long)c0 * sC2, I2, d2.Jtot(), K2s2, offCi_s, 0, 4);
-    } else if constexpr (T16) {
-      tg_direct_body_t16<AVEC1, BVEC1>(d1, A1g + baseA1 + (long)c0 * sA1, B1g + baseB1, s_mid, d1.Itot(), J1, K2s1, offCi_s, 0, 4, in_scale);
-      __syncthreads();
-      tg_direct_body_t16<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC + (long)c0 * sC2, I2, d2.Jtot(), K2s2, offCi_s, 0, 4);
+      tg_direct_body_f64<AVEC2, false>(d2, A2g + baseA2 + oA2, s_mid, C2g + (long)b * d2.wC + (long)c0 * sC2, I2, d2.Jtot(), K2s2, offCi_s, 0, 4);
     } else {
-      tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1 + (long)c0 * sA1, B1g + baseB1, s_mid, d1.Itot(), J1, K2s1, offCi_s, 0, 4, in_scale);
+      tg_direct_body<AVEC1, BVEC1>(d1, A1g + baseA1 + oA1, B1g + baseB1, s_mid, d1.Itot(), J1, K2s1, offCi_s, 0, 4, in_scale);
       __syncthreads();
-      if (S2P && d2.Jtot() > 32)
-        tg_direct_body_j2<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC + (long)c0 * sC2, I2, d2.Jtot(), K2s2, offCi_s, 0, 4);
-      else
-        tg_direct_body<AVEC2, false>(d2, A2g + baseA2, s_mid, C2g + (long)b * d2.wC + (long)c0 * sC2, I2, d2.Jtot(), K2s2, offCi_s, 0, 4);
+      tg_direct_body<AVEC2, false>(d2, A2g + baseA2 + oA2, s_mid, C2g + (long)b * d2.wC + (long)c0 * sC2, I2, d2.Jtot(), K2s2, offCi_s, 0, 4);
     }
   }
+  if (tri_req && d1.flopc && threadIdx.x == 0 && b % d1.flop_stride == 0) atomicAdd(d1.flopc, fl_exec * d1.flop_stride);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1465,7 +1153,7 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain3_kernel(TGemmDesc d1, T
 // no entry can be declined (every slice of the intermediate fits the buffer: the caller skips the fallback launches).
 inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemmDesc &d2_in, const TGemmChainMap &mp,
                               const float *A1, const float *B1, const float *A2, float *C2, int *flag, int allow_chunks = 0, int dense = 0,
-                              int f64acc = 0);
+                              int f64acc = 0, int tri = 0);
 
 inline int tgemm_chain3_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemmDesc &d2_in, const TGemmDesc &d3_in, const TGemmChainMap &mp,
                                const TGemmChain3Map &mp3, const float *A1, const float *B1, const float *A2, const float *B3, float *C3, int *flag,
@@ -1582,7 +1270,10 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
 }
 
 inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemmDesc &d2_in, const TGemmChainMap &mp,
-                              const float *A1, const float *B1, const float *A2, float *C2, int *flag, int allow_chunks, int dense, int f64acc) {
+                              const float *A1, const float *B1, const float *A2, float *C2, int *flag, int allow_chunks, int dense, int f64acc,
+                              int tri) {
+  // tri: the A operand of stage 1 is a row-compacted upper-triangular factor (see the chunk loop of the kernel)
+  const int akf = (allow_chunks ? 1 : 0) | (tri ? 2 : 0);
   if (!tgemm_use_mfma() || d1_in.dynK || d2_in.dynK || d1_in.nbatch != d2_in.nbatch || d1_in.nbatch <= 0) return 0;
   if (d1_in.bdivA != 1 || d1_in.bdivB != 1 || d2_in.bdivA != 1 || d2_in.bdivC != 1) return 0;
   TGemmDesc d1 = d1_in, d2 = d2_in;
@@ -1601,28 +1292,14 @@ inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemm
   // dense walker batch (hint of the caller): the intermediate is walked in chunks anyway; a 32 KB buffer holds four values of
   // the chunked sub-index = 32 full rows per stage-1 tile and eight balanced stage-2 tiles (24 KB: 24 rows, six tiles), at four
   // blocks per CU instead of six (PEPSGPU_CHAIN_DENSE_LDS = 0 / 8192 / 16384 floats)
-  static const int dense_lds = getenv("PEPSGPU_CHAIN_DENSE_LDS") ? atoi(getenv("PEPSGPU_CHAIN_DENSE_LDS")) : 8192;
-  int ldsf = (dense && allow_chunks && dense_lds >= 8192) ? (dense_lds >= 16384 ? 16384 : 8192) : TG_CHAIN_LDS_FLOATS;
+  int ldsf = (dense && allow_chunks) ? 8192 : TG_CHAIN_LDS_FLOATS;
   if (f64acc && ldsf > 8192) ldsf = 8192;       // (the float64-accumulating form is built for the two default buffer sizes)
-  // stage 2 with two J tiles per wave (tg_direct_body_j2; low-rank walker batches: the 24 KB / non-dense form), PEPSGPU_CHAIN_S2PAIR=1.
-  // MEASURED AND NOT ADOPTED (round 5, headline, 49 152 walkers, chained launches per three steps): 412 ms as is (six blocks per CU,
-  // 73-79 VGPRs), 497 ms with the paired form at five blocks per CU (96 VGPRs + 100-140 B of scratch), 546 ms at four blocks (no
-  // scratch): halving the chain of dependent operand round trips of a wave does not pay for the waves it costs -- the kernel lives
-  // on the number of blocks in flight, not on the length of one block's chain.  Kept behind the switch for the A/B.
-  static const int s2pair = getenv("PEPSGPU_CHAIN_S2PAIR") ? atoi(getenv("PEPSGPU_CHAIN_S2PAIR")) : 0;
-  // both stages on 16 x 16 x 4 MFMAs with dead quadrants skipped (tg_direct_body_t16), PEPSGPU_TILE16=1 (read per launch: the kernel
-  // test switches it inside one process)
-  const char *t16s = getenv("PEPSGPU_TILE16");
-  const int tile16 = t16s ? atoi(t16s) : 0;
 #define PG_CHAIN(a1, b1, a2)                                                                                                   \
   do {                                                                                                                         \
-    if (f64acc && ldsf >= 8192) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 8192, 4, true>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
-    else if (f64acc) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 4, true>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
-    else if (tile16 && ldsf == TG_CHAIN_LDS_FLOATS) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 6, false, false, true>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
-    else if (s2pair && ldsf == TG_CHAIN_LDS_FLOATS) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 5, false, true>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
-    else if (ldsf == 16384) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 16384, 2>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
-    else if (ldsf == 8192) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 8192, 4>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
-    else hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 6>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, allow_chunks); \
+    if (f64acc && ldsf >= 8192) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 8192, 4, true>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, akf); \
+    else if (f64acc) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 4, true>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, akf); \
+    else if (ldsf == 8192) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 8192, 4>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, akf); \
+    else hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 6>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, akf); \
   } while (0)
   if (avec1 && bvec1 && avec2) PG_CHAIN(true, true, true);
   else if (avec1 && bvec1) PG_CHAIN(true, true, false);

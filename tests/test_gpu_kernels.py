@@ -387,28 +387,37 @@ def test_chained_contraction_pair_with_live_extents(f64acc, monkeypatch):
     (X still never leaves the chip); an entry is declined (flag -1, result untouched) only when one carry row's slice of X
     does not fit."""
     from peps_amd import capi
-    # (f64acc = 2: the f32 form on 16 x 16 x 4 MFMAs with dead quadrants skipped, tg_direct_body_t16 -- measured and left off, kept tested)
+    # (f64acc = 2: the triangular form of round 6 on the 32 KB buffer of dense batches -- R a factor with row j zero before column j, its
+    # zero l-blocks skipped in both stages)
     monkeypatch.setenv("PEPSGPU_DIAG_CHAIN_F64", "1" if f64acc == 1 else "0")
-    if f64acc == 2:
-        monkeypatch.setenv("PEPSGPU_TILE16", "1")
+    monkeypatch.setenv("PEPSGPU_DIAG_TRI", "1" if f64acc == 2 else "0")
     rng = np.random.default_rng(5)
     for (nb, m, l, a, p, a2, l2, u) in [(48, 24, 8, 16, 8, 16, 8, 8), (6, 40, 8, 32, 8, 32, 8, 8), (4, 5, 8, 8, 8, 128, 4, 4)]:
         R = rng.standard_normal((nb, m, l, a)).astype(np.float32)
+        tri = f64acc == 2
+        if tri:       # a row-compacted triangular factor: row j zero before column j of the flattened (l, a) index
+            Rf = R.reshape(nb, m, l * a)
+            Rf[:, np.arange(m)[:, None] > np.arange(l * a)[None, :]] = 0.0
+        cap = 8192 if tri else 6144
         A = rng.standard_normal((nb, a, p, a2)).astype(np.float32)
         W = rng.standard_normal((nb, l, p, l2, u)).astype(np.float32)
         live = np.stack([rng.integers(1, m + 1, nb), rng.integers(1, a + 1, nb), rng.integers(1, a2 + 1, nb)], axis=1)
         live[0] = (m, a, a2)                       # static extents: chunks of carry rows (or declined: third shape)
         live[1] = (min(m, 8), min(a, 10), 10)      # the headline's typical live sizes: 8*8*8*10 = 5120 -> one chunk
         P, fl = capi.diag_tgemm_chain(R, A, W, live)
+        if tri and m > a:     # control: the skip is real -- a factor that is NOT triangular loses the blocks before its rows
+            Rbad = R.copy(); Rbad[0, m - 1, 0, 0] = 1.0
+            Pbad, _ = capi.diag_tgemm_chain(Rbad, A, W, live)
+            assert np.array_equal(Pbad[0], P[0])
         n_chunked = 0
         for b in range(nb):
             ml, al, a2l = (int(x) for x in live[b])
-            fits_row = l * p * a2l <= 6144
+            fits_row = l * p * a2l <= cap
             assert fl[b] == (0 if fits_row else -1), (b, live[b], fl[b])
             if not fits_row:
                 assert not np.any(P[b])
                 continue
-            n_chunked += ml * l * p * a2l > 6144
+            n_chunked += ml * l * p * a2l > cap
             X = np.einsum("mla,apc->mlpc", R[b, :ml, :, :al].astype(np.float64), A[b, :al, :, :a2l].astype(np.float64))
             want = np.einsum("mlpc,lpqu->muqc", X, W[b].astype(np.float64))
             got = P[b, :ml, :, :, :a2l]
@@ -416,7 +425,7 @@ def test_chained_contraction_pair_with_live_extents(f64acc, monkeypatch):
         if a2 <= 32:
             assert n_chunked >= 1
         else:
-            assert fl[0] == -1
+            assert fl[0] == (-1 if l * p * a2 > cap else 0)
 
 
 @pytest.mark.parametrize("kernel", [4, 5, 6, 7, 8])
@@ -634,7 +643,8 @@ def _lds_gram_chol_case(which, n, K, rank):
 
 @pytest.mark.parametrize("m,l,a,u,k2,tsw", [(256, 8, 32, 8, 32, 1), (241, 8, 32, 8, 32, 0), (200, 8, 32, 8, 28, 1), (160, 8, 24, 8, 32, 1),
                                              (256, 6, 24, 6, 32, 0)])
-def test_mgemm_dense_kernel(m, l, a, u, k2, tsw):
+@pytest.mark.parametrize("tri", [0, 1])
+def test_mgemm_dense_kernel(m, l, a, u, k2, tsw, tri, monkeypatch):
     """mgemm_dense_kernel (round 3): M = R Tt of dense walkers against NumPy -- live carry rows, live a (rows of Tt beyond it are
     garbage by contract: NaN here), live k2 (columns of M beyond it come back as zeros), both storage orders of Tt."""
     capi = _capi()
@@ -644,6 +654,10 @@ def test_mgemm_dense_kernel(m, l, a, u, k2, tsw):
     rng = np.random.default_rng(m + la + uk + tsw)
     nb = 4
     R = rng.standard_normal((nb, m, l, a)).astype(np.float32)
+    monkeypatch.setenv("PEPSGPU_DIAG_TRI", str(tri))
+    if tri:    # (round 6) R a row-compacted triangular factor: the row blocks below a k-chunk are not multiplied
+        Rf = R.reshape(nb, m, la)
+        Rf[:, np.arange(m)[:, None] > np.arange(la)[None, :]] = 0.0
     T = rng.standard_normal((nb, l, a, u, k2)).astype(np.float32)
     m_live = np.array([m, max(1, m - 17), 129, m], dtype=np.int32)
     a_live = np.array([a, a - 3, a, max(1, a // 2)], dtype=np.int32)
@@ -653,6 +667,10 @@ def test_mgemm_dense_kernel(m, l, a, u, k2, tsw):
         Tdev[b, :, a_live[b]:] = np.nan                      # never written by the producer: must not be read
     Tstore = np.transpose(Tdev, (0, 1, 2, 4, 3)) if tsw else Tdev
     M = capi.diag_mgemm_dense(R.reshape(nb, m, la), Tstore.reshape(nb, la, uk), a, u, k2, tsw, m_live, a_live, k_live)
+    if tri:    # control: the skip is real -- an entry below the diagonal blocks is never read
+        Rbad = R.copy().reshape(nb, m, la); Rbad[0, m - 1, 0] = 1.0
+        Mbad = capi.diag_mgemm_dense(Rbad, Tstore.reshape(nb, la, uk), a, u, k2, tsw, m_live, a_live, k_live)
+        assert np.array_equal(Mbad[0, :m_live[0]], M[0, :m_live[0]])
     for b in range(nb):
         ref = np.einsum("mla,lauk->muk", R[b, :, :, :a_live[b]].astype(np.float64), T[b, :, :a_live[b]].astype(np.float64))
         ref[:, :, k_live[b]:] = 0.0
