@@ -44,7 +44,8 @@ enum {
  * BMPS tensor 2 x elements; pepsgpu_state_upload additionally accepts host_dtype = PEPSGPU_C128.  The complex type covers
  * SVD and (since round 5) variational compression, every contraction / trace / hole entry point, the walker calls, the gradient
  * accumulation (pepsgpu_grad_* below, with the reference's conjugations: psi, eloc and the accumulators are interleaved pairs) and
- * the SR / MinSR family (pepsgpu_sr_*); the two device-side slice calls are real only and return PEPSGPU_EINVAL. */
+ * the SR / MinSR family (pepsgpu_sr_*) and (round 6) the device-side sweep slices; the device-side ENERGY slice
+ * (pepsgpu_nn_exchange_slice) is real only and returns PEPSGPU_EINVAL. */
 enum { PEPSGPU_F32 = 0, PEPSGPU_F64 = 1, PEPSGPU_C128 = 3 };
 enum { PEPSGPU_LEFT = 0, PEPSGPU_DOWN = 1, PEPSGPU_RIGHT = 2, PEPSGPU_UP = 3 };
 enum { PEPSGPU_HORIZONTAL = 0, PEPSGPU_VERTICAL = 1 };
@@ -100,9 +101,31 @@ int pepsgpu_bmps_unpark(pepsgpu_ctx *ctx, int pos);
  *                   reference's chain when the caller pops exactly those from its queue;
  *   amplitude_inout [n] psi of every walker before / after the slice;  accepted_out [n] accepted exchanges;
  *   slice_states_out [n][slice length] (may be NULL) the configuration along the slice after the pass.
- * Real element types only (PEPSGPU_C128 -> PEPSGPU_EINVAL: the per-bond calls remain). */
+ * Every element type (round 6; a PEPSGPU_C128 context takes and returns interleaved (re, im) amplitudes, the test is on |psi'| / |psi|). */
 int pepsgpu_sweep_slice_exchange(pepsgpu_ctx *ctx, int orientation, int slice, int n_uniform, const double *uniforms,
                                  double *amplitude_inout, int32_t *consumed_out, int32_t *accepted_out, int32_t *slice_states_out);
+/* The same with the move given as a table (round 6): pair_table [phys_dim^2][2] (phys_dim = that of the context), the pair of states the
+ * "exchange" proposes for the states (a, b) of a bond = pair_table[a * phys_dim + b]; NULL = the swap (b, a).  A fermionic state lives on
+ * the device as EXTENDED states (state + d * variant: mode order x parity of the fermions before the site); the exchange of two sites
+ * adjacent in the mode order changes their variants by a rule local in (a, b) -- TPSWaveFunctionComponent::DeviceStatesNN
+ * (peps_amd/host/qlpeps_gpu.h) tabulated -- so MCUpdateSquareNNExchangeOBC on a fermionic state runs on the device too
+ * (square_nn_updater.h:142-189 with the fermionic UpdateLocal of wave_function_component.h:345-378).  The amplitudes are those of
+ * the decorated network of the current mode order (no sign factors: the Metropolis test sees moduli only; the caller restores
+ * Sigma / Kappa from the configuration it gets back). */
+int pepsgpu_sweep_slice_exchange_tab(pepsgpu_ctx *ctx, int orientation, int slice, int n_uniform, const double *uniforms,
+                                     const int32_t *pair_table, double *amplitude_inout, int32_t *consumed_out, int32_t *accepted_out,
+                                     int32_t *slice_states_out);
+/* One row / column of MCUpdateSquareNNFullSpaceUpdateOBC (square_nn_updater.h:253-293) on the device: per bond the replacement trace of
+ * all phys_dim^2 states of the pair (ReplaceNNSiteTrace with phys_dim^2 candidates), the weights |psi_k / psi|^2 (the current state
+ * keeps its stored amplitude), SuwaTodoStateUpdate (suwa_todo_update.h:53-112) and UpdateLocal.
+ *   engine_words [n][2 (slice length - 1)]: per walker the next raw 32-bit outputs of its std::mt19937 -- the reference draws
+ *                std::uniform_real_distribution<long double>, i.e. two words per bond whatever the data, so the walker's engine is
+ *                consumed exactly as by the reference's updater (identical chains; the kernel's arithmetic is float64 where
+ *                SuwaTodoStateUpdate uses long double: a decision can differ only within 2^-53 of a boundary of the cumulative weights);
+ *   phys_dim     states per site the move ranges over (phys_dim^2 <= 16); bosonic states (not the extended fermionic ones);
+ *   amplitude_inout, accepted_out, slice_states_out as above (accepted = moves that changed the pair). */
+int pepsgpu_sweep_slice_fullspace(pepsgpu_ctx *ctx, int orientation, int slice, int phys_dim, const uint32_t *engine_words,
+                                  double *amplitude_inout, int32_t *accepted_out, int32_t *slice_states_out);
 
 /* One row / column of the energy evaluation for models whose nearest-neighbour off-diagonal term exchanges the two site states (XXZ,
  * J1-J2, t-J ...): the slice part of SquareNNNModelEnergySolver::CalEnergyAndHolesImpl (square_nnn_energy_solver.h:142-200 row pass:

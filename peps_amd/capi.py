@@ -26,7 +26,7 @@ SYMBOLS = [
     "pepsgpu_walkers_set_configs", "pepsgpu_walkers_get_configs", "pepsgpu_n_walkers",
     "pepsgpu_grow_bmps_step", "pepsgpu_grow_full_bmps", "pepsgpu_grow_bmps_for_row", "pepsgpu_grow_bmps_for_col",
     "pepsgpu_shift_bmps_window", "pepsgpu_delete_inner_bmps", "pepsgpu_bmps_park", "pepsgpu_bmps_unpark", "pepsgpu_generate_bmps_approach",
-    "pepsgpu_sweep_slice_exchange", "pepsgpu_nn_exchange_slice", "pepsgpu_walker_create", "pepsgpu_walker_clone", "pepsgpu_walker_destroy", "pepsgpu_walker_info", "pepsgpu_walker_set_mpo", "pepsgpu_walker_evolve",
+    "pepsgpu_sweep_slice_exchange", "pepsgpu_sweep_slice_exchange_tab", "pepsgpu_sweep_slice_fullspace", "pepsgpu_nn_exchange_slice", "pepsgpu_walker_create", "pepsgpu_walker_clone", "pepsgpu_walker_destroy", "pepsgpu_walker_info", "pepsgpu_walker_set_mpo", "pepsgpu_walker_evolve",
     "pepsgpu_walker_evolve_step", "pepsgpu_walker_contract_row", "pepsgpu_walker_init_bten", "pepsgpu_walker_grow_bten_step",
     "pepsgpu_walker_shift_bten_window", "pepsgpu_walker_trace_with_bten", "pepsgpu_walker_clear_bten", "pepsgpu_walker_get_bmps_tensor",
     "pepsgpu_bmps_stack_size", "pepsgpu_get_bmps_tensor", "pepsgpu_init_bten", "pepsgpu_grow_full_bten",
@@ -101,6 +101,8 @@ def load_library(path=LIB_PATH):
     lib.pepsgpu_comm_destroy.argtypes = [vp]
     lib.pepsgpu_allreduce.argtypes = [vp, vp, C.c_long, C.c_int, C.c_int, C.c_int]
     lib.pepsgpu_sweep_slice_exchange.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp, dp, ip, ip, ip]
+    lib.pepsgpu_sweep_slice_exchange_tab.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp, ip, dp, ip, ip, ip]
+    lib.pepsgpu_sweep_slice_fullspace.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), dp, ip, ip]
     lib.pepsgpu_nn_exchange_slice.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp, dp]
     lib.pepsgpu_walker_create.argtypes = [vp, C.c_int, C.c_int, ip]
     lib.pepsgpu_walker_clone.argtypes = [vp, C.c_int, ip]
@@ -161,12 +163,33 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+class _ReapingLib:
+    """The library as a Context sees it: looking a function up first frees the BMPSWalker ids whose Python objects were finalised
+    since the last call (Walker.__del__ only queues them), so the release happens on the thread that uses the context, between two
+    calls, and before the next one can observe the walker."""
+
+    def __init__(self, raw, ctx):
+        object.__setattr__(self, "_raw", raw)
+        object.__setattr__(self, "_ctx", ctx)
+
+    def __getattr__(self, name):
+        ctx = object.__getattribute__(self, "_ctx")
+        raw = object.__getattribute__(self, "_raw")
+        dead = ctx.__dict__.get("_dead_walkers")
+        if dead and name != "pepsgpu_ctx_destroy":
+            h = ctx.__dict__.get("_h")
+            while dead and h:
+                raw.pepsgpu_walker_destroy(h, dead.pop())
+        return getattr(raw, name)
+
+
 class Context:
     """Thin RAII wrapper of a pepsgpu_ctx: one walker batch on one GPU."""
 
     def __init__(self, rows, cols, D, phys_dim, chi, dtype=F32, device=0, max_walkers=256, chi_min=None,
                  trunc_err=0.0, scheme=0, convergence_tol=None, iter_max=None):
-        self._l = lib()
+        self._l = _ReapingLib(lib(), self)
+        self._dead_walkers = []
         self.rows, self.cols, self.D, self.d = rows, cols, D, phys_dim
         self.dtype = dtype
         self._ot = np.complex128 if dtype == C128 else np.float64      # type of every scalar / tensor the calls return
@@ -183,8 +206,9 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._l.pepsgpu_ctx_destroy(self._h)
+            self._l.pepsgpu_ctx_destroy(self._h)      # (drops every BMPSWalker of the context with it)
             self._h = None
+        self._dead_walkers = []
 
     def __del__(self):
         try:
@@ -252,17 +276,37 @@ class Context:
         self._ck(self._l.pepsgpu_get_bmps_tensor(self._h, pos, level, idx, _ip(dims), _dp(data), _dp(ls)))
         return data, ls
 
-    def sweep_slice_exchange(self, orientation, slice_num, uniforms, amplitude):
+    def sweep_slice_exchange(self, orientation, slice_num, uniforms, amplitude, pair_table=None):
         """one row / column of the NN-exchange sweep on the device; uniforms [n][nu] (next deviates of each walker's stream);
-        returns (amplitude, consumed [n], accepted [n], slice_states [n][N])"""
+        pair_table [d * d][2] (optional): the pair of states the move proposes for the states (a, b) of a bond (fermionic extended
+        states); returns (amplitude, consumed [n], accepted [n], slice_states [n][N])"""
         u = np.ascontiguousarray(uniforms, dtype=np.float64)
         assert u.ndim == 2 and u.shape[0] == self.n
-        amp = np.array(amplitude, dtype=np.float64)
+        amp = np.array(amplitude, dtype=self._ot)
         N = self.cols if orientation == HORIZONTAL else self.rows
         cons, acc = np.zeros(self.n, dtype=np.int32), np.zeros(self.n, dtype=np.int32)
         st = np.zeros((self.n, N), dtype=np.int32)
-        self._ck(self._l.pepsgpu_sweep_slice_exchange(self._h, orientation, slice_num, u.shape[1], _dp(u), _dp(amp), _ip(cons), _ip(acc), _ip(st)))
+        if pair_table is None:
+            self._ck(self._l.pepsgpu_sweep_slice_exchange(self._h, orientation, slice_num, u.shape[1], _dp(u), _dp(amp), _ip(cons), _ip(acc), _ip(st)))
+        else:
+            tab = np.ascontiguousarray(pair_table, dtype=np.int32)
+            assert tab.shape == (self.d * self.d, 2), tab.shape
+            self._ck(self._l.pepsgpu_sweep_slice_exchange_tab(self._h, orientation, slice_num, u.shape[1], _dp(u), _ip(tab), _dp(amp), _ip(cons),
+                                                              _ip(acc), _ip(st)))
         return amp, cons, acc, st
+
+    def sweep_slice_fullspace(self, orientation, slice_num, phys_dim, engine_words, amplitude):
+        """one row / column of the full-space NN updater (Suwa-Todo over phys_dim^2 states per bond) on the device; engine_words
+        [n][2 (N - 1)] uint32 = the next raw outputs of each walker's mt19937; returns (amplitude, accepted [n], slice_states [n][N])"""
+        N = self.cols if orientation == HORIZONTAL else self.rows
+        wd = np.ascontiguousarray(engine_words, dtype=np.uint32)
+        assert wd.shape == (self.n, 2 * (N - 1)), wd.shape
+        amp = np.array(amplitude, dtype=self._ot)
+        acc = np.zeros(self.n, dtype=np.int32)
+        st = np.zeros((self.n, N), dtype=np.int32)
+        self._ck(self._l.pepsgpu_sweep_slice_fullspace(self._h, orientation, slice_num, phys_dim, wd.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                       _dp(amp), _ip(acc), _ip(st)))
+        return amp, acc, st
 
     def nn_exchange_slice(self, orientation, slice_num, punch_holes=False):
         """psi [n] and the amplitudes with the two sites of every bond of the slice exchanged [n][N-1], one read-back"""
@@ -321,7 +365,9 @@ class Context:
             self._ck(self._l.pepsgpu_cfg_override_slice(self._h, orient, num, None))
         else:
             st = np.ascontiguousarray(states, dtype=np.int32)
-            assert st.ndim == 2 and st.shape[0] == self.n
+            # (the C ABI carries no length: the engine reads states[w * N + j], N = columns of a row / rows of a column)
+            want = self.cols if orient == HORIZONTAL else self.rows
+            assert st.ndim == 2 and st.shape[0] == self.n and st.shape[1] == want, (st.shape, self.n, want)
             self._ck(self._l.pepsgpu_cfg_override_slice(self._h, orient, num, _ip(st)))
 
     def replace_plaquette_trace(self, row, col, cand_states=None, left_set=0, right_set=0):
@@ -822,8 +868,16 @@ class Walker:
                 pass
 
     def __del__(self):
+        # The documented release paths are destroy() and the context manager.  A finalizer must not enter the engine (it may run on
+        # another thread while a call on the same context is in flight: ctypes releases the GIL): it queues the id, the context frees
+        # it at its next call from the owning thread (_ReapingLib) or drops it with close().
         try:
-            self._release_quietly()
+            wid, self.wid = self.wid, None
+            if wid is not None and getattr(self.ctx, "_h", None):
+                q = getattr(self.ctx, "_dead_walkers", None)
+                if q is None:
+                    q = self.ctx._dead_walkers = []
+                q.append(wid)
         except Exception:
             pass
 

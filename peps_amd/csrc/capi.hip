@@ -122,8 +122,21 @@ int pepsgpu_delete_inner_bmps(pepsgpu_ctx *ctx, int pos) { CTX_CALL(check_pos(po
 int pepsgpu_sweep_slice_exchange(pepsgpu_ctx *ctx, int orientation, int slice, int n_uniform, const double *uniforms,
                                  double *amplitude_inout, int32_t *consumed_out, int32_t *accepted_out, int32_t *slice_states_out) {
   CTX_CALL(PG_REQUIRE(uniforms && amplitude_inout && consumed_out && accepted_out, 1, "null buffer");
-           ctx->eng->sweep_slice_exchange(orientation, slice, n_uniform, uniforms, amplitude_inout, consumed_out, accepted_out,
-                                          slice_states_out));
+           ctx->eng->sweep_slice_impl(0, orientation, slice, n_uniform, uniforms, nullptr, 0, nullptr, amplitude_inout, consumed_out,
+                                      accepted_out, slice_states_out));
+}
+int pepsgpu_sweep_slice_exchange_tab(pepsgpu_ctx *ctx, int orientation, int slice, int n_uniform, const double *uniforms,
+                                     const int32_t *pair_table, double *amplitude_inout, int32_t *consumed_out, int32_t *accepted_out,
+                                     int32_t *slice_states_out) {
+  CTX_CALL(PG_REQUIRE(uniforms && amplitude_inout && consumed_out && accepted_out, 1, "null buffer");
+           ctx->eng->sweep_slice_impl(0, orientation, slice, n_uniform, uniforms, pair_table, 0, nullptr, amplitude_inout, consumed_out,
+                                      accepted_out, slice_states_out));
+}
+int pepsgpu_sweep_slice_fullspace(pepsgpu_ctx *ctx, int orientation, int slice, int phys_dim, const uint32_t *engine_words,
+                                  double *amplitude_inout, int32_t *accepted_out, int32_t *slice_states_out) {
+  CTX_CALL(PG_REQUIRE(engine_words && amplitude_inout && accepted_out, 1, "null buffer");
+           ctx->eng->sweep_slice_impl(1, orientation, slice, 0, nullptr, nullptr, phys_dim, engine_words, amplitude_inout, nullptr,
+                                      accepted_out, slice_states_out));
 }
 int pepsgpu_nn_exchange_slice(pepsgpu_ctx *ctx, int orientation, int slice, int punch_holes, double *psi_out, double *psi_exchanged_out) {
   CTX_CALL(PG_REQUIRE(psi_out && psi_exchanged_out, 1, "null buffer");

@@ -108,8 +108,10 @@ struct EngineBase {
   virtual void sr_gram(const void *remote_o, const int32_t *remote_cfg, int n_remote, double *out) = 0;
   virtual void sr_weighted_sum(const double *y, double *out) = 0;
   virtual void sr_copy_samples(void *dst_o, int32_t *dst_cfg) = 0;
-  virtual void sweep_slice_exchange(int orient, int slice, int n_uniform, const double *uniforms, double *amp_inout,
-                                    int32_t *consumed_out, int32_t *accepted_out, int32_t *slice_states_out) = 0;
+  // mode 0: exchange move (pair_table nullable), mode 1: full-space move (Suwa-Todo over phys_dim^2 states); engine_sweep.h
+  virtual void sweep_slice_impl(int mode, int orient, int slice, int n_uniform, const double *uniforms, const int32_t *pair_table,
+                                int phys_dim, const uint32_t *words, double *amp_inout, int32_t *consumed_out, int32_t *accepted_out,
+                                int32_t *slice_states_out) = 0;
   virtual void nn_exchange_slice(int orient, int slice, int punch_holes, double *psi_out, double *psi_ex_out) = 0;
   // BMPSWalker (bmps_contractor.h:357-646)
   virtual int walker_create(int pos, int level) = 0;
@@ -814,6 +816,10 @@ class Engine : public EngineBase {
 
   // ------------------------------------------------------------------------------------------
   void erase_envs_after_update(int row, int col) override {   // trace.h:538-589
+    // (an update while the twisted set is selected: the TRUE environments are the inactive ones -- back to set 0 first, so that what
+    // is freed below is the scratch set, and the slice override, stale for the updated slice, goes with it; pepsgpu.h says so)
+    if (bten2_active_ != 0) bten2_select_set(0);
+    if (cfg_ovr_tab_) { arena_.free(cfg_ovr_tab_); cfg_ovr_tab_ = nullptr; ovr_on_ = false; ovr_cfg_ = nullptr; }
     if (bmps_size(LEFT) > col + 1) clear_bmps(LEFT, col + 1);
     if (bmps_size(UP) > row + 1) clear_bmps(UP, row + 1);
     if (bmps_size(DOWN) > Ly_ - row) clear_bmps(DOWN, Ly_ - row);
@@ -912,8 +918,9 @@ class Engine : public EngineBase {
   }
   hipStream_t stream() const { return stream_; }
   // ---- Monte-Carlo sweep of one row / column of bonds on the device (engine_sweep.h) ----
-  void sweep_slice_exchange(int orient, int slice, int n_uniform, const double *uniforms, double *amp_inout, int32_t *consumed_out,
-                            int32_t *accepted_out, int32_t *slice_states_out) override;
+  void sweep_slice_impl(int mode, int orient, int slice, int n_uniform, const double *uniforms, const int32_t *pair_table, int phys_dim,
+                        const uint32_t *words, double *amp_inout, int32_t *consumed_out, int32_t *accepted_out,
+                        int32_t *slice_states_out) override;
   void nn_exchange_slice(int orient, int slice, int punch_holes, double *psi_out, double *psi_ex_out) override;
   // ---- BMPSWalker (engine_walker.h) ----
   int walker_create(int pos, int level) override;

@@ -533,6 +533,9 @@ class BMPSContractorT {
   // of a fermionic state (SquareSpinlessFermion::AddNNNHopEnergyLocal below; include/pepsgpu.h has the statement)
   void SelectBTen2Set(int set) { check_rc(pepsgpu_bten2_select_set(ctx_, set), ctx_); }
   void OverrideSlice(BondOrientation orient, size_t num, const std::vector<int32_t> *states) {
+    // (the C ABI carries no length: the engine reads states[w * N + j], N = columns of a row / rows of a column)
+    if (states && states->size() != walkers() * (orient == HORIZONTAL ? cols() : rows()))
+      throw std::invalid_argument("OverrideSlice: states must hold walkers x (length of the slice) entries");
     check_rc(pepsgpu_cfg_override_slice(ctx_, orient, (int)num, states ? states->data() : nullptr), ctx_);
   }
   std::vector<TenElemT> ReplacePlaquetteTrace(const SiteIdx &left_up, int n_cand, const std::vector<int32_t> &cand, int left_set,
@@ -878,19 +881,21 @@ class MCUpdateSquareNNUpdateBaseOBC : public MonteCarloSweepUpdaterBase {
     const size_t rows = c.rows(), cols = c.cols(), n = comp.config.walkers();
     std::vector<size_t> acc(n, 0);
     auto add = [&](const std::vector<uint8_t> &a) { for (size_t w = 0; w < n; ++w) acc[w] += a[w]; };
-    // An updater whose bond move the device implements (the exchange updater, real bosonic states) runs a whole row / column of
-    // bonds in ONE call (pepsgpu_sweep_slice_exchange: traces, Metropolis tests and exchanges on the device, same deviates in the
-    // same order -> the same chain); every other updater goes through its TwoSiteNNUpdateLocalImpl hook bond by bond.
-    // PEPSHOST_NO_DEVICE_SWEEP=1 forces the hook path (A/B and the identical-chain test of the two paths).
+    // An updater whose bond move the device implements runs a whole row / column of bonds in ONE call (traces, acceptance tests and
+    // moves on the device, the walker's random stream consumed in the same order -> the same chain): the exchange updater (round 4:
+    // real bosonic states; round 6: complex states and -- through the tabulated move of pepsgpu_sweep_slice_exchange_tab --
+    // fermionic states) and the full-space updater (round 6: pepsgpu_sweep_slice_fullspace, bosonic states, real and complex).
+    // Every other combination goes through its TwoSiteNNUpdateLocalImpl hook bond by bond.
+    // PEPSHOST_NO_DEVICE_SWEEP=1 forces the hook path (A/B and the identical-chain tests of the two paths).
     static const bool no_dev = std::getenv("PEPSHOST_NO_DEVICE_SWEEP") != nullptr;
     bool dev_slice = false;
-    if constexpr (std::is_same<TenElemT, double>::value && HasDeviceSliceSweep<MCUpdater>::value) dev_slice = !no_dev && !comp.fermion;
+    if constexpr (HasDeviceSliceSweep<MCUpdater>::value) dev_slice = !no_dev && (!comp.fermion || MCUpdater::kDeviceSliceSweepFermions);
     comp.SetOrder(ROW_MAJOR);                // fermions: horizontal bonds are local in the row-major mode order
     c.GenerateBMPSApproach(UP);
     for (size_t row = 0; row < rows; row++) {
       if (dev_slice) {
-        if constexpr (std::is_same<TenElemT, double>::value && HasDeviceSliceSweep<MCUpdater>::value)
-          static_cast<MCUpdater *>(this)->SweepSliceOnDevice(HORIZONTAL, row, comp, acc);
+        if constexpr (HasDeviceSliceSweep<MCUpdater>::value)
+          static_cast<MCUpdater *>(this)->SweepSliceOnDevice(HORIZONTAL, row, sitps, comp, acc);
       } else {
         c.InitBTen(LEFT, row);
         c.GrowFullBTen(RIGHT, row, 2, true);
@@ -907,8 +912,8 @@ class MCUpdateSquareNNUpdateBaseOBC : public MonteCarloSweepUpdaterBase {
     c.GenerateBMPSApproach(LEFT);
     for (size_t col = 0; col < cols; col++) {
       if (dev_slice) {
-        if constexpr (std::is_same<TenElemT, double>::value && HasDeviceSliceSweep<MCUpdater>::value)
-          static_cast<MCUpdater *>(this)->SweepSliceOnDevice(VERTICAL, col, comp, acc);
+        if constexpr (HasDeviceSliceSweep<MCUpdater>::value)
+          static_cast<MCUpdater *>(this)->SweepSliceOnDevice(VERTICAL, col, sitps, comp, acc);
       } else {
         c.InitBTen(UP, col);
         c.GrowFullBTen(DOWN, col, 2, true);
@@ -931,9 +936,12 @@ class MCUpdateSquareNNExchangeOBC : public MCUpdateSquareNNUpdateBaseOBC<MCUpdat
  public:
   using MCUpdateSquareNNUpdateBaseOBC<MCUpdateSquareNNExchangeOBC>::MCUpdateSquareNNUpdateBaseOBC;
   static constexpr bool kDeviceSliceSweep = true;
-  // one row / column of exchange moves on the device (pepsgpu_sweep_slice_exchange); walker w consumes the next consumed[w]
+  static constexpr bool kDeviceSliceSweepFermions = true;
+  // one row / column of exchange moves on the device (pepsgpu_sweep_slice_exchange / _tab); walker w consumes the next consumed[w]
   // deviates of its stream, exactly those TwoSiteNNUpdateLocalImpl would draw
-  void SweepSliceOnDevice(BondOrientation dir, size_t slice, TPSWaveFunctionComponentT<double> &comp, std::vector<size_t> &acc) {
+  template <typename TenElemT>
+  void SweepSliceOnDevice(BondOrientation dir, size_t slice, const SplitIndexTPST<TenElemT> &, TPSWaveFunctionComponentT<TenElemT> &comp,
+                          std::vector<size_t> &acc) {
     auto &c = comp.contractor;
     const size_t n = comp.config.walkers(), N = dir == HORIZONTAL ? c.cols() : c.rows(), nu = N - 1;
     std::vector<double> uni(n * nu);
@@ -942,12 +950,46 @@ class MCUpdateSquareNNExchangeOBC : public MCUpdateSquareNNUpdateBaseOBC<MCUpdat
       std::copy(q, q + nu, uni.begin() + (long)(w * nu));
     }
     std::vector<int32_t> consumed(n), accepted(n), states(n * N);
-    check_rc(pepsgpu_sweep_slice_exchange(c.ctx(), dir, (int)slice, (int)nu, uni.data(), comp.amplitude.data(), consumed.data(), accepted.data(),
-                                          states.data()), c.ctx());
+    if (!comp.fermion) {
+      check_rc(pepsgpu_sweep_slice_exchange(c.ctx(), dir, (int)slice, (int)nu, uni.data(), dptr(comp.amplitude.data()), consumed.data(),
+                                            accepted.data(), states.data()), c.ctx());
+      for (size_t w = 0; w < n; ++w) {
+        ConsumeUniforms(w, (size_t)consumed[w]);
+        acc[w] += (size_t)accepted[w];
+        for (size_t j = 0; j < N; ++j) comp.config(w, dir == HORIZONTAL ? SiteIdx{slice, j} : SiteIdx{j, slice}) = states[w * N + j];
+      }
+      return;
+    }
+    // Fermions: the device holds extended states (state + d * variant) of the current mode order; the exchange of two sites adjacent
+    // in that order is DeviceStatesNN tabulated over the pair of extended states.  The slice returns decorated amplitudes (the
+    // Metropolis test sees moduli only); a walker that moved gets its signs back from its new configuration, as UpdateLocal does.
+    const FermionDecoration &fd = *comp.fermion;
+    const int32_t d = (int32_t)fd.d(), dp = 4 * d;
+    std::vector<int32_t> tab((size_t)dp * dp * 2);
+    for (int32_t e1 = 0; e1 < dp; ++e1)
+      for (int32_t e2 = 0; e2 < dp; ++e2) {
+        const int32_t a1 = e1 % d, var1 = e1 / d, a2 = e2 % d, var2 = e2 / d;
+        int32_t c1 = e1, c2 = e2;
+        const bool row_ok = comp.order == ROW_MAJOR && var1 < 2 && var2 < 2, col_ok = comp.order == COL_MAJOR && var1 >= 2 && var2 >= 2;
+        if (row_ok || col_ok) {
+          const int32_t a = a2, b = a1;                     // the exchanged physical states
+          const int na = fd.n(a), nb = fd.n(b);
+          const int before = row_ok ? ((var1 & 1) ^ fd.n(a1)) : (var1 & 1);
+          if (row_ok) { c1 = a + d * (before ^ na); c2 = b + d * (before ^ na ^ nb); }
+          else { c1 = a + d * (2 + before); c2 = b + d * (2 + (before ^ na)); }
+        }
+        tab[2 * ((size_t)e1 * dp + e2)] = c1;
+        tab[2 * ((size_t)e1 * dp + e2) + 1] = c2;
+      }
+    std::vector<TenElemT> amp = comp.amplitude;
+    check_rc(pepsgpu_sweep_slice_exchange_tab(c.ctx(), dir, (int)slice, (int)nu, uni.data(), tab.data(), dptr(amp.data()), consumed.data(),
+                                              accepted.data(), states.data()), c.ctx());
     for (size_t w = 0; w < n; ++w) {
       ConsumeUniforms(w, (size_t)consumed[w]);
       acc[w] += (size_t)accepted[w];
-      for (size_t j = 0; j < N; ++j) comp.config(w, dir == HORIZONTAL ? SiteIdx{slice, j} : SiteIdx{j, slice}) = states[w * N + j];
+      for (size_t j = 0; j < N; ++j) comp.config(w, dir == HORIZONTAL ? SiteIdx{slice, j} : SiteIdx{j, slice}) = states[w * N + j] % d;
+      if (accepted[w] > 0)
+        comp.amplitude[w] = amp[w] * double(fd.Sigma(comp.config, w) * (comp.order == COL_MAJOR ? fd.Kappa(comp.config, w) : 1));
     }
   }
   template <typename TenElemT>
@@ -982,7 +1024,26 @@ class MCUpdateSquareNNExchangeOBC : public MCUpdateSquareNNUpdateBaseOBC<MCUpdat
 class MCUpdateSquareNNFullSpaceUpdateOBC : public MCUpdateSquareNNUpdateBaseOBC<MCUpdateSquareNNFullSpaceUpdateOBC> {
  public:
   using MCUpdateSquareNNUpdateBaseOBC<MCUpdateSquareNNFullSpaceUpdateOBC>::MCUpdateSquareNNUpdateBaseOBC;
-  static constexpr bool kDeviceSliceSweep = false;
+  static constexpr bool kDeviceSliceSweep = true;
+  static constexpr bool kDeviceSliceSweepFermions = false;    // (the move ranges over physical states: the hook path keeps fermions)
+  // one row / column of full-space moves on the device (pepsgpu_sweep_slice_fullspace): SuwaTodoStateUpdate draws a long double
+  // from the walker's engine = two raw 32-bit words per bond, whatever the data -- handed over in drawing order
+  template <typename TenElemT>
+  void SweepSliceOnDevice(BondOrientation dir, size_t slice, const SplitIndexTPST<TenElemT> &sitps, TPSWaveFunctionComponentT<TenElemT> &comp,
+                          std::vector<size_t> &acc) {
+    auto &c = comp.contractor;
+    const size_t n = comp.config.walkers(), N = dir == HORIZONTAL ? c.cols() : c.rows(), nwd = 2 * (N - 1);
+    std::vector<uint32_t> words(n * nwd);
+    for (size_t w = 0; w < n; ++w)
+      for (size_t k = 0; k < nwd; ++k) words[w * nwd + k] = (uint32_t)engines_[w]();
+    std::vector<int32_t> accepted(n), states(n * N);
+    check_rc(pepsgpu_sweep_slice_fullspace(c.ctx(), dir, (int)slice, (int)sitps.PhysicalDim(), words.data(), dptr(comp.amplitude.data()),
+                                           accepted.data(), states.data()), c.ctx());
+    for (size_t w = 0; w < n; ++w) {
+      acc[w] += (size_t)accepted[w];
+      for (size_t j = 0; j < N; ++j) comp.config(w, dir == HORIZONTAL ? SiteIdx{slice, j} : SiteIdx{j, slice}) = states[w * N + j];
+    }
+  }
   template <typename TenElemT>
   std::vector<uint8_t> TwoSiteNNUpdateLocalImpl(const SiteIdx &s1, const SiteIdx &s2, BondOrientation dir,
                                                 const SplitIndexTPST<TenElemT> &sitps, TPSWaveFunctionComponentT<TenElemT> &comp) {
@@ -1402,8 +1463,8 @@ struct SpinOneHalfMeasurementHooks {
     // Default: every DOWN environment is grown first, every pair y1 < y2 is measured.  SetStructureFactorReferenceStackState(true):
     // the mixin exactly as the reference runs it -- it reads GetBMPS(DOWN) as the traversal left it (one level after the row pass),
     // pushes zeros for a row y2 whose environment is not in the stack and `continue`s past the walker's Evolve (:139-149): this
-    // form reproduces the reference's regression vector in the oracle (K8, tests/test_oracle_measure.py); here it is NOT yet run on
-    // the GPU (round 4) and therefore off.
+    // form reproduces the reference's regression vector in the oracle (K8, tests/test_oracle_measure.py) and, since round 5, on the
+    // device (tests/test_gpu_measure.py::test_k8_reference_structure_factor_regression_on_the_device, 96 values at 1e-10); off by default.
     if (!structure_factor_reference_stack_state_) c.GenerateBMPSApproach(UP);   // UP = vacuum, DOWN fully grown (traversal start state)
     const size_t n_down = c.BMPSStackSize(DOWN);
     auto main_walker = c.MakeWalker(UP, 0);                    // BMPSWalker(tn, up_stack[0], UP, 1, trunc_params)
@@ -2096,7 +2157,8 @@ class TransverseFieldIsingSquareOBC {
   }
   // Registry of the model (:60-152): energy, spin_z, sigma_x per site (= -off-diagonal term / h; 0 for h = 0), SzSz_row along the
   // middle row (x0 = lx / 4, i = 1 .. lx / 2).  Same row pass as the energy.  (Round 4: the oracle form is pinned on the reference's
-  // exact-sum measurer numbers at 1e-10, tests/test_oracle_measure.py; this device form has not been run on the GPU yet.)
+  // exact-sum measurer numbers at 1e-10, tests/test_oracle_measure.py; round 5: the device form runs the same registries in
+  // tests/test_gpu_measure.py, real and complex.)
   template <typename TenElemT>
   ObservableMapT<TenElemT> EvaluateObservables(const SplitIndexTPST<TenElemT> &, TPSWaveFunctionComponentT<TenElemT> &comp) {
     auto &c = comp.contractor;
@@ -2409,6 +2471,11 @@ class MCPEPSMeasurer {
       : sitps_(sitps), comp_(comp), params_(params), updater_(updater), solver_(solver) {
     observables_meta_ = solver_.DescribeObservables(comp.contractor.rows(), comp.contractor.cols());
   }
+  // NOTE on ownership (differs from the reference, where the measurer owns engine and state): the warm-up's NormalizeStateOrder1
+  // rescales the measurer's PRIVATE copy of the state and uploads it into the caller's contractor / component; the caller's own
+  // SplitIndexTPS is only held by const reference and is NOT rescaled.  After Execute() the device holds State(), which differs from
+  // the caller's host state by StateScaleFactor(): keep using State() (or re-upload your own state) with this component afterwards.
+  // The engine constructor also runs EnsureConfigurationValidity: invalid walkers throw here instead of being swept.
   void Execute() {                                  // monte_carlo_peps_measurer_impl.h:172-178
     // engine_.WarmUp() (monte_carlo_engine.h:146-173): the warm-up sweeps, the amplitude sanity check and NormalizeStateOrder1 -- the
     // measurer's own copy of the state is rescaled to max_w |psi_w| = 1 and the components are rebuilt.  Ratios do not see it; the

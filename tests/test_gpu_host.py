@@ -214,6 +214,61 @@ print(json.dumps(out))
     assert res["device"]["f64"]["cfg"] != synthetic.make_configs(6, 24, "heisenberg", seed0=13).tolist()      # ... and it moved
 
 
+def test_device_slice_sweeps_of_the_other_updaters_and_types():
+    """Round 6: the device-side slice sweeps beyond the real bosonic exchange updater, each against the per-bond
+    hook path of the same updater (PEPSHOST_NO_DEVICE_SWEEP=1) -- identical configurations and accept rates after two sweeps:
+      * MCUpdateSquareNNFullSpaceUpdateOBC (square_nn_updater.h:253-293; pepsgpu_sweep_slice_fullspace: Suwa-Todo over the d^2 states
+        of a bond on the device, the walker's mt19937 consumed two words per bond as the reference's long double draw does), real
+        f64 / f32 and complex;
+      * MCUpdateSquareNNExchangeOBC on a COMPLEX state (interleaved amplitudes, |psi'| / |psi|);
+      * MCUpdateSquareNNExchangeOBC on a FERMIONIC state (pepsgpu_sweep_slice_exchange_tab: the exchange of the decorated extended
+        states as a table), real f64 / f32 -- the chain of the hook path is the one K9 pins on the reference's regression energy."""
+    import json
+    import subprocess
+    import sys
+    code = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from peps_amd import hostapi, synthetic, fermion
+L, D, chi = 6, 4, 12
+flat = synthetic.sitps_to_flat(synthetic.make_sitps(L, D, noise=0.5), D)
+rng = np.random.default_rng(3)
+cflat = flat * np.exp(2j * np.pi * rng.uniform(size=flat.shape))
+cfgs = synthetic.make_configs(L, 16, "heisenberg", seed0=13)
+seeds = np.arange(16, dtype=np.uint64) + 90
+out = {}
+for name, dt in (("fullspace_f64", 1), ("fullspace_f32", 0)):
+    c, a, r = hostapi.mc_sweeps(flat, cfgs, seeds, chi, "fullspace", 2, dt)
+    out[name] = {"cfg": c.tolist(), "amp": [float(x) for x in a], "rate": [float(x) for x in r]}
+for name, upd in (("exchange_c128", "exchange"), ("fullspace_c128", "fullspace")):
+    c, a, r = hostapi.mc_sweeps_complex(cflat, cfgs, seeds, chi, upd, 2)
+    out[name] = {"cfg": c.tolist(), "amp": [[float(x.real), float(x.imag)] for x in a], "rate": [float(x) for x in r]}
+st = fermion.random_even_state(5, 4, 3, seed=11)
+fc = np.stack([np.random.default_rng(100 + k).permutation(np.r_[np.zeros(10, dtype=int), np.ones(10, dtype=int)]).reshape(5, 4) for k in range(12)])
+for name, dt in (("fermion_f64", 1), ("fermion_f32", 0)):
+    c, a, r = hostapi.fermion_mc_sweeps(st, fc, np.arange(12, dtype=np.uint64) + 7, 9, 2, dt)
+    out[name] = {"cfg": c.tolist(), "amp": [float(x) for x in a], "rate": [float(x) for x in r], "start": fc.tolist()}
+print(json.dumps(out))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for name, env in (("device", {}), ("hook", {"PEPSHOST_NO_DEVICE_SWEEP": "1"})):
+        r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=1800)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    for key, tol in (("fullspace_f64", 1e-12), ("fullspace_f32", 1e-5), ("exchange_c128", 1e-12), ("fullspace_c128", 1e-12),
+                     ("fermion_f64", 1e-12), ("fermion_f32", 1e-5)):
+        a, b = res["device"][key], res["hook"][key]
+        assert a["cfg"] == b["cfg"], key                     # the same chain
+        assert a["rate"] == b["rate"] and max(a["rate"]) > 0, key
+        x, y = np.array(a["amp"]), np.array(b["amp"])
+        if x.ndim == 2:
+            x, y = x[:, 0] + 1j * x[:, 1], y[:, 0] + 1j * y[:, 1]
+        assert np.max(np.abs(x / y - 1)) < tol, (key, np.max(np.abs(x / y - 1)))
+    assert res["device"]["fermion_f64"]["cfg"] != res["device"]["fermion_f64"]["start"]
+
+
 def test_monte_carlo_engine_rescue_and_normalize_order1(fixtures_dir):
     """MonteCarloEngine of the host layer (monte_carlo_engine.h:146-240 WarmUp / StepSweep / NormalizeStateOrder1, :340-414
     EnsureConfigurationValidity): walkers whose amplitude falls outside the rescue window take the configuration of the first
