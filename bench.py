@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--sweep-walkers", type=int, default=16384)
     ap.add_argument("--real-sweep-walkers", type=int, default=2048, help="walkers of the sweep / VMC-sample rates on the real_rank leg")
     ap.add_argument("--real-sweep-count", type=int, default=3, help="timed sweeps / samples there")
-    ap.add_argument("--sweep-count", type=int, default=3)
+    ap.add_argument("--sweep-count", type=int, default=10)
     ap.add_argument("--no-other-modes", action="store_true", help="skip the short runs of the f64 / variational / complex / C5 modes")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-walker latency measurement (n1_ms)")
     ap.add_argument("--energy-n", type=int, default=8, help="configurations of the E_loc parity sample of the main leg (half of it on the extra legs)")
@@ -612,6 +612,63 @@ def other_modes(capi, synthetic, device, L, D, chi):
     return out
 
 
+def baseline_config_rates(capi, synthetic, device):
+    """BASELINE configs C2 (8x8 TFIM, D = 4, chi = 16, "local MC updater" = MCUpdateSquareNNFullSpaceUpdateOBC), C3 (10x10 Heisenberg,
+    D = 6, chi = 24, exchange updater) and C5 (8x8 spinless fermions, D = 6, chi = 24, exchange updater on the decorated network):
+    fresh amplitudes/s through the C ABI and Monte-Carlo sweeps/s through the C++ host layer with the device-side slice sweeps of
+    round 6 (marginal rate: a call with 1 + n sweeps against a call with 1), f32, synthetic states."""
+    from peps_amd import hostapi, fermion
+    hostapi.set_device(device)
+    out = {}
+
+    def amp_rate(ctx, batches):
+        ctx.set_configs(batches[0]); ctx.evaluate_amplitude()
+        ctx.sync(); t0 = time.perf_counter()
+        for b in batches[1:]:
+            ctx.set_configs(b); ctx.evaluate_amplitude()
+        ctx.sync()
+        return sum(len(b) for b in batches[1:]) / (time.perf_counter() - t0)
+
+    def sweep_rate(call, n_sweeps):
+        call(1)                                   # untimed: kernels loaded, allocator warm
+        t0 = time.perf_counter(); call(1); t1 = time.perf_counter() - t0
+        t0 = time.perf_counter(); rates = call(1 + n_sweeps); tn = time.perf_counter() - t0
+        t0 = time.perf_counter(); call(1); t1 = min(t1, time.perf_counter() - t0)
+        return max(tn - t1, 1e-9), rates
+
+    for name, upd, nw in (("C2", "fullspace", 8192), ("C3", "exchange", 8192)):   # (walkers x candidates <= 65535: the grid z limit)
+        try:
+            L, D, chi, model = synthetic.CONFIGS[name]
+            flat = synthetic.sitps_to_flat(synthetic.make_sitps(L, D), D, np.float64)
+            mk = lambda k: synthetic.make_configs(L, nw, "heisenberg" if model == "heisenberg" else "tfim", seed0=91000 + 7 * k)
+            c = capi.Context(L, L, D, 2, chi, dtype=capi.F32, device=device, max_walkers=nw)
+            c.state_upload(flat)
+            r = {"amp_per_s": amp_rate(c, [mk(k) for k in range(3)]), "walkers": nw, "dtype": "f32",
+                 "workload": "%dx%d %s, D = %d, chi = %d, synthetic state (noise 0.1)" % (L, L, model, D, chi)}
+            c.close()
+            cfgs, seeds, ns = mk(0), np.arange(nw, dtype=np.uint64) + 300, 3
+            dt_s, rates = sweep_rate(lambda n: hostapi.mc_sweeps(flat, cfgs, seeds, chi, upd, n, 0)[2], ns)
+            r.update(mc_sweeps_per_s=ns * nw / dt_s, sweeps_timed=ns, accept_rate=float(np.mean(rates)),
+                     updater="MCUpdateSquareNNFullSpaceUpdateOBC (Suwa-Todo over 4 states per bond on the device)" if upd == "fullspace"
+                     else "MCUpdateSquareNNExchangeOBC")
+            out[name] = r
+        except Exception as e:
+            out[name] = {"error": repr(e)}
+    try:
+        l5, d5, chi5, nw = 8, 6, 24, 4096
+        st = fermion.random_even_state(l5, l5, d5, seed=11)
+        rng = np.random.default_rng(1)
+        cfgs = np.stack([rng.permutation(np.r_[np.zeros(32, dtype=int), np.ones(32, dtype=int)]).reshape(l5, l5) for _ in range(nw)])
+        seeds, ns = np.arange(nw, dtype=np.uint64) + 700, 3
+        dt_s, rates = sweep_rate(lambda n: hostapi.fermion_mc_sweeps(st, cfgs, seeds, chi5, n, 0)[2], ns)
+        out["C5"] = {"mc_sweeps_per_s": ns * nw / dt_s, "sweeps_timed": ns, "walkers": nw, "dtype": "f32", "accept_rate": float(np.mean(rates)),
+                     "updater": "MCUpdateSquareNNExchangeOBC on the fermionic state (tabulated exchange of the extended states on the device)",
+                     "workload": "8x8 spinless fermions (fZ2-graded, sign-decorated), D = 6, chi = 24; amplitudes/s: other_modes.C5_spinless_tV_8x8_D6_chi24"}
+    except Exception as e:
+        out["C5"] = {"error": repr(e)}
+    return out
+
+
 def n1_latency(leg, reps=3):
     """latency floor: one walker, one fresh EvaluateAmplitude (what a reference-style one-walker-per-call binding pays)"""
     c = leg.capi.Context(leg.L, leg.L, leg.D, leg.pdim, leg.chi, dtype=leg.dt, device=leg.device, max_walkers=1)
@@ -866,6 +923,10 @@ def main():
             out["other_modes"] = other_modes(capi, synthetic, local_rank, L, D, chi)
         except Exception as e:
             out["other_modes"] = {"error": repr(e)}
+        try:
+            out["baseline_configs"] = baseline_config_rates(capi, synthetic, local_rank)
+        except Exception as e:
+            out["baseline_configs"] = {"error": repr(e)}
 
     # ---- further legs on the same shapes: a state of full rank (i.i.d. random site tensors) and a state of the rank of a
     #      REAL PEPS (the reference's optimised 4x4 D=8 fixture tiled to L x L, configurations near the Neel state) ----

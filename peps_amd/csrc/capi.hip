@@ -716,10 +716,6 @@ static void diag_jacobi_t(void *M, int m, int len, int nbatch, int k, void *Vt, 
     PG_REQUIRE(m <= 256 && len <= 256, 1, "register Jacobi handles up to 256 x 256");
     hipLaunchKernelGGL(jacobi_rows_reg256_kernel, dim3(nbatch), dim3(512), 0, 0, (float *)dM, (long)m * len, m, len, len,
                        40, dsw, (const int *)nullptr, 1, 0);
-  } else if (sizeof(T) == 4 && force_global == 4) {   // tournament kernel of the preconditioned mid route (up to 128 x 128)
-    PG_REQUIRE(m <= 128 && len <= 128, 1, "regx<4,2> handles up to 128 x 128");
-    hipLaunchKernelGGL((jacobi_rows_regx_kernel<4, 2>), dim3(nbatch), dim3(256), 0, 0, (float *)dM, (long)m * len, m, len, len, 40,
-                       dsw, (const int *)nullptr, 1);
   } else if (sizeof(T) == 4 && force_global >= 5 && force_global <= 8) {
     // 16-lanes-per-row tournament: 5 = four waves (128 rows), 6 = two (64), rows up to 128 long; 7 / 8 = the same with rows up to 256 long
     const int wide = force_global >= 7, four = force_global == 5 || force_global == 7;
@@ -747,9 +743,12 @@ static void diag_jacobi_t(void *M, int m, int len, int nbatch, int k, void *Vt, 
     int *dm;
     PG_CHECK_HIP(hipMalloc(&dm, nbatch * sizeof(int)));
     PG_CHECK_HIP(hipMemcpy(dm, hm.data(), nbatch * sizeof(int), hipMemcpyHostToDevice));
-    if (m <= JR_BR && len <= 128)     // as the absorption: short rows -> two walkers per wave
-      hipLaunchKernelGGL(jacobi_rows_tiny2_kernel, dim3((nbatch + 7) / 8), dim3(256), 0, 0, (float *)dM, (long)m * len, m, len,
-                         len, 40, dsw, (const int *)dm, 1, nbatch);
+    if (m <= JR_BR && len <= 64)      // as the absorption: short rows -> four walkers per wave, 16 lanes x 4 columns
+      hipLaunchKernelGGL((jacobi_rows_tiny4_kernel<4>), dim3((nbatch + 15) / 16), dim3(256), 0, 0, (float *)dM, (long)m * len, m, len,
+                         len, 40, dsw, (const int *)dm, 1, nbatch, JrSelect());
+    else if (m <= JR_BR && len <= 128)   // ... 16 lanes x 8 columns
+      hipLaunchKernelGGL((jacobi_rows_tiny4_kernel<8>), dim3((nbatch + 15) / 16), dim3(256), 0, 0, (float *)dM, (long)m * len, m, len,
+                         len, 40, dsw, (const int *)dm, 1, nbatch, JrSelect());
     else if (m <= JR_BR)     // <= 16 rows -> tiny kernel, 17..32 -> small kernel
       hipLaunchKernelGGL(jacobi_rows_tiny_kernel, dim3((nbatch + 3) / 4), dim3(256), 0, 0, (float *)dM, (long)m * len, m, len,
                          len, 40, dsw, (const int *)dm, 1, nbatch);

@@ -970,7 +970,7 @@ class Engine : public EngineBase {
     // A bracket that follows another one directly starts at that one's end event (an event costs ~2.3 us on the stream: 4 000 of
     // them were 9 ms of the 441 ms headline step): the few unbracketed operations in between (flag memsets, list kernels) are
     // charged to the bracket that follows.  Not for the chained contraction, whose pair brackets exactly its launch (roofline).
-    static const bool share = getenv("PEPSGPU_PROF_NO_SHARE") == nullptr;
+    constexpr bool share = true;
     r.a_shared = share && prof_chain_ok_ && cat != PROF_CHAIN && !prof_.empty();
     if (r.a_shared) r.a = prof_.back().b;
     else if (!ev_pool_.empty()) { r.a = ev_pool_.back(); ev_pool_.pop_back(); } else PG_CHECK_HIP(hipEventCreate(&r.a));
@@ -1088,7 +1088,7 @@ class Engine : public EngineBase {
   }
 
   void normalize(T *x, long n, long stride, int nb, double *logscale, const int *ndyn = nullptr, int ndyn_mul = 1) {
-    static const bool no_wave = getenv("PEPSGPU_NO_WAVE_NORM") != nullptr;
+    constexpr bool no_wave = false;
     if (n <= 4096 && nb >= 64 && !no_wave)   // short tensors, many walkers: one wave per walker
       hipLaunchKernelGGL(normalize_wave_kernel<T>, dim3((nb + 3) / 4), dim3(256), 0, stream_, x, stride, (int)n, logscale, flag_,
                          ndyn, ndyn_mul, nb);
@@ -1106,23 +1106,13 @@ class Engine : public EngineBase {
     PG_REQUIRE(t2.d[0] == t5.d[2] && t2.d[1] == t5.d[1] && t2.d[2] == t5.d[0], 3, "trace: environment bond mismatch");
     const int nb = nw_ * nc;
     Acc *res = (Acc *)arena_.alloc(sizeof(Acc) * nb);
-    static const bool old_dot = getenv("PEPSGPU_OLD_TRACE_DOT") != nullptr;
-    if (!old_dot) {     // dedicated dot kernel (linalg.h: trace_dot_kernel)
-      const size_t bytes = sizeof(T) * (size_t)t5.n;
-      const int use_lds = bytes <= 64 * 1024;
-      if (use_lds) allow_dynamic_lds(reinterpret_cast<const void *>(&trace_dot_kernel<T, Acc>), bytes);
-      hipLaunchKernelGGL((trace_dot_kernel<T, Acc>), dim3(nb), dim3(256), use_lds ? bytes : 0, stream_, (const T *)t2.p, t2.n, nc / nc2,
-                         (const T *)t5.p, t5.n, nc / nc5, t2.d[0], t2.d[1], t2.d[2], res, use_lds);
-      PG_CHECK_HIP(hipGetLastError());
-      return res;
-    }
-    TGemmDesc g;
-    g.K[0] = t2.d[0]; g.K[1] = t2.d[1]; g.K[2] = t2.d[2];
-    g.sAk[0] = t2.d[1] * t2.d[2]; g.sAk[1] = t2.d[2]; g.sAk[2] = 1;
-    g.sBk[0] = 1; g.sBk[1] = t5.d[2]; g.sBk[2] = t5.d[1] * t5.d[2];
-    g.wA = t2.n; g.wB = t5.n; g.wC = 1; g.nbatch = nb;
-    g.bdivA = nc / nc2; g.bdivB = nc / nc5;
-    tgemm_launch<T, T, Acc, Acc>(stream_, g, t2.p, t5.p, res);
+    // dedicated dot kernel (linalg.h: trace_dot_kernel; the generic tensor GEMM ran this 1 x 1 output at 1.36 ms per call: HISTORY.md)
+    const size_t bytes = sizeof(T) * (size_t)t5.n;
+    const int use_lds = bytes <= 64 * 1024;
+    if (use_lds) allow_dynamic_lds(reinterpret_cast<const void *>(&trace_dot_kernel<T, Acc>), bytes);
+    hipLaunchKernelGGL((trace_dot_kernel<T, Acc>), dim3(nb), dim3(256), use_lds ? bytes : 0, stream_, (const T *)t2.p, t2.n, nc / nc2,
+                       (const T *)t5.p, t5.n, nc / nc5, t2.d[0], t2.d[1], t2.d[2], res, use_lds);
+    PG_CHECK_HIP(hipGetLastError());
     return res;
   }
   // out[i] = res[i] * exp(lsum[i / nc])  (to the host)
@@ -1156,7 +1146,7 @@ class Engine : public EngineBase {
                     int ncand, bool normalise, int bt_ncand = 1, const int *vx = nullptr, const int *vc = nullptr,
                     const int *vb = nullptr, const int *vy = nullptr, const int *skip = nullptr) {
     ArenaScope scope(arena_);
-    static const bool no_live_env = getenv("PEPSGPU_NO_LIVE_ENV") != nullptr;
+    constexpr bool no_live_env = false;
     if (no_live_env || sizeof(T) != 4) vx = vc = vb = vy = nullptr;
     const int nb = nw_ * ncand, nb1 = nw_ * bt_ncand;
     PG_REQUIRE(ncand % bt_ncand == 0 && (!normalise || ncand == 1), 1, "BTen step: bad candidate batching");
@@ -1176,7 +1166,7 @@ class Engine : public EngineBase {
     int bt_chained = 0;
     DTen<T> tmp2c;
     if constexpr (sizeof(T) == 4) {
-      static const bool no_btc = getenv("PEPSGPU_NO_BTEN_CHAIN") != nullptr;
+      constexpr bool no_btc = false;
       if (!no_btc && ncand == 1 && bt_ncand == 1 && x * p1 > 1 && b1 * b2 > 1) {
         tmp2c = alloc_ten(b2, x, s1, s2, nb);
         bt_chain_flag = (int *)arena_.alloc(sizeof(int) * nb);
@@ -1199,7 +1189,7 @@ class Engine : public EngineBase {
         const double fl = 2.0 * nb * ((double)(x * p1) * cdim * (double)(b1 * b2) + (double)(b2 * x) * (double)(p1 * b1) * (double)(s1 * s2));
         // round 4: all three contractions in one launch (tgemm_chain3_kernel: tmp1 and tmp2 resident in LDS, the bond x walked in
         // chunks when the live intermediates exceed the buffers); PEPSGPU_NO_BTEN_CHAIN3=1 for the two-stage chain + separate launch
-        static const bool no_bt3 = getenv("PEPSGPU_NO_BTEN_CHAIN3") != nullptr;
+        constexpr bool no_bt3 = false;
         // ... when the bond x is walked in at most three chunks of the 4096-float buffers (static extents; they follow the live bonds
         // through the bond shrink): with the bonds of a real state (x = b2 = 32: sixteen chunks of two) the three-stage kernel is 2 %
         // slower than the two-stage chain + separate launch (368 against 375 sweeps/s at 2048 walkers)

@@ -179,7 +179,7 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_simple(int pos, int num, const BMP
           tgemm_launch<T, T, Acc, Acc>(stream_, g, M.p, M.p, Gm);
         };
         gram_m(nullptr);
-        static const double tscale = getenv("PEPSGPU_ROUTE_THRESH_SCALE") ? atof(getenv("PEPSGPU_ROUTE_THRESH_SCALE")) : 1.0;
+        constexpr double tscale = 1.0;
         hipLaunchKernelGGL(chol_upper_cplx_kernel<T>, dim3(nw_), dim3(1024), 0, stream_, (c128 *)Gm, (long)m * m, m, B1.p, B1.n, mB1,
                            (const int *)nullptr, tscale);
         // second chance for the walkers whose factor kept more than 128 rows: pivot threshold x REDO_SCALE (the guard prices it)
@@ -247,7 +247,7 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_simple(int pos, int num, const BMP
                            (const int *)rflag, 1);
         hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)Zt.p, Zt.n, kq, uk, uk, k, V.p, V.n,
                            (T *)nullptr, 0L, (const int *)kW, 1, (int *)nullptr, 0.0, chi_min_, (double *)nullptr, (const int *)rflag, 1);
-        static const double guard_tol = getenv("PEPSGPU_F64_ROUTE_TOL") ? atof(getenv("PEPSGPU_F64_ROUTE_TOL")) : 1e-10;
+        constexpr double guard_tol = 1e-10;
         hipLaunchKernelGGL(f64_route_guard_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)Zt.p, Zt.n, uk, (const int *)kW, k, guard_tol,
                            rflag, kq, (const int *)lvl, 5.7e-14 * tscale * REDO_SCALE, 5.7e-14 * tscale * REDO_SCALE * REDO_SCALE, 5.7e-14 * tscale,
                            tscale > 1.0 ? 1 : 0);

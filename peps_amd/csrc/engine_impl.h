@@ -24,10 +24,7 @@ void Engine<T>::add_log(double *acc, const double *a) {
 // mid_hi > 0: walkers with 32 < rows <= mid_hi are on the preconditioned mid route (absorb_impl) and are skipped here.
 template <typename T>
 bool Engine<T>::jacobi_small_ok(int len, int m, const int *mdyn) {
-  if constexpr (sizeof(T) == 4) {
-    static const bool no_small = getenv("PEPSGPU_NO_SMALLJACOBI") != nullptr;
-    return len <= 256 && !no_small && (mdyn || m <= JR_SMALL_ROWS);
-  }
+  if constexpr (sizeof(T) == 4) return len <= 256 && (mdyn || m <= JR_SMALL_ROWS);
   return false;
 }
 
@@ -37,57 +34,43 @@ bool Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
   int small = 0;
   bool sel_used = false;
   if constexpr (sizeof(T) == 4) {
-    static const bool no_reg = getenv("PEPSGPU_NO_REGJACOBI") != nullptr;
-    // walkers whose block has at most 32 existing rows: one wave each (jacobi_rows_small_kernel);
-    // the kernels below return at once for those walkers
+    // walkers whose block has at most 32 existing rows: one wave each; the kernels below return at once for those walkers
     if (jacobi_small_ok(len, m, mdyn)) {
       small = 1;
-      static const bool no_tiny = getenv("PEPSGPU_NO_TINYJACOBI") != nullptr;
       // (small batches: giving every walker with <= 32 rows a wave of its own on the sixteen-lanes-per-row tournament -- four pairs
       // per instruction instead of the pairs of a walker one after the other -- was measured as a latency measure: one walker
       // 18.0 -> 19.6 ms per amplitude, 2048 walkers 34.4 -> 40.4 ms: the exchange rounds and the ranking prologue of that kernel
       // cost more than the shorter pair chain saves)
-      if (!no_tiny) {   // walkers with <= 16 rows first (low register count: all of them resident at once)
-        static const bool no_tiny2 = getenv("PEPSGPU_NO_TINY2JACOBI") != nullptr;
-        static const int tiny4 = getenv("PEPSGPU_TINY4") ? atoi(getenv("PEPSGPU_TINY4")) : 1;
-        if (len <= 64 && !no_tiny2 && tiny4)          // short rows (shrunk bonds): four walkers per wave, 16 lanes x 4 columns
-        {
-          hipLaunchKernelGGL((jacobi_rows_tiny4_kernel<4>), dim3((nw_ + 15) / 16), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
-                             sweeps_, mdyn, mdyn_mul, nw_, sel ? *sel : JrSelect());
-          sel_used = sel != nullptr;
-        }
-        else if (len <= 128 && !no_tiny2 && tiny4 == 1)   // ... 16 lanes x 8 columns
-        {
-          hipLaunchKernelGGL((jacobi_rows_tiny4_kernel<8>), dim3((nw_ + 15) / 16), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
-                             sweeps_, mdyn, mdyn_mul, nw_, sel ? *sel : JrSelect());
-          sel_used = sel != nullptr;
-        }
-        else if (len <= 128 && !no_tiny2)             // two walkers per wave (32 lanes x 4 columns)
-          hipLaunchKernelGGL(jacobi_rows_tiny2_kernel, dim3((nw_ + 7) / 8), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
-                             sweeps_, mdyn, mdyn_mul, nw_);
-        else
-          hipLaunchKernelGGL(jacobi_rows_tiny_kernel, dim3((nw_ + 3) / 4), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
-                             sweeps_, mdyn, mdyn_mul, nw_);
-        PG_CHECK_HIP(hipGetLastError());
-        if (m <= JR_BR || (rows_cap > 0 && rows_cap <= JR_BR)) return sel_used;
-      }
+      // walkers with <= 16 rows first (low register count: all of them resident at once)
+      if (len <= 64) {          // short rows (shrunk bonds): four walkers per wave, 16 lanes x 4 columns
+        hipLaunchKernelGGL((jacobi_rows_tiny4_kernel<4>), dim3((nw_ + 15) / 16), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
+                           sweeps_, mdyn, mdyn_mul, nw_, sel ? *sel : JrSelect());
+        sel_used = sel != nullptr;
+      } else if (len <= 128) {  // ... 16 lanes x 8 columns
+        hipLaunchKernelGGL((jacobi_rows_tiny4_kernel<8>), dim3((nw_ + 15) / 16), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
+                           sweeps_, mdyn, mdyn_mul, nw_, sel ? *sel : JrSelect());
+        sel_used = sel != nullptr;
+      } else
+        hipLaunchKernelGGL(jacobi_rows_tiny_kernel, dim3((nw_ + 3) / 4), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
+                           sweeps_, mdyn, mdyn_mul, nw_);
+      PG_CHECK_HIP(hipGetLastError());
+      if (m <= JR_BR || (rows_cap > 0 && rows_cap <= JR_BR)) return sel_used;
       // walkers with 17..32 rows: the sixteen-lanes-per-row tournament with one wave per walker (four players of two blocks of
-      // four rows, four pairs per wave instruction) or the one-pair-per-instruction kernel (PEPSGPU_GRP_POLISH=0); measured, jacobi
+      // four rows, four pairs per wave instruction) or, for short rows, the one-pair-per-instruction kernel; measured, jacobi
       // category per step of 4096 walkers: full-rank state 58.7 -> 54.6 ms, real state 515 -> 500 ms
-      static const int grp_polish = getenv("PEPSGPU_GRP_POLISH") ? atoi(getenv("PEPSGPU_GRP_POLISH")) : 1;
-      if (grp_polish && !no_tiny && len > 128)
+      if (len > 128)
         launch_jacobi_grp<1, 16>(stream_, nw_, (float *)M, wM, m, len, len, 40, sweeps_, mdyn, mdyn_mul, JR_BR, JR_SMALL_ROWS);
-      else if (grp_polish && !no_tiny && len > 64)
+      else if (len > 64)
         launch_jacobi_grp<1, 8>(stream_, nw_, (float *)M, wM, m, len, len, 40, sweeps_, mdyn, mdyn_mul, JR_BR, JR_SMALL_ROWS);
       else
         hipLaunchKernelGGL(jacobi_rows_small_kernel, dim3((nw_ + 3) / 4), dim3(256), 0, stream_, (float *)M, wM, m, len, len, 40,
-                           sweeps_, mdyn, mdyn_mul, nw_, no_tiny ? 0 : 1);
+                           sweeps_, mdyn, mdyn_mul, nw_, 1);
       PG_CHECK_HIP(hipGetLastError());
       if (m <= JR_SMALL_ROWS || (rows_cap > 0 && rows_cap <= JR_SMALL_ROWS)) return sel_used;
     }
     if (mid_hi && m <= mid_hi) return sel_used;        // every remaining walker is on the mid route
     const int skip = mid_hi ? mid_hi : small;          // rows <= max(skip, 32) are taken elsewhere
-    if (!use_lds && m <= 256 && len <= 256 && !no_reg) {
+    if (!use_lds && m <= 256 && len <= 256) {
       hipLaunchKernelGGL(jacobi_rows_reg256_kernel, dim3(nw_), dim3(512), 0, stream_, (float *)M, wM, m, len, len, 40,
                          sweeps_, mdyn, mdyn_mul, skip);
       PG_CHECK_HIP(hipGetLastError());
@@ -101,8 +84,7 @@ bool Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
   int skip_le = 0;
   if constexpr (std::is_same<T, double>::value) {
     // f64: walkers with at most JR_BR live rows of at most 128 elements in the register kernel (16 or 32 lanes per row)
-    static const bool no_t64 = getenv("PEPSGPU_NO_TINY_F64") != nullptr;
-    if (!no_t64 && len <= 128 && (mdyn || m <= JR_BR)) {
+    if (len <= 128 && (mdyn || m <= JR_BR)) {
       if (len <= 64)
         hipLaunchKernelGGL((jacobi_rows_tiny_f64_kernel<4, 16>), dim3((nw_ + 15) / 16), dim3(256), 0, stream_, (double *)M, wM, m, len, len,
                            40, sweeps_, mdyn, mdyn_mul, nw_);
@@ -121,8 +103,7 @@ bool Engine<T>::launch_jacobi(T *M, long wM, int m, int len, int use_lds, size_t
     allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), need);
   }
   // the static block does not fit LDS: 64 KB of dynamic LDS (two blocks per CU as before) for the walkers whose live rows do
-  static const bool no_dyn_lds = getenv("PEPSGPU_NO_JACOBI_DYN_LDS") != nullptr;
-  if (!use_lds && mdyn && !no_dyn_lds) {
+  if (!use_lds && mdyn) {
     // (136 KB at one block per CU for blocks like C5's 144 x 145 doubles was measured: C5 f64 2 273 -> 2 109 amp/s -- not adopted)
     constexpr int CAP = 64 * 1024;
     allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), (size_t)CAP);
@@ -168,7 +149,7 @@ void Engine<T>::absorb(int pos, int num) {
 
 template <typename T>
 typename Engine<T>::BMPSDev Engine<T>::absorb_svd(int pos, int num, const BMPSDev &in) {
-  static const bool no_shrink = getenv("PEPSGPU_NO_BOND_SHRINK") != nullptr;
+  constexpr bool no_shrink = false;
   ArenaScope scope(arena_);   // a throw inside returns every temporary and the half-built BMPS to the arena
   BMPSDev out;
   // A row whose hint-sized attempt had to be redone (its bonds grow faster than the margin: the first rows of a dense state)
@@ -214,7 +195,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
   const double *cur_log = in.logscale;
   // live bond dimensions of the absorbing BMPS (per walker, device) and of the one being built:
   // every contraction below runs over the live part of a bond only; persistent tensors stay zero padded
-  static const bool bond_adapt = getenv("PEPSGPU_NO_BOND_ADAPT") == nullptr && getenv("PEPSGPU_NO_RANK_ADAPT") == nullptr;
+  static const bool bond_adapt = true && getenv("PEPSGPU_NO_RANK_ADAPT") == nullptr;
   std::vector<int *> clive = in.live;
   clive.resize(N + 1, nullptr);
   if (!bond_adapt) std::fill(clive.begin(), clive.end(), nullptr);
@@ -233,7 +214,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
   };
   const int ll = (pos + 3) % 4, lp = pos, lr = (pos + 1) % 4, lu = (pos + 2) % 4;
   static const bool adaptive = getenv("PEPSGPU_NO_RANK_ADAPT") == nullptr;
-  static const int chain_chunks = getenv("PEPSGPU_CHAIN_CHUNKS") ? atoi(getenv("PEPSGPU_CHAIN_CHUNKS")) : 1;
+  constexpr int chain_chunks = 1;
   // error-budget experiments (scripts/error_budget.py): contractions of the f32 engine with float64 accumulation, by stage
   // (1: X / P, 2: Z1 / Tt, 4: M = R Tt, 8: Y = Tt V^T; the separate LDS-tiled launches on the f64 matrix cores)
   static const int acc64 = (sizeof(T) == 4 && getenv("PEPSGPU_ACC64")) ? atoi(getenv("PEPSGPU_ACC64")) : 0;
@@ -284,7 +265,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       int *chain_flag = nullptr;
       int chained = 0;
       if constexpr (sizeof(T) == 4) {
-        static const bool no_chain = getenv("PEPSGPU_NO_CHAIN") != nullptr;
+        constexpr bool no_chain = false;
         if (!no_chain && !(acc64 & 1)) {
           // both contractions in one launch, X stays in LDS; walkers whose live X does not fit are flagged and take the
           // two separate launches below
@@ -321,7 +302,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     // hint from the row absorbed before: its carry at the next site ran above the small rank cap of the factor kernels
     const bool hint_dense = in.depth >= 3 && (int)in.mlmax.size() > i + 1 && in.mlmax[i + 1] > 14;
     constexpr int FUSED_KCAP = sizeof(T) == 4 ? 96 : 48;   // rows of P a thread of the fused kernel holds in registers
-    static const bool no_fused = getenv("PEPSGPU_NO_FUSED_GRAMCHOL") != nullptr;
+    constexpr bool no_fused = false;
     if (rows < cols && adaptive && !no_fused && cols <= 256 && rows >= 16 && rows <= FUSED_KCAP) {
       // Fewer rows than columns, but already more rows than the usual numerical rank: compress now
       // (gram_chol_lowrank_kernel) instead of letting the carry grow by the factor u per site until it
@@ -368,7 +349,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       // factor covers (rank 32, 288 rows) -- the launches for the walkers it would flag (Gram, low-rank and blocked Cholesky:
       // ~66 us per site on an empty list) are not issued.  Verified after the absorption: a walker left flagged (ml < 0) fails
       // the attempt and the absorption is redone with every launch (absorb_svd), as for the other hints.
-      static const bool no_skip_fb = getenv("PEPSGPU_NO_SKIP_FALLBACK") != nullptr;
+      constexpr bool no_skip_fb = false;
       static const bool force_skip_fb = getenv("PEPSGPU_FORCE_SKIP_FALLBACK") != nullptr;     // tests: a wrong hint
       const bool skip_fb = fused && !full_bonds && !no_skip_fb && sizeof(T) == 4 &&
                            (force_skip_fb || (in.depth >= 3 && (int)in.mlmax.size() > i + 1 && in.mlmax[i] >= 0 && in.mlmax[i] <= 24 &&
@@ -376,7 +357,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       if (fused) {
         // more live rows than one pass holds (moderate rank): fold the rows of P in over up to four passes
         // (covers K <= KCAP + 3 (KCAP - 32) rows); walkers beyond that, or of rank > 32, are flagged
-        static const int max_pass = getenv("PEPSGPU_FUSED_PASSES") ? atoi(getenv("PEPSGPU_FUSED_PASSES")) : 4;
+        constexpr int max_pass = 4;
         const int npass = (mdyn[i] && rows > FUSED_KCAP) ? std::max(1, max_pass) : 1;
         prof_begin(PROF_CHOL, 0.0, 0.0);
         int *flist = (int *)arena_.alloc(sizeof(int) * (nw_ + 1));
@@ -388,7 +369,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       if (skip_fb) assume_fused[i + 1] = 1;
       else {
       G = (double *)arena_.alloc(sizeof(double) * (size_t)cols * cols * nw_);
-      static const bool no_gd = getenv("PEPSGPU_NO_GRAMDIRECT") != nullptr;
+      constexpr bool no_gd = false;
       const bool gram_direct = !no_gd && cols >= 32 && cols <= 256;
       if (clive[i + 1] && !gram_direct) {   // the Gram GEMM reads whole rows: define the never-written columns (flagged walkers only)
         hipLaunchKernelGGL(zero_dead_cols_kernel<T>, dim3(nw_), dim3(256), 0, stream_, P.p, P.n, cols, (const int *)mdyn[i],
@@ -419,7 +400,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       PG_REQUIRE(smem <= 150 * 1024 && cols < 32768, 1, "Cholesky panel does not fit LDS (D*chi too large)");
       allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
       prof_begin(PROF_CHOL, 0.0, 0.0);   // (executed flops of this category: the MFMA flops of the fused Gram kernels, counted on the device)
-      static const bool no_lowrank = getenv("PEPSGPU_NO_LOWRANK_CHOL") != nullptr;
+      constexpr bool no_lowrank = false;
       // (hint from the row absorbed before: when its carry at this site ran well above the cap, every walker would spend 32
       // steps here only to be handed on; the blocked kernel takes any rank)
       const bool above_cap = in.depth >= 3 && (int)in.mlmax.size() > i + 1 && in.mlmax[i + 1] > CH_LR_CAP + 8;
@@ -482,7 +463,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       precise_site = precise == 2 || (precise == 1 && (hinted ? in.mlmax[i] > 24 : (seen < 0 || seen > 24)));
     }
     // PEPSGPU_TT_ACC64: 1 (default) = the backward pair of a precise site on the float64-accumulating chained kernel, 0 = f32 (round 4)
-    static const int tt_mode = getenv("PEPSGPU_TT_ACC64") ? atoi(getenv("PEPSGPU_TT_ACC64")) : 1;
+    constexpr int tt_mode = 1;
     const bool tt_f64 = sizeof(T) == 4 && precise_site && tt_mode != 0;
     // Z1[a,p,l2,k2] = sum_{a2} A[a,p,a2] Y[l2,a2,k2]
     // Tt[l,a,u,k2] = sum_{p,l2} Z1[a,p,l2,k2] W[l,p,l2,u]
@@ -491,7 +472,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     // Layout of Tt (internal to this site step: written once, read by M = R Tt and by Y = Tt V^T): with the partially live
     // bond k2 innermost the live part of a (l, a) slice is u runs of k2_live floats (40 bytes in 64-byte requests); with the
     // full leg u innermost it is ONE run of k2_live * u floats.  Not at i == 0, where Tt becomes the first tensor (u, k2).
-    static const bool tt_swap = getenv("PEPSGPU_NO_TT_SWAP") == nullptr;
+    constexpr bool tt_swap = true;
     const bool tsw = tt_swap && i > 0 && sizeof(T) == 4;
     {
       TGemmDesc gz, gt;
@@ -516,7 +497,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       int *chain_flag = nullptr;
       int chained = 0;
       if constexpr (sizeof(T) == 4) {
-        static const bool no_chain = getenv("PEPSGPU_NO_CHAIN") != nullptr;
+        constexpr bool no_chain = false;
         if (!no_chain && !(acc64 & 2)) {   // Z1 stays in LDS (see the forward pair)
           chain_flag = (int *)arena_.alloc(sizeof(int) * nw_);
           TGemmDesc g2 = gt;
@@ -575,14 +556,14 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       g.dK[2].p = clive[i];
       g.dJ[2].p = kn[i + 1]; g.dJ[2].mask = 1;   // the Jacobi reads whole rows of M: dead columns are written as zeros
       // dense carry at this site (hint of the row absorbed before): the LDS-tiled kernel
-      static const bool no_tiled_hint = getenv("PEPSGPU_NO_TILED_HINT") != nullptr;
+      constexpr bool no_tiled_hint = false;
       dense_site = !no_tiled_hint && in.depth >= 3 && (int)in.mlmax.size() > i && in.mlmax[i] > 96 && la >= 128 && uk >= 128;
       g.prefer_tiled = dense_site;
       prof_begin(PROF_CONTRACT, 0.0, 2.0 * nw_ * (double)m * la * (double)uk);
       bool mg_done = false;
       if constexpr (sizeof(T) == 4) {
         // dense carry: the workgroup-per-walker kernel (mgemm_dense.h): R and Tt through LDS once, eight waves x 32 columns
-        static const bool no_mgd = getenv("PEPSGPU_NO_MGEMM_DENSE") != nullptr;
+        constexpr bool no_mgd = false;
         if (dense_site && !no_mgd && !(acc64 & 4) && m > 128 && mgemm_dense_ok(m, la, a, u, k2, R[i].n, Tt.n, R[i].p, Tt.p)) {
           launch_mgemm_dense(stream_, nw_, (const float *)R[i].p, R[i].n, (const float *)Tt.p, Tt.n, (float *)M.p, M.n, m, la, a, u, k2,
                              tsw ? 1 : 0, (const int *)mdyn[i], mmul[i], (const int *)clive[i], (const int *)kn[i + 1], tg_flop_counter,
@@ -610,7 +591,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     // numerically of rank ~60-100 at the f32 floor (the singular values of the truncation input fall by five orders of magnitude
     // over the first 32): the Cholesky of M M^T drops the dependent rows, the Jacobi runs on the <= 128 live rows of B (256 long)
     // instead of on the 240 rows of M (19 sweeps of the 256 x 256 register kernel: 80 % of the step before).
-    static const bool no_dense_mid = getenv("PEPSGPU_NO_DENSE_MID") != nullptr;
+    constexpr bool no_dense_mid = false;
     // hint from the row absorbed before: no walker came near 128 live rows at this site -> the route keeps its <= 128-row form
     // (walkers that do exceed 128 rows are then taken by the general kernels: time, never correctness)
     const bool hint_le128 = !full_bonds && in.depth >= 3 && (int)in.mlmax.size() > i && in.mlmax[i] >= 0 && in.mlmax[i] + 12 <= 128;
@@ -643,7 +624,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       PG_CHECK_HIP(hipGetLastError());
       Bt = alloc_ten(GS, GS, 1);
       prof_begin(PROF_TRUNC_GRAM, 0.0, 0.0);
-      static const bool no_fused_mid = getenv("PEPSGPU_NO_FUSED_MIDGRAM") != nullptr;
+      constexpr bool no_fused_mid = false;
       if constexpr (sizeof(T) == 4) {
         if (!no_fused_mid)   // G = M M^T and its Cholesky in one kernel, G resident in LDS (trunc_mid.h)
           launch_mid_gram_chol<T>(stream_, nw_, (const T *)M.p, M.n, uk, (const int *)nmid, (const int *)midflag, GS, Bt.p, Bt.n, mB);
@@ -668,8 +649,8 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         g.dI[2].p = nhi; g.dJ[2].p = nhi;
         g.upper_only = 1;
         g.batch_flag = hiflag;
-        static const bool no_rowgram = getenv("PEPSGPU_NO_ROWGRAM") != nullptr;
-        static const bool no_two_level = getenv("PEPSGPU_NO_TWO_LEVEL") != nullptr;
+        constexpr bool no_rowgram = false;
+        constexpr bool no_two_level = false;
         bool rowgram = false;
         if constexpr (sizeof(T) == 4) {
           if (!no_rowgram && uk % 16 == 0 && M.n % 4 == 0 && m <= 256) {   // streaming wave-per-block kernel (gram.h)
@@ -805,7 +786,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         }
         // (PEPSGPU_ROUTE_THRESH_SCALE: the pivot threshold of the first factorisation for EVERY walker, an experiment knob: fewer kept
         // rows = smaller Jacobi problems, priced by the guard)
-        static const double tscale = getenv("PEPSGPU_ROUTE_THRESH_SCALE") ? atof(getenv("PEPSGPU_ROUTE_THRESH_SCALE")) : 1.0;
+        constexpr double tscale = 1.0;
         launch_chol_upper<T>(stream_, nw_, Gm, (long)GSd * GSd, GSd, B1.p, B1.n, mB1, 0, GSd, (const int *)rowsM, 1, (const int *)nullptr, tscale);
         // Second chance for the walkers whose factor kept more than 128 rows (1-3 of 1 024 per site on the real state -- each of them
         // would otherwise cost a whole general Jacobi, ~40 ms per site whatever the batch): the Gram again (the factorisation works in
@@ -857,7 +838,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         count_on(0, nullptr);
         // The few walkers that leave here (1-3 of 1 024 per site with more than 128 rows, some tens at the edge sites) each cost a whole
         // general Jacobi from global memory, ~50 ms per site whatever the batch: it starts NOW on the side stream, beside the route.
-        static const bool no_side = getenv("PEPSGPU_NO_F64_ROUTE_SIDE") != nullptr;
+        constexpr bool no_side = false;
         if (!no_side) {
           early = (int *)arena_.alloc(sizeof(int) * nw_);
           fb_early = (int *)arena_.alloc(sizeof(int) * nw_);
@@ -957,7 +938,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         PG_CHECK_HIP(hipGetLastError());
         prof_end();
         // guard (f64_route_guard_kernel): a spectrum that falls to the resolution of a Gram inside the subspace leaves the route
-        static const double guard_tol = getenv("PEPSGPU_F64_ROUTE_TOL") ? atof(getenv("PEPSGPU_F64_ROUTE_TOL")) : 1e-10;
+        constexpr double guard_tol = 1e-10;
         hipLaunchKernelGGL(f64_route_guard_kernel<double>, dim3(nw_), dim3(256), 0, stream_, (const double *)Zt.p, Zt.n, uk, (const int *)kW, k_full,
                            guard_tol, rflag, kq, (const int *)lvl, 5.7e-14 * tscale * REDO_SCALE, 5.7e-14 * tscale * REDO_SCALE * REDO_SCALE,
                            5.7e-14 * tscale, tscale > 1.0 ? 1 : 0);
@@ -994,7 +975,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
         prof_begin(bulk ? PROF_JACOBI : PROF_JACOBI_EDGE, nw_ * (4.0 * rr * cc * cc + 22.0 * cc * cc * cc), 0.0);
       }
       JrSelect jsel;
-      static const bool no_jsel = getenv("PEPSGPU_NO_JACOBI_SELECT") != nullptr;
+      constexpr bool no_jsel = false;
       if constexpr (sizeof(T) == 4) {
         if (!no_jsel && kn[i]) { jsel.V = (float *)V.p; jsel.wV = V.n; jsel.k = k; jsel.klive_out = kn[i]; jsel.trunc_err = trunc_err_; jsel.dmin = chi_min_; }
       }
@@ -1003,7 +984,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       // a miss redoes the absorption without hints (absorb_svd).
       int rows_cap = 0;
       if constexpr (sizeof(T) == 4) {
-        static const bool no_hint_skip = getenv("PEPSGPU_NO_RANK_HINT_SKIP") != nullptr;
+        constexpr bool no_hint_skip = false;
         static const int force_cap = getenv("PEPSGPU_FORCE_ROWS_CAP") ? atoi(getenv("PEPSGPU_FORCE_ROWS_CAP")) : 0;   // tests: a wrong hint
         if (!full_bonds && !no_hint_skip && adaptive && mdyn[i] && !mid) {
           if (force_cap) rows_cap = force_cap;
@@ -1016,16 +997,8 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
                                jsel.V ? &jsel : nullptr, rows_cap);
       if constexpr (sizeof(T) == 4) {
         if (mid) {
-          // <= 64 live rows: two waves per walker, else four; rows of 16 lanes, four pairs per wave instruction
-          // (jacobi_rows_grp_kernel; PEPSGPU_NO_GRP_JACOBI=1: the 64-lanes-per-row tournament it replaced)
-          static const bool no_grp = getenv("PEPSGPU_NO_GRP_JACOBI") != nullptr;
-          if (no_grp) {
-            hipLaunchKernelGGL((jacobi_rows_regx_kernel<2, 2>), dim3(nw_), dim3(128), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS,
-                               40, sweeps_, (const int *)mB, 1, 0);
-            if (GS > 64)
-              hipLaunchKernelGGL((jacobi_rows_regx_kernel<4, 2>), dim3(nw_), dim3(256), 0, stream_, (float *)Bt.p, Bt.n, GS, GS, GS,
-                                 40, sweeps_, (const int *)mB, 1, 64);
-          } else if (GS <= 128) {
+          // <= 64 live rows: two waves per walker, else four; rows of 16 lanes, four pairs per wave instruction (jacobi_rows_grp_kernel)
+          if (GS <= 128) {
             launch_jacobi_grp<2, 8>(stream_, nw_, (float *)Bt.p, Bt.n, GS, GS, GS, 40, sweeps_, (const int *)mB, 1, 0);
             if (GS > 64) launch_jacobi_grp<4, 8>(stream_, nw_, (float *)Bt.p, Bt.n, GS, GS, GS, 40, sweeps_, (const int *)mB, 1, 64);
           } else if (two_level) {
@@ -1077,7 +1050,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     prof_begin(PROF_SELECT, 0.0, 0.0);
     // (behind the rank hint "no walker above 16 rows" the short-row Jacobi has selected every walker itself: the launch would
     // return at once for all of them -- 15 us x 160 sites per step of 49 152 walkers; a miss is caught by the same read-back)
-    static const bool no_sel_skip = getenv("PEPSGPU_NO_SELECT_SKIP") != nullptr;
+    constexpr bool no_sel_skip = false;
     const bool skip_select = sel_done && !mid && !no_sel_skip && assume_rows[i] > 0 && assume_rows[i] <= JR_BR;
     if (!skip_select)
       hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)M.p, M.n, m, uk, uk, k, V.p,
@@ -1191,7 +1164,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
     }
     free_ten(M);
     if constexpr (sizeof(T) == 4) {
-      static const int ortho = getenv("PEPSGPU_ORTHO_POLISH") ? atoi(getenv("PEPSGPU_ORTHO_POLISH")) : 1;
+      constexpr int ortho = 1;
       const size_t osm = ortho_rows_smem(k, uk);
       if (ortho && precise_site && k >= 2 && k <= 64 && osm <= 96 * 1024) {
         allow_dynamic_lds(reinterpret_cast<const void *>(&ortho_rows_kernel), osm);
@@ -1221,14 +1194,14 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       }
       g.dJ[2].p = kn[i]; g.dJ[2].mask = 1;
       g.prefer_tiled = dense_site;
-      static const bool y_tiled = getenv("PEPSGPU_Y_TILED") != nullptr;     // experiments: Y on the LDS-tiled f32 kernel
+      constexpr bool y_tiled = false;     // experiments: Y on the LDS-tiled f32 kernel
       if (y_tiled) g.prefer_tiled = true;
       // Y on precise sites: 2 = float64 accumulation on the LDS-tiled kernel (f64 matrix cores) + separate normalisation (round 4);
       // 1 = the wave-per-tile kernel with float64 accumulation (tg_direct_body_f64, round 5; the norm stays fused into the launch);
       // 0 = the f32 chain of round 3
       // (measured, round 5, real state at C4, n = 256 vs the f64 mode: mode 1 max 6.8e-6 / median 1.67e-6 at 2 235 amp/s (4 096
       // walkers), mode 2 8.0e-6 / 1.81e-6 at 2 200)
-      static const int y_mode = getenv("PEPSGPU_Y_ACC64") ? atoi(getenv("PEPSGPU_Y_ACC64")) : 1;
+      constexpr int y_mode = 1;
       bool y_f64 = false;
       if constexpr (sizeof(T) == 4) {
         g.acc64 = (precise_site && y_mode == 1) ? 1 : 0;
@@ -1245,7 +1218,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       // per-walker scale that the contraction reading Yn at the next site applies to its own result: no pass over Yn.
       bool fused_norm = false;
       if constexpr (sizeof(T) == 4) {
-        static const bool no_fn = getenv("PEPSGPU_NO_FUSED_NORM") != nullptr;
+        constexpr bool no_fn = false;
         if (!no_fn && !acc64 && !y_tiled && !y_f64 && bond_adapt && kn[i] && tgemm_one_block_direct(g)) {
           if (!yscale) yscale = (float *)arena_.alloc(sizeof(float) * nw_);
           g.scale_out = yscale; g.norm_log = out.logscale; g.norm_flag = flag_;

@@ -337,7 +337,7 @@ void Engine<T>::sweep_slice_impl(int mode, int orient, int slice, int n_uniform,
         PG_CHECK_HIP(hipGetLastError());
         // the left half of the replacement trace IS the next environment tensor of the walkers that accept the exchange (the same
         // kernel on the same operands): it is kept, and the growth step behind the Metropolis test runs for the others only
-        static const bool no_reuse = getenv("PEPSGPU_NO_SWEEP_REUSE") != nullptr;
+        constexpr bool no_reuse = false;
         const bool reuse = j + 2 < N && !no_reuse;
         Acc *res = nn_trace_device(r1, c1, orient, 1, dcand, &lsum, dsame, reuse ? &half : nullptr);
         hipLaunchKernelGGL(sweep_metropolis_exchange_kernel<Acc>, dim3(gb), dim3(256), 0, stream_, cfg_, sites, s1, s2, (const Acc *)res,

@@ -121,7 +121,7 @@ void Engine<T>::ein(const EinView<T> &a, const EinView<T> &b, const EinView<T> &
 // rows of M (m x len, contiguous) -> mutually orthogonal; the k rows of largest norm, normalised -> V (k x len);
 // optionally their norms -> S (k per walker)
 inline bool svd_rows_compresses(int m, int len) {
-  static const bool no_compress = getenv("PEPSGPU_NO_VAR_COMPRESS") != nullptr;
+  constexpr bool no_compress = false;
   return !no_compress && len <= 256 && m > 16;
 }
 
@@ -324,7 +324,7 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, cons
   // site i of the absorbing BMPS / of the result.  Contractions run over the live parts only (ein(): compact legs on
   // tensors only ein() reads, masked -- zeros written -- legs where a whole-row kernel or a persistent tensor follows);
   // every truncation returns the live count of the bond it made.  PEPSGPU_NO_VAR_ADAPT=1: static shapes throughout.
-  static const bool no_adapt_env = getenv("PEPSGPU_NO_VAR_ADAPT") != nullptr;
+  constexpr bool no_adapt_env = false;
   const bool no_adapt = no_adapt_env || kCplx;      // (the complex kernels have no live extents)
   std::vector<int *> il(in.live.begin(), in.live.end()), rl = res.live;
   il.resize(N + 1, nullptr);

@@ -253,7 +253,7 @@ inline void launch_gram_cols_f64(hipStream_t s, int nbatch, const T *P, long wP,
   if (nbatch <= 0 || n <= 0) return;
   PG_REQUIRE(nbatch <= 65535, 1, "walker batch exceeds 65535 (grid y limit)");
   if constexpr (sizeof(T) == 4) {
-    static const bool no_lds_gram = getenv("PEPSGPU_NO_LDS_GRAM") != nullptr;
+    constexpr bool no_lds_gram = false;
     // dense walkers (hint of the caller: kmax rows, 193..256 columns = four 64-column blocks): P through LDS once per walker
     if (!no_lds_gram && n > 192 && n <= 256 && ld % 4 == 0 && wP % 4 == 0 && (((uintptr_t)P) & 15) == 0 && kmax >= 256) {
       // round 4: the same Gram as exact integer arithmetic on the i8 matrix cores (gram_i8.h), PEPSGPU_NO_I8_GRAM=1 for the f64 form
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void gram_rows_f64_kernel(const T *__restri
 
 inline bool gram_rows_i8_ok(const void *M, int nmax) {
   // round 4: exact integer arithmetic on the i8 matrix cores (gram_i8.h, ROWS form), PEPSGPU_NO_I8_GRAM=1 for the f64 form
-  static const bool no_i8_gram = getenv("PEPSGPU_NO_I8_GRAM") != nullptr || getenv("PEPSGPU_NO_I8_ROWGRAM") != nullptr;
+  static const bool no_i8_gram = getenv("PEPSGPU_NO_I8_GRAM") != nullptr || false;
   return !no_i8_gram && nmax > 128 && nmax <= 256 && (((uintptr_t)M) & 15) == 0;
 }
 

@@ -382,210 +382,8 @@ __device__ __forceinline__ int jrx_apply(JrRowT<CPL> &x, JrRowT<CPL> &y, float &
   return go ? 1 : 0;
 }
 
-template <int NW, int CPL>
-__global__ __launch_bounds__(NW * 64) void jacobi_rows_regx_kernel(float *__restrict__ Mg, long wM, int m, int len, int ld,
-                                                                   int max_sweeps, int *__restrict__ sweeps_out,
-                                                                   const int *__restrict__ mdyn, int mdyn_mul,
-                                                                   int lo_rows = 0) {
-  // lo_rows: walkers with at most lo_rows rows belong to a narrower instantiation launched beside this one
-  constexpr int SLOTS = NW + 1, MAXR = NW * 2 * JR_BR, NT = NW * 64;
-  __shared__ float xch[SLOTS][JR_BR][CPL][64];
-  __shared__ float xnorm[SLOTS][JR_BR];
-  __shared__ float s_n2[MAXR];
-  __shared__ short s_perm[MAXR];
-  __shared__ double s_fro[NW];
-  __shared__ int s_rot, s_live0;
-  if (mdyn) m = max(0, min(m, mdyn[blockIdx.x] * mdyn_mul));
-  if (m <= lo_rows || m > MAXR) return;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  float *M = Mg + (long)blockIdx.x * wM;
-  if (tid == 0) s_live0 = 0;
-  for (int r = w; r < MAXR; r += NW) {
-    float n2 = 0.f;
-    if (r < m) {
-#pragma unroll
-      for (int q = 0; q < CPL; ++q) {
-        const int c = CPL * lane + q;
-        const float v = c < len ? M[(long)r * ld + c] : 0.f;
-        n2 = fmaf(v, v, n2);
-      }
-    }
-    n2 = jr_allsum(n2);
-    if (lane == 0) s_n2[r] = n2;
-  }
-  __syncthreads();
-  {
-    double f = 0.0;
-    for (int r = tid; r < MAXR; r += NT) f += (double)s_n2[r];
-    f = wave_sum(f);
-    if (lane == 0) s_fro[w] = f;
-    __syncthreads();
-    if (tid == 0) { double t = 0.0; for (int k = 0; k < NW; ++k) t += s_fro[k]; s_fro[0] = t; }
-    __syncthreads();
-  }
-  const float floor2 = (float)(NOISE_C * NOISE_C * (double)Eps<float>::v * (double)Eps<float>::v * s_fro[0]);
-  const float tol2 = 4.f * (float)len * Eps<float>::v * Eps<float>::v;
-  for (int r = tid; r < MAXR; r += NT) {
-    const float v = s_n2[r];
-    int rk = 0;
-    for (int q = 0; q < MAXR; ++q) {
-      const float u = s_n2[q];
-      rk += (u > v) || (u == v && q < r);
-    }
-    s_perm[rk] = (short)r;
-    if (v > floor2) atomicAdd(&s_live0, 1);
-  }
-  __syncthreads();
-  const int live0 = s_live0;
-  const int nbl = (live0 + JR_BR - 1) / JR_BR;
-  const int nwv = nbl <= 2 ? 1 : (nbl + 1) / 2;
-  const bool active = w < nwv;
-
-  JrRowT<CPL> a[JR_BR], b[JR_BR];
-  float na[JR_BR], nb[JR_BR];
-  auto load_block = [&](JrRowT<CPL>(&blk)[JR_BR], int bid) {
-#pragma unroll
-    for (int i = 0; i < JR_BR; ++i) {
-      const int pos = bid * JR_BR + i;
-      const int r = (active && pos < nbl * JR_BR) ? (int)s_perm[pos] : m;
-#pragma unroll
-      for (int q = 0; q < CPL; ++q) {
-        const int c = CPL * lane + q;
-        blk[i].set(q, (r < m && c < len) ? M[(long)r * ld + c] : 0.f);
-      }
-    }
-  };
-  load_block(a, w);
-  load_block(b, nwv + w);
-
-  int sweep = 0;
-  for (; sweep < max_sweeps; ++sweep) {
-    if (tid == 0) s_rot = 0;
-#pragma unroll
-    for (int i = 0; i < JR_BR; ++i) {
-      na[i] = jr_allsum(jrx_dot<CPL>(a[i], a[i]));
-      nb[i] = jr_allsum(jrx_dot<CPL>(b[i], b[i]));
-    }
-    int rot = 0;
-#pragma unroll 1
-    for (int r = 0; r < (active ? JR_BR - 1 : 0); ++r) {
-      float ga[JR_BR / 2], gb[JR_BR / 2];
-#pragma unroll
-      for (int p = 0; p < JR_BR / 2; ++p) {
-        ga[p] = jr_allsum(jrx_dot<CPL>(a[p], a[JR_BR - 1 - p]));
-        gb[p] = jr_allsum(jrx_dot<CPL>(b[p], b[JR_BR - 1 - p]));
-      }
-#pragma unroll
-      for (int p = 0; p < JR_BR / 2; ++p) {
-        rot += jrx_apply<CPL>(a[p], a[JR_BR - 1 - p], na[p], na[JR_BR - 1 - p], ga[p], tol2, floor2);
-        rot += jrx_apply<CPL>(b[p], b[JR_BR - 1 - p], nb[p], nb[JR_BR - 1 - p], gb[p], tol2, floor2);
-      }
-      {
-        const JrRowT<CPL> ta = a[JR_BR - 1], tb = b[JR_BR - 1];
-        const float fa = na[JR_BR - 1], fb = nb[JR_BR - 1];
-#pragma unroll
-        for (int i = JR_BR - 1; i >= 2; --i) { a[i] = a[i - 1]; b[i] = b[i - 1]; na[i] = na[i - 1]; nb[i] = nb[i - 1]; }
-        a[1] = ta; b[1] = tb; na[1] = fa; nb[1] = fb;
-      }
-    }
-    __syncthreads();
-    for (int sr = 0; sr < 2 * nwv - 1; ++sr) {
-      float mxa = na[0], mxb = nb[0];
-#pragma unroll
-      for (int i = 1; i < JR_BR; ++i) { mxa = fmaxf(mxa, na[i]); mxb = fmaxf(mxb, nb[i]); }
-      const bool live = active && mxa > floor2 && mxb > floor2;
-#pragma unroll 1
-      for (int t = 0; t < (live ? JR_BR : 0); ++t) {
-        float g[JR_BR];
-#pragma unroll
-        for (int i = 0; i < JR_BR; ++i) g[i] = jr_allsum(jrx_dot<CPL>(a[i], b[i]));
-#pragma unroll
-        for (int i = 0; i < JR_BR; ++i) rot += jrx_apply<CPL>(a[i], b[i], na[i], nb[i], g[i], tol2, floor2);
-        {
-          const JrRowT<CPL> tb = b[0];
-          const float fb = nb[0];
-#pragma unroll
-          for (int i = 0; i < JR_BR - 1; ++i) { b[i] = b[i + 1]; nb[i] = nb[i + 1]; }
-          b[JR_BR - 1] = tb; nb[JR_BR - 1] = fb;
-        }
-      }
-      if (nwv == 1) continue;
-      if (active) {
-#pragma unroll
-        for (int i = 0; i < JR_BR; ++i)
-#pragma unroll
-          for (int q = 0; q < CPL; ++q) xch[w][i][q][lane] = b[i].get(q);
-        if (lane == 0) {
-#pragma unroll
-          for (int i = 0; i < JR_BR; ++i) xnorm[w][i] = nb[i];
-        }
-        if (w == nwv - 1) {
-#pragma unroll
-          for (int i = 0; i < JR_BR; ++i)
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) xch[nwv][i][q][lane] = a[i].get(q);
-          if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < JR_BR; ++i) xnorm[nwv][i] = na[i];
-          }
-        }
-      }
-      __syncthreads();
-      if (active) {
-        const int src = (w == nwv - 1) ? nwv : w + 1;
-#pragma unroll
-        for (int i = 0; i < JR_BR; ++i) {
-#pragma unroll
-          for (int q = 0; q < CPL; ++q) b[i].set(q, xch[src][i][q][lane]);
-          nb[i] = xnorm[src][i];
-        }
-      }
-      __syncthreads();
-      if (active && w >= 1 && w <= nwv - 2) {
-#pragma unroll
-        for (int i = 0; i < JR_BR; ++i)
-#pragma unroll
-          for (int q = 0; q < CPL; ++q) xch[w][i][q][lane] = a[i].get(q);
-        if (lane == 0) {
-#pragma unroll
-          for (int i = 0; i < JR_BR; ++i) xnorm[w][i] = na[i];
-        }
-      }
-      __syncthreads();
-      if (active && w >= 1) {
-        const int src = w - 1;
-#pragma unroll
-        for (int i = 0; i < JR_BR; ++i) {
-#pragma unroll
-          for (int q = 0; q < CPL; ++q) a[i].set(q, xch[src][i][q][lane]);
-          na[i] = xnorm[src][i];
-        }
-      }
-      __syncthreads();
-    }
-    if (lane == 0 && rot) atomicAdd(&s_rot, rot);
-    __syncthreads();
-    const int total = s_rot;
-    __syncthreads();
-    if (total == 0) { ++sweep; break; }
-  }
-  auto store_block = [&](JrRowT<CPL>(&blk)[JR_BR], int bid) {
-#pragma unroll
-    for (int i = 0; i < JR_BR; ++i) {
-      const int pos = bid * JR_BR + i;
-      const int r = (active && pos < nbl * JR_BR) ? (int)s_perm[pos] : m;
-#pragma unroll
-      for (int q = 0; q < CPL; ++q) {
-        const int c = CPL * lane + q;
-        if (r < m && c < len) M[(long)r * ld + c] = blk[i].get(q);
-      }
-    }
-  };
-  store_block(a, w);
-  store_block(b, nwv + w);
-  if (tid == 0 && sweeps_out) sweeps_out[blockIdx.x] = sweep | (live0 << 8);
-}
-
+// (the 64-lanes-per-row tournament kernel of round 3, jacobi_rows_regx_kernel, was replaced by the sixteen-lanes-per-row form below
+// and removed in round 6; the row type and the pair helpers above are shared with it)
 
 // ---------------------------------------------------------------------------------------------
 // The mid-route tournament with SIXTEEN LANES PER ROW.  The rows of the triangular factor are at most 128 long: spread over
@@ -1001,103 +799,9 @@ __global__ __launch_bounds__(256, 3) void jacobi_rows_tiny_kernel(float *__restr
 }
 
 
-// Two walkers per wave: with shrunk bonds the rows are short (len <= 128 = 32 lanes x 4), so each half-wave
-// holds one walker's block of 16 rows; dot products reduce over 32 lanes (no permlane32 step).  Everything per
-// row (norms, rotation parameters) is per half-wave; the loops are wave-uniform and run until both walkers
-// have converged (a converged walker only sees identity rotations).
-__device__ __forceinline__ float jr_allsum32(float v) {
-  v = jr_dpp_add<0xB1>(v);
-  v = jr_dpp_add<0x4E>(v);
-  v = jr_dpp_add<0x141>(v);
-  v = jr_dpp_add<0x140>(v);
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  const auto p = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  return __builtin_bit_cast(float, (unsigned)p[0]) + __builtin_bit_cast(float, (unsigned)p[1]);
-}
-
-template <int NB>
-__device__ __forceinline__ int jr_intra32(JrRow (&a)[JR_BR], float (&na)[JR_BR], const float tol2, const float floor2) {
-  int rot = 0;
-#pragma unroll 1
-  for (int r = 0; r < NB - 1; ++r) {
-    float ga[NB / 2];
-#pragma unroll
-    for (int p = 0; p < NB / 2; ++p) ga[p] = jr_allsum32(jr_dot(a[p], a[NB - 1 - p]));
-#pragma unroll
-    for (int p = 0; p < NB / 2; ++p) rot += jr_apply(a[p], a[NB - 1 - p], na[p], na[NB - 1 - p], ga[p], tol2, floor2);
-    const JrRow ta = a[NB - 1];
-    const float fa = na[NB - 1];
-#pragma unroll
-    for (int i = NB - 1; i >= 2; --i) { a[i] = a[i - 1]; na[i] = na[i - 1]; }
-    a[1] = ta; na[1] = fa;
-  }
-  return rot;
-}
-
-__global__ __launch_bounds__(256, 3) void jacobi_rows_tiny2_kernel(float *__restrict__ Mg, long wM, int m, int len, int ld,
-                                                                   int max_sweeps, int *__restrict__ sweeps_out,
-                                                                   const int *__restrict__ mdyn, int mdyn_mul, int nwalkers) {
-  const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
-  const int walker = blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + half;
-  const bool have = walker < nwalkers;
-  int mm = have ? (mdyn ? max(0, min(m, mdyn[walker] * mdyn_mul)) : m) : 0;
-  if (mm > JR_BR) mm = 0;                                     // the 32-row / 8-wave kernels take this walker
-  const int mm_max = max(mm, __shfl_xor(mm, 32, 64));         // wave-uniform
-  if (mm_max == 0) return;
-  float *M = Mg + (long)(have ? walker : 0) * wM;
-  JrRow a[JR_BR];
-  float na[JR_BR];
-  float fro = 0.f;
-#pragma unroll
-  for (int i = 0; i < JR_BR; ++i) {
-    float v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = 4 * l32 + q;
-      v[q] = (i < mm && c < len) ? M[(long)i * ld + c] : 0.f;
-    }
-    a[i].lo = jr_f2{v[0], v[1]};
-    a[i].hi = jr_f2{v[2], v[3]};
-  }
-#pragma unroll
-  for (int i = 0; i < JR_BR; ++i) {
-    na[i] = jr_allsum32(jr_dot(a[i], a[i]));
-    fro += na[i];
-  }
-  const float floor2 = (float)(NOISE_C * NOISE_C * (double)Eps<float>::v * (double)Eps<float>::v) * fro;
-  const float tol2 = 4.f * (float)len * Eps<float>::v * Eps<float>::v;
-  int sweep = 0;
-  for (; sweep < max_sweeps; ++sweep) {
-    if (sweep) {
-#pragma unroll
-      for (int i = 0; i < JR_BR; ++i)
-        if (i < mm_max) na[i] = jr_allsum32(jr_dot(a[i], a[i]));     // rows beyond both walkers' counts are zero
-    }
-    int rot;
-    if (mm_max <= 6) rot = jr_intra32<6>(a, na, tol2, floor2);
-    else if (mm_max <= 8) rot = jr_intra32<8>(a, na, tol2, floor2);
-    else if (mm_max <= 10) rot = jr_intra32<10>(a, na, tol2, floor2);
-    else if (mm_max <= 12) rot = jr_intra32<12>(a, na, tol2, floor2);
-    else if (mm_max <= 14) rot = jr_intra32<14>(a, na, tol2, floor2);
-    else rot = jr_intra32<JR_BR>(a, na, tol2, floor2);
-    if (!__any(rot != 0)) { ++sweep; break; }
-  }
-#pragma unroll
-  for (int i = 0; i < JR_BR; ++i) {
-    const float v[4] = {a[i].lo.x, a[i].lo.y, a[i].hi.x, a[i].hi.y};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = 4 * l32 + q;
-      if (i < mm && c < len) M[(long)i * ld + c] = v[q];
-    }
-  }
-  if (l32 == 0 && mm > 0 && sweeps_out) sweeps_out[walker] = sweep | (mm << 8);
-}
-
-
 // Four walkers per wave: a row of at most 128 elements lives in one DPP row of 16 lanes (CPL = 8 columns per lane, 4 when
 // len <= 64), a dot product ends with four DPP steps inside the lane group and every wave instruction works on four
-// walkers' pairs at once (the two-walker kernel above: five steps, two walkers).  Same rotation, threshold and noise floor.
+// walkers' pairs at once (the two-walkers-per-wave kernel it replaced, removed in round 6: five steps, two walkers).  Same rotation, threshold and noise floor.
 template <int NB, int CPL>
 __device__ __forceinline__ int jr_intra16(JrRowT<CPL> (&a)[JR_BR], float (&na)[JR_BR], const float tol2, const float floor2) {
   int rot = 0;

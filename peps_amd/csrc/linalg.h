@@ -538,303 +538,19 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
   for (int e = tid + mlive * n; e < n * n; e += 256) Rout[(long)(e / n) * ldg + (e % n)] = T(0);
 }
 
-// ---------------------------------------------------------------------------------------------
-// The same factorisation once more (same pivot rule, same output contract, same signature) with the TRAILING MATRIX RESIDENT IN
-// REGISTERS (round 5).  The left-looking kernel above re-reads the finished factor rows for every panel: 1.39 MB per order-256
-// walker from L2 / MALL / HBM (10.9 GB per launch of 8192 walkers, 76 % of its wave cycles waiting), with three blocks per CU to
-// hide the pivot chain.  Here ONE 512-thread block per CU holds the upper triangle of G as 136 tiles of 16 x 16 in the accumulator
-// layout of v_mfma_f64_16x16x4_f64 (wave 0: the 16 diagonal tiles, waves 1-7: the 120 others, round robin in row order; 8 VGPRs a
-// tile), reads G ONCE (263 KB per walker) and writes only the factor.  Right-looking, per panel p of 16 rows, three barriers:
-//   A  the owners lay the block row down in LDS (16 x n doubles);
-//   C  forward substitution of the block row against the diagonal factor, one thread per column;
-//   D  every tile below the block row takes  S_IJ -= X_I^T X_J : four MFMAs, both operands read from the LDS block row (uniform
-//      if-chain over the slots: a jump table made the compiler copy the 144 accumulator registers at the joins -- 143 spills);
-//      the finished rows go out as type T with their squared norms;
-//   B  the 16 x 16 diagonal block of panel p + 1 is factored by wave 0 INSIDE D(p), right after its own update of that tile
-//      (look-ahead: the 16 dependent pivots run under the other waves' matrix work).
-// Orders 129 .. 256.  Opt-in (PEPSGPU_CHOL_RESIDENT, see launch_chol_upper): measured per block of order 256, phases switched off one at
-// a time (instrumentation removed afterwards): 181 us = G load 5 + pivot chains 34 + substitutions 33 + trailing MFMAs 21 + output rows 17 + the rest (barriers, LDS staging,
-// start-up) ~ 70; the phases add up -- nothing overlaps with one block per CU -- where the left-looking kernel hides them behind two
-// other blocks.  HISTORY (round 5, item 11) has the account.
-constexpr int CR_NS = 256 + 8;          // LDS row stride of the block row: the four rows of one k-step fall on four different bank groups
-constexpr int CR_SLOTS = 18;            // tiles per wave: 16 diagonal ones (wave 0) or ceil(120 / 7) = 18 others
-
-template <typename T>
-__global__ __launch_bounds__(512) void chol_resident_kernel(const double *__restrict__ Gg, long wG, int n,
-                                                            T *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
-                                                            int only_flagged = 0, int ld = 0,
-                                                            const int *__restrict__ ndyn = nullptr, int ndyn_mul = 1,
-                                                            const int *__restrict__ run_flag = nullptr, double thresh_scale = 1.0) {
-  if (only_flagged && mlive_out[blockIdx.x] >= 0) return;
-  if (run_flag && run_flag[blockIdx.x] >= 0) return;
-  const int ldg = ld ? ld : n;
-  const int nfull = n;
-  if (ndyn) n = max(0, min(n, ndyn[blockIdx.x] * ndyn_mul));
-  __shared__ double sP[CH_NB][CR_NS];              // the block row
-  __shared__ double sN[256];                       // squared norms of the finished rows
-  __shared__ short sPos[256];
-  __shared__ double sD[CH_NB][CH_NB + 1], sDinv[CH_NB];
-  __shared__ double sDg[CH_NB][CH_NB + 1];         // wave 0: the diagonal tile on its way from the accumulator layout to one column per lane
-  __shared__ double s_maxd, s_fro;
-  __shared__ double s_red[8];
-  __shared__ int s_nlive;
-  __shared__ unsigned s_livemask;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i16 = lane & 15, k4 = lane >> 4;
-  const double *G = Gg + (long)blockIdx.x * wG;
-  T *Rout = Rg + (long)blockIdx.x * wR;
-  const int NT = (n + 15) >> 4;
-
-  // ---- tiles of this wave: (tI[s], tJ[s]), -1 = empty slot; loaded once ----
-  int tI[CR_SLOTS], tJ[CR_SLOTS];
-  chb_f64x4 acc[CR_SLOTS];
-  double md = 0.0;
-#pragma unroll
-  for (int s = 0; s < CR_SLOTS; ++s) {
-    int I = -1, J = -1;
-    if (wave == 0) { if (s < 16) I = J = s; }
-    else {
-      int t = (wave - 1) + 7 * s;
-      if (t < 120) { I = 0; while (t >= 15 - I) { t -= 15 - I; ++I; } J = I + 1 + t; }
-    }
-    if (J >= NT) I = J = -1;
-    tI[s] = I; tJ[s] = J;
-  }
-  // (the loads in a loop of their own, unconditional at clamped addresses: next to the index loops above they were waited for slot by
-  // slot -- 33 of the 208 us of a block, measured with the load switched off)
-#pragma unroll
-  for (int s = 0; s < CR_SLOTS; ++s) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * tI[s] + k4 + 4 * r, col = 16 * tJ[s] + i16;
-      const bool ok = tI[s] >= 0 && row < n && col < n && col >= row;
-      const long off = ok ? (long)row * ldg + col : 0;
-      const double g = G[off];
-      acc[s][r] = ok ? g : 0.0;
-    }
-  }
-#pragma unroll
-  for (int s = 0; s < CH_NB; ++s)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (wave == 0 && tI[s] >= 0 && k4 + 4 * r == i16) md = fmax(md, acc[s][r]);     // the diagonal lives in wave 0
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
-  if (lane == 0) s_red[wave] = md;
-  if (tid == 0) s_nlive = 0;
-  __syncthreads();
-  if (tid == 0) s_maxd = s_red[0];                 // (the diagonal lives in wave 0)
-  __syncthreads();
-  const double maxd = s_maxd;
-  const double eT = NOISE_C * eps_rt<T>();
-  const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd * thresh_scale;
-  const double sc_out = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
-  const int wout = ndyn ? ldg : n;
-
-  // wave 0: bring diagonal tile q up to date with block row q - 1 (upd), then factor it (look-ahead): 16 dependent pivots in registers,
-  // one column per lane -> sD, sDinv, s_livemask of panel q
-  auto diag_factor = [&](int q, bool upd) {
-#pragma unroll
-    for (int s = 0; s < CH_NB; ++s)
-      if (s == q) {
-        if (upd) {
-          const int ca = 16 * s + i16;
-#pragma unroll
-          for (int k0 = 0; k0 < CH_NB; k0 += 4) {
-            const double a = -sP[k0 + k4][ca], b = sP[k0 + k4][ca];
-            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[s], 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sDg[k4 + 4 * r][i16] = acc[s][r];
-      }
-    const int nbq = min(CH_NB, n - 16 * q);
-
-      double d[CH_NB];
-#pragma unroll
-      for (int c = 0; c < CH_NB; ++c) d[c] = (lane < nbq && c <= lane) ? sDg[c][lane] : 0.0;
-      unsigned livemask = 0;
-#pragma unroll
-      for (int c = 0; c < CH_NB; ++c) {
-        const double piv = chb_readlane(d[c], c);
-        const bool live = c < nbq && piv > thresh;             // wave-uniform
-        const double pv = live ? piv : 1.0;
-        double sc = __builtin_amdgcn_rsq(pv);                 // ~2^-26 relative; two Newton steps -> float64
-        sc = sc * (1.5 - 0.5 * pv * sc * sc);
-        sc = sc * (1.5 - 0.5 * pv * sc * sc);
-        d[c] = live ? d[c] * sc : 0.0;
-#pragma unroll
-        for (int c2 = c + 1; c2 < CH_NB; ++c2) {
-          const double f = chb_readlane(d[c], c2);
-          d[c2] -= f * d[c];
-        }
-        livemask |= live ? 1u << c : 0u;
-      }
-#pragma unroll
-      for (int c = 0; c < CH_NB; ++c)
-        if (lane < CH_NB) sD[c][lane] = lane >= c ? d[c] : 0.0;
-      if (lane < CH_NB) {
-        double dg = 0.0;
-#pragma unroll
-        for (int c = 0; c < CH_NB; ++c) dg = lane == c ? d[c] : dg;
-        double iv = __builtin_amdgcn_rcp(dg);
-        iv = iv * (2.0 - dg * iv);
-        iv = iv * (2.0 - dg * iv);
-        sDinv[lane] = ((livemask >> lane) & 1u) ? iv : 0.0;
-      }
-      if (lane == 0) s_livemask = livemask;
-      };
-  if (wave == 0 && NT > 0) diag_factor(0, false);
-
-  for (int p = 0; p < NT; ++p) {
-    const int jb = 16 * p, nb = min(CH_NB, n - jb);
-    // ---- A: the block row into LDS ----
-#pragma unroll
-    for (int s = 0; s < CR_SLOTS; ++s)
-      if (tI[s] == p && wave != 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sP[k4 + 4 * r][16 * tJ[s] + i16] = acc[s][r];
-      }
-    __syncthreads();
-    const unsigned livemask = s_livemask;
-    const int nprev = s_nlive;
-    // ---- C: the rest of the block row: forward substitution per column; the block's own columns take the factor ----
-    {
-      const int r = jb + tid;
-      if (r < n) {
-        if (tid < CH_NB) {
-#pragma unroll
-          for (int c = 0; c < CH_NB; ++c) sP[c][r] = sD[c][tid];
-        } else {
-          double v[CH_NB];
-#pragma unroll
-          for (int c = 0; c < CH_NB; ++c) v[c] = sP[c][r];
-#pragma unroll
-          for (int c1 = 0; c1 < CH_NB; ++c1) {
-            const double x = v[c1] * sDinv[c1];    // dropped row: sDinv = 0
-            sP[c1][r] = x;
-#pragma unroll
-            for (int c = c1 + 1; c < CH_NB; ++c) v[c] -= sD[c1][c] * x;
-            __asm__ volatile("" ::: "memory");
-          }
-        }
-      }
-    }
-    __syncthreads();
-    // ---- D: trailing update from the LDS block row ----
-    if (wave == 0 && p + 1 < NT) diag_factor(p + 1, true);
-    const int plim = wave == 0 ? p + 1 : p;
-#pragma unroll
-    for (int s = 0; s < CR_SLOTS; ++s)
-      if (tI[s] > plim) {
-        const int ca = 16 * tI[s] + i16, cb = 16 * tJ[s] + i16;
-#pragma unroll
-        for (int k0 = 0; k0 < CH_NB; k0 += 4) {
-          const double a = -sP[k0 + k4][ca], b = sP[k0 + k4][cb];
-          acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[s], 0, 0, 0);
-        }
-      }
-    // the finished rows: scaled, as type T, at their provisional position (rank in the live list); squared norms for the compaction
-    for (int c = wave; c < nb; c += 8) {
-      if (!((livemask >> c) & 1u)) continue;
-      const int pos = nprev + __popc(livemask & ((1u << c) - 1u));
-      double a = 0.0;
-      for (int r = lane; r < wout; r += 64) {
-        const double x = (r >= jb + c && r < n) ? sP[c][r] : 0.0;
-        a += x * x;
-        Rout[(long)pos * ldg + r] = T(x * sc_out);
-      }
-      a = wave_sum(a);
-      if (lane == 0) sN[pos] = a;
-    }
-    if (tid == 0) s_nlive = nprev + __popc(livemask);
-    __syncthreads();
-  }
-  // ---- rank compaction: rows with norm below NOISE_C*eps_T*|R|_F are dropped (as the kernels above) ----
-  const int nfac = s_nlive;
-  {
-    double f = 0.0;
-    for (int q = tid; q < nfac; q += 512) f += sN[q];
-    f = wave_sum(f);
-    if (lane == 0) s_red[wave] = f;
-    __syncthreads();
-    if (tid == 0) { double t = 0.0; for (int w = 0; w < 8; ++w) t += s_red[w]; s_fro = t; }
-    __syncthreads();
-  }
-  const double nfloor = eT * eT * s_fro;
-  if (wave == 0) {
-    int cnt = 0;
-    for (int base = 0; base < nfac; base += 64) {
-      const int q = base + lane;
-      const bool f = q < nfac && sN[q] > nfloor;
-      const unsigned long long mask = __ballot(f);
-      if (q < nfac) sPos[q] = f ? (short)(cnt + __popcll(mask & ((1ull << lane) - 1ull))) : (short)-1;
-      cnt += __popcll(mask);
-    }
-    if (lane == 0) { s_nlive = cnt; if (mlive_out) mlive_out[blockIdx.x] = cnt; }
-  }
-  __syncthreads();
-  const int mlive = s_nlive;
-  if (mlive != nfac) {
-    const int wrow = ndyn ? ldg : n;
-    for (int q = 0; q < nfac; ++q) {
-      const int pos = sPos[q];
-      if (pos >= 0 && pos != q)
-        for (int r = tid; r < wrow; r += 512) Rout[(long)pos * ldg + r] = Rout[(long)q * ldg + r];
-      __syncthreads();
-    }
-  }
-  if (mlive_out) return;
-  (void)nfull;
-  for (int e = tid + mlive * n; e < n * n; e += 512) Rout[(long)(e / n) * ldg + (e % n)] = T(0);
-}
-
-// launch of the blocked factorisation: the MFMA form above for orders >= 48 (PEPSGPU_OLD_CHOL=1: always the older kernel)
+// launch of the blocked factorisation: the MFMA form above for orders >= 48, chol_upper_kernel below that.
+// (Measured and removed in round 6, numbers in HISTORY.md: the register-resident kernel of round 5 -- 181 us per block of order 256
+// against 452, but one block per CU against three: 4.57 ms against 3.67 ms per launch of 8192 walkers --, four / two blocks per CU, and
+// three / five / eight k-steps of the panel update in flight.)
 template <typename T>
 inline void launch_chol_upper(hipStream_t s, int nbatch, double *G, long wG, int n, T *R, long wR, int *mlive_out, int only_flagged = 0,
                               int ld = 0, const int *ndyn = nullptr, int ndyn_mul = 1, const int *run_flag = nullptr, double thresh_scale = 1.0) {
   PG_REQUIRE(thresh_scale == 1.0 || n >= 48, 1, "pivot threshold scaling needs the blocked Cholesky (order >= 48)");
-  static const bool old_chol = getenv("PEPSGPU_OLD_CHOL") != nullptr;
-  // the register-resident kernel (opt-in): 181 us for a block of order 256 against 452 us of the left-looking one, but one block per CU
-  // against three -- 4.57 ms against 3.67 ms per launch of 8192 walkers (5.35 before the loads left the index loops).  PEPSGPU_CHOL_RESIDENT=1: every launch of order 129 .. 256;
-  // =2: only the launches that do not fill the chip once (<= 256 walkers: straggler lists, partial batches; measured +0.3 % on the real
-  // leg, within the noise, with another rounding of the affected walkers); default 0: never.
-  static const int resident = getenv("PEPSGPU_CHOL_RESIDENT") ? atoi(getenv("PEPSGPU_CHOL_RESIDENT")) : 0;
-  if (!old_chol && n > 128 && n <= 256 && (resident == 1 || (resident == 2 && nbatch <= 256))) {
-    hipLaunchKernelGGL((chol_resident_kernel<T>), dim3(nbatch), dim3(512), 0, s, (const double *)G, wG, n, R, wR, mlive_out, only_flagged, ld,
-                       ndyn, ndyn_mul, run_flag, thresh_scale);
-  } else if (!old_chol && n >= 48) {
+  if (n >= 48) {
     const size_t smem = chol_blocked_smem_bytes(n);
-    // (four blocks per CU -- 128 registers, 300 bytes of scratch -- measured on the real state: cholesky + trunc_gram 484 -> 531 ms)
-    static const int minb = getenv("PEPSGPU_CHB_MINB") ? atoi(getenv("PEPSGPU_CHB_MINB")) : 3;
-    if (minb == 2) {          // (two blocks per CU, 256 registers: no scratch)
-      allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 2>), smem);
-      hipLaunchKernelGGL((chol_blocked_kernel<T, 2>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
-                         ndyn_mul, run_flag, thresh_scale);
-    } else if (minb >= 4) {
-      allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 4>), smem);
-      hipLaunchKernelGGL((chol_blocked_kernel<T, 4>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
-                         ndyn_mul, run_flag, thresh_scale);
-    } else {
-      static const int pfd = getenv("PEPSGPU_CHB_PF") ? atoi(getenv("PEPSGPU_CHB_PF")) : 2;     // (real leg, 8192 walkers: cholesky 925 ms per two steps with three k-steps in flight, 908 with two, 963 with five, 986 with eight; two blocks per CU: 979)
-      if (pfd >= 8) {
-        allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3, 8>), smem);
-        hipLaunchKernelGGL((chol_blocked_kernel<T, 3, 8>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
-                           ndyn_mul, run_flag, thresh_scale);
-      } else if (pfd >= 5) {
-        allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3, 5>), smem);
-        hipLaunchKernelGGL((chol_blocked_kernel<T, 3, 5>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
-                           ndyn_mul, run_flag, thresh_scale);
-      } else if (pfd == 2) {
-        allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3, 2>), smem);
-        hipLaunchKernelGGL((chol_blocked_kernel<T, 3, 2>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
-                           ndyn_mul, run_flag, thresh_scale);
-      } else {
-        allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3>), smem);
-        hipLaunchKernelGGL((chol_blocked_kernel<T, 3>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
-                           ndyn_mul, run_flag, thresh_scale);
-      }
-    }
+    allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3, 2>), smem);
+    hipLaunchKernelGGL((chol_blocked_kernel<T, 3, 2>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
+                       ndyn_mul, run_flag, thresh_scale);
   } else {
     const size_t smem = chol_smem_bytes(n);
     allow_dynamic_lds(reinterpret_cast<const void *>(&chol_upper_kernel<T>), smem);
@@ -1152,172 +868,6 @@ __global__ __launch_bounds__(NT, MINW) void gram_chol_lowrank_list_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Same interface and output contract as gram_chol_lowrank_kernel, other arithmetic: Householder QR of the live rows
-// of P in the working precision T instead of a Cholesky of the (never formed) Gram matrix in f64.  Orthogonal
-// transformations do not square the condition number, so no f64 is needed to resolve directions down to the
-// rounding of the T-typed data; a step costs 3 (K - nl) FMAs of type T per column (dot with the reflector, update,
-// remaining norm) against 2 K f64 FMAs + K conversions + the 32-term factor correction of the Gram form, the factor
-// rows live in the registers that held the finished rows of P (no second register array), and the rank is bounded
-// by the rows a thread holds (KCAP), not by CH_LR_CAP.  Thread r owns column r; the owner of the pivot column
-// publishes it through LDS, every thread builds the same reflector from it.  Columns are taken in index order,
-// skipping those whose remaining norm^2 is below the threshold (same rule as the Cholesky kernels).  More live rows
-// than KCAP: further passes re-triangularise [factor so far ; next rows of P] inside the kernel.
-template <typename T, int KCAP, int NT>
-__global__ __launch_bounds__(NT, 2) void qr_lowrank_kernel(const T *__restrict__ Pg, long wP, int n,
-                                                          const int *__restrict__ kdyn, int kdyn_mul, int kmax,
-                                                          T *__restrict__ Rg, long wR, int *__restrict__ mlive_out,
-                                                          int inner = 1, const int *__restrict__ inner_live = nullptr,
-                                                          int retry_only = 0, int max_pass = 1, double noise_c = NOISE_C) {
-  constexpr int NWV = NT / 64;
-  constexpr int CHK = 8;                       // rows per uniform chunk of the unrolled loops
-  static_assert(KCAP % CHK == 0, "KCAP must be a multiple of the chunk");
-  if (retry_only && mlive_out[blockIdx.x] != -2) return;
-  __shared__ __attribute__((aligned(16))) T s_v[KCAP];   // pivot column
-  __shared__ T s_dn;                                     // its remaining norm^2
-  __shared__ double s_red[2][NWV], s_nrm[KCAP], s_part[2 * NWV];
-  __shared__ int s_first[2][NWV];
-  __shared__ short s_pos[KCAP];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Ktot = kdyn ? max(0, min(kmax, kdyn[blockIdx.x] * kdyn_mul)) : kmax;
-  const T *P = Pg + (long)blockIdx.x * wP;
-  T *Rout = Rg + (long)blockIdx.x * wR;
-  const int ilive = inner_live ? min(inner, inner_live[blockIdx.x]) : inner;
-  const int ncols = (n / inner) * ilive;
-  if (ncols > NT) {
-    if (tid == 0) mlive_out[blockIdx.x] = -2;
-    return;
-  }
-  const bool col_ok = tid < ncols;
-  const int r = col_ok ? (tid / ilive) * inner + (tid % ilive) : n;
-  const double eT = noise_c * eps_rt<T>();
-  T pc[KCAP];
-#pragma unroll
-  for (int k = 0; k < KCAP; ++k) pc[k] = T(0);
-  int nl = 0, step = 0, k0 = 0;
-  double maxd = 0.0;
-#pragma unroll 1
-  for (int pass = 0;; ++pass) {
-    const int nfr = nl;                                  // factor rows carried over (rows 0..nfr of pc)
-    const int npr = min(Ktot - k0, KCAP - nfr);          // rows of P taken in this pass
-    if (pass >= max_pass || npr < min(Ktot - k0, CHK)) { // out of passes / no room left next to the factor: decline
-      if (tid == 0) mlive_out[blockIdx.x] = -1;
-      return;
-    }
-    const int K = nfr + npr;
-    T d = T(0);
-#pragma unroll
-    for (int k = 0; k < KCAP; ++k) {
-      if (k >= nfr) pc[k] = (k < K && col_ok) ? P[(long)(k0 + k - nfr) * n + r] : T(0);
-      d += pc[k] * pc[k];
-    }
-    double md = (double)d;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
-    if (lane == 0) s_red[pass & 1][wave] = md;
-    __syncthreads();
-    maxd = s_red[pass & 1][0];
-#pragma unroll
-    for (int q = 1; q < NWV; ++q) maxd = fmax(maxd, s_red[pass & 1][q]);
-    const T thresh = T(fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd);
-    int f = -1;
-    nl = 0;
-#pragma unroll 1
-    for (;; ++step) {
-      int cand = (col_ok && r > f && d > thresh) ? r : 0x7fffffff;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
-      if (lane == 0) s_first[step & 1][wave] = cand;
-      __syncthreads();
-      if (tid == 0 && nl > 0) {                           // squared norm of the row finished in the previous step
-        double a = 0.0;
-#pragma unroll
-        for (int q = 0; q < NWV; ++q) a += s_part[NWV * ((step + 1) & 1) + q];
-        s_nrm[nl - 1] = a;
-      }
-      f = s_first[step & 1][0];
-#pragma unroll
-      for (int q = 1; q < NWV; ++q) f = min(f, s_first[step & 1][q]);
-      if (f == 0x7fffffff || nl >= K) { ++step; break; }
-      if (r == f) {                                       // the owner publishes the pivot column
-#pragma unroll
-        for (int k = 0; k < KCAP; ++k) s_v[k] = pc[k];
-        s_dn = d;
-      }
-      __syncthreads();
-      // reflector H = 1 - tau v v^T on rows nl..K-1:  v = x - alpha e_nl,  alpha = -sign(x_nl) |x|,  H x = alpha e_nl
-      const T dn = s_dn, x0 = s_v[nl];
-      const T nrmx = sqrt(dn);
-      const T alpha = x0 >= T(0) ? -nrmx : nrmx;
-      const T v0 = x0 - alpha;
-      const T tau = T(1) / (dn - x0 * alpha);             // 2 / (v^T v),  v^T v = 2 (|x|^2 - x_nl alpha)
-      T dot = T(0);
-#pragma unroll
-      for (int kb = 0; kb < KCAP; kb += CHK) {
-        if (kb + CHK > nl && kb < K) {                    // skip finished rows and rows beyond K (uniform)
-          asm volatile("" ::: "memory");                   // keep the LDS reads of later chunks from being hoisted
-#pragma unroll
-          for (int k = kb; k < kb + CHK; ++k) {
-            const T vk = k > nl ? s_v[k] : (k == nl ? v0 : T(0));
-            dot = fma(vk, pc[k], dot);
-          }
-        }
-      }
-      const T w = tau * dot;
-      T newd = T(0), rv = T(0);
-      const bool is_piv = r == f, right = col_ok && r > f;
-#pragma unroll
-      for (int kb = 0; kb < KCAP; kb += CHK) {
-        if (kb + CHK > nl && kb < K) {
-          asm volatile("" ::: "memory");
-#pragma unroll
-          for (int k = kb; k < kb + CHK; ++k) {
-            const T vk = k > nl ? s_v[k] : (k == nl ? v0 : T(0));
-            T x = fma(-w, vk, pc[k]);
-            if (k == nl) {                                // the new factor row: alpha at the pivot, 0 left of it
-              x = is_piv ? alpha : (right ? x : T(0));
-              rv = x;
-            } else if (k > nl) {
-              x = right ? x : T(0);                       // the pivot column is eliminated below row nl
-              newd = fma(x, x, newd);
-            } else x = pc[k];
-            pc[k] = x;
-          }
-        }
-      }
-      d = right ? newd : T(0);
-      const double a = wave_sum((double)rv * (double)rv);
-      if (lane == 0) s_part[NWV * (step & 1) + wave] = a;
-      ++nl;
-    }
-    k0 += npr;
-    if (k0 >= Ktot) break;
-  }
-  __syncthreads();
-  double fro = 0.0;
-  for (int j = 0; j < nl; ++j) fro += s_nrm[j];
-  const double nfloor = eT * eT * fro;
-  const T sc = maxd > 0.0 ? T(1.0 / sqrt(maxd)) : T(1);
-  if (tid == 0) {
-    int cnt = 0;
-    for (int j = 0; j < nl; ++j) s_pos[j] = s_nrm[j] > nfloor ? (short)cnt++ : (short)-1;
-    mlive_out[blockIdx.x] = cnt;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int kb = 0; kb < KCAP; kb += CHK) {
-    if (kb < nl) {
-#pragma unroll
-      for (int j = kb; j < kb + CHK; ++j) {
-        if (j < nl) {
-          const int pos = s_pos[j];
-          if (pos >= 0 && r < n) Rout[(long)pos * n + r] = pc[j] * sc;
-        }
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // The Gram-free factor with ONE WAVE PER WALKER (f32 data; the first kernel every walker of the rank-adaptive absorption
 // meets).  A lane owns two packed data columns (lane, lane + 64: at most 128 columns): its rows of P (64 per pass) and its
 // entries of the factor (rank <= 16, f64) stay in registers; the pivot column is handed to the other lanes with
@@ -1485,49 +1035,34 @@ inline void launch_gram_chol_lowrank(hipStream_t s, int nbatch, const T *P, long
                                      int kmax, T *R, long wR, int *mlive, int inner, const int *inner_live,
                                      int max_pass = 1, bool hint_dense = false, int *scratch_list = nullptr) {
   // scratch_list (optional, nbatch + 1 ints of device memory): the walkers the one-wave kernel hands on go through a list kernel
-  static const bool no_narrow = getenv("PEPSGPU_NO_NARROW_FUSED") != nullptr;
+  constexpr bool no_narrow = false;
   const bool narrow = !no_narrow && (inner_live != nullptr || n <= 128);
-  // Householder form (working precision, no rank cap): measured on the headline workload it is slower than the Gram
-  // form at the same noise floor (cholesky category 226 ms vs 162 ms per two steps: f32 rounding of the reflections
-  // leaves more near-threshold columns to process) and only wins with a looser floor (PEPSGPU_QR_NOISE=128: 61.3k
-  // vs 57.4k amp/s, through fewer live carry rows in the Jacobi) -- kept for A/B runs, off by default.
-  static const bool use_qr = getenv("PEPSGPU_QR_FACTOR") != nullptr && atoi(getenv("PEPSGPU_QR_FACTOR")) != 0;
-  if (use_qr) {
-    static const double qr_noise = getenv("PEPSGPU_QR_NOISE") ? atof(getenv("PEPSGPU_QR_NOISE")) : NOISE_C;
-    if (narrow)
-      hipLaunchKernelGGL((qr_lowrank_kernel<T, KCAP, 128>), dim3(nbatch), dim3(128), 0, s, P, wP, n, kdyn, kdyn_mul, kmax, R, wR,
-                         mlive, inner, inner_live, 0, max_pass, qr_noise);
-    if (!narrow || n > 128)
-      hipLaunchKernelGGL((qr_lowrank_kernel<T, KCAP, 256>), dim3(nbatch), dim3(256), 0, s, P, wP, n, kdyn, kdyn_mul, kmax, R, wR,
-                         mlive, inner, inner_live, narrow ? 1 : 0, max_pass, qr_noise);
-    PG_CHECK_HIP(hipGetLastError());
-    return;
-  }
+  // (a Householder form of the factor -- qr_lowrank_kernel, rounds 2-5 behind a switch -- was slower at the same noise floor: removed, HISTORY.md)
   // Short columns and a small rank cap first (fewer registers: three waves per SIMD instead of two), then the walkers
   // it handed on (-4) with the full KCAP / CH_LR_CAP, then the ones with more data columns than 128 threads (-2).
   constexpr int KCAP_S = sizeof(T) == 4 ? 64 : 32;
-  static const bool short_on = getenv("PEPSGPU_NO_SHORT_FUSED") == nullptr;   // measured: cholesky category 272 -> 215 ms per two steps
+  constexpr bool short_on = true;   // measured: cholesky category 272 -> 215 ms per two steps
   // (without per-walker row counts -- the second site of an absorption, whose 64 static rows fit one pass -- the one-wave kernel
   // takes the launch as well: that site ran on the 128-thread kernel, 1.49 ms against ~1.0 ms per launch of 49 152 walkers)
-  static const bool no_wave_static = getenv("PEPSGPU_NO_WAVE_STATIC") != nullptr;
-  const bool wave_static = sizeof(T) == 4 && !no_wave_static && kdyn == nullptr && kmax <= 64 && getenv("PEPSGPU_NO_WAVE_FACTOR") == nullptr;
+  constexpr bool no_wave_static = false;
+  const bool wave_static = sizeof(T) == 4 && !no_wave_static && kdyn == nullptr && kmax <= 64 && true;
   const bool short_first = narrow && short_on && (kdyn != nullptr || wave_static);
   bool first_done = false;
   if constexpr (sizeof(T) == 4) {
     // dense states (hint): MFMA Gram in registers + low-rank Cholesky (trunc_mid.h) takes every walker with <= 128 live
     // columns and rank <= 96, whatever the number of rows; what it declines (-4) goes down the kernels below
-    static const bool no_cg = getenv("PEPSGPU_NO_COLGRAM") != nullptr;
+    constexpr bool no_cg = false;
     if (!no_cg && hint_dense && inner > 0 && n % inner == 0) {
       launch_colgram_chol<T>(s, nbatch, P, wP, n, kdyn, kdyn_mul, kmax, R, wR, mlive, inner, inner_live, -4, hint_dense);
       first_done = true;
     }
   }
   if (short_first && !first_done) {
-    static const bool no_wave = getenv("PEPSGPU_NO_WAVE_FACTOR") != nullptr;
+    constexpr bool no_wave = false;
     bool done = false;
     if constexpr (sizeof(T) == 4) {
       if (!no_wave) {   // one wave per walker, no LDS, no barrier (gram_chol_wave_kernel)
-        static const bool no_list = getenv("PEPSGPU_NO_FACTOR_LIST") != nullptr;
+        constexpr bool no_list = false;
         int *dl = no_list ? nullptr : scratch_list;
         if (dl) PG_CHECK_HIP(hipMemsetAsync(dl + nbatch, 0, sizeof(int), s));
         hipLaunchKernelGGL(gram_chol_wave_kernel, dim3((nbatch + 3) / 4), dim3(256), 0, s, (const float *)P, wP, n, kdyn, kdyn_mul, kmax,

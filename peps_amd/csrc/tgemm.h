@@ -1168,8 +1168,8 @@ inline thread_local unsigned long long *tg_byte_counter = nullptr;
 // whether tgemm_launch<float ...> takes the wave-per-tile kernel with ONE block per batch entry for this descriptor: the
 // condition under which scale_in / scale_out may be set
 inline bool tgemm_one_block_direct(const TGemmDesc &d) {
-  static const int direct_mode = getenv("PEPSGPU_TGEMM_DIRECT") ? atoi(getenv("PEPSGPU_TGEMM_DIRECT")) : 1;
-  static const int gx_dyn = getenv("PEPSGPU_TGD_GX") ? atoi(getenv("PEPSGPU_TGD_GX")) : 1;
+  constexpr int direct_mode = 1;
+  constexpr int gx_dyn = 1;
   bool any_dyn = d.dynI != nullptr;
   for (int q = 0; q < 3; ++q) any_dyn = any_dyn || d.dI[q].p || d.dJ[q].p || d.dK[q].p;
   return tgemm_use_mfma() && !d.dynK && direct_mode == 1 && any_dyn && gx_dyn == 1 && d.bdivC == 1 && !d.accumulate &&
@@ -1191,8 +1191,8 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
   dim3 grid(gx, (d.Jtot() + TG_BN - 1) / TG_BN, d.nbatch);
   if constexpr (sizeof(TA) == 4 && sizeof(TB) == 4 && sizeof(TC) == 4 && sizeof(TAcc) == 4) {
     // small per-walker extents (rank-adaptive absorption): wave-per-tile kernel without LDS staging
-    static const int direct_mode = getenv("PEPSGPU_TGEMM_DIRECT") ? atoi(getenv("PEPSGPU_TGEMM_DIRECT")) : 1;
-    static const bool no_vec = getenv("PEPSGPU_TGEMM_NOVEC") != nullptr;
+    constexpr int direct_mode = 1;
+    constexpr bool no_vec = false;
     const bool any_dyn = dyn_i || d.dK[0].p || d.dK[1].p || d.dK[2].p || d.dJ[0].p || d.dJ[1].p || d.dJ[2].p;
     if (tgemm_use_mfma() && !d.dynK && !d.prefer_tiled && (direct_mode == 2 || (direct_mode == 1 && any_dyn))) {
       // 16-byte loads along k2 where the operand is contiguous there and every other offset keeps the alignment
@@ -1207,7 +1207,7 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
       const int tiles = ((d.Itot() + 31) / 32) * ((d.Jtot() + 31) / 32);
       // with per-walker live extents the tile count is a few: one block (four waves) walks them; extra blocks
       // would only pay the chain of dependent loads (extents, selector, offsets) and exit
-      static const int gx_dyn = getenv("PEPSGPU_TGD_GX") ? atoi(getenv("PEPSGPU_TGD_GX")) : 1;
+      constexpr int gx_dyn = 1;
       const dim3 gd(any_dyn ? std::min(gx_dyn, std::max(1, tiles / 4)) : (tiles >= 64 ? 4 : tiles >= 16 ? 2 : 1), 1,
                     d.nbatch);
       PG_REQUIRE(!d.scale_out || (gd.x == 1 && d.bdivC == 1 && !d.accumulate && !d.batch_flag), 5,
@@ -1232,7 +1232,7 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
   PG_REQUIRE(!d.scale_out && !d.scale_in, 5, "tensor GEMM: scale_in / scale_out need the wave-per-tile kernel");
   if constexpr (std::is_same<TAcc, double>::value && !is_cplx<TA>::value && !is_cplx<TB>::value && !is_cplx<TC>::value) {
     // skinny float64-accumulated products (one side <= 32): 128 x 32 / 32 x 128 block tiles, every wave on a live quadrant
-    static const bool no_skinny = getenv("PEPSGPU_NO_SKINNY") != nullptr;
+    constexpr bool no_skinny = false;
     if (tgemm_use_mfma() && !no_skinny && !d.upper_only && d.Itot() > 1 && d.Jtot() > 1) {
       if (d.Jtot() <= 32 && d.Itot() >= 64) {
         int gxs = (d.Itot() + 127) / 128;
@@ -1251,7 +1251,7 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
   if constexpr (is_cplx<TAcc>::value) {
     // complex element type: four real v_mfma_f64_16x16x4_f64 products per tile from the interleaved LDS operands
     // (PEPSGPU_NO_CPLX_MFMA=1: the same tiling on the vector ALUs, round 2's path)
-    static const bool no_cmfma = getenv("PEPSGPU_NO_CPLX_MFMA") != nullptr;
+    constexpr bool no_cmfma = false;
     if constexpr (std::is_same<TAcc, c128>::value) {
       if (tgemm_use_mfma() && !no_cmfma) {
         hipLaunchKernelGGL((tgemm_kernel<TA, TB, TC, TAcc, true>), grid, dim3(256), 0, s, d, A, B, C);
@@ -1280,7 +1280,7 @@ inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemm
   if (d1.Itot() >= (1 << 22) || d1.Jtot() >= (1 << 22) || d2.Itot() >= (1 << 22) || d2.Jtot() >= (1 << 22)) return 0;
   d1.flopc = tg_flop_counter; d1.bytec = tg_byte_counter;
   d1.flop_stride = d1.nbatch >= 256 ? 64 : 1;
-  static const bool no_vec = getenv("PEPSGPU_TGEMM_NOVEC") != nullptr;
+  constexpr bool no_vec = false;
   auto al4 = [](long v) { return (v & 3) == 0; };
   const bool avec1 = !no_vec && d1.sAk[2] == 1 && al4(d1.K[2]) && al4(d1.sAi[0]) && al4(d1.sAi[1]) && al4(d1.sAi[2]) &&
                      al4(d1.sAk[0]) && al4(d1.sAk[1]) && al4(d1.wA) && al4(d1.selA_mul) && (((uintptr_t)A1) & 15) == 0;
@@ -1337,8 +1337,8 @@ inline int tgemm_chain3_launch(hipStream_t s, const TGemmDesc &d1_in, const TGem
   if (d1.Itot() >= (1 << 22) || d1.Jtot() >= (1 << 22) || d2.Itot() >= (1 << 22) || d2.Jtot() >= (1 << 22) || d3.Itot() >= (1 << 22) ||
       d3.Jtot() >= (1 << 22))
     return 0;
-  static const int lds3 = getenv("PEPSGPU_CHAIN3_LDS") ? atoi(getenv("PEPSGPU_CHAIN3_LDS")) : 4096;     // (measured: 8192 walkers of the headline state 15.9 k sweeps/s at 4096 floats x 2 / four blocks per CU, 15.0 k at 6656 / three, 15.7 k without the third stage)
-  const int ldsf = lds3 >= 6656 ? 6656 : 4096;
+  constexpr int lds3 = 4096;     // (measured: 8192 walkers of the headline state 15.9 k sweeps/s at 4096 floats x 2 / four blocks per CU, 15.0 k at 6656 / three, 15.7 k without the third stage)
+  const int ldsf = lds3;
   // the kernel's own test, on the static extents (live extents are never larger)
   int jsub = -1;
   for (int q = 0; q < 3; ++q) {
@@ -1352,7 +1352,7 @@ inline int tgemm_chain3_launch(hipStream_t s, const TGemmDesc &d1_in, const TGem
   if (per1 > ldsf || per2 > ldsf) return 0;
   d1.flopc = tg_flop_counter; d1.bytec = tg_byte_counter;
   d1.flop_stride = d1.nbatch >= 256 ? 64 : 1;
-  static const bool no_vec = getenv("PEPSGPU_TGEMM_NOVEC") != nullptr;
+  constexpr bool no_vec = false;
   auto al4 = [](long v) { return (v & 3) == 0; };
   const bool avec1 = !no_vec && d1.sAk[2] == 1 && al4(d1.K[2]) && al4(d1.sAi[0]) && al4(d1.sAi[1]) && al4(d1.sAi[2]) &&
                      al4(d1.sAk[0]) && al4(d1.sAk[1]) && al4(d1.wA) && al4(d1.selA_mul) && (((uintptr_t)A1) & 15) == 0;
@@ -1363,8 +1363,7 @@ inline int tgemm_chain3_launch(hipStream_t s, const TGemmDesc &d1_in, const TGem
   const dim3 g(d1.nbatch), blk(256);
 #define PG_CHAIN3(a1, b1, a2)                                                                                                               \
   do {                                                                                                                                      \
-    if (ldsf == 6656) hipLaunchKernelGGL((tgemm_chain3_kernel<a1, b1, a2, 6656, 3>), g, blk, 0, s, d1, d2, d3, mp, mp3, A1, B1, A2, B3, C3, flag, skip); \
-    else hipLaunchKernelGGL((tgemm_chain3_kernel<a1, b1, a2, 4096, 4>), g, blk, 0, s, d1, d2, d3, mp, mp3, A1, B1, A2, B3, C3, flag, skip);   \
+    hipLaunchKernelGGL((tgemm_chain3_kernel<a1, b1, a2, 4096, 4>), g, blk, 0, s, d1, d2, d3, mp, mp3, A1, B1, A2, B3, C3, flag, skip);   \
   } while (0)
   if (avec1 && bvec1 && avec2) PG_CHAIN3(true, true, true);
   else if (avec1 && bvec1) PG_CHAIN3(true, true, false);

@@ -398,7 +398,7 @@ inline void launch_mid_gram_chol(hipStream_t s, int nbatch, const T *M, long wM,
     const int cap = std::min(caps[c], GS);
     if (cap <= lo) break;
     const size_t smem = mid_gram_chol_smem_bytes(cap);
-    static const int minb = getenv("PEPSGPU_MID_MINB") ? atoi(getenv("PEPSGPU_MID_MINB")) : 4;
+    constexpr int minb = 4;
     if (cap <= 80 && minb >= 4) {      // <= 5 tile rows: 15 tiles, four per wave
       allow_dynamic_lds(reinterpret_cast<const void *>(&mid_gram_chol_kernel<T, 4, 4>), smem);
       hipLaunchKernelGGL((mid_gram_chol_kernel<T, 4, 4>), dim3(nbatch), dim3(256), smem, s, M, wM, uk, nrows, run_flag, lo, cap, B, wB, GS,
@@ -782,14 +782,14 @@ template <typename T>
 inline void launch_colgram_chol(hipStream_t s, int nbatch, const T *P, long wP, int n, const int *kdyn, int kdyn_mul, int kmax,
                                 T *R, long wR, int *mlive, int inner, const int *inner_live, int decline_code, bool hint_dense) {
   (void)hint_dense;
-  static const bool lowrank_form = getenv("PEPSGPU_COLGRAM_LOWRANK") != nullptr;
+  constexpr bool lowrank_form = false;
   if (!lowrank_form) {   // dense walkers: blocked Cholesky of the packed triangle in LDS (colgram_dense_kernel), two size classes
     auto smem_of = [](int nc) {
       const size_t tri = sizeof(double) * (size_t)nc * (nc + 1) / 2, stg = (sizeof(float) * (size_t)nc * TM_LDM + 7) & ~(size_t)7;
       return std::max(tri, stg) + sizeof(double) * (size_t)nc + sizeof(short) * 2 * (size_t)nc + 64;
     };
     unsigned long long *st = nbatch >= 1024 ? cg_stats_dev() : nullptr;
-    static const bool one_class = getenv("PEPSGPU_COLGRAM_ONE_CLASS") != nullptr;
+    constexpr bool one_class = false;
     int lo = 0;
     // (a third class of 80 columns at four blocks per CU -- four of five walkers of a full-rank state -- was measured: cholesky
     // category 86 -> 91 ms per step: at 128 registers the kernel spills and four Gram phases share one MFMA pipe)
@@ -807,7 +807,7 @@ inline void launch_colgram_chol(hipStream_t s, int nbatch, const T *P, long wP, 
     PG_CHECK_HIP(hipGetLastError());
     return;
   }
-  static const int rcap_env = getenv("PEPSGPU_COLGRAM_RCAP") ? atoi(getenv("PEPSGPU_COLGRAM_RCAP")) : 88;   // (diagnostics: 0 = Gram phase only)
+  constexpr int rcap_env = 88;   // (diagnostics: 0 = Gram phase only)
   const int rcap = rcap_env;
   const size_t sm = colgram_chol_smem_bytes(rcap);
   allow_dynamic_lds(reinterpret_cast<const void *>(&colgram_chol_kernel<T>), sm);

@@ -297,31 +297,6 @@ def test_gram_free_lowrank_factor(K, n, rank, dt):
         assert np.max(np.abs(Rb.T @ Rb * sc - G)) / sc < tol
 
 
-def test_householder_factor_variant_in_subprocess():
-    """qr_lowrank_kernel (PEPSGPU_QR_FACTOR=1, an A/B variant of the Gram-free factor): R^T R = P^T P and the reported
-    rank on low-rank inputs; the switch is read once per process, hence the subprocess."""
-    import subprocess, sys, os
-    code = r'''
-import numpy as np
-from peps_amd import capi
-rng = np.random.default_rng(3)
-for dt, t, tol in ((capi.F32, np.float32, 3e-6), (capi.F64, np.float64, 1e-13)):
-    for K, n, rank in ((80, 80, 10), (40, 96, 33), (96, 128, 5)):
-        P = (rng.standard_normal((3, K, rank)) @ rng.standard_normal((3, rank, n))).astype(t)
-        R, ml = capi.diag_gram_chol(dt, P)
-        for b in range(3):
-            assert rank <= ml[b] <= rank + 2, (K, n, rank, ml)
-            G = P[b].astype(np.float64).T @ P[b].astype(np.float64)
-            Rb = R[b][:ml[b]].astype(np.float64)
-            assert np.max(np.abs(Rb.T @ Rb - G / np.max(np.diag(G)))) < tol * 10, (K, n, rank)
-print("OK")
-'''
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root,
-                       env=dict(os.environ, PEPSGPU_QR_FACTOR="1", PYTHONPATH=root))
-    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
-
-
 def test_rows_at_the_noise_floor_never_enter_vt_unorthogonalised():
     """A row whose norm sits at the Jacobi freeze threshold (NOISE_C eps |M|_F) is not rotated; select_rows must not
     keep it as a live direction (normalised it would overlap the dominant one).  4096 matrices with a residue-like row
@@ -428,13 +403,12 @@ def test_chained_contraction_pair_with_live_extents(f64acc, monkeypatch):
             assert fl[0] == (-1 if l * p * a2 > cap else 0)
 
 
-@pytest.mark.parametrize("kernel", [4, 5, 6, 7, 8])
+@pytest.mark.parametrize("kernel", [5, 6, 7, 8])
 @pytest.mark.parametrize("shape", [(128, 128), (70, 70), (96, 96), (33, 64), (100, 128), (17, 40), (64, 64), (5, 16), (61, 128),
                                    (128, 256), (90, 241), (64, 256), (40, 200)])
 def test_jacobi_mid_route_kernel(shape, kernel):
     """Tournament kernels of the preconditioned mid route (up to 128 x 128) on triangular, graded input (the Cholesky factor
-    they are given in the absorption): singular values, orthonormal Vt and dominant subspace against LAPACK.  kernel 4:
-    jacobi_rows_regx_kernel<4,2> (a row over 64 lanes); 5 / 6: jacobi_rows_grp_kernel<4,8> / <2,8> (16 lanes per row, four
+    they are given in the absorption): singular values, orthonormal Vt and dominant subspace against LAPACK.  5 / 6: jacobi_rows_grp_kernel<4,8> / <2,8> (16 lanes per row, four
     pairs per wave instruction; the two-wave form takes up to 64 rows); 7 / 8: <4,16> / <2,16>, rows up to 256 long (round 3: the
     route for walkers with up to 256 live carry rows, whose factor B keeps <= 128 live rows of length 256)."""
     capi = _capi()
@@ -709,49 +683,6 @@ def test_jacobi_one_wave_grouped_tournament(shape, kernel):
         assert np.max(np.abs(G[np.ix_(live, live)] - np.eye(int(live.sum())))) < 1e-4, b
         assert abs(np.linalg.norm(Mo[b]) / np.linalg.norm(M[b]) - 1) < 1e-5
         assert sw[b] < 40
-
-
-def test_register_resident_cholesky_same_contract_as_the_left_looking_kernel():
-    """chol_resident_kernel (round 5, opt-in through PEPSGPU_CHOL_RESIDENT=1, read once per process: hence the subprocess): the order-129 .. 256
-    factorisation with the trailing matrix in registers gives R^T R = G at the same tolerances as the left-looking kernel -- full rank and graded
-    deficient rank, f32 and f64 output, orders that are and are not multiples of the tile size -- and the two kernels keep the same rows."""
-    import json
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r'''
-import json, numpy as np
-from peps_amd import capi
-out = {}
-for n, rank in ((256, 256), (256, 97), (241, 180), (160, 33), (129, 129)):
-    rng = np.random.default_rng(n + rank)
-    X = rng.standard_normal((3, rank, n)) * np.logspace(0, -4, rank)[None, :, None]
-    G = np.einsum("bri,brj->bij", X, X)
-    for dt, name in ((capi.F32, "f32"), (capi.F64, "f64")):
-        R = capi.diag_chol(dt, G).astype(np.float64)
-        errs, lives = [], []
-        for b in range(3):
-            sc = np.max(np.diag(G[b]))
-            errs.append(float(np.max(np.abs(R[b].T @ R[b] * sc - G[b])) / sc))
-            live = int(np.sum(np.any(R[b] != 0, axis=1)))
-            assert np.all(R[b][live:] == 0)
-            lives.append(live)
-        out["%d_%d_%s" % (n, rank, name)] = [max(errs), lives]
-print("RESULT " + json.dumps(out))
-'''
-    res = {}
-    for name, env in (("left_looking", {"PEPSGPU_CHOL_RESIDENT": "0"}), ("resident", {"PEPSGPU_CHOL_RESIDENT": "1"})):
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=dict(os.environ, PYTHONPATH=root, **env),
-                           timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        res[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
-    for key, (err, lives) in res["resident"].items():
-        n, rank, dt = key.split("_")
-        assert err < (3e-6 if dt == "f32" else 3e-6 if int(rank) < int(n) else 1e-12), (key, err)      # (deficient rank: the f32-noise pivot floor)
-        err0, lives0 = res["left_looking"][key]
-        assert all(abs(a - b) <= 1 for a, b in zip(lives, lives0)), (key, lives, lives0)
-        assert all(l <= min(int(rank) + 2, int(n)) for l in lives), (key, lives)
 
 
 @pytest.mark.parametrize("n,K,rank,kcap", [(256, 256, 256, 64), (224, 256, 40, 64), (200, 128, 70, 56), (256, 256, 256, 48), (130, 64, 20, 64)])

@@ -235,3 +235,46 @@ def test_real_rank_c4_energy_vs_oracle_golden():
         print("C4 real state, n = %d, %s: E_loc max rel err %.2e, psi ratio max rel err %.2e" % (len(cfgs), "f32" if dt == capi.F32 else "f64", err_e, err_a))
         assert err_e < tol_e, (dt, err_e)
         assert err_a < 2 * tol_a, (dt, err_a)      # (a ratio of two amplitudes: twice the single-amplitude tolerance)
+
+
+def test_round6_routes_against_their_predecessors_and_the_oracle():
+    """The three route changes of round 6 keep their A/B switches (read once per process: subprocesses): PEPSGPU_PIVOT_CHOL=0 (full
+    factorisation of the truncation Gram in the natural order instead of the pivoted one capped at 56 rows), PEPSGPU_ROWS_QR=0 (polishing
+    Jacobi + select + Newton-Schulz instead of the float64 Cholesky-QR of the projected rows), PEPSGPU_TRI=0 (the chained contraction
+    and M = R Tt multiply the zero blocks of the triangular carry).  8x8 at C4's bond dimensions (carry of 256 rows, dense route):
+    every variant within SURVEY 8(d)'s 1e-5 of the float64 oracle; the triangular form skips exact zeros, so it is BIT-identical."""
+    import json
+    import subprocess
+    import sys
+    L, D, chi = 8, 8, 32
+    flat = _state(L, D)
+    cfgs = synthetic.make_configs_near_neel(L, 4, seed0=211)
+    ref_a, _ = _oracle(flat, cfgs, chi)
+    code = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from peps_amd import capi
+flat, cfgs = np.load(sys.argv[2])["flat"], np.load(sys.argv[2])["cfgs"]
+ctx = capi.Context(8, 8, 8, 2, 32, dtype=capi.F32, max_walkers=len(cfgs))
+ctx.state_upload(flat); ctx.set_configs(cfgs)
+a = ctx.evaluate_amplitude()
+assert np.all(ctx.walker_flags() == 0)
+print(json.dumps([float(x) for x in a]))
+"""
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "in.npz")
+        np.savez(f, flat=flat, cfgs=cfgs)
+        res = {}
+        for name, env in (("default", {}), ("no_pivot", {"PEPSGPU_PIVOT_CHOL": "0"}), ("no_rows_qr", {"PEPSGPU_ROWS_QR": "0"}), ("no_tri", {"PEPSGPU_TRI": "0"})):
+            r = subprocess.run([sys.executable, "-c", code, root, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[name] = np.array(json.loads(r.stdout.strip().splitlines()[-1]))
+    for name, a in res.items():
+        err = np.max(np.abs(a / ref_a - 1))
+        print("8x8 D = 8 chi = 32 real state, f32, %s: max rel err vs oracle %.2e" % (name, err))
+        assert err < 1e-5, (name, err)
+    assert np.array_equal(res["default"], res["no_tri"])
+    assert not np.array_equal(res["default"], res["no_pivot"]) and not np.array_equal(res["default"], res["no_rows_qr"])     # ... and the switches switch
