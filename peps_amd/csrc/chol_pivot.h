@@ -28,7 +28,14 @@ namespace pepsgpu {
 template <typename T, int KCAP, int NB, int MINW>
 __global__ __launch_bounds__(256, MINW) void chol_pivot_kernel(const double *__restrict__ Gg, long wG, int n, T *__restrict__ Rg, long wR,
                                                                int *__restrict__ mlive_out, int ld, const int *__restrict__ ndyn,
-                                                               int ndyn_mul, const int *__restrict__ run_flag) {
+                                                               int ndyn_mul, const int *__restrict__ run_flag,
+                                                               double *__restrict__ resid_out = nullptr, double thresh_scale = 1.0,
+                                                               int *__restrict__ piv_out = nullptr) {
+  // thresh_scale: multiplies the pivot threshold (0: pivots are taken down to the rounding noise of G -- the caller wants KCAP rows
+  // SELECTED, not a factor: piv_out [b][KCAP] then lists the pivot columns in the order taken, -1 beyond the count, and the rows are
+  // not compacted by their norm)
+  // resid_out (optional): the largest diagonal of the Schur complement that is left when the kernel stops, relative to max diag(G) --
+  // what the cap cut off (0 when every pivot above the threshold was taken); the float64 route prices its subspace with it
   static_assert(KCAP % NB == 0 && NB <= 4 && KCAP <= 64, "slots");
   const int b = blockIdx.x;
   if (run_flag && run_flag[b] >= 0) return;
@@ -41,6 +48,7 @@ __global__ __launch_bounds__(256, MINW) void chol_pivot_kernel(const double *__r
   __shared__ double s_x[NB][NB];
   __shared__ double s_part[4][KCAP];
   __shared__ short s_pos[KCAP];
+  __shared__ short s_pcol[KCAP];
   __shared__ int s_cnt;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const double *G = Gg + (long)b * wG;
@@ -57,7 +65,7 @@ __global__ __launch_bounds__(256, MINW) void chol_pivot_kernel(const double *__r
   const double maxd = fmax(fmax(s_wv[0][0], s_wv[0][1]), fmax(s_wv[0][2], s_wv[0][3]));
   __syncthreads();
   const double eT = NOISE_C * eps_rt<T>();
-  const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd;
+  const double thresh = fmax((double)n * 2.220446049250313e-16, eT * eT) * maxd * thresh_scale;
   const double sc_out = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
 
   double Lc[KCAP];
@@ -151,6 +159,7 @@ __global__ __launch_bounds__(256, MINW) void chol_pivot_kernel(const double *__r
       const double num = (t == cand[q]) ? piv : ((d >= 0.0) ? v[q] : 0.0);
       const double x = live ? num * sc : 0.0;
       xr[q] = x;
+      if (t == 0) s_pcol[rd * NB + q] = live ? (short)cand[q] : (short)-1;
       d = !live ? d : ((t == cand[q]) ? -1.0 : (d >= 0.0 ? fma(-x, x, d) : d));
       if (q + 1 < NB) {
         // later candidates: their entry of this row (for everybody's correction) and, for the next one, its corrected pivot
@@ -175,6 +184,18 @@ __global__ __launch_bounds__(256, MINW) void chol_pivot_kernel(const double *__r
     __syncthreads();      // s_rf / s_piv / s_x are rewritten by the next round
   }
 
+  if (resid_out) {
+    double md = fmax(d, 0.0);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) md = fmax(md, __shfl_xor(md, o, 64));
+    if (lane == 0) s_wv[0][wave] = md;
+    __syncthreads();
+    if (t == 0) {
+      const double r = fmax(fmax(s_wv[0][0], s_wv[0][1]), fmax(s_wv[0][2], s_wv[0][3]));
+      resid_out[b] = (maxd > 0.0 && r >= thresh) ? r / maxd : 0.0;
+    }
+    __syncthreads();
+  }
   // ---- rank compaction: rows with norm below NOISE_C * eps_T * |R|_F are dropped (as chol_blocked_kernel) ----
 #pragma unroll
   for (int j = 0; j < KCAP; ++j) {
@@ -191,8 +212,11 @@ __global__ __launch_bounds__(256, MINW) void chol_pivot_kernel(const double *__r
     int cnt = 0;
     for (int j = 0; j < nslots; ++j) {
       const double nj = s_part[0][j] + s_part[1][j] + s_part[2][j] + s_part[3][j];
-      s_pos[j] = nj > nfloor ? (short)cnt++ : (short)-1;
+      const bool keep = piv_out ? (s_pcol[j] >= 0) : (nj > nfloor);
+      s_pos[j] = keep ? (short)cnt++ : (short)-1;
+      if (piv_out && keep) piv_out[(long)b * KCAP + cnt - 1] = s_pcol[j];
     }
+    if (piv_out) for (int j = cnt; j < KCAP; ++j) piv_out[(long)b * KCAP + j] = -1;
     s_cnt = cnt;
     if (mlive_out) mlive_out[b] = cnt;
   }
@@ -210,16 +234,20 @@ __global__ __launch_bounds__(256, MINW) void chol_pivot_kernel(const double *__r
 }
 
 // KCAP rows at most; G holds both triangles.  Orders up to 256 (one thread per column).
+inline int chol_pivot_slots(int kcap) { return kcap <= 48 ? 48 : kcap <= 56 ? 56 : 64; }
+
 template <typename T>
 inline void launch_chol_pivot(hipStream_t s, int nbatch, const double *G, long wG, int n, T *R, long wR, int *mlive_out, int ld,
-                              const int *ndyn, int ndyn_mul, const int *run_flag, int kcap) {
+                              const int *ndyn, int ndyn_mul, const int *run_flag, int kcap, double *resid_out = nullptr,
+                              double thresh_scale = 1.0, int *piv_out = nullptr) {
+  // (piv_out: [nbatch][KCAP of the instantiation taken = 48 / 56 / 64 for kcap <= 48 / <= 56 / else])
   PG_REQUIRE(n <= 256 && (ld == 0 || ld <= 256), 1, "pivoted Cholesky: order above 256");
   if (kcap <= 48)
-    hipLaunchKernelGGL((chol_pivot_kernel<T, 48, 4, 3>), dim3(nbatch), dim3(256), 0, s, G, wG, n, R, wR, mlive_out, ld, ndyn, ndyn_mul, run_flag);
+    hipLaunchKernelGGL((chol_pivot_kernel<T, 48, 4, 3>), dim3(nbatch), dim3(256), 0, s, G, wG, n, R, wR, mlive_out, ld, ndyn, ndyn_mul, run_flag, resid_out, thresh_scale, piv_out);
   else if (kcap <= 56)
-    hipLaunchKernelGGL((chol_pivot_kernel<T, 56, 4, 3>), dim3(nbatch), dim3(256), 0, s, G, wG, n, R, wR, mlive_out, ld, ndyn, ndyn_mul, run_flag);
+    hipLaunchKernelGGL((chol_pivot_kernel<T, 56, 4, 3>), dim3(nbatch), dim3(256), 0, s, G, wG, n, R, wR, mlive_out, ld, ndyn, ndyn_mul, run_flag, resid_out, thresh_scale, piv_out);
   else
-    hipLaunchKernelGGL((chol_pivot_kernel<T, 64, 4, 2>), dim3(nbatch), dim3(256), 0, s, G, wG, n, R, wR, mlive_out, ld, ndyn, ndyn_mul, run_flag);
+    hipLaunchKernelGGL((chol_pivot_kernel<T, 64, 4, 2>), dim3(nbatch), dim3(256), 0, s, G, wG, n, R, wR, mlive_out, ld, ndyn, ndyn_mul, run_flag, resid_out, thresh_scale, piv_out);
   PG_CHECK_HIP(hipGetLastError());
 }
 

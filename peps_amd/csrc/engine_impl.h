@@ -745,7 +745,146 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       static const bool no_route = getenv("PEPSGPU_NO_F64_DENSE_ROUTE") != nullptr;
       // oversampled subspace: 2 chi directions, at most three quarters of the rank M can have (the right-edge sites are 256 x 64)
       const int kq = std::min(2 * k_full, (3 * std::min(m, uk)) / 4);
-      if (!no_route && adaptive && trunc_err_ == 0.0 && m > 128 && m <= 256 && uk <= 256 && kq <= 64 && kq >= k_full + 8 && i > 0) {
+      // Round 6: the subspace from a diagonally PIVOTED factorisation of G = M M^T stopped after kq rows (chol_pivot.h; measured on
+      // the truncation inputs of the real state in float64, scripts/proto_subspace.py: the kept sigma_k v_k lost by the subspace of 64
+      // pivot rows 2.5e-10 median / 4.4e-9 max of sigma_1, 56 rows 1.8e-9 / 1.9e-8), made orthonormal by a Cholesky-QR2 in float64
+      // (chol_solve_rows_kernel: U = L^-1 B twice), sharpened by ONE step of subspace iteration on M itself (U <- orth(orth(U M) M^T): the
+      // part outside shrinks by (sigma_kq+1 / sigma_chi)^2 ~ 3e-3) and followed by the same accurate Jacobi on Z = U M as before.
+      // No Gram-resolution cliff (a pivoted factor simply stops at the numerical rank: C5's synthetic state keeps 30-47 directions and
+      // stays on the route) and no Jacobi on a 128 x 128 factor.  PEPSGPU_F64_PIVOT=0: the two-Cholesky route of round 5.
+      static const int f64_pivot = getenv("PEPSGPU_F64_PIVOT") ? atoi(getenv("PEPSGPU_F64_PIVOT")) : 1;
+      constexpr int f64_pivot_mlo = 63;     // blocks of 64 .. 256 rows (measured, real state at 2 048 walkers: 443 amp/s with the route above 128 rows only, 490 from 64)
+      if (f64_pivot && !no_route && adaptive && trunc_err_ == 0.0 && m > f64_pivot_mlo && m <= 256 && uk <= 256 && uk % 4 == 0 && kq <= 64 &&
+          kq >= k_full + 8 && i > 0) {
+        const int GSd = m;
+        const int gb = (nw_ + 255) / 256;
+        rflag = (int *)arena_.alloc(sizeof(int) * nw_);
+        fbrows = (int *)arena_.alloc(sizeof(int) * nw_);
+        int *rowsM = (int *)arena_.alloc(sizeof(int) * nw_), *mB1 = (int *)arena_.alloc(sizeof(int) * nw_);
+        double *resid = (double *)arena_.alloc(sizeof(double) * nw_);
+        PG_CHECK_HIP(hipMemsetAsync(mB1, 0, sizeof(int) * nw_, stream_));
+        hipLaunchKernelGGL(f64_route_init_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)mdyn[i], mmul[i], m, nw_, rowsM, rflag);
+        PG_CHECK_HIP(hipGetLastError());
+        prof_begin(PROF_TRUNC_GRAM, 0.0, 0.0);
+        double *Gm = (double *)arena_.alloc(sizeof(double) * (size_t)GSd * GSd * nw_);
+        DTen<T> Bq = alloc_ten(64, GSd, 1), Zt = alloc_ten(64, uk, 1);
+        double *Sq = (double *)arena_.alloc(sizeof(double) * 64 * 64 * (size_t)nw_);
+        auto gram_rows = [&](const DTen<T> &X, int len, const int *rows, int rmax, double *S, int ldS, bool full, const int *lenlive) {
+          TGemmDesc g;      // S = X X^T over the live rows (upper triangle unless `full`)
+          g.I[2] = rmax; g.sAi[2] = len; g.sCi[2] = ldS;
+          g.K[2] = len; g.sAk[2] = 1; g.sBk[2] = 1;
+          g.J[2] = rmax; g.sBj[2] = len; g.sCj[2] = 1;
+          g.wA = X.n; g.wB = X.n; g.wC = (long)ldS * ldS; g.nbatch = nw_;
+          g.dI[2].p = rows; g.dJ[2].p = rows;
+          g.dK[2].p = lenlive;
+          g.upper_only = full ? 0 : 1;
+          g.batch_flag = rflag;
+          tgemm_launch<T, T, double, double>(stream_, g, X.p, X.p, S);
+        };
+        gram_rows(M, uk, rowsM, m, Gm, GSd, true, nullptr);           // both triangles: the pivoted factorisation reads whole rows
+        // The factorisation only SELECTS rows of M here (pivot order, down to the rounding noise of G: thresh_scale 0): what the
+        // Gram cannot resolve (directions below 2.4e-7 sigma_1 -- C5's synthetic state has ~25 above it for chi = 24: taking the factor
+        // itself as the basis left the f64 amplitude at 2.9e-7) comes from the rows themselves, Gram-Schmidt'ed in float64.
+        const int slots = chol_pivot_slots(kq);
+        int *piv = (int *)arena_.alloc(sizeof(int) * (size_t)slots * nw_);
+        launch_chol_pivot<T>(stream_, nw_, (const double *)Gm, (long)GSd * GSd, GSd, Bq.p, Bq.n, mB1, GSd, (const int *)rowsM, 1,
+                             (const int *)rflag, kq, resid, 0.0, piv);
+        arena_.free(Gm);
+        hipLaunchKernelGGL(gather_rows_kernel<T>, dim3(64, nw_), dim3(256), 0, stream_, (const T *)M.p, M.n, uk, (const int *)piv, slots,
+                           (const int *)mB1, Zt.p, Zt.n, (const int *)rflag);
+        PG_CHECK_HIP(hipGetLastError());
+        arena_.free(piv);
+        auto orthonormalise = [&](DTen<T> &X, int len, const int *lenlive) {     // Cholesky-QR2 of the mB1 rows of X (in place)
+          for (int pass = 0; pass < 2; ++pass) {
+            gram_rows(X, len, mB1, 64, Sq, 64, false, lenlive);
+            hipLaunchKernelGGL(chol_solve_rows_kernel, dim3(nw_), dim3(256), 0, stream_, (const double *)Sq, 64L * 64, 64, (double *)X.p, X.n,
+                               len, (const int *)mB1, (const int *)rflag);
+            PG_CHECK_HIP(hipGetLastError());
+          }
+        };
+        orthonormalise(Zt, uk, nullptr);                            // Q0: the selected rows of M, orthonormal (right space)
+        prof_end();
+        prof_begin(PROF_TRUNC_APPLY, 0.0, 0.0);
+        auto times_mt = [&](const DTen<T> &Q, DTen<T> &Uout) {      // U = Q M^T (rows of Q: uk long; rows of U: GSd long, zeros beyond the live rows of M)
+          TGemmDesc g;
+          g.I[2] = 64; g.sAi[2] = uk; g.sCi[2] = GSd;
+          g.K[2] = uk; g.sAk[2] = 1; g.sBk[2] = 1;
+          g.J[2] = m; g.sBj[2] = uk; g.sCj[2] = 1;
+          g.wA = Q.n; g.wB = M.n; g.wC = Uout.n; g.nbatch = nw_;
+          g.dI[2].p = mB1;
+          g.dJ[2].p = rowsM; g.dJ[2].mask = 1;
+          g.batch_flag = rflag;
+          tgemm_launch<T, T, T, double>(stream_, g, Q.p, M.p, Uout.p);
+        };
+        times_mt(Zt, Bq);                                           // the pivoted factor itself, from M: B = Q0 M^T
+        prof_end();
+        prof_begin(PROF_TRUNC_GRAM, 0.0, 0.0);
+        orthonormalise(Bq, GSd, rowsM);
+        prof_end();
+        prof_begin(PROF_TRUNC_APPLY, 0.0, 0.0);
+        auto times_m = [&](const DTen<T> &U, DTen<T> &Zout) {       // Z = U M (rows of U: GSd long, live part rowsM)
+          TGemmDesc g;
+          g.I[2] = 64; g.sAi[2] = GSd; g.sCi[2] = uk;
+          g.K[2] = m; g.sAk[2] = 1; g.sBk[2] = uk;
+          g.J[2] = uk; g.sBj[2] = 1; g.sCj[2] = 1;
+          g.wA = U.n; g.wB = M.n; g.wC = Zout.n; g.nbatch = nw_;
+          g.dI[2].p = mB1;
+          g.dK[2].p = rowsM;
+          g.batch_flag = rflag;
+          tgemm_launch<T, T, T, double>(stream_, g, U.p, M.p, Zout.p);
+        };
+        times_m(Bq, Zt);
+        prof_end();
+        prof_begin(PROF_TRUNC_GRAM, 0.0, 0.0);
+        orthonormalise(Zt, uk, nullptr);      // (each half step re-orthonormalised: U M M^T has the SQUARED condition, 1e12 -- no Gram survives it)
+        prof_end();
+        prof_begin(PROF_TRUNC_APPLY, 0.0, 0.0);
+        times_mt(Zt, Bq);                                           // one step of subspace iteration: U <- orth(orth(U M) M^T)
+        prof_end();
+        prof_begin(PROF_TRUNC_GRAM, 0.0, 0.0);
+        orthonormalise(Bq, GSd, rowsM);
+        prof_end();
+        prof_begin(PROF_TRUNC_APPLY, 0.0, 0.0);
+        times_m(Bq, Zt);
+        prof_end();
+        prof_begin(PROF_JACOBI, 0.0, 0.0);
+        {   // the accurate SVD inside the subspace: one-sided Jacobi on the <= kq rows of Z, LDS resident
+          const size_t needz = sizeof(T) * (size_t)kq * (uk | 1);
+          allow_dynamic_lds(reinterpret_cast<const void *>(&jacobi_rows_kernel<T>), needz);
+          hipLaunchKernelGGL(jacobi_rows_kernel<T>, dim3(nw_), dim3(1024), needz, stream_, Zt.p, Zt.n, kq, uk, uk, 40, 1, sweeps_,
+                             (const int *)mB1, 1, 0, 0);
+          PG_CHECK_HIP(hipGetLastError());
+        }
+        prof_end();
+        prof_begin(PROF_SELECT, 0.0, 0.0);
+        hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)Zt.p, Zt.n, kq, uk, uk, k, V.p, V.n,
+                           (T *)nullptr, 0L, (const int *)mB1, 1, kn[i], 0.0, chi_min_, (double *)nullptr, (const int *)rflag, 1);
+        PG_CHECK_HIP(hipGetLastError());
+        // guard: a cap that cut into the spectrum (resid > 0) is priced by what one step of subspace iteration leaves of it,
+        // resid (sigma_1 / sigma_chi)^2; a walker above the tolerance takes the general kernel
+        hipLaunchKernelGGL(f64_pivot_guard_kernel<double>, dim3(nw_), dim3(256), 0, stream_, (const double *)Zt.p, Zt.n, uk, (const int *)mB1,
+                           k_full, (const double *)resid, 3e-2, rflag);
+        PG_CHECK_HIP(hipGetLastError());
+        prof_end();
+        if (dbg_sweeps_ && getenv("PEPSGPU_DEBUG_VERBOSE")) {
+          std::vector<int> hf(nw_), hk(nw_);
+          std::vector<double> hr(nw_);
+          PG_CHECK_HIP(hipMemcpyAsync(hf.data(), rflag, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+          PG_CHECK_HIP(hipMemcpyAsync(hk.data(), mB1, nw_ * sizeof(int), hipMemcpyDeviceToHost, stream_));
+          PG_CHECK_HIP(hipMemcpyAsync(hr.data(), resid, nw_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+          PG_CHECK_HIP(hipStreamSynchronize(stream_));
+          long on = 0, sk = 0; double rmx = 0.0;
+          for (int w = 0; w < nw_; ++w) { on += hf[w] < 0; sk += hk[w]; rmx = std::max(rmx, hr[w]); }
+          fprintf(stderr, "[pepsgpu] f64 pivoted route site %d (m = %d, uk = %d, kq = %d): %ld of %d walkers on the route, pivot rows mean %.1f, residual pivot max %.2e\n",
+                  i, m, uk, kq, on, nw_, (double)sk / nw_, rmx);
+        }
+        lateflag = (int *)arena_.alloc(sizeof(int) * nw_);
+        hipLaunchKernelGGL(f64_route_fallback_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)rflag, (const int *)rowsM, nw_, fbrows,
+                           (const int *)nullptr, lateflag);
+        PG_CHECK_HIP(hipGetLastError());
+        free_ten(Bq); free_ten(Zt);
+        arena_.free(Sq); arena_.free(rowsM); arena_.free(mB1); arena_.free(resid);
+      } else if (!no_route && adaptive && trunc_err_ == 0.0 && m > 128 && m <= 256 && uk <= 256 && kq <= 64 && kq >= k_full + 8 && i > 0) {
         const int GSd = m;
         // a walker stays on the route with as few as chi + 4 directions above the resolution of a Gram: the guard prices what its
         // factors dropped (C5: the synthetic fermionic state keeps 30-47 of kq = 48; real state: the edge sites)

@@ -1459,6 +1459,41 @@ __global__ __launch_bounds__(256) void f64_route_guard_kernel(const TZ *__restri
   }
 }
 
+// Guard of the pivoted form of the route (round 6): resid[b] = the largest pivot the cap cut off, relative to max diag(M M^T) ~ sigma_1^2
+// (0: the factor took every direction above its threshold).  After one step of subspace iteration what is left of it inside the kept
+// directions is bounded by resid (sigma_1 / sigma_k)^2; above `tol`, or with fewer than k directions in a capped subspace, the walker
+// leaves the route.
+template <typename TZ>
+__global__ __launch_bounds__(256) void f64_pivot_guard_kernel(const TZ *__restrict__ Zg, long wZ, int len, const int *__restrict__ kz, int k,
+                                                              const double *__restrict__ resid, double tol, int *__restrict__ flag) {
+  const int b = blockIdx.x;
+  if (flag[b] >= 0) return;
+  __shared__ double s_n[64];
+  const int rows = min(kz[b], 64), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const TZ *Z = Zg + (long)b * wZ;
+  for (int r = wave; r < rows; r += 4) {
+    double a = 0.0;
+    for (int c = lane; c < len; c += 64) a += abs2_of(Z[(long)r * len + c]);
+    a = wave_sum(a);
+    if (lane == 0) s_n[r] = a;           // squared norms
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s1 = 0.0;
+    for (int r = 0; r < rows; ++r) s1 = fmax(s1, s_n[r]);
+    double sk = 0.0;
+    const int kk = min(k, rows);
+    for (int r = 0; r < rows; ++r) {
+      int larger = 0;
+      for (int q = 0; q < rows; ++q) larger += (s_n[q] > s_n[r]) || (s_n[q] == s_n[r] && q < r);
+      if (larger == kk - 1) sk = s_n[r];
+    }
+    const double rs = resid[b];
+    const bool ok = rows >= 1 && s1 > 0.0 && (rs == 0.0 || (rows >= k && sk > 0.0 && rs * (s1 / sk) <= tol));
+    if (!ok) flag[b] = 0;
+  }
+}
+
 // live rows of M for the walkers off the route (the general kernels take them), 0 for the walkers on it.  `early` (optional): the
 // walkers that left at the first check are being handled on the side stream already (early[b] >= 0): they count 0 rows here and
 // `late_flag` (optional) marks what is left for the main stream (0: left the route later, -1: nothing to do)

@@ -137,6 +137,106 @@ __global__ __launch_bounds__(256) void rows_qr_kernel(const float *__restrict__ 
   for (int e = t + cnt * len; e < k * len; e += 256) V[e] = 0.f;
 }
 
+// X <- L^-1 X per walker, L L^T = S (round 6, the float64 dense route): one pass of a Cholesky-QR on r <= 64 rows that are already
+// in global memory together with their Gram matrix S (upper triangle, r x r, leading dimension lds) -- the rows of the pivoted factor
+// B (S = B B^T), then the rows of the result once more (Cholesky-QR2: the first pass leaves eps cond(B)^2 ~ 1e-5 of
+// non-orthogonality at cond(B) ~ 1e5, the second removes it).  r = rows[b] (dynamic), len <= 256 columns (one thread per column, the
+// solution in registers), L in LDS.  A pivot that is not positive (rows dependent to rounding) zeroes its row.
+constexpr int CS_K = 64;
+__global__ __launch_bounds__(256) void chol_solve_rows_kernel(const double *__restrict__ Sg, long wS, int lds, double *__restrict__ Xg, long wX,
+                                                              int len, const int *__restrict__ rows, const int *__restrict__ run_flag) {
+  const int b = blockIdx.x;
+  if (run_flag && run_flag[b] >= 0) return;
+  __shared__ double sL[CS_K][CS_K + 1];
+  const int t = threadIdx.x;
+  const int r = max(0, min(CS_K, rows[b]));
+  if (r <= 0) return;
+  const double *S = Sg + (long)b * wS;
+  double *X = Xg + (long)b * wX;
+  for (int e = t; e < r * r; e += 256) {
+    const int i = e / r, j = e - i * r;
+    if (j >= i) sL[j][i] = S[(long)i * lds + j];         // lower triangle of the symmetric matrix from its upper storage
+  }
+  __syncthreads();
+  for (int j = 0; j < r; ++j) {
+    const double piv = sL[j][j];
+    const bool live = piv > 0.0;                          // (block-uniform)
+    const double inv = live ? 1.0 / sqrt(piv) : 0.0;
+    __syncthreads();
+    if (t < r && t >= j) sL[t][j] = (t == j) ? (live ? sqrt(piv) : 0.0) : sL[t][j] * inv;
+    __syncthreads();
+    if (live) {
+      const int nrem = r - j - 1;                         // trailing block (a, c), j < c <= a < r
+      for (int e = t; e < nrem * nrem; e += 256) {
+        const int a = j + 1 + e / nrem, c = j + 1 + e % nrem;
+        if (c <= a) sL[a][c] = fma(-sL[a][j], sL[c][j], sL[a][c]);
+      }
+    }
+    __syncthreads();
+  }
+  // forward substitution, one thread per column, the solution in registers.  Rows in chunks of CS_CH behind block-uniform branches: a
+  // run-time loop over the chunks with static register indices inside (the fully unrolled triangle -- 2016 FMAs, as many LDS reads --
+  // came out of the compiler with 256 VGPRs and 464 spilled dwords, as chol_pivot_kernel's did)
+  constexpr int CS_CH = 8, CS_NCH = CS_K / CS_CH;
+  for (int c0 = 0; c0 < len; c0 += 256) {
+    const int c = min(c0 + t, len - 1);
+    double x[CS_K];
+#pragma unroll
+    for (int a = 0; a < CS_K; ++a) x[a] = 0.0;
+    const int nch = (r + CS_CH - 1) / CS_CH;
+    for (int ca = 0; ca < nch; ++ca) {
+      double v[CS_CH];
+#pragma unroll
+      for (int a = 0; a < CS_CH; ++a) v[a] = (ca * CS_CH + a < r) ? X[(long)(ca * CS_CH + a) * len + c] : 0.0;
+#pragma unroll
+      for (int cq = 0; cq < CS_NCH; ++cq)
+        if (cq < ca) {
+#pragma unroll
+          for (int k = 0; k < CS_CH; ++k) {
+            const double xq = x[cq * CS_CH + k];
+#pragma unroll
+            for (int a = 0; a < CS_CH; ++a) v[a] = fma(-sL[ca * CS_CH + a][cq * CS_CH + k], xq, v[a]);
+          }
+        }
+#pragma unroll
+      for (int a = 0; a < CS_CH; ++a) {
+        const int ra = ca * CS_CH + a;
+        double sv = v[a];
+#pragma unroll
+        for (int q = 0; q < a; ++q) sv = fma(-sL[ra][ca * CS_CH + q], v[q], sv);
+        const double laa = ra < r ? sL[ra][ra] : 0.0;
+        v[a] = laa > 0.0 ? sv / laa : 0.0;
+      }
+#pragma unroll
+      for (int cq = 0; cq < CS_NCH; ++cq)
+        if (cq == ca) {
+#pragma unroll
+          for (int a = 0; a < CS_CH; ++a) x[cq * CS_CH + a] = v[a];
+        }
+      if (c0 + t < len) {
+#pragma unroll
+        for (int a = 0; a < CS_CH; ++a)
+          if (ca * CS_CH + a < r) X[(long)(ca * CS_CH + a) * len + c] = v[a];
+      }
+    }
+  }
+}
+
+// Q[b][j][:] = M[b][piv[b][j]][:] for the j < rows[b] pivot rows a selection run of chol_pivot_kernel listed (pivot order); len elements per row
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T *__restrict__ Mg, long wM, int len, const int *__restrict__ piv, int slots,
+                                                          const int *__restrict__ rows, T *__restrict__ Qg, long wQ,
+                                                          const int *__restrict__ run_flag) {
+  const int b = blockIdx.y, j = blockIdx.x;
+  if (run_flag && run_flag[b] >= 0) return;
+  if (j >= rows[b]) return;
+  const int p = piv[(long)b * slots + j];
+  if (p < 0) return;
+  const T *src = Mg + (long)b * wM + (long)p * len;
+  T *dst = Qg + (long)b * wQ + (long)j * len;
+  for (int c = threadIdx.x; c < len; c += 256) dst[c] = src[c];
+}
+
 inline void launch_rows_qr(hipStream_t s, int nbatch, const float *X, long wX, int k, int len, const int *kdyn, float *V, long wV,
                            int *klive_out, const int *run_flag) {
   PG_REQUIRE(rows_qr_ok(k, len), 1, "rows_qr: k <= 32 rows of <= 256 elements (a multiple of 4)");

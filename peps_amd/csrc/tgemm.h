@@ -928,7 +928,8 @@ struct TGemmChainMap { int mapK[3] = {-1, -1, -1}, mapJ[3] = {-1, -1, -1}; };
 // F64: both stages accumulate in float64 on the f64 matrix cores (tg_direct_body_f64; the intermediate stays f32 in LDS)
 // (two measured-and-rejected bodies of round 5 -- 16 x 16 x 4 tiles with dead quadrants skipped, two J tiles per wave in stage 2 -- were
 // removed in round 6; HISTORY.md has their numbers)
-template <bool AVEC1, bool BVEC1, bool AVEC2, int LDSF, int MINB, bool F64 = false>
+// TRI: the triangular-carry form of the chunk loop (round 6; its own instantiation: the per-chunk bookkeeping cost the low-rank headline 2.6 % of this kernel)
+template <bool AVEC1, bool BVEC1, bool AVEC2, int LDSF, int MINB, bool F64 = false, bool TRI = false>
 __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TGemmDesc d2, TGemmChainMap mp, const float *__restrict__ A1g,
                                                             const float *__restrict__ B1g, const float *__restrict__ A2g,
                                                             float *__restrict__ C2g, int *__restrict__ flag, int only_flagged, int allow_chunks) {
@@ -972,7 +973,7 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TG
   }
   if (threadIdx.x == 0) flag[b] = 0;
   if (I1 <= 0 || J1 <= 0 || I2 <= 0 || J2 <= 0) return;
-  const bool tri_req = (allow_chunks & 2) && chunk < d1.I[1];     // (executed flops of the triangular form: counted chunk by chunk below)
+  const bool tri_req = TRI && (allow_chunks & 2) && chunk < d1.I[1];     // (executed flops of the triangular form: counted chunk by chunk below)
   if (d1.flopc && threadIdx.x == 0 && b % d1.flop_stride == 0) {
     if (!tri_req) atomicAdd(d1.flopc, 2ull * d1.flop_stride * ((unsigned long long)I1 * J1 * d1.Ktot() + (unsigned long long)I2 * J2 * d2.Ktot()));
     if (d1.bytec)
@@ -1015,20 +1016,25 @@ __global__ __launch_bounds__(256, MINB) void tgemm_chain_kernel(TGemmDesc d1, TG
   for (int s = 0; s < 3; ++s) if (mp.mapK[s] == 2) ksub = s;
   const int L1 = d1.I[2], sAl = d1.sAi[2];
   const int sA2l = ksub == 0 ? d2.sAk[0] : ksub == 1 ? d2.sAk[1] : d2.sAk[2];
-  const bool tri = (allow_chunks & 2) && ksub >= 0 && sAl > 0 && d1.Imask[2] == 0x7fffffff;
+  const bool tri = TRI && (allow_chunks & 2) && ksub >= 0 && sAl > 0 && d1.Imask[2] == 0x7fffffff;
   unsigned long long fl_exec = 0;
   for (int c0 = 0; c0 < n1; c0 += chunk) {
     const int cn = min(chunk, n1 - c0);
-    const int l0 = tri ? min(c0 / sAl, L1 - 1) : 0;
     d1.I[1] = cn;
-    d1.I[2] = L1 - l0;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {      // (no dynamic indexing: the descriptors stay in registers)
+    for (int s = 0; s < 3; ++s)      // (no dynamic indexing: the descriptors stay in registers)
       if (s == jsub) d2.J[s] = cn;
-      if (tri && s == ksub) d2.K[s] = L1 - l0;
+    long oA1 = (long)c0 * sA1, oA2 = 0;
+    if constexpr (TRI) {
+      const int l0 = tri ? min(c0 / sAl, L1 - 1) : 0;
+      d1.I[2] = L1 - l0;
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        if (tri && s == ksub) d2.K[s] = L1 - l0;
+      oA1 += (long)l0 * sAl;
+      oA2 = (long)l0 * sA2l;
+      if (tri_req) fl_exec += 2ull * ((unsigned long long)d1.Itot() * J1 * d1.Ktot() + (unsigned long long)I2 * d2.Jtot() * d2.Ktot());
     }
-    const long oA1 = (long)c0 * sA1 + (long)l0 * sAl, oA2 = (long)l0 * sA2l;
-    if (tri_req) fl_exec += 2ull * ((unsigned long long)d1.Itot() * J1 * d1.Ktot() + (unsigned long long)I2 * d2.Jtot() * d2.Ktot());
     if (c0) __syncthreads();     // stage 2 of the chunk before has read the buffer
     if constexpr (F64) {
       tg_direct_body_f64<AVEC1, BVEC1>(d1, A1g + baseA1 + oA1, B1g + baseB1, s_mid, d1.Itot(), J1, K2s1, offCi_s, 0, 4, in_scale);
@@ -1298,6 +1304,7 @@ inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemm
   do {                                                                                                                         \
     if (f64acc && ldsf >= 8192) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 8192, 4, true>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, akf); \
     else if (f64acc) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 4, true>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, akf); \
+    else if (ldsf == 8192 && tri) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 8192, 4, false, true>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, akf); \
     else if (ldsf == 8192) hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, 8192, 4>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, akf); \
     else hipLaunchKernelGGL((tgemm_chain_kernel<a1, b1, a2, TG_CHAIN_LDS_FLOATS, 6>), g, blk, 0, s, d1, d2, mp, A1, B1, A2, C2, flag, 0, akf); \
   } while (0)

@@ -7,7 +7,7 @@ times (calibration with 1 walker, warm-up and timed step at full size, rank diag
 are identified by their grid in the kernel trace (the two largest launch groups of the kernel) and carry all but ~0.1 % of the bytes."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ("tgemm_chain_kernel", "tgemm_chain3_kernel", "tgemm_direct_kernel", "tgemm_skinny_f64_kernel", "gram_cols_i8_kernel", "gram_cols_f64_kernel", "gram_cols_lds_kernel", "gram_rows_f64_kernel", "chol_blocked_kernel",
+KERNELS = ("chol_pivot_kernel", "rows_qr_kernel", "tgemm_chain_kernel", "tgemm_chain3_kernel", "tgemm_direct_kernel", "tgemm_skinny_f64_kernel", "gram_cols_i8_kernel", "gram_cols_f64_kernel", "gram_cols_lds_kernel", "gram_rows_f64_kernel", "chol_blocked_kernel",
            "gram_chol_wave_kernel", "jacobi_rows_grp_kernel", "jacobi_rows_tiny4_kernel", "colgram_dense_kernel", "mid_gram_chol_kernel",
            "ortho_rows_kernel", "mgemm_dense_kernel", "tgemm_kernel")
 RND = "r%02d" % (int(sys.argv[1]) if len(sys.argv) > 1 else 4)
@@ -37,7 +37,8 @@ def sq_shares(path):
             ent["mfma_busy_over_cu_busy"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / c["SQ_BUSY_CU_CYCLES"]
         out[k.replace("void ", "").replace("pepsgpu::", "")] = ent
     return out
-LEGS = {"c4_f32_noise0.1": "c4_f32_noise0.1_nw49152", "c4_f32_noise1": "c4_f32_noise1_nw8192", "c4_f32_real": "c4_f32_real_nw8192"}
+LEGS = {"c4_f32_noise0.1": "c4_f32_noise0.1_nw49152", "c4_f32_noise1": "c4_f32_noise1_nw8192",
+        "c4_f32_real": "c4_f32_real_nw12288" if RND >= "r06" else "c4_f32_real_nw8192"}
 
 
 def totals(path):
