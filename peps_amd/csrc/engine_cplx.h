@@ -154,7 +154,71 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_simple(int pos, int num, const BMP
     if constexpr (kCplx) {
       static const bool no_route = getenv("PEPSGPU_NO_C128_DENSE_ROUTE") != nullptr;
       const int kq = std::min(2 * k, (3 * std::min(m, uk)) / 4);
-      if (!no_route && trunc_err_ == 0.0 && m > 128 && m <= 256 && uk <= 256 && kq <= 64 && kq >= k + 8) {
+      // Round 6: the oversampled subspace from a RANDOMISED range finder -- a fixed table of signs times M, three re-orthonormalised steps
+      // of subspace iteration (every half step a Cholesky-QR2 in complex float64, chol_solve_rows_cplx_kernel), then the same complex
+      // Jacobi on Z = U M.  What lies outside the kq = 2 chi directions enters direction chi damped by (sigma_kq+1 / sigma_chi)^6
+      // (~2e-8 on a state of the real spectrum): no Gram of M, no factorisation, no Jacobi on a 128 x 128 factor.  (The float64 route
+      // selects its start rows by a pivoted factorisation, chol_pivot.h; a complex factor column does not fit a thread's registers.)
+      // PEPSGPU_F64_PIVOT=0: the two-Cholesky route of round 5.
+      static const int f64_pivot = getenv("PEPSGPU_F64_PIVOT") ? atoi(getenv("PEPSGPU_F64_PIVOT")) : 1;
+      if (f64_pivot && !no_route && trunc_err_ == 0.0 && m >= 64 && m <= 256 && uk <= 256 && kq <= 64 && kq >= k + 8) {
+        const int gb = (nw_ + 255) / 256;
+        rflag = (int *)arena_.alloc(sizeof(int) * nw_);
+        int *rowsM = (int *)arena_.alloc(sizeof(int) * nw_);
+        hipLaunchKernelGGL(f64_route_init_kernel, dim3(gb), dim3(256), 0, stream_, (const int *)nullptr, 1, m, nw_, rowsM, rflag);
+        arena_.free(rowsM);
+        DTen<T> Om = alloc_ten(kq, m, 1);           // (only the first walker's slice is used: the table is shared, batch stride 0)
+        hipLaunchKernelGGL(sign_table_kernel<T>, dim3((kq * m + 255) / 256), dim3(256), 0, stream_, Om.p, kq, m);
+        PG_CHECK_HIP(hipGetLastError());
+        DTen<T> Qz = alloc_ten(kq, uk, 1), Uz = alloc_ten(kq, m, 1);
+        Acc *Sq = (Acc *)arena_.alloc(sizeof(Acc) * 64 * 64 * (size_t)nw_);
+        auto orth = [&](DTen<T> &X, int len) {      // Cholesky-QR2 of the kq rows of X (in place)
+          for (int pass = 0; pass < 2; ++pass) {
+            TGemmDesc g;
+            g.I[2] = kq; g.sAi[2] = len; g.sCi[2] = 64;
+            g.K[2] = len; g.sAk[2] = 1; g.sBk[2] = 1;
+            g.J[2] = kq; g.sBj[2] = len; g.sCj[2] = 1;
+            g.wA = X.n; g.wB = X.n; g.wC = 64L * 64; g.nbatch = nw_;
+            g.conjB = 1;
+            g.upper_only = 1;
+            tgemm_launch<T, T, Acc, Acc>(stream_, g, X.p, X.p, Sq);
+            hipLaunchKernelGGL(chol_solve_rows_cplx_kernel, dim3(nw_), dim3(256), 0, stream_, (const c128 *)Sq, 64L * 64, 64, (c128 *)X.p, X.n, len, kq,
+                               (const int *)nullptr);
+            PG_CHECK_HIP(hipGetLastError());
+          }
+        };
+        auto times_m = [&](const DTen<T> &U, long wU, DTen<T> &Zout) {       // Z = U M (kq x uk)
+          TGemmDesc g;
+          g.I[2] = kq; g.sAi[2] = m; g.sCi[2] = uk;
+          g.K[2] = m; g.sAk[2] = 1; g.sBk[2] = uk;
+          g.J[2] = uk; g.sBj[2] = 1; g.sCj[2] = 1;
+          g.wA = wU; g.wB = M.n; g.wC = Zout.n; g.nbatch = nw_;
+          tgemm_launch<T, T, T, T>(stream_, g, U.p, M.p, Zout.p);
+        };
+        auto times_mh = [&](const DTen<T> &Q, DTen<T> &Uout) {               // U = Q M^H (kq x m)
+          TGemmDesc g;
+          g.I[2] = kq; g.sAi[2] = uk; g.sCi[2] = m;
+          g.K[2] = uk; g.sAk[2] = 1; g.sBk[2] = 1;
+          g.J[2] = m; g.sBj[2] = uk; g.sCj[2] = 1;
+          g.wA = Q.n; g.wB = M.n; g.wC = Uout.n; g.nbatch = nw_;
+          g.conjB = 1;
+          tgemm_launch<T, T, T, T>(stream_, g, Q.p, M.p, Uout.p);
+        };
+        times_m(Om, 0L, Qz);                          // the sketch: signs times M
+        for (int it = 0; it < 3; ++it) {
+          orth(Qz, uk);
+          times_mh(Qz, Uz);
+          orth(Uz, m);
+          times_m(Uz, Uz.n, Qz);
+        }
+        hipLaunchKernelGGL(jacobi_rows_cplx_kernel<T>, dim3(nw_), dim3(1024), 0, stream_, Qz.p, Qz.n, kq, uk, uk, 60, sweeps_,
+                           (const int *)rflag, 1);
+        hipLaunchKernelGGL(select_rows_kernel<T>, dim3(nw_), dim3(256), 0, stream_, (const T *)Qz.p, Qz.n, kq, uk, uk, k, V.p, V.n,
+                           (T *)nullptr, 0L, (const int *)nullptr, 1, (int *)nullptr, 0.0, chi_min_, (double *)nullptr, (const int *)rflag, 1);
+        PG_CHECK_HIP(hipGetLastError());
+        free_ten(Om); free_ten(Qz); free_ten(Uz);
+        arena_.free(Sq);
+      } else if (!no_route && trunc_err_ == 0.0 && m > 128 && m <= 256 && uk <= 256 && kq <= 64 && kq >= k + 8) {
         const int gb = (nw_ + 255) / 256, route_lo = std::min(kq, k + 4);
         constexpr double REDO_SCALE = 64.0;
         rflag = (int *)arena_.alloc(sizeof(int) * nw_);

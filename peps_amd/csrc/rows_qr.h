@@ -15,6 +15,7 @@
 // tile per wave), the 32-step factorisation with its 528 entries dealt over the block, the forward substitution one thread per column with the solution in registers.
 #pragma once
 #include "linalg.h"
+#include "cplx.h"
 
 namespace pepsgpu {
 
@@ -220,6 +221,79 @@ __global__ __launch_bounds__(256) void chol_solve_rows_kernel(const double *__re
       }
     }
   }
+}
+
+// The same pass for COMPLEX rows (round 6, the complex dense route): S = X X^H Hermitian (upper triangle stored), L L^H = S,
+// X <- L^-1 X in place.  The solution of 64 complex rows does not fit the registers of one thread: the rows go in chunks of
+// CSC_CH = 16 (the chunk in registers, the rows solved before re-read from global memory -- written by the same thread).
+constexpr int CSC_CH = 16;
+__global__ __launch_bounds__(256, 2) void chol_solve_rows_cplx_kernel(const c128 *__restrict__ Sg, long wS, int lds, c128 *__restrict__ Xg,
+                                                                      long wX, int len, int r, const int *__restrict__ run_flag) {
+  const int b = blockIdx.x;
+  if (run_flag && run_flag[b] >= 0) return;
+  __shared__ c128 sL[CS_K][CS_K + 1];
+  const int t = threadIdx.x;
+  r = max(0, min(CS_K, r));
+  if (r <= 0) return;
+  const c128 *S = Sg + (long)b * wS;
+  c128 *X = Xg + (long)b * wX;
+  for (int e = t; e < r * r; e += 256) {
+    const int i = e / r, j = e - i * r;
+    if (j >= i) sL[j][i] = conj_of(S[(long)i * lds + j]);   // lower triangle of the Hermitian matrix from its upper storage
+  }
+  __syncthreads();
+  for (int j = 0; j < r; ++j) {
+    const double piv = sL[j][j].re;
+    const bool live = piv > 0.0;                          // (block-uniform)
+    const double inv = live ? 1.0 / sqrt(piv) : 0.0;
+    __syncthreads();
+    if (t < r && t >= j) sL[t][j] = (t == j) ? c128(live ? sqrt(piv) : 0.0, 0.0) : sL[t][j] * inv;
+    __syncthreads();
+    if (live) {
+      const int nrem = r - j - 1;
+      for (int e = t; e < nrem * nrem; e += 256) {
+        const int a = j + 1 + e / nrem, c = j + 1 + e % nrem;
+        if (c <= a) sL[a][c] -= sL[a][j] * conj_of(sL[c][j]);
+      }
+    }
+    __syncthreads();
+  }
+  for (int c0 = 0; c0 < len; c0 += 256) {
+    const int c = c0 + t;
+    if (c >= len) continue;
+    for (int a0 = 0; a0 < r; a0 += CSC_CH) {
+      c128 v[CSC_CH];
+#pragma unroll
+      for (int a = 0; a < CSC_CH; ++a) v[a] = (a0 + a < r) ? X[(long)(a0 + a) * len + c] : c128(0.0, 0.0);
+      for (int q = 0; q < a0; ++q) {
+        const c128 xq = X[(long)q * len + c];
+#pragma unroll
+        for (int a = 0; a < CSC_CH; ++a) v[a] -= sL[min(a0 + a, CS_K - 1)][q] * xq;
+      }
+#pragma unroll
+      for (int a = 0; a < CSC_CH; ++a) {
+        const int ra = min(a0 + a, CS_K - 1);
+        c128 sv = v[a];
+#pragma unroll
+        for (int q = 0; q < a; ++q) sv -= sL[ra][a0 + q] * v[q];
+        const double laa = a0 + a < r ? sL[ra][ra].re : 0.0;
+        v[a] = laa > 0.0 ? sv * (1.0 / laa) : c128(0.0, 0.0);
+      }
+#pragma unroll
+      for (int a = 0; a < CSC_CH; ++a)
+        if (a0 + a < r) X[(long)(a0 + a) * len + c] = v[a];
+    }
+  }
+}
+
+// A fixed table of signs (+1 / -1, the same for every walker): the start of the randomised range finder of the complex route
+template <typename T>
+__global__ void sign_table_kernel(T *__restrict__ out, int rows, int cols) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * cols) return;
+  unsigned h = (unsigned)e * 2654435761u;
+  h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+  out[e] = T((h & 1u) ? 1.0 : -1.0);
 }
 
 // Q[b][j][:] = M[b][piv[b][j]][:] for the j < rows[b] pivot rows a selection run of chol_pivot_kernel listed (pivot order); len elements per row
