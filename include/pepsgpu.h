@@ -376,6 +376,9 @@ int pepsgpu_diag_chol_pivot(const float *X, int n, int K, int nbatch, const int3
 /* rows_qr_kernel alone (round 6): the k <= 32 nearly orthogonal rows X = [nbatch][k][len] (len <= 256, by decreasing norm) made orthonormal in
  * float64 (Cholesky-QR of the unit-scaled rows); V_out: live rows first, the rest zero; klive_out = their count */
 int pepsgpu_diag_rows_qr(const float *X, int k, int len, int nbatch, const int32_t *klive, float *V_out, int32_t *klive_out);
+/* the device's SuwaTodoStateUpdate alone (round 6, the decision of pepsgpu_sweep_slice_fullspace): a chain of `steps` updates on one
+ * weight vector (n <= 16), words = 2 * steps raw outputs of the caller's std::mt19937; out_chain[s] = the state after step s */
+int pepsgpu_diag_suwa_todo(const double *weights, int n, int init, const uint32_t *words, int steps, int32_t *out_chain);
 /* the rank-adaptive pair used by the absorption: low-rank right-looking kernel, then the blocked
  * kernel for the walkers whose rank exceeds its cap; mlive_out[b] = rows of R_out[b] that exist */
 /* the Gram-free low-rank kernel alone: P = [nbatch][K][n] (dtype), R^T R = P^T P; mlive_out[b] = -1 where

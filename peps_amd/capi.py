@@ -43,7 +43,7 @@ SYMBOLS = [
     "pepsgpu_sr_cg_solve", "pepsgpu_sr_gram", "pepsgpu_sr_weighted_sum", "pepsgpu_sr_copy_samples",
     "pepsgpu_update_local", "pepsgpu_erase_envs_after_update", "pepsgpu_evaluate_amplitude",
     "pepsgpu_walker_flags", "pepsgpu_sync", "pepsgpu_stats", "pepsgpu_profile_enable", "pepsgpu_profile_read",
-    "pepsgpu_diag_tgemm", "pepsgpu_diag_tgemm_chain", "pepsgpu_diag_chol", "pepsgpu_diag_chol_adaptive", "pepsgpu_diag_chol_pivot", "pepsgpu_diag_rows_qr", "pepsgpu_diag_gram_chol", "pepsgpu_diag_gram_cols", "pepsgpu_diag_gram_rows", "pepsgpu_diag_mgemm_dense", "pepsgpu_diag_jacobi", "pepsgpu_version",
+    "pepsgpu_diag_tgemm", "pepsgpu_diag_tgemm_chain", "pepsgpu_diag_chol", "pepsgpu_diag_chol_adaptive", "pepsgpu_diag_chol_pivot", "pepsgpu_diag_rows_qr", "pepsgpu_diag_suwa_todo", "pepsgpu_diag_gram_chol", "pepsgpu_diag_gram_cols", "pepsgpu_diag_gram_rows", "pepsgpu_diag_mgemm_dense", "pepsgpu_diag_jacobi", "pepsgpu_version",
 ]
 
 
@@ -724,6 +724,20 @@ def diag_rows_qr(X, klive):
     if rc != 0:
         raise RuntimeError("diag_rows_qr failed: %s" % lib().pepsgpu_last_error(None).decode())
     return V, ml
+
+
+def diag_suwa_todo(weights, init, words):
+    """the device's SuwaTodoStateUpdate: a chain of len(words) / 2 updates; words = raw uint32 outputs of std::mt19937"""
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    wd = np.ascontiguousarray(words, dtype=np.uint32)
+    steps = len(wd) // 2
+    out = np.zeros(steps, dtype=np.int32)
+    f = lib().pepsgpu_diag_suwa_todo
+    f.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int32)]
+    rc = f(_dp(w), len(w), int(init), wd.ctypes.data_as(C.POINTER(C.c_uint32)), steps, _ip(out))
+    if rc != 0:
+        raise RuntimeError("diag_suwa_todo failed: %s" % lib().pepsgpu_last_error(None).decode())
+    return out
 
 
 def diag_mgemm_dense(R, Tt, a_dim, u_dim, k2_dim, tt_u_inner, m_live=None, a_live=None, k2_live=None):

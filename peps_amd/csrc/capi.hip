@@ -693,6 +693,24 @@ extern "C" int pepsgpu_diag_rows_qr(const float *X, int k, int len, int nbatch, 
     (void)hipFree(dX); (void)hipFree(dV); (void)hipFree(dn); (void)hipFree(dm);
   });
 }
+// The device's SuwaTodoStateUpdate alone (round 6): a chain of `steps` updates on one weight vector (n <= 16 states), fed with the
+// raw 32-bit outputs of the caller's std::mt19937 (two per step, the reference's long double draw); out_chain[s] = the state after step s.
+extern "C" int pepsgpu_diag_suwa_todo(const double *weights, int n, int init, const uint32_t *words, int steps, int32_t *out_chain) {
+  return guarded(nullptr, [&]() {
+    PG_REQUIRE(weights && words && out_chain && n >= 1 && n <= SW_MAXC && init >= 0 && init < n && steps >= 1, 1, "bad arguments");
+    double *dw; unsigned *dd; int *dout;
+    PG_CHECK_HIP(hipMalloc(&dw, n * sizeof(double)));
+    PG_CHECK_HIP(hipMalloc(&dd, 2 * (size_t)steps * sizeof(unsigned)));
+    PG_CHECK_HIP(hipMalloc(&dout, (size_t)steps * sizeof(int)));
+    PG_CHECK_HIP(hipMemcpy(dw, weights, n * sizeof(double), hipMemcpyHostToDevice));
+    PG_CHECK_HIP(hipMemcpy(dd, words, 2 * (size_t)steps * sizeof(unsigned), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(sweep_suwa_todo_chain_kernel, dim3(1), dim3(64), 0, 0, (const double *)dw, n, init, (const unsigned *)dd, steps, dout);
+    PG_CHECK_HIP(hipGetLastError());
+    PG_CHECK_HIP(hipDeviceSynchronize());
+    PG_CHECK_HIP(hipMemcpy(out_chain, dout, (size_t)steps * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(dw); (void)hipFree(dd); (void)hipFree(dout);
+  });
+}
 extern "C" int pepsgpu_diag_chol(int dtype_out, const double *G, int n, int nbatch, void *R_out) {
   return guarded(nullptr, [&]() {
     if (dtype_out == 0) diag_chol_t<float>(G, n, nbatch, R_out); else diag_chol_t<double>(G, n, nbatch, R_out);

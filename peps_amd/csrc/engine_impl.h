@@ -661,14 +661,16 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
             // without, 2 626 with 64 rows at two blocks per SIMD, 2 699 with 56 at three; graded subspace error of the prototype 3.7e-8 / 6e-8
             // median against 2.1e-7 of the unpivoted factor).
             static const int pivot_cap = getenv("PEPSGPU_PIVOT_CHOL") ? atoi(getenv("PEPSGPU_PIVOT_CHOL")) : 56;
-            pivoted = pivot_cap > 0 && fused_mid_ran && GS > 128 && !no_two_level && gram_rows_i8_ok(M.p, m) &&
-                      std::min(chi_, std::min(m, uk)) + 24 <= std::max(48, std::min(64, pivot_cap));
+            // (the cap leaves chi + 24 rows of oversampling: 56 rows up to chi = 32 -- three blocks per SIMD --, 64 up to chi = 40)
+            const int kf = std::min(chi_, std::min(m, uk));
+            const int kcap = (kf + 24 <= std::min(64, pivot_cap)) ? std::min(64, pivot_cap) : 64;
+            pivoted = pivot_cap > 0 && fused_mid_ran && GS > 128 && !no_two_level && gram_rows_i8_ok(M.p, m) && kf + 24 <= kcap;
             launch_gram_rows_f64<T>(stream_, nw_, (const T *)M.p, M.n, uk, m, (const int *)nhi, Gm, (long)GS * GS, GS,
                                     (const int *)hiflag, tg_flop_counter, tg_byte_counter, pivoted ? 1 : 0);
             rowgram = true;
             if (pivoted)
               launch_chol_pivot<T>(stream_, nw_, (const double *)Gm, (long)GS * GS, GS, Bt.p, Bt.n, mB, GS, (const int *)nhi, 1, (const int *)hiflag,
-                                   pivot_cap);
+                                   kcap);
           }
         }
         if (!rowgram) tgemm_launch<T, T, double, double>(stream_, g, M.p, M.p, Gm);

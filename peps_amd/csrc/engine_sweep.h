@@ -94,26 +94,12 @@ __global__ void sweep_all_cand_kernel(int *__restrict__ cand, int dim, int n) {
 // walker consumes its engine exactly as the reference's updater does.  The arithmetic here is float64 where the reference's is
 // long double: a decision differs only when the deviate falls within 2^-53 of a boundary of the cumulative weights.
 constexpr int SW_MAXC = 16;
-template <typename AccT>
-__global__ void sweep_suwa_todo_kernel(int *__restrict__ cfg, int sites, int s1, int s2, int dim, const AccT *__restrict__ res,
-                                       const double *__restrict__ lsum, AccT *__restrict__ amp, const unsigned *__restrict__ words,
-                                       int words_per_walker, int bond, int *__restrict__ acc, int *__restrict__ acc_now, int n) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= n) return;
-  const int nc = dim * dim;
-  const int c1 = cfg[(long)w * sites + s1], c2 = cfg[(long)w * sites + s2];
-  int init = c1 * dim + c2;
-  const int init0 = init;
-  const double sc = exp(lsum[w]);
-  const AccT a0 = amp[w];
-  const double pa = sw_abs(a0);
-  double wt[SW_MAXC];
+// SuwaTodoStateUpdate (suwa_todo_update.h:53-112) for nc <= SW_MAXC states: wt (modified: the largest weight is swapped to the front, as
+// the reference does), init = the current state, (w0, w1) = the two engine words of the long double draw.  Returns the new state.
+__device__ __forceinline__ int sw_suwa_todo_decide(double *wt, int nc, int init, unsigned w0, unsigned w1) {
   int mx = 0;
-  for (int k = 0; k < nc; ++k) {
-    const double r = (k == init0) ? 1.0 : sw_abs(sw_scaled(AccT(res[(long)w * nc + k]), sc)) / pa;
-    wt[k] = r * r;
+  for (int k = 1; k < nc; ++k)
     if (wt[k] > wt[mx]) mx = k;                           // std::max_element: the first of equal maxima
-  }
   if (mx != 0) { const double t = wt[0]; wt[0] = wt[mx]; wt[mx] = t; }
   if (init == mx) init = 0;
   else if (init == 0) init = mx;
@@ -124,7 +110,6 @@ __global__ void sweep_suwa_todo_kernel(int *__restrict__ cfg, int sites, int s1,
   const double s_im1 = init == 0 ? 0.0 : cs[init - 1];
   double start = s_im1 + wt[0];
   if (start >= S) start -= S;
-  const unsigned w0 = words[(long)w * words_per_walker + 2 * bond], w1 = words[(long)w * words_per_walker + 2 * bond + 1];
   double u = ((double)w0 + 4294967296.0 * (double)w1) * 5.421010862427522e-20;      // / 2^64
   if (u >= 1.0) u = 0.9999999999999999;
   const double hi = nextafter(start + wt[init], start);
@@ -137,6 +122,40 @@ __global__ void sweep_suwa_todo_kernel(int *__restrict__ cfg, int sites, int s1,
     if (fin == 0) fin = mx;
     else if (fin == mx) fin = 0;
   }
+  return fin;
+}
+
+// a chain of the update on one weight vector (kernel test: the reference's unit cases against the host's long double form)
+__global__ void sweep_suwa_todo_chain_kernel(const double *__restrict__ weights, int nc, int init, const unsigned *__restrict__ words, int steps,
+                                             int *__restrict__ out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int st = init;
+  for (int s = 0; s < steps; ++s) {
+    double wt[SW_MAXC];
+    for (int k = 0; k < nc; ++k) wt[k] = weights[k];
+    st = sw_suwa_todo_decide(wt, nc, st, words[2 * s], words[2 * s + 1]);
+    out[s] = st;
+  }
+}
+
+template <typename AccT>
+__global__ void sweep_suwa_todo_kernel(int *__restrict__ cfg, int sites, int s1, int s2, int dim, const AccT *__restrict__ res,
+                                       const double *__restrict__ lsum, AccT *__restrict__ amp, const unsigned *__restrict__ words,
+                                       int words_per_walker, int bond, int *__restrict__ acc, int *__restrict__ acc_now, int n) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n) return;
+  const int nc = dim * dim;
+  const int c1 = cfg[(long)w * sites + s1], c2 = cfg[(long)w * sites + s2];
+  const int init0 = c1 * dim + c2;
+  const double sc = exp(lsum[w]);
+  const AccT a0 = amp[w];
+  const double pa = sw_abs(a0);
+  double wt[SW_MAXC];
+  for (int k = 0; k < nc; ++k) {
+    const double r = (k == init0) ? 1.0 : sw_abs(sw_scaled(AccT(res[(long)w * nc + k]), sc)) / pa;
+    wt[k] = r * r;
+  }
+  const int fin = sw_suwa_todo_decide(wt, nc, init0, words[(long)w * words_per_walker + 2 * bond], words[(long)w * words_per_walker + 2 * bond + 1]);
   const int changed = fin != init0;
   acc_now[w] = changed;
   if (changed) {

@@ -545,8 +545,11 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
 template <typename T>
 inline void launch_chol_upper(hipStream_t s, int nbatch, double *G, long wG, int n, T *R, long wR, int *mlive_out, int only_flagged = 0,
                               int ld = 0, const int *ndyn = nullptr, int ndyn_mul = 1, const int *run_flag = nullptr, double thresh_scale = 1.0) {
-  PG_REQUIRE(thresh_scale == 1.0 || n >= 48, 1, "pivot threshold scaling needs the blocked Cholesky (order >= 48)");
-  if (n >= 48) {
+  PG_REQUIRE(thresh_scale == 1.0 || (n >= 48 && n <= 256), 1, "pivot threshold scaling needs the blocked Cholesky (orders 48 .. 256)");
+  // (round 6: the blocked kernel's four waves own four 16-column tiles each = 256 columns; rounds 3-5 launched it for ANY order >= 48 and
+  // a carry of D chi > 256 columns got a factor whose columns beyond 256 were never updated -- wrong amplitudes without a flag on full-rank
+  // states with D chi > 256, found with scripts/bigbond_probe.py; larger orders take the general kernel)
+  if (n >= 48 && n <= 256) {
     const size_t smem = chol_blocked_smem_bytes(n);
     allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3, 2>), smem);
     hipLaunchKernelGGL((chol_blocked_kernel<T, 3, 2>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,

@@ -154,3 +154,31 @@ print(json.dumps({"amps": [float(x) for x in a] + [float(x) for x in b[::-1]], "
     # the failed attempt must not leave its sticky walker flags behind (a valid configuration was reported as 'Empty tensor')
     assert not any(outs["forced"]["flags"]) and not any(outs["plain"]["flags"])
     assert np.allclose(outs["forced"]["host_e"], outs["plain"]["host_e"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("L,D,chi", [(8, 7, 42), (8, 5, 60), (8, 8, 36)])
+def test_carry_of_more_than_256_columns(L, D, chi):
+    """D chi > 256 on a state of full rank (the carry really fills its 294 / 300 / 288 columns): amplitudes against the float64 oracle,
+    f32 and f64.  Round 6 found this combination broken since round 3 -- launch_chol_upper handed every order >= 48 to the blocked
+    Cholesky, whose four waves cover 256 columns, so the columns beyond were never updated: zeros, flags, or a silently wrong f64
+    amplitude (2.7e-3 at D = 8, chi = 36).  No BASELINE config goes there (C4 is D chi = 256 exactly), the C ABI accepts it."""
+    from peps_amd import capi
+    sitps = synthetic.make_sitps(L, D, noise=1.0)
+    flat = synthetic.sitps_to_flat(sitps, D, np.float64)
+    cfgs = synthetic.make_configs(L, 3, "heisenberg", seed0=5)
+    tp = BMPSTruncateParams.SVD(chi, chi, 0.0)
+    ref = np.array([vmc.TPSWaveFunctionComponent(sitps, c, tp).amplitude for c in cfgs])
+    for dt, tol in ((capi.F32, 1e-5), (capi.F64, 1e-9)):
+        os.environ["PEPSGPU_DEBUG_SWEEPS"] = "1"
+        try:
+            ctx = capi.Context(L, L, D, 2, chi, dtype=dt, max_walkers=len(cfgs))
+        finally:
+            os.environ.pop("PEPSGPU_DEBUG_SWEEPS", None)
+        ctx.state_upload(flat)
+        ctx.set_configs(cfgs)
+        a = ctx.evaluate_amplitude()
+        st = ctx.stats()
+        assert np.all(ctx.walker_flags() == 0)
+        ctx.close()
+        assert st["carry_live_max"] > 256, st
+        assert np.max(np.abs(a / ref - 1)) < tol, (dt, a, ref)

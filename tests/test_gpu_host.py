@@ -517,3 +517,19 @@ def test_xxz_energy_with_variational_truncate_params(scheme, name):
         assert abs(amps[w] / a - 1) < 1e-7
         assert abs(en[w] - e) < 1e-6 * max(1.0, abs(e))
     assert max(abs(svd[w][1] - ref[w][1]) for w in range(len(ref))) > 1e-5      # the scheme is in effect
+
+
+@pytest.mark.parametrize("weights,init", [([1, 0.5, 0.3, 0.01, 0.06, 2], 0), ([1, 0.3, 1e-30], 0), ([9.6, 9.6, 1], 1), ([0.0, 1.0, 0.0], 1)])
+def test_device_suwa_todo_is_the_reference_chain(weights, init):
+    """The decision of pepsgpu_sweep_slice_fullspace (sw_suwa_todo_decide, float64) on the unit cases of the reference's
+    test_suwa_todo_update.cpp:100-103 (+ an absorbing state, :52-58) against the host layer's SuwaTodoStateUpdate (long double, the
+    reference's arithmetic; tests/test_cpu_suwa_todo.py pins it on the reference's cases and on the oracle): the same std::mt19937
+    stream -> the same chain, 4000 steps, two seeds."""
+    from peps_amd import capi, hostapi
+    from oracle import vmc
+    for seed in (0, 20240115):
+        rng = vmc.StdMT19937(seed)
+        words = np.array([rng.raw() for _ in range(2 * 4000)], dtype=np.uint32)
+        dev = capi.diag_suwa_todo(weights, init, words)
+        host = hostapi.suwa_todo_chain(init, weights, seed, 4000)
+        assert np.array_equal(dev, host), int(np.argmax(dev != host))
