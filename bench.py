@@ -536,6 +536,20 @@ def c5_parity(capi, fermion, st, chi, device, cfgs):
     return res
 
 
+def mode_profile(mode):
+    """dominant kernels of a secondary mode from its committed rocprofv3 runs (profiles/r06_mode_meta.json, scripts/make_mode_meta.py):
+    share of the kernel time, HBM bytes per launch and TB/s from the PMC passes, SQ shares; None when the file is not there"""
+    p = os.path.join(ROOT, "profiles", "r06_mode_meta.json")
+    try:
+        e = json.load(open(p)).get(mode)
+    except Exception:
+        return None
+    if not e:
+        return None
+    return {"source": e["source"], "profiled_amp_per_s": (e.get("probe") or {}).get("amp_per_s"), "profiled_walkers": (e.get("probe") or {}).get("walkers"),
+            "dominant_kernels": [{k: v for k, v in kk.items() if k != "calls"} for kk in e["kernels"][:3]]}
+
+
 def other_modes(capi, synthetic, device, L, D, chi):
     """Driver-measured figures of the secondary modes of the path (one short run each, outside the timed region; rounds 1-2 quoted
     them from builder scripts only): the f64 device mode, the two variational compression schemes (bmps_impl.h:864-1172), the
@@ -578,8 +592,8 @@ def other_modes(capi, synthetic, device, L, D, chi):
         c.state_upload(cflat)
         out["complex128"] = {"amp_per_s": rate(c, [synthetic.make_configs(L, nw, "heisenberg", seed0=70000 + 7 * k) for k in range(2)]), "walkers": nw,
                              "note": "static shapes (no rank adaptivity), GEMMs on the f64 matrix cores; this synthetic state falls to the resolution of a "
-                                     "Gram within a few directions, so the dense route of round 5 does not take it -- its figure on a dense state is "
-                                     "real_rank.complex128 (6.6 -> 70-83 amp/s)"}
+                                     "Gram within a few directions -- its figure on a dense state is real_rank.complex128 (round 4: 6.6, round 5: 82, "
+                                     "round 6: 164 amp/s)"}
         c.close()
     except Exception as e:
         out["complex128"] = {"error": repr(e)}
@@ -597,7 +611,8 @@ def other_modes(capi, synthetic, device, L, D, chi):
         nw64 = 1024
         c = capi.Context(l5, l5, d5, fermion.NVAR * st.d, chi5, dtype=capi.F64, device=device, max_walkers=nw64)
         c.state_upload(st.extended_flat(d5))
-        c5["f64_mode"] = {"amp_per_s": rate(c, [st.ext_config(p[:nw64], fermion.ROW) for p in phys[:2]]), "walkers": nw64}
+        c5["f64_mode"] = {"amp_per_s": rate(c, [st.ext_config(p[:nw64], fermion.ROW) for p in phys[:2]]), "walkers": nw64, "profile": mode_profile("c5_f64")}
+        c5["profile"] = mode_profile("c5_f32")
         c.close()
         c5["tolerance"] = {"f32": {"amplitude": 2e-5, "energy": 2e-5}, "f64": {"amplitude": 1e-7, "energy": 1e-7},
                            "north_star_energy": 1e-6, "note": "relative, asserted in tests/test_gpu_fermion.py (C5_TOL) on eight chain-visited "
@@ -979,8 +994,8 @@ def main():
                     if not args.no_energy_check:
                         pend_energy[name] = ((L, chi, 0 if dt == capi.F32 else 1, local_rank, fleg.flat), fleg.batches[0][:max(2, args.energy_n // 2)])
                 if real and world == 1 and not args.no_other_modes and dt == capi.F32:
-                    # the reference's own arithmetic on the realistic state: the f64 device mode (round 5: dense truncation route of
-                    # the f64 engine -- two-level preconditioning with oversampling, Jacobi problems in LDS), 2 048 walkers
+                    # the reference's own arithmetic on the realistic state: the f64 device mode (round 6: oversampled subspace from a pivoted
+                    # row selection + float64 Gram-Schmidt + one step of subspace iteration, Jacobi on Z = U M in LDS; round 5: 297 amp/s), 2 048 walkers
                     try:
                         n64 = min(2048, fnw)
                         c64 = capi.Context(L, L, D, 2, chi, dtype=capi.F64, device=local_rank, max_walkers=n64)
@@ -999,14 +1014,15 @@ def main():
                                                                         "kernels the same configurations give the same error (scripts/f64_route_parity.py: 5.19e-9 / "
                                                                         "5.17e-9 and 7.601e-9 / 7.609e-9 max over 64); tests/test_gpu_realrank.py asserts 1e-8 on its sample"}
                                                                if oracle_sample is not None else None),
+                                          "profile": mode_profile("f64_real"),
                                           "f32_vs_f64_amplitude": {"max_rel": float(np.max(rel)), "median_rel": float(np.median(rel)),
                                                                    "p99_rel": float(np.percentile(rel, 99)),
                                                                    "share_above_1e-5": float(np.mean(rel > 1e-5)), "n": int(n64)}}
                     except Exception as e:
                         fr["f64_mode"] = {"error": repr(e)}
                 if real and world == 1 and not args.no_other_modes and dt == capi.F32:
-                    # the complex element type on the same state (a random phase on every tensor element): round 5's dense route of
-                    # Engine<cplx<double>> -- 6.6 amp/s before it, whatever the batch
+                    # the complex element type on the same state (a random phase on every tensor element): the dense route of
+                    # Engine<cplx<double>> (round 6: randomised range finder + subspace iteration; round 5: 82 amp/s; round 4: 6.6)
                     try:
                         nc = min(512, fnw)
                         cflat = fleg.flat * np.exp(2j * np.pi * np.random.default_rng(5).uniform(size=fleg.flat.shape))
@@ -1016,7 +1032,7 @@ def main():
                         t0 = time.perf_counter()
                         cc.set_configs(fleg.batches[0][:nc]); cc.evaluate_amplitude(); cc.sync()
                         fr["complex128"] = {"amp_per_s": nc / (time.perf_counter() - t0), "walkers": nc,
-                                            "flagged_walkers": int(np.sum(cc.walker_flags() != 0))}
+                                            "flagged_walkers": int(np.sum(cc.walker_flags() != 0)), "profile": mode_profile("c128_real")}
                         cc.close()
                     except Exception as e:
                         fr["complex128"] = {"error": repr(e)}
