@@ -25,6 +25,11 @@ def short(n):
     return re.sub(r"\(.*", "", n).replace("void ", "").replace("pepsgpu::", "")[:70]
 
 
+def same(a, b):
+    m = min(len(a), len(b), 60)
+    return a[:m] == b[:m]
+
+
 meta = {}
 for mode, tag in MODES.items():
     ks = os.path.join(ROOT, "profiles", "%s_kernel_stats_%s.csv" % (RND, tag))
@@ -41,14 +46,14 @@ for mode, tag in MODES.items():
     for r in rows[:5]:
         n = short(r["Name"])
         k = {"kernel": n, "share": int(r["TotalDurationNs"]) / tot, "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3}
-        f = next((v for kk, v in fe.items() if kk[:44] == n[:44]), None)
-        w = next((v for kk, v in wr.items() if kk[:44] == n[:44]), None)
+        f = next((v for kk, v in fe.items() if same(kk, n)), None)
+        w = next((v for kk, v in wr.items() if same(kk, n)), None)
         if f and w and f["FETCH_SIZE"][0] > 0:
             b = (2.0 * f["FETCH_SIZE"][1] + w["WRITE_SIZE"][1]) * 1024.0
             k["hbm_bytes_per_launch_avg"] = b / f["FETCH_SIZE"][0]
             k["hbm_TB_per_s"] = b / (int(r["TotalDurationNs"]) * 1e-9) / 1e12
             k["frac_of_hbm_peak"] = k["hbm_TB_per_s"] / 8.0
-        s = next((v for kk, v in sq.items() if kk[:44] == n[:44]), None)
+        s = next((v for kk, v in sq.items() if same(kk, n)), None)
         if s and s.get("SQ_WAVE_CYCLES", (0, 0))[1] > 0:
             wc = s["SQ_WAVE_CYCLES"][1]
             k["sq"] = {"wait_any": s.get("SQ_WAIT_ANY", (0, 0))[1] / wc, "wait_inst_any": s.get("SQ_WAIT_INST_ANY", (0, 0))[1] / wc,
