@@ -182,6 +182,11 @@ class Engine : public EngineBase {
       if (const char *e = getenv("PEPSGPU_F64_EPS")) eps = atof(e);
       PG_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_eps64_rt), &eps, sizeof(double)));
     }
+    if constexpr (std::is_same<T, float>::value) {
+      double eps = 5.9604644775390625e-8;
+      if (const char *e = getenv("PEPSGPU_F32_EPS")) eps = atof(e);
+      PG_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_eps32_rt), &eps, sizeof(double)));
+    }
     PG_CHECK_HIP(hipMemsetAsync(flag_, 0, sizeof(int) * (size_t)maxw_, stream_));
     dtype = kCplx ? 3 : (sizeof(T) == 4 ? 0 : 1);
     for (int q = 0; q < 4; ++q) { redo_seen_[q].assign(std::max(Ly_, Lx_) + 1, 0); carry_seen_[q].assign(std::max(Ly_, Lx_) + 1, -1); }

@@ -22,8 +22,11 @@ template <> struct Eps<double> { static constexpr double v = 1.1102230246251565e
 template <typename R> struct Eps<cplx<R>> { static constexpr R v = Eps<R>::v; };
 // Error-budget experiments (scripts/error_budget.py): the float64 engine can run with the noise floors of the float32 one
 // (PEPSGPU_F64_EPS=<eps> at context creation sets this device global; default = the float64 epsilon, i.e. no change).
+// PEPSGPU_F32_EPS: the same instrument the other way round -- the factor kernels of the float32 engine with lower (or higher) floors.
 __device__ double g_eps64_rt = 1.1102230246251565e-16;
+__device__ double g_eps32_rt = 5.9604644775390625e-8;
 template <typename T> __device__ __forceinline__ double eps_rt() { return (double)Eps<T>::v; }
+template <> __device__ __forceinline__ double eps_rt<float>() { return g_eps32_rt; }
 template <> __device__ __forceinline__ double eps_rt<double>() { return g_eps64_rt; }
 
 // 64-lane all-reductions on the DPP / permlane-swap path (a few cycles of latency per step, no LDS crossbar): the step
@@ -278,8 +281,9 @@ __device__ __forceinline__ double chb_readlane(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
 }
+constexpr int CH_NS = 256;                      // LDS row stride of the panel (orders up to 256)
 inline size_t chol_blocked_smem_bytes(int n) {
-  return sizeof(double) * ((size_t)CH_NB * n + n) + sizeof(short) * 2 * (size_t)n + 64;
+  return sizeof(double) * ((size_t)CH_NB * CH_NS + n) + sizeof(short) * 2 * (size_t)n + 64;
 }
 
 template <typename T, int MINB = 3, int PFD = 3>      // PFD: k-steps of the update in flight (loads from L2 ahead of the MFMAs)
@@ -295,8 +299,8 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
   const int ldg = ld ? ld : n;
   if (ndyn) n = max(0, min(n, ndyn[blockIdx.x] * ndyn_mul));
   extern __shared__ double chb_smem[];
-  double *sP = chb_smem;                          // [CH_NB][n]   current block row
-  double *sN = sP + CH_NB * n;                    // [n]          row norms^2 of the finished factor
+  double *sP = chb_smem;                          // [CH_NB][CH_NS]   current block row
+  double *sN = sP + CH_NB * CH_NS;                // [n]          row norms^2 of the finished factor
   short *sList = reinterpret_cast<short *>(sN + n);   // [n] live rows so far
   short *sPos = sList + n;                             // [n] output position of a row, -1 = dropped
   __shared__ double sD[CH_NB][CH_NB + 1], sDinv[CH_NB];
@@ -323,25 +327,47 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
   const double sc_out = maxd > 0.0 ? 1.0 / sqrt(maxd) : 1.0;
   const int i16 = lane & 15, k4 = lane >> 4;
 
+  // Round 6 (phase counters of an instrumented build, scripts/chb_phase_patch.py: a walker alone took 475 us -- update 266, publish 68,
+  // diagonal block 48, substitution 47, staging 17): thread = column everywhere (no e / n index arithmetic: ~3 us per panel), the
+  // panel's rows of G travel to LDS by LDS-DMA while the update loop runs (no registers: PFD k-steps of the update in flight instead
+  // of two), two rows of the substitution's factor reads in flight.  Measured and not kept: panels in PAIRS (one pass over the finished
+  // rows for two panels, the second panel's sums waiting in registers: update 266 -> 160 us, but 32 more live registers through the
+  // diagonal block / substitution / publish phases spill at three blocks per CU -- 560 us per walker at full occupancy against 440).
+  constexpr int NS = CH_NS;                     // LDS row stride of the panel (the DMA writes whole 16-byte chunks: a fixed, even stride)
+  const bool dma = (ldg & 1) == 0 && n >= 2;    // 16-byte aligned row starts (block-uniform); odd leading dimensions take the register path
+  auto request_panel = [&](int jb, int nb) {
+    // wave w brings rows w, w + 4, ...: lane l the doubles 2 l, 2 l + 1 (+ 128 for the second half) of the row, clamped inside the row
+    for (int c = wave; c < nb; c += 4) {
+      const double *row = G + (long)(jb + c) * ldg;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (128 * h < n) {
+          const int e = min(128 * h + 2 * lane, ((n + 1) & ~1) - 2);      // (odd n: column n exists, the leading dimension is even)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(row + e),
+                                           (__attribute__((address_space(3))) void *)(sP + c * NS + 128 * h), 16, 0, 0);
+        }
+      }
+    }
+  };
+  auto load_panel = [&](int jb, int nb, double (&pv)[CH_NB]) {
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) pv[c] = (c < nb && tid >= jb && tid < n) ? G[(long)(jb + c) * ldg + tid] : 0.0;
+  };
+
   for (int jb = 0; jb < n; jb += CH_NB) {
     const int nb = min(CH_NB, n - jb);
-    // the panel's rows of G: requested now (registers), laid down in LDS after the update loop has issued its own loads
-    double pv[CH_NB];
-#pragma unroll
-    for (int q = 0; q < CH_NB; ++q) {
-      const int e = tid + 256 * q;
-      const int c = e / n, r = e - c * n;
-      pv[q] = (e < CH_NB * n && c < nb && r >= jb) ? G[(long)(jb + c) * ldg + r] : 0.0;
-    }
     const int nprev = s_nlive;
+    // the panel's rows of G: requested now, in LDS when the update loop is through
+    double pv[CH_NB];
+    if (dma) request_panel(jb, nb); else load_panel(jb, nb, pv);
+    chb_f64x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[q][r] = 0.0;
+    const int ntile = (n - jb + 15) >> 4;
     // ---- left-looking update on the matrix cores ----
     {
-      const int ntile = (n - jb + 15) >> 4;
-      chb_f64x4 acc[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[q][r] = 0.0;
       int col[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -351,55 +377,62 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
       }
       const bool aok = jb + i16 < n;
       const int acol = aok ? jb + i16 : jb;
-      const int nq = (ntile - wave + 3) >> 2;    // tiles of this wave (wave-uniform)
-      // unconditional loads at clamped addresses (a row beyond the live list reads the last one, its A operand is zeroed):
-      // no exec-masked load, the wait counters stay exact and PF k-steps are in flight
-      auto load = [&](int k0, double &a, double (&b)[4]) {
-        const int kk = min(k0 + k4, nprev - 1);
-        const double *row = G + (long)kk * ldg;      // finished rows sit compacted in the first rows of G (see the publish step)
-        a = row[acol];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) b[q] = row[col[q]];
-      };
-      auto step = [&](int k0, const double a, const double (&b)[4]) {
-        const double am = (k0 + k4 < nprev && aok) ? a : 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (q < nq) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(am, b[q], acc[q], 0, 0, 0);
-      };
-      if (nq > 0 && nprev > 0) {
+      const int nq = __builtin_amdgcn_readfirstlane((ntile - wave + 3) >> 2);    // tiles of this wave (wave-uniform)
+      // The loop body is straight-line code for a compile-time tile count NQC (the wave's tiles of the block row; a switch outside the
+      // loop picks it): every load and every MFMA unconditional -- rows beyond the live list are clamped copies whose A operand is
+      // zeroed.  (Rounds 3-5 and the first form of this round had `if (q < nq)` / `if (cur + PF - 1 < nks)` inside: the compiler turned
+      // them into exec-mask branches and waited for vmcnt(0) before the first MFMA of a k-step -- ONE k-step in flight whatever PF, which
+      // is why 2 / 3 / 5 / 8 k-steps in flight all measured the same.)
+      auto run = [&](auto NQC_) {
+        constexpr int NQC = decltype(NQC_)::value;
         constexpr int PF = PFD;
-        double av[PF], bv[PF][4];
+        double av[PF], bv[PF][NQC];
         const int nks = (nprev + 3) >> 2;
+        auto load = [&](int k0, double &a, double (&b)[NQC]) {
+          const int kk = min(k0 + k4, nprev - 1);
+          const unsigned row = (unsigned)(kk * ldg);   // finished rows sit compacted in the first rows of G (see the publish step);
+          a = G[row + (unsigned)acol];                 // 32-bit offsets from the walker's (scalar) base: no 64-bit address per load
 #pragma unroll
-        for (int p = 0; p < PF; ++p) { av[p] = 0.0; for (int q = 0; q < 4; ++q) bv[p][q] = 0.0; }
+          for (int q = 0; q < NQC; ++q) b[q] = G[row + (unsigned)col[q]];
+        };
 #pragma unroll
-        for (int p = 0; p < PF - 1; ++p)
-          if (p < nks) load(4 * p, av[p], bv[p]);
+        for (int p = 0; p < PF - 1; ++p) load(4 * p, av[p], bv[p]);
         for (int ks = 0; ks < nks; ks += PF) {
 #pragma unroll
           for (int p = 0; p < PF; ++p) {
             const int cur = ks + p;
-            if (cur + PF - 1 < nks) load(4 * (cur + PF - 1), av[(p + PF - 1) % PF], bv[(p + PF - 1) % PF]);
-            if (cur < nks) step(4 * cur, av[p], bv[p]);
+            load(4 * (cur + PF - 1), av[(p + PF - 1) % PF], bv[(p + PF - 1) % PF]);
+            __builtin_amdgcn_sched_barrier(0);      // keep the rotation: without the fences the scheduler gathers the loads of PF steps
+            const double am = (4 * cur + k4 < nprev && aok) ? av[p] : 0.0;      // in front of their MFMAs and waits for all of them
+#pragma unroll
+            for (int q = 0; q < NQC; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bv[p][q], acc[q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
-      }
-#pragma unroll
-      for (int q = 0; q < CH_NB; ++q) {
-        const int e = tid + 256 * q;
-        if (e < CH_NB * n) sP[e] = pv[q];
-      }
-      __syncthreads();                           // the panel is staged
+      };
       if (nprev > 0) {
+        switch (nq) {
+          case 4: run(std::integral_constant<int, 4>()); break;
+          case 3: run(std::integral_constant<int, 3>()); break;
+          case 2: run(std::integral_constant<int, 2>()); break;
+          case 1: run(std::integral_constant<int, 1>()); break;
+          default: break;
+        }
+      }
+    }
+    if (!dma && tid < n) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int t = wave + 4 * q;
-          const int cc = jb + 16 * t + i16;
-          if (t < ntile && cc < n) {
+      for (int c = 0; c < CH_NB; ++c) sP[c * NS + tid] = pv[c];
+    }
+    __syncthreads();                           // the panel is staged (the barrier's fence waits for the LDS-DMA: vmcnt(0))
+    if (nprev > 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sP[(k4 + 4 * r) * n + cc] -= acc[q][r];      // acc[r] = C[k4 + 4 r][i16]
-          }
+      for (int q = 0; q < 4; ++q) {
+        const int t = wave + 4 * q;
+        const int cc = jb + 16 * t + i16;
+        if (t < ntile && cc < n) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sP[(k4 + 4 * r) * NS + cc] -= acc[q][r];      // acc[r] = C[k4 + 4 r][i16]
         }
       }
     }
@@ -408,7 +441,7 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
     if (wave == 0) {
       double d[CH_NB];
 #pragma unroll
-      for (int c = 0; c < CH_NB; ++c) d[c] = (lane < nb && c <= lane) ? sP[c * n + jb + lane] : 0.0;
+      for (int c = 0; c < CH_NB; ++c) d[c] = (lane < nb && c <= lane) ? sP[c * NS + jb + lane] : 0.0;
       unsigned livemask = 0;
 #pragma unroll
       for (int c = 0; c < CH_NB; ++c) {
@@ -417,10 +450,10 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
         // branch-free (round 4): a dropped pivot zeroes its row and the updates below become no-ops -- under `if (live)` the
         // compiler copied the whole d[] (16 v_mov_b64) at the join of every pivot step, 256 moves per panel on the one wave
         // every other wave of the block waits for
-        const double pv = live ? piv : 1.0;
-        double sc = __builtin_amdgcn_rsq(pv);                 // ~2^-26 relative; two Newton steps -> float64
-        sc = sc * (1.5 - 0.5 * pv * sc * sc);
-        sc = sc * (1.5 - 0.5 * pv * sc * sc);
+        const double pvt = live ? piv : 1.0;
+        double sc = __builtin_amdgcn_rsq(pvt);                // ~2^-26 relative; two Newton steps -> float64
+        sc = sc * (1.5 - 0.5 * pvt * sc * sc);
+        sc = sc * (1.5 - 0.5 * pvt * sc * sc);
         d[c] = live ? d[c] * sc : 0.0;
 #pragma unroll
         for (int c2 = c + 1; c2 < CH_NB; ++c2) {
@@ -451,17 +484,17 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
       if (r < n) {
         if (tid < CH_NB) {
 #pragma unroll
-          for (int c = 0; c < CH_NB; ++c) sP[c * n + r] = sD[c][tid];
+          for (int c = 0; c < CH_NB; ++c) sP[c * NS + r] = sD[c][tid];
         } else {
           double x[CH_NB];
 #pragma unroll
           for (int c = 0; c < CH_NB; ++c) {
-            double v = sP[c * n + r];
+            double v = sP[c * NS + r];
 #pragma unroll
             for (int c1 = 0; c1 < c; ++c1) v -= sD[c1][c] * x[c1];
             x[c] = v * sDinv[c];                  // dropped row: sDinv = 0
-            sP[c * n + r] = x[c];
-            __asm__ volatile("" ::: "memory");    // keep the factor reads of the later rows from being hoisted (136 doubles)
+            sP[c * NS + r] = x[c];
+            if (c & 1) __asm__ volatile("" ::: "memory");    // keep the factor reads of the later rows from being hoisted (136 doubles): two rows' worth in flight
           }
         }
       }
@@ -474,16 +507,18 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
     // first rows of G, so the update loop addresses them without the live list; their columns below jb + c keep stale data
     // that no later panel reads)
     const int wout = ndyn ? ldg : n;
-    for (int e = tid; e < nb * n; e += 256) {
-      const int c = e / n, r = e - c * n;
-      if (r >= jb + c && ((livemask >> c) & 1u)) G[(long)(nprev + __popc(livemask & ((1u << c) - 1u))) * ldg + r] = sP[c * n + r];
+    if (tid < n) {
+#pragma unroll
+      for (int c = 0; c < CH_NB; ++c)
+        if (c < nb && tid >= jb + c && ((livemask >> c) & 1u))
+          G[(long)(nprev + __popc(livemask & ((1u << c) - 1u))) * ldg + tid] = sP[c * NS + tid];
     }
     for (int c = wave; c < nb; c += 4) {
       if (!((livemask >> c) & 1u)) continue;
       const int pos = nprev + __popc(livemask & ((1u << c) - 1u));
       double a = 0.0;
       for (int r = lane; r < wout; r += 64) {
-        const double x = (r >= jb + c && r < n) ? sP[c * n + r] : 0.0;
+        const double x = (r >= jb + c && r < n) ? sP[c * NS + r] : 0.0;
         a += x * x;
         Rout[(long)pos * ldg + r] = T(x * sc_out);
       }
@@ -551,8 +586,8 @@ inline void launch_chol_upper(hipStream_t s, int nbatch, double *G, long wG, int
   // states with D chi > 256, found with scripts/bigbond_probe.py; larger orders take the general kernel)
   if (n >= 48 && n <= 256) {
     const size_t smem = chol_blocked_smem_bytes(n);
-    allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3, 2>), smem);
-    hipLaunchKernelGGL((chol_blocked_kernel<T, 3, 2>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
+    allow_dynamic_lds(reinterpret_cast<const void *>(&chol_blocked_kernel<T, 3, 4>), smem);
+    hipLaunchKernelGGL((chol_blocked_kernel<T, 3, 4>), dim3(nbatch), dim3(256), smem, s, G, wG, n, R, wR, mlive_out, only_flagged, ld, ndyn,
                        ndyn_mul, run_flag, thresh_scale);
   } else {
     const size_t smem = chol_smem_bytes(n);

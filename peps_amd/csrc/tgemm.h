@@ -188,8 +188,12 @@ __device__ __forceinline__ void tgemm_tile(const TGemmDesc &d, const TA *__restr
         if (b_jfast) { jb = e & 63; kb = e >> 6; } else { kb = e & 15; jb = e >> 4; }
         int kka = kt * TG_BK + ka, kkb = kt * TG_BK + kb;
         int oa = offAi[ia], ob = offBj[jb];
-        ra[r] = (oa >= 0 && kka < kchunk) ? TAcc(A[oa + offAk[kka]]) : TAcc(0);
-        rb[r] = (ob >= 0 && kkb < kchunk) ? TAcc(B[ob + offBk[kkb]]) : TAcc(0);
+        // unconditional loads at clamped (always valid) addresses, the predicate applied to the value: a load under `?:` became an
+        // exec-masked branch with its own s_waitcnt vmcnt(0) at the join -- eight memory latencies in a row per k-tile (rounds 1-5)
+        const TA va = A[max(oa, 0) + offAk[min(kka, kchunk - 1)]];
+        const TB vb = B[max(ob, 0) + offBk[min(kkb, kchunk - 1)]];
+        ra[r] = (oa >= 0 && kka < kchunk) ? TAcc(va) : TAcc(0);
+        rb[r] = (ob >= 0 && kkb < kchunk) ? TAcc(vb) : TAcc(0);
         if constexpr (is_cplx<TAcc>::value) {
           if (d.conjA) ra[r] = conj_of(ra[r]);
           if (d.conjB) rb[r] = conj_of(rb[r]);
@@ -381,7 +385,8 @@ __device__ __forceinline__ void tgemm_tile_skinny(const TGemmDesc &d, const TA *
         int ia, ka;
         if (a_ifast) { ia = e % BM; ka = e / BM; } else { ka = e & 15; ia = e >> 4; }
         const int kk = kt * TG_BK + ka, oa = offAi[ia];
-        ra[r] = (oa >= 0 && kk < kchunk) ? (double)A[oa + offAk[kk]] : 0.0;
+        const TA va = A[max(oa, 0) + offAk[min(kk, kchunk - 1)]];      // unconditional, clamped (see tgemm_tile)
+        ra[r] = (oa >= 0 && kk < kchunk) ? (double)va : 0.0;
       }
 #pragma unroll
       for (int r = 0; r < NB; ++r) {
@@ -389,7 +394,8 @@ __device__ __forceinline__ void tgemm_tile_skinny(const TGemmDesc &d, const TA *
         int jb, kb;
         if (b_jfast) { jb = e % BN; kb = e / BN; } else { kb = e & 15; jb = e >> 4; }
         const int kk = kt * TG_BK + kb, ob = offBj[jb];
-        rb[r] = (ob >= 0 && kk < kchunk) ? (double)B[ob + offBk[kk]] : 0.0;
+        const TB vb = B[max(ob, 0) + offBk[min(kk, kchunk - 1)]];
+        rb[r] = (ob >= 0 && kk < kchunk) ? (double)vb : 0.0;
       }
     };
     auto store_regs = [&]() {
@@ -569,6 +575,9 @@ __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *
   // index), K walked with uniform counters, loads unconditional at clamped addresses (rows and columns that do not exist
   // read row / column 0 and are never stored; k beyond the live extent is zeroed in the last round of a k2 run only),
   // the loads of round r+1 issued before and consumed after the MFMAs of round r.
+  // (Round 6 measured a ring of three / four rounds in flight here and in the f64 body -- s_waitcnt vmcnt(10..23) in the loops instead
+  // of 0..11 --: direct launches 416 -> 400 ms, chained launches and the headline unchanged (121.1 k): these loops do not wait for one
+  // round trip per round; not kept.)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ntj = (Jtot + 31) >> 5, ntiles = ((Itot + 31) >> 5) * ntj;
   const float alpha = (float)d.alpha * scale;

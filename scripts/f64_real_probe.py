@@ -17,6 +17,13 @@ if what == "real":
     if dt == capi.C128:
         flat = flat * np.exp(2j * np.pi * np.random.default_rng(5).uniform(size=flat.shape))
     batches = [synthetic.make_configs_near_neel(L, nw, seed0=307 + 1000 * k) for k in range(2)]
+elif what.startswith("noise"):      # the synthetic state of bench.py: noise0.1 = headline, noise1 = full rank
+    L, D, chi, dphys = 12, 8, 32, 2
+    sitps = synthetic.make_sitps(L, D, noise=float(what[5:]))
+    ctx = capi.Context(L, L, D, 2, chi, dtype=capi.F32, max_walkers=1)
+    ctx.state_upload(synthetic.sitps_to_flat(sitps, D, np.float64)); ctx.set_configs(synthetic.checkerboard(L)[None])
+    flat = synthetic.sitps_to_flat(synthetic.rescale_sitps(sitps, float(ctx.evaluate_amplitude()[0])), D, np.float64); ctx.close()
+    batches = [synthetic.make_configs(L, nw, "heisenberg", seed0=7 + 1000 * k) for k in range(2)]
 else:
     from peps_amd import fermion
     L, D, chi = 8, 6, 24
