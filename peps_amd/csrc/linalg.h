@@ -762,11 +762,15 @@ __device__ __forceinline__ void gram_chol_lowrank_body(const int walker, const T
     const int npr = min(Ktot - k0, KCAP - (pass > 0 ? RCAP : 0));    // rows of P taken in this pass
     const int K = nfr + npr;
     double d = 0.0;
+    // (rows requested unconditionally at clamped addresses, the predicates applied to the values: see gram_chol_wave_kernel)
+    const int klast = max(K - 1, nfr);
+    const unsigned rcl = col_ok ? (unsigned)r : 0u;
+#pragma unroll
+    for (int k = 0; k < KCAP; ++k) pc[k] = P[(unsigned)((k0 + min(max(k, nfr), klast) - nfr) * n) + rcl];
 #pragma unroll
     for (int k = 0; k < KCAP; ++k) {
-      T x = T(0);
+      T x = (k < K && col_ok) ? pc[k] : T(0);
       if (k < RCAP && k < nfr) x = T(rc[k < RCAP ? k : 0]);
-      else if (k < K && col_ok) x = P[(long)(k0 + k - nfr) * n + r];
       pc[k] = x;
       d += (double)pc[k] * (double)pc[k];
     }
@@ -955,15 +959,22 @@ __global__ __launch_bounds__(256, 2) void gram_chol_wave_kernel(const float *__r
     const int npr = min(Ktot - k0, KC - (pass > 0 ? RC : 0));
     const int K = nfr + npr;
     double d0 = 0.0, d1 = 0.0;
+    // Every row is requested unconditionally at a clamped address (a row that does not exist reads the last one that does, a
+    // column that does not exist reads column 0) and the predicates are applied to the VALUES: under `if (ok0) x0 = P[...]` each
+    // load sat in its own exec-masked block with an s_waitcnt vmcnt(0) at the join -- 18 full memory round trips per pass where
+    // the 128 requests now go out back to back (round 6, found in the ISA: 304 exec branches in this loop).
+    const int klast = max(K - 1, nfr);
+    float y0[KC], y1[KC];
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
-      float x0 = 0.f, x1 = 0.f;
+      const unsigned ro = (unsigned)((k0 + min(max(k, nfr), klast) - nfr) * n);
+      y0[k] = P[ro + (unsigned)r0];
+      y1[k] = P[ro + (unsigned)r1];
+    }
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      float x0 = (k < K && ok0) ? y0[k] : 0.f, x1 = (k < K && ok1) ? y1[k] : 0.f;
       if (k < RC && k < nfr) { x0 = (float)q0[k < RC ? k : 0]; x1 = (float)q1[k < RC ? k : 0]; }
-      else if (k < K) {
-        const long ro = (long)(k0 + k - nfr) * n;
-        if (ok0) x0 = P[ro + r0];
-        if (ok1) x1 = P[ro + r1];
-      }
       p0[k] = x0; p1[k] = x1;
       d0 += (double)x0 * (double)x0;
       d1 += (double)x1 * (double)x1;

@@ -168,7 +168,9 @@ __device__ __forceinline__ void tgemm_tile(const TGemmDesc &d, const TA *__restr
       for (int c = 0; c < 4; ++c) accv[a][c] = TAcc(0);
   }
 
-  TAcc ra[4], rb[4];
+  TA va[4];
+  TB vb[4];
+  unsigned okm = 0u;      // bit 2 r: element r of A exists, bit 2 r + 1: of B
   for (int kc = 0; kc < Ktot; kc += TG_KTAB) {
     const int kchunk = min(TG_KTAB, Ktot - kc);
     __syncthreads();
@@ -180,6 +182,7 @@ __device__ __forceinline__ void tgemm_tile(const TGemmDesc &d, const TA *__restr
     const int nkt = (kchunk + TG_BK - 1) / TG_BK;
 
     auto load_regs = [&](int kt) {
+      okm = 0u;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int e = tid + 256 * r;
@@ -188,16 +191,12 @@ __device__ __forceinline__ void tgemm_tile(const TGemmDesc &d, const TA *__restr
         if (b_jfast) { jb = e & 63; kb = e >> 6; } else { kb = e & 15; jb = e >> 4; }
         int kka = kt * TG_BK + ka, kkb = kt * TG_BK + kb;
         int oa = offAi[ia], ob = offBj[jb];
-        // unconditional loads at clamped (always valid) addresses, the predicate applied to the value: a load under `?:` became an
-        // exec-masked branch with its own s_waitcnt vmcnt(0) at the join -- eight memory latencies in a row per k-tile (rounds 1-5)
-        const TA va = A[max(oa, 0) + offAk[min(kka, kchunk - 1)]];
-        const TB vb = B[max(ob, 0) + offBk[min(kkb, kchunk - 1)]];
-        ra[r] = (oa >= 0 && kka < kchunk) ? TAcc(va) : TAcc(0);
-        rb[r] = (ob >= 0 && kkb < kchunk) ? TAcc(vb) : TAcc(0);
-        if constexpr (is_cplx<TAcc>::value) {
-          if (d.conjA) ra[r] = conj_of(ra[r]);
-          if (d.conjB) rb[r] = conj_of(rb[r]);
-        }
+        // unconditional loads at clamped (always valid) addresses; the predicate is applied to the VALUE when it is stored to LDS,
+        // behind the MFMAs of the tile before: a load under `?:` became an exec-masked branch with its own s_waitcnt vmcnt(0) at
+        // the join -- eight memory latencies in a row per k-tile (rounds 1-5, found in the ISA in round 6)
+        va[r] = A[max(oa, 0) + offAk[min(kka, kchunk - 1)]];
+        vb[r] = B[max(ob, 0) + offBk[min(kkb, kchunk - 1)]];
+        okm |= ((oa >= 0 && kka < kchunk) ? 1u : 0u) << (2 * r) | ((ob >= 0 && kkb < kchunk) ? 2u : 0u) << (2 * r);
       }
     };
     auto store_regs = [&]() {
@@ -207,8 +206,14 @@ __device__ __forceinline__ void tgemm_tile(const TGemmDesc &d, const TA *__restr
         int ia, ka, jb, kb;
         if (a_ifast) { ia = e & 63; ka = e >> 6; } else { ka = e & 15; ia = e >> 4; }
         if (b_jfast) { jb = e & 63; kb = e >> 6; } else { kb = e & 15; jb = e >> 4; }
-        As[ka][ia] = ra[r];
-        Bs[kb][jb] = rb[r];
+        TAcc ra = ((okm >> (2 * r)) & 1u) ? TAcc(va[r]) : TAcc(0);
+        TAcc rb = ((okm >> (2 * r)) & 2u) ? TAcc(vb[r]) : TAcc(0);
+        if constexpr (is_cplx<TAcc>::value) {
+          if (d.conjA) ra = conj_of(ra);
+          if (d.conjB) rb = conj_of(rb);
+        }
+        As[ka][ia] = ra;
+        Bs[kb][jb] = rb;
       }
     };
 
@@ -368,7 +373,9 @@ __device__ __forceinline__ void tgemm_tile_skinny(const TGemmDesc &d, const TA *
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[a][c][r] = 0.0;
   constexpr int NA = BM * TG_BK / 256, NB = BN * TG_BK / 256;
-  double ra[NA], rb[NB];
+  TA va[NA];
+  TB vb[NB];
+  unsigned okm = 0u;      // bit r: element r of A exists, bit NA + r: of B
   for (int kc = 0; kc < Ktot; kc += TG_KTAB) {
     const int kchunk = min(TG_KTAB, Ktot - kc);
     __syncthreads();
@@ -379,14 +386,15 @@ __device__ __forceinline__ void tgemm_tile_skinny(const TGemmDesc &d, const TA *
     __syncthreads();
     const int nkt = (kchunk + TG_BK - 1) / TG_BK;
     auto load_regs = [&](int kt) {
+      okm = 0u;
 #pragma unroll
       for (int r = 0; r < NA; ++r) {
         const int e = tid + 256 * r;
         int ia, ka;
         if (a_ifast) { ia = e % BM; ka = e / BM; } else { ka = e & 15; ia = e >> 4; }
         const int kk = kt * TG_BK + ka, oa = offAi[ia];
-        const TA va = A[max(oa, 0) + offAk[min(kk, kchunk - 1)]];      // unconditional, clamped (see tgemm_tile)
-        ra[r] = (oa >= 0 && kk < kchunk) ? (double)va : 0.0;
+        va[r] = A[max(oa, 0) + offAk[min(kk, kchunk - 1)]];      // unconditional, clamped; predicate at the LDS store (see tgemm_tile)
+        okm |= ((oa >= 0 && kk < kchunk) ? 1u : 0u) << r;
       }
 #pragma unroll
       for (int r = 0; r < NB; ++r) {
@@ -394,8 +402,8 @@ __device__ __forceinline__ void tgemm_tile_skinny(const TGemmDesc &d, const TA *
         int jb, kb;
         if (b_jfast) { jb = e % BN; kb = e / BN; } else { kb = e & 15; jb = e >> 4; }
         const int kk = kt * TG_BK + kb, ob = offBj[jb];
-        const TB vb = B[max(ob, 0) + offBk[min(kk, kchunk - 1)]];
-        rb[r] = (ob >= 0 && kk < kchunk) ? (double)vb : 0.0;
+        vb[r] = B[max(ob, 0) + offBk[min(kk, kchunk - 1)]];
+        okm |= ((ob >= 0 && kk < kchunk) ? 1u : 0u) << (NA + r);
       }
     };
     auto store_regs = [&]() {
@@ -404,14 +412,14 @@ __device__ __forceinline__ void tgemm_tile_skinny(const TGemmDesc &d, const TA *
         const int e = tid + 256 * r;
         int ia, ka;
         if (a_ifast) { ia = e % BM; ka = e / BM; } else { ka = e & 15; ia = e >> 4; }
-        As[ka][ia] = ra[r];
+        As[ka][ia] = ((okm >> r) & 1u) ? (double)va[r] : 0.0;
       }
 #pragma unroll
       for (int r = 0; r < NB; ++r) {
         const int e = tid + 256 * r;
         int jb, kb;
         if (b_jfast) { jb = e % BN; kb = e / BN; } else { kb = e & 15; jb = e >> 4; }
-        Bs[kb][jb] = rb[r];
+        Bs[kb][jb] = ((okm >> (NA + r)) & 1u) ? (double)vb[r] : 0.0;
       }
     };
     load_regs(0);
