@@ -1191,6 +1191,132 @@ __global__ __launch_bounds__(256) void zero_dead_cols_kernel(T *__restrict__ Pg,
 // or a rank-deficient carry) the surplus rows can never become "relatively" orthogonal.  The
 // working copy lives in LDS when it fits (use_lds), else in global memory (L2-resident).
 // mdyn (optional): per-walker number of existing rows, mdyn[b]*mdyn_mul <= m (rank-adaptive carry).
+// LDS-resident rows of 193 .. 256 elements (the Z = U M blocks of the dense f64 route: 40 % of its step), round 6: the sweeps on the
+// LDS array itself -- ds_read instead of the FLAT loads behind the generic pointer `use_lds ? sM : Mglob`, which were waited for one at
+// a time (the dot-product and rotation loops of a pair were 4 + 4 serial round trips) -- with both rows of a pair in registers between
+// the inner products and the rotation (one read and one write per row and pair instead of two reads and a write).  The same sums in
+// the same order: bit-identical results.  (Shorter rows and rows in global memory keep the loops below: the same form on 144-element
+// rows measured 169 against 154 ms on C5.)
+template <typename T>
+__device__ __forceinline__ int jacobi_rows_lds256(T *sM, const int m, const int len, const int lds_ld, const int max_sweeps, int &s_rot,
+                                                  double *s_fro, short *s_idx, unsigned char *s_flag, int &s_nl) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const T tol = T(2) * sqrt(T(len)) * T(eps_rt<T>());
+  T *M = sM;
+  constexpr int NQ = 4;
+  constexpr bool REG = true;
+  {
+    {
+      double f = 0.0;
+      for (int e = tid; e < m * len; e += blockDim.x) { double x = (double)M[(long)(e / len) * lds_ld + (e % len)]; f += x * x; }
+      f = wave_sum(f);
+      if (lane == 0) s_fro[wave] = f;
+      __syncthreads();
+      if (tid == 0) { double t = 0.0; for (int w = 0; w < nw; ++w) t += s_fro[w]; s_fro[0] = t; }
+      __syncthreads();
+    }
+    const T floor2 = T(NOISE_C * NOISE_C * eps_rt<T>() * eps_rt<T>() * s_fro[0]);
+    int sweep = 0;
+    for (; sweep < max_sweeps; ++sweep) {
+      if (tid == 0) s_rot = 0;
+      for (int r = wave; r < m; r += nw) {
+        const auto *pr = M + (long)r * lds_ld;
+        T n2 = 0;
+        for (int c = lane; c < len; c += 64) { T x = pr[c]; n2 += x * x; }
+        n2 = wave_sum(n2);
+        if (lane == 0) s_flag[r] = n2 > floor2;
+      }
+      __syncthreads();
+      if (wave == 0) {   // deterministic compaction of the live row list
+        int cnt = 0;
+        for (int base = 0; base < m; base += 64) {
+          const int r = base + lane;
+          const bool f = r < m && s_flag[r];
+          const unsigned long long mask = __ballot(f);
+          if (f) s_idx[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (short)r;
+          cnt += __popcll(mask);
+        }
+        if (lane == 0) s_nl = cnt;
+      }
+      __syncthreads();
+      const int nl = s_nl;
+      const int lp = nl + (nl & 1);
+      // (round 5, measured and removed: a wave taking four pairs of a round at a time -- eight rows requested together, rotated from
+      // registers -- moved the f64 mode on the dense real state 25.2 -> 28.6 amp/s and C5 f64 2 268 -> 1 897: with the rows in global
+      // memory the kernel is bound by the TRAFFIC of a sweep, m - 1 passes over the whole matrix (261 MB per sweep of a 256 x 256
+      // float64 block, 512 blocks in flight = 256 MB of working set), not by the latency of a pair.  The dense f64 sites take the
+      // two-level preconditioned route of engine_impl.h instead, whose Jacobi problems fit LDS.)
+      for (int r = 0; r < lp - 1; ++r) {
+        auto pair_of = [&](const int p, int &a, int &b) -> bool {      // rows of pair p of round r; false: a bye
+          if (p >= lp / 2) return false;
+          if (p == 0) { a = lp - 1; b = r; }
+          else { a = (r + p) % (lp - 1); b = (r - p + (lp - 1)) % (lp - 1); }
+          if (a > b) { int t = a; a = b; b = t; }
+          if (b >= nl) return false;
+          a = s_idx[a]; b = s_idx[b];
+          return true;
+        };
+        // (measured and not kept, round 6: two pairs of the round per pass of a wave with their reads, reductions and rotation
+        // parameters interleaved -- f64 real state: Jacobi 1 057 -> 1 107 ms per step, C5 f64 169 -> 206)
+        for (int p = wave; p < lp / 2; p += nw) {
+          int a, b;
+          if (!pair_of(p, a, b)) continue;
+          auto *pa = M + (long)a * lds_ld, *pb = M + (long)b * lds_ld;
+          T alpha = 0, beta = 0, gamma = 0;
+          T xr[REG ? NQ : 1], yr[REG ? NQ : 1];
+          if constexpr (REG) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {      // unconditional reads at clamped positions, the predicate on the value
+              const int c = lane + 64 * q, cc = min(c, len - 1);
+              const T x = pa[cc], y = pb[cc];
+              xr[q] = c < len ? x : T(0); yr[q] = c < len ? y : T(0);
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { alpha += xr[q] * xr[q]; beta += yr[q] * yr[q]; gamma += xr[q] * yr[q]; }
+          } else {
+            for (int c = lane; c < len; c += 64) {
+              T x = pa[c], y = pb[c];
+              alpha += x * x; beta += y * y; gamma += x * y;
+            }
+          }
+          alpha = wave_sum(alpha); beta = wave_sum(beta); gamma = wave_sum(gamma);
+          const T ab = sqrt(alpha) * sqrt(beta);
+          // no de Rijk row swapping: exchanging rows inside a round-robin tournament breaks the
+          // pair coverage of the sweep (measured: 2x the sweeps); select_rows_kernel sorts afterwards
+          if (fabs(gamma) > tol * ab && alpha > floor2 && beta > floor2) {
+            // rotation parameters in f64 (one scalar per pair): keeps c^2 + s^2 = 1 to f32 rounding
+            const double zeta = ((double)beta - (double)alpha) / (2.0 * (double)gamma);
+            const double td = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            const double cd = 1.0 / sqrt(1.0 + td * td);
+            const T cs = T(cd), sn = T(cd * td);
+            if constexpr (REG) {
+#pragma unroll
+              for (int q = 0; q < NQ; ++q) {
+                const int c = lane + 64 * q;
+                if (c < len) { pa[c] = cs * xr[q] - sn * yr[q]; pb[c] = sn * xr[q] + cs * yr[q]; }
+              }
+            } else {
+              for (int c = lane; c < len; c += 64) {
+                T x = pa[c], y = pb[c];
+                T xn = cs * x - sn * y, yn = sn * x + cs * y;
+                pa[c] = xn;
+                pb[c] = yn;
+              }
+            }
+            if (lane == 0) atomicAdd(&s_rot, 1);
+          }
+        }
+        __threadfence_block();
+        __syncthreads();
+      }
+      const int rot = s_rot;
+      __syncthreads();
+      if (rot == 0) { ++sweep; break; }
+    }
+    return sweep;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, long wM, int m, int len,
                                                            int ld, int max_sweeps, int use_lds,
@@ -1220,6 +1346,15 @@ __global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, l
   const int mp = m + (m & 1);
   const T tol = T(2) * sqrt(T(len)) * T(eps_rt<T>());
   __shared__ double s_fro[16];
+  __shared__ short s_idx[1024];
+  __shared__ unsigned char s_flag[1024];
+  __shared__ int s_nl;
+  if (use_lds && len > 192 && len <= 256) {      // block-uniform
+    const int sw = jacobi_rows_lds256<T>(sM, m, len, lds_ld, max_sweeps, s_rot, s_fro, s_idx, s_flag, s_nl);
+    for (int e = tid; e < m * len; e += blockDim.x) Mglob[(long)(e / len) * ld + (e % len)] = sM[(e / len) * lds_ld + (e % len)];
+    if (tid == 0 && sweeps_out) sweeps_out[blockIdx.x] = sw;
+    return;
+  }
   {
     double f = 0.0;
     for (int e = tid; e < m * len; e += blockDim.x) { double x = (double)M[(long)(e / len) * lds_ld + (e % len)]; f += x * x; }
@@ -1233,9 +1368,6 @@ __global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, l
   // The tournament runs over the LIVE rows only (norm above the noise floor), re-listed at the
   // start of every sweep: a row below the floor takes part in no rotation anyway, and with a
   // fast-decaying boundary spectrum most rows of M are dead (cost ~ rank^2, not m^2).
-  __shared__ short s_idx[1024];
-  __shared__ unsigned char s_flag[1024];
-  __shared__ int s_nl;
   (void)mp;
   int sweep = 0;
   for (; sweep < max_sweeps; ++sweep) {
