@@ -1191,6 +1191,31 @@ __global__ __launch_bounds__(256) void zero_dead_cols_kernel(T *__restrict__ Pg,
 // or a rank-deficient carry) the surplus rows can never become "relatively" orthogonal.  The
 // working copy lives in LDS when it fits (use_lds), else in global memory (L2-resident).
 // mdyn (optional): per-walker number of existing rows, mdyn[b]*mdyn_mul <= m (rank-adaptive carry).
+// Rotation of a row pair (squared norms alpha, beta, inner product gamma), round 6: reciprocal and reciprocal square root from the
+// hardware estimates (~2^-26) + two Newton steps each instead of four IEEE square roots and three divisions in float64 (~350
+// dependent instructions on the critical path of every pair); the test |gamma| > tol sqrt(alpha beta) on the squares.
+__device__ __forceinline__ double jr_rcp64(const double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
+  return r * (2.0 - x * r);
+}
+__device__ __forceinline__ double jr_rsq64(const double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * (1.5 - 0.5 * x * r * r);
+  return r * (1.5 - 0.5 * x * r * r);
+}
+template <typename T>
+__device__ __forceinline__ bool jr_rotation(const T alpha, const T beta, const T gamma, const T tol, const T floor2, T &cs, T &sn) {
+  const double a = (double)alpha, b = (double)beta, g = (double)gamma;
+  if (!(g * g > (double)tol * (double)tol * (a * b) && alpha > floor2 && beta > floor2)) return false;
+  const double zeta = (b - a) * jr_rcp64(2.0 * g);
+  const double az = fabs(zeta), w = fma(az, az, 1.0);
+  const double td = copysign(jr_rcp64(az + w * jr_rsq64(w)), zeta);
+  const double cd = jr_rsq64(fma(td, td, 1.0));
+  cs = T(cd); sn = T(cd * td);
+  return true;
+}
+
 // LDS-resident rows of 193 .. 256 elements (the Z = U M blocks of the dense f64 route: 40 % of its step), round 6: the sweeps on the
 // LDS array itself -- ds_read instead of the FLAT loads behind the generic pointer `use_lds ? sM : Mglob`, which were waited for one at
 // a time (the dot-product and rotation loops of a pair were 4 + 4 serial round trips) -- with both rows of a pair in registers between
@@ -1280,15 +1305,10 @@ __device__ __forceinline__ int jacobi_rows_lds256(T *sM, const int m, const int 
             }
           }
           alpha = wave_sum(alpha); beta = wave_sum(beta); gamma = wave_sum(gamma);
-          const T ab = sqrt(alpha) * sqrt(beta);
           // no de Rijk row swapping: exchanging rows inside a round-robin tournament breaks the
           // pair coverage of the sweep (measured: 2x the sweeps); select_rows_kernel sorts afterwards
-          if (fabs(gamma) > tol * ab && alpha > floor2 && beta > floor2) {
-            // rotation parameters in f64 (one scalar per pair): keeps c^2 + s^2 = 1 to f32 rounding
-            const double zeta = ((double)beta - (double)alpha) / (2.0 * (double)gamma);
-            const double td = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            const double cd = 1.0 / sqrt(1.0 + td * td);
-            const T cs = T(cd), sn = T(cd * td);
+          T cs, sn;      // rotation parameters in f64 (one scalar per pair): keeps c^2 + s^2 = 1 to f32 rounding
+          if (jr_rotation(alpha, beta, gamma, tol, floor2, cs, sn)) {
             if constexpr (REG) {
 #pragma unroll
               for (int q = 0; q < NQ; ++q) {
@@ -1414,15 +1434,10 @@ __global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, l
           alpha += x * x; beta += y * y; gamma += x * y;
         }
         alpha = wave_sum(alpha); beta = wave_sum(beta); gamma = wave_sum(gamma);
-        const T ab = sqrt(alpha) * sqrt(beta);
         // no de Rijk row swapping: exchanging rows inside a round-robin tournament breaks the
         // pair coverage of the sweep (measured: 2x the sweeps); select_rows_kernel sorts afterwards
-        if (fabs(gamma) > tol * ab && alpha > floor2 && beta > floor2) {
-          // rotation parameters in f64 (one scalar per pair): keeps c^2 + s^2 = 1 to f32 rounding
-          const double zeta = ((double)beta - (double)alpha) / (2.0 * (double)gamma);
-          const double td = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-          const double cd = 1.0 / sqrt(1.0 + td * td);
-          const T cs = T(cd), sn = T(cd * td);
+        T cs, sn;      // rotation parameters in f64 (one scalar per pair): keeps c^2 + s^2 = 1 to f32 rounding
+        if (jr_rotation(alpha, beta, gamma, tol, floor2, cs, sn)) {
           for (int c = lane; c < len; c += 64) {
             T x = pa[c], y = pb[c];
             T xn = cs * x - sn * y, yn = sn * x + cs * y;
