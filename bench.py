@@ -593,7 +593,7 @@ def other_modes(capi, synthetic, device, L, D, chi):
         out["complex128"] = {"amp_per_s": rate(c, [synthetic.make_configs(L, nw, "heisenberg", seed0=70000 + 7 * k) for k in range(2)]), "walkers": nw,
                              "note": "static shapes (no rank adaptivity), GEMMs on the f64 matrix cores; this synthetic state falls to the resolution of a "
                                      "Gram within a few directions -- its figure on a dense state is real_rank.complex128 (round 4: 6.6, round 5: 82, "
-                                     "round 6: 164 amp/s)"}
+                                     "round 6: 170 amp/s)"}
         c.close()
     except Exception as e:
         out["complex128"] = {"error": repr(e)}

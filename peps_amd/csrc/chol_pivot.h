@@ -152,9 +152,7 @@ __global__ __launch_bounds__(256, MINW) void chol_pivot_kernel(const double *__r
       const double piv = cand[q] >= 0 ? s_piv[q] : 0.0;
       const bool live = piv > 0.0 && piv >= thresh;       // (block-uniform)
       const double pv = live ? piv : 1.0;
-      double sc = __builtin_amdgcn_rsq(pv);               // ~2^-26 relative; two Newton steps -> float64 (as chol_blocked_kernel)
-      sc = sc * (1.5 - 0.5 * pv * sc * sc);
-      sc = sc * (1.5 - 0.5 * pv * sc * sc);
+      const double sc = jr_rsq64(pv);
       // the pivot column itself gets sqrt(piv) = piv / sqrt(piv); columns that are pivots already (or do not exist) get zero
       const double num = (t == cand[q]) ? piv : ((d >= 0.0) ? v[q] : 0.0);
       const double x = live ? num * sc : 0.0;

@@ -1010,11 +1010,12 @@ __device__ __forceinline__ int jd_apply(JrRowD<CPL> &x, JrRowD<CPL> &y, double &
                                         const double floor2) {
   const bool go = g * g > tol2 * nx * ny && nx > floor2 && ny > floor2;
   if (!__any(go)) return 0;
-  const double zeta = (ny - nx) / (2.0 * (go ? g : 1.0));
+  const double zeta = (ny - nx) * jr_rcp64(2.0 * (go ? g : 1.0));
   const double az = fabs(zeta);
-  double t = copysign(1.0 / (az + sqrt(fma(az, az, 1.0))), zeta);
+  const double wz = fma(az, az, 1.0);
+  double t = copysign(jr_rcp64(az + wz * jr_rsq64(wz)), zeta);
   t = go ? t : 0.0;
-  const double cs = 1.0 / sqrt(fma(t, t, 1.0)), sn = cs * t;
+  const double cs = jr_rsq64(fma(t, t, 1.0)), sn = cs * t;
 #pragma unroll
   for (int q = 0; q < CPL; ++q) {
     const double xv = x.v[q], yv = y.v[q];

@@ -29,6 +29,23 @@ template <typename T> __device__ __forceinline__ double eps_rt() { return (doubl
 template <> __device__ __forceinline__ double eps_rt<float>() { return g_eps32_rt; }
 template <> __device__ __forceinline__ double eps_rt<double>() { return g_eps64_rt; }
 
+// 1 / x and 1 / sqrt(x) in float64 from the hardware estimates + three Newton steps: a few dependent instructions where
+// the IEEE division / square root sequences are ~50 each -- on the critical path of every pivot step and every Jacobi pair (round 6)
+// (three steps: with two, a rank-20 Gram matrix kept a 21st pivot above the 2.3e-13 threshold -- the estimates of this part are
+// coarser than the 2^-26 the blocked Cholesky of round 3 assumed; e -> 1.5 e^2 per step reaches 1e-16 from 2^-10 in three)
+__device__ __forceinline__ double jr_rcp64(const double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
+  r = r * (2.0 - x * r);
+  return r * (2.0 - x * r);
+}
+__device__ __forceinline__ double jr_rsq64(const double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * (1.5 - 0.5 * x * r * r);
+  r = r * (1.5 - 0.5 * x * r * r);
+  return r * (1.5 - 0.5 * x * r * r);
+}
+
 // 64-lane all-reductions on the DPP / permlane-swap path (a few cycles of latency per step, no LDS crossbar): the step
 // loops of the factor kernels are chains of dependent reductions, where the ds_bpermute behind __shfl_xor costs most
 template <int CTRL>
@@ -197,7 +214,7 @@ __global__ __launch_bounds__(256) void chol_upper_kernel(double *__restrict__ Gg
       const int f = lm ? c + __ffsll((long long)lm) - 1 : nb;     // first live column at or after c
       for (int e = tid; e < (f - c) * (n - jb); e += 256) sP[(c + e / (n - jb)) * n + jb + e % (n - jb)] = 0.0;
       if (f >= nb) break;
-      const double inv = 1.0 / sqrt(sP[f * n + jb + f]);
+      const double inv = jr_rsq64(sP[f * n + jb + f]);
       __syncthreads();                       // every wave has read the diagonal before row f is scaled
       for (int r = jb + f + tid; r < n; r += 256) sP[f * n + r] *= inv;
       if (tid == 0) { sList[s_nlive] = (short)(jb + f); s_nlive = s_nlive + 1; }
@@ -451,9 +468,7 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
         // compiler copied the whole d[] (16 v_mov_b64) at the join of every pivot step, 256 moves per panel on the one wave
         // every other wave of the block waits for
         const double pvt = live ? piv : 1.0;
-        double sc = __builtin_amdgcn_rsq(pvt);                // ~2^-26 relative; two Newton steps -> float64
-        sc = sc * (1.5 - 0.5 * pvt * sc * sc);
-        sc = sc * (1.5 - 0.5 * pvt * sc * sc);
+        const double sc = jr_rsq64(pvt);
         d[c] = live ? d[c] * sc : 0.0;
 #pragma unroll
         for (int c2 = c + 1; c2 < CH_NB; ++c2) {
@@ -469,9 +484,7 @@ __global__ __launch_bounds__(256, MINB) void chol_blocked_kernel(double *__restr
         double dg = 0.0;
 #pragma unroll
         for (int c = 0; c < CH_NB; ++c) dg = lane == c ? d[c] : dg;
-        double iv = __builtin_amdgcn_rcp(dg);
-        iv = iv * (2.0 - dg * iv);
-        iv = iv * (2.0 - dg * iv);
+        const double iv = jr_rcp64(dg);
         sDinv[lane] = ((livemask >> lane) & 1u) ? iv : 0.0;
       }
       if (lane == 0) s_livemask = livemask;
@@ -655,7 +668,7 @@ __global__ __launch_bounds__(256) void chol_lowrank_kernel(const double *__restr
     }
     double piv = G[(long)f * n + f];
     for (int j = 0; j < nl; ++j) { const double x = lr_R[j * n + f]; piv -= x * x; }
-    const double inv = 1.0 / sqrt(piv);
+    const double inv = jr_rsq64(piv);
 #pragma unroll
     for (int q = 0; q < CH_LR_Q; ++q) {
       const int r = tid + 256 * q;
@@ -846,7 +859,7 @@ __device__ __forceinline__ void gram_chol_lowrank_body(const int walker, const T
           }
         }
       }
-      const double v = (r >= f && r < n) ? g / sqrt(piv) : 0.0;
+      const double v = (r >= f && r < n) ? g * jr_rsq64(piv) : 0.0;
 #pragma unroll
       for (int jb = 0; jb < RCAP; jb += 8) {
         if ((nl & ~7) == jb) {
@@ -1037,7 +1050,7 @@ __global__ __launch_bounds__(256, 2) void gram_chol_wave_kernel(const float *__r
       };
       if (f < 64) step(p0, q0, d0); else step(p1, q1, d1);
       g0 += h0; g1 += h1;
-      const double inv = 1.0 / sqrt(piv);
+      const double inv = jr_rsq64(piv);
       const double v0 = (ok0 && c0 >= f) ? g0 * inv : 0.0, v1 = (ok1 && c1 >= f) ? g1 * inv : 0.0;
 #pragma unroll
       for (int jb = 0; jb < RC; jb += 8) {
@@ -1194,16 +1207,6 @@ __global__ __launch_bounds__(256) void zero_dead_cols_kernel(T *__restrict__ Pg,
 // Rotation of a row pair (squared norms alpha, beta, inner product gamma), round 6: reciprocal and reciprocal square root from the
 // hardware estimates (~2^-26) + two Newton steps each instead of four IEEE square roots and three divisions in float64 (~350
 // dependent instructions on the critical path of every pair); the test |gamma| > tol sqrt(alpha beta) on the squares.
-__device__ __forceinline__ double jr_rcp64(const double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = r * (2.0 - x * r);
-  return r * (2.0 - x * r);
-}
-__device__ __forceinline__ double jr_rsq64(const double x) {
-  double r = __builtin_amdgcn_rsq(x);
-  r = r * (1.5 - 0.5 * x * r * r);
-  return r * (1.5 - 0.5 * x * r * r);
-}
 template <typename T>
 __device__ __forceinline__ bool jr_rotation(const T alpha, const T beta, const T gamma, const T tol, const T floor2, T &cs, T &sn) {
   const double a = (double)alpha, b = (double)beta, g = (double)gamma;

@@ -85,6 +85,22 @@ __global__ __launch_bounds__(1024) void chol_upper_cplx_kernel(c128 *__restrict_
 // row pair.  A pair (x, y) with gamma = x^H y: y is first turned by the phase conj(gamma) / |gamma| (rows of Vt are defined up
 // to a phase), which makes the inner product real, then the real Hestenes rotation applies.  Threshold, noise floor and
 // termination as jacobi_rows_kernel.
+// complex rotation of a row pair: phase of the inner product and (c, s) from the hardware reciprocal / rsqrt estimates + Newton steps
+// (jr_rcp64 / jr_rsq64 of linalg.h) instead of five IEEE square roots and five divisions per pair
+__device__ __forceinline__ bool jr_rotation_cplx(const double alpha, const double beta, const double gre, const double gim, const double tol,
+                                                 const double floor2, double &phre, double &phim, double &cd, double &sd) {
+  const double g2 = gre * gre + gim * gim;
+  if (!(g2 > tol * tol * (alpha * beta) && alpha > floor2 && beta > floor2)) return false;
+  const double ig = jr_rsq64(g2);                 // 1 / |gamma|
+  phre = gre * ig; phim = -gim * ig;
+  const double zeta = 0.5 * (beta - alpha) * ig;
+  const double az = fabs(zeta), w = fma(az, az, 1.0);
+  const double td = copysign(jr_rcp64(az + w * jr_rsq64(w)), zeta);
+  cd = jr_rsq64(fma(td, td, 1.0));
+  sd = cd * td;
+  return true;
+}
+
 template <typename T>
 __global__ __launch_bounds__(1024) void jacobi_rows_cplx_kernel(T *__restrict__ Mg, long wM, int m, int len, int ld, int max_sweeps,
                                                                 int *__restrict__ sweeps_out, const int *__restrict__ run_flag = nullptr,
@@ -177,12 +193,9 @@ __global__ __launch_bounds__(1024) void jacobi_rows_cplx_kernel(T *__restrict__ 
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
             if (!ok[q]) continue;
-            const double absg = sqrt(gre[q] * gre[q] + gim[q] * gim[q]);
-            if (absg > tol * sqrt(alpha[q]) * sqrt(beta[q]) && alpha[q] > floor2 && beta[q] > floor2) {
-              const T ph = T(R(gre[q] / absg), R(-gim[q] / absg));
-              const double zeta = (beta[q] - alpha[q]) / (2.0 * absg);
-              const double td = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-              const double cd = 1.0 / sqrt(1.0 + td * td), sd = cd * td;
+            double phre, phim, cd, sd;
+            if (jr_rotation_cplx(alpha[q], beta[q], gre[q], gim[q], tol, floor2, phre, phim, cd, sd)) {
+              const T ph = T(R(phre), R(phim));
               T *pa = M + (long)s_live[a[q]] * ld, *pb = M + (long)s_live[b[q]] * ld;
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
@@ -210,12 +223,9 @@ __global__ __launch_bounds__(1024) void jacobi_rows_cplx_kernel(T *__restrict__ 
           gre += (double)g.re; gim += (double)g.im;
         }
         alpha = wave_sum(alpha); beta = wave_sum(beta); gre = wave_sum(gre); gim = wave_sum(gim);
-        const double absg = sqrt(gre * gre + gim * gim);
-        if (absg > tol * sqrt(alpha) * sqrt(beta) && alpha > floor2 && beta > floor2) {
-          const T ph = T(R(gre / absg), R(-gim / absg));
-          const double zeta = (beta - alpha) / (2.0 * absg);
-          const double td = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-          const double cd = 1.0 / sqrt(1.0 + td * td), sd = cd * td;
+        double phre, phim, cd, sd;
+        if (jr_rotation_cplx(alpha, beta, gre, gim, tol, floor2, phre, phim, cd, sd)) {
+          const T ph = T(R(phre), R(phim));
           for (int c = lane; c < len; c += 64) {
             const T x = pa[c], y = pb[c] * ph;
             pa[c] = scaled(x, cd) - scaled(y, sd);

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void rows_qr_kernel(const float *__restrict__ 
     const double piv = sS[j][j];
     // remaining part of row j: sqrt(piv) in units of its own norm, sqrt(piv |row|^2) in absolute terms
     const bool live = sD[j] > 0.0 && piv > 0.0 && piv * sN[j] > nfloor * nfloor;       // (block-uniform)
-    const double inv = live ? 1.0 / sqrt(piv) : 0.0;
+    const double inv = live ? jr_rsq64(piv) : 0.0;
     __syncthreads();
     if (t < RQ_K && t >= j) sS[t][j] = (t == j) ? (live ? sqrt(piv) : 0.0) : sS[t][j] * inv;
     __syncthreads();
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void chol_solve_rows_kernel(const double *__re
   for (int j = 0; j < r; ++j) {
     const double piv = sL[j][j];
     const bool live = piv > 0.0;                          // (block-uniform)
-    const double inv = live ? 1.0 / sqrt(piv) : 0.0;
+    const double inv = live ? jr_rsq64(piv) : 0.0;
     __syncthreads();
     if (t < r && t >= j) sL[t][j] = (t == j) ? (live ? sqrt(piv) : 0.0) : sL[t][j] * inv;
     __syncthreads();
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void chol_solve_rows_cplx_kernel(const c128
   for (int j = 0; j < r; ++j) {
     const double piv = sL[j][j].re;
     const bool live = piv > 0.0;                          // (block-uniform)
-    const double inv = live ? 1.0 / sqrt(piv) : 0.0;
+    const double inv = live ? jr_rsq64(piv) : 0.0;
     __syncthreads();
     if (t < r && t >= j) sL[t][j] = (t == j) ? c128(live ? sqrt(piv) : 0.0, 0.0) : sL[t][j] * inv;
     __syncthreads();

@@ -100,9 +100,7 @@ __device__ __forceinline__ int lds_chol_blocked(double *__restrict__ sG, const A
         const bool live = c < nb && piv > thresh && cnt < kcap;   // wave-uniform
         // branch-free (round 4, as chol_blocked_kernel): no copy of d[] at the join of every pivot step
         const double pv = live ? piv : 1.0;
-        double sc = __builtin_amdgcn_rsq(pv);                     // ~2^-26 relative; two Newton steps -> float64
-        sc = sc * (1.5 - 0.5 * pv * sc * sc);
-        sc = sc * (1.5 - 0.5 * pv * sc * sc);
+        const double sc = jr_rsq64(pv);
         d[c] = live ? d[c] * sc : 0.0;
 #pragma unroll
         for (int c2 = c + 1; c2 < 16; ++c2) {
@@ -120,9 +118,7 @@ __device__ __forceinline__ int lds_chol_blocked(double *__restrict__ sG, const A
           if (lane < nb && c <= lane) sG[at(jb + c, jb + lane)] = d[c];
           dg = lane == c ? d[c] : dg;
         }
-        double iv = __builtin_amdgcn_rcp(dg);
-        iv = iv * (2.0 - dg * iv);
-        iv = iv * (2.0 - dg * iv);
+        const double iv = jr_rcp64(dg);
         const bool mine = (livemask >> lane) & 1u;
         sDinv[lane] = mine ? iv : 0.0;
         if (mine) sList[nl + __popc(livemask & ((1u << lane) - 1u))] = (short)(jb + lane);
@@ -735,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void colgram_chol_kernel(const T *__restric
       }
       for (; j < nl; ++j) g0 = fma(-sR[cg_row(j) + f], sR[cg_row(j) + tid], g0);
       const double g = (g0 + g1) + (g2 + g3);
-      const double v = g / sqrt(s_piv);
+      const double v = g * jr_rsq64(s_piv);
       sR[cg_row(nl) + tid] = v;
       if (tid > f) d -= v * v;
     } else if (tid >= nl && tid < f) {
