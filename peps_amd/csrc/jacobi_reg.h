@@ -959,7 +959,7 @@ __global__ __launch_bounds__(256, CPL <= 4 ? 3 : 2) void jacobi_rows_tiny4_kerne
   for (int i = 0; i < JR_BR; ++i) {
     if (i < mm && rank[i] < kcut) {
       const bool live = n2[i] > nfloor2;
-      const float inv = live ? (float)(1.0 / sqrt(n2[i])) : 0.f;     // numerically zero direction -> zero row of Vt
+      const float inv = live ? (float)jr_rsq64((double)n2[i]) : 0.f;     // numerically zero direction -> zero row of Vt
       klive += live ? 1 : 0;
 #pragma unroll
       for (int q = 0; q < CPL; ++q) {

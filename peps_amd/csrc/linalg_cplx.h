@@ -43,7 +43,7 @@ __global__ __launch_bounds__(1024) void chol_upper_cplx_kernel(c128 *__restrict_
     const double piv = G[(long)j * n + j].re;
     if (!(piv > thresh)) continue;                      // block-uniform
     if (tid == 0) { s_piv[s_nl] = piv; s_list[s_nl] = (short)j; s_nl = s_nl + 1; }
-    const double invp = 1.0 / piv;
+    const double invp = jr_rcp64(piv);
     for (int i = j + 1 + wave; i < n; i += nwv) {         // G[i][r] -= conj(G[j][i]) G[j][r] / piv,  r >= i
       const c128 f = conj_of(G[(long)j * n + i]) * invp;
       for (int r = i + lane; r < n; r += 64) G[(long)i * n + r] -= f * G[(long)j * n + r];

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void rows_qr_kernel(const float *__restrict__ 
   __shared__ float sV[RQ_K * RQ_LD];
   __shared__ double sS[RQ_K][RQ_K + 1];
   __shared__ double sD[RQ_K];          // 1 / |row|
+  __shared__ double sInv[RQ_K];        // 1 / L[a][a] of the factor (0: dead row)
   __shared__ double sN[RQ_K];          // |row|^2
   __shared__ short sPos[RQ_K];
   __shared__ int s_cnt;
@@ -95,7 +96,8 @@ __global__ __launch_bounds__(256) void rows_qr_kernel(const float *__restrict__ 
     const bool live = sD[j] > 0.0 && piv > 0.0 && piv * sN[j] > nfloor * nfloor;       // (block-uniform)
     const double inv = live ? jr_rsq64(piv) : 0.0;
     __syncthreads();
-    if (t < RQ_K && t >= j) sS[t][j] = (t == j) ? (live ? sqrt(piv) : 0.0) : sS[t][j] * inv;
+    if (t < RQ_K && t >= j) sS[t][j] = (t == j) ? piv * inv : sS[t][j] * inv;      // (sqrt(piv) = piv / sqrt(piv); dead row: 0)
+    if (t == 0) sInv[j] = inv;
     __syncthreads();
     if (live) {
 #pragma unroll
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void rows_qr_kernel(const float *__restrict__ 
         s = sD[a] * (double)sV[a * RQ_LD + t];
 #pragma unroll
         for (int q = 0; q < a; ++q) s = fma(-sS[a][q], x[q], s);
-        s = laa > 0.0 ? s / laa : 0.0;
+        s = laa > 0.0 ? s * sInv[a] : 0.0;        // (1 / L[a][a] kept from the factorisation: an IEEE division per row was most of this loop)
       }
       x[a] = s;
     }
@@ -149,6 +151,7 @@ __global__ __launch_bounds__(256) void chol_solve_rows_kernel(const double *__re
   const int b = blockIdx.x;
   if (run_flag && run_flag[b] >= 0) return;
   __shared__ double sL[CS_K][CS_K + 1];
+  __shared__ double sInv[CS_K];        // 1 / L[a][a] (0: dead row)
   const int t = threadIdx.x;
   const int r = max(0, min(CS_K, rows[b]));
   if (r <= 0) return;
@@ -164,14 +167,14 @@ __global__ __launch_bounds__(256) void chol_solve_rows_kernel(const double *__re
     const bool live = piv > 0.0;                          // (block-uniform)
     const double inv = live ? jr_rsq64(piv) : 0.0;
     __syncthreads();
-    if (t < r && t >= j) sL[t][j] = (t == j) ? (live ? sqrt(piv) : 0.0) : sL[t][j] * inv;
+    if (t < r && t >= j) sL[t][j] = (t == j) ? piv * inv : sL[t][j] * inv;
+    if (t == 0) sInv[j] = inv;
     __syncthreads();
     if (live) {
-      const int nrem = r - j - 1;                         // trailing block (a, c), j < c <= a < r
-      for (int e = t; e < nrem * nrem; e += 256) {
-        const int a = j + 1 + e / nrem, c = j + 1 + e % nrem;
-        if (c <= a) sL[a][c] = fma(-sL[a][j], sL[c][j], sL[a][c]);
-      }
+      // trailing block (a, c), j < c <= a < r, on a 16 x 16 thread grid (round 6: `e / nrem`, `e % nrem` per element with a run-time
+      // nrem were two integer divisions per FMA)
+      for (int a = j + 1 + (t >> 4); a < r; a += 16)
+        for (int c = j + 1 + (t & 15); c <= a; c += 16) sL[a][c] = fma(-sL[a][j], sL[c][j], sL[a][c]);
     }
     __syncthreads();
   }
@@ -205,8 +208,7 @@ __global__ __launch_bounds__(256) void chol_solve_rows_kernel(const double *__re
         double sv = v[a];
 #pragma unroll
         for (int q = 0; q < a; ++q) sv = fma(-sL[ra][ca * CS_CH + q], v[q], sv);
-        const double laa = ra < r ? sL[ra][ra] : 0.0;
-        v[a] = laa > 0.0 ? sv / laa : 0.0;
+        v[a] = ra < r ? sv * sInv[ra] : 0.0;       // (1 / L[a][a] from the factorisation; 0 for a dead row)
       }
 #pragma unroll
       for (int cq = 0; cq < CS_NCH; ++cq)
@@ -232,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void chol_solve_rows_cplx_kernel(const c128
   const int b = blockIdx.x;
   if (run_flag && run_flag[b] >= 0) return;
   __shared__ c128 sL[CS_K][CS_K + 1];
+  __shared__ double sInv[CS_K];
   const int t = threadIdx.x;
   r = max(0, min(CS_K, r));
   if (r <= 0) return;
@@ -247,14 +250,12 @@ __global__ __launch_bounds__(256, 2) void chol_solve_rows_cplx_kernel(const c128
     const bool live = piv > 0.0;                          // (block-uniform)
     const double inv = live ? jr_rsq64(piv) : 0.0;
     __syncthreads();
-    if (t < r && t >= j) sL[t][j] = (t == j) ? c128(live ? sqrt(piv) : 0.0, 0.0) : sL[t][j] * inv;
+    if (t < r && t >= j) sL[t][j] = (t == j) ? c128(piv * inv, 0.0) : sL[t][j] * inv;
+    if (t == 0) sInv[j] = inv;
     __syncthreads();
     if (live) {
-      const int nrem = r - j - 1;
-      for (int e = t; e < nrem * nrem; e += 256) {
-        const int a = j + 1 + e / nrem, c = j + 1 + e % nrem;
-        if (c <= a) sL[a][c] -= sL[a][j] * conj_of(sL[c][j]);
-      }
+      for (int a = j + 1 + (t >> 4); a < r; a += 16)
+        for (int c = j + 1 + (t & 15); c <= a; c += 16) sL[a][c] -= sL[a][j] * conj_of(sL[c][j]);
     }
     __syncthreads();
   }
@@ -276,8 +277,7 @@ __global__ __launch_bounds__(256, 2) void chol_solve_rows_cplx_kernel(const c128
         c128 sv = v[a];
 #pragma unroll
         for (int q = 0; q < a; ++q) sv -= sL[ra][a0 + q] * v[q];
-        const double laa = a0 + a < r ? sL[ra][ra].re : 0.0;
-        v[a] = laa > 0.0 ? sv * (1.0 / laa) : c128(0.0, 0.0);
+        v[a] = a0 + a < r ? sv * sInv[ra] : c128(0.0, 0.0);
       }
 #pragma unroll
       for (int a = 0; a < CSC_CH; ++a)
