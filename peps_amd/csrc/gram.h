@@ -70,50 +70,61 @@ __global__ __launch_bounds__(256, 2) void gram_cols_f64_kernel(const T *__restri
       for (int r = 0; r < 4; ++r) acc[a][c][r] = 0.0;
 
   const int nks = (K + 3) >> 2;
-  // (unconditional loads at clamped addresses + a select were measured here: 334 -> 553 ms per step of 2048 dense walkers -- the
-  // extra live registers cost the second wave per SIMD; the predicated loads stay)
-  auto load = [&](int ks, T(&av)[4], T(&bv)[4]) {
-    const int row = 4 * ks + r4;
-    const bool ok = row < K;
-    const T *pr = P + (long)row * ld;
+  // Round 6: the k loop as straight-line code (one instantiation per kind of block: diagonal / off-diagonal), every load unconditional
+  // at a clamped address (a row beyond K reads the last one, a dead column reads column 0; the operand is zeroed by a select), the
+  // rotation of PF steps kept by scheduling fences.  Rounds 3-5 had `(ok && col < n) ? pr[col] : 0` and `if (cur < nks) step(...)`:
+  // exec-mask branches with an s_waitcnt vmcnt(0) at every join -- the "PF steps deep" pipeline had one step in flight.  (Round 3
+  // measured unconditional loads + select at 334 -> 553 ms: that form kept the raw and the selected values alive; here the select
+  // happens in place, right before the MFMAs.)
+  bool oka[4], okb[4];
+  unsigned offa[4], offb[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) av[c] = (ok && cola[c] < n) ? pr[cola[c]] : T(0);
-    if (!diag) {
+  for (int c = 0; c < 4; ++c) {
+    oka[c] = cola[c] < n; okb[c] = colb[c] < n;
+    offa[c] = oka[c] ? (unsigned)cola[c] : 0u; offb[c] = okb[c] ? (unsigned)colb[c] : 0u;
+  }
+  auto run = [&](auto DIAG_) {
+    constexpr bool DIAG = decltype(DIAG_)::value;
+    constexpr int PF = 4;
+    T av[PF][4], bv[PF][DIAG ? 1 : 4];
+    auto load = [&](int ks, T(&a)[4], T(&bb)[DIAG ? 1 : 4]) {
+      const unsigned row = (unsigned)min(4 * ks + r4, K - 1) * (unsigned)ld;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) bv[c] = (ok && colb[c] < n) ? pr[colb[c]] : T(0);
+      for (int c = 0; c < 4; ++c) a[c] = P[row + offa[c]];
+      if constexpr (!DIAG) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bb[c] = P[row + offb[c]];
+      }
+    };
+#pragma unroll
+    for (int p = 0; p < PF - 1; ++p) load(p, av[p], bv[p]);
+    for (int ks = 0; ks < nks; ks += PF) {
+#pragma unroll
+      for (int p = 0; p < PF; ++p) {
+        const int cur = ks + p;
+        load(cur + PF - 1, av[(p + PF - 1) % PF], bv[(p + PF - 1) % PF]);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool rok = 4 * cur + r4 < K;      // (k-steps beyond nks: every row is beyond K, the MFMAs add zeros)
+        double ad[4], bd[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ad[c] = (rok && oka[c]) ? (double)av[p][c] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if constexpr (DIAG) bd[c] = ad[c];
+          else bd[c] = (rok && okb[c]) ? (double)bv[p][c] : 0.0;
+        }
+        // a diagonal block needs its tiles on or above the diagonal only (ten of sixteen; the Cholesky reads the upper triangle)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (!DIAG || c >= a) acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[a], bd[c], acc[a][c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
-  auto step = [&](const T(&av)[4], const T(&bv)[4]) {
-    double ad[4], bd[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) ad[c] = (double)av[c];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) bd[c] = diag ? ad[c] : (double)bv[c];
-    // a diagonal block needs its tiles on or above the diagonal only (ten of sixteen; the Cholesky reads the upper triangle)
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (!diag || c >= a) acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[a], bd[c], acc[a][c], 0, 0, 0);
-  };
-  // software pipeline, PF steps deep: a step's operands are requested PF - 1 steps (PF - 1 x 16 MFMAs of 64 cycles) before
-  // they are consumed, which covers an L2 / Infinity-Cache round trip at two waves per SIMD
-  constexpr int PF = 4;
-  T av[PF][4], bv[PF][4];
-#pragma unroll
-  for (int p = 0; p < PF; ++p)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { av[p][c] = T(0); bv[p][c] = T(0); }
-#pragma unroll
-  for (int p = 0; p < PF - 1; ++p)
-    if (p < nks) load(p, av[p], bv[p]);
-  for (int ks = 0; ks < nks; ks += PF) {
-#pragma unroll
-    for (int p = 0; p < PF; ++p) {
-      const int cur = ks + p;
-      if (cur + PF - 1 < nks) load(cur + PF - 1, av[(p + PF - 1) % PF], bv[(p + PF - 1) % PF]);
-      if (cur < nks) step(av[p], bv[p]);
-    }
+  if (K > 0) {
+    if (diag) run(std::true_type()); else run(std::false_type());
   }
   // accumulator layout of v_mfma_f64_16x16x4_f64: acc[r] = C[(lane >> 4) + 4 r][lane & 15]
 #pragma unroll
