@@ -1278,7 +1278,7 @@ __device__ __forceinline__ int jacobi_rows_lds256(T *sM, const int m, const int 
         auto pair_of = [&](const int p, int &a, int &b) -> bool {      // rows of pair p of round r; false: a bye
           if (p >= lp / 2) return false;
           if (p == 0) { a = lp - 1; b = r; }
-          else { a = (r + p) % (lp - 1); b = (r - p + (lp - 1)) % (lp - 1); }
+          else { a = r + p; a -= a >= lp - 1 ? lp - 1 : 0; b = r - p; b += b < 0 ? lp - 1 : 0; }      // (0 <= r < lp - 1, 0 < p < lp / 2: no division)
           if (a > b) { int t = a; a = b; b = t; }
           if (b >= nl) return false;
           a = s_idx[a]; b = s_idx[b];
@@ -1426,7 +1426,7 @@ __global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, l
       for (int p = wave; p < lp / 2; p += nw) {
         int a, b;
         if (p == 0) { a = lp - 1; b = r; }
-        else { a = (r + p) % (lp - 1); b = (r - p + (lp - 1)) % (lp - 1); }
+        else { a = r + p; a -= a >= lp - 1 ? lp - 1 : 0; b = r - p; b += b < 0 ? lp - 1 : 0; }      // (0 <= r < lp - 1, 0 < p < lp / 2: no division)
         if (a > b) { int t = a; a = b; b = t; }
         if (b >= nl) continue;
         a = s_idx[a]; b = s_idx[b];

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(1024) void jacobi_rows_cplx_kernel(T *__restrict__ 
       auto pair_of = [&](int p, int &a, int &b) -> bool {      // pair p of tournament step r; false: a bye or a dead row
         if (p >= lp / 2) return false;
         if (p == 0) { a = lp - 1; b = r; }
-        else { a = (r + p) % (lp - 1); b = (r - p + (lp - 1)) % (lp - 1); }
+        else { a = r + p; a -= a >= lp - 1 ? lp - 1 : 0; b = r - p; b += b < 0 ? lp - 1 : 0; }      // (0 <= r < lp - 1, 0 < p < lp / 2: no division)
         if (a > b) { const int t = a; a = b; b = t; }
         return b < ml;
       };
