@@ -226,7 +226,9 @@ def test_sr_matvec_complex_vs_oracle():
         assert why_d == why_r == osr.K_CONVERGED and abs(idv - ir) <= 1, (idv, ir, why_d, why_r)
         # (both iterates satisfy the termination criterion; between them stands the conditioning of S + shift times the rounding of
         # two different summation orders)
-        assert np.max(np.abs(xd.ravel() - xr)) < 1e-4 * np.max(np.abs(xr)) and abs(rd - rr) < 1e-6 * np.linalg.norm(b.ravel()) + 0.5 * rr
+        # (the iteration counts may differ by one: the residual of the later exit is smaller by a CG contraction factor -- the device's
+        # must not be WORSE than the oracle's by more than that)
+        assert np.max(np.abs(xd.ravel() - xr)) < 1e-4 * np.max(np.abs(xr)) and rd < 1e-6 * np.linalg.norm(b.ravel()) + 1.5 * rr
         assert np.linalg.norm((full * xd.ravel()) - b.ravel()) <= 1.5 * rtol * np.linalg.norm(b.ravel())
     # MinSR on the complex store (MinSRTMatrix / ReplicatedEigenSolveComplex are templated over TenElemT): Gram with the conjugated
     # pairing on the device, epsilon_bar = conj(E_loc - E) / Ns, back-substitution with complex weights -- against the oracle
