@@ -588,6 +588,7 @@ __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *
   // round trip per round; not kept.)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ntj = (Jtot + 31) >> 5, ntiles = ((Itot + 31) >> 5) * ntj;
+  const float rntj = __builtin_amdgcn_rcpf((float)ntj);
   const float alpha = (float)d.alpha * scale;
   double ss = 0.0;     // (f64: the norm it feeds replaces an f64 reduction over the stored tensor)
   const int half = lane >> 5, l31 = lane & 31;
@@ -600,7 +601,8 @@ __device__ __forceinline__ void tg_direct_body(const TGemmDesc &d, const float *
   const bool accumulate = d.accumulate != 0;
 
   for (int t = tile0 + wave; t < ntiles; t += tile_step) {
-    const int ti = t / ntj, tj = t - ti * ntj;
+    int tj;
+    const int ti = tg_fdivmod(t, ntj, rntj, tj);      // (round 6: the integer division was ~35 of a tile's ~400 vector instructions)
     const int i = ti * 32 + l31, j = tj * 32 + l31;
     unsigned oab, obb;    // byte offsets of this lane's A row / B column (0 when it does not exist)
     int ocj;              // element offset of column j in C, -1: not stored; TG_ZERO_ROW set: stored as zero
@@ -735,6 +737,7 @@ __device__ __forceinline__ void tg_direct_body_f64(const TGemmDesc &d, const flo
                                                    const float scale = 1.f, double *__restrict__ sumsq = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ntj = (Jtot + 31) >> 5, ntiles = ((Itot + 31) >> 5) * ntj;
+  const float rntj = __builtin_amdgcn_rcpf((float)ntj);
   const double alpha = d.alpha * (double)scale;
   double ss = 0.0;
   const int g4 = lane >> 4, c16 = lane & 15;
@@ -747,7 +750,8 @@ __device__ __forceinline__ void tg_direct_body_f64(const TGemmDesc &d, const flo
   const bool accumulate = d.accumulate != 0;
 
   for (int t = tile0 + wave; t < ntiles; t += tile_step) {
-    const int ti = t / ntj, tj = t - ti * ntj;
+    int tj;
+    const int ti = tg_fdivmod(t, ntj, rntj, tj);      // (round 6: the integer division was ~35 of a tile's ~400 vector instructions)
     unsigned oab[2], obb[2];
     int ocj[2];
 #pragma unroll
