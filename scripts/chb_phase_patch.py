@@ -35,7 +35,7 @@ i = s.index("chol_blocked_kernel(double")
 j = s.index("  if (mlive_out) return;\n  for (int e = tid + mlive * n; e < n * n; e += 256)", i)
 s = s[:j] + "  if (tid == 0) { atomicAdd(&g_chb_phase[6], wall_clock64() - tk0); atomicAdd(&g_chb_phase[7], 1ull); }\n" + s[j:]
 if pfd:
-    rep("chol_blocked_kernel<T, 3, 2>", "chol_blocked_kernel<T, 3, %d>" % pfd, 2)
+    rep("chol_blocked_kernel<T, 3, 4>", "chol_blocked_kernel<T, 3, %d>" % pfd, 2)      # (the launch instantiates four k-steps in flight)
 open(p, "w").write(s)
 p = os.path.join(dst, "capi.hip")
 s = open(p).read()
