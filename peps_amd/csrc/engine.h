@@ -1193,7 +1193,7 @@ class Engine : public EngineBase {
         mp.mapJ[1] = 1; mp.mapJ[2] = 5;      // J2 = (x, b2):  x = I1[1],  b2 = J1[2]
         const double fl = 2.0 * nb * ((double)(x * p1) * cdim * (double)(b1 * b2) + (double)(b2 * x) * (double)(p1 * b1) * (double)(s1 * s2));
         // round 4: all three contractions in one launch (tgemm_chain3_kernel: tmp1 and tmp2 resident in LDS, the bond x walked in
-        // chunks when the live intermediates exceed the buffers); PEPSGPU_NO_BTEN_CHAIN3=1 for the two-stage chain + separate launch
+        // chunks when the live intermediates exceed the buffers) (the two-stage chain + separate launch of round 3 was a switch until round 6)
         constexpr bool no_bt3 = false;
         // ... when the bond x is walked in at most three chunks of the 4096-float buffers (static extents; they follow the live bonds
         // through the bond shrink): with the bonds of a real state (x = b2 = 32: sixteen chunks of two) the three-stage kernel is 2 %

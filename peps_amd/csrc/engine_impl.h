@@ -462,7 +462,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
       const bool hinted = in.depth >= 3 && (int)in.mlmax.size() > i && in.mlmax[i] >= 0;
       precise_site = precise == 2 || (precise == 1 && (hinted ? in.mlmax[i] > 24 : (seen < 0 || seen > 24)));
     }
-    // PEPSGPU_TT_ACC64: 1 (default) = the backward pair of a precise site on the float64-accumulating chained kernel, 0 = f32 (round 4)
+    // the backward pair of a precise site runs on the float64-accumulating chained kernel (round 5; f32 in round 4)
     constexpr int tt_mode = 1;
     const bool tt_f64 = sizeof(T) == 4 && precise_site && tt_mode != 0;
     // Z1[a,p,l2,k2] = sum_{a2} A[a,p,a2] Y[l2,a2,k2]
@@ -925,7 +925,7 @@ bool Engine<T>::absorb_impl(int pos, int num, bool full_bonds, const BMPSDev &in
           g.upper_only = 1;
           tgemm_launch<T, T, double, double>(stream_, g, M.p, M.p, Gm);
         }
-        // (PEPSGPU_ROUTE_THRESH_SCALE: the pivot threshold of the first factorisation for EVERY walker, an experiment knob: fewer kept
+        // (tscale: the pivot threshold of the first factorisation for EVERY walker -- an experiment constant of round 5: fewer kept
         // rows = smaller Jacobi problems, priced by the guard)
         constexpr double tscale = 1.0;
         launch_chol_upper<T>(stream_, nw_, Gm, (long)GSd * GSd, GSd, B1.p, B1.n, mB1, 0, GSd, (const int *)rowsM, 1, (const int *)nullptr, tscale);

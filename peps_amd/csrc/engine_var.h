@@ -323,7 +323,7 @@ typename Engine<T>::BMPSDev Engine<T>::absorb_variational(int pos, int num, cons
   // Per-walker live extents of every bond (device arrays, nullptr = the static dim): il[i] / rl[i] = bond to the left of
   // site i of the absorbing BMPS / of the result.  Contractions run over the live parts only (ein(): compact legs on
   // tensors only ein() reads, masked -- zeros written -- legs where a whole-row kernel or a persistent tensor follows);
-  // every truncation returns the live count of the bond it made.  PEPSGPU_NO_VAR_ADAPT=1: static shapes throughout.
+  // every truncation returns the live count of the bond it made.
   constexpr bool no_adapt_env = false;
   const bool no_adapt = no_adapt_env || kCplx;      // (the complex kernels have no live extents)
   std::vector<int *> il(in.live.begin(), in.live.end()), rl = res.live;

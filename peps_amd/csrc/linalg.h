@@ -1626,7 +1626,7 @@ __global__ __launch_bounds__(256) void f64_route_guard_kernel(const TZ *__restri
                                                               const int *__restrict__ lvl = nullptr, double lvl_floor2 = 0.0,
                                                               double lvl2_floor2 = 0.0, double base_floor2 = 5.7e-14, int base_always = 0) {
   // base_floor2: (relative, squared) what the FIRST factorisation drops -- (2.4e-7)^2 at the default pivot threshold; base_always: it
-  // was raised for every walker (PEPSGPU_ROUTE_THRESH_SCALE), so it bounds the strongest direction outside whatever was kept
+  // was raised for every walker (tscale of the route), so it bounds the strongest direction outside whatever was kept
   // lvl[b] != 0: the walker's first factor was taken with the raised pivot threshold -- what it dropped is up to sqrt(lvl_floor2) s_1
   const int b = blockIdx.x;
   if (flag[b] >= 0) return;

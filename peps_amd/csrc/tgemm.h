@@ -1277,7 +1277,7 @@ void tgemm_launch(hipStream_t s, const TGemmDesc &d_in, const TA *A, const TB *B
   }
   if constexpr (is_cplx<TAcc>::value) {
     // complex element type: four real v_mfma_f64_16x16x4_f64 products per tile from the interleaved LDS operands
-    // (PEPSGPU_NO_CPLX_MFMA=1: the same tiling on the vector ALUs, round 2's path)
+    // (the same tiling on the vector ALUs was round 2's path: USE_MFMA = false)
     constexpr bool no_cmfma = false;
     if constexpr (std::is_same<TAcc, c128>::value) {
       if (tgemm_use_mfma() && !no_cmfma) {
@@ -1318,7 +1318,7 @@ inline int tgemm_chain_launch(hipStream_t s, const TGemmDesc &d1_in, const TGemm
   const dim3 g(d1.nbatch), blk(256);
   // dense walker batch (hint of the caller): the intermediate is walked in chunks anyway; a 32 KB buffer holds four values of
   // the chunked sub-index = 32 full rows per stage-1 tile and eight balanced stage-2 tiles (24 KB: 24 rows, six tiles), at four
-  // blocks per CU instead of six (PEPSGPU_CHAIN_DENSE_LDS = 0 / 8192 / 16384 floats)
+  // blocks per CU instead of six (0 / 8192 / 16384 floats were measured in round 5: HISTORY item 13)
   int ldsf = (dense && allow_chunks) ? 8192 : TG_CHAIN_LDS_FLOATS;
   if (f64acc && ldsf > 8192) ldsf = 8192;       // (the float64-accumulating form is built for the two default buffer sizes)
 #define PG_CHAIN(a1, b1, a2)                                                                                                   \
