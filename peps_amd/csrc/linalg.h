@@ -1219,19 +1219,20 @@ __device__ __forceinline__ bool jr_rotation(const T alpha, const T beta, const T
   return true;
 }
 
-// LDS-resident rows of 193 .. 256 elements (the Z = U M blocks of the dense f64 route: 40 % of its step), round 6: the sweeps on the
+// LDS-resident rows of 129 .. 256 elements (the Z = U M blocks of the dense f64 route: 40 % of its step), round 6: the sweeps on the
 // LDS array itself -- ds_read instead of the FLAT loads behind the generic pointer `use_lds ? sM : Mglob`, which were waited for one at
 // a time (the dot-product and rotation loops of a pair were 4 + 4 serial round trips) -- with both rows of a pair in registers between
 // the inner products and the rotation (one read and one write per row and pair instead of two reads and a write).  The same sums in
-// the same order: bit-identical results.  (Shorter rows and rows in global memory keep the loops below: the same form on 144-element
-// rows measured 169 against 154 ms on C5.)
-template <typename T>
+// the same order: bit-identical results.  Two instantiations (rows of 129-192 and of 193-256 elements; C5's 144-element rows: Jacobi
+// 115 -> 94 ms).  Measured and not kept: instantiations for rows of <= 128 elements too (C5 f64 6.99 k -> 6.36 k amp/s, the real state's
+// 256-element rows 733 -> 775 ms: the kernel grows by two more copies of the sweep), ONE restructured body for every storage and
+// length (169 against 154 ms on C5).  Shorter / longer rows and rows in global memory keep the loops below.
+template <typename T, int NQ = 4>      // NQ: 64-element pieces of a row, len in (64 (NQ - 1), 64 NQ]
 __device__ __forceinline__ int jacobi_rows_lds256(T *sM, const int m, const int len, const int lds_ld, const int max_sweeps, int &s_rot,
                                                   double *s_fro, short *s_idx, unsigned char *s_flag, int &s_nl) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const T tol = T(2) * sqrt(T(len)) * T(eps_rt<T>());
   T *M = sM;
-  constexpr int NQ = 4;
   constexpr bool REG = true;
   {
     {
@@ -1372,8 +1373,9 @@ __global__ __launch_bounds__(1024) void jacobi_rows_kernel(T *__restrict__ Mg, l
   __shared__ short s_idx[1024];
   __shared__ unsigned char s_flag[1024];
   __shared__ int s_nl;
-  if (use_lds && len > 192 && len <= 256) {      // block-uniform
-    const int sw = jacobi_rows_lds256<T>(sM, m, len, lds_ld, max_sweeps, s_rot, s_fro, s_idx, s_flag, s_nl);
+  if (use_lds && len > 128 && len <= 256) {      // block-uniform
+    const int sw = len > 192 ? jacobi_rows_lds256<T, 4>(sM, m, len, lds_ld, max_sweeps, s_rot, s_fro, s_idx, s_flag, s_nl)
+                             : jacobi_rows_lds256<T, 3>(sM, m, len, lds_ld, max_sweeps, s_rot, s_fro, s_idx, s_flag, s_nl);
     for (int e = tid; e < m * len; e += blockDim.x) Mglob[(long)(e / len) * ld + (e % len)] = sM[(e / len) * lds_ld + (e % len)];
     if (tid == 0 && sweeps_out) sweeps_out[blockIdx.x] = sw;
     return;
